@@ -1,0 +1,391 @@
+/*
+ * vx355.h — C ABI of libvx355, the MI355X (gfx950) implementation of Velox's
+ * HashAggregation / HashBuild / HashProbe hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ types, no
+ * torch types, no exceptions. Every entry point names the reference interface
+ * it replaces (paths relative to /root/reference/velox). INTEGRATION.md shows
+ * the exec::Operator shim a Velox maintainer adds on top of this header.
+ *
+ * Conventions
+ *  - Every function returning int returns a vx355_status. On failure
+ *    vx355_last_error() (thread local) describes it. VX355_EUSER maps to
+ *    VELOX_USER_FAIL, everything else to VELOX_FAIL; VX355_EUNSUPPORTED at
+ *    *_create time means "leave the CPU operator in place"
+ *    (cf. experimental/cudf/exec/ToCudf.cpp:230-242).
+ *  - Null bitmaps follow common/base/Nulls.h:26-38: bit = 1 means NOT null.
+ *  - BOOLEAN values are bit packed (vector/FlatVector.h), VARCHAR values are
+ *    16-byte StringView (type/StringView.h:76-77): u32 size, 4-byte prefix,
+ *    then 8 more inline bytes (size <= 12) or a pointer (size > 12).
+ *  - Inputs are borrowed for the duration of the call. Outputs are written
+ *    into caller allocated buffers (host or device, see vx355_mem).
+ *  - Handles are single threaded (one Driver thread at a time, exec/Driver.cpp
+ *    :538). A vx355_join_table is immutable after finish and may be shared by
+ *    any number of probe handles on any thread.
+ */
+#ifndef VX355_H_
+#define VX355_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VX355_ABI_VERSION 1
+
+typedef enum vx355_status {
+  VX355_OK = 0,
+  VX355_EUSER = 1,        /* user error, e.g. "integer overflow" in sum(BIGINT) */
+  VX355_EUNSUPPORTED = 2, /* type / encoding / join kind not handled on device */
+  VX355_ENOMEM = 3,       /* HBM arena exhausted */
+  VX355_EINTERNAL = 4,    /* HIP error or broken invariant */
+  VX355_EINVAL = 5        /* malformed argument */
+} vx355_status;
+
+/* Values equal velox::TypeKind (type/TypeKind.h:41-52). DATE is INTEGER. */
+typedef enum vx355_type_kind {
+  VX355_BOOLEAN = 0,
+  VX355_TINYINT = 1,
+  VX355_SMALLINT = 2,
+  VX355_INTEGER = 3,
+  VX355_BIGINT = 4,
+  VX355_REAL = 5,
+  VX355_DOUBLE = 6,
+  VX355_VARCHAR = 7,
+  VX355_VARBINARY = 8,
+  VX355_TIMESTAMP = 9
+} vx355_type_kind;
+
+/* vector/VectorEncoding.h: the three encodings DecodedVector reduces to. */
+typedef enum vx355_encoding {
+  VX355_FLAT = 0,
+  VX355_CONSTANT = 1,
+  VX355_DICTIONARY = 2
+} vx355_encoding;
+
+typedef enum vx355_mem { VX355_MEM_HOST = 0, VX355_MEM_DEVICE = 1 } vx355_mem;
+
+/* One input column, i.e. what DecodedVector (vector/DecodedVector.h) exposes:
+ * data(), nulls(&rows), indices(). */
+typedef struct vx355_column {
+  int32_t type_kind;     /* vx355_type_kind */
+  int32_t encoding;      /* vx355_encoding */
+  const void* values;    /* FLAT: num_rows values. CONSTANT: 1 value.
+                            DICTIONARY: base_size base values. */
+  const uint64_t* nulls; /* bit per ROW (top level, after decoding), 1 = valid;
+                            NULL = no nulls. CONSTANT: only bit 0 is read. */
+  const int32_t* indices; /* DICTIONARY: num_rows indices into values. */
+  int32_t base_size;      /* DICTIONARY: number of base values; else 0. */
+  int32_t mem;            /* vx355_mem of values / nulls / indices. */
+} vx355_column;
+
+/* RowVector (vector/ComplexVector.h) reduced to its decoded children. */
+typedef struct vx355_batch {
+  int32_t num_rows; /* vector_size_t: <= 2^31-1 */
+  int32_t num_cols;
+  const vx355_column* cols; /* host array */
+} vx355_batch;
+
+/* One caller-allocated flat output column. */
+typedef struct vx355_out_column {
+  int32_t type_kind;
+  int32_t mem;      /* vx355_mem of values / nulls */
+  void* values;     /* capacity rows (BOOLEAN: bit packed) */
+  uint64_t* nulls;  /* capacity bits, 1 = valid; may be NULL when the caller
+                       knows the column cannot be null (keys with
+                       ignore_null_keys, count) */
+} vx355_out_column;
+
+/* ---- runtime ----------------------------------------------------------- */
+
+/* Binds the calling process to one GPU and creates the library stream and
+ * HBM arena. Idempotent for the same device. */
+int vx355_init(int device);
+void vx355_shutdown(void);
+int vx355_abi_version(void);
+int vx355_device_count(void);
+const char* vx355_last_error(void);
+
+/* Device memory helpers for callers that keep columns resident in HBM
+ * (tests, bench, the adapter's staging buffers). */
+void* vx355_device_malloc(size_t bytes);
+void vx355_device_free(void* p);
+int vx355_memcpy_h2d(void* dst, const void* src, size_t bytes);
+int vx355_memcpy_d2h(void* dst, const void* src, size_t bytes);
+int vx355_memset_d(void* dst, int value, size_t bytes);
+int vx355_synchronize(void);
+
+/* Per-kernel timing with HIP events on the library's own stream. While
+ * enabled every launch of a profiled kernel is bracketed by two events;
+ * vx355_profile_get sums the elapsed times after synchronising. */
+int vx355_profile_enable(int on);
+int vx355_profile_reset(void);
+int vx355_profile_get(const char* kernel, double* total_ms, int64_t* launches);
+/* Writes up to cap names of kernels seen since the last reset, '\n' joined. */
+int vx355_profile_names(char* buf, size_t cap);
+
+/* ---- standalone kernels (parity-test surface) --------------------------- */
+
+/* VectorHasher::hash (exec/VectorHasher.cpp:567-584, hashValues :86-126) for
+ * n_keys columns in one pass: out[row] = h(key0) then hashMix(out[row],
+ * h(key_i)) (common/base/BitUtil.h:775-784); nulls hash to kNullHash = 1.
+ * rows: selection bitmap (SelectivityVector bits, 1 = selected) or NULL for
+ * all rows; unselected slots of out are left untouched. mix_first != 0 mixes
+ * key0 into the existing out[row] (the `mix` argument of the reference).
+ * out/rows live in out_mem. */
+int vx355_hash_columns(
+    const vx355_batch* batch,
+    const int32_t* key_cols,
+    int32_t n_keys,
+    const uint64_t* rows,
+    int32_t mix_first,
+    uint64_t* out,
+    int32_t out_mem);
+
+/* Per-key value-id mapping state: what VectorHasher holds after
+ * enableValueRange (exec/VectorHasher.cpp:923-944). Only range mode runs on
+ * the device; distinct-value dictionaries (enableValueIds) stay on the host. */
+typedef struct vx355_value_id_spec {
+  int64_t min;         /* min_ (inclusive, after reserve padding) */
+  int64_t max;         /* max_ */
+  uint64_t multiplier; /* multiplier_ */
+} vx355_value_id_spec;
+
+/* VectorHasher::computeValueIds (exec/VectorHasher.cpp:354-360; lookup = 0)
+ * and VectorHasher::lookupValueIds (:550-565; lookup = 1) in range mode for
+ * n_keys columns: result[row] = sum_i multiplier_i * (value_i - min_i + 1),
+ * null contributes 0 (VectorHasher.h:560-566, VectorHasher.cpp:196-224).
+ * lookup = 0: *all_mapped = 0 if any selected non-null value is out of range
+ *   (the reference then re-decides the hash mode); result for such rows is
+ *   unspecified. rows_out is not written.
+ * lookup = 1: rows whose value is out of range are cleared in rows_out
+ *   (proven misses); rows_out must hold ceil(num_rows/64) words and receives
+ *   rows (or all-ones) AND mapped. */
+int vx355_value_ids(
+    const vx355_batch* batch,
+    const int32_t* key_cols,
+    const vx355_value_id_spec* specs,
+    int32_t n_keys,
+    const uint64_t* rows,
+    int32_t lookup,
+    uint64_t* result,
+    uint64_t* rows_out,
+    int32_t* all_mapped,
+    int32_t out_mem);
+
+/* processFilterResults, flat case (exec/OperatorUtils.cpp:231-257): selected =
+ * values & nulls & rows; idx_out receives the ascending row numbers of the set
+ * bits (== FilterEvalCtx::selectedIndices), *n_out their count. nulls and rows
+ * may be NULL. All buffers live in mem. */
+int vx355_filter_compact(
+    const uint64_t* values,
+    const uint64_t* nulls,
+    const uint64_t* rows,
+    int32_t num_rows,
+    int32_t* idx_out,
+    int32_t* n_out,
+    int32_t mem);
+
+typedef enum vx355_partition_kind {
+  VX355_PART_MODULO = 0,     /* hash % num_partitions (HashPartitionFunction.cpp:112-115) */
+  VX355_PART_BIT_RANGE = 1,  /* (hash >> begin) & mask (HashBitRange.h:38-41) */
+  VX355_PART_LOCAL_MODULO = 2,    /* XXH32(reverseBits(hash32)) % n (:25-30,:104-107) */
+  VX355_PART_LOCAL_BIT_RANGE = 3  /* same then bit range (:96-99) */
+} vx355_partition_kind;
+
+/* HashPartitionFunction::partition (exec/HashPartitionFunction.cpp:76-118)
+ * applied to precomputed VectorHasher hashes. For the BIT_RANGE kinds
+ * num_partitions is ignored and bits [bit_begin, bit_end) are used. */
+int vx355_partition(
+    const uint64_t* hashes,
+    int32_t num_rows,
+    int32_t kind,
+    int32_t num_partitions,
+    int32_t bit_begin,
+    int32_t bit_end,
+    uint32_t* partitions_out,
+    int32_t mem);
+
+/* ---- HashAggregation (exec/HashAggregation.h, exec/GroupingSet.h) ------- */
+
+typedef enum vx355_agg_kind {
+  VX355_AGG_SUM = 0,        /* SumAggregate.cpp:39-118 */
+  VX355_AGG_COUNT = 1,      /* count(x), CountAggregate.cpp:27-147 */
+  VX355_AGG_COUNT_STAR = 2, /* count(*) */
+  VX355_AGG_MIN = 3,        /* MinMaxAggregateBase.cpp:101-305 */
+  VX355_AGG_MAX = 4,
+  VX355_AGG_AVG = 5         /* AverageAggregateBase.h:66-260 */
+} vx355_agg_kind;
+
+/* core::AggregationNode::Step (core/PlanNode.h:1122-1131), same values. */
+typedef enum vx355_agg_step {
+  VX355_STEP_PARTIAL = 0,      /* raw in, intermediate out */
+  VX355_STEP_FINAL = 1,        /* intermediate in, final out */
+  VX355_STEP_INTERMEDIATE = 2, /* intermediate in, intermediate out */
+  VX355_STEP_SINGLE = 3        /* raw in, final out */
+} vx355_agg_step;
+
+typedef struct vx355_agg_fn {
+  int32_t kind;       /* vx355_agg_kind */
+  int32_t input_col;  /* batch column; -1 for count(*) */
+  int32_t input_col2; /* avg with intermediate input: the BIGINT count child
+                         of ROW(DOUBLE sum, BIGINT count); else -1 */
+  int32_t input_type; /* raw input vx355_type_kind (decides result type even
+                         for intermediate input: sum(REAL) returns REAL) */
+  int32_t mask_col;   /* BOOLEAN column, FILTER (WHERE m); -1 = none
+                         (exec/AggregationMasks.h) */
+} vx355_agg_fn;
+
+typedef struct vx355_agg_spec {
+  int32_t num_keys; /* 0 = global aggregation: always one output row */
+  const int32_t* key_cols;
+  const int32_t* key_types;
+  int32_t num_aggs;
+  const vx355_agg_fn* aggs;
+  int32_t step;             /* vx355_agg_step */
+  int32_t ignore_null_keys; /* AggregationNode::ignoreNullKeys */
+} vx355_agg_spec;
+
+typedef struct vx355_agg vx355_agg;
+
+/* HashAggregation::initialize (exec/HashAggregation.cpp:44-130). */
+int vx355_agg_create(const vx355_agg_spec* spec, vx355_agg** out);
+/* HashAggregation::addInput (:191-236) -> GroupingSet::addInput
+ * (exec/GroupingSet.cpp:190-223,288-365). */
+int vx355_agg_add_input(vx355_agg* h, const vx355_batch* batch);
+/* Operator::noMoreInput (exec/Operator.h:252). */
+int vx355_agg_no_more_input(vx355_agg* h);
+/* Number of output columns: keys, then per aggregate 1 column (2 for avg in
+ * partial/intermediate steps: DOUBLE sum, BIGINT count), and their types. */
+int vx355_agg_output_types(const vx355_agg* h, int32_t* types, int32_t cap, int32_t* n);
+/* HashAggregation::getOutput (:357-424) -> GroupingSet::getOutput (:810-884):
+ * groups in first-seen order, at most max_rows per call. Valid after
+ * no_more_input. *finished = 1 once every group has been returned. */
+int vx355_agg_get_output(
+    vx355_agg* h,
+    vx355_out_column* cols,
+    int32_t num_cols,
+    int32_t max_rows,
+    int32_t* n_out,
+    int32_t* finished);
+
+/* hashtable.* runtime stats (exec/HashTable.h:155-182). */
+typedef struct vx355_agg_stats {
+  int64_t num_groups;   /* hashtable.numDistinct */
+  int64_t capacity;     /* hashtable.capacity */
+  int64_t num_rehashes; /* hashtable.numRehashes */
+  int32_t hash_mode;    /* 0 kHash, 1 kArray, 2 kNormalizedKey (BaseHashTable::HashMode) */
+  int32_t reserved;
+  int64_t input_rows;
+  int64_t deferred_rows; /* rows replayed after a key-range widening */
+} vx355_agg_stats;
+int vx355_agg_get_stats(const vx355_agg* h, vx355_agg_stats* out);
+void vx355_agg_destroy(vx355_agg* h);
+
+/* ---- HashBuild / HashProbe (exec/HashBuild.h, exec/HashProbe.h) --------- */
+
+/* core::JoinType (core/PlanNode.h:3081-3165), same values. Device support in
+ * this version: INNER, LEFT, LEFT_SEMI_FILTER, ANTI (not null aware), without
+ * an extra filter; others return VX355_EUNSUPPORTED at create. */
+typedef enum vx355_join_type {
+  VX355_JOIN_INNER = 0,
+  VX355_JOIN_LEFT = 1,
+  VX355_JOIN_RIGHT = 2,
+  VX355_JOIN_FULL = 3,
+  VX355_JOIN_LEFT_SEMI_FILTER = 4,
+  VX355_JOIN_COUNTING_LEFT_SEMI_FILTER = 5,
+  VX355_JOIN_LEFT_SEMI_PROJECT = 6,
+  VX355_JOIN_RIGHT_SEMI_FILTER = 7,
+  VX355_JOIN_RIGHT_SEMI_PROJECT = 8,
+  VX355_JOIN_ANTI = 9,
+  VX355_JOIN_COUNTING_ANTI = 10,
+  VX355_JOIN_RIGHT_ANTI = 11
+} vx355_join_type;
+
+typedef struct vx355_join_build_spec {
+  int32_t num_keys;
+  const int32_t* key_cols;
+  const int32_t* key_types;
+  int32_t num_dependents; /* build-side payload columns */
+  const int32_t* dependent_cols;
+  const int32_t* dependent_types;
+  int32_t join_type;  /* vx355_join_type */
+  int32_t null_aware; /* HashJoinNode::isNullAware */
+} vx355_join_build_spec;
+
+typedef struct vx355_join_build vx355_join_build;
+typedef struct vx355_join_table vx355_join_table;
+typedef struct vx355_join_probe vx355_join_probe;
+
+/* HashBuild::initialize / setupTable (exec/HashBuild.cpp:239-300). */
+int vx355_join_build_create(const vx355_join_build_spec* spec, vx355_join_build** out);
+/* HashBuild::addInput (:442-598): drops rows with a null key, appends keys and
+ * dependents to the HBM-resident build columns. */
+int vx355_join_build_add_input(vx355_join_build* h, const vx355_batch* batch);
+/* HashBuild::noMoreInput -> finishHashBuild (:799-993) ->
+ * HashTable::prepareJoinTable (exec/HashTable.cpp:1989-2069). others: build
+ * handles of the peer Drivers whose rows are merged into this table (may be
+ * NULL/0). The returned table carries one reference. */
+int vx355_join_build_finish(
+    vx355_join_build* h,
+    vx355_join_build* const* others,
+    int32_t num_others,
+    vx355_join_table** out);
+void vx355_join_build_destroy(vx355_join_build* h);
+
+/* HashJoinBridge::setHashTable / tableOrFuture (exec/HashJoinBridge.h:57,116)
+ * hand a shared_ptr; here: explicit reference counting. */
+void vx355_join_table_retain(vx355_join_table* t);
+void vx355_join_table_release(vx355_join_table* t);
+
+typedef struct vx355_join_table_stats {
+  int64_t num_rows;     /* build rows with non-null keys */
+  int64_t num_distinct; /* distinct keys */
+  int64_t capacity;     /* slots */
+  int32_t hash_mode;    /* as vx355_agg_stats.hash_mode */
+  int32_t has_duplicates;
+} vx355_join_table_stats;
+int vx355_join_table_get_stats(const vx355_join_table* t, vx355_join_table_stats* out);
+
+typedef struct vx355_join_probe_spec {
+  int32_t num_keys;
+  const int32_t* key_cols; /* probe-side key columns */
+  int32_t join_type;
+  int32_t null_aware;
+} vx355_join_probe_spec;
+
+int vx355_join_probe_create(
+    vx355_join_table* table,
+    const vx355_join_probe_spec* spec,
+    vx355_join_probe** out);
+/* HashProbe::addInput (exec/HashProbe.cpp:796-900): prepareForJoinProbe
+ * (HashTable.cpp:2680-2712) + joinProbe (:610-652) for the whole batch. */
+int vx355_join_probe_add_input(vx355_join_probe* h, const vx355_batch* batch);
+/* HashProbe::getOutput (:1154) -> listJoinResults (HashTable.cpp:2133-2350) +
+ * fillOutput (HashProbe.cpp:968-991). Emits at most max_rows result rows in
+ * ascending probe-row order, all matches of one probe row contiguous.
+ * mapping_out[i] = probe row (the indices the shim wraps the probe columns
+ * with, OperatorUtils.cpp:380-422); build_rows_out[i] = build row id or -1
+ * for a miss (LEFT / ANTI); build_cols[j] receives dependent column
+ * build_col_ids[j] gathered at build_rows_out (extractColumns,
+ * HashProbe.cpp:82-118; null for misses). *finished = 1 when the current
+ * input batch is drained. mapping_out/build_rows_out live in out_mem. */
+int vx355_join_probe_get_output(
+    vx355_join_probe* h,
+    int32_t max_rows,
+    int32_t* mapping_out,
+    int32_t* build_rows_out,
+    int32_t out_mem,
+    vx355_out_column* build_cols,
+    const int32_t* build_col_ids,
+    int32_t num_build_cols,
+    int32_t* n_out,
+    int32_t* finished);
+void vx355_join_probe_destroy(vx355_join_probe* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VX355_H_ */

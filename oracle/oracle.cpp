@@ -1,0 +1,973 @@
+// TEST INFRASTRUCTURE ONLY — CPU oracle, see oracle.h.
+// GroupingSet / HashAggregation / HashBuild / HashProbe / filter compaction /
+// partition function restated on top of table.h, and the C API.
+#include "oracle.h"
+
+#include <cmath>
+#include <cstdio>
+
+#include "table.h"
+
+namespace orc {
+namespace {
+
+thread_local std::string gLastError;
+
+bool isIntKind(int32_t k) { return k >= VX355_BOOLEAN && k <= VX355_BIGINT; }
+bool isStringKind(int32_t k) { return k == VX355_VARCHAR || k == VX355_VARBINARY; }
+
+// ---- aggregate functions (Appendix C of SURVEY.md) ------------------------
+
+// Accumulator bytes: sum/count/min/max 8, avg 16 {double sum; int64 count}
+// (AverageAggregateBase.h:66-69).
+int32_t accBytes(const vx355_agg_fn& f) { return f.kind == VX355_AGG_AVG ? 16 : 8; }
+
+bool rawInput(int32_t step) { return step == VX355_STEP_PARTIAL || step == VX355_STEP_SINGLE; }
+bool finalOutput(int32_t step) { return step == VX355_STEP_FINAL || step == VX355_STEP_SINGLE; }
+
+// Intermediate / final result type of an aggregate (SumAggregate.cpp:39-118,
+// CountAggregate.cpp, MinMaxAggregateBase.cpp:34-99, AverageAggregate.cpp).
+void outputTypes(const vx355_agg_fn& f, int32_t step, std::vector<int32_t>& out) {
+  bool fin = finalOutput(step);
+  switch (f.kind) {
+    case VX355_AGG_SUM:
+      if (isIntKind(f.input_type)) {
+        out.push_back(VX355_BIGINT);
+      } else if (f.input_type == VX355_REAL) {
+        out.push_back(fin ? VX355_REAL : VX355_DOUBLE);
+      } else {
+        out.push_back(VX355_DOUBLE);
+      }
+      break;
+    case VX355_AGG_COUNT:
+    case VX355_AGG_COUNT_STAR:
+      out.push_back(VX355_BIGINT);
+      break;
+    case VX355_AGG_MIN:
+    case VX355_AGG_MAX:
+      out.push_back(f.input_type);
+      break;
+    case VX355_AGG_AVG:
+      if (fin) {
+        out.push_back(f.input_type == VX355_REAL ? VX355_REAL : VX355_DOUBLE);
+      } else {
+        out.push_back(VX355_DOUBLE);
+        out.push_back(VX355_BIGINT);
+      }
+      break;
+  }
+}
+
+// checkedPlus (vector/AggregationHook.h:126-135 SumHook::add with
+// Overflow=false, SumAggregate.cpp:24).
+int64_t checkedPlus(int64_t a, int64_t b) {
+  int64_t r;
+  if (__builtin_add_overflow(a, b, &r)) {
+    throw UserError("integer overflow: " + std::to_string(a) + " + " + std::to_string(b));
+  }
+  return r;
+}
+
+// NaN-aware compare (MinMaxAggregateBase.cpp:174-184, :267-277): NaN is larger
+// than everything.
+bool lessThan(double a, double b) {
+  if (std::isnan(b)) {
+    return !std::isnan(a);
+  }
+  if (std::isnan(a)) {
+    return false;
+  }
+  return a < b;
+}
+bool greaterThan(double a, double b) { return lessThan(b, a); }
+
+void writeOut(vx355_out_column& col, int32_t row, bool isNull, const void* value, int width) {
+  if (col.nulls) {
+    setBit(col.nulls, row, !isNull);
+  }
+  if (isNull) {
+    if (col.type_kind == VX355_BOOLEAN) {
+      setBit(static_cast<uint64_t*>(col.values), row, false);
+    } else {
+      std::memset(static_cast<char*>(col.values) + static_cast<int64_t>(row) * width, 0, width);
+    }
+    return;
+  }
+  if (col.type_kind == VX355_BOOLEAN) {
+    setBit(static_cast<uint64_t*>(col.values), row, *static_cast<const uint8_t*>(value) != 0);
+    return;
+  }
+  std::memcpy(static_cast<char*>(col.values) + static_cast<int64_t>(row) * width, value, width);
+}
+
+// Stored 8-byte key slot back to the column type (RowContainer::extractColumn,
+// RowContainer.h:439-536).
+void extractStored(const char* row, const RowContainer::Column& c, vx355_out_column& out,
+                   int32_t outRow) {
+  bool isNull = row[c.nullOffset] != 0;
+  const char* p = row + c.offset;
+  switch (c.kind) {
+    case VX355_BOOLEAN: {
+      int64_t v;
+      std::memcpy(&v, p, 8);
+      uint8_t b = v != 0;
+      writeOut(out, outRow, isNull, &b, 0);
+      break;
+    }
+    case VX355_TINYINT:
+    case VX355_SMALLINT:
+    case VX355_INTEGER:
+    case VX355_BIGINT: {
+      int64_t v;
+      std::memcpy(&v, p, 8);
+      writeOut(out, outRow, isNull, &v, kindWidth(c.kind));  // little endian truncation
+      break;
+    }
+    case VX355_REAL:
+      writeOut(out, outRow, isNull, p, 4);
+      break;
+    case VX355_DOUBLE:
+      writeOut(out, outRow, isNull, p, 8);
+      break;
+    default:
+      writeOut(out, outRow, isNull, p, 16);
+  }
+}
+
+}  // namespace
+
+// exec/GroupingSet.{h,cpp} + exec/HashAggregation.{h,cpp}.
+class Aggregation {
+ public:
+  Aggregation(const vx355_agg_spec& spec, bool hashAdaptivity)
+      : step_(spec.step), ignoreNullKeys_(spec.ignore_null_keys != 0) {
+    keyCols_.assign(spec.key_cols, spec.key_cols + spec.num_keys);
+    keyKinds_.assign(spec.key_types, spec.key_types + spec.num_keys);
+    aggs_.assign(spec.aggs, spec.aggs + spec.num_aggs);
+    std::vector<int32_t> bytes;
+    for (auto& f : aggs_) {
+      bytes.push_back(accBytes(f));
+    }
+    table_ = std::make_unique<HashTable>(keyKinds_, bytes, std::vector<int32_t>{}, false, false,
+                                         ignoreNullKeys_);
+    if (!hashAdaptivity && !keyKinds_.empty()) {
+      table_->forceGenericHashMode();
+    }
+    if (keyKinds_.empty()) {
+      // Global aggregation: one row, always (GroupingSet.cpp:623-669).
+      globalRow_ = table_->rows()->newRow();
+      for (size_t i = 0; i < aggs_.size(); ++i) {
+        initGroup(globalRow_, i);
+      }
+    }
+  }
+
+  // GroupingSet::addInput (GroupingSet.cpp:190-223) -> addInputForActiveRows
+  // (:288-365).
+  void addInput(const vx355_batch& batch) {
+    const int32_t n = batch.num_rows;
+    inputRows_ += n;
+    if (n == 0) {
+      return;
+    }
+    std::vector<uint64_t> rows((n + 63) / 64, ~0ULL);
+    if (n & 63) {
+      rows.back() = (1ULL << (n & 63)) - 1;
+    }
+    std::vector<char*> groupsStorage;
+    char** groups;
+    HashLookup lookup;
+    if (keyKinds_.empty()) {
+      groupsStorage.assign(n, globalRow_);
+      groups = groupsStorage.data();
+    } else {
+      std::vector<Decoded> keys;
+      for (auto c : keyCols_) {
+        keys.emplace_back(&batch.cols[c]);
+      }
+      table_->prepareForGroupProbe(lookup, keys, n, rows);
+      table_->groupProbe(lookup, keys);
+      groups = lookup.hits.data();
+      // Aggregate::initializeNewGroups (Aggregate.h:152).
+      for (auto r : lookup.newGroups) {
+        for (size_t i = 0; i < aggs_.size(); ++i) {
+          initGroup(groups[r], i);
+        }
+      }
+    }
+    for (size_t i = 0; i < aggs_.size(); ++i) {
+      update(i, batch, rows.data(), n, groups);
+    }
+  }
+
+  void noMoreInput() { noMoreInput_ = true; }
+
+  std::vector<int32_t> outputKinds() const {
+    std::vector<int32_t> out = keyKinds_;
+    for (auto& f : aggs_) {
+      outputTypes(f, step_, out);
+    }
+    return out;
+  }
+
+  // GroupingSet::getOutput (GroupingSet.cpp:810-841) + extractGroups (:843-884):
+  // rows in RowContainer order == first-seen order of groups.
+  void getOutput(vx355_out_column* cols, int32_t numCols, int32_t maxRows, int32_t* nOut,
+                 int32_t* finished) {
+    auto kinds = outputKinds();
+    if (numCols != static_cast<int32_t>(kinds.size())) {
+      throw std::runtime_error("getOutput: wrong number of output columns");
+    }
+    const auto& rows = table_->rows()->rows();
+    int64_t total = static_cast<int64_t>(rows.size());
+    int32_t n = static_cast<int32_t>(std::min<int64_t>(maxRows, total - outputCursor_));
+    for (int32_t i = 0; i < n; ++i) {
+      char* row = rows[outputCursor_ + i];
+      int c = 0;
+      for (size_t k = 0; k < keyKinds_.size(); ++k) {
+        extractStored(row, table_->rows()->keys()[k], cols[c++], i);
+      }
+      for (size_t a = 0; a < aggs_.size(); ++a) {
+        extract(a, row, cols, c, i);
+      }
+    }
+    outputCursor_ += n;
+    *nOut = n;
+    *finished = outputCursor_ >= total;
+  }
+
+  void stats(vx355_agg_stats* out) const {
+    out->num_groups = table_->rows()->numRows();
+    out->capacity = static_cast<int64_t>(table_->capacity());
+    out->num_rehashes = table_->numRehashes();
+    out->hash_mode = static_cast<int32_t>(table_->hashMode());
+    out->reserved = 0;
+    out->input_rows = inputRows_;
+    out->deferred_rows = 0;
+  }
+
+ private:
+  char* acc(char* group, size_t i) const { return group + table_->rows()->accOffset(i); }
+  char& accNull(char* group, size_t i) const { return group[table_->rows()->accNullOffset(i)]; }
+
+  // initializeNewGroups: sum/min/max/avg start null (SumAggregateBase.h:144-151,
+  // MinMaxAggregateBase.cpp:191-201/:293-303, AverageAggregateBase.h), count
+  // starts at 0 and is never null (CountAggregate.cpp:135-142).
+  void initGroup(char* group, size_t i) {
+    const auto& f = aggs_[i];
+    accNull(group, i) = (f.kind == VX355_AGG_COUNT || f.kind == VX355_AGG_COUNT_STAR) ? 0 : 1;
+    char* a = acc(group, i);
+    if (f.kind == VX355_AGG_MIN || f.kind == VX355_AGG_MAX) {
+      bool isMin = f.kind == VX355_AGG_MIN;
+      if (isIntKind(f.input_type)) {
+        int64_t v = isMin ? limitMax(f.input_type) : limitMin(f.input_type);
+        std::memcpy(a, &v, 8);
+      } else {
+        double v = isMin ? std::numeric_limits<double>::infinity()
+                         : -std::numeric_limits<double>::infinity();
+        std::memcpy(a, &v, 8);
+      }
+    } else {
+      std::memset(a, 0, accBytes(f));
+    }
+  }
+  static int64_t limitMax(int32_t kind) {
+    switch (kind) {
+      case VX355_BOOLEAN:
+        return 1;
+      case VX355_TINYINT:
+        return INT8_MAX;
+      case VX355_SMALLINT:
+        return INT16_MAX;
+      case VX355_INTEGER:
+        return INT32_MAX;
+      default:
+        return INT64_MAX;
+    }
+  }
+  static int64_t limitMin(int32_t kind) {
+    switch (kind) {
+      case VX355_BOOLEAN:
+        return 0;
+      case VX355_TINYINT:
+        return INT8_MIN;
+      case VX355_SMALLINT:
+        return INT16_MIN;
+      case VX355_INTEGER:
+        return INT32_MIN;
+      default:
+        return INT64_MIN;
+    }
+  }
+
+  // Aggregate::addRawInput (Aggregate.h:179) / addIntermediateResults (:227):
+  // one pass over groups[] per aggregate, like the reference
+  // (SimpleNumericAggregate.h:94 updateGroups).
+  void update(size_t i, const vx355_batch& batch, const uint64_t* rows, int32_t n, char** groups) {
+    const auto& f = aggs_[i];
+    const bool raw = rawInput(step_);
+    std::unique_ptr<Decoded> mask, in, in2;
+    if (f.mask_col >= 0) {
+      mask = std::make_unique<Decoded>(&batch.cols[f.mask_col]);
+    }
+    if (f.input_col >= 0) {
+      in = std::make_unique<Decoded>(&batch.cols[f.input_col]);
+    }
+    if (f.input_col2 >= 0) {
+      in2 = std::make_unique<Decoded>(&batch.cols[f.input_col2]);
+    }
+    const bool intSum = isIntKind(f.input_type);
+    for (int32_t r = 0; r < n; ++r) {
+      if (!bitSet(rows, r)) {
+        continue;
+      }
+      if (mask && (mask->isNull(r) || !mask->int64At(r))) {
+        continue;  // AggregationMasks: false or null mask excludes the row
+      }
+      char* g = groups[r];
+      char* a = acc(g, i);
+      switch (f.kind) {
+        case VX355_AGG_COUNT_STAR:
+          if (raw) {
+            ++*reinterpret_cast<int64_t*>(a);
+          } else if (!in->isNull(r)) {
+            *reinterpret_cast<int64_t*>(a) += in->int64At(r);  // CountAggregate.cpp:72-80
+          }
+          break;
+        case VX355_AGG_COUNT:
+          if (in->isNull(r)) {
+            break;
+          }
+          if (raw) {
+            ++*reinterpret_cast<int64_t*>(a);
+          } else {
+            *reinterpret_cast<int64_t*>(a) += in->int64At(r);
+          }
+          break;
+        case VX355_AGG_SUM:
+          if (in->isNull(r)) {
+            break;
+          }
+          accNull(g, i) = 0;
+          if (intSum) {
+            auto* s = reinterpret_cast<int64_t*>(a);
+            *s = checkedPlus(*s, in->int64At(r));
+          } else {
+            *reinterpret_cast<double*>(a) += in->doubleAt(r);
+          }
+          break;
+        case VX355_AGG_MIN:
+        case VX355_AGG_MAX: {
+          if (in->isNull(r)) {
+            break;
+          }
+          accNull(g, i) = 0;
+          bool isMin = f.kind == VX355_AGG_MIN;
+          if (intSum) {
+            auto* s = reinterpret_cast<int64_t*>(a);
+            int64_t v = in->int64At(r);
+            if (isMin ? v < *s : v > *s) {
+              *s = v;
+            }
+          } else {
+            auto* s = reinterpret_cast<double*>(a);
+            double v = in->doubleAt(r);
+            if (isMin ? lessThan(v, *s) : greaterThan(v, *s)) {
+              *s = v;
+            }
+          }
+          break;
+        }
+        case VX355_AGG_AVG: {
+          auto* sum = reinterpret_cast<double*>(a);
+          auto* cnt = reinterpret_cast<int64_t*>(a + 8);
+          if (raw) {
+            if (in->isNull(r)) {
+              break;
+            }
+            accNull(g, i) = 0;
+            *sum += in->doubleAt(r);  // AverageAggregateBase.h:241-258
+            *cnt = checkedPlus(*cnt, 1);
+          } else {
+            if (in->isNull(r)) {
+              break;
+            }
+            accNull(g, i) = 0;
+            *sum += in->doubleAt(r);  // :265-330
+            *cnt = checkedPlus(*cnt, in2->int64At(r));
+          }
+          break;
+        }
+      }
+    }
+  }
+
+  // extractValues (Aggregate.h:277) / extractAccumulators (:289).
+  void extract(size_t i, char* group, vx355_out_column* cols, int& c, int32_t outRow) {
+    const auto& f = aggs_[i];
+    const bool fin = finalOutput(step_);
+    bool isNull = accNull(group, i) != 0;
+    char* a = acc(group, i);
+    switch (f.kind) {
+      case VX355_AGG_COUNT:
+      case VX355_AGG_COUNT_STAR:
+        writeOut(cols[c++], outRow, false, a, 8);
+        break;
+      case VX355_AGG_SUM:
+        if (isIntKind(f.input_type)) {
+          writeOut(cols[c++], outRow, isNull, a, 8);
+        } else if (f.input_type == VX355_REAL && fin) {
+          float v = static_cast<float>(*reinterpret_cast<double*>(a));
+          writeOut(cols[c++], outRow, isNull, &v, 4);
+        } else {
+          writeOut(cols[c++], outRow, isNull, a, 8);
+        }
+        break;
+      case VX355_AGG_MIN:
+      case VX355_AGG_MAX:
+        if (isIntKind(f.input_type)) {
+          if (f.input_type == VX355_BOOLEAN) {
+            uint8_t b = *reinterpret_cast<int64_t*>(a) != 0;
+            writeOut(cols[c++], outRow, isNull, &b, 0);
+          } else {
+            writeOut(cols[c++], outRow, isNull, a, kindWidth(f.input_type));
+          }
+        } else if (f.input_type == VX355_REAL) {
+          float v = static_cast<float>(*reinterpret_cast<double*>(a));
+          writeOut(cols[c++], outRow, isNull, &v, 4);
+        } else {
+          writeOut(cols[c++], outRow, isNull, a, 8);
+        }
+        break;
+      case VX355_AGG_AVG: {
+        double sum = *reinterpret_cast<double*>(a);
+        int64_t cnt = *reinterpret_cast<int64_t*>(a + 8);
+        if (fin) {
+          // AverageAggregateBase.h:86-109
+          if (f.input_type == VX355_REAL) {
+            float v = isNull ? 0.f : static_cast<float>(sum / cnt);
+            writeOut(cols[c++], outRow, isNull, &v, 4);
+          } else {
+            double v = isNull ? 0. : sum / cnt;
+            writeOut(cols[c++], outRow, isNull, &v, 8);
+          }
+        } else {
+          writeOut(cols[c++], outRow, isNull, &sum, 8);
+          writeOut(cols[c++], outRow, isNull, &cnt, 8);
+        }
+        break;
+      }
+    }
+  }
+
+  int32_t step_;
+  bool ignoreNullKeys_;
+  std::vector<int32_t> keyCols_, keyKinds_;
+  std::vector<vx355_agg_fn> aggs_;
+  std::unique_ptr<HashTable> table_;
+  char* globalRow_ = nullptr;
+  bool noMoreInput_ = false;
+  int64_t outputCursor_ = 0;
+  int64_t inputRows_ = 0;
+};
+
+// exec/HashBuild.{h,cpp}: one per build Driver.
+class JoinBuild {
+ public:
+  explicit JoinBuild(const vx355_join_build_spec& spec) : joinType_(spec.join_type) {
+    keyCols_.assign(spec.key_cols, spec.key_cols + spec.num_keys);
+    keyKinds_.assign(spec.key_types, spec.key_types + spec.num_keys);
+    depCols_.assign(spec.dependent_cols, spec.dependent_cols + spec.num_dependents);
+    depKinds_.assign(spec.dependent_types, spec.dependent_types + spec.num_dependents);
+    table_ = std::make_unique<HashTable>(keyKinds_, std::vector<int32_t>{}, depKinds_, true, true,
+                                         true);
+  }
+
+  // HashBuild::addInput (HashBuild.cpp:442-598).
+  void addInput(const vx355_batch& batch) {
+    const int32_t n = batch.num_rows;
+    if (n == 0) {
+      return;
+    }
+    std::vector<Decoded> keys, deps;
+    for (auto c : keyCols_) {
+      keys.emplace_back(&batch.cols[c]);
+    }
+    for (auto c : depCols_) {
+      deps.emplace_back(&batch.cols[c]);
+    }
+    std::vector<uint64_t> rows((n + 63) / 64, ~0ULL);
+    if (n & 63) {
+      rows.back() = (1ULL << (n & 63)) - 1;
+    }
+    // Null keys never match (inner/left/semi/anti-not-null-aware): drop them
+    // (:475-494).
+    for (auto& d : keys) {
+      for (int32_t r = 0; r < n; ++r) {
+        if (d.isNull(r)) {
+          if (bitSet(rows.data(), r)) {
+            hasNullKeys_ = true;
+          }
+          setBit(rows.data(), r, false);
+        }
+      }
+    }
+    table_->analyzeJoinKeys(keys, n, rows.data());
+    for (int32_t r = 0; r < n; ++r) {
+      if (bitSet(rows.data(), r)) {
+        table_->appendJoinRow(keys, deps, r);
+      }
+    }
+  }
+
+  std::unique_ptr<HashTable> table_;
+  std::vector<int32_t> keyCols_, keyKinds_, depCols_, depKinds_;
+  int32_t joinType_;
+  bool hasNullKeys_ = false;
+};
+
+// The finished table handed over the HashJoinBridge.
+struct JoinTable {
+  std::unique_ptr<HashTable> table;
+  std::vector<std::unique_ptr<HashTable>> others;
+  // Row id = position in [table rows..., others' rows...] (the order
+  // vx355_join_build_finish documents).
+  std::vector<int64_t> containerBase;
+  std::vector<RowContainer*> containers;
+  std::vector<int32_t> depKinds;
+  int64_t numRows = 0;
+};
+
+// exec/HashProbe.{h,cpp}.
+class JoinProbe {
+ public:
+  JoinProbe(JoinTable* t, const vx355_join_probe_spec& spec) : table_(t), joinType_(spec.join_type) {
+    keyCols_.assign(spec.key_cols, spec.key_cols + spec.num_keys);
+  }
+
+  // HashProbe::addInput (HashProbe.cpp:796-900).
+  void addInput(const vx355_batch& batch) {
+    numRows_ = batch.num_rows;
+    cursorRow_ = 0;
+    cursorChain_ = nullptr;
+    keys_.clear();
+    for (auto c : keyCols_) {
+      keys_.emplace_back(&batch.cols[c]);
+    }
+    std::vector<uint64_t> rows((numRows_ + 63) / 64, ~0ULL);
+    if (numRows_ & 63) {
+      rows.back() = (1ULL << (numRows_ & 63)) - 1;
+    }
+    if (numRows_ == 0) {
+      lookup_.reset(0);
+      return;
+    }
+    table_->table->prepareForJoinProbe(lookup_, keys_, numRows_, rows);
+    table_->table->joinProbe(lookup_, keys_);
+  }
+
+  // HashTable::listJoinResults (HashTable.cpp:2133-2350): pairs in ascending
+  // probe-row order, all matches of one probe row contiguous, resumable.
+  void getOutput(int32_t maxRows, int32_t* mapping, int32_t* buildRows, vx355_out_column* cols,
+                 const int32_t* colIds, int32_t numCols, int32_t* nOut, int32_t* finished) {
+    int32_t n = 0;
+    const bool includeMisses = joinType_ == VX355_JOIN_LEFT;
+    while (cursorRow_ < numRows_ && n < maxRows) {
+      char* hit = lookup_.hits[cursorRow_];
+      if (joinType_ == VX355_JOIN_ANTI) {
+        // Not null aware: rows without a match, including rows with null keys
+        // (core/PlanNode.h:3147-3150).
+        if (!hit) {
+          emit(n++, cursorRow_, nullptr, mapping, buildRows, cols, colIds, numCols);
+        }
+        ++cursorRow_;
+        continue;
+      }
+      if (joinType_ == VX355_JOIN_LEFT_SEMI_FILTER) {
+        if (hit) {
+          emit(n++, cursorRow_, nullptr, mapping, buildRows, cols, colIds, numCols);
+        }
+        ++cursorRow_;
+        continue;
+      }
+      if (!hit) {
+        if (includeMisses) {
+          emit(n++, cursorRow_, nullptr, mapping, buildRows, cols, colIds, numCols);
+        }
+        ++cursorRow_;
+        continue;
+      }
+      char* cur = cursorChain_ ? cursorChain_ : hit;
+      while (cur && n < maxRows) {
+        emit(n++, cursorRow_, cur, mapping, buildRows, cols, colIds, numCols);
+        cur = table_->table->nextRow(cur);
+      }
+      if (cur) {
+        cursorChain_ = cur;
+      } else {
+        cursorChain_ = nullptr;
+        ++cursorRow_;
+      }
+    }
+    *nOut = n;
+    *finished = cursorRow_ >= numRows_;
+  }
+
+ private:
+  int64_t rowId(char* row) const {
+    // Local allocation index, re-based at finish for merged containers.
+    return *reinterpret_cast<int64_t*>(row + table_->containers[0]->rowIdOffset());
+  }
+  void emit(int32_t i, int32_t probeRow, char* buildRow, int32_t* mapping, int32_t* buildRows,
+            vx355_out_column* cols, const int32_t* colIds, int32_t numCols) {
+    mapping[i] = probeRow;
+    if (buildRows) {
+      buildRows[i] = buildRow ? static_cast<int32_t>(rowId(buildRow)) : -1;
+    }
+    for (int32_t c = 0; c < numCols; ++c) {
+      const auto& col = table_->containers[0]->deps()[colIds[c]];
+      if (!buildRow) {
+        writeOut(cols[c], i, true, nullptr, kindWidth(col.kind));
+      } else {
+        extractStored(buildRow, col, cols[c], i);
+      }
+    }
+  }
+
+  JoinTable* table_;
+  int32_t joinType_;
+  std::vector<int32_t> keyCols_;
+  std::vector<Decoded> keys_;
+  HashLookup lookup_;
+  int32_t numRows_ = 0;
+  int32_t cursorRow_ = 0;
+  char* cursorChain_ = nullptr;
+};
+
+}  // namespace orc
+
+// ---------------------------------------------------------------------------
+// C API
+// ---------------------------------------------------------------------------
+
+using namespace orc;
+
+struct orc_hasher {
+  VectorHasher h;
+  explicit orc_hasher(int32_t k) : h(k) {}
+};
+struct orc_agg {
+  Aggregation a;
+  orc_agg(const vx355_agg_spec& s, bool ad) : a(s, ad) {}
+};
+struct orc_join_build {
+  JoinBuild b;
+  explicit orc_join_build(const vx355_join_build_spec& s) : b(s) {}
+};
+struct orc_join_table {
+  JoinTable t;
+};
+struct orc_join_probe {
+  JoinProbe p;
+  orc_join_probe(JoinTable* t, const vx355_join_probe_spec& s) : p(t, s) {}
+};
+
+#define ORC_TRY try {
+#define ORC_CATCH                          \
+  }                                        \
+  catch (const UserError& e) {             \
+    gLastError = e.what();                 \
+    return VX355_EUSER;                    \
+  }                                        \
+  catch (const std::exception& e) {        \
+    gLastError = e.what();                 \
+    return VX355_EINTERNAL;                \
+  }                                        \
+  return VX355_OK;
+
+extern "C" {
+
+uint64_t orc_twang_mix64(uint64_t key) { return twangMix64(key); }
+uint32_t orc_twang_32from64(uint64_t key) { return twang32From64(key); }
+uint32_t orc_jenkins_rev_mix32(uint32_t key) { return jenkinsRevMix32(key); }
+uint64_t orc_hash_mix(uint64_t upper, uint64_t lower) { return hashMix(upper, lower); }
+uint32_t orc_crc32c_u64(uint32_t checksum, uint64_t value) { return crc32U64(checksum, value); }
+uint64_t orc_hash_bytes(uint64_t seed, const char* data, size_t size) {
+  return hashBytes(seed, data, size);
+}
+uint32_t orc_xxh32_u32(uint32_t value, uint32_t seed) { return xxh32U32(value, seed); }
+uint64_t orc_hash_value(int32_t type_kind, const void* value) { return hashValue(type_kind, value); }
+const char* orc_last_error(void) { return gLastError.c_str(); }
+
+int orc_hash_columns(const vx355_batch* batch, const int32_t* key_cols, int32_t n_keys,
+                     const uint64_t* rows, int32_t mix_first, uint64_t* out) {
+  ORC_TRY
+  for (int32_t i = 0; i < n_keys; ++i) {
+    const vx355_column* col = &batch->cols[key_cols[i]];
+    VectorHasher h(col->type_kind);
+    Decoded d(col);
+    h.hash(d, batch->num_rows, rows, i > 0 || mix_first, out);
+  }
+  ORC_CATCH
+}
+
+orc_hasher* orc_hasher_create(int32_t type_kind) { return new orc_hasher(type_kind); }
+void orc_hasher_destroy(orc_hasher* h) { delete h; }
+int orc_hasher_compute_value_ids(orc_hasher* h, const vx355_column* col, int32_t num_rows,
+                                 const uint64_t* rows, uint64_t* result) {
+  Decoded d(col);
+  return h->h.computeValueIds(d, num_rows, rows, result) ? 1 : 0;
+}
+void orc_hasher_lookup_value_ids(const orc_hasher* h, const vx355_column* col, int32_t num_rows,
+                                 uint64_t* rows_inout, uint64_t* result) {
+  Decoded d(col);
+  h->h.lookupValueIds(d, num_rows, rows_inout, result);
+}
+void orc_hasher_cardinality(orc_hasher* h, int32_t reserve_pct, uint64_t* as_range,
+                            uint64_t* as_distinct) {
+  h->h.cardinality(reserve_pct, *as_range, *as_distinct);
+}
+uint64_t orc_hasher_enable_value_range(orc_hasher* h, uint64_t multiplier, int32_t reserve_pct) {
+  return h->h.enableValueRange(multiplier, reserve_pct);
+}
+uint64_t orc_hasher_enable_value_ids(orc_hasher* h, uint64_t multiplier, int32_t reserve_pct) {
+  return h->h.enableValueIds(multiplier, reserve_pct);
+}
+void orc_hasher_merge(orc_hasher* h, const orc_hasher* other, uint64_t max_num_distinct) {
+  h->h.merge(other->h, max_num_distinct);
+}
+void orc_hasher_get_state(const orc_hasher* h, orc_hasher_state* out) {
+  out->is_range = h->h.isRange();
+  out->has_range = h->h.hasRange();
+  out->range_overflow = h->h.rangeOverflow();
+  out->distinct_overflow = h->h.distinctOverflow();
+  out->min = h->h.min();
+  out->max = h->h.max();
+  out->multiplier = h->h.multiplier();
+  out->range_size = h->h.rangeSize();
+  out->num_distinct = h->h.numDistinct();
+}
+
+// Range-mode value ids for several keys at once; the per-key arithmetic is
+// VectorHasher.h:523-566 (tryMapToRange / valueId) and VectorHasher.cpp:196-224.
+int orc_value_ids(const vx355_batch* batch, const int32_t* key_cols,
+                  const vx355_value_id_spec* specs, int32_t n_keys, const uint64_t* rows,
+                  int32_t lookup, uint64_t* result, uint64_t* rows_out, int32_t* all_mapped) {
+  ORC_TRY
+  const int32_t n = batch->num_rows;
+  const int32_t words = (n + 63) / 64;
+  std::vector<uint64_t> sel(words, ~0ULL);
+  if (rows) {
+    std::memcpy(sel.data(), rows, words * 8);
+  }
+  if (n & 63) {
+    sel.back() &= (1ULL << (n & 63)) - 1;
+  }
+  bool mapped = true;
+  for (int32_t k = 0; k < n_keys; ++k) {
+    const vx355_column* col = &batch->cols[key_cols[k]];
+    Decoded d(col);
+    const auto& s = specs[k];
+    const bool isString = isStringKind(col->type_kind);
+    for (int32_t r = 0; r < n; ++r) {
+      if (!bitSet(sel.data(), r)) {
+        continue;
+      }
+      if (d.isNull(r)) {
+        if (s.multiplier == 1) {
+          result[r] = 0;
+        }
+        continue;
+      }
+      uint64_t id;
+      if (col->type_kind == VX355_BOOLEAN) {
+        id = d.int64At(r) ? 2 : 1;
+      } else {
+        int64_t v;
+        bool ok = true;
+        if (isString) {
+          uint8_t tmp;
+          auto* sv = static_cast<const StringView*>(d.valuePtr(r, &tmp));
+          if (sv->size > VectorHasher::kStringASRangeMaxSize) {
+            ok = false;
+            v = 0;
+          } else {
+            v = VectorHasher::stringAsNumber(sv->data(), sv->size);
+          }
+        } else {
+          v = d.int64At(r);
+        }
+        if (!ok || v < s.min || v > s.max) {
+          if (lookup) {
+            setBit(sel.data(), r, false);
+          } else {
+            mapped = false;
+          }
+          continue;
+        }
+        id = static_cast<uint64_t>(v) - static_cast<uint64_t>(s.min) + 1;
+      }
+      result[r] = s.multiplier == 1 ? id : result[r] + s.multiplier * id;
+    }
+  }
+  if (lookup && rows_out) {
+    std::memcpy(rows_out, sel.data(), words * 8);
+  }
+  if (all_mapped) {
+    *all_mapped = mapped ? 1 : 0;
+  }
+  ORC_CATCH
+}
+
+// processFlatFilterResults (exec/OperatorUtils.cpp:231-257).
+int orc_filter_compact(const uint64_t* values, const uint64_t* nulls, const uint64_t* rows,
+                       int32_t num_rows, int32_t* idx_out, int32_t* n_out) {
+  int32_t passed = 0;
+  for (int32_t r = 0; r < num_rows; ++r) {
+    if (bitSet(values, r) && (!nulls || bitSet(nulls, r)) && (!rows || bitSet(rows, r))) {
+      idx_out[passed++] = r;
+    }
+  }
+  *n_out = passed;
+  return VX355_OK;
+}
+
+// HashPartitionFunction::partition (exec/HashPartitionFunction.cpp:76-118).
+int orc_partition(const uint64_t* hashes, int32_t num_rows, int32_t kind, int32_t num_partitions,
+                  int32_t bit_begin, int32_t bit_end, uint32_t* out) {
+  const uint64_t mask = bit_end - bit_begin >= 64 ? ~0ULL : ((1ULL << (bit_end - bit_begin)) - 1);
+  for (int32_t i = 0; i < num_rows; ++i) {
+    uint64_t h = hashes[i];
+    switch (kind) {
+      case VX355_PART_MODULO:
+        out[i] = static_cast<uint32_t>(h % static_cast<uint64_t>(num_partitions));
+        break;
+      case VX355_PART_BIT_RANGE:
+        out[i] = static_cast<uint32_t>((h >> bit_begin) & mask);
+        break;
+      case VX355_PART_LOCAL_MODULO: {
+        uint32_t l = xxh32U32(reverseBitsPerByte(static_cast<uint32_t>(h)), 0);
+        out[i] = l % static_cast<uint32_t>(num_partitions);
+        break;
+      }
+      case VX355_PART_LOCAL_BIT_RANGE: {
+        uint32_t l = xxh32U32(reverseBitsPerByte(static_cast<uint32_t>(h)), 0);
+        out[i] = static_cast<uint32_t>((static_cast<uint64_t>(l) >> bit_begin) & mask);
+        break;
+      }
+      default:
+        return VX355_EINVAL;
+    }
+  }
+  return VX355_OK;
+}
+
+int orc_agg_create(const vx355_agg_spec* spec, int32_t hash_adaptivity, orc_agg** out) {
+  ORC_TRY
+  *out = new orc_agg(*spec, hash_adaptivity != 0);
+  ORC_CATCH
+}
+int orc_agg_add_input(orc_agg* h, const vx355_batch* batch) {
+  ORC_TRY
+  h->a.addInput(*batch);
+  ORC_CATCH
+}
+int orc_agg_no_more_input(orc_agg* h) {
+  h->a.noMoreInput();
+  return VX355_OK;
+}
+int orc_agg_get_output(orc_agg* h, vx355_out_column* cols, int32_t num_cols, int32_t max_rows,
+                       int32_t* n_out, int32_t* finished) {
+  ORC_TRY
+  h->a.getOutput(cols, num_cols, max_rows, n_out, finished);
+  ORC_CATCH
+}
+int orc_agg_get_stats(const orc_agg* h, vx355_agg_stats* out) {
+  h->a.stats(out);
+  return VX355_OK;
+}
+void orc_agg_destroy(orc_agg* h) { delete h; }
+
+int orc_join_build_create(const vx355_join_build_spec* spec, orc_join_build** out) {
+  ORC_TRY
+  *out = new orc_join_build(*spec);
+  ORC_CATCH
+}
+int orc_join_build_add_input(orc_join_build* h, const vx355_batch* batch) {
+  ORC_TRY
+  h->b.addInput(*batch);
+  ORC_CATCH
+}
+// HashBuild::finishHashBuild (HashBuild.cpp:819-993): the last driver steals
+// its peers' tables and builds one table.
+int orc_join_build_finish(orc_join_build* h, orc_join_build* const* others, int32_t num_others,
+                          orc_join_table** out) {
+  ORC_TRY
+  auto* t = new orc_join_table();
+  t->t.table = std::move(h->b.table_);
+  t->t.depKinds = h->b.depKinds_;
+  std::vector<HashTable*> raw;
+  int64_t base = 0;
+  t->t.containers.push_back(t->t.table->rows());
+  t->t.containerBase.push_back(0);
+  base += t->t.table->rows()->numRows();
+  for (int32_t i = 0; i < num_others; ++i) {
+    t->t.others.push_back(std::move(others[i]->b.table_));
+    auto* other = t->t.others.back().get();
+    raw.push_back(other);
+    // Re-number the merged rows after this table's rows.
+    for (char* row : other->rows()->rows()) {
+      *reinterpret_cast<int64_t*>(row + other->rows()->rowIdOffset()) += base;
+    }
+    t->t.containers.push_back(other->rows());
+    t->t.containerBase.push_back(base);
+    base += other->rows()->numRows();
+  }
+  t->t.numRows = base;
+  t->t.table->prepareJoinTable(raw);
+  *out = t;
+  ORC_CATCH
+}
+void orc_join_build_destroy(orc_join_build* h) { delete h; }
+void orc_join_table_release(orc_join_table* t) { delete t; }
+int orc_join_table_get_stats(const orc_join_table* t, vx355_join_table_stats* out) {
+  out->num_rows = t->t.numRows;
+  out->num_distinct = t->t.table->numDistinctKeys();
+  out->capacity = static_cast<int64_t>(t->t.table->capacity());
+  out->hash_mode = static_cast<int32_t>(t->t.table->hashMode());
+  out->has_duplicates = t->t.table->hasDuplicates();
+  return VX355_OK;
+}
+int orc_join_probe_create(orc_join_table* t, const vx355_join_probe_spec* spec,
+                          orc_join_probe** out) {
+  ORC_TRY
+  switch (spec->join_type) {
+    case VX355_JOIN_INNER:
+    case VX355_JOIN_LEFT:
+    case VX355_JOIN_LEFT_SEMI_FILTER:
+    case VX355_JOIN_ANTI:
+      break;
+    default:
+      gLastError = "join type not restated in the oracle";
+      return VX355_EUNSUPPORTED;
+  }
+  *out = new orc_join_probe(&t->t, *spec);
+  ORC_CATCH
+}
+int orc_join_probe_add_input(orc_join_probe* h, const vx355_batch* batch) {
+  ORC_TRY
+  h->p.addInput(*batch);
+  ORC_CATCH
+}
+int orc_join_probe_get_output(orc_join_probe* h, int32_t max_rows, int32_t* mapping_out,
+                              int32_t* build_rows_out, vx355_out_column* build_cols,
+                              const int32_t* build_col_ids, int32_t num_build_cols,
+                              int32_t* n_out, int32_t* finished) {
+  ORC_TRY
+  h->p.getOutput(max_rows, mapping_out, build_rows_out, build_cols, build_col_ids, num_build_cols,
+                 n_out, finished);
+  ORC_CATCH
+}
+void orc_join_probe_destroy(orc_join_probe* h) { delete h; }
+
+}  // extern "C"

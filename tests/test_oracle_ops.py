@@ -1,0 +1,322 @@
+"""Oracle group-by / join / filter / partition checked against independent
+implementations (pandas, numpy) and the reference's hash-mode expectations
+(/root/reference/velox/exec/tests/HashTableTest.cpp:607-655)."""
+import math
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from velox_amd import abi
+
+M64 = (1 << 64) - 1
+
+
+def _int_batch(cols, valids=None):
+    hc = []
+    for i, c in enumerate(cols):
+        c = np.asarray(c)
+        kind = {np.dtype(np.int64): abi.BIGINT, np.dtype(np.int32): abi.INTEGER,
+                np.dtype(np.float64): abi.DOUBLE, np.dtype(np.float32): abi.REAL,
+                np.dtype(np.int16): abi.SMALLINT, np.dtype(np.int8): abi.TINYINT}[c.dtype]
+        hc.append(abi.HostColumn(kind, c, None if valids is None else valids[i]))
+    return abi.HostBatch(hc)
+
+
+# ---- hash mode decisions (HashTableTest.cpp testCycle) ----------------------
+def _join_mode(oracle, size, ways, key_kinds, spacing=1):
+    builds = []
+    seq = 0
+    for _ in range(ways):
+        cols = []
+        for k in key_kinds:
+            vals = spacing * (seq + np.arange(size, dtype=np.int64))
+            if k == abi.VARCHAR:
+                strs = []
+                for r, v in enumerate(vals):
+                    s = str(int(v))
+                    if r > 10000 and r % 10 == 0:
+                        s += "----" + s + "----" + s
+                    strs.append(s.encode())
+                cols.append(abi.HostColumn(abi.VARCHAR, strs))
+            else:
+                cols.append(abi.HostColumn(abi.BIGINT, vals))
+        b = oracle.JoinBuild(list(range(len(key_kinds))), key_kinds)
+        b.add_input(abi.HostBatch(cols))
+        builds.append(b)
+        seq += size
+    table = builds[0].finish(builds[1:])
+    st = table.stats()
+    assert st.num_rows == size * ways
+    return st.hash_mode, table, builds
+
+
+def test_mode_int2_dense_array(oracle):
+    assert _join_mode(oracle, 500, 2, [abi.BIGINT, abi.BIGINT])[0] == abi.MODE_ARRAY
+
+
+def test_mode_string1_dense_array(oracle):
+    assert _join_mode(oracle, 500, 2, [abi.VARCHAR])[0] == abi.MODE_ARRAY
+
+
+def test_mode_string2_normalized(oracle):
+    assert _join_mode(oracle, 5000, 19, [abi.VARCHAR, abi.VARCHAR])[0] == abi.MODE_NORMALIZED_KEY
+
+
+def test_mode_int2_sparse_array(oracle):
+    assert _join_mode(oracle, 500, 2, [abi.BIGINT, abi.BIGINT], spacing=1000)[0] == abi.MODE_ARRAY
+
+
+def test_mode_int2_sparse_normalized(oracle):
+    assert _join_mode(oracle, 10000, 2, [abi.BIGINT, abi.BIGINT], spacing=1000)[0] == abi.MODE_NORMALIZED_KEY
+
+
+def test_mode_mixed6_sparse_hash(oracle):
+    kinds = [abi.BIGINT] * 5 + [abi.VARCHAR]
+    assert _join_mode(oracle, 20000, 9, kinds, spacing=1000)[0] == abi.MODE_HASH
+
+
+def test_probe_every_key_hits_its_row(oracle):
+    """HashTableTest::testProbe (:466): every inserted key is found, others miss."""
+    mode, table, _ = _join_mode(oracle, 3000, 2, [abi.BIGINT, abi.BIGINT], spacing=1000)
+    keys = 1000 * np.arange(0, 7000, dtype=np.int64)
+    probe = oracle.JoinProbe(table, [0, 1], abi.JOIN_LEFT)
+    probe.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, keys), abi.HostColumn(abi.BIGINT, keys)]))
+    mapping, build_rows, _, fin = probe.get_output(10000, build_col_ids=[])
+    assert fin and list(mapping) == list(range(7000))
+    assert (build_rows[:6000] == np.arange(6000)).all()
+    assert (build_rows[6000:] == -1).all()
+
+
+# ---- group by vs pandas --------------------------------------------------------
+def _run_agg(oracle, batches, key_cols, key_types, aggs, step=abi.STEP_SINGLE, **kw):
+    op = oracle.Aggregation(key_cols, key_types, aggs, step, **kw)
+    for b in batches:
+        op.add_input(b)
+    op.no_more_input()
+    return oracle.collect_output(op, 777), op
+
+
+@pytest.mark.parametrize("adaptive", [True, False])
+def test_groupby_c1_shape_vs_pandas(oracle, adaptive):
+    rng = np.random.default_rng(7)
+    n = 50000
+    k = rng.integers(0, 1000, n).astype(np.int64)
+    v = rng.random(n)
+    batches = [_int_batch([k[i:i + 10000], v[i:i + 10000]]) for i in range(0, n, 10000)]
+    aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT),
+            (abi.AGG_MIN, 1, abi.DOUBLE), (abi.AGG_MAX, 1, abi.DOUBLE), (abi.AGG_AVG, 1, abi.DOUBLE)]
+    out, op = _run_agg(oracle, batches, [0], [abi.BIGINT], aggs, hash_adaptivity=adaptive)
+    assert op.stats().hash_mode == (abi.MODE_ARRAY if adaptive else abi.MODE_HASH)
+    keys = out[0][0]
+    # first-seen order (GroupingSet.cpp:828-839)
+    _, first = np.unique(k, return_index=True)
+    assert list(keys) == list(k[np.sort(first)])
+    df = pd.DataFrame({"k": k, "v": v}).groupby("k", sort=False)["v"]
+    ref = df.agg(["sum", "count", "min", "max", "mean"]).loc[keys]
+    # Sequential sum in input order is what the reference computes; pandas may
+    # reassociate, so compare sums with a few-ULP tolerance and the rest exactly.
+    np.testing.assert_allclose(out[1][0], ref["sum"].values, rtol=1e-13)
+    assert (out[2][0] == ref["count"].values).all()
+    assert (out[3][0] == ref["min"].values).all()
+    assert (out[4][0] == ref["max"].values).all()
+    np.testing.assert_allclose(out[5][0], ref["mean"].values, rtol=1e-13)
+    # and bit-exact against a straight Python left-to-right sum for a few groups
+    for g in keys[:5]:
+        s = 0.0
+        for x in v[k == g]:
+            s += x
+        assert out[1][0][list(keys).index(g)] == s
+
+
+def test_groupby_modes_and_null_keys(oracle):
+    rng = np.random.default_rng(8)
+    n = 20000
+    # sparse keys in a huge range -> not an array; two keys -> normalized key
+    k1 = (rng.integers(0, 400000, n) * 1000003).astype(np.int64)
+    k2 = rng.integers(-500, 500, n).astype(np.int32)
+    valid1 = rng.random(n) > 0.1
+    v = rng.integers(-1000, 1000, n).astype(np.int64)
+    vvalid = rng.random(n) > 0.2
+    batch = abi.HostBatch([abi.HostColumn(abi.BIGINT, k1, valid1), abi.HostColumn(abi.INTEGER, k2),
+                           abi.HostColumn(abi.BIGINT, v, vvalid)])
+    aggs = [(abi.AGG_SUM, 2, abi.BIGINT), (abi.AGG_COUNT, 2, abi.BIGINT), (abi.AGG_AVG, 2, abi.BIGINT)]
+    out, op = _run_agg(oracle, [batch], [0, 1], [abi.BIGINT, abi.INTEGER], aggs)
+    assert op.stats().hash_mode == abi.MODE_NORMALIZED_KEY
+    df = pd.DataFrame({"k1": pd.array(np.where(valid1, k1, 0), dtype="Int64"), "k2": k2,
+                       "v": pd.array(v, dtype="Int64")})
+    df.loc[~valid1, "k1"] = pd.NA
+    df.loc[~vvalid, "v"] = pd.NA
+    ref = df.groupby(["k1", "k2"], dropna=False, sort=False)["v"].agg(["sum", "count", "mean"])
+    got = {}
+    for i in range(len(out[0][0])):
+        key = (int(out[0][0][i]) if out[0][1][i] else None, int(out[1][0][i]))
+        got[key] = (int(out[2][0][i]) if out[2][1][i] else None, int(out[3][0][i]),
+                    float(out[4][0][i]) if out[4][1][i] else None)
+    assert len(got) == len(ref)
+    for (a, b), row in ref.iterrows():
+        key = (None if pd.isna(a) else int(a), int(b))
+        s, c, m = got[key]
+        assert c == row["count"]
+        if row["count"] == 0:
+            assert s is None and m is None  # all-null group -> NULL sum/avg, count 0
+        else:
+            assert s == row["sum"] and m == pytest.approx(float(row["mean"]), rel=1e-15)
+    # ignoreNullKeys drops the rows with a null key
+    out2, _ = _run_agg(oracle, [batch], [0, 1], [abi.BIGINT, abi.INTEGER], aggs, ignore_null_keys=True)
+    assert len(out2[0][0]) == sum(1 for k in got if k[0] is not None)
+    assert out2[0][1].all()
+
+
+def test_groupby_string_and_double_keys_hash_mode(oracle):
+    rng = np.random.default_rng(9)
+    n = 5000
+    flags = [bytes([c]) for c in rng.choice(list(b"ANR"), n)]
+    d = rng.choice([0.0, -0.0, 1.5, float("nan"), -2.25], n)
+    v = rng.random(n).astype(np.float32)
+    batch = abi.HostBatch([abi.HostColumn(abi.VARCHAR, flags), abi.HostColumn(abi.DOUBLE, d),
+                           abi.HostColumn(abi.REAL, v)])
+    aggs = [(abi.AGG_SUM, 2, abi.REAL), (abi.AGG_MAX, 2, abi.REAL), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    out, op = _run_agg(oracle, [batch], [0, 1], [abi.VARCHAR, abi.DOUBLE], aggs)
+    assert op.stats().hash_mode == abi.MODE_HASH  # DOUBLE keys have no value ids
+    # 0.0 and -0.0 are one group, all NaNs are one group: 3 flags x 4 values
+    assert len(out[0][0]) == 12
+    total = 0
+    for i in range(12):
+        f, dv = out[0][0][i], out[1][0][i]
+        sel = np.array([flags[j] == f and (d[j] == dv or (math.isnan(d[j]) and math.isnan(dv)))
+                        for j in range(n)])
+        assert out[4][0][i] == sel.sum()
+        acc = 0.0
+        for x in v[sel]:
+            acc += float(x)  # sum(REAL) accumulates in double
+        assert out[2][0][i] == np.float32(acc)
+        assert out[3][0][i] == v[sel].max()
+        total += sel.sum()
+    assert total == n
+
+
+def test_global_aggregation_and_masks(oracle):
+    v = np.array([1.0, 2.0, 3.0, 4.0])
+    m = abi.HostColumn(abi.BOOLEAN, [True, False, True, True], valid=[True, True, False, True])
+    batch = abi.HostBatch([abi.HostColumn(abi.DOUBLE, v), m])
+    aggs = [(abi.AGG_SUM, 0, abi.DOUBLE, 1), (abi.AGG_COUNT_STAR, -1, abi.BIGINT, 1),
+            (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    out, _ = _run_agg(oracle, [batch], [], [], aggs)
+    assert out[0][0][0] == 5.0 and out[1][0][0] == 2 and out[2][0][0] == 4
+    # empty input still yields one row: NULL sum, zero counts
+    out, _ = _run_agg(oracle, [], [], [], aggs)
+    assert len(out[0][0]) == 1 and not out[0][1][0] and out[1][0][0] == 0
+
+
+def test_sum_bigint_overflow_is_a_user_error(oracle):
+    big = np.array([2 ** 62, 2 ** 62, 5], dtype=np.int64)
+    op = oracle.Aggregation([], [], [(abi.AGG_SUM, 0, abi.BIGINT)])
+    with pytest.raises(oracle.OracleError) as e:
+        op.add_input(_int_batch([big]))
+    assert e.value.status == abi.EUSER and "integer overflow" in str(e.value)
+
+
+def test_partial_then_final_equals_single(oracle):
+    rng = np.random.default_rng(10)
+    n = 30000
+    k = rng.integers(0, 97, n).astype(np.int64)
+    v = rng.random(n)
+    aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_AVG, 1, abi.DOUBLE), (abi.AGG_COUNT, 1, abi.DOUBLE),
+            (abi.AGG_MIN, 1, abi.DOUBLE)]
+    single, _ = _run_agg(oracle, [_int_batch([k, v])], [0], [abi.BIGINT], aggs)
+    parts = []
+    for lo in range(0, n, 10000):
+        p, _ = _run_agg(oracle, [_int_batch([k[lo:lo + 10000], v[lo:lo + 10000]])], [0], [abi.BIGINT],
+                        aggs, step=abi.STEP_PARTIAL)
+        parts.append(p)
+    # partial output: k, sum, (avg.sum, avg.count), count, min
+    fin_aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_AVG, 2, abi.DOUBLE, -1, 3),
+                (abi.AGG_COUNT, 4, abi.DOUBLE), (abi.AGG_MIN, 5, abi.DOUBLE)]
+    fin = oracle.Aggregation([0], [abi.BIGINT], fin_aggs, abi.STEP_FINAL)
+    for p in parts:
+        cols = [abi.HostColumn(abi.BIGINT, p[0][0]), abi.HostColumn(abi.DOUBLE, p[1][0], p[1][1]),
+                abi.HostColumn(abi.DOUBLE, p[2][0], p[2][1]), abi.HostColumn(abi.BIGINT, p[3][0], p[3][1]),
+                abi.HostColumn(abi.BIGINT, p[4][0]), abi.HostColumn(abi.DOUBLE, p[5][0], p[5][1])]
+        fin.add_input(abi.HostBatch(cols))
+    fin.no_more_input()
+    final = oracle.collect_output(fin)
+    a = {int(kk): i for i, kk in enumerate(single[0][0])}
+    for i, kk in enumerate(final[0][0]):
+        j = a[int(kk)]
+        assert final[1][0][i] == pytest.approx(single[1][0][j], rel=1e-14)
+        assert final[2][0][i] == pytest.approx(single[2][0][j], rel=1e-14)
+        assert final[3][0][i] == single[3][0][j]
+        assert final[4][0][i] == single[4][0][j]
+
+
+# ---- joins vs pandas -----------------------------------------------------------
+@pytest.mark.parametrize("join_type", [abi.JOIN_INNER, abi.JOIN_LEFT, abi.JOIN_LEFT_SEMI_FILTER, abi.JOIN_ANTI])
+def test_join_vs_pandas(oracle, join_type):
+    rng = np.random.default_rng(11)
+    nb, npb = 4000, 9000
+    bk = rng.integers(0, 1500, nb).astype(np.int64)  # duplicates
+    bvalid = rng.random(nb) > 0.05
+    bpay = rng.integers(0, 1 << 40, nb).astype(np.int64)
+    pk = rng.integers(0, 3000, npb).astype(np.int64)
+    pvalid = rng.random(npb) > 0.05
+    builds = []
+    for lo in (0, 2500):
+        b = oracle.JoinBuild([0], [abi.BIGINT], [1], [abi.BIGINT], join_type)
+        for s in range(lo, min(nb, lo + 2500), 1000):
+            e = min(lo + 2500, s + 1000, nb)
+            b.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, bk[s:e], bvalid[s:e]),
+                                       abi.HostColumn(abi.BIGINT, bpay[s:e])]))
+        builds.append(b)
+    table = builds[0].finish(builds[1:])
+    st = table.stats()
+    assert st.num_rows == bvalid.sum() and st.has_duplicates == 1
+    assert st.num_distinct == len(np.unique(bk[bvalid]))
+    probe = oracle.JoinProbe(table, [0], join_type)
+    probe.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, pk, pvalid)]))
+    got = []
+    last = -1
+    while True:
+        mapping, build_rows, cols, fin = probe.get_output(1000)
+        assert (np.diff(mapping) >= 0).all() and (len(mapping) == 0 or mapping[0] >= last)
+        if len(mapping):
+            last = mapping[-1]
+        for i in range(len(mapping)):
+            got.append((int(mapping[i]), int(cols[0][0][i]) if cols[0][1][i] else None))
+        if fin:
+            break
+    bdf = pd.DataFrame({"k": bk[bvalid], "pay": bpay[bvalid]})
+    pdf = pd.DataFrame({"row": np.arange(npb), "k": pk})[pvalid]
+    if join_type == abi.JOIN_INNER:
+        m = pdf.merge(bdf, on="k")
+        want = sorted(zip(m["row"], m["pay"]))
+    elif join_type == abi.JOIN_LEFT:
+        m = pdf.merge(bdf, on="k", how="left")
+        want = [(int(r), None if pd.isna(p) else int(p)) for r, p in zip(m["row"], m["pay"])]
+        want += [(int(r), None) for r in np.arange(npb)[~pvalid]]
+        want = sorted(want, key=lambda t: (t[0], -1 if t[1] is None else t[1]))
+    elif join_type == abi.JOIN_LEFT_SEMI_FILTER:
+        want = [(int(r), None) for r in pdf["row"][pdf["k"].isin(bdf["k"])]]
+    else:
+        hit = set(pdf["row"][pdf["k"].isin(bdf["k"])])
+        want = [(r, None) for r in range(npb) if r not in hit]
+    assert sorted(got, key=lambda t: (t[0], -1 if t[1] is None else t[1])) == list(want)
+
+
+def test_filter_compact_and_partition(oracle):
+    rng = np.random.default_rng(12)
+    n = 1000
+    v, nl, rw = rng.random(n) > 0.3, rng.random(n) > 0.1, rng.random(n) > 0.2
+    assert list(oracle.filter_compact(v, nl, rw)) == list(np.nonzero(v & nl & rw)[0])
+    assert list(oracle.filter_compact(v)) == list(np.nonzero(v)[0])
+    xxhash = pytest.importorskip("xxhash")
+    h = rng.integers(0, 1 << 63, n, dtype=np.uint64) * 2 + 1
+    assert (oracle.partition(h, abi.PART_MODULO, 7) == (h % np.uint64(7))).all()
+    assert (oracle.partition(h, abi.PART_BIT_RANGE, bit_begin=29, bit_end=32) == ((h >> np.uint64(29)) & np.uint64(7))).all()
+    import struct
+    def local(x):
+        x32 = int(x) & 0xFFFFFFFF
+        rev = int.from_bytes(bytes(int(f"{b:08b}"[::-1], 2) for b in x32.to_bytes(4, "little")), "little")
+        return xxhash.xxh32(struct.pack("<I", rev), seed=0).intdigest()
+    want = np.array([local(x) % 5 for x in h], dtype=np.uint32)
+    assert (oracle.partition(h, abi.PART_LOCAL_MODULO, 5) == want).all()
