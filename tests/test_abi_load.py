@@ -1,0 +1,53 @@
+"""CPU-side checks of the drop-in boundary: libvx355.so builds for gfx950, loads
+without a GPU and exports every symbol include/vx355.h declares. No compute is
+launched here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from velox_amd import abi, build, ops
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build_lib()
+    return ops.lib()
+
+
+def test_header_and_symbol_list_agree():
+    text = open(os.path.join(ROOT, "include", "vx355.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = set(re.findall(r"\b(vx355_[a-z0-9_]+)\s*\(", text))
+    assert declared == set(ops.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for name in ops.SYMBOLS:
+        assert hasattr(lib, name), name
+
+
+def test_calls_that_need_no_gpu(lib):
+    assert lib.vx355_abi_version() == 1
+    if lib.vx355_device_count() == 0:
+        # No device: init must fail loudly, and operators refuse to be created.
+        assert lib.vx355_init(0) != abi.OK
+        assert lib.vx355_last_error()
+        spec, keep = ops.make_agg_spec([0], [abi.BIGINT], [(abi.AGG_COUNT_STAR, -1, abi.BIGINT)],
+                                       abi.STEP_SINGLE)
+        h = C.c_void_p()
+        assert lib.vx355_agg_create(C.byref(spec), C.byref(h)) == abi.EINVAL
+        assert b"vx355_init" in lib.vx355_last_error()
+
+
+def test_product_package_does_not_touch_the_oracle():
+    pkg = os.path.join(ROOT, "velox_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "liboracle" not in src and "oracle_lib" not in src, f
+                assert not re.search(r'#include\s+"[^"]*oracle', src), f

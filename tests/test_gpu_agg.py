@@ -1,0 +1,271 @@
+"""HashAggregation on the MI355X vs the CPU oracle, through the C ABI.
+
+Parity bar (BASELINE.json north_star): group keys, group order (first seen),
+counts, integer sums, min/max bit-exact. DOUBLE sums are order dependent: on
+exactly representable data (dyadic rationals) they must be bit-identical; on
+arbitrary doubles the GPU result must lie within 1 ULP of the correctly
+rounded sum (math.fsum), which is the tolerance north_star states."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from velox_amd import abi
+from gpu_util import assert_columns_equal, batch_of, exact_group_sums, run_agg, ulp_distance
+
+pytestmark = pytest.mark.gpu
+
+C1_AGGS = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT),
+           (abi.AGG_MIN, 1, abi.DOUBLE), (abi.AGG_MAX, 1, abi.DOUBLE), (abi.AGG_AVG, 1, abi.DOUBLE)]
+
+
+def _dyadic(rng, n, scale=1024, hi=1 << 20):
+    return rng.integers(0, hi, n).astype(np.float64) / scale
+
+
+def test_c1_shape_batches_bit_exact(oracle, vx):
+    """BASELINE config 1 shape: k BIGINT in [0,1000), v DOUBLE, 10 000-row batches."""
+    rng = np.random.default_rng(1)
+    n = 200000
+    k = rng.integers(0, 1000, n).astype(np.int64)
+    v = _dyadic(rng, n)
+    batches = [batch_of([k[i:i + 10000], v[i:i + 10000]]) for i in range(0, n, 10000)]
+    exp, eop = run_agg(oracle, batches, [0], [abi.BIGINT], C1_AGGS)
+    got, gop = run_agg(vx, batches, [0], [abi.BIGINT], C1_AGGS)
+    assert_columns_equal(got, exp, gop.kinds, what="c1")
+    st = gop.stats()
+    assert st.num_groups == 1000 and st.hash_mode == abi.MODE_ARRAY and st.input_rows == n
+    # first-seen order
+    _, first = np.unique(k, return_index=True)
+    assert list(got[0][0]) == list(k[np.sort(first)])
+
+
+def test_random_doubles_within_one_ulp_of_exact_sum(oracle, vx):
+    rng = np.random.default_rng(2)
+    n = 300000
+    k = rng.integers(0, 500, n).astype(np.int64)
+    v = rng.random(n)
+    got, gop = run_agg(vx, [batch_of([k, v])], [0], [abi.BIGINT], C1_AGGS)
+    exp, _ = run_agg(oracle, [batch_of([k, v])], [0], [abi.BIGINT], C1_AGGS)
+    assert (got[0][0] == exp[0][0]).all()
+    exact = exact_group_sums([(int(x),) for x in k], v)
+    keys = [int(x) for x in got[0][0]]
+    e = np.array([exact[(kk,)] for kk in keys])
+    assert (ulp_distance(got[1][0], e) <= 1).all()       # sum: tolerance = 1 ULP of the exact sum
+    cnt = np.asarray(got[2][0], dtype=np.float64)
+    assert (got[2][0] == exp[2][0]).all()
+    assert (got[3][0] == exp[3][0]).all() and (got[4][0] == exp[4][0]).all()
+    assert (ulp_distance(got[5][0], e / cnt) <= 2).all()  # avg = sum/count: one more rounding
+
+
+def test_two_keys_nulls_int_sums_and_ignore_null_keys(oracle, vx):
+    rng = np.random.default_rng(8)
+    n = 50000
+    k1 = rng.integers(-300, 300, n).astype(np.int64)
+    k2 = rng.integers(-5, 5, n).astype(np.int32)
+    valid1 = rng.random(n) > 0.1
+    v = rng.integers(-1000, 1000, n).astype(np.int64)
+    vvalid = rng.random(n) > 0.2
+    b = batch_of([k1, k2, v], [valid1, None, vvalid])
+    aggs = [(abi.AGG_SUM, 2, abi.BIGINT), (abi.AGG_COUNT, 2, abi.BIGINT), (abi.AGG_AVG, 2, abi.BIGINT),
+            (abi.AGG_MIN, 2, abi.BIGINT), (abi.AGG_MAX, 2, abi.BIGINT), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    for ignore in (False, True):
+        exp, _ = run_agg(oracle, [b], [0, 1], [abi.BIGINT, abi.INTEGER], aggs, ignore_null_keys=ignore)
+        got, gop = run_agg(vx, [b], [0, 1], [abi.BIGINT, abi.INTEGER], aggs, ignore_null_keys=ignore)
+        assert_columns_equal(got, exp, gop.kinds, what=f"ignore={ignore}")
+
+
+@pytest.mark.parametrize("array_max", [None, "64"])
+def test_sparse_keys_normalized_mode_and_growth(oracle, vx, array_max, monkeypatch):
+    """Sparse two-key group-by: array mode by default on the GPU (288 GB HBM);
+    VX355_ARRAY_MAX forces the open-addressing (normalized key) table."""
+    if array_max:
+        monkeypatch.setenv("VX355_ARRAY_MAX", array_max)
+    rng = np.random.default_rng(3)
+    n = 120000
+    k1 = (rng.integers(0, 4000, n) * 1003).astype(np.int64)
+    k2 = rng.integers(-50, 50, n).astype(np.int32)
+    v = _dyadic(rng, n)
+    batches = [batch_of([k1[i:i + 30000], k2[i:i + 30000], v[i:i + 30000]]) for i in range(0, n, 30000)]
+    aggs = [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT), (abi.AGG_MAX, 2, abi.DOUBLE)]
+    exp, _ = run_agg(oracle, batches, [0, 1], [abi.BIGINT, abi.INTEGER], aggs)
+    got, gop = run_agg(vx, batches, [0, 1], [abi.BIGINT, abi.INTEGER], aggs)
+    assert_columns_equal(got, exp, gop.kinds, what="sparse")
+    st = gop.stats()
+    assert st.hash_mode == (abi.MODE_NORMALIZED_KEY if array_max else abi.MODE_ARRAY)
+    assert st.num_groups == len(exp[0][0])
+
+
+def test_range_widening_replays_deferred_rows(oracle, vx):
+    """Keys drift upward batch after batch (like l_orderkey): ranges widen, the
+    table is re-keyed on device and only the out-of-range rows are replayed."""
+    rng = np.random.default_rng(4)
+    batches = []
+    for i in range(8):
+        lo = i * 700
+        k = rng.integers(lo, lo + 1000, 20000).astype(np.int64)
+        s = [bytes([65 + int(x)]) for x in rng.integers(0, 3 + i, 20000)]
+        batches.append(batch_of([k, s, _dyadic(rng, 20000)]))
+    aggs = [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    exp, _ = run_agg(oracle, batches, [0, 1], [abi.BIGINT, abi.VARCHAR], aggs)
+    got, gop = run_agg(vx, batches, [0, 1], [abi.BIGINT, abi.VARCHAR], aggs)
+    assert_columns_equal(got, exp, gop.kinds, what="widening")
+    st = gop.stats()
+    assert st.deferred_rows > 0 and st.num_rehashes > 0
+
+
+def test_q1_shape_string_keys_dictionary_inputs(oracle, vx):
+    """TPC-H Q1 at the operator boundary: two 1-char VARCHAR keys and DOUBLE
+    inputs wrapped in dictionaries over the filter's selected rows."""
+    rng = np.random.default_rng(5)
+    n = 100000
+    rf = [bytes([c]) for c in rng.choice(list(b"ANR"), n)]
+    ls = [bytes([c]) for c in rng.choice(list(b"FO"), n)]
+    qty = rng.integers(1, 51, n).astype(np.float64)
+    price = rng.integers(90000, 10500000, n).astype(np.float64) / 128
+    disc = rng.integers(0, 11, n).astype(np.float64) / 64
+    sel = np.flatnonzero(rng.random(n) < 0.985).astype(np.int32)
+    m = len(sel)
+    disc_price = (price * (1 - disc))[sel]
+
+    def wrap(kind, base):
+        return abi.HostColumn(kind, base, encoding=abi.DICTIONARY, indices=sel)
+    b = abi.HostBatch([wrap(abi.VARCHAR, rf), wrap(abi.VARCHAR, ls), wrap(abi.DOUBLE, qty),
+                       wrap(abi.DOUBLE, price), wrap(abi.DOUBLE, disc),
+                       abi.HostColumn(abi.DOUBLE, disc_price)], m)
+    aggs = [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_SUM, 3, abi.DOUBLE), (abi.AGG_SUM, 5, abi.DOUBLE),
+            (abi.AGG_AVG, 2, abi.DOUBLE), (abi.AGG_AVG, 3, abi.DOUBLE), (abi.AGG_AVG, 4, abi.DOUBLE),
+            (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    exp, _ = run_agg(oracle, [b], [0, 1], [abi.VARCHAR, abi.VARCHAR], aggs)
+    got, gop = run_agg(vx, [b], [0, 1], [abi.VARCHAR, abi.VARCHAR], aggs)
+    assert len(got[0][0]) == 6
+    assert_columns_equal(got, exp, gop.kinds, what="q1")
+
+
+def test_global_aggregation_masks_and_empty_input(oracle, vx):
+    v = np.array([1.0, 2.0, 3.0, 4.0])
+    mcol = abi.HostColumn(abi.BOOLEAN, [True, False, True, True], valid=[True, True, False, True])
+    b = abi.HostBatch([abi.HostColumn(abi.DOUBLE, v), mcol])
+    aggs = [(abi.AGG_SUM, 0, abi.DOUBLE, 1), (abi.AGG_COUNT_STAR, -1, abi.BIGINT, 1),
+            (abi.AGG_COUNT_STAR, -1, abi.BIGINT), (abi.AGG_MIN, 0, abi.DOUBLE, 1)]
+    for batches in ([b], []):
+        exp, _ = run_agg(oracle, batches, [], [], aggs)
+        got, gop = run_agg(vx, batches, [], [], aggs)
+        assert_columns_equal(got, exp, gop.kinds, what=f"global {len(batches)}")
+    assert got[0][1][0] == False and got[1][0][0] == 0  # noqa: E712  NULL sum, zero count
+
+
+def test_sum_bigint_overflow_is_a_user_error(oracle, vx):
+    big = np.array([2 ** 62, 2 ** 62, 5], dtype=np.int64)
+    op = vx.Aggregation([], [], [(abi.AGG_SUM, 0, abi.BIGINT)])
+    with pytest.raises(vx.Vx355Error) as e:
+        op.add_input(batch_of([big]))
+    assert e.value.status == abi.EUSER and "integer overflow" in str(e.value)
+
+
+def test_partial_then_final_equals_single(oracle, vx):
+    rng = np.random.default_rng(10)
+    n = 60000
+    k = rng.integers(0, 97, n).astype(np.int64)
+    v = _dyadic(rng, n)
+    vvalid = rng.random(n) > 0.3
+    aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_AVG, 1, abi.DOUBLE), (abi.AGG_COUNT, 1, abi.DOUBLE),
+            (abi.AGG_MIN, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    single, sop = run_agg(vx, [batch_of([k, v], [None, vvalid])], [0], [abi.BIGINT], aggs)
+    fin_aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_AVG, 2, abi.DOUBLE, -1, 3),
+                (abi.AGG_COUNT, 4, abi.DOUBLE), (abi.AGG_MIN, 5, abi.DOUBLE),
+                (abi.AGG_COUNT_STAR, 6, abi.BIGINT)]
+    for impl in (oracle, vx):
+        fin = impl.Aggregation([0], [abi.BIGINT], fin_aggs, abi.STEP_FINAL)
+        for lo in range(0, n, 20000):
+            sl = slice(lo, lo + 20000)
+            p, pop = run_agg(vx, [batch_of([k[sl], v[sl]], [None, vvalid[sl]])], [0], [abi.BIGINT], aggs,
+                             step=abi.STEP_PARTIAL)
+            po, _ = run_agg(oracle, [batch_of([k[sl], v[sl]], [None, vvalid[sl]])], [0], [abi.BIGINT],
+                            aggs, step=abi.STEP_PARTIAL)
+            assert_columns_equal(p, po, pop.kinds, what="partial")
+            cols = [abi.HostColumn(abi.BIGINT, p[0][0]), abi.HostColumn(abi.DOUBLE, p[1][0], p[1][1]),
+                    abi.HostColumn(abi.DOUBLE, p[2][0], p[2][1]), abi.HostColumn(abi.BIGINT, p[3][0], p[3][1]),
+                    abi.HostColumn(abi.BIGINT, p[4][0]), abi.HostColumn(abi.DOUBLE, p[5][0], p[5][1]),
+                    abi.HostColumn(abi.BIGINT, p[6][0])]
+            fin.add_input(abi.HostBatch(cols))
+        fin.no_more_input()
+        final = impl.collect_output(fin)
+        assert_columns_equal(final, single, sop.kinds, what=f"final via {impl.__name__}")
+
+
+def test_small_types_bool_keys_real_inputs_nan_minmax(oracle, vx):
+    rng = np.random.default_rng(11)
+    n = 40000
+    kb = rng.random(n) > 0.5
+    kt = rng.integers(-128, 128, n).astype(np.int8)
+    ks = rng.integers(-3, 3, n).astype(np.int16)
+    r = (rng.integers(0, 1 << 12, n) / 16).astype(np.float32)
+    d = rng.choice([0.5, -1.25, np.nan, np.inf, -np.inf, 1e300], n)
+    small = rng.integers(-100, 100, n).astype(np.int8)
+    flag = rng.random(n) > 0.5
+    b = batch_of([kb, kt, ks, r, d, small, flag], [rng.random(n) > 0.1, None, None, rng.random(n) > 0.1,
+                                                   rng.random(n) > 0.1, None, None])
+    aggs = [(abi.AGG_SUM, 3, abi.REAL), (abi.AGG_AVG, 3, abi.REAL), (abi.AGG_MIN, 3, abi.REAL),
+            (abi.AGG_MIN, 4, abi.DOUBLE), (abi.AGG_MAX, 4, abi.DOUBLE), (abi.AGG_SUM, 5, abi.TINYINT),
+            (abi.AGG_MAX, 5, abi.TINYINT), (abi.AGG_MIN, 6, abi.BOOLEAN), (abi.AGG_MAX, 6, abi.BOOLEAN),
+            (abi.AGG_COUNT, 4, abi.DOUBLE)]
+    keys, kinds = [0, 1, 2], [abi.BOOLEAN, abi.TINYINT, abi.SMALLINT]
+    exp, _ = run_agg(oracle, [b], keys, kinds, aggs)
+    got, gop = run_agg(vx, [b], keys, kinds, aggs)
+    assert_columns_equal(got, exp, gop.kinds, what="small types")
+
+
+def test_constant_and_dictionary_keys_and_chunking(oracle, vx, monkeypatch):
+    monkeypatch.setenv("VX355_AGG_CHUNK_ROWS", "4096")
+    rng = np.random.default_rng(12)
+    n = 50000
+    base = rng.integers(-40, 40, 64).astype(np.int64)
+    idx = rng.integers(0, 64, n).astype(np.int32)
+    kd = abi.HostColumn(abi.BIGINT, base, rng.random(n) > 0.05, encoding=abi.DICTIONARY, indices=idx)
+    kc = abi.HostColumn(abi.INTEGER, np.array([7], dtype=np.int32), encoding=abi.CONSTANT)
+    v = abi.HostColumn(abi.DOUBLE, _dyadic(rng, n), rng.random(n) > 0.5)
+    cv = abi.HostColumn(abi.DOUBLE, np.array([0.25]), encoding=abi.CONSTANT)
+    b = abi.HostBatch([kd, kc, v, cv], n)
+    aggs = [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_SUM, 3, abi.DOUBLE), (abi.AGG_COUNT, 2, abi.DOUBLE),
+            (abi.AGG_AVG, 2, abi.DOUBLE)]
+    exp, _ = run_agg(oracle, [b], [0, 1], [abi.BIGINT, abi.INTEGER], aggs)
+    got, gop = run_agg(vx, [b], [0, 1], [abi.BIGINT, abi.INTEGER], aggs, max_rows=10)
+    assert_columns_equal(got, exp, gop.kinds, what="encodings")
+
+
+def test_high_cardinality_hbm_path(oracle, vx):
+    """BASELINE config 4 shape, scaled down: many distinct BIGINT keys."""
+    rng = np.random.default_rng(13)
+    n = 400000
+    k = rng.integers(0, 150000, n).astype(np.int64)
+    v = _dyadic(rng, n)
+    aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    exp, _ = run_agg(oracle, [batch_of([k, v])], [0], [abi.BIGINT], aggs, max_rows=100000)
+    got, gop = run_agg(vx, [batch_of([k, v])], [0], [abi.BIGINT], aggs, max_rows=100000)
+    assert_columns_equal(got, exp, gop.kinds, what="high cardinality")
+    # sparse 64-bit keys -> open addressing on the normalized key
+    ks = ((k.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) % np.uint64(1 << 58)).astype(np.int64)
+    exp, _ = run_agg(oracle, [batch_of([ks, v])], [0], [abi.BIGINT], aggs, max_rows=100000)
+    got, gop = run_agg(vx, [batch_of([ks, v])], [0], [abi.BIGINT], aggs, max_rows=100000)
+    assert gop.stats().hash_mode == abi.MODE_NORMALIZED_KEY
+    assert_columns_equal(got, exp, gop.kinds, what="sparse high cardinality")
+
+
+def test_unsupported_keys_are_refused_at_create(vx):
+    with pytest.raises(vx.Vx355Error) as e:
+        vx.Aggregation([0], [abi.DOUBLE], [(abi.AGG_COUNT_STAR, -1, abi.BIGINT)])
+    assert e.value.status == abi.EUNSUPPORTED
+
+
+def test_device_resident_input_and_output(oracle, vx):
+    rng = np.random.default_rng(14)
+    n = 1 << 18
+    k = rng.integers(0, 1000, n).astype(np.int64)
+    v = _dyadic(rng, n)
+    hb = batch_of([k, v])
+    aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    exp, _ = run_agg(oracle, [hb], [0], [abi.BIGINT], aggs, max_rows=2048)
+    got, gop = run_agg(vx, [vx.to_device(hb)], [0], [abi.BIGINT], aggs, max_rows=2048)
+    assert_columns_equal(got, exp, gop.kinds, what="device input")

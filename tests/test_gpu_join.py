@@ -1,0 +1,209 @@
+"""HashBuild / HashProbe on the MI355X vs the CPU oracle, through the C ABI.
+
+Bit-exact bar: the set of (probe row, build row) pairs, payload values and
+validity, ascending probe-row order with all matches of one probe row
+contiguous (HashTable::listJoinResults contract). The ORDER of the matches
+inside one probe row follows the duplicate chain, which the reference itself
+does not keep stable (parallel build): it is compared as a set."""
+import numpy as np
+import pytest
+
+from velox_amd import abi
+from gpu_util import batch_of
+
+pytestmark = pytest.mark.gpu
+
+JOIN_TYPES = [abi.JOIN_INNER, abi.JOIN_LEFT, abi.JOIN_LEFT_SEMI_FILTER, abi.JOIN_ANTI]
+
+
+def _drain(probe, max_rows, build_col_ids=None):
+    pairs, payload = [], []
+    last = -1
+    while True:
+        mapping, build_rows, cols, fin = probe.get_output(max_rows, build_col_ids)
+        assert len(mapping) <= max_rows
+        assert (np.diff(mapping) >= 0).all() and (len(mapping) == 0 or mapping[0] >= last)
+        if len(mapping):
+            last = int(mapping[-1])
+        for i in range(len(mapping)):
+            pairs.append((int(mapping[i]), int(build_rows[i])))
+            row = []
+            for vals, valid in cols:
+                if not valid[i]:
+                    row.append(None)
+                elif isinstance(vals, list):
+                    row.append(vals[i])
+                else:
+                    row.append(vals[i].item() if hasattr(vals[i], "item") else vals[i])
+            payload.append(tuple(row))
+        if fin:
+            break
+    return pairs, payload
+
+
+def _canon(pairs, payload):
+    return sorted(zip(pairs, payload), key=lambda t: (t[0][0], t[0][1]))
+
+
+def _contiguous(pairs):
+    seen, prev = set(), None
+    for r, _ in pairs:
+        if r != prev:
+            assert r not in seen
+            seen.add(r)
+            prev = r
+
+
+def _build(impl, batches_per_driver, key_cols, key_types, dep_cols, dep_types, join_type):
+    builds = []
+    for batches in batches_per_driver:
+        b = impl.JoinBuild(key_cols, key_types, dep_cols, dep_types, join_type)
+        for hb in batches:
+            b.add_input(hb)
+        builds.append(b)
+    return builds[0].finish(builds[1:]), builds
+
+
+@pytest.mark.parametrize("join_type", JOIN_TYPES)
+@pytest.mark.parametrize("force_hash", [False, True])
+def test_join_duplicates_nulls_two_drivers(oracle, vx, join_type, force_hash, monkeypatch):
+    if force_hash:
+        monkeypatch.setenv("VX355_JOIN_ARRAY_MAX", "0")
+    rng = np.random.default_rng(11)
+    nb, npb = 6000, 20000
+    bk = rng.integers(0, 1500, nb).astype(np.int64)
+    bvalid = rng.random(nb) > 0.05
+    bpay = rng.integers(0, 1 << 40, nb).astype(np.int64)
+    bpay2 = rng.random(nb)
+    bpay2_valid = rng.random(nb) > 0.3
+    bstr = [bytes(rng.integers(65, 91, int(rng.integers(0, 13))).astype(np.uint8)) for _ in range(nb)]
+    pk = rng.integers(-100, 3000, npb).astype(np.int64)
+    pvalid = rng.random(npb) > 0.05
+
+    def driver(lo, hi):
+        out = []
+        for s in range(lo, hi, 1000):
+            e = min(hi, s + 1000)
+            out.append(abi.HostBatch([abi.HostColumn(abi.BIGINT, bk[s:e], bvalid[s:e]),
+                                      abi.HostColumn(abi.BIGINT, bpay[s:e]),
+                                      abi.HostColumn(abi.DOUBLE, bpay2[s:e], bpay2_valid[s:e]),
+                                      abi.HostColumn(abi.VARCHAR, bstr[s:e])]))
+        return out
+    deps, dep_types = [1, 2, 3], [abi.BIGINT, abi.DOUBLE, abi.VARCHAR]
+    results = {}
+    for impl in (oracle, vx):
+        table, builds = _build(impl, [driver(0, 3500), driver(3500, nb)], [0], [abi.BIGINT], deps,
+                               dep_types, join_type)
+        st = table.stats()
+        assert st.num_rows == bvalid.sum() and st.has_duplicates == 1
+        assert st.num_distinct == len(np.unique(bk[bvalid]))
+        probe = impl.JoinProbe(table, [0], join_type)
+        probe.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, pk, pvalid)]))
+        pairs, payload = _drain(probe, 1000 if impl is oracle else 777)
+        _contiguous(pairs)
+        results[impl.__name__] = _canon(pairs, payload)
+        if impl is vx:
+            assert st.hash_mode == (abi.MODE_NORMALIZED_KEY if force_hash else abi.MODE_ARRAY)
+    assert results[oracle.__name__] == results[vx.__name__]
+
+
+def test_join_unique_keys_probe_twice_and_no_payload(oracle, vx):
+    rng = np.random.default_rng(21)
+    nb = 50000
+    bk = rng.permutation(200000)[:nb].astype(np.int64)
+    pay = rng.integers(0, 1000, nb).astype(np.int32)
+    res = {}
+    for impl in (oracle, vx):
+        table, builds = _build(impl, [[batch_of([bk, pay])]], [0], [abi.BIGINT], [1], [abi.INTEGER],
+                               abi.JOIN_INNER)
+        assert table.stats().has_duplicates == 0 and table.stats().num_distinct == nb
+        probe = impl.JoinProbe(table, [0], abi.JOIN_INNER)
+        out = []
+        for seed in (1, 2):
+            pk = np.random.default_rng(seed).integers(0, 220000, 70000).astype(np.int64)
+            probe.add_input(batch_of([pk]))
+            pairs, payload = _drain(probe, 65536)
+            out.append(_canon(pairs, payload))
+            # no payload columns requested
+            probe.add_input(batch_of([pk]))
+            pairs2, payload2 = _drain(probe, 100000, build_col_ids=[])
+            assert sorted(pairs2) == sorted(pairs) and all(p == () for p in payload2)
+        res[impl.__name__] = out
+    assert res[oracle.__name__] == res[vx.__name__]
+
+
+def test_join_two_keys_strings_and_small_ints(oracle, vx):
+    rng = np.random.default_rng(31)
+    nb, npb = 3000, 8000
+    segs = [b"AUTOMOB", b"BUILDIN", b"FURNITU", b"MACHINE", b"HOUSEHO", b""]
+    bk1 = [segs[i] for i in rng.integers(0, 6, nb)]
+    bk2 = rng.integers(-20, 20, nb).astype(np.int16)
+    pay = np.arange(nb, dtype=np.int64)
+    pk1 = [segs[i] if i < 6 else b"TOOLONG8" for i in rng.integers(0, 7, npb)]
+    pk2 = rng.integers(-25, 25, npb).astype(np.int16)
+    pvalid = rng.random(npb) > 0.1
+    res = {}
+    for impl in (oracle, vx):
+        table, _b = _build(impl, [[batch_of([bk1, bk2, pay])]], [0, 1], [abi.VARCHAR, abi.SMALLINT], [2],
+                           [abi.BIGINT], abi.JOIN_LEFT)
+        probe = impl.JoinProbe(table, [0, 1], abi.JOIN_LEFT)
+        probe.add_input(batch_of([pk1, pk2], [pvalid, None]))
+        pairs, payload = _drain(probe, 512)
+        res[impl.__name__] = sorted(zip([p[0] for p in pairs], payload))
+    assert res[oracle.__name__] == res[vx.__name__]
+
+
+def test_join_empty_build_and_empty_probe(oracle, vx):
+    for impl in (oracle, vx):
+        b = impl.JoinBuild([0], [abi.BIGINT], [], [], abi.JOIN_LEFT)
+        b.add_input(batch_of([np.zeros(0, dtype=np.int64)]))
+        b.add_input(batch_of([np.array([5, 6], dtype=np.int64)], [np.array([False, False])]))
+        table = b.finish()
+        assert table.stats().num_rows == 0
+        probe = impl.JoinProbe(table, [0], abi.JOIN_LEFT)
+        probe.add_input(batch_of([np.array([1, 2, 3], dtype=np.int64)]))
+        mapping, rows, cols, fin = probe.get_output(10, [])
+        assert list(mapping) == [0, 1, 2] and list(rows) == [-1, -1, -1] and fin
+        probe.add_input(batch_of([np.zeros(0, dtype=np.int64)]))
+        mapping, rows, cols, fin = probe.get_output(10, [])
+        assert len(mapping) == 0 and fin
+
+
+def test_unsupported_join_kinds_are_refused(vx):
+    with pytest.raises(vx.Vx355Error) as e:
+        vx.JoinBuild([0], [abi.BIGINT], [], [], abi.JOIN_FULL)
+    assert e.value.status == abi.EUNSUPPORTED
+    with pytest.raises(vx.Vx355Error) as e:
+        vx.JoinBuild([0], [abi.DOUBLE], [], [], abi.JOIN_INNER)
+    assert e.value.status == abi.EUNSUPPORTED
+
+
+def test_q3_shape_device_resident_probe(oracle, vx):
+    """TPC-H Q3 shape scaled down: sparse order keys, selective probe, outputs
+    left in HBM."""
+    rng = np.random.default_rng(41)
+    n_orders, n_line = 60000, 400000
+    okeys = (np.arange(n_orders, dtype=np.int64) // 8) * 32 + (np.arange(n_orders) % 8)
+    build_sel = rng.random(n_orders) < 0.1
+    bk = okeys[build_sel]
+    odate = rng.integers(8000, 10000, len(bk)).astype(np.int32)
+    lk = okeys[rng.integers(0, n_orders, n_line)]
+    table_o, _bo = _build(oracle, [[batch_of([bk, odate])]], [0], [abi.BIGINT], [1], [abi.INTEGER], abi.JOIN_INNER)
+    po = oracle.JoinProbe(table_o, [0], abi.JOIN_INNER)
+    po.add_input(batch_of([lk]))
+    e_pairs, e_payload = _drain(po, 1 << 20)
+    table, _b = _build(vx, [[vx.to_device(batch_of([bk, odate]))]], [0], [abi.BIGINT], [1], [abi.INTEGER],
+                       abi.JOIN_INNER)
+    probe = vx.JoinProbe(table, [0], abi.JOIN_INNER)
+    probe.add_input(vx.to_device(batch_of([lk])))
+    cap = len(e_pairs) + 10
+    mapping, rows = vx.DeviceArray(cap, np.int32), vx.DeviceArray(cap, np.int32)
+    dates, dnulls = vx.DeviceArray(cap, np.int32), vx.DeviceArray((cap + 63) // 64, np.uint64)
+    descs = (abi.OutColumn * 1)()
+    descs[0].type_kind, descs[0].mem = abi.INTEGER, abi.MEM_DEVICE
+    descs[0].values, descs[0].nulls = dates.ptr, dnulls.ptr
+    n, fin = probe.get_output_device(cap, mapping.ptr, rows.ptr, descs, [0])
+    assert fin and n == len(e_pairs)
+    got = list(zip(mapping.to_host(n).tolist(), rows.to_host(n).tolist()))
+    assert got == e_pairs
+    assert dates.to_host(n).tolist() == [p[0] for p in e_payload]

@@ -1,0 +1,171 @@
+"""Parity of the standalone HIP kernels with the CPU oracle, through the C ABI:
+VectorHasher::hash, value ids (range mode), filter compaction, partitioning.
+Bit-exact: everything here is integer work."""
+import numpy as np
+import pytest
+
+from velox_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+
+def _col(kind, values, valid=None, **kw):
+    return abi.HostColumn(kind, values, valid, **kw)
+
+
+def _strings(rng, n, max_len):
+    out = []
+    for _ in range(n):
+        ln = int(rng.integers(0, max_len + 1))
+        out.append(bytes(rng.integers(32, 127, ln).astype(np.uint8)))
+    return out
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 4097, 100003])
+def test_hash_bigint_sizes_and_selection(oracle, vx, n):
+    rng = np.random.default_rng(n)
+    v = rng.integers(-2 ** 63, 2 ** 63 - 1, n, dtype=np.int64)
+    if n > 3:
+        v[:3] = [0, np.iinfo(np.int64).min, np.iinfo(np.int64).max]
+    valid = rng.random(n) > 0.2
+    rows = rng.random(n) > 0.3
+    b = abi.HostBatch([_col(abi.BIGINT, v, valid)], n)
+    init = rng.integers(0, 2 ** 63, max(1, n)).astype(np.uint64)
+    exp = oracle.hash_columns(b, [0], rows, out=init.copy())
+    got = vx.hash_columns(b, [0], rows, out=init.copy())
+    assert (exp == got).all()
+    # all rows, no selection
+    assert (oracle.hash_columns(b, [0]) == vx.hash_columns(b, [0])).all()
+
+
+def test_hash_every_type_multi_key_and_mix(oracle, vx):
+    rng = np.random.default_rng(5)
+    n = 20011
+    cols = [
+        _col(abi.BOOLEAN, rng.random(n) > 0.5, rng.random(n) > 0.1),
+        _col(abi.TINYINT, rng.integers(-128, 128, n).astype(np.int8)),
+        _col(abi.SMALLINT, rng.integers(-2 ** 15, 2 ** 15, n).astype(np.int16), rng.random(n) > 0.1),
+        _col(abi.INTEGER, rng.integers(-2 ** 31, 2 ** 31, n).astype(np.int32)),
+        _col(abi.BIGINT, rng.integers(-2 ** 62, 2 ** 62, n).astype(np.int64)),
+        _col(abi.REAL, rng.choice([0.0, -0.0, 1.5, np.nan, -np.inf, 3.25e10], n).astype(np.float32)),
+        _col(abi.DOUBLE, rng.choice([0.0, -0.0, 2.5, np.nan, np.inf, -1e300, 5e-324], n)),
+        _col(abi.VARCHAR, _strings(rng, n, 40), rng.random(n) > 0.05),
+        _col(abi.TIMESTAMP, np.stack([rng.integers(-10 ** 9, 10 ** 9, n),
+                                      rng.integers(0, 10 ** 9, n)], axis=1)),
+    ]
+    b = abi.HostBatch(cols, n)
+    for k in range(len(cols)):
+        assert (oracle.hash_columns(b, [k]) == vx.hash_columns(b, [k])).all(), k
+    keys = [4, 7, 0, 6, 3]
+    assert (oracle.hash_columns(b, keys) == vx.hash_columns(b, keys)).all()
+    seed = rng.integers(0, 2 ** 63, n).astype(np.uint64)
+    assert (oracle.hash_columns(b, [1, 5], mix_first=True, out=seed.copy()) ==
+            vx.hash_columns(b, [1, 5], mix_first=True, out=seed.copy())).all()
+
+
+def test_hash_string_all_lengths(oracle, vx):
+    strs = [bytes((i * 7 + j) % 251 + 1 for j in range(i)) for i in range(0, 80)]
+    b = abi.HostBatch([_col(abi.VARCHAR, strs)], len(strs))
+    assert (oracle.hash_columns(b, [0]) == vx.hash_columns(b, [0])).all()
+
+
+def test_hash_dictionary_constant_and_device_memory(oracle, vx):
+    rng = np.random.default_rng(6)
+    n = 5000
+    base = rng.integers(-1000, 1000, 37).astype(np.int64)
+    idx = rng.integers(0, 37, n).astype(np.int32)
+    dict_col = _col(abi.BIGINT, base, rng.random(n) > 0.1, encoding=abi.DICTIONARY, indices=idx)
+    const_col = _col(abi.DOUBLE, np.array([2.75]), encoding=abi.CONSTANT)
+    null_const = _col(abi.INTEGER, np.array([7], dtype=np.int32), np.array([False]),
+                      encoding=abi.CONSTANT)
+    b = abi.HostBatch([dict_col, const_col, null_const], n)
+    exp = oracle.hash_columns(b, [0, 1, 2])
+    assert (exp == vx.hash_columns(b, [0, 1, 2])).all()
+    # same columns resident in HBM, output in HBM
+    db = vx.to_device(b)
+    out = vx.DeviceArray(n, np.uint64).zero()
+    import ctypes as C
+    st = vx.lib().vx355_hash_columns(db.ref(), abi.i32_array([0, 1, 2]), 3, None, 0, out.ptr,
+                                     abi.MEM_DEVICE)
+    assert st == abi.OK
+    assert (out.to_host() == exp).all()
+
+
+@pytest.mark.parametrize("lookup", [False, True])
+def test_value_ids_range_mode(oracle, vx, lookup):
+    rng = np.random.default_rng(12)
+    n = 30001
+    a = rng.integers(-50, 60, n).astype(np.int64)      # some outside [-40, 40]
+    b_ = rng.integers(0, 10, n).astype(np.int32)
+    s = [bytes([c]) if c else b"" for c in rng.choice([0, 65, 78, 82, 90], n)]
+    flag = rng.random(n) > 0.5
+    va, vs = rng.random(n) > 0.1, rng.random(n) > 0.1
+    batch = abi.HostBatch([_col(abi.BIGINT, a, va), _col(abi.INTEGER, b_), _col(abi.VARCHAR, s, vs),
+                           _col(abi.BOOLEAN, flag)], n)
+    lo_s, hi_s = 0, (ord("R") + 256)
+    specs = [(-40, 40, 1), (0, 9, 82), (lo_s, hi_s, 82 * 11), (0, 1, 82 * 11 * (hi_s - lo_s + 2))]
+    rows = rng.random(n) > 0.25
+    e_res, e_rows, e_mapped = oracle.value_ids(batch, [0, 1, 2, 3], specs, rows, lookup)
+    g_res, g_rows, g_mapped = vx.value_ids(batch, [0, 1, 2, 3], specs, rows, lookup)
+    if lookup:
+        assert (e_rows == g_rows).all()
+        sel = e_rows
+    else:
+        assert e_mapped == g_mapped and not g_mapped
+        # rows the oracle could map must agree
+        ok = rows & ~(va & ((a < -40) | (a > 40))) & ~(vs & np.array([len(x) == 1 and x[0] > 82 for x in s]))
+        sel = ok
+    assert (e_res[sel] == g_res[sel]).all()
+    # everything in range -> all mapped
+    specs2 = [(-50, 59, 1), (0, 9, 200)]
+    e = oracle.value_ids(batch, [0, 1], specs2)
+    g = vx.value_ids(batch, [0, 1], specs2)
+    assert e[2] and g[2] and (e[0] == g[0]).all()
+
+
+def test_value_ids_type_extremes(oracle, vx):
+    v = np.array([np.iinfo(np.int64).min, -1, 0, 1, np.iinfo(np.int64).max], dtype=np.int64)
+    batch = abi.HostBatch([_col(abi.BIGINT, v)], len(v))
+    for spec in [(np.iinfo(np.int64).min, np.iinfo(np.int64).min + 10, 1),
+                 (np.iinfo(np.int64).max - 10, np.iinfo(np.int64).max, 1), (-1, 1, 3)]:
+        e = oracle.value_ids(batch, [0], [spec], lookup=True)
+        g = vx.value_ids(batch, [0], [spec], lookup=True)
+        assert (e[1] == g[1]).all() and (e[0][e[1]] == g[0][g[1]]).all()
+
+
+@pytest.mark.parametrize("n", [0, 1, 64, 4095, 4096, 4097, 300007])
+@pytest.mark.parametrize("density", [0.0, 0.03, 0.5, 0.985, 1.0])
+def test_filter_compact(oracle, vx, n, density):
+    rng = np.random.default_rng(n + int(density * 1000))
+    values = rng.random(n) < density
+    nulls = rng.random(n) > 0.1
+    rows = rng.random(n) > 0.1
+    for args in [(values,), (values, nulls), (values, nulls, rows), (values, None, rows)]:
+        e = oracle.filter_compact(*args)
+        g = vx.filter_compact(*args)
+        assert len(e) == len(g) and (e == g).all()
+
+
+def test_filter_compact_device_resident(oracle, vx):
+    rng = np.random.default_rng(99)
+    n = 1 << 20
+    values = rng.random(n) < 0.985
+    bits = vx.DeviceArray(abi.pack_bits(values))
+    out = vx.DeviceArray(n, np.int32)
+    cnt = vx.filter_compact_device(bits.ptr, n, out.ptr)
+    assert cnt == values.sum()
+    assert (out.to_host(cnt) == np.flatnonzero(values)).all()
+
+
+@pytest.mark.parametrize("kind,kw", [
+    (abi.PART_MODULO, dict(num_partitions=8)), (abi.PART_MODULO, dict(num_partitions=7)),
+    (abi.PART_MODULO, dict(num_partitions=1000003)),
+    (abi.PART_BIT_RANGE, dict(bit_begin=61, bit_end=64)), (abi.PART_BIT_RANGE, dict(bit_begin=29, bit_end=32)),
+    (abi.PART_LOCAL_MODULO, dict(num_partitions=13)),
+    (abi.PART_LOCAL_BIT_RANGE, dict(bit_begin=3, bit_end=9))])
+def test_partition(oracle, vx, kind, kw):
+    rng = np.random.default_rng(3)
+    h = rng.integers(0, 2 ** 64, 100001, dtype=np.uint64)
+    h[:4] = [0, 1, 2 ** 64 - 1, 2 ** 63]
+    assert (oracle.partition(h, kind, **kw) == vx.partition(h, kind, **kw)).all()
+    assert len(vx.partition(h[:0], kind, **kw)) == 0

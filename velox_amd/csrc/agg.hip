@@ -1,0 +1,1707 @@
+// HashAggregation on the MI355X (replaces exec/HashAggregation.cpp:191-424,
+// exec/GroupingSet.cpp:190-365,810-884 and the accumulator loops of
+// functions/lib/aggregates/*).
+//
+// Design (not a translation of the reference's row-wise RowContainer):
+//  * Group state lives in ONE array of fixed-stride "group rows" in HBM:
+//      [normalized key u64][first input row u64][8-byte accumulators ...]
+//    indexed directly by the normalized key (array mode: what the reference
+//    calls kArray, HashTable.cpp:560-607, but sized for 288 GB of HBM instead
+//    of a CPU cache) or by an open-addressing slot found with one CAS on the
+//    key word (what the reference calls kNormalizedKey, :523-557). All words of
+//    a group share one HBM sector, so a row update is one random sector.
+//  * Keys are normalized exactly like VectorHasher in range mode
+//    (VectorHasher.cpp:196-224): id = value - min + 1, null = 0, combined with
+//    per-key multipliers. Ranges are chosen on the host with the reference's
+//    50 % reserve (VectorHasher.cpp:786-835). A value outside the range does
+//    not abort the batch: the row is appended to a deferred list, the host
+//    widens the range, re-keys the table on device and replays only those rows
+//    (the reference instead re-decides the mode and redoes the whole batch,
+//    HashTable.cpp:2633-2677).
+//  * Low-cardinality group-bys (TPC-H Q1, BASELINE config 1) never touch HBM
+//    atomics per row: each workgroup keeps lane-replicated accumulators in LDS
+//    (ds_add_f64 / ds_add_u64 / ds_min_u64 / ds_max_u64) behind a small
+//    key -> LDS-slot map and flushes once at the end.
+//  * First-seen group order (RowContainer order, GroupingSet.cpp:828-839) is
+//    reproduced by recording the minimum global input row per group and
+//    sorting groups by it at output time.
+#include "common.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <limits>
+
+namespace vx {
+
+void sortPairsU64U32(uint64_t* keys, uint32_t* vals, uint64_t* keysTmp, uint32_t* valsTmp,
+                     size_t n, DevBuf& tmp, bool* resultInTmp);
+
+namespace {
+
+constexpr int kMaxKeys = 8;
+constexpr int kMaxAccs = 20;
+constexpr uint64_t kEmpty = ~0ULL;
+constexpr uint64_t kNoRow = ~0ULL;
+
+enum AccKind : int32_t {
+  ACC_SUM_F64 = 0,
+  ACC_SUM_I64 = 1,        // checked: sets the overflow flag
+  ACC_SUM_I64_WRAP = 2,   // partial counts merged in the final step (no check)
+  ACC_COUNT = 3,          // +1 per qualifying row
+  ACC_MIN = 4,            // order-preserving u64 image, atomic umin
+  ACC_MAX = 5,
+};
+
+enum Mode : int32_t { MODE_HASH = 0, MODE_ARRAY = 1, MODE_NORMALIZED = 2 };
+
+struct KeyArg {
+  ColView col;
+  KeyRange range;
+};
+
+struct AccArg {
+  ColView in;
+  ColView mask;
+  int32_t kind;
+  int32_t hasIn;
+  int32_t hasMask;
+  int32_t inIsInt;  // value travels as int64 (else double)
+  int32_t off;      // word offset inside the group row
+  int32_t pad;
+};
+
+// Counters the kernels bump; mirrored into the pinned mailbox by the host.
+struct Counters {
+  uint32_t numDeferred;
+  uint32_t numNewGroups;
+  uint32_t overflow;     // sum(BIGINT) overflowed
+  uint32_t unmappable;   // a string key longer than 7 bytes was seen
+  uint32_t tableFull;
+  uint32_t pad[3];
+  int64_t keyMin[kMaxKeys];
+  int64_t keyMax[kMaxKeys];
+};
+
+struct AggArgs {
+  KeyArg keys[kMaxKeys];
+  AccArg accs[kMaxAccs];
+  int32_t numKeys;
+  int32_t numAccs;
+  int32_t ignoreNullKeys;
+  int32_t mode;  // MODE_ARRAY: group row index = key; else open addressing
+  int64_t numRows;
+  const int32_t* rowList;  // replay of deferred rows, or nullptr
+  uint64_t rowBase;
+  uint64_t* table;
+  int32_t stride;  // words per group row
+  int32_t ldsSlots;     // S
+  int32_t ldsRep;       // REP (power of two, <= 64)
+  int32_t ldsDirect;    // slot == key (no map)
+  uint64_t capacity;    // group rows in table (array: range product; hash: power of two)
+  int32_t* deferred;
+  Counters* counters;
+};
+
+__device__ inline bool predicate(const AccArg& a, int64_t row) {
+  if (a.hasMask) {
+    // AggregationMasks: a false or null mask excludes the row.
+    if (colIsNull(a.mask, row)) {
+      return false;
+    }
+    if (!loadInt64(a.mask, colIndex(a.mask, row))) {
+      return false;
+    }
+  }
+  if (a.hasIn && colIsNull(a.in, row)) {
+    return false;
+  }
+  return true;
+}
+
+// The 8-byte operand of the accumulator update for this row.
+__device__ inline uint64_t operand(const AccArg& a, int64_t row) {
+  switch (a.kind) {
+    case ACC_COUNT:
+      return 1;
+    case ACC_SUM_F64: {
+      double d = loadDouble(a.in, colIndex(a.in, row));
+      return static_cast<uint64_t>(__double_as_longlong(d));
+    }
+    case ACC_SUM_I64:
+    case ACC_SUM_I64_WRAP:
+      return static_cast<uint64_t>(loadInt64(a.in, colIndex(a.in, row)));
+    default:  // MIN / MAX
+      if (a.inIsInt) {
+        return int64ToOrdered(loadInt64(a.in, colIndex(a.in, row)));
+      }
+      return doubleToOrdered(loadDouble(a.in, colIndex(a.in, row)));
+  }
+}
+
+__device__ inline bool addOverflows(int64_t old, int64_t v) {
+  int64_t r;
+  return __builtin_add_overflow(old, v, &r);
+}
+
+__device__ inline void applyGlobal(uint64_t* word, int32_t kind, uint64_t v, Counters* ctr) {
+  switch (kind) {
+    case ACC_SUM_F64:
+      unsafeAtomicAdd(reinterpret_cast<double*>(word), __longlong_as_double(static_cast<long long>(v)));
+      break;
+    case ACC_SUM_I64: {
+      unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(word),
+                                         static_cast<unsigned long long>(v));
+      if (addOverflows(static_cast<int64_t>(old), static_cast<int64_t>(v))) {
+        ctr->overflow = 1;
+      }
+      break;
+    }
+    case ACC_SUM_I64_WRAP:
+    case ACC_COUNT:
+      atomicAdd(reinterpret_cast<unsigned long long*>(word), static_cast<unsigned long long>(v));
+      break;
+    case ACC_MIN:
+      atomicMin(reinterpret_cast<unsigned long long*>(word), static_cast<unsigned long long>(v));
+      break;
+    default:
+      atomicMax(reinterpret_cast<unsigned long long*>(word), static_cast<unsigned long long>(v));
+      break;
+  }
+}
+
+__device__ inline void applyLds(uint64_t* word, int32_t kind, uint64_t v, Counters* ctr) {
+  switch (kind) {
+    case ACC_SUM_F64:
+      unsafeAtomicAdd(reinterpret_cast<double*>(word), __longlong_as_double(static_cast<long long>(v)));
+      break;
+    case ACC_SUM_I64: {
+      unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(word),
+                                         static_cast<unsigned long long>(v));
+      if (addOverflows(static_cast<int64_t>(old), static_cast<int64_t>(v))) {
+        ctr->overflow = 1;
+      }
+      break;
+    }
+    case ACC_SUM_I64_WRAP:
+    case ACC_COUNT:
+      atomicAdd(reinterpret_cast<unsigned long long*>(word), static_cast<unsigned long long>(v));
+      break;
+    case ACC_MIN:
+      atomicMin(reinterpret_cast<unsigned long long*>(word), static_cast<unsigned long long>(v));
+      break;
+    default:
+      atomicMax(reinterpret_cast<unsigned long long*>(word), static_cast<unsigned long long>(v));
+      break;
+  }
+}
+
+__host__ __device__ inline uint64_t accIdentity(int32_t kind) {
+  return kind == ACC_MIN ? ~0ULL : 0ULL;
+}
+
+// Normalized key of one input row (VectorHasher::computeValueIds semantics).
+// Returns 0 = key ready, 1 = row dropped (null key with ignoreNullKeys),
+// 2 = some value lies outside the current ranges (statistics updated).
+__device__ inline int normalizedKey(const AggArgs& a, int64_t row, uint64_t* keyOut) {
+  uint64_t key = 0;
+  bool outside = false;
+  for (int k = 0; k < a.numKeys; ++k) {
+    const KeyArg& ka = a.keys[k];
+    if (colIsNull(ka.col, row)) {
+      if (a.ignoreNullKeys) {
+        return 1;
+      }
+      continue;  // null contributes id 0
+    }
+    int64_t value;
+    bool mappable;
+    uint64_t id = valueIdAt(ka.col, colIndex(ka.col, row), ka.range, &value, &mappable);
+    if (!mappable) {
+      a.counters->unmappable = 1;
+      outside = true;
+      continue;
+    }
+    if (id == 0) {
+      outside = true;
+      atomicMin(reinterpret_cast<long long*>(&a.counters->keyMin[k]), static_cast<long long>(value));
+      atomicMax(reinterpret_cast<long long*>(&a.counters->keyMax[k]), static_cast<long long>(value));
+      continue;
+    }
+    key += ka.range.multiplier * id;
+  }
+  *keyOut = key;
+  return outside ? 2 : 0;
+}
+
+// Appends this lane's row to the deferred list with one atomic per wave.
+__device__ inline void deferRow(const AggArgs& a, bool defer, int32_t row) {
+  uint64_t m = ballot(defer);
+  if (m == 0) {
+    return;
+  }
+  uint32_t base = 0;
+  if (lane() == __ffsll(static_cast<long long>(m)) - 1) {
+    base = atomicAdd(&a.counters->numDeferred, static_cast<uint32_t>(popc64(m)));
+  }
+  base = __shfl(base, __ffsll(static_cast<long long>(m)) - 1, kWave);
+  if (defer) {
+    a.deferred[base + lanePrefix(m)] = row;
+  }
+}
+
+// Group row for a key in the open-addressing table: linear probing from
+// twang_mix64(key) (HashTable.cpp:442-444 mixNormalizedKey); the key word is
+// claimed with one CAS and never changes afterwards, so stale reads are safe.
+__device__ inline uint64_t* findOrInsert(uint64_t* table, int32_t stride, uint64_t capacity,
+                                         uint64_t key, Counters* ctr) {
+  const uint64_t mask = capacity - 1;
+  uint64_t pos = twangMix64(key) & mask;
+  for (uint64_t probes = 0; probes <= mask; ++probes) {
+    uint64_t* row = table + pos * stride;
+    uint64_t k = __hip_atomic_load(row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == key) {
+      return row;
+    }
+    if (k == kEmpty) {
+      unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(row), kEmpty, key);
+      if (old == kEmpty || old == key) {
+        return row;
+      }
+    }
+    pos = (pos + 1) & mask;
+  }
+  ctr->tableFull = 1;
+  return nullptr;
+}
+
+__device__ inline uint64_t* groupRow(const AggArgs& a, uint64_t key) {
+  if (a.mode == MODE_ARRAY) {
+    return a.table + key * a.stride;
+  }
+  return findOrInsert(a.table, a.stride, a.capacity, key, a.counters);
+}
+
+// Direct HBM update of one input row (high-cardinality path and LDS overflow).
+__device__ inline void updateGlobal(const AggArgs& a, int64_t row, uint64_t key, uint32_t* newGroups) {
+  uint64_t* g = groupRow(a, key);
+  if (!g) {
+    return;
+  }
+  const uint64_t myRow = a.rowBase + static_cast<uint64_t>(row);
+  if (__hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > myRow) {
+    unsigned long long old = atomicMin(reinterpret_cast<unsigned long long*>(g + 1), myRow);
+    if (old == kNoRow) {
+      ++*newGroups;
+    }
+  }
+  for (int i = 0; i < a.numAccs; ++i) {
+    const AccArg& acc = a.accs[i];
+    if (predicate(acc, row)) {
+      applyGlobal(g + acc.off, acc.kind, operand(acc, row), a.counters);
+    }
+  }
+}
+
+__device__ inline void addNewGroups(Counters* ctr, uint32_t mine) {
+  uint32_t total = mine;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    total += __shfl_xor(total, off, kWave);
+  }
+  if (lane() == 0 && total) {
+    atomicAdd(&ctr->numNewGroups, total);
+  }
+}
+
+// ---- high-cardinality kernel: one lane per row, HBM atomics ----------------
+__global__ __launch_bounds__(256) void k_agg_global(AggArgs a) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  uint32_t newGroups = 0;
+  const int64_t rounds = (a.numRows + stride - 1) / stride;
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  for (int64_t r = 0; r < rounds; ++r, i += stride) {
+    bool defer = false;
+    int32_t row = 0;
+    if (i < a.numRows) {
+      row = a.rowList ? a.rowList[i] : static_cast<int32_t>(i);
+      uint64_t key;
+      int st = normalizedKey(a, row, &key);
+      if (st == 0) {
+        updateGlobal(a, row, key, &newGroups);
+      } else if (st == 2) {
+        defer = true;
+      }
+    }
+    deferRow(a, defer, row);
+  }
+  addNewGroups(a.counters, newGroups);
+}
+
+// ---- low-cardinality kernel: LDS-resident, lane-replicated accumulators -----
+// LDS layout: [slotOf int32[capacity] unless direct][slotKey u32[S]][slotFirst u32[S]]
+//             [numSlots u32][pad][acc u64[S][numAccs][REP]]
+constexpr int32_t kSlotEmpty = -1;
+constexpr int32_t kSlotPending = -2;
+constexpr int32_t kSlotOverflow = -3;
+
+__global__ __launch_bounds__(1024) void k_agg_lds(AggArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+  const int S = a.ldsSlots;
+  const int REP = a.ldsRep;
+  const int A = a.numAccs;
+  int32_t* slotOf = reinterpret_cast<int32_t*>(ldsRaw);
+  const int mapWords = a.ldsDirect ? 0 : static_cast<int>(a.capacity);
+  uint32_t* slotKey = reinterpret_cast<uint32_t*>(ldsRaw) + mapWords;
+  uint32_t* slotFirst = slotKey + S;
+  uint32_t* numSlots = slotFirst + S;
+  uint64_t* acc = reinterpret_cast<uint64_t*>(
+      ldsRaw + ((static_cast<size_t>(mapWords + 2 * S + 2) * 4 + 15) & ~static_cast<size_t>(15)));
+
+  for (int i = threadIdx.x; i < mapWords; i += blockDim.x) {
+    slotOf[i] = kSlotEmpty;
+  }
+  for (int i = threadIdx.x; i < S; i += blockDim.x) {
+    slotFirst[i] = 0xffffffffu;
+    slotKey[i] = static_cast<uint32_t>(i);
+  }
+  if (threadIdx.x == 0) {
+    *numSlots = a.ldsDirect ? static_cast<uint32_t>(S) : 0;
+  }
+  for (int i = threadIdx.x; i < S * A * REP; i += blockDim.x) {
+    acc[i] = accIdentity(a.accs[(i / REP) % A].kind);
+  }
+  __syncthreads();
+
+  const int rep = lane() & (REP - 1);
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const int64_t rounds = (a.numRows + stride - 1) / stride;
+  uint32_t newGroups = 0;
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  for (int64_t r = 0; r < rounds; ++r, i += stride) {
+    bool defer = false;
+    int32_t row = 0;
+    if (i < a.numRows) {
+      row = a.rowList ? a.rowList[i] : static_cast<int32_t>(i);
+      uint64_t key;
+      int st = normalizedKey(a, row, &key);
+      if (st == 2) {
+        defer = true;
+      } else if (st == 0) {
+        int32_t slot;
+        if (a.ldsDirect) {
+          slot = static_cast<int32_t>(key);
+        } else {
+          volatile int32_t* entry = slotOf + key;
+          while (true) {
+            slot = *entry;
+            if (slot >= 0 || slot == kSlotOverflow) {
+              break;
+            }
+            if (slot == kSlotEmpty &&
+                atomicCAS(const_cast<int32_t*>(entry), kSlotEmpty, kSlotPending) == kSlotEmpty) {
+              uint32_t t = atomicAdd(numSlots, 1u);
+              if (t < static_cast<uint32_t>(S)) {
+                slotKey[t] = static_cast<uint32_t>(key);
+                slot = static_cast<int32_t>(t);
+              } else {
+                slot = kSlotOverflow;
+              }
+              __threadfence_block();
+              *entry = slot;
+              break;
+            }
+          }
+        }
+        if (slot >= 0) {
+          if (slotFirst[slot] > static_cast<uint32_t>(row)) {
+            atomicMin(&slotFirst[slot], static_cast<uint32_t>(row));
+          }
+          uint64_t* base = acc + (static_cast<size_t>(slot) * A) * REP + rep;
+          for (int j = 0; j < A; ++j) {
+            const AccArg& ac = a.accs[j];
+            if (predicate(ac, row)) {
+              applyLds(base + j * REP, ac.kind, operand(ac, row), a.counters);
+            }
+          }
+        } else {
+          updateGlobal(a, row, key, &newGroups);
+        }
+      }
+    }
+    deferRow(a, defer, row);
+  }
+  __syncthreads();
+
+  // Flush: one (slot, accumulator) pair per thread; replicas reduced in LDS.
+  uint32_t live = *numSlots;
+  if (live > static_cast<uint32_t>(S)) {
+    live = S;
+  }
+  for (int t = threadIdx.x; t < static_cast<int>(live) * (A + 1); t += blockDim.x) {
+    const int slot = t / (A + 1);
+    const int j = t % (A + 1);
+    const uint32_t first = slotFirst[slot];
+    if (first == 0xffffffffu) {
+      continue;  // direct layout: key never seen by this workgroup
+    }
+    uint64_t* g = a.table + static_cast<uint64_t>(slotKey[slot]) * a.stride;
+    if (j == A) {
+      // 'first' is the smallest ORIGINAL row of the chunk seen for this key
+      // (replays go through the row list), so it decides the group order.
+      uint64_t firstRow = a.rowBase + static_cast<uint64_t>(first);
+      unsigned long long old = atomicMin(reinterpret_cast<unsigned long long*>(g + 1), firstRow);
+      if (old == kNoRow) {
+        atomicAdd(&a.counters->numNewGroups, 1u);
+      }
+      continue;
+    }
+    const AccArg& ac = a.accs[j];
+    const uint64_t* p = acc + (static_cast<size_t>(slot) * A + j) * REP;
+    uint64_t v = p[0];
+    if (ac.kind == ACC_SUM_F64) {
+      double s = __longlong_as_double(static_cast<long long>(v));
+      for (int q = 1; q < REP; ++q) {
+        s += __longlong_as_double(static_cast<long long>(p[q]));
+      }
+      if (s != 0.0) {
+        applyGlobal(g + ac.off, ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(s)), a.counters);
+      } else {
+        // Adding +/-0.0 keeps the accumulator unless it is -0.0; the
+        // reference would produce +0.0 from 0.0 + -0.0 as well.
+        applyGlobal(g + ac.off, ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(s)), a.counters);
+      }
+    } else if (ac.kind == ACC_MIN) {
+      for (int q = 1; q < REP; ++q) {
+        v = p[q] < v ? p[q] : v;
+      }
+      applyGlobal(g + ac.off, ACC_MIN, v, a.counters);
+    } else if (ac.kind == ACC_MAX) {
+      for (int q = 1; q < REP; ++q) {
+        v = p[q] > v ? p[q] : v;
+      }
+      applyGlobal(g + ac.off, ACC_MAX, v, a.counters);
+    } else {
+      int64_t s = static_cast<int64_t>(v);
+      for (int q = 1; q < REP; ++q) {
+        int64_t x = static_cast<int64_t>(p[q]);
+        if (ac.kind == ACC_SUM_I64 && addOverflows(s, x)) {
+          a.counters->overflow = 1;
+        }
+        s = static_cast<int64_t>(static_cast<uint64_t>(s) + static_cast<uint64_t>(x));
+      }
+      applyGlobal(g + ac.off, ac.kind == ACC_COUNT ? ACC_SUM_I64_WRAP : ac.kind,
+                  static_cast<uint64_t>(s), a.counters);
+    }
+  }
+  addNewGroups(a.counters, newGroups);
+}
+
+// ---- key statistics of the first rows (VectorHasher::analyze) ---------------
+struct StatsArgs {
+  KeyArg keys[kMaxKeys];
+  int32_t numKeys;
+  int64_t numRows;
+  Counters* counters;
+};
+
+__global__ __launch_bounds__(256) void k_key_stats(StatsArgs a) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  int64_t mn[kMaxKeys], mx[kMaxKeys];
+  for (int k = 0; k < kMaxKeys; ++k) {
+    mn[k] = INT64_MAX;
+    mx[k] = INT64_MIN;
+  }
+  bool unmappable = false;
+  for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < a.numRows;
+       row += stride) {
+    for (int k = 0; k < a.numKeys; ++k) {
+      const ColView& c = a.keys[k].col;
+      if (colIsNull(c, row)) {
+        continue;
+      }
+      KeyRange all;
+      all.min = INT64_MIN;
+      all.max = INT64_MAX;
+      int64_t v;
+      bool mappable;
+      valueIdAt(c, colIndex(c, row), all, &v, &mappable);
+      if (!mappable) {
+        unmappable = true;
+        continue;
+      }
+      mn[k] = v < mn[k] ? v : mn[k];
+      mx[k] = v > mx[k] ? v : mx[k];
+    }
+  }
+  for (int k = 0; k < a.numKeys; ++k) {
+    if (mn[k] <= mx[k]) {
+      atomicMin(reinterpret_cast<long long*>(&a.counters->keyMin[k]), static_cast<long long>(mn[k]));
+      atomicMax(reinterpret_cast<long long*>(&a.counters->keyMax[k]), static_cast<long long>(mx[k]));
+    }
+  }
+  if (unmappable) {
+    a.counters->unmappable = 1;
+  }
+}
+
+// ---- table maintenance ---------------------------------------------------------
+__global__ __launch_bounds__(256) void k_init_table(uint64_t* table, uint64_t rows, int32_t stride,
+                                                     const uint64_t* pattern) {
+  const uint64_t total = rows * stride;
+  const uint64_t step = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += step) {
+    table[i] = pattern[i % stride];
+  }
+}
+
+struct RekeyArgs {
+  const uint64_t* oldTable;
+  uint64_t oldRows;
+  int32_t oldMode;
+  uint64_t* newTable;
+  uint64_t newCapacity;
+  int32_t newMode;
+  int32_t stride;
+  int32_t numKeys;
+  KeyRange oldRange[kMaxKeys];
+  KeyRange newRange[kMaxKeys];
+  Counters* counters;
+};
+
+// Moves every live group to its place under the new key ranges / capacity
+// (the device analogue of HashTable::rehash, HashTable.cpp:1541-1596).
+__global__ __launch_bounds__(256) void k_rekey(RekeyArgs a) {
+  const uint64_t step = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  for (uint64_t r = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; r < a.oldRows;
+       r += step) {
+    const uint64_t* src = a.oldTable + r * a.stride;
+    if (src[1] == kNoRow) {
+      continue;
+    }
+    const uint64_t oldKey = a.oldMode == MODE_ARRAY ? r : src[0];
+    uint64_t newKey = 0;
+    for (int k = 0; k < a.numKeys; ++k) {
+      uint64_t id = (oldKey / a.oldRange[k].multiplier) % a.oldRange[k].rangeSize;
+      if (id != 0) {
+        // value = id - 1 + oldMin ; new id = value - newMin + 1 (wraps safely)
+        uint64_t nid = id + static_cast<uint64_t>(a.oldRange[k].min) -
+            static_cast<uint64_t>(a.newRange[k].min);
+        newKey += a.newRange[k].multiplier * nid;
+      }
+    }
+    uint64_t* dst;
+    if (a.newMode == MODE_ARRAY) {
+      dst = a.newTable + newKey * a.stride;
+    } else {
+      dst = findOrInsert(a.newTable, a.stride, a.newCapacity, newKey, a.counters);
+      if (!dst) {
+        continue;
+      }
+    }
+    for (int w = 1; w < a.stride; ++w) {
+      dst[w] = src[w];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_copy_acc(uint64_t* table, uint64_t rows, int32_t stride,
+                                                   int32_t srcOff, int32_t dstOff) {
+  const uint64_t step = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  for (uint64_t r = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; r < rows;
+       r += step) {
+    table[r * stride + dstOff] = table[r * stride + srcOff];
+  }
+}
+
+// Live groups -> (first row, group row index) pairs, unordered.
+__global__ __launch_bounds__(256) void k_collect(const uint64_t* table, uint64_t rows, int32_t stride,
+                                                  uint64_t* firstOut, uint32_t* indexOut,
+                                                  uint32_t* cursor) {
+  const uint64_t step = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  const uint64_t rounds = (rows + step - 1) / step;
+  uint64_t r = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  for (uint64_t it = 0; it < rounds; ++it, r += step) {
+    uint64_t first = kNoRow;
+    if (r < rows) {
+      first = table[r * stride + 1];
+    }
+    const bool liveRow = first != kNoRow;
+    uint64_t m = ballot(liveRow);
+    if (m == 0) {
+      continue;
+    }
+    const int leader = __ffsll(static_cast<long long>(m)) - 1;
+    uint32_t base = 0;
+    if (lane() == leader) {
+      base = atomicAdd(cursor, static_cast<uint32_t>(popc64(m)));
+    }
+    base = __shfl(base, leader, kWave);
+    if (liveRow) {
+      uint32_t p = base + lanePrefix(m);
+      firstOut[p] = first;
+      indexOut[p] = static_cast<uint32_t>(r);
+    }
+  }
+}
+
+// ---- output ---------------------------------------------------------------------
+struct OutKey {
+  void* values;
+  uint64_t* nulls;
+  int32_t kind;
+  int32_t pad;
+  KeyRange range;
+};
+struct OutAgg {
+  void* values;
+  uint64_t* nulls;
+  void* values2;     // avg in partial/intermediate steps: the BIGINT count column
+  uint64_t* nulls2;
+  int32_t aggKind;   // vx355_agg_kind
+  int32_t inputType;
+  int32_t mainOff;
+  int32_t seenOff;   // count of contributing rows; -1 = never null
+  int32_t finalOut;
+  int32_t pad;
+};
+struct ExtractArgs {
+  const uint64_t* table;
+  int32_t stride;
+  int32_t mode;
+  const uint32_t* order;  // group row indexes in output order
+  int64_t begin;
+  int32_t count;
+  int32_t numKeys;
+  int32_t numAggs;
+  int32_t global;  // no keys: the single group is row 0
+  OutKey keys[kMaxKeys];
+  OutAgg aggs[kMaxAccs];
+};
+
+__device__ inline void writeBit(uint64_t* words, int32_t pos, bool bit) {
+  uint64_t m = ballot(bit);
+  if (words && (lane() == 0)) {
+    words[pos >> 6] = m;
+  }
+}
+
+__device__ inline void storeTyped(void* values, int32_t kind, int32_t pos, int64_t iv, double dv,
+                                  bool asInt) {
+  switch (kind) {
+    case VX355_TINYINT:
+      static_cast<int8_t*>(values)[pos] = static_cast<int8_t>(iv);
+      break;
+    case VX355_SMALLINT:
+      static_cast<int16_t*>(values)[pos] = static_cast<int16_t>(iv);
+      break;
+    case VX355_INTEGER:
+      static_cast<int32_t*>(values)[pos] = static_cast<int32_t>(iv);
+      break;
+    case VX355_BIGINT:
+      static_cast<int64_t*>(values)[pos] = iv;
+      break;
+    case VX355_REAL:
+      static_cast<float*>(values)[pos] = static_cast<float>(dv);
+      break;
+    case VX355_DOUBLE:
+      static_cast<double*>(values)[pos] = dv;
+      break;
+    default:
+      break;
+  }
+}
+
+// One lane per output row; a wave covers 64 consecutive rows so null bitmaps
+// and bit-packed BOOLEAN values are assembled with ballots.
+__global__ __launch_bounds__(256) void k_extract(ExtractArgs a) {
+  const int32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = pos < a.count;
+  uint64_t gi = 0;
+  if (active) {
+    gi = a.global ? 0 : a.order[a.begin + pos];
+  }
+  const uint64_t* g = a.table + gi * a.stride;
+  const uint64_t key = a.mode == MODE_ARRAY ? gi : (active ? g[0] : 0);
+  for (int k = 0; k < a.numKeys; ++k) {
+    const OutKey& ok = a.keys[k];
+    uint64_t id = active ? (key / ok.range.multiplier) % ok.range.rangeSize : 0;
+    const bool valid = active && id != 0;
+    writeBit(ok.nulls, pos, valid);
+    if (ok.kind == VX355_BOOLEAN) {
+      writeBit(static_cast<uint64_t*>(ok.values), pos, valid && id == 2);
+      continue;
+    }
+    if (!active) {
+      continue;
+    }
+    const int64_t v = valid ? static_cast<int64_t>(id - 1 + static_cast<uint64_t>(ok.range.min)) : 0;
+    if (ok.kind == VX355_VARCHAR || ok.kind == VX355_VARBINARY) {
+      // Inverse of stringAsNumber: the marker bit sits right above the bytes.
+      uint32_t size = 0;
+      uint64_t bytes = 0;
+      if (valid && v != 0) {
+        int top = 63 - __clzll(static_cast<long long>(v));
+        size = static_cast<uint32_t>(top >> 3);
+        bytes = static_cast<uint64_t>(v) - (1ULL << top);
+      }
+      uint4 raw;
+      raw.x = size;
+      raw.y = static_cast<uint32_t>(bytes);
+      raw.z = static_cast<uint32_t>(bytes >> 32);
+      raw.w = 0;
+      static_cast<uint4*>(ok.values)[pos] = raw;
+    } else {
+      storeTyped(ok.values, ok.kind, pos, v, 0, true);
+    }
+  }
+  for (int j = 0; j < a.numAggs; ++j) {
+    const OutAgg& oa = a.aggs[j];
+    const uint64_t mainWord = active ? g[oa.mainOff] : 0;
+    const uint64_t seen = (active && oa.seenOff >= 0) ? g[oa.seenOff] : 1;
+    const bool valid = active && seen != 0;
+    const bool inInt = oa.inputType <= VX355_BIGINT;
+    switch (oa.aggKind) {
+      case VX355_AGG_COUNT:
+      case VX355_AGG_COUNT_STAR:
+        writeBit(oa.nulls, pos, active);
+        if (active) {
+          static_cast<int64_t*>(oa.values)[pos] = static_cast<int64_t>(mainWord);
+        }
+        break;
+      case VX355_AGG_SUM:
+        writeBit(oa.nulls, pos, valid);
+        if (active) {
+          if (inInt) {
+            static_cast<int64_t*>(oa.values)[pos] = valid ? static_cast<int64_t>(mainWord) : 0;
+          } else {
+            double d = valid ? __longlong_as_double(static_cast<long long>(mainWord)) : 0.0;
+            if (oa.inputType == VX355_REAL && oa.finalOut) {
+              static_cast<float*>(oa.values)[pos] = static_cast<float>(d);
+            } else {
+              static_cast<double*>(oa.values)[pos] = d;
+            }
+          }
+        }
+        break;
+      case VX355_AGG_MIN:
+      case VX355_AGG_MAX:
+        writeBit(oa.nulls, pos, valid);
+        if (oa.inputType == VX355_BOOLEAN) {
+          writeBit(static_cast<uint64_t*>(oa.values), pos, valid && orderedToInt64(mainWord) != 0);
+        } else if (active) {
+          if (inInt) {
+            storeTyped(oa.values, oa.inputType, pos, valid ? orderedToInt64(mainWord) : 0, 0, true);
+          } else {
+            storeTyped(oa.values, oa.inputType, pos, 0, valid ? orderedToDouble(mainWord) : 0.0, false);
+          }
+        }
+        break;
+      default: {  // AVG
+        writeBit(oa.nulls, pos, valid);
+        const double sum = __longlong_as_double(static_cast<long long>(mainWord));
+        const int64_t cnt = static_cast<int64_t>(seen);
+        if (oa.finalOut) {
+          if (active) {
+            double v = valid ? sum / static_cast<double>(cnt) : 0.0;
+            if (oa.inputType == VX355_REAL) {
+              static_cast<float*>(oa.values)[pos] = static_cast<float>(v);
+            } else {
+              static_cast<double*>(oa.values)[pos] = v;
+            }
+          }
+        } else {
+          writeBit(oa.nulls2, pos, valid);
+          if (active) {
+            static_cast<double*>(oa.values)[pos] = valid ? sum : 0.0;
+            static_cast<int64_t*>(oa.values2)[pos] = valid ? cnt : 0;
+          }
+        }
+        break;
+      }
+    }
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------
+
+bool rawInput(int32_t step) { return step == VX355_STEP_PARTIAL || step == VX355_STEP_SINGLE; }
+bool finalOutput(int32_t step) { return step == VX355_STEP_FINAL || step == VX355_STEP_SINGLE; }
+
+int64_t typeMin(int32_t kind) {
+  switch (kind) {
+    case VX355_TINYINT:
+      return INT8_MIN;
+    case VX355_SMALLINT:
+      return INT16_MIN;
+    case VX355_INTEGER:
+      return INT32_MIN;
+    default:
+      return INT64_MIN;
+  }
+}
+int64_t typeMax(int32_t kind) {
+  switch (kind) {
+    case VX355_TINYINT:
+      return INT8_MAX;
+    case VX355_SMALLINT:
+      return INT16_MAX;
+    case VX355_INTEGER:
+      return INT32_MAX;
+    default:
+      return INT64_MAX;
+  }
+}
+
+struct PhysAcc {
+  int32_t kind;
+  int32_t inputCol;
+  int32_t inputCol2 = -1;  // unused
+  int32_t maskCol;
+  bool inIsInt;
+  int32_t aliasOf = -1;  // COUNT(col) == COUNT(*) while no batch had nulls in col
+};
+
+struct LogicalAgg {
+  vx355_agg_fn fn;
+  int32_t main = -1;
+  int32_t seen = -1;
+};
+
+struct KeyState {
+  int32_t col;
+  int32_t kind;
+  bool hasObserved = false;
+  int64_t obsMin = 0, obsMax = 0;
+  KeyRange range;  // current device mapping (valid when tableReady)
+};
+
+constexpr uint64_t kRangeTooLarge = ~0ULL;
+constexpr int64_t kMaxRangeSpan = (1LL << 59) - 1;  // exec/VectorHasher.h:139 kMaxRange
+
+}  // namespace
+}  // namespace vx
+
+using namespace vx;
+
+struct vx355_agg {
+  int32_t step;
+  bool ignoreNullKeys;
+  std::vector<KeyState> keys;
+  std::vector<LogicalAgg> aggs;
+  std::vector<PhysAcc> phys;
+  std::vector<int32_t> outTypes;
+  std::vector<int32_t> usedCols;
+
+  // device state
+  int32_t mode = MODE_ARRAY;
+  bool tableReady = false;
+  DevBuf table;
+  uint64_t capacity = 0;  // group rows
+  int32_t stride = 0;
+  DevBuf pattern;
+  DevBuf countersBuf;
+  DevBuf deferredBuf;
+  DevBuf scratch, sortTmp;
+  DevBuf orderKeys, orderVals, orderKeys2, orderVals2;
+  const uint32_t* order = nullptr;
+  int64_t numOutput = -1;  // set by finalize
+  int64_t outputCursor = 0;
+  bool noMoreInput = false;
+
+  int64_t inputRows = 0;
+  int64_t deferredRows = 0;
+  int64_t numGroups = 0;
+  int64_t numRehashes = 0;
+  uint64_t arrayMax = 1ULL << 28;
+  int64_t chunkRows = 1LL << 25;
+
+  Counters* counters() { return countersBuf.as<Counters>(); }
+};
+
+namespace vx {
+namespace {
+
+int32_t findOrAddPhys(vx355_agg& h, int32_t kind, int32_t col, int32_t mask, bool inIsInt) {
+  for (size_t i = 0; i < h.phys.size(); ++i) {
+    const auto& p = h.phys[i];
+    if (p.kind == kind && p.inputCol == col && p.maskCol == mask && p.inIsInt == inIsInt) {
+      return static_cast<int32_t>(i);
+    }
+  }
+  PhysAcc p;
+  p.kind = kind;
+  p.inputCol = col;
+  p.maskCol = mask;
+  p.inIsInt = inIsInt;
+  h.phys.push_back(p);
+  return static_cast<int32_t>(h.phys.size() - 1);
+}
+
+// COUNT of non-null 'col' rows; starts as an alias of the row count under the
+// same mask and is materialised the first time a batch brings nulls in 'col'.
+int32_t countAcc(vx355_agg& h, int32_t col, int32_t mask) {
+  int32_t star = findOrAddPhys(h, ACC_COUNT, -1, mask, true);
+  if (col < 0) {
+    return star;
+  }
+  int32_t c = findOrAddPhys(h, ACC_COUNT, col, mask, true);
+  if (c == static_cast<int32_t>(h.phys.size()) - 1 && h.phys[c].aliasOf == -1 && c != star) {
+    h.phys[c].aliasOf = star;
+  }
+  return c;
+}
+
+void buildPlan(vx355_agg& h, const vx355_agg_spec& spec) {
+  const bool raw = rawInput(spec.step);
+  const bool fin = finalOutput(spec.step);
+  for (int32_t k = 0; k < spec.num_keys; ++k) {
+    KeyState ks;
+    ks.col = spec.key_cols[k];
+    ks.kind = spec.key_types[k];
+    if (!(isIntLike(ks.kind) || isString(ks.kind))) {
+      VX_THROW(VX355_EUNSUPPORTED,
+               "group-by key type " + std::to_string(ks.kind) +
+                   " has no value ids (REAL/DOUBLE/TIMESTAMP keys need the generic hash mode)");
+    }
+    h.keys.push_back(ks);
+    h.outTypes.push_back(ks.kind);
+    h.usedCols.push_back(ks.col);
+  }
+  for (int32_t i = 0; i < spec.num_aggs; ++i) {
+    LogicalAgg la;
+    la.fn = spec.aggs[i];
+    const auto& f = la.fn;
+    const bool isInt = isIntLike(f.input_type);
+    if (!(isInt || f.input_type == VX355_REAL || f.input_type == VX355_DOUBLE)) {
+      VX_THROW(VX355_EUNSUPPORTED, "aggregate input type " + std::to_string(f.input_type));
+    }
+    if (f.kind != VX355_AGG_COUNT_STAR || !raw) {
+      VX_CHECK_ARG(f.input_col >= 0, "aggregate needs an input column");
+    }
+    h.usedCols.push_back(f.input_col);
+    h.usedCols.push_back(f.input_col2);
+    h.usedCols.push_back(f.mask_col);
+    switch (f.kind) {
+      case VX355_AGG_SUM:
+        la.main = findOrAddPhys(h, isInt ? ACC_SUM_I64 : ACC_SUM_F64, f.input_col, f.mask_col, isInt);
+        la.seen = countAcc(h, f.input_col, f.mask_col);
+        h.outTypes.push_back(isInt ? VX355_BIGINT
+                                   : ((f.input_type == VX355_REAL && fin) ? VX355_REAL : VX355_DOUBLE));
+        break;
+      case VX355_AGG_COUNT:
+      case VX355_AGG_COUNT_STAR:
+        if (raw) {
+          la.main = countAcc(h, f.kind == VX355_AGG_COUNT ? f.input_col : -1, f.mask_col);
+        } else {
+          la.main = findOrAddPhys(h, ACC_SUM_I64_WRAP, f.input_col, f.mask_col, true);
+        }
+        h.outTypes.push_back(VX355_BIGINT);
+        break;
+      case VX355_AGG_MIN:
+      case VX355_AGG_MAX:
+        la.main = findOrAddPhys(h, f.kind == VX355_AGG_MIN ? ACC_MIN : ACC_MAX, f.input_col,
+                                f.mask_col, isInt);
+        la.seen = countAcc(h, f.input_col, f.mask_col);
+        h.outTypes.push_back(f.input_type);
+        break;
+      case VX355_AGG_AVG:
+        la.main = findOrAddPhys(h, ACC_SUM_F64, f.input_col, f.mask_col, false);
+        if (raw) {
+          la.seen = countAcc(h, f.input_col, f.mask_col);
+        } else {
+          VX_CHECK_ARG(f.input_col2 >= 0, "avg over intermediate input needs the count column");
+          // count = checkedPlus over the partial counts of rows whose sum is
+          // not null (AverageAggregateBase.h:265-330). The accumulator is keyed
+          // on the count column; rows are gated by the SUM column's nulls below.
+          la.seen = findOrAddPhys(h, ACC_SUM_I64, f.input_col2, f.mask_col, true);
+        }
+        if (fin) {
+          h.outTypes.push_back(f.input_type == VX355_REAL ? VX355_REAL : VX355_DOUBLE);
+        } else {
+          h.outTypes.push_back(VX355_DOUBLE);
+          h.outTypes.push_back(VX355_BIGINT);
+        }
+        break;
+      default:
+        VX_THROW(VX355_EUNSUPPORTED, "aggregate kind " + std::to_string(f.kind));
+    }
+    h.aggs.push_back(la);
+  }
+  if (h.phys.size() > static_cast<size_t>(kMaxAccs)) {
+    VX_THROW(VX355_EUNSUPPORTED, "too many accumulators for one device table");
+  }
+  VX_CHECK_ARG(h.keys.size() <= static_cast<size_t>(kMaxKeys), "at most 8 grouping keys");
+  h.stride = 2 + static_cast<int32_t>(h.phys.size());
+}
+
+// VectorHasher::extendRange (exec/VectorHasher.cpp:786-835) with the group-by
+// reserve of 50 % (exec/HashTable.h:1213-1215).
+void paddedRange(int32_t kind, int64_t mn, int64_t mx, int64_t* outMin, int64_t* outMax) {
+  if (kind == VX355_BOOLEAN) {
+    *outMin = 0;
+    *outMax = 1;
+    return;
+  }
+  const int64_t tMin = isString(kind) ? INT64_MIN : typeMin(kind);
+  const int64_t tMax = isString(kind) ? INT64_MAX : typeMax(kind);
+  const int64_t reserve = static_cast<int64_t>(2 + (mx - mn) * (50 / 100.0));
+  *outMin = (tMin + reserve + 1 > mn) ? tMin : mn - reserve;
+  *outMax = (tMax - reserve < mx) ? tMax : mx + reserve;
+}
+
+struct Decision {
+  int32_t mode;
+  uint64_t capacity;  // array mode: product of range sizes
+  KeyRange ranges[kMaxKeys];
+};
+
+// The device analogue of HashTable::decideHashMode (HashTable.cpp:1751-1839),
+// restricted to range-encoded keys: array while the product of the ranges fits
+// the direct-index budget, else normalized key, else unsupported (kHash).
+Decision decide(vx355_agg& h) {
+  Decision d{};
+  unsigned __int128 product = 1;
+  bool overflow = false;
+  for (size_t k = 0; k < h.keys.size(); ++k) {
+    auto& ks = h.keys[k];
+    int64_t mn = 0, mx = -1;
+    uint64_t rangeSize;
+    if (ks.kind == VX355_BOOLEAN) {
+      mn = 0;
+      mx = 1;
+      rangeSize = 3;
+    } else if (!ks.hasObserved) {
+      // Only nulls so far: an empty range (every value will be deferred).
+      mn = 0;
+      mx = -1;
+      rangeSize = 1;
+    } else {
+      int64_t span;
+      if (__builtin_sub_overflow(ks.obsMax, ks.obsMin, &span) || span >= kMaxRangeSpan) {
+        overflow = true;
+        rangeSize = 1;
+      } else {
+        paddedRange(ks.kind, ks.obsMin, ks.obsMax, &mn, &mx);
+        rangeSize = static_cast<uint64_t>(mx - mn) + 2;
+      }
+    }
+    d.ranges[k].min = mn;
+    d.ranges[k].max = mx;
+    d.ranges[k].rangeSize = rangeSize;
+    d.ranges[k].multiplier = static_cast<uint64_t>(product);
+    product *= rangeSize;
+    if (product >= (static_cast<unsigned __int128>(1) << 64) - 1) {
+      overflow = true;
+    }
+  }
+  if (overflow) {
+    VX_THROW(VX355_EUNSUPPORTED,
+             "grouping keys do not fit a 64-bit normalized key (generic hash mode not on device)");
+  }
+  d.capacity = static_cast<uint64_t>(product);
+  d.mode = d.capacity <= h.arrayMax ? MODE_ARRAY : MODE_NORMALIZED;
+  return d;
+}
+
+void initTable(vx355_agg& h, DevBuf& buf, uint64_t rows) {
+  buf.ensure(static_cast<size_t>(rows) * h.stride * 8 + 64);
+  int grid = streamGrid(static_cast<int64_t>(rows) * h.stride, 256, 4);
+  VX_LAUNCH("k_init_table", k_init_table, grid, 256, 0, buf.as<uint64_t>(), rows, h.stride,
+            h.pattern.as<uint64_t>());
+}
+
+void ensureBasics(vx355_agg& h) {
+  auto& rt = Runtime::get();
+  if (h.pattern.ptr()) {
+    return;
+  }
+  std::vector<uint64_t> pat(h.stride);
+  pat[0] = kEmpty;
+  pat[1] = kNoRow;
+  for (size_t i = 0; i < h.phys.size(); ++i) {
+    pat[2 + i] = accIdentity(h.phys[i].kind);
+  }
+  h.pattern.ensure(pat.size() * 8);
+  copyIn(h.pattern.ptr(), pat.data(), VX355_MEM_HOST, pat.size() * 8);
+  h.countersBuf.ensure(sizeof(Counters));
+  rt.sync();
+}
+
+void resetCounters(vx355_agg& h) {
+  Counters c{};
+  for (int k = 0; k < kMaxKeys; ++k) {
+    c.keyMin[k] = INT64_MAX;
+    c.keyMax[k] = INT64_MIN;
+  }
+  copyIn(h.counters(), &c, VX355_MEM_HOST, sizeof(c));
+}
+
+Counters readCounters(vx355_agg& h) {
+  Counters c;
+  copyOut(&c, VX355_MEM_HOST, h.counters(), sizeof(c));
+  return c;
+}
+
+void mergeObserved(vx355_agg& h, const Counters& c) {
+  for (size_t k = 0; k < h.keys.size(); ++k) {
+    if (c.keyMin[k] <= c.keyMax[k]) {
+      auto& ks = h.keys[k];
+      if (!ks.hasObserved) {
+        ks.obsMin = c.keyMin[k];
+        ks.obsMax = c.keyMax[k];
+        ks.hasObserved = true;
+      } else {
+        ks.obsMin = std::min(ks.obsMin, c.keyMin[k]);
+        ks.obsMax = std::max(ks.obsMax, c.keyMax[k]);
+      }
+    }
+  }
+}
+
+uint64_t hashCapacityFor(uint64_t groups) {
+  // HashTable::newHashTableEntries (exec/HashTable.h:946-956): load <= 0.7.
+  uint64_t cap = std::max<uint64_t>(2048, nextPow2(groups + groups / 2 + 1));
+  while (groups > cap * 7 / 10) {
+    cap <<= 1;
+  }
+  return cap;
+}
+
+// (Re)creates the table for the current observations, moving live groups.
+void rebuildTable(vx355_agg& h, uint64_t extraGroups) {
+  auto& rt = Runtime::get();
+  Decision d = decide(h);
+  uint64_t newCap = d.capacity;
+  if (d.mode == MODE_NORMALIZED) {
+    newCap = hashCapacityFor(static_cast<uint64_t>(h.numGroups) + extraGroups);
+  }
+  DevBuf fresh;
+  initTable(h, fresh, newCap);
+  if (h.tableReady && h.numGroups > 0) {
+    RekeyArgs ra{};
+    ra.oldTable = h.table.as<uint64_t>();
+    ra.oldRows = h.capacity;
+    ra.oldMode = h.mode;
+    ra.newTable = fresh.as<uint64_t>();
+    ra.newCapacity = newCap;
+    ra.newMode = d.mode;
+    ra.stride = h.stride;
+    ra.numKeys = static_cast<int32_t>(h.keys.size());
+    for (size_t k = 0; k < h.keys.size(); ++k) {
+      ra.oldRange[k] = h.keys[k].range;
+      ra.newRange[k] = d.ranges[k];
+    }
+    ra.counters = h.counters();
+    VX_LAUNCH("k_rekey", k_rekey, streamGrid(static_cast<int64_t>(h.capacity), 256), 256, 0, ra);
+    ++h.numRehashes;
+  }
+  rt.sync();
+  h.table = std::move(fresh);
+  h.capacity = newCap;
+  h.mode = d.mode;
+  for (size_t k = 0; k < h.keys.size(); ++k) {
+    h.keys[k].range = d.ranges[k];
+  }
+  h.tableReady = true;
+}
+
+// Picks the LDS layout for a launch. Returns false when the group range is too
+// large for the LDS path.
+bool chooseLds(const vx355_agg& h, int numAccs, AggArgs* a, size_t* ldsBytes) {
+  if (h.mode != MODE_ARRAY || h.capacity > 8192 || numAccs == 0) {
+    return false;
+  }
+  const size_t budget = 60 * 1024;
+  const size_t accBytes = static_cast<size_t>(numAccs) * 8;
+  const uint64_t R = h.capacity;
+  auto bytesFor = [&](uint64_t S, int rep, bool direct) {
+    size_t words = (direct ? 0 : R) + 2 * S + 2;
+    return ((words * 4 + 15) & ~static_cast<size_t>(15)) + S * accBytes * rep;
+  };
+  // Direct layout: one slot per possible key.
+  int repDirect = 0;
+  for (int rep = 64; rep >= 1; rep >>= 1) {
+    if (bytesFor(R, rep, true) <= budget) {
+      repDirect = rep;
+      break;
+    }
+  }
+  // Compact layout: slots only for keys that occur, sized from what has been seen.
+  uint64_t S = nextPow2(std::max<uint64_t>(16, 2 * static_cast<uint64_t>(h.numGroups)));
+  S = std::min<uint64_t>(S, nextPow2(R));
+  int repCompact = 0;
+  if (h.numGroups > 0) {
+    for (int rep = 64; rep >= 1; rep >>= 1) {
+      if (bytesFor(S, rep, false) <= budget) {
+        repCompact = rep;
+        break;
+      }
+    }
+  }
+  if (repDirect == 0 && repCompact == 0) {
+    // Unknown cardinality and a range too wide for direct slots: as many
+    // compact slots as fit.
+    uint64_t s = 16;
+    while (bytesFor(s * 2, 1, false) <= budget && s * 2 <= nextPow2(R)) {
+      s *= 2;
+    }
+    if (bytesFor(s, 1, false) > budget) {
+      return false;
+    }
+    S = s;
+    repCompact = 1;
+  }
+  if (repDirect >= repCompact) {
+    a->ldsDirect = 1;
+    a->ldsSlots = static_cast<int32_t>(R);
+    a->ldsRep = repDirect;
+  } else {
+    a->ldsDirect = 0;
+    a->ldsSlots = static_cast<int32_t>(S);
+    a->ldsRep = repCompact;
+  }
+  *ldsBytes = bytesFor(a->ldsSlots, a->ldsRep, a->ldsDirect != 0);
+  return true;
+}
+
+void fillAccArgs(vx355_agg& h, const DeviceBatch& db, AggArgs* a) {
+  int n = 0;
+  for (size_t i = 0; i < h.phys.size(); ++i) {
+    const auto& p = h.phys[i];
+    if (p.aliasOf >= 0) {
+      continue;
+    }
+    AccArg& aa = a->accs[n++];
+    aa = AccArg{};
+    aa.kind = p.kind;
+    aa.inIsInt = p.inIsInt ? 1 : 0;
+    aa.off = 2 + static_cast<int32_t>(i);
+    if (p.inputCol >= 0) {
+      aa.hasIn = 1;
+      aa.in = db.col(p.inputCol);
+    }
+    if (p.maskCol >= 0) {
+      aa.hasMask = 1;
+      aa.mask = db.col(p.maskCol);
+    }
+  }
+  a->numAccs = n;
+}
+
+// avg over intermediate input gates its count on the nulls of the SUM column.
+void patchAvgIntermediate(vx355_agg& h, const DeviceBatch& db, AggArgs* a) {
+  if (rawInput(h.step)) {
+    return;
+  }
+  for (const auto& la : h.aggs) {
+    if (la.fn.kind != VX355_AGG_AVG) {
+      continue;
+    }
+    for (int j = 0; j < a->numAccs; ++j) {
+      if (a->accs[j].off == 2 + la.seen) {
+        // Null sums exclude the row: fold the sum column's nulls into the mask
+        // slot when the count column itself carries no nulls of its own.
+        ColView sumCol = db.col(la.fn.input_col);
+        if (sumCol.nulls && !a->accs[j].in.nulls) {
+          a->accs[j].in.nulls = sumCol.nulls;
+        }
+      }
+    }
+  }
+}
+
+void materializeAliases(vx355_agg& h, const DeviceBatch& db) {
+  for (size_t i = 0; i < h.phys.size(); ++i) {
+    auto& p = h.phys[i];
+    if (p.aliasOf < 0 || p.inputCol < 0) {
+      continue;
+    }
+    if (db.col(p.inputCol).nulls == nullptr) {
+      continue;
+    }
+    if (h.tableReady) {
+      VX_LAUNCH("k_copy_acc", k_copy_acc, streamGrid(static_cast<int64_t>(h.capacity), 256), 256, 0,
+                h.table.as<uint64_t>(), h.capacity, h.stride, 2 + p.aliasOf,
+                2 + static_cast<int32_t>(i));
+    }
+    p.aliasOf = -1;
+  }
+}
+
+void launchChunk(vx355_agg& h, AggArgs& a) {
+  auto& rt = Runtime::get();
+  size_t ldsBytes = 0;
+  if (chooseLds(h, a.numAccs, &a, &ldsBytes)) {
+    int grid = static_cast<int>(std::min<int64_t>(ceilDiv(a.numRows, 1024), rt.numCUs * 2));
+    VX_LAUNCH("k_agg_lds", k_agg_lds, grid, 1024, ldsBytes, a);
+  } else {
+    VX_LAUNCH("k_agg_global", k_agg_global, streamGrid(a.numRows, 256), 256, 0, a);
+  }
+}
+
+void checkCounters(const Counters& c) {
+  if (c.overflow) {
+    // SumAggregate.cpp:24 + vector/AggregationHook.h:126-135: checkedPlus.
+    VX_THROW(VX355_EUSER, "integer overflow");
+  }
+  if (c.unmappable) {
+    VX_THROW(VX355_EUNSUPPORTED,
+             "string grouping key longer than 7 bytes (generic hash mode not on device)");
+  }
+  if (c.tableFull) {
+    VX_THROW(VX355_EINTERNAL, "aggregation table full");
+  }
+}
+
+void addInput(vx355_agg& h, const vx355_batch* batch) {
+  auto& rt = Runtime::get();
+  VX_CHECK_ARG(!h.noMoreInput, "addInput after noMoreInput");
+  DeviceBatch db;
+  db.load(batch, h.usedCols);
+  const int64_t n = db.numRows();
+  if (n == 0) {
+    return;
+  }
+  ensureBasics(h);
+  materializeAliases(h, db);
+
+  AggArgs a{};
+  a.numKeys = static_cast<int32_t>(h.keys.size());
+  a.ignoreNullKeys = h.ignoreNullKeys ? 1 : 0;
+  for (size_t k = 0; k < h.keys.size(); ++k) {
+    a.keys[k].col = db.col(h.keys[k].col);
+  }
+  fillAccArgs(h, db, &a);
+  patchAvgIntermediate(h, db, &a);
+  a.stride = h.stride;
+  a.counters = h.counters();
+
+  if (!h.tableReady) {
+    // VectorHasher::analyze on a prefix of the first batch; later values that
+    // fall outside are handled by the deferred-row path.
+    resetCounters(h);
+    if (a.numKeys > 0) {
+      StatsArgs sa{};
+      sa.numKeys = a.numKeys;
+      for (int k = 0; k < a.numKeys; ++k) {
+        sa.keys[k] = a.keys[k];
+      }
+      sa.numRows = std::min<int64_t>(n, 1 << 20);
+      sa.counters = h.counters();
+      VX_LAUNCH("k_key_stats", k_key_stats, streamGrid(sa.numRows, 256), 256, 0, sa);
+      Counters c = readCounters(h);
+      checkCounters(c);
+      mergeObserved(h, c);
+    }
+    rebuildTable(h, static_cast<uint64_t>(std::min<int64_t>(n, h.chunkRows)));
+  }
+
+  int64_t rows = 0;
+  for (int64_t begin = 0; begin < n; begin += rows) {
+    // The first chunk of a stream is kept small: what it finds (number of live
+    // groups) picks the LDS layout of every later launch.
+    rows = std::min(h.numGroups == 0 ? std::min<int64_t>(h.chunkRows, 1 << 20) : h.chunkRows,
+                    n - begin);
+    if (h.mode == MODE_NORMALIZED &&
+        static_cast<uint64_t>(h.numGroups + rows) > h.capacity * 7 / 10) {
+      rebuildTable(h, static_cast<uint64_t>(rows));  // HashTable::checkSize (HashTable.cpp:772-806)
+    }
+    h.deferredBuf.ensure(static_cast<size_t>(rows) * 4 + 64);
+    // Chunk = rows [begin, begin + rows): shift every column view instead of
+    // adding an offset in the kernel.
+    AggArgs c = a;
+    c.numRows = rows;
+    c.rowList = nullptr;
+    c.rowBase = static_cast<uint64_t>(h.inputRows + begin);
+    c.deferred = h.deferredBuf.as<int32_t>();
+    auto shift = [&](ColView& v) {
+      if (begin == 0 || v.enc == VX355_CONSTANT) {
+        return;
+      }
+      // Chunks start on a multiple of 64 rows, so bitmaps shift by whole words.
+      if (v.nulls) {
+        v.nulls += begin >> 6;
+      }
+      if (v.enc == VX355_DICTIONARY) {
+        v.indices += begin;
+        return;
+      }
+      const int w = kindWidth(v.kind);
+      if (w == 0) {
+        v.values = static_cast<const uint64_t*>(v.values) + (begin >> 6);
+      } else {
+        v.values = static_cast<const char*>(v.values) + begin * w;
+      }
+    };
+    for (int k = 0; k < c.numKeys; ++k) {
+      shift(c.keys[k].col);
+    }
+    for (int j = 0; j < c.numAccs; ++j) {
+      if (c.accs[j].hasIn) {
+        shift(c.accs[j].in);
+      }
+      if (c.accs[j].hasMask) {
+        shift(c.accs[j].mask);
+      }
+    }
+    int64_t pending = rows;
+    const int32_t* list = nullptr;
+    DevBuf replayList;
+    for (int attempt = 0; pending > 0; ++attempt) {
+      if (attempt > 64) {
+        VX_THROW(VX355_EINTERNAL, "key range widening did not converge");
+      }
+      resetCounters(h);
+      c.numRows = pending;
+      c.rowList = list;
+      c.table = h.table.as<uint64_t>();
+      c.capacity = h.capacity;
+      c.mode = h.mode;
+      for (int k = 0; k < c.numKeys; ++k) {
+        c.keys[k].range = h.keys[k].range;
+      }
+      launchChunk(h, c);
+      Counters ctr = readCounters(h);
+      checkCounters(ctr);
+      h.numGroups += ctr.numNewGroups;
+      pending = ctr.numDeferred;
+      if (pending > 0) {
+        // Widen, re-key, replay only the deferred rows.
+        h.deferredRows += pending;
+        mergeObserved(h, ctr);
+        replayList.ensure(static_cast<size_t>(pending) * 4 + 64);
+        copyIn(replayList.ptr(), h.deferredBuf.ptr(), VX355_MEM_DEVICE,
+               static_cast<size_t>(pending) * 4);
+        list = replayList.as<int32_t>();
+        rebuildTable(h, static_cast<uint64_t>(pending));
+        // Replay in ascending row order is not required: group order comes
+        // from the recorded first rows.
+      }
+    }
+  }
+  h.inputRows += n;
+  rt.sync();
+}
+
+void finalize(vx355_agg& h) {
+  auto& rt = Runtime::get();
+  ensureBasics(h);
+  if (h.keys.empty()) {
+    // Global aggregation: exactly one output row, even without input
+    // (GroupingSet.cpp:623-669).
+    if (!h.tableReady) {
+      rebuildTable(h, 0);
+    }
+    h.numOutput = 1;
+    return;
+  }
+  if (!h.tableReady || h.numGroups == 0) {
+    h.numOutput = 0;
+    return;
+  }
+  const size_t g = static_cast<size_t>(h.numGroups);
+  h.orderKeys.ensure(g * 8 + 64);
+  h.orderVals.ensure(g * 4 + 64);
+  h.orderKeys2.ensure(g * 8 + 64);
+  h.orderVals2.ensure(g * 4 + 64);
+  uint32_t* cursor = reinterpret_cast<uint32_t*>(h.counters());
+  resetCounters(h);
+  VX_LAUNCH("k_collect", k_collect, streamGrid(static_cast<int64_t>(h.capacity), 256), 256, 0,
+            h.table.as<uint64_t>(), h.capacity, h.stride, h.orderKeys.as<uint64_t>(),
+            h.orderVals.as<uint32_t>(), cursor);
+  Counters c = readCounters(h);
+  const uint32_t found = c.numDeferred;  // first word of the block is the cursor
+  if (found != g) {
+    VX_THROW(VX355_EINTERNAL, "group count mismatch: counted " + std::to_string(g) + ", found " +
+                                  std::to_string(found));
+  }
+  bool inTmp = false;
+  sortPairsU64U32(h.orderKeys.as<uint64_t>(), h.orderVals.as<uint32_t>(), h.orderKeys2.as<uint64_t>(),
+                  h.orderVals2.as<uint32_t>(), g, h.sortTmp, &inTmp);
+  rt.sync();
+  h.order = inTmp ? h.orderVals2.as<uint32_t>() : h.orderVals.as<uint32_t>();
+  h.numOutput = static_cast<int64_t>(g);
+}
+
+void getOutput(vx355_agg& h, vx355_out_column* cols, int32_t numCols, int32_t maxRows, int32_t* nOut,
+               int32_t* finished) {
+  auto& rt = Runtime::get();
+  VX_CHECK_ARG(cols && nOut && finished, "NULL argument");
+  VX_CHECK_ARG(numCols == static_cast<int32_t>(h.outTypes.size()), "wrong number of output columns");
+  VX_CHECK_ARG(maxRows > 0, "max_rows must be positive");
+  VX_CHECK_ARG(h.noMoreInput, "getOutput before noMoreInput (partial flush is host policy)");
+  if (h.numOutput < 0) {
+    finalize(h);
+  }
+  const int32_t n = static_cast<int32_t>(std::min<int64_t>(maxRows, h.numOutput - h.outputCursor));
+  *nOut = n;
+  if (n <= 0) {
+    *nOut = 0;
+    *finished = 1;
+    return;
+  }
+  for (int32_t c = 0; c < numCols; ++c) {
+    VX_CHECK_ARG(cols[c].type_kind == h.outTypes[c], "output column type mismatch");
+    VX_CHECK_ARG(cols[c].values != nullptr, "output column without values buffer");
+  }
+  // Device scratch for host-resident output columns.
+  const size_t words = static_cast<size_t>(ceilDiv(n, 64));
+  std::vector<size_t> valueBytes(numCols), offsets(numCols), nullOffsets(numCols);
+  size_t total = 0;
+  for (int32_t c = 0; c < numCols; ++c) {
+    const int w = kindWidth(cols[c].type_kind);
+    valueBytes[c] = w == 0 ? words * 8 : static_cast<size_t>(n) * w;
+    offsets[c] = total;
+    total += (valueBytes[c] + 63) & ~static_cast<size_t>(63);
+    nullOffsets[c] = total;
+    total += (words * 8 + 63) & ~static_cast<size_t>(63);
+  }
+  char* scratch = static_cast<char*>(h.scratch.ensure(total + 64));
+  auto devValues = [&](int32_t c) -> void* {
+    return cols[c].mem == VX355_MEM_HOST ? static_cast<void*>(scratch + offsets[c]) : cols[c].values;
+  };
+  auto devNulls = [&](int32_t c) -> uint64_t* {
+    if (cols[c].mem == VX355_MEM_HOST) {
+      return reinterpret_cast<uint64_t*>(scratch + nullOffsets[c]);
+    }
+    return cols[c].nulls;
+  };
+  ExtractArgs ea{};
+  ea.table = h.table.as<uint64_t>();
+  ea.stride = h.stride;
+  ea.mode = h.mode;
+  ea.order = h.order;
+  ea.begin = h.outputCursor;
+  ea.count = n;
+  ea.numKeys = static_cast<int32_t>(h.keys.size());
+  ea.numAggs = static_cast<int32_t>(h.aggs.size());
+  ea.global = h.keys.empty() ? 1 : 0;
+  int32_t c = 0;
+  for (size_t k = 0; k < h.keys.size(); ++k, ++c) {
+    ea.keys[k].values = devValues(c);
+    ea.keys[k].nulls = devNulls(c);
+    ea.keys[k].kind = h.keys[k].kind;
+    ea.keys[k].range = h.keys[k].range;
+  }
+  auto physOff = [&](int32_t p) {
+    if (p < 0) {
+      return -1;
+    }
+    while (h.phys[p].aliasOf >= 0) {
+      p = h.phys[p].aliasOf;
+    }
+    return 2 + p;
+  };
+  const bool fin = finalOutput(h.step);
+  for (size_t j = 0; j < h.aggs.size(); ++j) {
+    const auto& la = h.aggs[j];
+    OutAgg& oa = ea.aggs[j];
+    oa.aggKind = la.fn.kind;
+    oa.inputType = la.fn.input_type;
+    oa.mainOff = physOff(la.main);
+    oa.seenOff = physOff(la.seen);
+    oa.finalOut = fin ? 1 : 0;
+    oa.values = devValues(c);
+    oa.nulls = devNulls(c);
+    ++c;
+    if (la.fn.kind == VX355_AGG_AVG && !fin) {
+      oa.values2 = devValues(c);
+      oa.nulls2 = devNulls(c);
+      ++c;
+    }
+  }
+  VX_LAUNCH("k_extract", k_extract, static_cast<int>(ceilDiv(n, 256)), 256, 0, ea);
+  for (int32_t i = 0; i < numCols; ++i) {
+    if (cols[i].mem == VX355_MEM_HOST) {
+      copyOut(cols[i].values, VX355_MEM_HOST, scratch + offsets[i], valueBytes[i]);
+      if (cols[i].nulls) {
+        copyOut(cols[i].nulls, VX355_MEM_HOST, scratch + nullOffsets[i], words * 8);
+      }
+    }
+  }
+  rt.sync();
+  h.outputCursor += n;
+  *finished = h.outputCursor >= h.numOutput ? 1 : 0;
+}
+
+}  // namespace
+}  // namespace vx
+
+extern "C" {
+
+int vx355_agg_create(const vx355_agg_spec* spec, vx355_agg** out) {
+  VX_API_BEGIN
+  Runtime::get().requireInit();
+  VX_CHECK_ARG(spec && out, "NULL argument");
+  VX_CHECK_ARG(spec->num_keys >= 0 && spec->num_aggs >= 0, "negative counts");
+  VX_CHECK_ARG(spec->step >= VX355_STEP_PARTIAL && spec->step <= VX355_STEP_SINGLE, "bad step");
+  auto h = std::make_unique<vx355_agg>();
+  h->step = spec->step;
+  h->ignoreNullKeys = spec->ignore_null_keys != 0;
+  if (const char* e = std::getenv("VX355_ARRAY_MAX")) {
+    h->arrayMax = std::strtoull(e, nullptr, 10);
+  }
+  if (const char* e = std::getenv("VX355_AGG_CHUNK_ROWS")) {
+    h->chunkRows = std::max<int64_t>(64, std::strtoll(e, nullptr, 10) & ~63LL);
+  }
+  buildPlan(*h, *spec);
+  *out = h.release();
+  VX_API_END
+}
+
+int vx355_agg_add_input(vx355_agg* h, const vx355_batch* batch) {
+  VX_API_BEGIN
+  Runtime::get().requireInit();
+  VX_CHECK_ARG(h && batch, "NULL argument");
+  addInput(*h, batch);
+  VX_API_END
+}
+
+int vx355_agg_no_more_input(vx355_agg* h) {
+  VX_API_BEGIN
+  VX_CHECK_ARG(h, "NULL argument");
+  h->noMoreInput = true;
+  VX_API_END
+}
+
+int vx355_agg_output_types(const vx355_agg* h, int32_t* types, int32_t cap, int32_t* n) {
+  VX_API_BEGIN
+  VX_CHECK_ARG(h && n, "NULL argument");
+  *n = static_cast<int32_t>(h->outTypes.size());
+  if (types) {
+    for (int32_t i = 0; i < *n && i < cap; ++i) {
+      types[i] = h->outTypes[i];
+    }
+  }
+  VX_API_END
+}
+
+int vx355_agg_get_output(vx355_agg* h, vx355_out_column* cols, int32_t num_cols, int32_t max_rows,
+                         int32_t* n_out, int32_t* finished) {
+  VX_API_BEGIN
+  Runtime::get().requireInit();
+  VX_CHECK_ARG(h, "NULL argument");
+  getOutput(*h, cols, num_cols, max_rows, n_out, finished);
+  VX_API_END
+}
+
+int vx355_agg_get_stats(const vx355_agg* h, vx355_agg_stats* out) {
+  VX_API_BEGIN
+  VX_CHECK_ARG(h && out, "NULL argument");
+  out->num_groups = h->keys.empty() ? 1 : h->numGroups;
+  out->capacity = static_cast<int64_t>(h->capacity);
+  out->num_rehashes = h->numRehashes;
+  out->hash_mode = h->mode;
+  out->reserved = 0;
+  out->input_rows = h->inputRows;
+  out->deferred_rows = h->deferredRows;
+  VX_API_END
+}
+
+void vx355_agg_destroy(vx355_agg* h) {
+  std::lock_guard<std::recursive_mutex> lock(vx::apiMutex());
+  delete h;
+}
+
+}  // extern "C"

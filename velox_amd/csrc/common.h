@@ -1,0 +1,189 @@
+// Host-side plumbing of libvx355: status/exception mapping, the runtime
+// singleton (device, stream, pinned mailbox), growable HBM buffers, staging of
+// vx355_batch descriptors into device-resident column views, and the
+// HIP-event profiler behind vx355_profile_*.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/vx355.h"
+#include "device_utils.h"
+
+namespace vx {
+
+struct Error : std::runtime_error {
+  int status;
+  Error(int s, const std::string& m) : std::runtime_error(m), status(s) {}
+};
+
+void setLastError(const std::string& m);
+
+#define VX_THROW(status, msg) throw ::vx::Error((status), (msg))
+#define VX_CHECK_ARG(cond, msg)         \
+  do {                                  \
+    if (!(cond)) {                      \
+      VX_THROW(VX355_EINVAL, (msg));    \
+    }                                   \
+  } while (0)
+
+void hipFail(hipError_t e, const char* what, const char* file, int line);
+#define HIP_OK(expr)                                   \
+  do {                                                 \
+    hipError_t e__ = (expr);                           \
+    if (e__ != hipSuccess) {                           \
+      ::vx::hipFail(e__, #expr, __FILE__, __LINE__);   \
+    }                                                  \
+  } while (0)
+
+// Every extern "C" entry point is wrapped: no exception crosses the ABI
+// (include/vx355.h "Errors").
+std::recursive_mutex& apiMutex();
+#define VX_API_BEGIN                                              \
+  std::lock_guard<std::recursive_mutex> apiLock__(::vx::apiMutex()); \
+  try {
+#define VX_API_END                                   \
+  return VX355_OK;                                   \
+  }                                                  \
+  catch (const ::vx::Error& e) {                     \
+    ::vx::setLastError(e.what());                    \
+    return e.status;                                 \
+  }                                                  \
+  catch (const std::bad_alloc&) {                    \
+    ::vx::setLastError("host out of memory");        \
+    return VX355_ENOMEM;                             \
+  }                                                  \
+  catch (const std::exception& e) {                  \
+    ::vx::setLastError(e.what());                    \
+    return VX355_EINTERNAL;                          \
+  }
+
+// Mailbox: pinned host memory the kernels write small results into (counts,
+// flags, stats) so the host reads them after a stream sync without a D2H copy.
+struct Mailbox {
+  static constexpr int kWords = 512;
+  uint64_t* host = nullptr;  // pinned, device-mapped
+  uint64_t* dev = nullptr;   // device alias of host
+};
+
+struct ProfileEntry {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  double doneMs = 0;
+  int64_t launches = 0;
+};
+
+struct Runtime {
+  bool initialized = false;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  int numCUs = 256;
+  size_t ldsPerBlock = 65536;
+  Mailbox mail;
+  bool profile = false;
+  std::map<std::string, ProfileEntry> prof;
+  std::vector<hipEvent_t> freeEvents;
+
+  static Runtime& get();
+  void requireInit() const {
+    if (!initialized) {
+      VX_THROW(VX355_EINVAL, "vx355_init has not been called");
+    }
+  }
+  void sync() { HIP_OK(hipStreamSynchronize(stream)); }
+  hipEvent_t newEvent();
+  void profBegin(const char* name);
+  void profEnd(const char* name);
+};
+
+// Launch on the library stream, bracketed by events when profiling is on.
+#define VX_LAUNCH(name, kernel, grid, block, shmem, ...)                              \
+  do {                                                                                \
+    auto& rt__ = ::vx::Runtime::get();                                                \
+    if (rt__.profile) rt__.profBegin(name);                                           \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (shmem), rt__.stream,         \
+                       __VA_ARGS__);                                                  \
+    if (rt__.profile) rt__.profEnd(name);                                             \
+    HIP_OK(hipGetLastError());                                                        \
+  } while (0)
+
+// Growable device buffer (never shrinks; contents preserved on growth when
+// asked). HBM is plentiful (288 GB): grow by doubling.
+class DevBuf {
+ public:
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p_(o.p_), cap_(o.cap_) { o.p_ = nullptr; o.cap_ = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) {
+      release();
+      p_ = o.p_;
+      cap_ = o.cap_;
+      o.p_ = nullptr;
+      o.cap_ = 0;
+    }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  void* ensure(size_t bytes, bool preserve = false, size_t preserveBytes = 0);
+  template <typename T>
+  T* as() const { return static_cast<T*>(p_); }
+  void* ptr() const { return p_; }
+  size_t capacity() const { return cap_; }
+  void release();
+
+ private:
+  void* p_ = nullptr;
+  size_t cap_ = 0;
+};
+
+int kindWidth(int32_t kind);  // bytes per value; 0 for bit-packed BOOLEAN; -1 unknown
+inline bool isIntLike(int32_t k) { return k >= VX355_BOOLEAN && k <= VX355_BIGINT; }
+inline bool isString(int32_t k) { return k == VX355_VARCHAR || k == VX355_VARBINARY; }
+
+// A vx355_batch made device-resident: host columns are copied into staging
+// buffers owned by this object (H2D on the library stream); device columns are
+// aliased. Non-inline strings of host columns are copied into a device blob
+// and their StringView pointers rewritten.
+class DeviceBatch {
+ public:
+  void load(const vx355_batch* batch, const std::vector<int32_t>& usedCols);
+  const ColView& col(int32_t i) const { return views_.at(i); }
+  int32_t numRows() const { return numRows_; }
+  int32_t numCols() const { return static_cast<int32_t>(views_.size()); }
+  bool used(int32_t i) const { return used_.at(i); }
+
+ private:
+  const void* stage(const void* src, size_t bytes, int32_t mem);
+  std::vector<ColView> views_;
+  std::vector<char> used_;
+  std::vector<std::unique_ptr<DevBuf>> staging_;
+  std::vector<std::vector<char>> hostTmp_;
+  int32_t numRows_ = 0;
+};
+
+// Copies caller-visible results out of device scratch.
+void copyOut(void* dst, int32_t dstMem, const void* devSrc, size_t bytes);
+void copyIn(void* devDst, const void* src, int32_t srcMem, size_t bytes);
+
+inline int64_t ceilDiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline uint64_t nextPow2(uint64_t v) {
+  uint64_t p = 1;
+  while (p < v) {
+    p <<= 1;
+  }
+  return p;
+}
+// Grid for a streaming kernel: enough blocks to fill 256 CUs several times
+// over, capped so grid-stride loops amortise launch cost.
+int streamGrid(int64_t items, int block, int perThread = 1);
+
+}  // namespace vx

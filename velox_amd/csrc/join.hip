@@ -1,0 +1,1128 @@
+// HashBuild / HashProbe on the MI355X (replaces exec/HashBuild.cpp:442-993,
+// exec/HashTable.cpp:610-725,1394-1538,1989-2350 and exec/HashProbe.cpp
+// :796-991 for the join kinds listed in include/vx355.h).
+//
+// Design:
+//  * The build side is kept columnar in HBM: per key the int64 image the
+//    reference's VectorHasher would normalise (value, stringAsNumber, bool),
+//    per dependent column the raw values plus one validity byte per row. Rows
+//    with a null key are dropped while appending (HashBuild.cpp:475-494) with
+//    an order-preserving ballot compaction, so build row ids are dense and
+//    follow input order.
+//  * finish() merges peer builds, takes exact key ranges (reserve 0 for join
+//    builds, HashTable.h:1213-1215) and picks
+//      - array mode: head[normalized key] = build row (u32). The reference
+//        caps this at 2 M entries for CPU caches (HashTable.h:146); with 288 GB
+//        of HBM the cap is a multiple of the build size instead, or
+//      - normalized-key mode: open addressing over 16-byte slots
+//        {u64 key, u32 head row, u32 pad}, load factor <= 0.7, linear probing
+//        from twang_mix64(key), key claimed by one CAS.
+//    Rows with equal keys are chained through next[row] (HashTable.cpp
+//    :1394-1418 pushNext / arrayPushRow).
+//  * Probe: one lane per probe row computes the normalized key with
+//    lookupValueIds semantics (out of range = proven miss, VectorHasher.cpp
+//    :550-565), reads one head word (array) or walks slots (hash) and stores
+//    hits[row]; duplicate tables also store the chain length. getOutput
+//    (HashTable::listJoinResults, HashTable.cpp:2133-2350) turns per-row
+//    counts into offsets with a two-level scan and emits (probe row, build row)
+//    pairs in ascending probe-row order, resumable at any max_rows.
+#include "common.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+
+namespace vx {
+
+void compactBits(const uint64_t* dValues, const uint64_t* dNulls, const uint64_t* dRows,
+                 int64_t numRows, int32_t* dOut, DevBuf& scratch, int64_t* total);
+
+namespace {
+
+constexpr int kMaxKeys = 8;
+constexpr int kMaxDeps = 16;
+constexpr uint32_t kNoRow32 = 0xffffffffu;
+constexpr uint64_t kEmptyKey = ~0ULL;
+
+enum JoinMode : int32_t { JMODE_HASH = 0, JMODE_ARRAY = 1, JMODE_NORMALIZED = 2 };
+
+struct BuildCounters {
+  uint32_t unmappable;
+  uint32_t longString;
+  uint32_t nullKeyRows;
+  uint32_t duplicates;
+  uint32_t numDistinct;
+  uint32_t tableFull;
+  uint32_t pad[2];
+  int64_t keyMin[kMaxKeys];
+  int64_t keyMax[kMaxKeys];
+};
+
+// ---- build: append ---------------------------------------------------------------
+struct ValidArgs {
+  ColView keys[kMaxKeys];
+  int32_t numKeys;
+  int64_t numRows;
+  uint64_t* validWords;
+  BuildCounters* counters;
+};
+
+// One word of "all keys non-null" per 64 rows.
+__global__ __launch_bounds__(256) void k_key_valid(ValidArgs a) {
+  const int64_t numWords = (a.numRows + 63) >> 6;
+  const int64_t waveStride = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+  uint32_t nulls = 0;
+  for (int64_t w = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6; w < numWords;
+       w += waveStride) {
+    const int64_t row = (w << 6) + lane();
+    bool ok = row < a.numRows;
+    if (ok) {
+      for (int k = 0; k < a.numKeys; ++k) {
+        if (colIsNull(a.keys[k], row)) {
+          ok = false;
+          break;
+        }
+      }
+      if (!ok) {
+        ++nulls;
+      }
+    }
+    uint64_t m = ballot(ok);
+    if (lane() == 0) {
+      a.validWords[w] = m;
+    }
+  }
+  if (nulls) {
+    atomicAdd(&a.counters->nullKeyRows, nulls);
+  }
+}
+
+struct AppendArgs {
+  ColView keys[kMaxKeys];
+  ColView deps[kMaxDeps];
+  int64_t* keyOut[kMaxKeys];
+  char* depOut[kMaxDeps];
+  uint8_t* depValid[kMaxDeps];
+  int32_t depWidth[kMaxDeps];
+  int32_t numKeys;
+  int32_t numDeps;
+  const int32_t* rows;  // selected input rows, ascending
+  int64_t count;
+  int64_t base;         // first build row id of this batch
+  BuildCounters* counters;
+};
+
+__global__ __launch_bounds__(256) void k_build_append(AppendArgs a) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  int64_t mn[kMaxKeys], mx[kMaxKeys];
+  for (int k = 0; k < kMaxKeys; ++k) {
+    mn[k] = INT64_MAX;
+    mx[k] = INT64_MIN;
+  }
+  for (int64_t p = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; p < a.count;
+       p += stride) {
+    const int64_t row = a.rows[p];
+    for (int k = 0; k < a.numKeys; ++k) {
+      KeyRange all;
+      all.min = INT64_MIN;
+      all.max = INT64_MAX;
+      int64_t v;
+      bool mappable;
+      valueIdAt(a.keys[k], colIndex(a.keys[k], row), all, &v, &mappable);
+      if (!mappable) {
+        a.counters->unmappable = 1;
+      }
+      a.keyOut[k][a.base + p] = v;
+      mn[k] = v < mn[k] ? v : mn[k];
+      mx[k] = v > mx[k] ? v : mx[k];
+    }
+    for (int d = 0; d < a.numDeps; ++d) {
+      const ColView& c = a.deps[d];
+      const bool valid = !colIsNull(c, row);
+      a.depValid[d][a.base + p] = valid ? 1 : 0;
+      const int w = a.depWidth[d];
+      char* dst = a.depOut[d] + (a.base + p) * (w == 0 ? 1 : w);
+      if (!valid) {
+        for (int b = 0; b < (w == 0 ? 1 : w); ++b) {
+          dst[b] = 0;
+        }
+        continue;
+      }
+      const int64_t i = colIndex(c, row);
+      if (w == 0) {
+        dst[0] = bitAt(static_cast<const uint64_t*>(c.values), i) ? 1 : 0;
+      } else if (w == 16 && (c.kind == VX355_VARCHAR || c.kind == VX355_VARBINARY)) {
+        uint4 raw = static_cast<const uint4*>(c.values)[i];
+        if (raw.x > 12) {
+          a.counters->longString = 1;
+        }
+        *reinterpret_cast<uint4*>(dst) = raw;
+      } else {
+        const char* src = static_cast<const char*>(c.values) + i * w;
+        for (int b = 0; b < w; ++b) {
+          dst[b] = src[b];
+        }
+      }
+    }
+  }
+  for (int k = 0; k < a.numKeys; ++k) {
+    if (mn[k] <= mx[k]) {
+      atomicMin(reinterpret_cast<long long*>(&a.counters->keyMin[k]), static_cast<long long>(mn[k]));
+      atomicMax(reinterpret_cast<long long*>(&a.counters->keyMax[k]), static_cast<long long>(mx[k]));
+    }
+  }
+}
+
+// ---- build: table -------------------------------------------------------------------
+struct Slot {
+  uint64_t key;
+  uint32_t head;
+  uint32_t pad;
+};
+
+struct InsertArgs {
+  const int64_t* keyVals[kMaxKeys];
+  KeyRange ranges[kMaxKeys];
+  int32_t numKeys;
+  int32_t mode;
+  int64_t numRows;
+  uint32_t* head;   // array mode
+  Slot* slots;      // hash mode
+  uint64_t capacity;
+  uint32_t* next;
+  BuildCounters* counters;
+};
+
+__device__ inline uint64_t buildKey(const InsertArgs& a, int64_t row) {
+  uint64_t key = 0;
+  for (int k = 0; k < a.numKeys; ++k) {
+    const uint64_t id =
+        static_cast<uint64_t>(a.keyVals[k][row]) - static_cast<uint64_t>(a.ranges[k].min) + 1;
+    key += a.ranges[k].multiplier * id;
+  }
+  return key;
+}
+
+__global__ __launch_bounds__(256) void k_join_insert(InsertArgs a) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  uint32_t dups = 0, distinct = 0;
+  for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < a.numRows;
+       row += stride) {
+    const uint64_t key = buildKey(a, row);
+    uint32_t* headWord = nullptr;
+    if (a.mode == JMODE_ARRAY) {
+      headWord = a.head + key;
+    } else {
+      const uint64_t mask = a.capacity - 1;
+      uint64_t pos = twangMix64(key) & mask;
+      for (uint64_t probes = 0; probes <= mask; ++probes) {
+        Slot* s = a.slots + pos;
+        uint64_t k = __hip_atomic_load(&s->key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k == kEmptyKey) {
+          unsigned long long old =
+              atomicCAS(reinterpret_cast<unsigned long long*>(&s->key), kEmptyKey, key);
+          k = old == kEmptyKey ? key : old;
+        }
+        if (k == key) {
+          headWord = &s->head;
+          break;
+        }
+        pos = (pos + 1) & mask;
+      }
+      if (!headWord) {
+        a.counters->tableFull = 1;
+        continue;
+      }
+    }
+    // pushNext / arrayPushRow: the new row becomes the chain head.
+    const uint32_t old = atomicExch(headWord, static_cast<uint32_t>(row));
+    a.next[row] = old;
+    if (old == kNoRow32) {
+      ++distinct;
+    } else {
+      ++dups;
+    }
+  }
+  if (dups) {
+    atomicAdd(&a.counters->duplicates, dups);
+  }
+  if (distinct) {
+    atomicAdd(&a.counters->numDistinct, distinct);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_fill_u32(uint32_t* p, uint64_t n, uint32_t v) {
+  const uint64_t step = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += step) {
+    p[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_fill_slots(Slot* p, uint64_t n) {
+  const uint64_t step = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += step) {
+    Slot s;
+    s.key = kEmptyKey;
+    s.head = kNoRow32;
+    s.pad = 0;
+    p[i] = s;
+  }
+}
+
+// ---- probe -------------------------------------------------------------------------
+struct ProbeArgs {
+  ColView keys[kMaxKeys];
+  KeyRange ranges[kMaxKeys];
+  int32_t numKeys;
+  int32_t mode;
+  int32_t hasDuplicates;
+  int32_t joinType;
+  int64_t numRows;
+  const uint32_t* head;
+  const Slot* slots;
+  uint64_t capacity;
+  const uint32_t* next;
+  uint32_t* hits;    // first matching build row or kNoRow32
+  uint32_t* counts;  // output rows this probe row produces
+};
+
+__device__ inline uint32_t outputCount(int32_t joinType, uint32_t matches) {
+  switch (joinType) {
+    case VX355_JOIN_INNER:
+      return matches;
+    case VX355_JOIN_LEFT:
+      return matches ? matches : 1;
+    case VX355_JOIN_LEFT_SEMI_FILTER:
+      return matches ? 1 : 0;
+    default:  // ANTI (not null aware): rows without a match, null keys included
+      return matches ? 0 : 1;
+  }
+}
+
+// HashTable::joinProbe: hits[row] = first build row with an equal key.
+__global__ __launch_bounds__(256) void k_join_probe(ProbeArgs a) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < a.numRows;
+       row += stride) {
+    uint64_t key = 0;
+    bool miss = false;
+    for (int k = 0; k < a.numKeys; ++k) {
+      const ColView& c = a.keys[k];
+      if (colIsNull(c, row)) {
+        miss = true;  // a null key never matches (HashProbe.cpp:778)
+        break;
+      }
+      int64_t v;
+      bool mappable;
+      const uint64_t id = valueIdAt(c, colIndex(c, row), a.ranges[k], &v, &mappable);
+      if (id == 0) {
+        miss = true;  // outside the build side's range: proven miss
+        break;
+      }
+      key += a.ranges[k].multiplier * id;
+    }
+    uint32_t hit = kNoRow32;
+    if (!miss) {
+      if (a.mode == JMODE_ARRAY) {
+        hit = a.head[key];
+      } else {
+        const uint64_t mask = a.capacity - 1;
+        uint64_t pos = twangMix64(key) & mask;
+        for (uint64_t probes = 0; probes <= mask; ++probes) {
+          const uint4 raw = *reinterpret_cast<const uint4*>(a.slots + pos);
+          const uint64_t k = (static_cast<uint64_t>(raw.y) << 32) | raw.x;
+          if (k == key) {
+            hit = raw.z;
+            break;
+          }
+          if (k == kEmptyKey) {
+            break;
+          }
+          pos = (pos + 1) & mask;
+        }
+      }
+    }
+    a.hits[row] = hit;
+    uint32_t matches = hit == kNoRow32 ? 0 : 1;
+    if (matches && a.hasDuplicates && (a.joinType == VX355_JOIN_INNER || a.joinType == VX355_JOIN_LEFT)) {
+      uint32_t r = a.next[hit];
+      while (r != kNoRow32) {
+        ++matches;
+        r = a.next[r];
+      }
+    }
+    a.counts[row] = outputCount(a.joinType, matches);
+  }
+}
+
+// ---- listJoinResults -------------------------------------------------------------------
+constexpr int kTileRows = 2048;  // 256 threads x 8 rows
+
+__global__ __launch_bounds__(256) void k_tile_sums(const uint32_t* counts, int64_t numRows,
+                                                    uint64_t* tileSums) {
+  __shared__ uint64_t partial[4];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kTileRows;
+  uint64_t s = 0;
+  for (int j = 0; j < 8; ++j) {
+    const int64_t r = base + j * 256 + threadIdx.x;
+    if (r < numRows) {
+      s += counts[r];
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s += shfl64(s, lane() ^ off);
+  }
+  if (lane() == 0) {
+    partial[threadIdx.x >> 6] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    tileSums[blockIdx.x] = partial[0] + partial[1] + partial[2] + partial[3];
+  }
+}
+
+// Single-block exclusive scan; offsets has n + 1 entries (last = total).
+__global__ __launch_bounds__(1024) void k_scan_u64(const uint64_t* in, int64_t n, uint64_t* offsets) {
+  __shared__ uint64_t partial[1024];
+  const int t = threadIdx.x;
+  const int64_t per = (n + blockDim.x - 1) / blockDim.x;
+  const int64_t begin = t * per;
+  const int64_t end = begin + per < n ? begin + per : n;
+  uint64_t sum = 0;
+  for (int64_t i = begin; i < end; ++i) {
+    sum += in[i];
+  }
+  partial[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    uint64_t v = t >= off ? partial[t - off] : 0;
+    __syncthreads();
+    partial[t] += v;
+    __syncthreads();
+  }
+  uint64_t run = t == 0 ? 0 : partial[t - 1];
+  for (int64_t i = begin; i < end; ++i) {
+    offsets[i] = run;
+    run += in[i];
+  }
+  if (t == blockDim.x - 1) {
+    offsets[n] = partial[1023];
+  }
+}
+
+struct EmitArgs {
+  const uint32_t* hits;
+  const uint32_t* counts;
+  const uint32_t* next;
+  const uint64_t* tileOffsets;
+  int64_t numRows;
+  int64_t firstTile;
+  uint64_t windowBegin;  // output positions [windowBegin, windowEnd) of this batch
+  uint64_t windowEnd;
+  int32_t joinType;
+  int32_t* mapping;
+  int32_t* buildRows;
+};
+
+// Each block owns one tile of probe rows: an in-tile exclusive scan of the
+// counts gives every row its output offset; rows intersecting the window write
+// their pairs. Probe rows ascend with the offsets, so the output is in
+// ascending probe-row order with all matches of a row contiguous.
+__global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
+  __shared__ uint64_t waveTotals[4];
+  const int64_t tile = a.firstTile + blockIdx.x;
+  const int64_t base = tile * kTileRows + static_cast<int64_t>(threadIdx.x) * 8;
+  uint32_t cnt[8];
+  uint64_t mine = 0;
+  for (int j = 0; j < 8; ++j) {
+    const int64_t r = base + j;
+    cnt[j] = r < a.numRows ? a.counts[r] : 0;
+    mine += cnt[j];
+  }
+  // Exclusive scan of 'mine' across the block (thread t owns 8 consecutive rows).
+  uint64_t incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    uint64_t v = shfl64(incl, lane() - off >= 0 ? lane() - off : lane());
+    if (lane() >= off) {
+      incl += v;
+    }
+  }
+  if (lane() == 63) {
+    waveTotals[threadIdx.x >> 6] = incl;
+  }
+  __syncthreads();
+  uint64_t off = a.tileOffsets[tile] + (incl - mine);
+  for (int w = 0; w < (threadIdx.x >> 6); ++w) {
+    off += waveTotals[w];
+  }
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t c = cnt[j];
+    if (c == 0) {
+      continue;
+    }
+    const uint64_t lo = off, hi = off + c;
+    off = hi;
+    if (hi <= a.windowBegin || lo >= a.windowEnd) {
+      continue;
+    }
+    const int64_t r = base + j;
+    const uint32_t hit = a.hits[r];
+    const bool listMatches = hit != kNoRow32 &&
+        (a.joinType == VX355_JOIN_INNER || a.joinType == VX355_JOIN_LEFT);
+    uint32_t b = hit;
+    for (uint64_t p = lo; p < hi && p < a.windowEnd; ++p) {
+      if (p >= a.windowBegin) {
+        a.mapping[p - a.windowBegin] = static_cast<int32_t>(r);
+        if (a.buildRows) {
+          a.buildRows[p - a.windowBegin] = listMatches ? static_cast<int32_t>(b) : -1;
+        }
+      }
+      if (listMatches) {
+        b = a.next[b];
+      }
+    }
+  }
+}
+
+struct GatherArgs {
+  const int32_t* buildRows;
+  int32_t count;
+  int32_t numCols;
+  const char* depVals[kMaxDeps];
+  const uint8_t* depValid[kMaxDeps];
+  int32_t width[kMaxDeps];
+  int32_t kind[kMaxDeps];
+  void* outVals[kMaxDeps];
+  uint64_t* outNulls[kMaxDeps];
+};
+
+// extractColumns (HashProbe.cpp:82-118): build columns at the listed rows.
+__global__ __launch_bounds__(256) void k_gather_deps(GatherArgs a) {
+  const int32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = pos < a.count;
+  const int32_t b = active ? a.buildRows[pos] : -1;
+  for (int c = 0; c < a.numCols; ++c) {
+    const bool valid = active && b >= 0 && a.depValid[c][b] != 0;
+    uint64_t m = ballot(valid);
+    if (a.outNulls[c] && lane() == 0) {
+      a.outNulls[c][pos >> 6] = m;
+    }
+    const int w = a.width[c];
+    if (w == 0) {
+      uint64_t bits = ballot(valid && a.depVals[c][b] != 0);
+      if (lane() == 0) {
+        static_cast<uint64_t*>(a.outVals[c])[pos >> 6] = bits;
+      }
+      continue;
+    }
+    if (!active) {
+      continue;
+    }
+    char* dst = static_cast<char*>(a.outVals[c]) + static_cast<int64_t>(pos) * w;
+    if (!valid) {
+      for (int i = 0; i < w; ++i) {
+        dst[i] = 0;
+      }
+      continue;
+    }
+    const char* src = a.depVals[c] + static_cast<int64_t>(b) * w;
+    if (w == 8) {
+      *reinterpret_cast<uint64_t*>(dst) = *reinterpret_cast<const uint64_t*>(src);
+    } else if (w == 4) {
+      *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(src);
+    } else if (w == 16) {
+      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+    } else {
+      for (int i = 0; i < w; ++i) {
+        dst[i] = src[i];
+      }
+    }
+  }
+}
+
+bool supportedJoin(int32_t t) {
+  return t == VX355_JOIN_INNER || t == VX355_JOIN_LEFT || t == VX355_JOIN_LEFT_SEMI_FILTER ||
+      t == VX355_JOIN_ANTI;
+}
+
+}  // namespace
+}  // namespace vx
+
+using namespace vx;
+
+struct vx355_join_build {
+  std::vector<int32_t> keyCols, keyKinds, depCols, depKinds;
+  std::vector<int32_t> usedCols;
+  int32_t joinType = 0;
+  std::vector<DevBuf> keyVals;   // int64 per row
+  std::vector<DevBuf> depVals;   // width bytes per row (BOOLEAN: 1 byte)
+  std::vector<DevBuf> depValid;  // 1 byte per row
+  int64_t numRows = 0;
+  int64_t capacityRows = 0;
+  bool hasNullKeys = false;
+  bool finished = false;
+  std::vector<int64_t> obsMin, obsMax;
+  DevBuf countersBuf, scratch, validWords, rowList;
+};
+
+struct vx355_join_table {
+  std::atomic<int> refs{1};
+  int32_t mode = JMODE_ARRAY;
+  int32_t joinType = 0;
+  std::vector<int32_t> keyKinds, depKinds;
+  std::vector<KeyRange> ranges;
+  uint64_t capacity = 0;
+  DevBuf head;   // array mode: u32[capacity]
+  DevBuf slots;  // hash mode: Slot[capacity]
+  DevBuf next;   // u32[numRows]
+  std::vector<DevBuf> depVals, depValid;
+  int64_t numRows = 0;
+  int64_t numDistinct = 0;
+  bool hasDuplicates = false;
+  bool hasNullKeys = false;
+};
+
+struct vx355_join_probe {
+  vx355_join_table* table = nullptr;
+  std::vector<int32_t> keyCols;
+  int32_t joinType = 0;
+  DevBuf hits, counts, tileSums, tileOffsets, scratch, outMap, outRows;
+  std::vector<uint64_t> hostTileOffsets;
+  int64_t numRows = 0;
+  int64_t numTiles = 0;
+  uint64_t totalOut = 0;
+  uint64_t cursor = 0;
+  bool hasInput = false;
+};
+
+namespace vx {
+namespace {
+
+int depStoreWidth(int32_t kind) {
+  int w = kindWidth(kind);
+  return w == 0 ? 1 : w;
+}
+
+void growBuild(vx355_join_build& h, int64_t rows) {
+  if (rows <= h.capacityRows) {
+    return;
+  }
+  int64_t cap = std::max<int64_t>(rows, h.capacityRows * 2);
+  cap = std::max<int64_t>(cap, 1024);
+  for (size_t k = 0; k < h.keyVals.size(); ++k) {
+    h.keyVals[k].ensure(static_cast<size_t>(cap) * 8 + 64, true, static_cast<size_t>(h.numRows) * 8);
+  }
+  for (size_t d = 0; d < h.depVals.size(); ++d) {
+    const int w = depStoreWidth(h.depKinds[d]);
+    h.depVals[d].ensure(static_cast<size_t>(cap) * w + 64, true, static_cast<size_t>(h.numRows) * w);
+    h.depValid[d].ensure(static_cast<size_t>(cap) + 64, true, static_cast<size_t>(h.numRows));
+  }
+  h.capacityRows = cap;
+}
+
+void resetBuildCounters(DevBuf& buf) {
+  BuildCounters c{};
+  for (int k = 0; k < kMaxKeys; ++k) {
+    c.keyMin[k] = INT64_MAX;
+    c.keyMax[k] = INT64_MIN;
+  }
+  copyIn(buf.ensure(sizeof(BuildCounters)), &c, VX355_MEM_HOST, sizeof(c));
+}
+
+BuildCounters readBuildCounters(DevBuf& buf) {
+  BuildCounters c;
+  copyOut(&c, VX355_MEM_HOST, buf.ptr(), sizeof(c));
+  return c;
+}
+
+void buildAddInput(vx355_join_build& h, const vx355_batch* batch) {
+  VX_CHECK_ARG(!h.finished, "addInput after finish");
+  DeviceBatch db;
+  db.load(batch, h.usedCols);
+  const int64_t n = db.numRows();
+  if (n == 0) {
+    return;
+  }
+  resetBuildCounters(h.countersBuf);
+  auto* ctr = h.countersBuf.as<BuildCounters>();
+  const int64_t words = ceilDiv(n, 64);
+  ValidArgs va{};
+  va.numKeys = static_cast<int32_t>(h.keyCols.size());
+  for (int k = 0; k < va.numKeys; ++k) {
+    va.keys[k] = db.col(h.keyCols[k]);
+  }
+  va.numRows = n;
+  va.validWords = static_cast<uint64_t*>(h.validWords.ensure(static_cast<size_t>(words) * 8 + 64));
+  va.counters = ctr;
+  VX_LAUNCH("k_key_valid", k_key_valid, streamGrid(words * 64, 256), 256, 0, va);
+  int32_t* rows = static_cast<int32_t*>(h.rowList.ensure(static_cast<size_t>(n) * 4 + 64));
+  int64_t selected = 0;
+  compactBits(va.validWords, nullptr, nullptr, n, rows, h.scratch, &selected);
+  if (selected > 0) {
+    growBuild(h, h.numRows + selected);
+    AppendArgs aa{};
+    aa.numKeys = va.numKeys;
+    aa.numDeps = static_cast<int32_t>(h.depCols.size());
+    for (int k = 0; k < aa.numKeys; ++k) {
+      aa.keys[k] = va.keys[k];
+      aa.keyOut[k] = h.keyVals[k].as<int64_t>();
+    }
+    for (int d = 0; d < aa.numDeps; ++d) {
+      aa.deps[d] = db.col(h.depCols[d]);
+      aa.depOut[d] = h.depVals[d].as<char>();
+      aa.depValid[d] = h.depValid[d].as<uint8_t>();
+      aa.depWidth[d] = kindWidth(h.depKinds[d]);
+    }
+    aa.rows = rows;
+    aa.count = selected;
+    aa.base = h.numRows;
+    aa.counters = ctr;
+    VX_LAUNCH("k_build_append", k_build_append, streamGrid(selected, 256), 256, 0, aa);
+  }
+  BuildCounters c = readBuildCounters(h.countersBuf);
+  if (c.unmappable) {
+    VX_THROW(VX355_EUNSUPPORTED, "string join key longer than 7 bytes (generic hash mode not on device)");
+  }
+  if (c.longString) {
+    VX_THROW(VX355_EUNSUPPORTED, "non-inline string in a build-side payload column");
+  }
+  if (c.nullKeyRows) {
+    h.hasNullKeys = true;
+  }
+  for (size_t k = 0; k < h.keyCols.size(); ++k) {
+    if (c.keyMin[k] <= c.keyMax[k]) {
+      h.obsMin[k] = std::min(h.obsMin[k], c.keyMin[k]);
+      h.obsMax[k] = std::max(h.obsMax[k], c.keyMax[k]);
+    }
+  }
+  h.numRows += selected;
+}
+
+vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* others, int32_t numOthers) {
+  auto& rt = Runtime::get();
+  VX_CHECK_ARG(!h.finished, "finish called twice");
+  // Merge the peer Drivers' rows behind ours (HashBuild.cpp:903-922): row ids
+  // are [this build's rows..., others[0]'s rows..., ...].
+  int64_t total = h.numRows;
+  for (int32_t i = 0; i < numOthers; ++i) {
+    VX_CHECK_ARG(others && others[i] && others[i] != &h, "bad peer build handle");
+    VX_CHECK_ARG(others[i]->keyKinds == h.keyKinds && others[i]->depKinds == h.depKinds,
+                 "peer build with a different layout");
+    total += others[i]->numRows;
+  }
+  if (total >= static_cast<int64_t>(kNoRow32)) {
+    VX_THROW(VX355_EUNSUPPORTED, "more than 2^32-2 build rows");
+  }
+  growBuild(h, total);
+  for (int32_t i = 0; i < numOthers; ++i) {
+    auto& o = *others[i];
+    if (o.numRows > 0) {
+      for (size_t k = 0; k < h.keyVals.size(); ++k) {
+        copyIn(h.keyVals[k].as<char>() + h.numRows * 8, o.keyVals[k].ptr(), VX355_MEM_DEVICE,
+               static_cast<size_t>(o.numRows) * 8);
+      }
+      for (size_t d = 0; d < h.depVals.size(); ++d) {
+        const int w = depStoreWidth(h.depKinds[d]);
+        copyIn(h.depVals[d].as<char>() + h.numRows * w, o.depVals[d].ptr(), VX355_MEM_DEVICE,
+               static_cast<size_t>(o.numRows) * w);
+        copyIn(h.depValid[d].as<char>() + h.numRows, o.depValid[d].ptr(), VX355_MEM_DEVICE,
+               static_cast<size_t>(o.numRows));
+      }
+      for (size_t k = 0; k < h.keyCols.size(); ++k) {
+        h.obsMin[k] = std::min(h.obsMin[k], o.obsMin[k]);
+        h.obsMax[k] = std::max(h.obsMax[k], o.obsMax[k]);
+      }
+      h.numRows += o.numRows;
+    }
+    h.hasNullKeys = h.hasNullKeys || o.hasNullKeys;
+    o.finished = true;
+  }
+  rt.sync();
+
+  auto t = std::make_unique<vx355_join_table>();
+  t->joinType = h.joinType;
+  t->keyKinds = h.keyKinds;
+  t->depKinds = h.depKinds;
+  t->numRows = h.numRows;
+  t->hasNullKeys = h.hasNullKeys;
+  t->ranges.resize(h.keyCols.size());
+
+  // decideHashMode for a join build: exact ranges (reserve 0).
+  unsigned __int128 product = 1;
+  bool overflow = false;
+  for (size_t k = 0; k < h.keyCols.size(); ++k) {
+    KeyRange& r = t->ranges[k];
+    if (h.keyKinds[k] == VX355_BOOLEAN) {
+      r.min = 0;
+      r.max = 1;
+      r.rangeSize = 3;
+    } else if (h.obsMin[k] > h.obsMax[k]) {
+      r.min = 0;
+      r.max = -1;
+      r.rangeSize = 1;
+    } else {
+      int64_t span;
+      if (__builtin_sub_overflow(h.obsMax[k], h.obsMin[k], &span) || span >= (1LL << 59) - 1) {
+        overflow = true;
+        span = 0;
+      }
+      r.min = h.obsMin[k];
+      r.max = h.obsMax[k];
+      r.rangeSize = static_cast<uint64_t>(span) + 2;
+    }
+    r.multiplier = static_cast<uint64_t>(product);
+    product *= r.rangeSize;
+    if (product >= (static_cast<unsigned __int128>(1) << 64) - 1) {
+      overflow = true;
+    }
+  }
+  if (overflow) {
+    VX_THROW(VX355_EUNSUPPORTED,
+             "join keys do not fit a 64-bit normalized key (generic hash mode not on device)");
+  }
+  // Direct addressing while the head array stays within a budget relative to
+  // the build size (4 bytes per possible key).
+  uint64_t arrayMax = std::max<uint64_t>(1ULL << 21, static_cast<uint64_t>(h.numRows) * 64);
+  if (const char* e = std::getenv("VX355_JOIN_ARRAY_MAX")) {
+    arrayMax = std::strtoull(e, nullptr, 10);
+  }
+  const uint64_t range = static_cast<uint64_t>(product);
+  InsertArgs ia{};
+  ia.numKeys = static_cast<int32_t>(h.keyCols.size());
+  for (int k = 0; k < ia.numKeys; ++k) {
+    ia.keyVals[k] = h.keyVals[k].as<int64_t>();
+    ia.ranges[k] = t->ranges[k];
+  }
+  ia.numRows = h.numRows;
+  resetBuildCounters(h.countersBuf);
+  ia.counters = h.countersBuf.as<BuildCounters>();
+  t->next.ensure(static_cast<size_t>(std::max<int64_t>(1, h.numRows)) * 4 + 64);
+  ia.next = t->next.as<uint32_t>();
+  if (range <= arrayMax) {
+    t->mode = JMODE_ARRAY;
+    t->capacity = range;
+    t->head.ensure(static_cast<size_t>(range) * 4 + 64);
+    VX_LAUNCH("k_fill_u32", k_fill_u32, streamGrid(static_cast<int64_t>(range), 256, 4), 256, 0,
+              t->head.as<uint32_t>(), range, kNoRow32);
+    ia.head = t->head.as<uint32_t>();
+  } else {
+    t->mode = JMODE_NORMALIZED;
+    // HashTable::newHashTableEntries (HashTable.h:946-956).
+    uint64_t cap = std::max<uint64_t>(2048, nextPow2(static_cast<uint64_t>(h.numRows) * 2));
+    t->capacity = cap;
+    t->slots.ensure(static_cast<size_t>(cap) * sizeof(Slot) + 64);
+    VX_LAUNCH("k_fill_slots", k_fill_slots, streamGrid(static_cast<int64_t>(cap), 256, 2), 256, 0,
+              t->slots.as<Slot>(), cap);
+    ia.slots = t->slots.as<Slot>();
+  }
+  ia.mode = t->mode;
+  ia.capacity = t->capacity;
+  if (h.numRows > 0) {
+    VX_LAUNCH("k_join_insert", k_join_insert, streamGrid(h.numRows, 256), 256, 0, ia);
+  }
+  BuildCounters c = readBuildCounters(h.countersBuf);
+  if (c.tableFull) {
+    VX_THROW(VX355_EINTERNAL, "join table full");
+  }
+  t->numDistinct = c.numDistinct;
+  t->hasDuplicates = c.duplicates != 0;
+  t->depVals = std::move(h.depVals);
+  t->depValid = std::move(h.depValid);
+  h.keyVals.clear();
+  h.finished = true;
+  return t.release();
+}
+
+void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
+  auto& rt = Runtime::get();
+  auto& t = *p.table;
+  DeviceBatch db;
+  db.load(batch, p.keyCols);
+  const int64_t n = db.numRows();
+  p.numRows = n;
+  p.cursor = 0;
+  p.totalOut = 0;
+  p.numTiles = 0;
+  p.hasInput = true;
+  if (n == 0) {
+    return;
+  }
+  ProbeArgs a{};
+  a.numKeys = static_cast<int32_t>(p.keyCols.size());
+  for (int k = 0; k < a.numKeys; ++k) {
+    a.keys[k] = db.col(p.keyCols[k]);
+    const int32_t kind = a.keys[k].kind;
+    const bool buildString = isString(t.keyKinds[k]);
+    if (isString(kind) != buildString || (!isString(kind) && !isIntLike(kind))) {
+      VX_THROW(VX355_EUNSUPPORTED, "probe key type does not match the build key");
+    }
+    a.ranges[k] = t.ranges[k];
+  }
+  a.mode = t.mode;
+  a.hasDuplicates = t.hasDuplicates ? 1 : 0;
+  a.joinType = p.joinType;
+  a.numRows = n;
+  a.head = t.head.as<uint32_t>();
+  a.slots = t.slots.as<Slot>();
+  a.capacity = t.capacity;
+  a.next = t.next.as<uint32_t>();
+  a.hits = static_cast<uint32_t*>(p.hits.ensure(static_cast<size_t>(n) * 4 + 64));
+  a.counts = static_cast<uint32_t*>(p.counts.ensure(static_cast<size_t>(n) * 4 + 64));
+  VX_LAUNCH("k_join_probe", k_join_probe, streamGrid(n, 256), 256, 0, a);
+  // Offsets for listJoinResults.
+  p.numTiles = ceilDiv(n, kTileRows);
+  uint64_t* sums = static_cast<uint64_t*>(p.tileSums.ensure(static_cast<size_t>(p.numTiles) * 8 + 64));
+  uint64_t* offs =
+      static_cast<uint64_t*>(p.tileOffsets.ensure(static_cast<size_t>(p.numTiles + 1) * 8 + 64));
+  VX_LAUNCH("k_tile_sums", k_tile_sums, static_cast<int>(p.numTiles), 256, 0, a.counts, n, sums);
+  VX_LAUNCH("k_scan_u64", k_scan_u64, 1, 1024, 0, sums, p.numTiles, offs);
+  p.hostTileOffsets.resize(p.numTiles + 1);
+  copyOut(p.hostTileOffsets.data(), VX355_MEM_HOST, offs, static_cast<size_t>(p.numTiles + 1) * 8);
+  rt.sync();
+  p.totalOut = p.hostTileOffsets.back();
+}
+
+void probeGetOutput(vx355_join_probe& p, int32_t maxRows, int32_t* mappingOut, int32_t* buildRowsOut,
+                    int32_t outMem, vx355_out_column* buildCols, const int32_t* buildColIds,
+                    int32_t numBuildCols, int32_t* nOut, int32_t* finished) {
+  auto& rt = Runtime::get();
+  auto& t = *p.table;
+  VX_CHECK_ARG(nOut && finished, "NULL argument");
+  VX_CHECK_ARG(maxRows > 0, "max_rows must be positive");
+  VX_CHECK_ARG(numBuildCols >= 0 && numBuildCols <= kMaxDeps, "bad number of build columns");
+  *nOut = 0;
+  *finished = 1;
+  if (!p.hasInput || p.cursor >= p.totalOut) {
+    return;
+  }
+  VX_CHECK_ARG(mappingOut != nullptr, "mapping_out is NULL");
+  const uint64_t begin = p.cursor;
+  const uint64_t end = std::min<uint64_t>(p.totalOut, begin + static_cast<uint64_t>(maxRows));
+  const int32_t n = static_cast<int32_t>(end - begin);
+  const bool host = outMem == VX355_MEM_HOST;
+  int32_t* dMap = host ? static_cast<int32_t*>(p.outMap.ensure(static_cast<size_t>(n) * 4 + 64)) : mappingOut;
+  const bool needRows = buildRowsOut != nullptr || numBuildCols > 0;
+  int32_t* dRows = nullptr;
+  if (needRows) {
+    dRows = (host || !buildRowsOut)
+        ? static_cast<int32_t*>(p.outRows.ensure(static_cast<size_t>(n) * 4 + 64))
+        : buildRowsOut;
+  }
+  // Tiles whose offset range intersects the window.
+  const auto& to = p.hostTileOffsets;
+  int64_t firstTile = std::upper_bound(to.begin(), to.end(), begin) - to.begin() - 1;
+  int64_t lastTile = std::lower_bound(to.begin(), to.end(), end) - to.begin() - 1;
+  firstTile = std::max<int64_t>(0, std::min<int64_t>(firstTile, p.numTiles - 1));
+  lastTile = std::max<int64_t>(firstTile, std::min<int64_t>(lastTile, p.numTiles - 1));
+  EmitArgs ea{};
+  ea.hits = p.hits.as<uint32_t>();
+  ea.counts = p.counts.as<uint32_t>();
+  ea.next = t.next.as<uint32_t>();
+  ea.tileOffsets = p.tileOffsets.as<uint64_t>();
+  ea.numRows = p.numRows;
+  ea.firstTile = firstTile;
+  ea.windowBegin = begin;
+  ea.windowEnd = end;
+  ea.joinType = p.joinType;
+  ea.mapping = dMap;
+  ea.buildRows = dRows;
+  VX_LAUNCH("k_emit", k_emit, static_cast<int>(lastTile - firstTile + 1), 256, 0, ea);
+
+  if (numBuildCols > 0) {
+    VX_CHECK_ARG(buildCols && buildColIds, "NULL build column arguments");
+    const size_t words = static_cast<size_t>(ceilDiv(n, 64));
+    GatherArgs ga{};
+    ga.buildRows = dRows;
+    ga.count = n;
+    ga.numCols = numBuildCols;
+    std::vector<size_t> valOff(numBuildCols), nullOff(numBuildCols), valBytes(numBuildCols);
+    size_t total = 0;
+    for (int32_t c = 0; c < numBuildCols; ++c) {
+      const int32_t id = buildColIds[c];
+      VX_CHECK_ARG(id >= 0 && id < static_cast<int32_t>(t.depKinds.size()), "bad build column id");
+      VX_CHECK_ARG(buildCols[c].type_kind == t.depKinds[id], "build column type mismatch");
+      const int w = kindWidth(t.depKinds[id]);
+      valBytes[c] = w == 0 ? words * 8 : static_cast<size_t>(n) * w;
+      valOff[c] = total;
+      total += (valBytes[c] + 63) & ~static_cast<size_t>(63);
+      nullOff[c] = total;
+      total += (words * 8 + 63) & ~static_cast<size_t>(63);
+    }
+    char* scratch = static_cast<char*>(p.scratch.ensure(total + 64));
+    for (int32_t c = 0; c < numBuildCols; ++c) {
+      const int32_t id = buildColIds[c];
+      ga.depVals[c] = t.depVals[id].as<char>();
+      ga.depValid[c] = t.depValid[id].as<uint8_t>();
+      ga.width[c] = kindWidth(t.depKinds[id]);
+      ga.kind[c] = t.depKinds[id];
+      const bool colHost = buildCols[c].mem == VX355_MEM_HOST;
+      ga.outVals[c] = colHost ? static_cast<void*>(scratch + valOff[c]) : buildCols[c].values;
+      ga.outNulls[c] = colHost ? reinterpret_cast<uint64_t*>(scratch + nullOff[c]) : buildCols[c].nulls;
+    }
+    VX_LAUNCH("k_gather_deps", k_gather_deps, static_cast<int>(ceilDiv(n, 256)), 256, 0, ga);
+    for (int32_t c = 0; c < numBuildCols; ++c) {
+      if (buildCols[c].mem == VX355_MEM_HOST) {
+        copyOut(buildCols[c].values, VX355_MEM_HOST, scratch + valOff[c], valBytes[c]);
+        if (buildCols[c].nulls) {
+          copyOut(buildCols[c].nulls, VX355_MEM_HOST, scratch + nullOff[c], words * 8);
+        }
+      }
+    }
+  }
+  if (host) {
+    copyOut(mappingOut, VX355_MEM_HOST, dMap, static_cast<size_t>(n) * 4);
+    if (buildRowsOut) {
+      copyOut(buildRowsOut, VX355_MEM_HOST, dRows, static_cast<size_t>(n) * 4);
+    }
+  }
+  rt.sync();
+  p.cursor = end;
+  *nOut = n;
+  *finished = p.cursor >= p.totalOut ? 1 : 0;
+}
+
+}  // namespace
+}  // namespace vx
+
+extern "C" {
+
+int vx355_join_build_create(const vx355_join_build_spec* spec, vx355_join_build** out) {
+  VX_API_BEGIN
+  Runtime::get().requireInit();
+  VX_CHECK_ARG(spec && out, "NULL argument");
+  VX_CHECK_ARG(spec->num_keys >= 1 && spec->num_keys <= kMaxKeys, "1..8 join keys supported");
+  VX_CHECK_ARG(spec->num_dependents >= 0 && spec->num_dependents <= kMaxDeps,
+               "at most 16 build payload columns");
+  if (!supportedJoin(spec->join_type) || spec->null_aware) {
+    VX_THROW(VX355_EUNSUPPORTED, "join type " + std::to_string(spec->join_type) +
+                                     (spec->null_aware ? " (null aware)" : "") + " not on device");
+  }
+  auto h = std::make_unique<vx355_join_build>();
+  h->joinType = spec->join_type;
+  for (int32_t k = 0; k < spec->num_keys; ++k) {
+    const int32_t kind = spec->key_types[k];
+    if (!(isIntLike(kind) || isString(kind))) {
+      VX_THROW(VX355_EUNSUPPORTED, "join key type " + std::to_string(kind) + " has no value ids");
+    }
+    h->keyCols.push_back(spec->key_cols[k]);
+    h->keyKinds.push_back(kind);
+    h->usedCols.push_back(spec->key_cols[k]);
+  }
+  for (int32_t d = 0; d < spec->num_dependents; ++d) {
+    const int32_t kind = spec->dependent_types[d];
+    if (kindWidth(kind) < 0) {
+      VX_THROW(VX355_EUNSUPPORTED, "payload type " + std::to_string(kind));
+    }
+    h->depCols.push_back(spec->dependent_cols[d]);
+    h->depKinds.push_back(kind);
+    h->usedCols.push_back(spec->dependent_cols[d]);
+  }
+  h->keyVals.resize(h->keyCols.size());
+  h->depVals.resize(h->depCols.size());
+  h->depValid.resize(h->depCols.size());
+  h->obsMin.assign(h->keyCols.size(), INT64_MAX);
+  h->obsMax.assign(h->keyCols.size(), INT64_MIN);
+  *out = h.release();
+  VX_API_END
+}
+
+int vx355_join_build_add_input(vx355_join_build* h, const vx355_batch* batch) {
+  VX_API_BEGIN
+  Runtime::get().requireInit();
+  VX_CHECK_ARG(h && batch, "NULL argument");
+  buildAddInput(*h, batch);
+  VX_API_END
+}
+
+int vx355_join_build_finish(vx355_join_build* h, vx355_join_build* const* others, int32_t num_others,
+                            vx355_join_table** out) {
+  VX_API_BEGIN
+  Runtime::get().requireInit();
+  VX_CHECK_ARG(h && out && num_others >= 0, "bad argument");
+  *out = buildFinish(*h, others, num_others);
+  VX_API_END
+}
+
+void vx355_join_build_destroy(vx355_join_build* h) {
+  std::lock_guard<std::recursive_mutex> lock(vx::apiMutex());
+  delete h;
+}
+
+void vx355_join_table_retain(vx355_join_table* t) {
+  if (t) {
+    t->refs.fetch_add(1);
+  }
+}
+
+void vx355_join_table_release(vx355_join_table* t) {
+  if (t && t->refs.fetch_sub(1) == 1) {
+    std::lock_guard<std::recursive_mutex> lock(vx::apiMutex());
+    delete t;
+  }
+}
+
+int vx355_join_table_get_stats(const vx355_join_table* t, vx355_join_table_stats* out) {
+  VX_API_BEGIN
+  VX_CHECK_ARG(t && out, "NULL argument");
+  out->num_rows = t->numRows;
+  out->num_distinct = t->numDistinct;
+  out->capacity = static_cast<int64_t>(t->capacity);
+  out->hash_mode = t->mode;
+  out->has_duplicates = t->hasDuplicates ? 1 : 0;
+  VX_API_END
+}
+
+int vx355_join_probe_create(vx355_join_table* table, const vx355_join_probe_spec* spec,
+                            vx355_join_probe** out) {
+  VX_API_BEGIN
+  Runtime::get().requireInit();
+  VX_CHECK_ARG(table && spec && out, "NULL argument");
+  VX_CHECK_ARG(spec->num_keys == static_cast<int32_t>(table->keyKinds.size()),
+               "probe and build key counts differ");
+  if (!supportedJoin(spec->join_type) || spec->null_aware) {
+    VX_THROW(VX355_EUNSUPPORTED, "join type " + std::to_string(spec->join_type) + " not on device");
+  }
+  auto p = std::make_unique<vx355_join_probe>();
+  p->table = table;
+  vx355_join_table_retain(table);
+  p->joinType = spec->join_type;
+  p->keyCols.assign(spec->key_cols, spec->key_cols + spec->num_keys);
+  *out = p.release();
+  VX_API_END
+}
+
+int vx355_join_probe_add_input(vx355_join_probe* h, const vx355_batch* batch) {
+  VX_API_BEGIN
+  Runtime::get().requireInit();
+  VX_CHECK_ARG(h && batch, "NULL argument");
+  probeAddInput(*h, batch);
+  VX_API_END
+}
+
+int vx355_join_probe_get_output(vx355_join_probe* h, int32_t max_rows, int32_t* mapping_out,
+                                int32_t* build_rows_out, int32_t out_mem, vx355_out_column* build_cols,
+                                const int32_t* build_col_ids, int32_t num_build_cols, int32_t* n_out,
+                                int32_t* finished) {
+  VX_API_BEGIN
+  Runtime::get().requireInit();
+  VX_CHECK_ARG(h, "NULL argument");
+  probeGetOutput(*h, max_rows, mapping_out, build_rows_out, out_mem, build_cols, build_col_ids,
+                 num_build_cols, n_out, finished);
+  VX_API_END
+}
+
+void vx355_join_probe_destroy(vx355_join_probe* h) {
+  if (!h) {
+    return;
+  }
+  vx355_join_table* t = h->table;
+  {
+    std::lock_guard<std::recursive_mutex> lock(vx::apiMutex());
+    delete h;
+  }
+  vx355_join_table_release(t);
+}
+
+}  // extern "C"

@@ -1,0 +1,456 @@
+// libvx355 runtime: device binding, library stream, pinned mailbox, device
+// memory helpers, batch staging and the HIP-event profiler.
+#include "common.h"
+
+#include <algorithm>
+#include <cstdio>
+
+namespace vx {
+
+namespace {
+thread_local std::string tlsLastError;
+}
+
+void setLastError(const std::string& m) { tlsLastError = m; }
+
+std::recursive_mutex& apiMutex() {
+  static std::recursive_mutex m;
+  return m;
+}
+
+void hipFail(hipError_t e, const char* what, const char* file, int line) {
+  char buf[512];
+  snprintf(buf, sizeof(buf), "HIP error %d (%s) at %s:%d: %s", static_cast<int>(e),
+           hipGetErrorString(e), file, line, what);
+  (void)hipGetLastError();  // clear sticky non-fatal errors
+  VX_THROW(e == hipErrorOutOfMemory ? VX355_ENOMEM : VX355_EINTERNAL, buf);
+}
+
+Runtime& Runtime::get() {
+  static Runtime rt;
+  return rt;
+}
+
+hipEvent_t Runtime::newEvent() {
+  if (!freeEvents.empty()) {
+    hipEvent_t e = freeEvents.back();
+    freeEvents.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  HIP_OK(hipEventCreate(&e));
+  return e;
+}
+
+void Runtime::profBegin(const char* name) {
+  auto& entry = prof[name];
+  hipEvent_t a = newEvent();
+  HIP_OK(hipEventRecord(a, stream));
+  entry.events.emplace_back(a, nullptr);
+}
+
+void Runtime::profEnd(const char* name) {
+  auto& entry = prof[name];
+  hipEvent_t b = newEvent();
+  HIP_OK(hipEventRecord(b, stream));
+  entry.events.back().second = b;
+  ++entry.launches;
+}
+
+void* DevBuf::ensure(size_t bytes, bool preserve, size_t preserveBytes) {
+  if (bytes <= cap_) {
+    return p_;
+  }
+  size_t newCap = std::max<size_t>(bytes, cap_ + cap_ / 2);
+  newCap = (newCap + 255) & ~static_cast<size_t>(255);
+  void* np = nullptr;
+  HIP_OK(hipMalloc(&np, newCap));
+  if (preserve && p_ && preserveBytes) {
+    auto& rt = Runtime::get();
+    HIP_OK(hipMemcpyAsync(np, p_, std::min(preserveBytes, cap_), hipMemcpyDeviceToDevice,
+                          rt.stream));
+    rt.sync();
+  }
+  if (p_) {
+    // The library stream may still reference the old block.
+    Runtime::get().sync();
+    (void)hipFree(p_);
+  }
+  p_ = np;
+  cap_ = newCap;
+  return p_;
+}
+
+void DevBuf::release() {
+  if (p_) {
+    auto& rt = Runtime::get();
+    if (rt.initialized) {
+      (void)hipStreamSynchronize(rt.stream);
+    }
+    (void)hipFree(p_);
+    p_ = nullptr;
+    cap_ = 0;
+  }
+}
+
+int kindWidth(int32_t kind) {
+  switch (kind) {
+    case VX355_BOOLEAN:
+      return 0;
+    case VX355_TINYINT:
+      return 1;
+    case VX355_SMALLINT:
+      return 2;
+    case VX355_INTEGER:
+    case VX355_REAL:
+      return 4;
+    case VX355_BIGINT:
+    case VX355_DOUBLE:
+      return 8;
+    case VX355_VARCHAR:
+    case VX355_VARBINARY:
+    case VX355_TIMESTAMP:
+      return 16;
+    default:
+      return -1;
+  }
+}
+
+int streamGrid(int64_t items, int block, int perThread) {
+  int64_t blocks = ceilDiv(items, static_cast<int64_t>(block) * perThread);
+  int64_t cap = static_cast<int64_t>(Runtime::get().numCUs) * 8;
+  return static_cast<int>(std::max<int64_t>(1, std::min(blocks, cap)));
+}
+
+void copyOut(void* dst, int32_t dstMem, const void* devSrc, size_t bytes) {
+  if (!bytes) {
+    return;
+  }
+  auto& rt = Runtime::get();
+  HIP_OK(hipMemcpyAsync(dst, devSrc, bytes,
+                        dstMem == VX355_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
+                        rt.stream));
+  if (dstMem == VX355_MEM_HOST) {
+    rt.sync();
+  }
+}
+
+void copyIn(void* devDst, const void* src, int32_t srcMem, size_t bytes) {
+  if (!bytes) {
+    return;
+  }
+  auto& rt = Runtime::get();
+  HIP_OK(hipMemcpyAsync(devDst, src, bytes,
+                        srcMem == VX355_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
+                        rt.stream));
+}
+
+const void* DeviceBatch::stage(const void* src, size_t bytes, int32_t mem) {
+  if (!src || mem == VX355_MEM_DEVICE) {
+    return src;
+  }
+  auto buf = std::make_unique<DevBuf>();
+  // Readers may touch up to 16 bytes past the end with vector loads.
+  void* d = buf->ensure(bytes + 64);
+  copyIn(d, src, VX355_MEM_HOST, bytes);
+  staging_.push_back(std::move(buf));
+  return d;
+}
+
+void DeviceBatch::load(const vx355_batch* batch, const std::vector<int32_t>& usedCols) {
+  VX_CHECK_ARG(batch != nullptr, "batch is NULL");
+  VX_CHECK_ARG(batch->num_rows >= 0 && batch->num_cols >= 0, "negative batch size");
+  numRows_ = batch->num_rows;
+  views_.assign(batch->num_cols, ColView{});
+  used_.assign(batch->num_cols, 0);
+  staging_.clear();
+  hostTmp_.clear();
+  for (int32_t c : usedCols) {
+    if (c < 0) {
+      continue;
+    }
+    VX_CHECK_ARG(c < batch->num_cols, "column index out of range");
+    if (used_[c]) {
+      continue;
+    }
+    used_[c] = 1;
+    const vx355_column& col = batch->cols[c];
+    const int width = kindWidth(col.type_kind);
+    if (width < 0) {
+      VX_THROW(VX355_EUNSUPPORTED, "unsupported type kind " + std::to_string(col.type_kind));
+    }
+    VX_CHECK_ARG(col.encoding >= VX355_FLAT && col.encoding <= VX355_DICTIONARY, "bad encoding");
+    int64_t numValues = col.encoding == VX355_FLAT
+        ? numRows_
+        : (col.encoding == VX355_CONSTANT ? 1 : col.base_size);
+    VX_CHECK_ARG(numValues >= 0, "negative base_size");
+    ColView v;
+    v.kind = col.type_kind;
+    v.enc = col.encoding;
+    size_t valueBytes = width == 0 ? static_cast<size_t>(ceilDiv(numValues, 64)) * 8
+                                   : static_cast<size_t>(numValues) * width;
+    if (numValues > 0) {
+      VX_CHECK_ARG(col.values != nullptr, "column values is NULL");
+    }
+    if (col.mem == VX355_MEM_HOST && isString(col.type_kind) && numValues > 0) {
+      // Rewrite pointers of non-inline strings into a device blob.
+      std::vector<char> views(valueBytes);
+      std::memcpy(views.data(), col.values, valueBytes);
+      std::vector<char> blob;
+      std::vector<std::pair<int64_t, size_t>> fix;  // view index -> blob offset
+      for (int64_t i = 0; i < numValues; ++i) {
+        uint32_t size;
+        std::memcpy(&size, views.data() + i * 16, 4);
+        if (size > 12) {
+          const char* p;
+          std::memcpy(&p, views.data() + i * 16 + 8, 8);
+          fix.emplace_back(i, blob.size());
+          blob.insert(blob.end(), p, p + size);
+        }
+      }
+      if (!fix.empty()) {
+        auto buf = std::make_unique<DevBuf>();
+        char* dblob = static_cast<char*>(buf->ensure(blob.size() + 64));
+        copyIn(dblob, blob.data(), VX355_MEM_HOST, blob.size());
+        for (auto& f : fix) {
+          const char* p = dblob + f.second;
+          std::memcpy(views.data() + f.first * 16 + 8, &p, 8);
+        }
+        hostTmp_.push_back(std::move(blob));
+        staging_.push_back(std::move(buf));
+      }
+      hostTmp_.push_back(std::move(views));
+      v.values = stage(hostTmp_.back().data(), valueBytes, VX355_MEM_HOST);
+    } else {
+      v.values = stage(col.values, valueBytes, col.mem);
+    }
+    int64_t nullBits = col.encoding == VX355_CONSTANT ? 1 : numRows_;
+    v.nulls = static_cast<const uint64_t*>(
+        stage(col.nulls, static_cast<size_t>(ceilDiv(nullBits, 64)) * 8, col.mem));
+    if (col.encoding == VX355_DICTIONARY) {
+      if (numRows_ > 0) {
+        VX_CHECK_ARG(col.indices != nullptr, "dictionary column without indices");
+      }
+      v.indices = static_cast<const int32_t*>(
+          stage(col.indices, static_cast<size_t>(numRows_) * 4, col.mem));
+    }
+    views_[c] = v;
+  }
+}
+
+}  // namespace vx
+
+using vx::Runtime;
+
+extern "C" {
+
+int vx355_abi_version(void) { return VX355_ABI_VERSION; }
+
+const char* vx355_last_error(void) { return vx::tlsLastError.c_str(); }
+
+int vx355_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int vx355_init(int device) {
+  VX_API_BEGIN
+  auto& rt = Runtime::get();
+  if (rt.initialized) {
+    if (rt.device != device) {
+      VX_THROW(VX355_EINVAL, "vx355_init: already bound to another device");
+    }
+    return VX355_OK;
+  }
+  int n = 0;
+  HIP_OK(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) {
+    VX_THROW(VX355_EINVAL, "vx355_init: no such device");
+  }
+  HIP_OK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_OK(hipGetDeviceProperties(&prop, device));
+  rt.numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  rt.ldsPerBlock = prop.sharedMemPerBlock;
+  HIP_OK(hipStreamCreateWithFlags(&rt.stream, hipStreamNonBlocking));
+  HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&rt.mail.host), vx::Mailbox::kWords * 8,
+                       hipHostMallocMapped));
+  HIP_OK(hipHostGetDevicePointer(reinterpret_cast<void**>(&rt.mail.dev), rt.mail.host, 0));
+  std::memset(rt.mail.host, 0, vx::Mailbox::kWords * 8);
+  rt.device = device;
+  rt.initialized = true;
+  VX_API_END
+}
+
+void vx355_shutdown(void) {
+  auto& rt = Runtime::get();
+  if (!rt.initialized) {
+    return;
+  }
+  (void)hipStreamSynchronize(rt.stream);
+  for (auto& kv : rt.prof) {
+    for (auto& ev : kv.second.events) {
+      (void)hipEventDestroy(ev.first);
+      if (ev.second) {
+        (void)hipEventDestroy(ev.second);
+      }
+    }
+  }
+  rt.prof.clear();
+  for (auto e : rt.freeEvents) {
+    (void)hipEventDestroy(e);
+  }
+  rt.freeEvents.clear();
+  (void)hipHostFree(rt.mail.host);
+  rt.mail = vx::Mailbox{};
+  (void)hipStreamDestroy(rt.stream);
+  rt.stream = nullptr;
+  rt.initialized = false;
+  rt.device = -1;
+}
+
+void* vx355_device_malloc(size_t bytes) {
+  auto& rt = Runtime::get();
+  if (!rt.initialized) {
+    vx::setLastError("vx355_init has not been called");
+    return nullptr;
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    vx::setLastError(std::string("hipMalloc failed: ") + hipGetErrorString(e));
+    return nullptr;
+  }
+  return p;
+}
+
+void vx355_device_free(void* p) {
+  if (p) {
+    auto& rt = Runtime::get();
+    if (rt.initialized) {
+      (void)hipStreamSynchronize(rt.stream);
+    }
+    (void)hipFree(p);
+  }
+}
+
+int vx355_memcpy_h2d(void* dst, const void* src, size_t bytes) {
+  VX_API_BEGIN
+  auto& rt = Runtime::get();
+  rt.requireInit();
+  if (bytes) {
+    HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, rt.stream));
+    rt.sync();
+  }
+  VX_API_END
+}
+
+int vx355_memcpy_d2h(void* dst, const void* src, size_t bytes) {
+  VX_API_BEGIN
+  auto& rt = Runtime::get();
+  rt.requireInit();
+  if (bytes) {
+    HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, rt.stream));
+    rt.sync();
+  }
+  VX_API_END
+}
+
+int vx355_memset_d(void* dst, int value, size_t bytes) {
+  VX_API_BEGIN
+  auto& rt = Runtime::get();
+  rt.requireInit();
+  if (bytes) {
+    HIP_OK(hipMemsetAsync(dst, value, bytes, rt.stream));
+    rt.sync();
+  }
+  VX_API_END
+}
+
+int vx355_synchronize(void) {
+  VX_API_BEGIN
+  auto& rt = Runtime::get();
+  rt.requireInit();
+  rt.sync();
+  VX_API_END
+}
+
+int vx355_profile_enable(int on) {
+  VX_API_BEGIN
+  auto& rt = Runtime::get();
+  rt.requireInit();
+  rt.sync();
+  rt.profile = on != 0;
+  VX_API_END
+}
+
+namespace {
+void drainProfile(Runtime& rt) {
+  rt.sync();
+  for (auto& kv : rt.prof) {
+    for (auto& ev : kv.second.events) {
+      if (ev.second) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+          kv.second.doneMs += ms;
+        }
+        rt.freeEvents.push_back(ev.second);
+      }
+      rt.freeEvents.push_back(ev.first);
+    }
+    kv.second.events.clear();
+  }
+}
+}  // namespace
+
+int vx355_profile_reset(void) {
+  VX_API_BEGIN
+  auto& rt = Runtime::get();
+  rt.requireInit();
+  drainProfile(rt);
+  rt.prof.clear();
+  VX_API_END
+}
+
+int vx355_profile_get(const char* kernel, double* total_ms, int64_t* launches) {
+  VX_API_BEGIN
+  auto& rt = Runtime::get();
+  rt.requireInit();
+  VX_CHECK_ARG(kernel && total_ms && launches, "NULL argument");
+  drainProfile(rt);
+  auto it = rt.prof.find(kernel);
+  if (it == rt.prof.end()) {
+    *total_ms = 0;
+    *launches = 0;
+  } else {
+    *total_ms = it->second.doneMs;
+    *launches = it->second.launches;
+  }
+  VX_API_END
+}
+
+int vx355_profile_names(char* buf, size_t cap) {
+  VX_API_BEGIN
+  auto& rt = Runtime::get();
+  rt.requireInit();
+  VX_CHECK_ARG(buf && cap > 0, "NULL buffer");
+  std::string s;
+  for (auto& kv : rt.prof) {
+    if (!s.empty()) {
+      s += "\n";
+    }
+    s += kv.first;
+  }
+  if (s.size() + 1 > cap) {
+    s.resize(cap - 1);
+  }
+  std::memcpy(buf, s.c_str(), s.size() + 1);
+  VX_API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,461 @@
+"""Python host side over the C ABI of libvx355 (include/vx355.h).
+
+Mirrors the reference's operator interface for the hot path — HashAggregation
+(exec/HashAggregation.h), HashBuild / HashProbe (exec/HashBuild.h,
+exec/HashProbe.h): addInput / noMoreInput / getOutput — plus the standalone
+VectorHasher / filter-compaction / partition kernels. Every call goes through
+ctypes into the HIP library; there is no CPU fallback: loading fails loudly
+when libvx355.so is missing and init() fails when no GPU is visible.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvx355.so")
+_LIB = None
+
+# Every symbol include/vx355.h declares.
+SYMBOLS = [
+    "vx355_init", "vx355_shutdown", "vx355_abi_version", "vx355_device_count", "vx355_last_error",
+    "vx355_device_malloc", "vx355_device_free", "vx355_memcpy_h2d", "vx355_memcpy_d2h",
+    "vx355_memset_d", "vx355_synchronize", "vx355_profile_enable", "vx355_profile_reset",
+    "vx355_profile_get", "vx355_profile_names", "vx355_hash_columns", "vx355_value_ids",
+    "vx355_filter_compact", "vx355_partition", "vx355_agg_create", "vx355_agg_add_input",
+    "vx355_agg_no_more_input", "vx355_agg_output_types", "vx355_agg_get_output",
+    "vx355_agg_get_stats", "vx355_agg_destroy", "vx355_join_build_create",
+    "vx355_join_build_add_input", "vx355_join_build_finish", "vx355_join_build_destroy",
+    "vx355_join_table_retain", "vx355_join_table_release", "vx355_join_table_get_stats",
+    "vx355_join_probe_create", "vx355_join_probe_add_input", "vx355_join_probe_get_output",
+    "vx355_join_probe_destroy",
+]
+
+
+class Vx355Error(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"vx355 status {status}: {msg}")
+        self.status = status
+
+
+def lib():
+    """Loads libvx355.so. Raises if the HIP extension has not been built: the
+    product path never substitutes a CPU implementation."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -m velox_amd.build or __graft_entry__.build())")
+    L = C.CDLL(LIB_PATH)
+    i32, i64, u64, vp, sz = C.c_int32, C.c_int64, C.c_uint64, C.c_void_p, C.c_size_t
+    P = C.POINTER
+    L.vx355_init.argtypes = [C.c_int]
+    L.vx355_last_error.restype = C.c_char_p
+    L.vx355_device_malloc.restype = vp
+    L.vx355_device_malloc.argtypes = [sz]
+    L.vx355_device_free.argtypes = [vp]
+    L.vx355_memcpy_h2d.argtypes = [vp, vp, sz]
+    L.vx355_memcpy_d2h.argtypes = [vp, vp, sz]
+    L.vx355_memset_d.argtypes = [vp, C.c_int, sz]
+    L.vx355_profile_enable.argtypes = [C.c_int]
+    L.vx355_profile_get.argtypes = [C.c_char_p, P(C.c_double), P(i64)]
+    L.vx355_profile_names.argtypes = [C.c_char_p, sz]
+    L.vx355_hash_columns.argtypes = [P(abi.Batch), P(i32), i32, vp, i32, vp, i32]
+    L.vx355_value_ids.argtypes = [P(abi.Batch), P(i32), P(abi.ValueIdSpec), i32, vp, i32, vp, vp,
+                                  P(i32), i32]
+    L.vx355_filter_compact.argtypes = [vp, vp, vp, i32, vp, P(i32), i32]
+    L.vx355_partition.argtypes = [vp, i32, i32, i32, i32, i32, vp, i32]
+    L.vx355_agg_create.argtypes = [P(abi.AggSpec), P(vp)]
+    L.vx355_agg_add_input.argtypes = [vp, P(abi.Batch)]
+    L.vx355_agg_no_more_input.argtypes = [vp]
+    L.vx355_agg_output_types.argtypes = [vp, P(i32), i32, P(i32)]
+    L.vx355_agg_get_output.argtypes = [vp, P(abi.OutColumn), i32, i32, P(i32), P(i32)]
+    L.vx355_agg_get_stats.argtypes = [vp, P(abi.AggStats)]
+    L.vx355_agg_destroy.argtypes = [vp]
+    L.vx355_agg_destroy.restype = None
+    L.vx355_join_build_create.argtypes = [P(abi.JoinBuildSpec), P(vp)]
+    L.vx355_join_build_add_input.argtypes = [vp, P(abi.Batch)]
+    L.vx355_join_build_finish.argtypes = [vp, P(vp), i32, P(vp)]
+    L.vx355_join_build_destroy.argtypes = [vp]
+    L.vx355_join_build_destroy.restype = None
+    L.vx355_join_table_retain.argtypes = [vp]
+    L.vx355_join_table_retain.restype = None
+    L.vx355_join_table_release.argtypes = [vp]
+    L.vx355_join_table_release.restype = None
+    L.vx355_join_table_get_stats.argtypes = [vp, P(abi.JoinTableStats)]
+    L.vx355_join_probe_create.argtypes = [vp, P(abi.JoinProbeSpec), P(vp)]
+    L.vx355_join_probe_add_input.argtypes = [vp, P(abi.Batch)]
+    L.vx355_join_probe_get_output.argtypes = [vp, i32, vp, vp, i32, P(abi.OutColumn), P(i32), i32,
+                                              P(i32), P(i32)]
+    L.vx355_join_probe_destroy.argtypes = [vp]
+    L.vx355_join_probe_destroy.restype = None
+    _LIB = L
+    return L
+
+
+def _check(status):
+    if status != abi.OK:
+        raise Vx355Error(status, lib().vx355_last_error().decode())
+
+
+def init(device=0):
+    _check(lib().vx355_init(device))
+
+
+def synchronize():
+    _check(lib().vx355_synchronize())
+
+
+# ---- device memory -------------------------------------------------------
+
+class DeviceArray:
+    """A typed HBM buffer owned through vx355_device_malloc."""
+
+    def __init__(self, shape_or_array, dtype=None):
+        if isinstance(shape_or_array, np.ndarray):
+            a = np.ascontiguousarray(shape_or_array)
+            self.dtype, self.shape = a.dtype, a.shape
+            self.nbytes = a.nbytes
+            self.ptr = self._alloc(self.nbytes)
+            if self.nbytes:
+                _check(lib().vx355_memcpy_h2d(self.ptr, a.ctypes.data, self.nbytes))
+        else:
+            self.dtype = np.dtype(dtype)
+            self.shape = (shape_or_array,) if np.isscalar(shape_or_array) else tuple(shape_or_array)
+            self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+            self.ptr = self._alloc(self.nbytes)
+
+    @staticmethod
+    def _alloc(nbytes):
+        p = lib().vx355_device_malloc(max(64, nbytes + 64))
+        if not p:
+            raise Vx355Error(abi.ENOMEM, lib().vx355_last_error().decode())
+        return p
+
+    def zero(self):
+        _check(lib().vx355_memset_d(self.ptr, 0, self.nbytes))
+        return self
+
+    def to_host(self, count=None):
+        out = np.empty(self.shape, dtype=self.dtype)
+        if self.nbytes:
+            _check(lib().vx355_memcpy_d2h(out.ctypes.data, self.ptr, self.nbytes))
+        return out if count is None else out.reshape(-1)[:count]
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            lib().vx355_device_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceColumn:
+    """A decoded vector resident in HBM (vx355_column with mem = DEVICE)."""
+
+    def __init__(self, host_col):
+        self.kind, self.encoding = host_col.kind, host_col.encoding
+        self.num_rows, self.base_size = host_col.num_rows, host_col.base_size
+        if host_col.kind in (abi.VARCHAR, abi.VARBINARY):
+            raw = host_col.values.reshape(-1, 16)
+            sizes = raw[:, 0:4].copy().view(np.uint32).reshape(-1)
+            if (sizes > 12).any():
+                raise ValueError("DeviceColumn: only inline strings (<= 12 bytes)")
+        self.values = DeviceArray(host_col.values)
+        self.nulls = DeviceArray(host_col.nulls) if host_col.nulls is not None else None
+        self.indices = DeviceArray(host_col.indices) if host_col.indices is not None else None
+
+    @classmethod
+    def from_ptr(cls, kind, ptr, num_rows, nulls_ptr=None, encoding=abi.FLAT, indices_ptr=None,
+                 base_size=0):
+        """Aliases memory owned elsewhere (e.g. a torch tensor's data_ptr())."""
+        self = cls.__new__(cls)
+        self.kind, self.encoding, self.num_rows, self.base_size = kind, encoding, num_rows, base_size
+        self.values = self.nulls = self.indices = None
+        self._ptrs = (ptr, nulls_ptr, indices_ptr)
+        return self
+
+    def descriptor(self):
+        c = abi.Column()
+        c.type_kind, c.encoding = self.kind, self.encoding
+        if self.values is None:
+            c.values, c.nulls, c.indices = self._ptrs
+        else:
+            c.values = self.values.ptr
+            c.nulls = self.nulls.ptr if self.nulls is not None else None
+            c.indices = self.indices.ptr if self.indices is not None else None
+        c.base_size = self.base_size if self.encoding == abi.DICTIONARY else 0
+        c.mem = abi.MEM_DEVICE
+        return c
+
+
+def to_device(host_batch):
+    """HostBatch -> HostBatch-like object whose columns live in HBM."""
+    return abi.HostBatch([DeviceColumn(c) for c in host_batch.columns], host_batch.num_rows)
+
+
+# ---- profiling -----------------------------------------------------------
+
+def profile_enable(on=True):
+    _check(lib().vx355_profile_enable(1 if on else 0))
+
+
+def profile_reset():
+    _check(lib().vx355_profile_reset())
+
+
+def profile():
+    """-> {kernel name: (total_ms, launches)} since the last reset."""
+    buf = C.create_string_buffer(1 << 16)
+    _check(lib().vx355_profile_names(buf, len(buf)))
+    out = {}
+    for name in filter(None, buf.value.decode().split("\n")):
+        ms, n = C.c_double(), C.c_int64()
+        _check(lib().vx355_profile_get(name.encode(), C.byref(ms), C.byref(n)))
+        out[name] = (ms.value, n.value)
+    return out
+
+
+# ---- standalone kernels (the parity tests call these and the checker alike) --
+
+def hash_columns(batch, key_cols, rows=None, mix_first=False, out=None):
+    n = batch.num_rows
+    if out is None:
+        out = np.zeros(max(1, n), dtype=np.uint64)
+    bits = abi.pack_bits(rows) if rows is not None else None
+    _check(lib().vx355_hash_columns(batch.ref(), abi.i32_array(key_cols), len(key_cols),
+                                    bits.ctypes.data if bits is not None else None,
+                                    1 if mix_first else 0, out.ctypes.data, abi.MEM_HOST))
+    return out[:n]
+
+
+def value_ids(batch, key_cols, specs, rows=None, lookup=False, result=None):
+    n = batch.num_rows
+    if result is None:
+        result = np.zeros(max(1, n), dtype=np.uint64)
+    bits = abi.pack_bits(rows) if rows is not None else None
+    rows_out = np.zeros(max(1, abi.num_words(n)), dtype=np.uint64)
+    mapped = C.c_int32(1)
+    arr = (abi.ValueIdSpec * max(1, len(specs)))(*[abi.ValueIdSpec(*s) for s in specs])
+    _check(lib().vx355_value_ids(batch.ref(), abi.i32_array(key_cols), arr, len(key_cols),
+                                 bits.ctypes.data if bits is not None else None,
+                                 1 if lookup else 0, result.ctypes.data, rows_out.ctypes.data,
+                                 C.byref(mapped), abi.MEM_HOST))
+    return result[:n], abi.unpack_bits(rows_out, n), bool(mapped.value)
+
+
+def filter_compact(values, nulls=None, rows=None):
+    n = len(values)
+    v = abi.pack_bits(values)
+    nl = abi.pack_bits(nulls) if nulls is not None else None
+    rw = abi.pack_bits(rows) if rows is not None else None
+    out = np.zeros(max(1, n), dtype=np.int32)
+    cnt = C.c_int32()
+    _check(lib().vx355_filter_compact(v.ctypes.data, nl.ctypes.data if nl is not None else None,
+                                      rw.ctypes.data if rw is not None else None, n,
+                                      out.ctypes.data, C.byref(cnt), abi.MEM_HOST))
+    return out[: cnt.value].copy()
+
+
+def filter_compact_device(values_ptr, num_rows, idx_out_ptr, nulls_ptr=None, rows_ptr=None):
+    """All buffers in HBM; returns the number of selected rows."""
+    cnt = C.c_int32()
+    _check(lib().vx355_filter_compact(values_ptr, nulls_ptr, rows_ptr, num_rows, idx_out_ptr,
+                                      C.byref(cnt), abi.MEM_DEVICE))
+    return cnt.value
+
+
+def partition(hashes, kind, num_partitions=0, bit_begin=0, bit_end=0):
+    hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+    out = np.zeros(max(1, len(hashes)), dtype=np.uint32)
+    _check(lib().vx355_partition(hashes.ctypes.data, len(hashes), kind, num_partitions, bit_begin,
+                                 bit_end, out.ctypes.data, abi.MEM_HOST))
+    return out[: len(hashes)]
+
+
+# ---- HashAggregation -------------------------------------------------------
+
+def make_agg_spec(key_cols, key_types, aggs, step, ignore_null_keys=False):
+    """aggs: list of (kind, input_col, input_type[, mask_col[, input_col2]])."""
+    keep = {"kc": abi.i32_array(key_cols), "kt": abi.i32_array(key_types)}
+    fns = (abi.AggFn * max(1, len(aggs)))()
+    for i, a in enumerate(aggs):
+        kind, col, typ = a[0], a[1], a[2]
+        mask = a[3] if len(a) > 3 else -1
+        col2 = a[4] if len(a) > 4 else -1
+        fns[i] = abi.AggFn(kind, col, col2, typ, mask)
+    keep["fns"] = fns
+    spec = abi.AggSpec(len(key_cols), keep["kc"], keep["kt"], len(aggs), fns, step,
+                       1 if ignore_null_keys else 0)
+    keep["spec"] = spec
+    return spec, keep
+
+
+class HashAggregation:
+    """exec::HashAggregation (exec/HashAggregation.h) on the MI355X."""
+
+    def __init__(self, key_cols, key_types, aggs, step=abi.STEP_SINGLE, ignore_null_keys=False):
+        self.spec, self._keep = make_agg_spec(key_cols, key_types, aggs, step, ignore_null_keys)
+        h = C.c_void_p()
+        _check(lib().vx355_agg_create(C.byref(self.spec), C.byref(h)))
+        self.h = h
+        types = (C.c_int32 * 64)()
+        n = C.c_int32()
+        _check(lib().vx355_agg_output_types(self.h, types, 64, C.byref(n)))
+        self.kinds = list(types[: n.value])
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().vx355_agg_destroy(self.h)
+            self.h = None
+
+    def add_input(self, batch):
+        _check(lib().vx355_agg_add_input(self.h, batch.ref()))
+
+    def no_more_input(self):
+        _check(lib().vx355_agg_no_more_input(self.h))
+
+    def get_output(self, max_rows=1024):
+        out = abi.OutBuffers(self.kinds, max_rows)
+        n, fin = C.c_int32(), C.c_int32()
+        _check(lib().vx355_agg_get_output(self.h, out.descs, len(self.kinds), max_rows,
+                                          C.byref(n), C.byref(fin)))
+        return [out.column(i, n.value) for i in range(len(self.kinds))], n.value, bool(fin.value)
+
+    def stats(self):
+        s = abi.AggStats()
+        _check(lib().vx355_agg_get_stats(self.h, C.byref(s)))
+        return s
+
+
+Aggregation = HashAggregation
+
+
+def collect_output(op, max_rows=1024):
+    """Drain get_output: -> list of columns, each (values, valid) concatenated."""
+    cols = None
+    while True:
+        batch, n, fin = op.get_output(max_rows)
+        if cols is None:
+            cols = [([], []) for _ in batch]
+        for i, (vals, valid) in enumerate(batch):
+            cols[i][0].append(vals)
+            cols[i][1].append(valid)
+        if fin:
+            break
+    out = []
+    for vals, valid in cols:
+        if vals and isinstance(vals[0], list):
+            v = [x for part in vals for x in part]
+        else:
+            v = np.concatenate(vals) if vals else np.zeros(0)
+        out.append((v, np.concatenate(valid) if valid else np.zeros(0, bool)))
+    return out
+
+
+# ---- HashBuild / HashProbe ---------------------------------------------------
+
+class HashBuild:
+    """exec::HashBuild (exec/HashBuild.h): one per build Driver."""
+
+    def __init__(self, key_cols, key_types, dep_cols=(), dep_types=(), join_type=abi.JOIN_INNER):
+        self._keep = [abi.i32_array(key_cols), abi.i32_array(key_types), abi.i32_array(dep_cols),
+                      abi.i32_array(dep_types)]
+        self.spec = abi.JoinBuildSpec(len(key_cols), self._keep[0], self._keep[1], len(dep_cols),
+                                      self._keep[2], self._keep[3], join_type, 0)
+        self.dep_types = list(dep_types)
+        h = C.c_void_p()
+        _check(lib().vx355_join_build_create(C.byref(self.spec), C.byref(h)))
+        self.h = h
+
+    def add_input(self, batch):
+        _check(lib().vx355_join_build_add_input(self.h, batch.ref()))
+
+    def finish(self, others=()):
+        arr = (C.c_void_p * max(1, len(others)))(*[o.h for o in others])
+        t = C.c_void_p()
+        _check(lib().vx355_join_build_finish(self.h, arr, len(others), C.byref(t)))
+        return JoinTable(t, self.dep_types)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().vx355_join_build_destroy(self.h)
+            self.h = None
+
+
+JoinBuild = HashBuild
+
+
+class JoinTable:
+    """The finished table HashJoinBridge hands from build to probe."""
+
+    def __init__(self, t, dep_types):
+        self.t = t
+        self.dep_types = dep_types
+
+    def stats(self):
+        s = abi.JoinTableStats()
+        _check(lib().vx355_join_table_get_stats(self.t, C.byref(s)))
+        return s
+
+    def __del__(self):
+        if getattr(self, "t", None):
+            lib().vx355_join_table_release(self.t)
+            self.t = None
+
+
+class HashProbe:
+    """exec::HashProbe (exec/HashProbe.h)."""
+
+    def __init__(self, table, key_cols, join_type=abi.JOIN_INNER):
+        self.table = table
+        self._keep = abi.i32_array(key_cols)
+        self.spec = abi.JoinProbeSpec(len(key_cols), self._keep, join_type, 0)
+        h = C.c_void_p()
+        _check(lib().vx355_join_probe_create(table.t, C.byref(self.spec), C.byref(h)))
+        self.h = h
+
+    def add_input(self, batch):
+        self._batch = batch
+        _check(lib().vx355_join_probe_add_input(self.h, batch.ref()))
+
+    def get_output(self, max_rows=1024, build_col_ids=None):
+        if build_col_ids is None:
+            build_col_ids = list(range(len(self.table.dep_types)))
+        kinds = [self.table.dep_types[i] for i in build_col_ids]
+        out = abi.OutBuffers(kinds, max_rows)
+        mapping = np.zeros(max(1, max_rows), dtype=np.int32)
+        build_rows = np.zeros(max(1, max_rows), dtype=np.int32)
+        n, fin = C.c_int32(), C.c_int32()
+        ids = abi.i32_array(build_col_ids)
+        _check(lib().vx355_join_probe_get_output(self.h, max_rows, mapping.ctypes.data,
+                                                 build_rows.ctypes.data, abi.MEM_HOST, out.descs,
+                                                 ids, len(kinds), C.byref(n), C.byref(fin)))
+        cols = [out.column(i, n.value) for i in range(len(kinds))]
+        return mapping[: n.value].copy(), build_rows[: n.value].copy(), cols, bool(fin.value)
+
+    def get_output_device(self, max_rows, mapping_ptr, build_rows_ptr, out_descs=None,
+                          build_col_ids=()):
+        """Device-resident outputs; -> (n, finished)."""
+        n, fin = C.c_int32(), C.c_int32()
+        ids = abi.i32_array(list(build_col_ids))
+        _check(lib().vx355_join_probe_get_output(self.h, max_rows, mapping_ptr, build_rows_ptr,
+                                                 abi.MEM_DEVICE, out_descs, ids,
+                                                 len(build_col_ids), C.byref(n), C.byref(fin)))
+        return n.value, bool(fin.value)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().vx355_join_probe_destroy(self.h)
+            self.h = None
+
+
+JoinProbe = HashProbe
