@@ -1,0 +1,531 @@
+#!/usr/bin/env python
+"""bench.py — one "step" = one pass of the hot path over one resident batch.
+
+Default workload (BASELINE.json configs[1]): TPC-H Q1 at SF100 — 600 037 902
+synthetic lineitem rows per GPU, resident in HBM in Velox's FlatVector layout
+(two 16-byte StringView key columns, four DOUBLE columns, one DATE column =
+68 B/row) -> FilterProject (l_shipdate <= 1998-09-02; disc_price, charge) ->
+HashAggregation (2 keys, 8 aggregates), exactly the reference's plan
+(exec/tests/utils/TpchQueryBuilder.cpp:203-252). Everything between the
+resident input columns and the final 4-6 group rows on the host is inside the
+timed region.
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Other workloads (not the headline line): --workload c1 | c4 | q3.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from velox_amd import abi, ops  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+SHIP_LO, SHIP_HI = 8036, 10561     # 1992-01-02 .. 1998-12-01, days since epoch
+Q1_CUTOFF = 10471                   # 1998-09-02
+STATUS_DATE = 9298                  # 1995-06-17
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="q1", choices=["q1", "c1", "c4", "q3"])
+    ap.add_argument("--rows", type=int, default=0, help="override the row count (debug)")
+    ap.add_argument("--cpu-sample-rows", type=int, default=16_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def dcol(kind, tensor, indices=None, base_size=0):
+    """torch tensor in HBM -> DeviceColumn aliasing it."""
+    if indices is None:
+        return ops.DeviceColumn.from_ptr(kind, tensor.data_ptr(), tensor.shape[0])
+    return ops.DeviceColumn.from_ptr(kind, tensor.data_ptr(), 0, None, abi.DICTIONARY,
+                                     indices.data_ptr(), base_size)
+
+
+class DevBatch:
+    """vx355_batch over DeviceColumns with an explicit row count."""
+
+    def __init__(self, cols, num_rows):
+        self.cols = cols
+        self.num_rows = num_rows
+        self._descs = (abi.Column * len(cols))(*[c.descriptor() for c in cols])
+        self.batch = abi.Batch(num_rows, len(cols), self._descs)
+
+    def ref(self):
+        return C.byref(self.batch)
+
+
+# ---------------------------------------------------------------- Q1 ----------
+def string_views(torch, codes):
+    """1-char inline StringViews (type/StringView.h:76-77) from byte codes."""
+    sv = torch.zeros((codes.shape[0], 4), dtype=torch.int32, device=codes.device)
+    sv[:, 0] = 1
+    sv[:, 1] = codes
+    return sv
+
+
+def gen_q1(torch, n, device, seed):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+
+    def ri(lo, hi, dtype=torch.int32):
+        return torch.randint(lo, hi, (n,), dtype=dtype, device=device, generator=g)
+    ship = ri(SHIP_LO, SHIP_HI + 1)
+    receipt = ship + ri(1, 31)
+    ra = ri(0, 2)
+    rf = torch.where(receipt > STATUS_DATE, torch.full_like(ship, 78),
+                     torch.where(ra == 1, torch.full_like(ship, 82), torch.full_like(ship, 65)))
+    ls = torch.where(ship > STATUS_DATE, torch.full_like(ship, 79), torch.full_like(ship, 70))
+    del receipt, ra
+    cols = {"rf": string_views(torch, rf), "ls": string_views(torch, ls)}
+    del rf, ls
+    qty = ri(1, 51).to(torch.float64)
+    cols["qty"] = qty
+    cols["ep"] = qty * (ri(90000, 210001).to(torch.float64) / 100.0)
+    cols["disc"] = ri(0, 11).to(torch.float64) / 100.0
+    cols["tax"] = ri(0, 9).to(torch.float64) / 100.0
+    cols["ship"] = ship
+    return cols
+
+
+Q1_TERMS = [(6, abi.CMP_LE, Q1_CUTOFF)]
+Q1_PROJ = [[(3, 1.0, 0.0), (4, -1.0, 1.0)], [(3, 1.0, 0.0), (4, -1.0, 1.0), (5, 1.0, 1.0)]]
+# post-FilterProject columns: 0 rf, 1 ls, 2 qty, 3 ep, 4 disc, 5 disc_price, 6 charge
+Q1_AGGS = [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_SUM, 3, abi.DOUBLE), (abi.AGG_SUM, 5, abi.DOUBLE),
+           (abi.AGG_SUM, 6, abi.DOUBLE), (abi.AGG_AVG, 2, abi.DOUBLE), (abi.AGG_AVG, 3, abi.DOUBLE),
+           (abi.AGG_AVG, 4, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+Q1_KEYS = ([0, 1], [abi.VARCHAR, abi.VARCHAR])
+
+
+class Q1:
+    name = "tpch_q1_sf100"
+    bytes_per_row = 68          # Velox layout of the 7 scanned columns
+    agg_bytes_per_row = 72      # at the HashAggregation boundary: 2 x 16 + 5 x 8
+    dominant = "k_agg_lds"
+
+    def __init__(self, torch, n, device, seed):
+        self.torch, self.n = torch, n
+        self.c = gen_q1(torch, n, device, seed)
+        c = self.c
+        self.scan = DevBatch([dcol(abi.VARCHAR, c["rf"]), dcol(abi.VARCHAR, c["ls"]),
+                              dcol(abi.DOUBLE, c["qty"]), dcol(abi.DOUBLE, c["ep"]),
+                              dcol(abi.DOUBLE, c["disc"]), dcol(abi.DOUBLE, c["tax"]),
+                              dcol(abi.INTEGER, c["ship"])], n)
+        self.idx = torch.empty(n, dtype=torch.int32, device=device)
+        self.dp = torch.empty(n, dtype=torch.float64, device=device)
+        self.charge = torch.empty(n, dtype=torch.float64, device=device)
+        torch.cuda.synchronize()
+
+    def step(self, step_kind=abi.STEP_SINGLE):
+        c, n = self.c, self.n
+        m = ops.filter_project_device(self.scan, Q1_TERMS, Q1_PROJ, self.idx.data_ptr(),
+                                      [self.dp.data_ptr(), self.charge.data_ptr()])
+        batch = DevBatch([dcol(abi.VARCHAR, c["rf"], self.idx, n), dcol(abi.VARCHAR, c["ls"], self.idx, n),
+                          dcol(abi.DOUBLE, c["qty"], self.idx, n), dcol(abi.DOUBLE, c["ep"], self.idx, n),
+                          dcol(abi.DOUBLE, c["disc"], self.idx, n), dcol(abi.DOUBLE, self.dp),
+                          dcol(abi.DOUBLE, self.charge)], m)
+        op = ops.HashAggregation(Q1_KEYS[0], Q1_KEYS[1], Q1_AGGS, step_kind)
+        op.add_input(batch)
+        op.no_more_input()
+        out = ops.collect_output(op, 1024)
+        self.selected = m
+        return out
+
+    def rows_per_step(self):
+        return self.n
+
+    def host_sample(self, rows):
+        rows = min(rows, self.n)
+        c = self.c
+        return {k: c[k][:rows].cpu().numpy() for k in c}
+
+    def cpu_reference(self, sample, oracle):
+        """Velox-algorithm CPU restatement of the same plan on the sample: numpy
+        FilterProject (vectorised C) + oracle HashAggregation, one thread."""
+        t0 = time.perf_counter()
+        sel = np.flatnonzero(sample["ship"] <= Q1_CUTOFF).astype(np.int32)
+        dp = (sample["ep"] * (1 - sample["disc"]))[sel]
+        charge = dp * (1 + sample["tax"][sel])
+        rows = len(sample["ship"])
+
+        def wrap(kind, base):
+            col = abi.HostColumn.__new__(abi.HostColumn)
+            col.kind, col.encoding, col.keep = kind, abi.DICTIONARY, []
+            col.values = np.ascontiguousarray(base)
+            col.base_size, col.indices, col.num_rows = rows, sel, len(sel)
+            col.valid = col.nulls = None
+            return col
+        batch = abi.HostBatch([wrap(abi.VARCHAR, sample["rf"].view(np.uint8).reshape(-1, 16)),
+                               wrap(abi.VARCHAR, sample["ls"].view(np.uint8).reshape(-1, 16)),
+                               wrap(abi.DOUBLE, sample["qty"]), wrap(abi.DOUBLE, sample["ep"]),
+                               wrap(abi.DOUBLE, sample["disc"]), abi.HostColumn(abi.DOUBLE, dp),
+                               abi.HostColumn(abi.DOUBLE, charge)], len(sel))
+        op = oracle.Aggregation(Q1_KEYS[0], Q1_KEYS[1], Q1_AGGS)
+        op.add_input(batch)
+        op.no_more_input()
+        out = oracle.collect_output(op, 1024)
+        return out, time.perf_counter() - t0
+
+
+# ---------------------------------------------------------------- C1 ----------
+class C1:
+    """BASELINE configs[0]: SELECT k, sum(v), count(*) GROUP BY k; 10 M rows, 1 K groups."""
+    name = "c1_groupby_10m_1k"
+    bytes_per_row = 16
+    agg_bytes_per_row = 16
+    dominant = "k_agg_lds"
+    AGGS = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+
+    def __init__(self, torch, n, device, seed):
+        g = torch.Generator(device=device)
+        g.manual_seed(seed)
+        self.n = n
+        self.k = torch.randint(0, 1000, (n,), dtype=torch.int64, device=device, generator=g)
+        self.v = torch.rand(n, dtype=torch.float64, device=device, generator=g)
+        self.batch = DevBatch([dcol(abi.BIGINT, self.k), dcol(abi.DOUBLE, self.v)], n)
+        torch.cuda.synchronize()
+
+    def step(self, step_kind=abi.STEP_SINGLE):
+        op = ops.HashAggregation([0], [abi.BIGINT], self.AGGS, step_kind)
+        op.add_input(self.batch)
+        op.no_more_input()
+        return ops.collect_output(op, 4096)
+
+    def rows_per_step(self):
+        return self.n
+
+    def host_sample(self, rows):
+        rows = min(rows, self.n)
+        return {"k": self.k[:rows].cpu().numpy(), "v": self.v[:rows].cpu().numpy()}
+
+    def cpu_reference(self, sample, oracle):
+        t0 = time.perf_counter()
+        batch = abi.HostBatch([abi.HostColumn(abi.BIGINT, sample["k"]), abi.HostColumn(abi.DOUBLE, sample["v"])])
+        op = oracle.Aggregation([0], [abi.BIGINT], self.AGGS)
+        op.add_input(batch)
+        op.no_more_input()
+        out = oracle.collect_output(op, 4096)
+        return out, time.perf_counter() - t0
+
+
+# ---------------------------------------------------------------- C4 ----------
+class C4(C1):
+    """BASELINE configs[3]: 1 B rows, 100 M distinct BIGINT keys, sum(DOUBLE)."""
+    name = "c4_groupby_1b_100m"
+    bytes_per_row = 40
+    agg_bytes_per_row = 40
+    dominant = "k_agg_global"
+    AGGS = [(abi.AGG_SUM, 1, abi.DOUBLE)]
+
+    def __init__(self, torch, n, device, seed):
+        g = torch.Generator(device=device)
+        g.manual_seed(seed)
+        self.n = n
+        distinct = max(1, n // 10)
+        self.k = torch.randint(0, distinct, (n,), dtype=torch.int64, device=device, generator=g)
+        self.v = torch.rand(n, dtype=torch.float64, device=device, generator=g)
+        self.batch = DevBatch([dcol(abi.BIGINT, self.k), dcol(abi.DOUBLE, self.v)], n)
+        torch.cuda.synchronize()
+
+    def step(self, step_kind=abi.STEP_SINGLE):
+        op = ops.HashAggregation([0], [abi.BIGINT], self.AGGS, step_kind)
+        op.add_input(self.batch)
+        op.no_more_input()
+        # 100 M groups: drain into HBM-resident output buffers, 16 M rows at a time.
+        torch = __import__("torch")
+        cap = 1 << 24
+        if not hasattr(self, "_out"):
+            dev = self.k.device
+            self._out = (torch.empty(cap, dtype=torch.int64, device=dev),
+                         torch.empty(cap, dtype=torch.float64, device=dev),
+                         torch.empty(cap // 64 + 1, dtype=torch.int64, device=dev),
+                         torch.empty(cap // 64 + 1, dtype=torch.int64, device=dev))
+        descs = (abi.OutColumn * 2)()
+        descs[0].type_kind, descs[0].mem = abi.BIGINT, abi.MEM_DEVICE
+        descs[0].values, descs[0].nulls = self._out[0].data_ptr(), self._out[2].data_ptr()
+        descs[1].type_kind, descs[1].mem = abi.DOUBLE, abi.MEM_DEVICE
+        descs[1].values, descs[1].nulls = self._out[1].data_ptr(), self._out[3].data_ptr()
+        total = 0
+        while True:
+            n, fin = C.c_int32(), C.c_int32()
+            ops._check(ops.lib().vx355_agg_get_output(op.h, descs, 2, cap, C.byref(n), C.byref(fin)))
+            total += n.value
+            if fin.value:
+                break
+        self.groups = total
+        return total
+
+    def cpu_reference(self, sample, oracle):
+        t0 = time.perf_counter()
+        batch = abi.HostBatch([abi.HostColumn(abi.BIGINT, sample["k"]), abi.HostColumn(abi.DOUBLE, sample["v"])])
+        op = oracle.Aggregation([0], [abi.BIGINT], self.AGGS)
+        op.add_input(batch)
+        op.no_more_input()
+        n = 0
+        while True:
+            _, got, fin = op.get_output(1 << 20)
+            n += got
+            if fin:
+                break
+        return n, time.perf_counter() - t0
+
+
+# ---------------------------------------------------------------- Q3 ----------
+class Q3:
+    """BASELINE configs[2], join part: orders (filtered) build, lineitem probe —
+    the second, dominant join of TPC-H Q3 (TpchQueryBuilder.cpp:467-558) with
+    TPC-H-shaped keys: 150 M orders with sparse keys (8 of every 32), o_orderdate
+    < 1995-03-15 kept (~48.6 %), then ~20 % survive the customer semi-join ->
+    ~14.6 M build rows; 600 M lineitems, l_shipdate > 1995-03-15 (~54 %) probe."""
+    name = "tpch_q3_sf100_join"
+    bytes_per_row = 24
+    agg_bytes_per_row = 24
+    dominant = "k_join_probe"
+    Q3_DATE = 9204  # 1995-03-15
+
+    def __init__(self, torch, n, device, seed):
+        g = torch.Generator(device=device)
+        g.manual_seed(seed)
+        self.torch, self.n = torch, n
+        n_orders = max(8, n // 4)
+        seq = torch.arange(n_orders, dtype=torch.int64, device=device)
+        okey = (seq // 8) * 32 + (seq % 8)
+        odate = torch.randint(8035, 10440, (n_orders,), dtype=torch.int32, device=device, generator=g)
+        keep = (odate < self.Q3_DATE) & (torch.rand(n_orders, device=device, generator=g) < 0.2)
+        self.bkey = okey[keep].contiguous()
+        self.bdate = odate[keep].contiguous()
+        self.bprio = torch.zeros_like(self.bdate)
+        li = torch.randint(0, n_orders, (n,), dtype=torch.int64, device=device, generator=g)
+        lkey = okey[li]
+        lship = odate[li] + torch.randint(1, 122, (n,), dtype=torch.int32, device=device, generator=g)
+        del li, okey, odate, seq
+        sel = lship > self.Q3_DATE
+        self.pkey = lkey[sel].contiguous()
+        self.probe_rows = int(self.pkey.shape[0])
+        del lkey, lship, sel
+        self.build = DevBatch([dcol(abi.BIGINT, self.bkey), dcol(abi.INTEGER, self.bdate),
+                               dcol(abi.INTEGER, self.bprio)], int(self.bkey.shape[0]))
+        self.probe = DevBatch([dcol(abi.BIGINT, self.pkey)], self.probe_rows)
+        cap = self.probe_rows
+        self.mapping = torch.empty(cap, dtype=torch.int32, device=device)
+        self.brows = torch.empty(cap, dtype=torch.int32, device=device)
+        self.odate_out = torch.empty(cap, dtype=torch.int32, device=device)
+        self.odate_nulls = torch.empty(cap // 64 + 1, dtype=torch.int64, device=device)
+        torch.cuda.synchronize()
+
+    def step(self, step_kind=None):
+        b = ops.HashBuild([0], [abi.BIGINT], [1, 2], [abi.INTEGER, abi.INTEGER], abi.JOIN_INNER)
+        b.add_input(self.build)
+        table = b.finish()
+        p = ops.HashProbe(table, [0], abi.JOIN_INNER)
+        p.add_input(self.probe)
+        descs = (abi.OutColumn * 1)()
+        descs[0].type_kind, descs[0].mem = abi.INTEGER, abi.MEM_DEVICE
+        descs[0].values, descs[0].nulls = self.odate_out.data_ptr(), self.odate_nulls.data_ptr()
+        n, fin = p.get_output_device(self.probe_rows, self.mapping.data_ptr(), self.brows.data_ptr(),
+                                     descs, [0])
+        assert fin
+        self.matches = n
+        self.stats = table.stats()
+        return n
+
+    def rows_per_step(self):
+        return self.probe_rows
+
+    def host_sample(self, rows):
+        rows = min(rows, self.probe_rows)
+        return {"bkey": self.bkey.cpu().numpy(), "bdate": self.bdate.cpu().numpy(),
+                "pkey": self.pkey[:rows].cpu().numpy()}
+
+    def cpu_reference(self, sample, oracle):
+        t0 = time.perf_counter()
+        b = oracle.JoinBuild([0], [abi.BIGINT], [1], [abi.INTEGER], abi.JOIN_INNER)
+        b.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, sample["bkey"]),
+                                   abi.HostColumn(abi.INTEGER, sample["bdate"])]))
+        t = b.finish()
+        p = oracle.JoinProbe(t, [0], abi.JOIN_INNER)
+        total = 0
+        pk = sample["pkey"]
+        for lo in range(0, len(pk), 1 << 20):
+            p.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, pk[lo:lo + (1 << 20)])]))
+            while True:
+                m, r, cols, fin = p.get_output(1 << 20)
+                total += len(m)
+                if fin:
+                    break
+        return total, time.perf_counter() - t0
+
+
+WORKLOADS = {"q1": (Q1, 600_037_902), "c1": (C1, 10_000_000), "c4": (C4, 1_000_000_000),
+             "q3": (Q3, 600_037_902)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    ops.init(local_rank)
+
+    cls, default_rows = WORKLOADS[args.workload]
+    n = args.rows or default_rows
+    wl = cls(torch, n, device, seed=1234 + rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        ops.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def one_step():
+        if world == 1 or args.workload != "q1":
+            return wl.step()
+        # N GPUs: every rank aggregates its own shard (Velox's partial step), the
+        # tiny partial results meet on every rank (RCCL all-gather) and the final
+        # step merges them — the same partial/final split the reference uses
+        # across Drivers (docs/develop/aggregations.rst:24-91).
+        part = wl.step(abi.STEP_PARTIAL)
+        return merge_partials(torch, dist, part, world, device)
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    ops.profile_reset()
+    ops.profile_enable(True)
+    t0 = time.perf_counter()
+    result = None
+    for _ in range(args.steps):
+        result = one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.profile_enable(False)
+    prof = ops.profile()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    rows = wl.rows_per_step() * world * args.steps
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    dom_ms, dom_launches = prof.get(wl.dominant, (0.0, 0))
+    dom_rows = getattr(wl, "selected", wl.rows_per_step()) * args.steps
+    achieved = (wl.agg_bytes_per_row * dom_rows / (dom_ms * 1e-3) / 1e9) if dom_ms > 0 else None
+    out = {
+        "metric": "rows/s + HBM GB/s (rocprof), TPC-H Q1 agg & Q3 join SF100, 1/2/4/8 MI355X",
+        "value": rows / elapsed,
+        "unit": "rows/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": wl.name, "rows_per_gpu": wl.rows_per_step(),
+                   "scan_bytes_per_row": wl.bytes_per_row,
+                   "plan": "FilterProject -> HashAggregation (2 keys, 8 aggregates)"
+                   if args.workload == "q1" else args.workload,
+                   "parallelism": "one process per GPU, row shards; partial/final merge over RCCL"
+                   if world > 1 else "1 GPU"},
+        "pipeline_algorithmic_GBps": wl.bytes_per_row * rows / elapsed / 1e9 / world,
+        "roofline": {
+            "bound": "hbm", "kernel": wl.dominant,
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+            "traffic": None,
+            "algorithmic_bytes_per_row": wl.agg_bytes_per_row,
+            "avg_launch_ms": (dom_ms / dom_launches) if dom_launches else None,
+            "launches": dom_launches,
+        },
+        "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())},
+    }
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+        oracle_lib.lib()
+        sample = wl.host_sample(args.cpu_sample_rows)
+        sample_rows = len(next(iter(sample.values()))) if args.workload != "q3" else len(sample["pkey"])
+        cpu_out, cpu_s = wl.cpu_reference(sample, oracle_lib)
+        out["cpu_baseline"] = {
+            "value": sample_rows / cpu_s, "unit": "rows/s", "cores": 1, "kind": "port",
+            "sample": f"first {sample_rows} rows of the same {wl.name} input, single thread: "
+                      "Velox-algorithm CPU restatement (oracle/) of the same plan"
+                      + (" with numpy FilterProject" if args.workload == "q1" else ""),
+            "host_cores_available": os.cpu_count(),
+        }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def merge_partials(torch, dist, part, world, device):
+    """All-gather the partial Q1 result (<= 64 groups) and run the final step."""
+    ncols = len(part)
+    rows = len(part[0][1])
+    cap = 64
+    buf = torch.zeros((cap, 2 * ncols + 1), dtype=torch.float64, device=device)
+    host = np.zeros((cap, 2 * ncols + 1))
+    host[:rows, 2 * ncols] = 1
+    for c, (vals, valid) in enumerate(part):
+        if isinstance(vals, list):
+            vals = np.array([v[0] if v else 0 for v in vals], dtype=np.float64)
+        host[:rows, 2 * c] = np.asarray(vals, dtype=np.float64)
+        host[:rows, 2 * c + 1] = np.asarray(valid, dtype=np.float64)
+    buf.copy_(torch.from_numpy(host))
+    gathered = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(gathered, buf)
+    allp = torch.cat(gathered).cpu().numpy()
+    allp = allp[allp[:, 2 * ncols] == 1]
+
+    def col(c, kind):
+        vals, valid = allp[:, 2 * c], allp[:, 2 * c + 1] > 0
+        if kind == abi.VARCHAR:
+            return abi.HostColumn(abi.VARCHAR, [bytes([int(v)]) for v in vals], valid)
+        if kind == abi.BIGINT:
+            return abi.HostColumn(abi.BIGINT, vals.astype(np.int64), valid)
+        return abi.HostColumn(abi.DOUBLE, vals, valid)
+    # partial layout: rf, ls, sum x4, (avg sum, avg count) x3, count
+    kinds = [abi.VARCHAR, abi.VARCHAR] + [abi.DOUBLE] * 4 + [abi.DOUBLE, abi.BIGINT] * 3 + [abi.BIGINT]
+    batch = abi.HostBatch([col(c, k) for c, k in enumerate(kinds)])
+    fin_aggs = [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_SUM, 3, abi.DOUBLE), (abi.AGG_SUM, 4, abi.DOUBLE),
+                (abi.AGG_SUM, 5, abi.DOUBLE), (abi.AGG_AVG, 6, abi.DOUBLE, -1, 7),
+                (abi.AGG_AVG, 8, abi.DOUBLE, -1, 9), (abi.AGG_AVG, 10, abi.DOUBLE, -1, 11),
+                (abi.AGG_COUNT_STAR, 12, abi.BIGINT)]
+    op = ops.HashAggregation([0, 1], [abi.VARCHAR, abi.VARCHAR], fin_aggs, abi.STEP_FINAL)
+    op.add_input(batch)
+    op.no_more_input()
+    return ops.collect_output(op, 1024)
+
+
+if __name__ == "__main__":
+    main()

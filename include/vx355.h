@@ -177,8 +177,8 @@ int vx355_value_ids(
 
 /* processFilterResults, flat case (exec/OperatorUtils.cpp:231-257): selected =
  * values & nulls & rows; idx_out receives the ascending row numbers of the set
- * bits (== FilterEvalCtx::selectedIndices), *n_out their count. nulls and rows
- * may be NULL. All buffers live in mem. */
+ * bits (== FilterEvalCtx::selectedIndices), *n_out (a host int) their count.
+ * nulls and rows may be NULL. The bitmaps and idx_out live in mem. */
 int vx355_filter_compact(
     const uint64_t* values,
     const uint64_t* nulls,
@@ -207,6 +207,71 @@ int vx355_partition(
     int32_t bit_end,
     uint32_t* partitions_out,
     int32_t mem);
+
+/* ---- FilterProject for the TPC-H Q1 / Q3 expression class ----------------- */
+
+/* The step immediately upstream of HashAggregation / HashProbe
+ * (exec/FilterProject.cpp:102-275): a conjunction of column-vs-constant
+ * comparisons (nulls fail, like exec/OperatorUtils.cpp:231-257) followed by
+ * projections of the form f0 * f1 * ... with f_i = scale_i * column_i +
+ * offset_i, evaluated left to right in DOUBLE (REAL and integer columns are
+ * widened first). That covers l_shipdate <= DATE c, c_mktsegment = 'BUILDING',
+ * l_extendedprice * (1 - l_discount) * (1 + l_tax) (exec/tests/utils/
+ * TpchQueryBuilder.cpp:203-252,467-558); anything else stays on the CPU
+ * evaluator. */
+typedef enum vx355_cmp {
+  VX355_CMP_EQ = 0,
+  VX355_CMP_NE = 1,
+  VX355_CMP_LT = 2,
+  VX355_CMP_LE = 3,
+  VX355_CMP_GT = 4,
+  VX355_CMP_GE = 5
+} vx355_cmp;
+
+typedef struct vx355_filter_term {
+  int32_t col;        /* batch column */
+  int32_t cmp;        /* vx355_cmp */
+  int32_t const_kind; /* VX355_BIGINT: i64 (any integer-like or DATE column);
+                         VX355_DOUBLE: f64 (REAL / DOUBLE column);
+                         VX355_VARCHAR: str (EQ / NE only, <= 12 bytes) */
+  int32_t str_size;
+  int64_t i64;
+  double f64;
+  char str[16];
+} vx355_filter_term;
+
+typedef struct vx355_factor {
+  int32_t col; /* -1: the factor is the constant 'offset' */
+  int32_t pad;
+  double scale;
+  double offset;
+} vx355_factor;
+
+typedef struct vx355_projection {
+  int32_t num_factors; /* 1..4 */
+  int32_t pad;
+  vx355_factor factors[4];
+} vx355_projection;
+
+/* Evaluates the filter over all rows of 'batch', writes the ascending selected
+ * row numbers to idx_out (capacity num_rows; == FilterEvalCtx::selectedIndices,
+ * the indices FilterProject wraps pass-through columns with,
+ * exec/OperatorUtils.cpp:393-422) and, for each projection j, the DOUBLE
+ * results of the selected rows to proj_out[j] (capacity num_rows, flat) with
+ * validity in proj_nulls_out[j] (may be NULL when no input can be null; a
+ * null input makes the result null). n_terms == 0 selects every row.
+ * idx_out / proj_out / proj_nulls_out live in out_mem; *n_out is a host int. */
+int vx355_filter_project(
+    const vx355_batch* batch,
+    const vx355_filter_term* terms,
+    int32_t n_terms,
+    const vx355_projection* projections,
+    int32_t n_projections,
+    int32_t* idx_out,
+    int32_t* n_out,
+    double* const* proj_out,
+    uint64_t* const* proj_nulls_out,
+    int32_t out_mem);
 
 /* ---- HashAggregation (exec/HashAggregation.h, exec/GroupingSet.h) ------- */
 

@@ -263,7 +263,9 @@ class Aggregation {
         int64_t v = isMin ? limitMax(f.input_type) : limitMin(f.input_type);
         std::memcpy(a, &v, 8);
       } else {
-        double v = isMin ? std::numeric_limits<double>::infinity()
+        // MinMaxAggregateBase.cpp:293-303: min starts at quiet_NaN ("NaN is
+        // considered larger than infinity"), :191-201: max at -infinity.
+        double v = isMin ? std::numeric_limits<double>::quiet_NaN()
                          : -std::numeric_limits<double>::infinity();
         std::memcpy(a, &v, 8);
       }
@@ -860,6 +862,83 @@ int orc_partition(const uint64_t* hashes, int32_t num_rows, int32_t kind, int32_
     }
   }
   return VX355_OK;
+}
+
+// FilterProject::filter + project (exec/FilterProject.cpp:102-275) for
+// conjunctions of column-vs-constant comparisons and products of affine
+// factors; a null input fails a comparison (exec/OperatorUtils.cpp:240-248) and
+// nulls a projection.
+int orc_filter_project(const vx355_batch* batch, const vx355_filter_term* terms, int32_t n_terms,
+                       const vx355_projection* projections, int32_t n_projections, int32_t* idx_out,
+                       int32_t* n_out, double* const* proj_out, uint64_t* const* proj_nulls_out) {
+  ORC_TRY
+  const int32_t n = batch->num_rows;
+  int32_t passed = 0;
+  for (int32_t r = 0; r < n; ++r) {
+    bool ok = true;
+    for (int32_t t = 0; t < n_terms && ok; ++t) {
+      const auto& term = terms[t];
+      Decoded d(&batch->cols[term.col]);
+      if (d.isNull(r)) {
+        ok = false;
+        break;
+      }
+      auto cmp = [&](auto a, auto b) {
+        switch (term.cmp) {
+          case VX355_CMP_EQ:
+            return a == b;
+          case VX355_CMP_NE:
+            return a != b;
+          case VX355_CMP_LT:
+            return a < b;
+          case VX355_CMP_LE:
+            return a <= b;
+          case VX355_CMP_GT:
+            return a > b;
+          default:
+            return a >= b;
+        }
+      };
+      if (term.const_kind == VX355_BIGINT) {
+        ok = cmp(d.int64At(r), term.i64);
+      } else if (term.const_kind == VX355_DOUBLE) {
+        ok = cmp(d.doubleAt(r), term.f64);
+      } else {
+        uint8_t tmp;
+        auto* sv = static_cast<const StringView*>(d.valuePtr(r, &tmp));
+        bool eq = sv->size == static_cast<uint32_t>(term.str_size) &&
+            std::memcmp(sv->data(), term.str, sv->size) == 0;
+        ok = term.cmp == VX355_CMP_EQ ? eq : !eq;
+      }
+    }
+    if (!ok) {
+      continue;
+    }
+    for (int32_t j = 0; j < n_projections; ++j) {
+      const auto& p = projections[j];
+      bool valid = true;
+      double acc = 0;
+      for (int32_t f = 0; f < p.num_factors; ++f) {
+        double v = p.factors[f].offset;
+        if (p.factors[f].col >= 0) {
+          Decoded d(&batch->cols[p.factors[f].col]);
+          if (d.isNull(r)) {
+            valid = false;
+            continue;
+          }
+          v = p.factors[f].scale * d.doubleAt(r) + p.factors[f].offset;
+        }
+        acc = f == 0 ? v : acc * v;
+      }
+      proj_out[j][passed] = valid ? acc : 0.0;
+      if (proj_nulls_out && proj_nulls_out[j]) {
+        setBit(proj_nulls_out[j], passed, valid);
+      }
+    }
+    idx_out[passed++] = r;
+  }
+  *n_out = passed;
+  ORC_CATCH
 }
 
 int orc_agg_create(const vx355_agg_spec* spec, int32_t hash_adaptivity, orc_agg** out) {

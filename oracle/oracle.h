@@ -78,6 +78,12 @@ int orc_filter_compact(const uint64_t* values, const uint64_t* nulls, const uint
 int orc_partition(const uint64_t* hashes, int32_t num_rows, int32_t kind, int32_t num_partitions,
                   int32_t bit_begin, int32_t bit_end, uint32_t* partitions_out);
 
+/* FilterProject for the vx355_filter_project expression class: row-at-a-time
+ * restatement of exec/FilterProject.cpp:102-275 + exec/OperatorUtils.cpp:231-257. */
+int orc_filter_project(const vx355_batch* batch, const vx355_filter_term* terms, int32_t n_terms,
+                       const vx355_projection* projections, int32_t n_projections, int32_t* idx_out,
+                       int32_t* n_out, double* const* proj_out, uint64_t* const* proj_nulls_out);
+
 /* HashAggregation. hash_adaptivity = 0 forces kHash (GroupingSet.cpp:494-496). */
 typedef struct orc_agg orc_agg;
 int orc_agg_create(const vx355_agg_spec* spec, int32_t hash_adaptivity, orc_agg** out);

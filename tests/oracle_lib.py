@@ -65,6 +65,9 @@ def lib():
                                 i32, vp, i32, vp, vp, C.POINTER(i32)]
     L.orc_filter_compact.argtypes = [vp, vp, vp, i32, vp, C.POINTER(i32)]
     L.orc_partition.argtypes = [vp, i32, i32, i32, i32, i32, vp]
+    L.orc_filter_project.argtypes = [C.POINTER(abi.Batch), C.POINTER(abi.FilterTerm), i32,
+                                     C.POINTER(abi.Projection), i32, vp, C.POINTER(i32),
+                                     C.POINTER(vp), C.POINTER(vp)]
     L.orc_agg_create.argtypes = [C.POINTER(abi.AggSpec), i32, C.POINTER(vp)]
     L.orc_agg_add_input.argtypes = [vp, C.POINTER(abi.Batch)]
     L.orc_agg_no_more_input.argtypes = [vp]
@@ -194,6 +197,22 @@ def filter_compact(values, nulls=None, rows=None):
                                     rw.ctypes.data if rw is not None else None, n,
                                     out.ctypes.data, C.byref(cnt)))
     return out[: cnt.value].copy()
+
+
+def filter_project(batch, terms, projs, with_nulls=False):
+    n = batch.num_rows
+    idx = np.zeros(max(1, n), dtype=np.int32)
+    outs = [np.zeros(max(1, n), dtype=np.float64) for _ in projs]
+    nulls = [np.zeros(max(1, abi.num_words(n)), dtype=np.uint64) for _ in projs] if with_nulls else None
+    cnt = C.c_int32()
+    out_ptrs = (C.c_void_p * max(1, len(projs)))(*[o.ctypes.data for o in outs])
+    null_ptrs = (C.c_void_p * max(1, len(projs)))(*[x.ctypes.data for x in nulls]) if with_nulls else None
+    _check(lib().orc_filter_project(batch.ref(), abi.filter_terms(terms), len(terms),
+                                    abi.projections(projs), len(projs), idx.ctypes.data,
+                                    C.byref(cnt), out_ptrs, null_ptrs))
+    m = cnt.value
+    return (idx[:m].copy(), [o[:m].copy() for o in outs],
+            [abi.unpack_bits(x, m) for x in nulls] if with_nulls else None)
 
 
 def partition(hashes, kind, num_partitions=0, bit_begin=0, bit_end=0):

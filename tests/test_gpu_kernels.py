@@ -169,3 +169,34 @@ def test_partition(oracle, vx, kind, kw):
     h[:4] = [0, 1, 2 ** 64 - 1, 2 ** 63]
     assert (oracle.partition(h, kind, **kw) == vx.partition(h, kind, **kw)).all()
     assert len(vx.partition(h[:0], kind, **kw)) == 0
+
+
+def test_filter_project_q1_q3_expressions(oracle, vx):
+    rng = np.random.default_rng(20)
+    n = 200003
+    ship = rng.integers(8036, 10562, n).astype(np.int32)
+    ep = rng.random(n) * 1e5
+    disc = rng.integers(0, 11, n) / 100.0
+    tax = rng.integers(0, 9, n) / 100.0
+    qty = rng.integers(1, 51, n).astype(np.int64)
+    seg = [[b"BUILDING", b"AUTOMOBILE", b"MACHINERY", b"", b"BUILDINGS"][i] for i in rng.integers(0, 5, n)]
+    valid_ship, valid_disc = rng.random(n) > 0.02, rng.random(n) > 0.02
+    b = abi.HostBatch([_col(abi.INTEGER, ship, valid_ship), _col(abi.DOUBLE, ep),
+                       _col(abi.DOUBLE, disc, valid_disc), _col(abi.DOUBLE, tax),
+                       _col(abi.VARCHAR, seg), _col(abi.BIGINT, qty)])
+    q1_proj = [[(1, 1.0, 0.0), (2, -1.0, 1.0)], [(1, 1.0, 0.0), (2, -1.0, 1.0), (3, 1.0, 1.0)],
+               [(5, 2.0, 0.5), (-1, 0.0, 3.0)]]
+    cases = [
+        ([(0, abi.CMP_LE, 10471)], q1_proj),
+        ([(0, abi.CMP_GT, 9204), (4, abi.CMP_EQ, b"BUILDING")], q1_proj[:1]),
+        ([(4, abi.CMP_NE, b"BUILDING"), (1, abi.CMP_LT, 5e4), (5, abi.CMP_GE, 10)], []),
+        ([], q1_proj[:2]),
+        ([(0, abi.CMP_EQ, 1)], q1_proj[:1]),  # nothing passes
+    ]
+    for terms, projs in cases:
+        e_idx, e_out, e_nulls = oracle.filter_project(b, terms, projs, with_nulls=True)
+        g_idx, g_out, g_nulls = vx.filter_project(b, terms, projs, with_nulls=True)
+        assert len(e_idx) == len(g_idx) and (e_idx == g_idx).all()
+        for j in range(len(projs)):
+            assert (e_nulls[j] == g_nulls[j]).all()
+            assert (e_out[j][e_nulls[j]] == g_out[j][g_nulls[j]]).all()  # bit-exact doubles

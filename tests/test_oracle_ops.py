@@ -320,3 +320,36 @@ def test_filter_compact_and_partition(oracle):
         return xxhash.xxh32(struct.pack("<I", rev), seed=0).intdigest()
     want = np.array([local(x) % 5 for x in h], dtype=np.uint32)
     assert (oracle.partition(h, abi.PART_LOCAL_MODULO, 5) == want).all()
+
+
+def test_filter_project_vs_numpy(oracle):
+    """The oracle's FilterProject restatement against straight numpy for the
+    TPC-H Q1 expressions (TpchQueryBuilder.cpp:203-252)."""
+    rng = np.random.default_rng(20)
+    n = 5000
+    ship = rng.integers(8036, 10562, n).astype(np.int32)
+    ep = rng.random(n) * 1e5
+    disc = rng.integers(0, 11, n) / 100.0
+    tax = rng.integers(0, 9, n) / 100.0
+    seg = [[b"BUILDING", b"AUTOMOBILE", b"MACHINERY"][i] for i in rng.integers(0, 3, n)]
+    b = abi.HostBatch([abi.HostColumn(abi.INTEGER, ship), abi.HostColumn(abi.DOUBLE, ep),
+                       abi.HostColumn(abi.DOUBLE, disc), abi.HostColumn(abi.DOUBLE, tax),
+                       abi.HostColumn(abi.VARCHAR, seg)])
+    idx, outs, _ = oracle.filter_project(
+        b, [(0, abi.CMP_LE, 10471), (4, abi.CMP_EQ, b"BUILDING")],
+        [[(1, 1.0, 0.0), (2, -1.0, 1.0)], [(1, 1.0, 0.0), (2, -1.0, 1.0), (3, 1.0, 1.0)]])
+    sel = np.flatnonzero((ship <= 10471) & (np.array(seg) == b"BUILDING"))
+    assert (idx == sel).all()
+    assert (outs[0] == (ep * (1 - disc))[sel]).all()
+    assert (outs[1] == (ep * (1 - disc) * (1 + tax))[sel]).all()
+
+
+def test_min_of_all_nan_group_is_nan(oracle):
+    """MinMaxAggregateBase.cpp:293-303: min starts at quiet_NaN, so a group
+    holding only NaNs keeps NaN; NaN and inf gives inf."""
+    k = np.array([1, 1, 2, 2, 3], dtype=np.int64)
+    v = np.array([np.nan, np.nan, np.nan, np.inf, 1.0])
+    out, _ = _run_agg(oracle, [_int_batch([k, v])], [0], [abi.BIGINT],
+                      [(abi.AGG_MIN, 1, abi.DOUBLE), (abi.AGG_MAX, 1, abi.DOUBLE)])
+    assert math.isnan(out[1][0][0]) and out[1][0][1] == np.inf and out[1][0][2] == 1.0
+    assert math.isnan(out[2][0][0]) and math.isnan(out[2][0][1]) and out[2][0][2] == 1.0

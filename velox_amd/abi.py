@@ -98,6 +98,50 @@ class JoinProbeSpec(C.Structure):
                 ("join_type", C.c_int32), ("null_aware", C.c_int32)]
 
 
+# vx355_cmp
+CMP_EQ, CMP_NE, CMP_LT, CMP_LE, CMP_GT, CMP_GE = range(6)
+
+
+class FilterTerm(C.Structure):
+    _fields_ = [("col", C.c_int32), ("cmp", C.c_int32), ("const_kind", C.c_int32),
+                ("str_size", C.c_int32), ("i64", C.c_int64), ("f64", C.c_double),
+                ("str", C.c_char * 16)]
+
+
+class Factor(C.Structure):
+    _fields_ = [("col", C.c_int32), ("pad", C.c_int32), ("scale", C.c_double),
+                ("offset", C.c_double)]
+
+
+class Projection(C.Structure):
+    _fields_ = [("num_factors", C.c_int32), ("pad", C.c_int32), ("factors", Factor * 4)]
+
+
+def filter_terms(terms):
+    """[(col, cmp, constant)] -> ctypes array; the constant's python type picks
+    const_kind (int -> BIGINT, float -> DOUBLE, bytes -> VARCHAR)."""
+    arr = (FilterTerm * max(1, len(terms)))()
+    for i, (col, cmp_, const) in enumerate(terms):
+        arr[i].col, arr[i].cmp = col, cmp_
+        if isinstance(const, bytes):
+            arr[i].const_kind, arr[i].str_size, arr[i].str = VARCHAR, len(const), const
+        elif isinstance(const, float):
+            arr[i].const_kind, arr[i].f64 = DOUBLE, const
+        else:
+            arr[i].const_kind, arr[i].i64 = BIGINT, int(const)
+    return arr
+
+
+def projections(projs):
+    """[[(col, scale, offset), ...], ...] -> ctypes array; col = -1 for a constant factor."""
+    arr = (Projection * max(1, len(projs)))()
+    for j, factors in enumerate(projs):
+        arr[j].num_factors = len(factors)
+        for f, (col, scale, offset) in enumerate(factors):
+            arr[j].factors[f] = Factor(col, 0, scale, offset)
+    return arr
+
+
 def i32_array(values):
     arr = (C.c_int32 * max(1, len(values)))(*values)
     return arr

@@ -391,25 +391,30 @@ __global__ __launch_bounds__(1024) void k_agg_lds(AggArgs a) {
         if (a.ldsDirect) {
           slot = static_cast<int32_t>(key);
         } else {
-          volatile int32_t* entry = slotOf + key;
-          while (true) {
-            slot = *entry;
-            if (slot >= 0 || slot == kSlotOverflow) {
-              break;
-            }
-            if (slot == kSlotEmpty &&
-                atomicCAS(const_cast<int32_t*>(entry), kSlotEmpty, kSlotPending) == kSlotEmpty) {
-              uint32_t t = atomicAdd(numSlots, 1u);
-              if (t < static_cast<uint32_t>(S)) {
-                slotKey[t] = static_cast<uint32_t>(key);
-                slot = static_cast<int32_t>(t);
+          // Claim protocol without waiting on an exit edge: the winner of the CAS
+          // allocates and publishes the slot INSIDE the loop body, every lane
+          // re-evaluates at the latch. (A `break` after the publish would let
+          // the compiler sink the publish behind the loop and spin the other
+          // lanes of the same wave forever.)
+          int32_t* entry = slotOf + key;
+          slot = kSlotPending;
+          while (slot == kSlotPending) {
+            int32_t s = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (s == kSlotEmpty) {
+              if (atomicCAS(entry, kSlotEmpty, kSlotPending) == kSlotEmpty) {
+                uint32_t t = atomicAdd(numSlots, 1u);
+                if (t < static_cast<uint32_t>(S)) {
+                  slotKey[t] = static_cast<uint32_t>(key);
+                  s = static_cast<int32_t>(t);
+                } else {
+                  s = kSlotOverflow;
+                }
+                __hip_atomic_store(entry, s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
               } else {
-                slot = kSlotOverflow;
+                s = kSlotPending;
               }
-              __threadfence_block();
-              *entry = slot;
-              break;
             }
+            slot = s;
           }
         }
         if (slot >= 0) {

@@ -24,7 +24,7 @@ SYMBOLS = [
     "vx355_device_malloc", "vx355_device_free", "vx355_memcpy_h2d", "vx355_memcpy_d2h",
     "vx355_memset_d", "vx355_synchronize", "vx355_profile_enable", "vx355_profile_reset",
     "vx355_profile_get", "vx355_profile_names", "vx355_hash_columns", "vx355_value_ids",
-    "vx355_filter_compact", "vx355_partition", "vx355_agg_create", "vx355_agg_add_input",
+    "vx355_filter_compact", "vx355_partition", "vx355_filter_project", "vx355_agg_create", "vx355_agg_add_input",
     "vx355_agg_no_more_input", "vx355_agg_output_types", "vx355_agg_get_output",
     "vx355_agg_get_stats", "vx355_agg_destroy", "vx355_join_build_create",
     "vx355_join_build_add_input", "vx355_join_build_finish", "vx355_join_build_destroy",
@@ -69,6 +69,8 @@ def lib():
                                   P(i32), i32]
     L.vx355_filter_compact.argtypes = [vp, vp, vp, i32, vp, P(i32), i32]
     L.vx355_partition.argtypes = [vp, i32, i32, i32, i32, i32, vp, i32]
+    L.vx355_filter_project.argtypes = [P(abi.Batch), P(abi.FilterTerm), i32, P(abi.Projection), i32,
+                                       vp, P(i32), P(vp), P(vp), i32]
     L.vx355_agg_create.argtypes = [P(abi.AggSpec), P(vp)]
     L.vx355_agg_add_input.argtypes = [vp, P(abi.Batch)]
     L.vx355_agg_no_more_input.argtypes = [vp]
@@ -270,6 +272,35 @@ def filter_compact_device(values_ptr, num_rows, idx_out_ptr, nulls_ptr=None, row
     cnt = C.c_int32()
     _check(lib().vx355_filter_compact(values_ptr, nulls_ptr, rows_ptr, num_rows, idx_out_ptr,
                                       C.byref(cnt), abi.MEM_DEVICE))
+    return cnt.value
+
+
+def filter_project(batch, terms, projs, with_nulls=False):
+    """FilterProject on host buffers -> (selected row numbers, [projection values],
+    [projection validity or None])."""
+    n = batch.num_rows
+    idx = np.zeros(max(1, n), dtype=np.int32)
+    outs = [np.zeros(max(1, n), dtype=np.float64) for _ in projs]
+    nulls = [np.zeros(max(1, abi.num_words(n)), dtype=np.uint64) for _ in projs] if with_nulls else None
+    cnt = C.c_int32()
+    out_ptrs = (C.c_void_p * max(1, len(projs)))(*[o.ctypes.data for o in outs])
+    null_ptrs = (C.c_void_p * max(1, len(projs)))(*[x.ctypes.data for x in nulls]) if with_nulls else None
+    _check(lib().vx355_filter_project(batch.ref(), abi.filter_terms(terms), len(terms),
+                                      abi.projections(projs), len(projs), idx.ctypes.data,
+                                      C.byref(cnt), out_ptrs, null_ptrs, abi.MEM_HOST))
+    m = cnt.value
+    return (idx[:m].copy(), [o[:m].copy() for o in outs],
+            [abi.unpack_bits(x, m) for x in nulls] if with_nulls else None)
+
+
+def filter_project_device(batch, terms, projs, idx_ptr, proj_ptrs, null_ptrs=None):
+    """Everything resident in HBM; returns the number of selected rows."""
+    cnt = C.c_int32()
+    out_ptrs = (C.c_void_p * max(1, len(projs)))(*proj_ptrs)
+    nptrs = (C.c_void_p * max(1, len(projs)))(*null_ptrs) if null_ptrs else None
+    _check(lib().vx355_filter_project(batch.ref(), abi.filter_terms(terms), len(terms),
+                                      abi.projections(projs), len(projs), idx_ptr, C.byref(cnt),
+                                      out_ptrs, nptrs, abi.MEM_DEVICE))
     return cnt.value
 
 
