@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--rows", type=int, default=0, help="override the row count (debug)")
     ap.add_argument("--cpu-sample-rows", type=int, default=16_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true",
+                    help="q1: FilterProject and HashAggregation as two operators")
     return ap.parse_args()
 
 
@@ -115,8 +117,17 @@ Q1_KEYS = ([0, 1], [abi.VARCHAR, abi.VARCHAR])
 class Q1:
     name = "tpch_q1_sf100"
     bytes_per_row = 68          # Velox layout of the 7 scanned columns
-    agg_bytes_per_row = 72      # at the HashAggregation boundary: 2 x 16 + 5 x 8
-    dominant = "k_agg_lds"
+    fused = True
+
+    @property
+    def agg_bytes_per_row(self):
+        # fused: the 7 scan columns (68 B); unfused, at the HashAggregation
+        # boundary: 2 x 16 + 5 x 8 = 72 B
+        return 68 if self.fused else 72
+
+    @property
+    def dominant(self):
+        return "k_agg_fast" if self.fused else "k_agg_lds"
 
     def __init__(self, torch, n, device, seed):
         self.torch, self.n = torch, n
@@ -131,7 +142,24 @@ class Q1:
         self.charge = torch.empty(n, dtype=torch.float64, device=device)
         torch.cuda.synchronize()
 
+    FUSED_AGGS = [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_SUM, 3, abi.DOUBLE),
+                  (abi.AGG_SUM, ops.PROJ(0), abi.DOUBLE), (abi.AGG_SUM, ops.PROJ(1), abi.DOUBLE),
+                  (abi.AGG_AVG, 2, abi.DOUBLE), (abi.AGG_AVG, 3, abi.DOUBLE), (abi.AGG_AVG, 4, abi.DOUBLE),
+                  (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+
     def step(self, step_kind=abi.STEP_SINGLE):
+        if self.fused:
+            # One operator: FilterProject fused into HashAggregation
+            # (vx355_agg_set_fused_input); the scan columns are read once.
+            op = ops.HashAggregation(Q1_KEYS[0], Q1_KEYS[1], self.FUSED_AGGS, step_kind)
+            op.set_fused_input(Q1_TERMS, Q1_PROJ)
+            op.add_input(self.scan)
+            op.no_more_input()
+            self.selected = self.n
+            return ops.collect_output(op, 1024)
+        return self.step_unfused(step_kind)
+
+    def step_unfused(self, step_kind=abi.STEP_SINGLE):
         c, n = self.c, self.n
         m = ops.filter_project_device(self.scan, Q1_TERMS, Q1_PROJ, self.idx.data_ptr(),
                                       [self.dp.data_ptr(), self.charge.data_ptr()])
@@ -188,7 +216,7 @@ class C1:
     name = "c1_groupby_10m_1k"
     bytes_per_row = 16
     agg_bytes_per_row = 16
-    dominant = "k_agg_lds"
+    dominant = "k_agg_fast"
     AGGS = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
 
     def __init__(self, torch, n, device, seed):
@@ -394,6 +422,8 @@ def main():
     cls, default_rows = WORKLOADS[args.workload]
     n = args.rows or default_rows
     wl = cls(torch, n, device, seed=1234 + rank)
+    if args.workload == "q1":
+        wl.fused = not args.unfused
 
     def barrier():
         torch.cuda.synchronize()
@@ -453,7 +483,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": wl.name, "rows_per_gpu": wl.rows_per_step(),
                    "scan_bytes_per_row": wl.bytes_per_row,
-                   "plan": "FilterProject -> HashAggregation (2 keys, 8 aggregates)"
+                   "plan": ("fused FilterProject+HashAggregation (2 keys, 8 aggregates)" if wl.fused else
+                            "FilterProject -> HashAggregation (2 keys, 8 aggregates)")
                    if args.workload == "q1" else args.workload,
                    "parallelism": "one process per GPU, row shards; partial/final merge over RCCL"
                    if world > 1 else "1 GPU"},

@@ -317,6 +317,21 @@ typedef struct vx355_agg vx355_agg;
 
 /* HashAggregation::initialize (exec/HashAggregation.cpp:44-130). */
 int vx355_agg_create(const vx355_agg_spec* spec, vx355_agg** out);
+/* Operator fusion FilterProject -> HashAggregation (the adapter replaces both
+ * operators with one, like experimental/cudf/exec/ToCudf.cpp:155-213 does for
+ * its own fusions). After this call the batches handed to vx355_agg_add_input
+ * are the FilterProject INPUT batches: rows failing the filter are skipped and
+ * an aggregate whose input_col is VX355_PROJECTION_COL_BASE + j reads
+ * projection j. Results equal vx355_filter_project followed by
+ * vx355_agg_add_input on its output. Call before the first add_input; raw
+ * steps (partial / single) only; projection inputs are DOUBLE. */
+#define VX355_PROJECTION_COL_BASE (1 << 20)
+int vx355_agg_set_fused_input(
+    vx355_agg* h,
+    const vx355_filter_term* terms,
+    int32_t n_terms,
+    const vx355_projection* projections,
+    int32_t n_projections);
 /* HashAggregation::addInput (:191-236) -> GroupingSet::addInput
  * (exec/GroupingSet.cpp:190-223,288-365). */
 int vx355_agg_add_input(vx355_agg* h, const vx355_batch* batch);

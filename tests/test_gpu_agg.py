@@ -276,3 +276,91 @@ def test_device_resident_input_and_output(oracle, vx):
     exp, _ = run_agg(oracle, [hb], [0], [abi.BIGINT], aggs, max_rows=2048)
     got, gop = run_agg(vx, [vx.to_device(hb)], [0], [abi.BIGINT], aggs, max_rows=2048)
     assert_columns_equal(got, exp, gop.kinds, what="device input")
+
+
+def _q1_scan_batch(rng, n, long_flags=False):
+    flags = [b"A", b"N", b"R"] + ([b"RETURN", b"NONE"] if long_flags else [])
+    rf = [flags[i] for i in rng.integers(0, len(flags), n)]
+    ls = [bytes([c]) for c in rng.choice(list(b"FO"), n)]
+    qty = rng.integers(1, 51, n).astype(np.float64)
+    ep = rng.integers(90000, 10500000, n).astype(np.float64) / 128
+    disc = rng.integers(0, 11, n).astype(np.float64) / 64
+    tax = rng.integers(0, 9, n).astype(np.float64) / 64
+    ship = rng.integers(8036, 10562, n).astype(np.int32)
+    return batch_of([rf, ls, qty, ep, disc, tax, ship]), (rf, ls, qty, ep, disc, tax, ship)
+
+
+Q1_TERMS = [(6, abi.CMP_LE, 10471)]
+Q1_PROJ = [[(3, 1.0, 0.0), (4, -1.0, 1.0)], [(3, 1.0, 0.0), (4, -1.0, 1.0), (5, 1.0, 1.0)]]
+
+
+def _q1_reference(oracle, scan, cols):
+    """FilterProject then HashAggregation on the oracle, the way the reference
+    runs the plan: pass-through columns wrapped in the selected-row dictionary."""
+    rf, ls, qty, ep, disc, tax, ship = cols
+    idx, proj, _ = oracle.filter_project(scan, Q1_TERMS, Q1_PROJ)
+
+    def wrap(kind, base):
+        return abi.HostColumn(kind, base, encoding=abi.DICTIONARY, indices=idx)
+    b = abi.HostBatch([wrap(abi.VARCHAR, rf), wrap(abi.VARCHAR, ls), wrap(abi.DOUBLE, qty),
+                       wrap(abi.DOUBLE, ep), wrap(abi.DOUBLE, disc), abi.HostColumn(abi.DOUBLE, proj[0]),
+                       abi.HostColumn(abi.DOUBLE, proj[1])], len(idx))
+    aggs = [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_SUM, 3, abi.DOUBLE), (abi.AGG_SUM, 5, abi.DOUBLE),
+            (abi.AGG_SUM, 6, abi.DOUBLE), (abi.AGG_AVG, 2, abi.DOUBLE), (abi.AGG_AVG, 3, abi.DOUBLE),
+            (abi.AGG_AVG, 4, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    return run_agg(oracle, [b], [0, 1], [abi.VARCHAR, abi.VARCHAR], aggs)[0]
+
+
+@pytest.mark.parametrize("device_resident,long_flags,no_fast", [(False, False, False), (True, False, False),
+                                                                 (True, True, False), (True, False, True)])
+def test_fused_filter_project_aggregation_q1(oracle, vx, device_resident, long_flags, no_fast, monkeypatch):
+    """vx355_agg_set_fused_input: the fused operator must equal FilterProject
+    followed by HashAggregation. Exactly representable inputs -> bit-exact sums.
+    Device-resident flat columns take the fast LDS kernel; 5/6-byte flags make
+    the range too wide for LDS: the same plan then runs on the HBM table."""
+    if no_fast:
+        monkeypatch.setenv("VX355_AGG_NO_FAST", "1")
+    rng = np.random.default_rng(77)
+    n = 300000
+    scan, cols = _q1_scan_batch(rng, n, long_flags)
+    exp = _q1_reference(oracle, scan, cols)
+    P = vx.PROJ
+    aggs = [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_SUM, 3, abi.DOUBLE), (abi.AGG_SUM, P(0), abi.DOUBLE),
+            (abi.AGG_SUM, P(1), abi.DOUBLE), (abi.AGG_AVG, 2, abi.DOUBLE), (abi.AGG_AVG, 3, abi.DOUBLE),
+            (abi.AGG_AVG, 4, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    op = vx.Aggregation([0, 1], [abi.VARCHAR, abi.VARCHAR], aggs)
+    op.set_fused_input(Q1_TERMS, Q1_PROJ)
+    vx.profile_reset()
+    vx.profile_enable(True)
+    inp = vx.to_device(scan) if device_resident else scan
+    op.add_input(inp)
+    op.no_more_input()
+    got = vx.collect_output(op, 100)
+    vx.profile_enable(False)
+    names = vx.profile()
+    assert_columns_equal(got, exp, op.kinds, what="fused q1")
+    # 6-byte flags blow the key range past the LDS limit: open addressing in HBM.
+    if device_resident and not no_fast and not long_flags:
+        assert "k_agg_fast" in names
+    else:
+        assert "k_agg_fast" not in names
+
+
+def test_c1_device_resident_takes_fast_kernel(oracle, vx):
+    rng = np.random.default_rng(78)
+    n = 1 << 20
+    k = rng.integers(0, 1000, n).astype(np.int64)
+    v = _dyadic(rng, n)
+    hb = batch_of([k, v])
+    aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    exp, _ = run_agg(oracle, [hb], [0], [abi.BIGINT], aggs, max_rows=2048)
+    vx.profile_reset()
+    vx.profile_enable(True)
+    db = vx.to_device(hb)
+    got, gop = run_agg(vx, [db, db], [0], [abi.BIGINT], aggs, max_rows=2048)
+    vx.profile_enable(False)
+    assert "k_agg_fast" in vx.profile()
+    # two passes over the same batch: sums and counts double exactly
+    assert (np.asarray(got[1][0]) == 2 * np.asarray(exp[1][0])).all()
+    assert (np.asarray(got[2][0]) == 2 * np.asarray(exp[2][0])).all()
+    assert (got[0][0] == exp[0][0]).all()

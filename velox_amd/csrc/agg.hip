@@ -26,6 +26,7 @@
 //    reproduced by recording the minimum global input row per group and
 //    sorting groups by it at output time.
 #include "common.h"
+#include "expr_device.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -35,11 +36,14 @@ namespace vx {
 
 void sortPairsU64U32(uint64_t* keys, uint32_t* vals, uint64_t* keysTmp, uint32_t* valsTmp,
                      size_t n, DevBuf& tmp, bool* resultInTmp);
+void makeTermArgs(const DeviceBatch& db, const vx355_filter_term* terms, int32_t n, TermArg* out);
+void makeProjectionArgs(const DeviceBatch& db, const vx355_projection* proj, int32_t n,
+                        ProjectionArg* out);
 
 namespace {
 
 constexpr int kMaxKeys = 8;
-constexpr int kMaxAccs = 20;
+constexpr int kMaxAccs = 16;
 constexpr uint64_t kEmpty = ~0ULL;
 constexpr uint64_t kNoRow = ~0ULL;
 
@@ -67,7 +71,7 @@ struct AccArg {
   int32_t hasMask;
   int32_t inIsInt;  // value travels as int64 (else double)
   int32_t off;      // word offset inside the group row
-  int32_t pad;
+  int32_t inProj;   // >= 0: the input is projection inProj of the fused FilterProject
 };
 
 // Counters the kernels bump; mirrored into the pinned mailbox by the host.
@@ -100,6 +104,12 @@ struct AggArgs {
   uint64_t capacity;    // group rows in table (array: range product; hash: power of two)
   int32_t* deferred;
   Counters* counters;
+  // Fused FilterProject (vx355_agg_set_fused_input): rows failing the filter
+  // are skipped, projections feed accumulators directly from the scan columns.
+  TermArg terms[kMaxTerms];
+  ProjectionArg proj[kMaxProjections];
+  int32_t numTerms;
+  int32_t numProj;
 };
 
 __device__ inline bool predicate(const AccArg& a, int64_t row) {
@@ -136,6 +146,40 @@ __device__ inline uint64_t operand(const AccArg& a, int64_t row) {
       }
       return doubleToOrdered(loadDouble(a.in, colIndex(a.in, row)));
   }
+}
+
+// Predicate and operand of one accumulator for one row in a single call;
+// projections are evaluated from the scan columns.
+__device__ inline bool accInput(const AggArgs& a, const AccArg& acc, int64_t row, uint64_t* out) {
+  if (acc.inProj < 0) {
+    if (!predicate(acc, row)) {
+      return false;
+    }
+    *out = operand(acc, row);
+    return true;
+  }
+  AccArg maskOnly = acc;
+  maskOnly.hasIn = 0;
+  if (acc.hasMask && !predicate(maskOnly, row)) {
+    return false;
+  }
+  bool valid = true;
+  const double d = evalProjection(a.proj[acc.inProj], row, &valid);
+  if (!valid) {
+    return false;
+  }
+  switch (acc.kind) {
+    case ACC_COUNT:
+      *out = 1;
+      break;
+    case ACC_SUM_F64:
+      *out = static_cast<uint64_t>(__double_as_longlong(d));
+      break;
+    default:
+      *out = doubleToOrdered(d);
+      break;
+  }
+  return true;
 }
 
 __device__ inline bool addOverflows(int64_t old, int64_t v) {
@@ -296,8 +340,9 @@ __device__ inline void updateGlobal(const AggArgs& a, int64_t row, uint64_t key,
   }
   for (int i = 0; i < a.numAccs; ++i) {
     const AccArg& acc = a.accs[i];
-    if (predicate(acc, row)) {
-      applyGlobal(g + acc.off, acc.kind, operand(acc, row), a.counters);
+    uint64_t v;
+    if (accInput(a, acc, row, &v)) {
+      applyGlobal(g + acc.off, acc.kind, v, a.counters);
     }
   }
 }
@@ -325,7 +370,7 @@ __global__ __launch_bounds__(256) void k_agg_global(AggArgs a) {
     if (i < a.numRows) {
       row = a.rowList ? a.rowList[i] : static_cast<int32_t>(i);
       uint64_t key;
-      int st = normalizedKey(a, row, &key);
+      int st = (a.numTerms && !evalFilter(a.terms, a.numTerms, row)) ? 1 : normalizedKey(a, row, &key);
       if (st == 0) {
         updateGlobal(a, row, key, &newGroups);
       } else if (st == 2) {
@@ -337,41 +382,175 @@ __global__ __launch_bounds__(256) void k_agg_global(AggArgs a) {
   addNewGroups(a.counters, newGroups);
 }
 
-// ---- low-cardinality kernel: LDS-resident, lane-replicated accumulators -----
+// ---- low-cardinality kernels: LDS-resident, lane-replicated accumulators ----
 // LDS layout: [slotOf int32[capacity] unless direct][slotKey u32[S]][slotFirst u32[S]]
 //             [numSlots u32][pad][acc u64[S][numAccs][REP]]
 constexpr int32_t kSlotEmpty = -1;
 constexpr int32_t kSlotPending = -2;
 constexpr int32_t kSlotOverflow = -3;
 
-__global__ __launch_bounds__(1024) void k_agg_lds(AggArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
-  const int S = a.ldsSlots;
-  const int REP = a.ldsRep;
-  const int A = a.numAccs;
-  int32_t* slotOf = reinterpret_cast<int32_t*>(ldsRaw);
-  const int mapWords = a.ldsDirect ? 0 : static_cast<int>(a.capacity);
-  uint32_t* slotKey = reinterpret_cast<uint32_t*>(ldsRaw) + mapWords;
-  uint32_t* slotFirst = slotKey + S;
-  uint32_t* numSlots = slotFirst + S;
-  uint64_t* acc = reinterpret_cast<uint64_t*>(
-      ldsRaw + ((static_cast<size_t>(mapWords + 2 * S + 2) * 4 + 15) & ~static_cast<size_t>(15)));
+// What both LDS kernels need to know about the accumulators and the table.
+struct LdsPlan {
+  int32_t S;
+  int32_t REP;
+  int32_t A;
+  int32_t direct;
+  uint64_t capacity;
+  uint64_t* table;
+  int32_t stride;
+  int32_t pad;
+  uint64_t rowBase;
+  Counters* counters;
+  int32_t kind[kMaxAccs];
+  int32_t off[kMaxAccs];
+};
 
+struct LdsState {
+  int32_t* slotOf;
+  uint32_t* slotKey;
+  uint32_t* slotFirst;
+  uint32_t* numSlots;
+  uint64_t* acc;
+};
+
+__device__ inline LdsState ldsInit(const LdsPlan& p, unsigned char* raw) {
+  LdsState st;
+  const int mapWords = p.direct ? 0 : static_cast<int>(p.capacity);
+  st.slotOf = reinterpret_cast<int32_t*>(raw);
+  st.slotKey = reinterpret_cast<uint32_t*>(raw) + mapWords;
+  st.slotFirst = st.slotKey + p.S;
+  st.numSlots = st.slotFirst + p.S;
+  st.acc = reinterpret_cast<uint64_t*>(
+      raw + ((static_cast<size_t>(mapWords + 2 * p.S + 2) * 4 + 15) & ~static_cast<size_t>(15)));
   for (int i = threadIdx.x; i < mapWords; i += blockDim.x) {
-    slotOf[i] = kSlotEmpty;
+    st.slotOf[i] = kSlotEmpty;
   }
-  for (int i = threadIdx.x; i < S; i += blockDim.x) {
-    slotFirst[i] = 0xffffffffu;
-    slotKey[i] = static_cast<uint32_t>(i);
+  for (int i = threadIdx.x; i < p.S; i += blockDim.x) {
+    st.slotFirst[i] = 0xffffffffu;
+    st.slotKey[i] = static_cast<uint32_t>(i);
   }
   if (threadIdx.x == 0) {
-    *numSlots = a.ldsDirect ? static_cast<uint32_t>(S) : 0;
+    *st.numSlots = p.direct ? static_cast<uint32_t>(p.S) : 0;
   }
-  for (int i = threadIdx.x; i < S * A * REP; i += blockDim.x) {
-    acc[i] = accIdentity(a.accs[(i / REP) % A].kind);
+  for (int i = threadIdx.x; i < p.S * p.A * p.REP; i += blockDim.x) {
+    st.acc[i] = accIdentity(p.kind[(i / p.REP) % p.A]);
   }
   __syncthreads();
+  return st;
+}
 
+// LDS slot of a key (>= 0) or kSlotOverflow when the workgroup's slots are used up.
+__device__ inline int32_t ldsSlot(const LdsPlan& p, const LdsState& st, uint64_t key) {
+  if (p.direct) {
+    return static_cast<int32_t>(key);
+  }
+  // Claim protocol without waiting on an exit edge: the winner of the CAS
+  // allocates and publishes the slot INSIDE the loop body, every lane
+  // re-evaluates at the latch. (A `break` after the publish would let the
+  // compiler sink the publish behind the loop and spin the other lanes of the
+  // same wave forever.)
+  int32_t* entry = st.slotOf + key;
+  int32_t slot = kSlotPending;
+  while (slot == kSlotPending) {
+    int32_t s = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (s == kSlotEmpty) {
+      if (atomicCAS(entry, kSlotEmpty, kSlotPending) == kSlotEmpty) {
+        uint32_t t = atomicAdd(st.numSlots, 1u);
+        if (t < static_cast<uint32_t>(p.S)) {
+          st.slotKey[t] = static_cast<uint32_t>(key);
+          s = static_cast<int32_t>(t);
+        } else {
+          s = kSlotOverflow;
+        }
+        __hip_atomic_store(entry, s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+        s = kSlotPending;
+      }
+    }
+    slot = s;
+  }
+  return slot;
+}
+
+__device__ inline void ldsTouchFirst(const LdsState& st, int32_t slot, uint32_t row) {
+  if (st.slotFirst[slot] > row) {
+    atomicMin(&st.slotFirst[slot], row);
+  }
+}
+
+// Flush: one (slot, accumulator) pair per thread; replicas reduced in LDS.
+__device__ inline void ldsFlush(const LdsPlan& p, const LdsState& st) {
+  __syncthreads();
+  const int S = p.S, A = p.A, REP = p.REP;
+  uint32_t live = *st.numSlots;
+  if (live > static_cast<uint32_t>(S)) {
+    live = S;
+  }
+  for (int t = threadIdx.x; t < static_cast<int>(live) * (A + 1); t += blockDim.x) {
+    const int slot = t / (A + 1);
+    const int j = t % (A + 1);
+    const uint32_t first = st.slotFirst[slot];
+    if (first == 0xffffffffu) {
+      continue;  // direct layout: key never seen by this workgroup
+    }
+    uint64_t* g = p.table + static_cast<uint64_t>(st.slotKey[slot]) * p.stride;
+    if (j == A) {
+      // 'first' is the smallest ORIGINAL row of the chunk seen for this key
+      // (replays go through the row list), so it decides the group order.
+      uint64_t firstRow = p.rowBase + static_cast<uint64_t>(first);
+      unsigned long long old = atomicMin(reinterpret_cast<unsigned long long*>(g + 1), firstRow);
+      if (old == kNoRow) {
+        atomicAdd(&p.counters->numNewGroups, 1u);
+      }
+      continue;
+    }
+    const int32_t kind = p.kind[j];
+    const uint64_t* q = st.acc + (static_cast<size_t>(slot) * A + j) * REP;
+    uint64_t v = q[0];
+    if (kind == ACC_SUM_F64) {
+      double s = __longlong_as_double(static_cast<long long>(v));
+      for (int r = 1; r < REP; ++r) {
+        s += __longlong_as_double(static_cast<long long>(q[r]));
+      }
+      applyGlobal(g + p.off[j], ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(s)), p.counters);
+    } else if (kind == ACC_MIN) {
+      for (int r = 1; r < REP; ++r) {
+        v = q[r] < v ? q[r] : v;
+      }
+      applyGlobal(g + p.off[j], ACC_MIN, v, p.counters);
+    } else if (kind == ACC_MAX) {
+      for (int r = 1; r < REP; ++r) {
+        v = q[r] > v ? q[r] : v;
+      }
+      applyGlobal(g + p.off[j], ACC_MAX, v, p.counters);
+    } else {
+      int64_t s = static_cast<int64_t>(v);
+      for (int r = 1; r < REP; ++r) {
+        int64_t x = static_cast<int64_t>(q[r]);
+        if (kind == ACC_SUM_I64 && addOverflows(s, x)) {
+          p.counters->overflow = 1;
+        }
+        s = static_cast<int64_t>(static_cast<uint64_t>(s) + static_cast<uint64_t>(x));
+      }
+      applyGlobal(g + p.off[j], kind == ACC_COUNT ? ACC_SUM_I64_WRAP : kind, static_cast<uint64_t>(s),
+                  p.counters);
+    }
+  }
+}
+
+struct LdsArgs {
+  AggArgs a;
+  LdsPlan plan;
+};
+static_assert(sizeof(LdsArgs) <= 4096, "kernel arguments are limited to 4 KB");
+
+// Generic LDS kernel: any column encoding / type / mask the ABI admits.
+__global__ __launch_bounds__(1024) void k_agg_lds(LdsArgs args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+  const AggArgs& a = args.a;
+  const LdsPlan& p = args.plan;
+  const LdsState st = ldsInit(p, ldsRaw);
+  const int A = p.A, REP = p.REP;
   const int rep = lane() & (REP - 1);
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   const int64_t rounds = (a.numRows + stride - 1) / stride;
@@ -383,49 +562,19 @@ __global__ __launch_bounds__(1024) void k_agg_lds(AggArgs a) {
     if (i < a.numRows) {
       row = a.rowList ? a.rowList[i] : static_cast<int32_t>(i);
       uint64_t key;
-      int st = normalizedKey(a, row, &key);
-      if (st == 2) {
+      int state = (a.numTerms && !evalFilter(a.terms, a.numTerms, row)) ? 1 : normalizedKey(a, row, &key);
+      if (state == 2) {
         defer = true;
-      } else if (st == 0) {
-        int32_t slot;
-        if (a.ldsDirect) {
-          slot = static_cast<int32_t>(key);
-        } else {
-          // Claim protocol without waiting on an exit edge: the winner of the CAS
-          // allocates and publishes the slot INSIDE the loop body, every lane
-          // re-evaluates at the latch. (A `break` after the publish would let
-          // the compiler sink the publish behind the loop and spin the other
-          // lanes of the same wave forever.)
-          int32_t* entry = slotOf + key;
-          slot = kSlotPending;
-          while (slot == kSlotPending) {
-            int32_t s = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (s == kSlotEmpty) {
-              if (atomicCAS(entry, kSlotEmpty, kSlotPending) == kSlotEmpty) {
-                uint32_t t = atomicAdd(numSlots, 1u);
-                if (t < static_cast<uint32_t>(S)) {
-                  slotKey[t] = static_cast<uint32_t>(key);
-                  s = static_cast<int32_t>(t);
-                } else {
-                  s = kSlotOverflow;
-                }
-                __hip_atomic_store(entry, s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-              } else {
-                s = kSlotPending;
-              }
-            }
-            slot = s;
-          }
-        }
+      } else if (state == 0) {
+        const int32_t slot = ldsSlot(p, st, key);
         if (slot >= 0) {
-          if (slotFirst[slot] > static_cast<uint32_t>(row)) {
-            atomicMin(&slotFirst[slot], static_cast<uint32_t>(row));
-          }
-          uint64_t* base = acc + (static_cast<size_t>(slot) * A) * REP + rep;
+          ldsTouchFirst(st, slot, static_cast<uint32_t>(row));
+          uint64_t* base = st.acc + (static_cast<size_t>(slot) * A) * REP + rep;
           for (int j = 0; j < A; ++j) {
             const AccArg& ac = a.accs[j];
-            if (predicate(ac, row)) {
-              applyLds(base + j * REP, ac.kind, operand(ac, row), a.counters);
+            uint64_t v;
+            if (accInput(a, ac, row, &v)) {
+              applyLds(base + j * REP, ac.kind, v, a.counters);
             }
           }
         } else {
@@ -435,70 +584,247 @@ __global__ __launch_bounds__(1024) void k_agg_lds(AggArgs a) {
     }
     deferRow(a, defer, row);
   }
-  __syncthreads();
-
-  // Flush: one (slot, accumulator) pair per thread; replicas reduced in LDS.
-  uint32_t live = *numSlots;
-  if (live > static_cast<uint32_t>(S)) {
-    live = S;
-  }
-  for (int t = threadIdx.x; t < static_cast<int>(live) * (A + 1); t += blockDim.x) {
-    const int slot = t / (A + 1);
-    const int j = t % (A + 1);
-    const uint32_t first = slotFirst[slot];
-    if (first == 0xffffffffu) {
-      continue;  // direct layout: key never seen by this workgroup
-    }
-    uint64_t* g = a.table + static_cast<uint64_t>(slotKey[slot]) * a.stride;
-    if (j == A) {
-      // 'first' is the smallest ORIGINAL row of the chunk seen for this key
-      // (replays go through the row list), so it decides the group order.
-      uint64_t firstRow = a.rowBase + static_cast<uint64_t>(first);
-      unsigned long long old = atomicMin(reinterpret_cast<unsigned long long*>(g + 1), firstRow);
-      if (old == kNoRow) {
-        atomicAdd(&a.counters->numNewGroups, 1u);
-      }
-      continue;
-    }
-    const AccArg& ac = a.accs[j];
-    const uint64_t* p = acc + (static_cast<size_t>(slot) * A + j) * REP;
-    uint64_t v = p[0];
-    if (ac.kind == ACC_SUM_F64) {
-      double s = __longlong_as_double(static_cast<long long>(v));
-      for (int q = 1; q < REP; ++q) {
-        s += __longlong_as_double(static_cast<long long>(p[q]));
-      }
-      if (s != 0.0) {
-        applyGlobal(g + ac.off, ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(s)), a.counters);
-      } else {
-        // Adding +/-0.0 keeps the accumulator unless it is -0.0; the
-        // reference would produce +0.0 from 0.0 + -0.0 as well.
-        applyGlobal(g + ac.off, ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(s)), a.counters);
-      }
-    } else if (ac.kind == ACC_MIN) {
-      for (int q = 1; q < REP; ++q) {
-        v = p[q] < v ? p[q] : v;
-      }
-      applyGlobal(g + ac.off, ACC_MIN, v, a.counters);
-    } else if (ac.kind == ACC_MAX) {
-      for (int q = 1; q < REP; ++q) {
-        v = p[q] > v ? p[q] : v;
-      }
-      applyGlobal(g + ac.off, ACC_MAX, v, a.counters);
-    } else {
-      int64_t s = static_cast<int64_t>(v);
-      for (int q = 1; q < REP; ++q) {
-        int64_t x = static_cast<int64_t>(p[q]);
-        if (ac.kind == ACC_SUM_I64 && addOverflows(s, x)) {
-          a.counters->overflow = 1;
-        }
-        s = static_cast<int64_t>(static_cast<uint64_t>(s) + static_cast<uint64_t>(x));
-      }
-      applyGlobal(g + ac.off, ac.kind == ACC_COUNT ? ACC_SUM_I64_WRAP : ac.kind,
-                  static_cast<uint64_t>(s), a.counters);
-    }
-  }
+  ldsFlush(p, st);
   addNewGroups(a.counters, newGroups);
+}
+
+// ---- fast LDS kernel: the TPC-H Q1 / BASELINE config-1 plan shape --------------
+// Flat, null-free columns only: <= 2 keys (1..7-byte strings read as the first
+// 8 bytes of their StringView, INTEGER or BIGINT), <= 2 filter terms on
+// INTEGER / BIGINT / DOUBLE columns, <= 8 DOUBLE columns feeding sum(column),
+// sum(product of affine factors) and count(*). Per thread and iteration the
+// loads of UNROLL rows (keys, filter columns, value columns) are issued before
+// anything is consumed, so each lane keeps UNROLL x (columns) requests in flight.
+constexpr int kFastKeys = 2;
+constexpr int kFastTerms = 2;
+constexpr int kFastCols = 8;
+constexpr int kFastVals = 8;
+constexpr int kFastAccs = 8;
+constexpr int kFastFactors = 3;
+
+enum FastKind : int32_t { FK_VIEW = 0, FK_I32 = 1, FK_I64 = 2, FK_F64 = 3 };
+
+struct FastTerm {
+  const void* ptr;
+  int32_t kind;  // FK_I32 / FK_I64 / FK_F64
+  int32_t cmp;
+  int64_t i64;
+  double f64;
+};
+struct FastFactor {
+  int32_t col;  // index into FastArgs::col, -1 = constant
+  int32_t pad;
+  double scale;
+  double offset;
+};
+struct FastVal {
+  int32_t numFactors;
+  int32_t pad;
+  FastFactor f[kFastFactors];
+};
+struct FastArgs {
+  const void* keyPtr[kFastKeys];
+  int32_t keyKind[kFastKeys];
+  KeyRange range[kFastKeys];
+  const double* col[kFastCols];
+  FastTerm term[kFastTerms];
+  FastVal val[kFastVals];
+  int32_t accVal[kFastAccs];  // value slot feeding accumulator j (-1: count)
+  int32_t numKeys;
+  int32_t numCols;
+  int32_t numTerms;
+  int32_t numVals;
+  int64_t numRows;
+  int32_t* deferred;
+  LdsPlan plan;
+};
+
+template <int UNROLL>
+__global__ __launch_bounds__(512) void k_agg_fast(FastArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+  const LdsPlan& p = a.plan;
+  const LdsState st = ldsInit(p, ldsRaw);
+  const int A = p.A, REP = p.REP;
+  const int rep = lane() & (REP - 1);
+  const int64_t tile = static_cast<int64_t>(blockDim.x) * UNROLL;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * tile;
+  const int64_t rounds = (a.numRows + stride - 1) / stride;
+  int64_t base = static_cast<int64_t>(blockIdx.x) * tile + threadIdx.x;
+  for (int64_t r = 0; r < rounds; ++r, base += stride) {
+    uint64_t kraw[UNROLL][kFastKeys];
+    uint64_t traw[UNROLL][kFastTerms];
+    double c[UNROLL][kFastCols];
+    // Phase 1: issue every load of this iteration.
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t row = base + static_cast<int64_t>(u) * blockDim.x;
+      const bool in = row < a.numRows;
+#pragma unroll
+      for (int k = 0; k < kFastKeys; ++k) {
+        kraw[u][k] = 0;
+        if (in && k < a.numKeys) {
+          if (a.keyKind[k] == FK_VIEW) {
+            kraw[u][k] = static_cast<const uint64_t*>(a.keyPtr[k])[row * 2];
+          } else if (a.keyKind[k] == FK_I32) {
+            kraw[u][k] = static_cast<uint64_t>(static_cast<int64_t>(static_cast<const int32_t*>(a.keyPtr[k])[row]));
+          } else {
+            kraw[u][k] = static_cast<const uint64_t*>(a.keyPtr[k])[row];
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < kFastTerms; ++t) {
+        traw[u][t] = 0;
+        if (in && t < a.numTerms) {
+          if (a.term[t].kind == FK_I32) {
+            traw[u][t] = static_cast<uint64_t>(static_cast<int64_t>(static_cast<const int32_t*>(a.term[t].ptr)[row]));
+          } else {
+            traw[u][t] = static_cast<const uint64_t*>(a.term[t].ptr)[row];
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kFastCols; ++j) {
+        c[u][j] = 0;
+        if (in && j < a.numCols) {
+          c[u][j] = a.col[j][row];
+        }
+      }
+    }
+    // Phase 2: filter, key, LDS updates.
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t row = base + static_cast<int64_t>(u) * blockDim.x;
+      bool live = row < a.numRows;
+#pragma unroll
+      for (int t = 0; t < kFastTerms; ++t) {
+        if (live && t < a.numTerms) {
+          if (a.term[t].kind == FK_F64) {
+            live = compareValues<double>(a.term[t].cmp,
+                                         __longlong_as_double(static_cast<long long>(traw[u][t])),
+                                         a.term[t].f64);
+          } else {
+            live = compareValues<int64_t>(a.term[t].cmp, static_cast<int64_t>(traw[u][t]), a.term[t].i64);
+          }
+        }
+      }
+      uint64_t key = 0;
+      bool defer = false;
+#pragma unroll
+      for (int k = 0; k < kFastKeys; ++k) {
+        if (live && k < a.numKeys) {
+          int64_t v;
+          if (a.keyKind[k] == FK_VIEW) {
+            // {size u32, first 4 bytes}: stringAsNumber for sizes 0..4; longer
+            // strings take the generic path through the deferred list.
+            const uint32_t size = static_cast<uint32_t>(kraw[u][k]);
+            const uint64_t bytes = kraw[u][k] >> 32;
+            if (size > 4) {
+              v = INT64_MIN;  // forces "outside"; the replay reads the full view
+              defer = true;
+            } else {
+              const uint64_t mask = (1ULL << (8 * size)) - 1;
+              v = static_cast<int64_t>((bytes & mask) + (size ? (1ULL << (8 * size)) : 0));
+            }
+          } else {
+            v = static_cast<int64_t>(kraw[u][k]);
+          }
+          if (v < a.range[k].min || v > a.range[k].max) {
+            defer = true;
+          } else {
+            key += a.range[k].multiplier *
+                (static_cast<uint64_t>(v) - static_cast<uint64_t>(a.range[k].min) + 1);
+          }
+        }
+      }
+      defer = defer && live;
+      if (live && !defer) {
+        const int32_t slot = ldsSlot(p, st, key);
+        double vals[kFastVals];
+#pragma unroll
+        for (int j = 0; j < kFastVals; ++j) {
+          vals[j] = 0;
+          if (j < a.numVals) {
+            double acc = 0;
+#pragma unroll
+            for (int f = 0; f < kFastFactors; ++f) {
+              if (f < a.val[j].numFactors) {
+                double x = a.val[j].f[f].offset;
+                const int cj = a.val[j].f[f].col;
+                if (cj >= 0) {
+                  double cv = 0;
+#pragma unroll
+                  for (int q = 0; q < kFastCols; ++q) {
+                    cv = q == cj ? c[u][q] : cv;
+                  }
+                  x = a.val[j].f[f].scale * cv + a.val[j].f[f].offset;
+                }
+                acc = f == 0 ? x : acc * x;
+              }
+            }
+            vals[j] = acc;
+          }
+        }
+        if (slot >= 0) {
+          ldsTouchFirst(st, slot, static_cast<uint32_t>(row));
+          uint64_t* dst = st.acc + (static_cast<size_t>(slot) * A) * REP + rep;
+#pragma unroll
+          for (int j = 0; j < kFastAccs; ++j) {
+            if (j < A) {
+              if (p.kind[j] == ACC_COUNT) {
+                atomicAdd(reinterpret_cast<unsigned long long*>(dst + j * REP), 1ULL);
+              } else {
+                double v = 0;
+#pragma unroll
+                for (int q = 0; q < kFastVals; ++q) {
+                  v = q == a.accVal[j] ? vals[q] : v;
+                }
+                unsafeAtomicAdd(reinterpret_cast<double*>(dst + j * REP), v);
+              }
+            }
+          }
+        } else {
+          // Workgroup out of LDS slots: straight to the group row in HBM.
+          uint64_t* g = p.table + key * p.stride;
+          const uint64_t myRow = p.rowBase + static_cast<uint64_t>(row);
+          unsigned long long old = atomicMin(reinterpret_cast<unsigned long long*>(g + 1), myRow);
+          if (old == kNoRow) {
+            atomicAdd(&p.counters->numNewGroups, 1u);
+          }
+#pragma unroll
+          for (int j = 0; j < kFastAccs; ++j) {
+            if (j < A) {
+              if (p.kind[j] == ACC_COUNT) {
+                applyGlobal(g + p.off[j], ACC_SUM_I64_WRAP, 1, p.counters);
+              } else {
+                double v = 0;
+#pragma unroll
+                for (int q = 0; q < kFastVals; ++q) {
+                  v = q == a.accVal[j] ? vals[q] : v;
+                }
+                applyGlobal(g + p.off[j], ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(v)),
+                            p.counters);
+              }
+            }
+          }
+        }
+      }
+      // Rows the fast path cannot place go to the deferred list (one atomic per wave).
+      const uint64_t m = ballot(defer);
+      if (m != 0) {
+        const int leader = __ffsll(static_cast<long long>(m)) - 1;
+        uint32_t at = 0;
+        if (lane() == leader) {
+          at = atomicAdd(&p.counters->numDeferred, static_cast<uint32_t>(popc64(m)));
+        }
+        at = __shfl(at, leader, kWave);
+        if (defer) {
+          a.deferred[at + lanePrefix(m)] = static_cast<int32_t>(row);
+        }
+      }
+    }
+  }
+  ldsFlush(p, st);
 }
 
 // ---- key statistics of the first rows (VectorHasher::analyze) ---------------
@@ -897,6 +1223,9 @@ struct vx355_agg {
   std::vector<PhysAcc> phys;
   std::vector<int32_t> outTypes;
   std::vector<int32_t> usedCols;
+  std::vector<vx355_filter_term> fusedTerms;
+  std::vector<vx355_projection> fusedProj;
+  int32_t maxProjRef = -1;
 
   // device state
   int32_t mode = MODE_ARRAY;
@@ -920,6 +1249,7 @@ struct vx355_agg {
   int64_t numRehashes = 0;
   uint64_t arrayMax = 1ULL << 28;
   int64_t chunkRows = 1LL << 25;
+  bool disableFast = false;
 
   Counters* counters() { return countersBuf.as<Counters>(); }
 };
@@ -984,7 +1314,16 @@ void buildPlan(vx355_agg& h, const vx355_agg_spec& spec) {
     if (f.kind != VX355_AGG_COUNT_STAR || !raw) {
       VX_CHECK_ARG(f.input_col >= 0, "aggregate needs an input column");
     }
-    h.usedCols.push_back(f.input_col);
+    if (f.input_col >= VX355_PROJECTION_COL_BASE) {
+      // Input = projection of the fused FilterProject: always DOUBLE.
+      if (f.input_type != VX355_DOUBLE || !rawInput(spec.step) ||
+          (f.kind == VX355_AGG_COUNT_STAR)) {
+        VX_THROW(VX355_EUNSUPPORTED, "projection inputs feed raw DOUBLE aggregates only");
+      }
+      h.maxProjRef = std::max(h.maxProjRef, f.input_col - VX355_PROJECTION_COL_BASE);
+    } else {
+      h.usedCols.push_back(f.input_col);
+    }
     h.usedCols.push_back(f.input_col2);
     h.usedCols.push_back(f.mask_col);
     switch (f.kind) {
@@ -1213,7 +1552,7 @@ void rebuildTable(vx355_agg& h, uint64_t extraGroups) {
 
 // Picks the LDS layout for a launch. Returns false when the group range is too
 // large for the LDS path.
-bool chooseLds(const vx355_agg& h, int numAccs, AggArgs* a, size_t* ldsBytes) {
+bool chooseLds(const vx355_agg& h, int numAccs, LdsPlan* plan, size_t* ldsBytes) {
   if (h.mode != MODE_ARRAY || h.capacity > 8192 || numAccs == 0) {
     return false;
   }
@@ -1258,15 +1597,132 @@ bool chooseLds(const vx355_agg& h, int numAccs, AggArgs* a, size_t* ldsBytes) {
     repCompact = 1;
   }
   if (repDirect >= repCompact) {
-    a->ldsDirect = 1;
-    a->ldsSlots = static_cast<int32_t>(R);
-    a->ldsRep = repDirect;
+    plan->direct = 1;
+    plan->S = static_cast<int32_t>(R);
+    plan->REP = repDirect;
   } else {
-    a->ldsDirect = 0;
-    a->ldsSlots = static_cast<int32_t>(S);
-    a->ldsRep = repCompact;
+    plan->direct = 0;
+    plan->S = static_cast<int32_t>(S);
+    plan->REP = repCompact;
   }
-  *ldsBytes = bytesFor(a->ldsSlots, a->ldsRep, a->ldsDirect != 0);
+  plan->A = numAccs;
+  plan->capacity = R;
+  *ldsBytes = bytesFor(plan->S, plan->REP, plan->direct != 0);
+  return true;
+}
+
+// Maps a launch onto the fast kernel's restricted plan shape; false = use the
+// generic kernel.
+bool buildFastArgs(const AggArgs& c, const LdsPlan& plan, FastArgs* f) {
+  if (c.rowList || c.numKeys < 1 || c.numKeys > kFastKeys || c.numTerms > kFastTerms ||
+      c.numAccs > kFastAccs) {
+    return false;
+  }
+  auto flatNoNulls = [](const ColView& v) { return v.enc == VX355_FLAT && v.nulls == nullptr; };
+  *f = FastArgs{};
+  for (int k = 0; k < c.numKeys; ++k) {
+    const ColView& v = c.keys[k].col;
+    if (!flatNoNulls(v)) {
+      return false;
+    }
+    if (isString(v.kind)) {
+      f->keyKind[k] = FK_VIEW;
+    } else if (v.kind == VX355_INTEGER) {
+      f->keyKind[k] = FK_I32;
+    } else if (v.kind == VX355_BIGINT) {
+      f->keyKind[k] = FK_I64;
+    } else {
+      return false;
+    }
+    f->keyPtr[k] = v.values;
+    f->range[k] = c.keys[k].range;
+  }
+  f->numKeys = c.numKeys;
+  for (int t = 0; t < c.numTerms; ++t) {
+    const TermArg& ta = c.terms[t];
+    if (!flatNoNulls(ta.col)) {
+      return false;
+    }
+    FastTerm& ft = f->term[t];
+    if (ta.constKind == VX355_BIGINT && ta.col.kind == VX355_INTEGER) {
+      ft.kind = FK_I32;
+    } else if (ta.constKind == VX355_BIGINT && ta.col.kind == VX355_BIGINT) {
+      ft.kind = FK_I64;
+    } else if (ta.constKind == VX355_DOUBLE && ta.col.kind == VX355_DOUBLE) {
+      ft.kind = FK_F64;
+    } else {
+      return false;
+    }
+    ft.ptr = ta.col.values;
+    ft.cmp = ta.cmp;
+    ft.i64 = ta.i64;
+    ft.f64 = ta.f64;
+  }
+  f->numTerms = c.numTerms;
+  auto colSlot = [&](const ColView& v) -> int {
+    if (!flatNoNulls(v) || v.kind != VX355_DOUBLE) {
+      return -1;
+    }
+    for (int j = 0; j < f->numCols; ++j) {
+      if (f->col[j] == v.values) {
+        return j;
+      }
+    }
+    if (f->numCols == kFastCols) {
+      return -1;
+    }
+    f->col[f->numCols] = static_cast<const double*>(v.values);
+    return f->numCols++;
+  };
+  for (int j = 0; j < c.numAccs; ++j) {
+    const AccArg& ac = c.accs[j];
+    if (ac.hasMask) {
+      return false;
+    }
+    if (ac.kind == ACC_COUNT && !ac.hasIn && ac.inProj < 0) {
+      f->accVal[j] = -1;
+      continue;
+    }
+    if (ac.kind != ACC_SUM_F64 || f->numVals == kFastVals) {
+      return false;
+    }
+    FastVal& fv = f->val[f->numVals];
+    if (ac.inProj >= 0) {
+      const ProjectionArg& pa = c.proj[ac.inProj];
+      if (pa.numFactors > kFastFactors) {
+        return false;
+      }
+      fv.numFactors = pa.numFactors;
+      for (int q = 0; q < pa.numFactors; ++q) {
+        fv.f[q].scale = pa.factors[q].scale;
+        fv.f[q].offset = pa.factors[q].offset;
+        fv.f[q].col = -1;
+        if (pa.factors[q].hasCol) {
+          const int slot = colSlot(pa.factors[q].col);
+          if (slot < 0) {
+            return false;
+          }
+          fv.f[q].col = slot;
+        }
+      }
+    } else {
+      if (!ac.hasIn) {
+        return false;
+      }
+      const int slot = colSlot(ac.in);
+      if (slot < 0) {
+        return false;
+      }
+      fv.numFactors = 1;
+      fv.f[0].col = slot;
+      fv.f[0].scale = 1.0;
+      fv.f[0].offset = 0.0;
+    }
+    f->accVal[j] = f->numVals++;
+  }
+  f->numRows = c.numRows;
+  f->deferred = c.deferred;
+  f->plan = plan;
   return true;
 }
 
@@ -1282,7 +1738,10 @@ void fillAccArgs(vx355_agg& h, const DeviceBatch& db, AggArgs* a) {
     aa.kind = p.kind;
     aa.inIsInt = p.inIsInt ? 1 : 0;
     aa.off = 2 + static_cast<int32_t>(i);
-    if (p.inputCol >= 0) {
+    aa.inProj = -1;
+    if (p.inputCol >= VX355_PROJECTION_COL_BASE) {
+      aa.inProj = p.inputCol - VX355_PROJECTION_COL_BASE;
+    } else if (p.inputCol >= 0) {
       aa.hasIn = 1;
       aa.in = db.col(p.inputCol);
     }
@@ -1322,7 +1781,18 @@ void materializeAliases(vx355_agg& h, const DeviceBatch& db) {
     if (p.aliasOf < 0 || p.inputCol < 0) {
       continue;
     }
-    if (db.col(p.inputCol).nulls == nullptr) {
+    bool mayBeNull = false;
+    if (p.inputCol >= VX355_PROJECTION_COL_BASE) {
+      const auto& pr = h.fusedProj.at(p.inputCol - VX355_PROJECTION_COL_BASE);
+      for (int f = 0; f < pr.num_factors; ++f) {
+        if (pr.factors[f].col >= 0 && db.col(pr.factors[f].col).nulls) {
+          mayBeNull = true;
+        }
+      }
+    } else {
+      mayBeNull = db.col(p.inputCol).nulls != nullptr;
+    }
+    if (!mayBeNull) {
       continue;
     }
     if (h.tableReady) {
@@ -1337,9 +1807,29 @@ void materializeAliases(vx355_agg& h, const DeviceBatch& db) {
 void launchChunk(vx355_agg& h, AggArgs& a) {
   auto& rt = Runtime::get();
   size_t ldsBytes = 0;
-  if (chooseLds(h, a.numAccs, &a, &ldsBytes)) {
+  LdsArgs la{};
+  if (chooseLds(h, a.numAccs, &la.plan, &ldsBytes)) {
+    LdsPlan& plan = la.plan;
+    plan.table = a.table;
+    plan.stride = a.stride;
+    plan.rowBase = a.rowBase;
+    plan.counters = a.counters;
+    for (int j = 0; j < a.numAccs; ++j) {
+      plan.kind[j] = a.accs[j].kind;
+      plan.off[j] = a.accs[j].off;
+    }
+    FastArgs fa;
+    if (!h.disableFast && buildFastArgs(a, plan, &fa)) {
+      constexpr int kUnroll = 4;
+      const int blocksPerCu = std::max<int>(1, std::min<int>(4, static_cast<int>((150 * 1024) / ldsBytes)));
+      int grid = static_cast<int>(
+          std::min<int64_t>(ceilDiv(a.numRows, 512 * kUnroll), static_cast<int64_t>(rt.numCUs) * blocksPerCu));
+      VX_LAUNCH("k_agg_fast", k_agg_fast<kUnroll>, grid, 512, ldsBytes, fa);
+      return;
+    }
+    la.a = a;
     int grid = static_cast<int>(std::min<int64_t>(ceilDiv(a.numRows, 1024), rt.numCUs * 2));
-    VX_LAUNCH("k_agg_lds", k_agg_lds, grid, 1024, ldsBytes, a);
+    VX_LAUNCH("k_agg_lds", k_agg_lds, grid, 1024, ldsBytes, la);
   } else {
     VX_LAUNCH("k_agg_global", k_agg_global, streamGrid(a.numRows, 256), 256, 0, a);
   }
@@ -1379,6 +1869,13 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
   }
   fillAccArgs(h, db, &a);
   patchAvgIntermediate(h, db, &a);
+  if (h.maxProjRef >= static_cast<int32_t>(h.fusedProj.size())) {
+    VX_THROW(VX355_EINVAL, "aggregate refers to a projection that vx355_agg_set_fused_input did not define");
+  }
+  a.numTerms = static_cast<int32_t>(h.fusedTerms.size());
+  a.numProj = static_cast<int32_t>(h.fusedProj.size());
+  makeTermArgs(db, h.fusedTerms.data(), a.numTerms, a.terms);
+  makeProjectionArgs(db, h.fusedProj.data(), a.numProj, a.proj);
   a.stride = h.stride;
   a.counters = h.counters();
 
@@ -1448,6 +1945,16 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
       }
       if (c.accs[j].hasMask) {
         shift(c.accs[j].mask);
+      }
+    }
+    for (int t = 0; t < c.numTerms; ++t) {
+      shift(c.terms[t].col);
+    }
+    for (int j = 0; j < c.numProj; ++j) {
+      for (int f = 0; f < c.proj[j].numFactors; ++f) {
+        if (c.proj[j].factors[f].hasCol) {
+          shift(c.proj[j].factors[f].col);
+        }
       }
     }
     int64_t pending = rows;
@@ -1647,11 +2154,41 @@ int vx355_agg_create(const vx355_agg_spec* spec, vx355_agg** out) {
   if (const char* e = std::getenv("VX355_ARRAY_MAX")) {
     h->arrayMax = std::strtoull(e, nullptr, 10);
   }
+  if (const char* e = std::getenv("VX355_AGG_NO_FAST")) {
+    h->disableFast = e[0] == '1';
+  }
   if (const char* e = std::getenv("VX355_AGG_CHUNK_ROWS")) {
     h->chunkRows = std::max<int64_t>(64, std::strtoll(e, nullptr, 10) & ~63LL);
   }
   buildPlan(*h, *spec);
   *out = h.release();
+  VX_API_END
+}
+
+int vx355_agg_set_fused_input(vx355_agg* h, const vx355_filter_term* terms, int32_t n_terms,
+                              const vx355_projection* projections, int32_t n_projections) {
+  VX_API_BEGIN
+  VX_CHECK_ARG(h, "NULL argument");
+  VX_CHECK_ARG(h->inputRows == 0 && !h->tableReady, "set_fused_input after the first add_input");
+  VX_CHECK_ARG(n_terms >= 0 && n_terms <= kMaxTerms && (n_terms == 0 || terms), "0..4 filter terms");
+  VX_CHECK_ARG(n_projections >= 0 && n_projections <= kMaxProjections &&
+                   (n_projections == 0 || projections),
+               "0..4 projections");
+  if (!rawInput(h->step)) {
+    VX_THROW(VX355_EUNSUPPORTED, "fused FilterProject needs raw input (partial or single step)");
+  }
+  h->fusedTerms.assign(terms, terms + n_terms);
+  h->fusedProj.assign(projections, projections + n_projections);
+  for (const auto& t : h->fusedTerms) {
+    VX_CHECK_ARG(t.col >= 0, "filter term without a column");
+    h->usedCols.push_back(t.col);
+  }
+  for (const auto& p : h->fusedProj) {
+    VX_CHECK_ARG(p.num_factors >= 1 && p.num_factors <= kMaxFactors, "1..4 factors per projection");
+    for (int f = 0; f < p.num_factors; ++f) {
+      h->usedCols.push_back(p.factors[f].col);
+    }
+  }
   VX_API_END
 }
 

@@ -24,7 +24,7 @@ SYMBOLS = [
     "vx355_device_malloc", "vx355_device_free", "vx355_memcpy_h2d", "vx355_memcpy_d2h",
     "vx355_memset_d", "vx355_synchronize", "vx355_profile_enable", "vx355_profile_reset",
     "vx355_profile_get", "vx355_profile_names", "vx355_hash_columns", "vx355_value_ids",
-    "vx355_filter_compact", "vx355_partition", "vx355_filter_project", "vx355_agg_create", "vx355_agg_add_input",
+    "vx355_filter_compact", "vx355_partition", "vx355_filter_project", "vx355_agg_create", "vx355_agg_set_fused_input", "vx355_agg_add_input",
     "vx355_agg_no_more_input", "vx355_agg_output_types", "vx355_agg_get_output",
     "vx355_agg_get_stats", "vx355_agg_destroy", "vx355_join_build_create",
     "vx355_join_build_add_input", "vx355_join_build_finish", "vx355_join_build_destroy",
@@ -72,6 +72,7 @@ def lib():
     L.vx355_filter_project.argtypes = [P(abi.Batch), P(abi.FilterTerm), i32, P(abi.Projection), i32,
                                        vp, P(i32), P(vp), P(vp), i32]
     L.vx355_agg_create.argtypes = [P(abi.AggSpec), P(vp)]
+    L.vx355_agg_set_fused_input.argtypes = [vp, P(abi.FilterTerm), i32, P(abi.Projection), i32]
     L.vx355_agg_add_input.argtypes = [vp, P(abi.Batch)]
     L.vx355_agg_no_more_input.argtypes = [vp]
     L.vx355_agg_output_types.argtypes = [vp, P(i32), i32, P(i32)]
@@ -348,6 +349,12 @@ class HashAggregation:
             lib().vx355_agg_destroy(self.h)
             self.h = None
 
+    def set_fused_input(self, terms, projs):
+        """Fuse the upstream FilterProject: add_input then takes its INPUT batches;
+        aggregate input PROJ(j) reads projection j."""
+        _check(lib().vx355_agg_set_fused_input(self.h, abi.filter_terms(terms), len(terms),
+                                               abi.projections(projs), len(projs)))
+
     def add_input(self, batch):
         _check(lib().vx355_agg_add_input(self.h, batch.ref()))
 
@@ -368,6 +375,11 @@ class HashAggregation:
 
 
 Aggregation = HashAggregation
+PROJECTION_COL_BASE = 1 << 20
+
+
+def PROJ(j):
+    return PROJECTION_COL_BASE + j
 
 
 def collect_output(op, max_rows=1024):
