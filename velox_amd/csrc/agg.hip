@@ -597,8 +597,8 @@ __global__ __launch_bounds__(1024) void k_agg_lds(LdsArgs args) {
 // anything is consumed, so each lane keeps UNROLL x (columns) requests in flight.
 constexpr int kFastKeys = 2;
 constexpr int kFastTerms = 2;
-constexpr int kFastCols = 8;
-constexpr int kFastVals = 8;
+constexpr int kFastCols = 6;
+constexpr int kFastVals = 6;
 constexpr int kFastAccs = 8;
 constexpr int kFastFactors = 3;
 
@@ -640,7 +640,7 @@ struct FastArgs {
 };
 
 template <int UNROLL>
-__global__ __launch_bounds__(512) void k_agg_fast(FastArgs a) {
+__global__ __launch_bounds__(512, 4) void k_agg_fast(FastArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
   const LdsPlan& p = a.plan;
   const LdsState st = ldsInit(p, ldsRaw);
@@ -654,40 +654,77 @@ __global__ __launch_bounds__(512) void k_agg_fast(FastArgs a) {
     uint64_t kraw[UNROLL][kFastKeys];
     uint64_t traw[UNROLL][kFastTerms];
     double c[UNROLL][kFastCols];
-    // Phase 1: issue every load of this iteration.
+    // Phase 1: issue every load of this iteration. Rows past the end are
+    // clamped to the last row (and ignored in phase 2) so that no load sits
+    // under a per-lane predicate: the loads of one column for all UNROLL rows
+    // go out back to back, and nothing waits before phase 2.
+    int64_t rowc[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const int64_t row = base + static_cast<int64_t>(u) * blockDim.x;
-      const bool in = row < a.numRows;
+      rowc[u] = row < a.numRows ? row : a.numRows - 1;
+    }
 #pragma unroll
-      for (int k = 0; k < kFastKeys; ++k) {
+    for (int k = 0; k < kFastKeys; ++k) {
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
         kraw[u][k] = 0;
-        if (in && k < a.numKeys) {
-          if (a.keyKind[k] == FK_VIEW) {
-            kraw[u][k] = static_cast<const uint64_t*>(a.keyPtr[k])[row * 2];
-          } else if (a.keyKind[k] == FK_I32) {
-            kraw[u][k] = static_cast<uint64_t>(static_cast<int64_t>(static_cast<const int32_t*>(a.keyPtr[k])[row]));
-          } else {
-            kraw[u][k] = static_cast<const uint64_t*>(a.keyPtr[k])[row];
+      }
+      if (k < a.numKeys) {
+        if (a.keyKind[k] == FK_VIEW) {
+          const uint64_t* ptr = static_cast<const uint64_t*>(a.keyPtr[k]);
+#pragma unroll
+          for (int u = 0; u < UNROLL; ++u) {
+            kraw[u][k] = ptr[rowc[u] * 2];
+          }
+        } else if (a.keyKind[k] == FK_I32) {
+          const int32_t* ptr = static_cast<const int32_t*>(a.keyPtr[k]);
+#pragma unroll
+          for (int u = 0; u < UNROLL; ++u) {
+            kraw[u][k] = static_cast<uint32_t>(ptr[rowc[u]]);  // sign-extended in phase 2
+          }
+        } else {
+          const uint64_t* ptr = static_cast<const uint64_t*>(a.keyPtr[k]);
+#pragma unroll
+          for (int u = 0; u < UNROLL; ++u) {
+            kraw[u][k] = ptr[rowc[u]];
           }
         }
       }
+    }
 #pragma unroll
-      for (int t = 0; t < kFastTerms; ++t) {
+    for (int t = 0; t < kFastTerms; ++t) {
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
         traw[u][t] = 0;
-        if (in && t < a.numTerms) {
-          if (a.term[t].kind == FK_I32) {
-            traw[u][t] = static_cast<uint64_t>(static_cast<int64_t>(static_cast<const int32_t*>(a.term[t].ptr)[row]));
-          } else {
-            traw[u][t] = static_cast<const uint64_t*>(a.term[t].ptr)[row];
+      }
+      if (t < a.numTerms) {
+        if (a.term[t].kind == FK_I32) {
+          const int32_t* ptr = static_cast<const int32_t*>(a.term[t].ptr);
+#pragma unroll
+          for (int u = 0; u < UNROLL; ++u) {
+            traw[u][t] = static_cast<uint32_t>(ptr[rowc[u]]);  // sign-extended in phase 2
+          }
+        } else {
+          const uint64_t* ptr = static_cast<const uint64_t*>(a.term[t].ptr);
+#pragma unroll
+          for (int u = 0; u < UNROLL; ++u) {
+            traw[u][t] = ptr[rowc[u]];
           }
         }
       }
+    }
 #pragma unroll
-      for (int j = 0; j < kFastCols; ++j) {
+    for (int j = 0; j < kFastCols; ++j) {
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
         c[u][j] = 0;
-        if (in && j < a.numCols) {
-          c[u][j] = a.col[j][row];
+      }
+      if (j < a.numCols) {
+        const double* ptr = a.col[j];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+          c[u][j] = ptr[rowc[u]];
         }
       }
     }
@@ -704,7 +741,10 @@ __global__ __launch_bounds__(512) void k_agg_fast(FastArgs a) {
                                          __longlong_as_double(static_cast<long long>(traw[u][t])),
                                          a.term[t].f64);
           } else {
-            live = compareValues<int64_t>(a.term[t].cmp, static_cast<int64_t>(traw[u][t]), a.term[t].i64);
+            const int64_t tv = a.term[t].kind == FK_I32
+                ? static_cast<int64_t>(static_cast<int32_t>(static_cast<uint32_t>(traw[u][t])))
+                : static_cast<int64_t>(traw[u][t]);
+            live = compareValues<int64_t>(a.term[t].cmp, tv, a.term[t].i64);
           }
         }
       }
@@ -726,6 +766,8 @@ __global__ __launch_bounds__(512) void k_agg_fast(FastArgs a) {
               const uint64_t mask = (1ULL << (8 * size)) - 1;
               v = static_cast<int64_t>((bytes & mask) + (size ? (1ULL << (8 * size)) : 0));
             }
+          } else if (a.keyKind[k] == FK_I32) {
+            v = static_cast<int64_t>(static_cast<int32_t>(static_cast<uint32_t>(kraw[u][k])));
           } else {
             v = static_cast<int64_t>(kraw[u][k]);
           }
@@ -1250,6 +1292,7 @@ struct vx355_agg {
   uint64_t arrayMax = 1ULL << 28;
   int64_t chunkRows = 1LL << 25;
   bool disableFast = false;
+  int fastUnroll = 2;
 
   Counters* counters() { return countersBuf.as<Counters>(); }
 };
@@ -1820,11 +1863,15 @@ void launchChunk(vx355_agg& h, AggArgs& a) {
     }
     FastArgs fa;
     if (!h.disableFast && buildFastArgs(a, plan, &fa)) {
-      constexpr int kUnroll = 4;
+      const int kUnroll = h.fastUnroll;
       const int blocksPerCu = std::max<int>(1, std::min<int>(4, static_cast<int>((150 * 1024) / ldsBytes)));
       int grid = static_cast<int>(
           std::min<int64_t>(ceilDiv(a.numRows, 512 * kUnroll), static_cast<int64_t>(rt.numCUs) * blocksPerCu));
-      VX_LAUNCH("k_agg_fast", k_agg_fast<kUnroll>, grid, 512, ldsBytes, fa);
+      if (kUnroll == 4) {
+        VX_LAUNCH("k_agg_fast", k_agg_fast<4>, grid, 512, ldsBytes, fa);
+      } else {
+        VX_LAUNCH("k_agg_fast", k_agg_fast<2>, grid, 512, ldsBytes, fa);
+      }
       return;
     }
     la.a = a;
@@ -2153,6 +2200,9 @@ int vx355_agg_create(const vx355_agg_spec* spec, vx355_agg** out) {
   h->ignoreNullKeys = spec->ignore_null_keys != 0;
   if (const char* e = std::getenv("VX355_ARRAY_MAX")) {
     h->arrayMax = std::strtoull(e, nullptr, 10);
+  }
+  if (const char* e = std::getenv("VX355_AGG_FAST_UNROLL")) {
+    h->fastUnroll = std::atoi(e) == 4 ? 4 : 2;
   }
   if (const char* e = std::getenv("VX355_AGG_NO_FAST")) {
     h->disableFast = e[0] == '1';
