@@ -122,6 +122,26 @@ def test_range_widening_replays_deferred_rows(oracle, vx):
     assert st.deferred_rows > 0 and st.num_rehashes > 0
 
 
+@pytest.mark.parametrize("device_resident", [False, True])
+def test_deferred_list_overflow_rescans_the_chunk(oracle, vx, device_resident, monkeypatch):
+    """More out-of-range rows than the deferred list holds: the chunk is
+    rescanned for exactly the rows the first launch could not place."""
+    monkeypatch.setenv("VX355_AGG_DEFER_CAP", "100")
+    rng = np.random.default_rng(44)
+    batches = []
+    for i in range(4):
+        n = 30000
+        k = rng.integers(i * 5000, i * 5000 + 3000, n).astype(np.int64)
+        k2 = rng.integers(0, 3, n).astype(np.int32)
+        batches.append(batch_of([k, k2, _dyadic(rng, n)]))
+    aggs = [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT), (abi.AGG_MIN, 2, abi.DOUBLE)]
+    exp, _ = run_agg(oracle, batches, [0, 1], [abi.BIGINT, abi.INTEGER], aggs)
+    inp = [vx.to_device(b) for b in batches] if device_resident else batches
+    got, gop = run_agg(vx, inp, [0, 1], [abi.BIGINT, abi.INTEGER], aggs)
+    assert_columns_equal(got, exp, gop.kinds, what="rescan")
+    assert gop.stats().deferred_rows > 100
+
+
 def test_q1_shape_string_keys_dictionary_inputs(oracle, vx):
     """TPC-H Q1 at the operator boundary: two 1-char VARCHAR keys and DOUBLE
     inputs wrapped in dictionaries over the filter's selected rows."""

@@ -103,6 +103,9 @@ struct AggArgs {
   int32_t ldsDirect;    // slot == key (no map)
   uint64_t capacity;    // group rows in table (array: range product; hash: power of two)
   int32_t* deferred;
+  uint32_t deferCap;            // entries the deferred list can hold
+  uint32_t pad2;
+  const KeyRange* rescanOld;    // non-null: process only rows outside THESE ranges
   Counters* counters;
   // Fused FilterProject (vx355_agg_set_fused_input): rows failing the filter
   // are skipped, projections feed accumulators directly from the scan columns.
@@ -249,6 +252,7 @@ __host__ __device__ inline uint64_t accIdentity(int32_t kind) {
 __device__ inline int normalizedKey(const AggArgs& a, int64_t row, uint64_t* keyOut) {
   uint64_t key = 0;
   bool outside = false;
+  bool outsideOld = false;
   for (int k = 0; k < a.numKeys; ++k) {
     const KeyArg& ka = a.keys[k];
     if (colIsNull(ka.col, row)) {
@@ -263,7 +267,12 @@ __device__ inline int normalizedKey(const AggArgs& a, int64_t row, uint64_t* key
     if (!mappable) {
       a.counters->unmappable = 1;
       outside = true;
+      outsideOld = true;
       continue;
+    }
+    if (a.rescanOld && ka.col.kind != VX355_BOOLEAN &&
+        (value < a.rescanOld[k].min || value > a.rescanOld[k].max)) {
+      outsideOld = true;
     }
     if (id == 0) {
       outside = true;
@@ -272,6 +281,9 @@ __device__ inline int normalizedKey(const AggArgs& a, int64_t row, uint64_t* key
       continue;
     }
     key += ka.range.multiplier * id;
+  }
+  if (a.rescanOld && !outsideOld) {
+    return 1;  // already aggregated by the launch that overflowed its deferred list
   }
   *keyOut = key;
   return outside ? 2 : 0;
@@ -288,7 +300,9 @@ __device__ inline void deferRow(const AggArgs& a, bool defer, int32_t row) {
     base = atomicAdd(&a.counters->numDeferred, static_cast<uint32_t>(popc64(m)));
   }
   base = __shfl(base, __ffsll(static_cast<long long>(m)) - 1, kWave);
-  if (defer) {
+  // Past the capacity only the count keeps growing: the host then rescans the
+  // chunk instead of replaying the list.
+  if (defer && base + lanePrefix(m) < a.deferCap) {
     a.deferred[base + lanePrefix(m)] = row;
   }
 }
@@ -636,6 +650,8 @@ struct FastArgs {
   int32_t numVals;
   int64_t numRows;
   int32_t* deferred;
+  uint32_t deferCap;
+  uint32_t pad;
   LdsPlan plan;
 };
 
@@ -773,6 +789,10 @@ __global__ __launch_bounds__(512, 4) void k_agg_fast(FastArgs a) {
           }
           if (v < a.range[k].min || v > a.range[k].max) {
             defer = true;
+            if (v != INT64_MIN) {
+              atomicMin(reinterpret_cast<long long*>(&p.counters->keyMin[k]), static_cast<long long>(v));
+              atomicMax(reinterpret_cast<long long*>(&p.counters->keyMax[k]), static_cast<long long>(v));
+            }
           } else {
             key += a.range[k].multiplier *
                 (static_cast<uint64_t>(v) - static_cast<uint64_t>(a.range[k].min) + 1);
@@ -860,7 +880,7 @@ __global__ __launch_bounds__(512, 4) void k_agg_fast(FastArgs a) {
           at = atomicAdd(&p.counters->numDeferred, static_cast<uint32_t>(popc64(m)));
         }
         at = __shfl(at, leader, kWave);
-        if (defer) {
+        if (defer && at + lanePrefix(m) < a.deferCap) {
           a.deferred[at + lanePrefix(m)] = static_cast<int32_t>(row);
         }
       }
@@ -1290,8 +1310,9 @@ struct vx355_agg {
   int64_t numGroups = 0;
   int64_t numRehashes = 0;
   uint64_t arrayMax = 1ULL << 28;
-  int64_t chunkRows = 1LL << 25;
+  int64_t chunkRows = 1LL << 31;
   bool disableFast = false;
+  int64_t deferCap = 1 << 20;
   int fastUnroll = 2;
 
   Counters* counters() { return countersBuf.as<Counters>(); }
@@ -1657,7 +1678,7 @@ bool chooseLds(const vx355_agg& h, int numAccs, LdsPlan* plan, size_t* ldsBytes)
 // Maps a launch onto the fast kernel's restricted plan shape; false = use the
 // generic kernel.
 bool buildFastArgs(const AggArgs& c, const LdsPlan& plan, FastArgs* f) {
-  if (c.rowList || c.numKeys < 1 || c.numKeys > kFastKeys || c.numTerms > kFastTerms ||
+  if (c.rowList || c.rescanOld || c.numKeys < 1 || c.numKeys > kFastKeys || c.numTerms > kFastTerms ||
       c.numAccs > kFastAccs) {
     return false;
   }
@@ -1765,6 +1786,7 @@ bool buildFastArgs(const AggArgs& c, const LdsPlan& plan, FastArgs* f) {
   }
   f->numRows = c.numRows;
   f->deferred = c.deferred;
+  f->deferCap = c.deferCap;
   f->plan = plan;
   return true;
 }
@@ -1952,11 +1974,17 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
     // groups) picks the LDS layout of every later launch.
     rows = std::min(h.numGroups == 0 ? std::min<int64_t>(h.chunkRows, 1 << 20) : h.chunkRows,
                     n - begin);
+    if (h.mode == MODE_NORMALIZED) {
+      // The open-addressing table is sized for the worst case "every row of the
+      // chunk is a new group": keep that bound reasonable.
+      rows = std::min<int64_t>(rows, 1 << 26);
+    }
     if (h.mode == MODE_NORMALIZED &&
         static_cast<uint64_t>(h.numGroups + rows) > h.capacity * 7 / 10) {
       rebuildTable(h, static_cast<uint64_t>(rows));  // HashTable::checkSize (HashTable.cpp:772-806)
     }
-    h.deferredBuf.ensure(static_cast<size_t>(rows) * 4 + 64);
+    const uint32_t deferCap = static_cast<uint32_t>(std::min<int64_t>(rows, h.deferCap));
+    h.deferredBuf.ensure(static_cast<size_t>(deferCap) * 4 + 64);
     // Chunk = rows [begin, begin + rows): shift every column view instead of
     // adding an offset in the kernel.
     AggArgs c = a;
@@ -1964,6 +1992,7 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
     c.rowList = nullptr;
     c.rowBase = static_cast<uint64_t>(h.inputRows + begin);
     c.deferred = h.deferredBuf.as<int32_t>();
+    c.deferCap = deferCap;
     auto shift = [&](ColView& v) {
       if (begin == 0 || v.enc == VX355_CONSTANT) {
         return;
@@ -2006,19 +2035,23 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
     }
     int64_t pending = rows;
     const int32_t* list = nullptr;
-    DevBuf replayList;
+    bool rescan = false;
+    DevBuf replayList, oldRanges;
     for (int attempt = 0; pending > 0; ++attempt) {
       if (attempt > 64) {
         VX_THROW(VX355_EINTERNAL, "key range widening did not converge");
       }
       resetCounters(h);
-      c.numRows = pending;
-      c.rowList = list;
+      c.numRows = rescan ? rows : pending;
+      c.rowList = rescan ? nullptr : list;
+      c.rescanOld = rescan ? oldRanges.as<KeyRange>() : nullptr;
       c.table = h.table.as<uint64_t>();
       c.capacity = h.capacity;
       c.mode = h.mode;
+      std::vector<KeyRange> used(c.numKeys);
       for (int k = 0; k < c.numKeys; ++k) {
         c.keys[k].range = h.keys[k].range;
+        used[k] = h.keys[k].range;
       }
       launchChunk(h, c);
       Counters ctr = readCounters(h);
@@ -2026,16 +2059,23 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
       h.numGroups += ctr.numNewGroups;
       pending = ctr.numDeferred;
       if (pending > 0) {
-        // Widen, re-key, replay only the deferred rows.
+        // Widen, re-key, then replay the deferred rows; when the list
+        // overflowed, rescan the chunk for the rows outside the ranges this
+        // launch used.
         h.deferredRows += pending;
         mergeObserved(h, ctr);
-        replayList.ensure(static_cast<size_t>(pending) * 4 + 64);
-        copyIn(replayList.ptr(), h.deferredBuf.ptr(), VX355_MEM_DEVICE,
-               static_cast<size_t>(pending) * 4);
-        list = replayList.as<int32_t>();
+        rescan = pending > static_cast<int64_t>(deferCap);
+        if (rescan) {
+          oldRanges.ensure(used.size() * sizeof(KeyRange) + 64);
+          copyIn(oldRanges.ptr(), used.data(), VX355_MEM_HOST, used.size() * sizeof(KeyRange));
+          rt.sync();
+        } else {
+          replayList.ensure(static_cast<size_t>(pending) * 4 + 64);
+          copyIn(replayList.ptr(), h.deferredBuf.ptr(), VX355_MEM_DEVICE,
+                 static_cast<size_t>(pending) * 4);
+          list = replayList.as<int32_t>();
+        }
         rebuildTable(h, static_cast<uint64_t>(pending));
-        // Replay in ascending row order is not required: group order comes
-        // from the recorded first rows.
       }
     }
   }
@@ -2200,6 +2240,9 @@ int vx355_agg_create(const vx355_agg_spec* spec, vx355_agg** out) {
   h->ignoreNullKeys = spec->ignore_null_keys != 0;
   if (const char* e = std::getenv("VX355_ARRAY_MAX")) {
     h->arrayMax = std::strtoull(e, nullptr, 10);
+  }
+  if (const char* e = std::getenv("VX355_AGG_DEFER_CAP")) {
+    h->deferCap = std::max<int64_t>(1, std::strtoll(e, nullptr, 10));
   }
   if (const char* e = std::getenv("VX355_AGG_FAST_UNROLL")) {
     h->fastUnroll = std::atoi(e) == 4 ? 4 : 2;

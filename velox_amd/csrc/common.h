@@ -91,6 +91,16 @@ struct Runtime {
   std::map<std::string, ProfileEntry> prof;
   std::vector<hipEvent_t> freeEvents;
 
+  // HBM block cache: operators are created and destroyed per query; their
+  // tables and scratch buffers are recycled instead of going through
+  // hipMalloc/hipFree (which synchronise the device).
+  std::multimap<size_t, void*> freeBlocks;
+  size_t cachedBytes = 0;
+  size_t cacheLimit = 16ULL << 30;
+  void* allocBlock(size_t bytes, size_t* actual);
+  void freeBlock(void* p, size_t bytes);
+  void trimCache();
+
   static Runtime& get();
   void requireInit() const {
     if (!initialized) {

@@ -57,24 +57,73 @@ void Runtime::profEnd(const char* name) {
   ++entry.launches;
 }
 
+void* Runtime::allocBlock(size_t bytes, size_t* actual) {
+  // Size classes: powers of two up to 1 MiB, then multiples of 1 MiB.
+  size_t want = bytes <= (1u << 20) ? static_cast<size_t>(nextPow2(std::max<size_t>(bytes, 256)))
+                                    : ((bytes + (1u << 20) - 1) >> 20) << 20;
+  auto it = freeBlocks.lower_bound(want);
+  if (it != freeBlocks.end() && it->first <= want + want / 4) {
+    void* p = it->second;
+    *actual = it->first;
+    cachedBytes -= it->first;
+    freeBlocks.erase(it);
+    return p;
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, want);
+  if (e == hipErrorOutOfMemory && !freeBlocks.empty()) {
+    (void)hipGetLastError();
+    trimCache();
+    e = hipMalloc(&p, want);
+  }
+  if (e != hipSuccess) {
+    hipFail(e, "hipMalloc", __FILE__, __LINE__);
+  }
+  *actual = want;
+  return p;
+}
+
+void Runtime::freeBlock(void* p, size_t bytes) {
+  if (!p) {
+    return;
+  }
+  if (!initialized || cachedBytes + bytes > cacheLimit) {
+    if (initialized) {
+      (void)hipStreamSynchronize(stream);
+    }
+    (void)hipFree(p);
+    return;
+  }
+  // Work already queued on the library stream may still touch the block; any
+  // later user is ordered behind it on the same stream.
+  freeBlocks.emplace(bytes, p);
+  cachedBytes += bytes;
+}
+
+void Runtime::trimCache() {
+  if (initialized) {
+    (void)hipStreamSynchronize(stream);
+  }
+  for (auto& kv : freeBlocks) {
+    (void)hipFree(kv.second);
+  }
+  freeBlocks.clear();
+  cachedBytes = 0;
+}
+
 void* DevBuf::ensure(size_t bytes, bool preserve, size_t preserveBytes) {
   if (bytes <= cap_) {
     return p_;
   }
   size_t newCap = std::max<size_t>(bytes, cap_ + cap_ / 2);
-  newCap = (newCap + 255) & ~static_cast<size_t>(255);
-  void* np = nullptr;
-  HIP_OK(hipMalloc(&np, newCap));
+  void* np = Runtime::get().allocBlock(newCap, &newCap);
   if (preserve && p_ && preserveBytes) {
     auto& rt = Runtime::get();
     HIP_OK(hipMemcpyAsync(np, p_, std::min(preserveBytes, cap_), hipMemcpyDeviceToDevice,
                           rt.stream));
-    rt.sync();
   }
   if (p_) {
-    // The library stream may still reference the old block.
-    Runtime::get().sync();
-    (void)hipFree(p_);
+    Runtime::get().freeBlock(p_, cap_);
   }
   p_ = np;
   cap_ = newCap;
@@ -83,11 +132,7 @@ void* DevBuf::ensure(size_t bytes, bool preserve, size_t preserveBytes) {
 
 void DevBuf::release() {
   if (p_) {
-    auto& rt = Runtime::get();
-    if (rt.initialized) {
-      (void)hipStreamSynchronize(rt.stream);
-    }
-    (void)hipFree(p_);
+    Runtime::get().freeBlock(p_, cap_);
     p_ = nullptr;
     cap_ = 0;
   }
@@ -292,6 +337,7 @@ void vx355_shutdown(void) {
     return;
   }
   (void)hipStreamSynchronize(rt.stream);
+  rt.trimCache();
   for (auto& kv : rt.prof) {
     for (auto& ev : kv.second.events) {
       (void)hipEventDestroy(ev.first);
