@@ -13,9 +13,9 @@ from collections import defaultdict
 
 
 def short(name):
-    name = name.split("(")[0]
-    for p in ("void ", "vx::(anonymous namespace)::", "vx::"):
+    for p in ("void ", "vx::(anonymous namespace)::", "(anonymous namespace)::", "vx::"):
         name = name.replace(p, "")
+    name = name.split("(")[0]
     return name[:60]
 
 

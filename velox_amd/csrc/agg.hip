@@ -29,6 +29,8 @@
 #include "expr_device.h"
 
 #include <algorithm>
+#include <utility>
+#include <cstdio>
 #include <cstdlib>
 #include <limits>
 
@@ -602,52 +604,43 @@ __global__ __launch_bounds__(1024) void k_agg_lds(LdsArgs args) {
   addNewGroups(a.counters, newGroups);
 }
 
-// ---- fast LDS kernel: the TPC-H Q1 / BASELINE config-1 plan shape --------------
-// Flat, null-free columns only: <= 2 keys (1..7-byte strings read as the first
-// 8 bytes of their StringView, INTEGER or BIGINT), <= 2 filter terms on
-// INTEGER / BIGINT / DOUBLE columns, <= 8 DOUBLE columns feeding sum(column),
-// sum(product of affine factors) and count(*). Per thread and iteration the
-// loads of UNROLL rows (keys, filter columns, value columns) are issued before
-// anything is consumed, so each lane keeps UNROLL x (columns) requests in flight.
+// ---- shape-specialised LDS kernel ------------------------------------------------
+// The generic LDS kernel interprets the plan per row (column encodings, types,
+// masks, expression tables): ~500 VALU instructions per 64 rows, which caps it
+// near 2 TB/s. For flat, null-free inputs the plan SHAPE is lifted into template
+// parameters instead, so every register index and every branch on the plan is
+// resolved at compile time and what is left per row is the arithmetic itself:
+//   keys   K0,K1  : FK_VIEW (short string, first 8 bytes of the StringView),
+//                   FK_I32, FK_I64, or -1 (absent)
+//   terms  T0,T1  : filter column kinds FK_I32 / FK_I64 / FK_F64 or -1
+//   NL            : distinct DOUBLE columns loaded per row (each loaded once)
+//   NA, ACC_LO/HI : per accumulator 16 bits {numFactors, load index of factor
+//                   0..2 (15 = constant factor)}; numFactors 0 = count(*)
+// Comparison operators, constants, scales, offsets, ranges stay runtime values.
+// Shapes are instantiated ahead of time below (VX_FAST_SHAPES); a plan whose
+// shape is not in the table runs on the generic kernel.
 constexpr int kFastKeys = 2;
 constexpr int kFastTerms = 2;
-constexpr int kFastCols = 6;
-constexpr int kFastVals = 6;
 constexpr int kFastAccs = 8;
 constexpr int kFastFactors = 3;
+constexpr int kFastLoads = 8;
 
-enum FastKind : int32_t { FK_VIEW = 0, FK_I32 = 1, FK_I64 = 2, FK_F64 = 3 };
+enum FastKind : int32_t { FK_NONE = -1, FK_VIEW = 0, FK_I32 = 1, FK_I64 = 2, FK_F64 = 3 };
 
 struct FastTerm {
   const void* ptr;
-  int32_t kind;  // FK_I32 / FK_I64 / FK_F64
   int32_t cmp;
+  int32_t pad;
   int64_t i64;
   double f64;
 };
-struct FastFactor {
-  int32_t col;  // index into FastArgs::col, -1 = constant
-  int32_t pad;
-  double scale;
-  double offset;
-};
-struct FastVal {
-  int32_t numFactors;
-  int32_t pad;
-  FastFactor f[kFastFactors];
-};
 struct FastArgs {
   const void* keyPtr[kFastKeys];
-  int32_t keyKind[kFastKeys];
   KeyRange range[kFastKeys];
-  const double* col[kFastCols];
+  const double* loadPtr[kFastLoads];
   FastTerm term[kFastTerms];
-  FastVal val[kFastVals];
-  int32_t accVal[kFastAccs];  // value slot feeding accumulator j (-1: count)
-  int32_t numKeys;
-  int32_t numCols;
-  int32_t numTerms;
-  int32_t numVals;
+  double scale[kFastAccs][kFastFactors];
+  double offset[kFastAccs][kFastFactors];
   int64_t numRows;
   int32_t* deferred;
   uint32_t deferCap;
@@ -655,12 +648,74 @@ struct FastArgs {
   LdsPlan plan;
 };
 
-template <int UNROLL>
+constexpr uint64_t accDesc(int numFactors, int l0 = 15, int l1 = 15, int l2 = 15) {
+  return static_cast<uint64_t>(numFactors) | (static_cast<uint64_t>(l0) << 4) |
+      (static_cast<uint64_t>(l1) << 8) | (static_cast<uint64_t>(l2) << 12);
+}
+constexpr uint64_t packAccs(uint64_t a0 = 0, uint64_t a1 = 0, uint64_t a2 = 0, uint64_t a3 = 0) {
+  return a0 | (a1 << 16) | (a2 << 32) | (a3 << 48);
+}
+
+template <int UNROLL, int K0, int K1, int T0, int T1, int NL, int NA, uint64_t ACC_LO, uint64_t ACC_HI>
+struct FastShape {
+  static constexpr int unroll = UNROLL;
+  static constexpr int keyKind(int k) { return k == 0 ? K0 : K1; }
+  static constexpr int termKind(int t) { return t == 0 ? T0 : T1; }
+  static constexpr int numLoads = NL;
+  static constexpr int numAccs = NA;
+  static constexpr uint64_t desc(int j) {
+    return ((j < 4 ? ACC_LO >> (16 * j) : ACC_HI >> (16 * (j - 4)))) & 0xffff;
+  }
+  static constexpr int numFactors(int j) { return static_cast<int>(desc(j) & 15); }
+  static constexpr int load(int j, int f) { return static_cast<int>((desc(j) >> (4 + 4 * f)) & 15); }
+};
+
+// Compile-time loop: f(std::integral_constant<int, 0>{}) ... f(<N-1>).
+template <int... Is, typename F>
+__device__ inline void staticForImpl(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ inline void staticFor(F&& f) {
+  staticForImpl(std::make_integer_sequence<int, N>{}, f);
+}
+
+template <int KIND>
+__device__ inline uint64_t fastLoadRaw(const void* ptr, int64_t row) {
+  if constexpr (KIND == FK_VIEW) {
+    return static_cast<const uint64_t*>(ptr)[row * 2];
+  } else if constexpr (KIND == FK_I32) {
+    return static_cast<const uint32_t*>(ptr)[row];  // sign-extended at use
+  } else {
+    return static_cast<const uint64_t*>(ptr)[row];
+  }
+}
+
+// int64 image of a key (VectorHasher::toInt64 / stringAsNumber); INT64_MIN for
+// strings the fast path does not decode (> 3 bytes: the replay reads the view).
+template <int KIND>
+__device__ inline int64_t fastKeyValue(uint64_t raw) {
+  if constexpr (KIND == FK_VIEW) {
+    const uint32_t size = static_cast<uint32_t>(raw);
+    const uint32_t bytes = static_cast<uint32_t>(raw >> 32);
+    const uint32_t shift = (size & 3u) * 8;
+    const int64_t v = static_cast<int64_t>((bytes & ((1u << shift) - 1)) + (size ? (1u << shift) : 0u));
+    return size > 3 ? INT64_MIN : v;
+  } else if constexpr (KIND == FK_I32) {
+    return static_cast<int64_t>(static_cast<int32_t>(static_cast<uint32_t>(raw)));
+  } else {
+    return static_cast<int64_t>(raw);
+  }
+}
+
+template <typename S>
 __global__ __launch_bounds__(512, 4) void k_agg_fast(FastArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+  constexpr int UNROLL = S::unroll;
+  constexpr int A = S::numAccs;
   const LdsPlan& p = a.plan;
   const LdsState st = ldsInit(p, ldsRaw);
-  const int A = p.A, REP = p.REP;
+  const int REP = p.REP;
   const int rep = lane() & (REP - 1);
   const int64_t tile = static_cast<int64_t>(blockDim.x) * UNROLL;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * tile;
@@ -669,11 +724,10 @@ __global__ __launch_bounds__(512, 4) void k_agg_fast(FastArgs a) {
   for (int64_t r = 0; r < rounds; ++r, base += stride) {
     uint64_t kraw[UNROLL][kFastKeys];
     uint64_t traw[UNROLL][kFastTerms];
-    double c[UNROLL][kFastCols];
-    // Phase 1: issue every load of this iteration. Rows past the end are
-    // clamped to the last row (and ignored in phase 2) so that no load sits
-    // under a per-lane predicate: the loads of one column for all UNROLL rows
-    // go out back to back, and nothing waits before phase 2.
+    double x[UNROLL][S::numLoads > 0 ? S::numLoads : 1];
+    // Phase 1: every load of this iteration, column by column, UNROLL rows
+    // back to back. Rows past the end are clamped (and ignored in phase 2) so
+    // that no load sits under a per-lane predicate.
     int64_t rowc[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
@@ -681,67 +735,34 @@ __global__ __launch_bounds__(512, 4) void k_agg_fast(FastArgs a) {
       rowc[u] = row < a.numRows ? row : a.numRows - 1;
     }
 #pragma unroll
-    for (int k = 0; k < kFastKeys; ++k) {
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-        kraw[u][k] = 0;
-      }
-      if (k < a.numKeys) {
-        if (a.keyKind[k] == FK_VIEW) {
-          const uint64_t* ptr = static_cast<const uint64_t*>(a.keyPtr[k]);
-#pragma unroll
-          for (int u = 0; u < UNROLL; ++u) {
-            kraw[u][k] = ptr[rowc[u] * 2];
-          }
-        } else if (a.keyKind[k] == FK_I32) {
-          const int32_t* ptr = static_cast<const int32_t*>(a.keyPtr[k]);
-#pragma unroll
-          for (int u = 0; u < UNROLL; ++u) {
-            kraw[u][k] = static_cast<uint32_t>(ptr[rowc[u]]);  // sign-extended in phase 2
-          }
-        } else {
-          const uint64_t* ptr = static_cast<const uint64_t*>(a.keyPtr[k]);
-#pragma unroll
-          for (int u = 0; u < UNROLL; ++u) {
-            kraw[u][k] = ptr[rowc[u]];
-          }
-        }
+    for (int u = 0; u < UNROLL; ++u) {
+      if constexpr (S::keyKind(0) != FK_NONE) {
+        kraw[u][0] = fastLoadRaw<S::keyKind(0)>(a.keyPtr[0], rowc[u]);
       }
     }
 #pragma unroll
-    for (int t = 0; t < kFastTerms; ++t) {
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-        traw[u][t] = 0;
-      }
-      if (t < a.numTerms) {
-        if (a.term[t].kind == FK_I32) {
-          const int32_t* ptr = static_cast<const int32_t*>(a.term[t].ptr);
-#pragma unroll
-          for (int u = 0; u < UNROLL; ++u) {
-            traw[u][t] = static_cast<uint32_t>(ptr[rowc[u]]);  // sign-extended in phase 2
-          }
-        } else {
-          const uint64_t* ptr = static_cast<const uint64_t*>(a.term[t].ptr);
-#pragma unroll
-          for (int u = 0; u < UNROLL; ++u) {
-            traw[u][t] = ptr[rowc[u]];
-          }
-        }
+    for (int u = 0; u < UNROLL; ++u) {
+      if constexpr (S::keyKind(1) != FK_NONE) {
+        kraw[u][1] = fastLoadRaw<S::keyKind(1)>(a.keyPtr[1], rowc[u]);
       }
     }
 #pragma unroll
-    for (int j = 0; j < kFastCols; ++j) {
+    for (int u = 0; u < UNROLL; ++u) {
+      if constexpr (S::termKind(0) != FK_NONE) {
+        traw[u][0] = fastLoadRaw<S::termKind(0)>(a.term[0].ptr, rowc[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      if constexpr (S::termKind(1) != FK_NONE) {
+        traw[u][1] = fastLoadRaw<S::termKind(1)>(a.term[1].ptr, rowc[u]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < S::numLoads; ++j) {
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {
-        c[u][j] = 0;
-      }
-      if (j < a.numCols) {
-        const double* ptr = a.col[j];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-          c[u][j] = ptr[rowc[u]];
-        }
+        x[u][j] = a.loadPtr[j][rowc[u]];
       }
     }
     // Phase 2: filter, key, LDS updates.
@@ -749,102 +770,69 @@ __global__ __launch_bounds__(512, 4) void k_agg_fast(FastArgs a) {
     for (int u = 0; u < UNROLL; ++u) {
       const int64_t row = base + static_cast<int64_t>(u) * blockDim.x;
       bool live = row < a.numRows;
-#pragma unroll
-      for (int t = 0; t < kFastTerms; ++t) {
-        if (live && t < a.numTerms) {
-          if (a.term[t].kind == FK_F64) {
-            live = compareValues<double>(a.term[t].cmp,
-                                         __longlong_as_double(static_cast<long long>(traw[u][t])),
-                                         a.term[t].f64);
-          } else {
-            const int64_t tv = a.term[t].kind == FK_I32
-                ? static_cast<int64_t>(static_cast<int32_t>(static_cast<uint32_t>(traw[u][t])))
-                : static_cast<int64_t>(traw[u][t]);
-            live = compareValues<int64_t>(a.term[t].cmp, tv, a.term[t].i64);
-          }
+      staticFor<kFastTerms>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        if constexpr (S::termKind(t) == FK_F64) {
+          live = live && compareValues<double>(a.term[t].cmp,
+                                               __longlong_as_double(static_cast<long long>(traw[u][t])),
+                                               a.term[t].f64);
+        } else if constexpr (S::termKind(t) == FK_I32) {
+          // the host only picks this shape when the constant fits int32
+          live = live && compareValues<int32_t>(a.term[t].cmp,
+                                                static_cast<int32_t>(static_cast<uint32_t>(traw[u][t])),
+                                                static_cast<int32_t>(a.term[t].i64));
+        } else if constexpr (S::termKind(t) == FK_I64) {
+          live = live && compareValues<int64_t>(a.term[t].cmp, static_cast<int64_t>(traw[u][t]),
+                                                a.term[t].i64);
         }
-      }
+      });
       uint64_t key = 0;
       bool defer = false;
-#pragma unroll
-      for (int k = 0; k < kFastKeys; ++k) {
-        if (live && k < a.numKeys) {
-          int64_t v;
-          if (a.keyKind[k] == FK_VIEW) {
-            // {size u32, first 4 bytes}: stringAsNumber for sizes 0..4; longer
-            // strings take the generic path through the deferred list.
-            const uint32_t size = static_cast<uint32_t>(kraw[u][k]);
-            const uint64_t bytes = kraw[u][k] >> 32;
-            if (size > 4) {
-              v = INT64_MIN;  // forces "outside"; the replay reads the full view
-              defer = true;
-            } else {
-              const uint64_t mask = (1ULL << (8 * size)) - 1;
-              v = static_cast<int64_t>((bytes & mask) + (size ? (1ULL << (8 * size)) : 0));
-            }
-          } else if (a.keyKind[k] == FK_I32) {
-            v = static_cast<int64_t>(static_cast<int32_t>(static_cast<uint32_t>(kraw[u][k])));
-          } else {
-            v = static_cast<int64_t>(kraw[u][k]);
-          }
+      staticFor<kFastKeys>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (S::keyKind(k) != FK_NONE) {
+          const int64_t v = fastKeyValue<S::keyKind(k)>(kraw[u][k]);
           if (v < a.range[k].min || v > a.range[k].max) {
-            defer = true;
-            if (v != INT64_MIN) {
-              atomicMin(reinterpret_cast<long long*>(&p.counters->keyMin[k]), static_cast<long long>(v));
-              atomicMax(reinterpret_cast<long long*>(&p.counters->keyMax[k]), static_cast<long long>(v));
+            if (live) {
+              defer = true;
+              if (v != INT64_MIN) {
+                atomicMin(reinterpret_cast<long long*>(&p.counters->keyMin[k]), static_cast<long long>(v));
+                atomicMax(reinterpret_cast<long long*>(&p.counters->keyMax[k]), static_cast<long long>(v));
+              }
             }
           } else {
             key += a.range[k].multiplier *
                 (static_cast<uint64_t>(v) - static_cast<uint64_t>(a.range[k].min) + 1);
           }
         }
-      }
-      defer = defer && live;
+      });
       if (live && !defer) {
         const int32_t slot = ldsSlot(p, st, key);
-        double vals[kFastVals];
-#pragma unroll
-        for (int j = 0; j < kFastVals; ++j) {
-          vals[j] = 0;
-          if (j < a.numVals) {
-            double acc = 0;
-#pragma unroll
-            for (int f = 0; f < kFastFactors; ++f) {
-              if (f < a.val[j].numFactors) {
-                double x = a.val[j].f[f].offset;
-                const int cj = a.val[j].f[f].col;
-                if (cj >= 0) {
-                  double cv = 0;
-#pragma unroll
-                  for (int q = 0; q < kFastCols; ++q) {
-                    cv = q == cj ? c[u][q] : cv;
-                  }
-                  x = a.val[j].f[f].scale * cv + a.val[j].f[f].offset;
-                }
-                acc = f == 0 ? x : acc * x;
-              }
+        double vals[A > 0 ? A : 1];
+        staticFor<A>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          double acc = 0;
+          staticFor<S::numFactors(j)>([&](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            double v = a.offset[j][f];
+            if constexpr (S::load(j, f) != 15) {
+              v = a.scale[j][f] * x[u][S::load(j, f)] + a.offset[j][f];
             }
-            vals[j] = acc;
-          }
-        }
+            acc = f == 0 ? v : acc * v;
+          });
+          vals[j] = acc;
+        });
         if (slot >= 0) {
           ldsTouchFirst(st, slot, static_cast<uint32_t>(row));
           uint64_t* dst = st.acc + (static_cast<size_t>(slot) * A) * REP + rep;
-#pragma unroll
-          for (int j = 0; j < kFastAccs; ++j) {
-            if (j < A) {
-              if (p.kind[j] == ACC_COUNT) {
-                atomicAdd(reinterpret_cast<unsigned long long*>(dst + j * REP), 1ULL);
-              } else {
-                double v = 0;
-#pragma unroll
-                for (int q = 0; q < kFastVals; ++q) {
-                  v = q == a.accVal[j] ? vals[q] : v;
-                }
-                unsafeAtomicAdd(reinterpret_cast<double*>(dst + j * REP), v);
-              }
+          staticFor<A>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (S::numFactors(j) == 0) {
+              atomicAdd(reinterpret_cast<unsigned long long*>(dst + j * REP), 1ULL);
+            } else {
+              unsafeAtomicAdd(reinterpret_cast<double*>(dst + j * REP), vals[j]);
             }
-          }
+          });
         } else {
           // Workgroup out of LDS slots: straight to the group row in HBM.
           uint64_t* g = p.table + key * p.stride;
@@ -853,22 +841,15 @@ __global__ __launch_bounds__(512, 4) void k_agg_fast(FastArgs a) {
           if (old == kNoRow) {
             atomicAdd(&p.counters->numNewGroups, 1u);
           }
-#pragma unroll
-          for (int j = 0; j < kFastAccs; ++j) {
-            if (j < A) {
-              if (p.kind[j] == ACC_COUNT) {
-                applyGlobal(g + p.off[j], ACC_SUM_I64_WRAP, 1, p.counters);
-              } else {
-                double v = 0;
-#pragma unroll
-                for (int q = 0; q < kFastVals; ++q) {
-                  v = q == a.accVal[j] ? vals[q] : v;
-                }
-                applyGlobal(g + p.off[j], ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(v)),
-                            p.counters);
-              }
+          staticFor<A>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (S::numFactors(j) == 0) {
+              applyGlobal(g + p.off[j], ACC_SUM_I64_WRAP, 1, p.counters);
+            } else {
+              applyGlobal(g + p.off[j], ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(vals[j])),
+                          p.counters);
             }
-          }
+          });
         }
       }
       // Rows the fast path cannot place go to the deferred list (one atomic per wave).
@@ -888,6 +869,56 @@ __global__ __launch_bounds__(512, 4) void k_agg_fast(FastArgs a) {
   }
   ldsFlush(p, st);
 }
+
+// What the host derives from a launch to pick an instantiation.
+struct FastSignature {
+  int k0 = FK_NONE, k1 = FK_NONE, t0 = FK_NONE, t1 = FK_NONE, numLoads = 0, numAccs = 0;
+  uint64_t accLo = 0, accHi = 0;
+  bool operator==(const FastSignature& o) const {
+    return k0 == o.k0 && k1 == o.k1 && t0 == o.t0 && t1 == o.t1 && numLoads == o.numLoads &&
+        numAccs == o.numAccs && accLo == o.accLo && accHi == o.accHi;
+  }
+};
+
+using FastLauncher = void (*)(const FastArgs&, int grid, size_t ldsBytes);
+
+template <typename S>
+void launchFast(const FastArgs& fa, int grid, size_t ldsBytes) {
+  VX_LAUNCH("k_agg_fast", k_agg_fast<S>, grid, 512, ldsBytes, fa);
+}
+
+struct FastEntry {
+  FastSignature sig;
+  int unroll;
+  FastLauncher launch;
+};
+
+#define VX_FAST_ENTRY(U, K0, K1, T0, T1, NL, NA, LO, HI)                                      \
+  FastEntry {                                                                                 \
+    FastSignature{K0, K1, T0, T1, NL, NA, LO, HI}, U,                                         \
+        &launchFast<FastShape<U, K0, K1, T0, T1, NL, NA, LO, HI>>                             \
+  }
+
+// Ahead-of-time shapes. Accumulators appear in the order buildPlan creates
+// them (aliased counts excluded).
+//  * TPC-H Q1, fused FilterProject + HashAggregation (TpchQueryBuilder.cpp
+//    :203-252): keys l_returnflag, l_linestatus; filter l_shipdate (DATE);
+//    loads qty=0, ep=1, disc=2, tax=3; sum(qty), count(*), sum(ep),
+//    sum(ep*(1-disc)), sum(ep*(1-disc)*(1+tax)), sum(disc).
+//  * BASELINE config 1: k BIGINT; sum(v), count(*).
+//  * one INTEGER / BIGINT key with sum + count and an INTEGER filter (Q1-like
+//    plans over dictionary-encoded flags).
+constexpr uint64_t kQ1Lo = packAccs(accDesc(1, 0), accDesc(0), accDesc(1, 1), accDesc(2, 1, 2));
+constexpr uint64_t kQ1Hi = packAccs(accDesc(3, 1, 2, 3), accDesc(1, 2));
+constexpr uint64_t kC1Lo = packAccs(accDesc(1, 0), accDesc(0));
+const FastEntry kFastTable[] = {
+    VX_FAST_ENTRY(2, FK_VIEW, FK_VIEW, FK_I32, FK_NONE, 4, 6, kQ1Lo, kQ1Hi),
+    VX_FAST_ENTRY(4, FK_VIEW, FK_VIEW, FK_I32, FK_NONE, 4, 6, kQ1Lo, kQ1Hi),
+    VX_FAST_ENTRY(2, FK_I64, FK_NONE, FK_NONE, FK_NONE, 1, 2, kC1Lo, 0),
+    VX_FAST_ENTRY(4, FK_I64, FK_NONE, FK_NONE, FK_NONE, 1, 2, kC1Lo, 0),
+    VX_FAST_ENTRY(4, FK_I32, FK_NONE, FK_NONE, FK_NONE, 1, 2, kC1Lo, 0),
+    VX_FAST_ENTRY(4, FK_I64, FK_NONE, FK_I32, FK_NONE, 1, 2, kC1Lo, 0),
+};
 
 // ---- key statistics of the first rows (VectorHasher::analyze) ---------------
 struct StatsArgs {
@@ -1312,6 +1343,7 @@ struct vx355_agg {
   uint64_t arrayMax = 1ULL << 28;
   int64_t chunkRows = 1LL << 31;
   bool disableFast = false;
+  bool logShapes = false;
   int64_t deferCap = 1 << 20;
   int fastUnroll = 2;
 
@@ -1675,120 +1707,139 @@ bool chooseLds(const vx355_agg& h, int numAccs, LdsPlan* plan, size_t* ldsBytes)
   return true;
 }
 
-// Maps a launch onto the fast kernel's restricted plan shape; false = use the
-// generic kernel.
-bool buildFastArgs(const AggArgs& c, const LdsPlan& plan, FastArgs* f) {
-  if (c.rowList || c.rescanOld || c.numKeys < 1 || c.numKeys > kFastKeys || c.numTerms > kFastTerms ||
-      c.numAccs > kFastAccs) {
+// Maps a launch onto the shape-specialised kernel: fills the runtime arguments
+// and the shape signature; false = the plan is outside the fast class.
+bool buildFastArgs(const AggArgs& c, const LdsPlan& plan, FastArgs* f, FastSignature* sig) {
+  if (c.rowList || c.rescanOld || c.numKeys < 1 || c.numKeys > kFastKeys ||
+      c.numTerms > kFastTerms || c.numAccs > kFastAccs) {
     return false;
   }
   auto flatNoNulls = [](const ColView& v) { return v.enc == VX355_FLAT && v.nulls == nullptr; };
   *f = FastArgs{};
+  *sig = FastSignature{};
   for (int k = 0; k < c.numKeys; ++k) {
     const ColView& v = c.keys[k].col;
     if (!flatNoNulls(v)) {
       return false;
     }
+    int kind;
     if (isString(v.kind)) {
-      f->keyKind[k] = FK_VIEW;
+      kind = FK_VIEW;
     } else if (v.kind == VX355_INTEGER) {
-      f->keyKind[k] = FK_I32;
+      kind = FK_I32;
     } else if (v.kind == VX355_BIGINT) {
-      f->keyKind[k] = FK_I64;
+      kind = FK_I64;
     } else {
       return false;
     }
+    (k == 0 ? sig->k0 : sig->k1) = kind;
     f->keyPtr[k] = v.values;
     f->range[k] = c.keys[k].range;
   }
-  f->numKeys = c.numKeys;
   for (int t = 0; t < c.numTerms; ++t) {
     const TermArg& ta = c.terms[t];
     if (!flatNoNulls(ta.col)) {
       return false;
     }
-    FastTerm& ft = f->term[t];
+    int kind;
     if (ta.constKind == VX355_BIGINT && ta.col.kind == VX355_INTEGER) {
-      ft.kind = FK_I32;
+      // The kernel compares in 32 bits: a constant outside int32 would wrap.
+      if (ta.i64 < INT32_MIN || ta.i64 > INT32_MAX) {
+        return false;
+      }
+      kind = FK_I32;
     } else if (ta.constKind == VX355_BIGINT && ta.col.kind == VX355_BIGINT) {
-      ft.kind = FK_I64;
+      kind = FK_I64;
     } else if (ta.constKind == VX355_DOUBLE && ta.col.kind == VX355_DOUBLE) {
-      ft.kind = FK_F64;
+      kind = FK_F64;
     } else {
       return false;
     }
-    ft.ptr = ta.col.values;
-    ft.cmp = ta.cmp;
-    ft.i64 = ta.i64;
-    ft.f64 = ta.f64;
+    (t == 0 ? sig->t0 : sig->t1) = kind;
+    f->term[t].ptr = ta.col.values;
+    f->term[t].cmp = ta.cmp;
+    f->term[t].i64 = ta.i64;
+    f->term[t].f64 = ta.f64;
   }
-  f->numTerms = c.numTerms;
-  auto colSlot = [&](const ColView& v) -> int {
+  auto loadSlot = [&](const ColView& v) -> int {
     if (!flatNoNulls(v) || v.kind != VX355_DOUBLE) {
       return -1;
     }
-    for (int j = 0; j < f->numCols; ++j) {
-      if (f->col[j] == v.values) {
+    for (int j = 0; j < sig->numLoads; ++j) {
+      if (f->loadPtr[j] == v.values) {
         return j;
       }
     }
-    if (f->numCols == kFastCols) {
+    if (sig->numLoads == kFastLoads) {
       return -1;
     }
-    f->col[f->numCols] = static_cast<const double*>(v.values);
-    return f->numCols++;
+    f->loadPtr[sig->numLoads] = static_cast<const double*>(v.values);
+    return sig->numLoads++;
   };
   for (int j = 0; j < c.numAccs; ++j) {
     const AccArg& ac = c.accs[j];
     if (ac.hasMask) {
       return false;
     }
+    uint64_t desc;
     if (ac.kind == ACC_COUNT && !ac.hasIn && ac.inProj < 0) {
-      f->accVal[j] = -1;
-      continue;
-    }
-    if (ac.kind != ACC_SUM_F64 || f->numVals == kFastVals) {
+      desc = accDesc(0);
+    } else if (ac.kind != ACC_SUM_F64) {
       return false;
-    }
-    FastVal& fv = f->val[f->numVals];
-    if (ac.inProj >= 0) {
+    } else if (ac.inProj >= 0) {
       const ProjectionArg& pa = c.proj[ac.inProj];
       if (pa.numFactors > kFastFactors) {
         return false;
       }
-      fv.numFactors = pa.numFactors;
+      int l[kFastFactors] = {15, 15, 15};
       for (int q = 0; q < pa.numFactors; ++q) {
-        fv.f[q].scale = pa.factors[q].scale;
-        fv.f[q].offset = pa.factors[q].offset;
-        fv.f[q].col = -1;
+        f->scale[j][q] = pa.factors[q].scale;
+        f->offset[j][q] = pa.factors[q].offset;
         if (pa.factors[q].hasCol) {
-          const int slot = colSlot(pa.factors[q].col);
-          if (slot < 0) {
+          l[q] = loadSlot(pa.factors[q].col);
+          if (l[q] < 0) {
             return false;
           }
-          fv.f[q].col = slot;
         }
       }
+      desc = accDesc(pa.numFactors, l[0], l[1], l[2]);
     } else {
       if (!ac.hasIn) {
         return false;
       }
-      const int slot = colSlot(ac.in);
+      const int slot = loadSlot(ac.in);
       if (slot < 0) {
         return false;
       }
-      fv.numFactors = 1;
-      fv.f[0].col = slot;
-      fv.f[0].scale = 1.0;
-      fv.f[0].offset = 0.0;
+      f->scale[j][0] = 1.0;
+      f->offset[j][0] = 0.0;
+      desc = accDesc(1, slot);
     }
-    f->accVal[j] = f->numVals++;
+    if (j < 4) {
+      sig->accLo |= desc << (16 * j);
+    } else {
+      sig->accHi |= desc << (16 * (j - 4));
+    }
   }
+  sig->numAccs = c.numAccs;
   f->numRows = c.numRows;
   f->deferred = c.deferred;
   f->deferCap = c.deferCap;
   f->plan = plan;
   return true;
+}
+
+const FastEntry* findFastEntry(const FastSignature& sig, int unroll) {
+  const FastEntry* any = nullptr;
+  for (const auto& e : kFastTable) {
+    if (e.sig == sig) {
+      if (e.unroll == unroll) {
+        return &e;
+      }
+      any = &e;
+    }
+  }
+  return any;
 }
 
 void fillAccArgs(vx355_agg& h, const DeviceBatch& db, AggArgs* a) {
@@ -1884,17 +1935,27 @@ void launchChunk(vx355_agg& h, AggArgs& a) {
       plan.off[j] = a.accs[j].off;
     }
     FastArgs fa;
-    if (!h.disableFast && buildFastArgs(a, plan, &fa)) {
-      const int kUnroll = h.fastUnroll;
-      const int blocksPerCu = std::max<int>(1, std::min<int>(4, static_cast<int>((150 * 1024) / ldsBytes)));
-      int grid = static_cast<int>(
-          std::min<int64_t>(ceilDiv(a.numRows, 512 * kUnroll), static_cast<int64_t>(rt.numCUs) * blocksPerCu));
-      if (kUnroll == 4) {
-        VX_LAUNCH("k_agg_fast", k_agg_fast<4>, grid, 512, ldsBytes, fa);
-      } else {
-        VX_LAUNCH("k_agg_fast", k_agg_fast<2>, grid, 512, ldsBytes, fa);
+    FastSignature sig;
+    if (!h.disableFast && buildFastArgs(a, plan, &fa, &sig)) {
+      if (const FastEntry* e = findFastEntry(sig, h.fastUnroll)) {
+        const int blocksPerCu =
+            std::max<int>(1, std::min<int>(4, static_cast<int>((150 * 1024) / ldsBytes)));
+        // Enough rows per workgroup that the LDS flush (slots x accumulators HBM
+        // atomics) stays a small fraction of the work.
+        const int64_t minRowsPerBlock = std::max<int64_t>(512 * e->unroll, 64LL * plan.S * plan.A);
+        int grid = static_cast<int>(std::max<int64_t>(
+            1, std::min<int64_t>(ceilDiv(a.numRows, minRowsPerBlock),
+                                 static_cast<int64_t>(rt.numCUs) * blocksPerCu)));
+        e->launch(fa, grid, ldsBytes);
+        return;
       }
-      return;
+      if (h.logShapes) {
+        fprintf(stderr,
+                "vx355: no specialised kernel for shape k=(%d,%d) t=(%d,%d) loads=%d accs=%d "
+                "lo=0x%llx hi=0x%llx\n",
+                sig.k0, sig.k1, sig.t0, sig.t1, sig.numLoads, sig.numAccs,
+                static_cast<unsigned long long>(sig.accLo), static_cast<unsigned long long>(sig.accHi));
+      }
     }
     la.a = a;
     int grid = static_cast<int>(std::min<int64_t>(ceilDiv(a.numRows, 1024), rt.numCUs * 2));
@@ -2240,6 +2301,9 @@ int vx355_agg_create(const vx355_agg_spec* spec, vx355_agg** out) {
   h->ignoreNullKeys = spec->ignore_null_keys != 0;
   if (const char* e = std::getenv("VX355_ARRAY_MAX")) {
     h->arrayMax = std::strtoull(e, nullptr, 10);
+  }
+  if (const char* e = std::getenv("VX355_LOG_SHAPES")) {
+    h->logShapes = e[0] == '1';
   }
   if (const char* e = std::getenv("VX355_AGG_DEFER_CAP")) {
     h->deferCap = std::max<int64_t>(1, std::strtoll(e, nullptr, 10));
