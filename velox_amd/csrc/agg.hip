@@ -957,10 +957,19 @@ __global__ __launch_bounds__(256) void k_key_stats(StatsArgs a) {
       mx[k] = v > mx[k] ? v : mx[k];
     }
   }
+  // One pair of atomics per wave, not per lane.
   for (int k = 0; k < a.numKeys; ++k) {
-    if (mn[k] <= mx[k]) {
-      atomicMin(reinterpret_cast<long long*>(&a.counters->keyMin[k]), static_cast<long long>(mn[k]));
-      atomicMax(reinterpret_cast<long long*>(&a.counters->keyMax[k]), static_cast<long long>(mx[k]));
+    int64_t lo = mn[k], hi = mx[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const int64_t olo = static_cast<int64_t>(shfl64(static_cast<uint64_t>(lo), lane() ^ off));
+      const int64_t ohi = static_cast<int64_t>(shfl64(static_cast<uint64_t>(hi), lane() ^ off));
+      lo = olo < lo ? olo : lo;
+      hi = ohi > hi ? ohi : hi;
+    }
+    if (lane() == 0 && lo <= hi) {
+      atomicMin(reinterpret_cast<long long*>(&a.counters->keyMin[k]), static_cast<long long>(lo));
+      atomicMax(reinterpret_cast<long long*>(&a.counters->keyMax[k]), static_cast<long long>(hi));
     }
   }
   if (unmappable) {
@@ -1942,7 +1951,7 @@ void launchChunk(vx355_agg& h, AggArgs& a) {
             std::max<int>(1, std::min<int>(4, static_cast<int>((150 * 1024) / ldsBytes)));
         // Enough rows per workgroup that the LDS flush (slots x accumulators HBM
         // atomics) stays a small fraction of the work.
-        const int64_t minRowsPerBlock = std::max<int64_t>(512 * e->unroll, 64LL * plan.S * plan.A);
+        const int64_t minRowsPerBlock = std::max<int64_t>(512 * e->unroll, 4LL * plan.S * plan.A);
         int grid = static_cast<int>(std::max<int64_t>(
             1, std::min<int64_t>(ceilDiv(a.numRows, minRowsPerBlock),
                                  static_cast<int64_t>(rt.numCUs) * blocksPerCu)));
