@@ -1354,7 +1354,7 @@ struct vx355_agg {
   bool disableFast = false;
   bool logShapes = false;
   int64_t deferCap = 1 << 20;
-  int fastUnroll = 2;
+  int fastUnroll = 4;
 
   Counters* counters() { return countersBuf.as<Counters>(); }
 };
@@ -2318,7 +2318,7 @@ int vx355_agg_create(const vx355_agg_spec* spec, vx355_agg** out) {
     h->deferCap = std::max<int64_t>(1, std::strtoll(e, nullptr, 10));
   }
   if (const char* e = std::getenv("VX355_AGG_FAST_UNROLL")) {
-    h->fastUnroll = std::atoi(e) == 4 ? 4 : 2;
+    h->fastUnroll = std::atoi(e) == 2 ? 2 : 4;
   }
   if (const char* e = std::getenv("VX355_AGG_NO_FAST")) {
     h->disableFast = e[0] == '1';
