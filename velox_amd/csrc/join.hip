@@ -186,12 +186,17 @@ struct InsertArgs {
   int32_t numKeys;
   int32_t mode;
   int64_t numRows;
-  uint32_t* head;   // array mode
-  Slot* slots;      // hash mode
+  uint32_t* head;     // array mode (NOT initialised: 'present' says which entries are live)
+  uint32_t* present;  // array mode: one bit per possible key
+  Slot* slots;        // hash mode
   uint64_t capacity;
   uint32_t* next;
+  int32_t phase;      // array mode: 1 = claim keys, 2 = chain the duplicates
+  int32_t pad;
   BuildCounters* counters;
 };
+
+constexpr uint32_t kPendingRow = 0xfffffffeu;
 
 __device__ inline uint64_t buildKey(const InsertArgs& a, int64_t row) {
   uint64_t key = 0;
@@ -203,38 +208,58 @@ __device__ inline uint64_t buildKey(const InsertArgs& a, int64_t row) {
   return key;
 }
 
+// Array mode never initialises the (possibly multi-GB) head array: phase 1
+// claims each key with one atomicOr on a presence bitmap that is 32x smaller
+// than the head array (and is what the probe consults first), the winner
+// stores its row as chain head; phase 2, launched only when duplicates exist,
+// pushes the other rows in front (HashTable.cpp:1394-1409 arrayPushRow).
 __global__ __launch_bounds__(256) void k_join_insert(InsertArgs a) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   uint32_t dups = 0, distinct = 0;
   for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < a.numRows;
        row += stride) {
+    if (a.mode == JMODE_ARRAY) {
+      if (a.phase == 1) {
+        const uint64_t key = buildKey(a, row);
+        const uint32_t bit = 1u << (key & 31);
+        const uint32_t prev = atomicOr(a.present + (key >> 5), bit);
+        if (!(prev & bit)) {
+          a.head[key] = static_cast<uint32_t>(row);
+          a.next[row] = kNoRow32;
+          ++distinct;
+        } else {
+          a.next[row] = kPendingRow;
+          ++dups;
+        }
+      } else if (a.next[row] == kPendingRow) {
+        const uint64_t key = buildKey(a, row);
+        a.next[row] = atomicExch(a.head + key, static_cast<uint32_t>(row));
+      }
+      continue;
+    }
     const uint64_t key = buildKey(a, row);
     uint32_t* headWord = nullptr;
-    if (a.mode == JMODE_ARRAY) {
-      headWord = a.head + key;
-    } else {
-      const uint64_t mask = a.capacity - 1;
-      uint64_t pos = twangMix64(key) & mask;
-      for (uint64_t probes = 0; probes <= mask; ++probes) {
-        Slot* s = a.slots + pos;
-        uint64_t k = __hip_atomic_load(&s->key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (k == kEmptyKey) {
-          unsigned long long old =
-              atomicCAS(reinterpret_cast<unsigned long long*>(&s->key), kEmptyKey, key);
-          k = old == kEmptyKey ? key : old;
-        }
-        if (k == key) {
-          headWord = &s->head;
-          break;
-        }
-        pos = (pos + 1) & mask;
+    const uint64_t mask = a.capacity - 1;
+    uint64_t pos = twangMix64(key) & mask;
+    for (uint64_t probes = 0; probes <= mask; ++probes) {
+      Slot* s = a.slots + pos;
+      uint64_t k = __hip_atomic_load(&s->key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (k == kEmptyKey) {
+        unsigned long long old =
+            atomicCAS(reinterpret_cast<unsigned long long*>(&s->key), kEmptyKey, key);
+        k = old == kEmptyKey ? key : old;
       }
-      if (!headWord) {
-        a.counters->tableFull = 1;
-        continue;
+      if (k == key) {
+        headWord = &s->head;
+        break;
       }
+      pos = (pos + 1) & mask;
     }
-    // pushNext / arrayPushRow: the new row becomes the chain head.
+    if (!headWord) {
+      a.counters->tableFull = 1;
+      continue;
+    }
+    // pushNext: the new row becomes the chain head.
     const uint32_t old = atomicExch(headWord, static_cast<uint32_t>(row));
     a.next[row] = old;
     if (old == kNoRow32) {
@@ -270,6 +295,9 @@ __global__ __launch_bounds__(256) void k_fill_slots(Slot* p, uint64_t n) {
 }
 
 // ---- probe -------------------------------------------------------------------------
+constexpr int kTileRows = 8192;  // probe rows per workgroup tile (256 lanes x 32)
+constexpr int kProbeUnroll = 4;
+
 struct ProbeArgs {
   ColView keys[kMaxKeys];
   KeyRange ranges[kMaxKeys];
@@ -278,12 +306,17 @@ struct ProbeArgs {
   int32_t hasDuplicates;
   int32_t joinType;
   int64_t numRows;
+  int64_t numTiles;
   const uint32_t* head;
+  const uint32_t* present;
   const Slot* slots;
   uint64_t capacity;
   const uint32_t* next;
-  uint32_t* hits;    // first matching build row or kNoRow32
-  uint32_t* counts;  // output rows this probe row produces
+  uint32_t* hits;       // first matching build row or kNoRow32
+  uint32_t* counts;     // output rows per probe row; only kept for duplicate tables
+  uint64_t* tileSums;   // output rows per tile
+  int32_t fastKey;      // 1: single flat non-null BIGINT key (FK of TPC-H joins)
+  int32_t pad;
 };
 
 __device__ inline uint32_t outputCount(int32_t joinType, uint32_t matches) {
@@ -299,89 +332,137 @@ __device__ inline uint32_t outputCount(int32_t joinType, uint32_t matches) {
   }
 }
 
-// HashTable::joinProbe: hits[row] = first build row with an equal key.
-__global__ __launch_bounds__(256) void k_join_probe(ProbeArgs a) {
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < a.numRows;
-       row += stride) {
-    uint64_t key = 0;
-    bool miss = false;
-    for (int k = 0; k < a.numKeys; ++k) {
-      const ColView& c = a.keys[k];
-      if (colIsNull(c, row)) {
-        miss = true;  // a null key never matches (HashProbe.cpp:778)
-        break;
-      }
-      int64_t v;
-      bool mappable;
-      const uint64_t id = valueIdAt(c, colIndex(c, row), a.ranges[k], &v, &mappable);
-      if (id == 0) {
-        miss = true;  // outside the build side's range: proven miss
-        break;
-      }
-      key += a.ranges[k].multiplier * id;
+// Normalized key of a probe row with lookupValueIds semantics: false = proven
+// miss (null key, or a value outside the build side's range).
+__device__ inline bool probeKey(const ProbeArgs& a, int64_t row, uint64_t* keyOut) {
+  uint64_t key = 0;
+  for (int k = 0; k < a.numKeys; ++k) {
+    const ColView& c = a.keys[k];
+    if (colIsNull(c, row)) {
+      return false;  // a null key never matches (HashProbe.cpp:778)
     }
-    uint32_t hit = kNoRow32;
-    if (!miss) {
-      if (a.mode == JMODE_ARRAY) {
-        hit = a.head[key];
+    int64_t v;
+    bool mappable;
+    const uint64_t id = valueIdAt(c, colIndex(c, row), a.ranges[k], &v, &mappable);
+    if (id == 0) {
+      return false;
+    }
+    key += a.ranges[k].multiplier * id;
+  }
+  *keyOut = key;
+  return true;
+}
+
+__device__ inline uint32_t lookupSlots(const ProbeArgs& a, uint64_t key) {
+  const uint64_t mask = a.capacity - 1;
+  uint64_t pos = twangMix64(key) & mask;
+  for (uint64_t probes = 0; probes <= mask; ++probes) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(a.slots + pos);
+    const uint64_t k = (static_cast<uint64_t>(raw.y) << 32) | raw.x;
+    if (k == key) {
+      return raw.z;
+    }
+    if (k == kEmptyKey) {
+      return kNoRow32;
+    }
+    pos = (pos + 1) & mask;
+  }
+  return kNoRow32;
+}
+
+// HashTable::joinProbe: hits[row] = first build row with an equal key. One
+// workgroup per tile of 8192 consecutive probe rows; each lane keeps
+// kProbeUnroll independent probes in flight: all key loads, then all presence
+// bits (a bitmap 32x smaller than the head array, Infinity-Cache resident for
+// TPC-H sized builds), then the head words of the survivors only. The tile's
+// output-row count falls out of the same pass (listJoinResults needs it).
+__global__ __launch_bounds__(256) void k_join_probe(ProbeArgs a) {
+  __shared__ uint64_t waveSums[4];
+  for (int64_t tile = blockIdx.x; tile < a.numTiles; tile += gridDim.x) {
+    const int64_t tileBase = tile * kTileRows;
+    uint64_t mine = 0;
+    for (int it = 0; it < kTileRows / (256 * kProbeUnroll); ++it) {
+      int64_t rows[kProbeUnroll];
+      uint64_t key[kProbeUnroll];
+      bool candidate[kProbeUnroll];
+      uint32_t hit[kProbeUnroll];
+#pragma unroll
+      for (int u = 0; u < kProbeUnroll; ++u) {
+        rows[u] = tileBase + (it * kProbeUnroll + u) * 256 + threadIdx.x;
+      }
+      if (a.fastKey) {
+        const int64_t* kp = static_cast<const int64_t*>(a.keys[0].values);
+        int64_t v[kProbeUnroll];
+#pragma unroll
+        for (int u = 0; u < kProbeUnroll; ++u) {
+          v[u] = kp[rows[u] < a.numRows ? rows[u] : a.numRows - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < kProbeUnroll; ++u) {
+          candidate[u] = rows[u] < a.numRows && v[u] >= a.ranges[0].min && v[u] <= a.ranges[0].max;
+          key[u] = static_cast<uint64_t>(v[u]) - static_cast<uint64_t>(a.ranges[0].min) + 1;
+        }
       } else {
-        const uint64_t mask = a.capacity - 1;
-        uint64_t pos = twangMix64(key) & mask;
-        for (uint64_t probes = 0; probes <= mask; ++probes) {
-          const uint4 raw = *reinterpret_cast<const uint4*>(a.slots + pos);
-          const uint64_t k = (static_cast<uint64_t>(raw.y) << 32) | raw.x;
-          if (k == key) {
-            hit = raw.z;
-            break;
+#pragma unroll
+        for (int u = 0; u < kProbeUnroll; ++u) {
+          candidate[u] = rows[u] < a.numRows && probeKey(a, rows[u], &key[u]);
+        }
+      }
+      if (a.mode == JMODE_ARRAY) {
+        uint32_t word[kProbeUnroll];
+#pragma unroll
+        for (int u = 0; u < kProbeUnroll; ++u) {
+          word[u] = candidate[u] ? a.present[key[u] >> 5] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < kProbeUnroll; ++u) {
+          candidate[u] = (word[u] >> (key[u] & 31)) & 1;
+        }
+#pragma unroll
+        for (int u = 0; u < kProbeUnroll; ++u) {
+          hit[u] = candidate[u] ? a.head[key[u]] : kNoRow32;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < kProbeUnroll; ++u) {
+          hit[u] = candidate[u] ? lookupSlots(a, key[u]) : kNoRow32;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kProbeUnroll; ++u) {
+        if (rows[u] < a.numRows) {
+          a.hits[rows[u]] = hit[u];
+          uint32_t matches = hit[u] == kNoRow32 ? 0 : 1;
+          if (a.counts) {
+            if (matches && (a.joinType == VX355_JOIN_INNER || a.joinType == VX355_JOIN_LEFT)) {
+              uint32_t r = a.next[hit[u]];
+              while (r != kNoRow32) {
+                ++matches;
+                r = a.next[r];
+              }
+            }
+            a.counts[rows[u]] = outputCount(a.joinType, matches);
           }
-          if (k == kEmptyKey) {
-            break;
-          }
-          pos = (pos + 1) & mask;
+          mine += outputCount(a.joinType, matches);
         }
       }
     }
-    a.hits[row] = hit;
-    uint32_t matches = hit == kNoRow32 ? 0 : 1;
-    if (matches && a.hasDuplicates && (a.joinType == VX355_JOIN_INNER || a.joinType == VX355_JOIN_LEFT)) {
-      uint32_t r = a.next[hit];
-      while (r != kNoRow32) {
-        ++matches;
-        r = a.next[r];
-      }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mine += shfl64(mine, lane() ^ off);
     }
-    a.counts[row] = outputCount(a.joinType, matches);
+    if (lane() == 0) {
+      waveSums[threadIdx.x >> 6] = mine;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      a.tileSums[tile] = waveSums[0] + waveSums[1] + waveSums[2] + waveSums[3];
+    }
+    __syncthreads();
   }
 }
 
 // ---- listJoinResults -------------------------------------------------------------------
-constexpr int kTileRows = 2048;  // 256 threads x 8 rows
-
-__global__ __launch_bounds__(256) void k_tile_sums(const uint32_t* counts, int64_t numRows,
-                                                    uint64_t* tileSums) {
-  __shared__ uint64_t partial[4];
-  const int64_t base = static_cast<int64_t>(blockIdx.x) * kTileRows;
-  uint64_t s = 0;
-  for (int j = 0; j < 8; ++j) {
-    const int64_t r = base + j * 256 + threadIdx.x;
-    if (r < numRows) {
-      s += counts[r];
-    }
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    s += shfl64(s, lane() ^ off);
-  }
-  if (lane() == 0) {
-    partial[threadIdx.x >> 6] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    tileSums[blockIdx.x] = partial[0] + partial[1] + partial[2] + partial[3];
-  }
-}
-
 // Single-block exclusive scan; offsets has n + 1 entries (last = total).
 __global__ __launch_bounds__(1024) void k_scan_u64(const uint64_t* in, int64_t n, uint64_t* offsets) {
   __shared__ uint64_t partial[1024];
@@ -413,7 +494,7 @@ __global__ __launch_bounds__(1024) void k_scan_u64(const uint64_t* in, int64_t n
 
 struct EmitArgs {
   const uint32_t* hits;
-  const uint32_t* counts;
+  const uint32_t* counts;  // nullptr: derive from hits (no duplicate chains)
   const uint32_t* next;
   const uint64_t* tileOffsets;
   int64_t numRows;
@@ -425,63 +506,68 @@ struct EmitArgs {
   int32_t* buildRows;
 };
 
-// Each block owns one tile of probe rows: an in-tile exclusive scan of the
-// counts gives every row its output offset; rows intersecting the window write
-// their pairs. Probe rows ascend with the offsets, so the output is in
-// ascending probe-row order with all matches of a row contiguous.
+// Each block owns one tile of probe rows and walks it in 256-row steps: a block
+// scan of the per-row output counts gives every row its output offset; rows
+// intersecting the window write their pairs. Probe rows ascend with the
+// offsets, so the output is in ascending probe-row order with all matches of a
+// row contiguous.
 __global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
   __shared__ uint64_t waveTotals[4];
+  __shared__ uint64_t running;
   const int64_t tile = a.firstTile + blockIdx.x;
-  const int64_t base = tile * kTileRows + static_cast<int64_t>(threadIdx.x) * 8;
-  uint32_t cnt[8];
-  uint64_t mine = 0;
-  for (int j = 0; j < 8; ++j) {
-    const int64_t r = base + j;
-    cnt[j] = r < a.numRows ? a.counts[r] : 0;
-    mine += cnt[j];
-  }
-  // Exclusive scan of 'mine' across the block (thread t owns 8 consecutive rows).
-  uint64_t incl = mine;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    uint64_t v = shfl64(incl, lane() - off >= 0 ? lane() - off : lane());
-    if (lane() >= off) {
-      incl += v;
-    }
-  }
-  if (lane() == 63) {
-    waveTotals[threadIdx.x >> 6] = incl;
+  if (threadIdx.x == 0) {
+    running = a.tileOffsets[tile];
   }
   __syncthreads();
-  uint64_t off = a.tileOffsets[tile] + (incl - mine);
-  for (int w = 0; w < (threadIdx.x >> 6); ++w) {
-    off += waveTotals[w];
-  }
-  for (int j = 0; j < 8; ++j) {
-    const uint32_t c = cnt[j];
-    if (c == 0) {
-      continue;
+  for (int step = 0; step < kTileRows / 256; ++step) {
+    const int64_t r = tile * kTileRows + step * 256 + threadIdx.x;
+    uint32_t hit = kNoRow32;
+    uint32_t c = 0;
+    if (r < a.numRows) {
+      hit = a.hits[r];
+      c = a.counts ? a.counts[r] : outputCount(a.joinType, hit == kNoRow32 ? 0 : 1);
     }
-    const uint64_t lo = off, hi = off + c;
-    off = hi;
-    if (hi <= a.windowBegin || lo >= a.windowEnd) {
-      continue;
+    uint64_t incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      uint64_t v = shfl64(incl, lane() - off >= 0 ? lane() - off : lane());
+      if (lane() >= off) {
+        incl += v;
+      }
     }
-    const int64_t r = base + j;
-    const uint32_t hit = a.hits[r];
-    const bool listMatches = hit != kNoRow32 &&
-        (a.joinType == VX355_JOIN_INNER || a.joinType == VX355_JOIN_LEFT);
-    uint32_t b = hit;
-    for (uint64_t p = lo; p < hi && p < a.windowEnd; ++p) {
-      if (p >= a.windowBegin) {
-        a.mapping[p - a.windowBegin] = static_cast<int32_t>(r);
-        if (a.buildRows) {
-          a.buildRows[p - a.windowBegin] = listMatches ? static_cast<int32_t>(b) : -1;
+    if (lane() == 63) {
+      waveTotals[threadIdx.x >> 6] = incl;
+    }
+    __syncthreads();
+    uint64_t lo = running + (incl - c);
+    for (int w = 0; w < (threadIdx.x >> 6); ++w) {
+      lo += waveTotals[w];
+    }
+    const uint64_t stepTotal = waveTotals[0] + waveTotals[1] + waveTotals[2] + waveTotals[3];
+    const uint64_t hi = lo + c;
+    if (c != 0 && hi > a.windowBegin && lo < a.windowEnd) {
+      const bool listMatches = hit != kNoRow32 &&
+          (a.joinType == VX355_JOIN_INNER || a.joinType == VX355_JOIN_LEFT);
+      uint32_t b = hit;
+      for (uint64_t p = lo; p < hi && p < a.windowEnd; ++p) {
+        if (p >= a.windowBegin) {
+          a.mapping[p - a.windowBegin] = static_cast<int32_t>(r);
+          if (a.buildRows) {
+            a.buildRows[p - a.windowBegin] = listMatches ? static_cast<int32_t>(b) : -1;
+          }
+        }
+        if (listMatches) {
+          b = a.next[b];
         }
       }
-      if (listMatches) {
-        b = a.next[b];
-      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      running += stepTotal;
+    }
+    __syncthreads();
+    if (running >= a.windowEnd) {
+      break;  // uniform: 'running' is shared
     }
   }
 }
@@ -574,7 +660,8 @@ struct vx355_join_table {
   std::vector<int32_t> keyKinds, depKinds;
   std::vector<KeyRange> ranges;
   uint64_t capacity = 0;
-  DevBuf head;   // array mode: u32[capacity]
+  DevBuf head;   // array mode: u32[capacity], only entries whose presence bit is set are valid
+  DevBuf present;  // array mode: bit per possible key
   DevBuf slots;  // hash mode: Slot[capacity]
   DevBuf next;   // u32[numRows]
   std::vector<DevBuf> depVals, depValid;
@@ -595,6 +682,7 @@ struct vx355_join_probe {
   uint64_t totalOut = 0;
   uint64_t cursor = 0;
   bool hasInput = false;
+  bool haveCounts = false;
 };
 
 namespace vx {
@@ -804,9 +892,12 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
     t->mode = JMODE_ARRAY;
     t->capacity = range;
     t->head.ensure(static_cast<size_t>(range) * 4 + 64);
-    VX_LAUNCH("k_fill_u32", k_fill_u32, streamGrid(static_cast<int64_t>(range), 256, 4), 256, 0,
-              t->head.as<uint32_t>(), range, kNoRow32);
+    const uint64_t words = (range + 31) / 32;
+    t->present.ensure(static_cast<size_t>(words) * 4 + 64);
+    VX_LAUNCH("k_fill_u32", k_fill_u32, streamGrid(static_cast<int64_t>(words), 256, 4), 256, 0,
+              t->present.as<uint32_t>(), words, 0u);
     ia.head = t->head.as<uint32_t>();
+    ia.present = t->present.as<uint32_t>();
   } else {
     t->mode = JMODE_NORMALIZED;
     // HashTable::newHashTableEntries (HashTable.h:946-956).
@@ -819,12 +910,18 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
   }
   ia.mode = t->mode;
   ia.capacity = t->capacity;
+  ia.phase = 1;
   if (h.numRows > 0) {
     VX_LAUNCH("k_join_insert", k_join_insert, streamGrid(h.numRows, 256), 256, 0, ia);
   }
   BuildCounters c = readBuildCounters(h.countersBuf);
   if (c.tableFull) {
     VX_THROW(VX355_EINTERNAL, "join table full");
+  }
+  if (t->mode == JMODE_ARRAY && c.duplicates) {
+    ia.phase = 2;
+    VX_LAUNCH("k_join_insert", k_join_insert, streamGrid(h.numRows, 256), 256, 0, ia);
+    rt.sync();
   }
   t->numDistinct = c.numDistinct;
   t->hasDuplicates = c.duplicates != 0;
@@ -868,15 +965,25 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
   a.slots = t.slots.as<Slot>();
   a.capacity = t.capacity;
   a.next = t.next.as<uint32_t>();
+  a.present = t.present.as<uint32_t>();
   a.hits = static_cast<uint32_t*>(p.hits.ensure(static_cast<size_t>(n) * 4 + 64));
-  a.counts = static_cast<uint32_t*>(p.counts.ensure(static_cast<size_t>(n) * 4 + 64));
-  VX_LAUNCH("k_join_probe", k_join_probe, streamGrid(n, 256), 256, 0, a);
-  // Offsets for listJoinResults.
+  // Per-row output counts are only materialised when chains can be longer than
+  // one row; otherwise listJoinResults derives them from the hit.
+  p.haveCounts = t.hasDuplicates && (p.joinType == VX355_JOIN_INNER || p.joinType == VX355_JOIN_LEFT);
+  a.counts = p.haveCounts ? static_cast<uint32_t*>(p.counts.ensure(static_cast<size_t>(n) * 4 + 64))
+                          : nullptr;
   p.numTiles = ceilDiv(n, kTileRows);
+  a.numTiles = p.numTiles;
   uint64_t* sums = static_cast<uint64_t*>(p.tileSums.ensure(static_cast<size_t>(p.numTiles) * 8 + 64));
   uint64_t* offs =
       static_cast<uint64_t*>(p.tileOffsets.ensure(static_cast<size_t>(p.numTiles + 1) * 8 + 64));
-  VX_LAUNCH("k_tile_sums", k_tile_sums, static_cast<int>(p.numTiles), 256, 0, a.counts, n, sums);
+  a.tileSums = sums;
+  a.fastKey = (a.numKeys == 1 && a.keys[0].kind == VX355_BIGINT && a.keys[0].enc == VX355_FLAT &&
+               a.keys[0].nulls == nullptr && a.ranges[0].multiplier == 1)
+      ? 1
+      : 0;
+  const int grid = static_cast<int>(std::min<int64_t>(p.numTiles, static_cast<int64_t>(rt.numCUs) * 8));
+  VX_LAUNCH("k_join_probe", k_join_probe, grid, 256, 0, a);
   VX_LAUNCH("k_scan_u64", k_scan_u64, 1, 1024, 0, sums, p.numTiles, offs);
   p.hostTileOffsets.resize(p.numTiles + 1);
   copyOut(p.hostTileOffsets.data(), VX355_MEM_HOST, offs, static_cast<size_t>(p.numTiles + 1) * 8);
@@ -918,7 +1025,7 @@ void probeGetOutput(vx355_join_probe& p, int32_t maxRows, int32_t* mappingOut, i
   lastTile = std::max<int64_t>(firstTile, std::min<int64_t>(lastTile, p.numTiles - 1));
   EmitArgs ea{};
   ea.hits = p.hits.as<uint32_t>();
-  ea.counts = p.counts.as<uint32_t>();
+  ea.counts = p.haveCounts ? p.counts.as<uint32_t>() : nullptr;
   ea.next = t.next.as<uint32_t>();
   ea.tileOffsets = p.tileOffsets.as<uint64_t>();
   ea.numRows = p.numRows;
