@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--rows", type=int, default=0, help="override the row count (debug)")
     ap.add_argument("--cpu-sample-rows", type=int, default=16_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--q3-random-probe", action="store_true",
+                    help="q3: lineitems in random order instead of dbgen's l_orderkey clustering")
     ap.add_argument("--unfused", action="store_true",
                     help="q1: FilterProject and HashAggregation as two operators")
     return ap.parse_args()
@@ -325,6 +327,7 @@ class Q3:
     agg_bytes_per_row = 24
     dominant = "k_join_probe"
     Q3_DATE = 9204  # 1995-03-15
+    random_probe = False
 
     def __init__(self, torch, n, device, seed):
         g = torch.Generator(device=device)
@@ -338,7 +341,16 @@ class Q3:
         self.bkey = okey[keep].contiguous()
         self.bdate = odate[keep].contiguous()
         self.bprio = torch.zeros_like(self.bdate)
-        li = torch.randint(0, n_orders, (n,), dtype=torch.int64, device=device, generator=g)
+        if self.random_probe:
+            # worst case for the probe: lineitems in random order
+            li = torch.randint(0, n_orders, (n,), dtype=torch.int64, device=device, generator=g)
+        else:
+            # dbgen order: lineitem is clustered by l_orderkey, 1..7 lines per order
+            counts = torch.randint(1, 8, (n_orders,), dtype=torch.int64, device=device, generator=g)
+            li = torch.repeat_interleave(seq, counts)
+            del counts
+        n = int(li.shape[0])
+        self.n = n
         lkey = okey[li]
         lship = odate[li] + torch.randint(1, 122, (n,), dtype=torch.int32, device=device, generator=g)
         del li, okey, odate, seq
@@ -374,6 +386,12 @@ class Q3:
 
     def rows_per_step(self):
         return self.probe_rows
+
+    def info(self):
+        return {"build_rows": int(self.bkey.shape[0]), "probe_rows": self.probe_rows,
+                "matches": int(self.matches), "table_mode": int(self.stats.hash_mode),
+                "table_capacity": int(self.stats.capacity),
+                "probe_order": "random" if self.random_probe else "dbgen (clustered by l_orderkey)"}
 
     def host_sample(self, rows):
         rows = min(rows, self.probe_rows)
@@ -421,6 +439,8 @@ def main():
 
     cls, default_rows = WORKLOADS[args.workload]
     n = args.rows or default_rows
+    if args.workload == "q3":
+        cls.random_probe = args.q3_random_probe
     wl = cls(torch, n, device, seed=1234 + rank)
     if args.workload == "q1":
         wl.fused = not args.unfused
@@ -488,6 +508,7 @@ def main():
                    if args.workload == "q1" else args.workload,
                    "parallelism": "one process per GPU, row shards; partial/final merge over RCCL"
                    if world > 1 else "1 GPU"},
+        "workload_info": wl.info() if hasattr(wl, "info") else {},
         "pipeline_algorithmic_GBps": wl.bytes_per_row * rows / elapsed / 1e9 / world,
         "roofline": {
             "bound": "hbm", "kernel": wl.dominant,

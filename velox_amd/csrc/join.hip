@@ -515,6 +515,54 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
   __shared__ uint64_t waveTotals[4];
   __shared__ uint64_t running;
   const int64_t tile = a.firstTile + blockIdx.x;
+  if (a.counts == nullptr) {
+    // Every probe row produces 0 or 1 output rows: ballot compaction. Each wave
+    // owns 2048 consecutive rows of the tile; one pass counts, one block-level
+    // exchange of the four wave totals, one pass writes.
+    constexpr int kWaveRows = kTileRows / 4;
+    const int64_t waveBase = tile * kTileRows + static_cast<int64_t>(threadIdx.x >> 6) * kWaveRows;
+    uint64_t total = 0;
+    for (int it = 0; it < kWaveRows / 64; ++it) {
+      const int64_t r = waveBase + it * 64 + lane();
+      const bool out = r < a.numRows && outputCount(a.joinType, a.hits[r] == kNoRow32 ? 0 : 1) != 0;
+      total += popc64(ballot(out));
+    }
+    if (lane() == 0) {
+      waveTotals[threadIdx.x >> 6] = total;
+    }
+    __syncthreads();
+    uint64_t run = a.tileOffsets[tile];
+    for (int w = 0; w < (threadIdx.x >> 6); ++w) {
+      run += waveTotals[w];
+    }
+    if (total == 0 || run >= a.windowEnd || run + total <= a.windowBegin) {
+      return;
+    }
+    for (int it = 0; it < kWaveRows / 64; ++it) {
+      const int64_t r = waveBase + it * 64 + lane();
+      uint32_t hit = kNoRow32;
+      bool out = false;
+      if (r < a.numRows) {
+        hit = a.hits[r];
+        out = outputCount(a.joinType, hit == kNoRow32 ? 0 : 1) != 0;
+      }
+      const uint64_t m = ballot(out);
+      if (m == 0) {
+        continue;
+      }
+      const uint64_t pos = run + lanePrefix(m);
+      if (out && pos >= a.windowBegin && pos < a.windowEnd) {
+        a.mapping[pos - a.windowBegin] = static_cast<int32_t>(r);
+        if (a.buildRows) {
+          const bool listMatch = hit != kNoRow32 &&
+              (a.joinType == VX355_JOIN_INNER || a.joinType == VX355_JOIN_LEFT);
+          a.buildRows[pos - a.windowBegin] = listMatch ? static_cast<int32_t>(hit) : -1;
+        }
+      }
+      run += popc64(m);
+    }
+    return;
+  }
   if (threadIdx.x == 0) {
     running = a.tileOffsets[tile];
   }
@@ -525,7 +573,7 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
     uint32_t c = 0;
     if (r < a.numRows) {
       hit = a.hits[r];
-      c = a.counts ? a.counts[r] : outputCount(a.joinType, hit == kNoRow32 ? 0 : 1);
+      c = a.counts[r];
     }
     uint64_t incl = c;
 #pragma unroll
