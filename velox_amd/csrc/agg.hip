@@ -1038,12 +1038,15 @@ __global__ __launch_bounds__(256) void k_rekey(RekeyArgs a) {
   }
 }
 
+// srcOff == 1 (the first-row word): dst = group exists ? 1 : 0 — used when a
+// count that was only ever needed as a "seen" flag has to become a real word.
 __global__ __launch_bounds__(256) void k_copy_acc(uint64_t* table, uint64_t rows, int32_t stride,
                                                    int32_t srcOff, int32_t dstOff) {
   const uint64_t step = static_cast<uint64_t>(gridDim.x) * blockDim.x;
   for (uint64_t r = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; r < rows;
        r += step) {
-    table[r * stride + dstOff] = table[r * stride + srcOff];
+    const uint64_t v = table[r * stride + srcOff];
+    table[r * stride + dstOff] = srcOff == 1 ? (v != kNoRow ? 1 : 0) : v;
   }
 }
 
@@ -1051,29 +1054,44 @@ __global__ __launch_bounds__(256) void k_copy_acc(uint64_t* table, uint64_t rows
 __global__ __launch_bounds__(256) void k_collect(const uint64_t* table, uint64_t rows, int32_t stride,
                                                   uint64_t* firstOut, uint32_t* indexOut,
                                                   uint32_t* cursor) {
-  const uint64_t step = static_cast<uint64_t>(gridDim.x) * blockDim.x;
-  const uint64_t rounds = (rows + step - 1) / step;
-  uint64_t r = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  for (uint64_t it = 0; it < rounds; ++it, r += step) {
-    uint64_t first = kNoRow;
-    if (r < rows) {
-      first = table[r * stride + 1];
+  // One wave owns 32 x 64 consecutive group rows and claims its output range
+  // with ONE atomic (a single HBM address takes ~88 M atomics/s, so one atomic
+  // per 64 rows would dominate at 10^8 groups).
+  constexpr int kGroups = 32;
+  const uint64_t waveRows = 64ULL * kGroups;
+  const uint64_t numWaveTiles = (rows + waveRows - 1) / waveRows;
+  const uint64_t waveStride = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+  for (uint64_t t = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6; t < numWaveTiles;
+       t += waveStride) {
+    uint64_t first[kGroups];
+    uint32_t total = 0;
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
+      const uint64_t r = t * waveRows + static_cast<uint64_t>(g) * 64 + lane();
+      first[g] = r < rows ? table[r * stride + 1] : kNoRow;
     }
-    const bool liveRow = first != kNoRow;
-    uint64_t m = ballot(liveRow);
-    if (m == 0) {
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
+      total += popc64(ballot(first[g] != kNoRow));
+    }
+    if (total == 0) {
       continue;
     }
-    const int leader = __ffsll(static_cast<long long>(m)) - 1;
     uint32_t base = 0;
-    if (lane() == leader) {
-      base = atomicAdd(cursor, static_cast<uint32_t>(popc64(m)));
+    if (lane() == 0) {
+      base = atomicAdd(cursor, total);
     }
-    base = __shfl(base, leader, kWave);
-    if (liveRow) {
-      uint32_t p = base + lanePrefix(m);
-      firstOut[p] = first;
-      indexOut[p] = static_cast<uint32_t>(r);
+    base = __shfl(base, 0, kWave);
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
+      const bool liveRow = first[g] != kNoRow;
+      const uint64_t m = ballot(liveRow);
+      if (liveRow) {
+        const uint32_t p = base + lanePrefix(m);
+        firstOut[p] = first[g];
+        indexOut[p] = static_cast<uint32_t>(t * waveRows + static_cast<uint64_t>(g) * 64 + lane());
+      }
+      base += popc64(m);
     }
   }
 }
@@ -1094,7 +1112,8 @@ struct OutAgg {
   int32_t aggKind;   // vx355_agg_kind
   int32_t inputType;
   int32_t mainOff;
-  int32_t seenOff;   // count of contributing rows; -1 = never null
+  int32_t seenOff;   // count of contributing rows; -1 = never null; 1 = the first-row word
+                     // (group exists <=> some row contributed)
   int32_t finalOut;
   int32_t pad;
 };
@@ -1191,7 +1210,10 @@ __global__ __launch_bounds__(256) void k_extract(ExtractArgs a) {
   for (int j = 0; j < a.numAggs; ++j) {
     const OutAgg& oa = a.aggs[j];
     const uint64_t mainWord = active ? g[oa.mainOff] : 0;
-    const uint64_t seen = (active && oa.seenOff >= 0) ? g[oa.seenOff] : 1;
+    uint64_t seen = (active && oa.seenOff >= 0) ? g[oa.seenOff] : 1;
+    if (oa.seenOff == 1) {
+      seen = seen != kNoRow ? 1 : 0;
+    }
     const bool valid = active && seen != 0;
     const bool inInt = oa.inputType <= VX355_BIGINT;
     switch (oa.aggKind) {
@@ -1293,6 +1315,7 @@ struct PhysAcc {
   int32_t maskCol;
   bool inIsInt;
   int32_t aliasOf = -1;  // COUNT(col) == COUNT(*) while no batch had nulls in col
+  bool valueNeeded = false;  // the count itself is an output (count / avg), not just a "seen" flag
 };
 
 struct LogicalAgg {
@@ -1442,6 +1465,7 @@ void buildPlan(vx355_agg& h, const vx355_agg_spec& spec) {
       case VX355_AGG_COUNT_STAR:
         if (raw) {
           la.main = countAcc(h, f.kind == VX355_AGG_COUNT ? f.input_col : -1, f.mask_col);
+          h.phys[la.main].valueNeeded = true;
         } else {
           la.main = findOrAddPhys(h, ACC_SUM_I64_WRAP, f.input_col, f.mask_col, true);
         }
@@ -1458,6 +1482,7 @@ void buildPlan(vx355_agg& h, const vx355_agg_spec& spec) {
         la.main = findOrAddPhys(h, ACC_SUM_F64, f.input_col, f.mask_col, false);
         if (raw) {
           la.seen = countAcc(h, f.input_col, f.mask_col);
+          h.phys[la.seen].valueNeeded = true;
         } else {
           VX_CHECK_ARG(f.input_col2 >= 0, "avg over intermediate input needs the count column");
           // count = checkedPlus over the partial counts of rows whose sum is
@@ -1851,11 +1876,27 @@ const FastEntry* findFastEntry(const FastSignature& sig, int unroll) {
   return any;
 }
 
+// A count that only serves as the "seen" flag of sum/min/max over a column
+// without nulls or mask equals "the group exists", which the first-row word
+// already records: such a count(*) is not maintained at all.
+bool flagFromFirstRow(const vx355_agg& h, int32_t i) {
+  const auto& p = h.phys[i];
+  if (p.kind != ACC_COUNT || p.aliasOf >= 0 || p.inputCol >= 0 || p.maskCol >= 0 || p.valueNeeded) {
+    return false;
+  }
+  for (const auto& q : h.phys) {
+    if (q.aliasOf == i && q.valueNeeded) {
+      return false;
+    }
+  }
+  return true;
+}
+
 void fillAccArgs(vx355_agg& h, const DeviceBatch& db, AggArgs* a) {
   int n = 0;
   for (size_t i = 0; i < h.phys.size(); ++i) {
     const auto& p = h.phys[i];
-    if (p.aliasOf >= 0) {
+    if (p.aliasOf >= 0 || flagFromFirstRow(h, static_cast<int32_t>(i))) {
       continue;
     }
     AccArg& aa = a->accs[n++];
@@ -1922,7 +1963,8 @@ void materializeAliases(vx355_agg& h, const DeviceBatch& db) {
     }
     if (h.tableReady) {
       VX_LAUNCH("k_copy_acc", k_copy_acc, streamGrid(static_cast<int64_t>(h.capacity), 256), 256, 0,
-                h.table.as<uint64_t>(), h.capacity, h.stride, 2 + p.aliasOf,
+                h.table.as<uint64_t>(), h.capacity, h.stride,
+                flagFromFirstRow(h, p.aliasOf) ? 1 : 2 + p.aliasOf,
                 2 + static_cast<int32_t>(i));
     }
     p.aliasOf = -1;
@@ -2260,7 +2302,7 @@ void getOutput(vx355_agg& h, vx355_out_column* cols, int32_t numCols, int32_t ma
     while (h.phys[p].aliasOf >= 0) {
       p = h.phys[p].aliasOf;
     }
-    return 2 + p;
+    return flagFromFirstRow(h, p) ? 1 : 2 + p;
   };
   const bool fin = finalOutput(h.step);
   for (size_t j = 0; j < h.aggs.size(); ++j) {
