@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from velox_amd import abi, ops  # noqa: E402
+from velox_amd import dist as vdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
@@ -430,12 +431,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # VX355_BENCH_SHARE_GPU=1 (debug on a 1-GPU box): every rank uses GPU 0 and
+    # the tiny exchange runs over gloo, because RCCL refuses two ranks per device.
+    share = os.environ.get("VX355_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    backend = "gloo" if share else "nccl"
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    ops.init(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    ops.init(dev_index)
 
     cls, default_rows = WORKLOADS[args.workload]
     n = args.rows or default_rows
@@ -460,7 +469,8 @@ def main():
         # step merges them — the same partial/final split the reference uses
         # across Drivers (docs/develop/aggregations.rst:24-91).
         part = wl.step(abi.STEP_PARTIAL)
-        return merge_partials(torch, dist, part, world, device)
+        return vdist.merge_partials(ops, dist, torch, part, Q1_KEYS[1], Q1.FUSED_AGGS,
+                                    device if backend == "nccl" else None)
 
     for _ in range(args.warmup):
         one_step()
@@ -476,7 +486,7 @@ def main():
     ops.profile_enable(False)
     prof = ops.profile()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     rows = wl.rows_per_step() * world * args.steps
@@ -538,45 +548,6 @@ def main():
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
-
-
-def merge_partials(torch, dist, part, world, device):
-    """All-gather the partial Q1 result (<= 64 groups) and run the final step."""
-    ncols = len(part)
-    rows = len(part[0][1])
-    cap = 64
-    buf = torch.zeros((cap, 2 * ncols + 1), dtype=torch.float64, device=device)
-    host = np.zeros((cap, 2 * ncols + 1))
-    host[:rows, 2 * ncols] = 1
-    for c, (vals, valid) in enumerate(part):
-        if isinstance(vals, list):
-            vals = np.array([v[0] if v else 0 for v in vals], dtype=np.float64)
-        host[:rows, 2 * c] = np.asarray(vals, dtype=np.float64)
-        host[:rows, 2 * c + 1] = np.asarray(valid, dtype=np.float64)
-    buf.copy_(torch.from_numpy(host))
-    gathered = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(gathered, buf)
-    allp = torch.cat(gathered).cpu().numpy()
-    allp = allp[allp[:, 2 * ncols] == 1]
-
-    def col(c, kind):
-        vals, valid = allp[:, 2 * c], allp[:, 2 * c + 1] > 0
-        if kind == abi.VARCHAR:
-            return abi.HostColumn(abi.VARCHAR, [bytes([int(v)]) for v in vals], valid)
-        if kind == abi.BIGINT:
-            return abi.HostColumn(abi.BIGINT, vals.astype(np.int64), valid)
-        return abi.HostColumn(abi.DOUBLE, vals, valid)
-    # partial layout: rf, ls, sum x4, (avg sum, avg count) x3, count
-    kinds = [abi.VARCHAR, abi.VARCHAR] + [abi.DOUBLE] * 4 + [abi.DOUBLE, abi.BIGINT] * 3 + [abi.BIGINT]
-    batch = abi.HostBatch([col(c, k) for c, k in enumerate(kinds)])
-    fin_aggs = [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_SUM, 3, abi.DOUBLE), (abi.AGG_SUM, 4, abi.DOUBLE),
-                (abi.AGG_SUM, 5, abi.DOUBLE), (abi.AGG_AVG, 6, abi.DOUBLE, -1, 7),
-                (abi.AGG_AVG, 8, abi.DOUBLE, -1, 9), (abi.AGG_AVG, 10, abi.DOUBLE, -1, 11),
-                (abi.AGG_COUNT_STAR, 12, abi.BIGINT)]
-    op = ops.HashAggregation([0, 1], [abi.VARCHAR, abi.VARCHAR], fin_aggs, abi.STEP_FINAL)
-    op.add_input(batch)
-    op.no_more_input()
-    return ops.collect_output(op, 1024)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,58 @@
+"""Worker for tests/test_dist_gloo.py: one rank of the sharded aggregation
+(partial step per rank -> all-gather -> final step) on CPU with gloo, with the
+oracle standing in for the GPU operator."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+def shard(rank, n=20000):
+    rng = np.random.default_rng(100 + rank)
+    flags = [bytes([c]) for c in rng.choice(list(b"ANR"), n)]
+    status = [bytes([c]) for c in rng.choice(list(b"FO"), n)]
+    qty = rng.integers(1, 51, n).astype(np.float64)
+    price = rng.integers(0, 1 << 20, n).astype(np.float64) / 64
+    valid = rng.random(n) > 0.1
+    return flags, status, qty, price, valid
+
+
+def raw_aggs(abi):
+    return [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_AVG, 3, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT),
+            (abi.AGG_MIN, 3, abi.DOUBLE), (abi.AGG_COUNT, 3, abi.DOUBLE), (abi.AGG_MAX, 2, abi.DOUBLE)]
+
+
+def batch_for(abi, rank):
+    flags, status, qty, price, valid = shard(rank)
+    return abi.HostBatch([abi.HostColumn(abi.VARCHAR, flags), abi.HostColumn(abi.VARCHAR, status),
+                          abi.HostColumn(abi.DOUBLE, qty), abi.HostColumn(abi.DOUBLE, price, valid)])
+
+
+def run(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    import oracle_lib
+    from velox_amd import abi
+    from velox_amd import dist as vdist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    key_types = [abi.VARCHAR, abi.VARCHAR]
+    op = oracle_lib.Aggregation([0, 1], key_types, raw_aggs(abi), abi.STEP_PARTIAL)
+    op.add_input(batch_for(abi, rank))
+    op.no_more_input()
+    part = oracle_lib.collect_output(op, 4096)
+    merged = vdist.merge_partials(oracle_lib, dist, torch, part, key_types, raw_aggs(abi), None)
+    # every rank holds the same final result
+    np.save(os.path.join(out_dir, f"rank{rank}.npy"),
+            np.array([[float(v) if not isinstance(v, bytes) else float(v[0]) for v in col[0]]
+                      for col in merged], dtype=np.float64))
+    np.save(os.path.join(out_dir, f"rank{rank}_valid.npy"), np.array([col[1] for col in merged]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
