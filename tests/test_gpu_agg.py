@@ -280,9 +280,56 @@ def test_high_cardinality_hbm_path(oracle, vx):
     assert_columns_equal(got, exp, gop.kinds, what="sparse high cardinality")
 
 
-def test_unsupported_keys_are_refused_at_create(vx):
+def test_generic_hash_mode_double_string_timestamp_keys(oracle, vx):
+    """Keys without value ids (exec/VectorHasher.h:338-357) run in the generic
+    hash mode: VectorHasher hash + tag/id slots + stored key images. 0.0 and
+    -0.0 are one group, all NaNs are one group (type/FloatingPointUtil.h:100-109)."""
+    rng = np.random.default_rng(9)
+    n = 60000
+    flags = [[b"A", b"NO", b"RETURNED", b"RETURNED-12b", b""][i] for i in rng.integers(0, 5, n)]
+    d = rng.choice([0.0, -0.0, 1.5, float("nan"), -2.25, 1e300, -np.inf], n)
+    r = rng.choice([0.0, 2.5, float("nan")], n).astype(np.float32)
+    ts = np.stack([rng.integers(0, 3, n), rng.integers(0, 2, n) * 1000], axis=1)
+    v = _dyadic(rng, n)
+    cols = [abi.HostColumn(abi.VARCHAR, flags, rng.random(n) > 0.05), abi.HostColumn(abi.DOUBLE, d, rng.random(n) > 0.05),
+            abi.HostColumn(abi.REAL, r), abi.HostColumn(abi.TIMESTAMP, ts), abi.HostColumn(abi.DOUBLE, v, rng.random(n) > 0.2)]
+    aggs = [(abi.AGG_SUM, 4, abi.DOUBLE), (abi.AGG_MAX, 4, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT),
+            (abi.AGG_AVG, 4, abi.DOUBLE)]
+    b = abi.HostBatch(cols, n)
+    for keys, kinds in [([0, 1], [abi.VARCHAR, abi.DOUBLE]), ([2], [abi.REAL]), ([3, 0], [abi.TIMESTAMP, abi.VARCHAR]),
+                        ([1, 2, 3, 0], [abi.DOUBLE, abi.REAL, abi.TIMESTAMP, abi.VARCHAR])]:
+        for ignore in (False, True):
+            exp, _ = run_agg(oracle, [b], keys, kinds, aggs, ignore_null_keys=ignore)
+            got, gop = run_agg(vx, [b], keys, kinds, aggs, ignore_null_keys=ignore)
+            assert_columns_equal(got, exp, gop.kinds, what=f"generic {keys} ignore={ignore}")
+            assert gop.stats().hash_mode == abi.MODE_HASH
+
+
+def test_generic_hash_mode_wide_int_keys_growth_and_order(oracle, vx):
+    """Three BIGINT keys spanning the whole int64 range do not fit a 64-bit
+    normalized key: decideHashMode's kHash case. Many batches -> slot rehash and
+    group-row growth; group order stays first-seen."""
+    rng = np.random.default_rng(10)
+    batches = []
+    for i in range(6):
+        n = 40000
+        k1 = rng.integers(-2 ** 62, 2 ** 62, 3000)[rng.integers(0, 3000, n)].astype(np.int64)
+        k2 = rng.integers(-2 ** 62, 2 ** 62, 7)[rng.integers(0, 7, n)].astype(np.int64)
+        k3 = rng.integers(-2 ** 62, 2 ** 62, 5)[rng.integers(0, 5, n)].astype(np.int64)
+        batches.append(batch_of([k1, k2, k3, _dyadic(rng, n)], [rng.random(n) > 0.02, None, None, None]))
+    aggs = [(abi.AGG_SUM, 3, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT), (abi.AGG_MIN, 3, abi.DOUBLE)]
+    exp, _ = run_agg(oracle, batches, [0, 1, 2], [abi.BIGINT] * 3, aggs, max_rows=50000)
+    got, gop = run_agg(vx, batches, [0, 1, 2], [abi.BIGINT] * 3, aggs, max_rows=50000)
+    assert_columns_equal(got, exp, gop.kinds, what="wide keys")
+    st = gop.stats()
+    assert st.hash_mode == abi.MODE_HASH and st.num_groups == len(exp[0][0]) and st.num_rehashes > 0
+
+
+def test_strings_longer_than_inline_are_refused(vx):
+    strs = [b"x" * 13, b"short"]
+    op = vx.Aggregation([0], [abi.VARCHAR], [(abi.AGG_COUNT_STAR, -1, abi.BIGINT)])
     with pytest.raises(vx.Vx355Error) as e:
-        vx.Aggregation([0], [abi.DOUBLE], [(abi.AGG_COUNT_STAR, -1, abi.BIGINT)])
+        op.add_input(batch_of([strs]))
     assert e.value.status == abi.EUNSUPPORTED
 
 

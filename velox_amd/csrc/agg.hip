@@ -920,6 +920,215 @@ const FastEntry kFastTable[] = {
     VX_FAST_ENTRY(4, FK_I64, FK_NONE, FK_I32, FK_NONE, 1, 2, kC1Lo, 0),
 };
 
+// ---- generic hash mode (the reference's kHash, HashTable.cpp:470-520) ---------------
+// Keys that have no 64-bit normalized form (REAL / DOUBLE / TIMESTAMP, strings
+// of 8..12 bytes, key sets wider than 64 bits) are grouped through an
+// open-addressing table of 8-byte slots {hash tag : 32 | group id + 1 : 32}
+// probed from the VectorHasher hash (hashOne + hashMix, VectorHasher.cpp:61-126).
+// A slot is claimed with one CAS (tag | PENDING); the winner takes the next dense
+// group id, stores the key images (8-byte agent-scope atomic stores: readers on
+// other XCDs use agent-scope atomic loads, the one form that is coherent across
+// the per-XCD L2s without fences), then publishes the id. A tag match is
+// confirmed by comparing the stored key images. Group rows (first input row +
+// accumulators) are indexed by the dense id, so everything downstream of
+// "which group row" is shared with array mode.
+constexpr uint32_t kPendingGid = 0xffffffffu;
+
+struct GenericPart {
+  uint64_t* slots;
+  uint64_t slotMask;
+  uint64_t* keyStore[kMaxKeys];   // 1 or 2 words per group
+  int32_t keyWords[kMaxKeys];
+  uint64_t* nullStore;            // bit k = key k is null
+  uint64_t* hashStore;
+  uint32_t* gidCounter;
+  uint32_t maxGroups;
+  uint32_t pad;
+};
+
+struct GenericArgs {
+  AggArgs a;
+  GenericPart g;
+};
+static_assert(sizeof(GenericArgs) <= 4096, "kernel arguments are limited to 4 KB");
+
+// Comparable image of the non-null key value at base index i: integers as
+// int64, floating point canonicalised (one NaN, +0.0 for both zeros: the same
+// classes hashOne hashes together), strings / timestamps as two words.
+__device__ inline void keyImage(const ColView& c, int64_t i, uint64_t* w0, uint64_t* w1, bool* supported) {
+  *w1 = 0;
+  switch (c.kind) {
+    case VX355_REAL: {
+      float f = static_cast<const float*>(c.values)[i];
+      uint32_t b = f != f ? 0x7fc00000u : (f == 0.0f ? 0u : __float_as_uint(f));
+      *w0 = b;
+      break;
+    }
+    case VX355_DOUBLE: {
+      double d = static_cast<const double*>(c.values)[i];
+      *w0 = d != d ? 0x7ff8000000000000ULL
+                   : (d == 0.0 ? 0ULL : static_cast<uint64_t>(__double_as_longlong(d)));
+      break;
+    }
+    case VX355_VARCHAR:
+    case VX355_VARBINARY: {
+      const StringView16 v = loadView(c, i);
+      if (v.size > 12) {
+        *supported = false;
+      }
+      *w0 = static_cast<uint64_t>(v.size) | (static_cast<uint64_t>(v.prefix) << 32);
+      *w1 = v.tail;
+      break;
+    }
+    case VX355_TIMESTAMP: {
+      const uint64_t* p = static_cast<const uint64_t*>(c.values) + 2 * i;
+      *w0 = p[0];
+      *w1 = p[1];
+      break;
+    }
+    default:
+      *w0 = static_cast<uint64_t>(loadInt64(c, i));
+      break;
+  }
+}
+
+__device__ inline uint64_t loadAgent(const uint64_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void storeAgent(uint64_t* p, uint64_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void k_agg_generic(GenericArgs args) {
+  const AggArgs& a = args.a;
+  const GenericPart& g = args.g;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  uint32_t newGroups = 0;
+  for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < a.numRows;
+       row += stride) {
+    if (a.numTerms && !evalFilter(a.terms, a.numTerms, row)) {
+      continue;
+    }
+    // Key images, null mask and the VectorHasher hash of the row.
+    uint64_t w0[kMaxKeys], w1[kMaxKeys];
+    uint64_t nullMask = 0;
+    uint64_t hash = 0;
+    bool supported = true;
+#pragma unroll
+    for (int k = 0; k < kMaxKeys; ++k) {
+      w0[k] = 0;
+      w1[k] = 0;
+      if (k < a.numKeys) {
+        const ColView& c = a.keys[k].col;
+        uint64_t hv = kNullHash;
+        if (colIsNull(c, row)) {
+          nullMask |= 1ULL << k;
+        } else {
+          const int64_t i = colIndex(c, row);
+          keyImage(c, i, &w0[k], &w1[k], &supported);
+          hv = hashValueAt(c, i);
+        }
+        hash = k == 0 ? hv : hashMix(hash, hv);
+      }
+    }
+    if (nullMask && a.ignoreNullKeys) {
+      continue;
+    }
+    if (!supported) {
+      a.counters->unmappable = 1;
+      continue;
+    }
+    const uint64_t tag = hash >> 32;
+    uint64_t pos = hash & g.slotMask;
+    uint32_t gid = kPendingGid;
+    uint64_t probes = 0;
+    while (gid == kPendingGid && probes <= g.slotMask) {
+      uint64_t w = loadAgent(g.slots + pos);
+      bool advance = false;
+      if (w == 0) {
+        const unsigned long long claim = (tag << 32) | kPendingGid;
+        const unsigned long long old =
+            atomicCAS(reinterpret_cast<unsigned long long*>(g.slots + pos), 0ULL, claim);
+        if (old == 0) {
+          const uint32_t id = atomicAdd(g.gidCounter, 1u);
+          if (id < g.maxGroups) {
+#pragma unroll
+            for (int k = 0; k < kMaxKeys; ++k) {
+              if (k < a.numKeys) {
+                storeAgent(g.keyStore[k] + static_cast<uint64_t>(id) * g.keyWords[k], w0[k]);
+                if (g.keyWords[k] == 2) {
+                  storeAgent(g.keyStore[k] + static_cast<uint64_t>(id) * 2 + 1, w1[k]);
+                }
+              }
+            }
+            storeAgent(g.nullStore + id, nullMask);
+            storeAgent(g.hashStore + id, hash);
+            __threadfence();
+            storeAgent(g.slots + pos, (tag << 32) | (static_cast<uint64_t>(id) + 1));
+            gid = id;
+          } else {
+            a.counters->tableFull = 1;
+            gid = 0;  // leave the loop; the host raises the error
+          }
+          w = 0;
+        } else {
+          w = old;
+        }
+      }
+      if (gid == kPendingGid && w != 0) {
+        if ((w >> 32) == tag) {
+          const uint32_t lo = static_cast<uint32_t>(w);
+          if (lo != kPendingGid) {
+            const uint32_t cand = lo - 1;
+            bool equal = loadAgent(g.nullStore + cand) == nullMask;
+#pragma unroll
+            for (int k = 0; k < kMaxKeys; ++k) {
+              if (equal && k < a.numKeys && !((nullMask >> k) & 1)) {
+                equal = loadAgent(g.keyStore[k] + static_cast<uint64_t>(cand) * g.keyWords[k]) == w0[k];
+                if (equal && g.keyWords[k] == 2) {
+                  equal = loadAgent(g.keyStore[k] + static_cast<uint64_t>(cand) * 2 + 1) == w1[k];
+                }
+              }
+            }
+            if (equal) {
+              gid = cand;
+            } else {
+              advance = true;
+            }
+          }
+          // else: the claimer has not published yet; look at this slot again
+        } else {
+          advance = true;
+        }
+      }
+      if (advance) {
+        pos = (pos + 1) & g.slotMask;
+        ++probes;
+      }
+    }
+    if (gid == kPendingGid) {
+      a.counters->tableFull = 1;
+      continue;
+    }
+    updateGlobal(a, row, gid, &newGroups);
+  }
+  addNewGroups(a.counters, newGroups);
+}
+
+// Re-inserts every group id into a larger slot array (HashTable::rehash).
+__global__ __launch_bounds__(256) void k_generic_rehash(uint64_t* slots, uint64_t slotMask,
+                                                         const uint64_t* hashStore, uint32_t numGroups) {
+  const uint32_t step = gridDim.x * blockDim.x;
+  for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < numGroups; id += step) {
+    const uint64_t hash = hashStore[id];
+    const unsigned long long word = ((hash >> 32) << 32) | (static_cast<uint64_t>(id) + 1);
+    uint64_t pos = hash & slotMask;
+    while (atomicCAS(reinterpret_cast<unsigned long long*>(slots + pos), 0ULL, word) != 0) {
+      pos = (pos + 1) & slotMask;
+    }
+  }
+}
+
 // ---- key statistics of the first rows (VectorHasher::analyze) ---------------
 struct StatsArgs {
   KeyArg keys[kMaxKeys];
@@ -1101,8 +1310,11 @@ struct OutKey {
   void* values;
   uint64_t* nulls;
   int32_t kind;
-  int32_t pad;
+  int32_t keyIndex;
   KeyRange range;
+  const uint64_t* store;  // generic hash mode: key images by group id
+  int32_t storeWords;
+  int32_t pad;
 };
 struct OutAgg {
   void* values;
@@ -1127,6 +1339,7 @@ struct ExtractArgs {
   int32_t numKeys;
   int32_t numAggs;
   int32_t global;  // no keys: the single group is row 0
+  const uint64_t* nullStore;  // generic hash mode
   OutKey keys[kMaxKeys];
   OutAgg aggs[kMaxAccs];
 };
@@ -1174,9 +1387,38 @@ __global__ __launch_bounds__(256) void k_extract(ExtractArgs a) {
     gi = a.global ? 0 : a.order[a.begin + pos];
   }
   const uint64_t* g = a.table + gi * a.stride;
-  const uint64_t key = a.mode == MODE_ARRAY ? gi : (active ? g[0] : 0);
+  const uint64_t key = a.mode == MODE_NORMALIZED ? (active ? g[0] : 0) : gi;
   for (int k = 0; k < a.numKeys; ++k) {
     const OutKey& ok = a.keys[k];
+    if (a.mode == MODE_HASH) {
+      // Stored key images by group id.
+      const bool valid = active && !((a.nullStore[gi] >> ok.keyIndex) & 1);
+      writeBit(ok.nulls, pos, valid);
+      const uint64_t w0 = active ? ok.store[gi * ok.storeWords] : 0;
+      if (ok.kind == VX355_BOOLEAN) {
+        writeBit(static_cast<uint64_t*>(ok.values), pos, valid && w0 != 0);
+        continue;
+      }
+      if (!active) {
+        continue;
+      }
+      if (ok.storeWords == 2) {
+        const uint64_t w1 = ok.store[gi * 2 + 1];
+        uint4 raw;
+        raw.x = valid ? static_cast<uint32_t>(w0) : 0;
+        raw.y = valid ? static_cast<uint32_t>(w0 >> 32) : 0;
+        raw.z = valid ? static_cast<uint32_t>(w1) : 0;
+        raw.w = valid ? static_cast<uint32_t>(w1 >> 32) : 0;
+        static_cast<uint4*>(ok.values)[pos] = raw;
+      } else if (ok.kind == VX355_REAL) {
+        static_cast<float*>(ok.values)[pos] = valid ? __uint_as_float(static_cast<uint32_t>(w0)) : 0.f;
+      } else if (ok.kind == VX355_DOUBLE) {
+        static_cast<double*>(ok.values)[pos] = valid ? __longlong_as_double(static_cast<long long>(w0)) : 0.0;
+      } else {
+        storeTyped(ok.values, ok.kind, pos, valid ? static_cast<int64_t>(w0) : 0, 0, true);
+      }
+      continue;
+    }
     uint64_t id = active ? (key / ok.range.multiplier) % ok.range.rangeSize : 0;
     const bool valid = active && id != 0;
     writeBit(ok.nulls, pos, valid);
@@ -1352,6 +1594,13 @@ struct vx355_agg {
   std::vector<vx355_projection> fusedProj;
   int32_t maxProjRef = -1;
 
+  // generic hash mode (keys without a normalized form)
+  bool generic = false;
+  DevBuf gSlots, gNullStore, gHashStore, gCounter;
+  std::vector<DevBuf> gKeyStore;
+  uint64_t gSlotCap = 0;
+  uint64_t gMaxGroups = 0;
+
   // device state
   int32_t mode = MODE_ARRAY;
   bool tableReady = false;
@@ -1422,10 +1671,11 @@ void buildPlan(vx355_agg& h, const vx355_agg_spec& spec) {
     KeyState ks;
     ks.col = spec.key_cols[k];
     ks.kind = spec.key_types[k];
+    if (kindWidth(ks.kind) < 0) {
+      VX_THROW(VX355_EUNSUPPORTED, "group-by key type " + std::to_string(ks.kind));
+    }
     if (!(isIntLike(ks.kind) || isString(ks.kind))) {
-      VX_THROW(VX355_EUNSUPPORTED,
-               "group-by key type " + std::to_string(ks.kind) +
-                   " has no value ids (REAL/DOUBLE/TIMESTAMP keys need the generic hash mode)");
+      h.generic = true;  // REAL / DOUBLE / TIMESTAMP have no value ids (VectorHasher.h:338-357)
     }
     h.keys.push_back(ks);
     h.outTypes.push_back(ks.kind);
@@ -2030,6 +2280,138 @@ void checkCounters(const Counters& c) {
   }
 }
 
+int keyStoreWords(int32_t kind) { return (isString(kind) || kind == VX355_TIMESTAMP) ? 2 : 1; }
+
+// Grows the generic-mode arrays so that 'needGroups' dense ids fit; slots are
+// kept at <= 50 % load (HashTable.h:946-956 asks for <= 70 %).
+void ensureGenericCapacity(vx355_agg& h, uint64_t needGroups) {
+  auto& rt = Runtime::get();
+  const size_t live = static_cast<size_t>(h.numGroups);
+  if (h.gKeyStore.empty()) {
+    h.gKeyStore.resize(h.keys.size());
+    h.gCounter.ensure(64);
+    HIP_OK(hipMemsetAsync(h.gCounter.ptr(), 0, 64, rt.stream));
+  }
+  if (needGroups > h.gMaxGroups) {
+    const uint64_t newMax = std::max<uint64_t>({needGroups, h.gMaxGroups + h.gMaxGroups / 2, 1024});
+    for (size_t k = 0; k < h.keys.size(); ++k) {
+      const size_t w = static_cast<size_t>(keyStoreWords(h.keys[k].kind)) * 8;
+      h.gKeyStore[k].ensure(newMax * w + 64, true, live * w);
+    }
+    h.gNullStore.ensure(newMax * 8 + 64, true, live * 8);
+    h.gHashStore.ensure(newMax * 8 + 64, true, live * 8);
+    DevBuf fresh;
+    initTable(h, fresh, newMax);
+    if (h.tableReady && live > 0) {
+      copyIn(fresh.ptr(), h.table.ptr(), VX355_MEM_DEVICE, live * h.stride * 8);
+      ++h.numRehashes;
+    }
+    rt.sync();
+    h.table = std::move(fresh);
+    h.gMaxGroups = newMax;
+    h.capacity = newMax;
+    h.tableReady = true;
+  }
+  const uint64_t wantSlots = nextPow2(std::max<uint64_t>(2048, 2 * h.gMaxGroups));
+  if (wantSlots > h.gSlotCap) {
+    DevBuf fresh;
+    fresh.ensure(wantSlots * 8 + 64);
+    HIP_OK(hipMemsetAsync(fresh.ptr(), 0, wantSlots * 8, rt.stream));
+    if (live > 0) {
+      VX_LAUNCH("k_generic_rehash", k_generic_rehash, streamGrid(static_cast<int64_t>(live), 256), 256, 0,
+                fresh.as<uint64_t>(), wantSlots - 1, h.gHashStore.as<uint64_t>(),
+                static_cast<uint32_t>(live));
+    }
+    rt.sync();
+    h.gSlots = std::move(fresh);
+    h.gSlotCap = wantSlots;
+  }
+}
+
+void shiftView(ColView& v, int64_t begin) {
+  if (begin == 0 || v.enc == VX355_CONSTANT) {
+    return;
+  }
+  // Chunks start on a multiple of 64 rows, so bitmaps shift by whole words.
+  if (v.nulls) {
+    v.nulls += begin >> 6;
+  }
+  if (v.enc == VX355_DICTIONARY) {
+    v.indices += begin;
+    return;
+  }
+  const int w = kindWidth(v.kind);
+  if (w == 0) {
+    v.values = static_cast<const uint64_t*>(v.values) + (begin >> 6);
+  } else {
+    v.values = static_cast<const char*>(v.values) + begin * w;
+  }
+}
+
+void shiftArgs(AggArgs& c, int64_t begin) {
+  for (int k = 0; k < c.numKeys; ++k) {
+    shiftView(c.keys[k].col, begin);
+  }
+  for (int j = 0; j < c.numAccs; ++j) {
+    if (c.accs[j].hasIn) {
+      shiftView(c.accs[j].in, begin);
+    }
+    if (c.accs[j].hasMask) {
+      shiftView(c.accs[j].mask, begin);
+    }
+  }
+  for (int t = 0; t < c.numTerms; ++t) {
+    shiftView(c.terms[t].col, begin);
+  }
+  for (int j = 0; j < c.numProj; ++j) {
+    for (int f = 0; f < c.proj[j].numFactors; ++f) {
+      if (c.proj[j].factors[f].hasCol) {
+        shiftView(c.proj[j].factors[f].col, begin);
+      }
+    }
+  }
+}
+
+void addInputGeneric(vx355_agg& h, AggArgs& a, int64_t n) {
+  h.mode = MODE_HASH;
+  const int64_t chunk = std::min<int64_t>(h.chunkRows, 1 << 22);
+  int64_t rows = 0;
+  for (int64_t begin = 0; begin < n; begin += rows) {
+    rows = std::min(chunk, n - begin);
+    ensureGenericCapacity(h, static_cast<uint64_t>(h.numGroups + rows));
+    GenericArgs ga{};
+    ga.a = a;
+    AggArgs& c = ga.a;
+    c.numRows = rows;
+    c.rowBase = static_cast<uint64_t>(h.inputRows + begin);
+    c.table = h.table.as<uint64_t>();
+    c.capacity = h.capacity;
+    c.mode = MODE_ARRAY;  // group row = table + group id * stride
+    shiftArgs(c, begin);
+    GenericPart& g = ga.g;
+    g.slots = h.gSlots.as<uint64_t>();
+    g.slotMask = h.gSlotCap - 1;
+    for (size_t k = 0; k < h.keys.size(); ++k) {
+      g.keyStore[k] = h.gKeyStore[k].as<uint64_t>();
+      g.keyWords[k] = keyStoreWords(h.keys[k].kind);
+    }
+    g.nullStore = h.gNullStore.as<uint64_t>();
+    g.hashStore = h.gHashStore.as<uint64_t>();
+    g.gidCounter = h.gCounter.as<uint32_t>();
+    g.maxGroups = static_cast<uint32_t>(std::min<uint64_t>(h.gMaxGroups, 0xfffffffeULL));
+    resetCounters(h);
+    VX_LAUNCH("k_agg_generic", k_agg_generic, streamGrid(rows, 256), 256, 0, ga);
+    Counters ctr = readCounters(h);
+    if (ctr.unmappable) {
+      VX_THROW(VX355_EUNSUPPORTED, "string grouping key longer than 12 bytes (not inline)");
+    }
+    checkCounters(ctr);
+    uint32_t ids = 0;
+    copyOut(&ids, VX355_MEM_HOST, h.gCounter.ptr(), 4);
+    h.numGroups = ids;
+  }
+}
+
 void addInput(vx355_agg& h, const vx355_batch* batch) {
   auto& rt = Runtime::get();
   VX_CHECK_ARG(!h.noMoreInput, "addInput after noMoreInput");
@@ -2060,10 +2442,17 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
   a.stride = h.stride;
   a.counters = h.counters();
 
+  if (h.generic) {
+    addInputGeneric(h, a, n);
+    h.inputRows += n;
+    rt.sync();
+    return;
+  }
   if (!h.tableReady) {
     // VectorHasher::analyze on a prefix of the first batch; later values that
     // fall outside are handled by the deferred-row path.
     resetCounters(h);
+    bool needGeneric = false;
     if (a.numKeys > 0) {
       StatsArgs sa{};
       sa.numKeys = a.numKeys;
@@ -2074,10 +2463,29 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
       sa.counters = h.counters();
       VX_LAUNCH("k_key_stats", k_key_stats, streamGrid(sa.numRows, 256), 256, 0, sa);
       Counters c = readCounters(h);
+      needGeneric = c.unmappable != 0;  // a string key longer than 7 bytes
+      c.unmappable = 0;
       checkCounters(c);
       mergeObserved(h, c);
     }
-    rebuildTable(h, static_cast<uint64_t>(std::min<int64_t>(n, h.chunkRows)));
+    if (!needGeneric) {
+      try {
+        rebuildTable(h, static_cast<uint64_t>(std::min<int64_t>(n, h.chunkRows)));
+      } catch (const Error& e) {
+        if (e.status != VX355_EUNSUPPORTED) {
+          throw;
+        }
+        needGeneric = true;  // keys do not fit a 64-bit normalized key
+      }
+    }
+    if (needGeneric) {
+      // decideHashMode falls back to kHash (HashTable.cpp:1751-1839, cases 4/6).
+      h.generic = true;
+      addInputGeneric(h, a, n);
+      h.inputRows += n;
+      rt.sync();
+      return;
+    }
   }
 
   int64_t rows = 0;
@@ -2294,7 +2702,13 @@ void getOutput(vx355_agg& h, vx355_out_column* cols, int32_t numCols, int32_t ma
     ea.keys[k].nulls = devNulls(c);
     ea.keys[k].kind = h.keys[k].kind;
     ea.keys[k].range = h.keys[k].range;
+    ea.keys[k].keyIndex = static_cast<int32_t>(k);
+    if (h.generic) {
+      ea.keys[k].store = h.gKeyStore[k].as<uint64_t>();
+      ea.keys[k].storeWords = keyStoreWords(h.keys[k].kind);
+    }
   }
+  ea.nullStore = h.generic ? h.gNullStore.as<uint64_t>() : nullptr;
   auto physOff = [&](int32_t p) {
     if (p < 0) {
       return -1;
