@@ -1849,7 +1849,7 @@ void ensureBasics(vx355_agg& h) {
   h.pattern.ensure(pat.size() * 8);
   copyIn(h.pattern.ptr(), pat.data(), VX355_MEM_HOST, pat.size() * 8);
   h.countersBuf.ensure(sizeof(Counters));
-  rt.sync();
+  rt.sync();  // 'pat' is a stack buffer: the upload must finish before it dies
 }
 
 void resetCounters(vx355_agg& h) {
@@ -2739,9 +2739,9 @@ void getOutput(vx355_agg& h, vx355_out_column* cols, int32_t numCols, int32_t ma
   VX_LAUNCH("k_extract", k_extract, static_cast<int>(ceilDiv(n, 256)), 256, 0, ea);
   for (int32_t i = 0; i < numCols; ++i) {
     if (cols[i].mem == VX355_MEM_HOST) {
-      copyOut(cols[i].values, VX355_MEM_HOST, scratch + offsets[i], valueBytes[i]);
+      copyOutAsync(cols[i].values, VX355_MEM_HOST, scratch + offsets[i], valueBytes[i]);
       if (cols[i].nulls) {
-        copyOut(cols[i].nulls, VX355_MEM_HOST, scratch + nullOffsets[i], words * 8);
+        copyOutAsync(cols[i].nulls, VX355_MEM_HOST, scratch + nullOffsets[i], words * 8);
       }
     }
   }

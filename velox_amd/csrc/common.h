@@ -182,6 +182,8 @@ class DeviceBatch {
 
 // Copies caller-visible results out of device scratch.
 void copyOut(void* dst, int32_t dstMem, const void* devSrc, size_t bytes);
+// Same without the stream synchronisation: the caller syncs once after a batch of copies.
+void copyOutAsync(void* dst, int32_t dstMem, const void* devSrc, size_t bytes);
 void copyIn(void* devDst, const void* src, int32_t srcMem, size_t bytes);
 
 inline int64_t ceilDiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1119,17 +1119,17 @@ void probeGetOutput(vx355_join_probe& p, int32_t maxRows, int32_t* mappingOut, i
     VX_LAUNCH("k_gather_deps", k_gather_deps, static_cast<int>(ceilDiv(n, 256)), 256, 0, ga);
     for (int32_t c = 0; c < numBuildCols; ++c) {
       if (buildCols[c].mem == VX355_MEM_HOST) {
-        copyOut(buildCols[c].values, VX355_MEM_HOST, scratch + valOff[c], valBytes[c]);
+        copyOutAsync(buildCols[c].values, VX355_MEM_HOST, scratch + valOff[c], valBytes[c]);
         if (buildCols[c].nulls) {
-          copyOut(buildCols[c].nulls, VX355_MEM_HOST, scratch + nullOff[c], words * 8);
+          copyOutAsync(buildCols[c].nulls, VX355_MEM_HOST, scratch + nullOff[c], words * 8);
         }
       }
     }
   }
   if (host) {
-    copyOut(mappingOut, VX355_MEM_HOST, dMap, static_cast<size_t>(n) * 4);
+    copyOutAsync(mappingOut, VX355_MEM_HOST, dMap, static_cast<size_t>(n) * 4);
     if (buildRowsOut) {
-      copyOut(buildRowsOut, VX355_MEM_HOST, dRows, static_cast<size_t>(n) * 4);
+      copyOutAsync(buildRowsOut, VX355_MEM_HOST, dRows, static_cast<size_t>(n) * 4);
     }
   }
   rt.sync();

@@ -180,6 +180,16 @@ void copyOut(void* dst, int32_t dstMem, const void* devSrc, size_t bytes) {
   }
 }
 
+void copyOutAsync(void* dst, int32_t dstMem, const void* devSrc, size_t bytes) {
+  if (!bytes) {
+    return;
+  }
+  auto& rt = Runtime::get();
+  HIP_OK(hipMemcpyAsync(dst, devSrc, bytes,
+                        dstMem == VX355_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
+                        rt.stream));
+}
+
 void copyIn(void* devDst, const void* src, int32_t srcMem, size_t bytes) {
   if (!bytes) {
     return;
