@@ -29,6 +29,7 @@
 #include "expr_device.h"
 
 #include <algorithm>
+#include <cmath>
 #include <utility>
 #include <cstdio>
 #include <cstdlib>
@@ -45,7 +46,8 @@ void makeProjectionArgs(const DeviceBatch& db, const vx355_projection* proj, int
 namespace {
 
 constexpr int kMaxKeys = 8;
-constexpr int kMaxAccs = 16;
+constexpr int kMaxAccs = 16;      // accumulators a kernel updates per row
+constexpr int kMaxLdsAccs = 28;   // LDS / table words they touch (DOUBLE sums own two)
 constexpr uint64_t kEmpty = ~0ULL;
 constexpr uint64_t kNoRow = ~0ULL;
 
@@ -74,6 +76,13 @@ struct AccArg {
   int32_t inIsInt;  // value travels as int64 (else double)
   int32_t off;      // word offset inside the group row
   int32_t inProj;   // >= 0: the input is projection inProj of the fused FilterProject
+  // DOUBLE sums are kept as two words: 'hi' receives the value rounded to a
+  // fixed grid (v + splitM) - splitM — sums of grid multiples are exact, hence
+  // order independent — and 'lo' (the next word) the exact remainder v - hi.
+  // splitM = 0: plain accumulation into hi.
+  double splitM;
+  int32_t ldsIdx;   // position of 'hi' among the LDS accumulators of the launch
+  int32_t pad;
 };
 
 // Counters the kernels bump; mirrored into the pinned mailbox by the host.
@@ -86,6 +95,7 @@ struct Counters {
   uint32_t pad[3];
   int64_t keyMin[kMaxKeys];
   int64_t keyMax[kMaxKeys];
+  uint64_t sumMax[kMaxAccs];  // largest |input| seen per DOUBLE sum (bit pattern), k_sum_stats
 };
 
 struct AggArgs {
@@ -248,6 +258,20 @@ __host__ __device__ inline uint64_t accIdentity(int32_t kind) {
   return kind == ACC_MIN ? ~0ULL : 0ULL;
 }
 
+// Error-free split of v against the grid encoded in m = 1.5 * 2^(G+52):
+// hi is v rounded to a multiple of 2^G, lo = v - hi exactly (|v| < 2^(G+51)).
+__device__ inline void splitDouble(double v, double m, double* hi, double* lo) {
+  if (!(fabs(v) < m * 0.25)) {
+    // Too large for the grid (or inf / NaN): plain accumulation for this value.
+    *hi = v;
+    *lo = 0.0;
+    return;
+  }
+  const double t = v + m;
+  *hi = t - m;
+  *lo = v - *hi;
+}
+
 // Normalized key of one input row (VectorHasher::computeValueIds semantics).
 // Returns 0 = key ready, 1 = row dropped (null key with ignoreNullKeys),
 // 2 = some value lies outside the current ranges (statistics updated).
@@ -358,7 +382,15 @@ __device__ inline void updateGlobal(const AggArgs& a, int64_t row, uint64_t key,
     const AccArg& acc = a.accs[i];
     uint64_t v;
     if (accInput(a, acc, row, &v)) {
-      applyGlobal(g + acc.off, acc.kind, v, a.counters);
+      if (acc.kind == ACC_SUM_F64 && acc.splitM != 0.0) {
+        double hi, lo;
+        splitDouble(__longlong_as_double(static_cast<long long>(v)), acc.splitM, &hi, &lo);
+        applyGlobal(g + acc.off, ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(hi)), a.counters);
+        applyGlobal(g + acc.off + 1, ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(lo)),
+                    a.counters);
+      } else {
+        applyGlobal(g + acc.off, acc.kind, v, a.counters);
+      }
     }
   }
 }
@@ -417,8 +449,8 @@ struct LdsPlan {
   int32_t pad;
   uint64_t rowBase;
   Counters* counters;
-  int32_t kind[kMaxAccs];
-  int32_t off[kMaxAccs];
+  int32_t kind[kMaxLdsAccs];
+  int32_t off[kMaxLdsAccs];
 };
 
 struct LdsState {
@@ -586,11 +618,20 @@ __global__ __launch_bounds__(1024) void k_agg_lds(LdsArgs args) {
         if (slot >= 0) {
           ldsTouchFirst(st, slot, static_cast<uint32_t>(row));
           uint64_t* base = st.acc + (static_cast<size_t>(slot) * A) * REP + rep;
-          for (int j = 0; j < A; ++j) {
+          for (int j = 0; j < a.numAccs; ++j) {
             const AccArg& ac = a.accs[j];
             uint64_t v;
             if (accInput(a, ac, row, &v)) {
-              applyLds(base + j * REP, ac.kind, v, a.counters);
+              if (ac.kind == ACC_SUM_F64 && ac.splitM != 0.0) {
+                double hi, lo;
+                splitDouble(__longlong_as_double(static_cast<long long>(v)), ac.splitM, &hi, &lo);
+                applyLds(base + ac.ldsIdx * REP, ACC_SUM_F64,
+                         static_cast<uint64_t>(__double_as_longlong(hi)), a.counters);
+                applyLds(base + (ac.ldsIdx + 1) * REP, ACC_SUM_F64,
+                         static_cast<uint64_t>(__double_as_longlong(lo)), a.counters);
+              } else {
+                applyLds(base + ac.ldsIdx * REP, ac.kind, v, a.counters);
+              }
             }
           }
         } else {
@@ -641,6 +682,7 @@ struct FastArgs {
   FastTerm term[kFastTerms];
   double scale[kFastAccs][kFastFactors];
   double offset[kFastAccs][kFastFactors];
+  double splitM[kFastAccs];  // grid of the hi/lo split of sum j (0 = accumulate into hi only)
   int64_t numRows;
   int32_t* deferred;
   uint32_t deferCap;
@@ -667,6 +709,15 @@ struct FastShape {
     return ((j < 4 ? ACC_LO >> (16 * j) : ACC_HI >> (16 * (j - 4)))) & 0xffff;
   }
   static constexpr int numFactors(int j) { return static_cast<int>(desc(j) & 15); }
+  // LDS / table word of accumulator j: every DOUBLE sum before it owns two words (hi, lo).
+  static constexpr int ldsIndex(int j) {
+    int idx = 0;
+    for (int q = 0; q < j; ++q) {
+      idx += numFactors(q) == 0 ? 1 : 2;
+    }
+    return idx;
+  }
+  static constexpr int numLdsAccs = ldsIndex(NA);
   static constexpr int load(int j, int f) { return static_cast<int>((desc(j) >> (4 + 4 * f)) & 15); }
 };
 
@@ -712,7 +763,8 @@ template <typename S>
 __global__ __launch_bounds__(512, 4) void k_agg_fast(FastArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
   constexpr int UNROLL = S::unroll;
-  constexpr int A = S::numAccs;
+  constexpr int NA = S::numAccs;     // accumulators of the plan
+  constexpr int A = S::numLdsAccs;   // words they own (DOUBLE sums: hi + lo)
   const LdsPlan& p = a.plan;
   const LdsState st = ldsInit(p, ldsRaw);
   const int REP = p.REP;
@@ -808,8 +860,8 @@ __global__ __launch_bounds__(512, 4) void k_agg_fast(FastArgs a) {
       });
       if (live && !defer) {
         const int32_t slot = ldsSlot(p, st, key);
-        double vals[A > 0 ? A : 1];
-        staticFor<A>([&](auto jc) {
+        double vals[NA > 0 ? NA : 1];
+        staticFor<NA>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
           double acc = 0;
           staticFor<S::numFactors(j)>([&](auto fc) {
@@ -825,12 +877,20 @@ __global__ __launch_bounds__(512, 4) void k_agg_fast(FastArgs a) {
         if (slot >= 0) {
           ldsTouchFirst(st, slot, static_cast<uint32_t>(row));
           uint64_t* dst = st.acc + (static_cast<size_t>(slot) * A) * REP + rep;
-          staticFor<A>([&](auto jc) {
+          staticFor<NA>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
+            constexpr int w = S::ldsIndex(j);
             if constexpr (S::numFactors(j) == 0) {
-              atomicAdd(reinterpret_cast<unsigned long long*>(dst + j * REP), 1ULL);
+              atomicAdd(reinterpret_cast<unsigned long long*>(dst + w * REP), 1ULL);
             } else {
-              unsafeAtomicAdd(reinterpret_cast<double*>(dst + j * REP), vals[j]);
+              if (a.splitM[j] != 0.0) {
+                double hi, lo;
+                splitDouble(vals[j], a.splitM[j], &hi, &lo);
+                unsafeAtomicAdd(reinterpret_cast<double*>(dst + w * REP), hi);
+                unsafeAtomicAdd(reinterpret_cast<double*>(dst + (w + 1) * REP), lo);
+              } else {
+                unsafeAtomicAdd(reinterpret_cast<double*>(dst + w * REP), vals[j]);
+              }
             }
           });
         } else {
@@ -841,13 +901,22 @@ __global__ __launch_bounds__(512, 4) void k_agg_fast(FastArgs a) {
           if (old == kNoRow) {
             atomicAdd(&p.counters->numNewGroups, 1u);
           }
-          staticFor<A>([&](auto jc) {
+          staticFor<NA>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
+            constexpr int w = S::ldsIndex(j);
             if constexpr (S::numFactors(j) == 0) {
-              applyGlobal(g + p.off[j], ACC_SUM_I64_WRAP, 1, p.counters);
+              applyGlobal(g + p.off[w], ACC_SUM_I64_WRAP, 1, p.counters);
             } else {
-              applyGlobal(g + p.off[j], ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(vals[j])),
+              double hi = vals[j], lo = 0;
+              if (a.splitM[j] != 0.0) {
+                splitDouble(vals[j], a.splitM[j], &hi, &lo);
+              }
+              applyGlobal(g + p.off[w], ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(hi)),
                           p.counters);
+              if (a.splitM[j] != 0.0) {
+                applyGlobal(g + p.off[w + 1], ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(lo)),
+                            p.counters);
+              }
             }
           });
         }
@@ -1186,6 +1255,47 @@ __global__ __launch_bounds__(256) void k_key_stats(StatsArgs a) {
   }
 }
 
+// Largest |input| of every DOUBLE sum over the analysed prefix: fixes the grid
+// of the hi/lo split (AccArg::splitM).
+__global__ __launch_bounds__(256) void k_sum_stats(AggArgs a) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  uint64_t mx[kMaxAccs];
+#pragma unroll
+  for (int j = 0; j < kMaxAccs; ++j) {
+    mx[j] = 0;
+  }
+  for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < a.numRows;
+       row += stride) {
+    if (a.numTerms && !evalFilter(a.terms, a.numTerms, row)) {
+      continue;
+    }
+#pragma unroll
+    for (int j = 0; j < kMaxAccs; ++j) {
+      if (j < a.numAccs && a.accs[j].kind == ACC_SUM_F64) {
+        uint64_t v;
+        if (accInput(a, a.accs[j], row, &v)) {
+          v &= 0x7fffffffffffffffULL;  // |v| as a bit pattern orders like the magnitude
+          mx[j] = v > mx[j] ? v : mx[j];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kMaxAccs; ++j) {
+    if (j < a.numAccs && a.accs[j].kind == ACC_SUM_F64) {
+      uint64_t m = mx[j];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t o = shfl64(m, lane() ^ off);
+        m = o > m ? o : m;
+      }
+      if (lane() == 0 && m != 0) {
+        atomicMax(reinterpret_cast<unsigned long long*>(&a.counters->sumMax[j]), m);
+      }
+    }
+  }
+}
+
 // ---- table maintenance ---------------------------------------------------------
 __global__ __launch_bounds__(256) void k_init_table(uint64_t* table, uint64_t rows, int32_t stride,
                                                      const uint64_t* pattern) {
@@ -1324,6 +1434,7 @@ struct OutAgg {
   int32_t aggKind;   // vx355_agg_kind
   int32_t inputType;
   int32_t mainOff;
+  int32_t loOff;     // DOUBLE sum / avg: the 'lo' word (value = hi + lo); -1 otherwise
   int32_t seenOff;   // count of contributing rows; -1 = never null; 1 = the first-row word
                      // (group exists <=> some row contributed)
   int32_t finalOut;
@@ -1472,7 +1583,9 @@ __global__ __launch_bounds__(256) void k_extract(ExtractArgs a) {
           if (inInt) {
             static_cast<int64_t*>(oa.values)[pos] = valid ? static_cast<int64_t>(mainWord) : 0;
           } else {
-            double d = valid ? __longlong_as_double(static_cast<long long>(mainWord)) : 0.0;
+            double d = valid ? __longlong_as_double(static_cast<long long>(mainWord)) +
+                    __longlong_as_double(static_cast<long long>(g[oa.loOff]))
+                             : 0.0;
             if (oa.inputType == VX355_REAL && oa.finalOut) {
               static_cast<float*>(oa.values)[pos] = static_cast<float>(d);
             } else {
@@ -1496,7 +1609,8 @@ __global__ __launch_bounds__(256) void k_extract(ExtractArgs a) {
         break;
       default: {  // AVG
         writeBit(oa.nulls, pos, valid);
-        const double sum = __longlong_as_double(static_cast<long long>(mainWord));
+        const double sum = __longlong_as_double(static_cast<long long>(mainWord)) +
+            (active ? __longlong_as_double(static_cast<long long>(g[oa.loOff])) : 0.0);
         const int64_t cnt = static_cast<int64_t>(seen);
         if (oa.finalOut) {
           if (active) {
@@ -1558,6 +1672,8 @@ struct PhysAcc {
   bool inIsInt;
   int32_t aliasOf = -1;  // COUNT(col) == COUNT(*) while no batch had nulls in col
   bool valueNeeded = false;  // the count itself is an output (count / avg), not just a "seen" flag
+  bool isLo = false;         // second word of a DOUBLE sum (exact remainder of the grid split)
+  double splitM = 0;         // DOUBLE sum: 1.5 * 2^(G+52) of the grid, 0 = no split
 };
 
 struct LogicalAgg {
@@ -1624,6 +1740,7 @@ struct vx355_agg {
   uint64_t arrayMax = 1ULL << 28;
   int64_t chunkRows = 1LL << 31;
   bool disableFast = false;
+  bool exactSums = true;
   bool logShapes = false;
   int64_t deferCap = 1 << 20;
   int fastUnroll = 4;
@@ -1637,7 +1754,7 @@ namespace {
 int32_t findOrAddPhys(vx355_agg& h, int32_t kind, int32_t col, int32_t mask, bool inIsInt) {
   for (size_t i = 0; i < h.phys.size(); ++i) {
     const auto& p = h.phys[i];
-    if (p.kind == kind && p.inputCol == col && p.maskCol == mask && p.inIsInt == inIsInt) {
+    if (!p.isLo && p.kind == kind && p.inputCol == col && p.maskCol == mask && p.inIsInt == inIsInt) {
       return static_cast<int32_t>(i);
     }
   }
@@ -1647,7 +1764,17 @@ int32_t findOrAddPhys(vx355_agg& h, int32_t kind, int32_t col, int32_t mask, boo
   p.maskCol = mask;
   p.inIsInt = inIsInt;
   h.phys.push_back(p);
-  return static_cast<int32_t>(h.phys.size() - 1);
+  const int32_t index = static_cast<int32_t>(h.phys.size() - 1);
+  if (kind == ACC_SUM_F64) {
+    PhysAcc lo;
+    lo.kind = ACC_SUM_F64;
+    lo.inputCol = -1;
+    lo.maskCol = -1;
+    lo.inIsInt = false;
+    lo.isLo = true;
+    h.phys.push_back(lo);  // always the word right after its 'hi'
+  }
+  return index;
 }
 
 // COUNT of non-null 'col' rows; starts as an alias of the row count under the
@@ -1752,7 +1879,11 @@ void buildPlan(vx355_agg& h, const vx355_agg_spec& spec) {
     }
     h.aggs.push_back(la);
   }
-  if (h.phys.size() > static_cast<size_t>(kMaxAccs)) {
+  size_t workAccs = 0;
+  for (const auto& p : h.phys) {
+    workAccs += p.isLo ? 0 : 1;
+  }
+  if (workAccs > static_cast<size_t>(kMaxAccs) || h.phys.size() > static_cast<size_t>(kMaxLdsAccs)) {
     VX_THROW(VX355_EUNSUPPORTED, "too many accumulators for one device table");
   }
   VX_CHECK_ARG(h.keys.size() <= static_cast<size_t>(kMaxKeys), "at most 8 grouping keys");
@@ -2099,6 +2230,7 @@ bool buildFastArgs(const AggArgs& c, const LdsPlan& plan, FastArgs* f, FastSigna
       f->offset[j][0] = 0.0;
       desc = accDesc(1, slot);
     }
+    f->splitM[j] = ac.kind == ACC_SUM_F64 ? ac.splitM : 0.0;
     if (j < 4) {
       sig->accLo |= desc << (16 * j);
     } else {
@@ -2146,11 +2278,12 @@ void fillAccArgs(vx355_agg& h, const DeviceBatch& db, AggArgs* a) {
   int n = 0;
   for (size_t i = 0; i < h.phys.size(); ++i) {
     const auto& p = h.phys[i];
-    if (p.aliasOf >= 0 || flagFromFirstRow(h, static_cast<int32_t>(i))) {
+    if (p.isLo || p.aliasOf >= 0 || flagFromFirstRow(h, static_cast<int32_t>(i))) {
       continue;
     }
     AccArg& aa = a->accs[n++];
     aa = AccArg{};
+    aa.splitM = p.splitM;
     aa.kind = p.kind;
     aa.inIsInt = p.inIsInt ? 1 : 0;
     aa.off = 2 + static_cast<int32_t>(i);
@@ -2225,16 +2358,25 @@ void launchChunk(vx355_agg& h, AggArgs& a) {
   auto& rt = Runtime::get();
   size_t ldsBytes = 0;
   LdsArgs la{};
-  if (chooseLds(h, a.numAccs, &la.plan, &ldsBytes)) {
+  // LDS / table words of the launch: a DOUBLE sum owns two (hi, lo).
+  int numWords = 0;
+  for (int j = 0; j < a.numAccs; ++j) {
+    a.accs[j].ldsIdx = numWords;
+    la.plan.kind[numWords] = a.accs[j].kind;
+    la.plan.off[numWords] = a.accs[j].off;
+    ++numWords;
+    if (a.accs[j].kind == ACC_SUM_F64) {
+      la.plan.kind[numWords] = ACC_SUM_F64;
+      la.plan.off[numWords] = a.accs[j].off + 1;
+      ++numWords;
+    }
+  }
+  if (chooseLds(h, numWords, &la.plan, &ldsBytes)) {
     LdsPlan& plan = la.plan;
     plan.table = a.table;
     plan.stride = a.stride;
     plan.rowBase = a.rowBase;
     plan.counters = a.counters;
-    for (int j = 0; j < a.numAccs; ++j) {
-      plan.kind[j] = a.accs[j].kind;
-      plan.off[j] = a.accs[j].off;
-    }
     FastArgs fa;
     FastSignature sig;
     if (!h.disableFast && buildFastArgs(a, plan, &fa, &sig)) {
@@ -2262,6 +2404,11 @@ void launchChunk(vx355_agg& h, AggArgs& a) {
     int grid = static_cast<int>(std::min<int64_t>(ceilDiv(a.numRows, 1024), rt.numCUs * 2));
     VX_LAUNCH("k_agg_lds", k_agg_lds, grid, 1024, ldsBytes, la);
   } else {
+    // One HBM atomic per sum and row is the budget of the high-cardinality
+    // path: no hi/lo split there (few rows per group: little to gain).
+    for (int j = 0; j < a.numAccs; ++j) {
+      a.accs[j].splitM = 0;
+    }
     VX_LAUNCH("k_agg_global", k_agg_global, streamGrid(a.numRows, 256), 256, 0, a);
   }
 }
@@ -2382,6 +2529,9 @@ void addInputGeneric(vx355_agg& h, AggArgs& a, int64_t n) {
     GenericArgs ga{};
     ga.a = a;
     AggArgs& c = ga.a;
+    for (int j = 0; j < c.numAccs; ++j) {
+      c.accs[j].splitM = 0;
+    }
     c.numRows = rows;
     c.rowBase = static_cast<uint64_t>(h.inputRows + begin);
     c.table = h.table.as<uint64_t>();
@@ -2467,6 +2617,34 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
       c.unmappable = 0;
       checkCounters(c);
       mergeObserved(h, c);
+    }
+    if (!needGeneric && h.exactSums) {
+      // Grid of the hi/lo split of every DOUBLE sum, from the largest magnitude
+      // in the analysed prefix: values < 2^L, grid 2^(L-21), so up to 2^32 grid
+      // multiples add up exactly in the 53-bit significand of 'hi'. A later
+      // value above 2^L only costs accuracy, never correctness.
+      AggArgs sa = a;
+      sa.numRows = std::min<int64_t>(n, 1 << 20);
+      resetCounters(h);
+      VX_LAUNCH("k_sum_stats", k_sum_stats, streamGrid(sa.numRows, 256), 256, 0, sa);
+      Counters c = readCounters(h);
+      for (int j = 0; j < a.numAccs; ++j) {
+        if (a.accs[j].kind != ACC_SUM_F64) {
+          continue;
+        }
+        const uint64_t bits = c.sumMax[j];
+        const int biased = static_cast<int>((bits >> 52) & 0x7ff);
+        double m = 0;
+        if (bits != 0 && biased != 0 && biased != 0x7ff) {
+          const int L = (biased - 1023) + 1 + 4;
+          const int G = L - 21;
+          if (G + 52 < 1000 && G + 52 > -1000) {
+            m = std::ldexp(1.5, G + 52);
+          }
+        }
+        h.phys[a.accs[j].off - 2].splitM = m;
+        a.accs[j].splitM = m;
+      }
     }
     if (!needGeneric) {
       try {
@@ -2725,6 +2903,7 @@ void getOutput(vx355_agg& h, vx355_out_column* cols, int32_t numCols, int32_t ma
     oa.aggKind = la.fn.kind;
     oa.inputType = la.fn.input_type;
     oa.mainOff = physOff(la.main);
+    oa.loOff = (la.main >= 0 && h.phys[la.main].kind == ACC_SUM_F64) ? oa.mainOff + 1 : -1;
     oa.seenOff = physOff(la.seen);
     oa.finalOut = fin ? 1 : 0;
     oa.values = devValues(c);
@@ -2766,6 +2945,9 @@ int vx355_agg_create(const vx355_agg_spec* spec, vx355_agg** out) {
   h->ignoreNullKeys = spec->ignore_null_keys != 0;
   if (const char* e = std::getenv("VX355_ARRAY_MAX")) {
     h->arrayMax = std::strtoull(e, nullptr, 10);
+  }
+  if (const char* e = std::getenv("VX355_EXACT_SUMS")) {
+    h->exactSums = e[0] != '0';
   }
   if (const char* e = std::getenv("VX355_LOG_SHAPES")) {
     h->logShapes = e[0] == '1';
