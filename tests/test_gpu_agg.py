@@ -59,6 +59,9 @@ def test_random_doubles_within_one_ulp_of_exact_sum(oracle, vx):
     # math.fsum. The reference's own sequential sum is several ULP away.
     gpu_err = ulp_distance(got[1][0], e)
     assert (gpu_err <= 1).all(), gpu_err.max()
+    cnt = np.asarray(got[2][0], dtype=np.float64)
+    assert (got[2][0] == exp[2][0]).all()
+    assert (got[3][0] == exp[3][0]).all() and (got[4][0] == exp[4][0]).all()
     assert (ulp_distance(got[5][0], e / cnt) <= 2).all()  # avg = sum/count: one more rounding
 
 
@@ -428,3 +431,27 @@ def test_c1_device_resident_takes_fast_kernel(oracle, vx):
     assert (np.asarray(got[1][0]) == 2 * np.asarray(exp[1][0])).all()
     assert (np.asarray(got[2][0]) == 2 * np.asarray(exp[2][0])).all()
     assert (got[0][0] == exp[0][0]).all()
+
+
+def test_decimal_like_sums_few_groups_within_one_ulp(oracle, vx):
+    """TPC-H-like money values (cents, not dyadic), 4 M rows into 4 hot groups
+    through the shape-specialised LDS kernel: every sum must be within 1 ULP of
+    the exact sum; the sequential CPU sum of the reference's algorithm is not."""
+    import math
+    rng = np.random.default_rng(123)
+    n = 1 << 22
+    k = rng.integers(0, 4, n).astype(np.int64)
+    v = rng.integers(90000, 10500000, n) / 100.0
+    hb = batch_of([k, v])
+    aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    vx.profile_reset()
+    vx.profile_enable(True)
+    got, gop = run_agg(vx, [vx.to_device(hb)], [0], [abi.BIGINT], aggs)
+    vx.profile_enable(False)
+    assert "k_agg_fast" in vx.profile()
+    exp, _ = run_agg(oracle, [hb], [0], [abi.BIGINT], aggs)
+    assert (got[0][0] == exp[0][0]).all() and (got[2][0] == exp[2][0]).all()
+    exact = np.array([math.fsum(v[k == g]) for g in got[0][0]])
+    gpu_err = ulp_distance(got[1][0], exact)
+    cpu_err = ulp_distance(exp[1][0], exact)
+    assert (gpu_err <= 1).all(), (gpu_err, cpu_err)

@@ -2609,7 +2609,7 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
       for (int k = 0; k < a.numKeys; ++k) {
         sa.keys[k] = a.keys[k];
       }
-      sa.numRows = std::min<int64_t>(n, 1 << 20);
+      sa.numRows = std::min<int64_t>(n, 1 << 18);
       sa.counters = h.counters();
       VX_LAUNCH("k_key_stats", k_key_stats, streamGrid(sa.numRows, 256), 256, 0, sa);
       Counters c = readCounters(h);
@@ -2624,7 +2624,7 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
       // multiples add up exactly in the 53-bit significand of 'hi'. A later
       // value above 2^L only costs accuracy, never correctness.
       AggArgs sa = a;
-      sa.numRows = std::min<int64_t>(n, 1 << 20);
+      sa.numRows = std::min<int64_t>(n, 1 << 16);
       resetCounters(h);
       VX_LAUNCH("k_sum_stats", k_sum_stats, streamGrid(sa.numRows, 256), 256, 0, sa);
       Counters c = readCounters(h);
