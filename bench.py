@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="q1", choices=["q1", "c1", "c4", "q3"])
+    ap.add_argument("--workload", default="q1", choices=["q1", "c1", "c4", "q3", "c5"])
     ap.add_argument("--rows", type=int, default=0, help="override the row count (debug)")
     ap.add_argument("--cpu-sample-rows", type=int, default=16_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -418,7 +418,67 @@ class Q3:
         return total, time.perf_counter() - t0
 
 
-WORKLOADS = {"q1": (Q1, 600_037_902), "c1": (C1, 10_000_000), "c4": (C4, 1_000_000_000),
+class C5:
+    """BASELINE configs[4]: fact (fk BIGINT, m DOUBLE) join dim (pk BIGINT unique, a BIGINT),
+    both row-range partitioned over the GPUs; radix repartition by VectorHasher
+    hash, one all-to-all per column over RCCL, local build + probe
+    (velox_amd/dist.py: repartitioned_join). rows = fact rows per GPU; the dim
+    side has rows / 10 per GPU. At N = 1 the exchange is a local copy."""
+    name = "c5_partitioned_join"
+    bytes_per_row = 32
+    agg_bytes_per_row = 24
+    dominant = "k_join_probe"
+
+    def __init__(self, torch, n, device, seed, rank=0, world=1):
+        g = torch.Generator(device=device)
+        g.manual_seed(seed)
+        self.torch, self.n, self.world = torch, n, world
+        nd = max(1, n // 10)
+        self.pk = (torch.arange(rank * nd, (rank + 1) * nd, dtype=torch.int64, device=device) * 7919) % (1 << 45)
+        self.a = torch.randint(0, 1 << 40, (nd,), dtype=torch.int64, device=device, generator=g)
+        idx = torch.randint(0, world * nd, (n,), dtype=torch.int64, device=device, generator=g)
+        self.fk = (idx * 7919) % (1 << 45)
+        self.m = torch.rand(n, dtype=torch.float64, device=device, generator=g)
+        self.backend = vdist.GpuJoinBackend(ops, torch)
+        torch.cuda.synchronize()
+
+    def step(self, step_kind=None):
+        import torch.distributed as dist
+        total, outputs, stats = vdist.repartitioned_join(self.backend, dist, self.torch,
+                                                         [self.pk, self.a], [self.fk, self.m])
+        self.matches, self.stats = total, stats
+        return total
+
+    def rows_per_step(self):
+        return self.n
+
+    def info(self):
+        return {"fact_rows_per_gpu": self.n, "dim_rows_per_gpu": int(self.pk.shape[0]),
+                "matches_on_rank0": int(self.matches), "table_mode": int(self.stats.hash_mode)}
+
+    def host_sample(self, rows):
+        rows = min(rows, self.n)
+        return {"pk": self.pk.cpu().numpy(), "a": self.a.cpu().numpy(), "pkey": self.fk[:rows].cpu().numpy()}
+
+    def cpu_reference(self, sample, oracle):
+        t0 = time.perf_counter()
+        b = oracle.JoinBuild([0], [abi.BIGINT], [1], [abi.BIGINT], abi.JOIN_INNER)
+        b.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, sample["pk"]), abi.HostColumn(abi.BIGINT, sample["a"])]))
+        t = b.finish()
+        p = oracle.JoinProbe(t, [0], abi.JOIN_INNER)
+        total = 0
+        pk = sample["pkey"]
+        for lo in range(0, len(pk), 1 << 20):
+            p.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, pk[lo:lo + (1 << 20)])]))
+            while True:
+                m, r, cols, fin = p.get_output(1 << 20)
+                total += len(m)
+                if fin:
+                    break
+        return total, time.perf_counter() - t0
+
+
+WORKLOADS = {"c5": (C5, 1_000_000_000), "q1": (Q1, 600_037_902), "c1": (C1, 10_000_000), "c4": (C4, 1_000_000_000),
              "q3": (Q3, 600_037_902)}
 
 
@@ -450,7 +510,14 @@ def main():
     n = args.rows or default_rows
     if args.workload == "q3":
         cls.random_probe = args.q3_random_probe
-    wl = cls(torch, n, device, seed=1234 + rank)
+    if args.workload == "c5":
+        if world == 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29544")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        wl = cls(torch, n, device, seed=1234 + rank, rank=rank, world=world)
+    else:
+        wl = cls(torch, n, device, seed=1234 + rank)
     if args.workload == "q1":
         wl.fused = not args.unfused
 
@@ -536,13 +603,14 @@ def main():
         import oracle_lib
         oracle_lib.lib()
         sample = wl.host_sample(args.cpu_sample_rows)
-        sample_rows = len(next(iter(sample.values()))) if args.workload != "q3" else len(sample["pkey"])
+        sample_rows = len(sample["pkey"]) if "pkey" in sample else len(next(iter(sample.values())))
         cpu_out, cpu_s = wl.cpu_reference(sample, oracle_lib)
         out["cpu_baseline"] = {
             "value": sample_rows / cpu_s, "unit": "rows/s", "cores": 1, "kind": "port",
             "sample": f"first {sample_rows} rows of the same {wl.name} input, single thread: "
                       "Velox-algorithm CPU restatement (oracle/) of the same plan"
-                      + (" with numpy FilterProject" if args.workload == "q1" else ""),
+                      + (" with numpy FilterProject" if args.workload == "q1" else "")
+                      + (" (local join only: no exchange on the CPU side)" if args.workload == "c5" else ""),
             "host_cores_available": os.cpu_count(),
         }
     print(json.dumps(out))

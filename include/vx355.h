@@ -208,6 +208,25 @@ int vx355_partition(
     uint32_t* partitions_out,
     int32_t mem);
 
+/* Repartitioning (exec/PartitionedOutput.cpp + exec/HashPartitionFunction.cpp,
+ * what feeds an Exchange): reorders num_cols fixed-width columns so that the
+ * rows of partition 0 come first, then partition 1, ... with the input order
+ * kept inside each partition (stable), and reports the row count of every
+ * partition. partitions[] is the output of vx355_partition. widths[c] is the
+ * byte width of column c (1, 2, 4, 8 or 16). counts_out is a host array of
+ * num_partitions entries; everything else lives in mem. num_partitions <= 64
+ * (one partition per GPU of a node, or per spill bucket). */
+int vx355_partition_scatter(
+    const uint32_t* partitions,
+    int32_t num_rows,
+    int32_t num_partitions,
+    const void* const* cols_in,
+    const int32_t* widths,
+    int32_t num_cols,
+    void* const* cols_out,
+    int64_t* counts_out,
+    int32_t mem);
+
 /* ---- FilterProject for the TPC-H Q1 / Q3 expression class ----------------- */
 
 /* The step immediately upstream of HashAggregation / HashProbe

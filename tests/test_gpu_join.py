@@ -207,3 +207,33 @@ def test_q3_shape_device_resident_probe(oracle, vx):
     got = list(zip(mapping.to_host(n).tolist(), rows.to_host(n).tolist()))
     assert got == e_pairs
     assert dates.to_host(n).tolist() == [p[0] for p in e_payload]
+
+
+def test_repartitioned_join_gpu_backend_single_rank(oracle, vx):
+    """The config-5 pipeline on one GPU (world = 1, RCCL): hash -> partition ->
+    stable scatter -> all-to-all -> local build + probe, all in HBM, against the
+    oracle's join of the same rows."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from velox_amd import dist as vdist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        rng = np.random.default_rng(51)
+        nd, nf = 50000, 400000
+        pk = rng.permutation(1 << 20)[:nd].astype(np.int64)
+        a = rng.integers(0, 1 << 40, nd).astype(np.int64)
+        fk = np.where(rng.random(nf) < 0.9, pk[rng.integers(0, nd, nf)], -1).astype(np.int64)
+        t = [torch.from_numpy(x).to(dev) for x in (pk, a, fk)]
+        backend = vdist.GpuJoinBackend(vx, torch)
+        total, outputs, stats = vdist.repartitioned_join(backend, dist, torch, [t[0], t[1]], [t[2]])
+        assert stats.num_rows == nd
+        lookup = dict(zip(pk.tolist(), a.tolist()))
+        want = sorted(lookup[k] for k in fk.tolist() if k in lookup)
+        got = sorted(np.concatenate([p.cpu().numpy() for _, p in outputs]).tolist())
+        assert total == len(want) and got == want
+    finally:
+        dist.destroy_process_group()

@@ -200,3 +200,19 @@ def test_filter_project_q1_q3_expressions(oracle, vx):
         for j in range(len(projs)):
             assert (e_nulls[j] == g_nulls[j]).all()
             assert (e_out[j][e_nulls[j]] == g_out[j][g_nulls[j]]).all()  # bit-exact doubles
+
+
+@pytest.mark.parametrize("num_parts", [1, 2, 8, 13, 64])
+@pytest.mark.parametrize("n", [0, 1, 4095, 4097, 100003])
+def test_partition_scatter_is_a_stable_partition(vx, num_parts, n):
+    rng = np.random.default_rng(n * 100 + num_parts)
+    parts = rng.integers(0, num_parts, n).astype(np.uint32)
+    k = rng.integers(-2 ** 62, 2 ** 62, n).astype(np.int64)
+    d = rng.integers(0, 1 << 20, n).astype(np.int32)
+    s16 = rng.integers(0, 255, (n, 16)).astype(np.uint8)
+    b = rng.integers(0, 255, n).astype(np.uint8)
+    outs, counts = vx.partition_scatter(parts, num_parts, [k, d, s16, b])
+    order = np.argsort(parts, kind="stable")
+    assert (counts == np.bincount(parts, minlength=num_parts)).all()
+    for got, col in zip(outs, [k, d, s16, b]):
+        assert (got == col[order]).all()

@@ -116,3 +116,137 @@ def merge_partials(impl, dist, torch, partial_columns, key_types, raw_aggs, devi
     op.add_input(batch)
     op.no_more_input()
     return impl.collect_output(op, MAX_GROUPS)
+
+
+# ---- repartitioned hash join (BASELINE config 5) ------------------------------
+# Both inputs start row-range partitioned over the ranks. Each rank hashes its
+# key column (VectorHasher::hash), maps hashes to a destination rank
+# (HashPartitionFunction::partition), groups its rows by destination
+# (vx355_partition_scatter) and sends every group straight to its owner: ONE
+# all-to-all per column (RCCL grouped send/recv over the direct xGMI links; gloo
+# in the CPU tests). After the exchange equal keys live on the same rank and the
+# join is local. Nothing else in the path communicates.
+
+def partition_spec(world):
+    """(kind, kwargs) of the HashPartitionFunction flavour used for 'world'
+    destinations: the top hash bits for powers of two (disjoint from the bits the
+    tables index with, cf. checkHashBitsOverlap, exec/HashTable.cpp:1853), else
+    hash % world (exec/HashPartitionFunction.cpp:112-115)."""
+    if world > 1 and world & (world - 1) == 0:
+        bits = world.bit_length() - 1
+        return abi.PART_BIT_RANGE, dict(bit_begin=64 - bits, bit_end=64)
+    return abi.PART_MODULO, dict(num_partitions=max(1, world))
+
+
+def exchange(dist, torch, cols, counts):
+    """cols: torch tensors whose rows are grouped by destination rank;
+    counts[r] = rows for rank r. Returns the received columns (source-rank
+    order) and the per-source row counts."""
+    world = dist.get_world_size()
+    dev = cols[0].device if cols else "cpu"
+    send = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=dev)
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send)
+    rc = [int(x) for x in recv.cpu().tolist()]
+    sc = [int(x) for x in counts]
+    assert len(sc) == world
+    out = []
+    for c in cols:
+        got = torch.empty((sum(rc),) + tuple(c.shape[1:]), dtype=c.dtype, device=c.device)
+        dist.all_to_all_single(got, c.contiguous(), output_split_sizes=rc, input_split_sizes=sc)
+        out.append(got)
+    return out, rc
+
+
+def repartitioned_join(backend, dist, torch, build_cols, probe_cols):
+    """build_cols / probe_cols: lists of torch tensors, column 0 is the BIGINT
+    join key. backend supplies the device work:
+      backend.partitions(key_tensor, world) -> uint32 partition number per row
+      backend.scatter(partitions, world, cols) -> (cols grouped by partition, counts)
+      backend.join(build_cols, probe_cols) -> whatever the caller wants back
+    """
+    world = dist.get_world_size()
+    sides = []
+    for cols in (build_cols, probe_cols):
+        parts = backend.partitions(cols[0], world)
+        grouped, counts = backend.scatter(parts, world, cols)
+        received, _ = exchange(dist, torch, grouped, counts)
+        sides.append(received)
+    return backend.join(sides[0], sides[1])
+
+
+class GpuJoinBackend:
+    """Device work of repartitioned_join on the MI355X through libvx355."""
+
+    def __init__(self, ops_module, torch, join_type=abi.JOIN_INNER):
+        self.ops, self.torch, self.join_type = ops_module, torch, join_type
+
+    def _dcol(self, kind, t):
+        return self.ops.DeviceColumn.from_ptr(kind, t.data_ptr(), t.shape[0])
+
+    def _batch(self, cols, kinds):
+        import ctypes as C
+        descs = (abi.Column * len(cols))(*[self._dcol(k, t).descriptor() for k, t in zip(kinds, cols)])
+        batch = abi.Batch(int(cols[0].shape[0]), len(cols), descs)
+
+        class B:
+            def ref(self_inner):
+                return C.byref(batch)
+        b = B()
+        b._keep = (descs, batch, cols)
+        return b
+
+    def partitions(self, key, world):
+        torch, ops = self.torch, self.ops
+        n = int(key.shape[0])
+        hashes = torch.empty(n, dtype=torch.int64, device=key.device)
+        parts = torch.empty(n, dtype=torch.int32, device=key.device)
+        b = self._batch([key], [abi.BIGINT])
+        ops._check(ops.lib().vx355_hash_columns(b.ref(), abi.i32_array([0]), 1, None, 0,
+                                                hashes.data_ptr(), abi.MEM_DEVICE))
+        kind, kw = partition_spec(world)
+        ops._check(ops.lib().vx355_partition(hashes.data_ptr(), n, kind, kw.get("num_partitions", 0),
+                                             kw.get("bit_begin", 0), kw.get("bit_end", 0),
+                                             parts.data_ptr(), abi.MEM_DEVICE))
+        return parts
+
+    def scatter(self, parts, world, cols):
+        torch, ops = self.torch, self.ops
+        outs = [torch.empty_like(c) for c in cols]
+        widths = [c.element_size() * (c.shape[1] if c.dim() == 2 else 1) for c in cols]
+        counts = ops.partition_scatter_device(parts.data_ptr(), int(parts.shape[0]), world,
+                                              [c.data_ptr() for c in cols], widths,
+                                              [o.data_ptr() for o in outs])
+        return outs, counts
+
+    def join(self, build_cols, probe_cols):
+        """Inner join; returns (matches, mapping tensor, gathered first payload tensor)."""
+        torch, ops = self.torch, self.ops
+        kinds = {torch.int64: abi.BIGINT, torch.int32: abi.INTEGER, torch.float64: abi.DOUBLE}
+        bkinds = [kinds[c.dtype] for c in build_cols]
+        deps = list(range(1, len(build_cols)))
+        build = ops.HashBuild([0], [abi.BIGINT], deps, [bkinds[i] for i in deps], self.join_type)
+        build.add_input(self._batch(build_cols, bkinds))
+        table = build.finish()
+        probe = ops.HashProbe(table, [0], self.join_type)
+        probe.add_input(self._batch([probe_cols[0]], [abi.BIGINT]))
+        cap = max(1, int(probe_cols[0].shape[0]))
+        dev = probe_cols[0].device
+        mapping = torch.empty(cap, dtype=torch.int32, device=dev)
+        rows = torch.empty(cap, dtype=torch.int32, device=dev)
+        payload = torch.empty(cap, dtype=build_cols[1].dtype, device=dev) if deps else None
+        nulls = torch.empty(cap // 64 + 1, dtype=torch.int64, device=dev)
+        descs = None
+        if deps:
+            descs = (abi.OutColumn * 1)()
+            descs[0].type_kind, descs[0].mem = bkinds[1], abi.MEM_DEVICE
+            descs[0].values, descs[0].nulls = payload.data_ptr(), nulls.data_ptr()
+        total, outputs = 0, []
+        while True:
+            n, fin = probe.get_output_device(cap, mapping.data_ptr(), rows.data_ptr(), descs,
+                                             [0] if deps else [])
+            total += n
+            outputs.append((mapping[:n].clone(), payload[:n].clone() if deps else None))
+            if fin:
+                break
+        return total, outputs, table.stats()

@@ -24,7 +24,7 @@ SYMBOLS = [
     "vx355_device_malloc", "vx355_device_free", "vx355_memcpy_h2d", "vx355_memcpy_d2h",
     "vx355_memset_d", "vx355_synchronize", "vx355_profile_enable", "vx355_profile_reset",
     "vx355_profile_get", "vx355_profile_names", "vx355_hash_columns", "vx355_value_ids",
-    "vx355_filter_compact", "vx355_partition", "vx355_filter_project", "vx355_agg_create", "vx355_agg_set_fused_input", "vx355_agg_add_input",
+    "vx355_filter_compact", "vx355_partition", "vx355_partition_scatter", "vx355_filter_project", "vx355_agg_create", "vx355_agg_set_fused_input", "vx355_agg_add_input",
     "vx355_agg_no_more_input", "vx355_agg_output_types", "vx355_agg_get_output",
     "vx355_agg_get_stats", "vx355_agg_destroy", "vx355_join_build_create",
     "vx355_join_build_add_input", "vx355_join_build_finish", "vx355_join_build_destroy",
@@ -69,6 +69,7 @@ def lib():
                                   P(i32), i32]
     L.vx355_filter_compact.argtypes = [vp, vp, vp, i32, vp, P(i32), i32]
     L.vx355_partition.argtypes = [vp, i32, i32, i32, i32, i32, vp, i32]
+    L.vx355_partition_scatter.argtypes = [vp, i32, i32, P(vp), P(i32), i32, P(vp), P(i64), i32]
     L.vx355_filter_project.argtypes = [P(abi.Batch), P(abi.FilterTerm), i32, P(abi.Projection), i32,
                                        vp, P(i32), P(vp), P(vp), i32]
     L.vx355_agg_create.argtypes = [P(abi.AggSpec), P(vp)]
@@ -274,6 +275,32 @@ def filter_compact_device(values_ptr, num_rows, idx_out_ptr, nulls_ptr=None, row
     _check(lib().vx355_filter_compact(values_ptr, nulls_ptr, rows_ptr, num_rows, idx_out_ptr,
                                       C.byref(cnt), abi.MEM_DEVICE))
     return cnt.value
+
+
+def partition_scatter(partitions, num_partitions, cols):
+    """Stable partition of numpy columns (host buffers) -> (reordered columns, counts)."""
+    partitions = np.ascontiguousarray(partitions, dtype=np.uint32)
+    n = len(partitions)
+    cols = [np.ascontiguousarray(c) for c in cols]
+    outs = [np.empty_like(c) for c in cols]
+    widths = abi.i32_array([c.dtype.itemsize * (c.shape[1] if c.ndim == 2 else 1) for c in cols])
+    ins = (C.c_void_p * max(1, len(cols)))(*[c.ctypes.data for c in cols])
+    outp = (C.c_void_p * max(1, len(cols)))(*[o.ctypes.data for o in outs])
+    counts = (C.c_int64 * num_partitions)()
+    _check(lib().vx355_partition_scatter(partitions.ctypes.data, n, num_partitions, ins, widths,
+                                         len(cols), outp, counts, abi.MEM_HOST))
+    return outs, np.array(list(counts), dtype=np.int64)
+
+
+def partition_scatter_device(partitions_ptr, num_rows, num_partitions, in_ptrs, widths, out_ptrs):
+    """Device-resident variant; returns the per-partition row counts."""
+    ins = (C.c_void_p * max(1, len(in_ptrs)))(*in_ptrs)
+    outp = (C.c_void_p * max(1, len(out_ptrs)))(*out_ptrs)
+    counts = (C.c_int64 * num_partitions)()
+    _check(lib().vx355_partition_scatter(partitions_ptr, num_rows, num_partitions, ins,
+                                         abi.i32_array(widths), len(in_ptrs), outp, counts,
+                                         abi.MEM_DEVICE))
+    return np.array(list(counts), dtype=np.int64)
 
 
 def filter_project(batch, terms, projs, with_nulls=False):
