@@ -24,6 +24,13 @@ def oracle():
 def vx():
     """The product library on a GPU box. Fails loudly when the HIP extension is
     missing or no device is visible."""
+    # torch bundles its own HIP runtime; bench.py loads torch first, and the one
+    # GPU test that needs torch.distributed must see the same arrangement, so
+    # load torch before libvx355 pulls in /opt/rocm's runtime.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     from velox_amd import ops
     ops.init(0)
     return ops
