@@ -352,7 +352,11 @@ int vx355_agg_set_fused_input(
     const vx355_projection* projections,
     int32_t n_projections);
 /* HashAggregation::addInput (:191-236) -> GroupingSet::addInput
- * (exec/GroupingSet.cpp:190-223,288-365). */
+ * (exec/GroupingSet.cpp:190-223,288-365). Host batches of fewer than 256 K rows
+ * (VX355_AGG_COALESCE_ROWS) are copied into host-side column buffers and
+ * aggregated in larger pieces; an error caused by such rows (integer overflow,
+ * unsupported value) is reported by the call that flushes them: a later
+ * add_input, no_more_input or get_output. */
 int vx355_agg_add_input(vx355_agg* h, const vx355_batch* batch);
 /* Operator::noMoreInput (exec/Operator.h:252). */
 int vx355_agg_no_more_input(vx355_agg* h);

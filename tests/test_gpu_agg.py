@@ -104,9 +104,10 @@ def test_sparse_keys_normalized_mode_and_growth(oracle, vx, array_max, monkeypat
     assert st.num_groups == len(exp[0][0])
 
 
-def test_range_widening_replays_deferred_rows(oracle, vx):
+def test_range_widening_replays_deferred_rows(oracle, vx, monkeypatch):
     """Keys drift upward batch after batch (like l_orderkey): ranges widen, the
     table is re-keyed on device and only the out-of-range rows are replayed."""
+    monkeypatch.setenv("VX355_AGG_COALESCE_ROWS", "0")  # one launch per batch
     rng = np.random.default_rng(4)
     batches = []
     for i in range(8):
@@ -127,6 +128,7 @@ def test_deferred_list_overflow_rescans_the_chunk(oracle, vx, device_resident, m
     """More out-of-range rows than the deferred list holds: the chunk is
     rescanned for exactly the rows the first launch could not place."""
     monkeypatch.setenv("VX355_AGG_DEFER_CAP", "100")
+    monkeypatch.setenv("VX355_AGG_COALESCE_ROWS", "0")
     rng = np.random.default_rng(44)
     batches = []
     for i in range(4):
@@ -188,6 +190,7 @@ def test_sum_bigint_overflow_is_a_user_error(oracle, vx):
     op = vx.Aggregation([], [], [(abi.AGG_SUM, 0, abi.BIGINT)])
     with pytest.raises(vx.Vx355Error) as e:
         op.add_input(batch_of([big]))
+        op.no_more_input()  # small host batches are coalesced: the error surfaces at the flush
     assert e.value.status == abi.EUSER and "integer overflow" in str(e.value)
 
 
@@ -305,10 +308,11 @@ def test_generic_hash_mode_double_string_timestamp_keys(oracle, vx):
             assert gop.stats().hash_mode == abi.MODE_HASH
 
 
-def test_generic_hash_mode_wide_int_keys_growth_and_order(oracle, vx):
+def test_generic_hash_mode_wide_int_keys_growth_and_order(oracle, vx, monkeypatch):
     """Three BIGINT keys spanning the whole int64 range do not fit a 64-bit
     normalized key: decideHashMode's kHash case. Many batches -> slot rehash and
     group-row growth; group order stays first-seen."""
+    monkeypatch.setenv("VX355_AGG_COALESCE_ROWS", "0")
     rng = np.random.default_rng(10)
     batches = []
     for i in range(6):
@@ -330,6 +334,7 @@ def test_strings_longer_than_inline_are_refused(vx):
     op = vx.Aggregation([0], [abi.VARCHAR], [(abi.AGG_COUNT_STAR, -1, abi.BIGINT)])
     with pytest.raises(vx.Vx355Error) as e:
         op.add_input(batch_of([strs]))
+        op.no_more_input()
     assert e.value.status == abi.EUNSUPPORTED
 
 
@@ -455,3 +460,32 @@ def test_decimal_like_sums_few_groups_within_one_ulp(oracle, vx):
     gpu_err = ulp_distance(got[1][0], exact)
     cpu_err = ulp_distance(exp[1][0], exact)
     assert (gpu_err <= 1).all(), (gpu_err, cpu_err)
+
+
+def test_thousand_small_batches_are_coalesced(oracle, vx):
+    """BASELINE config 1 as the reference feeds it (SimpleAggregates.cpp:33-34):
+    many 10 000-row vectors. Host batches below 256 K rows are appended to host
+    column buffers and launched in a few large pieces; encodings are flattened
+    on the way. Results and group order must not change."""
+    rng = np.random.default_rng(321)
+    batches, n_each = [], 2000
+    base = rng.integers(0, 1000, 300).astype(np.int64)
+    for i in range(400):
+        k = abi.HostColumn(abi.BIGINT, base, rng.random(n_each) > 0.02, encoding=abi.DICTIONARY,
+                           indices=rng.integers(0, 300, n_each).astype(np.int32))
+        flag = abi.HostColumn(abi.BOOLEAN, rng.random(n_each) > 0.5, rng.random(n_each) > 0.1)
+        v = abi.HostColumn(abi.DOUBLE, _dyadic(rng, n_each), rng.random(n_each) > 0.1)
+        c = abi.HostColumn(abi.DOUBLE, np.array([0.5]), encoding=abi.CONSTANT)
+        s = abi.HostColumn(abi.VARCHAR, [[b"A", b"NO", b"RETURNED"][j] for j in rng.integers(0, 3, n_each)])
+        batches.append(abi.HostBatch([k, flag, v, c, s], n_each))
+    aggs = [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT), (abi.AGG_AVG, 3, abi.DOUBLE),
+            (abi.AGG_MAX, 2, abi.DOUBLE), (abi.AGG_COUNT, 2, abi.DOUBLE, 1)]
+    exp, _ = run_agg(oracle, batches, [0, 4, 1], [abi.BIGINT, abi.VARCHAR, abi.BOOLEAN], aggs, max_rows=4096)
+    vx.profile_reset()
+    vx.profile_enable(True)
+    got, gop = run_agg(vx, batches, [0, 4, 1], [abi.BIGINT, abi.VARCHAR, abi.BOOLEAN], aggs, max_rows=4096)
+    vx.profile_enable(False)
+    assert_columns_equal(got, exp, gop.kinds, what="coalesced")
+    assert gop.stats().input_rows == 400 * n_each
+    launches = sum(v[1] for k, v in vx.profile().items() if k.startswith("k_agg_"))
+    assert launches <= 12  # 800 K rows in ~4 flushes, not 400 launches
