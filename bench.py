@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--rows", type=int, default=0, help="override the row count (debug)")
     ap.add_argument("--cpu-sample-rows", type=int, default=16_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--c1-stream", action="store_true",
+                    help="c1: feed 10 000-row host vectors instead of one resident batch")
     ap.add_argument("--q3-random-probe", action="store_true",
                     help="q3: lineitems in random order instead of dbgen's l_orderkey clustering")
     ap.add_argument("--unfused", action="store_true",
@@ -231,14 +233,29 @@ class C1:
         self.batch = DevBatch([dcol(abi.BIGINT, self.k), dcol(abi.DOUBLE, self.v)], n)
         torch.cuda.synchronize()
 
+    stream = False  # --c1-stream: 10 000-row HOST vectors, the way the reference feeds the operator
+
     def step(self, step_kind=abi.STEP_SINGLE):
         op = ops.HashAggregation([0], [abi.BIGINT], self.AGGS, step_kind)
-        op.add_input(self.batch)
+        if self.stream:
+            if not hasattr(self, "_host_batches"):
+                hk, hv = self.k.cpu().numpy(), self.v.cpu().numpy()
+                self._host_batches = [abi.HostBatch([abi.HostColumn(abi.BIGINT, hk[i:i + 10000]),
+                                                     abi.HostColumn(abi.DOUBLE, hv[i:i + 10000])])
+                                      for i in range(0, self.n, 10000)]
+            for b in self._host_batches:   # PCIe-inclusive: every vector starts in host memory
+                op.add_input(b)
+        else:
+            op.add_input(self.batch)
         op.no_more_input()
         return ops.collect_output(op, 4096)
 
     def rows_per_step(self):
         return self.n
+
+    def info(self):
+        return {"input": "1000 x 10 000-row host vectors (PCIe inclusive)" if self.stream
+                else "one HBM-resident batch"}
 
     def host_sample(self, rows):
         rows = min(rows, self.n)
@@ -510,6 +527,8 @@ def main():
     n = args.rows or default_rows
     if args.workload == "q3":
         cls.random_probe = args.q3_random_probe
+    if args.workload == "c1":
+        cls.stream = args.c1_stream
     if args.workload == "c5":
         if world == 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
