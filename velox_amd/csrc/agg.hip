@@ -2683,6 +2683,10 @@ bool tryCoalesce(vx355_agg& h, const vx355_batch* batch) {
     uint8_t* valid = pc.valid.data() + before;
     const char* src = static_cast<const char*>(col.values);
     const bool isBool = col.type_kind == VX355_BOOLEAN;
+    if (col.encoding == VX355_FLAT && !col.nulls && !isBool) {
+      std::memcpy(dst, src, static_cast<size_t>(n) * w);  // the common case: one copy
+      continue;
+    }
     for (int64_t r = 0; r < n; ++r) {
       const int64_t nullBit = col.encoding == VX355_CONSTANT ? 0 : r;
       const bool ok = !col.nulls || bitAt(col.nulls, nullBit);
