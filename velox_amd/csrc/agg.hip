@@ -1710,19 +1710,7 @@ struct vx355_agg {
   std::vector<vx355_projection> fusedProj;
   int32_t maxProjRef = -1;
 
-  // Coalescing of small host batches (Velox hands operators 1 K - 10 K row
-  // vectors; a launch wants >= 10^5 rows): rows are appended to host-side
-  // column buffers and pushed through the normal path in one piece.
-  struct PendingCol {
-    int32_t kind = -1;
-    std::vector<char> values;       // flat values (BOOLEAN: one byte per row)
-    std::vector<uint8_t> valid;     // one byte per row, only meaningful when anyNull
-    bool anyNull = false;
-  };
-  std::vector<PendingCol> pending;
-  int64_t pendingRows = 0;
-  int64_t coalescedRows = 0;
-  int64_t coalesceRows = 1 << 18;
+  HostCoalescer coalescer;  // small host batches -> large launches
 
   // generic hash mode (keys without a normalized form)
   bool generic = false;
@@ -2578,135 +2566,15 @@ void addInputGeneric(vx355_agg& h, AggArgs& a, int64_t n) {
 
 void addInput(vx355_agg& h, const vx355_batch* batch);
 
-// Pushes the coalesced rows through the regular path as one flat host batch.
 void flushPending(vx355_agg& h) {
-  if (h.pendingRows == 0) {
-    return;
-  }
-  const int64_t n = h.pendingRows;
-  std::vector<vx355_column> cols(h.pending.size());
-  std::vector<std::vector<uint64_t>> bitmaps;
-  bitmaps.reserve(h.pending.size() * 2);
-  auto packBits = [&](const uint8_t* bytes) -> const uint64_t* {
-    std::vector<uint64_t> words(static_cast<size_t>(ceilDiv(n, 64)), 0);
-    for (int64_t i = 0; i < n; ++i) {
-      if (bytes[i]) {
-        words[i >> 6] |= 1ULL << (i & 63);
-      }
-    }
-    bitmaps.push_back(std::move(words));
-    return bitmaps.back().data();
-  };
-  for (size_t c = 0; c < h.pending.size(); ++c) {
-    auto& pc = h.pending[c];
-    vx355_column col{};
-    col.encoding = VX355_FLAT;
-    col.mem = VX355_MEM_HOST;
-    if (pc.kind >= 0) {
-      col.type_kind = pc.kind;
-      col.values = pc.kind == VX355_BOOLEAN
-          ? static_cast<const void*>(packBits(reinterpret_cast<const uint8_t*>(pc.values.data())))
-          : static_cast<const void*>(pc.values.data());
-      col.nulls = pc.anyNull ? packBits(pc.valid.data()) : nullptr;
-    }
-    cols[c] = col;
-  }
-  vx355_batch flat{static_cast<int32_t>(n), static_cast<int32_t>(cols.size()), cols.data()};
-  h.pendingRows = 0;  // before the call: addInput must not see pending rows
-  try {
-    addInput(h, &flat);
-  } catch (...) {
-    h.pending.clear();
-    throw;
-  }
-  for (auto& pc : h.pending) {
-    pc.values.clear();
-    pc.valid.clear();
-    pc.anyNull = false;
-  }
+  h.coalescer.flush([&](const vx355_batch* flat) { addInput(h, flat); });
 }
 
-// Appends a small host batch to the pending buffers; false = not eligible (the
-// caller flushes and takes the direct path).
 bool tryCoalesce(vx355_agg& h, const vx355_batch* batch) {
-  const int64_t n = batch->num_rows;
-  if (h.coalesceRows <= 0 || n <= 0 || n >= h.coalesceRows || h.noMoreInput) {
+  if (h.noMoreInput || !h.coalescer.append(batch, h.usedCols)) {
     return false;
   }
-  for (int32_t c : h.usedCols) {
-    if (c < 0) {
-      continue;
-    }
-    if (c >= batch->num_cols) {
-      return false;
-    }
-    const vx355_column& col = batch->cols[c];
-    if (col.mem != VX355_MEM_HOST || kindWidth(col.type_kind) < 0) {
-      return false;
-    }
-    if (isString(col.type_kind)) {
-      // Non-inline strings point into buffers that die with the batch.
-      const int64_t count = col.encoding == VX355_FLAT ? n : (col.encoding == VX355_CONSTANT ? 1 : col.base_size);
-      const char* v = static_cast<const char*>(col.values);
-      for (int64_t i = 0; i < count; ++i) {
-        uint32_t size;
-        std::memcpy(&size, v + i * 16, 4);
-        if (size > 12) {
-          return false;
-        }
-      }
-    }
-  }
-  if (h.pending.size() < static_cast<size_t>(batch->num_cols)) {
-    h.pending.resize(batch->num_cols);
-  }
-  const int64_t before = h.pendingRows;
-  for (int32_t c : h.usedCols) {
-    if (c < 0) {
-      continue;
-    }
-    auto& pc = h.pending[c];
-    const vx355_column& col = batch->cols[c];
-    if (pc.kind >= 0 && static_cast<int64_t>(pc.valid.size()) == before + n) {
-      continue;  // column listed twice in usedCols: already appended
-    }
-    if (pc.kind < 0) {
-      pc.kind = col.type_kind;
-    } else if (pc.kind != col.type_kind) {
-      VX_THROW(VX355_EINVAL, "column type changed between batches");
-    }
-    const int w = kindWidth(col.type_kind) == 0 ? 1 : kindWidth(col.type_kind);
-    const size_t oldBytes = pc.values.size();
-    pc.values.resize(oldBytes + static_cast<size_t>(n) * w);
-    pc.valid.resize(static_cast<size_t>(before + n), 1);
-    char* dst = pc.values.data() + oldBytes;
-    uint8_t* valid = pc.valid.data() + before;
-    const char* src = static_cast<const char*>(col.values);
-    const bool isBool = col.type_kind == VX355_BOOLEAN;
-    if (col.encoding == VX355_FLAT && !col.nulls && !isBool) {
-      std::memcpy(dst, src, static_cast<size_t>(n) * w);  // the common case: one copy
-      continue;
-    }
-    for (int64_t r = 0; r < n; ++r) {
-      const int64_t nullBit = col.encoding == VX355_CONSTANT ? 0 : r;
-      const bool ok = !col.nulls || bitAt(col.nulls, nullBit);
-      valid[r] = ok ? 1 : 0;
-      if (!ok) {
-        pc.anyNull = true;
-        std::memset(dst + r * w, 0, w);
-        continue;
-      }
-      const int64_t i = col.encoding == VX355_FLAT ? r : (col.encoding == VX355_CONSTANT ? 0 : col.indices[r]);
-      if (isBool) {
-        dst[r] = bitAt(static_cast<const uint64_t*>(col.values), i) ? 1 : 0;
-      } else {
-        std::memcpy(dst + r * w, src + i * w, w);
-      }
-    }
-  }
-  h.pendingRows += n;
-  h.coalescedRows += n;
-  if (h.pendingRows >= h.coalesceRows) {
+  if (h.coalescer.pendingRows() >= h.coalescer.thresholdRows) {
     flushPending(h);
   }
   return true;
@@ -3097,7 +2965,7 @@ int vx355_agg_create(const vx355_agg_spec* spec, vx355_agg** out) {
     h->arrayMax = std::strtoull(e, nullptr, 10);
   }
   if (const char* e = std::getenv("VX355_AGG_COALESCE_ROWS")) {
-    h->coalesceRows = std::strtoll(e, nullptr, 10);
+    h->coalescer.thresholdRows = std::strtoll(e, nullptr, 10);
   }
   if (const char* e = std::getenv("VX355_EXACT_SUMS")) {
     h->exactSums = e[0] != '0';
@@ -3199,7 +3067,7 @@ int vx355_agg_get_stats(const vx355_agg* h, vx355_agg_stats* out) {
   out->num_rehashes = h->numRehashes;
   out->hash_mode = h->mode;
   out->reserved = 0;
-  out->input_rows = h->inputRows + h->pendingRows;
+  out->input_rows = h->inputRows + h->coalescer.pendingRows();
   out->deferred_rows = h->deferredRows;
   VX_API_END
 }

@@ -180,6 +180,51 @@ class DeviceBatch {
   int32_t numRows_ = 0;
 };
 
+// Coalescing of small host batches. Velox hands operators 1 K - 10 K row vectors
+// (core/QueryConfig.h:489 preferred_output_batch_rows); a launch wants >= 10^5
+// rows. Rows of eligible batches (host memory, inline strings) are appended to
+// host-side flat column buffers — dictionary and constant encodings are
+// flattened on the way — and handed to the operator's normal path in one piece,
+// the role CudfBatchConcat plays for the cuDF backend
+// (experimental/cudf/CudfConfig.h:114-125).
+class HostCoalescer {
+ public:
+  int64_t thresholdRows = 1 << 18;  // <= 0 disables coalescing
+  int64_t pendingRows() const { return pendingRows_; }
+  // Appends the used columns of 'batch'; false = not eligible, nothing appended.
+  bool append(const vx355_batch* batch, const std::vector<int32_t>& usedCols);
+  // Calls consume(flat batch) on the pending rows (if any) and clears them.
+  template <typename F>
+  void flush(F&& consume) {
+    if (pendingRows_ == 0) {
+      return;
+    }
+    std::vector<vx355_column> cols;
+    std::vector<std::vector<uint64_t>> bitmaps;
+    vx355_batch flat = makeBatch(&cols, &bitmaps);
+    pendingRows_ = 0;  // before the call: the consumer must not see pending rows
+    try {
+      consume(&flat);
+    } catch (...) {
+      clear();
+      throw;
+    }
+    clear();
+  }
+
+ private:
+  struct PendingCol {
+    int32_t kind = -1;
+    std::vector<char> values;    // flat values (BOOLEAN: one byte per row)
+    std::vector<uint8_t> valid;  // one byte per row
+    bool anyNull = false;
+  };
+  vx355_batch makeBatch(std::vector<vx355_column>* cols, std::vector<std::vector<uint64_t>>* bitmaps);
+  void clear();
+  std::vector<PendingCol> pending_;
+  int64_t pendingRows_ = 0;
+};
+
 // Copies caller-visible results out of device scratch.
 void copyOut(void* dst, int32_t dstMem, const void* devSrc, size_t bytes);
 // Same without the stream synchronisation: the caller syncs once after a batch of copies.

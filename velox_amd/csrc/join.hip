@@ -699,6 +699,7 @@ struct vx355_join_build {
   bool finished = false;
   std::vector<int64_t> obsMin, obsMax;
   DevBuf countersBuf, scratch, validWords, rowList;
+  HostCoalescer coalescer;  // small host batches -> large appends
 };
 
 struct vx355_join_table {
@@ -1187,7 +1188,15 @@ int vx355_join_build_add_input(vx355_join_build* h, const vx355_batch* batch) {
   VX_API_BEGIN
   Runtime::get().requireInit();
   VX_CHECK_ARG(h && batch, "NULL argument");
-  buildAddInput(*h, batch);
+  VX_CHECK_ARG(!h->finished, "addInput after finish");
+  if (h->coalescer.append(batch, h->usedCols)) {
+    if (h->coalescer.pendingRows() >= h->coalescer.thresholdRows) {
+      h->coalescer.flush([&](const vx355_batch* flat) { buildAddInput(*h, flat); });
+    }
+  } else {
+    h->coalescer.flush([&](const vx355_batch* flat) { buildAddInput(*h, flat); });
+    buildAddInput(*h, batch);
+  }
   VX_API_END
 }
 
@@ -1196,6 +1205,13 @@ int vx355_join_build_finish(vx355_join_build* h, vx355_join_build* const* others
   VX_API_BEGIN
   Runtime::get().requireInit();
   VX_CHECK_ARG(h && out && num_others >= 0, "bad argument");
+  h->coalescer.flush([&](const vx355_batch* flat) { buildAddInput(*h, flat); });
+  for (int32_t i = 0; i < num_others; ++i) {
+    if (others && others[i]) {
+      vx355_join_build* o = others[i];
+      o->coalescer.flush([&](const vx355_batch* flat) { buildAddInput(*o, flat); });
+    }
+  }
   *out = buildFinish(*h, others, num_others);
   VX_API_END
 }

@@ -200,6 +200,128 @@ void copyIn(void* devDst, const void* src, int32_t srcMem, size_t bytes) {
                         rt.stream));
 }
 
+bool HostCoalescer::append(const vx355_batch* batch, const std::vector<int32_t>& usedCols) {
+  const int64_t n = batch->num_rows;
+  if (thresholdRows <= 0 || n <= 0 || n >= thresholdRows) {
+    return false;
+  }
+  for (int32_t c : usedCols) {
+    if (c < 0) {
+      continue;
+    }
+    if (c >= batch->num_cols) {
+      return false;
+    }
+    const vx355_column& col = batch->cols[c];
+    if (col.mem != VX355_MEM_HOST || kindWidth(col.type_kind) < 0) {
+      return false;
+    }
+    if (isString(col.type_kind)) {
+      // Non-inline strings point into buffers that die with the batch.
+      const int64_t count =
+          col.encoding == VX355_FLAT ? n : (col.encoding == VX355_CONSTANT ? 1 : col.base_size);
+      const char* v = static_cast<const char*>(col.values);
+      for (int64_t i = 0; i < count; ++i) {
+        uint32_t size;
+        std::memcpy(&size, v + i * 16, 4);
+        if (size > 12) {
+          return false;
+        }
+      }
+    }
+  }
+  if (pending_.size() < static_cast<size_t>(batch->num_cols)) {
+    pending_.resize(batch->num_cols);
+  }
+  const int64_t before = pendingRows_;
+  for (int32_t c : usedCols) {
+    if (c < 0) {
+      continue;
+    }
+    auto& pc = pending_[c];
+    const vx355_column& col = batch->cols[c];
+    if (pc.kind >= 0 && static_cast<int64_t>(pc.valid.size()) == before + n) {
+      continue;  // column listed twice: already appended
+    }
+    if (pc.kind < 0) {
+      pc.kind = col.type_kind;
+    } else if (pc.kind != col.type_kind) {
+      VX_THROW(VX355_EINVAL, "column type changed between batches");
+    }
+    const int w = kindWidth(col.type_kind) == 0 ? 1 : kindWidth(col.type_kind);
+    const size_t oldBytes = pc.values.size();
+    pc.values.resize(oldBytes + static_cast<size_t>(n) * w);
+    pc.valid.resize(static_cast<size_t>(before + n), 1);
+    char* dst = pc.values.data() + oldBytes;
+    uint8_t* valid = pc.valid.data() + before;
+    const char* src = static_cast<const char*>(col.values);
+    const bool isBool = col.type_kind == VX355_BOOLEAN;
+    if (col.encoding == VX355_FLAT && !col.nulls && !isBool) {
+      std::memcpy(dst, src, static_cast<size_t>(n) * w);  // the common case: one copy
+      continue;
+    }
+    for (int64_t r = 0; r < n; ++r) {
+      const int64_t nullBit = col.encoding == VX355_CONSTANT ? 0 : r;
+      const bool ok = !col.nulls || bitAt(col.nulls, nullBit);
+      valid[r] = ok ? 1 : 0;
+      if (!ok) {
+        pc.anyNull = true;
+        std::memset(dst + r * w, 0, w);
+        continue;
+      }
+      const int64_t i =
+          col.encoding == VX355_FLAT ? r : (col.encoding == VX355_CONSTANT ? 0 : col.indices[r]);
+      if (isBool) {
+        dst[r] = bitAt(static_cast<const uint64_t*>(col.values), i) ? 1 : 0;
+      } else {
+        std::memcpy(dst + r * w, src + i * w, w);
+      }
+    }
+  }
+  pendingRows_ += n;
+  return true;
+}
+
+vx355_batch HostCoalescer::makeBatch(std::vector<vx355_column>* cols,
+                                     std::vector<std::vector<uint64_t>>* bitmaps) {
+  const int64_t n = pendingRows_;
+  cols->assign(pending_.size(), vx355_column{});
+  bitmaps->reserve(pending_.size() * 2);
+  auto packBits = [&](const uint8_t* bytes) -> const uint64_t* {
+    std::vector<uint64_t> words(static_cast<size_t>(ceilDiv(n, 64)), 0);
+    for (int64_t i = 0; i < n; ++i) {
+      if (bytes[i]) {
+        words[i >> 6] |= 1ULL << (i & 63);
+      }
+    }
+    bitmaps->push_back(std::move(words));
+    return bitmaps->back().data();
+  };
+  for (size_t c = 0; c < pending_.size(); ++c) {
+    auto& pc = pending_[c];
+    vx355_column& col = (*cols)[c];
+    col.encoding = VX355_FLAT;
+    col.mem = VX355_MEM_HOST;
+    if (pc.kind >= 0) {
+      col.type_kind = pc.kind;
+      col.values = pc.kind == VX355_BOOLEAN
+          ? static_cast<const void*>(packBits(reinterpret_cast<const uint8_t*>(pc.values.data())))
+          : static_cast<const void*>(pc.values.data());
+      col.nulls = pc.anyNull ? packBits(pc.valid.data()) : nullptr;
+    }
+  }
+  return vx355_batch{static_cast<int32_t>(n), static_cast<int32_t>(cols->size()), cols->data()};
+}
+
+void HostCoalescer::clear() {
+  for (auto& pc : pending_) {
+    pc.values.clear();
+    pc.valid.clear();
+    pc.anyNull = false;
+  }
+  pendingRows_ = 0;
+}
+
 const void* DeviceBatch::stage(const void* src, size_t bytes, int32_t mem) {
   if (!src || mem == VX355_MEM_DEVICE) {
     return src;
