@@ -174,7 +174,9 @@ def test_unsupported_join_kinds_are_refused(vx):
         vx.JoinBuild([0], [abi.BIGINT], [], [], abi.JOIN_FULL)
     assert e.value.status == abi.EUNSUPPORTED
     with pytest.raises(vx.Vx355Error) as e:
-        vx.JoinBuild([0], [abi.DOUBLE], [], [], abi.JOIN_INNER)
+        b = vx.JoinBuild([0], [abi.VARCHAR], [], [], abi.JOIN_INNER)
+        b.add_input(batch_of([[b"a string key longer than twelve bytes"]]))
+        b.finish()
     assert e.value.status == abi.EUNSUPPORTED
 
 
@@ -237,3 +239,50 @@ def test_repartitioned_join_gpu_backend_single_rank(oracle, vx):
         assert total == len(want) and got == want
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("join_type", JOIN_TYPES)
+def test_join_generic_hash_mode_keys(oracle, vx, join_type):
+    """Join keys without a 64-bit normalized form — DOUBLE (NaN == NaN, 0.0 == -0.0
+    as hashOne / the key compare treat them), 8..12-byte strings, three wide
+    BIGINTs — run in the generic hash mode: VectorHasher hash, {tag, row} slots,
+    stored key images; duplicates chained behind the first row of a key."""
+    rng = np.random.default_rng(61)
+    nb, npb = 5000, 16000
+    dvals = np.array([0.0, -0.0, 1.5, float("nan"), -2.25, 1e300, -np.inf] + list(rng.random(300)))
+    svals = [b"", b"A", b"BUILDING", b"AUTOMOBILE", b"HOUSEHOLD", b"twelve bytes", b"FURNITURE"]
+    wide = rng.integers(-2 ** 62, 2 ** 62, 40).astype(np.int64)
+    cases = {
+        "double": ([abi.DOUBLE], lambda n: [dvals[rng.integers(0, len(dvals), n)]]),
+        "string": ([abi.VARCHAR], lambda n: [[svals[i] for i in rng.integers(0, len(svals), n)]]),
+        "wide": ([abi.BIGINT] * 3, lambda n: [wide[rng.integers(0, 40, n)], wide[rng.integers(0, 3, n)],
+                                               wide[rng.integers(0, 2, n)]]),
+        "mixed": ([abi.VARCHAR, abi.DOUBLE, abi.INTEGER],
+                  lambda n: [[svals[i] for i in rng.integers(0, len(svals), n)], dvals[rng.integers(0, 7, n)],
+                             rng.integers(0, 3, n).astype(np.int32)]),
+    }
+    for name, (kinds, gen) in cases.items():
+        nk = len(kinds)
+        bcols, pcols = gen(nb), gen(npb)
+        bvalid = [rng.random(nb) > 0.05] + [None] * (nk - 1)
+        pvalid = [rng.random(npb) > 0.05] + [None] * (nk - 1)
+        pay = rng.integers(0, 1 << 40, nb).astype(np.int64)
+        results = {}
+        for impl in (oracle, vx):
+            half = nb // 2
+
+            def part(lo, hi):
+                cols = [c[lo:hi] for c in bcols] + [pay[lo:hi]]
+                valids = [None if v is None else v[lo:hi] for v in bvalid] + [None]
+                return batch_of(cols, valids)
+            table, _b = _build(impl, [[part(0, half)], [part(half, nb)]], list(range(nk)), kinds, [nk],
+                               [abi.BIGINT], join_type)
+            st = table.stats()
+            probe = impl.JoinProbe(table, list(range(nk)), join_type)
+            probe.add_input(batch_of(pcols, pvalid))
+            pairs, payload = _drain(probe, 997)
+            _contiguous(pairs)
+            results[impl.__name__] = (_canon(pairs, payload), st.num_rows, st.num_distinct, st.has_duplicates)
+            if impl is vx:
+                assert st.hash_mode == abi.MODE_HASH, name
+        assert results[oracle.__name__] == results[vx.__name__], name

@@ -332,6 +332,53 @@ __device__ inline uint64_t valueIdAt(const ColView& c, int64_t i, const KeyRange
   return static_cast<uint64_t>(v) - static_cast<uint64_t>(r.min) + 1;
 }
 
+// Comparable image of the non-null key value at base index i: integers as
+// int64, floating point canonicalised (one NaN, +0.0 for both zeros: the same
+// classes hashOne hashes together), strings / timestamps as two words.
+__device__ inline void keyImage(const ColView& c, int64_t i, uint64_t* w0, uint64_t* w1, bool* supported) {
+  *w1 = 0;
+  switch (c.kind) {
+    case VX355_REAL: {
+      float f = static_cast<const float*>(c.values)[i];
+      uint32_t b = f != f ? 0x7fc00000u : (f == 0.0f ? 0u : __float_as_uint(f));
+      *w0 = b;
+      break;
+    }
+    case VX355_DOUBLE: {
+      double d = static_cast<const double*>(c.values)[i];
+      *w0 = d != d ? 0x7ff8000000000000ULL
+                   : (d == 0.0 ? 0ULL : static_cast<uint64_t>(__double_as_longlong(d)));
+      break;
+    }
+    case VX355_VARCHAR:
+    case VX355_VARBINARY: {
+      const StringView16 v = loadView(c, i);
+      if (v.size > 12) {
+        *supported = false;
+      }
+      *w0 = static_cast<uint64_t>(v.size) | (static_cast<uint64_t>(v.prefix) << 32);
+      *w1 = v.tail;
+      break;
+    }
+    case VX355_TIMESTAMP: {
+      const uint64_t* p = static_cast<const uint64_t*>(c.values) + 2 * i;
+      *w0 = p[0];
+      *w1 = p[1];
+      break;
+    }
+    default:
+      *w0 = static_cast<uint64_t>(loadInt64(c, i));
+      break;
+  }
+}
+
+__device__ inline uint64_t loadAgent(const uint64_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void storeAgent(uint64_t* p, uint64_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Doubles mapped to unsigned keys whose integer order is Velox's NaN-aware
 // order (NaN greater than +inf; functions/lib/aggregates/MinMaxAggregateBase.cpp
 // :174-184), so min/max run as integer atomics.

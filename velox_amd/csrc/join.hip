@@ -100,7 +100,9 @@ __global__ __launch_bounds__(256) void k_key_valid(ValidArgs a) {
 struct AppendArgs {
   ColView keys[kMaxKeys];
   ColView deps[kMaxDeps];
-  int64_t* keyOut[kMaxKeys];
+  uint64_t* keyOut[kMaxKeys];   // key images: 1 word, 2 for strings / timestamps
+  int32_t keyWords[kMaxKeys];
+  uint64_t* hashOut;            // VectorHasher hash of the key columns
   char* depOut[kMaxDeps];
   uint8_t* depValid[kMaxDeps];
   int32_t depWidth[kMaxDeps];
@@ -122,20 +124,41 @@ __global__ __launch_bounds__(256) void k_build_append(AppendArgs a) {
   for (int64_t p = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; p < a.count;
        p += stride) {
     const int64_t row = a.rows[p];
+    uint64_t hash = 0;
     for (int k = 0; k < a.numKeys; ++k) {
+      const ColView& c = a.keys[k];
+      const int64_t i = colIndex(c, row);
+      uint64_t w0, w1;
+      bool inlineOk = true;
+      keyImage(c, i, &w0, &w1, &inlineOk);
+      if (!inlineOk) {
+        a.counters->longString = 1;
+      }
+      a.keyOut[k][(a.base + p) * a.keyWords[k]] = w0;
+      if (a.keyWords[k] == 2) {
+        a.keyOut[k][(a.base + p) * 2 + 1] = w1;
+      }
+      const uint64_t hv = hashValueAt(c, i);
+      hash = k == 0 ? hv : hashMix(hash, hv);
+      // Range statistics for the normalized-key decision (VectorHasher::analyze).
+      if (c.kind == VX355_REAL || c.kind == VX355_DOUBLE || c.kind == VX355_TIMESTAMP) {
+        a.counters->unmappable = 1;
+        continue;
+      }
       KeyRange all;
       all.min = INT64_MIN;
       all.max = INT64_MAX;
       int64_t v;
       bool mappable;
-      valueIdAt(a.keys[k], colIndex(a.keys[k], row), all, &v, &mappable);
+      valueIdAt(c, i, all, &v, &mappable);
       if (!mappable) {
         a.counters->unmappable = 1;
+        continue;
       }
-      a.keyOut[k][a.base + p] = v;
       mn[k] = v < mn[k] ? v : mn[k];
       mx[k] = v > mx[k] ? v : mx[k];
     }
+    a.hashOut[a.base + p] = hash;
     for (int d = 0; d < a.numDeps; ++d) {
       const ColView& c = a.deps[d];
       const bool valid = !colIsNull(c, row);
@@ -181,14 +204,18 @@ struct Slot {
 };
 
 struct InsertArgs {
-  const int64_t* keyVals[kMaxKeys];
+  const uint64_t* keyStore[kMaxKeys];
+  int32_t keyWords[kMaxKeys];
+  int32_t keyIsString[kMaxKeys];
+  const uint64_t* hashStore;
   KeyRange ranges[kMaxKeys];
   int32_t numKeys;
   int32_t mode;
   int64_t numRows;
   uint32_t* head;     // array mode (NOT initialised: 'present' says which entries are live)
   uint32_t* present;  // array mode: one bit per possible key
-  Slot* slots;        // hash mode
+  Slot* slots;        // normalized-key mode
+  uint64_t* gslots;   // generic hash mode: {hash tag:32 | representative row + 1:32}
   uint64_t capacity;
   uint32_t* next;
   int32_t phase;      // array mode: 1 = claim keys, 2 = chain the duplicates
@@ -198,14 +225,40 @@ struct InsertArgs {
 
 constexpr uint32_t kPendingRow = 0xfffffffeu;
 
+// int64 image VectorHasher normalises, from the stored key image.
+__device__ inline int64_t storedKeyValue(const uint64_t* store, int32_t words, int32_t isString, int64_t row) {
+  if (!isString) {
+    return static_cast<int64_t>(store[row * words]);
+  }
+  StringView16 v;
+  const uint64_t w0 = store[row * 2];
+  v.size = static_cast<uint32_t>(w0);
+  v.prefix = static_cast<uint32_t>(w0 >> 32);
+  v.tail = store[row * 2 + 1];
+  return stringAsNumber(v);
+}
+
 __device__ inline uint64_t buildKey(const InsertArgs& a, int64_t row) {
   uint64_t key = 0;
   for (int k = 0; k < a.numKeys; ++k) {
-    const uint64_t id =
-        static_cast<uint64_t>(a.keyVals[k][row]) - static_cast<uint64_t>(a.ranges[k].min) + 1;
+    const int64_t v = storedKeyValue(a.keyStore[k], a.keyWords[k], a.keyIsString[k], row);
+    const uint64_t id = static_cast<uint64_t>(v) - static_cast<uint64_t>(a.ranges[k].min) + 1;
     key += a.ranges[k].multiplier * id;
   }
   return key;
+}
+
+__device__ inline bool storedKeysEqual(const InsertArgs& a, int64_t r1, int64_t r2) {
+  for (int k = 0; k < a.numKeys; ++k) {
+    const int w = a.keyWords[k];
+    if (a.keyStore[k][r1 * w] != a.keyStore[k][r2 * w]) {
+      return false;
+    }
+    if (w == 2 && a.keyStore[k][r1 * 2 + 1] != a.keyStore[k][r2 * 2 + 1]) {
+      return false;
+    }
+  }
+  return true;
 }
 
 // Array mode never initialises the (possibly multi-GB) head array: phase 1
@@ -234,6 +287,46 @@ __global__ __launch_bounds__(256) void k_join_insert(InsertArgs a) {
       } else if (a.next[row] == kPendingRow) {
         const uint64_t key = buildKey(a, row);
         a.next[row] = atomicExch(a.head + key, static_cast<uint32_t>(row));
+      }
+      continue;
+    }
+    if (a.mode == JMODE_HASH) {
+      // Generic keys (the reference's kHash): slot = {hash tag, representative
+      // row}. The key images were stored by an earlier launch, so a claimed slot
+      // is immediately comparable; equal keys are pushed behind the
+      // representative (pushNext, HashTable.cpp:1412-1418); next[] was
+      // pre-filled with "no row".
+      const uint64_t hash = a.hashStore[row];
+      const uint64_t tag = hash >> 32;
+      const uint64_t gmask = a.capacity - 1;
+      uint64_t pos = hash & gmask;
+      bool placed = false;
+      for (uint64_t probes = 0; probes <= gmask && !placed; ++probes) {
+        unsigned long long w = __hip_atomic_load(a.gslots + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w == 0) {
+          const unsigned long long mine = (tag << 32) | (static_cast<uint64_t>(row) + 1);
+          const unsigned long long old =
+              atomicCAS(reinterpret_cast<unsigned long long*>(a.gslots + pos), 0ULL, mine);
+          if (old == 0) {
+            ++distinct;
+            placed = true;
+            break;
+          }
+          w = old;
+        }
+        if ((w >> 32) == tag) {
+          const int64_t rep = static_cast<int64_t>(static_cast<uint32_t>(w)) - 1;
+          if (storedKeysEqual(a, row, rep)) {
+            a.next[row] = atomicExch(a.next + rep, static_cast<uint32_t>(row));
+            ++dups;
+            placed = true;
+            break;
+          }
+        }
+        pos = (pos + 1) & gmask;
+      }
+      if (!placed) {
+        a.counters->tableFull = 1;
       }
       continue;
     }
@@ -310,6 +403,9 @@ struct ProbeArgs {
   const uint32_t* head;
   const uint32_t* present;
   const Slot* slots;
+  const uint64_t* gslots;              // generic hash mode
+  const uint64_t* keyStore[kMaxKeys];  // generic hash mode: build key images
+  int32_t keyWords[kMaxKeys];
   uint64_t capacity;
   const uint32_t* next;
   uint32_t* hits;       // first matching build row or kNoRow32
@@ -351,6 +447,58 @@ __device__ inline bool probeKey(const ProbeArgs& a, int64_t row, uint64_t* keyOu
   }
   *keyOut = key;
   return true;
+}
+
+// Generic mode probe: VectorHasher hash of the probe row, tag filter, key images.
+__device__ inline uint32_t lookupGeneric(const ProbeArgs& a, int64_t row) {
+  uint64_t w0[kMaxKeys], w1[kMaxKeys];
+  uint64_t hash = 0;
+#pragma unroll
+  for (int k = 0; k < kMaxKeys; ++k) {
+    w0[k] = 0;
+    w1[k] = 0;
+    if (k < a.numKeys) {
+      const ColView& c = a.keys[k];
+      if (colIsNull(c, row)) {
+        return kNoRow32;
+      }
+      const int64_t i = colIndex(c, row);
+      bool inlineOk = true;
+      keyImage(c, i, &w0[k], &w1[k], &inlineOk);
+      if (!inlineOk) {
+        return kNoRow32;  // the build side holds inline strings only
+      }
+      const uint64_t hv = hashValueAt(c, i);
+      hash = k == 0 ? hv : hashMix(hash, hv);
+    }
+  }
+  const uint64_t tag = hash >> 32;
+  const uint64_t mask = a.capacity - 1;
+  uint64_t pos = hash & mask;
+  for (uint64_t probes = 0; probes <= mask; ++probes) {
+    const uint64_t w = a.gslots[pos];
+    if (w == 0) {
+      return kNoRow32;
+    }
+    if ((w >> 32) == tag) {
+      const uint64_t rep = static_cast<uint64_t>(static_cast<uint32_t>(w)) - 1;
+      bool equal = true;
+#pragma unroll
+      for (int k = 0; k < kMaxKeys; ++k) {
+        if (equal && k < a.numKeys) {
+          equal = a.keyStore[k][rep * a.keyWords[k]] == w0[k];
+          if (equal && a.keyWords[k] == 2) {
+            equal = a.keyStore[k][rep * 2 + 1] == w1[k];
+          }
+        }
+      }
+      if (equal) {
+        return static_cast<uint32_t>(rep);
+      }
+    }
+    pos = (pos + 1) & mask;
+  }
+  return kNoRow32;
 }
 
 __device__ inline uint32_t lookupSlots(const ProbeArgs& a, uint64_t key) {
@@ -402,13 +550,18 @@ __global__ __launch_bounds__(256) void k_join_probe(ProbeArgs a) {
           candidate[u] = rows[u] < a.numRows && v[u] >= a.ranges[0].min && v[u] <= a.ranges[0].max;
           key[u] = static_cast<uint64_t>(v[u]) - static_cast<uint64_t>(a.ranges[0].min) + 1;
         }
-      } else {
+      } else if (a.mode != JMODE_HASH) {
 #pragma unroll
         for (int u = 0; u < kProbeUnroll; ++u) {
           candidate[u] = rows[u] < a.numRows && probeKey(a, rows[u], &key[u]);
         }
       }
-      if (a.mode == JMODE_ARRAY) {
+      if (a.mode == JMODE_HASH) {
+#pragma unroll
+        for (int u = 0; u < kProbeUnroll; ++u) {
+          hit[u] = rows[u] < a.numRows ? lookupGeneric(a, rows[u]) : kNoRow32;
+        }
+      } else if (a.mode == JMODE_ARRAY) {
         uint32_t word[kProbeUnroll];
 #pragma unroll
         for (int u = 0; u < kProbeUnroll; ++u) {
@@ -690,7 +843,9 @@ struct vx355_join_build {
   std::vector<int32_t> keyCols, keyKinds, depCols, depKinds;
   std::vector<int32_t> usedCols;
   int32_t joinType = 0;
-  std::vector<DevBuf> keyVals;   // int64 per row
+  std::vector<DevBuf> keyVals;   // key images per row: 1 word, 2 for strings / timestamps
+  DevBuf hashStore;              // VectorHasher hash per row
+  bool unmappable = false;       // some key has no 64-bit normalized form
   std::vector<DevBuf> depVals;   // width bytes per row (BOOLEAN: 1 byte)
   std::vector<DevBuf> depValid;  // 1 byte per row
   int64_t numRows = 0;
@@ -713,6 +868,8 @@ struct vx355_join_table {
   DevBuf present;  // array mode: bit per possible key
   DevBuf slots;  // hash mode: Slot[capacity]
   DevBuf next;   // u32[numRows]
+  DevBuf gslots;  // generic hash mode: u64[capacity]
+  std::vector<DevBuf> keyStore;  // generic hash mode: build key images
   std::vector<DevBuf> depVals, depValid;
   int64_t numRows = 0;
   int64_t numDistinct = 0;
@@ -737,6 +894,8 @@ struct vx355_join_probe {
 namespace vx {
 namespace {
 
+int keyWordsOf(int32_t kind) { return (isString(kind) || kind == VX355_TIMESTAMP) ? 2 : 1; }
+
 int depStoreWidth(int32_t kind) {
   int w = kindWidth(kind);
   return w == 0 ? 1 : w;
@@ -749,8 +908,10 @@ void growBuild(vx355_join_build& h, int64_t rows) {
   int64_t cap = std::max<int64_t>(rows, h.capacityRows * 2);
   cap = std::max<int64_t>(cap, 1024);
   for (size_t k = 0; k < h.keyVals.size(); ++k) {
-    h.keyVals[k].ensure(static_cast<size_t>(cap) * 8 + 64, true, static_cast<size_t>(h.numRows) * 8);
+    const size_t w = static_cast<size_t>(keyWordsOf(h.keyKinds[k])) * 8;
+    h.keyVals[k].ensure(static_cast<size_t>(cap) * w + 64, true, static_cast<size_t>(h.numRows) * w);
   }
+  h.hashStore.ensure(static_cast<size_t>(cap) * 8 + 64, true, static_cast<size_t>(h.numRows) * 8);
   for (size_t d = 0; d < h.depVals.size(); ++d) {
     const int w = depStoreWidth(h.depKinds[d]);
     h.depVals[d].ensure(static_cast<size_t>(cap) * w + 64, true, static_cast<size_t>(h.numRows) * w);
@@ -804,8 +965,10 @@ void buildAddInput(vx355_join_build& h, const vx355_batch* batch) {
     aa.numDeps = static_cast<int32_t>(h.depCols.size());
     for (int k = 0; k < aa.numKeys; ++k) {
       aa.keys[k] = va.keys[k];
-      aa.keyOut[k] = h.keyVals[k].as<int64_t>();
+      aa.keyOut[k] = h.keyVals[k].as<uint64_t>();
+      aa.keyWords[k] = keyWordsOf(h.keyKinds[k]);
     }
+    aa.hashOut = h.hashStore.as<uint64_t>();
     for (int d = 0; d < aa.numDeps; ++d) {
       aa.deps[d] = db.col(h.depCols[d]);
       aa.depOut[d] = h.depVals[d].as<char>();
@@ -820,10 +983,10 @@ void buildAddInput(vx355_join_build& h, const vx355_batch* batch) {
   }
   BuildCounters c = readBuildCounters(h.countersBuf);
   if (c.unmappable) {
-    VX_THROW(VX355_EUNSUPPORTED, "string join key longer than 7 bytes (generic hash mode not on device)");
+    h.unmappable = true;  // finish() picks the generic hash mode
   }
   if (c.longString) {
-    VX_THROW(VX355_EUNSUPPORTED, "non-inline string in a build-side payload column");
+    VX_THROW(VX355_EUNSUPPORTED, "non-inline string (> 12 bytes) in a build-side key or payload column");
   }
   if (c.nullKeyRows) {
     h.hasNullKeys = true;
@@ -857,9 +1020,13 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
     auto& o = *others[i];
     if (o.numRows > 0) {
       for (size_t k = 0; k < h.keyVals.size(); ++k) {
-        copyIn(h.keyVals[k].as<char>() + h.numRows * 8, o.keyVals[k].ptr(), VX355_MEM_DEVICE,
-               static_cast<size_t>(o.numRows) * 8);
+        const size_t w = static_cast<size_t>(keyWordsOf(h.keyKinds[k])) * 8;
+        copyIn(h.keyVals[k].as<char>() + h.numRows * w, o.keyVals[k].ptr(), VX355_MEM_DEVICE,
+               static_cast<size_t>(o.numRows) * w);
       }
+      copyIn(h.hashStore.as<char>() + h.numRows * 8, o.hashStore.ptr(), VX355_MEM_DEVICE,
+             static_cast<size_t>(o.numRows) * 8);
+      h.unmappable = h.unmappable || o.unmappable;
       for (size_t d = 0; d < h.depVals.size(); ++d) {
         const int w = depStoreWidth(h.depKinds[d]);
         copyIn(h.depVals[d].as<char>() + h.numRows * w, o.depVals[d].ptr(), VX355_MEM_DEVICE,
@@ -915,29 +1082,38 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
       overflow = true;
     }
   }
-  if (overflow) {
-    VX_THROW(VX355_EUNSUPPORTED,
-             "join keys do not fit a 64-bit normalized key (generic hash mode not on device)");
-  }
+  const bool generic = overflow || h.unmappable;  // decideHashMode's kHash cases
   // Direct addressing while the head array stays within a budget relative to
   // the build size (4 bytes per possible key).
   uint64_t arrayMax = std::max<uint64_t>(1ULL << 21, static_cast<uint64_t>(h.numRows) * 64);
   if (const char* e = std::getenv("VX355_JOIN_ARRAY_MAX")) {
     arrayMax = std::strtoull(e, nullptr, 10);
   }
-  const uint64_t range = static_cast<uint64_t>(product);
+  const uint64_t range = generic ? 0 : static_cast<uint64_t>(product);
   InsertArgs ia{};
   ia.numKeys = static_cast<int32_t>(h.keyCols.size());
   for (int k = 0; k < ia.numKeys; ++k) {
-    ia.keyVals[k] = h.keyVals[k].as<int64_t>();
+    ia.keyStore[k] = h.keyVals[k].as<uint64_t>();
+    ia.keyWords[k] = keyWordsOf(h.keyKinds[k]);
+    ia.keyIsString[k] = isString(h.keyKinds[k]) ? 1 : 0;
     ia.ranges[k] = t->ranges[k];
   }
+  ia.hashStore = h.hashStore.as<uint64_t>();
   ia.numRows = h.numRows;
   resetBuildCounters(h.countersBuf);
   ia.counters = h.countersBuf.as<BuildCounters>();
   t->next.ensure(static_cast<size_t>(std::max<int64_t>(1, h.numRows)) * 4 + 64);
   ia.next = t->next.as<uint32_t>();
-  if (range <= arrayMax) {
+  if (generic) {
+    t->mode = JMODE_HASH;
+    const uint64_t cap = std::max<uint64_t>(2048, nextPow2(static_cast<uint64_t>(h.numRows) * 2));
+    t->capacity = cap;
+    t->gslots.ensure(static_cast<size_t>(cap) * 8 + 64);
+    HIP_OK(hipMemsetAsync(t->gslots.ptr(), 0, static_cast<size_t>(cap) * 8, rt.stream));
+    VX_LAUNCH("k_fill_u32", k_fill_u32, streamGrid(std::max<int64_t>(1, h.numRows), 256, 4), 256, 0,
+              t->next.as<uint32_t>(), static_cast<uint64_t>(std::max<int64_t>(1, h.numRows)), kNoRow32);
+    ia.gslots = t->gslots.as<uint64_t>();
+  } else if (range <= arrayMax) {
     t->mode = JMODE_ARRAY;
     t->capacity = range;
     t->head.ensure(static_cast<size_t>(range) * 4 + 64);
@@ -976,6 +1152,9 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
   t->hasDuplicates = c.duplicates != 0;
   t->depVals = std::move(h.depVals);
   t->depValid = std::move(h.depValid);
+  if (t->mode == JMODE_HASH) {
+    t->keyStore = std::move(h.keyVals);  // the probe compares against the build key images
+  }
   h.keyVals.clear();
   h.finished = true;
   return t.release();
@@ -1000,11 +1179,16 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
   for (int k = 0; k < a.numKeys; ++k) {
     a.keys[k] = db.col(p.keyCols[k]);
     const int32_t kind = a.keys[k].kind;
-    const bool buildString = isString(t.keyKinds[k]);
-    if (isString(kind) != buildString || (!isString(kind) && !isIntLike(kind))) {
+    if (t.mode == JMODE_HASH ? kind != t.keyKinds[k]
+                             : (isString(kind) != isString(t.keyKinds[k]) ||
+                                (!isString(kind) && !isIntLike(kind)))) {
       VX_THROW(VX355_EUNSUPPORTED, "probe key type does not match the build key");
     }
     a.ranges[k] = t.ranges[k];
+    if (t.mode == JMODE_HASH) {
+      a.keyStore[k] = t.keyStore[k].as<uint64_t>();
+      a.keyWords[k] = keyWordsOf(t.keyKinds[k]);
+    }
   }
   a.mode = t.mode;
   a.hasDuplicates = t.hasDuplicates ? 1 : 0;
@@ -1012,6 +1196,7 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
   a.numRows = n;
   a.head = t.head.as<uint32_t>();
   a.slots = t.slots.as<Slot>();
+  a.gslots = t.gslots.as<uint64_t>();
   a.capacity = t.capacity;
   a.next = t.next.as<uint32_t>();
   a.present = t.present.as<uint32_t>();
@@ -1027,7 +1212,7 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
   uint64_t* offs =
       static_cast<uint64_t*>(p.tileOffsets.ensure(static_cast<size_t>(p.numTiles + 1) * 8 + 64));
   a.tileSums = sums;
-  a.fastKey = (a.numKeys == 1 && a.keys[0].kind == VX355_BIGINT && a.keys[0].enc == VX355_FLAT &&
+  a.fastKey = (t.mode != JMODE_HASH && a.numKeys == 1 && a.keys[0].kind == VX355_BIGINT && a.keys[0].enc == VX355_FLAT &&
                a.keys[0].nulls == nullptr && a.ranges[0].multiplier == 1)
       ? 1
       : 0;
@@ -1159,8 +1344,8 @@ int vx355_join_build_create(const vx355_join_build_spec* spec, vx355_join_build*
   h->joinType = spec->join_type;
   for (int32_t k = 0; k < spec->num_keys; ++k) {
     const int32_t kind = spec->key_types[k];
-    if (!(isIntLike(kind) || isString(kind))) {
-      VX_THROW(VX355_EUNSUPPORTED, "join key type " + std::to_string(kind) + " has no value ids");
+    if (kindWidth(kind) < 0) {
+      VX_THROW(VX355_EUNSUPPORTED, "join key type " + std::to_string(kind));
     }
     h->keyCols.push_back(spec->key_cols[k]);
     h->keyKinds.push_back(kind);
