@@ -380,7 +380,7 @@ typedef struct vx355_agg_stats {
   int64_t capacity;     /* hashtable.capacity */
   int64_t num_rehashes; /* hashtable.numRehashes */
   int32_t hash_mode;    /* 0 kHash, 1 kArray, 2 kNormalizedKey (BaseHashTable::HashMode) */
-  int32_t reserved;
+  int32_t reserved;     /* launches of a hiprtc-instantiated shape-specialised kernel */
   int64_t input_rows;
   int64_t deferred_rows; /* rows replayed after a key-range widening */
 } vx355_agg_stats;

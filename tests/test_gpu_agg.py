@@ -489,3 +489,43 @@ def test_thousand_small_batches_are_coalesced(oracle, vx):
     assert gop.stats().input_rows == 400 * n_each
     launches = sum(v[1] for k, v in vx.profile().items() if k.startswith("k_agg_"))
     assert launches <= 12  # 800 K rows in ~4 flushes, not 400 launches
+
+
+@pytest.mark.parametrize("jit", ["1", "0"])
+def test_plan_shape_outside_the_table_is_instantiated_with_hiprtc(oracle, vx, jit, monkeypatch):
+    """A flat plan whose shape is not among the ahead-of-time instantiations
+    (INTEGER + BIGINT keys, DOUBLE filter, three sums, avg, count) gets its own
+    instantiation of the same kernel body through hiprtc; with VX355_JIT=0 the
+    generic kernel runs instead. Same results either way."""
+    monkeypatch.setenv("VX355_JIT", jit)
+    rng = np.random.default_rng(202)
+    n = 1 << 20
+    k1 = rng.integers(0, 12, n).astype(np.int32)
+    k2 = rng.integers(100, 103, n).astype(np.int64)
+    a, b, c = _dyadic(rng, n), _dyadic(rng, n), _dyadic(rng, n)
+    hb = batch_of([k1, k2, a, b, c])
+    P = vx.PROJ
+    terms = [(3, abi.CMP_LT, 900.0)]
+    projs = [[(2, 1.0, 0.0), (4, 1.0, 1.0)]]
+    aggs = [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_SUM, 3, abi.DOUBLE), (abi.AGG_SUM, P(0), abi.DOUBLE),
+            (abi.AGG_AVG, 4, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    # reference: FilterProject then HashAggregation on the oracle
+    idx, proj, _ = oracle.filter_project(hb, terms, projs)
+    ref_b = batch_of([k1[idx], k2[idx], a[idx], b[idx], c[idx], proj[0]])
+    ref_aggs = [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_SUM, 3, abi.DOUBLE), (abi.AGG_SUM, 5, abi.DOUBLE),
+                (abi.AGG_AVG, 4, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    exp, _ = run_agg(oracle, [ref_b], [0, 1], [abi.INTEGER, abi.BIGINT], ref_aggs)
+    op = vx.Aggregation([0, 1], [abi.INTEGER, abi.BIGINT], aggs)
+    op.set_fused_input(terms, projs)
+    vx.profile_reset()
+    vx.profile_enable(True)
+    op.add_input(vx.to_device(hb))
+    op.no_more_input()
+    got = vx.collect_output(op, 100)
+    vx.profile_enable(False)
+    assert_columns_equal(got, exp, op.kinds, what=f"jit={jit}")
+    names = vx.profile()
+    if jit == "1":
+        assert op.stats().reserved > 0 and "k_agg_fast" in names
+    else:
+        assert op.stats().reserved == 0 and "k_agg_lds" in names

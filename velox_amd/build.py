@@ -60,7 +60,7 @@ def build_lib(force=False, verbose=False):
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lhiprtc", "-ldl"])
     return LIB
 
 

@@ -26,6 +26,11 @@
 //    reproduced by recording the minimum global input row per group and
 //    sorting groups by it at output time.
 #include "common.h"
+#include "agg_device.h"
+
+#include <dlfcn.h>
+#include <glob.h>
+#include <hip/hiprtc.h>
 #include "expr_device.h"
 
 #include <algorithm>
@@ -45,22 +50,8 @@ void makeProjectionArgs(const DeviceBatch& db, const vx355_projection* proj, int
 
 namespace {
 
-constexpr int kMaxKeys = 8;
-constexpr int kMaxAccs = 16;      // accumulators a kernel updates per row
-constexpr int kMaxLdsAccs = 28;   // LDS / table words they touch (DOUBLE sums own two)
-constexpr uint64_t kEmpty = ~0ULL;
-constexpr uint64_t kNoRow = ~0ULL;
 
-enum AccKind : int32_t {
-  ACC_SUM_F64 = 0,
-  ACC_SUM_I64 = 1,        // checked: sets the overflow flag
-  ACC_SUM_I64_WRAP = 2,   // partial counts merged in the final step (no check)
-  ACC_COUNT = 3,          // +1 per qualifying row
-  ACC_MIN = 4,            // order-preserving u64 image, atomic umin
-  ACC_MAX = 5,
-};
 
-enum Mode : int32_t { MODE_HASH = 0, MODE_ARRAY = 1, MODE_NORMALIZED = 2 };
 
 struct KeyArg {
   ColView col;
@@ -85,18 +76,6 @@ struct AccArg {
   int32_t pad;
 };
 
-// Counters the kernels bump; mirrored into the pinned mailbox by the host.
-struct Counters {
-  uint32_t numDeferred;
-  uint32_t numNewGroups;
-  uint32_t overflow;     // sum(BIGINT) overflowed
-  uint32_t unmappable;   // a string key longer than 7 bytes was seen
-  uint32_t tableFull;
-  uint32_t pad[3];
-  int64_t keyMin[kMaxKeys];
-  int64_t keyMax[kMaxKeys];
-  uint64_t sumMax[kMaxAccs];  // largest |input| seen per DOUBLE sum (bit pattern), k_sum_stats
-};
 
 struct AggArgs {
   KeyArg keys[kMaxKeys];
@@ -197,36 +176,7 @@ __device__ inline bool accInput(const AggArgs& a, const AccArg& acc, int64_t row
   return true;
 }
 
-__device__ inline bool addOverflows(int64_t old, int64_t v) {
-  int64_t r;
-  return __builtin_add_overflow(old, v, &r);
-}
 
-__device__ inline void applyGlobal(uint64_t* word, int32_t kind, uint64_t v, Counters* ctr) {
-  switch (kind) {
-    case ACC_SUM_F64:
-      unsafeAtomicAdd(reinterpret_cast<double*>(word), __longlong_as_double(static_cast<long long>(v)));
-      break;
-    case ACC_SUM_I64: {
-      unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(word),
-                                         static_cast<unsigned long long>(v));
-      if (addOverflows(static_cast<int64_t>(old), static_cast<int64_t>(v))) {
-        ctr->overflow = 1;
-      }
-      break;
-    }
-    case ACC_SUM_I64_WRAP:
-    case ACC_COUNT:
-      atomicAdd(reinterpret_cast<unsigned long long*>(word), static_cast<unsigned long long>(v));
-      break;
-    case ACC_MIN:
-      atomicMin(reinterpret_cast<unsigned long long*>(word), static_cast<unsigned long long>(v));
-      break;
-    default:
-      atomicMax(reinterpret_cast<unsigned long long*>(word), static_cast<unsigned long long>(v));
-      break;
-  }
-}
 
 __device__ inline void applyLds(uint64_t* word, int32_t kind, uint64_t v, Counters* ctr) {
   switch (kind) {
@@ -254,23 +204,7 @@ __device__ inline void applyLds(uint64_t* word, int32_t kind, uint64_t v, Counte
   }
 }
 
-__host__ __device__ inline uint64_t accIdentity(int32_t kind) {
-  return kind == ACC_MIN ? ~0ULL : 0ULL;
-}
 
-// Error-free split of v against the grid encoded in m = 1.5 * 2^(G+52):
-// hi is v rounded to a multiple of 2^G, lo = v - hi exactly (|v| < 2^(G+51)).
-__device__ inline void splitDouble(double v, double m, double* hi, double* lo) {
-  if (!(fabs(v) < m * 0.25)) {
-    // Too large for the grid (or inf / NaN): plain accumulation for this value.
-    *hi = v;
-    *lo = 0.0;
-    return;
-  }
-  const double t = v + m;
-  *hi = t - m;
-  *lo = v - *hi;
-}
 
 // Normalized key of one input row (VectorHasher::computeValueIds semantics).
 // Returns 0 = key ready, 1 = row dropped (null key with ignoreNullKeys),
@@ -430,162 +364,6 @@ __global__ __launch_bounds__(256) void k_agg_global(AggArgs a) {
   addNewGroups(a.counters, newGroups);
 }
 
-// ---- low-cardinality kernels: LDS-resident, lane-replicated accumulators ----
-// LDS layout: [slotOf int32[capacity] unless direct][slotKey u32[S]][slotFirst u32[S]]
-//             [numSlots u32][pad][acc u64[S][numAccs][REP]]
-constexpr int32_t kSlotEmpty = -1;
-constexpr int32_t kSlotPending = -2;
-constexpr int32_t kSlotOverflow = -3;
-
-// What both LDS kernels need to know about the accumulators and the table.
-struct LdsPlan {
-  int32_t S;
-  int32_t REP;
-  int32_t A;
-  int32_t direct;
-  uint64_t capacity;
-  uint64_t* table;
-  int32_t stride;
-  int32_t pad;
-  uint64_t rowBase;
-  Counters* counters;
-  int32_t kind[kMaxLdsAccs];
-  int32_t off[kMaxLdsAccs];
-};
-
-struct LdsState {
-  int32_t* slotOf;
-  uint32_t* slotKey;
-  uint32_t* slotFirst;
-  uint32_t* numSlots;
-  uint64_t* acc;
-};
-
-__device__ inline LdsState ldsInit(const LdsPlan& p, unsigned char* raw) {
-  LdsState st;
-  const int mapWords = p.direct ? 0 : static_cast<int>(p.capacity);
-  st.slotOf = reinterpret_cast<int32_t*>(raw);
-  st.slotKey = reinterpret_cast<uint32_t*>(raw) + mapWords;
-  st.slotFirst = st.slotKey + p.S;
-  st.numSlots = st.slotFirst + p.S;
-  st.acc = reinterpret_cast<uint64_t*>(
-      raw + ((static_cast<size_t>(mapWords + 2 * p.S + 2) * 4 + 15) & ~static_cast<size_t>(15)));
-  for (int i = threadIdx.x; i < mapWords; i += blockDim.x) {
-    st.slotOf[i] = kSlotEmpty;
-  }
-  for (int i = threadIdx.x; i < p.S; i += blockDim.x) {
-    st.slotFirst[i] = 0xffffffffu;
-    st.slotKey[i] = static_cast<uint32_t>(i);
-  }
-  if (threadIdx.x == 0) {
-    *st.numSlots = p.direct ? static_cast<uint32_t>(p.S) : 0;
-  }
-  for (int i = threadIdx.x; i < p.S * p.A * p.REP; i += blockDim.x) {
-    st.acc[i] = accIdentity(p.kind[(i / p.REP) % p.A]);
-  }
-  __syncthreads();
-  return st;
-}
-
-// LDS slot of a key (>= 0) or kSlotOverflow when the workgroup's slots are used up.
-__device__ inline int32_t ldsSlot(const LdsPlan& p, const LdsState& st, uint64_t key) {
-  if (p.direct) {
-    return static_cast<int32_t>(key);
-  }
-  // Claim protocol without waiting on an exit edge: the winner of the CAS
-  // allocates and publishes the slot INSIDE the loop body, every lane
-  // re-evaluates at the latch. (A `break` after the publish would let the
-  // compiler sink the publish behind the loop and spin the other lanes of the
-  // same wave forever.)
-  int32_t* entry = st.slotOf + key;
-  int32_t slot = kSlotPending;
-  while (slot == kSlotPending) {
-    int32_t s = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (s == kSlotEmpty) {
-      if (atomicCAS(entry, kSlotEmpty, kSlotPending) == kSlotEmpty) {
-        uint32_t t = atomicAdd(st.numSlots, 1u);
-        if (t < static_cast<uint32_t>(p.S)) {
-          st.slotKey[t] = static_cast<uint32_t>(key);
-          s = static_cast<int32_t>(t);
-        } else {
-          s = kSlotOverflow;
-        }
-        __hip_atomic_store(entry, s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      } else {
-        s = kSlotPending;
-      }
-    }
-    slot = s;
-  }
-  return slot;
-}
-
-__device__ inline void ldsTouchFirst(const LdsState& st, int32_t slot, uint32_t row) {
-  if (st.slotFirst[slot] > row) {
-    atomicMin(&st.slotFirst[slot], row);
-  }
-}
-
-// Flush: one (slot, accumulator) pair per thread; replicas reduced in LDS.
-__device__ inline void ldsFlush(const LdsPlan& p, const LdsState& st) {
-  __syncthreads();
-  const int S = p.S, A = p.A, REP = p.REP;
-  uint32_t live = *st.numSlots;
-  if (live > static_cast<uint32_t>(S)) {
-    live = S;
-  }
-  for (int t = threadIdx.x; t < static_cast<int>(live) * (A + 1); t += blockDim.x) {
-    const int slot = t / (A + 1);
-    const int j = t % (A + 1);
-    const uint32_t first = st.slotFirst[slot];
-    if (first == 0xffffffffu) {
-      continue;  // direct layout: key never seen by this workgroup
-    }
-    uint64_t* g = p.table + static_cast<uint64_t>(st.slotKey[slot]) * p.stride;
-    if (j == A) {
-      // 'first' is the smallest ORIGINAL row of the chunk seen for this key
-      // (replays go through the row list), so it decides the group order.
-      uint64_t firstRow = p.rowBase + static_cast<uint64_t>(first);
-      unsigned long long old = atomicMin(reinterpret_cast<unsigned long long*>(g + 1), firstRow);
-      if (old == kNoRow) {
-        atomicAdd(&p.counters->numNewGroups, 1u);
-      }
-      continue;
-    }
-    const int32_t kind = p.kind[j];
-    const uint64_t* q = st.acc + (static_cast<size_t>(slot) * A + j) * REP;
-    uint64_t v = q[0];
-    if (kind == ACC_SUM_F64) {
-      double s = __longlong_as_double(static_cast<long long>(v));
-      for (int r = 1; r < REP; ++r) {
-        s += __longlong_as_double(static_cast<long long>(q[r]));
-      }
-      applyGlobal(g + p.off[j], ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(s)), p.counters);
-    } else if (kind == ACC_MIN) {
-      for (int r = 1; r < REP; ++r) {
-        v = q[r] < v ? q[r] : v;
-      }
-      applyGlobal(g + p.off[j], ACC_MIN, v, p.counters);
-    } else if (kind == ACC_MAX) {
-      for (int r = 1; r < REP; ++r) {
-        v = q[r] > v ? q[r] : v;
-      }
-      applyGlobal(g + p.off[j], ACC_MAX, v, p.counters);
-    } else {
-      int64_t s = static_cast<int64_t>(v);
-      for (int r = 1; r < REP; ++r) {
-        int64_t x = static_cast<int64_t>(q[r]);
-        if (kind == ACC_SUM_I64 && addOverflows(s, x)) {
-          p.counters->overflow = 1;
-        }
-        s = static_cast<int64_t>(static_cast<uint64_t>(s) + static_cast<uint64_t>(x));
-      }
-      applyGlobal(g + p.off[j], kind == ACC_COUNT ? ACC_SUM_I64_WRAP : kind, static_cast<uint64_t>(s),
-                  p.counters);
-    }
-  }
-}
-
 struct LdsArgs {
   AggArgs a;
   LdsPlan plan;
@@ -645,298 +423,9 @@ __global__ __launch_bounds__(1024) void k_agg_lds(LdsArgs args) {
   addNewGroups(a.counters, newGroups);
 }
 
-// ---- shape-specialised LDS kernel ------------------------------------------------
-// The generic LDS kernel interprets the plan per row (column encodings, types,
-// masks, expression tables): ~500 VALU instructions per 64 rows, which caps it
-// near 2 TB/s. For flat, null-free inputs the plan SHAPE is lifted into template
-// parameters instead, so every register index and every branch on the plan is
-// resolved at compile time and what is left per row is the arithmetic itself:
-//   keys   K0,K1  : FK_VIEW (short string, first 8 bytes of the StringView),
-//                   FK_I32, FK_I64, or -1 (absent)
-//   terms  T0,T1  : filter column kinds FK_I32 / FK_I64 / FK_F64 or -1
-//   NL            : distinct DOUBLE columns loaded per row (each loaded once)
-//   NA, ACC_LO/HI : per accumulator 16 bits {numFactors, load index of factor
-//                   0..2 (15 = constant factor)}; numFactors 0 = count(*)
-// Comparison operators, constants, scales, offsets, ranges stay runtime values.
-// Shapes are instantiated ahead of time below (VX_FAST_SHAPES); a plan whose
-// shape is not in the table runs on the generic kernel.
-constexpr int kFastKeys = 2;
-constexpr int kFastTerms = 2;
-constexpr int kFastAccs = 8;
-constexpr int kFastFactors = 3;
-constexpr int kFastLoads = 8;
-
-enum FastKind : int32_t { FK_NONE = -1, FK_VIEW = 0, FK_I32 = 1, FK_I64 = 2, FK_F64 = 3 };
-
-struct FastTerm {
-  const void* ptr;
-  int32_t cmp;
-  int32_t pad;
-  int64_t i64;
-  double f64;
-};
-struct FastArgs {
-  const void* keyPtr[kFastKeys];
-  KeyRange range[kFastKeys];
-  const double* loadPtr[kFastLoads];
-  FastTerm term[kFastTerms];
-  double scale[kFastAccs][kFastFactors];
-  double offset[kFastAccs][kFastFactors];
-  double splitM[kFastAccs];  // grid of the hi/lo split of sum j (0 = accumulate into hi only)
-  int64_t numRows;
-  int32_t* deferred;
-  uint32_t deferCap;
-  uint32_t pad;
-  LdsPlan plan;
-};
-
-constexpr uint64_t accDesc(int numFactors, int l0 = 15, int l1 = 15, int l2 = 15) {
-  return static_cast<uint64_t>(numFactors) | (static_cast<uint64_t>(l0) << 4) |
-      (static_cast<uint64_t>(l1) << 8) | (static_cast<uint64_t>(l2) << 12);
-}
-constexpr uint64_t packAccs(uint64_t a0 = 0, uint64_t a1 = 0, uint64_t a2 = 0, uint64_t a3 = 0) {
-  return a0 | (a1 << 16) | (a2 << 32) | (a3 << 48);
-}
-
-template <int UNROLL, int K0, int K1, int T0, int T1, int NL, int NA, uint64_t ACC_LO, uint64_t ACC_HI>
-struct FastShape {
-  static constexpr int unroll = UNROLL;
-  static constexpr int keyKind(int k) { return k == 0 ? K0 : K1; }
-  static constexpr int termKind(int t) { return t == 0 ? T0 : T1; }
-  static constexpr int numLoads = NL;
-  static constexpr int numAccs = NA;
-  static constexpr uint64_t desc(int j) {
-    return ((j < 4 ? ACC_LO >> (16 * j) : ACC_HI >> (16 * (j - 4)))) & 0xffff;
-  }
-  static constexpr int numFactors(int j) { return static_cast<int>(desc(j) & 15); }
-  // LDS / table word of accumulator j: every DOUBLE sum before it owns two words (hi, lo).
-  static constexpr int ldsIndex(int j) {
-    int idx = 0;
-    for (int q = 0; q < j; ++q) {
-      idx += numFactors(q) == 0 ? 1 : 2;
-    }
-    return idx;
-  }
-  static constexpr int numLdsAccs = ldsIndex(NA);
-  static constexpr int load(int j, int f) { return static_cast<int>((desc(j) >> (4 + 4 * f)) & 15); }
-};
-
-// Compile-time loop: f(std::integral_constant<int, 0>{}) ... f(<N-1>).
-template <int... Is, typename F>
-__device__ inline void staticForImpl(std::integer_sequence<int, Is...>, F&& f) {
-  (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, typename F>
-__device__ inline void staticFor(F&& f) {
-  staticForImpl(std::make_integer_sequence<int, N>{}, f);
-}
-
-template <int KIND>
-__device__ inline uint64_t fastLoadRaw(const void* ptr, int64_t row) {
-  if constexpr (KIND == FK_VIEW) {
-    return static_cast<const uint64_t*>(ptr)[row * 2];
-  } else if constexpr (KIND == FK_I32) {
-    return static_cast<const uint32_t*>(ptr)[row];  // sign-extended at use
-  } else {
-    return static_cast<const uint64_t*>(ptr)[row];
-  }
-}
-
-// int64 image of a key (VectorHasher::toInt64 / stringAsNumber); INT64_MIN for
-// strings the fast path does not decode (> 3 bytes: the replay reads the view).
-template <int KIND>
-__device__ inline int64_t fastKeyValue(uint64_t raw) {
-  if constexpr (KIND == FK_VIEW) {
-    const uint32_t size = static_cast<uint32_t>(raw);
-    const uint32_t bytes = static_cast<uint32_t>(raw >> 32);
-    const uint32_t shift = (size & 3u) * 8;
-    const int64_t v = static_cast<int64_t>((bytes & ((1u << shift) - 1)) + (size ? (1u << shift) : 0u));
-    return size > 3 ? INT64_MIN : v;
-  } else if constexpr (KIND == FK_I32) {
-    return static_cast<int64_t>(static_cast<int32_t>(static_cast<uint32_t>(raw)));
-  } else {
-    return static_cast<int64_t>(raw);
-  }
-}
-
 template <typename S>
 __global__ __launch_bounds__(512, 4) void k_agg_fast(FastArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
-  constexpr int UNROLL = S::unroll;
-  constexpr int NA = S::numAccs;     // accumulators of the plan
-  constexpr int A = S::numLdsAccs;   // words they own (DOUBLE sums: hi + lo)
-  const LdsPlan& p = a.plan;
-  const LdsState st = ldsInit(p, ldsRaw);
-  const int REP = p.REP;
-  const int rep = lane() & (REP - 1);
-  const int64_t tile = static_cast<int64_t>(blockDim.x) * UNROLL;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * tile;
-  const int64_t rounds = (a.numRows + stride - 1) / stride;
-  int64_t base = static_cast<int64_t>(blockIdx.x) * tile + threadIdx.x;
-  for (int64_t r = 0; r < rounds; ++r, base += stride) {
-    uint64_t kraw[UNROLL][kFastKeys];
-    uint64_t traw[UNROLL][kFastTerms];
-    double x[UNROLL][S::numLoads > 0 ? S::numLoads : 1];
-    // Phase 1: every load of this iteration, column by column, UNROLL rows
-    // back to back. Rows past the end are clamped (and ignored in phase 2) so
-    // that no load sits under a per-lane predicate.
-    int64_t rowc[UNROLL];
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      const int64_t row = base + static_cast<int64_t>(u) * blockDim.x;
-      rowc[u] = row < a.numRows ? row : a.numRows - 1;
-    }
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      if constexpr (S::keyKind(0) != FK_NONE) {
-        kraw[u][0] = fastLoadRaw<S::keyKind(0)>(a.keyPtr[0], rowc[u]);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      if constexpr (S::keyKind(1) != FK_NONE) {
-        kraw[u][1] = fastLoadRaw<S::keyKind(1)>(a.keyPtr[1], rowc[u]);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      if constexpr (S::termKind(0) != FK_NONE) {
-        traw[u][0] = fastLoadRaw<S::termKind(0)>(a.term[0].ptr, rowc[u]);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      if constexpr (S::termKind(1) != FK_NONE) {
-        traw[u][1] = fastLoadRaw<S::termKind(1)>(a.term[1].ptr, rowc[u]);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < S::numLoads; ++j) {
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-        x[u][j] = a.loadPtr[j][rowc[u]];
-      }
-    }
-    // Phase 2: filter, key, LDS updates.
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      const int64_t row = base + static_cast<int64_t>(u) * blockDim.x;
-      bool live = row < a.numRows;
-      staticFor<kFastTerms>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        if constexpr (S::termKind(t) == FK_F64) {
-          live = live && compareValues<double>(a.term[t].cmp,
-                                               __longlong_as_double(static_cast<long long>(traw[u][t])),
-                                               a.term[t].f64);
-        } else if constexpr (S::termKind(t) == FK_I32) {
-          // the host only picks this shape when the constant fits int32
-          live = live && compareValues<int32_t>(a.term[t].cmp,
-                                                static_cast<int32_t>(static_cast<uint32_t>(traw[u][t])),
-                                                static_cast<int32_t>(a.term[t].i64));
-        } else if constexpr (S::termKind(t) == FK_I64) {
-          live = live && compareValues<int64_t>(a.term[t].cmp, static_cast<int64_t>(traw[u][t]),
-                                                a.term[t].i64);
-        }
-      });
-      uint64_t key = 0;
-      bool defer = false;
-      staticFor<kFastKeys>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        if constexpr (S::keyKind(k) != FK_NONE) {
-          const int64_t v = fastKeyValue<S::keyKind(k)>(kraw[u][k]);
-          if (v < a.range[k].min || v > a.range[k].max) {
-            if (live) {
-              defer = true;
-              if (v != INT64_MIN) {
-                atomicMin(reinterpret_cast<long long*>(&p.counters->keyMin[k]), static_cast<long long>(v));
-                atomicMax(reinterpret_cast<long long*>(&p.counters->keyMax[k]), static_cast<long long>(v));
-              }
-            }
-          } else {
-            key += a.range[k].multiplier *
-                (static_cast<uint64_t>(v) - static_cast<uint64_t>(a.range[k].min) + 1);
-          }
-        }
-      });
-      if (live && !defer) {
-        const int32_t slot = ldsSlot(p, st, key);
-        double vals[NA > 0 ? NA : 1];
-        staticFor<NA>([&](auto jc) {
-          constexpr int j = decltype(jc)::value;
-          double acc = 0;
-          staticFor<S::numFactors(j)>([&](auto fc) {
-            constexpr int f = decltype(fc)::value;
-            double v = a.offset[j][f];
-            if constexpr (S::load(j, f) != 15) {
-              v = a.scale[j][f] * x[u][S::load(j, f)] + a.offset[j][f];
-            }
-            acc = f == 0 ? v : acc * v;
-          });
-          vals[j] = acc;
-        });
-        if (slot >= 0) {
-          ldsTouchFirst(st, slot, static_cast<uint32_t>(row));
-          uint64_t* dst = st.acc + (static_cast<size_t>(slot) * A) * REP + rep;
-          staticFor<NA>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            constexpr int w = S::ldsIndex(j);
-            if constexpr (S::numFactors(j) == 0) {
-              atomicAdd(reinterpret_cast<unsigned long long*>(dst + w * REP), 1ULL);
-            } else {
-              if (a.splitM[j] != 0.0) {
-                double hi, lo;
-                splitDouble(vals[j], a.splitM[j], &hi, &lo);
-                unsafeAtomicAdd(reinterpret_cast<double*>(dst + w * REP), hi);
-                unsafeAtomicAdd(reinterpret_cast<double*>(dst + (w + 1) * REP), lo);
-              } else {
-                unsafeAtomicAdd(reinterpret_cast<double*>(dst + w * REP), vals[j]);
-              }
-            }
-          });
-        } else {
-          // Workgroup out of LDS slots: straight to the group row in HBM.
-          uint64_t* g = p.table + key * p.stride;
-          const uint64_t myRow = p.rowBase + static_cast<uint64_t>(row);
-          unsigned long long old = atomicMin(reinterpret_cast<unsigned long long*>(g + 1), myRow);
-          if (old == kNoRow) {
-            atomicAdd(&p.counters->numNewGroups, 1u);
-          }
-          staticFor<NA>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            constexpr int w = S::ldsIndex(j);
-            if constexpr (S::numFactors(j) == 0) {
-              applyGlobal(g + p.off[w], ACC_SUM_I64_WRAP, 1, p.counters);
-            } else {
-              double hi = vals[j], lo = 0;
-              if (a.splitM[j] != 0.0) {
-                splitDouble(vals[j], a.splitM[j], &hi, &lo);
-              }
-              applyGlobal(g + p.off[w], ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(hi)),
-                          p.counters);
-              if (a.splitM[j] != 0.0) {
-                applyGlobal(g + p.off[w + 1], ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(lo)),
-                            p.counters);
-              }
-            }
-          });
-        }
-      }
-      // Rows the fast path cannot place go to the deferred list (one atomic per wave).
-      const uint64_t m = ballot(defer);
-      if (m != 0) {
-        const int leader = __ffsll(static_cast<long long>(m)) - 1;
-        uint32_t at = 0;
-        if (lane() == leader) {
-          at = atomicAdd(&p.counters->numDeferred, static_cast<uint32_t>(popc64(m)));
-        }
-        at = __shfl(at, leader, kWave);
-        if (defer && at + lanePrefix(m) < a.deferCap) {
-          a.deferred[at + lanePrefix(m)] = static_cast<int32_t>(row);
-        }
-      }
-    }
-  }
-  ldsFlush(p, st);
+  aggFastBody<S>(a);
 }
 
 // What the host derives from a launch to pick an instantiation.
@@ -1695,6 +1184,7 @@ struct vx355_agg {
   uint64_t arrayMax = 1ULL << 28;
   int64_t chunkRows = 1LL << 31;
   bool disableFast = false;
+  int64_t jitLaunches = 0;
   bool exactSums = true;
   bool logShapes = false;
   int64_t deferCap = 1 << 20;
@@ -2200,6 +1690,136 @@ bool buildFastArgs(const AggArgs& c, const LdsPlan& plan, FastArgs* f, FastSigna
   return true;
 }
 
+// ---- hiprtc instantiation of aggFastBody<Shape> for shapes outside the table ----
+// The plan shape becomes template arguments of the same kernel body the
+// ahead-of-time table uses (agg_device.h), compiled once per shape and process
+// (~1 s) and cached; Velox's Wave backend does the same with NVRTC
+// (experimental/wave/common/Compile.cu). Anything that goes wrong (no hiprtc,
+// headers not next to the library) disables the JIT and the generic kernel runs.
+struct JitKernel {
+  hipModule_t module = nullptr;
+  hipFunction_t fn = nullptr;
+};
+
+struct JitState {
+  std::map<std::string, JitKernel> kernels;
+  bool disabled = false;
+  std::string csrcDir;
+  std::string clangInclude;
+};
+
+JitState& jitState() {
+  static JitState st;
+  return st;
+}
+
+bool jitPrepare(JitState& st) {
+  if (!st.csrcDir.empty()) {
+    return true;
+  }
+  if (const char* e = std::getenv("VX355_JIT")) {
+    if (e[0] == '0') {
+      st.disabled = true;
+      return false;
+    }
+  }
+  Dl_info info;
+  if (!dladdr(reinterpret_cast<const void*>(&vx355_agg_create), &info) || !info.dli_fname) {
+    st.disabled = true;
+    return false;
+  }
+  std::string lib = info.dli_fname;
+  const size_t slash = lib.rfind('/');
+  st.csrcDir = (slash == std::string::npos ? std::string(".") : lib.substr(0, slash)) + "/csrc";
+  glob_t g{};
+  if (glob("/opt/rocm/lib/llvm/lib/clang/*/include", 0, nullptr, &g) == 0 && g.gl_pathc > 0) {
+    st.clangInclude = g.gl_pathv[g.gl_pathc - 1];
+  }
+  globfree(&g);
+  if (FILE* f = fopen((st.csrcDir + "/agg_device.h").c_str(), "r")) {
+    fclose(f);
+  } else {
+    st.disabled = true;
+    return false;
+  }
+  return true;
+}
+
+hipFunction_t jitFastKernel(const FastSignature& sig, int unroll, bool log) {
+  JitState& st = jitState();
+  if (st.disabled || !jitPrepare(st)) {
+    return nullptr;
+  }
+  char key[256];
+  snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d,%lluull,%lluull", unroll, sig.k0, sig.k1, sig.t0, sig.t1,
+           sig.numLoads, sig.numAccs, static_cast<unsigned long long>(sig.accLo),
+           static_cast<unsigned long long>(sig.accHi));
+  auto it = st.kernels.find(key);
+  if (it != st.kernels.end()) {
+    return it->second.fn;
+  }
+  const std::string src = "#include \"" + st.csrcDir + "/agg_device.h\"\n"
+      "using S = vx::FastShape<" + std::string(key) + ">;\n"
+      "extern \"C\" __global__ __launch_bounds__(512, 4) void k_agg_fast_jit(vx::FastArgs a) {\n"
+      "  vx::aggFastBody<S>(a);\n}\n";
+  JitKernel k;
+  hiprtcProgram prog = nullptr;
+  bool ok = hiprtcCreateProgram(&prog, src.c_str(), "vx355_agg_fast_jit.hip", 0, nullptr, nullptr) == HIPRTC_SUCCESS;
+  std::string buildLog;
+  if (ok) {
+    const std::string inc1 = "-I/opt/rocm/include";
+    const std::string inc2 = "-I" + st.clangInclude;
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", inc1.c_str(),
+                          inc2.c_str()};
+    ok = hiprtcCompileProgram(prog, 6, opts) == HIPRTC_SUCCESS;
+    size_t logSize = 0;
+    if (hiprtcGetProgramLogSize(prog, &logSize) == HIPRTC_SUCCESS && logSize > 1) {
+      buildLog.resize(logSize);
+      hiprtcGetProgramLog(prog, &buildLog[0]);
+    }
+  }
+  std::vector<char> code;
+  if (ok) {
+    size_t size = 0;
+    ok = hiprtcGetCodeSize(prog, &size) == HIPRTC_SUCCESS && size > 0;
+    if (ok) {
+      code.resize(size);
+      ok = hiprtcGetCode(prog, code.data()) == HIPRTC_SUCCESS;
+    }
+  }
+  if (prog) {
+    hiprtcDestroyProgram(&prog);
+  }
+  if (ok) {
+    ok = hipModuleLoadData(&k.module, code.data()) == hipSuccess &&
+        hipModuleGetFunction(&k.fn, k.module, "k_agg_fast_jit") == hipSuccess;
+  }
+  if (!ok) {
+    (void)hipGetLastError();
+    if (log) {
+      fprintf(stderr, "vx355: hiprtc instantiation failed for shape %s\n%s\n", key, buildLog.c_str());
+    }
+    k = JitKernel{};
+  }
+  st.kernels[key] = k;  // failures are cached too: one attempt per shape
+  return k.fn;
+}
+
+void launchJitFast(hipFunction_t fn, const FastArgs& fa, int grid, size_t ldsBytes) {
+  auto& rt = Runtime::get();
+  size_t size = sizeof(FastArgs);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<FastArgs*>(&fa),
+                    HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  if (rt.profile) {
+    rt.profBegin("k_agg_fast");
+  }
+  HIP_OK(hipModuleLaunchKernel(fn, grid, 1, 1, 512, 1, 1, static_cast<unsigned>(ldsBytes), rt.stream, nullptr,
+                               config));
+  if (rt.profile) {
+    rt.profEnd("k_agg_fast");
+  }
+}
+
 const FastEntry* findFastEntry(const FastSignature& sig, int unroll) {
   const FastEntry* any = nullptr;
   for (const auto& e : kFastTable) {
@@ -2345,6 +1965,17 @@ void launchChunk(vx355_agg& h, AggArgs& a) {
             1, std::min<int64_t>(ceilDiv(a.numRows, minRowsPerBlock),
                                  static_cast<int64_t>(rt.numCUs) * blocksPerCu)));
         e->launch(fa, grid, ldsBytes);
+        return;
+      }
+      if (hipFunction_t fn = jitFastKernel(sig, h.fastUnroll, h.logShapes)) {
+        const int blocksPerCu =
+            std::max<int>(1, std::min<int>(4, static_cast<int>((150 * 1024) / ldsBytes)));
+        const int64_t minRowsPerBlock = std::max<int64_t>(512 * h.fastUnroll, 4LL * plan.S * plan.A);
+        int grid = static_cast<int>(std::max<int64_t>(
+            1, std::min<int64_t>(ceilDiv(a.numRows, minRowsPerBlock),
+                                 static_cast<int64_t>(rt.numCUs) * blocksPerCu)));
+        launchJitFast(fn, fa, grid, ldsBytes);
+        ++h.jitLaunches;
         return;
       }
       if (h.logShapes) {
@@ -3019,7 +2650,7 @@ int vx355_agg_get_stats(const vx355_agg* h, vx355_agg_stats* out) {
   out->capacity = static_cast<int64_t>(h->capacity);
   out->num_rehashes = h->numRehashes;
   out->hash_mode = h->mode;
-  out->reserved = 0;
+  out->reserved = static_cast<int32_t>(std::min<int64_t>(h->jitLaunches, INT32_MAX));
   out->input_rows = h->inputRows + h->coalescer.pendingRows();
   out->deferred_rows = h->deferredRows;
   VX_API_END

@@ -1,0 +1,554 @@
+// Device code shared by the ahead-of-time build of agg.hip and the hiprtc
+// instantiation of the shape-specialised aggregation kernel (jit.hip): group-row
+// constants, accumulator arithmetic, the LDS accumulation helpers and the
+// kernel body template. Depends only on device_utils.h / expr_device.h; no
+// host-only headers, so hiprtc can compile it.
+#pragma once
+#include "device_utils.h"
+#include "expr_device.h"
+
+namespace vx {
+
+constexpr int kMaxKeys = 8;
+constexpr int kMaxAccs = 16;      // accumulators a kernel updates per row
+constexpr int kMaxLdsAccs = 28;   // LDS / table words they touch (DOUBLE sums own two)
+constexpr uint64_t kEmpty = ~0ULL;
+constexpr uint64_t kNoRow = ~0ULL;
+
+enum AccKind : int32_t {
+  ACC_SUM_F64 = 0,
+  ACC_SUM_I64 = 1,        // checked: sets the overflow flag
+  ACC_SUM_I64_WRAP = 2,   // partial counts merged in the final step (no check)
+  ACC_COUNT = 3,          // +1 per qualifying row
+  ACC_MIN = 4,            // order-preserving u64 image, atomic umin
+  ACC_MAX = 5,
+};
+
+enum Mode : int32_t { MODE_HASH = 0, MODE_ARRAY = 1, MODE_NORMALIZED = 2 };
+
+// Counters the kernels bump; mirrored into the pinned mailbox by the host.
+struct Counters {
+  uint32_t numDeferred;
+  uint32_t numNewGroups;
+  uint32_t overflow;     // sum(BIGINT) overflowed
+  uint32_t unmappable;   // a string key longer than 7 bytes was seen
+  uint32_t tableFull;
+  uint32_t pad[3];
+  int64_t keyMin[kMaxKeys];
+  int64_t keyMax[kMaxKeys];
+  uint64_t sumMax[kMaxAccs];  // largest |input| seen per DOUBLE sum (bit pattern), k_sum_stats
+};
+
+__device__ inline bool addOverflows(int64_t old, int64_t v) {
+  int64_t r;
+  return __builtin_add_overflow(old, v, &r);
+}
+
+__device__ inline void applyGlobal(uint64_t* word, int32_t kind, uint64_t v, Counters* ctr) {
+  switch (kind) {
+    case ACC_SUM_F64:
+      unsafeAtomicAdd(reinterpret_cast<double*>(word), __longlong_as_double(static_cast<long long>(v)));
+      break;
+    case ACC_SUM_I64: {
+      unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(word),
+                                         static_cast<unsigned long long>(v));
+      if (addOverflows(static_cast<int64_t>(old), static_cast<int64_t>(v))) {
+        ctr->overflow = 1;
+      }
+      break;
+    }
+    case ACC_SUM_I64_WRAP:
+    case ACC_COUNT:
+      atomicAdd(reinterpret_cast<unsigned long long*>(word), static_cast<unsigned long long>(v));
+      break;
+    case ACC_MIN:
+      atomicMin(reinterpret_cast<unsigned long long*>(word), static_cast<unsigned long long>(v));
+      break;
+    default:
+      atomicMax(reinterpret_cast<unsigned long long*>(word), static_cast<unsigned long long>(v));
+      break;
+  }
+}
+
+__host__ __device__ inline uint64_t accIdentity(int32_t kind) {
+  return kind == ACC_MIN ? ~0ULL : 0ULL;
+}
+
+// Error-free split of v against the grid encoded in m = 1.5 * 2^(G+52):
+// hi is v rounded to a multiple of 2^G, lo = v - hi exactly (|v| < 2^(G+51)).
+__device__ inline void splitDouble(double v, double m, double* hi, double* lo) {
+  if (!(fabs(v) < m * 0.25)) {
+    // Too large for the grid (or inf / NaN): plain accumulation for this value.
+    *hi = v;
+    *lo = 0.0;
+    return;
+  }
+  const double t = v + m;
+  *hi = t - m;
+  *lo = v - *hi;
+}
+
+// ---- low-cardinality kernels: LDS-resident, lane-replicated accumulators ----
+// LDS layout: [slotOf int32[capacity] unless direct][slotKey u32[S]][slotFirst u32[S]]
+//             [numSlots u32][pad][acc u64[S][numAccs][REP]]
+constexpr int32_t kSlotEmpty = -1;
+constexpr int32_t kSlotPending = -2;
+constexpr int32_t kSlotOverflow = -3;
+
+// What both LDS kernels need to know about the accumulators and the table.
+struct LdsPlan {
+  int32_t S;
+  int32_t REP;
+  int32_t A;
+  int32_t direct;
+  uint64_t capacity;
+  uint64_t* table;
+  int32_t stride;
+  int32_t pad;
+  uint64_t rowBase;
+  Counters* counters;
+  int32_t kind[kMaxLdsAccs];
+  int32_t off[kMaxLdsAccs];
+};
+
+struct LdsState {
+  int32_t* slotOf;
+  uint32_t* slotKey;
+  uint32_t* slotFirst;
+  uint32_t* numSlots;
+  uint64_t* acc;
+};
+
+__device__ inline LdsState ldsInit(const LdsPlan& p, unsigned char* raw) {
+  LdsState st;
+  const int mapWords = p.direct ? 0 : static_cast<int>(p.capacity);
+  st.slotOf = reinterpret_cast<int32_t*>(raw);
+  st.slotKey = reinterpret_cast<uint32_t*>(raw) + mapWords;
+  st.slotFirst = st.slotKey + p.S;
+  st.numSlots = st.slotFirst + p.S;
+  st.acc = reinterpret_cast<uint64_t*>(
+      raw + ((static_cast<size_t>(mapWords + 2 * p.S + 2) * 4 + 15) & ~static_cast<size_t>(15)));
+  for (int i = threadIdx.x; i < mapWords; i += blockDim.x) {
+    st.slotOf[i] = kSlotEmpty;
+  }
+  for (int i = threadIdx.x; i < p.S; i += blockDim.x) {
+    st.slotFirst[i] = 0xffffffffu;
+    st.slotKey[i] = static_cast<uint32_t>(i);
+  }
+  if (threadIdx.x == 0) {
+    *st.numSlots = p.direct ? static_cast<uint32_t>(p.S) : 0;
+  }
+  for (int i = threadIdx.x; i < p.S * p.A * p.REP; i += blockDim.x) {
+    st.acc[i] = accIdentity(p.kind[(i / p.REP) % p.A]);
+  }
+  __syncthreads();
+  return st;
+}
+
+// LDS slot of a key (>= 0) or kSlotOverflow when the workgroup's slots are used up.
+__device__ inline int32_t ldsSlot(const LdsPlan& p, const LdsState& st, uint64_t key) {
+  if (p.direct) {
+    return static_cast<int32_t>(key);
+  }
+  // Claim protocol without waiting on an exit edge: the winner of the CAS
+  // allocates and publishes the slot INSIDE the loop body, every lane
+  // re-evaluates at the latch. (A `break` after the publish would let the
+  // compiler sink the publish behind the loop and spin the other lanes of the
+  // same wave forever.)
+  int32_t* entry = st.slotOf + key;
+  int32_t slot = kSlotPending;
+  while (slot == kSlotPending) {
+    int32_t s = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (s == kSlotEmpty) {
+      if (atomicCAS(entry, kSlotEmpty, kSlotPending) == kSlotEmpty) {
+        uint32_t t = atomicAdd(st.numSlots, 1u);
+        if (t < static_cast<uint32_t>(p.S)) {
+          st.slotKey[t] = static_cast<uint32_t>(key);
+          s = static_cast<int32_t>(t);
+        } else {
+          s = kSlotOverflow;
+        }
+        __hip_atomic_store(entry, s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+        s = kSlotPending;
+      }
+    }
+    slot = s;
+  }
+  return slot;
+}
+
+__device__ inline void ldsTouchFirst(const LdsState& st, int32_t slot, uint32_t row) {
+  if (st.slotFirst[slot] > row) {
+    atomicMin(&st.slotFirst[slot], row);
+  }
+}
+
+// Flush: one (slot, accumulator) pair per thread; replicas reduced in LDS.
+__device__ inline void ldsFlush(const LdsPlan& p, const LdsState& st) {
+  __syncthreads();
+  const int S = p.S, A = p.A, REP = p.REP;
+  uint32_t live = *st.numSlots;
+  if (live > static_cast<uint32_t>(S)) {
+    live = S;
+  }
+  for (int t = threadIdx.x; t < static_cast<int>(live) * (A + 1); t += blockDim.x) {
+    const int slot = t / (A + 1);
+    const int j = t % (A + 1);
+    const uint32_t first = st.slotFirst[slot];
+    if (first == 0xffffffffu) {
+      continue;  // direct layout: key never seen by this workgroup
+    }
+    uint64_t* g = p.table + static_cast<uint64_t>(st.slotKey[slot]) * p.stride;
+    if (j == A) {
+      // 'first' is the smallest ORIGINAL row of the chunk seen for this key
+      // (replays go through the row list), so it decides the group order.
+      uint64_t firstRow = p.rowBase + static_cast<uint64_t>(first);
+      unsigned long long old = atomicMin(reinterpret_cast<unsigned long long*>(g + 1), firstRow);
+      if (old == kNoRow) {
+        atomicAdd(&p.counters->numNewGroups, 1u);
+      }
+      continue;
+    }
+    const int32_t kind = p.kind[j];
+    const uint64_t* q = st.acc + (static_cast<size_t>(slot) * A + j) * REP;
+    uint64_t v = q[0];
+    if (kind == ACC_SUM_F64) {
+      double s = __longlong_as_double(static_cast<long long>(v));
+      for (int r = 1; r < REP; ++r) {
+        s += __longlong_as_double(static_cast<long long>(q[r]));
+      }
+      applyGlobal(g + p.off[j], ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(s)), p.counters);
+    } else if (kind == ACC_MIN) {
+      for (int r = 1; r < REP; ++r) {
+        v = q[r] < v ? q[r] : v;
+      }
+      applyGlobal(g + p.off[j], ACC_MIN, v, p.counters);
+    } else if (kind == ACC_MAX) {
+      for (int r = 1; r < REP; ++r) {
+        v = q[r] > v ? q[r] : v;
+      }
+      applyGlobal(g + p.off[j], ACC_MAX, v, p.counters);
+    } else {
+      int64_t s = static_cast<int64_t>(v);
+      for (int r = 1; r < REP; ++r) {
+        int64_t x = static_cast<int64_t>(q[r]);
+        if (kind == ACC_SUM_I64 && addOverflows(s, x)) {
+          p.counters->overflow = 1;
+        }
+        s = static_cast<int64_t>(static_cast<uint64_t>(s) + static_cast<uint64_t>(x));
+      }
+      applyGlobal(g + p.off[j], kind == ACC_COUNT ? ACC_SUM_I64_WRAP : kind, static_cast<uint64_t>(s),
+                  p.counters);
+    }
+  }
+}
+
+// ---- shape-specialised LDS kernel ------------------------------------------------
+// The generic LDS kernel interprets the plan per row (column encodings, types,
+// masks, expression tables): ~500 VALU instructions per 64 rows, which caps it
+// near 2 TB/s. For flat, null-free inputs the plan SHAPE is lifted into template
+// parameters instead, so every register index and every branch on the plan is
+// resolved at compile time and what is left per row is the arithmetic itself:
+//   keys   K0,K1  : FK_VIEW (short string, first 8 bytes of the StringView),
+//                   FK_I32, FK_I64, or -1 (absent)
+//   terms  T0,T1  : filter column kinds FK_I32 / FK_I64 / FK_F64 or -1
+//   NL            : distinct DOUBLE columns loaded per row (each loaded once)
+//   NA, ACC_LO/HI : per accumulator 16 bits {numFactors, load index of factor
+//                   0..2 (15 = constant factor)}; numFactors 0 = count(*)
+// Comparison operators, constants, scales, offsets, ranges stay runtime values.
+// Shapes are instantiated ahead of time below (VX_FAST_SHAPES); a plan whose
+// shape is not in the table runs on the generic kernel.
+constexpr int kFastKeys = 2;
+constexpr int kFastTerms = 2;
+constexpr int kFastAccs = 8;
+constexpr int kFastFactors = 3;
+constexpr int kFastLoads = 8;
+
+enum FastKind : int32_t { FK_NONE = -1, FK_VIEW = 0, FK_I32 = 1, FK_I64 = 2, FK_F64 = 3 };
+
+struct FastTerm {
+  const void* ptr;
+  int32_t cmp;
+  int32_t pad;
+  int64_t i64;
+  double f64;
+};
+struct FastArgs {
+  const void* keyPtr[kFastKeys];
+  KeyRange range[kFastKeys];
+  const double* loadPtr[kFastLoads];
+  FastTerm term[kFastTerms];
+  double scale[kFastAccs][kFastFactors];
+  double offset[kFastAccs][kFastFactors];
+  double splitM[kFastAccs];  // grid of the hi/lo split of sum j (0 = accumulate into hi only)
+  int64_t numRows;
+  int32_t* deferred;
+  uint32_t deferCap;
+  uint32_t pad;
+  LdsPlan plan;
+};
+
+constexpr uint64_t accDesc(int numFactors, int l0 = 15, int l1 = 15, int l2 = 15) {
+  return static_cast<uint64_t>(numFactors) | (static_cast<uint64_t>(l0) << 4) |
+      (static_cast<uint64_t>(l1) << 8) | (static_cast<uint64_t>(l2) << 12);
+}
+constexpr uint64_t packAccs(uint64_t a0 = 0, uint64_t a1 = 0, uint64_t a2 = 0, uint64_t a3 = 0) {
+  return a0 | (a1 << 16) | (a2 << 32) | (a3 << 48);
+}
+
+template <int UNROLL, int K0, int K1, int T0, int T1, int NL, int NA, uint64_t ACC_LO, uint64_t ACC_HI>
+struct FastShape {
+  static constexpr int unroll = UNROLL;
+  static constexpr int keyKind(int k) { return k == 0 ? K0 : K1; }
+  static constexpr int termKind(int t) { return t == 0 ? T0 : T1; }
+  static constexpr int numLoads = NL;
+  static constexpr int numAccs = NA;
+  static constexpr uint64_t desc(int j) {
+    return ((j < 4 ? ACC_LO >> (16 * j) : ACC_HI >> (16 * (j - 4)))) & 0xffff;
+  }
+  static constexpr int numFactors(int j) { return static_cast<int>(desc(j) & 15); }
+  // LDS / table word of accumulator j: every DOUBLE sum before it owns two words (hi, lo).
+  static constexpr int ldsIndex(int j) {
+    int idx = 0;
+    for (int q = 0; q < j; ++q) {
+      idx += numFactors(q) == 0 ? 1 : 2;
+    }
+    return idx;
+  }
+  static constexpr int numLdsAccs = ldsIndex(NA);
+  static constexpr int load(int j, int f) { return static_cast<int>((desc(j) >> (4 + 4 * f)) & 15); }
+};
+
+// Compile-time loop: f(std::integral_constant<int, 0>{}) ... f(<N-1>).
+template <int V>
+struct IntC {
+  static constexpr int value = V;
+};
+template <int... Is>
+struct IntSeq {};
+template <int N, int... Is>
+struct MakeIntSeq : MakeIntSeq<N - 1, N - 1, Is...> {};
+template <int... Is>
+struct MakeIntSeq<0, Is...> {
+  using type = IntSeq<Is...>;
+};
+template <int... Is, typename F>
+__device__ inline void staticForImpl(IntSeq<Is...>, F&& f) {
+  (f(IntC<Is>{}), ...);
+}
+template <int N, typename F>
+__device__ inline void staticFor(F&& f) {
+  staticForImpl(typename MakeIntSeq<N>::type{}, f);
+}
+
+template <int KIND>
+__device__ inline uint64_t fastLoadRaw(const void* ptr, int64_t row) {
+  if constexpr (KIND == FK_VIEW) {
+    return static_cast<const uint64_t*>(ptr)[row * 2];
+  } else if constexpr (KIND == FK_I32) {
+    return static_cast<const uint32_t*>(ptr)[row];  // sign-extended at use
+  } else {
+    return static_cast<const uint64_t*>(ptr)[row];
+  }
+}
+
+// int64 image of a key (VectorHasher::toInt64 / stringAsNumber); INT64_MIN for
+// strings the fast path does not decode (> 3 bytes: the replay reads the view).
+template <int KIND>
+__device__ inline int64_t fastKeyValue(uint64_t raw) {
+  if constexpr (KIND == FK_VIEW) {
+    const uint32_t size = static_cast<uint32_t>(raw);
+    const uint32_t bytes = static_cast<uint32_t>(raw >> 32);
+    const uint32_t shift = (size & 3u) * 8;
+    const int64_t v = static_cast<int64_t>((bytes & ((1u << shift) - 1)) + (size ? (1u << shift) : 0u));
+    return size > 3 ? INT64_MIN : v;
+  } else if constexpr (KIND == FK_I32) {
+    return static_cast<int64_t>(static_cast<int32_t>(static_cast<uint32_t>(raw)));
+  } else {
+    return static_cast<int64_t>(raw);
+  }
+}
+
+template <typename S>
+__device__ inline void aggFastBody(const FastArgs& a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+  constexpr int UNROLL = S::unroll;
+  constexpr int NA = S::numAccs;     // accumulators of the plan
+  constexpr int A = S::numLdsAccs;   // words they own (DOUBLE sums: hi + lo)
+  const LdsPlan& p = a.plan;
+  const LdsState st = ldsInit(p, ldsRaw);
+  const int REP = p.REP;
+  const int rep = lane() & (REP - 1);
+  const int64_t tile = static_cast<int64_t>(blockDim.x) * UNROLL;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * tile;
+  const int64_t rounds = (a.numRows + stride - 1) / stride;
+  int64_t base = static_cast<int64_t>(blockIdx.x) * tile + threadIdx.x;
+  for (int64_t r = 0; r < rounds; ++r, base += stride) {
+    uint64_t kraw[UNROLL][kFastKeys];
+    uint64_t traw[UNROLL][kFastTerms];
+    double x[UNROLL][S::numLoads > 0 ? S::numLoads : 1];
+    // Phase 1: every load of this iteration, column by column, UNROLL rows
+    // back to back. Rows past the end are clamped (and ignored in phase 2) so
+    // that no load sits under a per-lane predicate.
+    int64_t rowc[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t row = base + static_cast<int64_t>(u) * blockDim.x;
+      rowc[u] = row < a.numRows ? row : a.numRows - 1;
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      if constexpr (S::keyKind(0) != FK_NONE) {
+        kraw[u][0] = fastLoadRaw<S::keyKind(0)>(a.keyPtr[0], rowc[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      if constexpr (S::keyKind(1) != FK_NONE) {
+        kraw[u][1] = fastLoadRaw<S::keyKind(1)>(a.keyPtr[1], rowc[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      if constexpr (S::termKind(0) != FK_NONE) {
+        traw[u][0] = fastLoadRaw<S::termKind(0)>(a.term[0].ptr, rowc[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      if constexpr (S::termKind(1) != FK_NONE) {
+        traw[u][1] = fastLoadRaw<S::termKind(1)>(a.term[1].ptr, rowc[u]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < S::numLoads; ++j) {
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        x[u][j] = a.loadPtr[j][rowc[u]];
+      }
+    }
+    // Phase 2: filter, key, LDS updates.
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t row = base + static_cast<int64_t>(u) * blockDim.x;
+      bool live = row < a.numRows;
+      staticFor<kFastTerms>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        if constexpr (S::termKind(t) == FK_F64) {
+          live = live && compareValues<double>(a.term[t].cmp,
+                                               __longlong_as_double(static_cast<long long>(traw[u][t])),
+                                               a.term[t].f64);
+        } else if constexpr (S::termKind(t) == FK_I32) {
+          // the host only picks this shape when the constant fits int32
+          live = live && compareValues<int32_t>(a.term[t].cmp,
+                                                static_cast<int32_t>(static_cast<uint32_t>(traw[u][t])),
+                                                static_cast<int32_t>(a.term[t].i64));
+        } else if constexpr (S::termKind(t) == FK_I64) {
+          live = live && compareValues<int64_t>(a.term[t].cmp, static_cast<int64_t>(traw[u][t]),
+                                                a.term[t].i64);
+        }
+      });
+      uint64_t key = 0;
+      bool defer = false;
+      staticFor<kFastKeys>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (S::keyKind(k) != FK_NONE) {
+          const int64_t v = fastKeyValue<S::keyKind(k)>(kraw[u][k]);
+          if (v < a.range[k].min || v > a.range[k].max) {
+            if (live) {
+              defer = true;
+              if (v != INT64_MIN) {
+                atomicMin(reinterpret_cast<long long*>(&p.counters->keyMin[k]), static_cast<long long>(v));
+                atomicMax(reinterpret_cast<long long*>(&p.counters->keyMax[k]), static_cast<long long>(v));
+              }
+            }
+          } else {
+            key += a.range[k].multiplier *
+                (static_cast<uint64_t>(v) - static_cast<uint64_t>(a.range[k].min) + 1);
+          }
+        }
+      });
+      if (live && !defer) {
+        const int32_t slot = ldsSlot(p, st, key);
+        double vals[NA > 0 ? NA : 1];
+        staticFor<NA>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          double acc = 0;
+          staticFor<S::numFactors(j)>([&](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            double v = a.offset[j][f];
+            if constexpr (S::load(j, f) != 15) {
+              v = a.scale[j][f] * x[u][S::load(j, f)] + a.offset[j][f];
+            }
+            acc = f == 0 ? v : acc * v;
+          });
+          vals[j] = acc;
+        });
+        if (slot >= 0) {
+          ldsTouchFirst(st, slot, static_cast<uint32_t>(row));
+          uint64_t* dst = st.acc + (static_cast<size_t>(slot) * A) * REP + rep;
+          staticFor<NA>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int w = S::ldsIndex(j);
+            if constexpr (S::numFactors(j) == 0) {
+              atomicAdd(reinterpret_cast<unsigned long long*>(dst + w * REP), 1ULL);
+            } else {
+              if (a.splitM[j] != 0.0) {
+                double hi, lo;
+                splitDouble(vals[j], a.splitM[j], &hi, &lo);
+                unsafeAtomicAdd(reinterpret_cast<double*>(dst + w * REP), hi);
+                unsafeAtomicAdd(reinterpret_cast<double*>(dst + (w + 1) * REP), lo);
+              } else {
+                unsafeAtomicAdd(reinterpret_cast<double*>(dst + w * REP), vals[j]);
+              }
+            }
+          });
+        } else {
+          // Workgroup out of LDS slots: straight to the group row in HBM.
+          uint64_t* g = p.table + key * p.stride;
+          const uint64_t myRow = p.rowBase + static_cast<uint64_t>(row);
+          unsigned long long old = atomicMin(reinterpret_cast<unsigned long long*>(g + 1), myRow);
+          if (old == kNoRow) {
+            atomicAdd(&p.counters->numNewGroups, 1u);
+          }
+          staticFor<NA>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int w = S::ldsIndex(j);
+            if constexpr (S::numFactors(j) == 0) {
+              applyGlobal(g + p.off[w], ACC_SUM_I64_WRAP, 1, p.counters);
+            } else {
+              double hi = vals[j], lo = 0;
+              if (a.splitM[j] != 0.0) {
+                splitDouble(vals[j], a.splitM[j], &hi, &lo);
+              }
+              applyGlobal(g + p.off[w], ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(hi)),
+                          p.counters);
+              if (a.splitM[j] != 0.0) {
+                applyGlobal(g + p.off[w + 1], ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(lo)),
+                            p.counters);
+              }
+            }
+          });
+        }
+      }
+      // Rows the fast path cannot place go to the deferred list (one atomic per wave).
+      const uint64_t m = ballot(defer);
+      if (m != 0) {
+        const int leader = __ffsll(static_cast<long long>(m)) - 1;
+        uint32_t at = 0;
+        if (lane() == leader) {
+          at = atomicAdd(&p.counters->numDeferred, static_cast<uint32_t>(popc64(m)));
+        }
+        at = __shfl(at, leader, kWave);
+        if (defer && at + lanePrefix(m) < a.deferCap) {
+          a.deferred[at + lanePrefix(m)] = static_cast<int32_t>(row);
+        }
+      }
+    }
+  }
+  ldsFlush(p, st);
+}
+
+
+}  // namespace vx
