@@ -1185,6 +1185,7 @@ struct vx355_agg {
   int64_t chunkRows = 1LL << 31;
   bool disableFast = false;
   int64_t jitLaunches = 0;
+  bool jitEnabled = true;
   bool exactSums = true;
   bool logShapes = false;
   int64_t deferCap = 1 << 20;
@@ -1717,12 +1718,6 @@ bool jitPrepare(JitState& st) {
   if (!st.csrcDir.empty()) {
     return true;
   }
-  if (const char* e = std::getenv("VX355_JIT")) {
-    if (e[0] == '0') {
-      st.disabled = true;
-      return false;
-    }
-  }
   Dl_info info;
   if (!dladdr(reinterpret_cast<const void*>(&vx355_agg_create), &info) || !info.dli_fname) {
     st.disabled = true;
@@ -1967,7 +1962,7 @@ void launchChunk(vx355_agg& h, AggArgs& a) {
         e->launch(fa, grid, ldsBytes);
         return;
       }
-      if (hipFunction_t fn = jitFastKernel(sig, h.fastUnroll, h.logShapes)) {
+      if (hipFunction_t fn = h.jitEnabled ? jitFastKernel(sig, h.fastUnroll, h.logShapes) : nullptr) {
         const int blocksPerCu =
             std::max<int>(1, std::min<int>(4, static_cast<int>((150 * 1024) / ldsBytes)));
         const int64_t minRowsPerBlock = std::max<int64_t>(512 * h.fastUnroll, 4LL * plan.S * plan.A);
@@ -2547,6 +2542,9 @@ int vx355_agg_create(const vx355_agg_spec* spec, vx355_agg** out) {
   h->ignoreNullKeys = spec->ignore_null_keys != 0;
   if (const char* e = std::getenv("VX355_ARRAY_MAX")) {
     h->arrayMax = std::strtoull(e, nullptr, 10);
+  }
+  if (const char* e = std::getenv("VX355_JIT")) {
+    h->jitEnabled = e[0] != '0';
   }
   if (const char* e = std::getenv("VX355_AGG_COALESCE_ROWS")) {
     h->coalescer.thresholdRows = std::strtoll(e, nullptr, 10);
