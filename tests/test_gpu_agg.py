@@ -529,3 +529,40 @@ def test_plan_shape_outside_the_table_is_instantiated_with_hiprtc(oracle, vx, ji
         assert op.stats().reserved > 0 and "k_agg_fast" in names
     else:
         assert op.stats().reserved == 0 and "k_agg_lds" in names
+
+
+def test_dictionary_wrapped_device_inputs_take_the_specialised_kernel(oracle, vx):
+    """The unfused Velox pipeline: FilterProject hands HashAggregation columns
+    wrapped in ONE shared index vector plus flat computed columns, all in HBM.
+    That shape is instantiated through hiprtc (IND mask) instead of falling back
+    to the interpreting kernel."""
+    rng = np.random.default_rng(303)
+    n = 400000
+    scan, cols = _q1_scan_batch(rng, n)
+    rf, ls, qty, ep, disc, tax, ship = cols
+    idx, proj, _ = oracle.filter_project(scan, Q1_TERMS, Q1_PROJ)
+    m = len(idx)
+
+    def wrap(kind, base):
+        return abi.HostColumn(kind, base, encoding=abi.DICTIONARY, indices=idx)
+    host = abi.HostBatch([wrap(abi.VARCHAR, rf), wrap(abi.VARCHAR, ls), wrap(abi.DOUBLE, qty),
+                          wrap(abi.DOUBLE, ep), wrap(abi.DOUBLE, disc), abi.HostColumn(abi.DOUBLE, proj[0]),
+                          abi.HostColumn(abi.DOUBLE, proj[1])], m)
+    aggs = [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_SUM, 3, abi.DOUBLE), (abi.AGG_SUM, 5, abi.DOUBLE),
+            (abi.AGG_SUM, 6, abi.DOUBLE), (abi.AGG_AVG, 2, abi.DOUBLE), (abi.AGG_AVG, 3, abi.DOUBLE),
+            (abi.AGG_AVG, 4, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    exp, _ = run_agg(oracle, [host], [0, 1], [abi.VARCHAR, abi.VARCHAR], aggs)
+    # device side: base columns + ONE index vector shared by the five wrapped columns
+    d_idx = vx.DeviceArray(idx)
+    bases = [vx.DeviceArray(c.values) for c in host.columns[:5]]
+    flats = [vx.DeviceArray(proj[0]), vx.DeviceArray(proj[1])]
+    kinds = [abi.VARCHAR, abi.VARCHAR, abi.DOUBLE, abi.DOUBLE, abi.DOUBLE]
+    dcols = [vx.DeviceColumn.from_ptr(k, b.ptr, m, None, abi.DICTIONARY, d_idx.ptr, n) for k, b in zip(kinds, bases)]
+    dcols += [vx.DeviceColumn.from_ptr(abi.DOUBLE, f.ptr, m) for f in flats]
+    dev = abi.HostBatch(dcols, m)
+    vx.profile_reset()
+    vx.profile_enable(True)
+    got, gop = run_agg(vx, [dev], [0, 1], [abi.VARCHAR, abi.VARCHAR], aggs)
+    vx.profile_enable(False)
+    assert_columns_equal(got, exp, gop.kinds, what="dictionary wrapped")
+    assert "k_agg_fast" in vx.profile() and gop.stats().reserved > 0

@@ -432,9 +432,10 @@ __global__ __launch_bounds__(512, 4) void k_agg_fast(FastArgs a) {
 struct FastSignature {
   int k0 = FK_NONE, k1 = FK_NONE, t0 = FK_NONE, t1 = FK_NONE, numLoads = 0, numAccs = 0;
   uint64_t accLo = 0, accHi = 0;
+  uint32_t ind = 0;  // dictionary-wrapped columns (FastShape::IND)
   bool operator==(const FastSignature& o) const {
     return k0 == o.k0 && k1 == o.k1 && t0 == o.t0 && t1 == o.t1 && numLoads == o.numLoads &&
-        numAccs == o.numAccs && accLo == o.accLo && accHi == o.accHi;
+        numAccs == o.numAccs && accLo == o.accLo && accHi == o.accHi && ind == o.ind;
   }
 };
 
@@ -453,7 +454,7 @@ struct FastEntry {
 
 #define VX_FAST_ENTRY(U, K0, K1, T0, T1, NL, NA, LO, HI)                                      \
   FastEntry {                                                                                 \
-    FastSignature{K0, K1, T0, T1, NL, NA, LO, HI}, U,                                         \
+    FastSignature{K0, K1, T0, T1, NL, NA, LO, HI, 0}, U,                                      \
         &launchFast<FastShape<U, K0, K1, T0, T1, NL, NA, LO, HI>>                             \
   }
 
@@ -1575,14 +1576,30 @@ bool buildFastArgs(const AggArgs& c, const LdsPlan& plan, FastArgs* f, FastSigna
       c.numTerms > kFastTerms || c.numAccs > kFastAccs) {
     return false;
   }
-  auto flatNoNulls = [](const ColView& v) { return v.enc == VX355_FLAT && v.nulls == nullptr; };
   *f = FastArgs{};
   *sig = FastSignature{};
+  // Null-free columns that are flat, or dictionary wrapped by ONE shared index
+  // vector (FilterProject's output); returns -1 = not eligible, 1 = wrapped.
+  auto usable = [&](const ColView& v) -> int {
+    if (v.nulls != nullptr) {
+      return -1;
+    }
+    if (v.enc == VX355_FLAT) {
+      return 0;
+    }
+    if (v.enc == VX355_DICTIONARY && (f->indices == nullptr || f->indices == v.indices)) {
+      f->indices = v.indices;
+      return 1;
+    }
+    return -1;
+  };
   for (int k = 0; k < c.numKeys; ++k) {
     const ColView& v = c.keys[k].col;
-    if (!flatNoNulls(v)) {
+    const int wrapped = usable(v);
+    if (wrapped < 0) {
       return false;
     }
+    sig->ind |= static_cast<uint32_t>(wrapped) << k;
     int kind;
     if (isString(v.kind)) {
       kind = FK_VIEW;
@@ -1599,9 +1616,11 @@ bool buildFastArgs(const AggArgs& c, const LdsPlan& plan, FastArgs* f, FastSigna
   }
   for (int t = 0; t < c.numTerms; ++t) {
     const TermArg& ta = c.terms[t];
-    if (!flatNoNulls(ta.col)) {
+    const int wrapped = usable(ta.col);
+    if (wrapped < 0) {
       return false;
     }
+    sig->ind |= static_cast<uint32_t>(wrapped) << (2 + t);
     int kind;
     if (ta.constKind == VX355_BIGINT && ta.col.kind == VX355_INTEGER) {
       // The kernel compares in 32 bits: a constant outside int32 would wrap.
@@ -1623,11 +1642,15 @@ bool buildFastArgs(const AggArgs& c, const LdsPlan& plan, FastArgs* f, FastSigna
     f->term[t].f64 = ta.f64;
   }
   auto loadSlot = [&](const ColView& v) -> int {
-    if (!flatNoNulls(v) || v.kind != VX355_DOUBLE) {
+    if (v.kind != VX355_DOUBLE) {
+      return -1;
+    }
+    const int wrapped = usable(v);
+    if (wrapped < 0) {
       return -1;
     }
     for (int j = 0; j < sig->numLoads; ++j) {
-      if (f->loadPtr[j] == v.values) {
+      if (f->loadPtr[j] == v.values && ((sig->ind >> (4 + j)) & 1) == static_cast<uint32_t>(wrapped)) {
         return j;
       }
     }
@@ -1635,6 +1658,7 @@ bool buildFastArgs(const AggArgs& c, const LdsPlan& plan, FastArgs* f, FastSigna
       return -1;
     }
     f->loadPtr[sig->numLoads] = static_cast<const double*>(v.values);
+    sig->ind |= static_cast<uint32_t>(wrapped) << (4 + sig->numLoads);
     return sig->numLoads++;
   };
   for (int j = 0; j < c.numAccs; ++j) {
@@ -1746,9 +1770,9 @@ hipFunction_t jitFastKernel(const FastSignature& sig, int unroll, bool log) {
     return nullptr;
   }
   char key[256];
-  snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d,%lluull,%lluull", unroll, sig.k0, sig.k1, sig.t0, sig.t1,
+  snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d,%lluull,%lluull,%uu", unroll, sig.k0, sig.k1, sig.t0, sig.t1,
            sig.numLoads, sig.numAccs, static_cast<unsigned long long>(sig.accLo),
-           static_cast<unsigned long long>(sig.accHi));
+           static_cast<unsigned long long>(sig.accHi), sig.ind);
   auto it = st.kernels.find(key);
   if (it != st.kernels.end()) {
     return it->second.fn;

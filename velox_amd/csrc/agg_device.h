@@ -286,6 +286,10 @@ struct FastArgs {
   int32_t* deferred;
   uint32_t deferCap;
   uint32_t pad;
+  // Dictionary-wrapped inputs (what FilterProject hands downstream,
+  // exec/OperatorUtils.cpp:393-422): the columns flagged in the shape's IND mask
+  // are read at indices[row] instead of row; one shared index vector.
+  const int32_t* indices;
   LdsPlan plan;
 };
 
@@ -297,8 +301,12 @@ constexpr uint64_t packAccs(uint64_t a0 = 0, uint64_t a1 = 0, uint64_t a2 = 0, u
   return a0 | (a1 << 16) | (a2 << 32) | (a3 << 48);
 }
 
-template <int UNROLL, int K0, int K1, int T0, int T1, int NL, int NA, uint64_t ACC_LO, uint64_t ACC_HI>
+template <int UNROLL, int K0, int K1, int T0, int T1, int NL, int NA, uint64_t ACC_LO, uint64_t ACC_HI,
+          uint32_t IND = 0>
 struct FastShape {
+  // IND bit k: key k, bit 2 + t: filter term t, bit 4 + j: loaded column j is dictionary wrapped.
+  static constexpr bool indirect(int bit) { return (IND >> bit) & 1; }
+  static constexpr bool anyIndirect = IND != 0;
   static constexpr int unroll = UNROLL;
   static constexpr int keyKind(int k) { return k == 0 ? K0 : K1; }
   static constexpr int termKind(int t) { return t == 0 ? T0 : T1; }
@@ -392,6 +400,7 @@ __device__ inline void aggFastBody(const FastArgs& a) {
     // back to back. Rows past the end are clamped (and ignored in phase 2) so
     // that no load sits under a per-lane predicate.
     int64_t rowc[UNROLL];
+    int64_t rowi[UNROLL];  // base-vector row of the dictionary-wrapped columns
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const int64_t row = base + static_cast<int64_t>(u) * blockDim.x;
@@ -399,35 +408,42 @@ __device__ inline void aggFastBody(const FastArgs& a) {
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
+      rowi[u] = rowc[u];
+      if constexpr (S::anyIndirect) {
+        rowi[u] = a.indices[rowc[u]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
       if constexpr (S::keyKind(0) != FK_NONE) {
-        kraw[u][0] = fastLoadRaw<S::keyKind(0)>(a.keyPtr[0], rowc[u]);
+        kraw[u][0] = fastLoadRaw<S::keyKind(0)>(a.keyPtr[0], S::indirect(0) ? rowi[u] : rowc[u]);
       }
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       if constexpr (S::keyKind(1) != FK_NONE) {
-        kraw[u][1] = fastLoadRaw<S::keyKind(1)>(a.keyPtr[1], rowc[u]);
+        kraw[u][1] = fastLoadRaw<S::keyKind(1)>(a.keyPtr[1], S::indirect(1) ? rowi[u] : rowc[u]);
       }
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       if constexpr (S::termKind(0) != FK_NONE) {
-        traw[u][0] = fastLoadRaw<S::termKind(0)>(a.term[0].ptr, rowc[u]);
+        traw[u][0] = fastLoadRaw<S::termKind(0)>(a.term[0].ptr, S::indirect(2) ? rowi[u] : rowc[u]);
       }
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       if constexpr (S::termKind(1) != FK_NONE) {
-        traw[u][1] = fastLoadRaw<S::termKind(1)>(a.term[1].ptr, rowc[u]);
+        traw[u][1] = fastLoadRaw<S::termKind(1)>(a.term[1].ptr, S::indirect(3) ? rowi[u] : rowc[u]);
       }
     }
-#pragma unroll
-    for (int j = 0; j < S::numLoads; ++j) {
+    staticFor<S::numLoads>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {
-        x[u][j] = a.loadPtr[j][rowc[u]];
+        x[u][j] = a.loadPtr[j][S::indirect(4 + j) ? rowi[u] : rowc[u]];
       }
-    }
+    });
     // Phase 2: filter, key, LDS updates.
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
