@@ -132,7 +132,7 @@ class Q1:
 
     @property
     def dominant(self):
-        return "k_agg_fast" if self.fused else "k_agg_lds"
+        return "k_agg_fast"
 
     def __init__(self, torch, n, device, seed):
         self.torch, self.n = torch, n
