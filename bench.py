@@ -499,6 +499,23 @@ WORKLOADS = {"c5": (C5, 1_000_000_000), "q1": (Q1, 600_037_902), "c1": (C1, 10_0
              "q3": (Q3, 600_037_902)}
 
 
+def measured_copy_ceiling(torch, device):
+    """Device-to-device copy rate on this box (read + write bytes / time): the
+    practical HBM ceiling next to the 8 TB/s datasheet figure."""
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float64, device=device).fill_(1.0)
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(5):
+        b.copy_(a)
+    stop.record()
+    torch.cuda.synchronize()
+    return 5 * 2 * n * 8 / (start.elapsed_time(stop) * 1e-3) / 1e9
+
+
 def main():
     args = parse()
     import torch
@@ -581,6 +598,7 @@ def main():
             dist.destroy_process_group()
         return
 
+    copy_ceiling = measured_copy_ceiling(torch, device)
     dom_ms, dom_launches = prof.get(wl.dominant, (0.0, 0))
     dom_rows = getattr(wl, "selected", wl.rows_per_step()) * args.steps
     achieved = (wl.agg_bytes_per_row * dom_rows / (dom_ms * 1e-3) / 1e9) if dom_ms > 0 else None
@@ -612,6 +630,8 @@ def main():
             "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
             "traffic": None,
             "algorithmic_bytes_per_row": wl.agg_bytes_per_row,
+            "measured_copy_GBps": copy_ceiling,
+            "frac_of_measured_copy": (achieved / copy_ceiling) if (achieved and copy_ceiling) else None,
             "avg_launch_ms": (dom_ms / dom_launches) if dom_launches else None,
             "launches": dom_launches,
         },

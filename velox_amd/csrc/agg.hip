@@ -492,6 +492,7 @@ const FastEntry kFastTable[] = {
 // accumulators) are indexed by the dense id, so everything downstream of
 // "which group row" is shared with array mode.
 constexpr uint32_t kPendingGid = 0xffffffffu;
+constexpr uint32_t kDeadGid = 0xfffffffeu;  // a claim that could not get a group id (table full)
 
 struct GenericPart {
   uint64_t* slots;
@@ -554,7 +555,8 @@ __global__ __launch_bounds__(256) void k_agg_generic(GenericArgs args) {
     uint64_t pos = hash & g.slotMask;
     uint32_t gid = kPendingGid;
     uint64_t probes = 0;
-    while (gid == kPendingGid && probes <= g.slotMask) {
+    uint32_t spins = 0;  // every wait on another lane's publish is bounded
+    while (gid == kPendingGid && probes <= g.slotMask && spins < (1u << 22)) {
       uint64_t w = loadAgent(g.slots + pos);
       bool advance = false;
       if (w == 0) {
@@ -579,8 +581,10 @@ __global__ __launch_bounds__(256) void k_agg_generic(GenericArgs args) {
             storeAgent(g.slots + pos, (tag << 32) | (static_cast<uint64_t>(id) + 1));
             gid = id;
           } else {
+            // Never leave a PENDING slot behind: waiters would spin on it.
+            storeAgent(g.slots + pos, (tag << 32) | kDeadGid);
             a.counters->tableFull = 1;
-            gid = 0;  // leave the loop; the host raises the error
+            gid = kDeadGid;  // leave the loop; the host raises the error
           }
           w = 0;
         } else {
@@ -590,7 +594,11 @@ __global__ __launch_bounds__(256) void k_agg_generic(GenericArgs args) {
       if (gid == kPendingGid && w != 0) {
         if ((w >> 32) == tag) {
           const uint32_t lo = static_cast<uint32_t>(w);
-          if (lo != kPendingGid) {
+          if (lo == kDeadGid) {
+            advance = true;
+          } else if (lo == kPendingGid) {
+            ++spins;  // the claimer has not published yet; look at this slot again
+          } else {
             const uint32_t cand = lo - 1;
             bool equal = loadAgent(g.nullStore + cand) == nullMask;
 #pragma unroll
@@ -608,7 +616,6 @@ __global__ __launch_bounds__(256) void k_agg_generic(GenericArgs args) {
               advance = true;
             }
           }
-          // else: the claimer has not published yet; look at this slot again
         } else {
           advance = true;
         }
@@ -618,7 +625,7 @@ __global__ __launch_bounds__(256) void k_agg_generic(GenericArgs args) {
         ++probes;
       }
     }
-    if (gid == kPendingGid) {
+    if (gid == kPendingGid || gid == kDeadGid) {
       a.counters->tableFull = 1;
       continue;
     }
