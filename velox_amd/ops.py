@@ -15,7 +15,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvx355.so")
+LIB_PATH = os.environ.get("VX355_LIB_PATH") or os.path.join(_HERE, "libvx355.so")
 _LIB = None
 
 # Every symbol include/vx355.h declares.
