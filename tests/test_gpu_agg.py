@@ -566,3 +566,17 @@ def test_dictionary_wrapped_device_inputs_take_the_specialised_kernel(oracle, vx
     vx.profile_enable(False)
     assert_columns_equal(got, exp, gop.kinds, what="dictionary wrapped")
     assert "k_agg_fast" in vx.profile() and gop.stats().reserved > 0
+
+
+def test_distinct_without_aggregates_and_drain_in_small_pages(oracle, vx):
+    """SELECT DISTINCT k1, k2 (HashAggregation.cpp:426-488 semantics at the end
+    of input): no aggregates at all; output drained 7 rows at a time."""
+    rng = np.random.default_rng(404)
+    n = 30000
+    k1 = rng.integers(0, 40, n).astype(np.int64)
+    k2 = [[b"x", b"yy", b"", b"zzz"][i] for i in rng.integers(0, 4, n)]
+    b = batch_of([k1, k2], [rng.random(n) > 0.1, None])
+    exp, _ = run_agg(oracle, [b], [0, 1], [abi.BIGINT, abi.VARCHAR], [], max_rows=7)
+    got, gop = run_agg(vx, [b], [0, 1], [abi.BIGINT, abi.VARCHAR], [], max_rows=7)
+    assert_columns_equal(got, exp, gop.kinds, what="distinct")
+    assert len(got[0][0]) == len(set(zip(np.where(b.columns[0].valid, k1, -1).tolist(), k2)))
