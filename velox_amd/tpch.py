@@ -1,0 +1,132 @@
+"""TPC-H Q3 assembled from the library's operators (the reference's plan:
+exec/tests/utils/TpchQueryBuilder.cpp:467-558), everything resident in HBM:
+
+  customer -> FilterProject(c_mktsegment = 'BUILDING') -> HashBuild(c_custkey)
+  orders   -> FilterProject(o_orderdate < DATE) -> HashProbe(o_custkey)
+           -> HashBuild(o_orderkey; payload o_orderdate, o_shippriority)
+  lineitem -> FilterProject(l_shipdate > DATE) -> HashProbe(l_orderkey)
+           -> HashAggregation(l_orderkey, o_orderdate, o_shippriority;
+                              sum(l_extendedprice * (1 - l_discount)))
+
+Pass-through columns travel as dictionary vectors over the selected-row
+indices, exactly like FilterProject / HashProbe::fillOutput wrap them
+(exec/OperatorUtils.cpp:380-422); composing two index vectors (indices of
+indices) is the only thing torch is asked to do here.
+"""
+import ctypes as C
+
+from . import abi
+
+Q3_DATE = 9204  # 1995-03-15 in days since epoch
+
+
+class DevBatch:
+    """vx355_batch over device columns with an explicit row count."""
+
+    def __init__(self, cols, num_rows):
+        self.cols = cols
+        self.num_rows = num_rows
+        self._descs = (abi.Column * max(1, len(cols)))(*[c.descriptor() for c in cols])
+        self.batch = abi.Batch(num_rows, len(cols), self._descs)
+
+    def ref(self):
+        return C.byref(self.batch)
+
+
+def run_q3(ops, torch, tables, date=Q3_DATE):
+    """tables: dict of torch tensors in HBM:
+      c_custkey int64, c_mktsegment int32[n,4] (16-byte StringViews),
+      o_orderkey int64, o_custkey int64, o_orderdate int32, o_shippriority int32,
+      l_orderkey int64, l_shipdate int32, l_extendedprice float64, l_discount float64.
+    Returns (keys..., revenue) tensors of the aggregation output plus stage sizes."""
+    def flat(kind, t):
+        return ops.DeviceColumn.from_ptr(kind, t.data_ptr(), int(t.shape[0]))
+
+    def wrapped(kind, t, idx, n):
+        return ops.DeviceColumn.from_ptr(kind, t.data_ptr(), n, None, abi.DICTIONARY, idx.data_ptr(),
+                                         int(t.shape[0]))
+
+    dev = tables["c_custkey"].device
+    info = {}
+
+    def select(batch, terms, n):
+        idx = torch.empty(max(1, n), dtype=torch.int32, device=dev)
+        m = ops.filter_project_device(batch, terms, [], idx.data_ptr(), [])
+        return idx, m
+
+    # -- customer
+    nc = int(tables["c_custkey"].shape[0])
+    cust = DevBatch([flat(abi.BIGINT, tables["c_custkey"]), flat(abi.VARCHAR, tables["c_mktsegment"])], nc)
+    idx_c, mc = select(cust, [(1, abi.CMP_EQ, b"BUILDING")], nc)
+    b1 = ops.HashBuild([0], [abi.BIGINT], [], [], abi.JOIN_INNER)
+    b1.add_input(DevBatch([wrapped(abi.BIGINT, tables["c_custkey"], idx_c, mc)], mc))
+    t1 = b1.finish()
+    info["customers_selected"] = mc
+
+    # -- orders
+    no = int(tables["o_orderkey"].shape[0])
+    orders = DevBatch([flat(abi.INTEGER, tables["o_orderdate"])], no)
+    idx_o, mo = select(orders, [(0, abi.CMP_LT, date)], no)
+    p1 = ops.HashProbe(t1, [0], abi.JOIN_INNER)
+    p1.add_input(DevBatch([wrapped(abi.BIGINT, tables["o_custkey"], idx_o, mo)], mo))
+    map_o = torch.empty(max(1, mo), dtype=torch.int32, device=dev)
+    n1, fin = p1.get_output_device(max(1, mo), map_o.data_ptr(), None, None, [])
+    assert fin
+    ord_idx = idx_o[map_o[:n1].long()].contiguous() if n1 else idx_o[:0]
+    info["orders_selected"], info["orders_joined"] = mo, n1
+    b2 = ops.HashBuild([0], [abi.BIGINT], [1, 2], [abi.INTEGER, abi.INTEGER], abi.JOIN_INNER)
+    if n1:
+        b2.add_input(DevBatch([wrapped(abi.BIGINT, tables["o_orderkey"], ord_idx, n1),
+                               wrapped(abi.INTEGER, tables["o_orderdate"], ord_idx, n1),
+                               wrapped(abi.INTEGER, tables["o_shippriority"], ord_idx, n1)], n1))
+    t2 = b2.finish()
+
+    # -- lineitem
+    nl = int(tables["l_orderkey"].shape[0])
+    line = DevBatch([flat(abi.INTEGER, tables["l_shipdate"])], nl)
+    idx_l, ml = select(line, [(0, abi.CMP_GT, date)], nl)
+    p2 = ops.HashProbe(t2, [0], abi.JOIN_INNER)
+    p2.add_input(DevBatch([wrapped(abi.BIGINT, tables["l_orderkey"], idx_l, ml)], ml))
+    cap = max(1, ml)
+    map_l = torch.empty(cap, dtype=torch.int32, device=dev)
+    odate = torch.empty(cap, dtype=torch.int32, device=dev)
+    oprio = torch.empty(cap, dtype=torch.int32, device=dev)
+    nulls = torch.empty((cap // 64 + 1) * 2, dtype=torch.int64, device=dev)
+    descs = (abi.OutColumn * 2)()
+    for i, t in enumerate((odate, oprio)):
+        descs[i].type_kind, descs[i].mem = abi.INTEGER, abi.MEM_DEVICE
+        descs[i].values, descs[i].nulls = t.data_ptr(), nulls[i * (cap // 64 + 1):].data_ptr()
+    n2, fin = p2.get_output_device(cap, map_l.data_ptr(), None, descs, [0, 1])
+    assert fin
+    info["lineitems_selected"], info["lineitems_joined"] = ml, n2
+    li_idx = idx_l[map_l[:n2].long()].contiguous() if n2 else idx_l[:0]
+
+    # -- aggregation: group by (l_orderkey, o_orderdate, o_shippriority), sum(ep * (1 - disc))
+    agg = ops.HashAggregation([0, 1, 2], [abi.BIGINT, abi.INTEGER, abi.INTEGER],
+                              [(abi.AGG_SUM, ops.PROJ(0), abi.DOUBLE)])
+    agg.set_fused_input([], [[(3, 1.0, 0.0), (4, -1.0, 1.0)]])
+    if n2:
+        agg.add_input(DevBatch([wrapped(abi.BIGINT, tables["l_orderkey"], li_idx, n2),
+                                ops.DeviceColumn.from_ptr(abi.INTEGER, odate.data_ptr(), n2),
+                                ops.DeviceColumn.from_ptr(abi.INTEGER, oprio.data_ptr(), n2),
+                                wrapped(abi.DOUBLE, tables["l_extendedprice"], li_idx, n2),
+                                wrapped(abi.DOUBLE, tables["l_discount"], li_idx, n2)], n2))
+    agg.no_more_input()
+    groups = int(agg.stats().num_groups)
+    outcap = max(1, groups)
+    out = [torch.empty(outcap, dtype=torch.int64, device=dev), torch.empty(outcap, dtype=torch.int32, device=dev),
+           torch.empty(outcap, dtype=torch.int32, device=dev), torch.empty(outcap, dtype=torch.float64, device=dev)]
+    onulls = torch.empty((outcap // 64 + 1) * 4, dtype=torch.int64, device=dev)
+    od = (abi.OutColumn * 4)()
+    for i, (t, k) in enumerate(zip(out, (abi.BIGINT, abi.INTEGER, abi.INTEGER, abi.DOUBLE))):
+        od[i].type_kind, od[i].mem = k, abi.MEM_DEVICE
+        od[i].values, od[i].nulls = t.data_ptr(), onulls[i * (outcap // 64 + 1):].data_ptr()
+    total = 0
+    n, fin = C.c_int32(), C.c_int32(0)
+    if groups:
+        ops._check(ops.lib().vx355_agg_get_output(agg.h, od, 4, outcap, C.byref(n), C.byref(fin)))
+        total = n.value
+        assert fin.value
+    info["groups"] = total
+    info["agg_mode"] = int(agg.stats().hash_mode)
+    return [t[:total] for t in out], info
