@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="q1", choices=["q1", "c1", "c4", "q3", "c5"])
+    ap.add_argument("--workload", default="q1", choices=["q1", "c1", "c4", "q3", "q3full", "c5"])
     ap.add_argument("--rows", type=int, default=0, help="override the row count (debug)")
     ap.add_argument("--cpu-sample-rows", type=int, default=16_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -435,6 +435,135 @@ class Q3:
         return total, time.perf_counter() - t0
 
 
+class Q3Full:
+    """BASELINE configs[2], the whole query (TpchQueryBuilder.cpp:467-558) through
+    velox_amd/tpch.py: customer (15 M) -> build; orders (150 M) -> probe -> build;
+    lineitem (~600 M, dbgen order) -> probe -> 3-key aggregation. rows = customer +
+    orders + lineitem rows scanned per step; scan bytes 24 + 24 + 28 B/row."""
+    name = "tpch_q3_sf100_full_query"
+    agg_bytes_per_row = 24
+    dominant = "k_join_probe"
+
+    def __init__(self, torch, n, device, seed):
+        from velox_amd import tpch
+        self.tpch, self.torch = tpch, torch
+        g = torch.Generator(device=device)
+        g.manual_seed(seed)
+        n_orders = max(8, n // 4)
+        n_cust = max(3, n_orders // 10)
+        t = {}
+        t["c_custkey"] = torch.arange(1, n_cust + 1, dtype=torch.int64, device=device)
+        seg_words = {  # 16-byte StringViews of the five market segments (size, 4-byte prefix, 8-byte tail)
+            0: b"AUTOMOBILE", 1: b"BUILDING", 2: b"FURNITURE", 3: b"MACHINERY", 4: b"HOUSEHOLD"}
+        views = np.zeros((5, 16), dtype=np.uint8)
+        for i, sname in seg_words.items():
+            views[i, 0:4] = np.frombuffer(np.uint32(len(sname)).tobytes(), dtype=np.uint8)
+            views[i, 4:4 + len(sname)] = np.frombuffer(sname, dtype=np.uint8)
+        seg_table = torch.from_numpy(views.view(np.int32).reshape(5, 4)).to(device)
+        t["c_mktsegment"] = seg_table[torch.randint(0, 5, (n_cust,), device=device, generator=g)].contiguous()
+        seq = torch.arange(n_orders, dtype=torch.int64, device=device)
+        t["o_orderkey"] = (seq // 8) * 32 + (seq % 8)
+        ck = torch.randint(0, (n_cust * 2) // 3, (n_orders,), dtype=torch.int64, device=device, generator=g)
+        t["o_custkey"] = (ck // 2) * 3 + 1 + (ck % 2)          # the 2/3 of custkeys that are not 0 mod 3
+        t["o_orderdate"] = torch.randint(8035, 10440, (n_orders,), dtype=torch.int32, device=device, generator=g)
+        t["o_shippriority"] = torch.zeros(n_orders, dtype=torch.int32, device=device)
+        counts = torch.randint(1, 8, (n_orders,), dtype=torch.int64, device=device, generator=g)
+        li = torch.repeat_interleave(seq, counts)
+        nl = int(li.shape[0])
+        t["l_orderkey"] = t["o_orderkey"][li]
+        t["l_shipdate"] = t["o_orderdate"][li] + torch.randint(1, 122, (nl,), dtype=torch.int32, device=device,
+                                                                generator=g)
+        del li, counts, seq, ck
+        qty = torch.randint(1, 51, (nl,), dtype=torch.int32, device=device, generator=g).to(torch.float64)
+        t["l_extendedprice"] = qty * (torch.randint(90000, 210001, (nl,), dtype=torch.int32, device=device,
+                                                    generator=g).to(torch.float64) / 100.0)
+        t["l_discount"] = torch.randint(0, 11, (nl,), dtype=torch.int32, device=device, generator=g).to(
+            torch.float64) / 100.0
+        del qty
+        self.t = t
+        self.rows = n_cust + n_orders + nl
+        self.scan_bytes = 24 * n_cust + 24 * n_orders + 28 * nl
+        torch.cuda.synchronize()
+
+    @property
+    def bytes_per_row(self):
+        return self.scan_bytes / self.rows
+
+    def step(self, step_kind=None):
+        out, info = self.tpch.run_q3(ops, self.torch, self.t)
+        self.last_info = info
+        return out
+
+    def rows_per_step(self):
+        return self.rows
+
+    def info(self):
+        return dict(self.last_info, rows={k: int(v.shape[0]) for k, v in self.t.items()
+                                          if k in ("c_custkey", "o_orderkey", "l_orderkey")})
+
+    def host_sample(self, rows):
+        # An SF-scaled copy of the same generator: rows/ (765 M / SF100) of the data.
+        frac = max(1e-4, min(1.0, rows / float(self.rows)))
+        small = Q3Full(self.torch, max(64, int((self.rows * frac) * 600 / 765)), self.t["c_custkey"].device, 4321)
+        host = {k: v.cpu().numpy() for k, v in small.t.items()}
+        host["_rows"] = small.rows
+        return host
+
+    def cpu_reference(self, sample, oracle):
+        """numpy filters + oracle joins + oracle aggregation, one thread."""
+        t0 = time.perf_counter()
+        date = self.tpch.Q3_DATE
+        seg = sample["c_mktsegment"].view(np.uint8).reshape(-1, 16)
+        building = np.zeros(16, dtype=np.uint8)
+        building[0] = 8
+        building[4:12] = np.frombuffer(b"BUILDING", dtype=np.uint8)
+        csel = np.flatnonzero((seg == building).all(axis=1))
+        b1 = oracle.JoinBuild([0], [abi.BIGINT], [], [], abi.JOIN_INNER)
+        b1.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, sample["c_custkey"][csel])]))
+        t1 = b1.finish()
+        osel = np.flatnonzero(sample["o_orderdate"] < date)
+        p1 = oracle.JoinProbe(t1, [0], abi.JOIN_INNER)
+        p1.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, sample["o_custkey"][osel])]))
+        maps = []
+        while True:
+            m, r, cols, fin = p1.get_output(1 << 20, [])
+            maps.append(m)
+            if fin:
+                break
+        oidx = osel[np.concatenate(maps)] if maps else osel[:0]
+        b2 = oracle.JoinBuild([0], [abi.BIGINT], [1, 2], [abi.INTEGER, abi.INTEGER], abi.JOIN_INNER)
+        b2.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, sample["o_orderkey"][oidx]),
+                                   abi.HostColumn(abi.INTEGER, sample["o_orderdate"][oidx]),
+                                   abi.HostColumn(abi.INTEGER, sample["o_shippriority"][oidx])]))
+        t2 = b2.finish()
+        lsel = np.flatnonzero(sample["l_shipdate"] > date)
+        p2 = oracle.JoinProbe(t2, [0], abi.JOIN_INNER)
+        p2.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, sample["l_orderkey"][lsel])]))
+        maps, od, op_ = [], [], []
+        while True:
+            m, r, cols, fin = p2.get_output(1 << 20)
+            maps.append(m)
+            od.append(cols[0][0])
+            op_.append(cols[1][0])
+            if fin:
+                break
+        lidx = lsel[np.concatenate(maps)]
+        rev = sample["l_extendedprice"][lidx] * (1 - sample["l_discount"][lidx])
+        agg = oracle.Aggregation([0, 1, 2], [abi.BIGINT, abi.INTEGER, abi.INTEGER], [(abi.AGG_SUM, 3, abi.DOUBLE)])
+        agg.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, sample["l_orderkey"][lidx]),
+                                     abi.HostColumn(abi.INTEGER, np.concatenate(od)),
+                                     abi.HostColumn(abi.INTEGER, np.concatenate(op_)),
+                                     abi.HostColumn(abi.DOUBLE, rev)]))
+        agg.no_more_input()
+        groups = 0
+        while True:
+            _, got, fin = agg.get_output(1 << 20)
+            groups += got
+            if fin:
+                break
+        return groups, time.perf_counter() - t0
+
+
 class C5:
     """BASELINE configs[4]: fact (fk BIGINT, m DOUBLE) join dim (pk BIGINT unique, a BIGINT),
     both row-range partitioned over the GPUs; radix repartition by VectorHasher
@@ -495,7 +624,7 @@ class C5:
         return total, time.perf_counter() - t0
 
 
-WORKLOADS = {"c5": (C5, 1_000_000_000), "q1": (Q1, 600_037_902), "c1": (C1, 10_000_000), "c4": (C4, 1_000_000_000),
+WORKLOADS = {"q3full": (Q3Full, 600_037_902), "c5": (C5, 1_000_000_000), "q1": (Q1, 600_037_902), "c1": (C1, 10_000_000), "c4": (C4, 1_000_000_000),
              "q3": (Q3, 600_037_902)}
 
 
@@ -642,7 +771,10 @@ def main():
         import oracle_lib
         oracle_lib.lib()
         sample = wl.host_sample(args.cpu_sample_rows)
-        sample_rows = len(sample["pkey"]) if "pkey" in sample else len(next(iter(sample.values())))
+        if "_rows" in sample:
+            sample_rows = int(sample["_rows"])
+        else:
+            sample_rows = len(sample["pkey"]) if "pkey" in sample else len(next(iter(sample.values())))
         cpu_out, cpu_s = wl.cpu_reference(sample, oracle_lib)
         out["cpu_baseline"] = {
             "value": sample_rows / cpu_s, "unit": "rows/s", "cores": 1, "kind": "port",
