@@ -34,6 +34,25 @@ __global__ __launch_bounds__(256) void k_filter_bits(FilterArgs a) {
   }
 }
 
+// One comparison of a flat, null-free fixed-width column against a constant:
+// the filters of TPC-H Q1 / Q3 (l_shipdate, o_orderdate). No per-row plan
+// interpretation: one load, one compare, one ballot per 64 rows.
+template <typename T>
+__global__ __launch_bounds__(256) void k_filter_bits_flat(const T* values, T constant, int32_t cmp,
+                                                           int64_t numRows, uint64_t* bits) {
+  const int64_t numWords = (numRows + 63) >> 6;
+  const int64_t waveStride = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+  for (int64_t w = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6; w < numWords;
+       w += waveStride) {
+    const int64_t row = (w << 6) + lane();
+    const bool pass = row < numRows && compareValues<T>(cmp, values[row], constant);
+    const uint64_t m = ballot(pass);
+    if (lane() == 0) {
+      bits[w] = m;
+    }
+  }
+}
+
 struct ProjectArgs {
   ProjectionArg proj[kMaxProjections];
   double* out[kMaxProjections];
@@ -176,7 +195,22 @@ extern "C" int vx355_filter_project(const vx355_batch* batch, const vx355_filter
   fa.numTerms = n_terms;
   fa.numRows = n;
   fa.bits = static_cast<uint64_t*>(bitsBuf.ensure(static_cast<size_t>(words) * 8 + 64));
-  VX_LAUNCH("k_filter_bits", k_filter_bits, streamGrid(words * 64, 256), 256, 0, fa);
+  const TermArg* t0 = n_terms == 1 ? &fa.terms[0] : nullptr;
+  const bool flat = t0 && t0->col.enc == VX355_FLAT && t0->col.nulls == nullptr;
+  const int fgrid = streamGrid(words * 64, 256);
+  if (flat && t0->constKind == VX355_BIGINT && t0->col.kind == VX355_INTEGER && t0->i64 >= INT32_MIN &&
+      t0->i64 <= INT32_MAX) {
+    VX_LAUNCH("k_filter_bits", k_filter_bits_flat<int32_t>, fgrid, 256, 0,
+              static_cast<const int32_t*>(t0->col.values), static_cast<int32_t>(t0->i64), t0->cmp, n, fa.bits);
+  } else if (flat && t0->constKind == VX355_BIGINT && t0->col.kind == VX355_BIGINT) {
+    VX_LAUNCH("k_filter_bits", k_filter_bits_flat<int64_t>, fgrid, 256, 0,
+              static_cast<const int64_t*>(t0->col.values), t0->i64, t0->cmp, n, fa.bits);
+  } else if (flat && t0->constKind == VX355_DOUBLE && t0->col.kind == VX355_DOUBLE) {
+    VX_LAUNCH("k_filter_bits", k_filter_bits_flat<double>, fgrid, 256, 0,
+              static_cast<const double*>(t0->col.values), t0->f64, t0->cmp, n, fa.bits);
+  } else {
+    VX_LAUNCH("k_filter_bits", k_filter_bits, fgrid, 256, 0, fa);
+  }
   int32_t* dIdx = host ? static_cast<int32_t*>(idxBuf.ensure(static_cast<size_t>(n) * 4 + 64)) : idx_out;
   int64_t passed = 0;
   compactBits(fa.bits, nullptr, nullptr, n, dIdx, scratch, &passed);
