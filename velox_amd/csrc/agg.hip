@@ -2237,7 +2237,9 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
       for (int k = 0; k < a.numKeys; ++k) {
         sa.keys[k] = a.keys[k];
       }
-      sa.numRows = std::min<int64_t>(n, 1 << 18);
+      // Small first batches are analysed completely (no range widening later for
+      // them); large ones by a 256 K-row prefix.
+      sa.numRows = n <= (8 << 20) ? n : (1 << 18);
       sa.counters = h.counters();
       VX_LAUNCH("k_key_stats", k_key_stats, streamGrid(sa.numRows, 256), 256, 0, sa);
       Counters c = readCounters(h);

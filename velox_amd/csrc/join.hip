@@ -411,7 +411,7 @@ struct ProbeArgs {
   uint32_t* hits;       // first matching build row or kNoRow32
   uint32_t* counts;     // output rows per probe row; only kept for duplicate tables
   uint64_t* tileSums;   // output rows per tile
-  int32_t fastKey;      // 1: single flat non-null BIGINT key (FK of TPC-H joins)
+  int32_t fastKey;      // single non-null BIGINT key (FK of TPC-H joins): 1 flat, 2 dictionary wrapped
   int32_t pad;
 };
 
@@ -541,9 +541,21 @@ __global__ __launch_bounds__(256) void k_join_probe(ProbeArgs a) {
       if (a.fastKey) {
         const int64_t* kp = static_cast<const int64_t*>(a.keys[0].values);
         int64_t v[kProbeUnroll];
+        int64_t src[kProbeUnroll];
 #pragma unroll
         for (int u = 0; u < kProbeUnroll; ++u) {
-          v[u] = kp[rows[u] < a.numRows ? rows[u] : a.numRows - 1];
+          src[u] = rows[u] < a.numRows ? rows[u] : a.numRows - 1;
+        }
+        if (a.fastKey == 2) {
+          // dictionary-wrapped key (the probe input came through a FilterProject)
+#pragma unroll
+          for (int u = 0; u < kProbeUnroll; ++u) {
+            src[u] = a.keys[0].indices[src[u]];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kProbeUnroll; ++u) {
+          v[u] = kp[src[u]];
         }
 #pragma unroll
         for (int u = 0; u < kProbeUnroll; ++u) {
@@ -1212,10 +1224,11 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
   uint64_t* offs =
       static_cast<uint64_t*>(p.tileOffsets.ensure(static_cast<size_t>(p.numTiles + 1) * 8 + 64));
   a.tileSums = sums;
-  a.fastKey = (t.mode != JMODE_HASH && a.numKeys == 1 && a.keys[0].kind == VX355_BIGINT && a.keys[0].enc == VX355_FLAT &&
-               a.keys[0].nulls == nullptr && a.ranges[0].multiplier == 1)
-      ? 1
-      : 0;
+  a.fastKey = 0;
+  if (t.mode != JMODE_HASH && a.numKeys == 1 && a.keys[0].kind == VX355_BIGINT && a.keys[0].nulls == nullptr &&
+      a.ranges[0].multiplier == 1) {
+    a.fastKey = a.keys[0].enc == VX355_FLAT ? 1 : (a.keys[0].enc == VX355_DICTIONARY ? 2 : 0);
+  }
   const int grid = static_cast<int>(std::min<int64_t>(p.numTiles, static_cast<int64_t>(rt.numCUs) * 8));
   VX_LAUNCH("k_join_probe", k_join_probe, grid, 256, 0, a);
   VX_LAUNCH("k_scan_u64", k_scan_u64, 1, 1024, 0, sums, p.numTiles, offs);
