@@ -89,9 +89,6 @@ struct AggArgs {
   uint64_t rowBase;
   uint64_t* table;
   int32_t stride;  // words per group row
-  int32_t ldsSlots;     // S
-  int32_t ldsRep;       // REP (power of two, <= 64)
-  int32_t ldsDirect;    // slot == key (no map)
   uint64_t capacity;    // group rows in table (array: range product; hash: power of two)
   int32_t* deferred;
   uint32_t deferCap;            // entries the deferred list can hold
@@ -1140,7 +1137,6 @@ struct KeyState {
   KeyRange range;  // current device mapping (valid when tableReady)
 };
 
-constexpr uint64_t kRangeTooLarge = ~0ULL;
 constexpr int64_t kMaxRangeSpan = (1LL << 59) - 1;  // exec/VectorHasher.h:139 kMaxRange
 
 }  // namespace
