@@ -383,6 +383,7 @@ typedef struct vx355_agg_stats {
   int32_t reserved;     /* launches of a hiprtc-instantiated shape-specialised kernel */
   int64_t input_rows;
   int64_t deferred_rows; /* rows replayed after a key-range widening */
+  int64_t radix_launches; /* chunks aggregated through the radix-partitioned LDS path */
 } vx355_agg_stats;
 int vx355_agg_get_stats(const vx355_agg* h, vx355_agg_stats* out);
 void vx355_agg_destroy(vx355_agg* h);

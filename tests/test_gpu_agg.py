@@ -580,3 +580,55 @@ def test_distinct_without_aggregates_and_drain_in_small_pages(oracle, vx):
     got, gop = run_agg(vx, [b], [0, 1], [abi.BIGINT, abi.VARCHAR], [], max_rows=7)
     assert_columns_equal(got, exp, gop.kinds, what="distinct")
     assert len(got[0][0]) == len(set(zip(np.where(b.columns[0].valid, k1, -1).tolist(), k2)))
+
+
+@pytest.mark.parametrize("max_bins", [None, "8"])
+def test_radix_partitioned_lds_path_high_cardinality(oracle, vx, max_bins, monkeypatch):
+    """BASELINE config 4 ("LDS-tiled atomic path stress"): array-mode group-bys too wide
+    for one workgroup's LDS are radix-partitioned by group range (one level, or two when
+    max_bins forces it) and folded partition by partition. Same results, same first-seen
+    order as the oracle; the second batch widens the key range (deferred rows replay)."""
+    monkeypatch.setenv("VX355_AGG_RADIX_MIN_ROWS", "1")
+    monkeypatch.setenv("VX355_AGG_COALESCE_ROWS", "0")
+    if max_bins:
+        monkeypatch.setenv("VX355_AGG_RADIX_BINS", max_bins)
+    rng = np.random.default_rng(77)
+    n = 300000
+    k1 = rng.integers(40000, 110000, n).astype(np.int64)
+    k2 = rng.integers(0, 150000, n).astype(np.int64)
+    v = [_dyadic(rng, n), _dyadic(rng, n)]
+    w = [rng.integers(-1 << 40, 1 << 40, n).astype(np.int64) for _ in range(2)]
+    vvalid = [rng.random(n) > 0.1 for _ in range(2)]
+    kvalid = [rng.random(n) > 0.01 for _ in range(2)]
+    batches = [batch_of([k, v[i], w[i]], [kvalid[i], vvalid[i], None]) for i, k in enumerate([k1, k2])]
+    for aggs in ([(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)],
+                 [(abi.AGG_SUM, 2, abi.BIGINT), (abi.AGG_MIN, 1, abi.DOUBLE), (abi.AGG_COUNT, 1, abi.DOUBLE)],
+                 [(abi.AGG_MAX, 2, abi.BIGINT)]):
+        exp, _ = run_agg(oracle, batches, [0], [abi.BIGINT], aggs, max_rows=100000)
+        got, gop = run_agg(vx, batches, [0], [abi.BIGINT], aggs, max_rows=100000)
+        assert_columns_equal(got, exp, gop.kinds, what="radix %s" % (aggs,))
+        st = gop.stats()
+        assert st.hash_mode == abi.MODE_ARRAY and st.radix_launches >= 2 and st.deferred_rows > 0
+
+
+def test_radix_path_two_keys_fused_filter(oracle, vx, monkeypatch):
+    """Two grouping keys (the normalized key is the partitioning key) behind a fused filter."""
+    monkeypatch.setenv("VX355_AGG_RADIX_MIN_ROWS", "1")
+    rng = np.random.default_rng(78)
+    n = 800000
+    a = rng.integers(0, 200, n).astype(np.int64)
+    b = rng.integers(-100, 100, n).astype(np.int32)
+    v = _dyadic(rng, n)
+    d = rng.integers(0, 100, n).astype(np.int32)
+    aggs = [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_AVG, 2, abi.DOUBLE)]
+    terms = [(3, abi.CMP_LE, 70)]
+    keep = d <= 70
+    exp, _ = run_agg(oracle, [batch_of([a[keep], b[keep], v[keep]])], [0, 1], [abi.BIGINT, abi.INTEGER], aggs,
+                     max_rows=1 << 20)
+    op = vx.Aggregation([0, 1], [abi.BIGINT, abi.INTEGER], aggs, abi.STEP_SINGLE)
+    op.set_fused_input(terms, [])
+    op.add_input(batch_of([a, b, v, d]))
+    op.no_more_input()
+    got = vx.collect_output(op, 1 << 20)
+    assert_columns_equal(got, exp, op.kinds, what="radix two keys")
+    assert op.stats().radix_launches == 1

@@ -476,6 +476,486 @@ const FastEntry kFastTable[] = {
     VX_FAST_ENTRY(4, FK_I64, FK_NONE, FK_I32, FK_NONE, 1, 2, kC1Lo, 0),
 };
 
+// ---- LDS-tiled aggregation for high cardinality (BASELINE config 4) ------------
+// One HBM atomic per input row is the ceiling of k_agg_global: the chip retires
+// ~20 G atomic_add_f64 per second wherever the table lives (L2, Infinity Cache or
+// HBM), so 10^9 rows cost >= 50 ms. This path replaces per-row HBM atomics by
+// per-row LDS atomics: rows are radix-partitioned in two passes by
+// pid = normalized key / B (B groups fit one workgroup's LDS), then one
+// workgroup per partition folds its rows into LDS accumulators and touches each
+// HBM group row once. Everything streams: 2 x (read + write) of a compact
+// record {key, row, operands} plus one read.
+constexpr int kRadixMaxAccs = 3;
+constexpr int kRadixMaxBins = 4096;   // per level
+constexpr int kRadixKeyBits = 32;     // record word 0 = key : 32 | row of the chunk : 29 | accumulator mask : 3
+constexpr int kRadixRowBits = 29;
+
+struct RadixArgs {
+  AggArgs a;
+  int32_t numVals;     // operand words per record (accumulators other than counts)
+  int32_t recWords;    // 1 + numVals
+  int32_t shiftB;      // log2(groups per partition): pid = key >> shiftB
+  int32_t shift2;      // level-1 bin = pid >> shift2 (0 = single level)
+  int32_t numBins;     // level-1 bins
+  int32_t valIdx[kRadixMaxAccs];  // operand word of accumulator j, -1 for counts
+  int32_t accOfVal[kRadixMaxAccs];  // inverse: accumulator of operand word q
+  int64_t tileRows;    // rows per workgroup tile
+  int64_t numTiles;
+  uint32_t* hist;      // [bin][tile]
+  const uint64_t* offsets;
+  uint64_t* recs;      // output records of this pass
+};
+static_assert(sizeof(RadixArgs) <= 4096, "kernel arguments are limited to 4 KB");
+
+// KW = 8 / 4: a single flat BIGINT / INTEGER key without nulls and no fused filter
+// (loads issued ahead of their use, kRadixUnroll rows per lane in flight);
+// KW = 0: any key set the ABI admits.
+constexpr int kRadixUnroll = 4;
+
+template <int KW>
+__device__ inline int64_t rpLoadKey(const RadixArgs& r, int64_t row) {
+  if constexpr (KW == 8) {
+    return static_cast<const int64_t*>(r.a.keys[0].col.values)[row];
+  } else if constexpr (KW == 4) {
+    return static_cast<const int32_t*>(r.a.keys[0].col.values)[row];
+  } else {
+    return 0;
+  }
+}
+
+template <int KW>
+__device__ inline int rpKey(const RadixArgs& r, int64_t row, int64_t raw, uint64_t* key) {
+  const AggArgs& a = r.a;
+  if constexpr (KW != 0) {
+    const KeyRange& kr = a.keys[0].range;
+    if (raw >= kr.min && raw <= kr.max) {
+      *key = static_cast<uint64_t>(raw) - static_cast<uint64_t>(kr.min) + 1;
+      return 0;
+    }
+    return normalizedKey(a, row, key);  // out of range: statistics + deferral
+  } else {
+    return (a.numTerms && !evalFilter(a.terms, a.numTerms, row)) ? 1 : normalizedKey(a, row, key);
+  }
+}
+
+// Level 1, count: histogram of the level-1 bin over the rows of each tile that
+// pass the filter and map into the current key ranges (others: deferred list).
+template <int KW>
+__global__ __launch_bounds__(1024) void k_rp_count1(RadixArgs r) {
+  __shared__ uint32_t hist[kRadixMaxBins];
+  const AggArgs& a = r.a;
+  const int shift = r.shiftB + r.shift2;
+  for (int64_t tile = blockIdx.x; tile < r.numTiles; tile += gridDim.x) {
+    for (int i = threadIdx.x; i < r.numBins; i += blockDim.x) {
+      hist[i] = 0;
+    }
+    __syncthreads();
+    const int64_t begin = tile * r.tileRows;
+    const int64_t end = begin + r.tileRows < a.numRows ? begin + r.tileRows : a.numRows;
+    for (int64_t base = begin; base < end; base += kRadixUnroll * 1024) {
+      int64_t raw[kRadixUnroll];
+#pragma unroll
+      for (int u = 0; u < kRadixUnroll; ++u) {
+        const int64_t row = base + u * 1024 + threadIdx.x;
+        raw[u] = row < end ? rpLoadKey<KW>(r, row) : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < kRadixUnroll; ++u) {
+        const int64_t row = base + u * 1024 + threadIdx.x;
+        bool defer = false;
+        if (row < end) {
+          uint64_t key;
+          const int st = rpKey<KW>(r, row, raw[u], &key);
+          if (st == 0) {
+            atomicAdd(&hist[key >> shift], 1u);
+          } else if (st == 2) {
+            defer = true;
+          }
+        }
+        deferRow(a, defer, static_cast<int32_t>(row));
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < r.numBins; i += blockDim.x) {
+      r.hist[static_cast<int64_t>(i) * r.numTiles + tile] = hist[i];
+    }
+    __syncthreads();
+  }
+}
+
+template <int W>
+__device__ inline void rpStore(uint64_t* dst, const uint64_t* w) {
+  if constexpr (W == 2) {
+    *reinterpret_cast<ulonglong2*>(dst) = make_ulonglong2(w[0], w[1]);
+  } else if constexpr (W == 4) {
+    reinterpret_cast<ulonglong2*>(dst)[0] = make_ulonglong2(w[0], w[1]);
+    reinterpret_cast<ulonglong2*>(dst)[1] = make_ulonglong2(w[2], w[3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+      dst[i] = w[i];
+    }
+  }
+}
+
+template <int W>
+__device__ inline void rpLoad(const uint64_t* src, uint64_t* w) {
+  if constexpr (W == 2) {
+    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(src);
+    w[0] = v.x;
+    w[1] = v.y;
+  } else if constexpr (W == 4) {
+    const ulonglong2 v0 = reinterpret_cast<const ulonglong2*>(src)[0];
+    const ulonglong2 v1 = reinterpret_cast<const ulonglong2*>(src)[1];
+    w[0] = v0.x;
+    w[1] = v0.y;
+    w[2] = v1.x;
+    w[3] = v1.y;
+  } else {
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+      w[i] = src[i];
+    }
+  }
+}
+
+// Level 1, scatter: the same rows, as records of W words, to their level-1
+// bucket. FLATV: every operand is a flat 8-byte column without nulls or mask,
+// loaded ahead like the key.
+template <int KW, int W, bool FLATV>
+__global__ __launch_bounds__(1024) void k_rp_scatter1(RadixArgs r) {
+  __shared__ unsigned long long cursor[kRadixMaxBins];
+  const AggArgs& a = r.a;
+  const int shift = r.shiftB + r.shift2;
+  for (int64_t tile = blockIdx.x; tile < r.numTiles; tile += gridDim.x) {
+    for (int i = threadIdx.x; i < r.numBins; i += blockDim.x) {
+      cursor[i] = r.offsets[static_cast<int64_t>(i) * r.numTiles + tile];
+    }
+    __syncthreads();
+    const int64_t begin = tile * r.tileRows;
+    const int64_t end = begin + r.tileRows < a.numRows ? begin + r.tileRows : a.numRows;
+    for (int64_t base = begin; base < end; base += kRadixUnroll * 1024) {
+      int64_t raw[kRadixUnroll];
+      uint64_t vals[kRadixUnroll][W];
+#pragma unroll
+      for (int u = 0; u < kRadixUnroll; ++u) {
+        const int64_t row = base + u * 1024 + threadIdx.x;
+        raw[u] = row < end ? rpLoadKey<KW>(r, row) : 0;
+        if constexpr (FLATV) {
+#pragma unroll
+          for (int q = 1; q < W; ++q) {
+            vals[u][q] = row < end ? static_cast<const uint64_t*>(a.accs[r.accOfVal[q - 1]].in.values)[row] : 0;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kRadixUnroll; ++u) {
+        const int64_t row = base + u * 1024 + threadIdx.x;
+        if (row >= end) {
+          continue;
+        }
+        uint64_t key;
+        if (rpKey<KW>(r, row, raw[u], &key) != 0) {
+          continue;
+        }
+        uint64_t mask = 0;
+        if constexpr (FLATV) {
+          mask = (1ULL << a.numAccs) - 1;
+#pragma unroll
+          for (int q = 1; q < W; ++q) {
+            const AccArg& acc = a.accs[r.accOfVal[q - 1]];
+            if (acc.kind == ACC_MIN || acc.kind == ACC_MAX) {
+              vals[u][q] = acc.inIsInt ? int64ToOrdered(static_cast<int64_t>(vals[u][q]))
+                                       : doubleToOrdered(__longlong_as_double(static_cast<long long>(vals[u][q])));
+            }
+          }
+        } else {
+#pragma unroll
+          for (int q = 1; q < W; ++q) {
+            const int j = r.accOfVal[q - 1];
+            vals[u][q] = 0;
+            if (accInput(a, a.accs[j], row, &vals[u][q])) {
+              mask |= 1ULL << j;
+            }
+          }
+          for (int j = 0; j < a.numAccs; ++j) {
+            uint64_t one;
+            if (r.valIdx[j] < 0 && accInput(a, a.accs[j], row, &one)) {
+              mask |= 1ULL << j;
+            }
+          }
+        }
+        vals[u][0] = key | (static_cast<uint64_t>(row) << kRadixKeyBits) | (mask << (kRadixKeyBits + kRadixRowBits));
+        const unsigned long long pos = atomicAdd(&cursor[key >> shift], 1ULL);
+        rpStore<W>(r.recs + pos * W, vals[u]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Level 2 works on records; tiles never straddle level-1 buckets.
+struct RadixTile {
+  uint64_t begin;   // first record
+  uint32_t count;   // records in the tile
+  uint32_t cell;    // index of (this tile, bin 0) in the level-2 histogram; bins are 'stride' cells apart
+  uint32_t stride;  // tiles of the bucket
+  uint32_t pad;
+};
+
+// Builds the level-2 tile table and the partition -> histogram cell map from
+// the level-1 offsets, on device (no host round trip between the levels).
+__global__ __launch_bounds__(1024) void k_rp_tiles(const uint64_t* offsets1, int64_t numTiles1, int32_t numBins1,
+                                                    int32_t numBins2, int32_t shift2, uint32_t tileRecs,
+                                                    RadixTile* tiles, uint32_t* numTiles2, uint32_t* partCell,
+                                                    int64_t numParts) {
+  __shared__ uint32_t tileStart[kRadixMaxBins + 1];
+  for (int b = threadIdx.x; b < numBins1; b += blockDim.x) {
+    const uint64_t count =
+        offsets1[static_cast<int64_t>(b + 1) * numTiles1] - offsets1[static_cast<int64_t>(b) * numTiles1];
+    tileStart[b] = static_cast<uint32_t>((count + tileRecs - 1) / tileRecs);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int b = 0; b < numBins1; ++b) {
+      const uint32_t n = tileStart[b];
+      tileStart[b] = run;
+      run += n;
+    }
+    tileStart[numBins1] = run;
+    *numTiles2 = run;
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < numBins1; b += blockDim.x) {
+    const uint64_t first = offsets1[static_cast<int64_t>(b) * numTiles1];
+    const uint64_t count = offsets1[static_cast<int64_t>(b + 1) * numTiles1] - first;
+    const uint32_t n = tileStart[b + 1] - tileStart[b];
+    for (uint32_t j = 0; j < n; ++j) {
+      RadixTile t;
+      t.begin = first + static_cast<uint64_t>(j) * tileRecs;
+      const uint64_t left = count - static_cast<uint64_t>(j) * tileRecs;
+      t.count = static_cast<uint32_t>(left < tileRecs ? left : tileRecs);
+      t.cell = static_cast<uint32_t>(numBins2) * tileStart[b] + j;
+      t.stride = n;
+      t.pad = 0;
+      tiles[tileStart[b] + j] = t;
+    }
+  }
+  for (int64_t p = threadIdx.x; p <= numParts; p += blockDim.x) {
+    const int64_t b1 = p >> shift2;
+    const uint32_t b2 = static_cast<uint32_t>(p & (numBins2 - 1));
+    uint32_t cell;
+    if (b1 >= numBins1) {
+      cell = static_cast<uint32_t>(numBins2) * tileStart[numBins1];
+    } else {
+      cell = static_cast<uint32_t>(numBins2) * tileStart[b1] + b2 * (tileStart[b1 + 1] - tileStart[b1]);
+    }
+    partCell[p] = cell;
+  }
+}
+
+struct Radix2Args {
+  const uint64_t* in;   // records grouped by level-1 bucket
+  uint64_t* out;
+  const RadixTile* tiles;
+  const uint32_t* numTiles;
+  int32_t recWords;
+  int32_t shiftB;
+  int32_t numBins;      // level-2 bins (power of two)
+  int32_t pad;
+  uint32_t* hist;
+  const uint64_t* offsets;
+};
+
+__global__ __launch_bounds__(1024) void k_rp_count2(Radix2Args r) {
+  __shared__ uint32_t hist[kRadixMaxBins];
+  const uint32_t numTiles = *r.numTiles;
+  const uint32_t binMask = static_cast<uint32_t>(r.numBins - 1);
+  for (uint32_t t = blockIdx.x; t < numTiles; t += gridDim.x) {
+    const RadixTile tile = r.tiles[t];
+    for (int i = threadIdx.x; i < r.numBins; i += blockDim.x) {
+      hist[i] = 0;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < tile.count; i += blockDim.x) {
+      const uint32_t key = static_cast<uint32_t>(r.in[(tile.begin + i) * r.recWords]);
+      atomicAdd(&hist[(key >> r.shiftB) & binMask], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < r.numBins; i += blockDim.x) {
+      r.hist[tile.cell + static_cast<uint64_t>(i) * tile.stride] = hist[i];
+    }
+    __syncthreads();
+  }
+}
+
+template <int W>
+__global__ __launch_bounds__(1024) void k_rp_scatter2(Radix2Args r) {
+  __shared__ unsigned long long cursor[kRadixMaxBins];
+  const uint32_t numTiles = *r.numTiles;
+  const uint32_t binMask = static_cast<uint32_t>(r.numBins - 1);
+  for (uint32_t t = blockIdx.x; t < numTiles; t += gridDim.x) {
+    const RadixTile tile = r.tiles[t];
+    for (int i = threadIdx.x; i < r.numBins; i += blockDim.x) {
+      cursor[i] = r.offsets[tile.cell + static_cast<uint64_t>(i) * tile.stride];
+    }
+    __syncthreads();
+    for (uint32_t base = 0; base < tile.count; base += kRadixUnroll * 1024) {
+      uint64_t w[kRadixUnroll][W];
+#pragma unroll
+      for (int u = 0; u < kRadixUnroll; ++u) {
+        const uint32_t i = base + u * 1024 + threadIdx.x;
+        if (i < tile.count) {
+          rpLoad<W>(r.in + (tile.begin + i) * W, w[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kRadixUnroll; ++u) {
+        const uint32_t i = base + u * 1024 + threadIdx.x;
+        if (i < tile.count) {
+          const unsigned long long pos =
+              atomicAdd(&cursor[(static_cast<uint32_t>(w[u][0]) >> r.shiftB) & binMask], 1ULL);
+          rpStore<W>(r.out + pos * W, w[u]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+struct RadixAggArgs {
+  const uint64_t* recs;
+  const uint64_t* partBegin;   // record offsets per histogram cell
+  const uint32_t* partCell;    // partition p -> cell (numParts + 1 entries); null: cell = p * cellStride
+  int64_t cellStride;
+  int64_t numParts;
+  int32_t recWords;
+  int32_t numAccs;
+  int32_t shiftB;
+  int32_t stride;
+  uint64_t* table;
+  uint64_t rowBase;
+  uint64_t capacity;
+  Counters* counters;
+  int32_t kind[kRadixMaxAccs];
+  int32_t off[kRadixMaxAccs];
+  int32_t valIdx[kRadixMaxAccs];
+  int32_t accOfVal[kRadixMaxAccs];
+};
+
+// One workgroup per partition: fold its records into LDS, then touch each of
+// the <= B group rows in HBM once.
+template <int W>
+__global__ __launch_bounds__(512) void k_rp_aggregate(RadixAggArgs r) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+  const int B = 1 << r.shiftB;
+  const int A = r.numAccs;
+  uint64_t* acc = reinterpret_cast<uint64_t*>(ldsRaw);                               // [B][A]
+  uint32_t* first = reinterpret_cast<uint32_t*>(acc + static_cast<size_t>(B) * A);  // [B]
+  for (int64_t p = blockIdx.x; p < r.numParts; p += gridDim.x) {
+    const uint64_t begin = r.partBegin[r.partCell ? r.partCell[p] : p * r.cellStride];
+    const uint64_t end = r.partBegin[r.partCell ? r.partCell[p + 1] : (p + 1) * r.cellStride];
+    if (end == begin) {
+      continue;  // uniform per workgroup
+    }
+    for (int i = threadIdx.x; i < B * A; i += blockDim.x) {
+      acc[i] = accIdentity(r.kind[i % A]);
+    }
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+      first[i] = 0xffffffffu;
+    }
+    __syncthreads();
+    const uint64_t base = static_cast<uint64_t>(p) << r.shiftB;
+    for (uint64_t at = begin; at < end; at += kRadixUnroll * 512) {
+      uint64_t w[kRadixUnroll][W];
+#pragma unroll
+      for (int u = 0; u < kRadixUnroll; ++u) {
+        const uint64_t i = at + u * 512 + threadIdx.x;
+        if (i < end) {
+          rpLoad<W>(r.recs + i * W, w[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kRadixUnroll; ++u) {
+        const uint64_t i = at + u * 512 + threadIdx.x;
+        if (i >= end) {
+          continue;
+        }
+        const uint64_t w0 = w[u][0];
+        const uint32_t g = static_cast<uint32_t>(w0) & static_cast<uint32_t>(B - 1);
+        const uint32_t row = static_cast<uint32_t>(w0 >> kRadixKeyBits) & ((1u << kRadixRowBits) - 1);
+        const uint32_t mask = static_cast<uint32_t>(w0 >> (kRadixKeyBits + kRadixRowBits));
+        if (first[g] > row) {
+          atomicMin(&first[g], row);
+        }
+#pragma unroll
+        for (int q = 1; q < W; ++q) {
+          const int j = r.accOfVal[q - 1];
+          if ((mask >> j) & 1) {
+            applyLds(acc + static_cast<size_t>(g) * A + j, r.kind[j], w[u][q], r.counters);
+          }
+        }
+        for (int j = 0; j < A; ++j) {
+          if (r.valIdx[j] < 0 && ((mask >> j) & 1)) {
+            applyLds(acc + static_cast<size_t>(g) * A + j, r.kind[j], 1ULL, r.counters);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    uint32_t newGroups = 0;
+    for (int g = threadIdx.x; g < B; g += blockDim.x) {
+      const uint32_t f = first[g];
+      if (f == 0xffffffffu || base + g >= r.capacity) {
+        continue;
+      }
+      // This workgroup is the only writer of the partition's group rows during
+      // the launch: plain read-modify-write, coalesced over consecutive groups.
+      uint64_t* row = r.table + (base + g) * r.stride;
+      const uint64_t mine = r.rowBase + static_cast<uint64_t>(f);
+      const uint64_t old = row[1];
+      if (old == kNoRow) {
+        ++newGroups;
+      }
+      if (mine < old) {
+        row[1] = mine;
+      }
+      for (int j = 0; j < A; ++j) {
+        const uint64_t v = acc[static_cast<size_t>(g) * A + j];
+        uint64_t* word = row + r.off[j];
+        switch (r.kind[j]) {
+          case ACC_SUM_F64:
+            *reinterpret_cast<double*>(word) += __longlong_as_double(static_cast<long long>(v));
+            break;
+          case ACC_SUM_I64: {
+            const int64_t before = static_cast<int64_t>(*word);
+            if (addOverflows(before, static_cast<int64_t>(v))) {
+              r.counters->overflow = 1;
+            }
+            *word = static_cast<uint64_t>(before) + v;
+            break;
+          }
+          case ACC_SUM_I64_WRAP:
+          case ACC_COUNT:
+            *word += v;
+            break;
+          case ACC_MIN:
+            *word = v < *word ? v : *word;
+            break;
+          default:
+            *word = v > *word ? v : *word;
+            break;
+        }
+      }
+    }
+    if (newGroups) {
+      atomicAdd(&r.counters->numNewGroups, newGroups);
+    }
+    __syncthreads();
+  }
+}
+
 // ---- generic hash mode (the reference's kHash, HashTable.cpp:470-520) ---------------
 // Keys that have no 64-bit normalized form (REAL / DOUBLE / TIMESTAMP, strings
 // of 8..12 bytes, key sets wider than 64 bits) are grouped through an
@@ -1175,6 +1655,12 @@ struct vx355_agg {
   DevBuf countersBuf;
   DevBuf deferredBuf;
   DevBuf scratch, sortTmp;
+  // radix-partitioned path (high cardinality)
+  DevBuf rpRecs1, rpRecs2, rpHist, rpOffsets, rpTiles, rpMisc, rpScan;
+  int64_t radixMinRows = 4 << 20;
+  int32_t radixMaxBins = kRadixMaxBins;  // widest single-level fan-out
+  int64_t radixTileRows = 0;  // 0 = automatic
+  int64_t radixLaunches = 0;
   DevBuf orderKeys, orderVals, orderKeys2, orderVals2;
   const uint32_t* order = nullptr;
   int64_t numOutput = -1;  // set by finalize
@@ -1951,6 +2437,193 @@ void materializeAliases(vx355_agg& h, const DeviceBatch& db) {
   }
 }
 
+int log2Ceil(uint64_t v) {
+  int l = 0;
+  while ((1ULL << l) < v) {
+    ++l;
+  }
+  return l;
+}
+
+// Groups per partition of the radix path: B x (accumulators x 8 + 4) bytes of
+// LDS per workgroup, two workgroups per CU.
+int radixShiftB(int numAccs) { return numAccs <= 1 ? 12 : 11; }
+
+bool radixEligible(const vx355_agg& h, const AggArgs& a) {
+  if (h.radixMinRows < 0 || a.mode != MODE_ARRAY || a.rowList || a.rescanOld || a.numAccs < 1 ||
+      a.numAccs > kRadixMaxAccs || a.numRows < h.radixMinRows || a.numRows > (1LL << kRadixRowBits) ||
+      a.capacity > (1ULL << kRadixKeyBits)) {
+    return false;
+  }
+  const uint64_t parts = (a.capacity + (1ULL << radixShiftB(a.numAccs)) - 1) >> radixShiftB(a.numAccs);
+  // Worth it when rows outnumber partitions by far and two levels reach every partition.
+  return parts >= 2 && parts <= static_cast<uint64_t>(h.radixMaxBins) * kRadixMaxBins &&
+      static_cast<uint64_t>(a.numRows) >= parts * 1024;
+}
+
+// High-cardinality array-mode chunk: partition the rows by group range (one or
+// two LDS-histogram passes), then aggregate each partition in LDS.
+void launchRadix(vx355_agg& h, AggArgs& a) {
+  auto& rt = Runtime::get();
+  const int64_t n = a.numRows;
+  RadixArgs r{};
+  for (int j = 0; j < a.numAccs; ++j) {
+    a.accs[j].splitM = 0;
+  }
+  r.a = a;
+  r.shiftB = radixShiftB(a.numAccs);
+  const uint64_t parts = (a.capacity + (1ULL << r.shiftB) - 1) >> r.shiftB;
+  // One level while the fan-out fits the LDS cursors (measured: 2400 bins in one
+  // pass beat 64 x 64 in two); otherwise two balanced levels.
+  r.shift2 = parts <= static_cast<uint64_t>(h.radixMaxBins)
+      ? 0
+      : std::max(log2Ceil((parts + h.radixMaxBins - 1) / h.radixMaxBins), log2Ceil(parts) / 2);
+  r.numBins = static_cast<int32_t>((parts + (1ULL << r.shift2) - 1) >> r.shift2);
+  const int32_t bins2 = 1 << r.shift2;
+  for (int j = 0; j < a.numAccs; ++j) {
+    r.valIdx[j] = a.accs[j].kind == ACC_COUNT ? -1 : r.numVals++;
+    if (r.valIdx[j] >= 0) {
+      r.accOfVal[r.valIdx[j]] = j;
+    }
+  }
+  r.recWords = 1 + r.numVals;
+  int64_t tileRows = h.radixTileRows > 0 ? h.radixTileRows : std::max<int64_t>(32768, ceilDiv(n, 2048));
+  tileRows = (tileRows + 1023) & ~1023LL;
+  r.tileRows = tileRows;
+  r.numTiles = ceilDiv(n, tileRows);
+  const int64_t cells1 = static_cast<int64_t>(r.numBins) * r.numTiles;
+  const uint32_t tileRecs = 65536;
+  const int64_t maxTiles2 = ceilDiv(n, tileRecs) + r.numBins;
+  const int64_t cells2 = r.shift2 ? static_cast<int64_t>(bins2) * maxTiles2 : 0;
+  const size_t recBytes = static_cast<size_t>(n) * r.recWords * 8 + 64;
+  h.rpRecs1.ensure(recBytes);
+  if (r.shift2) {
+    h.rpRecs2.ensure(recBytes);
+  }
+  h.rpHist.ensure(static_cast<size_t>(std::max(cells1, cells2)) * 4 + 64);
+  // offsets: level 1 [cells1 + 1], level 2 [cells2 + 1]
+  h.rpOffsets.ensure(static_cast<size_t>(cells1 + 1 + cells2 + 1) * 8 + 64);
+  uint64_t* offsets1 = h.rpOffsets.as<uint64_t>();
+  uint64_t* offsets2 = offsets1 + cells1 + 1;
+  r.hist = h.rpHist.as<uint32_t>();
+  r.offsets = offsets1;
+  r.recs = h.rpRecs1.as<uint64_t>();
+  const int grid1 = static_cast<int>(std::min<int64_t>(r.numTiles, rt.numCUs * 2));
+  // Shape of pass 1: flat single integer key? flat 8-byte operands?
+  int kw = 0;
+  if (a.numKeys == 1 && a.numTerms == 0 && !a.ignoreNullKeys) {
+    const ColView& kc = a.keys[0].col;
+    if (kc.enc == VX355_FLAT && !kc.nulls && a.keys[0].range.multiplier == 1 &&
+        (kc.kind == VX355_BIGINT || kc.kind == VX355_INTEGER)) {
+      kw = kc.kind == VX355_BIGINT ? 8 : 4;
+    }
+  }
+  bool flatV = kw != 0;
+  for (int j = 0; j < a.numAccs; ++j) {
+    const AccArg& acc = a.accs[j];
+    if (acc.hasMask || acc.inProj >= 0) {
+      flatV = false;
+    } else if (acc.kind == ACC_COUNT) {
+      flatV = flatV && !acc.hasIn;
+    } else {
+      const bool wantInt = acc.kind == ACC_SUM_I64 || acc.kind == ACC_SUM_I64_WRAP ||
+          ((acc.kind == ACC_MIN || acc.kind == ACC_MAX) && acc.inIsInt);
+      flatV = flatV && acc.hasIn && acc.in.enc == VX355_FLAT && !acc.in.nulls &&
+          acc.in.kind == (wantInt ? VX355_BIGINT : VX355_DOUBLE);
+    }
+  }
+  if (kw == 8) {
+    VX_LAUNCH("k_rp_count1", k_rp_count1<8>, grid1, 1024, 0, r);
+  } else if (kw == 4) {
+    VX_LAUNCH("k_rp_count1", k_rp_count1<4>, grid1, 1024, 0, r);
+  } else {
+    VX_LAUNCH("k_rp_count1", k_rp_count1<0>, grid1, 1024, 0, r);
+  }
+  scanU32ToU64(r.hist, cells1, offsets1, h.rpScan);
+  auto scatter1 = [&](auto wTag) {
+    constexpr int W = decltype(wTag)::value;
+    if (flatV && kw == 8) {
+      VX_LAUNCH("k_rp_scatter1", (k_rp_scatter1<8, W, true>), grid1, 1024, 0, r);
+    } else if (flatV && kw == 4) {
+      VX_LAUNCH("k_rp_scatter1", (k_rp_scatter1<4, W, true>), grid1, 1024, 0, r);
+    } else {
+      VX_LAUNCH("k_rp_scatter1", (k_rp_scatter1<0, W, false>), grid1, 1024, 0, r);
+    }
+  };
+  auto byWidth = [&](auto&& fn) {
+    switch (r.recWords) {
+      case 1:
+        fn(std::integral_constant<int, 1>{});
+        break;
+      case 2:
+        fn(std::integral_constant<int, 2>{});
+        break;
+      case 3:
+        fn(std::integral_constant<int, 3>{});
+        break;
+      default:
+        fn(std::integral_constant<int, 4>{});
+        break;
+    }
+  };
+  byWidth(scatter1);
+
+  RadixAggArgs g{};
+  g.recs = h.rpRecs1.as<uint64_t>();
+  g.partBegin = offsets1;
+  g.partCell = nullptr;
+  g.cellStride = r.numTiles;
+  if (r.shift2) {
+    h.rpTiles.ensure(static_cast<size_t>(maxTiles2) * sizeof(RadixTile) + 64);
+    h.rpMisc.ensure(64 + static_cast<size_t>(parts + 1) * 4 + 64);
+    uint32_t* numTiles2 = h.rpMisc.as<uint32_t>();
+    uint32_t* partCell = numTiles2 + 16;
+    VX_LAUNCH("k_rp_tiles", k_rp_tiles, 1, 1024, 0, offsets1, r.numTiles, r.numBins, bins2, r.shift2, tileRecs,
+              h.rpTiles.as<RadixTile>(), numTiles2, partCell, static_cast<int64_t>(parts));
+    Radix2Args r2{};
+    r2.in = h.rpRecs1.as<uint64_t>();
+    r2.out = h.rpRecs2.as<uint64_t>();
+    r2.tiles = h.rpTiles.as<RadixTile>();
+    r2.numTiles = numTiles2;
+    r2.recWords = r.recWords;
+    r2.shiftB = r.shiftB;
+    r2.numBins = bins2;
+    r2.hist = h.rpHist.as<uint32_t>();
+    r2.offsets = offsets2;
+    HIP_OK(hipMemsetAsync(r2.hist, 0, static_cast<size_t>(cells2) * 4, rt.stream));
+    const int grid2 = static_cast<int>(std::min<int64_t>(maxTiles2, rt.numCUs * 2));
+    VX_LAUNCH("k_rp_count2", k_rp_count2, grid2, 1024, 0, r2);
+    scanU32ToU64(r2.hist, cells2, offsets2, h.rpScan);
+    byWidth([&](auto wTag) {
+      VX_LAUNCH("k_rp_scatter2", (k_rp_scatter2<decltype(wTag)::value>), grid2, 1024, 0, r2);
+    });
+    g.recs = h.rpRecs2.as<uint64_t>();
+    g.partBegin = offsets2;
+    g.partCell = partCell;
+  }
+  g.numParts = static_cast<int64_t>(parts);
+  g.recWords = r.recWords;
+  g.numAccs = a.numAccs;
+  g.shiftB = r.shiftB;
+  g.stride = a.stride;
+  g.table = a.table;
+  g.rowBase = a.rowBase;
+  g.capacity = a.capacity;
+  g.counters = a.counters;
+  for (int j = 0; j < a.numAccs; ++j) {
+    g.kind[j] = a.accs[j].kind;
+    g.off[j] = a.accs[j].off;
+    g.valIdx[j] = r.valIdx[j];
+    g.accOfVal[j] = r.accOfVal[j];
+  }
+  const size_t ldsBytes = (static_cast<size_t>(1) << r.shiftB) * (a.numAccs * 8 + 4);
+  const int gridA = static_cast<int>(std::min<int64_t>(g.numParts, rt.numCUs * 2));
+  byWidth([&](auto wTag) {
+    VX_LAUNCH("k_rp_aggregate", (k_rp_aggregate<decltype(wTag)::value>), gridA, 512, ldsBytes, g);
+  });
+  ++h.radixLaunches;
+}
+
 void launchChunk(vx355_agg& h, AggArgs& a) {
   auto& rt = Runtime::get();
   size_t ldsBytes = 0;
@@ -2012,6 +2685,10 @@ void launchChunk(vx355_agg& h, AggArgs& a) {
     int grid = static_cast<int>(std::min<int64_t>(ceilDiv(a.numRows, 1024), rt.numCUs * 2));
     VX_LAUNCH("k_agg_lds", k_agg_lds, grid, 1024, ldsBytes, la);
   } else {
+    if (radixEligible(h, a)) {
+      launchRadix(h, a);
+      return;
+    }
     // One HBM atomic per sum and row is the budget of the high-cardinality
     // path: no hi/lo split there (few rows per group: little to gain).
     for (int j = 0; j < a.numAccs; ++j) {
@@ -2298,6 +2975,9 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
     // groups) picks the LDS layout of every later launch.
     rows = std::min(h.numGroups == 0 ? std::min<int64_t>(h.chunkRows, 1 << 20) : h.chunkRows,
                     n - begin);
+    if (h.mode == MODE_ARRAY && h.radixMinRows >= 0) {
+      rows = std::min<int64_t>(rows, 1LL << kRadixRowBits);  // radix path: 29-bit row numbers in the records
+    }
     if (h.mode == MODE_NORMALIZED) {
       // The open-addressing table is sized for the worst case "every row of the
       // chunk is a new group": keep that bound reasonable.
@@ -2593,6 +3273,15 @@ int vx355_agg_create(const vx355_agg_spec* spec, vx355_agg** out) {
   if (const char* e = std::getenv("VX355_AGG_NO_FAST")) {
     h->disableFast = e[0] == '1';
   }
+  if (const char* e = std::getenv("VX355_AGG_RADIX_MIN_ROWS")) {
+    h->radixMinRows = std::strtoll(e, nullptr, 10);  // < 0 disables the path
+  }
+  if (const char* e = std::getenv("VX355_AGG_RADIX_BINS")) {
+    h->radixMaxBins = std::max(2, std::min(kRadixMaxBins, std::atoi(e)));
+  }
+  if (const char* e = std::getenv("VX355_AGG_RADIX_TILE_ROWS")) {
+    h->radixTileRows = std::strtoll(e, nullptr, 10);
+  }
   if (const char* e = std::getenv("VX355_AGG_CHUNK_ROWS")) {
     h->chunkRows = std::max<int64_t>(64, std::strtoll(e, nullptr, 10) & ~63LL);
   }
@@ -2678,6 +3367,7 @@ int vx355_agg_get_stats(const vx355_agg* h, vx355_agg_stats* out) {
   out->num_rehashes = h->numRehashes;
   out->hash_mode = h->mode;
   out->reserved = static_cast<int32_t>(std::min<int64_t>(h->jitLaunches, INT32_MAX));
+  out->radix_launches = h->radixLaunches;
   out->input_rows = h->inputRows + h->coalescer.pendingRows();
   out->deferred_rows = h->deferredRows;
   VX_API_END

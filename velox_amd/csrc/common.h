@@ -225,6 +225,9 @@ class HostCoalescer {
   int64_t pendingRows_ = 0;
 };
 
+// Exclusive scan of n u32 cells into n + 1 u64 offsets (last = total), on the library stream.
+void scanU32ToU64(const uint32_t* in, int64_t n, uint64_t* out, DevBuf& scratch);
+
 // Copies caller-visible results out of device scratch.
 void copyOut(void* dst, int32_t dstMem, const void* devSrc, size_t bytes);
 // Same without the stream synchronisation: the caller syncs once after a batch of copies.

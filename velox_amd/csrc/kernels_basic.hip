@@ -268,6 +268,116 @@ __global__ __launch_bounds__(256) void k_partition(PartitionArgs a) {
   }
 }
 
+// ---- exclusive scan u32 -> u64 for up to ~10^8 cells: block sums, a single-block
+// scan of those, block-local scans plus base. offsets has n + 1 entries.
+constexpr int kScanBlock = 1024;
+constexpr int kScanPerThread = 8;
+constexpr int kScanTile = kScanBlock * kScanPerThread;
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_block_sums(const uint32_t* in, int64_t n, uint64_t* sums) {
+  __shared__ uint64_t partial[kScanBlock / 64];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kScanTile;
+  uint64_t s = 0;
+#pragma unroll
+  for (int j = 0; j < kScanPerThread; ++j) {
+    const int64_t i = base + j * kScanBlock + threadIdx.x;
+    s += i < n ? in[i] : 0;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s += shfl64(s, lane() ^ off);
+  }
+  if (lane() == 0) {
+    partial[threadIdx.x >> 6] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint64_t t = 0;
+    for (int w = 0; w < kScanBlock / 64; ++w) {
+      t += partial[w];
+    }
+    sums[blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_scan_sums(uint64_t* sums, int64_t n, uint64_t* total) {
+  __shared__ uint64_t partial[1024];
+  const int t = threadIdx.x;
+  const int64_t per = (n + blockDim.x - 1) / blockDim.x;
+  const int64_t begin = t * per;
+  const int64_t end = begin + per < n ? begin + per : n;
+  uint64_t sum = 0;
+  for (int64_t i = begin; i < end; ++i) {
+    sum += sums[i];
+  }
+  partial[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    uint64_t v = t >= off ? partial[t - off] : 0;
+    __syncthreads();
+    partial[t] += v;
+    __syncthreads();
+  }
+  uint64_t run = t == 0 ? 0 : partial[t - 1];
+  for (int64_t i = begin; i < end; ++i) {
+    const uint64_t v = sums[i];
+    sums[i] = run;
+    run += v;
+  }
+  if (t == blockDim.x - 1) {
+    *total = partial[1023];
+  }
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_apply(const uint32_t* in, int64_t n, const uint64_t* blockBase,
+                                                            uint64_t* out) {
+  // Thread t owns kScanPerThread CONSECUTIVE cells so that a plain running sum
+  // finishes the scan; the block-level part scans the per-thread totals.
+  __shared__ uint64_t waveTotals[kScanBlock / 64];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kScanTile + static_cast<int64_t>(threadIdx.x) * kScanPerThread;
+  uint32_t v[kScanPerThread];
+  uint64_t mine = 0;
+#pragma unroll
+  for (int j = 0; j < kScanPerThread; ++j) {
+    v[j] = base + j < n ? in[base + j] : 0;
+    mine += v[j];
+  }
+  uint64_t incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint64_t o = shfl64(incl, lane() - off >= 0 ? lane() - off : lane());
+    if (lane() >= off) {
+      incl += o;
+    }
+  }
+  if (lane() == 63) {
+    waveTotals[threadIdx.x >> 6] = incl;
+  }
+  __syncthreads();
+  uint64_t run = blockBase[blockIdx.x] + (incl - mine);
+  for (int w = 0; w < (threadIdx.x >> 6); ++w) {
+    run += waveTotals[w];
+  }
+#pragma unroll
+  for (int j = 0; j < kScanPerThread; ++j) {
+    if (base + j < n) {
+      out[base + j] = run;
+    }
+    run += v[j];
+  }
+}
+
+void scanU32ToU64(const uint32_t* in, int64_t n, uint64_t* out, DevBuf& scratch) {
+  if (n <= 0) {
+    return;
+  }
+  const int64_t blocks = ceilDiv(n, kScanTile);
+  uint64_t* sums = static_cast<uint64_t*>(scratch.ensure(static_cast<size_t>(blocks) * 8 + 64));
+  VX_LAUNCH("k_scan_block_sums", k_scan_block_sums, static_cast<int>(blocks), kScanBlock, 0, in, n, sums);
+  VX_LAUNCH("k_scan_sums", k_scan_sums, 1, 1024, 0, sums, blocks, out + n);
+  VX_LAUNCH("k_scan_apply", k_scan_apply, static_cast<int>(blocks), kScanBlock, 0, in, n, sums, out);
+}
+
 // Shared with the operators (agg.hip / join.hip).
 void compactBits(const uint64_t* dValues, const uint64_t* dNulls, const uint64_t* dRows,
                  int64_t numRows, int32_t* dOut, DevBuf& scratch, int64_t* total) {

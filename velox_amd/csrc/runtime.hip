@@ -1,6 +1,7 @@
 // libvx355 runtime: device binding, library stream, pinned mailbox, device
 // memory helpers, batch staging and the HIP-event profiler.
 #include "common.h"
+#include <cstdlib>
 
 #include <algorithm>
 #include <cstdio>
@@ -458,6 +459,13 @@ int vx355_init(int device) {
                        hipHostMallocMapped));
   HIP_OK(hipHostGetDevicePointer(reinterpret_cast<void**>(&rt.mail.dev), rt.mail.host, 0));
   std::memset(rt.mail.host, 0, vx::Mailbox::kWords * 8);
+  // Scratch blocks released by operators are kept for reuse (hipMalloc/hipFree of
+  // multi-GB blocks cost ~100 ms): up to a quarter of the device memory, or
+  // VX355_CACHE_LIMIT_GB.
+  rt.cacheLimit = static_cast<size_t>(prop.totalGlobalMem / 4);
+  if (const char* e = std::getenv("VX355_CACHE_LIMIT_GB")) {
+    rt.cacheLimit = static_cast<size_t>(std::strtoull(e, nullptr, 10)) << 30;
+  }
   rt.device = device;
   rt.initialized = true;
   VX_API_END
