@@ -51,6 +51,8 @@ def parse():
                     help="c1: feed 10 000-row host vectors instead of one resident batch")
     ap.add_argument("--q3-random-probe", action="store_true",
                     help="q3: lineitems in random order instead of dbgen's l_orderkey clustering")
+    ap.add_argument("--c4-sparse", action="store_true",
+                    help="c4: keys = splitmix64(j), j < distinct (no dense range: open-addressing mode)")
     ap.add_argument("--unfused", action="store_true",
                     help="q1: FilterProject and HashAggregation as two operators")
     return ap.parse_args()
@@ -296,6 +298,13 @@ class C4(C1):
         self.n = n
         distinct = int(os.environ.get("VX355_C4_DISTINCT", max(1, n // 10)))
         self.k = torch.randint(0, distinct, (n,), dtype=torch.int64, device=device, generator=g)
+        if getattr(self, "sparse", False):
+            # splitmix64 finaliser in wrapping int64 arithmetic (logical shifts by masking).
+            z = self.k * -7046029254386353131  # 0x9E3779B97F4A7C15
+            z = (z ^ ((z >> 30) & ((1 << 34) - 1))) * -4658895280553007687  # 0xBF58476D1CE4E5B9
+            z = (z ^ ((z >> 27) & ((1 << 37) - 1))) * -7723592293110705685  # 0x94D049BB133111EB
+            self.k = z ^ ((z >> 31) & ((1 << 33) - 1))
+            del z
         self.v = torch.rand(n, dtype=torch.float64, device=device, generator=g)
         self.batch = DevBatch([dcol(abi.BIGINT, self.k), dcol(abi.DOUBLE, self.v)], n)
         torch.cuda.synchronize()
@@ -685,6 +694,10 @@ def main():
         cls.random_probe = args.q3_random_probe
     if args.workload == "c1":
         cls.stream = args.c1_stream
+    if args.workload == "c4":
+        cls.sparse = args.c4_sparse
+        if args.c4_sparse:
+            cls.name = "c4_groupby_1b_100m_sparse_keys"
     if args.workload == "c5":
         if world == 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
