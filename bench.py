@@ -665,6 +665,20 @@ def measured_copy_ceiling(torch, device):
     return 5 * 2 * n * 8 / (start.elapsed_time(stop) * 1e-3) / 1e9
 
 
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3
+    PMC passes (PMC collection needs its own runs; bench.py cannot do it inline)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return {}
+    try:
+        entry = json.load(open(files[-1])).get(workload, {})
+    except (OSError, ValueError):
+        return {}
+    return entry if entry.get("kernel") == kernel else {}
+
+
 def physical_cores():
     """Distinct (socket, core) pairs of /proc/cpuinfo; logical CPUs / 2 if unreadable."""
     try:
@@ -801,6 +815,7 @@ def main():
     dom_ms, dom_launches = prof.get(wl.dominant, (0.0, 0))
     dom_rows = getattr(wl, "selected", wl.rows_per_step()) * args.steps
     achieved = (wl.agg_bytes_per_row * dom_rows / (dom_ms * 1e-3) / 1e9) if dom_ms > 0 else None
+    pmc = pmc_traffic(wl.name, wl.dominant)
     out = {
         "metric": "rows/s + HBM GB/s (rocprof), TPC-H Q1 agg & Q3 join SF100, 1/2/4/8 MI355X",
         "value": rows / elapsed,
@@ -827,7 +842,8 @@ def main():
             "bound": "hbm", "kernel": wl.dominant,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-            "traffic": None,
+            "traffic": pmc.get("traffic_bytes_per_launch"),
+            "traffic_source": pmc.get("source"),
             "algorithmic_bytes_per_row": wl.agg_bytes_per_row,
             "measured_copy_GBps": copy_ceiling,
             "frac_of_measured_copy": (achieved / copy_ceiling) if (achieved and copy_ceiling) else None,
