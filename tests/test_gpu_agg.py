@@ -632,3 +632,46 @@ def test_radix_path_two_keys_fused_filter(oracle, vx, monkeypatch):
     got = vx.collect_output(op, 1 << 20)
     assert_columns_equal(got, exp, op.kinds, what="radix two keys")
     assert op.stats().radix_launches == 1
+
+
+@pytest.mark.parametrize("defer_cap", [None, "64"])
+def test_mid_stream_switch_to_generic_mode(oracle, vx, defer_cap, monkeypatch):
+    """The first batches fit a normalized key (array / open-addressing mode); a later batch
+    brings values whose ranges overflow 64 bits, or a string no value id can hold (8..12 bytes).
+    The reference re-decides the hash mode and rehashes (HashTable.cpp:1751-1839); here the live
+    groups move to the generic structures and the stream carries on. defer_cap=64 makes the
+    deferred list overflow, so the outstanding rows are found by rescanning the chunk."""
+    monkeypatch.setenv("VX355_AGG_COALESCE_ROWS", "0")
+    if defer_cap:
+        monkeypatch.setenv("VX355_AGG_DEFER_CAP", defer_cap)
+    rng = np.random.default_rng(91)
+    n = 50000
+    aggs = [(abi.AGG_SUM, 3, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT), (abi.AGG_MAX, 3, abi.DOUBLE),
+            (abi.AGG_AVG, 3, abi.DOUBLE)]
+
+    def batch(lo, hi, words):
+        k1 = rng.integers(lo, hi, 500)[rng.integers(0, 500, n)].astype(np.int64)
+        k2 = rng.integers(-40, 40, n).astype(np.int32)
+        s = [words[i] for i in rng.integers(0, len(words), n)]
+        return abi.HostBatch([abi.HostColumn(abi.BIGINT, k1, rng.random(n) > 0.03), abi.HostColumn(abi.INTEGER, k2),
+                              abi.HostColumn(abi.VARCHAR, s, rng.random(n) > 0.03),
+                              abi.HostColumn(abi.DOUBLE, _dyadic(rng, n), rng.random(n) > 0.1)], n)
+    short = [b"", b"A", b"NO", b"RETURN", b"7 bytes"]
+    # (a) integer ranges overflow in the third batch
+    batches = [batch(0, 1000, short), batch(-5000, 90000, short), batch(-2 ** 62, 2 ** 62, short),
+               batch(-2 ** 62, 2 ** 62, short)]
+    for keys, kinds in [([0, 1], [abi.BIGINT, abi.INTEGER]), ([0, 2, 1], [abi.BIGINT, abi.VARCHAR, abi.INTEGER])]:
+        exp, _ = run_agg(oracle, batches, keys, kinds, aggs, max_rows=100000)
+        got, gop = run_agg(vx, batches, keys, kinds, aggs, max_rows=100000)
+        assert_columns_equal(got, exp, gop.kinds, what=f"switch on range overflow {keys}")
+        st = gop.stats()
+        assert st.hash_mode == abi.MODE_HASH and st.num_groups == len(exp[0][0])
+    # (b) a string longer than 7 bytes appears in the second batch
+    batches = [batch(0, 300, short), batch(0, 300, short + [b"8 bytes!", b"twelve bytes"]), batch(0, 300, short)]
+    for ignore in (False, True):
+        exp, _ = run_agg(oracle, batches, [2, 0], [abi.VARCHAR, abi.BIGINT], aggs, max_rows=100000,
+                         ignore_null_keys=ignore)
+        got, gop = run_agg(vx, batches, [2, 0], [abi.VARCHAR, abi.BIGINT], aggs, max_rows=100000,
+                           ignore_null_keys=ignore)
+        assert_columns_equal(got, exp, gop.kinds, what=f"switch on long string ignore={ignore}")
+        assert gop.stats().hash_mode == abi.MODE_HASH

@@ -986,7 +986,26 @@ struct GenericPart {
 struct GenericArgs {
   AggArgs a;
   GenericPart g;
+  int32_t skipInside;  // rescan after a mode switch: rows inside a.keys[].range were aggregated already
+  int32_t pad;
 };
+
+// True when every key of the row maps into the ranges in a.keys[].range, i.e.
+// the normalized-key launch that ran before the switch consumed the row.
+__device__ inline bool insideRanges(const AggArgs& a, int64_t row) {
+  for (int k = 0; k < a.numKeys; ++k) {
+    const KeyArg& ka = a.keys[k];
+    if (colIsNull(ka.col, row)) {
+      continue;
+    }
+    int64_t value;
+    bool mappable;
+    if (valueIdAt(ka.col, colIndex(ka.col, row), ka.range, &value, &mappable) == 0) {
+      return false;
+    }
+  }
+  return true;
+}
 static_assert(sizeof(GenericArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
 __global__ __launch_bounds__(256) void k_agg_generic(GenericArgs args) {
@@ -994,9 +1013,12 @@ __global__ __launch_bounds__(256) void k_agg_generic(GenericArgs args) {
   const GenericPart& g = args.g;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   uint32_t newGroups = 0;
-  for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < a.numRows;
-       row += stride) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.numRows; i += stride) {
+    const int64_t row = a.rowList ? a.rowList[i] : i;
     if (a.numTerms && !evalFilter(a.terms, a.numTerms, row)) {
+      continue;
+    }
+    if (args.skipInside && insideRanges(a, row)) {
       continue;
     }
     // Key images, null mask and the VectorHasher hash of the row.
@@ -1126,6 +1148,94 @@ __global__ __launch_bounds__(256) void k_agg_generic(GenericArgs args) {
 }
 
 // Re-inserts every group id into a larger slot array (HashTable::rehash).
+struct ToGenericArgs {
+  const uint64_t* oldTable;
+  uint64_t oldRows;
+  int32_t oldMode;
+  int32_t stride;
+  int32_t numKeys;
+  int32_t pad;
+  KeyRange range[kMaxKeys];
+  int32_t kind[kMaxKeys];
+  uint64_t* newTable;
+  GenericPart g;
+};
+
+// Mode switch normalized key / array -> generic (the reference re-decides the
+// hash mode and rehashes when a VectorHasher can no longer produce value ids,
+// HashTable.cpp:1751-1839): every live group gets a dense id, its keys are
+// decoded from the normalized key into the stored images + VectorHasher hash the
+// generic kernel compares against, and its row words move to newTable[id].
+__global__ __launch_bounds__(256) void k_to_generic(ToGenericArgs a) {
+  const uint64_t step = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  const uint64_t rounds = (a.oldRows + step - 1) / step;
+  uint64_t r = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  for (uint64_t it = 0; it < rounds; ++it, r += step) {
+    const uint64_t* src = a.oldTable + r * a.stride;
+    const bool live = r < a.oldRows && src[1] != kNoRow;
+    const uint64_t m = ballot(live);
+    if (m == 0) {
+      continue;
+    }
+    const int leader = __ffsll(static_cast<long long>(m)) - 1;
+    uint32_t base = 0;
+    if (lane() == leader) {
+      base = atomicAdd(a.g.gidCounter, static_cast<uint32_t>(popc64(m)));
+    }
+    base = __shfl(base, leader, kWave);
+    if (!live) {
+      continue;
+    }
+    const uint32_t id = base + lanePrefix(m);
+    const uint64_t key = a.oldMode == MODE_ARRAY ? r : src[0];
+    uint64_t nullMask = 0;
+    uint64_t hash = 0;
+    for (int k = 0; k < a.numKeys; ++k) {
+      const uint64_t vid = (key / a.range[k].multiplier) % a.range[k].rangeSize;
+      uint64_t w0 = 0, w1 = 0, hv = kNullHash;
+      if (vid == 0) {
+        nullMask |= 1ULL << k;
+      } else if (a.kind[k] == VX355_BOOLEAN) {
+        w0 = vid == 2 ? 1 : 0;
+        hv = vid == 2 ? ~0ULL : 0ULL;
+      } else {
+        const int64_t v = static_cast<int64_t>(vid - 1 + static_cast<uint64_t>(a.range[k].min));
+        if (a.kind[k] == VX355_VARCHAR || a.kind[k] == VX355_VARBINARY) {
+          // Inverse of stringAsNumber: the marker bit sits right above the bytes.
+          const int top = 63 - __clzll(static_cast<long long>(v));
+          const uint32_t size = static_cast<uint32_t>(top >> 3);
+          const uint64_t bytes = static_cast<uint64_t>(v) - (1ULL << top);
+          w0 = static_cast<uint64_t>(size) | ((bytes & 0xffffffffULL) << 32);
+          w1 = bytes >> 32;
+          uint8_t buf[8];
+#pragma unroll
+          for (int b = 0; b < 8; ++b) {
+            buf[b] = static_cast<uint8_t>(bytes >> (8 * b));
+          }
+          hv = hashBytes(1, buf, static_cast<int32_t>(size));
+        } else if (a.kind[k] == VX355_BIGINT) {
+          w0 = static_cast<uint64_t>(v);
+          hv = twangMix64(static_cast<uint64_t>(v));
+        } else {
+          w0 = static_cast<uint64_t>(v);
+          hv = jenkinsRevMix32(static_cast<uint32_t>(static_cast<int32_t>(v)));
+        }
+      }
+      a.g.keyStore[k][static_cast<uint64_t>(id) * a.g.keyWords[k]] = w0;
+      if (a.g.keyWords[k] == 2) {
+        a.g.keyStore[k][static_cast<uint64_t>(id) * 2 + 1] = w1;
+      }
+      hash = k == 0 ? hv : hashMix(hash, hv);
+    }
+    a.g.nullStore[id] = nullMask;
+    a.g.hashStore[id] = hash;
+    uint64_t* dst = a.newTable + static_cast<uint64_t>(id) * a.stride;
+    for (int w = 1; w < a.stride; ++w) {
+      dst[w] = src[w];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_generic_rehash(uint64_t* slots, uint64_t slotMask,
                                                          const uint64_t* hashStore, uint32_t numGroups) {
   const uint32_t step = gridDim.x * blockDim.x;
@@ -2718,8 +2828,7 @@ void checkCounters(const Counters& c) {
     VX_THROW(VX355_EUSER, "integer overflow");
   }
   if (c.unmappable) {
-    VX_THROW(VX355_EUNSUPPORTED,
-             "string grouping key longer than 7 bytes (generic hash mode not on device)");
+    VX_THROW(VX355_EINTERNAL, "unmappable grouping key outside the mode switch");
   }
   if (c.tableFull) {
     VX_THROW(VX355_EINTERNAL, "aggregation table full");
@@ -2818,50 +2927,111 @@ void shiftArgs(AggArgs& c, int64_t begin) {
   }
 }
 
-void addInputGeneric(vx355_agg& h, AggArgs& a, int64_t n) {
+// One pass of the generic kernel over 'count' rows of 'base' (whose column views
+// already start at the first row), or over rowList[0, count) when given.
+void runGeneric(vx355_agg& h, const AggArgs& base, int64_t count, uint64_t rowBase, const int32_t* rowList,
+                bool skipInside) {
+  ensureGenericCapacity(h, static_cast<uint64_t>(h.numGroups + count));
+  GenericArgs ga{};
+  ga.a = base;
+  ga.skipInside = skipInside ? 1 : 0;
+  AggArgs& c = ga.a;
+  for (int j = 0; j < c.numAccs; ++j) {
+    c.accs[j].splitM = 0;
+  }
+  c.numRows = count;
+  c.rowList = rowList;
+  c.rescanOld = nullptr;
+  c.rowBase = rowBase;
+  c.table = h.table.as<uint64_t>();
+  c.capacity = h.capacity;
+  c.mode = MODE_ARRAY;  // group row = table + group id * stride
+  GenericPart& g = ga.g;
+  g.slots = h.gSlots.as<uint64_t>();
+  g.slotMask = h.gSlotCap - 1;
+  for (size_t k = 0; k < h.keys.size(); ++k) {
+    g.keyStore[k] = h.gKeyStore[k].as<uint64_t>();
+    g.keyWords[k] = keyStoreWords(h.keys[k].kind);
+  }
+  g.nullStore = h.gNullStore.as<uint64_t>();
+  g.hashStore = h.gHashStore.as<uint64_t>();
+  g.gidCounter = h.gCounter.as<uint32_t>();
+  g.maxGroups = static_cast<uint32_t>(std::min<uint64_t>(h.gMaxGroups, 0xfffffffeULL));
+  resetCounters(h);
+  VX_LAUNCH("k_agg_generic", k_agg_generic, streamGrid(count, 256), 256, 0, ga);
+  Counters ctr = readCounters(h);
+  if (ctr.unmappable) {
+    VX_THROW(VX355_EUNSUPPORTED, "string grouping key longer than 12 bytes (not inline)");
+  }
+  checkCounters(ctr);
+  uint32_t ids = 0;
+  copyOut(&ids, VX355_MEM_HOST, h.gCounter.ptr(), 4);
+  h.numGroups = ids;
+}
+
+// Rows [from, n) of the batch 'a' describes, in chunks.
+void addInputGeneric(vx355_agg& h, AggArgs& a, int64_t n, int64_t from = 0) {
   h.mode = MODE_HASH;
   int64_t rows = 0;
-  for (int64_t begin = 0; begin < n; begin += rows) {
+  for (int64_t begin = from; begin < n; begin += rows) {
     // Every row of a chunk may be a new group: the chunk bounds the headroom the
     // group arrays need, so it grows with the table (4 M .. 64 M rows).
     const int64_t chunk = std::min<int64_t>(
         h.chunkRows, std::max<int64_t>(1 << 22, std::min<int64_t>(1 << 26, static_cast<int64_t>(h.gMaxGroups))));
     rows = std::min(chunk, n - begin);
-    ensureGenericCapacity(h, static_cast<uint64_t>(h.numGroups + rows));
-    GenericArgs ga{};
-    ga.a = a;
-    AggArgs& c = ga.a;
-    for (int j = 0; j < c.numAccs; ++j) {
-      c.accs[j].splitM = 0;
-    }
-    c.numRows = rows;
-    c.rowBase = static_cast<uint64_t>(h.inputRows + begin);
-    c.table = h.table.as<uint64_t>();
-    c.capacity = h.capacity;
-    c.mode = MODE_ARRAY;  // group row = table + group id * stride
+    AggArgs c = a;
     shiftArgs(c, begin);
-    GenericPart& g = ga.g;
-    g.slots = h.gSlots.as<uint64_t>();
-    g.slotMask = h.gSlotCap - 1;
-    for (size_t k = 0; k < h.keys.size(); ++k) {
-      g.keyStore[k] = h.gKeyStore[k].as<uint64_t>();
-      g.keyWords[k] = keyStoreWords(h.keys[k].kind);
-    }
-    g.nullStore = h.gNullStore.as<uint64_t>();
-    g.hashStore = h.gHashStore.as<uint64_t>();
-    g.gidCounter = h.gCounter.as<uint32_t>();
-    g.maxGroups = static_cast<uint32_t>(std::min<uint64_t>(h.gMaxGroups, 0xfffffffeULL));
-    resetCounters(h);
-    VX_LAUNCH("k_agg_generic", k_agg_generic, streamGrid(rows, 256), 256, 0, ga);
-    Counters ctr = readCounters(h);
-    if (ctr.unmappable) {
-      VX_THROW(VX355_EUNSUPPORTED, "string grouping key longer than 12 bytes (not inline)");
-    }
-    checkCounters(ctr);
-    uint32_t ids = 0;
-    copyOut(&ids, VX355_MEM_HOST, h.gCounter.ptr(), 4);
-    h.numGroups = ids;
+    runGeneric(h, c, rows, static_cast<uint64_t>(h.inputRows + begin), nullptr, false);
   }
+}
+
+// Keys stopped fitting a 64-bit normalized key in the middle of the stream (or
+// a string key longer than 7 bytes showed up): move the live groups into the
+// generic-mode structures and carry on there.
+void switchToGeneric(vx355_agg& h) {
+  auto& rt = Runtime::get();
+  const uint64_t live = static_cast<uint64_t>(h.numGroups);
+  const uint64_t newMax = std::max<uint64_t>(live + live / 2, 1024);
+  h.gKeyStore.clear();
+  h.gKeyStore.resize(h.keys.size());
+  h.gCounter.ensure(64);
+  HIP_OK(hipMemsetAsync(h.gCounter.ptr(), 0, 64, rt.stream));
+  ToGenericArgs ta{};
+  for (size_t k = 0; k < h.keys.size(); ++k) {
+    const size_t w = static_cast<size_t>(keyStoreWords(h.keys[k].kind)) * 8;
+    h.gKeyStore[k].ensure(newMax * w + 64);
+    ta.g.keyStore[k] = h.gKeyStore[k].as<uint64_t>();
+    ta.g.keyWords[k] = keyStoreWords(h.keys[k].kind);
+    ta.range[k] = h.keys[k].range;
+    ta.kind[k] = h.keys[k].kind;
+  }
+  h.gNullStore.ensure(newMax * 8 + 64);
+  h.gHashStore.ensure(newMax * 8 + 64);
+  DevBuf fresh;
+  initTable(h, fresh, newMax);
+  if (h.tableReady && live > 0) {
+    ta.oldTable = h.table.as<uint64_t>();
+    ta.oldRows = h.capacity;
+    ta.oldMode = h.mode;
+    ta.stride = h.stride;
+    ta.numKeys = static_cast<int32_t>(h.keys.size());
+    ta.newTable = fresh.as<uint64_t>();
+    ta.g.nullStore = h.gNullStore.as<uint64_t>();
+    ta.g.hashStore = h.gHashStore.as<uint64_t>();
+    ta.g.gidCounter = h.gCounter.as<uint32_t>();
+    VX_LAUNCH("k_to_generic", k_to_generic, streamGrid(static_cast<int64_t>(h.capacity), 256), 256, 0, ta);
+    ++h.numRehashes;
+  }
+  rt.sync();
+  h.table = std::move(fresh);
+  h.capacity = newMax;
+  h.gMaxGroups = newMax;
+  h.tableReady = true;
+  h.generic = true;
+  h.mode = MODE_HASH;
+  h.gSlotCap = 0;
+  h.gSlots.release();
+  ensureGenericCapacity(h, live);  // builds the slot array from the stored hashes
 }
 
 void addInput(vx355_agg& h, const vx355_batch* batch);
@@ -3076,6 +3246,10 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
       }
       launchChunk(h, c);
       Counters ctr = readCounters(h);
+      // A key no VectorHasher range can hold (string longer than 7 bytes): its
+      // rows were deferred; they force the generic mode below.
+      bool toGeneric = ctr.unmappable != 0;
+      ctr.unmappable = 0;
       checkCounters(ctr);
       h.numGroups += ctr.numNewGroups;
       pending = ctr.numDeferred;
@@ -3096,7 +3270,36 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
                  static_cast<size_t>(pending) * 4);
           list = replayList.as<int32_t>();
         }
-        rebuildTable(h, static_cast<uint64_t>(pending));
+        if (!toGeneric) {
+          try {
+            rebuildTable(h, static_cast<uint64_t>(pending));
+          } catch (const Error& e) {
+            if (e.status != VX355_EUNSUPPORTED) {
+              throw;
+            }
+            toGeneric = true;  // the widened ranges no longer fit 64 bits
+          }
+        }
+        if (toGeneric) {
+          // decideHashMode falls back to kHash in the middle of the stream
+          // (HashTable.cpp:1751-1839): convert the table, finish this chunk's
+          // outstanding rows and the rest of the batch in generic mode.
+          switchToGeneric(h);
+          for (int k = 0; k < c.numKeys; ++k) {
+            c.keys[k].range = used[k];
+          }
+          if (rescan) {
+            runGeneric(h, c, rows, c.rowBase, nullptr, true);
+          } else {
+            for (int64_t at = 0; at < pending; at += 1 << 22) {
+              runGeneric(h, c, std::min<int64_t>(1 << 22, pending - at), c.rowBase, list + at, false);
+            }
+          }
+          addInputGeneric(h, a, n, begin + rows);
+          h.inputRows += n;
+          rt.sync();
+          return;
+        }
       }
     }
   }
