@@ -453,6 +453,46 @@ typedef struct vx355_join_table_stats {
 } vx355_join_table_stats;
 int vx355_join_table_get_stats(const vx355_join_table* t, vx355_join_table_stats* out);
 
+/* ---- dynamic filters from the build side (HashProbe::pushdownDynamicFilters,
+ * exec/HashProbe.cpp:408-457) --------------------------------------------------
+ * After the table is finished the reference pushes one filter per join key to
+ * the probe-side scan: VectorHasher::getFilter (exec/VectorHasher.cpp:731-780)
+ * -> common::createBigintValues (type/Filter.cpp:1052-1114: BigintRange /
+ * bitmask / hash table, decided from min, max and the value list) while the
+ * key has at most kMaxDistinct = 100'000 distinct values
+ * (exec/VectorHasher.h:139), else a BigintValuesUsingBloomFilter
+ * (type/Filter.h:1294-1360: SplitBlockBloomFilter over folly::hasher<int64_t>,
+ * sized by numBlocks(table.numDistinct, 0.01); HashTable.cpp:1133-1188).
+ * The shim asks for the description, then for the value list or the Bloom
+ * blocks, and constructs the common::Filter on the Velox side. Integer key
+ * kinds only (TINYINT..BIGINT, DATE as INTEGER); other kinds report NONE. */
+enum vx355_key_filter_kind {
+  VX355_KEY_FILTER_NONE = 0,
+  VX355_KEY_FILTER_VALUES = 1, /* <= 100'000 distinct values: fetch them with _values */
+  VX355_KEY_FILTER_BLOOM = 2   /* more: fetch Bloom blocks with _bloom */
+};
+typedef struct vx355_key_filter {
+  int32_t kind;          /* vx355_key_filter_kind */
+  int32_t pad;
+  int64_t min, max;      /* over the non-null build values of the key (kind != NONE) */
+  int64_t num_distinct;  /* VALUES: exact count; BLOOM: the table's distinct-key count (the capacity the reference sizes with) */
+} vx355_key_filter;
+int vx355_join_table_key_filter(vx355_join_table* t, int32_t key, vx355_key_filter* out);
+/* Ascending distinct values of the key; capacity >= num_distinct. */
+int vx355_join_table_key_filter_values(vx355_join_table* t, int32_t key, int64_t* values_out, int64_t capacity,
+                                       int32_t mem, int64_t* n_out);
+/* SplitBlockBloomFilter::numBlocks (common/base/SplitBlockBloomFilter.cpp:27-34) for blocks of 'lanes'
+ * 32-bit words: 8 = 256-bit SIMD hosts (AVX2), 4 = 128-bit (SSE / NEON). */
+int64_t vx355_bloom_num_blocks(int64_t num_elements, double false_positive, int32_t lanes);
+/* Fills num_blocks * lanes u32 words (zeroed first) with every non-null build value of the key:
+ * bit-identical to inserting them into the reference's SplitBlockBloomFilter of that block width. */
+int vx355_join_table_key_filter_bloom(vx355_join_table* t, int32_t key, int32_t lanes, uint32_t* blocks_out,
+                                      int64_t num_blocks, int32_t mem);
+/* BigintValuesUsingBloomFilter::testInt64 over a column (device-side scans): rows_out = rows (all if NULL)
+ * AND value is not null AND mayContain(value). 'blocks' and the bitmaps live in 'mem'. */
+int vx355_bloom_test(const uint32_t* blocks, int64_t num_blocks, int32_t lanes, const vx355_column* column,
+                     int32_t num_rows, const uint64_t* rows, uint64_t* rows_out, int32_t mem);
+
 typedef struct vx355_join_probe_spec {
   int32_t num_keys;
   const int32_t* key_cols; /* probe-side key columns */

@@ -701,6 +701,54 @@ uint32_t orc_xxh32_u32(uint32_t value, uint32_t seed) { return xxh32U32(value, s
 uint64_t orc_hash_value(int32_t type_kind, const void* value) { return hashValue(type_kind, value); }
 const char* orc_last_error(void) { return gLastError.c_str(); }
 
+// ---- SplitBlockBloomFilter (common/base/SplitBlockBloomFilter.h) ----------------------
+// A block is 'lanes' 32-bit words (one SIMD register of the host the reference
+// runs on). makeSaltsVec (:96-121): 8 lanes use all salts, 4 lanes every other one.
+static const uint32_t kBloomSalts[8] = {0x2df1424bU, 0x44974d91U, 0x47b6137bU, 0x5c6bfb31U,
+                                        0x705495c7U, 0x8824ad5bU, 0x9efc4947U, 0xa2b7289dU};
+
+int64_t orc_bloom_num_blocks(int64_t num_elements, double false_positive, int32_t lanes) {
+  // SplitBlockBloomFilter.cpp:27-34.
+  const int k = lanes;
+  const int64_t numBits = static_cast<int64_t>(
+      std::ceil(-k * num_elements / std::log(1 - std::pow(false_positive, 1.0 / k))));
+  const int64_t blockBits = 8 * static_cast<int64_t>(sizeof(uint32_t)) * lanes;
+  return (numBits + blockBits - 1) / blockBits;
+}
+
+static inline uint64_t bloomBlockIndex(uint64_t hash, int64_t numBlocks) {
+  return ((hash >> 32) * static_cast<uint64_t>(numBlocks)) >> 32;  // :91-93
+}
+
+static inline uint32_t bloomLaneBit(uint64_t hash, int32_t lanes, int lane) {
+  // makeMask(uint32_t hash) (:123-126): (salt * hash) >> 27 selects the bit of the lane.
+  const uint32_t salt = lanes == 8 ? kBloomSalts[lane] : kBloomSalts[2 * lane];
+  return 1u << ((salt * static_cast<uint32_t>(hash)) >> 27);
+}
+
+void orc_bloom_insert(uint32_t* blocks, int64_t num_blocks, int32_t lanes, const int64_t* values, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) {
+    const uint64_t h = twangMix64(static_cast<uint64_t>(values[i]));  // type/Filter.h:1354-1359
+    uint32_t* block = blocks + bloomBlockIndex(h, num_blocks) * lanes;
+    for (int l = 0; l < lanes; ++l) {
+      block[l] |= bloomLaneBit(h, lanes, l);  // insert (:72-76)
+    }
+  }
+}
+
+void orc_bloom_test(const uint32_t* blocks, int64_t num_blocks, int32_t lanes, const int64_t* values, int64_t n,
+                    uint8_t* may_contain_out) {
+  for (int64_t i = 0; i < n; ++i) {
+    const uint64_t h = twangMix64(static_cast<uint64_t>(values[i]));
+    const uint32_t* block = blocks + bloomBlockIndex(h, num_blocks) * lanes;
+    bool all = true;
+    for (int l = 0; l < lanes; ++l) {
+      all = all && (block[l] & bloomLaneBit(h, lanes, l));  // mayContain (:81-88)
+    }
+    may_contain_out[i] = all ? 1 : 0;
+  }
+}
+
 int orc_hash_columns(const vx355_batch* batch, const int32_t* key_cols, int32_t n_keys,
                      const uint64_t* rows, int32_t mix_first, uint64_t* out) {
   ORC_TRY

@@ -115,6 +115,14 @@ int orc_join_probe_get_output(orc_join_probe* h, int32_t max_rows, int32_t* mapp
                               int32_t* n_out, int32_t* finished);
 void orc_join_probe_destroy(orc_join_probe* h);
 
+/* SplitBlockBloomFilter (common/base/SplitBlockBloomFilter.h:26-129, .cpp:27-34) as used by
+ * BigintValuesUsingBloomFilter (type/Filter.h:1294-1360): hash = folly::hasher<int64_t>.
+ * 'lanes' = xsimd::batch<uint32_t>::size of the host the reference was built for (8 or 4). */
+int64_t orc_bloom_num_blocks(int64_t num_elements, double false_positive, int32_t lanes);
+void orc_bloom_insert(uint32_t* blocks, int64_t num_blocks, int32_t lanes, const int64_t* values, int64_t n);
+void orc_bloom_test(const uint32_t* blocks, int64_t num_blocks, int32_t lanes, const int64_t* values, int64_t n,
+                    uint8_t* may_contain_out);
+
 #ifdef __cplusplus
 }
 #endif

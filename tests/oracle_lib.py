@@ -48,6 +48,12 @@ def lib():
     L.orc_hash_value.restype = u64
     L.orc_hash_value.argtypes = [i32, vp]
     L.orc_last_error.restype = C.c_char_p
+    L.orc_bloom_num_blocks.restype = C.c_int64
+    L.orc_bloom_num_blocks.argtypes = [C.c_int64, C.c_double, i32]
+    L.orc_bloom_insert.restype = None
+    L.orc_bloom_insert.argtypes = [vp, C.c_int64, i32, vp, C.c_int64]
+    L.orc_bloom_test.restype = None
+    L.orc_bloom_test.argtypes = [vp, C.c_int64, i32, vp, C.c_int64, vp]
     L.orc_hash_columns.argtypes = [C.POINTER(abi.Batch), C.POINTER(i32), i32, vp, i32, vp]
     L.orc_hasher_create.restype = vp
     L.orc_hasher_create.argtypes = [i32]
@@ -213,6 +219,27 @@ def filter_project(batch, terms, projs, with_nulls=False):
     m = cnt.value
     return (idx[:m].copy(), [o[:m].copy() for o in outs],
             [abi.unpack_bits(x, m) for x in nulls] if with_nulls else None)
+
+
+def bloom_num_blocks(n, false_positive=0.01, lanes=8):
+    return lib().orc_bloom_num_blocks(n, false_positive, lanes)
+
+
+def bloom_build(values, lanes=8, false_positive=0.01, capacity=None):
+    """SplitBlockBloomFilter over folly::hasher<int64_t> -> uint32[num_blocks, lanes]."""
+    values = np.ascontiguousarray(values, dtype=np.int64)
+    nb = bloom_num_blocks(max(1, len(values) if capacity is None else capacity), false_positive, lanes)
+    blocks = np.zeros((nb, lanes), dtype=np.uint32)
+    lib().orc_bloom_insert(blocks.ctypes.data, nb, lanes, values.ctypes.data, len(values))
+    return blocks
+
+
+def bloom_test(blocks, values):
+    values = np.ascontiguousarray(values, dtype=np.int64)
+    out = np.zeros(max(1, len(values)), dtype=np.uint8)
+    lib().orc_bloom_test(blocks.ctypes.data, blocks.shape[0], blocks.shape[1], values.ctypes.data, len(values),
+                         out.ctypes.data)
+    return out[:len(values)].astype(bool)
 
 
 def partition(hashes, kind, num_partitions=0, bit_begin=0, bit_end=0):

@@ -286,3 +286,40 @@ def test_join_generic_hash_mode_keys(oracle, vx, join_type):
             if impl is vx:
                 assert st.hash_mode == abi.MODE_HASH, name
         assert results[oracle.__name__] == results[vx.__name__], name
+
+
+def test_dynamic_filters_from_the_build_side(oracle, vx):
+    """HashProbe::pushdownDynamicFilters (HashProbe.cpp:408-457): per join key either the distinct
+    value list (<= VectorHasher::kMaxDistinct = 100 000 values -> createBigintValues) or Bloom
+    blocks bit-identical to the reference's SplitBlockBloomFilter over folly::hasher<int64_t>."""
+    from velox_amd import ops
+    rng = np.random.default_rng(55)
+    nb = 300000
+    k0 = rng.integers(-2 ** 40, 2 ** 40, 200000)[rng.integers(0, 200000, nb)].astype(np.int64)  # > 100 K distinct
+    k1 = rng.integers(-500, 700, nb).astype(np.int32)                                           # few distinct
+    valid0 = rng.random(nb) > 0.02
+    s = [[b"a", b"bb"][i] for i in rng.integers(0, 2, nb)]
+    halves = [slice(0, nb // 2), slice(nb // 2, nb)]
+    batches = [[batch_of([k0[h], k1[h], s[h]], [valid0[h], None, None])] for h in halves]
+    table, builds = _build(vx, batches, [0, 1, 2], [abi.BIGINT, abi.INTEGER, abi.VARCHAR], [], [], abi.JOIN_INNER)
+    kept0, kept1 = k0[valid0], k1[valid0]   # rows with a null key never reach the table
+    # key 1: value list
+    f1 = table.key_filter(1)
+    assert f1.kind == abi.KEY_FILTER_VALUES and (f1.min, f1.max) == (kept1.min(), kept1.max())
+    assert (table.key_filter_values(1) == np.unique(kept1)).all() and f1.num_distinct == len(np.unique(kept1))
+    # key 0: Bloom blocks, both SIMD widths, equal to the reference algorithm's blocks
+    f0 = table.key_filter(0)
+    assert f0.kind == abi.KEY_FILTER_BLOOM and (f0.min, f0.max) == (kept0.min(), kept0.max())
+    assert f0.num_distinct == table.stats().num_distinct
+    for lanes in (8, 4):
+        blocks = table.key_filter_bloom(0, lanes)
+        assert blocks.shape[0] == oracle.bloom_num_blocks(f0.num_distinct, 0.01, lanes)
+        exp = oracle.bloom_build(kept0, lanes, capacity=f0.num_distinct)
+        assert (blocks == exp).all()
+        # device-side test of a probe column: never a false negative, nulls and unselected rows fail
+        probe = np.concatenate([kept0[:5000], rng.integers(-2 ** 40, 2 ** 40, 20000)]).astype(np.int64)
+        pvalid = rng.random(len(probe)) > 0.1
+        got = ops.bloom_test(blocks, abi.HostColumn(abi.BIGINT, probe, pvalid))
+        assert (got == (oracle.bloom_test(exp, probe) & pvalid)).all() and got[:5000][pvalid[:5000]].all()
+    # string keys: no filter (VectorHasher::getFilter for strings needs the opt-in config; not offered)
+    assert table.key_filter(2).kind == abi.KEY_FILTER_NONE

@@ -353,3 +353,28 @@ def test_min_of_all_nan_group_is_nan(oracle):
                       [(abi.AGG_MIN, 1, abi.DOUBLE), (abi.AGG_MAX, 1, abi.DOUBLE)])
     assert math.isnan(out[1][0][0]) and out[1][0][1] == np.inf and out[1][0][2] == 1.0
     assert math.isnan(out[2][0][0]) and math.isnan(out[2][0][1]) and out[2][0][2] == 1.0
+
+
+def test_split_block_bloom_filter_known_answers_and_properties(oracle):
+    """SplitBlockBloomFilterTest.cpp: numBlocks known answers (:42-51, both SIMD widths),
+    no false negatives and < 3 % false positives for contiguous and random values with
+    folly::hasher (:53-126)."""
+    assert oracle.bloom_num_blocks(50_000_000, 0.01, 8) * 32 == 60509568
+    assert oracle.bloom_num_blocks(50_000_000, 0.01, 4) * 16 == 65766912
+    assert oracle.bloom_num_blocks(45_523_964, 0.1, 8) * 32 == 32848640
+    assert oracle.bloom_num_blocks(45_523_964, 0.1, 4) * 16 == 27546352
+    rng = np.random.default_rng(42)
+    size = 100_000
+    for lanes in (8, 4):
+        members = np.flatnonzero(rng.integers(0, 10, size) == 0).astype(np.int64)
+        blocks = oracle.bloom_build(members, lanes)
+        got = oracle.bloom_test(blocks, np.arange(size, dtype=np.int64))
+        is_member = np.zeros(size, dtype=bool)
+        is_member[members] = True
+        assert got[is_member].all()
+        assert got[~is_member].mean() < 0.03
+        values = rng.integers(-2 ** 63, 2 ** 63 - 1, size, dtype=np.int64)
+        blocks = oracle.bloom_build(values, lanes)
+        assert oracle.bloom_test(blocks, values).all()
+        others = rng.integers(-2 ** 63, 2 ** 63 - 1, size, dtype=np.int64)
+        assert oracle.bloom_test(blocks, others).mean() < 0.03

@@ -80,6 +80,14 @@ class AggStats(C.Structure):
                 ("deferred_rows", C.c_int64), ("radix_launches", C.c_int64)]
 
 
+class KeyFilter(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("pad", C.c_int32), ("min", C.c_int64), ("max", C.c_int64),
+                ("num_distinct", C.c_int64)]
+
+
+KEY_FILTER_NONE, KEY_FILTER_VALUES, KEY_FILTER_BLOOM = 0, 1, 2
+
+
 class JoinBuildSpec(C.Structure):
     _fields_ = [("num_keys", C.c_int32), ("key_cols", C.POINTER(C.c_int32)),
                 ("key_types", C.POINTER(C.c_int32)), ("num_dependents", C.c_int32),

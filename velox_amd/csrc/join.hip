@@ -36,6 +36,7 @@ namespace vx {
 
 void compactBits(const uint64_t* dValues, const uint64_t* dNulls, const uint64_t* dRows,
                  int64_t numRows, int32_t* dOut, DevBuf& scratch, int64_t* total);
+void sortKeysU64(const uint64_t* in, uint64_t* out, size_t n, DevBuf& tmp);
 
 namespace {
 
@@ -887,6 +888,9 @@ struct vx355_join_table {
   int64_t numDistinct = 0;
   bool hasDuplicates = false;
   bool hasNullKeys = false;
+  // dynamic filters: ascending distinct values per key, computed on first request
+  std::vector<DevBuf> distinctVals;
+  std::vector<int64_t> distinctCount;  // -1 = not computed
 };
 
 struct vx355_join_probe {
@@ -1164,9 +1168,9 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
   t->hasDuplicates = c.duplicates != 0;
   t->depVals = std::move(h.depVals);
   t->depValid = std::move(h.depValid);
-  if (t->mode == JMODE_HASH) {
-    t->keyStore = std::move(h.keyVals);  // the probe compares against the build key images
-  }
+  // The build key images stay with the table: generic-mode probes compare
+  // against them, dynamic filters (value lists, Bloom blocks) are made from them.
+  t->keyStore = std::move(h.keyVals);
   h.keyVals.clear();
   h.finished = true;
   return t.release();
@@ -1337,6 +1341,140 @@ void probeGetOutput(vx355_join_probe& p, int32_t maxRows, int32_t* mappingOut, i
   *finished = p.cursor >= p.totalOut ? 1 : 0;
 }
 
+
+// ---- dynamic filters (HashProbe::pushdownDynamicFilters, HashProbe.cpp:408-457) ----
+constexpr int64_t kMaxDistinctForValues = 100000;  // VectorHasher::kMaxDistinct (VectorHasher.h:139)
+
+// SplitBlockBloomFilter::makeSaltsVec (common/base/SplitBlockBloomFilter.h:96-121).
+__device__ __host__ inline uint32_t bloomSalt(int lanes, int lane) {
+  constexpr uint32_t kSalts[8] = {0x2df1424bU, 0x44974d91U, 0x47b6137bU, 0x5c6bfb31U,
+                                  0x705495c7U, 0x8824ad5bU, 0x9efc4947U, 0xa2b7289dU};
+  return lanes == 8 ? kSalts[lane] : kSalts[2 * lane];
+}
+
+// insert(hash): block = ((hash >> 32) * numBlocks) >> 32; per lane the bit
+// (salt * uint32(hash)) >> 27 (SplitBlockBloomFilter.h:72-76,91-93,123-126).
+__global__ __launch_bounds__(256) void k_bloom_insert(const uint64_t* values, int64_t n, uint32_t* blocks,
+                                                       uint64_t numBlocks, int32_t lanes) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint64_t h = twangMix64(values[i]);  // folly::hasher<int64_t> (type/Filter.h:1354-1359)
+    uint32_t* block = blocks + (((h >> 32) * numBlocks) >> 32) * lanes;
+    const uint32_t low = static_cast<uint32_t>(h);
+    for (int l = 0; l < lanes; ++l) {
+      const uint32_t bit = 1u << ((bloomSalt(lanes, l) * low) >> 27);
+      if (!(__hip_atomic_load(block + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) {
+        atomicOr(block + l, bit);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bloom_test(ColView col, int64_t numRows, const uint32_t* blocks,
+                                                     uint64_t numBlocks, int32_t lanes, const uint64_t* rows,
+                                                     uint64_t* rowsOut) {
+  const int64_t numWords = (numRows + 63) >> 6;
+  const int64_t waveStride = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+  for (int64_t w = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6; w < numWords;
+       w += waveStride) {
+    const int64_t row = (w << 6) + lane();
+    bool pass = row < numRows && (!rows || bitAt(rows, row)) && !colIsNull(col, row);
+    if (pass) {
+      const uint64_t h = twangMix64(static_cast<uint64_t>(loadInt64(col, colIndex(col, row))));
+      const uint32_t* block = blocks + (((h >> 32) * numBlocks) >> 32) * lanes;
+      const uint32_t low = static_cast<uint32_t>(h);
+      for (int l = 0; l < lanes; ++l) {
+        pass = pass && ((block[l] >> ((bloomSalt(lanes, l) * low) >> 27)) & 1u);
+      }
+    }
+    const uint64_t word = ballot(pass);
+    if (lane() == 0) {
+      rowsOut[w] = word;
+    }
+  }
+}
+
+// Signed order through an unsigned sort.
+__global__ __launch_bounds__(256) void k_flip_sign(const uint64_t* in, uint64_t* out, int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    out[i] = in[i] ^ (1ULL << 63);
+  }
+}
+
+// bit i = sorted[i] starts a run.
+__global__ __launch_bounds__(256) void k_run_starts(const uint64_t* sorted, int64_t n, uint64_t* bits) {
+  const int64_t numWords = (n + 63) >> 6;
+  const int64_t waveStride = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+  for (int64_t w = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6; w < numWords;
+       w += waveStride) {
+    const int64_t i = (w << 6) + lane();
+    const bool start = i < n && (i == 0 || sorted[i] != sorted[i - 1]);
+    const uint64_t word = ballot(start);
+    if (lane() == 0) {
+      bits[w] = word;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gather_flipped(const uint64_t* sorted, const int32_t* idx, int64_t n,
+                                                         uint64_t* out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    out[i] = sorted[idx[i]] ^ (1ULL << 63);
+  }
+}
+
+bool filterableKey(const vx355_join_table& t, int32_t key) {
+  const int32_t kind = t.keyKinds.at(key);
+  return kind >= VX355_TINYINT && kind <= VX355_BIGINT;
+}
+
+// Distinct non-null build values of one key, ascending (uniqueValues_ of the
+// build-side VectorHasher, as a sorted list). Computed once per key.
+int64_t distinctKeyValues(vx355_join_table& t, int32_t key) {
+  auto& rt = Runtime::get();
+  if (t.distinctCount.empty()) {
+    t.distinctCount.assign(t.keyKinds.size(), -1);
+    t.distinctVals.resize(t.keyKinds.size());
+  }
+  if (t.distinctCount[key] >= 0) {
+    return t.distinctCount[key];
+  }
+  const int64_t n = t.numRows;
+  if (n == 0) {
+    t.distinctCount[key] = 0;
+    return 0;
+  }
+  DevBuf flipped, sorted, tmp, bits, idx, scratch;
+  flipped.ensure(static_cast<size_t>(n) * 8 + 64);
+  sorted.ensure(static_cast<size_t>(n) * 8 + 64);
+  VX_LAUNCH("k_flip_sign", k_flip_sign, streamGrid(n, 256), 256, 0, t.keyStore[key].as<uint64_t>(),
+            flipped.as<uint64_t>(), n);
+  sortKeysU64(flipped.as<uint64_t>(), sorted.as<uint64_t>(), static_cast<size_t>(n), tmp);
+  bits.ensure(static_cast<size_t>(ceilDiv(n, 64)) * 8 + 64);
+  VX_LAUNCH("k_run_starts", k_run_starts, streamGrid(n, 256), 256, 0, sorted.as<uint64_t>(), n,
+            bits.as<uint64_t>());
+  idx.ensure(static_cast<size_t>(n) * 4 + 64);
+  int64_t total = 0;
+  compactBits(bits.as<uint64_t>(), nullptr, nullptr, n, idx.as<int32_t>(), scratch, &total);
+  t.distinctVals[key].ensure(static_cast<size_t>(std::max<int64_t>(1, total)) * 8 + 64);
+  VX_LAUNCH("k_gather_flipped", k_gather_flipped, streamGrid(total, 256), 256, 0, sorted.as<uint64_t>(),
+            idx.as<int32_t>(), total, t.distinctVals[key].as<uint64_t>());
+  rt.sync();
+  t.distinctCount[key] = total;
+  return total;
+}
+
+int64_t bloomNumBlocks(int64_t numElements, double falsePositive, int32_t lanes) {
+  // SplitBlockBloomFilter::numBlocks (SplitBlockBloomFilter.cpp:27-34), K = lanes.
+  const double k = lanes;
+  const int64_t numBits =
+      static_cast<int64_t>(std::ceil(-k * numElements / std::log(1 - std::pow(falsePositive, 1.0 / k))));
+  const int64_t blockBits = 32LL * lanes;
+  return (numBits + blockBits - 1) / blockBits;
+}
+
 }  // namespace
 }  // namespace vx
 
@@ -1492,6 +1630,120 @@ void vx355_join_probe_destroy(vx355_join_probe* h) {
     delete h;
   }
   vx355_join_table_release(t);
+}
+
+int vx355_join_table_key_filter(vx355_join_table* t, int32_t key, vx355_key_filter* out) {
+  VX_API_BEGIN
+  Runtime::get().requireInit();
+  VX_CHECK_ARG(t && out, "NULL argument");
+  VX_CHECK_ARG(key >= 0 && key < static_cast<int32_t>(t->keyKinds.size()), "no such key");
+  *out = vx355_key_filter{};
+  if (!filterableKey(*t, key)) {
+    return VX355_OK;  // VectorHasher::getFilter returns nullptr (VectorHasher.cpp:776-778)
+  }
+  const int64_t distinct = distinctKeyValues(*t, key);
+  out->min = t->ranges[key].min;
+  out->max = t->ranges[key].max;
+  if (distinct <= kMaxDistinctForValues) {
+    out->kind = VX355_KEY_FILTER_VALUES;
+    out->num_distinct = distinct;
+  } else {
+    out->kind = VX355_KEY_FILTER_BLOOM;
+    out->num_distinct = t->numDistinct;  // HashTable.cpp:966-971 sizes with the table's distinct keys
+  }
+  VX_API_END
+}
+
+int vx355_join_table_key_filter_values(vx355_join_table* t, int32_t key, int64_t* values_out, int64_t capacity,
+                                       int32_t mem, int64_t* n_out) {
+  VX_API_BEGIN
+  Runtime::get().requireInit();
+  VX_CHECK_ARG(t && n_out, "NULL argument");
+  VX_CHECK_ARG(key >= 0 && key < static_cast<int32_t>(t->keyKinds.size()), "no such key");
+  if (!filterableKey(*t, key)) {
+    VX_THROW(VX355_EUNSUPPORTED, "no value filter for this key type");
+  }
+  const int64_t distinct = distinctKeyValues(*t, key);
+  *n_out = distinct;
+  VX_CHECK_ARG(capacity >= distinct, "values_out too small");
+  if (distinct > 0) {
+    VX_CHECK_ARG(values_out, "NULL argument");
+    copyOut(values_out, mem, t->distinctVals[key].ptr(), static_cast<size_t>(distinct) * 8);
+  }
+  VX_API_END
+}
+
+int64_t vx355_bloom_num_blocks(int64_t num_elements, double false_positive, int32_t lanes) {
+  if ((lanes != 4 && lanes != 8) || num_elements < 0 || !(false_positive > 0 && false_positive < 1)) {
+    return -1;
+  }
+  return bloomNumBlocks(num_elements, false_positive, lanes);
+}
+
+int vx355_join_table_key_filter_bloom(vx355_join_table* t, int32_t key, int32_t lanes, uint32_t* blocks_out,
+                                      int64_t num_blocks, int32_t mem) {
+  VX_API_BEGIN
+  auto& rt = Runtime::get();
+  rt.requireInit();
+  VX_CHECK_ARG(t && blocks_out, "NULL argument");
+  VX_CHECK_ARG(key >= 0 && key < static_cast<int32_t>(t->keyKinds.size()), "no such key");
+  VX_CHECK_ARG(lanes == 4 || lanes == 8, "lanes must be 4 or 8");
+  VX_CHECK_ARG(num_blocks > 0, "num_blocks must be positive");
+  if (!filterableKey(*t, key)) {
+    VX_THROW(VX355_EUNSUPPORTED, "no Bloom filter for this key type");  // supportsBloomFilter, VectorHasher.h:270-283
+  }
+  const size_t bytes = static_cast<size_t>(num_blocks) * lanes * 4;
+  DevBuf scratch;
+  uint32_t* blocks = mem == VX355_MEM_HOST ? static_cast<uint32_t*>(scratch.ensure(bytes + 64)) : blocks_out;
+  HIP_OK(hipMemsetAsync(blocks, 0, bytes, rt.stream));
+  if (t->numRows > 0) {
+    VX_LAUNCH("k_bloom_insert", k_bloom_insert, streamGrid(t->numRows, 256), 256, 0,
+              t->keyStore[key].as<uint64_t>(), t->numRows, blocks, static_cast<uint64_t>(num_blocks), lanes);
+  }
+  if (mem == VX355_MEM_HOST) {
+    copyOut(blocks_out, VX355_MEM_HOST, blocks, bytes);
+  }
+  rt.sync();
+  VX_API_END
+}
+
+int vx355_bloom_test(const uint32_t* blocks, int64_t num_blocks, int32_t lanes, const vx355_column* column,
+                     int32_t num_rows, const uint64_t* rows, uint64_t* rows_out, int32_t mem) {
+  VX_API_BEGIN
+  auto& rt = Runtime::get();
+  rt.requireInit();
+  VX_CHECK_ARG(blocks && column && rows_out, "NULL argument");
+  VX_CHECK_ARG(lanes == 4 || lanes == 8, "lanes must be 4 or 8");
+  VX_CHECK_ARG(num_blocks > 0 && num_rows >= 0, "bad sizes");
+  VX_CHECK_ARG(column->type_kind >= VX355_TINYINT && column->type_kind <= VX355_BIGINT, "integer columns only");
+  if (num_rows == 0) {
+    return VX355_OK;
+  }
+  vx355_batch one{num_rows, 1, column};
+  DeviceBatch db;
+  db.load(&one, std::vector<int32_t>{0});
+  const size_t words = static_cast<size_t>(ceilDiv(num_rows, 64));
+  const size_t blockBytes = static_cast<size_t>(num_blocks) * lanes * 4;
+  DevBuf dBlocks, dRows, dOut;
+  const uint32_t* b = blocks;
+  const uint64_t* r = rows;
+  uint64_t* o = rows_out;
+  if (mem == VX355_MEM_HOST) {
+    copyIn(dBlocks.ensure(blockBytes + 64), blocks, VX355_MEM_HOST, blockBytes);
+    b = dBlocks.as<uint32_t>();
+    if (rows) {
+      copyIn(dRows.ensure(words * 8 + 64), rows, VX355_MEM_HOST, words * 8);
+      r = dRows.as<uint64_t>();
+    }
+    o = static_cast<uint64_t*>(dOut.ensure(words * 8 + 64));
+  }
+  VX_LAUNCH("k_bloom_test", k_bloom_test, streamGrid(num_rows, 256), 256, 0, db.col(0),
+            static_cast<int64_t>(num_rows), b, static_cast<uint64_t>(num_blocks), lanes, r, o);
+  if (mem == VX355_MEM_HOST) {
+    copyOut(rows_out, VX355_MEM_HOST, o, words * 8);
+  }
+  rt.sync();
+  VX_API_END
 }
 
 }  // extern "C"

@@ -24,4 +24,16 @@ void sortPairsU64U32(uint64_t* keys, uint32_t* vals, uint64_t* keysTmp, uint32_t
   *resultInTmp = true;
 }
 
+// Ascending sort of n u64 keys: in -> out (both n entries, distinct buffers).
+void sortKeysU64(const uint64_t* in, uint64_t* out, size_t n, DevBuf& tmp) {
+  auto& rt = Runtime::get();
+  if (n == 0) {
+    return;
+  }
+  size_t bytes = 0;
+  HIP_OK(rocprim::radix_sort_keys(nullptr, bytes, in, out, n, 0, 64, rt.stream));
+  void* scratch = tmp.ensure(bytes + 64);
+  HIP_OK(rocprim::radix_sort_keys(scratch, bytes, in, out, n, 0, 64, rt.stream));
+}
+
 }  // namespace vx

@@ -30,7 +30,8 @@ SYMBOLS = [
     "vx355_join_build_add_input", "vx355_join_build_finish", "vx355_join_build_destroy",
     "vx355_join_table_retain", "vx355_join_table_release", "vx355_join_table_get_stats",
     "vx355_join_probe_create", "vx355_join_probe_add_input", "vx355_join_probe_get_output",
-    "vx355_join_probe_destroy",
+    "vx355_join_probe_destroy", "vx355_join_table_key_filter", "vx355_join_table_key_filter_values",
+    "vx355_bloom_num_blocks", "vx355_join_table_key_filter_bloom", "vx355_bloom_test",
 ]
 
 
@@ -97,6 +98,12 @@ def lib():
                                               P(i32), P(i32)]
     L.vx355_join_probe_destroy.argtypes = [vp]
     L.vx355_join_probe_destroy.restype = None
+    L.vx355_join_table_key_filter.argtypes = [vp, i32, P(abi.KeyFilter)]
+    L.vx355_join_table_key_filter_values.argtypes = [vp, i32, vp, i64, i32, P(i64)]
+    L.vx355_bloom_num_blocks.restype = i64
+    L.vx355_bloom_num_blocks.argtypes = [i64, C.c_double, i32]
+    L.vx355_join_table_key_filter_bloom.argtypes = [vp, i32, i32, vp, i64, i32]
+    L.vx355_bloom_test.argtypes = [vp, i64, i32, P(abi.Column), i32, vp, vp, i32]
     _LIB = L
     return L
 
@@ -476,10 +483,48 @@ class JoinTable:
         _check(lib().vx355_join_table_get_stats(self.t, C.byref(s)))
         return s
 
+    # Dynamic filters for the probe-side scan (HashProbe::pushdownDynamicFilters).
+    def key_filter(self, key):
+        f = abi.KeyFilter()
+        _check(lib().vx355_join_table_key_filter(self.t, key, C.byref(f)))
+        return f
+
+    def key_filter_values(self, key):
+        f = self.key_filter(key)
+        out = np.zeros(max(1, f.num_distinct), dtype=np.int64)
+        n = C.c_int64()
+        _check(lib().vx355_join_table_key_filter_values(self.t, key, out.ctypes.data, len(out), abi.MEM_HOST,
+                                                        C.byref(n)))
+        return out[:n.value]
+
+    def key_filter_bloom(self, key, lanes=8, false_positive=0.01):
+        """(blocks as uint32[num_blocks, lanes]) sized like BigintValuesUsingBloomFilter::numBlocks."""
+        f = self.key_filter(key)
+        nb = lib().vx355_bloom_num_blocks(max(1, f.num_distinct), false_positive, lanes)
+        blocks = np.zeros((nb, lanes), dtype=np.uint32)
+        _check(lib().vx355_join_table_key_filter_bloom(self.t, key, lanes, blocks.ctypes.data, nb, abi.MEM_HOST))
+        return blocks
+
     def __del__(self):
         if getattr(self, "t", None):
             lib().vx355_join_table_release(self.t)
             self.t = None
+
+
+def bloom_test(blocks, column, rows=None):
+    """BigintValuesUsingBloomFilter::testInt64 over a HostColumn -> bool array."""
+    n = column.num_rows
+    words = (n + 63) // 64
+    out = np.zeros(max(1, words), dtype=np.uint64)
+    rows_ptr = None
+    if rows is not None:
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        rows_ptr = rows.ctypes.data
+    desc = column.descriptor()
+    blocks = np.ascontiguousarray(blocks, dtype=np.uint32)
+    _check(lib().vx355_bloom_test(blocks.ctypes.data, blocks.shape[0], blocks.shape[1], C.byref(desc), n,
+                                  rows_ptr, out.ctypes.data, abi.MEM_HOST))
+    return np.unpackbits(out.view(np.uint8), bitorder="little")[:n].astype(bool)
 
 
 class HashProbe:
