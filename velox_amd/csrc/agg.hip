@@ -43,7 +43,7 @@
 namespace vx {
 
 void sortPairsU64U32(uint64_t* keys, uint32_t* vals, uint64_t* keysTmp, uint32_t* valsTmp,
-                     size_t n, DevBuf& tmp, bool* resultInTmp);
+                     size_t n, DevBuf& tmp, bool* resultInTmp, int endBit = 64);
 void makeTermArgs(const DeviceBatch& db, const vx355_filter_term* terms, int32_t n, TermArg* out);
 void makeProjectionArgs(const DeviceBatch& db, const vx355_projection* proj, int32_t n,
                         ProjectionArg* out);
@@ -624,12 +624,16 @@ __device__ inline void rpLoad(const uint64_t* src, uint64_t* w) {
 // loaded ahead like the key.
 template <int KW, int W, bool FLATV>
 __global__ __launch_bounds__(1024) void k_rp_scatter1(RadixArgs r) {
-  __shared__ unsigned long long cursor[kRadixMaxBins];
+  // Output position = base[bin] (u64, read only) + rank from a 32-bit LDS
+  // atomic (64-bit LDS atomics run at half rate).
+  __shared__ unsigned long long binBase[kRadixMaxBins];
+  __shared__ uint32_t cursor[kRadixMaxBins];
   const AggArgs& a = r.a;
   const int shift = r.shiftB + r.shift2;
   for (int64_t tile = blockIdx.x; tile < r.numTiles; tile += gridDim.x) {
     for (int i = threadIdx.x; i < r.numBins; i += blockDim.x) {
-      cursor[i] = r.offsets[static_cast<int64_t>(i) * r.numTiles + tile];
+      binBase[i] = r.offsets[static_cast<int64_t>(i) * r.numTiles + tile];
+      cursor[i] = 0;
     }
     __syncthreads();
     const int64_t begin = tile * r.tileRows;
@@ -686,7 +690,8 @@ __global__ __launch_bounds__(1024) void k_rp_scatter1(RadixArgs r) {
           }
         }
         vals[u][0] = key | (static_cast<uint64_t>(row) << kRadixKeyBits) | (mask << (kRadixKeyBits + kRadixRowBits));
-        const unsigned long long pos = atomicAdd(&cursor[key >> shift], 1ULL);
+        const uint32_t bin = static_cast<uint32_t>(key >> shift);
+        const unsigned long long pos = binBase[bin] + atomicAdd(&cursor[bin], 1u);
         rpStore<W>(r.recs + pos * W, vals[u]);
       }
     }
@@ -792,13 +797,15 @@ __global__ __launch_bounds__(1024) void k_rp_count2(Radix2Args r) {
 
 template <int W>
 __global__ __launch_bounds__(1024) void k_rp_scatter2(Radix2Args r) {
-  __shared__ unsigned long long cursor[kRadixMaxBins];
+  __shared__ unsigned long long binBase[kRadixMaxBins];
+  __shared__ uint32_t cursor[kRadixMaxBins];
   const uint32_t numTiles = *r.numTiles;
   const uint32_t binMask = static_cast<uint32_t>(r.numBins - 1);
   for (uint32_t t = blockIdx.x; t < numTiles; t += gridDim.x) {
     const RadixTile tile = r.tiles[t];
     for (int i = threadIdx.x; i < r.numBins; i += blockDim.x) {
-      cursor[i] = r.offsets[tile.cell + static_cast<uint64_t>(i) * tile.stride];
+      binBase[i] = r.offsets[tile.cell + static_cast<uint64_t>(i) * tile.stride];
+      cursor[i] = 0;
     }
     __syncthreads();
     for (uint32_t base = 0; base < tile.count; base += kRadixUnroll * 1024) {
@@ -814,8 +821,8 @@ __global__ __launch_bounds__(1024) void k_rp_scatter2(Radix2Args r) {
       for (int u = 0; u < kRadixUnroll; ++u) {
         const uint32_t i = base + u * 1024 + threadIdx.x;
         if (i < tile.count) {
-          const unsigned long long pos =
-              atomicAdd(&cursor[(static_cast<uint32_t>(w[u][0]) >> r.shiftB) & binMask], 1ULL);
+          const uint32_t bin = (static_cast<uint32_t>(w[u][0]) >> r.shiftB) & binMask;
+          const unsigned long long pos = binBase[bin] + atomicAdd(&cursor[bin], 1u);
           rpStore<W>(r.out + pos * W, w[u]);
         }
       }
@@ -2616,7 +2623,10 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
   r.tileRows = tileRows;
   r.numTiles = ceilDiv(n, tileRows);
   const int64_t cells1 = static_cast<int64_t>(r.numBins) * r.numTiles;
-  const uint32_t tileRecs = 65536;
+  uint32_t tileRecs = 65536;
+  if (const char* e = std::getenv("VX355_AGG_RADIX_TILE2")) {
+    tileRecs = static_cast<uint32_t>(std::max(1024, std::atoi(e)));
+  }
   const int64_t maxTiles2 = ceilDiv(n, tileRecs) + r.numBins;
   const int64_t cells2 = r.shift2 ? static_cast<int64_t>(bins2) * maxTiles2 : 0;
   const size_t recBytes = static_cast<size_t>(n) * r.recWords * 8 + 64;
@@ -3341,7 +3351,9 @@ void finalize(vx355_agg& h) {
   }
   bool inTmp = false;
   sortPairsU64U32(h.orderKeys.as<uint64_t>(), h.orderVals.as<uint32_t>(), h.orderKeys2.as<uint64_t>(),
-                  h.orderVals2.as<uint32_t>(), g, h.sortTmp, &inTmp);
+                  h.orderVals2.as<uint32_t>(), g, h.sortTmp, &inTmp,
+                  // first rows are < inputRows: sort only the bits that can be set
+                  std::max(1, 64 - __builtin_clzll(static_cast<unsigned long long>(std::max<int64_t>(1, h.inputRows)))));
   rt.sync();
   h.order = inTmp ? h.orderVals2.as<uint32_t>() : h.orderVals.as<uint32_t>();
   h.numOutput = static_cast<int64_t>(g);

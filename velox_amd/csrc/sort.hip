@@ -11,16 +11,16 @@
 namespace vx {
 
 void sortPairsU64U32(uint64_t* keys, uint32_t* vals, uint64_t* keysTmp, uint32_t* valsTmp,
-                     size_t n, DevBuf& tmp, bool* resultInTmp) {
+                     size_t n, DevBuf& tmp, bool* resultInTmp, int endBit) {
   auto& rt = Runtime::get();
   *resultInTmp = false;
   if (n <= 1) {
     return;
   }
   size_t bytes = 0;
-  HIP_OK(rocprim::radix_sort_pairs(nullptr, bytes, keys, keysTmp, vals, valsTmp, n, 0, 64, rt.stream));
+  HIP_OK(rocprim::radix_sort_pairs(nullptr, bytes, keys, keysTmp, vals, valsTmp, n, 0, endBit, rt.stream));
   void* scratch = tmp.ensure(bytes + 64);
-  HIP_OK(rocprim::radix_sort_pairs(scratch, bytes, keys, keysTmp, vals, valsTmp, n, 0, 64, rt.stream));
+  HIP_OK(rocprim::radix_sort_pairs(scratch, bytes, keys, keysTmp, vals, valsTmp, n, 0, endBit, rt.stream));
   *resultInTmp = true;
 }
 
