@@ -391,8 +391,10 @@ void vx355_agg_destroy(vx355_agg* h);
 /* ---- HashBuild / HashProbe (exec/HashBuild.h, exec/HashProbe.h) --------- */
 
 /* core::JoinType (core/PlanNode.h:3081-3165), same values. Device support in
- * this version: INNER, LEFT, LEFT_SEMI_FILTER, ANTI (not null aware), without
- * an extra filter; others return VX355_EUNSUPPORTED at create. */
+ * this version, all without an extra filter: INNER, LEFT, RIGHT, FULL,
+ * LEFT_SEMI_FILTER, LEFT_SEMI_PROJECT (not null aware), RIGHT_SEMI_FILTER, ANTI
+ * (null aware or not); others return VX355_EUNSUPPORTED at create. Build and
+ * probe must be created with the same join type. */
 typedef enum vx355_join_type {
   VX355_JOIN_INNER = 0,
   VX355_JOIN_LEFT = 1,
@@ -520,6 +522,25 @@ int vx355_join_probe_get_output(
     vx355_join_probe* h,
     int32_t max_rows,
     int32_t* mapping_out,
+    int32_t* build_rows_out,
+    int32_t out_mem,
+    vx355_out_column* build_cols,
+    const int32_t* build_col_ids,
+    int32_t num_build_cols,
+    int32_t* n_out,
+    int32_t* finished);
+/* HashProbe::getBuildSideOutput (exec/HashProbe.cpp:993-1080): the build rows a
+ * RIGHT / FULL join has to emit with null probe columns (listNotProbedRows: no
+ * probe of ANY vx355_join_probe of this table matched them, rows with null keys
+ * included), or the matched ones for RIGHT_SEMI_FILTER (listProbedRows), in
+ * ascending build-row order, max_rows at a time. Call it on ONE probe handle
+ * (the reference's last prober, HashProbe.cpp:1189-1219) after every probe of
+ * the table has consumed its input. LEFT_SEMI_PROJECT needs no such call: its
+ * get_output lists every probe row once with build_rows_out = first match or -1
+ * (the shim's 'match' column is build_rows_out >= 0). */
+int vx355_join_probe_get_build_side_output(
+    vx355_join_probe* h,
+    int32_t max_rows,
     int32_t* build_rows_out,
     int32_t out_mem,
     vx355_out_column* build_cols,

@@ -502,15 +502,18 @@ class JoinBuild {
     if (n & 63) {
       rows.back() = (1ULL << (n & 63)) - 1;
     }
-    // Null keys never match (inner/left/semi/anti-not-null-aware): drop them
-    // (:475-494).
+    // Null keys never match: drop them, except for right / full joins whose
+    // build rows all reach the output (HashBuild.cpp:475-494).
+    const bool keepNullKeys = joinType_ == VX355_JOIN_RIGHT || joinType_ == VX355_JOIN_FULL;
     for (auto& d : keys) {
       for (int32_t r = 0; r < n; ++r) {
         if (d.isNull(r)) {
           if (bitSet(rows.data(), r)) {
             hasNullKeys_ = true;
           }
-          setBit(rows.data(), r, false);
+          if (!keepNullKeys) {
+            setBit(rows.data(), r, false);
+          }
         }
       }
     }
@@ -538,12 +541,25 @@ struct JoinTable {
   std::vector<RowContainer*> containers;
   std::vector<int32_t> depKinds;
   int64_t numRows = 0;
+  bool hasNullKeys = false;
+  // RowContainer probed flags (RowContainer.h probedFlagOffset_), by row id; set by every
+  // probe of the table, read by the last one (HashProbe::getBuildSideOutput).
+  std::vector<uint8_t> probed;
+
+  char* rowById(int64_t id) const {
+    size_t c = containers.size() - 1;
+    while (c > 0 && containerBase[c] > id) {
+      --c;
+    }
+    return containers[c]->rows()[id - containerBase[c]];
+  }
 };
 
 // exec/HashProbe.{h,cpp}.
 class JoinProbe {
  public:
-  JoinProbe(JoinTable* t, const vx355_join_probe_spec& spec) : table_(t), joinType_(spec.join_type) {
+  JoinProbe(JoinTable* t, const vx355_join_probe_spec& spec)
+      : table_(t), joinType_(spec.join_type), nullAware_(spec.null_aware != 0) {
     keyCols_.assign(spec.key_cols, spec.key_cols + spec.num_keys);
   }
 
@@ -573,9 +589,51 @@ class JoinProbe {
   void getOutput(int32_t maxRows, int32_t* mapping, int32_t* buildRows, vx355_out_column* cols,
                  const int32_t* colIds, int32_t numCols, int32_t* nOut, int32_t* finished) {
     int32_t n = 0;
-    const bool includeMisses = joinType_ == VX355_JOIN_LEFT;
+    const bool includeMisses = joinType_ == VX355_JOIN_LEFT || joinType_ == VX355_JOIN_FULL;
+    const bool marksProbed = joinType_ == VX355_JOIN_RIGHT || joinType_ == VX355_JOIN_FULL ||
+        joinType_ == VX355_JOIN_RIGHT_SEMI_FILTER;
     while (cursorRow_ < numRows_ && n < maxRows) {
       char* hit = lookup_.hits[cursorRow_];
+      if (joinType_ == VX355_JOIN_RIGHT_SEMI_FILTER) {
+        // processRightSemiNoFilter: no probe-side output, only the probed flags.
+        for (char* cur = hit; cur; cur = table_->table->nextRow(cur)) {
+          table_->probed[rowId(cur)] = 1;
+        }
+        ++cursorRow_;
+        continue;
+      }
+      if (joinType_ == VX355_JOIN_LEFT_SEMI_PROJECT) {
+        // Every probe row once; the match column is "hit != null" (not null aware).
+        emit(n++, cursorRow_, nullptr, mapping, buildRows, cols, colIds, numCols);
+        if (buildRows) {
+          buildRows[n - 1] = hit ? static_cast<int32_t>(rowId(hit)) : -1;
+        }
+        ++cursorRow_;
+        continue;
+      }
+      if (joinType_ == VX355_JOIN_ANTI && nullAware_) {
+        // HashProbe.cpp:1316-1328 (no filter) + HashBuild's antiJoinHasNullKeys: a null on the
+        // build side empties the result; an empty build side passes everything; else rows with
+        // non-null keys and no match.
+        bool out;
+        if (table_->hasNullKeys) {
+          out = false;
+        } else if (table_->numRows == 0) {
+          out = true;
+        } else {
+          out = !hit;
+          for (auto& k : keys_) {
+            if (k.isNull(cursorRow_)) {
+              out = false;
+            }
+          }
+        }
+        if (out) {
+          emit(n++, cursorRow_, nullptr, mapping, buildRows, cols, colIds, numCols);
+        }
+        ++cursorRow_;
+        continue;
+      }
       if (joinType_ == VX355_JOIN_ANTI) {
         // Not null aware: rows without a match, including rows with null keys
         // (core/PlanNode.h:3147-3150).
@@ -602,6 +660,9 @@ class JoinProbe {
       char* cur = cursorChain_ ? cursorChain_ : hit;
       while (cur && n < maxRows) {
         emit(n++, cursorRow_, cur, mapping, buildRows, cols, colIds, numCols);
+        if (marksProbed) {
+          table_->probed[rowId(cur)] = 1;
+        }
         cur = table_->table->nextRow(cur);
       }
       if (cur) {
@@ -613,6 +674,31 @@ class JoinProbe {
     }
     *nOut = n;
     *finished = cursorRow_ >= numRows_;
+  }
+
+  // HashProbe::getBuildSideOutput (HashProbe.cpp:993-1080), called by the last prober after
+  // all probe input: right / full joins list the build rows no probe matched
+  // (listNotProbedRows), right semi filter the matched ones (listProbedRows); container
+  // order = ascending row id. Probe-side columns of these rows are null.
+  void getBuildSideOutput(int32_t maxRows, int32_t* buildRows, vx355_out_column* cols, const int32_t* colIds,
+                          int32_t numCols, int32_t* nOut, int32_t* finished) {
+    const bool wantProbed = joinType_ == VX355_JOIN_RIGHT_SEMI_FILTER;
+    int32_t n = 0;
+    while (buildCursor_ < table_->numRows && n < maxRows) {
+      if ((table_->probed[buildCursor_] != 0) == wantProbed) {
+        char* row = table_->rowById(buildCursor_);
+        if (buildRows) {
+          buildRows[n] = static_cast<int32_t>(buildCursor_);
+        }
+        for (int32_t c = 0; c < numCols; ++c) {
+          extractStored(row, table_->containers[0]->deps()[colIds[c]], cols[c], n);
+        }
+        ++n;
+      }
+      ++buildCursor_;
+    }
+    *nOut = n;
+    *finished = buildCursor_ >= table_->numRows;
   }
 
  private:
@@ -638,6 +724,8 @@ class JoinProbe {
 
   JoinTable* table_;
   int32_t joinType_;
+  bool nullAware_;
+  int64_t buildCursor_ = 0;
   std::vector<int32_t> keyCols_;
   std::vector<Decoded> keys_;
   HashLookup lookup_;
@@ -1051,6 +1139,11 @@ int orc_join_build_finish(orc_join_build* h, orc_join_build* const* others, int3
     base += other->rows()->numRows();
   }
   t->t.numRows = base;
+  t->t.probed.assign(static_cast<size_t>(base), 0);
+  t->t.hasNullKeys = h->b.hasNullKeys_;
+  for (int32_t i = 0; i < num_others; ++i) {
+    t->t.hasNullKeys = t->t.hasNullKeys || others[i]->b.hasNullKeys_;
+  }
   t->t.table->prepareJoinTable(raw);
   *out = t;
   ORC_CATCH
@@ -1073,10 +1166,18 @@ int orc_join_probe_create(orc_join_table* t, const vx355_join_probe_spec* spec,
     case VX355_JOIN_LEFT:
     case VX355_JOIN_LEFT_SEMI_FILTER:
     case VX355_JOIN_ANTI:
+    case VX355_JOIN_RIGHT:
+    case VX355_JOIN_FULL:
+    case VX355_JOIN_RIGHT_SEMI_FILTER:
+    case VX355_JOIN_LEFT_SEMI_PROJECT:
       break;
     default:
       gLastError = "join type not restated in the oracle";
       return VX355_EUNSUPPORTED;
+  }
+  if (spec->null_aware && spec->join_type != VX355_JOIN_ANTI) {
+    gLastError = "null-aware semantics restated for the anti join only";
+    return VX355_EUNSUPPORTED;
   }
   *out = new orc_join_probe(&t->t, *spec);
   ORC_CATCH
@@ -1093,6 +1194,13 @@ int orc_join_probe_get_output(orc_join_probe* h, int32_t max_rows, int32_t* mapp
   ORC_TRY
   h->p.getOutput(max_rows, mapping_out, build_rows_out, build_cols, build_col_ids, num_build_cols,
                  n_out, finished);
+  ORC_CATCH
+}
+int orc_join_probe_get_build_side_output(orc_join_probe* h, int32_t max_rows, int32_t* build_rows_out,
+                                         vx355_out_column* build_cols, const int32_t* build_col_ids,
+                                         int32_t num_build_cols, int32_t* n_out, int32_t* finished) {
+  ORC_TRY
+  h->p.getBuildSideOutput(max_rows, build_rows_out, build_cols, build_col_ids, num_build_cols, n_out, finished);
   ORC_CATCH
 }
 void orc_join_probe_destroy(orc_join_probe* h) { delete h; }

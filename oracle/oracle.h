@@ -113,6 +113,10 @@ int orc_join_probe_get_output(orc_join_probe* h, int32_t max_rows, int32_t* mapp
                               int32_t* build_rows_out, vx355_out_column* build_cols,
                               const int32_t* build_col_ids, int32_t num_build_cols,
                               int32_t* n_out, int32_t* finished);
+/* HashProbe::getBuildSideOutput: right / full (not probed rows), right semi filter (probed rows). */
+int orc_join_probe_get_build_side_output(orc_join_probe* h, int32_t max_rows, int32_t* build_rows_out,
+                                         vx355_out_column* build_cols, const int32_t* build_col_ids,
+                                         int32_t num_build_cols, int32_t* n_out, int32_t* finished);
 void orc_join_probe_destroy(orc_join_probe* h);
 
 /* SplitBlockBloomFilter (common/base/SplitBlockBloomFilter.h:26-129, .cpp:27-34) as used by

@@ -91,6 +91,8 @@ def lib():
     L.orc_join_probe_add_input.argtypes = [vp, C.POINTER(abi.Batch)]
     L.orc_join_probe_get_output.argtypes = [vp, i32, vp, vp, C.POINTER(abi.OutColumn), vp, i32,
                                             C.POINTER(i32), C.POINTER(i32)]
+    L.orc_join_probe_get_build_side_output.argtypes = [vp, i32, vp, C.POINTER(abi.OutColumn), vp, i32,
+                                                       C.POINTER(i32), C.POINTER(i32)]
     L.orc_join_probe_destroy.argtypes = [vp]
     _LIB = L
     return L
@@ -347,11 +349,11 @@ def collect_output(op, max_rows=1024):
 
 
 class JoinBuild:
-    def __init__(self, key_cols, key_types, dep_cols=(), dep_types=(), join_type=abi.JOIN_INNER):
+    def __init__(self, key_cols, key_types, dep_cols=(), dep_types=(), join_type=abi.JOIN_INNER, null_aware=False):
         self._keep = [abi.i32_array(key_cols), abi.i32_array(key_types), abi.i32_array(dep_cols),
                       abi.i32_array(dep_types)]
         self.spec = abi.JoinBuildSpec(len(key_cols), self._keep[0], self._keep[1], len(dep_cols),
-                                      self._keep[2], self._keep[3], join_type, 0)
+                                      self._keep[2], self._keep[3], join_type, 1 if null_aware else 0)
         self.dep_types = list(dep_types)
         h = C.c_void_p()
         _check(lib().orc_join_build_create(C.byref(self.spec), C.byref(h)))
@@ -389,13 +391,26 @@ class JoinTable:
 
 
 class JoinProbe:
-    def __init__(self, table, key_cols, join_type=abi.JOIN_INNER):
+    def __init__(self, table, key_cols, join_type=abi.JOIN_INNER, null_aware=False):
         self.table = table
         self._keep = abi.i32_array(key_cols)
-        self.spec = abi.JoinProbeSpec(len(key_cols), self._keep, join_type, 0)
+        self.spec = abi.JoinProbeSpec(len(key_cols), self._keep, join_type, 1 if null_aware else 0)
         h = C.c_void_p()
         _check(lib().orc_join_probe_create(table.t, C.byref(self.spec), C.byref(h)))
         self.h = h
+
+    def get_build_side_output(self, max_rows=1024, build_col_ids=None):
+        if build_col_ids is None:
+            build_col_ids = list(range(len(self.table.dep_types)))
+        kinds = [self.table.dep_types[i] for i in build_col_ids]
+        out = abi.OutBuffers(kinds, max_rows)
+        build_rows = np.zeros(max(1, max_rows), dtype=np.int32)
+        n, fin = C.c_int32(), C.c_int32()
+        ids = abi.i32_array(build_col_ids)
+        _check(lib().orc_join_probe_get_build_side_output(self.h, max_rows, build_rows.ctypes.data, out.descs, ids,
+                                                          len(kinds), C.byref(n), C.byref(fin)))
+        cols = [out.column(i, n.value) for i in range(len(kinds))]
+        return build_rows[: n.value].copy(), cols, bool(fin.value)
 
     def add_input(self, batch):
         self._batch = batch

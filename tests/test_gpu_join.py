@@ -171,7 +171,10 @@ def test_join_empty_build_and_empty_probe(oracle, vx):
 
 def test_unsupported_join_kinds_are_refused(vx):
     with pytest.raises(vx.Vx355Error) as e:
-        vx.JoinBuild([0], [abi.BIGINT], [], [], abi.JOIN_FULL)
+        vx.JoinBuild([0], [abi.BIGINT], [], [], abi.JOIN_RIGHT_SEMI_PROJECT)
+    assert e.value.status == abi.EUNSUPPORTED
+    with pytest.raises(vx.Vx355Error) as e:
+        vx.JoinBuild([0], [abi.BIGINT], [], [], abi.JOIN_LEFT, null_aware=True)
     assert e.value.status == abi.EUNSUPPORTED
     with pytest.raises(vx.Vx355Error) as e:
         b = vx.JoinBuild([0], [abi.VARCHAR], [], [], abi.JOIN_INNER)
@@ -323,3 +326,106 @@ def test_dynamic_filters_from_the_build_side(oracle, vx):
         assert (got == (oracle.bloom_test(exp, probe) & pvalid)).all() and got[:5000][pvalid[:5000]].all()
     # string keys: no filter (VectorHasher::getFilter for strings needs the opt-in config; not offered)
     assert table.key_filter(2).kind == abi.KEY_FILTER_NONE
+
+
+def _drain_build_side(probe, max_rows):
+    rows, payload = [], []
+    while True:
+        build_rows, cols, fin = probe.get_build_side_output(max_rows)
+        assert len(build_rows) <= max_rows
+        for i in range(len(build_rows)):
+            rows.append(int(build_rows[i]))
+            payload.append(tuple(None if not valid[i] else (vals[i] if isinstance(vals, list) else vals[i].item())
+                                 for vals, valid in cols))
+        if fin:
+            break
+    return rows, payload
+
+
+@pytest.mark.parametrize("join_type", [abi.JOIN_RIGHT, abi.JOIN_FULL, abi.JOIN_RIGHT_SEMI_FILTER,
+                                       abi.JOIN_LEFT_SEMI_PROJECT])
+@pytest.mark.parametrize("mode", ["array", "normalized", "generic"])
+def test_right_full_semi_project_joins(oracle, vx, join_type, mode, monkeypatch):
+    """Right / full joins (unmatched build rows, null keys included, after the last probe), right
+    semi filter (matched build rows once) and left semi project (every probe row + first match)
+    in all three table modes, two build drivers, two probe batches on two probe handles."""
+    if mode == "normalized":
+        monkeypatch.setenv("VX355_JOIN_ARRAY_MAX", "0")
+    rng = np.random.default_rng(31)
+    nb, npb = 5000, 12000
+    if mode == "generic":
+        pool = rng.integers(-2 ** 62, 2 ** 62, 1500).astype(np.int64)
+    else:
+        pool = np.arange(1500, dtype=np.int64)
+    bk = pool[rng.integers(0, 1500, nb)]
+    bk2 = rng.integers(0, 3, nb).astype(np.int32)
+    bvalid = rng.random(nb) > 0.05
+    bpay = np.arange(nb, dtype=np.int64) * 7
+    bpay_valid = rng.random(nb) > 0.2
+    pk = np.concatenate([pool[rng.integers(0, 1200, npb - 2000)], rng.integers(-50, 0, 2000).astype(np.int64)])
+    rng.shuffle(pk)
+    pk2 = rng.integers(0, 3, npb).astype(np.int32)
+    pvalid = rng.random(npb) > 0.05
+    key_types = [abi.BIGINT, abi.INTEGER]
+    results = {}
+    for impl in (oracle, vx):
+        def driver(lo, hi):
+            return [abi.HostBatch([abi.HostColumn(abi.BIGINT, bk[lo:hi], bvalid[lo:hi]),
+                                   abi.HostColumn(abi.INTEGER, bk2[lo:hi]),
+                                   abi.HostColumn(abi.BIGINT, bpay[lo:hi], bpay_valid[lo:hi])])]
+        table, builds = _build(impl, [driver(0, 3000), driver(3000, nb)], [0, 1], key_types, [2], [abi.BIGINT],
+                               join_type)
+        keeps_nulls = join_type in (abi.JOIN_RIGHT, abi.JOIN_FULL)
+        assert table.stats().num_rows == (nb if keeps_nulls else bvalid.sum())
+        if impl is vx:
+            want = {"array": abi.MODE_ARRAY, "normalized": abi.MODE_NORMALIZED_KEY, "generic": abi.MODE_HASH}[mode]
+            assert table.stats().hash_mode == want
+        probes = [impl.JoinProbe(table, [0, 1], join_type) for _ in range(2)]
+        out = []
+        for h, sl in zip(probes, [slice(0, 7000), slice(7000, npb)]):
+            h.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, pk[sl], pvalid[sl]),
+                                       abi.HostColumn(abi.INTEGER, pk2[sl])]))
+            pairs, payload = _drain(h, 1000 if impl is oracle else 513)
+            _contiguous(pairs)
+            out.append(_canon(pairs, payload))
+        if join_type != abi.JOIN_LEFT_SEMI_PROJECT:
+            out.append(_drain_build_side(probes[1], 999 if impl is oracle else 300))
+        results[impl.__name__] = out
+    if join_type == abi.JOIN_LEFT_SEMI_PROJECT:
+        # The representative of a duplicate chain is not stable (parallel build): compare the match flag.
+        flags = {k: [[(p[0], p[1] >= 0) for p, _ in part] for part in v] for k, v in results.items()}
+        assert flags[oracle.__name__] == flags[vx.__name__]
+        assert [p[0] for p, _ in results[vx.__name__][0]] == list(range(7000))
+    else:
+        assert results[oracle.__name__] == results[vx.__name__]
+        assert len(results[vx.__name__][2][0]) > 0
+
+
+@pytest.mark.parametrize("case", ["build_has_null", "regular", "empty_build"])
+def test_null_aware_anti_join(oracle, vx, case):
+    """NOT IN (HashProbe.cpp:1316-1328 + HashBuild's antiJoinHasNullKeys)."""
+    rng = np.random.default_rng(32)
+    nb, npb = 3000, 9000
+    bk = rng.integers(0, 800, nb).astype(np.int64)
+    bvalid = rng.random(nb) > 0.02 if case == "build_has_null" else np.ones(nb, dtype=bool)
+    if case == "empty_build":
+        bk, bvalid = bk[:0], bvalid[:0]
+    pk = rng.integers(-100, 1200, npb).astype(np.int64)
+    pvalid = rng.random(npb) > 0.05
+    got = {}
+    for impl in (oracle, vx):
+        b = impl.JoinBuild([0], [abi.BIGINT], [], [], abi.JOIN_ANTI, True)
+        b.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, bk, bvalid)], len(bk)))
+        table = b.finish()
+        probe = impl.JoinProbe(table, [0], abi.JOIN_ANTI, True)
+        probe.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, pk, pvalid)]))
+        pairs, _ = _drain(probe, 4096)
+        got[impl.__name__] = [p[0] for p in pairs]
+    assert got[oracle.__name__] == got[vx.__name__]
+    if case == "build_has_null":
+        assert got[vx.__name__] == []
+    elif case == "empty_build":
+        assert got[vx.__name__] == list(range(npb))
+    else:
+        keys = set(bk.tolist())
+        assert got[vx.__name__] == [i for i in range(npb) if pvalid[i] and int(pk[i]) not in keys]

@@ -378,3 +378,89 @@ def test_split_block_bloom_filter_known_answers_and_properties(oracle):
         assert oracle.bloom_test(blocks, values).all()
         others = rng.integers(-2 ** 63, 2 ** 63 - 1, size, dtype=np.int64)
         assert oracle.bloom_test(blocks, others).mean() < 0.03
+
+
+def _join_case(seed=5, nb=400, npb=900):
+    rng = np.random.default_rng(seed)
+    bk = rng.integers(0, 120, nb).astype(np.int64)
+    bvalid = rng.random(nb) > 0.1
+    bpay = np.arange(nb, dtype=np.int64) * 10
+    pk = rng.integers(-20, 160, npb).astype(np.int64)
+    pvalid = rng.random(npb) > 0.1
+    return bk, bvalid, bpay, pk, pvalid
+
+
+def _oracle_join(oracle, join_type, bk, bvalid, bpay, pk, pvalid, null_aware=False, max_rows=97):
+    b1 = oracle.JoinBuild([0], [abi.BIGINT], [1], [abi.BIGINT], join_type, null_aware)
+    b2 = oracle.JoinBuild([0], [abi.BIGINT], [1], [abi.BIGINT], join_type, null_aware)
+    h = len(bk) // 2
+    b1.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, bk[:h], bvalid[:h]), abi.HostColumn(abi.BIGINT, bpay[:h])]))
+    b2.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, bk[h:], bvalid[h:]), abi.HostColumn(abi.BIGINT, bpay[h:])]))
+    table = b1.finish([b2])
+    probe = oracle.JoinProbe(table, [0], join_type, null_aware)
+    probe.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, pk, pvalid)]))
+    pairs = []
+    while True:
+        mapping, rows, cols, fin = probe.get_output(max_rows)
+        pairs += [(int(m), None if not cols[0][1][i] else int(cols[0][0][i])) for i, m in enumerate(mapping)]
+        if fin:
+            break
+    build_side = []
+    if join_type in (abi.JOIN_RIGHT, abi.JOIN_FULL, abi.JOIN_RIGHT_SEMI_FILTER):
+        while True:
+            rows, cols, fin = probe.get_build_side_output(max_rows)
+            build_side += [int(cols[0][0][i]) for i in range(len(rows))]
+            if fin:
+                break
+    return pairs, build_side, (b1, b2, table)
+
+
+def test_oracle_right_full_semi_joins_against_brute_force(oracle):
+    """core/PlanNode.h:3081-3165 semantics restated in the oracle (HashProbe.cpp:993-1080,
+    1274-1377), checked against nested loops in Python: right / full list unmatched build rows
+    (null keys included) after the probe, right semi filter lists the matched build rows once,
+    left semi project lists every probe row with its match flag."""
+    bk, bvalid, bpay, pk, pvalid = _join_case()
+    match = {}
+    for j in range(len(bk)):
+        if bvalid[j]:
+            match.setdefault(int(bk[j]), []).append(int(bpay[j]))
+    inner = sorted((i, p) for i in range(len(pk)) if pvalid[i] for p in match.get(int(pk[i]), []))
+    hit_pays = {p for i in range(len(pk)) if pvalid[i] for p in match.get(int(pk[i]), [])}
+    kept = [int(bpay[j]) for j in range(len(bk)) if bvalid[j]]
+    # right: inner pairs + every build row (null keys too) that no probe row matched
+    pairs, build_side, _ = _oracle_join(oracle, abi.JOIN_RIGHT, bk, bvalid, bpay, pk, pvalid)
+    assert sorted(pairs) == inner
+    assert build_side == [int(p) for p in bpay if int(p) not in hit_pays]
+    # full: left pairs + the same build rows
+    pairs, build_side, _ = _oracle_join(oracle, abi.JOIN_FULL, bk, bvalid, bpay, pk, pvalid)
+    misses = [(i, None) for i in range(len(pk)) if not (pvalid[i] and int(pk[i]) in match)]
+    assert sorted(pairs, key=lambda t: (t[0], -1 if t[1] is None else t[1])) == sorted(
+        inner + misses, key=lambda t: (t[0], -1 if t[1] is None else t[1]))
+    assert build_side == [int(p) for p in bpay if int(p) not in hit_pays]
+    # right semi filter: matched build rows, once, in build order; no probe-side output
+    pairs, build_side, _ = _oracle_join(oracle, abi.JOIN_RIGHT_SEMI_FILTER, bk, bvalid, bpay, pk, pvalid)
+    assert pairs == [] and build_side == [p for p in kept if p in hit_pays]
+    # left semi project: every probe row once
+    pairs, _, _ = _oracle_join(oracle, abi.JOIN_LEFT_SEMI_PROJECT, bk, bvalid, bpay, pk, pvalid)
+    assert [m for m, _ in pairs] == list(range(len(pk)))
+
+
+def test_oracle_null_aware_anti_join(oracle):
+    """NOT IN semantics (HashProbe.cpp:1316-1328, HashBuild's antiJoinHasNullKeys)."""
+    bk, bvalid, bpay, pk, pvalid = _join_case(seed=6)
+    keys = {int(bk[j]) for j in range(len(bk)) if bvalid[j]}
+    # build side with a null key: nothing qualifies
+    pairs, _, _ = _oracle_join(oracle, abi.JOIN_ANTI, bk, bvalid, bpay, pk, pvalid, null_aware=True)
+    assert pairs == []
+    # no nulls on the build side: non-null probe keys without a match
+    allv = np.ones(len(bk), dtype=bool)
+    keys_all = {int(k) for k in bk}
+    pairs, _, _ = _oracle_join(oracle, abi.JOIN_ANTI, bk, allv, bpay, pk, pvalid, null_aware=True)
+    assert [m for m, _ in pairs] == [i for i in range(len(pk)) if pvalid[i] and int(pk[i]) not in keys_all]
+    # empty build side: every probe row, null keys included
+    pairs, _, _ = _oracle_join(oracle, abi.JOIN_ANTI, bk[:0], allv[:0], bpay[:0], pk, pvalid, null_aware=True)
+    assert [m for m, _ in pairs] == list(range(len(pk)))
+    # not null aware for comparison: rows without a match, null keys included
+    pairs, _, _ = _oracle_join(oracle, abi.JOIN_ANTI, bk, bvalid, bpay, pk, pvalid)
+    assert [m for m, _ in pairs] == [i for i in range(len(pk)) if not (pvalid[i] and int(pk[i]) in keys)]

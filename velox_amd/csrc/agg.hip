@@ -3172,7 +3172,7 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
     // groups) picks the LDS layout of every later launch.
     rows = std::min(h.numGroups == 0 ? std::min<int64_t>(h.chunkRows, 1 << 20) : h.chunkRows,
                     n - begin);
-    if (h.mode == MODE_ARRAY && h.radixMinRows >= 0) {
+    if (h.mode == MODE_ARRAY && h.radixMinRows >= 0 && h.capacity > (1u << 12)) {
       rows = std::min<int64_t>(rows, 1LL << kRadixRowBits);  // radix path: 29-bit row numbers in the records
     }
     if (h.mode == MODE_NORMALIZED) {

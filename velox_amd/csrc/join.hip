@@ -109,10 +109,14 @@ struct AppendArgs {
   int32_t depWidth[kMaxDeps];
   int32_t numKeys;
   int32_t numDeps;
-  const int32_t* rows;  // selected input rows, ascending
+  const int32_t* rows;  // selected input rows, ascending; nullptr = all rows
   int64_t count;
   int64_t base;         // first build row id of this batch
   BuildCounters* counters;
+  // right / full joins keep rows with null keys (they reach the output as
+  // unmatched rows, HashBuild.cpp:475-494) but never enter the table:
+  const uint64_t* keyValidWords;  // bit per input row: all keys non-null
+  uint8_t* keyNullOut;            // per build row
 };
 
 __global__ __launch_bounds__(256) void k_build_append(AppendArgs a) {
@@ -124,10 +128,21 @@ __global__ __launch_bounds__(256) void k_build_append(AppendArgs a) {
   }
   for (int64_t p = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; p < a.count;
        p += stride) {
-    const int64_t row = a.rows[p];
+    const int64_t row = a.rows ? a.rows[p] : p;
     uint64_t hash = 0;
+    const bool keyOk = !a.keyValidWords || bitAt(a.keyValidWords, row);
+    if (a.keyNullOut) {
+      a.keyNullOut[a.base + p] = keyOk ? 0 : 1;
+    }
     for (int k = 0; k < a.numKeys; ++k) {
       const ColView& c = a.keys[k];
+      if (!keyOk) {
+        a.keyOut[k][(a.base + p) * a.keyWords[k]] = 0;
+        if (a.keyWords[k] == 2) {
+          a.keyOut[k][(a.base + p) * 2 + 1] = 0;
+        }
+        continue;
+      }
       const int64_t i = colIndex(c, row);
       uint64_t w0, w1;
       bool inlineOk = true;
@@ -222,6 +237,7 @@ struct InsertArgs {
   int32_t phase;      // array mode: 1 = claim keys, 2 = chain the duplicates
   int32_t pad;
   BuildCounters* counters;
+  const uint8_t* keyNull;  // rows kept for right / full joins only: not inserted
 };
 
 constexpr uint32_t kPendingRow = 0xfffffffeu;
@@ -272,6 +288,12 @@ __global__ __launch_bounds__(256) void k_join_insert(InsertArgs a) {
   uint32_t dups = 0, distinct = 0;
   for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < a.numRows;
        row += stride) {
+    if (a.keyNull && a.keyNull[row]) {
+      if (a.phase == 1) {
+        a.next[row] = kNoRow32;
+      }
+      continue;
+    }
     if (a.mode == JMODE_ARRAY) {
       if (a.phase == 1) {
         const uint64_t key = buildKey(a, row);
@@ -413,20 +435,37 @@ struct ProbeArgs {
   uint32_t* counts;     // output rows per probe row; only kept for duplicate tables
   uint64_t* tileSums;   // output rows per tile
   int32_t fastKey;      // single non-null BIGINT key (FK of TPC-H joins): 1 flat, 2 dictionary wrapped
-  int32_t pad;
+  int32_t nullAware;    // null-aware anti join on a non-empty build side: null probe keys produce nothing
+  uint8_t* probed;      // right / full / right semi: build rows some probe row matched
 };
 
-__device__ inline uint32_t outputCount(int32_t joinType, uint32_t matches) {
+constexpr uint32_t kNullKey32 = 0xfffffffeu;  // hits[]: the probe key holds a null (null-aware anti only)
+
+__device__ inline bool isHit(uint32_t hit) { return hit < kNullKey32; }
+
+// Output rows of one probe row with 'matches' matching build rows.
+__device__ inline uint32_t outputCount(int32_t joinType, uint32_t matches, bool nullKey = false) {
   switch (joinType) {
     case VX355_JOIN_INNER:
+    case VX355_JOIN_RIGHT:
       return matches;
     case VX355_JOIN_LEFT:
+    case VX355_JOIN_FULL:
       return matches ? matches : 1;
     case VX355_JOIN_LEFT_SEMI_FILTER:
       return matches ? 1 : 0;
-    default:  // ANTI (not null aware): rows without a match, null keys included
-      return matches ? 0 : 1;
+    case VX355_JOIN_LEFT_SEMI_PROJECT:
+      return 1;
+    case VX355_JOIN_RIGHT_SEMI_FILTER:
+      return 0;  // build-side output only (processRightSemiNoFilter)
+    default:  // ANTI: rows without a match; null keys included unless null aware
+      return (matches || nullKey) ? 0 : 1;
   }
+}
+
+__device__ inline bool listsMatches(int32_t joinType) {
+  return joinType == VX355_JOIN_INNER || joinType == VX355_JOIN_LEFT || joinType == VX355_JOIN_RIGHT ||
+      joinType == VX355_JOIN_FULL;
 }
 
 // Normalized key of a probe row with lookupValueIds semantics: false = proven
@@ -597,19 +636,34 @@ __global__ __launch_bounds__(256) void k_join_probe(ProbeArgs a) {
 #pragma unroll
       for (int u = 0; u < kProbeUnroll; ++u) {
         if (rows[u] < a.numRows) {
+          bool nullKey = false;
+          if (a.nullAware && hit[u] == kNoRow32) {
+            for (int k = 0; k < a.numKeys; ++k) {
+              nullKey = nullKey || colIsNull(a.keys[k], rows[u]);
+            }
+            if (nullKey) {
+              hit[u] = kNullKey32;
+            }
+          }
           a.hits[rows[u]] = hit[u];
-          uint32_t matches = hit[u] == kNoRow32 ? 0 : 1;
+          uint32_t matches = isHit(hit[u]) ? 1 : 0;
+          if (matches && a.probed) {
+            // setProbedFlag on every row of the chain (the rows listJoinResults hands out).
+            for (uint32_t r = hit[u]; r != kNoRow32; r = a.next[r]) {
+              a.probed[r] = 1;
+            }
+          }
           if (a.counts) {
-            if (matches && (a.joinType == VX355_JOIN_INNER || a.joinType == VX355_JOIN_LEFT)) {
+            if (matches && listsMatches(a.joinType)) {
               uint32_t r = a.next[hit[u]];
               while (r != kNoRow32) {
                 ++matches;
                 r = a.next[r];
               }
             }
-            a.counts[rows[u]] = outputCount(a.joinType, matches);
+            a.counts[rows[u]] = outputCount(a.joinType, matches, nullKey);
           }
-          mine += outputCount(a.joinType, matches);
+          mine += outputCount(a.joinType, matches, nullKey);
         }
       }
     }
@@ -690,7 +744,8 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
     uint64_t total = 0;
     for (int it = 0; it < kWaveRows / 64; ++it) {
       const int64_t r = waveBase + it * 64 + lane();
-      const bool out = r < a.numRows && outputCount(a.joinType, a.hits[r] == kNoRow32 ? 0 : 1) != 0;
+      const bool out = r < a.numRows &&
+          outputCount(a.joinType, isHit(a.hits[r]) ? 1 : 0, a.hits[r] == kNullKey32) != 0;
       total += popc64(ballot(out));
     }
     if (lane() == 0) {
@@ -710,7 +765,7 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
       bool out = false;
       if (r < a.numRows) {
         hit = a.hits[r];
-        out = outputCount(a.joinType, hit == kNoRow32 ? 0 : 1) != 0;
+        out = outputCount(a.joinType, isHit(hit) ? 1 : 0, hit == kNullKey32) != 0;
       }
       const uint64_t m = ballot(out);
       if (m == 0) {
@@ -720,8 +775,8 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
       if (out && pos >= a.windowBegin && pos < a.windowEnd) {
         a.mapping[pos - a.windowBegin] = static_cast<int32_t>(r);
         if (a.buildRows) {
-          const bool listMatch = hit != kNoRow32 &&
-              (a.joinType == VX355_JOIN_INNER || a.joinType == VX355_JOIN_LEFT);
+          const bool listMatch = isHit(hit) &&
+              (listsMatches(a.joinType) || a.joinType == VX355_JOIN_LEFT_SEMI_PROJECT);
           a.buildRows[pos - a.windowBegin] = listMatch ? static_cast<int32_t>(hit) : -1;
         }
       }
@@ -760,14 +815,14 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
     const uint64_t stepTotal = waveTotals[0] + waveTotals[1] + waveTotals[2] + waveTotals[3];
     const uint64_t hi = lo + c;
     if (c != 0 && hi > a.windowBegin && lo < a.windowEnd) {
-      const bool listMatches = hit != kNoRow32 &&
-          (a.joinType == VX355_JOIN_INNER || a.joinType == VX355_JOIN_LEFT);
+      const bool listMatches = isHit(hit) && listsMatches(a.joinType);
+      const bool firstOnly = isHit(hit) && a.joinType == VX355_JOIN_LEFT_SEMI_PROJECT;
       uint32_t b = hit;
       for (uint64_t p = lo; p < hi && p < a.windowEnd; ++p) {
         if (p >= a.windowBegin) {
           a.mapping[p - a.windowBegin] = static_cast<int32_t>(r);
           if (a.buildRows) {
-            a.buildRows[p - a.windowBegin] = listMatches ? static_cast<int32_t>(b) : -1;
+            a.buildRows[p - a.windowBegin] = (listMatches || firstOnly) ? static_cast<int32_t>(b) : -1;
           }
         }
         if (listMatches) {
@@ -844,7 +899,29 @@ __global__ __launch_bounds__(256) void k_gather_deps(GatherArgs a) {
 
 bool supportedJoin(int32_t t) {
   return t == VX355_JOIN_INNER || t == VX355_JOIN_LEFT || t == VX355_JOIN_LEFT_SEMI_FILTER ||
-      t == VX355_JOIN_ANTI;
+      t == VX355_JOIN_ANTI || t == VX355_JOIN_RIGHT || t == VX355_JOIN_FULL ||
+      t == VX355_JOIN_RIGHT_SEMI_FILTER || t == VX355_JOIN_LEFT_SEMI_PROJECT;
+}
+
+bool keepsNullKeyRows(int32_t t) { return t == VX355_JOIN_RIGHT || t == VX355_JOIN_FULL; }
+bool marksProbedRows(int32_t t) {
+  return t == VX355_JOIN_RIGHT || t == VX355_JOIN_FULL || t == VX355_JOIN_RIGHT_SEMI_FILTER;
+}
+
+// bit r = (probed[r] != 0) == wantProbed
+__global__ __launch_bounds__(256) void k_probed_bits(const uint8_t* probed, int64_t n, int32_t wantProbed,
+                                                      uint64_t* bits) {
+  const int64_t numWords = (n + 63) >> 6;
+  const int64_t waveStride = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+  for (int64_t w = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6; w < numWords;
+       w += waveStride) {
+    const int64_t r = (w << 6) + lane();
+    const bool on = r < n && (probed[r] != 0) == (wantProbed != 0);
+    const uint64_t word = ballot(on);
+    if (lane() == 0) {
+      bits[w] = word;
+    }
+  }
 }
 
 }  // namespace
@@ -865,6 +942,7 @@ struct vx355_join_build {
   int64_t capacityRows = 0;
   bool hasNullKeys = false;
   bool finished = false;
+  DevBuf keyNull;  // right / full joins: 1 byte per row, set for rows with a null key
   std::vector<int64_t> obsMin, obsMax;
   DevBuf countersBuf, scratch, validWords, rowList;
   HostCoalescer coalescer;  // small host batches -> large appends
@@ -888,6 +966,8 @@ struct vx355_join_table {
   int64_t numDistinct = 0;
   bool hasDuplicates = false;
   bool hasNullKeys = false;
+  DevBuf probed;   // right / full / right semi joins: 1 byte per build row
+  bool keepsNullRows = false;
   // dynamic filters: ascending distinct values per key, computed on first request
   std::vector<DevBuf> distinctVals;
   std::vector<int64_t> distinctCount;  // -1 = not computed
@@ -905,6 +985,11 @@ struct vx355_join_probe {
   uint64_t cursor = 0;
   bool hasInput = false;
   bool haveCounts = false;
+  bool nullAware = false;
+  // build-side output (right / full / right semi): the listed rows, computed on first request
+  DevBuf buildSideRows;
+  int64_t buildSideCount = -1;
+  int64_t buildSideCursor = 0;
 };
 
 namespace vx {
@@ -928,6 +1013,9 @@ void growBuild(vx355_join_build& h, int64_t rows) {
     h.keyVals[k].ensure(static_cast<size_t>(cap) * w + 64, true, static_cast<size_t>(h.numRows) * w);
   }
   h.hashStore.ensure(static_cast<size_t>(cap) * 8 + 64, true, static_cast<size_t>(h.numRows) * 8);
+  if (keepsNullKeyRows(h.joinType)) {
+    h.keyNull.ensure(static_cast<size_t>(cap) + 64, true, static_cast<size_t>(h.numRows));
+  }
   for (size_t d = 0; d < h.depVals.size(); ++d) {
     const int w = depStoreWidth(h.depKinds[d]);
     h.depVals[d].ensure(static_cast<size_t>(cap) * w + 64, true, static_cast<size_t>(h.numRows) * w);
@@ -971,9 +1059,13 @@ void buildAddInput(vx355_join_build& h, const vx355_batch* batch) {
   va.validWords = static_cast<uint64_t*>(h.validWords.ensure(static_cast<size_t>(words) * 8 + 64));
   va.counters = ctr;
   VX_LAUNCH("k_key_valid", k_key_valid, streamGrid(words * 64, 256), 256, 0, va);
-  int32_t* rows = static_cast<int32_t*>(h.rowList.ensure(static_cast<size_t>(n) * 4 + 64));
-  int64_t selected = 0;
-  compactBits(va.validWords, nullptr, nullptr, n, rows, h.scratch, &selected);
+  const bool keepNulls = keepsNullKeyRows(h.joinType);
+  int32_t* rows = nullptr;
+  int64_t selected = n;
+  if (!keepNulls) {
+    rows = static_cast<int32_t*>(h.rowList.ensure(static_cast<size_t>(n) * 4 + 64));
+    compactBits(va.validWords, nullptr, nullptr, n, rows, h.scratch, &selected);
+  }
   if (selected > 0) {
     growBuild(h, h.numRows + selected);
     AppendArgs aa{};
@@ -995,6 +1087,10 @@ void buildAddInput(vx355_join_build& h, const vx355_batch* batch) {
     aa.count = selected;
     aa.base = h.numRows;
     aa.counters = ctr;
+    if (keepNulls) {
+      aa.keyValidWords = va.validWords;
+      aa.keyNullOut = h.keyNull.as<uint8_t>();
+    }
     VX_LAUNCH("k_build_append", k_build_append, streamGrid(selected, 256), 256, 0, aa);
   }
   BuildCounters c = readBuildCounters(h.countersBuf);
@@ -1024,7 +1120,8 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
   int64_t total = h.numRows;
   for (int32_t i = 0; i < numOthers; ++i) {
     VX_CHECK_ARG(others && others[i] && others[i] != &h, "bad peer build handle");
-    VX_CHECK_ARG(others[i]->keyKinds == h.keyKinds && others[i]->depKinds == h.depKinds,
+    VX_CHECK_ARG(others[i]->keyKinds == h.keyKinds && others[i]->depKinds == h.depKinds &&
+                     others[i]->joinType == h.joinType,
                  "peer build with a different layout");
     total += others[i]->numRows;
   }
@@ -1042,6 +1139,9 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
       }
       copyIn(h.hashStore.as<char>() + h.numRows * 8, o.hashStore.ptr(), VX355_MEM_DEVICE,
              static_cast<size_t>(o.numRows) * 8);
+      if (keepsNullKeyRows(h.joinType)) {
+        copyIn(h.keyNull.as<char>() + h.numRows, o.keyNull.ptr(), VX355_MEM_DEVICE, static_cast<size_t>(o.numRows));
+      }
       h.unmappable = h.unmappable || o.unmappable;
       for (size_t d = 0; d < h.depVals.size(); ++d) {
         const int w = depStoreWidth(h.depKinds[d]);
@@ -1116,6 +1216,10 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
   }
   ia.hashStore = h.hashStore.as<uint64_t>();
   ia.numRows = h.numRows;
+  if (keepsNullKeyRows(h.joinType) && h.hasNullKeys) {
+    ia.keyNull = h.keyNull.as<uint8_t>();
+    t->keepsNullRows = true;
+  }
   resetBuildCounters(h.countersBuf);
   ia.counters = h.countersBuf.as<BuildCounters>();
   t->next.ensure(static_cast<size_t>(std::max<int64_t>(1, h.numRows)) * 4 + 64);
@@ -1166,6 +1270,11 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
   }
   t->numDistinct = c.numDistinct;
   t->hasDuplicates = c.duplicates != 0;
+  if (marksProbedRows(h.joinType)) {
+    t->probed.ensure(static_cast<size_t>(std::max<int64_t>(1, h.numRows)) + 64);
+    HIP_OK(hipMemsetAsync(t->probed.ptr(), 0, static_cast<size_t>(std::max<int64_t>(1, h.numRows)), rt.stream));
+    rt.sync();
+  }
   t->depVals = std::move(h.depVals);
   t->depValid = std::move(h.depValid);
   // The build key images stay with the table: generic-mode probes compare
@@ -1191,6 +1300,13 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
     return;
   }
   ProbeArgs a{};
+  if (p.nullAware && p.joinType == VX355_JOIN_ANTI) {
+    if (t.hasNullKeys) {
+      return;  // NOT IN over a set holding a null: no row qualifies (HashBuild's antiJoinHasNullKeys)
+    }
+    a.nullAware = t.numRows > 0 ? 1 : 0;  // an empty build side passes every row, null keys included
+  }
+  a.probed = marksProbedRows(p.joinType) ? t.probed.as<uint8_t>() : nullptr;
   a.numKeys = static_cast<int32_t>(p.keyCols.size());
   for (int k = 0; k < a.numKeys; ++k) {
     a.keys[k] = db.col(p.keyCols[k]);
@@ -1219,7 +1335,9 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
   a.hits = static_cast<uint32_t*>(p.hits.ensure(static_cast<size_t>(n) * 4 + 64));
   // Per-row output counts are only materialised when chains can be longer than
   // one row; otherwise listJoinResults derives them from the hit.
-  p.haveCounts = t.hasDuplicates && (p.joinType == VX355_JOIN_INNER || p.joinType == VX355_JOIN_LEFT);
+  p.haveCounts = t.hasDuplicates &&
+      (p.joinType == VX355_JOIN_INNER || p.joinType == VX355_JOIN_LEFT || p.joinType == VX355_JOIN_RIGHT ||
+       p.joinType == VX355_JOIN_FULL);
   a.counts = p.haveCounts ? static_cast<uint32_t*>(p.counts.ensure(static_cast<size_t>(n) * 4 + 64))
                           : nullptr;
   p.numTiles = ceilDiv(n, kTileRows);
@@ -1240,6 +1358,50 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
   copyOut(p.hostTileOffsets.data(), VX355_MEM_HOST, offs, static_cast<size_t>(p.numTiles + 1) * 8);
   rt.sync();
   p.totalOut = p.hostTileOffsets.back();
+}
+
+// extractColumns for 'n' listed build rows (-1 = null row) into caller columns.
+void gatherBuildCols(vx355_join_probe& p, const vx355_join_table& t, const int32_t* dRows, int32_t n,
+                     vx355_out_column* buildCols, const int32_t* buildColIds, int32_t numBuildCols) {
+    VX_CHECK_ARG(buildCols && buildColIds, "NULL build column arguments");
+    const size_t words = static_cast<size_t>(ceilDiv(n, 64));
+    GatherArgs ga{};
+    ga.buildRows = dRows;
+    ga.count = n;
+    ga.numCols = numBuildCols;
+    std::vector<size_t> valOff(numBuildCols), nullOff(numBuildCols), valBytes(numBuildCols);
+    size_t total = 0;
+    for (int32_t c = 0; c < numBuildCols; ++c) {
+      const int32_t id = buildColIds[c];
+      VX_CHECK_ARG(id >= 0 && id < static_cast<int32_t>(t.depKinds.size()), "bad build column id");
+      VX_CHECK_ARG(buildCols[c].type_kind == t.depKinds[id], "build column type mismatch");
+      const int w = kindWidth(t.depKinds[id]);
+      valBytes[c] = w == 0 ? words * 8 : static_cast<size_t>(n) * w;
+      valOff[c] = total;
+      total += (valBytes[c] + 63) & ~static_cast<size_t>(63);
+      nullOff[c] = total;
+      total += (words * 8 + 63) & ~static_cast<size_t>(63);
+    }
+    char* scratch = static_cast<char*>(p.scratch.ensure(total + 64));
+    for (int32_t c = 0; c < numBuildCols; ++c) {
+      const int32_t id = buildColIds[c];
+      ga.depVals[c] = t.depVals[id].as<char>();
+      ga.depValid[c] = t.depValid[id].as<uint8_t>();
+      ga.width[c] = kindWidth(t.depKinds[id]);
+      ga.kind[c] = t.depKinds[id];
+      const bool colHost = buildCols[c].mem == VX355_MEM_HOST;
+      ga.outVals[c] = colHost ? static_cast<void*>(scratch + valOff[c]) : buildCols[c].values;
+      ga.outNulls[c] = colHost ? reinterpret_cast<uint64_t*>(scratch + nullOff[c]) : buildCols[c].nulls;
+    }
+    VX_LAUNCH("k_gather_deps", k_gather_deps, static_cast<int>(ceilDiv(n, 256)), 256, 0, ga);
+    for (int32_t c = 0; c < numBuildCols; ++c) {
+      if (buildCols[c].mem == VX355_MEM_HOST) {
+        copyOutAsync(buildCols[c].values, VX355_MEM_HOST, scratch + valOff[c], valBytes[c]);
+        if (buildCols[c].nulls) {
+          copyOutAsync(buildCols[c].nulls, VX355_MEM_HOST, scratch + nullOff[c], words * 8);
+        }
+      }
+    }
 }
 
 void probeGetOutput(vx355_join_probe& p, int32_t maxRows, int32_t* mappingOut, int32_t* buildRowsOut,
@@ -1289,45 +1451,7 @@ void probeGetOutput(vx355_join_probe& p, int32_t maxRows, int32_t* mappingOut, i
   VX_LAUNCH("k_emit", k_emit, static_cast<int>(lastTile - firstTile + 1), 256, 0, ea);
 
   if (numBuildCols > 0) {
-    VX_CHECK_ARG(buildCols && buildColIds, "NULL build column arguments");
-    const size_t words = static_cast<size_t>(ceilDiv(n, 64));
-    GatherArgs ga{};
-    ga.buildRows = dRows;
-    ga.count = n;
-    ga.numCols = numBuildCols;
-    std::vector<size_t> valOff(numBuildCols), nullOff(numBuildCols), valBytes(numBuildCols);
-    size_t total = 0;
-    for (int32_t c = 0; c < numBuildCols; ++c) {
-      const int32_t id = buildColIds[c];
-      VX_CHECK_ARG(id >= 0 && id < static_cast<int32_t>(t.depKinds.size()), "bad build column id");
-      VX_CHECK_ARG(buildCols[c].type_kind == t.depKinds[id], "build column type mismatch");
-      const int w = kindWidth(t.depKinds[id]);
-      valBytes[c] = w == 0 ? words * 8 : static_cast<size_t>(n) * w;
-      valOff[c] = total;
-      total += (valBytes[c] + 63) & ~static_cast<size_t>(63);
-      nullOff[c] = total;
-      total += (words * 8 + 63) & ~static_cast<size_t>(63);
-    }
-    char* scratch = static_cast<char*>(p.scratch.ensure(total + 64));
-    for (int32_t c = 0; c < numBuildCols; ++c) {
-      const int32_t id = buildColIds[c];
-      ga.depVals[c] = t.depVals[id].as<char>();
-      ga.depValid[c] = t.depValid[id].as<uint8_t>();
-      ga.width[c] = kindWidth(t.depKinds[id]);
-      ga.kind[c] = t.depKinds[id];
-      const bool colHost = buildCols[c].mem == VX355_MEM_HOST;
-      ga.outVals[c] = colHost ? static_cast<void*>(scratch + valOff[c]) : buildCols[c].values;
-      ga.outNulls[c] = colHost ? reinterpret_cast<uint64_t*>(scratch + nullOff[c]) : buildCols[c].nulls;
-    }
-    VX_LAUNCH("k_gather_deps", k_gather_deps, static_cast<int>(ceilDiv(n, 256)), 256, 0, ga);
-    for (int32_t c = 0; c < numBuildCols; ++c) {
-      if (buildCols[c].mem == VX355_MEM_HOST) {
-        copyOutAsync(buildCols[c].values, VX355_MEM_HOST, scratch + valOff[c], valBytes[c]);
-        if (buildCols[c].nulls) {
-          copyOutAsync(buildCols[c].nulls, VX355_MEM_HOST, scratch + nullOff[c], words * 8);
-        }
-      }
-    }
+    gatherBuildCols(p, t, dRows, n, buildCols, buildColIds, numBuildCols);
   }
   if (host) {
     copyOutAsync(mappingOut, VX355_MEM_HOST, dMap, static_cast<size_t>(n) * 4);
@@ -1341,6 +1465,50 @@ void probeGetOutput(vx355_join_probe& p, int32_t maxRows, int32_t* mappingOut, i
   *finished = p.cursor >= p.totalOut ? 1 : 0;
 }
 
+
+// HashProbe::getBuildSideOutput (HashProbe.cpp:993-1080): listNotProbedRows for
+// right / full joins, listProbedRows for right semi filter, ascending row id.
+void probeGetBuildSideOutput(vx355_join_probe& p, int32_t maxRows, int32_t* buildRowsOut, int32_t outMem,
+                             vx355_out_column* buildCols, const int32_t* buildColIds, int32_t numBuildCols,
+                             int32_t* nOut, int32_t* finished) {
+  auto& rt = Runtime::get();
+  auto& t = *p.table;
+  VX_CHECK_ARG(nOut && finished, "NULL argument");
+  VX_CHECK_ARG(maxRows > 0, "max_rows must be positive");
+  VX_CHECK_ARG(numBuildCols >= 0 && numBuildCols <= kMaxDeps, "bad number of build columns");
+  if (!marksProbedRows(p.joinType)) {
+    VX_THROW(VX355_EINVAL, "this join type has no build-side output");
+  }
+  *nOut = 0;
+  *finished = 1;
+  if (p.buildSideCount < 0) {
+    p.buildSideCount = 0;
+    if (t.numRows > 0) {
+      DevBuf bits, scratch;
+      bits.ensure(static_cast<size_t>(ceilDiv(t.numRows, 64)) * 8 + 64);
+      VX_LAUNCH("k_probed_bits", k_probed_bits, streamGrid(t.numRows, 256), 256, 0, t.probed.as<uint8_t>(),
+                t.numRows, p.joinType == VX355_JOIN_RIGHT_SEMI_FILTER ? 1 : 0, bits.as<uint64_t>());
+      p.buildSideRows.ensure(static_cast<size_t>(t.numRows) * 4 + 64);
+      compactBits(bits.as<uint64_t>(), nullptr, nullptr, t.numRows, p.buildSideRows.as<int32_t>(), scratch,
+                  &p.buildSideCount);
+    }
+  }
+  if (p.buildSideCursor >= p.buildSideCount) {
+    return;
+  }
+  const int32_t n = static_cast<int32_t>(std::min<int64_t>(maxRows, p.buildSideCount - p.buildSideCursor));
+  const int32_t* dRows = p.buildSideRows.as<int32_t>() + p.buildSideCursor;
+  if (numBuildCols > 0) {
+    gatherBuildCols(p, t, dRows, n, buildCols, buildColIds, numBuildCols);
+  }
+  if (buildRowsOut) {
+    copyOutAsync(buildRowsOut, outMem, dRows, static_cast<size_t>(n) * 4);
+  }
+  rt.sync();
+  p.buildSideCursor += n;
+  *nOut = n;
+  *finished = p.buildSideCursor >= p.buildSideCount ? 1 : 0;
+}
 
 // ---- dynamic filters (HashProbe::pushdownDynamicFilters, HashProbe.cpp:408-457) ----
 constexpr int64_t kMaxDistinctForValues = 100000;  // VectorHasher::kMaxDistinct (VectorHasher.h:139)
@@ -1427,7 +1595,8 @@ __global__ __launch_bounds__(256) void k_gather_flipped(const uint64_t* sorted, 
 
 bool filterableKey(const vx355_join_table& t, int32_t key) {
   const int32_t kind = t.keyKinds.at(key);
-  return kind >= VX355_TINYINT && kind <= VX355_BIGINT;
+  // Right / full builds keep rows with null keys (zero key images): no filter from those.
+  return kind >= VX355_TINYINT && kind <= VX355_BIGINT && !t.keepsNullRows;
 }
 
 // Distinct non-null build values of one key, ascending (uniqueValues_ of the
@@ -1487,7 +1656,7 @@ int vx355_join_build_create(const vx355_join_build_spec* spec, vx355_join_build*
   VX_CHECK_ARG(spec->num_keys >= 1 && spec->num_keys <= kMaxKeys, "1..8 join keys supported");
   VX_CHECK_ARG(spec->num_dependents >= 0 && spec->num_dependents <= kMaxDeps,
                "at most 16 build payload columns");
-  if (!supportedJoin(spec->join_type) || spec->null_aware) {
+  if (!supportedJoin(spec->join_type) || (spec->null_aware && spec->join_type != VX355_JOIN_ANTI)) {
     VX_THROW(VX355_EUNSUPPORTED, "join type " + std::to_string(spec->join_type) +
                                      (spec->null_aware ? " (null aware)" : "") + " not on device");
   }
@@ -1588,13 +1757,18 @@ int vx355_join_probe_create(vx355_join_table* table, const vx355_join_probe_spec
   VX_CHECK_ARG(table && spec && out, "NULL argument");
   VX_CHECK_ARG(spec->num_keys == static_cast<int32_t>(table->keyKinds.size()),
                "probe and build key counts differ");
-  if (!supportedJoin(spec->join_type) || spec->null_aware) {
+  if (!supportedJoin(spec->join_type) || (spec->null_aware && spec->join_type != VX355_JOIN_ANTI)) {
     VX_THROW(VX355_EUNSUPPORTED, "join type " + std::to_string(spec->join_type) + " not on device");
+  }
+  if ((marksProbedRows(spec->join_type) || marksProbedRows(table->joinType)) &&
+      spec->join_type != table->joinType) {
+    VX_THROW(VX355_EINVAL, "right / full / right semi joins need a table built for that join type");
   }
   auto p = std::make_unique<vx355_join_probe>();
   p->table = table;
   vx355_join_table_retain(table);
   p->joinType = spec->join_type;
+  p->nullAware = spec->null_aware != 0;
   p->keyCols.assign(spec->key_cols, spec->key_cols + spec->num_keys);
   *out = p.release();
   VX_API_END
@@ -1617,6 +1791,18 @@ int vx355_join_probe_get_output(vx355_join_probe* h, int32_t max_rows, int32_t* 
   VX_CHECK_ARG(h, "NULL argument");
   probeGetOutput(*h, max_rows, mapping_out, build_rows_out, out_mem, build_cols, build_col_ids,
                  num_build_cols, n_out, finished);
+  VX_API_END
+}
+
+int vx355_join_probe_get_build_side_output(vx355_join_probe* h, int32_t max_rows, int32_t* build_rows_out,
+                                           int32_t out_mem, vx355_out_column* build_cols,
+                                           const int32_t* build_col_ids, int32_t num_build_cols, int32_t* n_out,
+                                           int32_t* finished) {
+  VX_API_BEGIN
+  Runtime::get().requireInit();
+  VX_CHECK_ARG(h, "NULL argument");
+  probeGetBuildSideOutput(*h, max_rows, build_rows_out, out_mem, build_cols, build_col_ids, num_build_cols,
+                          n_out, finished);
   VX_API_END
 }
 
