@@ -675,3 +675,35 @@ def test_mid_stream_switch_to_generic_mode(oracle, vx, defer_cap, monkeypatch):
                            ignore_null_keys=ignore)
         assert_columns_equal(got, exp, gop.kinds, what=f"switch on long string ignore={ignore}")
         assert gop.stats().hash_mode == abi.MODE_HASH
+
+
+def test_single_wide_integer_key_stays_in_normalized_mode(oracle, vx, monkeypatch):
+    """One BIGINT key spanning (almost) all of int64: the reference drops to kHash above
+    VectorHasher::kMaxRange; here the value itself is the 64-bit normalized key (open addressing,
+    one random sector per row). The two largest int64 values use reserved ids: their appearance
+    moves the table to the generic mode in mid stream."""
+    monkeypatch.setenv("VX355_AGG_COALESCE_ROWS", "0")
+    rng = np.random.default_rng(93)
+    n = 120000
+    pool = rng.integers(-2 ** 63, 2 ** 63 - 3, 30000, dtype=np.int64)
+    pool[:3] = [-2 ** 63, 2 ** 63 - 3, 0]
+    aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT), (abi.AGG_MIN, 1, abi.DOUBLE)]
+
+    def batch(keys):
+        return abi.HostBatch([abi.HostColumn(abi.BIGINT, keys, rng.random(len(keys)) > 0.02),
+                              abi.HostColumn(abi.DOUBLE, _dyadic(rng, len(keys)), rng.random(len(keys)) > 0.1)])
+    small = rng.integers(-1000, 1000, n).astype(np.int64)           # first batch: a narrow range (array mode)
+    batches = [batch(small), batch(pool[rng.integers(0, 30000, n)]), batch(pool[rng.integers(0, 30000, n)])]
+    exp, _ = run_agg(oracle, batches, [0], [abi.BIGINT], aggs, max_rows=100000)
+    got, gop = run_agg(vx, batches, [0], [abi.BIGINT], aggs, max_rows=100000)
+    assert_columns_equal(got, exp, gop.kinds, what="wide single key")
+    assert gop.stats().hash_mode == abi.MODE_NORMALIZED_KEY
+    # the reserved values arrive: generic mode takes over, results unchanged
+    top = pool[rng.integers(0, 30000, n)].copy()
+    top[::97] = 2 ** 63 - 1
+    top[1::89] = 2 ** 63 - 2
+    batches.append(batch(top))
+    exp, _ = run_agg(oracle, batches, [0], [abi.BIGINT], aggs, max_rows=100000)
+    got, gop = run_agg(vx, batches, [0], [abi.BIGINT], aggs, max_rows=100000)
+    assert_columns_equal(got, exp, gop.kinds, what="wide single key + reserved values")
+    assert gop.stats().hash_mode == abi.MODE_HASH

@@ -1985,6 +1985,28 @@ Decision decide(vx355_agg& h) {
   Decision d{};
   unsigned __int128 product = 1;
   bool overflow = false;
+  // A single integer key is its own 64-bit normalized key whatever its range
+  // (the reference falls back to kHash above kMaxRange; here the open-addressing
+  // mode on id = value - INT64_MIN + 1 is the cheaper equivalent). Two ids are
+  // reserved (0 = null, ~0 = empty slot): the two largest int64 values force
+  // the generic mode.
+  if (h.keys.size() == 1 && h.keys[0].kind >= VX355_TINYINT && h.keys[0].kind <= VX355_BIGINT &&
+      h.keys[0].hasObserved) {
+    const auto& ks = h.keys[0];
+    int64_t span;
+    if (__builtin_sub_overflow(ks.obsMax, ks.obsMin, &span) || span >= kMaxRangeSpan) {
+      if (ks.obsMax > INT64_MAX - 2) {
+        VX_THROW(VX355_EUNSUPPORTED, "grouping key uses the reserved ids of the wide single-key mode");
+      }
+      d.ranges[0].min = INT64_MIN;
+      d.ranges[0].max = INT64_MAX - 2;
+      d.ranges[0].rangeSize = ~0ULL;  // max - min + 2
+      d.ranges[0].multiplier = 1;
+      d.capacity = ~0ULL;
+      d.mode = MODE_NORMALIZED;
+      return d;
+    }
+  }
   for (size_t k = 0; k < h.keys.size(); ++k) {
     auto& ks = h.keys[k];
     int64_t mn = 0, mx = -1;
@@ -3148,7 +3170,9 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
     }
     if (!needGeneric) {
       try {
-        rebuildTable(h, static_cast<uint64_t>(std::min<int64_t>(n, h.chunkRows)));
+        // Sized for the first chunk (<= 1 M rows); the chunk loop grows an
+        // open-addressing table before every later chunk (checkSize).
+        rebuildTable(h, static_cast<uint64_t>(std::min<int64_t>({n, h.chunkRows, 1LL << 20})));
       } catch (const Error& e) {
         if (e.status != VX355_EUNSUPPORTED) {
           throw;

@@ -40,15 +40,28 @@ __global__ __launch_bounds__(256) void k_filter_bits(FilterArgs a) {
 template <typename T>
 __global__ __launch_bounds__(256) void k_filter_bits_flat(const T* values, T constant, int32_t cmp,
                                                            int64_t numRows, uint64_t* bits) {
+  // A wave covers 4 consecutive selection words per step: four independent
+  // coalesced loads in flight per lane.
+  constexpr int kWords = 4;
   const int64_t numWords = (numRows + 63) >> 6;
+  const int64_t numGroups = (numWords + kWords - 1) / kWords;
   const int64_t waveStride = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
-  for (int64_t w = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6; w < numWords;
-       w += waveStride) {
-    const int64_t row = (w << 6) + lane();
-    const bool pass = row < numRows && compareValues<T>(cmp, values[row], constant);
-    const uint64_t m = ballot(pass);
-    if (lane() == 0) {
-      bits[w] = m;
+  for (int64_t g = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6; g < numGroups;
+       g += waveStride) {
+    T v[kWords];
+#pragma unroll
+    for (int j = 0; j < kWords; ++j) {
+      const int64_t row = ((g * kWords + j) << 6) + lane();
+      v[j] = row < numRows ? values[row] : T();
+    }
+#pragma unroll
+    for (int j = 0; j < kWords; ++j) {
+      const int64_t w = g * kWords + j;
+      const int64_t row = (w << 6) + lane();
+      const uint64_t m = ballot(row < numRows && compareValues<T>(cmp, v[j], constant));
+      if (lane() == 0 && w < numWords) {
+        bits[w] = m;
+      }
     }
   }
 }

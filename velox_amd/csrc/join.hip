@@ -564,8 +564,14 @@ __device__ inline uint32_t lookupSlots(const ProbeArgs& a, uint64_t key) {
 // bits (a bitmap 32x smaller than the head array, Infinity-Cache resident for
 // TPC-H sized builds), then the head words of the survivors only. The tile's
 // output-row count falls out of the same pass (listJoinResults needs it).
-__global__ __launch_bounds__(256) void k_join_probe(ProbeArgs a) {
+// MODE / FAST >= 0 fix a.mode / a.fastKey at compile time (the array-mode fast
+// paths then need half the registers of the all-purpose instantiation <-1, -1>).
+template <int MODE, int FAST>
+__global__ __launch_bounds__(256) void k_join_probe(ProbeArgs args) {
   __shared__ uint64_t waveSums[4];
+  const ProbeArgs& a = args;
+  const int mode = MODE >= 0 ? MODE : a.mode;
+  const int fastKey = FAST >= 0 ? FAST : a.fastKey;
   for (int64_t tile = blockIdx.x; tile < a.numTiles; tile += gridDim.x) {
     const int64_t tileBase = tile * kTileRows;
     uint64_t mine = 0;
@@ -578,7 +584,7 @@ __global__ __launch_bounds__(256) void k_join_probe(ProbeArgs a) {
       for (int u = 0; u < kProbeUnroll; ++u) {
         rows[u] = tileBase + (it * kProbeUnroll + u) * 256 + threadIdx.x;
       }
-      if (a.fastKey) {
+      if (fastKey) {
         const int64_t* kp = static_cast<const int64_t*>(a.keys[0].values);
         int64_t v[kProbeUnroll];
         int64_t src[kProbeUnroll];
@@ -586,7 +592,7 @@ __global__ __launch_bounds__(256) void k_join_probe(ProbeArgs a) {
         for (int u = 0; u < kProbeUnroll; ++u) {
           src[u] = rows[u] < a.numRows ? rows[u] : a.numRows - 1;
         }
-        if (a.fastKey == 2) {
+        if (fastKey == 2) {
           // dictionary-wrapped key (the probe input came through a FilterProject)
 #pragma unroll
           for (int u = 0; u < kProbeUnroll; ++u) {
@@ -602,18 +608,18 @@ __global__ __launch_bounds__(256) void k_join_probe(ProbeArgs a) {
           candidate[u] = rows[u] < a.numRows && v[u] >= a.ranges[0].min && v[u] <= a.ranges[0].max;
           key[u] = static_cast<uint64_t>(v[u]) - static_cast<uint64_t>(a.ranges[0].min) + 1;
         }
-      } else if (a.mode != JMODE_HASH) {
+      } else if (mode != JMODE_HASH) {
 #pragma unroll
         for (int u = 0; u < kProbeUnroll; ++u) {
           candidate[u] = rows[u] < a.numRows && probeKey(a, rows[u], &key[u]);
         }
       }
-      if (a.mode == JMODE_HASH) {
+      if (mode == JMODE_HASH) {
 #pragma unroll
         for (int u = 0; u < kProbeUnroll; ++u) {
           hit[u] = rows[u] < a.numRows ? lookupGeneric(a, rows[u]) : kNoRow32;
         }
-      } else if (a.mode == JMODE_ARRAY) {
+      } else if (mode == JMODE_ARRAY) {
         uint32_t word[kProbeUnroll];
 #pragma unroll
         for (int u = 0; u < kProbeUnroll; ++u) {
@@ -1352,7 +1358,17 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
     a.fastKey = a.keys[0].enc == VX355_FLAT ? 1 : (a.keys[0].enc == VX355_DICTIONARY ? 2 : 0);
   }
   const int grid = static_cast<int>(std::min<int64_t>(p.numTiles, static_cast<int64_t>(rt.numCUs) * 8));
-  VX_LAUNCH("k_join_probe", k_join_probe, grid, 256, 0, a);
+  if (t.mode == JMODE_ARRAY && a.fastKey == 1) {
+    VX_LAUNCH("k_join_probe", (k_join_probe<JMODE_ARRAY, 1>), grid, 256, 0, a);
+  } else if (t.mode == JMODE_ARRAY && a.fastKey == 2) {
+    VX_LAUNCH("k_join_probe", (k_join_probe<JMODE_ARRAY, 2>), grid, 256, 0, a);
+  } else if (t.mode == JMODE_NORMALIZED && a.fastKey == 1) {
+    VX_LAUNCH("k_join_probe", (k_join_probe<JMODE_NORMALIZED, 1>), grid, 256, 0, a);
+  } else if (t.mode == JMODE_ARRAY) {
+    VX_LAUNCH("k_join_probe", (k_join_probe<JMODE_ARRAY, 0>), grid, 256, 0, a);
+  } else {
+    VX_LAUNCH("k_join_probe", (k_join_probe<-1, -1>), grid, 256, 0, a);
+  }
   VX_LAUNCH("k_scan_u64", k_scan_u64, 1, 1024, 0, sums, p.numTiles, offs);
   p.hostTileOffsets.resize(p.numTiles + 1);
   copyOut(p.hostTileOffsets.data(), VX355_MEM_HOST, offs, static_cast<size_t>(p.numTiles + 1) * 8);
