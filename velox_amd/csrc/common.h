@@ -187,6 +187,27 @@ class DeviceBatch {
 // flattened on the way — and handed to the operator's normal path in one piece,
 // the role CudfBatchConcat plays for the cuDF backend
 // (experimental/cudf/CudfConfig.h:114-125).
+// Growable pinned host buffer (hipHostMalloc): H2D copies from it are real
+// DMA transfers at PCIe speed instead of the driver's bounce-buffer path.
+class PinnedBuf {
+ public:
+  PinnedBuf() = default;
+  PinnedBuf(const PinnedBuf&) = delete;
+  PinnedBuf& operator=(const PinnedBuf&) = delete;
+  PinnedBuf(PinnedBuf&& o) noexcept : p_(o.p_), cap_(o.cap_), size_(o.size_) { o.p_ = nullptr; o.cap_ = o.size_ = 0; }
+  ~PinnedBuf();
+  // Extends the used size by 'bytes' (contents preserved) and returns the new tail.
+  char* extend(size_t bytes);
+  char* data() const { return p_; }
+  size_t size() const { return size_; }
+  void clear() { size_ = 0; }
+
+ private:
+  char* p_ = nullptr;
+  size_t cap_ = 0;
+  size_t size_ = 0;
+};
+
 class HostCoalescer {
  public:
   int64_t thresholdRows = 1 << 18;  // <= 0 disables coalescing
@@ -215,7 +236,7 @@ class HostCoalescer {
  private:
   struct PendingCol {
     int32_t kind = -1;
-    std::vector<char> values;    // flat values (BOOLEAN: one byte per row)
+    PinnedBuf values;            // flat values (BOOLEAN: one byte per row)
     std::vector<uint8_t> valid;  // one byte per row
     bool anyNull = false;
   };

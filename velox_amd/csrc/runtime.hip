@@ -201,6 +201,32 @@ void copyIn(void* devDst, const void* src, int32_t srcMem, size_t bytes) {
                         rt.stream));
 }
 
+PinnedBuf::~PinnedBuf() {
+  if (p_) {
+    (void)hipHostFree(p_);
+  }
+}
+
+char* PinnedBuf::extend(size_t bytes) {
+  if (size_ + bytes > cap_) {
+    const size_t cap = std::max<size_t>({size_ + bytes, cap_ * 2, static_cast<size_t>(1) << 20});
+    char* np = nullptr;
+    HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&np), cap, hipHostMallocDefault));
+    if (size_) {
+      std::memcpy(np, p_, size_);
+    }
+    if (p_) {
+      // Earlier H2D copies from the old block are complete: flush() syncs before clear().
+      (void)hipHostFree(p_);
+    }
+    p_ = np;
+    cap_ = cap;
+  }
+  char* tail = p_ + size_;
+  size_ += bytes;
+  return tail;
+}
+
 bool HostCoalescer::append(const vx355_batch* batch, const std::vector<int32_t>& usedCols) {
   const int64_t n = batch->num_rows;
   if (thresholdRows <= 0 || n <= 0 || n >= thresholdRows) {
@@ -250,10 +276,8 @@ bool HostCoalescer::append(const vx355_batch* batch, const std::vector<int32_t>&
       VX_THROW(VX355_EINVAL, "column type changed between batches");
     }
     const int w = kindWidth(col.type_kind) == 0 ? 1 : kindWidth(col.type_kind);
-    const size_t oldBytes = pc.values.size();
-    pc.values.resize(oldBytes + static_cast<size_t>(n) * w);
+    char* dst = pc.values.extend(static_cast<size_t>(n) * w);
     pc.valid.resize(static_cast<size_t>(before + n), 1);
-    char* dst = pc.values.data() + oldBytes;
     uint8_t* valid = pc.valid.data() + before;
     const char* src = static_cast<const char*>(col.values);
     const bool isBool = col.type_kind == VX355_BOOLEAN;
