@@ -78,7 +78,9 @@ typedef struct vx355_column {
                             NULL = no nulls. CONSTANT: only bit 0 is read. */
   const int32_t* indices; /* DICTIONARY: num_rows indices into values. */
   int32_t base_size;      /* DICTIONARY: number of base values; else 0. */
-  int32_t mem;            /* vx355_mem of values / nulls / indices. */
+  int32_t mem;            /* vx355_mem of values / nulls / indices. VX355_MEM_DEVICE buffers must
+                             be complete when the call is made: the library works on its own
+                             HIP stream and does not order itself behind the producer's. */
 } vx355_column;
 
 /* RowVector (vector/ComplexVector.h) reduced to its decoded children. */

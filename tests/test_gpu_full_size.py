@@ -1,0 +1,157 @@
+"""Parity at BASELINE.json's full sizes, through properties that do not need the CPU
+oracle to chew through 10^9 rows: integer results are checked bit-exactly against torch
+integer reductions of the same HBM-resident columns, DOUBLE results against exact
+integer sums where the data allows it, and the partial -> final split, join
+completeness and pair validity against the algebra of the operators. The inputs are
+bench.py's generators (the workloads BENCH lines are quoted on)."""
+import numpy as np
+import pytest
+
+from velox_amd import abi
+from gpu_util import ulp_distance
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_gpu(vx):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch
+
+
+def test_q1_sf100_counts_and_integer_sums_are_exact_and_partial_final_agrees(vx, torch_gpu):
+    """TPC-H Q1 at SF100 (600 037 902 rows), fused FilterProject + HashAggregation."""
+    torch = torch_gpu
+    import bench
+    from velox_amd import dist as vdist
+    n = 600_037_902
+    wl = bench.Q1(torch, n, "cuda:0", 4321)
+    out = wl.step()
+    c = wl.c
+    keep = c["ship"] <= bench.Q1_CUTOFF
+    code = (c["rf"][:, 1].to(torch.int64) * 256 + c["ls"][:, 1].to(torch.int64))[keep]
+    groups, inverse, counts = torch.unique(code, return_inverse=True, return_counts=True)
+    qty_sum = torch.zeros(len(groups), dtype=torch.int64, device=code.device).index_add_(
+        0, inverse, c["qty"][keep].to(torch.int64))
+    exp = {int(g): (int(cnt), int(q)) for g, cnt, q in zip(groups.tolist(), counts.tolist(), qty_sum.tolist())}
+    del code, inverse, keep
+    rf, ls = out[0][0], out[1][0]
+    assert len(rf) == len(exp) and int(sum(out[9][0])) == sum(v[0] for v in exp.values())
+    for i in range(len(rf)):
+        cnt, q = exp[rf[i][0] * 256 + ls[i][0]]
+        assert int(out[9][0][i]) == cnt                      # count(*): bit exact
+        assert out[2][0][i] == float(q)                      # sum(l_quantity): integers as doubles, exact
+        assert out[6][0][i] == float(q) / cnt                # avg = sum / count (AverageAggregateBase.h)
+    # partial over two halves + final == single pass: keys, counts, integer sums exact, other sums <= 1 ULP
+    half = (n // 2) & ~63
+    parts = []
+    for lo, hi in ((0, half), (half, n)):
+        scan = bench.DevBatch([bench.dcol(abi.VARCHAR, c["rf"][lo:hi]), bench.dcol(abi.VARCHAR, c["ls"][lo:hi]),
+                               bench.dcol(abi.DOUBLE, c["qty"][lo:hi]), bench.dcol(abi.DOUBLE, c["ep"][lo:hi]),
+                               bench.dcol(abi.DOUBLE, c["disc"][lo:hi]), bench.dcol(abi.DOUBLE, c["tax"][lo:hi]),
+                               bench.dcol(abi.INTEGER, c["ship"][lo:hi])], hi - lo)
+        op = vx.HashAggregation(bench.Q1_KEYS[0], bench.Q1_KEYS[1], bench.Q1.FUSED_AGGS, abi.STEP_PARTIAL)
+        op.set_fused_input(bench.Q1_TERMS, bench.Q1_PROJ)
+        op.add_input(scan)
+        op.no_more_input()
+        parts.append(vx.collect_output(op, 1024))
+    kinds = vdist.partial_kinds(bench.Q1_KEYS[1], bench.Q1.FUSED_AGGS)
+    mat = np.concatenate([vdist.encode_partial(p, kinds, len(p[0][1])) for p in parts])
+    fin = vx.HashAggregation([0, 1], bench.Q1_KEYS[1], vdist.final_aggs_for(bench.Q1.FUSED_AGGS, 2), abi.STEP_FINAL)
+    fin.add_input(vdist.decode_partials(mat, kinds))
+    fin.no_more_input()
+    merged = vx.collect_output(fin, 1024)
+    order = {(rf[i], ls[i]): i for i in range(len(rf))}
+    for j in range(len(merged[0][0])):
+        i = order[(merged[0][0][j], merged[1][0][j])]
+        assert merged[9][0][j] == out[9][0][i] and merged[2][0][j] == out[2][0][i]
+        for col in (3, 4, 5, 6, 7, 8):
+            assert ulp_distance(np.array([merged[col][0][j]]), np.array([out[col][0][i]]))[0] <= 1, col
+
+
+def test_q3_sf100_join_is_complete_and_every_pair_is_valid(vx, torch_gpu):
+    """The dominant join of TPC-H Q3 at SF100: ~14.6 M build rows, ~323 M probe rows."""
+    torch = torch_gpu
+    import bench
+    wl = bench.Q3(torch, 600_037_902, "cuda:0", 999)
+    n = wl.step()
+    # completeness: orders keys are unique, so the inner join emits one pair per probe key present in the build side
+    sorted_keys, order = torch.sort(wl.bkey)
+    pos = torch.searchsorted(sorted_keys, wl.pkey).clamp_(max=len(sorted_keys) - 1)
+    present = sorted_keys[pos] == wl.pkey
+    assert n == int(present.sum())
+    mapping, brows = wl.mapping[:n].to(torch.int64), wl.brows[:n].to(torch.int64)
+    # ascending probe rows, exactly the probe rows with a match
+    assert bool((mapping[1:] > mapping[:-1]).all())
+    assert bool((mapping == torch.nonzero(present).flatten()).all())
+    # every pair joins equal keys; the gathered payload is the build row's payload
+    assert bool((wl.bkey[brows] == wl.pkey[mapping]).all())
+    assert bool((wl.odate_out[:n] == wl.bdate[brows]).all())
+    # semi + anti partition the probe side
+    totals = {}
+    for jt in (abi.JOIN_LEFT_SEMI_FILTER, abi.JOIN_ANTI):
+        b = vx.HashBuild([0], [abi.BIGINT], [], [], jt)
+        b.add_input(wl.build)
+        p = vx.HashProbe(b.finish(), [0], jt)
+        p.add_input(wl.probe)
+        totals[jt], fin = p.get_output_device(wl.probe_rows, wl.mapping.data_ptr(), 0)
+        assert fin
+    assert totals[abi.JOIN_LEFT_SEMI_FILTER] == n and totals[abi.JOIN_ANTI] == wl.probe_rows - n
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_c4_one_billion_rows_counts_exact_sums_close(vx, torch_gpu, sparse):
+    """BASELINE config 4 at full size (dense keys: radix-partitioned LDS path; sparse keys:
+    open addressing on the value): sum(v) + count(*) per group against torch reductions."""
+    torch = torch_gpu
+    import bench
+    n, distinct = 1_000_000_000, 100_000_000
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(7)
+    j = torch.randint(0, distinct, (n,), dtype=torch.int64, device="cuda:0", generator=g)
+    v = torch.randint(0, 1 << 20, (n,), dtype=torch.int64, device="cuda:0", generator=g).to(torch.float64) / 1024.0
+    k = j
+    if sparse:
+        k = (j * -7046029254386353131) ^ 0x5DEECE66D   # odd multiplier mod 2^64: a bijection, keys all over int64
+    torch.cuda.synchronize()   # the library runs on its own stream: device inputs must be complete
+    op = vx.HashAggregation([0], [abi.BIGINT], [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)],
+                            abi.STEP_SINGLE)
+    op.add_input(bench.DevBatch([bench.dcol(abi.BIGINT, k), bench.dcol(abi.DOUBLE, v)], n))
+    op.no_more_input()
+    st = op.stats()
+    assert st.input_rows == n
+    if not sparse:
+        assert st.hash_mode == abi.MODE_ARRAY and st.radix_launches >= 2
+    else:
+        assert st.hash_mode == abi.MODE_NORMALIZED_KEY
+    cap = 1 << 24
+    keys = torch.empty(cap, dtype=torch.int64, device="cuda:0")
+    sums = torch.empty(cap, dtype=torch.float64, device="cuda:0")
+    cnts = torch.empty(cap, dtype=torch.int64, device="cuda:0")
+    nulls = [torch.empty(cap // 64 + 1, dtype=torch.int64, device="cuda:0") for _ in range(3)]
+    descs = (abi.OutColumn * 3)()
+    for i, (kind, t) in enumerate(((abi.BIGINT, keys), (abi.DOUBLE, sums), (abi.BIGINT, cnts))):
+        descs[i].type_kind, descs[i].mem = kind, abi.MEM_DEVICE
+        descs[i].values, descs[i].nulls = t.data_ptr(), nulls[i].data_ptr()
+    exp_cnt = torch.bincount(j, minlength=distinct)
+    exp_sum = torch.zeros(distinct, dtype=torch.int64, device="cuda:0").index_add_(0, j, (v * 1024.0).to(torch.int64))
+    import ctypes as C
+    seen, total_groups = torch.zeros(distinct, dtype=torch.bool, device="cuda:0"), 0
+    while True:
+        m, fin = C.c_int32(), C.c_int32()
+        vx._check(vx.lib().vx355_agg_get_output(op.h, descs, 3, cap, C.byref(m), C.byref(fin)))
+        m = m.value
+        if m:
+            kk = keys[:m]
+            jj = ((kk ^ 0x5DEECE66D) * -1018231460777725123) if sparse else kk   # inverse of the bijection
+            assert bool(((jj >= 0) & (jj < distinct)).all()) and not bool(seen[jj].any())
+            seen[jj] = True
+            assert bool((cnts[:m] == exp_cnt[jj]).all())                          # counts: bit exact
+            # dyadic values: the exact sum is an integer multiple of 2^-10 below 2^53 -> bit exact too
+            assert bool((sums[:m] == exp_sum[jj].to(torch.float64) / 1024.0).all())
+            total_groups += m
+        if fin.value:
+            break
+    assert total_groups == int((exp_cnt > 0).sum()) == st.num_groups
