@@ -381,9 +381,12 @@ class HashAggregation:
         self.kinds = list(types[: n.value])
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().vx355_agg_destroy(self.h)
-            self.h = None
+        try:  # at interpreter shutdown module globals may already be gone
+            if getattr(self, "h", None):
+                lib().vx355_agg_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
 
     def set_fused_input(self, terms, projs):
         """Fuse the upstream FilterProject: add_input then takes its INPUT batches;
@@ -465,9 +468,12 @@ class HashBuild:
         return JoinTable(t, self.dep_types)
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().vx355_join_build_destroy(self.h)
-            self.h = None
+        try:  # at interpreter shutdown module globals may already be gone
+            if getattr(self, "h", None):
+                lib().vx355_join_build_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
 
 
 JoinBuild = HashBuild
@@ -508,9 +514,12 @@ class JoinTable:
         return blocks
 
     def __del__(self):
-        if getattr(self, "t", None):
-            lib().vx355_join_table_release(self.t)
-            self.t = None
+        try:  # at interpreter shutdown module globals may already be gone
+            if getattr(self, "t", None):
+                lib().vx355_join_table_release(self.t)
+                self.t = None
+        except Exception:
+            pass
 
 
 def bloom_test(blocks, column, rows=None):
@@ -584,9 +593,12 @@ class HashProbe:
         return n.value, bool(fin.value)
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().vx355_join_probe_destroy(self.h)
-            self.h = None
+        try:  # at interpreter shutdown module globals may already be gone
+            if getattr(self, "h", None):
+                lib().vx355_join_probe_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
 
 
 JoinProbe = HashProbe
