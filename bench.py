@@ -362,7 +362,12 @@ class Q3:
     ~14.6 M build rows; 600 M lineitems, l_shipdate > 1995-03-15 (~54 %) probe."""
     name = "tpch_q3_sf100_join"
     bytes_per_row = 24
-    agg_bytes_per_row = 24
+    # What k_join_probe has to move per probe row in array mode: the 8-byte key in, the
+    # 4-byte hit out (the presence bitmap and the head words of the ~1 % matching rows are
+    # cache resident / negligible). SURVEY.md §8(d) prices the reference's layout instead:
+    # key + one 16-byte table slot = 24 B/probe, reported next to it.
+    agg_bytes_per_row = 12
+    contract_bytes_per_row = 24
     dominant = "k_join_probe"
     Q3_DATE = 9204  # 1995-03-15
     random_probe = False
@@ -461,7 +466,9 @@ class Q3Full:
     lineitem (~600 M, dbgen order) -> probe -> 3-key aggregation. rows = customer +
     orders + lineitem rows scanned per step; scan bytes 24 + 24 + 28 B/row."""
     name = "tpch_q3_sf100_full_query"
-    agg_bytes_per_row = 24
+    # both probes read dictionary-wrapped keys: 4-byte index + 8-byte key in, 4-byte hit out
+    agg_bytes_per_row = 16
+    contract_bytes_per_row = 24
     dominant = "k_join_probe"
 
     def __init__(self, torch, n, device, seed):
@@ -512,6 +519,7 @@ class Q3Full:
     def step(self, step_kind=None):
         out, info = self.tpch.run_q3(ops, self.torch, self.t)
         self.last_info = info
+        self.selected = info["orders_selected"] + info["lineitems_selected"]   # rows the two probes see
         return out
 
     def rows_per_step(self):
@@ -845,6 +853,9 @@ def main():
             "traffic": pmc.get("traffic_bytes_per_launch"),
             "traffic_source": pmc.get("source"),
             "algorithmic_bytes_per_row": wl.agg_bytes_per_row,
+            "contract_bytes_per_row": getattr(wl, "contract_bytes_per_row", None),
+            "frac_at_contract_bytes": (achieved / HBM_PEAK_GBS * wl.contract_bytes_per_row / wl.agg_bytes_per_row)
+            if (achieved and getattr(wl, "contract_bytes_per_row", None)) else None,
             "measured_copy_GBps": copy_ceiling,
             "frac_of_measured_copy": (achieved / copy_ceiling) if (achieved and copy_ceiling) else None,
             "avg_launch_ms": (dom_ms / dom_launches) if dom_launches else None,
