@@ -863,7 +863,7 @@ def main():
         },
         "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())},
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:   # the CPU legs are timed at N = 1 only
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
         oracle_lib.lib()

@@ -91,3 +91,29 @@ def test_repartitioned_join_over_gloo_matches_single_process(world, tmp_path):
     for i in range(world):
         for j in range(i + 1, world):
             assert not (per_rank_keys[i] & per_rank_keys[j])
+
+
+def test_partial_gather_small_and_large_group_counts():
+    """all_gather_partials: one fixed-size collective up to 64 groups per rank, a second,
+    exactly sized one above (driven here by a 1-rank stand-in for torch.distributed)."""
+    import torch
+    from velox_amd import dist as vdist
+
+    class OneRank:
+        calls = 0
+
+        def get_world_size(self):
+            return 1
+
+        def all_gather(self, out, t):
+            OneRank.calls += 1
+            out[0].copy_(t)
+    kinds = [abi.BIGINT, abi.DOUBLE]
+    for groups, expect_calls in ((5, 1), (64, 1), (65, 2), (3000, 2)):
+        cols = [(np.arange(groups, dtype=np.int64) * 3, np.ones(groups, dtype=bool)),
+                (np.arange(groups) / 8.0, np.arange(groups) % 5 != 0)]
+        OneRank.calls = 0
+        batch = vdist.all_gather_partials(OneRank(), torch, cols, kinds)
+        assert OneRank.calls == expect_calls and batch.num_rows == groups
+        assert (batch.columns[0].values == cols[0][0]).all()
+        assert (batch.columns[1].values == cols[1][0]).all() and (batch.columns[1].valid == cols[1][1]).all()
