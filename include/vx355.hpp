@@ -1,0 +1,278 @@
+// vx355.hpp — header-only C++ host side over the C ABI (vx355.h).
+//
+// The classes mirror the part of exec::Operator (exec/Operator.h:232-342) the
+// three replaced operators implement — needsInput / addInput / noMoreInput /
+// getOutput / isFinished / close — with the same call order, so that an
+// exec::Operator shim forwards one to one and host programs
+// read like the reference's operator tests. Errors surface the way Velox's do:
+// VX355_EUSER -> vx355::UserError (VeloxUserError), everything else ->
+// vx355::RuntimeError (VeloxRuntimeError). Nothing here touches HIP: all device
+// work is behind libvx355.so.
+#ifndef VX355_HPP_
+#define VX355_HPP_
+
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "vx355.h"
+
+namespace vx355 {
+
+struct Error : std::runtime_error {
+  Error(int status, const std::string& what) : std::runtime_error(what), status(status) {}
+  int status;
+};
+struct UserError : Error {  // common/base/VeloxException.h:354 VeloxUserError
+  using Error::Error;
+};
+struct RuntimeError : Error {  // :420 VeloxRuntimeError
+  using Error::Error;
+};
+
+inline void check(int status) {
+  if (status == VX355_OK) {
+    return;
+  }
+  const char* msg = vx355_last_error();
+  if (status == VX355_EUSER) {
+    throw UserError(status, msg ? msg : "user error");
+  }
+  throw RuntimeError(status, msg ? msg : "vx355 failure");
+}
+
+inline void init(int device = 0) { check(vx355_init(device)); }
+
+// exec::HashAggregation (exec/HashAggregation.h:24-118).
+class HashAggregation {
+ public:
+  HashAggregation(std::vector<int32_t> keyChannels, std::vector<int32_t> keyTypes, std::vector<vx355_agg_fn> aggregates,
+                  vx355_agg_step step = VX355_STEP_SINGLE, bool ignoreNullKeys = false)
+      : keyChannels_(std::move(keyChannels)), keyTypes_(std::move(keyTypes)), aggregates_(std::move(aggregates)) {
+    vx355_agg_spec spec{};
+    spec.num_keys = static_cast<int32_t>(keyChannels_.size());
+    spec.key_cols = keyChannels_.data();
+    spec.key_types = keyTypes_.data();
+    spec.num_aggs = static_cast<int32_t>(aggregates_.size());
+    spec.aggs = aggregates_.data();
+    spec.step = step;
+    spec.ignore_null_keys = ignoreNullKeys ? 1 : 0;
+    check(vx355_agg_create(&spec, &handle_));  // VX355_EUNSUPPORTED: keep the CPU operator
+  }
+  HashAggregation(const HashAggregation&) = delete;
+  HashAggregation& operator=(const HashAggregation&) = delete;
+  ~HashAggregation() { close(); }
+
+  // Fuse the upstream FilterProject (vx355_agg_set_fused_input).
+  void setFusedInput(const std::vector<vx355_filter_term>& terms, const std::vector<vx355_projection>& projections) {
+    check(vx355_agg_set_fused_input(handle_, terms.data(), static_cast<int32_t>(terms.size()), projections.data(),
+                                    static_cast<int32_t>(projections.size())));
+  }
+
+  bool needsInput() const { return !noMoreInput_; }  // HashAggregation.h:50
+  void addInput(const vx355_batch& input) { check(vx355_agg_add_input(handle_, &input)); }
+  void noMoreInput() {
+    noMoreInput_ = true;
+    check(vx355_agg_no_more_input(handle_));
+  }
+  // Result types in output order (keys, then aggregates; partial avg = sum, count).
+  std::vector<int32_t> outputTypes() const {
+    std::vector<int32_t> types(64);
+    int32_t n = 0;
+    check(vx355_agg_output_types(handle_, types.data(), static_cast<int32_t>(types.size()), &n));
+    types.resize(n);
+    return types;
+  }
+  // Writes at most maxRows rows into caller-owned columns; returns the row count (0 = nothing left,
+  // exec::Operator::getOutput's nullptr).
+  int32_t getOutput(vx355_out_column* columns, int32_t numColumns, int32_t maxRows) {
+    if (!noMoreInput_ || finished_) {
+      return 0;
+    }
+    int32_t n = 0, finished = 0;
+    check(vx355_agg_get_output(handle_, columns, numColumns, maxRows, &n, &finished));
+    finished_ = finished != 0;
+    return n;
+  }
+  bool isFinished() const { return finished_; }
+  vx355_agg_stats stats() const {
+    vx355_agg_stats s{};
+    check(vx355_agg_get_stats(handle_, &s));
+    return s;
+  }
+  void close() {
+    if (handle_) {
+      vx355_agg_destroy(handle_);
+      handle_ = nullptr;
+    }
+  }
+
+ private:
+  std::vector<int32_t> keyChannels_, keyTypes_;
+  std::vector<vx355_agg_fn> aggregates_;
+  vx355_agg* handle_ = nullptr;
+  bool noMoreInput_ = false;
+  bool finished_ = false;
+};
+
+// The table HashJoinBridge hands from build to probe (exec/HashJoinBridge.h:57,116).
+class JoinTable {
+ public:
+  explicit JoinTable(vx355_join_table* t = nullptr) : t_(t) {}
+  JoinTable(const JoinTable& o) : t_(o.t_) {
+    if (t_) {
+      vx355_join_table_retain(t_);
+    }
+  }
+  JoinTable(JoinTable&& o) noexcept : t_(o.t_) { o.t_ = nullptr; }
+  JoinTable& operator=(JoinTable o) {
+    std::swap(t_, o.t_);
+    return *this;
+  }
+  ~JoinTable() {
+    if (t_) {
+      vx355_join_table_release(t_);
+    }
+  }
+  vx355_join_table* get() const { return t_; }
+  vx355_join_table_stats stats() const {
+    vx355_join_table_stats s{};
+    check(vx355_join_table_get_stats(t_, &s));
+    return s;
+  }
+  // HashProbe::pushdownDynamicFilters: what to push to the probe-side scan for key 'key'.
+  vx355_key_filter keyFilter(int32_t key) const {
+    vx355_key_filter f{};
+    check(vx355_join_table_key_filter(t_, key, &f));
+    return f;
+  }
+
+ private:
+  vx355_join_table* t_;
+};
+
+// exec::HashBuild (exec/HashBuild.h): one per build Driver.
+class HashBuild {
+ public:
+  HashBuild(std::vector<int32_t> keyChannels, std::vector<int32_t> keyTypes, std::vector<int32_t> dependentChannels,
+            std::vector<int32_t> dependentTypes, vx355_join_type joinType = VX355_JOIN_INNER, bool nullAware = false)
+      : keyChannels_(std::move(keyChannels)),
+        keyTypes_(std::move(keyTypes)),
+        dependentChannels_(std::move(dependentChannels)),
+        dependentTypes_(std::move(dependentTypes)) {
+    vx355_join_build_spec spec{};
+    spec.num_keys = static_cast<int32_t>(keyChannels_.size());
+    spec.key_cols = keyChannels_.data();
+    spec.key_types = keyTypes_.data();
+    spec.num_dependents = static_cast<int32_t>(dependentChannels_.size());
+    spec.dependent_cols = dependentChannels_.data();
+    spec.dependent_types = dependentTypes_.data();
+    spec.join_type = joinType;
+    spec.null_aware = nullAware ? 1 : 0;
+    check(vx355_join_build_create(&spec, &handle_));
+  }
+  HashBuild(const HashBuild&) = delete;
+  HashBuild& operator=(const HashBuild&) = delete;
+  ~HashBuild() { close(); }
+
+  bool needsInput() const { return !finished_; }
+  void addInput(const vx355_batch& input) { check(vx355_join_build_add_input(handle_, &input)); }
+  // HashBuild::noMoreInput + finishHashBuild (HashBuild.cpp:819-993): called on the LAST of the
+  // peer build operators with the others; returns the table the bridge publishes.
+  JoinTable noMoreInput(const std::vector<HashBuild*>& peers = {}) {
+    std::vector<vx355_join_build*> raw;
+    for (auto* p : peers) {
+      raw.push_back(p->handle_);
+    }
+    vx355_join_table* t = nullptr;
+    check(vx355_join_build_finish(handle_, raw.data(), static_cast<int32_t>(raw.size()), &t));
+    finished_ = true;
+    for (auto* p : peers) {
+      p->finished_ = true;
+    }
+    return JoinTable(t);
+  }
+  bool isFinished() const { return finished_; }
+  void close() {
+    if (handle_) {
+      vx355_join_build_destroy(handle_);
+      handle_ = nullptr;
+    }
+  }
+
+ private:
+  std::vector<int32_t> keyChannels_, keyTypes_, dependentChannels_, dependentTypes_;
+  vx355_join_build* handle_ = nullptr;
+  bool finished_ = false;
+};
+
+// exec::HashProbe (exec/HashProbe.h).
+class HashProbe {
+ public:
+  HashProbe(const JoinTable& table, std::vector<int32_t> keyChannels, vx355_join_type joinType = VX355_JOIN_INNER,
+            bool nullAware = false)
+      : keyChannels_(std::move(keyChannels)), joinType_(joinType) {
+    vx355_join_probe_spec spec{};
+    spec.num_keys = static_cast<int32_t>(keyChannels_.size());
+    spec.key_cols = keyChannels_.data();
+    spec.join_type = joinType;
+    spec.null_aware = nullAware ? 1 : 0;
+    check(vx355_join_probe_create(table.get(), &spec, &handle_));
+  }
+  HashProbe(const HashProbe&) = delete;
+  HashProbe& operator=(const HashProbe&) = delete;
+  ~HashProbe() { close(); }
+
+  bool needsInput() const { return !noMoreInput_ && drained_; }  // HashProbe.h: one input batch at a time
+  void addInput(const vx355_batch& input) {
+    check(vx355_join_probe_add_input(handle_, &input));
+    drained_ = false;
+  }
+  void noMoreInput() { noMoreInput_ = true; }
+  // One output batch: mapping[i] = probe row, buildRows[i] = build row or -1, buildColumns gathered at
+  // buildRows (extractColumns). Returns the row count; 0 = the current input is drained.
+  int32_t getOutput(int32_t maxRows, int32_t* mapping, int32_t* buildRows, vx355_out_column* buildColumns = nullptr,
+                    const int32_t* buildColumnIds = nullptr, int32_t numBuildColumns = 0, int32_t mem = VX355_MEM_HOST) {
+    if (drained_) {
+      return 0;
+    }
+    int32_t n = 0, finished = 0;
+    check(vx355_join_probe_get_output(handle_, maxRows, mapping, buildRows, mem, buildColumns, buildColumnIds,
+                                      numBuildColumns, &n, &finished));
+    drained_ = finished != 0;
+    return n;
+  }
+  // HashProbe::getBuildSideOutput (right / full / right semi), on the last prober after noMoreInput.
+  int32_t getBuildSideOutput(int32_t maxRows, int32_t* buildRows, vx355_out_column* buildColumns = nullptr,
+                             const int32_t* buildColumnIds = nullptr, int32_t numBuildColumns = 0,
+                             int32_t mem = VX355_MEM_HOST) {
+    if (buildSideDone_) {
+      return 0;
+    }
+    int32_t n = 0, finished = 0;
+    check(vx355_join_probe_get_build_side_output(handle_, maxRows, buildRows, mem, buildColumns, buildColumnIds,
+                                                 numBuildColumns, &n, &finished));
+    buildSideDone_ = finished != 0;
+    return n;
+  }
+  bool isFinished() const { return noMoreInput_ && drained_; }
+  void close() {
+    if (handle_) {
+      vx355_join_probe_destroy(handle_);
+      handle_ = nullptr;
+    }
+  }
+
+ private:
+  std::vector<int32_t> keyChannels_;
+  vx355_join_type joinType_;
+  vx355_join_probe* handle_ = nullptr;
+  bool noMoreInput_ = false;
+  bool drained_ = true;
+  bool buildSideDone_ = false;
+};
+
+}  // namespace vx355
+
+#endif  // VX355_HPP_

@@ -1,0 +1,257 @@
+// C++ consumer of the drop-in boundary, written the way the reference's operator tests are
+// (exec/tests/AggregationTest.cpp, HashJoinTest.cpp: feed RowVectors, drain the operator,
+// compare with an expected result computed independently). Expected values come from plain
+// loops over the same host data — this program never touches the oracle.
+//   g++ -std=c++17 -I include tests/cpp/operator_test.cpp -L velox_amd -lvx355 -Wl,-rpath,$PWD/velox_amd
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <random>
+#include <set>
+#include <vector>
+
+#include "vx355.hpp"
+
+#define EXPECT(cond)                                                      \
+  do {                                                                    \
+    if (!(cond)) {                                                        \
+      std::fprintf(stderr, "%s:%d: EXPECT(%s) failed\n", __FILE__, __LINE__, #cond); \
+      return 1;                                                           \
+    }                                                                     \
+  } while (0)
+
+namespace {
+
+vx355_column flat(int32_t kind, const void* values, const uint64_t* nulls = nullptr) {
+  vx355_column c{};
+  c.type_kind = kind;
+  c.encoding = VX355_FLAT;
+  c.values = values;
+  c.nulls = nulls;
+  c.mem = VX355_MEM_HOST;
+  return c;
+}
+
+struct OutCol {
+  std::vector<char> values;
+  std::vector<uint64_t> nulls;
+  vx355_out_column desc{};
+  OutCol(int32_t kind, int32_t width, int32_t capacity) : values(size_t(capacity) * width), nulls(capacity / 64 + 1) {
+    desc.type_kind = kind;
+    desc.mem = VX355_MEM_HOST;
+    desc.values = values.data();
+    desc.nulls = nulls.data();
+  }
+  template <typename T>
+  T at(int32_t i) const {
+    T v;
+    std::memcpy(&v, values.data() + size_t(i) * sizeof(T), sizeof(T));
+    return v;
+  }
+  bool valid(int32_t i) const { return (nulls[i >> 6] >> (i & 63)) & 1; }
+};
+
+int testAggregation() {
+  // SELECT k, sum(v), count(*), min(v), max(v), avg(v) GROUP BY k — batches of 10 000 rows like
+  // exec/benchmarks/SimpleAggregates.cpp:33-34; v = multiples of 1/8 so DOUBLE sums are exact.
+  std::mt19937_64 rng(7);
+  const int kBatches = 30, kRows = 10000;
+  vx355::HashAggregation op({0}, {VX355_BIGINT},
+                            {{VX355_AGG_SUM, 1, -1, VX355_DOUBLE, -1},
+                             {VX355_AGG_COUNT_STAR, -1, -1, VX355_BIGINT, -1},
+                             {VX355_AGG_MIN, 1, -1, VX355_DOUBLE, -1},
+                             {VX355_AGG_MAX, 1, -1, VX355_DOUBLE, -1},
+                             {VX355_AGG_AVG, 1, -1, VX355_DOUBLE, -1}});
+  struct Acc {
+    double sum = 0, mn = INFINITY, mx = -INFINITY;
+    int64_t count = 0, seen = 0;
+  };
+  std::map<int64_t, Acc> expected;
+  std::vector<int64_t> firstSeen;
+  for (int b = 0; b < kBatches; ++b) {
+    std::vector<int64_t> k(kRows);
+    std::vector<double> v(kRows);
+    std::vector<uint64_t> vNulls((kRows + 63) / 64, ~0ULL);
+    for (int i = 0; i < kRows; ++i) {
+      k[i] = int64_t(rng() % 1000) - 300;
+      v[i] = double(rng() % 4096) / 8.0;
+      if (rng() % 10 == 0) {
+        vNulls[i >> 6] &= ~(1ULL << (i & 63));
+      }
+      auto it = expected.find(k[i]);
+      if (it == expected.end()) {
+        firstSeen.push_back(k[i]);
+        it = expected.emplace(k[i], Acc{}).first;
+      }
+      ++it->second.count;
+      if ((vNulls[i >> 6] >> (i & 63)) & 1) {
+        it->second.sum += v[i];
+        it->second.mn = std::min(it->second.mn, v[i]);
+        it->second.mx = std::max(it->second.mx, v[i]);
+        ++it->second.seen;
+      }
+    }
+    vx355_column cols[2] = {flat(VX355_BIGINT, k.data()), flat(VX355_DOUBLE, v.data(), vNulls.data())};
+    EXPECT(op.needsInput());
+    op.addInput(vx355_batch{kRows, 2, cols});
+  }
+  op.noMoreInput();
+  EXPECT(!op.needsInput());
+  EXPECT((op.outputTypes() == std::vector<int32_t>{VX355_BIGINT, VX355_DOUBLE, VX355_BIGINT, VX355_DOUBLE,
+                                                   VX355_DOUBLE, VX355_DOUBLE}));
+  size_t row = 0;
+  const int32_t kMax = 333;
+  while (!op.isFinished()) {
+    OutCol key(VX355_BIGINT, 8, kMax), sum(VX355_DOUBLE, 8, kMax), cnt(VX355_BIGINT, 8, kMax), mn(VX355_DOUBLE, 8, kMax),
+        mx(VX355_DOUBLE, 8, kMax), avg(VX355_DOUBLE, 8, kMax);
+    vx355_out_column out[6] = {key.desc, sum.desc, cnt.desc, mn.desc, mx.desc, avg.desc};
+    const int32_t n = op.getOutput(out, 6, kMax);
+    EXPECT(n <= kMax);
+    for (int32_t i = 0; i < n; ++i, ++row) {
+      EXPECT(row < firstSeen.size() && key.at<int64_t>(i) == firstSeen[row]);  // groups in first-seen order
+      const Acc& e = expected.at(firstSeen[row]);
+      EXPECT(cnt.at<int64_t>(i) == e.count);
+      EXPECT(sum.valid(i) == (e.seen > 0));
+      if (e.seen > 0) {
+        EXPECT(sum.at<double>(i) == e.sum && mn.at<double>(i) == e.mn && mx.at<double>(i) == e.mx);
+        EXPECT(avg.at<double>(i) == e.sum / double(e.seen));
+      }
+    }
+  }
+  EXPECT(row == firstSeen.size());
+  EXPECT(op.stats().num_groups == int64_t(firstSeen.size()) && op.stats().input_rows == int64_t(kBatches) * kRows);
+  // sum(BIGINT) overflow is a user error (SumAggregate.cpp:24), as in AggregationTest's overflow cases.
+  vx355::HashAggregation ovf({}, {}, {{VX355_AGG_SUM, 0, -1, VX355_BIGINT, -1}});
+  std::vector<int64_t> big(4, INT64_MAX / 2);
+  vx355_column c = flat(VX355_BIGINT, big.data());
+  bool threw = false;
+  try {
+    ovf.addInput(vx355_batch{4, 1, &c});
+    ovf.noMoreInput();
+  } catch (const vx355::UserError& e) {
+    threw = std::string(e.what()).find("overflow") != std::string::npos;
+  }
+  EXPECT(threw);
+  return 0;
+}
+
+int testJoin(vx355_join_type type) {
+  // Two build drivers, duplicate and null keys, one payload column; inner / left / right / full.
+  std::mt19937_64 rng(11);
+  const int kBuild = 4000, kProbe = 9000;
+  std::vector<int64_t> bk(kBuild), bpay(kBuild), pk(kProbe);
+  std::vector<uint64_t> bNulls((kBuild + 63) / 64, ~0ULL), pNulls((kProbe + 63) / 64, ~0ULL);
+  for (int i = 0; i < kBuild; ++i) {
+    bk[i] = rng() % 1500;
+    bpay[i] = i * 10;
+    if (rng() % 20 == 0) {
+      bNulls[i >> 6] &= ~(1ULL << (i & 63));
+    }
+  }
+  for (int i = 0; i < kProbe; ++i) {
+    pk[i] = int64_t(rng() % 2500) - 200;
+    if (rng() % 20 == 0) {
+      pNulls[i >> 6] &= ~(1ULL << (i & 63));
+    }
+  }
+  auto valid = [](const std::vector<uint64_t>& w, int i) { return (w[i >> 6] >> (i & 63)) & 1; };
+  const bool keepsNulls = type == VX355_JOIN_RIGHT || type == VX355_JOIN_FULL;
+  // expected multiset of (probe row or -1, payload or -1)
+  std::multiset<std::pair<int32_t, int64_t>> expected;
+  std::vector<char> buildMatched(kBuild, 0);
+  for (int p = 0; p < kProbe; ++p) {
+    bool any = false;
+    if (valid(pNulls, p)) {
+      for (int b = 0; b < kBuild; ++b) {
+        if (valid(bNulls, b) && bk[b] == pk[p]) {
+          expected.insert({p, bpay[b]});
+          buildMatched[b] = 1;
+          any = true;
+        }
+      }
+    }
+    if (!any && (type == VX355_JOIN_LEFT || type == VX355_JOIN_FULL)) {
+      expected.insert({p, -1});
+    }
+  }
+  if (keepsNulls) {
+    for (int b = 0; b < kBuild; ++b) {
+      if (!buildMatched[b]) {
+        expected.insert({-1, bpay[b]});
+      }
+    }
+  }
+  const int half = 2048;  // a multiple of 64: null bitmaps split on a word boundary
+  vx355::HashBuild b1({0}, {VX355_BIGINT}, {1}, {VX355_BIGINT}, type), b2({0}, {VX355_BIGINT}, {1}, {VX355_BIGINT}, type);
+  vx355_column c1[2] = {flat(VX355_BIGINT, bk.data(), bNulls.data()), flat(VX355_BIGINT, bpay.data())};
+  vx355_column c2[2] = {flat(VX355_BIGINT, bk.data() + half, bNulls.data() + half / 64),
+                        flat(VX355_BIGINT, bpay.data() + half)};
+  b1.addInput(vx355_batch{half, 2, c1});
+  b2.addInput(vx355_batch{kBuild - half, 2, c2});
+  vx355::JoinTable table = b1.noMoreInput({&b2});
+  EXPECT(b1.isFinished() && b2.isFinished());
+  EXPECT(table.stats().has_duplicates == 1);
+  vx355::HashProbe probe(table, {0}, type);
+  vx355_column pc = flat(VX355_BIGINT, pk.data(), pNulls.data());
+  EXPECT(probe.needsInput());
+  probe.addInput(vx355_batch{kProbe, 1, &pc});
+  std::multiset<std::pair<int32_t, int64_t>> got;
+  const int32_t kMax = 1000;
+  std::vector<int32_t> mapping(kMax), rows(kMax);
+  int32_t last = -1;
+  for (;;) {
+    OutCol pay(VX355_BIGINT, 8, kMax);
+    const int32_t id = 0;
+    const int32_t n = probe.getOutput(kMax, mapping.data(), rows.data(), &pay.desc, &id, 1);
+    if (n == 0) {
+      break;
+    }
+    for (int32_t i = 0; i < n; ++i) {
+      EXPECT(mapping[i] >= last);  // ascending probe rows, matches of one row contiguous
+      last = mapping[i];
+      EXPECT(pay.valid(i) == (rows[i] >= 0));
+      got.insert({mapping[i], rows[i] >= 0 ? pay.at<int64_t>(i) : -1});
+    }
+  }
+  probe.noMoreInput();
+  EXPECT(probe.isFinished());
+  if (keepsNulls) {
+    for (;;) {
+      OutCol pay(VX355_BIGINT, 8, kMax);
+      const int32_t id = 0;
+      const int32_t n = probe.getBuildSideOutput(kMax, rows.data(), &pay.desc, &id, 1);
+      if (n == 0) {
+        break;
+      }
+      for (int32_t i = 0; i < n; ++i) {
+        got.insert({-1, pay.at<int64_t>(i)});
+      }
+    }
+  }
+  EXPECT(got == expected);
+  return 0;
+}
+
+}  // namespace
+
+int main() {
+  try {
+    vx355::init(0);
+    if (testAggregation()) {
+      return 1;
+    }
+    for (auto t : {VX355_JOIN_INNER, VX355_JOIN_LEFT, VX355_JOIN_RIGHT, VX355_JOIN_FULL}) {
+      if (testJoin(t)) {
+        std::fprintf(stderr, "join type %d failed\n", int(t));
+        return 1;
+      }
+    }
+  } catch (const vx355::Error& e) {
+    std::fprintf(stderr, "vx355 error %d: %s\n", e.status, e.what());
+    return 2;
+  }
+  std::printf("operator_test: aggregation and inner/left/right/full joins match the expected results\n");
+  return 0;
+}
