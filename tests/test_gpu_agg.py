@@ -707,3 +707,23 @@ def test_single_wide_integer_key_stays_in_normalized_mode(oracle, vx, monkeypatc
     got, gop = run_agg(vx, batches, [0], [abi.BIGINT], aggs, max_rows=100000)
     assert_columns_equal(got, exp, gop.kinds, what="wide single key + reserved values")
     assert gop.stats().hash_mode == abi.MODE_HASH
+
+
+@pytest.mark.parametrize("key_dtype", [np.int64, np.int32])
+def test_radix_path_flat_null_free_specialisation(oracle, vx, key_dtype, monkeypatch):
+    """The loads-ahead instances of the radix kernels (flat BIGINT / INTEGER key, flat 8-byte
+    operands without nulls): checked sum(BIGINT), min(DOUBLE), max(BIGINT) and count(*) only."""
+    monkeypatch.setenv("VX355_AGG_RADIX_MIN_ROWS", "1")
+    rng = np.random.default_rng(79)
+    n = 600000
+    k = rng.integers(-3000, 90000, n).astype(key_dtype)
+    w = rng.integers(-1 << 40, 1 << 40, n).astype(np.int64)
+    v = _dyadic(rng, n)
+    kind = abi.BIGINT if key_dtype == np.int64 else abi.INTEGER
+    for aggs in ([(abi.AGG_SUM, 1, abi.BIGINT), (abi.AGG_MIN, 2, abi.DOUBLE), (abi.AGG_MAX, 1, abi.BIGINT)],
+                 [(abi.AGG_COUNT_STAR, -1, abi.BIGINT)],
+                 [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT), (abi.AGG_MAX, 2, abi.DOUBLE)]):
+        exp, _ = run_agg(oracle, [batch_of([k, w, v])], [0], [kind], aggs, max_rows=100000)
+        got, gop = run_agg(vx, [batch_of([k, w, v])], [0], [kind], aggs, max_rows=100000)
+        assert_columns_equal(got, exp, gop.kinds, what="radix flat %s" % (aggs,))
+        assert gop.stats().radix_launches >= 1
