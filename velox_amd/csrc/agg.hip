@@ -510,7 +510,7 @@ static_assert(sizeof(RadixArgs) <= 4096, "kernel arguments are limited to 4 KB")
 // KW = 8 / 4: a single flat BIGINT / INTEGER key without nulls and no fused filter
 // (loads issued ahead of their use, kRadixUnroll rows per lane in flight);
 // KW = 0: any key set the ABI admits.
-constexpr int kRadixUnroll = 4;
+constexpr int kRadixUnroll = 8;
 
 template <int KW>
 __device__ inline int64_t rpLoadKey(const RadixArgs& r, int64_t row) {
