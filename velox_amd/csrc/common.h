@@ -100,6 +100,13 @@ struct Runtime {
   void* allocBlock(size_t bytes, size_t* actual);
   void freeBlock(void* p, size_t bytes);
   void trimCache();
+  // Pinned host blocks (power-of-two sizes >= 64 KB): hipHostMalloc costs ~0.3 ms a
+  // call, so released blocks are kept (up to pinnedLimit bytes) for the next operator.
+  std::multimap<size_t, void*> freePinned;
+  size_t cachedPinned = 0;
+  size_t pinnedLimit = 2ULL << 30;
+  char* allocPinned(size_t bytes, size_t* actual);
+  void releasePinned(char* p, size_t bytes);
 
   static Runtime& get();
   void requireInit() const {

@@ -110,6 +110,11 @@ void Runtime::trimCache() {
   }
   freeBlocks.clear();
   cachedBytes = 0;
+  for (auto& kv : freePinned) {
+    (void)hipHostFree(kv.second);
+  }
+  freePinned.clear();
+  cachedPinned = 0;
 }
 
 void* DevBuf::ensure(size_t bytes, bool preserve, size_t preserveBytes) {
@@ -201,24 +206,47 @@ void copyIn(void* devDst, const void* src, int32_t srcMem, size_t bytes) {
                         rt.stream));
 }
 
-PinnedBuf::~PinnedBuf() {
-  if (p_) {
-    (void)hipHostFree(p_);
+char* Runtime::allocPinned(size_t bytes, size_t* actual) {
+  const size_t want = static_cast<size_t>(nextPow2(std::max<size_t>(bytes, 64 << 10)));
+  auto it = freePinned.lower_bound(want);
+  if (it != freePinned.end() && it->first <= want * 2) {
+    char* p = static_cast<char*>(it->second);
+    *actual = it->first;
+    cachedPinned -= it->first;
+    freePinned.erase(it);
+    return p;
   }
+  char* p = nullptr;
+  HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&p), want, hipHostMallocDefault));
+  *actual = want;
+  return p;
+}
+
+void Runtime::releasePinned(char* p, size_t bytes) {
+  if (!p) {
+    return;
+  }
+  if (!initialized || cachedPinned + bytes > pinnedLimit) {
+    (void)hipHostFree(p);
+    return;
+  }
+  freePinned.emplace(bytes, p);
+  cachedPinned += bytes;
+}
+
+PinnedBuf::~PinnedBuf() {
+  // Copies out of this block were synchronised by the consumer before it returned.
+  Runtime::get().releasePinned(p_, cap_);
 }
 
 char* PinnedBuf::extend(size_t bytes) {
   if (size_ + bytes > cap_) {
-    const size_t cap = std::max<size_t>({size_ + bytes, cap_ * 2, static_cast<size_t>(1) << 20});
-    char* np = nullptr;
-    HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&np), cap, hipHostMallocDefault));
+    size_t cap = 0;
+    char* np = Runtime::get().allocPinned(std::max<size_t>(size_ + bytes, cap_ * 2), &cap);
     if (size_) {
       std::memcpy(np, p_, size_);
     }
-    if (p_) {
-      // Earlier H2D copies from the old block are complete: flush() syncs before clear().
-      (void)hipHostFree(p_);
-    }
+    Runtime::get().releasePinned(p_, cap_);
     p_ = np;
     cap_ = cap;
   }
