@@ -1,0 +1,201 @@
+"""Differential fuzzing: random plans (key types and counts, encodings, nulls, masks, aggregate
+sets, steps, batch sizes; join types, duplicates, payload types) through the MI355X library and
+through the CPU oracle, same seeds, results compared exactly. Values are dyadic rationals so
+that DOUBLE sums are exact and the comparison can be bit for bit."""
+import numpy as np
+import pytest
+
+from velox_amd import abi
+from gpu_util import assert_columns_equal, run_agg
+
+pytestmark = pytest.mark.gpu
+
+WORDS = [b"", b"A", b"NO", b"RET", b"FURN", b"7 bytes", b"BUILDING", b"AUTOMOBILE", b"twelve bytes"]
+
+
+def _values(rng, kind, n, card):
+    if kind == abi.BOOLEAN:
+        return rng.random(n) > 0.5
+    if kind == abi.TINYINT:
+        return rng.integers(-100, 100, n).astype(np.int8)
+    if kind == abi.SMALLINT:
+        return rng.integers(-3000, 3000, n).astype(np.int16)
+    if kind == abi.INTEGER:
+        return (rng.integers(0, card, n) * 7 - 1000).astype(np.int32)
+    if kind == abi.BIGINT:
+        pool = rng.integers(-2 ** 40, 2 ** 40, card) if rng.random() < 0.5 else np.arange(card) - 50
+        return pool[rng.integers(0, card, n)].astype(np.int64)
+    if kind == abi.REAL:
+        return (rng.integers(-4096, 4096, n) / 16.0).astype(np.float32)
+    if kind == abi.DOUBLE:
+        return rng.integers(-1 << 20, 1 << 20, n) / 1024.0
+    if kind == abi.VARCHAR:
+        top = int(rng.integers(3, len(WORDS) + 1))
+        return [WORDS[i] for i in rng.integers(0, top, n)]
+    raise AssertionError(kind)
+
+
+def _column(rng, kind, n, card=200):
+    """A column of n rows in a random encoding with a random share of nulls."""
+    enc = rng.choice(["flat", "flat", "dict", "const"])
+    valid = None
+    if rng.random() < 0.6:
+        valid = rng.random(n) > rng.choice([0.02, 0.3])
+    if enc == "dict" and n > 0:
+        base = max(1, int(rng.integers(1, 50)))
+        return abi.HostColumn(kind, _values(rng, kind, base, card), valid, abi.DICTIONARY, rng.integers(0, base, n))
+    if enc == "const" and n > 0:
+        c = abi.HostColumn(kind, _values(rng, kind, 1, card), None if valid is None else valid[:1], abi.CONSTANT)
+        return c
+    return abi.HostColumn(kind, _values(rng, kind, n, card), valid)
+
+
+@pytest.mark.parametrize("seed", range(100))
+def test_random_aggregation_plans(oracle, vx, seed, monkeypatch):
+    rng = np.random.default_rng(1000 + seed)
+    if seed % 4 != 0:
+        monkeypatch.setenv("VX355_JIT", "0")   # a hiprtc instantiation costs ~0.8 s per new plan shape
+    if rng.random() < 0.3:
+        monkeypatch.setenv("VX355_AGG_COALESCE_ROWS", "0")
+    if rng.random() < 0.2:
+        monkeypatch.setenv("VX355_AGG_RADIX_MIN_ROWS", "1")
+    if rng.random() < 0.2:
+        monkeypatch.setenv("VX355_ARRAY_MAX", str(int(rng.choice([0, 64, 4096]))))
+    key_pool = [abi.BIGINT, abi.INTEGER, abi.SMALLINT, abi.TINYINT, abi.BOOLEAN, abi.VARCHAR, abi.DOUBLE]
+    num_keys = int(rng.integers(0, 4))
+    key_types = [int(rng.choice(key_pool)) for _ in range(num_keys)]
+    val_types = [int(rng.choice([abi.DOUBLE, abi.BIGINT, abi.INTEGER, abi.REAL, abi.SMALLINT]))
+                 for _ in range(int(rng.integers(1, 4)))]
+    has_mask = rng.random() < 0.3
+    layout = key_types + val_types + ([abi.BOOLEAN] if has_mask else [])
+    aggs = []
+    for _ in range(int(rng.integers(0 if num_keys else 1, 6))):
+        v = int(rng.integers(0, len(val_types)))
+        fn = int(rng.choice([abi.AGG_SUM, abi.AGG_COUNT, abi.AGG_COUNT_STAR, abi.AGG_MIN, abi.AGG_MAX, abi.AGG_AVG]))
+        col = -1 if fn == abi.AGG_COUNT_STAR else num_keys + v
+        typ = abi.BIGINT if fn == abi.AGG_COUNT_STAR else val_types[v]
+        mask = len(layout) - 1 if (has_mask and rng.random() < 0.5) else -1
+        aggs.append((fn, col, typ, mask))
+    card = int(rng.choice([3, 40, 3000]))
+    batches = []
+    for _ in range(int(rng.integers(1, 5))):
+        n = int(rng.choice([1, 63, 64, 1000, 5000, 20000]))
+        batches.append(abi.HostBatch([_column(rng, k, n, card) for k in layout], n))
+    kw = dict(ignore_null_keys=bool(rng.random() < 0.3))
+    key_cols = list(range(num_keys))
+    exp, _ = run_agg(oracle, batches, key_cols, key_types, aggs, max_rows=100000, **kw)
+    got, gop = run_agg(vx, batches, key_cols, key_types, aggs, max_rows=int(rng.choice([7, 1000, 100000])), **kw)
+    assert_columns_equal(got, exp, gop.kinds, what=f"seed {seed}: keys {key_types} aggs {aggs}")
+    if rng.random() < 0.5 and aggs:
+        # partial per batch -> final over the partial outputs == single (docs/develop/aggregations.rst)
+        from velox_amd import dist as vdist
+        raw = [(a[0], a[1], a[2], a[3]) for a in aggs]
+        parts = []
+        for b in batches:
+            out, op = run_agg(vx, [b], key_cols, key_types, raw, step=abi.STEP_PARTIAL, max_rows=100000, **kw)
+            parts.append((out, op.kinds))
+        cols = []
+        for c, kind in enumerate(parts[0][1]):
+            vals = [p[0][c][0] for p in parts]
+            valid = np.concatenate([np.asarray(p[0][c][1], dtype=bool) for p in parts])
+            vals = sum((list(v) for v in vals), []) if kind == abi.VARCHAR else np.concatenate(vals)
+            if kind == abi.VARCHAR:
+                vals = [v if v is not None else b"" for v in vals]
+            cols.append(abi.HostColumn(kind, vals, valid))
+        fin_aggs = vdist.final_aggs_for([(a[0], a[1], a[2]) for a in raw], num_keys)
+        merged, mop = run_agg(vx, [abi.HostBatch(cols, len(cols[0].valid))], key_cols, key_types, fin_aggs,
+                              step=abi.STEP_FINAL, max_rows=100000, **kw)
+        assert_columns_equal(merged, exp, mop.kinds, what=f"seed {seed}: partial -> final")
+
+
+def _canon_join(probe, join_type, max_rows):
+    rows = []
+    while True:
+        mapping, build_rows, cols, fin = probe.get_output(max_rows)
+        for i in range(len(mapping)):
+            pay = tuple(None if not valid[i] else (vals[i] if isinstance(vals, list) else vals[i].item())
+                        for vals, valid in cols)
+            if join_type == abi.JOIN_LEFT_SEMI_PROJECT:
+                rows.append((int(mapping[i]), bool(build_rows[i] >= 0)))
+            else:
+                rows.append((int(mapping[i]), pay))
+        if fin:
+            break
+    assert [r[0] for r in rows] == sorted(r[0] for r in rows)       # ascending probe rows
+    out = [sorted(rows, key=repr)]
+    if join_type in (abi.JOIN_RIGHT, abi.JOIN_FULL, abi.JOIN_RIGHT_SEMI_FILTER):
+        side = []
+        while True:
+            build_rows, cols, fin = probe.get_build_side_output(max_rows)
+            for i in range(len(build_rows)):
+                side.append((int(build_rows[i]),) + tuple(
+                    None if not valid[i] else (vals[i] if isinstance(vals, list) else vals[i].item())
+                    for vals, valid in cols))
+            if fin:
+                break
+        out.append(side)
+    return out
+
+
+@pytest.mark.parametrize("seed", range(100))
+def test_random_join_plans(oracle, vx, seed, monkeypatch):
+    rng = np.random.default_rng(5000 + seed)
+    if rng.random() < 0.3:
+        monkeypatch.setenv("VX355_JOIN_ARRAY_MAX", "0")
+    join_type = int(rng.choice([abi.JOIN_INNER, abi.JOIN_LEFT, abi.JOIN_RIGHT, abi.JOIN_FULL, abi.JOIN_LEFT_SEMI_FILTER,
+                                abi.JOIN_LEFT_SEMI_PROJECT, abi.JOIN_RIGHT_SEMI_FILTER, abi.JOIN_ANTI]))
+    null_aware = join_type == abi.JOIN_ANTI and rng.random() < 0.5
+    key_types = [int(rng.choice([abi.BIGINT, abi.INTEGER, abi.VARCHAR, abi.SMALLINT, abi.DOUBLE]))
+                 for _ in range(int(rng.integers(1, 3)))]
+    dep_types = [int(rng.choice([abi.BIGINT, abi.DOUBLE, abi.INTEGER, abi.VARCHAR, abi.BOOLEAN, abi.REAL]))
+                 for _ in range(int(rng.integers(0, 4)))]
+    card = int(rng.choice([5, 300, 5000]))
+    nk = len(key_types)
+    results = {}
+    build_batches = []
+    for _ in range(int(rng.integers(1, 3))):       # build drivers
+        batches = []
+        for _ in range(int(rng.integers(1, 3))):
+            n = int(rng.choice([0, 1, 200, 3000])) if rng.random() < 0.9 else 0
+            batches.append(abi.HostBatch([_column(rng, k, n, card) for k in key_types + dep_types], n))
+        build_batches.append(batches)
+    if null_aware and rng.random() < 0.5:
+        # keep the build side free of null keys so that the regular NOT IN branch is exercised
+        build_batches = [[abi.HostBatch([abi.HostColumn(k, _values(rng, k, 500, card)) for k in key_types + dep_types], 500)]]
+    probes = []
+    for _ in range(int(rng.integers(1, 3))):
+        n = int(rng.choice([1, 64, 2000, 9000]))
+        probes.append(abi.HostBatch([_column(rng, k, n, card) for k in key_types], n))
+    for impl in (oracle, vx):
+        builds = []
+        for batches in build_batches:
+            b = impl.JoinBuild(list(range(nk)), key_types, list(range(nk, nk + len(dep_types))), dep_types, join_type,
+                               null_aware)
+            for hb in batches:
+                b.add_input(hb)
+            builds.append(b)
+        table = builds[0].finish(builds[1:])
+        handles = [impl.JoinProbe(table, list(range(nk)), join_type, null_aware) for _ in probes]
+        out = []
+        for h, pb in zip(handles, probes):
+            h.add_input(pb)
+            part = _canon_join(h, join_type, int(rng.choice([5, 1000])) if impl is vx else 1000) \
+                if h is handles[-1] else _canon_join_probe_only(h, join_type)
+            out.append(part)
+        results[impl.__name__] = out
+    assert results[oracle.__name__] == results[vx.__name__], f"seed {seed}: {join_type} keys {key_types} deps {dep_types}"
+
+
+def _canon_join_probe_only(probe, join_type):
+    """Drains the probe-side output of a handle that is not the last prober."""
+    rows = []
+    while True:
+        mapping, build_rows, cols, fin = probe.get_output(777)
+        for i in range(len(mapping)):
+            pay = tuple(None if not valid[i] else (vals[i] if isinstance(vals, list) else vals[i].item())
+                        for vals, valid in cols)
+            rows.append((int(mapping[i]), bool(build_rows[i] >= 0)) if join_type == abi.JOIN_LEFT_SEMI_PROJECT
+                        else (int(mapping[i]), pay))
+        if fin:
+            break
+    return [sorted(rows, key=repr)]

@@ -297,6 +297,11 @@ class OutBuffers:
             vals = unpack_bits(self.values[i], n)
         elif k in (VARCHAR, VARBINARY):
             raw = self.values[i][: n * 16].reshape(n, 16)
+            sizes = raw[:, 0:4].copy().view(np.uint32).reshape(-1)
+            bad = np.flatnonzero((sizes > 12) & valid[:n])
+            if len(bad):   # the library only ever returns inline strings
+                raise AssertionError(f"output column {i}: non-inline StringView at rows {bad[:5].tolist()}: "
+                                     f"{raw[bad[0]].tobytes().hex()}")
             vals = [view_to_bytes(raw[j]) if valid[j] else None for j in range(n)]
         elif k == TIMESTAMP:
             vals = self.values[i][: n * 16].view(np.int64).reshape(n, 2).copy()

@@ -1208,10 +1208,15 @@ __global__ __launch_bounds__(256) void k_to_generic(ToGenericArgs a) {
       } else {
         const int64_t v = static_cast<int64_t>(vid - 1 + static_cast<uint64_t>(a.range[k].min));
         if (a.kind[k] == VX355_VARCHAR || a.kind[k] == VX355_VARBINARY) {
-          // Inverse of stringAsNumber: the marker bit sits right above the bytes.
-          const int top = 63 - __clzll(static_cast<long long>(v));
-          const uint32_t size = static_cast<uint32_t>(top >> 3);
-          const uint64_t bytes = static_cast<uint64_t>(v) - (1ULL << top);
+          // Inverse of stringAsNumber: the marker bit sits right above the bytes;
+          // 0 is the empty string.
+          uint32_t size = 0;
+          uint64_t bytes = 0;
+          if (v != 0) {
+            const int top = 63 - __clzll(static_cast<long long>(v));
+            size = static_cast<uint32_t>(top >> 3);
+            bytes = static_cast<uint64_t>(v) - (1ULL << top);
+          }
           w0 = static_cast<uint64_t>(size) | ((bytes & 0xffffffffULL) << 32);
           w1 = bytes >> 32;
           uint8_t buf[8];

@@ -1701,6 +1701,13 @@ int vx355_join_build_create(const vx355_join_build_spec* spec, vx355_join_build*
   h->depValid.resize(h->depCols.size());
   h->obsMin.assign(h->keyCols.size(), INT64_MAX);
   h->obsMax.assign(h->keyCols.size(), INT64_MIN);
+  for (int32_t kind : h->keyKinds) {
+    // No value ids for these types (VectorHasher.h:338-357): generic mode whatever the
+    // data, also for an empty build side.
+    if (kind == VX355_REAL || kind == VX355_DOUBLE || kind == VX355_TIMESTAMP) {
+      h->unmappable = true;
+    }
+  }
   *out = h.release();
   VX_API_END
 }
