@@ -2049,7 +2049,8 @@ Decision decide(vx355_agg& h) {
              "grouping keys do not fit a 64-bit normalized key (generic hash mode not on device)");
   }
   d.capacity = static_cast<uint64_t>(product);
-  d.mode = d.capacity <= h.arrayMax ? MODE_ARRAY : MODE_NORMALIZED;
+  // A global aggregation (no keys) is the one-row array table whatever the budget says.
+  d.mode = (h.keys.empty() || d.capacity <= h.arrayMax) ? MODE_ARRAY : MODE_NORMALIZED;
   return d;
 }
 
