@@ -147,17 +147,30 @@ def test_random_aggregation_plans(oracle, vx, seed, monkeypatch):
         for b in batches:
             out, op = run_agg(vx, [b], key_cols, key_types, raw, step=abi.STEP_PARTIAL, max_rows=100000, **kw)
             parts.append((out, op.kinds))
-        cols = []
-        for c, kind in enumerate(parts[0][1]):
-            vals = [p[0][c][0] for p in parts]
-            valid = np.concatenate([np.asarray(p[0][c][1], dtype=bool) for p in parts])
-            vals = sum((list(v) for v in vals), []) if kind == abi.VARCHAR else np.concatenate(vals)
-            if kind == abi.VARCHAR:
-                vals = [v if v is not None else b"" for v in vals]
-            cols.append(abi.HostColumn(kind, vals, valid))
+        def as_batch(outputs):
+            """collect_output() results of the same layout -> one HostBatch (rows concatenated)."""
+            cols = []
+            for c, kind in enumerate(outputs[0][1]):
+                vals = [p[0][c][0] for p in outputs]
+                valid = np.concatenate([np.asarray(p[0][c][1], dtype=bool) for p in outputs])
+                if kind == abi.VARCHAR:
+                    vals = [v if v is not None else b"" for v in sum((list(v) for v in vals), [])]
+                else:
+                    vals = np.concatenate(vals)
+                cols.append(abi.HostColumn(kind, vals, valid))
+            return abi.HostBatch(cols, len(cols[0].valid))
         fin_aggs = vdist.final_aggs_for([(a[0], a[1], a[2]) for a in raw], num_keys)
-        merged, mop = run_agg(vx, [abi.HostBatch(cols, len(cols[0].valid))], key_cols, key_types, fin_aggs,
-                              step=abi.STEP_FINAL, max_rows=100000, **kw)
+        if rng.random() < 0.5 and len(parts) > 1:
+            # partial -> intermediate (intermediate layout in and out) -> final
+            mid = []
+            for group in (parts[:len(parts) // 2], parts[len(parts) // 2:]):
+                out, op = run_agg(vx, [as_batch(group)], key_cols, key_types, fin_aggs, step=abi.STEP_INTERMEDIATE,
+                                  max_rows=100000, **kw)
+                assert op.kinds == group[0][1]
+                mid.append((out, op.kinds))
+            parts = mid
+        merged, mop = run_agg(vx, [as_batch(parts)], key_cols, key_types, fin_aggs, step=abi.STEP_FINAL,
+                              max_rows=100000, **kw)
         assert_columns_equal(merged, exp, mop.kinds, what=f"seed {seed}: partial -> final")
 
 
