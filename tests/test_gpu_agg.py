@@ -727,3 +727,27 @@ def test_radix_path_flat_null_free_specialisation(oracle, vx, key_dtype, monkeyp
         got, gop = run_agg(vx, [batch_of([k, w, v])], [0], [kind], aggs, max_rows=100000)
         assert_columns_equal(got, exp, gop.kinds, what="radix flat %s" % (aggs,))
         assert gop.stats().radix_launches >= 1
+
+
+@pytest.mark.parametrize("slice_recs", [None, "4096"])
+def test_radix_path_skewed_keys_and_few_partitions(oracle, vx, slice_recs, monkeypatch):
+    """Partitions much larger than the rest (90 % of the rows on one key; a key range of a few
+    partitions only) are folded slice by slice by many workgroups and flushed with atomics."""
+    monkeypatch.setenv("VX355_AGG_RADIX_MIN_ROWS", "1")
+    if slice_recs:
+        monkeypatch.setenv("VX355_AGG_RADIX_SLICE", slice_recs)
+    rng = np.random.default_rng(80)
+    n = 700000
+    k = rng.integers(0, 100000, n).astype(np.int64)
+    k[rng.random(n) < 0.9] = 77777
+    w = rng.integers(-1 << 30, 1 << 30, n).astype(np.int64)
+    v = _dyadic(rng, n)
+    aggs = [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT), (abi.AGG_MIN, 1, abi.BIGINT)]
+    exp, _ = run_agg(oracle, [batch_of([k, w, v])], [0], [abi.BIGINT], aggs, max_rows=200000)
+    got, gop = run_agg(vx, [batch_of([k, w, v])], [0], [abi.BIGINT], aggs, max_rows=200000)
+    assert_columns_equal(got, exp, gop.kinds, what="radix skew")
+    assert gop.stats().radix_launches >= 1
+    k2 = rng.integers(0, 9000, n).astype(np.int64)      # a handful of partitions
+    exp, _ = run_agg(oracle, [batch_of([k2, w, v])], [0], [abi.BIGINT], aggs, max_rows=200000)
+    got, gop = run_agg(vx, [batch_of([k2, w, v])], [0], [abi.BIGINT], aggs, max_rows=200000)
+    assert_columns_equal(got, exp, gop.kinds, what="radix few partitions")

@@ -549,7 +549,7 @@ __global__ __launch_bounds__(1024) void k_rp_count1(RadixArgs r) {
     for (int i = threadIdx.x; i < r.numBins; i += blockDim.x) {
       hist[i] = 0;
     }
-    __syncthreads();
+    blockSync();
     const int64_t begin = tile * r.tileRows;
     const int64_t end = begin + r.tileRows < a.numRows ? begin + r.tileRows : a.numRows;
     for (int64_t base = begin; base < end; base += kRadixUnroll * 1024) {
@@ -575,11 +575,11 @@ __global__ __launch_bounds__(1024) void k_rp_count1(RadixArgs r) {
         deferRow(a, defer, static_cast<int32_t>(row));
       }
     }
-    __syncthreads();
+    blockSync();
     for (int i = threadIdx.x; i < r.numBins; i += blockDim.x) {
       r.hist[static_cast<int64_t>(i) * r.numTiles + tile] = hist[i];
     }
-    __syncthreads();
+    blockSync();
   }
 }
 
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(1024) void k_rp_scatter1(RadixArgs r) {
       binBase[i] = r.offsets[static_cast<int64_t>(i) * r.numTiles + tile];
       cursor[i] = 0;
     }
-    __syncthreads();
+    blockSync();
     const int64_t begin = tile * r.tileRows;
     const int64_t end = begin + r.tileRows < a.numRows ? begin + r.tileRows : a.numRows;
     for (int64_t base = begin; base < end; base += kRadixUnroll * 1024) {
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(1024) void k_rp_scatter1(RadixArgs r) {
         rpStore<W>(r.recs + pos * W, vals[u]);
       }
     }
-    __syncthreads();
+    blockSync();
   }
 }
 
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(1024) void k_rp_tiles(const uint64_t* offsets1, int
         offsets1[static_cast<int64_t>(b + 1) * numTiles1] - offsets1[static_cast<int64_t>(b) * numTiles1];
     tileStart[b] = static_cast<uint32_t>((count + tileRecs - 1) / tileRecs);
   }
-  __syncthreads();
+  blockSync();
   if (threadIdx.x == 0) {
     uint32_t run = 0;
     for (int b = 0; b < numBins1; ++b) {
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(1024) void k_rp_tiles(const uint64_t* offsets1, int
     tileStart[numBins1] = run;
     *numTiles2 = run;
   }
-  __syncthreads();
+  blockSync();
   for (int b = threadIdx.x; b < numBins1; b += blockDim.x) {
     const uint64_t first = offsets1[static_cast<int64_t>(b) * numTiles1];
     const uint64_t count = offsets1[static_cast<int64_t>(b + 1) * numTiles1] - first;
@@ -782,16 +782,16 @@ __global__ __launch_bounds__(1024) void k_rp_count2(Radix2Args r) {
     for (int i = threadIdx.x; i < r.numBins; i += blockDim.x) {
       hist[i] = 0;
     }
-    __syncthreads();
+    blockSync();
     for (uint32_t i = threadIdx.x; i < tile.count; i += blockDim.x) {
       const uint32_t key = static_cast<uint32_t>(r.in[(tile.begin + i) * r.recWords]);
       atomicAdd(&hist[(key >> r.shiftB) & binMask], 1u);
     }
-    __syncthreads();
+    blockSync();
     for (int i = threadIdx.x; i < r.numBins; i += blockDim.x) {
       r.hist[tile.cell + static_cast<uint64_t>(i) * tile.stride] = hist[i];
     }
-    __syncthreads();
+    blockSync();
   }
 }
 
@@ -807,7 +807,7 @@ __global__ __launch_bounds__(1024) void k_rp_scatter2(Radix2Args r) {
       binBase[i] = r.offsets[tile.cell + static_cast<uint64_t>(i) * tile.stride];
       cursor[i] = 0;
     }
-    __syncthreads();
+    blockSync();
     for (uint32_t base = 0; base < tile.count; base += kRadixUnroll * 1024) {
       uint64_t w[kRadixUnroll][W];
 #pragma unroll
@@ -827,7 +827,7 @@ __global__ __launch_bounds__(1024) void k_rp_scatter2(Radix2Args r) {
         }
       }
     }
-    __syncthreads();
+    blockSync();
   }
 }
 
@@ -849,117 +849,200 @@ struct RadixAggArgs {
   int32_t off[kRadixMaxAccs];
   int32_t valIdx[kRadixMaxAccs];
   int32_t accOfVal[kRadixMaxAccs];
+  uint64_t sliceRecs;          // records one workgroup folds at a time (see k_rp_aggregate)
 };
 
-// One workgroup per partition: fold its records into LDS, then touch each of
-// the <= B group rows in HBM once.
+// LDS state of one fold: acc[B][A] + first[B].
+struct RpFold {
+  uint64_t* acc;
+  uint32_t* first;
+  int B;
+  int A;
+};
+
+__device__ inline void rpFoldInit(const RpFold& f, const RadixAggArgs& r) {
+  for (int i = threadIdx.x; i < f.B * f.A; i += blockDim.x) {
+    f.acc[i] = accIdentity(r.kind[i % f.A]);
+  }
+  for (int i = threadIdx.x; i < f.B; i += blockDim.x) {
+    f.first[i] = 0xffffffffu;
+  }
+  blockSync();
+}
+
+// Folds records [begin, end) of one partition into the LDS accumulators.
 template <int W>
-__global__ __launch_bounds__(512) void k_rp_aggregate(RadixAggArgs r) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
-  const int B = 1 << r.shiftB;
-  const int A = r.numAccs;
-  uint64_t* acc = reinterpret_cast<uint64_t*>(ldsRaw);                               // [B][A]
-  uint32_t* first = reinterpret_cast<uint32_t*>(acc + static_cast<size_t>(B) * A);  // [B]
-  for (int64_t p = blockIdx.x; p < r.numParts; p += gridDim.x) {
-    const uint64_t begin = r.partBegin[r.partCell ? r.partCell[p] : p * r.cellStride];
-    const uint64_t end = r.partBegin[r.partCell ? r.partCell[p + 1] : (p + 1) * r.cellStride];
-    if (end == begin) {
-      continue;  // uniform per workgroup
-    }
-    for (int i = threadIdx.x; i < B * A; i += blockDim.x) {
-      acc[i] = accIdentity(r.kind[i % A]);
-    }
-    for (int i = threadIdx.x; i < B; i += blockDim.x) {
-      first[i] = 0xffffffffu;
-    }
-    __syncthreads();
-    const uint64_t base = static_cast<uint64_t>(p) << r.shiftB;
-    for (uint64_t at = begin; at < end; at += kRadixUnroll * 512) {
-      uint64_t w[kRadixUnroll][W];
+__device__ inline void rpFoldRecords(const RpFold& f, const RadixAggArgs& r, uint64_t begin, uint64_t end) {
+  const int A = f.A;
+  for (uint64_t at = begin; at < end; at += kRadixUnroll * 512) {
+    uint64_t w[kRadixUnroll][W];
 #pragma unroll
-      for (int u = 0; u < kRadixUnroll; ++u) {
-        const uint64_t i = at + u * 512 + threadIdx.x;
-        if (i < end) {
-          rpLoad<W>(r.recs + i * W, w[u]);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < kRadixUnroll; ++u) {
-        const uint64_t i = at + u * 512 + threadIdx.x;
-        if (i >= end) {
-          continue;
-        }
-        const uint64_t w0 = w[u][0];
-        const uint32_t g = static_cast<uint32_t>(w0) & static_cast<uint32_t>(B - 1);
-        const uint32_t row = static_cast<uint32_t>(w0 >> kRadixKeyBits) & ((1u << kRadixRowBits) - 1);
-        const uint32_t mask = static_cast<uint32_t>(w0 >> (kRadixKeyBits + kRadixRowBits));
-        if (first[g] > row) {
-          atomicMin(&first[g], row);
-        }
-#pragma unroll
-        for (int q = 1; q < W; ++q) {
-          const int j = r.accOfVal[q - 1];
-          if ((mask >> j) & 1) {
-            applyLds(acc + static_cast<size_t>(g) * A + j, r.kind[j], w[u][q], r.counters);
-          }
-        }
-        for (int j = 0; j < A; ++j) {
-          if (r.valIdx[j] < 0 && ((mask >> j) & 1)) {
-            applyLds(acc + static_cast<size_t>(g) * A + j, r.kind[j], 1ULL, r.counters);
-          }
-        }
+    for (int u = 0; u < kRadixUnroll; ++u) {
+      const uint64_t i = at + u * 512 + threadIdx.x;
+      if (i < end) {
+        rpLoad<W>(r.recs + i * W, w[u]);
       }
     }
-    __syncthreads();
-    uint32_t newGroups = 0;
-    for (int g = threadIdx.x; g < B; g += blockDim.x) {
-      const uint32_t f = first[g];
-      if (f == 0xffffffffu || base + g >= r.capacity) {
+#pragma unroll
+    for (int u = 0; u < kRadixUnroll; ++u) {
+      const uint64_t i = at + u * 512 + threadIdx.x;
+      if (i >= end) {
         continue;
       }
-      // This workgroup is the only writer of the partition's group rows during
-      // the launch: plain read-modify-write, coalesced over consecutive groups.
-      uint64_t* row = r.table + (base + g) * r.stride;
-      const uint64_t mine = r.rowBase + static_cast<uint64_t>(f);
-      const uint64_t old = row[1];
+      const uint64_t w0 = w[u][0];
+      const uint32_t g = static_cast<uint32_t>(w0) & static_cast<uint32_t>(f.B - 1);
+      const uint32_t row = static_cast<uint32_t>(w0 >> kRadixKeyBits) & ((1u << kRadixRowBits) - 1);
+      const uint32_t mask = static_cast<uint32_t>(w0 >> (kRadixKeyBits + kRadixRowBits));
+      if (f.first[g] > row) {
+        atomicMin(&f.first[g], row);
+      }
+#pragma unroll
+      for (int q = 1; q < W; ++q) {
+        const int j = r.accOfVal[q - 1];
+        if ((mask >> j) & 1) {
+          applyLds(f.acc + static_cast<size_t>(g) * A + j, r.kind[j], w[u][q], r.counters);
+        }
+      }
+      for (int j = 0; j < A; ++j) {
+        if (r.valIdx[j] < 0 && ((mask >> j) & 1)) {
+          applyLds(f.acc + static_cast<size_t>(g) * A + j, r.kind[j], 1ULL, r.counters);
+        }
+      }
+    }
+  }
+  blockSync();
+}
+
+// Adds the LDS block into the partition's group rows. exclusive: this workgroup
+// is the only writer of those rows during the launch — plain read-modify-write,
+// coalesced over consecutive groups; otherwise (the partition is shared by
+// several workgroups, see below) HBM atomics.
+__device__ inline void rpFoldFlush(const RpFold& f, const RadixAggArgs& r, int64_t p, bool exclusive) {
+  const int A = f.A;
+  const uint64_t base = static_cast<uint64_t>(p) << r.shiftB;
+  uint32_t newGroups = 0;
+  for (int g = threadIdx.x; g < f.B; g += blockDim.x) {
+    const uint32_t fr = f.first[g];
+    if (fr == 0xffffffffu || base + g >= r.capacity) {
+      continue;
+    }
+    uint64_t* row = r.table + (base + g) * r.stride;
+    const uint64_t mine = r.rowBase + static_cast<uint64_t>(fr);
+    if (!exclusive) {
+      const unsigned long long old = atomicMin(reinterpret_cast<unsigned long long*>(row + 1), mine);
       if (old == kNoRow) {
         ++newGroups;
       }
-      if (mine < old) {
-        row[1] = mine;
-      }
       for (int j = 0; j < A; ++j) {
-        const uint64_t v = acc[static_cast<size_t>(g) * A + j];
-        uint64_t* word = row + r.off[j];
-        switch (r.kind[j]) {
-          case ACC_SUM_F64:
-            *reinterpret_cast<double*>(word) += __longlong_as_double(static_cast<long long>(v));
-            break;
-          case ACC_SUM_I64: {
-            const int64_t before = static_cast<int64_t>(*word);
-            if (addOverflows(before, static_cast<int64_t>(v))) {
-              r.counters->overflow = 1;
-            }
-            *word = static_cast<uint64_t>(before) + v;
-            break;
-          }
-          case ACC_SUM_I64_WRAP:
-          case ACC_COUNT:
-            *word += v;
-            break;
-          case ACC_MIN:
-            *word = v < *word ? v : *word;
-            break;
-          default:
-            *word = v > *word ? v : *word;
-            break;
+        const uint64_t v = f.acc[static_cast<size_t>(g) * A + j];
+        if (v != accIdentity(r.kind[j]) || r.kind[j] == ACC_SUM_F64) {
+          applyGlobal(row + r.off[j], r.kind[j] == ACC_COUNT ? ACC_SUM_I64_WRAP : r.kind[j], v, r.counters);
         }
       }
+      continue;
     }
-    if (newGroups) {
-      atomicAdd(&r.counters->numNewGroups, newGroups);
+    const uint64_t old = row[1];
+    if (old == kNoRow) {
+      ++newGroups;
     }
-    __syncthreads();
+    if (mine < old) {
+      row[1] = mine;
+    }
+    for (int j = 0; j < A; ++j) {
+      const uint64_t v = f.acc[static_cast<size_t>(g) * A + j];
+      uint64_t* word = row + r.off[j];
+      switch (r.kind[j]) {
+        case ACC_SUM_F64:
+          *reinterpret_cast<double*>(word) += __longlong_as_double(static_cast<long long>(v));
+          break;
+        case ACC_SUM_I64: {
+          const int64_t before = static_cast<int64_t>(*word);
+          if (addOverflows(before, static_cast<int64_t>(v))) {
+            r.counters->overflow = 1;
+          }
+          *word = static_cast<uint64_t>(before) + v;
+          break;
+        }
+        case ACC_SUM_I64_WRAP:
+        case ACC_COUNT:
+          *word += v;
+          break;
+        case ACC_MIN:
+          *word = v < *word ? v : *word;
+          break;
+        default:
+          *word = v > *word ? v : *word;
+          break;
+      }
+    }
+  }
+  if (newGroups) {
+    atomicAdd(&r.counters->numNewGroups, newGroups);
+  }
+  blockSync();
+}
+
+__device__ inline void rpPartitionRange(const RadixAggArgs& r, int64_t p, uint64_t* begin, uint64_t* end) {
+  *begin = r.partBegin[r.partCell ? r.partCell[p] : p * r.cellStride];
+  *end = r.partBegin[r.partCell ? r.partCell[p + 1] : (p + 1) * r.cellStride];
+}
+
+// Fold: one workgroup per partition folds its records into LDS, then touches
+// each of the <= B group rows in HBM once. A partition with more than
+// sliceRecs records (few partitions, or skewed keys) is cut into slices:
+// its owner folds the first one, the others are spread over all workgroups
+// in a second phase, and every slice of such a partition is flushed with
+// atomics instead of plain read-modify-write.
+template <int W>
+__global__ __launch_bounds__(512) void k_rp_aggregate(RadixAggArgs r) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+  __shared__ uint32_t bigList[512];
+  __shared__ uint32_t bigCount;
+  RpFold f;
+  f.B = 1 << r.shiftB;
+  f.A = r.numAccs;
+  f.acc = reinterpret_cast<uint64_t*>(ldsRaw);                                       // [B][A]
+  f.first = reinterpret_cast<uint32_t*>(f.acc + static_cast<size_t>(f.B) * f.A);   // [B]
+  for (int64_t p = blockIdx.x; p < r.numParts; p += gridDim.x) {
+    uint64_t begin, end;
+    rpPartitionRange(r, p, &begin, &end);
+    if (end == begin) {
+      continue;  // uniform per workgroup
+    }
+    const bool split = end - begin > r.sliceRecs;
+    rpFoldInit(f, r);
+    rpFoldRecords<W>(f, r, begin, split ? begin + r.sliceRecs : end);
+    rpFoldFlush(f, r, p, !split);
+  }
+  // Remaining slices of the split partitions.
+  for (int64_t p0 = 0; p0 < r.numParts; p0 += blockDim.x) {
+    if (threadIdx.x == 0) {
+      bigCount = 0;
+    }
+    blockSync();
+    const int64_t mine = p0 + threadIdx.x;
+    if (mine < r.numParts) {
+      uint64_t begin, end;
+      rpPartitionRange(r, mine, &begin, &end);
+      if (end - begin > r.sliceRecs) {
+        bigList[atomicAdd(&bigCount, 1u)] = static_cast<uint32_t>(threadIdx.x);
+      }
+    }
+    blockSync();
+    const uint32_t n = bigCount;
+    for (uint32_t k = 0; k < n; ++k) {
+      const int64_t p = p0 + bigList[k];
+      uint64_t begin, end;
+      rpPartitionRange(r, p, &begin, &end);
+      const uint64_t slices = (end - begin + r.sliceRecs - 1) / r.sliceRecs;
+      for (uint64_t s = 1 + blockIdx.x; s < slices; s += gridDim.x) {
+        const uint64_t b = begin + s * r.sliceRecs;
+        rpFoldInit(f, r);
+        rpFoldRecords<W>(f, r, b, b + r.sliceRecs < end ? b + r.sliceRecs : end);
+        rpFoldFlush(f, r, p, false);
+      }
+    }
+    blockSync();
   }
 }
 
@@ -2779,7 +2862,12 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
     g.accOfVal[j] = r.accOfVal[j];
   }
   const size_t ldsBytes = (static_cast<size_t>(1) << r.shiftB) * (a.numAccs * 8 + 4);
-  const int gridA = static_cast<int>(std::min<int64_t>(g.numParts, rt.numCUs * 2));
+  // Few partitions or skewed keys: slices keep every CU busy.
+  g.sliceRecs = static_cast<uint64_t>(std::max<int64_t>(1 << 16, ceilDiv(n, 2048)));
+  if (const char* e = std::getenv("VX355_AGG_RADIX_SLICE")) {
+    g.sliceRecs = static_cast<uint64_t>(std::max<int64_t>(512, std::strtoll(e, nullptr, 10)));
+  }
+  const int gridA = rt.numCUs * 2;
   byWidth([&](auto wTag) {
     VX_LAUNCH("k_rp_aggregate", (k_rp_aggregate<decltype(wTag)::value>), gridA, 512, ldsBytes, g);
   });

@@ -141,7 +141,7 @@ __device__ inline LdsState ldsInit(const LdsPlan& p, unsigned char* raw) {
   for (int i = threadIdx.x; i < p.S * p.A * p.REP; i += blockDim.x) {
     st.acc[i] = accIdentity(p.kind[(i / p.REP) % p.A]);
   }
-  __syncthreads();
+  blockSync();
   return st;
 }
 
@@ -186,7 +186,7 @@ __device__ inline void ldsTouchFirst(const LdsState& st, int32_t slot, uint32_t 
 
 // Flush: one (slot, accumulator) pair per thread; replicas reduced in LDS.
 __device__ inline void ldsFlush(const LdsPlan& p, const LdsState& st) {
-  __syncthreads();
+  blockSync();
   const int S = p.S, A = p.A, REP = p.REP;
   uint32_t live = *st.numSlots;
   if (live > static_cast<uint32_t>(S)) {

@@ -31,6 +31,20 @@ __host__ __device__ inline bool bitAt(const uint64_t* bits, int64_t i) {
   return (bits[i >> 6] >> (i & 63)) & 1;
 }
 
+// Workgroup barrier used everywhere instead of __syncthreads(): LDS atomics
+// that return nothing (ds_add / ds_min / ds_max) are fire-and-forget, and the
+// workgroup is about to read what they produce, so this wave's LDS operations
+// are drained (lgkmcnt(0)) before it signals the barrier. hipcc's own
+// __syncthreads() was observed to leave that wait out on a loop-exit path of
+// the histogram kernels: under heavy same-bin contention the counts of one
+// wave instruction went missing.
+__device__ inline void blockSync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // vmcnt(63) expcnt(7) lgkmcnt(0)
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 __device__ inline int lane() { return __lane_id(); }
 __device__ inline uint64_t ballot(bool p) { return __ballot(p); }
 // Number of set bits of m below this lane.

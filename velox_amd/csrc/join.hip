@@ -680,11 +680,11 @@ __global__ __launch_bounds__(256) void k_join_probe(ProbeArgs args) {
     if (lane() == 0) {
       waveSums[threadIdx.x >> 6] = mine;
     }
-    __syncthreads();
+    blockSync();
     if (threadIdx.x == 0) {
       a.tileSums[tile] = waveSums[0] + waveSums[1] + waveSums[2] + waveSums[3];
     }
-    __syncthreads();
+    blockSync();
   }
 }
 
@@ -701,12 +701,12 @@ __global__ __launch_bounds__(1024) void k_scan_u64(const uint64_t* in, int64_t n
     sum += in[i];
   }
   partial[t] = sum;
-  __syncthreads();
+  blockSync();
   for (int off = 1; off < 1024; off <<= 1) {
     uint64_t v = t >= off ? partial[t - off] : 0;
-    __syncthreads();
+    blockSync();
     partial[t] += v;
-    __syncthreads();
+    blockSync();
   }
   uint64_t run = t == 0 ? 0 : partial[t - 1];
   for (int64_t i = begin; i < end; ++i) {
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
     if (lane() == 0) {
       waveTotals[threadIdx.x >> 6] = total;
     }
-    __syncthreads();
+    blockSync();
     uint64_t run = a.tileOffsets[tile];
     for (int w = 0; w < (threadIdx.x >> 6); ++w) {
       run += waveTotals[w];
@@ -793,7 +793,7 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
   if (threadIdx.x == 0) {
     running = a.tileOffsets[tile];
   }
-  __syncthreads();
+  blockSync();
   for (int step = 0; step < kTileRows / 256; ++step) {
     const int64_t r = tile * kTileRows + step * 256 + threadIdx.x;
     uint32_t hit = kNoRow32;
@@ -813,7 +813,7 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
     if (lane() == 63) {
       waveTotals[threadIdx.x >> 6] = incl;
     }
-    __syncthreads();
+    blockSync();
     uint64_t lo = running + (incl - c);
     for (int w = 0; w < (threadIdx.x >> 6); ++w) {
       lo += waveTotals[w];
@@ -836,11 +836,11 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
         }
       }
     }
-    __syncthreads();
+    blockSync();
     if (threadIdx.x == 0) {
       running += stepTotal;
     }
-    __syncthreads();
+    blockSync();
     if (running >= a.windowEnd) {
       break;  // uniform: 'running' is shared
     }

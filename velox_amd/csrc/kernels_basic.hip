@@ -174,13 +174,13 @@ __global__ __launch_bounds__(1024) void k_scan_counts(const uint32_t* counts, in
     sum += counts[i];
   }
   partial[t] = sum;
-  __syncthreads();
+  blockSync();
   // Hillis-Steele over 1024 partials.
   for (int off = 1; off < 1024; off <<= 1) {
     uint32_t v = t >= off ? partial[t - off] : 0;
-    __syncthreads();
+    blockSync();
     partial[t] += v;
-    __syncthreads();
+    blockSync();
   }
   uint32_t run = t == 0 ? 0 : partial[t - 1];
   for (int64_t i = begin; i < end; ++i) {
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_block_sums(const uint32_t* 
   if (lane() == 0) {
     partial[threadIdx.x >> 6] = s;
   }
-  __syncthreads();
+  blockSync();
   if (threadIdx.x == 0) {
     uint64_t t = 0;
     for (int w = 0; w < kScanBlock / 64; ++w) {
@@ -309,12 +309,12 @@ __global__ __launch_bounds__(1024) void k_scan_sums(uint64_t* sums, int64_t n, u
     sum += sums[i];
   }
   partial[t] = sum;
-  __syncthreads();
+  blockSync();
   for (int off = 1; off < 1024; off <<= 1) {
     uint64_t v = t >= off ? partial[t - off] : 0;
-    __syncthreads();
+    blockSync();
     partial[t] += v;
-    __syncthreads();
+    blockSync();
   }
   uint64_t run = t == 0 ? 0 : partial[t - 1];
   for (int64_t i = begin; i < end; ++i) {
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_apply(const uint32_t* in, i
   if (lane() == 63) {
     waveTotals[threadIdx.x >> 6] = incl;
   }
-  __syncthreads();
+  blockSync();
   uint64_t run = blockBase[blockIdx.x] + (incl - mine);
   for (int w = 0; w < (threadIdx.x >> 6); ++w) {
     run += waveTotals[w];

@@ -21,19 +21,19 @@ __global__ __launch_bounds__(256) void k_part_hist(const uint32_t* parts, int64_
     if (threadIdx.x < kMaxParts) {
       hist[threadIdx.x] = 0;
     }
-    __syncthreads();
+    blockSync();
     for (int j = 0; j < kTile / 256; ++j) {
       const int64_t r = tile * kTile + j * 256 + threadIdx.x;
       if (r < numRows) {
         atomicAdd(&hist[parts[r]], 1u);
       }
     }
-    __syncthreads();
+    blockSync();
     if (threadIdx.x < numParts) {
       // partition-major layout: counts[p * numTiles + tile]
       tileCounts[static_cast<int64_t>(threadIdx.x) * numTiles + tile] = hist[threadIdx.x];
     }
-    __syncthreads();
+    blockSync();
   }
 }
 
@@ -49,12 +49,12 @@ __global__ __launch_bounds__(1024) void k_part_scan(const uint32_t* counts, int6
     sum += counts[i];
   }
   partial[t] = sum;
-  __syncthreads();
+  blockSync();
   for (int off = 1; off < 1024; off <<= 1) {
     uint64_t v = t >= off ? partial[t - off] : 0;
-    __syncthreads();
+    blockSync();
     partial[t] += v;
-    __syncthreads();
+    blockSync();
   }
   uint64_t run = t == 0 ? 0 : partial[t - 1];
   for (int64_t i = begin; i < end; ++i) {
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void k_part_scatter(ScatterArgs a) {
     if (threadIdx.x < kMaxParts) {
       running[threadIdx.x] = 0;
     }
-    __syncthreads();
+    blockSync();
     const int wave = threadIdx.x >> 6;
     for (int j = 0; j < kTile / 256; ++j) {
       const int64_t r = tile * kTile + j * 256 + threadIdx.x;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void k_part_scatter(ScatterArgs a) {
           waveCount[wave][q] = static_cast<uint32_t>(popc64(m));
         }
       }
-      __syncthreads();
+      blockSync();
       if (live) {
         uint32_t before = running[p];
         for (int w = 0; w < wave; ++w) {
@@ -127,12 +127,12 @@ __global__ __launch_bounds__(256) void k_part_scatter(ScatterArgs a) {
           }
         }
       }
-      __syncthreads();
+      blockSync();
       if (threadIdx.x < a.numParts) {
         running[threadIdx.x] += waveCount[0][threadIdx.x] + waveCount[1][threadIdx.x] +
             waveCount[2][threadIdx.x] + waveCount[3][threadIdx.x];
       }
-      __syncthreads();
+      blockSync();
     }
   }
 }
