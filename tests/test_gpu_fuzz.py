@@ -38,6 +38,17 @@ def _values(rng, kind, n, card):
     raise AssertionError(kind)
 
 
+def _skew(rng, values, n):
+    """Sometimes most rows carry one value (hot keys are where LDS atomics contend)."""
+    if n > 1 and rng.random() < 0.3:
+        hot = rng.random(n) < rng.choice([0.6, 0.95])
+        if isinstance(values, list):
+            return [values[0] if h else v for h, v in zip(hot, values)]
+        values = values.copy()
+        values[hot] = values[0]
+    return values
+
+
 def _spec(rng, kind, n, card=200):
     """Raw material of a column of n rows: random encoding, random share of nulls."""
     enc = rng.choice(["flat", "flat", "dict", "const"]) if n > 0 else "flat"
@@ -51,7 +62,7 @@ def _spec(rng, kind, n, card=200):
     if enc == "const":
         return dict(kind=kind, enc=enc, values=_values(rng, kind, 1, card), indices=None,
                     valid=None if valid is None else np.full(n, bool(valid[0])))
-    return dict(kind=kind, enc=enc, values=_values(rng, kind, n, card), indices=None, valid=valid)
+    return dict(kind=kind, enc=enc, values=_skew(rng, _values(rng, kind, n, card), n), indices=None, valid=valid)
 
 
 def _build(spec, sel=None):
@@ -113,7 +124,7 @@ def test_random_aggregation_plans(oracle, vx, seed, monkeypatch):
     cut = int(rng.integers(10, 90))
     batches, filtered = [], []
     for _ in range(int(rng.integers(1, 5))):
-        n = int(rng.choice([1, 63, 64, 1000, 5000, 20000]))
+        n = int(rng.choice([1, 63, 64, 1000, 5000, 20000, 150000]))
         specs = [_spec(rng, k, n, card) for k in layout]
         cols = [_build(sp) for sp in specs]
         if fused:
