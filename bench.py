@@ -618,8 +618,15 @@ class C5:
 
     def step(self, step_kind=None):
         import torch.distributed as dist
-        total, outputs, stats = vdist.repartitioned_join(self.backend, dist, self.torch,
-                                                         [self.pk, self.a], [self.fk, self.m])
+        if self.world > 1:
+            # probe side in 4 chunks: the all-to-all of one chunk overlaps the partitioning of the next
+            per_chunk, table = vdist.repartitioned_join_pipelined(self.backend, dist, self.torch,
+                                                                  [self.pk, self.a], [self.fk, self.m], chunks=4)
+            total = sum(int(m.shape[0]) for _, outs in per_chunk for m, _ in outs)
+            stats = table.stats()
+        else:
+            total, outputs, stats = vdist.repartitioned_join(self.backend, dist, self.torch,
+                                                             [self.pk, self.a], [self.fk, self.m])
         self.matches, self.stats = total, stats
         return total
 

@@ -42,12 +42,18 @@ class OracleBackend:
         counts = np.bincount(p, minlength=world).astype(np.int64)
         return [c[self.torch.from_numpy(order)] for c in cols], counts
 
-    def join(self, build_cols, probe_cols):
+    def build(self, build_cols):
         abi, oracle = self.abi, self.oracle
         b = oracle.JoinBuild([0], [abi.BIGINT], [1], [abi.BIGINT], abi.JOIN_INNER)
         b.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, build_cols[0].numpy()),
                                    abi.HostColumn(abi.BIGINT, build_cols[1].numpy())]))
-        table = b.finish()
+        return b.finish()
+
+    def join(self, build_cols, probe_cols):
+        return self.probe(self.build(build_cols), probe_cols)
+
+    def probe(self, table, probe_cols):
+        abi, oracle = self.abi, self.oracle
         p = oracle.JoinProbe(table, [0], abi.JOIN_INNER)
         fk, m = probe_cols[0].numpy(), probe_cols[1].numpy()
         p.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, fk)], len(fk)))
@@ -61,7 +67,7 @@ class OracleBackend:
         return out
 
 
-def run(rank, world, port, out_dir):
+def run(rank, world, port, out_dir, chunks=0):
     import torch
     import torch.distributed as dist
     import oracle_lib
@@ -70,13 +76,18 @@ def run(rank, world, port, out_dir):
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     (pk, a), (fk, m) = shard(rank, world)
     backend = OracleBackend(torch, oracle_lib, abi)
-    rows = vdist.repartitioned_join(backend, dist, torch,
-                                    [torch.from_numpy(pk), torch.from_numpy(a)],
-                                    [torch.from_numpy(fk), torch.from_numpy(m)])
+    build_cols = [torch.from_numpy(pk), torch.from_numpy(a)]
+    probe_cols = [torch.from_numpy(fk), torch.from_numpy(m)]
+    if chunks:
+        # chunked exchange overlapped with the next chunk's partitioning (async all-to-all)
+        per_chunk, _ = vdist.repartitioned_join_pipelined(backend, dist, torch, build_cols, probe_cols, chunks)
+        rows = [r for _, out in per_chunk for r in out]
+    else:
+        rows = vdist.repartitioned_join(backend, dist, torch, build_cols, probe_cols)
     np.save(os.path.join(out_dir, f"join_rank{rank}.npy"), np.array(rows, dtype=np.float64).reshape(-1, 3))
     dist.barrier()
     dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
+    run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]) if len(sys.argv) > 5 else 0)

@@ -240,6 +240,15 @@ def test_repartitioned_join_gpu_backend_single_rank(oracle, vx):
         want = sorted(lookup[k] for k in fk.tolist() if k in lookup)
         got = sorted(np.concatenate([p.cpu().numpy() for _, p in outputs]).tolist())
         assert total == len(want) and got == want
+        # the pipelined form (probe side in chunks, asynchronous all-to-all) gives the same rows
+        per_chunk, table = vdist.repartitioned_join_pipelined(backend, dist, torch, [t[0], t[1]], [t[2]], chunks=3)
+        assert len(per_chunk) == 3 and table.stats().num_rows == nd
+        got = sorted(np.concatenate([p.cpu().numpy() for _, outs in per_chunk for _, p in outs]).tolist())
+        assert got == want
+        for received, outs in per_chunk:      # mappings index the rows of their own chunk
+            for m, p in outs:
+                keys = received[0][m.long()].cpu().numpy().tolist()
+                assert [lookup[k] for k in keys] == p.cpu().numpy().tolist()
     finally:
         dist.destroy_process_group()
 
