@@ -326,6 +326,99 @@ __device__ inline void updateGlobal(const AggArgs& a, int64_t row, uint64_t key,
   }
 }
 
+// Wave-wide reduction of one accumulator operand over the lanes in 'members'
+// (others contribute the identity); every lane returns the total.
+__device__ inline uint64_t waveCombine(int32_t kind, uint64_t v, bool member, Counters* ctr) {
+  uint64_t x = member ? v : accIdentity(kind);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint64_t o = shfl64(x, lane() ^ off);
+    switch (kind) {
+      case ACC_SUM_F64:
+        x = static_cast<uint64_t>(__double_as_longlong(__longlong_as_double(static_cast<long long>(x)) +
+                                                        __longlong_as_double(static_cast<long long>(o))));
+        break;
+      case ACC_SUM_I64:
+        if (addOverflows(static_cast<int64_t>(x), static_cast<int64_t>(o))) {
+          ctr->overflow = 1;
+        }
+        x += o;
+        break;
+      case ACC_SUM_I64_WRAP:
+      case ACC_COUNT:
+        x += o;
+        break;
+      case ACC_MIN:
+        x = o < x ? o : x;
+        break;
+      default:
+        x = o > x ? o : x;
+        break;
+    }
+  }
+  return x;
+}
+
+// updateGlobal for a whole wave (called by all 64 lanes, 'active' says which
+// rows count). One HBM address retires ~88 M atomics/s, so rows of a hot key
+// must not each bring their own atomic: the lanes that share the first active
+// lane's key — when there are at least kHotLanes of them — are reduced in
+// registers and the leader applies one update per accumulator. Everything
+// else takes the per-row path.
+constexpr int kHotLanes = 8;
+
+__device__ inline void updateGlobalWave(const AggArgs& a, int64_t row, uint64_t key, bool active,
+                                        uint32_t* newGroups) {
+  const uint64_t act = ballot(active);
+  if (act == 0) {
+    return;
+  }
+  // Up to four candidate leaders: with half of the rows on one key the chance
+  // that none of them carries it is 1/16.
+  uint64_t candidates = act;
+  uint64_t done = 0;
+  for (int round = 0; round < 4 && candidates != 0; ++round) {
+    const int leader = __ffsll(static_cast<long long>(candidates)) - 1;
+    const uint64_t leaderKey = shfl64(key, leader);
+    const bool member = active && !((done >> lane()) & 1) && key == leaderKey;
+    const uint64_t same = ballot(member);
+    if (popc64(same) < kHotLanes) {
+      candidates &= ~(1ULL << leader);  // stays on the per-row path
+      continue;
+    }
+    uint64_t* g = nullptr;
+    if (lane() == leader) {
+      g = groupRow(a, key);
+    }
+    g = reinterpret_cast<uint64_t*>(shfl64(reinterpret_cast<uint64_t>(g), leader));
+    if (g != nullptr) {  // null: table full, flagged by findOrInsert
+      const uint64_t firstRow =
+          waveCombine(ACC_MIN, a.rowBase + static_cast<uint64_t>(row), member, a.counters);
+      if (lane() == leader && __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > firstRow) {
+        const unsigned long long old = atomicMin(reinterpret_cast<unsigned long long*>(g + 1), firstRow);
+        if (old == kNoRow) {
+          ++*newGroups;
+        }
+      }
+      for (int i = 0; i < a.numAccs; ++i) {
+        const AccArg& acc = a.accs[i];
+        uint64_t v = 0;
+        const bool has = member && accInput(a, acc, row, &v);
+        const uint64_t any = ballot(has);
+        const uint64_t total = waveCombine(acc.kind, v, has, a.counters);
+        if (any != 0 && lane() == leader) {
+          applyGlobal(g + acc.off, acc.kind, total, a.counters);
+        }
+      }
+    }
+    done |= same;
+    candidates &= ~same;
+  }
+  if (active && !((done >> lane()) & 1)) {
+    updateGlobal(a, row, key, newGroups);
+  }
+}
+
 __device__ inline void addNewGroups(Counters* ctr, uint32_t mine) {
   uint32_t total = mine;
 #pragma unroll
@@ -345,17 +438,16 @@ __global__ __launch_bounds__(256) void k_agg_global(AggArgs a) {
   int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   for (int64_t r = 0; r < rounds; ++r, i += stride) {
     bool defer = false;
+    bool active = false;
     int32_t row = 0;
+    uint64_t key = 0;
     if (i < a.numRows) {
       row = a.rowList ? a.rowList[i] : static_cast<int32_t>(i);
-      uint64_t key;
       int st = (a.numTerms && !evalFilter(a.terms, a.numTerms, row)) ? 1 : normalizedKey(a, row, &key);
-      if (st == 0) {
-        updateGlobal(a, row, key, &newGroups);
-      } else if (st == 2) {
-        defer = true;
-      }
+      active = st == 0;
+      defer = st == 2;
     }
+    updateGlobalWave(a, row, key, active, &newGroups);
     deferRow(a, defer, row);
   }
   addNewGroups(a.counters, newGroups);
