@@ -373,6 +373,15 @@ __device__ inline void updateGlobalWave(const AggArgs& a, int64_t row, uint64_t 
   if (act == 0) {
     return;
   }
+  // Cheap screen first: a key frequent enough to matter makes neighbouring lanes
+  // agree; random keys never do, and then the rounds below are skipped.
+  const bool pairEqual = active && key == shfl64(key, lane() ^ 1);
+  if (popc64(ballot(pairEqual)) < kHotLanes) {
+    if (active) {
+      updateGlobal(a, row, key, newGroups);
+    }
+    return;
+  }
   // Up to four candidate leaders: with half of the rows on one key the chance
   // that none of them carries it is 1/16.
   uint64_t candidates = act;
