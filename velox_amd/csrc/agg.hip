@@ -1199,141 +1199,158 @@ __device__ inline bool insideRanges(const AggArgs& a, int64_t row) {
 }
 static_assert(sizeof(GenericArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
-__global__ __launch_bounds__(256) void k_agg_generic(GenericArgs args) {
+// Dense group id of one input row in generic mode (claims a slot for a new key);
+// false: the row does not take part (filtered, null key dropped, unsupported key).
+__device__ inline bool genericGroupId(const GenericArgs& args, int64_t row, uint32_t* gidOut) {
   const AggArgs& a = args.a;
   const GenericPart& g = args.g;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  uint32_t newGroups = 0;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.numRows; i += stride) {
-    const int64_t row = a.rowList ? a.rowList[i] : i;
-    if (a.numTerms && !evalFilter(a.terms, a.numTerms, row)) {
-      continue;
-    }
-    if (args.skipInside && insideRanges(a, row)) {
-      continue;
-    }
-    // Key images, null mask and the VectorHasher hash of the row.
-    uint64_t w0[kMaxKeys], w1[kMaxKeys];
-    uint64_t nullMask = 0;
-    uint64_t hash = 0;
-    bool supported = true;
+  if (a.numTerms && !evalFilter(a.terms, a.numTerms, row)) {
+    return false;
+  }
+  if (args.skipInside && insideRanges(a, row)) {
+    return false;
+  }
+  // Key images, null mask and the VectorHasher hash of the row.
+  uint64_t w0[kMaxKeys], w1[kMaxKeys];
+  uint64_t nullMask = 0;
+  uint64_t hash = 0;
+  bool supported = true;
 #pragma unroll
-    for (int k = 0; k < kMaxKeys; ++k) {
-      w0[k] = 0;
-      w1[k] = 0;
-      if (k < a.numKeys) {
-        const ColView& c = a.keys[k].col;
-        uint64_t hv = kNullHash;
-        if (colIsNull(c, row)) {
-          nullMask |= 1ULL << k;
-        } else {
-          const int64_t i = colIndex(c, row);
-          keyImage(c, i, &w0[k], &w1[k], &supported);
-          hv = hashValueAt(c, i);
-        }
-        hash = k == 0 ? hv : hashMix(hash, hv);
+  for (int k = 0; k < kMaxKeys; ++k) {
+    w0[k] = 0;
+    w1[k] = 0;
+    if (k < a.numKeys) {
+      const ColView& c = a.keys[k].col;
+      uint64_t hv = kNullHash;
+      if (colIsNull(c, row)) {
+        nullMask |= 1ULL << k;
+      } else {
+        const int64_t i = colIndex(c, row);
+        keyImage(c, i, &w0[k], &w1[k], &supported);
+        hv = hashValueAt(c, i);
       }
+      hash = k == 0 ? hv : hashMix(hash, hv);
     }
-    if (nullMask && a.ignoreNullKeys) {
-      continue;
-    }
-    if (!supported) {
-      a.counters->unmappable = 1;
-      continue;
-    }
-    const uint64_t tag = hash >> 32;
-    uint64_t pos = hash & g.slotMask;
-    uint32_t gid = kPendingGid;
-    uint64_t probes = 0;
-    uint32_t spins = 0;  // every wait on another lane's publish is bounded
-    while (gid == kPendingGid && probes <= g.slotMask && spins < (1u << 22)) {
-      uint64_t w = loadAgent(g.slots + pos);
-      bool advance = false;
-      if (w == 0) {
-        const unsigned long long claim = (tag << 32) | kPendingGid;
-        const unsigned long long old =
-            atomicCAS(reinterpret_cast<unsigned long long*>(g.slots + pos), 0ULL, claim);
-        if (old == 0) {
-          // Dense group ids: one atomic per wave for all lanes that claimed a slot in
-          // this iteration (a single address takes < 100 M atomics/s).
-          const uint64_t winners = ballot(true);
-          const int leader = __ffsll(static_cast<long long>(winners)) - 1;
-          uint32_t idBase = 0;
-          if (lane() == leader) {
-            idBase = atomicAdd(g.gidCounter, static_cast<uint32_t>(popc64(winners)));
-          }
-          const uint32_t id = __shfl(idBase, leader, kWave) + lanePrefix(winners);
-          if (id < g.maxGroups) {
+  }
+  if (nullMask && a.ignoreNullKeys) {
+    return false;
+  }
+  if (!supported) {
+    a.counters->unmappable = 1;
+    return false;
+  }
+  const uint64_t tag = hash >> 32;
+  uint64_t pos = hash & g.slotMask;
+  uint32_t gid = kPendingGid;
+  uint64_t probes = 0;
+  uint32_t spins = 0;  // every wait on another lane's publish is bounded
+  while (gid == kPendingGid && probes <= g.slotMask && spins < (1u << 22)) {
+    uint64_t w = loadAgent(g.slots + pos);
+    bool advance = false;
+    if (w == 0) {
+      const unsigned long long claim = (tag << 32) | kPendingGid;
+      const unsigned long long old =
+          atomicCAS(reinterpret_cast<unsigned long long*>(g.slots + pos), 0ULL, claim);
+      if (old == 0) {
+        // Dense group ids: one atomic per wave for all lanes that claimed a slot in
+        // this iteration (a single address takes < 100 M atomics/s).
+        const uint64_t winners = ballot(true);
+        const int leader = __ffsll(static_cast<long long>(winners)) - 1;
+        uint32_t idBase = 0;
+        if (lane() == leader) {
+          idBase = atomicAdd(g.gidCounter, static_cast<uint32_t>(popc64(winners)));
+        }
+        const uint32_t id = __shfl(idBase, leader, kWave) + lanePrefix(winners);
+        if (id < g.maxGroups) {
 #pragma unroll
-            for (int k = 0; k < kMaxKeys; ++k) {
-              if (k < a.numKeys) {
-                storeAgent(g.keyStore[k] + static_cast<uint64_t>(id) * g.keyWords[k], w0[k]);
-                if (g.keyWords[k] == 2) {
-                  storeAgent(g.keyStore[k] + static_cast<uint64_t>(id) * 2 + 1, w1[k]);
-                }
+          for (int k = 0; k < kMaxKeys; ++k) {
+            if (k < a.numKeys) {
+              storeAgent(g.keyStore[k] + static_cast<uint64_t>(id) * g.keyWords[k], w0[k]);
+              if (g.keyWords[k] == 2) {
+                storeAgent(g.keyStore[k] + static_cast<uint64_t>(id) * 2 + 1, w1[k]);
               }
             }
-            storeAgent(g.nullStore + id, nullMask);
-            storeAgent(g.hashStore + id, hash);
-            // Publish after the key images: those were agent-scope (write-through)
-            // atomic stores, so waiting for their acknowledgement orders them before
-            // the slot store for every reader that uses agent-scope loads. A full
-            // agent-scope release fence (__threadfence) also writes back the XCD's L2
-            // on gfx950 and made this kernel 3x slower.
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_s_waitcnt(0);
-            storeAgent(g.slots + pos, (tag << 32) | (static_cast<uint64_t>(id) + 1));
-            gid = id;
-          } else {
-            // Never leave a PENDING slot behind: waiters would spin on it.
-            storeAgent(g.slots + pos, (tag << 32) | kDeadGid);
-            a.counters->tableFull = 1;
-            gid = kDeadGid;  // leave the loop; the host raises the error
           }
-          w = 0;
+          storeAgent(g.nullStore + id, nullMask);
+          storeAgent(g.hashStore + id, hash);
+          // Publish after the key images: those were agent-scope (write-through)
+          // atomic stores, so waiting for their acknowledgement orders them before
+          // the slot store for every reader that uses agent-scope loads. A full
+          // agent-scope release fence (__threadfence) also writes back the XCD's L2
+          // on gfx950 and made this kernel 3x slower.
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_s_waitcnt(0);
+          storeAgent(g.slots + pos, (tag << 32) | (static_cast<uint64_t>(id) + 1));
+          gid = id;
         } else {
-          w = old;
+          // Never leave a PENDING slot behind: waiters would spin on it.
+          storeAgent(g.slots + pos, (tag << 32) | kDeadGid);
+          a.counters->tableFull = 1;
+          gid = kDeadGid;  // leave the loop; the host raises the error
         }
+        w = 0;
+      } else {
+        w = old;
       }
-      if (gid == kPendingGid && w != 0) {
-        if ((w >> 32) == tag) {
-          const uint32_t lo = static_cast<uint32_t>(w);
-          if (lo == kDeadGid) {
-            advance = true;
-          } else if (lo == kPendingGid) {
-            ++spins;  // the claimer has not published yet; look at this slot again
-          } else {
-            const uint32_t cand = lo - 1;
-            bool equal = loadAgent(g.nullStore + cand) == nullMask;
-#pragma unroll
-            for (int k = 0; k < kMaxKeys; ++k) {
-              if (equal && k < a.numKeys && !((nullMask >> k) & 1)) {
-                equal = loadAgent(g.keyStore[k] + static_cast<uint64_t>(cand) * g.keyWords[k]) == w0[k];
-                if (equal && g.keyWords[k] == 2) {
-                  equal = loadAgent(g.keyStore[k] + static_cast<uint64_t>(cand) * 2 + 1) == w1[k];
-                }
-              }
-            }
-            if (equal) {
-              gid = cand;
-            } else {
-              advance = true;
-            }
-          }
-        } else {
+    }
+    if (gid == kPendingGid && w != 0) {
+      if ((w >> 32) == tag) {
+        const uint32_t lo = static_cast<uint32_t>(w);
+        if (lo == kDeadGid) {
           advance = true;
+        } else if (lo == kPendingGid) {
+          ++spins;  // the claimer has not published yet; look at this slot again
+        } else {
+          const uint32_t cand = lo - 1;
+          bool equal = loadAgent(g.nullStore + cand) == nullMask;
+#pragma unroll
+          for (int k = 0; k < kMaxKeys; ++k) {
+            if (equal && k < a.numKeys && !((nullMask >> k) & 1)) {
+              equal = loadAgent(g.keyStore[k] + static_cast<uint64_t>(cand) * g.keyWords[k]) == w0[k];
+              if (equal && g.keyWords[k] == 2) {
+                equal = loadAgent(g.keyStore[k] + static_cast<uint64_t>(cand) * 2 + 1) == w1[k];
+              }
+            }
+          }
+          if (equal) {
+            gid = cand;
+          } else {
+            advance = true;
+          }
         }
-      }
-      if (advance) {
-        pos = (pos + 1) & g.slotMask;
-        ++probes;
+      } else {
+        advance = true;
       }
     }
-    if (gid == kPendingGid || gid == kDeadGid) {
-      a.counters->tableFull = 1;
-      continue;
+    if (advance) {
+      pos = (pos + 1) & g.slotMask;
+      ++probes;
     }
-    updateGlobal(a, row, gid, &newGroups);
+  }
+  if (gid == kPendingGid || gid == kDeadGid) {
+    a.counters->tableFull = 1;
+    return false;
+  }
+  *gidOut = gid;
+  return true;
+}
+
+__global__ __launch_bounds__(256) void k_agg_generic(GenericArgs args) {
+  const AggArgs& a = args.a;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const int64_t rounds = (a.numRows + stride - 1) / stride;
+  uint32_t newGroups = 0;
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  for (int64_t r = 0; r < rounds; ++r, i += stride) {
+    bool active = false;
+    int64_t row = 0;
+    uint32_t gid = 0;
+    if (i < a.numRows) {
+      row = a.rowList ? a.rowList[i] : i;
+      active = genericGroupId(args, row, &gid);
+    }
+    // the group row is table + gid * stride (mode = array): hot groups are combined per wave
+    updateGlobalWave(a, row, gid, active, &newGroups);
   }
   addNewGroups(a.counters, newGroups);
 }
