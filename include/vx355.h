@@ -20,8 +20,10 @@
  *  - Inputs are borrowed for the duration of the call. Outputs are written
  *    into caller allocated buffers (host or device, see vx355_mem).
  *  - Handles are single threaded (one Driver thread at a time, exec/Driver.cpp
- *    :538). A vx355_join_table is immutable after finish and may be shared by
- *    any number of probe handles on any thread.
+ *    :538) and each owns one HIP stream; different handles run concurrently
+ *    from different threads (no library-wide lock). A vx355_join_table is
+ *    immutable after finish and may be shared by any number of probe handles
+ *    on any thread.
  */
 #ifndef VX355_H_
 #define VX355_H_
@@ -79,8 +81,9 @@ typedef struct vx355_column {
   const int32_t* indices; /* DICTIONARY: num_rows indices into values. */
   int32_t base_size;      /* DICTIONARY: number of base values; else 0. */
   int32_t mem;            /* vx355_mem of values / nulls / indices. VX355_MEM_DEVICE buffers must
-                             be complete when the call is made: the library works on its own
-                             HIP stream and does not order itself behind the producer's. */
+                             be complete when the library's kernels read them: either they
+                             are complete when the call is made, or the consuming context
+                             was told to wait for the producer (vx355_stream_wait_event). */
 } vx355_column;
 
 /* RowVector (vector/ComplexVector.h) reduced to its decoded children. */
@@ -102,9 +105,28 @@ typedef struct vx355_out_column {
 
 /* ---- runtime ----------------------------------------------------------- */
 
-/* Binds the calling process to one GPU and creates the library stream and
- * HBM arena. Idempotent for the same device. */
+/* Prepares one GPU for use by this process: HBM block cache, pinned-buffer
+ * cache and the device's default execution context (one HIP stream + one pinned
+ * mailbox). May be called for several devices: ONE process can drive all the
+ * GPUs of a node; the first device initialised is the
+ * process default, and the calling thread is bound to the device it just
+ * initialised. Idempotent.
+ *
+ * Threading (exec/Driver.cpp:538, SURVEY.md section 8(b) "Threading"): there is
+ * no library-wide lock. Every operator handle (vx355_agg, vx355_join_build,
+ * vx355_join_probe) owns its own execution context — created on the calling
+ * thread's device by *_create — so operators of different Drivers run
+ * concurrently on different streams; one handle must not be used by two
+ * threads at once (a Driver never does). Handle-less entry points (the
+ * standalone kernels, memcpy helpers, join-table filter queries) run on the
+ * default context of the calling thread's device and serialise on it. When an
+ * entry point returns, everything it queued on its stream has completed. */
 int vx355_init(int device);
+/* Binds the calling thread to an initialised device: handles created afterwards
+ * and handle-less calls use it. Threads that never call it use the process
+ * default device. */
+int vx355_set_device(int device);
+int vx355_current_device(void); /* -1 before vx355_init */
 void vx355_shutdown(void);
 int vx355_abi_version(void);
 int vx355_device_count(void);
@@ -117,7 +139,20 @@ void vx355_device_free(void* p);
 int vx355_memcpy_h2d(void* dst, const void* src, size_t bytes);
 int vx355_memcpy_d2h(void* dst, const void* src, size_t bytes);
 int vx355_memset_d(void* dst, int value, size_t bytes);
+/* Waits for every context (default + operator handles) of the calling thread's device. */
 int vx355_synchronize(void);
+
+/* Stream handshake with the producer of device-resident inputs. VX355_MEM_DEVICE
+ * buffers must be complete before the library's kernels read them; instead of
+ * synchronising the device the caller records a hipEvent_t on its own stream
+ * after the producing kernel and makes the consuming context wait for it:
+ *   hipEventRecord(ev, producer_stream);
+ *   vx355_stream_wait_event(vx355_agg_stream(op), ev);   // or any *_stream()
+ *   vx355_agg_add_input(op, &device_batch);
+ * 'stream' is a hipStream_t returned by vx355_default_stream() / *_stream(),
+ * 'event' a hipEvent_t (both passed as void* to keep HIP types out of the ABI). */
+int vx355_stream_wait_event(void* stream, void* event);
+void* vx355_default_stream(void); /* default context of the calling thread's device */
 
 /* Per-kernel timing with HIP events on the library's own stream. While
  * enabled every launch of a profiled kernel is bracketed by two events;
@@ -389,6 +424,8 @@ typedef struct vx355_agg_stats {
 } vx355_agg_stats;
 int vx355_agg_get_stats(const vx355_agg* h, vx355_agg_stats* out);
 void vx355_agg_destroy(vx355_agg* h);
+/* hipStream_t of the operator's execution context (see vx355_stream_wait_event). */
+void* vx355_agg_stream(vx355_agg* h);
 
 /* ---- HashBuild / HashProbe (exec/HashBuild.h, exec/HashProbe.h) --------- */
 
@@ -442,6 +479,7 @@ int vx355_join_build_finish(
     int32_t num_others,
     vx355_join_table** out);
 void vx355_join_build_destroy(vx355_join_build* h);
+void* vx355_join_build_stream(vx355_join_build* h);
 
 /* HashJoinBridge::setHashTable / tableOrFuture (exec/HashJoinBridge.h:57,116)
  * hand a shared_ptr; here: explicit reference counting. */
@@ -551,6 +589,7 @@ int vx355_join_probe_get_build_side_output(
     int32_t* n_out,
     int32_t* finished);
 void vx355_join_probe_destroy(vx355_join_probe* h);
+void* vx355_join_probe_stream(vx355_join_probe* h);
 
 #ifdef __cplusplus
 }

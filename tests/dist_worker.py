@@ -18,18 +18,22 @@ def shard(rank, n=20000):
     qty = rng.integers(1, 51, n).astype(np.float64)
     price = rng.integers(0, 1 << 20, n).astype(np.float64) / 64
     valid = rng.random(n) > 0.1
-    return flags, status, qty, price, valid
+    # integers far above 2^53: the N > 1 merge must keep every bit (sum / min / max of BIGINT)
+    big = rng.integers(1 << 54, 1 << 56, n).astype(np.int64) * rng.choice([-1, 1], n)
+    return flags, status, qty, price, valid, big
 
 
 def raw_aggs(abi):
     return [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_AVG, 3, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT),
-            (abi.AGG_MIN, 3, abi.DOUBLE), (abi.AGG_COUNT, 3, abi.DOUBLE), (abi.AGG_MAX, 2, abi.DOUBLE)]
+            (abi.AGG_MIN, 3, abi.DOUBLE), (abi.AGG_COUNT, 3, abi.DOUBLE), (abi.AGG_MAX, 2, abi.DOUBLE),
+            (abi.AGG_SUM, 4, abi.BIGINT), (abi.AGG_MIN, 4, abi.BIGINT), (abi.AGG_MAX, 4, abi.BIGINT)]
 
 
 def batch_for(abi, rank):
-    flags, status, qty, price, valid = shard(rank)
+    flags, status, qty, price, valid, big = shard(rank)
     return abi.HostBatch([abi.HostColumn(abi.VARCHAR, flags), abi.HostColumn(abi.VARCHAR, status),
-                          abi.HostColumn(abi.DOUBLE, qty), abi.HostColumn(abi.DOUBLE, price, valid)])
+                          abi.HostColumn(abi.DOUBLE, qty), abi.HostColumn(abi.DOUBLE, price, valid),
+                          abi.HostColumn(abi.BIGINT, big)])
 
 
 def run(rank, world, port, out_dir):
@@ -46,10 +50,10 @@ def run(rank, world, port, out_dir):
     part = oracle_lib.collect_output(op, 4096)
     merged = vdist.merge_partials(oracle_lib, dist, torch, part, key_types, raw_aggs(abi), None)
     # every rank holds the same final result
-    np.save(os.path.join(out_dir, f"rank{rank}.npy"),
-            np.array([[float(v) if not isinstance(v, bytes) else float(v[0]) for v in col[0]]
-                      for col in merged], dtype=np.float64))
-    np.save(os.path.join(out_dir, f"rank{rank}_valid.npy"), np.array([col[1] for col in merged]))
+    import pickle
+    with open(os.path.join(out_dir, f"rank{rank}.pkl"), "wb") as f:
+        pickle.dump([(np.asarray(col[0]).tolist() if not isinstance(col[0], list) else list(col[0]),
+                      np.asarray(col[1]).tolist()) for col in merged], f)
     dist.barrier()
     dist.destroy_process_group()
 

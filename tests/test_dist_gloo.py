@@ -35,30 +35,40 @@ def test_two_rank_partial_final_matches_single_process(oracle, tmp_path):
         single.add_input(dist_worker.batch_for(abi, r))
     single.no_more_input()
     exp = oracle.collect_output(single, 4096)
-    exp_vals = np.array([[float(v) if not isinstance(v, bytes) else float(v[0]) for v in col[0]]
-                         for col in exp], dtype=np.float64)
-    exp_valid = np.array([col[1] for col in exp])
+    import pickle
     for r in range(world):
-        got = np.load(os.path.join(tmp_path, f"rank{r}.npy"))
-        valid = np.load(os.path.join(tmp_path, f"rank{r}_valid.npy"))
-        assert got.shape == exp_vals.shape
-        assert (valid == exp_valid).all()
-        assert (got[exp_valid] == exp_vals[exp_valid]).all()   # dyadic inputs: bit-exact
+        with open(os.path.join(tmp_path, f"rank{r}.pkl"), "rb") as f:
+            got = pickle.load(f)
+        assert len(got) == len(exp)
+        for (gv, gvalid), (ev, evalid) in zip(got, exp):
+            evalid = np.asarray(evalid).tolist()
+            assert gvalid == evalid
+            ev = list(ev) if isinstance(ev, list) else np.asarray(ev).tolist()
+            # dyadic doubles and integers (beyond 2^53 included): every bit must survive the merge
+            assert [g for g, ok in zip(gv, evalid) if ok] == [e for e, ok in zip(ev, evalid) if ok]
 
 
 def test_gather_encoding_round_trip():
     from velox_amd import dist as vdist
-    cols = [([b"A", b"", b"RETURN", None], np.array([True, True, True, False])),
-            (np.array([1.5, -2.0, 0.0, 7.0]), np.array([True, False, True, True])),
-            (np.array([3, 0, 2 ** 40, -5], dtype=np.int64), np.array([True, True, True, True]))]
-    kinds = [abi.VARCHAR, abi.DOUBLE, abi.BIGINT]
+    i64 = np.iinfo(np.int64)
+    cols = [([b"A", b"", b"RETURN", None, b"twelve bytes", b"12345678"], np.array([True, True, True, False, True, True])),
+            (np.array([1.5, -2.0, 0.0, 7.0, np.nextafter(1.0, 2.0), -0.0]), np.array([True, False, True, True, True, True])),
+            (np.array([3, 0, 2 ** 40, -5, i64.max, i64.min], dtype=np.int64), np.ones(6, dtype=bool)),
+            (np.array([2 ** 53 + 1, -(2 ** 53) - 1, 2 ** 62 + 12345, 1, 2, 3], dtype=np.int64), np.ones(6, dtype=bool)),
+            (np.array([1.25, 3.0, -1.0, 0.5, 2.0 ** -20, 1e30], dtype=np.float32), np.ones(6, dtype=bool))]
+    kinds = [abi.VARCHAR, abi.DOUBLE, abi.BIGINT, abi.BIGINT, abi.REAL]
     batch = vdist.decode_partials(vdist.encode_partial(cols, kinds), kinds)
-    assert batch.num_rows == 4
+    assert batch.num_rows == 6
     from velox_amd.abi import view_to_bytes
-    back = [view_to_bytes(batch.columns[0].values[i]) for i in range(3)]
-    assert back == [b"A", b"", b"RETURN"] and not batch.columns[0].valid[3]
-    assert (batch.columns[1].values == cols[1][0]).all() and (batch.columns[1].valid == cols[1][1]).all()
-    assert (batch.columns[2].values == cols[2][0]).all()
+    back = [view_to_bytes(batch.columns[0].values[i]) for i in (0, 1, 2, 4, 5)]
+    assert back == [b"A", b"", b"RETURN", b"twelve bytes", b"12345678"] and not batch.columns[0].valid[3]
+    assert (batch.columns[1].values.view(np.int64) == cols[1][0].view(np.int64)).all()   # -0.0 and 1 + ulp included
+    assert (batch.columns[1].valid == cols[1][1]).all()
+    assert (batch.columns[2].values == cols[2][0]).all()   # INT64 min / max
+    assert (batch.columns[3].values == cols[3][0]).all()   # beyond 2^53: no float64 detour
+    assert (batch.columns[4].values == cols[4][0]).all()
+    with pytest.raises(ValueError):
+        vdist.encode_partial([([b"thirteen bytes"], np.array([True]))], [abi.VARCHAR])
 
 
 import pytest

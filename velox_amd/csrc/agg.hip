@@ -414,6 +414,22 @@ __device__ inline void updateGlobalWave(const AggArgs& a, int64_t row, uint64_t 
         uint64_t v = 0;
         const bool has = member && accInput(a, acc, row, &v);
         const uint64_t any = ballot(has);
+        if (acc.kind == ACC_SUM_F64 && acc.splitM != 0.0) {
+          // Grid multiples add up exactly in any order; the remainders are tiny.
+          double hi = 0.0, lo = 0.0;
+          if (has) {
+            splitDouble(__longlong_as_double(static_cast<long long>(v)), acc.splitM, &hi, &lo);
+          }
+          const uint64_t totalHi =
+              waveCombine(ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(hi)), has, a.counters);
+          const uint64_t totalLo =
+              waveCombine(ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(lo)), has, a.counters);
+          if (any != 0 && lane() == leader) {
+            applyGlobal(g + acc.off, ACC_SUM_F64, totalHi, a.counters);
+            applyGlobal(g + acc.off + 1, ACC_SUM_F64, totalLo, a.counters);
+          }
+          continue;
+        }
         const uint64_t total = waveCombine(acc.kind, v, has, a.counters);
         if (any != 0 && lane() == leader) {
           applyGlobal(g + acc.off, acc.kind, total, a.counters);
@@ -951,9 +967,16 @@ struct RadixAggArgs {
   int32_t valIdx[kRadixMaxAccs];
   int32_t accOfVal[kRadixMaxAccs];
   uint64_t sliceRecs;          // records one workgroup folds at a time (see k_rp_aggregate)
+  // LDS / table words of the fold: a DOUBLE sum owns two (hi on the grid, lo the
+  // exact remainder: same split as every other aggregation kernel).
+  int32_t numWords;
+  int32_t ldsIdx[kRadixMaxAccs];            // first LDS word of accumulator j
+  int32_t wordKind[2 * kRadixMaxAccs];
+  int32_t wordOff[2 * kRadixMaxAccs];       // word offset inside the group row
+  double splitM[kRadixMaxAccs];
 };
 
-// LDS state of one fold: acc[B][A] + first[B].
+// LDS state of one fold: acc[B][A] + first[B], A = LDS words per group.
 struct RpFold {
   uint64_t* acc;
   uint32_t* first;
@@ -963,7 +986,7 @@ struct RpFold {
 
 __device__ inline void rpFoldInit(const RpFold& f, const RadixAggArgs& r) {
   for (int i = threadIdx.x; i < f.B * f.A; i += blockDim.x) {
-    f.acc[i] = accIdentity(r.kind[i % f.A]);
+    f.acc[i] = accIdentity(r.wordKind[i % f.A]);
   }
   for (int i = threadIdx.x; i < f.B; i += blockDim.x) {
     f.first[i] = 0xffffffffu;
@@ -1001,12 +1024,20 @@ __device__ inline void rpFoldRecords(const RpFold& f, const RadixAggArgs& r, uin
       for (int q = 1; q < W; ++q) {
         const int j = r.accOfVal[q - 1];
         if ((mask >> j) & 1) {
-          applyLds(f.acc + static_cast<size_t>(g) * A + j, r.kind[j], w[u][q], r.counters);
+          uint64_t* word = f.acc + static_cast<size_t>(g) * A + r.ldsIdx[j];
+          if (r.kind[j] == ACC_SUM_F64 && r.splitM[j] != 0.0) {
+            double hi, lo;
+            splitDouble(__longlong_as_double(static_cast<long long>(w[u][q])), r.splitM[j], &hi, &lo);
+            applyLds(word, ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(hi)), r.counters);
+            applyLds(word + 1, ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(lo)), r.counters);
+          } else {
+            applyLds(word, r.kind[j], w[u][q], r.counters);
+          }
         }
       }
-      for (int j = 0; j < A; ++j) {
+      for (int j = 0; j < r.numAccs; ++j) {
         if (r.valIdx[j] < 0 && ((mask >> j) & 1)) {
-          applyLds(f.acc + static_cast<size_t>(g) * A + j, r.kind[j], 1ULL, r.counters);
+          applyLds(f.acc + static_cast<size_t>(g) * A + r.ldsIdx[j], r.kind[j], 1ULL, r.counters);
         }
       }
     }
@@ -1036,8 +1067,9 @@ __device__ inline void rpFoldFlush(const RpFold& f, const RadixAggArgs& r, int64
       }
       for (int j = 0; j < A; ++j) {
         const uint64_t v = f.acc[static_cast<size_t>(g) * A + j];
-        if (v != accIdentity(r.kind[j]) || r.kind[j] == ACC_SUM_F64) {
-          applyGlobal(row + r.off[j], r.kind[j] == ACC_COUNT ? ACC_SUM_I64_WRAP : r.kind[j], v, r.counters);
+        const int32_t kind = r.wordKind[j];
+        if (v != accIdentity(kind)) {
+          applyGlobal(row + r.wordOff[j], kind == ACC_COUNT ? ACC_SUM_I64_WRAP : kind, v, r.counters);
         }
       }
       continue;
@@ -1051,8 +1083,8 @@ __device__ inline void rpFoldFlush(const RpFold& f, const RadixAggArgs& r, int64
     }
     for (int j = 0; j < A; ++j) {
       const uint64_t v = f.acc[static_cast<size_t>(g) * A + j];
-      uint64_t* word = row + r.off[j];
-      switch (r.kind[j]) {
+      uint64_t* word = row + r.wordOff[j];
+      switch (r.wordKind[j]) {
         case ACC_SUM_F64:
           *reinterpret_cast<double*>(word) += __longlong_as_double(static_cast<long long>(v));
           break;
@@ -1101,7 +1133,7 @@ __global__ __launch_bounds__(512) void k_rp_aggregate(RadixAggArgs r) {
   __shared__ uint32_t bigCount;
   RpFold f;
   f.B = 1 << r.shiftB;
-  f.A = r.numAccs;
+  f.A = r.numWords;
   f.acc = reinterpret_cast<uint64_t*>(ldsRaw);                                       // [B][A]
   f.first = reinterpret_cast<uint32_t*>(f.acc + static_cast<size_t>(f.B) * f.A);   // [B]
   for (int64_t p = blockIdx.x; p < r.numParts; p += gridDim.x) {
@@ -1756,6 +1788,9 @@ __device__ inline void storeTyped(void* values, int32_t kind, int32_t pos, int64
 // and bit-packed BOOLEAN values are assembled with ballots.
 __global__ __launch_bounds__(256) void k_extract(ExtractArgs a) {
   const int32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos - static_cast<int32_t>(lane()) >= a.count) {
+    return;  // whole wave past the end: its bitmap word lies outside ceil(count / 64) words
+  }
   const bool active = pos < a.count;
   uint64_t gi = 0;
   if (active) {
@@ -1962,6 +1997,7 @@ constexpr int64_t kMaxRangeSpan = (1LL << 59) - 1;  // exec/VectorHasher.h:139 k
 using namespace vx;
 
 struct vx355_agg {
+  vx::Runtime* ctx = nullptr;  // this operator's execution context (stream, mailbox)
   int32_t step;
   bool ignoreNullKeys;
   std::vector<KeyState> keys;
@@ -2014,6 +2050,7 @@ struct vx355_agg {
   int64_t jitLaunches = 0;
   bool jitEnabled = true;
   bool exactSums = true;
+  bool sumGridsChosen = false;
   bool logShapes = false;
   int64_t deferCap = 1 << 20;
   int fastUnroll = 4;
@@ -2576,6 +2613,7 @@ struct JitKernel {
 };
 
 struct JitState {
+  std::mutex mutex;
   std::map<std::string, JitKernel> kernels;
   bool disabled = false;
   std::string csrcDir;
@@ -2615,6 +2653,7 @@ bool jitPrepare(JitState& st) {
 
 hipFunction_t jitFastKernel(const FastSignature& sig, int unroll, bool log) {
   JitState& st = jitState();
+  std::lock_guard<std::mutex> lock(st.mutex);  // operators on several Driver threads share the cache
   if (st.disabled || !jitPrepare(st)) {
     return nullptr;
   }
@@ -2622,7 +2661,9 @@ hipFunction_t jitFastKernel(const FastSignature& sig, int unroll, bool log) {
   snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d,%lluull,%lluull,%uu", unroll, sig.k0, sig.k1, sig.t0, sig.t1,
            sig.numLoads, sig.numAccs, static_cast<unsigned long long>(sig.accLo),
            static_cast<unsigned long long>(sig.accHi), sig.ind);
-  auto it = st.kernels.find(key);
+  // A loaded module belongs to one GPU.
+  const std::string cacheKey = std::to_string(Runtime::get().device) + ":" + key;
+  auto it = st.kernels.find(cacheKey);
   if (it != st.kernels.end()) {
     return it->second.fn;
   }
@@ -2669,7 +2710,7 @@ hipFunction_t jitFastKernel(const FastSignature& sig, int unroll, bool log) {
     }
     k = JitKernel{};
   }
-  st.kernels[key] = k;  // failures are cached too: one attempt per shape
+  st.kernels[cacheKey] = k;  // failures are cached too: one attempt per shape
   return k.fn;
 }
 
@@ -2807,7 +2848,16 @@ int log2Ceil(uint64_t v) {
 
 // Groups per partition of the radix path: B x (accumulators x 8 + 4) bytes of
 // LDS per workgroup, two workgroups per CU.
-int radixShiftB(int numAccs) { return numAccs <= 1 ? 12 : 11; }
+int radixShiftB(int numWords) { return numWords <= 1 ? 12 : (numWords <= 4 ? 11 : 10); }
+
+// LDS words per group of the fold: a DOUBLE sum owns two (hi, lo).
+int radixWords(const AggArgs& a) {
+  int n = 0;
+  for (int j = 0; j < a.numAccs; ++j) {
+    n += a.accs[j].kind == ACC_SUM_F64 ? 2 : 1;
+  }
+  return n;
+}
 
 bool radixEligible(const vx355_agg& h, const AggArgs& a) {
   if (h.radixMinRows < 0 || a.mode != MODE_ARRAY || a.rowList || a.rescanOld || a.numAccs < 1 ||
@@ -2815,7 +2865,8 @@ bool radixEligible(const vx355_agg& h, const AggArgs& a) {
       a.capacity > (1ULL << kRadixKeyBits)) {
     return false;
   }
-  const uint64_t parts = (a.capacity + (1ULL << radixShiftB(a.numAccs)) - 1) >> radixShiftB(a.numAccs);
+  const int shiftB = radixShiftB(radixWords(a));
+  const uint64_t parts = (a.capacity + (1ULL << shiftB) - 1) >> shiftB;
   // Worth it when rows outnumber partitions by far and two levels reach every partition.
   return parts >= 2 && parts <= static_cast<uint64_t>(h.radixMaxBins) * kRadixMaxBins &&
       static_cast<uint64_t>(a.numRows) >= parts * 1024;
@@ -2827,11 +2878,8 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
   auto& rt = Runtime::get();
   const int64_t n = a.numRows;
   RadixArgs r{};
-  for (int j = 0; j < a.numAccs; ++j) {
-    a.accs[j].splitM = 0;
-  }
   r.a = a;
-  r.shiftB = radixShiftB(a.numAccs);
+  r.shiftB = radixShiftB(radixWords(a));
   const uint64_t parts = (a.capacity + (1ULL << r.shiftB) - 1) >> r.shiftB;
   // One level while the fan-out fits the LDS cursors (measured: 2400 bins in one
   // pass beat 64 x 64 in two); otherwise two balanced levels.
@@ -2978,8 +3026,18 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
     g.off[j] = a.accs[j].off;
     g.valIdx[j] = r.valIdx[j];
     g.accOfVal[j] = r.accOfVal[j];
+    g.splitM[j] = a.accs[j].splitM;
+    g.ldsIdx[j] = g.numWords;
+    g.wordKind[g.numWords] = a.accs[j].kind;
+    g.wordOff[g.numWords] = a.accs[j].off;
+    ++g.numWords;
+    if (a.accs[j].kind == ACC_SUM_F64) {
+      g.wordKind[g.numWords] = ACC_SUM_F64;
+      g.wordOff[g.numWords] = a.accs[j].off + 1;
+      ++g.numWords;
+    }
   }
-  const size_t ldsBytes = (static_cast<size_t>(1) << r.shiftB) * (a.numAccs * 8 + 4);
+  const size_t ldsBytes = (static_cast<size_t>(1) << r.shiftB) * (g.numWords * 8 + 4);
   // Few partitions or skewed keys: slices keep every CU busy.
   g.sliceRecs = static_cast<uint64_t>(std::max<int64_t>(1 << 16, ceilDiv(n, 2048)));
   if (const char* e = std::getenv("VX355_AGG_RADIX_SLICE")) {
@@ -3057,11 +3115,8 @@ void launchChunk(vx355_agg& h, AggArgs& a) {
       launchRadix(h, a);
       return;
     }
-    // One HBM atomic per sum and row is the budget of the high-cardinality
-    // path: no hi/lo split there (few rows per group: little to gain).
-    for (int j = 0; j < a.numAccs; ++j) {
-      a.accs[j].splitM = 0;
-    }
+    // DOUBLE sums keep their hi/lo split here too (two HBM atomics per sum and
+    // row): the <= 1 ULP bound must not depend on which kernel a chunk takes.
     VX_LAUNCH("k_agg_global", k_agg_global, streamGrid(a.numRows, 256), 256, 0, a);
   }
 }
@@ -3180,9 +3235,6 @@ void runGeneric(vx355_agg& h, const AggArgs& base, int64_t count, uint64_t rowBa
   ga.a = base;
   ga.skipInside = skipInside ? 1 : 0;
   AggArgs& c = ga.a;
-  for (int j = 0; j < c.numAccs; ++j) {
-    c.accs[j].splitM = 0;
-  }
   c.numRows = count;
   c.rowList = rowList;
   c.rescanOld = nullptr;
@@ -3278,6 +3330,47 @@ void switchToGeneric(vx355_agg& h) {
   ensureGenericCapacity(h, live);  // builds the slot array from the stored hashes
 }
 
+// Grid of the hi/lo split of every DOUBLE sum, chosen once per operator from the
+// largest magnitude in a prefix of the first batch: values < 2^L, grid 2^(L-21),
+// so up to 2^32 grid multiples add up exactly in the 53-bit significand of 'hi'
+// whatever kernel, lane, workgroup or GPU adds them. A later value above 2^L is
+// accumulated plainly (splitDouble): it only costs accuracy, never correctness.
+void chooseSumGrids(vx355_agg& h, AggArgs& a, int64_t n) {
+  if (h.sumGridsChosen || !h.exactSums) {
+    return;
+  }
+  h.sumGridsChosen = true;
+  bool any = false;
+  for (int j = 0; j < a.numAccs; ++j) {
+    any = any || a.accs[j].kind == ACC_SUM_F64;
+  }
+  if (!any) {
+    return;
+  }
+  AggArgs sa = a;
+  sa.numRows = std::min<int64_t>(n, 1 << 16);
+  resetCounters(h);
+  VX_LAUNCH("k_sum_stats", k_sum_stats, streamGrid(sa.numRows, 256), 256, 0, sa);
+  Counters c = readCounters(h);
+  for (int j = 0; j < a.numAccs; ++j) {
+    if (a.accs[j].kind != ACC_SUM_F64) {
+      continue;
+    }
+    const uint64_t bits = c.sumMax[j];
+    const int biased = static_cast<int>((bits >> 52) & 0x7ff);
+    double m = 0;
+    if (bits != 0 && biased != 0 && biased != 0x7ff) {
+      const int L = (biased - 1023) + 1 + 4;
+      const int G = L - 21;
+      if (G + 52 < 1000 && G + 52 > -1000) {
+        m = std::ldexp(1.5, G + 52);
+      }
+    }
+    h.phys[a.accs[j].off - 2].splitM = m;
+    a.accs[j].splitM = m;
+  }
+}
+
 void addInput(vx355_agg& h, const vx355_batch* batch);
 
 void flushPending(vx355_agg& h) {
@@ -3324,6 +3417,7 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
   a.stride = h.stride;
   a.counters = h.counters();
 
+  chooseSumGrids(h, a, n);
   if (h.generic) {
     addInputGeneric(h, a, n);
     h.inputRows += n;
@@ -3351,34 +3445,6 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
       c.unmappable = 0;
       checkCounters(c);
       mergeObserved(h, c);
-    }
-    if (!needGeneric && h.exactSums) {
-      // Grid of the hi/lo split of every DOUBLE sum, from the largest magnitude
-      // in the analysed prefix: values < 2^L, grid 2^(L-21), so up to 2^32 grid
-      // multiples add up exactly in the 53-bit significand of 'hi'. A later
-      // value above 2^L only costs accuracy, never correctness.
-      AggArgs sa = a;
-      sa.numRows = std::min<int64_t>(n, 1 << 16);
-      resetCounters(h);
-      VX_LAUNCH("k_sum_stats", k_sum_stats, streamGrid(sa.numRows, 256), 256, 0, sa);
-      Counters c = readCounters(h);
-      for (int j = 0; j < a.numAccs; ++j) {
-        if (a.accs[j].kind != ACC_SUM_F64) {
-          continue;
-        }
-        const uint64_t bits = c.sumMax[j];
-        const int biased = static_cast<int>((bits >> 52) & 0x7ff);
-        double m = 0;
-        if (bits != 0 && biased != 0 && biased != 0x7ff) {
-          const int L = (biased - 1023) + 1 + 4;
-          const int G = L - 21;
-          if (G + 52 < 1000 && G + 52 > -1000) {
-            m = std::ldexp(1.5, G + 52);
-          }
-        }
-        h.phys[a.accs[j].off - 2].splitM = m;
-        a.accs[j].splitM = m;
-      }
     }
     if (!needGeneric) {
       try {
@@ -3754,13 +3820,14 @@ int vx355_agg_create(const vx355_agg_spec* spec, vx355_agg** out) {
     h->chunkRows = std::max<int64_t>(64, std::strtoll(e, nullptr, 10) & ~63LL);
   }
   buildPlan(*h, *spec);
+  h->ctx = Runtime::createContext();  // the operator's own stream + mailbox
   *out = h.release();
   VX_API_END
 }
 
 int vx355_agg_set_fused_input(vx355_agg* h, const vx355_filter_term* terms, int32_t n_terms,
                               const vx355_projection* projections, int32_t n_projections) {
-  VX_API_BEGIN
+  VX_API_BEGIN_CTX(VX_CTX_OF(h))
   VX_CHECK_ARG(h, "NULL argument");
   VX_CHECK_ARG(h->inputRows == 0 && !h->tableReady, "set_fused_input after the first add_input");
   VX_CHECK_ARG(n_terms >= 0 && n_terms <= kMaxTerms && (n_terms == 0 || terms), "0..4 filter terms");
@@ -3786,7 +3853,7 @@ int vx355_agg_set_fused_input(vx355_agg* h, const vx355_filter_term* terms, int3
 }
 
 int vx355_agg_add_input(vx355_agg* h, const vx355_batch* batch) {
-  VX_API_BEGIN
+  VX_API_BEGIN_CTX(VX_CTX_OF(h))
   Runtime::get().requireInit();
   VX_CHECK_ARG(h && batch, "NULL argument");
   VX_CHECK_ARG(!h->noMoreInput, "addInput after noMoreInput");
@@ -3798,7 +3865,7 @@ int vx355_agg_add_input(vx355_agg* h, const vx355_batch* batch) {
 }
 
 int vx355_agg_no_more_input(vx355_agg* h) {
-  VX_API_BEGIN
+  VX_API_BEGIN_CTX(VX_CTX_OF(h))
   VX_CHECK_ARG(h, "NULL argument");
   Runtime::get().requireInit();
   flushPending(*h);
@@ -3820,7 +3887,7 @@ int vx355_agg_output_types(const vx355_agg* h, int32_t* types, int32_t cap, int3
 
 int vx355_agg_get_output(vx355_agg* h, vx355_out_column* cols, int32_t num_cols, int32_t max_rows,
                          int32_t* n_out, int32_t* finished) {
-  VX_API_BEGIN
+  VX_API_BEGIN_CTX(VX_CTX_OF(h))
   Runtime::get().requireInit();
   VX_CHECK_ARG(h, "NULL argument");
   getOutput(*h, cols, num_cols, max_rows, n_out, finished);
@@ -3841,9 +3908,19 @@ int vx355_agg_get_stats(const vx355_agg* h, vx355_agg_stats* out) {
   VX_API_END
 }
 
+void* vx355_agg_stream(vx355_agg* h) { return h ? static_cast<void*>(h->ctx->stream) : nullptr; }
+
 void vx355_agg_destroy(vx355_agg* h) {
-  std::lock_guard<std::recursive_mutex> lock(vx::apiMutex());
-  delete h;
+  if (!h) {
+    return;
+  }
+  Runtime* ctx = h->ctx;
+  try {
+    vx::ContextScope scope(ctx);  // the handle's buffers are released under its own context
+    delete h;
+  } catch (...) {
+  }
+  Runtime::destroyContext(ctx);
 }
 
 }  // extern "C"

@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -45,12 +46,12 @@ void hipFail(hipError_t e, const char* what, const char* file, int line);
   } while (0)
 
 // Every extern "C" entry point is wrapped: no exception crosses the ABI
-// (include/vx355.h "Errors").
-std::recursive_mutex& apiMutex();
-#define VX_API_BEGIN                                              \
-  std::lock_guard<std::recursive_mutex> apiLock__(::vx::apiMutex()); \
-  try {
-#define VX_API_END                                   \
+// (include/vx355.h "Errors"). There is no library-wide lock: an entry point
+// runs in an execution context (struct Runtime below: one HIP stream + one
+// pinned mailbox on one GPU). Operator handles own their context
+// (VX_API_BEGIN_CTX), handle-less calls use the default context of the calling
+// thread's device and serialise on its mutex (VX_API_BEGIN).
+#define VX_API_CATCH                                 \
   return VX355_OK;                                   \
   }                                                  \
   catch (const ::vx::Error& e) {                     \
@@ -65,6 +66,18 @@ std::recursive_mutex& apiMutex();
     ::vx::setLastError(e.what());                    \
     return VX355_EINTERNAL;                          \
   }
+#define VX_API_BEGIN \
+  try {              \
+    ::vx::ContextScope ctxScope__(nullptr);
+#define VX_API_BEGIN_CTX(ctx) \
+  try {                       \
+    ::vx::ContextScope ctxScope__(ctx);
+// Default context of one device (join-table functions: the table knows its device).
+#define VX_API_BEGIN_DEV(device) \
+  try {                          \
+    ::vx::ContextScope ctxScope__(::vx::Runtime::defaultContext(device));
+#define VX_API_END VX_API_CATCH
+#define VX_CTX_OF(h) ((h) ? (h)->ctx : nullptr)
 
 // Mailbox: pinned host memory the kernels write small results into (counts,
 // flags, stats) so the host reads them after a stream sync without a D2H copy.
@@ -76,48 +89,113 @@ struct Mailbox {
 
 struct ProfileEntry {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  std::map<uint64_t, hipEvent_t> open;  // begin event of the launch in flight, per context
   double doneMs = 0;
   int64_t launches = 0;
 };
 
+// Per-GPU state shared by every context on that device: the HBM block cache,
+// the pinned-block cache and the profiler, each behind its own mutex.
+struct Runtime;
+struct CachedBlock {
+  void* p;
+  uint64_t ownerCtx;   // context whose stream may still touch the block (0 = nobody)
+  uint64_t ownerCall;  // that context's call number when the block was released
+};
+struct DeviceState {
+  int device = -1;
+  bool alive = false;
+  int numCUs = 256;
+  size_t ldsPerBlock = 65536;
+  size_t totalMem = 0;
+  Runtime* defaultCtx = nullptr;
+
+  std::mutex memMutex;
+  // HBM block cache: operators are created and destroyed per query; their
+  // tables and scratch buffers are recycled instead of going through
+  // hipMalloc/hipFree (which synchronise the device).
+  std::multimap<size_t, CachedBlock> freeBlocks;
+  size_t cachedBytes = 0;
+  size_t cacheLimit = 16ULL << 30;
+  // Pinned host blocks (power-of-two sizes >= 64 KB): hipHostMalloc costs ~0.3 ms a
+  // call, so released blocks are kept (up to pinnedLimit bytes) for the next operator.
+  std::multimap<size_t, void*> freePinned;
+  size_t cachedPinned = 0;
+  size_t pinnedLimit = 2ULL << 30;
+  // live contexts by id: a cached block released by a context whose call is still in
+  // flight is only handed to another context after that stream has drained
+  std::map<uint64_t, Runtime*> contexts;
+
+  std::mutex profMutex;
+  bool profile = false;
+  std::map<std::string, ProfileEntry> prof;
+  std::vector<hipEvent_t> freeEvents;
+
+  void* allocBlock(size_t bytes, size_t* actual);
+  void freeBlock(void* p, size_t bytes);
+  void trimCache();
+  char* allocPinned(size_t bytes, size_t* actual);
+  void releasePinned(char* p, size_t bytes);
+};
+
+// An execution context: one HIP stream and one pinned mailbox on one GPU. Every
+// operator handle owns one (handles are single threaded, exec/Driver.cpp:538, so
+// a context is never used by two threads at once); every device has a default
+// one for handle-less entry points, guarded by callMutex.
 struct Runtime {
+  DeviceState* ds = nullptr;
   bool initialized = false;
   int device = -1;
   hipStream_t stream = nullptr;
   int numCUs = 256;
   size_t ldsPerBlock = 65536;
   Mailbox mail;
-  bool profile = false;
-  std::map<std::string, ProfileEntry> prof;
-  std::vector<hipEvent_t> freeEvents;
+  uint64_t id = 0;
+  uint64_t currentCall = 1;          // number of the API call in flight (or the next one)
+  std::atomic<uint64_t> doneCalls{0};  // calls that have returned (their stream work is complete)
+  std::recursive_mutex callMutex;    // default contexts only
+  bool isDefault = false;
+  bool& profile;                     // = ds->profile
 
-  // HBM block cache: operators are created and destroyed per query; their
-  // tables and scratch buffers are recycled instead of going through
-  // hipMalloc/hipFree (which synchronise the device).
-  std::multimap<size_t, void*> freeBlocks;
-  size_t cachedBytes = 0;
-  size_t cacheLimit = 16ULL << 30;
-  void* allocBlock(size_t bytes, size_t* actual);
-  void freeBlock(void* p, size_t bytes);
-  void trimCache();
-  // Pinned host blocks (power-of-two sizes >= 64 KB): hipHostMalloc costs ~0.3 ms a
-  // call, so released blocks are kept (up to pinnedLimit bytes) for the next operator.
-  std::multimap<size_t, void*> freePinned;
-  size_t cachedPinned = 0;
-  size_t pinnedLimit = 2ULL << 30;
-  char* allocPinned(size_t bytes, size_t* actual);
-  void releasePinned(char* p, size_t bytes);
+  explicit Runtime(DeviceState* d) : ds(d), profile(d->profile) {}
 
+  // The context of the calling thread: set by the entry point (ContextScope).
   static Runtime& get();
+  static Runtime* tryGet();
+  static Runtime* defaultContext(int device);  // device < 0: the calling thread's device
+  static Runtime* createContext();             // on the calling thread's device
+  static void destroyContext(Runtime* ctx);
+
   void requireInit() const {
     if (!initialized) {
       VX_THROW(VX355_EINVAL, "vx355_init has not been called");
     }
   }
   void sync() { HIP_OK(hipStreamSynchronize(stream)); }
+  void* allocBlock(size_t bytes, size_t* actual) { return ds->allocBlock(bytes, actual); }
+  char* allocPinned(size_t bytes, size_t* actual) { return ds->allocPinned(bytes, actual); }
+  void releasePinned(char* p, size_t bytes) { ds->releasePinned(p, bytes); }
   hipEvent_t newEvent();
   void profBegin(const char* name);
   void profEnd(const char* name);
+};
+
+// Makes 'ctx' (nullptr: the default context of the thread's device, locked) the
+// calling thread's context for the duration of an entry point. On exit the
+// context's stream is drained: when an entry point returns, everything it
+// queued has completed (outputs are usable, released blocks are reusable).
+class ContextScope {
+ public:
+  explicit ContextScope(Runtime* ctx);
+  ~ContextScope();
+  ContextScope(const ContextScope&) = delete;
+  ContextScope& operator=(const ContextScope&) = delete;
+
+ private:
+  Runtime* ctx_;
+  Runtime* prev_;
+  bool locked_ = false;
+  bool outer_ = false;
 };
 
 // Launch on the library stream, bracketed by events when profiling is on.
@@ -138,12 +216,13 @@ class DevBuf {
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  DevBuf(DevBuf&& o) noexcept : p_(o.p_), cap_(o.cap_) { o.p_ = nullptr; o.cap_ = 0; }
+  DevBuf(DevBuf&& o) noexcept : p_(o.p_), cap_(o.cap_), ds_(o.ds_) { o.p_ = nullptr; o.cap_ = 0; }
   DevBuf& operator=(DevBuf&& o) noexcept {
     if (this != &o) {
       release();
       p_ = o.p_;
       cap_ = o.cap_;
+      ds_ = o.ds_;
       o.p_ = nullptr;
       o.cap_ = 0;
     }
@@ -160,6 +239,7 @@ class DevBuf {
  private:
   void* p_ = nullptr;
   size_t cap_ = 0;
+  DeviceState* ds_ = nullptr;  // the GPU the block lives on
 };
 
 int kindWidth(int32_t kind);  // bytes per value; 0 for bit-packed BOOLEAN; -1 unknown
@@ -201,7 +281,7 @@ class PinnedBuf {
   PinnedBuf() = default;
   PinnedBuf(const PinnedBuf&) = delete;
   PinnedBuf& operator=(const PinnedBuf&) = delete;
-  PinnedBuf(PinnedBuf&& o) noexcept : p_(o.p_), cap_(o.cap_), size_(o.size_) { o.p_ = nullptr; o.cap_ = o.size_ = 0; }
+  PinnedBuf(PinnedBuf&& o) noexcept : p_(o.p_), cap_(o.cap_), size_(o.size_), ds_(o.ds_) { o.p_ = nullptr; o.cap_ = o.size_ = 0; }
   ~PinnedBuf();
   // Extends the used size by 'bytes' (contents preserved) and returns the new tail.
   char* extend(size_t bytes);
@@ -213,6 +293,7 @@ class PinnedBuf {
   char* p_ = nullptr;
   size_t cap_ = 0;
   size_t size_ = 0;
+  DeviceState* ds_ = nullptr;
 };
 
 class HostCoalescer {

@@ -34,6 +34,8 @@
 
 namespace vx {
 
+std::mutex gNoTableMutex;
+
 void compactBits(const uint64_t* dValues, const uint64_t* dNulls, const uint64_t* dRows,
                  int64_t numRows, int32_t* dOut, DevBuf& scratch, int64_t* total);
 void sortKeysU64(const uint64_t* in, uint64_t* out, size_t n, DevBuf& tmp);
@@ -862,6 +864,9 @@ struct GatherArgs {
 // extractColumns (HashProbe.cpp:82-118): build columns at the listed rows.
 __global__ __launch_bounds__(256) void k_gather_deps(GatherArgs a) {
   const int32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos - static_cast<int32_t>(lane()) >= a.count) {
+    return;  // whole wave past the end: its bitmap word lies outside ceil(count / 64) words
+  }
   const bool active = pos < a.count;
   const int32_t b = active ? a.buildRows[pos] : -1;
   for (int c = 0; c < a.numCols; ++c) {
@@ -936,6 +941,7 @@ __global__ __launch_bounds__(256) void k_probed_bits(const uint8_t* probed, int6
 using namespace vx;
 
 struct vx355_join_build {
+  vx::Runtime* ctx = nullptr;  // this operator's execution context (stream, mailbox)
   std::vector<int32_t> keyCols, keyKinds, depCols, depKinds;
   std::vector<int32_t> usedCols;
   int32_t joinType = 0;
@@ -956,6 +962,8 @@ struct vx355_join_build {
 
 struct vx355_join_table {
   std::atomic<int> refs{1};
+  int device = -1;        // the GPU the table lives on
+  std::mutex lazyMutex;   // dynamic-filter state computed on first request
   int32_t mode = JMODE_ARRAY;
   int32_t joinType = 0;
   std::vector<int32_t> keyKinds, depKinds;
@@ -980,6 +988,7 @@ struct vx355_join_table {
 };
 
 struct vx355_join_probe {
+  vx::Runtime* ctx = nullptr;  // this operator's execution context (stream, mailbox)
   vx355_join_table* table = nullptr;
   std::vector<int32_t> keyCols;
   int32_t joinType = 0;
@@ -1131,8 +1140,9 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
                  "peer build with a different layout");
     total += others[i]->numRows;
   }
-  if (total >= static_cast<int64_t>(kNoRow32)) {
-    VX_THROW(VX355_EUNSUPPORTED, "more than 2^32-2 build rows");
+  if (total > static_cast<int64_t>(INT32_MAX)) {
+    // build row ids travel as int32 (build_rows_out) and as u32 with two sentinels (next[], head[])
+    VX_THROW(VX355_EUNSUPPORTED, "more than 2^31-1 build rows in one table");
   }
   growBuild(h, total);
   for (int32_t i = 0; i < numOthers; ++i) {
@@ -1168,6 +1178,7 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
   rt.sync();
 
   auto t = std::make_unique<vx355_join_table>();
+  t->device = rt.device;
   t->joinType = h.joinType;
   t->keyKinds = h.keyKinds;
   t->depKinds = h.depKinds;
@@ -1701,6 +1712,7 @@ int vx355_join_build_create(const vx355_join_build_spec* spec, vx355_join_build*
   h->depValid.resize(h->depCols.size());
   h->obsMin.assign(h->keyCols.size(), INT64_MAX);
   h->obsMax.assign(h->keyCols.size(), INT64_MIN);
+  h->ctx = Runtime::createContext();
   for (int32_t kind : h->keyKinds) {
     // No value ids for these types (VectorHasher.h:338-357): generic mode whatever the
     // data, also for an empty build side.
@@ -1713,7 +1725,7 @@ int vx355_join_build_create(const vx355_join_build_spec* spec, vx355_join_build*
 }
 
 int vx355_join_build_add_input(vx355_join_build* h, const vx355_batch* batch) {
-  VX_API_BEGIN
+  VX_API_BEGIN_CTX(VX_CTX_OF(h))
   Runtime::get().requireInit();
   VX_CHECK_ARG(h && batch, "NULL argument");
   VX_CHECK_ARG(!h->finished, "addInput after finish");
@@ -1730,7 +1742,7 @@ int vx355_join_build_add_input(vx355_join_build* h, const vx355_batch* batch) {
 
 int vx355_join_build_finish(vx355_join_build* h, vx355_join_build* const* others, int32_t num_others,
                             vx355_join_table** out) {
-  VX_API_BEGIN
+  VX_API_BEGIN_CTX(VX_CTX_OF(h))
   Runtime::get().requireInit();
   VX_CHECK_ARG(h && out && num_others >= 0, "bad argument");
   h->coalescer.flush([&](const vx355_batch* flat) { buildAddInput(*h, flat); });
@@ -1744,9 +1756,19 @@ int vx355_join_build_finish(vx355_join_build* h, vx355_join_build* const* others
   VX_API_END
 }
 
+void* vx355_join_build_stream(vx355_join_build* h) { return h ? static_cast<void*>(h->ctx->stream) : nullptr; }
+
 void vx355_join_build_destroy(vx355_join_build* h) {
-  std::lock_guard<std::recursive_mutex> lock(vx::apiMutex());
-  delete h;
+  if (!h) {
+    return;
+  }
+  Runtime* ctx = h->ctx;
+  try {
+    vx::ContextScope scope(ctx);
+    delete h;
+  } catch (...) {
+  }
+  Runtime::destroyContext(ctx);
 }
 
 void vx355_join_table_retain(vx355_join_table* t) {
@@ -1757,8 +1779,19 @@ void vx355_join_table_retain(vx355_join_table* t) {
 
 void vx355_join_table_release(vx355_join_table* t) {
   if (t && t->refs.fetch_sub(1) == 1) {
-    std::lock_guard<std::recursive_mutex> lock(vx::apiMutex());
-    delete t;
+    // The last reference may go away on any thread (probe destroy, the bridge): every
+    // entry point that used the table has drained its stream, so the blocks are idle.
+    Runtime* def = nullptr;
+    try {
+      def = Runtime::defaultContext(t->device);
+    } catch (...) {  // after vx355_shutdown: blocks go straight back to the driver
+    }
+    if (def) {
+      vx::ContextScope scope(def);
+      delete t;
+    } else {
+      delete t;
+    }
   }
 }
 
@@ -1787,7 +1820,11 @@ int vx355_join_probe_create(vx355_join_table* table, const vx355_join_probe_spec
       spec->join_type != table->joinType) {
     VX_THROW(VX355_EINVAL, "right / full / right semi joins need a table built for that join type");
   }
+  if (Runtime::get().device != table->device) {
+    VX_THROW(VX355_EINVAL, "probe created on another GPU than its join table (vx355_set_device)");
+  }
   auto p = std::make_unique<vx355_join_probe>();
+  p->ctx = Runtime::createContext();
   p->table = table;
   vx355_join_table_retain(table);
   p->joinType = spec->join_type;
@@ -1798,7 +1835,7 @@ int vx355_join_probe_create(vx355_join_table* table, const vx355_join_probe_spec
 }
 
 int vx355_join_probe_add_input(vx355_join_probe* h, const vx355_batch* batch) {
-  VX_API_BEGIN
+  VX_API_BEGIN_CTX(VX_CTX_OF(h))
   Runtime::get().requireInit();
   VX_CHECK_ARG(h && batch, "NULL argument");
   probeAddInput(*h, batch);
@@ -1809,7 +1846,7 @@ int vx355_join_probe_get_output(vx355_join_probe* h, int32_t max_rows, int32_t* 
                                 int32_t* build_rows_out, int32_t out_mem, vx355_out_column* build_cols,
                                 const int32_t* build_col_ids, int32_t num_build_cols, int32_t* n_out,
                                 int32_t* finished) {
-  VX_API_BEGIN
+  VX_API_BEGIN_CTX(VX_CTX_OF(h))
   Runtime::get().requireInit();
   VX_CHECK_ARG(h, "NULL argument");
   probeGetOutput(*h, max_rows, mapping_out, build_rows_out, out_mem, build_cols, build_col_ids,
@@ -1821,7 +1858,7 @@ int vx355_join_probe_get_build_side_output(vx355_join_probe* h, int32_t max_rows
                                            int32_t out_mem, vx355_out_column* build_cols,
                                            const int32_t* build_col_ids, int32_t num_build_cols, int32_t* n_out,
                                            int32_t* finished) {
-  VX_API_BEGIN
+  VX_API_BEGIN_CTX(VX_CTX_OF(h))
   Runtime::get().requireInit();
   VX_CHECK_ARG(h, "NULL argument");
   probeGetBuildSideOutput(*h, max_rows, build_rows_out, out_mem, build_cols, build_col_ids, num_build_cols,
@@ -1834,15 +1871,21 @@ void vx355_join_probe_destroy(vx355_join_probe* h) {
     return;
   }
   vx355_join_table* t = h->table;
-  {
-    std::lock_guard<std::recursive_mutex> lock(vx::apiMutex());
+  Runtime* ctx = h->ctx;
+  try {
+    vx::ContextScope scope(ctx);
     delete h;
+  } catch (...) {
   }
+  Runtime::destroyContext(ctx);
   vx355_join_table_release(t);
 }
 
+void* vx355_join_probe_stream(vx355_join_probe* h) { return h ? static_cast<void*>(h->ctx->stream) : nullptr; }
+
 int vx355_join_table_key_filter(vx355_join_table* t, int32_t key, vx355_key_filter* out) {
-  VX_API_BEGIN
+  VX_API_BEGIN_DEV(t ? t->device : -1)
+  std::lock_guard<std::mutex> tableLock(t ? t->lazyMutex : vx::gNoTableMutex);
   Runtime::get().requireInit();
   VX_CHECK_ARG(t && out, "NULL argument");
   VX_CHECK_ARG(key >= 0 && key < static_cast<int32_t>(t->keyKinds.size()), "no such key");
@@ -1865,7 +1908,8 @@ int vx355_join_table_key_filter(vx355_join_table* t, int32_t key, vx355_key_filt
 
 int vx355_join_table_key_filter_values(vx355_join_table* t, int32_t key, int64_t* values_out, int64_t capacity,
                                        int32_t mem, int64_t* n_out) {
-  VX_API_BEGIN
+  VX_API_BEGIN_DEV(t ? t->device : -1)
+  std::lock_guard<std::mutex> tableLock(t ? t->lazyMutex : vx::gNoTableMutex);
   Runtime::get().requireInit();
   VX_CHECK_ARG(t && n_out, "NULL argument");
   VX_CHECK_ARG(key >= 0 && key < static_cast<int32_t>(t->keyKinds.size()), "no such key");
@@ -1891,7 +1935,8 @@ int64_t vx355_bloom_num_blocks(int64_t num_elements, double false_positive, int3
 
 int vx355_join_table_key_filter_bloom(vx355_join_table* t, int32_t key, int32_t lanes, uint32_t* blocks_out,
                                       int64_t num_blocks, int32_t mem) {
-  VX_API_BEGIN
+  VX_API_BEGIN_DEV(t ? t->device : -1)
+  std::lock_guard<std::mutex> tableLock(t ? t->lazyMutex : vx::gNoTableMutex);
   auto& rt = Runtime::get();
   rt.requireInit();
   VX_CHECK_ARG(t && blocks_out, "NULL argument");

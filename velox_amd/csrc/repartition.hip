@@ -15,7 +15,7 @@ constexpr int kMaxScatterCols = 16;
 constexpr int kTile = 4096;  // rows per workgroup (256 lanes x 16)
 
 __global__ __launch_bounds__(256) void k_part_hist(const uint32_t* parts, int64_t numRows, int32_t numParts,
-                                                   int64_t numTiles, uint32_t* tileCounts) {
+                                                   int64_t numTiles, uint32_t* tileCounts, uint32_t* badFlag) {
   __shared__ uint32_t hist[kMaxParts];
   for (int64_t tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
     if (threadIdx.x < kMaxParts) {
@@ -25,7 +25,12 @@ __global__ __launch_bounds__(256) void k_part_hist(const uint32_t* parts, int64_
     for (int j = 0; j < kTile / 256; ++j) {
       const int64_t r = tile * kTile + j * 256 + threadIdx.x;
       if (r < numRows) {
-        atomicAdd(&hist[parts[r]], 1u);
+        const uint32_t p = parts[r];
+        if (p < static_cast<uint32_t>(numParts)) {
+          atomicAdd(&hist[p], 1u);
+        } else {
+          *badFlag = 1;  // reported as VX355_EINVAL; the scatter skips the row
+        }
       }
     }
     blockSync();
@@ -89,8 +94,9 @@ __global__ __launch_bounds__(256) void k_part_scatter(ScatterArgs a) {
     const int wave = threadIdx.x >> 6;
     for (int j = 0; j < kTile / 256; ++j) {
       const int64_t r = tile * kTile + j * 256 + threadIdx.x;
-      const bool live = r < a.numRows;
-      const uint32_t p = live ? a.parts[r] : 0xffffffffu;
+      uint32_t p = r < a.numRows ? a.parts[r] : 0xffffffffu;
+      const bool live = p < static_cast<uint32_t>(a.numParts);
+      p = live ? p : 0xffffffffu;
       // Rank among the lanes of this wave with the same partition, and the
       // wave's count per partition.
       uint32_t rank = 0;
@@ -190,10 +196,12 @@ extern "C" int vx355_partition_scatter(const uint32_t* partitions, int32_t num_r
     }
   }
   const int64_t cells = numTiles * num_partitions;
-  uint32_t* counts = static_cast<uint32_t*>(dCounts.ensure(static_cast<size_t>(cells) * 4 + 64));
+  uint32_t* counts = static_cast<uint32_t*>(dCounts.ensure(static_cast<size_t>(cells + 1) * 4 + 64));
+  uint32_t* badFlag = counts + cells;
+  HIP_OK(hipMemsetAsync(badFlag, 0, 4, rt.stream));
   uint64_t* offsets = static_cast<uint64_t*>(dOffsets.ensure(static_cast<size_t>(cells + 1) * 8 + 64));
   const int grid = static_cast<int>(std::min<int64_t>(numTiles, static_cast<int64_t>(rt.numCUs) * 8));
-  VX_LAUNCH("k_part_hist", k_part_hist, grid, 256, 0, parts, n, num_partitions, numTiles, counts);
+  VX_LAUNCH("k_part_hist", k_part_hist, grid, 256, 0, parts, n, num_partitions, numTiles, counts, badFlag);
   VX_LAUNCH("k_part_scan", k_part_scan, 1, 1024, 0, counts, cells, offsets);
   sa.offsets = offsets;
   VX_LAUNCH("k_part_scatter", k_part_scatter, grid, 256, 0, sa);
@@ -203,12 +211,17 @@ extern "C" int vx355_partition_scatter(const uint32_t* partitions, int32_t num_r
     copyOutAsync(&firsts[p], VX355_MEM_HOST, offsets + static_cast<int64_t>(p) * numTiles, 8);
   }
   copyOutAsync(&firsts[num_partitions], VX355_MEM_HOST, offsets + cells, 8);
+  uint32_t bad = 0;
+  copyOutAsync(&bad, VX355_MEM_HOST, badFlag, 4);
   if (host) {
     for (int32_t c = 0; c < num_cols; ++c) {
       copyOutAsync(cols_out[c], VX355_MEM_HOST, sa.out[c], static_cast<size_t>(n) * sa.width[c]);
     }
   }
   rt.sync();
+  if (bad) {
+    VX_THROW(VX355_EINVAL, "partitions[] holds a value >= num_partitions");
+  }
   for (int32_t p = 0; p < num_partitions; ++p) {
     counts_out[p] = static_cast<int64_t>(firsts[p + 1] - firsts[p]);
   }

@@ -8,16 +8,57 @@
 
 namespace vx {
 
-namespace {
+// (internal linkage is not needed: these names live in namespace vx and are used by the
+// extern "C" entry points at the end of this file)
 thread_local std::string tlsLastError;
+thread_local Runtime* tlsCurrent = nullptr;  // context of the entry point running on this thread
+thread_local int tlsDevice = -1;             // vx355_set_device
+thread_local int tlsHipDevice = -1;          // what hipSetDevice was last told on this thread
+
+constexpr int kMaxDevices = 64;
+std::mutex gInitMutex;
+DeviceState* gDevices[kMaxDevices] = {};     // never deleted: buffers may outlive vx355_shutdown
+std::atomic<int> gDefaultDevice{-1};
+std::atomic<uint64_t> gNextContextId{1};
+
+void bindHipDevice(int device) {
+  if (tlsHipDevice != device) {
+    HIP_OK(hipSetDevice(device));
+    tlsHipDevice = device;
+  }
+}
+
+DeviceState* deviceState(int device) {
+  if (device < 0) {
+    device = tlsDevice >= 0 ? tlsDevice : gDefaultDevice.load();
+  }
+  if (device < 0 || device >= kMaxDevices || !gDevices[device] || !gDevices[device]->alive) {
+    VX_THROW(VX355_EINVAL, "vx355_init has not been called");
+  }
+  return gDevices[device];
+}
+
+Runtime* newContext(DeviceState* ds, bool isDefault) {
+  bindHipDevice(ds->device);
+  auto ctx = std::make_unique<Runtime>(ds);
+  ctx->device = ds->device;
+  ctx->numCUs = ds->numCUs;
+  ctx->ldsPerBlock = ds->ldsPerBlock;
+  ctx->isDefault = isDefault;
+  ctx->id = gNextContextId.fetch_add(1);
+  HIP_OK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&ctx->mail.host), Mailbox::kWords * 8, hipHostMallocMapped));
+  HIP_OK(hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->mail.dev), ctx->mail.host, 0));
+  std::memset(ctx->mail.host, 0, Mailbox::kWords * 8);
+  ctx->initialized = true;
+  {
+    std::lock_guard<std::mutex> lock(ds->memMutex);
+    ds->contexts[ctx->id] = ctx.get();
+  }
+  return ctx.release();
 }
 
 void setLastError(const std::string& m) { tlsLastError = m; }
-
-std::recursive_mutex& apiMutex() {
-  static std::recursive_mutex m;
-  return m;
-}
 
 void hipFail(hipError_t e, const char* what, const char* file, int line) {
   char buf[512];
@@ -27,16 +68,91 @@ void hipFail(hipError_t e, const char* what, const char* file, int line) {
   VX_THROW(e == hipErrorOutOfMemory ? VX355_ENOMEM : VX355_EINTERNAL, buf);
 }
 
+Runtime* Runtime::tryGet() {
+  if (tlsCurrent) {
+    return tlsCurrent;
+  }
+  const int device = tlsDevice >= 0 ? tlsDevice : gDefaultDevice.load();
+  if (device < 0 || !gDevices[device] || !gDevices[device]->alive) {
+    return nullptr;
+  }
+  return gDevices[device]->defaultCtx;
+}
+
 Runtime& Runtime::get() {
-  static Runtime rt;
-  return rt;
+  Runtime* rt = tryGet();
+  if (!rt) {
+    VX_THROW(VX355_EINVAL, "vx355_init has not been called");
+  }
+  return *rt;
+}
+
+Runtime* Runtime::defaultContext(int device) { return deviceState(device)->defaultCtx; }
+
+Runtime* Runtime::createContext() {
+  // A handle created inside another handle's entry point lives on that handle's device.
+  DeviceState* ds = tlsCurrent ? tlsCurrent->ds : deviceState(-1);
+  return newContext(ds, false);
+}
+
+void Runtime::destroyContext(Runtime* ctx) {
+  if (!ctx) {
+    return;
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  {
+    std::lock_guard<std::mutex> lock(ctx->ds->memMutex);
+    ctx->ds->contexts.erase(ctx->id);
+  }
+  (void)hipHostFree(ctx->mail.host);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+ContextScope::ContextScope(Runtime* ctx) : ctx_(ctx), prev_(tlsCurrent) {
+  if (!ctx_) {
+    // Handle-less entry point. Nested inside another entry point (the Python
+    // harness never does that, the library itself may): stay in its context.
+    ctx_ = tlsCurrent ? tlsCurrent : deviceState(-1)->defaultCtx;
+  }
+  outer_ = ctx_ != prev_;
+  if (!outer_) {
+    return;
+  }
+  if (ctx_->isDefault) {
+    ctx_->callMutex.lock();
+    locked_ = true;
+  }
+  bindHipDevice(ctx_->device);
+  tlsCurrent = ctx_;
+}
+
+ContextScope::~ContextScope() {
+  if (!outer_) {
+    return;
+  }
+  // Everything the entry point queued is complete when it returns.
+  (void)hipStreamSynchronize(ctx_->stream);
+  ctx_->doneCalls.store(ctx_->currentCall);
+  ++ctx_->currentCall;
+  tlsCurrent = prev_;
+  if (prev_) {
+    (void)hipSetDevice(prev_->device);
+    tlsHipDevice = prev_->device;
+  }
+  if (locked_) {
+    ctx_->callMutex.unlock();
+  }
 }
 
 hipEvent_t Runtime::newEvent() {
-  if (!freeEvents.empty()) {
-    hipEvent_t e = freeEvents.back();
-    freeEvents.pop_back();
-    return e;
+  {
+    std::lock_guard<std::mutex> lock(ds->profMutex);
+    if (!ds->freeEvents.empty()) {
+      hipEvent_t e = ds->freeEvents.back();
+      ds->freeEvents.pop_back();
+      return e;
+    }
   }
   hipEvent_t e;
   HIP_OK(hipEventCreate(&e));
@@ -44,35 +160,57 @@ hipEvent_t Runtime::newEvent() {
 }
 
 void Runtime::profBegin(const char* name) {
-  auto& entry = prof[name];
   hipEvent_t a = newEvent();
   HIP_OK(hipEventRecord(a, stream));
-  entry.events.emplace_back(a, nullptr);
+  std::lock_guard<std::mutex> lock(ds->profMutex);
+  auto& entry = ds->prof[name];
+  entry.open[id] = a;
 }
 
 void Runtime::profEnd(const char* name) {
-  auto& entry = prof[name];
   hipEvent_t b = newEvent();
   HIP_OK(hipEventRecord(b, stream));
-  entry.events.back().second = b;
-  ++entry.launches;
+  std::lock_guard<std::mutex> lock(ds->profMutex);
+  auto& entry = ds->prof[name];
+  auto it = entry.open.find(id);
+  if (it != entry.open.end()) {
+    entry.events.emplace_back(it->second, b);
+    entry.open.erase(it);
+    ++entry.launches;
+  } else {
+    ds->freeEvents.push_back(b);
+  }
 }
 
-void* Runtime::allocBlock(size_t bytes, size_t* actual) {
+void* DeviceState::allocBlock(size_t bytes, size_t* actual) {
   // Size classes: powers of two up to 1 MiB, then multiples of 1 MiB.
   size_t want = bytes <= (1u << 20) ? static_cast<size_t>(nextPow2(std::max<size_t>(bytes, 256)))
                                     : ((bytes + (1u << 20) - 1) >> 20) << 20;
-  auto it = freeBlocks.lower_bound(want);
-  if (it != freeBlocks.end() && it->first <= want + want / 4) {
-    void* p = it->second;
-    *actual = it->first;
-    cachedBytes -= it->first;
-    freeBlocks.erase(it);
-    return p;
+  Runtime* cur = Runtime::tryGet();
+  {
+    std::unique_lock<std::mutex> lock(memMutex);
+    auto it = freeBlocks.lower_bound(want);
+    if (it != freeBlocks.end() && it->first <= want + want / 4) {
+      const CachedBlock b = it->second;
+      *actual = it->first;
+      cachedBytes -= it->first;
+      freeBlocks.erase(it);
+      // Released by another context whose call has not returned yet: its stream
+      // may still touch the block. Same context: ordered on the same stream.
+      if (b.ownerCtx != 0 && (!cur || b.ownerCtx != cur->id)) {
+        auto owner = contexts.find(b.ownerCtx);
+        if (owner != contexts.end() && owner->second->doneCalls.load() < b.ownerCall) {
+          hipStream_t s = owner->second->stream;
+          lock.unlock();
+          (void)hipStreamSynchronize(s);
+        }
+      }
+      return b.p;
+    }
   }
   void* p = nullptr;
   hipError_t e = hipMalloc(&p, want);
-  if (e == hipErrorOutOfMemory && !freeBlocks.empty()) {
+  if (e == hipErrorOutOfMemory) {
     (void)hipGetLastError();
     trimCache();
     e = hipMalloc(&p, want);
@@ -84,53 +222,74 @@ void* Runtime::allocBlock(size_t bytes, size_t* actual) {
   return p;
 }
 
-void Runtime::freeBlock(void* p, size_t bytes) {
+void DeviceState::freeBlock(void* p, size_t bytes) {
   if (!p) {
     return;
   }
-  if (!initialized || cachedBytes + bytes > cacheLimit) {
-    if (initialized) {
-      (void)hipStreamSynchronize(stream);
-    }
-    (void)hipFree(p);
-    return;
+  Runtime* cur = Runtime::tryGet();
+  if (cur && cur->ds != this) {
+    cur = nullptr;  // freed from a context on another GPU: nothing of ours is in flight on it
   }
-  // Work already queued on the library stream may still touch the block; any
-  // later user is ordered behind it on the same stream.
-  freeBlocks.emplace(bytes, p);
-  cachedBytes += bytes;
+  {
+    std::lock_guard<std::mutex> lock(memMutex);
+    if (alive && cachedBytes + bytes <= cacheLimit) {
+      // Work already queued on the releasing context's stream may still touch the
+      // block: a later user on the same stream is ordered behind it, any other
+      // context waits for that call to finish (allocBlock).
+      freeBlocks.emplace(bytes, CachedBlock{p, cur ? cur->id : 0, cur ? cur->currentCall : 0});
+      cachedBytes += bytes;
+      return;
+    }
+  }
+  if (cur) {
+    (void)hipStreamSynchronize(cur->stream);
+  }
+  (void)hipFree(p);
 }
 
-void Runtime::trimCache() {
-  if (initialized) {
-    (void)hipStreamSynchronize(stream);
+void DeviceState::trimCache() {
+  std::multimap<size_t, CachedBlock> blocks;
+  std::multimap<size_t, void*> pinned;
+  std::vector<hipStream_t> streams;
+  {
+    std::lock_guard<std::mutex> lock(memMutex);
+    blocks.swap(freeBlocks);
+    pinned.swap(freePinned);
+    cachedBytes = 0;
+    cachedPinned = 0;
+    for (auto& kv : contexts) {
+      streams.push_back(kv.second->stream);
+    }
   }
-  for (auto& kv : freeBlocks) {
-    (void)hipFree(kv.second);
+  for (hipStream_t s : streams) {
+    (void)hipStreamSynchronize(s);
   }
-  freeBlocks.clear();
-  cachedBytes = 0;
-  for (auto& kv : freePinned) {
+  for (auto& kv : blocks) {
+    (void)hipFree(kv.second.p);
+  }
+  for (auto& kv : pinned) {
     (void)hipHostFree(kv.second);
   }
-  freePinned.clear();
-  cachedPinned = 0;
 }
 
 void* DevBuf::ensure(size_t bytes, bool preserve, size_t preserveBytes) {
   if (bytes <= cap_) {
     return p_;
   }
+  auto& rt = Runtime::get();
+  if (p_ && ds_ != rt.ds) {
+    VX_THROW(VX355_EINTERNAL, "device buffer used from a context on another GPU");
+  }
   size_t newCap = std::max<size_t>(bytes, cap_ + cap_ / 2);
-  void* np = Runtime::get().allocBlock(newCap, &newCap);
+  void* np = rt.allocBlock(newCap, &newCap);
   if (preserve && p_ && preserveBytes) {
-    auto& rt = Runtime::get();
     HIP_OK(hipMemcpyAsync(np, p_, std::min(preserveBytes, cap_), hipMemcpyDeviceToDevice,
                           rt.stream));
   }
   if (p_) {
-    Runtime::get().freeBlock(p_, cap_);
+    ds_->freeBlock(p_, cap_);
   }
+  ds_ = rt.ds;
   p_ = np;
   cap_ = newCap;
   return p_;
@@ -138,7 +297,7 @@ void* DevBuf::ensure(size_t bytes, bool preserve, size_t preserveBytes) {
 
 void DevBuf::release() {
   if (p_) {
-    Runtime::get().freeBlock(p_, cap_);
+    ds_->freeBlock(p_, cap_);
     p_ = nullptr;
     cap_ = 0;
   }
@@ -206,15 +365,18 @@ void copyIn(void* devDst, const void* src, int32_t srcMem, size_t bytes) {
                         rt.stream));
 }
 
-char* Runtime::allocPinned(size_t bytes, size_t* actual) {
+char* DeviceState::allocPinned(size_t bytes, size_t* actual) {
   const size_t want = static_cast<size_t>(nextPow2(std::max<size_t>(bytes, 64 << 10)));
-  auto it = freePinned.lower_bound(want);
-  if (it != freePinned.end() && it->first <= want * 2) {
-    char* p = static_cast<char*>(it->second);
-    *actual = it->first;
-    cachedPinned -= it->first;
-    freePinned.erase(it);
-    return p;
+  {
+    std::lock_guard<std::mutex> lock(memMutex);
+    auto it = freePinned.lower_bound(want);
+    if (it != freePinned.end() && it->first <= want * 2) {
+      char* p = static_cast<char*>(it->second);
+      *actual = it->first;
+      cachedPinned -= it->first;
+      freePinned.erase(it);
+      return p;
+    }
   }
   char* p = nullptr;
   HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&p), want, hipHostMallocDefault));
@@ -222,31 +384,40 @@ char* Runtime::allocPinned(size_t bytes, size_t* actual) {
   return p;
 }
 
-void Runtime::releasePinned(char* p, size_t bytes) {
+void DeviceState::releasePinned(char* p, size_t bytes) {
   if (!p) {
     return;
   }
-  if (!initialized || cachedPinned + bytes > pinnedLimit) {
-    (void)hipHostFree(p);
-    return;
+  {
+    std::lock_guard<std::mutex> lock(memMutex);
+    if (alive && cachedPinned + bytes <= pinnedLimit) {
+      freePinned.emplace(bytes, p);
+      cachedPinned += bytes;
+      return;
+    }
   }
-  freePinned.emplace(bytes, p);
-  cachedPinned += bytes;
+  (void)hipHostFree(p);
 }
 
 PinnedBuf::~PinnedBuf() {
   // Copies out of this block were synchronised by the consumer before it returned.
-  Runtime::get().releasePinned(p_, cap_);
+  if (p_) {
+    ds_->releasePinned(p_, cap_);
+  }
 }
 
 char* PinnedBuf::extend(size_t bytes) {
   if (size_ + bytes > cap_) {
+    auto& rt = Runtime::get();
     size_t cap = 0;
-    char* np = Runtime::get().allocPinned(std::max<size_t>(size_ + bytes, cap_ * 2), &cap);
+    char* np = rt.allocPinned(std::max<size_t>(size_ + bytes, cap_ * 2), &cap);
     if (size_) {
       std::memcpy(np, p_, size_);
     }
-    Runtime::get().releasePinned(p_, cap_);
+    if (p_) {
+      ds_->releasePinned(p_, cap_);
+    }
+    ds_ = rt.ds;
     p_ = np;
     cap_ = cap;
   }
@@ -471,6 +642,7 @@ void DeviceBatch::load(const vx355_batch* batch, const std::vector<int32_t>& use
 }  // namespace vx
 
 using vx::Runtime;
+using vx::DeviceState;
 
 extern "C" {
 
@@ -488,74 +660,103 @@ int vx355_device_count(void) {
 }
 
 int vx355_init(int device) {
-  VX_API_BEGIN
-  auto& rt = Runtime::get();
-  if (rt.initialized) {
-    if (rt.device != device) {
-      VX_THROW(VX355_EINVAL, "vx355_init: already bound to another device");
+  try {
+    std::lock_guard<std::mutex> lock(vx::gInitMutex);
+    int n = 0;
+    HIP_OK(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n || device >= vx::kMaxDevices) {
+      VX_THROW(VX355_EINVAL, "vx355_init: no such device");
     }
-    return VX355_OK;
-  }
-  int n = 0;
-  HIP_OK(hipGetDeviceCount(&n));
-  if (device < 0 || device >= n) {
-    VX_THROW(VX355_EINVAL, "vx355_init: no such device");
-  }
-  HIP_OK(hipSetDevice(device));
-  hipDeviceProp_t prop;
-  HIP_OK(hipGetDeviceProperties(&prop, device));
-  rt.numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  rt.ldsPerBlock = prop.sharedMemPerBlock;
-  HIP_OK(hipStreamCreateWithFlags(&rt.stream, hipStreamNonBlocking));
-  HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&rt.mail.host), vx::Mailbox::kWords * 8,
-                       hipHostMallocMapped));
-  HIP_OK(hipHostGetDevicePointer(reinterpret_cast<void**>(&rt.mail.dev), rt.mail.host, 0));
-  std::memset(rt.mail.host, 0, vx::Mailbox::kWords * 8);
-  // Scratch blocks released by operators are kept for reuse (hipMalloc/hipFree of
-  // multi-GB blocks cost ~100 ms): up to a quarter of the device memory, or
-  // VX355_CACHE_LIMIT_GB.
-  rt.cacheLimit = static_cast<size_t>(prop.totalGlobalMem / 4);
-  if (const char* e = std::getenv("VX355_CACHE_LIMIT_GB")) {
-    rt.cacheLimit = static_cast<size_t>(std::strtoull(e, nullptr, 10)) << 30;
-  }
-  rt.device = device;
-  rt.initialized = true;
-  VX_API_END
+    DeviceState* ds = vx::gDevices[device];
+    if (!ds) {
+      ds = new DeviceState();
+      ds->device = device;
+      vx::gDevices[device] = ds;
+    }
+    if (!ds->alive) {
+      vx::bindHipDevice(device);
+      hipDeviceProp_t prop;
+      HIP_OK(hipGetDeviceProperties(&prop, device));
+      ds->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+      ds->ldsPerBlock = prop.sharedMemPerBlock;
+      ds->totalMem = prop.totalGlobalMem;
+      // Scratch blocks released by operators are kept for reuse (hipMalloc/hipFree of
+      // multi-GB blocks cost ~100 ms): up to a quarter of the device memory, or
+      // VX355_CACHE_LIMIT_GB.
+      ds->cacheLimit = static_cast<size_t>(prop.totalGlobalMem / 4);
+      if (const char* e = std::getenv("VX355_CACHE_LIMIT_GB")) {
+        ds->cacheLimit = static_cast<size_t>(std::strtoull(e, nullptr, 10)) << 30;
+      }
+      ds->alive = true;
+      ds->defaultCtx = vx::newContext(ds, true);
+    }
+    // The first device initialised is the process default; the calling thread is
+    // bound to the one it just initialised (vx355_set_device changes that).
+    int expected = -1;
+    vx::gDefaultDevice.compare_exchange_strong(expected, device);
+    vx::tlsDevice = device;
+    vx::bindHipDevice(device);
+  VX_API_CATCH
+}
+
+int vx355_set_device(int device) {
+  try {
+    (void)vx::deviceState(device < 0 ? vx::kMaxDevices : device);  // throws unless initialised
+    vx::tlsDevice = device;
+    vx::bindHipDevice(device);
+  VX_API_CATCH
+}
+
+int vx355_current_device(void) {
+  Runtime* rt = Runtime::tryGet();
+  return rt ? rt->device : -1;
 }
 
 void vx355_shutdown(void) {
-  auto& rt = Runtime::get();
-  if (!rt.initialized) {
-    return;
-  }
-  (void)hipStreamSynchronize(rt.stream);
-  rt.trimCache();
-  for (auto& kv : rt.prof) {
-    for (auto& ev : kv.second.events) {
-      (void)hipEventDestroy(ev.first);
-      if (ev.second) {
-        (void)hipEventDestroy(ev.second);
-      }
+  std::lock_guard<std::mutex> lock(vx::gInitMutex);
+  for (int d = 0; d < vx::kMaxDevices; ++d) {
+    DeviceState* ds = vx::gDevices[d];
+    if (!ds || !ds->alive) {
+      continue;
     }
+    (void)hipSetDevice(d);
+    vx::tlsHipDevice = d;
+    ds->trimCache();
+    {
+      std::lock_guard<std::mutex> plock(ds->profMutex);
+      for (auto& kv : ds->prof) {
+        for (auto& ev : kv.second.events) {
+          (void)hipEventDestroy(ev.first);
+          (void)hipEventDestroy(ev.second);
+        }
+        for (auto& ev : kv.second.open) {
+          (void)hipEventDestroy(ev.second);
+        }
+      }
+      ds->prof.clear();
+      for (auto e : ds->freeEvents) {
+        (void)hipEventDestroy(e);
+      }
+      ds->freeEvents.clear();
+    }
+    Runtime* def = ds->defaultCtx;
+    ds->defaultCtx = nullptr;
+    ds->alive = false;  // blocks released from now on go straight back to the driver
+    Runtime::destroyContext(def);
   }
-  rt.prof.clear();
-  for (auto e : rt.freeEvents) {
-    (void)hipEventDestroy(e);
-  }
-  rt.freeEvents.clear();
-  (void)hipHostFree(rt.mail.host);
-  rt.mail = vx::Mailbox{};
-  (void)hipStreamDestroy(rt.stream);
-  rt.stream = nullptr;
-  rt.initialized = false;
-  rt.device = -1;
+  vx::gDefaultDevice.store(-1);
+  vx::tlsDevice = -1;
 }
 
 void* vx355_device_malloc(size_t bytes) {
-  auto& rt = Runtime::get();
-  if (!rt.initialized) {
+  Runtime* rt = Runtime::tryGet();
+  if (!rt) {
     vx::setLastError("vx355_init has not been called");
     return nullptr;
+  }
+  if (vx::tlsHipDevice != rt->device) {
+    (void)hipSetDevice(rt->device);
+    vx::tlsHipDevice = rt->device;
   }
   void* p = nullptr;
   hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
@@ -569,10 +770,7 @@ void* vx355_device_malloc(size_t bytes) {
 
 void vx355_device_free(void* p) {
   if (p) {
-    auto& rt = Runtime::get();
-    if (rt.initialized) {
-      (void)hipStreamSynchronize(rt.stream);
-    }
+    // Every entry point drains its stream before it returns: nothing of ours is in flight.
     (void)hipFree(p);
   }
 }
@@ -580,7 +778,6 @@ void vx355_device_free(void* p) {
 int vx355_memcpy_h2d(void* dst, const void* src, size_t bytes) {
   VX_API_BEGIN
   auto& rt = Runtime::get();
-  rt.requireInit();
   if (bytes) {
     HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, rt.stream));
     rt.sync();
@@ -591,7 +788,6 @@ int vx355_memcpy_h2d(void* dst, const void* src, size_t bytes) {
 int vx355_memcpy_d2h(void* dst, const void* src, size_t bytes) {
   VX_API_BEGIN
   auto& rt = Runtime::get();
-  rt.requireInit();
   if (bytes) {
     HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, rt.stream));
     rt.sync();
@@ -602,7 +798,6 @@ int vx355_memcpy_d2h(void* dst, const void* src, size_t bytes) {
 int vx355_memset_d(void* dst, int value, size_t bytes) {
   VX_API_BEGIN
   auto& rt = Runtime::get();
-  rt.requireInit();
   if (bytes) {
     HIP_OK(hipMemsetAsync(dst, value, bytes, rt.stream));
     rt.sync();
@@ -611,35 +806,54 @@ int vx355_memset_d(void* dst, int value, size_t bytes) {
 }
 
 int vx355_synchronize(void) {
-  VX_API_BEGIN
-  auto& rt = Runtime::get();
-  rt.requireInit();
-  rt.sync();
-  VX_API_END
+  try {
+    // Every context of the calling thread's device (operator handles included).
+    DeviceState* ds = vx::deviceState(-1);
+    std::vector<hipStream_t> streams;
+    {
+      std::lock_guard<std::mutex> lock(ds->memMutex);
+      for (auto& kv : ds->contexts) {
+        streams.push_back(kv.second->stream);
+      }
+    }
+    for (hipStream_t s : streams) {
+      HIP_OK(hipStreamSynchronize(s));
+    }
+  VX_API_CATCH
+}
+
+int vx355_stream_wait_event(void* stream, void* event) {
+  try {
+    VX_CHECK_ARG(stream && event, "NULL argument");
+    HIP_OK(hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(event), 0));
+  VX_API_CATCH
+}
+
+void* vx355_default_stream(void) {
+  Runtime* rt = Runtime::tryGet();
+  return rt ? static_cast<void*>(rt->stream) : nullptr;
 }
 
 int vx355_profile_enable(int on) {
-  VX_API_BEGIN
-  auto& rt = Runtime::get();
-  rt.requireInit();
-  rt.sync();
-  rt.profile = on != 0;
-  VX_API_END
+  try {
+    DeviceState* ds = vx::deviceState(-1);
+    (void)vx355_synchronize();
+    std::lock_guard<std::mutex> lock(ds->profMutex);
+    ds->profile = on != 0;
+  VX_API_CATCH
 }
 
 namespace {
-void drainProfile(Runtime& rt) {
-  rt.sync();
-  for (auto& kv : rt.prof) {
+// Caller holds ds->profMutex and has synchronised the device's streams.
+void drainProfile(DeviceState* ds) {
+  for (auto& kv : ds->prof) {
     for (auto& ev : kv.second.events) {
-      if (ev.second) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
-          kv.second.doneMs += ms;
-        }
-        rt.freeEvents.push_back(ev.second);
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+        kv.second.doneMs += ms;
       }
-      rt.freeEvents.push_back(ev.first);
+      ds->freeEvents.push_back(ev.second);
+      ds->freeEvents.push_back(ev.first);
     }
     kv.second.events.clear();
   }
@@ -647,48 +861,50 @@ void drainProfile(Runtime& rt) {
 }  // namespace
 
 int vx355_profile_reset(void) {
-  VX_API_BEGIN
-  auto& rt = Runtime::get();
-  rt.requireInit();
-  drainProfile(rt);
-  rt.prof.clear();
-  VX_API_END
+  try {
+    DeviceState* ds = vx::deviceState(-1);
+    (void)vx355_synchronize();
+    std::lock_guard<std::mutex> lock(ds->profMutex);
+    drainProfile(ds);
+    ds->prof.clear();
+  VX_API_CATCH
 }
 
 int vx355_profile_get(const char* kernel, double* total_ms, int64_t* launches) {
-  VX_API_BEGIN
-  auto& rt = Runtime::get();
-  rt.requireInit();
-  VX_CHECK_ARG(kernel && total_ms && launches, "NULL argument");
-  drainProfile(rt);
-  auto it = rt.prof.find(kernel);
-  if (it == rt.prof.end()) {
-    *total_ms = 0;
-    *launches = 0;
-  } else {
-    *total_ms = it->second.doneMs;
-    *launches = it->second.launches;
-  }
-  VX_API_END
+  try {
+    DeviceState* ds = vx::deviceState(-1);
+    VX_CHECK_ARG(kernel && total_ms && launches, "NULL argument");
+    (void)vx355_synchronize();
+    std::lock_guard<std::mutex> lock(ds->profMutex);
+    drainProfile(ds);
+    auto it = ds->prof.find(kernel);
+    if (it == ds->prof.end()) {
+      *total_ms = 0;
+      *launches = 0;
+    } else {
+      *total_ms = it->second.doneMs;
+      *launches = it->second.launches;
+    }
+  VX_API_CATCH
 }
 
 int vx355_profile_names(char* buf, size_t cap) {
-  VX_API_BEGIN
-  auto& rt = Runtime::get();
-  rt.requireInit();
-  VX_CHECK_ARG(buf && cap > 0, "NULL buffer");
-  std::string s;
-  for (auto& kv : rt.prof) {
-    if (!s.empty()) {
-      s += "\n";
+  try {
+    DeviceState* ds = vx::deviceState(-1);
+    VX_CHECK_ARG(buf && cap > 0, "NULL buffer");
+    std::lock_guard<std::mutex> lock(ds->profMutex);
+    std::string s;
+    for (auto& kv : ds->prof) {
+      if (!s.empty()) {
+        s += "\n";
+      }
+      s += kv.first;
     }
-    s += kv.first;
-  }
-  if (s.size() + 1 > cap) {
-    s.resize(cap - 1);
-  }
-  std::memcpy(buf, s.c_str(), s.size() + 1);
-  VX_API_END
+    if (s.size() + 1 > cap) {
+      s.resize(cap - 1);
+    }
+    std::memcpy(buf, s.c_str(), s.size() + 1);
+  VX_API_CATCH
 }
 
 }  // extern "C"

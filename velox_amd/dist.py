@@ -15,49 +15,64 @@ MAX_GROUPS = 4096
 
 
 def encode_partial(columns, kinds, pad_rows=MAX_GROUPS):
-    """collect_output() columns -> float64 matrix [pad_rows, 2 * ncols + 1]
-    (value, validity per column; last column marks live rows). Strings of up to
-    7 bytes travel as their stringAsNumber image, BIGINT counts as doubles
-    (exact below 2^53)."""
+    """collect_output() columns -> int64 matrix [pad_rows, 3 * ncols + 1]: two value
+    words and a validity word per column, last column marks live rows. Every value
+    travels as its own bits: BIGINT / INTEGER / ... as int64, DOUBLE / REAL bit-cast
+    (float64.view(int64)), strings of up to 12 bytes (what the library keeps inline) as
+    {size : 8 | bytes 0..6} and {bytes 7..11}. Nothing is rounded on the way: the
+    FINAL step sees exactly what the PARTIAL step produced (sum(BIGINT) beyond 2^53,
+    INT64 min / max, counts)."""
     ncols = len(columns)
     rows = len(columns[0][1]) if ncols else 0
     if rows > MAX_GROUPS or rows > pad_rows:
         raise ValueError(f"{rows} partial groups exceed the gather buffer ({min(pad_rows, MAX_GROUPS)})")
-    out = np.zeros((pad_rows, 2 * ncols + 1))
-    out[:rows, 2 * ncols] = 1
+    out = np.zeros((pad_rows, 3 * ncols + 1), dtype=np.int64)
+    out[:rows, 3 * ncols] = 1
     for c, ((vals, valid), kind) in enumerate(zip(columns, kinds)):
+        valid = np.asarray(valid, dtype=bool)
         if kind in (abi.VARCHAR, abi.VARBINARY):
-            enc = np.zeros(rows)
             for i, v in enumerate(vals):
-                if v is not None:
-                    if len(v) > 6:
-                        raise ValueError("string keys longer than 6 bytes do not fit the gather encoding")
-                    enc[i] = int.from_bytes(v, "little") + ((1 << (8 * len(v))) if len(v) else 0)
-            vals = enc
-        out[:rows, 2 * c] = np.asarray(vals, dtype=np.float64)
-        out[:rows, 2 * c + 1] = np.asarray(valid, dtype=np.float64)
+                if v is None or not valid[i]:
+                    continue
+                v = bytes(v)
+                if len(v) > 12:
+                    raise ValueError("string keys longer than 12 bytes are not inline: not supported on device")
+                w0 = len(v) | (int.from_bytes(v[:7], "little") << 8)
+                out[i, 3 * c] = w0 - (1 << 64) if w0 >= (1 << 63) else w0
+                out[i, 3 * c + 1] = int.from_bytes(v[7:], "little")
+        elif kind in (abi.DOUBLE, abi.REAL):
+            out[:rows, 3 * c] = np.asarray(vals, dtype=np.float64).view(np.int64)
+        elif kind == abi.BOOLEAN or kind in abi.KIND_DTYPE:
+            out[:rows, 3 * c] = np.asarray(vals).astype(np.int64)
+        else:
+            raise ValueError(f"kind {kind} not supported by the gather encoding")
+        out[:rows, 3 * c + 2] = valid
     return out
 
 
 def decode_partials(matrix, kinds):
     """Gathered matrices (stacked) -> HostBatch of all ranks' partial rows."""
     ncols = len(kinds)
-    live = matrix[matrix[:, 2 * ncols] == 1]
+    matrix = np.asarray(matrix, dtype=np.int64)
+    live = matrix[matrix[:, 3 * ncols] == 1]
     cols = []
     for c, kind in enumerate(kinds):
-        vals, valid = live[:, 2 * c], live[:, 2 * c + 1] > 0
+        w0, w1, valid = live[:, 3 * c], live[:, 3 * c + 1], live[:, 3 * c + 2] != 0
         if kind in (abi.VARCHAR, abi.VARBINARY):
             strs = []
-            for v in vals.astype(np.int64):
-                v = int(v)
-                if v == 0:
-                    strs.append(b"")
-                else:
-                    size = (v.bit_length() - 1) // 8
-                    strs.append((v - (1 << (8 * size))).to_bytes(size, "little"))
+            for a, b in zip(w0.tolist(), w1.tolist()):
+                a &= (1 << 64) - 1
+                size = a & 0xFF
+                raw = (a >> 8).to_bytes(7, "little") + (b & ((1 << 40) - 1)).to_bytes(5, "little")
+                strs.append(raw[:size])
             cols.append(abi.HostColumn(kind, strs, valid))
-        elif kind in abi.KIND_DTYPE:
+        elif kind in (abi.DOUBLE, abi.REAL):
+            vals = np.ascontiguousarray(w0).view(np.float64)
             cols.append(abi.HostColumn(kind, vals.astype(abi.KIND_DTYPE[kind]), valid))
+        elif kind == abi.BOOLEAN:
+            cols.append(abi.HostColumn(kind, w0 != 0, valid))
+        elif kind in abi.KIND_DTYPE:
+            cols.append(abi.HostColumn(kind, w0.astype(abi.KIND_DTYPE[kind]), valid))
         else:
             raise ValueError(f"kind {kind} not supported by the gather encoding")
     return abi.HostBatch(cols, len(live))
@@ -76,7 +91,7 @@ def all_gather_partials(dist, torch, columns, kinds, device=None):
     rows = len(columns[0][1]) if columns else 0
     if rows > MAX_GROUPS:
         raise ValueError(f"{rows} partial groups exceed the gather buffer ({MAX_GROUPS})")
-    width = 2 * len(kinds) + 1
+    width = 3 * len(kinds) + 1
 
     def gather(mat):
         t = torch.from_numpy(mat)
@@ -86,7 +101,7 @@ def all_gather_partials(dist, torch, columns, kinds, device=None):
         dist.all_gather(gathered, t)
         return torch.stack(gathered).cpu().numpy()
 
-    first = np.zeros((1 + SMALL_GROUPS, width))
+    first = np.zeros((1 + SMALL_GROUPS, width), dtype=np.int64)
     first[0, 0] = rows
     if rows <= SMALL_GROUPS:
         first[1:] = encode_partial(columns, kinds, SMALL_GROUPS)
@@ -160,6 +175,16 @@ def partition_spec(world):
     return abi.PART_MODULO, dict(num_partitions=max(1, world))
 
 
+def _drain(torch, cols):
+    """libvx355 runs on its own HIP streams and takes device buffers as complete
+    (include/vx355.h, vx355_column.mem): after a collective or a torch kernel produced
+    them, the producing stream must have finished before the library is called.
+    dist.all_to_all_single / Work.wait() only order torch's CURRENT stream behind the
+    communication stream; they do not block the host."""
+    if cols and getattr(cols[0], "is_cuda", False):
+        torch.cuda.current_stream(cols[0].device).synchronize()
+
+
 def exchange(dist, torch, cols, counts):
     """cols: torch tensors whose rows are grouped by destination rank;
     counts[r] = rows for rank r. Returns the received columns (source-rank
@@ -177,6 +202,7 @@ def exchange(dist, torch, cols, counts):
         got = torch.empty((sum(rc),) + tuple(c.shape[1:]), dtype=c.dtype, device=c.device)
         dist.all_to_all_single(got, c.contiguous(), output_split_sizes=rc, input_split_sizes=sc)
         out.append(got)
+    _drain(torch, out)
     return out, rc
 
 
@@ -204,6 +230,7 @@ def exchange_async(dist, torch, cols, counts):
     def wait():
         for w in works:
             w.wait()
+        _drain(torch, out)
         keep.clear()
         return out, rc
     return wait
@@ -341,6 +368,9 @@ class GpuJoinBackend:
             n, fin = probe.get_output_device(cap, mapping.data_ptr(), rows.data_ptr(), descs,
                                              [0] if deps else [])
             outputs.append((mapping[:n].clone(), payload[:n].clone() if deps else None))
+            # the clones run on torch's stream; the next get_output_device overwrites
+            # mapping / payload on the probe's own stream
+            _drain(torch, [mapping])
             if fin:
                 break
         return outputs

@@ -32,6 +32,8 @@ SYMBOLS = [
     "vx355_join_probe_create", "vx355_join_probe_add_input", "vx355_join_probe_get_output",
     "vx355_join_probe_destroy", "vx355_join_probe_get_build_side_output", "vx355_join_table_key_filter", "vx355_join_table_key_filter_values",
     "vx355_bloom_num_blocks", "vx355_join_table_key_filter_bloom", "vx355_bloom_test",
+    "vx355_set_device", "vx355_current_device", "vx355_stream_wait_event", "vx355_default_stream",
+    "vx355_agg_stream", "vx355_join_build_stream", "vx355_join_probe_stream",
 ]
 
 
@@ -106,6 +108,12 @@ def lib():
     L.vx355_bloom_num_blocks.argtypes = [i64, C.c_double, i32]
     L.vx355_join_table_key_filter_bloom.argtypes = [vp, i32, i32, vp, i64, i32]
     L.vx355_bloom_test.argtypes = [vp, i64, i32, P(abi.Column), i32, vp, vp, i32]
+    L.vx355_set_device.argtypes = [C.c_int]
+    L.vx355_stream_wait_event.argtypes = [vp, vp]
+    L.vx355_default_stream.restype = vp
+    for name in ("vx355_agg_stream", "vx355_join_build_stream", "vx355_join_probe_stream"):
+        getattr(L, name).restype = vp
+        getattr(L, name).argtypes = [vp]
     _LIB = L
     return L
 
