@@ -56,6 +56,11 @@ def parse():
                     help="c4: keys = splitmix64(j), j < distinct (no dense range: open-addressing mode)")
     ap.add_argument("--unfused", action="store_true",
                     help="q1: FilterProject and HashAggregation as two operators")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="q1 at N = 1: skip the Q3 SF100 join block (the other half of BASELINE's metric)")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the rocprofv3 FETCH_SIZE / WRITE_SIZE passes behind roofline.traffic")
+    ap.add_argument("--secondary-steps", type=int, default=5)
     return ap.parse_args()
 
 
@@ -427,6 +432,17 @@ class Q3:
         self.stats = table.stats()
         return n
 
+    def pick_dominant(self, prof):
+        """The probe pass is k_join_probe_list when it also lists the hits (low hit rates: 8-byte key
+        in, 8 bytes out per MATCH) or k_join_probe + k_emit (4-byte hit out per probe row)."""
+        lst, dense = prof.get("k_join_probe_list", (0.0, 0))[0], prof.get("k_join_probe", (0.0, 0))[0]
+        if lst >= dense:
+            self.dominant = "k_join_probe_list"
+            self.agg_bytes_per_row = 8 + 8.0 * self.matches / max(1, self.probe_rows)
+        else:
+            self.dominant = "k_join_probe"
+            self.agg_bytes_per_row = 12
+
     def rows_per_step(self):
         return self.probe_rows
 
@@ -681,8 +697,8 @@ def measured_copy_ceiling(torch, device):
 
 
 def pmc_traffic(workload, kernel):
-    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3
-    PMC passes (PMC collection needs its own runs; bench.py cannot do it inline)."""
+    """Fallback for roofline.traffic when rocprofv3 is not available to bench.py: HBM bytes
+    per STEP of the dominant kernel from the committed rocprofv3 PMC passes."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
@@ -692,6 +708,57 @@ def pmc_traffic(workload, kernel):
     except (OSError, ValueError):
         return {}
     return entry if entry.get("kernel") == kernel else {}
+
+
+FETCH_CORRECTION = 2.0   # MI355X_MICROARCH.md "HBM": gfx950 FETCH_SIZE reports half of the bytes of wide reads
+
+
+def measure_traffic(child_flags, kernel, steps=1):
+    """HBM traffic of `kernel` per step, measured NOW: two child runs of this script under
+    rocprofv3 (one --pmc FETCH_SIZE pass, one --pmc WRITE_SIZE pass, each with --kernel-trace only,
+    as MI355X_MICROARCH.md prescribes), `steps` timed steps and no warm-up each. FETCH_SIZE /
+    WRITE_SIZE are KB per dispatch; summed over the kernel's dispatches, divided by the steps.
+    Returns {} when rocprofv3 is missing or a pass fails (the caller falls back to profiles/)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    tool = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not tool:
+        return {}
+    out = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="vx355_pmc_", dir="/tmp")
+        cmd = [tool, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", tmp, "--",
+               sys.executable, os.path.abspath(__file__)] + child_flags + [
+                   "--steps", str(steps), "--warmup", "0", "--no-cpu-baseline", "--no-secondary", "--no-traffic"]
+        env = dict(os.environ, TMPDIR="/tmp")
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            if r.returncode != 0:
+                return {}
+            kb, dispatches = 0.0, 0
+            for path in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        if row["Counter_Name"] == counter and (kernel + "<" in row["Kernel_Name"]
+                                                                or kernel + "(" in row["Kernel_Name"]):
+                            kb += float(row["Counter_Value"])
+                            dispatches += 1
+            if dispatches == 0:
+                return {}
+            out[counter] = kb * 1024.0 / steps
+            out["dispatches_per_step"] = dispatches / steps
+        except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+            return {}
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    fetch = out["FETCH_SIZE"] * FETCH_CORRECTION
+    return {"traffic_bytes_per_step": fetch + out["WRITE_SIZE"], "fetch_bytes_per_step": fetch,
+            "write_bytes_per_step": out["WRITE_SIZE"], "fetch_correction": FETCH_CORRECTION,
+            "dispatches_per_step": out["dispatches_per_step"],
+            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child runs of this bench (measured in this run)"}
 
 
 def physical_cores():
@@ -825,12 +892,14 @@ def main():
         return
 
     copy_ceiling = measured_copy_ceiling(torch, device)
-    if hasattr(wl, "pick_dominant"):
-        wl.pick_dominant(prof)
-    dom_ms, dom_launches = prof.get(wl.dominant, (0.0, 0))
-    dom_rows = getattr(wl, "selected", wl.rows_per_step()) * args.steps
-    achieved = (wl.agg_bytes_per_row * dom_rows / (dom_ms * 1e-3) / 1e9) if dom_ms > 0 else None
-    pmc = pmc_traffic(wl.name, wl.dominant)
+    child_flags = ["--workload", args.workload]
+    for flag, on in (("--q3-random-probe", args.q3_random_probe), ("--c4-sparse", args.c4_sparse),
+                     ("--unfused", args.unfused), ("--c1-stream", args.c1_stream)):
+        if on:
+            child_flags.append(flag)
+    if args.rows:
+        child_flags += ["--rows", str(args.rows)]
+    measure = (not args.no_traffic) and world == 1
     out = {
         "metric": "rows/s + HBM GB/s (rocprof), TPC-H Q1 agg & Q3 join SF100, 1/2/4/8 MI355X",
         "value": rows / elapsed,
@@ -853,46 +922,129 @@ def main():
                    if world > 1 else "1 GPU"},
         "workload_info": wl.info() if hasattr(wl, "info") else {},
         "pipeline_algorithmic_GBps": wl.bytes_per_row * rows / elapsed / 1e9 / world,
-        "roofline": {
-            "bound": "hbm", "kernel": wl.dominant,
-            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-            "traffic": pmc.get("traffic_bytes_per_launch"),
-            "traffic_source": pmc.get("source"),
-            "algorithmic_bytes_per_row": wl.agg_bytes_per_row,
-            "contract_bytes_per_row": getattr(wl, "contract_bytes_per_row", None),
-            "frac_at_contract_bytes": (achieved / HBM_PEAK_GBS * wl.contract_bytes_per_row / wl.agg_bytes_per_row)
-            if (achieved and getattr(wl, "contract_bytes_per_row", None)) else None,
-            "measured_copy_GBps": copy_ceiling,
-            "frac_of_measured_copy": (achieved / copy_ceiling) if (achieved and copy_ceiling) else None,
-            "avg_launch_ms": (dom_ms / dom_launches) if dom_launches else None,
-            "launches": dom_launches,
-        },
+        "roofline": roofline_block(wl, prof, args.steps, copy_ceiling, child_flags if measure else None),
         "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())},
     }
     if not args.no_cpu_baseline and world == 1:   # the CPU legs are timed at N = 1 only
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
         oracle_lib.lib()
-        sample = wl.host_sample(args.cpu_sample_rows)
-        if "_rows" in sample:
-            sample_rows = int(sample["_rows"])
-        else:
-            sample_rows = len(sample["pkey"]) if "pkey" in sample else len(next(iter(sample.values())))
-        cpu_out, cpu_s = wl.cpu_reference(sample, oracle_lib)
-        out["cpu_baseline"] = {
-            "value": sample_rows / cpu_s, "unit": "rows/s", "cores": 1, "kind": "port",
-            "sample": f"first {sample_rows} rows of the same {wl.name} input, single thread: "
-                      "Velox-algorithm CPU restatement (oracle/) of the same plan"
-                      + (" with numpy FilterProject" if args.workload == "q1" else "")
-                      + (" (local join only: no exchange on the CPU side)" if args.workload == "c5" else ""),
-            "host_cores_available": os.cpu_count(),
-        }
+        out["cpu_baseline"] = cpu_baseline_block(wl, oracle_lib, args.cpu_sample_rows, args.workload)
         if args.workload in ("q1", "c1", "c4") and not args.no_cpu_mt:
             out["cpu_baseline_mt"] = cpu_baseline_mt(wl, oracle_lib, args.cpu_sample_rows)
+    if args.workload == "q1" and world == 1 and not args.no_secondary and not args.rows:
+        # The other half of BASELINE's metric ("Q1 agg & Q3 join"): the dominant join of TPC-H Q3 at
+        # SF100 in dbgen order and with the probe rows in random order (the cache-hostile case).
+        del wl
+        torch.cuda.empty_cache()
+        out["secondary"] = {}
+        for order in ("dbgen", "random"):
+            out["secondary"]["tpch_q3_sf100_join" + ("" if order == "dbgen" else "_random_probe_order")] = \
+                q3_block(torch, device, order == "random", args, copy_ceiling, measure)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def roofline_block(wl, prof, steps, copy_ceiling, child_flags):
+    """roofline of the workload's dominant kernel. achieved = algorithmic bytes per step / the
+    kernel's time per step (HIP events on the operator's own stream, vx355_profile_*); traffic =
+    HBM bytes per STEP from rocprofv3 PMC passes (measured now when child_flags is given)."""
+    if hasattr(wl, "pick_dominant"):
+        wl.pick_dominant(prof)
+    dom_ms, dom_launches = prof.get(wl.dominant, (0.0, 0))
+    dom_rows = getattr(wl, "selected", wl.rows_per_step()) * steps
+    achieved = (wl.agg_bytes_per_row * dom_rows / (dom_ms * 1e-3) / 1e9) if dom_ms > 0 else None
+    symbol = "k_join_probe" if wl.dominant == "k_join_probe_list" else wl.dominant   # profile label -> kernel symbol
+    pmc = measure_traffic(child_flags, symbol) if child_flags is not None else {}
+    if not pmc:
+        pmc = pmc_traffic(wl.name, wl.dominant)
+    block = {
+        "bound": "hbm", "kernel": wl.dominant,
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+        "traffic": pmc.get("traffic_bytes_per_step"),
+        "traffic_basis": "HBM bytes per step (all launches of the kernel in one step); FETCH_SIZE x %g + WRITE_SIZE"
+                         % FETCH_CORRECTION,
+        "traffic_fetch": pmc.get("fetch_bytes_per_step"),
+        "traffic_write": pmc.get("write_bytes_per_step"),
+        "traffic_source": pmc.get("source"),
+        "algorithmic_bytes_per_step": wl.agg_bytes_per_row * dom_rows / steps,
+        "algorithmic_bytes_per_row": wl.agg_bytes_per_row,
+        "measured_copy_GBps": copy_ceiling,
+        "frac_of_measured_copy": (achieved / copy_ceiling) if (achieved and copy_ceiling) else None,
+        "kernel_ms_per_step": dom_ms / steps,
+        "avg_launch_ms": (dom_ms / dom_launches) if dom_launches else None,
+        "launches_per_step": dom_launches / steps,
+    }
+    contract = getattr(wl, "contract_bytes_per_row", None)
+    if contract and achieved:
+        # SURVEY.md section 8(d) prices the reference's layout (key + 16-byte slot = 24 B/probe). The
+        # same time priced at those bytes; omitted when it would exceed the peak (the design simply
+        # does not move those bytes).
+        at_contract = achieved * contract / wl.agg_bytes_per_row
+        block["contract_bytes_per_row"] = contract
+        if at_contract <= HBM_PEAK_GBS:
+            block["achieved_at_contract_bytes"] = at_contract
+            block["frac_at_contract_bytes"] = at_contract / HBM_PEAK_GBS
+    return block
+
+
+def cpu_baseline_block(wl, oracle_lib, cpu_sample_rows, workload):
+    sample = wl.host_sample(cpu_sample_rows)
+    if "_rows" in sample:
+        sample_rows = int(sample["_rows"])
+    else:
+        sample_rows = len(sample["pkey"]) if "pkey" in sample else len(next(iter(sample.values())))
+    cpu_out, cpu_s = wl.cpu_reference(sample, oracle_lib)
+    return {
+        "value": sample_rows / cpu_s, "unit": "rows/s", "cores": 1, "kind": "port",
+        "sample": f"first {sample_rows} rows of the same {wl.name} input, single thread: "
+                  "Velox-algorithm CPU restatement (oracle/) of the same plan"
+                  + (" with numpy FilterProject" if workload == "q1" else "")
+                  + (" (local join only: no exchange on the CPU side)" if workload == "c5" else ""),
+        "host_cores_available": os.cpu_count(),
+    }
+
+
+def q3_block(torch, device, random_order, args, copy_ceiling, measure):
+    """One entry of `secondary`: build + probe + result listing of the Q3 SF100 join, timed like the
+    headline (inputs resident, barrier + synchronize on both sides)."""
+    Q3.random_probe = random_order
+    wl = Q3(torch, WORKLOADS["q3"][1], device, seed=1234)
+    steps = max(1, args.secondary_steps)
+    for _ in range(2):
+        wl.step()
+    torch.cuda.synchronize()
+    ops.synchronize()
+    ops.profile_reset()
+    ops.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+    torch.cuda.synchronize()
+    ops.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.profile_enable(False)
+    prof = ops.profile()
+    child = ["--workload", "q3"] + (["--q3-random-probe"] if random_order else [])
+    block = {
+        "value": wl.rows_per_step() * steps / elapsed, "unit": "probe rows/s", "steps": steps, "warmup": 2,
+        "ms_per_step": elapsed / steps * 1e3,
+        "config": {"workload": wl.name, "step": "HashBuild (add_input + finish) + HashProbe (add_input + "
+                                               "get_output with one payload column), inner join"},
+        "workload_info": wl.info(),
+        "roofline": roofline_block(wl, prof, steps, copy_ceiling, child if measure else None),
+        "kernels_ms_per_step": {k: round(v[0] / steps, 4) for k, v in sorted(prof.items())},
+    }
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+        oracle_lib.lib()
+        block["cpu_baseline"] = cpu_baseline_block(wl, oracle_lib, min(args.cpu_sample_rows, 8_000_000), "q3")
+    del wl
+    torch.cuda.empty_cache()
+    return block
 
 
 if __name__ == "__main__":

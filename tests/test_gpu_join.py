@@ -438,3 +438,57 @@ def test_null_aware_anti_join(oracle, vx, case):
     else:
         keys = set(bk.tolist())
         assert got[vx.__name__] == [i for i in range(npb) if pvalid[i] and int(pk[i]) not in keys]
+
+
+@pytest.mark.parametrize("sparse", ["0", "1", "adaptive"])
+@pytest.mark.parametrize("join_type", [abi.JOIN_INNER, abi.JOIN_LEFT_SEMI_FILTER, abi.JOIN_RIGHT])
+@pytest.mark.parametrize("force_hash", [False, True])
+def test_low_hit_rate_joins_list_their_hits_in_the_probe_pass(oracle, vx, sparse, join_type, force_hash, monkeypatch):
+    """Joins that emit matches only over unique build keys: the probe pass lists the hits of every
+    8192-row tile itself (k_join_probe_list, listJoinResultsFastPath's role) instead of writing
+    hits[] for every probe row. The probe rows below mix long runs of misses, a stretch where every
+    row hits (tiles that overflow their staging segment fall back to the dense form) and the tail
+    of the batch; outputs are drained in windows that cut through tiles. 3 M probe rows = 367 tiles:
+    the adaptive mode measures the first 256 and decides for the rest."""
+    if sparse != "adaptive":
+        monkeypatch.setenv("VX355_JOIN_SPARSE", sparse)
+    if force_hash:
+        monkeypatch.setenv("VX355_JOIN_ARRAY_MAX", "0")
+    rng = np.random.default_rng(31)
+    nb, npb = 40000, 3_000_000
+    bk = (rng.permutation(4_000_000)[:nb]).astype(np.int64)
+    pay = rng.integers(0, 1 << 30, nb).astype(np.int64)
+    pk = rng.integers(0, 4_000_000, npb).astype(np.int64)          # ~1 % hit
+    pk[1_000_000:1_030_000] = bk[rng.integers(0, nb, 30000)]       # a dense stretch: every row hits
+    pk[-5:] = bk[:5]
+    res = {}
+    for impl in (oracle, vx):
+        table, _ = _build(impl, [[batch_of([bk, pay])]], [0], [abi.BIGINT], [1], [abi.BIGINT], join_type)
+        probe = impl.JoinProbe(table, [0], join_type)
+        if impl is vx:
+            vx.profile_reset()
+            vx.profile_enable(True)
+        probe.add_input(batch_of([pk]))
+        maps, rows, pays = [], [], []
+        while True:
+            m, r, cols, fin = probe.get_output(7001, [0])
+            maps.append(np.asarray(m))
+            rows.append(np.asarray(r))
+            pays.append(np.where(np.asarray(cols[0][1]), np.asarray(cols[0][0]), -1))
+            if fin:
+                break
+        if impl is vx:
+            vx.profile_enable(False)
+            names = set(vx.profile().keys())
+            assert ("k_join_probe_list" in names) == (sparse != "0")
+        res[impl.__name__] = (np.concatenate(maps), np.concatenate(rows), np.concatenate(pays))
+        if join_type == abi.JOIN_RIGHT:
+            bm, br, bcols, bfin = [], [], [], False
+            while not bfin:
+                r2, c2, bfin = probe.get_build_side_output(9000, [0])
+                br.append(np.asarray(r2))
+                bcols.append(np.asarray(c2[0][0]))
+            res[impl.__name__] += (np.concatenate(br), np.concatenate(bcols))
+    for g, e in zip(res[vx.__name__], res[oracle.__name__]):
+        assert len(g) == len(e) and (g == e).all()
+    assert len(res[vx.__name__][0]) > 30000

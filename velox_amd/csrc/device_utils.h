@@ -386,6 +386,44 @@ __device__ inline void keyImage(const ColView& c, int64_t i, uint64_t* w0, uint6
   }
 }
 
+// hashOne of a key from its stored image (keyImage above) and its type kind:
+// the same value hashValueAt computes from the column.
+__device__ inline uint64_t hashFromImage(int32_t kind, uint64_t w0, uint64_t w1) {
+  switch (kind) {
+    case VX355_BOOLEAN:
+      return w0 ? ~0ULL : 0ULL;
+    case VX355_TINYINT:
+    case VX355_SMALLINT:
+    case VX355_INTEGER:
+      return jenkinsRevMix32(static_cast<uint32_t>(static_cast<int32_t>(static_cast<int64_t>(w0))));
+    case VX355_BIGINT:
+      return twangMix64(w0);
+    case VX355_REAL:
+    case VX355_DOUBLE:
+      return w0 == 0 ? 0 : twangMix64(w0);  // the image is canonical: one NaN, +0.0 for both zeros
+    case VX355_VARCHAR:
+    case VX355_VARBINARY: {
+      const uint32_t size = static_cast<uint32_t>(w0);
+      uint8_t buf[12];
+      const uint64_t lo = (w0 >> 32) | (w1 << 32);
+      const uint32_t hi = static_cast<uint32_t>(w1 >> 32);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        buf[k] = static_cast<uint8_t>(lo >> (8 * k));
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        buf[8 + k] = static_cast<uint8_t>(hi >> (8 * k));
+      }
+      return hashBytes(1, buf, static_cast<int32_t>(size <= 12 ? size : 12));
+    }
+    case VX355_TIMESTAMP:
+      return hashMix(w0, w1);
+    default:
+      return 0;
+  }
+}
+
 __device__ inline uint64_t loadAgent(const uint64_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

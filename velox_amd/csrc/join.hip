@@ -105,7 +105,6 @@ struct AppendArgs {
   ColView deps[kMaxDeps];
   uint64_t* keyOut[kMaxKeys];   // key images: 1 word, 2 for strings / timestamps
   int32_t keyWords[kMaxKeys];
-  uint64_t* hashOut;            // VectorHasher hash of the key columns
   char* depOut[kMaxDeps];
   uint8_t* depValid[kMaxDeps];
   int32_t depWidth[kMaxDeps];
@@ -131,7 +130,6 @@ __global__ __launch_bounds__(256) void k_build_append(AppendArgs a) {
   for (int64_t p = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; p < a.count;
        p += stride) {
     const int64_t row = a.rows ? a.rows[p] : p;
-    uint64_t hash = 0;
     const bool keyOk = !a.keyValidWords || bitAt(a.keyValidWords, row);
     if (a.keyNullOut) {
       a.keyNullOut[a.base + p] = keyOk ? 0 : 1;
@@ -156,53 +154,52 @@ __global__ __launch_bounds__(256) void k_build_append(AppendArgs a) {
       if (a.keyWords[k] == 2) {
         a.keyOut[k][(a.base + p) * 2 + 1] = w1;
       }
-      const uint64_t hv = hashValueAt(c, i);
-      hash = k == 0 ? hv : hashMix(hash, hv);
       // Range statistics for the normalized-key decision (VectorHasher::analyze).
       if (c.kind == VX355_REAL || c.kind == VX355_DOUBLE || c.kind == VX355_TIMESTAMP) {
         a.counters->unmappable = 1;
         continue;
       }
-      KeyRange all;
-      all.min = INT64_MIN;
-      all.max = INT64_MAX;
       int64_t v;
-      bool mappable;
-      valueIdAt(c, i, all, &v, &mappable);
-      if (!mappable) {
-        a.counters->unmappable = 1;
-        continue;
+      if (c.kind == VX355_VARCHAR || c.kind == VX355_VARBINARY) {
+        KeyRange all;
+        all.min = INT64_MIN;
+        all.max = INT64_MAX;
+        bool mappable;
+        valueIdAt(c, i, all, &v, &mappable);
+        if (!mappable) {
+          a.counters->unmappable = 1;
+          continue;
+        }
+      } else {
+        v = static_cast<int64_t>(w0);  // integer kinds: the image is the widened value
       }
       mn[k] = v < mn[k] ? v : mn[k];
       mx[k] = v > mx[k] ? v : mx[k];
     }
-    a.hashOut[a.base + p] = hash;
     for (int d = 0; d < a.numDeps; ++d) {
       const ColView& c = a.deps[d];
       const bool valid = !colIsNull(c, row);
       a.depValid[d][a.base + p] = valid ? 1 : 0;
       const int w = a.depWidth[d];
       char* dst = a.depOut[d] + (a.base + p) * (w == 0 ? 1 : w);
-      if (!valid) {
-        for (int b = 0; b < (w == 0 ? 1 : w); ++b) {
-          dst[b] = 0;
-        }
-        continue;
-      }
-      const int64_t i = colIndex(c, row);
-      if (w == 0) {
-        dst[0] = bitAt(static_cast<const uint64_t*>(c.values), i) ? 1 : 0;
-      } else if (w == 16 && (c.kind == VX355_VARCHAR || c.kind == VX355_VARBINARY)) {
-        uint4 raw = static_cast<const uint4*>(c.values)[i];
-        if (raw.x > 12) {
+      const int64_t i = valid ? colIndex(c, row) : 0;
+      // fixed-width payloads move as whole words (both sides are naturally aligned)
+      if (w == 8) {
+        *reinterpret_cast<uint64_t*>(dst) = valid ? static_cast<const uint64_t*>(c.values)[i] : 0;
+      } else if (w == 4) {
+        *reinterpret_cast<uint32_t*>(dst) = valid ? static_cast<const uint32_t*>(c.values)[i] : 0;
+      } else if (w == 2) {
+        *reinterpret_cast<uint16_t*>(dst) = valid ? static_cast<const uint16_t*>(c.values)[i] : 0;
+      } else if (w == 1) {
+        dst[0] = valid ? static_cast<const char*>(c.values)[i] : 0;
+      } else if (w == 0) {
+        dst[0] = (valid && bitAt(static_cast<const uint64_t*>(c.values), i)) ? 1 : 0;
+      } else {  // 16: StringView or Timestamp
+        uint4 raw = valid ? static_cast<const uint4*>(c.values)[i] : make_uint4(0, 0, 0, 0);
+        if (valid && (c.kind == VX355_VARCHAR || c.kind == VX355_VARBINARY) && raw.x > 12) {
           a.counters->longString = 1;
         }
         *reinterpret_cast<uint4*>(dst) = raw;
-      } else {
-        const char* src = static_cast<const char*>(c.values) + i * w;
-        for (int b = 0; b < w; ++b) {
-          dst[b] = src[b];
-        }
       }
     }
   }
@@ -225,7 +222,7 @@ struct InsertArgs {
   const uint64_t* keyStore[kMaxKeys];
   int32_t keyWords[kMaxKeys];
   int32_t keyIsString[kMaxKeys];
-  const uint64_t* hashStore;
+  int32_t keyKind[kMaxKeys];
   KeyRange ranges[kMaxKeys];
   int32_t numKeys;
   int32_t mode;
@@ -280,6 +277,42 @@ __device__ inline bool storedKeysEqual(const InsertArgs& a, int64_t r1, int64_t 
   return true;
 }
 
+// Sets the presence bit of 'key' for every active lane of the wave and tells each
+// lane whether it was the first to claim its key. HBM atomics retire at ~20 G/s
+// chip-wide, and build sides usually arrive in key order (a scan of the dimension
+// table): consecutive lanes whose keys share a 32-bit word of the bitmap are
+// combined (segmented OR scan over the run) and issue ONE atomicOr per run.
+// Called by all 64 lanes.
+__device__ inline bool claimPresence(uint32_t* present, bool active, uint64_t key) {
+  const int ln = lane();
+  const uint64_t word = active ? (key >> 5) : ~static_cast<uint64_t>(ln);  // inactive lanes: runs of their own
+  const uint32_t bit = active ? 1u << (key & 31) : 0u;
+  const uint64_t prevLaneWord = shfl64(word, ln > 0 ? ln - 1 : 0);
+  const bool head = ln == 0 || prevLaneWord != word;
+  const uint64_t heads = ballot(head);
+  const int run = static_cast<int>(popc64(heads & ((2ULL << ln) - 1)));  // 1-based run id, ascending
+  uint32_t incl = bit;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t v = __shfl_up(incl, off, kWave);
+    const int r = __shfl_up(run, off, kWave);
+    if (ln >= off && r == run) {
+      incl |= v;
+    }
+  }
+  const bool tail = ln == 63 || ((heads >> (ln + 1)) & 1);
+  uint32_t prev = 0;
+  if (tail && active) {
+    prev = atomicOr(present + word, incl);
+  }
+  const uint64_t tails = ballot(tail);
+  const int myTail = ln + __ffsll(static_cast<long long>(tails >> ln)) - 1;
+  prev = __shfl(prev, myTail, kWave);
+  const uint32_t before = __shfl_up(incl, 1, kWave);
+  const uint32_t earlier = head ? 0u : before;
+  return active && !((prev | earlier) & bit);
+}
+
 // Array mode never initialises the (possibly multi-GB) head array: phase 1
 // claims each key with one atomicOr on a presence bitmap that is 32x smaller
 // than the head array (and is what the probe consults first), the winner
@@ -288,6 +321,37 @@ __device__ inline bool storedKeysEqual(const InsertArgs& a, int64_t r1, int64_t 
 __global__ __launch_bounds__(256) void k_join_insert(InsertArgs a) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   uint32_t dups = 0, distinct = 0;
+  if (a.mode == JMODE_ARRAY && a.phase == 1) {
+    // whole waves iterate together (claimPresence is a wave-wide operation)
+    const int64_t rounds = (a.numRows + stride - 1) / stride;
+    int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    for (int64_t r = 0; r < rounds; ++r, row += stride) {
+      const bool inRange = row < a.numRows;
+      const bool nullKey = inRange && a.keyNull && a.keyNull[row];
+      const bool active = inRange && !nullKey;
+      const uint64_t key = active ? buildKey(a, row) : 0;
+      const bool first = claimPresence(a.present, active, key);
+      if (nullKey) {
+        a.next[row] = kNoRow32;
+      } else if (active) {
+        if (first) {
+          a.head[key] = static_cast<uint32_t>(row);
+          a.next[row] = kNoRow32;
+          ++distinct;
+        } else {
+          a.next[row] = kPendingRow;
+          ++dups;
+        }
+      }
+    }
+    if (dups) {
+      atomicAdd(&a.counters->duplicates, dups);
+    }
+    if (distinct) {
+      atomicAdd(&a.counters->numDistinct, distinct);
+    }
+    return;
+  }
   for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < a.numRows;
        row += stride) {
     if (a.keyNull && a.keyNull[row]) {
@@ -297,19 +361,7 @@ __global__ __launch_bounds__(256) void k_join_insert(InsertArgs a) {
       continue;
     }
     if (a.mode == JMODE_ARRAY) {
-      if (a.phase == 1) {
-        const uint64_t key = buildKey(a, row);
-        const uint32_t bit = 1u << (key & 31);
-        const uint32_t prev = atomicOr(a.present + (key >> 5), bit);
-        if (!(prev & bit)) {
-          a.head[key] = static_cast<uint32_t>(row);
-          a.next[row] = kNoRow32;
-          ++distinct;
-        } else {
-          a.next[row] = kPendingRow;
-          ++dups;
-        }
-      } else if (a.next[row] == kPendingRow) {
+      if (a.next[row] == kPendingRow) {
         const uint64_t key = buildKey(a, row);
         a.next[row] = atomicExch(a.head + key, static_cast<uint32_t>(row));
       }
@@ -321,7 +373,12 @@ __global__ __launch_bounds__(256) void k_join_insert(InsertArgs a) {
       // is immediately comparable; equal keys are pushed behind the
       // representative (pushNext, HashTable.cpp:1412-1418); next[] was
       // pre-filled with "no row".
-      const uint64_t hash = a.hashStore[row];
+      uint64_t hash = 0;
+      for (int k = 0; k < a.numKeys; ++k) {
+        const int w = a.keyWords[k];
+        const uint64_t hv = hashFromImage(a.keyKind[k], a.keyStore[k][row * w], w == 2 ? a.keyStore[k][row * 2 + 1] : 0);
+        hash = k == 0 ? hv : hashMix(hash, hv);
+      }
       const uint64_t tag = hash >> 32;
       const uint64_t gmask = a.capacity - 1;
       uint64_t pos = hash & gmask;
@@ -439,7 +496,16 @@ struct ProbeArgs {
   int32_t fastKey;      // single non-null BIGINT key (FK of TPC-H joins): 1 flat, 2 dictionary wrapped
   int32_t nullAware;    // null-aware anti join on a non-empty build side: null probe keys produce nothing
   uint8_t* probed;      // right / full / right semi: build rows some probe row matched
+  // Sparse listing (low hit rates): the probe pass itself lists the hits of every
+  // tile, in probe-row order, into staged[tile * kSparseCap ...]; hits[] is only
+  // written for the tiles that overflow the staging segment (tileDense).
+  int64_t tileBegin;    // tiles [tileBegin, numTiles) of this launch
+  uint2* staged;        // {probe row, build row}
+  uint8_t* tileDense;
+  uint64_t* sparseStats;  // [0] overflowed tiles, [1] hits listed (device-visible mailbox)
 };
+
+constexpr int kSparseCap = 1024;  // staged pairs per tile of 8192 probe rows (12.5 % hit rate)
 
 constexpr uint32_t kNullKey32 = 0xfffffffeu;  // hits[]: the probe key holds a null (null-aware anti only)
 
@@ -568,112 +634,216 @@ __device__ inline uint32_t lookupSlots(const ProbeArgs& a, uint64_t key) {
 // output-row count falls out of the same pass (listJoinResults needs it).
 // MODE / FAST >= 0 fix a.mode / a.fastKey at compile time (the array-mode fast
 // paths then need half the registers of the all-purpose instantiation <-1, -1>).
-template <int MODE, int FAST>
-__global__ __launch_bounds__(256) void k_join_probe(ProbeArgs args) {
-  __shared__ uint64_t waveSums[4];
-  const ProbeArgs& a = args;
+//
+// SPARSE (listJoinResultsFastPath for joins that emit matches only and whose
+// chains have one row, HashTable.cpp:2293-2350): instead of writing hits[] for
+// every probe row and scanning it again at output time, the tile's hits are
+// collected in LDS — a bit per row plus an unordered {row, build row} list — and
+// written out once, in probe-row order (rank = popcount prefix of the bitmap).
+// A tile with more than kSparseCap hits falls back to the dense form.
+struct SparseLds {
+  uint32_t bits[kTileRows / 32];
+  uint32_t wordPrefix[kTileRows / 32];
+  unsigned long long list[kSparseCap];
+  uint32_t cursor;
+  uint32_t waveTotals[4];
+};
+
+template <int MODE, int FAST, bool SPARSE>
+__device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, SparseLds* lds) {
   const int mode = MODE >= 0 ? MODE : a.mode;
   const int fastKey = FAST >= 0 ? FAST : a.fastKey;
-  for (int64_t tile = blockIdx.x; tile < a.numTiles; tile += gridDim.x) {
-    const int64_t tileBase = tile * kTileRows;
-    uint64_t mine = 0;
-    for (int it = 0; it < kTileRows / (256 * kProbeUnroll); ++it) {
-      int64_t rows[kProbeUnroll];
-      uint64_t key[kProbeUnroll];
-      bool candidate[kProbeUnroll];
-      uint32_t hit[kProbeUnroll];
+  const int64_t tileBase = tile * kTileRows;
+  uint64_t mine = 0;
+  for (int it = 0; it < kTileRows / (256 * kProbeUnroll); ++it) {
+    int64_t rows[kProbeUnroll];
+    uint64_t key[kProbeUnroll];
+    bool candidate[kProbeUnroll];
+    uint32_t hit[kProbeUnroll];
+#pragma unroll
+    for (int u = 0; u < kProbeUnroll; ++u) {
+      rows[u] = tileBase + (it * kProbeUnroll + u) * 256 + threadIdx.x;
+    }
+    if (fastKey) {
+      const int64_t* kp = static_cast<const int64_t*>(a.keys[0].values);
+      int64_t v[kProbeUnroll];
+      int64_t src[kProbeUnroll];
 #pragma unroll
       for (int u = 0; u < kProbeUnroll; ++u) {
-        rows[u] = tileBase + (it * kProbeUnroll + u) * 256 + threadIdx.x;
+        src[u] = rows[u] < a.numRows ? rows[u] : a.numRows - 1;
       }
-      if (fastKey) {
-        const int64_t* kp = static_cast<const int64_t*>(a.keys[0].values);
-        int64_t v[kProbeUnroll];
-        int64_t src[kProbeUnroll];
+      if (fastKey == 2) {
+        // dictionary-wrapped key (the probe input came through a FilterProject)
 #pragma unroll
         for (int u = 0; u < kProbeUnroll; ++u) {
-          src[u] = rows[u] < a.numRows ? rows[u] : a.numRows - 1;
-        }
-        if (fastKey == 2) {
-          // dictionary-wrapped key (the probe input came through a FilterProject)
-#pragma unroll
-          for (int u = 0; u < kProbeUnroll; ++u) {
-            src[u] = a.keys[0].indices[src[u]];
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < kProbeUnroll; ++u) {
-          v[u] = kp[src[u]];
-        }
-#pragma unroll
-        for (int u = 0; u < kProbeUnroll; ++u) {
-          candidate[u] = rows[u] < a.numRows && v[u] >= a.ranges[0].min && v[u] <= a.ranges[0].max;
-          key[u] = static_cast<uint64_t>(v[u]) - static_cast<uint64_t>(a.ranges[0].min) + 1;
-        }
-      } else if (mode != JMODE_HASH) {
-#pragma unroll
-        for (int u = 0; u < kProbeUnroll; ++u) {
-          candidate[u] = rows[u] < a.numRows && probeKey(a, rows[u], &key[u]);
-        }
-      }
-      if (mode == JMODE_HASH) {
-#pragma unroll
-        for (int u = 0; u < kProbeUnroll; ++u) {
-          hit[u] = rows[u] < a.numRows ? lookupGeneric(a, rows[u]) : kNoRow32;
-        }
-      } else if (mode == JMODE_ARRAY) {
-        uint32_t word[kProbeUnroll];
-#pragma unroll
-        for (int u = 0; u < kProbeUnroll; ++u) {
-          word[u] = candidate[u] ? a.present[key[u] >> 5] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < kProbeUnroll; ++u) {
-          candidate[u] = (word[u] >> (key[u] & 31)) & 1;
-        }
-#pragma unroll
-        for (int u = 0; u < kProbeUnroll; ++u) {
-          hit[u] = candidate[u] ? a.head[key[u]] : kNoRow32;
-        }
-      } else {
-#pragma unroll
-        for (int u = 0; u < kProbeUnroll; ++u) {
-          hit[u] = candidate[u] ? lookupSlots(a, key[u]) : kNoRow32;
+          src[u] = a.keys[0].indices[src[u]];
         }
       }
 #pragma unroll
       for (int u = 0; u < kProbeUnroll; ++u) {
-        if (rows[u] < a.numRows) {
-          bool nullKey = false;
-          if (a.nullAware && hit[u] == kNoRow32) {
-            for (int k = 0; k < a.numKeys; ++k) {
-              nullKey = nullKey || colIsNull(a.keys[k], rows[u]);
-            }
-            if (nullKey) {
-              hit[u] = kNullKey32;
-            }
-          }
-          a.hits[rows[u]] = hit[u];
-          uint32_t matches = isHit(hit[u]) ? 1 : 0;
-          if (matches && a.probed) {
-            // setProbedFlag on every row of the chain (the rows listJoinResults hands out).
-            for (uint32_t r = hit[u]; r != kNoRow32; r = a.next[r]) {
-              a.probed[r] = 1;
-            }
-          }
-          if (a.counts) {
-            if (matches && listsMatches(a.joinType)) {
-              uint32_t r = a.next[hit[u]];
-              while (r != kNoRow32) {
-                ++matches;
-                r = a.next[r];
-              }
-            }
-            a.counts[rows[u]] = outputCount(a.joinType, matches, nullKey);
-          }
-          mine += outputCount(a.joinType, matches, nullKey);
-        }
+        v[u] = kp[src[u]];
       }
+#pragma unroll
+      for (int u = 0; u < kProbeUnroll; ++u) {
+        candidate[u] = rows[u] < a.numRows && v[u] >= a.ranges[0].min && v[u] <= a.ranges[0].max;
+        key[u] = static_cast<uint64_t>(v[u]) - static_cast<uint64_t>(a.ranges[0].min) + 1;
+      }
+    } else if (mode != JMODE_HASH) {
+#pragma unroll
+      for (int u = 0; u < kProbeUnroll; ++u) {
+        candidate[u] = rows[u] < a.numRows && probeKey(a, rows[u], &key[u]);
+      }
+    }
+    if (mode == JMODE_HASH) {
+#pragma unroll
+      for (int u = 0; u < kProbeUnroll; ++u) {
+        hit[u] = rows[u] < a.numRows ? lookupGeneric(a, rows[u]) : kNoRow32;
+      }
+    } else if (mode == JMODE_ARRAY) {
+      uint32_t word[kProbeUnroll];
+#pragma unroll
+      for (int u = 0; u < kProbeUnroll; ++u) {
+        word[u] = candidate[u] ? a.present[key[u] >> 5] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < kProbeUnroll; ++u) {
+        candidate[u] = (word[u] >> (key[u] & 31)) & 1;
+      }
+#pragma unroll
+      for (int u = 0; u < kProbeUnroll; ++u) {
+        hit[u] = candidate[u] ? a.head[key[u]] : kNoRow32;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < kProbeUnroll; ++u) {
+        hit[u] = candidate[u] ? lookupSlots(a, key[u]) : kNoRow32;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kProbeUnroll; ++u) {
+      if (rows[u] < a.numRows) {
+        if constexpr (SPARSE) {
+          // joins that list matches only, chains of one row, not null aware
+          if (hit[u] != kNoRow32) {
+            if (a.probed) {
+              a.probed[hit[u]] = 1;
+            }
+            const uint32_t r = static_cast<uint32_t>(rows[u] - tileBase);
+            atomicOr(&lds->bits[r >> 5], 1u << (r & 31));
+            const uint32_t at = atomicAdd(&lds->cursor, 1u);
+            if (at < kSparseCap) {
+              lds->list[at] = (static_cast<unsigned long long>(r) << 32) | hit[u];
+            }
+            ++mine;
+          }
+          continue;
+        }
+        bool nullKey = false;
+        if (a.nullAware && hit[u] == kNoRow32) {
+          for (int k = 0; k < a.numKeys; ++k) {
+            nullKey = nullKey || colIsNull(a.keys[k], rows[u]);
+          }
+          if (nullKey) {
+            hit[u] = kNullKey32;
+          }
+        }
+        a.hits[rows[u]] = hit[u];
+        uint32_t matches = isHit(hit[u]) ? 1 : 0;
+        if (matches && a.probed) {
+          // setProbedFlag on every row of the chain (the rows listJoinResults hands out).
+          for (uint32_t r = hit[u]; r != kNoRow32; r = a.next[r]) {
+            a.probed[r] = 1;
+          }
+        }
+        if (a.counts) {
+          if (matches && listsMatches(a.joinType)) {
+            uint32_t r = a.next[hit[u]];
+            while (r != kNoRow32) {
+              ++matches;
+              r = a.next[r];
+            }
+          }
+          a.counts[rows[u]] = outputCount(a.joinType, matches, nullKey);
+        }
+        mine += outputCount(a.joinType, matches, nullKey);
+      }
+    }
+  }
+  return mine;
+}
+
+template <int MODE, int FAST, bool SPARSE>
+__global__ __launch_bounds__(256) void k_join_probe(ProbeArgs args) {
+  __shared__ uint64_t waveSums[4];
+  __shared__ __attribute__((aligned(16))) unsigned char sparseRaw[SPARSE ? sizeof(SparseLds) : 16];
+  const ProbeArgs& a = args;
+  SparseLds* lds = reinterpret_cast<SparseLds*>(sparseRaw);
+  if constexpr (SPARSE) {
+    for (int i = threadIdx.x; i < kTileRows / 32; i += 256) {
+      lds->bits[i] = 0;
+    }
+    if (threadIdx.x == 0) {
+      lds->cursor = 0;
+    }
+    blockSync();
+  }
+  for (int64_t tile = a.tileBegin + blockIdx.x; tile < a.numTiles; tile += gridDim.x) {
+    uint64_t mine = probeTileBody<MODE, FAST, SPARSE>(a, tile, lds);
+    if constexpr (SPARSE) {
+      blockSync();
+      const uint32_t k = lds->cursor;
+      if (k <= kSparseCap) {  // uniform: cursor is shared
+        // rank of a hit = number of hits on earlier rows of the tile
+        const uint32_t w = lds->bits[threadIdx.x];
+        const uint32_t c = static_cast<uint32_t>(__popc(w));
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t o = __shfl_up(incl, off, kWave);
+          if (lane() >= off) {
+            incl += o;
+          }
+        }
+        if (lane() == 63) {
+          lds->waveTotals[threadIdx.x >> 6] = incl;
+        }
+        blockSync();
+        uint32_t before = incl - c;
+        for (int wv = 0; wv < (threadIdx.x >> 6); ++wv) {
+          before += lds->waveTotals[wv];
+        }
+        lds->wordPrefix[threadIdx.x] = before;
+        blockSync();
+        uint2* out = a.staged + tile * kSparseCap;
+        for (uint32_t i = threadIdx.x; i < k; i += 256) {
+          const unsigned long long e = lds->list[i];
+          const uint32_t r = static_cast<uint32_t>(e >> 32);
+          const uint32_t rank = lds->wordPrefix[r >> 5] + __popc(lds->bits[r >> 5] & ((1u << (r & 31)) - 1));
+          out[rank] = make_uint2(static_cast<uint32_t>(tile * kTileRows + r), static_cast<uint32_t>(e));
+        }
+        blockSync();
+        lds->bits[threadIdx.x] = 0;
+        if (threadIdx.x == 0) {
+          lds->cursor = 0;
+          a.tileSums[tile] = k;
+          a.tileDense[tile] = 0;
+          if (k) {
+            atomicAdd(reinterpret_cast<unsigned long long*>(a.sparseStats + 1), static_cast<unsigned long long>(k));
+          }
+        }
+        blockSync();
+        continue;
+      }
+      // More hits than the staging segment holds: redo the tile in the dense form
+      // (hits[] for every row); the output pass scans it like a dense tile.
+      lds->bits[threadIdx.x] = 0;
+      if (threadIdx.x == 0) {
+        lds->cursor = 0;
+        a.tileDense[tile] = 1;
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.sparseStats), 1ULL);
+      }
+      blockSync();
+      mine = probeTileBody<MODE, FAST, false>(a, tile, lds);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -691,32 +861,61 @@ __global__ __launch_bounds__(256) void k_join_probe(ProbeArgs args) {
 }
 
 // ---- listJoinResults -------------------------------------------------------------------
-// Single-block exclusive scan; offsets has n + 1 entries (last = total).
+// Single-block exclusive scan; offsets has n + 1 entries (last = total). 4096
+// cells per iteration: coalesced loads of four consecutive cells per lane, wave
+// scans with shuffles, one LDS exchange of the 16 wave totals.
 __global__ __launch_bounds__(1024) void k_scan_u64(const uint64_t* in, int64_t n, uint64_t* offsets) {
-  __shared__ uint64_t partial[1024];
+  __shared__ uint64_t waveTotal[16];
+  __shared__ uint64_t carryShared;
   const int t = threadIdx.x;
-  const int64_t per = (n + blockDim.x - 1) / blockDim.x;
-  const int64_t begin = t * per;
-  const int64_t end = begin + per < n ? begin + per : n;
-  uint64_t sum = 0;
-  for (int64_t i = begin; i < end; ++i) {
-    sum += in[i];
+  const int wave = t >> 6;
+  if (t == 0) {
+    carryShared = 0;
   }
-  partial[t] = sum;
   blockSync();
-  for (int off = 1; off < 1024; off <<= 1) {
-    uint64_t v = t >= off ? partial[t - off] : 0;
+  for (int64_t base = 0; base < n; base += 4096) {
+    const int64_t i0 = base + static_cast<int64_t>(t) * 4;
+    uint64_t v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = i0 + k < n ? in[i0 + k] : 0;
+    }
+    const uint64_t mine = v[0] + v[1] + v[2] + v[3];
+    uint64_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint64_t o = shfl64(incl, lane() >= off ? lane() - off : lane());
+      if (lane() >= off) {
+        incl += o;
+      }
+    }
+    if (lane() == 63) {
+      waveTotal[wave] = incl;
+    }
     blockSync();
-    partial[t] += v;
+    uint64_t run = carryShared + (incl - mine);
+    uint64_t total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const uint64_t wt = waveTotal[w];
+      run += w < wave ? wt : 0;
+      total += wt;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (i0 + k < n) {
+        offsets[i0 + k] = run;
+      }
+      run += v[k];
+    }
+    blockSync();
+    if (t == 0) {
+      carryShared += total;
+    }
     blockSync();
   }
-  uint64_t run = t == 0 ? 0 : partial[t - 1];
-  for (int64_t i = begin; i < end; ++i) {
-    offsets[i] = run;
-    run += in[i];
-  }
-  if (t == blockDim.x - 1) {
-    offsets[n] = partial[1023];
+  if (t == 0) {
+    offsets[n] = carryShared;
   }
 }
 
@@ -732,6 +931,8 @@ struct EmitArgs {
   int32_t joinType;
   int32_t* mapping;
   int32_t* buildRows;
+  const uint2* staged;       // sparse listing: {probe row, build row} per tile, kSparseCap apart
+  const uint8_t* tileDense;  // tiles that fell back to hits[]
 };
 
 // Each block owns one tile of probe rows and walks it in 256-row steps: a block
@@ -743,6 +944,23 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
   __shared__ uint64_t waveTotals[4];
   __shared__ uint64_t running;
   const int64_t tile = a.firstTile + blockIdx.x;
+  if (a.staged && !a.tileDense[tile]) {
+    // The probe pass already listed this tile's hits in probe-row order.
+    const uint64_t off = a.tileOffsets[tile];
+    const uint64_t k = a.tileOffsets[tile + 1] - off;
+    const bool wantBuild = listsMatches(a.joinType);
+    for (uint64_t i = threadIdx.x; i < k; i += blockDim.x) {
+      const uint64_t pos = off + i;
+      if (pos >= a.windowBegin && pos < a.windowEnd) {
+        const uint2 pair = a.staged[tile * kSparseCap + i];
+        a.mapping[pos - a.windowBegin] = static_cast<int32_t>(pair.x);
+        if (a.buildRows) {
+          a.buildRows[pos - a.windowBegin] = wantBuild ? static_cast<int32_t>(pair.y) : -1;
+        }
+      }
+    }
+    return;
+  }
   if (a.counts == nullptr) {
     // Every probe row produces 0 or 1 output rows: ballot compaction. Each wave
     // owns 2048 consecutive rows of the tile; one pass counts, one block-level
@@ -946,7 +1164,6 @@ struct vx355_join_build {
   std::vector<int32_t> usedCols;
   int32_t joinType = 0;
   std::vector<DevBuf> keyVals;   // key images per row: 1 word, 2 for strings / timestamps
-  DevBuf hashStore;              // VectorHasher hash per row
   bool unmappable = false;       // some key has no 64-bit normalized form
   std::vector<DevBuf> depVals;   // width bytes per row (BOOLEAN: 1 byte)
   std::vector<DevBuf> depValid;  // 1 byte per row
@@ -993,6 +1210,11 @@ struct vx355_join_probe {
   std::vector<int32_t> keyCols;
   int32_t joinType = 0;
   DevBuf hits, counts, tileSums, tileOffsets, scratch, outMap, outRows;
+  DevBuf staged, tileDense;  // sparse listing (probeAddInput)
+  bool sparse = false;
+  int32_t sparseMode = -1;   // VX355_JOIN_SPARSE: -1 adaptive, 0 never, 1 always
+  int64_t sparseTiles = 0;   // statistics of the last batch: tiles listed by the probe pass
+  int64_t denseTiles = 0;
   std::vector<uint64_t> hostTileOffsets;
   int64_t numRows = 0;
   int64_t numTiles = 0;
@@ -1027,7 +1249,6 @@ void growBuild(vx355_join_build& h, int64_t rows) {
     const size_t w = static_cast<size_t>(keyWordsOf(h.keyKinds[k])) * 8;
     h.keyVals[k].ensure(static_cast<size_t>(cap) * w + 64, true, static_cast<size_t>(h.numRows) * w);
   }
-  h.hashStore.ensure(static_cast<size_t>(cap) * 8 + 64, true, static_cast<size_t>(h.numRows) * 8);
   if (keepsNullKeyRows(h.joinType)) {
     h.keyNull.ensure(static_cast<size_t>(cap) + 64, true, static_cast<size_t>(h.numRows));
   }
@@ -1071,15 +1292,21 @@ void buildAddInput(vx355_join_build& h, const vx355_batch* batch) {
     va.keys[k] = db.col(h.keyCols[k]);
   }
   va.numRows = n;
-  va.validWords = static_cast<uint64_t*>(h.validWords.ensure(static_cast<size_t>(words) * 8 + 64));
-  va.counters = ctr;
-  VX_LAUNCH("k_key_valid", k_key_valid, streamGrid(words * 64, 256), 256, 0, va);
+  bool anyKeyNulls = false;
+  for (int k = 0; k < va.numKeys; ++k) {
+    anyKeyNulls = anyKeyNulls || va.keys[k].nulls != nullptr;
+  }
   const bool keepNulls = keepsNullKeyRows(h.joinType);
   int32_t* rows = nullptr;
   int64_t selected = n;
-  if (!keepNulls) {
-    rows = static_cast<int32_t*>(h.rowList.ensure(static_cast<size_t>(n) * 4 + 64));
-    compactBits(va.validWords, nullptr, nullptr, n, rows, h.scratch, &selected);
+  if (anyKeyNulls) {  // key columns without null bitmaps (the common case) skip both passes
+    va.validWords = static_cast<uint64_t*>(h.validWords.ensure(static_cast<size_t>(words) * 8 + 64));
+    va.counters = ctr;
+    VX_LAUNCH("k_key_valid", k_key_valid, streamGrid(words * 64, 256), 256, 0, va);
+    if (!keepNulls) {
+      rows = static_cast<int32_t*>(h.rowList.ensure(static_cast<size_t>(n) * 4 + 64));
+      compactBits(va.validWords, nullptr, nullptr, n, rows, h.scratch, &selected);
+    }
   }
   if (selected > 0) {
     growBuild(h, h.numRows + selected);
@@ -1091,7 +1318,6 @@ void buildAddInput(vx355_join_build& h, const vx355_batch* batch) {
       aa.keyOut[k] = h.keyVals[k].as<uint64_t>();
       aa.keyWords[k] = keyWordsOf(h.keyKinds[k]);
     }
-    aa.hashOut = h.hashStore.as<uint64_t>();
     for (int d = 0; d < aa.numDeps; ++d) {
       aa.deps[d] = db.col(h.depCols[d]);
       aa.depOut[d] = h.depVals[d].as<char>();
@@ -1103,7 +1329,7 @@ void buildAddInput(vx355_join_build& h, const vx355_batch* batch) {
     aa.base = h.numRows;
     aa.counters = ctr;
     if (keepNulls) {
-      aa.keyValidWords = va.validWords;
+      aa.keyValidWords = anyKeyNulls ? va.validWords : nullptr;
       aa.keyNullOut = h.keyNull.as<uint8_t>();
     }
     VX_LAUNCH("k_build_append", k_build_append, streamGrid(selected, 256), 256, 0, aa);
@@ -1153,8 +1379,6 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
         copyIn(h.keyVals[k].as<char>() + h.numRows * w, o.keyVals[k].ptr(), VX355_MEM_DEVICE,
                static_cast<size_t>(o.numRows) * w);
       }
-      copyIn(h.hashStore.as<char>() + h.numRows * 8, o.hashStore.ptr(), VX355_MEM_DEVICE,
-             static_cast<size_t>(o.numRows) * 8);
       if (keepsNullKeyRows(h.joinType)) {
         copyIn(h.keyNull.as<char>() + h.numRows, o.keyNull.ptr(), VX355_MEM_DEVICE, static_cast<size_t>(o.numRows));
       }
@@ -1229,9 +1453,9 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
     ia.keyStore[k] = h.keyVals[k].as<uint64_t>();
     ia.keyWords[k] = keyWordsOf(h.keyKinds[k]);
     ia.keyIsString[k] = isString(h.keyKinds[k]) ? 1 : 0;
+    ia.keyKind[k] = h.keyKinds[k];
     ia.ranges[k] = t->ranges[k];
   }
-  ia.hashStore = h.hashStore.as<uint64_t>();
   ia.numRows = h.numRows;
   if (keepsNullKeyRows(h.joinType) && h.hasNullKeys) {
     ia.keyNull = h.keyNull.as<uint8_t>();
@@ -1368,23 +1592,73 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
       a.ranges[0].multiplier == 1) {
     a.fastKey = a.keys[0].enc == VX355_FLAT ? 1 : (a.keys[0].enc == VX355_DICTIONARY ? 2 : 0);
   }
-  const int grid = static_cast<int>(std::min<int64_t>(p.numTiles, static_cast<int64_t>(rt.numCUs) * 8));
-  if (t.mode == JMODE_ARRAY && a.fastKey == 1) {
-    VX_LAUNCH("k_join_probe", (k_join_probe<JMODE_ARRAY, 1>), grid, 256, 0, a);
-  } else if (t.mode == JMODE_ARRAY && a.fastKey == 2) {
-    VX_LAUNCH("k_join_probe", (k_join_probe<JMODE_ARRAY, 2>), grid, 256, 0, a);
-  } else if (t.mode == JMODE_NORMALIZED && a.fastKey == 1) {
-    VX_LAUNCH("k_join_probe", (k_join_probe<JMODE_NORMALIZED, 1>), grid, 256, 0, a);
-  } else if (t.mode == JMODE_ARRAY) {
-    VX_LAUNCH("k_join_probe", (k_join_probe<JMODE_ARRAY, 0>), grid, 256, 0, a);
+  auto launch = [&](auto sparseTag, int64_t tileBegin, int64_t tileEnd) {
+    constexpr bool SP = decltype(sparseTag)::value;
+    ProbeArgs la = a;
+    la.tileBegin = tileBegin;
+    la.numTiles = tileEnd;
+    const int grid =
+        static_cast<int>(std::min<int64_t>(tileEnd - tileBegin, static_cast<int64_t>(rt.numCUs) * 8));
+    if (grid <= 0) {
+      return;
+    }
+    // profile names: "k_join_probe" writes hits[] for k_emit, "k_join_probe_list" also lists the hits
+    const char* name = SP ? "k_join_probe_list" : "k_join_probe";
+    if (t.mode == JMODE_ARRAY && a.fastKey == 1) {
+      VX_LAUNCH(name, (k_join_probe<JMODE_ARRAY, 1, SP>), grid, 256, 0, la);
+    } else if (t.mode == JMODE_ARRAY && a.fastKey == 2) {
+      VX_LAUNCH(name, (k_join_probe<JMODE_ARRAY, 2, SP>), grid, 256, 0, la);
+    } else if (t.mode == JMODE_NORMALIZED && a.fastKey == 1) {
+      VX_LAUNCH(name, (k_join_probe<JMODE_NORMALIZED, 1, SP>), grid, 256, 0, la);
+    } else if (t.mode == JMODE_ARRAY) {
+      VX_LAUNCH(name, (k_join_probe<JMODE_ARRAY, 0, SP>), grid, 256, 0, la);
+    } else {
+      VX_LAUNCH(name, (k_join_probe<-1, -1, SP>), grid, 256, 0, la);
+    }
+  };
+  // Sparse listing: joins that emit matches only, one build row per match, not null
+  // aware. Whether the hit rate is low enough is measured on the first tiles of the
+  // batch (the probe pass reports tiles that overflowed their staging segment).
+  const bool sparseEligible = p.sparseMode != 0 && !p.haveCounts && !a.nullAware &&
+      (p.joinType == VX355_JOIN_INNER || p.joinType == VX355_JOIN_LEFT_SEMI_FILTER ||
+       (p.joinType == VX355_JOIN_RIGHT && !t.hasDuplicates));
+  p.sparse = false;
+  p.sparseTiles = p.denseTiles = 0;
+  if (sparseEligible) {
+    a.staged = static_cast<uint2*>(p.staged.ensure(static_cast<size_t>(p.numTiles) * kSparseCap * sizeof(uint2) + 64));
+    a.tileDense = static_cast<uint8_t*>(p.tileDense.ensure(static_cast<size_t>(p.numTiles) + 64));
+    a.sparseStats = rt.mail.dev;
+    rt.mail.host[0] = 0;
+    rt.mail.host[1] = 0;
+    const int64_t sample = p.sparseMode == 1 ? p.numTiles : std::min<int64_t>(p.numTiles, 256);
+    launch(std::true_type{}, 0, sample);
+    p.sparse = true;
+    if (sample < p.numTiles) {
+      rt.sync();
+      const uint64_t overflowed = rt.mail.host[0];
+      // dense when more than 1 tile in 16 overflowed or the average tile is half full
+      const bool stay = overflowed * 16 <= static_cast<uint64_t>(sample) &&
+          rt.mail.host[1] <= static_cast<uint64_t>(sample) * (kSparseCap / 2);
+      if (stay) {
+        launch(std::true_type{}, sample, p.numTiles);
+      } else {
+        HIP_OK(hipMemsetAsync(a.tileDense + sample, 1, static_cast<size_t>(p.numTiles - sample), rt.stream));
+        launch(std::false_type{}, sample, p.numTiles);
+        p.denseTiles = p.numTiles - sample;
+      }
+    }
   } else {
-    VX_LAUNCH("k_join_probe", (k_join_probe<-1, -1>), grid, 256, 0, a);
+    launch(std::false_type{}, 0, p.numTiles);
   }
   VX_LAUNCH("k_scan_u64", k_scan_u64, 1, 1024, 0, sums, p.numTiles, offs);
   p.hostTileOffsets.resize(p.numTiles + 1);
   copyOut(p.hostTileOffsets.data(), VX355_MEM_HOST, offs, static_cast<size_t>(p.numTiles + 1) * 8);
   rt.sync();
   p.totalOut = p.hostTileOffsets.back();
+  if (p.sparse) {
+    p.denseTiles += static_cast<int64_t>(rt.mail.host[0]);
+    p.sparseTiles = p.numTiles - p.denseTiles;
+  }
 }
 
 // extractColumns for 'n' listed build rows (-1 = null row) into caller columns.
@@ -1475,6 +1749,8 @@ void probeGetOutput(vx355_join_probe& p, int32_t maxRows, int32_t* mappingOut, i
   ea.joinType = p.joinType;
   ea.mapping = dMap;
   ea.buildRows = dRows;
+  ea.staged = p.sparse ? p.staged.as<uint2>() : nullptr;
+  ea.tileDense = p.sparse ? p.tileDense.as<uint8_t>() : nullptr;
   VX_LAUNCH("k_emit", k_emit, static_cast<int>(lastTile - firstTile + 1), 256, 0, ea);
 
   if (numBuildCols > 0) {
@@ -1829,6 +2105,12 @@ int vx355_join_probe_create(vx355_join_table* table, const vx355_join_probe_spec
   vx355_join_table_retain(table);
   p->joinType = spec->join_type;
   p->nullAware = spec->null_aware != 0;
+  if (const char* e = std::getenv("VX355_JOIN_SPARSE")) {
+    p->sparseMode = std::atoi(e);  // 0 never, 1 always, otherwise adaptive
+    if (p->sparseMode != 0 && p->sparseMode != 1) {
+      p->sparseMode = -1;
+    }
+  }
   p->keyCols.assign(spec->key_cols, spec->key_cols + spec->num_keys);
   *out = p.release();
   VX_API_END
