@@ -429,11 +429,15 @@ void* vx355_agg_stream(vx355_agg* h);
 
 /* ---- HashBuild / HashProbe (exec/HashBuild.h, exec/HashProbe.h) --------- */
 
-/* core::JoinType (core/PlanNode.h:3081-3165), same values. Device support in
- * this version, all without an extra filter: INNER, LEFT, RIGHT, FULL,
- * LEFT_SEMI_FILTER, LEFT_SEMI_PROJECT (not null aware), RIGHT_SEMI_FILTER, ANTI
- * (null aware or not); others return VX355_EUNSUPPORTED at create. Build and
- * probe must be created with the same join type. */
+/* core::JoinType (core/PlanNode.h:3081-3165), same values. All twelve kinds run
+ * on the device. Null-aware semantics (HashJoinNode::isNullAware) are supported
+ * for ANTI without an extra filter only; null-aware LEFT / RIGHT_SEMI_PROJECT and
+ * isNullAsValue return VX355_EUNSUPPORTED at create. An extra join filter
+ * (vx355_join_probe_set_filter) works with every kind except the two counting
+ * ones (the reference has none there either, HashProbe.cpp:1345-1365). Build and
+ * probe must be created with the same join type. Counting joins keep one
+ * remaining-count per distinct build key in the table: probe them from one
+ * thread at a time. */
 typedef enum vx355_join_type {
   VX355_JOIN_INNER = 0,
   VX355_JOIN_LEFT = 1,
@@ -546,6 +550,33 @@ int vx355_join_probe_create(
     vx355_join_table* table,
     const vx355_join_probe_spec* spec,
     vx355_join_probe** out);
+
+/* The join's extra filter (HashJoinNode::filter, evaluated by HashProbe::evalFilter,
+ * exec/HashProbe.cpp:1713, on every (probe row, build row) candidate pair): a
+ * conjunction of up to 4 comparisons between a probe column or a build-side
+ * dependent column and a constant, a probe column or a build dependent. A null
+ * operand fails the term. Integer-like and DATE columns compare as int64 (as
+ * DOUBLE against REAL / DOUBLE), VARCHAR / VARBINARY (inline, <= 12 bytes) with
+ * EQ / NE only. Semantics per join kind (HashProbe.cpp:1487-1711): INNER / RIGHT
+ * keep the passing pairs; LEFT / FULL emit (row, null) when no pair of the row
+ * passes; the semi kinds ask "does any pair pass", ANTI "does none"; probed flags
+ * (right / full / right semi / right anti) are set for passing pairs only.
+ * Call before the first add_input; the probe batch must stay alive until its
+ * output is drained (the filter reads its columns at output time). */
+typedef struct vx355_join_filter_term {
+  int32_t left_side;  /* 0 = probe batch column, 1 = build dependent (index into dependent_cols) */
+  int32_t left_col;
+  int32_t cmp;        /* vx355_cmp */
+  int32_t right_kind; /* 0 = constant, 1 = probe batch column, 2 = build dependent */
+  int32_t right_col;
+  int32_t const_kind; /* as vx355_filter_term */
+  int32_t str_size;
+  int32_t pad;
+  int64_t i64;
+  double f64;
+  char str[16];
+} vx355_join_filter_term;
+int vx355_join_probe_set_filter(vx355_join_probe* h, const vx355_join_filter_term* terms, int32_t n_terms);
 /* HashProbe::addInput (exec/HashProbe.cpp:796-900): prepareForJoinProbe
  * (HashTable.cpp:2680-2712) + joinProbe (:610-652) for the whole batch. */
 int vx355_join_probe_add_input(vx355_join_probe* h, const vx355_batch* batch);
@@ -570,14 +601,17 @@ int vx355_join_probe_get_output(
     int32_t* n_out,
     int32_t* finished);
 /* HashProbe::getBuildSideOutput (exec/HashProbe.cpp:993-1080): the build rows a
- * RIGHT / FULL join has to emit with null probe columns (listNotProbedRows: no
- * probe of ANY vx355_join_probe of this table matched them, rows with null keys
- * included), or the matched ones for RIGHT_SEMI_FILTER (listProbedRows), in
- * ascending build-row order, max_rows at a time. Call it on ONE probe handle
+ * RIGHT / FULL / RIGHT_ANTI join has to emit (listNotProbedRows: no probe of ANY
+ * vx355_join_probe of this table matched them, rows with null keys included),
+ * the matched ones for RIGHT_SEMI_FILTER (listProbedRows), or every build row
+ * for RIGHT_SEMI_PROJECT (listAllRows) whose 'match' column is requested as
+ * build column id VX355_BUILD_COL_MATCH (BOOLEAN, never null: not null aware),
+ * in ascending build-row order, max_rows at a time. Call it on ONE probe handle
  * (the reference's last prober, HashProbe.cpp:1189-1219) after every probe of
  * the table has consumed its input. LEFT_SEMI_PROJECT needs no such call: its
  * get_output lists every probe row once with build_rows_out = first match or -1
  * (the shim's 'match' column is build_rows_out >= 0). */
+#define VX355_BUILD_COL_MATCH (-1)
 int vx355_join_probe_get_build_side_output(
     vx355_join_probe* h,
     int32_t max_rows,

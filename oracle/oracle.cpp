@@ -4,6 +4,8 @@
 #include "oracle.h"
 
 #include <cmath>
+#include <map>
+#include <string>
 #include <cstdio>
 
 #include "table.h"
@@ -504,7 +506,9 @@ class JoinBuild {
     }
     // Null keys never match: drop them, except for right / full joins whose
     // build rows all reach the output (HashBuild.cpp:475-494).
-    const bool keepNullKeys = joinType_ == VX355_JOIN_RIGHT || joinType_ == VX355_JOIN_FULL;
+    // (HashBuild.cpp:257-268: right, full, right semi project and right anti retain null keys)
+    const bool keepNullKeys = joinType_ == VX355_JOIN_RIGHT || joinType_ == VX355_JOIN_FULL ||
+        joinType_ == VX355_JOIN_RIGHT_SEMI_PROJECT || joinType_ == VX355_JOIN_RIGHT_ANTI;
     for (auto& d : keys) {
       for (int32_t r = 0; r < n; ++r) {
         if (d.isNull(r)) {
@@ -545,6 +549,9 @@ struct JoinTable {
   // RowContainer probed flags (RowContainer.h probedFlagOffset_), by row id; set by every
   // probe of the table, read by the last one (HashProbe::getBuildSideOutput).
   std::vector<uint8_t> probed;
+  // Counting joins (HashBuild.cpp:534-548, RowContainer::count): occurrences of each distinct
+  // key not yet consumed by a probe row, by chain head; filled on first use.
+  std::map<char*, int64_t> remaining;
 
   char* rowById(int64_t id) const {
     size_t c = containers.size() - 1;
@@ -566,8 +573,10 @@ class JoinProbe {
   // HashProbe::addInput (HashProbe.cpp:796-900).
   void addInput(const vx355_batch& batch) {
     numRows_ = batch.num_rows;
+    batch_ = &batch;
     cursorRow_ = 0;
     cursorChain_ = nullptr;
+    chainOpen_ = false;
     keys_.clear();
     for (auto c : keyCols_) {
       keys_.emplace_back(&batch.cols[c]);
@@ -584,29 +593,51 @@ class JoinProbe {
     table_->table->joinProbe(lookup_, keys_);
   }
 
-  // HashTable::listJoinResults (HashTable.cpp:2133-2350): pairs in ascending
-  // probe-row order, all matches of one probe row contiguous, resumable.
+  // HashJoinNode::filter as a conjunction of vx355_join_filter_term (include/vx355.h).
+  void setFilter(const vx355_join_filter_term* terms, int32_t n) { filter_.assign(terms, terms + n); }
+
+  // HashTable::listJoinResults (HashTable.cpp:2133-2350) + HashProbe::evalFilter and the
+  // per-join-kind bookkeeping around it (HashProbe.cpp:1276-1437,1487-1711), row at a time:
+  // pairs in ascending probe-row order, all matches of one probe row contiguous, resumable.
   void getOutput(int32_t maxRows, int32_t* mapping, int32_t* buildRows, vx355_out_column* cols,
                  const int32_t* colIds, int32_t numCols, int32_t* nOut, int32_t* finished) {
     int32_t n = 0;
     const bool includeMisses = joinType_ == VX355_JOIN_LEFT || joinType_ == VX355_JOIN_FULL;
-    const bool marksProbed = joinType_ == VX355_JOIN_RIGHT || joinType_ == VX355_JOIN_FULL ||
-        joinType_ == VX355_JOIN_RIGHT_SEMI_FILTER;
+    const bool marksProbed = joinType_ == VX355_JOIN_RIGHT || joinType_ == VX355_JOIN_FULL;
+    const bool buildSideOnly = joinType_ == VX355_JOIN_RIGHT_SEMI_FILTER ||
+        joinType_ == VX355_JOIN_RIGHT_SEMI_PROJECT || joinType_ == VX355_JOIN_RIGHT_ANTI;
     while (cursorRow_ < numRows_ && n < maxRows) {
       char* hit = lookup_.hits[cursorRow_];
-      if (joinType_ == VX355_JOIN_RIGHT_SEMI_FILTER) {
-        // processRightSemiNoFilter: no probe-side output, only the probed flags.
+      if (buildSideOnly) {
+        // processRightSemiNoFilter and friends: no probe-side output, only the probed flags
+        // of the build rows a probe row matches (with the filter: of the passing pairs).
         for (char* cur = hit; cur; cur = table_->table->nextRow(cur)) {
-          table_->probed[rowId(cur)] = 1;
+          if (passes(cursorRow_, cur)) {
+            table_->probed[rowId(cur)] = 1;
+          }
         }
         ++cursorRow_;
         continue;
       }
-      if (joinType_ == VX355_JOIN_LEFT_SEMI_PROJECT) {
-        // Every probe row once; the match column is "hit != null" (not null aware).
-        emit(n++, cursorRow_, nullptr, mapping, buildRows, cols, colIds, numCols);
-        if (buildRows) {
-          buildRows[n - 1] = hit ? static_cast<int32_t>(rowId(hit)) : -1;
+      if (joinType_ == VX355_JOIN_COUNTING_LEFT_SEMI_FILTER || joinType_ == VX355_JOIN_COUNTING_ANTI) {
+        // HashProbe.cpp:1345-1365: a match consumes one occurrence of the key while any is left.
+        bool consumed = false;
+        if (hit) {
+          auto it = table_->remaining.find(hit);
+          if (it == table_->remaining.end()) {
+            int64_t count = 0;
+            for (char* cur = hit; cur; cur = table_->table->nextRow(cur)) {
+              ++count;
+            }
+            it = table_->remaining.emplace(hit, count).first;
+          }
+          if (it->second > 0) {
+            --it->second;
+            consumed = true;
+          }
+        }
+        if (consumed == (joinType_ == VX355_JOIN_COUNTING_LEFT_SEMI_FILTER)) {
+          emit(n++, cursorRow_, nullptr, mapping, buildRows, cols, colIds, numCols);
         }
         ++cursorRow_;
         continue;
@@ -634,64 +665,86 @@ class JoinProbe {
         ++cursorRow_;
         continue;
       }
-      if (joinType_ == VX355_JOIN_ANTI) {
-        // Not null aware: rows without a match, including rows with null keys
-        // (core/PlanNode.h:3147-3150).
-        if (!hit) {
+      if (joinType_ == VX355_JOIN_LEFT_SEMI_PROJECT || joinType_ == VX355_JOIN_ANTI ||
+          joinType_ == VX355_JOIN_LEFT_SEMI_FILTER) {
+        // One output row at most: "does any pair of this probe row pass?" (rows with null keys
+        // have no pair: regular anti returns them, core/PlanNode.h:3147-3150).
+        char* first = nullptr;
+        for (char* cur = hit; cur && !first; cur = table_->table->nextRow(cur)) {
+          if (passes(cursorRow_, cur)) {
+            first = cur;
+          }
+        }
+        if (joinType_ == VX355_JOIN_LEFT_SEMI_PROJECT) {
+          // every probe row once; the match column is "first != null" (not null aware)
+          emit(n++, cursorRow_, nullptr, mapping, buildRows, cols, colIds, numCols);
+          if (buildRows) {
+            buildRows[n - 1] = first ? static_cast<int32_t>(rowId(first)) : -1;
+          }
+        } else if ((first != nullptr) == (joinType_ == VX355_JOIN_LEFT_SEMI_FILTER)) {
           emit(n++, cursorRow_, nullptr, mapping, buildRows, cols, colIds, numCols);
         }
         ++cursorRow_;
         continue;
       }
-      if (joinType_ == VX355_JOIN_LEFT_SEMI_FILTER) {
-        if (hit) {
-          emit(n++, cursorRow_, nullptr, mapping, buildRows, cols, colIds, numCols);
-        }
-        ++cursorRow_;
-        continue;
+      // inner / left / right / full: list the passing pairs of the chain
+      char* cur = cursorChain_;
+      if (!chainOpen_) {
+        cur = hit;
+        chainOpen_ = true;
+        anyPass_ = false;
       }
-      if (!hit) {
-        if (includeMisses) {
-          emit(n++, cursorRow_, nullptr, mapping, buildRows, cols, colIds, numCols);
-        }
-        ++cursorRow_;
-        continue;
-      }
-      char* cur = cursorChain_ ? cursorChain_ : hit;
       while (cur && n < maxRows) {
-        emit(n++, cursorRow_, cur, mapping, buildRows, cols, colIds, numCols);
-        if (marksProbed) {
-          table_->probed[rowId(cur)] = 1;
+        if (passes(cursorRow_, cur)) {
+          emit(n++, cursorRow_, cur, mapping, buildRows, cols, colIds, numCols);
+          anyPass_ = true;
+          if (marksProbed) {
+            table_->probed[rowId(cur)] = 1;
+          }
         }
         cur = table_->table->nextRow(cur);
       }
       if (cur) {
-        cursorChain_ = cur;
-      } else {
-        cursorChain_ = nullptr;
-        ++cursorRow_;
+        cursorChain_ = cur;  // output page full in the middle of the chain
+        break;
       }
+      cursorChain_ = nullptr;
+      if (!anyPass_ && includeMisses) {
+        if (n >= maxRows) {
+          break;  // the miss row opens the next page (NoMatchDetector's carried-over row)
+        }
+        emit(n++, cursorRow_, nullptr, mapping, buildRows, cols, colIds, numCols);
+      }
+      chainOpen_ = false;
+      ++cursorRow_;
     }
     *nOut = n;
     *finished = cursorRow_ >= numRows_;
   }
 
   // HashProbe::getBuildSideOutput (HashProbe.cpp:993-1080), called by the last prober after
-  // all probe input: right / full joins list the build rows no probe matched
-  // (listNotProbedRows), right semi filter the matched ones (listProbedRows); container
-  // order = ascending row id. Probe-side columns of these rows are null.
+  // all probe input: right / full / right anti joins list the build rows no probe matched
+  // (listNotProbedRows), right semi filter the matched ones (listProbedRows), right semi
+  // project every row with its probed flag as the 'match' column (listAllRows +
+  // extractProbedFlags; column id VX355_BUILD_COL_MATCH); container order = ascending row id.
   void getBuildSideOutput(int32_t maxRows, int32_t* buildRows, vx355_out_column* cols, const int32_t* colIds,
                           int32_t numCols, int32_t* nOut, int32_t* finished) {
     const bool wantProbed = joinType_ == VX355_JOIN_RIGHT_SEMI_FILTER;
+    const bool all = joinType_ == VX355_JOIN_RIGHT_SEMI_PROJECT;
     int32_t n = 0;
     while (buildCursor_ < table_->numRows && n < maxRows) {
-      if ((table_->probed[buildCursor_] != 0) == wantProbed) {
+      if (all || (table_->probed[buildCursor_] != 0) == wantProbed) {
         char* row = table_->rowById(buildCursor_);
         if (buildRows) {
           buildRows[n] = static_cast<int32_t>(buildCursor_);
         }
         for (int32_t c = 0; c < numCols; ++c) {
-          extractStored(row, table_->containers[0]->deps()[colIds[c]], cols[c], n);
+          if (colIds[c] == VX355_BUILD_COL_MATCH) {
+            const uint8_t match = table_->probed[buildCursor_] != 0;
+            writeOut(cols[c], n, false, &match, 0);
+          } else {
+            extractStored(row, table_->containers[0]->deps()[colIds[c]], cols[c], n);
+          }
         }
         ++n;
       }
@@ -722,9 +775,122 @@ class JoinProbe {
     }
   }
 
+  struct Operand {
+    bool null = false;
+    int cls = 0;  // 0 int64, 1 double, 2 string
+    int64_t i = 0;
+    double d = 0;
+    std::string s;
+  };
+  Operand probeOperand(int32_t col, int32_t row) const {
+    Operand o;
+    Decoded d(&batch_->cols[col]);
+    if (d.isNull(row)) {
+      o.null = true;
+      return o;
+    }
+    const int32_t kind = batch_->cols[col].type_kind;
+    if (kind == VX355_VARCHAR || kind == VX355_VARBINARY) {
+      uint8_t tmp;
+      auto* sv = static_cast<const StringView*>(d.valuePtr(row, &tmp));
+      o.cls = 2;
+      o.s.assign(sv->data(), sv->size);
+    } else if (kind == VX355_REAL || kind == VX355_DOUBLE) {
+      o.cls = 1;
+      o.d = d.doubleAt(row);
+    } else {
+      o.i = d.int64At(row);
+    }
+    return o;
+  }
+  Operand buildOperand(int32_t dep, const char* row) const {
+    Operand o;
+    const auto& c = table_->containers[0]->deps()[dep];
+    if (row[c.nullOffset] != 0) {
+      o.null = true;
+      return o;
+    }
+    const char* p = row + c.offset;
+    if (c.kind == VX355_VARCHAR || c.kind == VX355_VARBINARY) {
+      auto* sv = reinterpret_cast<const StringView*>(p);
+      o.cls = 2;
+      o.s.assign(sv->data(), sv->size);
+    } else if (c.kind == VX355_REAL) {
+      float f;
+      std::memcpy(&f, p, 4);
+      o.cls = 1;
+      o.d = f;
+    } else if (c.kind == VX355_DOUBLE) {
+      o.cls = 1;
+      std::memcpy(&o.d, p, 8);
+    } else {
+      std::memcpy(&o.i, p, 8);  // integer kinds are stored widened (extractStored)
+    }
+    return o;
+  }
+  // evalFilter (HashProbe.cpp:1713): true when every term holds for the pair; a null operand
+  // makes the conjunct null, i.e. not passing.
+  bool passes(int32_t probeRow, const char* buildRow) const {
+    for (const auto& t : filter_) {
+      Operand l = t.left_side == 0 ? probeOperand(t.left_col, probeRow) : buildOperand(t.left_col, buildRow);
+      Operand r;
+      if (t.right_kind == 1) {
+        r = probeOperand(t.right_col, probeRow);
+      } else if (t.right_kind == 2) {
+        r = buildOperand(t.right_col, buildRow);
+      } else if (t.const_kind == VX355_BIGINT) {
+        r.i = t.i64;
+      } else if (t.const_kind == VX355_DOUBLE) {
+        r.cls = 1;
+        r.d = t.f64;
+      } else {
+        r.cls = 2;
+        r.s.assign(t.str, t.str_size);
+      }
+      if (l.null || r.null) {
+        return false;
+      }
+      auto cmp = [&](auto a, auto b) {
+        switch (t.cmp) {
+          case VX355_CMP_EQ:
+            return a == b;
+          case VX355_CMP_NE:
+            return a != b;
+          case VX355_CMP_LT:
+            return a < b;
+          case VX355_CMP_LE:
+            return a <= b;
+          case VX355_CMP_GT:
+            return a > b;
+          default:
+            return a >= b;
+        }
+      };
+      bool ok;
+      if (l.cls == 2 || r.cls == 2) {
+        if (l.cls != r.cls || (t.cmp != VX355_CMP_EQ && t.cmp != VX355_CMP_NE)) {
+          throw std::runtime_error("join filter: strings compare with strings, = and <> only");
+        }
+        ok = cmp(l.s, r.s);
+      } else if (l.cls == 0 && r.cls == 0) {
+        ok = cmp(l.i, r.i);
+      } else {
+        ok = cmp(l.cls == 0 ? static_cast<double>(l.i) : l.d, r.cls == 0 ? static_cast<double>(r.i) : r.d);
+      }
+      if (!ok) {
+        return false;
+      }
+    }
+    return true;
+  }
+
   JoinTable* table_;
   int32_t joinType_;
   bool nullAware_;
+  std::vector<vx355_join_filter_term> filter_;
+  const vx355_batch* batch_ = nullptr;  // the batch being probed (filter operands), borrowed
+  bool chainOpen_ = false;
+  bool anyPass_ = false;
   int64_t buildCursor_ = 0;
   std::vector<int32_t> keyCols_;
   std::vector<Decoded> keys_;
@@ -1170,6 +1336,10 @@ int orc_join_probe_create(orc_join_table* t, const vx355_join_probe_spec* spec,
     case VX355_JOIN_FULL:
     case VX355_JOIN_RIGHT_SEMI_FILTER:
     case VX355_JOIN_LEFT_SEMI_PROJECT:
+    case VX355_JOIN_COUNTING_LEFT_SEMI_FILTER:
+    case VX355_JOIN_COUNTING_ANTI:
+    case VX355_JOIN_RIGHT_SEMI_PROJECT:
+    case VX355_JOIN_RIGHT_ANTI:
       break;
     default:
       gLastError = "join type not restated in the oracle";
@@ -1180,6 +1350,11 @@ int orc_join_probe_create(orc_join_table* t, const vx355_join_probe_spec* spec,
     return VX355_EUNSUPPORTED;
   }
   *out = new orc_join_probe(&t->t, *spec);
+  ORC_CATCH
+}
+int orc_join_probe_set_filter(orc_join_probe* h, const vx355_join_filter_term* terms, int32_t n_terms) {
+  ORC_TRY
+  h->p.setFilter(terms, n_terms);
   ORC_CATCH
 }
 int orc_join_probe_add_input(orc_join_probe* h, const vx355_batch* batch) {

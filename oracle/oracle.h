@@ -108,6 +108,9 @@ void orc_join_table_release(orc_join_table* t);
 int orc_join_table_get_stats(const orc_join_table* t, vx355_join_table_stats* out);
 int orc_join_probe_create(orc_join_table* t, const vx355_join_probe_spec* spec,
                           orc_join_probe** out);
+/* HashJoinNode::filter as vx355_join_filter_term conjunction (HashProbe::evalFilter). The batch given
+ * to add_input must stay alive until its output is drained. */
+int orc_join_probe_set_filter(orc_join_probe* h, const vx355_join_filter_term* terms, int32_t n_terms);
 int orc_join_probe_add_input(orc_join_probe* h, const vx355_batch* batch);
 int orc_join_probe_get_output(orc_join_probe* h, int32_t max_rows, int32_t* mapping_out,
                               int32_t* build_rows_out, vx355_out_column* build_cols,

@@ -89,6 +89,7 @@ def lib():
     L.orc_join_table_get_stats.argtypes = [vp, C.POINTER(abi.JoinTableStats)]
     L.orc_join_probe_create.argtypes = [vp, C.POINTER(abi.JoinProbeSpec), C.POINTER(vp)]
     L.orc_join_probe_add_input.argtypes = [vp, C.POINTER(abi.Batch)]
+    L.orc_join_probe_set_filter.argtypes = [vp, C.POINTER(abi.JoinFilterTerm), i32]
     L.orc_join_probe_get_output.argtypes = [vp, i32, vp, vp, C.POINTER(abi.OutColumn), vp, i32,
                                             C.POINTER(i32), C.POINTER(i32)]
     L.orc_join_probe_get_build_side_output.argtypes = [vp, i32, vp, C.POINTER(abi.OutColumn), vp, i32,
@@ -402,7 +403,7 @@ class JoinProbe:
     def get_build_side_output(self, max_rows=1024, build_col_ids=None):
         if build_col_ids is None:
             build_col_ids = list(range(len(self.table.dep_types)))
-        kinds = [self.table.dep_types[i] for i in build_col_ids]
+        kinds = [abi.BOOLEAN if i == abi.BUILD_COL_MATCH else self.table.dep_types[i] for i in build_col_ids]
         out = abi.OutBuffers(kinds, max_rows)
         build_rows = np.zeros(max(1, max_rows), dtype=np.int32)
         n, fin = C.c_int32(), C.c_int32()
@@ -411,6 +412,11 @@ class JoinProbe:
                                                           len(kinds), C.byref(n), C.byref(fin)))
         cols = [out.column(i, n.value) for i in range(len(kinds))]
         return build_rows[: n.value].copy(), cols, bool(fin.value)
+
+    def set_filter(self, terms):
+        """HashJoinNode::filter: [(left, cmp, right)], see abi.join_filter_terms."""
+        self._filter = abi.join_filter_terms(terms)
+        _check(lib().orc_join_probe_set_filter(self.h, self._filter, len(terms)))
 
     def add_input(self, batch):
         self._batch = batch

@@ -492,3 +492,136 @@ def test_low_hit_rate_joins_list_their_hits_in_the_probe_pass(oracle, vx, sparse
     for g, e in zip(res[vx.__name__], res[oracle.__name__]):
         assert len(g) == len(e) and (g == e).all()
     assert len(res[vx.__name__][0]) > 30000
+
+
+ALL_FILTER_KINDS = [abi.JOIN_INNER, abi.JOIN_LEFT, abi.JOIN_RIGHT, abi.JOIN_FULL, abi.JOIN_LEFT_SEMI_FILTER,
+                    abi.JOIN_LEFT_SEMI_PROJECT, abi.JOIN_ANTI, abi.JOIN_RIGHT_SEMI_FILTER,
+                    abi.JOIN_RIGHT_SEMI_PROJECT, abi.JOIN_RIGHT_ANTI]
+
+
+def _probe_all(impl, table, key_cols, join_type, batches, flt, max_rows, dep_ids):
+    """-> (sorted pairs per batch incl. payload, build-side output) with the oracle's conventions."""
+    probe = impl.JoinProbe(table, key_cols, join_type)
+    if flt:
+        probe.set_filter(flt)
+    out = []
+    for hb in batches:
+        probe.add_input(hb)
+        pairs, payload = _drain(probe, max_rows, dep_ids)
+        _contiguous(pairs)
+        if join_type == abi.JOIN_LEFT_SEMI_PROJECT:
+            pairs = [(r, 0 if b >= 0 else -1) for r, b in pairs]    # which match is reported is chain order
+            payload = [() for _ in payload]
+        out.append(_canon(pairs, payload))
+    side = None
+    if join_type in (abi.JOIN_RIGHT, abi.JOIN_FULL, abi.JOIN_RIGHT_ANTI, abi.JOIN_RIGHT_SEMI_FILTER,
+                     abi.JOIN_RIGHT_SEMI_PROJECT):
+        ids = list(dep_ids) + ([abi.BUILD_COL_MATCH] if join_type == abi.JOIN_RIGHT_SEMI_PROJECT else [])
+        rows, cols_acc = [], None
+        while True:
+            r, cols, fin = probe.get_build_side_output(max_rows, ids)
+            rows += r.tolist()
+            vals = [[None if not ok else (v.item() if hasattr(v, "item") else v) for v, ok in zip(c[0], c[1])]
+                    for c in cols]
+            cols_acc = vals if cols_acc is None else [a + b for a, b in zip(cols_acc, vals)]
+            if fin:
+                break
+        side = (rows, cols_acc)
+    return out, side
+
+
+@pytest.mark.parametrize("join_type", ALL_FILTER_KINDS)
+@pytest.mark.parametrize("flt", [None, "int_lt", "mixed"])
+@pytest.mark.parametrize("force_hash", [False, True])
+def test_every_join_kind_with_and_without_extra_filter(oracle, vx, join_type, flt, force_hash, monkeypatch):
+    """HashProbe::evalFilter semantics per join kind (HashProbe.cpp:1487-1713) and the build-side
+    outputs of the right-side kinds incl. right semi project's match column and right anti, vs the
+    oracle (itself pinned to nested loops in test_oracle_ops.py). Duplicate build keys, null keys
+    and null filter operands on both sides; two probe batches share the probed flags."""
+    if force_hash:
+        monkeypatch.setenv("VX355_JOIN_ARRAY_MAX", "0")
+    rng = np.random.default_rng(200 + join_type)
+    nb, npb = 5000, 30000
+    bk = rng.integers(0, 1200, nb).astype(np.int64)
+    bvalid = rng.random(nb) > 0.05
+    bw = rng.integers(0, 100, nb).astype(np.int32)
+    bwvalid = rng.random(nb) > 0.1
+    bd = rng.random(nb) * 100
+    bs = [bytes(rng.choice([b"AIR", b"SHIP", b"TRUCK", b"REG AIR", b"twelve bytes"])) for _ in range(nb)]
+    pk = rng.integers(-50, 1500, npb).astype(np.int64)
+    pvalid = rng.random(npb) > 0.05
+    pv = rng.integers(0, 100, npb).astype(np.int64)
+    pvvalid = rng.random(npb) > 0.1
+    ps = [bytes(rng.choice([b"AIR", b"SHIP", b"TRUCK", b"REG AIR", b"twelve bytes"])) for _ in range(npb)]
+    terms = {None: None,
+             "int_lt": [(("probe", 1), abi.CMP_LT, ("build", 0))],
+             "mixed": [(("build", 1), abi.CMP_GE, ("probe", 1)),            # DOUBLE vs BIGINT: compares as double
+                       (("probe", 2), abi.CMP_EQ, ("build", 2)),            # inline strings
+                       (("build", 0), abi.CMP_NE, 17), (("probe", 2), abi.CMP_NE, b"TRUCK")]}[flt]
+    build_batch = abi.HostBatch([abi.HostColumn(abi.BIGINT, bk, bvalid), abi.HostColumn(abi.INTEGER, bw, bwvalid),
+                                 abi.HostColumn(abi.DOUBLE, bd), abi.HostColumn(abi.VARCHAR, bs)])
+    half = npb // 2
+    probe_batches = [abi.HostBatch([abi.HostColumn(abi.BIGINT, pk[lo:hi], pvalid[lo:hi]),
+                                    abi.HostColumn(abi.BIGINT, pv[lo:hi], pvvalid[lo:hi]),
+                                    abi.HostColumn(abi.VARCHAR, ps[lo:hi])])
+                     for lo, hi in ((0, half), (half, npb))]
+    res = {}
+    for impl in (oracle, vx):
+        table, _ = _build(impl, [[build_batch]], [0], [abi.BIGINT], [1, 2, 3], [abi.INTEGER, abi.DOUBLE, abi.VARCHAR],
+                          join_type)
+        res[impl.__name__] = _probe_all(impl, table, [0], join_type, probe_batches, terms,
+                                        997 if impl is vx else 1500, [0, 2])
+    assert res[vx.__name__][0] == res[oracle.__name__][0]
+    assert res[vx.__name__][1] == res[oracle.__name__][1]
+    if join_type in (abi.JOIN_INNER, abi.JOIN_LEFT):
+        assert sum(len(b) for b in res[vx.__name__][0]) > 100
+
+
+@pytest.mark.parametrize("join_type", [abi.JOIN_COUNTING_LEFT_SEMI_FILTER, abi.JOIN_COUNTING_ANTI])
+@pytest.mark.parametrize("force_hash", [False, True])
+def test_counting_joins_intersect_all_except_all(oracle, vx, join_type, force_hash, monkeypatch):
+    """core/PlanNode.h:3112-3116,3152-3156, HashProbe.cpp:1345-1365: every match consumes one
+    occurrence of the build key, in probe-row order, across batches; two key columns."""
+    if force_hash:
+        monkeypatch.setenv("VX355_JOIN_ARRAY_MAX", "0")
+    rng = np.random.default_rng(77)
+    nb, npb = 20000, 60000
+    bk1 = rng.integers(0, 300, nb).astype(np.int64)
+    bk2 = rng.integers(0, 20, nb).astype(np.int32)
+    bvalid = rng.random(nb) > 0.02
+    pk1 = rng.integers(-10, 320, npb).astype(np.int64)
+    pk2 = rng.integers(0, 22, npb).astype(np.int32)
+    pvalid = rng.random(npb) > 0.02
+    res = {}
+    for impl in (oracle, vx):
+        table, _ = _build(impl, [[abi.HostBatch([abi.HostColumn(abi.BIGINT, bk1, bvalid),
+                                                 abi.HostColumn(abi.INTEGER, bk2)])]],
+                          [0, 1], [abi.BIGINT, abi.INTEGER], [], [], join_type)
+        probe = impl.JoinProbe(table, [0, 1], join_type)
+        got = []
+        for lo in range(0, npb, 25000):
+            hi = min(npb, lo + 25000)
+            probe.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, pk1[lo:hi], pvalid[lo:hi]),
+                                           abi.HostColumn(abi.INTEGER, pk2[lo:hi])]))
+            while True:
+                m, r, cols, fin = probe.get_output(7777, [])
+                got.append(np.asarray(m) + lo)
+                if fin:
+                    break
+        res[impl.__name__] = np.concatenate(got)
+    assert len(res[vx.__name__]) == len(res[oracle.__name__]) and (res[vx.__name__] == res[oracle.__name__]).all()
+    assert 1000 < len(res[vx.__name__]) < npb - 1000
+
+
+def test_unsupported_join_flavours_are_refused_at_create(vx):
+    b = vx.JoinBuild([0], [abi.BIGINT], [], [], abi.JOIN_COUNTING_ANTI)
+    b.add_input(batch_of([np.arange(10, dtype=np.int64)]))
+    t = b.finish()
+    p = vx.JoinProbe(t, [0], abi.JOIN_COUNTING_ANTI)
+    with pytest.raises(vx.Vx355Error) as e:
+        p.set_filter([(("probe", 0), abi.CMP_LT, 5)])
+    assert e.value.status == abi.EUNSUPPORTED
+    with pytest.raises(vx.Vx355Error):
+        vx.JoinProbe(t, [0], abi.JOIN_INNER)               # counting table, non-counting probe
+    with pytest.raises(vx.Vx355Error):
+        vx.JoinBuild([0], [abi.BIGINT], [], [], abi.JOIN_LEFT_SEMI_PROJECT, null_aware=True)

@@ -498,3 +498,132 @@ def test_sequential_double_sum_is_within_the_reference_tolerance_of_the_exact_su
     # the sequential sum is NOT within 1 ULP of the exact sum on this data (10 000 rows per group):
     # bit equality with any parallel order is not attainable, closeness to the exact sum is
     assert worst_ulp > 1
+
+
+def _brute_force_join(bk, bv, pk, pv, bvalid=None, pvalid=None, flt=None):
+    """Nested loops: for every probe row the list of build rows with an equal non-null key that
+    pass flt(probe value, build value)."""
+    out = []
+    for i in range(len(pk)):
+        m = []
+        if pvalid is None or pvalid[i]:
+            for j in range(len(bk)):
+                if (bvalid is None or bvalid[j]) and bk[j] == pk[i] and (flt is None or flt(pv[i], bv[j])):
+                    m.append(j)
+        out.append(m)
+    return out
+
+
+JOIN_FILTER_KINDS = [abi.JOIN_INNER, abi.JOIN_LEFT, abi.JOIN_RIGHT, abi.JOIN_FULL, abi.JOIN_LEFT_SEMI_FILTER,
+                     abi.JOIN_LEFT_SEMI_PROJECT, abi.JOIN_ANTI, abi.JOIN_RIGHT_SEMI_FILTER,
+                     abi.JOIN_RIGHT_SEMI_PROJECT, abi.JOIN_RIGHT_ANTI]
+
+
+@pytest.mark.parametrize("join_type", JOIN_FILTER_KINDS)
+@pytest.mark.parametrize("with_filter", [False, True])
+def test_oracle_joins_with_extra_filter_against_nested_loops(oracle, join_type, with_filter):
+    """HashProbe::evalFilter semantics per join kind (HashProbe.cpp:1487-1713) and the build-side
+    outputs of the right-side kinds, against nested loops: filter = probe.v < build.w."""
+    rng = np.random.default_rng(41 + join_type)
+    nb, npb = 300, 500
+    bk = rng.integers(0, 60, nb).astype(np.int64)
+    bvalid = rng.random(nb) > 0.1
+    bw = rng.integers(0, 100, nb).astype(np.int64)
+    bwvalid = rng.random(nb) > 0.1
+    pk = rng.integers(-5, 70, npb).astype(np.int64)
+    pvalid = rng.random(npb) > 0.1
+    pv = rng.integers(0, 100, npb).astype(np.int64)
+    pvvalid = rng.random(npb) > 0.1
+    b = oracle.JoinBuild([0], [abi.BIGINT], [1], [abi.BIGINT], join_type)
+    b.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, bk, bvalid), abi.HostColumn(abi.BIGINT, bw, bwvalid)]))
+    t = b.finish()
+    p = oracle.JoinProbe(t, [0], join_type)
+    if with_filter:
+        p.set_filter([(("probe", 1), abi.CMP_LT, ("build", 0))])
+    p.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, pk, pvalid), abi.HostColumn(abi.BIGINT, pv, pvvalid)]))
+    pairs = []
+    while True:
+        m, r, cols, fin = p.get_output(37, [0])
+        pairs += list(zip(m.tolist(), r.tolist()))
+        if fin:
+            break
+    keeps_null_rows = join_type in (abi.JOIN_RIGHT, abi.JOIN_FULL, abi.JOIN_RIGHT_SEMI_PROJECT, abi.JOIN_RIGHT_ANTI)
+    kept = [j for j in range(nb) if bvalid[j] or keeps_null_rows]          # build row id -> input row
+    rid = {j: i for i, j in enumerate(kept)}
+
+    def flt(pvi, bwj):
+        return True
+    matches = []
+    for i in range(npb):
+        m = []
+        if pvalid[i]:
+            for j in range(nb):
+                if bvalid[j] and bk[j] == pk[i] and (not with_filter or (pvvalid[i] and bwvalid[j] and pv[i] < bw[j])):
+                    m.append(rid[j])
+        matches.append(m)
+    exp = []
+    for i, m in enumerate(matches):
+        if join_type in (abi.JOIN_INNER, abi.JOIN_RIGHT):
+            exp += [(i, j) for j in m]
+        elif join_type in (abi.JOIN_LEFT, abi.JOIN_FULL):
+            exp += [(i, j) for j in m] if m else [(i, -1)]
+        elif join_type == abi.JOIN_LEFT_SEMI_FILTER and m:
+            exp.append((i, -1))
+        elif join_type == abi.JOIN_ANTI and not m:
+            exp.append((i, -1))
+        elif join_type == abi.JOIN_LEFT_SEMI_PROJECT:
+            exp.append((i, 0 if m else -1))
+    got = pairs
+    if join_type == abi.JOIN_LEFT_SEMI_PROJECT:
+        got = [(i, 0 if j >= 0 else -1) for i, j in pairs]          # which match is reported is chain order
+    assert [i for i, _ in got] == [i for i, _ in exp]                  # ascending probe rows, same multiplicity
+    assert sorted(got) == sorted(exp)
+    probed = set(j for m in matches for j in m)
+    if join_type in (abi.JOIN_RIGHT, abi.JOIN_FULL, abi.JOIN_RIGHT_ANTI, abi.JOIN_RIGHT_SEMI_FILTER,
+                     abi.JOIN_RIGHT_SEMI_PROJECT):
+        ids = [0, abi.BUILD_COL_MATCH] if join_type == abi.JOIN_RIGHT_SEMI_PROJECT else [0]
+        rows, flags = [], []
+        while True:
+            r, cols, fin = p.get_build_side_output(41, ids)
+            rows += r.tolist()
+            if join_type == abi.JOIN_RIGHT_SEMI_PROJECT:
+                flags += np.asarray(cols[1][0]).tolist()
+            if fin:
+                break
+        if join_type == abi.JOIN_RIGHT_SEMI_FILTER:
+            assert rows == sorted(probed)
+        elif join_type == abi.JOIN_RIGHT_SEMI_PROJECT:
+            assert rows == list(range(len(kept))) and [bool(f) for f in flags] == [r in probed for r in rows]
+        else:
+            assert rows == [r for r in range(len(kept)) if r not in probed]
+
+
+@pytest.mark.parametrize("join_type", [abi.JOIN_COUNTING_LEFT_SEMI_FILTER, abi.JOIN_COUNTING_ANTI])
+def test_oracle_counting_joins_are_intersect_all_and_except_all(oracle, join_type):
+    """core/PlanNode.h:3112-3116,3152-3156: INTERSECT ALL / EXCEPT ALL over multisets, across batches."""
+    rng = np.random.default_rng(51)
+    bk = rng.integers(0, 30, 200).astype(np.int64)
+    pk = rng.integers(-3, 35, 400).astype(np.int64)
+    pvalid = rng.random(400) > 0.05
+    b = oracle.JoinBuild([0], [abi.BIGINT], [], [], join_type)
+    b.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, bk)]))
+    p = oracle.JoinProbe(b.finish(), [0], join_type)
+    left = {}
+    for k in bk.tolist():
+        left[k] = left.get(k, 0) + 1
+    got, exp = [], []
+    for lo in range(0, 400, 150):
+        hi = min(400, lo + 150)
+        p.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, pk[lo:hi], pvalid[lo:hi])]))
+        while True:
+            m, r, cols, fin = p.get_output(33, [])
+            got += (m + lo).tolist()
+            if fin:
+                break
+        for i in range(lo, hi):
+            consumed = bool(pvalid[i]) and left.get(int(pk[i]), 0) > 0
+            if consumed:
+                left[int(pk[i])] -= 1
+            if consumed == (join_type == abi.JOIN_COUNTING_LEFT_SEMI_FILTER):
+                exp.append(i)
+    assert got == exp

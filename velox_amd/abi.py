@@ -116,6 +116,37 @@ class FilterTerm(C.Structure):
                 ("str", C.c_char * 16)]
 
 
+class JoinFilterTerm(C.Structure):
+    _fields_ = [("left_side", C.c_int32), ("left_col", C.c_int32), ("cmp", C.c_int32),
+                ("right_kind", C.c_int32), ("right_col", C.c_int32), ("const_kind", C.c_int32),
+                ("str_size", C.c_int32), ("pad", C.c_int32), ("i64", C.c_int64), ("f64", C.c_double),
+                ("str", C.c_char * 16)]
+
+
+BUILD_COL_MATCH = -1   # VX355_BUILD_COL_MATCH: the 'match' column of RIGHT_SEMI_PROJECT
+
+
+def join_filter_terms(terms):
+    """[(left, cmp, right)] -> ctypes array. left / right: ("probe", col), ("build", dep index) or a
+    constant (int -> BIGINT, float -> DOUBLE, bytes -> VARCHAR); left must be a column."""
+    arr = (JoinFilterTerm * max(1, len(terms)))()
+    for i, (left, cmp_, right) in enumerate(terms):
+        t = arr[i]
+        t.left_side = 0 if left[0] == "probe" else 1
+        t.left_col = left[1]
+        t.cmp = cmp_
+        if isinstance(right, tuple):
+            t.right_kind = 1 if right[0] == "probe" else 2
+            t.right_col = right[1]
+        elif isinstance(right, bytes):
+            t.right_kind, t.const_kind, t.str_size, t.str = 0, VARCHAR, len(right), right
+        elif isinstance(right, float):
+            t.right_kind, t.const_kind, t.f64 = 0, DOUBLE, right
+        else:
+            t.right_kind, t.const_kind, t.i64 = 0, BIGINT, int(right)
+    return arr
+
+
 class Factor(C.Structure):
     _fields_ = [("col", C.c_int32), ("pad", C.c_int32), ("scale", C.c_double),
                 ("offset", C.c_double)]

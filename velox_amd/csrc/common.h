@@ -125,6 +125,9 @@ struct DeviceState {
   // live contexts by id: a cached block released by a context whose call is still in
   // flight is only handed to another context after that stream has drained
   std::map<uint64_t, Runtime*> contexts;
+  // Contexts of destroyed handles, kept for the next operator: creating a stream and a
+  // pinned mailbox costs ~0.5 ms, operators are created per query.
+  std::vector<Runtime*> idleContexts;
 
   std::mutex profMutex;
   bool profile = false;

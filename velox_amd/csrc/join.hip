@@ -458,6 +458,37 @@ __global__ __launch_bounds__(256) void k_fill_u32(uint32_t* p, uint64_t n, uint3
   }
 }
 
+// Counting joins: remaining[head of the row's chain] += 1 for every inserted build row
+// (the per-key count HashBuild keeps while it deduplicates, HashBuild.cpp:534-548).
+__global__ __launch_bounds__(256) void k_count_init(InsertArgs a, uint32_t* remaining) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < a.numRows;
+       row += stride) {
+    const uint64_t key = buildKey(a, row);
+    uint32_t head = kNoRow32;
+    if (a.mode == JMODE_ARRAY) {
+      head = a.head[key];
+    } else {
+      const uint64_t mask = a.capacity - 1;
+      uint64_t pos = twangMix64(key) & mask;
+      for (uint64_t probes = 0; probes <= mask; ++probes) {
+        const Slot sl = a.slots[pos];
+        if (sl.key == key) {
+          head = sl.head;
+          break;
+        }
+        if (sl.key == kEmptyKey) {
+          break;
+        }
+        pos = (pos + 1) & mask;
+      }
+    }
+    if (head != kNoRow32) {
+      atomicAdd(remaining + head, 1u);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_fill_slots(Slot* p, uint64_t n) {
   const uint64_t step = static_cast<uint64_t>(gridDim.x) * blockDim.x;
   for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += step) {
@@ -502,7 +533,9 @@ struct ProbeArgs {
   int64_t tileBegin;    // tiles [tileBegin, numTiles) of this launch
   uint2* staged;        // {probe row, build row}
   uint8_t* tileDense;
-  uint64_t* sparseStats;  // [0] overflowed tiles, [1] hits listed (device-visible mailbox)
+  int32_t countHits;    // add every tile's hit count to sparseStats[1] (the sample launch)
+  int32_t pad3;
+  uint64_t* sparseStats;  // [0] overflowed tiles, [1] hits listed (HBM: atomics on the pinned mailbox cross PCIe)
 };
 
 constexpr int kSparseCap = 1024;  // staged pairs per tile of 8192 probe rows (12.5 % hit rate)
@@ -525,7 +558,11 @@ __device__ inline uint32_t outputCount(int32_t joinType, uint32_t matches, bool 
     case VX355_JOIN_LEFT_SEMI_PROJECT:
       return 1;
     case VX355_JOIN_RIGHT_SEMI_FILTER:
-      return 0;  // build-side output only (processRightSemiNoFilter)
+    case VX355_JOIN_RIGHT_SEMI_PROJECT:
+    case VX355_JOIN_RIGHT_ANTI:
+      return 0;  // build-side output only (processRightSemiNoFilter, HashProbe.cpp:1422-1429)
+    case VX355_JOIN_COUNTING_LEFT_SEMI_FILTER:
+      return matches ? 1 : 0;  // after k_count_consume: a hit = the row consumed an occurrence
     default:  // ANTI: rows without a match; null keys included unless null aware
       return (matches || nullKey) ? 0 : 1;
   }
@@ -637,16 +674,17 @@ __device__ inline uint32_t lookupSlots(const ProbeArgs& a, uint64_t key) {
 //
 // SPARSE (listJoinResultsFastPath for joins that emit matches only and whose
 // chains have one row, HashTable.cpp:2293-2350): instead of writing hits[] for
-// every probe row and scanning it again at output time, the tile's hits are
-// collected in LDS — a bit per row plus an unordered {row, build row} list — and
-// written out once, in probe-row order (rank = popcount prefix of the bitmap).
-// A tile with more than kSparseCap hits falls back to the dense form.
+// every probe row and scanning it again at output time, every wave owns 2048
+// consecutive rows of the tile and appends its hits {row, build row} to its own
+// LDS list in row order (ballot + lane prefix, no atomics); after one barrier
+// the four lists are written out back to back, i.e. in probe-row order. A tile
+// in which some wave finds more than kSparseWaveCap hits falls back to the
+// dense form.
+constexpr int kSparseWaveCap = kSparseCap / 4;  // staged pairs per wave (2048 probe rows)
+
 struct SparseLds {
-  uint32_t bits[kTileRows / 32];
-  uint32_t wordPrefix[kTileRows / 32];
-  unsigned long long list[kSparseCap];
-  uint32_t cursor;
-  uint32_t waveTotals[4];
+  unsigned long long list[4][kSparseWaveCap];  // per wave, in probe-row order
+  uint32_t waveCount[2][4];                    // double buffered by tile parity: one barrier per tile
 };
 
 template <int MODE, int FAST, bool SPARSE>
@@ -662,7 +700,8 @@ __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, Spars
     uint32_t hit[kProbeUnroll];
 #pragma unroll
     for (int u = 0; u < kProbeUnroll; ++u) {
-      rows[u] = tileBase + (it * kProbeUnroll + u) * 256 + threadIdx.x;
+      rows[u] = SPARSE ? tileBase + (threadIdx.x >> 6) * (kTileRows / 4) + (it * kProbeUnroll + u) * 64 + lane()
+                       : tileBase + (it * kProbeUnroll + u) * 256 + threadIdx.x;
     }
     if (fastKey) {
       const int64_t* kp = static_cast<const int64_t*>(a.keys[0].values);
@@ -719,25 +758,30 @@ __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, Spars
         hit[u] = candidate[u] ? lookupSlots(a, key[u]) : kNoRow32;
       }
     }
+    if constexpr (SPARSE) {
+      // joins that list matches only, chains of one row, not null aware; 'mine' is the
+      // wave's running hit count (uniform across the wave)
+#pragma unroll
+      for (int u = 0; u < kProbeUnroll; ++u) {
+        const bool isMatch = rows[u] < a.numRows && hit[u] != kNoRow32;
+        const uint64_t m = ballot(isMatch);
+        if (isMatch) {
+          if (a.probed) {
+            a.probed[hit[u]] = 1;
+          }
+          const uint64_t at = mine + lanePrefix(m);
+          if (at < kSparseWaveCap) {
+            lds->list[threadIdx.x >> 6][at] =
+                (static_cast<unsigned long long>(static_cast<uint32_t>(rows[u])) << 32) | hit[u];
+          }
+        }
+        mine += popc64(m);
+      }
+      continue;
+    }
 #pragma unroll
     for (int u = 0; u < kProbeUnroll; ++u) {
       if (rows[u] < a.numRows) {
-        if constexpr (SPARSE) {
-          // joins that list matches only, chains of one row, not null aware
-          if (hit[u] != kNoRow32) {
-            if (a.probed) {
-              a.probed[hit[u]] = 1;
-            }
-            const uint32_t r = static_cast<uint32_t>(rows[u] - tileBase);
-            atomicOr(&lds->bits[r >> 5], 1u << (r & 31));
-            const uint32_t at = atomicAdd(&lds->cursor, 1u);
-            if (at < kSparseCap) {
-              lds->list[at] = (static_cast<unsigned long long>(r) << 32) | hit[u];
-            }
-            ++mine;
-          }
-          continue;
-        }
         bool nullKey = false;
         if (a.nullAware && hit[u] == kNoRow32) {
           for (int k = 0; k < a.numKeys; ++k) {
@@ -778,71 +822,47 @@ __global__ __launch_bounds__(256) void k_join_probe(ProbeArgs args) {
   __shared__ __attribute__((aligned(16))) unsigned char sparseRaw[SPARSE ? sizeof(SparseLds) : 16];
   const ProbeArgs& a = args;
   SparseLds* lds = reinterpret_cast<SparseLds*>(sparseRaw);
-  if constexpr (SPARSE) {
-    for (int i = threadIdx.x; i < kTileRows / 32; i += 256) {
-      lds->bits[i] = 0;
-    }
-    if (threadIdx.x == 0) {
-      lds->cursor = 0;
-    }
-    blockSync();
-  }
-  for (int64_t tile = a.tileBegin + blockIdx.x; tile < a.numTiles; tile += gridDim.x) {
+  int parity = 0;
+  for (int64_t tile = a.tileBegin + blockIdx.x; tile < a.numTiles; tile += gridDim.x, parity ^= 1) {
     uint64_t mine = probeTileBody<MODE, FAST, SPARSE>(a, tile, lds);
     if constexpr (SPARSE) {
-      blockSync();
-      const uint32_t k = lds->cursor;
-      if (k <= kSparseCap) {  // uniform: cursor is shared
-        // rank of a hit = number of hits on earlier rows of the tile
-        const uint32_t w = lds->bits[threadIdx.x];
-        const uint32_t c = static_cast<uint32_t>(__popc(w));
-        uint32_t incl = c;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          const uint32_t o = __shfl_up(incl, off, kWave);
-          if (lane() >= off) {
-            incl += o;
-          }
-        }
-        if (lane() == 63) {
-          lds->waveTotals[threadIdx.x >> 6] = incl;
-        }
-        blockSync();
-        uint32_t before = incl - c;
-        for (int wv = 0; wv < (threadIdx.x >> 6); ++wv) {
-          before += lds->waveTotals[wv];
-        }
-        lds->wordPrefix[threadIdx.x] = before;
-        blockSync();
-        uint2* out = a.staged + tile * kSparseCap;
-        for (uint32_t i = threadIdx.x; i < k; i += 256) {
-          const unsigned long long e = lds->list[i];
-          const uint32_t r = static_cast<uint32_t>(e >> 32);
-          const uint32_t rank = lds->wordPrefix[r >> 5] + __popc(lds->bits[r >> 5] & ((1u << (r & 31)) - 1));
-          out[rank] = make_uint2(static_cast<uint32_t>(tile * kTileRows + r), static_cast<uint32_t>(e));
-        }
-        blockSync();
-        lds->bits[threadIdx.x] = 0;
-        if (threadIdx.x == 0) {
-          lds->cursor = 0;
-          a.tileSums[tile] = k;
-          a.tileDense[tile] = 0;
-          if (k) {
-            atomicAdd(reinterpret_cast<unsigned long long*>(a.sparseStats + 1), static_cast<unsigned long long>(k));
-          }
-        }
-        blockSync();
-        continue;
+      const int wave = threadIdx.x >> 6;
+      if (lane() == 0) {
+        lds->waveCount[parity][wave] = static_cast<uint32_t>(mine);
       }
-      // More hits than the staging segment holds: redo the tile in the dense form
+      blockSync();
+      uint32_t before = 0, total = 0;
+      bool overflow = false;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const uint32_t c = lds->waveCount[parity][w];
+        before += w < wave ? c : 0;
+        total += c;
+        overflow = overflow || c > kSparseWaveCap;
+      }
+      if (!overflow) {  // uniform
+        // the wave's own list, behind the lists of the waves that own earlier rows
+        uint2* out = a.staged + tile * kSparseCap + before;
+        for (uint32_t i = lane(); i < static_cast<uint32_t>(mine); i += 64) {
+          const unsigned long long e = lds->list[wave][i];
+          out[i] = make_uint2(static_cast<uint32_t>(e >> 32), static_cast<uint32_t>(e));
+        }
+        if (threadIdx.x == 0) {
+          a.tileSums[tile] = total;
+          a.tileDense[tile] = 0;
+          if (total && a.countHits) {  // sample launch only: one address takes < 100 M atomics/s
+            atomicAdd(reinterpret_cast<unsigned long long*>(a.sparseStats + 1), static_cast<unsigned long long>(total));
+          }
+        }
+        continue;  // no second barrier: the next tile uses the other waveCount buffer, and a wave only
+                   // overwrites its own list after every wave has passed this tile's barrier
+      }
+      // More hits than a staging segment holds: redo the tile in the dense form
       // (hits[] for every row); the output pass scans it like a dense tile.
-      lds->bits[threadIdx.x] = 0;
       if (threadIdx.x == 0) {
-        lds->cursor = 0;
         a.tileDense[tile] = 1;
         atomicAdd(reinterpret_cast<unsigned long long*>(a.sparseStats), 1ULL);
       }
-      blockSync();
       mine = probeTileBody<MODE, FAST, false>(a, tile, lds);
     }
 #pragma unroll
@@ -857,6 +877,270 @@ __global__ __launch_bounds__(256) void k_join_probe(ProbeArgs args) {
       a.tileSums[tile] = waveSums[0] + waveSums[1] + waveSums[2] + waveSums[3];
     }
     blockSync();
+  }
+}
+
+// ---- the join's extra filter (HashProbe::evalFilter, HashProbe.cpp:1713) -------------------
+constexpr int kMaxJoinFilterTerms = 4;
+
+struct JoinFilterTerm {
+  ColView leftProbe, rightProbe;  // operand = probe column
+  int32_t leftSide;               // 0 probe column, 1 build dependent
+  int32_t leftDep, rightDep;      // operand = build dependent (index)
+  int32_t cmp;
+  int32_t rightKind;              // 0 constant, 1 probe column, 2 build dependent
+  int32_t constKind;
+  int64_t i64;
+  double f64;
+  uint4 str;                      // constant string as an inline StringView
+};
+
+struct JoinFilterArgs {
+  int32_t numTerms;
+  int32_t pad;
+  JoinFilterTerm terms[kMaxJoinFilterTerms];
+  const char* depVals[kMaxDeps];
+  const uint8_t* depValid[kMaxDeps];
+  int32_t depWidth[kMaxDeps];
+  int32_t depKind[kMaxDeps];
+};
+
+struct FilterOperand {
+  bool null;
+  int cls;  // 0 int64, 1 double, 2 inline string
+  int64_t i;
+  double d;
+  uint4 s;
+};
+
+__device__ inline FilterOperand probeOperand(const ColView& c, int64_t row) {
+  FilterOperand o{};
+  if (colIsNull(c, row)) {
+    o.null = true;
+    return o;
+  }
+  const int64_t i = colIndex(c, row);
+  if (c.kind == VX355_VARCHAR || c.kind == VX355_VARBINARY) {
+    o.cls = 2;
+    o.s = static_cast<const uint4*>(c.values)[i];
+  } else if (c.kind == VX355_REAL || c.kind == VX355_DOUBLE) {
+    o.cls = 1;
+    o.d = loadDouble(c, i);
+  } else {
+    o.i = loadInt64(c, i);
+  }
+  return o;
+}
+
+__device__ inline FilterOperand buildOperand(const JoinFilterArgs& f, int dep, uint32_t row) {
+  FilterOperand o{};
+  if (!f.depValid[dep][row]) {
+    o.null = true;
+    return o;
+  }
+  const int w = f.depWidth[dep];
+  const char* p = f.depVals[dep] + static_cast<int64_t>(row) * (w == 0 ? 1 : w);
+  switch (f.depKind[dep]) {
+    case VX355_BOOLEAN:
+    case VX355_TINYINT:
+      o.i = *reinterpret_cast<const int8_t*>(p);
+      break;
+    case VX355_SMALLINT:
+      o.i = *reinterpret_cast<const int16_t*>(p);
+      break;
+    case VX355_INTEGER:
+      o.i = *reinterpret_cast<const int32_t*>(p);
+      break;
+    case VX355_BIGINT:
+      o.i = *reinterpret_cast<const int64_t*>(p);
+      break;
+    case VX355_REAL:
+      o.cls = 1;
+      o.d = *reinterpret_cast<const float*>(p);
+      break;
+    case VX355_DOUBLE:
+      o.cls = 1;
+      o.d = *reinterpret_cast<const double*>(p);
+      break;
+    default:
+      o.cls = 2;
+      o.s = *reinterpret_cast<const uint4*>(p);
+      break;
+  }
+  return o;
+}
+
+template <typename T>
+__device__ inline bool compareValues(int32_t cmp, T a, T b) {
+  switch (cmp) {
+    case VX355_CMP_EQ:
+      return a == b;
+    case VX355_CMP_NE:
+      return a != b;
+    case VX355_CMP_LT:
+      return a < b;
+    case VX355_CMP_LE:
+      return a <= b;
+    case VX355_CMP_GT:
+      return a > b;
+    default:
+      return a >= b;
+  }
+}
+
+// True when every term holds for the pair; a null operand fails its term.
+__device__ inline bool evalJoinFilter(const JoinFilterArgs& f, int64_t probeRow, uint32_t buildRow) {
+  for (int t = 0; t < f.numTerms; ++t) {
+    const JoinFilterTerm& term = f.terms[t];
+    const FilterOperand l =
+        term.leftSide == 0 ? probeOperand(term.leftProbe, probeRow) : buildOperand(f, term.leftDep, buildRow);
+    FilterOperand r{};
+    if (term.rightKind == 1) {
+      r = probeOperand(term.rightProbe, probeRow);
+    } else if (term.rightKind == 2) {
+      r = buildOperand(f, term.rightDep, buildRow);
+    } else if (term.constKind == VX355_BIGINT) {
+      r.i = term.i64;
+    } else if (term.constKind == VX355_DOUBLE) {
+      r.cls = 1;
+      r.d = term.f64;
+    } else {
+      r.cls = 2;
+      r.s = term.str;
+    }
+    if (l.null || r.null) {
+      return false;
+    }
+    bool ok;
+    if (l.cls == 2 || r.cls == 2) {
+      // inline strings: size, prefix and the 8 bytes behind it (unused bytes are zero)
+      const bool eq = l.cls == r.cls && l.s.x == r.s.x && l.s.y == r.s.y && l.s.z == r.s.z && l.s.w == r.s.w;
+      ok = term.cmp == VX355_CMP_EQ ? eq : !eq;
+    } else if (l.cls == 0 && r.cls == 0) {
+      ok = compareValues<int64_t>(term.cmp, l.i, r.i);
+    } else {
+      ok = compareValues<double>(term.cmp, l.cls == 0 ? static_cast<double>(l.i) : l.d,
+                                 r.cls == 0 ? static_cast<double>(r.i) : r.d);
+    }
+    if (!ok) {
+      return false;
+    }
+  }
+  return true;
+}
+
+struct FilterPassArgs {
+  JoinFilterArgs f;
+  uint32_t* hits;      // in: first row of the chain; out: first PASSING row, or kNoRow32
+  uint32_t* counts;    // out: output rows of the probe row
+  uint64_t* tileSums;
+  const uint32_t* next;
+  uint8_t* probed;     // right / full / right semi / right anti: flags of the passing pairs
+  int64_t numRows;
+  int64_t numTiles;
+  int32_t joinType;
+  int32_t pad;
+};
+
+// Second pass of a probe with an extra filter (or of any probe whose per-row output
+// has to be recomputed from hits[]): walks every chain, evaluates the filter per
+// pair, turns a probe row without a passing pair into a miss, counts the output
+// rows and the tile sums, sets the probed flags of the passing pairs.
+__global__ __launch_bounds__(256) void k_join_filter(FilterPassArgs a) {
+  __shared__ uint64_t waveSums[4];
+  const bool lists = listsMatches(a.joinType);
+  for (int64_t tile = blockIdx.x; tile < a.numTiles; tile += gridDim.x) {
+    uint64_t mine = 0;
+    for (int it = 0; it < kTileRows / 256; ++it) {
+      const int64_t r = tile * kTileRows + it * 256 + threadIdx.x;
+      if (r >= a.numRows) {
+        continue;
+      }
+      const uint32_t hit = a.hits[r];
+      uint32_t passing = 0;
+      uint32_t first = kNoRow32;
+      if (isHit(hit)) {
+        for (uint32_t b = hit; b != kNoRow32; b = a.next[b]) {
+          if (a.f.numTerms == 0 || evalJoinFilter(a.f, r, b)) {
+            if (first == kNoRow32) {
+              first = b;
+            }
+            ++passing;
+            if (a.probed) {
+              a.probed[b] = 1;
+            }
+            if (!lists && !a.probed) {
+              break;  // "does any pair pass" is all the semi / anti kinds ask
+            }
+          }
+        }
+        a.hits[r] = first;
+      }
+      const uint32_t c = outputCount(a.joinType, passing, hit == kNullKey32);
+      a.counts[r] = c;
+      mine += c;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mine += shfl64(mine, lane() ^ off);
+    }
+    if (lane() == 0) {
+      waveSums[threadIdx.x >> 6] = mine;
+    }
+    blockSync();
+    if (threadIdx.x == 0) {
+      a.tileSums[tile] = waveSums[0] + waveSums[1] + waveSums[2] + waveSums[3];
+    }
+    blockSync();
+  }
+}
+
+// ---- counting joins (INTERSECT ALL / EXCEPT ALL, HashProbe.cpp:1345-1365) -------------------
+// remaining[head row] = occurrences of the key not yet consumed by a probe row.
+// Probe rows of one batch that hit the same key are ranked in probe-row order
+// (sorted {head, probe row} words); the first 'remaining' of them consume one
+// occurrence each, exactly like the reference's row-at-a-time loop.
+__global__ __launch_bounds__(256) void k_hit_bits(const uint32_t* hits, int64_t n, uint64_t* bits) {
+  const int64_t numWords = (n + 63) >> 6;
+  const int64_t waveStride = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+  for (int64_t w = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6; w < numWords;
+       w += waveStride) {
+    const int64_t r = (w << 6) + lane();
+    const uint64_t word = ballot(r < n && isHit(hits[r]));
+    if (lane() == 0) {
+      bits[w] = word;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_hit_words(const uint32_t* hits, const int32_t* rows, int64_t n,
+                                                    uint64_t* words) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint32_t row = static_cast<uint32_t>(rows[i]);
+    words[i] = (static_cast<uint64_t>(hits[row]) << 32) | row;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_count_consume(const uint64_t* sorted, int64_t n, uint32_t* remaining,
+                                                        uint32_t* hits) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint32_t head = static_cast<uint32_t>(sorted[i] >> 32);
+    if (i > 0 && static_cast<uint32_t>(sorted[i - 1] >> 32) == head) {
+      continue;  // the lane at the start of the run walks it
+    }
+    const uint32_t left = remaining[head];
+    uint32_t used = 0;
+    for (int64_t j = i; j < n && static_cast<uint32_t>(sorted[j] >> 32) == head; ++j) {
+      const uint32_t row = static_cast<uint32_t>(sorted[j]);
+      if (used < left) {
+        ++used;  // consumes one occurrence: stays a hit
+      } else {
+        hits[row] = kNoRow32;
+      }
+    }
+    remaining[head] = left - used;
   }
 }
 
@@ -933,7 +1217,9 @@ struct EmitArgs {
   int32_t* buildRows;
   const uint2* staged;       // sparse listing: {probe row, build row} per tile, kSparseCap apart
   const uint8_t* tileDense;  // tiles that fell back to hits[]
+  JoinFilterArgs f;          // extra filter: only the passing rows of a chain are listed
 };
+static_assert(sizeof(EmitArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
 // Each block owns one tile of probe rows and walks it in 256-row steps: a block
 // scan of the per-row output counts gives every row its output offset; rows
@@ -1045,6 +1331,12 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
       const bool firstOnly = isHit(hit) && a.joinType == VX355_JOIN_LEFT_SEMI_PROJECT;
       uint32_t b = hit;
       for (uint64_t p = lo; p < hi && p < a.windowEnd; ++p) {
+        if (listMatches && a.f.numTerms) {
+          // hits[] holds the first passing row (k_join_filter); later ones are found by re-evaluating
+          while (p != lo && !evalJoinFilter(a.f, r, b)) {
+            b = a.next[b];
+          }
+        }
         if (p >= a.windowBegin) {
           a.mapping[p - a.windowBegin] = static_cast<int32_t>(r);
           if (a.buildRows) {
@@ -1088,7 +1380,7 @@ __global__ __launch_bounds__(256) void k_gather_deps(GatherArgs a) {
   const bool active = pos < a.count;
   const int32_t b = active ? a.buildRows[pos] : -1;
   for (int c = 0; c < a.numCols; ++c) {
-    const bool valid = active && b >= 0 && a.depValid[c][b] != 0;
+    const bool valid = active && b >= 0 && (a.depValid[c] == nullptr || a.depValid[c][b] != 0);
     uint64_t m = ballot(valid);
     if (a.outNulls[c] && lane() == 0) {
       a.outNulls[c][pos >> 6] = m;
@@ -1126,15 +1418,19 @@ __global__ __launch_bounds__(256) void k_gather_deps(GatherArgs a) {
   }
 }
 
-bool supportedJoin(int32_t t) {
-  return t == VX355_JOIN_INNER || t == VX355_JOIN_LEFT || t == VX355_JOIN_LEFT_SEMI_FILTER ||
-      t == VX355_JOIN_ANTI || t == VX355_JOIN_RIGHT || t == VX355_JOIN_FULL ||
-      t == VX355_JOIN_RIGHT_SEMI_FILTER || t == VX355_JOIN_LEFT_SEMI_PROJECT;
-}
+bool supportedJoin(int32_t t) { return t >= VX355_JOIN_INNER && t <= VX355_JOIN_RIGHT_ANTI; }
 
-bool keepsNullKeyRows(int32_t t) { return t == VX355_JOIN_RIGHT || t == VX355_JOIN_FULL; }
+// HashBuild.cpp:257-268: these kinds list build rows, so rows with null keys stay in the table.
+bool keepsNullKeyRows(int32_t t) {
+  return t == VX355_JOIN_RIGHT || t == VX355_JOIN_FULL || t == VX355_JOIN_RIGHT_SEMI_PROJECT ||
+      t == VX355_JOIN_RIGHT_ANTI;
+}
 bool marksProbedRows(int32_t t) {
-  return t == VX355_JOIN_RIGHT || t == VX355_JOIN_FULL || t == VX355_JOIN_RIGHT_SEMI_FILTER;
+  return t == VX355_JOIN_RIGHT || t == VX355_JOIN_FULL || t == VX355_JOIN_RIGHT_SEMI_FILTER ||
+      t == VX355_JOIN_RIGHT_SEMI_PROJECT || t == VX355_JOIN_RIGHT_ANTI;
+}
+bool countingJoin(int32_t t) {
+  return t == VX355_JOIN_COUNTING_LEFT_SEMI_FILTER || t == VX355_JOIN_COUNTING_ANTI;
 }
 
 // bit r = (probed[r] != 0) == wantProbed
@@ -1145,7 +1441,7 @@ __global__ __launch_bounds__(256) void k_probed_bits(const uint8_t* probed, int6
   for (int64_t w = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6; w < numWords;
        w += waveStride) {
     const int64_t r = (w << 6) + lane();
-    const bool on = r < n && (probed[r] != 0) == (wantProbed != 0);
+    const bool on = r < n && (wantProbed == 2 || (probed[r] != 0) == (wantProbed != 0));  // 2 = every row
     const uint64_t word = ballot(on);
     if (lane() == 0) {
       bits[w] = word;
@@ -1197,7 +1493,8 @@ struct vx355_join_table {
   int64_t numDistinct = 0;
   bool hasDuplicates = false;
   bool hasNullKeys = false;
-  DevBuf probed;   // right / full / right semi joins: 1 byte per build row
+  DevBuf probed;   // right / full / right semi / right anti joins: 1 byte per build row
+  DevBuf remaining;  // counting joins: occurrences left per distinct key, at the chain's head row
   bool keepsNullRows = false;
   // dynamic filters: ascending distinct values per key, computed on first request
   std::vector<DevBuf> distinctVals;
@@ -1210,7 +1507,11 @@ struct vx355_join_probe {
   std::vector<int32_t> keyCols;
   int32_t joinType = 0;
   DevBuf hits, counts, tileSums, tileOffsets, scratch, outMap, outRows;
-  DevBuf staged, tileDense;  // sparse listing (probeAddInput)
+  DevBuf staged, tileDense, sparseStats;  // sparse listing (probeAddInput)
+  DeviceBatch batch;                       // the batch being probed: the filter reads it at output time
+  std::vector<vx355_join_filter_term> filter;
+  std::vector<int32_t> usedCols;           // key columns + the filter's probe columns
+  DevBuf hitBits, hitRows, hitWords, hitSorted, sortTmp;  // counting joins
   bool sparse = false;
   int32_t sparseMode = -1;   // VX355_JOIN_SPARSE: -1 adaptive, 0 never, 1 always
   int64_t sparseTiles = 0;   // statistics of the last batch: tiles listed by the probe pass
@@ -1511,6 +1812,18 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
   }
   t->numDistinct = c.numDistinct;
   t->hasDuplicates = c.duplicates != 0;
+  if (countingJoin(h.joinType)) {
+    if (t->mode == JMODE_HASH) {
+      VX_THROW(VX355_EUNSUPPORTED, "counting joins over keys without a normalized form");
+    }
+    const size_t bytes = static_cast<size_t>(std::max<int64_t>(1, h.numRows)) * 4;
+    t->remaining.ensure(bytes + 64);
+    HIP_OK(hipMemsetAsync(t->remaining.ptr(), 0, bytes, rt.stream));
+    if (h.numRows > 0) {
+      VX_LAUNCH("k_count_init", k_count_init, streamGrid(h.numRows, 256), 256, 0, ia, t->remaining.as<uint32_t>());
+    }
+    rt.sync();
+  }
   if (marksProbedRows(h.joinType)) {
     t->probed.ensure(static_cast<size_t>(std::max<int64_t>(1, h.numRows)) + 64);
     HIP_OK(hipMemsetAsync(t->probed.ptr(), 0, static_cast<size_t>(std::max<int64_t>(1, h.numRows)), rt.stream));
@@ -1526,12 +1839,83 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
   return t.release();
 }
 
+// The filter of 'p' over the batch in 'db' and the table's dependent columns.
+void fillFilterArgs(const vx355_join_probe& p, const DeviceBatch& db, JoinFilterArgs* f) {
+  const auto& t = *p.table;
+  *f = JoinFilterArgs{};
+  f->numTerms = static_cast<int32_t>(p.filter.size());
+  for (size_t d = 0; d < t.depKinds.size(); ++d) {
+    f->depVals[d] = t.depVals[d].as<char>();
+    f->depValid[d] = t.depValid[d].as<uint8_t>();
+    f->depWidth[d] = kindWidth(t.depKinds[d]);
+    f->depKind[d] = t.depKinds[d];
+  }
+  auto classOf = [](int32_t kind) { return isString(kind) ? 2 : ((kind == VX355_REAL || kind == VX355_DOUBLE) ? 1 : 0); };
+  for (int32_t i = 0; i < f->numTerms; ++i) {
+    const vx355_join_filter_term& src = p.filter[i];
+    JoinFilterTerm& term = f->terms[i];
+    term.leftSide = src.left_side;
+    term.cmp = src.cmp;
+    term.rightKind = src.right_kind;
+    term.constKind = src.const_kind;
+    term.i64 = src.i64;
+    term.f64 = src.f64;
+    int leftClass, rightClass;
+    auto depKind = [&](int32_t dep) {
+      VX_CHECK_ARG(dep >= 0 && dep < static_cast<int32_t>(t.depKinds.size()), "join filter: no such build column");
+      return t.depKinds[dep];
+    };
+    auto probeCol = [&](int32_t col) -> const ColView& {
+      VX_CHECK_ARG(col >= 0 && col < db.numCols() && db.used(col), "join filter: no such probe column");
+      return db.col(col);
+    };
+    if (src.left_side == 0) {
+      term.leftProbe = probeCol(src.left_col);
+      leftClass = classOf(term.leftProbe.kind);
+      if (term.leftProbe.kind == VX355_TIMESTAMP) {
+        VX_THROW(VX355_EUNSUPPORTED, "join filter over TIMESTAMP");
+      }
+    } else {
+      term.leftDep = src.left_col;
+      leftClass = classOf(depKind(src.left_col));
+      if (depKind(src.left_col) == VX355_TIMESTAMP) {
+        VX_THROW(VX355_EUNSUPPORTED, "join filter over TIMESTAMP");
+      }
+    }
+    if (src.right_kind == 1) {
+      term.rightProbe = probeCol(src.right_col);
+      rightClass = classOf(term.rightProbe.kind);
+    } else if (src.right_kind == 2) {
+      term.rightDep = src.right_col;
+      rightClass = classOf(depKind(src.right_col));
+    } else {
+      rightClass = src.const_kind == VX355_BIGINT ? 0 : (src.const_kind == VX355_DOUBLE ? 1 : 2);
+      if (rightClass == 2) {
+        VX_CHECK_ARG(src.str_size >= 0 && src.str_size <= 12, "join filter: string constants of at most 12 bytes");
+        char view[16] = {0};
+        const uint32_t size = static_cast<uint32_t>(src.str_size);
+        std::memcpy(view, &size, 4);
+        std::memcpy(view + 4, src.str, size);
+        std::memcpy(&term.str, view, 16);
+      }
+    }
+    if ((leftClass == 2) != (rightClass == 2)) {
+      VX_THROW(VX355_EINVAL, "join filter compares a string with a number");
+    }
+    if (leftClass == 2 && src.cmp != VX355_CMP_EQ && src.cmp != VX355_CMP_NE) {
+      VX_THROW(VX355_EUNSUPPORTED, "join filter: strings compare with = and <> only");
+    }
+  }
+}
+
 void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
   auto& rt = Runtime::get();
   auto& t = *p.table;
-  DeviceBatch db;
-  db.load(batch, p.keyCols);
+  DeviceBatch& db = p.batch;
+  db.load(batch, p.usedCols);
   const int64_t n = db.numRows();
+  const bool filtered = !p.filter.empty();
+  const bool counting = countingJoin(p.joinType);
   p.numRows = n;
   p.cursor = 0;
   p.totalOut = 0;
@@ -1547,7 +1931,8 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
     }
     a.nullAware = t.numRows > 0 ? 1 : 0;  // an empty build side passes every row, null keys included
   }
-  a.probed = marksProbedRows(p.joinType) ? t.probed.as<uint8_t>() : nullptr;
+  // with a filter the probed flags belong to the passing pairs: k_join_filter sets them
+  a.probed = (marksProbedRows(p.joinType) && !filtered) ? t.probed.as<uint8_t>() : nullptr;
   a.numKeys = static_cast<int32_t>(p.keyCols.size());
   for (int k = 0; k < a.numKeys; ++k) {
     a.keys[k] = db.col(p.keyCols[k]);
@@ -1581,6 +1966,12 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
        p.joinType == VX355_JOIN_FULL);
   a.counts = p.haveCounts ? static_cast<uint32_t*>(p.counts.ensure(static_cast<size_t>(n) * 4 + 64))
                           : nullptr;
+  if (filtered) {
+    // the filter pass counts the passing pairs itself
+    p.haveCounts = true;
+    p.counts.ensure(static_cast<size_t>(n) * 4 + 64);
+    a.counts = nullptr;
+  }
   p.numTiles = ceilDiv(n, kTileRows);
   a.numTiles = p.numTiles;
   uint64_t* sums = static_cast<uint64_t*>(p.tileSums.ensure(static_cast<size_t>(p.numTiles) * 8 + 64));
@@ -1597,6 +1988,7 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
     ProbeArgs la = a;
     la.tileBegin = tileBegin;
     la.numTiles = tileEnd;
+    la.countHits = tileBegin == 0 && tileEnd < p.numTiles ? 1 : 0;
     const int grid =
         static_cast<int>(std::min<int64_t>(tileEnd - tileBegin, static_cast<int64_t>(rt.numCUs) * 8));
     if (grid <= 0) {
@@ -1619,7 +2011,7 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
   // Sparse listing: joins that emit matches only, one build row per match, not null
   // aware. Whether the hit rate is low enough is measured on the first tiles of the
   // batch (the probe pass reports tiles that overflowed their staging segment).
-  const bool sparseEligible = p.sparseMode != 0 && !p.haveCounts && !a.nullAware &&
+  const bool sparseEligible = p.sparseMode != 0 && !p.haveCounts && !a.nullAware && !filtered && !counting &&
       (p.joinType == VX355_JOIN_INNER || p.joinType == VX355_JOIN_LEFT_SEMI_FILTER ||
        (p.joinType == VX355_JOIN_RIGHT && !t.hasDuplicates));
   p.sparse = false;
@@ -1627,18 +2019,18 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
   if (sparseEligible) {
     a.staged = static_cast<uint2*>(p.staged.ensure(static_cast<size_t>(p.numTiles) * kSparseCap * sizeof(uint2) + 64));
     a.tileDense = static_cast<uint8_t*>(p.tileDense.ensure(static_cast<size_t>(p.numTiles) + 64));
-    a.sparseStats = rt.mail.dev;
-    rt.mail.host[0] = 0;
-    rt.mail.host[1] = 0;
+    a.sparseStats = static_cast<uint64_t*>(p.sparseStats.ensure(64));
+    HIP_OK(hipMemsetAsync(a.sparseStats, 0, 16, rt.stream));
     const int64_t sample = p.sparseMode == 1 ? p.numTiles : std::min<int64_t>(p.numTiles, 256);
     launch(std::true_type{}, 0, sample);
     p.sparse = true;
     if (sample < p.numTiles) {
-      rt.sync();
-      const uint64_t overflowed = rt.mail.host[0];
+      uint64_t stats[2] = {0, 0};
+      copyOut(stats, VX355_MEM_HOST, a.sparseStats, 16);  // synchronises the stream
+      const uint64_t overflowed = stats[0];
       // dense when more than 1 tile in 16 overflowed or the average tile is half full
       const bool stay = overflowed * 16 <= static_cast<uint64_t>(sample) &&
-          rt.mail.host[1] <= static_cast<uint64_t>(sample) * (kSparseCap / 2);
+          stats[1] <= static_cast<uint64_t>(sample) * (kSparseCap / 2);
       if (stay) {
         launch(std::true_type{}, sample, p.numTiles);
       } else {
@@ -1650,13 +2042,48 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
   } else {
     launch(std::false_type{}, 0, p.numTiles);
   }
+  if (counting && t.numRows > 0) {
+    // Rank the probe rows of every key in probe order and let the first 'remaining' consume.
+    const size_t words = static_cast<size_t>(ceilDiv(n, 64));
+    uint64_t* bits = static_cast<uint64_t*>(p.hitBits.ensure(words * 8 + 64));
+    VX_LAUNCH("k_hit_bits", k_hit_bits, streamGrid(n, 256), 256, 0, a.hits, n, bits);
+    int32_t* rows = static_cast<int32_t*>(p.hitRows.ensure(static_cast<size_t>(n) * 4 + 64));
+    int64_t numHits = 0;
+    compactBits(bits, nullptr, nullptr, n, rows, p.scratch, &numHits);
+    if (numHits > 0) {
+      uint64_t* wordsIn = static_cast<uint64_t*>(p.hitWords.ensure(static_cast<size_t>(numHits) * 8 + 64));
+      uint64_t* sorted = static_cast<uint64_t*>(p.hitSorted.ensure(static_cast<size_t>(numHits) * 8 + 64));
+      VX_LAUNCH("k_hit_words", k_hit_words, streamGrid(numHits, 256), 256, 0, a.hits, rows, numHits, wordsIn);
+      sortKeysU64(wordsIn, sorted, static_cast<size_t>(numHits), p.sortTmp);
+      VX_LAUNCH("k_count_consume", k_count_consume, streamGrid(numHits, 256), 256, 0, sorted, numHits,
+                t.remaining.as<uint32_t>(), a.hits);
+    }
+  }
+  if (filtered || counting) {
+    FilterPassArgs fa{};
+    fillFilterArgs(p, db, &fa.f);
+    fa.hits = a.hits;
+    fa.counts = static_cast<uint32_t*>(p.counts.ensure(static_cast<size_t>(n) * 4 + 64));
+    p.haveCounts = true;
+    fa.tileSums = sums;
+    fa.next = a.next;
+    // a counting join asks about the head row only (one row per distinct key consumed)
+    fa.probed = (filtered && marksProbedRows(p.joinType)) ? t.probed.as<uint8_t>() : nullptr;
+    fa.numRows = n;
+    fa.numTiles = p.numTiles;
+    fa.joinType = p.joinType;
+    const int fgrid = static_cast<int>(std::min<int64_t>(p.numTiles, static_cast<int64_t>(rt.numCUs) * 8));
+    VX_LAUNCH("k_join_filter", k_join_filter, fgrid, 256, 0, fa);
+  }
   VX_LAUNCH("k_scan_u64", k_scan_u64, 1, 1024, 0, sums, p.numTiles, offs);
   p.hostTileOffsets.resize(p.numTiles + 1);
   copyOut(p.hostTileOffsets.data(), VX355_MEM_HOST, offs, static_cast<size_t>(p.numTiles + 1) * 8);
   rt.sync();
   p.totalOut = p.hostTileOffsets.back();
   if (p.sparse) {
-    p.denseTiles += static_cast<int64_t>(rt.mail.host[0]);
+    uint64_t stats[2] = {0, 0};
+    copyOut(stats, VX355_MEM_HOST, p.sparseStats.ptr(), 16);
+    p.denseTiles += static_cast<int64_t>(stats[0]);
     p.sparseTiles = p.numTiles - p.denseTiles;
   }
 }
@@ -1674,9 +2101,14 @@ void gatherBuildCols(vx355_join_probe& p, const vx355_join_table& t, const int32
     size_t total = 0;
     for (int32_t c = 0; c < numBuildCols; ++c) {
       const int32_t id = buildColIds[c];
-      VX_CHECK_ARG(id >= 0 && id < static_cast<int32_t>(t.depKinds.size()), "bad build column id");
-      VX_CHECK_ARG(buildCols[c].type_kind == t.depKinds[id], "build column type mismatch");
-      const int w = kindWidth(t.depKinds[id]);
+      if (id == VX355_BUILD_COL_MATCH) {
+        VX_CHECK_ARG(p.joinType == VX355_JOIN_RIGHT_SEMI_PROJECT && buildCols[c].type_kind == VX355_BOOLEAN,
+                     "the match column is a BOOLEAN of right semi project joins");
+      } else {
+        VX_CHECK_ARG(id >= 0 && id < static_cast<int32_t>(t.depKinds.size()), "bad build column id");
+        VX_CHECK_ARG(buildCols[c].type_kind == t.depKinds[id], "build column type mismatch");
+      }
+      const int w = id == VX355_BUILD_COL_MATCH ? 0 : kindWidth(t.depKinds[id]);
       valBytes[c] = w == 0 ? words * 8 : static_cast<size_t>(n) * w;
       valOff[c] = total;
       total += (valBytes[c] + 63) & ~static_cast<size_t>(63);
@@ -1686,10 +2118,18 @@ void gatherBuildCols(vx355_join_probe& p, const vx355_join_table& t, const int32
     char* scratch = static_cast<char*>(p.scratch.ensure(total + 64));
     for (int32_t c = 0; c < numBuildCols; ++c) {
       const int32_t id = buildColIds[c];
-      ga.depVals[c] = t.depVals[id].as<char>();
-      ga.depValid[c] = t.depValid[id].as<uint8_t>();
-      ga.width[c] = kindWidth(t.depKinds[id]);
-      ga.kind[c] = t.depKinds[id];
+      if (id == VX355_BUILD_COL_MATCH) {
+        // extractProbedFlags (not null aware): match = some probe row matched this build row
+        ga.depVals[c] = t.probed.as<char>();
+        ga.depValid[c] = nullptr;
+        ga.width[c] = 0;
+        ga.kind[c] = VX355_BOOLEAN;
+      } else {
+        ga.depVals[c] = t.depVals[id].as<char>();
+        ga.depValid[c] = t.depValid[id].as<uint8_t>();
+        ga.width[c] = kindWidth(t.depKinds[id]);
+        ga.kind[c] = t.depKinds[id];
+      }
       const bool colHost = buildCols[c].mem == VX355_MEM_HOST;
       ga.outVals[c] = colHost ? static_cast<void*>(scratch + valOff[c]) : buildCols[c].values;
       ga.outNulls[c] = colHost ? reinterpret_cast<uint64_t*>(scratch + nullOff[c]) : buildCols[c].nulls;
@@ -1751,6 +2191,9 @@ void probeGetOutput(vx355_join_probe& p, int32_t maxRows, int32_t* mappingOut, i
   ea.buildRows = dRows;
   ea.staged = p.sparse ? p.staged.as<uint2>() : nullptr;
   ea.tileDense = p.sparse ? p.tileDense.as<uint8_t>() : nullptr;
+  if (!p.filter.empty()) {
+    fillFilterArgs(p, p.batch, &ea.f);
+  }
   VX_LAUNCH("k_emit", k_emit, static_cast<int>(lastTile - firstTile + 1), 256, 0, ea);
 
   if (numBuildCols > 0) {
@@ -1790,7 +2233,9 @@ void probeGetBuildSideOutput(vx355_join_probe& p, int32_t maxRows, int32_t* buil
       DevBuf bits, scratch;
       bits.ensure(static_cast<size_t>(ceilDiv(t.numRows, 64)) * 8 + 64);
       VX_LAUNCH("k_probed_bits", k_probed_bits, streamGrid(t.numRows, 256), 256, 0, t.probed.as<uint8_t>(),
-                t.numRows, p.joinType == VX355_JOIN_RIGHT_SEMI_FILTER ? 1 : 0, bits.as<uint64_t>());
+                t.numRows,
+                p.joinType == VX355_JOIN_RIGHT_SEMI_FILTER ? 1 : (p.joinType == VX355_JOIN_RIGHT_SEMI_PROJECT ? 2 : 0),
+                bits.as<uint64_t>());
       p.buildSideRows.ensure(static_cast<size_t>(t.numRows) * 4 + 64);
       compactBits(bits.as<uint64_t>(), nullptr, nullptr, t.numRows, p.buildSideRows.as<int32_t>(), scratch,
                   &p.buildSideCount);
@@ -1963,6 +2408,9 @@ int vx355_join_build_create(const vx355_join_build_spec* spec, vx355_join_build*
     VX_THROW(VX355_EUNSUPPORTED, "join type " + std::to_string(spec->join_type) +
                                      (spec->null_aware ? " (null aware)" : "") + " not on device");
   }
+  if (countingJoin(spec->join_type) && spec->num_dependents != 0) {
+    VX_THROW(VX355_EINVAL, "counting joins (INTERSECT ALL / EXCEPT ALL) have no build payload columns");
+  }
   auto h = std::make_unique<vx355_join_build>();
   h->joinType = spec->join_type;
   for (int32_t k = 0; k < spec->num_keys; ++k) {
@@ -2096,6 +2544,10 @@ int vx355_join_probe_create(vx355_join_table* table, const vx355_join_probe_spec
       spec->join_type != table->joinType) {
     VX_THROW(VX355_EINVAL, "right / full / right semi joins need a table built for that join type");
   }
+  if (countingJoin(spec->join_type) != countingJoin(table->joinType) ||
+      (countingJoin(spec->join_type) && spec->join_type != table->joinType)) {
+    VX_THROW(VX355_EINVAL, "counting joins need a table built for that join type");
+  }
   if (Runtime::get().device != table->device) {
     VX_THROW(VX355_EINVAL, "probe created on another GPU than its join table (vx355_set_device)");
   }
@@ -2112,7 +2564,35 @@ int vx355_join_probe_create(vx355_join_table* table, const vx355_join_probe_spec
     }
   }
   p->keyCols.assign(spec->key_cols, spec->key_cols + spec->num_keys);
+  p->usedCols = p->keyCols;
   *out = p.release();
+  VX_API_END
+}
+
+int vx355_join_probe_set_filter(vx355_join_probe* h, const vx355_join_filter_term* terms, int32_t n_terms) {
+  VX_API_BEGIN_CTX(VX_CTX_OF(h))
+  VX_CHECK_ARG(h && (terms || n_terms == 0), "NULL argument");
+  VX_CHECK_ARG(n_terms >= 0 && n_terms <= kMaxJoinFilterTerms, "0..4 join filter terms");
+  VX_CHECK_ARG(!h->hasInput, "set_filter after the first add_input");
+  if (n_terms > 0 && countingJoin(h->joinType)) {
+    VX_THROW(VX355_EUNSUPPORTED, "counting joins take no extra filter (exec/HashProbe.cpp:1345-1365)");
+  }
+  if (n_terms > 0 && h->nullAware) {
+    VX_THROW(VX355_EUNSUPPORTED, "null-aware anti join with an extra filter");
+  }
+  h->filter.assign(terms, terms + n_terms);
+  h->usedCols = h->keyCols;
+  for (const auto& t : h->filter) {
+    VX_CHECK_ARG(t.left_side == 0 || t.left_side == 1, "join filter: left_side is 0 (probe) or 1 (build)");
+    VX_CHECK_ARG(t.right_kind >= 0 && t.right_kind <= 2, "join filter: bad right_kind");
+    VX_CHECK_ARG(t.cmp >= VX355_CMP_EQ && t.cmp <= VX355_CMP_GE, "join filter: bad comparison");
+    if (t.left_side == 0) {
+      h->usedCols.push_back(t.left_col);
+    }
+    if (t.right_kind == 1) {
+      h->usedCols.push_back(t.right_col);
+    }
+  }
   VX_API_END
 }
 

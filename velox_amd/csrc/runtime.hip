@@ -92,7 +92,22 @@ Runtime* Runtime::defaultContext(int device) { return deviceState(device)->defau
 Runtime* Runtime::createContext() {
   // A handle created inside another handle's entry point lives on that handle's device.
   DeviceState* ds = tlsCurrent ? tlsCurrent->ds : deviceState(-1);
+  {
+    std::lock_guard<std::mutex> lock(ds->memMutex);
+    if (!ds->idleContexts.empty()) {
+      Runtime* ctx = ds->idleContexts.back();
+      ds->idleContexts.pop_back();
+      return ctx;  // idle: its last entry point drained the stream
+    }
+  }
   return newContext(ds, false);
+}
+
+void freeContext(Runtime* ctx) {
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipHostFree(ctx->mail.host);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
 }
 
 void Runtime::destroyContext(Runtime* ctx) {
@@ -100,13 +115,16 @@ void Runtime::destroyContext(Runtime* ctx) {
     return;
   }
   (void)hipStreamSynchronize(ctx->stream);
+  DeviceState* ds = ctx->ds;
   {
-    std::lock_guard<std::mutex> lock(ctx->ds->memMutex);
-    ctx->ds->contexts.erase(ctx->id);
+    std::lock_guard<std::mutex> lock(ds->memMutex);
+    if (ds->alive && !ctx->isDefault && ds->idleContexts.size() < 64) {
+      ds->idleContexts.push_back(ctx);  // stays registered in ds->contexts
+      return;
+    }
+    ds->contexts.erase(ctx->id);
   }
-  (void)hipHostFree(ctx->mail.host);
-  (void)hipStreamDestroy(ctx->stream);
-  delete ctx;
+  freeContext(ctx);
 }
 
 ContextScope::ContextScope(Runtime* ctx) : ctx_(ctx), prev_(tlsCurrent) {
@@ -741,7 +759,18 @@ void vx355_shutdown(void) {
     }
     Runtime* def = ds->defaultCtx;
     ds->defaultCtx = nullptr;
-    ds->alive = false;  // blocks released from now on go straight back to the driver
+    std::vector<Runtime*> idle;
+    {
+      std::lock_guard<std::mutex> mlock(ds->memMutex);
+      ds->alive = false;  // blocks released from now on go straight back to the driver
+      idle.swap(ds->idleContexts);
+      for (Runtime* c : idle) {
+        ds->contexts.erase(c->id);
+      }
+    }
+    for (Runtime* c : idle) {
+      vx::freeContext(c);
+    }
     Runtime::destroyContext(def);
   }
   vx::gDefaultDevice.store(-1);

@@ -34,6 +34,7 @@ SYMBOLS = [
     "vx355_bloom_num_blocks", "vx355_join_table_key_filter_bloom", "vx355_bloom_test",
     "vx355_set_device", "vx355_current_device", "vx355_stream_wait_event", "vx355_default_stream",
     "vx355_agg_stream", "vx355_join_build_stream", "vx355_join_probe_stream",
+    "vx355_join_probe_set_filter",
 ]
 
 
@@ -108,6 +109,7 @@ def lib():
     L.vx355_bloom_num_blocks.argtypes = [i64, C.c_double, i32]
     L.vx355_join_table_key_filter_bloom.argtypes = [vp, i32, i32, vp, i64, i32]
     L.vx355_bloom_test.argtypes = [vp, i64, i32, P(abi.Column), i32, vp, vp, i32]
+    L.vx355_join_probe_set_filter.argtypes = [vp, P(abi.JoinFilterTerm), i32]
     L.vx355_set_device.argtypes = [C.c_int]
     L.vx355_stream_wait_event.argtypes = [vp, vp]
     L.vx355_default_stream.restype = vp
@@ -561,7 +563,7 @@ class HashProbe:
         """HashProbe::getBuildSideOutput (right / full / right semi): -> (build rows, columns, finished)."""
         if build_col_ids is None:
             build_col_ids = list(range(len(self.table.dep_types)))
-        kinds = [self.table.dep_types[i] for i in build_col_ids]
+        kinds = [abi.BOOLEAN if i == abi.BUILD_COL_MATCH else self.table.dep_types[i] for i in build_col_ids]
         out = abi.OutBuffers(kinds, max_rows)
         build_rows = np.zeros(max(1, max_rows), dtype=np.int32)
         n, fin = C.c_int32(), C.c_int32()
@@ -570,6 +572,11 @@ class HashProbe:
                                                             out.descs, ids, len(kinds), C.byref(n), C.byref(fin)))
         cols = [out.column(i, n.value) for i in range(len(kinds))]
         return build_rows[: n.value].copy(), cols, bool(fin.value)
+
+    def set_filter(self, terms):
+        """HashJoinNode::filter: [(left, cmp, right)], see abi.join_filter_terms."""
+        self._filter = abi.join_filter_terms(terms)
+        _check(lib().vx355_join_probe_set_filter(self.h, self._filter, len(terms)))
 
     def add_input(self, batch):
         self._batch = batch
