@@ -625,6 +625,51 @@ int vx355_join_probe_get_build_side_output(
 void vx355_join_probe_destroy(vx355_join_probe* h);
 void* vx355_join_probe_stream(vx355_join_probe* h);
 
+/* ---- multi-GPU exchange (RCCL over xGMI) ------------------
+ * The hot path shards without communication except for two steps: the exchange of a
+ * repartitioned join (exec/PartitionedOutput.cpp + exec/Exchange.cpp in the reference,
+ * experimental/ucx-exchange for its GPU backend) and the partial -> final merge of a
+ * row-sharded aggregation (docs/develop/aggregations.rst:24-91). Both run inside the
+ * library on communicators it owns; librccl is loaded at first use.
+ *
+ * A communicator is bound to one GPU and carries its own execution context.
+ *  - one process per GPU: rank 0 calls vx355_comm_get_unique_id, the 128 bytes travel out
+ *    of band (MPI, a file, torch.distributed ...), every rank calls vx355_comm_create on
+ *    the thread bound to its GPU (vx355_set_device);
+ *  - one process for all GPUs of the node: vx355_init each device, then
+ *    vx355_comm_create_all; out[i] lives on devices[i]. Collective calls block until the
+ *    peers arrive: drive each communicator from its own thread (one Driver per GPU). */
+typedef struct vx355_comm vx355_comm;
+#define VX355_COMM_ID_BYTES 128
+int vx355_comm_get_unique_id(void* id_out /* VX355_COMM_ID_BYTES */);
+int vx355_comm_create(const void* id, int32_t world, int32_t rank, vx355_comm** out);
+int vx355_comm_create_all(int32_t num_devices, const int32_t* devices, vx355_comm** out /* num_devices */);
+int vx355_comm_info(const vx355_comm* c, int32_t* world, int32_t* rank, int32_t* device);
+void* vx355_comm_stream(vx355_comm* c);
+void vx355_comm_destroy(vx355_comm* c);
+
+/* Exchange of rows already grouped by destination rank (vx355_partition_scatter with
+ * num_partitions = world): send_counts[p] rows go to rank p.
+ * vx355_exchange_counts: recv_counts[s] = rows rank s sends to this rank (host arrays of
+ *   'world' entries; one small all-gather).
+ * vx355_exchange_columns: for every column (device buffers, widths[c] bytes per row) the
+ *   slice of rank p goes straight to rank p and the slices of all ranks arrive in rank
+ *   order: one ncclGroupStart / ncclSend + ncclRecv per peer and column / ncclGroupEnd, so
+ *   every slice rides its own xGMI link. recv_cols[c] must hold sum(recv_counts) rows. */
+int vx355_exchange_counts(vx355_comm* c, const int64_t* send_counts, int64_t* recv_counts);
+int vx355_exchange_columns(
+    vx355_comm* c,
+    const void* const* send_cols,
+    const int32_t* widths,
+    int32_t num_cols,
+    const int64_t* send_counts,
+    const int64_t* recv_counts,
+    void* const* recv_cols);
+/* All-gather of bytes_per_rank bytes from every rank (device buffers; recv holds world
+ * blocks in rank order): the partial results of a row-sharded aggregation meet on every
+ * rank before its FINAL step. */
+int vx355_all_gather(vx355_comm* c, const void* send, void* recv, size_t bytes_per_rank);
+
 #ifdef __cplusplus
 }
 #endif

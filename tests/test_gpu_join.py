@@ -171,7 +171,7 @@ def test_join_empty_build_and_empty_probe(oracle, vx):
 
 def test_unsupported_join_kinds_are_refused(vx):
     with pytest.raises(vx.Vx355Error) as e:
-        vx.JoinBuild([0], [abi.BIGINT], [], [], abi.JOIN_RIGHT_SEMI_PROJECT)
+        vx.JoinBuild([0], [abi.BIGINT], [], [], abi.JOIN_RIGHT_SEMI_PROJECT, null_aware=True)
     assert e.value.status == abi.EUNSUPPORTED
     with pytest.raises(vx.Vx355Error) as e:
         vx.JoinBuild([0], [abi.BIGINT], [], [], abi.JOIN_LEFT, null_aware=True)
@@ -249,8 +249,37 @@ def test_repartitioned_join_gpu_backend_single_rank(oracle, vx):
             for m, p in outs:
                 keys = received[0][m.long()].cpu().numpy().tolist()
                 assert [lookup[k] for k in keys] == p.cpu().numpy().tolist()
+        # the same exchange through the library's own RCCL communicator (vx355_comm_*,
+        # vx355_exchange_*): what a C++ host calls; torch.distributed is not involved
+        comm = vx.Comm(vx.Comm.unique_id(), 1, 0)
+        total2, outputs2, _ = vdist.repartitioned_join(backend, dist, torch, [t[0], t[1]], [t[2]],
+                                                      exchange_fn=vdist.LibExchange(torch, comm))
+        got = sorted(np.concatenate([p.cpu().numpy() for _, p in outputs2]).tolist())
+        assert total2 == len(want) and got == want
     finally:
         dist.destroy_process_group()
+
+
+def test_in_library_collectives_world_size_one(vx):
+    """vx355_comm_create / vx355_exchange_counts / vx355_exchange_columns / vx355_all_gather on a
+    one-rank communicator (the only size a 1-GPU box offers): slices addressed to the own rank
+    come back unchanged, counts and gathers are identities."""
+    import torch
+    dev = torch.device("cuda", 0)
+    comm = vx.Comm(vx.Comm.unique_id(), 1, 0)
+    assert comm.exchange_counts([12345]) == [12345]
+    a = torch.arange(12345, dtype=torch.int64, device=dev) * 3
+    b = torch.rand(12345, dtype=torch.float64, device=dev)
+    c = torch.arange(12345 * 4, dtype=torch.int32, device=dev).reshape(12345, 4)
+    outs = [torch.zeros_like(x) for x in (a, b, c)]
+    torch.cuda.synchronize()
+    comm.exchange_columns([x.data_ptr() for x in (a, b, c)], [8, 8, 16], [12345], [12345],
+                          [o.data_ptr() for o in outs])
+    for x, o in zip((a, b, c), outs):
+        assert bool((x == o).all())
+    g = torch.zeros_like(a)
+    comm.all_gather(a.data_ptr(), g.data_ptr(), a.numel() * 8)
+    assert bool((g == a).all())
 
 
 @pytest.mark.parametrize("join_type", JOIN_TYPES)

@@ -693,17 +693,70 @@ __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, Spars
   const int fastKey = FAST >= 0 ? FAST : a.fastKey;
   const int64_t tileBase = tile * kTileRows;
   uint64_t mine = 0;
-  for (int it = 0; it < kTileRows / (256 * kProbeUnroll); ++it) {
+  constexpr int kIters = kTileRows / (256 * kProbeUnroll);
+  auto rowOf = [&](int it, int u) -> int64_t {
+    return SPARSE ? tileBase + (threadIdx.x >> 6) * (kTileRows / 4) + (it * kProbeUnroll + u) * 64 + lane()
+                  : tileBase + (it * kProbeUnroll + u) * 256 + threadIdx.x;
+  };
+  // Flat BIGINT key (FAST == 1): the key loads of iteration it + 1 are issued behind the
+  // bitmap gathers of iteration it, so the HBM latency of the keys overlaps the cache
+  // latency of the dependent gathers instead of adding to it.
+  int64_t vnext[kProbeUnroll];
+  if (FAST == 1) {
+    const int64_t* kp = static_cast<const int64_t*>(a.keys[0].values);
+#pragma unroll
+    for (int u = 0; u < kProbeUnroll; ++u) {
+      const int64_t r = rowOf(0, u);
+      vnext[u] = kp[r < a.numRows ? r : a.numRows - 1];
+    }
+  }
+  for (int it = 0; it < kIters; ++it) {
     int64_t rows[kProbeUnroll];
     uint64_t key[kProbeUnroll];
     bool candidate[kProbeUnroll];
     uint32_t hit[kProbeUnroll];
 #pragma unroll
     for (int u = 0; u < kProbeUnroll; ++u) {
-      rows[u] = SPARSE ? tileBase + (threadIdx.x >> 6) * (kTileRows / 4) + (it * kProbeUnroll + u) * 64 + lane()
-                       : tileBase + (it * kProbeUnroll + u) * 256 + threadIdx.x;
+      rows[u] = rowOf(it, u);
     }
-    if (fastKey) {
+    if (FAST == 1) {
+      uint32_t word[kProbeUnroll];
+#pragma unroll
+      for (int u = 0; u < kProbeUnroll; ++u) {
+        const int64_t v = vnext[u];
+        candidate[u] = rows[u] < a.numRows && v >= a.ranges[0].min && v <= a.ranges[0].max;
+        key[u] = static_cast<uint64_t>(v) - static_cast<uint64_t>(a.ranges[0].min) + 1;
+      }
+      if (mode == JMODE_ARRAY) {
+#pragma unroll
+        for (int u = 0; u < kProbeUnroll; ++u) {
+          word[u] = candidate[u] ? a.present[key[u] >> 5] : 0;
+        }
+      }
+      if (it + 1 < kIters) {
+        const int64_t* kp = static_cast<const int64_t*>(a.keys[0].values);
+#pragma unroll
+        for (int u = 0; u < kProbeUnroll; ++u) {
+          const int64_t r = rowOf(it + 1, u);
+          vnext[u] = kp[r < a.numRows ? r : a.numRows - 1];
+        }
+      }
+      if (mode == JMODE_ARRAY) {
+#pragma unroll
+        for (int u = 0; u < kProbeUnroll; ++u) {
+          candidate[u] = (word[u] >> (key[u] & 31)) & 1;
+        }
+#pragma unroll
+        for (int u = 0; u < kProbeUnroll; ++u) {
+          hit[u] = candidate[u] ? a.head[key[u]] : kNoRow32;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < kProbeUnroll; ++u) {
+          hit[u] = candidate[u] ? lookupSlots(a, key[u]) : kNoRow32;
+        }
+      }
+    } else if (fastKey) {
       const int64_t* kp = static_cast<const int64_t*>(a.keys[0].values);
       int64_t v[kProbeUnroll];
       int64_t src[kProbeUnroll];
@@ -733,7 +786,9 @@ __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, Spars
         candidate[u] = rows[u] < a.numRows && probeKey(a, rows[u], &key[u]);
       }
     }
-    if (mode == JMODE_HASH) {
+    if (FAST == 1) {
+      // looked up above
+    } else if (mode == JMODE_HASH) {
 #pragma unroll
       for (int u = 0; u < kProbeUnroll; ++u) {
         hit[u] = rows[u] < a.numRows ? lookupGeneric(a, rows[u]) : kNoRow32;

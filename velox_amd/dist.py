@@ -206,6 +206,25 @@ def exchange(dist, torch, cols, counts):
     return out, rc
 
 
+class LibExchange:
+    """exchange() through libvx355's own RCCL communicator (vx355_exchange_counts /
+    vx355_exchange_columns, include/vx355.h): the form a C++ host uses; torch only allocates
+    the receive buffers here. comm: velox_amd.ops.Comm."""
+
+    def __init__(self, torch, comm):
+        self.torch, self.comm = torch, comm
+
+    def __call__(self, cols, counts):
+        torch = self.torch
+        rc = self.comm.exchange_counts(counts)
+        out = [torch.empty((sum(rc),) + tuple(c.shape[1:]), dtype=c.dtype, device=c.device) for c in cols]
+        src = [c.contiguous() for c in cols]
+        _drain(torch, src + out)   # the library's stream does not order itself behind torch's
+        widths = [c.element_size() * (c.shape[1] if c.dim() == 2 else 1) for c in src]
+        self.comm.exchange_columns([c.data_ptr() for c in src], widths, counts, rc, [o.data_ptr() for o in out])
+        return out, rc
+
+
 def exchange_async(dist, torch, cols, counts):
     """exchange() split in two: the row counts travel first (one tiny blocking all-to-all),
     the column payloads are posted with async_op=True. Returns a function that waits for
@@ -267,7 +286,7 @@ def repartitioned_join_pipelined(backend, dist, torch, build_cols, probe_cols, c
     return results, table
 
 
-def repartitioned_join(backend, dist, torch, build_cols, probe_cols):
+def repartitioned_join(backend, dist, torch, build_cols, probe_cols, exchange_fn=None):
     """build_cols / probe_cols: lists of torch tensors, column 0 is the BIGINT
     join key. backend supplies the device work:
       backend.partitions(key_tensor, world) -> uint32 partition number per row
@@ -279,7 +298,7 @@ def repartitioned_join(backend, dist, torch, build_cols, probe_cols):
     for cols in (build_cols, probe_cols):
         parts = backend.partitions(cols[0], world)
         grouped, counts = backend.scatter(parts, world, cols)
-        received, _ = exchange(dist, torch, grouped, counts)
+        received, _ = exchange_fn(grouped, counts) if exchange_fn else exchange(dist, torch, grouped, counts)
         sides.append(received)
     return backend.join(sides[0], sides[1])
 

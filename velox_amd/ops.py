@@ -35,6 +35,9 @@ SYMBOLS = [
     "vx355_set_device", "vx355_current_device", "vx355_stream_wait_event", "vx355_default_stream",
     "vx355_agg_stream", "vx355_join_build_stream", "vx355_join_probe_stream",
     "vx355_join_probe_set_filter",
+    "vx355_comm_get_unique_id", "vx355_comm_create", "vx355_comm_create_all", "vx355_comm_info",
+    "vx355_comm_stream", "vx355_comm_destroy", "vx355_exchange_counts", "vx355_exchange_columns",
+    "vx355_all_gather",
 ]
 
 
@@ -110,6 +113,17 @@ def lib():
     L.vx355_join_table_key_filter_bloom.argtypes = [vp, i32, i32, vp, i64, i32]
     L.vx355_bloom_test.argtypes = [vp, i64, i32, P(abi.Column), i32, vp, vp, i32]
     L.vx355_join_probe_set_filter.argtypes = [vp, P(abi.JoinFilterTerm), i32]
+    L.vx355_comm_get_unique_id.argtypes = [vp]
+    L.vx355_comm_create.argtypes = [vp, i32, i32, P(vp)]
+    L.vx355_comm_create_all.argtypes = [i32, P(i32), P(vp)]
+    L.vx355_comm_info.argtypes = [vp, P(i32), P(i32), P(i32)]
+    L.vx355_comm_stream.restype = vp
+    L.vx355_comm_stream.argtypes = [vp]
+    L.vx355_comm_destroy.argtypes = [vp]
+    L.vx355_comm_destroy.restype = None
+    L.vx355_exchange_counts.argtypes = [vp, P(i64), P(i64)]
+    L.vx355_exchange_columns.argtypes = [vp, P(vp), P(i32), i32, P(i64), P(i64), P(vp)]
+    L.vx355_all_gather.argtypes = [vp, vp, vp, sz]
     L.vx355_set_device.argtypes = [C.c_int]
     L.vx355_stream_wait_event.argtypes = [vp, vp]
     L.vx355_default_stream.restype = vp
@@ -131,6 +145,48 @@ def init(device=0):
 
 def synchronize():
     _check(lib().vx355_synchronize())
+
+
+# ---- multi-GPU exchange (RCCL inside the library) -----------------------------
+
+class Comm:
+    """vx355_comm: one rank's communicator, bound to the GPU of the calling thread."""
+
+    def __init__(self, unique_id, world, rank):
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        _check(lib().vx355_comm_create(buf, world, rank, C.byref(h)))
+        self.h, self.world, self.rank = h, world, rank
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        _check(lib().vx355_comm_get_unique_id(buf))
+        return buf.raw
+
+    def exchange_counts(self, send_counts):
+        send = (C.c_int64 * self.world)(*[int(x) for x in send_counts])
+        recv = (C.c_int64 * self.world)()
+        _check(lib().vx355_exchange_counts(self.h, send, recv))
+        return list(recv)
+
+    def exchange_columns(self, send_ptrs, widths, send_counts, recv_counts, recv_ptrs):
+        n = len(send_ptrs)
+        _check(lib().vx355_exchange_columns(self.h, (C.c_void_p * n)(*send_ptrs), abi.i32_array(widths), n,
+                                            (C.c_int64 * self.world)(*[int(x) for x in send_counts]),
+                                            (C.c_int64 * self.world)(*[int(x) for x in recv_counts]),
+                                            (C.c_void_p * n)(*recv_ptrs)))
+
+    def all_gather(self, send_ptr, recv_ptr, bytes_per_rank):
+        _check(lib().vx355_all_gather(self.h, send_ptr, recv_ptr, bytes_per_rank))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().vx355_comm_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
 
 
 # ---- device memory -------------------------------------------------------
