@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VX355_ABI_VERSION 1
+#define VX355_ABI_VERSION 2
 
 typedef enum vx355_status {
   VX355_OK = 0,
@@ -421,8 +421,33 @@ typedef struct vx355_agg_stats {
   int64_t input_rows;
   int64_t deferred_rows; /* rows replayed after a key-range widening */
   int64_t radix_launches; /* chunks aggregated through the radix-partitioned LDS path */
+  int64_t table_bytes;    /* HBM held by the group table (what isPartialFull compares with
+                             max_partial_aggregation_memory, GroupingSet::isPartialFull) */
+  int64_t num_flushes;    /* vx355_agg_flush calls completed (kFlushTimes) */
 } vx355_agg_stats;
 int vx355_agg_get_stats(const vx355_agg* h, vx355_agg_stats* out);
+
+/* Partial-aggregation flush (HashAggregation.cpp:191-236,293-327: when the partial table
+ * is "full" the operator emits what it has and starts over). PARTIAL / INTERMEDIATE steps
+ * with grouping keys only. After this call vx355_agg_get_output lists the groups
+ * accumulated so far (first-seen order) although no_more_input has not been called; when it
+ * reports finished the table is empty again (GroupingSet::resetTable) and add_input carries
+ * on. WHEN to flush is the shim's policy, from vx355_agg_get_stats: table_bytes against
+ * max_partial_aggregation_memory (16 MB default, core/QueryConfig.h), or the abandon test
+ * num_groups / input_rows >= abandon_partial_aggregation_min_pct after
+ * abandon_partial_aggregation_min_rows (HashAggregation.cpp:185-189). */
+int vx355_agg_flush(vx355_agg* h);
+
+/* Abandoned partial aggregation (HashAggregation.cpp:185-189,357-375 ->
+ * GroupingSet::toIntermediate, exec/GroupingSet.cpp:1589-1675): the raw input rows of
+ * 'batch' in the PARTIAL step's output layout WITHOUT grouping, one output row per input
+ * row, as if every row were its own group: sum -> the value (BIGINT for integer inputs,
+ * DOUBLE for REAL / DOUBLE) or null; count -> 1 or 0, never null; min / max -> the value;
+ * avg -> (DOUBLE value, BIGINT 1) or (null, null). A false or null mask and a null input
+ * make the row inactive for that aggregate. 'cols' receives the aggregate columns only, in
+ * output order (the key columns pass through unchanged: the shim reuses the input
+ * vectors), each with capacity batch->num_rows. Raw-input steps only; stateless. */
+int vx355_agg_to_intermediate(vx355_agg* h, const vx355_batch* batch, vx355_out_column* cols, int32_t num_cols);
 void vx355_agg_destroy(vx355_agg* h);
 /* hipStream_t of the operator's execution context (see vx355_stream_wait_event). */
 void* vx355_agg_stream(vx355_agg* h);

@@ -751,3 +751,106 @@ def test_radix_path_skewed_keys_and_few_partitions(oracle, vx, slice_recs, monke
     exp, _ = run_agg(oracle, [batch_of([k2, w, v])], [0], [abi.BIGINT], aggs, max_rows=200000)
     got, gop = run_agg(vx, [batch_of([k2, w, v])], [0], [abi.BIGINT], aggs, max_rows=200000)
     assert_columns_equal(got, exp, gop.kinds, what="radix few partitions")
+
+
+@pytest.mark.parametrize("shape", ["array", "normalized", "generic"])
+def test_partial_flush_emits_and_restarts(oracle, vx, shape, monkeypatch):
+    """HashAggregation.cpp:191-236,293-327: a PARTIAL operator that is "full" emits its groups and
+    starts over. Flushes in the middle of the stream must not lose or duplicate anything: the FINAL
+    step over all flushed pages equals a SINGLE aggregation of the whole input (oracle), and every
+    page lists its groups in first-seen order of the rows since the previous flush."""
+    monkeypatch.setenv("VX355_AGG_COALESCE_ROWS", "0")
+    rng = np.random.default_rng(61)
+    n, pieces = 240000, 6
+    if shape == "array":
+        k = rng.integers(0, 3000, n).astype(np.int64)
+    elif shape == "normalized":
+        k = ((rng.integers(0, 3000, n).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) % np.uint64(1 << 58)).astype(np.int64)
+    else:
+        k = rng.integers(0, 3000, n).astype(np.float64) * 0.5
+    ktype = abi.DOUBLE if shape == "generic" else abi.BIGINT
+    v = _dyadic(rng, n)
+    w = rng.integers(-1000, 1000, n).astype(np.int64)
+    vvalid = rng.random(n) > 0.1
+    raw = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT), (abi.AGG_AVG, 1, abi.DOUBLE),
+           (abi.AGG_MIN, 2, abi.BIGINT), (abi.AGG_COUNT, 1, abi.DOUBLE)]
+    op = vx.Aggregation([0], [ktype], raw, abi.STEP_PARTIAL)
+    pages = []
+    step = n // pieces
+    for i in range(pieces):
+        lo, hi = i * step, (i + 1) * step
+        op.add_input(batch_of([k[lo:hi], v[lo:hi], w[lo:hi]], [None, vvalid[lo:hi], None]))
+        if i % 2 == 1 and i != pieces - 1:
+            op.flush()
+            page = vx.collect_output(op, 777)
+            first = {}
+            for r in range((i - 1) * step, hi):
+                first.setdefault(k[r].item(), r)
+            assert list(page[0][0]) == [kk for kk, _ in sorted(first.items(), key=lambda t: t[1])]
+            pages.append(page)
+            assert op.stats().num_groups == 0
+    op.no_more_input()
+    pages.append(vx.collect_output(op, 777))
+    assert op.stats().num_flushes == 2 and op.stats().table_bytes > 0
+    from velox_amd import dist as vdist
+    kinds = vdist.partial_kinds([ktype], raw)
+    merged = []
+    for c in range(len(kinds)):
+        vals = np.concatenate([np.asarray(p[c][0]) for p in pages])
+        valid = np.concatenate([np.asarray(p[c][1]) for p in pages])
+        merged.append(abi.HostColumn(kinds[c], vals, valid))
+    fin = vx.Aggregation([0], [ktype], vdist.final_aggs_for(raw, 1), abi.STEP_FINAL)
+    fin.add_input(abi.HostBatch(merged))
+    fin.no_more_input()
+    got = vx.collect_output(fin, 5000)
+    exp, eop = run_agg(oracle, [batch_of([k, v, w], [None, vvalid, None])], [0], [ktype], raw, max_rows=5000)
+    order = np.argsort(np.asarray(got[0][0]), kind="stable")
+    eorder = np.argsort(np.asarray(exp[0][0]), kind="stable")
+    for c in range(len(exp)):
+        g, e = np.asarray(got[c][0])[order], np.asarray(exp[c][0])[eorder]
+        gv, ev = np.asarray(got[c][1])[order], np.asarray(exp[c][1])[eorder]
+        assert (gv == ev).all() and (g[ev] == e[ev]).all(), c
+    with pytest.raises(vx.Vx355Error):
+        vx.Aggregation([0], [ktype], raw, abi.STEP_SINGLE).flush()
+
+
+def test_to_intermediate_is_the_partial_layout_of_single_row_groups(oracle, vx):
+    """Abandoned partial aggregation (HashAggregation.cpp:185-189 -> GroupingSet::toIntermediate,
+    GroupingSet.cpp:1589-1675): raw rows straight into the PARTIAL layout. Checked against the rules
+    of Appendix C row by row, and by feeding the result to a FINAL step: it must equal the SINGLE
+    aggregation of the same rows (oracle)."""
+    rng = np.random.default_rng(62)
+    n = 100000
+    k = rng.integers(0, 700, n).astype(np.int64)
+    x = _dyadic(rng, n)
+    xvalid = rng.random(n) > 0.2
+    y = rng.integers(-50, 50, n).astype(np.int32)
+    yvalid = rng.random(n) > 0.2
+    f = rng.random(n).astype(np.float32)
+    m = rng.random(n) > 0.5
+    mvalid = rng.random(n) > 0.1
+    b = batch_of([k, x, y, f, m], [None, xvalid, yvalid, None, mvalid])
+    raw = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_SUM, 2, abi.INTEGER), (abi.AGG_COUNT_STAR, -1, abi.BIGINT),
+           (abi.AGG_COUNT, 2, abi.INTEGER, 4), (abi.AGG_AVG, 1, abi.DOUBLE, 4), (abi.AGG_MIN, 2, abi.INTEGER),
+           (abi.AGG_MAX, 3, abi.REAL), (abi.AGG_SUM, 3, abi.REAL)]
+    from velox_amd import dist as vdist
+    kinds = vdist.partial_kinds([abi.BIGINT], raw)
+    op = vx.Aggregation([0], [abi.BIGINT], raw, abi.STEP_PARTIAL)
+    cols = op.to_intermediate(b, kinds[1:])
+    mask_ok = m & mvalid
+    exp = [(x, xvalid), (y.astype(np.int64), yvalid), (np.ones(n, dtype=np.int64), np.ones(n, bool)),
+           ((yvalid & mask_ok).astype(np.int64), np.ones(n, bool)), (x, xvalid & mask_ok),
+           ((xvalid & mask_ok).astype(np.int64), xvalid & mask_ok), (y, yvalid), (f, np.ones(n, bool)),
+           (f.astype(np.float64), np.ones(n, bool))]
+    assert len(cols) == len(exp)
+    for c, ((gv, gvalid), (ev, evalid)) in enumerate(zip(cols, exp)):
+        assert (np.asarray(gvalid) == evalid).all(), c
+        assert (np.asarray(gv)[evalid] == np.asarray(ev)[evalid]).all(), c
+    fin = vx.Aggregation([0], [abi.BIGINT], vdist.final_aggs_for(raw, 1), abi.STEP_FINAL)
+    fin.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, k)] +
+                                [abi.HostColumn(kind, np.asarray(v), np.asarray(valid))
+                                 for kind, (v, valid) in zip(kinds[1:], cols)]))
+    fin.no_more_input()
+    got = vx.collect_output(fin, 5000)
+    exp_single, eop = run_agg(oracle, [b], [0], [abi.BIGINT], raw, max_rows=5000)
+    assert_columns_equal(got, exp_single, eop.kinds, what="final(toIntermediate) vs single")

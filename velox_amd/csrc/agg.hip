@@ -1933,6 +1933,87 @@ __global__ __launch_bounds__(256) void k_extract(ExtractArgs a) {
   }
 }
 
+// ---- GroupingSet::toIntermediate (GroupingSet.cpp:1589-1675) ---------------------------------
+struct ToIntermediateAgg {
+  ColView in, mask;
+  int32_t aggKind;    // vx355_agg_kind
+  int32_t hasIn, hasMask;
+  int32_t inIsInt;
+  int32_t inputType;
+  int32_t pad;
+  void* values;
+  uint64_t* nulls;
+  void* values2;      // avg: the BIGINT count column
+  uint64_t* nulls2;
+};
+
+struct ToIntermediateArgs {
+  int32_t numAggs;
+  int32_t count;
+  ToIntermediateAgg aggs[kMaxAccs];
+};
+static_assert(sizeof(ToIntermediateArgs) <= 4096, "kernel arguments are limited to 4 KB");
+
+// One lane per input row: the PARTIAL step's output row of a group that holds this row only.
+__global__ __launch_bounds__(256) void k_to_intermediate(ToIntermediateArgs a) {
+  const int32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos - static_cast<int32_t>(lane()) >= a.count) {
+    return;
+  }
+  const bool inRange = pos < a.count;
+  for (int j = 0; j < a.numAggs; ++j) {
+    const ToIntermediateAgg& g = a.aggs[j];
+    bool active = inRange;
+    if (active && g.hasMask) {
+      active = !colIsNull(g.mask, pos) && loadInt64(g.mask, colIndex(g.mask, pos)) != 0;
+    }
+    if (active && g.hasIn) {
+      active = !colIsNull(g.in, pos);
+    }
+    const int64_t i = (active && g.hasIn) ? colIndex(g.in, pos) : 0;
+    switch (g.aggKind) {
+      case VX355_AGG_COUNT:
+      case VX355_AGG_COUNT_STAR:
+        writeBit(g.nulls, pos, inRange);
+        if (inRange) {
+          static_cast<int64_t*>(g.values)[pos] = active ? 1 : 0;
+        }
+        break;
+      case VX355_AGG_SUM:
+        writeBit(g.nulls, pos, active);
+        if (inRange) {
+          if (g.inIsInt) {
+            static_cast<int64_t*>(g.values)[pos] = active ? loadInt64(g.in, i) : 0;
+          } else {
+            static_cast<double*>(g.values)[pos] = active ? loadDouble(g.in, i) : 0.0;
+          }
+        }
+        break;
+      case VX355_AGG_MIN:
+      case VX355_AGG_MAX:
+        writeBit(g.nulls, pos, active);
+        if (g.inputType == VX355_BOOLEAN) {
+          writeBit(static_cast<uint64_t*>(g.values), pos, active && loadInt64(g.in, i) != 0);
+        } else if (inRange) {
+          if (g.inIsInt) {
+            storeTyped(g.values, g.inputType, pos, active ? loadInt64(g.in, i) : 0, 0, true);
+          } else {
+            storeTyped(g.values, g.inputType, pos, 0, active ? loadDouble(g.in, i) : 0.0, false);
+          }
+        }
+        break;
+      default:  // AVG: ROW(DOUBLE sum, BIGINT count)
+        writeBit(g.nulls, pos, active);
+        writeBit(g.nulls2, pos, active);
+        if (inRange) {
+          static_cast<double*>(g.values)[pos] = active ? loadDouble(g.in, i) : 0.0;
+          static_cast<int64_t*>(g.values2)[pos] = active ? 1 : 0;
+        }
+        break;
+    }
+  }
+}
+
 // ---- host side ---------------------------------------------------------------------
 
 bool rawInput(int32_t step) { return step == VX355_STEP_PARTIAL || step == VX355_STEP_SINGLE; }
@@ -2039,6 +2120,8 @@ struct vx355_agg {
   int64_t numOutput = -1;  // set by finalize
   int64_t outputCursor = 0;
   bool noMoreInput = false;
+  bool flushing = false;   // vx355_agg_flush: the groups are being drained before noMoreInput
+  int64_t numFlushes = 0;
 
   int64_t inputRows = 0;
   int64_t deferredRows = 0;
@@ -3661,13 +3744,37 @@ void finalize(vx355_agg& h) {
   h.numOutput = static_cast<int64_t>(g);
 }
 
+// GroupingSet::resetTable after a partial flush (HashAggregation::resetPartialOutputIfNeed,
+// HashAggregation.cpp:293-318): the table is emptied, key ranges and the mode stay.
+void resetAfterFlush(vx355_agg& h) {
+  auto& rt = Runtime::get();
+  if (h.generic) {
+    if (h.gSlotCap) {
+      HIP_OK(hipMemsetAsync(h.gSlots.ptr(), 0, static_cast<size_t>(h.gSlotCap) * 8, rt.stream));
+    }
+    if (h.gCounter.ptr()) {
+      HIP_OK(hipMemsetAsync(h.gCounter.ptr(), 0, 64, rt.stream));
+    }
+  }
+  if (h.tableReady) {
+    initTable(h, h.table, h.capacity);
+  }
+  rt.sync();
+  h.numGroups = 0;
+  h.numOutput = -1;
+  h.outputCursor = 0;
+  h.order = nullptr;
+  h.flushing = false;
+  ++h.numFlushes;
+}
+
 void getOutput(vx355_agg& h, vx355_out_column* cols, int32_t numCols, int32_t maxRows, int32_t* nOut,
                int32_t* finished) {
   auto& rt = Runtime::get();
   VX_CHECK_ARG(cols && nOut && finished, "NULL argument");
   VX_CHECK_ARG(numCols == static_cast<int32_t>(h.outTypes.size()), "wrong number of output columns");
   VX_CHECK_ARG(maxRows > 0, "max_rows must be positive");
-  VX_CHECK_ARG(h.noMoreInput, "getOutput before noMoreInput (partial flush is host policy)");
+  VX_CHECK_ARG(h.noMoreInput || h.flushing, "getOutput before noMoreInput (vx355_agg_flush opens a partial flush)");
   if (h.numOutput < 0) {
     finalize(h);
   }
@@ -3676,6 +3783,9 @@ void getOutput(vx355_agg& h, vx355_out_column* cols, int32_t numCols, int32_t ma
   if (n <= 0) {
     *nOut = 0;
     *finished = 1;
+    if (h.flushing) {
+      resetAfterFlush(h);
+    }
     return;
   }
   for (int32_t c = 0; c < numCols; ++c) {
@@ -3767,6 +3877,121 @@ void getOutput(vx355_agg& h, vx355_out_column* cols, int32_t numCols, int32_t ma
   rt.sync();
   h.outputCursor += n;
   *finished = h.outputCursor >= h.numOutput ? 1 : 0;
+  if (*finished && h.flushing) {
+    resetAfterFlush(h);
+  }
+}
+
+// GroupingSet::toIntermediate for one batch: see include/vx355.h.
+void toIntermediate(vx355_agg& h, const vx355_batch* batch, vx355_out_column* cols, int32_t numCols) {
+  auto& rt = Runtime::get();
+  VX_CHECK_ARG(batch && (cols || numCols == 0), "NULL argument");
+  if (!rawInput(h.step)) {
+    VX_THROW(VX355_EINVAL, "toIntermediate applies to raw input (partial / single steps); intermediate input passes through");
+  }
+  if (!h.fusedTerms.empty() || !h.fusedProj.empty()) {
+    VX_THROW(VX355_EUNSUPPORTED, "toIntermediate with a fused FilterProject");
+  }
+  const int32_t expected = static_cast<int32_t>(h.outTypes.size() - h.keys.size());
+  VX_CHECK_ARG(numCols == expected, "wrong number of aggregate output columns");
+  std::vector<int32_t> used;
+  for (const auto& la : h.aggs) {
+    used.push_back(la.fn.input_col);
+    used.push_back(la.fn.mask_col);
+  }
+  DeviceBatch db;
+  db.load(batch, used);
+  const int32_t n = db.numRows();
+  if (n == 0) {
+    return;
+  }
+  // the PARTIAL layout of the aggregate columns, whatever this operator's own step
+  std::vector<int32_t> types;
+  for (const auto& la : h.aggs) {
+    const auto& f = la.fn;
+    const bool isInt = isIntLike(f.input_type);
+    switch (f.kind) {
+      case VX355_AGG_SUM:
+        types.push_back(isInt ? VX355_BIGINT : VX355_DOUBLE);
+        break;
+      case VX355_AGG_COUNT:
+      case VX355_AGG_COUNT_STAR:
+        types.push_back(VX355_BIGINT);
+        break;
+      case VX355_AGG_MIN:
+      case VX355_AGG_MAX:
+        types.push_back(f.input_type);
+        break;
+      default:
+        types.push_back(VX355_DOUBLE);
+        types.push_back(VX355_BIGINT);
+        break;
+    }
+  }
+  // (a SINGLE / FINAL operator has one avg column in outTypes; the intermediate layout has two)
+  VX_CHECK_ARG(h.step == VX355_STEP_PARTIAL || types.size() >= static_cast<size_t>(numCols), "column count");
+  VX_CHECK_ARG(static_cast<int32_t>(types.size()) == numCols || h.step != VX355_STEP_PARTIAL,
+               "wrong number of aggregate output columns");
+  if (static_cast<int32_t>(types.size()) != numCols) {
+    VX_THROW(VX355_EINVAL, "toIntermediate needs the PARTIAL step's column layout (two columns per avg)");
+  }
+  const size_t words = static_cast<size_t>(ceilDiv(n, 64));
+  std::vector<size_t> valueBytes(numCols), offsets(numCols), nullOffsets(numCols);
+  size_t total = 0;
+  for (int32_t c = 0; c < numCols; ++c) {
+    VX_CHECK_ARG(cols[c].type_kind == types[c], "output column type mismatch");
+    VX_CHECK_ARG(cols[c].values != nullptr, "output column without values buffer");
+    const int w = kindWidth(types[c]);
+    valueBytes[c] = w == 0 ? words * 8 : static_cast<size_t>(n) * w;
+    offsets[c] = total;
+    total += (valueBytes[c] + 63) & ~static_cast<size_t>(63);
+    nullOffsets[c] = total;
+    total += (words * 8 + 63) & ~static_cast<size_t>(63);
+  }
+  char* scratch = static_cast<char*>(h.scratch.ensure(total + 64));
+  auto devValues = [&](int32_t c) -> void* {
+    return cols[c].mem == VX355_MEM_HOST ? static_cast<void*>(scratch + offsets[c]) : cols[c].values;
+  };
+  auto devNulls = [&](int32_t c) -> uint64_t* {
+    return cols[c].mem == VX355_MEM_HOST ? reinterpret_cast<uint64_t*>(scratch + nullOffsets[c]) : cols[c].nulls;
+  };
+  ToIntermediateArgs ta{};
+  ta.numAggs = static_cast<int32_t>(h.aggs.size());
+  ta.count = n;
+  int32_t c = 0;
+  for (size_t j = 0; j < h.aggs.size(); ++j) {
+    const auto& f = h.aggs[j].fn;
+    ToIntermediateAgg& g = ta.aggs[j];
+    g.aggKind = f.kind;
+    g.inputType = f.input_type;
+    g.inIsInt = isIntLike(f.input_type) ? 1 : 0;
+    g.hasIn = f.kind == VX355_AGG_COUNT_STAR ? 0 : 1;
+    if (g.hasIn) {
+      g.in = db.col(f.input_col);
+    }
+    g.hasMask = f.mask_col >= 0 ? 1 : 0;
+    if (g.hasMask) {
+      g.mask = db.col(f.mask_col);
+    }
+    g.values = devValues(c);
+    g.nulls = devNulls(c);
+    ++c;
+    if (f.kind == VX355_AGG_AVG) {
+      g.values2 = devValues(c);
+      g.nulls2 = devNulls(c);
+      ++c;
+    }
+  }
+  VX_LAUNCH("k_to_intermediate", k_to_intermediate, static_cast<int>(ceilDiv(n, 256)), 256, 0, ta);
+  for (int32_t i = 0; i < numCols; ++i) {
+    if (cols[i].mem == VX355_MEM_HOST) {
+      copyOutAsync(cols[i].values, VX355_MEM_HOST, scratch + offsets[i], valueBytes[i]);
+      if (cols[i].nulls) {
+        copyOutAsync(cols[i].nulls, VX355_MEM_HOST, scratch + nullOffsets[i], words * 8);
+      }
+    }
+  }
+  rt.sync();
 }
 
 }  // namespace
@@ -3857,6 +4082,7 @@ int vx355_agg_add_input(vx355_agg* h, const vx355_batch* batch) {
   Runtime::get().requireInit();
   VX_CHECK_ARG(h && batch, "NULL argument");
   VX_CHECK_ARG(!h->noMoreInput, "addInput after noMoreInput");
+  VX_CHECK_ARG(!h->flushing, "addInput while a partial flush is being drained");
   if (!tryCoalesce(*h, batch)) {
     flushPending(*h);
     addInput(*h, batch);
@@ -3894,6 +4120,28 @@ int vx355_agg_get_output(vx355_agg* h, vx355_out_column* cols, int32_t num_cols,
   VX_API_END
 }
 
+int vx355_agg_flush(vx355_agg* h) {
+  VX_API_BEGIN_CTX(VX_CTX_OF(h))
+  VX_CHECK_ARG(h, "NULL argument");
+  VX_CHECK_ARG(!h->noMoreInput, "flush after noMoreInput");
+  if (finalOutput(h->step) || h->keys.empty()) {
+    // HashAggregation.cpp:218-224: only partial output is flushed, never a global aggregation
+    VX_THROW(VX355_EINVAL, "flush applies to partial / intermediate steps with grouping keys");
+  }
+  flushPending(*h);
+  h->flushing = true;
+  h->numOutput = -1;
+  h->outputCursor = 0;
+  VX_API_END
+}
+
+int vx355_agg_to_intermediate(vx355_agg* h, const vx355_batch* batch, vx355_out_column* cols, int32_t num_cols) {
+  VX_API_BEGIN_CTX(VX_CTX_OF(h))
+  VX_CHECK_ARG(h, "NULL argument");
+  toIntermediate(*h, batch, cols, num_cols);
+  VX_API_END
+}
+
 int vx355_agg_get_stats(const vx355_agg* h, vx355_agg_stats* out) {
   VX_API_BEGIN
   VX_CHECK_ARG(h && out, "NULL argument");
@@ -3905,6 +4153,8 @@ int vx355_agg_get_stats(const vx355_agg* h, vx355_agg_stats* out) {
   out->radix_launches = h->radixLaunches;
   out->input_rows = h->inputRows + h->coalescer.pendingRows();
   out->deferred_rows = h->deferredRows;
+  out->table_bytes = static_cast<int64_t>(h->table.capacity());
+  out->num_flushes = h->numFlushes;
   VX_API_END
 }
 

@@ -37,7 +37,7 @@ SYMBOLS = [
     "vx355_join_probe_set_filter",
     "vx355_comm_get_unique_id", "vx355_comm_create", "vx355_comm_create_all", "vx355_comm_info",
     "vx355_comm_stream", "vx355_comm_destroy", "vx355_exchange_counts", "vx355_exchange_columns",
-    "vx355_all_gather",
+    "vx355_all_gather", "vx355_agg_flush", "vx355_agg_to_intermediate",
 ]
 
 
@@ -86,6 +86,8 @@ def lib():
     L.vx355_agg_output_types.argtypes = [vp, P(i32), i32, P(i32)]
     L.vx355_agg_get_output.argtypes = [vp, P(abi.OutColumn), i32, i32, P(i32), P(i32)]
     L.vx355_agg_get_stats.argtypes = [vp, P(abi.AggStats)]
+    L.vx355_agg_flush.argtypes = [vp]
+    L.vx355_agg_to_intermediate.argtypes = [vp, P(abi.Batch), P(abi.OutColumn), i32]
     L.vx355_agg_destroy.argtypes = [vp]
     L.vx355_agg_destroy.restype = None
     L.vx355_join_build_create.argtypes = [P(abi.JoinBuildSpec), P(vp)]
@@ -465,6 +467,18 @@ class HashAggregation:
 
     def no_more_input(self):
         _check(lib().vx355_agg_no_more_input(self.h))
+
+    def flush(self):
+        """Partial flush: get_output then drains the groups so far; the table restarts empty."""
+        _check(lib().vx355_agg_flush(self.h))
+
+    def to_intermediate(self, batch, kinds):
+        """GroupingSet::toIntermediate: the aggregate columns of the PARTIAL layout for the raw
+        rows of 'batch' (kinds = their types, e.g. dist.partial_kinds(...)[num_keys:])."""
+        n = batch.num_rows
+        out = abi.OutBuffers(kinds, n)
+        _check(lib().vx355_agg_to_intermediate(self.h, batch.ref(), out.descs, len(kinds)))
+        return [out.column(i, n) for i in range(len(kinds))]
 
     def get_output(self, max_rows=1024):
         out = abi.OutBuffers(self.kinds, max_rows)
