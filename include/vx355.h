@@ -367,7 +367,17 @@ typedef struct vx355_agg_spec {
   const vx355_agg_fn* aggs;
   int32_t step;             /* vx355_agg_step */
   int32_t ignore_null_keys; /* AggregationNode::ignoreNullKeys */
+  int32_t flags;            /* vx355_agg_flags */
+  int32_t pad;
 } vx355_agg_spec;
+
+typedef enum vx355_agg_flags {
+  /* The consumer does not depend on the group order (a FINAL aggregation, an exchange, an
+   * ORDER BY above): groups come out in table order instead of first-seen order
+   * (GroupingSet.cpp:828-839), which saves the sort of the groups by first input row —
+   * a fifth of the time of a 100 M-group aggregation. Results per group are unchanged. */
+  VX355_AGG_UNORDERED_OUTPUT = 1
+} vx355_agg_flags;
 
 typedef struct vx355_agg vx355_agg;
 

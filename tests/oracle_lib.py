@@ -253,7 +253,7 @@ def partition(hashes, kind, num_partitions=0, bit_begin=0, bit_end=0):
     return out[: len(hashes)]
 
 
-def make_agg_spec(key_cols, key_types, aggs, step, ignore_null_keys=False):
+def make_agg_spec(key_cols, key_types, aggs, step, ignore_null_keys=False, flags=0):
     """aggs: list of (kind, input_col, input_type[, mask_col[, input_col2]])."""
     keep = {}
     keep["kc"] = abi.i32_array(key_cols)
@@ -266,7 +266,7 @@ def make_agg_spec(key_cols, key_types, aggs, step, ignore_null_keys=False):
         fns[i] = abi.AggFn(kind, col, col2, typ, mask)
     keep["fns"] = fns
     spec = abi.AggSpec(len(key_cols), keep["kc"], keep["kt"], len(aggs), fns, step,
-                       1 if ignore_null_keys else 0)
+                       1 if ignore_null_keys else 0, flags, 0)
     keep["spec"] = spec
     return spec, keep
 

@@ -854,3 +854,25 @@ def test_to_intermediate_is_the_partial_layout_of_single_row_groups(oracle, vx):
     got = vx.collect_output(fin, 5000)
     exp_single, eop = run_agg(oracle, [b], [0], [abi.BIGINT], raw, max_rows=5000)
     assert_columns_equal(got, exp_single, eop.kinds, what="final(toIntermediate) vs single")
+
+
+def test_unordered_output_flag_skips_the_first_seen_sort(oracle, vx, monkeypatch):
+    """VX355_AGG_UNORDERED_OUTPUT: same groups and values, table order instead of first-seen order."""
+    monkeypatch.setenv("VX355_AGG_COALESCE_ROWS", "0")
+    rng = np.random.default_rng(63)
+    n = 300000
+    k = rng.integers(0, 50000, n).astype(np.int64)
+    v = _dyadic(rng, n)
+    aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    exp, _ = run_agg(oracle, [batch_of([k, v])], [0], [abi.BIGINT], aggs, max_rows=100000)
+    vx.profile_reset()
+    vx.profile_enable(True)
+    op = vx.Aggregation([0], [abi.BIGINT], aggs, abi.STEP_SINGLE, flags=abi.AGG_UNORDERED_OUTPUT)
+    op.add_input(batch_of([k, v]))
+    op.no_more_input()
+    got = vx.collect_output(op, 100000)
+    vx.profile_enable(False)
+    assert not any("Sort" in name or "sort" in name for name in vx.profile())
+    go, eo = np.argsort(got[0][0], kind="stable"), np.argsort(exp[0][0], kind="stable")
+    for c in range(3):
+        assert (np.asarray(got[c][0])[go] == np.asarray(exp[c][0])[eo]).all()

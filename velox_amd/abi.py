@@ -71,7 +71,11 @@ class AggFn(C.Structure):
 class AggSpec(C.Structure):
     _fields_ = [("num_keys", C.c_int32), ("key_cols", C.POINTER(C.c_int32)),
                 ("key_types", C.POINTER(C.c_int32)), ("num_aggs", C.c_int32),
-                ("aggs", C.POINTER(AggFn)), ("step", C.c_int32), ("ignore_null_keys", C.c_int32)]
+                ("aggs", C.POINTER(AggFn)), ("step", C.c_int32), ("ignore_null_keys", C.c_int32),
+                ("flags", C.c_int32), ("pad", C.c_int32)]
+
+
+AGG_UNORDERED_OUTPUT = 1
 
 
 class AggStats(C.Structure):

@@ -2120,6 +2120,7 @@ struct vx355_agg {
   int64_t numOutput = -1;  // set by finalize
   int64_t outputCursor = 0;
   bool noMoreInput = false;
+  bool unorderedOutput = false;  // VX355_AGG_UNORDERED_OUTPUT: no first-seen sort
   bool flushing = false;   // vx355_agg_flush: the groups are being drained before noMoreInput
   int64_t numFlushes = 0;
 
@@ -3734,6 +3735,12 @@ void finalize(vx355_agg& h) {
     VX_THROW(VX355_EINTERNAL, "group count mismatch: counted " + std::to_string(g) + ", found " +
                                   std::to_string(found));
   }
+  if (h.unorderedOutput) {
+    rt.sync();
+    h.order = h.orderVals.as<uint32_t>();  // table order as k_collect found it
+    h.numOutput = static_cast<int64_t>(g);
+    return;
+  }
   bool inTmp = false;
   sortPairsU64U32(h.orderKeys.as<uint64_t>(), h.orderVals.as<uint32_t>(), h.orderKeys2.as<uint64_t>(),
                   h.orderVals2.as<uint32_t>(), g, h.sortTmp, &inTmp,
@@ -4008,6 +4015,7 @@ int vx355_agg_create(const vx355_agg_spec* spec, vx355_agg** out) {
   auto h = std::make_unique<vx355_agg>();
   h->step = spec->step;
   h->ignoreNullKeys = spec->ignore_null_keys != 0;
+  h->unorderedOutput = (spec->flags & VX355_AGG_UNORDERED_OUTPUT) != 0;
   if (const char* e = std::getenv("VX355_ARRAY_MAX")) {
     h->arrayMax = std::strtoull(e, nullptr, 10);
   }

@@ -419,7 +419,7 @@ def partition(hashes, kind, num_partitions=0, bit_begin=0, bit_end=0):
 
 # ---- HashAggregation -------------------------------------------------------
 
-def make_agg_spec(key_cols, key_types, aggs, step, ignore_null_keys=False):
+def make_agg_spec(key_cols, key_types, aggs, step, ignore_null_keys=False, flags=0):
     """aggs: list of (kind, input_col, input_type[, mask_col[, input_col2]])."""
     keep = {"kc": abi.i32_array(key_cols), "kt": abi.i32_array(key_types)}
     fns = (abi.AggFn * max(1, len(aggs)))()
@@ -430,7 +430,7 @@ def make_agg_spec(key_cols, key_types, aggs, step, ignore_null_keys=False):
         fns[i] = abi.AggFn(kind, col, col2, typ, mask)
     keep["fns"] = fns
     spec = abi.AggSpec(len(key_cols), keep["kc"], keep["kt"], len(aggs), fns, step,
-                       1 if ignore_null_keys else 0)
+                       1 if ignore_null_keys else 0, flags, 0)
     keep["spec"] = spec
     return spec, keep
 
@@ -438,8 +438,8 @@ def make_agg_spec(key_cols, key_types, aggs, step, ignore_null_keys=False):
 class HashAggregation:
     """exec::HashAggregation (exec/HashAggregation.h) on the MI355X."""
 
-    def __init__(self, key_cols, key_types, aggs, step=abi.STEP_SINGLE, ignore_null_keys=False):
-        self.spec, self._keep = make_agg_spec(key_cols, key_types, aggs, step, ignore_null_keys)
+    def __init__(self, key_cols, key_types, aggs, step=abi.STEP_SINGLE, ignore_null_keys=False, flags=0):
+        self.spec, self._keep = make_agg_spec(key_cols, key_types, aggs, step, ignore_null_keys, flags)
         h = C.c_void_p()
         _check(lib().vx355_agg_create(C.byref(self.spec), C.byref(h)))
         self.h = h
