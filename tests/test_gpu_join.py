@@ -654,3 +654,78 @@ def test_unsupported_join_flavours_are_refused_at_create(vx):
         vx.JoinProbe(t, [0], abi.JOIN_INNER)               # counting table, non-counting probe
     with pytest.raises(vx.Vx355Error):
         vx.JoinBuild([0], [abi.BIGINT], [], [], abi.JOIN_LEFT_SEMI_PROJECT, null_aware=True)
+
+
+def _join_arrays(impl, vxmod, bk, pay, pk, join_type, max_rows=500000):
+    table, _ = _build(impl, [[batch_of([bk, pay])]], [0], [abi.BIGINT], [1], [abi.BIGINT], join_type)
+    probe = impl.JoinProbe(table, [0], join_type)
+    if impl is vxmod:
+        vxmod.profile_reset()
+        vxmod.profile_enable(True)
+    probe.add_input(batch_of([pk]))
+    maps, rows, pays = [], [], []
+    while True:
+        m, r, cols, fin = probe.get_output(max_rows, [0])
+        maps.append(np.asarray(m))
+        rows.append(np.asarray(r))
+        pays.append(np.where(np.asarray(cols[0][1]), np.asarray(cols[0][0]), -1))
+        if fin:
+            break
+    names = set()
+    if impl is vxmod:
+        vxmod.profile_enable(False)
+        names = set(vxmod.profile().keys())
+    out = [np.concatenate(maps), np.concatenate(rows), np.concatenate(pays)]
+    if join_type == abi.JOIN_RIGHT:
+        br, bfin = [], False
+        while not bfin:
+            r2, c2, bfin = probe.get_build_side_output(max_rows, [0])
+            br.append(np.asarray(r2))
+        out.append(np.concatenate(br))
+    return out, names
+
+
+@pytest.mark.parametrize("join_type", [abi.JOIN_INNER, abi.JOIN_LEFT_SEMI_FILTER, abi.JOIN_RIGHT])
+def test_range_partitioned_probe_forced(oracle, vx, join_type, monkeypatch):
+    """k_pp_count / k_pp_scatter / k_join_probe_part: probe rows range-partitioned by key, every bin
+    probed against its slice of the presence bitmap in LDS, hits re-ordered by probe row. Forced on
+    (VX355_JOIN_PARTITION=1) for a key range of 8 bins; keys below / above the build range, a
+    stretch of certain hits and windows that cut through the output."""
+    monkeypatch.setenv("VX355_JOIN_PARTITION", "1")
+    rng = np.random.default_rng(91)
+    nb, npb = 40000, 1_500_000
+    bk = (rng.permutation(4_000_000)[:nb] + 1000).astype(np.int64)
+    pay = rng.integers(0, 1 << 30, nb).astype(np.int64)
+    pk = rng.integers(0, 4_100_000, npb).astype(np.int64)
+    pk[700_000:705_000] = bk[rng.integers(0, nb, 5000)]
+    res = {}
+    for impl in (oracle, vx):
+        res[impl.__name__], names = _join_arrays(impl, vx, bk, pay, pk, join_type, max_rows=7001)
+        if impl is vx:
+            assert "k_join_probe_part" in names and "k_pp_scatter" in names
+    for g, e in zip(res[vx.__name__], res[oracle.__name__]):
+        assert len(g) == len(e) and (g == e).all()
+    assert len(res[vx.__name__][0]) > 15000
+
+
+@pytest.mark.parametrize("order", ["random", "clustered"])
+def test_range_partitioned_probe_is_chosen_for_scattered_keys_only(oracle, vx, order):
+    """Adaptive choice: a 25 MB presence bitmap (200 M possible keys), 5 M probe rows. Random probe
+    order takes the partitioned path, key-ordered probe rows (what a fact table stored in key order
+    gives) keep the direct one. Results equal the oracle's either way."""
+    rng = np.random.default_rng(92)
+    nb, npb = 3_300_000, 5_000_000
+    bk = (rng.permutation(200_000_000)[:nb]).astype(np.int64)
+    pay = np.arange(nb, dtype=np.int64)
+    pk = rng.integers(0, 200_000_000, npb).astype(np.int64)
+    pk[::50] = bk[rng.integers(0, nb, len(pk[::50]))]
+    if order == "clustered":
+        pk = np.sort(pk)
+    res = {}
+    for impl in (oracle, vx):
+        res[impl.__name__], names = _join_arrays(impl, vx, bk, pay, pk, abi.JOIN_INNER)
+        if impl is vx:
+            assert ("k_join_probe_part" in names) == (order == "random"), names
+    for g, e in zip(res[vx.__name__], res[oracle.__name__]):
+        assert len(g) == len(e) and (g == e).all()
+    assert len(res[vx.__name__][0]) >= npb // 50

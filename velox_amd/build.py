@@ -28,11 +28,32 @@ def _headers():
     return hs
 
 
+def _digest(paths):
+    """Content hash of the inputs of one object file (mtimes do not survive the copy to a GPU box)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for path in sorted(paths):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def _stale(target, deps):
-    if not os.path.exists(target):
+    """True when 'target' is missing or was not built from the current contents of 'deps'
+    (recorded next to it in target + '.stamp')."""
+    stamp = target + ".stamp"
+    if not os.path.exists(target) or not os.path.exists(stamp):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    try:
+        return open(stamp).read().strip() != _digest(deps)
+    except OSError:
+        return True
+
+
+def _write_stamp(target, deps):
+    with open(target + ".stamp", "w") as f:
+        f.write(_digest(deps))
 
 
 def build_lib(force=False, verbose=False):
@@ -59,8 +80,11 @@ def build_lib(force=False, verbose=False):
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(run, jobs))
+        for cmd in jobs:
+            _write_stamp(cmd[-1], [cmd[-3]] + headers)
     if force or jobs or _stale(LIB, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lhiprtc", "-ldl"])
+        _write_stamp(LIB, objs)
     return LIB
 
 

@@ -568,7 +568,7 @@ __device__ inline uint32_t outputCount(int32_t joinType, uint32_t matches, bool 
   }
 }
 
-__device__ inline bool listsMatches(int32_t joinType) {
+__host__ __device__ inline bool listsMatches(int32_t joinType) {
   return joinType == VX355_JOIN_INNER || joinType == VX355_JOIN_LEFT || joinType == VX355_JOIN_RIGHT ||
       joinType == VX355_JOIN_FULL;
 }
@@ -932,6 +932,197 @@ __global__ __launch_bounds__(256) void k_join_probe(ProbeArgs args) {
       a.tileSums[tile] = waveSums[0] + waveSums[1] + waveSums[2] + waveSums[3];
     }
     blockSync();
+  }
+}
+
+// ---- range-partitioned probe (array mode, probe keys in no particular order) -----------------
+// tools/gather_bench.hip: dependent random reads of a structure larger than the per-XCD L2
+// retire at ~50 G/s on this chip whatever the occupancy (75 MB presence bitmap, probe keys in
+// random order: 6 ms per 323 M probes); even an L2-resident structure stops at ~150 G/s
+// (address processing in the CU's texture path). LDS does not have that limit. So when the
+// probe keys of a batch are scattered (k_key_locality) and the join lists matches only, the
+// probe side is range-partitioned: {key offset, probe row} records go to bin = key >> 19
+// (one LDS-histogram pass, one scatter pass, as the radix aggregation does), then one
+// workgroup per bin loads its 64 KB slice of the bitmap into LDS and streams its records
+// against it. Hits leave as {probe row, build row} words and are put back into probe-row
+// order by one radix sort of the HITS (few: the path is taken at hit rates <= 12.5 %).
+constexpr int kPartShift = 19;                       // keys per bin = bits of the bitmap slice
+constexpr int kPartSliceWords = 1 << (kPartShift - 5);  // u32 words of one slice: 64 KB
+constexpr int kPartMaxBins = 4096;
+constexpr int kPartTileRows = 32768;
+
+struct PartArgs {
+  const int64_t* keys;   // flat BIGINT probe keys
+  int64_t numRows;
+  int64_t numTiles;
+  int64_t keyMin, keyMax;
+  int32_t numBins;
+  int32_t pad;
+  uint32_t* hist;        // [bin][tile]
+  const uint64_t* offsets;
+  uint64_t* recs;        // {key offset inside the bin : 32 | probe row : 32}
+};
+
+__global__ __launch_bounds__(1024) void k_pp_count(PartArgs a) {
+  __shared__ uint32_t hist[kPartMaxBins];
+  for (int64_t tile = blockIdx.x; tile < a.numTiles; tile += gridDim.x) {
+    for (int i = threadIdx.x; i < a.numBins; i += blockDim.x) {
+      hist[i] = 0;
+    }
+    blockSync();
+    const int64_t begin = tile * kPartTileRows;
+    const int64_t end = begin + kPartTileRows < a.numRows ? begin + kPartTileRows : a.numRows;
+    for (int64_t base = begin; base < end; base += 8 * 1024) {
+      int64_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t r = base + u * 1024 + threadIdx.x;
+        v[u] = r < end ? a.keys[r] : INT64_MIN;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t r = base + u * 1024 + threadIdx.x;
+        if (r < end && v[u] >= a.keyMin && v[u] <= a.keyMax) {
+          const uint64_t key = static_cast<uint64_t>(v[u]) - static_cast<uint64_t>(a.keyMin) + 1;
+          atomicAdd(&hist[key >> kPartShift], 1u);
+        }
+      }
+    }
+    blockSync();
+    for (int i = threadIdx.x; i < a.numBins; i += blockDim.x) {
+      a.hist[static_cast<int64_t>(i) * a.numTiles + tile] = hist[i];
+    }
+    blockSync();
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_pp_scatter(PartArgs a) {
+  __shared__ unsigned long long binBase[kPartMaxBins];
+  __shared__ uint32_t cursor[kPartMaxBins];
+  for (int64_t tile = blockIdx.x; tile < a.numTiles; tile += gridDim.x) {
+    for (int i = threadIdx.x; i < a.numBins; i += blockDim.x) {
+      binBase[i] = a.offsets[static_cast<int64_t>(i) * a.numTiles + tile];
+      cursor[i] = 0;
+    }
+    blockSync();
+    const int64_t begin = tile * kPartTileRows;
+    const int64_t end = begin + kPartTileRows < a.numRows ? begin + kPartTileRows : a.numRows;
+    for (int64_t base = begin; base < end; base += 8 * 1024) {
+      int64_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t r = base + u * 1024 + threadIdx.x;
+        v[u] = r < end ? a.keys[r] : INT64_MIN;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t r = base + u * 1024 + threadIdx.x;
+        if (r < end && v[u] >= a.keyMin && v[u] <= a.keyMax) {
+          const uint64_t key = static_cast<uint64_t>(v[u]) - static_cast<uint64_t>(a.keyMin) + 1;
+          const uint32_t bin = static_cast<uint32_t>(key >> kPartShift);
+          const unsigned long long pos = binBase[bin] + atomicAdd(&cursor[bin], 1u);
+          a.recs[pos] = ((key & ((1ULL << kPartShift) - 1)) << 32) | static_cast<uint32_t>(r);
+        }
+      }
+    }
+    blockSync();
+  }
+}
+
+struct PartProbeArgs {
+  const uint64_t* recs;
+  const uint64_t* offsets;   // record offsets per (bin, tile) cell, bin major
+  int64_t numTiles;
+  int32_t numBins;
+  int32_t pad;
+  const uint32_t* present;
+  uint64_t presentWords;     // u32 words of the whole bitmap
+  const uint32_t* head;
+  uint8_t* probed;
+  uint64_t* pairs;           // out: {probe row : 32 | build row : 32}
+  unsigned long long* numPairs;
+};
+
+__global__ __launch_bounds__(1024) void k_pp_probe(PartProbeArgs a) {
+  __shared__ uint32_t slice[kPartSliceWords];
+  for (int32_t bin = blockIdx.x; bin < a.numBins; bin += gridDim.x) {
+    const uint64_t begin = a.offsets[static_cast<int64_t>(bin) * a.numTiles];
+    const uint64_t end = a.offsets[static_cast<int64_t>(bin + 1) * a.numTiles];
+    if (begin == end) {
+      continue;  // uniform
+    }
+    const uint64_t wordBase = static_cast<uint64_t>(bin) * kPartSliceWords;
+    for (int i = threadIdx.x; i < kPartSliceWords; i += blockDim.x) {
+      slice[i] = wordBase + i < a.presentWords ? a.present[wordBase + i] : 0;
+    }
+    blockSync();
+    for (uint64_t at = begin; at < end; at += 4 * 1024) {
+      uint64_t rec[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint64_t i = at + u * 1024 + threadIdx.x;
+        rec[u] = i < end ? a.recs[i] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint64_t i = at + u * 1024 + threadIdx.x;
+        const uint32_t off = static_cast<uint32_t>(rec[u] >> 32);
+        const bool hit = i < end && ((slice[off >> 5] >> (off & 31)) & 1);
+        const uint64_t m = ballot(hit);
+        if (m == 0) {
+          continue;
+        }
+        unsigned long long base = 0;
+        const int leader = __ffsll(static_cast<long long>(m)) - 1;
+        if (lane() == leader) {
+          base = atomicAdd(a.numPairs, static_cast<unsigned long long>(popc64(m)));
+        }
+        base = shfl64(base, leader);
+        if (hit) {
+          const uint32_t build = a.head[(static_cast<uint64_t>(bin) << kPartShift) + off];
+          if (a.probed) {
+            a.probed[build] = 1;
+          }
+          a.pairs[base + lanePrefix(m)] = (static_cast<uint64_t>(static_cast<uint32_t>(rec[u])) << 32) | build;
+        }
+      }
+    }
+    blockSync();
+  }
+}
+
+// Average number of distinct 128-byte lines of the presence bitmap that the 64 keys of a wave
+// touch, over 64 sample waves spread across the batch: ~1-4 when the probe side is clustered
+// by key (a fact table stored in key order), ~64 when it is not.
+__global__ __launch_bounds__(64) void k_key_locality(const int64_t* keys, int64_t numRows, uint32_t* out) {
+  const int64_t waves = numRows / 64;
+  if (waves == 0) {
+    return;
+  }
+  const int64_t w = (waves * blockIdx.x) / gridDim.x;
+  const uint64_t line = static_cast<uint64_t>(keys[w * 64 + lane()]) >> 10;
+  bool first = true;
+  for (int l = 0; l < 64; ++l) {
+    const uint64_t other = shfl64(line, l);
+    if (l < static_cast<int>(lane()) && other == line) {
+      first = false;
+    }
+  }
+  const uint64_t m = ballot(first);
+  if (lane() == 0) {
+    atomicAdd(out, static_cast<uint32_t>(popc64(m)));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_emit_pairs(const uint64_t* sorted, int64_t begin, int32_t n, int32_t wantBuild,
+                                                     int32_t* mapping, int32_t* buildRows) {
+  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const uint64_t w = sorted[begin + i];
+    mapping[i] = static_cast<int32_t>(w >> 32);
+    if (buildRows) {
+      buildRows[i] = wantBuild ? static_cast<int32_t>(static_cast<uint32_t>(w)) : -1;
+    }
   }
 }
 
@@ -1563,6 +1754,10 @@ struct vx355_join_probe {
   int32_t joinType = 0;
   DevBuf hits, counts, tileSums, tileOffsets, scratch, outMap, outRows;
   DevBuf staged, tileDense, sparseStats;  // sparse listing (probeAddInput)
+  // range-partitioned probe: records, histogram, offsets, hit words (unsorted / sorted)
+  DevBuf ppRecs, ppHist, ppOffsets, ppScan, ppPairs, ppSorted, ppSortTmp;
+  bool pairList = false;     // the batch's output is ppSorted[0, totalOut)
+  int32_t partitionMode = -1;  // VX355_JOIN_PARTITION: -1 adaptive, 0 never, 1 whenever eligible
   DeviceBatch batch;                       // the batch being probed: the filter reads it at output time
   std::vector<vx355_join_filter_term> filter;
   std::vector<int32_t> usedCols;           // key columns + the filter's probe columns
@@ -2070,23 +2265,83 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
       (p.joinType == VX355_JOIN_INNER || p.joinType == VX355_JOIN_LEFT_SEMI_FILTER ||
        (p.joinType == VX355_JOIN_RIGHT && !t.hasDuplicates));
   p.sparse = false;
+  p.pairList = false;
   p.sparseTiles = p.denseTiles = 0;
+  // Range-partitioned probe (see k_pp_*): flat BIGINT key into an array-mode table whose bitmap
+  // is far larger than an L2, a batch big enough to pay for two extra passes.
+  const uint64_t presentWords = (t.capacity + 31) / 32;
+  const int64_t partBins = static_cast<int64_t>((t.capacity + (1ULL << kPartShift) - 1) >> kPartShift);
+  const bool partEligible = p.partitionMode != 0 && t.mode == JMODE_ARRAY && a.fastKey == 1 &&
+      partBins <= kPartMaxBins && n < (1LL << 32) &&
+      (p.partitionMode == 1 || (n >= (4LL << 20) && presentWords * 4 > (16ULL << 20)));
   if (sparseEligible) {
     a.staged = static_cast<uint2*>(p.staged.ensure(static_cast<size_t>(p.numTiles) * kSparseCap * sizeof(uint2) + 64));
     a.tileDense = static_cast<uint8_t*>(p.tileDense.ensure(static_cast<size_t>(p.numTiles) + 64));
     a.sparseStats = static_cast<uint64_t*>(p.sparseStats.ensure(64));
-    HIP_OK(hipMemsetAsync(a.sparseStats, 0, 16, rt.stream));
-    const int64_t sample = p.sparseMode == 1 ? p.numTiles : std::min<int64_t>(p.numTiles, 256);
+    HIP_OK(hipMemsetAsync(a.sparseStats, 0, 32, rt.stream));
+    if (partEligible) {
+      VX_LAUNCH("k_key_locality", k_key_locality, 64, 64, 0, static_cast<const int64_t*>(a.keys[0].values), n,
+                reinterpret_cast<uint32_t*>(a.sparseStats + 2));
+    }
+    const bool decideHere = partEligible || p.sparseMode != 1;
+    const int64_t sample = decideHere ? std::min<int64_t>(p.numTiles, 256) : p.numTiles;
     launch(std::true_type{}, 0, sample);
     p.sparse = true;
-    if (sample < p.numTiles) {
-      uint64_t stats[2] = {0, 0};
-      copyOut(stats, VX355_MEM_HOST, a.sparseStats, 16);  // synchronises the stream
+    if (sample < p.numTiles || partEligible) {
+      uint64_t stats[4] = {0, 0, 0, 0};
+      copyOut(stats, VX355_MEM_HOST, a.sparseStats, 32);  // synchronises the stream
       const uint64_t overflowed = stats[0];
       // dense when more than 1 tile in 16 overflowed or the average tile is half full
-      const bool stay = overflowed * 16 <= static_cast<uint64_t>(sample) &&
-          stats[1] <= static_cast<uint64_t>(sample) * (kSparseCap / 2);
-      if (stay) {
+      const bool stay = p.sparseMode == 1 ||
+          (overflowed * 16 <= static_cast<uint64_t>(sample) &&
+           stats[1] <= static_cast<uint64_t>(sample) * (kSparseCap / 2));
+      // scattered probe keys: more than 16 distinct bitmap lines per wave on average
+      const bool scattered = p.partitionMode == 1 || (stats[2] & 0xffffffffULL) > 64ULL * 16;
+      if (stay && partEligible && scattered) {
+        p.sparse = false;
+        p.pairList = true;
+        PartArgs pa{};
+        pa.keys = static_cast<const int64_t*>(a.keys[0].values);
+        pa.numRows = n;
+        pa.numTiles = ceilDiv(n, kPartTileRows);
+        pa.keyMin = a.ranges[0].min;
+        pa.keyMax = a.ranges[0].max;
+        pa.numBins = static_cast<int32_t>(partBins);
+        const int64_t cells = pa.numTiles * pa.numBins;
+        pa.hist = static_cast<uint32_t*>(p.ppHist.ensure(static_cast<size_t>(cells) * 4 + 64));
+        uint64_t* offsets = static_cast<uint64_t*>(p.ppOffsets.ensure(static_cast<size_t>(cells + 1) * 8 + 64));
+        pa.offsets = offsets;
+        pa.recs = static_cast<uint64_t*>(p.ppRecs.ensure(static_cast<size_t>(n) * 8 + 64));
+        const int pgrid = static_cast<int>(std::min<int64_t>(pa.numTiles, static_cast<int64_t>(rt.numCUs) * 2));
+        VX_LAUNCH("k_pp_count", k_pp_count, pgrid, 1024, 0, pa);
+        scanU32ToU64(pa.hist, cells, offsets, p.ppScan);
+        VX_LAUNCH("k_pp_scatter", k_pp_scatter, pgrid, 1024, 0, pa);
+        PartProbeArgs pp{};
+        pp.recs = pa.recs;
+        pp.offsets = offsets;
+        pp.numTiles = pa.numTiles;
+        pp.numBins = pa.numBins;
+        pp.present = a.present;
+        pp.presentWords = presentWords;
+        pp.head = a.head;
+        pp.probed = a.probed;
+        // at most one hit per probe row (chains of one row, or the head only for semi joins)
+        pp.pairs = static_cast<uint64_t*>(p.ppPairs.ensure(static_cast<size_t>(n) * 8 + 64));
+        pp.numPairs = reinterpret_cast<unsigned long long*>(a.sparseStats + 3);
+        VX_LAUNCH("k_join_probe_part", k_pp_probe, std::min<int>(pa.numBins, rt.numCUs * 2), 1024, 0, pp);
+        uint64_t numPairs = 0;
+        copyOut(&numPairs, VX355_MEM_HOST, a.sparseStats + 3, 8);
+        if (numPairs > 0) {
+          sortKeysU64(pp.pairs, static_cast<uint64_t*>(p.ppSorted.ensure(static_cast<size_t>(numPairs) * 8 + 64)),
+                      static_cast<size_t>(numPairs), p.ppSortTmp);
+        }
+        rt.sync();
+        p.totalOut = numPairs;
+        return;
+      }
+      if (sample >= p.numTiles) {
+        // whole batch already probed by the sample launch
+      } else if (stay) {
         launch(std::true_type{}, sample, p.numTiles);
       } else {
         HIP_OK(hipMemsetAsync(a.tileDense + sample, 1, static_cast<size_t>(p.numTiles - sample), rt.stream));
@@ -2225,6 +2480,25 @@ void probeGetOutput(vx355_join_probe& p, int32_t maxRows, int32_t* mappingOut, i
     dRows = (host || !buildRowsOut)
         ? static_cast<int32_t*>(p.outRows.ensure(static_cast<size_t>(n) * 4 + 64))
         : buildRowsOut;
+  }
+  if (p.pairList) {
+    // range-partitioned probe: the hits already sit in probe-row order
+    VX_LAUNCH("k_emit_pairs", k_emit_pairs, static_cast<int>(ceilDiv(n, 256)), 256, 0, p.ppSorted.as<uint64_t>(),
+              static_cast<int64_t>(begin), n, listsMatches(p.joinType) ? 1 : 0, dMap, dRows);
+    if (numBuildCols > 0) {
+      gatherBuildCols(p, t, dRows, n, buildCols, buildColIds, numBuildCols);
+    }
+    if (host) {
+      copyOutAsync(mappingOut, VX355_MEM_HOST, dMap, static_cast<size_t>(n) * 4);
+      if (buildRowsOut) {
+        copyOutAsync(buildRowsOut, VX355_MEM_HOST, dRows, static_cast<size_t>(n) * 4);
+      }
+    }
+    rt.sync();
+    p.cursor = end;
+    *nOut = n;
+    *finished = p.cursor >= p.totalOut ? 1 : 0;
+    return;
   }
   // Tiles whose offset range intersects the window.
   const auto& to = p.hostTileOffsets;
@@ -2612,6 +2886,12 @@ int vx355_join_probe_create(vx355_join_table* table, const vx355_join_probe_spec
   vx355_join_table_retain(table);
   p->joinType = spec->join_type;
   p->nullAware = spec->null_aware != 0;
+  if (const char* e = std::getenv("VX355_JOIN_PARTITION")) {
+    p->partitionMode = std::atoi(e);  // 0 never, 1 whenever eligible, otherwise adaptive
+    if (p->partitionMode != 0 && p->partitionMode != 1) {
+      p->partitionMode = -1;
+    }
+  }
   if (const char* e = std::getenv("VX355_JOIN_SPARSE")) {
     p->sparseMode = std::atoi(e);  // 0 never, 1 always, otherwise adaptive
     if (p->sparseMode != 0 && p->sparseMode != 1) {
