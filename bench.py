@@ -56,6 +56,8 @@ def parse():
                     help="c4: keys = splitmix64(j), j < distinct (no dense range: open-addressing mode)")
     ap.add_argument("--unfused", action="store_true",
                     help="q1: FilterProject and HashAggregation as two operators")
+    ap.add_argument("--c4-unordered", action="store_true",
+                    help="c4: VX355_AGG_UNORDERED_OUTPUT (the consumer does not need first-seen group order)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="q1 at N = 1: skip the Q3 SF100 join block (the other half of BASELINE's metric)")
     ap.add_argument("--no-traffic", action="store_true",
@@ -315,8 +317,11 @@ class C4(C1):
         self.batch = DevBatch([dcol(abi.BIGINT, self.k), dcol(abi.DOUBLE, self.v)], n)
         torch.cuda.synchronize()
 
+    unordered = False
+
     def step(self, step_kind=abi.STEP_SINGLE):
-        op = ops.HashAggregation([0], [abi.BIGINT], self.AGGS, step_kind)
+        op = ops.HashAggregation([0], [abi.BIGINT], self.AGGS, step_kind,
+                                 flags=abi.AGG_UNORDERED_OUTPUT if self.unordered else 0)
         op.add_input(self.batch)
         op.no_more_input()
         # 100 M groups: drain into HBM-resident output buffers, 16 M rows at a time.
@@ -837,8 +842,11 @@ def main():
         cls.stream = args.c1_stream
     if args.workload == "c4":
         cls.sparse = args.c4_sparse
+        cls.unordered = args.c4_unordered
         if args.c4_sparse:
             cls.name = "c4_groupby_1b_100m_sparse_keys"
+        if args.c4_unordered:
+            cls.name += "_unordered_output"
     if args.workload == "c5":
         if world == 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -894,6 +902,7 @@ def main():
     copy_ceiling = measured_copy_ceiling(torch, device)
     child_flags = ["--workload", args.workload]
     for flag, on in (("--q3-random-probe", args.q3_random_probe), ("--c4-sparse", args.c4_sparse),
+                     ("--c4-unordered", args.c4_unordered),
                      ("--unfused", args.unfused), ("--c1-stream", args.c1_stream)):
         if on:
             child_flags.append(flag)

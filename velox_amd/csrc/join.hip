@@ -1043,8 +1043,29 @@ struct PartProbeArgs {
   unsigned long long* numPairs;
 };
 
+constexpr int kPartWaveBuf = 256;  // hits a wave collects in LDS before it claims output space
+
+// Writes the wave's collected hits behind one claim on the global cursor (a single HBM
+// address takes < 100 M atomics/s: one atomic per HIT would cost more than the probe).
+__device__ inline void ppFlushWave(const PartProbeArgs& a, const uint64_t* buf, uint32_t count) {
+  if (count == 0) {
+    return;
+  }
+  unsigned long long base = 0;
+  if (lane() == 0) {
+    base = atomicAdd(a.numPairs, static_cast<unsigned long long>(count));
+  }
+  base = shfl64(base, 0);
+  for (uint32_t i = lane(); i < count; i += 64) {
+    a.pairs[base + i] = buf[i];
+  }
+}
+
 __global__ __launch_bounds__(1024) void k_pp_probe(PartProbeArgs a) {
   __shared__ uint32_t slice[kPartSliceWords];
+  __shared__ uint64_t waveBuf[16][kPartWaveBuf];
+  uint64_t* buf = waveBuf[threadIdx.x >> 6];
+  uint32_t count = 0;  // uniform across the wave
   for (int32_t bin = blockIdx.x; bin < a.numBins; bin += gridDim.x) {
     const uint64_t begin = a.offsets[static_cast<int64_t>(bin) * a.numTiles];
     const uint64_t end = a.offsets[static_cast<int64_t>(bin + 1) * a.numTiles];
@@ -1072,23 +1093,24 @@ __global__ __launch_bounds__(1024) void k_pp_probe(PartProbeArgs a) {
         if (m == 0) {
           continue;
         }
-        unsigned long long base = 0;
-        const int leader = __ffsll(static_cast<long long>(m)) - 1;
-        if (lane() == leader) {
-          base = atomicAdd(a.numPairs, static_cast<unsigned long long>(popc64(m)));
+        const uint32_t hits = static_cast<uint32_t>(popc64(m));
+        if (count + hits > kPartWaveBuf) {
+          ppFlushWave(a, buf, count);
+          count = 0;
         }
-        base = shfl64(base, leader);
         if (hit) {
           const uint32_t build = a.head[(static_cast<uint64_t>(bin) << kPartShift) + off];
           if (a.probed) {
             a.probed[build] = 1;
           }
-          a.pairs[base + lanePrefix(m)] = (static_cast<uint64_t>(static_cast<uint32_t>(rec[u])) << 32) | build;
+          buf[count + lanePrefix(m)] = (static_cast<uint64_t>(static_cast<uint32_t>(rec[u])) << 32) | build;
         }
+        count += hits;
       }
     }
-    blockSync();
+    blockSync();  // the next bin overwrites the slice
   }
+  ppFlushWave(a, buf, count);
 }
 
 // Average number of distinct 128-byte lines of the presence bitmap that the 64 keys of a wave
