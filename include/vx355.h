@@ -182,8 +182,7 @@ int vx355_hash_columns(
     int32_t out_mem);
 
 /* Per-key value-id mapping state: what VectorHasher holds after
- * enableValueRange (exec/VectorHasher.cpp:923-944). Only range mode runs on
- * the device; distinct-value dictionaries (enableValueIds) stay on the host. */
+ * enableValueRange (exec/VectorHasher.cpp:923-944). */
 typedef struct vx355_value_id_spec {
   int64_t min;         /* min_ (inclusive, after reserve padding) */
   int64_t max;         /* max_ */
@@ -193,7 +192,8 @@ typedef struct vx355_value_id_spec {
 /* VectorHasher::computeValueIds (exec/VectorHasher.cpp:354-360; lookup = 0)
  * and VectorHasher::lookupValueIds (:550-565; lookup = 1) in range mode for
  * n_keys columns: result[row] = sum_i multiplier_i * (value_i - min_i + 1),
- * null contributes 0 (VectorHasher.h:560-566, VectorHasher.cpp:196-224).
+ * null contributes 0 (VectorHasher.h:560-566, VectorHasher.cpp:196-224). The
+ * distinct-value mode of the same two functions is vx355_value_dict_* below.
  * lookup = 0: *all_mapped = 0 if any selected non-null value is out of range
  *   (the reference then re-decides the hash mode); result for such rows is
  *   unspecified. rows_out is not written.
@@ -211,6 +211,41 @@ int vx355_value_ids(
     uint64_t* rows_out,
     int32_t* all_mapped,
     int32_t out_mem);
+
+/* VectorHasher in distinct-value mode (enableValueIds, exec/VectorHasher.cpp:906-921;
+ * makeValueIds :128-161,196-224; valueId, VectorHasher.h:567-580): the value ids of a key column
+ * are the 1-based insertion numbers of its distinct values, handed out in row order. The
+ * dictionary lives in HBM and persists across batches like uniqueValues_.
+ *  - compute (computeValueIds): result[row] = id (multiplier 1; null rows get 0) or result[row] +
+ *    multiplier * id for the selected rows; new values are added in first-occurrence order.
+ *    *all_mapped = 0 once the dictionary holds range_size values or more (the value that fills it
+ *    is unmappable, VectorHasher.h:573-576): the caller re-decides the hash mode, as in range mode.
+ *  - lookup (lookupValueIds, VectorHasher.cpp:408-492): values not in the dictionary are proven
+ *    misses: their rows are cleared in rows_out (ceil(num_rows / 64) words; may be NULL).
+ * Integer-like kinds, DATE, and strings of at most 7 bytes (their stringAsNumber image);
+ * result / rows / rows_out live in 'mem'. */
+typedef struct vx355_value_dict vx355_value_dict;
+int vx355_value_dict_create(int32_t type_kind, int64_t range_size, vx355_value_dict** out);
+int vx355_value_dict_compute(
+    vx355_value_dict* d,
+    const vx355_batch* batch,
+    int32_t col,
+    const uint64_t* rows,
+    uint64_t multiplier,
+    uint64_t* result,
+    int32_t* all_mapped,
+    int32_t mem);
+int vx355_value_dict_lookup(
+    vx355_value_dict* d,
+    const vx355_batch* batch,
+    int32_t col,
+    const uint64_t* rows,
+    uint64_t multiplier,
+    uint64_t* result,
+    uint64_t* rows_out,
+    int32_t mem);
+int64_t vx355_value_dict_size(const vx355_value_dict* d);
+void vx355_value_dict_destroy(vx355_value_dict* d);
 
 /* processFilterResults, flat case (exec/OperatorUtils.cpp:231-257): selected =
  * values & nulls & rows; idx_out receives the ascending row numbers of the set
@@ -612,6 +647,10 @@ typedef struct vx355_join_filter_term {
   char str[16];
 } vx355_join_filter_term;
 int vx355_join_probe_set_filter(vx355_join_probe* h, const vx355_join_filter_term* terms, int32_t n_terms);
+/* QueryConfig::preferredOutputBatchBytes (core/QueryConfig.h:479), the second bound of
+ * listJoinResults (exec/HashTable.cpp:2087-2153): get_output stops a page once the requested build
+ * columns of its rows reach 'bytes' (at least one row per page). 0 = row bound only. */
+int vx355_join_probe_set_output_batch_bytes(vx355_join_probe* h, int64_t bytes);
 /* HashProbe::addInput (exec/HashProbe.cpp:796-900): prepareForJoinProbe
  * (HashTable.cpp:2680-2712) + joinProbe (:610-652) for the whole batch. */
 int vx355_join_probe_add_input(vx355_join_probe* h, const vx355_batch* batch);

@@ -730,3 +730,32 @@ def test_range_partitioned_probe_is_chosen_for_scattered_keys_only(oracle, vx, o
     for g, e in zip(res[vx.__name__], res[oracle.__name__]):
         assert len(g) == len(e) and (g == e).all()
     assert len(res[vx.__name__][0]) >= npb // 50
+
+
+def test_output_pages_respect_preferred_output_batch_bytes(oracle, vx):
+    """listJoinResults' byte bound (HashTable.cpp:2087-2153, QueryConfig::preferredOutputBatchBytes):
+    pages stop at the byte budget of the projected build columns; the concatenation is unchanged."""
+    rng = np.random.default_rng(95)
+    bk = rng.integers(0, 3000, 20000).astype(np.int64)
+    pay = rng.integers(0, 1 << 40, 20000).astype(np.int64)
+    pay2 = rng.integers(0, 1 << 20, 20000).astype(np.int32)
+    pk = rng.integers(0, 4000, 30000).astype(np.int64)
+    res = {}
+    for impl in (oracle, vx):
+        table, _ = _build(impl, [[batch_of([bk, pay, pay2])]], [0], [abi.BIGINT], [1, 2], [abi.BIGINT, abi.INTEGER],
+                          abi.JOIN_INNER)
+        probe = impl.JoinProbe(table, [0], abi.JOIN_INNER)
+        if impl is vx:
+            probe.set_output_batch_bytes(12 * 1000)          # 12 bytes per row -> at most 1000 rows per page
+        probe.add_input(batch_of([pk]))
+        pages, pairs, payload = [], [], []
+        while True:
+            m, r, cols, fin = probe.get_output(50000, [0, 1])
+            pages.append(len(m))
+            pairs += list(zip(m.tolist(), r.tolist()))
+            if fin:
+                break
+        res[impl.__name__] = sorted(pairs)
+        if impl is vx:
+            assert max(pages) == 1000 and sum(pages) == len(pairs) and len(pages) > 100
+    assert res[vx.__name__] == res[oracle.__name__]

@@ -216,3 +216,49 @@ def test_partition_scatter_is_a_stable_partition(vx, num_parts, n):
     assert (counts == np.bincount(parts, minlength=num_parts)).all()
     for got, col in zip(outs, [k, d, s16, b]):
         assert (got == col[order]).all()
+
+
+@pytest.mark.parametrize("kind", ["bigint", "integer", "string"])
+def test_distinct_value_id_mode_matches_the_vector_hasher(oracle, vx, kind):
+    """VectorHasher::computeValueIds / lookupValueIds in distinct-value mode (VectorHasher.cpp:128-161,
+    196-224,408-492; valueId, VectorHasher.h:567-580): ids are the insertion numbers of the distinct
+    values in row order, across batches, with selection bitmaps, nulls and a multiplier; once the set
+    reaches its range size the batch is reported unmappable."""
+    rng = np.random.default_rng(17)
+    n = 50000
+    pool = rng.integers(-10**12, 10**12, 3000)
+    if kind == "bigint":
+        mk = lambda idx: abi.HostColumn(abi.BIGINT, pool[idx].astype(np.int64), rng.random(len(idx)) > 0.05)
+        k = abi.BIGINT
+    elif kind == "integer":
+        mk = lambda idx: abi.HostColumn(abi.INTEGER, (pool[idx] % 100000).astype(np.int32), rng.random(len(idx)) > 0.05)
+        k = abi.INTEGER
+    else:
+        words = [b"w%05d" % i for i in range(3000)] + [b""]
+        mk = lambda idx: abi.HostColumn(abi.VARCHAR, [words[i] for i in idx.tolist()], rng.random(len(idx)) > 0.05)
+        k = abi.VARCHAR
+    batches = [mk(rng.integers(0, 1000, n)), mk(rng.integers(0, 3000, n)), mk(rng.integers(500, 2500, 777))]
+    sels = [None, rng.random(n) > 0.3, None]
+    h = oracle.Hasher(k)
+    for col, sel in zip(batches, sels):                       # analysis pass fills the distinct set
+        h.compute_value_ids(col, rows=np.ones(col.num_rows, bool) if sel is None else sel)
+    for mult in (1, 7):
+        h = oracle.Hasher(k)
+        h.compute_value_ids(batches[0], rows=np.ones(n, bool))
+        range_size = h.enable_value_ids(mult, 50) // mult      # = rangeSize_
+        d = vx.ValueDict(k, range_size)
+        for col, sel in zip(batches, sels):
+            rows = np.ones(col.num_rows, bool) if sel is None else sel
+            base = rng.integers(0, 5, col.num_rows).astype(np.uint64)
+            ok_e, ids_e = h.compute_value_ids(col, rows=rows, result=base.copy())
+            ok_g, ids_g = d.compute(abi.HostBatch([col]), 0, rows=sel, multiplier=mult, result=base.copy())
+            assert ok_g == ok_e
+            assert d.size() == h.state().num_distinct
+            if ok_e:
+                assert (ids_g[rows] == ids_e[rows]).all()
+        probe = mk(rng.integers(0, 3000, 5000))
+        prow = rng.random(5000) > 0.2
+        rows_e, ids_e = h.lookup_value_ids(probe, prow.copy())
+        rows_g, ids_g = d.lookup(abi.HostBatch([probe]), 0, rows=prow, multiplier=mult)
+        assert (np.asarray(rows_g) == np.asarray(rows_e)).all()
+        assert (ids_g[np.asarray(rows_e)] == ids_e[np.asarray(rows_e)]).all()

@@ -1779,6 +1779,7 @@ struct vx355_join_probe {
   // range-partitioned probe: records, histogram, offsets, hit words (unsorted / sorted)
   DevBuf ppRecs, ppHist, ppOffsets, ppScan, ppPairs, ppSorted, ppSortTmp;
   bool pairList = false;     // the batch's output is ppSorted[0, totalOut)
+  int64_t outputBatchBytes = 0;  // preferred_output_batch_bytes (0 = rows only)
   int32_t partitionMode = -1;  // VX355_JOIN_PARTITION: -1 adaptive, 0 never, 1 whenever eligible
   DeviceBatch batch;                       // the batch being probed: the filter reads it at output time
   std::vector<vx355_join_filter_term> filter;
@@ -2491,6 +2492,19 @@ void probeGetOutput(vx355_join_probe& p, int32_t maxRows, int32_t* mappingOut, i
     return;
   }
   VX_CHECK_ARG(mappingOut != nullptr, "mapping_out is NULL");
+  if (p.outputBatchBytes > 0 && numBuildCols > 0) {
+    // listJoinResults stops once the projected build columns of the listed hits reach
+    // preferredOutputBatchBytes (JoinResultEmitter, HashTable.cpp:2087-2108): with fixed-width
+    // columns that is a row bound. Every output row is priced as a hit, so a page is never
+    // larger than the reference's.
+    int64_t rowBytes = 0;
+    for (int32_t c = 0; c < numBuildCols; ++c) {
+      const int32_t id = buildColIds ? buildColIds[c] : -1;
+      rowBytes += (id >= 0 && id < static_cast<int32_t>(t.depKinds.size())) ? std::max(1, kindWidth(t.depKinds[id])) : 1;
+    }
+    const int64_t byBytes = std::max<int64_t>(1, ceilDiv(p.outputBatchBytes, std::max<int64_t>(1, rowBytes)));
+    maxRows = static_cast<int32_t>(std::min<int64_t>(maxRows, byBytes));
+  }
   const uint64_t begin = p.cursor;
   const uint64_t end = std::min<uint64_t>(p.totalOut, begin + static_cast<uint64_t>(maxRows));
   const int32_t n = static_cast<int32_t>(end - begin);
@@ -2951,6 +2965,13 @@ int vx355_join_probe_set_filter(vx355_join_probe* h, const vx355_join_filter_ter
     }
   }
   VX_API_END
+}
+
+int vx355_join_probe_set_output_batch_bytes(vx355_join_probe* h, int64_t bytes) {
+  try {
+    VX_CHECK_ARG(h && bytes >= 0, "bad argument");
+    h->outputBatchBytes = bytes;
+  VX_API_CATCH
 }
 
 int vx355_join_probe_add_input(vx355_join_probe* h, const vx355_batch* batch) {

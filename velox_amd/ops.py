@@ -34,10 +34,12 @@ SYMBOLS = [
     "vx355_bloom_num_blocks", "vx355_join_table_key_filter_bloom", "vx355_bloom_test",
     "vx355_set_device", "vx355_current_device", "vx355_stream_wait_event", "vx355_default_stream",
     "vx355_agg_stream", "vx355_join_build_stream", "vx355_join_probe_stream",
-    "vx355_join_probe_set_filter",
+    "vx355_join_probe_set_filter", "vx355_join_probe_set_output_batch_bytes",
     "vx355_comm_get_unique_id", "vx355_comm_create", "vx355_comm_create_all", "vx355_comm_info",
     "vx355_comm_stream", "vx355_comm_destroy", "vx355_exchange_counts", "vx355_exchange_columns",
     "vx355_all_gather", "vx355_agg_flush", "vx355_agg_to_intermediate",
+    "vx355_value_dict_create", "vx355_value_dict_compute", "vx355_value_dict_lookup", "vx355_value_dict_size",
+    "vx355_value_dict_destroy",
 ]
 
 
@@ -115,6 +117,7 @@ def lib():
     L.vx355_join_table_key_filter_bloom.argtypes = [vp, i32, i32, vp, i64, i32]
     L.vx355_bloom_test.argtypes = [vp, i64, i32, P(abi.Column), i32, vp, vp, i32]
     L.vx355_join_probe_set_filter.argtypes = [vp, P(abi.JoinFilterTerm), i32]
+    L.vx355_join_probe_set_output_batch_bytes.argtypes = [vp, i64]
     L.vx355_comm_get_unique_id.argtypes = [vp]
     L.vx355_comm_create.argtypes = [vp, i32, i32, P(vp)]
     L.vx355_comm_create_all.argtypes = [i32, P(i32), P(vp)]
@@ -126,6 +129,13 @@ def lib():
     L.vx355_exchange_counts.argtypes = [vp, P(i64), P(i64)]
     L.vx355_exchange_columns.argtypes = [vp, P(vp), P(i32), i32, P(i64), P(i64), P(vp)]
     L.vx355_all_gather.argtypes = [vp, vp, vp, sz]
+    L.vx355_value_dict_create.argtypes = [i32, i64, P(vp)]
+    L.vx355_value_dict_compute.argtypes = [vp, P(abi.Batch), i32, vp, u64, vp, P(i32), i32]
+    L.vx355_value_dict_lookup.argtypes = [vp, P(abi.Batch), i32, vp, u64, vp, vp, i32]
+    L.vx355_value_dict_size.restype = i64
+    L.vx355_value_dict_size.argtypes = [vp]
+    L.vx355_value_dict_destroy.argtypes = [vp]
+    L.vx355_value_dict_destroy.restype = None
     L.vx355_set_device.argtypes = [C.c_int]
     L.vx355_stream_wait_event.argtypes = [vp, vp]
     L.vx355_default_stream.restype = vp
@@ -147,6 +157,46 @@ def init(device=0):
 
 def synchronize():
     _check(lib().vx355_synchronize())
+
+
+class ValueDict:
+    """VectorHasher in distinct-value mode (vx355_value_dict_*)."""
+
+    def __init__(self, kind, range_size):
+        h = C.c_void_p()
+        _check(lib().vx355_value_dict_create(kind, range_size, C.byref(h)))
+        self.h = h
+
+    def compute(self, batch, col=0, rows=None, multiplier=1, result=None):
+        n = batch.num_rows
+        if result is None:
+            result = np.zeros(max(1, n), dtype=np.uint64)
+        bits = abi.pack_bits(rows) if rows is not None else None
+        ok = C.c_int32()
+        _check(lib().vx355_value_dict_compute(self.h, batch.ref(), col, bits.ctypes.data if bits is not None else None,
+                                              multiplier, result.ctypes.data, C.byref(ok), abi.MEM_HOST))
+        return bool(ok.value), result[:n]
+
+    def lookup(self, batch, col=0, rows=None, multiplier=1, result=None):
+        n = batch.num_rows
+        if result is None:
+            result = np.zeros(max(1, n), dtype=np.uint64)
+        bits = abi.pack_bits(rows) if rows is not None else None
+        out = np.zeros(max(1, (n + 63) // 64), dtype=np.uint64)
+        _check(lib().vx355_value_dict_lookup(self.h, batch.ref(), col, bits.ctypes.data if bits is not None else None,
+                                             multiplier, result.ctypes.data, out.ctypes.data, abi.MEM_HOST))
+        return abi.unpack_bits(out, n), result[:n]
+
+    def size(self):
+        return lib().vx355_value_dict_size(self.h)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().vx355_value_dict_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
 
 
 # ---- multi-GPU exchange (RCCL inside the library) -----------------------------
@@ -647,6 +697,9 @@ class HashProbe:
         """HashJoinNode::filter: [(left, cmp, right)], see abi.join_filter_terms."""
         self._filter = abi.join_filter_terms(terms)
         _check(lib().vx355_join_probe_set_filter(self.h, self._filter, len(terms)))
+
+    def set_output_batch_bytes(self, nbytes):
+        _check(lib().vx355_join_probe_set_output_batch_bytes(self.h, nbytes))
 
     def add_input(self, batch):
         self._batch = batch
