@@ -93,7 +93,12 @@ typedef struct vx355_batch {
   const vx355_column* cols; /* host array */
 } vx355_batch;
 
-/* One caller-allocated flat output column. */
+/* One caller-allocated flat output column. VARCHAR / VARBINARY values are 16-byte
+ * StringViews; strings longer than 12 bytes (grouping keys of the generic hash mode) are
+ * non-inline views: in a VX355_MEM_DEVICE column they point into the operator's HBM arena
+ * (valid while the handle lives), in a VX355_MEM_HOST column into a host buffer the handle
+ * keeps until its next get_output — the shim copies or wraps them like any string buffer
+ * (FlatVector::stringBuffers_). */
 typedef struct vx355_out_column {
   int32_t type_kind;
   int32_t mem;      /* vx355_mem of values / nulls */

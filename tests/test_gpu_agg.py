@@ -329,13 +329,42 @@ def test_generic_hash_mode_wide_int_keys_growth_and_order(oracle, vx, monkeypatc
     assert st.hash_mode == abi.MODE_HASH and st.num_groups == len(exp[0][0]) and st.num_rehashes > 0
 
 
-def test_strings_longer_than_inline_are_refused(vx):
-    strs = [b"x" * 13, b"short"]
-    op = vx.Aggregation([0], [abi.VARCHAR], [(abi.AGG_COUNT_STAR, -1, abi.BIGINT)])
-    with pytest.raises(vx.Vx355Error) as e:
-        op.add_input(batch_of([strs]))
-        op.no_more_input()
-    assert e.value.status == abi.EUNSUPPORTED
+@pytest.mark.parametrize("start_short", [False, True])
+def test_grouping_strings_longer_than_12_bytes(oracle, vx, start_short, monkeypatch):
+    """Non-inline StringViews (type/StringView.h:76-77: size > 12, pointer instead of inline bytes) as
+    grouping keys: generic hash mode (the reference's kHash), the group keeps a copy of the string in
+    the operator's HBM arena and compares by content. Second key, nulls, strings of every length
+    around the inline / prefix / word boundaries, several batches; start_short: the stream begins
+    with <= 7-byte strings (array mode) and switches in the middle. Keys, first-seen order and
+    aggregates must equal the oracle's."""
+    monkeypatch.setenv("VX355_AGG_COALESCE_ROWS", "0")
+    rng = np.random.default_rng(71)
+    lens = [0, 1, 7, 8, 12, 13, 15, 16, 17, 23, 24, 25, 31, 40, 64, 100, 255]
+    words = []
+    for i in range(400):
+        ln = lens[i % len(lens)]
+        body = (b"%06d-" % i + bytes(rng.integers(97, 123, 300).astype(np.uint8)))[:ln]
+        words.append(body)
+    words = list(dict.fromkeys(words))
+    # pairs that differ only past the 4-byte prefix / only in the last byte
+    words += [b"common-prefix-and-then-A", b"common-prefix-and-then-B", b"x" * 40 + b"1", b"x" * 40 + b"2"]
+    batches = []
+    for bi in range(4):
+        n = 20000
+        pool = [w for w in words if len(w) <= 7] if (start_short and bi == 0) else words
+        k = [pool[i] for i in rng.integers(0, len(pool), n)]
+        kvalid = rng.random(n) > 0.03
+        k2 = rng.integers(0, 3, n).astype(np.int32)
+        v = rng.integers(-1000, 1000, n).astype(np.int64)
+        d = _dyadic(rng, n)
+        batches.append(batch_of([k, k2, v, d], [kvalid, None, None, None]))
+    aggs = [(abi.AGG_SUM, 2, abi.BIGINT), (abi.AGG_COUNT_STAR, -1, abi.BIGINT), (abi.AGG_SUM, 3, abi.DOUBLE),
+            (abi.AGG_MIN, 2, abi.BIGINT)]
+    exp, eop = run_agg(oracle, batches, [0, 1], [abi.VARCHAR, abi.INTEGER], aggs, max_rows=333)
+    got, gop = run_agg(vx, batches, [0, 1], [abi.VARCHAR, abi.INTEGER], aggs, max_rows=333)
+    assert gop.stats().hash_mode == abi.MODE_HASH
+    assert_columns_equal(got, exp, gop.kinds, what="long string keys")
+    assert any(len(x) > 12 for x, ok in zip(got[0][0], got[0][1]) if ok)
 
 
 def test_device_resident_input_and_output(oracle, vx):

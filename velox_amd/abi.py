@@ -334,11 +334,17 @@ class OutBuffers:
         elif k in (VARCHAR, VARBINARY):
             raw = self.values[i][: n * 16].reshape(n, 16)
             sizes = raw[:, 0:4].copy().view(np.uint32).reshape(-1)
-            bad = np.flatnonzero((sizes > 12) & valid[:n])
-            if len(bad):   # the library only ever returns inline strings
-                raise AssertionError(f"output column {i}: non-inline StringView at rows {bad[:5].tolist()}: "
-                                     f"{raw[bad[0]].tobytes().hex()}")
-            vals = [view_to_bytes(raw[j]) if valid[j] else None for j in range(n)]
+            vals = []
+            for j in range(n):
+                if not valid[j]:
+                    vals.append(None)
+                elif sizes[j] <= 12:
+                    vals.append(view_to_bytes(raw[j]))
+                else:
+                    # non-inline view of a HOST output column: the pointer leads into a buffer the
+                    # operator keeps alive until its next get_output (include/vx355.h, vx355_out_column)
+                    ptr = int(raw[j, 8:16].copy().view(np.uint64)[0])
+                    vals.append(C.string_at(ptr, int(sizes[j])))
         elif k == TIMESTAMP:
             vals = self.values[i][: n * 16].view(np.int64).reshape(n, 2).copy()
         else:

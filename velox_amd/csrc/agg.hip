@@ -1204,7 +1204,55 @@ struct GenericPart {
   uint32_t* gidCounter;
   uint32_t maxGroups;
   uint32_t pad;
+  // Arena for grouping strings longer than 12 bytes (StringView's non-inline form,
+  // type/StringView.h:76-77): the group's key image keeps {size | prefix, arena pointer}.
+  char* arenaBase;
+  unsigned long long* arenaCursor;  // bytes handed out of the current block
+  uint64_t arenaCap;
 };
+
+// Up to 8 bytes at p (n >= 1), zero padded: strings end anywhere.
+__device__ inline uint64_t loadBytes8(const uint8_t* p, uint32_t n) {
+  uint64_t v = 0;
+  const uint32_t m = n < 8 ? n : 8;
+  for (uint32_t i = 0; i < m; ++i) {
+    v |= static_cast<uint64_t>(p[i]) << (8 * i);
+  }
+  return v;
+}
+
+// Total arena bytes the long strings of the key columns of a chunk can ask for.
+struct LongBytesArgs {
+  ColView keys[kMaxKeys];
+  int32_t numKeys;
+  int64_t numRows;
+  const int32_t* rowList;
+  unsigned long long* total;
+};
+
+__global__ __launch_bounds__(256) void k_long_key_bytes(LongBytesArgs a) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  unsigned long long mine = 0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.numRows; i += stride) {
+    const int64_t row = a.rowList ? a.rowList[i] : i;
+    for (int k = 0; k < a.numKeys; ++k) {
+      const ColView& c = a.keys[k];
+      if ((c.kind == VX355_VARCHAR || c.kind == VX355_VARBINARY) && !colIsNull(c, row)) {
+        const uint32_t size = static_cast<const uint4*>(c.values)[colIndex(c, row)].x;
+        if (size > 12) {
+          mine += (size + 7) & ~7u;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    mine += shfl64(mine, lane() ^ off);
+  }
+  if (lane() == 0 && mine) {
+    atomicAdd(a.total, mine);
+  }
+}
 
 struct GenericArgs {
   AggArgs a;
@@ -1258,7 +1306,7 @@ __device__ inline bool genericGroupId(const GenericArgs& args, int64_t row, uint
         nullMask |= 1ULL << k;
       } else {
         const int64_t i = colIndex(c, row);
-        keyImage(c, i, &w0[k], &w1[k], &supported);
+        keyImage(c, i, &w0[k], &w1[k], &supported);  // long strings: {size | prefix, pointer}
         hv = hashValueAt(c, i);
       }
       hash = k == 0 ? hv : hashMix(hash, hv);
@@ -1267,9 +1315,15 @@ __device__ inline bool genericGroupId(const GenericArgs& args, int64_t row, uint
   if (nullMask && a.ignoreNullKeys) {
     return false;
   }
-  if (!supported) {
-    a.counters->unmappable = 1;
-    return false;
+  // which keys of this row are non-inline strings (compared by content, stored in the arena)
+  uint32_t longMask = 0;
+#pragma unroll
+  for (int k = 0; k < kMaxKeys; ++k) {
+    if (k < a.numKeys && !((nullMask >> k) & 1) &&
+        (a.keys[k].col.kind == VX355_VARCHAR || a.keys[k].col.kind == VX355_VARBINARY) &&
+        static_cast<uint32_t>(w0[k]) > 12) {
+      longMask |= 1u << k;
+    }
   }
   const uint64_t tag = hash >> 32;
   uint64_t pos = hash & g.slotMask;
@@ -1293,7 +1347,29 @@ __device__ inline bool genericGroupId(const GenericArgs& args, int64_t row, uint
           idBase = atomicAdd(g.gidCounter, static_cast<uint32_t>(popc64(winners)));
         }
         const uint32_t id = __shfl(idBase, leader, kWave) + lanePrefix(winners);
-        if (id < g.maxGroups) {
+        bool arenaOk = true;
+        if (id < g.maxGroups && longMask) {
+          // copy the long strings into the arena (write-through stores, like the key images)
+#pragma unroll
+          for (int k = 0; k < kMaxKeys; ++k) {
+            if ((longMask >> k) & 1) {
+              const uint32_t size = static_cast<uint32_t>(w0[k]);
+              const uint32_t padded = (size + 7) & ~7u;
+              const unsigned long long at = atomicAdd(g.arenaCursor, static_cast<unsigned long long>(padded));
+              if (at + padded > g.arenaCap) {
+                arenaOk = false;
+              } else {
+                const uint8_t* src = reinterpret_cast<const uint8_t*>(w1[k]);
+                uint64_t* dst = reinterpret_cast<uint64_t*>(g.arenaBase + at);
+                for (uint32_t off = 0; off < size; off += 8) {
+                  storeAgent(dst + (off >> 3), loadBytes8(src + off, size - off));
+                }
+                w1[k] = reinterpret_cast<uint64_t>(dst);
+              }
+            }
+          }
+        }
+        if (id < g.maxGroups && arenaOk) {
 #pragma unroll
           for (int k = 0; k < kMaxKeys; ++k) {
             if (k < a.numKeys) {
@@ -1340,7 +1416,18 @@ __device__ inline bool genericGroupId(const GenericArgs& args, int64_t row, uint
             if (equal && k < a.numKeys && !((nullMask >> k) & 1)) {
               equal = loadAgent(g.keyStore[k] + static_cast<uint64_t>(cand) * g.keyWords[k]) == w0[k];
               if (equal && g.keyWords[k] == 2) {
-                equal = loadAgent(g.keyStore[k] + static_cast<uint64_t>(cand) * 2 + 1) == w1[k];
+                const uint64_t stored = loadAgent(g.keyStore[k] + static_cast<uint64_t>(cand) * 2 + 1);
+                if ((longMask >> k) & 1) {
+                  // same size and prefix: compare the bytes (the group's copy is zero padded to 8)
+                  const uint32_t size = static_cast<uint32_t>(w0[k]);
+                  const uint64_t* theirs = reinterpret_cast<const uint64_t*>(stored);
+                  const uint8_t* mine = reinterpret_cast<const uint8_t*>(w1[k]);
+                  for (uint32_t off = 0; off < size && equal; off += 8) {
+                    equal = loadAgent(theirs + (off >> 3)) == loadBytes8(mine + off, size - off);
+                  }
+                } else {
+                  equal = stored == w1[k];
+                }
               }
             }
           }
@@ -1933,6 +2020,18 @@ __global__ __launch_bounds__(256) void k_extract(ExtractArgs a) {
   }
 }
 
+// One wave per string: desc = {source pointer, size, offset in 'out'} per string.
+__global__ __launch_bounds__(64) void k_gather_strings(const uint64_t* desc, int64_t n, char* out) {
+  for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const char* src = reinterpret_cast<const char*>(desc[i * 3]);
+    const uint64_t size = desc[i * 3 + 1];
+    char* dst = out + desc[i * 3 + 2];
+    for (uint64_t b = threadIdx.x; b < size; b += 64) {
+      dst[b] = src[b];
+    }
+  }
+}
+
 // ---- GroupingSet::toIntermediate (GroupingSet.cpp:1589-1675) ---------------------------------
 struct ToIntermediateAgg {
   ColView in, mask;
@@ -2098,6 +2197,13 @@ struct vx355_agg {
   std::vector<DevBuf> gKeyStore;
   uint64_t gSlotCap = 0;
   uint64_t gMaxGroups = 0;
+  // arena of grouping strings longer than 12 bytes: blocks are never moved (key images point into them)
+  std::vector<DevBuf> strBlocks;
+  DevBuf strCursor;          // u64: bytes used of the newest block
+  uint64_t strCap = 0;       // capacity of the newest block
+  uint64_t strUsedHost = 0;  // upper bound of what the kernels have taken from it
+  bool hasStringKeys = false;
+  std::vector<std::vector<char>> hostStrings;  // long strings of the last page handed to a host caller
 
   // device state
   int32_t mode = MODE_ARRAY;
@@ -2198,6 +2304,7 @@ void buildPlan(vx355_agg& h, const vx355_agg_spec& spec) {
     if (!(isIntLike(ks.kind) || isString(ks.kind))) {
       h.generic = true;  // REAL / DOUBLE / TIMESTAMP have no value ids (VectorHasher.h:338-357)
     }
+    h.hasStringKeys = h.hasStringKeys || isString(ks.kind);
     h.keys.push_back(ks);
     h.outTypes.push_back(ks.kind);
     h.usedCols.push_back(ks.col);
@@ -3337,11 +3444,40 @@ void runGeneric(vx355_agg& h, const AggArgs& base, int64_t count, uint64_t rowBa
   g.hashStore = h.gHashStore.as<uint64_t>();
   g.gidCounter = h.gCounter.as<uint32_t>();
   g.maxGroups = static_cast<uint32_t>(std::min<uint64_t>(h.gMaxGroups, 0xfffffffeULL));
+  if (h.hasStringKeys) {
+    // Worst case every long string of the chunk founds a group: make sure the newest arena
+    // block can take them all (one small reduction over the key columns).
+    auto& rt = Runtime::get();
+    unsigned long long* cursor = static_cast<unsigned long long*>(h.strCursor.ensure(64));
+    LongBytesArgs lb{};
+    lb.numKeys = c.numKeys;
+    for (int k = 0; k < c.numKeys; ++k) {
+      lb.keys[k] = c.keys[k].col;
+    }
+    lb.numRows = count;
+    lb.rowList = rowList;
+    lb.total = cursor + 1;
+    HIP_OK(hipMemsetAsync(cursor + 1, 0, 8, rt.stream));
+    VX_LAUNCH("k_long_key_bytes", k_long_key_bytes, streamGrid(count, 256), 256, 0, lb);
+    unsigned long long need = 0;
+    copyOut(&need, VX355_MEM_HOST, cursor + 1, 8);
+    if (h.strBlocks.empty() || h.strUsedHost + need > h.strCap) {
+      h.strBlocks.emplace_back();
+      h.strCap = std::max<uint64_t>(need, 64ULL << 20);
+      h.strBlocks.back().ensure(static_cast<size_t>(h.strCap) + 64);
+      h.strUsedHost = 0;
+      HIP_OK(hipMemsetAsync(cursor, 0, 8, rt.stream));
+    }
+    h.strUsedHost += need;
+    g.arenaBase = h.strBlocks.back().as<char>();
+    g.arenaCursor = cursor;
+    g.arenaCap = h.strCap;
+  }
   resetCounters(h);
   VX_LAUNCH("k_agg_generic", k_agg_generic, streamGrid(count, 256), 256, 0, ga);
   Counters ctr = readCounters(h);
   if (ctr.unmappable) {
-    VX_THROW(VX355_EUNSUPPORTED, "string grouping key longer than 12 bytes (not inline)");
+    VX_THROW(VX355_EINTERNAL, "unmappable grouping key in generic mode");
   }
   checkCounters(ctr);
   uint32_t ids = 0;
@@ -3756,6 +3892,8 @@ void finalize(vx355_agg& h) {
 void resetAfterFlush(vx355_agg& h) {
   auto& rt = Runtime::get();
   if (h.generic) {
+    h.strBlocks.clear();  // the flushed pages were drained: their strings are no longer referenced
+    h.strCap = h.strUsedHost = 0;
     if (h.gSlotCap) {
       HIP_OK(hipMemsetAsync(h.gSlots.ptr(), 0, static_cast<size_t>(h.gSlotCap) * 8, rt.stream));
     }
@@ -3882,6 +4020,55 @@ void getOutput(vx355_agg& h, vx355_out_column* cols, int32_t numCols, int32_t ma
     }
   }
   rt.sync();
+  if (h.generic && h.hasStringKeys) {
+    // Key strings longer than 12 bytes came out as views into the operator's HBM arena. Device
+    // output columns keep those (valid while the handle lives); for host columns the bytes follow
+    // into a buffer owned by the handle (valid until its next get_output) and the views are
+    // re-pointed.
+    h.hostStrings.clear();
+    for (size_t k = 0; k < h.keys.size(); ++k) {
+      if (!isString(h.keys[k].kind) || cols[k].mem != VX355_MEM_HOST) {
+        continue;
+      }
+      char* views = static_cast<char*>(cols[k].values);
+      std::vector<std::pair<int32_t, uint32_t>> longRows;  // row, size
+      size_t total = 0;
+      for (int32_t r = 0; r < n; ++r) {
+        uint32_t size;
+        std::memcpy(&size, views + static_cast<size_t>(r) * 16, 4);
+        if (size > 12) {
+          longRows.emplace_back(r, size);
+          total += size;
+        }
+      }
+      if (longRows.empty()) {
+        continue;
+      }
+      h.hostStrings.emplace_back(total);
+      char* dst = h.hostStrings.back().data();
+      // one gather kernel + one copy for the whole page
+      const size_t m = longRows.size();
+      std::vector<uint64_t> desc(m * 3);  // source pointer, size, offset
+      size_t at = 0;
+      for (size_t i = 0; i < m; ++i) {
+        uint64_t src;
+        std::memcpy(&src, views + static_cast<size_t>(longRows[i].first) * 16 + 8, 8);
+        desc[i * 3] = src;
+        desc[i * 3 + 1] = longRows[i].second;
+        desc[i * 3 + 2] = at;
+        char* hostPtr = dst + at;
+        std::memcpy(views + static_cast<size_t>(longRows[i].first) * 16 + 8, &hostPtr, 8);
+        at += longRows[i].second;
+      }
+      DevBuf dDesc, dBlob;
+      uint64_t* devDesc = static_cast<uint64_t*>(dDesc.ensure(desc.size() * 8 + 64));
+      char* devBlob = static_cast<char*>(dBlob.ensure(total + 64));
+      copyIn(devDesc, desc.data(), VX355_MEM_HOST, desc.size() * 8);
+      VX_LAUNCH("k_gather_strings", k_gather_strings, static_cast<int>(std::min<size_t>(m, 65535)), 64, 0, devDesc,
+                static_cast<int64_t>(m), devBlob);
+      copyOut(dst, VX355_MEM_HOST, devBlob, total);
+    }
+  }
   h.outputCursor += n;
   *finished = h.outputCursor >= h.numOutput ? 1 : 0;
   if (*finished && h.flushing) {
