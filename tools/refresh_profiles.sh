@@ -1,5 +1,7 @@
 # Re-measures every workload bench.py knows on the GPU box; JSON lines land in gpurun_out/refresh/.
+# ROUND=r02 sh tools/refresh_profiles.sh
 R=${GRAFT_REPO_ROOT:-/root/repo}
+P=${ROUND:-r02}
 cd $R
 O=gpurun_out/refresh
 mkdir -p $O
@@ -8,18 +10,19 @@ import json
 try:
     d = json.load(open("$O/$name.json"))
     print("$name", round(d["ms_per_step"], 3), "ms", "%.3g" % d["value"], "rows/s", {k: v for k, v in d["kernels_ms_per_step"].items() if v > 0.3})
+    for k, v in d.get("secondary", {}).items():
+        print("   ", k, round(v["ms_per_step"], 3), "ms", v["roofline"]["kernel"], round(v["roofline"]["achieved"] or 0), "GB/s")
 except Exception as e:
     print("$name FAILED", e)
 PY
 }
-run r01_bench_q1_sf100
-run r01_bench_q1_unfused --unfused
-run r01_bench_c1 --workload c1
-run r01_bench_c1_streamed_host_batches --workload c1 --c1-stream
-run r01_bench_q3_join --workload q3
-run r01_bench_q3_join_random_probe_order --workload q3 --q3-random-probe
-run r01_bench_q3_full_query --workload q3full
-run r01_bench_c4 --workload c4 --steps 3 --warmup 1
-run r01_bench_c4_sparse_keys --workload c4 --c4-sparse --steps 3 --warmup 1
-VX355_AGG_RADIX_MIN_ROWS=-1 run r01_bench_c4_atomics_only --workload c4 --steps 2 --warmup 1 --no-cpu-baseline
-run r01_bench_c5_one_gpu --workload c5 --rows 200000000 --steps 3 --warmup 1
+run ${P}_bench_default --steps 20 --warmup 5
+run ${P}_bench_q1_unfused --unfused --no-secondary --no-traffic
+run ${P}_bench_c1 --workload c1 --no-traffic
+run ${P}_bench_c1_streamed_host_batches --workload c1 --c1-stream --no-traffic
+run ${P}_bench_q3_full_query --workload q3full --no-traffic
+VX355_JOIN_PARTITION=0 run ${P}_bench_q3_join_random_direct_probe --workload q3 --q3-random-probe --no-traffic --no-cpu-baseline
+run ${P}_bench_c4 --workload c4 --steps 3 --warmup 1
+run ${P}_bench_c4_unordered_output --workload c4 --c4-unordered --steps 3 --warmup 1 --no-traffic --no-cpu-baseline
+run ${P}_bench_c4_sparse_keys --workload c4 --c4-sparse --steps 3 --warmup 1 --no-traffic
+run ${P}_bench_c5_one_gpu --workload c5 --rows 200000000 --steps 3 --warmup 1 --no-traffic
