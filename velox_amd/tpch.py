@@ -73,6 +73,10 @@ def run_q3(ops, torch, tables, date=Q3_DATE):
     n1, fin = p1.get_output_device(max(1, mo), map_o.data_ptr(), None, None, [])
     assert fin
     ord_idx = idx_o[map_o[:n1].long()].contiguous() if n1 else idx_o[:0]
+    # ord_idx is produced by torch kernels on torch's stream; the library's operators run on their own
+    # streams and take device inputs as complete (include/vx355.h, vx355_column.mem): drain torch's
+    # stream first (a C++ host would use vx355_stream_wait_event with the producer's event instead).
+    torch.cuda.current_stream(dev).synchronize()
     info["orders_selected"], info["orders_joined"] = mo, n1
     b2 = ops.HashBuild([0], [abi.BIGINT], [1, 2], [abi.INTEGER, abi.INTEGER], abi.JOIN_INNER)
     if n1:
@@ -100,6 +104,7 @@ def run_q3(ops, torch, tables, date=Q3_DATE):
     assert fin
     info["lineitems_selected"], info["lineitems_joined"] = ml, n2
     li_idx = idx_l[map_l[:n2].long()].contiguous() if n2 else idx_l[:0]
+    torch.cuda.current_stream(dev).synchronize()
 
     # -- aggregation: group by (l_orderkey, o_orderdate, o_shippriority), sum(ep * (1 - disc))
     agg = ops.HashAggregation([0, 1, 2], [abi.BIGINT, abi.INTEGER, abi.INTEGER],
