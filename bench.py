@@ -438,15 +438,17 @@ class Q3:
         return n
 
     def pick_dominant(self, prof):
-        """The probe pass is k_join_probe_list when it also lists the hits (low hit rates: 8-byte key
-        in, 8 bytes out per MATCH) or k_join_probe + k_emit (4-byte hit out per probe row)."""
-        lst, dense = prof.get("k_join_probe_list", (0.0, 0))[0], prof.get("k_join_probe", (0.0, 0))[0]
-        if lst >= dense:
-            self.dominant = "k_join_probe_list"
-            self.agg_bytes_per_row = 8 + 8.0 * self.matches / max(1, self.probe_rows)
-        else:
-            self.dominant = "k_join_probe"
-            self.agg_bytes_per_row = 12
+        """The roofline kernel of the step = the slowest kernel of the probe phase, priced at the bytes
+        IT has to move per probe row: k_join_probe_list (probe pass that also lists the hits: 8-byte key
+        in, 8 bytes out per MATCH), k_join_probe (4-byte hit out per probe row, k_emit lists later), or
+        — range-partitioned probe for scattered keys — k_pp_count (8 in), k_pp_scatter (8 in, 8-byte
+        record out), k_join_probe_part (8-byte record in, bitmap slice from LDS)."""
+        per_row = {"k_join_probe_list": 8 + 8.0 * self.matches / max(1, self.probe_rows), "k_join_probe": 12,
+                   "k_pp_count": 8, "k_pp_scatter": 16, "k_join_probe_part": 8 + 8.0 * self.matches / max(1, self.probe_rows)}
+        name = max(per_row, key=lambda k: prof.get(k, (0.0, 0))[0])
+        self.dominant = name
+        self.agg_bytes_per_row = per_row[name]
+        self.probe_phase_ms = sum(prof.get(k, (0.0, 0))[0] for k in per_row)
 
     def rows_per_step(self):
         return self.probe_rows
@@ -964,7 +966,7 @@ def roofline_block(wl, prof, steps, copy_ceiling, child_flags):
     dom_ms, dom_launches = prof.get(wl.dominant, (0.0, 0))
     dom_rows = getattr(wl, "selected", wl.rows_per_step()) * steps
     achieved = (wl.agg_bytes_per_row * dom_rows / (dom_ms * 1e-3) / 1e9) if dom_ms > 0 else None
-    symbol = "k_join_probe" if wl.dominant == "k_join_probe_list" else wl.dominant   # profile label -> kernel symbol
+    symbol = {"k_join_probe_list": "k_join_probe", "k_join_probe_part": "k_pp_probe"}.get(wl.dominant, wl.dominant)  # profile label -> kernel symbol
     pmc = measure_traffic(child_flags, symbol) if child_flags is not None else {}
     if not pmc:
         pmc = pmc_traffic(wl.name, wl.dominant)
@@ -1046,6 +1048,11 @@ def q3_block(torch, device, random_order, args, copy_ceiling, measure):
         "roofline": roofline_block(wl, prof, steps, copy_ceiling, child if measure else None),
         "kernels_ms_per_step": {k: round(v[0] / steps, 4) for k, v in sorted(prof.items())},
     }
+    if getattr(wl, "probe_phase_ms", None):
+        # all probe-side kernels together, priced at key in + hit out (12 B/probe) and at SURVEY section 8(d)'s 24 B
+        ms = wl.probe_phase_ms / steps
+        block["probe_phase"] = {"ms_per_step": ms, "GBps_at_12B_per_probe": wl.rows_per_step() * 12 / (ms * 1e-3) / 1e9,
+                                "GBps_at_24B_per_probe": wl.rows_per_step() * 24 / (ms * 1e-3) / 1e9}
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
