@@ -996,36 +996,109 @@ __global__ __launch_bounds__(1024) void k_pp_count(PartArgs a) {
   }
 }
 
+// Scatter with an LDS sort in front: a tile (32 K rows, the unit of the global histogram) is
+// handled in sub-tiles of 8192 records. Each sub-tile is counting-sorted by bin inside LDS
+// (histogram, scan, placement), then written out: the records of one bin form a run of
+// consecutive lanes storing to consecutive addresses, instead of 1024 lanes storing 8 bytes
+// to 1024 unrelated lines (the plain scatter reached 1.6 TB/s with ~1100 open bins).
+constexpr int kPartSub = 8192;
+
 __global__ __launch_bounds__(1024) void k_pp_scatter(PartArgs a) {
-  __shared__ unsigned long long binBase[kPartMaxBins];
-  __shared__ uint32_t cursor[kPartMaxBins];
+  __shared__ unsigned long long binBase[kPartMaxBins];  // next free record of the bin inside this tile's range
+  __shared__ uint32_t cnt[kPartMaxBins];                // sub-tile histogram, then placement cursor
+  __shared__ uint32_t start[kPartMaxBins];              // sub-tile exclusive scan
+  __shared__ uint64_t recs[kPartSub];
+  __shared__ uint16_t binOf[kPartSub];
+  __shared__ uint32_t waveTotals[16];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
   for (int64_t tile = blockIdx.x; tile < a.numTiles; tile += gridDim.x) {
-    for (int i = threadIdx.x; i < a.numBins; i += blockDim.x) {
+    for (int i = tid; i < a.numBins; i += blockDim.x) {
       binBase[i] = a.offsets[static_cast<int64_t>(i) * a.numTiles + tile];
-      cursor[i] = 0;
     }
-    blockSync();
     const int64_t begin = tile * kPartTileRows;
     const int64_t end = begin + kPartTileRows < a.numRows ? begin + kPartTileRows : a.numRows;
-    for (int64_t base = begin; base < end; base += 8 * 1024) {
-      int64_t v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int64_t r = base + u * 1024 + threadIdx.x;
-        v[u] = r < end ? a.keys[r] : INT64_MIN;
+    for (int64_t base = begin; base < end; base += kPartSub) {
+      for (int i = tid; i < a.numBins; i += blockDim.x) {
+        cnt[i] = 0;
       }
+      blockSync();
+      // 1. load + histogram
+      uint64_t rec[8];
+      uint32_t bin[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int64_t r = base + u * 1024 + threadIdx.x;
-        if (r < end && v[u] >= a.keyMin && v[u] <= a.keyMax) {
-          const uint64_t key = static_cast<uint64_t>(v[u]) - static_cast<uint64_t>(a.keyMin) + 1;
-          const uint32_t bin = static_cast<uint32_t>(key >> kPartShift);
-          const unsigned long long pos = binBase[bin] + atomicAdd(&cursor[bin], 1u);
-          a.recs[pos] = ((key & ((1ULL << kPartShift) - 1)) << 32) | static_cast<uint32_t>(r);
+        const int64_t r = base + u * 1024 + tid;
+        const int64_t v = r < end ? a.keys[r] : INT64_MIN;
+        bin[u] = 0xffffffffu;
+        if (r < end && v >= a.keyMin && v <= a.keyMax) {
+          const uint64_t key = static_cast<uint64_t>(v) - static_cast<uint64_t>(a.keyMin) + 1;
+          bin[u] = static_cast<uint32_t>(key >> kPartShift);
+          rec[u] = ((key & ((1ULL << kPartShift) - 1)) << 32) | static_cast<uint32_t>(r);
+          atomicAdd(&cnt[bin[u]], 1u);
         }
       }
+      blockSync();
+      // 2. exclusive scan of the histogram (up to 4 bins per thread)
+      uint32_t mine[4];
+      uint32_t sum = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int b = tid * 4 + k;
+        mine[k] = b < a.numBins ? cnt[b] : 0;
+        sum += mine[k];
+      }
+      uint32_t incl = sum;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, kWave);
+        if (lane() >= off) {
+          incl += o;
+        }
+      }
+      if (lane() == 63) {
+        waveTotals[wave] = incl;
+      }
+      blockSync();
+      uint32_t run = incl - sum;
+      for (int w = 0; w < wave; ++w) {
+        run += waveTotals[w];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int b = tid * 4 + k;
+        if (b < a.numBins) {
+          start[b] = run;
+          cnt[b] = run;  // placement cursor
+        }
+        run += mine[k];
+      }
+      blockSync();
+      // 3. placement inside LDS
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (bin[u] != 0xffffffffu) {
+          const uint32_t pos = atomicAdd(&cnt[bin[u]], 1u);
+          recs[pos] = rec[u];
+          binOf[pos] = static_cast<uint16_t>(bin[u]);
+        }
+      }
+      blockSync();
+      // 4. runs out: record i of the sorted sub-tile goes behind the bin's earlier records
+      uint32_t total = 0;
+      for (int w = 0; w < 16; ++w) {
+        total += waveTotals[w];
+      }
+      for (uint32_t i = tid; i < total; i += 1024) {
+        const uint32_t b = binOf[i];
+        a.recs[binBase[b] + (i - start[b])] = recs[i];
+      }
+      blockSync();
+      for (int b = tid; b < a.numBins; b += blockDim.x) {
+        binBase[b] += cnt[b] - start[b];
+      }
+      blockSync();
     }
-    blockSync();
   }
 }
 
