@@ -759,3 +759,56 @@ def test_output_pages_respect_preferred_output_batch_bytes(oracle, vx):
         if impl is vx:
             assert max(pages) == 1000 and sum(pages) == len(pairs) and len(pages) > 100
     assert res[vx.__name__] == res[oracle.__name__]
+
+
+@pytest.mark.parametrize("join_type", [abi.JOIN_INNER, abi.JOIN_LEFT, abi.JOIN_RIGHT, abi.JOIN_ANTI])
+def test_join_keys_and_payloads_longer_than_12_bytes(oracle, vx, join_type):
+    """Non-inline StringViews (size > 12) as join keys and as payload: the build side copies them into
+    its HBM arena, the generic hash mode hashes and compares them by content, gathered payload views
+    reach host outputs through a buffer owned by the probe handle. Strings around the inline / prefix
+    boundaries, pairs that differ only past the prefix, nulls, two build drivers, an extra filter on
+    the long payload (=)."""
+    rng = np.random.default_rng(97)
+    lens = [0, 3, 12, 13, 16, 17, 24, 33, 64, 200]
+    words = list(dict.fromkeys((b"%05d/" % i + bytes(rng.integers(97, 123, 250).astype(np.uint8)))[:lens[i % len(lens)]]
+                               for i in range(300)))
+    words += [b"same-prefix-then-differs-A", b"same-prefix-then-differs-B"]
+    nb, npb = 4000, 15000
+    bk = [words[i] for i in rng.integers(0, len(words), nb)]
+    bvalid = rng.random(nb) > 0.05
+    bpay = [words[i] for i in rng.integers(0, len(words), nb)]
+    bpvalid = rng.random(nb) > 0.1
+    bnum = rng.integers(0, 100, nb).astype(np.int64)
+    pk = [words[i] for i in rng.integers(0, len(words), npb)] 
+    pvalid = rng.random(npb) > 0.05
+    ps = [words[i] for i in rng.integers(0, len(words), npb)]
+    res = {}
+    for with_filter in (False, True):
+        for impl in (oracle, vx):
+            half = nb // 2
+            parts = [[abi.HostBatch([abi.HostColumn(abi.VARCHAR, bk[lo:hi], bvalid[lo:hi]),
+                                     abi.HostColumn(abi.VARCHAR, bpay[lo:hi], bpvalid[lo:hi]),
+                                     abi.HostColumn(abi.BIGINT, bnum[lo:hi])])] for lo, hi in ((0, half), (half, nb))]
+            table, _ = _build(impl, parts, [0], [abi.VARCHAR], [1, 2], [abi.VARCHAR, abi.BIGINT], join_type)
+            probe = impl.JoinProbe(table, [0], join_type)
+            if with_filter:
+                probe.set_filter([(("build", 1), abi.CMP_LT, 60)])
+            probe.add_input(abi.HostBatch([abi.HostColumn(abi.VARCHAR, pk, pvalid), abi.HostColumn(abi.VARCHAR, ps)]))
+            pairs, payload = _drain(probe, 1013)
+            _contiguous(pairs)
+            out = [_canon(pairs, payload)]
+            if join_type == abi.JOIN_RIGHT:
+                rows, strs = [], []
+                while True:
+                    r, cols, fin = probe.get_build_side_output(777, [0])
+                    rows += r.tolist()
+                    strs += [v if ok else None for v, ok in zip(cols[0][0], cols[0][1])]
+                    if fin:
+                        break
+                out.append((rows, strs))
+            res[(impl.__name__, with_filter)] = out
+            if impl is vx:
+                assert table.stats().hash_mode == abi.MODE_HASH
+        assert res[(vx.__name__, with_filter)] == res[(oracle.__name__, with_filter)]
+    if join_type == abi.JOIN_INNER:
+        assert any(p[0] is not None and len(p[0]) > 12 for _, p in res[(vx.__name__, False)][0])

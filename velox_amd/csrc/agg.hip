@@ -2020,18 +2020,6 @@ __global__ __launch_bounds__(256) void k_extract(ExtractArgs a) {
   }
 }
 
-// One wave per string: desc = {source pointer, size, offset in 'out'} per string.
-__global__ __launch_bounds__(64) void k_gather_strings(const uint64_t* desc, int64_t n, char* out) {
-  for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
-    const char* src = reinterpret_cast<const char*>(desc[i * 3]);
-    const uint64_t size = desc[i * 3 + 1];
-    char* dst = out + desc[i * 3 + 2];
-    for (uint64_t b = threadIdx.x; b < size; b += 64) {
-      dst[b] = src[b];
-    }
-  }
-}
-
 // ---- GroupingSet::toIntermediate (GroupingSet.cpp:1589-1675) ---------------------------------
 struct ToIntermediateAgg {
   ColView in, mask;
@@ -4027,46 +4015,9 @@ void getOutput(vx355_agg& h, vx355_out_column* cols, int32_t numCols, int32_t ma
     // re-pointed.
     h.hostStrings.clear();
     for (size_t k = 0; k < h.keys.size(); ++k) {
-      if (!isString(h.keys[k].kind) || cols[k].mem != VX355_MEM_HOST) {
-        continue;
+      if (isString(h.keys[k].kind) && cols[k].mem == VX355_MEM_HOST) {
+        fetchLongStrings(static_cast<char*>(cols[k].values), n, h.hostStrings);
       }
-      char* views = static_cast<char*>(cols[k].values);
-      std::vector<std::pair<int32_t, uint32_t>> longRows;  // row, size
-      size_t total = 0;
-      for (int32_t r = 0; r < n; ++r) {
-        uint32_t size;
-        std::memcpy(&size, views + static_cast<size_t>(r) * 16, 4);
-        if (size > 12) {
-          longRows.emplace_back(r, size);
-          total += size;
-        }
-      }
-      if (longRows.empty()) {
-        continue;
-      }
-      h.hostStrings.emplace_back(total);
-      char* dst = h.hostStrings.back().data();
-      // one gather kernel + one copy for the whole page
-      const size_t m = longRows.size();
-      std::vector<uint64_t> desc(m * 3);  // source pointer, size, offset
-      size_t at = 0;
-      for (size_t i = 0; i < m; ++i) {
-        uint64_t src;
-        std::memcpy(&src, views + static_cast<size_t>(longRows[i].first) * 16 + 8, 8);
-        desc[i * 3] = src;
-        desc[i * 3 + 1] = longRows[i].second;
-        desc[i * 3 + 2] = at;
-        char* hostPtr = dst + at;
-        std::memcpy(views + static_cast<size_t>(longRows[i].first) * 16 + 8, &hostPtr, 8);
-        at += longRows[i].second;
-      }
-      DevBuf dDesc, dBlob;
-      uint64_t* devDesc = static_cast<uint64_t*>(dDesc.ensure(desc.size() * 8 + 64));
-      char* devBlob = static_cast<char*>(dBlob.ensure(total + 64));
-      copyIn(devDesc, desc.data(), VX355_MEM_HOST, desc.size() * 8);
-      VX_LAUNCH("k_gather_strings", k_gather_strings, static_cast<int>(std::min<size_t>(m, 65535)), 64, 0, devDesc,
-                static_cast<int64_t>(m), devBlob);
-      copyOut(dst, VX355_MEM_HOST, devBlob, total);
     }
   }
   h.outputCursor += n;

@@ -346,6 +346,11 @@ void copyOut(void* dst, int32_t dstMem, const void* devSrc, size_t bytes);
 void copyOutAsync(void* dst, int32_t dstMem, const void* devSrc, size_t bytes);
 void copyIn(void* devDst, const void* src, int32_t srcMem, size_t bytes);
 
+// Host output column of n 16-byte StringViews whose non-inline entries (size > 12) still hold DEVICE
+// pointers: copies those strings to the host (one gather kernel + one copy) into a buffer appended
+// to 'keep' and re-points the views. The caller keeps 'keep' alive until its next output call.
+void fetchLongStrings(char* hostViews, int32_t n, std::vector<std::vector<char>>& keep);
+
 inline int64_t ceilDiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline uint64_t nextPow2(uint64_t v) {
   uint64_t p = 1;

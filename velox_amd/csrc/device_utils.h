@@ -415,13 +415,37 @@ __device__ inline uint64_t hashFromImage(int32_t kind, uint64_t w0, uint64_t w1)
       for (int k = 0; k < 4; ++k) {
         buf[8 + k] = static_cast<uint8_t>(hi >> (8 * k));
       }
-      return hashBytes(1, buf, static_cast<int32_t>(size <= 12 ? size : 12));
+      if (size > 12) {
+        // non-inline: w1 is the pointer (the build side's copy in its string arena)
+        return hashBytes(1, reinterpret_cast<const uint8_t*>(w1), static_cast<int32_t>(size));
+      }
+      return hashBytes(1, buf, static_cast<int32_t>(size));
     }
     case VX355_TIMESTAMP:
       return hashMix(w0, w1);
     default:
       return 0;
   }
+}
+
+// Equality of two string key images {size | prefix, tail-or-pointer}: inline strings by
+// their words, longer ones by size, prefix and content.
+__device__ inline bool stringImagesEqual(uint64_t a0, uint64_t a1, uint64_t b0, uint64_t b1) {
+  if (a0 != b0) {
+    return false;
+  }
+  const uint32_t size = static_cast<uint32_t>(a0);
+  if (size <= 12) {
+    return a1 == b1;
+  }
+  const uint8_t* pa = reinterpret_cast<const uint8_t*>(a1);
+  const uint8_t* pb = reinterpret_cast<const uint8_t*>(b1);
+  for (uint32_t i = 4; i < size; ++i) {  // the first 4 bytes are the prefix, already equal
+    if (pa[i] != pb[i]) {
+      return false;
+    }
+  }
+  return true;
 }
 
 __device__ inline uint64_t loadAgent(const uint64_t* p) {

@@ -118,7 +118,51 @@ struct AppendArgs {
   // unmatched rows, HashBuild.cpp:475-494) but never enter the table:
   const uint64_t* keyValidWords;  // bit per input row: all keys non-null
   uint8_t* keyNullOut;            // per build row
+  // strings longer than 12 bytes (keys and payloads) are copied into the build side's arena
+  char* arenaBase;
+  unsigned long long* arenaCursor;
+  uint64_t arenaCap;
 };
+
+// Copies a non-inline string into the arena; returns the new pointer (0: arena exhausted).
+__device__ inline uint64_t arenaCopy(const AppendArgs& a, uint64_t srcPtr, uint32_t size) {
+  const uint32_t padded = (size + 7) & ~7u;
+  const unsigned long long at = atomicAdd(a.arenaCursor, static_cast<unsigned long long>(padded));
+  if (!a.arenaBase || at + padded > a.arenaCap) {
+    return 0;
+  }
+  const uint8_t* src = reinterpret_cast<const uint8_t*>(srcPtr);
+  uint8_t* dst = reinterpret_cast<uint8_t*>(a.arenaBase + at);
+  for (uint32_t i = 0; i < size; ++i) {
+    dst[i] = src[i];
+  }
+  return reinterpret_cast<uint64_t>(dst);
+}
+
+// Arena bytes the selected rows of a batch need.
+__global__ __launch_bounds__(256) void k_build_long_bytes(AppendArgs a, unsigned long long* total) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  unsigned long long mine = 0;
+  for (int64_t p = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; p < a.count; p += stride) {
+    const int64_t row = a.rows ? a.rows[p] : p;
+    for (int k = 0; k < a.numKeys + a.numDeps; ++k) {
+      const ColView& c = k < a.numKeys ? a.keys[k] : a.deps[k - a.numKeys];
+      if ((c.kind == VX355_VARCHAR || c.kind == VX355_VARBINARY) && !colIsNull(c, row)) {
+        const uint32_t size = static_cast<const uint4*>(c.values)[colIndex(c, row)].x;
+        if (size > 12) {
+          mine += (size + 7) & ~7u;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    mine += shfl64(mine, lane() ^ off);
+  }
+  if (lane() == 0 && mine) {
+    atomicAdd(total, mine);
+  }
+}
 
 __global__ __launch_bounds__(256) void k_build_append(AppendArgs a) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
@@ -148,7 +192,10 @@ __global__ __launch_bounds__(256) void k_build_append(AppendArgs a) {
       bool inlineOk = true;
       keyImage(c, i, &w0, &w1, &inlineOk);
       if (!inlineOk) {
-        a.counters->longString = 1;
+        w1 = arenaCopy(a, w1, static_cast<uint32_t>(w0));
+        if (w1 == 0) {
+          a.counters->longString = 1;  // arena exhausted (host sized it from k_build_long_bytes)
+        }
       }
       a.keyOut[k][(a.base + p) * a.keyWords[k]] = w0;
       if (a.keyWords[k] == 2) {
@@ -197,7 +244,12 @@ __global__ __launch_bounds__(256) void k_build_append(AppendArgs a) {
       } else {  // 16: StringView or Timestamp
         uint4 raw = valid ? static_cast<const uint4*>(c.values)[i] : make_uint4(0, 0, 0, 0);
         if (valid && (c.kind == VX355_VARCHAR || c.kind == VX355_VARBINARY) && raw.x > 12) {
-          a.counters->longString = 1;
+          const uint64_t p2 = arenaCopy(a, (static_cast<uint64_t>(raw.w) << 32) | raw.z, raw.x);
+          if (p2 == 0) {
+            a.counters->longString = 1;
+          }
+          raw.z = static_cast<uint32_t>(p2);
+          raw.w = static_cast<uint32_t>(p2 >> 32);
         }
         *reinterpret_cast<uint4*>(dst) = raw;
       }
@@ -267,6 +319,13 @@ __device__ inline uint64_t buildKey(const InsertArgs& a, int64_t row) {
 __device__ inline bool storedKeysEqual(const InsertArgs& a, int64_t r1, int64_t r2) {
   for (int k = 0; k < a.numKeys; ++k) {
     const int w = a.keyWords[k];
+    if (a.keyIsString[k]) {
+      if (!stringImagesEqual(a.keyStore[k][r1 * 2], a.keyStore[k][r1 * 2 + 1], a.keyStore[k][r2 * 2],
+                             a.keyStore[k][r2 * 2 + 1])) {
+        return false;
+      }
+      continue;
+    }
     if (a.keyStore[k][r1 * w] != a.keyStore[k][r2 * w]) {
       return false;
     }
@@ -609,10 +668,7 @@ __device__ inline uint32_t lookupGeneric(const ProbeArgs& a, int64_t row) {
       }
       const int64_t i = colIndex(c, row);
       bool inlineOk = true;
-      keyImage(c, i, &w0[k], &w1[k], &inlineOk);
-      if (!inlineOk) {
-        return kNoRow32;  // the build side holds inline strings only
-      }
+      keyImage(c, i, &w0[k], &w1[k], &inlineOk);  // non-inline strings: {size | prefix, pointer}
       const uint64_t hv = hashValueAt(c, i);
       hash = k == 0 ? hv : hashMix(hash, hv);
     }
@@ -631,9 +687,13 @@ __device__ inline uint32_t lookupGeneric(const ProbeArgs& a, int64_t row) {
 #pragma unroll
       for (int k = 0; k < kMaxKeys; ++k) {
         if (equal && k < a.numKeys) {
-          equal = a.keyStore[k][rep * a.keyWords[k]] == w0[k];
-          if (equal && a.keyWords[k] == 2) {
-            equal = a.keyStore[k][rep * 2 + 1] == w1[k];
+          if (a.keys[k].kind == VX355_VARCHAR || a.keys[k].kind == VX355_VARBINARY) {
+            equal = stringImagesEqual(w0[k], w1[k], a.keyStore[k][rep * 2], a.keyStore[k][rep * 2 + 1]);
+          } else {
+            equal = a.keyStore[k][rep * a.keyWords[k]] == w0[k];
+            if (equal && a.keyWords[k] == 2) {
+              equal = a.keyStore[k][rep * 2 + 1] == w1[k];
+            }
           }
         }
       }
@@ -941,13 +1001,13 @@ __global__ __launch_bounds__(256) void k_join_probe(ProbeArgs args) {
 // random order: 6 ms per 323 M probes); even an L2-resident structure stops at ~150 G/s
 // (address processing in the CU's texture path). LDS does not have that limit. So when the
 // probe keys of a batch are scattered (k_key_locality) and the join lists matches only, the
-// probe side is range-partitioned: {key offset, probe row} records go to bin = key >> 19
+// probe side is range-partitioned: {key offset, probe row} records go to bin = key >> 20
 // (one LDS-histogram pass, one scatter pass, as the radix aggregation does), then one
-// workgroup per bin loads its 64 KB slice of the bitmap into LDS and streams its records
+// workgroup per bin loads its 128 KB slice of the bitmap into LDS and streams its records
 // against it. Hits leave as {probe row, build row} words and are put back into probe-row
 // order by one radix sort of the HITS (few: the path is taken at hit rates <= 12.5 %).
-constexpr int kPartShift = 19;                       // keys per bin = bits of the bitmap slice
-constexpr int kPartSliceWords = 1 << (kPartShift - 5);  // u32 words of one slice: 64 KB
+constexpr int kPartShift = 20;                       // keys per bin = bits of the bitmap slice
+constexpr int kPartSliceWords = 1 << (kPartShift - 5);  // u32 words of one slice: 128 KB
 constexpr int kPartMaxBins = 4096;
 constexpr int kPartTileRows = 32768;
 
@@ -1116,7 +1176,7 @@ struct PartProbeArgs {
   unsigned long long* numPairs;
 };
 
-constexpr int kPartWaveBuf = 256;  // hits a wave collects in LDS before it claims output space
+constexpr int kPartWaveBuf = 128;  // hits a wave collects in LDS before it claims output space
 
 // Writes the wave's collected hits behind one claim on the global cursor (a single HBM
 // address takes < 100 M atomics/s: one atomic per HIT would cost more than the probe).
@@ -1355,7 +1415,11 @@ __device__ inline bool evalJoinFilter(const JoinFilterArgs& f, int64_t probeRow,
     bool ok;
     if (l.cls == 2 || r.cls == 2) {
       // inline strings: size, prefix and the 8 bytes behind it (unused bytes are zero)
-      const bool eq = l.cls == r.cls && l.s.x == r.s.x && l.s.y == r.s.y && l.s.z == r.s.z && l.s.w == r.s.w;
+      const bool eq = l.cls == r.cls &&
+          stringImagesEqual(static_cast<uint64_t>(l.s.x) | (static_cast<uint64_t>(l.s.y) << 32),
+                            static_cast<uint64_t>(l.s.z) | (static_cast<uint64_t>(l.s.w) << 32),
+                            static_cast<uint64_t>(r.s.x) | (static_cast<uint64_t>(r.s.y) << 32),
+                            static_cast<uint64_t>(r.s.z) | (static_cast<uint64_t>(r.s.w) << 32));
       ok = term.cmp == VX355_CMP_EQ ? eq : !eq;
     } else if (l.cls == 0 && r.cls == 0) {
       ok = compareValues<int64_t>(term.cmp, l.i, r.i);
@@ -1811,6 +1875,11 @@ struct vx355_join_build {
   DevBuf keyNull;  // right / full joins: 1 byte per row, set for rows with a null key
   std::vector<int64_t> obsMin, obsMax;
   DevBuf countersBuf, scratch, validWords, rowList;
+  // arena of key / payload strings longer than 12 bytes (blocks never move: stored views point into them)
+  std::vector<DevBuf> strBlocks;
+  DevBuf strCursor;
+  uint64_t strCap = 0, strUsed = 0;
+  bool hasStringCols = false;
   HostCoalescer coalescer;  // small host batches -> large appends
 };
 
@@ -1836,6 +1905,7 @@ struct vx355_join_table {
   bool hasNullKeys = false;
   DevBuf probed;   // right / full / right semi / right anti joins: 1 byte per build row
   DevBuf remaining;  // counting joins: occurrences left per distinct key, at the chain's head row
+  std::vector<DevBuf> strBlocks;  // the builds' string arenas
   bool keepsNullRows = false;
   // dynamic filters: ascending distinct values per key, computed on first request
   std::vector<DevBuf> distinctVals;
@@ -1855,6 +1925,7 @@ struct vx355_join_probe {
   int64_t outputBatchBytes = 0;  // preferred_output_batch_bytes (0 = rows only)
   int32_t partitionMode = -1;  // VX355_JOIN_PARTITION: -1 adaptive, 0 never, 1 whenever eligible
   DeviceBatch batch;                       // the batch being probed: the filter reads it at output time
+  std::vector<std::vector<char>> hostStrings;  // long payload strings of the last page handed to a host caller
   std::vector<vx355_join_filter_term> filter;
   std::vector<int32_t> usedCols;           // key columns + the filter's probe columns
   DevBuf hitBits, hitRows, hitWords, hitSorted, sortTmp;  // counting joins
@@ -1975,6 +2046,30 @@ void buildAddInput(vx355_join_build& h, const vx355_batch* batch) {
     aa.count = selected;
     aa.base = h.numRows;
     aa.counters = ctr;
+    if (h.hasStringCols) {
+      auto& rt = Runtime::get();
+      unsigned long long* cursor = static_cast<unsigned long long*>(h.strCursor.ensure(64));
+      HIP_OK(hipMemsetAsync(cursor + 1, 0, 8, rt.stream));
+      VX_LAUNCH("k_build_long_bytes", k_build_long_bytes, streamGrid(selected, 256), 256, 0, aa, cursor + 1);
+      unsigned long long need = 0;
+      copyOut(&need, VX355_MEM_HOST, cursor + 1, 8);
+      if (need > 0) {
+        if (h.strBlocks.empty() || h.strUsed + need > h.strCap) {
+          h.strBlocks.emplace_back();
+          h.strCap = std::max<uint64_t>(need, 16ULL << 20);
+          h.strBlocks.back().ensure(static_cast<size_t>(h.strCap) + 64);
+          h.strUsed = 0;
+          HIP_OK(hipMemsetAsync(cursor, 0, 8, rt.stream));
+        }
+        h.strUsed += need;
+        aa.arenaBase = h.strBlocks.back().as<char>();
+        aa.arenaCursor = cursor;
+        aa.arenaCap = h.strCap;
+      }
+    }
+    if (!aa.arenaCursor) {
+      aa.arenaCursor = static_cast<unsigned long long*>(h.strCursor.ensure(64));  // never dereferenced usefully
+    }
     if (keepNulls) {
       aa.keyValidWords = anyKeyNulls ? va.validWords : nullptr;
       aa.keyNullOut = h.keyNull.as<uint8_t>();
@@ -1986,7 +2081,7 @@ void buildAddInput(vx355_join_build& h, const vx355_batch* batch) {
     h.unmappable = true;  // finish() picks the generic hash mode
   }
   if (c.longString) {
-    VX_THROW(VX355_EUNSUPPORTED, "non-inline string (> 12 bytes) in a build-side key or payload column");
+    VX_THROW(VX355_EINTERNAL, "build-side string arena exhausted");
   }
   if (c.nullKeyRows) {
     h.hasNullKeys = true;
@@ -2174,6 +2269,16 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
     t->probed.ensure(static_cast<size_t>(std::max<int64_t>(1, h.numRows)) + 64);
     HIP_OK(hipMemsetAsync(t->probed.ptr(), 0, static_cast<size_t>(std::max<int64_t>(1, h.numRows)), rt.stream));
     rt.sync();
+  }
+  for (auto& b : h.strBlocks) {
+    t->strBlocks.push_back(std::move(b));
+  }
+  h.strBlocks.clear();
+  for (int32_t i = 0; i < numOthers; ++i) {
+    for (auto& b : others[i]->strBlocks) {
+      t->strBlocks.push_back(std::move(b));
+    }
+    others[i]->strBlocks.clear();
   }
   t->depVals = std::move(h.depVals);
   t->depValid = std::move(h.depValid);
@@ -2541,11 +2646,24 @@ void gatherBuildCols(vx355_join_probe& p, const vx355_join_table& t, const int32
       ga.outNulls[c] = colHost ? reinterpret_cast<uint64_t*>(scratch + nullOff[c]) : buildCols[c].nulls;
     }
     VX_LAUNCH("k_gather_deps", k_gather_deps, static_cast<int>(ceilDiv(n, 256)), 256, 0, ga);
+    bool longStrings = false;
     for (int32_t c = 0; c < numBuildCols; ++c) {
       if (buildCols[c].mem == VX355_MEM_HOST) {
         copyOutAsync(buildCols[c].values, VX355_MEM_HOST, scratch + valOff[c], valBytes[c]);
         if (buildCols[c].nulls) {
           copyOutAsync(buildCols[c].nulls, VX355_MEM_HOST, scratch + nullOff[c], words * 8);
+        }
+        longStrings = longStrings || (isString(buildCols[c].type_kind) && !t.strBlocks.empty());
+      }
+    }
+    p.hostStrings.clear();
+    if (longStrings) {
+      // payload strings longer than 12 bytes: the views hold pointers into the table's HBM arena; a
+      // host caller gets them re-pointed into a buffer this handle keeps until its next output call
+      Runtime::get().sync();
+      for (int32_t c = 0; c < numBuildCols; ++c) {
+        if (buildCols[c].mem == VX355_MEM_HOST && isString(buildCols[c].type_kind)) {
+          fetchLongStrings(static_cast<char*>(buildCols[c].values), n, p.hostStrings);
         }
       }
     }
@@ -2875,6 +2993,12 @@ int vx355_join_build_create(const vx355_join_build_spec* spec, vx355_join_build*
   h->obsMin.assign(h->keyCols.size(), INT64_MAX);
   h->obsMax.assign(h->keyCols.size(), INT64_MIN);
   h->ctx = Runtime::createContext();
+  for (int32_t kind : h->keyKinds) {
+    h->hasStringCols = h->hasStringCols || isString(kind);
+  }
+  for (int32_t kind : h->depKinds) {
+    h->hasStringCols = h->hasStringCols || isString(kind);
+  }
   for (int32_t kind : h->keyKinds) {
     // No value ids for these types (VectorHasher.h:338-357): generic mode whatever the
     // data, also for an empty build side.
