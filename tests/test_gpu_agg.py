@@ -560,6 +560,42 @@ def test_plan_shape_outside_the_table_is_instantiated_with_hiprtc(oracle, vx, ji
         assert op.stats().reserved == 0 and "k_agg_lds" in names
 
 
+def test_async_instantiation_does_not_stall_the_first_batches(oracle, vx, monkeypatch):
+    """VX355_JIT=async: the first batches of a plan shape outside the table run
+    on the interpreting kernel while hiprtc works on a helper thread; once the
+    code object is there later batches take it. Results do not depend on which
+    kernel consumed which batch."""
+    import time
+    monkeypatch.setenv("VX355_JIT", "async")
+    rng = np.random.default_rng(2025)
+    n = 1 << 18
+    k1 = rng.integers(0, 7, n).astype(np.int64)
+    k2 = rng.integers(-3, 3, n).astype(np.int32)
+    a, b = _dyadic(rng, n), _dyadic(rng, n)
+    hb = batch_of([k1, k2, a, b])
+    aggs = [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_SUM, 3, abi.DOUBLE), (abi.AGG_AVG, 2, abi.DOUBLE),
+            (abi.AGG_AVG, 3, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    op = vx.Aggregation([0, 1], [abi.BIGINT, abi.INTEGER], aggs)
+    db = vx.to_device(hb)
+    t0 = time.time()
+    op.add_input(db)
+    first = time.time() - t0
+    batches = 1
+    deadline = time.time() + 60
+    while op.stats().reserved == 0 and time.time() < deadline:
+        time.sleep(0.05)
+        op.add_input(db)
+        batches += 1
+    assert op.stats().reserved > 0, "the instantiation never arrived"
+    assert first < 0.5, f"first add_input took {first:.2f} s"
+    op.add_input(db)
+    batches += 1
+    op.no_more_input()
+    got = vx.collect_output(op, 100)
+    exp, _ = run_agg(oracle, [hb] * batches, [0, 1], [abi.BIGINT, abi.INTEGER], aggs)
+    assert_columns_equal(got, exp, op.kinds, what="async jit")
+
+
 def test_dictionary_wrapped_device_inputs_take_the_specialised_kernel(oracle, vx):
     """The unfused Velox pipeline: FilterProject hands HashAggregation columns
     wrapped in ONE shared index vector plus flat computed columns, all in HBM.

@@ -34,7 +34,9 @@
 #include "expr_device.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <future>
 #include <utility>
 #include <cstdio>
 #include <cstdlib>
@@ -2227,6 +2229,7 @@ struct vx355_agg {
   bool disableFast = false;
   int64_t jitLaunches = 0;
   bool jitEnabled = true;
+  bool jitAsync = false;   // VX355_JIT=async
   bool exactSums = true;
   bool sumGridsChosen = false;
   bool logShapes = false;
@@ -2794,6 +2797,7 @@ struct JitKernel {
 struct JitState {
   std::mutex mutex;
   std::map<std::string, JitKernel> kernels;
+  std::map<std::string, std::shared_future<std::vector<char>>> pending;  // VX355_JIT=async: code objects on their way
   bool disabled = false;
   std::string csrcDir;
   std::string clangInclude;
@@ -2830,7 +2834,44 @@ bool jitPrepare(JitState& st) {
   return true;
 }
 
-hipFunction_t jitFastKernel(const FastSignature& sig, int unroll, bool log) {
+// hiprtc half of an instantiation: CPU only, may run on any thread. Empty result = failure.
+std::vector<char> jitCompile(const std::string& src, const std::string& clangInclude, std::string* buildLog) {
+  hiprtcProgram prog = nullptr;
+  bool ok = hiprtcCreateProgram(&prog, src.c_str(), "vx355_agg_fast_jit.hip", 0, nullptr, nullptr) == HIPRTC_SUCCESS;
+  if (ok) {
+    const std::string inc1 = "-I/opt/rocm/include";
+    const std::string inc2 = "-I" + clangInclude;
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", inc1.c_str(),
+                          inc2.c_str()};
+    ok = hiprtcCompileProgram(prog, 6, opts) == HIPRTC_SUCCESS;
+    size_t logSize = 0;
+    if (hiprtcGetProgramLogSize(prog, &logSize) == HIPRTC_SUCCESS && logSize > 1) {
+      buildLog->resize(logSize);
+      hiprtcGetProgramLog(prog, &(*buildLog)[0]);
+    }
+  }
+  std::vector<char> code;
+  if (ok) {
+    size_t size = 0;
+    ok = hiprtcGetCodeSize(prog, &size) == HIPRTC_SUCCESS && size > 0;
+    if (ok) {
+      code.resize(size);
+      ok = hiprtcGetCode(prog, code.data()) == HIPRTC_SUCCESS;
+    }
+  }
+  if (prog) {
+    hiprtcDestroyProgram(&prog);
+  }
+  if (!ok) {
+    code.clear();
+  }
+  return code;
+}
+
+// async: the compilation runs on a helper thread and this call returns nullptr until the code
+// object is there (the caller launches the interpreting kernel meanwhile): a new plan shape does
+// not stall the Driver thread for the ~0.8 s hiprtc needs (VX355_JIT=async).
+hipFunction_t jitFastKernel(const FastSignature& sig, int unroll, bool log, bool async) {
   JitState& st = jitState();
   std::lock_guard<std::mutex> lock(st.mutex);  // operators on several Driver threads share the cache
   if (st.disabled || !jitPrepare(st)) {
@@ -2850,34 +2891,26 @@ hipFunction_t jitFastKernel(const FastSignature& sig, int unroll, bool log) {
       "using S = vx::FastShape<" + std::string(key) + ">;\n"
       "extern \"C\" __global__ __launch_bounds__(512, 4) void k_agg_fast_jit(vx::FastArgs a) {\n"
       "  vx::aggFastBody<S>(a);\n}\n";
-  JitKernel k;
-  hiprtcProgram prog = nullptr;
-  bool ok = hiprtcCreateProgram(&prog, src.c_str(), "vx355_agg_fast_jit.hip", 0, nullptr, nullptr) == HIPRTC_SUCCESS;
-  std::string buildLog;
-  if (ok) {
-    const std::string inc1 = "-I/opt/rocm/include";
-    const std::string inc2 = "-I" + st.clangInclude;
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", inc1.c_str(),
-                          inc2.c_str()};
-    ok = hiprtcCompileProgram(prog, 6, opts) == HIPRTC_SUCCESS;
-    size_t logSize = 0;
-    if (hiprtcGetProgramLogSize(prog, &logSize) == HIPRTC_SUCCESS && logSize > 1) {
-      buildLog.resize(logSize);
-      hiprtcGetProgramLog(prog, &buildLog[0]);
-    }
-  }
   std::vector<char> code;
-  if (ok) {
-    size_t size = 0;
-    ok = hiprtcGetCodeSize(prog, &size) == HIPRTC_SUCCESS && size > 0;
-    if (ok) {
-      code.resize(size);
-      ok = hiprtcGetCode(prog, code.data()) == HIPRTC_SUCCESS;
+  std::string buildLog;
+  auto pend = st.pending.find(key);
+  if (pend != st.pending.end()) {
+    if (pend->second.wait_for(std::chrono::seconds(0)) != std::future_status::ready) {
+      return nullptr;  // still compiling
     }
+    code = pend->second.get();
+  } else if (async) {
+    const std::string inc = st.clangInclude;
+    st.pending[key] = std::async(std::launch::async, [src, inc]() {
+                        std::string ignored;
+                        return jitCompile(src, inc, &ignored);
+                      }).share();
+    return nullptr;
+  } else {
+    code = jitCompile(src, st.clangInclude, &buildLog);
   }
-  if (prog) {
-    hiprtcDestroyProgram(&prog);
-  }
+  JitKernel k;
+  bool ok = !code.empty();
   if (ok) {
     ok = hipModuleLoadData(&k.module, code.data()) == hipSuccess &&
         hipModuleGetFunction(&k.fn, k.module, "k_agg_fast_jit") == hipSuccess;
@@ -3267,7 +3300,7 @@ void launchChunk(vx355_agg& h, AggArgs& a) {
         e->launch(fa, grid, ldsBytes);
         return;
       }
-      if (hipFunction_t fn = h.jitEnabled ? jitFastKernel(sig, h.fastUnroll, h.logShapes) : nullptr) {
+      if (hipFunction_t fn = h.jitEnabled ? jitFastKernel(sig, h.fastUnroll, h.logShapes, h.jitAsync) : nullptr) {
         const int blocksPerCu =
             std::max<int>(1, std::min<int>(4, static_cast<int>((150 * 1024) / ldsBytes)));
         const int64_t minRowsPerBlock = std::max<int64_t>(512 * h.fastUnroll, 4LL * plan.S * plan.A);
@@ -4159,6 +4192,7 @@ int vx355_agg_create(const vx355_agg_spec* spec, vx355_agg** out) {
   }
   if (const char* e = std::getenv("VX355_JIT")) {
     h->jitEnabled = e[0] != '0';
+    h->jitAsync = std::string(e) == "async";
   }
   if (const char* e = std::getenv("VX355_AGG_COALESCE_ROWS")) {
     h->coalescer.thresholdRows = std::strtoll(e, nullptr, 10);
