@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VX355_ABI_VERSION 2
+#define VX355_ABI_VERSION 3
 
 typedef enum vx355_status {
   VX355_OK = 0,
@@ -397,7 +397,20 @@ typedef struct vx355_agg_fn {
                          for intermediate input: sum(REAL) returns REAL) */
   int32_t mask_col;   /* BOOLEAN column, FILTER (WHERE m); -1 = none
                          (exec/AggregationMasks.h) */
+  int32_t flags;      /* vx355_agg_fn_flags */
 } vx355_agg_fn;
+
+typedef enum vx355_agg_fn_flags {
+  /* agg(DISTINCT x) (core::AggregationNode::Aggregate::distinct, exec/DistinctAggregations.cpp):
+   * the function sees each distinct input value of a group once, nulls included (and then
+   * ignores them as usual); the mask applies before the de-duplication
+   * (GroupingSet.cpp:317-332). SINGLE step only, like the reference ("Partial aggregations
+   * over distinct inputs are not supported", GroupingSet.cpp:117-121). For min / max the flag
+   * changes nothing. ORDER BY inside an aggregate needs no flag: sum / count / min / max / avg
+   * are registered orderSensitive = false and the reference drops their sorting keys itself
+   * (exec/AggregateInfo.cpp:124-138), so the shim passes such aggregates without the keys. */
+  VX355_AGG_FN_DISTINCT = 1
+} vx355_agg_fn_flags;
 
 typedef struct vx355_agg_spec {
   int32_t num_keys; /* 0 = global aggregation: always one output row */

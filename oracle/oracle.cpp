@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <map>
+#include <set>
 #include <string>
 #include <cstdio>
 
@@ -149,6 +150,10 @@ class Aggregation {
     std::vector<int32_t> bytes;
     for (auto& f : aggs_) {
       bytes.push_back(accBytes(f));
+      if ((f.flags & VX355_AGG_FN_DISTINCT) && step_ != VX355_STEP_SINGLE) {
+        // GroupingSet.cpp:117-121 (isPartial_), and no plan feeds intermediate input to one
+        throw UserError("Partial aggregations over distinct inputs are not supported");
+      }
     }
     table_ = std::make_unique<HashTable>(keyKinds_, bytes, std::vector<int32_t>{}, false, false,
                                          ignoreNullKeys_);
@@ -220,6 +225,7 @@ class Aggregation {
     if (numCols != static_cast<int32_t>(kinds.size())) {
       throw std::runtime_error("getOutput: wrong number of output columns");
     }
+    applyDistinctSets();
     const auto& rows = table_->rows()->rows();
     int64_t total = static_cast<int64_t>(rows.size());
     int32_t n = static_cast<int32_t>(std::min<int64_t>(maxRows, total - outputCursor_));
@@ -251,6 +257,49 @@ class Aggregation {
  private:
   char* acc(char* group, size_t i) const { return group + table_->rows()->accOffset(i); }
   char& accNull(char* group, size_t i) const { return group[table_->rows()->accNullOffset(i)]; }
+
+  static bool usesDistinctSet(const vx355_agg_fn& f) {
+    // min / max over the set of values == over the values; they go the plain way here.
+    return (f.flags & VX355_AGG_FN_DISTINCT) &&
+        (f.kind == VX355_AGG_SUM || f.kind == VX355_AGG_COUNT || f.kind == VX355_AGG_AVG);
+  }
+
+  // TypedDistinctAggregations::extractValues (DistinctAggregations.cpp:240-285): each group's
+  // distinct values go through addSingleGroupRawInput in the set's insertion order.
+  void applyDistinctSets() {
+    for (auto& entry : distinct_) {
+      char* g = entry.first.first;
+      const size_t i = entry.first.second;
+      const auto& f = aggs_[i];
+      char* a = acc(g, i);
+      for (const SetValue& v : entry.second.ordered) {
+        if (v.isNull) {
+          continue;
+        }
+        const bool isInt = isIntKind(f.input_type);
+        switch (f.kind) {
+          case VX355_AGG_COUNT:
+            ++*reinterpret_cast<int64_t*>(a);
+            break;
+          case VX355_AGG_SUM:
+            accNull(g, i) = 0;
+            if (isInt) {
+              auto* s = reinterpret_cast<int64_t*>(a);
+              *s = checkedPlus(*s, v.i);
+            } else {
+              *reinterpret_cast<double*>(a) += v.d;
+            }
+            break;
+          case VX355_AGG_AVG:
+            accNull(g, i) = 0;
+            *reinterpret_cast<double*>(a) += isInt ? static_cast<double>(v.i) : v.d;
+            *reinterpret_cast<int64_t*>(a + 8) = checkedPlus(*reinterpret_cast<int64_t*>(a + 8), 1);
+            break;
+        }
+      }
+    }
+    distinct_.clear();
+  }
 
   // initializeNewGroups: sum/min/max/avg start null (SumAggregateBase.h:144-151,
   // MinMaxAggregateBase.cpp:191-201/:293-303, AverageAggregateBase.h), count
@@ -330,6 +379,34 @@ class Aggregation {
       }
       char* g = groups[r];
       char* a = acc(g, i);
+      if (usesDistinctSet(f)) {
+        // TypedDistinctAggregations::addInput (DistinctAggregations.cpp:213-227):
+        // SetAccumulator::addValue keeps each value, null included, once, in arrival order.
+        DistinctSet& set = distinct_[{g, i}];
+        SetValue v;
+        v.isNull = in->isNull(r);
+        if (!v.isNull) {
+          if (intSum) {
+            v.i = in->int64At(r);
+            v.image = static_cast<uint64_t>(v.i);
+          } else {
+            v.d = in->doubleAt(r);
+            // NaNAwareEquals / NaNAwareHash (type/FloatingPointUtil.h): every NaN is one value,
+            // and 0.0 == -0.0
+            if (std::isnan(v.d)) {
+              v.image = 0x7ff8000000000000ULL;
+            } else if (v.d == 0.0) {
+              v.image = 0;
+            } else {
+              std::memcpy(&v.image, &v.d, 8);
+            }
+          }
+        }
+        if (set.seen.insert({v.isNull, v.isNull ? 0 : v.image}).second) {
+          set.ordered.push_back(v);
+        }
+        continue;
+      }
       switch (f.kind) {
         case VX355_AGG_COUNT_STAR:
           if (raw) {
@@ -468,6 +545,18 @@ class Aggregation {
   bool ignoreNullKeys_;
   std::vector<int32_t> keyCols_, keyKinds_;
   std::vector<vx355_agg_fn> aggs_;
+  // aggregate::prestosql::SetAccumulator<T> per (group, DISTINCT aggregate)
+  struct SetValue {
+    bool isNull = false;
+    int64_t i = 0;
+    double d = 0;
+    uint64_t image = 0;
+  };
+  struct DistinctSet {
+    std::set<std::pair<bool, uint64_t>> seen;
+    std::vector<SetValue> ordered;
+  };
+  std::map<std::pair<char*, size_t>, DistinctSet> distinct_;
   std::unique_ptr<HashTable> table_;
   char* globalRow_ = nullptr;
   bool noMoreInput_ = false;

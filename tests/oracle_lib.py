@@ -254,7 +254,7 @@ def partition(hashes, kind, num_partitions=0, bit_begin=0, bit_end=0):
 
 
 def make_agg_spec(key_cols, key_types, aggs, step, ignore_null_keys=False, flags=0):
-    """aggs: list of (kind, input_col, input_type[, mask_col[, input_col2]])."""
+    """aggs: list of (kind, input_col, input_type[, mask_col[, input_col2[, flags]]])."""
     keep = {}
     keep["kc"] = abi.i32_array(key_cols)
     keep["kt"] = abi.i32_array(key_types)
@@ -263,7 +263,8 @@ def make_agg_spec(key_cols, key_types, aggs, step, ignore_null_keys=False, flags
         kind, col, typ = a[0], a[1], a[2]
         mask = a[3] if len(a) > 3 else -1
         col2 = a[4] if len(a) > 4 else -1
-        fns[i] = abi.AggFn(kind, col, col2, typ, mask)
+        fn_flags = a[5] if len(a) > 5 else 0
+        fns[i] = abi.AggFn(kind, col, col2, typ, mask, fn_flags)
     keep["fns"] = fns
     spec = abi.AggSpec(len(key_cols), keep["kc"], keep["kt"], len(aggs), fns, step,
                        1 if ignore_null_keys else 0, flags, 0)

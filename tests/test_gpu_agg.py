@@ -941,3 +941,83 @@ def test_unordered_output_flag_skips_the_first_seen_sort(oracle, vx, monkeypatch
     go, eo = np.argsort(got[0][0], kind="stable"), np.argsort(exp[0][0], kind="stable")
     for c in range(3):
         assert (np.asarray(got[c][0])[go] == np.asarray(exp[c][0])[eo]).all()
+
+
+def _distinct_inputs(rng, n, key_shape):
+    """Grouping keys of one of the table modes + a few argument / mask columns."""
+    if key_shape == "array":
+        keys, kinds = [rng.integers(0, 200, n).astype(np.int64)], [abi.BIGINT]
+    elif key_shape == "normalized":
+        keys = [(rng.integers(0, 40, n) * 1000003).astype(np.int64), rng.integers(-5, 5, n).astype(np.int32)]
+        kinds = [abi.BIGINT, abi.INTEGER]
+    elif key_shape == "generic":
+        words = [b"alpha", b"a string that does not fit inline", b"", b"beta-beta-beta", b"z"]
+        keys = [[words[i] for i in rng.integers(0, len(words), n)], rng.integers(0, 9, n).astype(np.float64) / 2]
+        kinds = [abi.VARCHAR, abi.DOUBLE]
+    else:
+        keys, kinds = [], []
+    x = rng.integers(-30, 30, n).astype(np.int64)
+    d = rng.integers(0, 64, n).astype(np.float64) / 8.0  # dyadic: exact whatever the order
+    r = (rng.integers(0, 32, n) / 4.0).astype(np.float32)
+    m = rng.random(n) > 0.4
+    return keys, kinds, x, d, r, m
+
+
+@pytest.mark.parametrize("key_shape", ["array", "normalized", "generic", "global"])
+@pytest.mark.parametrize("ignore_null_keys", [False, True])
+def test_distinct_aggregates_next_to_plain_ones(oracle, vx, key_shape, ignore_null_keys):
+    """sum / count / avg (DISTINCT x) with null arguments, null keys, a mask and plain
+    aggregates in the same operator (exec/DistinctAggregations.cpp,
+    GroupingSet.cpp:317-332), in every table mode, several batches, small pages."""
+    rng = np.random.default_rng(77 + len(key_shape))
+    n = 60000
+    keys, kinds, x, d, r, m = _distinct_inputs(rng, n, key_shape)
+    nk = len(keys)
+    D = abi.AGG_FN_DISTINCT
+    xv, dv, mv = rng.random(n) > 0.1, rng.random(n) > 0.1, rng.random(n) > 0.05
+    kv = [rng.random(n) > 0.03 for _ in keys]
+
+    def piece(lo, hi):
+        cols = [abi.HostColumn(kinds[j], keys[j][lo:hi], valid=kv[j][lo:hi]) for j in range(nk)]
+        cols += [abi.HostColumn(abi.BIGINT, x[lo:hi], valid=xv[lo:hi]), abi.HostColumn(abi.DOUBLE, d[lo:hi], valid=dv[lo:hi]),
+                 abi.HostColumn(abi.REAL, r[lo:hi]), abi.HostColumn(abi.BOOLEAN, m[lo:hi], valid=mv[lo:hi])]
+        return abi.HostBatch(cols)
+
+    batches = [piece(i, min(n, i + 13000)) for i in range(0, n, 13000)]
+    X, Dd, R, M = nk, nk + 1, nk + 2, nk + 3
+    aggs = [(abi.AGG_SUM, X, abi.BIGINT, -1, -1, D), (abi.AGG_COUNT, X, abi.BIGINT, M, -1, D),
+            (abi.AGG_SUM, X, abi.BIGINT), (abi.AGG_AVG, Dd, abi.DOUBLE, -1, -1, D),
+            (abi.AGG_SUM, Dd, abi.DOUBLE, M, -1, D), (abi.AGG_COUNT_STAR, -1, abi.BIGINT),
+            (abi.AGG_SUM, R, abi.REAL, -1, -1, D), (abi.AGG_MAX, X, abi.BIGINT, -1, -1, D),
+            (abi.AGG_AVG, Dd, abi.DOUBLE)]
+    kw = dict(ignore_null_keys=ignore_null_keys) if nk else {}
+    exp, eop = run_agg(oracle, batches, list(range(nk)), kinds, aggs, max_rows=97, **kw)
+    got, gop = run_agg(vx, batches, list(range(nk)), kinds, aggs, max_rows=97, **kw)
+    assert gop.kinds == eop.kinds
+    assert_columns_equal(got, exp, gop.kinds, what=f"distinct {key_shape}")
+
+
+def test_distinct_only_aggregates_device_resident_many_values(oracle, vx):
+    """Only DISTINCT aggregates (the operator's own table holds just the keys), device-resident
+    input, 2 M rows with ~300 K distinct (group, value) pairs."""
+    rng = np.random.default_rng(99)
+    n = 2_000_000
+    k = rng.integers(0, 3000, n).astype(np.int32)
+    x = rng.integers(0, 100, n).astype(np.int64) * 7919
+    hb = batch_of([k, x])
+    D = abi.AGG_FN_DISTINCT
+    aggs = [(abi.AGG_COUNT, 1, abi.BIGINT, -1, -1, D), (abi.AGG_SUM, 1, abi.BIGINT, -1, -1, D)]
+    exp, _ = run_agg(oracle, [hb], [0], [abi.INTEGER], aggs, max_rows=1000)
+    op = vx.Aggregation([0], [abi.INTEGER], aggs)
+    op.add_input(vx.to_device(hb))
+    op.add_input(vx.to_device(hb))  # the second pass adds no new value
+    op.no_more_input()
+    got = vx.collect_output(op, 1000)
+    assert_columns_equal(got, exp, op.kinds, what="distinct only")
+
+
+def test_distinct_aggregates_are_refused_outside_the_single_step(vx):
+    with pytest.raises(Exception) as e:
+        vx.Aggregation([0], [abi.BIGINT], [(abi.AGG_SUM, 1, abi.BIGINT, -1, -1, abi.AGG_FN_DISTINCT)],
+                       abi.STEP_PARTIAL)
+    assert "distinct inputs" in str(e.value)

@@ -627,3 +627,62 @@ def test_oracle_counting_joins_are_intersect_all_and_except_all(oracle, join_typ
             if consumed == (join_type == abi.JOIN_COUNTING_LEFT_SEMI_FILTER):
                 exp.append(i)
     assert got == exp
+
+
+def test_distinct_aggregates_vs_pandas(oracle):
+    """sum / count / avg (DISTINCT x) with nulls, a mask and plain aggregates beside
+    them (exec/DistinctAggregations.cpp; GroupingSet.cpp:317-332): every group keeps
+    the set of its input values; pandas drop_duplicates is the independent reference."""
+    rng = np.random.default_rng(4242)
+    n = 40000
+    k = rng.integers(0, 300, n).astype(np.int64)
+    x = rng.integers(-20, 20, n).astype(np.int64)        # many repeats per group
+    d = rng.integers(0, 16, n).astype(np.float64) / 4.0  # dyadic: sums exact in any order
+    xv = rng.random(n) > 0.1
+    m = rng.random(n) > 0.5
+    mv = rng.random(n) > 0.05
+    D = abi.AGG_FN_DISTINCT
+    def piece(lo, hi):
+        return abi.HostBatch([abi.HostColumn(abi.BIGINT, k[lo:hi]), abi.HostColumn(abi.BIGINT, x[lo:hi], valid=xv[lo:hi]),
+                              abi.HostColumn(abi.DOUBLE, d[lo:hi]),
+                              abi.HostColumn(abi.BOOLEAN, m[lo:hi], valid=mv[lo:hi])])
+    batches = [piece(i, min(n, i + 7000)) for i in range(0, n, 7000)]
+    aggs = [(abi.AGG_SUM, 1, abi.BIGINT, -1, -1, D), (abi.AGG_COUNT, 1, abi.BIGINT, -1, -1, D),
+            (abi.AGG_AVG, 2, abi.DOUBLE, -1, -1, D), (abi.AGG_SUM, 2, abi.DOUBLE, 3, -1, D),
+            (abi.AGG_SUM, 1, abi.BIGINT), (abi.AGG_MIN, 1, abi.BIGINT, -1, -1, D), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    out, _ = _run_agg(oracle, batches, [0], [abi.BIGINT], aggs)
+    keys = out[0][0]
+    _, first = np.unique(k, return_index=True)
+    assert list(keys) == list(k[np.sort(first)])
+    df = pd.DataFrame({"k": k, "x": np.where(xv, x, 0), "xv": xv, "d": d, "m": m & mv})
+    for pos, g in enumerate(keys):
+        rows = df[df.k == g]
+        xs = rows[rows.xv].x.drop_duplicates()
+        assert bool(out[1][1][pos]) == (len(xs) > 0)
+        if len(xs):
+            assert out[1][0][pos] == xs.sum()
+        assert out[2][0][pos] == len(xs)
+        ds = rows.d.drop_duplicates()
+        assert out[3][0][pos] == ds.sum() / len(ds)
+        dm = rows[rows.m].d.drop_duplicates()
+        assert bool(out[4][1][pos]) == (len(dm) > 0)
+        if len(dm):
+            assert out[4][0][pos] == dm.sum()
+        assert out[5][0][pos] == rows[rows.xv].x.sum() or not out[5][1][pos]
+        if rows.xv.any():
+            assert out[6][0][pos] == rows[rows.xv].x.min()
+        assert out[7][0][pos] == len(rows)
+
+
+def test_distinct_aggregates_are_refused_outside_the_single_step(oracle):
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.Aggregation([0], [abi.BIGINT], [(abi.AGG_SUM, 1, abi.BIGINT, -1, -1, abi.AGG_FN_DISTINCT)],
+                           step=abi.STEP_PARTIAL)
+    assert e.value.status == abi.EUSER and "distinct inputs" in str(e.value)
+
+
+def test_distinct_doubles_treat_every_nan_as_one_value_and_zero_signs_as_equal(oracle):
+    nan2 = np.frombuffer(np.array([0x7ff8000000000001], dtype=np.uint64).tobytes(), dtype=np.float64)[0]
+    v = np.array([np.nan, nan2, 0.0, -0.0, 1.5, 1.5])
+    out, _ = _run_agg(oracle, [_int_batch([v])], [], [], [(abi.AGG_COUNT, 0, abi.DOUBLE, -1, -1, abi.AGG_FN_DISTINCT)])
+    assert out[0][0][0] == 3

@@ -65,7 +65,7 @@ class ValueIdSpec(C.Structure):
 
 class AggFn(C.Structure):
     _fields_ = [("kind", C.c_int32), ("input_col", C.c_int32), ("input_col2", C.c_int32),
-                ("input_type", C.c_int32), ("mask_col", C.c_int32)]
+                ("input_type", C.c_int32), ("mask_col", C.c_int32), ("flags", C.c_int32)]
 
 
 class AggSpec(C.Structure):
@@ -76,6 +76,7 @@ class AggSpec(C.Structure):
 
 
 AGG_UNORDERED_OUTPUT = 1
+AGG_FN_DISTINCT = 1  # vx355_agg_fn.flags
 
 
 class AggStats(C.Structure):

@@ -1889,6 +1889,9 @@ __global__ __launch_bounds__(256) void k_extract(ExtractArgs a) {
   const uint64_t key = a.mode == MODE_NORMALIZED ? (active ? g[0] : 0) : gi;
   for (int k = 0; k < a.numKeys; ++k) {
     const OutKey& ok = a.keys[k];
+    if (ok.values == nullptr) {
+      continue;  // the caller has the keys from elsewhere (DistinctPart::outer)
+    }
     if (a.mode == MODE_HASH) {
       // Stored key images by group id.
       const bool valid = active && !((a.nullStore[gi] >> ok.keyIndex) & 1);
@@ -2235,6 +2238,29 @@ struct vx355_agg {
   bool logShapes = false;
   int64_t deferCap = 1 << 20;
   int fastUnroll = 4;
+
+  // agg(DISTINCT x), exec/DistinctAggregations.cpp: the SetAccumulator of one aggregate is a
+  // second group table keyed on (grouping keys, x [, mask]) that sees every input batch; at
+  // noMoreInput its rows, already in first-seen order, feed 'outer', an aggregation of x over
+  // the grouping keys. 'outer' lists the same groups in the same order as this operator, so
+  // get_output takes the aggregate's column from it row for row.
+  struct DistinctPart {
+    int32_t specIndex = 0;  // position among the caller's aggregates
+    vx355_agg* dedup = nullptr;
+    vx355_agg* outer = nullptr;
+  };
+  std::vector<DistinctPart> distinct;
+  std::vector<int32_t> specIsDistinct;  // per caller aggregate
+  std::vector<int32_t> fullOutTypes;    // what the caller sees when 'distinct' is not empty
+  bool keysOptional = false;  // an 'outer': key output columns without a buffer are skipped
+  bool ownsCtx = true;        // dedup / outer run on their parent's context
+
+  ~vx355_agg() {
+    for (auto& d : distinct) {
+      delete d.dedup;
+      delete d.outer;
+    }
+  }
 
   Counters* counters() { return countersBuf.as<Counters>(); }
 };
@@ -3956,7 +3982,9 @@ void getOutput(vx355_agg& h, vx355_out_column* cols, int32_t numCols, int32_t ma
   }
   for (int32_t c = 0; c < numCols; ++c) {
     VX_CHECK_ARG(cols[c].type_kind == h.outTypes[c], "output column type mismatch");
-    VX_CHECK_ARG(cols[c].values != nullptr, "output column without values buffer");
+    const bool skippedKey = h.keysOptional && c < static_cast<int32_t>(h.keys.size()) &&
+        cols[c].mem == VX355_MEM_DEVICE;
+    VX_CHECK_ARG(cols[c].values != nullptr || skippedKey, "output column without values buffer");
   }
   // Device scratch for host-resident output columns.
   const size_t words = static_cast<size_t>(ceilDiv(n, 64));
@@ -4172,6 +4200,171 @@ void toIntermediate(vx355_agg& h, const vx355_batch* batch, vx355_out_column* co
   rt.sync();
 }
 
+// Knobs every operator (and the dedup / outer operators of a DISTINCT aggregate) reads.
+void configureFromEnv(vx355_agg& h) {
+  if (const char* e = std::getenv("VX355_ARRAY_MAX")) {
+    h.arrayMax = std::strtoull(e, nullptr, 10);
+  }
+  if (const char* e = std::getenv("VX355_JIT")) {
+    h.jitEnabled = e[0] != '0';
+    h.jitAsync = std::string(e) == "async";
+  }
+  if (const char* e = std::getenv("VX355_AGG_COALESCE_ROWS")) {
+    h.coalescer.thresholdRows = std::strtoll(e, nullptr, 10);
+  }
+  if (const char* e = std::getenv("VX355_EXACT_SUMS")) {
+    h.exactSums = e[0] != '0';
+  }
+  if (const char* e = std::getenv("VX355_LOG_SHAPES")) {
+    h.logShapes = e[0] == '1';
+  }
+  if (const char* e = std::getenv("VX355_AGG_DEFER_CAP")) {
+    h.deferCap = std::max<int64_t>(1, std::strtoll(e, nullptr, 10));
+  }
+  if (const char* e = std::getenv("VX355_AGG_FAST_UNROLL")) {
+    h.fastUnroll = std::atoi(e) == 2 ? 2 : 4;
+  }
+  if (const char* e = std::getenv("VX355_AGG_NO_FAST")) {
+    h.disableFast = e[0] == '1';
+  }
+  if (const char* e = std::getenv("VX355_AGG_RADIX_MIN_ROWS")) {
+    h.radixMinRows = std::strtoll(e, nullptr, 10);  // < 0 disables the path
+  }
+  if (const char* e = std::getenv("VX355_AGG_RADIX_BINS")) {
+    h.radixMaxBins = std::max(2, std::min(kRadixMaxBins, std::atoi(e)));
+  }
+  if (const char* e = std::getenv("VX355_AGG_RADIX_TILE_ROWS")) {
+    h.radixTileRows = std::strtoll(e, nullptr, 10);
+  }
+  if (const char* e = std::getenv("VX355_AGG_CHUNK_ROWS")) {
+    h.chunkRows = std::max<int64_t>(64, std::strtoll(e, nullptr, 10) & ~63LL);
+  }
+}
+
+bool needsDistinctSet(const vx355_agg_fn& f) {
+  // min / max of the distinct values == min / max of the values
+  return (f.flags & VX355_AGG_FN_DISTINCT) &&
+      (f.kind == VX355_AGG_SUM || f.kind == VX355_AGG_COUNT || f.kind == VX355_AGG_AVG);
+}
+
+vx355_agg* makeChild(vx355_agg& parent, const vx355_agg_spec& spec) {
+  auto c = std::make_unique<vx355_agg>();
+  c->step = spec.step;
+  c->ignoreNullKeys = spec.ignore_null_keys != 0;
+  configureFromEnv(*c);
+  buildPlan(*c, spec);
+  c->ownsCtx = false;
+  return c.release();
+}
+
+// The set accumulators and their consumers of the DISTINCT aggregates of 'spec'
+// (GroupingSet.cpp:117-126, DistinctAggregations::create).
+void buildDistinctParts(vx355_agg& h, const vx355_agg_spec& spec) {
+  const int32_t nk = spec.num_keys;
+  for (int32_t i = 0; i < spec.num_aggs; ++i) {
+    const vx355_agg_fn& f = spec.aggs[i];
+    if (!needsDistinctSet(f)) {
+      continue;
+    }
+    VX_CHECK_ARG(f.input_col >= 0 && f.input_col < VX355_PROJECTION_COL_BASE, "DISTINCT aggregate needs an input column");
+    vx355_agg::DistinctPart part;
+    part.specIndex = i;
+    // dedup: GROUP BY keys..., x [, mask] without aggregates; null keys are values here
+    std::vector<int32_t> cols(spec.key_cols, spec.key_cols + nk), types(spec.key_types, spec.key_types + nk);
+    cols.push_back(f.input_col);
+    types.push_back(f.input_type);
+    if (f.mask_col >= 0) {
+      cols.push_back(f.mask_col);
+      types.push_back(VX355_BOOLEAN);
+    }
+    vx355_agg_spec ds{};
+    ds.num_keys = static_cast<int32_t>(cols.size());
+    ds.key_cols = cols.data();
+    ds.key_types = types.data();
+    ds.step = VX355_STEP_SINGLE;
+    part.dedup = makeChild(h, ds);
+    h.distinct.push_back(part);  // owned from here on
+    // outer: the aggregate over dedup's output columns 0..nk-1 | x | mask
+    std::vector<int32_t> ocols(nk);
+    for (int32_t k = 0; k < nk; ++k) {
+      ocols[k] = k;
+    }
+    vx355_agg_fn of = f;
+    of.flags = 0;
+    of.input_col = nk;
+    of.input_col2 = -1;
+    of.mask_col = f.mask_col >= 0 ? nk + 1 : -1;
+    vx355_agg_spec os{};
+    os.num_keys = nk;
+    os.key_cols = ocols.data();
+    os.key_types = spec.key_types;
+    os.num_aggs = 1;
+    os.aggs = &of;
+    os.step = VX355_STEP_SINGLE;
+    os.ignore_null_keys = spec.ignore_null_keys;
+    os.flags = spec.flags;
+    h.distinct.back().outer = makeChild(h, os);
+    h.distinct.back().outer->keysOptional = true;
+    h.distinct.back().outer->unorderedOutput = false;  // rows pair up with the parent's by order
+  }
+}
+
+void feedInput(vx355_agg& h, const vx355_batch* batch) {
+  if (!tryCoalesce(h, batch)) {
+    flushPending(h);
+    addInput(h, batch);
+  }
+}
+
+// noMoreInput of one DISTINCT aggregate: dedup's rows -> outer (TypedDistinctAggregations::
+// extractValues, DistinctAggregations.cpp:240-285, with the per-group loop turned into one more
+// aggregation).
+void pumpDistinct(vx355_agg& h, vx355_agg::DistinctPart& part) {
+  vx355_agg& dedup = *part.dedup;
+  vx355_agg& outer = *part.outer;
+  flushPending(dedup);
+  dedup.noMoreInput = true;
+  const int32_t nc = static_cast<int32_t>(dedup.outTypes.size());
+  const int32_t chunk = 1 << 22;
+  const size_t words = static_cast<size_t>(chunk / 64);
+  std::vector<DevBuf> values(nc), nulls(nc);
+  std::vector<vx355_out_column> out(nc);
+  std::vector<vx355_column> in(nc);
+  bool allocated = false;
+  for (;;) {
+    if (!allocated) {
+      for (int32_t c = 0; c < nc; ++c) {
+        const int w = kindWidth(dedup.outTypes[c]);
+        out[c].type_kind = dedup.outTypes[c];
+        out[c].mem = VX355_MEM_DEVICE;
+        out[c].values = values[c].ensure(w == 0 ? words * 8 : static_cast<size_t>(chunk) * w);
+        out[c].nulls = static_cast<uint64_t*>(nulls[c].ensure(words * 8));
+      }
+      allocated = true;
+    }
+    int32_t n = 0, fin = 0;
+    getOutput(dedup, out.data(), nc, chunk, &n, &fin);
+    if (n > 0) {
+      for (int32_t c = 0; c < nc; ++c) {
+        in[c] = vx355_column{};
+        in[c].type_kind = out[c].type_kind;
+        in[c].encoding = VX355_FLAT;
+        in[c].values = out[c].values;
+        in[c].nulls = out[c].nulls;
+        in[c].mem = VX355_MEM_DEVICE;
+      }
+      vx355_batch b{n, nc, in.data()};
+      addInput(outer, &b);
+    }
+    if (fin) {
+      break;
+    }
+  }
+  outer.noMoreInput = true;
+  delete part.dedup;  // the outer operator has copied what it keeps (long strings included)
+  part.dedup = nullptr;
+}
+
 }  // namespace
 }  // namespace vx
 
@@ -4187,45 +4380,51 @@ int vx355_agg_create(const vx355_agg_spec* spec, vx355_agg** out) {
   h->step = spec->step;
   h->ignoreNullKeys = spec->ignore_null_keys != 0;
   h->unorderedOutput = (spec->flags & VX355_AGG_UNORDERED_OUTPUT) != 0;
-  if (const char* e = std::getenv("VX355_ARRAY_MAX")) {
-    h->arrayMax = std::strtoull(e, nullptr, 10);
+  configureFromEnv(*h);
+  // DISTINCT aggregates get their own tables; this operator keeps the others.
+  std::vector<vx355_agg_fn> plain;
+  bool anyDistinct = false;
+  for (int32_t i = 0; i < spec->num_aggs; ++i) {
+    vx355_agg_fn f = spec->aggs[i];
+    const bool d = needsDistinctSet(f);
+    if ((f.flags & VX355_AGG_FN_DISTINCT) && f.kind == VX355_AGG_COUNT_STAR) {
+      VX_THROW(VX355_EINVAL, "count(*) has no input to be DISTINCT over");
+    }
+    anyDistinct = anyDistinct || d;
+    h->specIsDistinct.push_back(d ? 1 : 0);
+    if (!d) {
+      f.flags &= ~VX355_AGG_FN_DISTINCT;
+      plain.push_back(f);
+    }
   }
-  if (const char* e = std::getenv("VX355_JIT")) {
-    h->jitEnabled = e[0] != '0';
-    h->jitAsync = std::string(e) == "async";
+  if (anyDistinct) {
+    if (spec->step != VX355_STEP_SINGLE) {
+      // GroupingSet.cpp:117-121
+      VX_THROW(VX355_EUSER, "Partial aggregations over distinct inputs are not supported");
+    }
+    vx355_agg_spec mainSpec = *spec;
+    mainSpec.num_aggs = static_cast<int32_t>(plain.size());
+    mainSpec.aggs = plain.data();
+    buildPlan(*h, mainSpec);
+    h->unorderedOutput = false;  // the parts pair up with this operator's rows by order
+    buildDistinctParts(*h, *spec);
+    h->fullOutTypes.assign(h->outTypes.begin(), h->outTypes.begin() + spec->num_keys);
+    size_t nextPlain = static_cast<size_t>(spec->num_keys), nextPart = 0;
+    for (int32_t i = 0; i < spec->num_aggs; ++i) {
+      if (h->specIsDistinct[i]) {
+        h->fullOutTypes.push_back(h->distinct[nextPart++].outer->outTypes.back());
+      } else {
+        h->fullOutTypes.push_back(h->outTypes[nextPlain++]);
+      }
+    }
+  } else {
+    buildPlan(*h, *spec);
   }
-  if (const char* e = std::getenv("VX355_AGG_COALESCE_ROWS")) {
-    h->coalescer.thresholdRows = std::strtoll(e, nullptr, 10);
-  }
-  if (const char* e = std::getenv("VX355_EXACT_SUMS")) {
-    h->exactSums = e[0] != '0';
-  }
-  if (const char* e = std::getenv("VX355_LOG_SHAPES")) {
-    h->logShapes = e[0] == '1';
-  }
-  if (const char* e = std::getenv("VX355_AGG_DEFER_CAP")) {
-    h->deferCap = std::max<int64_t>(1, std::strtoll(e, nullptr, 10));
-  }
-  if (const char* e = std::getenv("VX355_AGG_FAST_UNROLL")) {
-    h->fastUnroll = std::atoi(e) == 2 ? 2 : 4;
-  }
-  if (const char* e = std::getenv("VX355_AGG_NO_FAST")) {
-    h->disableFast = e[0] == '1';
-  }
-  if (const char* e = std::getenv("VX355_AGG_RADIX_MIN_ROWS")) {
-    h->radixMinRows = std::strtoll(e, nullptr, 10);  // < 0 disables the path
-  }
-  if (const char* e = std::getenv("VX355_AGG_RADIX_BINS")) {
-    h->radixMaxBins = std::max(2, std::min(kRadixMaxBins, std::atoi(e)));
-  }
-  if (const char* e = std::getenv("VX355_AGG_RADIX_TILE_ROWS")) {
-    h->radixTileRows = std::strtoll(e, nullptr, 10);
-  }
-  if (const char* e = std::getenv("VX355_AGG_CHUNK_ROWS")) {
-    h->chunkRows = std::max<int64_t>(64, std::strtoll(e, nullptr, 10) & ~63LL);
-  }
-  buildPlan(*h, *spec);
   h->ctx = Runtime::createContext();  // the operator's own stream + mailbox
+  for (auto& d : h->distinct) {
+    d.dedup->ctx = h->ctx;
+    d.outer->ctx = h->ctx;
+  }
   *out = h.release();
   VX_API_END
 }
@@ -4241,6 +4440,9 @@ int vx355_agg_set_fused_input(vx355_agg* h, const vx355_filter_term* terms, int3
                "0..4 projections");
   if (!rawInput(h->step)) {
     VX_THROW(VX355_EUNSUPPORTED, "fused FilterProject needs raw input (partial or single step)");
+  }
+  if (!h->distinct.empty()) {
+    VX_THROW(VX355_EUNSUPPORTED, "fused FilterProject under DISTINCT aggregates");
   }
   h->fusedTerms.assign(terms, terms + n_terms);
   h->fusedProj.assign(projections, projections + n_projections);
@@ -4263,9 +4465,9 @@ int vx355_agg_add_input(vx355_agg* h, const vx355_batch* batch) {
   VX_CHECK_ARG(h && batch, "NULL argument");
   VX_CHECK_ARG(!h->noMoreInput, "addInput after noMoreInput");
   VX_CHECK_ARG(!h->flushing, "addInput while a partial flush is being drained");
-  if (!tryCoalesce(*h, batch)) {
-    flushPending(*h);
-    addInput(*h, batch);
+  feedInput(*h, batch);
+  for (auto& d : h->distinct) {
+    feedInput(*d.dedup, batch);
   }
   VX_API_END
 }
@@ -4275,6 +4477,11 @@ int vx355_agg_no_more_input(vx355_agg* h) {
   VX_CHECK_ARG(h, "NULL argument");
   Runtime::get().requireInit();
   flushPending(*h);
+  if (!h->noMoreInput) {
+    for (auto& d : h->distinct) {
+      pumpDistinct(*h, d);
+    }
+  }
   h->noMoreInput = true;
   VX_API_END
 }
@@ -4282,10 +4489,11 @@ int vx355_agg_no_more_input(vx355_agg* h) {
 int vx355_agg_output_types(const vx355_agg* h, int32_t* types, int32_t cap, int32_t* n) {
   VX_API_BEGIN
   VX_CHECK_ARG(h && n, "NULL argument");
-  *n = static_cast<int32_t>(h->outTypes.size());
+  const std::vector<int32_t>& seen = h->distinct.empty() ? h->outTypes : h->fullOutTypes;
+  *n = static_cast<int32_t>(seen.size());
   if (types) {
     for (int32_t i = 0; i < *n && i < cap; ++i) {
-      types[i] = h->outTypes[i];
+      types[i] = seen[i];
     }
   }
   VX_API_END
@@ -4296,7 +4504,33 @@ int vx355_agg_get_output(vx355_agg* h, vx355_out_column* cols, int32_t num_cols,
   VX_API_BEGIN_CTX(VX_CTX_OF(h))
   Runtime::get().requireInit();
   VX_CHECK_ARG(h, "NULL argument");
-  getOutput(*h, cols, num_cols, max_rows, n_out, finished);
+  if (h->distinct.empty()) {
+    getOutput(*h, cols, num_cols, max_rows, n_out, finished);
+  } else {
+    VX_CHECK_ARG(cols && n_out && finished, "NULL argument");
+    VX_CHECK_ARG(num_cols == static_cast<int32_t>(h->fullOutTypes.size()), "wrong number of output columns");
+    const int32_t nk = static_cast<int32_t>(h->keys.size());
+    std::vector<vx355_out_column> mine(cols, cols + nk);
+    for (size_t i = 0; i < h->specIsDistinct.size(); ++i) {
+      if (!h->specIsDistinct[i]) {
+        mine.push_back(cols[nk + i]);
+      }
+    }
+    getOutput(*h, mine.data(), static_cast<int32_t>(mine.size()), max_rows, n_out, finished);
+    for (auto& d : h->distinct) {
+      std::vector<vx355_out_column> theirs(nk + 1);
+      for (int32_t k = 0; k < nk; ++k) {
+        theirs[k] = vx355_out_column{h->keys[k].kind, VX355_MEM_DEVICE, nullptr, nullptr};
+      }
+      theirs[nk] = cols[nk + d.specIndex];
+      int32_t n2 = 0, fin2 = 0;
+      getOutput(*d.outer, theirs.data(), nk + 1, max_rows, &n2, &fin2);
+      if (n2 != *n_out) {
+        VX_THROW(VX355_EINTERNAL, "DISTINCT aggregate lists " + std::to_string(n2) + " groups, the operator " +
+                                     std::to_string(*n_out));
+      }
+    }
+  }
   VX_API_END
 }
 
@@ -4318,6 +4552,9 @@ int vx355_agg_flush(vx355_agg* h) {
 int vx355_agg_to_intermediate(vx355_agg* h, const vx355_batch* batch, vx355_out_column* cols, int32_t num_cols) {
   VX_API_BEGIN_CTX(VX_CTX_OF(h))
   VX_CHECK_ARG(h, "NULL argument");
+  if (!h->distinct.empty()) {
+    VX_THROW(VX355_EUNSUPPORTED, "toIntermediate with DISTINCT aggregates");
+  }
   toIntermediate(*h, batch, cols, num_cols);
   VX_API_END
 }

@@ -477,7 +477,8 @@ def make_agg_spec(key_cols, key_types, aggs, step, ignore_null_keys=False, flags
         kind, col, typ = a[0], a[1], a[2]
         mask = a[3] if len(a) > 3 else -1
         col2 = a[4] if len(a) > 4 else -1
-        fns[i] = abi.AggFn(kind, col, col2, typ, mask)
+        fn_flags = a[5] if len(a) > 5 else 0
+        fns[i] = abi.AggFn(kind, col, col2, typ, mask, fn_flags)
     keep["fns"] = fns
     spec = abi.AggSpec(len(key_cols), keep["kc"], keep["kt"], len(aggs), fns, step,
                        1 if ignore_null_keys else 0, flags, 0)
