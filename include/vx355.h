@@ -94,8 +94,8 @@ typedef struct vx355_batch {
 } vx355_batch;
 
 /* One caller-allocated flat output column. VARCHAR / VARBINARY values are 16-byte
- * StringViews; strings longer than 12 bytes (grouping keys of the generic hash mode) are
- * non-inline views: in a VX355_MEM_DEVICE column they point into the operator's HBM arena
+ * StringViews; strings longer than 12 bytes (grouping keys of the generic hash mode, min / max
+ * over strings) are non-inline views: in a VX355_MEM_DEVICE column they point into the operator's HBM arena
  * (valid while the handle lives), in a VX355_MEM_HOST column into a host buffer the handle
  * keeps until its next get_output — the shim copies or wraps them like any string buffer
  * (FlatVector::stringBuffers_). */
@@ -375,7 +375,10 @@ typedef enum vx355_agg_kind {
   VX355_AGG_SUM = 0,        /* SumAggregate.cpp:39-118 */
   VX355_AGG_COUNT = 1,      /* count(x), CountAggregate.cpp:27-147 */
   VX355_AGG_COUNT_STAR = 2, /* count(*) */
-  VX355_AGG_MIN = 3,        /* MinMaxAggregateBase.cpp:101-305 */
+  VX355_AGG_MIN = 3,        /* MinMaxAggregateBase.cpp:101-305; over VARCHAR / VARBINARY input
+                               :305-480 (any step: the intermediate type is the input type;
+                               no partial flush). Strings longer than 12 bytes come out as
+                               described at vx355_out_column. */
   VX355_AGG_MAX = 4,
   VX355_AGG_AVG = 5         /* AverageAggregateBase.h:66-260 */
 } vx355_agg_kind;

@@ -407,6 +407,24 @@ class Aggregation {
         }
         continue;
       }
+      if (isStringKind(f.input_type)) {
+        // MinMaxAggregateBase.cpp:395-419 (non-numeric doUpdate): SingleValueAccumulator holds
+        // the current extreme; compare() is StringView::compare (bytes, then length). Raw and
+        // intermediate input are the same thing (:377-381).
+        if (in->isNull(r)) {
+          continue;
+        }
+        uint8_t tmp;
+        const auto* sv = static_cast<const StringView*>(in->valuePtr(r, &tmp));
+        std::string v(sv->data(), sv->size);
+        auto it = stringAcc_.find({g, i});
+        if (it == stringAcc_.end()) {
+          stringAcc_.emplace(std::make_pair(g, i), std::move(v));
+        } else if (f.kind == VX355_AGG_MIN ? v < it->second : v > it->second) {
+          it->second = std::move(v);
+        }
+        continue;
+      }
       switch (f.kind) {
         case VX355_AGG_COUNT_STAR:
           if (raw) {
@@ -506,6 +524,23 @@ class Aggregation {
         break;
       case VX355_AGG_MIN:
       case VX355_AGG_MAX:
+        if (isStringKind(f.input_type)) {
+          // extractValues (MinMaxAggregateBase.cpp:352-375): null without a value
+          auto it = stringAcc_.find({group, i});
+          StringView view{};
+          if (it != stringAcc_.end()) {
+            const std::string& v = it->second;
+            view.size = static_cast<uint32_t>(v.size());
+            if (view.isInline()) {
+              std::memcpy(view.prefix, v.data(), v.size());
+            } else {
+              std::memcpy(view.prefix, v.data(), 4);
+              view.value.data = v.data();
+            }
+          }
+          writeOut(cols[c++], outRow, it == stringAcc_.end(), &view, 16);
+          break;
+        }
         if (isIntKind(f.input_type)) {
           if (f.input_type == VX355_BOOLEAN) {
             uint8_t b = *reinterpret_cast<int64_t*>(a) != 0;
@@ -557,6 +592,8 @@ class Aggregation {
     std::vector<SetValue> ordered;
   };
   std::map<std::pair<char*, size_t>, DistinctSet> distinct_;
+  // SingleValueAccumulator of min / max over VARCHAR / VARBINARY, per (group, aggregate)
+  std::map<std::pair<char*, size_t>, std::string> stringAcc_;
   std::unique_ptr<HashTable> table_;
   char* globalRow_ = nullptr;
   bool noMoreInput_ = false;

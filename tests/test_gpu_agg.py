@@ -1021,3 +1021,62 @@ def test_distinct_aggregates_are_refused_outside_the_single_step(vx):
         vx.Aggregation([0], [abi.BIGINT], [(abi.AGG_SUM, 1, abi.BIGINT, -1, -1, abi.AGG_FN_DISTINCT)],
                        abi.STEP_PARTIAL)
     assert "distinct inputs" in str(e.value)
+
+
+_WORDS = [b"", b"a", b"a\x00", b"ab", b"abcdefg", b"abcdefgh", b"abcdefgh\x00", b"abcdefghi", b"twelve bytes", b"thirteen byte",
+          b"a string that is clearly longer than twelve bytes", b"a string that is clearly longer than twelve bytes!",
+          b"\xff\xfe high bytes sort last", b"\x7f", b"\x80", b"zzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzzz"]
+
+
+@pytest.mark.parametrize("key_shape", ["array", "normalized", "generic", "global"])
+def test_min_max_over_strings(oracle, vx, key_shape):
+    """min / max over VARCHAR (MinMaxAggregateBase.cpp:305-480): byte order, a string before
+    its extensions, nulls skipped, a group without a value is null, masks, strings on both
+    sides of the 12-byte inline limit; next to plain and DISTINCT aggregates; small pages."""
+    rng = np.random.default_rng(500 + len(key_shape))
+    n = 50000
+    keys, kinds, x, d, r, m = _distinct_inputs(rng, n, key_shape)
+    nk = len(keys)
+    s = [_WORDS[i] for i in rng.integers(0, len(_WORDS), n)]
+    # some groups see only nulls: null out every string of the rows whose x is a multiple of 7... and more
+    sv = (rng.random(n) > 0.2) & (x % 7 != 0)
+    mv = rng.random(n) > 0.05
+
+    def piece(lo, hi):
+        cols = [abi.HostColumn(kinds[j], keys[j][lo:hi]) for j in range(nk)]
+        cols += [abi.HostColumn(abi.VARCHAR, s[lo:hi], valid=sv[lo:hi]), abi.HostColumn(abi.BIGINT, x[lo:hi]),
+                 abi.HostColumn(abi.BOOLEAN, m[lo:hi], valid=mv[lo:hi])]
+        return abi.HostBatch(cols)
+
+    batches = [piece(i, min(n, i + 9000)) for i in range(0, n, 9000)]
+    S, X, M = nk, nk + 1, nk + 2
+    aggs = [(abi.AGG_MIN, S, abi.VARCHAR), (abi.AGG_MAX, S, abi.VARCHAR), (abi.AGG_SUM, X, abi.BIGINT),
+            (abi.AGG_MAX, S, abi.VARCHAR, M), (abi.AGG_COUNT, X, abi.BIGINT, -1, -1, abi.AGG_FN_DISTINCT),
+            (abi.AGG_MIN, S, abi.VARCHAR, M)]
+    exp, eop = run_agg(oracle, batches, list(range(nk)), kinds, aggs, max_rows=61)
+    got, gop = run_agg(vx, batches, list(range(nk)), kinds, aggs, max_rows=61)
+    assert gop.kinds == eop.kinds
+    assert_columns_equal(got, exp, gop.kinds, what=f"string min/max {key_shape}")
+
+
+def test_min_max_over_strings_partial_then_final(oracle, vx):
+    """The intermediate type of min / max is the input type: partial results of two operators
+    merged by a FINAL one equal the SINGLE aggregation."""
+    rng = np.random.default_rng(321)
+    n = 30000
+    k = rng.integers(0, 50, n).astype(np.int64)
+    s = [_WORDS[i] for i in rng.integers(0, len(_WORDS), n)]
+    sv = rng.random(n) > 0.3
+    aggs = [(abi.AGG_MIN, 1, abi.VARCHAR), (abi.AGG_MAX, 1, abi.VARCHAR), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    halves = [abi.HostBatch([abi.HostColumn(abi.BIGINT, k[lo:hi]), abi.HostColumn(abi.VARCHAR, s[lo:hi], valid=sv[lo:hi])])
+              for lo, hi in ((0, n // 2), (n // 2, n))]
+    exp, _ = run_agg(oracle, halves, [0], [abi.BIGINT], aggs)
+    partials = []
+    for hb in halves:
+        out, op = run_agg(vx, [hb], [0], [abi.BIGINT], aggs, abi.STEP_PARTIAL)
+        assert op.kinds == [abi.BIGINT, abi.VARCHAR, abi.VARCHAR, abi.BIGINT]
+        partials.append(abi.HostBatch([abi.HostColumn(kind, v if isinstance(v, list) else np.asarray(v), valid=np.asarray(valid, bool))
+                                       for kind, (v, valid) in zip(op.kinds, out)]))
+    final_aggs = [(abi.AGG_MIN, 1, abi.VARCHAR), (abi.AGG_MAX, 2, abi.VARCHAR), (abi.AGG_COUNT_STAR, 3, abi.BIGINT)]
+    got, gop = run_agg(vx, partials, [0], [abi.BIGINT], final_aggs, abi.STEP_FINAL)
+    assert_columns_equal(got, exp, gop.kinds, what="string min/max partial -> final")

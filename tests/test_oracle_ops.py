@@ -686,3 +686,21 @@ def test_distinct_doubles_treat_every_nan_as_one_value_and_zero_signs_as_equal(o
     v = np.array([np.nan, nan2, 0.0, -0.0, 1.5, 1.5])
     out, _ = _run_agg(oracle, [_int_batch([v])], [], [], [(abi.AGG_COUNT, 0, abi.DOUBLE, -1, -1, abi.AGG_FN_DISTINCT)])
     assert out[0][0][0] == 3
+
+
+def test_min_max_over_strings_vs_python(oracle):
+    """Non-numeric min / max (MinMaxAggregateBase.cpp:305-480): bytes compared as unsigned,
+    a prefix before its extensions, nulls skipped, no value -> null."""
+    words = [b"", b"a", b"a\x00", b"ab", b"\x80", b"\x7f", b"longer than twelve bytes", b"longer than twelve bytes!"]
+    rng = np.random.default_rng(11)
+    n = 5000
+    k = rng.integers(0, 40, n).astype(np.int64)
+    s = [words[i] for i in rng.integers(0, len(words), n)]
+    valid = (rng.random(n) > 0.3) & (k % 5 != 0)
+    batch = abi.HostBatch([abi.HostColumn(abi.BIGINT, k), abi.HostColumn(abi.VARCHAR, s, valid=valid)])
+    out, _ = _run_agg(oracle, [batch], [0], [abi.BIGINT], [(abi.AGG_MIN, 1, abi.VARCHAR), (abi.AGG_MAX, 1, abi.VARCHAR)])
+    for pos, g in enumerate(out[0][0]):
+        vals = [s[i] for i in range(n) if k[i] == g and valid[i]]
+        assert bool(out[1][1][pos]) == bool(vals) == bool(out[2][1][pos])
+        if vals:
+            assert out[1][0][pos] == min(vals) and out[2][0][pos] == max(vals)

@@ -2244,10 +2244,19 @@ struct vx355_agg {
   // noMoreInput its rows, already in first-seen order, feed 'outer', an aggregation of x over
   // the grouping keys. 'outer' lists the same groups in the same order as this operator, so
   // get_output takes the aggregate's column from it row for row.
+  //
+  // min / max over VARCHAR / VARBINARY reuse the scheme (any step; the intermediate type is the
+  // input type): dedup holds the distinct (keys, string [, mask]) rows, at noMoreInput the
+  // strings are ranked on the device and 'outer' computes min / max over the BIGINT ranks; the
+  // output column maps ranks back to string views (into dedup's arena for strings > 12 bytes).
   struct DistinctPart {
     int32_t specIndex = 0;  // position among the caller's aggregates
     vx355_agg* dedup = nullptr;
     vx355_agg* outer = nullptr;
+    bool stringMinMax = false;
+    std::vector<DevBuf> pairValues, pairNulls;  // dedup's rows, all at once (stringMinMax)
+    DevBuf perm, permTmp, sortKeys, sortKeysTmp, rank, sortScratch, outRank, outRankNulls, outViews, outViewNulls;
+    const uint32_t* sortedRows = nullptr;  // sorted position -> dedup row
   };
   std::vector<DistinctPart> distinct;
   std::vector<int32_t> specIsDistinct;  // per caller aggregate
@@ -3960,6 +3969,99 @@ void resetAfterFlush(vx355_agg& h) {
   ++h.numFlushes;
 }
 
+// ---- min / max over VARCHAR / VARBINARY ----------------------------------------------------
+// (MinMaxAggregateBase.cpp:305-480, SingleValueAccumulator.) The distinct (keys, string) pairs
+// of the operator live in a dedup table (see vx355_agg::DistinctPart); at noMoreInput their
+// strings are ranked by an LSD radix sort over 8-byte big-endian words - length first (it only
+// decides between a string and its zero-padded extension), then the words from the last to
+// the first - and the aggregation becomes min / max over BIGINT ranks.
+
+// Bytes [8 * level, 8 * level + 8) of the string, big-endian, zero-padded.
+__device__ inline uint64_t stringWordBE(const uint4 v, int level) {
+  const uint32_t size = v.x;
+  const uint32_t off = 8u * static_cast<uint32_t>(level);
+  if (off >= size) {
+    return 0;
+  }
+  uint64_t r = 0;
+  if (size <= 12) {
+    const uint32_t w[3] = {v.y, v.z, v.w};
+    for (uint32_t b = 0; b < 8 && off + b < size; ++b) {
+      const uint32_t i = off + b;
+      r |= static_cast<uint64_t>((w[i >> 2] >> ((i & 3) * 8)) & 0xff) << (56 - 8 * b);
+    }
+  } else {
+    const unsigned char* p =
+        reinterpret_cast<const unsigned char*>((static_cast<uint64_t>(v.w) << 32) | v.z);
+    for (uint32_t b = 0; b < 8 && off + b < size; ++b) {
+      r |= static_cast<uint64_t>(p[off + b]) << (56 - 8 * b);
+    }
+  }
+  return r;
+}
+
+__global__ __launch_bounds__(256) void k_str_max_len(const uint4* views, const uint64_t* nulls, int64_t n,
+                                                     uint32_t* out) {
+  uint32_t m = 0;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    if (!nulls || ((nulls[i >> 6] >> (i & 63)) & 1)) {
+      m = max(m, views[i].x);
+    }
+  }
+  for (int d = kWave / 2; d > 0; d >>= 1) {
+    m = max(m, static_cast<uint32_t>(__shfl_xor(static_cast<int>(m), d, kWave)));
+  }
+  if (lane() == 0 && m) {
+    atomicMax(out, m);
+  }
+}
+
+// level < 0: the length
+__global__ __launch_bounds__(256) void k_str_sort_key(const uint4* views, const uint64_t* nulls,
+                                                      const uint32_t* perm, int64_t n, int level, uint64_t* keys) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) {
+    return;
+  }
+  const uint32_t row = perm[i];
+  uint64_t k = 0;
+  if (!nulls || ((nulls[row >> 6] >> (row & 63)) & 1)) {
+    const uint4 v = views[row];
+    k = level < 0 ? v.x : stringWordBE(v, level);
+  }
+  keys[i] = k;
+}
+
+__global__ __launch_bounds__(256) void k_iota_u32(uint32_t* out, int64_t n) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i < n) {
+    out[i] = static_cast<uint32_t>(i);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_rank_from_perm(const uint32_t* perm, int64_t n, int64_t* rank) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i < n) {
+    rank[perm[i]] = i;
+  }
+}
+
+// The aggregate's output column: rank -> the string that holds it.
+__global__ __launch_bounds__(256) void k_rank_to_view(const int64_t* ranks, const uint64_t* rankNulls, int32_t n,
+                                                      const uint32_t* perm, const uint4* views, uint4* out,
+                                                      uint64_t* outNulls) {
+  const int32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos - static_cast<int32_t>(lane()) >= n) {
+    return;
+  }
+  const bool valid = pos < n && ((rankNulls[pos >> 6] >> (pos & 63)) & 1);
+  writeBit(outNulls, pos, valid);
+  if (pos < n) {
+    out[pos] = valid ? views[perm[ranks[pos]]] : make_uint4(0, 0, 0, 0);
+  }
+}
+
 void getOutput(vx355_agg& h, vx355_out_column* cols, int32_t numCols, int32_t maxRows, int32_t* nOut,
                int32_t* finished) {
   auto& rt = Runtime::get();
@@ -4247,6 +4349,10 @@ bool needsDistinctSet(const vx355_agg_fn& f) {
       (f.kind == VX355_AGG_SUM || f.kind == VX355_AGG_COUNT || f.kind == VX355_AGG_AVG);
 }
 
+bool isStringMinMax(const vx355_agg_fn& f) {
+  return (f.kind == VX355_AGG_MIN || f.kind == VX355_AGG_MAX) && isString(f.input_type);
+}
+
 vx355_agg* makeChild(vx355_agg& parent, const vx355_agg_spec& spec) {
   auto c = std::make_unique<vx355_agg>();
   c->step = spec.step;
@@ -4263,12 +4369,14 @@ void buildDistinctParts(vx355_agg& h, const vx355_agg_spec& spec) {
   const int32_t nk = spec.num_keys;
   for (int32_t i = 0; i < spec.num_aggs; ++i) {
     const vx355_agg_fn& f = spec.aggs[i];
-    if (!needsDistinctSet(f)) {
+    if (!needsDistinctSet(f) && !isStringMinMax(f)) {
       continue;
     }
-    VX_CHECK_ARG(f.input_col >= 0 && f.input_col < VX355_PROJECTION_COL_BASE, "DISTINCT aggregate needs an input column");
-    vx355_agg::DistinctPart part;
+    VX_CHECK_ARG(f.input_col >= 0 && f.input_col < VX355_PROJECTION_COL_BASE, "aggregate needs an input column");
+    h.distinct.emplace_back();
+    vx355_agg::DistinctPart& part = h.distinct.back();
     part.specIndex = i;
+    part.stringMinMax = isStringMinMax(f);
     // dedup: GROUP BY keys..., x [, mask] without aggregates; null keys are values here
     std::vector<int32_t> cols(spec.key_cols, spec.key_cols + nk), types(spec.key_types, spec.key_types + nk);
     cols.push_back(f.input_col);
@@ -4283,7 +4391,6 @@ void buildDistinctParts(vx355_agg& h, const vx355_agg_spec& spec) {
     ds.key_types = types.data();
     ds.step = VX355_STEP_SINGLE;
     part.dedup = makeChild(h, ds);
-    h.distinct.push_back(part);  // owned from here on
     // outer: the aggregate over dedup's output columns 0..nk-1 | x | mask
     std::vector<int32_t> ocols(nk);
     for (int32_t k = 0; k < nk; ++k) {
@@ -4293,6 +4400,9 @@ void buildDistinctParts(vx355_agg& h, const vx355_agg_spec& spec) {
     of.flags = 0;
     of.input_col = nk;
     of.input_col2 = -1;
+    if (part.stringMinMax) {
+      of.input_type = VX355_BIGINT;  // ranks
+    }
     of.mask_col = f.mask_col >= 0 ? nk + 1 : -1;
     vx355_agg_spec os{};
     os.num_keys = nk;
@@ -4303,9 +4413,140 @@ void buildDistinctParts(vx355_agg& h, const vx355_agg_spec& spec) {
     os.step = VX355_STEP_SINGLE;
     os.ignore_null_keys = spec.ignore_null_keys;
     os.flags = spec.flags;
-    h.distinct.back().outer = makeChild(h, os);
-    h.distinct.back().outer->keysOptional = true;
-    h.distinct.back().outer->unorderedOutput = false;  // rows pair up with the parent's by order
+    part.outer = makeChild(h, os);
+    part.outer->keysOptional = true;
+    part.outer->unorderedOutput = false;  // rows pair up with the parent's by order
+  }
+}
+
+// Ranks of the m strings of 'views' (nulls get an arbitrary one): part.rank[row], part.sortedRows[rank].
+void rankStrings(vx355_agg::DistinctPart& part, const uint4* views, const uint64_t* nulls, int64_t m) {
+  auto& rt = Runtime::get();
+  const size_t cap = static_cast<size_t>(std::max<int64_t>(m, 1));
+  uint32_t* perm = static_cast<uint32_t*>(part.perm.ensure(cap * 4 + 64));
+  uint32_t* permTmp = static_cast<uint32_t*>(part.permTmp.ensure(cap * 4 + 64));
+  uint64_t* keys = static_cast<uint64_t*>(part.sortKeys.ensure(cap * 8 + 64));
+  uint64_t* keysTmp = static_cast<uint64_t*>(part.sortKeysTmp.ensure(cap * 8 + 64));
+  int64_t* rank = static_cast<int64_t*>(part.rank.ensure(cap * 8 + 64));
+  part.sortedRows = perm;
+  if (m == 0) {
+    return;
+  }
+  const int grid = static_cast<int>(ceilDiv(m, 256));
+  HIP_OK(hipMemsetAsync(keys, 0, 4, rt.stream));
+  VX_LAUNCH("k_str_max_len", k_str_max_len, streamGrid(m, 256), 256, 0, views, nulls, m, reinterpret_cast<uint32_t*>(keys));
+  uint32_t maxLen = 0;
+  copyOut(&maxLen, VX355_MEM_HOST, keys, 4);
+  VX_LAUNCH("k_iota_u32", k_iota_u32, grid, 256, 0, perm, m);
+  const int levels = static_cast<int>((static_cast<uint64_t>(maxLen) + 7) / 8);
+  for (int level = -1, pass = 0; pass <= levels; ++pass) {
+    VX_LAUNCH("k_str_sort_key", k_str_sort_key, grid, 256, 0, views, nulls, perm, m, level, keys);
+    bool inTmp = false;
+    sortPairsU64U32(keys, perm, keysTmp, permTmp, static_cast<size_t>(m), part.sortScratch, &inTmp, level < 0 ? 32 : 64);
+    if (inTmp) {
+      std::swap(keys, keysTmp);
+      std::swap(perm, permTmp);
+    }
+    level = levels - 1 - pass;  // after the length: the last word first
+  }
+  part.sortedRows = perm;
+  VX_LAUNCH("k_rank_from_perm", k_rank_from_perm, grid, 256, 0, perm, m, rank);
+}
+
+// noMoreInput of a min / max over strings: all of dedup's rows at once, the strings ranked,
+// min / max of the ranks per group.
+void pumpStringMinMax(vx355_agg& h, vx355_agg::DistinctPart& part) {
+  auto& rt = Runtime::get();
+  vx355_agg& dedup = *part.dedup;
+  vx355_agg& outer = *part.outer;
+  flushPending(dedup);
+  dedup.noMoreInput = true;
+  if (dedup.numOutput < 0) {
+    finalize(dedup);
+  }
+  const int64_t total = dedup.numOutput;
+  if (total > (1LL << 31) - 64) {
+    VX_THROW(VX355_EUNSUPPORTED, "min / max over strings: more than 2^31 distinct (keys, string) rows");
+  }
+  const int32_t nc = static_cast<int32_t>(dedup.outTypes.size());
+  const int32_t nk = static_cast<int32_t>(h.keys.size());
+  const size_t cap = static_cast<size_t>(std::max<int64_t>(total, 1));
+  const size_t words = (cap + 63) / 64;
+  part.pairValues.resize(nc);
+  part.pairNulls.resize(nc);
+  std::vector<vx355_out_column> out(nc);
+  for (int32_t c = 0; c < nc; ++c) {
+    const int w = kindWidth(dedup.outTypes[c]);
+    out[c].type_kind = dedup.outTypes[c];
+    out[c].mem = VX355_MEM_DEVICE;
+    out[c].values = part.pairValues[c].ensure((w == 0 ? words * 8 : cap * w) + 64);
+    out[c].nulls = static_cast<uint64_t*>(part.pairNulls[c].ensure(words * 8 + 64));
+  }
+  int32_t n = 0, fin = 0;
+  getOutput(dedup, out.data(), nc, static_cast<int32_t>(cap), &n, &fin);
+  if (!fin) {
+    VX_THROW(VX355_EINTERNAL, "dedup table listed fewer rows than it holds");
+  }
+  rankStrings(part, static_cast<const uint4*>(out[nk].values), out[nk].nulls, n);
+  if (n > 0) {
+    std::vector<vx355_column> in(nc);
+    for (int32_t c = 0; c < nc; ++c) {
+      in[c] = vx355_column{};
+      in[c].type_kind = out[c].type_kind;
+      in[c].encoding = VX355_FLAT;
+      in[c].values = out[c].values;
+      in[c].nulls = out[c].nulls;
+      in[c].mem = VX355_MEM_DEVICE;
+    }
+    in[nk].type_kind = VX355_BIGINT;
+    in[nk].values = part.rank.ptr();
+    vx355_batch b{n, nc, in.data()};
+    addInput(outer, &b);
+  }
+  outer.noMoreInput = true;
+  rt.sync();
+  // dedup stays: the views of strings longer than 12 bytes point into its arena
+}
+
+// One page of a string min / max column: outer's ranks -> views -> the caller's column.
+void stringMinMaxOutput(vx355_agg& h, vx355_agg::DistinctPart& part, vx355_out_column& dst, int32_t maxRows,
+                        int32_t expected) {
+  auto& rt = Runtime::get();
+  const int32_t nk = static_cast<int32_t>(h.keys.size());
+  const size_t cap = static_cast<size_t>(std::max(maxRows, 1));
+  const size_t words = (cap + 63) / 64;
+  std::vector<vx355_out_column> theirs(nk + 1);
+  for (int32_t k = 0; k < nk; ++k) {
+    theirs[k] = vx355_out_column{h.keys[k].kind, VX355_MEM_DEVICE, nullptr, nullptr};
+  }
+  theirs[nk] = vx355_out_column{VX355_BIGINT, VX355_MEM_DEVICE, part.outRank.ensure(cap * 8 + 64),
+                                static_cast<uint64_t*>(part.outRankNulls.ensure(words * 8 + 64))};
+  int32_t n = 0, fin = 0;
+  getOutput(*part.outer, theirs.data(), nk + 1, maxRows, &n, &fin);
+  if (n != expected) {
+    VX_THROW(VX355_EINTERNAL, "string min / max lists " + std::to_string(n) + " groups, the operator " +
+                                 std::to_string(expected));
+  }
+  if (n == 0) {
+    return;
+  }
+  VX_CHECK_ARG(dst.values != nullptr, "output column without values buffer");
+  const bool host = dst.mem == VX355_MEM_HOST;
+  uint4* views = host ? static_cast<uint4*>(part.outViews.ensure(cap * 16 + 64)) : static_cast<uint4*>(dst.values);
+  uint64_t* nulls = host ? static_cast<uint64_t*>(part.outViewNulls.ensure(words * 8 + 64)) : dst.nulls;
+  const int32_t sv = nk;  // dedup's columns: keys..., string [, mask]
+  VX_LAUNCH("k_rank_to_view", k_rank_to_view, static_cast<int>(ceilDiv(n, 256)), 256, 0,
+            static_cast<const int64_t*>(part.outRank.ptr()), static_cast<const uint64_t*>(part.outRankNulls.ptr()), n,
+            part.sortedRows, static_cast<const uint4*>(part.pairValues[sv].ptr()), views, nulls);
+  if (host) {
+    copyOutAsync(dst.values, VX355_MEM_HOST, views, static_cast<size_t>(n) * 16);
+    if (dst.nulls) {
+      copyOutAsync(dst.nulls, VX355_MEM_HOST, nulls, static_cast<size_t>(ceilDiv(n, 64)) * 8);
+    }
+    rt.sync();
+    fetchLongStrings(static_cast<char*>(dst.values), n, h.hostStrings);
+  } else {
+    rt.sync();
   }
 }
 
@@ -4383,25 +4624,27 @@ int vx355_agg_create(const vx355_agg_spec* spec, vx355_agg** out) {
   configureFromEnv(*h);
   // DISTINCT aggregates get their own tables; this operator keeps the others.
   std::vector<vx355_agg_fn> plain;
-  bool anyDistinct = false;
+  bool anyDistinct = false, anyParts = false;
   for (int32_t i = 0; i < spec->num_aggs; ++i) {
     vx355_agg_fn f = spec->aggs[i];
-    const bool d = needsDistinctSet(f);
+    const bool ds = needsDistinctSet(f);
+    const bool d = ds || isStringMinMax(f);
     if ((f.flags & VX355_AGG_FN_DISTINCT) && f.kind == VX355_AGG_COUNT_STAR) {
       VX_THROW(VX355_EINVAL, "count(*) has no input to be DISTINCT over");
     }
-    anyDistinct = anyDistinct || d;
+    anyDistinct = anyDistinct || ds;
+    anyParts = anyParts || d;
     h->specIsDistinct.push_back(d ? 1 : 0);
     if (!d) {
       f.flags &= ~VX355_AGG_FN_DISTINCT;
       plain.push_back(f);
     }
   }
-  if (anyDistinct) {
-    if (spec->step != VX355_STEP_SINGLE) {
-      // GroupingSet.cpp:117-121
-      VX_THROW(VX355_EUSER, "Partial aggregations over distinct inputs are not supported");
-    }
+  if (anyDistinct && spec->step != VX355_STEP_SINGLE) {
+    // GroupingSet.cpp:117-121
+    VX_THROW(VX355_EUSER, "Partial aggregations over distinct inputs are not supported");
+  }
+  if (anyParts) {
     vx355_agg_spec mainSpec = *spec;
     mainSpec.num_aggs = static_cast<int32_t>(plain.size());
     mainSpec.aggs = plain.data();
@@ -4412,7 +4655,8 @@ int vx355_agg_create(const vx355_agg_spec* spec, vx355_agg** out) {
     size_t nextPlain = static_cast<size_t>(spec->num_keys), nextPart = 0;
     for (int32_t i = 0; i < spec->num_aggs; ++i) {
       if (h->specIsDistinct[i]) {
-        h->fullOutTypes.push_back(h->distinct[nextPart++].outer->outTypes.back());
+        const auto& part = h->distinct[nextPart++];
+        h->fullOutTypes.push_back(part.stringMinMax ? spec->aggs[i].input_type : part.outer->outTypes.back());
       } else {
         h->fullOutTypes.push_back(h->outTypes[nextPlain++]);
       }
@@ -4479,7 +4723,11 @@ int vx355_agg_no_more_input(vx355_agg* h) {
   flushPending(*h);
   if (!h->noMoreInput) {
     for (auto& d : h->distinct) {
-      pumpDistinct(*h, d);
+      if (d.stringMinMax) {
+        pumpStringMinMax(*h, d);
+      } else {
+        pumpDistinct(*h, d);
+      }
     }
   }
   h->noMoreInput = true;
@@ -4516,8 +4764,19 @@ int vx355_agg_get_output(vx355_agg* h, vx355_out_column* cols, int32_t num_cols,
         mine.push_back(cols[nk + i]);
       }
     }
+    h->hostStrings.clear();
+    const bool keepStrings = h->generic && h->hasStringKeys;  // getOutput clears the list itself then
+    std::vector<std::vector<char>> keyStrings;
     getOutput(*h, mine.data(), static_cast<int32_t>(mine.size()), max_rows, n_out, finished);
+    if (keepStrings) {
+      keyStrings.swap(h->hostStrings);
+    }
     for (auto& d : h->distinct) {
+      if (d.stringMinMax) {
+        VX_CHECK_ARG(cols[nk + d.specIndex].type_kind == h->fullOutTypes[nk + d.specIndex], "output column type mismatch");
+        stringMinMaxOutput(*h, d, cols[nk + d.specIndex], max_rows, *n_out);
+        continue;
+      }
       std::vector<vx355_out_column> theirs(nk + 1);
       for (int32_t k = 0; k < nk; ++k) {
         theirs[k] = vx355_out_column{h->keys[k].kind, VX355_MEM_DEVICE, nullptr, nullptr};
@@ -4530,6 +4789,9 @@ int vx355_agg_get_output(vx355_agg* h, vx355_out_column* cols, int32_t num_cols,
                                      std::to_string(*n_out));
       }
     }
+    for (auto& block : keyStrings) {
+      h->hostStrings.push_back(std::move(block));
+    }
   }
   VX_API_END
 }
@@ -4538,6 +4800,9 @@ int vx355_agg_flush(vx355_agg* h) {
   VX_API_BEGIN_CTX(VX_CTX_OF(h))
   VX_CHECK_ARG(h, "NULL argument");
   VX_CHECK_ARG(!h->noMoreInput, "flush after noMoreInput");
+  if (!h->distinct.empty()) {
+    VX_THROW(VX355_EUNSUPPORTED, "partial flush with min / max over strings");
+  }
   if (finalOutput(h->step) || h->keys.empty()) {
     // HashAggregation.cpp:218-224: only partial output is flushed, never a global aggregation
     VX_THROW(VX355_EINVAL, "flush applies to partial / intermediate steps with grouping keys");
@@ -4553,7 +4818,7 @@ int vx355_agg_to_intermediate(vx355_agg* h, const vx355_batch* batch, vx355_out_
   VX_API_BEGIN_CTX(VX_CTX_OF(h))
   VX_CHECK_ARG(h, "NULL argument");
   if (!h->distinct.empty()) {
-    VX_THROW(VX355_EUNSUPPORTED, "toIntermediate with DISTINCT aggregates");
+    VX_THROW(VX355_EUNSUPPORTED, "toIntermediate with DISTINCT aggregates or min / max over strings");
   }
   toIntermediate(*h, batch, cols, num_cols);
   VX_API_END
