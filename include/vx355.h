@@ -304,6 +304,46 @@ int vx355_partition_scatter(
     int64_t* counts_out,
     int32_t mem);
 
+/* ---- PrestoPage wire format (serializers/PrestoSerializer.h) --------------- */
+
+typedef enum vx355_page_flags {
+  /* A PrestoOutputStreamListener is attached (serializers/PrestoSerializerSerializationUtils.h:
+   * 167-187): codec marker bit 4 and the CRC32 of [column count + columns | codec | numRows |
+   * uncompressedSize] in the header. Host output only. Without it codec and checksum are 0. */
+  VX355_PAGE_CHECKSUM = 1,
+  /* PrestoOptions::useLosslessTimestamp: {seconds, nanos} instead of milliseconds. */
+  VX355_PAGE_LOSSLESS_TIMESTAMP = 2
+} vx355_page_flags;
+
+/* What PartitionedOutput's Destination does with the rows routed to it
+ * (exec/PartitionedOutput.cpp:59-133: IterativeVectorSerializer::append(rows) + flush), for all
+ * destinations of a batch in one call: page p holds the batch rows
+ * rows[offsets[p] .. offsets[p + 1]) in that order (rows == NULL: the batch rows themselves in
+ * that range), every column flattened, uncompressed:
+ *   numRows i32 | codec i8 | uncompressedSize i32 | size i32 | checksum i64 | numColumns i32 |
+ *   per column: encoding name (i32 length + BYTE_ARRAY / SHORT_ARRAY / INT_ARRAY / LONG_ARRAY /
+ *   VARIABLE_WIDTH, PrestoSerializerSerializationUtils.cpp:997-1040) | numRows i32 |
+ *   [VARIABLE_WIDTH: i32 end offset per row] | hasNulls i8 [| null bits, first row in the most
+ *   significant bit, 1 = null] | [VARIABLE_WIDTH: total bytes i32] | the non-null values
+ *   (VectorStream::flush, serializers/VectorStream.cpp:207-299).
+ * BOOLEAN travels as one byte per value, TIMESTAMP as milliseconds (Timestamp::toMillis; out
+ * of range -> VX355_EUSER) unless VX355_PAGE_LOSSLESS_TIMESTAMP. A range without rows yields
+ * no bytes (Destination::flush returns early). offsets / page_offsets are host arrays of
+ * num_pages + 1 entries; rows lives in rows_mem, out in out_mem. out == NULL only fills
+ * page_offsets (the exact sizes: page p occupies [page_offsets[p], page_offsets[p + 1]) of out),
+ * so the caller can allocate and call again. */
+int vx355_presto_serialize(
+    const vx355_batch* batch,
+    const int32_t* rows,
+    int32_t rows_mem,
+    const int64_t* offsets,
+    int32_t num_pages,
+    int32_t flags,
+    void* out,
+    int64_t out_capacity,
+    int32_t out_mem,
+    int64_t* page_offsets);
+
 /* ---- FilterProject for the TPC-H Q1 / Q3 expression class ----------------- */
 
 /* The step immediately upstream of HashAggregation / HashProbe

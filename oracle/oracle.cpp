@@ -9,6 +9,7 @@
 #include <string>
 #include <cstdio>
 
+#include "presto_page.h"
 #include "table.h"
 
 namespace orc {
@@ -1290,6 +1291,36 @@ int orc_partition(const uint64_t* hashes, int32_t num_rows, int32_t kind, int32_
     }
   }
   return VX355_OK;
+}
+
+// PartitionedOutput's pages: see presto_page.h. Same contract as vx355_presto_serialize with
+// host buffers.
+int orc_presto_serialize(const vx355_batch* batch, const int32_t* rows, const int64_t* offsets, int32_t num_pages,
+                         int32_t flags, void* out, int64_t out_capacity, int64_t* page_offsets) {
+  ORC_TRY
+  int64_t at = 0;
+  for (int32_t p = 0; p < num_pages; ++p) {
+    page_offsets[p] = at;
+    if (offsets[p + 1] == offsets[p]) {
+      continue;
+    }
+    std::vector<unsigned char> page;
+    try {
+      page = prestoPage(*batch, rows, offsets[p], offsets[p + 1], (flags & VX355_PAGE_CHECKSUM) != 0,
+                        (flags & VX355_PAGE_LOSSLESS_TIMESTAMP) != 0);
+    } catch (const UserErrorTag& e) {
+      throw UserError(e.what());
+    }
+    if (out) {
+      if (at + static_cast<int64_t>(page.size()) > out_capacity) {
+        throw std::runtime_error("orc_presto_serialize: output buffer too small");
+      }
+      std::memcpy(static_cast<char*>(out) + at, page.data(), page.size());
+    }
+    at += static_cast<int64_t>(page.size());
+  }
+  page_offsets[num_pages] = at;
+  ORC_CATCH
 }
 
 // FilterProject::filter + project (exec/FilterProject.cpp:102-275) for

@@ -78,6 +78,10 @@ int orc_filter_compact(const uint64_t* values, const uint64_t* nulls, const uint
 int orc_partition(const uint64_t* hashes, int32_t num_rows, int32_t kind, int32_t num_partitions,
                   int32_t bit_begin, int32_t bit_end, uint32_t* partitions_out);
 
+/* PrestoPage writer (oracle/presto_page.h): vx355_presto_serialize with host buffers. */
+int orc_presto_serialize(const vx355_batch* batch, const int32_t* rows, const int64_t* offsets, int32_t num_pages,
+                         int32_t flags, void* out, int64_t out_capacity, int64_t* page_offsets);
+
 /* FilterProject for the vx355_filter_project expression class: row-at-a-time
  * restatement of exec/FilterProject.cpp:102-275 + exec/OperatorUtils.cpp:231-257. */
 int orc_filter_project(const vx355_batch* batch, const vx355_filter_term* terms, int32_t n_terms,

@@ -71,6 +71,7 @@ def lib():
                                 i32, vp, i32, vp, vp, C.POINTER(i32)]
     L.orc_filter_compact.argtypes = [vp, vp, vp, i32, vp, C.POINTER(i32)]
     L.orc_partition.argtypes = [vp, i32, i32, i32, i32, i32, vp]
+    L.orc_presto_serialize.argtypes = [C.POINTER(abi.Batch), vp, vp, i32, i32, vp, C.c_int64, vp]
     L.orc_filter_project.argtypes = [C.POINTER(abi.Batch), C.POINTER(abi.FilterTerm), i32,
                                      C.POINTER(abi.Projection), i32, vp, C.POINTER(i32),
                                      C.POINTER(vp), C.POINTER(vp)]
@@ -251,6 +252,24 @@ def partition(hashes, kind, num_partitions=0, bit_begin=0, bit_end=0):
     _check(lib().orc_partition(hashes.ctypes.data, len(hashes), kind, num_partitions, bit_begin,
                                bit_end, out.ctypes.data))
     return out[: len(hashes)]
+
+
+def presto_serialize(batch, offsets, rows=None, flags=0):
+    """oracle/presto_page.h: -> list of bytes objects, one page per row range."""
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    num_pages = len(offsets) - 1
+    rows_ptr = None
+    if rows is not None:
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        rows_ptr = rows.ctypes.data
+    page_offsets = np.zeros(num_pages + 1, dtype=np.int64)
+    _check(lib().orc_presto_serialize(batch.ref(), rows_ptr, offsets.ctypes.data, num_pages, flags, None, 0,
+                                      page_offsets.ctypes.data))
+    total = int(page_offsets[-1])
+    out = np.zeros(max(total, 1), dtype=np.uint8)
+    _check(lib().orc_presto_serialize(batch.ref(), rows_ptr, offsets.ctypes.data, num_pages, flags,
+                                      out.ctypes.data, total, page_offsets.ctypes.data))
+    return [out[page_offsets[p]:page_offsets[p + 1]].tobytes() for p in range(num_pages)]
 
 
 def make_agg_spec(key_cols, key_types, aggs, step, ignore_null_keys=False, flags=0):

@@ -262,3 +262,61 @@ def test_distinct_value_id_mode_matches_the_vector_hasher(oracle, vx, kind):
         rows_g, ids_g = d.lookup(abi.HostBatch([probe]), 0, rows=prow, multiplier=mult)
         assert (np.asarray(rows_g) == np.asarray(rows_e)).all()
         assert (ids_g[np.asarray(rows_e)] == ids_e[np.asarray(rows_e)]).all()
+
+
+@pytest.mark.parametrize("device_resident", [False, True])
+def test_presto_pages_equal_the_oracle_byte_for_byte(oracle, vx, device_resident):
+    """vx355_presto_serialize vs oracle/presto_page.h: every kind, null bitmaps present and
+    absent, a row list, page sizes around the 8-row null byte and the 2048-row tile, empty
+    ranges, strings beyond the inline limit, checksums, lossless timestamps; and the pages
+    decode back to the input rows through the independent reader."""
+    from presto_page_reader import check_pages_decode_to_rows, millis, random_page_batch
+    rng = np.random.default_rng(707)
+    n = 9000
+    batch, py = random_page_batch(rng, n)
+    kinds = [c.kind for c in batch.columns]
+    rows = rng.permutation(n).astype(np.int32)
+    offsets = [0, 0, 1, 8, 17, 2065, 4113, 4113, 4114 + 2047, n]
+    src = vx.to_device(batch) if device_resident else batch
+    for flags in (0, abi.PAGE_CHECKSUM, abi.PAGE_LOSSLESS_TIMESTAMP):
+        exp = oracle.presto_serialize(batch, offsets, rows, flags)
+        got = vx.presto_serialize(src, offsets, rows, flags)
+        assert [len(g) for g in got] == [len(e) for e in exp]
+        assert got == exp, f"flags {flags}"
+    check_pages_decode_to_rows(vx.presto_serialize(src, offsets, rows), millis(py), kinds, offsets, rows)
+    # pages left in HBM (for an exchange that sends from device memory); no checksum there
+    assert vx.presto_serialize(src, offsets, rows, device_out=True) == oracle.presto_serialize(batch, offsets, rows)
+    with pytest.raises(Exception) as e:
+        vx.presto_serialize(src, offsets, rows, abi.PAGE_CHECKSUM, device_out=True)
+    assert "host output" in str(e.value)
+    # no row list: the ranges are batch rows; a batch without any null has no bitmap at all
+    dense, _ = random_page_batch(rng, 5000, with_nulls=False)
+    assert vx.presto_serialize(dense, [0, 2048, 5000]) == oracle.presto_serialize(dense, [0, 2048, 5000])
+
+
+def test_presto_pages_of_encoded_columns_are_flattened(oracle, vx):
+    """Dictionary and constant inputs (the iterative serializer always flattens,
+    serializers/PrestoSerializer.h:27-35)."""
+    rng = np.random.default_rng(808)
+    n = 5000
+    base = rng.integers(0, 1000, 50).astype(np.int64)
+    idx = rng.integers(0, 50, n).astype(np.int32)
+    words = [b"alpha", b"a dictionary value longer than twelve bytes", b""]
+    cols = [abi.HostColumn(abi.BIGINT, base, valid=rng.random(n) > 0.2, encoding=abi.DICTIONARY, indices=idx),
+            abi.HostColumn(abi.VARCHAR, words, encoding=abi.DICTIONARY, indices=rng.integers(0, 3, n).astype(np.int32)),
+            abi.HostColumn(abi.DOUBLE, np.array([2.5]), encoding=abi.CONSTANT),
+            abi.HostColumn(abi.INTEGER, np.array([7], dtype=np.int32), valid=[False], encoding=abi.CONSTANT)]
+    batch = abi.HostBatch(cols, n)
+    offsets = [0, 3000, n]
+    assert vx.presto_serialize(batch, offsets) == oracle.presto_serialize(batch, offsets)
+
+
+def test_presto_page_timestamp_out_of_range_is_a_user_error(oracle, vx):
+    ts = np.array([[2 ** 62, 0]], dtype=np.int64)
+    batch = abi.HostBatch([abi.HostColumn(abi.TIMESTAMP, ts)])
+    for impl in (oracle, vx):
+        with pytest.raises(Exception) as e:
+            impl.presto_serialize(batch, [0, 1])
+        assert "milliseconds" in str(e.value)
+    assert vx.presto_serialize(batch, [0, 1], flags=abi.PAGE_LOSSLESS_TIMESTAMP) == \
+        oracle.presto_serialize(batch, [0, 1], flags=abi.PAGE_LOSSLESS_TIMESTAMP)

@@ -704,3 +704,50 @@ def test_min_max_over_strings_vs_python(oracle):
         assert bool(out[1][1][pos]) == bool(vals) == bool(out[2][1][pos])
         if vals:
             assert out[1][0][pos] == min(vals) and out[2][0][pos] == max(vals)
+
+
+def _i32(v):
+    return int(v).to_bytes(4, "little", signed=True)
+
+
+def test_presto_page_known_answers(oracle):
+    """Pages assembled by hand from the format description: 21-byte header (rows, codec,
+    uncompressed size, size, checksum), column count, then per column the encoding name, the
+    row count, [end offsets,] the null flag, [MSB-first null bits,] [byte count,] non-null values
+    (VectorStream.cpp:207-299, PrestoSerializerSerializationUtils.h:37-45)."""
+    b = abi.HostBatch([abi.HostColumn(abi.BIGINT, np.array([1, 0, 3], dtype=np.int64), valid=[True, False, True]),
+                       abi.HostColumn(abi.VARCHAR, [b"ab", b"", b""], valid=[True, False, True]),
+                       abi.HostColumn(abi.BOOLEAN, [True, False, True])])
+    (page,) = oracle.presto_serialize(b, [0, 3])
+    body = _i32(3)
+    body += _i32(10) + b"LONG_ARRAY" + _i32(3) + b"\x01" + bytes([0b01000000]) + (1).to_bytes(8, "little") + (3).to_bytes(8, "little")
+    body += _i32(14) + b"VARIABLE_WIDTH" + _i32(3) + _i32(2) + _i32(2) + _i32(2) + b"\x01" + bytes([0b01000000]) + _i32(2) + b"ab"
+    body += _i32(10) + b"BYTE_ARRAY" + _i32(3) + b"\x00" + b"\x01\x00\x01"
+    want = _i32(3) + b"\x00" + _i32(len(body)) + _i32(len(body)) + bytes(8) + body
+    assert page == want
+    # with a listener: codec bit 4 and crc32(data | codec | rows | size), zlib's polynomial
+    import zlib
+    (summed,) = oracle.presto_serialize(b, [0, 3], flags=abi.PAGE_CHECKSUM)
+    assert summed[4] == 4 and summed[21:] == body
+    crc = zlib.crc32(body + b"\x04" + _i32(3) + _i32(len(body))) & 0xffffffff
+    assert summed[13:21] == crc.to_bytes(8, "little")
+
+
+from presto_page_reader import check_pages_decode_to_rows as _check_pages_decode_to_rows, millis as _millis, random_page_batch as _random_page_batch  # noqa: E402
+
+
+def test_presto_pages_decode_back_to_the_rows(oracle):
+    rng = np.random.default_rng(606)
+    n = 3000
+    batch, py = _random_page_batch(rng, n)
+    kinds = [c.kind for c in batch.columns]
+    rows = rng.permutation(n).astype(np.int32)
+    offsets = [0, 0, 1, 9, 2057, 2057, n]
+    for flags in (0, abi.PAGE_CHECKSUM):
+        pages = oracle.presto_serialize(batch, offsets, rows, flags)
+        _check_pages_decode_to_rows(pages, _millis(py), kinds, offsets, rows)
+    pages = oracle.presto_serialize(batch, offsets, rows, abi.PAGE_LOSSLESS_TIMESTAMP)
+    _check_pages_decode_to_rows(pages, py, kinds, offsets, rows, lossless=True)
+    # without a row list the ranges address the batch rows themselves
+    pages = oracle.presto_serialize(batch, [0, 100, n])
+    _check_pages_decode_to_rows(pages, _millis(py), kinds, [0, 100, n], None)

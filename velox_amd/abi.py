@@ -77,6 +77,8 @@ class AggSpec(C.Structure):
 
 AGG_UNORDERED_OUTPUT = 1
 AGG_FN_DISTINCT = 1  # vx355_agg_fn.flags
+PAGE_CHECKSUM = 1
+PAGE_LOSSLESS_TIMESTAMP = 2
 
 
 class AggStats(C.Structure):

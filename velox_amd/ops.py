@@ -24,7 +24,7 @@ SYMBOLS = [
     "vx355_device_malloc", "vx355_device_free", "vx355_memcpy_h2d", "vx355_memcpy_d2h",
     "vx355_memset_d", "vx355_synchronize", "vx355_profile_enable", "vx355_profile_reset",
     "vx355_profile_get", "vx355_profile_names", "vx355_hash_columns", "vx355_value_ids",
-    "vx355_filter_compact", "vx355_partition", "vx355_partition_scatter", "vx355_filter_project", "vx355_agg_create", "vx355_agg_set_fused_input", "vx355_agg_add_input",
+    "vx355_filter_compact", "vx355_partition", "vx355_partition_scatter", "vx355_presto_serialize", "vx355_filter_project", "vx355_agg_create", "vx355_agg_set_fused_input", "vx355_agg_add_input",
     "vx355_agg_no_more_input", "vx355_agg_output_types", "vx355_agg_get_output",
     "vx355_agg_get_stats", "vx355_agg_destroy", "vx355_join_build_create",
     "vx355_join_build_add_input", "vx355_join_build_finish", "vx355_join_build_destroy",
@@ -79,6 +79,7 @@ def lib():
     L.vx355_filter_compact.argtypes = [vp, vp, vp, i32, vp, P(i32), i32]
     L.vx355_partition.argtypes = [vp, i32, i32, i32, i32, i32, vp, i32]
     L.vx355_partition_scatter.argtypes = [vp, i32, i32, P(vp), P(i32), i32, P(vp), P(i64), i32]
+    L.vx355_presto_serialize.argtypes = [P(abi.Batch), vp, i32, vp, i32, i32, vp, i64, i32, vp]
     L.vx355_filter_project.argtypes = [P(abi.Batch), P(abi.FilterTerm), i32, P(abi.Projection), i32,
                                        vp, P(i32), P(vp), P(vp), i32]
     L.vx355_agg_create.argtypes = [P(abi.AggSpec), P(vp)]
@@ -295,12 +296,24 @@ class DeviceColumn:
     def __init__(self, host_col):
         self.kind, self.encoding = host_col.kind, host_col.encoding
         self.num_rows, self.base_size = host_col.num_rows, host_col.base_size
+        values = host_col.values
+        self.blob = None
         if host_col.kind in (abi.VARCHAR, abi.VARBINARY):
-            raw = host_col.values.reshape(-1, 16)
+            raw = np.ascontiguousarray(host_col.values).view(np.uint8).reshape(-1, 16).copy()
             sizes = raw[:, 0:4].copy().view(np.uint32).reshape(-1)
-            if (sizes > 12).any():
-                raise ValueError("DeviceColumn: only inline strings (<= 12 bytes)")
-        self.values = DeviceArray(host_col.values)
+            long_rows = np.nonzero(sizes > 12)[0]
+            if len(long_rows):
+                # bytes of the non-inline strings move to one HBM blob, the views point into it
+                ptrs = raw[:, 8:16].copy().view(np.uint64).reshape(-1)
+                parts = [C.string_at(int(ptrs[r]), int(sizes[r])) for r in long_rows]
+                self.blob = DeviceArray(np.frombuffer(b"".join(parts), dtype=np.uint8).copy())
+                at = 0
+                for r, part in zip(long_rows, parts):
+                    ptrs[r] = self.blob.ptr + at
+                    at += len(part)
+                raw[:, 8:16] = ptrs.view(np.uint8).reshape(-1, 8)
+            values = raw
+        self.values = DeviceArray(values)
         self.nulls = DeviceArray(host_col.nulls) if host_col.nulls is not None else None
         self.indices = DeviceArray(host_col.indices) if host_col.indices is not None else None
 
@@ -465,6 +478,35 @@ def partition(hashes, kind, num_partitions=0, bit_begin=0, bit_end=0):
     _check(lib().vx355_partition(hashes.ctypes.data, len(hashes), kind, num_partitions, bit_begin,
                                  bit_end, out.ctypes.data, abi.MEM_HOST))
     return out[: len(hashes)]
+
+
+def presto_serialize(batch, offsets, rows=None, flags=0, device_out=False):
+    """PartitionedOutput's pages (vx355_presto_serialize): -> list of bytes objects, one per
+    row range [offsets[p], offsets[p + 1]) of rows (or of the batch rows when rows is None).
+    device_out: the pages are written to an HBM buffer (and fetched from there)."""
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    num_pages = len(offsets) - 1
+    rows_ptr = None
+    if rows is not None:
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        rows_ptr = rows.ctypes.data
+    page_offsets = np.zeros(num_pages + 1, dtype=np.int64)
+    _check(lib().vx355_presto_serialize(batch.ref(), rows_ptr, abi.MEM_HOST, offsets.ctypes.data, num_pages, flags,
+                                        None, 0, abi.MEM_HOST, page_offsets.ctypes.data))
+    total = int(page_offsets[-1])
+    out = np.zeros(max(total, 1), dtype=np.uint8)
+    again = np.zeros(num_pages + 1, dtype=np.int64)
+    if device_out:
+        dev = DeviceArray(max(total, 1), np.uint8)
+        _check(lib().vx355_presto_serialize(batch.ref(), rows_ptr, abi.MEM_HOST, offsets.ctypes.data, num_pages,
+                                            flags, dev.ptr, total, abi.MEM_DEVICE, again.ctypes.data))
+        if total:
+            _check(lib().vx355_memcpy_d2h(out.ctypes.data, dev.ptr, total))
+    else:
+        _check(lib().vx355_presto_serialize(batch.ref(), rows_ptr, abi.MEM_HOST, offsets.ctypes.data, num_pages,
+                                            flags, out.ctypes.data, total, abi.MEM_HOST, again.ctypes.data))
+    assert (again == page_offsets).all()
+    return [out[page_offsets[p]:page_offsets[p + 1]].tobytes() for p in range(num_pages)]
 
 
 # ---- HashAggregation -------------------------------------------------------
