@@ -83,7 +83,7 @@ __device__ inline uint64_t blockExclusive(uint64_t v, uint64_t* lds, uint64_t* t
 }
 
 __global__ __launch_bounds__(256) void k_page_count(PageArgs a) {
-  __shared__ uint64_t lds[256];
+  __shared__ uint64_t lds[8];
   const int64_t tile = blockIdx.x;
   const int col = blockIdx.y;
   const ColView c = a.cols[col];
@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void k_page_count(PageArgs a) {
   const bool str = isStringKind(c.kind);
   uint64_t nonNull = 0, bytes = 0;
   for (int j = 0; j < kRowsPerLane; ++j) {
-    const int r = threadIdx.x * kRowsPerLane + j;
+    // strings: lane-blocked like k_page_write's string branch; fixed width: lane-cyclic (coalesced)
+    const int r = str ? threadIdx.x * kRowsPerLane + j : j * 256 + static_cast<int>(threadIdx.x);
     if (r < pt.count) {
       const int64_t pos = pt.rowBegin + r;
       const int64_t row = a.rows ? a.rows[pos] : pos;
@@ -103,13 +104,21 @@ __global__ __launch_bounds__(256) void k_page_count(PageArgs a) {
       }
     }
   }
-  uint64_t totalNonNull, totalBytes;
-  blockExclusive(nonNull, lds, &totalNonNull);
-  blockExclusive(bytes, lds, &totalBytes);
+  // workgroup totals: wave shuffles, then four partial sums through LDS
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    nonNull += shfl64(nonNull, lane() ^ off);
+    bytes += shfl64(bytes, lane() ^ off);
+  }
+  if (lane() == 0) {
+    lds[(threadIdx.x >> 6) * 2] = nonNull;
+    lds[(threadIdx.x >> 6) * 2 + 1] = bytes;
+  }
+  blockSync();
   if (threadIdx.x == 0) {
     uint64_t* o = a.counts + (static_cast<int64_t>(col) * a.numTiles + tile) * 2;
-    o[0] = totalNonNull;
-    o[1] = totalBytes;
+    o[0] = lds[0] + lds[2] + lds[4] + lds[6];
+    o[1] = lds[1] + lds[3] + lds[5] + lds[7];
   }
 }
 
@@ -127,61 +136,69 @@ __global__ __launch_bounds__(256) void k_page_write(PageArgs a) {
   const PageTile pt = a.tiles[tile];
   const TileOut lo = a.layout[static_cast<int64_t>(col) * a.numTiles + tile];
   const bool str = isStringKind(c.kind);
-  const int first = threadIdx.x * kRowsPerLane;
-  // validity of this lane's 8 rows
-  uint32_t valid = 0;
-  int64_t rowOf[kRowsPerLane];
-  for (int j = 0; j < kRowsPerLane; ++j) {
-    rowOf[j] = -1;
-    const int r = first + j;
-    if (r < pt.count) {
-      const int64_t pos = pt.rowBegin + r;
-      rowOf[j] = a.rows ? a.rows[pos] : pos;
-      if (!colIsNull(c, rowOf[j])) {
-        valid |= 1u << j;
-      }
-    }
-  }
-  if (lo.nullPos != ~0ULL && first < pt.count) {
-    // wire polarity: 1 = null, first row in the most significant bit (ByteOutputStream with
-    // isReverseBitOrder, VectorStream.cpp:64); bits past the last row stay 0
-    uint32_t byte = 0;
-    for (int j = 0; j < kRowsPerLane; ++j) {
-      if (first + j < pt.count && !((valid >> j) & 1)) {
-        byte |= 0x80u >> j;
-      }
-    }
-    a.out[lo.nullPos + static_cast<uint64_t>(pt.pageRowBegin + first) / 8] = static_cast<unsigned char>(byte);
-  }
   if (!str) {
-    uint64_t total;
-    uint64_t at = blockExclusive(__popc(valid), lds, &total);
-    int w;
-    switch (c.kind) {
-      case VX355_BOOLEAN:
-      case VX355_TINYINT:
-        w = 1;
-        break;
-      case VX355_SMALLINT:
-        w = 2;
-        break;
-      case VX355_INTEGER:
-      case VX355_REAL:
-        w = 4;
-        break;
-      case VX355_TIMESTAMP:
-        w = a.lossless ? 16 : 8;
-        break;
-      default:
-        w = 8;
-    }
+    // Fixed width. A wave owns 512 consecutive rows of the tile and lane l takes rows
+    // base + j * 64 + l: every load instruction reads 64 consecutive values, the validity of
+    // 64 rows is one ballot (= 8 finished null bytes), and the compacted position of a value
+    // is the count of valid rows before it: earlier waves, earlier ballots, lower lanes.
+    __shared__ uint32_t waveTotals[4];
+    const int wave = threadIdx.x >> 6;
+    const int ln = lane();
+    const int waveBase = wave * (kPageTile / 4);
+    uint64_t ballots[kRowsPerLane];
+    int64_t rowOf[kRowsPerLane];
+    uint32_t mine = 0;
+#pragma unroll
     for (int j = 0; j < kRowsPerLane; ++j) {
-      if (!((valid >> j) & 1)) {
+      const int r = waveBase + j * 64 + ln;
+      bool v = false;
+      rowOf[j] = -1;
+      if (r < pt.count) {
+        const int64_t pos = pt.rowBegin + r;
+        rowOf[j] = a.rows ? a.rows[pos] : pos;
+        v = !colIsNull(c, rowOf[j]);
+      }
+      ballots[j] = ballot(v);
+      mine += static_cast<uint32_t>(popc64(ballots[j]));
+      if (lo.nullPos != ~0ULL && ln < 8) {
+        // wire polarity: 1 = null, first row in the most significant bit (ByteOutputStream with
+        // isReverseBitOrder, VectorStream.cpp:64); bits past the last row stay 0
+        const int firstRow = waveBase + j * 64 + ln * 8;
+        if (firstRow < pt.count) {
+          const uint32_t validBits = static_cast<uint32_t>(ballots[j] >> (ln * 8)) & 0xffu;
+          const int rowsHere = pt.count - firstRow < 8 ? pt.count - firstRow : 8;
+          uint32_t byte = 0;
+          for (int k = 0; k < rowsHere; ++k) {
+            if (!((validBits >> k) & 1)) {
+              byte |= 0x80u >> k;
+            }
+          }
+          a.out[lo.nullPos + static_cast<uint64_t>(pt.pageRowBegin + firstRow) / 8] = static_cast<unsigned char>(byte);
+        }
+      }
+    }
+    if (ln == 0) {
+      waveTotals[wave] = mine;
+    }
+    blockSync();
+    uint64_t run = 0;
+    for (int w2 = 0; w2 < wave; ++w2) {
+      run += waveTotals[w2];
+    }
+    const int w = c.kind == VX355_BOOLEAN || c.kind == VX355_TINYINT ? 1
+        : c.kind == VX355_SMALLINT                                   ? 2
+        : (c.kind == VX355_INTEGER || c.kind == VX355_REAL)          ? 4
+        : c.kind == VX355_TIMESTAMP                                  ? (a.lossless ? 16 : 8)
+                                                                     : 8;
+#pragma unroll
+    for (int j = 0; j < kRowsPerLane; ++j) {
+      const uint64_t at = run + static_cast<uint64_t>(lanePrefix(ballots[j]));
+      run += static_cast<uint64_t>(popc64(ballots[j]));
+      if (!((ballots[j] >> ln) & 1)) {
         continue;
       }
       const int64_t i = colIndex(c, rowOf[j]);
       unsigned char* dst = a.out + lo.valuePos + at * w;
-      ++at;
       switch (c.kind) {
         case VX355_BOOLEAN:
           *dst = bitAt(static_cast<const uint64_t*>(c.values), i) ? 1 : 0;
@@ -217,6 +234,30 @@ __global__ __launch_bounds__(256) void k_page_write(PageArgs a) {
       }
     }
     return;
+  }
+  // VARIABLE_WIDTH: lane-blocked, 8 consecutive rows per lane (one null byte per lane)
+  const int first = threadIdx.x * kRowsPerLane;
+  uint32_t valid = 0;
+  int64_t rowOf[kRowsPerLane];
+  for (int j = 0; j < kRowsPerLane; ++j) {
+    rowOf[j] = -1;
+    const int r = first + j;
+    if (r < pt.count) {
+      const int64_t pos = pt.rowBegin + r;
+      rowOf[j] = a.rows ? a.rows[pos] : pos;
+      if (!colIsNull(c, rowOf[j])) {
+        valid |= 1u << j;
+      }
+    }
+  }
+  if (lo.nullPos != ~0ULL && first < pt.count) {
+    uint32_t byte = 0;
+    for (int j = 0; j < kRowsPerLane; ++j) {
+      if (first + j < pt.count && !((valid >> j) & 1)) {
+        byte |= 0x80u >> j;
+      }
+    }
+    a.out[lo.nullPos + static_cast<uint64_t>(pt.pageRowBegin + first) / 8] = static_cast<unsigned char>(byte);
   }
   // VARIABLE_WIDTH: end offset of every row (a null repeats the previous one), then the bytes
   uint64_t mine = 0;
