@@ -185,6 +185,57 @@ def test_random_aggregation_plans(oracle, vx, seed, monkeypatch):
         assert_columns_equal(merged, exp, mop.kinds, what=f"seed {seed}: partial -> final")
 
 
+LONG_WORDS = WORDS + [b"thirteen bytes", b"a string well beyond the inline limit of a view", b"a string well beyond the inline limit",
+                      b"twelve bytes\x00", b"\xff\xff", b"A\x00"]
+
+
+@pytest.mark.parametrize("seed", range(200))
+def test_random_distinct_and_string_aggregates(oracle, vx, seed, monkeypatch):
+    """DISTINCT sum / count / avg and min / max over VARCHAR mixed with plain aggregates: random
+    key sets (every table mode), encodings, nulls, masks, batch counts; SINGLE step, exact compare."""
+    rng = np.random.default_rng(77000 + seed)
+    monkeypatch.setenv("VX355_JIT", "0")
+    if rng.random() < 0.3:
+        monkeypatch.setenv("VX355_ARRAY_MAX", str(int(rng.choice([0, 64, 4096]))))
+    if rng.random() < 0.3:
+        monkeypatch.setenv("VX355_AGG_COALESCE_ROWS", "0")
+    key_pool = [abi.BIGINT, abi.INTEGER, abi.SMALLINT, abi.BOOLEAN, abi.VARCHAR, abi.DOUBLE]
+    num_keys = int(rng.integers(0, 4))
+    key_types = [int(rng.choice(key_pool)) for _ in range(num_keys)]
+    val_types = [int(rng.choice([abi.DOUBLE, abi.BIGINT, abi.INTEGER, abi.REAL])) for _ in range(2)] + [abi.VARCHAR]
+    has_mask = rng.random() < 0.5
+    layout = key_types + val_types + ([abi.BOOLEAN] if has_mask else [])
+    S = num_keys + 2
+    aggs = []
+    for _ in range(int(rng.integers(1, 6))):
+        mask = len(layout) - 1 if (has_mask and rng.random() < 0.5) else -1
+        what = rng.random()
+        if what < 0.35:
+            aggs.append((int(rng.choice([abi.AGG_MIN, abi.AGG_MAX])), S, abi.VARCHAR, mask))
+        else:
+            v = int(rng.integers(0, 2))
+            fn = int(rng.choice([abi.AGG_SUM, abi.AGG_COUNT, abi.AGG_AVG, abi.AGG_MIN, abi.AGG_MAX]))
+            flags = abi.AGG_FN_DISTINCT if rng.random() < 0.7 else 0
+            aggs.append((fn, num_keys + v, val_types[v], mask, -1, flags))
+    card = int(rng.choice([3, 40, 3000]))
+    batches = []
+    for _ in range(int(rng.integers(1, 4))):
+        n = int(rng.choice([1, 64, 1000, 5000, 30000]))
+        cols = []
+        for j, k in enumerate(layout):
+            sp = _spec(rng, k, n, card)
+            if j == S:  # strings on both sides of the inline limit for min / max
+                m = len(sp["values"]) if isinstance(sp["values"], list) else n
+                sp["values"] = [LONG_WORDS[i] for i in rng.integers(0, len(LONG_WORDS), m)]
+            cols.append(_build(sp))
+        batches.append(abi.HostBatch(cols, n))
+    kw = dict(ignore_null_keys=bool(rng.random() < 0.3))
+    key_cols = list(range(num_keys))
+    exp, _ = run_agg(oracle, batches, key_cols, key_types, aggs, max_rows=100000, **kw)
+    got, gop = run_agg(vx, batches, key_cols, key_types, aggs, max_rows=int(rng.choice([7, 1000, 100000])), **kw)
+    assert_columns_equal(got, exp, gop.kinds, what=f"seed {seed}: keys {key_types} aggs {aggs}")
+
+
 def _canon_join(probe, join_type, max_rows):
     rows = []
     while True:

@@ -4065,7 +4065,7 @@ __global__ __launch_bounds__(256) void k_rank_to_view(const int64_t* ranks, cons
 void getOutput(vx355_agg& h, vx355_out_column* cols, int32_t numCols, int32_t maxRows, int32_t* nOut,
                int32_t* finished) {
   auto& rt = Runtime::get();
-  VX_CHECK_ARG(cols && nOut && finished, "NULL argument");
+  VX_CHECK_ARG((cols || numCols == 0) && nOut && finished, "NULL argument");
   VX_CHECK_ARG(numCols == static_cast<int32_t>(h.outTypes.size()), "wrong number of output columns");
   VX_CHECK_ARG(maxRows > 0, "max_rows must be positive");
   VX_CHECK_ARG(h.noMoreInput || h.flushing, "getOutput before noMoreInput (vx355_agg_flush opens a partial flush)");
