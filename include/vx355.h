@@ -413,7 +413,7 @@ int vx355_filter_project(
 
 typedef enum vx355_agg_kind {
   VX355_AGG_SUM = 0,        /* SumAggregate.cpp:39-118 */
-  VX355_AGG_COUNT = 1,      /* count(x), CountAggregate.cpp:27-147 */
+  VX355_AGG_COUNT = 1,      /* count(x), CountAggregate.cpp:27-147; x of any column type (raw input) */
   VX355_AGG_COUNT_STAR = 2, /* count(*) */
   VX355_AGG_MIN = 3,        /* MinMaxAggregateBase.cpp:101-305; over VARCHAR / VARBINARY input
                                :305-480 (any step: the intermediate type is the input type;

@@ -386,8 +386,14 @@ class Aggregation {
         DistinctSet& set = distinct_[{g, i}];
         SetValue v;
         v.isNull = in->isNull(r);
+        std::string identity;
         if (!v.isNull) {
-          if (intSum) {
+          if (isStringKind(f.input_type)) {
+            // count(DISTINCT s): the set compares contents (SetAccumulator<StringView>)
+            uint8_t tmp;
+            const auto* sv = static_cast<const StringView*>(in->valuePtr(r, &tmp));
+            identity.assign(sv->data(), sv->size);
+          } else if (intSum) {
             v.i = in->int64At(r);
             v.image = static_cast<uint64_t>(v.i);
           } else {
@@ -402,13 +408,16 @@ class Aggregation {
               std::memcpy(&v.image, &v.d, 8);
             }
           }
+          if (!isStringKind(f.input_type)) {
+            identity.assign(reinterpret_cast<const char*>(&v.image), 8);
+          }
         }
-        if (set.seen.insert({v.isNull, v.isNull ? 0 : v.image}).second) {
+        if (set.seen.insert({v.isNull, identity}).second) {
           set.ordered.push_back(v);
         }
         continue;
       }
-      if (isStringKind(f.input_type)) {
+      if (isStringKind(f.input_type) && (f.kind == VX355_AGG_MIN || f.kind == VX355_AGG_MAX)) {
         // MinMaxAggregateBase.cpp:395-419 (non-numeric doUpdate): SingleValueAccumulator holds
         // the current extreme; compare() is StringView::compare (bytes, then length). Raw and
         // intermediate input are the same thing (:377-381).
@@ -589,7 +598,7 @@ class Aggregation {
     uint64_t image = 0;
   };
   struct DistinctSet {
-    std::set<std::pair<bool, uint64_t>> seen;
+    std::set<std::pair<bool, std::string>> seen;
     std::vector<SetValue> ordered;
   };
   std::map<std::pair<char*, size_t>, DistinctSet> distinct_;

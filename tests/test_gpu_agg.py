@@ -1080,3 +1080,32 @@ def test_min_max_over_strings_partial_then_final(oracle, vx):
     final_aggs = [(abi.AGG_MIN, 1, abi.VARCHAR), (abi.AGG_MAX, 2, abi.VARCHAR), (abi.AGG_COUNT_STAR, 3, abi.BIGINT)]
     got, gop = run_agg(vx, partials, [0], [abi.BIGINT], final_aggs, abi.STEP_FINAL)
     assert_columns_equal(got, exp, gop.kinds, what="string min/max partial -> final")
+
+
+def test_count_over_any_column_type(oracle, vx):
+    """count(x) only reads x's validity (CountAggregate.cpp:27-147): VARCHAR (inline and not),
+    TIMESTAMP, BOOLEAN, REAL inputs, flat and dictionary encoded, with and without DISTINCT."""
+    rng = np.random.default_rng(4711)
+    n = 40000
+    k = rng.integers(0, 300, n).astype(np.int64)
+    s = [_WORDS[i] for i in rng.integers(0, len(_WORDS), n)]
+    ts = np.stack([rng.integers(0, 5, n), rng.integers(0, 3, n)], axis=1).astype(np.int64)
+    b = rng.random(n) > 0.5
+    r = rng.integers(0, 8, n).astype(np.float32)
+    base = [_WORDS[i] for i in range(6)]
+    cols = [abi.HostColumn(abi.BIGINT, k),
+            abi.HostColumn(abi.VARCHAR, s, valid=rng.random(n) > 0.3),
+            abi.HostColumn(abi.TIMESTAMP, ts, valid=rng.random(n) > 0.1),
+            abi.HostColumn(abi.BOOLEAN, b, valid=rng.random(n) > 0.5),
+            abi.HostColumn(abi.REAL, r),
+            abi.HostColumn(abi.VARCHAR, base, valid=rng.random(n) > 0.2, encoding=abi.DICTIONARY,
+                           indices=rng.integers(0, 6, n).astype(np.int32))]
+    hb = abi.HostBatch(cols, n)
+    D = abi.AGG_FN_DISTINCT
+    aggs = [(abi.AGG_COUNT, 1, abi.VARCHAR), (abi.AGG_COUNT, 2, abi.TIMESTAMP), (abi.AGG_COUNT, 3, abi.BOOLEAN),
+            (abi.AGG_COUNT, 4, abi.REAL), (abi.AGG_COUNT, 5, abi.VARCHAR), (abi.AGG_COUNT_STAR, -1, abi.BIGINT),
+            (abi.AGG_COUNT, 1, abi.VARCHAR, -1, -1, D), (abi.AGG_COUNT, 3, abi.BOOLEAN, -1, -1, D)]
+    for keys, kinds in (([0], [abi.BIGINT]), ([], [])):
+        exp, _ = run_agg(oracle, [hb, hb], keys, kinds, aggs)
+        got, gop = run_agg(vx, [hb, hb], keys, kinds, aggs)
+        assert_columns_equal(got, exp, gop.kinds, what=f"count any type, keys {keys}")

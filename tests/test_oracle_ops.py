@@ -751,3 +751,11 @@ def test_presto_pages_decode_back_to_the_rows(oracle):
     # without a row list the ranges address the batch rows themselves
     pages = oracle.presto_serialize(batch, [0, 100, n])
     _check_pages_decode_to_rows(pages, _millis(py), kinds, [0, 100, n], None)
+
+
+def test_count_of_a_string_column_counts_its_non_null_rows(oracle):
+    s = [b"a", b"", b"a string longer than twelve bytes", b"a", b"a string longer than twelve byteS", b"abcdX", b"abcdY"]
+    batch = abi.HostBatch([abi.HostColumn(abi.VARCHAR, s, valid=[True, False, True, True, True, True, True])])
+    out, _ = _run_agg(oracle, [batch], [], [], [(abi.AGG_COUNT, 0, abi.VARCHAR),
+                                               (abi.AGG_COUNT, 0, abi.VARCHAR, -1, -1, abi.AGG_FN_DISTINCT)])
+    assert out[0][0][0] == 6 and out[1][0][0] == 5

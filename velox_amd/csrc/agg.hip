@@ -2340,7 +2340,9 @@ void buildPlan(vx355_agg& h, const vx355_agg_spec& spec) {
     la.fn = spec.aggs[i];
     const auto& f = la.fn;
     const bool isInt = isIntLike(f.input_type);
-    if (!(isInt || f.input_type == VX355_REAL || f.input_type == VX355_DOUBLE)) {
+    // count(x) only looks at x's nulls: any column type (CountAggregate.cpp:27-147)
+    const bool countsAnyType = f.kind == VX355_AGG_COUNT && raw && kindWidth(f.input_type) >= 0;
+    if (!(isInt || f.input_type == VX355_REAL || f.input_type == VX355_DOUBLE || countsAnyType)) {
       VX_THROW(VX355_EUNSUPPORTED, "aggregate input type " + std::to_string(f.input_type));
     }
     if (f.kind != VX355_AGG_COUNT_STAR || !raw) {
