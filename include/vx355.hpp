@@ -48,7 +48,7 @@ inline void init(int device = 0) { check(vx355_init(device)); }
 class HashAggregation {
  public:
   HashAggregation(std::vector<int32_t> keyChannels, std::vector<int32_t> keyTypes, std::vector<vx355_agg_fn> aggregates,
-                  vx355_agg_step step = VX355_STEP_SINGLE, bool ignoreNullKeys = false)
+                  vx355_agg_step step = VX355_STEP_SINGLE, bool ignoreNullKeys = false, int32_t flags = 0)
       : keyChannels_(std::move(keyChannels)), keyTypes_(std::move(keyTypes)), aggregates_(std::move(aggregates)) {
     vx355_agg_spec spec{};
     spec.num_keys = static_cast<int32_t>(keyChannels_.size());
@@ -58,6 +58,7 @@ class HashAggregation {
     spec.aggs = aggregates_.data();
     spec.step = step;
     spec.ignore_null_keys = ignoreNullKeys ? 1 : 0;
+    spec.flags = flags;  // VX355_AGG_UNORDERED_OUTPUT
     check(vx355_agg_create(&spec, &handle_));  // VX355_EUNSUPPORTED: keep the CPU operator
   }
   HashAggregation(const HashAggregation&) = delete;
@@ -115,6 +116,21 @@ class HashAggregation {
   bool noMoreInput_ = false;
   bool finished_ = false;
 };
+
+// PartitionedOutput's byte work (exec/PartitionedOutput.cpp:59-133): the rows of every destination
+// as PrestoPages. Returns the pages back to back; pageOffsets gets numPages + 1 entries.
+inline std::vector<char> prestoSerialize(const vx355_batch& input, const int32_t* rows, int32_t rowsMem,
+                                         const std::vector<int64_t>& offsets, int32_t flags,
+                                         std::vector<int64_t>* pageOffsets) {
+  const int32_t numPages = static_cast<int32_t>(offsets.size()) - 1;
+  pageOffsets->assign(offsets.size(), 0);
+  check(vx355_presto_serialize(&input, rows, rowsMem, offsets.data(), numPages, flags, nullptr, 0, VX355_MEM_HOST,
+                               pageOffsets->data()));
+  std::vector<char> out(static_cast<size_t>(pageOffsets->back()));
+  check(vx355_presto_serialize(&input, rows, rowsMem, offsets.data(), numPages, flags, out.data(),
+                               static_cast<int64_t>(out.size()), VX355_MEM_HOST, pageOffsets->data()));
+  return out;
+}
 
 // The table HashJoinBridge hands from build to probe (exec/HashJoinBridge.h:57,116).
 class JoinTable {

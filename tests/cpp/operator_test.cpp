@@ -234,12 +234,86 @@ int testJoin(vx355_join_type type) {
   return 0;
 }
 
+
+int testDistinctAndPages() {
+  // SELECT k, count(DISTINCT v), sum(DISTINCT v) GROUP BY k (exec/DistinctAggregations.cpp) against
+  // std::set, then the same rows as two PrestoPages (exec/PartitionedOutput.cpp) whose framing is
+  // checked field by field.
+  std::mt19937_64 rng(11);
+  const int kRows = 20000;
+  std::vector<int64_t> k(kRows), v(kRows);
+  std::vector<uint64_t> vNulls((kRows + 63) / 64, ~0ULL);
+  std::map<int64_t, std::set<int64_t>> expected;
+  std::vector<int64_t> firstSeen;
+  int64_t nullsInFirstPage = 0;
+  const int kSplit = 7777;
+  for (int i = 0; i < kRows; ++i) {
+    k[i] = int64_t(rng() % 50);
+    v[i] = int64_t(rng() % 20) - 5;
+    if (rng() % 8 == 0) {
+      vNulls[i >> 6] &= ~(1ULL << (i & 63));
+      nullsInFirstPage += i < kSplit;
+    }
+    if (!expected.count(k[i])) {
+      firstSeen.push_back(k[i]);
+      expected[k[i]];
+    }
+    if ((vNulls[i >> 6] >> (i & 63)) & 1) {
+      expected[k[i]].insert(v[i]);
+    }
+  }
+  vx355_column cols[2] = {flat(VX355_BIGINT, k.data()), flat(VX355_BIGINT, v.data(), vNulls.data())};
+  vx355_batch batch{kRows, 2, cols};
+  vx355::HashAggregation op({0}, {VX355_BIGINT},
+                            {{VX355_AGG_COUNT, 1, -1, VX355_BIGINT, -1, VX355_AGG_FN_DISTINCT},
+                             {VX355_AGG_SUM, 1, -1, VX355_BIGINT, -1, VX355_AGG_FN_DISTINCT}});
+  op.addInput(batch);
+  op.noMoreInput();
+  OutCol key(VX355_BIGINT, 8, 64), cnt(VX355_BIGINT, 8, 64), sum(VX355_BIGINT, 8, 64);
+  vx355_out_column out[3] = {key.desc, cnt.desc, sum.desc};
+  const int32_t n = op.getOutput(out, 3, 64);
+  EXPECT(n == int32_t(firstSeen.size()) && op.isFinished());
+  for (int32_t i = 0; i < n; ++i) {
+    EXPECT(key.at<int64_t>(i) == firstSeen[i]);
+    const auto& values = expected[firstSeen[i]];
+    EXPECT(cnt.at<int64_t>(i) == int64_t(values.size()));
+    int64_t total = 0;
+    for (auto x : values) {
+      total += x;
+    }
+    EXPECT(sum.valid(i) == !values.empty());
+    EXPECT(values.empty() || sum.at<int64_t>(i) == total);
+  }
+
+  std::vector<int64_t> pageOffsets;
+  const std::vector<char> pages = vx355::prestoSerialize(batch, nullptr, VX355_MEM_HOST, {0, kSplit, kRows}, 0, &pageOffsets);
+  EXPECT(pageOffsets.size() == 3 && pageOffsets[2] == int64_t(pages.size()));
+  auto i32 = [&](int64_t at) {
+    int32_t x;
+    std::memcpy(&x, pages.data() + at, 4);
+    return x;
+  };
+  // page 0: 21-byte header, 2 columns; column 0 without nulls, column 1 with a bitmap
+  EXPECT(i32(0) == kSplit && pages[4] == 0 && i32(5) == pageOffsets[1] - 21 && i32(9) == i32(5));
+  EXPECT(i32(21) == 2 && i32(25) == 10 && std::memcmp(pages.data() + 29, "LONG_ARRAY", 10) == 0 && i32(39) == kSplit);
+  EXPECT(pages[43] == 0);
+  int64_t at = 44 + int64_t(kSplit) * 8;  // past column 0's values
+  EXPECT(i32(at) == 10 && i32(at + 14) == kSplit && pages[at + 18] == 1);
+  at += 19 + (kSplit + 7) / 8 + (kSplit - nullsInFirstPage) * 8;
+  EXPECT(at == pageOffsets[1]);
+  EXPECT(i32(pageOffsets[1]) == kRows - kSplit);
+  return 0;
+}
+
 }  // namespace
 
 int main() {
   try {
     vx355::init(0);
     if (testAggregation()) {
+      return 1;
+    }
+    if (testDistinctAndPages()) {
       return 1;
     }
     for (auto t : {VX355_JOIN_INNER, VX355_JOIN_LEFT, VX355_JOIN_RIGHT, VX355_JOIN_FULL}) {
