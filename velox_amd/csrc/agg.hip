@@ -1111,7 +1111,12 @@ __device__ inline void rpFoldFlush(const RpFold& f, const RadixAggArgs& r, int64
       }
     }
   }
-  if (newGroups) {
+  // one add per wave instead of one per lane
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    newGroups += __shfl_xor(newGroups, off, kWave);
+  }
+  if (lane() == 0 && newGroups) {
     atomicAdd(&r.counters->numNewGroups, newGroups);
   }
   blockSync();

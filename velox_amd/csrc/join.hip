@@ -95,7 +95,11 @@ __global__ __launch_bounds__(256) void k_key_valid(ValidArgs a) {
       a.validWords[w] = m;
     }
   }
-  if (nulls) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    nulls += __shfl_xor(nulls, off, kWave);
+  }
+  if (lane() == 0 && nulls) {
     atomicAdd(&a.counters->nullKeyRows, nulls);
   }
 }
@@ -342,15 +346,30 @@ __device__ inline bool storedKeysEqual(const InsertArgs& a, int64_t r1, int64_t 
 // table): consecutive lanes whose keys share a 32-bit word of the bitmap are
 // combined (segmented OR scan over the run) and issue ONE atomicOr per run.
 // Called by all 64 lanes.
-__device__ inline bool claimPresence(uint32_t* present, bool active, uint64_t key) {
+// Split in two so that a lane can have several claims in flight: the atomic's return value is
+// only consumed by resolveClaim. (Measured on the Q3 build: no gain - that insert is bound by
+// the 14.6 M scattered 4-byte head stores, one 32-byte sector each, which the fabric retires at
+// the ~30 G/s of tools/atomic_bench.hip's plain read-modify-write line.)
+struct PresenceClaim {
+  uint32_t prev;  // the tail lane's atomicOr result
+  uint32_t incl;  // OR of the bits of this lane's run up to and including this lane
+  uint32_t bit;
+  int myTail;
+  bool head;
+  bool active;
+};
+
+__device__ inline PresenceClaim issueClaim(uint32_t* present, bool active, uint64_t key) {
+  PresenceClaim c;
   const int ln = lane();
   const uint64_t word = active ? (key >> 5) : ~static_cast<uint64_t>(ln);  // inactive lanes: runs of their own
-  const uint32_t bit = active ? 1u << (key & 31) : 0u;
+  c.bit = active ? 1u << (key & 31) : 0u;
+  c.active = active;
   const uint64_t prevLaneWord = shfl64(word, ln > 0 ? ln - 1 : 0);
-  const bool head = ln == 0 || prevLaneWord != word;
-  const uint64_t heads = ballot(head);
+  c.head = ln == 0 || prevLaneWord != word;
+  const uint64_t heads = ballot(c.head);
   const int run = static_cast<int>(popc64(heads & ((2ULL << ln) - 1)));  // 1-based run id, ascending
-  uint32_t incl = bit;
+  uint32_t incl = c.bit;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     const uint32_t v = __shfl_up(incl, off, kWave);
@@ -359,17 +378,26 @@ __device__ inline bool claimPresence(uint32_t* present, bool active, uint64_t ke
       incl |= v;
     }
   }
+  c.incl = incl;
   const bool tail = ln == 63 || ((heads >> (ln + 1)) & 1);
-  uint32_t prev = 0;
-  if (tail && active) {
-    prev = atomicOr(present + word, incl);
-  }
   const uint64_t tails = ballot(tail);
-  const int myTail = ln + __ffsll(static_cast<long long>(tails >> ln)) - 1;
-  prev = __shfl(prev, myTail, kWave);
-  const uint32_t before = __shfl_up(incl, 1, kWave);
-  const uint32_t earlier = head ? 0u : before;
-  return active && !((prev | earlier) & bit);
+  c.myTail = ln + __ffsll(static_cast<long long>(tails >> ln)) - 1;
+  c.prev = 0;
+  if (tail && active) {
+    c.prev = atomicOr(present + word, incl);
+  }
+  return c;
+}
+
+__device__ inline bool resolveClaim(const PresenceClaim& c) {
+  const uint32_t prev = __shfl(c.prev, c.myTail, kWave);
+  const uint32_t before = __shfl_up(c.incl, 1, kWave);
+  const uint32_t earlier = c.head ? 0u : before;
+  return c.active && !((prev | earlier) & c.bit);
+}
+
+__device__ inline bool claimPresence(uint32_t* present, bool active, uint64_t key) {
+  return resolveClaim(issueClaim(present, active, key));
 }
 
 // Array mode never initialises the (possibly multi-GB) head array: phase 1
@@ -381,32 +409,52 @@ __global__ __launch_bounds__(256) void k_join_insert(InsertArgs a) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   uint32_t dups = 0, distinct = 0;
   if (a.mode == JMODE_ARRAY && a.phase == 1) {
-    // whole waves iterate together (claimPresence is a wave-wide operation)
+    // whole waves iterate together (the claims are wave-wide operations); four rows per lane in
+    // flight, so four atomics of a wave overlap their round trips
+    constexpr int kInFlight = 4;
     const int64_t rounds = (a.numRows + stride - 1) / stride;
-    int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    for (int64_t r = 0; r < rounds; ++r, row += stride) {
-      const bool inRange = row < a.numRows;
-      const bool nullKey = inRange && a.keyNull && a.keyNull[row];
-      const bool active = inRange && !nullKey;
-      const uint64_t key = active ? buildKey(a, row) : 0;
-      const bool first = claimPresence(a.present, active, key);
-      if (nullKey) {
-        a.next[row] = kNoRow32;
-      } else if (active) {
-        if (first) {
-          a.head[key] = static_cast<uint32_t>(row);
+    int64_t row0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    for (int64_t r = 0; r < rounds; r += kInFlight, row0 += stride * kInFlight) {
+      PresenceClaim claim[kInFlight];
+      uint64_t keys[kInFlight];
+      bool nullKey[kInFlight];
+#pragma unroll
+      for (int u = 0; u < kInFlight; ++u) {
+        const int64_t row = row0 + u * stride;
+        const bool inRange = r + u < rounds && row < a.numRows;
+        nullKey[u] = inRange && a.keyNull && a.keyNull[row];
+        const bool active = inRange && !nullKey[u];
+        keys[u] = active ? buildKey(a, row) : 0;
+        claim[u] = issueClaim(a.present, active, keys[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < kInFlight; ++u) {
+        const int64_t row = row0 + u * stride;
+        const bool first = resolveClaim(claim[u]);
+        if (nullKey[u]) {
           a.next[row] = kNoRow32;
-          ++distinct;
-        } else {
-          a.next[row] = kPendingRow;
-          ++dups;
+        } else if (claim[u].active) {
+          if (first) {
+            a.head[keys[u]] = static_cast<uint32_t>(row);
+            a.next[row] = kNoRow32;
+            ++distinct;
+          } else {
+            a.next[row] = kPendingRow;
+            ++dups;
+          }
         }
       }
     }
-    if (dups) {
+    // one add per wave instead of one per lane
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      dups += __shfl_xor(dups, off, kWave);
+      distinct += __shfl_xor(distinct, off, kWave);
+    }
+    if (lane() == 0 && dups) {
       atomicAdd(&a.counters->duplicates, dups);
     }
-    if (distinct) {
+    if (lane() == 0 && distinct) {
       atomicAdd(&a.counters->numDistinct, distinct);
     }
     return;
@@ -502,10 +550,16 @@ __global__ __launch_bounds__(256) void k_join_insert(InsertArgs a) {
       ++dups;
     }
   }
-  if (dups) {
+  // the loops above leave the wave converged here: one add per wave (see phase 1)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    dups += __shfl_xor(dups, off, kWave);
+    distinct += __shfl_xor(distinct, off, kWave);
+  }
+  if (lane() == 0 && dups) {
     atomicAdd(&a.counters->duplicates, dups);
   }
-  if (distinct) {
+  if (lane() == 0 && distinct) {
     atomicAdd(&a.counters->numDistinct, distinct);
   }
 }
