@@ -1109,3 +1109,37 @@ def test_count_over_any_column_type(oracle, vx):
         exp, _ = run_agg(oracle, [hb, hb], keys, kinds, aggs)
         got, gop = run_agg(vx, [hb, hb], keys, kinds, aggs)
         assert_columns_equal(got, exp, gop.kinds, what=f"count any type, keys {keys}")
+
+
+@pytest.mark.parametrize("global_agg", [False, True])
+def test_distinct_and_string_aggregates_on_empty_and_tiny_inputs(oracle, vx, global_agg):
+    """No input at all, a zero-row batch, one row, only nulls; one row per output page."""
+    D = abi.AGG_FN_DISTINCT
+    keys, kinds = ([], []) if global_agg else ([0], [abi.BIGINT])
+    aggs = [(abi.AGG_MIN, 1, abi.VARCHAR), (abi.AGG_SUM, 2, abi.BIGINT, -1, -1, D), (abi.AGG_COUNT, 1, abi.VARCHAR, -1, -1, D),
+            (abi.AGG_COUNT_STAR, -1, abi.BIGINT), (abi.AGG_MAX, 1, abi.VARCHAR)]
+
+    def batch(k, s, sv, x):
+        return abi.HostBatch([abi.HostColumn(abi.BIGINT, np.array(k, dtype=np.int64)),
+                              abi.HostColumn(abi.VARCHAR, s, valid=sv),
+                              abi.HostColumn(abi.BIGINT, np.array(x, dtype=np.int64))], len(k))
+
+    cases = {
+        "no input": [],
+        "zero rows": [batch([], [], [], [])],
+        "one row": [batch([5], [b"only"], [True], [7])],
+        "only nulls": [batch([1, 1, 2], [b"", b"", b""], [False, False, False], [3, 3, 3])],
+        "one per page": [batch([3, 1, 3, 2, 1], [b"b", b"a string beyond twelve bytes", b"a", b"", b"a string beyond twelve byte"],
+                               [True, True, True, True, True], [1, 2, 1, 2, 2])],
+    }
+    for name, batches in cases.items():
+        exp, _ = run_agg(oracle, batches, keys, kinds, aggs, max_rows=1)
+        got, gop = run_agg(vx, batches, keys, kinds, aggs, max_rows=1)
+        assert_columns_equal(got, exp, gop.kinds, what=name)
+
+
+def test_operator_with_parts_refuses_flush_and_to_intermediate(vx):
+    op = vx.Aggregation([0], [abi.BIGINT], [(abi.AGG_MIN, 1, abi.VARCHAR)], abi.STEP_PARTIAL)
+    with pytest.raises(Exception) as e:
+        op.flush()
+    assert "flush" in str(e.value)
