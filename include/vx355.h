@@ -674,7 +674,7 @@ typedef struct vx355_join_probe_spec {
   int32_t num_keys;
   const int32_t* key_cols; /* probe-side key columns */
   int32_t join_type;
-  int32_t null_aware;
+  int32_t null_aware; /* ANTI (NOT IN) and LEFT_SEMI_PROJECT (IN as a column), without an extra filter */
 } vx355_join_probe_spec;
 
 int vx355_join_probe_create(
@@ -745,7 +745,10 @@ int vx355_join_probe_get_output(
  * (the reference's last prober, HashProbe.cpp:1189-1219) after every probe of
  * the table has consumed its input. LEFT_SEMI_PROJECT needs no such call: its
  * get_output lists every probe row once with build_rows_out = first match or -1
- * (the shim's 'match' column is build_rows_out >= 0). */
+ * (the shim's 'match' column is build_rows_out >= 0); when null aware, -2 stands for a NULL
+ * match: a null probe key against a build side that is not both empty and null-free, or no
+ * match while the build side holds a null key (HashProbe::fillLeftSemiProjectMatchColumn,
+ * exec/HashProbe.cpp:923-966). */
 #define VX355_BUILD_COL_MATCH (-1)
 int vx355_join_probe_get_build_side_output(
     vx355_join_probe* h,

@@ -815,7 +815,22 @@ class JoinProbe {
           // every probe row once; the match column is "first != null" (not null aware)
           emit(n++, cursorRow_, nullptr, mapping, buildRows, cols, colIds, numCols);
           if (buildRows) {
-            buildRows[n - 1] = first ? static_cast<int32_t>(rowId(first)) : -1;
+            int32_t value = first ? static_cast<int32_t>(rowId(first)) : -1;
+            if (nullAware_ && !first) {
+              // fillLeftSemiProjectMatchColumn (HashProbe.cpp:923-966) without a filter; -2 = NULL:
+              // empty build side: NULL if it held null keys, else FALSE; otherwise NULL for a null
+              // probe key, and NULL instead of FALSE when the build side holds a null key
+              bool nullKey = false;
+              for (auto& k : keys_) {
+                nullKey = nullKey || k.isNull(cursorRow_);
+              }
+              if (table_->numRows == 0) {
+                value = table_->hasNullKeys ? -2 : -1;
+              } else if (nullKey || table_->hasNullKeys) {
+                value = -2;
+              }
+            }
+            buildRows[n - 1] = value;
           }
         } else if ((first != nullptr) == (joinType_ == VX355_JOIN_LEFT_SEMI_FILTER)) {
           emit(n++, cursorRow_, nullptr, mapping, buildRows, cols, colIds, numCols);
@@ -1511,8 +1526,8 @@ int orc_join_probe_create(orc_join_table* t, const vx355_join_probe_spec* spec,
       gLastError = "join type not restated in the oracle";
       return VX355_EUNSUPPORTED;
   }
-  if (spec->null_aware && spec->join_type != VX355_JOIN_ANTI) {
-    gLastError = "null-aware semantics restated for the anti join only";
+  if (spec->null_aware && spec->join_type != VX355_JOIN_ANTI && spec->join_type != VX355_JOIN_LEFT_SEMI_PROJECT) {
+    gLastError = "null-aware semantics restated for the anti and the left semi project join";
     return VX355_EUNSUPPORTED;
   }
   *out = new orc_join_probe(&t->t, *spec);

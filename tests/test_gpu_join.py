@@ -437,6 +437,52 @@ def test_right_full_semi_project_joins(oracle, vx, join_type, mode, monkeypatch)
         assert len(results[vx.__name__][2][0]) > 0
 
 
+@pytest.mark.parametrize("case", ["build_has_null", "regular", "empty_build", "only_null_build"])
+@pytest.mark.parametrize("hash_mode", [False, True])
+def test_null_aware_left_semi_project(oracle, vx, case, hash_mode):
+    """x IN (subquery) as a column (HashProbe::fillLeftSemiProjectMatchColumn, HashProbe.cpp:923-966):
+    TRUE / FALSE / NULL per probe row; build_rows_out carries first match / -1 / -2."""
+    rng = np.random.default_rng(33)
+    nb, npb = 3000, 9000
+    spread = 10 ** 12 if hash_mode else 800
+    bk = (rng.integers(0, 800, nb) * (spread // 800)).astype(np.int64)
+    bvalid = rng.random(nb) > 0.02 if case == "build_has_null" else np.ones(nb, dtype=bool)
+    if case == "empty_build":
+        bk, bvalid = bk[:0], bvalid[:0]
+    if case == "only_null_build":
+        bk, bvalid = bk[:5], np.zeros(5, dtype=bool)
+    pk = (rng.integers(-100, 1200, npb) * (spread // 800)).astype(np.int64)
+    pvalid = rng.random(npb) > 0.05
+    got = {}
+    for impl in (oracle, vx):
+        b = impl.JoinBuild([0], [abi.BIGINT], [], [], abi.JOIN_LEFT_SEMI_PROJECT, True)
+        b.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, bk, bvalid)], len(bk)))
+        table = b.finish()
+        probe = impl.JoinProbe(table, [0], abi.JOIN_LEFT_SEMI_PROJECT, True)
+        probe.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, pk, pvalid)]))
+        rows_out = []
+        while True:
+            mapping, rows, _, fin = probe.get_output(1000, [])
+            rows_out += [(int(m), "T" if r >= 0 else ("F" if r == -1 else "N")) for m, r in zip(mapping, rows)]
+            if fin:
+                break
+        got[impl.__name__] = rows_out
+    assert got[oracle.__name__] == got[vx.__name__]
+    keys = set(bk[bvalid].tolist())
+    has_null = bool((~bvalid).any())
+    for i, (m, flag) in enumerate(got[vx.__name__]):
+        assert m == i
+        if not keys:
+            want = "N" if has_null else "F"
+        elif not pvalid[i]:
+            want = "N"
+        elif int(pk[i]) in keys:
+            want = "T"
+        else:
+            want = "N" if has_null else "F"
+        assert flag == want, (i, flag, want)
+
+
 @pytest.mark.parametrize("case", ["build_has_null", "regular", "empty_build"])
 def test_null_aware_anti_join(oracle, vx, case):
     """NOT IN (HashProbe.cpp:1316-1328 + HashBuild's antiJoinHasNullKeys)."""
@@ -650,8 +696,11 @@ def test_unsupported_join_flavours_are_refused_at_create(vx):
     assert e.value.status == abi.EUNSUPPORTED
     with pytest.raises(vx.Vx355Error):
         vx.JoinProbe(t, [0], abi.JOIN_INNER)               # counting table, non-counting probe
-    with pytest.raises(vx.Vx355Error):
-        vx.JoinBuild([0], [abi.BIGINT], [], [], abi.JOIN_LEFT_SEMI_PROJECT, null_aware=True)
+    p2 = vx.JoinProbe(vx.JoinBuild([0], [abi.BIGINT], [], [], abi.JOIN_LEFT_SEMI_PROJECT, null_aware=True).finish(), [0],
+                      abi.JOIN_LEFT_SEMI_PROJECT, True)
+    with pytest.raises(vx.Vx355Error) as e:
+        p2.set_filter([(("probe", 0), abi.CMP_LT, 5)])     # null aware + extra filter
+    assert e.value.status == abi.EUNSUPPORTED
 
 
 def _join_arrays(impl, vxmod, bk, pay, pk, join_type, max_rows=500000):

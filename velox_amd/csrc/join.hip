@@ -1677,6 +1677,10 @@ struct EmitArgs {
   const uint2* staged;       // sparse listing: {probe row, build row} per tile, kSparseCap apart
   const uint8_t* tileDense;  // tiles that fell back to hits[]
   JoinFilterArgs f;          // extra filter: only the passing rows of a chain are listed
+  // build_rows_out of a probe row without a match / with a null key: -1, or -2 where the
+  // null-aware semi project join says NULL (HashProbe::fillLeftSemiProjectMatchColumn)
+  int32_t missValue;
+  int32_t nullKeyValue;
 };
 static_assert(sizeof(EmitArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
@@ -1748,7 +1752,8 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
         if (a.buildRows) {
           const bool listMatch = isHit(hit) &&
               (listsMatches(a.joinType) || a.joinType == VX355_JOIN_LEFT_SEMI_PROJECT);
-          a.buildRows[pos - a.windowBegin] = listMatch ? static_cast<int32_t>(hit) : -1;
+          a.buildRows[pos - a.windowBegin] =
+              listMatch ? static_cast<int32_t>(hit) : (hit == kNullKey32 ? a.nullKeyValue : a.missValue);
         }
       }
       run += popc64(m);
@@ -1799,7 +1804,9 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
         if (p >= a.windowBegin) {
           a.mapping[p - a.windowBegin] = static_cast<int32_t>(r);
           if (a.buildRows) {
-            a.buildRows[p - a.windowBegin] = (listMatches || firstOnly) ? static_cast<int32_t>(b) : -1;
+            a.buildRows[p - a.windowBegin] = (listMatches || firstOnly)
+                ? static_cast<int32_t>(b)
+                : (hit == kNullKey32 ? a.nullKeyValue : a.missValue);
           }
         }
         if (listMatches) {
@@ -1995,6 +2002,7 @@ struct vx355_join_probe {
   bool hasInput = false;
   bool haveCounts = false;
   bool nullAware = false;
+  int32_t missValue = -1, nullKeyValue = -1;  // see EmitArgs
   // build-side output (right / full / right semi): the listed rows, computed on first request
   DevBuf buildSideRows;
   int64_t buildSideCount = -1;
@@ -2436,6 +2444,14 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
     }
     a.nullAware = t.numRows > 0 ? 1 : 0;  // an empty build side passes every row, null keys included
   }
+  if (p.nullAware && p.joinType == VX355_JOIN_LEFT_SEMI_PROJECT) {
+    // x IN (subquery) as a column (HashProbe.cpp:923-966, no filter): NULL for a null probe key
+    // unless the build side is empty and null-free, NULL instead of FALSE once the build side
+    // holds a null key
+    a.nullAware = 1;
+    p.nullKeyValue = (t.numRows > 0 || t.hasNullKeys) ? -2 : -1;
+    p.missValue = t.hasNullKeys ? -2 : -1;
+  }
   // with a filter the probed flags belong to the passing pairs: k_join_filter sets them
   a.probed = (marksProbedRows(p.joinType) && !filtered) ? t.probed.as<uint8_t>() : nullptr;
   a.numKeys = static_cast<int32_t>(p.keyCols.size());
@@ -2797,6 +2813,8 @@ void probeGetOutput(vx355_join_probe& p, int32_t maxRows, int32_t* mappingOut, i
   ea.windowBegin = begin;
   ea.windowEnd = end;
   ea.joinType = p.joinType;
+  ea.missValue = p.missValue;
+  ea.nullKeyValue = p.nullKeyValue;
   ea.mapping = dMap;
   ea.buildRows = dRows;
   ea.staged = p.sparse ? p.staged.as<uint2>() : nullptr;
@@ -3014,7 +3032,8 @@ int vx355_join_build_create(const vx355_join_build_spec* spec, vx355_join_build*
   VX_CHECK_ARG(spec->num_keys >= 1 && spec->num_keys <= kMaxKeys, "1..8 join keys supported");
   VX_CHECK_ARG(spec->num_dependents >= 0 && spec->num_dependents <= kMaxDeps,
                "at most 16 build payload columns");
-  if (!supportedJoin(spec->join_type) || (spec->null_aware && spec->join_type != VX355_JOIN_ANTI)) {
+  if (!supportedJoin(spec->join_type) ||
+      (spec->null_aware && spec->join_type != VX355_JOIN_ANTI && spec->join_type != VX355_JOIN_LEFT_SEMI_PROJECT)) {
     VX_THROW(VX355_EUNSUPPORTED, "join type " + std::to_string(spec->join_type) +
                                      (spec->null_aware ? " (null aware)" : "") + " not on device");
   }
@@ -3153,7 +3172,8 @@ int vx355_join_probe_create(vx355_join_table* table, const vx355_join_probe_spec
   VX_CHECK_ARG(table && spec && out, "NULL argument");
   VX_CHECK_ARG(spec->num_keys == static_cast<int32_t>(table->keyKinds.size()),
                "probe and build key counts differ");
-  if (!supportedJoin(spec->join_type) || (spec->null_aware && spec->join_type != VX355_JOIN_ANTI)) {
+  if (!supportedJoin(spec->join_type) ||
+      (spec->null_aware && spec->join_type != VX355_JOIN_ANTI && spec->join_type != VX355_JOIN_LEFT_SEMI_PROJECT)) {
     VX_THROW(VX355_EUNSUPPORTED, "join type " + std::to_string(spec->join_type) + " not on device");
   }
   if ((marksProbedRows(spec->join_type) || marksProbedRows(table->joinType)) &&
@@ -3200,7 +3220,7 @@ int vx355_join_probe_set_filter(vx355_join_probe* h, const vx355_join_filter_ter
     VX_THROW(VX355_EUNSUPPORTED, "counting joins take no extra filter (exec/HashProbe.cpp:1345-1365)");
   }
   if (n_terms > 0 && h->nullAware) {
-    VX_THROW(VX355_EUNSUPPORTED, "null-aware anti join with an extra filter");
+    VX_THROW(VX355_EUNSUPPORTED, "null-aware join with an extra filter");
   }
   h->filter.assign(terms, terms + n_terms);
   h->usedCols = h->keyCols;
