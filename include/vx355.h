@@ -593,6 +593,12 @@ typedef struct vx355_join_build_spec {
   const int32_t* dependent_types;
   int32_t join_type;  /* vx355_join_type */
   int32_t null_aware; /* HashJoinNode::isNullAware */
+  int32_t null_as_value; /* HashJoinNode::isNullAsValue: keys compare IS NOT DISTINCT FROM (NULL equals
+                            NULL), what INTERSECT / EXCEPT plan their counting joins with
+                            (core/PlanNode.h:3442-3445); rows with null keys enter the table
+                            (HashBuild.cpp:273,477) and null probe keys are looked up
+                            (HashProbe.cpp:787). Excludes null_aware. */
+  int32_t pad;
 } vx355_join_build_spec;
 
 typedef struct vx355_join_build vx355_join_build;
@@ -675,6 +681,8 @@ typedef struct vx355_join_probe_spec {
   const int32_t* key_cols; /* probe-side key columns */
   int32_t join_type;
   int32_t null_aware; /* ANTI (NOT IN) and LEFT_SEMI_PROJECT (IN as a column), without an extra filter */
+  int32_t null_as_value; /* must equal the build side's */
+  int32_t pad;
 } vx355_join_probe_spec;
 
 int vx355_join_probe_create(

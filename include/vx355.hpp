@@ -172,7 +172,8 @@ class JoinTable {
 class HashBuild {
  public:
   HashBuild(std::vector<int32_t> keyChannels, std::vector<int32_t> keyTypes, std::vector<int32_t> dependentChannels,
-            std::vector<int32_t> dependentTypes, vx355_join_type joinType = VX355_JOIN_INNER, bool nullAware = false)
+            std::vector<int32_t> dependentTypes, vx355_join_type joinType = VX355_JOIN_INNER, bool nullAware = false,
+            bool nullAsValue = false)
       : keyChannels_(std::move(keyChannels)),
         keyTypes_(std::move(keyTypes)),
         dependentChannels_(std::move(dependentChannels)),
@@ -186,6 +187,7 @@ class HashBuild {
     spec.dependent_types = dependentTypes_.data();
     spec.join_type = joinType;
     spec.null_aware = nullAware ? 1 : 0;
+    spec.null_as_value = nullAsValue ? 1 : 0;
     check(vx355_join_build_create(&spec, &handle_));
   }
   HashBuild(const HashBuild&) = delete;
@@ -227,13 +229,14 @@ class HashBuild {
 class HashProbe {
  public:
   HashProbe(const JoinTable& table, std::vector<int32_t> keyChannels, vx355_join_type joinType = VX355_JOIN_INNER,
-            bool nullAware = false)
+            bool nullAware = false, bool nullAsValue = false)
       : keyChannels_(std::move(keyChannels)), joinType_(joinType) {
     vx355_join_probe_spec spec{};
     spec.num_keys = static_cast<int32_t>(keyChannels_.size());
     spec.key_cols = keyChannels_.data();
     spec.join_type = joinType;
     spec.null_aware = nullAware ? 1 : 0;
+    spec.null_as_value = nullAsValue ? 1 : 0;
     check(vx355_join_probe_create(table.get(), &spec, &handle_));
   }
   HashProbe(const HashProbe&) = delete;

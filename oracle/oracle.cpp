@@ -614,7 +614,8 @@ class Aggregation {
 // exec/HashBuild.{h,cpp}: one per build Driver.
 class JoinBuild {
  public:
-  explicit JoinBuild(const vx355_join_build_spec& spec) : joinType_(spec.join_type) {
+  explicit JoinBuild(const vx355_join_build_spec& spec)
+      : joinType_(spec.join_type), nullAsValue_(spec.null_as_value != 0) {
     keyCols_.assign(spec.key_cols, spec.key_cols + spec.num_keys);
     keyKinds_.assign(spec.key_types, spec.key_types + spec.num_keys);
     depCols_.assign(spec.dependent_cols, spec.dependent_cols + spec.num_dependents);
@@ -643,8 +644,9 @@ class JoinBuild {
     // Null keys never match: drop them, except for right / full joins whose
     // build rows all reach the output (HashBuild.cpp:475-494).
     // (HashBuild.cpp:257-268: right, full, right semi project and right anti retain null keys)
+    // ... and so does nullAsValue (HashBuild.cpp:273,477): there the rows are ordinary table entries
     const bool keepNullKeys = joinType_ == VX355_JOIN_RIGHT || joinType_ == VX355_JOIN_FULL ||
-        joinType_ == VX355_JOIN_RIGHT_SEMI_PROJECT || joinType_ == VX355_JOIN_RIGHT_ANTI;
+        joinType_ == VX355_JOIN_RIGHT_SEMI_PROJECT || joinType_ == VX355_JOIN_RIGHT_ANTI || nullAsValue_;
     for (auto& d : keys) {
       for (int32_t r = 0; r < n; ++r) {
         if (d.isNull(r)) {
@@ -668,6 +670,7 @@ class JoinBuild {
   std::unique_ptr<HashTable> table_;
   std::vector<int32_t> keyCols_, keyKinds_, depCols_, depKinds_;
   int32_t joinType_;
+  bool nullAsValue_ = false;
   bool hasNullKeys_ = false;
 };
 
@@ -702,7 +705,8 @@ struct JoinTable {
 class JoinProbe {
  public:
   JoinProbe(JoinTable* t, const vx355_join_probe_spec& spec)
-      : table_(t), joinType_(spec.join_type), nullAware_(spec.null_aware != 0) {
+      : table_(t), joinType_(spec.join_type), nullAware_(spec.null_aware != 0),
+        nullAsValue_(spec.null_as_value != 0) {
     keyCols_.assign(spec.key_cols, spec.key_cols + spec.num_keys);
   }
 
@@ -725,7 +729,7 @@ class JoinProbe {
       lookup_.reset(0);
       return;
     }
-    table_->table->prepareForJoinProbe(lookup_, keys_, numRows_, rows);
+    table_->table->prepareForJoinProbe(lookup_, keys_, numRows_, rows, nullAsValue_);
     table_->table->joinProbe(lookup_, keys_);
   }
 
@@ -1038,6 +1042,7 @@ class JoinProbe {
   JoinTable* table_;
   int32_t joinType_;
   bool nullAware_;
+  bool nullAsValue_ = false;
   std::vector<vx355_join_filter_term> filter_;
   const vx355_batch* batch_ = nullptr;  // the batch being probed (filter operands), borrowed
   bool chainOpen_ = false;

@@ -392,8 +392,10 @@ class HashTable {
   // HashTable::joinProbe (HashTable.cpp:610-652). lookup.rows / hashes must be
   // prepared by prepareForJoinProbe.
   void prepareForJoinProbe(HashLookup& lookup, const std::vector<Decoded>& keys, int32_t numRows,
-                           std::vector<uint64_t>& rows) {
-    deselectRowsWithNulls(keys, numRows, rows);
+                           std::vector<uint64_t>& rows, bool nullAsValue = false) {
+    if (!nullAsValue) {  // HashProbe.cpp:787-789
+      deselectRowsWithNulls(keys, numRows, rows);
+    }
     lookup.reset(numRows);
     for (size_t i = 0; i < hashers_.size(); ++i) {
       if (hashMode_ != HashMode::kHash) {

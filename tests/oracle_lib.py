@@ -370,11 +370,13 @@ def collect_output(op, max_rows=1024):
 
 
 class JoinBuild:
-    def __init__(self, key_cols, key_types, dep_cols=(), dep_types=(), join_type=abi.JOIN_INNER, null_aware=False):
+    def __init__(self, key_cols, key_types, dep_cols=(), dep_types=(), join_type=abi.JOIN_INNER, null_aware=False,
+                 null_as_value=False):
         self._keep = [abi.i32_array(key_cols), abi.i32_array(key_types), abi.i32_array(dep_cols),
                       abi.i32_array(dep_types)]
         self.spec = abi.JoinBuildSpec(len(key_cols), self._keep[0], self._keep[1], len(dep_cols),
-                                      self._keep[2], self._keep[3], join_type, 1 if null_aware else 0)
+                                      self._keep[2], self._keep[3], join_type, 1 if null_aware else 0,
+                                      1 if null_as_value else 0, 0)
         self.dep_types = list(dep_types)
         h = C.c_void_p()
         _check(lib().orc_join_build_create(C.byref(self.spec), C.byref(h)))
@@ -412,10 +414,11 @@ class JoinTable:
 
 
 class JoinProbe:
-    def __init__(self, table, key_cols, join_type=abi.JOIN_INNER, null_aware=False):
+    def __init__(self, table, key_cols, join_type=abi.JOIN_INNER, null_aware=False, null_as_value=False):
         self.table = table
         self._keep = abi.i32_array(key_cols)
-        self.spec = abi.JoinProbeSpec(len(key_cols), self._keep, join_type, 1 if null_aware else 0)
+        self.spec = abi.JoinProbeSpec(len(key_cols), self._keep, join_type, 1 if null_aware else 0,
+                                      1 if null_as_value else 0, 0)
         h = C.c_void_p()
         _check(lib().orc_join_probe_create(table.t, C.byref(self.spec), C.byref(h)))
         self.h = h

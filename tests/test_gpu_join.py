@@ -859,3 +859,85 @@ def test_join_keys_and_payloads_longer_than_12_bytes(oracle, vx, join_type):
         assert res[(vx.__name__, with_filter)] == res[(oracle.__name__, with_filter)]
     if join_type == abi.JOIN_INNER:
         assert any(p[0] is not None and len(p[0]) > 12 for _, p in res[(vx.__name__, False)][0])
+
+
+@pytest.mark.parametrize("shape", ["array", "normalized", "hash", "two_keys", "string_key"])
+@pytest.mark.parametrize("join_type", [abi.JOIN_INNER, abi.JOIN_LEFT, abi.JOIN_FULL, abi.JOIN_LEFT_SEMI_FILTER, abi.JOIN_ANTI,
+                                       abi.JOIN_COUNTING_LEFT_SEMI_FILTER, abi.JOIN_COUNTING_ANTI])
+def test_null_as_value_joins(oracle, vx, shape, join_type):
+    """HashJoinNode::isNullAsValue (IS NOT DISTINCT FROM keys; what INTERSECT / EXCEPT plan their
+    counting joins with, core/PlanNode.h:3442-3445): NULL keys are values on both sides, in every
+    table mode; oracle parity (the oracle itself is checked against nested loops on the CPU)."""
+    counting = join_type in (abi.JOIN_COUNTING_LEFT_SEMI_FILTER, abi.JOIN_COUNTING_ANTI)
+    if counting and shape in ("hash", "string_key"):
+        pytest.skip("counting joins need a normalized key")
+    rng = np.random.default_rng(1234 + hash(shape) % 100)
+    nb, npb = 4000, 15000
+    if shape == "array":
+        kinds, spread = [abi.BIGINT], [1]
+    elif shape == "normalized":
+        kinds, spread = [abi.BIGINT], [10 ** 12]
+    elif shape == "hash":
+        kinds, spread = [abi.DOUBLE], [1]
+    elif shape == "two_keys":
+        kinds, spread = [abi.INTEGER, abi.BIGINT], [1, 1]
+    else:
+        kinds, spread = [abi.VARCHAR, abi.BIGINT], [1, 1]
+
+    def column(kind, n, mult):
+        if kind == abi.VARCHAR:
+            words = [b"", b"a", b"bb", b"a key of more than twelve bytes", b"a key of more than twelve byteS"]
+            return [words[i] for i in rng.integers(0, len(words), n)]
+        v = rng.integers(0, 40, n) * mult
+        return v.astype({abi.BIGINT: np.int64, abi.INTEGER: np.int32, abi.DOUBLE: np.float64}[kind])
+
+    nk = len(kinds)
+    bcols = [column(kinds[k], nb, spread[k]) for k in range(nk)]
+    pcols = [column(kinds[k], npb, spread[k]) for k in range(nk)]
+    bvalids = [rng.random(nb) > 0.1 for _ in kinds]
+    pvalids = [rng.random(npb) > 0.1 for _ in kinds]
+    results = {}
+    for impl in (oracle, vx):
+        deps = ([], []) if counting else ([nk], [abi.BIGINT])
+        halves = []
+        for lo, hi in ((0, nb // 2), (nb // 2, nb)):
+            b = impl.JoinBuild(list(range(nk)), kinds, deps[0], deps[1], join_type, False, True)
+            cols = [abi.HostColumn(kinds[k], bcols[k][lo:hi], bvalids[k][lo:hi]) for k in range(nk)]
+            cols.append(abi.HostColumn(abi.BIGINT, np.arange(lo, hi, dtype=np.int64)))
+            b.add_input(abi.HostBatch(cols, hi - lo))
+            halves.append(b)
+        table = halves[0].finish(halves[1:])
+        probe = impl.JoinProbe(table, list(range(nk)), join_type, False, True)
+        probe.add_input(abi.HostBatch([abi.HostColumn(kinds[k], pcols[k], pvalids[k]) for k in range(nk)], npb))
+        rows_out = []
+        while True:
+            mapping, rows, cols, fin = probe.get_output(1777)
+            pay = cols[0] if cols else None
+            for i, m in enumerate(mapping):
+                rows_out.append((int(m), None if pay is None or not pay[1][i] else int(pay[0][i])))
+            if fin:
+                break
+        build_side = []
+        if join_type == abi.JOIN_FULL:
+            while True:
+                rows, cols, fin = probe.get_build_side_output(999)
+                build_side += [int(cols[0][0][i]) for i in range(len(rows))]
+                if fin:
+                    break
+        # matches of one probe row are compared as a set (SURVEY.md A.7)
+        results[impl.__name__] = (sorted(rows_out, key=lambda t: (t[0], -1 if t[1] is None else t[1])), sorted(build_side))
+    assert results[oracle.__name__] == results[vx.__name__]
+    # some probe rows with a null key found a build row with a null key
+    if join_type == abi.JOIN_INNER:
+        null_probe = {i for i in range(npb) if not all(pvalids[k][i] for k in range(nk))}
+        assert any(m in null_probe for m, _ in results[vx.__name__][0])
+
+
+def test_null_as_value_excludes_null_aware_and_must_match_the_table(vx):
+    with pytest.raises(vx.Vx355Error) as e:
+        vx.JoinBuild([0], [abi.BIGINT], [], [], abi.JOIN_ANTI, True, True)
+    assert e.value.status == abi.EINVAL
+    t = vx.JoinBuild([0], [abi.BIGINT], [], [], abi.JOIN_INNER, False, True).finish()
+    with pytest.raises(vx.Vx355Error) as e:
+        vx.JoinProbe(t, [0], abi.JOIN_INNER)
+    assert e.value.status == abi.EINVAL

@@ -759,3 +759,73 @@ def test_count_of_a_string_column_counts_its_non_null_rows(oracle):
     out, _ = _run_agg(oracle, [batch], [], [], [(abi.AGG_COUNT, 0, abi.VARCHAR),
                                                (abi.AGG_COUNT, 0, abi.VARCHAR, -1, -1, abi.AGG_FN_DISTINCT)])
     assert out[0][0][0] == 6 and out[1][0][0] == 5
+
+
+def _nav_join(impl, join_type, bcols, bvalids, pcols, pvalids, kinds, max_rows=333):
+    """Join with nullAsValue over len(kinds) keys; build payload = build row number."""
+    nk = len(kinds)
+    b = impl.JoinBuild(list(range(nk)), kinds, [] if join_type in (abi.JOIN_COUNTING_LEFT_SEMI_FILTER, abi.JOIN_COUNTING_ANTI) else [nk],
+                       [] if join_type in (abi.JOIN_COUNTING_LEFT_SEMI_FILTER, abi.JOIN_COUNTING_ANTI) else [abi.BIGINT],
+                       join_type, False, True)
+    nb = len(bcols[0])
+    cols = [abi.HostColumn(kinds[k], bcols[k], bvalids[k]) for k in range(nk)]
+    cols.append(abi.HostColumn(abi.BIGINT, np.arange(nb, dtype=np.int64)))
+    b.add_input(abi.HostBatch(cols, nb))
+    table = b.finish()
+    probe = impl.JoinProbe(table, list(range(nk)), join_type, False, True)
+    probe.add_input(abi.HostBatch([abi.HostColumn(kinds[k], pcols[k], pvalids[k]) for k in range(nk)], len(pcols[0])))
+    out = []
+    while True:
+        mapping, rows, cols, fin = probe.get_output(max_rows)
+        for i, m in enumerate(mapping):
+            out.append((int(m), int(rows[i])))
+        if fin:
+            break
+    return out
+
+
+def _nav_cases(rng, nb, npb, kinds):
+    def column(kind, n):
+        if kind == abi.VARCHAR:
+            words = [b"", b"a", b"bb", b"a key of more than twelve bytes"]
+            return [words[i] for i in rng.integers(0, len(words), n)]
+        return rng.integers(0, 6, n).astype(np.int64)
+    bcols = [column(k, nb) for k in kinds]
+    pcols = [column(k, npb) for k in kinds]
+    bvalids = [rng.random(nb) > 0.3 for _ in kinds]
+    pvalids = [rng.random(npb) > 0.3 for _ in kinds]
+    def keyof(cols, valids, r):
+        return tuple((cols[k][r] if not isinstance(cols[k][r], np.integer) else int(cols[k][r])) if valids[k][r] else None
+                     for k in range(len(kinds)))
+    bkeys = [keyof(bcols, bvalids, r) for r in range(nb)]
+    pkeys = [keyof(pcols, pvalids, r) for r in range(npb)]
+    return bcols, bvalids, pcols, pvalids, bkeys, pkeys
+
+
+@pytest.mark.parametrize("kinds", [[abi.BIGINT], [abi.BIGINT, abi.BIGINT], [abi.VARCHAR, abi.BIGINT]])
+def test_null_as_value_joins_against_nested_loops(oracle, kinds):
+    """HashJoinNode::isNullAsValue (core/PlanNode.h:3442-3445): keys compare IS NOT DISTINCT FROM.
+    Inner / left pairs and the counting joins (INTERSECT ALL / EXCEPT ALL) against plain Python
+    over key tuples in which None equals None."""
+    rng = np.random.default_rng(909 + len(kinds))
+    nb, npb = 300, 700
+    bcols, bvalids, pcols, pvalids, bkeys, pkeys = _nav_cases(rng, nb, npb, kinds)
+    assert any(None in k for k in bkeys) and any(None in k for k in pkeys)
+    want_inner = sorted((i, j) for i in range(npb) for j in range(nb) if pkeys[i] == bkeys[j])
+    got = _nav_join(oracle, abi.JOIN_INNER, bcols, bvalids, pcols, pvalids, kinds)
+    assert sorted(got) == want_inner
+    got = _nav_join(oracle, abi.JOIN_LEFT, bcols, bvalids, pcols, pvalids, kinds)
+    matched = {i for i, _ in want_inner}
+    assert sorted(got) == sorted(want_inner + [(i, -1) for i in range(npb) if i not in matched])
+    # counting joins: every probe row consumes one occurrence of its key while any is left
+    from collections import Counter
+    left = Counter(bkeys)
+    inter, exc = [], []
+    for i, k in enumerate(pkeys):
+        if left[k] > 0:
+            left[k] -= 1
+            inter.append(i)
+        else:
+            exc.append(i)
+    assert [m for m, _ in _nav_join(oracle, abi.JOIN_COUNTING_LEFT_SEMI_FILTER, bcols, bvalids, pcols, pvalids, kinds)] == inter
+    assert [m for m, _ in _nav_join(oracle, abi.JOIN_COUNTING_ANTI, bcols, bvalids, pcols, pvalids, kinds)] == exc

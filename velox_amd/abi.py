@@ -101,7 +101,7 @@ class JoinBuildSpec(C.Structure):
                 ("key_types", C.POINTER(C.c_int32)), ("num_dependents", C.c_int32),
                 ("dependent_cols", C.POINTER(C.c_int32)),
                 ("dependent_types", C.POINTER(C.c_int32)), ("join_type", C.c_int32),
-                ("null_aware", C.c_int32)]
+                ("null_aware", C.c_int32), ("null_as_value", C.c_int32), ("pad", C.c_int32)]
 
 
 class JoinTableStats(C.Structure):
@@ -111,7 +111,8 @@ class JoinTableStats(C.Structure):
 
 class JoinProbeSpec(C.Structure):
     _fields_ = [("num_keys", C.c_int32), ("key_cols", C.POINTER(C.c_int32)),
-                ("join_type", C.c_int32), ("null_aware", C.c_int32)]
+                ("join_type", C.c_int32), ("null_aware", C.c_int32), ("null_as_value", C.c_int32),
+                ("pad", C.c_int32)]
 
 
 # vx355_cmp

@@ -122,6 +122,9 @@ struct AppendArgs {
   // unmatched rows, HashBuild.cpp:475-494) but never enter the table:
   const uint64_t* keyValidWords;  // bit per input row: all keys non-null
   uint8_t* keyNullOut;            // per build row
+  // HashJoinNode::isNullAsValue (IS NOT DISTINCT FROM keys, set operations): a null key is a
+  // value (id 0 / kNullHash), the row is inserted, keyNullOut[row] = bit k for a null key k
+  int32_t nullAsValue;
   // strings longer than 12 bytes (keys and payloads) are copied into the build side's arena
   char* arenaBase;
   unsigned long long* arenaCursor;
@@ -179,12 +182,19 @@ __global__ __launch_bounds__(256) void k_build_append(AppendArgs a) {
        p += stride) {
     const int64_t row = a.rows ? a.rows[p] : p;
     const bool keyOk = !a.keyValidWords || bitAt(a.keyValidWords, row);
+    uint8_t nullMask = keyOk ? 0 : 1;
+    if (a.nullAsValue) {
+      nullMask = 0;
+      for (int k = 0; k < a.numKeys; ++k) {
+        nullMask |= colIsNull(a.keys[k], row) ? static_cast<uint8_t>(1u << k) : 0;
+      }
+    }
     if (a.keyNullOut) {
-      a.keyNullOut[a.base + p] = keyOk ? 0 : 1;
+      a.keyNullOut[a.base + p] = nullMask;
     }
     for (int k = 0; k < a.numKeys; ++k) {
       const ColView& c = a.keys[k];
-      if (!keyOk) {
+      if (a.nullAsValue ? ((nullMask >> k) & 1) != 0 : !keyOk) {
         a.keyOut[k][(a.base + p) * a.keyWords[k]] = 0;
         if (a.keyWords[k] == 2) {
           a.keyOut[k][(a.base + p) * 2 + 1] = 0;
@@ -293,6 +303,8 @@ struct InsertArgs {
   int32_t pad;
   BuildCounters* counters;
   const uint8_t* keyNull;  // rows kept for right / full joins only: not inserted
+  int32_t nullAsValue;     // keyNull[row] is a mask of null keys instead, and such rows are inserted
+  int32_t pad2;
 };
 
 constexpr uint32_t kPendingRow = 0xfffffffeu;
@@ -313,6 +325,9 @@ __device__ inline int64_t storedKeyValue(const uint64_t* store, int32_t words, i
 __device__ inline uint64_t buildKey(const InsertArgs& a, int64_t row) {
   uint64_t key = 0;
   for (int k = 0; k < a.numKeys; ++k) {
+    if (a.nullAsValue && a.keyNull && ((a.keyNull[row] >> k) & 1)) {
+      continue;  // value id 0 = null (VectorHasher.h:188)
+    }
     const int64_t v = storedKeyValue(a.keyStore[k], a.keyWords[k], a.keyIsString[k], row);
     const uint64_t id = static_cast<uint64_t>(v) - static_cast<uint64_t>(a.ranges[k].min) + 1;
     key += a.ranges[k].multiplier * id;
@@ -321,6 +336,9 @@ __device__ inline uint64_t buildKey(const InsertArgs& a, int64_t row) {
 }
 
 __device__ inline bool storedKeysEqual(const InsertArgs& a, int64_t r1, int64_t r2) {
+  if (a.nullAsValue && a.keyNull && a.keyNull[r1] != a.keyNull[r2]) {
+    return false;  // null equals null only (the images of null keys are zero)
+  }
   for (int k = 0; k < a.numKeys; ++k) {
     const int w = a.keyWords[k];
     if (a.keyIsString[k]) {
@@ -422,7 +440,7 @@ __global__ __launch_bounds__(256) void k_join_insert(InsertArgs a) {
       for (int u = 0; u < kInFlight; ++u) {
         const int64_t row = row0 + u * stride;
         const bool inRange = r + u < rounds && row < a.numRows;
-        nullKey[u] = inRange && a.keyNull && a.keyNull[row];
+        nullKey[u] = inRange && !a.nullAsValue && a.keyNull && a.keyNull[row];
         const bool active = inRange && !nullKey[u];
         keys[u] = active ? buildKey(a, row) : 0;
         claim[u] = issueClaim(a.present, active, keys[u]);
@@ -461,7 +479,7 @@ __global__ __launch_bounds__(256) void k_join_insert(InsertArgs a) {
   }
   for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < a.numRows;
        row += stride) {
-    if (a.keyNull && a.keyNull[row]) {
+    if (!a.nullAsValue && a.keyNull && a.keyNull[row]) {
       if (a.phase == 1) {
         a.next[row] = kNoRow32;
       }
@@ -483,7 +501,10 @@ __global__ __launch_bounds__(256) void k_join_insert(InsertArgs a) {
       uint64_t hash = 0;
       for (int k = 0; k < a.numKeys; ++k) {
         const int w = a.keyWords[k];
-        const uint64_t hv = hashFromImage(a.keyKind[k], a.keyStore[k][row * w], w == 2 ? a.keyStore[k][row * 2 + 1] : 0);
+        uint64_t hv = hashFromImage(a.keyKind[k], a.keyStore[k][row * w], w == 2 ? a.keyStore[k][row * 2 + 1] : 0);
+        if (a.nullAsValue && a.keyNull && ((a.keyNull[row] >> k) & 1)) {
+          hv = kNullHash;
+        }
         hash = k == 0 ? hv : hashMix(hash, hv);
       }
       const uint64_t tag = hash >> 32;
@@ -649,6 +670,9 @@ struct ProbeArgs {
   int32_t countHits;    // add every tile's hit count to sparseStats[1] (the sample launch)
   int32_t pad3;
   uint64_t* sparseStats;  // [0] overflowed tiles, [1] hits listed (HBM: atomics on the pinned mailbox cross PCIe)
+  int32_t nullAsValue;            // a null probe key is a value: id 0 / kNullHash
+  int32_t pad4;
+  const uint8_t* keyNullStore;    // generic hash mode + nullAsValue: null-key mask per build row
 };
 
 constexpr int kSparseCap = 1024;  // staged pairs per tile of 8192 probe rows (12.5 % hit rate)
@@ -693,6 +717,9 @@ __device__ inline bool probeKey(const ProbeArgs& a, int64_t row, uint64_t* keyOu
   for (int k = 0; k < a.numKeys; ++k) {
     const ColView& c = a.keys[k];
     if (colIsNull(c, row)) {
+      if (a.nullAsValue) {
+        continue;  // value id 0
+      }
       return false;  // a null key never matches (HashProbe.cpp:778)
     }
     int64_t v;
@@ -711,6 +738,7 @@ __device__ inline bool probeKey(const ProbeArgs& a, int64_t row, uint64_t* keyOu
 __device__ inline uint32_t lookupGeneric(const ProbeArgs& a, int64_t row) {
   uint64_t w0[kMaxKeys], w1[kMaxKeys];
   uint64_t hash = 0;
+  uint32_t nullMask = 0;
 #pragma unroll
   for (int k = 0; k < kMaxKeys; ++k) {
     w0[k] = 0;
@@ -718,7 +746,12 @@ __device__ inline uint32_t lookupGeneric(const ProbeArgs& a, int64_t row) {
     if (k < a.numKeys) {
       const ColView& c = a.keys[k];
       if (colIsNull(c, row)) {
-        return kNoRow32;
+        if (!a.nullAsValue) {
+          return kNoRow32;
+        }
+        nullMask |= 1u << k;
+        hash = k == 0 ? kNullHash : hashMix(hash, kNullHash);
+        continue;
       }
       const int64_t i = colIndex(c, row);
       bool inlineOk = true;
@@ -737,7 +770,7 @@ __device__ inline uint32_t lookupGeneric(const ProbeArgs& a, int64_t row) {
     }
     if ((w >> 32) == tag) {
       const uint64_t rep = static_cast<uint64_t>(static_cast<uint32_t>(w)) - 1;
-      bool equal = true;
+      bool equal = !a.nullAsValue || (a.keyNullStore ? a.keyNullStore[rep] : 0) == nullMask;
 #pragma unroll
       for (int k = 0; k < kMaxKeys; ++k) {
         if (equal && k < a.numKeys) {
@@ -1891,6 +1924,8 @@ bool keepsNullKeyRows(int32_t t) {
   return t == VX355_JOIN_RIGHT || t == VX355_JOIN_FULL || t == VX355_JOIN_RIGHT_SEMI_PROJECT ||
       t == VX355_JOIN_RIGHT_ANTI;
 }
+// Rows with null keys stay in the row store (and, with nullAsValue, enter the table).
+bool retainsNullKeyRows(int32_t joinType, bool nullAsValue) { return keepsNullKeyRows(joinType) || nullAsValue; }
 bool marksProbedRows(int32_t t) {
   return t == VX355_JOIN_RIGHT || t == VX355_JOIN_FULL || t == VX355_JOIN_RIGHT_SEMI_FILTER ||
       t == VX355_JOIN_RIGHT_SEMI_PROJECT || t == VX355_JOIN_RIGHT_ANTI;
@@ -1933,7 +1968,8 @@ struct vx355_join_build {
   int64_t capacityRows = 0;
   bool hasNullKeys = false;
   bool finished = false;
-  DevBuf keyNull;  // right / full joins: 1 byte per row, set for rows with a null key
+  DevBuf keyNull;  // right / full joins: 1 byte per row, set for rows with a null key (nullAsValue: mask of null keys)
+  bool nullAsValue = false;  // HashJoinNode::isNullAsValue
   std::vector<int64_t> obsMin, obsMax;
   DevBuf countersBuf, scratch, validWords, rowList;
   // arena of key / payload strings longer than 12 bytes (blocks never move: stored views point into them)
@@ -1968,6 +2004,8 @@ struct vx355_join_table {
   DevBuf remaining;  // counting joins: occurrences left per distinct key, at the chain's head row
   std::vector<DevBuf> strBlocks;  // the builds' string arenas
   bool keepsNullRows = false;
+  bool nullAsValue = false;
+  DevBuf keyNull;  // nullAsValue: the builds' null-key masks, by build row
   // dynamic filters: ascending distinct values per key, computed on first request
   std::vector<DevBuf> distinctVals;
   std::vector<int64_t> distinctCount;  // -1 = not computed
@@ -2029,7 +2067,7 @@ void growBuild(vx355_join_build& h, int64_t rows) {
     const size_t w = static_cast<size_t>(keyWordsOf(h.keyKinds[k])) * 8;
     h.keyVals[k].ensure(static_cast<size_t>(cap) * w + 64, true, static_cast<size_t>(h.numRows) * w);
   }
-  if (keepsNullKeyRows(h.joinType)) {
+  if (retainsNullKeyRows(h.joinType, h.nullAsValue)) {
     h.keyNull.ensure(static_cast<size_t>(cap) + 64, true, static_cast<size_t>(h.numRows));
   }
   for (size_t d = 0; d < h.depVals.size(); ++d) {
@@ -2076,7 +2114,7 @@ void buildAddInput(vx355_join_build& h, const vx355_batch* batch) {
   for (int k = 0; k < va.numKeys; ++k) {
     anyKeyNulls = anyKeyNulls || va.keys[k].nulls != nullptr;
   }
-  const bool keepNulls = keepsNullKeyRows(h.joinType);
+  const bool keepNulls = retainsNullKeyRows(h.joinType, h.nullAsValue);
   int32_t* rows = nullptr;
   int64_t selected = n;
   if (anyKeyNulls) {  // key columns without null bitmaps (the common case) skip both passes
@@ -2136,6 +2174,7 @@ void buildAddInput(vx355_join_build& h, const vx355_batch* batch) {
       aa.keyValidWords = anyKeyNulls ? va.validWords : nullptr;
       aa.keyNullOut = h.keyNull.as<uint8_t>();
     }
+    aa.nullAsValue = h.nullAsValue ? 1 : 0;
     VX_LAUNCH("k_build_append", k_build_append, streamGrid(selected, 256), 256, 0, aa);
   }
   BuildCounters c = readBuildCounters(h.countersBuf);
@@ -2183,7 +2222,7 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
         copyIn(h.keyVals[k].as<char>() + h.numRows * w, o.keyVals[k].ptr(), VX355_MEM_DEVICE,
                static_cast<size_t>(o.numRows) * w);
       }
-      if (keepsNullKeyRows(h.joinType)) {
+      if (retainsNullKeyRows(h.joinType, h.nullAsValue)) {
         copyIn(h.keyNull.as<char>() + h.numRows, o.keyNull.ptr(), VX355_MEM_DEVICE, static_cast<size_t>(o.numRows));
       }
       h.unmappable = h.unmappable || o.unmappable;
@@ -2261,10 +2300,12 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
     ia.ranges[k] = t->ranges[k];
   }
   ia.numRows = h.numRows;
-  if (keepsNullKeyRows(h.joinType) && h.hasNullKeys) {
+  if (retainsNullKeyRows(h.joinType, h.nullAsValue) && h.hasNullKeys) {
     ia.keyNull = h.keyNull.as<uint8_t>();
     t->keepsNullRows = true;
   }
+  ia.nullAsValue = h.nullAsValue ? 1 : 0;
+  t->nullAsValue = h.nullAsValue;
   resetBuildCounters(h.countersBuf);
   ia.counters = h.countersBuf.as<BuildCounters>();
   t->next.ensure(static_cast<size_t>(std::max<int64_t>(1, h.numRows)) * 4 + 64);
@@ -2348,6 +2389,9 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
   // against them, dynamic filters (value lists, Bloom blocks) are made from them.
   t->keyStore = std::move(h.keyVals);
   h.keyVals.clear();
+  if (h.nullAsValue) {
+    t->keyNull = std::move(h.keyNull);  // generic-mode probes compare null masks too
+  }
   h.finished = true;
   return t.release();
 }
@@ -2470,6 +2514,8 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
     }
   }
   a.mode = t.mode;
+  a.nullAsValue = t.nullAsValue ? 1 : 0;
+  a.keyNullStore = (t.nullAsValue && t.keepsNullRows) ? t.keyNull.as<uint8_t>() : nullptr;
   a.hasDuplicates = t.hasDuplicates ? 1 : 0;
   a.joinType = p.joinType;
   a.numRows = n;
@@ -3040,8 +3086,12 @@ int vx355_join_build_create(const vx355_join_build_spec* spec, vx355_join_build*
   if (countingJoin(spec->join_type) && spec->num_dependents != 0) {
     VX_THROW(VX355_EINVAL, "counting joins (INTERSECT ALL / EXCEPT ALL) have no build payload columns");
   }
+  if (spec->null_as_value && spec->null_aware) {
+    VX_THROW(VX355_EINVAL, "nullAware and nullAsValue are mutually exclusive");  // core/PlanNode.h:3474
+  }
   auto h = std::make_unique<vx355_join_build>();
   h->joinType = spec->join_type;
+  h->nullAsValue = spec->null_as_value != 0;
   for (int32_t k = 0; k < spec->num_keys; ++k) {
     const int32_t kind = spec->key_types[k];
     if (kindWidth(kind) < 0) {
@@ -3186,6 +3236,9 @@ int vx355_join_probe_create(vx355_join_table* table, const vx355_join_probe_spec
   }
   if (Runtime::get().device != table->device) {
     VX_THROW(VX355_EINVAL, "probe created on another GPU than its join table (vx355_set_device)");
+  }
+  if ((spec->null_as_value != 0) != table->nullAsValue) {
+    VX_THROW(VX355_EINVAL, "nullAsValue of the probe and of its join table differ");
   }
   auto p = std::make_unique<vx355_join_probe>();
   p->ctx = Runtime::createContext();
