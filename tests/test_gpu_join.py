@@ -869,8 +869,6 @@ def test_null_as_value_joins(oracle, vx, shape, join_type):
     counting joins with, core/PlanNode.h:3442-3445): NULL keys are values on both sides, in every
     table mode; oracle parity (the oracle itself is checked against nested loops on the CPU)."""
     counting = join_type in (abi.JOIN_COUNTING_LEFT_SEMI_FILTER, abi.JOIN_COUNTING_ANTI)
-    if counting and shape in ("hash", "string_key"):
-        pytest.skip("counting joins need a normalized key")
     rng = np.random.default_rng(1234 + hash(shape) % 100)
     nb, npb = 4000, 15000
     if shape == "array":

@@ -358,6 +358,20 @@ __device__ inline bool storedKeysEqual(const InsertArgs& a, int64_t r1, int64_t 
   return true;
 }
 
+// VectorHasher hash of a build row's keys from their stored images (generic hash mode).
+__device__ inline uint64_t storedRowHash(const InsertArgs& a, int64_t row) {
+  uint64_t hash = 0;
+  for (int k = 0; k < a.numKeys; ++k) {
+    const int w = a.keyWords[k];
+    uint64_t hv = hashFromImage(a.keyKind[k], a.keyStore[k][row * w], w == 2 ? a.keyStore[k][row * 2 + 1] : 0);
+    if (a.nullAsValue && a.keyNull && ((a.keyNull[row] >> k) & 1)) {
+      hv = kNullHash;
+    }
+    hash = k == 0 ? hv : hashMix(hash, hv);
+  }
+  return hash;
+}
+
 // Sets the presence bit of 'key' for every active lane of the wave and tells each
 // lane whether it was the first to claim its key. HBM atomics retire at ~20 G/s
 // chip-wide, and build sides usually arrive in key order (a scan of the dimension
@@ -498,15 +512,7 @@ __global__ __launch_bounds__(256) void k_join_insert(InsertArgs a) {
       // is immediately comparable; equal keys are pushed behind the
       // representative (pushNext, HashTable.cpp:1412-1418); next[] was
       // pre-filled with "no row".
-      uint64_t hash = 0;
-      for (int k = 0; k < a.numKeys; ++k) {
-        const int w = a.keyWords[k];
-        uint64_t hv = hashFromImage(a.keyKind[k], a.keyStore[k][row * w], w == 2 ? a.keyStore[k][row * 2 + 1] : 0);
-        if (a.nullAsValue && a.keyNull && ((a.keyNull[row] >> k) & 1)) {
-          hv = kNullHash;
-        }
-        hash = k == 0 ? hv : hashMix(hash, hv);
-      }
+      const uint64_t hash = storedRowHash(a, row);
       const uint64_t tag = hash >> 32;
       const uint64_t gmask = a.capacity - 1;
       uint64_t pos = hash & gmask;
@@ -598,11 +604,31 @@ __global__ __launch_bounds__(256) void k_count_init(InsertArgs a, uint32_t* rema
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < a.numRows;
        row += stride) {
-    const uint64_t key = buildKey(a, row);
     uint32_t head = kNoRow32;
-    if (a.mode == JMODE_ARRAY) {
-      head = a.head[key];
+    if (a.mode == JMODE_HASH) {
+      // the chain hangs off the slot's representative row, which is what a probe's hits[] names
+      const uint64_t hash = storedRowHash(a, row);
+      const uint64_t tag = hash >> 32;
+      const uint64_t mask = a.capacity - 1;
+      uint64_t pos = hash & mask;
+      for (uint64_t probes = 0; probes <= mask; ++probes) {
+        const uint64_t w = a.gslots[pos];
+        if (w == 0) {
+          break;
+        }
+        if ((w >> 32) == tag) {
+          const int64_t candidate = static_cast<int64_t>(static_cast<uint32_t>(w)) - 1;
+          if (storedKeysEqual(a, row, candidate)) {
+            head = static_cast<uint32_t>(candidate);
+            break;
+          }
+        }
+        pos = (pos + 1) & mask;
+      }
+    } else if (a.mode == JMODE_ARRAY) {
+      head = a.head[buildKey(a, row)];
     } else {
+      const uint64_t key = buildKey(a, row);
       const uint64_t mask = a.capacity - 1;
       uint64_t pos = twangMix64(key) & mask;
       for (uint64_t probes = 0; probes <= mask; ++probes) {
@@ -2357,9 +2383,6 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
   t->numDistinct = c.numDistinct;
   t->hasDuplicates = c.duplicates != 0;
   if (countingJoin(h.joinType)) {
-    if (t->mode == JMODE_HASH) {
-      VX_THROW(VX355_EUNSUPPORTED, "counting joins over keys without a normalized form");
-    }
     const size_t bytes = static_cast<size_t>(std::max<int64_t>(1, h.numRows)) * 4;
     t->remaining.ensure(bytes + 64);
     HIP_OK(hipMemsetAsync(t->remaining.ptr(), 0, bytes, rt.stream));
