@@ -416,8 +416,8 @@ typedef enum vx355_agg_kind {
   VX355_AGG_COUNT = 1,      /* count(x), CountAggregate.cpp:27-147; x of any column type (raw input) */
   VX355_AGG_COUNT_STAR = 2, /* count(*) */
   VX355_AGG_MIN = 3,        /* MinMaxAggregateBase.cpp:101-305; over VARCHAR / VARBINARY input
-                               :305-480 (any step: the intermediate type is the input type;
-                               no partial flush). Strings longer than 12 bytes come out as
+                               :305-480 (any step: the intermediate type is the input type).
+                               Strings longer than 12 bytes come out as
                                described at vx355_out_column. */
   VX355_AGG_MAX = 4,
   VX355_AGG_AVG = 5         /* AverageAggregateBase.h:66-260 */

@@ -1138,8 +1138,46 @@ def test_distinct_and_string_aggregates_on_empty_and_tiny_inputs(oracle, vx, glo
         assert_columns_equal(got, exp, gop.kinds, what=name)
 
 
-def test_operator_with_parts_refuses_flush_and_to_intermediate(vx):
+def test_partial_flush_with_min_max_over_strings(oracle, vx):
+    """A PARTIAL operator carrying min / max over VARCHAR is flushed in the middle of its input
+    (HashAggregation.cpp:191-236): the flushed pages plus the rest, merged by a FINAL operator,
+    equal the SINGLE aggregation; the operator starts over with empty tables after each flush."""
+    rng = np.random.default_rng(8080)
+    n = 24000
+    k = rng.integers(0, 200, n).astype(np.int64)
+    s = [_WORDS[i] for i in rng.integers(0, len(_WORDS), n)]
+    sv = rng.random(n) > 0.2
+    x = rng.integers(-50, 50, n).astype(np.int64)
+    aggs = [(abi.AGG_MIN, 1, abi.VARCHAR), (abi.AGG_SUM, 2, abi.BIGINT), (abi.AGG_MAX, 1, abi.VARCHAR)]
+
+    def piece(lo, hi):
+        return abi.HostBatch([abi.HostColumn(abi.BIGINT, k[lo:hi]), abi.HostColumn(abi.VARCHAR, s[lo:hi], valid=sv[lo:hi]),
+                              abi.HostColumn(abi.BIGINT, x[lo:hi])], hi - lo)
+
+    exp, _ = run_agg(oracle, [piece(0, n)], [0], [abi.BIGINT], aggs)
+    op = vx.Aggregation([0], [abi.BIGINT], aggs, abi.STEP_PARTIAL)
+    pages = []
+    for lo in range(0, n, 6000):
+        op.add_input(piece(lo, lo + 6000))
+        if lo in (6000, 12000):
+            op.flush()
+            pages.append(vx.collect_output(op, 77))
+            assert op.stats().num_groups == 0
+    op.no_more_input()
+    pages.append(vx.collect_output(op, 77))
+    assert op.stats().num_flushes == 2
+    partial = abi.HostBatch([abi.HostColumn(kind, sum((list(p[c][0]) for p in pages), []) if kind == abi.VARCHAR
+                                            else np.concatenate([np.asarray(p[c][0]) for p in pages]),
+                                            valid=np.concatenate([np.asarray(p[c][1], bool) for p in pages]))
+                             for c, kind in enumerate(op.kinds)])
+    final_aggs = [(abi.AGG_MIN, 1, abi.VARCHAR), (abi.AGG_SUM, 2, abi.BIGINT), (abi.AGG_MAX, 3, abi.VARCHAR)]
+    got, gop = run_agg(vx, [partial], [0], [abi.BIGINT], final_aggs, abi.STEP_FINAL)
+    assert_columns_equal(got, exp, gop.kinds, what="flush with string min / max")
+
+
+def test_operator_with_parts_refuses_to_intermediate(vx):
     op = vx.Aggregation([0], [abi.BIGINT], [(abi.AGG_MIN, 1, abi.VARCHAR)], abi.STEP_PARTIAL)
+    b = abi.HostBatch([abi.HostColumn(abi.BIGINT, np.arange(3, dtype=np.int64)), abi.HostColumn(abi.VARCHAR, [b"a", b"b", b"c"])])
     with pytest.raises(Exception) as e:
-        op.flush()
-    assert "flush" in str(e.value)
+        op.to_intermediate(b, [abi.VARCHAR])
+    assert "toIntermediate" in str(e.value)

@@ -2264,16 +2264,26 @@ struct vx355_agg {
     const uint32_t* sortedRows = nullptr;  // sorted position -> dedup row
   };
   std::vector<DistinctPart> distinct;
+  std::vector<DistinctPart> retired;  // parts of the last flush: device output views point into their arenas
+  // the caller's spec, kept to rebuild the parts after a partial flush
+  std::vector<int32_t> specKeyCols, specKeyTypes;
+  std::vector<vx355_agg_fn> specAggs;
+  int32_t specFlags = 0;
   std::vector<int32_t> specIsDistinct;  // per caller aggregate
   std::vector<int32_t> fullOutTypes;    // what the caller sees when 'distinct' is not empty
   bool keysOptional = false;  // an 'outer': key output columns without a buffer are skipped
   bool ownsCtx = true;        // dedup / outer run on their parent's context
 
-  ~vx355_agg() {
-    for (auto& d : distinct) {
+  void dropParts(std::vector<DistinctPart>& parts) {
+    for (auto& d : parts) {
       delete d.dedup;
       delete d.outer;
     }
+    parts.clear();
+  }
+  ~vx355_agg() {
+    dropParts(distinct);
+    dropParts(retired);
   }
 
   Counters* counters() { return countersBuf.as<Counters>(); }
@@ -4657,6 +4667,10 @@ int vx355_agg_create(const vx355_agg_spec* spec, vx355_agg** out) {
     mainSpec.aggs = plain.data();
     buildPlan(*h, mainSpec);
     h->unorderedOutput = false;  // the parts pair up with this operator's rows by order
+    h->specKeyCols.assign(spec->key_cols, spec->key_cols + spec->num_keys);
+    h->specKeyTypes.assign(spec->key_types, spec->key_types + spec->num_keys);
+    h->specAggs.assign(spec->aggs, spec->aggs + spec->num_aggs);
+    h->specFlags = spec->flags;
     buildDistinctParts(*h, *spec);
     h->fullOutTypes.assign(h->outTypes.begin(), h->outTypes.begin() + spec->num_keys);
     size_t nextPlain = static_cast<size_t>(spec->num_keys), nextPart = 0;
@@ -4772,6 +4786,7 @@ int vx355_agg_get_output(vx355_agg* h, vx355_out_column* cols, int32_t num_cols,
       }
     }
     h->hostStrings.clear();
+    const bool wasFlushing = h->flushing;
     const bool keepStrings = h->generic && h->hasStringKeys;  // getOutput clears the list itself then
     std::vector<std::vector<char>> keyStrings;
     getOutput(*h, mine.data(), static_cast<int32_t>(mine.size()), max_rows, n_out, finished);
@@ -4799,6 +4814,26 @@ int vx355_agg_get_output(vx355_agg* h, vx355_out_column* cols, int32_t num_cols,
     for (auto& block : keyStrings) {
       h->hostStrings.push_back(std::move(block));
     }
+    if (wasFlushing && !h->flushing) {
+      // the flush has been drained (getOutput reset this operator's table): fresh parts. The
+      // old ones stay until the next flush: device output columns point into their arenas.
+      h->dropParts(h->retired);
+      h->retired.swap(h->distinct);
+      vx355_agg_spec spec{};
+      spec.num_keys = static_cast<int32_t>(h->specKeyCols.size());
+      spec.key_cols = h->specKeyCols.data();
+      spec.key_types = h->specKeyTypes.data();
+      spec.num_aggs = static_cast<int32_t>(h->specAggs.size());
+      spec.aggs = h->specAggs.data();
+      spec.step = h->step;
+      spec.ignore_null_keys = h->ignoreNullKeys ? 1 : 0;
+      spec.flags = h->specFlags;
+      buildDistinctParts(*h, spec);
+      for (auto& d : h->distinct) {
+        d.dedup->ctx = h->ctx;
+        d.outer->ctx = h->ctx;
+      }
+    }
   }
   VX_API_END
 }
@@ -4807,14 +4842,16 @@ int vx355_agg_flush(vx355_agg* h) {
   VX_API_BEGIN_CTX(VX_CTX_OF(h))
   VX_CHECK_ARG(h, "NULL argument");
   VX_CHECK_ARG(!h->noMoreInput, "flush after noMoreInput");
-  if (!h->distinct.empty()) {
-    VX_THROW(VX355_EUNSUPPORTED, "partial flush with min / max over strings");
-  }
   if (finalOutput(h->step) || h->keys.empty()) {
     // HashAggregation.cpp:218-224: only partial output is flushed, never a global aggregation
     VX_THROW(VX355_EINVAL, "flush applies to partial / intermediate steps with grouping keys");
   }
   flushPending(*h);
+  // min / max over strings: their tables are closed like at noMoreInput and rebuilt once the
+  // flushed groups are drained (DISTINCT parts only exist in the SINGLE step)
+  for (auto& d : h->distinct) {
+    pumpStringMinMax(*h, d);
+  }
   h->flushing = true;
   h->numOutput = -1;
   h->outputCursor = 0;
