@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
@@ -91,6 +92,47 @@ __global__ __launch_bounds__(256) void k_bits(const uint64_t* keys, int64_t n, c
   }
 }
 
+// The wave-cooperative bucket of the F14-style design (one 64-byte line of 64 one-byte tags per
+// bucket, all 64 lanes compare it with one ballot): every probe costs the WAVE one line read,
+// so a wave has U probes in flight instead of 64 * U. Upper bound of that design: the tag line
+// only, no key confirmation behind it.
+template <bool AFFINE, int U>
+__global__ __launch_bounds__(256) void k_tagline(const uint64_t* keys, int64_t n, const uint32_t* table,
+                                                 uint64_t tableWords, uint32_t* out) {
+  const uint8_t* tags = reinterpret_cast<const uint8_t*>(table);
+  const uint64_t sliceBytes = (AFFINE ? tableWords / 8 : tableWords) * 4;
+  const uint64_t sliceBase = AFFINE ? (blockIdx.x & 7) * sliceBytes : 0;
+  const uint64_t lines = sliceBytes / 64;
+  const int ln = threadIdx.x & 63;
+  const int64_t wave = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) >> 6;
+  const int64_t waves = static_cast<int64_t>(gridDim.x) * 4;
+  for (int64_t base = wave * 64; base < n; base += waves * 64) {
+    const uint64_t mine = keys[base + ln < n ? base + ln : n - 1];
+    uint32_t result = 0;
+    for (int j = 0; j < 64; j += U) {
+      uint64_t h[U];
+      uint8_t t[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t lo = __shfl(static_cast<uint32_t>(mine), j + u, 64);
+        const uint32_t hi = __shfl(static_cast<uint32_t>(mine >> 32), j + u, 64);
+        h[u] = mix((static_cast<uint64_t>(hi) << 32) | lo);
+        t[u] = tags[sliceBase + (h[u] % lines) * 64 + ln];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t m = __ballot(t[u] == static_cast<uint8_t>(h[u] >> 56));
+        if (ln == j + u) {
+          result = static_cast<uint32_t>(m) ^ static_cast<uint32_t>(m >> 32) ^ t[u];
+        }
+      }
+    }
+    if (base + ln < n) {
+      out[base + ln] = result;
+    }
+  }
+}
+
 // Random 16-byte record scatter into B open bins (the partition pass): where do writes top out?
 __global__ __launch_bounds__(256) void k_stream_copy(const uint4* in, uint4* out, int64_t n) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
@@ -132,6 +174,17 @@ int main(int argc, char** argv) {
            bytes / 1048576.0, grid, ms, n / ms / 1e6, n * 12.0 / ms / 1e6);
     fflush(stdout);
   };
+  if (argc > 1 && std::string(argv[1]) == "tagline") {
+    // wave-cooperative tag lines vs one lane per probe, at an L2-sized and an HBM-sized table
+    for (uint64_t s : {16ULL << 20, 512ULL << 20}) {
+      run("gather16 U4 (lane/probe)", (k_gather<16, false, 4>), s, 2048);
+      run("tagline  U4 (wave/probe)", (k_tagline<false, 4>), s, 2048);
+      run("tagline  U8 (wave/probe)", (k_tagline<false, 8>), s, 2048);
+      run("tagline  U16 (wave/probe)", (k_tagline<false, 16>), s, 2048);
+      run("tagline  U8 xcd-affine", (k_tagline<true, 8>), s, 2048);
+    }
+    return 0;
+  }
   const uint64_t sizes[] = {1ULL << 20, 4ULL << 20, 16ULL << 20, 32ULL << 20, 64ULL << 20, 128ULL << 20,
                             256ULL << 20, 512ULL << 20, 1ULL << 30, 4ULL << 30};
   for (uint64_t s : sizes) {
