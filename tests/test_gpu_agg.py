@@ -1175,9 +1175,37 @@ def test_partial_flush_with_min_max_over_strings(oracle, vx):
     assert_columns_equal(got, exp, gop.kinds, what="flush with string min / max")
 
 
-def test_operator_with_parts_refuses_to_intermediate(vx):
-    op = vx.Aggregation([0], [abi.BIGINT], [(abi.AGG_MIN, 1, abi.VARCHAR)], abi.STEP_PARTIAL)
-    b = abi.HostBatch([abi.HostColumn(abi.BIGINT, np.arange(3, dtype=np.int64)), abi.HostColumn(abi.VARCHAR, [b"a", b"b", b"c"])])
-    with pytest.raises(Exception) as e:
-        op.to_intermediate(b, [abi.VARCHAR])
-    assert "toIntermediate" in str(e.value)
+def test_to_intermediate_passes_strings_of_min_max_through(oracle, vx):
+    """Abandoned partial aggregation with min / max over VARCHAR: the value itself where the mask
+    lets the row through (MinMaxAggregateBase.cpp:319-349), next to the numeric aggregates; a
+    FINAL step over the result equals the SINGLE aggregation."""
+    rng = np.random.default_rng(63)
+    n = 30000
+    k = rng.integers(0, 300, n).astype(np.int64)
+    s = [_WORDS[i] for i in rng.integers(0, len(_WORDS), n)]
+    svalid = rng.random(n) > 0.2
+    x = _dyadic(rng, n)
+    m = rng.random(n) > 0.5
+    mvalid = rng.random(n) > 0.1
+    b = abi.HostBatch([abi.HostColumn(abi.BIGINT, k), abi.HostColumn(abi.VARCHAR, s, valid=svalid),
+                       abi.HostColumn(abi.DOUBLE, x), abi.HostColumn(abi.BOOLEAN, m, valid=mvalid)])
+    raw = [(abi.AGG_MIN, 1, abi.VARCHAR), (abi.AGG_AVG, 2, abi.DOUBLE), (abi.AGG_MAX, 1, abi.VARCHAR, 3),
+           (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    kinds = [abi.VARCHAR, abi.DOUBLE, abi.BIGINT, abi.VARCHAR, abi.BIGINT]
+    op = vx.Aggregation([0], [abi.BIGINT], raw, abi.STEP_PARTIAL)
+    cols = op.to_intermediate(b, kinds)
+    ok = m & mvalid
+    assert [v for v, valid in zip(cols[0][0], cols[0][1]) if valid] == [v for v, valid in zip(s, svalid) if valid]
+    assert (np.asarray(cols[0][1]) == svalid).all()
+    assert (np.asarray(cols[3][1]) == (svalid & ok)).all()
+    assert [v for v, valid in zip(cols[3][0], cols[3][1]) if valid] == [v for v, valid in zip(s, svalid & ok) if valid]
+    final_aggs = [(abi.AGG_MIN, 1, abi.VARCHAR), (abi.AGG_AVG, 2, abi.DOUBLE, -1, 3), (abi.AGG_MAX, 4, abi.VARCHAR),
+                  (abi.AGG_COUNT_STAR, 5, abi.BIGINT)]
+    fin = vx.Aggregation([0], [abi.BIGINT], final_aggs, abi.STEP_FINAL)
+    fin.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, k)] +
+                                [abi.HostColumn(kind, v if isinstance(v, list) else np.asarray(v), np.asarray(valid, bool))
+                                 for kind, (v, valid) in zip(kinds, cols)]))
+    fin.no_more_input()
+    got = vx.collect_output(fin, 5000)
+    exp_single, eop = run_agg(oracle, [b], [0], [abi.BIGINT], raw, max_rows=5000)
+    assert_columns_equal(got, exp_single, eop.kinds, what="final(toIntermediate) vs single, strings")

@@ -4079,6 +4079,24 @@ __global__ __launch_bounds__(256) void k_rank_to_view(const int64_t* ranks, cons
   }
 }
 
+// toIntermediate of min / max over strings: the value itself where the mask lets the row through
+// (MinMaxAggregateBase.cpp:319-349).
+__global__ __launch_bounds__(256) void k_string_pass(ColView in, ColView mask, int32_t hasMask, int32_t n, uint4* out,
+                                                     uint64_t* outNulls) {
+  const int32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos - static_cast<int32_t>(lane()) >= n) {
+    return;
+  }
+  bool valid = pos < n && !colIsNull(in, pos);
+  if (valid && hasMask) {
+    valid = !colIsNull(mask, pos) && loadInt64(mask, colIndex(mask, pos)) != 0;
+  }
+  writeBit(outNulls, pos, valid);
+  if (pos < n) {
+    out[pos] = valid ? static_cast<const uint4*>(in.values)[colIndex(in, pos)] : make_uint4(0, 0, 0, 0);
+  }
+}
+
 void getOutput(vx355_agg& h, vx355_out_column* cols, int32_t numCols, int32_t maxRows, int32_t* nOut,
                int32_t* finished) {
   auto& rt = Runtime::get();
@@ -4567,6 +4585,41 @@ void stringMinMaxOutput(vx355_agg& h, vx355_agg::DistinctPart& part, vx355_out_c
   }
 }
 
+void stringToIntermediate(vx355_agg& h, const vx355_batch* batch, const vx355_agg_fn& f, vx355_out_column& dst) {
+  auto& rt = Runtime::get();
+  VX_CHECK_ARG(dst.type_kind == f.input_type && dst.values != nullptr, "output column of a string min / max");
+  VX_CHECK_ARG(f.input_col >= 0 && f.input_col < batch->num_cols, "aggregate input column");
+  const bool host = dst.mem == VX355_MEM_HOST;
+  if (!host && batch->cols[f.input_col].mem == VX355_MEM_HOST) {
+    // the views of a staged host column would outlive their bytes
+    VX_THROW(VX355_EUNSUPPORTED, "toIntermediate: device output of a host string column");
+  }
+  DeviceBatch db;
+  db.load(batch, {f.input_col, f.mask_col});
+  const int32_t n = db.numRows();
+  if (n == 0) {
+    return;
+  }
+  const size_t words = static_cast<size_t>(ceilDiv(n, 64));
+  DevBuf dViews, dNulls;
+  uint4* views = host ? static_cast<uint4*>(dViews.ensure(static_cast<size_t>(n) * 16 + 64)) : static_cast<uint4*>(dst.values);
+  uint64_t* nulls = host ? static_cast<uint64_t*>(dNulls.ensure(words * 8 + 64)) : dst.nulls;
+  const ColView in = db.col(f.input_col);
+  const ColView mask = f.mask_col >= 0 ? db.col(f.mask_col) : ColView{};
+  VX_LAUNCH("k_string_pass", k_string_pass, static_cast<int>(ceilDiv(n, 256)), 256, 0, in, mask, f.mask_col >= 0 ? 1 : 0, n,
+            views, nulls);
+  if (host) {
+    copyOutAsync(dst.values, VX355_MEM_HOST, views, static_cast<size_t>(n) * 16);
+    if (dst.nulls) {
+      copyOutAsync(dst.nulls, VX355_MEM_HOST, nulls, words * 8);
+    }
+    rt.sync();
+    fetchLongStrings(static_cast<char*>(dst.values), n, h.hostStrings);
+  } else {
+    rt.sync();
+  }
+}
+
 void feedInput(vx355_agg& h, const vx355_batch* batch) {
   if (!tryCoalesce(h, batch)) {
     flushPending(h);
@@ -4861,10 +4914,38 @@ int vx355_agg_flush(vx355_agg* h) {
 int vx355_agg_to_intermediate(vx355_agg* h, const vx355_batch* batch, vx355_out_column* cols, int32_t num_cols) {
   VX_API_BEGIN_CTX(VX_CTX_OF(h))
   VX_CHECK_ARG(h, "NULL argument");
-  if (!h->distinct.empty()) {
-    VX_THROW(VX355_EUNSUPPORTED, "toIntermediate with DISTINCT aggregates or min / max over strings");
+  if (h->distinct.empty()) {
+    toIntermediate(*h, batch, cols, num_cols);
+  } else {
+    // min / max over strings pass their input through; the other aggregates go the usual way
+    VX_CHECK_ARG(batch && cols, "NULL argument");
+    std::vector<vx355_out_column> plain;
+    std::vector<std::pair<size_t, int32_t>> strings;  // aggregate, output column
+    int32_t c = 0;
+    for (size_t i = 0; i < h->specAggs.size(); ++i) {
+      const int32_t width = h->specAggs[i].kind == VX355_AGG_AVG ? 2 : 1;  // the PARTIAL layout
+      VX_CHECK_ARG(c + width <= num_cols, "wrong number of aggregate output columns");
+      if (h->specIsDistinct[i]) {
+        if (!isStringMinMax(h->specAggs[i])) {
+          VX_THROW(VX355_EUNSUPPORTED, "toIntermediate with DISTINCT aggregates");
+        }
+        strings.emplace_back(i, c);
+      } else {
+        plain.insert(plain.end(), cols + c, cols + c + width);
+      }
+      c += width;
+    }
+    VX_CHECK_ARG(c == num_cols, "wrong number of aggregate output columns");
+    if (!plain.empty()) {
+      toIntermediate(*h, batch, plain.data(), static_cast<int32_t>(plain.size()));
+    } else if (!rawInput(h->step)) {
+      VX_THROW(VX355_EINVAL, "toIntermediate applies to raw input (partial / single steps); intermediate input passes through");
+    }
+    h->hostStrings.clear();
+    for (const auto& job : strings) {
+      stringToIntermediate(*h, batch, h->specAggs[job.first], cols[job.second]);
+    }
   }
-  toIntermediate(*h, batch, cols, num_cols);
   VX_API_END
 }
 
