@@ -322,7 +322,7 @@ struct Decoded {
   }
   // Integer-like kinds widened to int64 (VectorHasher::toInt64).
   int64_t int64At(int32_t row) const {
-    uint8_t tmp;
+    uint8_t tmp = 0;
     const void* p = valuePtr(row, &tmp);
     switch (c->type_kind) {
       case VX355_BOOLEAN:
@@ -347,7 +347,7 @@ struct Decoded {
     }
   }
   double doubleAt(int32_t row) const {
-    uint8_t tmp;
+    uint8_t tmp = 0;
     const void* p = valuePtr(row, &tmp);
     if (c->type_kind == VX355_REAL) {
       float v;
@@ -362,7 +362,7 @@ struct Decoded {
     return static_cast<double>(int64At(row));
   }
   uint64_t hashAt(int32_t row) const {
-    uint8_t tmp;
+    uint8_t tmp = 0;
     return hashValue(c->type_kind, valuePtr(row, &tmp));
   }
 };
