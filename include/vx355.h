@@ -344,6 +344,29 @@ int vx355_presto_serialize(
     int32_t out_mem,
     int64_t* page_offsets);
 
+/* The other direction, what an Exchange does with the pages it received
+ * (PrestoVectorSerde::deserialize, serializers/PrestoSerializer.cpp:120-200, appending page
+ * after page into one RowVector): pages (host memory, uncompressed; a checksum is verified when
+ * the codec marker carries one, "Received corrupted serialized page." -> VX355_EUSER) become
+ * flat columns in HBM, rows of page 0 first. types[] is the RowType the exchange expects; a
+ * page whose column encodings do not fit it is a VX355_EUSER. The page bytes are copied into
+ * device_bytes (>= the sum of sizes); views of strings longer than 12 bytes point into that
+ * buffer, so the caller keeps it as long as the columns (a vector's string buffer). cols: device
+ * memory, capacity_rows rows each (the row count of a page is its first little-endian int32,
+ * so the caller sizes them before the call). Null rows hold the type's default value. */
+int vx355_presto_deserialize(
+    const void* const* pages,
+    const int64_t* sizes,
+    int32_t num_pages,
+    const int32_t* types,
+    int32_t num_cols,
+    int32_t flags,
+    void* device_bytes,
+    int64_t device_bytes_capacity,
+    vx355_out_column* cols,
+    int64_t capacity_rows,
+    int64_t* rows_out);
+
 /* ---- FilterProject for the TPC-H Q1 / Q3 expression class ----------------- */
 
 /* The step immediately upstream of HashAggregation / HashProbe

@@ -320,3 +320,76 @@ def test_presto_page_timestamp_out_of_range_is_a_user_error(oracle, vx):
         assert "milliseconds" in str(e.value)
     assert vx.presto_serialize(batch, [0, 1], flags=abi.PAGE_LOSSLESS_TIMESTAMP) == \
         oracle.presto_serialize(batch, [0, 1], flags=abi.PAGE_LOSSLESS_TIMESTAMP)
+
+
+def _expect_rows(py, rows, lossless):
+    """Columns of presto_page_reader.random_page_batch in the order 'rows', TIMESTAMP as the
+    reader of the wire format sees it: {seconds, nanos} after Timestamp::fromMillis(toMillis)
+    unless lossless."""
+    out = []
+    for kind_values, valid in py:
+        out.append(([kind_values[r] for r in rows], [bool(valid[r]) for r in rows]))
+    if not lossless:
+        vals, valid = out[-1]
+        conv = []
+        for s, ns in vals:
+            ms = s * 1000 + ns // 1000000
+            conv.append((ms // 1000, (ms % 1000) * 1000000))  # floor semantics == fromMillis
+        out[-1] = (conv, valid)
+    return out
+
+
+@pytest.mark.parametrize("flags", [0, abi.PAGE_CHECKSUM, abi.PAGE_LOSSLESS_TIMESTAMP])
+def test_presto_pages_deserialize_to_device_columns(oracle, vx, flags):
+    """vx355_presto_deserialize (PrestoVectorSerde::deserialize): pages written by the oracle's
+    writer and by the GPU's come back as the rows they were made of - every kind, null bitmaps
+    present and absent, several pages appended (sizes around 8 / 64 rows and the empty page),
+    strings on both sides of the inline limit, checksums verified."""
+    from presto_page_reader import random_page_batch
+    rng = np.random.default_rng(4040)
+    n = 7000
+    batch, py = random_page_batch(rng, n)
+    kinds = [c.kind for c in batch.columns]
+    rows = rng.permutation(n).astype(np.int32)
+    offsets = [0, 0, 1, 9, 73, 137, 2185, 2185, n]
+    lossless = bool(flags & abi.PAGE_LOSSLESS_TIMESTAMP)
+    want = _expect_rows(py, list(rows), lossless)
+    for writer in (oracle, vx):
+        pages = writer.presto_serialize(batch, offsets, rows, flags)
+        got_n, got = vx.presto_deserialize(pages, kinds, flags & abi.PAGE_LOSSLESS_TIMESTAMP)
+        assert got_n == n
+        for c, kind in enumerate(kinds):
+            gv, gvalid = got[c]
+            wv, wvalid = want[c]
+            assert list(gvalid) == wvalid, (writer.__name__, c)
+            for r in range(n):
+                if not wvalid[r]:
+                    continue
+                g = tuple(int(x) for x in gv[r]) if kind == abi.TIMESTAMP else gv[r]
+                assert g == wv[r], (writer.__name__, c, r)
+    # a batch without nulls: no bitmaps on the wire
+    dense, dpy = random_page_batch(rng, 3000, with_nulls=False)
+    pages = oracle.presto_serialize(dense, [0, 3000], flags=flags)
+    got_n, got = vx.presto_deserialize(pages, kinds, flags & abi.PAGE_LOSSLESS_TIMESTAMP)
+    assert got_n == 3000 and all(all(valid) for _, valid in got)
+    assert [int(x) for x in got[0][0]] == dpy[0][0]
+
+
+def test_presto_deserialize_rejects_corrupt_and_mismatched_pages(oracle, vx):
+    from presto_page_reader import random_page_batch
+    rng = np.random.default_rng(5050)
+    batch, _ = random_page_batch(rng, 500)
+    kinds = [c.kind for c in batch.columns]
+    (page,) = oracle.presto_serialize(batch, [0, 500], flags=abi.PAGE_CHECKSUM)
+    broken = bytearray(page)
+    broken[len(broken) // 2] ^= 0x40
+    with pytest.raises(vx.Vx355Error) as e:
+        vx.presto_deserialize([bytes(broken)], kinds)
+    assert e.value.status == abi.EUSER and "corrupted" in str(e.value)
+    with pytest.raises(vx.Vx355Error) as e:
+        vx.presto_deserialize([page], [abi.INTEGER] + kinds[1:])      # BIGINT column read as INTEGER
+    assert e.value.status == abi.EUSER
+    with pytest.raises(vx.Vx355Error) as e:
+        vx.presto_deserialize([page[:-3]], kinds)                       # truncated
+    assert e.value.status == abi.EUSER
+    assert vx.presto_deserialize([], kinds)[0] == 0

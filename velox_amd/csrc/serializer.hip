@@ -618,6 +618,329 @@ void serializePages(const vx355_batch* batch, const int32_t* rows, int32_t rowsM
   }
 }
 
+// ---- the other direction: pages an Exchange received -> flat columns in HBM --------------------
+// (PrestoVectorSerde::deserialize, serializers/PrestoSerializer.cpp:120-200; column readers in
+// serializers/PrestoSerializerDeserializationUtils.cpp: read<T>, readNulls, the VARIABLE_WIDTH
+// reader.) The host walks the framing of every page (a few dozen bytes per column plus a popcount
+// over the null bytes, which it needs to find where the values end), the page bytes go to HBM
+// once, and one launch expands all pages and columns: a lane per output row finds its page, reads
+// its null bit, ranks itself among the non-null rows of its page (host prefix per 64 rows + a
+// popcount of the bits before it) and moves its value from the packed stream to its row.
+
+struct ReadSection {
+  int64_t nullPos;    // device byte offset of the null bytes; -1: the column has no nulls in this page
+  int64_t valuePos;   // first value / first string byte
+  int64_t offsetsPos; // VARIABLE_WIDTH: the i32 end offsets
+  int64_t prefixBase; // index of this page column's first 64-row block in 'prefix'
+};
+
+struct ReadArgs {
+  const unsigned char* bytes;    // all pages, back to back
+  const int64_t* pageRowBegin;   // numPages + 1
+  int32_t numPages;
+  int32_t numCols;
+  int32_t lossless;
+  int32_t pad;
+  int64_t totalRows;
+  const ReadSection* sections;   // [page * numCols + col]
+  const uint32_t* prefix;        // non-null rows before each 64-row block of a page column
+  const int32_t* kinds;          // per column
+  void* const* values;           // per column, device
+  uint64_t* const* nulls;        // per column, device, may hold nullptr
+};
+
+__device__ inline void storeBitWord(uint64_t* words, int64_t pos, bool bit) {
+  const uint64_t m = ballot(bit);
+  if (words && lane() == 0) {
+    words[pos >> 6] = m;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_page_read(ReadArgs a) {
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (r - lane() >= a.totalRows) {
+    return;  // whole wave past the end
+  }
+  const int col = blockIdx.y;
+  const int32_t kind = a.kinds[col];
+  const bool active = r < a.totalRows;
+  // page of this row
+  int32_t lo = 0, hi = a.numPages - 1;
+  while (active && lo < hi) {
+    const int32_t mid = (lo + hi + 1) >> 1;
+    if (a.pageRowBegin[mid] <= r) {
+      lo = mid;
+    } else {
+      hi = mid - 1;
+    }
+  }
+  const int64_t lr = active ? r - a.pageRowBegin[lo] : 0;
+  const ReadSection sec = active ? a.sections[static_cast<int64_t>(lo) * a.numCols + col] : ReadSection{-1, 0, 0, 0};
+  bool valid = active;
+  uint64_t rank = static_cast<uint64_t>(lr);
+  if (active && sec.nullPos >= 0) {
+    const unsigned char* nb = a.bytes + sec.nullPos;
+    valid = !((nb[lr >> 3] >> (7 - (lr & 7))) & 1);  // first row in the most significant bit, 1 = null
+    // rank among the non-null rows: rows of earlier 64-row blocks (host), then the bits before mine
+    rank = a.prefix[sec.prefixBase + (lr >> 6)];
+    const int64_t blockFirst = lr & ~63LL;
+    for (int64_t b = blockFirst >> 3; b < (lr >> 3); ++b) {
+      rank += 8 - __popc(static_cast<uint32_t>(nb[b]));
+    }
+    const uint32_t before = static_cast<uint32_t>(nb[lr >> 3]) >> (8 - (lr & 7));  // the (lr & 7) bits above mine
+    rank += (lr & 7) - __popc((lr & 7) ? before : 0u);
+  }
+  storeBitWord(a.nulls[col], r, valid);
+  if (kind == VX355_BOOLEAN) {
+    const bool v = valid && a.bytes[sec.valuePos + rank] != 0;
+    storeBitWord(static_cast<uint64_t*>(a.values[col]), r, v);
+    return;
+  }
+  if (!active) {
+    return;
+  }
+  const unsigned char* src = a.bytes + sec.valuePos;
+  switch (kind) {
+    case VX355_TINYINT:
+      static_cast<unsigned char*>(a.values[col])[r] = valid ? src[rank] : 0;
+      break;
+    case VX355_SMALLINT:
+      static_cast<uint16_t*>(a.values[col])[r] = valid ? reinterpret_cast<const Packed16*>(src + rank * 2)->v : 0;
+      break;
+    case VX355_INTEGER:
+    case VX355_REAL:
+      static_cast<uint32_t*>(a.values[col])[r] = valid ? reinterpret_cast<const Packed32*>(src + rank * 4)->v : 0;
+      break;
+    case VX355_BIGINT:
+    case VX355_DOUBLE:
+      static_cast<uint64_t*>(a.values[col])[r] = valid ? reinterpret_cast<const Packed64*>(src + rank * 8)->v : 0;
+      break;
+    case VX355_TIMESTAMP: {
+      int64_t seconds = 0;
+      uint64_t nanos = 0;
+      if (valid && a.lossless) {
+        seconds = static_cast<int64_t>(reinterpret_cast<const Packed64*>(src + rank * 16)->v);
+        nanos = reinterpret_cast<const Packed64*>(src + rank * 16 + 8)->v;
+      } else if (valid) {
+        // Timestamp::fromMillis (type/Timestamp.h:228-235)
+        const int64_t ms = static_cast<int64_t>(reinterpret_cast<const Packed64*>(src + rank * 8)->v);
+        if (ms >= 0 || ms % 1000 == 0) {
+          seconds = ms / 1000;
+          nanos = static_cast<uint64_t>(ms % 1000) * 1000000;
+        } else {
+          seconds = ms / 1000 - 1;
+          nanos = static_cast<uint64_t>((ms - seconds * 1000) % 1000) * 1000000;
+        }
+      }
+      static_cast<int64_t*>(a.values[col])[r * 2] = seconds;
+      static_cast<uint64_t*>(a.values[col])[r * 2 + 1] = nanos;
+      break;
+    }
+    default: {  // VARCHAR / VARBINARY: end offsets per row, nulls repeat the previous one
+      const unsigned char* ends = a.bytes + sec.offsetsPos;
+      const uint32_t end = reinterpret_cast<const Packed32*>(ends + 4 * lr)->v;
+      const uint32_t begin = lr ? reinterpret_cast<const Packed32*>(ends + 4 * (lr - 1))->v : 0;
+      const uint32_t size = valid ? end - begin : 0;
+      const unsigned char* data = src + begin;
+      uint4 view = make_uint4(size, 0, 0, 0);
+      if (size <= 12) {
+        uint32_t w[3] = {0, 0, 0};
+        for (uint32_t i = 0; i < size; ++i) {
+          w[i >> 2] |= static_cast<uint32_t>(data[i]) << ((i & 3) * 8);
+        }
+        view.y = w[0];
+        view.z = w[1];
+        view.w = w[2];
+      } else {
+        view.y = static_cast<uint32_t>(data[0]) | (static_cast<uint32_t>(data[1]) << 8) |
+            (static_cast<uint32_t>(data[2]) << 16) | (static_cast<uint32_t>(data[3]) << 24);
+        const uint64_t p = reinterpret_cast<uint64_t>(data);
+        view.z = static_cast<uint32_t>(p);
+        view.w = static_cast<uint32_t>(p >> 32);
+      }
+      static_cast<uint4*>(a.values[col])[r] = view;
+    }
+  }
+}
+
+int32_t getI32(const unsigned char* p) {
+  int32_t v;
+  std::memcpy(&v, p, 4);
+  return v;
+}
+
+void deserializePages(const void* const* pages, const int64_t* sizes, int32_t numPages, const int32_t* types,
+                      int32_t numCols, int32_t flags, void* deviceBytes, int64_t deviceCapacity, vx355_out_column* cols,
+                      int64_t capacityRows, int64_t* rowsOut) {
+  auto& rt = Runtime::get();
+  VX_CHECK_ARG(rowsOut && numPages >= 0 && numCols >= 0, "NULL argument");
+  VX_CHECK_ARG(numPages == 0 || (pages && sizes), "NULL argument");
+  VX_CHECK_ARG(numCols == 0 || (types && cols), "NULL argument");
+  const bool lossless = (flags & VX355_PAGE_LOSSLESS_TIMESTAMP) != 0;
+  static const Crc32 crc;
+  std::vector<int64_t> pageRowBegin(numPages + 1, 0), pageDevBegin(numPages + 1, 0);
+  std::vector<ReadSection> sections(static_cast<size_t>(numPages) * std::max(numCols, 1));
+  std::vector<uint32_t> prefix;
+  for (int32_t p = 0; p < numPages; ++p) {
+    const unsigned char* page = static_cast<const unsigned char*>(pages[p]);
+    const int64_t size = sizes[p];
+    auto bad = [&](const std::string& what) {
+      VX_THROW(VX355_EUSER, "PrestoPage " + std::to_string(p) + ": " + what);  // PrestoHeader::read / the readers' checks
+    };
+    if (!page || size < kPageHeader + 4) {
+      bad(std::to_string(size) + " bytes for header");
+    }
+    const int32_t n = getI32(page);
+    const unsigned char codec = page[4];
+    const int32_t uncompressed = getI32(page + 5);
+    const int32_t stored = getI32(page + 9);
+    if (n < 0 || uncompressed < 0 || stored < 0) {
+      bad("negative header field");
+    }
+    if (codec & 3) {
+      VX_THROW(VX355_EUNSUPPORTED, "compressed or encrypted PrestoPage (the shim decompresses first)");
+    }
+    if (uncompressed != stored || static_cast<int64_t>(stored) + kPageHeader != size) {
+      bad("size fields do not match the page length");
+    }
+    if (codec & 4) {
+      // computeChecksum (PrestoSerializer.cpp:39-79)
+      uint32_t state = ~0u;
+      state = crc.update(state, page + kPageHeader, static_cast<size_t>(stored));
+      state = crc.update(state, page + 4, 1);
+      state = crc.update(state, page, 4);
+      state = crc.update(state, page + 5, 4);
+      int64_t expected;
+      std::memcpy(&expected, page + 13, 8);
+      if (expected != static_cast<int64_t>(static_cast<uint32_t>(~state))) {
+        bad("Received corrupted serialized page.");
+      }
+    }
+    pageRowBegin[p + 1] = pageRowBegin[p] + n;
+    pageDevBegin[p + 1] = pageDevBegin[p] + size;
+    int64_t pos = kPageHeader;
+    if (getI32(page + pos) != numCols) {
+      bad("column count " + std::to_string(getI32(page + pos)) + ", expected " + std::to_string(numCols));
+    }
+    pos += 4;
+    for (int32_t c = 0; c < numCols; ++c) {
+      const char* name = encodingName(types[c]);
+      if (!name) {
+        VX_THROW(VX355_EUNSUPPORTED, "PrestoPage column of type kind " + std::to_string(types[c]));
+      }
+      const int32_t nameLen = static_cast<int32_t>(std::strlen(name));
+      if (pos + 8 + nameLen > size || getI32(page + pos) != nameLen || std::memcmp(page + pos + 4, name, nameLen) != 0) {
+        bad("column " + std::to_string(c) + " is not " + name);  // the reader's encoding check
+      }
+      pos += 4 + nameLen;
+      if (getI32(page + pos) != n) {
+        bad("column " + std::to_string(c) + " row count");
+      }
+      pos += 4;
+      ReadSection& sec = sections[static_cast<size_t>(p) * numCols + c];
+      sec.nullPos = -1;
+      sec.offsetsPos = 0;
+      const bool str = isString(types[c]);
+      if (str) {
+        sec.offsetsPos = pageDevBegin[p] + pos;
+        pos += 4LL * n;
+      }
+      if (pos + 1 > size) {
+        bad("truncated column " + std::to_string(c));
+      }
+      const bool hasNulls = page[pos] != 0;
+      pos += 1;
+      int64_t nonNull = n;
+      sec.prefixBase = static_cast<int64_t>(prefix.size());
+      if (hasNulls) {
+        const int64_t nullBytes = (static_cast<int64_t>(n) + 7) / 8;
+        if (pos + nullBytes > size) {
+          bad("truncated null flags of column " + std::to_string(c));
+        }
+        sec.nullPos = pageDevBegin[p] + pos;
+        uint32_t run = 0;
+        for (int64_t b = 0; b < nullBytes; ++b) {
+          if ((b & 7) == 0) {
+            prefix.push_back(run);  // non-null rows before this 64-row block
+          }
+          const int64_t rowsHere = std::min<int64_t>(8, n - b * 8);
+          run += static_cast<uint32_t>(rowsHere - __builtin_popcount(page[pos + b]));
+        }
+        nonNull = run;
+        pos += nullBytes;
+      }
+      int64_t valueBytes;
+      if (str) {
+        if (pos + 4 > size) {
+          bad("truncated column " + std::to_string(c));
+        }
+        valueBytes = getI32(page + pos);
+        pos += 4;
+      } else {
+        valueBytes = nonNull * valueWidth(types[c], lossless);
+      }
+      sec.valuePos = pageDevBegin[p] + pos;
+      pos += valueBytes;
+      if (valueBytes < 0 || pos > size) {
+        bad("truncated values of column " + std::to_string(c));
+      }
+    }
+    if (pos != size) {
+      bad("trailing bytes");
+    }
+  }
+  const int64_t totalRows = pageRowBegin[numPages];
+  *rowsOut = totalRows;
+  if (totalRows == 0 || numCols == 0) {
+    return;
+  }
+  VX_CHECK_ARG(totalRows <= capacityRows, "output columns smaller than the pages' rows");
+  VX_CHECK_ARG(deviceBytes && deviceCapacity >= pageDevBegin[numPages], "device buffer smaller than the pages");
+  for (int32_t c = 0; c < numCols; ++c) {
+    VX_CHECK_ARG(cols[c].type_kind == types[c] && cols[c].mem == VX355_MEM_DEVICE && cols[c].values,
+                 "output columns: device memory of the expected types");
+  }
+  for (int32_t p = 0; p < numPages; ++p) {
+    copyIn(static_cast<char*>(deviceBytes) + pageDevBegin[p], pages[p], VX355_MEM_HOST, static_cast<size_t>(sizes[p]));
+  }
+  DevBuf dRows, dSections, dPrefix, dKinds, dValues, dNulls;
+  int64_t* devRows = static_cast<int64_t*>(dRows.ensure(pageRowBegin.size() * 8 + 64));
+  copyIn(devRows, pageRowBegin.data(), VX355_MEM_HOST, pageRowBegin.size() * 8);
+  ReadSection* devSections = static_cast<ReadSection*>(dSections.ensure(sections.size() * sizeof(ReadSection) + 64));
+  copyIn(devSections, sections.data(), VX355_MEM_HOST, sections.size() * sizeof(ReadSection));
+  uint32_t* devPrefix = static_cast<uint32_t*>(dPrefix.ensure(prefix.size() * 4 + 64));
+  if (!prefix.empty()) {
+    copyIn(devPrefix, prefix.data(), VX355_MEM_HOST, prefix.size() * 4);
+  }
+  int32_t* devKinds = static_cast<int32_t*>(dKinds.ensure(static_cast<size_t>(numCols) * 4 + 64));
+  copyIn(devKinds, types, VX355_MEM_HOST, static_cast<size_t>(numCols) * 4);
+  std::vector<void*> values(numCols);
+  std::vector<uint64_t*> nulls(numCols);
+  for (int32_t c = 0; c < numCols; ++c) {
+    values[c] = cols[c].values;
+    nulls[c] = cols[c].nulls;
+  }
+  void** devValues = static_cast<void**>(dValues.ensure(static_cast<size_t>(numCols) * 8 + 64));
+  uint64_t** devNulls = static_cast<uint64_t**>(dNulls.ensure(static_cast<size_t>(numCols) * 8 + 64));
+  copyIn(devValues, values.data(), VX355_MEM_HOST, static_cast<size_t>(numCols) * 8);
+  copyIn(devNulls, nulls.data(), VX355_MEM_HOST, static_cast<size_t>(numCols) * 8);
+  ReadArgs a{};
+  a.bytes = static_cast<const unsigned char*>(deviceBytes);
+  a.pageRowBegin = devRows;
+  a.numPages = numPages;
+  a.numCols = numCols;
+  a.lossless = lossless ? 1 : 0;
+  a.totalRows = totalRows;
+  a.sections = devSections;
+  a.prefix = devPrefix;
+  a.kinds = devKinds;
+  a.values = devValues;
+  a.nulls = devNulls;
+  VX_LAUNCH("k_page_read", k_page_read,
+            dim3(static_cast<unsigned>(ceilDiv(totalRows, 256)), static_cast<unsigned>(numCols)), 256, 0, a);
+  rt.sync();
+}
+
 }  // namespace
 }  // namespace vx
 
@@ -629,6 +952,16 @@ int vx355_presto_serialize(const vx355_batch* batch, const int32_t* rows, int32_
   VX_API_BEGIN
   vx::Runtime::get().requireInit();
   vx::serializePages(batch, rows, rows_mem, offsets, num_pages, flags, out, out_capacity, out_mem, page_offsets);
+  VX_API_END
+}
+
+int vx355_presto_deserialize(const void* const* pages, const int64_t* sizes, int32_t num_pages, const int32_t* types,
+                             int32_t num_cols, int32_t flags, void* device_bytes, int64_t device_bytes_capacity,
+                             vx355_out_column* cols, int64_t capacity_rows, int64_t* rows_out) {
+  VX_API_BEGIN
+  vx::Runtime::get().requireInit();
+  vx::deserializePages(pages, sizes, num_pages, types, num_cols, flags, device_bytes, device_bytes_capacity, cols,
+                       capacity_rows, rows_out);
   VX_API_END
 }
 

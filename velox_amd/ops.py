@@ -24,7 +24,7 @@ SYMBOLS = [
     "vx355_device_malloc", "vx355_device_free", "vx355_memcpy_h2d", "vx355_memcpy_d2h",
     "vx355_memset_d", "vx355_synchronize", "vx355_profile_enable", "vx355_profile_reset",
     "vx355_profile_get", "vx355_profile_names", "vx355_hash_columns", "vx355_value_ids",
-    "vx355_filter_compact", "vx355_partition", "vx355_partition_scatter", "vx355_presto_serialize", "vx355_filter_project", "vx355_agg_create", "vx355_agg_set_fused_input", "vx355_agg_add_input",
+    "vx355_filter_compact", "vx355_partition", "vx355_partition_scatter", "vx355_presto_serialize", "vx355_presto_deserialize", "vx355_filter_project", "vx355_agg_create", "vx355_agg_set_fused_input", "vx355_agg_add_input",
     "vx355_agg_no_more_input", "vx355_agg_output_types", "vx355_agg_get_output",
     "vx355_agg_get_stats", "vx355_agg_destroy", "vx355_join_build_create",
     "vx355_join_build_add_input", "vx355_join_build_finish", "vx355_join_build_destroy",
@@ -80,6 +80,7 @@ def lib():
     L.vx355_partition.argtypes = [vp, i32, i32, i32, i32, i32, vp, i32]
     L.vx355_partition_scatter.argtypes = [vp, i32, i32, P(vp), P(i32), i32, P(vp), P(i64), i32]
     L.vx355_presto_serialize.argtypes = [P(abi.Batch), vp, i32, vp, i32, i32, vp, i64, i32, vp]
+    L.vx355_presto_deserialize.argtypes = [vp, vp, i32, vp, i32, i32, vp, i64, vp, i64, vp]
     L.vx355_filter_project.argtypes = [P(abi.Batch), P(abi.FilterTerm), i32, P(abi.Projection), i32,
                                        vp, P(i32), P(vp), P(vp), i32]
     L.vx355_agg_create.argtypes = [P(abi.AggSpec), P(vp)]
@@ -507,6 +508,62 @@ def presto_serialize(batch, offsets, rows=None, flags=0, device_out=False):
                                             flags, out.ctypes.data, total, abi.MEM_HOST, again.ctypes.data))
     assert (again == page_offsets).all()
     return [out[page_offsets[p]:page_offsets[p + 1]].tobytes() for p in range(num_pages)]
+
+
+def presto_deserialize(pages, kinds, flags=0):
+    """vx355_presto_deserialize: list of page bytes -> [(values, valid)] per column, fetched back
+    from the HBM columns the library wrote (strings longer than 12 bytes through the device copy
+    of the pages their views point into)."""
+    import struct
+    pages = [bytes(p) for p in pages if len(p)]
+    total_rows = sum(struct.unpack_from("<i", p, 0)[0] for p in pages)
+    keep = [C.create_string_buffer(p, len(p)) for p in pages]
+    ptrs = (C.c_void_p * max(1, len(pages)))(*[C.addressof(k) for k in keep])
+    sizes = np.array([len(p) for p in pages] or [0], dtype=np.int64)
+    total_bytes = int(sum(len(p) for p in pages))
+    dev_bytes = DeviceArray(max(total_bytes, 1), np.uint8)
+    cap = max(total_rows, 1)
+    words = (cap + 63) // 64
+    vals, nulls = [], []
+    descs = (abi.OutColumn * max(1, len(kinds)))()
+    for c, kind in enumerate(kinds):
+        width = {abi.BOOLEAN: 0, abi.TINYINT: 1, abi.SMALLINT: 2, abi.INTEGER: 4, abi.REAL: 4, abi.BIGINT: 8,
+                 abi.DOUBLE: 8, abi.TIMESTAMP: 16, abi.VARCHAR: 16, abi.VARBINARY: 16}[kind]
+        vals.append(DeviceArray(words * 8 if width == 0 else cap * width, np.uint8))
+        nulls.append(DeviceArray(words, np.uint64))
+        descs[c].type_kind, descs[c].mem = kind, abi.MEM_DEVICE
+        descs[c].values, descs[c].nulls = vals[c].ptr, nulls[c].ptr
+    rows = C.c_int64()
+    types = abi.i32_array(kinds)
+    _check(lib().vx355_presto_deserialize(ptrs, sizes.ctypes.data, len(pages), types, len(kinds), flags, dev_bytes.ptr,
+                                          total_bytes, descs, cap, C.byref(rows)))
+    n = rows.value
+    assert n == total_rows
+    host_bytes = dev_bytes.to_host().tobytes() if total_bytes else b""
+    out = []
+    for c, kind in enumerate(kinds):
+        valid = abi.unpack_bits(nulls[c].to_host(), n)
+        raw = vals[c].to_host()
+        if kind == abi.BOOLEAN:
+            v = abi.unpack_bits(raw.view(np.uint64), n)
+        elif kind in (abi.VARCHAR, abi.VARBINARY):
+            views = raw[: n * 16].reshape(n, 16)
+            v = []
+            for r in range(n):
+                size = int(views[r, 0:4].view(np.uint32)[0])
+                if size <= 12:
+                    v.append(views[r, 4:4 + size].tobytes())
+                else:
+                    at = int(views[r, 8:16].view(np.uint64)[0]) - dev_bytes.ptr
+                    assert 0 <= at and at + size <= total_bytes
+                    assert host_bytes[at:at + 4] == views[r, 4:8].tobytes()  # the prefix
+                    v.append(host_bytes[at:at + size])
+        elif kind == abi.TIMESTAMP:
+            v = raw[: n * 16].view(np.int64).reshape(n, 2)
+        else:
+            v = raw[: n * np.dtype(abi.KIND_DTYPE[kind]).itemsize].view(abi.KIND_DTYPE[kind])
+        out.append((v, valid))
+    return n, out
 
 
 # ---- HashAggregation -------------------------------------------------------
