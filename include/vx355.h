@@ -348,7 +348,8 @@ int vx355_presto_serialize(
  * (PrestoVectorSerde::deserialize, serializers/PrestoSerializer.cpp:120-200, appending page
  * after page into one RowVector): pages (host memory, uncompressed; a checksum is verified when
  * the codec marker carries one, "Received corrupted serialized page." -> VX355_EUSER) become
- * flat columns in HBM, rows of page 0 first. types[] is the RowType the exchange expects; a
+ * flat columns in HBM, rows of page 0 first (RLE and DICTIONARY columns are flattened on the
+ * way). types[] is the RowType the exchange expects; a
  * page whose column encodings do not fit it is a VX355_EUSER. The page bytes are copied into
  * device_bytes (>= the sum of sizes); views of strings longer than 12 bytes point into that
  * buffer, so the caller keeps it as long as the columns (a vector's string buffer). cols: device

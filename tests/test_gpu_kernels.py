@@ -393,3 +393,58 @@ def test_presto_deserialize_rejects_corrupt_and_mismatched_pages(oracle, vx):
         vx.presto_deserialize([page[:-3]], kinds)                       # truncated
     assert e.value.status == abi.EUSER
     assert vx.presto_deserialize([], kinds)[0] == 0
+
+
+def _column_bytes(oracle, column):
+    """The wire bytes of one flat column (header, row count, nulls, values) from the oracle writer."""
+    n = len(column.valid) if column.valid is not None else column.num_rows
+    (page,) = oracle.presto_serialize(abi.HostBatch([column], n), [0, n])
+    return page[25:]
+
+
+def _frame(columns, n):
+    body = len(columns).to_bytes(4, "little") + b"".join(columns)
+    return n.to_bytes(4, "little") + b"\x00" + len(body).to_bytes(4, "little") * 2 + bytes(8) + body
+
+
+def test_presto_deserialize_reads_rle_and_dictionary_columns(oracle, vx):
+    """Pages from writers that keep encodings (Presto's Java workers, the batch serializer):
+    RLE = a one-row nested column repeated, DICTIONARY = nested dictionary + int32 indices + 24
+    bytes of instance id (VectorStream::flush, serializers/VectorStream.cpp:210-232)."""
+    rng = np.random.default_rng(6060)
+    n, d = 1000, 37
+    words = [b"", b"dict", b"a dictionary entry beyond twelve bytes", b"x" * 12, b"y" * 13]
+    dict_s = [words[i % len(words)] + str(i).encode() for i in range(d)]
+    dict_valid = rng.random(d) > 0.2
+    dict_i = rng.integers(-1000, 1000, d).astype(np.int64)
+    idx_s = rng.integers(0, d, n).astype(np.int32)
+    idx_i = rng.integers(0, d, n).astype(np.int32)
+    rle = lambda child: (3).to_bytes(4, "little") + b"RLE" + n.to_bytes(4, "little") + child
+    dic = lambda child, idx: (10).to_bytes(4, "little") + b"DICTIONARY" + n.to_bytes(4, "little") + child + idx.tobytes() + bytes(24)
+    cols = [
+        rle(_column_bytes(oracle, abi.HostColumn(abi.DOUBLE, np.array([2.5])))),
+        rle(_column_bytes(oracle, abi.HostColumn(abi.BIGINT, np.array([7], dtype=np.int64), valid=np.array([False])))),
+        rle(_column_bytes(oracle, abi.HostColumn(abi.VARCHAR, [b"a constant longer than twelve bytes"]))),
+        dic(_column_bytes(oracle, abi.HostColumn(abi.VARCHAR, dict_s, valid=dict_valid)), idx_s),
+        dic(_column_bytes(oracle, abi.HostColumn(abi.BIGINT, dict_i)), idx_i),
+        _column_bytes(oracle, abi.HostColumn(abi.INTEGER, np.arange(n, dtype=np.int32))),
+    ]
+    kinds = [abi.DOUBLE, abi.BIGINT, abi.VARCHAR, abi.VARCHAR, abi.BIGINT, abi.INTEGER]
+    page = _frame(cols, n)
+    got_n, got = vx.presto_deserialize([page, page], kinds)
+    assert got_n == 2 * n
+    for half in (0, n):
+        assert all(got[0][1][half:half + n]) and (np.asarray(got[0][0][half:half + n]) == 2.5).all()
+        assert not any(got[1][1][half:half + n])
+        assert all(v == b"a constant longer than twelve bytes" for v in got[2][0][half:half + n])
+        for r in range(n):
+            assert bool(got[3][1][half + r]) == bool(dict_valid[idx_s[r]])
+            if dict_valid[idx_s[r]]:
+                assert got[3][0][half + r] == dict_s[idx_s[r]]
+        assert (np.asarray(got[4][0][half:half + n]) == dict_i[idx_i]).all() and all(got[4][1][half:half + n])
+        assert (np.asarray(got[5][0][half:half + n]) == np.arange(n)).all()
+    # an index past the dictionary is refused
+    bad = _frame([dic(_column_bytes(oracle, abi.HostColumn(abi.BIGINT, dict_i)), np.full(n, d, dtype=np.int32))], n)
+    with pytest.raises(vx.Vx355Error) as e:
+        vx.presto_deserialize([bad], [abi.BIGINT])
+    assert e.value.status == abi.EUSER

@@ -632,6 +632,12 @@ struct ReadSection {
   int64_t valuePos;   // first value / first string byte
   int64_t offsetsPos; // VARIABLE_WIDTH: the i32 end offsets
   int64_t prefixBase; // index of this page column's first 64-row block in 'prefix'
+  // RLE: every row is row 0 of the nested one-row column. DICTIONARY: row r is row indices[r] of
+  // the nested dictionary column (VectorStream::flush's CONSTANT / DICTIONARY branches,
+  // serializers/VectorStream.cpp:210-232; readers: readConstantVector / readDictionaryVector).
+  int64_t indicesPos; // DICTIONARY: the i32 indices; -1 otherwise
+  int32_t constant;   // RLE
+  int32_t pad;
 };
 
 struct ReadArgs {
@@ -674,8 +680,14 @@ __global__ __launch_bounds__(256) void k_page_read(ReadArgs a) {
       hi = mid - 1;
     }
   }
-  const int64_t lr = active ? r - a.pageRowBegin[lo] : 0;
-  const ReadSection sec = active ? a.sections[static_cast<int64_t>(lo) * a.numCols + col] : ReadSection{-1, 0, 0, 0};
+  int64_t lr = active ? r - a.pageRowBegin[lo] : 0;
+  const ReadSection sec =
+      active ? a.sections[static_cast<int64_t>(lo) * a.numCols + col] : ReadSection{-1, 0, 0, 0, -1, 0, 0};
+  if (sec.constant) {
+    lr = 0;
+  } else if (sec.indicesPos >= 0) {
+    lr = static_cast<int64_t>(reinterpret_cast<const Packed32*>(a.bytes + sec.indicesPos + 4 * lr)->v);
+  }
   bool valid = active;
   uint64_t rank = static_cast<uint64_t>(lr);
   if (active && sec.nullPos >= 0) {
@@ -828,32 +840,62 @@ void deserializePages(const void* const* pages, const int64_t* sizes, int32_t nu
       if (!name) {
         VX_THROW(VX355_EUNSUPPORTED, "PrestoPage column of type kind " + std::to_string(types[c]));
       }
-      const int32_t nameLen = static_cast<int32_t>(std::strlen(name));
-      if (pos + 8 + nameLen > size || getI32(page + pos) != nameLen || std::memcmp(page + pos + 4, name, nameLen) != 0) {
-        bad("column " + std::to_string(c) + " is not " + name);  // the reader's encoding check
-      }
-      pos += 4 + nameLen;
-      if (getI32(page + pos) != n) {
-        bad("column " + std::to_string(c) + " row count");
-      }
-      pos += 4;
       ReadSection& sec = sections[static_cast<size_t>(p) * numCols + c];
       sec.nullPos = -1;
       sec.offsetsPos = 0;
+      sec.indicesPos = -1;
+      sec.constant = 0;
+      auto nameIs = [&](const char* what) {
+        const int32_t len = static_cast<int32_t>(std::strlen(what));
+        return pos + 4 + len <= size && getI32(page + pos) == len && std::memcmp(page + pos + 4, what, len) == 0;
+      };
+      int64_t flatRows = n;  // rows of the flat column that holds the values
+      int64_t dictTail = -1;  // DICTIONARY: where the indices start is known after the nested column
+      if (nameIs("RLE")) {
+        pos += 4 + 3;
+        if (pos + 4 > size || getI32(page + pos) != n) {
+          bad("column " + std::to_string(c) + " run length");
+        }
+        pos += 4;
+        sec.constant = 1;
+        flatRows = 1;
+      } else if (nameIs("DICTIONARY")) {
+        pos += 4 + 10;
+        if (pos + 4 > size || getI32(page + pos) != n) {
+          bad("column " + std::to_string(c) + " row count");
+        }
+        pos += 4;
+        dictTail = 0;
+        flatRows = -1;  // read from the nested column's own header
+      }
+      const int32_t nameLen = static_cast<int32_t>(std::strlen(name));
+      if (!nameIs(name)) {
+        bad("column " + std::to_string(c) + " is not " + name);  // the reader's encoding check
+      }
+      pos += 4 + nameLen;
+      if (pos + 4 > size) {
+        bad("truncated column " + std::to_string(c));
+      }
+      const int64_t rowsHere = getI32(page + pos);
+      if (flatRows >= 0 ? rowsHere != flatRows : rowsHere < 0) {
+        bad("column " + std::to_string(c) + " row count");
+      }
+      flatRows = rowsHere;
+      pos += 4;
       const bool str = isString(types[c]);
       if (str) {
         sec.offsetsPos = pageDevBegin[p] + pos;
-        pos += 4LL * n;
+        pos += 4LL * flatRows;
       }
       if (pos + 1 > size) {
         bad("truncated column " + std::to_string(c));
       }
       const bool hasNulls = page[pos] != 0;
       pos += 1;
-      int64_t nonNull = n;
+      int64_t nonNull = flatRows;
       sec.prefixBase = static_cast<int64_t>(prefix.size());
       if (hasNulls) {
-        const int64_t nullBytes = (static_cast<int64_t>(n) + 7) / 8;
+        const int64_t nullBytes = (flatRows + 7) / 8;
         if (pos + nullBytes > size) {
           bad("truncated null flags of column " + std::to_string(c));
         }
@@ -863,8 +905,8 @@ void deserializePages(const void* const* pages, const int64_t* sizes, int32_t nu
           if ((b & 7) == 0) {
             prefix.push_back(run);  // non-null rows before this 64-row block
           }
-          const int64_t rowsHere = std::min<int64_t>(8, n - b * 8);
-          run += static_cast<uint32_t>(rowsHere - __builtin_popcount(page[pos + b]));
+          const int64_t inByte = std::min<int64_t>(8, flatRows - b * 8);
+          run += static_cast<uint32_t>(inByte - __builtin_popcount(page[pos + b]));
         }
         nonNull = run;
         pos += nullBytes;
@@ -883,6 +925,20 @@ void deserializePages(const void* const* pages, const int64_t* sizes, int32_t nu
       pos += valueBytes;
       if (valueBytes < 0 || pos > size) {
         bad("truncated values of column " + std::to_string(c));
+      }
+      if (dictTail == 0) {
+        // indices, then 24 bytes of instance id
+        if (pos + 4LL * n + 24 > size) {
+          bad("truncated dictionary indices of column " + std::to_string(c));
+        }
+        for (int64_t i = 0; i < n; ++i) {
+          const int32_t idx = getI32(page + pos + 4 * i);
+          if (idx < 0 || idx >= flatRows) {
+            bad("dictionary index out of range in column " + std::to_string(c));
+          }
+        }
+        sec.indicesPos = pageDevBegin[p] + pos;
+        pos += 4LL * n + 24;
       }
     }
     if (pos != size) {
