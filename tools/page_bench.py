@@ -53,7 +53,36 @@ def main():
     ops.profile_enable(False)
     prof = {k2: round(v[0] / steps, 4) for k2, v in ops.profile().items()}
     in_bytes = n * (8 + 8 + 4) + words * 8
-    print(json.dumps({"rows": n, "pages": pages, "page_bytes": total, "input_bytes": in_bytes,
+    # the way back: the pages in host memory (as an Exchange holds them) -> HBM columns
+    read = {}
+    if n <= 200_000_000:
+        host = out.cpu().numpy()
+        keep = [host[page_offsets[p]:page_offsets[p + 1]] for p in range(pages)]
+        ptrs = (C.c_void_p * pages)(*[k.ctypes.data for k in keep])
+        sizes = np.array([len(k) for k in keep], dtype=np.int64)
+        kinds = abi.i32_array([abi.BIGINT, abi.DOUBLE, abi.INTEGER])
+        dev_bytes = torch.empty(total, dtype=torch.uint8, device=dev)
+        outs = [torch.empty(n, dtype=torch.int64, device=dev), torch.empty(n, dtype=torch.float64, device=dev),
+                torch.empty(n, dtype=torch.int32, device=dev)]
+        onulls = [torch.empty(words, dtype=torch.int64, device=dev) for _ in range(3)]
+        descs = (abi.OutColumn * 3)()
+        for c, kind in enumerate([abi.BIGINT, abi.DOUBLE, abi.INTEGER]):
+            descs[c].type_kind, descs[c].mem = kind, abi.MEM_DEVICE
+            descs[c].values, descs[c].nulls = outs[c].data_ptr(), onulls[c].data_ptr()
+        torch.cuda.synchronize()
+        rows = C.c_int64()
+        ops.profile_reset()
+        ops.profile_enable(True)
+        t0 = time.perf_counter()
+        ops._check(lib.vx355_presto_deserialize(ptrs, sizes.ctypes.data, pages, kinds, 3, 0, dev_bytes.data_ptr(), total,
+                                                descs, n, C.byref(rows)))
+        dt = time.perf_counter() - t0
+        ops.profile_enable(False)
+        assert rows.value == n and bool((outs[0] == k).all()) and bool((outs[2] == i).all())
+        read = {"deserialize_call_ms_incl_pcie_copy_of_pages": dt * 1e3,
+                "k_page_read_ms": ops.profile().get("k_page_read", (0, 0))[0],
+                "k_page_read_GBps_in_plus_out": (in_bytes + total) / (ops.profile().get("k_page_read", (1e9, 0))[0] * 1e-3) / 1e9}
+    print(json.dumps({"rows": n, "pages": pages, "page_bytes": total, "input_bytes": in_bytes, "read_back": read,
                       "best_call_ms": best * 1e3, "kernels_ms": prof,
                       "write_kernel_GBps": (in_bytes + total) / (prof.get("k_page_write", 0) * 1e-3) / 1e9
                       if prof.get("k_page_write") else None,
