@@ -36,6 +36,19 @@ def batch_for(abi, rank):
                           abi.HostColumn(abi.BIGINT, big)])
 
 
+def wide_batch(abi, rank, n=30000):
+    """Many groups and keys beyond the inline string limit: the merge goes through PrestoPages."""
+    rng = np.random.default_rng(500 + rank)
+    ids = rng.integers(0, 900, n)
+    keys = [b"a grouping key well beyond twelve bytes #%03d" % i for i in ids]
+    x = rng.integers(-(1 << 40), 1 << 40, n).astype(np.int64)
+    return abi.HostBatch([abi.HostColumn(abi.VARCHAR, keys), abi.HostColumn(abi.BIGINT, x, rng.random(n) > 0.05)])
+
+
+def wide_aggs(abi):
+    return [(abi.AGG_SUM, 1, abi.BIGINT), (abi.AGG_COUNT, 1, abi.BIGINT), (abi.AGG_MAX, 1, abi.BIGINT)]
+
+
 def run(rank, world, port, out_dir):
     import torch
     import torch.distributed as dist
@@ -52,6 +65,15 @@ def run(rank, world, port, out_dir):
     # every rank holds the same final result
     import pickle
     with open(os.path.join(out_dir, f"rank{rank}.pkl"), "wb") as f:
+        pickle.dump([(np.asarray(col[0]).tolist() if not isinstance(col[0], list) else list(col[0]),
+                      np.asarray(col[1]).tolist()) for col in merged], f)
+    # second plan: ~900 groups per rank, long string keys -> page transport
+    op = oracle_lib.Aggregation([0], [abi.VARCHAR], wide_aggs(abi), abi.STEP_PARTIAL)
+    op.add_input(wide_batch(abi, rank))
+    op.no_more_input()
+    part = oracle_lib.collect_output(op, 4096)
+    merged = vdist.merge_partials(oracle_lib, dist, torch, part, [abi.VARCHAR], wide_aggs(abi), None)
+    with open(os.path.join(out_dir, f"wide_rank{rank}.pkl"), "wb") as f:
         pickle.dump([(np.asarray(col[0]).tolist() if not isinstance(col[0], list) else list(col[0]),
                       np.asarray(col[1]).tolist()) for col in merged], f)
     dist.barrier()

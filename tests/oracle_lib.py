@@ -272,6 +272,44 @@ def presto_serialize(batch, offsets, rows=None, flags=0):
     return [out[page_offsets[p]:page_offsets[p + 1]].tobytes() for p in range(num_pages)]
 
 
+def presto_deserialize(pages, kinds, flags=0):
+    """Pages -> (rows, [(values, valid)] per column) through the independent Python reader of the
+    wire format (tests/presto_page_reader.py), in the shape of velox_amd.ops.presto_deserialize."""
+    from presto_page_reader import read_page
+    lossless = bool(flags & abi.PAGE_LOSSLESS_TIMESTAMP)
+    cols = [([], []) for _ in kinds]
+    total = 0
+    for page in pages:
+        if not page:
+            continue
+        n, page_cols = read_page(page, kinds, lossless)
+        total += n
+        for c, (values, valid) in enumerate(page_cols):
+            cols[c][0].extend(values)
+            cols[c][1].extend(valid)
+    out = []
+    for (values, valid), kind in zip(cols, kinds):
+        valid = np.asarray(valid, dtype=bool)
+        if kind in (abi.VARCHAR, abi.VARBINARY):
+            v = [x if x is not None else b"" for x in values]
+        elif kind == abi.TIMESTAMP:
+            pairs = []
+            for x in values:
+                if x is None:
+                    pairs.append((0, 0))
+                elif lossless:
+                    pairs.append((int(x[0]), int(x[1])))
+                else:
+                    pairs.append((x // 1000, (x % 1000) * 1000000))   # Timestamp::fromMillis
+            v = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
+        elif kind == abi.BOOLEAN:
+            v = np.asarray([bool(x) for x in values], dtype=bool)
+        else:
+            v = np.asarray([0 if x is None else x for x in values], dtype=abi.KIND_DTYPE[kind])
+        out.append((v, valid))
+    return total, out
+
+
 def make_agg_spec(key_cols, key_types, aggs, step, ignore_null_keys=False, flags=0):
     """aggs: list of (kind, input_col, input_type[, mask_col[, input_col2[, flags]]])."""
     keep = {}

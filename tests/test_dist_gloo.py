@@ -46,6 +46,20 @@ def test_two_rank_partial_final_matches_single_process(oracle, tmp_path):
             ev = list(ev) if isinstance(ev, list) else np.asarray(ev).tolist()
             # dyadic doubles and integers (beyond 2^53 included): every bit must survive the merge
             assert [g for g, ok in zip(gv, evalid) if ok] == [e for e, ok in zip(ev, evalid) if ok]
+    # the plan whose partial rows travel as PrestoPages (900 groups, long string keys)
+    single = oracle.Aggregation([0], [abi.VARCHAR], dist_worker.wide_aggs(abi), abi.STEP_SINGLE)
+    for r in range(world):
+        single.add_input(dist_worker.wide_batch(abi, r))
+    single.no_more_input()
+    exp = oracle.collect_output(single, 4096)
+    for r in range(world):
+        with open(os.path.join(tmp_path, f"wide_rank{r}.pkl"), "rb") as f:
+            got = pickle.load(f)
+        for (gv, gvalid), (ev, evalid) in zip(got, exp):
+            evalid = np.asarray(evalid).tolist()
+            assert gvalid == evalid
+            ev = list(ev) if isinstance(ev, list) else np.asarray(ev).tolist()
+            assert [g for g, ok in zip(gv, evalid) if ok] == [e for e, ok in zip(ev, evalid) if ok]
 
 
 def test_gather_encoding_round_trip():

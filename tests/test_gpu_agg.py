@@ -1209,3 +1209,33 @@ def test_to_intermediate_passes_strings_of_min_max_through(oracle, vx):
     got = vx.collect_output(fin, 5000)
     exp_single, eop = run_agg(oracle, [b], [0], [abi.BIGINT], raw, max_rows=5000)
     assert_columns_equal(got, exp_single, eop.kinds, what="final(toIntermediate) vs single, strings")
+
+
+def test_partial_rows_merge_through_presto_pages(oracle, vx):
+    """The N > 1 merge with the library's own writer and reader (velox_amd/dist.py
+    all_gather_partial_pages): PARTIAL on the GPU, the partial rows as checksummed PrestoPages,
+    read back into HBM, FINAL - equal to the SINGLE aggregation. A one-rank stand-in replaces
+    torch.distributed (the 2-rank gloo run of the same code is tests/test_dist_gloo.py)."""
+    import torch
+    from velox_amd import dist as vdist
+
+    class OneRank:
+        def get_world_size(self):
+            return 1
+
+        def all_gather(self, out, t):
+            out[0].copy_(t)
+
+    rng = np.random.default_rng(1717)
+    n = 50000
+    ids = rng.integers(0, 3000, n)
+    keys = [b"a grouping key well beyond twelve bytes #%04d" % i for i in ids]
+    x = rng.integers(-(1 << 40), 1 << 40, n).astype(np.int64)
+    d = _dyadic(rng, n)
+    b = abi.HostBatch([abi.HostColumn(abi.VARCHAR, keys), abi.HostColumn(abi.BIGINT, x, rng.random(n) > 0.05),
+                       abi.HostColumn(abi.DOUBLE, d)])
+    raw = [(abi.AGG_SUM, 1, abi.BIGINT), (abi.AGG_AVG, 2, abi.DOUBLE), (abi.AGG_MIN, 0, abi.VARCHAR), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    part, pop = run_agg(vx, [b], [0], [abi.VARCHAR], raw, abi.STEP_PARTIAL, max_rows=5000)
+    merged = vdist.merge_partials(vx, OneRank(), torch, part, [abi.VARCHAR], raw, None)
+    exp, eop = run_agg(oracle, [b], [0], [abi.VARCHAR], raw, max_rows=5000)
+    assert_columns_equal(merged, exp, eop.kinds, what="merge through pages")

@@ -2270,6 +2270,7 @@ struct vx355_agg {
   std::vector<vx355_agg_fn> specAggs;
   int32_t specFlags = 0;
   std::vector<int32_t> specIsDistinct;  // per caller aggregate
+  std::vector<int32_t> specColBegin;    // first output column of caller aggregate i (+ one past the last)
   std::vector<int32_t> fullOutTypes;    // what the caller sees when 'distinct' is not empty
   bool keysOptional = false;  // an 'outer': key output columns without a buffer are skipped
   bool ownsCtx = true;        // dedup / outer run on their parent's context
@@ -4728,13 +4729,19 @@ int vx355_agg_create(const vx355_agg_spec* spec, vx355_agg** out) {
     h->fullOutTypes.assign(h->outTypes.begin(), h->outTypes.begin() + spec->num_keys);
     size_t nextPlain = static_cast<size_t>(spec->num_keys), nextPart = 0;
     for (int32_t i = 0; i < spec->num_aggs; ++i) {
+      h->specColBegin.push_back(static_cast<int32_t>(h->fullOutTypes.size()));
       if (h->specIsDistinct[i]) {
         const auto& part = h->distinct[nextPart++];
         h->fullOutTypes.push_back(part.stringMinMax ? spec->aggs[i].input_type : part.outer->outTypes.back());
       } else {
-        h->fullOutTypes.push_back(h->outTypes[nextPlain++]);
+        // avg has two columns (sum, count) in the partial / intermediate layout
+        const int width = (spec->aggs[i].kind == VX355_AGG_AVG && !finalOutput(spec->step)) ? 2 : 1;
+        for (int w = 0; w < width; ++w) {
+          h->fullOutTypes.push_back(h->outTypes[nextPlain++]);
+        }
       }
     }
+    h->specColBegin.push_back(static_cast<int32_t>(h->fullOutTypes.size()));
   } else {
     buildPlan(*h, *spec);
   }
@@ -4835,7 +4842,7 @@ int vx355_agg_get_output(vx355_agg* h, vx355_out_column* cols, int32_t num_cols,
     std::vector<vx355_out_column> mine(cols, cols + nk);
     for (size_t i = 0; i < h->specIsDistinct.size(); ++i) {
       if (!h->specIsDistinct[i]) {
-        mine.push_back(cols[nk + i]);
+        mine.insert(mine.end(), cols + h->specColBegin[i], cols + h->specColBegin[i + 1]);
       }
     }
     h->hostStrings.clear();
@@ -4848,15 +4855,16 @@ int vx355_agg_get_output(vx355_agg* h, vx355_out_column* cols, int32_t num_cols,
     }
     for (auto& d : h->distinct) {
       if (d.stringMinMax) {
-        VX_CHECK_ARG(cols[nk + d.specIndex].type_kind == h->fullOutTypes[nk + d.specIndex], "output column type mismatch");
-        stringMinMaxOutput(*h, d, cols[nk + d.specIndex], max_rows, *n_out);
+        const int32_t at = h->specColBegin[d.specIndex];
+        VX_CHECK_ARG(cols[at].type_kind == h->fullOutTypes[at], "output column type mismatch");
+        stringMinMaxOutput(*h, d, cols[at], max_rows, *n_out);
         continue;
       }
       std::vector<vx355_out_column> theirs(nk + 1);
       for (int32_t k = 0; k < nk; ++k) {
         theirs[k] = vx355_out_column{h->keys[k].kind, VX355_MEM_DEVICE, nullptr, nullptr};
       }
-      theirs[nk] = cols[nk + d.specIndex];
+      theirs[nk] = cols[h->specColBegin[d.specIndex]];
       int32_t n2 = 0, fin2 = 0;
       getOutput(*d.outer, theirs.data(), nk + 1, max_rows, &n2, &fin2);
       if (n2 != *n_out) {

@@ -81,17 +81,77 @@ def decode_partials(matrix, kinds):
 SMALL_GROUPS = 64
 
 
-def all_gather_partials(dist, torch, columns, kinds, device=None):
+def _inline_only(columns, kinds):
+    """True when the fixed-width matrix can carry every value (strings of <= 12 bytes)."""
+    for (vals, valid), kind in zip(columns, kinds):
+        if kind in (abi.VARCHAR, abi.VARBINARY):
+            if any(v is not None and ok and len(v) > 12 for v, ok in zip(vals, valid)):
+                return False
+        elif kind != abi.BOOLEAN and kind not in abi.KIND_DTYPE:
+            return False
+    return True
+
+
+def columns_to_batch(columns, kinds):
+    """collect_output() / presto_deserialize() columns -> HostBatch."""
+    cols = []
+    rows = len(columns[0][1]) if columns else 0
+    for (vals, valid), kind in zip(columns, kinds):
+        valid = np.asarray(valid, dtype=bool)
+        if kind in (abi.VARCHAR, abi.VARBINARY):
+            vals = [bytes(v) if (v is not None and ok) else b"" for v, ok in zip(vals, valid)]
+        elif kind == abi.TIMESTAMP:
+            vals = np.asarray(vals, dtype=np.int64).reshape(-1, 2)
+        else:
+            vals = np.asarray(vals)
+        cols.append(abi.HostColumn(kind, vals, valid))
+    return abi.HostBatch(cols, rows)
+
+
+def all_gather_partial_pages(impl, dist, torch, columns, kinds, device=None):
+    """The partial rows of every rank as PrestoPages, the wire format Velox's own exchange moves
+    (impl.presto_serialize / presto_deserialize: vx355_presto_serialize and _deserialize on the
+    GPUs, the oracle's writer and an independent reader in the CPU tests): any number of groups,
+    strings of any length, checksummed. Two collectives: page sizes, then the padded bytes."""
+    rows = len(columns[0][1]) if columns else 0
+    pages = impl.presto_serialize(columns_to_batch(columns, kinds), [0, rows], flags=abi.PAGE_CHECKSUM)
+    page = pages[0] if pages else b""
+    world = dist.get_world_size()
+
+    def gather(t):
+        if device is not None:
+            t = t.to(device)
+        got = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        return [g.cpu() for g in got]
+
+    sizes = [int(t.item()) for t in gather(torch.tensor([len(page)], dtype=torch.int64))]
+    padded = np.zeros(max(max(sizes), 1), dtype=np.uint8)
+    padded[: len(page)] = np.frombuffer(page, dtype=np.uint8)
+    received = gather(torch.from_numpy(padded))
+    all_pages = [received[r].numpy()[: sizes[r]].tobytes() for r in range(world) if sizes[r]]
+    _, cols = impl.presto_deserialize(all_pages, kinds)
+    return columns_to_batch(cols, kinds)
+
+
+def all_gather_partials(dist, torch, columns, kinds, device=None, impl=None):
     """Every rank contributes its partial result; returns the HostBatch of all
     partial rows in rank order. device: a cuda device for RCCL, None for gloo.
 
     One collective in the common case: a fixed [1 + SMALL_GROUPS, width] matrix per rank
     whose first row carries the rank's true group count. Only when some rank has more
-    groups does a second gather, sized by the largest count, follow."""
+    groups (or values the matrix cannot carry: strings beyond 12 bytes) does a second
+    exchange follow: PrestoPages when impl offers the serializer, else a matrix sized by
+    the largest count."""
     rows = len(columns[0][1]) if columns else 0
-    if rows > MAX_GROUPS:
-        raise ValueError(f"{rows} partial groups exceed the gather buffer ({MAX_GROUPS})")
     width = 3 * len(kinds) + 1
+    pages_ok = impl is not None and hasattr(impl, "presto_serialize") and hasattr(impl, "presto_deserialize")
+    inline = _inline_only(columns, kinds)
+    if not pages_ok:
+        if rows > MAX_GROUPS:
+            raise ValueError(f"{rows} partial groups exceed the gather buffer ({MAX_GROUPS})")
+        if not inline:
+            raise ValueError("string keys longer than 12 bytes need the page transport (impl with presto_serialize)")
 
     def gather(mat):
         t = torch.from_numpy(mat)
@@ -101,14 +161,17 @@ def all_gather_partials(dist, torch, columns, kinds, device=None):
         dist.all_gather(gathered, t)
         return torch.stack(gathered).cpu().numpy()
 
-    first = np.zeros((1 + SMALL_GROUPS, width), dtype=np.int64)
+    first = np.zeros((1 + SMALL_GROUPS, max(width, 2)), dtype=np.int64)
     first[0, 0] = rows
-    if rows <= SMALL_GROUPS:
-        first[1:] = encode_partial(columns, kinds, SMALL_GROUPS)
+    first[0, 1] = 0 if inline else 1   # this rank needs the page transport
+    if rows <= SMALL_GROUPS and inline:
+        first[1:, :width] = encode_partial(columns, kinds, SMALL_GROUPS)
     got = gather(first)
     largest = int(got[:, 0, 0].max())
-    if largest <= SMALL_GROUPS:
-        return decode_partials(got[:, 1:].reshape(-1, width), kinds)
+    if largest <= SMALL_GROUPS and not got[:, 0, 1].any():
+        return decode_partials(got[:, 1:, :width].reshape(-1, width), kinds)
+    if pages_ok:
+        return all_gather_partial_pages(impl, dist, torch, columns, kinds, device)
     got = gather(encode_partial(columns, kinds, largest))
     return decode_partials(got.reshape(-1, width), kinds)
 
@@ -147,12 +210,12 @@ def merge_partials(impl, dist, torch, partial_columns, key_types, raw_aggs, devi
     """All-gather + FINAL step. impl: module with Aggregation / collect_output
     (velox_amd.ops on GPUs)."""
     kinds = partial_kinds(key_types, raw_aggs)
-    batch = all_gather_partials(dist, torch, partial_columns, kinds, device)
+    batch = all_gather_partials(dist, torch, partial_columns, kinds, device, impl)
     op = impl.Aggregation(list(range(len(key_types))), list(key_types),
                           final_aggs_for(raw_aggs, len(key_types)), abi.STEP_FINAL)
     op.add_input(batch)
     op.no_more_input()
-    return impl.collect_output(op, MAX_GROUPS)
+    return impl.collect_output(op, max(MAX_GROUPS, batch.num_rows))
 
 
 # ---- repartitioned hash join (BASELINE config 5) ------------------------------
