@@ -132,6 +132,18 @@ inline std::vector<char> prestoSerialize(const vx355_batch& input, const int32_t
   return out;
 }
 
+// Exchange side: pages (host memory) -> flat device columns; returns the number of rows. The caller
+// owns 'deviceBytes' (>= the sum of the page sizes): long strings are views into it.
+inline int64_t prestoDeserialize(const std::vector<const void*>& pages, const std::vector<int64_t>& sizes,
+                                 const std::vector<int32_t>& types, int32_t flags, void* deviceBytes,
+                                 int64_t deviceBytesCapacity, vx355_out_column* columns, int64_t capacityRows) {
+  int64_t rows = 0;
+  check(vx355_presto_deserialize(pages.data(), sizes.data(), static_cast<int32_t>(pages.size()), types.data(),
+                                 static_cast<int32_t>(types.size()), flags, deviceBytes, deviceBytesCapacity, columns,
+                                 capacityRows, &rows));
+  return rows;
+}
+
 // The table HashJoinBridge hands from build to probe (exec/HashJoinBridge.h:57,116).
 class JoinTable {
  public:
