@@ -393,6 +393,14 @@ def test_presto_deserialize_rejects_corrupt_and_mismatched_pages(oracle, vx):
         vx.presto_deserialize([page[:-3]], kinds)                       # truncated
     assert e.value.status == abi.EUSER
     assert vx.presto_deserialize([], kinds)[0] == 0
+    # string offsets that run backwards are refused before any kernel trusts them
+    (spage,) = oracle.presto_serialize(abi.HostBatch([abi.HostColumn(abi.VARCHAR, [b"abc", b"de", b"f"])]), [0, 3])
+    at = 25 + 4 + 14 + 4     # header, column count | name length, name, row count -> first end offset
+    assert spage[at:at + 12] == (3).to_bytes(4, "little") + (5).to_bytes(4, "little") + (6).to_bytes(4, "little")
+    evil = spage[:at + 4] + (2).to_bytes(4, "little") + spage[at + 8:]
+    with pytest.raises(vx.Vx355Error) as e:
+        vx.presto_deserialize([evil], [abi.VARCHAR])
+    assert e.value.status == abi.EUSER and "offsets" in str(e.value)
 
 
 def _column_bytes(oracle, column):

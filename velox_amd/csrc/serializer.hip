@@ -883,7 +883,19 @@ void deserializePages(const void* const* pages, const int64_t* sizes, int32_t nu
       flatRows = rowsHere;
       pos += 4;
       const bool str = isString(types[c]);
+      int64_t lastEnd = 0;
       if (str) {
+        if (pos + 4LL * flatRows > size) {
+          bad("truncated offsets of column " + std::to_string(c));
+        }
+        // the kernel trusts these: ascending, and (checked below) ending at the byte count
+        for (int64_t i = 0; i < flatRows; ++i) {
+          const int64_t end = getI32(page + pos + 4 * i);
+          if (end < lastEnd) {
+            bad("descending string offsets in column " + std::to_string(c));
+          }
+          lastEnd = end;
+        }
         sec.offsetsPos = pageDevBegin[p] + pos;
         pos += 4LL * flatRows;
       }
@@ -918,6 +930,9 @@ void deserializePages(const void* const* pages, const int64_t* sizes, int32_t nu
         }
         valueBytes = getI32(page + pos);
         pos += 4;
+        if (valueBytes != lastEnd) {
+          bad("string offsets of column " + std::to_string(c) + " do not end at its byte count");
+        }
       } else {
         valueBytes = nonNull * valueWidth(types[c], lossless);
       }
