@@ -829,3 +829,32 @@ def test_null_as_value_joins_against_nested_loops(oracle, kinds):
             exc.append(i)
     assert [m for m, _ in _nav_join(oracle, abi.JOIN_COUNTING_LEFT_SEMI_FILTER, bcols, bvalids, pcols, pvalids, kinds)] == inter
     assert [m for m, _ in _nav_join(oracle, abi.JOIN_COUNTING_ANTI, bcols, bvalids, pcols, pvalids, kinds)] == exc
+
+
+@pytest.mark.parametrize("build", ["regular", "with_null_key", "empty", "only_null_keys"])
+def test_oracle_null_aware_left_semi_project_truth_table(oracle, build):
+    """x IN (subquery) as a three-valued column (HashProbe::fillLeftSemiProjectMatchColumn,
+    HashProbe.cpp:923-966): build_rows_out = first match (TRUE), -1 (FALSE), -2 (NULL), against the
+    SQL truth table written out in Python."""
+    bk = {"regular": [1, 2, 2, 5], "with_null_key": [1, 2, None, 5], "empty": [], "only_null_keys": [None, None]}[build]
+    pk = [1, 3, None, 5, 2, None, 9]
+    b = oracle.JoinBuild([0], [abi.BIGINT], [], [], abi.JOIN_LEFT_SEMI_PROJECT, True)
+    b.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, np.array([0 if v is None else v for v in bk], dtype=np.int64),
+                                              valid=np.array([v is not None for v in bk], dtype=bool))], len(bk)))
+    probe = oracle.JoinProbe(b.finish(), [0], abi.JOIN_LEFT_SEMI_PROJECT, True)
+    probe.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, np.array([0 if v is None else v for v in pk], dtype=np.int64),
+                                                  valid=np.array([v is not None for v in pk], dtype=bool))]))
+    mapping, rows, _, fin = probe.get_output(100, [])
+    assert fin and list(mapping) == list(range(len(pk)))
+    values = [v for v in bk if v is not None]
+    has_null = any(v is None for v in bk)
+    for x, r in zip(pk, rows):
+        if not bk:
+            want = "F"                       # IN over an empty set
+        elif x is not None and x in values:
+            want = "T"
+        elif x is None or has_null:
+            want = "N"                       # unknown: a NULL on either side and no definite match
+        else:
+            want = "F"
+        assert ("T" if r >= 0 else "F" if r == -1 else "N") == want, (x, r)
