@@ -3,7 +3,7 @@
 set -x
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-for wl in q1 q3 q3r c4; do
+for wl in ${WLS:-q1 q3 q3r c4}; do
   args="--steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-traffic"
   [ $wl = q3 ] && args="--workload q3 $args"
   [ $wl = q3r ] && args="--workload q3 --q3-random-probe $args"
