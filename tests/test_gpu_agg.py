@@ -1160,6 +1160,7 @@ def test_partial_flush_with_min_max_over_strings(oracle, vx):
     for lo in range(0, n, 6000):
         op.add_input(piece(lo, lo + 6000))
         if lo in (6000, 12000):
+            assert op.stats().table_bytes > 200 * 16   # the strings' set table counts towards isPartialFull
             op.flush()
             pages.append(vx.collect_output(op, 77))
             assert op.stats().num_groups == 0

@@ -4969,6 +4969,15 @@ int vx355_agg_get_stats(const vx355_agg* h, vx355_agg_stats* out) {
   out->input_rows = h->inputRows + h->coalescer.pendingRows();
   out->deferred_rows = h->deferredRows;
   out->table_bytes = static_cast<int64_t>(h->table.capacity());
+  for (const auto& d : h->distinct) {
+    // the set tables of DISTINCT aggregates / min / max over strings count towards isPartialFull
+    if (d.dedup) {
+      out->table_bytes += static_cast<int64_t>(d.dedup->table.capacity());
+      for (const auto& b : d.dedup->strBlocks) {
+        out->table_bytes += static_cast<int64_t>(b.capacity());
+      }
+    }
+  }
   out->num_flushes = h->numFlushes;
   VX_API_END
 }
