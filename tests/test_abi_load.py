@@ -51,3 +51,32 @@ def test_product_package_does_not_touch_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert "liboracle" not in src and "oracle_lib" not in src, f
                 assert not re.search(r'#include\s+"[^"]*oracle', src), f
+
+
+def test_ctypes_structures_have_the_layout_of_the_header(tmp_path):
+    """The ctypes mirrors in velox_amd/abi.py against the C compiler's view of include/vx355.h:
+    size of every struct and offset of every field (a field added on one side only, or in another
+    order, would otherwise corrupt arguments silently)."""
+    import subprocess
+    pairs = {"vx355_column": abi.Column, "vx355_batch": abi.Batch, "vx355_out_column": abi.OutColumn,
+             "vx355_value_id_spec": abi.ValueIdSpec, "vx355_agg_fn": abi.AggFn, "vx355_agg_spec": abi.AggSpec,
+             "vx355_agg_stats": abi.AggStats, "vx355_key_filter": abi.KeyFilter,
+             "vx355_join_build_spec": abi.JoinBuildSpec, "vx355_join_table_stats": abi.JoinTableStats,
+             "vx355_join_probe_spec": abi.JoinProbeSpec, "vx355_filter_term": abi.FilterTerm,
+             "vx355_join_filter_term": abi.JoinFilterTerm, "vx355_factor": abi.Factor,
+             "vx355_projection": abi.Projection}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "vx355.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for field, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{field} %zu\\n", offsetof({cname}, {field}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs.items():
+        assert int(out[cname]) == C.sizeof(cls), cname
+        for field, _ in cls._fields_:
+            assert int(out[f"{cname}.{field}"]) == getattr(cls, field).offset, f"{cname}.{field}"
