@@ -63,7 +63,77 @@ def parse():
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the rocprofv3 FETCH_SIZE / WRITE_SIZE passes behind roofline.traffic")
     ap.add_argument("--secondary-steps", type=int, default=5)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = every GPU gets the full per-GPU row count (default); strong = the "
+                         "N = 1 row count (SF100 for q1) is sharded N ways, BASELINE's 1/2/4/8 metric")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "lib", "torch"],
+                    help="N > 1 data path: lib = libvx355's own RCCL communicator (vx355_exchange_* / "
+                         "vx355_agg_merge_partials), torch = torch.distributed collectives; auto = lib after "
+                         "a self-check in child processes (velox_amd/commcheck.py), else torch")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only start the ranks, form the process group and report n_gpus (no GPU work; CPU test of the launcher)")
     return ap.parse_args()
+
+
+def free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves
+    (one process per GPU, the same command the driver uses) and pass their output through."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def library_comm(args, torch, dist, rank, world, dev_index, share):
+    """The communicator of the in-library exchange, or (None, why not). With --exchange auto the
+    communicator is first tried in throw-away child processes under a timeout, so that a RCCL
+    problem on this node degrades the run to torch.distributed instead of hanging it."""
+    import subprocess
+    import tempfile
+    if args.exchange == "torch":
+        return None, "--exchange torch"
+    if share:
+        return None, "ranks share one GPU (VX355_BENCH_SHARE_GPU): RCCL refuses two ranks per device"
+    ok = 1
+    why = ""
+    if args.exchange == "auto" and world > 1:
+        box = [None]
+        if rank == 0:
+            box[0] = os.path.join(tempfile.gettempdir(), "vx355_comm_id_%d_%d" % (os.getpid(), free_port()))
+        dist.broadcast_object_list(box, src=0)
+        try:
+            r = subprocess.run([sys.executable, "-m", "velox_amd.commcheck", str(rank), str(world), str(dev_index), box[0]],
+                               cwd=ROOT, capture_output=True, text=True, timeout=150)
+            if r.returncode != 0:
+                ok, why = 0, "commcheck rank %d: rc %d %s" % (rank, r.returncode, r.stderr.strip()[-300:])
+        except subprocess.TimeoutExpired:
+            ok, why = 0, "commcheck rank %d timed out" % rank
+        flag = torch.tensor([ok], dtype=torch.int64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        reasons = [None] * world
+        dist.all_gather_object(reasons, why)
+        if rank == 0 and os.path.exists(box[0]):
+            os.unlink(box[0])
+        if int(flag.item()) == 0:
+            return None, "; ".join(x for x in reasons if x) or "commcheck failed"
+    uid = [ops.Comm.unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(uid, src=0)
+    comm = ops.Comm(uid[0], world, rank)
+    got = comm.info()
+    if got != (world, rank, dev_index):
+        raise SystemExit(f"RCCL reports (world, rank, device) = {got}, the launcher said {(world, rank, dev_index)}")
+    return comm, "libvx355 RCCL communicator (vx355_comm_create)"
 
 
 def dcol(kind, tensor, indices=None, base_size=0):
@@ -173,6 +243,29 @@ class Q1:
             self.selected = self.n
             return ops.collect_output(op, 1024)
         return self.step_unfused(step_kind)
+
+    def partial_operator(self):
+        """The PARTIAL operator of this rank's shard after noMoreInput (N > 1: vx355_agg_merge_partials drains it)."""
+        if not self.fused:
+            raise SystemExit("N > 1 with --unfused uses the torch exchange (--exchange torch)")
+        op = ops.HashAggregation(Q1_KEYS[0], Q1_KEYS[1], self.FUSED_AGGS, abi.STEP_PARTIAL)
+        op.set_fused_input(Q1_TERMS, Q1_PROJ)
+        op.add_input(self.scan)
+        op.no_more_input()
+        self.selected = self.n
+        return op
+
+    def shard_view(self, rows):
+        """The same workload over the first 'rows' rows of the resident columns (strong scaling)."""
+        import copy
+        v = copy.copy(self)
+        c = {k: t[:rows] for k, t in self.c.items()}
+        v.c, v.n = c, rows
+        v.scan = DevBatch([dcol(abi.VARCHAR, c["rf"]), dcol(abi.VARCHAR, c["ls"]),
+                           dcol(abi.DOUBLE, c["qty"]), dcol(abi.DOUBLE, c["ep"]),
+                           dcol(abi.DOUBLE, c["disc"]), dcol(abi.DOUBLE, c["tax"]),
+                           dcol(abi.INTEGER, c["ship"])], rows)
+        return v
 
     def step_unfused(self, step_kind=abi.STEP_SINGLE):
         c, n = self.c, self.n
@@ -654,8 +747,13 @@ class C5:
         self.backend = vdist.GpuJoinBackend(ops, torch)
         torch.cuda.synchronize()
 
+    comm = None    # ops.Comm: the in-library exchange (vx355_join_repartition)
+    tdist = None   # else: torch.distributed (module or GroupDist) through velox_amd/dist.py
+
     def step(self, step_kind=None):
-        import torch.distributed as dist
+        if self.comm is not None:
+            return self.step_library()
+        dist = self.tdist
         if self.world > 1:
             # probe side in 4 chunks: the all-to-all of one chunk overlaps the partitioning of the next
             per_chunk, table = vdist.repartitioned_join_pipelined(self.backend, dist, self.torch,
@@ -667,6 +765,36 @@ class C5:
                                                              [self.pk, self.a], [self.fk, self.m])
         self.matches, self.stats = total, stats
         return total
+
+    def step_library(self):
+        """The whole repartitioned join inside libvx355 (vx355_join_repartition): hash, partition,
+        group by destination, exchange, build; probe side in 4 pipelined chunks. The sink drains
+        every chunk's probe into HBM-resident output buffers (mapping, build rows, payload a)."""
+        torch = self.torch
+        chunks = 4
+        cap = int(self.n // chunks * 1.25) + (1 << 20)
+        if not hasattr(self, "_out"):
+            dev = self.fk.device
+            self._out = (torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.int32, device=dev),
+                         torch.empty(cap, dtype=torch.int64, device=dev), torch.empty(cap // 64 + 1, dtype=torch.int64, device=dev))
+            self._build = DevBatch([dcol(abi.BIGINT, self.pk), dcol(abi.BIGINT, self.a)], int(self.pk.shape[0]))
+            self._probe = DevBatch([dcol(abi.BIGINT, self.fk), dcol(abi.DOUBLE, self.m)], self.n)
+        mapping, brows, payload, nulls = self._out
+        descs = (abi.OutColumn * 1)()
+        descs[0].type_kind, descs[0].mem = abi.BIGINT, abi.MEM_DEVICE
+        descs[0].values, descs[0].nulls = payload.data_ptr(), nulls.data_ptr()
+        total = [0]
+
+        def sink(chunk, received, probe):
+            while True:
+                got, fin = probe.get_output_device(cap, mapping.data_ptr(), brows.data_ptr(), descs, [0])
+                total[0] += got
+                if fin:
+                    break
+        table = ops.join_repartition(self.comm, ([0], [abi.BIGINT], [1], [abi.BIGINT], abi.JOIN_INNER), self._build,
+                                     ([0], abi.JOIN_INNER), self._probe, chunks, sink)
+        self.matches, self.stats = total[0], table.stats()
+        return total[0]
 
     def rows_per_step(self):
         return self.n
@@ -829,30 +957,64 @@ def cpu_baseline_mt(wl, oracle_lib, sample_rows):
 
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: launch exactly one rank "
+                         "per GPU (python -m torch.distributed.run --nproc-per-node N bench.py --gpus N) or let "
+                         "bench.py start the ranks itself (no WORLD_SIZE in the environment)")
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.launch_check:
+        # CPU-only: the ranks exist, find each other and agree on the world size.
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([1], dtype=torch.int64)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": int(t.item()), "requested_gpus": args.gpus}))
+        dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     # VX355_BENCH_SHARE_GPU=1 (debug on a 1-GPU box): every rank uses GPU 0 and
     # the tiny exchange runs over gloo, because RCCL refuses two ranks per device.
     share = os.environ.get("VX355_BENCH_SHARE_GPU") == "1"
     dev_index = 0 if share else local_rank
-    backend = "gloo" if share else "nccl"
+    if not share and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    # Control plane (barriers, the max over ranks of the elapsed time, the communicator id) over
+    # gloo; the DATA path is RCCL: libvx355's own communicator, or — when that is not usable —
+    # a torch.distributed NCCL (= RCCL) group.
+    backend = "gloo"
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     ops.init(dev_index)
+    comm, exchange_note = (None, "1 GPU")
+    nccl_group = None
+    if world > 1 or args.workload == "c5":
+        comm, exchange_note = library_comm(args, torch, dist, rank, world, dev_index, share)
+        if comm is None and args.exchange == "lib":
+            raise SystemExit("--exchange lib: " + exchange_note)
+        if comm is None and not share:
+            if not dist.is_initialized():
+                os.environ.setdefault("MASTER_PORT", str(free_port()))
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            nccl_group = dist.new_group(backend="nccl", device_id=device)
+            backend = "nccl"
+    n_gpus = comm.info()[0] if comm is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+    if n_gpus != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the communicator spans {n_gpus} ranks")
 
     cls, default_rows = WORKLOADS[args.workload]
-    n = args.rows or default_rows
+    n_total = args.rows or default_rows
+    # weak: every GPU gets the per-GPU row count; strong: that row count is the WHOLE job
+    n = n_total if (world == 1 or args.scaling == "weak") else max(1, n_total // world)
     if args.workload == "q3":
         cls.random_probe = args.q3_random_probe
     if args.workload == "c1":
@@ -865,15 +1027,15 @@ def main():
         if args.c4_unordered:
             cls.name += "_unordered_output"
     if args.workload == "c5":
-        if world == 1 and not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29544")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
         wl = cls(torch, n, device, seed=1234 + rank, rank=rank, world=world)
+        wl.comm = comm
+        wl.tdist = GroupDist(dist, nccl_group) if nccl_group is not None else dist
     else:
         wl = cls(torch, n, device, seed=1234 + rank)
     if args.workload == "q1":
         wl.fused = not args.unfused
+    if world > 1 and args.workload not in ("q1", "c5"):
+        raise SystemExit(f"--workload {args.workload} is a single-GPU measurement; q1 and c5 shard over GPUs")
 
     def barrier():
         torch.cuda.synchronize()
@@ -882,37 +1044,61 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def q1_step_sharded(w):
+        # N GPUs: every rank aggregates its own shard (Velox's partial step), the tiny partial
+        # results meet on every rank and the final step merges them — the same partial / final
+        # split the reference uses across Drivers and exchanges (docs/develop/aggregations.rst:24-91).
+        if comm is not None:
+            part = w.partial_operator()
+            fin = ops.merge_partials(comm, part, list(range(len(Q1_KEYS[1]))), Q1_KEYS[1],
+                                     vdist.final_aggs_for(Q1.FUSED_AGGS if w.fused else Q1_AGGS, len(Q1_KEYS[1])))
+            return ops.collect_output(fin, 1024)
+        part = w.step(abi.STEP_PARTIAL)
+        group = GroupDist(dist, nccl_group) if nccl_group is not None else dist
+        return vdist.merge_partials(ops, group, torch, part, Q1_KEYS[1], Q1.FUSED_AGGS if w.fused else Q1_AGGS,
+                                    device if nccl_group is not None else None)
+
     def one_step():
         if world == 1 or args.workload != "q1":
             return wl.step()
-        # N GPUs: every rank aggregates its own shard (Velox's partial step), the
-        # tiny partial results meet on every rank (RCCL all-gather) and the final
-        # step merges them — the same partial/final split the reference uses
-        # across Drivers (docs/develop/aggregations.rst:24-91).
-        part = wl.step(abi.STEP_PARTIAL)
-        return vdist.merge_partials(ops, dist, torch, part, Q1_KEYS[1], Q1.FUSED_AGGS,
-                                    device if backend == "nccl" else None)
+        return q1_step_sharded(wl)
 
-    for _ in range(args.warmup):
-        one_step()
-    barrier()
-    ops.profile_reset()
-    ops.profile_enable(True)
-    t0 = time.perf_counter()
-    result = None
-    for _ in range(args.steps):
-        result = one_step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ops.profile_enable(False)
-    prof = ops.profile()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(step_fn, steps, warmup):
+        for _ in range(warmup):
+            step_fn()
+        barrier()
+        ops.profile_reset()
+        ops.profile_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        ops.profile_enable(False)
+        prof_ = ops.profile()
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, prof_
+
+    elapsed, prof = timed(one_step, args.steps, args.warmup)
     rows = wl.rows_per_step() * world * args.steps
+
+    # N > 1, q1, weak scaling: the strong-scaling form of the same query (the N = 1 row count
+    # sharded N ways = BASELINE's "SF100 at 1/2/4/8 GPUs") is measured next to the headline.
+    strong = None
+    if world > 1 and args.workload == "q1" and args.scaling == "weak" and not args.no_secondary:
+        shard = max(1, n // world)
+        wl_strong = wl.shard_view(shard)
+        dt, _ = timed(lambda: q1_step_sharded(wl_strong), max(1, args.secondary_steps), 2)
+        strong = {"scaling": "strong", "value": shard * world * max(1, args.secondary_steps) / dt, "unit": "rows/s",
+                  "steps": max(1, args.secondary_steps), "warmup": 2,
+                  "ms_per_step": dt / max(1, args.secondary_steps) * 1e3,
+                  "rows_total": shard * world, "rows_per_gpu": shard}
     if rank != 0:
         if world > 1:
+            dist.barrier()
             dist.destroy_process_group()
         return
 
@@ -930,12 +1116,12 @@ def main():
         "metric": "rows/s + HBM GB/s (rocprof), TPC-H Q1 agg & Q3 join SF100, 1/2/4/8 MI355X",
         "value": rows / elapsed,
         "unit": "rows/s",
-        "n_gpus": world,
+        "n_gpus": n_gpus,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling if world > 1 else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -944,13 +1130,18 @@ def main():
                    "plan": ("fused FilterProject+HashAggregation (2 keys, 8 aggregates)" if wl.fused else
                             "FilterProject -> HashAggregation (2 keys, 8 aggregates)")
                    if args.workload == "q1" else args.workload,
-                   "parallelism": "one process per GPU, row shards; partial/final merge over RCCL"
-                   if world > 1 else "1 GPU"},
+                   "parallelism": ("one process per GPU, row shards; " +
+                                   ("partial -> PrestoPages -> all-gather -> final" if args.workload == "q1" else
+                                    "hash repartition of both sides, grouped send / recv per peer, local join") +
+                                   " over RCCL") if world > 1 else "1 GPU",
+                   "exchange": exchange_note},
         "workload_info": wl.info() if hasattr(wl, "info") else {},
         "pipeline_algorithmic_GBps": wl.bytes_per_row * rows / elapsed / 1e9 / world,
         "roofline": roofline_block(wl, prof, args.steps, copy_ceiling, child_flags if measure else None),
         "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())},
     }
+    if strong is not None:
+        out["strong_scaling"] = strong
     if not args.no_cpu_baseline and world == 1:   # the CPU legs are timed at N = 1 only
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
@@ -967,9 +1158,28 @@ def main():
         for order in ("dbgen", "random"):
             out["secondary"]["tpch_q3_sf100_join" + ("" if order == "dbgen" else "_random_probe_order")] = \
                 q3_block(torch, device, order == "random", args, copy_ceiling, measure)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+class GroupDist:
+    """torch.distributed restricted to one process group (the NCCL = RCCL group of the data path
+    when the default group is gloo), with the call shapes velox_amd/dist.py uses."""
+
+    def __init__(self, dist, group):
+        self.dist, self.group = dist, group
+
+    def get_world_size(self):
+        return self.dist.get_world_size(self.group)
+
+    def all_gather(self, out, t):
+        return self.dist.all_gather(out, t, group=self.group)
+
+    def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None, async_op=False):
+        return self.dist.all_to_all_single(out, inp, output_split_sizes, input_split_sizes, group=self.group,
+                                           async_op=async_op)
 
 
 def roofline_block(wl, prof, steps, copy_ceiling, child_flags):

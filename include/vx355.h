@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VX355_ABI_VERSION 3
+#define VX355_ABI_VERSION 4
 
 typedef enum vx355_status {
   VX355_OK = 0,
@@ -839,6 +839,65 @@ int vx355_exchange_columns(
  * blocks in rank order): the partial results of a row-sharded aggregation meet on every
  * rank before its FINAL step. */
 int vx355_all_gather(vx355_comm* c, const void* send, void* recv, size_t bytes_per_rank);
+/* The same for blocks of different sizes: sizes[s] bytes arrive from rank s (sizes[rank] is
+ * this rank's own block; a host array of 'world' entries, e.g. from vx355_exchange_counts with
+ * every send count set to the own size), back to back in rank order. */
+int vx355_all_gather_v(vx355_comm* c, const void* send, const int64_t* sizes, void* recv);
+
+/* ---- the plan fragments around the exchange, orchestrated inside the library --------------
+ * One plan edge "PartitionedOutput(keys) -> Exchange" of a repartitioned join
+ * (exec/PartitionedOutput.cpp:59-133 with exec/HashPartitionFunction.cpp:76-118 on the sending
+ * side, exec/Exchange.cpp on the receiving side), both halves on one handle per rank:
+ *  - send (PartitionedOutput::addInput): VectorHasher::hash of the key columns, partition =
+ *    the top log2(world) hash bits (world a power of two; disjoint from the bits the join tables
+ *    index with, cf. checkHashBitsOverlap exec/HashTable.cpp:1853) or hash % world
+ *    (HashPartitionFunction.cpp:112-115), rows grouped by destination (stable), slice sizes
+ *    all-gathered, then every slice posted straight to its owner (grouped ncclSend / ncclRecv on
+ *    a stream of the handle's own). The call returns while the slices are on the links; two
+ *    sends may be in flight. Collective: every rank sends the same number of batches.
+ *    Columns: FLAT, no nulls, fixed width (strings inline, <= 12 bytes); host or device memory.
+ *  - receive (Exchange::getOutput): waits for the oldest send in flight and hands out the rows
+ *    that landed on this rank as FLAT device columns, source ranks in rank order, input order
+ *    kept inside a source. The buffers belong to the handle and stay valid until the next
+ *    receive on it. */
+typedef struct vx355_exchange vx355_exchange;
+int vx355_exchange_create(vx355_comm* c, const int32_t* col_types, int32_t num_cols, const int32_t* key_cols,
+                          int32_t num_keys, vx355_exchange** out);
+int vx355_exchange_send(vx355_exchange* x, const vx355_batch* batch);
+int vx355_exchange_receive(vx355_exchange* x, vx355_column* cols_out /* num_cols */, int64_t* rows_out);
+void* vx355_exchange_stream(vx355_exchange* x);
+void vx355_exchange_destroy(vx355_exchange* x);
+
+/* The repartitioned join of BASELINE config 5 in one call (what velox_amd/dist.py did in
+ * Python until ABI 3): build_rows / probe_rows are this rank's row-range shards (FLAT columns;
+ * the specs' key_cols / dependent_cols index them). Build side: exchange, HashBuild::addInput,
+ * noMoreInput -> *table_out (one reference, the caller releases it). Probe side: cut into
+ * 'chunks' row ranges; the slices of chunk i are on the links while chunk i + 1 is hashed and
+ * grouped and chunk i - 1 is probed. For every chunk the sink is called once, after
+ * HashProbe::addInput of the rows that landed here: it drains 'probe' (vx355_join_probe_get_output)
+ * before it returns; 'received' (device columns) is valid during the call. A non-zero return
+ * aborts the join with that status. Collective: every rank calls it with the same 'chunks'. */
+typedef int (*vx355_join_chunk_sink)(void* arg, int32_t chunk, const vx355_batch* received, vx355_join_probe* probe);
+int vx355_join_repartition(
+    vx355_comm* c,
+    const vx355_join_build_spec* build_spec,
+    const vx355_batch* build_rows,
+    const vx355_join_probe_spec* probe_spec,
+    const vx355_batch* probe_rows,
+    int32_t chunks,
+    vx355_join_chunk_sink sink,
+    void* sink_arg,
+    vx355_join_table** table_out);
+
+/* Partial -> final merge of a row-sharded aggregation (docs/develop/aggregations.rst:24-91):
+ * 'partial' (PARTIAL / INTERMEDIATE step, after vx355_agg_no_more_input) is drained, its groups
+ * leave as one PrestoPage per rank (the wire format of Velox's exchange, lossless timestamps),
+ * every rank receives every page, and a new operator created from final_spec (FINAL or
+ * INTERMEDIATE step; its column numbers refer to the partial operator's output layout) consumes
+ * them in rank order and is returned after noMoreInput: the caller drains *final_out with
+ * vx355_agg_get_output and destroys both operators. Collective. */
+int vx355_agg_merge_partials(vx355_comm* c, vx355_agg* partial, const vx355_agg_spec* final_spec,
+                             vx355_agg** final_out);
 
 #ifdef __cplusplus
 }

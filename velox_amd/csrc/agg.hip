@@ -606,8 +606,20 @@ const FastEntry kFastTable[] = {
 // record {key, row, operands} plus one read.
 constexpr int kRadixMaxAccs = 3;
 constexpr int kRadixMaxBins = 4096;   // per level
-constexpr int kRadixKeyBits = 32;     // record word 0 = key : 32 | row of the chunk : 29 | accumulator mask : 3
-constexpr int kRadixRowBits = 29;
+constexpr int kRadixKeyBits = 32;     // widest key field of a record
+constexpr int kRadixMaskBits = 3;     // = kRadixMaxAccs
+// Record word 0 = normalized key : keyBits | row of the chunk : rowBits | accumulator mask : 3,
+// keyBits = bits of the table's capacity, rowBits = min(31, 61 - keyBits): a 2^28-group table
+// takes chunks of 2^31 rows (BASELINE config 4, 10^9 rows, is ONE chunk: every partition is
+// folded once).
+inline int radixKeyBits(uint64_t capacity) {
+  int b = 1;
+  while ((1ULL << b) < capacity) {
+    ++b;
+  }
+  return b;
+}
+inline int radixRowBits(uint64_t capacity) { return std::min(31, 64 - kRadixMaskBits - radixKeyBits(capacity)); }
 
 struct RadixArgs {
   AggArgs a;
@@ -616,6 +628,8 @@ struct RadixArgs {
   int32_t shiftB;      // log2(groups per partition): pid = key >> shiftB
   int32_t shift2;      // level-1 bin = pid >> shift2 (0 = single level)
   int32_t numBins;     // level-1 bins
+  int32_t keyBits;     // layout of record word 0
+  int32_t rowBits;
   int32_t valIdx[kRadixMaxAccs];  // operand word of accumulator j, -1 for counts
   int32_t accOfVal[kRadixMaxAccs];  // inverse: accumulator of operand word q
   int64_t tileRows;    // rows per workgroup tile
@@ -808,7 +822,7 @@ __global__ __launch_bounds__(1024) void k_rp_scatter1(RadixArgs r) {
             }
           }
         }
-        vals[u][0] = key | (static_cast<uint64_t>(row) << kRadixKeyBits) | (mask << (kRadixKeyBits + kRadixRowBits));
+        vals[u][0] = key | (static_cast<uint64_t>(row) << r.keyBits) | (mask << (r.keyBits + r.rowBits));
         const uint32_t bin = static_cast<uint32_t>(key >> shift);
         const unsigned long long pos = binBase[bin] + atomicAdd(&cursor[bin], 1u);
         rpStore<W>(r.recs + pos * W, vals[u]);
@@ -976,12 +990,29 @@ struct RadixAggArgs {
   int32_t wordKind[2 * kRadixMaxAccs];
   int32_t wordOff[2 * kRadixMaxAccs];       // word offset inside the group row
   double splitM[kRadixMaxAccs];
+  int32_t keyBits;                          // layout of record word 0
+  int32_t rowBits;
+  // virgin: the table has never been written (no k_init_table ran): the owner of a partition
+  // stores every one of its group rows completely - untouched words from 'pattern' - instead of
+  // read-modify-write, and empty partitions are initialised on the way.
+  int32_t virgin;
+  int32_t phase;                            // 0: owners only, 1: remaining slices of split partitions, -1: both
+  const uint64_t* pattern;                  // stride words of an empty group row
+  int8_t ldsOfWord[2 + kMaxLdsAccs];        // word of the group row -> LDS word of the fold, -1 = none
+  // (first input row, group row index) of every group this launch creates: finalize sorts these
+  // instead of scanning the whole table for live rows (k_collect). A group's first row is final
+  // when it is created - later chunks only bring larger row numbers - except in partitions split
+  // into slices, which set counters->pairsBroken.
+  uint64_t* pairKeys;
+  uint32_t* pairVals;
+  uint64_t pairBase;
 };
 
 // LDS state of one fold: acc[B][A] + first[B], A = LDS words per group.
 struct RpFold {
   uint64_t* acc;
   uint32_t* first;
+  uint32_t* scratch;   // [0] groups created by this flush, [1] their base in the launch's pair list
   int B;
   int A;
 };
@@ -1017,8 +1048,8 @@ __device__ inline void rpFoldRecords(const RpFold& f, const RadixAggArgs& r, uin
       }
       const uint64_t w0 = w[u][0];
       const uint32_t g = static_cast<uint32_t>(w0) & static_cast<uint32_t>(f.B - 1);
-      const uint32_t row = static_cast<uint32_t>(w0 >> kRadixKeyBits) & ((1u << kRadixRowBits) - 1);
-      const uint32_t mask = static_cast<uint32_t>(w0 >> (kRadixKeyBits + kRadixRowBits));
+      const uint32_t row = static_cast<uint32_t>(w0 >> r.keyBits) & static_cast<uint32_t>((1ULL << r.rowBits) - 1);
+      const uint32_t mask = static_cast<uint32_t>(w0 >> (r.keyBits + r.rowBits));
       if (f.first[g] > row) {
         atomicMin(&f.first[g], row);
       }
@@ -1047,26 +1078,51 @@ __device__ inline void rpFoldRecords(const RpFold& f, const RadixAggArgs& r, uin
   blockSync();
 }
 
-// Adds the LDS block into the partition's group rows. exclusive: this workgroup
-// is the only writer of those rows during the launch — plain read-modify-write,
-// coalesced over consecutive groups; otherwise (the partition is shared by
-// several workgroups, see below) HBM atomics.
-__device__ inline void rpFoldFlush(const RpFold& f, const RadixAggArgs& r, int64_t p, bool exclusive) {
+// Adds the LDS block into the partition's group rows. exclusive: this workgroup is the only
+// writer of those rows during the launch — plain read-modify-write, coalesced over consecutive
+// groups (virgin table: plain stores of complete rows, nothing is read); otherwise (the partition
+// is shared by several workgroups, see below) HBM atomics. hasRecords = false: an empty partition
+// of a virgin table, whose rows only get their initial pattern. Groups created here are counted
+// with ONE atomic per flush and listed as (first row, group row) pairs.
+constexpr int kRpMaxPerThread = 8;  // B <= 4096 groups, 512 threads
+
+__device__ inline void rpFoldFlush(const RpFold& f, const RadixAggArgs& r, int64_t p, bool exclusive, bool hasRecords) {
   const int A = f.A;
   const uint64_t base = static_cast<uint64_t>(p) << r.shiftB;
-  uint32_t newGroups = 0;
-  for (int g = threadIdx.x; g < f.B; g += blockDim.x) {
-    const uint32_t fr = f.first[g];
-    if (fr == 0xffffffffu || base + g >= r.capacity) {
+  const bool virgin = r.virgin != 0 && exclusive;
+  if (threadIdx.x == 0) {
+    f.scratch[0] = 0;
+    if (!exclusive) {
+      r.counters->pairsBroken = 1;
+    }
+  }
+  blockSync();
+  uint32_t myPos[kRpMaxPerThread];
+  int k = 0;
+  for (int g = threadIdx.x; g < f.B; g += blockDim.x, ++k) {
+    myPos[k] = 0xffffffffu;
+    if (base + g >= r.capacity) {
       continue;
     }
+    const uint32_t fr = hasRecords ? f.first[g] : 0xffffffffu;
     uint64_t* row = r.table + (base + g) * r.stride;
     const uint64_t mine = r.rowBase + static_cast<uint64_t>(fr);
-    if (!exclusive) {
-      const unsigned long long old = atomicMin(reinterpret_cast<unsigned long long*>(row + 1), mine);
-      if (old == kNoRow) {
-        ++newGroups;
+    bool isNew = false;
+    if (virgin) {
+      isNew = fr != 0xffffffffu;
+      for (int w = 0; w < r.stride; ++w) {
+        uint64_t v = r.pattern[w];
+        if (isNew) {
+          const int j = r.ldsOfWord[w];
+          v = w == 1 ? mine : (j >= 0 ? f.acc[static_cast<size_t>(g) * A + j] : v);
+        }
+        row[w] = v;
       }
+    } else if (fr == 0xffffffffu) {
+      // nothing for this group
+    } else if (!exclusive) {
+      const unsigned long long old = atomicMin(reinterpret_cast<unsigned long long*>(row + 1), mine);
+      isNew = old == kNoRow;
       for (int j = 0; j < A; ++j) {
         const uint64_t v = f.acc[static_cast<size_t>(g) * A + j];
         const int32_t kind = r.wordKind[j];
@@ -1074,52 +1130,60 @@ __device__ inline void rpFoldFlush(const RpFold& f, const RadixAggArgs& r, int64
           applyGlobal(row + r.wordOff[j], kind == ACC_COUNT ? ACC_SUM_I64_WRAP : kind, v, r.counters);
         }
       }
-      continue;
-    }
-    const uint64_t old = row[1];
-    if (old == kNoRow) {
-      ++newGroups;
-    }
-    if (mine < old) {
-      row[1] = mine;
-    }
-    for (int j = 0; j < A; ++j) {
-      const uint64_t v = f.acc[static_cast<size_t>(g) * A + j];
-      uint64_t* word = row + r.wordOff[j];
-      switch (r.wordKind[j]) {
-        case ACC_SUM_F64:
-          *reinterpret_cast<double*>(word) += __longlong_as_double(static_cast<long long>(v));
-          break;
-        case ACC_SUM_I64: {
-          const int64_t before = static_cast<int64_t>(*word);
-          if (addOverflows(before, static_cast<int64_t>(v))) {
-            r.counters->overflow = 1;
+    } else {
+      const uint64_t old = row[1];
+      isNew = old == kNoRow;
+      if (mine < old) {
+        row[1] = mine;
+      }
+      for (int j = 0; j < A; ++j) {
+        const uint64_t v = f.acc[static_cast<size_t>(g) * A + j];
+        uint64_t* word = row + r.wordOff[j];
+        switch (r.wordKind[j]) {
+          case ACC_SUM_F64:
+            *reinterpret_cast<double*>(word) += __longlong_as_double(static_cast<long long>(v));
+            break;
+          case ACC_SUM_I64: {
+            const int64_t before = static_cast<int64_t>(*word);
+            if (addOverflows(before, static_cast<int64_t>(v))) {
+              r.counters->overflow = 1;
+            }
+            *word = static_cast<uint64_t>(before) + v;
+            break;
           }
-          *word = static_cast<uint64_t>(before) + v;
-          break;
+          case ACC_SUM_I64_WRAP:
+          case ACC_COUNT:
+            *word += v;
+            break;
+          case ACC_MIN:
+            *word = v < *word ? v : *word;
+            break;
+          default:
+            *word = v > *word ? v : *word;
+            break;
         }
-        case ACC_SUM_I64_WRAP:
-        case ACC_COUNT:
-          *word += v;
-          break;
-        case ACC_MIN:
-          *word = v < *word ? v : *word;
-          break;
-        default:
-          *word = v > *word ? v : *word;
-          break;
+      }
+    }
+    if (isNew) {
+      myPos[k] = atomicAdd(&f.scratch[0], 1u);
+    }
+  }
+  blockSync();
+  if (threadIdx.x == 0 && f.scratch[0] != 0) {
+    f.scratch[1] = atomicAdd(&r.counters->numNewGroups, f.scratch[0]);
+  }
+  blockSync();
+  if (r.pairKeys != nullptr && f.scratch[0] != 0) {
+    k = 0;
+    for (int g = threadIdx.x; g < f.B; g += blockDim.x, ++k) {
+      if (myPos[k] != 0xffffffffu) {
+        const uint64_t at = r.pairBase + f.scratch[1] + myPos[k];
+        r.pairKeys[at] = r.rowBase + static_cast<uint64_t>(f.first[g]);
+        r.pairVals[at] = static_cast<uint32_t>(base + g);
       }
     }
   }
-  // one add per wave instead of one per lane
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    newGroups += __shfl_xor(newGroups, off, kWave);
-  }
-  if (lane() == 0 && newGroups) {
-    atomicAdd(&r.counters->numNewGroups, newGroups);
-  }
-  blockSync();
+  blockSync();  // the LDS block is reused by the next partition
 }
 
 __device__ inline void rpPartitionRange(const RadixAggArgs& r, int64_t p, uint64_t* begin, uint64_t* end) {
@@ -1138,21 +1202,36 @@ __global__ __launch_bounds__(512) void k_rp_aggregate(RadixAggArgs r) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
   __shared__ uint32_t bigList[512];
   __shared__ uint32_t bigCount;
+  __shared__ uint32_t scratch[2];
   RpFold f;
   f.B = 1 << r.shiftB;
   f.A = r.numWords;
   f.acc = reinterpret_cast<uint64_t*>(ldsRaw);                                       // [B][A]
   f.first = reinterpret_cast<uint32_t*>(f.acc + static_cast<size_t>(f.B) * f.A);   // [B]
-  for (int64_t p = blockIdx.x; p < r.numParts; p += gridDim.x) {
-    uint64_t begin, end;
-    rpPartitionRange(r, p, &begin, &end);
-    if (end == begin) {
-      continue;  // uniform per workgroup
+  f.scratch = scratch;
+  if (r.phase != 1) {
+    for (int64_t p = blockIdx.x; p < r.numParts; p += gridDim.x) {
+      uint64_t begin, end;
+      rpPartitionRange(r, p, &begin, &end);
+      if (end == begin) {  // uniform per workgroup
+        if (r.virgin) {
+          rpFoldFlush(f, r, p, true, false);  // its rows still need their initial pattern
+        }
+        continue;
+      }
+      const bool split = end - begin > r.sliceRecs;
+      rpFoldInit(f, r);
+      rpFoldRecords<W>(f, r, begin, split ? begin + r.sliceRecs : end);
+      // the owner of a split partition of a virgin table stores complete rows like any owner: the
+      // other slices run in the next launch (phase 1), behind the launch boundary
+      rpFoldFlush(f, r, p, !split || r.virgin != 0, true);
+      if (split && threadIdx.x == 0) {
+        r.counters->pairsBroken = 1;
+      }
     }
-    const bool split = end - begin > r.sliceRecs;
-    rpFoldInit(f, r);
-    rpFoldRecords<W>(f, r, begin, split ? begin + r.sliceRecs : end);
-    rpFoldFlush(f, r, p, !split);
+  }
+  if (r.phase == 0) {
+    return;
   }
   // Remaining slices of the split partitions.
   for (int64_t p0 = 0; p0 < r.numParts; p0 += blockDim.x) {
@@ -1179,7 +1258,7 @@ __global__ __launch_bounds__(512) void k_rp_aggregate(RadixAggArgs r) {
         const uint64_t b = begin + s * r.sliceRecs;
         rpFoldInit(f, r);
         rpFoldRecords<W>(f, r, b, b + r.sliceRecs < end ? b + r.sliceRecs : end);
-        rpFoldFlush(f, r, p, false);
+        rpFoldFlush(f, r, p, false, true);
       }
     }
     blockSync();
@@ -2219,6 +2298,13 @@ struct vx355_agg {
   int32_t radixMaxBins = kRadixMaxBins;  // widest single-level fan-out
   int64_t radixTileRows = 0;  // 0 = automatic
   int64_t radixLaunches = 0;
+  // The table was allocated but never written (rebuildTable skipped k_init_table because a radix
+  // fold may come first and store every row itself); settleTable initialises it for anyone else.
+  bool tableVirgin = false;
+  // (first row, group row) pairs of the groups created so far, in orderKeys / orderVals: complete
+  // while every group came out of an exclusive radix fold of the current table.
+  int64_t pairCount = 0;
+  bool pairsComplete = true;
   DevBuf orderKeys, orderVals, orderKeys2, orderVals2;
   const uint32_t* order = nullptr;
   int64_t numOutput = -1;  // set by finalize
@@ -2534,6 +2620,14 @@ void initTable(vx355_agg& h, DevBuf& buf, uint64_t rows) {
             h.pattern.as<uint64_t>());
 }
 
+// Anything but a radix fold needs initialised group rows.
+void settleTable(vx355_agg& h) {
+  if (h.tableVirgin) {
+    initTable(h, h.table, h.capacity);
+    h.tableVirgin = false;
+  }
+}
+
 void ensureBasics(vx355_agg& h) {
   auto& rt = Runtime::get();
   if (h.pattern.ptr()) {
@@ -2600,8 +2694,20 @@ void rebuildTable(vx355_agg& h, uint64_t extraGroups) {
     newCap = hashCapacityFor(static_cast<uint64_t>(h.numGroups) + extraGroups);
   }
   DevBuf fresh;
-  initTable(h, fresh, newCap);
+  // An empty direct-index table beyond the LDS path: leave it unwritten, the first launch is
+  // most likely a radix fold that stores every row itself (else settleTable).
+  const bool virgin = d.mode == MODE_ARRAY && newCap > 8192 && h.radixMinRows >= 0 && h.numGroups == 0 &&
+      !h.keys.empty();
+  if (virgin) {
+    fresh.ensure(static_cast<size_t>(newCap) * h.stride * 8 + 64);
+  } else {
+    initTable(h, fresh, newCap);
+  }
+  // group rows move: the listed pairs would point at the old places
+  h.pairsComplete = h.numGroups == 0;
+  h.pairCount = 0;
   if (h.tableReady && h.numGroups > 0) {
+    settleTable(h);
     RekeyArgs ra{};
     ra.oldTable = h.table.as<uint64_t>();
     ra.oldRows = h.capacity;
@@ -2621,6 +2727,7 @@ void rebuildTable(vx355_agg& h, uint64_t extraGroups) {
   }
   rt.sync();
   h.table = std::move(fresh);
+  h.tableVirgin = virgin;
   h.capacity = newCap;
   h.mode = d.mode;
   for (size_t k = 0; k < h.keys.size(); ++k) {
@@ -3094,6 +3201,7 @@ void materializeAliases(vx355_agg& h, const DeviceBatch& db) {
       continue;
     }
     if (h.tableReady) {
+      settleTable(h);
       VX_LAUNCH("k_copy_acc", k_copy_acc, streamGrid(static_cast<int64_t>(h.capacity), 256), 256, 0,
                 h.table.as<uint64_t>(), h.capacity, h.stride,
                 flagFromFirstRow(h, p.aliasOf) ? 1 : 2 + p.aliasOf,
@@ -3126,8 +3234,8 @@ int radixWords(const AggArgs& a) {
 
 bool radixEligible(const vx355_agg& h, const AggArgs& a) {
   if (h.radixMinRows < 0 || a.mode != MODE_ARRAY || a.rowList || a.rescanOld || a.numAccs < 1 ||
-      a.numAccs > kRadixMaxAccs || a.numRows < h.radixMinRows || a.numRows > (1LL << kRadixRowBits) ||
-      a.capacity > (1ULL << kRadixKeyBits)) {
+      a.numAccs > kRadixMaxAccs || a.numRows < h.radixMinRows || a.capacity > (1ULL << kRadixKeyBits) ||
+      a.numRows > (1LL << radixRowBits(a.capacity))) {
     return false;
   }
   const int shiftB = radixShiftB(radixWords(a));
@@ -3152,6 +3260,8 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
       ? 0
       : std::max(log2Ceil((parts + h.radixMaxBins - 1) / h.radixMaxBins), log2Ceil(parts) / 2);
   r.numBins = static_cast<int32_t>((parts + (1ULL << r.shift2) - 1) >> r.shift2);
+  r.keyBits = radixKeyBits(a.capacity);
+  r.rowBits = radixRowBits(a.capacity);
   const int32_t bins2 = 1 << r.shift2;
   for (int j = 0; j < a.numAccs; ++j) {
     r.valIdx[j] = a.accs[j].kind == ACC_COUNT ? -1 : r.numVals++;
@@ -3308,10 +3418,47 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
   if (const char* e = std::getenv("VX355_AGG_RADIX_SLICE")) {
     g.sliceRecs = static_cast<uint64_t>(std::max<int64_t>(512, std::strtoll(e, nullptr, 10)));
   }
+  g.keyBits = r.keyBits;
+  g.rowBits = r.rowBits;
+  g.virgin = h.tableVirgin ? 1 : 0;
+  g.pattern = h.pattern.as<uint64_t>();
+  for (int w = 0; w < 2 + kMaxLdsAccs; ++w) {
+    g.ldsOfWord[w] = -1;
+  }
+  for (int j = 0; j < g.numWords; ++j) {
+    g.ldsOfWord[g.wordOff[j]] = static_cast<int8_t>(j);
+  }
+  if (h.pairsComplete && h.pairCount == h.numGroups) {
+    // room for one new group per row of the chunk, at most one per group row
+    const size_t room = static_cast<size_t>(std::min<uint64_t>(a.capacity, static_cast<uint64_t>(h.numGroups + n)));
+    const size_t live = static_cast<size_t>(h.pairCount);
+    h.orderKeys.ensure(room * 8 + 64, true, live * 8);
+    h.orderVals.ensure(room * 4 + 64, true, live * 4);
+    g.pairKeys = h.orderKeys.as<uint64_t>();
+    g.pairVals = h.orderVals.as<uint32_t>();
+    g.pairBase = static_cast<uint64_t>(h.pairCount);
+  } else {
+    h.pairsComplete = false;
+  }
   const int gridA = rt.numCUs * 2;
-  byWidth([&](auto wTag) {
-    VX_LAUNCH("k_rp_aggregate", (k_rp_aggregate<decltype(wTag)::value>), gridA, 512, ldsBytes, g);
-  });
+  if (g.virgin) {
+    // owners store complete rows; the other slices of split partitions wait for the launch boundary
+    g.phase = 0;
+    byWidth([&](auto wTag) {
+      VX_LAUNCH("k_rp_aggregate", (k_rp_aggregate<decltype(wTag)::value>), gridA, 512, ldsBytes, g);
+    });
+    g.phase = 1;
+    g.virgin = 0;
+    byWidth([&](auto wTag) {
+      VX_LAUNCH("k_rp_aggregate", (k_rp_aggregate<decltype(wTag)::value>), gridA, 512, ldsBytes, g);
+    });
+    h.tableVirgin = false;
+  } else {
+    g.phase = -1;
+    byWidth([&](auto wTag) {
+      VX_LAUNCH("k_rp_aggregate", (k_rp_aggregate<decltype(wTag)::value>), gridA, 512, ldsBytes, g);
+    });
+  }
   ++h.radixLaunches;
 }
 
@@ -3333,6 +3480,8 @@ void launchChunk(vx355_agg& h, AggArgs& a) {
     }
   }
   if (chooseLds(h, numWords, &la.plan, &ldsBytes)) {
+    settleTable(h);
+    h.pairsComplete = false;
     LdsPlan& plan = la.plan;
     plan.table = a.table;
     plan.stride = a.stride;
@@ -3380,6 +3529,8 @@ void launchChunk(vx355_agg& h, AggArgs& a) {
       launchRadix(h, a);
       return;
     }
+    settleTable(h);
+    h.pairsComplete = false;
     // DOUBLE sums keep their hi/lo split here too (two HBM atomics per sum and
     // row): the <= 1 ULP bound must not depend on which kernel a chunk takes.
     VX_LAUNCH("k_agg_global", k_agg_global, streamGrid(a.numRows, 256), 256, 0, a);
@@ -3599,7 +3750,9 @@ void switchToGeneric(vx355_agg& h) {
   h.gHashStore.ensure(newMax * 8 + 64);
   DevBuf fresh;
   initTable(h, fresh, newMax);
+  h.pairsComplete = false;
   if (h.tableReady && live > 0) {
+    settleTable(h);
     ta.oldTable = h.table.as<uint64_t>();
     ta.oldRows = h.capacity;
     ta.oldMode = h.mode;
@@ -3614,6 +3767,7 @@ void switchToGeneric(vx355_agg& h) {
   }
   rt.sync();
   h.table = std::move(fresh);
+  h.tableVirgin = false;
   h.capacity = newMax;
   h.gMaxGroups = newMax;
   h.tableReady = true;
@@ -3766,10 +3920,12 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
   for (int64_t begin = 0; begin < n; begin += rows) {
     // The first chunk of a stream is kept small: what it finds (number of live
     // groups) picks the LDS layout of every later launch.
-    rows = std::min(h.numGroups == 0 ? std::min<int64_t>(h.chunkRows, 1 << 20) : h.chunkRows,
+    // (A direct-index table beyond the LDS path's 8192 groups has no layout to pick.)
+    const bool wideArray = h.mode == MODE_ARRAY && h.capacity > 8192;
+    rows = std::min((h.numGroups == 0 && !wideArray) ? std::min<int64_t>(h.chunkRows, 1 << 20) : h.chunkRows,
                     n - begin);
-    if (h.mode == MODE_ARRAY && h.radixMinRows >= 0 && h.capacity > (1u << 12)) {
-      rows = std::min<int64_t>(rows, 1LL << kRadixRowBits);  // radix path: 29-bit row numbers in the records
+    if (wideArray && h.radixMinRows >= 0) {
+      rows = std::min<int64_t>(rows, 1LL << radixRowBits(h.capacity));  // radix path: row numbers live in the records
     }
     if (h.mode == MODE_NORMALIZED) {
       // The open-addressing table is sized for the worst case "every row of the
@@ -3857,6 +4013,11 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
       bool toGeneric = ctr.unmappable != 0;
       ctr.unmappable = 0;
       checkCounters(ctr);
+      if (h.pairsComplete && !ctr.pairsBroken) {
+        h.pairCount += ctr.numNewGroups;  // a radix fold listed them (any other launch cleared pairsComplete)
+      } else {
+        h.pairsComplete = false;
+      }
       h.numGroups += ctr.numNewGroups;
       pending = ctr.numDeferred;
       if (pending > 0) {
@@ -3930,21 +4091,26 @@ void finalize(vx355_agg& h) {
     return;
   }
   const size_t g = static_cast<size_t>(h.numGroups);
-  h.orderKeys.ensure(g * 8 + 64);
-  h.orderVals.ensure(g * 4 + 64);
+  settleTable(h);
+  // Every group was listed by the radix folds that created it: no scan of the table.
+  const bool listed = h.pairsComplete && h.pairCount == h.numGroups;
+  if (!listed) {
+    h.orderKeys.ensure(g * 8 + 64);
+    h.orderVals.ensure(g * 4 + 64);
+    uint32_t* cursor = reinterpret_cast<uint32_t*>(h.counters());
+    resetCounters(h);
+    VX_LAUNCH("k_collect", k_collect, streamGrid(static_cast<int64_t>(h.capacity), 256), 256, 0,
+              h.table.as<uint64_t>(), h.capacity, h.stride, h.orderKeys.as<uint64_t>(),
+              h.orderVals.as<uint32_t>(), cursor);
+    Counters c = readCounters(h);
+    const uint32_t found = c.numDeferred;  // first word of the block is the cursor
+    if (found != g) {
+      VX_THROW(VX355_EINTERNAL, "group count mismatch: counted " + std::to_string(g) + ", found " +
+                                    std::to_string(found));
+    }
+  }
   h.orderKeys2.ensure(g * 8 + 64);
   h.orderVals2.ensure(g * 4 + 64);
-  uint32_t* cursor = reinterpret_cast<uint32_t*>(h.counters());
-  resetCounters(h);
-  VX_LAUNCH("k_collect", k_collect, streamGrid(static_cast<int64_t>(h.capacity), 256), 256, 0,
-            h.table.as<uint64_t>(), h.capacity, h.stride, h.orderKeys.as<uint64_t>(),
-            h.orderVals.as<uint32_t>(), cursor);
-  Counters c = readCounters(h);
-  const uint32_t found = c.numDeferred;  // first word of the block is the cursor
-  if (found != g) {
-    VX_THROW(VX355_EINTERNAL, "group count mismatch: counted " + std::to_string(g) + ", found " +
-                                  std::to_string(found));
-  }
   if (h.unorderedOutput) {
     rt.sync();
     h.order = h.orderVals.as<uint32_t>();  // table order as k_collect found it
@@ -3977,8 +4143,11 @@ void resetAfterFlush(vx355_agg& h) {
   }
   if (h.tableReady) {
     initTable(h, h.table, h.capacity);
+    h.tableVirgin = false;
   }
   rt.sync();
+  h.pairCount = 0;
+  h.pairsComplete = true;
   h.numGroups = 0;
   h.numOutput = -1;
   h.outputCursor = 0;

@@ -33,7 +33,8 @@ struct Counters {
   uint32_t overflow;     // sum(BIGINT) overflowed
   uint32_t unmappable;   // a string key longer than 7 bytes was seen
   uint32_t tableFull;
-  uint32_t pad[3];
+  uint32_t pairsBroken;  // a radix fold split a partition into slices: its (first row, group) pairs may be stale
+  uint32_t pad[2];
   int64_t keyMin[kMaxKeys];
   int64_t keyMax[kMaxKeys];
   uint64_t sumMax[kMaxAccs];  // largest |input| seen per DOUBLE sum (bit pattern), k_sum_stats

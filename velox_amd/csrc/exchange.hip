@@ -45,6 +45,9 @@ struct Rccl {
   int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
+  int (*CommCount)(ncclComm_t, int*) = nullptr;      // optional: what the communicator itself reports
+  int (*CommUserRank)(ncclComm_t, int*) = nullptr;
+  int (*CommCuDevice)(ncclComm_t, int*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   std::string path;
 };
@@ -93,6 +96,9 @@ Rccl& rccl() {
     r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
     r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+    r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(sym("ncclCommUserRank"));
+    r.CommCuDevice = reinterpret_cast<decltype(r.CommCuDevice)>(sym("ncclCommCuDevice"));
     if (r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.Send && r.Recv && r.AllGather &&
         r.GroupStart && r.GroupEnd) {
       gRccl = r;
@@ -112,6 +118,26 @@ void ncclOk(int rc, const char* what) {
   }
 }
 
+// ncclGroupStart ... ncclGroupEnd that cannot be left open: an exception between the two would
+// leave the thread's RCCL group open and the next collective would silently join it.
+class GroupGuard {
+ public:
+  explicit GroupGuard(Rccl& r) : r_(r) { ncclOk(r_.GroupStart(), "ncclGroupStart"); }
+  void end() {
+    open_ = false;
+    ncclOk(r_.GroupEnd(), "ncclGroupEnd");
+  }
+  ~GroupGuard() {
+    if (open_) {
+      (void)r_.GroupEnd();
+    }
+  }
+
+ private:
+  Rccl& r_;
+  bool open_ = true;
+};
+
 }  // namespace
 }  // namespace vx
 
@@ -124,6 +150,81 @@ struct vx355_comm {
   int32_t rank = 0;
   DevBuf countsDev;            // all-gather of the slice sizes
 };
+
+namespace vx {
+namespace {
+
+// ---- PartitionedOutput -> Exchange edge of a repartitioned join -----------------------------
+// (exec/PartitionedOutput.cpp:59-133 + exec/HashPartitionFunction.cpp:76-118 on the sending
+// side, exec/Exchange.cpp on the receiving side; here both halves of the edge on one handle.)
+constexpr int kExMaxCols = 16;
+constexpr int kExMaxKeys = 8;
+constexpr int kExSlots = 3;   // two exchanges in flight + the one the caller is consuming
+
+struct HashPartArgs {
+  ColView keys[kExMaxKeys];
+  int32_t numKeys;
+  int32_t kind;            // VX355_PART_MODULO / VX355_PART_BIT_RANGE
+  uint32_t numPartitions;
+  int32_t bitBegin;
+  uint64_t mask;
+  int64_t numRows;
+  uint32_t* out;
+};
+
+// VectorHasher::hash over the key columns (hashValueAt + hashMix, nulls = kNullHash) and
+// HashPartitionFunction::partition of that hash, fused: the 8-byte hashes never reach HBM.
+__global__ __launch_bounds__(256) void k_hash_partition(HashPartArgs a) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < a.numRows; row += stride) {
+    uint64_t h = 0;
+    for (int k = 0; k < a.numKeys; ++k) {
+      const ColView& c = a.keys[k];
+      const uint64_t hv = colIsNull(c, row) ? kNullHash : hashValueAt(c, colIndex(c, row));
+      h = k == 0 ? hv : hashMix(h, hv);
+    }
+    a.out[row] = a.kind == VX355_PART_MODULO ? static_cast<uint32_t>(h % a.numPartitions)
+                                             : static_cast<uint32_t>((h >> a.bitBegin) & a.mask);
+  }
+}
+
+// Sets *flag when a StringView column holds a non-inline string (size > 12: the view carries a
+// pointer that means nothing on another GPU).
+__global__ __launch_bounds__(256) void k_any_long_string(const uint4* views, int64_t n, uint32_t* flag) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  bool any = false;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    any = any || views[i].x > 12u;
+  }
+  if (any) {
+    *flag = 1;
+  }
+}
+
+struct ExSlot {
+  std::vector<DevBuf> grouped;   // rows grouped by destination (send side)
+  std::vector<DevBuf> received;  // rows of every source rank, rank order
+  std::vector<int64_t> sendCounts, recvCounts;
+  int64_t rows = 0;              // received rows
+  hipEvent_t done = nullptr;     // recorded on the payload stream behind the last send / recv
+  bool inFlight = false;
+};
+
+}  // namespace
+}  // namespace vx
+
+struct vx355_exchange {
+  vx::Runtime* ctx = nullptr;
+  vx355_comm* comm = nullptr;
+  std::vector<int32_t> types, widths, keyCols;
+  hipStream_t payload = nullptr;     // the RCCL sends / recvs of the column slices run here, so that
+                                     // an entry point returns while they are still on the links
+  hipEvent_t staged = nullptr;       // grouped columns complete (recorded on ctx->stream)
+  vx::ExSlot slots[vx::kExSlots];
+  int64_t sent = 0, receivedCount = 0;
+  vx::DevBuf parts;
+};
+
 
 extern "C" {
 
@@ -145,7 +246,12 @@ int vx355_comm_create(const void* id, int32_t world, int32_t rank, vx355_comm** 
   ncclUniqueId uid;
   std::memcpy(uid.internal, id, kUniqueIdBytes);
   ncclOk(rccl().CommInitRank(&c->comm, world, uid, rank), "ncclCommInitRank");
-  c->ctx = Runtime::createContext();
+  try {
+    c->ctx = Runtime::createContext();
+  } catch (...) {
+    (void)rccl().CommDestroy(c->comm);
+    throw;
+  }
   *out = c.release();
   VX_API_END
 }
@@ -159,29 +265,52 @@ int vx355_comm_create_all(int32_t num_devices, const int32_t* devices, vx355_com
       (void)Runtime::defaultContext(d);  // throws unless vx355_init(d) was called
     }
     ncclOk(rccl().CommInitAll(comms.data(), num_devices, devs.data()), "ncclCommInitAll");
+    std::vector<std::unique_ptr<vx355_comm>> made;
+    try {
+      for (int32_t i = 0; i < num_devices; ++i) {
+        vx::ContextScope scope(Runtime::defaultContext(devs[i]));  // re-binds the thread: RCCL moved it
+        auto c = std::make_unique<vx355_comm>();
+        c->world = num_devices;
+        c->rank = i;
+        c->comm = comms[i];
+        c->ctx = Runtime::createContext();
+        made.push_back(std::move(c));
+      }
+    } catch (...) {
+      for (auto& c : made) {
+        Runtime::destroyContext(c->ctx);
+      }
+      for (void* raw : comms) {
+        (void)rccl().CommDestroy(raw);
+      }
+      throw;
+    }
     for (int32_t i = 0; i < num_devices; ++i) {
-      vx::ContextScope scope(Runtime::defaultContext(devs[i]));
-      auto c = std::make_unique<vx355_comm>();
-      c->world = num_devices;
-      c->rank = i;
-      c->comm = comms[i];
-      c->ctx = Runtime::createContext();
-      out[i] = c.release();
+      out[i] = made[i].release();
     }
   VX_API_CATCH
 }
 
+// world / rank / device as the communicator itself reports them (ncclCommCount /
+// ncclCommUserRank / ncclCommCuDevice), not as the caller said at creation.
 int vx355_comm_info(const vx355_comm* c, int32_t* world, int32_t* rank, int32_t* device) {
   try {
     VX_CHECK_ARG(c, "NULL argument");
+    Rccl& r = rccl();
+    int w = c->world, k = c->rank, d = c->ctx->device;
+    if (c->comm && r.CommCount && r.CommUserRank && r.CommCuDevice) {
+      ncclOk(r.CommCount(c->comm, &w), "ncclCommCount");
+      ncclOk(r.CommUserRank(c->comm, &k), "ncclCommUserRank");
+      ncclOk(r.CommCuDevice(c->comm, &d), "ncclCommCuDevice");
+    }
     if (world) {
-      *world = c->world;
+      *world = w;
     }
     if (rank) {
-      *rank = c->rank;
+      *rank = k;
     }
     if (device) {
-      *device = c->ctx->device;
+      *device = d;
     }
   VX_API_CATCH
 }
@@ -204,20 +333,91 @@ void vx355_comm_destroy(vx355_comm* c) {
   Runtime::destroyContext(ctx);
 }
 
-// recv_counts[s] = rows rank s holds for this rank. One all-gather of 'world' int64 per rank.
-int vx355_exchange_counts(vx355_comm* c, const int64_t* send_counts, int64_t* recv_counts) {
-  VX_API_BEGIN_CTX(VX_CTX_OF(c))
-  VX_CHECK_ARG(c && send_counts && recv_counts, "NULL argument");
+}  // extern "C"
+
+namespace vx {
+namespace {
+
+// recv[s] = rows rank s holds for this rank: one all-gather of 'world' int64 per rank on the
+// current context's stream.
+void exchangeCounts(vx355_comm* c, const int64_t* send, int64_t* recv) {
   auto& rt = Runtime::get();
   const size_t w = static_cast<size_t>(c->world);
+  if (w == 1) {
+    recv[0] = send[0];
+    return;
+  }
   int64_t* dev = static_cast<int64_t*>(c->countsDev.ensure((w + w * w) * 8 + 64));
-  copyIn(dev, send_counts, VX355_MEM_HOST, w * 8);
+  copyIn(dev, send, VX355_MEM_HOST, w * 8);
   ncclOk(rccl().AllGather(dev, dev + w, w, kNcclInt64, c->comm, rt.stream), "ncclAllGather(counts)");
   std::vector<int64_t> all(w * w);
   copyOut(all.data(), VX355_MEM_HOST, dev + w, w * w * 8);
   for (size_t s = 0; s < w; ++s) {
-    recv_counts[s] = all[s * w + static_cast<size_t>(c->rank)];
+    recv[s] = all[s * w + static_cast<size_t>(c->rank)];
   }
+}
+
+// Posts the slices of every column on 'stream': slice p of the send buffer goes straight to rank
+// p, the slices of all ranks arrive in rank order; the rank's own slice is a device copy.
+void postColumns(vx355_comm* c, hipStream_t stream, const void* const* sendCols, const int32_t* widths, int32_t numCols,
+                 const int64_t* sendCounts, const int64_t* recvCounts, void* const* recvCols) {
+  for (int32_t col = 0; col < numCols; ++col) {
+    VX_CHECK_ARG(widths[col] >= 1, "column width");
+  }
+  int64_t totalSend = 0, totalRecv = 0;
+  for (int32_t peer = 0; peer < c->world; ++peer) {
+    VX_CHECK_ARG(sendCounts[peer] >= 0 && recvCounts[peer] >= 0, "negative slice size");
+    totalSend += sendCounts[peer];
+    totalRecv += recvCounts[peer];
+  }
+  for (int32_t col = 0; col < numCols; ++col) {
+    VX_CHECK_ARG((totalSend == 0 || sendCols[col]) && (totalRecv == 0 || recvCols[col]), "NULL column");
+  }
+  VX_CHECK_ARG(sendCounts[c->rank] == recvCounts[c->rank], "a rank's slice for itself has one size");
+  Rccl* r = c->world > 1 ? &rccl() : nullptr;
+  // Grouped point-to-point: all slices of all columns are posted together so that the seven
+  // outgoing links of the GPU work concurrently.
+  std::unique_ptr<GroupGuard> group;
+  if (r) {
+    group = std::make_unique<GroupGuard>(*r);
+  }
+  for (int32_t col = 0; col < numCols; ++col) {
+    const int64_t w = widths[col];
+    int64_t sendAt = 0, recvAt = 0;
+    for (int32_t peer = 0; peer < c->world; ++peer) {
+      const int64_t ns = sendCounts[peer], nr = recvCounts[peer];
+      const char* src = static_cast<const char*>(sendCols[col]) + sendAt * w;
+      char* dst = static_cast<char*>(recvCols[col]) + recvAt * w;
+      if (peer == c->rank) {
+        if (ns > 0) {
+          HIP_OK(hipMemcpyAsync(dst, src, static_cast<size_t>(ns * w), hipMemcpyDeviceToDevice, stream));
+        }
+      } else {
+        if (ns > 0) {
+          ncclOk(r->Send(src, static_cast<size_t>(ns * w), kNcclUint8, peer, c->comm, stream), "ncclSend");
+        }
+        if (nr > 0) {
+          ncclOk(r->Recv(dst, static_cast<size_t>(nr * w), kNcclUint8, peer, c->comm, stream), "ncclRecv");
+        }
+      }
+      sendAt += ns;
+      recvAt += nr;
+    }
+  }
+  if (group) {
+    group->end();
+  }
+}
+
+}  // namespace
+}  // namespace vx
+
+extern "C" {
+
+int vx355_exchange_counts(vx355_comm* c, const int64_t* send_counts, int64_t* recv_counts) {
+  VX_API_BEGIN_CTX(VX_CTX_OF(c))
+  VX_CHECK_ARG(c && send_counts && recv_counts, "NULL argument");
+  exchangeCounts(c, send_counts, recv_counts);
   VX_API_END
 }
 
@@ -227,32 +427,7 @@ int vx355_exchange_columns(vx355_comm* c, const void* const* send_cols, const in
   VX_CHECK_ARG(c && send_counts && recv_counts && num_cols >= 0, "bad argument");
   VX_CHECK_ARG(num_cols == 0 || (send_cols && widths && recv_cols), "NULL column arrays");
   auto& rt = Runtime::get();
-  Rccl& r = rccl();
-  // Grouped point-to-point: all slices of all columns are posted together so that the
-  // seven outgoing links of the GPU work concurrently.
-  ncclOk(r.GroupStart(), "ncclGroupStart");
-  for (int32_t col = 0; col < num_cols; ++col) {
-    const int64_t w = widths[col];
-    VX_CHECK_ARG(w >= 1, "column width");
-    int64_t sendAt = 0, recvAt = 0;
-    for (int32_t peer = 0; peer < c->world; ++peer) {
-      const int64_t ns = send_counts[peer], nr = recv_counts[peer];
-      VX_CHECK_ARG(ns >= 0 && nr >= 0, "negative slice size");
-      if (ns > 0) {
-        ncclOk(r.Send(static_cast<const char*>(send_cols[col]) + sendAt * w, static_cast<size_t>(ns * w), kNcclUint8,
-                      peer, c->comm, rt.stream),
-               "ncclSend");
-      }
-      if (nr > 0) {
-        ncclOk(r.Recv(static_cast<char*>(recv_cols[col]) + recvAt * w, static_cast<size_t>(nr * w), kNcclUint8, peer,
-                      c->comm, rt.stream),
-               "ncclRecv");
-      }
-      sendAt += ns;
-      recvAt += nr;
-    }
-  }
-  ncclOk(r.GroupEnd(), "ncclGroupEnd");
+  postColumns(c, rt.stream, send_cols, widths, num_cols, send_counts, recv_counts, recv_cols);
   rt.sync();
   VX_API_END
 }
@@ -262,10 +437,255 @@ int vx355_all_gather(vx355_comm* c, const void* send, void* recv, size_t bytes_p
   VX_CHECK_ARG(c && send && recv, "NULL argument");
   auto& rt = Runtime::get();
   if (bytes_per_rank) {
-    ncclOk(rccl().AllGather(send, recv, bytes_per_rank, kNcclInt8, c->comm, rt.stream), "ncclAllGather");
+    if (c->world == 1) {
+      HIP_OK(hipMemcpyAsync(recv, send, bytes_per_rank, hipMemcpyDeviceToDevice, rt.stream));
+    } else {
+      ncclOk(rccl().AllGather(send, recv, bytes_per_rank, kNcclInt8, c->comm, rt.stream), "ncclAllGather");
+    }
   }
   rt.sync();
   VX_API_END
+}
+
+// All-gather of blocks of different sizes: sizes[s] bytes arrive from rank s (sizes[rank] = this
+// rank's block), back to back in rank order. Grouped point-to-point like the column exchange.
+int vx355_all_gather_v(vx355_comm* c, const void* send, const int64_t* sizes, void* recv) {
+  VX_API_BEGIN_CTX(VX_CTX_OF(c))
+  VX_CHECK_ARG(c && sizes, "NULL argument");
+  auto& rt = Runtime::get();
+  int64_t total = 0;
+  for (int32_t p = 0; p < c->world; ++p) {
+    VX_CHECK_ARG(sizes[p] >= 0, "negative block size");
+    total += sizes[p];
+  }
+  const int64_t mine = sizes[c->rank];
+  VX_CHECK_ARG((mine == 0 || send) && (total == 0 || recv), "NULL buffer");
+  Rccl* r = c->world > 1 ? &rccl() : nullptr;
+  std::unique_ptr<GroupGuard> group;
+  if (r) {
+    group = std::make_unique<GroupGuard>(*r);
+  }
+  int64_t at = 0;
+  for (int32_t peer = 0; peer < c->world; ++peer) {
+    char* dst = static_cast<char*>(recv) + at;
+    if (peer == c->rank) {
+      if (mine > 0) {
+        HIP_OK(hipMemcpyAsync(dst, send, static_cast<size_t>(mine), hipMemcpyDeviceToDevice, rt.stream));
+      }
+    } else {
+      if (mine > 0) {
+        ncclOk(r->Send(send, static_cast<size_t>(mine), kNcclUint8, peer, c->comm, rt.stream), "ncclSend");
+      }
+      if (sizes[peer] > 0) {
+        ncclOk(r->Recv(dst, static_cast<size_t>(sizes[peer]), kNcclUint8, peer, c->comm, rt.stream), "ncclRecv");
+      }
+    }
+    at += sizes[peer];
+  }
+  if (group) {
+    group->end();
+  }
+  rt.sync();
+  VX_API_END
+}
+
+// ---- the exchange edge ---------------------------------------------------------------------
+
+int vx355_exchange_create(vx355_comm* c, const int32_t* col_types, int32_t num_cols, const int32_t* key_cols,
+                          int32_t num_keys, vx355_exchange** out) {
+  VX_API_BEGIN_CTX(VX_CTX_OF(c))
+  VX_CHECK_ARG(c && col_types && key_cols && out, "NULL argument");
+  VX_CHECK_ARG(num_cols >= 1 && num_cols <= kExMaxCols, "1..16 columns");
+  VX_CHECK_ARG(num_keys >= 1 && num_keys <= kExMaxKeys, "1..8 partitioning keys");
+  auto x = std::make_unique<vx355_exchange>();
+  x->comm = c;
+  for (int32_t i = 0; i < num_cols; ++i) {
+    const int w = kindWidth(col_types[i]);
+    if (w <= 0) {
+      // BOOLEAN columns are bit packed: no per-row slice to send
+      VX_THROW(VX355_EUNSUPPORTED, "exchange column of type kind " + std::to_string(col_types[i]));
+    }
+    x->types.push_back(col_types[i]);
+    x->widths.push_back(w);
+  }
+  for (int32_t k = 0; k < num_keys; ++k) {
+    VX_CHECK_ARG(key_cols[k] >= 0 && key_cols[k] < num_cols, "partitioning key column");
+    x->keyCols.push_back(key_cols[k]);
+  }
+  x->ctx = Runtime::createContext();
+  {
+    vx::ContextScope scope(x->ctx);
+    HIP_OK(hipStreamCreateWithFlags(&x->payload, hipStreamNonBlocking));
+    HIP_OK(hipEventCreateWithFlags(&x->staged, hipEventDisableTiming));
+    for (auto& s : x->slots) {
+      HIP_OK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    }
+  }
+  *out = x.release();
+  VX_API_END
+}
+
+int vx355_exchange_send(vx355_exchange* x, const vx355_batch* batch) {
+  VX_API_BEGIN_CTX(VX_CTX_OF(x))
+  VX_CHECK_ARG(x && batch, "NULL argument");
+  auto& rt = Runtime::get();
+  vx355_comm* c = x->comm;
+  const int32_t numCols = static_cast<int32_t>(x->types.size());
+  VX_CHECK_ARG(batch->num_cols == numCols, "batch does not have the exchange's columns");
+  if (x->sent - x->receivedCount >= kExSlots - 1) {
+    VX_THROW(VX355_EINVAL, "two exchanges are in flight: receive one before the next send");
+  }
+  ExSlot& slot = x->slots[x->sent % kExSlots];
+  const int64_t n = batch->num_rows;
+  std::vector<int32_t> all(numCols);
+  for (int32_t i = 0; i < numCols; ++i) {
+    all[i] = i;
+    const vx355_column& col = batch->cols[i];
+    VX_CHECK_ARG(col.type_kind == x->types[i], "column type differs from the exchange's");
+    if (col.encoding != VX355_FLAT || col.nulls) {
+      // The wire carries the rows' values only (Destination::flush serialises flat pages,
+      // exec/PartitionedOutput.cpp:59-133): the shim flattens encodings; nulls are not carried yet.
+      VX_THROW(VX355_EUNSUPPORTED, "exchange columns must be FLAT without nulls");
+    }
+  }
+  DeviceBatch db;
+  db.load(batch, all);   // host columns are staged; device columns aliased
+  if (n > 0 && c->world > 1) {
+    uint32_t* flag = nullptr;
+    for (int32_t i = 0; i < numCols; ++i) {
+      if (!isString(x->types[i])) {
+        continue;
+      }
+      if (!flag) {
+        flag = static_cast<uint32_t*>(x->parts.ensure(static_cast<size_t>(n) * 4 + 64));
+        HIP_OK(hipMemsetAsync(flag, 0, 4, rt.stream));
+      }
+      VX_LAUNCH("k_any_long_string", k_any_long_string, streamGrid(n, 256), 256, 0,
+                static_cast<const uint4*>(db.col(i).values), n, flag);
+    }
+    if (flag) {
+      uint32_t any = 0;
+      copyOut(&any, VX355_MEM_HOST, flag, 4);
+      if (any) {
+        VX_THROW(VX355_EUNSUPPORTED, "strings longer than 12 bytes travel as PrestoPages (vx355_presto_serialize)");
+      }
+    }
+  }
+  slot.sendCounts.assign(c->world, 0);
+  slot.recvCounts.assign(c->world, 0);
+  slot.grouped.resize(numCols);
+  slot.received.resize(numCols);
+  std::vector<const void*> in(numCols);
+  std::vector<void*> grouped(numCols);
+  for (int32_t i = 0; i < numCols; ++i) {
+    in[i] = db.col(i).values;
+    grouped[i] = slot.grouped[i].ensure(static_cast<size_t>(std::max<int64_t>(n, 1)) * x->widths[i] + 64);
+  }
+  if (c->world == 1) {
+    // one destination: nothing to hash or group
+    slot.sendCounts[0] = n;
+    for (int32_t i = 0; i < numCols && n > 0; ++i) {
+      HIP_OK(hipMemcpyAsync(grouped[i], in[i], static_cast<size_t>(n) * x->widths[i], hipMemcpyDeviceToDevice,
+                            rt.stream));
+    }
+  } else if (n > 0) {
+    HashPartArgs a{};
+    for (size_t k = 0; k < x->keyCols.size(); ++k) {
+      a.keys[k] = db.col(x->keyCols[k]);
+    }
+    a.numKeys = static_cast<int32_t>(x->keyCols.size());
+    const uint32_t world = static_cast<uint32_t>(c->world);
+    if ((world & (world - 1)) == 0) {
+      // powers of two: the TOP hash bits, disjoint from the bits the join tables index with
+      // (cf. checkHashBitsOverlap, exec/HashTable.cpp:1853)
+      int bits = 0;
+      while ((1u << bits) < world) {
+        ++bits;
+      }
+      a.kind = VX355_PART_BIT_RANGE;
+      a.bitBegin = 64 - bits;
+      a.mask = world - 1;
+    } else {
+      a.kind = VX355_PART_MODULO;  // exec/HashPartitionFunction.cpp:112-115
+    }
+    a.numPartitions = world;
+    a.numRows = n;
+    a.out = static_cast<uint32_t*>(x->parts.ensure(static_cast<size_t>(n) * 4 + 64));
+    VX_LAUNCH("k_hash_partition", k_hash_partition, streamGrid(n, 256), 256, 0, a);
+    std::vector<int32_t> widths(x->widths);
+    const int rc = vx355_partition_scatter(a.out, static_cast<int32_t>(n), c->world, in.data(), widths.data(), numCols,
+                                           grouped.data(), slot.sendCounts.data(), VX355_MEM_DEVICE);
+    if (rc != VX355_OK) {
+      VX_THROW(rc, vx355_last_error());
+    }
+  }
+  exchangeCounts(c, slot.sendCounts.data(), slot.recvCounts.data());
+  slot.rows = 0;
+  for (int64_t r : slot.recvCounts) {
+    slot.rows += r;
+  }
+  std::vector<void*> received(numCols);
+  for (int32_t i = 0; i < numCols; ++i) {
+    received[i] = slot.received[i].ensure(static_cast<size_t>(std::max<int64_t>(slot.rows, 1)) * x->widths[i] + 64);
+  }
+  // The payload rides its own stream: this call returns while the slices are on the links, and
+  // the caller hashes / groups the next batch or probes the previous one meanwhile.
+  HIP_OK(hipEventRecord(x->staged, rt.stream));
+  HIP_OK(hipStreamWaitEvent(x->payload, x->staged, 0));
+  std::vector<const void*> sendPtrs(grouped.begin(), grouped.end());
+  postColumns(c, x->payload, sendPtrs.data(), x->widths.data(), numCols, slot.sendCounts.data(),
+              slot.recvCounts.data(), received.data());
+  HIP_OK(hipEventRecord(slot.done, x->payload));
+  slot.inFlight = true;
+  ++x->sent;
+  VX_API_END
+}
+
+int vx355_exchange_receive(vx355_exchange* x, vx355_column* cols_out, int64_t* rows_out) {
+  VX_API_BEGIN_CTX(VX_CTX_OF(x))
+  VX_CHECK_ARG(x && cols_out && rows_out, "NULL argument");
+  VX_CHECK_ARG(x->receivedCount < x->sent, "nothing was sent");
+  ExSlot& slot = x->slots[x->receivedCount % kExSlots];
+  HIP_OK(hipEventSynchronize(slot.done));
+  slot.inFlight = false;
+  ++x->receivedCount;
+  for (size_t i = 0; i < x->types.size(); ++i) {
+    vx355_column col{};
+    col.type_kind = x->types[i];
+    col.encoding = VX355_FLAT;
+    col.values = slot.received[i].ptr();
+    col.mem = VX355_MEM_DEVICE;
+    cols_out[i] = col;
+  }
+  *rows_out = slot.rows;
+  VX_API_END
+}
+
+void* vx355_exchange_stream(vx355_exchange* x) { return x ? static_cast<void*>(x->ctx->stream) : nullptr; }
+
+void vx355_exchange_destroy(vx355_exchange* x) {
+  if (!x) {
+    return;
+  }
+  Runtime* ctx = x->ctx;
+  try {
+    vx::ContextScope scope(ctx);
+    if (x->payload) {
+      (void)hipStreamSynchronize(x->payload);
+      (void)hipStreamDestroy(x->payload);
+    }
+    if (x->staged) {
+      (void)hipEventDestroy(x->staged);
+    }
+    for (auto& s : x->slots) {
+      if (s.done) {
+        (void)hipEventDestroy(s.done);
+      }
+    }
+    delete x;
+  } catch (...) {
+  }
+  Runtime::destroyContext(ctx);
 }
 
 }  // extern "C"

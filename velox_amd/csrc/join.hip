@@ -697,8 +697,9 @@ struct ProbeArgs {
   int32_t pad3;
   uint64_t* sparseStats;  // [0] overflowed tiles, [1] hits listed (HBM: atomics on the pinned mailbox cross PCIe)
   int32_t nullAsValue;            // a null probe key is a value: id 0 / kNullHash
-  int32_t pad4;
+  int32_t window;                 // listing probe, array mode, flat BIGINT key: presence bits through a per-wave window
   const uint8_t* keyNullStore;    // generic hash mode + nullAsValue: null-key mask per build row
+  uint64_t presentWords;          // u32 words of the presence bitmap
 };
 
 constexpr int kSparseCap = 1024;  // staged pairs per tile of 8192 probe rows (12.5 % hit rate)
@@ -901,9 +902,28 @@ __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, Spars
         key[u] = static_cast<uint64_t>(v) - static_cast<uint64_t>(a.ranges[0].min) + 1;
       }
       if (mode == JMODE_ARRAY) {
+        if (SPARSE && a.window) {
+          // A wave of the listing probe covers 256 consecutive rows per iteration. When the probe
+          // side is clustered by key (a fact table stored in key order) their presence bits sit in
+          // a handful of neighbouring words: ONE coalesced load fetches the 64 words from the
+          // first row's word on (2048 keys), every row takes its word from that window with a
+          // lane permute, and only rows outside it (unordered probe sides) gather on their own.
+          // A dependent gather costs the CU's address path ~80 cycles per wave instruction even
+          // when all 64 lanes hit one line; the permute costs a tenth of that.
+          const uint64_t w0 = readFirst64(candidate[0] ? key[0] >> 5 : 0);
+          const uint64_t mineWord = w0 + lane();
+          const uint32_t win = a.present[mineWord < a.presentWords ? mineWord : a.presentWords - 1];
 #pragma unroll
-        for (int u = 0; u < kProbeUnroll; ++u) {
-          word[u] = candidate[u] ? a.present[key[u] >> 5] : 0;
+          for (int u = 0; u < kProbeUnroll; ++u) {
+            const uint64_t idx = (key[u] >> 5) - w0;
+            const uint32_t fromWindow = static_cast<uint32_t>(__shfl(static_cast<int>(win), static_cast<int>(idx & 63), kWave));
+            word[u] = candidate[u] ? (idx < 64 ? fromWindow : a.present[key[u] >> 5]) : 0;
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < kProbeUnroll; ++u) {
+            word[u] = candidate[u] ? a.present[key[u] >> 5] : 0;
+          }
         }
       }
       if (it + 1 < kIters) {
@@ -2049,6 +2069,7 @@ struct vx355_join_probe {
   bool pairList = false;     // the batch's output is ppSorted[0, totalOut)
   int64_t outputBatchBytes = 0;  // preferred_output_batch_bytes (0 = rows only)
   int32_t partitionMode = -1;  // VX355_JOIN_PARTITION: -1 adaptive, 0 never, 1 whenever eligible
+  bool window = true;          // VX355_JOIN_WINDOW=0: the listing probe gathers every presence word itself
   DeviceBatch batch;                       // the batch being probed: the filter reads it at output time
   std::vector<std::vector<char>> hostStrings;  // long payload strings of the last page handed to a host caller
   std::vector<vx355_join_filter_term> filter;
@@ -2573,6 +2594,8 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
       a.ranges[0].multiplier == 1) {
     a.fastKey = a.keys[0].enc == VX355_FLAT ? 1 : (a.keys[0].enc == VX355_DICTIONARY ? 2 : 0);
   }
+  a.window = p.window ? 1 : 0;
+  a.presentWords = (t.capacity + 31) / 32;
   auto launch = [&](auto sparseTag, int64_t tileBegin, int64_t tileEnd) {
     constexpr bool SP = decltype(sparseTag)::value;
     ProbeArgs la = a;
@@ -3274,6 +3297,9 @@ int vx355_join_probe_create(vx355_join_table* table, const vx355_join_probe_spec
     if (p->partitionMode != 0 && p->partitionMode != 1) {
       p->partitionMode = -1;
     }
+  }
+  if (const char* e = std::getenv("VX355_JOIN_WINDOW")) {
+    p->window = std::atoi(e) != 0;
   }
   if (const char* e = std::getenv("VX355_JOIN_SPARSE")) {
     p->sparseMode = std::atoi(e);  // 0 never, 1 always, otherwise adaptive

@@ -13,7 +13,6 @@ namespace vx {
 thread_local std::string tlsLastError;
 thread_local Runtime* tlsCurrent = nullptr;  // context of the entry point running on this thread
 thread_local int tlsDevice = -1;             // vx355_set_device
-thread_local int tlsHipDevice = -1;          // what hipSetDevice was last told on this thread
 
 constexpr int kMaxDevices = 64;
 std::mutex gInitMutex;
@@ -21,12 +20,11 @@ DeviceState* gDevices[kMaxDevices] = {};     // never deleted: buffers may outli
 std::atomic<int> gDefaultDevice{-1};
 std::atomic<uint64_t> gNextContextId{1};
 
-void bindHipDevice(int device) {
-  if (tlsHipDevice != device) {
-    HIP_OK(hipSetDevice(device));
-    tlsHipDevice = device;
-  }
-}
+// The thread's HIP device is never cached: the embedding host and librccl
+// (ncclCommInitAll / ncclCommInitRank) change it behind the library's back, and a
+// stale binding would make hipMalloc / hipStreamCreate / launches land on another GPU.
+// hipSetDevice costs ~50 ns when the device is already current.
+void bindHipDevice(int device) { HIP_OK(hipSetDevice(device)); }
 
 DeviceState* deviceState(int device) {
   if (device < 0) {
@@ -156,7 +154,6 @@ ContextScope::~ContextScope() {
   tlsCurrent = prev_;
   if (prev_) {
     (void)hipSetDevice(prev_->device);
-    tlsHipDevice = prev_->device;
   }
   if (locked_) {
     ctx_->callMutex.unlock();
@@ -227,6 +224,7 @@ void* DeviceState::allocBlock(size_t bytes, size_t* actual) {
     }
   }
   void* p = nullptr;
+  bindHipDevice(device);
   hipError_t e = hipMalloc(&p, want);
   if (e == hipErrorOutOfMemory) {
     (void)hipGetLastError();
@@ -449,6 +447,7 @@ char* DeviceState::allocPinned(size_t bytes, size_t* actual) {
     }
   }
   char* p = nullptr;
+  bindHipDevice(device);
   HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&p), want, hipHostMallocDefault));
   *actual = want;
   return p;
@@ -790,7 +789,6 @@ void vx355_shutdown(void) {
       continue;
     }
     (void)hipSetDevice(d);
-    vx::tlsHipDevice = d;
     ds->trimCache();
     {
       std::lock_guard<std::mutex> plock(ds->profMutex);
@@ -835,10 +833,7 @@ void* vx355_device_malloc(size_t bytes) {
     vx::setLastError("vx355_init has not been called");
     return nullptr;
   }
-  if (vx::tlsHipDevice != rt->device) {
-    (void)hipSetDevice(rt->device);
-    vx::tlsHipDevice = rt->device;
-  }
+  (void)hipSetDevice(rt->device);
   void* p = nullptr;
   hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
   if (e != hipSuccess) {

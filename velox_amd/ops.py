@@ -40,7 +40,12 @@ SYMBOLS = [
     "vx355_all_gather", "vx355_agg_flush", "vx355_agg_to_intermediate",
     "vx355_value_dict_create", "vx355_value_dict_compute", "vx355_value_dict_lookup", "vx355_value_dict_size",
     "vx355_value_dict_destroy",
+    "vx355_all_gather_v", "vx355_exchange_create", "vx355_exchange_send", "vx355_exchange_receive",
+    "vx355_exchange_stream", "vx355_exchange_destroy", "vx355_join_repartition", "vx355_agg_merge_partials",
 ]
+
+# int (*vx355_join_chunk_sink)(void* arg, int32_t chunk, const vx355_batch* received, vx355_join_probe* probe)
+JOIN_CHUNK_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(abi.Batch), C.c_void_p)
 
 
 class Vx355Error(RuntimeError):
@@ -131,6 +136,17 @@ def lib():
     L.vx355_exchange_counts.argtypes = [vp, P(i64), P(i64)]
     L.vx355_exchange_columns.argtypes = [vp, P(vp), P(i32), i32, P(i64), P(i64), P(vp)]
     L.vx355_all_gather.argtypes = [vp, vp, vp, sz]
+    L.vx355_all_gather_v.argtypes = [vp, vp, P(i64), vp]
+    L.vx355_exchange_create.argtypes = [vp, P(i32), i32, P(i32), i32, P(vp)]
+    L.vx355_exchange_send.argtypes = [vp, P(abi.Batch)]
+    L.vx355_exchange_receive.argtypes = [vp, P(abi.Column), P(i64)]
+    L.vx355_exchange_stream.restype = vp
+    L.vx355_exchange_stream.argtypes = [vp]
+    L.vx355_exchange_destroy.argtypes = [vp]
+    L.vx355_exchange_destroy.restype = None
+    L.vx355_join_repartition.argtypes = [vp, P(abi.JoinBuildSpec), P(abi.Batch), P(abi.JoinProbeSpec), P(abi.Batch),
+                                         i32, JOIN_CHUNK_SINK, vp, P(vp)]
+    L.vx355_agg_merge_partials.argtypes = [vp, vp, P(abi.AggSpec), P(vp)]
     L.vx355_value_dict_create.argtypes = [i32, i64, P(vp)]
     L.vx355_value_dict_compute.argtypes = [vp, P(abi.Batch), i32, vp, u64, vp, P(i32), i32]
     L.vx355_value_dict_lookup.argtypes = [vp, P(abi.Batch), i32, vp, u64, vp, vp, i32]
@@ -234,6 +250,15 @@ class Comm:
     def all_gather(self, send_ptr, recv_ptr, bytes_per_rank):
         _check(lib().vx355_all_gather(self.h, send_ptr, recv_ptr, bytes_per_rank))
 
+    def all_gather_v(self, send_ptr, sizes, recv_ptr):
+        _check(lib().vx355_all_gather_v(self.h, send_ptr, (C.c_int64 * self.world)(*[int(x) for x in sizes]), recv_ptr))
+
+    def info(self):
+        """(world, rank, device) as the RCCL communicator itself reports them."""
+        w, r, d = C.c_int32(), C.c_int32(), C.c_int32()
+        _check(lib().vx355_comm_info(self.h, C.byref(w), C.byref(r), C.byref(d)))
+        return w.value, r.value, d.value
+
     def __del__(self):
         try:
             if getattr(self, "h", None):
@@ -241,6 +266,83 @@ class Comm:
                 self.h = None
         except Exception:
             pass
+
+
+class Exchange:
+    """vx355_exchange: one PartitionedOutput(keys) -> Exchange edge of a repartitioned join."""
+
+    def __init__(self, comm, col_types, key_cols):
+        h = C.c_void_p()
+        _check(lib().vx355_exchange_create(comm.h, abi.i32_array(col_types), len(col_types), abi.i32_array(key_cols),
+                                           len(key_cols), C.byref(h)))
+        self.h, self.comm, self.col_types = h, comm, list(col_types)
+
+    def send(self, batch):
+        _check(lib().vx355_exchange_send(self.h, batch.ref()))
+
+    def receive(self):
+        """-> (vx355_column array of FLAT device columns, rows); valid until the next receive."""
+        cols = (abi.Column * len(self.col_types))()
+        rows = C.c_int64()
+        _check(lib().vx355_exchange_receive(self.h, cols, C.byref(rows)))
+        return cols, rows.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().vx355_exchange_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def join_repartition(comm, build, build_batch, probe_spec_owner, probe_batch, chunks, sink):
+    """vx355_join_repartition. build: (key_cols, key_types, dep_cols, dep_types, join_type) of the
+    build side over build_batch's columns; probe_spec_owner: (key_cols, join_type) over
+    probe_batch's; sink(chunk, received vx355_batch pointer, HashProbe) drains the probe.
+    Returns the JoinTable."""
+    key_cols, key_types, dep_cols, dep_types, join_type = build
+    keep = [abi.i32_array(key_cols), abi.i32_array(key_types), abi.i32_array(dep_cols), abi.i32_array(dep_types)]
+    bspec = abi.JoinBuildSpec(len(key_cols), keep[0], keep[1], len(dep_cols), keep[2], keep[3], join_type, 0, 0, 0)
+    pkeys, pjoin = probe_spec_owner
+    pk = abi.i32_array(pkeys)
+    pspec = abi.JoinProbeSpec(len(pkeys), pk, pjoin, 0, 0, 0)
+    table = JoinTable(None, list(dep_types))
+    errors = []
+
+    def trampoline(_arg, chunk, received, probe_handle):
+        try:
+            probe = HashProbe.__new__(HashProbe)   # borrowed handle: the library owns it
+            probe.h, probe.table = None, table
+            probe.borrowed = C.c_void_p(probe_handle)
+            sink(chunk, received, probe)
+            return abi.OK
+        except Exception as e:  # noqa: BLE001 - must not unwind through the C frames
+            errors.append(e)
+            return abi.EINTERNAL
+    cb = JOIN_CHUNK_SINK(trampoline)
+    t = C.c_void_p()
+    status = lib().vx355_join_repartition(comm.h, C.byref(bspec), build_batch.ref(), C.byref(pspec), probe_batch.ref(),
+                                          chunks, cb, None, C.byref(t))
+    if errors:
+        raise errors[0]
+    _check(status)
+    table.t = t
+    return table
+
+
+def merge_partials(comm, partial, final_key_cols, final_key_types, final_aggs, step=abi.STEP_FINAL):
+    """vx355_agg_merge_partials: -> HashAggregation (FINAL) that has consumed every rank's partial rows."""
+    spec, keep = make_agg_spec(final_key_cols, final_key_types, final_aggs, step)
+    h = C.c_void_p()
+    _check(lib().vx355_agg_merge_partials(comm.h, partial.h, C.byref(spec), C.byref(h)))
+    op = HashAggregation.__new__(HashAggregation)
+    op.spec, op._keep, op.h = spec, keep, h
+    types = (C.c_int32 * 64)()
+    n = C.c_int32()
+    _check(lib().vx355_agg_output_types(op.h, types, 64, C.byref(n)))
+    op.kinds = list(types[: n.value])
+    return op
 
 
 # ---- device memory -------------------------------------------------------
@@ -828,7 +930,7 @@ class HashProbe:
         """Device-resident outputs; -> (n, finished)."""
         n, fin = C.c_int32(), C.c_int32()
         ids = abi.i32_array(list(build_col_ids))
-        _check(lib().vx355_join_probe_get_output(self.h, max_rows, mapping_ptr, build_rows_ptr,
+        _check(lib().vx355_join_probe_get_output(self.h or self.borrowed, max_rows, mapping_ptr, build_rows_ptr,
                                                  abi.MEM_DEVICE, out_descs, ids,
                                                  len(build_col_ids), C.byref(n), C.byref(fin)))
         return n.value, bool(fin.value)
