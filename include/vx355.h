@@ -586,8 +586,8 @@ void* vx355_agg_stream(vx355_agg* h);
 
 /* core::JoinType (core/PlanNode.h:3081-3165), same values. All twelve kinds run
  * on the device. Null-aware semantics (HashJoinNode::isNullAware) are supported
- * for ANTI without an extra filter only; null-aware LEFT / RIGHT_SEMI_PROJECT and
- * isNullAsValue return VX355_EUNSUPPORTED at create. An extra join filter
+ * for ANTI and LEFT_SEMI_PROJECT, isNullAsValue keys (IS NOT DISTINCT FROM) for every kind;
+ * null-aware RIGHT_SEMI_PROJECT returns VX355_EUNSUPPORTED at create. An extra join filter
  * (vx355_join_probe_set_filter) works with every kind except the two counting
  * ones (the reference has none there either, HashProbe.cpp:1345-1365). Build and
  * probe must be created with the same join type. Counting joins keep one

@@ -3,6 +3,7 @@
 // partition function restated on top of table.h, and the C API.
 #include "oracle.h"
 
+#include <type_traits>
 #include <cmath>
 #include <map>
 #include <set>
@@ -62,6 +63,14 @@ void outputTypes(const vx355_agg_fn& f, int32_t step, std::vector<int32_t>& out)
   }
 }
 
+// Which overflow rule sum(BIGINT) follows (orc_set_sum_overflow_rule):
+//   0 = the reference's: every add is a checkedPlus on the running sum, in input order
+//       (vector/AggregationHook.h:126-135, SumAggregate.cpp:24): a PREFIX that leaves int64 throws;
+//   1 = "total": the exact (128-bit) total is checked once, when it is read out — the one rule a
+//       parallel implementation can follow whatever order it adds in (libvx355).
+// The two agree unless a prefix overflows and later rows bring the sum back into range.
+int gSumOverflowRule = 0;
+
 // checkedPlus (vector/AggregationHook.h:126-135 SumHook::add with
 // Overflow=false, SumAggregate.cpp:24).
 int64_t checkedPlus(int64_t a, int64_t b) {
@@ -70,6 +79,48 @@ int64_t checkedPlus(int64_t a, int64_t b) {
     throw UserError("integer overflow: " + std::to_string(a) + " + " + std::to_string(b));
   }
   return r;
+}
+
+// Comparison of two values the way the reference's comparison functions do it
+// (functions/prestosql/Comparisons.h:42-121 -> util::floating_point::NaNAware*): for REAL / DOUBLE
+// NaN equals NaN and is greater than every other value; integers compare as usual.
+template <typename T>
+bool compareLikeVelox(int32_t cmp, T a, T b) {
+  if constexpr (std::is_floating_point<T>::value) {
+    const bool an = std::isnan(a), bn = std::isnan(b);
+    const bool eq = (an && bn) || a == b;
+    const bool lt = !an && (bn || a < b);
+    const bool gt = !bn && (an || a > b);
+    switch (cmp) {
+      case VX355_CMP_EQ:
+        return eq;
+      case VX355_CMP_NE:
+        return !eq;
+      case VX355_CMP_LT:
+        return lt;
+      case VX355_CMP_LE:
+        return lt || eq;
+      case VX355_CMP_GT:
+        return gt;
+      default:
+        return gt || eq;
+    }
+  } else {
+    switch (cmp) {
+      case VX355_CMP_EQ:
+        return a == b;
+      case VX355_CMP_NE:
+        return a != b;
+      case VX355_CMP_LT:
+        return a < b;
+      case VX355_CMP_LE:
+        return a <= b;
+      case VX355_CMP_GT:
+        return a > b;
+      default:
+        return a >= b;
+    }
+  }
 }
 
 // NaN-aware compare (MinMaxAggregateBase.cpp:174-184, :267-277): NaN is larger
@@ -142,6 +193,28 @@ void extractStored(const char* row, const RowContainer::Column& c, vx355_out_col
 
 // exec/GroupingSet.{h,cpp} + exec/HashAggregation.{h,cpp}.
 class Aggregation {
+  // rule 1: exact totals of the BIGINT sums, by accumulator address
+  std::unordered_map<char*, __int128> wideSums_;
+  void addBigintSum(char* a, int64_t v) {
+    auto* s = reinterpret_cast<int64_t*>(a);
+    if (gSumOverflowRule == 0) {
+      *s = checkedPlus(*s, v);
+      return;
+    }
+    __int128& w = wideSums_[a];
+    w += v;
+    *s = static_cast<int64_t>(static_cast<uint64_t>(*s) + static_cast<uint64_t>(v));
+  }
+  void checkBigintTotal(char* a) {
+    if (gSumOverflowRule == 0) {
+      return;
+    }
+    auto it = wideSums_.find(a);
+    if (it != wideSums_.end() && (it->second > INT64_MAX || it->second < INT64_MIN)) {
+      throw UserError("integer overflow: the total of sum(BIGINT) does not fit int64");
+    }
+  }
+
  public:
   Aggregation(const vx355_agg_spec& spec, bool hashAdaptivity)
       : step_(spec.step), ignoreNullKeys_(spec.ignore_null_keys != 0) {
@@ -285,8 +358,7 @@ class Aggregation {
           case VX355_AGG_SUM:
             accNull(g, i) = 0;
             if (isInt) {
-              auto* s = reinterpret_cast<int64_t*>(a);
-              *s = checkedPlus(*s, v.i);
+              addBigintSum(a, v.i);
             } else {
               *reinterpret_cast<double*>(a) += v.d;
             }
@@ -459,8 +531,7 @@ class Aggregation {
           }
           accNull(g, i) = 0;
           if (intSum) {
-            auto* s = reinterpret_cast<int64_t*>(a);
-            *s = checkedPlus(*s, in->int64At(r));
+            addBigintSum(a, in->int64At(r));
           } else {
             *reinterpret_cast<double*>(a) += in->doubleAt(r);
           }
@@ -524,6 +595,7 @@ class Aggregation {
         break;
       case VX355_AGG_SUM:
         if (isIntKind(f.input_type)) {
+          checkBigintTotal(a);
           writeOut(cols[c++], outRow, isNull, a, 8);
         } else if (f.input_type == VX355_REAL && fin) {
           float v = static_cast<float>(*reinterpret_cast<double*>(a));
@@ -1005,22 +1077,7 @@ class JoinProbe {
       if (l.null || r.null) {
         return false;
       }
-      auto cmp = [&](auto a, auto b) {
-        switch (t.cmp) {
-          case VX355_CMP_EQ:
-            return a == b;
-          case VX355_CMP_NE:
-            return a != b;
-          case VX355_CMP_LT:
-            return a < b;
-          case VX355_CMP_LE:
-            return a <= b;
-          case VX355_CMP_GT:
-            return a > b;
-          default:
-            return a >= b;
-        }
-      };
+      auto cmp = [&](auto a, auto b) { return compareLikeVelox(t.cmp, a, b); };
       bool ok;
       if (l.cls == 2 || r.cls == 2) {
         if (l.cls != r.cls || (t.cmp != VX355_CMP_EQ && t.cmp != VX355_CMP_NE)) {
@@ -1110,6 +1167,8 @@ uint64_t orc_hash_bytes(uint64_t seed, const char* data, size_t size) {
 uint32_t orc_xxh32_u32(uint32_t value, uint32_t seed) { return xxh32U32(value, seed); }
 uint64_t orc_hash_value(int32_t type_kind, const void* value) { return hashValue(type_kind, value); }
 const char* orc_last_error(void) { return gLastError.c_str(); }
+
+void orc_set_sum_overflow_rule(int32_t rule) { gSumOverflowRule = rule ? 1 : 0; }
 
 // ---- SplitBlockBloomFilter (common/base/SplitBlockBloomFilter.h) ----------------------
 // A block is 'lanes' 32-bit words (one SIMD register of the host the reference
@@ -1371,22 +1430,7 @@ int orc_filter_project(const vx355_batch* batch, const vx355_filter_term* terms,
         ok = false;
         break;
       }
-      auto cmp = [&](auto a, auto b) {
-        switch (term.cmp) {
-          case VX355_CMP_EQ:
-            return a == b;
-          case VX355_CMP_NE:
-            return a != b;
-          case VX355_CMP_LT:
-            return a < b;
-          case VX355_CMP_LE:
-            return a <= b;
-          case VX355_CMP_GT:
-            return a > b;
-          default:
-            return a >= b;
-        }
-      };
+      auto cmp = [&](auto a, auto b) { return compareLikeVelox(term.cmp, a, b); };
       if (term.const_kind == VX355_BIGINT) {
         ok = cmp(d.int64At(r), term.i64);
       } else if (term.const_kind == VX355_DOUBLE) {

@@ -98,6 +98,10 @@ int orc_agg_get_output(orc_agg* h, vx355_out_column* cols, int32_t num_cols, int
 int orc_agg_get_stats(const orc_agg* h, vx355_agg_stats* out);
 void orc_agg_destroy(orc_agg* h);
 const char* orc_last_error(void);
+/* sum(BIGINT) overflow rule of every aggregation created afterwards: 0 = the reference's
+ * (checkedPlus on the running sum in input order, vector/AggregationHook.h:126-135), 1 = the
+ * exact total must fit int64 (what libvx355 implements; see oracle.cpp gSumOverflowRule). */
+void orc_set_sum_overflow_rule(int32_t rule);
 
 /* HashBuild / HashProbe. */
 typedef struct orc_join_build orc_join_build;

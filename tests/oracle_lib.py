@@ -48,6 +48,8 @@ def lib():
     L.orc_hash_value.restype = u64
     L.orc_hash_value.argtypes = [i32, vp]
     L.orc_last_error.restype = C.c_char_p
+    L.orc_set_sum_overflow_rule.argtypes = [C.c_int32]
+    L.orc_set_sum_overflow_rule.restype = None
     L.orc_bloom_num_blocks.restype = C.c_int64
     L.orc_bloom_num_blocks.argtypes = [C.c_int64, C.c_double, i32]
     L.orc_bloom_insert.restype = None
@@ -502,3 +504,13 @@ class JoinProbe:
         if getattr(self, "h", None):
             lib().orc_join_probe_destroy(self.h)
             self.h = None
+
+
+SUM_RULE_REFERENCE, SUM_RULE_TOTAL = 0, 1
+
+
+def set_sum_overflow_rule(rule):
+    """sum(BIGINT) overflow rule of aggregations created afterwards: SUM_RULE_REFERENCE = checkedPlus
+    on the running sum in input order (vector/AggregationHook.h:126-135), SUM_RULE_TOTAL = the exact
+    total must fit int64 (libvx355's order-independent rule)."""
+    lib().orc_set_sum_overflow_rule(rule)

@@ -224,7 +224,7 @@ def test_c4_one_billion_rows_counts_exact_sums_close(vx, torch_gpu, sparse):
     st = op.stats()
     assert st.input_rows == n
     if not sparse:
-        assert st.hash_mode == abi.MODE_ARRAY and st.radix_launches >= 2
+        assert st.hash_mode == abi.MODE_ARRAY and st.radix_launches >= 1   # 10^9 rows are ONE radix chunk since round 3
     else:
         assert st.hash_mode == abi.MODE_NORMALIZED_KEY
     cap = 1 << 24

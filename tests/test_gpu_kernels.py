@@ -202,6 +202,20 @@ def test_filter_project_q1_q3_expressions(oracle, vx):
             assert (e_out[j][e_nulls[j]] == g_out[j][g_nulls[j]]).all()  # bit-exact doubles
 
 
+def test_filter_terms_order_nan_like_the_reference(oracle, vx):
+    """DOUBLE comparisons are NaN aware (functions/prestosql/Comparisons.h:42-121): NaN = NaN, NaN
+    above +inf. Every operator against NaN, inf and finite constants, GPU == oracle."""
+    rng = np.random.default_rng(23)
+    pool = np.array([np.nan, np.inf, -np.inf, 0.0, -0.0, 1.5, -2.25, 1e300])
+    v = pool[rng.integers(0, len(pool), 20011)]
+    b = abi.HostBatch([_col(abi.DOUBLE, v)])
+    for const in (float("nan"), float("inf"), 1.5, -0.0):
+        for cmp in (abi.CMP_EQ, abi.CMP_NE, abi.CMP_LT, abi.CMP_LE, abi.CMP_GT, abi.CMP_GE):
+            e_idx = oracle.filter_project(b, [(0, cmp, const)], [])[0]
+            g_idx = vx.filter_project(b, [(0, cmp, const)], [])[0]
+            assert len(e_idx) == len(g_idx) and (e_idx == g_idx).all(), (const, cmp)
+
+
 @pytest.mark.parametrize("num_parts", [1, 2, 8, 13, 64])
 @pytest.mark.parametrize("n", [0, 1, 4095, 4097, 100003])
 def test_partition_scatter_is_a_stable_partition(vx, num_parts, n):

@@ -858,3 +858,51 @@ def test_oracle_null_aware_left_semi_project_truth_table(oracle, build):
         else:
             want = "F"
         assert ("T" if r >= 0 else "F" if r == -1 else "N") == want, (x, r)
+
+
+def test_sum_bigint_overflow_rules(oracle):
+    """The oracle's two sum(BIGINT) rules: the reference's checkedPlus on the running sum in input
+    order (vector/AggregationHook.h:126-135) and the order-independent 'exact total must fit int64'
+    rule libvx355 implements. They differ exactly where a prefix overflows and comes back."""
+    big = 1 << 62
+    aggs = [(abi.AGG_SUM, 1, abi.BIGINT)]
+
+    def run(values, rule):
+        oracle.set_sum_overflow_rule(rule)
+        try:
+            op = oracle.Aggregation([0], [abi.BIGINT], aggs)
+            op.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, np.zeros(len(values), dtype=np.int64)),
+                                        abi.HostColumn(abi.BIGINT, np.array(values, dtype=np.int64))]))
+            op.no_more_input()
+            return int(np.asarray(oracle.collect_output(op, 16)[1][0])[0])
+        finally:
+            oracle.set_sum_overflow_rule(oracle.SUM_RULE_REFERENCE)
+
+    for values in ([big, -big, big, -big], [big, big - 1], [-big, -big], [1, 2, 3]):
+        assert run(values, oracle.SUM_RULE_REFERENCE) == run(values, oracle.SUM_RULE_TOTAL) == sum(values)
+    # a prefix reaches 2^63, the total is 0: only the reference's rule throws
+    with pytest.raises(oracle.OracleError, match="integer overflow"):
+        run([big, big, -big, -big], oracle.SUM_RULE_REFERENCE)
+    assert run([big, big, -big, -big], oracle.SUM_RULE_TOTAL) == 0
+    assert run([-big, -big, -big, big, big], oracle.SUM_RULE_TOTAL) == -big
+    # the total itself does not fit: both throw
+    for values in ([big, big], [big, big, big, -big], [-big, -big, -1]):
+        for rule in (oracle.SUM_RULE_REFERENCE, oracle.SUM_RULE_TOTAL):
+            with pytest.raises(oracle.OracleError, match="integer overflow"):
+                run(values, rule)
+
+
+def test_double_comparisons_order_nan_like_the_reference(oracle):
+    """functions/prestosql/Comparisons.h:42-121 (util::floating_point::NaNAware*): NaN = NaN, and
+    NaN is greater than every other DOUBLE, +inf included — in FilterProject's terms."""
+    v = np.array([1.0, np.nan, np.inf, -np.inf, 0.0, np.nan])
+    b = abi.HostBatch([abi.HostColumn(abi.DOUBLE, v)])
+    nan = float("nan")
+
+    def sel(cmp, const):
+        return oracle.filter_project(b, [(0, cmp, const)], [])[0].tolist()
+    assert sel(abi.CMP_EQ, nan) == [1, 5] and sel(abi.CMP_NE, nan) == [0, 2, 3, 4]
+    assert sel(abi.CMP_LT, nan) == [0, 2, 3, 4] and sel(abi.CMP_LE, nan) == [0, 1, 2, 3, 4, 5]
+    assert sel(abi.CMP_GT, nan) == [] and sel(abi.CMP_GE, nan) == [1, 5]
+    assert sel(abi.CMP_GT, np.inf) == [1, 5] and sel(abi.CMP_GE, np.inf) == [1, 2, 5]
+    assert sel(abi.CMP_LT, 1.0) == [3, 4] and sel(abi.CMP_LE, 1.0) == [0, 3, 4]

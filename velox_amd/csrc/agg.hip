@@ -75,7 +75,7 @@ struct AccArg {
   // splitM = 0: plain accumulation into hi.
   double splitM;
   int32_t ldsIdx;   // position of 'hi' among the LDS accumulators of the launch
-  int32_t pad;
+  int32_t phys;     // index of the accumulator in vx355_agg::phys (host bookkeeping)
 };
 
 
@@ -177,19 +177,22 @@ __device__ inline bool accInput(const AggArgs& a, const AccArg& acc, int64_t row
 
 
 
-__device__ inline void applyLds(uint64_t* word, int32_t kind, uint64_t v, Counters* ctr) {
+// hiStride: distance (in words) from an ACC_SUM_I64 word to its high word in this LDS layout.
+__device__ inline void applyLds(uint64_t* word, int32_t kind, uint64_t v, Counters* ctr, int hiStride = 1) {
   switch (kind) {
     case ACC_SUM_F64:
       unsafeAtomicAdd(reinterpret_cast<double*>(word), __longlong_as_double(static_cast<long long>(v)));
       break;
     case ACC_SUM_I64: {
-      unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(word),
-                                         static_cast<unsigned long long>(v));
-      if (addOverflows(static_cast<int64_t>(old), static_cast<int64_t>(v))) {
-        ctr->overflow = 1;
+      const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(word),
+                                               static_cast<unsigned long long>(v));
+      const int64_t up = carrySigned(old, static_cast<int64_t>(v));
+      if (up != 0) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(word + hiStride), static_cast<unsigned long long>(up));
       }
       break;
     }
+    case ACC_SUM_I64_HI:
     case ACC_SUM_I64_WRAP:
     case ACC_COUNT:
       atomicAdd(reinterpret_cast<unsigned long long*>(word), static_cast<unsigned long long>(v));
@@ -340,12 +343,6 @@ __device__ inline uint64_t waveCombine(int32_t kind, uint64_t v, bool member, Co
         x = static_cast<uint64_t>(__double_as_longlong(__longlong_as_double(static_cast<long long>(x)) +
                                                         __longlong_as_double(static_cast<long long>(o))));
         break;
-      case ACC_SUM_I64:
-        if (addOverflows(static_cast<int64_t>(x), static_cast<int64_t>(o))) {
-          ctr->overflow = 1;
-        }
-        x += o;
-        break;
       case ACC_SUM_I64_WRAP:
       case ACC_COUNT:
         x += o;
@@ -359,6 +356,21 @@ __device__ inline uint64_t waveCombine(int32_t kind, uint64_t v, bool member, Co
     }
   }
   return x;
+}
+
+// Wave-wide 128-bit sum of the members' signed values: {lo, hi} on every lane.
+__device__ inline void waveCombine128(uint64_t v, bool member, uint64_t* loOut, int64_t* hiOut) {
+  uint64_t lo = member ? v : 0;
+  int64_t hi = (member && static_cast<int64_t>(v) < 0) ? -1 : 0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint64_t olo = shfl64(lo, lane() ^ off);
+    const int64_t ohi = static_cast<int64_t>(shfl64(static_cast<uint64_t>(hi), lane() ^ off));
+    hi += ohi + carryUnsigned(lo, olo);
+    lo += olo;
+  }
+  *loOut = lo;
+  *hiOut = hi;
 }
 
 // updateGlobal for a whole wave (called by all 64 lanes, 'active' says which
@@ -429,6 +441,15 @@ __device__ inline void updateGlobalWave(const AggArgs& a, int64_t row, uint64_t 
           if (any != 0 && lane() == leader) {
             applyGlobal(g + acc.off, ACC_SUM_F64, totalHi, a.counters);
             applyGlobal(g + acc.off + 1, ACC_SUM_F64, totalLo, a.counters);
+          }
+          continue;
+        }
+        if (acc.kind == ACC_SUM_I64) {
+          uint64_t lo;
+          int64_t hi;
+          waveCombine128(v, has, &lo, &hi);
+          if (any != 0 && lane() == leader) {
+            addPartial128Global(g + acc.off, lo, hi);
           }
           continue;
         }
@@ -524,7 +545,7 @@ __global__ __launch_bounds__(1024) void k_agg_lds(LdsArgs args) {
                 applyLds(base + (ac.ldsIdx + 1) * REP, ACC_SUM_F64,
                          static_cast<uint64_t>(__double_as_longlong(lo)), a.counters);
               } else {
-                applyLds(base + ac.ldsIdx * REP, ac.kind, v, a.counters);
+                applyLds(base + ac.ldsIdx * REP, ac.kind, v, a.counters, REP);
               }
             }
           }
@@ -832,6 +853,166 @@ __global__ __launch_bounds__(1024) void k_rp_scatter1(RadixArgs r) {
   }
 }
 
+// ---- scatter with an LDS sort in front (tools/scatter_bench.hip, profiles/r03_scatter_bench.txt) ----
+// A lane that stores its 16-byte record straight to base[bin] + cursor makes every store
+// instruction touch 64 unrelated lines: 2.9 TB/s at 191 bins, 2.7 at 382 (read + write), against
+// 4.8 TB/s for a plain copy. Counting-sorting every sub-tile of kSortSub records by bin inside LDS
+// first (histogram, scan, placement) turns the records of a bin into a run of consecutive lanes
+// storing to consecutive addresses: 4.5 TB/s at 191 bins, 4.0 at 382. One workgroup of 1024
+// lanes per CU (the sub-tile occupies 64 KB of LDS), 4 rows per lane.
+constexpr int kSortBins = 1024;    // widest fan-out of the sorted scatters
+constexpr int kSortThreads = 1024;
+template <int W>
+struct SortLds {
+  static constexpr int kSub = (W <= 2 ? 4096 : 2048);   // records per sub-tile: <= 64 KB of LDS
+  static constexpr int kRounds = kSub / kSortThreads;   // rows per lane and sub-tile
+  unsigned long long binBase[kSortBins];  // next free record of the bin inside this tile's range
+  uint32_t cnt[kSortBins];                // sub-tile histogram, then placement cursor
+  uint32_t start[kSortBins];              // sub-tile exclusive scan
+  uint64_t recs[kSub * W];
+  uint16_t binOf[kSub];
+  uint32_t waveTotals[kSortThreads / 64];
+};
+
+// The sub-tile's records (rec[u], bin[u] = 0xffffffff: none) leave for their bins. Called by all
+// 1024 lanes; cnt[] must be zero on entry and is zero again on return.
+template <int W, int R>
+__device__ inline void rpSortedEmit(SortLds<W>& l, int numBins, const uint64_t (&rec)[R][W], const uint32_t (&bin)[R],
+                                    uint64_t* out) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    if (bin[u] != 0xffffffffu) {
+      atomicAdd(&l.cnt[bin[u]], 1u);
+    }
+  }
+  blockSync();
+  // exclusive scan of the histogram: one bin per lane
+  const uint32_t mine = tid < numBins ? l.cnt[tid] : 0;
+  uint32_t incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = __shfl_up(incl, off, kWave);
+    if (lane() >= off) {
+      incl += o;
+    }
+  }
+  if (lane() == 63) {
+    l.waveTotals[tid >> 6] = incl;
+  }
+  blockSync();
+  uint32_t run = incl - mine;
+  for (int w = 0; w < (tid >> 6); ++w) {
+    run += l.waveTotals[w];
+  }
+  if (tid < numBins) {
+    l.start[tid] = run;
+    l.cnt[tid] = run;  // placement cursor
+  }
+  blockSync();
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    if (bin[u] != 0xffffffffu) {
+      const uint32_t pos = atomicAdd(&l.cnt[bin[u]], 1u);
+      rpStore<W>(l.recs + static_cast<size_t>(pos) * W, rec[u]);
+      l.binOf[pos] = static_cast<uint16_t>(bin[u]);
+    }
+  }
+  blockSync();
+  uint32_t total = 0;
+#pragma unroll
+  for (int w = 0; w < kSortThreads / 64; ++w) {
+    total += l.waveTotals[w];
+  }
+  for (uint32_t i = tid; i < total; i += kSortThreads) {
+    const uint32_t b = l.binOf[i];
+    uint64_t w[W];
+    rpLoad<W>(l.recs + static_cast<size_t>(i) * W, w);
+    rpStore<W>(out + (l.binBase[b] + (i - l.start[b])) * W, w);
+  }
+  blockSync();
+  if (tid < numBins) {
+    l.binBase[tid] += l.cnt[tid] - l.start[tid];
+    l.cnt[tid] = 0;
+  }
+  blockSync();
+}
+
+// Level 1 with sorted sub-tiles (numBins <= kSortBins); same records as k_rp_scatter1.
+template <int KW, int W, bool FLATV>
+__global__ __launch_bounds__(kSortThreads) void k_rp_scatter1_sorted(RadixArgs r) {
+  __shared__ SortLds<W> l;
+  constexpr int R = SortLds<W>::kRounds;
+  const AggArgs& a = r.a;
+  const int shift = r.shiftB + r.shift2;
+  for (int i = threadIdx.x; i < kSortBins; i += kSortThreads) {
+    l.cnt[i] = 0;
+  }
+  for (int64_t tile = blockIdx.x; tile < r.numTiles; tile += gridDim.x) {
+    for (int i = threadIdx.x; i < r.numBins; i += kSortThreads) {
+      l.binBase[i] = r.offsets[static_cast<int64_t>(i) * r.numTiles + tile];
+    }
+    blockSync();
+    const int64_t begin = tile * r.tileRows;
+    const int64_t end = begin + r.tileRows < a.numRows ? begin + r.tileRows : a.numRows;
+    for (int64_t base = begin; base < end; base += SortLds<W>::kSub) {
+      int64_t raw[R];
+      uint64_t vals[R][W];
+      uint32_t bin[R];
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const int64_t row = base + u * kSortThreads + threadIdx.x;
+        raw[u] = row < end ? rpLoadKey<KW>(r, row) : 0;
+        if constexpr (FLATV) {
+#pragma unroll
+          for (int q = 1; q < W; ++q) {
+            vals[u][q] = row < end ? static_cast<const uint64_t*>(a.accs[r.accOfVal[q - 1]].in.values)[row] : 0;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const int64_t row = base + u * kSortThreads + threadIdx.x;
+        bin[u] = 0xffffffffu;
+        uint64_t key;
+        if (row >= end || rpKey<KW>(r, row, raw[u], &key) != 0) {
+          continue;
+        }
+        uint64_t mask = 0;
+        if constexpr (FLATV) {
+          mask = (1ULL << a.numAccs) - 1;
+#pragma unroll
+          for (int q = 1; q < W; ++q) {
+            const AccArg& acc = a.accs[r.accOfVal[q - 1]];
+            if (acc.kind == ACC_MIN || acc.kind == ACC_MAX) {
+              vals[u][q] = acc.inIsInt ? int64ToOrdered(static_cast<int64_t>(vals[u][q]))
+                                       : doubleToOrdered(__longlong_as_double(static_cast<long long>(vals[u][q])));
+            }
+          }
+        } else {
+#pragma unroll
+          for (int q = 1; q < W; ++q) {
+            const int j = r.accOfVal[q - 1];
+            vals[u][q] = 0;
+            if (accInput(a, a.accs[j], row, &vals[u][q])) {
+              mask |= 1ULL << j;
+            }
+          }
+          for (int j = 0; j < a.numAccs; ++j) {
+            uint64_t one;
+            if (r.valIdx[j] < 0 && accInput(a, a.accs[j], row, &one)) {
+              mask |= 1ULL << j;
+            }
+          }
+        }
+        vals[u][0] = key | (static_cast<uint64_t>(row) << r.keyBits) | (mask << (r.keyBits + r.rowBits));
+        bin[u] = static_cast<uint32_t>(key >> shift);
+      }
+      rpSortedEmit<W, R>(l, r.numBins, vals, bin, r.recs);
+    }
+  }
+}
+
 // Level 2 works on records; tiles never straddle level-1 buckets.
 struct RadixTile {
   uint64_t begin;   // first record
@@ -961,6 +1142,39 @@ __global__ __launch_bounds__(1024) void k_rp_scatter2(Radix2Args r) {
       }
     }
     blockSync();
+  }
+}
+
+// Level 2 with sorted sub-tiles (numBins <= kSortBins).
+template <int W>
+__global__ __launch_bounds__(kSortThreads) void k_rp_scatter2_sorted(Radix2Args r) {
+  __shared__ SortLds<W> l;
+  constexpr int R = SortLds<W>::kRounds;
+  const uint32_t numTiles = *r.numTiles;
+  const uint32_t binMask = static_cast<uint32_t>(r.numBins - 1);
+  for (int i = threadIdx.x; i < kSortBins; i += kSortThreads) {
+    l.cnt[i] = 0;
+  }
+  for (uint32_t t = blockIdx.x; t < numTiles; t += gridDim.x) {
+    const RadixTile tile = r.tiles[t];
+    for (int i = threadIdx.x; i < r.numBins; i += kSortThreads) {
+      l.binBase[i] = r.offsets[tile.cell + static_cast<uint64_t>(i) * tile.stride];
+    }
+    blockSync();
+    for (uint32_t base = 0; base < tile.count; base += SortLds<W>::kSub) {
+      uint64_t w[R][W];
+      uint32_t bin[R];
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const uint32_t i = base + u * kSortThreads + threadIdx.x;
+        bin[u] = 0xffffffffu;
+        if (i < tile.count) {
+          rpLoad<W>(r.in + (tile.begin + i) * W, w[u]);
+          bin[u] = (static_cast<uint32_t>(w[u][0]) >> r.shiftB) & binMask;
+        }
+      }
+      rpSortedEmit<W, R>(l, r.numBins, w, bin, r.out);
+    }
   }
 }
 
@@ -1127,7 +1341,11 @@ __device__ inline void rpFoldFlush(const RpFold& f, const RadixAggArgs& r, int64
         const uint64_t v = f.acc[static_cast<size_t>(g) * A + j];
         const int32_t kind = r.wordKind[j];
         if (v != accIdentity(kind)) {
-          applyGlobal(row + r.wordOff[j], kind == ACC_COUNT ? ACC_SUM_I64_WRAP : kind, v, r.counters);
+          if (kind == ACC_SUM_I64) {
+            addPartial128Global(row + r.wordOff[j], v, 0);  // its high word follows as word j + 1
+          } else {
+            applyGlobal(row + r.wordOff[j], kind == ACC_COUNT ? ACC_SUM_I64_WRAP : kind, v, r.counters);
+          }
         }
       }
     } else {
@@ -1144,13 +1362,12 @@ __device__ inline void rpFoldFlush(const RpFold& f, const RadixAggArgs& r, int64
             *reinterpret_cast<double*>(word) += __longlong_as_double(static_cast<long long>(v));
             break;
           case ACC_SUM_I64: {
-            const int64_t before = static_cast<int64_t>(*word);
-            if (addOverflows(before, static_cast<int64_t>(v))) {
-              r.counters->overflow = 1;
-            }
-            *word = static_cast<uint64_t>(before) + v;
+            const uint64_t before = *word;
+            *word = before + v;
+            word[1] += static_cast<uint64_t>(carryUnsigned(before, v));  // the fold's own high word is word j + 1
             break;
           }
+          case ACC_SUM_I64_HI:
           case ACC_SUM_I64_WRAP:
           case ACC_COUNT:
             *word += v;
@@ -1826,6 +2043,18 @@ __global__ __launch_bounds__(256) void k_rekey(RekeyArgs a) {
   }
 }
 
+// Group rows of 'oldStride' words -> rows of 'newStride' (> oldStride) words; new words = pattern.
+__global__ __launch_bounds__(256) void k_restride(const uint64_t* src, uint64_t* dst, uint64_t rows, int32_t oldStride,
+                                                   int32_t newStride, const uint64_t* pattern) {
+  const uint64_t total = rows * newStride;
+  const uint64_t step = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += step) {
+    const uint64_t r = i / newStride;
+    const int32_t w = static_cast<int32_t>(i % newStride);
+    dst[i] = w < oldStride ? src[r * oldStride + w] : pattern[w];
+  }
+}
+
 // srcOff == 1 (the first-row word): dst = group exists ? 1 : 0 — used when a
 // count that was only ever needed as a "seen" flag has to become a real word.
 __global__ __launch_bounds__(256) void k_copy_acc(uint64_t* table, uint64_t rows, int32_t stride,
@@ -1903,7 +2132,8 @@ struct OutAgg {
   int32_t aggKind;   // vx355_agg_kind
   int32_t inputType;
   int32_t mainOff;
-  int32_t loOff;     // DOUBLE sum / avg: the 'lo' word (value = hi + lo); -1 otherwise
+  int32_t loOff;     // DOUBLE sum / avg: the 'lo' word (value = hi + lo); BIGINT sum: the high word of
+                     // the 128-bit total; -1 otherwise
   int32_t seenOff;   // count of contributing rows; -1 = never null; 1 = the first-row word
                      // (group exists <=> some row contributed)
   int32_t finalOut;
@@ -1920,6 +2150,7 @@ struct ExtractArgs {
   int32_t numAggs;
   int32_t global;  // no keys: the single group is row 0
   const uint64_t* nullStore;  // generic hash mode
+  uint32_t* overflow;         // set when a sum(BIGINT) total does not fit int64 (Counters::overflow)
   OutKey keys[kMaxKeys];
   OutAgg aggs[kMaxAccs];
 };
@@ -2056,6 +2287,11 @@ __global__ __launch_bounds__(256) void k_extract(ExtractArgs a) {
         writeBit(oa.nulls, pos, valid);
         if (active) {
           if (inInt) {
+            // the 128-bit total must fit int64: high word = sign extension of the low word
+            if (valid && oa.loOff >= 0 &&
+                static_cast<int64_t>(g[oa.loOff]) != (static_cast<int64_t>(mainWord) < 0 ? -1 : 0)) {
+              *a.overflow = 1;
+            }
             static_cast<int64_t*>(oa.values)[pos] = valid ? static_cast<int64_t>(mainWord) : 0;
           } else {
             double d = valid ? __longlong_as_double(static_cast<long long>(mainWord)) +
@@ -2260,6 +2496,11 @@ struct vx355_agg {
   std::vector<KeyState> keys;
   std::vector<LogicalAgg> aggs;
   std::vector<PhysAcc> phys;
+  // Word of the group row each accumulator owns (row word = 2 + wordOf), -1 = none: a count that
+  // only ever serves as a "group seen" flag is read off the first-row word, and a count(x) that
+  // aliases count(*) gets a word the day a batch brings nulls in x (growWord re-lays the table).
+  // BASELINE config 4 (sum(DOUBLE) per key): 4 words per group instead of 6.
+  std::vector<int32_t> wordOf;
   std::vector<int32_t> outTypes;
   std::vector<int32_t> usedCols;
   std::vector<vx355_filter_term> fusedTerms;
@@ -2298,6 +2539,7 @@ struct vx355_agg {
   int32_t radixMaxBins = kRadixMaxBins;  // widest single-level fan-out
   int64_t radixTileRows = 0;  // 0 = automatic
   int64_t radixLaunches = 0;
+  bool radixSorted = true;   // VX355_AGG_RADIX_SORTED=0: scatter passes store record by record
   // The table was allocated but never written (rebuildTable skipped k_init_table because a radix
   // fold may come first and store every row itself); settleTable initialises it for anyone else.
   bool tableVirgin = false;
@@ -2379,6 +2621,33 @@ struct vx355_agg {
 namespace vx {
 namespace {
 
+bool flagFromFirstRow(const vx355_agg& h, int32_t i);
+
+// Row word of accumulator i; only for accumulators that own one.
+int32_t offOf(const vx355_agg& h, int32_t i) {
+  if (h.wordOf.at(i) < 0) {
+    VX_THROW(VX355_EINTERNAL, "accumulator without a word in the group row");
+  }
+  return 2 + h.wordOf[i];
+}
+
+void assignWords(vx355_agg& h) {
+  h.wordOf.assign(h.phys.size(), -1);
+  int32_t next = 0;
+  for (size_t i = 0; i < h.phys.size(); ++i) {
+    const auto& p = h.phys[i];
+    if (p.isLo) {
+      h.wordOf[i] = h.wordOf[i - 1] < 0 ? -1 : next++;  // right behind its first word
+      continue;
+    }
+    if (p.aliasOf >= 0 || flagFromFirstRow(h, static_cast<int32_t>(i))) {
+      continue;
+    }
+    h.wordOf[i] = next++;
+  }
+  h.stride = 2 + next;
+}
+
 int32_t findOrAddPhys(vx355_agg& h, int32_t kind, int32_t col, int32_t mask, bool inIsInt) {
   for (size_t i = 0; i < h.phys.size(); ++i) {
     const auto& p = h.phys[i];
@@ -2393,14 +2662,15 @@ int32_t findOrAddPhys(vx355_agg& h, int32_t kind, int32_t col, int32_t mask, boo
   p.inIsInt = inIsInt;
   h.phys.push_back(p);
   const int32_t index = static_cast<int32_t>(h.phys.size() - 1);
-  if (kind == ACC_SUM_F64) {
+  if (accWords(kind) == 2) {
+    // DOUBLE sum: the exact remainders; BIGINT sum: the high word of the 128-bit total
     PhysAcc lo;
-    lo.kind = ACC_SUM_F64;
+    lo.kind = accSecondKind(kind);
     lo.inputCol = -1;
     lo.maskCol = -1;
-    lo.inIsInt = false;
+    lo.inIsInt = kind == ACC_SUM_I64;
     lo.isLo = true;
-    h.phys.push_back(lo);  // always the word right after its 'hi'
+    h.phys.push_back(lo);  // always the word right after the first
   }
   return index;
 }
@@ -2496,7 +2766,8 @@ void buildPlan(vx355_agg& h, const vx355_agg_spec& spec) {
           // count = checkedPlus over the partial counts of rows whose sum is
           // not null (AverageAggregateBase.h:265-330). The accumulator is keyed
           // on the count column; rows are gated by the SUM column's nulls below.
-          la.seen = findOrAddPhys(h, ACC_SUM_I64, f.input_col2, f.mask_col, true);
+          // (counts cannot leave int64: no 128-bit total for them)
+          la.seen = findOrAddPhys(h, ACC_SUM_I64_WRAP, f.input_col2, f.mask_col, true);
         }
         if (fin) {
           h.outTypes.push_back(f.input_type == VX355_REAL ? VX355_REAL : VX355_DOUBLE);
@@ -2518,7 +2789,7 @@ void buildPlan(vx355_agg& h, const vx355_agg_spec& spec) {
     VX_THROW(VX355_EUNSUPPORTED, "too many accumulators for one device table");
   }
   VX_CHECK_ARG(h.keys.size() <= static_cast<size_t>(kMaxKeys), "at most 8 grouping keys");
-  h.stride = 2 + static_cast<int32_t>(h.phys.size());
+  assignWords(h);
 }
 
 // VectorHasher::extendRange (exec/VectorHasher.cpp:786-835) with the group-by
@@ -2637,7 +2908,9 @@ void ensureBasics(vx355_agg& h) {
   pat[0] = kEmpty;
   pat[1] = kNoRow;
   for (size_t i = 0; i < h.phys.size(); ++i) {
-    pat[2 + i] = accIdentity(h.phys[i].kind);
+    if (h.wordOf[i] >= 0) {
+      pat[2 + h.wordOf[i]] = accIdentity(h.phys[i].kind);
+    }
   }
   h.pattern.ensure(pat.size() * 8);
   copyIn(h.pattern.ptr(), pat.data(), VX355_MEM_HOST, pat.size() * 8);
@@ -3142,7 +3415,8 @@ void fillAccArgs(vx355_agg& h, const DeviceBatch& db, AggArgs* a) {
     aa.splitM = p.splitM;
     aa.kind = p.kind;
     aa.inIsInt = p.inIsInt ? 1 : 0;
-    aa.off = 2 + static_cast<int32_t>(i);
+    aa.off = offOf(h, static_cast<int32_t>(i));
+    aa.phys = static_cast<int32_t>(i);
     aa.inProj = -1;
     if (p.inputCol >= VX355_PROJECTION_COL_BASE) {
       aa.inProj = p.inputCol - VX355_PROJECTION_COL_BASE;
@@ -3168,7 +3442,7 @@ void patchAvgIntermediate(vx355_agg& h, const DeviceBatch& db, AggArgs* a) {
       continue;
     }
     for (int j = 0; j < a->numAccs; ++j) {
-      if (a->accs[j].off == 2 + la.seen) {
+      if (a->accs[j].phys == la.seen) {
         // Null sums exclude the row: fold the sum column's nulls into the mask
         // slot when the count column itself carries no nulls of its own.
         ColView sumCol = db.col(la.fn.input_col);
@@ -3178,6 +3452,41 @@ void patchAvgIntermediate(vx355_agg& h, const DeviceBatch& db, AggArgs* a) {
       }
     }
   }
+}
+
+// Accumulator i gets a word of its own: the group rows grow by one word (new word = identity).
+void growWord(vx355_agg& h, int32_t i) {
+  if (h.wordOf[i] >= 0) {
+    return;
+  }
+  auto& rt = Runtime::get();
+  const int32_t oldStride = h.stride;
+  h.wordOf[i] = oldStride - 2;
+  h.stride = oldStride + 1;
+  // the pattern follows the layout
+  ensureBasics(h);
+  std::vector<uint64_t> pat(h.stride);
+  pat[0] = kEmpty;
+  pat[1] = kNoRow;
+  for (size_t q = 0; q < h.phys.size(); ++q) {
+    if (h.wordOf[q] >= 0) {
+      pat[2 + h.wordOf[q]] = accIdentity(h.phys[q].kind);
+    }
+  }
+  h.pattern.ensure(pat.size() * 8 + 64);
+  copyIn(h.pattern.ptr(), pat.data(), VX355_MEM_HOST, pat.size() * 8);
+  rt.sync();
+  if (!h.tableReady) {
+    return;
+  }
+  DevBuf fresh;
+  fresh.ensure(static_cast<size_t>(h.capacity) * h.stride * 8 + 64);
+  if (!h.tableVirgin) {
+    VX_LAUNCH("k_restride", k_restride, streamGrid(static_cast<int64_t>(h.capacity) * h.stride, 256, 4), 256, 0,
+              h.table.as<uint64_t>(), fresh.as<uint64_t>(), h.capacity, oldStride, h.stride, h.pattern.as<uint64_t>());
+    rt.sync();
+  }
+  h.table = std::move(fresh);
 }
 
 void materializeAliases(vx355_agg& h, const DeviceBatch& db) {
@@ -3200,12 +3509,11 @@ void materializeAliases(vx355_agg& h, const DeviceBatch& db) {
     if (!mayBeNull) {
       continue;
     }
-    if (h.tableReady) {
-      settleTable(h);
+    const int32_t srcOff = flagFromFirstRow(h, p.aliasOf) ? 1 : offOf(h, p.aliasOf);
+    growWord(h, static_cast<int32_t>(i));
+    if (h.tableReady && !h.tableVirgin) {
       VX_LAUNCH("k_copy_acc", k_copy_acc, streamGrid(static_cast<int64_t>(h.capacity), 256), 256, 0,
-                h.table.as<uint64_t>(), h.capacity, h.stride,
-                flagFromFirstRow(h, p.aliasOf) ? 1 : 2 + p.aliasOf,
-                2 + static_cast<int32_t>(i));
+                h.table.as<uint64_t>(), h.capacity, h.stride, srcOff, offOf(h, static_cast<int32_t>(i)));
     }
     p.aliasOf = -1;
   }
@@ -3227,7 +3535,7 @@ int radixShiftB(int numWords) { return numWords <= 1 ? 12 : (numWords <= 4 ? 11 
 int radixWords(const AggArgs& a) {
   int n = 0;
   for (int j = 0; j < a.numAccs; ++j) {
-    n += a.accs[j].kind == ACC_SUM_F64 ? 2 : 1;
+    n += accWords(a.accs[j].kind);
   }
   return n;
 }
@@ -3326,8 +3634,20 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
     VX_LAUNCH("k_rp_count1", k_rp_count1<0>, grid1, 1024, 0, r);
   }
   scanU32ToU64(r.hist, cells1, offsets1, h.rpScan);
+  const bool sorted1 = h.radixSorted && r.numBins <= kSortBins;
   auto scatter1 = [&](auto wTag) {
     constexpr int W = decltype(wTag)::value;
+    if (sorted1) {
+      const int grid = static_cast<int>(std::min<int64_t>(r.numTiles, rt.numCUs * 2));
+      if (flatV && kw == 8) {
+        VX_LAUNCH("k_rp_scatter1", (k_rp_scatter1_sorted<8, W, true>), grid, kSortThreads, 0, r);
+      } else if (flatV && kw == 4) {
+        VX_LAUNCH("k_rp_scatter1", (k_rp_scatter1_sorted<4, W, true>), grid, kSortThreads, 0, r);
+      } else {
+        VX_LAUNCH("k_rp_scatter1", (k_rp_scatter1_sorted<0, W, false>), grid, kSortThreads, 0, r);
+      }
+      return;
+    }
     if (flatV && kw == 8) {
       VX_LAUNCH("k_rp_scatter1", (k_rp_scatter1<8, W, true>), grid1, 1024, 0, r);
     } else if (flatV && kw == 4) {
@@ -3381,7 +3701,11 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
     VX_LAUNCH("k_rp_count2", k_rp_count2, grid2, 1024, 0, r2);
     scanU32ToU64(r2.hist, cells2, offsets2, h.rpScan);
     byWidth([&](auto wTag) {
-      VX_LAUNCH("k_rp_scatter2", (k_rp_scatter2<decltype(wTag)::value>), grid2, 1024, 0, r2);
+      if (h.radixSorted && bins2 <= kSortBins) {
+        VX_LAUNCH("k_rp_scatter2", (k_rp_scatter2_sorted<decltype(wTag)::value>), grid2, kSortThreads, 0, r2);
+      } else {
+        VX_LAUNCH("k_rp_scatter2", (k_rp_scatter2<decltype(wTag)::value>), grid2, 1024, 0, r2);
+      }
     });
     g.recs = h.rpRecs2.as<uint64_t>();
     g.partBegin = offsets2;
@@ -3406,8 +3730,8 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
     g.wordKind[g.numWords] = a.accs[j].kind;
     g.wordOff[g.numWords] = a.accs[j].off;
     ++g.numWords;
-    if (a.accs[j].kind == ACC_SUM_F64) {
-      g.wordKind[g.numWords] = ACC_SUM_F64;
+    if (accWords(a.accs[j].kind) == 2) {
+      g.wordKind[g.numWords] = accSecondKind(a.accs[j].kind);
       g.wordOff[g.numWords] = a.accs[j].off + 1;
       ++g.numWords;
     }
@@ -3440,7 +3764,13 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
   } else {
     h.pairsComplete = false;
   }
-  const int gridA = rt.numCUs * 2;
+  // workgroups per CU: as many as the LDS holds, at most 4 (a fold alternates between streaming
+  // records in and flushing its partition: the other workgroups of the CU cover those phases)
+  int perCu = static_cast<int>(std::min<size_t>(4, (150 * 1024) / (ldsBytes + 2304)));
+  if (const char* e = std::getenv("VX355_AGG_FOLD_WGS")) {
+    perCu = std::atoi(e);
+  }
+  const int gridA = rt.numCUs * std::max(1, perCu);
   if (g.virgin) {
     // owners store complete rows; the other slices of split partitions wait for the launch boundary
     g.phase = 0;
@@ -3473,8 +3803,8 @@ void launchChunk(vx355_agg& h, AggArgs& a) {
     la.plan.kind[numWords] = a.accs[j].kind;
     la.plan.off[numWords] = a.accs[j].off;
     ++numWords;
-    if (a.accs[j].kind == ACC_SUM_F64) {
-      la.plan.kind[numWords] = ACC_SUM_F64;
+    if (accWords(a.accs[j].kind) == 2) {
+      la.plan.kind[numWords] = accSecondKind(a.accs[j].kind);
       la.plan.off[numWords] = a.accs[j].off + 1;
       ++numWords;
     }
@@ -3814,7 +4144,7 @@ void chooseSumGrids(vx355_agg& h, AggArgs& a, int64_t n) {
         m = std::ldexp(1.5, G + 52);
       }
     }
-    h.phys[a.accs[j].off - 2].splitM = m;
+    h.phys[a.accs[j].phys].splitM = m;
     a.accs[j].splitM = m;
   }
 }
@@ -4345,7 +4675,7 @@ void getOutput(vx355_agg& h, vx355_out_column* cols, int32_t numCols, int32_t ma
     while (h.phys[p].aliasOf >= 0) {
       p = h.phys[p].aliasOf;
     }
-    return flagFromFirstRow(h, p) ? 1 : 2 + p;
+    return flagFromFirstRow(h, p) ? 1 : offOf(h, p);
   };
   const bool fin = finalOutput(h.step);
   for (size_t j = 0; j < h.aggs.size(); ++j) {
@@ -4354,7 +4684,7 @@ void getOutput(vx355_agg& h, vx355_out_column* cols, int32_t numCols, int32_t ma
     oa.aggKind = la.fn.kind;
     oa.inputType = la.fn.input_type;
     oa.mainOff = physOff(la.main);
-    oa.loOff = (la.main >= 0 && h.phys[la.main].kind == ACC_SUM_F64) ? oa.mainOff + 1 : -1;
+    oa.loOff = (la.main >= 0 && accWords(h.phys[la.main].kind) == 2) ? oa.mainOff + 1 : -1;
     oa.seenOff = physOff(la.seen);
     oa.finalOut = fin ? 1 : 0;
     oa.values = devValues(c);
@@ -4366,7 +4696,19 @@ void getOutput(vx355_agg& h, vx355_out_column* cols, int32_t numCols, int32_t ma
       ++c;
     }
   }
+  ea.overflow = &h.counters()->overflow;
+  bool checksTotals = false;
+  for (int j = 0; j < ea.numAggs; ++j) {
+    checksTotals = checksTotals || (ea.aggs[j].aggKind == VX355_AGG_SUM && ea.aggs[j].inputType <= VX355_BIGINT &&
+                                    ea.aggs[j].loOff >= 0);
+  }
+  if (checksTotals) {
+    resetCounters(h);
+  }
   VX_LAUNCH("k_extract", k_extract, static_cast<int>(ceilDiv(n, 256)), 256, 0, ea);
+  if (checksTotals) {
+    checkCounters(readCounters(h));  // "integer overflow": a sum(BIGINT) total left int64
+  }
   for (int32_t i = 0; i < numCols; ++i) {
     if (cols[i].mem == VX355_MEM_HOST) {
       copyOutAsync(cols[i].values, VX355_MEM_HOST, scratch + offsets[i], valueBytes[i]);
@@ -4533,6 +4875,9 @@ void configureFromEnv(vx355_agg& h) {
   }
   if (const char* e = std::getenv("VX355_AGG_NO_FAST")) {
     h.disableFast = e[0] == '1';
+  }
+  if (const char* e = std::getenv("VX355_AGG_RADIX_SORTED")) {
+    h.radixSorted = std::atoi(e) != 0;
   }
   if (const char* e = std::getenv("VX355_AGG_RADIX_MIN_ROWS")) {
     h.radixMinRows = std::strtoll(e, nullptr, 10);  // < 0 disables the path

@@ -17,12 +17,31 @@ constexpr uint64_t kNoRow = ~0ULL;
 
 enum AccKind : int32_t {
   ACC_SUM_F64 = 0,
-  ACC_SUM_I64 = 1,        // checked: sets the overflow flag
+  ACC_SUM_I64 = 1,        // sum(BIGINT): LOW word of a 128-bit total, carries go to the next word
   ACC_SUM_I64_WRAP = 2,   // partial counts merged in the final step (no check)
   ACC_COUNT = 3,          // +1 per qualifying row
   ACC_MIN = 4,            // order-preserving u64 image, atomic umin
   ACC_MAX = 5,
+  ACC_SUM_I64_HI = 6,     // high word of the 128-bit total behind an ACC_SUM_I64 word: plain wrapping adds
 };
+
+// sum(BIGINT) keeps a 128-bit total per group (two words) so that "integer overflow" depends on
+// the rows alone, not on the order in which lanes, waves and workgroups add them: the reference
+// checks its running sum in input order (vector/AggregationHook.h:126-135 checkedPlus); any
+// parallel order sees other partial sums, and a check on those would raise — or not — at random
+// on mixed-sign data. Here every add is exact (wrapping low word + carry into the high word,
+// both commutative), and the total is checked once, when it is read out: it must fit int64.
+__host__ __device__ inline int accWords(int32_t kind) { return (kind == ACC_SUM_F64 || kind == ACC_SUM_I64) ? 2 : 1; }
+__host__ __device__ inline int32_t accSecondKind(int32_t kind) { return kind == ACC_SUM_I64 ? ACC_SUM_I64_HI : kind; }
+
+// What adding the signed value v to a low word that held oldLo sends to the high word.
+__device__ inline int64_t carrySigned(uint64_t oldLo, int64_t v) {
+  const uint64_t nl = oldLo + static_cast<uint64_t>(v);
+  return static_cast<int64_t>(nl < oldLo ? 1 : 0) - (v < 0 ? 1 : 0);
+}
+// Same for an UNSIGNED partial low word (a low word accumulated elsewhere, whose own carries
+// already sit in its high word).
+__device__ inline int64_t carryUnsigned(uint64_t oldLo, uint64_t lo) { return (oldLo + lo) < oldLo ? 1 : 0; }
 
 enum Mode : int32_t { MODE_HASH = 0, MODE_ARRAY = 1, MODE_NORMALIZED = 2 };
 
@@ -51,13 +70,16 @@ __device__ inline void applyGlobal(uint64_t* word, int32_t kind, uint64_t v, Cou
       unsafeAtomicAdd(reinterpret_cast<double*>(word), __longlong_as_double(static_cast<long long>(v)));
       break;
     case ACC_SUM_I64: {
-      unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(word),
-                                         static_cast<unsigned long long>(v));
-      if (addOverflows(static_cast<int64_t>(old), static_cast<int64_t>(v))) {
-        ctr->overflow = 1;
+      // v is a signed input value; the high word is the next word of the group row
+      const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(word),
+                                               static_cast<unsigned long long>(v));
+      const int64_t up = carrySigned(old, static_cast<int64_t>(v));
+      if (up != 0) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(word + 1), static_cast<unsigned long long>(up));
       }
       break;
     }
+    case ACC_SUM_I64_HI:
     case ACC_SUM_I64_WRAP:
     case ACC_COUNT:
       atomicAdd(reinterpret_cast<unsigned long long*>(word), static_cast<unsigned long long>(v));
@@ -68,6 +90,18 @@ __device__ inline void applyGlobal(uint64_t* word, int32_t kind, uint64_t v, Cou
     default:
       atomicMax(reinterpret_cast<unsigned long long*>(word), static_cast<unsigned long long>(v));
       break;
+  }
+}
+
+// Adds the 128-bit partial {lo, hi} (lo unsigned) to the total at word / word + 1 in HBM.
+__device__ inline void addPartial128Global(uint64_t* word, uint64_t lo, int64_t hi) {
+  int64_t up = hi;
+  if (lo != 0) {
+    const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(word), static_cast<unsigned long long>(lo));
+    up += carryUnsigned(old, lo);
+  }
+  if (up != 0) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(word + 1), static_cast<unsigned long long>(up));
   }
 }
 
@@ -230,17 +264,22 @@ __device__ inline void ldsFlush(const LdsPlan& p, const LdsState& st) {
         v = q[r] > v ? q[r] : v;
       }
       applyGlobal(g + p.off[j], ACC_MAX, v, p.counters);
-    } else {
-      int64_t s = static_cast<int64_t>(v);
+    } else if (kind == ACC_SUM_I64) {
+      // low words of the replicas (their carries sit in the replicas' high words, flushed by
+      // the thread of word j + 1): unsigned adds, the carries join the high word in HBM
+      uint64_t s = v;
+      int64_t up = 0;
       for (int r = 1; r < REP; ++r) {
-        int64_t x = static_cast<int64_t>(q[r]);
-        if (kind == ACC_SUM_I64 && addOverflows(s, x)) {
-          p.counters->overflow = 1;
-        }
-        s = static_cast<int64_t>(static_cast<uint64_t>(s) + static_cast<uint64_t>(x));
+        up += carryUnsigned(s, q[r]);
+        s += q[r];
       }
-      applyGlobal(g + p.off[j], kind == ACC_COUNT ? ACC_SUM_I64_WRAP : kind, static_cast<uint64_t>(s),
-                  p.counters);
+      addPartial128Global(g + p.off[j], s, up);
+    } else {
+      uint64_t s = v;
+      for (int r = 1; r < REP; ++r) {
+        s += q[r];
+      }
+      applyGlobal(g + p.off[j], kind == ACC_COUNT ? ACC_SUM_I64_WRAP : kind, s, p.counters);
     }
   }
 }

@@ -36,6 +36,8 @@ struct ProjectionArg {
   int32_t pad;
 };
 
+// The reference's comparison functions (functions/prestosql/Comparisons.h:42-121 ->
+// util::floating_point::NaNAware*): for DOUBLE, NaN equals NaN and is greater than everything else.
 template <typename T>
 __device__ inline bool compareValues(int32_t cmp, T a, T b) {
   switch (cmp) {
@@ -51,6 +53,27 @@ __device__ inline bool compareValues(int32_t cmp, T a, T b) {
       return a > b;
     default:
       return a >= b;
+  }
+}
+template <>
+__device__ inline bool compareValues<double>(int32_t cmp, double a, double b) {
+  const bool an = a != a, bn = b != b;
+  const bool eq = (an && bn) || a == b;
+  const bool lt = !an && (bn || a < b);
+  const bool gt = !bn && (an || a > b);
+  switch (cmp) {
+    case VX355_CMP_EQ:
+      return eq;
+    case VX355_CMP_NE:
+      return !eq;
+    case VX355_CMP_LT:
+      return lt;
+    case VX355_CMP_LE:
+      return lt || eq;
+    case VX355_CMP_GT:
+      return gt;
+    default:
+      return gt || eq;
   }
 }
 

@@ -50,7 +50,8 @@ struct PageArgs {
   uint64_t* counts;       // [col * numTiles + tile] * 2: non-null rows, string bytes
   const TileOut* layout;  // [col * numTiles + tile]
   unsigned char* out;
-  uint32_t* errorFlag;
+  uint32_t* errorFlag;    // 1: a timestamp does not fit milliseconds; 2: rows[] holds a row outside the batch
+  int64_t batchRows;
 };
 
 struct __attribute__((packed)) Packed16 {
@@ -96,6 +97,10 @@ __global__ __launch_bounds__(256) void k_page_count(PageArgs a) {
     if (r < pt.count) {
       const int64_t pos = pt.rowBegin + r;
       const int64_t row = a.rows ? a.rows[pos] : pos;
+      if (row < 0 || row >= a.batchRows) {
+        *a.errorFlag = 2;  // the host refuses the call before anything is written
+        continue;
+      }
       if (!colIsNull(c, row)) {
         ++nonNull;
         if (str) {
@@ -466,10 +471,16 @@ void serializePages(const vx355_batch* batch, const int32_t* rows, int32_t rowsM
   a.lossless = lossless ? 1 : 0;
   a.counts = devCounts;
   a.errorFlag = devFlag;
+  a.batchRows = batch->num_rows;
   std::vector<uint64_t> counts(numCells * 2, 0);
   if (nc > 0) {
     VX_LAUNCH("k_page_count", k_page_count, dim3(static_cast<unsigned>(numTiles), static_cast<unsigned>(nc)), 256, 0, a);
     copyOut(counts.data(), VX355_MEM_HOST, devCounts, numCells * 16);
+    uint32_t flag = 0;
+    copyOut(&flag, VX355_MEM_HOST, devFlag, 4);
+    if (flag == 2) {
+      VX_THROW(VX355_EINVAL, "rows[] holds a row number outside the batch");
+    }
   }
   // layout
   std::vector<TileOut> layout(numCells);
@@ -904,6 +915,10 @@ void deserializePages(const void* const* pages, const int64_t* sizes, int32_t nu
       }
       const bool hasNulls = page[pos] != 0;
       pos += 1;
+      if (hasNulls && cols[c].nulls == nullptr) {
+        VX_THROW(VX355_EINVAL, "page " + std::to_string(p) + " carries nulls in column " + std::to_string(c) +
+                                   " but the output column has no null buffer");
+      }
       int64_t nonNull = flatRows;
       sec.prefixBase = static_cast<int64_t>(prefix.size());
       if (hasNulls) {
@@ -918,7 +933,9 @@ void deserializePages(const void* const* pages, const int64_t* sizes, int32_t nu
             prefix.push_back(run);  // non-null rows before this 64-row block
           }
           const int64_t inByte = std::min<int64_t>(8, flatRows - b * 8);
-          run += static_cast<uint32_t>(inByte - __builtin_popcount(page[pos + b]));
+          // rows sit in the byte's top bits; pad bits of the last byte are not rows, whatever they hold
+          const unsigned flags = page[pos + b] & (0xffu << (8 - inByte)) & 0xffu;
+          run += static_cast<uint32_t>(inByte - __builtin_popcount(flags));
         }
         nonNull = run;
         pos += nullBytes;
