@@ -218,9 +218,24 @@ class Q1:
         self.torch, self.n = torch, n
         self.c = gen_q1(torch, n, device, seed)
         c = self.c
+        disc_col = dcol(abi.DOUBLE, c["disc"])
+        null_frac = float(os.environ.get("VX355_Q1_NULLS", "0"))
+        if null_frac > 0:
+            # --q1 with a nullable l_discount (1 bit per row, 1 = valid): the plan must stay on k_agg_fast
+            words = (n + 63) // 64
+            bits = torch.ones(words * 64, dtype=torch.bool, device=device)
+            bits[:n] = torch.rand(n, device=device, generator=torch.Generator(device=device).manual_seed(seed + 99)) >= null_frac
+            weights = (torch.ones(64, dtype=torch.int64, device=device) << torch.arange(64, device=device))
+            self.disc_nulls = torch.zeros(words, dtype=torch.int64, device=device)
+            for lo in range(0, words, 1 << 22):   # pack in slices: the int64 expansion is 8 bytes per bit
+                hi = min(words, lo + (1 << 22))
+                self.disc_nulls[lo:hi] = (bits[lo * 64:hi * 64].view(-1, 64).to(torch.int64) * weights).sum(1)
+            del bits
+            disc_col = ops.DeviceColumn.from_ptr(abi.DOUBLE, c["disc"].data_ptr(), n, self.disc_nulls.data_ptr())
+            self.name = "tpch_q1_sf100_nullable_discount"
         self.scan = DevBatch([dcol(abi.VARCHAR, c["rf"]), dcol(abi.VARCHAR, c["ls"]),
                               dcol(abi.DOUBLE, c["qty"]), dcol(abi.DOUBLE, c["ep"]),
-                              dcol(abi.DOUBLE, c["disc"]), dcol(abi.DOUBLE, c["tax"]),
+                              disc_col, dcol(abi.DOUBLE, c["tax"]),
                               dcol(abi.INTEGER, c["ship"])], n)
         self.idx = torch.empty(n, dtype=torch.int32, device=device)
         self.dp = torch.empty(n, dtype=torch.float64, device=device)
@@ -771,7 +786,7 @@ class C5:
         group by destination, exchange, build; probe side in 4 pipelined chunks. The sink drains
         every chunk's probe into HBM-resident output buffers (mapping, build rows, payload a)."""
         torch = self.torch
-        chunks = 4
+        chunks = int(os.environ.get("VX355_C5_CHUNKS", "4"))
         cap = int(self.n // chunks * 1.25) + (1 << 20)
         if not hasattr(self, "_out"):
             dev = self.fk.device
@@ -1158,10 +1173,14 @@ def main():
         for order in ("dbgen", "random"):
             out["secondary"]["tpch_q3_sf100_join" + ("" if order == "dbgen" else "_random_probe_order")] = \
                 q3_block(torch, device, order == "random", args, copy_ceiling, measure)
+    C.CDLL(None).fflush(None)   # C stdio (RCCL prints a version banner there): the JSON line stays the last line
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    C.CDLL(None).fflush(None)
+    os._exit(0)   # library teardown prints nothing behind the JSON line
 
 
 class GroupDist:

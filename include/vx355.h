@@ -588,7 +588,7 @@ void* vx355_agg_stream(vx355_agg* h);
  * on the device. Null-aware semantics (HashJoinNode::isNullAware) are supported
  * for ANTI and LEFT_SEMI_PROJECT, isNullAsValue keys (IS NOT DISTINCT FROM) for every kind;
  * null-aware RIGHT_SEMI_PROJECT returns VX355_EUNSUPPORTED at create. An extra join filter
- * (vx355_join_probe_set_filter) works with every kind except the two counting
+ * (vx355_join_probe_set_filter) works with every kind, null aware or not, except the two counting
  * ones (the reference has none there either, HashProbe.cpp:1345-1365). Build and
  * probe must be created with the same join type. Counting joins keep one
  * remaining-count per distinct build key in the table: probe them from one
@@ -704,7 +704,9 @@ typedef struct vx355_join_probe_spec {
   int32_t num_keys;
   const int32_t* key_cols; /* probe-side key columns */
   int32_t join_type;
-  int32_t null_aware; /* ANTI (NOT IN) and LEFT_SEMI_PROJECT (IN as a column), without an extra filter */
+  int32_t null_aware; /* ANTI (NOT IN) and LEFT_SEMI_PROJECT (IN as a column); with an extra filter the
+                         result follows HashProbe::evalFilterForNullAwareJoin (exec/HashProbe.cpp:1639-1700):
+                         three-valued IN over the build rows that pass the filter */
   int32_t null_as_value; /* must equal the build side's */
   int32_t pad;
 } vx355_join_probe_spec;
@@ -865,6 +867,12 @@ int vx355_exchange_create(vx355_comm* c, const int32_t* col_types, int32_t num_c
                           int32_t num_keys, vx355_exchange** out);
 int vx355_exchange_send(vx355_exchange* x, const vx355_batch* batch);
 int vx355_exchange_receive(vx355_exchange* x, vx355_column* cols_out /* num_cols */, int64_t* rows_out);
+/* The destination rank of every row of 'batch' as the edge computes it for num_destinations ranks
+ * (0 = the communicator's size): VectorHasher::hash of the key columns fused with
+ * HashPartitionFunction::partition, i.e. what vx355_exchange_send groups by. out: num_rows entries
+ * in out_mem. (Inspection; lets a 1-GPU box check the N > 1 grouping against the CPU hash.) */
+int vx355_exchange_destinations(vx355_exchange* x, const vx355_batch* batch, int32_t num_destinations,
+                                uint32_t* out, int32_t out_mem);
 void* vx355_exchange_stream(vx355_exchange* x);
 void vx355_exchange_destroy(vx355_exchange* x);
 

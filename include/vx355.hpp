@@ -97,6 +97,7 @@ class HashAggregation {
     return n;
   }
   bool isFinished() const { return finished_; }
+  vx355_agg* handle() const { return handle_; }  // for the entry points that take the handle (mergePartials)
   vx355_agg_stats stats() const {
     vx355_agg_stats s{};
     check(vx355_agg_get_stats(handle_, &s));
@@ -303,6 +304,96 @@ class HashProbe {
   bool drained_ = true;
   bool buildSideDone_ = false;
 };
+
+// ---- multi-GPU (vx355.h "multi-GPU exchange"): one Communicator per GPU ---------------------------
+class Communicator {
+ public:
+  // one process per GPU: the id comes from uniqueId() on rank 0 and travels out of band
+  Communicator(const std::vector<char>& id, int32_t world, int32_t rank) {
+    check(vx355_comm_create(id.data(), world, rank, &handle_));
+  }
+  Communicator(const Communicator&) = delete;
+  Communicator& operator=(const Communicator&) = delete;
+  ~Communicator() { vx355_comm_destroy(handle_); }
+  static std::vector<char> uniqueId() {
+    std::vector<char> id(VX355_COMM_ID_BYTES);
+    check(vx355_comm_get_unique_id(id.data()));
+    return id;
+  }
+  int32_t worldSize() const {  // as RCCL reports it
+    int32_t world = 0;
+    check(vx355_comm_info(handle_, &world, nullptr, nullptr));
+    return world;
+  }
+  vx355_comm* get() const { return handle_; }
+
+ private:
+  vx355_comm* handle_ = nullptr;
+};
+
+// One PartitionedOutput(keys) -> Exchange edge of a repartitioned plan (vx355_exchange_*).
+class Exchange {
+ public:
+  Exchange(Communicator& comm, std::vector<int32_t> columnTypes, std::vector<int32_t> keyChannels)
+      : types_(std::move(columnTypes)), keys_(std::move(keyChannels)) {
+    check(vx355_exchange_create(comm.get(), types_.data(), static_cast<int32_t>(types_.size()), keys_.data(),
+                                static_cast<int32_t>(keys_.size()), &handle_));
+  }
+  Exchange(const Exchange&) = delete;
+  Exchange& operator=(const Exchange&) = delete;
+  ~Exchange() { vx355_exchange_destroy(handle_); }
+  // PartitionedOutput::addInput: returns while the slices are on the links (two may be in flight)
+  void send(const vx355_batch& input) { check(vx355_exchange_send(handle_, &input)); }
+  // Exchange::getOutput: the rows that landed here, as device columns valid until the next receive
+  vx355_batch receive(std::vector<vx355_column>& columns) {
+    columns.resize(types_.size());
+    int64_t rows = 0;
+    check(vx355_exchange_receive(handle_, columns.data(), &rows));
+    return vx355_batch{static_cast<int32_t>(rows), static_cast<int32_t>(columns.size()), columns.data()};
+  }
+
+ private:
+  std::vector<int32_t> types_, keys_;
+  vx355_exchange* handle_ = nullptr;
+};
+
+// BASELINE config 5 in one call (vx355_join_repartition): sink(chunk, received rows, probe handle)
+// drains the probe of every chunk. F: void(int32_t, const vx355_batch&, vx355_join_probe*).
+template <typename F>
+JoinTable repartitionedJoin(Communicator& comm, const vx355_join_build_spec& buildSpec, const vx355_batch& buildRows,
+                            const vx355_join_probe_spec& probeSpec, const vx355_batch& probeRows, int32_t chunks,
+                            F&& sink) {
+  struct Thunk {
+    F* f;
+    std::string error;
+    static int call(void* arg, int32_t chunk, const vx355_batch* received, vx355_join_probe* probe) {
+      auto* self = static_cast<Thunk*>(arg);
+      try {
+        (*self->f)(chunk, *received, probe);
+        return VX355_OK;
+      } catch (const std::exception& e) {  // no exception crosses the C frames
+        self->error = e.what();
+        return VX355_EINTERNAL;
+      }
+    }
+  } thunk{&sink, {}};
+  vx355_join_table* table = nullptr;
+  const int status = vx355_join_repartition(comm.get(), &buildSpec, &buildRows, &probeSpec, &probeRows, chunks,
+                                            &Thunk::call, &thunk, &table);
+  if (!thunk.error.empty()) {
+    throw RuntimeError(VX355_EINTERNAL, thunk.error);
+  }
+  check(status);
+  return JoinTable(table);
+}
+
+// partial -> PrestoPages -> every rank -> final (vx355_agg_merge_partials): the returned handle has
+// consumed all ranks' partial rows; drain it with vx355_agg_get_output, then vx355_agg_destroy.
+inline vx355_agg* mergePartials(Communicator& comm, vx355_agg* partial, const vx355_agg_spec& finalSpec) {
+  vx355_agg* fin = nullptr;
+  check(vx355_agg_merge_partials(comm.get(), partial, &finalSpec, &fin));
+  return fin;
+}
 
 }  // namespace vx355
 

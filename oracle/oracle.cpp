@@ -687,7 +687,7 @@ class Aggregation {
 class JoinBuild {
  public:
   explicit JoinBuild(const vx355_join_build_spec& spec)
-      : joinType_(spec.join_type), nullAsValue_(spec.null_as_value != 0) {
+      : joinType_(spec.join_type), nullAsValue_(spec.null_as_value != 0), nullAware_(spec.null_aware != 0) {
     keyCols_.assign(spec.key_cols, spec.key_cols + spec.num_keys);
     keyKinds_.assign(spec.key_types, spec.key_types + spec.num_keys);
     depCols_.assign(spec.dependent_cols, spec.dependent_cols + spec.num_dependents);
@@ -717,8 +717,11 @@ class JoinBuild {
     // build rows all reach the output (HashBuild.cpp:475-494).
     // (HashBuild.cpp:257-268: right, full, right semi project and right anti retain null keys)
     // ... and so does nullAsValue (HashBuild.cpp:273,477): there the rows are ordinary table entries
+    // ... and a null-aware join: with an extra filter its null-key build rows take part in the
+    // result (HashBuild.cpp:257-268 keeps them unless "anti join, null aware, no filter";
+    // HashProbe::evalFilterForNullAwareJoin, HashProbe.cpp:1639-1700, lists them)
     const bool keepNullKeys = joinType_ == VX355_JOIN_RIGHT || joinType_ == VX355_JOIN_FULL ||
-        joinType_ == VX355_JOIN_RIGHT_SEMI_PROJECT || joinType_ == VX355_JOIN_RIGHT_ANTI || nullAsValue_;
+        joinType_ == VX355_JOIN_RIGHT_SEMI_PROJECT || joinType_ == VX355_JOIN_RIGHT_ANTI || nullAsValue_ || nullAware_;
     for (auto& d : keys) {
       for (int32_t r = 0; r < n; ++r) {
         if (d.isNull(r)) {
@@ -743,6 +746,7 @@ class JoinBuild {
   std::vector<int32_t> keyCols_, keyKinds_, depCols_, depKinds_;
   int32_t joinType_;
   bool nullAsValue_ = false;
+  bool nullAware_ = false;
   bool hasNullKeys_ = false;
 };
 
@@ -850,6 +854,56 @@ class JoinProbe {
         }
         if (consumed == (joinType_ == VX355_JOIN_COUNTING_LEFT_SEMI_FILTER)) {
           emit(n++, cursorRow_, nullptr, mapping, buildRows, cols, colIds, numCols);
+        }
+        ++cursorRow_;
+        continue;
+      }
+      if (nullAware_ && !filter_.empty() &&
+          (joinType_ == VX355_JOIN_ANTI || joinType_ == VX355_JOIN_LEFT_SEMI_PROJECT)) {
+        // HashProbe::evalFilter + evalFilterForNullAwareJoin (HashProbe.cpp:1639-1700,1826-1890):
+        //   TRUE  = some build row with an equal key passes the filter;
+        //   NULL  = none does, but the filter passes on some build row whose key is null (probe key
+        //           not null: nullKeyProbeRows x listNullKeyRows) or on ANY build row (probe key
+        //           null: crossJoinProbeRows x listAllRows);
+        //   FALSE = neither. A null probe-side filter input makes the filter NULL for every pair
+        //           (filterPropagateNulls): passes() is false for all of them, the row is FALSE.
+        bool nullKey = false;
+        for (auto& k : keys_) {
+          nullKey = nullKey || k.isNull(cursorRow_);
+        }
+        char* first = nullptr;
+        for (char* cur = nullKey ? nullptr : hit; cur && !first; cur = table_->table->nextRow(cur)) {
+          if (passes(cursorRow_, cur)) {
+            first = cur;
+          }
+        }
+        bool isNull = false;
+        if (!first) {
+          for (auto* container : table_->containers) {
+            for (char* row : container->rows()) {
+              bool rowKeyNull = false;
+              for (const auto& col : container->keys()) {
+                rowKeyNull = rowKeyNull || row[col.nullOffset] != 0;
+              }
+              if ((nullKey || rowKeyNull) && passes(cursorRow_, row)) {
+                isNull = true;
+                break;
+              }
+            }
+            if (isNull) {
+              break;
+            }
+          }
+        }
+        if (joinType_ == VX355_JOIN_ANTI) {
+          if (!first && !isNull) {
+            emit(n++, cursorRow_, nullptr, mapping, buildRows, cols, colIds, numCols);
+          }
+        } else {
+          emit(n++, cursorRow_, nullptr, mapping, buildRows, cols, colIds, numCols);
+          if (buildRows) {
+            buildRows[n - 1] = first ? static_cast<int32_t>(rowId(first)) : (isNull ? -2 : -1);
+          }
         }
         ++cursorRow_;
         continue;

@@ -313,9 +313,118 @@ int testDistinctAndPages() {
 
 }  // namespace
 
+// The multi-GPU orchestration a C++ host calls, at the world size one GPU
+// offers: partial -> final merge through vx355_agg_merge_partials and the repartitioned join of
+// BASELINE config 5 through vx355_join_repartition, checked against straight C++.
+int testDistributedEntryPoints() {
+  vx355::Communicator comm(vx355::Communicator::uniqueId(), 1, 0);
+  EXPECT(comm.worldSize() == 1);
+  std::mt19937_64 rng(23);
+  const int kRows = 50000, kGroups = 37;
+  std::vector<int64_t> keys(kRows), vals(kRows);
+  std::map<int64_t, std::pair<int64_t, int64_t>> want;  // key -> (sum, count)
+  for (int i = 0; i < kRows; ++i) {
+    keys[i] = int64_t(rng() % kGroups) * 1000003;
+    vals[i] = int64_t(rng() % 100000) - 50000;
+    want[keys[i]].first += vals[i];
+    want[keys[i]].second += 1;
+  }
+  vx355_column cols[2] = {flat(VX355_BIGINT, keys.data()), flat(VX355_BIGINT, vals.data())};
+  vx355::HashAggregation partial({0}, {VX355_BIGINT},
+                                 {{VX355_AGG_SUM, 1, -1, VX355_BIGINT, -1, 0}, {VX355_AGG_COUNT_STAR, -1, -1, VX355_BIGINT, -1, 0}},
+                                 VX355_STEP_PARTIAL);
+  partial.addInput(vx355_batch{kRows, 2, cols});
+  partial.noMoreInput();
+  const int32_t keyCol = 0, keyType = VX355_BIGINT;
+  const vx355_agg_fn finalAggs[2] = {{VX355_AGG_SUM, 1, -1, VX355_BIGINT, -1, 0}, {VX355_AGG_COUNT, 2, -1, VX355_BIGINT, -1, 0}};
+  vx355_agg_spec finalSpec{};
+  finalSpec.num_keys = 1;
+  finalSpec.key_cols = &keyCol;
+  finalSpec.key_types = &keyType;
+  finalSpec.num_aggs = 2;
+  finalSpec.aggs = finalAggs;
+  finalSpec.step = VX355_STEP_FINAL;
+  vx355_agg* merged = vx355::mergePartials(comm, partial.handle(), finalSpec);
+  std::vector<int64_t> outKey(kGroups), outSum(kGroups), outCount(kGroups);
+  std::vector<uint64_t> valid(3, 0);
+  vx355_out_column out[3] = {{VX355_BIGINT, VX355_MEM_HOST, outKey.data(), &valid[0]},
+                             {VX355_BIGINT, VX355_MEM_HOST, outSum.data(), &valid[1]},
+                             {VX355_BIGINT, VX355_MEM_HOST, outCount.data(), &valid[2]}};
+  int32_t n = 0, finished = 0;
+  vx355::check(vx355_agg_get_output(merged, out, 3, kGroups, &n, &finished));
+  vx355_agg_destroy(merged);
+  EXPECT(n == int32_t(want.size()) && finished == 1);
+  for (int32_t i = 0; i < n; ++i) {
+    EXPECT(want.count(outKey[i]) == 1 && want[outKey[i]].first == outSum[i] && want[outKey[i]].second == outCount[i]);
+  }
+  // repartitioned join: dim(pk unique, a) x fact(fk, m), probe side in 3 pipelined chunks
+  const int kDim = 4000, kFact = 30000;
+  std::vector<int64_t> pk(kDim), a(kDim), fk(kFact), m(kFact);
+  std::map<int64_t, int64_t> dim;
+  for (int i = 0; i < kDim; ++i) {
+    pk[i] = int64_t(i) * 7919 + 11;
+    a[i] = int64_t(rng() >> 20);
+    dim[pk[i]] = a[i];
+  }
+  for (int i = 0; i < kFact; ++i) {
+    fk[i] = (rng() % 10 == 0) ? -5 : pk[rng() % kDim];
+    m[i] = i;
+  }
+  vx355_column buildCols[2] = {flat(VX355_BIGINT, pk.data()), flat(VX355_BIGINT, a.data())};
+  vx355_column probeCols[2] = {flat(VX355_BIGINT, fk.data()), flat(VX355_BIGINT, m.data())};
+  const int32_t zero = 0, one = 1, bigint = VX355_BIGINT;
+  vx355_join_build_spec buildSpec{};
+  buildSpec.num_keys = 1;
+  buildSpec.key_cols = &zero;
+  buildSpec.key_types = &bigint;
+  buildSpec.num_dependents = 1;
+  buildSpec.dependent_cols = &one;
+  buildSpec.dependent_types = &bigint;
+  buildSpec.join_type = VX355_JOIN_INNER;
+  vx355_join_probe_spec probeSpec{};
+  probeSpec.num_keys = 1;
+  probeSpec.key_cols = &zero;
+  probeSpec.join_type = VX355_JOIN_INNER;
+  int64_t matches = 0, chunksSeen = 0;
+  bool wrong = false;
+  vx355::JoinTable table = vx355::repartitionedJoin(
+      comm, buildSpec, vx355_batch{kDim, 2, buildCols}, probeSpec, vx355_batch{kFact, 2, probeCols}, 3,
+      [&](int32_t chunk, const vx355_batch& received, vx355_join_probe* probe) {
+        wrong = wrong || chunk != chunksSeen;
+        ++chunksSeen;
+        std::vector<int64_t> keysHere(received.num_rows);
+        vx355::check(vx355_memcpy_d2h(keysHere.data(), received.cols[0].values, size_t(received.num_rows) * 8));
+        std::vector<int32_t> mapping(1000), buildRows(1000);
+        std::vector<int64_t> payload(1000);
+        uint64_t payloadValid[16];
+        vx355_out_column payloadCol{VX355_BIGINT, VX355_MEM_HOST, payload.data(), payloadValid};
+        for (;;) {
+          int32_t got = 0, fin = 0;
+          vx355::check(vx355_join_probe_get_output(probe, 1000, mapping.data(), buildRows.data(), VX355_MEM_HOST,
+                                                   &payloadCol, &zero, 1, &got, &fin));
+          for (int32_t i = 0; i < got; ++i) {
+            wrong = wrong || dim.at(keysHere[mapping[i]]) != payload[i];
+          }
+          matches += got;
+          if (fin) {
+            break;
+          }
+        }
+      });
+  int64_t expected = 0;
+  for (int i = 0; i < kFact; ++i) {
+    expected += dim.count(fk[i]);
+  }
+  EXPECT(!wrong && chunksSeen == 3 && matches == expected && table.stats().num_rows == kDim);
+  return 0;
+}
+
 int main() {
   try {
     vx355::init(0);
+    if (testDistributedEntryPoints()) {
+      return 1;
+    }
     if (testAggregation()) {
       return 1;
     }

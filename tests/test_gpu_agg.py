@@ -597,11 +597,12 @@ def test_async_instantiation_does_not_stall_the_first_batches(oracle, vx, monkey
     assert_columns_equal(got, exp, op.kinds, what="async jit")
 
 
-def test_dictionary_wrapped_device_inputs_take_the_specialised_kernel(oracle, vx):
+def test_dictionary_wrapped_device_inputs_take_the_specialised_kernel(oracle, vx, monkeypatch):
     """The unfused Velox pipeline: FilterProject hands HashAggregation columns
     wrapped in ONE shared index vector plus flat computed columns, all in HBM.
     That shape is instantiated through hiprtc (IND mask) instead of falling back
     to the interpreting kernel."""
+    monkeypatch.setenv("VX355_JIT", "sync")   # (the default compiles in the background)
     rng = np.random.default_rng(303)
     n = 400000
     scan, cols = _q1_scan_batch(rng, n)
@@ -632,6 +633,51 @@ def test_dictionary_wrapped_device_inputs_take_the_specialised_kernel(oracle, vx
     vx.profile_enable(False)
     assert_columns_equal(got, exp, gop.kinds, what="dictionary wrapped")
     assert "k_agg_fast" in vx.profile() and gop.stats().reserved > 0
+
+
+@pytest.mark.parametrize("ignore_null_keys", [False, True])
+def test_nullable_columns_stay_on_the_specialised_kernel(oracle, vx, monkeypatch, ignore_null_keys):
+    """TPC-H Q1 with nulls in a key, in the filter column and in two aggregate inputs: the plan keeps
+    its shape-specialised kernel (null bitmaps are one bit per row: FastShape::NUL) instead of
+    dropping to the interpreting kernel; a null key is a group of its own (or drops the row with
+    ignoreNullKeys), a null filter input fails the filter, a null input skips its accumulators
+    (sum / avg / count of non-null) - SimpleNumericAggregate.h:94-160 in the same pass."""
+    monkeypatch.setenv("VX355_JIT", "sync")
+    rng = np.random.default_rng(505)
+    n = 300_000
+    scan, cols = _q1_scan_batch(rng, n)
+    rf, ls, qty, ep, disc, tax, ship = cols
+    valid = [rng.random(n) > p for p in (0.03, 0.0, 0.0, 0.01, 0.02, 0.0, 0.015)]
+    valid[1] = valid[2] = valid[5] = None
+    host = batch_of(list(cols), valid)
+    P = vx.PROJ
+    aggs = [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_SUM, 3, abi.DOUBLE), (abi.AGG_SUM, P(0), abi.DOUBLE),
+            (abi.AGG_SUM, P(1), abi.DOUBLE), (abi.AGG_AVG, 2, abi.DOUBLE), (abi.AGG_AVG, 3, abi.DOUBLE),
+            (abi.AGG_AVG, 4, abi.DOUBLE), (abi.AGG_COUNT, 4, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    # reference: FilterProject, then HashAggregation over its output, both on the oracle
+    idx, proj, pnulls = oracle.filter_project(host, Q1_TERMS, Q1_PROJ, with_nulls=True)
+
+    def take(c, v):
+        picked = [c[i] for i in idx] if isinstance(c, list) else np.asarray(c)[idx]
+        return picked, (None if v is None else np.asarray(v)[idx])
+    picked = [take(c, v) for c, v in zip(cols, valid)]
+    ref = batch_of([p[0] for p in picked[:5]] + [proj[0], proj[1]],
+                   [p[1] for p in picked[:5]] + [pnulls[0], pnulls[1]])
+    ref_aggs = [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_SUM, 3, abi.DOUBLE), (abi.AGG_SUM, 5, abi.DOUBLE),
+                (abi.AGG_SUM, 6, abi.DOUBLE), (abi.AGG_AVG, 2, abi.DOUBLE), (abi.AGG_AVG, 3, abi.DOUBLE),
+                (abi.AGG_AVG, 4, abi.DOUBLE), (abi.AGG_COUNT, 4, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    exp, _ = run_agg(oracle, [ref], [0, 1], [abi.VARCHAR, abi.VARCHAR], ref_aggs, ignore_null_keys=ignore_null_keys)
+    op = vx.Aggregation([0, 1], [abi.VARCHAR, abi.VARCHAR], aggs, ignore_null_keys=ignore_null_keys)
+    op.set_fused_input(Q1_TERMS, Q1_PROJ)
+    vx.profile_reset()
+    vx.profile_enable(True)
+    op.add_input(vx.to_device(host))
+    op.no_more_input()
+    got = vx.collect_output(op, 100)
+    vx.profile_enable(False)
+    assert_columns_equal(got, exp, op.kinds, what="nullable fast shape")   # dyadic data: exact sums
+    names = vx.profile()
+    assert "k_agg_fast" in names and "k_agg_lds" not in names and op.stats().reserved > 0
 
 
 def test_distinct_without_aggregates_and_drain_in_small_pages(oracle, vx):

@@ -60,6 +60,28 @@ def test_exchange_edge_round_trip_and_pipelining(vx):
     assert e.value.status == abi.EUNSUPPORTED
 
 
+@pytest.mark.parametrize("world", [2, 3, 4, 8, 7])
+def test_exchange_destinations_equal_the_cpu_hash_partition(oracle, vx, world):
+    """What the edge groups by at N > 1 (the fused hash + partition kernel) against the oracle's
+    VectorHasher::hash and HashPartitionFunction::partition: top hash bits for powers of two,
+    hash % world otherwise; one and two key columns, host and device batches."""
+    rng = np.random.default_rng(world)
+    n = 50_001
+    k1 = rng.integers(-2 ** 50, 2 ** 50, n).astype(np.int64)
+    k2 = rng.integers(0, 1000, n).astype(np.int32)
+    v = rng.random(n)
+    comm = vx.Comm(vx.Comm.unique_id(), 1, 0)
+    for key_cols in ([0], [0, 1]):
+        ex = vx.Exchange(comm, [abi.BIGINT, abi.INTEGER, abi.DOUBLE], key_cols)
+        batch = batch_of([k1, k2, v])
+        hashes = oracle.hash_columns(batch, key_cols)
+        kind, kw = vdist.partition_spec(world)
+        want = oracle.partition(hashes, kind, **kw)
+        assert (ex.destinations(batch, world) == want).all()
+        assert (ex.destinations(vx.to_device(batch), world) == want).all()
+        assert len(np.unique(want)) == world
+
+
 def test_join_repartition_matches_the_oracle_join(oracle, vx):
     """vx355_join_repartition (exchange + build, then the probe side in pipelined chunks through
     the sink) against the oracle's join of the same rows."""

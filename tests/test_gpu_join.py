@@ -696,10 +696,8 @@ def test_unsupported_join_flavours_are_refused_at_create(vx):
     assert e.value.status == abi.EUNSUPPORTED
     with pytest.raises(vx.Vx355Error):
         vx.JoinProbe(t, [0], abi.JOIN_INNER)               # counting table, non-counting probe
-    p2 = vx.JoinProbe(vx.JoinBuild([0], [abi.BIGINT], [], [], abi.JOIN_LEFT_SEMI_PROJECT, null_aware=True).finish(), [0],
-                      abi.JOIN_LEFT_SEMI_PROJECT, True)
-    with pytest.raises(vx.Vx355Error) as e:
-        p2.set_filter([(("probe", 0), abi.CMP_LT, 5)])     # null aware + extra filter
+    with pytest.raises(vx.Vx355Error) as e:                # null aware exists for ANTI and LEFT_SEMI_PROJECT
+        vx.JoinBuild([0], [abi.BIGINT], [], [], abi.JOIN_RIGHT_SEMI_PROJECT, null_aware=True)
     assert e.value.status == abi.EUNSUPPORTED
 
 
@@ -939,3 +937,30 @@ def test_null_as_value_excludes_null_aware_and_must_match_the_table(vx):
     with pytest.raises(vx.Vx355Error) as e:
         vx.JoinProbe(t, [0], abi.JOIN_INNER)
     assert e.value.status == abi.EINVAL
+
+
+@pytest.mark.parametrize("build_nulls", [0.0, 0.1, 1.0])
+@pytest.mark.parametrize("join_type", [abi.JOIN_ANTI, abi.JOIN_LEFT_SEMI_PROJECT])
+def test_null_aware_joins_with_extra_filter(oracle, vx, join_type, build_nulls):
+    """x [NOT] IN (SELECT y FROM build WHERE probe.v < build.w), HashProbe::evalFilterForNullAwareJoin
+    (HashProbe.cpp:1639-1700): rows without a passing equal-key pair meet the null-key build rows
+    (key not null) or every build row (key null). GPU == oracle == SQL's three-valued logic, two
+    build drivers, output drained in small pages; larger case GPU == oracle."""
+    from test_oracle_ops import null_aware_filter_case, run_null_aware_filter_join, sql_in_with_filter
+    case = null_aware_filter_case(91 + join_type, build_nulls=build_nulls)
+    bk, bvalid, bw, bwvalid, pk, pvalid, pv, pvvalid = case
+    truth = sql_in_with_filter(pk, pvalid, pv, pvvalid, bk, bvalid, bw, bwvalid)
+    got = run_null_aware_filter_join(vx, join_type, case)
+    exp = run_null_aware_filter_join(oracle, join_type, case)
+    if join_type == abi.JOIN_ANTI:
+        assert got == exp and [i for i, _ in got] == [i for i, t in enumerate(truth) if t is False]
+    else:
+        state = lambda r: True if r >= 0 else (None if r == -2 else False)   # which match is reported is chain order
+        assert [(i, state(r)) for i, r in got] == [(i, state(r)) for i, r in exp] == list(enumerate(truth))
+    big = null_aware_filter_case(191 + join_type, nb=3000, npb=60000, build_nulls=build_nulls)
+    got = run_null_aware_filter_join(vx, join_type, big, max_rows=7777)
+    exp = run_null_aware_filter_join(oracle, join_type, big, max_rows=7777)
+    if join_type == abi.JOIN_ANTI:
+        assert got == exp
+    else:
+        assert [(i, min(r, 0)) for i, r in got] == [(i, min(r, 0)) for i, r in exp]

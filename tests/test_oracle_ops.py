@@ -906,3 +906,75 @@ def test_double_comparisons_order_nan_like_the_reference(oracle):
     assert sel(abi.CMP_GT, nan) == [] and sel(abi.CMP_GE, nan) == [1, 5]
     assert sel(abi.CMP_GT, np.inf) == [1, 5] and sel(abi.CMP_GE, np.inf) == [1, 2, 5]
     assert sel(abi.CMP_LT, 1.0) == [3, 4] and sel(abi.CMP_LE, 1.0) == [0, 3, 4]
+
+
+def sql_in_with_filter(pk, pvalid, pv, pvvalid, bk, bvalid, bw, bwvalid):
+    """Three-valued `x IN (SELECT y FROM build WHERE probe.v < build.w)` per probe row, straight from
+    SQL: TRUE if some filtered y equals x; else FALSE if no build row passes the filter; else NULL if
+    x is null or some filtered y is null; else FALSE. -> list of True / False / None."""
+    out = []
+    for i in range(len(pk)):
+        passing = [j for j in range(len(bk)) if pvvalid[i] and bwvalid[j] and pv[i] < bw[j]]
+        if pvalid[i] and any(bvalid[j] and bk[j] == pk[i] for j in passing):
+            out.append(True)
+        elif not passing:
+            out.append(False)
+        elif not pvalid[i] or any(not bvalid[j] for j in passing):
+            out.append(None)
+        else:
+            out.append(False)
+    return out
+
+
+def null_aware_filter_case(seed, nb=120, npb=400, build_nulls=0.1):
+    rng = np.random.default_rng(seed)
+    bk = rng.integers(0, 40, nb).astype(np.int64)
+    bvalid = rng.random(nb) >= build_nulls
+    bw = rng.integers(0, 100, nb).astype(np.int64)
+    bwvalid = rng.random(nb) > 0.1
+    pk = rng.integers(-5, 50, npb).astype(np.int64)
+    pvalid = rng.random(npb) > 0.1
+    pv = rng.integers(0, 110, npb).astype(np.int64)     # some values pass no build row at all
+    pvvalid = rng.random(npb) > 0.1
+    return bk, bvalid, bw, bwvalid, pk, pvalid, pv, pvvalid
+
+
+def run_null_aware_filter_join(impl, join_type, case, max_rows=53):
+    bk, bvalid, bw, bwvalid, pk, pvalid, pv, pvvalid = case
+    h = len(bk) // 2
+    builds = []
+    for lo, hi in ((0, h), (h, len(bk))):
+        b = impl.JoinBuild([0], [abi.BIGINT], [1], [abi.BIGINT], join_type, True)
+        b.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, bk[lo:hi], bvalid[lo:hi]),
+                                   abi.HostColumn(abi.BIGINT, bw[lo:hi], bwvalid[lo:hi])]))
+        builds.append(b)
+    table = builds[0].finish(builds[1:])
+    p = impl.JoinProbe(table, [0], join_type, True)
+    p.set_filter([(("probe", 1), abi.CMP_LT, ("build", 0))])
+    p.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, pk, pvalid), abi.HostColumn(abi.BIGINT, pv, pvvalid)]))
+    pairs = []
+    while True:
+        m, r, cols, fin = p.get_output(max_rows, [])
+        pairs += list(zip(m.tolist(), r.tolist()))
+        if fin:
+            break
+    return pairs
+
+
+@pytest.mark.parametrize("build_nulls", [0.0, 0.1, 1.0])
+@pytest.mark.parametrize("join_type", [abi.JOIN_ANTI, abi.JOIN_LEFT_SEMI_PROJECT])
+def test_oracle_null_aware_joins_with_extra_filter_follow_sql(oracle, join_type, build_nulls):
+    """HashProbe::evalFilterForNullAwareJoin (HashProbe.cpp:1639-1700) restated in the oracle against
+    SQL's three-valued IN / NOT IN over the filtered subquery: null-key probe rows meet every build
+    row, unmatched rows meet the null-key build rows."""
+    case = null_aware_filter_case(77 + join_type, build_nulls=build_nulls)
+    bk, bvalid, bw, bwvalid, pk, pvalid, pv, pvvalid = case
+    truth = sql_in_with_filter(pk, pvalid, pv, pvvalid, bk, bvalid, bw, bwvalid)
+    pairs = run_null_aware_filter_join(oracle, join_type, case)
+    if join_type == abi.JOIN_ANTI:
+        assert [i for i, _ in pairs] == [i for i, t in enumerate(truth) if t is False]   # NOT IN is TRUE
+    else:
+        assert [i for i, _ in pairs] == list(range(len(pk)))
+        got = [True if r >= 0 else (None if r == -2 else False) for _, r in pairs]
+        assert got == truth
+    assert {True, False, None} <= set(truth) or build_nulls in (0.0, 1.0)

@@ -133,6 +133,160 @@ __global__ __launch_bounds__(256) void k_tagline(const uint64_t* keys, int64_t n
   }
 }
 
+
+// ---- bucket shapes for the generic (kHash) mode: key confirmation included -----------------------
+// All three read, per probe, (1) the slot / tag group at a hashed position, (2) the row id it
+// names (dependent), (3) the 16-byte key image of that row (dependent) and compare it — what a
+// hit costs when keys have no 64-bit normalized form (strings, wide key sets). The table is not
+// really built: the "matching" slot of a bucket and the row it names are derived from the hash,
+// which keeps the access pattern and the dependency chain of a real probe.
+//   slotkey : the library's layout — one 8-byte {tag32, row} slot per lane, then the key image
+//   tagswar : F14-shaped bucket (16 one-byte tags + 16 four-byte row ids in one 128-byte line,
+//             exec/HashTable.h:897-930), ONE LANE per probe: 16-byte tag load, SWAR compare
+//   taggroup<G>: the same bucket, G lanes per probe (8 or 16): every lane loads 16 / G tag bytes,
+//             a ballot restricted to the group finds the match, one lane fetches id and key
+template <int U>
+__global__ __launch_bounds__(256) void k_slotkey(const uint64_t* keys, int64_t n, const uint32_t* table,
+                                                 uint64_t tableWords, uint32_t* out) {
+  const uint64_t slotBytes = tableWords * 4 / 3;              // a third of the area: slots; the rest: key images
+  const uint64_t numSlots = slotBytes / 8;
+  const uint64_t numKeys = (tableWords * 4 - slotBytes) / 16;
+  const uint64_t* slots = reinterpret_cast<const uint64_t*>(table);
+  const uint4* images = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(table) + slotBytes);
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * 256 * U;
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * 256 * U; base < n; base += stride) {
+    uint64_t h[U], s[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = base + u * 256 + threadIdx.x;
+      h[u] = mix(keys[i < n ? i : n - 1]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      s[u] = slots[h[u] % numSlots];
+    }
+    uint4 img[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      img[u] = images[mix(s[u] ^ h[u]) % numKeys];  // row named by the slot
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = base + u * 256 + threadIdx.x;
+      if (i < n) {
+        out[i] = (img[u].x == static_cast<uint32_t>(h[u])) + img[u].y + img[u].z + img[u].w;
+      }
+    }
+  }
+}
+
+template <int U>
+__global__ __launch_bounds__(256) void k_tagswar(const uint64_t* keys, int64_t n, const uint32_t* table,
+                                                 uint64_t tableWords, uint32_t* out) {
+  const uint64_t bucketBytes = tableWords * 4 / 3;
+  const uint64_t numBuckets = bucketBytes / 128;
+  const uint64_t numKeys = (tableWords * 4 - bucketBytes) / 16;
+  const char* buckets = reinterpret_cast<const char*>(table);
+  const uint4* images = reinterpret_cast<const uint4*>(buckets + bucketBytes);
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * 256 * U;
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * 256 * U; base < n; base += stride) {
+    uint64_t h[U];
+    uint4 tags[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = base + u * 256 + threadIdx.x;
+      h[u] = mix(keys[i < n ? i : n - 1]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      tags[u] = *reinterpret_cast<const uint4*>(buckets + (h[u] % numBuckets) * 128);
+    }
+    uint32_t id[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      // SWAR: which of the 16 tag bytes equal the probe's tag (the table holds 0x5a everywhere, so
+      // every byte "matches"; the hash picks which match is taken, as a real probe takes the first)
+      const uint32_t want = 0x5a5a5a5au;
+      uint32_t hits = 0;
+      const uint32_t w[4] = {tags[u].x, tags[u].y, tags[u].z, tags[u].w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t x = w[q] ^ want;
+        const uint32_t zero = (x - 0x01010101u) & ~x & 0x80808080u;   // 0x80 in every byte that is zero
+        hits |= ((zero >> 7) & 1) << (4 * q) | ((zero >> 15) & 1) << (4 * q + 1) | ((zero >> 23) & 1) << (4 * q + 2) |
+            ((zero >> 31) & 1) << (4 * q + 3);
+      }
+      const uint32_t slot = (hits ? static_cast<uint32_t>(h[u] >> 20) : 0u) & 15u;
+      id[u] = *reinterpret_cast<const uint32_t*>(buckets + (h[u] % numBuckets) * 128 + 16 + slot * 4);
+    }
+    uint4 img[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      img[u] = images[mix(id[u] ^ h[u]) % numKeys];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = base + u * 256 + threadIdx.x;
+      if (i < n) {
+        out[i] = (img[u].x == static_cast<uint32_t>(h[u])) + img[u].y + img[u].z + img[u].w;
+      }
+    }
+  }
+}
+
+template <int G, int U>
+__global__ __launch_bounds__(256) void k_taggroup(const uint64_t* keys, int64_t n, const uint32_t* table,
+                                                  uint64_t tableWords, uint32_t* out) {
+  constexpr int kPerWave = 64 / G;            // probes a wave works on at once
+  const uint64_t bucketBytes = tableWords * 4 / 3;
+  const uint64_t numBuckets = bucketBytes / 128;
+  const uint64_t numKeys = (tableWords * 4 - bucketBytes) / 16;
+  const char* buckets = reinterpret_cast<const char*>(table);
+  const uint4* images = reinterpret_cast<const uint4*>(buckets + bucketBytes);
+  const int ln = threadIdx.x & 63;
+  const int group = ln / G, inGroup = ln % G;
+  const int64_t wave = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) >> 6;
+  const int64_t waves = static_cast<int64_t>(gridDim.x) * 4;
+  for (int64_t base = wave * 64; base < n; base += waves * 64) {
+    const uint64_t mine = keys[base + ln < n ? base + ln : n - 1];
+    uint32_t result = 0;
+    for (int j = 0; j < 64; j += kPerWave * U) {
+      uint64_t h[U];
+      uint32_t t[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int src = j + u * kPerWave + group;   // the probe this group serves
+        const uint32_t lo = __shfl(static_cast<uint32_t>(mine), src, 64);
+        const uint32_t hi = __shfl(static_cast<uint32_t>(mine >> 32), src, 64);
+        h[u] = mix((static_cast<uint64_t>(hi) << 32) | lo);
+        const char* b = buckets + (h[u] % numBuckets) * 128;
+        t[u] = G == 16 ? static_cast<uint32_t>(*reinterpret_cast<const uint8_t*>(b + inGroup))
+                       : static_cast<uint32_t>(*reinterpret_cast<const uint16_t*>(b + inGroup * 2));
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool match = G == 16 ? t[u] == 0x5au : ((t[u] & 0xff) == 0x5au || (t[u] >> 8) == 0x5au);
+        const uint64_t all = __ballot(match);
+        const uint32_t mineMask = static_cast<uint32_t>(all >> (group * G)) & ((1u << G) - 1);
+        // the group's leader fetches the row id of the matching slot and the key image
+        if (inGroup == 0) {
+          const uint32_t slot = (mineMask ? static_cast<uint32_t>(h[u] >> 20) : 0u) & 15u;
+          const uint32_t id = *reinterpret_cast<const uint32_t*>(buckets + (h[u] % numBuckets) * 128 + 16 + slot * 4);
+          const uint4 img = images[mix(id ^ h[u]) % numKeys];
+          t[u] = (img.x == static_cast<uint32_t>(h[u])) + img.y + img.z + img.w;
+        }
+        const uint32_t answer = __shfl(t[u], group * G, 64);
+        if (ln == j + u * kPerWave + group) {
+          result = answer;
+        }
+      }
+    }
+    if (base + ln < n) {
+      out[base + ln] = result;
+    }
+  }
+}
+
 // Random 16-byte record scatter into B open bins (the partition pass): where do writes top out?
 __global__ __launch_bounds__(256) void k_stream_copy(const uint4* in, uint4* out, int64_t n) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
@@ -170,7 +324,7 @@ int main(int argc, char** argv) {
     float ms;
     hipEventElapsedTime(&ms, a, b);
     ms /= 3;
-    printf("%-26s table %8.1f MiB grid %5d: %7.3f ms  %7.1f G probes/s  %6.0f GB/s at 12 B/probe\n", name,
+    printf("%-34s table %8.1f MiB grid %5d: %7.3f ms  %7.1f G probes/s  %6.0f GB/s at 12 B/probe\n", name,
            bytes / 1048576.0, grid, ms, n / ms / 1e6, n * 12.0 / ms / 1e6);
     fflush(stdout);
   };
@@ -182,6 +336,20 @@ int main(int argc, char** argv) {
       run("tagline  U8 (wave/probe)", (k_tagline<false, 8>), s, 2048);
       run("tagline  U16 (wave/probe)", (k_tagline<false, 16>), s, 2048);
       run("tagline  U8 xcd-affine", (k_tagline<true, 8>), s, 2048);
+    }
+    return 0;
+  }
+  if (argc > 1 && std::string(argv[1]) == "taggroup") {
+    // generic (kHash) mode bucket shapes with key confirmation: lane per probe vs sub-wave groups
+    for (uint64_t s : {64ULL << 20, 512ULL << 20, 4ULL << 30}) {
+      run("slotkey  U4 (lane/probe)", (k_slotkey<4>), s, 2048);
+      run("slotkey  U8 (lane/probe)", (k_slotkey<8>), s, 2048);
+      run("tagswar  U4 (lane/probe)", (k_tagswar<4>), s, 2048);
+      run("tagswar  U8 (lane/probe)", (k_tagswar<8>), s, 2048);
+      run("taggroup G16 U2 (4 probes/wave)", (k_taggroup<16, 2>), s, 2048);
+      run("taggroup G16 U4 (4 probes/wave)", (k_taggroup<16, 4>), s, 2048);
+      run("taggroup G8  U2 (8 probes/wave)", (k_taggroup<8, 2>), s, 2048);
+      run("taggroup G8  U4 (8 probes/wave)", (k_taggroup<8, 4>), s, 2048);
     }
     return 0;
   }

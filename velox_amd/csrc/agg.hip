@@ -34,6 +34,7 @@
 #include "expr_device.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <chrono>
 #include <cmath>
 #include <future>
@@ -568,11 +569,13 @@ __global__ __launch_bounds__(512, 4) void k_agg_fast(FastArgs a) {
 // What the host derives from a launch to pick an instantiation.
 struct FastSignature {
   int k0 = FK_NONE, k1 = FK_NONE, t0 = FK_NONE, t1 = FK_NONE, numLoads = 0, numAccs = 0;
-  uint64_t accLo = 0, accHi = 0;
+  uint64_t accLo = 0, accHi = 0, accEx = 0;   // 16 bits per accumulator: 0-3, 4-7, 8-11
   uint32_t ind = 0;  // dictionary-wrapped columns (FastShape::IND)
+  uint32_t nul = 0;  // columns with a null bitmap (FastShape::NUL)
   bool operator==(const FastSignature& o) const {
     return k0 == o.k0 && k1 == o.k1 && t0 == o.t0 && t1 == o.t1 && numLoads == o.numLoads &&
-        numAccs == o.numAccs && accLo == o.accLo && accHi == o.accHi && ind == o.ind;
+        numAccs == o.numAccs && accLo == o.accLo && accHi == o.accHi && accEx == o.accEx && ind == o.ind &&
+        nul == o.nul;
   }
 };
 
@@ -591,7 +594,7 @@ struct FastEntry {
 
 #define VX_FAST_ENTRY(U, K0, K1, T0, T1, NL, NA, LO, HI)                                      \
   FastEntry {                                                                                 \
-    FastSignature{K0, K1, T0, T1, NL, NA, LO, HI, 0}, U,                                      \
+    FastSignature{K0, K1, T0, T1, NL, NA, LO, HI, 0, 0, 0}, U,                                      \
         &launchFast<FastShape<U, K0, K1, T0, T1, NL, NA, LO, HI>>                             \
   }
 
@@ -858,27 +861,34 @@ __global__ __launch_bounds__(1024) void k_rp_scatter1(RadixArgs r) {
 // instruction touch 64 unrelated lines: 2.9 TB/s at 191 bins, 2.7 at 382 (read + write), against
 // 4.8 TB/s for a plain copy. Counting-sorting every sub-tile of kSortSub records by bin inside LDS
 // first (histogram, scan, placement) turns the records of a bin into a run of consecutive lanes
-// storing to consecutive addresses: 4.5 TB/s at 191 bins, 4.0 at 382. One workgroup of 1024
-// lanes per CU (the sub-tile occupies 64 KB of LDS), 4 rows per lane.
+// storing to consecutive addresses: 4.5 TB/s at 191 bins, 4.0 at 382 with sub-tiles of 4096
+// records; the longer the runs the better, so a sub-tile takes what the LDS holds: 8192 16-byte
+// records (128 KB), one workgroup of 1024 lanes per CU, 8 rows per lane.
 constexpr int kSortBins = 1024;    // widest fan-out of the sorted scatters
 constexpr int kSortThreads = 1024;
 template <int W>
 struct SortLds {
-  static constexpr int kSub = (W <= 2 ? 4096 : 2048);   // records per sub-tile: <= 64 KB of LDS
+  static constexpr int kSub = (W <= 2 ? 8192 : 4096);   // records per sub-tile: <= 128 KB of LDS
   static constexpr int kRounds = kSub / kSortThreads;   // rows per lane and sub-tile
   unsigned long long binBase[kSortBins];  // next free record of the bin inside this tile's range
   uint32_t cnt[kSortBins];                // sub-tile histogram, then placement cursor
   uint32_t start[kSortBins];              // sub-tile exclusive scan
   uint64_t recs[kSub * W];
-  uint16_t binOf[kSub];
   uint32_t waveTotals[kSortThreads / 64];
 };
 
 // The sub-tile's records (rec[u], bin[u] = 0xffffffff: none) leave for their bins. Called by all
 // 1024 lanes; cnt[] must be zero on entry and is zero again on return.
-template <int W, int R>
+// binOfWord0: bin of a record from its first word (the write-out pass recomputes it instead of
+// keeping a bin per staged record in LDS).
+struct NoReserve {};
+// reserve (optional): called by the lane of every non-empty bin with (bin, records of the sub-tile);
+// returns the first record position of that run in 'out', or ~0 to drop the run — the optimistic
+// level 2 claims its space from a global cursor per partition instead of a counted offset.
+template <int W, int R, typename BinFn, typename ReserveFn = NoReserve>
 __device__ inline void rpSortedEmit(SortLds<W>& l, int numBins, const uint64_t (&rec)[R][W], const uint32_t (&bin)[R],
-                                    uint64_t* out) {
+                                    uint64_t* out, BinFn&& binOfWord0, ReserveFn&& reserve = NoReserve{}) {
+  constexpr bool kReserves = !std::is_same<typename std::decay<ReserveFn>::type, NoReserve>::value;
   const int tid = threadIdx.x;
 #pragma unroll
   for (int u = 0; u < R; ++u) {
@@ -908,6 +918,11 @@ __device__ inline void rpSortedEmit(SortLds<W>& l, int numBins, const uint64_t (
   if (tid < numBins) {
     l.start[tid] = run;
     l.cnt[tid] = run;  // placement cursor
+    if constexpr (kReserves) {
+      if (mine != 0) {
+        l.binBase[tid] = reserve(static_cast<uint32_t>(tid), mine);
+      }
+    }
   }
   blockSync();
 #pragma unroll
@@ -915,7 +930,6 @@ __device__ inline void rpSortedEmit(SortLds<W>& l, int numBins, const uint64_t (
     if (bin[u] != 0xffffffffu) {
       const uint32_t pos = atomicAdd(&l.cnt[bin[u]], 1u);
       rpStore<W>(l.recs + static_cast<size_t>(pos) * W, rec[u]);
-      l.binOf[pos] = static_cast<uint16_t>(bin[u]);
     }
   }
   blockSync();
@@ -925,14 +939,19 @@ __device__ inline void rpSortedEmit(SortLds<W>& l, int numBins, const uint64_t (
     total += l.waveTotals[w];
   }
   for (uint32_t i = tid; i < total; i += kSortThreads) {
-    const uint32_t b = l.binOf[i];
     uint64_t w[W];
     rpLoad<W>(l.recs + static_cast<size_t>(i) * W, w);
+    const uint32_t b = binOfWord0(w[0]);
+    if (kReserves && l.binBase[b] == ~0ULL) {
+      continue;  // the partition's optimistic region is full: the host redoes the level exactly
+    }
     rpStore<W>(out + (l.binBase[b] + (i - l.start[b])) * W, w);
   }
   blockSync();
   if (tid < numBins) {
-    l.binBase[tid] += l.cnt[tid] - l.start[tid];
+    if constexpr (!kReserves) {
+      l.binBase[tid] += l.cnt[tid] - l.start[tid];
+    }
     l.cnt[tid] = 0;
   }
   blockSync();
@@ -1008,7 +1027,9 @@ __global__ __launch_bounds__(kSortThreads) void k_rp_scatter1_sorted(RadixArgs r
         vals[u][0] = key | (static_cast<uint64_t>(row) << r.keyBits) | (mask << (r.keyBits + r.rowBits));
         bin[u] = static_cast<uint32_t>(key >> shift);
       }
-      rpSortedEmit<W, R>(l, r.numBins, vals, bin, r.recs);
+      const uint64_t keyMask = (1ULL << r.keyBits) - 1;
+      rpSortedEmit<W, R>(l, r.numBins, vals, bin, r.recs,
+                         [&](uint64_t w0) { return static_cast<uint32_t>((w0 & keyMask) >> shift); });
     }
   }
 }
@@ -1173,7 +1194,119 @@ __global__ __launch_bounds__(kSortThreads) void k_rp_scatter2_sorted(Radix2Args 
           bin[u] = (static_cast<uint32_t>(w[u][0]) >> r.shiftB) & binMask;
         }
       }
-      rpSortedEmit<W, R>(l, r.numBins, w, bin, r.out);
+      rpSortedEmit<W, R>(l, r.numBins, w, bin, r.out,
+                         [&](uint64_t w0) { return (static_cast<uint32_t>(w0) >> r.shiftB) & binMask; });
+    }
+  }
+}
+
+// ---- optimistic level 2: no counting pass -----------------------------------------------------
+// k_rp_count2 reads every record of level 1 once more (16 GB at 10^9 rows) only to size the
+// partitions exactly. Level 1 already knows every bucket's record count; when keys are spread
+// evenly inside a bucket each of its 2^shift2 partitions holds about 1 / 2^shift2 of them. So the
+// partitions of bucket b get regions of cap_b = 1.5 x that share + 256 records, a sub-tile claims
+// the space of each of its runs with ONE atomic on the partition's cursor, and a partition that
+// outgrows its region raises a flag: the host then redoes the level with the exact passes
+// (count2 + scan + scatter2). Uniform keys never raise it (the share's standard deviation is
+// ~1 % of it); skewed keys pay one wasted pass.
+struct Radix2OptArgs {
+  const uint64_t* in;
+  uint64_t* out;
+  const RadixTile* tiles;
+  const uint32_t* numTiles;
+  int32_t shiftB;
+  int32_t shift2;
+  int32_t numBins;          // 2^shift2
+  int32_t keyBits;          // key field of record word 0
+  const uint64_t* partBase; // [numParts + 1]
+  const uint32_t* bucketCap;  // region size of every partition of bucket b
+  uint32_t* partCount;      // cursors, zero on entry
+  uint32_t* overflow;       // set when a region is full
+};
+
+// partBase / bucketCap from the level-1 bucket sizes (one workgroup; buckets <= kRadixMaxBins).
+// Every partition's region holds 1.5 x the even share of the FULLEST bucket + 256 records — a
+// bucket at the edge of the live key range has few live partitions, each as full as those of a
+// full bucket — but never more than its bucket holds.
+__global__ __launch_bounds__(1024) void k_rp_layout2(const uint64_t* offsets1, int64_t numTiles1, int32_t numBins1,
+                                                      int32_t shift2, int64_t numParts, uint64_t* partBase,
+                                                      uint32_t* bucketCap, uint64_t* totalOut) {
+  __shared__ unsigned long long bucketBase[kRadixMaxBins + 1];
+  __shared__ unsigned long long maxCount;
+  const int32_t bins2 = 1 << shift2;
+  if (threadIdx.x == 0) {
+    maxCount = 0;
+  }
+  blockSync();
+  for (int b = threadIdx.x; b < numBins1; b += blockDim.x) {
+    const unsigned long long count =
+        offsets1[static_cast<int64_t>(b + 1) * numTiles1] - offsets1[static_cast<int64_t>(b) * numTiles1];
+    atomicMax(&maxCount, count);
+  }
+  blockSync();
+  const uint64_t share = (maxCount + bins2 - 1) / bins2;
+  const uint64_t cap = share + share / 2 + 256;
+  for (int b = threadIdx.x; b < numBins1; b += blockDim.x) {
+    const uint64_t count = offsets1[static_cast<int64_t>(b + 1) * numTiles1] - offsets1[static_cast<int64_t>(b) * numTiles1];
+    bucketCap[b] = static_cast<uint32_t>(count < cap ? count : cap);
+  }
+  blockSync();
+  if (threadIdx.x == 0) {
+    unsigned long long run = 0;
+    for (int b = 0; b < numBins1; ++b) {
+      bucketBase[b] = run;
+      run += static_cast<unsigned long long>(bucketCap[b]) * bins2;
+    }
+    bucketBase[numBins1] = run;
+    *totalOut = run;
+  }
+  blockSync();
+  for (int64_t p = threadIdx.x; p <= numParts; p += blockDim.x) {
+    const int64_t b = p >> shift2;
+    partBase[p] = b >= numBins1 ? bucketBase[numBins1]
+                                : bucketBase[b] + static_cast<uint64_t>(p & (bins2 - 1)) * bucketCap[b];
+  }
+}
+
+template <int W>
+__global__ __launch_bounds__(kSortThreads) void k_rp_scatter2_opt(Radix2OptArgs r) {
+  __shared__ SortLds<W> l;
+  constexpr int R = SortLds<W>::kRounds;
+  const uint32_t numTiles = *r.numTiles;
+  const uint32_t binMask = static_cast<uint32_t>(r.numBins - 1);
+  for (int i = threadIdx.x; i < kSortBins; i += kSortThreads) {
+    l.cnt[i] = 0;
+  }
+  blockSync();
+  for (uint32_t t = blockIdx.x; t < numTiles; t += gridDim.x) {
+    const RadixTile tile = r.tiles[t];
+    // every record of a level-2 tile belongs to one level-1 bucket: its partitions are consecutive
+    const uint64_t firstKey = r.in[tile.begin * W] & ((1ULL << r.keyBits) - 1);
+    const uint64_t bucket = (firstKey >> r.shiftB) >> r.shift2;
+    const uint64_t part0 = bucket << r.shift2;
+    const uint32_t cap = r.bucketCap[bucket];
+    for (uint32_t base = 0; base < tile.count; base += SortLds<W>::kSub) {
+      uint64_t w[R][W];
+      uint32_t bin[R];
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const uint32_t i = base + u * kSortThreads + threadIdx.x;
+        bin[u] = 0xffffffffu;
+        if (i < tile.count) {
+          rpLoad<W>(r.in + (tile.begin + i) * W, w[u]);
+          bin[u] = (static_cast<uint32_t>(w[u][0]) >> r.shiftB) & binMask;
+        }
+      }
+      rpSortedEmit<W, R>(
+          l, r.numBins, w, bin, r.out, [&](uint64_t w0) { return (static_cast<uint32_t>(w0) >> r.shiftB) & binMask; },
+          [&](uint32_t b, uint32_t count) -> unsigned long long {
+            const uint32_t at = atomicAdd(&r.partCount[part0 + b], count);
+            if (at + count > cap) {
+              *r.overflow = 1;
+              return ~0ULL;
+            }
+            return r.partBase[part0 + b] + at;
+          });
     }
   }
 }
@@ -1181,6 +1314,9 @@ __global__ __launch_bounds__(kSortThreads) void k_rp_scatter2_sorted(Radix2Args 
 struct RadixAggArgs {
   const uint64_t* recs;
   const uint64_t* partBegin;   // record offsets per histogram cell
+  // optimistic level 2 (k_rp_scatter2_opt): partition p = partCount[p] records from partBase[p]
+  const uint64_t* partBase;
+  const uint32_t* partCount;
   const uint32_t* partCell;    // partition p -> cell (numParts + 1 entries); null: cell = p * cellStride
   int64_t cellStride;
   int64_t numParts;
@@ -1404,6 +1540,11 @@ __device__ inline void rpFoldFlush(const RpFold& f, const RadixAggArgs& r, int64
 }
 
 __device__ inline void rpPartitionRange(const RadixAggArgs& r, int64_t p, uint64_t* begin, uint64_t* end) {
+  if (r.partBase != nullptr) {
+    *begin = r.partBase[p];
+    *end = *begin + r.partCount[p];
+    return;
+  }
   *begin = r.partBegin[r.partCell ? r.partCell[p] : p * r.cellStride];
   *end = r.partBegin[r.partCell ? r.partCell[p + 1] : (p + 1) * r.cellStride];
 }
@@ -2534,7 +2675,9 @@ struct vx355_agg {
   DevBuf deferredBuf;
   DevBuf scratch, sortTmp;
   // radix-partitioned path (high cardinality)
-  DevBuf rpRecs1, rpRecs2, rpHist, rpOffsets, rpTiles, rpMisc, rpScan;
+  DevBuf rpRecs1, rpRecs2, rpHist, rpOffsets, rpTiles, rpMisc, rpScan, rpLayout2;
+  bool radixOptimistic = true;  // VX355_AGG_RADIX_OPTIMISTIC=0: level 2 always counts first
+  int64_t radixRedone = 0;      // level-2 passes redone exactly after a region overflowed
   int64_t radixMinRows = 4 << 20;
   int32_t radixMaxBins = kRadixMaxBins;  // widest single-level fan-out
   int64_t radixTileRows = 0;  // 0 = automatic
@@ -2565,7 +2708,7 @@ struct vx355_agg {
   bool disableFast = false;
   int64_t jitLaunches = 0;
   bool jitEnabled = true;
-  bool jitAsync = false;   // VX355_JIT=async
+  bool jitAsync = true;    // VX355_JIT=sync (or 1): a new plan shape waits ~0.8 s for hiprtc instead
   bool exactSums = true;
   bool sumGridsChosen = false;
   bool logShapes = false;
@@ -3079,12 +3222,9 @@ bool buildFastArgs(const AggArgs& c, const LdsPlan& plan, FastArgs* f, FastSigna
   }
   *f = FastArgs{};
   *sig = FastSignature{};
-  // Null-free columns that are flat, or dictionary wrapped by ONE shared index
-  // vector (FilterProject's output); returns -1 = not eligible, 1 = wrapped.
+  // Columns that are flat, or dictionary wrapped by ONE shared index vector (FilterProject's
+  // output), with or without a null bitmap; returns -1 = not eligible, 1 = wrapped.
   auto usable = [&](const ColView& v) -> int {
-    if (v.nulls != nullptr) {
-      return -1;
-    }
     if (v.enc == VX355_FLAT) {
       return 0;
     }
@@ -3101,6 +3241,10 @@ bool buildFastArgs(const AggArgs& c, const LdsPlan& plan, FastArgs* f, FastSigna
       return false;
     }
     sig->ind |= static_cast<uint32_t>(wrapped) << k;
+    if (v.nulls) {
+      sig->nul |= 1u << k;
+      f->keyNulls[k] = v.nulls;
+    }
     int kind;
     if (isString(v.kind)) {
       kind = FK_VIEW;
@@ -3122,6 +3266,10 @@ bool buildFastArgs(const AggArgs& c, const LdsPlan& plan, FastArgs* f, FastSigna
       return false;
     }
     sig->ind |= static_cast<uint32_t>(wrapped) << (2 + t);
+    if (ta.col.nulls) {
+      sig->nul |= 1u << (2 + t);
+      f->termNulls[t] = ta.col.nulls;
+    }
     int kind;
     if (ta.constKind == VX355_BIGINT && ta.col.kind == VX355_INTEGER) {
       // The kernel compares in 32 bits: a constant outside int32 would wrap.
@@ -3160,6 +3308,10 @@ bool buildFastArgs(const AggArgs& c, const LdsPlan& plan, FastArgs* f, FastSigna
     }
     f->loadPtr[sig->numLoads] = static_cast<const double*>(v.values);
     sig->ind |= static_cast<uint32_t>(wrapped) << (4 + sig->numLoads);
+    if (v.nulls) {
+      sig->nul |= 1u << (4 + sig->numLoads);
+      f->loadNulls[sig->numLoads] = v.nulls;
+    }
     return sig->numLoads++;
   };
   for (int j = 0; j < c.numAccs; ++j) {
@@ -3170,6 +3322,29 @@ bool buildFastArgs(const AggArgs& c, const LdsPlan& plan, FastArgs* f, FastSigna
     uint64_t desc;
     if (ac.kind == ACC_COUNT && !ac.hasIn && ac.inProj < 0) {
       desc = accDesc(0);
+    } else if (ac.kind == ACC_COUNT && ac.hasIn && ac.inProj < 0) {
+      // count(x): rows where the DOUBLE column x is not null (gated by the load's null bit)
+      const int slot = loadSlot(ac.in);
+      if (slot < 0) {
+        return false;
+      }
+      desc = accDesc(0, slot);
+    } else if (ac.kind == ACC_COUNT && ac.inProj >= 0) {
+      // count(projection): rows where none of its factor columns is null
+      const ProjectionArg& pa = c.proj[ac.inProj];
+      if (pa.numFactors > kFastFactors) {
+        return false;
+      }
+      int l[kFastFactors] = {15, 15, 15};
+      for (int q = 0; q < pa.numFactors; ++q) {
+        if (pa.factors[q].hasCol) {
+          l[q] = loadSlot(pa.factors[q].col);
+          if (l[q] < 0) {
+            return false;
+          }
+        }
+      }
+      desc = accDesc(0, l[0], l[1], l[2]);
     } else if (ac.kind != ACC_SUM_F64) {
       return false;
     } else if (ac.inProj >= 0) {
@@ -3204,11 +3379,14 @@ bool buildFastArgs(const AggArgs& c, const LdsPlan& plan, FastArgs* f, FastSigna
     f->splitM[j] = ac.kind == ACC_SUM_F64 ? ac.splitM : 0.0;
     if (j < 4) {
       sig->accLo |= desc << (16 * j);
-    } else {
+    } else if (j < 8) {
       sig->accHi |= desc << (16 * (j - 4));
+    } else {
+      sig->accEx |= desc << (16 * (j - 8));
     }
   }
   sig->numAccs = c.numAccs;
+  f->ignoreNullKeys = c.ignoreNullKeys;
   f->numRows = c.numRows;
   f->deferred = c.deferred;
   f->deferCap = c.deferCap;
@@ -3311,9 +3489,9 @@ hipFunction_t jitFastKernel(const FastSignature& sig, int unroll, bool log, bool
     return nullptr;
   }
   char key[256];
-  snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d,%lluull,%lluull,%uu", unroll, sig.k0, sig.k1, sig.t0, sig.t1,
-           sig.numLoads, sig.numAccs, static_cast<unsigned long long>(sig.accLo),
-           static_cast<unsigned long long>(sig.accHi), sig.ind);
+  snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d,%lluull,%lluull,%uu,%uu,%lluull", unroll, sig.k0, sig.k1, sig.t0,
+           sig.t1, sig.numLoads, sig.numAccs, static_cast<unsigned long long>(sig.accLo),
+           static_cast<unsigned long long>(sig.accHi), sig.ind, sig.nul, static_cast<unsigned long long>(sig.accEx));
   // A loaded module belongs to one GPU.
   const std::string cacheKey = std::to_string(Runtime::get().device) + ":" + key;
   auto it = st.kernels.find(cacheKey);
@@ -3696,20 +3874,66 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
     r2.numBins = bins2;
     r2.hist = h.rpHist.as<uint32_t>();
     r2.offsets = offsets2;
-    HIP_OK(hipMemsetAsync(r2.hist, 0, static_cast<size_t>(cells2) * 4, rt.stream));
     const int grid2 = static_cast<int>(std::min<int64_t>(maxTiles2, rt.numCUs * 2));
-    VX_LAUNCH("k_rp_count2", k_rp_count2, grid2, 1024, 0, r2);
-    scanU32ToU64(r2.hist, cells2, offsets2, h.rpScan);
-    byWidth([&](auto wTag) {
-      if (h.radixSorted && bins2 <= kSortBins) {
-        VX_LAUNCH("k_rp_scatter2", (k_rp_scatter2_sorted<decltype(wTag)::value>), grid2, kSortThreads, 0, r2);
+    bool exact = true;
+    if (h.radixOptimistic && h.radixSorted && bins2 <= kSortBins) {
+      // no counting pass: regions of 1.5 x the even share per partition, claimed with atomics
+      const size_t partsPadded = static_cast<size_t>(r.numBins) * bins2;
+      char* lay = static_cast<char*>(h.rpLayout2.ensure((partsPadded + 1) * 8 + static_cast<size_t>(r.numBins) * 4 +
+                                                        partsPadded * 4 + 64 + 64));
+      uint64_t* partBase = reinterpret_cast<uint64_t*>(lay);
+      uint32_t* bucketCap = reinterpret_cast<uint32_t*>(lay + (partsPadded + 1) * 8);
+      uint32_t* partCount = bucketCap + r.numBins;
+      uint32_t* overflow = partCount + partsPadded;   // [0] flag, [2..3] total records of the layout
+      HIP_OK(hipMemsetAsync(partCount, 0, (partsPadded + 16) * 4, rt.stream));
+      VX_LAUNCH("k_rp_layout2", k_rp_layout2, 1, 1024, 0, offsets1, r.numTiles, r.numBins, r.shift2,
+                static_cast<int64_t>(partsPadded), partBase, bucketCap, reinterpret_cast<uint64_t*>(overflow + 2));
+      uint64_t layoutRecs = 0;
+      copyOut(&layoutRecs, VX355_MEM_HOST, overflow + 2, 8);
+      h.rpRecs2.ensure((static_cast<size_t>(layoutRecs) + 64) * r.recWords * 8 + 64);
+      r2.out = h.rpRecs2.as<uint64_t>();
+      Radix2OptArgs o{};
+      o.in = r2.in;
+      o.out = r2.out;
+      o.tiles = r2.tiles;
+      o.numTiles = numTiles2;
+      o.shiftB = r.shiftB;
+      o.shift2 = r.shift2;
+      o.numBins = bins2;
+      o.keyBits = r.keyBits;
+      o.partBase = partBase;
+      o.bucketCap = bucketCap;
+      o.partCount = partCount;
+      o.overflow = overflow;
+      byWidth([&](auto wTag) {
+        VX_LAUNCH("k_rp_scatter2", (k_rp_scatter2_opt<decltype(wTag)::value>), grid2, kSortThreads, 0, o);
+      });
+      uint32_t full = 0;
+      copyOut(&full, VX355_MEM_HOST, overflow, 4);
+      exact = full != 0;  // some partition outgrew its region (skewed keys): redo the level exactly
+      if (!exact) {
+        g.partBase = partBase;
+        g.partCount = partCount;
       } else {
-        VX_LAUNCH("k_rp_scatter2", (k_rp_scatter2<decltype(wTag)::value>), grid2, 1024, 0, r2);
+        ++h.radixRedone;
+        h.radixOptimistic = false;  // skewed keys: this operator counts from now on
       }
-    });
+    }
+    if (exact) {
+      HIP_OK(hipMemsetAsync(r2.hist, 0, static_cast<size_t>(cells2) * 4, rt.stream));
+      VX_LAUNCH("k_rp_count2", k_rp_count2, grid2, 1024, 0, r2);
+      scanU32ToU64(r2.hist, cells2, offsets2, h.rpScan);
+      byWidth([&](auto wTag) {
+        if (h.radixSorted && bins2 <= kSortBins) {
+          VX_LAUNCH("k_rp_scatter2", (k_rp_scatter2_sorted<decltype(wTag)::value>), grid2, kSortThreads, 0, r2);
+        } else {
+          VX_LAUNCH("k_rp_scatter2", (k_rp_scatter2<decltype(wTag)::value>), grid2, 1024, 0, r2);
+        }
+      });
+      g.partBegin = offsets2;
+      g.partCell = partCell;
+    }
     g.recs = h.rpRecs2.as<uint64_t>();
-    g.partBegin = offsets2;
-    g.partCell = partCell;
   }
   g.numParts = static_cast<int64_t>(parts);
   g.recWords = r.recWords;
@@ -3819,7 +4043,12 @@ void launchChunk(vx355_agg& h, AggArgs& a) {
     plan.counters = a.counters;
     FastArgs fa;
     FastSignature sig;
-    if (!h.disableFast && buildFastArgs(a, plan, &fa, &sig)) {
+    const bool fastClass = !h.disableFast && buildFastArgs(a, plan, &fa, &sig);
+    if (!fastClass && h.logShapes && !h.disableFast) {
+      fprintf(stderr, "vx355: plan outside the specialised class (keys %d, terms %d, accumulators %d)\n", a.numKeys,
+              a.numTerms, a.numAccs);
+    }
+    if (fastClass) {
       if (const FastEntry* e = findFastEntry(sig, h.fastUnroll)) {
         const int blocksPerCu =
             std::max<int>(1, std::min<int>(4, static_cast<int>((150 * 1024) / ldsBytes)));
@@ -4855,8 +5084,10 @@ void configureFromEnv(vx355_agg& h) {
     h.arrayMax = std::strtoull(e, nullptr, 10);
   }
   if (const char* e = std::getenv("VX355_JIT")) {
+    // 0 = off; 1 / sync = compile on the calling thread; async (the default) = on a helper thread
+    // while the interpreting kernel takes the first batches
     h.jitEnabled = e[0] != '0';
-    h.jitAsync = std::string(e) == "async";
+    h.jitAsync = !(std::string(e) == "1" || std::string(e) == "sync");
   }
   if (const char* e = std::getenv("VX355_AGG_COALESCE_ROWS")) {
     h.coalescer.thresholdRows = std::strtoll(e, nullptr, 10);
@@ -4875,6 +5106,9 @@ void configureFromEnv(vx355_agg& h) {
   }
   if (const char* e = std::getenv("VX355_AGG_NO_FAST")) {
     h.disableFast = e[0] == '1';
+  }
+  if (const char* e = std::getenv("VX355_AGG_RADIX_OPTIMISTIC")) {
+    h.radixOptimistic = std::atoi(e) != 0;
   }
   if (const char* e = std::getenv("VX355_AGG_RADIX_SORTED")) {
     h.radixSorted = std::atoi(e) != 0;

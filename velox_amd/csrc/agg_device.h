@@ -301,7 +301,7 @@ __device__ inline void ldsFlush(const LdsPlan& p, const LdsState& st) {
 // shape is not in the table runs on the generic kernel.
 constexpr int kFastKeys = 2;
 constexpr int kFastTerms = 2;
-constexpr int kFastAccs = 8;
+constexpr int kFastAccs = 12;
 constexpr int kFastFactors = 3;
 constexpr int kFastLoads = 8;
 
@@ -330,6 +330,17 @@ struct FastArgs {
   // exec/OperatorUtils.cpp:393-422): the columns flagged in the shape's IND mask
   // are read at indices[row] instead of row; one shared index vector.
   const int32_t* indices;
+  // Null bitmaps (1 = valid, one bit per top-level row) of the columns flagged in the shape's
+  // NUL mask: a null key is id 0 (or drops the row: ignoreNullKeys), a null filter input fails
+  // the filter, a null aggregate input skips that accumulator for the row - what
+  // SimpleNumericAggregate::updateGroups does in the same pass
+  // (functions/lib/aggregates/SimpleNumericAggregate.h:94-160). One bit per row and column:
+  // free in bandwidth next to the 8-byte values.
+  const uint64_t* keyNulls[kFastKeys];
+  const uint64_t* termNulls[kFastTerms];
+  const uint64_t* loadNulls[kFastLoads];
+  int32_t ignoreNullKeys;
+  int32_t pad2;
   LdsPlan plan;
 };
 
@@ -342,18 +353,20 @@ constexpr uint64_t packAccs(uint64_t a0 = 0, uint64_t a1 = 0, uint64_t a2 = 0, u
 }
 
 template <int UNROLL, int K0, int K1, int T0, int T1, int NL, int NA, uint64_t ACC_LO, uint64_t ACC_HI,
-          uint32_t IND = 0>
+          uint32_t IND = 0, uint32_t NUL = 0, uint64_t ACC_EX = 0>
 struct FastShape {
   // IND bit k: key k, bit 2 + t: filter term t, bit 4 + j: loaded column j is dictionary wrapped.
   static constexpr bool indirect(int bit) { return (IND >> bit) & 1; }
   static constexpr bool anyIndirect = IND != 0;
+  // NUL, same bit numbering: the column carries a null bitmap.
+  static constexpr bool nullable(int bit) { return (NUL >> bit) & 1; }
   static constexpr int unroll = UNROLL;
   static constexpr int keyKind(int k) { return k == 0 ? K0 : K1; }
   static constexpr int termKind(int t) { return t == 0 ? T0 : T1; }
   static constexpr int numLoads = NL;
   static constexpr int numAccs = NA;
   static constexpr uint64_t desc(int j) {
-    return ((j < 4 ? ACC_LO >> (16 * j) : ACC_HI >> (16 * (j - 4)))) & 0xffff;
+    return ((j < 4 ? ACC_LO >> (16 * j) : (j < 8 ? ACC_HI >> (16 * (j - 4)) : ACC_EX >> (16 * (j - 8))))) & 0xffff;
   }
   static constexpr int numFactors(int j) { return static_cast<int>(desc(j) & 15); }
   // LDS / table word of accumulator j: every DOUBLE sum before it owns two words (hi, lo).
@@ -484,11 +497,36 @@ __device__ inline void aggFastBody(const FastArgs& a) {
         x[u][j] = a.loadPtr[j][S::indirect(4 + j) ? rowi[u] : rowc[u]];
       }
     });
+    // null flags of the nullable columns: bit (4 + j) of nul[u] set = load j is null, bit k = key
+    // k, bit 2 + t = filter input t (the 64 lanes of a wave share each bitmap word)
+    uint32_t nul[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      nul[u] = 0;
+      staticFor<kFastKeys>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (S::keyKind(k) != FK_NONE && S::nullable(k)) {
+          nul[u] |= ((a.keyNulls[k][rowc[u] >> 6] >> (rowc[u] & 63)) & 1) ? 0u : (1u << k);
+        }
+      });
+      staticFor<kFastTerms>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        if constexpr (S::termKind(t) != FK_NONE && S::nullable(2 + t)) {
+          nul[u] |= ((a.termNulls[t][rowc[u] >> 6] >> (rowc[u] & 63)) & 1) ? 0u : (1u << (2 + t));
+        }
+      });
+      staticFor<S::numLoads>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (S::nullable(4 + j)) {
+          nul[u] |= ((a.loadNulls[j][rowc[u] >> 6] >> (rowc[u] & 63)) & 1) ? 0u : (1u << (4 + j));
+        }
+      });
+    }
     // Phase 2: filter, key, LDS updates.
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const int64_t row = base + static_cast<int64_t>(u) * blockDim.x;
-      bool live = row < a.numRows;
+      bool live = row < a.numRows && (nul[u] & 0xcu) == 0;  // a null filter input fails the filter
       staticFor<kFastTerms>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
         if constexpr (S::termKind(t) == FK_F64) {
@@ -511,7 +549,9 @@ __device__ inline void aggFastBody(const FastArgs& a) {
         constexpr int k = decltype(kc)::value;
         if constexpr (S::keyKind(k) != FK_NONE) {
           const int64_t v = fastKeyValue<S::keyKind(k)>(kraw[u][k]);
-          if (v < a.range[k].min || v > a.range[k].max) {
+          if (S::nullable(k) && ((nul[u] >> k) & 1)) {
+            live = live && !a.ignoreNullKeys;  // else: a null key is value id 0
+          } else if (v < a.range[k].min || v > a.range[k].max) {
             if (live) {
               defer = true;
               if (v != INT64_MIN) {
@@ -528,17 +568,34 @@ __device__ inline void aggFastBody(const FastArgs& a) {
       if (live && !defer) {
         const int32_t slot = ldsSlot(p, st, key);
         double vals[NA > 0 ? NA : 1];
+        bool have[NA > 0 ? NA : 1];  // false: some input of accumulator j is null in this row
         staticFor<NA>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
           double acc = 0;
+          have[j] = true;
           staticFor<S::numFactors(j)>([&](auto fc) {
             constexpr int f = decltype(fc)::value;
             double v = a.offset[j][f];
             if constexpr (S::load(j, f) != 15) {
               v = a.scale[j][f] * x[u][S::load(j, f)] + a.offset[j][f];
+              if constexpr (S::nullable(4 + S::load(j, f))) {
+                have[j] = have[j] && !((nul[u] >> (4 + S::load(j, f))) & 1);
+              }
             }
             acc = f == 0 ? v : acc * v;
           });
+          // count(x) / count(projection): numFactors 0 with up to three load indexes = rows where
+          // none of those columns is null
+          if constexpr (S::numFactors(j) == 0) {
+            staticFor<kFastFactors>([&](auto gc) {
+              constexpr int g = decltype(gc)::value;
+              if constexpr (S::load(j, g) != 15) {
+                if constexpr (S::nullable(4 + S::load(j, g))) {
+                  have[j] = have[j] && !((nul[u] >> (4 + S::load(j, g))) & 1);
+                }
+              }
+            });
+          }
           vals[j] = acc;
         });
         if (slot >= 0) {
@@ -547,6 +604,9 @@ __device__ inline void aggFastBody(const FastArgs& a) {
           staticFor<NA>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             constexpr int w = S::ldsIndex(j);
+            if (!have[j]) {
+              return;
+            }
             if constexpr (S::numFactors(j) == 0) {
               atomicAdd(reinterpret_cast<unsigned long long*>(dst + w * REP), 1ULL);
             } else {
@@ -571,6 +631,9 @@ __device__ inline void aggFastBody(const FastArgs& a) {
           staticFor<NA>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             constexpr int w = S::ldsIndex(j);
+            if (!have[j]) {
+              return;
+            }
             if constexpr (S::numFactors(j) == 0) {
               applyGlobal(g + p.off[w], ACC_SUM_I64_WRAP, 1, p.counters);
             } else {

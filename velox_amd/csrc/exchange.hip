@@ -16,6 +16,7 @@
 #include "common.h"
 
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -117,6 +118,30 @@ void ncclOk(int rc, const char* what) {
                                   (r.GetErrorString ? r.GetErrorString(rc) : std::to_string(rc).c_str()));
   }
 }
+
+// RCCL prints a version banner on stdout when the first communicator is created (C stdio,
+// flushed at exit: it lands behind whatever the host printed last). A library has no business
+// writing to the host's stdout: the banner is sent to stderr instead.
+class StdoutToStderr {
+ public:
+  StdoutToStderr() {
+    fflush(stdout);
+    saved_ = dup(1);
+    if (saved_ >= 0) {
+      dup2(2, 1);
+    }
+  }
+  ~StdoutToStderr() {
+    fflush(stdout);
+    if (saved_ >= 0) {
+      dup2(saved_, 1);
+      close(saved_);
+    }
+  }
+
+ private:
+  int saved_ = -1;
+};
 
 // ncclGroupStart ... ncclGroupEnd that cannot be left open: an exception between the two would
 // leave the thread's RCCL group open and the next collective would silently join it.
@@ -226,6 +251,35 @@ struct vx355_exchange {
 };
 
 
+namespace vx {
+namespace {
+// HashPartitionFunction of the edge for 'world' destinations: the TOP hash bits for powers of
+// two (disjoint from the bits the join tables index with, cf. checkHashBitsOverlap,
+// exec/HashTable.cpp:1853), else hash % world (exec/HashPartitionFunction.cpp:112-115).
+HashPartArgs destinationArgs(const vx355_exchange& x, const DeviceBatch& db, uint32_t world, int64_t n) {
+  HashPartArgs a{};
+  for (size_t k = 0; k < x.keyCols.size(); ++k) {
+    a.keys[k] = db.col(x.keyCols[k]);
+  }
+  a.numKeys = static_cast<int32_t>(x.keyCols.size());
+  if ((world & (world - 1)) == 0) {
+    int bits = 0;
+    while ((1u << bits) < world) {
+      ++bits;
+    }
+    a.kind = VX355_PART_BIT_RANGE;
+    a.bitBegin = 64 - bits;
+    a.mask = world - 1;
+  } else {
+    a.kind = VX355_PART_MODULO;
+  }
+  a.numPartitions = world;
+  a.numRows = n;
+  return a;
+}
+}  // namespace
+}  // namespace vx
+
 extern "C" {
 
 int vx355_comm_get_unique_id(void* id_out) {
@@ -245,7 +299,10 @@ int vx355_comm_create(const void* id, int32_t world, int32_t rank, vx355_comm** 
   c->rank = rank;
   ncclUniqueId uid;
   std::memcpy(uid.internal, id, kUniqueIdBytes);
-  ncclOk(rccl().CommInitRank(&c->comm, world, uid, rank), "ncclCommInitRank");
+  {
+    StdoutToStderr quiet;
+    ncclOk(rccl().CommInitRank(&c->comm, world, uid, rank), "ncclCommInitRank");
+  }
   try {
     c->ctx = Runtime::createContext();
   } catch (...) {
@@ -264,7 +321,10 @@ int vx355_comm_create_all(int32_t num_devices, const int32_t* devices, vx355_com
     for (int d : devs) {
       (void)Runtime::defaultContext(d);  // throws unless vx355_init(d) was called
     }
-    ncclOk(rccl().CommInitAll(comms.data(), num_devices, devs.data()), "ncclCommInitAll");
+    {
+      StdoutToStderr quiet;
+      ncclOk(rccl().CommInitAll(comms.data(), num_devices, devs.data()), "ncclCommInitAll");
+    }
     std::vector<std::unique_ptr<vx355_comm>> made;
     try {
       for (int32_t i = 0; i < num_devices; ++i) {
@@ -579,37 +639,28 @@ int vx355_exchange_send(vx355_exchange* x, const vx355_batch* batch) {
   std::vector<void*> grouped(numCols);
   for (int32_t i = 0; i < numCols; ++i) {
     in[i] = db.col(i).values;
-    grouped[i] = slot.grouped[i].ensure(static_cast<size_t>(std::max<int64_t>(n, 1)) * x->widths[i] + 64);
   }
   if (c->world == 1) {
-    // one destination: nothing to hash or group
-    slot.sendCounts[0] = n;
-    for (int32_t i = 0; i < numCols && n > 0; ++i) {
-      HIP_OK(hipMemcpyAsync(grouped[i], in[i], static_cast<size_t>(n) * x->widths[i], hipMemcpyDeviceToDevice,
-                            rt.stream));
-    }
-  } else if (n > 0) {
-    HashPartArgs a{};
-    for (size_t k = 0; k < x->keyCols.size(); ++k) {
-      a.keys[k] = db.col(x->keyCols[k]);
-    }
-    a.numKeys = static_cast<int32_t>(x->keyCols.size());
-    const uint32_t world = static_cast<uint32_t>(c->world);
-    if ((world & (world - 1)) == 0) {
-      // powers of two: the TOP hash bits, disjoint from the bits the join tables index with
-      // (cf. checkHashBitsOverlap, exec/HashTable.cpp:1853)
-      int bits = 0;
-      while ((1u << bits) < world) {
-        ++bits;
+    // one destination: nothing to hash, group or send — the rows go straight to the receive
+    // buffers (one device copy: the caller's batch is only borrowed for this call)
+    slot.sendCounts[0] = slot.recvCounts[0] = n;
+    slot.rows = n;
+    for (int32_t i = 0; i < numCols; ++i) {
+      void* dst = slot.received[i].ensure(static_cast<size_t>(std::max<int64_t>(n, 1)) * x->widths[i] + 64);
+      if (n > 0) {
+        HIP_OK(hipMemcpyAsync(dst, in[i], static_cast<size_t>(n) * x->widths[i], hipMemcpyDeviceToDevice, rt.stream));
       }
-      a.kind = VX355_PART_BIT_RANGE;
-      a.bitBegin = 64 - bits;
-      a.mask = world - 1;
-    } else {
-      a.kind = VX355_PART_MODULO;  // exec/HashPartitionFunction.cpp:112-115
     }
-    a.numPartitions = world;
-    a.numRows = n;
+    HIP_OK(hipEventRecord(slot.done, rt.stream));
+    slot.inFlight = true;
+    ++x->sent;
+    return VX355_OK;
+  }
+  for (int32_t i = 0; i < numCols; ++i) {
+    grouped[i] = slot.grouped[i].ensure(static_cast<size_t>(std::max<int64_t>(n, 1)) * x->widths[i] + 64);
+  }
+  if (n > 0) {
+    HashPartArgs a = destinationArgs(*x, db, static_cast<uint32_t>(c->world), n);
     a.out = static_cast<uint32_t*>(x->parts.ensure(static_cast<size_t>(n) * 4 + 64));
     VX_LAUNCH("k_hash_partition", k_hash_partition, streamGrid(n, 256), 256, 0, a);
     std::vector<int32_t> widths(x->widths);
@@ -658,6 +709,32 @@ int vx355_exchange_receive(vx355_exchange* x, vx355_column* cols_out, int64_t* r
     cols_out[i] = col;
   }
   *rows_out = slot.rows;
+  VX_API_END
+}
+
+// The destination rank of every row of 'batch' as this edge computes it for 'num_destinations'
+// ranks (0 = the communicator's size): VectorHasher::hash of the key columns +
+// HashPartitionFunction::partition, the fused kernel vx355_exchange_send runs. For inspection and
+// for parity tests of the N > 1 grouping on a box with one GPU.
+int vx355_exchange_destinations(vx355_exchange* x, const vx355_batch* batch, int32_t num_destinations,
+                                uint32_t* out, int32_t out_mem) {
+  VX_API_BEGIN_CTX(VX_CTX_OF(x))
+  VX_CHECK_ARG(x && batch && out, "NULL argument");
+  VX_CHECK_ARG(num_destinations >= 0 && num_destinations <= 64, "0..64 destinations");
+  const int64_t n = batch->num_rows;
+  if (n == 0) {
+    return VX355_OK;
+  }
+  DeviceBatch db;
+  db.load(batch, x->keyCols);
+  const uint32_t world = num_destinations ? static_cast<uint32_t>(num_destinations) : static_cast<uint32_t>(x->comm->world);
+  HashPartArgs a = destinationArgs(*x, db, world, n);
+  DevBuf tmp;
+  a.out = out_mem == VX355_MEM_HOST ? static_cast<uint32_t*>(tmp.ensure(static_cast<size_t>(n) * 4 + 64)) : out;
+  VX_LAUNCH("k_hash_partition", k_hash_partition, streamGrid(n, 256), 256, 0, a);
+  if (out_mem == VX355_MEM_HOST) {
+    copyOut(out, VX355_MEM_HOST, a.out, static_cast<size_t>(n) * 4);
+  }
   VX_API_END
 }
 

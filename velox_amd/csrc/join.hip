@@ -1625,6 +1625,127 @@ __global__ __launch_bounds__(256) void k_join_filter(FilterPassArgs a) {
   }
 }
 
+// ---- null-aware joins with an extra filter (HashProbe::evalFilterForNullAwareJoin,
+// HashProbe.cpp:1639-1700) -----------------------------------------------------------------------
+// x [NOT] IN (SELECT y FROM build WHERE filter(probe, build)) is three valued. After k_join_filter
+// a probe row is TRUE when a build row with an equal key passes the filter. Of the others,
+//   a row whose key is not null is NULL iff the filter passes on some build row whose key IS null,
+//   a row whose key is null     is NULL iff the filter passes on ANY build row
+// (the reference pairs them with listNullKeyRows / listAllRows), else FALSE. hits[r] becomes
+// kNullKey32 for NULL and kNoRow32 for FALSE; NOT IN (anti) emits the FALSE rows, IN as a column
+// (left semi project) reports first match / -2 / -1.
+__global__ __launch_bounds__(256) void k_list_null_keys(const uint8_t* keyNull, int64_t n, uint32_t* rows,
+                                                         uint32_t* count) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const int64_t rounds = (n + stride - 1) / stride;
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  for (int64_t r = 0; r < rounds; ++r, i += stride) {
+    const bool isNull = i < n && keyNull[i] != 0;
+    const uint64_t m = ballot(isNull);
+    if (m == 0) {
+      continue;
+    }
+    uint32_t base = 0;
+    const int leader = __ffsll(static_cast<long long>(m)) - 1;
+    if (lane() == leader) {
+      base = atomicAdd(count, static_cast<uint32_t>(popc64(m)));
+    }
+    base = __shfl(base, leader, kWave);
+    if (isNull) {
+      rows[base + lanePrefix(m)] = static_cast<uint32_t>(i);
+    }
+  }
+}
+
+// Probe rows that k_na_resolve has to look at: no passing pair with an equal key.
+__global__ __launch_bounds__(256) void k_na_pending(const uint32_t* hits, int64_t n, int64_t numNullKeyRows,
+                                                     uint32_t* pending, uint32_t* count) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const int64_t rounds = (n + stride - 1) / stride;
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  for (int64_t r = 0; r < rounds; ++r, i += stride) {
+    // a row with a non-null key only has candidates when the build side holds null keys
+    const bool want = i < n && !isHit(hits[i]) && (hits[i] == kNullKey32 || numNullKeyRows > 0);
+    const uint64_t m = ballot(want);
+    if (m == 0) {
+      continue;
+    }
+    uint32_t base = 0;
+    const int leader = __ffsll(static_cast<long long>(m)) - 1;
+    if (lane() == leader) {
+      base = atomicAdd(count, static_cast<uint32_t>(popc64(m)));
+    }
+    base = __shfl(base, leader, kWave);
+    if (want) {
+      pending[base + lanePrefix(m)] = static_cast<uint32_t>(i);
+    }
+  }
+}
+
+struct NullAwareArgs {
+  JoinFilterArgs f;
+  uint32_t* hits;
+  const uint32_t* pending;
+  uint32_t numPending;
+  uint32_t pad;
+  const uint32_t* nullKeyRows;
+  int64_t numNullKeyRows;
+  int64_t numBuildRows;
+};
+
+// One wave per pending probe row: the lanes share out the candidate build rows.
+__global__ __launch_bounds__(256) void k_na_resolve(NullAwareArgs a) {
+  const uint32_t waves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t p = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; p < a.numPending; p += waves) {
+    const uint32_t row = a.pending[p];
+    const bool nullKey = a.hits[row] == kNullKey32;
+    const int64_t candidates = nullKey ? a.numBuildRows : a.numNullKeyRows;
+    bool found = false;
+    for (int64_t base = 0; base < candidates && !found; base += 64) {
+      const int64_t c = base + lane();
+      bool pass = false;
+      if (c < candidates) {
+        const uint32_t b = nullKey ? static_cast<uint32_t>(c) : a.nullKeyRows[c];
+        pass = evalJoinFilter(a.f, row, b);
+      }
+      found = ballot(pass) != 0;
+    }
+    if (lane() == 0) {
+      a.hits[row] = found ? kNullKey32 : kNoRow32;
+    }
+  }
+}
+
+// Output counts and tile sums from the resolved hits[] (TRUE = a build row, kNullKey32 = NULL,
+// kNoRow32 = FALSE).
+__global__ __launch_bounds__(256) void k_na_counts(const uint32_t* hits, int64_t numRows, int64_t numTiles,
+                                                    int32_t joinType, uint32_t* counts, uint64_t* tileSums) {
+  __shared__ uint64_t waveSums[4];
+  for (int64_t tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+    uint64_t mine = 0;
+    for (int it = 0; it < kTileRows / 256; ++it) {
+      const int64_t r = tile * kTileRows + it * 256 + threadIdx.x;
+      if (r < numRows) {
+        const uint32_t c = joinType == VX355_JOIN_ANTI ? (hits[r] == kNoRow32 ? 1 : 0) : 1;
+        counts[r] = c;
+        mine += c;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mine += shfl64(mine, lane() ^ off);
+    }
+    if (lane() == 0) {
+      waveSums[threadIdx.x >> 6] = mine;
+    }
+    blockSync();
+    if (threadIdx.x == 0) {
+      tileSums[tile] = waveSums[0] + waveSums[1] + waveSums[2] + waveSums[3];
+    }
+    blockSync();
+  }
+}
+
 // ---- counting joins (INTERSECT ALL / EXCEPT ALL, HashProbe.cpp:1345-1365) -------------------
 // remaining[head row] = occurrences of the key not yet consumed by a probe row.
 // Probe rows of one batch that hit the same key are ranked in probe-row order
@@ -1998,7 +2119,11 @@ bool keepsNullKeyRows(int32_t t) {
       t == VX355_JOIN_RIGHT_ANTI;
 }
 // Rows with null keys stay in the row store (and, with nullAsValue, enter the table).
-bool retainsNullKeyRows(int32_t joinType, bool nullAsValue) { return keepsNullKeyRows(joinType) || nullAsValue; }
+// ... and in the row store of a null-aware join: with an extra filter its null-key build rows
+// take part in the result (HashProbe::evalFilterForNullAwareJoin, HashProbe.cpp:1639-1700).
+bool retainsNullKeyRows(int32_t joinType, bool nullAsValue, bool nullAware = false) {
+  return keepsNullKeyRows(joinType) || nullAsValue || nullAware;
+}
 bool marksProbedRows(int32_t t) {
   return t == VX355_JOIN_RIGHT || t == VX355_JOIN_FULL || t == VX355_JOIN_RIGHT_SEMI_FILTER ||
       t == VX355_JOIN_RIGHT_SEMI_PROJECT || t == VX355_JOIN_RIGHT_ANTI;
@@ -2043,6 +2168,7 @@ struct vx355_join_build {
   bool finished = false;
   DevBuf keyNull;  // right / full joins: 1 byte per row, set for rows with a null key (nullAsValue: mask of null keys)
   bool nullAsValue = false;  // HashJoinNode::isNullAsValue
+  bool nullAware = false;    // HashJoinNode::isNullAware
   std::vector<int64_t> obsMin, obsMax;
   DevBuf countersBuf, scratch, validWords, rowList;
   // arena of key / payload strings longer than 12 bytes (blocks never move: stored views point into them)
@@ -2079,6 +2205,8 @@ struct vx355_join_table {
   bool keepsNullRows = false;
   bool nullAsValue = false;
   DevBuf keyNull;  // nullAsValue: the builds' null-key masks, by build row
+  DevBuf nullKeyRows;         // null-aware joins: the build rows whose key is null (u32 list)
+  int64_t numNullKeyRows = 0;
   // dynamic filters: ascending distinct values per key, computed on first request
   std::vector<DevBuf> distinctVals;
   std::vector<int64_t> distinctCount;  // -1 = not computed
@@ -2141,7 +2269,7 @@ void growBuild(vx355_join_build& h, int64_t rows) {
     const size_t w = static_cast<size_t>(keyWordsOf(h.keyKinds[k])) * 8;
     h.keyVals[k].ensure(static_cast<size_t>(cap) * w + 64, true, static_cast<size_t>(h.numRows) * w);
   }
-  if (retainsNullKeyRows(h.joinType, h.nullAsValue)) {
+  if (retainsNullKeyRows(h.joinType, h.nullAsValue, h.nullAware)) {
     h.keyNull.ensure(static_cast<size_t>(cap) + 64, true, static_cast<size_t>(h.numRows));
   }
   for (size_t d = 0; d < h.depVals.size(); ++d) {
@@ -2188,7 +2316,7 @@ void buildAddInput(vx355_join_build& h, const vx355_batch* batch) {
   for (int k = 0; k < va.numKeys; ++k) {
     anyKeyNulls = anyKeyNulls || va.keys[k].nulls != nullptr;
   }
-  const bool keepNulls = retainsNullKeyRows(h.joinType, h.nullAsValue);
+  const bool keepNulls = retainsNullKeyRows(h.joinType, h.nullAsValue, h.nullAware);
   int32_t* rows = nullptr;
   int64_t selected = n;
   if (anyKeyNulls) {  // key columns without null bitmaps (the common case) skip both passes
@@ -2296,7 +2424,7 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
         copyIn(h.keyVals[k].as<char>() + h.numRows * w, o.keyVals[k].ptr(), VX355_MEM_DEVICE,
                static_cast<size_t>(o.numRows) * w);
       }
-      if (retainsNullKeyRows(h.joinType, h.nullAsValue)) {
+      if (retainsNullKeyRows(h.joinType, h.nullAsValue, h.nullAware)) {
         copyIn(h.keyNull.as<char>() + h.numRows, o.keyNull.ptr(), VX355_MEM_DEVICE, static_cast<size_t>(o.numRows));
       }
       h.unmappable = h.unmappable || o.unmappable;
@@ -2374,7 +2502,7 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
     ia.ranges[k] = t->ranges[k];
   }
   ia.numRows = h.numRows;
-  if (retainsNullKeyRows(h.joinType, h.nullAsValue) && h.hasNullKeys) {
+  if (retainsNullKeyRows(h.joinType, h.nullAsValue, h.nullAware) && h.hasNullKeys) {
     ia.keyNull = h.keyNull.as<uint8_t>();
     t->keepsNullRows = true;
   }
@@ -2460,6 +2588,17 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
   // against them, dynamic filters (value lists, Bloom blocks) are made from them.
   t->keyStore = std::move(h.keyVals);
   h.keyVals.clear();
+  if (h.nullAware && h.hasNullKeys && h.numRows > 0) {
+    // the rows a null-aware join with an extra filter tests every unmatched probe row against
+    t->nullKeyRows.ensure(static_cast<size_t>(h.numRows) * 4 + 64);
+    uint32_t* count = reinterpret_cast<uint32_t*>(h.countersBuf.ensure(64));
+    HIP_OK(hipMemsetAsync(count, 0, 4, rt.stream));
+    VX_LAUNCH("k_list_null_keys", k_list_null_keys, streamGrid(h.numRows, 256), 256, 0, h.keyNull.as<uint8_t>(),
+              h.numRows, t->nullKeyRows.as<uint32_t>(), count);
+    uint32_t n = 0;
+    copyOut(&n, VX355_MEM_HOST, count, 4);
+    t->numNullKeyRows = n;
+  }
   if (h.nullAsValue) {
     t->keyNull = std::move(h.keyNull);  // generic-mode probes compare null masks too
   }
@@ -2559,13 +2698,18 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
     return;
   }
   ProbeArgs a{};
-  if (p.nullAware && p.joinType == VX355_JOIN_ANTI) {
+  if (p.nullAware && filtered) {
+    // three-valued IN over the FILTERED build rows: resolved behind k_join_filter (k_na_resolve)
+    a.nullAware = 1;
+    p.nullKeyValue = -2;
+    p.missValue = -1;
+  } else if (p.nullAware && p.joinType == VX355_JOIN_ANTI) {
     if (t.hasNullKeys) {
       return;  // NOT IN over a set holding a null: no row qualifies (HashBuild's antiJoinHasNullKeys)
     }
     a.nullAware = t.numRows > 0 ? 1 : 0;  // an empty build side passes every row, null keys included
   }
-  if (p.nullAware && p.joinType == VX355_JOIN_LEFT_SEMI_PROJECT) {
+  if (p.nullAware && !filtered && p.joinType == VX355_JOIN_LEFT_SEMI_PROJECT) {
     // x IN (subquery) as a column (HashProbe.cpp:923-966, no filter): NULL for a null probe key
     // unless the build side is empty and null-free, NULL instead of FALSE once the build side
     // holds a null key
@@ -2782,6 +2926,29 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
     fa.joinType = p.joinType;
     const int fgrid = static_cast<int>(std::min<int64_t>(p.numTiles, static_cast<int64_t>(rt.numCUs) * 8));
     VX_LAUNCH("k_join_filter", k_join_filter, fgrid, 256, 0, fa);
+    if (filtered && p.nullAware) {
+      // HashProbe::evalFilterForNullAwareJoin: rows without a passing equal-key pair meet the
+      // null-key build rows (key not null) or every build row (key null)
+      uint32_t* pending = static_cast<uint32_t*>(p.hitRows.ensure(static_cast<size_t>(n) * 4 + 64));
+      uint32_t* count = reinterpret_cast<uint32_t*>(p.sparseStats.ensure(64));
+      HIP_OK(hipMemsetAsync(count, 0, 4, rt.stream));
+      VX_LAUNCH("k_na_pending", k_na_pending, streamGrid(n, 256), 256, 0, a.hits, n, t.numNullKeyRows, pending, count);
+      uint32_t numPending = 0;
+      copyOut(&numPending, VX355_MEM_HOST, count, 4);
+      if (numPending > 0) {
+        NullAwareArgs na{};
+        na.f = fa.f;
+        na.hits = a.hits;
+        na.pending = pending;
+        na.numPending = numPending;
+        na.nullKeyRows = t.nullKeyRows.as<uint32_t>();
+        na.numNullKeyRows = t.numNullKeyRows;
+        na.numBuildRows = t.numRows;
+        const int64_t waves = std::min<int64_t>(numPending, static_cast<int64_t>(rt.numCUs) * 32);
+        VX_LAUNCH("k_na_resolve", k_na_resolve, static_cast<int>(ceilDiv(waves, 4)), 256, 0, na);
+      }
+      VX_LAUNCH("k_na_counts", k_na_counts, fgrid, 256, 0, a.hits, n, p.numTiles, p.joinType, fa.counts, sums);
+    }
   }
   VX_LAUNCH("k_scan_u64", k_scan_u64, 1, 1024, 0, sums, p.numTiles, offs);
   p.hostTileOffsets.resize(p.numTiles + 1);
@@ -3173,6 +3340,7 @@ int vx355_join_build_create(const vx355_join_build_spec* spec, vx355_join_build*
   auto h = std::make_unique<vx355_join_build>();
   h->joinType = spec->join_type;
   h->nullAsValue = spec->null_as_value != 0;
+  h->nullAware = spec->null_aware != 0;
   for (int32_t k = 0; k < spec->num_keys; ++k) {
     const int32_t kind = spec->key_types[k];
     if (kindWidth(kind) < 0) {
@@ -3355,9 +3523,6 @@ int vx355_join_probe_set_filter(vx355_join_probe* h, const vx355_join_filter_ter
   VX_CHECK_ARG(!h->hasInput, "set_filter after the first add_input");
   if (n_terms > 0 && countingJoin(h->joinType)) {
     VX_THROW(VX355_EUNSUPPORTED, "counting joins take no extra filter (exec/HashProbe.cpp:1345-1365)");
-  }
-  if (n_terms > 0 && h->nullAware) {
-    VX_THROW(VX355_EUNSUPPORTED, "null-aware join with an extra filter");
   }
   h->filter.assign(terms, terms + n_terms);
   h->usedCols = h->keyCols;

@@ -41,7 +41,7 @@ SYMBOLS = [
     "vx355_value_dict_create", "vx355_value_dict_compute", "vx355_value_dict_lookup", "vx355_value_dict_size",
     "vx355_value_dict_destroy",
     "vx355_all_gather_v", "vx355_exchange_create", "vx355_exchange_send", "vx355_exchange_receive",
-    "vx355_exchange_stream", "vx355_exchange_destroy", "vx355_join_repartition", "vx355_agg_merge_partials",
+    "vx355_exchange_stream", "vx355_exchange_destroy", "vx355_exchange_destinations", "vx355_join_repartition", "vx355_agg_merge_partials",
 ]
 
 # int (*vx355_join_chunk_sink)(void* arg, int32_t chunk, const vx355_batch* received, vx355_join_probe* probe)
@@ -140,6 +140,7 @@ def lib():
     L.vx355_exchange_create.argtypes = [vp, P(i32), i32, P(i32), i32, P(vp)]
     L.vx355_exchange_send.argtypes = [vp, P(abi.Batch)]
     L.vx355_exchange_receive.argtypes = [vp, P(abi.Column), P(i64)]
+    L.vx355_exchange_destinations.argtypes = [vp, P(abi.Batch), i32, vp, i32]
     L.vx355_exchange_stream.restype = vp
     L.vx355_exchange_stream.argtypes = [vp]
     L.vx355_exchange_destroy.argtypes = [vp]
@@ -279,6 +280,12 @@ class Exchange:
 
     def send(self, batch):
         _check(lib().vx355_exchange_send(self.h, batch.ref()))
+
+    def destinations(self, batch, num_destinations=0):
+        """Destination rank per row for num_destinations ranks (0 = the communicator's size)."""
+        out = np.zeros(max(1, batch.num_rows), dtype=np.uint32)
+        _check(lib().vx355_exchange_destinations(self.h, batch.ref(), num_destinations, out.ctypes.data, abi.MEM_HOST))
+        return out[: batch.num_rows]
 
     def receive(self):
         """-> (vx355_column array of FLAT device columns, rows); valid until the next receive."""
