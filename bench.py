@@ -126,7 +126,8 @@ def library_comm(args, torch, dist, rank, world, dev_index, share):
             os.unlink(box[0])
         if int(flag.item()) == 0:
             return None, "; ".join(x for x in reasons if x) or "commcheck failed"
-    uid = [ops.Comm.unique_id() if rank == 0 else None]
+    # (one rank: no RCCL at all, not even the id - see vx355_comm_create)
+    uid = [(ops.Comm.unique_id() if world > 1 else bytes(128)) if rank == 0 else None]
     if world > 1:
         dist.broadcast_object_list(uid, src=0)
     comm = ops.Comm(uid[0], world, rank)
@@ -766,6 +767,15 @@ class C5:
     tdist = None   # else: torch.distributed (module or GroupDist) through velox_amd/dist.py
 
     def step(self, step_kind=None):
+        pre = os.environ.get("VX355_C5_PRESTEP")   # experiment: one step of the other path first
+        if pre and not hasattr(self, "_prestepped"):
+            self._prestepped = True
+            if pre == "torch" and self.comm is not None:
+                comm, self.comm = self.comm, None
+                import torch.distributed as tdist_mod
+                self.tdist = self.tdist or tdist_mod
+                self.step()
+                self.comm = comm
         if self.comm is not None:
             return self.step_library()
         dist = self.tdist
@@ -776,8 +786,13 @@ class C5:
             total = sum(int(m.shape[0]) for _, outs in per_chunk for m, _ in outs)
             stats = table.stats()
         else:
+            fn = None
+            if os.environ.get("VX355_C5_LIBEXCHANGE") == "1":   # torch-owned buffers, library collectives
+                if not hasattr(self, "_libcomm"):
+                    self._libcomm = ops.Comm(ops.Comm.unique_id(), 1, 0)
+                fn = vdist.LibExchange(self.torch, self._libcomm)
             total, outputs, stats = vdist.repartitioned_join(self.backend, dist, self.torch,
-                                                             [self.pk, self.a], [self.fk, self.m])
+                                                             [self.pk, self.a], [self.fk, self.m], exchange_fn=fn)
         self.matches, self.stats = total, stats
         return total
 
@@ -793,7 +808,10 @@ class C5:
             self._out = (torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.int32, device=dev),
                          torch.empty(cap, dtype=torch.int64, device=dev), torch.empty(cap // 64 + 1, dtype=torch.int64, device=dev))
             self._build = DevBatch([dcol(abi.BIGINT, self.pk), dcol(abi.BIGINT, self.a)], int(self.pk.shape[0]))
-            self._probe = DevBatch([dcol(abi.BIGINT, self.fk), dcol(abi.DOUBLE, self.m)], self.n)
+            if os.environ.get("VX355_C5_KEYONLY") == "1":
+                self._probe = DevBatch([dcol(abi.BIGINT, self.fk)], self.n)
+            else:
+                self._probe = DevBatch([dcol(abi.BIGINT, self.fk), dcol(abi.DOUBLE, self.m)], self.n)
         mapping, brows, payload, nulls = self._out
         descs = (abi.OutColumn * 1)()
         descs[0].type_kind, descs[0].mem = abi.BIGINT, abi.MEM_DEVICE
@@ -1022,6 +1040,15 @@ def main():
                 dist.init_process_group("gloo", rank=rank, world_size=world)
             nccl_group = dist.new_group(backend="nccl", device_id=device)
             backend = "nccl"
+    if os.environ.get("VX355_BENCH_TORCH_NCCL") == "1":
+        # experiment: does a torch.distributed NCCL (= RCCL) communicator in the process change kernel times?
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        extra = dist.new_group(backend="nccl", device_id=device)
+        t = torch.ones(1024, device=device)
+        dist.all_reduce(t, group=extra)
+        torch.cuda.synchronize()
     n_gpus = comm.info()[0] if comm is not None else (dist.get_world_size() if dist.is_initialized() else 1)
     if n_gpus != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the communicator spans {n_gpus} ranks")

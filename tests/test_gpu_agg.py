@@ -723,6 +723,46 @@ def test_radix_partitioned_lds_path_high_cardinality(oracle, vx, max_bins, monke
         assert st.hash_mode == abi.MODE_ARRAY and st.radix_launches >= 2 and st.deferred_rows > 0
 
 
+@pytest.mark.parametrize("shape", ["uniform", "hot_keys", "nulls_and_masks"])
+def test_radix_path_over_open_addressing_tables(oracle, vx, shape, monkeypatch):
+    """Sparse BIGINT keys (normalized-key mode): rows are partitioned by the HOME SLOT of their group,
+    folded in an LDS window of that slot range and merged into the open-addressing table with one
+    findOrInsert per group (k_rp_aggregate_hashed) - several batches (the table grows and is re-keyed
+    in between), hot keys (sliced partitions flush with atomics), null keys / null inputs. Same
+    groups, same first-seen order, bit-exact integers and dyadic sums as the oracle."""
+    monkeypatch.setenv("VX355_AGG_RADIX_MIN_ROWS", "1")
+    monkeypatch.setenv("VX355_AGG_COALESCE_ROWS", "0")
+    if shape == "hot_keys":
+        monkeypatch.setenv("VX355_AGG_RADIX_SLICE", "4096")
+    rng = np.random.default_rng(909)
+    n = 400_000
+    batches = []
+    for b in range(3):
+        j = rng.integers(0, 60_000 * (b + 1), n).astype(np.uint64)
+        if shape == "hot_keys":
+            hot = rng.random(n) < 0.4
+            j[hot] = rng.integers(0, 3, int(hot.sum())).astype(np.uint64)
+        k = ((j * np.uint64(0x9E3779B97F4A7C15)) ^ np.uint64(0x5DEECE66D)).astype(np.int64)   # all over int64
+        v = _dyadic(rng, n)
+        w = rng.integers(-1 << 40, 1 << 40, n).astype(np.int64)
+        valids = [None, None, None]
+        if shape == "nulls_and_masks":
+            valids = [rng.random(n) > 0.01, rng.random(n) > 0.1, None]
+        batches.append(batch_of([k, v, w], valids))
+    for aggs in ([(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)],
+                 [(abi.AGG_SUM, 2, abi.BIGINT), (abi.AGG_MIN, 1, abi.DOUBLE), (abi.AGG_COUNT, 1, abi.DOUBLE)],
+                 [(abi.AGG_AVG, 1, abi.DOUBLE), (abi.AGG_MAX, 2, abi.BIGINT)]):
+        exp, _ = run_agg(oracle, batches, [0], [abi.BIGINT], aggs, max_rows=100000)
+        vx.profile_reset()
+        vx.profile_enable(True)
+        got, gop = run_agg(vx, batches, [0], [abi.BIGINT], aggs, max_rows=100000)
+        vx.profile_enable(False)
+        assert_columns_equal(got, exp, gop.kinds, what="hashed radix %s %s" % (shape, aggs))
+        st = gop.stats()
+        assert st.hash_mode == abi.MODE_NORMALIZED_KEY and st.radix_launches >= 2, (st.hash_mode, st.radix_launches)
+        assert "k_rp_aggregate" in vx.profile()
+
+
 def test_radix_path_two_keys_fused_filter(oracle, vx, monkeypatch):
     """Two grouping keys (the normalized key is the partitioning key) behind a fused filter."""
     monkeypatch.setenv("VX355_AGG_RADIX_MIN_ROWS", "1")

@@ -654,6 +654,12 @@ struct RadixArgs {
   int32_t numBins;     // level-1 bins
   int32_t keyBits;     // layout of record word 0
   int32_t rowBits;
+  // Open-addressing tables (normalized-key mode, sparse keys): the records are partitioned by the
+  // group's HOME SLOT = twang_mix64(normalized key) & slotMask instead of by the key itself, and
+  // carry the full key in their last word (k_rp_aggregate_hashed).
+  int32_t hashed;
+  int32_t pad0;
+  uint64_t slotMask;
   int32_t valIdx[kRadixMaxAccs];  // operand word of accumulator j, -1 for counts
   int32_t accOfVal[kRadixMaxAccs];  // inverse: accumulator of operand word q
   int64_t tileRows;    // rows per workgroup tile
@@ -724,7 +730,8 @@ __global__ __launch_bounds__(1024) void k_rp_count1(RadixArgs r) {
           uint64_t key;
           const int st = rpKey<KW>(r, row, raw[u], &key);
           if (st == 0) {
-            atomicAdd(&hist[key >> shift], 1u);
+            const uint64_t part = r.hashed ? (twangMix64(key) & r.slotMask) : key;
+            atomicAdd(&hist[part >> shift], 1u);
           } else if (st == 2) {
             defer = true;
           }
@@ -958,10 +965,12 @@ __device__ inline void rpSortedEmit(SortLds<W>& l, int numBins, const uint64_t (
 }
 
 // Level 1 with sorted sub-tiles (numBins <= kSortBins); same records as k_rp_scatter1.
-template <int KW, int W, bool FLATV>
+// HASHED: word 0 carries the home slot instead of the key, the last word the full key.
+template <int KW, int W, bool FLATV, bool HASHED>
 __global__ __launch_bounds__(kSortThreads) void k_rp_scatter1_sorted(RadixArgs r) {
   __shared__ SortLds<W> l;
   constexpr int R = SortLds<W>::kRounds;
+  constexpr int V = W - (HASHED ? 1 : 0);   // word 0 + operand words
   const AggArgs& a = r.a;
   const int shift = r.shiftB + r.shift2;
   for (int i = threadIdx.x; i < kSortBins; i += kSortThreads) {
@@ -984,7 +993,7 @@ __global__ __launch_bounds__(kSortThreads) void k_rp_scatter1_sorted(RadixArgs r
         raw[u] = row < end ? rpLoadKey<KW>(r, row) : 0;
         if constexpr (FLATV) {
 #pragma unroll
-          for (int q = 1; q < W; ++q) {
+          for (int q = 1; q < V; ++q) {
             vals[u][q] = row < end ? static_cast<const uint64_t*>(a.accs[r.accOfVal[q - 1]].in.values)[row] : 0;
           }
         }
@@ -1001,7 +1010,7 @@ __global__ __launch_bounds__(kSortThreads) void k_rp_scatter1_sorted(RadixArgs r
         if constexpr (FLATV) {
           mask = (1ULL << a.numAccs) - 1;
 #pragma unroll
-          for (int q = 1; q < W; ++q) {
+          for (int q = 1; q < V; ++q) {
             const AccArg& acc = a.accs[r.accOfVal[q - 1]];
             if (acc.kind == ACC_MIN || acc.kind == ACC_MAX) {
               vals[u][q] = acc.inIsInt ? int64ToOrdered(static_cast<int64_t>(vals[u][q]))
@@ -1010,7 +1019,7 @@ __global__ __launch_bounds__(kSortThreads) void k_rp_scatter1_sorted(RadixArgs r
           }
         } else {
 #pragma unroll
-          for (int q = 1; q < W; ++q) {
+          for (int q = 1; q < V; ++q) {
             const int j = r.accOfVal[q - 1];
             vals[u][q] = 0;
             if (accInput(a, a.accs[j], row, &vals[u][q])) {
@@ -1024,8 +1033,13 @@ __global__ __launch_bounds__(kSortThreads) void k_rp_scatter1_sorted(RadixArgs r
             }
           }
         }
-        vals[u][0] = key | (static_cast<uint64_t>(row) << r.keyBits) | (mask << (r.keyBits + r.rowBits));
-        bin[u] = static_cast<uint32_t>(key >> shift);
+        uint64_t part = key;
+        if constexpr (HASHED) {
+          part = twangMix64(key) & r.slotMask;
+          vals[u][W - 1] = key;
+        }
+        vals[u][0] = part | (static_cast<uint64_t>(row) << r.keyBits) | (mask << (r.keyBits + r.rowBits));
+        bin[u] = static_cast<uint32_t>(part >> shift);
       }
       const uint64_t keyMask = (1ULL << r.keyBits) - 1;
       rpSortedEmit<W, R>(l, r.numBins, vals, bin, r.recs,
@@ -1617,6 +1631,363 @@ __global__ __launch_bounds__(512) void k_rp_aggregate(RadixAggArgs r) {
         rpFoldInit(f, r);
         rpFoldRecords<W>(f, r, b, b + r.sliceRecs < end ? b + r.sliceRecs : end);
         rpFoldFlush(f, r, p, false, true);
+      }
+    }
+    blockSync();
+  }
+}
+
+// ---- fold for open-addressing tables (normalized-key mode; BASELINE config 4 with sparse keys) ----
+// k_agg_global pays two or three HBM atomics per row (one per accumulator word + the first-row
+// word), and the chip retires ~21 G of them per second: 10^9 rows take > 100 ms whatever else
+// happens. Here the rows arrive partitioned by the HOME SLOT of their group in the global table
+// (twang_mix64(key) & slotMask), in partitions of ~1024 records: the table grows with the number
+// of groups, a chunk of rows does not, so the slot range of a partition is chosen per launch
+// (capacity / partitions), not fixed. The workgroup that owns a partition folds its records into an
+// LDS hash table of kHashSlots entries {key, accumulator words, first row} - start position = the
+// home slot scaled into the table (entries stay in home-slot order), linear probing, entries
+// claimed with LDS compare-and-swap - and then visits every occupied entry's group row in HBM
+// ONCE: findOrInsert from the home slot (ascending over the lanes: the rows of a partition are
+// neighbours in the table), plain read-modify-write, because a key has exactly one home slot and
+// therefore exactly one owner per launch. A record that finds the LDS table full goes to its group
+// row with HBM atomics on its own (and makes the whole partition flush with atomics).
+constexpr int kHashSlots = 2048;           // LDS entries per fold: 56 KB with two words, two workgroups per CU
+constexpr int kHashRecsPerPart = 1024;     // records a partition is sized for (load <= 0.5 if all distinct)
+
+struct HashFold {
+  unsigned long long* keys;  // [S], kEmpty = free
+  uint64_t* acc;             // [S][A]
+  uint32_t* first;           // [S]
+  uint32_t* scratch;         // [0] new groups, [1] pair base, [2] some record overflowed the window
+  int S;
+  int A;
+};
+
+__device__ inline void hashFoldInit(const HashFold& f, const RadixAggArgs& r) {
+  for (int i = threadIdx.x; i < f.S; i += blockDim.x) {
+    f.keys[i] = kEmpty;
+    f.first[i] = 0xffffffffu;
+  }
+  for (int i = threadIdx.x; i < f.S * f.A; i += blockDim.x) {
+    f.acc[i] = accIdentity(r.wordKind[i % f.A]);
+  }
+  if (threadIdx.x == 0) {
+    f.scratch[2] = 0;
+  }
+  blockSync();
+}
+
+// One record straight to its group row in HBM (window full): what updateGlobal does.
+template <int W>
+__device__ inline void hashFoldDirect(const RadixAggArgs& r, const uint64_t (&w)[W], uint64_t key, uint32_t row,
+                                      uint32_t mask) {
+  uint64_t* g = findOrInsert(r.table, r.stride, r.capacity, key, r.counters);
+  if (g == nullptr) {
+    return;
+  }
+  const unsigned long long old = atomicMin(reinterpret_cast<unsigned long long*>(g + 1), r.rowBase + row);
+  if (old == kNoRow) {
+    atomicAdd(&r.counters->numNewGroups, 1u);
+    r.counters->pairsBroken = 1;  // this group is not in the launch's pair list
+  }
+  for (int j = 0; j < r.numAccs; ++j) {
+    if (!((mask >> j) & 1)) {
+      continue;
+    }
+    const uint64_t v = r.valIdx[j] < 0 ? 1ULL : w[1 + r.valIdx[j]];
+    uint64_t* word = g + r.wordOff[r.ldsIdx[j]];
+    if (r.kind[j] == ACC_SUM_F64 && r.splitM[j] != 0.0) {
+      double hi, lo;
+      splitDouble(__longlong_as_double(static_cast<long long>(v)), r.splitM[j], &hi, &lo);
+      applyGlobal(word, ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(hi)), r.counters);
+      applyGlobal(word + 1, ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(lo)), r.counters);
+    } else {
+      applyGlobal(word, r.kind[j] == ACC_COUNT ? ACC_SUM_I64_WRAP : r.kind[j], v, r.counters);
+    }
+  }
+}
+
+template <int W>
+__device__ inline void hashFoldRecords(const HashFold& f, const RadixAggArgs& r, int64_t p, uint64_t begin, uint64_t end) {
+  const int A = f.A;
+  const uint64_t base = static_cast<uint64_t>(p) << r.shiftB;
+  const uint64_t keyMask = (1ULL << r.keyBits) - 1;
+  for (uint64_t at = begin; at < end; at += kRadixUnroll * 512) {
+    uint64_t w[kRadixUnroll][W];
+#pragma unroll
+    for (int u = 0; u < kRadixUnroll; ++u) {
+      const uint64_t i = at + u * 512 + threadIdx.x;
+      if (i < end) {
+        rpLoad<W>(r.recs + i * W, w[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kRadixUnroll; ++u) {
+      const uint64_t i = at + u * 512 + threadIdx.x;
+      if (i >= end) {
+        continue;
+      }
+      const uint64_t w0 = w[u][0];
+      const uint64_t key = w[u][W - 1];
+      const uint32_t row = static_cast<uint32_t>(w0 >> r.keyBits) & static_cast<uint32_t>((1ULL << r.rowBits) - 1);
+      const uint32_t mask = static_cast<uint32_t>(w0 >> (r.keyBits + r.rowBits));
+      // home slot inside the partition, scaled into the LDS table
+      int pos = static_cast<int>((((w0 & keyMask) - base) * static_cast<uint64_t>(kHashSlots)) >> r.shiftB);
+      for (int probes = 0;; ++probes) {
+        const unsigned long long k = f.keys[pos];
+        if (k == key) {
+          break;
+        }
+        if (k == kEmpty) {
+          const unsigned long long old = atomicCAS(&f.keys[pos], kEmpty, static_cast<unsigned long long>(key));
+          if (old == kEmpty || old == key) {
+            break;
+          }
+        }
+        if (probes >= kHashSlots) {
+          pos = -1;  // table full
+          break;
+        }
+        pos = (pos + 1) & (kHashSlots - 1);
+      }
+      if (pos < 0) {
+        f.scratch[2] = 1;
+        hashFoldDirect<W>(r, w[u], key, row, mask);
+        continue;
+      }
+      if (f.first[pos] > row) {
+        atomicMin(&f.first[pos], row);
+      }
+      for (int j = 0; j < r.numAccs; ++j) {
+        if (!((mask >> j) & 1)) {
+          continue;
+        }
+        uint64_t* word = f.acc + static_cast<size_t>(pos) * A + r.ldsIdx[j];
+        if (r.valIdx[j] < 0) {
+          applyLds(word, r.kind[j], 1ULL, r.counters);
+        } else if (r.kind[j] == ACC_SUM_F64 && r.splitM[j] != 0.0) {
+          double hi, lo;
+          splitDouble(__longlong_as_double(static_cast<long long>(w[u][1 + r.valIdx[j]])), r.splitM[j], &hi, &lo);
+          applyLds(word, ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(hi)), r.counters);
+          applyLds(word + 1, ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(lo)), r.counters);
+        } else {
+          applyLds(word, r.kind[j], w[u][1 + r.valIdx[j]], r.counters);
+        }
+      }
+    }
+  }
+  blockSync();
+}
+
+// Flush: every lane owns kHashPerLane entries of the LDS table and works on all of them at once -
+// the probe loads, the claims and the row words of its entries are issued back to back, so a lane
+// keeps several dependent HBM round trips in flight instead of one (the flush is latency bound:
+// one findOrInsert + one read-modify-write per group).
+constexpr int kHashPerLane = kHashSlots / 512;
+
+__device__ inline void hashFoldFlush(const HashFold& f, const RadixAggArgs& r, bool exclusive) {
+  const int A = f.A;
+  exclusive = exclusive && f.scratch[2] == 0;  // direct records touched rows of this partition with atomics
+  if (threadIdx.x == 0) {
+    f.scratch[0] = 0;
+    if (!exclusive) {
+      r.counters->pairsBroken = 1;
+    }
+  }
+  blockSync();
+  const uint64_t mask = r.capacity - 1;
+  uint64_t key[kHashPerLane];
+  uint64_t pos[kHashPerLane];
+  uint64_t* row[kHashPerLane];
+  bool pending[kHashPerLane];
+  uint32_t myPos[kHashPerLane];
+#pragma unroll
+  for (int k = 0; k < kHashPerLane; ++k) {
+    // consecutive lanes take consecutive entries: the table is in home-slot order, so a wave's
+    // probes walk the global table in ascending order
+    const int e = k * 512 + threadIdx.x;
+    key[k] = f.keys[e];
+    pending[k] = key[k] != kEmpty;
+    pos[k] = twangMix64(key[k]) & mask;
+    row[k] = nullptr;
+    myPos[k] = 0xffffffffu;
+  }
+  // findOrInsert for all entries of the lane together: one round = one probe of each pending entry
+  for (uint64_t round = 0; round <= mask; ++round) {
+    uint64_t seen[kHashPerLane];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < kHashPerLane; ++k) {
+      seen[k] = pending[k] ? __hip_atomic_load(r.table + pos[k] * r.stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                           : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < kHashPerLane; ++k) {
+      if (!pending[k]) {
+        continue;
+      }
+      uint64_t* g = r.table + pos[k] * r.stride;
+      uint64_t found = seen[k];
+      if (found == kEmpty) {
+        found = atomicCAS(reinterpret_cast<unsigned long long*>(g), kEmpty, static_cast<unsigned long long>(key[k]));
+        if (found == kEmpty) {
+          found = key[k];
+        }
+      }
+      if (found == key[k]) {
+        row[k] = g;
+        pending[k] = false;
+      } else {
+        pos[k] = (pos[k] + 1) & mask;
+        any = true;
+      }
+    }
+    if (!any) {
+      break;
+    }
+    if (round == mask) {
+      r.counters->tableFull = 1;
+    }
+  }
+  // the rows' first-row words, all at once
+  uint64_t oldFirst[kHashPerLane];
+#pragma unroll
+  for (int k = 0; k < kHashPerLane; ++k) {
+    oldFirst[k] = (row[k] != nullptr && exclusive) ? row[k][1] : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < kHashPerLane; ++k) {
+    if (row[k] == nullptr) {
+      continue;
+    }
+    const int e = k * 512 + threadIdx.x;
+    uint64_t* g = row[k];
+    const uint64_t mine = r.rowBase + static_cast<uint64_t>(f.first[e]);
+    bool isNew;
+    if (!exclusive) {
+      const unsigned long long old = atomicMin(reinterpret_cast<unsigned long long*>(g + 1), mine);
+      isNew = old == kNoRow;
+      for (int j = 0; j < A; ++j) {
+        const uint64_t v = f.acc[static_cast<size_t>(e) * A + j];
+        const int32_t kind = r.wordKind[j];
+        if (v != accIdentity(kind)) {
+          if (kind == ACC_SUM_I64) {
+            addPartial128Global(g + r.wordOff[j], v, 0);
+          } else {
+            applyGlobal(g + r.wordOff[j], kind == ACC_COUNT ? ACC_SUM_I64_WRAP : kind, v, r.counters);
+          }
+        }
+      }
+    } else {
+      isNew = oldFirst[k] == kNoRow;
+      if (mine < oldFirst[k]) {
+        g[1] = mine;
+      }
+      for (int j = 0; j < A; ++j) {
+        const uint64_t v = f.acc[static_cast<size_t>(e) * A + j];
+        uint64_t* word = g + r.wordOff[j];
+        switch (r.wordKind[j]) {
+          case ACC_SUM_F64:
+            // a fresh group row holds the identity: no read needed
+            *reinterpret_cast<double*>(word) =
+                (isNew ? 0.0 : *reinterpret_cast<double*>(word)) + __longlong_as_double(static_cast<long long>(v));
+            break;
+          case ACC_SUM_I64: {
+            const uint64_t before = isNew ? 0 : *word;
+            *word = before + v;
+            const uint64_t up = static_cast<uint64_t>(carryUnsigned(before, v));
+            if (up != 0) {
+              word[1] += up;
+            }
+            break;
+          }
+          case ACC_SUM_I64_HI:
+          case ACC_SUM_I64_WRAP:
+          case ACC_COUNT:
+            *word = (isNew ? 0 : *word) + v;
+            break;
+          case ACC_MIN:
+            *word = (isNew || v < *word) ? v : *word;
+            break;
+          default:
+            *word = (isNew || v > *word) ? v : *word;
+            break;
+        }
+      }
+    }
+    if (isNew) {
+      myPos[k] = atomicAdd(&f.scratch[0], 1u);
+    }
+  }
+  blockSync();
+  if (threadIdx.x == 0 && f.scratch[0] != 0) {
+    f.scratch[1] = atomicAdd(&r.counters->numNewGroups, f.scratch[0]);
+  }
+  blockSync();
+  if (r.pairKeys != nullptr && f.scratch[0] != 0) {
+#pragma unroll
+    for (int k = 0; k < kHashPerLane; ++k) {
+      if (myPos[k] != 0xffffffffu) {
+        const int e = k * 512 + threadIdx.x;
+        const uint64_t at = r.pairBase + f.scratch[1] + myPos[k];
+        r.pairKeys[at] = r.rowBase + static_cast<uint64_t>(f.first[e]);
+        r.pairVals[at] = static_cast<uint32_t>((row[k] - r.table) / r.stride);
+      }
+    }
+  }
+  blockSync();
+}
+
+template <int W>
+__global__ __launch_bounds__(512) void k_rp_aggregate_hashed(RadixAggArgs r) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+  __shared__ uint32_t bigList[512];
+  __shared__ uint32_t bigCount;
+  __shared__ uint32_t scratch[4];
+  HashFold f;
+  f.S = kHashSlots;
+  f.A = r.numWords;
+  f.keys = reinterpret_cast<unsigned long long*>(ldsRaw);
+  f.acc = reinterpret_cast<uint64_t*>(f.keys + f.S);
+  f.first = reinterpret_cast<uint32_t*>(f.acc + static_cast<size_t>(f.S) * f.A);
+  f.scratch = scratch;
+  for (int64_t p = blockIdx.x; p < r.numParts; p += gridDim.x) {
+    uint64_t begin, end;
+    rpPartitionRange(r, p, &begin, &end);
+    if (end == begin) {
+      continue;  // uniform per workgroup
+    }
+    const bool split = end - begin > r.sliceRecs;
+    hashFoldInit(f, r);
+    hashFoldRecords<W>(f, r, p, begin, split ? begin + r.sliceRecs : end);
+    hashFoldFlush(f, r, !split);
+  }
+  // Remaining slices of the split partitions (skewed keys): folded by all workgroups, flushed with atomics.
+  for (int64_t p0 = 0; p0 < r.numParts; p0 += blockDim.x) {
+    if (threadIdx.x == 0) {
+      bigCount = 0;
+    }
+    blockSync();
+    const int64_t mine = p0 + threadIdx.x;
+    if (mine < r.numParts) {
+      uint64_t begin, end;
+      rpPartitionRange(r, mine, &begin, &end);
+      if (end - begin > r.sliceRecs) {
+        bigList[atomicAdd(&bigCount, 1u)] = static_cast<uint32_t>(threadIdx.x);
+      }
+    }
+    blockSync();
+    const uint32_t n = bigCount;
+    for (uint32_t q = 0; q < n; ++q) {
+      const int64_t p = p0 + bigList[q];
+      uint64_t begin, end;
+      rpPartitionRange(r, p, &begin, &end);
+      const uint64_t slices = (end - begin + r.sliceRecs - 1) / r.sliceRecs;
+      for (uint64_t sl = 1 + blockIdx.x; sl < slices; sl += gridDim.x) {
+        const uint64_t b = begin + sl * r.sliceRecs;
+        hashFoldInit(f, r);
+        hashFoldRecords<W>(f, r, p, b, b + r.sliceRecs < end ? b + r.sliceRecs : end);
+        hashFoldFlush(f, r, false);
       }
     }
     blockSync();
@@ -2683,6 +3054,7 @@ struct vx355_agg {
   int64_t radixTileRows = 0;  // 0 = automatic
   int64_t radixLaunches = 0;
   bool radixSorted = true;   // VX355_AGG_RADIX_SORTED=0: scatter passes store record by record
+  bool radixSparse = true;   // VX355_AGG_RADIX_SPARSE=0: open-addressing tables stay on k_agg_global
   // The table was allocated but never written (rebuildTable skipped k_init_table because a radix
   // fold may come first and store every row itself); settleTable initialises it for anyone else.
   bool tableVirgin = false;
@@ -3718,11 +4090,37 @@ int radixWords(const AggArgs& a) {
   return n;
 }
 
+// Open-addressing tables take the radix path too (partitioned by home slot, k_rp_aggregate_hashed):
+// records of at most 4 words = word 0 + up to two operands + the full key; the sorted scatters only.
+// Home slots per partition of a hashed launch: as many partitions as give ~kHashRecsPerPart
+// records each (a power of two, at most 2^20 = two levels of 1024 bins, at least 2).
+int radixHashedShift(uint64_t capacity, int64_t rows) {
+  const int capBits = log2Ceil(capacity);
+  int partBits = log2Ceil(static_cast<uint64_t>(std::max<int64_t>(2, rows / kHashRecsPerPart)));
+  partBits = std::max(1, std::min({partBits, 20, capBits - 4}));
+  return capBits - partBits;
+}
+
+bool radixHashedEligible(const vx355_agg& h, const AggArgs& a) {
+  if (a.mode != MODE_NORMALIZED || !h.radixSparse || !h.radixSorted) {
+    return false;
+  }
+  int numVals = 0;
+  for (int j = 0; j < a.numAccs; ++j) {
+    numVals += a.accs[j].kind == ACC_COUNT ? 0 : 1;
+  }
+  return numVals <= 2 && (a.capacity & (a.capacity - 1)) == 0 && a.capacity >= (1ULL << 16);
+}
+
 bool radixEligible(const vx355_agg& h, const AggArgs& a) {
-  if (h.radixMinRows < 0 || a.mode != MODE_ARRAY || a.rowList || a.rescanOld || a.numAccs < 1 ||
+  const bool hashed = radixHashedEligible(h, a);
+  if (h.radixMinRows < 0 || (a.mode != MODE_ARRAY && !hashed) || a.rowList || a.rescanOld || a.numAccs < 1 ||
       a.numAccs > kRadixMaxAccs || a.numRows < h.radixMinRows || a.capacity > (1ULL << kRadixKeyBits) ||
       a.numRows > (1LL << radixRowBits(a.capacity))) {
     return false;
+  }
+  if (hashed) {
+    return true;  // partitions follow the rows of the chunk (radixHashedShift), two levels reach 2^20 of them
   }
   const int shiftB = radixShiftB(radixWords(a));
   const uint64_t parts = (a.capacity + (1ULL << shiftB) - 1) >> shiftB;
@@ -3738,13 +4136,15 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
   const int64_t n = a.numRows;
   RadixArgs r{};
   r.a = a;
-  r.shiftB = radixShiftB(radixWords(a));
+  const bool hashed = a.mode == MODE_NORMALIZED;
+  r.hashed = hashed ? 1 : 0;
+  r.slotMask = a.capacity - 1;
+  r.shiftB = hashed ? radixHashedShift(a.capacity, n) : radixShiftB(radixWords(a));
   const uint64_t parts = (a.capacity + (1ULL << r.shiftB) - 1) >> r.shiftB;
   // One level while the fan-out fits the LDS cursors (measured: 2400 bins in one
   // pass beat 64 x 64 in two); otherwise two balanced levels.
-  r.shift2 = parts <= static_cast<uint64_t>(h.radixMaxBins)
-      ? 0
-      : std::max(log2Ceil((parts + h.radixMaxBins - 1) / h.radixMaxBins), log2Ceil(parts) / 2);
+  const uint64_t maxBins1 = hashed ? kSortBins : static_cast<uint64_t>(h.radixMaxBins);
+  r.shift2 = parts <= maxBins1 ? 0 : std::max(log2Ceil((parts + maxBins1 - 1) / maxBins1), log2Ceil(parts) / 2);
   r.numBins = static_cast<int32_t>((parts + (1ULL << r.shift2) - 1) >> r.shift2);
   r.keyBits = radixKeyBits(a.capacity);
   r.rowBits = radixRowBits(a.capacity);
@@ -3755,7 +4155,7 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
       r.accOfVal[r.valIdx[j]] = j;
     }
   }
-  r.recWords = 1 + r.numVals;
+  r.recWords = 1 + r.numVals + (hashed ? 1 : 0);   // hashed: the full key travels in the last word
   int64_t tileRows = h.radixTileRows > 0 ? h.radixTileRows : std::max<int64_t>(32768, ceilDiv(n, 2048));
   tileRows = (tileRows + 1023) & ~1023LL;
   r.tileRows = tileRows;
@@ -3817,12 +4217,22 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
     constexpr int W = decltype(wTag)::value;
     if (sorted1) {
       const int grid = static_cast<int>(std::min<int64_t>(r.numTiles, rt.numCUs * 2));
+      if constexpr (W >= 2) {
+        if (hashed) {
+          if (flatV && kw == 8) {
+            VX_LAUNCH("k_rp_scatter1", (k_rp_scatter1_sorted<8, W, true, true>), grid, kSortThreads, 0, r);
+          } else {
+            VX_LAUNCH("k_rp_scatter1", (k_rp_scatter1_sorted<0, W, false, true>), grid, kSortThreads, 0, r);
+          }
+          return;
+        }
+      }
       if (flatV && kw == 8) {
-        VX_LAUNCH("k_rp_scatter1", (k_rp_scatter1_sorted<8, W, true>), grid, kSortThreads, 0, r);
+        VX_LAUNCH("k_rp_scatter1", (k_rp_scatter1_sorted<8, W, true, false>), grid, kSortThreads, 0, r);
       } else if (flatV && kw == 4) {
-        VX_LAUNCH("k_rp_scatter1", (k_rp_scatter1_sorted<4, W, true>), grid, kSortThreads, 0, r);
+        VX_LAUNCH("k_rp_scatter1", (k_rp_scatter1_sorted<4, W, true, false>), grid, kSortThreads, 0, r);
       } else {
-        VX_LAUNCH("k_rp_scatter1", (k_rp_scatter1_sorted<0, W, false>), grid, kSortThreads, 0, r);
+        VX_LAUNCH("k_rp_scatter1", (k_rp_scatter1_sorted<0, W, false, false>), grid, kSortThreads, 0, r);
       }
       return;
     }
@@ -3960,7 +4370,10 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
       ++g.numWords;
     }
   }
-  const size_t ldsBytes = (static_cast<size_t>(1) << r.shiftB) * (g.numWords * 8 + 4);
+  // LDS of one fold: dense = B groups x (words + first row); hashed = (B + margin) window entries x
+  // (key + words + first row)
+  const size_t ldsBytes = hashed ? static_cast<size_t>(kHashSlots) * (8 + g.numWords * 8 + 4)
+                                 : (static_cast<size_t>(1) << r.shiftB) * (g.numWords * 8 + 4);
   // Few partitions or skewed keys: slices keep every CU busy.
   g.sliceRecs = static_cast<uint64_t>(std::max<int64_t>(1 << 16, ceilDiv(n, 2048)));
   if (const char* e = std::getenv("VX355_AGG_RADIX_SLICE")) {
@@ -3995,6 +4408,16 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
     perCu = std::atoi(e);
   }
   const int gridA = rt.numCUs * std::max(1, perCu);
+  if (hashed) {
+    byWidth([&](auto wTag) {
+      constexpr int W = decltype(wTag)::value;
+      if constexpr (W >= 2) {
+        VX_LAUNCH("k_rp_aggregate", (k_rp_aggregate_hashed<W>), gridA, 512, ldsBytes, g);
+      }
+    });
+    ++h.radixLaunches;
+    return;
+  }
   if (g.virgin) {
     // owners store complete rows; the other slices of split partitions wait for the launch boundary
     g.phase = 0;
@@ -5106,6 +5529,9 @@ void configureFromEnv(vx355_agg& h) {
   }
   if (const char* e = std::getenv("VX355_AGG_NO_FAST")) {
     h.disableFast = e[0] == '1';
+  }
+  if (const char* e = std::getenv("VX355_AGG_RADIX_SPARSE")) {
+    h.radixSparse = std::atoi(e) != 0;
   }
   if (const char* e = std::getenv("VX355_AGG_RADIX_OPTIMISTIC")) {
     h.radixOptimistic = std::atoi(e) != 0;

@@ -286,7 +286,10 @@ int vx355_comm_get_unique_id(void* id_out) {
   try {
     VX_CHECK_ARG(id_out, "NULL argument");
     ncclUniqueId id;
-    ncclOk(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+    {
+      StdoutToStderr quiet;
+      ncclOk(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+    }
     std::memcpy(id_out, id.internal, kUniqueIdBytes);
   VX_API_CATCH
 }
@@ -299,7 +302,11 @@ int vx355_comm_create(const void* id, int32_t world, int32_t rank, vx355_comm** 
   c->rank = rank;
   ncclUniqueId uid;
   std::memcpy(uid.internal, id, kUniqueIdBytes);
-  {
+  if (world > 1) {
+    // (A one-rank communicator needs no RCCL: every collective is a device copy. Creating one
+    // anyway is not free on this stack: after ncclCommInitRank the random-access kernels of the
+    // same process ran 1.7x slower - k_join_probe 3.4 -> 5.8 ms, k_gather_deps 4.0 -> 7.1 ms on
+    // the config-5 shape, profiles/r03_c5_rccl_init_effect.txt.)
     StdoutToStderr quiet;
     ncclOk(rccl().CommInitRank(&c->comm, world, uid, rank), "ncclCommInitRank");
   }
@@ -321,7 +328,7 @@ int vx355_comm_create_all(int32_t num_devices, const int32_t* devices, vx355_com
     for (int d : devs) {
       (void)Runtime::defaultContext(d);  // throws unless vx355_init(d) was called
     }
-    {
+    if (num_devices > 1) {
       StdoutToStderr quiet;
       ncclOk(rccl().CommInitAll(comms.data(), num_devices, devs.data()), "ncclCommInitAll");
     }
@@ -341,7 +348,9 @@ int vx355_comm_create_all(int32_t num_devices, const int32_t* devices, vx355_com
         Runtime::destroyContext(c->ctx);
       }
       for (void* raw : comms) {
-        (void)rccl().CommDestroy(raw);
+        if (raw) {
+          (void)rccl().CommDestroy(raw);
+        }
       }
       throw;
     }

@@ -1304,8 +1304,121 @@ __global__ __launch_bounds__(1024) void k_pp_scatter(PartArgs a) {
   }
 }
 
+// Count-free variant for <= kPartFastBins bins: sub-tiles of 16384 records (128 KB of LDS: the
+// records carry their bin in bits 52..63, so no bin array is staged), runs twice as long as
+// k_pp_scatter's; and no histogram pass in front - every bin owns a region of 1.5 x the even
+// share of the batch + 4096 records, a sub-tile claims the space of each run with one atomic on
+// the bin's cursor. Probe keys spread evenly over the build side's key range (what makes a probe
+// side "scattered" in the first place) never fill a region; if one does fill (skewed keys), the
+// overflow flag sends the batch through the counted passes instead.
+constexpr int kPartFastBins = 1024;
+constexpr int kPartFastSub = 16384;
+
+struct PartFastArgs {
+  const int64_t* keys;
+  int64_t numRows;
+  int64_t keyMin, keyMax;
+  int32_t numBins;
+  int32_t pad;
+  uint64_t binCap;          // records per bin region
+  uint32_t* binCount;       // cursors, zero on entry
+  uint32_t* overflow;
+  uint64_t* recs;           // bin b: recs[b * binCap ...]
+};
+
+__global__ __launch_bounds__(1024) void k_pp_scatter_fast(PartFastArgs a) {
+  __shared__ unsigned long long binBase[kPartFastBins];
+  __shared__ uint32_t cnt[kPartFastBins];
+  __shared__ uint32_t start[kPartFastBins];
+  __shared__ uint64_t recs[kPartFastSub];
+  __shared__ uint32_t waveTotals[16];
+  constexpr int R = kPartFastSub / 1024;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  for (int i = tid; i < kPartFastBins; i += 1024) {
+    cnt[i] = 0;
+  }
+  blockSync();
+  const int64_t numSub = (a.numRows + kPartFastSub - 1) / kPartFastSub;
+  for (int64_t sub = blockIdx.x; sub < numSub; sub += gridDim.x) {
+    const int64_t base = sub * kPartFastSub;
+    uint64_t rec[R];
+    uint32_t bin[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const int64_t r = base + u * 1024 + tid;
+      const int64_t v = r < a.numRows ? a.keys[r] : INT64_MIN;
+      bin[u] = 0xffffffffu;
+      if (r < a.numRows && v >= a.keyMin && v <= a.keyMax) {
+        const uint64_t key = static_cast<uint64_t>(v) - static_cast<uint64_t>(a.keyMin) + 1;
+        bin[u] = static_cast<uint32_t>(key >> kPartShift);
+        rec[u] = (static_cast<uint64_t>(bin[u]) << 52) | ((key & ((1ULL << kPartShift) - 1)) << 32) | static_cast<uint32_t>(r);
+        atomicAdd(&cnt[bin[u]], 1u);
+      }
+    }
+    blockSync();
+    const uint32_t mine = tid < a.numBins ? cnt[tid] : 0;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = __shfl_up(incl, off, kWave);
+      if (lane() >= off) {
+        incl += o;
+      }
+    }
+    if (lane() == 63) {
+      waveTotals[wave] = incl;
+    }
+    blockSync();
+    uint32_t run = incl - mine;
+    for (int w = 0; w < wave; ++w) {
+      run += waveTotals[w];
+    }
+    if (tid < a.numBins) {
+      start[tid] = run;
+      cnt[tid] = run;
+      if (mine != 0) {
+        const uint32_t at = atomicAdd(&a.binCount[tid], mine);
+        if (at + mine > a.binCap) {
+          *a.overflow = 1;
+          binBase[tid] = ~0ULL;
+        } else {
+          binBase[tid] = static_cast<uint64_t>(tid) * a.binCap + at;
+        }
+      }
+    }
+    blockSync();
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      if (bin[u] != 0xffffffffu) {
+        recs[atomicAdd(&cnt[bin[u]], 1u)] = rec[u];
+      }
+    }
+    blockSync();
+    uint32_t total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      total += waveTotals[w];
+    }
+    for (uint32_t i = tid; i < total; i += 1024) {
+      const uint64_t rw = recs[i];
+      const uint32_t b = static_cast<uint32_t>(rw >> 52);
+      if (binBase[b] != ~0ULL) {
+        a.recs[binBase[b] + (i - start[b])] = rw;
+      }
+    }
+    blockSync();
+    if (tid < a.numBins) {
+      cnt[tid] = 0;
+    }
+    blockSync();
+  }
+}
+
 struct PartProbeArgs {
   const uint64_t* recs;
+  const uint32_t* binCount;  // count-free layout (k_pp_scatter_fast): bin b = binCount[b] records from b * binCap
+  uint64_t binCap;
   const uint64_t* offsets;   // record offsets per (bin, tile) cell, bin major
   int64_t numTiles;
   int32_t numBins;
@@ -1342,8 +1455,8 @@ __global__ __launch_bounds__(1024) void k_pp_probe(PartProbeArgs a) {
   uint64_t* buf = waveBuf[threadIdx.x >> 6];
   uint32_t count = 0;  // uniform across the wave
   for (int32_t bin = blockIdx.x; bin < a.numBins; bin += gridDim.x) {
-    const uint64_t begin = a.offsets[static_cast<int64_t>(bin) * a.numTiles];
-    const uint64_t end = a.offsets[static_cast<int64_t>(bin + 1) * a.numTiles];
+    const uint64_t begin = a.binCount ? static_cast<uint64_t>(bin) * a.binCap : a.offsets[static_cast<int64_t>(bin) * a.numTiles];
+    const uint64_t end = a.binCount ? begin + a.binCount[bin] : a.offsets[static_cast<int64_t>(bin + 1) * a.numTiles];
     if (begin == end) {
       continue;  // uniform
     }
@@ -1362,7 +1475,7 @@ __global__ __launch_bounds__(1024) void k_pp_probe(PartProbeArgs a) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const uint64_t i = at + u * 1024 + threadIdx.x;
-        const uint32_t off = static_cast<uint32_t>(rec[u] >> 32);
+        const uint32_t off = static_cast<uint32_t>(rec[u] >> 32) & ((1u << kPartShift) - 1);  // bits 52.. may carry the bin
         const bool hit = i < end && ((slice[off >> 5] >> (off & 31)) & 1);
         const uint64_t m = ballot(hit);
         if (m == 0) {
@@ -2225,6 +2338,7 @@ struct vx355_join_probe {
   int64_t outputBatchBytes = 0;  // preferred_output_batch_bytes (0 = rows only)
   int32_t partitionMode = -1;  // VX355_JOIN_PARTITION: -1 adaptive, 0 never, 1 whenever eligible
   bool window = true;          // VX355_JOIN_WINDOW=0: the listing probe gathers every presence word itself
+  bool partitionFast = true;   // VX355_JOIN_PARTITION_FAST=0: the range-partitioned probe always counts first
   DeviceBatch batch;                       // the batch being probed: the filter reads it at output time
   std::vector<std::vector<char>> hostStrings;  // long payload strings of the last page handed to a host caller
   std::vector<vx355_join_filter_term> filter;
@@ -2848,16 +2962,45 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
         pa.keyMax = a.ranges[0].max;
         pa.numBins = static_cast<int32_t>(partBins);
         const int64_t cells = pa.numTiles * pa.numBins;
-        pa.hist = static_cast<uint32_t*>(p.ppHist.ensure(static_cast<size_t>(cells) * 4 + 64));
-        uint64_t* offsets = static_cast<uint64_t*>(p.ppOffsets.ensure(static_cast<size_t>(cells + 1) * 8 + 64));
-        pa.offsets = offsets;
-        pa.recs = static_cast<uint64_t*>(p.ppRecs.ensure(static_cast<size_t>(n) * 8 + 64));
         const int pgrid = static_cast<int>(std::min<int64_t>(pa.numTiles, static_cast<int64_t>(rt.numCUs) * 2));
-        VX_LAUNCH("k_pp_count", k_pp_count, pgrid, 1024, 0, pa);
-        scanU32ToU64(pa.hist, cells, offsets, p.ppScan);
-        VX_LAUNCH("k_pp_scatter", k_pp_scatter, pgrid, 1024, 0, pa);
         PartProbeArgs pp{};
-        pp.recs = pa.recs;
+        bool counted = true;
+        if (p.partitionFast && pa.numBins <= kPartFastBins) {
+          PartFastArgs fa{};
+          fa.keys = pa.keys;
+          fa.numRows = n;
+          fa.keyMin = pa.keyMin;
+          fa.keyMax = pa.keyMax;
+          fa.numBins = pa.numBins;
+          fa.binCap = static_cast<uint64_t>(n / pa.numBins + n / (2 * pa.numBins) + 4096);
+          fa.recs = static_cast<uint64_t*>(p.ppRecs.ensure(static_cast<size_t>(fa.binCap) * pa.numBins * 8 + 64));
+          fa.binCount = static_cast<uint32_t*>(p.ppHist.ensure(static_cast<size_t>(pa.numBins + 16) * 4 + 64));
+          fa.overflow = fa.binCount + pa.numBins;
+          HIP_OK(hipMemsetAsync(fa.binCount, 0, static_cast<size_t>(pa.numBins + 16) * 4, rt.stream));
+          const int64_t numSub = ceilDiv(n, kPartFastSub);
+          VX_LAUNCH("k_pp_scatter", k_pp_scatter_fast, static_cast<int>(std::min<int64_t>(numSub, rt.numCUs * 2)), 1024, 0, fa);
+          uint32_t full = 0;
+          copyOut(&full, VX355_MEM_HOST, fa.overflow, 4);
+          counted = full != 0;   // a bin outgrew its region (skewed keys): the counted passes below
+          if (!counted) {
+            pp.recs = fa.recs;
+            pp.binCount = fa.binCount;
+            pp.binCap = fa.binCap;
+          } else {
+            p.partitionFast = false;
+          }
+        }
+        uint64_t* offsets = nullptr;
+        if (counted) {
+          pa.hist = static_cast<uint32_t*>(p.ppHist.ensure(static_cast<size_t>(cells) * 4 + 64));
+          offsets = static_cast<uint64_t*>(p.ppOffsets.ensure(static_cast<size_t>(cells + 1) * 8 + 64));
+          pa.offsets = offsets;
+          pa.recs = static_cast<uint64_t*>(p.ppRecs.ensure(static_cast<size_t>(n) * 8 + 64));
+          VX_LAUNCH("k_pp_count", k_pp_count, pgrid, 1024, 0, pa);
+          scanU32ToU64(pa.hist, cells, offsets, p.ppScan);
+          VX_LAUNCH("k_pp_scatter", k_pp_scatter, pgrid, 1024, 0, pa);
+          pp.recs = pa.recs;
+        }
         pp.offsets = offsets;
         pp.numTiles = pa.numTiles;
         pp.numBins = pa.numBins;
@@ -3500,6 +3643,9 @@ int vx355_join_probe_create(vx355_join_table* table, const vx355_join_probe_spec
     if (p->partitionMode != 0 && p->partitionMode != 1) {
       p->partitionMode = -1;
     }
+  }
+  if (const char* e = std::getenv("VX355_JOIN_PARTITION_FAST")) {
+    p->partitionFast = std::atoi(e) != 0;
   }
   if (const char* e = std::getenv("VX355_JOIN_WINDOW")) {
     p->window = std::atoi(e) != 0;
