@@ -760,6 +760,24 @@ class C5:
         idx = torch.randint(0, world * nd, (n,), dtype=torch.int64, device=device, generator=g)
         self.fk = (idx * 7919) % (1 << 45)
         self.m = torch.rand(n, dtype=torch.float64, device=device, generator=g)
+        # What the join must deliver for this rank's fact rows: sum (mod 2^64) of dim.a over the
+        # partner of every fk. Every rank's `a` is the first draw of its seeded generator, so
+        # any rank can restate all of them.
+        expected = 0
+        for r in range(world):
+            if r == rank:
+                a_r = self.a
+            else:
+                g_r = torch.Generator(device=device)
+                g_r.manual_seed(seed - rank + r)
+                a_r = torch.randint(0, 1 << 40, (nd,), dtype=torch.int64, device=device, generator=g_r)
+            mine = (idx >= r * nd) & (idx < (r + 1) * nd)
+            expected += int((a_r[(idx - r * nd).clamp_(0, nd - 1)] * mine).sum().item())
+            del a_r, mine
+        self.expected_payload_sum = expected & ((1 << 64) - 1)
+        self.payload_sum = None   # set by a step run with self.checking
+        self.checking = False
+        del idx
         self.backend = vdist.GpuJoinBackend(ops, torch)
         torch.cuda.synchronize()
 
@@ -767,15 +785,6 @@ class C5:
     tdist = None   # else: torch.distributed (module or GroupDist) through velox_amd/dist.py
 
     def step(self, step_kind=None):
-        pre = os.environ.get("VX355_C5_PRESTEP")   # experiment: one step of the other path first
-        if pre and not hasattr(self, "_prestepped"):
-            self._prestepped = True
-            if pre == "torch" and self.comm is not None:
-                comm, self.comm = self.comm, None
-                import torch.distributed as tdist_mod
-                self.tdist = self.tdist or tdist_mod
-                self.step()
-                self.comm = comm
         if self.comm is not None:
             return self.step_library()
         dist = self.tdist
@@ -785,6 +794,8 @@ class C5:
                                                                   [self.pk, self.a], [self.fk, self.m], chunks=4)
             total = sum(int(m.shape[0]) for _, outs in per_chunk for m, _ in outs)
             stats = table.stats()
+            if self.checking:
+                self.payload_sum = sum(int(p.sum().item()) for _, outs in per_chunk for _, p in outs)
         else:
             fn = None
             if os.environ.get("VX355_C5_LIBEXCHANGE") == "1":   # torch-owned buffers, library collectives
@@ -793,6 +804,8 @@ class C5:
                 fn = vdist.LibExchange(self.torch, self._libcomm)
             total, outputs, stats = vdist.repartitioned_join(self.backend, dist, self.torch,
                                                              [self.pk, self.a], [self.fk, self.m], exchange_fn=fn)
+            if self.checking:
+                self.payload_sum = sum(int(p.sum().item()) for _, p in outputs)
         self.matches, self.stats = total, stats
         return total
 
@@ -808,26 +821,36 @@ class C5:
             self._out = (torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.int32, device=dev),
                          torch.empty(cap, dtype=torch.int64, device=dev), torch.empty(cap // 64 + 1, dtype=torch.int64, device=dev))
             self._build = DevBatch([dcol(abi.BIGINT, self.pk), dcol(abi.BIGINT, self.a)], int(self.pk.shape[0]))
-            if os.environ.get("VX355_C5_KEYONLY") == "1":
-                self._probe = DevBatch([dcol(abi.BIGINT, self.fk)], self.n)
-            else:
-                self._probe = DevBatch([dcol(abi.BIGINT, self.fk), dcol(abi.DOUBLE, self.m)], self.n)
+            self._probe = DevBatch([dcol(abi.BIGINT, self.fk), dcol(abi.DOUBLE, self.m)], self.n)
         mapping, brows, payload, nulls = self._out
         descs = (abi.OutColumn * 1)()
         descs[0].type_kind, descs[0].mem = abi.BIGINT, abi.MEM_DEVICE
         descs[0].values, descs[0].nulls = payload.data_ptr(), nulls.data_ptr()
-        total = [0]
+        total, sums = [0], []
 
         def sink(chunk, received, probe):
             while True:
                 got, fin = probe.get_output_device(cap, mapping.data_ptr(), brows.data_ptr(), descs, [0])
                 total[0] += got
+                if self.checking:   # (get_output_device has synchronised the probe's stream)
+                    sums.append(int(payload[:got].sum().item()))
                 if fin:
                     break
         table = ops.join_repartition(self.comm, ([0], [abi.BIGINT], [1], [abi.BIGINT], abi.JOIN_INNER), self._build,
                                      ([0], abi.JOIN_INNER), self._probe, chunks, sink)
         self.matches, self.stats = total[0], table.stats()
+        if self.checking:
+            self.payload_sum = sum(sums)
         return total[0]
+
+    def verify(self):
+        """One untimed step with the outputs summed: (sum of the gathered dim.a, expected), mod 2^64."""
+        self.checking = True
+        try:
+            self.step()
+        finally:
+            self.checking = False
+        return self.payload_sum & ((1 << 64) - 1), self.expected_payload_sum
 
     def rows_per_step(self):
         return self.n
@@ -1040,15 +1063,6 @@ def main():
                 dist.init_process_group("gloo", rank=rank, world_size=world)
             nccl_group = dist.new_group(backend="nccl", device_id=device)
             backend = "nccl"
-    if os.environ.get("VX355_BENCH_TORCH_NCCL") == "1":
-        # experiment: does a torch.distributed NCCL (= RCCL) communicator in the process change kernel times?
-        if not dist.is_initialized():
-            os.environ.setdefault("MASTER_PORT", str(free_port()))
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        extra = dist.new_group(backend="nccl", device_id=device)
-        t = torch.ones(1024, device=device)
-        dist.all_reduce(t, group=extra)
-        torch.cuda.synchronize()
     n_gpus = comm.info()[0] if comm is not None else (dist.get_world_size() if dist.is_initialized() else 1)
     if n_gpus != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the communicator spans {n_gpus} ranks")
@@ -1126,6 +1140,19 @@ def main():
 
     elapsed, prof = timed(one_step, args.steps, args.warmup)
     rows = wl.rows_per_step() * world * args.steps
+    result_check = None
+    if hasattr(wl, "verify"):
+        # the job's output against what the generator implies, over all ranks (not timed)
+        got_sum, want_sum = wl.verify()
+        if world > 1:
+            both = [None] * world
+            dist.all_gather_object(both, (got_sum, want_sum))
+            got_sum = sum(b[0] for b in both) & ((1 << 64) - 1)
+            want_sum = sum(b[1] for b in both) & ((1 << 64) - 1)
+        result_check = {"what": "sum mod 2^64 of the joined dim.a over every fact row, all ranks",
+                        "ok": got_sum == want_sum}
+        if got_sum != want_sum:
+            raise SystemExit(f"c5: the join's output checksum is {got_sum}, the generator implies {want_sum}")
 
     # N > 1, q1, weak scaling: the strong-scaling form of the same query (the N = 1 row count
     # sharded N ways = BASELINE's "SF100 at 1/2/4/8 GPUs") is measured next to the headline.
@@ -1178,6 +1205,7 @@ def main():
                                    " over RCCL") if world > 1 else "1 GPU",
                    "exchange": exchange_note},
         "workload_info": wl.info() if hasattr(wl, "info") else {},
+        "result_check": result_check,
         "pipeline_algorithmic_GBps": wl.bytes_per_row * rows / elapsed / 1e9 / world,
         "roofline": roofline_block(wl, prof, args.steps, copy_ceiling, child_flags if measure else None),
         "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())},
@@ -1226,6 +1254,13 @@ class GroupDist:
     def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None, async_op=False):
         return self.dist.all_to_all_single(out, inp, output_split_sizes, input_split_sizes, group=self.group,
                                            async_op=async_op)
+
+    @property
+    def ReduceOp(self):
+        return self.dist.ReduceOp
+
+    def all_reduce(self, t, op=None):
+        return self.dist.all_reduce(t, op=op if op is not None else self.dist.ReduceOp.SUM, group=self.group)
 
 
 def roofline_block(wl, prof, steps, copy_ceiling, child_flags):

@@ -67,12 +67,14 @@ class OracleBackend:
         return out
 
 
-def run(rank, world, port, out_dir, chunks=0):
+def run(rank, world, port, out_dir, chunks=0, max_message=0):
     import torch
     import torch.distributed as dist
     import oracle_lib
     from velox_amd import abi
     from velox_amd import dist as vdist
+    if max_message:
+        vdist.MAX_MESSAGE_BYTES = max_message
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     (pk, a), (fk, m) = shard(rank, world)
     backend = OracleBackend(torch, oracle_lib, abi)
@@ -90,4 +92,5 @@ def run(rank, world, port, out_dir, chunks=0):
 
 
 if __name__ == "__main__":
-    run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]) if len(sys.argv) > 5 else 0)
+    run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]) if len(sys.argv) > 5 else 0,
+        int(sys.argv[6]) if len(sys.argv) > 6 else 0)

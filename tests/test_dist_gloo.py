@@ -88,19 +88,20 @@ def test_gather_encoding_round_trip():
 import pytest
 
 
-@pytest.mark.parametrize("world,chunks", [(2, 0), (3, 0), (2, 3), (3, 5)])
-def test_repartitioned_join_over_gloo_matches_single_process(world, chunks, tmp_path):
+@pytest.mark.parametrize("world,chunks,max_message", [(2, 0, 0), (3, 0, 0), (2, 3, 0), (3, 5, 0), (2, 0, 4096), (3, 2, 4096)])
+def test_repartitioned_join_over_gloo_matches_single_process(world, chunks, max_message, tmp_path):
     """BASELINE config 5 on CPU: hash-partition both sides, one all-to-all per
     column (velox_amd/dist.py), local joins; the union over ranks must equal the
     single-process join of the concatenated inputs. world = 3 exercises the
     hash % n flavour, world = 2 the bit-range flavour; chunks > 0 the pipelined form
     (probe side in chunks, asynchronous all-to-all overlapped with the next chunk's
-    partitioning)."""
+    partitioning); max_message > 0 forces the exchange to cut its slices into several rounds
+    (what it does above 256 MiB per message on the GPU)."""
     import dist_join_worker
     import pandas as pd
     port = _free_port()
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_join_worker.py"), str(r), str(world),
-                               str(port), str(tmp_path), str(chunks)]) for r in range(world)]
+                               str(port), str(tmp_path), str(chunks), str(max_message)]) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=240) == 0
     got = np.concatenate([np.load(os.path.join(tmp_path, f"join_rank{r}.npy")) for r in range(world)])

@@ -428,6 +428,28 @@ void exchangeCounts(vx355_comm* c, const int64_t* send, int64_t* recv) {
 
 // Posts the slices of every column on 'stream': slice p of the send buffer goes straight to rank
 // p, the slices of all ranks arrive in rank order; the rank's own slice is a device copy.
+// Messages are cut into pieces of at most kMaxMessageBytes (both ends cut the same byte count the
+// same way): RCCL 2.26.6 as shipped with this image delivers only the first half of a message above
+// 2^30 bytes (tools/torch_a2a_repro.py shows it through torch.distributed on one rank;
+// profiles/r03_rccl_large_message.txt).
+constexpr int64_t kMaxMessageBytes = 256LL << 20;
+
+void sendBytes(Rccl& r, vx355_comm* c, hipStream_t stream, const char* src, int64_t bytes, int32_t peer) {
+  for (int64_t at = 0; at < bytes; at += kMaxMessageBytes) {
+    ncclOk(r.Send(src + at, static_cast<size_t>(std::min(kMaxMessageBytes, bytes - at)), kNcclUint8, peer, c->comm,
+                  stream),
+           "ncclSend");
+  }
+}
+
+void recvBytes(Rccl& r, vx355_comm* c, hipStream_t stream, char* dst, int64_t bytes, int32_t peer) {
+  for (int64_t at = 0; at < bytes; at += kMaxMessageBytes) {
+    ncclOk(r.Recv(dst + at, static_cast<size_t>(std::min(kMaxMessageBytes, bytes - at)), kNcclUint8, peer, c->comm,
+                  stream),
+           "ncclRecv");
+  }
+}
+
 void postColumns(vx355_comm* c, hipStream_t stream, const void* const* sendCols, const int32_t* widths, int32_t numCols,
                  const int64_t* sendCounts, const int64_t* recvCounts, void* const* recvCols) {
   for (int32_t col = 0; col < numCols; ++col) {
@@ -462,12 +484,8 @@ void postColumns(vx355_comm* c, hipStream_t stream, const void* const* sendCols,
           HIP_OK(hipMemcpyAsync(dst, src, static_cast<size_t>(ns * w), hipMemcpyDeviceToDevice, stream));
         }
       } else {
-        if (ns > 0) {
-          ncclOk(r->Send(src, static_cast<size_t>(ns * w), kNcclUint8, peer, c->comm, stream), "ncclSend");
-        }
-        if (nr > 0) {
-          ncclOk(r->Recv(dst, static_cast<size_t>(nr * w), kNcclUint8, peer, c->comm, stream), "ncclRecv");
-        }
+        sendBytes(*r, c, stream, src, ns * w, peer);
+        recvBytes(*r, c, stream, dst, nr * w, peer);
       }
       sendAt += ns;
       recvAt += nr;
@@ -508,8 +526,22 @@ int vx355_all_gather(vx355_comm* c, const void* send, void* recv, size_t bytes_p
   if (bytes_per_rank) {
     if (c->world == 1) {
       HIP_OK(hipMemcpyAsync(recv, send, bytes_per_rank, hipMemcpyDeviceToDevice, rt.stream));
-    } else {
+    } else if (static_cast<int64_t>(bytes_per_rank) <= kMaxMessageBytes) {
       ncclOk(rccl().AllGather(send, recv, bytes_per_rank, kNcclInt8, c->comm, rt.stream), "ncclAllGather");
+    } else {
+      // large blocks: as cut point-to-point messages (see kMaxMessageBytes)
+      Rccl& r = rccl();
+      GroupGuard group(r);
+      for (int32_t peer = 0; peer < c->world; ++peer) {
+        char* dst = static_cast<char*>(recv) + static_cast<size_t>(peer) * bytes_per_rank;
+        if (peer == c->rank) {
+          HIP_OK(hipMemcpyAsync(dst, send, bytes_per_rank, hipMemcpyDeviceToDevice, rt.stream));
+        } else {
+          sendBytes(r, c, rt.stream, static_cast<const char*>(send), static_cast<int64_t>(bytes_per_rank), peer);
+          recvBytes(r, c, rt.stream, dst, static_cast<int64_t>(bytes_per_rank), peer);
+        }
+      }
+      group.end();
     }
   }
   rt.sync();
@@ -542,12 +574,8 @@ int vx355_all_gather_v(vx355_comm* c, const void* send, const int64_t* sizes, vo
         HIP_OK(hipMemcpyAsync(dst, send, static_cast<size_t>(mine), hipMemcpyDeviceToDevice, rt.stream));
       }
     } else {
-      if (mine > 0) {
-        ncclOk(r->Send(send, static_cast<size_t>(mine), kNcclUint8, peer, c->comm, rt.stream), "ncclSend");
-      }
-      if (sizes[peer] > 0) {
-        ncclOk(r->Recv(dst, static_cast<size_t>(sizes[peer]), kNcclUint8, peer, c->comm, rt.stream), "ncclRecv");
-      }
+      sendBytes(*r, c, rt.stream, static_cast<const char*>(send), mine, peer);
+      recvBytes(*r, c, rt.stream, dst, sizes[peer], peer);
     }
     at += sizes[peer];
   }

@@ -197,6 +197,11 @@ void Runtime::profEnd(const char* name) {
   }
 }
 
+static bool logAlloc() {
+  static const bool on = std::getenv("VX355_LOG_ALLOC") != nullptr;
+  return on;
+}
+
 void* DeviceState::allocBlock(size_t bytes, size_t* actual) {
   // Size classes: powers of two up to 1 MiB, then multiples of 1 MiB.
   size_t want = bytes <= (1u << 20) ? static_cast<size_t>(nextPow2(std::max<size_t>(bytes, 256)))
@@ -220,12 +225,18 @@ void* DeviceState::allocBlock(size_t bytes, size_t* actual) {
           (void)hipStreamSynchronize(s);
         }
       }
+      if (logAlloc()) {
+        fprintf(stderr, "vx355 alloc: cached %p %zu (asked %zu)\n", b.p, *actual, want);
+      }
       return b.p;
     }
   }
   void* p = nullptr;
   bindHipDevice(device);
   hipError_t e = hipMalloc(&p, want);
+  if (logAlloc()) {
+    fprintf(stderr, "vx355 alloc: fresh %p %zu\n", p, want);
+  }
   if (e == hipErrorOutOfMemory) {
     (void)hipGetLastError();
     trimCache();
@@ -239,6 +250,9 @@ void* DeviceState::allocBlock(size_t bytes, size_t* actual) {
 }
 
 void DeviceState::freeBlock(void* p, size_t bytes) {
+  if (logAlloc() && p) {
+    fprintf(stderr, "vx355 alloc: release %p %zu\n", p, bytes);
+  }
   if (!p) {
     return;
   }

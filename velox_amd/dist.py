@@ -248,6 +248,46 @@ def _drain(torch, cols):
         torch.cuda.current_stream(cols[0].device).synchronize()
 
 
+MAX_MESSAGE_BYTES = 256 << 20
+
+
+def _row_bytes(t):
+    return t.element_size() * (t.shape[1] if t.dim() == 2 else 1)
+
+
+def _all_to_all_rows(dist, torch, got, src, rc, sc):
+    """dist.all_to_all_single(got, src, rc, sc) with every rank-to-rank message kept under
+    MAX_MESSAGE_BYTES: the RCCL of this image (2.26.6) delivers only the first half of a message
+    above 2^30 bytes - tools/torch_a2a_repro.py, profiles/r03_rccl_large_message.txt. One rank:
+    a copy, no collective. Large slices travel as row-range pieces; every rank runs the same
+    number of rounds (the largest slice anywhere decides), empty pieces included."""
+    world = dist.get_world_size()
+    if world == 1:
+        got.copy_(src)
+        return
+    piece = max(1, MAX_MESSAGE_BYTES // _row_bytes(src))
+    largest = torch.tensor([max(list(rc) + list(sc) + [0])], dtype=torch.int64, device=src.device)
+    dist.all_reduce(largest, op=dist.ReduceOp.MAX)
+    rounds = max(1, -(-int(largest.item()) // piece))
+    if rounds == 1:
+        dist.all_to_all_single(got, src, output_split_sizes=list(rc), input_split_sizes=list(sc))
+        return
+    s_off = [sum(sc[:i]) for i in range(world)]
+    r_off = [sum(rc[:i]) for i in range(world)]
+    for k in range(rounds):
+        lo = k * piece
+        sk = [max(0, min(piece, n - lo)) for n in sc]
+        rk = [max(0, min(piece, n - lo)) for n in rc]
+        part = torch.cat([src.narrow(0, s_off[i] + lo, sk[i]) for i in range(world) if sk[i] > 0] or [src[:0]])
+        tmp = torch.empty((sum(rk),) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        dist.all_to_all_single(tmp, part, output_split_sizes=rk, input_split_sizes=sk)
+        at = 0
+        for i in range(world):
+            if rk[i] > 0:
+                got.narrow(0, r_off[i] + lo, rk[i]).copy_(tmp.narrow(0, at, rk[i]))
+                at += rk[i]
+
+
 def exchange(dist, torch, cols, counts):
     """cols: torch tensors whose rows are grouped by destination rank;
     counts[r] = rows for rank r. Returns the received columns (source-rank
@@ -263,7 +303,7 @@ def exchange(dist, torch, cols, counts):
     out = []
     for c in cols:
         got = torch.empty((sum(rc),) + tuple(c.shape[1:]), dtype=c.dtype, device=c.device)
-        dist.all_to_all_single(got, c.contiguous(), output_split_sizes=rc, input_split_sizes=sc)
+        _all_to_all_rows(dist, torch, got, c.contiguous(), rc, sc)
         out.append(got)
     _drain(torch, out)
     return out, rc
@@ -302,10 +342,19 @@ def exchange_async(dist, torch, cols, counts):
     sc = [int(x) for x in counts]
     assert len(sc) == world
     out, works, keep = [], [], []
+    # every rank must take the same branch: the largest slice anywhere decides
+    widest = max([_row_bytes(c) for c in cols] + [1])
+    flag = torch.tensor([max(rc + sc + [0]) * widest], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    big = int(flag.item()) > MAX_MESSAGE_BYTES
     for c in cols:
         src = c.contiguous()
         got = torch.empty((sum(rc),) + tuple(c.shape[1:]), dtype=c.dtype, device=c.device)
-        works.append(dist.all_to_all_single(got, src, output_split_sizes=rc, input_split_sizes=sc, async_op=True))
+        if world == 1 or big:
+            _all_to_all_rows(dist, torch, got, src, rc, sc)   # large slices: in pieces, not overlapped
+        else:
+            works.append(dist.all_to_all_single(got, src, output_split_sizes=rc, input_split_sizes=sc, async_op=True))
         out.append(got)
         keep.append(src)
 
