@@ -763,6 +763,57 @@ def test_radix_path_over_open_addressing_tables(oracle, vx, shape, monkeypatch):
         assert "k_rp_aggregate" in vx.profile()
 
 
+@pytest.mark.parametrize("shape", ["one_batch", "more_batches", "refold", "hot_keys", "nulls_and_masks", "part_of_a_batch"])
+def test_dense_folds_into_an_operator_without_groups(oracle, vx, shape, monkeypatch):
+    """Open-addressing mode, no groups yet, a large batch: the radix folds APPEND their groups to a plain
+    array of group rows (hashFoldFlushDense) and that array is the table until a key has to be looked up
+    (then it is re-keyed into a real table): one batch (statistics show capacity == groups), more batches
+    behind it, a first guess of the group count that is too small (folded twice), hot keys whose partition
+    is folded in slices (rows of one key merged afterwards, k_dense_merge), null keys / inputs, and a
+    batch larger than one dense launch takes."""
+    monkeypatch.setenv("VX355_AGG_RADIX_MIN_ROWS", "1")
+    monkeypatch.setenv("VX355_AGG_DENSE_MIN_ROWS", "1")
+    monkeypatch.setenv("VX355_AGG_COALESCE_ROWS", "0")
+    if shape == "refold":
+        monkeypatch.setenv("VX355_AGG_DENSE_CAP", "1000")
+    if shape == "hot_keys":
+        monkeypatch.setenv("VX355_AGG_RADIX_SLICE", "4096")
+    if shape == "part_of_a_batch":
+        monkeypatch.setenv("VX355_AGG_DENSE_MAX_ROWS", "100032")
+    rng = np.random.default_rng(4242)
+    n = 400_000
+    batches = []
+    for b in range(1 if shape in ("one_batch", "refold") else 3):
+        j = rng.integers(0, 60_000 * (b + 1), n).astype(np.uint64)
+        if shape == "hot_keys":
+            hot = rng.random(n) < 0.4
+            j[hot] = rng.integers(0, 3, int(hot.sum())).astype(np.uint64)
+        k = ((j * np.uint64(0x9E3779B97F4A7C15)) ^ np.uint64(0x5DEECE66D)).astype(np.int64)
+        v = _dyadic(rng, n)
+        w = rng.integers(-1 << 40, 1 << 40, n).astype(np.int64)
+        valids = [None, None, None]
+        if shape == "nulls_and_masks":
+            valids = [rng.random(n) > 0.01, rng.random(n) > 0.1, None]
+        batches.append(batch_of([k, v, w], valids))
+    for aggs in ([(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)],
+                 [(abi.AGG_SUM, 2, abi.BIGINT), (abi.AGG_MIN, 1, abi.DOUBLE), (abi.AGG_COUNT, 1, abi.DOUBLE)],
+                 [(abi.AGG_AVG, 1, abi.DOUBLE), (abi.AGG_MAX, 2, abi.BIGINT)]):
+        exp, _ = run_agg(oracle, batches, [0], [abi.BIGINT], aggs, max_rows=100000)
+        vx.profile_reset()
+        vx.profile_enable(True)
+        got, gop = run_agg(vx, batches, [0], [abi.BIGINT], aggs, max_rows=100000)
+        vx.profile_enable(False)
+        assert_columns_equal(got, exp, gop.kinds, what="dense folds %s %s" % (shape, aggs))
+        st = gop.stats()
+        prof = vx.profile()
+        assert st.hash_mode == abi.MODE_NORMALIZED_KEY and "k_rp_aggregate" in prof
+        if shape in ("one_batch", "refold"):
+            assert st.capacity == st.num_groups, (st.capacity, st.num_groups)   # the array of rows is the table
+            assert prof["k_rp_aggregate"][1] == (2 if shape == "refold" else 1)
+        if shape == "hot_keys":
+            assert "k_dense_merge" in prof
+
+
 def test_radix_path_two_keys_fused_filter(oracle, vx, monkeypatch):
     """Two grouping keys (the normalized key is the partitioning key) behind a fused filter."""
     monkeypatch.setenv("VX355_AGG_RADIX_MIN_ROWS", "1")

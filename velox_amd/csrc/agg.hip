@@ -1370,6 +1370,13 @@ struct RadixAggArgs {
   uint64_t* pairKeys;
   uint32_t* pairVals;
   uint64_t pairBase;
+  // dense (hashed folds into an operator without groups, see hashFoldFlushDense): 'table' is a plain
+  // array of group rows that the folds APPEND to - row index = counters->numNewGroups before the
+  // flush - instead of an open-addressing table; rows beyond denseCap are counted, not written;
+  // denseFlags[0] = 1 when some key may own more than one row (split partitions, LDS overflow).
+  int32_t dense;
+  uint64_t denseCap;
+  uint32_t* denseFlags;
 };
 
 // LDS state of one fold: acc[B][A] + first[B], A = LDS words per group.
@@ -1677,24 +1684,26 @@ __device__ inline void hashFoldInit(const HashFold& f, const RadixAggArgs& r) {
   blockSync();
 }
 
-// One record straight to its group row in HBM (window full): what updateGlobal does.
+// Word 'idx' (1 .. W - 1) of a record held in registers: a chain of selects, because a register
+// array indexed with a run-time value is moved to scratch memory.
 template <int W>
-__device__ inline void hashFoldDirect(const RadixAggArgs& r, const uint64_t (&w)[W], uint64_t key, uint32_t row,
-                                      uint32_t mask) {
-  uint64_t* g = findOrInsert(r.table, r.stride, r.capacity, key, r.counters);
-  if (g == nullptr) {
-    return;
+__device__ inline uint64_t recordWord(const uint64_t (&w)[W], int idx) {
+  uint64_t v = 0;
+#pragma unroll
+  for (int q = 1; q < W; ++q) {
+    v = q == idx ? w[q] : v;
   }
-  const unsigned long long old = atomicMin(reinterpret_cast<unsigned long long*>(g + 1), r.rowBase + row);
-  if (old == kNoRow) {
-    atomicAdd(&r.counters->numNewGroups, 1u);
-    r.counters->pairsBroken = 1;  // this group is not in the launch's pair list
-  }
+  return v;
+}
+
+// The operands of one record applied to a group row in HBM with atomics: what updateGlobal does.
+template <int W>
+__device__ inline void hashApplyRecordGlobal(const RadixAggArgs& r, uint64_t* g, const uint64_t (&w)[W], uint32_t mask) {
   for (int j = 0; j < r.numAccs; ++j) {
     if (!((mask >> j) & 1)) {
       continue;
     }
-    const uint64_t v = r.valIdx[j] < 0 ? 1ULL : w[1 + r.valIdx[j]];
+    const uint64_t v = r.valIdx[j] < 0 ? 1ULL : recordWord<W>(w, 1 + r.valIdx[j]);
     uint64_t* word = g + r.wordOff[r.ldsIdx[j]];
     if (r.kind[j] == ACC_SUM_F64 && r.splitM[j] != 0.0) {
       double hi, lo;
@@ -1707,7 +1716,39 @@ __device__ inline void hashFoldDirect(const RadixAggArgs& r, const uint64_t (&w)
   }
 }
 
-template <int W>
+// One record straight to its group row in HBM (window full).
+template <int W, bool DENSE>
+__device__ inline void hashFoldDirect(const RadixAggArgs& r, const uint64_t (&w)[W], uint64_t key, uint32_t row,
+                                      uint32_t mask) {
+  if constexpr (DENSE) {
+    // a row of its own; the merge pass (k_dense_merge) brings the rows of one key together
+    const uint64_t idx = atomicAdd(&r.counters->numNewGroups, 1u);
+    r.denseFlags[0] = 1;
+    if (idx >= r.denseCap) {
+      return;
+    }
+    uint64_t* g = r.table + idx * r.stride;
+    for (int x = 0; x < r.stride; ++x) {
+      g[x] = r.pattern[x];
+    }
+    g[0] = key;
+    g[1] = r.rowBase + row;
+    hashApplyRecordGlobal<W>(r, g, w, mask);
+    return;
+  }
+  uint64_t* g = findOrInsert(r.table, r.stride, r.capacity, key, r.counters);
+  if (g == nullptr) {
+    return;
+  }
+  const unsigned long long old = atomicMin(reinterpret_cast<unsigned long long*>(g + 1), r.rowBase + row);
+  if (old == kNoRow) {
+    atomicAdd(&r.counters->numNewGroups, 1u);
+    r.counters->pairsBroken = 1;  // this group is not in the launch's pair list
+  }
+  hashApplyRecordGlobal<W>(r, g, w, mask);
+}
+
+template <int W, bool DENSE>
 __device__ inline void hashFoldRecords(const HashFold& f, const RadixAggArgs& r, int64_t p, uint64_t begin, uint64_t end) {
   const int A = f.A;
   const uint64_t base = static_cast<uint64_t>(p) << r.shiftB;
@@ -1752,7 +1793,7 @@ __device__ inline void hashFoldRecords(const HashFold& f, const RadixAggArgs& r,
       }
       if (pos < 0) {
         f.scratch[2] = 1;
-        hashFoldDirect<W>(r, w[u], key, row, mask);
+        hashFoldDirect<W, DENSE>(r, w[u], key, row, mask);
         continue;
       }
       if (f.first[pos] > row) {
@@ -1767,11 +1808,11 @@ __device__ inline void hashFoldRecords(const HashFold& f, const RadixAggArgs& r,
           applyLds(word, r.kind[j], 1ULL, r.counters);
         } else if (r.kind[j] == ACC_SUM_F64 && r.splitM[j] != 0.0) {
           double hi, lo;
-          splitDouble(__longlong_as_double(static_cast<long long>(w[u][1 + r.valIdx[j]])), r.splitM[j], &hi, &lo);
+          splitDouble(__longlong_as_double(static_cast<long long>(recordWord<W>(w[u], 1 + r.valIdx[j]))), r.splitM[j], &hi, &lo);
           applyLds(word, ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(hi)), r.counters);
           applyLds(word + 1, ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(lo)), r.counters);
         } else {
-          applyLds(word, r.kind[j], w[u][1 + r.valIdx[j]], r.counters);
+          applyLds(word, r.kind[j], recordWord<W>(w[u], 1 + r.valIdx[j]), r.counters);
         }
       }
     }
@@ -1938,7 +1979,58 @@ __device__ inline void hashFoldFlush(const HashFold& f, const RadixAggArgs& r, b
   blockSync();
 }
 
-template <int W>
+// Flush of a fold into an operator that has no groups yet: nothing to look up, so the fold's
+// entries are APPENDED to a plain array of group rows - one atomic on the group counter per
+// flush, complete rows stored side by side (coalesced) instead of one findOrInsert + one
+// read-modify-write per group at random places of an open-addressing table. Rows of one key come
+// from one fold only (a key has one partition), except when a partition is folded in slices or a
+// record overflowed the LDS table: denseFlags[0] tells the host to merge (k_dense_merge).
+__device__ inline void hashFoldFlushDense(const HashFold& f, const RadixAggArgs& r, bool owner) {
+  const int A = f.A;
+  if (threadIdx.x == 0) {
+    f.scratch[0] = 0;
+    if (!owner) {
+      r.denseFlags[0] = 1;
+    }
+  }
+  blockSync();
+  uint32_t myPos[kHashPerLane];
+#pragma unroll
+  for (int k = 0; k < kHashPerLane; ++k) {
+    const int e = k * 512 + threadIdx.x;
+    myPos[k] = f.keys[e] != kEmpty ? atomicAdd(&f.scratch[0], 1u) : 0xffffffffu;
+  }
+  blockSync();
+  if (threadIdx.x == 0 && f.scratch[0] != 0) {
+    f.scratch[1] = atomicAdd(&r.counters->numNewGroups, f.scratch[0]);
+  }
+  blockSync();
+#pragma unroll
+  for (int k = 0; k < kHashPerLane; ++k) {
+    if (myPos[k] == 0xffffffffu) {
+      continue;
+    }
+    const int e = k * 512 + threadIdx.x;
+    const uint64_t idx = static_cast<uint64_t>(f.scratch[1]) + myPos[k];
+    if (idx >= r.denseCap) {
+      continue;  // counted: the host grows the array and folds again
+    }
+    uint64_t* g = r.table + idx * r.stride;
+    const uint64_t first = r.rowBase + static_cast<uint64_t>(f.first[e]);
+    for (int x = 0; x < r.stride; ++x) {
+      const int j = r.ldsOfWord[x];
+      g[x] = x == 0 ? static_cast<uint64_t>(f.keys[e])
+                    : (x == 1 ? first : (j >= 0 ? f.acc[static_cast<size_t>(e) * A + j] : r.pattern[x]));
+    }
+    if (r.pairKeys != nullptr) {
+      r.pairKeys[r.pairBase + idx] = first;
+      r.pairVals[r.pairBase + idx] = static_cast<uint32_t>(idx);
+    }
+  }
+  blockSync();
+}
+
+template <int W, bool DENSE>
 __global__ __launch_bounds__(512) void k_rp_aggregate_hashed(RadixAggArgs r) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
   __shared__ uint32_t bigList[512];
@@ -1959,8 +2051,12 @@ __global__ __launch_bounds__(512) void k_rp_aggregate_hashed(RadixAggArgs r) {
     }
     const bool split = end - begin > r.sliceRecs;
     hashFoldInit(f, r);
-    hashFoldRecords<W>(f, r, p, begin, split ? begin + r.sliceRecs : end);
-    hashFoldFlush(f, r, !split);
+    hashFoldRecords<W, DENSE>(f, r, p, begin, split ? begin + r.sliceRecs : end);
+    if constexpr (DENSE) {
+      hashFoldFlushDense(f, r, !split);
+    } else {
+      hashFoldFlush(f, r, !split);
+    }
   }
   // Remaining slices of the split partitions (skewed keys): folded by all workgroups, flushed with atomics.
   for (int64_t p0 = 0; p0 < r.numParts; p0 += blockDim.x) {
@@ -1986,11 +2082,56 @@ __global__ __launch_bounds__(512) void k_rp_aggregate_hashed(RadixAggArgs r) {
       for (uint64_t sl = 1 + blockIdx.x; sl < slices; sl += gridDim.x) {
         const uint64_t b = begin + sl * r.sliceRecs;
         hashFoldInit(f, r);
-        hashFoldRecords<W>(f, r, p, b, b + r.sliceRecs < end ? b + r.sliceRecs : end);
-        hashFoldFlush(f, r, false);
+        hashFoldRecords<W, DENSE>(f, r, p, b, b + r.sliceRecs < end ? b + r.sliceRecs : end);
+        if constexpr (DENSE) {
+          hashFoldFlushDense(f, r, false);
+        } else {
+          hashFoldFlush(f, r, false);
+        }
       }
     }
     blockSync();
+  }
+}
+
+// Rows appended by dense folds where one key may own several rows (skewed keys: a partition
+// folded in slices): every row goes to its group row in an initialised open-addressing table
+// with atomics, like the flush of a slice.
+struct DenseMergeArgs {
+  const uint64_t* rows;
+  uint64_t numRows;
+  uint64_t* table;
+  uint64_t capacity;
+  int32_t stride;
+  int32_t numWords;
+  int32_t wordKind[2 * kRadixMaxAccs];
+  int32_t wordOff[2 * kRadixMaxAccs];
+  Counters* counters;
+};
+
+__global__ __launch_bounds__(256) void k_dense_merge(DenseMergeArgs a) {
+  for (uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; i < a.numRows;
+       i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const uint64_t* row = a.rows + i * a.stride;
+    uint64_t* g = findOrInsert(a.table, a.stride, a.capacity, row[0], a.counters);
+    if (g == nullptr) {
+      continue;
+    }
+    const unsigned long long old = atomicMin(reinterpret_cast<unsigned long long*>(g + 1), row[1]);
+    if (old == kNoRow) {
+      atomicAdd(&a.counters->numNewGroups, 1u);
+    }
+    for (int j = 0; j < a.numWords; ++j) {
+      const uint64_t v = row[a.wordOff[j]];
+      const int32_t kind = a.wordKind[j];
+      if (v != accIdentity(kind)) {
+        if (kind == ACC_SUM_I64) {
+          addPartial128Global(g + a.wordOff[j], v, 0);  // the row's own high word follows as word j + 1
+        } else {
+          applyGlobal(g + a.wordOff[j], kind == ACC_COUNT ? ACC_SUM_I64_WRAP : kind, v, a.counters);
+        }
+      }
+    }
   }
 }
 
@@ -3055,6 +3196,16 @@ struct vx355_agg {
   int64_t radixLaunches = 0;
   bool radixSorted = true;   // VX355_AGG_RADIX_SORTED=0: scatter passes store record by record
   bool radixSparse = true;   // VX355_AGG_RADIX_SPARSE=0: open-addressing tables stay on k_agg_global
+  // Open-addressing mode, operator without groups, a large batch: the radix folds append their
+  // groups to a plain array of group rows (hashFoldFlushDense) and that array IS the table until
+  // someone has to look a key up (tableDense: capacity = number of rows, all live; rebuildTable
+  // re-keys it into a real open-addressing table before the next input is aggregated).
+  bool radixDense = true;    // VX355_AGG_RADIX_DENSE=0: off
+  bool tableDense = false;
+  bool denseNext = false;    // the next launchChunk is such a launch
+  int64_t denseMinRows = 1 << 22;   // VX355_AGG_DENSE_MIN_ROWS
+  int64_t denseLaunches = 0, denseRefolds = 0, denseMerges = 0;
+  DevBuf denseFlags;
   // The table was allocated but never written (rebuildTable skipped k_init_table because a radix
   // fold may come first and store every row itself); settleTable initialises it for anyone else.
   bool tableVirgin = false;
@@ -3516,6 +3667,7 @@ void rebuildTable(vx355_agg& h, uint64_t extraGroups) {
   rt.sync();
   h.table = std::move(fresh);
   h.tableVirgin = virgin;
+  h.tableDense = false;
   h.capacity = newCap;
   h.mode = d.mode;
   for (size_t k = 0; k < h.keys.size(); ++k) {
@@ -4101,6 +4253,43 @@ int radixHashedShift(uint64_t capacity, int64_t rows) {
   return capBits - partBits;
 }
 
+// Slot space of a dense launch over 'rows' rows: partitions of ~kHashRecsPerPart records (at most
+// 2^20 of them), kHashSlots virtual slots each.
+uint64_t denseSlotSpace(int64_t rows) {
+  const int partBits =
+      std::max(1, std::min(20, log2Ceil(static_cast<uint64_t>(std::max<int64_t>(2, rows / kHashRecsPerPart)))));
+  return 1ULL << (partBits + log2Ceil(static_cast<uint64_t>(kHashSlots)));
+}
+
+int radixHashedVals(const AggArgs& a) {
+  int numVals = 0;
+  for (int j = 0; j < a.numAccs; ++j) {
+    numVals += a.accs[j].kind == ACC_COUNT ? 0 : 1;
+  }
+  return numVals;
+}
+
+// A batch into an operator in open-addressing mode that has no groups yet (see tableDense).
+bool radixDenseEligible(const vx355_agg& h, const AggArgs& a, int64_t rows) {
+  return h.radixDense && h.radixSparse && h.radixSorted && h.radixMinRows >= 0 && h.mode == MODE_NORMALIZED &&
+      h.numGroups == 0 && a.numAccs >= 1 && a.numAccs <= kRadixMaxAccs && radixHashedVals(a) <= 2 &&
+      rows >= std::max<int64_t>(h.radixMinRows, h.denseMinRows);
+}
+
+// Rows one dense launch takes: row numbers must fit the record, and the two record buffers stay
+// under ~30 % of the GPU's memory.
+int64_t denseMaxRows(const AggArgs& a) {
+  size_t freeBytes = 0, totalBytes = 0;
+  HIP_OK(hipMemGetInfo(&freeBytes, &totalBytes));
+  const int64_t recBytes = (2 + radixHashedVals(a)) * 8;
+  const int64_t byMemory = static_cast<int64_t>(totalBytes * 3 / 10) / (2 * recBytes);
+  int64_t rows = std::max<int64_t>(1 << 22, std::min<int64_t>(1LL << radixRowBits(denseSlotSpace(1LL << 30)), byMemory));
+  if (const char* e = std::getenv("VX355_AGG_DENSE_MAX_ROWS")) {
+    rows = std::max<int64_t>(64, std::strtoll(e, nullptr, 10));
+  }
+  return rows & ~63LL;
+}
+
 bool radixHashedEligible(const vx355_agg& h, const AggArgs& a) {
   if (a.mode != MODE_NORMALIZED || !h.radixSparse || !h.radixSorted) {
     return false;
@@ -4137,17 +4326,22 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
   RadixArgs r{};
   r.a = a;
   const bool hashed = a.mode == MODE_NORMALIZED;
+  const bool dense = hashed && h.denseNext;
+  h.denseNext = false;
+  // dense: no table to address - the "home slots" are those of a virtual table of
+  // partitions x kHashSlots slots, so that a partition maps onto the LDS table one to one
+  const uint64_t slotSpace = dense ? denseSlotSpace(n) : a.capacity;
   r.hashed = hashed ? 1 : 0;
-  r.slotMask = a.capacity - 1;
-  r.shiftB = hashed ? radixHashedShift(a.capacity, n) : radixShiftB(radixWords(a));
-  const uint64_t parts = (a.capacity + (1ULL << r.shiftB) - 1) >> r.shiftB;
+  r.slotMask = slotSpace - 1;
+  r.shiftB = hashed ? radixHashedShift(slotSpace, n) : radixShiftB(radixWords(a));
+  const uint64_t parts = (slotSpace + (1ULL << r.shiftB) - 1) >> r.shiftB;
   // One level while the fan-out fits the LDS cursors (measured: 2400 bins in one
   // pass beat 64 x 64 in two); otherwise two balanced levels.
   const uint64_t maxBins1 = hashed ? kSortBins : static_cast<uint64_t>(h.radixMaxBins);
   r.shift2 = parts <= maxBins1 ? 0 : std::max(log2Ceil((parts + maxBins1 - 1) / maxBins1), log2Ceil(parts) / 2);
   r.numBins = static_cast<int32_t>((parts + (1ULL << r.shift2) - 1) >> r.shift2);
-  r.keyBits = radixKeyBits(a.capacity);
-  r.rowBits = radixRowBits(a.capacity);
+  r.keyBits = radixKeyBits(slotSpace);
+  r.rowBits = radixRowBits(slotSpace);
   const int32_t bins2 = 1 << r.shift2;
   for (int j = 0; j < a.numAccs; ++j) {
     r.valIdx[j] = a.accs[j].kind == ACC_COUNT ? -1 : r.numVals++;
@@ -4389,9 +4583,29 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
   for (int j = 0; j < g.numWords; ++j) {
     g.ldsOfWord[g.wordOff[j]] = static_cast<int8_t>(j);
   }
+  // dense: the folds append to a fresh array of group rows, sized for "a quarter of the rows are
+  // new groups" first and exactly on the second try (the folds count every group they find)
+  DevBuf denseRows;
+  uint64_t denseCap = 0;
+  if (dense) {
+    denseCap = static_cast<uint64_t>(std::min<int64_t>(n, std::max<int64_t>(1 << 20, n / 4)));
+    if (const char* e = std::getenv("VX355_AGG_DENSE_CAP")) {
+      denseCap = static_cast<uint64_t>(std::max<int64_t>(64, std::strtoll(e, nullptr, 10)));
+    }
+    denseRows.ensure(static_cast<size_t>(denseCap) * a.stride * 8 + 64);
+    h.denseFlags.ensure(64);
+    HIP_OK(hipMemsetAsync(h.denseFlags.ptr(), 0, 64, rt.stream));
+    g.dense = 1;
+    g.denseCap = denseCap;
+    g.denseFlags = h.denseFlags.as<uint32_t>();
+    g.table = denseRows.as<uint64_t>();
+    h.pairsComplete = true;  // no groups yet: this launch lists all of them
+    h.pairCount = 0;
+  }
   if (h.pairsComplete && h.pairCount == h.numGroups) {
     // room for one new group per row of the chunk, at most one per group row
-    const size_t room = static_cast<size_t>(std::min<uint64_t>(a.capacity, static_cast<uint64_t>(h.numGroups + n)));
+    const size_t room = dense ? static_cast<size_t>(denseCap)
+                              : static_cast<size_t>(std::min<uint64_t>(a.capacity, static_cast<uint64_t>(h.numGroups + n)));
     const size_t live = static_cast<size_t>(h.pairCount);
     h.orderKeys.ensure(room * 8 + 64, true, live * 8);
     h.orderVals.ensure(room * 4 + 64, true, live * 4);
@@ -4409,13 +4623,80 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
   }
   const int gridA = rt.numCUs * std::max(1, perCu);
   if (hashed) {
-    byWidth([&](auto wTag) {
-      constexpr int W = decltype(wTag)::value;
-      if constexpr (W >= 2) {
-        VX_LAUNCH("k_rp_aggregate", (k_rp_aggregate_hashed<W>), gridA, 512, ldsBytes, g);
-      }
-    });
+    auto fold = [&]() {
+      byWidth([&](auto wTag) {
+        constexpr int W = decltype(wTag)::value;
+        if constexpr (W >= 2) {
+          if (dense) {
+            VX_LAUNCH("k_rp_aggregate", (k_rp_aggregate_hashed<W, true>), gridA, 512, ldsBytes, g);
+          } else {
+            VX_LAUNCH("k_rp_aggregate", (k_rp_aggregate_hashed<W, false>), gridA, 512, ldsBytes, g);
+          }
+        }
+      });
+    };
+    fold();
     ++h.radixLaunches;
+    if (!dense) {
+      return;
+    }
+    ++h.denseLaunches;
+    uint32_t* newGroups = &a.counters->numNewGroups;
+    uint32_t found = 0;
+    copyOut(&found, VX355_MEM_HOST, newGroups, 4);
+    if (found > denseCap) {
+      // more groups than the guess: now the number is known, fold the same records again
+      ++h.denseRefolds;
+      denseCap = found;
+      denseRows.ensure(static_cast<size_t>(denseCap) * a.stride * 8 + 64);
+      h.orderKeys.ensure(static_cast<size_t>(denseCap) * 8 + 64);
+      h.orderVals.ensure(static_cast<size_t>(denseCap) * 4 + 64);
+      g.pairKeys = h.orderKeys.as<uint64_t>();
+      g.pairVals = h.orderVals.as<uint32_t>();
+      g.denseCap = denseCap;
+      g.table = denseRows.as<uint64_t>();
+      HIP_OK(hipMemsetAsync(newGroups, 0, 4, rt.stream));
+      HIP_OK(hipMemsetAsync(h.denseFlags.ptr(), 0, 64, rt.stream));
+      fold();
+      copyOut(&found, VX355_MEM_HOST, newGroups, 4);
+    }
+    uint32_t several = 0;
+    copyOut(&several, VX355_MEM_HOST, h.denseFlags.ptr(), 4);
+    if (several == 0) {
+      // the array of rows is the table from here on
+      h.table = std::move(denseRows);
+      h.capacity = found;
+      h.tableDense = true;
+      h.tableVirgin = false;
+      h.tableReady = true;
+      return;
+    }
+    // some key may own several rows (a partition folded in slices): merge them in a real table
+    ++h.denseMerges;
+    const uint64_t cap = hashCapacityFor(static_cast<uint64_t>(found));
+    DevBuf fresh;
+    initTable(h, fresh, cap);
+    HIP_OK(hipMemsetAsync(newGroups, 0, 4, rt.stream));
+    DenseMergeArgs m{};
+    m.rows = denseRows.as<uint64_t>();
+    m.numRows = found;
+    m.table = fresh.as<uint64_t>();
+    m.capacity = cap;
+    m.stride = a.stride;
+    m.numWords = g.numWords;
+    for (int j = 0; j < g.numWords; ++j) {
+      m.wordKind[j] = g.wordKind[j];
+      m.wordOff[j] = g.wordOff[j];
+    }
+    m.counters = a.counters;
+    VX_LAUNCH("k_dense_merge", k_dense_merge, streamGrid(static_cast<int64_t>(found), 256), 256, 0, m);
+    rt.sync();
+    h.table = std::move(fresh);
+    h.capacity = cap;
+    h.tableDense = false;
+    h.tableVirgin = false;
+    h.tableReady = true;
+    h.pairsComplete = false;
     return;
   }
   if (g.virgin) {
@@ -4507,7 +4788,7 @@ void launchChunk(vx355_agg& h, AggArgs& a) {
     int grid = static_cast<int>(std::min<int64_t>(ceilDiv(a.numRows, 1024), rt.numCUs * 2));
     VX_LAUNCH("k_agg_lds", k_agg_lds, grid, 1024, ldsBytes, la);
   } else {
-    if (radixEligible(h, a)) {
+    if (h.denseNext || radixEligible(h, a)) {
       launchRadix(h, a);
       return;
     }
@@ -4904,18 +5185,23 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
     // groups) picks the LDS layout of every later launch.
     // (A direct-index table beyond the LDS path's 8192 groups has no layout to pick.)
     const bool wideArray = h.mode == MODE_ARRAY && h.capacity > 8192;
+    // (nor has an open-addressing table in front of a large batch: the dense folds need no table)
+    const bool denseChunk = radixDenseEligible(h, a, n - begin);
     rows = std::min((h.numGroups == 0 && !wideArray) ? std::min<int64_t>(h.chunkRows, 1 << 20) : h.chunkRows,
                     n - begin);
+    if (denseChunk) {
+      rows = std::min(n - begin, denseMaxRows(a));
+    }
     if (wideArray && h.radixMinRows >= 0) {
       rows = std::min<int64_t>(rows, 1LL << radixRowBits(h.capacity));  // radix path: row numbers live in the records
     }
-    if (h.mode == MODE_NORMALIZED) {
+    if (h.mode == MODE_NORMALIZED && !denseChunk) {
       // The open-addressing table is sized for the worst case "every row of the
       // chunk is a new group": keep that bound reasonable.
       rows = std::min<int64_t>(rows, 1 << 26);
     }
-    if (h.mode == MODE_NORMALIZED &&
-        static_cast<uint64_t>(h.numGroups + rows) > h.capacity * 7 / 10) {
+    if (h.mode == MODE_NORMALIZED && !denseChunk &&
+        (h.tableDense || static_cast<uint64_t>(h.numGroups + rows) > h.capacity * 7 / 10)) {
       rebuildTable(h, static_cast<uint64_t>(rows));  // HashTable::checkSize (HashTable.cpp:772-806)
     }
     const uint32_t deferCap = static_cast<uint32_t>(std::min<int64_t>(rows, h.deferCap));
@@ -4988,7 +5274,9 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
         c.keys[k].range = h.keys[k].range;
         used[k] = h.keys[k].range;
       }
+      h.denseNext = denseChunk && attempt == 0 && !rescan && list == nullptr && h.numGroups == 0;
       launchChunk(h, c);
+      h.denseNext = false;
       Counters ctr = readCounters(h);
       // A key no VectorHasher range can hold (string longer than 7 bytes): its
       // rows were deferred; they force the generic mode below.
@@ -5123,7 +5411,10 @@ void resetAfterFlush(vx355_agg& h) {
       HIP_OK(hipMemsetAsync(h.gCounter.ptr(), 0, 64, rt.stream));
     }
   }
-  if (h.tableReady) {
+  if (h.tableReady && h.tableDense) {
+    h.numGroups = 0;
+    rebuildTable(h, 0);  // an empty open-addressing table in place of the array of rows
+  } else if (h.tableReady) {
     initTable(h, h.table, h.capacity);
     h.tableVirgin = false;
   }
@@ -5532,6 +5823,12 @@ void configureFromEnv(vx355_agg& h) {
   }
   if (const char* e = std::getenv("VX355_AGG_RADIX_SPARSE")) {
     h.radixSparse = std::atoi(e) != 0;
+  }
+  if (const char* e = std::getenv("VX355_AGG_RADIX_DENSE")) {
+    h.radixDense = std::atoi(e) != 0;
+  }
+  if (const char* e = std::getenv("VX355_AGG_DENSE_MIN_ROWS")) {
+    h.denseMinRows = std::max<int64_t>(1, std::strtoll(e, nullptr, 10));
   }
   if (const char* e = std::getenv("VX355_AGG_RADIX_OPTIMISTIC")) {
     h.radixOptimistic = std::atoi(e) != 0;
