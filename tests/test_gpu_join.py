@@ -212,6 +212,83 @@ def test_q3_shape_device_resident_probe(oracle, vx):
     assert dates.to_host(n).tolist() == [p[0] for p in e_payload]
 
 
+@pytest.mark.parametrize("hit_rate,windowed,wide", [(1.0, False, "1"), (0.9, True, "1"), (0.02, False, "1"), (1.0, False, "-1"), (1.0, False, "0")])
+def test_inline_dependents_of_wide_slots(oracle, vx, hit_rate, windowed, wide, monkeypatch):
+    """Inner join, unique sparse build keys (normalized-key mode), outputs left in HBM: the probe finds
+    up to two 8-byte dependents in the slot next to the key (WideSlot) and the emit pass writes them,
+    the other build columns (a nullable BIGINT, an INTEGER, a third 8-byte column) are gathered by build
+    row - high hit rates (every tile dense), a low one (tiles listed by the probe pass), output taken
+    in windows, the adaptive rule (-1: this batch is 8 x the build side) and the switch off (0)."""
+    monkeypatch.setenv("VX355_JOIN_WIDE", wide)
+    rng = np.random.default_rng(77)
+    nb, npr = 50_000, (1_200_000 if wide == "-1" else 400_000)   # adaptive: batches of >= 2^20 rows, >= 2 x the build
+    bk = (rng.permutation(1 << 22)[:nb].astype(np.int64) * 104729 + 12345) * 1_000_003   # sparse: no array mode
+    d0 = rng.integers(-1 << 60, 1 << 60, nb).astype(np.int64)
+    d1 = rng.random(nb)
+    d2 = rng.integers(0, 1 << 40, nb).astype(np.int64)
+    d2_valid = rng.random(nb) > 0.2
+    d3 = rng.integers(0, 1 << 30, nb).astype(np.int32)
+    d4 = rng.integers(0, 1 << 50, nb).astype(np.int64)
+    lk = np.where(rng.random(npr) < hit_rate, bk[rng.integers(0, nb, npr)], -7).astype(np.int64)
+    dep_kinds = [abi.BIGINT, abi.DOUBLE, abi.BIGINT, abi.INTEGER, abi.BIGINT]
+    build = batch_of([bk, d0, d1, d2, d3, d4], [None, None, None, d2_valid, None, None])
+    table_o, _bo = _build(oracle, [[build]], [0], [abi.BIGINT], [1, 2, 3, 4, 5], dep_kinds, abi.JOIN_INNER)
+    po = oracle.JoinProbe(table_o, [0], abi.JOIN_INNER)
+    po.add_input(batch_of([lk]))
+    e_map, e_rows, e_cols = [], [], None
+    while True:
+        m, r, cols, fin = po.get_output(1 << 20)
+        e_map += list(m)
+        e_rows += list(r)
+        e_cols = cols if e_cols is None else [(np.concatenate([a[0], b[0]]), np.concatenate([a[1], b[1]])) for a, b in zip(e_cols, cols)]
+        if fin:
+            break
+    table, _b = _build(vx, [[vx.to_device(build)]], [0], [abi.BIGINT], [1, 2, 3, 4, 5], dep_kinds, abi.JOIN_INNER)
+    assert table.stats().hash_mode == abi.MODE_NORMALIZED_KEY
+    vx.profile_reset()
+    vx.profile_enable(True)
+    probe = vx.JoinProbe(table, [0], abi.JOIN_INNER)
+    probe.add_input(vx.to_device(batch_of([lk])))
+    cap = 70_000 if windowed else len(e_map) + 64
+    mapping, rows = vx.DeviceArray(cap, np.int32), vx.DeviceArray(cap, np.int32)
+    np_types = [np.int64, np.float64, np.int64, np.int32, np.int64]
+    vals = [vx.DeviceArray(cap, t) for t in np_types]
+    nulls = [vx.DeviceArray((cap + 63) // 64, np.uint64) for _ in np_types]
+    order = [4, 1, 0, 2, 3]   # not the table's order
+    descs = (abi.OutColumn * 5)()
+    for i, c in enumerate(order):
+        descs[i].type_kind, descs[i].mem = dep_kinds[c], abi.MEM_DEVICE
+        descs[i].values, descs[i].nulls = vals[c].ptr, nulls[c].ptr
+    got_map, got_rows, got_cols = [], [], [[] for _ in np_types]
+    got_valid = [[] for _ in np_types]
+    while True:
+        n, fin = probe.get_output_device(cap, mapping.ptr, rows.ptr, descs, order)
+        got_map += mapping.to_host(n).tolist()
+        got_rows += rows.to_host(n).tolist()
+        for c in range(5):
+            got_cols[c] += vals[c].to_host(n).tolist()
+            words = nulls[c].to_host((n + 63) // 64)
+            got_valid[c] += [bool((int(words[i >> 6]) >> (i & 63)) & 1) for i in range(n)]
+            if n % 64:
+                assert int(words[-1]) >> (n % 64) == 0   # bits past the page stay clear, as the gather leaves them
+        if fin:
+            break
+    vx.profile_enable(False)
+    assert got_map == [int(x) for x in e_map] and got_rows == [int(x) for x in e_rows]
+    for c in range(5):
+        ev, evalid = e_cols[c]
+        evalid = np.asarray(evalid).astype(bool).tolist()
+        assert got_valid[c] == evalid, c
+        ev = np.asarray(ev)
+        if ev.dtype.kind == "f":
+            assert [np.float64(g).view(np.int64) for g, ok in zip(got_cols[c], evalid) if ok] == \
+                [np.float64(e).view(np.int64) for e, ok in zip(ev.tolist(), evalid) if ok]
+        else:
+            assert [g for g, ok in zip(got_cols[c], evalid) if ok] == [e for e, ok in zip(ev.tolist(), evalid) if ok], c
+    prof = vx.profile()
+    assert ("k_widen_slots" in prof) == (wide != "0")
+
+
 def test_repartitioned_join_gpu_backend_single_rank(oracle, vx):
     """The config-5 pipeline on one GPU (world = 1, RCCL): hash -> partition ->
     stable scatter -> all-to-all -> local build + probe, all in HBM, against the

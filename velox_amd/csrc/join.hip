@@ -57,7 +57,8 @@ struct BuildCounters {
   uint32_t duplicates;
   uint32_t numDistinct;
   uint32_t tableFull;
-  uint32_t pad[2];
+  uint32_t depNulls;   // bit d: dependent column d holds a null in some build row
+  uint32_t pad;
   int64_t keyMin[kMaxKeys];
   int64_t keyMax[kMaxKeys];
 };
@@ -242,6 +243,9 @@ __global__ __launch_bounds__(256) void k_build_append(AppendArgs a) {
       const ColView& c = a.deps[d];
       const bool valid = !colIsNull(c, row);
       a.depValid[d][a.base + p] = valid ? 1 : 0;
+      if (!valid && !((__hip_atomic_load(&a.counters->depNulls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> d) & 1)) {
+        atomicOr(&a.counters->depNulls, 1u << d);
+      }
       const int w = a.depWidth[d];
       char* dst = a.depOut[d] + (a.base + p) * (w == 0 ? 1 : w);
       const int64_t i = valid ? colIndex(c, row) : 0;
@@ -284,6 +288,35 @@ struct Slot {
   uint32_t head;
   uint32_t pad;
 };
+
+// Slot with up to two 8-byte dependents of its (only) build row next to the key: a probe that finds
+// the key has the payload in the same 32 bytes instead of gathering it by build row later (the
+// reference's RowContainer keeps keys and dependents of a row side by side for the same reason).
+// Built on demand for tables without duplicate keys when a probe batch is large enough to pay
+// for the pass (vx355_join_table::wide).
+constexpr int kWideDeps = 2;
+struct WideSlot {
+  uint64_t key;
+  uint32_t head;
+  uint32_t pad;
+  uint64_t dep[kWideDeps];
+};
+
+__global__ __launch_bounds__(256) void k_widen_slots(const Slot* slots, WideSlot* wide, uint64_t capacity,
+                                                     const uint64_t* dep0, const uint64_t* dep1) {
+  for (uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; i < capacity;
+       i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const Slot s = slots[i];
+    WideSlot w;
+    w.key = s.key;
+    w.head = s.head;
+    w.pad = 0;
+    const bool live = s.key != kEmptyKey;
+    w.dep[0] = live && dep0 ? dep0[s.head] : 0;
+    w.dep[1] = live && dep1 ? dep1[s.head] : 0;
+    wide[i] = w;
+  }
+}
 
 struct InsertArgs {
   const uint64_t* keyStore[kMaxKeys];
@@ -705,6 +738,8 @@ struct ProbeArgs {
   int32_t window;                 // listing probe, array mode, flat BIGINT key: presence bits through a per-wave window
   const uint8_t* keyNullStore;    // generic hash mode + nullAsValue: null-key mask per build row
   uint64_t presentWords;          // u32 words of the presence bitmap
+  const WideSlot* wide;           // WIDE probes: slots with inline dependents ...
+  uint64_t* hitVals[kWideDeps];   // ... whose values are staged per probe row next to hits[]
 };
 
 constexpr int kSparseCap = 1024;  // staged pairs per tile of 8192 probe rows (12.5 % hit rate)
@@ -842,6 +877,30 @@ __device__ inline uint32_t lookupSlots(const ProbeArgs& a, uint64_t key) {
   return kNoRow32;
 }
 
+template <int WIDE>
+__device__ inline uint32_t lookupWide(const ProbeArgs& a, uint64_t key, uint64_t (&vals)[kWideDeps]) {
+  const uint64_t mask = a.capacity - 1;
+  uint64_t pos = twangMix64(key) & mask;
+  for (uint64_t probes = 0; probes <= mask; ++probes) {
+    const uint4* at = reinterpret_cast<const uint4*>(a.wide + pos);
+    const uint4 raw = at[0];
+    const uint4 dep = at[1];   // same 32-byte sector as the key
+    const uint64_t k = (static_cast<uint64_t>(raw.y) << 32) | raw.x;
+    if (k == key) {
+      vals[0] = (static_cast<uint64_t>(dep.y) << 32) | dep.x;
+      if (WIDE > 1) {
+        vals[1] = (static_cast<uint64_t>(dep.w) << 32) | dep.z;
+      }
+      return raw.z;
+    }
+    if (k == kEmptyKey) {
+      return kNoRow32;
+    }
+    pos = (pos + 1) & mask;
+  }
+  return kNoRow32;
+}
+
 // HashTable::joinProbe: hits[row] = first build row with an equal key. One
 // workgroup per tile of 8192 consecutive probe rows; each lane keeps
 // kProbeUnroll independent probes in flight: all key loads, then all presence
@@ -866,7 +925,7 @@ struct SparseLds {
   uint32_t waveCount[2][4];                    // double buffered by tile parity: one barrier per tile
 };
 
-template <int MODE, int FAST, bool SPARSE>
+template <int MODE, int FAST, bool SPARSE, int WIDE = 0>
 __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, SparseLds* lds) {
   const int mode = MODE >= 0 ? MODE : a.mode;
   const int fastKey = FAST >= 0 ? FAST : a.fastKey;
@@ -898,6 +957,7 @@ __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, Spars
     uint64_t key[kU];
     bool candidate[kU];
     uint32_t hit[kU];
+    uint64_t vals[WIDE > 0 && !SPARSE ? kU : 1][kWideDeps];
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       rows[u] = rowOf(it, u);
@@ -951,6 +1011,11 @@ __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, Spars
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
           hit[u] = candidate[u] ? a.head[key[u]] : kNoRow32;
+        }
+      } else if constexpr (WIDE > 0 && !SPARSE) {
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          hit[u] = candidate[u] ? lookupWide<WIDE>(a, key[u], vals[u]) : kNoRow32;
         }
       } else {
 #pragma unroll
@@ -1049,6 +1114,14 @@ __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, Spars
           }
         }
         a.hits[rows[u]] = hit[u];
+        if constexpr (WIDE > 0 && !SPARSE) {
+          if (isHit(hit[u])) {
+            a.hitVals[0][rows[u]] = vals[u][0];
+            if (WIDE > 1) {
+              a.hitVals[1][rows[u]] = vals[u][1];
+            }
+          }
+        }
         uint32_t matches = isHit(hit[u]) ? 1 : 0;
         if (matches && a.probed) {
           // setProbedFlag on every row of the chain (the rows listJoinResults hands out).
@@ -1073,7 +1146,7 @@ __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, Spars
   return mine;
 }
 
-template <int MODE, int FAST, bool SPARSE>
+template <int MODE, int FAST, bool SPARSE, int WIDE = 0>
 __global__ __launch_bounds__(256) void k_join_probe(ProbeArgs args) {
   __shared__ uint64_t waveSums[4];
   __shared__ __attribute__((aligned(16))) unsigned char sparseRaw[SPARSE ? sizeof(SparseLds) : 16];
@@ -1081,7 +1154,7 @@ __global__ __launch_bounds__(256) void k_join_probe(ProbeArgs args) {
   SparseLds* lds = reinterpret_cast<SparseLds*>(sparseRaw);
   int parity = 0;
   for (int64_t tile = a.tileBegin + blockIdx.x; tile < a.numTiles; tile += gridDim.x, parity ^= 1) {
-    uint64_t mine = probeTileBody<MODE, FAST, SPARSE>(a, tile, lds);
+    uint64_t mine = probeTileBody<MODE, FAST, SPARSE, WIDE>(a, tile, lds);
     if constexpr (SPARSE) {
       const int wave = threadIdx.x >> 6;
       if (lane() == 0) {
@@ -1120,7 +1193,7 @@ __global__ __launch_bounds__(256) void k_join_probe(ProbeArgs args) {
         a.tileDense[tile] = 1;
         atomicAdd(reinterpret_cast<unsigned long long*>(a.sparseStats), 1ULL);
       }
-      mine = probeTileBody<MODE, FAST, false>(a, tile, lds);
+      mine = probeTileBody<MODE, FAST, false, WIDE>(a, tile, lds);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -2021,6 +2094,11 @@ struct EmitArgs {
   // null-aware semi project join says NULL (HashProbe::fillLeftSemiProjectMatchColumn)
   int32_t missValue;
   int32_t nullKeyValue;
+  // inline dependents (inner joins over wide slots): output column i = the value staged next to
+  // the hit; listed tiles take it from the dependent column by build row
+  const uint64_t* hitVals[kWideDeps];
+  const uint64_t* depVals[kWideDeps];
+  uint64_t* outVals[kWideDeps];
 };
 static_assert(sizeof(EmitArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
@@ -2045,6 +2123,12 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
         a.mapping[pos - a.windowBegin] = static_cast<int32_t>(pair.x);
         if (a.buildRows) {
           a.buildRows[pos - a.windowBegin] = wantBuild ? static_cast<int32_t>(pair.y) : -1;
+        }
+#pragma unroll
+        for (int d = 0; d < kWideDeps; ++d) {
+          if (a.outVals[d]) {
+            a.outVals[d][pos - a.windowBegin] = a.depVals[d][pair.y];
+          }
         }
       }
     }
@@ -2094,6 +2178,12 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
               (listsMatches(a.joinType) || a.joinType == VX355_JOIN_LEFT_SEMI_PROJECT);
           a.buildRows[pos - a.windowBegin] =
               listMatch ? static_cast<int32_t>(hit) : (hit == kNullKey32 ? a.nullKeyValue : a.missValue);
+        }
+#pragma unroll
+        for (int d = 0; d < kWideDeps; ++d) {
+          if (a.outVals[d]) {
+            a.outVals[d][pos - a.windowBegin] = a.hitVals[d][r];
+          }
         }
       }
       run += popc64(m);
@@ -2162,6 +2252,15 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
     if (running >= a.windowEnd) {
       break;  // uniform: 'running' is shared
     }
+  }
+}
+
+// Validity words of n rows that are all valid (what k_gather_deps writes for a column without nulls).
+__global__ __launch_bounds__(256) void k_fill_valid(uint64_t* words, int64_t n) {
+  const int64_t w = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (w * 64 < n) {
+    const int64_t rest = n - w * 64;
+    words[w] = rest >= 64 ? ~0ULL : ((1ULL << rest) - 1);
   }
 }
 
@@ -2275,6 +2374,7 @@ struct vx355_join_build {
   bool unmappable = false;       // some key has no 64-bit normalized form
   std::vector<DevBuf> depVals;   // width bytes per row (BOOLEAN: 1 byte)
   std::vector<DevBuf> depValid;  // 1 byte per row
+  uint32_t depNulls = 0;         // bit d: column d holds a null
   int64_t numRows = 0;
   int64_t capacityRows = 0;
   bool hasNullKeys = false;
@@ -2308,6 +2408,13 @@ struct vx355_join_table {
   DevBuf gslots;  // generic hash mode: u64[capacity]
   std::vector<DevBuf> keyStore;  // generic hash mode: build key images
   std::vector<DevBuf> depVals, depValid;
+  uint32_t depNulls = 0;   // bit d: dependent column d holds nulls (else depValid[d] is all ones and nobody reads it)
+  // slots with inline dependents (WideSlot), built by the first probe batch large enough to pay
+  // for it (ensureWide, under lazyMutex); wideDeps = the dependents they carry
+  DevBuf wide;
+  int32_t wideDeps[kWideDeps] = {-1, -1};
+  int32_t numWide = 0;
+  bool wideTried = false;
   int64_t numRows = 0;
   int64_t numDistinct = 0;
   bool hasDuplicates = false;
@@ -2338,6 +2445,10 @@ struct vx355_join_probe {
   int64_t outputBatchBytes = 0;  // preferred_output_batch_bytes (0 = rows only)
   int32_t partitionMode = -1;  // VX355_JOIN_PARTITION: -1 adaptive, 0 never, 1 whenever eligible
   bool window = true;          // VX355_JOIN_WINDOW=0: the listing probe gathers every presence word itself
+  int32_t wideMode = -1;       // VX355_JOIN_WIDE: -1 adaptive (large batches), 0 never, 1 whenever eligible
+  DevBuf hitVals[kWideDeps];   // inline dependents of the batch's hits, by probe row
+  int32_t wideStaged = 0;      // how many of the table's wide dependents this batch staged
+  int32_t denseStreak = 0;     // batches that still skip the sparse-listing sample
   bool partitionFast = true;   // VX355_JOIN_PARTITION_FAST=0: the range-partitioned probe always counts first
   DeviceBatch batch;                       // the batch being probed: the filter reads it at output time
   std::vector<std::vector<char>> hostStrings;  // long payload strings of the last page handed to a host caller
@@ -2503,6 +2614,7 @@ void buildAddInput(vx355_join_build& h, const vx355_batch* batch) {
   if (c.nullKeyRows) {
     h.hasNullKeys = true;
   }
+  h.depNulls |= c.depNulls;
   for (size_t k = 0; k < h.keyCols.size(); ++k) {
     if (c.keyMin[k] <= c.keyMax[k]) {
       h.obsMin[k] = std::min(h.obsMin[k], c.keyMin[k]);
@@ -2556,6 +2668,7 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
       h.numRows += o.numRows;
     }
     h.hasNullKeys = h.hasNullKeys || o.hasNullKeys;
+    h.depNulls |= o.depNulls;
     o.finished = true;
   }
   rt.sync();
@@ -2698,6 +2811,7 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
   }
   t->depVals = std::move(h.depVals);
   t->depValid = std::move(h.depValid);
+  t->depNulls = h.depNulls;
   // The build key images stay with the table: generic-mode probes compare
   // against them, dynamic filters (value lists, Bloom blocks) are made from them.
   t->keyStore = std::move(h.keyVals);
@@ -2795,6 +2909,8 @@ void fillFilterArgs(const vx355_join_probe& p, const DeviceBatch& db, JoinFilter
   }
 }
 
+int32_t ensureWide(vx355_join_table& t, int32_t mode, int64_t probeRows);
+
 void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
   auto& rt = Runtime::get();
   auto& t = *p.table;
@@ -2887,6 +3003,17 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
   }
   a.window = p.window ? 1 : 0;
   a.presentWords = (t.capacity + 31) / 32;
+  // inline dependents: inner joins whose output is one row per hit (no filter, no counting)
+  p.wideStaged = 0;
+  if (a.fastKey == 1 && p.joinType == VX355_JOIN_INNER && !filtered && !counting && !a.nullAware) {
+    p.wideStaged = ensureWide(t, p.wideMode, n);
+    if (p.wideStaged > 0) {
+      a.wide = t.wide.as<WideSlot>();
+      for (int i = 0; i < p.wideStaged; ++i) {
+        a.hitVals[i] = static_cast<uint64_t*>(p.hitVals[i].ensure(static_cast<size_t>(n) * 8 + 64));
+      }
+    }
+  }
   auto launch = [&](auto sparseTag, int64_t tileBegin, int64_t tileEnd) {
     constexpr bool SP = decltype(sparseTag)::value;
     ProbeArgs la = a;
@@ -2904,6 +3031,12 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
       VX_LAUNCH(name, (k_join_probe<JMODE_ARRAY, 1, SP>), grid, 256, 0, la);
     } else if (t.mode == JMODE_ARRAY && a.fastKey == 2) {
       VX_LAUNCH(name, (k_join_probe<JMODE_ARRAY, 2, SP>), grid, 256, 0, la);
+    } else if (t.mode == JMODE_NORMALIZED && a.fastKey == 1 && la.wide != nullptr) {
+      if (la.hitVals[1] != nullptr) {
+        VX_LAUNCH(name, (k_join_probe<JMODE_NORMALIZED, 1, SP, 2>), grid, 256, 0, la);
+      } else {
+        VX_LAUNCH(name, (k_join_probe<JMODE_NORMALIZED, 1, SP, 1>), grid, 256, 0, la);
+      }
     } else if (t.mode == JMODE_NORMALIZED && a.fastKey == 1) {
       VX_LAUNCH(name, (k_join_probe<JMODE_NORMALIZED, 1, SP>), grid, 256, 0, la);
     } else if (t.mode == JMODE_ARRAY) {
@@ -2915,7 +3048,14 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
   // Sparse listing: joins that emit matches only, one build row per match, not null
   // aware. Whether the hit rate is low enough is measured on the first tiles of the
   // batch (the probe pass reports tiles that overflowed their staging segment).
-  const bool sparseEligible = p.sparseMode != 0 && !p.haveCounts && !a.nullAware && !filtered && !counting &&
+  // (a batch whose sample sent it to the dense form lets the next seven batches of this operator
+  // skip the sample: the hit rate of a stream does not change from batch to batch)
+  const bool recentlyDense = p.sparseMode < 0 && p.denseStreak > 0;
+  if (recentlyDense) {
+    --p.denseStreak;
+  }
+  const bool sparseEligible = p.sparseMode != 0 && !recentlyDense && !p.haveCounts && !a.nullAware && !filtered &&
+      !counting &&
       (p.joinType == VX355_JOIN_INNER || p.joinType == VX355_JOIN_LEFT_SEMI_FILTER ||
        (p.joinType == VX355_JOIN_RIGHT && !t.hasDuplicates));
   p.sparse = false;
@@ -3030,6 +3170,7 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
         HIP_OK(hipMemsetAsync(a.tileDense + sample, 1, static_cast<size_t>(p.numTiles - sample), rt.stream));
         launch(std::false_type{}, sample, p.numTiles);
         p.denseTiles = p.numTiles - sample;
+        p.denseStreak = 7;
       }
     }
   } else {
@@ -3107,6 +3248,42 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
 }
 
 // extractColumns for 'n' listed build rows (-1 = null row) into caller columns.
+// The table's wide slots, built now if this is the first batch to ask and the table qualifies:
+// normalized-key mode, no duplicate keys, at least one 8-byte dependent without nulls. A batch
+// qualifies when it is at least twice the build side (the pass writes capacity x 32 bytes and
+// gathers one dependent per build row; it saves one random access per probe row). -> number of
+// inline dependents (0 = none).
+int32_t ensureWide(vx355_join_table& t, int32_t mode, int64_t probeRows) {
+  if (mode == 0 || t.mode != JMODE_NORMALIZED || t.hasDuplicates || t.numRows == 0) {
+    return 0;
+  }
+  std::lock_guard<std::mutex> lock(t.lazyMutex);
+  if (t.numWide > 0) {
+    return t.numWide;
+  }
+  if (t.wideTried || (mode < 0 && (probeRows < (1 << 20) || probeRows < 2 * t.numRows))) {
+    return 0;
+  }
+  t.wideTried = true;
+  int32_t found = 0;
+  for (size_t d = 0; d < t.depKinds.size() && found < kWideDeps; ++d) {
+    if (kindWidth(t.depKinds[d]) == 8 && !isString(t.depKinds[d]) && !((t.depNulls >> d) & 1)) {
+      t.wideDeps[found++] = static_cast<int32_t>(d);
+    }
+  }
+  if (found == 0) {
+    return 0;
+  }
+  auto& rt = Runtime::get();
+  t.wide.ensure(static_cast<size_t>(t.capacity) * sizeof(WideSlot) + 64);
+  VX_LAUNCH("k_widen_slots", k_widen_slots, streamGrid(static_cast<int64_t>(t.capacity), 256, 2), 256, 0,
+            t.slots.as<Slot>(), t.wide.as<WideSlot>(), t.capacity, t.depVals[t.wideDeps[0]].as<uint64_t>(),
+            found > 1 ? t.depVals[t.wideDeps[1]].as<uint64_t>() : nullptr);
+  rt.sync();
+  t.numWide = found;
+  return found;
+}
+
 void gatherBuildCols(vx355_join_probe& p, const vx355_join_table& t, const int32_t* dRows, int32_t n,
                      vx355_out_column* buildCols, const int32_t* buildColIds, int32_t numBuildCols) {
     VX_CHECK_ARG(buildCols && buildColIds, "NULL build column arguments");
@@ -3144,7 +3321,7 @@ void gatherBuildCols(vx355_join_probe& p, const vx355_join_table& t, const int32
         ga.kind[c] = VX355_BOOLEAN;
       } else {
         ga.depVals[c] = t.depVals[id].as<char>();
-        ga.depValid[c] = t.depValid[id].as<uint8_t>();
+        ga.depValid[c] = ((t.depNulls >> id) & 1) ? t.depValid[id].as<uint8_t>() : nullptr;
         ga.width[c] = kindWidth(t.depKinds[id]);
         ga.kind[c] = t.depKinds[id];
       }
@@ -3258,6 +3435,39 @@ void probeGetOutput(vx355_join_probe& p, int32_t maxRows, int32_t* mappingOut, i
   ea.tileDense = p.sparse ? p.tileDense.as<uint8_t>() : nullptr;
   if (!p.filter.empty()) {
     fillFilterArgs(p, p.batch, &ea.f);
+  }
+  // Build columns the probe staged next to the hits (wide slots) leave with the emit pass; the
+  // others are gathered by build row afterwards.
+  std::vector<vx355_out_column> restCols;
+  std::vector<int32_t> restIds;
+  if (p.wideStaged > 0 && !p.haveCounts && numBuildCols > 0) {
+    VX_CHECK_ARG(buildCols && buildColIds, "NULL build column arguments");
+    bool taken[kWideDeps] = {false, false};
+    for (int32_t c = 0; c < numBuildCols; ++c) {
+      int slot = -1;
+      for (int i = 0; i < p.wideStaged; ++i) {
+        if (!taken[i] && buildColIds[c] == t.wideDeps[i] && buildCols[c].mem == VX355_MEM_DEVICE &&
+            buildCols[c].type_kind == t.depKinds[t.wideDeps[i]]) {
+          slot = i;
+        }
+      }
+      if (slot < 0) {
+        restCols.push_back(buildCols[c]);
+        restIds.push_back(buildColIds[c]);
+        continue;
+      }
+      taken[slot] = true;
+      ea.hitVals[slot] = p.hitVals[slot].as<uint64_t>();
+      ea.depVals[slot] = t.depVals[t.wideDeps[slot]].as<uint64_t>();
+      ea.outVals[slot] = static_cast<uint64_t*>(buildCols[c].values);
+      if (buildCols[c].nulls && n > 0) {
+        VX_LAUNCH("k_fill_valid", k_fill_valid, static_cast<int>(ceilDiv(ceilDiv(n, 64), 256)), 256, 0,
+                  buildCols[c].nulls, static_cast<int64_t>(n));
+      }
+    }
+    buildCols = restCols.data();
+    buildColIds = restIds.data();
+    numBuildCols = static_cast<int32_t>(restCols.size());
   }
   VX_LAUNCH("k_emit", k_emit, static_cast<int>(lastTile - firstTile + 1), 256, 0, ea);
 
@@ -3646,6 +3856,9 @@ int vx355_join_probe_create(vx355_join_table* table, const vx355_join_probe_spec
   }
   if (const char* e = std::getenv("VX355_JOIN_PARTITION_FAST")) {
     p->partitionFast = std::atoi(e) != 0;
+  }
+  if (const char* e = std::getenv("VX355_JOIN_WIDE")) {
+    p->wideMode = std::atoi(e);
   }
   if (const char* e = std::getenv("VX355_JOIN_WINDOW")) {
     p->window = std::atoi(e) != 0;
