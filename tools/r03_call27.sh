@@ -1,0 +1,21 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+summ() {
+python - "$1" <<'PY'
+import json, sys
+try:
+    lines = [l for l in open(sys.argv[1]) if l.startswith("{")]
+    d = json.loads(lines[-1])
+    print(sys.argv[1], "ms/step", round(d["ms_per_step"], 3), {k: v for k, v in sorted(d["kernels_ms_per_step"].items(), key=lambda x: -x[1]) if v > 0.05}, "frac", d["roofline"]["frac"])
+except Exception as e:
+    print(sys.argv[1], "failed", e)
+PY
+}
+for lib in libvx355.so libvx355_nt.so libvx355.so libvx355_nt.so; do
+  VX355_LIB_PATH=$PWD/velox_amd/$lib timeout 300 python bench.py --workload q1 --steps 20 --warmup 5 --no-cpu-baseline --no-traffic --no-secondary > gpurun_out/c27_q1_$lib.json 2> gpurun_out/c27_q1_$lib.err; summ gpurun_out/c27_q1_$lib.json
+done
+for lib in libvx355.so libvx355_nt.so; do
+  VX355_LIB_PATH=$PWD/velox_amd/$lib timeout 300 python bench.py --workload c1 --no-cpu-baseline --no-traffic > gpurun_out/c27_c1_$lib.json 2> gpurun_out/c27_c1_$lib.err; summ gpurun_out/c27_c1_$lib.json
+done

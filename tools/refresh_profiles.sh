@@ -1,7 +1,7 @@
 # Re-measures every workload bench.py knows on the GPU box; JSON lines land in gpurun_out/refresh/.
-# ROUND=r02 sh tools/refresh_profiles.sh
+# ROUND=r03 sh tools/refresh_profiles.sh
 R=${GRAFT_REPO_ROOT:-/root/repo}
-P=${ROUND:-r02}
+P=${ROUND:-r03}
 cd $R
 O=gpurun_out/refresh
 mkdir -p $O
@@ -25,4 +25,12 @@ VX355_JOIN_PARTITION=0 run ${P}_bench_q3_join_random_direct_probe --workload q3 
 run ${P}_bench_c4 --workload c4 --steps 3 --warmup 1
 run ${P}_bench_c4_unordered_output --workload c4 --c4-unordered --steps 3 --warmup 1 --no-traffic --no-cpu-baseline
 run ${P}_bench_c4_sparse_keys --workload c4 --c4-sparse --steps 3 --warmup 1 --no-traffic
-run ${P}_bench_c5_one_gpu --workload c5 --rows 200000000 --steps 3 --warmup 1 --no-traffic
+run ${P}_bench_c4_sparse_keys_unordered_output --workload c4 --c4-sparse --c4-unordered --steps 3 --warmup 1 --no-traffic --no-cpu-baseline
+VX355_C5_CHUNKS=1 run ${P}_bench_c5_one_gpu --workload c5 --rows 200000000 --steps 5 --warmup 2 --no-traffic
+run ${P}_bench_q3_join --workload q3 --steps 20 --warmup 5
+run ${P}_bench_q3_join_random_probe_order --workload q3 --q3-random-probe --steps 10 --warmup 3
+VX355_JIT=sync VX355_Q1_NULLS=0.01 run ${P}_bench_q1_nullable_discount --workload q1 --steps 10 --warmup 3 --no-traffic --no-secondary --no-cpu-baseline
+# two ranks SHARING the one GPU of this box: the launcher, the in-library RCCL exchange and the
+# merge run end to end (a functional record, not a scaling number: both ranks use the same HBM)
+VX355_BENCH_SHARE_GPU=1 run ${P}_bench_q1_2ranks_sharing_one_gpu --gpus 2 --rows 100000000 --steps 5 --warmup 2
+VX355_BENCH_SHARE_GPU=1 run ${P}_bench_c5_2ranks_sharing_one_gpu --gpus 2 --workload c5 --rows 50000000 --steps 3 --warmup 1

@@ -675,12 +675,20 @@ static_assert(sizeof(RadixArgs) <= 4096, "kernel arguments are limited to 4 KB")
 // KW = 0: any key set the ABI admits.
 constexpr int kRadixUnroll = 8;
 
+// Read-once streams of the radix passes (input columns, records): nontemporal under -DVX355_RP_NT_LOADS.
+#ifdef VX355_RP_NT_LOADS
+#define VX355_RP_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define VX355_RP_LOAD(p) (*(p))
+#endif
+typedef unsigned long long RpU64x2 __attribute__((ext_vector_type(2)));
+
 template <int KW>
 __device__ inline int64_t rpLoadKey(const RadixArgs& r, int64_t row) {
   if constexpr (KW == 8) {
-    return static_cast<const int64_t*>(r.a.keys[0].col.values)[row];
+    return VX355_RP_LOAD(static_cast<const int64_t*>(r.a.keys[0].col.values) + row);
   } else if constexpr (KW == 4) {
-    return static_cast<const int32_t*>(r.a.keys[0].col.values)[row];
+    return VX355_RP_LOAD(static_cast<const int32_t*>(r.a.keys[0].col.values) + row);
   } else {
     return 0;
   }
@@ -765,12 +773,12 @@ __device__ inline void rpStore(uint64_t* dst, const uint64_t* w) {
 template <int W>
 __device__ inline void rpLoad(const uint64_t* src, uint64_t* w) {
   if constexpr (W == 2) {
-    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(src);
+    const RpU64x2 v = VX355_RP_LOAD(reinterpret_cast<const RpU64x2*>(src));
     w[0] = v.x;
     w[1] = v.y;
   } else if constexpr (W == 4) {
-    const ulonglong2 v0 = reinterpret_cast<const ulonglong2*>(src)[0];
-    const ulonglong2 v1 = reinterpret_cast<const ulonglong2*>(src)[1];
+    const RpU64x2 v0 = VX355_RP_LOAD(reinterpret_cast<const RpU64x2*>(src));
+    const RpU64x2 v1 = VX355_RP_LOAD(reinterpret_cast<const RpU64x2*>(src) + 1);
     w[0] = v0.x;
     w[1] = v0.y;
     w[2] = v1.x;
@@ -778,7 +786,7 @@ __device__ inline void rpLoad(const uint64_t* src, uint64_t* w) {
   } else {
 #pragma unroll
     for (int i = 0; i < W; ++i) {
-      w[i] = src[i];
+      w[i] = VX355_RP_LOAD(src + i);
     }
   }
 }
@@ -812,7 +820,7 @@ __global__ __launch_bounds__(1024) void k_rp_scatter1(RadixArgs r) {
         if constexpr (FLATV) {
 #pragma unroll
           for (int q = 1; q < W; ++q) {
-            vals[u][q] = row < end ? static_cast<const uint64_t*>(a.accs[r.accOfVal[q - 1]].in.values)[row] : 0;
+            vals[u][q] = row < end ? VX355_RP_LOAD(static_cast<const uint64_t*>(a.accs[r.accOfVal[q - 1]].in.values) + row) : 0;
           }
         }
       }
@@ -994,7 +1002,7 @@ __global__ __launch_bounds__(kSortThreads) void k_rp_scatter1_sorted(RadixArgs r
         if constexpr (FLATV) {
 #pragma unroll
           for (int q = 1; q < V; ++q) {
-            vals[u][q] = row < end ? static_cast<const uint64_t*>(a.accs[r.accOfVal[q - 1]].in.values)[row] : 0;
+            vals[u][q] = row < end ? VX355_RP_LOAD(static_cast<const uint64_t*>(a.accs[r.accOfVal[q - 1]].in.values) + row) : 0;
           }
         }
       }

@@ -403,14 +403,22 @@ __device__ inline void staticFor(F&& f) {
   staticForImpl(typename MakeIntSeq<N>::type{}, f);
 }
 
+// Columns the kernel reads exactly once stream past the caches (nontemporal loads): k_agg_fast on
+// TPC-H Q1 SF100 6.95 -> 6.64 ms on the same box. -DVX355_FAST_CACHED_LOADS restores plain loads.
+#ifdef VX355_FAST_CACHED_LOADS
+#define VX355_FAST_LOAD(p) (*(p))
+#else
+#define VX355_FAST_LOAD(p) __builtin_nontemporal_load(p)
+#endif
+
 template <int KIND>
 __device__ inline uint64_t fastLoadRaw(const void* ptr, int64_t row) {
   if constexpr (KIND == FK_VIEW) {
-    return static_cast<const uint64_t*>(ptr)[row * 2];
+    return VX355_FAST_LOAD(static_cast<const uint64_t*>(ptr) + row * 2);
   } else if constexpr (KIND == FK_I32) {
-    return static_cast<const uint32_t*>(ptr)[row];  // sign-extended at use
+    return VX355_FAST_LOAD(static_cast<const uint32_t*>(ptr) + row);  // sign-extended at use
   } else {
-    return static_cast<const uint64_t*>(ptr)[row];
+    return VX355_FAST_LOAD(static_cast<const uint64_t*>(ptr) + row);
   }
 }
 
