@@ -948,8 +948,8 @@ def measure_traffic(child_flags, kernel, steps=1):
             for path in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
                 with open(path) as f:
                     for row in csv.DictReader(f):
-                        if row["Counter_Name"] == counter and (kernel + "<" in row["Kernel_Name"]
-                                                                or kernel + "(" in row["Kernel_Name"]):
+                        if row["Counter_Name"] == counter and any(k + "<" in row["Kernel_Name"] or k + "(" in row["Kernel_Name"]
+                                                                  for k in kernel.split("|")):
                             kb += float(row["Counter_Value"])
                             dispatches += 1
             if dispatches == 0:
@@ -1235,7 +1235,9 @@ def main():
         dist.destroy_process_group()
     sys.stdout.flush()
     C.CDLL(None).fflush(None)
-    os._exit(0)   # library teardown prints nothing behind the JSON line
+    # Whatever a library prints while the process winds down goes to stderr: the JSON line stays the
+    # last line of stdout. (Not os._exit: a profiler - rocprofv3 - writes its output at normal exit.)
+    os.dup2(2, 1)
 
 
 class GroupDist:
@@ -1272,7 +1274,11 @@ def roofline_block(wl, prof, steps, copy_ceiling, child_flags):
     dom_ms, dom_launches = prof.get(wl.dominant, (0.0, 0))
     dom_rows = getattr(wl, "selected", wl.rows_per_step()) * steps
     achieved = (wl.agg_bytes_per_row * dom_rows / (dom_ms * 1e-3) / 1e9) if dom_ms > 0 else None
-    symbol = {"k_join_probe_list": "k_join_probe", "k_join_probe_part": "k_pp_probe"}.get(wl.dominant, wl.dominant)  # profile label -> kernel symbol
+    symbol = {"k_join_probe_list": "k_join_probe", "k_join_probe_part": "k_pp_probe",
+              "k_pp_scatter": "k_pp_scatter_fast|k_pp_scatter",
+              "k_rp_scatter1": "k_rp_scatter1_sorted|k_rp_scatter1",
+              "k_rp_scatter2": "k_rp_scatter2_opt|k_rp_scatter2_sorted|k_rp_scatter2",
+              "k_rp_aggregate": "k_rp_aggregate_hashed|k_rp_aggregate"}.get(wl.dominant, wl.dominant)  # profile label -> kernel symbol
     pmc = measure_traffic(child_flags, symbol) if child_flags is not None else {}
     if not pmc:
         pmc = pmc_traffic(wl.name, wl.dominant)

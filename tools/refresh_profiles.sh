@@ -17,7 +17,9 @@ except Exception as e:
 PY
 }
 run ${P}_bench_default --steps 20 --warmup 5
-run ${P}_bench_q1_unfused --unfused --no-secondary --no-traffic
+# (hiprtc compiles in the background by default: a bench of 25 short-lived operators would be over before
+# the specialised kernel is ready, so this line waits for it)
+VX355_JIT=sync run ${P}_bench_q1_unfused --unfused --no-secondary --no-traffic
 run ${P}_bench_c1 --workload c1 --no-traffic
 run ${P}_bench_c1_streamed_host_batches --workload c1 --c1-stream --no-traffic
 run ${P}_bench_q3_full_query --workload q3full --no-traffic
