@@ -441,11 +441,12 @@ def test_fused_filter_project_aggregation_q1(oracle, vx, device_resident, long_f
     vx.profile_enable(False)
     names = vx.profile()
     assert_columns_equal(got, exp, op.kinds, what="fused q1")
-    # 6-byte flags blow the key range past the LDS limit: open addressing in HBM.
+    # 6-byte flags: open addressing in HBM behind an LDS fold with a hashed slot map (few groups);
+    # the shape-specialised kernel decodes keys of up to three bytes only.
     if not no_fast and not long_flags:  # host batches are staged flat into HBM first
         assert "k_agg_fast" in names
     else:
-        assert "k_agg_fast" not in names
+        assert "k_agg_fast" not in names and "k_agg_lds" in names
 
 
 def test_c1_device_resident_takes_fast_kernel(oracle, vx):
@@ -676,6 +677,47 @@ def test_nullable_columns_stay_on_the_specialised_kernel(oracle, vx, monkeypatch
     got = vx.collect_output(op, 100)
     vx.profile_enable(False)
     assert_columns_equal(got, exp, op.kinds, what="nullable fast shape")   # dyadic data: exact sums
+    names = vx.profile()
+    assert "k_agg_fast" in names and "k_agg_lds" not in names and op.stats().reserved > 0
+
+
+@pytest.mark.parametrize("nullable", [False, True])
+@pytest.mark.parametrize("plan", ["sums_counts_masks", "integer_sums_min_max"])
+def test_real_and_integer_operands_and_masks_stay_on_the_specialised_kernel(oracle, vx, monkeypatch, nullable, plan):
+    """Low-cardinality plans whose operands are REAL / BIGINT / INTEGER columns (every operand reaches the
+    arithmetic as a double, FastShape::LK) and whose aggregates carry FILTER masks (flat BOOLEAN columns,
+    FastShape::MSK; a false or null mask skips the accumulator for the row): sum(REAL), avg(BIGINT),
+    avg(INTEGER), sum(DOUBLE) FILTER m1, count(*) FILTER m2, count(REAL) - on k_agg_fast, equal to the oracle
+    (dyadic values: sums are exact)."""
+    monkeypatch.setenv("VX355_JIT", "sync")
+    rng = np.random.default_rng(606 + nullable)
+    n = 250_000
+    k = rng.integers(0, 40, n).astype(np.int32)
+    r = (rng.integers(-4096, 4096, n) / 16.0).astype(np.float32)
+    b = rng.integers(-2 ** 31, 2 ** 31, n).astype(np.int64)
+    i = rng.integers(-10 ** 6, 10 ** 6, n).astype(np.int32)
+    d = rng.integers(-1 << 20, 1 << 20, n) / 1024.0
+    m1 = rng.random(n) > 0.4
+    m2 = rng.random(n) > 0.7
+    valids = [None] * 7
+    if nullable:
+        valids = [None, rng.random(n) > 0.05, rng.random(n) > 0.1, None, rng.random(n) > 0.02, rng.random(n) > 0.03, None]
+    host = batch_of([k, r, b, i, d, m1, m2], valids)
+    aggs = [(abi.AGG_SUM, 1, abi.REAL), (abi.AGG_AVG, 2, abi.BIGINT), (abi.AGG_AVG, 3, abi.INTEGER),
+            (abi.AGG_SUM, 4, abi.DOUBLE, 5), (abi.AGG_COUNT_STAR, -1, abi.BIGINT, 6), (abi.AGG_COUNT, 1, abi.REAL),
+            (abi.AGG_SUM, 4, abi.DOUBLE)]
+    if plan == "integer_sums_min_max":
+        # FastShape::OPS: checked BIGINT sums (128-bit totals in LDS), min / max on ordered images
+        # (every (column, mask) pair also owns a count of its non-null rows: five pairs here)
+        aggs = [(abi.AGG_SUM, 2, abi.BIGINT), (abi.AGG_MAX, 2, abi.BIGINT), (abi.AGG_SUM, 3, abi.INTEGER, 5),
+                (abi.AGG_MIN, 3, abi.INTEGER, 5), (abi.AGG_MIN, 4, abi.DOUBLE), (abi.AGG_MAX, 4, abi.DOUBLE),
+                (abi.AGG_MAX, 1, abi.REAL), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    exp, _ = run_agg(oracle, [host], [0], [abi.INTEGER], aggs)
+    vx.profile_reset()
+    vx.profile_enable(True)
+    got, op = run_agg(vx, [vx.to_device(host)], [0], [abi.INTEGER], aggs)
+    vx.profile_enable(False)
+    assert_columns_equal(got, exp, op.kinds, what="REAL / integer operands and masks on the fast shape")
     names = vx.profile()
     assert "k_agg_fast" in names and "k_agg_lds" not in names and op.stats().reserved > 0
 

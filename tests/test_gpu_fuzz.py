@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from velox_amd import abi
-from gpu_util import assert_columns_equal, run_agg
+from gpu_util import assert_columns_equal, batch_of, run_agg
 
 pytestmark = pytest.mark.gpu
 
@@ -183,6 +183,91 @@ def test_random_aggregation_plans(oracle, vx, seed, monkeypatch):
         merged, mop = run_agg(vx, [as_batch(parts)], key_cols, key_types, fin_aggs, step=abi.STEP_FINAL,
                               max_rows=100000, **kw)
         assert_columns_equal(merged, exp, mop.kinds, what=f"seed {seed}: partial -> final")
+
+
+def test_low_cardinality_plans_with_nulls_report_their_kernel(oracle, vx, monkeypatch, capsys):
+    """Which kernel do low-cardinality plans over flat, nullable columns take? 32 random plans: one or two
+    keys (INTEGER / BIGINT / strings of <= 3 bytes, nullable), two to four aggregates from sum / avg / min /
+    max / count over DOUBLE / REAL / BIGINT / INTEGER operands (nullable), count(*), FILTER masks, sometimes
+    a fused filter term; every result equals the oracle's, and the census of kernels is printed. At least
+    90 % of them must run on the shape-specialised kernel (k_agg_fast), not on the interpreting one."""
+    monkeypatch.setenv("VX355_JIT", "sync")
+    monkeypatch.setenv("VX355_AGG_COALESCE_ROWS", "0")
+    census = {}
+    slow = []
+    plans = 32
+    for seed in range(plans):
+        rng = np.random.default_rng(7000 + seed)
+        n = 60_000
+        num_keys = int(rng.integers(1, 3))
+        key_types = [int(rng.choice([abi.INTEGER, abi.BIGINT, abi.VARCHAR])) for _ in range(num_keys)]
+        val_types = [int(rng.choice([abi.DOUBLE, abi.REAL, abi.BIGINT, abi.INTEGER])) for _ in range(int(rng.integers(1, 4)))]
+        cols, valids, kinds = [], [], []
+        for kt in key_types:
+            card = int(rng.choice([3, 12, 40]))
+            if kt == abi.VARCHAR:
+                words = [b"A", b"NO", b"RET", b"", b"F", b"O"][:max(2, card % 7)]
+                cols.append([words[i] for i in rng.integers(0, len(words), n)])
+            else:
+                cols.append((rng.integers(0, card, n) * 3 - 7).astype(np.int32 if kt == abi.INTEGER else np.int64))
+            valids.append(rng.random(n) > 0.03 if rng.random() < 0.5 else None)
+            kinds.append(kt)
+        for vt in val_types:
+            cols.append(_values(rng, vt, n, 200))
+            valids.append(rng.random(n) > float(rng.choice([0.01, 0.2])) if rng.random() < 0.7 else None)
+            kinds.append(vt)
+        mask_cols = []
+        for _ in range(int(rng.integers(0, 3))):
+            mask_cols.append(len(cols))
+            cols.append(rng.random(n) > 0.5)
+            valids.append(rng.random(n) > 0.1 if rng.random() < 0.5 else None)
+            kinds.append(abi.BOOLEAN)
+        aggs = []
+        for _ in range(int(rng.integers(2, 5))):
+            v = int(rng.integers(0, len(val_types)))
+            fn = int(rng.choice([abi.AGG_SUM, abi.AGG_AVG, abi.AGG_MIN, abi.AGG_MAX, abi.AGG_COUNT, abi.AGG_COUNT_STAR]))
+            col = -1 if fn == abi.AGG_COUNT_STAR else num_keys + v
+            typ = abi.BIGINT if fn == abi.AGG_COUNT_STAR else val_types[v]
+            mask = int(rng.choice(mask_cols)) if (mask_cols and rng.random() < 0.4) else -1
+            aggs.append((fn, col, typ, mask))
+        fused = rng.random() < 0.4
+        kw = dict(ignore_null_keys=bool(rng.random() < 0.3))
+        key_cols = list(range(num_keys))
+        if fused:
+            f = rng.integers(0, 100, n).astype(np.int32)
+            fvalid = rng.random(n) > 0.02
+            cut = int(rng.integers(10, 90))
+            keep = np.flatnonzero((f <= cut) & fvalid)
+
+            def take(c):
+                return [c[i] for i in keep] if isinstance(c, list) else np.asarray(c)[keep]
+            ref = batch_of([take(c) for c in cols], [None if v is None else v[keep] for v in valids])
+            exp, _ = run_agg(oracle, [ref], key_cols, key_types, aggs, max_rows=100000, **kw)
+            host = batch_of(cols + [f], valids + [fvalid])
+        else:
+            host = batch_of(cols, valids)
+            exp, _ = run_agg(oracle, [host], key_cols, key_types, aggs, max_rows=100000, **kw)
+        op = vx.Aggregation(key_cols, key_types, aggs, abi.STEP_SINGLE, **kw)
+        if fused:
+            op.set_fused_input([(len(cols), abi.CMP_LE, cut)], [])
+        vx.profile_reset()
+        vx.profile_enable(True)
+        op.add_input(vx.to_device(host))
+        op.no_more_input()
+        got = vx.collect_output(op, 100000)
+        vx.profile_enable(False)
+        assert_columns_equal(got, exp, op.kinds, what=f"census plan {seed}: keys {key_types} aggs {aggs}")
+        names = vx.profile()
+        took = "k_agg_fast" if ("k_agg_fast" in names and "k_agg_lds" not in names) else \
+            ("k_agg_lds" if "k_agg_lds" in names else "+".join(sorted(k for k in names if k.startswith("k_agg"))))
+        census[took] = census.get(took, 0) + 1
+        if took != "k_agg_fast":
+            slow.append((seed, key_types, val_types, aggs, fused))
+    with capsys.disabled():
+        print("\nkernel census of %d low-cardinality plans with nulls / masks: %s" % (plans, census))
+        for item in slow:
+            print("  not on the specialised kernel: seed %d keys %s operands %s aggs %s fused %s" % item)
+    assert census.get("k_agg_fast", 0) >= 0.9 * plans, census
 
 
 LONG_WORDS = WORDS + [b"thirteen bytes", b"a string well beyond the inline limit of a view", b"a string well beyond the inline limit",

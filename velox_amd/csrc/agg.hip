@@ -178,37 +178,6 @@ __device__ inline bool accInput(const AggArgs& a, const AccArg& acc, int64_t row
 
 
 
-// hiStride: distance (in words) from an ACC_SUM_I64 word to its high word in this LDS layout.
-__device__ inline void applyLds(uint64_t* word, int32_t kind, uint64_t v, Counters* ctr, int hiStride = 1) {
-  switch (kind) {
-    case ACC_SUM_F64:
-      unsafeAtomicAdd(reinterpret_cast<double*>(word), __longlong_as_double(static_cast<long long>(v)));
-      break;
-    case ACC_SUM_I64: {
-      const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(word),
-                                               static_cast<unsigned long long>(v));
-      const int64_t up = carrySigned(old, static_cast<int64_t>(v));
-      if (up != 0) {
-        atomicAdd(reinterpret_cast<unsigned long long*>(word + hiStride), static_cast<unsigned long long>(up));
-      }
-      break;
-    }
-    case ACC_SUM_I64_HI:
-    case ACC_SUM_I64_WRAP:
-    case ACC_COUNT:
-      atomicAdd(reinterpret_cast<unsigned long long*>(word), static_cast<unsigned long long>(v));
-      break;
-    case ACC_MIN:
-      atomicMin(reinterpret_cast<unsigned long long*>(word), static_cast<unsigned long long>(v));
-      break;
-    default:
-      atomicMax(reinterpret_cast<unsigned long long*>(word), static_cast<unsigned long long>(v));
-      break;
-  }
-}
-
-
-
 // Normalized key of one input row (VectorHasher::computeValueIds semantics).
 // Returns 0 = key ready, 1 = row dropped (null key with ignoreNullKeys),
 // 2 = some value lies outside the current ranges (statistics updated).
@@ -268,31 +237,6 @@ __device__ inline void deferRow(const AggArgs& a, bool defer, int32_t row) {
   if (defer && base + lanePrefix(m) < a.deferCap) {
     a.deferred[base + lanePrefix(m)] = row;
   }
-}
-
-// Group row for a key in the open-addressing table: linear probing from
-// twang_mix64(key) (HashTable.cpp:442-444 mixNormalizedKey); the key word is
-// claimed with one CAS and never changes afterwards, so stale reads are safe.
-__device__ inline uint64_t* findOrInsert(uint64_t* table, int32_t stride, uint64_t capacity,
-                                         uint64_t key, Counters* ctr) {
-  const uint64_t mask = capacity - 1;
-  uint64_t pos = twangMix64(key) & mask;
-  for (uint64_t probes = 0; probes <= mask; ++probes) {
-    uint64_t* row = table + pos * stride;
-    uint64_t k = __hip_atomic_load(row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (k == key) {
-      return row;
-    }
-    if (k == kEmpty) {
-      unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(row), kEmpty, key);
-      if (old == kEmpty || old == key) {
-        return row;
-      }
-    }
-    pos = (pos + 1) & mask;
-  }
-  ctr->tableFull = 1;
-  return nullptr;
 }
 
 __device__ inline uint64_t* groupRow(const AggArgs& a, uint64_t key) {
@@ -572,10 +516,13 @@ struct FastSignature {
   uint64_t accLo = 0, accHi = 0, accEx = 0;   // 16 bits per accumulator: 0-3, 4-7, 8-11
   uint32_t ind = 0;  // dictionary-wrapped columns (FastShape::IND)
   uint32_t nul = 0;  // columns with a null bitmap (FastShape::NUL)
+  uint32_t lk = 0;   // element types of the loaded columns (FastShape::LK)
+  uint32_t msk = 0;  // accumulators with a mask column (FastShape::MSK)
+  uint64_t ops = 0;  // what each accumulator does with its operand (FastShape::OPS)
   bool operator==(const FastSignature& o) const {
     return k0 == o.k0 && k1 == o.k1 && t0 == o.t0 && t1 == o.t1 && numLoads == o.numLoads &&
         numAccs == o.numAccs && accLo == o.accLo && accHi == o.accHi && accEx == o.accEx && ind == o.ind &&
-        nul == o.nul;
+        nul == o.nul && lk == o.lk && msk == o.msk && ops == o.ops;
   }
 };
 
@@ -2553,6 +2500,51 @@ struct StatsArgs {
   Counters* counters;
 };
 
+// Distinct normalized keys among 'a.numRows' rows taken every 'step' rows of the batch (one
+// workgroup, an LDS hash set of 8192 entries): out[0] = the count, saturating near 4096.
+constexpr int kCardSetSize = 8192;
+__global__ __launch_bounds__(1024) void k_card_sample(AggArgs a, int64_t step, uint32_t* out) {
+  __shared__ uint32_t set[kCardSetSize];
+  __shared__ uint32_t count;
+  for (int i = threadIdx.x; i < kCardSetSize; i += blockDim.x) {
+    set[i] = 0xffffffffu;
+  }
+  if (threadIdx.x == 0) {
+    count = 0;
+  }
+  blockSync();
+  for (int64_t i = threadIdx.x; i < a.numRows; i += blockDim.x) {
+    uint64_t key;
+    if (count >= kCardSetSize / 2 || normalizedKey(a, i * step, &key) != 0) {
+      continue;  // (dropped row, or a key outside the ranges the first statistics pass found)
+    }
+    // (open-addressing tables: 64-bit keys; 32 mixed bits tell them apart well enough for an estimate)
+    const uint32_t k32 = static_cast<uint32_t>(twangMix64(key) >> 7) & 0x7fffffffu;
+    uint32_t pos = static_cast<uint32_t>((key * 0x9E3779B97F4A7C15ULL) >> 40) & (kCardSetSize - 1);
+    for (int probes = 0; probes < 64; ++probes) {
+      const uint32_t seen = set[pos];
+      if (seen == k32) {
+        break;
+      }
+      if (seen == 0xffffffffu) {
+        const uint32_t old = atomicCAS(&set[pos], 0xffffffffu, k32);
+        if (old == 0xffffffffu) {
+          atomicAdd(&count, 1u);
+          break;
+        }
+        if (old == k32) {
+          break;
+        }
+      }
+      pos = (pos + 1) & (kCardSetSize - 1);
+    }
+  }
+  blockSync();
+  if (threadIdx.x == 0) {
+    out[0] = count;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_key_stats(StatsArgs a) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   int64_t mn[kMaxKeys], mx[kMaxKeys];
@@ -3243,6 +3235,11 @@ struct vx355_agg {
   bool jitAsync = true;    // VX355_JIT=sync (or 1): a new plan shape waits ~0.8 s for hiprtc instead
   bool exactSums = true;
   bool sumGridsChosen = false;
+  // Direct-index tables beyond the LDS path's one-entry-per-key map (capacity > 8192): how many
+  // distinct keys a strided sample of the first batch holds (sampleCardinality). Few -> the LDS
+  // kernels run with a hashed key -> slot map instead of handing every row to HBM atomics.
+  bool cardSampled = false;
+  int64_t sampledGroups = -1;
   bool logShapes = false;
   int64_t deferCap = 1 << 20;
   int fastUnroll = 4;
@@ -3687,12 +3684,46 @@ void rebuildTable(vx355_agg& h, uint64_t extraGroups) {
 
 // Picks the LDS layout for a launch. Returns false when the group range is too
 // large for the LDS path.
+constexpr int64_t kLdsHashedMaxGroups = 1024;
+
 bool chooseLds(const vx355_agg& h, int numAccs, LdsPlan* plan, size_t* ldsBytes) {
-  if (h.mode != MODE_ARRAY || h.capacity > 8192 || numAccs == 0) {
+  if ((h.mode != MODE_ARRAY && h.mode != MODE_NORMALIZED) || numAccs == 0) {
     return false;
   }
   const size_t budget = 60 * 1024;
   const size_t accBytes = static_cast<size_t>(numAccs) * 8;
+  if (h.mode == MODE_NORMALIZED || h.capacity > 8192) {
+    // Too many possible keys for a map entry each (or an open-addressing table). Few of them
+    // occurring (sampled on the first batch, then counted): a hashed map over the keys that occur,
+    // slots = twice the groups, the slots keep the full normalized key.
+    const int64_t groups = std::max<int64_t>(h.numGroups, h.sampledGroups);
+    if (h.sampledGroups < 0 || groups > kLdsHashedMaxGroups) {
+      return false;
+    }
+    const uint64_t S = nextPow2(std::max<uint64_t>(16, 2 * static_cast<uint64_t>(groups)));
+    const uint64_t M = 4 * S;
+    auto bytes = [&](int rep) {
+      return (((M + 2 * S + 2) * 4 + 15) & ~static_cast<size_t>(15)) + S * 8 + S * accBytes * rep;
+    };
+    int rep = 0;
+    for (int r = 64; r >= 1; r >>= 1) {
+      if (bytes(r) <= budget) {
+        rep = r;
+        break;
+      }
+    }
+    if (rep == 0) {
+      return false;
+    }
+    plan->direct = 2;
+    plan->mapWords = static_cast<int32_t>(M);
+    plan->S = static_cast<int32_t>(S);
+    plan->REP = rep;
+    plan->A = numAccs;
+    plan->capacity = h.capacity;
+    *ldsBytes = bytes(rep);
+    return true;
+  }
   const uint64_t R = h.capacity;
   auto bytesFor = [&](uint64_t S, int rep, bool direct) {
     size_t words = (direct ? 0 : R) + 2 * S + 2;
@@ -3780,6 +3811,11 @@ bool buildFastArgs(const AggArgs& c, const LdsPlan& plan, FastArgs* f, FastSigna
     }
     int kind;
     if (isString(v.kind)) {
+      // the kernel decodes strings of up to three bytes (fastKeyValue); a range that reaches
+      // beyond them means longer keys occur: every such row would only be deferred and replayed
+      if (c.keys[k].range.max >= (1LL << 25)) {
+        return false;
+      }
       kind = FK_VIEW;
     } else if (v.kind == VX355_INTEGER) {
       kind = FK_I32;
@@ -3824,8 +3860,23 @@ bool buildFastArgs(const AggArgs& c, const LdsPlan& plan, FastArgs* f, FastSigna
     f->term[t].f64 = ta.f64;
   }
   auto loadSlot = [&](const ColView& v) -> int {
-    if (v.kind != VX355_DOUBLE) {
-      return -1;
+    // operands reach the arithmetic as doubles (loadDouble): DOUBLE, REAL, BIGINT, INTEGER
+    uint32_t lk;
+    switch (v.kind) {
+      case VX355_DOUBLE:
+        lk = FL_F64;
+        break;
+      case VX355_REAL:
+        lk = FL_F32;
+        break;
+      case VX355_BIGINT:
+        lk = FL_I64;
+        break;
+      case VX355_INTEGER:
+        lk = FL_I32;
+        break;
+      default:
+        return -1;
     }
     const int wrapped = usable(v);
     if (wrapped < 0) {
@@ -3839,7 +3890,8 @@ bool buildFastArgs(const AggArgs& c, const LdsPlan& plan, FastArgs* f, FastSigna
     if (sig->numLoads == kFastLoads) {
       return -1;
     }
-    f->loadPtr[sig->numLoads] = static_cast<const double*>(v.values);
+    f->loadPtr[sig->numLoads] = v.values;
+    sig->lk |= lk << (2 * sig->numLoads);
     sig->ind |= static_cast<uint32_t>(wrapped) << (4 + sig->numLoads);
     if (v.nulls) {
       sig->nul |= 1u << (4 + sig->numLoads);
@@ -3850,7 +3902,13 @@ bool buildFastArgs(const AggArgs& c, const LdsPlan& plan, FastArgs* f, FastSigna
   for (int j = 0; j < c.numAccs; ++j) {
     const AccArg& ac = c.accs[j];
     if (ac.hasMask) {
-      return false;
+      // one flat BOOLEAN column per masked accumulator
+      if (ac.mask.enc != VX355_FLAT || ac.mask.kind != VX355_BOOLEAN) {
+        return false;
+      }
+      sig->msk |= 1u << j;
+      f->maskBits[j] = static_cast<const uint64_t*>(ac.mask.values);
+      f->maskNulls[j] = ac.mask.nulls;
     }
     uint64_t desc;
     if (ac.kind == ACC_COUNT && !ac.hasIn && ac.inProj < 0) {
@@ -3878,6 +3936,33 @@ bool buildFastArgs(const AggArgs& c, const LdsPlan& plan, FastArgs* f, FastSigna
         }
       }
       desc = accDesc(0, l[0], l[1], l[2]);
+    } else if (ac.kind == ACC_SUM_I64 || ac.kind == ACC_MIN || ac.kind == ACC_MAX) {
+      // one unscaled operand: checked BIGINT sum of an integer column; min / max on the
+      // order-preserving image of an integer (inIsInt) or floating column
+      if (!ac.hasIn || ac.inProj >= 0) {
+        return false;
+      }
+      const bool intCol = ac.in.kind == VX355_BIGINT || ac.in.kind == VX355_INTEGER;
+      const bool floatCol = ac.in.kind == VX355_DOUBLE || ac.in.kind == VX355_REAL;
+      uint64_t op;
+      if (ac.kind == ACC_SUM_I64) {
+        if (!intCol) {
+          return false;
+        }
+        op = FO_SUM_I64;
+      } else if (ac.inIsInt ? !intCol : !floatCol) {
+        return false;
+      } else {
+        op = ac.kind == ACC_MIN ? (ac.inIsInt ? FO_MIN_I : FO_MIN_F) : (ac.inIsInt ? FO_MAX_I : FO_MAX_F);
+      }
+      const int slot = loadSlot(ac.in);
+      if (slot < 0) {
+        return false;
+      }
+      f->scale[j][0] = 1.0;
+      f->offset[j][0] = 0.0;
+      desc = accDesc(1, slot);
+      sig->ops |= op << (4 * j);
     } else if (ac.kind != ACC_SUM_F64) {
       return false;
     } else if (ac.inProj >= 0) {
@@ -4022,9 +4107,10 @@ hipFunction_t jitFastKernel(const FastSignature& sig, int unroll, bool log, bool
     return nullptr;
   }
   char key[256];
-  snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d,%lluull,%lluull,%uu,%uu,%lluull", unroll, sig.k0, sig.k1, sig.t0,
-           sig.t1, sig.numLoads, sig.numAccs, static_cast<unsigned long long>(sig.accLo),
-           static_cast<unsigned long long>(sig.accHi), sig.ind, sig.nul, static_cast<unsigned long long>(sig.accEx));
+  snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d,%lluull,%lluull,%uu,%uu,%lluull,%uu,%uu,%lluull", unroll, sig.k0,
+           sig.k1, sig.t0, sig.t1, sig.numLoads, sig.numAccs, static_cast<unsigned long long>(sig.accLo),
+           static_cast<unsigned long long>(sig.accHi), sig.ind, sig.nul, static_cast<unsigned long long>(sig.accEx),
+           sig.lk, sig.msk, static_cast<unsigned long long>(sig.ops));
   // A loaded module belongs to one GPU.
   const std::string cacheKey = std::to_string(Runtime::get().device) + ":" + key;
   auto it = st.kernels.find(cacheKey);
@@ -4754,6 +4840,7 @@ void launchChunk(vx355_agg& h, AggArgs& a) {
     plan.stride = a.stride;
     plan.rowBase = a.rowBase;
     plan.counters = a.counters;
+    plan.tableMode = a.mode;
     FastArgs fa;
     FastSignature sig;
     const bool fastClass = !h.disableFast && buildFastArgs(a, plan, &fa, &sig);
@@ -4982,6 +5069,31 @@ void runGeneric(vx355_agg& h, const AggArgs& base, int64_t count, uint64_t rowBa
   h.numGroups = ids;
 }
 
+// How many distinct keys does the batch hold? 16384 rows spread evenly over it (sorted inputs must
+// not fool the answer) into an LDS hash set; the count decides whether the LDS kernels take a
+// wide-range table (chooseLds) or the radix / atomics paths do.
+void sampleCardinality(vx355_agg& h, const AggArgs& a, int64_t n) {
+  h.cardSampled = true;
+  AggArgs c = a;
+  c.numRows = std::min<int64_t>(n, 1 << 14);
+  c.rowList = nullptr;
+  c.rescanOld = nullptr;
+  c.table = h.table.as<uint64_t>();
+  c.capacity = h.capacity;
+  c.mode = h.mode;
+  for (int k = 0; k < c.numKeys; ++k) {
+    c.keys[k].range = h.keys[k].range;
+  }
+  const int64_t step = std::max<int64_t>(1, n / c.numRows);
+  resetCounters(h);
+  uint32_t* out = reinterpret_cast<uint32_t*>(h.denseFlags.ensure(64));
+  VX_LAUNCH("k_card_sample", k_card_sample, 1, 1024, 0, c, step, out);
+  uint32_t found = 0;
+  copyOut(&found, VX355_MEM_HOST, out, 4);
+  resetCounters(h);   // rows outside the sampled ranges touched the statistics
+  h.sampledGroups = found;
+}
+
 // Rows [from, n) of the batch 'a' describes, in chunks.
 void addInputGeneric(vx355_agg& h, AggArgs& a, int64_t n, int64_t from = 0) {
   h.mode = MODE_HASH;
@@ -5193,6 +5305,10 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
     }
   }
 
+  if (!h.cardSampled && ((h.mode == MODE_ARRAY && h.capacity > 8192) || h.mode == MODE_NORMALIZED) &&
+      h.numGroups == 0 && n > 0 && !a.rowList) {
+    sampleCardinality(h, a, n);
+  }
   int64_t rows = 0;
   for (int64_t begin = 0; begin < n; begin += rows) {
     // The first chunk of a stream is kept small: what it finds (number of live
@@ -5200,7 +5316,8 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
     // (A direct-index table beyond the LDS path's 8192 groups has no layout to pick.)
     const bool wideArray = h.mode == MODE_ARRAY && h.capacity > 8192;
     // (nor has an open-addressing table in front of a large batch: the dense folds need no table)
-    const bool denseChunk = radixDenseEligible(h, a, n - begin);
+    const bool fewGroups = h.sampledGroups >= 0 && std::max<int64_t>(h.numGroups, h.sampledGroups) <= kLdsHashedMaxGroups;
+    const bool denseChunk = !fewGroups && radixDenseEligible(h, a, n - begin);   // few groups: the LDS kernels
     rows = std::min((h.numGroups == 0 && !wideArray) ? std::min<int64_t>(h.chunkRows, 1 << 20) : h.chunkRows,
                     n - begin);
     if (denseChunk) {

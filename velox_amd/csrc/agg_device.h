@@ -130,6 +130,31 @@ constexpr int32_t kSlotEmpty = -1;
 constexpr int32_t kSlotPending = -2;
 constexpr int32_t kSlotOverflow = -3;
 
+// Group row for a key in the open-addressing table: linear probing from
+// twang_mix64(key) (HashTable.cpp:442-444 mixNormalizedKey); the key word is
+// claimed with one CAS and never changes afterwards, so stale reads are safe.
+__device__ inline uint64_t* findOrInsert(uint64_t* table, int32_t stride, uint64_t capacity,
+                                         uint64_t key, Counters* ctr) {
+  const uint64_t mask = capacity - 1;
+  uint64_t pos = twangMix64(key) & mask;
+  for (uint64_t probes = 0; probes <= mask; ++probes) {
+    uint64_t* row = table + pos * stride;
+    uint64_t k = __hip_atomic_load(row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == key) {
+      return row;
+    }
+    if (k == kEmpty) {
+      unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(row), kEmpty, key);
+      if (old == kEmpty || old == key) {
+        return row;
+      }
+    }
+    pos = (pos + 1) & mask;
+  }
+  ctr->tableFull = 1;
+  return nullptr;
+}
+
 // What both LDS kernels need to know about the accumulators and the table.
 struct LdsPlan {
   int32_t S;
@@ -139,6 +164,8 @@ struct LdsPlan {
   uint64_t capacity;
   uint64_t* table;
   int32_t stride;
+  int32_t mapWords;   // direct == 2: entries of the hashed key -> slot map (a power of two)
+  int32_t tableMode;  // MODE_ARRAY: group row = table + key * stride; MODE_NORMALIZED: findOrInsert(key)
   int32_t pad;
   uint64_t rowBase;
   Counters* counters;
@@ -151,18 +178,30 @@ struct LdsState {
   uint32_t* slotKey;
   uint32_t* slotFirst;
   uint32_t* numSlots;
+  uint64_t* slotKey64;   // direct == 2: the slots' full normalized keys
   uint64_t* acc;
 };
 
+// The group row of a normalized key in the operator's table.
+__device__ inline uint64_t* ldsGroupRow(const LdsPlan& p, uint64_t key) {
+  if (p.tableMode == MODE_NORMALIZED) {
+    return findOrInsert(p.table, p.stride, p.capacity, key, p.counters);
+  }
+  return p.table + key * p.stride;
+}
+
 __device__ inline LdsState ldsInit(const LdsPlan& p, unsigned char* raw) {
   LdsState st;
-  const int mapWords = p.direct ? 0 : static_cast<int>(p.capacity);
+  // key -> slot map: none (direct == 1: slot = key), one entry per possible key (0), or an open-
+  // addressing table over the keys that occur (2: key ranges too wide for an entry per key)
+  const int mapWords = p.direct == 1 ? 0 : (p.direct == 2 ? p.mapWords : static_cast<int>(p.capacity));
   st.slotOf = reinterpret_cast<int32_t*>(raw);
   st.slotKey = reinterpret_cast<uint32_t*>(raw) + mapWords;
   st.slotFirst = st.slotKey + p.S;
   st.numSlots = st.slotFirst + p.S;
-  st.acc = reinterpret_cast<uint64_t*>(
+  st.slotKey64 = reinterpret_cast<uint64_t*>(
       raw + ((static_cast<size_t>(mapWords + 2 * p.S + 2) * 4 + 15) & ~static_cast<size_t>(15)));
+  st.acc = st.slotKey64 + (p.direct == 2 ? p.S : 0);
   for (int i = threadIdx.x; i < mapWords; i += blockDim.x) {
     st.slotOf[i] = kSlotEmpty;
   }
@@ -171,7 +210,7 @@ __device__ inline LdsState ldsInit(const LdsPlan& p, unsigned char* raw) {
     st.slotKey[i] = static_cast<uint32_t>(i);
   }
   if (threadIdx.x == 0) {
-    *st.numSlots = p.direct ? static_cast<uint32_t>(p.S) : 0;
+    *st.numSlots = p.direct == 1 ? static_cast<uint32_t>(p.S) : 0;
   }
   for (int i = threadIdx.x; i < p.S * p.A * p.REP; i += blockDim.x) {
     st.acc[i] = accIdentity(p.kind[(i / p.REP) % p.A]);
@@ -182,8 +221,40 @@ __device__ inline LdsState ldsInit(const LdsPlan& p, unsigned char* raw) {
 
 // LDS slot of a key (>= 0) or kSlotOverflow when the workgroup's slots are used up.
 __device__ inline int32_t ldsSlot(const LdsPlan& p, const LdsState& st, uint64_t key) {
-  if (p.direct) {
+  if (p.direct == 1) {
     return static_cast<int32_t>(key);
+  }
+  if (p.direct == 2) {
+    // Few groups spread over a wide key range (keys of two or three characters, sparse integer
+    // codes): the map is a hash table of slot numbers, the slot's key (slotKey) confirms a hit.
+    // Same claim protocol as below; an entry holding another key sends the lane to the next one.
+    const uint32_t mask = static_cast<uint32_t>(p.mapWords) - 1;
+    uint32_t pos = static_cast<uint32_t>((key * 0x9E3779B97F4A7C15ULL) >> 40) & mask;
+    uint32_t probes = 0;
+    int32_t slot = kSlotPending;
+    while (slot == kSlotPending) {
+      int32_t* entry = st.slotOf + pos;
+      int32_t s = __hip_atomic_load(entry, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (s == kSlotEmpty) {
+        if (atomicCAS(entry, kSlotEmpty, kSlotPending) == kSlotEmpty) {
+          uint32_t t = atomicAdd(st.numSlots, 1u);
+          if (t < static_cast<uint32_t>(p.S)) {
+            st.slotKey64[t] = key;
+            s = static_cast<int32_t>(t);
+          } else {
+            s = kSlotOverflow;
+          }
+          __hip_atomic_store(entry, s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+          s = kSlotPending;
+        }
+      } else if (s >= 0 && st.slotKey64[s] != key) {
+        pos = (pos + 1) & mask;
+        s = ++probes > mask ? kSlotOverflow : kSlotPending;
+      }
+      slot = s;
+    }
+    return slot;
   }
   // Claim protocol without waiting on an exit edge: the winner of the CAS
   // allocates and publishes the slot INSIDE the loop body, every lane
@@ -234,7 +305,10 @@ __device__ inline void ldsFlush(const LdsPlan& p, const LdsState& st) {
     if (first == 0xffffffffu) {
       continue;  // direct layout: key never seen by this workgroup
     }
-    uint64_t* g = p.table + static_cast<uint64_t>(st.slotKey[slot]) * p.stride;
+    uint64_t* g = ldsGroupRow(p, p.direct == 2 ? st.slotKey64[slot] : static_cast<uint64_t>(st.slotKey[slot]));
+    if (g == nullptr) {
+      continue;  // table full: flagged in the counters
+    }
     if (j == A) {
       // 'first' is the smallest ORIGINAL row of the chunk seen for this key
       // (replays go through the row list), so it decides the group order.
@@ -284,6 +358,38 @@ __device__ inline void ldsFlush(const LdsPlan& p, const LdsState& st) {
   }
 }
 
+// hiStride: distance (in words) from an ACC_SUM_I64 word to its high word in this LDS layout.
+__device__ inline void applyLds(uint64_t* word, int32_t kind, uint64_t v, Counters* ctr, int hiStride = 1) {
+  switch (kind) {
+    case ACC_SUM_F64:
+      unsafeAtomicAdd(reinterpret_cast<double*>(word), __longlong_as_double(static_cast<long long>(v)));
+      break;
+    case ACC_SUM_I64: {
+      const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(word),
+                                               static_cast<unsigned long long>(v));
+      const int64_t up = carrySigned(old, static_cast<int64_t>(v));
+      if (up != 0) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(word + hiStride), static_cast<unsigned long long>(up));
+      }
+      break;
+    }
+    case ACC_SUM_I64_HI:
+    case ACC_SUM_I64_WRAP:
+    case ACC_COUNT:
+      atomicAdd(reinterpret_cast<unsigned long long*>(word), static_cast<unsigned long long>(v));
+      break;
+    case ACC_MIN:
+      atomicMin(reinterpret_cast<unsigned long long*>(word), static_cast<unsigned long long>(v));
+      break;
+    default:
+      atomicMax(reinterpret_cast<unsigned long long*>(word), static_cast<unsigned long long>(v));
+      break;
+  }
+}
+
+
+
+
 // ---- shape-specialised LDS kernel ------------------------------------------------
 // The generic LDS kernel interprets the plan per row (column encodings, types,
 // masks, expression tables): ~500 VALU instructions per 64 rows, which caps it
@@ -317,7 +423,7 @@ struct FastTerm {
 struct FastArgs {
   const void* keyPtr[kFastKeys];
   KeyRange range[kFastKeys];
-  const double* loadPtr[kFastLoads];
+  const void* loadPtr[kFastLoads];   // element type per the shape's LK mask
   FastTerm term[kFastTerms];
   double scale[kFastAccs][kFastFactors];
   double offset[kFastAccs][kFastFactors];
@@ -339,10 +445,22 @@ struct FastArgs {
   const uint64_t* keyNulls[kFastKeys];
   const uint64_t* termNulls[kFastTerms];
   const uint64_t* loadNulls[kFastLoads];
+  // AggregationMasks of the accumulators flagged in the shape's MSK mask: flat BOOLEAN columns
+  // (bit-packed values + optional null bitmap); a false or null mask skips the accumulator for the row.
+  const uint64_t* maskBits[kFastAccs];
+  const uint64_t* maskNulls[kFastAccs];
   int32_t ignoreNullKeys;
   int32_t pad2;
   LdsPlan plan;
 };
+
+// Element types of the loaded operand columns (FastShape::LK, two bits per load): every operand
+// reaches the arithmetic as a double, as loadDouble() hands it to the interpreting kernel.
+enum FastLoadKind : int32_t { FL_F64 = 0, FL_F32 = 1, FL_I64 = 2, FL_I32 = 3 };
+// FastShape::OPS. FO_DEFAULT: count (no factors) or DOUBLE sum of the product of the factors; the
+// others take ONE unscaled operand: checked BIGINT sum of an integer column (128-bit total), min /
+// max on the order-preserving image of a floating or of an integer column.
+enum FastOp : int32_t { FO_DEFAULT = 0, FO_SUM_I64 = 1, FO_MIN_F = 2, FO_MAX_F = 3, FO_MIN_I = 4, FO_MAX_I = 5 };
 
 constexpr uint64_t accDesc(int numFactors, int l0 = 15, int l1 = 15, int l2 = 15) {
   return static_cast<uint64_t>(numFactors) | (static_cast<uint64_t>(l0) << 4) |
@@ -353,8 +471,14 @@ constexpr uint64_t packAccs(uint64_t a0 = 0, uint64_t a1 = 0, uint64_t a2 = 0, u
 }
 
 template <int UNROLL, int K0, int K1, int T0, int T1, int NL, int NA, uint64_t ACC_LO, uint64_t ACC_HI,
-          uint32_t IND = 0, uint32_t NUL = 0, uint64_t ACC_EX = 0>
+          uint32_t IND = 0, uint32_t NUL = 0, uint64_t ACC_EX = 0, uint32_t LK = 0, uint32_t MSK = 0, uint64_t OPS = 0>
 struct FastShape {
+  static constexpr int loadKind(int j) { return static_cast<int>((LK >> (2 * j)) & 3); }
+  static constexpr bool masked(int j) { return (MSK >> j) & 1; }
+  // OPS, four bits per accumulator: what is done with its (single, unscaled) operand - FastOp.
+  static constexpr int op(int j) { return static_cast<int>((OPS >> (4 * j)) & 15); }
+  static constexpr bool intLoad(int j) { return loadKind(j) == 2 || loadKind(j) == 3; }
+  static constexpr bool anyIntLoad = (LK & 0xaaaau) != 0;
   // IND bit k: key k, bit 2 + t: filter term t, bit 4 + j: loaded column j is dictionary wrapped.
   static constexpr bool indirect(int bit) { return (IND >> bit) & 1; }
   static constexpr bool anyIndirect = IND != 0;
@@ -369,11 +493,12 @@ struct FastShape {
     return ((j < 4 ? ACC_LO >> (16 * j) : (j < 8 ? ACC_HI >> (16 * (j - 4)) : ACC_EX >> (16 * (j - 8))))) & 0xffff;
   }
   static constexpr int numFactors(int j) { return static_cast<int>(desc(j) & 15); }
-  // LDS / table word of accumulator j: every DOUBLE sum before it owns two words (hi, lo).
+  // LDS / table word of accumulator j: every DOUBLE sum (hi, lo) and every BIGINT sum (low, carry)
+  // before it owns two words, counts / min / max one.
   static constexpr int ldsIndex(int j) {
     int idx = 0;
     for (int q = 0; q < j; ++q) {
-      idx += numFactors(q) == 0 ? 1 : 2;
+      idx += (numFactors(q) == 0 || op(q) >= 2) ? 1 : 2;
     }
     return idx;
   }
@@ -457,6 +582,7 @@ __device__ inline void aggFastBody(const FastArgs& a) {
     uint64_t kraw[UNROLL][kFastKeys];
     uint64_t traw[UNROLL][kFastTerms];
     double x[UNROLL][S::numLoads > 0 ? S::numLoads : 1];
+    int64_t xi[S::anyIntLoad ? UNROLL : 1][S::numLoads > 0 ? S::numLoads : 1];  // integer columns, unconverted
     // Phase 1: every load of this iteration, column by column, UNROLL rows
     // back to back. Rows past the end are clamped (and ignored in phase 2) so
     // that no load sits under a per-lane predicate.
@@ -502,7 +628,18 @@ __device__ inline void aggFastBody(const FastArgs& a) {
       constexpr int j = decltype(jc)::value;
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {
-        x[u][j] = a.loadPtr[j][S::indirect(4 + j) ? rowi[u] : rowc[u]];
+        const int64_t at = S::indirect(4 + j) ? rowi[u] : rowc[u];
+        if constexpr (S::loadKind(j) == FL_F32) {
+          x[u][j] = static_cast<double>(VX355_FAST_LOAD(static_cast<const float*>(a.loadPtr[j]) + at));
+        } else if constexpr (S::loadKind(j) == FL_I64) {
+          xi[u][j] = VX355_FAST_LOAD(static_cast<const int64_t*>(a.loadPtr[j]) + at);
+          x[u][j] = static_cast<double>(xi[u][j]);
+        } else if constexpr (S::loadKind(j) == FL_I32) {
+          xi[u][j] = VX355_FAST_LOAD(static_cast<const int32_t*>(a.loadPtr[j]) + at);
+          x[u][j] = static_cast<double>(xi[u][j]);
+        } else {
+          x[u][j] = VX355_FAST_LOAD(static_cast<const double*>(a.loadPtr[j]) + at);
+        }
       }
     });
     // null flags of the nullable columns: bit (4 + j) of nul[u] set = load j is null, bit k = key
@@ -576,11 +713,17 @@ __device__ inline void aggFastBody(const FastArgs& a) {
       if (live && !defer) {
         const int32_t slot = ldsSlot(p, st, key);
         double vals[NA > 0 ? NA : 1];
+        uint64_t opv[NA > 0 ? NA : 1];  // operand word of the accumulators with an op (FastOp)
         bool have[NA > 0 ? NA : 1];  // false: some input of accumulator j is null in this row
         staticFor<NA>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
           double acc = 0;
           have[j] = true;
+          if constexpr (S::masked(j)) {
+            const uint64_t bit = 1ULL << (rowc[u] & 63);
+            have[j] = (a.maskBits[j][rowc[u] >> 6] & bit) != 0 &&
+                (a.maskNulls[j] == nullptr || (a.maskNulls[j][rowc[u] >> 6] & bit) != 0);
+          }
           staticFor<S::numFactors(j)>([&](auto fc) {
             constexpr int f = decltype(fc)::value;
             double v = a.offset[j][f];
@@ -605,6 +748,14 @@ __device__ inline void aggFastBody(const FastArgs& a) {
             });
           }
           vals[j] = acc;
+          opv[j] = 0;
+          if constexpr (S::op(j) == FO_SUM_I64) {
+            opv[j] = static_cast<uint64_t>(xi[S::anyIntLoad ? u : 0][S::load(j, 0)]);
+          } else if constexpr (S::op(j) == FO_MIN_I || S::op(j) == FO_MAX_I) {
+            opv[j] = int64ToOrdered(xi[S::anyIntLoad ? u : 0][S::load(j, 0)]);
+          } else if constexpr (S::op(j) == FO_MIN_F || S::op(j) == FO_MAX_F) {
+            opv[j] = doubleToOrdered(x[u][S::load(j, 0)]);
+          }
         });
         if (slot >= 0) {
           ldsTouchFirst(st, slot, static_cast<uint32_t>(row));
@@ -617,6 +768,12 @@ __device__ inline void aggFastBody(const FastArgs& a) {
             }
             if constexpr (S::numFactors(j) == 0) {
               atomicAdd(reinterpret_cast<unsigned long long*>(dst + w * REP), 1ULL);
+            } else if constexpr (S::op(j) == FO_SUM_I64) {
+              applyLds(dst + w * REP, ACC_SUM_I64, opv[j], p.counters, REP);
+            } else if constexpr (S::op(j) == FO_MIN_F || S::op(j) == FO_MIN_I) {
+              atomicMin(reinterpret_cast<unsigned long long*>(dst + w * REP), static_cast<unsigned long long>(opv[j]));
+            } else if constexpr (S::op(j) == FO_MAX_F || S::op(j) == FO_MAX_I) {
+              atomicMax(reinterpret_cast<unsigned long long*>(dst + w * REP), static_cast<unsigned long long>(opv[j]));
             } else {
               if (a.splitM[j] != 0.0) {
                 double hi, lo;
@@ -630,7 +787,8 @@ __device__ inline void aggFastBody(const FastArgs& a) {
           });
         } else {
           // Workgroup out of LDS slots: straight to the group row in HBM.
-          uint64_t* g = p.table + key * p.stride;
+          uint64_t* g = ldsGroupRow(p, key);
+          if (g != nullptr) {  // (nullptr: table full, flagged in the counters)
           const uint64_t myRow = p.rowBase + static_cast<uint64_t>(row);
           unsigned long long old = atomicMin(reinterpret_cast<unsigned long long*>(g + 1), myRow);
           if (old == kNoRow) {
@@ -644,6 +802,12 @@ __device__ inline void aggFastBody(const FastArgs& a) {
             }
             if constexpr (S::numFactors(j) == 0) {
               applyGlobal(g + p.off[w], ACC_SUM_I64_WRAP, 1, p.counters);
+            } else if constexpr (S::op(j) == FO_SUM_I64) {
+              applyGlobal(g + p.off[w], ACC_SUM_I64, opv[j], p.counters);
+            } else if constexpr (S::op(j) == FO_MIN_F || S::op(j) == FO_MIN_I) {
+              applyGlobal(g + p.off[w], ACC_MIN, opv[j], p.counters);
+            } else if constexpr (S::op(j) == FO_MAX_F || S::op(j) == FO_MAX_I) {
+              applyGlobal(g + p.off[w], ACC_MAX, opv[j], p.counters);
             } else {
               double hi = vals[j], lo = 0;
               if (a.splitM[j] != 0.0) {
@@ -657,6 +821,7 @@ __device__ inline void aggFastBody(const FastArgs& a) {
               }
             }
           });
+          }
         }
       }
       // Rows the fast path cannot place go to the deferred list (one atomic per wave).
