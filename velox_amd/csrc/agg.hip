@@ -3238,7 +3238,7 @@ struct vx355_agg {
   // Direct-index tables beyond the LDS path's one-entry-per-key map (capacity > 8192): how many
   // distinct keys a strided sample of the first batch holds (sampleCardinality). Few -> the LDS
   // kernels run with a hashed key -> slot map instead of handing every row to HBM atomics.
-  bool cardSampled = false;
+  bool cardSampled = false;   // (VX355_AGG_LDS_HASHED=0 sets it up front: no sample, no hashed map)
   int64_t sampledGroups = -1;
   bool logShapes = false;
   int64_t deferCap = 1 << 20;
@@ -5981,6 +5981,9 @@ void configureFromEnv(vx355_agg& h) {
   }
   if (const char* e = std::getenv("VX355_AGG_RADIX_DENSE")) {
     h.radixDense = std::atoi(e) != 0;
+  }
+  if (const char* e = std::getenv("VX355_AGG_LDS_HASHED")) {
+    h.cardSampled = std::atoi(e) == 0;
   }
   if (const char* e = std::getenv("VX355_AGG_DENSE_MIN_ROWS")) {
     h.denseMinRows = std::max<int64_t>(1, std::strtoll(e, nullptr, 10));
