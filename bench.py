@@ -362,8 +362,16 @@ class C1:
                 self._host_batches = [abi.HostBatch([abi.HostColumn(abi.BIGINT, hk[i:i + 10000]),
                                                      abi.HostColumn(abi.DOUBLE, hv[i:i + 10000])])
                                       for i in range(0, self.n, 10000)]
-            for b in self._host_batches:   # PCIe-inclusive: every vector starts in host memory
-                op.add_input(b)
+            if os.environ.get("VX355_C1_ASYNC") == "1":
+                # asynchronous boundary: the Driver thread only queues; the handle's worker stages and launches
+                t0 = time.perf_counter()
+                for b in self._host_batches:
+                    op.add_input_async(b)
+                self.submit_ms = (time.perf_counter() - t0) * 1e3
+                op.wait()
+            else:
+                for b in self._host_batches:   # PCIe-inclusive: every vector starts in host memory
+                    op.add_input(b)
         else:
             op.add_input(self.batch)
         op.no_more_input()
@@ -373,6 +381,9 @@ class C1:
         return self.n
 
     def info(self):
+        if self.stream and hasattr(self, "submit_ms"):
+            return {"input": "1000 x 10 000-row host vectors through vx355_agg_add_input_async (PCIe inclusive)",
+                    "driver_thread_ms_queueing_the_last_step": round(self.submit_ms, 3)}
         return {"input": "1000 x 10 000-row host vectors (PCIe inclusive)" if self.stream
                 else "one HBM-resident batch"}
 

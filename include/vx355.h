@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VX355_ABI_VERSION 4
+#define VX355_ABI_VERSION 5
 
 typedef enum vx355_status {
   VX355_OK = 0,
@@ -541,6 +541,24 @@ int vx355_agg_get_output(
     int32_t* n_out,
     int32_t* finished);
 
+/* ---- asynchronous boundary (ABI 5) -------------------------------------------------------
+ * exec::Operator::isBlocked(ContinueFuture*) / needsInput() (exec/Operator.h:280-299): a Driver
+ * thread must not sit in addInput while staging copies, transfers and kernels run.
+ * vx355_agg_add_input_async queues the batch for the handle's worker thread and returns at once
+ * with a ticket (1, 2, ...); batches are processed in submission order. The buffers 'batch' points
+ * to must stay valid until its ticket has completed (the descriptor itself is copied): the shim
+ * keeps the RowVectorPtr and drops it when vx355_agg_poll reports completed >= ticket.
+ * vx355_agg_poll never blocks: submitted / completed ticket counts (needsInput = few in flight,
+ * isBlocked = completed < submitted when the shim wants to wait). vx355_agg_wait blocks until the
+ * queue is empty and returns the first failure among the batches since the last wait (its message
+ * is then the calling thread's vx355_last_error(); batches behind a failed one are skipped).
+ * Every other entry point of the handle (add_input, no_more_input, get_output, flush, get_stats,
+ * destroy ...) waits for the queue first, so mixing synchronous and asynchronous calls is safe and
+ * ordered. The same three calls exist for HashBuild. */
+int vx355_agg_add_input_async(vx355_agg* h, const vx355_batch* batch, int64_t* ticket_out);
+int vx355_agg_poll(vx355_agg* h, int64_t* submitted, int64_t* completed);
+int vx355_agg_wait(vx355_agg* h);
+
 /* hashtable.* runtime stats (exec/HashTable.h:155-182). */
 typedef struct vx355_agg_stats {
   int64_t num_groups;   /* hashtable.numDistinct */
@@ -634,6 +652,11 @@ int vx355_join_build_create(const vx355_join_build_spec* spec, vx355_join_build*
 /* HashBuild::addInput (:442-598): drops rows with a null key, appends keys and
  * dependents to the HBM-resident build columns. */
 int vx355_join_build_add_input(vx355_join_build* h, const vx355_batch* batch);
+/* Asynchronous forms, as for the aggregation (see vx355_agg_add_input_async): queue / poll / wait;
+ * vx355_join_build_finish waits for this build's and the peers' queues. */
+int vx355_join_build_add_input_async(vx355_join_build* h, const vx355_batch* batch, int64_t* ticket_out);
+int vx355_join_build_poll(vx355_join_build* h, int64_t* submitted, int64_t* completed);
+int vx355_join_build_wait(vx355_join_build* h);
 /* HashBuild::noMoreInput -> finishHashBuild (:799-993) ->
  * HashTable::prepareJoinTable (exec/HashTable.cpp:1989-2069). others: build
  * handles of the peer Drivers whose rows are merged into this table (may be

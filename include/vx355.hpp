@@ -73,6 +73,26 @@ class HashAggregation {
 
   bool needsInput() const { return !noMoreInput_; }  // HashAggregation.h:50
   void addInput(const vx355_batch& input) { check(vx355_agg_add_input(handle_, &input)); }
+  // Asynchronous boundary: the batch is queued for the handle's worker thread; its buffers must stay
+  // valid until inFlight() no longer counts its ticket. isBlocked() is what exec::Operator::isBlocked
+  // polls; wait() rethrows the first failure among the queued batches.
+  int64_t addInputAsync(const vx355_batch& input) {
+    int64_t ticket = 0;
+    check(vx355_agg_add_input_async(handle_, &input, &ticket));
+    return ticket;
+  }
+  int64_t completedTickets() const {
+    int64_t submitted = 0, completed = 0;
+    check(vx355_agg_poll(handle_, &submitted, &completed));
+    return completed;
+  }
+  int64_t inFlight() const {
+    int64_t submitted = 0, completed = 0;
+    check(vx355_agg_poll(handle_, &submitted, &completed));
+    return submitted - completed;
+  }
+  bool isBlocked(int64_t maxInFlight = 2) const { return inFlight() >= maxInFlight; }
+  void wait() { check(vx355_agg_wait(handle_)); }
   void noMoreInput() {
     noMoreInput_ = true;
     check(vx355_agg_no_more_input(handle_));
@@ -209,6 +229,17 @@ class HashBuild {
 
   bool needsInput() const { return !finished_; }
   void addInput(const vx355_batch& input) { check(vx355_join_build_add_input(handle_, &input)); }
+  int64_t addInputAsync(const vx355_batch& input) {   // see HashAggregation::addInputAsync
+    int64_t ticket = 0;
+    check(vx355_join_build_add_input_async(handle_, &input, &ticket));
+    return ticket;
+  }
+  int64_t inFlight() const {
+    int64_t submitted = 0, completed = 0;
+    check(vx355_join_build_poll(handle_, &submitted, &completed));
+    return submitted - completed;
+  }
+  void wait() { check(vx355_join_build_wait(handle_)); }
   // HashBuild::noMoreInput + finishHashBuild (HashBuild.cpp:819-993): called on the LAST of the
   // peer build operators with the others; returns the table the bridge publishes.
   JoinTable noMoreInput(const std::vector<HashBuild*>& peers = {}) {

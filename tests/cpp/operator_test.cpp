@@ -10,6 +10,8 @@
 #include <map>
 #include <random>
 #include <set>
+#include <thread>
+#include <array>
 #include <vector>
 
 #include "vx355.hpp"
@@ -419,6 +421,51 @@ int testDistributedEntryPoints() {
   return 0;
 }
 
+// The asynchronous boundary as a Driver would use it: queue vectors while isBlocked() allows,
+// release each vector when its ticket has completed, noMoreInput drains the rest.
+int testAsyncInput() {
+  std::mt19937_64 rng(29);
+  const int kBatches = 64, kRows = 4096, kGroups = 101;
+  std::vector<std::vector<int64_t>> keys(kBatches), vals(kBatches);
+  std::map<int64_t, std::pair<int64_t, int64_t>> want;
+  for (int b = 0; b < kBatches; ++b) {
+    keys[b].resize(kRows);
+    vals[b].resize(kRows);
+    for (int i = 0; i < kRows; ++i) {
+      keys[b][i] = int64_t(rng() % kGroups) * 7 - 100;
+      vals[b][i] = int64_t(rng() % 2000) - 1000;
+      want[keys[b][i]].first += vals[b][i];
+      want[keys[b][i]].second += 1;
+    }
+  }
+  vx355::HashAggregation op({0}, {VX355_BIGINT},
+                            {{VX355_AGG_SUM, 1, -1, VX355_BIGINT, -1, 0}, {VX355_AGG_COUNT_STAR, -1, -1, VX355_BIGINT, -1, 0}});
+  std::vector<std::array<vx355_column, 2>> cols(kBatches);
+  int64_t lastTicket = 0;
+  for (int b = 0; b < kBatches; ++b) {
+    while (op.isBlocked(4)) {
+      std::this_thread::yield();  // a Driver would return its ContinueFuture here
+    }
+    cols[b] = {flat(VX355_BIGINT, keys[b].data()), flat(VX355_BIGINT, vals[b].data())};
+    lastTicket = op.addInputAsync(vx355_batch{kRows, 2, cols[b].data()});
+  }
+  EXPECT(lastTicket == kBatches);
+  op.noMoreInput();   // waits for the queue
+  EXPECT(op.inFlight() == 0 && op.completedTickets() == kBatches);
+  std::vector<int64_t> outKey(kGroups), outSum(kGroups), outCount(kGroups);
+  std::vector<uint64_t> valid(6, 0);
+  vx355_out_column out[3] = {{VX355_BIGINT, VX355_MEM_HOST, outKey.data(), valid.data()},
+                             {VX355_BIGINT, VX355_MEM_HOST, outSum.data(), valid.data() + 2},
+                             {VX355_BIGINT, VX355_MEM_HOST, outCount.data(), valid.data() + 4}};
+  const int32_t n = op.getOutput(out, 3, kGroups);
+  EXPECT(n == static_cast<int32_t>(want.size()));
+  for (int32_t i = 0; i < n; ++i) {
+    EXPECT(want.count(outKey[i]) == 1);
+    EXPECT(outSum[i] == want[outKey[i]].first && outCount[i] == want[outKey[i]].second);
+  }
+  return 0;
+}
+
 int main() {
   try {
     vx355::init(0);
@@ -426,6 +473,10 @@ int main() {
       return 1;
     }
     if (testAggregation()) {
+      return 1;
+    }
+    if (testAsyncInput()) {
+      std::fprintf(stderr, "asynchronous input failed\n");
       return 1;
     }
     if (testDistinctAndPages()) {

@@ -3144,6 +3144,7 @@ using namespace vx;
 
 struct vx355_agg {
   vx::Runtime* ctx = nullptr;  // this operator's execution context (stream, mailbox)
+  vx::AsyncQueue* aq = nullptr;  // worker of vx355_agg_add_input_async (created on first use)
   int32_t step;
   bool ignoreNullKeys;
   std::vector<KeyState> keys;
@@ -6385,6 +6386,7 @@ int vx355_agg_create(const vx355_agg_spec* spec, vx355_agg** out) {
 
 int vx355_agg_set_fused_input(vx355_agg* h, const vx355_filter_term* terms, int32_t n_terms,
                               const vx355_projection* projections, int32_t n_projections) {
+  VX_ASYNC_DRAIN(h)
   VX_API_BEGIN_CTX(VX_CTX_OF(h))
   VX_CHECK_ARG(h, "NULL argument");
   VX_CHECK_ARG(h->inputRows == 0 && !h->tableReady, "set_fused_input after the first add_input");
@@ -6414,6 +6416,7 @@ int vx355_agg_set_fused_input(vx355_agg* h, const vx355_filter_term* terms, int3
 }
 
 int vx355_agg_add_input(vx355_agg* h, const vx355_batch* batch) {
+  VX_ASYNC_DRAIN(h)
   VX_API_BEGIN_CTX(VX_CTX_OF(h))
   Runtime::get().requireInit();
   VX_CHECK_ARG(h && batch, "NULL argument");
@@ -6427,6 +6430,7 @@ int vx355_agg_add_input(vx355_agg* h, const vx355_batch* batch) {
 }
 
 int vx355_agg_no_more_input(vx355_agg* h) {
+  VX_ASYNC_DRAIN(h)
   VX_API_BEGIN_CTX(VX_CTX_OF(h))
   VX_CHECK_ARG(h, "NULL argument");
   Runtime::get().requireInit();
@@ -6459,6 +6463,7 @@ int vx355_agg_output_types(const vx355_agg* h, int32_t* types, int32_t cap, int3
 
 int vx355_agg_get_output(vx355_agg* h, vx355_out_column* cols, int32_t num_cols, int32_t max_rows,
                          int32_t* n_out, int32_t* finished) {
+  VX_ASYNC_DRAIN(h)
   VX_API_BEGIN_CTX(VX_CTX_OF(h))
   Runtime::get().requireInit();
   VX_CHECK_ARG(h, "NULL argument");
@@ -6529,6 +6534,7 @@ int vx355_agg_get_output(vx355_agg* h, vx355_out_column* cols, int32_t num_cols,
 }
 
 int vx355_agg_flush(vx355_agg* h) {
+  VX_ASYNC_DRAIN(h)
   VX_API_BEGIN_CTX(VX_CTX_OF(h))
   VX_CHECK_ARG(h, "NULL argument");
   VX_CHECK_ARG(!h->noMoreInput, "flush after noMoreInput");
@@ -6549,6 +6555,7 @@ int vx355_agg_flush(vx355_agg* h) {
 }
 
 int vx355_agg_to_intermediate(vx355_agg* h, const vx355_batch* batch, vx355_out_column* cols, int32_t num_cols) {
+  VX_ASYNC_DRAIN(h)
   VX_API_BEGIN_CTX(VX_CTX_OF(h))
   VX_CHECK_ARG(h, "NULL argument");
   if (h->distinct.empty()) {
@@ -6587,6 +6594,7 @@ int vx355_agg_to_intermediate(vx355_agg* h, const vx355_batch* batch, vx355_out_
 }
 
 int vx355_agg_get_stats(const vx355_agg* h, vx355_agg_stats* out) {
+  VX_ASYNC_DRAIN(h)
   VX_API_BEGIN
   VX_CHECK_ARG(h && out, "NULL argument");
   out->num_groups = h->keys.empty() ? 1 : h->numGroups;
@@ -6617,6 +6625,8 @@ void vx355_agg_destroy(vx355_agg* h) {
   if (!h) {
     return;
   }
+  vx::asyncDestroy(h->aq);  // waits for the batches in flight
+  h->aq = nullptr;
   Runtime* ctx = h->ctx;
   try {
     vx::ContextScope scope(ctx);  // the handle's buffers are released under its own context
@@ -6624,6 +6634,63 @@ void vx355_agg_destroy(vx355_agg* h) {
   } catch (...) {
   }
   Runtime::destroyContext(ctx);
+}
+
+// ---- asynchronous boundary (async.hip) ----
+int vx355_agg_add_input_async(vx355_agg* h, const vx355_batch* batch, int64_t* ticket_out) {
+  try {
+    if (!h || !batch || (batch->num_cols > 0 && !batch->cols)) {
+      vx::setLastError("NULL argument");
+      return VX355_EINVAL;
+    }
+    if (!h->aq) {
+      h->aq = vx::asyncCreate();
+    }
+    const int64_t ticket = vx::asyncSubmit(h->aq, vx::asyncBatchTask(batch, [h](const vx355_batch* b) -> int {
+      // the synchronous entry point minus its drain (this IS the queue's worker)
+      VX_API_BEGIN_CTX(VX_CTX_OF(h))
+      Runtime::get().requireInit();
+      VX_CHECK_ARG(!h->noMoreInput, "addInput after noMoreInput");
+      VX_CHECK_ARG(!h->flushing, "addInput while a partial flush is being drained");
+      feedInput(*h, b);
+      for (auto& d : h->distinct) {
+        feedInput(*d.dedup, b);
+      }
+      VX_API_END
+    }));
+    if (ticket_out) {
+      *ticket_out = ticket;
+    }
+    return VX355_OK;
+  } catch (const std::exception& e) {
+    vx::setLastError(e.what());
+    return VX355_EINTERNAL;
+  }
+}
+
+int vx355_agg_poll(vx355_agg* h, int64_t* submitted, int64_t* completed) {
+  if (!h) {
+    vx::setLastError("NULL argument");
+    return VX355_EINVAL;
+  }
+  if (submitted) {
+    *submitted = 0;
+  }
+  if (completed) {
+    *completed = 0;
+  }
+  if (h->aq) {
+    vx::asyncPoll(h->aq, submitted, completed);
+  }
+  return VX355_OK;
+}
+
+int vx355_agg_wait(vx355_agg* h) {
+  if (!h) {
+    vx::setLastError("NULL argument");
+    return VX355_EINVAL;
+  }
+  return h->aq ? vx::asyncWait(h->aq) : VX355_OK;
 }
 
 }  // extern "C"

@@ -8,6 +8,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -27,6 +28,23 @@ struct Error : std::runtime_error {
 };
 
 void setLastError(const std::string& m);
+
+// Asynchronous boundary (async.hip): one worker thread per handle runs its *_add_input_async
+// batches in order; every other entry point of the handle drains the queue first (VX_ASYNC_DRAIN).
+struct AsyncQueue;
+AsyncQueue* asyncCreate();
+int64_t asyncSubmit(AsyncQueue* q, std::function<int(std::string*)> task);
+void asyncPoll(AsyncQueue* q, int64_t* submitted, int64_t* completed);
+int asyncWait(AsyncQueue* q);
+void asyncDestroy(AsyncQueue* q);
+std::function<int(std::string*)> asyncBatchTask(const vx355_batch* batch, std::function<int(const vx355_batch*)> call);
+#define VX_ASYNC_DRAIN(h)                                  \
+  if ((h) != nullptr && (h)->aq != nullptr) {              \
+    const int asyncStatus__ = ::vx::asyncWait((h)->aq);    \
+    if (asyncStatus__ != VX355_OK) {                       \
+      return asyncStatus__;                                \
+    }                                                      \
+  }
 
 #define VX_THROW(status, msg) throw ::vx::Error((status), (msg))
 #define VX_CHECK_ARG(cond, msg)         \

@@ -2376,6 +2376,7 @@ using namespace vx;
 
 struct vx355_join_build {
   vx::Runtime* ctx = nullptr;  // this operator's execution context (stream, mailbox)
+  vx::AsyncQueue* aq = nullptr;  // worker of vx355_join_build_add_input_async (created on first use)
   std::vector<int32_t> keyCols, keyKinds, depCols, depKinds;
   std::vector<int32_t> usedCols;
   int32_t joinType = 0;
@@ -3744,7 +3745,7 @@ int vx355_join_build_create(const vx355_join_build_spec* spec, vx355_join_build*
   VX_API_END
 }
 
-int vx355_join_build_add_input(vx355_join_build* h, const vx355_batch* batch) {
+static int joinBuildAddInputNow(vx355_join_build* h, const vx355_batch* batch) {
   VX_API_BEGIN_CTX(VX_CTX_OF(h))
   Runtime::get().requireInit();
   VX_CHECK_ARG(h && batch, "NULL argument");
@@ -3760,8 +3761,66 @@ int vx355_join_build_add_input(vx355_join_build* h, const vx355_batch* batch) {
   VX_API_END
 }
 
+int vx355_join_build_add_input(vx355_join_build* h, const vx355_batch* batch) {
+  VX_ASYNC_DRAIN(h)
+  return joinBuildAddInputNow(h, batch);
+}
+
+// Asynchronous boundary (async.hip): the batch is processed by the handle's worker thread.
+int vx355_join_build_add_input_async(vx355_join_build* h, const vx355_batch* batch, int64_t* ticket_out) {
+  try {
+    if (!h || !batch || (batch->num_cols > 0 && !batch->cols)) {
+      vx::setLastError("NULL argument");
+      return VX355_EINVAL;
+    }
+    if (!h->aq) {
+      h->aq = vx::asyncCreate();
+    }
+    const int64_t ticket = vx::asyncSubmit(
+        h->aq, vx::asyncBatchTask(batch, [h](const vx355_batch* b) { return joinBuildAddInputNow(h, b); }));
+    if (ticket_out) {
+      *ticket_out = ticket;
+    }
+    return VX355_OK;
+  } catch (const std::exception& e) {
+    vx::setLastError(e.what());
+    return VX355_EINTERNAL;
+  }
+}
+
+int vx355_join_build_poll(vx355_join_build* h, int64_t* submitted, int64_t* completed) {
+  if (!h) {
+    vx::setLastError("NULL argument");
+    return VX355_EINVAL;
+  }
+  if (submitted) {
+    *submitted = 0;
+  }
+  if (completed) {
+    *completed = 0;
+  }
+  if (h->aq) {
+    vx::asyncPoll(h->aq, submitted, completed);
+  }
+  return VX355_OK;
+}
+
+int vx355_join_build_wait(vx355_join_build* h) {
+  if (!h) {
+    vx::setLastError("NULL argument");
+    return VX355_EINVAL;
+  }
+  return h->aq ? vx::asyncWait(h->aq) : VX355_OK;
+}
+
 int vx355_join_build_finish(vx355_join_build* h, vx355_join_build* const* others, int32_t num_others,
                             vx355_join_table** out) {
+  VX_ASYNC_DRAIN(h)
+  for (int32_t i = 0; i < num_others; ++i) {
+    if (others && others[i]) {
+      VX_ASYNC_DRAIN(others[i])
+    }
+  }
   VX_API_BEGIN_CTX(VX_CTX_OF(h))
   Runtime::get().requireInit();
   VX_CHECK_ARG(h && out && num_others >= 0, "bad argument");
@@ -3782,6 +3841,8 @@ void vx355_join_build_destroy(vx355_join_build* h) {
   if (!h) {
     return;
   }
+  vx::asyncDestroy(h->aq);  // waits for the batches in flight
+  h->aq = nullptr;
   Runtime* ctx = h->ctx;
   try {
     vx::ContextScope scope(ctx);

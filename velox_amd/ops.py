@@ -26,7 +26,8 @@ SYMBOLS = [
     "vx355_profile_get", "vx355_profile_names", "vx355_hash_columns", "vx355_value_ids",
     "vx355_filter_compact", "vx355_partition", "vx355_partition_scatter", "vx355_presto_serialize", "vx355_presto_deserialize", "vx355_filter_project", "vx355_agg_create", "vx355_agg_set_fused_input", "vx355_agg_add_input",
     "vx355_agg_no_more_input", "vx355_agg_output_types", "vx355_agg_get_output",
-    "vx355_agg_get_stats", "vx355_agg_destroy", "vx355_join_build_create",
+    "vx355_agg_get_stats", "vx355_agg_destroy", "vx355_agg_add_input_async", "vx355_agg_poll", "vx355_agg_wait",
+    "vx355_join_build_add_input_async", "vx355_join_build_poll", "vx355_join_build_wait", "vx355_join_build_create",
     "vx355_join_build_add_input", "vx355_join_build_finish", "vx355_join_build_destroy",
     "vx355_join_table_retain", "vx355_join_table_release", "vx355_join_table_get_stats",
     "vx355_join_probe_create", "vx355_join_probe_add_input", "vx355_join_probe_get_output",
@@ -91,6 +92,10 @@ def lib():
     L.vx355_agg_create.argtypes = [P(abi.AggSpec), P(vp)]
     L.vx355_agg_set_fused_input.argtypes = [vp, P(abi.FilterTerm), i32, P(abi.Projection), i32]
     L.vx355_agg_add_input.argtypes = [vp, P(abi.Batch)]
+    for name in ("vx355_agg", "vx355_join_build"):
+        getattr(L, name + "_add_input_async").argtypes = [vp, P(abi.Batch), P(i64)]
+        getattr(L, name + "_poll").argtypes = [vp, P(i64), P(i64)]
+        getattr(L, name + "_wait").argtypes = [vp]
     L.vx355_agg_no_more_input.argtypes = [vp]
     L.vx355_agg_output_types.argtypes = [vp, P(i32), i32, P(i32)]
     L.vx355_agg_get_output.argtypes = [vp, P(abi.OutColumn), i32, i32, P(i32), P(i32)]
@@ -724,6 +729,27 @@ class HashAggregation:
     def add_input(self, batch):
         _check(lib().vx355_agg_add_input(self.h, batch.ref()))
 
+    # asynchronous boundary: the batch (and its buffers) is kept alive here until wait() / poll()
+    # reports its ticket completed
+    def add_input_async(self, batch):
+        ticket = C.c_int64()
+        _check(lib().vx355_agg_add_input_async(self.h, batch.ref(), C.byref(ticket)))
+        self.__dict__.setdefault("_in_flight", {})[ticket.value] = batch
+        return ticket.value
+
+    def poll(self):
+        sub, done = C.c_int64(), C.c_int64()
+        _check(lib().vx355_agg_poll(self.h, C.byref(sub), C.byref(done)))
+        held = self.__dict__.get("_in_flight", {})
+        for t in [t for t in held if t <= done.value]:
+            del held[t]
+        return sub.value, done.value
+
+    def wait(self):
+        status = lib().vx355_agg_wait(self.h)
+        self.__dict__.get("_in_flight", {}).clear()
+        _check(status)
+
     def no_more_input(self):
         _check(lib().vx355_agg_no_more_input(self.h))
 
@@ -801,6 +827,23 @@ class HashBuild:
 
     def add_input(self, batch):
         _check(lib().vx355_join_build_add_input(self.h, batch.ref()))
+
+    def add_input_async(self, batch):
+        """Queues the batch for the handle's worker thread (kept alive here until wait())."""
+        ticket = C.c_int64()
+        _check(lib().vx355_join_build_add_input_async(self.h, batch.ref(), C.byref(ticket)))
+        self.__dict__.setdefault("_in_flight", {})[ticket.value] = batch
+        return ticket.value
+
+    def poll(self):
+        sub, done = C.c_int64(), C.c_int64()
+        _check(lib().vx355_join_build_poll(self.h, C.byref(sub), C.byref(done)))
+        return sub.value, done.value
+
+    def wait(self):
+        status = lib().vx355_join_build_wait(self.h)
+        self.__dict__.get("_in_flight", {}).clear()
+        _check(status)
 
     def finish(self, others=()):
         arr = (C.c_void_p * max(1, len(others)))(*[o.h for o in others])
