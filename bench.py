@@ -349,7 +349,19 @@ class C1:
         self.n = n
         self.k = torch.randint(0, 1000, (n,), dtype=torch.int64, device=device, generator=g)
         self.v = torch.rand(n, dtype=torch.float64, device=device, generator=g)
-        self.batch = DevBatch([dcol(abi.BIGINT, self.k), dcol(abi.DOUBLE, self.v)], n)
+        vcol = dcol(abi.DOUBLE, self.v)
+        null_frac = float(os.environ.get("VX355_C1_NULLS", "0"))
+        if null_frac > 0:
+            # the reference's *_halfnull variants (SimpleAggregates.cpp): v carries a null bitmap
+            words = (n + 63) // 64
+            bits = torch.ones(words * 64, dtype=torch.bool, device=device)
+            bits[:n] = torch.rand(n, device=device, generator=g) >= null_frac
+            weights = torch.ones(64, dtype=torch.int64, device=device) << torch.arange(64, device=device)
+            self.v_nulls = (bits.view(-1, 64).to(torch.int64) * weights).sum(1)
+            vcol = ops.DeviceColumn.from_ptr(abi.DOUBLE, self.v.data_ptr(), n, self.v_nulls.data_ptr())
+            self.name = "c1_groupby_10m_1k_%d_percent_null_values" % round(null_frac * 100)
+            self.v_valid = bits[:n]
+        self.batch = DevBatch([dcol(abi.BIGINT, self.k), vcol], n)
         torch.cuda.synchronize()
 
     stream = False  # --c1-stream: 10 000-row HOST vectors, the way the reference feeds the operator
@@ -389,11 +401,15 @@ class C1:
 
     def host_sample(self, rows):
         rows = min(rows, self.n)
-        return {"k": self.k[:rows].cpu().numpy(), "v": self.v[:rows].cpu().numpy()}
+        out = {"k": self.k[:rows].cpu().numpy(), "v": self.v[:rows].cpu().numpy()}
+        if hasattr(self, "v_valid"):
+            out["v_valid"] = self.v_valid[:rows].cpu().numpy()
+        return out
 
     def cpu_reference(self, sample, oracle):
         t0 = time.perf_counter()
-        batch = abi.HostBatch([abi.HostColumn(abi.BIGINT, sample["k"]), abi.HostColumn(abi.DOUBLE, sample["v"])])
+        batch = abi.HostBatch([abi.HostColumn(abi.BIGINT, sample["k"]),
+                               abi.HostColumn(abi.DOUBLE, sample["v"], sample.get("v_valid"))])
         op = oracle.Aggregation([0], [abi.BIGINT], self.AGGS)
         op.add_input(batch)
         op.no_more_input()

@@ -31,8 +31,9 @@ run ${P}_bench_c4_sparse_keys_unordered_output --workload c4 --c4-sparse --c4-un
 VX355_C5_CHUNKS=1 run ${P}_bench_c5_one_gpu --workload c5 --rows 200000000 --steps 5 --warmup 2 --no-traffic
 run ${P}_bench_q3_join --workload q3 --steps 20 --warmup 5
 run ${P}_bench_q3_join_random_probe_order --workload q3 --q3-random-probe --steps 10 --warmup 3
-VX355_JIT=sync VX355_Q1_NULLS=0.01 run ${P}_bench_q1_nullable_discount --workload q1 --steps 10 --warmup 3 --no-traffic --no-secondary --no-cpu-baseline
+VX355_Q1_NULLS=0.01 run ${P}_bench_q1_nullable_discount --workload q1 --steps 10 --warmup 3 --no-traffic --no-secondary --no-cpu-baseline
 # two ranks SHARING the one GPU of this box: the launcher, the in-library RCCL exchange and the
 # merge run end to end (a functional record, not a scaling number: both ranks use the same HBM)
 VX355_BENCH_SHARE_GPU=1 run ${P}_bench_q1_2ranks_sharing_one_gpu --gpus 2 --rows 100000000 --steps 5 --warmup 2
 VX355_BENCH_SHARE_GPU=1 run ${P}_bench_c5_2ranks_sharing_one_gpu --gpus 2 --workload c5 --rows 50000000 --steps 3 --warmup 1
+VX355_C1_NULLS=0.5 run ${P}_bench_c1_half_null_values --workload c1 --no-traffic
