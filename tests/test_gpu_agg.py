@@ -979,6 +979,7 @@ def test_radix_path_skewed_keys_and_few_partitions(oracle, vx, slice_recs, monke
     """Partitions much larger than the rest (90 % of the rows on one key; a key range of a few
     partitions only) are folded slice by slice by many workgroups and flushed with atomics."""
     monkeypatch.setenv("VX355_AGG_RADIX_MIN_ROWS", "1")
+    monkeypatch.setenv("VX355_AGG_LDS_HASHED", "0")   # (no cardinality sample: the direct-index table and its radix path)
     if slice_recs:
         monkeypatch.setenv("VX355_AGG_RADIX_SLICE", slice_recs)
     rng = np.random.default_rng(80)

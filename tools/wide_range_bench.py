@@ -10,11 +10,12 @@ from bench import DevBatch, dcol
 dev = torch.device("cuda:0")
 ops.init(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 600_000_000
+G = int(os.environ.get("VX355_BENCH_GROUPS", "100"))
 g = torch.Generator(device=dev); g.manual_seed(5)
 out = {}
 for name, spread in (("range_2^27", 1 << 27), ("range_2^40", 1 << 40)):
-    codes = torch.randint(0, spread, (100,), dtype=torch.int64, device=dev, generator=g)
-    k = codes[torch.randint(0, 100, (n,), dtype=torch.int64, device=dev, generator=g)]
+    codes = torch.randint(0, spread, (G,), dtype=torch.int64, device=dev, generator=g)
+    k = codes[torch.randint(0, G, (n,), dtype=torch.int64, device=dev, generator=g)]
     v = torch.rand(n, dtype=torch.float64, device=dev, generator=g)
     batch = DevBatch([dcol(abi.BIGINT, k), dcol(abi.DOUBLE, v)], n)
     aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]

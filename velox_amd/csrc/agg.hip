@@ -3274,6 +3274,12 @@ struct vx355_agg {
   // kernels run with a hashed key -> slot map instead of handing every row to HBM atomics.
   bool cardSampled = false;   // (VX355_AGG_LDS_HASHED=0 sets it up front: no sample, no hashed map)
   int64_t sampledGroups = -1;
+  // The sample found few keys (it did not saturate) in a key range far wider than the LDS kernels'
+  // direct map: the operator keeps an open-addressing table instead of a direct-index one whose
+  // rows would be 99.99 % empty - no multi-GB table to initialise and to scan for live rows, and the
+  // radix path partitions by hash (rows spread evenly) instead of by key range (all rows of a key
+  // in one partition: 124 ms for 200 M rows over 1800 keys against 17 ms).
+  bool preferNormalized = false;
   bool logShapes = false;
   int64_t deferCap = 1 << 20;
   int fastUnroll = 4;
@@ -3587,6 +3593,9 @@ Decision decide(vx355_agg& h) {
   d.capacity = static_cast<uint64_t>(product);
   // A global aggregation (no keys) is the one-row array table whatever the budget says.
   d.mode = (h.keys.empty() || d.capacity <= h.arrayMax) ? MODE_ARRAY : MODE_NORMALIZED;
+  if (h.preferNormalized && !h.keys.empty() && d.capacity > 8192) {
+    d.mode = MODE_NORMALIZED;  // few keys over a wide range: see sampleCardinality
+  }
   return d;
 }
 
@@ -3718,7 +3727,7 @@ void rebuildTable(vx355_agg& h, uint64_t extraGroups) {
 
 // Picks the LDS layout for a launch. Returns false when the group range is too
 // large for the LDS path.
-constexpr int64_t kLdsHashedMaxGroups = 1024;
+constexpr int64_t kLdsHashedMaxGroups = 2048;
 
 bool chooseLds(const vx355_agg& h, int numAccs, LdsPlan* plan, size_t* ldsBytes) {
   if ((h.mode != MODE_ARRAY && h.mode != MODE_NORMALIZED) || numAccs == 0) {
@@ -3739,9 +3748,11 @@ bool chooseLds(const vx355_agg& h, int numAccs, LdsPlan* plan, size_t* ldsBytes)
     auto bytes = [&](int rep) {
       return (((M + 2 * S + 2) * 4 + 15) & ~static_cast<size_t>(15)) + S * 8 + S * accBytes * rep;
     };
+    // up to 60 KB two workgroups share a CU; hundreds of groups with several accumulator words may
+    // take one CU's worth (128 KB, one workgroup per CU): still far ahead of one HBM atomic per row
     int rep = 0;
     for (int r = 64; r >= 1; r >>= 1) {
-      if (bytes(r) <= budget) {
+      if (bytes(r) <= (r == 1 ? 128 * 1024 : budget)) {
         rep = r;
         break;
       }
@@ -5345,6 +5356,10 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
   if (!h.cardSampled && ((h.mode == MODE_ARRAY && h.capacity > 8192) || h.mode == MODE_NORMALIZED) &&
       h.numGroups == 0 && n > 0 && !a.rowList) {
     sampleCardinality(h, a, n);
+    if (h.mode == MODE_ARRAY && h.capacity > 8192 && h.sampledGroups >= 0 && h.sampledGroups < kCardSetSize / 2 - 64) {
+      h.preferNormalized = true;
+      rebuildTable(h, static_cast<uint64_t>(std::min<int64_t>({n, h.chunkRows, 1LL << 20})));
+    }
   }
   int64_t rows = 0;
   for (int64_t begin = 0; begin < n; begin += rows) {
