@@ -722,6 +722,41 @@ def test_real_and_integer_operands_and_masks_stay_on_the_specialised_kernel(orac
     assert "k_agg_fast" in names and "k_agg_lds" not in names and op.stats().reserved > 0
 
 
+@pytest.mark.parametrize("groups", [100, 500, 3000])
+def test_few_keys_over_a_wide_range(oracle, vx, groups, monkeypatch):
+    """One BIGINT key with a few hundred / thousand distinct values spread over a range of 2^27: by the
+    reference's rule a direct-index table (99.99 % empty rows); here the cardinality sample keeps an
+    open-addressing table, the LDS kernels take it with a hashed key -> slot map while the groups fit, the
+    hash-partitioned radix fold beyond. Two batches (the second meets a table with groups), nulls in the
+    operand, same groups in the same first-seen order as the oracle."""
+    monkeypatch.setenv("VX355_JIT", "sync")
+    monkeypatch.setenv("VX355_AGG_RADIX_MIN_ROWS", "1")
+    monkeypatch.setenv("VX355_AGG_COALESCE_ROWS", "0")
+    rng = np.random.default_rng(groups)
+    codes = rng.integers(0, 1 << 27, groups).astype(np.int64)
+    batches = []
+    for _ in range(2):
+        n = 400_000
+        k = codes[rng.integers(0, groups, n)]
+        v = _dyadic(rng, n)
+        w = rng.integers(-1 << 40, 1 << 40, n).astype(np.int64)
+        batches.append(batch_of([k, v, w], [None, rng.random(n) > 0.05, None]))
+    # (three accumulators: the sum, the count of its non-null inputs, count(*) - what the radix records hold)
+    aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    exp, _ = run_agg(oracle, batches, [0], [abi.BIGINT], aggs, max_rows=100000)
+    vx.profile_reset()
+    vx.profile_enable(True)
+    got, op = run_agg(vx, [vx.to_device(b) for b in batches], [0], [abi.BIGINT], aggs, max_rows=100000)
+    vx.profile_enable(False)
+    assert_columns_equal(got, exp, op.kinds, what="few keys over a wide range (%d)" % groups)
+    names = vx.profile()
+    assert op.stats().hash_mode == abi.MODE_NORMALIZED_KEY and "k_card_sample" in names
+    if groups <= 500:
+        assert "k_agg_fast" in names and "k_agg_global" not in names and "k_rp_aggregate" not in names
+    else:
+        assert "k_rp_aggregate" in names and "k_agg_fast" not in names
+
+
 def test_distinct_without_aggregates_and_drain_in_small_pages(oracle, vx):
     """SELECT DISTINCT k1, k2 (HashAggregation.cpp:426-488 semantics at the end
     of input): no aggregates at all; output drained 7 rows at a time."""
