@@ -43,7 +43,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="q1", choices=["q1", "c1", "c4", "q3", "q3full", "c5"])
+    ap.add_argument("--workload", default="q1", choices=["q1", "q1x4", "c1", "c4", "q3", "q3full", "c5"],
+                    help="q1 = the reference's TPC-H Q1 plan (2 keys, 8 aggregates; the headline); q1x4 = BASELINE.json's "
+                         "wording of it (4 keys, 6 aggregates)")
     ap.add_argument("--rows", type=int, default=0, help="override the row count (debug)")
     ap.add_argument("--cpu-sample-rows", type=int, default=16_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -328,6 +330,89 @@ class Q1:
                                wrap(abi.DOUBLE, sample["disc"]), abi.HostColumn(abi.DOUBLE, dp),
                                abi.HostColumn(abi.DOUBLE, charge)], len(sel))
         op = oracle.Aggregation(Q1_KEYS[0], Q1_KEYS[1], Q1_AGGS)
+        op.add_input(batch)
+        op.no_more_input()
+        out = oracle.collect_output(op, 1024)
+        return out, time.perf_counter() - t0
+
+
+class Q1FourKeys(Q1):
+    """BASELINE.json's literal wording of configs[1]: "8-column scan + filter + 4-key group-by with 6
+    aggregates". The reference's own Q1 has 2 keys and 8 aggregates (class Q1, the headline); this is
+    the same scan with two more low-cardinality INTEGER keys — l_linenumber (1..7) and a ship-mode
+    code (0..6) — and six aggregates: sum(qty), sum(ep), sum(ep * (1 - disc)), avg(qty), avg(disc),
+    count(*): 8 columns (2 x 16-byte StringView, 2 x INTEGER, 3 x DOUBLE, 1 x DATE) = 68 B/row,
+    4 x 7 x 7 = 196 groups."""
+    name = "tpch_q1_sf100_4key_6agg"
+    bytes_per_row = 68
+    KEYS = ([0, 1, 2, 3], [abi.VARCHAR, abi.VARCHAR, abi.INTEGER, abi.INTEGER])
+    TERMS = [(7, abi.CMP_LE, Q1_CUTOFF)]
+    PROJ = [[(5, 1.0, 0.0), (6, -1.0, 1.0)]]
+    AGGS6 = [(abi.AGG_SUM, 4, abi.DOUBLE), (abi.AGG_SUM, 5, abi.DOUBLE), (abi.AGG_SUM, ops.PROJ(0), abi.DOUBLE),
+             (abi.AGG_AVG, 4, abi.DOUBLE), (abi.AGG_AVG, 6, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+
+    @property
+    def agg_bytes_per_row(self):
+        return 68
+
+    def __init__(self, torch, n, device, seed):
+        self.torch, self.n = torch, n
+        c = gen_q1(torch, n, device, seed)
+        del c["tax"]
+        g = torch.Generator(device=device)
+        g.manual_seed(seed + 7)
+        c["lnum"] = torch.randint(1, 8, (n,), dtype=torch.int32, device=device, generator=g)
+        c["mode"] = torch.randint(0, 7, (n,), dtype=torch.int32, device=device, generator=g)
+        self.c = c
+        self.scan = self.make_scan(c, n)
+        torch.cuda.synchronize()
+
+    @staticmethod
+    def make_scan(c, n):
+        return DevBatch([dcol(abi.VARCHAR, c["rf"]), dcol(abi.VARCHAR, c["ls"]), dcol(abi.INTEGER, c["lnum"]),
+                         dcol(abi.INTEGER, c["mode"]), dcol(abi.DOUBLE, c["qty"]), dcol(abi.DOUBLE, c["ep"]),
+                         dcol(abi.DOUBLE, c["disc"]), dcol(abi.INTEGER, c["ship"])], n)
+
+    def operator(self, step_kind):
+        op = ops.HashAggregation(self.KEYS[0], self.KEYS[1], self.AGGS6, step_kind)
+        op.set_fused_input(self.TERMS, self.PROJ)
+        return op
+
+    def step(self, step_kind=abi.STEP_SINGLE):
+        op = self.operator(step_kind)
+        op.add_input(self.scan)
+        op.no_more_input()
+        self.selected = self.n
+        return ops.collect_output(op, 1024)
+
+    def partial_operator(self):
+        raise SystemExit("the 4-key variant is a single-GPU line")
+
+    def shard_view(self, rows):
+        raise SystemExit("the 4-key variant is a single-GPU line")
+
+    def cpu_reference(self, sample, oracle):
+        t0 = time.perf_counter()
+        sel = np.flatnonzero(sample["ship"] <= Q1_CUTOFF).astype(np.int32)
+        dp = (sample["ep"] * (1 - sample["disc"]))[sel]
+        rows = len(sample["ship"])
+
+        def wrap(kind, base):
+            col = abi.HostColumn.__new__(abi.HostColumn)
+            col.kind, col.encoding, col.keep = kind, abi.DICTIONARY, []
+            col.values = np.ascontiguousarray(base)
+            col.base_size, col.indices, col.num_rows = rows, sel, len(sel)
+            col.valid = col.nulls = None
+            return col
+        # post-FilterProject columns: 0 rf, 1 ls, 2 lnum, 3 mode, 4 qty, 5 ep, 6 disc, 7 disc_price
+        batch = abi.HostBatch([wrap(abi.VARCHAR, sample["rf"].view(np.uint8).reshape(-1, 16)),
+                               wrap(abi.VARCHAR, sample["ls"].view(np.uint8).reshape(-1, 16)),
+                               wrap(abi.INTEGER, sample["lnum"]), wrap(abi.INTEGER, sample["mode"]),
+                               wrap(abi.DOUBLE, sample["qty"]), wrap(abi.DOUBLE, sample["ep"]),
+                               wrap(abi.DOUBLE, sample["disc"]), abi.HostColumn(abi.DOUBLE, dp)], len(sel))
+        aggs = [(abi.AGG_SUM, 4, abi.DOUBLE), (abi.AGG_SUM, 5, abi.DOUBLE), (abi.AGG_SUM, 7, abi.DOUBLE),
+                (abi.AGG_AVG, 4, abi.DOUBLE), (abi.AGG_AVG, 6, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+        op = oracle.Aggregation(self.KEYS[0], self.KEYS[1], aggs)
         op.add_input(batch)
         op.no_more_input()
         out = oracle.collect_output(op, 1024)
@@ -908,7 +993,7 @@ class C5:
         return total, time.perf_counter() - t0
 
 
-WORKLOADS = {"q3full": (Q3Full, 600_037_902), "c5": (C5, 1_000_000_000), "q1": (Q1, 600_037_902), "c1": (C1, 10_000_000), "c4": (C4, 1_000_000_000),
+WORKLOADS = {"q1x4": (Q1FourKeys, 600_037_902), "q3full": (Q3Full, 600_037_902), "c5": (C5, 1_000_000_000), "q1": (Q1, 600_037_902), "c1": (C1, 10_000_000), "c4": (C4, 1_000_000_000),
              "q3": (Q3, 600_037_902)}
 
 

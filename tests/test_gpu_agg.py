@@ -1456,3 +1456,102 @@ def test_partial_rows_merge_through_presto_pages(oracle, vx):
     merged = vdist.merge_partials(vx, OneRank(), torch, part, [abi.VARCHAR], raw, None)
     exp, eop = run_agg(oracle, [b], [0], [abi.VARCHAR], raw, max_rows=5000)
     assert_columns_equal(merged, exp, eop.kinds, what="merge through pages")
+
+
+@pytest.mark.parametrize("num_keys,nullable", [(3, False), (4, False), (4, True)])
+def test_three_and_four_grouping_keys_stay_on_the_specialised_kernel(oracle, vx, monkeypatch, num_keys, nullable):
+    """BASELINE.json words configs[1] as a "4-key group-by with 6 aggregates": TPC-H Q1's two flag
+    keys plus one or two low-cardinality INTEGER keys (FastShape::KX), the fused filter and
+    sum / avg / count. The 4-key plan without nulls is in the ahead-of-time table (bench.py
+    --workload q1x4); the others are instantiated with hiprtc. Nullable third / fourth keys use the
+    null bits behind the loads (fastKeyBit)."""
+    monkeypatch.setenv("VX355_JIT", "sync")
+    rng = np.random.default_rng(4100 + num_keys)
+    n = 250_000
+    flags = [b"A", b"N", b"R"]
+    rf = [flags[i] for i in rng.integers(0, 3, n)]
+    ls = [bytes([c]) for c in rng.choice(list(b"FO"), n)]
+    lnum = rng.integers(1, 8, n).astype(np.int32)
+    mode = rng.integers(0, 7, n).astype(np.int32)
+    qty = rng.integers(1, 51, n).astype(np.float64)
+    ep = rng.integers(90000, 10500000, n).astype(np.float64) / 128
+    disc = rng.integers(0, 11, n).astype(np.float64) / 64
+    ship = rng.integers(8036, 10562, n).astype(np.int32)
+    cols = [rf, ls, lnum, mode, qty, ep, disc, ship]
+    valid = [None] * 8
+    if nullable:
+        valid[2] = rng.random(n) > 0.05
+        valid[3] = rng.random(n) > 0.02
+        valid[6] = rng.random(n) > 0.01
+    host = batch_of(cols, valid)
+    terms = [(7, abi.CMP_LE, 10471)]
+    projs = [[(5, 1.0, 0.0), (6, -1.0, 1.0)]]
+    keys = list(range(num_keys))
+    key_types = [abi.VARCHAR, abi.VARCHAR, abi.INTEGER, abi.INTEGER][:num_keys]
+    P = vx.PROJ
+    aggs = [(abi.AGG_SUM, 4, abi.DOUBLE), (abi.AGG_SUM, 5, abi.DOUBLE), (abi.AGG_SUM, P(0), abi.DOUBLE),
+            (abi.AGG_AVG, 4, abi.DOUBLE), (abi.AGG_AVG, 6, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    idx, proj, pnulls = oracle.filter_project(host, terms, projs, with_nulls=True)
+
+    def take(c, v):
+        picked = [c[i] for i in idx] if isinstance(c, list) else np.asarray(c)[idx]
+        return picked, (None if v is None else np.asarray(v)[idx])
+    picked = [take(c, v) for c, v in zip(cols, valid)]
+    ref = batch_of([p[0] for p in picked[:7]] + [proj[0]], [p[1] for p in picked[:7]] + [pnulls[0]])
+    ref_aggs = [(abi.AGG_SUM, 4, abi.DOUBLE), (abi.AGG_SUM, 5, abi.DOUBLE), (abi.AGG_SUM, 7, abi.DOUBLE),
+                (abi.AGG_AVG, 4, abi.DOUBLE), (abi.AGG_AVG, 6, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    for ignore in ((False, True) if nullable else (False,)):
+        exp, _ = run_agg(oracle, [ref], keys, key_types, ref_aggs, ignore_null_keys=ignore)
+        op = vx.Aggregation(keys, key_types, aggs, ignore_null_keys=ignore)
+        op.set_fused_input(terms, projs)
+        vx.profile_reset()
+        vx.profile_enable(True)
+        op.add_input(vx.to_device(host))
+        op.no_more_input()
+        got = vx.collect_output(op, 500)
+        vx.profile_enable(False)
+        assert_columns_equal(got, exp, op.kinds, what=f"{num_keys} keys, nullable={nullable}, ignore={ignore}")
+        names = vx.profile()
+        assert "k_agg_fast" in names and "k_agg_lds" not in names, names
+        assert len(exp[0][0]) >= 6 * 7 * (7 if num_keys == 4 else 1)
+
+
+@pytest.mark.parametrize("plan", ["c1", "two_keys_int_sums_min_max", "interpreting_kernel"])
+@pytest.mark.parametrize("scratch", ["1", "0"])
+def test_direct_index_flush_through_scratch_copies(oracle, vx, monkeypatch, plan, scratch):
+    """Many live keys in a direct-index table (BASELINE config 1: 1000 groups): the LDS kernels
+    store their reduced words per workgroup and k_lds_reduce folds them into the table instead of
+    one HBM atomic per (key, word, workgroup). Same results as the atomics flush
+    (VX355_AGG_SCRATCH_FLUSH=0), bit for bit - counts, 128-bit BIGINT totals with carries between
+    the copies, min / max, first-seen order - over several batches."""
+    monkeypatch.setenv("VX355_AGG_SCRATCH_FLUSH", scratch)
+    monkeypatch.setenv("VX355_JIT", "sync")
+    rng = np.random.default_rng(77)
+    n = 1 << 21
+    if plan == "c1":
+        cols = [rng.integers(0, 1000, n).astype(np.int64), _dyadic(rng, n)]
+        keys, key_types = [0], [abi.BIGINT]
+        aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+        valid = None
+    else:
+        big = rng.integers(-(1 << 40), 1 << 40, n).astype(np.int64)   # mixed signs: low words wrap, carries between copies
+        cols = [rng.integers(0, 20, n).astype(np.int64), rng.integers(-5, 5, n).astype(np.int32), big,
+                rng.standard_normal(n)]
+        keys, key_types = [0, 1], [abi.BIGINT, abi.INTEGER]
+        aggs = [(abi.AGG_SUM, 2, abi.BIGINT), (abi.AGG_MIN, 2, abi.BIGINT), (abi.AGG_MAX, 3, abi.DOUBLE),
+                (abi.AGG_COUNT, 3, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+        valid = [None, None, rng.random(n) > 0.1, rng.random(n) > 0.3]
+        if plan == "interpreting_kernel":
+            monkeypatch.setenv("VX355_AGG_NO_FAST", "1")
+    first = batch_of(cols, valid)
+    second = batch_of([c[::-1].copy() for c in cols], None if valid is None else
+                      [None if v is None else v[::-1].copy() for v in valid])
+    exp, _ = run_agg(oracle, [first, second], keys, key_types, aggs, max_rows=4096)
+    vx.profile_reset()
+    vx.profile_enable(True)
+    got, gop = run_agg(vx, [vx.to_device(first), vx.to_device(second)], keys, key_types, aggs, max_rows=4096)
+    vx.profile_enable(False)
+    assert_columns_equal(got, exp, gop.kinds, what=f"{plan} scratch={scratch}")
+    names = vx.profile()
+    assert ("k_lds_reduce" in names) == (scratch == "1"), names
+    assert ("k_agg_lds" in names) == (plan == "interpreting_kernel")

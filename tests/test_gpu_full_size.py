@@ -172,6 +172,72 @@ def test_q1_sf100_double_sums_within_one_ulp_of_exact_integer_reference(vx, torc
     print("Q1 SF100 worst ULP distance from the exact sums:", worst)
 
 
+def test_q1_sf100_four_keys_six_aggregates_on_the_specialised_kernel(vx, torch_gpu):
+    """BASELINE.json's wording of configs[1] at full size (bench.py --workload q1x4): 600 037 902 rows,
+    8 scan columns, 4 grouping keys (196 groups), 6 aggregates, fused filter. Counts and sum(qty)
+    bit exact against torch integer reductions, the other DOUBLE sums within 1 ULP of the exact
+    integer reference, avg = sum / count, groups in first-seen order, and the whole batch on
+    k_agg_fast (ahead-of-time instance: no hiprtc, no interpreting kernel)."""
+    torch = torch_gpu
+    import bench
+    n = 600_037_902
+    wl = bench.Q1FourKeys(torch, n, "cuda:0", 4321)
+    vx.profile_reset()
+    vx.profile_enable(True)
+    op = wl.operator(abi.STEP_SINGLE)
+    op.add_input(wl.scan)
+    op.no_more_input()
+    out = vx.collect_output(op, 1024)
+    vx.profile_enable(False)
+    names = vx.profile()
+    assert "k_agg_fast" in names and "k_agg_lds" not in names and "k_agg_global" not in names, names
+    c = wl.c
+    keep = c["ship"] <= bench.Q1_CUTOFF
+    code_all = ((c["rf"][:, 1].to(torch.int64) * 256 + c["ls"][:, 1].to(torch.int64)) * 16 +
+                c["lnum"].to(torch.int64)) * 16 + c["mode"].to(torch.int64)
+    code = code_all[keep]
+    groups, inverse, counts = torch.unique(code, return_inverse=True, return_counts=True)
+    ng = len(groups)
+    assert ng == 4 * 7 * 7
+    order = {int(g): i for i, g in enumerate(groups.tolist())}
+    rf, ls, lnum, mode = out[0][0], out[1][0], out[2][0], out[3][0]
+    assert len(rf) == ng
+    got_code = [((rf[i][0] * 256 + ls[i][0]) * 16 + int(lnum[i])) * 16 + int(mode[i]) for i in range(ng)]
+    row_of = [order[g] for g in got_code]
+    assert sorted(row_of) == list(range(ng))
+    # first-seen order (GroupingSet.cpp:828-839): the first passing row of every group, ascending
+    first_row = torch.full((ng,), n, dtype=torch.int64, device=code.device).scatter_reduce_(
+        0, inverse, torch.nonzero(keep).flatten(), reduce="amin")
+    assert [int(x) for x in torch.argsort(first_row).tolist()] == row_of
+    cnt = counts.tolist()
+    qty_sum = torch.zeros(ng, dtype=torch.int64, device=code.device).index_add_(
+        0, inverse, c["qty"][keep].to(torch.int64)).tolist()
+    # output columns: 4 sum(qty) 5 sum(ep) 6 sum(disc_price) 7 avg(qty) 8 avg(disc) 9 count(*)
+    for i in range(ng):
+        g = row_of[i]
+        assert int(out[9][0][i]) == cnt[g]
+        assert out[4][0][i] == float(qty_sum[g])
+        assert out[7][0][i] == float(qty_sum[g]) / cnt[g]
+    ep = c["ep"][keep]
+    disc = c["disc"][keep]
+    disc_price = (ep * 1.0 + 0.0) * (disc * -1.0 + 1.0)
+    worst = {}
+    for name, tensor, sum_col, avg_col in (("ep", ep, 5, None), ("disc_price", disc_price, 6, None),
+                                            ("disc", disc, None, 8)):
+        exact = exact_group_sums_torch(torch, tensor, inverse, ng)
+        for i in range(ng):
+            ex = exact[row_of[i]]
+            if sum_col is not None:
+                d = ulp_distance(np.array([out[sum_col][0][i]]), np.array([float(ex)]))[0]
+                worst[name] = max(worst.get(name, 0), d)
+                assert d <= 1, (name, i, out[sum_col][0][i], float(ex))
+            else:
+                d = ulp_distance(np.array([out[avg_col][0][i]]), np.array([float(ex / cnt[row_of[i]])]))[0]
+                worst["avg_" + name] = max(worst.get("avg_" + name, 0), d)
+                assert d <= 2, ("avg " + name, i)
+    print("Q1 4-key SF100 worst ULP distance from the exact sums:", worst)
+
+
 def test_q3_sf100_join_is_complete_and_every_pair_is_valid(vx, torch_gpu):
     """The dominant join of TPC-H Q3 at SF100: ~14.6 M build rows, ~323 M probe rows."""
     torch = torch_gpu

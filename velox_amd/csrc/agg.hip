@@ -510,6 +510,93 @@ __global__ __launch_bounds__(512, 4) void k_agg_fast(FastArgs a) {
   aggFastBody<S>(a);
 }
 
+// Second half of the scratch flush (ldsFlushScratch, agg_device.h): folds the workgroups' copies
+// scratch[copy][word][key] into the direct-index table. A block owns 64 consecutive (word, key)
+// elements; its 16 waves read them from every 16th copy (512-byte coalesced loads, ~numCopies / 16
+// independent loads per lane), the partial results meet in LDS and wave 0 applies the total to the
+// group row: one update per (key, word) of the table instead of one per (key, word) and workgroup.
+__global__ __launch_bounds__(1024) void k_lds_reduce(LdsPlan p, int32_t numCopies) {
+  __shared__ uint64_t part[16][64];
+  __shared__ uint64_t partLow[16][64];
+  const int R = static_cast<int>(p.capacity);
+  const int A = p.A;
+  const int64_t E = static_cast<int64_t>(R) * (A + 1);
+  const int l = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * 64 + l;
+  const bool in = e < E;
+  const int j = in ? static_cast<int>(e / R) : 0;
+  const int key = in ? static_cast<int>(e - static_cast<int64_t>(j) * R) : 0;
+  const int32_t kind = (!in || j == A) ? static_cast<int32_t>(ACC_MIN) : p.kind[j];  // first rows: a minimum
+  uint64_t v = accIdentity(kind);
+  uint64_t low = 0;  // ACC_SUM_I64_HI: running sum of the LOW word's copies, whose carries belong here
+  if (in) {
+    const uint64_t* src = p.scratch + e;
+#pragma unroll 4
+    for (int c = w; c < numCopies; c += 16) {
+      const uint64_t q = src[static_cast<int64_t>(c) * E];
+      if (kind == ACC_SUM_F64) {
+        v = static_cast<uint64_t>(__double_as_longlong(__longlong_as_double(static_cast<long long>(v)) +
+                                                       __longlong_as_double(static_cast<long long>(q))));
+      } else if (kind == ACC_MIN) {
+        v = q < v ? q : v;
+      } else if (kind == ACC_MAX) {
+        v = q > v ? q : v;
+      } else {
+        v += q;
+        if (kind == ACC_SUM_I64_HI) {
+          const uint64_t ql = src[static_cast<int64_t>(c) * E - R];
+          v += carryUnsigned(low, ql);
+          low += ql;
+        }
+      }
+    }
+  }
+  part[w][l] = v;
+  partLow[w][l] = low;
+  __syncthreads();
+  if (w != 0) {
+    return;
+  }
+  bool isNew = false;
+  if (in) {
+    for (int o = 1; o < 16; ++o) {
+      const uint64_t q = part[o][l];
+      if (kind == ACC_SUM_F64) {
+        v = static_cast<uint64_t>(__double_as_longlong(__longlong_as_double(static_cast<long long>(v)) +
+                                                       __longlong_as_double(static_cast<long long>(q))));
+      } else if (kind == ACC_MIN) {
+        v = q < v ? q : v;
+      } else if (kind == ACC_MAX) {
+        v = q > v ? q : v;
+      } else {
+        v += q;
+        if (kind == ACC_SUM_I64_HI) {
+          v += carryUnsigned(low, partLow[o][l]);
+          low += partLow[o][l];
+        }
+      }
+    }
+    uint64_t* g = p.table + static_cast<uint64_t>(key) * p.stride;
+    if (j == A) {
+      if (v != kNoRow) {
+        isNew = atomicMin(reinterpret_cast<unsigned long long*>(g + 1), static_cast<unsigned long long>(v)) == kNoRow;
+      }
+    } else if (v != accIdentity(kind)) {
+      // (a total equal to the identity changes nothing; keys nobody saw are not touched at all)
+      if (kind == ACC_SUM_I64) {
+        addPartial128Global(g + p.off[j], v, 0);
+      } else {
+        applyGlobal(g + p.off[j], kind == ACC_COUNT ? static_cast<int32_t>(ACC_SUM_I64_WRAP) : kind, v, p.counters);
+      }
+    }
+  }
+  const uint64_t m = ballot(isNew);
+  if (m != 0 && l == __ffsll(static_cast<long long>(m)) - 1) {
+    atomicAdd(&p.counters->numNewGroups, static_cast<uint32_t>(popc64(m)));
+  }
+}
+
 // What the host derives from a launch to pick an instantiation.
 struct FastSignature {
   int k0 = FK_NONE, k1 = FK_NONE, t0 = FK_NONE, t1 = FK_NONE, numLoads = 0, numAccs = 0;
@@ -519,10 +606,11 @@ struct FastSignature {
   uint32_t lk = 0;   // element types of the loaded columns (FastShape::LK)
   uint32_t msk = 0;  // accumulators with a mask column (FastShape::MSK)
   uint64_t ops = 0;  // what each accumulator does with its operand (FastShape::OPS)
+  uint32_t kx = kFastNoExtraKeys;  // kinds of the third and fourth key (FastShape::KX)
   bool operator==(const FastSignature& o) const {
     return k0 == o.k0 && k1 == o.k1 && t0 == o.t0 && t1 == o.t1 && numLoads == o.numLoads &&
         numAccs == o.numAccs && accLo == o.accLo && accHi == o.accHi && accEx == o.accEx && ind == o.ind &&
-        nul == o.nul && lk == o.lk && msk == o.msk && ops == o.ops;
+        nul == o.nul && lk == o.lk && msk == o.msk && ops == o.ops && kx == o.kx;
   }
 };
 
@@ -563,6 +651,12 @@ constexpr uint64_t kC1Lo = packAccs(accDesc(1, 0), accDesc(0));
     FastSignature{K0, K1, T0, T1, NL, NA, LO, HI, EX, IND, NUL, LK, MSK, OPS}, U,                       \
         &launchFast<FastShape<U, K0, K1, T0, T1, NL, NA, LO, HI, IND, NUL, EX, LK, MSK, OPS>>           \
   }
+// ... and with a third / fourth key (KX).
+#define VX_FAST_ENTRY_K(U, K0, K1, T0, T1, NL, NA, LO, HI, IND, NUL, EX, LK, MSK, OPS, KX)              \
+  FastEntry {                                                                                         \
+    FastSignature{K0, K1, T0, T1, NL, NA, LO, HI, EX, IND, NUL, LK, MSK, OPS, KX}, U,                   \
+        &launchFast<FastShape<U, K0, K1, T0, T1, NL, NA, LO, HI, IND, NUL, EX, LK, MSK, OPS, KX>>       \
+  }
 
 const FastEntry kFastTable[] = {
     VX_FAST_ENTRY(2, FK_VIEW, FK_VIEW, FK_I32, FK_NONE, 4, 6, kQ1Lo, kQ1Hi),
@@ -576,6 +670,11 @@ const FastEntry kFastTable[] = {
     //  * config 1 with nulls in v (the reference's *_halfnull benchmarks): sum(v), count(v), count(*)
     VX_FAST_ENTRY_X(4, FK_I64, FK_NONE, FK_NONE, FK_NONE, 1, 3, 0xff00fff0ff01ull, 0x0ull, 0x0u, 0x10u, 0x0ull, 0x0u, 0x0u,
                     0x0ull),
+    //  * BASELINE.json's wording of configs[1], "8-column scan, 4-key group-by with 6 aggregates": Q1 with
+    //    two more low-cardinality INTEGER keys (l_linenumber, a ship-mode code) and sum(qty), sum(ep),
+    //    sum(ep*(1-disc)), avg(qty), avg(disc), count(*): loads qty=0, ep=1, disc=2
+    VX_FAST_ENTRY_K(4, FK_VIEW, FK_VIEW, FK_I32, FK_NONE, 3, 5, kQ1Lo, packAccs(accDesc(1, 2)), 0x0u, 0x0u, 0x0ull, 0x0u,
+                    0x0u, 0x0ull, packExtraKeys(FK_I32, FK_I32)),
     //  * TPC-H Q1 with a nullable l_discount
     VX_FAST_ENTRY_X(4, FK_VIEW, FK_VIEW, FK_I32, FK_NONE, 4, 9, 0xf212ff11fff0ff01ull, 0xff2132103213f210ull, 0x0u, 0x40u,
                     0xff20ull, 0x0u, 0x0u, 0x0ull),
@@ -3169,6 +3268,7 @@ struct KeyState {
 };
 
 constexpr int64_t kMaxRangeSpan = (1LL << 59) - 1;  // exec/VectorHasher.h:139 kMaxRange
+constexpr size_t kCountersTemplateAt = 512;  // offset of the pristine Counters inside vx355_agg::countersBuf
 
 }  // namespace
 }  // namespace vx
@@ -3220,6 +3320,9 @@ struct vx355_agg {
   DevBuf countersBuf;
   DevBuf deferredBuf;
   DevBuf scratch, sortTmp;
+  DevBuf ldsScratch;            // per-workgroup copies of the scratch flush (ldsGrid)
+  bool ldsScratchFlush = true;  // VX355_AGG_SCRATCH_FLUSH=0: every LDS flush goes through HBM atomics
+  int64_t scratchFlushes = 0;
   // radix-partitioned path (high cardinality)
   DevBuf rpRecs1, rpRecs2, rpHist, rpOffsets, rpTiles, rpMisc, rpScan, rpLayout2;
   bool radixOptimistic = true;  // VX355_AGG_RADIX_OPTIMISTIC=0: level 2 always counts first
@@ -3281,6 +3384,7 @@ struct vx355_agg {
   // in one partition: 124 ms for 200 M rows over 1800 keys against 17 ms).
   bool preferNormalized = false;
   bool logShapes = false;
+  bool shapeLogged = false;
   int64_t deferCap = 1 << 20;
   int fastUnroll = 4;
 
@@ -3629,22 +3733,32 @@ void ensureBasics(vx355_agg& h) {
   }
   h.pattern.ensure(pat.size() * 8);
   copyIn(h.pattern.ptr(), pat.data(), VX355_MEM_HOST, pat.size() * 8);
-  h.countersBuf.ensure(sizeof(Counters));
-  rt.sync();  // 'pat' is a stack buffer: the upload must finish before it dies
-}
-
-void resetCounters(vx355_agg& h) {
+  // [0] the live counters, [kCountersTemplateAt] a pristine copy: a reset is one device-to-device
+  // copy queued on the stream (a pageable host source made every reset a blocking staged copy)
+  h.countersBuf.ensure(kCountersTemplateAt + sizeof(Counters));
   Counters c{};
   for (int k = 0; k < kMaxKeys; ++k) {
     c.keyMin[k] = INT64_MAX;
     c.keyMax[k] = INT64_MIN;
   }
-  copyIn(h.counters(), &c, VX355_MEM_HOST, sizeof(c));
+  copyIn(static_cast<char*>(h.countersBuf.ptr()) + kCountersTemplateAt, &c, VX355_MEM_HOST, sizeof(c));
+  rt.sync();  // 'pat' and 'c' are stack buffers: the uploads must finish before they die
 }
 
+void resetCounters(vx355_agg& h) {
+  copyIn(h.counters(), static_cast<const char*>(h.countersBuf.ptr()) + kCountersTemplateAt, VX355_MEM_DEVICE,
+         sizeof(Counters));
+}
+
+// Through the context's pinned mailbox (words 64...): a real DMA transfer behind the kernels of the
+// stream instead of the driver's pageable-destination path.
 Counters readCounters(vx355_agg& h) {
+  auto& rt = Runtime::get();
+  static_assert(64 * 8 + sizeof(Counters) <= Mailbox::kWords * 8, "the mailbox holds the counters");
+  HIP_OK(hipMemcpyAsync(rt.mail.host + 64, h.counters(), sizeof(Counters), hipMemcpyDeviceToHost, rt.stream));
+  rt.sync();
   Counters c;
-  copyOut(&c, VX355_MEM_HOST, h.counters(), sizeof(c));
+  std::memcpy(&c, rt.mail.host + 64, sizeof(c));
   return c;
 }
 
@@ -3849,9 +3963,9 @@ bool buildFastArgs(const AggArgs& c, const LdsPlan& plan, FastArgs* f, FastSigna
     if (wrapped < 0) {
       return false;
     }
-    sig->ind |= static_cast<uint32_t>(wrapped) << k;
+    sig->ind |= static_cast<uint32_t>(wrapped) << fastKeyBit(k);
     if (v.nulls) {
-      sig->nul |= 1u << k;
+      sig->nul |= 1u << fastKeyBit(k);
       f->keyNulls[k] = v.nulls;
     }
     int kind;
@@ -3869,7 +3983,11 @@ bool buildFastArgs(const AggArgs& c, const LdsPlan& plan, FastArgs* f, FastSigna
     } else {
       return false;
     }
-    (k == 0 ? sig->k0 : sig->k1) = kind;
+    if (k < 2) {
+      (k == 0 ? sig->k0 : sig->k1) = kind;
+    } else {
+      sig->kx = (sig->kx & ~(15u << (4 * (k - 2)))) | (static_cast<uint32_t>(kind) << (4 * (k - 2)));
+    }
     f->keyPtr[k] = v.values;
     f->range[k] = c.keys[k].range;
   }
@@ -4152,10 +4270,10 @@ hipFunction_t jitFastKernel(const FastSignature& sig, int unroll, bool log, bool
     return nullptr;
   }
   char key[256];
-  snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d,%lluull,%lluull,%uu,%uu,%lluull,%uu,%uu,%lluull", unroll, sig.k0,
+  snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d,%lluull,%lluull,%uu,%uu,%lluull,%uu,%uu,%lluull,%uu", unroll, sig.k0,
            sig.k1, sig.t0, sig.t1, sig.numLoads, sig.numAccs, static_cast<unsigned long long>(sig.accLo),
            static_cast<unsigned long long>(sig.accHi), sig.ind, sig.nul, static_cast<unsigned long long>(sig.accEx),
-           sig.lk, sig.msk, static_cast<unsigned long long>(sig.ops));
+           sig.lk, sig.msk, static_cast<unsigned long long>(sig.ops), sig.kx);
   // A loaded module belongs to one GPU.
   const std::string cacheKey = std::to_string(Runtime::get().device) + ":" + key;
   auto it = st.kernels.find(cacheKey);
@@ -4860,6 +4978,42 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
   ++h.radixLaunches;
 }
 
+// Grid of an LDS launch and how it flushes. Atomics: enough rows per workgroup that the flush (live
+// slots x words HBM atomics per workgroup, ~20 G/s chip-wide) stays a small fraction of the work.
+// Scratch (direct-index tables whose flush would retire > 256 K atomics - BASELINE config 1's 1000
+// groups x 4 words x 800 workgroups = 3 M, 0.15 ms on a 27-us problem): as many workgroups as fill
+// the chip, every one stores capacity x (words + 1) values, k_lds_reduce folds them.
+int ldsGrid(vx355_agg& h, LdsPlan& plan, size_t ldsBytes, int64_t rows, int threads, int unroll, int maxBlocksPerCu) {
+  auto& rt = Runtime::get();
+  const int blocksPerCu = std::max<int>(1, std::min<int>(maxBlocksPerCu, static_cast<int>((150 * 1024) / ldsBytes)));
+  const int64_t full = static_cast<int64_t>(rt.numCUs) * blocksPerCu;
+  const int64_t tile = static_cast<int64_t>(threads) * unroll;
+  const int64_t minRowsPerBlock = std::max<int64_t>(tile, 4LL * plan.S * plan.A);
+  const int64_t gridAtomic = std::max<int64_t>(1, std::min<int64_t>(ceilDiv(rows, minRowsPerBlock), full));
+  plan.scratch = nullptr;
+  if (h.ldsScratchFlush && plan.tableMode == MODE_ARRAY && plan.direct != 2) {
+    const int64_t live = plan.direct == 1 ? static_cast<int64_t>(plan.capacity)
+                                          : std::min<int64_t>(plan.S, std::max<int64_t>(h.numGroups, 1));
+    const int64_t gridScratch = std::max<int64_t>(1, std::min<int64_t>(ceilDiv(rows, tile), full));
+    const int64_t perCopy = static_cast<int64_t>(plan.capacity) * (plan.A + 1) * 8;
+    if (live * (plan.A + 1) * gridAtomic > (256 << 10) && perCopy * gridScratch <= (64LL << 20)) {
+      h.ldsScratch.ensure(static_cast<size_t>(perCopy * gridScratch) + 64);
+      plan.scratch = h.ldsScratch.as<uint64_t>();
+      return static_cast<int>(gridScratch);
+    }
+  }
+  return static_cast<int>(gridAtomic);
+}
+
+void ldsReduce(vx355_agg& h, const LdsPlan& plan, int grid) {
+  if (plan.scratch == nullptr) {
+    return;
+  }
+  const int64_t elements = static_cast<int64_t>(plan.capacity) * (plan.A + 1);
+  ++h.scratchFlushes;
+  VX_LAUNCH("k_lds_reduce", k_lds_reduce, static_cast<int>(ceilDiv(elements, 64)), 1024, 0, plan, grid);
+}
+
 void launchChunk(vx355_agg& h, AggArgs& a) {
   auto& rt = Runtime::get();
   size_t ldsBytes = 0;
@@ -4895,41 +5049,38 @@ void launchChunk(vx355_agg& h, AggArgs& a) {
     }
     if (fastClass) {
       if (const FastEntry* e = findFastEntry(sig, h.fastUnroll)) {
-        const int blocksPerCu =
-            std::max<int>(1, std::min<int>(4, static_cast<int>((150 * 1024) / ldsBytes)));
-        // Enough rows per workgroup that the LDS flush (slots x accumulators HBM
-        // atomics) stays a small fraction of the work.
-        const int64_t minRowsPerBlock = std::max<int64_t>(512 * e->unroll, 4LL * plan.S * plan.A);
-        int grid = static_cast<int>(std::max<int64_t>(
-            1, std::min<int64_t>(ceilDiv(a.numRows, minRowsPerBlock),
-                                 static_cast<int64_t>(rt.numCUs) * blocksPerCu)));
+        const int grid = ldsGrid(h, fa.plan, ldsBytes, a.numRows, 512, e->unroll, 4);
         e->launch(fa, grid, ldsBytes);
+        ldsReduce(h, fa.plan, grid);
         return;
       }
-      if (hipFunction_t fn = h.jitEnabled ? jitFastKernel(sig, h.fastUnroll, h.logShapes, h.jitAsync) : nullptr) {
-        const int blocksPerCu =
-            std::max<int>(1, std::min<int>(4, static_cast<int>((150 * 1024) / ldsBytes)));
-        const int64_t minRowsPerBlock = std::max<int64_t>(512 * h.fastUnroll, 4LL * plan.S * plan.A);
-        int grid = static_cast<int>(std::max<int64_t>(
-            1, std::min<int64_t>(ceilDiv(a.numRows, minRowsPerBlock),
-                                 static_cast<int64_t>(rt.numCUs) * blocksPerCu)));
-        launchJitFast(fn, fa, grid, ldsBytes);
-        ++h.jitLaunches;
-        return;
-      }
-      if (h.logShapes) {
-        // (the template arguments of FastShape after UNROLL, ready for kFastTable)
+      if (h.logShapes && !h.shapeLogged) {
+        // (the template arguments of FastShape after UNROLL, ready for kFastTable's VX_FAST_ENTRY_K)
+        h.shapeLogged = true;
         fprintf(stderr,
-                "vx355: no specialised kernel yet for FastShape<U, %d, %d, %d, %d, %d, %d, 0x%llxull, 0x%llxull, 0x%xu, "
-                "0x%xu, 0x%llxull, 0x%xu, 0x%xu, 0x%llxull>\n",
+                "vx355: plan shape outside the ahead-of-time table: FastShape<U, %d, %d, %d, %d, %d, %d, 0x%llxull, "
+                "0x%llxull, 0x%xu, 0x%xu, 0x%llxull, 0x%xu, 0x%xu, 0x%llxull, 0x%xu>\n",
                 sig.k0, sig.k1, sig.t0, sig.t1, sig.numLoads, sig.numAccs,
                 static_cast<unsigned long long>(sig.accLo), static_cast<unsigned long long>(sig.accHi), sig.ind, sig.nul,
-                static_cast<unsigned long long>(sig.accEx), sig.lk, sig.msk, static_cast<unsigned long long>(sig.ops));
+                static_cast<unsigned long long>(sig.accEx), sig.lk, sig.msk, static_cast<unsigned long long>(sig.ops),
+                sig.kx);
+      }
+      if (hipFunction_t fn = h.jitEnabled ? jitFastKernel(sig, h.fastUnroll, h.logShapes, h.jitAsync) : nullptr) {
+        const int grid = ldsGrid(h, fa.plan, ldsBytes, a.numRows, 512, h.fastUnroll, 4);
+        launchJitFast(fn, fa, grid, ldsBytes);
+        ldsReduce(h, fa.plan, grid);
+        ++h.jitLaunches;
+        return;
       }
     }
     la.a = a;
     int grid = static_cast<int>(std::min<int64_t>(ceilDiv(a.numRows, 1024), rt.numCUs * 2));
+    if (h.ldsScratchFlush) {
+      const int scratchGrid = ldsGrid(h, plan, ldsBytes, a.numRows, 1024, 1, 2);
+      grid = plan.scratch ? scratchGrid : grid;
+    }
     VX_LAUNCH("k_agg_lds", k_agg_lds, grid, 1024, ldsBytes, la);
+    ldsReduce(h, plan, grid);
   } else {
     if (h.denseNext || radixEligible(h, a)) {
       launchRadix(h, a);
@@ -5214,9 +5365,13 @@ void switchToGeneric(vx355_agg& h) {
 // so up to 2^32 grid multiples add up exactly in the 53-bit significand of 'hi'
 // whatever kernel, lane, workgroup or GPU adds them. A later value above 2^L is
 // accumulated plainly (splitDouble): it only costs accuracy, never correctness.
-void chooseSumGrids(vx355_agg& h, AggArgs& a, int64_t n) {
+void applySumStats(vx355_agg& h, AggArgs& a, const Counters& c);
+
+// deferRead: the caller launches the key statistics behind this kernel and reads the counters once
+// for both (applySumStats) - one stream synchronisation less on the first batch.
+bool chooseSumGrids(vx355_agg& h, AggArgs& a, int64_t n, bool deferRead = false) {
   if (h.sumGridsChosen || !h.exactSums) {
-    return;
+    return false;
   }
   h.sumGridsChosen = true;
   bool any = false;
@@ -5224,7 +5379,7 @@ void chooseSumGrids(vx355_agg& h, AggArgs& a, int64_t n) {
     any = any || a.accs[j].kind == ACC_SUM_F64;
   }
   if (!any) {
-    return;
+    return false;
   }
   AggArgs sa = a;
   sa.numRows = std::min<int64_t>(n, 1 << 16);
@@ -5232,7 +5387,14 @@ void chooseSumGrids(vx355_agg& h, AggArgs& a, int64_t n) {
   // few workgroups: every wave ends with atomics on the same handful of counter words, and one
   // address retires < 100 M atomics per second
   VX_LAUNCH("k_sum_stats", k_sum_stats, std::min(streamGrid(sa.numRows, 256), 64), 256, 0, sa);
-  Counters c = readCounters(h);
+  if (deferRead) {
+    return true;
+  }
+  applySumStats(h, a, readCounters(h));
+  return false;
+}
+
+void applySumStats(vx355_agg& h, AggArgs& a, const Counters& c) {
   for (int j = 0; j < a.numAccs; ++j) {
     if (a.accs[j].kind != ACC_SUM_F64) {
       continue;
@@ -5298,7 +5460,8 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
   a.stride = h.stride;
   a.counters = h.counters();
 
-  chooseSumGrids(h, a, n);
+  const bool keyStatsFollow = !h.generic && !h.tableReady && a.numKeys > 0;
+  const bool sumStatsPending = chooseSumGrids(h, a, n, keyStatsFollow);
   if (h.generic) {
     addInputGeneric(h, a, n);
     h.inputRows += n;
@@ -5308,7 +5471,9 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
   if (!h.tableReady) {
     // VectorHasher::analyze on a prefix of the first batch; later values that
     // fall outside are handled by the deferred-row path.
-    resetCounters(h);
+    if (!sumStatsPending) {
+      resetCounters(h);
+    }
     bool needGeneric = false;
     if (a.numKeys > 0) {
       StatsArgs sa{};
@@ -5326,6 +5491,9 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
                                         : std::min(streamGrid(sa.numRows, 256), rt.numCUs * 8),
                 256, 0, sa);
       Counters c = readCounters(h);
+      if (sumStatsPending) {
+        applySumStats(h, a, c);
+      }
       needGeneric = c.unmappable != 0;  // a string key longer than 7 bytes
       c.unmappable = 0;
       checkCounters(c);
@@ -6027,6 +6195,9 @@ void configureFromEnv(vx355_agg& h) {
   }
   if (const char* e = std::getenv("VX355_AGG_NO_FAST")) {
     h.disableFast = e[0] == '1';
+  }
+  if (const char* e = std::getenv("VX355_AGG_SCRATCH_FLUSH")) {
+    h.ldsScratchFlush = std::atoi(e) != 0;
   }
   if (const char* e = std::getenv("VX355_AGG_RADIX_SPARSE")) {
     h.radixSparse = std::atoi(e) != 0;

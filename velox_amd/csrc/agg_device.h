@@ -169,6 +169,11 @@ struct LdsPlan {
   int32_t pad;
   uint64_t rowBase;
   Counters* counters;
+  // Direct-index tables with many live keys (BASELINE config 1: 1000 groups): instead of one HBM
+  // atomic per (key, word) and WORKGROUP, every workgroup stores its reduced words side by side in
+  // scratch[workgroup][word][key] (plain coalesced stores) and k_lds_reduce folds the workgroups'
+  // copies into the table: the flush costs bytes, not atomics (3 M atomics -> 32 MB). nullptr = atomics.
+  uint64_t* scratch;
   int32_t kind[kMaxLdsAccs];
   int32_t off[kMaxLdsAccs];
 };
@@ -290,8 +295,77 @@ __device__ inline void ldsTouchFirst(const LdsState& st, int32_t slot, uint32_t 
   }
 }
 
+// The replicas of LDS word j of a slot, reduced (what one workgroup contributes to the group row).
+// ACC_SUM_I64 low words are unsigned partials: how often their sum wraps does not depend on the
+// order of the adds, so the thread of the HIGH word counts the carries of word j - 1 itself.
+__device__ inline uint64_t ldsReduceReplicas(const LdsPlan& p, const LdsState& st, int slot, int j) {
+  const int A = p.A, REP = p.REP;
+  const int32_t kind = p.kind[j];
+  const uint64_t* q = st.acc + (static_cast<size_t>(slot) * A + j) * REP;
+  uint64_t v = q[0];
+  if (kind == ACC_SUM_F64) {
+    double s = __longlong_as_double(static_cast<long long>(v));
+    for (int r = 1; r < REP; ++r) {
+      s += __longlong_as_double(static_cast<long long>(q[r]));
+    }
+    return static_cast<uint64_t>(__double_as_longlong(s));
+  }
+  if (kind == ACC_MIN) {
+    for (int r = 1; r < REP; ++r) {
+      v = q[r] < v ? q[r] : v;
+    }
+    return v;
+  }
+  if (kind == ACC_MAX) {
+    for (int r = 1; r < REP; ++r) {
+      v = q[r] > v ? q[r] : v;
+    }
+    return v;
+  }
+  for (int r = 1; r < REP; ++r) {
+    v += q[r];
+  }
+  if (kind == ACC_SUM_I64_HI) {
+    const uint64_t* lowWords = q - REP;  // word j - 1 of the same slot
+    uint64_t low = 0;
+    for (int r = 0; r < REP; ++r) {
+      v += carryUnsigned(low, lowWords[r]);
+      low += lowWords[r];
+    }
+  }
+  return v;
+}
+
+// Scratch flush (LdsPlan::scratch): element t = word * capacity + key of this workgroup's copy; keys
+// the workgroup never saw store the word's identity (and kNoRow as first row).
+__device__ inline void ldsFlushScratch(const LdsPlan& p, const LdsState& st) {
+  blockSync();
+  const int A = p.A;
+  const int R = static_cast<int>(p.capacity);
+  uint64_t* out = p.scratch + static_cast<size_t>(blockIdx.x) * R * (A + 1);
+  for (int t = threadIdx.x; t < R * (A + 1); t += blockDim.x) {
+    const int j = t / R;
+    const int key = t - j * R;
+    const int32_t slot = p.direct == 1 ? key : st.slotOf[key];
+    const uint32_t first = slot >= 0 ? st.slotFirst[slot] : 0xffffffffu;
+    uint64_t v;
+    if (first == 0xffffffffu) {
+      v = j == A ? kNoRow : accIdentity(p.kind[j]);
+    } else if (j == A) {
+      v = p.rowBase + static_cast<uint64_t>(first);
+    } else {
+      v = ldsReduceReplicas(p, st, slot, j);
+    }
+    out[t] = v;
+  }
+}
+
 // Flush: one (slot, accumulator) pair per thread; replicas reduced in LDS.
 __device__ inline void ldsFlush(const LdsPlan& p, const LdsState& st) {
+  if (p.scratch != nullptr) {
+    ldsFlushScratch(p, st);
+    return;
+  }
   blockSync();
   const int S = p.S, A = p.A, REP = p.REP;
   uint32_t live = *st.numSlots;
@@ -405,7 +479,7 @@ __device__ inline void applyLds(uint64_t* word, int32_t kind, uint64_t v, Counte
 // Comparison operators, constants, scales, offsets, ranges stay runtime values.
 // Shapes are instantiated ahead of time below (VX_FAST_SHAPES); a plan whose
 // shape is not in the table runs on the generic kernel.
-constexpr int kFastKeys = 2;
+constexpr int kFastKeys = 4;
 constexpr int kFastTerms = 2;
 constexpr int kFastAccs = 12;
 constexpr int kFastFactors = 3;
@@ -470,8 +544,18 @@ constexpr uint64_t packAccs(uint64_t a0 = 0, uint64_t a1 = 0, uint64_t a2 = 0, u
   return a0 | (a1 << 16) | (a2 << 32) | (a3 << 48);
 }
 
+// Bit of key k in the IND / NUL masks: keys 0 and 1 sit at bits 0 and 1 (terms at 2, 3, loads at
+// 4..11), keys 2 and 3 behind the loads at bits 12 and 13.
+__host__ __device__ constexpr int fastKeyBit(int k) { return k < 2 ? k : 10 + k; }
+// KX: kinds of the third and fourth key, four bits each (0xf = absent) - BASELINE's "4-key" Q1.
+constexpr uint32_t kFastNoExtraKeys = 0xffu;
+constexpr uint32_t packExtraKeys(int k2, int k3) {
+  return (static_cast<uint32_t>(k2) & 15u) | ((static_cast<uint32_t>(k3) & 15u) << 4);
+}
+
 template <int UNROLL, int K0, int K1, int T0, int T1, int NL, int NA, uint64_t ACC_LO, uint64_t ACC_HI,
-          uint32_t IND = 0, uint32_t NUL = 0, uint64_t ACC_EX = 0, uint32_t LK = 0, uint32_t MSK = 0, uint64_t OPS = 0>
+          uint32_t IND = 0, uint32_t NUL = 0, uint64_t ACC_EX = 0, uint32_t LK = 0, uint32_t MSK = 0, uint64_t OPS = 0,
+          uint32_t KX = kFastNoExtraKeys>
 struct FastShape {
   static constexpr int loadKind(int j) { return static_cast<int>((LK >> (2 * j)) & 3); }
   static constexpr bool masked(int j) { return (MSK >> j) & 1; }
@@ -479,13 +563,16 @@ struct FastShape {
   static constexpr int op(int j) { return static_cast<int>((OPS >> (4 * j)) & 15); }
   static constexpr bool intLoad(int j) { return loadKind(j) == 2 || loadKind(j) == 3; }
   static constexpr bool anyIntLoad = (LK & 0xaaaau) != 0;
-  // IND bit k: key k, bit 2 + t: filter term t, bit 4 + j: loaded column j is dictionary wrapped.
+  // IND bit fastKeyBit(k): key k, bit 2 + t: filter term t, bit 4 + j: loaded column j is dictionary wrapped.
   static constexpr bool indirect(int bit) { return (IND >> bit) & 1; }
   static constexpr bool anyIndirect = IND != 0;
   // NUL, same bit numbering: the column carries a null bitmap.
   static constexpr bool nullable(int bit) { return (NUL >> bit) & 1; }
   static constexpr int unroll = UNROLL;
-  static constexpr int keyKind(int k) { return k == 0 ? K0 : K1; }
+  static constexpr int extraKind(int nibble) { return nibble == 15 ? static_cast<int>(FK_NONE) : nibble; }
+  static constexpr int keyKind(int k) {
+    return k == 0 ? K0 : (k == 1 ? K1 : extraKind(static_cast<int>((KX >> (4 * (k - 2))) & 15u)));
+  }
   static constexpr int termKind(int t) { return t == 0 ? T0 : T1; }
   static constexpr int numLoads = NL;
   static constexpr int numAccs = NA;
@@ -600,18 +687,15 @@ __device__ inline void aggFastBody(const FastArgs& a) {
         rowi[u] = a.indices[rowc[u]];
       }
     }
+    staticFor<kFastKeys>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if constexpr (S::keyKind(k) != FK_NONE) {
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      if constexpr (S::keyKind(0) != FK_NONE) {
-        kraw[u][0] = fastLoadRaw<S::keyKind(0)>(a.keyPtr[0], S::indirect(0) ? rowi[u] : rowc[u]);
+        for (int u = 0; u < UNROLL; ++u) {
+          kraw[u][k] = fastLoadRaw<S::keyKind(k)>(a.keyPtr[k], S::indirect(fastKeyBit(k)) ? rowi[u] : rowc[u]);
+        }
       }
-    }
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      if constexpr (S::keyKind(1) != FK_NONE) {
-        kraw[u][1] = fastLoadRaw<S::keyKind(1)>(a.keyPtr[1], S::indirect(1) ? rowi[u] : rowc[u]);
-      }
-    }
+    });
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       if constexpr (S::termKind(0) != FK_NONE) {
@@ -642,16 +726,16 @@ __device__ inline void aggFastBody(const FastArgs& a) {
         }
       }
     });
-    // null flags of the nullable columns: bit (4 + j) of nul[u] set = load j is null, bit k = key
-    // k, bit 2 + t = filter input t (the 64 lanes of a wave share each bitmap word)
+    // null flags of the nullable columns: bit (4 + j) of nul[u] set = load j is null, bit
+    // fastKeyBit(k) = key k, bit 2 + t = filter input t (the 64 lanes of a wave share each bitmap word)
     uint32_t nul[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       nul[u] = 0;
       staticFor<kFastKeys>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
-        if constexpr (S::keyKind(k) != FK_NONE && S::nullable(k)) {
-          nul[u] |= ((a.keyNulls[k][rowc[u] >> 6] >> (rowc[u] & 63)) & 1) ? 0u : (1u << k);
+        if constexpr (S::keyKind(k) != FK_NONE && S::nullable(fastKeyBit(k))) {
+          nul[u] |= ((a.keyNulls[k][rowc[u] >> 6] >> (rowc[u] & 63)) & 1) ? 0u : (1u << fastKeyBit(k));
         }
       });
       staticFor<kFastTerms>([&](auto tc) {
@@ -694,7 +778,7 @@ __device__ inline void aggFastBody(const FastArgs& a) {
         constexpr int k = decltype(kc)::value;
         if constexpr (S::keyKind(k) != FK_NONE) {
           const int64_t v = fastKeyValue<S::keyKind(k)>(kraw[u][k]);
-          if (S::nullable(k) && ((nul[u] >> k) & 1)) {
+          if (S::nullable(fastKeyBit(k)) && ((nul[u] >> fastKeyBit(k)) & 1)) {
             live = live && !a.ignoreNullKeys;  // else: a null key is value id 0
           } else if (v < a.range[k].min || v > a.range[k].max) {
             if (live) {
