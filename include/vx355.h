@@ -550,8 +550,11 @@ int vx355_agg_get_output(
  * keeps the RowVectorPtr and drops it when vx355_agg_poll reports completed >= ticket.
  * vx355_agg_poll never blocks: submitted / completed ticket counts (needsInput = few in flight,
  * isBlocked = completed < submitted when the shim wants to wait). vx355_agg_wait blocks until the
- * queue is empty and returns the first failure among the batches since the last wait (its message
- * is then the calling thread's vx355_last_error(); batches behind a failed one are skipped).
+ * queue is empty and returns the first failure among the queued batches (its message is then the
+ * calling thread's vx355_last_error(); batches behind a failed one are skipped). The failure stays
+ * with the handle: every later wait, add_input(_async), no_more_input, get_output, flush ... returns
+ * it again until the handle is destroyed - the operator is short of input and must not produce a
+ * result quietly. (get_stats and poll stay usable.)
  * Every other entry point of the handle (add_input, no_more_input, get_output, flush, get_stats,
  * destroy ...) waits for the queue first, so mixing synchronous and asynchronous calls is safe and
  * ordered. The same three calls exist for HashBuild. */

@@ -1541,6 +1541,7 @@ def test_direct_index_flush_through_scratch_copies(oracle, vx, monkeypatch, plan
         aggs = [(abi.AGG_SUM, 2, abi.BIGINT), (abi.AGG_MIN, 2, abi.BIGINT), (abi.AGG_MAX, 3, abi.DOUBLE),
                 (abi.AGG_COUNT, 3, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
         valid = [None, None, rng.random(n) > 0.1, rng.random(n) > 0.3]
+        monkeypatch.setenv("VX355_AGG_SCRATCH_MIN_ATOMICS", "1")   # 200 groups would keep the atomics flush
         if plan == "interpreting_kernel":
             monkeypatch.setenv("VX355_AGG_NO_FAST", "1")
     first = batch_of(cols, valid)
@@ -1555,3 +1556,30 @@ def test_direct_index_flush_through_scratch_copies(oracle, vx, monkeypatch, plan
     names = vx.profile()
     assert ("k_lds_reduce" in names) == (scratch == "1"), names
     assert ("k_agg_lds" in names) == (plan == "interpreting_kernel")
+
+
+@pytest.mark.parametrize("slots_only", ["1", "0"])
+def test_later_batch_with_many_new_keys_overflows_the_lds_slots_and_is_replayed(oracle, vx, monkeypatch, slots_only):
+    """Few groups in an open-addressing table: the LDS kernels run with a hashed slot map and the
+    table is sized for workgroups x slots new groups per launch, not for a chunk of new groups
+    (LdsPlan::deferOverflow). The first batch shows 100 keys; the second brings 60 000 more. Its
+    workgroups run out of slots, their rows are deferred and replayed into a grown table: same
+    groups, sums, counts and first-seen order as the oracle; VX355_AGG_SLOTS_ONLY=0 (tables sized
+    for the chunk, overflow rows straight to HBM) gives the same answer."""
+    monkeypatch.setenv("VX355_JIT", "sync")
+    monkeypatch.setenv("VX355_AGG_COALESCE_ROWS", "0")
+    monkeypatch.setenv("VX355_AGG_SLOTS_ONLY", slots_only)
+    rng = np.random.default_rng(61)
+    few = rng.integers(0, 1 << 40, 100).astype(np.int64)
+    n1, n2 = 300_000, 1_500_000
+    k1 = few[rng.integers(0, 100, n1)]
+    k2 = np.where(rng.random(n2) < 0.06, rng.integers(0, 60_000, n2).astype(np.int64) * 7_919 + (1 << 41),
+                  few[rng.integers(0, 100, n2)])
+    batches = [batch_of([k1, _dyadic(rng, n1)]), batch_of([k2, _dyadic(rng, n2)])]
+    aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    exp, _ = run_agg(oracle, batches, [0], [abi.BIGINT], aggs, max_rows=100000)
+    got, op = run_agg(vx, [vx.to_device(b) for b in batches], [0], [abi.BIGINT], aggs, max_rows=100000)
+    assert_columns_equal(got, exp, op.kinds, what="slot overflow, slots_only=" + slots_only)
+    st = op.stats()
+    assert st.hash_mode == abi.MODE_NORMALIZED_KEY and st.num_groups == len(exp[0][0]) > 40_000
+    assert (st.deferred_rows > 10_000) == (slots_only == "1")

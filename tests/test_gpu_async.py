@@ -57,8 +57,13 @@ def test_a_failed_batch_is_reported_by_wait_and_poisons_the_ones_behind_it(vx):
         op.wait()
     assert e.value.status == abi.EINVAL
     assert op.poll() == (3, 3)
-    op.wait()                           # reported once
-    assert op.stats().input_rows == 1000   # the batch behind the failure was skipped
+    assert op.stats().input_rows == 1000   # the batch behind the failure was skipped (stats stay readable)
+    # the failure stays with the handle: the operator is short of input, so nothing may succeed quietly
+    for call in (op.wait, lambda: op.add_input_async(good[2]), lambda: op.add_input(good[2]), op.no_more_input,
+                 lambda: vx.collect_output(op, 100)):
+        with pytest.raises(vx.Vx355Error) as again:
+            call()
+        assert again.value.status == abi.EINVAL
 
 
 def test_join_build_async_input(oracle, vx):

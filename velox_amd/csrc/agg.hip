@@ -494,6 +494,8 @@ __global__ __launch_bounds__(1024) void k_agg_lds(LdsArgs args) {
               }
             }
           }
+        } else if (p.deferOverflow) {
+          defer = true;
         } else {
           updateGlobal(a, row, key, &newGroups);
         }
@@ -515,7 +517,11 @@ __global__ __launch_bounds__(512, 4) void k_agg_fast(FastArgs a) {
 // elements; its 16 waves read them from every 16th copy (512-byte coalesced loads, ~numCopies / 16
 // independent loads per lane), the partial results meet in LDS and wave 0 applies the total to the
 // group row: one update per (key, word) of the table instead of one per (key, word) and workgroup.
-__global__ __launch_bounds__(1024) void k_lds_reduce(LdsPlan p, int32_t numCopies) {
+// storeAll: the table has never been written (vx355_agg::tableVirgin) and one block column covers
+// every copy: the totals are STORED, identities included - the launch that would have initialised
+// the table (k_init_table) is not needed. Otherwise gridDim.y block columns share the copies and
+// meet in the table with atomics.
+__global__ __launch_bounds__(1024) void k_lds_reduce(LdsPlan p, int32_t numCopies, int32_t storeAll) {
   __shared__ uint64_t part[16][64];
   __shared__ uint64_t partLow[16][64];
   const int R = static_cast<int>(p.capacity);
@@ -532,8 +538,9 @@ __global__ __launch_bounds__(1024) void k_lds_reduce(LdsPlan p, int32_t numCopie
   uint64_t low = 0;  // ACC_SUM_I64_HI: running sum of the LOW word's copies, whose carries belong here
   if (in) {
     const uint64_t* src = p.scratch + e;
+    const int step = 16 * static_cast<int>(gridDim.y);
 #pragma unroll 4
-    for (int c = w; c < numCopies; c += 16) {
+    for (int c = static_cast<int>(blockIdx.y) * 16 + w; c < numCopies; c += step) {
       const uint64_t q = src[static_cast<int64_t>(c) * E];
       if (kind == ACC_SUM_F64) {
         v = static_cast<uint64_t>(__double_as_longlong(__longlong_as_double(static_cast<long long>(v)) +
@@ -578,7 +585,15 @@ __global__ __launch_bounds__(1024) void k_lds_reduce(LdsPlan p, int32_t numCopie
       }
     }
     uint64_t* g = p.table + static_cast<uint64_t>(key) * p.stride;
-    if (j == A) {
+    if (storeAll) {
+      if (j == A) {
+        g[0] = kEmpty;
+        g[1] = v;
+        isNew = v != kNoRow;
+      } else {
+        g[p.off[j]] = v;
+      }
+    } else if (j == A) {
       if (v != kNoRow) {
         isNew = atomicMin(reinterpret_cast<unsigned long long*>(g + 1), static_cast<unsigned long long>(v)) == kNoRow;
       }
@@ -2351,7 +2366,7 @@ __device__ inline bool genericGroupId(const GenericArgs& args, int64_t row, uint
     }
   }
   const uint64_t tag = hash >> 32;
-  uint64_t pos = hash & g.slotMask;
+  uint64_t pos = slotOfHash(hash, g.slotMask);
   uint32_t gid = kPendingGid;
   uint64_t probes = 0;
   uint32_t spins = 0;  // every wait on another lane's publish is bounded
@@ -2599,7 +2614,7 @@ __global__ __launch_bounds__(256) void k_generic_rehash(uint64_t* slots, uint64_
   for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < numGroups; id += step) {
     const uint64_t hash = hashStore[id];
     const unsigned long long word = ((hash >> 32) << 32) | (static_cast<uint64_t>(id) + 1);
-    uint64_t pos = hash & slotMask;
+    uint64_t pos = slotOfHash(hash, slotMask);
     while (atomicCAS(reinterpret_cast<unsigned long long*>(slots + pos), 0ULL, word) != 0) {
       pos = (pos + 1) & slotMask;
     }
@@ -2627,30 +2642,46 @@ __global__ __launch_bounds__(1024) void k_card_sample(AggArgs a, int64_t step, u
     count = 0;
   }
   blockSync();
-  for (int64_t i = threadIdx.x; i < a.numRows; i += blockDim.x) {
-    uint64_t key;
-    if (count >= kCardSetSize / 2 || normalizedKey(a, i * step, &key) != 0) {
-      continue;  // (dropped row, or a key outside the ranges the first statistics pass found)
+  // The sampled rows lie ~n / 16384 rows apart: every one of them is a cold line (and a cold page)
+  // in each key column. Eight rows' keys are fetched back to back before any of them is inserted,
+  // so that their misses overlap instead of queueing behind the set's atomics (0.21 -> ms on Q1).
+  constexpr int kBatch = 8;
+  for (int64_t base = threadIdx.x; base < a.numRows; base += static_cast<int64_t>(blockDim.x) * kBatch) {
+    uint64_t keys[kBatch];
+    bool use[kBatch];
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      const int64_t i = base + static_cast<int64_t>(u) * blockDim.x;
+      keys[u] = 0;
+      // (dropped row, or a key outside the ranges the first statistics pass found: not counted)
+      use[u] = i < a.numRows && normalizedKey(a, i * step, &keys[u]) == 0;
     }
-    // (open-addressing tables: 64-bit keys; 32 mixed bits tell them apart well enough for an estimate)
-    const uint32_t k32 = static_cast<uint32_t>(twangMix64(key) >> 7) & 0x7fffffffu;
-    uint32_t pos = static_cast<uint32_t>((key * 0x9E3779B97F4A7C15ULL) >> 40) & (kCardSetSize - 1);
-    for (int probes = 0; probes < 64; ++probes) {
-      const uint32_t seen = set[pos];
-      if (seen == k32) {
-        break;
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      if (!use[u] || count >= kCardSetSize / 2) {
+        continue;
       }
-      if (seen == 0xffffffffu) {
-        const uint32_t old = atomicCAS(&set[pos], 0xffffffffu, k32);
-        if (old == 0xffffffffu) {
-          atomicAdd(&count, 1u);
+      const uint64_t key = keys[u];
+      // (open-addressing tables: 64-bit keys; 32 mixed bits tell them apart well enough for an estimate)
+      const uint32_t k32 = static_cast<uint32_t>(twangMix64(key) >> 7) & 0x7fffffffu;
+      uint32_t pos = static_cast<uint32_t>((key * 0x9E3779B97F4A7C15ULL) >> 40) & (kCardSetSize - 1);
+      for (int probes = 0; probes < 64; ++probes) {
+        const uint32_t seen = set[pos];
+        if (seen == k32) {
           break;
         }
-        if (old == k32) {
-          break;
+        if (seen == 0xffffffffu) {
+          const uint32_t old = atomicCAS(&set[pos], 0xffffffffu, k32);
+          if (old == 0xffffffffu) {
+            atomicAdd(&count, 1u);
+            break;
+          }
+          if (old == k32) {
+            break;
+          }
         }
+        pos = (pos + 1) & (kCardSetSize - 1);
       }
-      pos = (pos + 1) & (kCardSetSize - 1);
     }
   }
   blockSync();
@@ -2659,15 +2690,77 @@ __global__ __launch_bounds__(1024) void k_card_sample(AggArgs a, int64_t step, u
   }
 }
 
-__global__ __launch_bounds__(256) void k_key_stats(StatsArgs a) {
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+// Distinct keys among the first kFirstRowsProbe rows (block 0 only; an LDS hash set over a mix of the
+// keys' int64 images): with a few hundred of them among so few rows, lane-shared LDS accumulators
+// will not pile up on a handful of addresses, and a direct LDS layout can be chosen for the whole
+// first batch without the small probing chunk that otherwise counts the live groups first.
+constexpr int kFirstRowsProbe = 2048;
+__device__ inline void firstRowsDistinct(const KeyArg* keys, int32_t numKeys, int64_t numRows, Counters* counters) {
+  __shared__ uint64_t set[2 * kFirstRowsProbe];
+  __shared__ uint32_t distinct;
+  for (int i = threadIdx.x; i < 2 * kFirstRowsProbe; i += blockDim.x) {
+    set[i] = ~0ULL;
+  }
+  if (threadIdx.x == 0) {
+    distinct = 0;
+  }
+  blockSync();
+  const int64_t rows = numRows < kFirstRowsProbe ? numRows : kFirstRowsProbe;
+  for (int64_t row = threadIdx.x; row < rows; row += blockDim.x) {
+    uint64_t h = 0x51ed270b27b4f3cfULL;
+    for (int k = 0; k < numKeys; ++k) {
+      const ColView& c = keys[k].col;
+      uint64_t v = 0x7ff8dead00000000ULL;  // null
+      if (!colIsNull(c, row)) {
+        KeyRange all;
+        all.min = INT64_MIN;
+        all.max = INT64_MAX;
+        int64_t id;
+        bool mappable;
+        valueIdAt(c, colIndex(c, row), all, &id, &mappable);
+        v = static_cast<uint64_t>(id);
+      }
+      h = hashMix(h, v);
+    }
+    h &= ~(1ULL << 63);  // never the empty marker
+    uint32_t pos = static_cast<uint32_t>(h >> 20) & (2 * kFirstRowsProbe - 1);
+    for (int probes = 0; probes < 2 * kFirstRowsProbe; ++probes) {
+      const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&set[pos]), ~0ULL, h);
+      if (old == ~0ULL) {
+        atomicAdd(&distinct, 1u);
+        break;
+      }
+      if (old == h) {
+        break;
+      }
+      pos = (pos + 1) & (2 * kFirstRowsProbe - 1);
+    }
+  }
+  blockSync();
+  if (threadIdx.x == 0) {
+    counters->firstRowsDistinct = distinct;
+  }
+}
+
+__device__ inline void keyStatsBody(const KeyArg* keys, int32_t numKeys, int64_t numRows, Counters* counters,
+                                    int block, int numBlocks) {
+  struct {
+    const KeyArg* keys;
+    int32_t numKeys;
+    int64_t numRows;
+    Counters* counters;
+  } a{keys, numKeys, numRows, counters};
+  if (block == 0) {
+    firstRowsDistinct(keys, numKeys, numRows, counters);
+  }
+  const int64_t stride = static_cast<int64_t>(numBlocks) * blockDim.x;
   int64_t mn[kMaxKeys], mx[kMaxKeys];
   for (int k = 0; k < kMaxKeys; ++k) {
     mn[k] = INT64_MAX;
     mx[k] = INT64_MIN;
   }
   bool unmappable = false;
-  for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < a.numRows;
+  for (int64_t row = static_cast<int64_t>(block) * blockDim.x + threadIdx.x; row < a.numRows;
        row += stride) {
     for (int k = 0; k < a.numKeys; ++k) {
       const ColView& c = a.keys[k].col;
@@ -2724,16 +2817,20 @@ __global__ __launch_bounds__(256) void k_key_stats(StatsArgs a) {
   }
 }
 
+__global__ __launch_bounds__(256) void k_key_stats(StatsArgs a) {
+  keyStatsBody(a.keys, a.numKeys, a.numRows, a.counters, blockIdx.x, gridDim.x);
+}
+
 // Largest |input| of every DOUBLE sum over the analysed prefix: fixes the grid
 // of the hi/lo split (AccArg::splitM).
-__global__ __launch_bounds__(256) void k_sum_stats(AggArgs a) {
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+__device__ inline void sumStatsBody(const AggArgs& a, int64_t numRows, int block, int numBlocks) {
+  const int64_t stride = static_cast<int64_t>(numBlocks) * blockDim.x;
   uint64_t mx[kMaxAccs];
 #pragma unroll
   for (int j = 0; j < kMaxAccs; ++j) {
     mx[j] = 0;
   }
-  for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < a.numRows;
+  for (int64_t row = static_cast<int64_t>(block) * blockDim.x + threadIdx.x; row < numRows;
        row += stride) {
     if (a.numTerms && !evalFilter(a.terms, a.numTerms, row)) {
       continue;
@@ -2762,6 +2859,21 @@ __global__ __launch_bounds__(256) void k_sum_stats(AggArgs a) {
         atomicMax(reinterpret_cast<unsigned long long*>(&a.counters->sumMax[j]), m);
       }
     }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_sum_stats(AggArgs a) {
+  sumStatsBody(a, a.numRows, blockIdx.x, gridDim.x);
+}
+
+// Both statistics passes of an operator's first batch in ONE launch (two tiny latency-bound kernels
+// in a row cost more in launch gaps than in work): blocks [0, keyBlocks) analyse the keys of the
+// first keyRows rows, the others the DOUBLE sums' inputs of the first a.numRows rows.
+__global__ __launch_bounds__(256) void k_first_stats(AggArgs a, int64_t keyRows, int32_t keyBlocks) {
+  if (static_cast<int32_t>(blockIdx.x) < keyBlocks) {
+    keyStatsBody(a.keys, a.numKeys, keyRows, a.counters, blockIdx.x, keyBlocks);
+  } else {
+    sumStatsBody(a, a.numRows, static_cast<int>(blockIdx.x) - keyBlocks, static_cast<int>(gridDim.x) - keyBlocks);
   }
 }
 
@@ -2895,6 +3007,67 @@ __global__ __launch_bounds__(256) void k_collect(const uint64_t* table, uint64_t
       }
       base += popc64(m);
     }
+  }
+}
+
+// Small tables (BASELINE configs 1 and 2: a few to a few thousand groups): live rows collected and
+// put into first-seen order by ONE workgroup - LDS list, bitonic sort on the first-row words (they
+// are distinct: a row belongs to one group) - instead of k_collect + a count read-back + a
+// device-wide radix sort: no stream synchronisation between noMoreInput and the output page.
+constexpr int kSmallSortMax = 4096;
+__global__ __launch_bounds__(1024) void k_collect_sort_small(const uint64_t* table, uint32_t rows, int32_t stride,
+                                                              uint32_t* orderOut, uint32_t* found) {
+  __shared__ uint64_t keys[kSmallSortMax];
+  __shared__ uint32_t vals[kSmallSortMax];
+  __shared__ uint32_t count;
+  if (threadIdx.x == 0) {
+    count = 0;
+  }
+  blockSync();
+  for (uint32_t r = threadIdx.x; r < rows; r += blockDim.x) {
+    const uint64_t first = table[static_cast<uint64_t>(r) * stride + 1];
+    if (first != kNoRow) {
+      const uint32_t p = atomicAdd(&count, 1u);
+      if (p < static_cast<uint32_t>(kSmallSortMax)) {
+        keys[p] = first;
+        vals[p] = r;
+      }
+    }
+  }
+  blockSync();
+  const uint32_t n = count < static_cast<uint32_t>(kSmallSortMax) ? count : static_cast<uint32_t>(kSmallSortMax);
+  uint32_t m = 2;
+  while (m < n) {
+    m <<= 1;
+  }
+  for (uint32_t i = n + threadIdx.x; i < m; i += blockDim.x) {
+    keys[i] = ~0ULL;
+    vals[i] = ~0u;
+  }
+  blockSync();
+  for (uint32_t k = 2; k <= m; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+        const uint32_t o = i ^ j;
+        if (o > i) {
+          const uint64_t a = keys[i], b = keys[o];
+          if ((a > b) == ((i & k) == 0)) {
+            keys[i] = b;
+            keys[o] = a;
+            const uint32_t t = vals[i];
+            vals[i] = vals[o];
+            vals[o] = t;
+          }
+        }
+      }
+      blockSync();
+    }
+  }
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    orderOut[i] = vals[i];
+  }
+  if (threadIdx.x == 0) {
+    *found = count;
   }
 }
 
@@ -3323,6 +3496,7 @@ struct vx355_agg {
   DevBuf ldsScratch;            // per-workgroup copies of the scratch flush (ldsGrid)
   bool ldsScratchFlush = true;  // VX355_AGG_SCRATCH_FLUSH=0: every LDS flush goes through HBM atomics
   int64_t scratchFlushes = 0;
+  int64_t scratchMinAtomics = 256 << 10;  // VX355_AGG_SCRATCH_MIN_ATOMICS: flushes below this many HBM atomics keep them
   // radix-partitioned path (high cardinality)
   DevBuf rpRecs1, rpRecs2, rpHist, rpOffsets, rpTiles, rpMisc, rpScan, rpLayout2;
   bool radixOptimistic = true;  // VX355_AGG_RADIX_OPTIMISTIC=0: level 2 always counts first
@@ -3354,6 +3528,7 @@ struct vx355_agg {
   DevBuf orderKeys, orderVals, orderKeys2, orderVals2;
   const uint32_t* order = nullptr;
   int64_t numOutput = -1;  // set by finalize
+  int64_t collectCheck = -1;  // groups k_collect_sort_small must have found (its count sits behind 'order')
   int64_t outputCursor = 0;
   bool noMoreInput = false;
   bool unorderedOutput = false;  // VX355_AGG_UNORDERED_OUTPUT: no first-seen sort
@@ -3377,12 +3552,15 @@ struct vx355_agg {
   // kernels run with a hashed key -> slot map instead of handing every row to HBM atomics.
   bool cardSampled = false;   // (VX355_AGG_LDS_HASHED=0 sets it up front: no sample, no hashed map)
   int64_t sampledGroups = -1;
+  int64_t firstRowsDistinct = 0;  // distinct keys among the first 2048 rows of the first batch (k_key_stats)
   // The sample found few keys (it did not saturate) in a key range far wider than the LDS kernels'
   // direct map: the operator keeps an open-addressing table instead of a direct-index one whose
   // rows would be 99.99 % empty - no multi-GB table to initialise and to scan for live rows, and the
   // radix path partitions by hash (rows spread evenly) instead of by key range (all rows of a key
   // in one partition: 124 ms for 200 M rows over 1800 keys against 17 ms).
   bool preferNormalized = false;
+  bool slotsOnlyTables = true;   // VX355_AGG_SLOTS_ONLY=0: open-addressing tables always sized for a chunk of new groups
+  bool slotsOnlyLaunch = false;  // the next launchChunk defers the rows of workgroups that run out of LDS slots
   bool logShapes = false;
   bool shapeLogged = false;
   int64_t deferCap = 1 << 20;
@@ -3723,7 +3901,11 @@ void ensureBasics(vx355_agg& h) {
   if (h.pattern.ptr()) {
     return;
   }
-  std::vector<uint64_t> pat(h.stride);
+  // Both uploads start in the context's pinned mailbox (words 128... and 192...: nothing else
+  // writes them, and the stream is drained whenever an entry point returns), so neither needs a
+  // stream synchronisation to protect a stack buffer.
+  static_assert(2 + kMaxLdsAccs <= 64 && 192 * 8 + sizeof(Counters) <= Mailbox::kWords * 8, "mailbox layout");
+  uint64_t* pat = rt.mail.host + 128;
   pat[0] = kEmpty;
   pat[1] = kNoRow;
   for (size_t i = 0; i < h.phys.size(); ++i) {
@@ -3731,8 +3913,8 @@ void ensureBasics(vx355_agg& h) {
       pat[2 + h.wordOf[i]] = accIdentity(h.phys[i].kind);
     }
   }
-  h.pattern.ensure(pat.size() * 8);
-  copyIn(h.pattern.ptr(), pat.data(), VX355_MEM_HOST, pat.size() * 8);
+  h.pattern.ensure(static_cast<size_t>(h.stride) * 8);
+  copyIn(h.pattern.ptr(), pat, VX355_MEM_HOST, static_cast<size_t>(h.stride) * 8);
   // [0] the live counters, [kCountersTemplateAt] a pristine copy: a reset is one device-to-device
   // copy queued on the stream (a pageable host source made every reset a blocking staged copy)
   h.countersBuf.ensure(kCountersTemplateAt + sizeof(Counters));
@@ -3741,8 +3923,8 @@ void ensureBasics(vx355_agg& h) {
     c.keyMin[k] = INT64_MAX;
     c.keyMax[k] = INT64_MIN;
   }
-  copyIn(static_cast<char*>(h.countersBuf.ptr()) + kCountersTemplateAt, &c, VX355_MEM_HOST, sizeof(c));
-  rt.sync();  // 'pat' and 'c' are stack buffers: the uploads must finish before they die
+  std::memcpy(rt.mail.host + 192, &c, sizeof(c));
+  copyIn(static_cast<char*>(h.countersBuf.ptr()) + kCountersTemplateAt, rt.mail.host + 192, VX355_MEM_HOST, sizeof(c));
 }
 
 void resetCounters(vx355_agg& h) {
@@ -3798,8 +3980,10 @@ void rebuildTable(vx355_agg& h, uint64_t extraGroups) {
   DevBuf fresh;
   // An empty direct-index table beyond the LDS path: leave it unwritten, the first launch is
   // most likely a radix fold that stores every row itself (else settleTable).
-  const bool virgin = d.mode == MODE_ARRAY && newCap > 8192 && h.radixMinRows >= 0 && h.numGroups == 0 &&
-      !h.keys.empty();
+  // (The same for a small one when the LDS kernels may flush through scratch copies: k_lds_reduce
+  // then stores every word of every row.)
+  const bool virgin = d.mode == MODE_ARRAY && h.numGroups == 0 && !h.keys.empty() &&
+      (newCap > 8192 ? h.radixMinRows >= 0 : h.ldsScratchFlush);
   if (virgin) {
     fresh.ensure(static_cast<size_t>(newCap) * h.stride * 8 + 64);
   } else {
@@ -3826,8 +4010,8 @@ void rebuildTable(vx355_agg& h, uint64_t extraGroups) {
     ra.counters = h.counters();
     VX_LAUNCH("k_rekey", k_rekey, streamGrid(static_cast<int64_t>(h.capacity), 256), 256, 0, ra);
     ++h.numRehashes;
+    rt.sync();  // (k_rekey reads the old table, which the assignment below releases)
   }
-  rt.sync();
   h.table = std::move(fresh);
   h.tableVirgin = virgin;
   h.tableDense = false;
@@ -3857,7 +4041,9 @@ bool chooseLds(const vx355_agg& h, int numAccs, LdsPlan* plan, size_t* ldsBytes)
     if (h.sampledGroups < 0 || groups > kLdsHashedMaxGroups) {
       return false;
     }
-    const uint64_t S = nextPow2(std::max<uint64_t>(16, 2 * static_cast<uint64_t>(groups)));
+    // (slots are handed out one by one, so a quarter of headroom over the estimate is plenty; the
+    // map keeps a load below 1/4; a workgroup that still runs out defers its rows)
+    const uint64_t S = nextPow2(std::max<uint64_t>(16, static_cast<uint64_t>(groups + groups / 4 + 8)));
     const uint64_t M = 4 * S;
     auto bytes = [&](int rep) {
       return (((M + 2 * S + 2) * 4 + 15) & ~static_cast<size_t>(15)) + S * 8 + S * accBytes * rep;
@@ -3866,7 +4052,8 @@ bool chooseLds(const vx355_agg& h, int numAccs, LdsPlan* plan, size_t* ldsBytes)
     // take one CU's worth (128 KB, one workgroup per CU): still far ahead of one HBM atomic per row
     int rep = 0;
     for (int r = 64; r >= 1; r >>= 1) {
-      if (bytes(r) <= (r == 1 ? 128 * 1024 : budget)) {
+      // (never beyond what a workgroup of this device may allocate: 160 KB on gfx950, 64 KB elsewhere)
+      if (bytes(r) <= (r == 1 ? std::min<size_t>(128 * 1024, Runtime::get().ldsPerBlock) : budget)) {
         rep = r;
         break;
       }
@@ -4996,7 +5183,7 @@ int ldsGrid(vx355_agg& h, LdsPlan& plan, size_t ldsBytes, int64_t rows, int thre
                                           : std::min<int64_t>(plan.S, std::max<int64_t>(h.numGroups, 1));
     const int64_t gridScratch = std::max<int64_t>(1, std::min<int64_t>(ceilDiv(rows, tile), full));
     const int64_t perCopy = static_cast<int64_t>(plan.capacity) * (plan.A + 1) * 8;
-    if (live * (plan.A + 1) * gridAtomic > (256 << 10) && perCopy * gridScratch <= (64LL << 20)) {
+    if (live * (plan.A + 1) * gridAtomic > h.scratchMinAtomics && perCopy * gridScratch <= (64LL << 20)) {
       h.ldsScratch.ensure(static_cast<size_t>(perCopy * gridScratch) + 64);
       plan.scratch = h.ldsScratch.as<uint64_t>();
       return static_cast<int>(gridScratch);
@@ -5005,13 +5192,28 @@ int ldsGrid(vx355_agg& h, LdsPlan& plan, size_t ldsBytes, int64_t rows, int thre
   return static_cast<int>(gridAtomic);
 }
 
-void ldsReduce(vx355_agg& h, const LdsPlan& plan, int grid) {
+// Before an LDS launch: the table must be initialised - unless the launch flushes through scratch
+// copies into a table nobody has written (every word of every row is then stored by k_lds_reduce).
+bool ldsPrepareTable(vx355_agg& h, const LdsPlan& plan) {
+  // (direct slots only: with a compact map a workgroup that runs out of slots updates the table itself)
+  const bool storeAll = plan.scratch != nullptr && h.tableVirgin && plan.A == h.stride - 2 && plan.direct == 1;
+  if (!storeAll) {
+    settleTable(h);
+  }
+  return storeAll;
+}
+
+void ldsReduce(vx355_agg& h, const LdsPlan& plan, int grid, bool storeAll) {
   if (plan.scratch == nullptr) {
     return;
   }
   const int64_t elements = static_cast<int64_t>(plan.capacity) * (plan.A + 1);
+  const int tiles = static_cast<int>(ceilDiv(elements, 64));
+  // few (word, key) tiles: several block columns share the copies so that the chip is busy
+  int columns = storeAll ? 1 : std::max(1, std::min({4, grid / 64, (Runtime::get().numCUs * 2) / std::max(1, tiles)}));
   ++h.scratchFlushes;
-  VX_LAUNCH("k_lds_reduce", k_lds_reduce, static_cast<int>(ceilDiv(elements, 64)), 1024, 0, plan, grid);
+  VX_LAUNCH("k_lds_reduce", k_lds_reduce, dim3(tiles, columns), 1024, 0, plan, grid, storeAll ? 1 : 0);
+  h.tableVirgin = false;
 }
 
 void launchChunk(vx355_agg& h, AggArgs& a) {
@@ -5032,7 +5234,6 @@ void launchChunk(vx355_agg& h, AggArgs& a) {
     }
   }
   if (chooseLds(h, numWords, &la.plan, &ldsBytes)) {
-    settleTable(h);
     h.pairsComplete = false;
     LdsPlan& plan = la.plan;
     plan.table = a.table;
@@ -5040,6 +5241,8 @@ void launchChunk(vx355_agg& h, AggArgs& a) {
     plan.rowBase = a.rowBase;
     plan.counters = a.counters;
     plan.tableMode = a.mode;
+    plan.deferOverflow = (h.slotsOnlyLaunch && a.mode == MODE_NORMALIZED && plan.direct == 2 && !a.rowList &&
+                          !a.rescanOld) ? 1 : 0;
     FastArgs fa;
     FastSignature sig;
     const bool fastClass = !h.disableFast && buildFastArgs(a, plan, &fa, &sig);
@@ -5050,8 +5253,9 @@ void launchChunk(vx355_agg& h, AggArgs& a) {
     if (fastClass) {
       if (const FastEntry* e = findFastEntry(sig, h.fastUnroll)) {
         const int grid = ldsGrid(h, fa.plan, ldsBytes, a.numRows, 512, e->unroll, 4);
+        const bool storeAll = ldsPrepareTable(h, fa.plan);
         e->launch(fa, grid, ldsBytes);
-        ldsReduce(h, fa.plan, grid);
+        ldsReduce(h, fa.plan, grid, storeAll);
         return;
       }
       if (h.logShapes && !h.shapeLogged) {
@@ -5067,8 +5271,9 @@ void launchChunk(vx355_agg& h, AggArgs& a) {
       }
       if (hipFunction_t fn = h.jitEnabled ? jitFastKernel(sig, h.fastUnroll, h.logShapes, h.jitAsync) : nullptr) {
         const int grid = ldsGrid(h, fa.plan, ldsBytes, a.numRows, 512, h.fastUnroll, 4);
+        const bool storeAll = ldsPrepareTable(h, fa.plan);
         launchJitFast(fn, fa, grid, ldsBytes);
-        ldsReduce(h, fa.plan, grid);
+        ldsReduce(h, fa.plan, grid, storeAll);
         ++h.jitLaunches;
         return;
       }
@@ -5079,8 +5284,9 @@ void launchChunk(vx355_agg& h, AggArgs& a) {
       const int scratchGrid = ldsGrid(h, plan, ldsBytes, a.numRows, 1024, 1, 2);
       grid = plan.scratch ? scratchGrid : grid;
     }
+    const bool storeAll = ldsPrepareTable(h, plan);
     VX_LAUNCH("k_agg_lds", k_agg_lds, grid, 1024, ldsBytes, la);
-    ldsReduce(h, plan, grid);
+    ldsReduce(h, plan, grid, storeAll);
   } else {
     if (h.denseNext || radixEligible(h, a)) {
       launchRadix(h, a);
@@ -5346,8 +5552,8 @@ void switchToGeneric(vx355_agg& h) {
     ta.g.gidCounter = h.gCounter.as<uint32_t>();
     VX_LAUNCH("k_to_generic", k_to_generic, streamGrid(static_cast<int64_t>(h.capacity), 256), 256, 0, ta);
     ++h.numRehashes;
+    rt.sync();  // (k_rekey reads the old table, which the assignment below releases)
   }
-  rt.sync();
   h.table = std::move(fresh);
   h.tableVirgin = false;
   h.capacity = newMax;
@@ -5381,15 +5587,15 @@ bool chooseSumGrids(vx355_agg& h, AggArgs& a, int64_t n, bool deferRead = false)
   if (!any) {
     return false;
   }
+  if (deferRead) {
+    return true;  // the caller runs k_first_stats: key statistics and these in one launch
+  }
   AggArgs sa = a;
   sa.numRows = std::min<int64_t>(n, 1 << 16);
   resetCounters(h);
   // few workgroups: every wave ends with atomics on the same handful of counter words, and one
   // address retires < 100 M atomics per second
   VX_LAUNCH("k_sum_stats", k_sum_stats, std::min(streamGrid(sa.numRows, 256), 64), 256, 0, sa);
-  if (deferRead) {
-    return true;
-  }
   applySumStats(h, a, readCounters(h));
   return false;
 }
@@ -5471,26 +5677,32 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
   if (!h.tableReady) {
     // VectorHasher::analyze on a prefix of the first batch; later values that
     // fall outside are handled by the deferred-row path.
-    if (!sumStatsPending) {
-      resetCounters(h);
-    }
+    resetCounters(h);
     bool needGeneric = false;
     if (a.numKeys > 0) {
-      StatsArgs sa{};
-      sa.numKeys = a.numKeys;
-      for (int k = 0; k < a.numKeys; ++k) {
-        sa.keys[k] = a.keys[k];
-      }
       // Small first batches are analysed completely (no range widening later for
       // them); large ones by a 256 K-row prefix.
-      sa.numRows = n <= (8 << 20) ? n : (1 << 18);
-      sa.counters = h.counters();
+      const int64_t keyRows = n <= (8 << 20) ? n : (1 << 18);
       // (small prefixes only: a whole batch of up to 8 M rows wants the chip)
-      VX_LAUNCH("k_key_stats", k_key_stats,
-                sa.numRows <= (1 << 18) ? std::min(streamGrid(sa.numRows, 256), 64)
-                                        : std::min(streamGrid(sa.numRows, 256), rt.numCUs * 8),
-                256, 0, sa);
+      const int keyBlocks = keyRows <= (1 << 18) ? std::min(streamGrid(keyRows, 256), 64)
+                                                 : std::min(streamGrid(keyRows, 256), rt.numCUs * 8);
+      if (sumStatsPending) {
+        AggArgs sa = a;
+        sa.numRows = std::min<int64_t>(n, 1 << 16);
+        VX_LAUNCH("k_first_stats", k_first_stats, keyBlocks + std::min(streamGrid(sa.numRows, 256), 64), 256, 0, sa,
+                  keyRows, keyBlocks);
+      } else {
+        StatsArgs sa{};
+        sa.numKeys = a.numKeys;
+        for (int k = 0; k < a.numKeys; ++k) {
+          sa.keys[k] = a.keys[k];
+        }
+        sa.numRows = keyRows;
+        sa.counters = h.counters();
+        VX_LAUNCH("k_key_stats", k_key_stats, keyBlocks, 256, 0, sa);
+      }
       Counters c = readCounters(h);
+      h.firstRowsDistinct = c.firstRowsDistinct;
       if (sumStatsPending) {
         applySumStats(h, a, c);
       }
@@ -5538,7 +5750,12 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
     // (nor has an open-addressing table in front of a large batch: the dense folds need no table)
     const bool fewGroups = h.sampledGroups >= 0 && std::max<int64_t>(h.numGroups, h.sampledGroups) <= kLdsHashedMaxGroups;
     const bool denseChunk = !fewGroups && radixDenseEligible(h, a, n - begin);   // few groups: the LDS kernels
-    rows = std::min((h.numGroups == 0 && !wideArray) ? std::min<int64_t>(h.chunkRows, 1 << 20) : h.chunkRows,
+    // (Nor does a small direct-index table whose first rows already show hundreds of keys: one LDS
+    // word per key and accumulator will do, whatever the exact count - BASELINE config 1.)
+    const bool manyKeysSeen = h.mode == MODE_ARRAY && h.capacity <= 8192 && h.firstRowsDistinct >= 256 &&
+        h.inputRows == 0;
+    rows = std::min((h.numGroups == 0 && !wideArray && !manyKeysSeen) ? std::min<int64_t>(h.chunkRows, 1 << 20)
+                                                                      : h.chunkRows,
                     n - begin);
     if (denseChunk) {
       rows = std::min(n - begin, denseMaxRows(a));
@@ -5546,16 +5763,38 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
     if (wideArray && h.radixMinRows >= 0) {
       rows = std::min<int64_t>(rows, 1LL << radixRowBits(h.capacity));  // radix path: row numbers live in the records
     }
-    if (h.mode == MODE_NORMALIZED && !denseChunk) {
+    // Few groups in an open-addressing table, aggregated by the LDS kernels with a hashed slot map:
+    // the launch creates at most workgroups x slots groups (rows of a workgroup that runs out of
+    // slots are deferred and replayed), so the table is sized for that and the chunk is not cut
+    // at 2^26 rows - TPC-H Q1 with four keys: one 50 MB table and three launches instead of a
+    // 12 GB table (2.5 ms to initialise, 1.9 ms to scan for live rows) and ten.
+    uint64_t slotGroups = 0;
+    if (h.mode == MODE_NORMALIZED && fewGroups && !denseChunk && h.slotsOnlyTables && h.numGroups > 0) {
+      int words = 0;
+      for (int j = 0; j < a.numAccs; ++j) {
+        words += accWords(a.accs[j].kind);
+      }
+      LdsPlan probe{};
+      size_t probeBytes = 0;
+      if (chooseLds(h, words, &probe, &probeBytes)) {
+        slotGroups = static_cast<uint64_t>(rt.numCUs) * 4 * static_cast<uint64_t>(probe.S);
+      }
+    }
+    if (slotGroups > 0) {
+      rows = std::min<int64_t>(rows, 1 << 28);  // (the deferred list holds every row of the chunk: 1 GB)
+      if (h.tableDense || static_cast<uint64_t>(h.numGroups) + slotGroups > h.capacity * 7 / 10) {
+        rebuildTable(h, slotGroups);
+      }
+    } else if (h.mode == MODE_NORMALIZED && !denseChunk) {
       // The open-addressing table is sized for the worst case "every row of the
       // chunk is a new group": keep that bound reasonable.
       rows = std::min<int64_t>(rows, 1 << 26);
+      if (h.tableDense || static_cast<uint64_t>(h.numGroups + rows) > h.capacity * 7 / 10) {
+        rebuildTable(h, static_cast<uint64_t>(rows));  // HashTable::checkSize (HashTable.cpp:772-806)
+      }
     }
-    if (h.mode == MODE_NORMALIZED && !denseChunk &&
-        (h.tableDense || static_cast<uint64_t>(h.numGroups + rows) > h.capacity * 7 / 10)) {
-      rebuildTable(h, static_cast<uint64_t>(rows));  // HashTable::checkSize (HashTable.cpp:772-806)
-    }
-    const uint32_t deferCap = static_cast<uint32_t>(std::min<int64_t>(rows, h.deferCap));
+    const uint32_t deferCap =
+        static_cast<uint32_t>(slotGroups > 0 ? rows : std::min<int64_t>(rows, h.deferCap));
     h.deferredBuf.ensure(static_cast<size_t>(deferCap) * 4 + 64);
     // Chunk = rows [begin, begin + rows): shift every column view instead of
     // adding an offset in the kernel.
@@ -5626,8 +5865,10 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
         used[k] = h.keys[k].range;
       }
       h.denseNext = denseChunk && attempt == 0 && !rescan && list == nullptr && h.numGroups == 0;
+      h.slotsOnlyLaunch = slotGroups > 0 && attempt == 0;
       launchChunk(h, c);
       h.denseNext = false;
+      h.slotsOnlyLaunch = false;
       Counters ctr = readCounters(h);
       // A key no VectorHasher range can hold (string longer than 7 bytes): its
       // rows were deferred; they force the generic mode below.
@@ -5715,6 +5956,15 @@ void finalize(vx355_agg& h) {
   settleTable(h);
   // Every group was listed by the radix folds that created it: no scan of the table.
   const bool listed = h.pairsComplete && h.pairCount == h.numGroups;
+  if (!listed && !h.unorderedOutput && h.capacity <= 65536 && g <= static_cast<size_t>(kSmallSortMax)) {
+    uint32_t* order = static_cast<uint32_t*>(h.orderVals.ensure(g * 4 + 64));
+    VX_LAUNCH("k_collect_sort_small", k_collect_sort_small, 1, 1024, 0, h.table.as<uint64_t>(),
+              static_cast<uint32_t>(h.capacity), h.stride, order, order + g);
+    h.order = order;
+    h.numOutput = static_cast<int64_t>(g);
+    h.collectCheck = static_cast<int64_t>(g);  // verified behind the first output page's synchronisation
+    return;
+  }
   if (!listed) {
     h.orderKeys.ensure(g * 8 + 64);
     h.orderVals.ensure(g * 4 + 64);
@@ -6009,6 +6259,21 @@ void getOutput(vx355_agg& h, vx355_out_column* cols, int32_t numCols, int32_t ma
   for (int32_t i = 0; i < numCols; ++i) {
     anyHost = anyHost || cols[i].mem == VX355_MEM_HOST;
   }
+  const int64_t expectFound = h.collectCheck;
+  if (expectFound >= 0) {
+    h.collectCheck = -1;
+    HIP_OK(hipMemcpyAsync(rt.mail.host + 63, h.order + expectFound, 4, hipMemcpyDeviceToHost, rt.stream));
+  }
+  struct FoundCheck {
+    vx::Runtime& rt;
+    int64_t expect;
+    void operator()() const {
+      if (expect >= 0 && static_cast<int64_t>(static_cast<uint32_t>(rt.mail.host[63])) != expect) {
+        VX_THROW(VX355_EINTERNAL, "group count mismatch: counted " + std::to_string(expect) + ", found " +
+                                      std::to_string(static_cast<uint32_t>(rt.mail.host[63])));
+      }
+    }
+  } foundCheck{rt, expectFound};
   if (anyHost && total <= kSmallPageBytes) {
     // A small page (Q1: four rows of ten columns): one copy of the whole scratch block into pinned
     // memory instead of twenty copies into the caller's pageable buffers (each of those is a
@@ -6017,6 +6282,7 @@ void getOutput(vx355_agg& h, vx355_out_column* cols, int32_t numCols, int32_t ma
     char* stage = h.outStage.extend(total);
     copyOutAsync(stage, VX355_MEM_HOST, scratch, total);
     rt.sync();
+    foundCheck();
     for (int32_t i = 0; i < numCols; ++i) {
       if (cols[i].mem == VX355_MEM_HOST) {
         std::memcpy(cols[i].values, stage + offsets[i], valueBytes[i]);
@@ -6035,6 +6301,7 @@ void getOutput(vx355_agg& h, vx355_out_column* cols, int32_t numCols, int32_t ma
       }
     }
     rt.sync();
+    foundCheck();
   }
   if (h.generic && h.hasStringKeys) {
     // Key strings longer than 12 bytes came out as views into the operator's HBM arena. Device
@@ -6196,8 +6463,14 @@ void configureFromEnv(vx355_agg& h) {
   if (const char* e = std::getenv("VX355_AGG_NO_FAST")) {
     h.disableFast = e[0] == '1';
   }
+  if (const char* e = std::getenv("VX355_AGG_SLOTS_ONLY")) {
+    h.slotsOnlyTables = std::atoi(e) != 0;
+  }
   if (const char* e = std::getenv("VX355_AGG_SCRATCH_FLUSH")) {
     h.ldsScratchFlush = std::atoi(e) != 0;
+  }
+  if (const char* e = std::getenv("VX355_AGG_SCRATCH_MIN_ATOMICS")) {
+    h.scratchMinAtomics = std::strtoll(e, nullptr, 10);
   }
   if (const char* e = std::getenv("VX355_AGG_RADIX_SPARSE")) {
     h.radixSparse = std::atoi(e) != 0;
@@ -6816,7 +7089,9 @@ int vx355_agg_to_intermediate(vx355_agg* h, const vx355_batch* batch, vx355_out_
 }
 
 int vx355_agg_get_stats(const vx355_agg* h, vx355_agg_stats* out) {
-  VX_ASYNC_DRAIN(h)
+  if (h != nullptr && h->aq != nullptr) {
+    vx::asyncQuiesce(h->aq);  // (inspection: readable on a handle whose queue has failed)
+  }
   VX_API_BEGIN
   VX_CHECK_ARG(h && out, "NULL argument");
   out->num_groups = h->keys.empty() ? 1 : h->numGroups;
@@ -6867,6 +7142,9 @@ int vx355_agg_add_input_async(vx355_agg* h, const vx355_batch* batch, int64_t* t
     }
     if (!h->aq) {
       h->aq = vx::asyncCreate();
+    }
+    if (const int failed = vx::asyncFailed(h->aq)) {
+      return failed;  // an earlier batch failed: the handle stays failed (asyncWait)
     }
     const int64_t ticket = vx::asyncSubmit(h->aq, vx::asyncBatchTask(batch, [h](const vx355_batch* b) -> int {
       // the synchronous entry point minus its drain (this IS the queue's worker)

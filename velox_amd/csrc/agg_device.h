@@ -53,7 +53,8 @@ struct Counters {
   uint32_t unmappable;   // a string key longer than 7 bytes was seen
   uint32_t tableFull;
   uint32_t pairsBroken;  // a radix fold split a partition into slices: its (first row, group) pairs may be stale
-  uint32_t pad[2];
+  uint32_t firstRowsDistinct;  // distinct keys among the first 2048 rows of the first batch (key statistics)
+  uint32_t pad;
   int64_t keyMin[kMaxKeys];
   int64_t keyMax[kMaxKeys];
   uint64_t sumMax[kMaxAccs];  // largest |input| seen per DOUBLE sum (bit pattern), k_sum_stats
@@ -166,7 +167,12 @@ struct LdsPlan {
   int32_t stride;
   int32_t mapWords;   // direct == 2: entries of the hashed key -> slot map (a power of two)
   int32_t tableMode;  // MODE_ARRAY: group row = table + key * stride; MODE_NORMALIZED: findOrInsert(key)
-  int32_t pad;
+  // Hashed slot map over an open-addressing table (direct == 2): a row whose workgroup has run out
+  // of LDS slots is DEFERRED (replayed by the host) instead of inserted straight into the table.
+  // New groups per launch are then bounded by workgroups x slots, so the table is sized for that -
+  // not for "every row of the chunk is a new group" (a 12 GB table to initialise and to scan for
+  // Q1's 600 M rows and 196 groups).
+  int32_t deferOverflow;
   uint64_t rowBase;
   Counters* counters;
   // Direct-index tables with many live keys (BASELINE config 1: 1000 groups): instead of one HBM
@@ -869,6 +875,8 @@ __device__ inline void aggFastBody(const FastArgs& a) {
               }
             }
           });
+        } else if (p.deferOverflow) {
+          defer = true;  // workgroup out of LDS slots, table sized for the slots only: the host replays the row
         } else {
           // Workgroup out of LDS slots: straight to the group row in HBM.
           uint64_t* g = ldsGroupRow(p, key);

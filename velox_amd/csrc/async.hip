@@ -78,18 +78,34 @@ void asyncPoll(AsyncQueue* q, int64_t* submitted, int64_t* completed) {
   }
 }
 
-// Waits until every submitted batch has been processed; the first failure since the last wait
-// is reported once (status + message on the calling thread).
+// Waits until every submitted batch has been processed and reports the first failure (status +
+// message on the calling thread). The failure STAYS: the batches queued behind the failed one were
+// skipped, so the operator's state is short of input - every later wait, and every entry point
+// that drains the queue (add_input, no_more_input, get_output ...), keeps failing with it until the
+// handle is destroyed. A shim that only checks no_more_input / get_output cannot miss it.
 int asyncWait(AsyncQueue* q) {
   std::unique_lock<std::mutex> lock(q->m);
   q->idle.wait(lock, [&] { return q->completed == q->submitted; });
   const int status = q->firstError;
   if (status != VX355_OK) {
     setLastError(q->errorText);
-    q->firstError = VX355_OK;
-    q->errorText.clear();
   }
   return status;
+}
+
+// Waits for the queue without reporting anything (inspection entry points: get_stats).
+void asyncQuiesce(AsyncQueue* q) {
+  std::unique_lock<std::mutex> lock(q->m);
+  q->idle.wait(lock, [&] { return q->completed == q->submitted; });
+}
+
+// The sticky failure of the queue without waiting (VX355_OK = none so far).
+int asyncFailed(AsyncQueue* q) {
+  std::lock_guard<std::mutex> lock(q->m);
+  if (q->firstError != VX355_OK) {
+    setLastError(q->errorText);
+  }
+  return q->firstError;
 }
 
 void asyncDestroy(AsyncQueue* q) {

@@ -36,6 +36,8 @@ AsyncQueue* asyncCreate();
 int64_t asyncSubmit(AsyncQueue* q, std::function<int(std::string*)> task);
 void asyncPoll(AsyncQueue* q, int64_t* submitted, int64_t* completed);
 int asyncWait(AsyncQueue* q);
+void asyncQuiesce(AsyncQueue* q);
+int asyncFailed(AsyncQueue* q);
 void asyncDestroy(AsyncQueue* q);
 std::function<int(std::string*)> asyncBatchTask(const vx355_batch* batch, std::function<int(const vx355_batch*)> call);
 #define VX_ASYNC_DRAIN(h)                                  \

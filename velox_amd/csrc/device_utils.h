@@ -100,6 +100,15 @@ __host__ __device__ inline uint64_t hashMix(uint64_t upper, uint64_t lower) {
 }
 constexpr uint64_t kNullHash = 1;  // common/base/BitUtil.h:52
 
+// Home slot of a VectorHasher hash in the generic-mode ({tag, row} / {tag, group}) tables. Not the
+// hash's low bits: behind a hash-partitioned exchange every row of a rank has the same
+// hash % numRanks (HashPartitionFunction.cpp:112-115) - for a power-of-two rank count the same low
+// bits - and a table indexed by them would use one slot in numRanks. A multiplicative mix spreads
+// any residue class over the whole table; the tag stays the hash's high half.
+__host__ __device__ inline uint64_t slotOfHash(uint64_t hash, uint64_t mask) {
+  return ((hash * 0x9E3779B97F4A7C15ULL) >> 20) & mask;
+}
+
 // CRC32-C step over 8 bytes (common/base/SimdUtil-inl.h:1387-1399), 4 bits at
 // a time through a 16-entry table kept in registers/constant space.
 __device__ inline uint32_t crc32cNibbles(uint32_t crc, uint32_t word) {

@@ -118,8 +118,21 @@ int vx355_join_repartition(vx355_comm* c, const vx355_join_build_spec* build_spe
   }
   // ---- probe side, pipelined
   const int64_t n = probe_rows->num_rows;
-  int64_t numChunks = std::max<int64_t>(1, std::min<int64_t>(chunks, std::max<int64_t>(n, 1)));
-  numChunks = std::max(numChunks, ceilDiv(n, kMaxBatchRows));
+  // Every chunk is a collective (vx355_exchange_send all-gathers the slice sizes and posts grouped
+  // sends / receives): all ranks must run the SAME number of them, whatever their own row counts
+  // are - a rank with fewer rows (or none) sends empty chunks. The count is the caller's 'chunks'
+  // (the same on every rank by contract), raised to what the largest shard needs to keep a chunk
+  // inside a batch's int32 row count; the ranks agree on that with one all-gather of the counts.
+  int64_t numChunks = std::max<int64_t>(1, chunks);
+  {
+    int32_t world = 1;
+    ok(vx355_comm_info(c, &world, nullptr, nullptr));
+    std::vector<int64_t> mine(static_cast<size_t>(world), ceilDiv(n, kMaxBatchRows)), theirs(static_cast<size_t>(world), 0);
+    ok(vx355_exchange_counts(c, mine.data(), theirs.data()));
+    for (int64_t need : theirs) {
+      numChunks = std::max(numChunks, need);
+    }
+  }
   ExchangeHandle ex;
   const auto types = typesOf(probe_rows);
   ok(vx355_exchange_create(c, types.data(), probe_rows->num_cols, probe_spec->key_cols, probe_spec->num_keys, &ex.x));

@@ -173,6 +173,12 @@ struct vx355_comm {
   void* comm = nullptr;        // ncclComm_t
   int32_t world = 1;
   int32_t rank = 0;
+  // true: every collective of this communicator goes through RCCL, the rank's own slice included
+  // (a send / recv pair to itself inside the group). Always so for world > 1 peers; a one-rank
+  // communicator only with VX355_COMM_FORCE_RCCL=1 - the way to execute ncclCommInitRank, the
+  // grouped send / recv, the 256 MiB message cutting and the receive-slot pipeline on a 1-GPU box.
+  bool selfViaRccl = false;
+  bool viaRccl() const { return world > 1 || selfViaRccl; }
   DevBuf countsDev;            // all-gather of the slice sizes
 };
 
@@ -248,21 +254,25 @@ struct vx355_exchange {
   vx::ExSlot slots[vx::kExSlots];
   int64_t sent = 0, receivedCount = 0;
   vx::DevBuf parts;
+  bool topBits = false;              // VX355_EXCHANGE_TOP_BITS=1 (see destinationArgs)
 };
 
 
 namespace vx {
 namespace {
-// HashPartitionFunction of the edge for 'world' destinations: the TOP hash bits for powers of
-// two (disjoint from the bits the join tables index with, cf. checkHashBitsOverlap,
-// exec/HashTable.cpp:1853), else hash % world (exec/HashPartitionFunction.cpp:112-115).
+// HashPartitionFunction of the edge for 'world' destinations: hash % world, what the reference's
+// PartitionedOutput computes without a HashBitRange (exec/HashPartitionFunction.cpp:112-115) - a
+// shim that precomputes partitions, or a CPU Velox peer on the same edge, sends a row to the same
+// rank. (The tables behind the edge do not index with the hash's low bits: normalized keys go
+// through twang_mix64, generic-mode slots through slotOfHash.) VX355_EXCHANGE_TOP_BITS=1 selects
+// the HashBitRange flavour for power-of-two worlds: the top log2(world) bits.
 HashPartArgs destinationArgs(const vx355_exchange& x, const DeviceBatch& db, uint32_t world, int64_t n) {
   HashPartArgs a{};
   for (size_t k = 0; k < x.keyCols.size(); ++k) {
     a.keys[k] = db.col(x.keyCols[k]);
   }
   a.numKeys = static_cast<int32_t>(x.keyCols.size());
-  if ((world & (world - 1)) == 0) {
+  if (x.topBits && world > 1 && (world & (world - 1)) == 0) {
     int bits = 0;
     while ((1u << bits) < world) {
       ++bits;
@@ -302,7 +312,10 @@ int vx355_comm_create(const void* id, int32_t world, int32_t rank, vx355_comm** 
   c->rank = rank;
   ncclUniqueId uid;
   std::memcpy(uid.internal, id, kUniqueIdBytes);
-  if (world > 1) {
+  if (const char* e = std::getenv("VX355_COMM_FORCE_RCCL")) {
+    c->selfViaRccl = std::atoi(e) != 0;
+  }
+  if (c->viaRccl()) {
     // (A one-rank communicator needs no RCCL: every collective is a device copy. Creating one
     // anyway is not free on this stack: after ncclCommInitRank the random-access kernels of the
     // same process ran 1.7x slower - k_join_probe 3.4 -> 5.8 ms, k_gather_deps 4.0 -> 7.1 ms on
@@ -412,7 +425,7 @@ namespace {
 void exchangeCounts(vx355_comm* c, const int64_t* send, int64_t* recv) {
   auto& rt = Runtime::get();
   const size_t w = static_cast<size_t>(c->world);
-  if (w == 1) {
+  if (!c->viaRccl()) {
     recv[0] = send[0];
     return;
   }
@@ -465,7 +478,7 @@ void postColumns(vx355_comm* c, hipStream_t stream, const void* const* sendCols,
     VX_CHECK_ARG((totalSend == 0 || sendCols[col]) && (totalRecv == 0 || recvCols[col]), "NULL column");
   }
   VX_CHECK_ARG(sendCounts[c->rank] == recvCounts[c->rank], "a rank's slice for itself has one size");
-  Rccl* r = c->world > 1 ? &rccl() : nullptr;
+  Rccl* r = c->viaRccl() ? &rccl() : nullptr;
   // Grouped point-to-point: all slices of all columns are posted together so that the seven
   // outgoing links of the GPU work concurrently.
   std::unique_ptr<GroupGuard> group;
@@ -479,7 +492,7 @@ void postColumns(vx355_comm* c, hipStream_t stream, const void* const* sendCols,
       const int64_t ns = sendCounts[peer], nr = recvCounts[peer];
       const char* src = static_cast<const char*>(sendCols[col]) + sendAt * w;
       char* dst = static_cast<char*>(recvCols[col]) + recvAt * w;
-      if (peer == c->rank) {
+      if (peer == c->rank && !c->selfViaRccl) {
         if (ns > 0) {
           HIP_OK(hipMemcpyAsync(dst, src, static_cast<size_t>(ns * w), hipMemcpyDeviceToDevice, stream));
         }
@@ -524,7 +537,7 @@ int vx355_all_gather(vx355_comm* c, const void* send, void* recv, size_t bytes_p
   VX_CHECK_ARG(c && send && recv, "NULL argument");
   auto& rt = Runtime::get();
   if (bytes_per_rank) {
-    if (c->world == 1) {
+    if (!c->viaRccl()) {
       HIP_OK(hipMemcpyAsync(recv, send, bytes_per_rank, hipMemcpyDeviceToDevice, rt.stream));
     } else if (static_cast<int64_t>(bytes_per_rank) <= kMaxMessageBytes) {
       ncclOk(rccl().AllGather(send, recv, bytes_per_rank, kNcclInt8, c->comm, rt.stream), "ncclAllGather");
@@ -534,7 +547,7 @@ int vx355_all_gather(vx355_comm* c, const void* send, void* recv, size_t bytes_p
       GroupGuard group(r);
       for (int32_t peer = 0; peer < c->world; ++peer) {
         char* dst = static_cast<char*>(recv) + static_cast<size_t>(peer) * bytes_per_rank;
-        if (peer == c->rank) {
+        if (peer == c->rank && !c->selfViaRccl) {
           HIP_OK(hipMemcpyAsync(dst, send, bytes_per_rank, hipMemcpyDeviceToDevice, rt.stream));
         } else {
           sendBytes(r, c, rt.stream, static_cast<const char*>(send), static_cast<int64_t>(bytes_per_rank), peer);
@@ -561,7 +574,7 @@ int vx355_all_gather_v(vx355_comm* c, const void* send, const int64_t* sizes, vo
   }
   const int64_t mine = sizes[c->rank];
   VX_CHECK_ARG((mine == 0 || send) && (total == 0 || recv), "NULL buffer");
-  Rccl* r = c->world > 1 ? &rccl() : nullptr;
+  Rccl* r = c->viaRccl() ? &rccl() : nullptr;
   std::unique_ptr<GroupGuard> group;
   if (r) {
     group = std::make_unique<GroupGuard>(*r);
@@ -569,7 +582,7 @@ int vx355_all_gather_v(vx355_comm* c, const void* send, const int64_t* sizes, vo
   int64_t at = 0;
   for (int32_t peer = 0; peer < c->world; ++peer) {
     char* dst = static_cast<char*>(recv) + at;
-    if (peer == c->rank) {
+    if (peer == c->rank && !c->selfViaRccl) {
       if (mine > 0) {
         HIP_OK(hipMemcpyAsync(dst, send, static_cast<size_t>(mine), hipMemcpyDeviceToDevice, rt.stream));
       }
@@ -609,6 +622,9 @@ int vx355_exchange_create(vx355_comm* c, const int32_t* col_types, int32_t num_c
     VX_CHECK_ARG(key_cols[k] >= 0 && key_cols[k] < num_cols, "partitioning key column");
     x->keyCols.push_back(key_cols[k]);
   }
+  if (const char* e = std::getenv("VX355_EXCHANGE_TOP_BITS")) {
+    x->topBits = std::atoi(e) != 0;
+  }
   x->ctx = Runtime::createContext();
   {
     vx::ContextScope scope(x->ctx);
@@ -647,7 +663,7 @@ int vx355_exchange_send(vx355_exchange* x, const vx355_batch* batch) {
   }
   DeviceBatch db;
   db.load(batch, all);   // host columns are staged; device columns aliased
-  if (n > 0 && c->world > 1) {
+  if (n > 0 && c->viaRccl()) {
     uint32_t* flag = nullptr;
     for (int32_t i = 0; i < numCols; ++i) {
       if (!isString(x->types[i])) {
@@ -677,7 +693,7 @@ int vx355_exchange_send(vx355_exchange* x, const vx355_batch* batch) {
   for (int32_t i = 0; i < numCols; ++i) {
     in[i] = db.col(i).values;
   }
-  if (c->world == 1) {
+  if (!c->viaRccl()) {
     // one destination: nothing to hash, group or send — the rows go straight to the receive
     // buffers (one device copy: the caller's batch is only borrowed for this call)
     slot.sendCounts[0] = slot.recvCounts[0] = n;

@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256) void k_join_insert(InsertArgs a) {
       const uint64_t hash = storedRowHash(a, row);
       const uint64_t tag = hash >> 32;
       const uint64_t gmask = a.capacity - 1;
-      uint64_t pos = hash & gmask;
+      uint64_t pos = slotOfHash(hash, gmask);
       bool placed = false;
       for (uint64_t probes = 0; probes <= gmask && !placed; ++probes) {
         unsigned long long w = __hip_atomic_load(a.gslots + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(256) void k_count_init(InsertArgs a, uint32_t* rema
       const uint64_t hash = storedRowHash(a, row);
       const uint64_t tag = hash >> 32;
       const uint64_t mask = a.capacity - 1;
-      uint64_t pos = hash & mask;
+      uint64_t pos = slotOfHash(hash, mask);
       for (uint64_t probes = 0; probes <= mask; ++probes) {
         const uint64_t w = a.gslots[pos];
         if (w == 0) {
@@ -829,7 +829,7 @@ __device__ inline uint32_t lookupGeneric(const ProbeArgs& a, int64_t row) {
   }
   const uint64_t tag = hash >> 32;
   const uint64_t mask = a.capacity - 1;
-  uint64_t pos = hash & mask;
+  uint64_t pos = slotOfHash(hash, mask);
   for (uint64_t probes = 0; probes <= mask; ++probes) {
     const uint64_t w = a.gslots[pos];
     if (w == 0) {
@@ -3775,6 +3775,9 @@ int vx355_join_build_add_input_async(vx355_join_build* h, const vx355_batch* bat
     }
     if (!h->aq) {
       h->aq = vx::asyncCreate();
+    }
+    if (const int failed = vx::asyncFailed(h->aq)) {
+      return failed;  // an earlier batch failed: the handle stays failed (asyncWait)
     }
     const int64_t ticket = vx::asyncSubmit(
         h->aq, vx::asyncBatchTask(batch, [h](const vx355_batch* b) { return joinBuildAddInputNow(h, b); }));

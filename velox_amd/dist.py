@@ -7,6 +7,8 @@ own partial/final split (docs/develop/aggregations.rst:24-91), with
 torch.distributed (RCCL on GPUs, gloo in the CPU tests) as the exchange. No
 input row ever crosses a link.
 """
+import os
+
 import numpy as np
 
 from . import abi
@@ -227,12 +229,15 @@ def merge_partials(impl, dist, torch, partial_columns, key_types, raw_aggs, devi
 # in the CPU tests). After the exchange equal keys live on the same rank and the
 # join is local. Nothing else in the path communicates.
 
-def partition_spec(world):
+def partition_spec(world, top_bits=None):
     """(kind, kwargs) of the HashPartitionFunction flavour used for 'world'
-    destinations: the top hash bits for powers of two (disjoint from the bits the
-    tables index with, cf. checkHashBitsOverlap, exec/HashTable.cpp:1853), else
-    hash % world (exec/HashPartitionFunction.cpp:112-115)."""
-    if world > 1 and world & (world - 1) == 0:
+    destinations: hash % world (exec/HashPartitionFunction.cpp:112-115), what a
+    PartitionedOutput without a HashBitRange computes - a CPU Velox peer sends a row to
+    the same rank. top_bits (default: VX355_EXCHANGE_TOP_BITS=1, as in libvx355's edge):
+    the HashBitRange flavour for powers of two, the top log2(world) bits."""
+    if top_bits is None:
+        top_bits = os.environ.get("VX355_EXCHANGE_TOP_BITS", "0") not in ("", "0")
+    if top_bits and world > 1 and world & (world - 1) == 0:
         bits = world.bit_length() - 1
         return abi.PART_BIT_RANGE, dict(bit_begin=64 - bits, bit_end=64)
     return abi.PART_MODULO, dict(num_partitions=max(1, world))

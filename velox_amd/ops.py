@@ -838,6 +838,9 @@ class HashBuild:
     def poll(self):
         sub, done = C.c_int64(), C.c_int64()
         _check(lib().vx355_join_build_poll(self.h, C.byref(sub), C.byref(done)))
+        held = self.__dict__.get("_in_flight", {})
+        for t in [t for t in held if t <= done.value]:   # completed batches are no longer kept alive
+            del held[t]
         return sub.value, done.value
 
     def wait(self):
@@ -849,6 +852,7 @@ class HashBuild:
         arr = (C.c_void_p * max(1, len(others)))(*[o.h for o in others])
         t = C.c_void_p()
         _check(lib().vx355_join_build_finish(self.h, arr, len(others), C.byref(t)))
+        self.__dict__.get("_in_flight", {}).clear()   # finish waited for the queue
         return JoinTable(t, self.dep_types)
 
     def __del__(self):
