@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the rocprofv3 FETCH_SIZE / WRITE_SIZE passes behind roofline.traffic")
     ap.add_argument("--secondary-steps", type=int, default=5)
+    ap.add_argument("--secondary", default="",
+                    help="comma-separated keys of the secondary blocks to run (default: all of bench.SECONDARY)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = every GPU gets the full per-GPU row count (default); strong = the "
                          "N = 1 row count (SF100 for q1) is sharded N ways, BASELINE's 1/2/4/8 metric")
@@ -997,21 +999,18 @@ WORKLOADS = {"q1x4": (Q1FourKeys, 600_037_902), "q3full": (Q3Full, 600_037_902),
              "q3": (Q3, 600_037_902)}
 
 
-def measured_copy_ceiling(torch, device):
-    """Device-to-device copy rate on this box (read + write bytes / time): the
-    practical HBM ceiling next to the 8 TB/s datasheet figure."""
-    n = 1 << 28
-    a = torch.empty(n, dtype=torch.float64, device=device).fill_(1.0)
-    b = torch.empty_like(a)
-    for _ in range(2):
-        b.copy_(a)
-    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    start.record()
-    for _ in range(5):
-        b.copy_(a)
-    stop.record()
-    torch.cuda.synchronize()
-    return 5 * 2 * n * 8 / (start.elapsed_time(stop) * 1e-3) / 1e9
+def measured_ceilings():
+    """What this box's HBM delivers to plain streaming kernels, next to the 8 TB/s datasheet peak
+    (SURVEY.md section 8(d)): the library's own read-only stream (the shape of k_agg_fast: bytes in,
+    nothing out) and copy (bytes in, as many out: the scatter passes) kernels, vx355_hbm_ceiling.
+    A kernel is compared with the ceiling of ITS shape."""
+    return {"read_GBps": ops.hbm_ceiling(abi.CEILING_READ, 8 << 30, 5),
+            "copy_GBps": ops.hbm_ceiling(abi.CEILING_COPY, 4 << 30, 5),
+            "how": "vx355_hbm_ceiling: 16-byte accesses, four per lane in flight, 8 workgroups per CU; "
+                   "read = 8 GiB nontemporal read-only stream, copy = 4 GiB read + 4 GiB written"}
+
+
+READ_ONLY_KERNELS = ("k_agg_fast", "k_agg_lds", "k_join_probe", "k_join_probe_list", "k_rp_count1", "k_pp_count")
 
 
 def pmc_traffic(workload, kernel):
@@ -1053,7 +1052,7 @@ def measure_traffic(child_flags, kernel, steps=1):
                    "--steps", str(steps), "--warmup", "0", "--no-cpu-baseline", "--no-secondary", "--no-traffic"]
         env = dict(os.environ, TMPDIR="/tmp")
         try:
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
             if r.returncode != 0:
                 return {}
             kb, dispatches = 0.0, 0
@@ -1283,7 +1282,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    copy_ceiling = measured_copy_ceiling(torch, device)
+    copy_ceiling = measured_ceilings()
     child_flags = ["--workload", args.workload]
     for flag, on in (("--q3-random-probe", args.q3_random_probe), ("--c4-sparse", args.c4_sparse),
                      ("--c4-unordered", args.c4_unordered),
@@ -1310,7 +1309,7 @@ def main():
                    "scan_bytes_per_row": wl.bytes_per_row,
                    "plan": ("fused FilterProject+HashAggregation (2 keys, 8 aggregates)" if wl.fused else
                             "FilterProject -> HashAggregation (2 keys, 8 aggregates)")
-                   if args.workload == "q1" else args.workload,
+                   if args.workload == "q1" else (STEP_TEXT.get(args.workload, args.workload)),
                    "parallelism": ("one process per GPU, row shards; " +
                                    ("partial -> PrestoPages -> all-gather -> final" if args.workload == "q1" else
                                     "hash repartition of both sides, grouped send / recv per peer, local join") +
@@ -1329,17 +1328,25 @@ def main():
         import oracle_lib
         oracle_lib.lib()
         out["cpu_baseline"] = cpu_baseline_block(wl, oracle_lib, args.cpu_sample_rows, args.workload)
-        if args.workload in ("q1", "c1", "c4") and not args.no_cpu_mt:
+        if args.workload in ("q1", "q1x4", "c1", "c4") and not args.no_cpu_mt:
             out["cpu_baseline_mt"] = cpu_baseline_mt(wl, oracle_lib, args.cpu_sample_rows)
     if args.workload == "q1" and world == 1 and not args.no_secondary and not args.rows:
-        # The other half of BASELINE's metric ("Q1 agg & Q3 join"): the dominant join of TPC-H Q3 at
-        # SF100 in dbgen order and with the probe rows in random order (the cache-hostile case).
+        # The rest of BASELINE's single-GPU configs next to the headline, each with its own roofline and
+        # CPU baseline: Q1 in BASELINE.json's own wording (4 keys / 6 aggregates), config 1, the Q3 join
+        # (the other half of the metric) in dbgen and in random probe order, the whole Q3, config 4 with
+        # dense and with sparse keys. --secondary NAME[,NAME] restricts the list.
         del wl
         torch.cuda.empty_cache()
         out["secondary"] = {}
-        for order in ("dbgen", "random"):
-            out["secondary"]["tpch_q3_sf100_join" + ("" if order == "dbgen" else "_random_probe_order")] = \
-                q3_block(torch, device, order == "random", args, copy_ceiling, measure)
+        wanted = set(args.secondary.split(",")) if args.secondary else None
+        for key, workload, attrs, flags, steps, warmup in SECONDARY:
+            if wanted is not None and key not in wanted:
+                continue
+            try:
+                out["secondary"][key] = secondary_block(torch, device, args, copy_ceiling, measure, workload, attrs,
+                                                        flags, steps, warmup)
+            except Exception as e:   # a failing secondary must not take the headline with it; it is reported
+                out["secondary"][key] = {"error": f"{type(e).__name__}: {e}"}
     C.CDLL(None).fflush(None)   # C stdio (RCCL prints a version banner there): the JSON line stays the last line
     print(json.dumps(out), flush=True)
     if world > 1:
@@ -1408,8 +1415,11 @@ def roofline_block(wl, prof, steps, copy_ceiling, child_flags):
         "traffic_source": pmc.get("source"),
         "algorithmic_bytes_per_step": wl.agg_bytes_per_row * dom_rows / steps,
         "algorithmic_bytes_per_row": wl.agg_bytes_per_row,
-        "measured_copy_GBps": copy_ceiling,
-        "frac_of_measured_copy": (achieved / copy_ceiling) if (achieved and copy_ceiling) else None,
+        "measured_ceiling": copy_ceiling,
+        "frac_of_measured_ceiling": ((achieved / copy_ceiling["read_GBps" if wl.dominant in READ_ONLY_KERNELS
+                                                             else "copy_GBps"])
+                                     if (achieved and copy_ceiling) else None),
+        "measured_ceiling_kind": "read" if wl.dominant in READ_ONLY_KERNELS else "copy",
         "kernel_ms_per_step": dom_ms / steps,
         "avg_launch_ms": (dom_ms / dom_launches) if dom_launches else None,
         "launches_per_step": dom_launches / steps,
@@ -1444,13 +1454,31 @@ def cpu_baseline_block(wl, oracle_lib, cpu_sample_rows, workload):
     }
 
 
-def q3_block(torch, device, random_order, args, copy_ceiling, measure):
-    """One entry of `secondary`: build + probe + result listing of the Q3 SF100 join, timed like the
-    headline (inputs resident, barrier + synchronize on both sides)."""
-    Q3.random_probe = random_order
-    wl = Q3(torch, WORKLOADS["q3"][1], device, seed=1234)
-    steps = max(1, args.secondary_steps)
-    for _ in range(2):
+SECONDARY = [
+    # key in `secondary`, --workload, class attributes, child flags of the traffic passes, steps, warm-up
+    ("tpch_q1_sf100_4key_6agg", "q1x4", {}, [], None, 2),
+    ("c1_groupby_10m_1k", "c1", {"stream": False}, [], 50, 5),
+    ("tpch_q3_sf100_join", "q3", {"random_probe": False}, [], None, 2),
+    ("tpch_q3_sf100_join_random_probe_order", "q3", {"random_probe": True}, ["--q3-random-probe"], None, 2),
+    ("tpch_q3_sf100_full_query", "q3full", {}, [], None, 2),
+    ("c4_groupby_1b_100m", "c4", {"sparse": False, "unordered": False, "name": "c4_groupby_1b_100m"}, [], 3, 1),
+    ("c4_groupby_1b_100m_sparse_keys", "c4", {"sparse": True, "unordered": False,
+                                              "name": "c4_groupby_1b_100m_sparse_keys"}, ["--c4-sparse"], 3, 1),
+]
+
+
+def secondary_block(torch, device, args, copy_ceiling, measure, workload, attrs, child_flags, steps, warmup):
+    """One entry of `secondary`: a BASELINE config other than the headline, timed like the headline
+    (inputs resident, synchronised on both sides), with its own roofline (counter traffic from
+    rocprofv3 child passes of the same workload) and CPU baseline."""
+    cls, rows = WORKLOADS[workload]
+    for k, v in attrs.items():
+        setattr(cls, k, v)
+    wl = cls(torch, rows, device, seed=1234)
+    if workload in ("q1", "q1x4"):
+        wl.fused = True
+    steps = max(1, steps or args.secondary_steps)
+    for _ in range(warmup):
         wl.step()
     torch.cuda.synchronize()
     ops.synchronize()
@@ -1464,13 +1492,12 @@ def q3_block(torch, device, random_order, args, copy_ceiling, measure):
     elapsed = time.perf_counter() - t0
     ops.profile_enable(False)
     prof = ops.profile()
-    child = ["--workload", "q3"] + (["--q3-random-probe"] if random_order else [])
+    child = ["--workload", workload] + child_flags
     block = {
-        "value": wl.rows_per_step() * steps / elapsed, "unit": "probe rows/s", "steps": steps, "warmup": 2,
-        "ms_per_step": elapsed / steps * 1e3,
-        "config": {"workload": wl.name, "step": "HashBuild (add_input + finish) + HashProbe (add_input + "
-                                               "get_output with one payload column), inner join"},
-        "workload_info": wl.info(),
+        "value": wl.rows_per_step() * steps / elapsed, "unit": "probe rows/s" if workload == "q3" else "rows/s",
+        "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+        "config": {"workload": wl.name, "rows": wl.rows_per_step(), "step": STEP_TEXT[workload]},
+        "workload_info": wl.info() if hasattr(wl, "info") else {},
         "roofline": roofline_block(wl, prof, steps, copy_ceiling, child if measure else None),
         "kernels_ms_per_step": {k: round(v[0] / steps, 4) for k, v in sorted(prof.items())},
     }
@@ -1479,14 +1506,29 @@ def q3_block(torch, device, random_order, args, copy_ceiling, measure):
         ms = wl.probe_phase_ms / steps
         block["probe_phase"] = {"ms_per_step": ms, "GBps_at_12B_per_probe": wl.rows_per_step() * 12 / (ms * 1e-3) / 1e9,
                                 "GBps_at_24B_per_probe": wl.rows_per_step() * 24 / (ms * 1e-3) / 1e9}
+    if workload == "c4":
+        # every pass of the radix path next to the bytes it has to move (the step's roofline kernel is the slowest)
+        block["passes"] = {k: {"ms_per_step": round(prof[k][0] / steps, 4),
+                               "algorithmic_GBps": wl.PASS_BYTES[k] * wl.rows_per_step() * steps / (prof[k][0] * 1e-3) / 1e9}
+                           for k in wl.PASS_BYTES if prof.get(k, (0, 0))[0] > 0}
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
         oracle_lib.lib()
-        block["cpu_baseline"] = cpu_baseline_block(wl, oracle_lib, min(args.cpu_sample_rows, 8_000_000), "q3")
+        block["cpu_baseline"] = cpu_baseline_block(wl, oracle_lib, min(args.cpu_sample_rows, 8_000_000), workload)
     del wl
     torch.cuda.empty_cache()
     return block
+
+
+STEP_TEXT = {
+    "q1x4": "fused FilterProject + HashAggregation, 4 keys / 6 aggregates (BASELINE.json's wording of configs[1])",
+    "c1": "HashAggregation k -> sum(v), count(*), one HBM-resident batch (BASELINE configs[0])",
+    "q3": "HashBuild (add_input + finish) + HashProbe (add_input + get_output with one payload column), inner join",
+    "q3full": "the whole TPC-H Q3: customer -> build; orders -> filter, probe, build; lineitem -> filter, probe; "
+              "3-key aggregation (BASELINE configs[2])",
+    "c4": "HashAggregation k -> sum(v) over 10^9 rows / 10^8 groups, groups drained into HBM pages (BASELINE configs[3])",
+}
 
 
 if __name__ == "__main__":

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VX355_ABI_VERSION 5
+#define VX355_ABI_VERSION 6
 
 typedef enum vx355_status {
   VX355_OK = 0,
@@ -168,6 +168,16 @@ int vx355_profile_get(const char* kernel, double* total_ms, int64_t* launches);
 /* Writes up to cap names of kernels seen since the last reset, '\n' joined. */
 int vx355_profile_names(char* buf, size_t cap);
 
+/* What this GPU's HBM delivers to plain streaming kernels (measurement aid; bench.py quotes every
+ * roofline fraction against the 8 TB/s datasheet peak and reports these next to it).
+ * VX355_CEILING_READ: a read-only stream of 'bytes' bytes (16-byte nontemporal loads, nothing written);
+ * VX355_CEILING_COPY: 'bytes' bytes read and as many written. Runs the kernel 'iterations' times on the
+ * default context's stream (after two warm-up launches) between two HIP events and reports
+ * bytes moved / elapsed time in GB/s. bytes >= 1 MiB. */
+#define VX355_CEILING_READ 0
+#define VX355_CEILING_COPY 1
+int vx355_hbm_ceiling(int32_t kind, size_t bytes, int32_t iterations, double* gbytes_per_second);
+
 /* ---- standalone kernels (parity-test surface) --------------------------- */
 
 /* VectorHasher::hash (exec/VectorHasher.cpp:567-584, hashValues :86-126) for
@@ -284,6 +294,14 @@ int vx355_partition(
     int32_t bit_end,
     uint32_t* partitions_out,
     int32_t mem);
+
+/* Dictionary over a dictionary (exec/OperatorUtils.cpp:393-422, wrapChild on an already wrapped
+ * vector - what HashProbe::fillOutput produces over FilterProject's output, and what the probe of
+ * TPC-H Q3's second join feeds the next operator): out[i] = inner[outer[i]] for i < num_rows.
+ * inner has inner_size entries; an outer index outside [0, inner_size) is VX355_EINVAL. All three
+ * arrays live in mem. */
+int vx355_compose_indices(const int32_t* inner, int32_t inner_size, const int32_t* outer, int32_t num_rows,
+                          int32_t* out, int32_t mem);
 
 /* Repartitioning (exec/PartitionedOutput.cpp + exec/HashPartitionFunction.cpp,
  * what feeds an Exchange): reorders num_cols fixed-width columns so that the

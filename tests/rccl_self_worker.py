@@ -7,9 +7,12 @@ the ncclGroupStart / ncclGroupEnd bracket - the code path N > 1 ranks take (Grou
 256 MiB cutting, the all-gather of counts, the exchange edge's payload stream and receive slots),
 executed on a 1-GPU box. Prints one JSON line of checks."""
 import ctypes as C
+import faulthandler
 import json
 import os
 import sys
+
+faulthandler.enable()   # a crash inside RCCL leaves a Python traceback on stderr
 
 import numpy as np
 
@@ -41,8 +44,12 @@ def d2h(p, n, dtype):
 def main():
     vx.init(0)
     checks = {}
+    def progress(what):
+        print("rccl_self_worker:", what, file=sys.stderr, flush=True)
+    progress("creating the communicator")
     comm = vx.Comm(vx.Comm.unique_id(), 1, 0)
     checks["comm_info"] = list(comm.info())
+    progress("all-gather of counts")
     checks["counts"] = comm.exchange_counts([12345])
     rng = np.random.default_rng(9)
     # grouped send / recv to self: a 4-byte and an 8-byte column; the 8-byte one is 320 MiB, so
@@ -53,11 +60,13 @@ def main():
     sa, sb, ra, rb = dev_alloc(a.nbytes), dev_alloc(b.nbytes), dev_alloc(a.nbytes), dev_alloc(b.nbytes)
     h2d(sa, a)
     h2d(sb, b)
+    progress("grouped send / recv to self")
     comm.exchange_columns([sa.value, sb.value], [8, 4], [n], [n], [ra.value, rb.value])
     checks["columns_8_byte_320MiB"] = bool((d2h(ra, n, np.int64) == a).all())
     checks["columns_4_byte"] = bool((d2h(rb, n, np.int32) == b).all())
     # all-gather (one ncclAllGather) and the cut form above 256 MiB
     small = 1 << 20
+    progress("all-gather")
     comm.all_gather(sa.value, ra.value, small)
     checks["all_gather"] = bool((d2h(ra, small // 8, np.int64) == a[: small // 8]).all())
     vx._check(vx.lib().vx355_memcpy_h2d(ra, np.zeros(n, dtype=np.int64).ctypes.data, a.nbytes))
@@ -66,6 +75,7 @@ def main():
     comm.all_gather_v(sb.value, [b.nbytes], rb.value)
     checks["all_gather_v"] = bool((d2h(rb, n, np.int32) == b).all())
     # the exchange edge: hash + partition + grouping, counts, payload on the edge's own stream
+    progress("exchange edge")
     ex = vx.Exchange(comm, [abi.BIGINT, abi.DOUBLE], [0])
     sent = []
     for rows in (100_000, 0, 3_000_001):

@@ -470,3 +470,31 @@ def test_presto_deserialize_reads_rle_and_dictionary_columns(oracle, vx):
     with pytest.raises(vx.Vx355Error) as e:
         vx.presto_deserialize([bad], [abi.BIGINT])
     assert e.value.status == abi.EUSER
+
+
+def test_compose_indices_is_a_dictionary_over_a_dictionary(vx):
+    """vx355_compose_indices: out[i] = inner[outer[i]] (wrapChild over a wrapped vector,
+    exec/OperatorUtils.cpp:393-422), host and device memory; an index outside the inner vector is refused."""
+    rng = np.random.default_rng(91)
+    for n_inner, n in ((1, 1), (1000, 64), (200_000, 1_000_003)):
+        inner = rng.integers(0, 1 << 30, n_inner).astype(np.int32)
+        outer = rng.integers(0, n_inner, n).astype(np.int32)
+        assert (vx.compose_indices(inner, outer) == inner[outer]).all()
+        di, do = vx.DeviceArray(inner), vx.DeviceArray(outer)
+        out = vx.DeviceArray(np.zeros(n, dtype=np.int32))
+        vx.compose_indices_device(di.ptr, n_inner, do.ptr, n, out.ptr)
+        assert (out.to_host() == inner[outer]).all()
+    assert len(vx.compose_indices(np.zeros(3, np.int32), np.zeros(0, np.int32))) == 0
+    with pytest.raises(vx.Vx355Error) as e:
+        vx.compose_indices(np.arange(10, dtype=np.int32), np.array([3, 10], dtype=np.int32))
+    assert e.value.status == abi.EINVAL
+
+
+def test_hbm_ceiling_kernels_report_plausible_rates(vx):
+    """The library's own read-only-stream and copy kernels (bench.py quotes them next to the 8 TB/s
+    datasheet peak): both land between 1 and 8 TB/s on an MI355X, the read-only stream not below
+    the copy."""
+    read = vx.hbm_ceiling(abi.CEILING_READ, 2 << 30, 3)
+    copy = vx.hbm_ceiling(abi.CEILING_COPY, 1 << 30, 3)
+    assert 1000 < copy < 8000 and 1000 < read < 8000, (read, copy)
+    print("hbm ceilings GB/s: read", round(read), "copy", round(copy))

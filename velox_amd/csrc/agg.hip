@@ -2632,61 +2632,40 @@ struct StatsArgs {
 // Distinct normalized keys among 'a.numRows' rows taken every 'step' rows of the batch (one
 // workgroup, an LDS hash set of 8192 entries): out[0] = the count, saturating near 4096.
 constexpr int kCardSetSize = 8192;
-__global__ __launch_bounds__(1024) void k_card_sample(AggArgs a, int64_t step, uint32_t* out) {
-  __shared__ uint32_t set[kCardSetSize];
-  __shared__ uint32_t count;
-  for (int i = threadIdx.x; i < kCardSetSize; i += blockDim.x) {
-    set[i] = 0xffffffffu;
-  }
-  if (threadIdx.x == 0) {
-    count = 0;
-  }
-  blockSync();
-  // The sampled rows lie ~n / 16384 rows apart: every one of them is a cold line (and a cold page)
-  // in each key column. Eight rows' keys are fetched back to back before any of them is inserted,
-  // so that their misses overlap instead of queueing behind the set's atomics (0.21 -> ms on Q1).
-  constexpr int kBatch = 8;
-  for (int64_t base = threadIdx.x; base < a.numRows; base += static_cast<int64_t>(blockDim.x) * kBatch) {
-    uint64_t keys[kBatch];
-    bool use[kBatch];
-#pragma unroll
-    for (int u = 0; u < kBatch; ++u) {
-      const int64_t i = base + static_cast<int64_t>(u) * blockDim.x;
-      keys[u] = 0;
-      // (dropped row, or a key outside the ranges the first statistics pass found: not counted)
-      use[u] = i < a.numRows && normalizedKey(a, i * step, &keys[u]) == 0;
+__global__ __launch_bounds__(1024) void k_card_sample(AggArgs a, int64_t step, uint32_t* set, uint32_t* out) {
+  // The sampled rows lie ~n / 16384 rows apart: every one of them is a cold line AND a cold page in
+  // each key column, so the pass is bound by translation misses per lane. 16 workgroups share the
+  // work (one or two rows per lane) and the set - 8192 words in HBM, filled with 0xff by the host;
+  // out[0] counts the insertions (one workgroup with an LDS set took 0.21 ms on TPC-H Q1).
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.numRows; i += stride) {
+    uint64_t key;
+    if (normalizedKey(a, i * step, &key) != 0) {
+      continue;  // (dropped row, or a key outside the ranges the first statistics pass found)
     }
-#pragma unroll
-    for (int u = 0; u < kBatch; ++u) {
-      if (!use[u] || count >= kCardSetSize / 2) {
-        continue;
+    if (__hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= static_cast<uint32_t>(kCardSetSize / 2)) {
+      continue;  // saturated
+    }
+    // (open-addressing tables: 64-bit keys; 32 mixed bits tell them apart well enough for an estimate)
+    const uint32_t k32 = static_cast<uint32_t>(twangMix64(key) >> 7) & 0x7fffffffu;
+    uint32_t pos = static_cast<uint32_t>((key * 0x9E3779B97F4A7C15ULL) >> 40) & (kCardSetSize - 1);
+    for (int probes = 0; probes < 64; ++probes) {
+      const uint32_t seen = __hip_atomic_load(&set[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (seen == k32) {
+        break;
       }
-      const uint64_t key = keys[u];
-      // (open-addressing tables: 64-bit keys; 32 mixed bits tell them apart well enough for an estimate)
-      const uint32_t k32 = static_cast<uint32_t>(twangMix64(key) >> 7) & 0x7fffffffu;
-      uint32_t pos = static_cast<uint32_t>((key * 0x9E3779B97F4A7C15ULL) >> 40) & (kCardSetSize - 1);
-      for (int probes = 0; probes < 64; ++probes) {
-        const uint32_t seen = set[pos];
-        if (seen == k32) {
+      if (seen == 0xffffffffu) {
+        const uint32_t old = atomicCAS(&set[pos], 0xffffffffu, k32);
+        if (old == 0xffffffffu) {
+          atomicAdd(out, 1u);
           break;
         }
-        if (seen == 0xffffffffu) {
-          const uint32_t old = atomicCAS(&set[pos], 0xffffffffu, k32);
-          if (old == 0xffffffffu) {
-            atomicAdd(&count, 1u);
-            break;
-          }
-          if (old == k32) {
-            break;
-          }
+        if (old == k32) {
+          break;
         }
-        pos = (pos + 1) & (kCardSetSize - 1);
       }
+      pos = (pos + 1) & (kCardSetSize - 1);
     }
-  }
-  blockSync();
-  if (threadIdx.x == 0) {
-    out[0] = count;
   }
 }
 
@@ -2706,23 +2685,38 @@ __device__ inline void firstRowsDistinct(const KeyArg* keys, int32_t numKeys, in
   }
   blockSync();
   const int64_t rows = numRows < kFirstRowsProbe ? numRows : kFirstRowsProbe;
-  for (int64_t row = threadIdx.x; row < rows; row += blockDim.x) {
+  // every thread first fetches ALL its rows' keys (independent loads: one memory latency, not
+  // eight in a row behind the set's atomics), then inserts their hashes
+  constexpr int kPerThread = kFirstRowsProbe / 256;
+  uint64_t hs[kPerThread];
+#pragma unroll
+  for (int u = 0; u < kPerThread; ++u) {
+    const int64_t row = static_cast<int64_t>(threadIdx.x) + static_cast<int64_t>(u) * blockDim.x;
     uint64_t h = 0x51ed270b27b4f3cfULL;
-    for (int k = 0; k < numKeys; ++k) {
-      const ColView& c = keys[k].col;
-      uint64_t v = 0x7ff8dead00000000ULL;  // null
-      if (!colIsNull(c, row)) {
-        KeyRange all;
-        all.min = INT64_MIN;
-        all.max = INT64_MAX;
-        int64_t id;
-        bool mappable;
-        valueIdAt(c, colIndex(c, row), all, &id, &mappable);
-        v = static_cast<uint64_t>(id);
+    if (row < rows) {
+      for (int k = 0; k < numKeys; ++k) {
+        const ColView& c = keys[k].col;
+        uint64_t v = 0x7ff8dead00000000ULL;  // null
+        if (!colIsNull(c, row)) {
+          KeyRange all;
+          all.min = INT64_MIN;
+          all.max = INT64_MAX;
+          int64_t id;
+          bool mappable;
+          valueIdAt(c, colIndex(c, row), all, &id, &mappable);
+          v = static_cast<uint64_t>(id);
+        }
+        h = hashMix(h, v);
       }
-      h = hashMix(h, v);
     }
-    h &= ~(1ULL << 63);  // never the empty marker
+    hs[u] = row < rows ? (h & ~(1ULL << 63)) : ~0ULL;  // (never the empty marker)
+  }
+#pragma unroll
+  for (int u = 0; u < kPerThread; ++u) {
+    const uint64_t h = hs[u];
+    if (h == ~0ULL) {
+      continue;
+    }
     uint32_t pos = static_cast<uint32_t>(h >> 20) & (2 * kFirstRowsProbe - 1);
     for (int probes = 0; probes < 2 * kFirstRowsProbe; ++probes) {
       const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&set[pos]), ~0ULL, h);
@@ -2750,8 +2744,11 @@ __device__ inline void keyStatsBody(const KeyArg* keys, int32_t numKeys, int64_t
     int64_t numRows;
     Counters* counters;
   } a{keys, numKeys, numRows, counters};
-  if (block == 0) {
+  // (the LAST block of the launch only probes the first rows: it runs next to the others instead of
+  // in front of one of them)
+  if (block == numBlocks) {
     firstRowsDistinct(keys, numKeys, numRows, counters);
+    return;
   }
   const int64_t stride = static_cast<int64_t>(numBlocks) * blockDim.x;
   int64_t mn[kMaxKeys], mx[kMaxKeys];
@@ -2818,7 +2815,7 @@ __device__ inline void keyStatsBody(const KeyArg* keys, int32_t numKeys, int64_t
 }
 
 __global__ __launch_bounds__(256) void k_key_stats(StatsArgs a) {
-  keyStatsBody(a.keys, a.numKeys, a.numRows, a.counters, blockIdx.x, gridDim.x);
+  keyStatsBody(a.keys, a.numKeys, a.numRows, a.counters, blockIdx.x, static_cast<int>(gridDim.x) - 1);
 }
 
 // Largest |input| of every DOUBLE sum over the analysed prefix: fixes the grid
@@ -2870,10 +2867,11 @@ __global__ __launch_bounds__(256) void k_sum_stats(AggArgs a) {
 // in a row cost more in launch gaps than in work): blocks [0, keyBlocks) analyse the keys of the
 // first keyRows rows, the others the DOUBLE sums' inputs of the first a.numRows rows.
 __global__ __launch_bounds__(256) void k_first_stats(AggArgs a, int64_t keyRows, int32_t keyBlocks) {
-  if (static_cast<int32_t>(blockIdx.x) < keyBlocks) {
-    keyStatsBody(a.keys, a.numKeys, keyRows, a.counters, blockIdx.x, keyBlocks);
+  if (static_cast<int32_t>(blockIdx.x) <= keyBlocks) {
+    keyStatsBody(a.keys, a.numKeys, keyRows, a.counters, blockIdx.x, keyBlocks);  // block keyBlocks: the distinct probe
   } else {
-    sumStatsBody(a, a.numRows, static_cast<int>(blockIdx.x) - keyBlocks, static_cast<int>(gridDim.x) - keyBlocks);
+    sumStatsBody(a, a.numRows, static_cast<int>(blockIdx.x) - keyBlocks - 1,
+                 static_cast<int>(gridDim.x) - keyBlocks - 1);
   }
 }
 
@@ -3011,8 +3009,8 @@ __global__ __launch_bounds__(256) void k_collect(const uint64_t* table, uint64_t
 }
 
 // Small tables (BASELINE configs 1 and 2: a few to a few thousand groups): live rows collected and
-// put into first-seen order by ONE workgroup - LDS list, bitonic sort on the first-row words (they
-// are distinct: a row belongs to one group) - instead of k_collect + a count read-back + a
+// put into first-seen order by ONE workgroup - LDS list, ranks by counting on the first-row words
+// (they are distinct: a row belongs to one group) - instead of k_collect + a count read-back + a
 // device-wide radix sort: no stream synchronisation between noMoreInput and the output page.
 constexpr int kSmallSortMax = 4096;
 __global__ __launch_bounds__(1024) void k_collect_sort_small(const uint64_t* table, uint32_t rows, int32_t stride,
@@ -3036,38 +3034,39 @@ __global__ __launch_bounds__(1024) void k_collect_sort_small(const uint64_t* tab
   }
   blockSync();
   const uint32_t n = count < static_cast<uint32_t>(kSmallSortMax) ? count : static_cast<uint32_t>(kSmallSortMax);
-  uint32_t m = 2;
-  while (m < n) {
-    m <<= 1;
-  }
-  for (uint32_t i = n + threadIdx.x; i < m; i += blockDim.x) {
-    keys[i] = ~0ULL;
-    vals[i] = ~0u;
-  }
-  blockSync();
-  for (uint32_t k = 2; k <= m; k <<= 1) {
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
-        const uint32_t o = i ^ j;
-        if (o > i) {
-          const uint64_t a = keys[i], b = keys[o];
-          if ((a > b) == ((i & k) == 0)) {
-            keys[i] = b;
-            keys[o] = a;
-            const uint32_t t = vals[i];
-            vals[i] = vals[o];
-            vals[o] = t;
-          }
-        }
-      }
-      blockSync();
-    }
-  }
+  // Rank of an entry = entries with a smaller first row (they are distinct). Every lane of a wave
+  // reads the same LDS word at a time (a broadcast): n / 1024 x n reads per thread - 2 us for
+  // 1000 groups, where 55 barrier-separated bitonic stages took 20.
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-    orderOut[i] = vals[i];
+    const uint64_t mine = keys[i];
+    uint32_t rank = 0;
+    for (uint32_t o = 0; o < n; ++o) {
+      rank += keys[o] < mine ? 1u : 0u;
+    }
+    orderOut[rank] = vals[i];
   }
   if (threadIdx.x == 0) {
     *found = count;
+  }
+}
+
+// The same for a table too large for one workgroup to scan: k_collect has listed the live rows,
+// *count of them (<= kSmallSortMax, the host knows the number of groups); one workgroup ranks them.
+__global__ __launch_bounds__(1024) void k_rank_sort_small(const uint64_t* firstIn, const uint32_t* indexIn,
+                                                           const uint32_t* count, uint32_t* orderOut) {
+  __shared__ uint64_t keys[kSmallSortMax];
+  const uint32_t n = *count < static_cast<uint32_t>(kSmallSortMax) ? *count : static_cast<uint32_t>(kSmallSortMax);
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    keys[i] = firstIn[i];
+  }
+  blockSync();
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const uint64_t mine = keys[i];
+    uint32_t rank = 0;
+    for (uint32_t o = 0; o < n; ++o) {
+      rank += keys[o] < mine ? 1u : 0u;
+    }
+    orderOut[rank] = indexIn[i];
   }
 }
 
@@ -3517,6 +3516,7 @@ struct vx355_agg {
   int64_t denseMinRows = 1 << 22;   // VX355_AGG_DENSE_MIN_ROWS
   int64_t denseLaunches = 0, denseRefolds = 0, denseMerges = 0;
   DevBuf denseFlags;
+  DevBuf cardSet;            // k_card_sample: [0] count, [16...] the set
   PinnedBuf outStage;        // small output pages leave through one pinned copy (getOutput)
   // The table was allocated but never written (rebuildTable skipped k_init_table because a radix
   // fold may come first and store every row itself); settleTable initialises it for anyone else.
@@ -4031,7 +4031,9 @@ bool chooseLds(const vx355_agg& h, int numAccs, LdsPlan* plan, size_t* ldsBytes)
   if ((h.mode != MODE_ARRAY && h.mode != MODE_NORMALIZED) || numAccs == 0) {
     return false;
   }
-  const size_t budget = 60 * 1024;
+  // (two workgroups of up to 72 KB share a CU's 160 KB; BASELINE config 1's direct layout - 2003
+  // possible keys x 3 words + the first-row words - takes 64 KB)
+  const size_t budget = 72 * 1024;
   const size_t accBytes = static_cast<size_t>(numAccs) * 8;
   if (h.mode == MODE_NORMALIZED || h.capacity > 8192) {
     // Too many possible keys for a map entry each (or an open-addressing table). Few of them
@@ -5179,8 +5181,10 @@ int ldsGrid(vx355_agg& h, LdsPlan& plan, size_t ldsBytes, int64_t rows, int thre
   const int64_t gridAtomic = std::max<int64_t>(1, std::min<int64_t>(ceilDiv(rows, minRowsPerBlock), full));
   plan.scratch = nullptr;
   if (h.ldsScratchFlush && plan.tableMode == MODE_ARRAY && plan.direct != 2) {
-    const int64_t live = plan.direct == 1 ? static_cast<int64_t>(plan.capacity)
-                                          : std::min<int64_t>(plan.S, std::max<int64_t>(h.numGroups, 1));
+    // (compact slots before the first launch has counted the groups: what the first rows showed)
+    const int64_t live = plan.direct == 1
+        ? static_cast<int64_t>(plan.capacity)
+        : std::min<int64_t>(plan.S, std::max<int64_t>({h.numGroups, h.firstRowsDistinct, 1}));
     const int64_t gridScratch = std::max<int64_t>(1, std::min<int64_t>(ceilDiv(rows, tile), full));
     const int64_t perCopy = static_cast<int64_t>(plan.capacity) * (plan.A + 1) * 8;
     if (live * (plan.A + 1) * gridAtomic > h.scratchMinAtomics && perCopy * gridScratch <= (64LL << 20)) {
@@ -5490,8 +5494,10 @@ void sampleCardinality(vx355_agg& h, const AggArgs& a, int64_t n) {
   }
   const int64_t step = std::max<int64_t>(1, n / c.numRows);
   resetCounters(h);
-  uint32_t* out = reinterpret_cast<uint32_t*>(h.denseFlags.ensure(64));
-  VX_LAUNCH("k_card_sample", k_card_sample, 1, 1024, 0, c, step, out);
+  uint32_t* out = reinterpret_cast<uint32_t*>(h.cardSet.ensure(64 + kCardSetSize * 4));
+  HIP_OK(hipMemsetAsync(out, 0, 64, Runtime::get().stream));
+  HIP_OK(hipMemsetAsync(out + 16, 0xff, kCardSetSize * 4, Runtime::get().stream));
+  VX_LAUNCH("k_card_sample", k_card_sample, 16, 1024, 0, c, step, out + 16, out);
   uint32_t found = 0;
   copyOut(&found, VX355_MEM_HOST, out, 4);
   resetCounters(h);   // rows outside the sampled ranges touched the statistics
@@ -5689,7 +5695,7 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
       if (sumStatsPending) {
         AggArgs sa = a;
         sa.numRows = std::min<int64_t>(n, 1 << 16);
-        VX_LAUNCH("k_first_stats", k_first_stats, keyBlocks + std::min(streamGrid(sa.numRows, 256), 64), 256, 0, sa,
+        VX_LAUNCH("k_first_stats", k_first_stats, keyBlocks + 1 + std::min(streamGrid(sa.numRows, 256), 64), 256, 0, sa,
                   keyRows, keyBlocks);
       } else {
         StatsArgs sa{};
@@ -5699,7 +5705,7 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
         }
         sa.numRows = keyRows;
         sa.counters = h.counters();
-        VX_LAUNCH("k_key_stats", k_key_stats, keyBlocks, 256, 0, sa);
+        VX_LAUNCH("k_key_stats", k_key_stats, keyBlocks + 1, 256, 0, sa);  // + the distinct probe's block
       }
       Counters c = readCounters(h);
       h.firstRowsDistinct = c.firstRowsDistinct;
@@ -5973,6 +5979,18 @@ void finalize(vx355_agg& h) {
     VX_LAUNCH("k_collect", k_collect, streamGrid(static_cast<int64_t>(h.capacity), 256), 256, 0,
               h.table.as<uint64_t>(), h.capacity, h.stride, h.orderKeys.as<uint64_t>(),
               h.orderVals.as<uint32_t>(), cursor);
+    if (!h.unorderedOutput && g <= static_cast<size_t>(kSmallSortMax)) {
+      // few groups in a large table (TPC-H Q1 with four keys: 196 of them): ranked by one workgroup
+      // straight from the list, no read-back of the count, no device-wide radix sort
+      uint32_t* order = static_cast<uint32_t*>(h.orderVals2.ensure(g * 4 + 64));
+      VX_LAUNCH("k_rank_sort_small", k_rank_sort_small, 1, 1024, 0, h.orderKeys.as<uint64_t>(),
+                h.orderVals.as<uint32_t>(), cursor, order);
+      copyIn(order + g, cursor, VX355_MEM_DEVICE, 4);  // the count, for the check behind the output page
+      h.order = order;
+      h.numOutput = static_cast<int64_t>(g);
+      h.collectCheck = static_cast<int64_t>(g);
+      return;
+    }
     Counters c = readCounters(h);
     const uint32_t found = c.numDeferred;  // first word of the block is the cursor
     if (found != g) {

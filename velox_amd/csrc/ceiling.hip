@@ -1,0 +1,102 @@
+// What the HBM of THIS box delivers to plain streaming kernels: the practical ceiling next to
+// the 8 TB/s datasheet figure every roofline fraction of bench.py is quoted against. Two
+// hand-written kernels in the style of the library's streaming passes (16-byte accesses, four
+// independent accesses per lane in flight, grid-stride over a few workgroups per CU):
+//   VX355_CEILING_READ  a read-only stream - nontemporal loads folded into one word per lane, one
+//                       store per workgroup: the shape of k_agg_fast (68 B read per row, nothing
+//                       written), bounded by the read rate alone;
+//   VX355_CEILING_COPY  read + write of the same number of bytes: the shape of the radix scatters,
+//                       the partitioned probe's record pass and the page writer.
+// MI355X_MICROARCH.md measures ~6.3 TB/s for a float4 copy; torch's Tensor.copy_ (what bench.py
+// used before) reaches 4.7-5.0 TB/s and therefore sat BELOW kernels it was meant to bound.
+#include "common.h"
+#include "device_utils.h"
+
+namespace vx {
+namespace {
+
+typedef unsigned int U32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(512) void k_ceiling_read(const U32x4* src, int64_t n, uint32_t* sink) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x * 4;
+  U32x4 acc = {0u, 0u, 0u, 0u};
+  int64_t i = (static_cast<int64_t>(blockIdx.x) * blockDim.x) * 4 + threadIdx.x;
+  for (; i + 3 * static_cast<int64_t>(blockDim.x) < n; i += stride) {
+    const U32x4 a = __builtin_nontemporal_load(src + i);
+    const U32x4 b = __builtin_nontemporal_load(src + i + blockDim.x);
+    const U32x4 c = __builtin_nontemporal_load(src + i + 2 * static_cast<int64_t>(blockDim.x));
+    const U32x4 d = __builtin_nontemporal_load(src + i + 3 * static_cast<int64_t>(blockDim.x));
+    acc ^= a ^ b ^ c ^ d;
+  }
+  for (; i < n; i += blockDim.x) {
+    acc ^= __builtin_nontemporal_load(src + i);
+  }
+  const uint32_t v = acc.x ^ acc.y ^ acc.z ^ acc.w;
+  if (v == 0x9e3779b9u) {  // (never true for the fill pattern: keeps the loads alive without a store per lane)
+    sink[blockIdx.x] = v;
+  }
+}
+
+__global__ __launch_bounds__(512) void k_ceiling_copy(const U32x4* src, U32x4* dst, int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x * 4;
+  int64_t i = (static_cast<int64_t>(blockIdx.x) * blockDim.x) * 4 + threadIdx.x;
+  for (; i + 3 * static_cast<int64_t>(blockDim.x) < n; i += stride) {
+    const U32x4 a = src[i];
+    const U32x4 b = src[i + blockDim.x];
+    const U32x4 c = src[i + 2 * static_cast<int64_t>(blockDim.x)];
+    const U32x4 d = src[i + 3 * static_cast<int64_t>(blockDim.x)];
+    dst[i] = a;
+    dst[i + blockDim.x] = b;
+    dst[i + 2 * static_cast<int64_t>(blockDim.x)] = c;
+    dst[i + 3 * static_cast<int64_t>(blockDim.x)] = d;
+  }
+  for (; i < n; i += blockDim.x) {
+    dst[i] = src[i];
+  }
+}
+
+}  // namespace
+}  // namespace vx
+
+using namespace vx;
+
+extern "C" int vx355_hbm_ceiling(int32_t kind, size_t bytes, int32_t iterations, double* gbytes_per_second) {
+  VX_API_BEGIN
+  VX_CHECK_ARG(gbytes_per_second && iterations >= 1 && bytes >= (1u << 20), "bad argument");
+  VX_CHECK_ARG(kind == VX355_CEILING_READ || kind == VX355_CEILING_COPY, "unknown ceiling kernel");
+  auto& rt = Runtime::get();
+  rt.requireInit();
+  const int64_t n = static_cast<int64_t>(bytes / 16);
+  DevBuf src, dst, sink;
+  src.ensure(static_cast<size_t>(n) * 16);
+  HIP_OK(hipMemsetAsync(src.ptr(), 0x5a, static_cast<size_t>(n) * 16, rt.stream));
+  const int grid = rt.numCUs * 8;
+  sink.ensure(static_cast<size_t>(grid) * 4 + 64);
+  if (kind == VX355_CEILING_COPY) {
+    dst.ensure(static_cast<size_t>(n) * 16);
+  }
+  hipEvent_t begin = rt.newEvent(), end = rt.newEvent();
+  auto launch = [&]() {
+    if (kind == VX355_CEILING_READ) {
+      hipLaunchKernelGGL(k_ceiling_read, dim3(grid), dim3(512), 0, rt.stream, src.as<U32x4>(), n, sink.as<uint32_t>());
+    } else {
+      hipLaunchKernelGGL(k_ceiling_copy, dim3(grid), dim3(512), 0, rt.stream, src.as<U32x4>(), dst.as<U32x4>(), n);
+    }
+  };
+  launch();
+  launch();  // warm-up: clocks, TLB
+  HIP_OK(hipEventRecord(begin, rt.stream));
+  for (int32_t i = 0; i < iterations; ++i) {
+    launch();
+  }
+  HIP_OK(hipEventRecord(end, rt.stream));
+  HIP_OK(hipEventSynchronize(end));
+  HIP_OK(hipGetLastError());
+  float ms = 0;
+  HIP_OK(hipEventElapsedTime(&ms, begin, end));
+  (void)hipEventDestroy(begin);
+  (void)hipEventDestroy(end);
+  const double moved = static_cast<double>(n) * 16 * (kind == VX355_CEILING_COPY ? 2 : 1) * iterations;
+  *gbytes_per_second = moved / (static_cast<double>(ms) * 1e-3) / 1e9;
+  VX_API_END
+}

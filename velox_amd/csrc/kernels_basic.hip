@@ -414,6 +414,24 @@ void compactBits(const uint64_t* dValues, const uint64_t* dNulls, const uint64_t
   *total = static_cast<int64_t>(rt.mail.host[0]);
 }
 
+
+// wrap-of-a-wrap (exec/OperatorUtils.cpp:393-422 wrapChild over an already wrapped vector, what
+// HashProbe::fillOutput does with FilterProject's output): out[i] = inner[outer[i]].
+__global__ __launch_bounds__(256) void k_compose_indices(const int32_t* inner, int32_t innerSize, const int32_t* outer,
+                                                         int64_t n, int32_t* out, uint32_t* bad) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  bool any = false;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int32_t at = __builtin_nontemporal_load(outer + i);
+    const bool ok = at >= 0 && at < innerSize;
+    any = any || !ok;
+    out[i] = ok ? inner[at] : 0;
+  }
+  if (any) {
+    *bad = 1;
+  }
+}
+
 }  // namespace vx
 
 using namespace vx;
@@ -567,6 +585,42 @@ int vx355_filter_compact(const uint64_t* values, const uint64_t* nulls, const ui
     copyOut(idx_out, VX355_MEM_HOST, dIdx, static_cast<size_t>(total) * 4);
   }
   *n_out = static_cast<int32_t>(total);
+  VX_API_END
+}
+
+int vx355_compose_indices(const int32_t* inner, int32_t inner_size, const int32_t* outer, int32_t num_rows,
+                          int32_t* out, int32_t mem) {
+  VX_API_BEGIN
+  auto& rt = Runtime::get();
+  rt.requireInit();
+  VX_CHECK_ARG(num_rows >= 0 && inner_size >= 0, "negative size");
+  if (num_rows == 0) {
+    return VX355_OK;
+  }
+  VX_CHECK_ARG(inner && outer && out, "NULL argument");
+  const bool host = mem == VX355_MEM_HOST;
+  DevBuf dIn, dOut;
+  const int32_t *di = inner, *dp = outer;
+  int32_t* dout = out;
+  if (host) {
+    int32_t* base = static_cast<int32_t*>(dIn.ensure((static_cast<size_t>(inner_size) + num_rows) * 4 + 64));
+    copyIn(base, inner, VX355_MEM_HOST, static_cast<size_t>(inner_size) * 4);
+    copyIn(base + inner_size, outer, VX355_MEM_HOST, static_cast<size_t>(num_rows) * 4);
+    di = base;
+    dp = base + inner_size;
+    dout = static_cast<int32_t*>(dOut.ensure(static_cast<size_t>(num_rows) * 4 + 64));
+  }
+  rt.mail.host[0] = 0;
+  VX_LAUNCH("k_compose_indices", k_compose_indices, streamGrid(num_rows, 256, 4), 256, 0, di, inner_size, dp,
+            static_cast<int64_t>(num_rows), dout, reinterpret_cast<uint32_t*>(rt.mail.dev));
+  if (host) {
+    copyOut(out, VX355_MEM_HOST, dout, static_cast<size_t>(num_rows) * 4);
+  } else {
+    rt.sync();
+  }
+  if (rt.mail.host[0] & 0xffffffffULL) {
+    VX_THROW(VX355_EINVAL, "vx355_compose_indices: an outer index lies outside the inner index vector");
+  }
   VX_API_END
 }
 

@@ -43,6 +43,7 @@ SYMBOLS = [
     "vx355_value_dict_destroy",
     "vx355_all_gather_v", "vx355_exchange_create", "vx355_exchange_send", "vx355_exchange_receive",
     "vx355_exchange_stream", "vx355_exchange_destroy", "vx355_exchange_destinations", "vx355_join_repartition", "vx355_agg_merge_partials",
+    "vx355_hbm_ceiling", "vx355_compose_indices",
 ]
 
 # int (*vx355_join_chunk_sink)(void* arg, int32_t chunk, const vx355_batch* received, vx355_join_probe* probe)
@@ -459,6 +460,29 @@ class DeviceColumn:
 def to_device(host_batch):
     """HostBatch -> HostBatch-like object whose columns live in HBM."""
     return abi.HostBatch([DeviceColumn(c) for c in host_batch.columns], host_batch.num_rows)
+
+
+def compose_indices_device(inner_ptr, inner_size, outer_ptr, n, out_ptr):
+    """out[i] = inner[outer[i]] on HBM-resident int32 arrays (dictionary over a dictionary)."""
+    _check(lib().vx355_compose_indices(C.c_void_p(inner_ptr), inner_size, C.c_void_p(outer_ptr), n, C.c_void_p(out_ptr),
+                                       abi.MEM_DEVICE))
+
+
+def compose_indices(inner, outer):
+    """Host arrays: numpy int32 inner[outer]."""
+    inner = np.ascontiguousarray(inner, dtype=np.int32)
+    outer = np.ascontiguousarray(outer, dtype=np.int32)
+    out = np.empty(len(outer), dtype=np.int32)
+    _check(lib().vx355_compose_indices(inner.ctypes.data_as(C.c_void_p), len(inner), outer.ctypes.data_as(C.c_void_p),
+                                       len(outer), out.ctypes.data_as(C.c_void_p), abi.MEM_HOST))
+    return out
+
+
+def hbm_ceiling(kind, nbytes=4 << 30, iterations=5):
+    """GB/s of the library's read-only stream (abi.CEILING_READ) or copy (abi.CEILING_COPY) kernel."""
+    out = C.c_double()
+    _check(lib().vx355_hbm_ceiling(kind, C.c_size_t(nbytes), iterations, C.byref(out)))
+    return out.value
 
 
 # ---- profiling -----------------------------------------------------------

@@ -10,8 +10,9 @@ exec/tests/utils/TpchQueryBuilder.cpp:467-558), everything resident in HBM:
 
 Pass-through columns travel as dictionary vectors over the selected-row
 indices, exactly like FilterProject / HashProbe::fillOutput wrap them
-(exec/OperatorUtils.cpp:380-422); composing two index vectors (indices of
-indices) is the only thing torch is asked to do here.
+(exec/OperatorUtils.cpp:380-422); two index vectors are composed by the
+library (vx355_compose_indices). torch only allocates the buffers: no torch
+kernel runs inside the query.
 """
 import ctypes as C
 
@@ -72,11 +73,11 @@ def run_q3(ops, torch, tables, date=Q3_DATE):
     map_o = torch.empty(max(1, mo), dtype=torch.int32, device=dev)
     n1, fin = p1.get_output_device(max(1, mo), map_o.data_ptr(), None, None, [])
     assert fin
-    ord_idx = idx_o[map_o[:n1].long()].contiguous() if n1 else idx_o[:0]
-    # ord_idx is produced by torch kernels on torch's stream; the library's operators run on their own
-    # streams and take device inputs as complete (include/vx355.h, vx355_column.mem): drain torch's
-    # stream first (a C++ host would use vx355_stream_wait_event with the producer's event instead).
-    torch.cuda.current_stream(dev).synchronize()
+    # pass-through columns of the probe output = dictionary over FilterProject's dictionary: the
+    # library composes the two index vectors (vx355_compose_indices, wrapChild of a wrapped vector)
+    ord_idx = torch.empty(max(1, n1), dtype=torch.int32, device=dev)
+    if n1:
+        ops.compose_indices_device(idx_o.data_ptr(), mo, map_o.data_ptr(), n1, ord_idx.data_ptr())
     info["orders_selected"], info["orders_joined"] = mo, n1
     b2 = ops.HashBuild([0], [abi.BIGINT], [1, 2], [abi.INTEGER, abi.INTEGER], abi.JOIN_INNER)
     if n1:
@@ -103,8 +104,9 @@ def run_q3(ops, torch, tables, date=Q3_DATE):
     n2, fin = p2.get_output_device(cap, map_l.data_ptr(), None, descs, [0, 1])
     assert fin
     info["lineitems_selected"], info["lineitems_joined"] = ml, n2
-    li_idx = idx_l[map_l[:n2].long()].contiguous() if n2 else idx_l[:0]
-    torch.cuda.current_stream(dev).synchronize()
+    li_idx = torch.empty(max(1, n2), dtype=torch.int32, device=dev)
+    if n2:
+        ops.compose_indices_device(idx_l.data_ptr(), ml, map_l.data_ptr(), n2, li_idx.data_ptr())
 
     # -- aggregation: group by (l_orderkey, o_orderdate, o_shippriority), sum(ep * (1 - disc))
     agg = ops.HashAggregation([0, 1, 2], [abi.BIGINT, abi.INTEGER, abi.INTEGER],
