@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--no-cpu-mt", action="store_true", help="skip the one-worker-per-core CPU leg")
     ap.add_argument("--c1-stream", action="store_true",
                     help="c1: feed 10 000-row host vectors instead of one resident batch")
+    ap.add_argument("--host-stream", action="store_true",
+                    help="q1: the scan arrives as 10 000-row HOST vectors through the asynchronous boundary (use --rows)")
     ap.add_argument("--q3-random-probe", action="store_true",
                     help="q3: lineitems in random order instead of dbgen's l_orderkey clustering")
     ap.add_argument("--c4-sparse", action="store_true",
@@ -162,6 +164,29 @@ class DevBatch:
         return C.byref(self.batch)
 
 
+def raw_host_column(kind, values):
+    """FLAT host column over a numpy buffer that already has Velox's layout (StringViews as (n, 16)
+    uint8 rows): no per-value conversion."""
+    col = abi.HostColumn.__new__(abi.HostColumn)
+    col.kind, col.encoding, col.keep = kind, abi.FLAT, []
+    col.values = np.ascontiguousarray(values)
+    col.base_size = col.num_rows = len(col.values)
+    col.indices = col.valid = col.nulls = None
+    return col
+
+
+def stream_host_batches(op, batches):
+    """Feeds an operator the way a Velox Driver does - many small HOST vectors - through the
+    asynchronous boundary (queue, parallel ingest into pinned chunks, one upload + launch per chunk);
+    returns the milliseconds the calling thread spent queueing."""
+    t0 = time.perf_counter()
+    for b in batches:
+        op.add_input_async(b)
+    queued = (time.perf_counter() - t0) * 1e3
+    op.wait()
+    return queued
+
+
 # ---------------------------------------------------------------- Q1 ----------
 def string_views(torch, codes):
     """1-char inline StringViews (type/StringView.h:76-77) from byte codes."""
@@ -252,17 +277,42 @@ class Q1:
                   (abi.AGG_AVG, 2, abi.DOUBLE), (abi.AGG_AVG, 3, abi.DOUBLE), (abi.AGG_AVG, 4, abi.DOUBLE),
                   (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
 
+    stream = False   # --host-stream: the scan arrives as 10 000-row HOST vectors (PCIe inclusive)
+
+    def host_batches(self):
+        if not hasattr(self, "_host_batches"):
+            c = self.c
+            host = [(abi.VARCHAR, c["rf"].cpu().numpy().view(np.uint8).reshape(-1, 16)),
+                    (abi.VARCHAR, c["ls"].cpu().numpy().view(np.uint8).reshape(-1, 16)),
+                    (abi.DOUBLE, c["qty"].cpu().numpy()), (abi.DOUBLE, c["ep"].cpu().numpy()),
+                    (abi.DOUBLE, c["disc"].cpu().numpy()), (abi.DOUBLE, c["tax"].cpu().numpy()),
+                    (abi.INTEGER, c["ship"].cpu().numpy())]
+            self._host_batches = [abi.HostBatch([raw_host_column(k, v[i:i + 10000]) for k, v in host])
+                                  for i in range(0, self.n, 10000)]
+        return self._host_batches
+
     def step(self, step_kind=abi.STEP_SINGLE):
         if self.fused:
             # One operator: FilterProject fused into HashAggregation
             # (vx355_agg_set_fused_input); the scan columns are read once.
             op = ops.HashAggregation(Q1_KEYS[0], Q1_KEYS[1], self.FUSED_AGGS, step_kind)
             op.set_fused_input(Q1_TERMS, Q1_PROJ)
-            op.add_input(self.scan)
+            if self.stream:
+                self.submit_ms = stream_host_batches(op, self.host_batches())
+            else:
+                op.add_input(self.scan)
             op.no_more_input()
             self.selected = self.n
             return ops.collect_output(op, 1024)
         return self.step_unfused(step_kind)
+
+    def info(self):
+        if self.stream:
+            return {"input": "%d x 10 000-row host vectors through vx355_agg_add_input_async (PCIe inclusive)"
+                             % len(self.host_batches()),
+                    "driver_thread_ms_queueing_the_last_step": round(self.submit_ms, 3),
+                    "host_bytes_per_step": self.n * 68}
+        return {"input": "one HBM-resident batch"}
 
     def partial_operator(self):
         """The PARTIAL operator of this rank's shard after noMoreInput (N > 1: vx355_agg_merge_partials drains it)."""
@@ -461,16 +511,13 @@ class C1:
                 self._host_batches = [abi.HostBatch([abi.HostColumn(abi.BIGINT, hk[i:i + 10000]),
                                                      abi.HostColumn(abi.DOUBLE, hv[i:i + 10000])])
                                       for i in range(0, self.n, 10000)]
-            if os.environ.get("VX355_C1_ASYNC") == "1":
-                # asynchronous boundary: the Driver thread only queues; the handle's worker stages and launches
-                t0 = time.perf_counter()
-                for b in self._host_batches:
-                    op.add_input_async(b)
-                self.submit_ms = (time.perf_counter() - t0) * 1e3
-                op.wait()
-            else:
-                for b in self._host_batches:   # PCIe-inclusive: every vector starts in host memory
+            if os.environ.get("VX355_C1_SYNC") == "1":
+                for b in self._host_batches:   # synchronous addInput: the calling thread stages every vector itself
                     op.add_input(b)
+            else:
+                # asynchronous boundary: the Driver thread only queues; copier threads fill pinned chunks,
+                # the handle's worker uploads and launches
+                self.submit_ms = stream_host_batches(op, self._host_batches)
         else:
             op.add_input(self.batch)
         op.no_more_input()
@@ -482,7 +529,8 @@ class C1:
     def info(self):
         if self.stream and hasattr(self, "submit_ms"):
             return {"input": "1000 x 10 000-row host vectors through vx355_agg_add_input_async (PCIe inclusive)",
-                    "driver_thread_ms_queueing_the_last_step": round(self.submit_ms, 3)}
+                    "driver_thread_ms_queueing_the_last_step": round(self.submit_ms, 3),
+                    "host_bytes_per_step": self.n * 16}
         return {"input": "1000 x 10 000-row host vectors (PCIe inclusive)" if self.stream
                 else "one HBM-resident batch"}
 
@@ -1201,6 +1249,10 @@ def main():
         wl = cls(torch, n, device, seed=1234 + rank)
     if args.workload == "q1":
         wl.fused = not args.unfused
+        wl.stream = args.host_stream
+        if args.host_stream:
+            wl.name = "tpch_q1_streamed_host_vectors"
+
     if world > 1 and args.workload not in ("q1", "c5"):
         raise SystemExit(f"--workload {args.workload} is a single-GPU measurement; q1 and c5 shard over GPUs")
 
@@ -1286,7 +1338,7 @@ def main():
     child_flags = ["--workload", args.workload]
     for flag, on in (("--q3-random-probe", args.q3_random_probe), ("--c4-sparse", args.c4_sparse),
                      ("--c4-unordered", args.c4_unordered),
-                     ("--unfused", args.unfused), ("--c1-stream", args.c1_stream)):
+                     ("--unfused", args.unfused), ("--c1-stream", args.c1_stream), ("--host-stream", args.host_stream)):
         if on:
             child_flags.append(flag)
     if args.rows:
@@ -1464,6 +1516,10 @@ SECONDARY = [
     ("c4_groupby_1b_100m", "c4", {"sparse": False, "unordered": False, "name": "c4_groupby_1b_100m"}, [], 3, 1),
     ("c4_groupby_1b_100m_sparse_keys", "c4", {"sparse": True, "unordered": False,
                                               "name": "c4_groupby_1b_100m_sparse_keys"}, ["--c4-sparse"], 3, 1),
+    # the boundary north_star names: host RowVectors of 10 000 rows (PCIe inclusive; roofline = the link, not HBM)
+    ("c1_groupby_10m_1k_streamed_host_vectors", "c1", {"stream": True}, None, 10, 2),
+    ("tpch_q1_60m_rows_streamed_host_vectors", "q1", {"stream": True, "rows_override": 60_000_000,
+                                                      "name": "tpch_q1_streamed_host_vectors"}, None, 3, 1),
 ]
 
 
@@ -1472,9 +1528,13 @@ def secondary_block(torch, device, args, copy_ceiling, measure, workload, attrs,
     (inputs resident, synchronised on both sides), with its own roofline (counter traffic from
     rocprofv3 child passes of the same workload) and CPU baseline."""
     cls, rows = WORKLOADS[workload]
+    saved = {k: getattr(cls, k, None) for k in attrs}
     for k, v in attrs.items():
         setattr(cls, k, v)
+    rows = attrs.get("rows_override", rows)
     wl = cls(torch, rows, device, seed=1234)
+    host_stream = child_flags is None   # PCIe-inclusive blocks: no HBM roofline, no counter passes
+    child_flags = child_flags or []
     if workload in ("q1", "q1x4"):
         wl.fused = True
     steps = max(1, steps or args.secondary_steps)
@@ -1498,9 +1558,15 @@ def secondary_block(torch, device, args, copy_ceiling, measure, workload, attrs,
         "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
         "config": {"workload": wl.name, "rows": wl.rows_per_step(), "step": STEP_TEXT[workload]},
         "workload_info": wl.info() if hasattr(wl, "info") else {},
-        "roofline": roofline_block(wl, prof, steps, copy_ceiling, child if measure else None),
         "kernels_ms_per_step": {k: round(v[0] / steps, 4) for k, v in sorted(prof.items())},
     }
+    if host_stream:
+        nbytes = block["workload_info"].get("host_bytes_per_step", 0)
+        block["host_ingest"] = {"GBps": nbytes * steps / elapsed / 1e9, "pcie_gen5_x16_GBps": 63.0,
+                                "note": "PCIe inclusive: every vector starts in pageable host memory; not comparable "
+                                        "with the HBM-resident lines"}
+    else:
+        block["roofline"] = roofline_block(wl, prof, steps, copy_ceiling, child if measure else None)
     if getattr(wl, "probe_phase_ms", None):
         # all probe-side kernels together, priced at key in + hit out (12 B/probe) and at SURVEY section 8(d)'s 24 B
         ms = wl.probe_phase_ms / steps
@@ -1517,6 +1583,11 @@ def secondary_block(torch, device, args, copy_ceiling, measure, workload, attrs,
         oracle_lib.lib()
         block["cpu_baseline"] = cpu_baseline_block(wl, oracle_lib, min(args.cpu_sample_rows, 8_000_000), workload)
     del wl
+    for k, v in saved.items():
+        if v is None and k in cls.__dict__:
+            delattr(cls, k)
+        elif v is not None:
+            setattr(cls, k, v)
     torch.cuda.empty_cache()
     return block
 

@@ -94,3 +94,57 @@ def test_join_build_async_input(oracle, vx):
         return sorted(rows)
     want = run(oracle, False)
     assert run(vx, True) == want and len(want) > 0
+
+
+@pytest.mark.parametrize("chunk_rows", [None, "40000"])
+def test_parallel_ingest_of_small_host_vectors_keeps_order_and_results(oracle, vx, monkeypatch, chunk_rows):
+    """Host vectors without null bitmaps go through the parallel ingest (copier threads fill pinned
+    chunks, the worker takes whole chunks): same groups in the same first-seen order as the oracle fed
+    the same vectors one by one. In the middle of the stream: a vector with a null bitmap (ordinary
+    path, in order), one with a 20-byte string (its chunk falls back to vector-by-vector input) and
+    an empty one. Small chunks (VX355_INGEST_CHUNK_ROWS) make the ring of four chunks go round."""
+    if chunk_rows:
+        monkeypatch.setenv("VX355_INGEST_CHUNK_ROWS", chunk_rows)
+    rng = np.random.default_rng(21)
+    codes = [b"AA", b"B", b"CCC", b"", b"DDDDDDDDDDDD"]
+    batches = []
+    for i in range(150):
+        n = 0 if i == 70 else int(rng.integers(3000, 9000))
+        # new keys keep appearing: the first-seen order depends on the order the vectors take effect
+        k = rng.integers(0, 50 + 20 * i, n).astype(np.int64)
+        s = [codes[j] for j in rng.integers(0, len(codes), n)]
+        if i == 90 and n:
+            s[5] = b"a string of 20 bytes"
+        v = rng.integers(-1 << 20, 1 << 20, n) / 1024.0
+        valid = [None, None, (rng.random(n) > 0.1) if i == 40 else None]
+        batches.append(batch_of([k, s, v], valid))
+    aggs = [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_COUNT, 2, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    exp, _ = run_agg(oracle, batches, [0, 1], [abi.BIGINT, abi.VARCHAR], aggs, max_rows=1 << 20)
+    op = vx.Aggregation([0, 1], [abi.BIGINT, abi.VARCHAR], aggs)
+    tickets = [op.add_input_async(b) for b in batches]
+    assert tickets == list(range(1, 151))
+    sub, done = op.poll()
+    assert sub == 150 and 0 <= done <= 150
+    op.wait()
+    assert op.poll() == (150, 150)
+    op.no_more_input()
+    got = vx.collect_output(op, 1 << 20)
+    assert_columns_equal(got, exp, op.kinds, what="parallel ingest")
+    assert op.stats().input_rows == sum(b.num_rows for b in batches)
+
+
+def test_polling_alone_completes_the_batches_of_an_open_chunk(vx):
+    """A shim that never calls wait: the batches assigned to a chunk that is not full yet complete
+    once polls see no new submissions (the open chunk is handed to the worker)."""
+    import time
+    rng = np.random.default_rng(22)
+    op = vx.Aggregation([0], [abi.BIGINT], [(abi.AGG_COUNT_STAR, -1, abi.BIGINT)])
+    for _ in range(3):
+        op.add_input_async(batch_of([rng.integers(0, 10, 1000).astype(np.int64)]))
+    deadline = time.time() + 30
+    while op.poll() != (3, 3):
+        assert time.time() < deadline, op.poll()
+        time.sleep(0.001)
+    op.no_more_input()
+    got = vx.collect_output(op, 100)
+    assert int(np.sum(got[1][0])) == 3000

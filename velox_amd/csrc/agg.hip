@@ -2674,7 +2674,8 @@ __global__ __launch_bounds__(1024) void k_card_sample(AggArgs a, int64_t step, u
 // will not pile up on a handful of addresses, and a direct LDS layout can be chosen for the whole
 // first batch without the small probing chunk that otherwise counts the live groups first.
 constexpr int kFirstRowsProbe = 2048;
-__device__ inline void firstRowsDistinct(const KeyArg* keys, int32_t numKeys, int64_t numRows, Counters* counters) {
+template <typename Args>
+__device__ inline void firstRowsDistinct(const Args& keys, int32_t numKeys, int64_t numRows, Counters* counters) {
   __shared__ uint64_t set[2 * kFirstRowsProbe];
   __shared__ uint32_t distinct;
   for (int i = threadIdx.x; i < 2 * kFirstRowsProbe; i += blockDim.x) {
@@ -2695,7 +2696,7 @@ __device__ inline void firstRowsDistinct(const KeyArg* keys, int32_t numKeys, in
     uint64_t h = 0x51ed270b27b4f3cfULL;
     if (row < rows) {
       for (int k = 0; k < numKeys; ++k) {
-        const ColView& c = keys[k].col;
+        const ColView& c = keys.keys[k].col;
         uint64_t v = 0x7ff8dead00000000ULL;  // null
         if (!colIsNull(c, row)) {
           KeyRange all;
@@ -2736,18 +2737,20 @@ __device__ inline void firstRowsDistinct(const KeyArg* keys, int32_t numKeys, in
   }
 }
 
-__device__ inline void keyStatsBody(const KeyArg* keys, int32_t numKeys, int64_t numRows, Counters* counters,
-                                    int block, int numBlocks) {
+// (Args = the kernel's own argument struct, StatsArgs or AggArgs: the key views are read straight
+// from the kernel arguments - a pointer into them would turn every access into a flat load.)
+template <typename Args>
+__device__ inline void keyStatsBody(const Args& args, int64_t numRows, int block, int numBlocks) {
   struct {
-    const KeyArg* keys;
+    const Args& k;
     int32_t numKeys;
     int64_t numRows;
     Counters* counters;
-  } a{keys, numKeys, numRows, counters};
+  } a{args, args.numKeys, numRows, args.counters};
   // (the LAST block of the launch only probes the first rows: it runs next to the others instead of
   // in front of one of them)
   if (block == numBlocks) {
-    firstRowsDistinct(keys, numKeys, numRows, counters);
+    firstRowsDistinct(args, args.numKeys, numRows, args.counters);
     return;
   }
   const int64_t stride = static_cast<int64_t>(numBlocks) * blockDim.x;
@@ -2760,7 +2763,7 @@ __device__ inline void keyStatsBody(const KeyArg* keys, int32_t numKeys, int64_t
   for (int64_t row = static_cast<int64_t>(block) * blockDim.x + threadIdx.x; row < a.numRows;
        row += stride) {
     for (int k = 0; k < a.numKeys; ++k) {
-      const ColView& c = a.keys[k].col;
+      const ColView& c = a.k.keys[k].col;
       if (colIsNull(c, row)) {
         continue;
       }
@@ -2815,7 +2818,7 @@ __device__ inline void keyStatsBody(const KeyArg* keys, int32_t numKeys, int64_t
 }
 
 __global__ __launch_bounds__(256) void k_key_stats(StatsArgs a) {
-  keyStatsBody(a.keys, a.numKeys, a.numRows, a.counters, blockIdx.x, static_cast<int>(gridDim.x) - 1);
+  keyStatsBody(a, a.numRows, blockIdx.x, static_cast<int>(gridDim.x) - 1);
 }
 
 // Largest |input| of every DOUBLE sum over the analysed prefix: fixes the grid
@@ -2868,7 +2871,7 @@ __global__ __launch_bounds__(256) void k_sum_stats(AggArgs a) {
 // first keyRows rows, the others the DOUBLE sums' inputs of the first a.numRows rows.
 __global__ __launch_bounds__(256) void k_first_stats(AggArgs a, int64_t keyRows, int32_t keyBlocks) {
   if (static_cast<int32_t>(blockIdx.x) <= keyBlocks) {
-    keyStatsBody(a.keys, a.numKeys, keyRows, a.counters, blockIdx.x, keyBlocks);  // block keyBlocks: the distinct probe
+    keyStatsBody(a, keyRows, blockIdx.x, keyBlocks);  // block keyBlocks: the distinct probe
   } else {
     sumStatsBody(a, a.numRows, static_cast<int>(blockIdx.x) - keyBlocks - 1,
                  static_cast<int>(gridDim.x) - keyBlocks - 1);
@@ -3022,14 +3025,21 @@ __global__ __launch_bounds__(1024) void k_collect_sort_small(const uint64_t* tab
     count = 0;
   }
   blockSync();
-  for (uint32_t r = threadIdx.x; r < rows; r += blockDim.x) {
-    const uint64_t first = table[static_cast<uint64_t>(r) * stride + 1];
-    if (first != kNoRow) {
-      const uint32_t p = atomicAdd(&count, 1u);
-      if (p < static_cast<uint32_t>(kSmallSortMax)) {
-        keys[p] = first;
-        vals[p] = r;
-      }
+  // (one LDS atomic per wave and round, not per live row: a thousand atomics on one LDS word cost
+  // more than everything else in this kernel)
+  for (uint32_t base = 0; base < rows; base += blockDim.x) {
+    const uint32_t r = base + threadIdx.x;
+    const uint64_t first = r < rows ? table[static_cast<uint64_t>(r) * stride + 1] : kNoRow;
+    const bool liveRow = first != kNoRow;
+    const uint64_t m = ballot(liveRow);
+    uint32_t at = 0;
+    if (m != 0 && lane() == 0) {
+      at = atomicAdd(&count, static_cast<uint32_t>(popc64(m)));
+    }
+    at = __shfl(at, 0, kWave) + lanePrefix(m);
+    if (liveRow && at < static_cast<uint32_t>(kSmallSortMax)) {
+      keys[at] = first;
+      vals[at] = r;
     }
   }
   blockSync();
@@ -3495,6 +3505,7 @@ struct vx355_agg {
   DevBuf ldsScratch;            // per-workgroup copies of the scratch flush (ldsGrid)
   bool ldsScratchFlush = true;  // VX355_AGG_SCRATCH_FLUSH=0: every LDS flush goes through HBM atomics
   int64_t scratchFlushes = 0;
+  int scratchBlocksPerCu = 2;  // VX355_AGG_SCRATCH_BLOCKS_PER_CU: workgroups (= copies) per CU of a scratch-flush launch
   int64_t scratchMinAtomics = 256 << 10;  // VX355_AGG_SCRATCH_MIN_ATOMICS: flushes below this many HBM atomics keep them
   // radix-partitioned path (high cardinality)
   DevBuf rpRecs1, rpRecs2, rpHist, rpOffsets, rpTiles, rpMisc, rpScan, rpLayout2;
@@ -5176,6 +5187,7 @@ int ldsGrid(vx355_agg& h, LdsPlan& plan, size_t ldsBytes, int64_t rows, int thre
   auto& rt = Runtime::get();
   const int blocksPerCu = std::max<int>(1, std::min<int>(maxBlocksPerCu, static_cast<int>((150 * 1024) / ldsBytes)));
   const int64_t full = static_cast<int64_t>(rt.numCUs) * blocksPerCu;
+  const int64_t fullScratch = static_cast<int64_t>(rt.numCUs) * std::min(blocksPerCu, h.scratchBlocksPerCu);
   const int64_t tile = static_cast<int64_t>(threads) * unroll;
   const int64_t minRowsPerBlock = std::max<int64_t>(tile, 4LL * plan.S * plan.A);
   const int64_t gridAtomic = std::max<int64_t>(1, std::min<int64_t>(ceilDiv(rows, minRowsPerBlock), full));
@@ -5185,7 +5197,7 @@ int ldsGrid(vx355_agg& h, LdsPlan& plan, size_t ldsBytes, int64_t rows, int thre
     const int64_t live = plan.direct == 1
         ? static_cast<int64_t>(plan.capacity)
         : std::min<int64_t>(plan.S, std::max<int64_t>({h.numGroups, h.firstRowsDistinct, 1}));
-    const int64_t gridScratch = std::max<int64_t>(1, std::min<int64_t>(ceilDiv(rows, tile), full));
+    const int64_t gridScratch = std::max<int64_t>(1, std::min<int64_t>(ceilDiv(rows, tile), fullScratch));
     const int64_t perCopy = static_cast<int64_t>(plan.capacity) * (plan.A + 1) * 8;
     if (live * (plan.A + 1) * gridAtomic > h.scratchMinAtomics && perCopy * gridScratch <= (64LL << 20)) {
       h.ldsScratch.ensure(static_cast<size_t>(perCopy * gridScratch) + 64);
@@ -6487,6 +6499,9 @@ void configureFromEnv(vx355_agg& h) {
   if (const char* e = std::getenv("VX355_AGG_SCRATCH_FLUSH")) {
     h.ldsScratchFlush = std::atoi(e) != 0;
   }
+  if (const char* e = std::getenv("VX355_AGG_SCRATCH_BLOCKS_PER_CU")) {
+    h.scratchBlocksPerCu = std::max(1, std::atoi(e));
+  }
   if (const char* e = std::getenv("VX355_AGG_SCRATCH_MIN_ATOMICS")) {
     h.scratchMinAtomics = std::strtoll(e, nullptr, 10);
   }
@@ -7164,7 +7179,7 @@ int vx355_agg_add_input_async(vx355_agg* h, const vx355_batch* batch, int64_t* t
     if (const int failed = vx::asyncFailed(h->aq)) {
       return failed;  // an earlier batch failed: the handle stays failed (asyncWait)
     }
-    const int64_t ticket = vx::asyncSubmit(h->aq, vx::asyncBatchTask(batch, [h](const vx355_batch* b) -> int {
+    const int64_t ticket = vx::asyncSubmitBatch(h->aq, h->ctx->ds, batch, h->usedCols, [h](const vx355_batch* b) -> int {
       // the synchronous entry point minus its drain (this IS the queue's worker)
       VX_API_BEGIN_CTX(VX_CTX_OF(h))
       Runtime::get().requireInit();
@@ -7175,7 +7190,7 @@ int vx355_agg_add_input_async(vx355_agg* h, const vx355_batch* batch, int64_t* t
         feedInput(*d.dedup, b);
       }
       VX_API_END
-    }));
+    });
     if (ticket_out) {
       *ticket_out = ticket;
     }

@@ -34,6 +34,11 @@ void setLastError(const std::string& m);
 struct AsyncQueue;
 AsyncQueue* asyncCreate();
 int64_t asyncSubmit(AsyncQueue* q, std::function<int(std::string*)> task);
+struct DeviceState;
+// A batch for the handle: through the parallel ingest (async.hip) when it qualifies, else as an
+// ordinary task; 'call' is how the handle takes a batch (on the queue's worker thread).
+int64_t asyncSubmitBatch(AsyncQueue* q, DeviceState* ds, const vx355_batch* batch, const std::vector<int32_t>& usedCols,
+                         std::function<int(const vx355_batch*)> call);
 void asyncPoll(AsyncQueue* q, int64_t* submitted, int64_t* completed);
 int asyncWait(AsyncQueue* q);
 void asyncQuiesce(AsyncQueue* q);
@@ -121,6 +126,7 @@ struct CachedBlock {
   void* p;
   uint64_t ownerCtx;   // context whose stream may still touch the block (0 = nobody)
   uint64_t ownerCall;  // that context's call number when the block was released
+  uint64_t seq = 0;    // order of release: the cache evicts the blocks that have waited longest
 };
 struct DeviceState {
   int device = -1;
@@ -136,6 +142,7 @@ struct DeviceState {
   // hipMalloc/hipFree (which synchronise the device).
   std::multimap<size_t, CachedBlock> freeBlocks;
   size_t cachedBytes = 0;
+  uint64_t cacheSeq = 0;
   size_t cacheLimit = 16ULL << 30;
   // Pinned host blocks (power-of-two sizes >= 64 KB): hipHostMalloc costs ~0.3 ms a
   // call, so released blocks are kept (up to pinnedLimit bytes) for the next operator.

@@ -3779,8 +3779,8 @@ int vx355_join_build_add_input_async(vx355_join_build* h, const vx355_batch* bat
     if (const int failed = vx::asyncFailed(h->aq)) {
       return failed;  // an earlier batch failed: the handle stays failed (asyncWait)
     }
-    const int64_t ticket = vx::asyncSubmit(
-        h->aq, vx::asyncBatchTask(batch, [h](const vx355_batch* b) { return joinBuildAddInputNow(h, b); }));
+    const int64_t ticket = vx::asyncSubmitBatch(h->aq, h->ctx->ds, batch, h->usedCols,
+                                                [h](const vx355_batch* b) { return joinBuildAddInputNow(h, b); });
     if (ticket_out) {
       *ticket_out = ticket;
     }
