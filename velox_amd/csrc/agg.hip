@@ -2824,40 +2824,32 @@ __global__ __launch_bounds__(256) void k_key_stats(StatsArgs a) {
 // Largest |input| of every DOUBLE sum over the analysed prefix: fixes the grid
 // of the hi/lo split (AccArg::splitM).
 __device__ inline void sumStatsBody(const AggArgs& a, int64_t numRows, int block, int numBlocks) {
+  // One accumulator after the other (a few rows per thread: re-reading them per DOUBLE sum is
+  // nothing) - sixteen unrolled copies of accInput needed 332 registers and 3.5 KB of scratch per
+  // lane, which every block of k_first_stats paid for, the key-statistics blocks included.
   const int64_t stride = static_cast<int64_t>(numBlocks) * blockDim.x;
-  uint64_t mx[kMaxAccs];
-#pragma unroll
-  for (int j = 0; j < kMaxAccs; ++j) {
-    mx[j] = 0;
-  }
-  for (int64_t row = static_cast<int64_t>(block) * blockDim.x + threadIdx.x; row < numRows;
-       row += stride) {
-    if (a.numTerms && !evalFilter(a.terms, a.numTerms, row)) {
+  for (int j = 0; j < a.numAccs; ++j) {
+    if (a.accs[j].kind != ACC_SUM_F64) {
       continue;
     }
-#pragma unroll
-    for (int j = 0; j < kMaxAccs; ++j) {
-      if (j < a.numAccs && a.accs[j].kind == ACC_SUM_F64) {
-        uint64_t v;
-        if (accInput(a, a.accs[j], row, &v)) {
-          v &= 0x7fffffffffffffffULL;  // |v| as a bit pattern orders like the magnitude
-          mx[j] = v > mx[j] ? v : mx[j];
-        }
+    uint64_t m = 0;
+    for (int64_t row = static_cast<int64_t>(block) * blockDim.x + threadIdx.x; row < numRows; row += stride) {
+      if (a.numTerms && !evalFilter(a.terms, a.numTerms, row)) {
+        continue;
+      }
+      uint64_t v;
+      if (accInput(a, a.accs[j], row, &v)) {
+        v &= 0x7fffffffffffffffULL;  // |v| as a bit pattern orders like the magnitude
+        m = v > m ? v : m;
       }
     }
-  }
 #pragma unroll
-  for (int j = 0; j < kMaxAccs; ++j) {
-    if (j < a.numAccs && a.accs[j].kind == ACC_SUM_F64) {
-      uint64_t m = mx[j];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const uint64_t o = shfl64(m, lane() ^ off);
-        m = o > m ? o : m;
-      }
-      if (lane() == 0 && m != 0) {
-        atomicMax(reinterpret_cast<unsigned long long*>(&a.counters->sumMax[j]), m);
-      }
+    for (int off = 32; off > 0; off >>= 1) {
+      const uint64_t o = shfl64(m, lane() ^ off);
+      m = o > m ? o : m;
+    }
+    if (lane() == 0 && m != 0) {
+      atomicMax(reinterpret_cast<unsigned long long*>(&a.counters->sumMax[j]), m);
     }
   }
 }
@@ -3012,50 +3004,66 @@ __global__ __launch_bounds__(256) void k_collect(const uint64_t* table, uint64_t
 }
 
 // Small tables (BASELINE configs 1 and 2: a few to a few thousand groups): live rows collected and
-// put into first-seen order by ONE workgroup - LDS list, ranks by counting on the first-row words
-// (they are distinct: a row belongs to one group) - instead of k_collect + a count read-back + a
-// device-wide radix sort: no stream synchronisation between noMoreInput and the output page.
+// put into first-seen order without k_collect + a count read-back + a device-wide radix sort: no
+// stream synchronisation between noMoreInput and the output page. Every workgroup lists ALL live
+// rows in its LDS (the table is a few KB; the list is the same in every workgroup: rows in table
+// order) and ranks 64 of them by counting the entries with a smaller first-row word (they are
+// distinct: a row belongs to one group): lane = one of the 64 entries x one of 16 segments of the
+// list, so a thousand groups are ranked by 16 workgroups in ~60 LDS reads per lane (one workgroup
+// ranking all of them alone took 20 us: 16 000 broadcast reads on one CU).
 constexpr int kSmallSortMax = 4096;
 __global__ __launch_bounds__(1024) void k_collect_sort_small(const uint64_t* table, uint32_t rows, int32_t stride,
                                                               uint32_t* orderOut, uint32_t* found) {
   __shared__ uint64_t keys[kSmallSortMax];
   __shared__ uint32_t vals[kSmallSortMax];
-  __shared__ uint32_t count;
-  if (threadIdx.x == 0) {
-    count = 0;
-  }
-  blockSync();
-  // (one LDS atomic per wave and round, not per live row: a thousand atomics on one LDS word cost
-  // more than everything else in this kernel)
+  __shared__ uint32_t waveCount[16];
+  __shared__ uint32_t rank[64];
+  uint32_t n = 0;
   for (uint32_t base = 0; base < rows; base += blockDim.x) {
     const uint32_t r = base + threadIdx.x;
     const uint64_t first = r < rows ? table[static_cast<uint64_t>(r) * stride + 1] : kNoRow;
     const bool liveRow = first != kNoRow;
     const uint64_t m = ballot(liveRow);
-    uint32_t at = 0;
-    if (m != 0 && lane() == 0) {
-      at = atomicAdd(&count, static_cast<uint32_t>(popc64(m)));
+    if (lane() == 0) {
+      waveCount[threadIdx.x >> 6] = static_cast<uint32_t>(popc64(m));
     }
-    at = __shfl(at, 0, kWave) + lanePrefix(m);
+    blockSync();
+    uint32_t before = n;
+    for (int w = 0; w < 16; ++w) {
+      const uint32_t c = waveCount[w];
+      before += w < static_cast<int>(threadIdx.x >> 6) ? c : 0;
+      n += c;
+    }
+    const uint32_t at = before + lanePrefix(m);
     if (liveRow && at < static_cast<uint32_t>(kSmallSortMax)) {
       keys[at] = first;
       vals[at] = r;
     }
+    blockSync();
+  }
+  const uint32_t count = n;
+  n = n < static_cast<uint32_t>(kSmallSortMax) ? n : static_cast<uint32_t>(kSmallSortMax);
+  if (threadIdx.x < 64) {
+    rank[threadIdx.x] = 0;
   }
   blockSync();
-  const uint32_t n = count < static_cast<uint32_t>(kSmallSortMax) ? count : static_cast<uint32_t>(kSmallSortMax);
-  // Rank of an entry = entries with a smaller first row (they are distinct). Every lane of a wave
-  // reads the same LDS word at a time (a broadcast): n / 1024 x n reads per thread - 2 us for
-  // 1000 groups, where 55 barrier-separated bitonic stages took 20.
-  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-    const uint64_t mine = keys[i];
-    uint32_t rank = 0;
-    for (uint32_t o = 0; o < n; ++o) {
-      rank += keys[o] < mine ? 1u : 0u;
+  const uint32_t mineAt = blockIdx.x * 64 + (threadIdx.x & 63);
+  if (mineAt < n) {
+    const uint64_t mine = keys[mineAt];
+    const uint32_t segment = threadIdx.x >> 6;
+    const uint32_t per = (n + 15) / 16;
+    const uint32_t end = (segment + 1) * per < n ? (segment + 1) * per : n;
+    uint32_t smaller = 0;
+    for (uint32_t o = segment * per; o < end; ++o) {
+      smaller += keys[o] < mine ? 1u : 0u;
     }
-    orderOut[rank] = vals[i];
+    atomicAdd(&rank[threadIdx.x & 63], smaller);
   }
-  if (threadIdx.x == 0) {
+  blockSync();
+  if (threadIdx.x < 64 && mineAt < n) {
+    orderOut[rank[threadIdx.x]] = vals[mineAt];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     *found = count;
   }
 }
@@ -3065,18 +3073,31 @@ __global__ __launch_bounds__(1024) void k_collect_sort_small(const uint64_t* tab
 __global__ __launch_bounds__(1024) void k_rank_sort_small(const uint64_t* firstIn, const uint32_t* indexIn,
                                                            const uint32_t* count, uint32_t* orderOut) {
   __shared__ uint64_t keys[kSmallSortMax];
+  __shared__ uint32_t rank[64];
   const uint32_t n = *count < static_cast<uint32_t>(kSmallSortMax) ? *count : static_cast<uint32_t>(kSmallSortMax);
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
     keys[i] = firstIn[i];
   }
+  if (threadIdx.x < 64) {
+    rank[threadIdx.x] = 0;
+  }
   blockSync();
-  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-    const uint64_t mine = keys[i];
-    uint32_t rank = 0;
-    for (uint32_t o = 0; o < n; ++o) {
-      rank += keys[o] < mine ? 1u : 0u;
+  // (as in k_collect_sort_small: 64 entries per workgroup, 16 segments of the list per entry)
+  const uint32_t mineAt = blockIdx.x * 64 + (threadIdx.x & 63);
+  if (mineAt < n) {
+    const uint64_t mine = keys[mineAt];
+    const uint32_t segment = threadIdx.x >> 6;
+    const uint32_t per = (n + 15) / 16;
+    const uint32_t end = (segment + 1) * per < n ? (segment + 1) * per : n;
+    uint32_t smaller = 0;
+    for (uint32_t o = segment * per; o < end; ++o) {
+      smaller += keys[o] < mine ? 1u : 0u;
     }
-    orderOut[rank] = indexIn[i];
+    atomicAdd(&rank[threadIdx.x & 63], smaller);
+  }
+  blockSync();
+  if (threadIdx.x < 64 && mineAt < n) {
+    orderOut[rank[threadIdx.x]] = indexIn[mineAt];
   }
 }
 
@@ -5976,8 +5997,8 @@ void finalize(vx355_agg& h) {
   const bool listed = h.pairsComplete && h.pairCount == h.numGroups;
   if (!listed && !h.unorderedOutput && h.capacity <= 65536 && g <= static_cast<size_t>(kSmallSortMax)) {
     uint32_t* order = static_cast<uint32_t*>(h.orderVals.ensure(g * 4 + 64));
-    VX_LAUNCH("k_collect_sort_small", k_collect_sort_small, 1, 1024, 0, h.table.as<uint64_t>(),
-              static_cast<uint32_t>(h.capacity), h.stride, order, order + g);
+    VX_LAUNCH("k_collect_sort_small", k_collect_sort_small, static_cast<int>(ceilDiv(static_cast<int64_t>(g), 64)), 1024,
+              0, h.table.as<uint64_t>(), static_cast<uint32_t>(h.capacity), h.stride, order, order + g);
     h.order = order;
     h.numOutput = static_cast<int64_t>(g);
     h.collectCheck = static_cast<int64_t>(g);  // verified behind the first output page's synchronisation
@@ -5995,7 +6016,8 @@ void finalize(vx355_agg& h) {
       // few groups in a large table (TPC-H Q1 with four keys: 196 of them): ranked by one workgroup
       // straight from the list, no read-back of the count, no device-wide radix sort
       uint32_t* order = static_cast<uint32_t*>(h.orderVals2.ensure(g * 4 + 64));
-      VX_LAUNCH("k_rank_sort_small", k_rank_sort_small, 1, 1024, 0, h.orderKeys.as<uint64_t>(),
+      VX_LAUNCH("k_rank_sort_small", k_rank_sort_small, static_cast<int>(ceilDiv(static_cast<int64_t>(g), 64)), 1024, 0,
+                h.orderKeys.as<uint64_t>(),
                 h.orderVals.as<uint32_t>(), cursor, order);
       copyIn(order + g, cursor, VX355_MEM_DEVICE, 4);  // the count, for the check behind the output page
       h.order = order;

@@ -87,12 +87,17 @@ class CopierPool {
 
 constexpr int kIngestChunks = 4;
 
+constexpr size_t kCopyGroup = 16;  // batches per copier task: one wake-up of a copier per 16 vectors
+
 struct IngestChunk {
   std::vector<char*> data;   // per layout column: pinned
   std::vector<size_t> cap;
   int64_t rows = 0;          // rows assigned so far (submitter side)
   int64_t tickets = 0;
-  std::vector<std::shared_ptr<OwnedBatch>> batches;  // alive until the chunk has been processed
+  // alive until the chunk has been processed
+  std::vector<std::unique_ptr<OwnedBatch>> batches;
+  std::vector<int64_t> offsets;   // row offset of batches[i] in the chunk
+  size_t handedOut = 0;           // batches[0 .. handedOut) have a copier task
   std::mutex m;
   std::condition_variable copied;
   int64_t pending = 0;       // copy tasks in flight
@@ -194,6 +199,58 @@ int64_t reserveTicket(AsyncQueue* q) {
   return ++q->submitted;
 }
 
+// Copies a group of batches into the chunk's pinned columns (a copier thread).
+struct CopyItem {
+  const OwnedBatch* batch;
+  int64_t offset;
+};
+void copyBatches(Ingest* ing, IngestChunk* c, const std::vector<CopyItem>& items) {
+  bool bad = false;
+  for (const CopyItem& item : items) {
+    const OwnedBatch& owned = *item.batch;
+    const int64_t n = owned.batch.num_rows;
+    for (size_t i = 0; i < ing->cols.size(); ++i) {
+      const vx355_column& col = owned.cols[ing->cols[i]];
+      const int w = ing->widths[i];
+      const char* src = static_cast<const char*>(col.values);
+      if (isString(ing->kinds[i])) {
+        // inline StringViews are plain 16-byte values; a longer string points into the caller's buffers
+        for (int64_t r = 0; r < n && !bad; ++r) {
+          uint32_t size;
+          std::memcpy(&size, src + r * 16, 4);
+          bad = size > 12;
+        }
+      }
+      std::memcpy(c->data[i] + item.offset * w, src, static_cast<size_t>(n) * w);
+    }
+  }
+  std::lock_guard<std::mutex> lock(c->m);
+  c->fallback = c->fallback || bad;
+  if (--c->pending == 0) {
+    c->copied.notify_all();
+  }
+}
+
+// Gives the batches appended since the last call to the copier pool (all of them when 'all', else
+// whole groups of kCopyGroup). Submitting thread only.
+void handOutCopies(Ingest* ing, IngestChunk* c, bool all) {
+  while (c->handedOut < c->batches.size() && (all || c->batches.size() - c->handedOut >= kCopyGroup)) {
+    const size_t begin = c->handedOut;
+    const size_t end = std::min(c->batches.size(), begin + kCopyGroup);
+    c->handedOut = end;
+    std::vector<CopyItem> items;
+    items.reserve(end - begin);
+    for (size_t b = begin; b < end; ++b) {
+      items.push_back(CopyItem{c->batches[b].get(), c->offsets[b]});
+    }
+    {
+      std::lock_guard<std::mutex> lock(c->m);
+      ++c->pending;
+    }
+    CopierPool::get().submit([ing, c, items = std::move(items)] { copyBatches(ing, c, items); });
+  }
+}
+
 // Hands the open chunk (if any) to the worker: its task waits for the chunk's copies, feeds the
 // operator and gives the chunk back to the ring. Caller holds ing.m.
 void sealOpenChunk(AsyncQueue* q, Ingest& ing, const std::function<int(const vx355_batch*)>& call) {
@@ -203,6 +260,7 @@ void sealOpenChunk(AsyncQueue* q, Ingest& ing, const std::function<int(const vx3
   IngestChunk* c = &ing.chunk[ing.open];
   ing.open = -1;
   Ingest* ingp = &ing;
+  handOutCopies(ingp, c, true);
   enqueue(
       q,
       [c, ingp, call](std::string* text) -> int {
@@ -221,6 +279,7 @@ void sealOpenChunk(AsyncQueue* q, Ingest& ing, const std::function<int(const vx3
             col.values = c->data[i];
           }
           vx355_batch flat{static_cast<int32_t>(c->rows), ingp->batchCols, cols.data()};
+          InlineStringsVerified verified;  // (the copiers looked at every view: DeviceBatch::load need not)
           status = call(&flat);
         } else {
           for (auto& b : c->batches) {
@@ -248,6 +307,8 @@ void sealOpenChunk(AsyncQueue* q, Ingest& ing, const std::function<int(const vx3
           c->rows = 0;
           c->tickets = 0;
           c->batches.clear();
+          c->offsets.clear();
+          c->handedOut = 0;
           c->fallback = false;
           c->busy = false;
         }
@@ -401,37 +462,12 @@ int64_t asyncSubmitBatch(AsyncQueue* q, DeviceState* ds, const vx355_batch* batc
     c->rows += n;
     ++c->tickets;
   }
-  auto owned = std::make_shared<OwnedBatch>(batch);
-  c->batches.push_back(owned);  // (only the submitting thread appends; the worker clears after pending == 0)
-  {
-    std::lock_guard<std::mutex> lock(c->m);
-    ++c->pending;
-  }
-  const int64_t ticket = reserveTicket(q);
-  Ingest* ingp = ing;
-  CopierPool::get().submit([c, ingp, owned, offset, n] {
-    bool bad = false;
-    for (size_t i = 0; i < ingp->cols.size(); ++i) {
-      const vx355_column& col = owned->cols[ingp->cols[i]];
-      const int w = ingp->widths[i];
-      const char* src = static_cast<const char*>(col.values);
-      if (isString(ingp->kinds[i])) {
-        // inline StringViews are plain 16-byte values; a longer string points into the caller's buffers
-        for (int64_t r = 0; r < n && !bad; ++r) {
-          uint32_t size;
-          std::memcpy(&size, src + r * 16, 4);
-          bad = size > 12;
-        }
-      }
-      std::memcpy(c->data[i] + offset * w, src, static_cast<size_t>(n) * w);
-    }
-    std::lock_guard<std::mutex> lock(c->m);
-    c->fallback = c->fallback || bad;
-    if (--c->pending == 0) {
-      c->copied.notify_all();
-    }
-  });
-  return ticket;
+  // (only the submitting thread appends; copier tasks carry pointers to the batches themselves; the
+  // worker clears the list after pending == 0)
+  c->batches.push_back(std::make_unique<OwnedBatch>(batch));
+  c->offsets.push_back(offset);
+  handOutCopies(ing, c, false);
+  return reserveTicket(q);
 }
 
 void asyncPoll(AsyncQueue* q, int64_t* submitted, int64_t* completed) {

@@ -272,6 +272,15 @@ class DevBuf {
   DeviceState* ds_ = nullptr;  // the GPU the block lives on
 };
 
+// While alive on a thread: host StringView columns handed to DeviceBatch::load hold inline strings
+// only (the parallel ingest's copiers looked at every view), so load stages them as plain 16-byte
+// values instead of scanning a million views per chunk for pointers to rewrite.
+struct InlineStringsVerified {
+  InlineStringsVerified();
+  ~InlineStringsVerified();
+  static bool active();
+};
+
 int kindWidth(int32_t kind);  // bytes per value; 0 for bit-packed BOOLEAN; -1 unknown
 inline bool isIntLike(int32_t k) { return k >= VX355_BOOLEAN && k <= VX355_BIGINT; }
 inline bool isString(int32_t k) { return k == VX355_VARCHAR || k == VX355_VARBINARY; }

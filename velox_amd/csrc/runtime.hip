@@ -653,6 +653,13 @@ void HostCoalescer::clear() {
   pendingRows_ = 0;
 }
 
+namespace {
+thread_local int tlsInlineStringsVerified = 0;
+}
+InlineStringsVerified::InlineStringsVerified() { ++tlsInlineStringsVerified; }
+InlineStringsVerified::~InlineStringsVerified() { --tlsInlineStringsVerified; }
+bool InlineStringsVerified::active() { return tlsInlineStringsVerified > 0; }
+
 const void* DeviceBatch::stage(const void* src, size_t bytes, int32_t mem) {
   if (!src || mem == VX355_MEM_DEVICE) {
     return src;
@@ -700,7 +707,7 @@ void DeviceBatch::load(const vx355_batch* batch, const std::vector<int32_t>& use
     if (numValues > 0) {
       VX_CHECK_ARG(col.values != nullptr, "column values is NULL");
     }
-    if (col.mem == VX355_MEM_HOST && isString(col.type_kind) && numValues > 0) {
+    if (col.mem == VX355_MEM_HOST && isString(col.type_kind) && numValues > 0 && !InlineStringsVerified::active()) {
       // Rewrite pointers of non-inline strings into a device blob.
       std::vector<char> views(valueBytes);
       std::memcpy(views.data(), col.values, valueBytes);
