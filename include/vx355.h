@@ -57,7 +57,13 @@ typedef enum vx355_type_kind {
   VX355_DOUBLE = 6,
   VX355_VARCHAR = 7,
   VX355_VARBINARY = 8,
-  VX355_TIMESTAMP = 9
+  VX355_TIMESTAMP = 9,
+  /* A struct column (RowVector child of a RowVector), PrestoPage entry points only: the intermediate
+   * type of avg is ROW(DOUBLE sum, BIGINT count) (functions/lib/aggregates/AverageAggregateBase.h:
+   * 66-260). vx355_column: encoding FLAT, values = the children as a HOST array of base_size
+   * vx355_column (scalar kinds, FLAT / CONSTANT / DICTIONARY, in 'mem'), nulls = the struct's own
+   * null bitmap. A ROW inside a ROW is VX355_EUNSUPPORTED. */
+  VX355_ROW = 32
 } vx355_type_kind;
 
 /* vector/VectorEncoding.h: the three encodings DecodedVector reduces to. */
@@ -349,7 +355,13 @@ typedef enum vx355_page_flags {
  * no bytes (Destination::flush returns early). offsets / page_offsets are host arrays of
  * num_pages + 1 entries; rows lives in rows_mem, out in out_mem. out == NULL only fills
  * page_offsets (the exact sizes: page p occupies [page_offsets[p], page_offsets[p + 1]) of out),
- * so the caller can allocate and call again. */
+ * so the caller can allocate and call again.
+ * A VX355_ROW column (see vx355_type_kind) is written in the ROW encoding (VectorStream::flush,
+ * serializers/VectorStream.cpp:236-262; serializeRowVector, PrestoSerializerSerializationUtils.cpp:
+ * 883-919): "ROW" | number of fields i32 | the fields' column streams, each holding only the rows
+ * whose struct is NOT null | numRows i32 | numRows + 1 offsets i32 (0, then + 1 behind every
+ * non-null struct) | hasNulls i8 [| null bits]. This is how a PARTIAL avg travels to a stock Velox
+ * FINAL aggregation: ROW(DOUBLE sum, BIGINT count). */
 int vx355_presto_serialize(
     const vx355_batch* batch,
     const int32_t* rows,
@@ -372,7 +384,14 @@ int vx355_presto_serialize(
  * device_bytes (>= the sum of sizes); views of strings longer than 12 bytes point into that
  * buffer, so the caller keeps it as long as the columns (a vector's string buffer). cols: device
  * memory, capacity_rows rows each (the row count of a page is its first little-endian int32,
- * so the caller sizes them before the call). Null rows hold the type's default value. */
+ * so the caller sizes them before the call). Null rows hold the type's default value.
+ * Struct columns: types[] / cols[] list the column tree in prefix order - a struct's own entry is
+ * VX355_ROW_OF(number of fields) in types[] and a vx355_out_column of kind VX355_ROW in cols[]
+ * (only its nulls buffer is written: the struct's validity), followed by one entry per field; a
+ * field's column has a row per struct row, null where the struct is null (readRowVector,
+ * PrestoSerializerDeserializationUtils.cpp:1041-1110). num_cols counts the entries; the pages'
+ * own column count is the number of top-level entries. */
+#define VX355_ROW_OF(num_fields) (VX355_ROW | ((num_fields) << 8))
 int vx355_presto_deserialize(
     const void* const* pages,
     const int64_t* sizes,

@@ -165,22 +165,113 @@ class PrestoColumnStream {
   std::vector<unsigned char> values_;
 };
 
+// A ROW column (VX355_ROW: values = the children, nulls = the struct's own bitmap), the way
+// serializeRowVector feeds a ROW VectorStream (PrestoSerializerSerializationUtils.cpp:883-919): a
+// null struct appends a null and repeats the running length, a non-null struct appends length 1
+// and hands its row to every child stream - the children only hold the rows of non-null structs.
+// VectorStream::flush, ROW branch without nullsFirst (VectorStream.cpp:236-262): "ROW", the number
+// of children, the child streams, the row count, rows + 1 offsets (the first is 0:
+// VectorStream::clear, :317-324), the null flag and bits.
+class PrestoRowStream {
+ public:
+  PrestoRowStream(const vx355_column& col, bool lossless) : nulls_(col.nulls) {
+    if (col.encoding != VX355_FLAT) {
+      throw std::runtime_error("PrestoPage: a ROW column must be FLAT");
+    }
+    const auto* kids = static_cast<const vx355_column*>(col.values);
+    for (int32_t i = 0; i < col.base_size; ++i) {
+      if (kids[i].type_kind == VX355_ROW) {
+        throw std::runtime_error("PrestoPage: ROW inside ROW");
+      }
+      children_.emplace_back(kids[i].type_kind, lossless);
+      decoded_.emplace_back(&kids[i]);
+    }
+    offsets_.push_back(0);
+  }
+
+  void append(int32_t row) {
+    const bool null = nulls_ != nullptr && !((nulls_[row >> 6] >> (row & 63)) & 1);
+    nullBits_.push_back(null);
+    if (null) {
+      ++nullCount_;
+      offsets_.push_back(total_);
+      return;
+    }
+    offsets_.push_back(++total_);
+    for (size_t c = 0; c < children_.size(); ++c) {
+      if (decoded_[c].isNull(row)) {
+        children_[c].appendNull();
+      } else {
+        children_[c].appendValue(decoded_[c], row);
+      }
+    }
+  }
+
+  void flush(std::vector<unsigned char>& out) const {
+    PrestoColumnStream::putI32(out, 3);
+    out.insert(out.end(), {'R', 'O', 'W'});
+    PrestoColumnStream::putI32(out, static_cast<int32_t>(children_.size()));
+    for (const auto& child : children_) {
+      child.flush(out);
+    }
+    PrestoColumnStream::putI32(out, static_cast<int32_t>(nullBits_.size()));
+    for (int32_t o : offsets_) {
+      PrestoColumnStream::putI32(out, o);
+    }
+    if (nullCount_ == 0) {
+      out.push_back(0);
+    } else {
+      out.push_back(1);
+      const size_t n = nullBits_.size();
+      for (size_t b = 0; b < (n + 7) / 8; ++b) {
+        unsigned char byte = 0;
+        for (int j = 0; j < 8 && b * 8 + j < n; ++j) {
+          if (nullBits_[b * 8 + j]) {
+            byte |= static_cast<unsigned char>(0x80u >> j);
+          }
+        }
+        out.push_back(byte);
+      }
+    }
+  }
+
+ private:
+  const uint64_t* nulls_;
+  std::vector<PrestoColumnStream> children_;
+  std::vector<Decoded> decoded_;
+  std::vector<bool> nullBits_;
+  std::vector<int32_t> offsets_;
+  int32_t nullCount_ = 0, total_ = 0;
+};
+
 // One page: flushUncompressed (PrestoSerializerSerializationUtils.h:216-268).
 inline std::vector<unsigned char> prestoPage(const vx355_batch& batch, const int32_t* rows, int64_t begin,
                                              int64_t end, bool checksum, bool lossless) {
+  // per column: a scalar stream or a ROW stream (index into the respective vector)
   std::vector<PrestoColumnStream> streams;
   std::vector<Decoded> decoded;
+  std::vector<PrestoRowStream> rowStreams;
+  std::vector<std::pair<bool, size_t>> which;
   for (int32_t c = 0; c < batch.num_cols; ++c) {
-    streams.emplace_back(batch.cols[c].type_kind, lossless);
-    decoded.emplace_back(&batch.cols[c]);
+    if (batch.cols[c].type_kind == VX355_ROW) {
+      which.emplace_back(true, rowStreams.size());
+      rowStreams.emplace_back(batch.cols[c], lossless);
+    } else {
+      which.emplace_back(false, streams.size());
+      streams.emplace_back(batch.cols[c].type_kind, lossless);
+      decoded.emplace_back(&batch.cols[c]);
+    }
   }
   for (int64_t i = begin; i < end; ++i) {
     const int32_t row = rows ? rows[i] : static_cast<int32_t>(i);
     for (int32_t c = 0; c < batch.num_cols; ++c) {
-      if (decoded[c].isNull(row)) {
-        streams[c].appendNull();
+      const size_t at = which[c].second;
+      if (which[c].first) {
+        rowStreams[at].append(row);
+      } else if (decoded[at].isNull(row)) {
+        streams[at].appendNull();
       } else {
-        streams[c].appendValue(decoded[c], row);
+        streams[at].appendValue(decoded[at], row);
       }
     }
   }
@@ -193,8 +284,12 @@ inline std::vector<unsigned char> prestoPage(const vx355_batch& batch, const int
   PrestoColumnStream::putI32(out, 0);
   out.insert(out.end(), 8, 0);
   PrestoColumnStream::putI32(out, batch.num_cols);
-  for (auto& s : streams) {
-    s.flush(out);
+  for (int32_t c = 0; c < batch.num_cols; ++c) {
+    if (which[c].first) {
+      rowStreams[which[c].second].flush(out);
+    } else {
+      streams[which[c].second].flush(out);
+    }
   }
   const int32_t uncompressed = static_cast<int32_t>(out.size()) - 21;
   std::memcpy(out.data() + 5, &uncompressed, 4);

@@ -11,6 +11,11 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # hiprtc instances are cached on disk (VX355_CACHE_DIR): a fresh directory per test session, so
+    # that no test depends on what an earlier session left behind
+    if "VX355_CACHE_DIR" not in os.environ:
+        import tempfile
+        os.environ["VX355_CACHE_DIR"] = tempfile.mkdtemp(prefix="vx355_test_cache_")
 
 
 @pytest.fixture(scope="session")

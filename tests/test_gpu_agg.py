@@ -1586,3 +1586,43 @@ def test_later_batch_with_many_new_keys_overflows_the_lds_slots_and_is_replayed(
     st = op.stats()
     assert st.hash_mode == abi.MODE_NORMALIZED_KEY and st.num_groups == len(exp[0][0]) > 40_000
     assert (st.deferred_rows > 10_000) == (slots_only == "1")
+
+
+def test_a_second_process_loads_hiprtc_instances_from_the_disk_cache(tmp_path):
+    """Plan shapes outside the ahead-of-time table are compiled once per MACHINE: the code object is
+    kept under VX355_CACHE_DIR, keyed by shape, architecture and a hash of the device headers. The
+    first process compiles, a second process with the same cache directory loads the instance and
+    compiles nothing - also with the default asynchronous mode, so a short-lived operator in a new
+    worker process runs on the specialised kernel from its first batch."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import numpy as np, sys\\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\\n"
+        "from velox_amd import abi, ops\\n"
+        "from gpu_util import batch_of\\n"
+        "ops.init(0)\\n"
+        "rng = np.random.default_rng(5)\\n"
+        "n = 1 << 18\\n"
+        "hb = batch_of([rng.integers(0, 9, n).astype(np.int32), rng.integers(0, 5, n).astype(np.int64),\\n"
+        "               rng.integers(0, 1 << 20, n) / 1024.0, rng.integers(0, 1 << 20, n) / 1024.0])\\n"
+        "aggs = [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_MAX, 3, abi.DOUBLE), (abi.AGG_AVG, 3, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]\\n"
+        "op = ops.Aggregation([0, 1], [abi.INTEGER, abi.BIGINT], aggs)\\n"
+        "ops.profile_enable(True)\\n"
+        "op.add_input(ops.to_device(hb)); op.no_more_input()\\n"
+        "out = ops.collect_output(op, 100)\\n"
+        "print('KERNELS', sorted(ops.profile()), 'JIT', op.stats().reserved, 'SUM', float(np.sum(out[2][0])))\\n"
+    ) % (root, os.path.join(root, "tests"))
+    outs = []
+    for jit in ("sync", "async"):
+        env = dict(os.environ, VX355_CACHE_DIR=str(tmp_path), VX355_LOG_SHAPES="1", VX355_JIT=jit)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(r)
+    first, second = outs
+    assert "compiling an instance" in first.stderr and "loaded from" not in first.stderr
+    assert "loaded from" in second.stderr and "compiling an instance" not in second.stderr
+    assert "k_agg_fast" in second.stdout and "k_agg_lds" not in second.stdout   # first batch, asynchronous mode
+    assert first.stdout.split("SUM")[1] == second.stdout.split("SUM")[1]
+    assert len(list(tmp_path.glob("agg_fast_*.hsaco"))) == 1

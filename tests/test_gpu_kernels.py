@@ -498,3 +498,59 @@ def test_hbm_ceiling_kernels_report_plausible_rates(vx):
     copy = vx.hbm_ceiling(abi.CEILING_COPY, 1 << 30, 3)
     assert 1000 < copy < 8000 and 1000 < read < 8000, (read, copy)
     print("hbm ceilings GB/s: read", round(read), "copy", round(copy))
+
+
+@pytest.mark.parametrize("device_resident", [False, True])
+def test_presto_pages_with_struct_columns_equal_the_oracle_and_read_back(oracle, vx, device_resident):
+    """ROW columns (VX355_ROW; the intermediate type of avg is ROW(DOUBLE, BIGINT),
+    AverageAggregateBase.h:66-260) through vx355_presto_serialize and vx355_presto_deserialize:
+    byte for byte the oracle's pages (VectorStream::flush ROW branch + serializeRowVector), decoded
+    by the independent reader, and read back into HBM columns - null structs, nulls inside fields, a
+    string field, a struct whose every row is null, a row list, page sizes around the null byte and
+    the 2048-row tile, empty pages, checksums."""
+    from presto_page_reader import check_pages_decode_to_rows, random_row_page_batch
+    rng = np.random.default_rng(909)
+    n = 7000
+    batch, py, kinds = random_row_page_batch(rng, n)
+    src = batch
+    if device_resident:
+        cols = []
+        for c in batch.columns:
+            if isinstance(c, abi.HostRowColumn):
+                cols.append(abi.HostRowColumn([vx.DeviceColumn(k) for k in c.children], c.valid))
+            else:
+                cols.append(vx.DeviceColumn(c))
+        src = abi.HostBatch(cols, n)
+    rows = rng.permutation(n).astype(np.int32)
+    offsets = [0, 0, 1, 8, 17, 2065, 4113, 4113, 4114 + 2047, n]
+    for flags in (0, abi.PAGE_CHECKSUM):
+        exp = oracle.presto_serialize(batch, offsets, rows, flags)
+        got = vx.presto_serialize(src, offsets, rows, flags)
+        assert [len(g) for g in got] == [len(e) for e in exp]
+        assert got == exp, f"flags {flags}"
+    pages = vx.presto_serialize(src, offsets, rows, abi.PAGE_CHECKSUM)
+    check_pages_decode_to_rows(pages, py, kinds, offsets, rows)
+    assert vx.presto_serialize(src, [0, 3000, n]) == oracle.presto_serialize(batch, [0, 3000, n])
+    # ... and back: the reader's columns hold a row per struct row, fields null where the struct is
+    for writer_pages in (pages, oracle.presto_serialize(batch, offsets, rows)):
+        got_n, got = vx.presto_deserialize(writer_pages, kinds)
+        assert got_n == n
+        for c, kind in enumerate(kinds):
+            src_vals, src_valid = py[c]
+            gv, gvalid = got[c]
+            want_valid = [bool(src_valid[r]) for r in rows]
+            assert list(gvalid) == want_valid, c
+            if not isinstance(kind, tuple):
+                assert [int(x) for x in gv] == [src_vals[r] for r in rows]
+                continue
+            for f, (fv, fvalid) in enumerate(gv):
+                sv, svalid = src_vals[f]
+                for i, r in enumerate(rows):
+                    assert bool(fvalid[i]) == (want_valid[i] and bool(svalid[r])), (c, f, i)
+                    if fvalid[i]:
+                        assert fv[i] == sv[r], (c, f, i)
+    # a ROW inside a ROW is refused
+    nested = abi.HostBatch([abi.HostRowColumn([abi.HostRowColumn([abi.HostColumn(abi.BIGINT, np.arange(4))])])])
+    with pytest.raises(vx.Vx355Error) as e:
+        vx.presto_serialize(nested, [0, 4])
+    assert e.value.status == abi.EUNSUPPORTED

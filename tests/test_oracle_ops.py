@@ -733,7 +733,50 @@ def test_presto_page_known_answers(oracle):
     assert summed[13:21] == crc.to_bytes(8, "little")
 
 
-from presto_page_reader import check_pages_decode_to_rows as _check_pages_decode_to_rows, millis as _millis, random_page_batch as _random_page_batch  # noqa: E402
+def test_presto_page_row_column_known_answer(oracle):
+    """A struct column assembled by hand from VectorStream::flush's ROW branch
+    (serializers/VectorStream.cpp:236-262) and serializeRowVector
+    (PrestoSerializerSerializationUtils.cpp:883-919): "ROW", the number of fields, the fields' streams -
+    each holding only the rows of the NON-NULL structs -, the row count, rows + 1 offsets (0, then + 1
+    behind every non-null struct), the null flag and the MSB-first null bits. The intermediate type of
+    avg, ROW(DOUBLE sum, BIGINT count) (AverageAggregateBase.h:66-260), next to a key column."""
+    sums = np.array([1.5, 0.0, -2.25, 8.0])
+    counts = np.array([3, 0, 1, 5], dtype=np.int64)
+    row = abi.HostRowColumn([abi.HostColumn(abi.DOUBLE, sums), abi.HostColumn(abi.BIGINT, counts, valid=[True, True, True, False])],
+                            valid=[True, False, True, True])
+    b = abi.HostBatch([abi.HostColumn(abi.INTEGER, np.array([7, 8, 9, 10], dtype=np.int32)), row])
+    (page,) = oracle.presto_serialize(b, [0, 4])
+    f64 = lambda v: np.float64(v).tobytes()  # noqa: E731
+    body = _i32(2)
+    body += _i32(9) + b"INT_ARRAY" + _i32(4) + b"\x00" + b"".join(_i32(v) for v in (7, 8, 9, 10))
+    body += _i32(3) + b"ROW" + _i32(2)
+    # the fields see structs 0, 2, 3 only
+    body += _i32(10) + b"LONG_ARRAY" + _i32(3) + b"\x00" + f64(1.5) + f64(-2.25) + f64(8.0)
+    body += _i32(10) + b"LONG_ARRAY" + _i32(3) + b"\x01" + bytes([0b00100000]) + (3).to_bytes(8, "little") + (1).to_bytes(8, "little")
+    body += _i32(4) + b"".join(_i32(v) for v in (0, 1, 1, 2, 3)) + b"\x01" + bytes([0b01000000])
+    want = _i32(4) + b"\x00" + _i32(len(body)) + _i32(len(body)) + bytes(8) + body
+    assert page == want
+    # a struct column without null structs: no bitmap, the fields hold every row
+    dense = abi.HostBatch([abi.HostRowColumn([abi.HostColumn(abi.BIGINT, counts)])])
+    (page,) = oracle.presto_serialize(dense, [1, 3])
+    body = _i32(1) + _i32(3) + b"ROW" + _i32(1)
+    body += _i32(10) + b"LONG_ARRAY" + _i32(2) + b"\x00" + (0).to_bytes(8, "little") + (1).to_bytes(8, "little")
+    body += _i32(2) + _i32(0) + _i32(1) + _i32(2) + b"\x00"
+    assert page == _i32(2) + b"\x00" + _i32(len(body)) + _i32(len(body)) + bytes(8) + body
+
+
+from presto_page_reader import check_pages_decode_to_rows as _check_pages_decode_to_rows, millis as _millis, random_page_batch as _random_page_batch, random_row_page_batch as _random_row_page_batch  # noqa: E402
+
+
+def test_presto_pages_with_struct_columns_decode_back_to_the_rows(oracle):
+    rng = np.random.default_rng(616)
+    n = 2500
+    batch, py, kinds = _random_row_page_batch(rng, n)
+    rows = rng.permutation(n).astype(np.int32)
+    offsets = [0, 0, 1, 9, 2057, 2057, n]
+    for flags in (0, abi.PAGE_CHECKSUM):
+        pages = oracle.presto_serialize(batch, offsets, rows, flags)
+        _check_pages_decode_to_rows(pages, py, kinds, offsets, rows)
 
 
 def test_presto_pages_decode_back_to_the_rows(oracle):

@@ -14,6 +14,7 @@ OK, EUSER, EUNSUPPORTED, ENOMEM, EINTERNAL, EINVAL = range(6)
 
 # vx355_type_kind == velox::TypeKind (type/TypeKind.h:41-52)
 BOOLEAN, TINYINT, SMALLINT, INTEGER, BIGINT, REAL, DOUBLE, VARCHAR, VARBINARY, TIMESTAMP = range(10)
+ROW = 32   # PrestoPage entry points only: a struct column (HostRowColumn)
 
 # vx355_encoding
 FLAT, CONSTANT, DICTIONARY = range(3)
@@ -289,6 +290,31 @@ class HostColumn:
         c.nulls = self.nulls.ctypes.data if self.nulls is not None else None
         c.indices = self.indices.ctypes.data if self.indices is not None else None
         c.base_size = self.base_size if self.encoding == DICTIONARY else 0
+        c.mem = MEM_HOST
+        return c
+
+
+class HostRowColumn:
+    """A struct column (VX355_ROW) for the PrestoPage entry points: children = HostColumns (or
+    device columns with a descriptor()), valid = the struct's own validity (bool array) or None."""
+
+    def __init__(self, children, valid=None):
+        self.kind = ROW
+        self.encoding = FLAT
+        self.children = list(children)
+        self.num_rows = next((c.num_rows for c in self.children if c.num_rows is not None), 0)
+        self.valid = None if valid is None else np.asarray(valid, dtype=bool)
+        self.nulls = None if valid is None else pack_bits(self.valid)
+        self._descs = (Column * max(1, len(self.children)))(*[c.descriptor() for c in self.children])
+
+    def descriptor(self):
+        c = Column()
+        c.type_kind = ROW
+        c.encoding = FLAT
+        c.values = C.cast(self._descs, C.c_void_p).value
+        c.nulls = self.nulls.ctypes.data if self.nulls is not None else None
+        c.indices = None
+        c.base_size = len(self.children)
         c.mem = MEM_HOST
         return c
 

@@ -373,6 +373,10 @@ class HostCoalescer {
   int64_t pendingRows_ = 0;
 };
 
+// Output columns of a PARTIAL / INTERMEDIATE aggregation that hold the sum half of an avg's
+// (sum, count) pair (agg.hip); the count follows in the next column.
+std::vector<int32_t> aggPartialAvgColumns(const vx355_agg* h);
+
 // Exclusive scan of n u32 cells into n + 1 u64 offsets (last = total), on the library stream.
 void scanU32ToU64(const uint32_t* in, int64_t n, uint64_t* out, DevBuf& scratch);
 

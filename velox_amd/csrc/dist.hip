@@ -17,6 +17,9 @@
 #include "common.h"
 
 #include <algorithm>
+#include <array>
+
+#include <algorithm>
 
 using namespace vx;
 
@@ -215,13 +218,41 @@ int vx355_agg_merge_partials(vx355_comm* c, vx355_agg* partial, const vx355_agg_
       break;
     }
   }
-  // ---- PartitionedOutput: one PrestoPage (the wire format of Velox's own exchange)
-  std::vector<vx355_column> cols(numCols);
+  // ---- PartitionedOutput: one PrestoPage (the wire format of Velox's own exchange). An avg's
+  // (sum, count) pair travels as the reference's intermediate type ROW(DOUBLE, BIGINT)
+  // (AverageAggregateBase.h:66-260): a stock Velox FINAL aggregation can consume the page, and a
+  // page a Velox PARTIAL wrote can be consumed here. The struct is null where the sum is (a group
+  // without non-null inputs).
+  const std::vector<int32_t> avgSums = aggPartialAvgColumns(partial);
+  auto isAvgSum = [&](int32_t i) { return std::find(avgSums.begin(), avgSums.end(), i) != avgSums.end(); };
+  std::vector<vx355_column> cols;
+  std::vector<std::array<vx355_column, 2>> fields(avgSums.size());
+  std::vector<int32_t> wireTypes;   // prefix order, for the reader
+  std::vector<int32_t> nodeOfColumn(numCols, -1);
+  size_t pair = 0;
   for (int32_t i = 0; i < numCols; ++i) {
-    cols[i] = vx355_column{types[i], VX355_FLAT, values[i].ptr(), nulls[i].as<uint64_t>(), nullptr, 0, VX355_MEM_DEVICE};
+    if (isAvgSum(i)) {
+      VX_CHECK_ARG(i + 1 < numCols && types[i] == VX355_DOUBLE && types[i + 1] == VX355_BIGINT, "avg pair layout");
+      fields[pair][0] = vx355_column{VX355_DOUBLE, VX355_FLAT, values[i].ptr(), nullptr, nullptr, 0, VX355_MEM_DEVICE};
+      fields[pair][1] = vx355_column{VX355_BIGINT, VX355_FLAT, values[i + 1].ptr(), nulls[i + 1].as<uint64_t>(), nullptr, 0,
+                                     VX355_MEM_DEVICE};
+      cols.push_back(vx355_column{VX355_ROW, VX355_FLAT, fields[pair].data(), nulls[i].as<uint64_t>(), nullptr, 2,
+                                  VX355_MEM_DEVICE});
+      wireTypes.push_back(VX355_ROW_OF(2));
+      nodeOfColumn[i] = static_cast<int32_t>(wireTypes.size());
+      wireTypes.push_back(VX355_DOUBLE);
+      nodeOfColumn[i + 1] = static_cast<int32_t>(wireTypes.size());
+      wireTypes.push_back(VX355_BIGINT);
+      ++pair;
+      ++i;
+      continue;
+    }
+    cols.push_back(vx355_column{types[i], VX355_FLAT, values[i].ptr(), nulls[i].as<uint64_t>(), nullptr, 0, VX355_MEM_DEVICE});
+    nodeOfColumn[i] = static_cast<int32_t>(wireTypes.size());
+    wireTypes.push_back(types[i]);
   }
   VX_CHECK_ARG(groups <= INT32_MAX, "more than 2^31 partial groups on one rank");
-  vx355_batch mine{static_cast<int32_t>(groups), numCols, cols.data()};
+  vx355_batch mine{static_cast<int32_t>(groups), static_cast<int32_t>(cols.size()), cols.data()};
   const int64_t offsets[2] = {0, groups};
   int64_t pageOffsets[2] = {0, 0};
   const int32_t flags = VX355_PAGE_LOSSLESS_TIMESTAMP;
@@ -272,10 +303,23 @@ int vx355_agg_merge_partials(vx355_comm* c, vx355_agg* partial, const vx355_agg_
     inCols[i].nulls = static_cast<uint64_t*>(inNulls[i].ensure(static_cast<size_t>(inCap / 8) + 64));
   }
   int64_t rowsOut = 0;
+  // the reader's column tree: every flat column, and per avg pair the struct's own entry (its validity
+  // is not needed downstream: a field of a null struct comes back null) followed by its two fields
+  std::vector<vx355_out_column> wireCols(wireTypes.size());
+  DevBuf structNulls;
+  structNulls.ensure(static_cast<size_t>(inCap / 8) + 64);
+  for (size_t n = 0; n < wireTypes.size(); ++n) {
+    if ((wireTypes[n] & 0xff) == VX355_ROW) {
+      wireCols[n] = vx355_out_column{VX355_ROW, VX355_MEM_DEVICE, nullptr, structNulls.as<uint64_t>()};
+    }
+  }
+  for (int32_t i = 0; i < numCols; ++i) {
+    wireCols[nodeOfColumn[i]] = inCols[i];
+  }
   // gathered doubles as the string buffer of the deserialised views (strings > 12 bytes)
-  ok(vx355_presto_deserialize(pages.data(), pageSizes.data(), static_cast<int32_t>(pages.size()), types.data(), numCols,
-                              flags, gathered.ptr(), static_cast<int64_t>(gathered.capacity()), inCols.data(), inCap,
-                              &rowsOut));
+  ok(vx355_presto_deserialize(pages.data(), pageSizes.data(), static_cast<int32_t>(pages.size()), wireTypes.data(),
+                              static_cast<int32_t>(wireTypes.size()), flags, gathered.ptr(),
+                              static_cast<int64_t>(gathered.capacity()), wireCols.data(), inCap, &rowsOut));
   AggHandle fin;
   ok(vx355_agg_create(final_spec, &fin.a));
   std::vector<vx355_column> finCols(numCols);

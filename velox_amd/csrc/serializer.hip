@@ -40,15 +40,30 @@ struct PagePatch {
   unsigned char data[32];
 };
 
-struct PageArgs {
-  const ColView* cols;
-  const int32_t* rows;  // may be null
+// The rows a column stream serialises and how they are cut into tiles. Top-level columns share the
+// page rows; the children of a ROW column with a null bitmap see the rows of the NON-NULL structs
+// only (serializeRowVector, PrestoSerializerSerializationUtils.cpp:883-919): their own row list,
+// their own tiles.
+struct ColTiles {
+  const int32_t* rows;      // positions -> batch rows; null = the position is the row
   const PageTile* tiles;
   int64_t numTiles;
-  int32_t numCols;
+  int64_t cellBase;         // first cell of this stream in counts / layout (one cell per tile)
+};
+
+// ColView::kind of a ROW node: the stream carries the struct's null bits and, per row, the running
+// number of non-null structs (the "offsets" of the ROW encoding) - a VARIABLE_WIDTH column whose
+// every non-null value is one "byte" long and has no bytes.
+constexpr int32_t kRowNodeKind = 1000;
+
+struct PageArgs {
+  const ColView* cols;        // every stream of the batch (top-level columns, ROW nodes, ROW children)
+  const ColTiles* colTiles;   // per stream
+  const int32_t* launchCols;  // blockIdx.y -> stream
   int32_t lossless;
-  uint64_t* counts;       // [col * numTiles + tile] * 2: non-null rows, string bytes
-  const TileOut* layout;  // [col * numTiles + tile]
+  int32_t pad;
+  uint64_t* counts;       // [cell] * 2: non-null rows, string bytes
+  const TileOut* layout;  // [cell]
   unsigned char* out;
   uint32_t* errorFlag;    // 1: a timestamp does not fit milliseconds; 2: rows[] holds a row outside the batch
   int64_t batchRows;
@@ -64,7 +79,8 @@ struct __attribute__((packed)) Packed64 {
   uint64_t v;
 };
 
-__device__ inline bool isStringKind(int32_t k) { return k == VX355_VARCHAR || k == VX355_VARBINARY; }
+// (lane-blocked streams: real strings and ROW nodes)
+__device__ inline bool isStringKind(int32_t k) { return k == VX355_VARCHAR || k == VX355_VARBINARY || k == kRowNodeKind; }
 
 // Exclusive prefix over the 256 lanes of the workgroup; *total = sum of all.
 __device__ inline uint64_t blockExclusive(uint64_t v, uint64_t* lds, uint64_t* total) {
@@ -86,9 +102,13 @@ __device__ inline uint64_t blockExclusive(uint64_t v, uint64_t* lds, uint64_t* t
 __global__ __launch_bounds__(256) void k_page_count(PageArgs a) {
   __shared__ uint64_t lds[8];
   const int64_t tile = blockIdx.x;
-  const int col = blockIdx.y;
+  const int col = a.launchCols[blockIdx.y];
+  const ColTiles ct = a.colTiles[col];
+  if (tile >= ct.numTiles) {
+    return;
+  }
   const ColView c = a.cols[col];
-  const PageTile pt = a.tiles[tile];
+  const PageTile pt = ct.tiles[tile];
   const bool str = isStringKind(c.kind);
   uint64_t nonNull = 0, bytes = 0;
   for (int j = 0; j < kRowsPerLane; ++j) {
@@ -96,14 +116,16 @@ __global__ __launch_bounds__(256) void k_page_count(PageArgs a) {
     const int r = str ? threadIdx.x * kRowsPerLane + j : j * 256 + static_cast<int>(threadIdx.x);
     if (r < pt.count) {
       const int64_t pos = pt.rowBegin + r;
-      const int64_t row = a.rows ? a.rows[pos] : pos;
+      const int64_t row = ct.rows ? ct.rows[pos] : pos;
       if (row < 0 || row >= a.batchRows) {
         *a.errorFlag = 2;  // the host refuses the call before anything is written
         continue;
       }
       if (!colIsNull(c, row)) {
         ++nonNull;
-        if (str) {
+        if (c.kind == kRowNodeKind) {
+          bytes += 1;
+        } else if (str) {
           bytes += loadView(c, colIndex(c, row)).size;
         }
       }
@@ -121,9 +143,38 @@ __global__ __launch_bounds__(256) void k_page_count(PageArgs a) {
   }
   blockSync();
   if (threadIdx.x == 0) {
-    uint64_t* o = a.counts + (static_cast<int64_t>(col) * a.numTiles + tile) * 2;
+    uint64_t* o = a.counts + (ct.cellBase + tile) * 2;
     o[0] = lds[0] + lds[2] + lds[4] + lds[6];
     o[1] = lds[1] + lds[3] + lds[5] + lds[7];
+  }
+}
+
+// The row list of a ROW column's children: the rows of the node's tile whose struct is not null,
+// in order, at tileBase[tile] of 'out' (tileBase = non-null structs in the tiles before this one).
+__global__ __launch_bounds__(256) void k_row_compact(ColView node, ColTiles ct, const uint64_t* tileBase, int32_t* out) {
+  __shared__ uint64_t lds[256];
+  const int64_t tile = blockIdx.x;
+  const PageTile pt = ct.tiles[tile];
+  const int first = threadIdx.x * kRowsPerLane;
+  int32_t rowOf[kRowsPerLane];
+  uint32_t valid = 0;
+  for (int j = 0; j < kRowsPerLane; ++j) {
+    const int r = first + j;
+    rowOf[j] = -1;
+    if (r < pt.count) {
+      const int64_t pos = pt.rowBegin + r;
+      rowOf[j] = static_cast<int32_t>(ct.rows ? ct.rows[pos] : pos);
+      if (!colIsNull(node, rowOf[j])) {
+        valid |= 1u << j;
+      }
+    }
+  }
+  uint64_t total;
+  uint64_t at = tileBase[tile] + blockExclusive(static_cast<uint64_t>(__popc(valid)), lds, &total);
+  for (int j = 0; j < kRowsPerLane; ++j) {
+    if ((valid >> j) & 1) {
+      out[at++] = rowOf[j];
+    }
   }
 }
 
@@ -136,10 +187,14 @@ __device__ inline const unsigned char* viewBytes(const StringView16& v, const ui
 __global__ __launch_bounds__(256) void k_page_write(PageArgs a) {
   __shared__ uint64_t lds[256];
   const int64_t tile = blockIdx.x;
-  const int col = blockIdx.y;
+  const int col = a.launchCols[blockIdx.y];
+  const ColTiles ct = a.colTiles[col];
+  if (tile >= ct.numTiles) {
+    return;
+  }
   const ColView c = a.cols[col];
-  const PageTile pt = a.tiles[tile];
-  const TileOut lo = a.layout[static_cast<int64_t>(col) * a.numTiles + tile];
+  const PageTile pt = ct.tiles[tile];
+  const TileOut lo = a.layout[ct.cellBase + tile];
   const bool str = isStringKind(c.kind);
   if (!str) {
     // Fixed width. A wave owns 512 consecutive rows of the tile and lane l takes rows
@@ -160,7 +215,7 @@ __global__ __launch_bounds__(256) void k_page_write(PageArgs a) {
       rowOf[j] = -1;
       if (r < pt.count) {
         const int64_t pos = pt.rowBegin + r;
-        rowOf[j] = a.rows ? a.rows[pos] : pos;
+        rowOf[j] = ct.rows ? ct.rows[pos] : pos;
         v = !colIsNull(c, rowOf[j]);
       }
       ballots[j] = ballot(v);
@@ -249,7 +304,7 @@ __global__ __launch_bounds__(256) void k_page_write(PageArgs a) {
     const int r = first + j;
     if (r < pt.count) {
       const int64_t pos = pt.rowBegin + r;
-      rowOf[j] = a.rows ? a.rows[pos] : pos;
+      rowOf[j] = ct.rows ? ct.rows[pos] : pos;
       if (!colIsNull(c, rowOf[j])) {
         valid |= 1u << j;
       }
@@ -270,7 +325,7 @@ __global__ __launch_bounds__(256) void k_page_write(PageArgs a) {
   for (int j = 0; j < kRowsPerLane; ++j) {
     sizes[j] = 0;
     if ((valid >> j) & 1) {
-      sizes[j] = loadView(c, colIndex(c, rowOf[j])).size;
+      sizes[j] = c.kind == kRowNodeKind ? 1u : loadView(c, colIndex(c, rowOf[j])).size;
       mine += sizes[j];
     }
   }
@@ -283,7 +338,9 @@ __global__ __launch_bounds__(256) void k_page_write(PageArgs a) {
     if (r >= pt.count) {
       break;
     }
-    if ((valid >> j) & 1) {
+    if (((valid >> j) & 1) && c.kind == kRowNodeKind) {
+      run += 1;  // a non-null struct: one more row in every child stream, no bytes of its own
+    } else if ((valid >> j) & 1) {
       const int64_t i = colIndex(c, rowOf[j]);
       const uint4* slot = static_cast<const uint4*>(c.values) + i;
       const StringView16 v = loadView(c, i);
@@ -393,6 +450,44 @@ void putI32(unsigned char* p, int64_t v) {
 
 constexpr int kPageHeader = 4 + 1 + 4 + 4 + 8;  // PrestoSerializerSerializationUtils.h:37-45
 
+// One column stream of the pages: a top-level column, a ROW node or a child of a ROW node.
+struct StreamNode {
+  int32_t kind = 0;             // vx355_type_kind (VX355_ROW for a node)
+  ColView view{};               // device view (ROW node: kRowNodeKind, nulls = the struct's bitmap)
+  int group = 0;                // whose rows it serialises: 0 = the page rows
+  std::vector<int> children;    // streams of a ROW node's fields
+  int64_t cellBase = 0;
+};
+
+// The rows of one group of streams, page by page.
+struct RowGroup {
+  const int32_t* devRows = nullptr;   // null: position = batch row
+  std::vector<int64_t> pageBegin;     // numPages + 1 positions into devRows
+  std::vector<PageTile> tiles;
+  std::vector<int64_t> firstTile;     // numPages + 1
+  DevBuf rowsBuf, tilesBuf;
+  const PageTile* devTiles = nullptr;
+
+  void cut(int32_t numPages) {
+    tiles.clear();
+    firstTile.assign(numPages + 1, 0);
+    for (int32_t p = 0; p < numPages; ++p) {
+      firstTile[p] = static_cast<int64_t>(tiles.size());
+      const int64_t n = pageBegin[p + 1] - pageBegin[p];
+      for (int64_t b = 0; b < n; b += kPageTile) {
+        tiles.push_back(PageTile{pageBegin[p] + b, static_cast<int32_t>(std::min<int64_t>(kPageTile, n - b)),
+                                 static_cast<int32_t>(b)});
+      }
+    }
+    firstTile[numPages] = static_cast<int64_t>(tiles.size());
+  }
+  void upload() {
+    PageTile* d = static_cast<PageTile*>(tilesBuf.ensure(std::max<size_t>(tiles.size(), 1) * sizeof(PageTile) + 64));
+    copyIn(d, tiles.data(), VX355_MEM_HOST, tiles.size() * sizeof(PageTile));
+    devTiles = d;
+  }
+};
+
 void serializePages(const vx355_batch* batch, const int32_t* rows, int32_t rowsMem, const int64_t* offsets,
                     int32_t numPages, int32_t flags, void* out, int64_t outCapacity, int32_t outMem,
                     int64_t* pageOffsets) {
@@ -405,11 +500,59 @@ void serializePages(const vx355_batch* batch, const int32_t* rows, int32_t rowsM
   }
   const int32_t nc = batch->num_cols;
   VX_CHECK_ARG(nc >= 0 && (nc == 0 || batch->cols), "batch without columns array");
-  std::vector<int32_t> used(nc);
+  // The stream tree, flattened: every scalar column (top level or field of a struct) is one column
+  // of 'leaves', loaded like any batch; ROW nodes only bring their null bitmap.
+  std::vector<StreamNode> nodes;
+  std::vector<int> topLevel;
+  std::vector<vx355_column> leaves;
+  std::vector<int> leafOfNode;
+  std::vector<DevBuf> structNulls;
+  structNulls.reserve(static_cast<size_t>(nc));
+  auto addLeaf = [&](const vx355_column& col) {
+    if (!encodingName(col.type_kind)) {
+      VX_THROW(VX355_EUNSUPPORTED, "PrestoPage column of type kind " + std::to_string(col.type_kind));
+    }
+    StreamNode n;
+    n.kind = col.type_kind;
+    nodes.push_back(n);
+    leafOfNode.push_back(static_cast<int>(leaves.size()));
+    leaves.push_back(col);
+    return static_cast<int>(nodes.size()) - 1;
+  };
   for (int32_t c = 0; c < nc; ++c) {
-    used[c] = c;
-    if (!encodingName(batch->cols[c].type_kind)) {
-      VX_THROW(VX355_EUNSUPPORTED, "PrestoPage column of type kind " + std::to_string(batch->cols[c].type_kind));
+    const vx355_column& col = batch->cols[c];
+    if (col.type_kind != VX355_ROW) {
+      topLevel.push_back(addLeaf(col));
+      continue;
+    }
+    VX_CHECK_ARG(col.encoding == VX355_FLAT, "a ROW column is FLAT");
+    VX_CHECK_ARG(col.base_size >= 0 && (col.base_size == 0 || col.values), "ROW column without children");
+    StreamNode n;
+    n.kind = VX355_ROW;
+    n.view.kind = kRowNodeKind;
+    n.view.enc = VX355_FLAT;
+    if (col.nulls) {
+      const size_t bytes = static_cast<size_t>(ceilDiv(std::max<int64_t>(batch->num_rows, 1), 64)) * 8;
+      if (col.mem == VX355_MEM_HOST) {
+        structNulls.emplace_back();
+        uint64_t* d = static_cast<uint64_t*>(structNulls.back().ensure(bytes + 64));
+        copyIn(d, col.nulls, VX355_MEM_HOST, bytes);
+        n.view.nulls = d;
+      } else {
+        n.view.nulls = col.nulls;
+      }
+    }
+    nodes.push_back(n);
+    leafOfNode.push_back(-1);
+    const int self = static_cast<int>(nodes.size()) - 1;
+    topLevel.push_back(self);
+    const auto* kids = static_cast<const vx355_column*>(col.values);
+    for (int32_t k = 0; k < col.base_size; ++k) {
+      if (kids[k].type_kind == VX355_ROW) {
+        VX_THROW(VX355_EUNSUPPORTED, "PrestoPage: a ROW inside a ROW");
+      }
+      const int child = addLeaf(kids[k]);
+      nodes[self].children.push_back(child);
     }
   }
   const int64_t limit = rows ? INT64_MAX : batch->num_rows;
@@ -418,72 +561,153 @@ void serializePages(const vx355_batch* batch, const int32_t* rows, int32_t rowsM
     VX_CHECK_ARG(offsets[p + 1] - offsets[p] <= INT32_MAX, "more than 2^31 rows in a page");
   }
   DeviceBatch db;
-  db.load(batch, used);
-  // tiles
-  std::vector<PageTile> tiles;
-  std::vector<int64_t> firstTile(numPages + 1, 0);
-  for (int32_t p = 0; p < numPages; ++p) {
-    firstTile[p] = static_cast<int64_t>(tiles.size());
-    const int64_t n = offsets[p + 1] - offsets[p];
-    for (int64_t b = 0; b < n; b += kPageTile) {
-      tiles.push_back(PageTile{offsets[p] + b, static_cast<int32_t>(std::min<int64_t>(kPageTile, n - b)),
-                               static_cast<int32_t>(b)});
+  {
+    std::vector<int32_t> all(leaves.size());
+    for (size_t i = 0; i < leaves.size(); ++i) {
+      all[i] = static_cast<int32_t>(i);
+    }
+    vx355_batch leafBatch{batch->num_rows, static_cast<int32_t>(leaves.size()), leaves.data()};
+    db.load(&leafBatch, all);
+  }
+  for (size_t i = 0; i < nodes.size(); ++i) {
+    if (leafOfNode[i] >= 0) {
+      nodes[i].view = db.col(leafOfNode[i]);
     }
   }
-  firstTile[numPages] = static_cast<int64_t>(tiles.size());
-  const int64_t numTiles = static_cast<int64_t>(tiles.size());
-  if (numTiles == 0) {
+  // group 0: the page rows
+  std::vector<std::unique_ptr<RowGroup>> groups;
+  groups.push_back(std::make_unique<RowGroup>());
+  RowGroup& g0 = *groups[0];
+  g0.pageBegin.assign(offsets, offsets + numPages + 1);
+  g0.cut(numPages);
+  if (g0.tiles.empty()) {
     for (int32_t p = 0; p <= numPages; ++p) {
       pageOffsets[p] = 0;
     }
     return;
   }
-  DevBuf dRows, dTiles, dCols, dCounts, dLayout, dPatches, dOut, dFlag;
-  const int32_t* devRows = nullptr;
+  DevBuf dCols, dColTiles, dLaunch, dCounts, dLayout, dPatches, dOut, dFlag, dTileBase;
   if (rows) {
     const int64_t last = offsets[numPages];
     if (rowsMem == VX355_MEM_HOST) {
-      int32_t* staged = static_cast<int32_t*>(dRows.ensure(static_cast<size_t>(std::max<int64_t>(last, 1)) * 4 + 64));
+      int32_t* staged = static_cast<int32_t*>(g0.rowsBuf.ensure(static_cast<size_t>(std::max<int64_t>(last, 1)) * 4 + 64));
       copyIn(staged, rows, VX355_MEM_HOST, static_cast<size_t>(last) * 4);
-      devRows = staged;
+      g0.devRows = staged;
     } else {
-      devRows = rows;
+      g0.devRows = rows;
     }
   }
-  PageTile* devTiles = static_cast<PageTile*>(dTiles.ensure(tiles.size() * sizeof(PageTile) + 64));
-  copyIn(devTiles, tiles.data(), VX355_MEM_HOST, tiles.size() * sizeof(PageTile));
-  std::vector<ColView> views(std::max(nc, 1));
-  for (int32_t c = 0; c < nc; ++c) {
-    views[c] = db.col(c);
-  }
-  ColView* devCols = static_cast<ColView*>(dCols.ensure(views.size() * sizeof(ColView) + 64));
-  copyIn(devCols, views.data(), VX355_MEM_HOST, views.size() * sizeof(ColView));
-  const size_t numCells = static_cast<size_t>(numTiles) * std::max(nc, 1);
-  uint64_t* devCounts = static_cast<uint64_t*>(dCounts.ensure(numCells * 16 + 64));
+  g0.upload();
   uint32_t* devFlag = static_cast<uint32_t*>(dFlag.ensure(64));
   HIP_OK(hipMemsetAsync(devFlag, 0, 4, rt.stream));
+  // cells: one per (stream, tile of its group); a child group has at most as many rows as group 0
+  const int64_t maxTiles = static_cast<int64_t>(g0.tiles.size()) + numPages;
+  for (size_t i = 0; i < nodes.size(); ++i) {
+    nodes[i].cellBase = static_cast<int64_t>(i) * maxTiles;
+  }
+  const size_t numCells = nodes.size() * static_cast<size_t>(maxTiles);
+  uint64_t* devCounts = static_cast<uint64_t*>(dCounts.ensure(std::max<size_t>(numCells, 1) * 16 + 64));
+  std::vector<uint64_t> counts(std::max<size_t>(numCells, 1) * 2, 0);
+  ColView* devCols = static_cast<ColView*>(dCols.ensure(std::max<size_t>(nodes.size(), 1) * sizeof(ColView) + 64));
+  ColTiles* devColTiles = static_cast<ColTiles*>(dColTiles.ensure(std::max<size_t>(nodes.size(), 1) * sizeof(ColTiles) + 64));
+  int32_t* devLaunch = static_cast<int32_t*>(dLaunch.ensure(std::max<size_t>(nodes.size(), 1) * 4 + 64));
   PageArgs a{};
   a.cols = devCols;
-  a.rows = devRows;
-  a.tiles = devTiles;
-  a.numTiles = numTiles;
-  a.numCols = nc;
+  a.colTiles = devColTiles;
+  a.launchCols = devLaunch;
   a.lossless = lossless ? 1 : 0;
   a.counts = devCounts;
   a.errorFlag = devFlag;
   a.batchRows = batch->num_rows;
-  std::vector<uint64_t> counts(numCells * 2, 0);
-  if (nc > 0) {
-    VX_LAUNCH("k_page_count", k_page_count, dim3(static_cast<unsigned>(numTiles), static_cast<unsigned>(nc)), 256, 0, a);
-    copyOut(counts.data(), VX355_MEM_HOST, devCounts, numCells * 16);
+  std::vector<ColView> hostViews(nodes.size());
+  std::vector<ColTiles> hostColTiles(nodes.size());
+  auto uploadStreams = [&]() {
+    for (size_t i = 0; i < nodes.size(); ++i) {
+      const RowGroup& g = *groups[nodes[i].group];
+      hostViews[i] = nodes[i].view;
+      hostColTiles[i] = ColTiles{g.devRows, g.devTiles, static_cast<int64_t>(g.tiles.size()), nodes[i].cellBase};
+    }
+    copyIn(devCols, hostViews.data(), VX355_MEM_HOST, nodes.size() * sizeof(ColView));
+    copyIn(devColTiles, hostColTiles.data(), VX355_MEM_HOST, nodes.size() * sizeof(ColTiles));
+  };
+  // counts of the streams in 'which' (all of one level: their groups exist)
+  auto countStreams = [&](const std::vector<int32_t>& which) {
+    if (which.empty()) {
+      return;
+    }
+    int64_t gridTiles = 0;
+    for (int32_t n : which) {
+      gridTiles = std::max<int64_t>(gridTiles, static_cast<int64_t>(groups[nodes[n].group]->tiles.size()));
+    }
+    if (gridTiles == 0) {
+      return;
+    }
+    rt.sync();  // (the staged launch list of the previous level must have been consumed)
+    copyIn(devLaunch, which.data(), VX355_MEM_HOST, which.size() * 4);
+    VX_LAUNCH("k_page_count", k_page_count, dim3(static_cast<unsigned>(gridTiles), static_cast<unsigned>(which.size())), 256,
+              0, a);
+    for (int32_t n : which) {
+      const size_t tilesOf = groups[nodes[n].group]->tiles.size();
+      if (tilesOf) {
+        copyOutAsync(&counts[static_cast<size_t>(nodes[n].cellBase) * 2], VX355_MEM_HOST, devCounts + nodes[n].cellBase * 2,
+                     tilesOf * 16);
+      }
+    }
+    rt.sync();
     uint32_t flag = 0;
     copyOut(&flag, VX355_MEM_HOST, devFlag, 4);
     if (flag == 2) {
       VX_THROW(VX355_EINVAL, "rows[] holds a row number outside the batch");
     }
+  };
+  uploadStreams();
+  {
+    std::vector<int32_t> level0(topLevel.begin(), topLevel.end());
+    countStreams(level0);
+  }
+  // ROW nodes with a null bitmap: the row list of their children = the rows of the non-null structs
+  std::vector<int32_t> level1;
+  for (int t : topLevel) {
+    StreamNode& node = nodes[t];
+    if (node.kind != VX355_ROW) {
+      continue;
+    }
+    if (node.view.nulls != nullptr && !node.children.empty()) {
+      groups.push_back(std::make_unique<RowGroup>());
+      RowGroup& g = *groups.back();
+      const int gid = static_cast<int>(groups.size()) - 1;
+      std::vector<uint64_t> tileBase(g0.tiles.size() + 1, 0);
+      for (size_t tt = 0; tt < g0.tiles.size(); ++tt) {
+        tileBase[tt + 1] = tileBase[tt] + counts[(static_cast<size_t>(node.cellBase) + tt) * 2];
+      }
+      g.pageBegin.resize(numPages + 1);
+      for (int32_t p = 0; p <= numPages; ++p) {
+        g.pageBegin[p] = static_cast<int64_t>(tileBase[g0.firstTile[p]]);
+      }
+      g.cut(numPages);
+      int32_t* childRows = static_cast<int32_t*>(g.rowsBuf.ensure(static_cast<size_t>(tileBase.back() + 1) * 4 + 64));
+      uint64_t* devTileBase = static_cast<uint64_t*>(dTileBase.ensure(tileBase.size() * 8 + 64));
+      rt.sync();
+      copyIn(devTileBase, tileBase.data(), VX355_MEM_HOST, tileBase.size() * 8);
+      VX_LAUNCH("k_row_compact", k_row_compact, static_cast<int>(g0.tiles.size()), 256, 0, node.view,
+                ColTiles{g0.devRows, g0.devTiles, static_cast<int64_t>(g0.tiles.size()), 0}, devTileBase, childRows);
+      rt.sync();  // (tileBase is reused by the next ROW column)
+      g.devRows = childRows;
+      g.upload();
+      for (int child : node.children) {
+        nodes[child].group = gid;
+      }
+    }
+    for (int child : node.children) {
+      level1.push_back(child);
+    }
+  }
+  if (!level1.empty()) {
+    uploadStreams();
+    countStreams(level1);
   }
   // layout
-  std::vector<TileOut> layout(numCells);
+  std::vector<TileOut> layout(std::max<size_t>(numCells, 1));
   std::vector<PagePatch> patches;
   auto patch = [&](uint64_t pos, const void* data, uint32_t len) {
     PagePatch pp{};
@@ -491,6 +715,107 @@ void serializePages(const vx355_batch* batch, const int32_t* rows, int32_t rowsM
     pp.len = len;
     std::memcpy(pp.data, data, len);
     patches.push_back(pp);
+  };
+  unsigned char word[32];
+  // VectorStream::flush of a scalar stream at *pos (default / VARCHAR branches); advances *pos
+  auto layoutScalar = [&](const StreamNode& node, int32_t p, int64_t* posInOut) {
+    int64_t pos = *posInOut;
+    const RowGroup& g = *groups[node.group];
+    const int64_t n = g.pageBegin[p + 1] - g.pageBegin[p];
+    const char* name = encodingName(node.kind);
+    const int32_t nameLen = static_cast<int32_t>(std::strlen(name));
+    const bool str = isString(node.kind);
+    uint64_t nonNull = 0, bytes = 0;
+    for (int64_t t = g.firstTile[p]; t < g.firstTile[p + 1]; ++t) {
+      const uint64_t* cell = &counts[static_cast<size_t>(node.cellBase + t) * 2];
+      nonNull += cell[0];
+      bytes += cell[1];
+    }
+    if (bytes > INT32_MAX) {
+      VX_THROW(VX355_EUSER, "more than 2 GB of string bytes in one page column");
+    }
+    const bool hasNulls = nonNull < static_cast<uint64_t>(n);
+    putI32(word, nameLen);
+    std::memcpy(word + 4, name, nameLen);
+    putI32(word + 4 + nameLen, n);
+    patch(static_cast<uint64_t>(pos), word, 8 + nameLen);
+    pos += 8 + nameLen;
+    uint64_t offsetsPos = 0;
+    if (str) {
+      offsetsPos = static_cast<uint64_t>(pos);
+      pos += 4 * n;
+    }
+    const unsigned char flag = hasNulls ? 1 : 0;
+    patch(static_cast<uint64_t>(pos), &flag, 1);
+    pos += 1;
+    uint64_t nullPos = ~0ULL;
+    if (hasNulls) {
+      nullPos = static_cast<uint64_t>(pos);
+      pos += (n + 7) / 8;
+    }
+    if (str) {
+      putI32(word, static_cast<int64_t>(bytes));
+      patch(static_cast<uint64_t>(pos), word, 4);
+      pos += 4;
+    }
+    const int w = str ? 1 : valueWidth(node.kind, lossless);
+    uint64_t valueRun = 0, byteRun = 0;
+    for (int64_t t = g.firstTile[p]; t < g.firstTile[p + 1]; ++t) {
+      const size_t cellIndex = static_cast<size_t>(node.cellBase + t);
+      TileOut& lo = layout[cellIndex];
+      lo.nullPos = nullPos;
+      lo.offsetsPos = offsetsPos;
+      lo.bytesBefore = byteRun;
+      lo.valuePos = static_cast<uint64_t>(pos) + (str ? byteRun : valueRun * w);
+      valueRun += counts[cellIndex * 2];
+      byteRun += counts[cellIndex * 2 + 1];
+    }
+    pos += str ? static_cast<int64_t>(bytes) : static_cast<int64_t>(nonNull) * w;
+    *posInOut = pos;
+  };
+  // VectorStream::flush, ROW branch (VectorStream.cpp:236-262): "ROW", the number of fields, the
+  // field streams, then the struct's own row count, rows + 1 offsets, null flag and bits
+  auto layoutRow = [&](const StreamNode& node, int32_t p, int64_t* posInOut) {
+    int64_t pos = *posInOut;
+    const int64_t n = g0.pageBegin[p + 1] - g0.pageBegin[p];
+    putI32(word, 3);
+    std::memcpy(word + 4, "ROW", 3);
+    putI32(word + 7, static_cast<int64_t>(node.children.size()));
+    patch(static_cast<uint64_t>(pos), word, 11);
+    pos += 11;
+    for (int child : node.children) {
+      layoutScalar(nodes[child], p, &pos);
+    }
+    uint64_t nonNull = 0;
+    for (int64_t t = g0.firstTile[p]; t < g0.firstTile[p + 1]; ++t) {
+      nonNull += counts[static_cast<size_t>(node.cellBase + t) * 2];
+    }
+    const bool hasNulls = nonNull < static_cast<uint64_t>(n);
+    putI32(word, n);
+    putI32(word + 4, 0);  // offsets[0] (VectorStream::clear, :317-324)
+    patch(static_cast<uint64_t>(pos), word, 8);
+    pos += 8;
+    const uint64_t offsetsPos = static_cast<uint64_t>(pos);  // offsets[1 ...]: the running count behind every row
+    pos += 4 * n;
+    const unsigned char flag = hasNulls ? 1 : 0;
+    patch(static_cast<uint64_t>(pos), &flag, 1);
+    pos += 1;
+    uint64_t nullPos = ~0ULL;
+    if (hasNulls) {
+      nullPos = static_cast<uint64_t>(pos);
+      pos += (n + 7) / 8;
+    }
+    uint64_t run = 0;
+    for (int64_t t = g0.firstTile[p]; t < g0.firstTile[p + 1]; ++t) {
+      const size_t cellIndex = static_cast<size_t>(node.cellBase + t);
+      TileOut& lo = layout[cellIndex];
+      lo.nullPos = nullPos;
+      lo.offsetsPos = offsetsPos;
+      lo.bytesBefore = run;
+      lo.valuePos = 0;  // a ROW node has no bytes of its own
+      run += counts[cellIndex * 2 + 1];
+    }
+    *posInOut = pos;
   };
   struct PageInfo {
     int64_t begin = 0, size = 0;
@@ -507,62 +832,15 @@ void serializePages(const vx355_batch* batch, const int32_t* rows, int32_t rowsM
       continue;  // Destination::flush: nothing to send
     }
     int64_t pos = at + kPageHeader;
-    unsigned char word[32];
     putI32(word, nc);
     patch(static_cast<uint64_t>(pos), word, 4);
     pos += 4;
-    for (int32_t c = 0; c < nc; ++c) {
-      const int32_t kind = batch->cols[c].type_kind;
-      const char* name = encodingName(kind);
-      const int32_t nameLen = static_cast<int32_t>(std::strlen(name));
-      const bool str = isString(kind);
-      uint64_t nonNull = 0, bytes = 0;
-      for (int64_t t = firstTile[p]; t < firstTile[p + 1]; ++t) {
-        const uint64_t* cell = &counts[(static_cast<size_t>(c) * numTiles + t) * 2];
-        nonNull += cell[0];
-        bytes += cell[1];
+    for (int t : topLevel) {
+      if (nodes[t].kind == VX355_ROW) {
+        layoutRow(nodes[t], p, &pos);
+      } else {
+        layoutScalar(nodes[t], p, &pos);
       }
-      if (bytes > INT32_MAX) {
-        VX_THROW(VX355_EUSER, "more than 2 GB of string bytes in one page column");
-      }
-      const bool hasNulls = nonNull < static_cast<uint64_t>(n);
-      // header: name, row count (VectorStream::flush default / VARCHAR branches)
-      putI32(word, nameLen);
-      std::memcpy(word + 4, name, nameLen);
-      putI32(word + 4 + nameLen, n);
-      patch(static_cast<uint64_t>(pos), word, 8 + nameLen);
-      pos += 8 + nameLen;
-      uint64_t offsetsPos = 0;
-      if (str) {
-        offsetsPos = static_cast<uint64_t>(pos);
-        pos += 4 * n;
-      }
-      const unsigned char flag = hasNulls ? 1 : 0;
-      patch(static_cast<uint64_t>(pos), &flag, 1);
-      pos += 1;
-      uint64_t nullPos = ~0ULL;
-      if (hasNulls) {
-        nullPos = static_cast<uint64_t>(pos);
-        pos += (n + 7) / 8;
-      }
-      if (str) {
-        putI32(word, static_cast<int64_t>(bytes));
-        patch(static_cast<uint64_t>(pos), word, 4);
-        pos += 4;
-      }
-      const int w = str ? 1 : valueWidth(kind, lossless);
-      uint64_t valueRun = 0, byteRun = 0;
-      for (int64_t t = firstTile[p]; t < firstTile[p + 1]; ++t) {
-        const size_t cellIndex = static_cast<size_t>(c) * numTiles + t;
-        TileOut& lo = layout[cellIndex];
-        lo.nullPos = nullPos;
-        lo.offsetsPos = offsetsPos;
-        lo.bytesBefore = byteRun;
-        lo.valuePos = static_cast<uint64_t>(pos) + (str ? byteRun : valueRun * w);
-        valueRun += counts[cellIndex * 2];
-        byteRun += counts[cellIndex * 2 + 1];
-      }
-      pos += str ? static_cast<int64_t>(bytes) : static_cast<int64_t>(nonNull) * w;
     }
     pages[p].size = pos - at;
     if (pages[p].size - kPageHeader > INT32_MAX) {
@@ -588,11 +866,21 @@ void serializePages(const vx355_batch* batch, const int32_t* rows, int32_t rowsM
   unsigned char* devOut = outMem == VX355_MEM_DEVICE ? static_cast<unsigned char*>(out)
                                                      : static_cast<unsigned char*>(dOut.ensure(static_cast<size_t>(at) + 64));
   a.out = devOut;
-  if (nc > 0) {
+  if (!nodes.empty()) {
     TileOut* devLayout = static_cast<TileOut*>(dLayout.ensure(layout.size() * sizeof(TileOut) + 64));
     copyIn(devLayout, layout.data(), VX355_MEM_HOST, layout.size() * sizeof(TileOut));
     a.layout = devLayout;
-    VX_LAUNCH("k_page_write", k_page_write, dim3(static_cast<unsigned>(numTiles), static_cast<unsigned>(nc)), 256, 0, a);
+    std::vector<int32_t> every(nodes.size());
+    int64_t gridTiles = 0;
+    for (size_t i = 0; i < nodes.size(); ++i) {
+      every[i] = static_cast<int32_t>(i);
+      gridTiles = std::max<int64_t>(gridTiles, static_cast<int64_t>(groups[nodes[i].group]->tiles.size()));
+    }
+    rt.sync();
+    copyIn(devLaunch, every.data(), VX355_MEM_HOST, every.size() * 4);
+    VX_LAUNCH("k_page_write", k_page_write, dim3(static_cast<unsigned>(gridTiles), static_cast<unsigned>(nodes.size())), 256,
+              0, a);
+    rt.sync();  // ('every' is a local: its upload must have happened before it goes)
   }
   PagePatch* devPatches = static_cast<PagePatch*>(dPatches.ensure(patches.size() * sizeof(PagePatch) + 64));
   copyIn(devPatches, patches.data(), VX355_MEM_HOST, patches.size() * sizeof(PagePatch));
@@ -649,6 +937,12 @@ struct ReadSection {
   int64_t indicesPos; // DICTIONARY: the i32 indices; -1 otherwise
   int32_t constant;   // RLE
   int32_t pad;
+  // Field of a ROW column: the stream holds one row per NON-NULL struct (readRowVector,
+  // PrestoSerializerDeserializationUtils.cpp:1041-1110). outerNullPos: the struct's null bytes
+  // (-1: no struct is null, the stream has a row per page row), outerPrefixBase: their 64-row
+  // prefix counts. A page row first becomes its rank among the non-null structs.
+  int64_t outerNullPos;
+  int64_t outerPrefixBase;
 };
 
 struct ReadArgs {
@@ -693,15 +987,29 @@ __global__ __launch_bounds__(256) void k_page_read(ReadArgs a) {
   }
   int64_t lr = active ? r - a.pageRowBegin[lo] : 0;
   const ReadSection sec =
-      active ? a.sections[static_cast<int64_t>(lo) * a.numCols + col] : ReadSection{-1, 0, 0, 0, -1, 0, 0};
-  if (sec.constant) {
+      active ? a.sections[static_cast<int64_t>(lo) * a.numCols + col] : ReadSection{-1, 0, 0, 0, -1, 0, 0, -1, 0};
+  bool structValid = true;
+  if (active && sec.outerNullPos >= 0) {
+    // field of a struct: my row in the field's stream = my rank among the non-null structs
+    const unsigned char* nb = a.bytes + sec.outerNullPos;
+    structValid = !((nb[lr >> 3] >> (7 - (lr & 7))) & 1);
+    uint64_t rank0 = a.prefix[sec.outerPrefixBase + (lr >> 6)];
+    const int64_t blockFirst = lr & ~63LL;
+    for (int64_t b = blockFirst >> 3; b < (lr >> 3); ++b) {
+      rank0 += 8 - __popc(static_cast<uint32_t>(nb[b]));
+    }
+    const uint32_t before = static_cast<uint32_t>(nb[lr >> 3]) >> (8 - (lr & 7));
+    rank0 += (lr & 7) - __popc((lr & 7) ? before : 0u);
+    lr = structValid ? static_cast<int64_t>(rank0) : 0;
+  }
+  if (sec.constant || !structValid) {
     lr = 0;
   } else if (sec.indicesPos >= 0) {
     lr = static_cast<int64_t>(reinterpret_cast<const Packed32*>(a.bytes + sec.indicesPos + 4 * lr)->v);
   }
-  bool valid = active;
+  bool valid = active && structValid;
   uint64_t rank = static_cast<uint64_t>(lr);
-  if (active && sec.nullPos >= 0) {
+  if (valid && sec.nullPos >= 0) {
     const unsigned char* nb = a.bytes + sec.nullPos;
     valid = !((nb[lr >> 3] >> (7 - (lr & 7))) & 1);  // first row in the most significant bit, 1 = null
     // rank among the non-null rows: rows of earlier 64-row blocks (host), then the bits before mine
@@ -714,6 +1022,9 @@ __global__ __launch_bounds__(256) void k_page_read(ReadArgs a) {
     rank += (lr & 7) - __popc((lr & 7) ? before : 0u);
   }
   storeBitWord(a.nulls[col], r, valid);
+  if (kind == VX355_ROW) {
+    return;  // a struct column's own stream: its validity, nothing else
+  }
   if (kind == VX355_BOOLEAN) {
     const bool v = valid && a.bytes[sec.valuePos + rank] != 0;
     storeBitWord(static_cast<uint64_t*>(a.values[col]), r, v);
@@ -841,12 +1152,10 @@ void deserializePages(const void* const* pages, const int64_t* sizes, int32_t nu
     }
     pageRowBegin[p + 1] = pageRowBegin[p] + n;
     pageDevBegin[p + 1] = pageDevBegin[p] + size;
-    int64_t pos = kPageHeader;
-    if (getI32(page + pos) != numCols) {
-      bad("column count " + std::to_string(getI32(page + pos)) + ", expected " + std::to_string(numCols));
-    }
-    pos += 4;
-    for (int32_t c = 0; c < numCols; ++c) {
+    int64_t pos = kPageHeader + 4;  // (the column count is checked against the top-level entries of types[] below)
+    // One column stream at 'pos' into section 'c'. expectRows: the rows it must hold; -1 = a field of
+    // a struct (its row count = the non-null structs, checked by the caller). Returns its row count.
+    auto parseScalar = [&](int32_t c, int64_t expectRows) -> int64_t {
       const char* name = encodingName(types[c]);
       if (!name) {
         VX_THROW(VX355_EUNSUPPORTED, "PrestoPage column of type kind " + std::to_string(types[c]));
@@ -856,25 +1165,30 @@ void deserializePages(const void* const* pages, const int64_t* sizes, int32_t nu
       sec.offsetsPos = 0;
       sec.indicesPos = -1;
       sec.constant = 0;
+      sec.outerNullPos = -1;
+      sec.outerPrefixBase = 0;
       auto nameIs = [&](const char* what) {
         const int32_t len = static_cast<int32_t>(std::strlen(what));
         return pos + 4 + len <= size && getI32(page + pos) == len && std::memcmp(page + pos + 4, what, len) == 0;
       };
-      int64_t flatRows = n;  // rows of the flat column that holds the values
+      int64_t outerRows = expectRows;  // rows of the stream as its consumer sees it
+      int64_t flatRows = expectRows;   // rows of the flat column that holds the values
       int64_t dictTail = -1;  // DICTIONARY: where the indices start is known after the nested column
       if (nameIs("RLE")) {
         pos += 4 + 3;
-        if (pos + 4 > size || getI32(page + pos) != n) {
+        if (pos + 4 > size || (expectRows >= 0 ? getI32(page + pos) != expectRows : getI32(page + pos) < 0)) {
           bad("column " + std::to_string(c) + " run length");
         }
+        outerRows = getI32(page + pos);
         pos += 4;
         sec.constant = 1;
         flatRows = 1;
       } else if (nameIs("DICTIONARY")) {
         pos += 4 + 10;
-        if (pos + 4 > size || getI32(page + pos) != n) {
+        if (pos + 4 > size || (expectRows >= 0 ? getI32(page + pos) != expectRows : getI32(page + pos) < 0)) {
           bad("column " + std::to_string(c) + " row count");
         }
+        outerRows = getI32(page + pos);
         pos += 4;
         dictTail = 0;
         flatRows = -1;  // read from the nested column's own header
@@ -892,6 +1206,9 @@ void deserializePages(const void* const* pages, const int64_t* sizes, int32_t nu
         bad("column " + std::to_string(c) + " row count");
       }
       flatRows = rowsHere;
+      if (outerRows < 0) {
+        outerRows = rowsHere;
+      }
       pos += 4;
       const bool str = isString(types[c]);
       int64_t lastEnd = 0;
@@ -960,18 +1277,105 @@ void deserializePages(const void* const* pages, const int64_t* sizes, int32_t nu
       }
       if (dictTail == 0) {
         // indices, then 24 bytes of instance id
-        if (pos + 4LL * n + 24 > size) {
+        if (pos + 4LL * outerRows + 24 > size) {
           bad("truncated dictionary indices of column " + std::to_string(c));
         }
-        for (int64_t i = 0; i < n; ++i) {
+        for (int64_t i = 0; i < outerRows; ++i) {
           const int32_t idx = getI32(page + pos + 4 * i);
           if (idx < 0 || idx >= flatRows) {
             bad("dictionary index out of range in column " + std::to_string(c));
           }
         }
         sec.indicesPos = pageDevBegin[p] + pos;
-        pos += 4LL * n + 24;
+        pos += 4LL * outerRows + 24;
       }
+      return outerRows;
+    };
+    int32_t topLevelSeen = 0;
+    for (int32_t c = 0; c < numCols; ++topLevelSeen) {
+      if ((types[c] & 0xff) != VX355_ROW) {
+        parseScalar(c, n);
+        ++c;
+        continue;
+      }
+      // VectorStream::flush, ROW branch (VectorStream.cpp:236-262) / readRowVector
+      // (PrestoSerializerDeserializationUtils.cpp:1041-1110): "ROW", the number of fields, the fields'
+      // streams (one row per non-null struct), the struct's row count, rows + 1 offsets, null flag + bits
+      const int32_t fields = types[c] >> 8;
+      if (c + 1 + fields > numCols) {
+        VX_THROW(VX355_EINVAL, "types[]: a ROW entry announces more fields than follow");
+      }
+      if (!(pos + 4 + 3 + 4 <= size && getI32(page + pos) == 3 && std::memcmp(page + pos + 4, "ROW", 3) == 0)) {
+        bad("column " + std::to_string(c) + " is not ROW");
+      }
+      pos += 7;
+      if (getI32(page + pos) != fields) {
+        bad("ROW column " + std::to_string(c) + " has " + std::to_string(getI32(page + pos)) + " fields, expected " +
+            std::to_string(fields));
+      }
+      pos += 4;
+      std::vector<int64_t> fieldRows(fields);
+      for (int32_t f = 0; f < fields; ++f) {
+        if ((types[c + 1 + f] & 0xff) == VX355_ROW) {
+          VX_THROW(VX355_EUNSUPPORTED, "PrestoPage: a ROW inside a ROW");
+        }
+        fieldRows[f] = parseScalar(c + 1 + f, -1);
+      }
+      if (pos + 4 > size || getI32(page + pos) != n) {
+        bad("ROW column " + std::to_string(c) + " row count");
+      }
+      pos += 4;
+      if (pos + 4LL * (n + 1) + 1 > size) {
+        bad("truncated offsets of ROW column " + std::to_string(c));
+      }
+      const int64_t offsetsAt = pos;
+      pos += 4LL * (n + 1);
+      const bool hasNulls = page[pos] != 0;
+      pos += 1;
+      ReadSection& sec = sections[static_cast<size_t>(p) * numCols + c];
+      sec = ReadSection{-1, 0, 0, static_cast<int64_t>(prefix.size()), -1, 0, 0, -1, 0};
+      int64_t nonNull = n;
+      if (hasNulls) {
+        if (cols[c].nulls == nullptr) {
+          VX_THROW(VX355_EINVAL, "page " + std::to_string(p) + " carries null structs in column " + std::to_string(c) +
+                                     " but the output column has no null buffer");
+        }
+        const int64_t nullBytes = (n + 7) / 8;
+        if (pos + nullBytes > size) {
+          bad("truncated null flags of ROW column " + std::to_string(c));
+        }
+        sec.nullPos = pageDevBegin[p] + pos;
+        uint32_t run = 0;
+        for (int64_t b = 0; b < nullBytes; ++b) {
+          if ((b & 7) == 0) {
+            prefix.push_back(run);
+          }
+          const int64_t inByte = std::min<int64_t>(8, n - b * 8);
+          const unsigned flags = page[pos + b] & (0xffu << (8 - inByte)) & 0xffu;
+          run += static_cast<uint32_t>(inByte - __builtin_popcount(flags));
+        }
+        nonNull = run;
+        pos += nullBytes;
+      }
+      // the offsets count the non-null structs: 0, then + 1 behind every non-null row
+      if (getI32(page + offsetsAt) != 0 || getI32(page + offsetsAt + 4 * n) != nonNull) {
+        bad("offsets of ROW column " + std::to_string(c) + " do not count its non-null rows");
+      }
+      for (int32_t f = 0; f < fields; ++f) {
+        if (fieldRows[f] != nonNull) {
+          bad("field " + std::to_string(f) + " of ROW column " + std::to_string(c) + " does not hold one row per non-null struct");
+        }
+        ReadSection& child = sections[static_cast<size_t>(p) * numCols + c + 1 + f];
+        child.outerNullPos = sec.nullPos;
+        child.outerPrefixBase = sec.prefixBase;
+        if (hasNulls && cols[c + 1 + f].nulls == nullptr) {
+          VX_THROW(VX355_EINVAL, "a field of a ROW column with null structs needs a null buffer");
+        }
+      }
+      c += 1 + fields;
+    }
+    if (getI32(page + kPageHeader) != topLevelSeen) {
+      bad("column count " + std::to_string(getI32(page + kPageHeader)) + ", expected " + std::to_string(topLevelSeen));
     }
     if (pos != size) {
       bad("trailing bytes");
@@ -985,7 +1389,8 @@ void deserializePages(const void* const* pages, const int64_t* sizes, int32_t nu
   VX_CHECK_ARG(totalRows <= capacityRows, "output columns smaller than the pages' rows");
   VX_CHECK_ARG(deviceBytes && deviceCapacity >= pageDevBegin[numPages], "device buffer smaller than the pages");
   for (int32_t c = 0; c < numCols; ++c) {
-    VX_CHECK_ARG(cols[c].type_kind == types[c] && cols[c].mem == VX355_MEM_DEVICE && cols[c].values,
+    const bool rowNode = (types[c] & 0xff) == VX355_ROW;   // a struct's own entry only carries its null bitmap
+    VX_CHECK_ARG(cols[c].type_kind == (types[c] & 0xff) && cols[c].mem == VX355_MEM_DEVICE && (rowNode || cols[c].values),
                  "output columns: device memory of the expected types");
   }
   for (int32_t p = 0; p < numPages; ++p) {
@@ -1001,7 +1406,11 @@ void deserializePages(const void* const* pages, const int64_t* sizes, int32_t nu
     copyIn(devPrefix, prefix.data(), VX355_MEM_HOST, prefix.size() * 4);
   }
   int32_t* devKinds = static_cast<int32_t*>(dKinds.ensure(static_cast<size_t>(numCols) * 4 + 64));
-  copyIn(devKinds, types, VX355_MEM_HOST, static_cast<size_t>(numCols) * 4);
+  std::vector<int32_t> kinds(numCols);
+  for (int32_t c = 0; c < numCols; ++c) {
+    kinds[c] = types[c] & 0xff;
+  }
+  copyIn(devKinds, kinds.data(), VX355_MEM_HOST, static_cast<size_t>(numCols) * 4);
   std::vector<void*> values(numCols);
   std::vector<uint64_t*> nulls(numCols);
   for (int32_t c = 0; c < numCols; ++c) {

@@ -651,7 +651,8 @@ def presto_serialize(batch, offsets, rows=None, flags=0, device_out=False):
 def presto_deserialize(pages, kinds, flags=0):
     """vx355_presto_deserialize: list of page bytes -> [(values, valid)] per column, fetched back
     from the HBM columns the library wrote (strings longer than 12 bytes through the device copy
-    of the pages their views point into)."""
+    of the pages their views point into). A struct column is described as ("row", [field kinds])
+    and comes back as ([(values, valid) per field], struct valid)."""
     import struct
     pages = [bytes(p) for p in pages if len(p)]
     total_rows = sum(struct.unpack_from("<i", p, 0)[0] for p in pages)
@@ -662,25 +663,37 @@ def presto_deserialize(pages, kinds, flags=0):
     dev_bytes = DeviceArray(max(total_bytes, 1), np.uint8)
     cap = max(total_rows, 1)
     words = (cap + 63) // 64
+    # nodes in prefix order: a struct's own entry (validity only), then its fields
+    nodes, types = [], []
+    for kind in kinds:
+        if isinstance(kind, tuple):
+            nodes.append(abi.ROW)
+            types.append(abi.ROW | (len(kind[1]) << 8))   # VX355_ROW_OF(number of fields)
+            nodes.extend(kind[1])
+            types.extend(kind[1])
+        else:
+            nodes.append(kind)
+            types.append(kind)
     vals, nulls = [], []
-    descs = (abi.OutColumn * max(1, len(kinds)))()
-    for c, kind in enumerate(kinds):
+    descs = (abi.OutColumn * max(1, len(nodes)))()
+    for c, kind in enumerate(nodes):
         width = {abi.BOOLEAN: 0, abi.TINYINT: 1, abi.SMALLINT: 2, abi.INTEGER: 4, abi.REAL: 4, abi.BIGINT: 8,
-                 abi.DOUBLE: 8, abi.TIMESTAMP: 16, abi.VARCHAR: 16, abi.VARBINARY: 16}[kind]
+                 abi.DOUBLE: 8, abi.TIMESTAMP: 16, abi.VARCHAR: 16, abi.VARBINARY: 16, abi.ROW: 0}[kind]
         vals.append(DeviceArray(words * 8 if width == 0 else cap * width, np.uint8))
         nulls.append(DeviceArray(words, np.uint64))
         descs[c].type_kind, descs[c].mem = kind, abi.MEM_DEVICE
-        descs[c].values, descs[c].nulls = vals[c].ptr, nulls[c].ptr
+        descs[c].values, descs[c].nulls = (None if kind == abi.ROW else vals[c].ptr), nulls[c].ptr
     rows = C.c_int64()
-    types = abi.i32_array(kinds)
-    _check(lib().vx355_presto_deserialize(ptrs, sizes.ctypes.data, len(pages), types, len(kinds), flags, dev_bytes.ptr,
-                                          total_bytes, descs, cap, C.byref(rows)))
+    _check(lib().vx355_presto_deserialize(ptrs, sizes.ctypes.data, len(pages), abi.i32_array(types), len(nodes), flags,
+                                          dev_bytes.ptr, total_bytes, descs, cap, C.byref(rows)))
     n = rows.value
     assert n == total_rows
     host_bytes = dev_bytes.to_host().tobytes() if total_bytes else b""
-    out = []
-    for c, kind in enumerate(kinds):
+
+    def fetch(c, kind):
         valid = abi.unpack_bits(nulls[c].to_host(), n)
+        if kind == abi.ROW:
+            return None, valid
         raw = vals[c].to_host()
         if kind == abi.BOOLEAN:
             v = abi.unpack_bits(raw.view(np.uint64), n)
@@ -700,7 +713,17 @@ def presto_deserialize(pages, kinds, flags=0):
             v = raw[: n * 16].view(np.int64).reshape(n, 2)
         else:
             v = raw[: n * np.dtype(abi.KIND_DTYPE[kind]).itemsize].view(abi.KIND_DTYPE[kind])
-        out.append((v, valid))
+        return v, valid
+    out, c = [], 0
+    for kind in kinds:
+        if isinstance(kind, tuple):
+            _, struct_valid = fetch(c, abi.ROW)
+            fields = [fetch(c + 1 + f, k) for f, k in enumerate(kind[1])]
+            out.append((fields, struct_valid))
+            c += 1 + len(kind[1])
+        else:
+            out.append(fetch(c, kind))
+            c += 1
     return n, out
 
 
