@@ -680,7 +680,12 @@ typedef struct vx355_join_build_spec {
                             (core/PlanNode.h:3442-3445); rows with null keys enter the table
                             (HashBuild.cpp:273,477) and null probe keys are looked up
                             (HashProbe.cpp:787). Excludes null_aware. */
-  int32_t pad;
+  int32_t drop_duplicates; /* HashJoinNode::canDropDuplicates (core/PlanNode.h:3391-3398; HashBuild.cpp:517-548): a
+                              left semi (filter / project) or anti join WITHOUT an extra filter only asks
+                              whether a key exists; rows whose key is already in the table are not linked
+                              (table statistics report unique keys, probes never walk a chain). Any other join
+                              type with this flag, or vx355_join_probe_set_filter on such a table, is
+                              VX355_EINVAL. Counting joins always keep one entry per key and its count. */
 } vx355_join_build_spec;
 
 typedef struct vx355_join_build vx355_join_build;

@@ -6,6 +6,7 @@
 
 #include "velox/core/PlanNode.h"
 #include "velox/core/QueryConfig.h"
+#include "velox/exec/Aggregate.h"
 #include "velox/exec/HashAggregation.h"
 #include "velox/exec/Task.h"
 #include "velox/vector/FlatVector.h"
@@ -195,7 +196,7 @@ OutColumns::OutColumns(RowVector& result) {
     vx355_out_column col{};
     col.type_kind = static_cast<int32_t>(child->typeKind());
     col.mem = VX355_MEM_HOST;
-    col.values = child->valuesAsVoid();
+    col.values = child->values() ? child->values()->asMutable<void>() : nullptr;  // flat scalar children of the result
     col.nulls = child->mutableRawNulls();
     columns_.push_back(col);
   }

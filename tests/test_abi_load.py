@@ -80,3 +80,18 @@ def test_ctypes_structures_have_the_layout_of_the_header(tmp_path):
         assert int(out[cname]) == C.sizeof(cls), cname
         for field, _ in cls._fields_:
             assert int(out[f"{cname}.{field}"]) == getattr(cls, field).offset, f"{cname}.{field}"
+
+
+def test_shim_sources_only_use_declared_entry_points():
+    """shim/Vx355Adapter.{h,cpp} is compiled on the Velox side (no Velox here); what can be checked
+    without it: every vx355_* function, type and constant the adapter uses exists in include/vx355.h."""
+    header = open(os.path.join(ROOT, "include", "vx355.h")).read()
+    declared = set(re.findall(r"\b(vx355_[a-z0-9_]+|VX355_[A-Z0-9_]+)\b", header))
+    used = set()
+    for name in ("Vx355Adapter.h", "Vx355Adapter.cpp"):
+        text = open(os.path.join(ROOT, "shim", name)).read()
+        text = re.sub(r"//[^\n]*", "", text)
+        used |= set(re.findall(r"\b(vx355_[a-z0-9_]+|VX355_[A-Z0-9_]+)\b", text))
+    used -= {"vx355_adapter"}   # (a CMake target name, not an ABI symbol)
+    assert used and used <= declared, sorted(used - declared)
+    assert os.path.exists(os.path.join(ROOT, "shim", "CMakeLists.txt"))

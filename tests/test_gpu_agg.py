@@ -1597,27 +1597,34 @@ def test_a_second_process_loads_hiprtc_instances_from_the_disk_cache(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import numpy as np, sys\\n"
-        "sys.path.insert(0, %r); sys.path.insert(0, %r)\\n"
-        "from velox_amd import abi, ops\\n"
-        "from gpu_util import batch_of\\n"
-        "ops.init(0)\\n"
-        "rng = np.random.default_rng(5)\\n"
-        "n = 1 << 18\\n"
-        "hb = batch_of([rng.integers(0, 9, n).astype(np.int32), rng.integers(0, 5, n).astype(np.int64),\\n"
-        "               rng.integers(0, 1 << 20, n) / 1024.0, rng.integers(0, 1 << 20, n) / 1024.0])\\n"
-        "aggs = [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_MAX, 3, abi.DOUBLE), (abi.AGG_AVG, 3, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]\\n"
-        "op = ops.Aggregation([0, 1], [abi.INTEGER, abi.BIGINT], aggs)\\n"
-        "ops.profile_enable(True)\\n"
-        "op.add_input(ops.to_device(hb)); op.no_more_input()\\n"
-        "out = ops.collect_output(op, 100)\\n"
-        "print('KERNELS', sorted(ops.profile()), 'JIT', op.stats().reserved, 'SUM', float(np.sum(out[2][0])))\\n"
-    ) % (root, os.path.join(root, "tests"))
+    worker = tmp_path / "worker.py"
+    worker.write_text("""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+from velox_amd import abi, ops
+from gpu_util import batch_of
+ops.init(0)
+rng = np.random.default_rng(5)
+n = 1 << 18
+hb = batch_of([rng.integers(0, 9, n).astype(np.int32), rng.integers(0, 5, n).astype(np.int64),
+               rng.integers(0, 1 << 20, n) / 1024.0, rng.integers(0, 1 << 20, n) / 1024.0])
+aggs = [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_MAX, 3, abi.DOUBLE), (abi.AGG_AVG, 3, abi.DOUBLE),
+        (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+op = ops.Aggregation([0, 1], [abi.INTEGER, abi.BIGINT], aggs)
+ops.profile_enable(True)
+op.add_input(ops.to_device(hb))
+op.no_more_input()
+out = ops.collect_output(op, 100)
+print('KERNELS', sorted(ops.profile()), 'JIT', op.stats().reserved, 'SUM', float(np.sum(out[2][0])))
+""" % (root, os.path.join(root, "tests")))
+    cache = tmp_path / "cache"
+    cache.mkdir()
     outs = []
     for jit in ("sync", "async"):
-        env = dict(os.environ, VX355_CACHE_DIR=str(tmp_path), VX355_LOG_SHAPES="1", VX355_JIT=jit)
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+        env = dict(os.environ, VX355_CACHE_DIR=str(cache), VX355_LOG_SHAPES="1", VX355_JIT=jit)
+        r = subprocess.run([sys.executable, str(worker)], capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode == 0, r.stderr[-3000:]
         outs.append(r)
     first, second = outs
@@ -1625,4 +1632,4 @@ def test_a_second_process_loads_hiprtc_instances_from_the_disk_cache(tmp_path):
     assert "loaded from" in second.stderr and "compiling an instance" not in second.stderr
     assert "k_agg_fast" in second.stdout and "k_agg_lds" not in second.stdout   # first batch, asynchronous mode
     assert first.stdout.split("SUM")[1] == second.stdout.split("SUM")[1]
-    assert len(list(tmp_path.glob("agg_fast_*.hsaco"))) == 1
+    assert len(list(cache.glob("agg_fast_*.hsaco"))) == 1

@@ -1041,3 +1041,56 @@ def test_null_aware_joins_with_extra_filter(oracle, vx, join_type, build_nulls):
         assert got == exp
     else:
         assert [(i, min(r, 0)) for i, r in got] == [(i, min(r, 0)) for i, r in exp]
+
+
+@pytest.mark.parametrize("join_type", [abi.JOIN_LEFT_SEMI_FILTER, abi.JOIN_LEFT_SEMI_PROJECT, abi.JOIN_ANTI])
+@pytest.mark.parametrize("mode", ["array", "normalized", "generic"])
+def test_build_side_drops_duplicate_keys_for_semi_and_anti_joins(oracle, vx, join_type, mode, monkeypatch):
+    """HashJoinNode::canDropDuplicates (core/PlanNode.h:3391-3398; HashBuild.cpp:517-548): a left
+    semi (filter / project) or anti join without an extra filter only asks whether a key exists, so
+    the build links one row per key. Same probe rows out as the oracle's join over the full build
+    side, the table reports unique keys, and what does not fit the rule is refused."""
+    if mode == "normalized":
+        monkeypatch.setenv("VX355_JOIN_ARRAY_MAX", "0")
+    rng = np.random.default_rng(77 + join_type)
+    nb, npb = 30000, 50000
+    if mode == "generic":
+        bk = [b"key-%05d-of-the-build-side" % k for k in rng.integers(0, 2000, nb)]
+        pk = [b"key-%05d-of-the-build-side" % k for k in rng.integers(-50, 4000, npb)]
+        kind = abi.VARCHAR
+    else:
+        bk = rng.integers(0, 2000, nb).astype(np.int64)
+        pk = rng.integers(-50, 4000, npb).astype(np.int64)
+        kind = abi.BIGINT
+    bvalid = rng.random(nb) > 0.03
+    pvalid = rng.random(npb) > 0.03
+    build = abi.HostBatch([abi.HostColumn(kind, bk, bvalid)])
+    probe_batch = abi.HostBatch([abi.HostColumn(kind, pk, pvalid)])
+    results = {}
+    for impl in (oracle, vx):
+        kw = {"drop_duplicates": True} if impl is vx else {}
+        b = impl.JoinBuild([0], [kind], [], [], join_type, **kw)
+        for lo in range(0, nb, 7000):
+            cols = [abi.HostColumn(kind, bk[lo:lo + 7000], bvalid[lo:lo + 7000])]
+            b.add_input(abi.HostBatch(cols))
+        table = b.finish()
+        st = table.stats()
+        if impl is vx:
+            assert st.has_duplicates == 0
+            assert st.num_distinct == len(set(k for k, v in zip(bk, bvalid) if v))
+        p = impl.JoinProbe(table, [0], join_type)
+        p.add_input(probe_batch)
+        pairs, _ = _drain(p, 4096)
+        # the first match's row number may differ (any row of the key stands for it): compare the
+        # probe rows and, for the semi project, whether each of them matched
+        results[impl.__name__] = [(r, b_row >= 0 if join_type == abi.JOIN_LEFT_SEMI_PROJECT else True) for r, b_row in pairs]
+        if impl is vx:
+            with pytest.raises(vx.Vx355Error) as e:
+                p2 = vx.JoinProbe(table, [0], join_type)
+                p2.set_filter([(("probe", 0), abi.CMP_GE, 0)])
+            assert e.value.status == abi.EINVAL
+    assert results[oracle.__name__] == results[vx.__name__] and len(results[vx.__name__]) > 1000
+    del build
+    with pytest.raises(vx.Vx355Error) as e:
+        vx.JoinBuild([0], [kind], [], [], abi.JOIN_INNER, drop_duplicates=True)
+    assert e.value.status == abi.EINVAL

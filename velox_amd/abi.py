@@ -103,7 +103,7 @@ class JoinBuildSpec(C.Structure):
                 ("key_types", C.POINTER(C.c_int32)), ("num_dependents", C.c_int32),
                 ("dependent_cols", C.POINTER(C.c_int32)),
                 ("dependent_types", C.POINTER(C.c_int32)), ("join_type", C.c_int32),
-                ("null_aware", C.c_int32), ("null_as_value", C.c_int32), ("pad", C.c_int32)]
+                ("null_aware", C.c_int32), ("null_as_value", C.c_int32), ("drop_duplicates", C.c_int32)]
 
 
 class JoinTableStats(C.Structure):

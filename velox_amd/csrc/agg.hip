@@ -692,6 +692,11 @@ const FastEntry kFastTable[] = {
     //    sum(ep*(1-disc)), avg(qty), avg(disc), count(*): loads qty=0, ep=1, disc=2
     VX_FAST_ENTRY_K(4, FK_VIEW, FK_VIEW, FK_I32, FK_NONE, 3, 5, kQ1Lo, packAccs(accDesc(1, 2)), 0x0u, 0x0u, 0x0ull, 0x0u,
                     0x0u, 0x0ull, packExtraKeys(FK_I32, FK_I32)),
+    //  * TPC-H Q1 as Velox really hands it over when the FilterProject is NOT fused: keys and operands
+    //    dictionary-wrapped by the filter's selected-row indices, the two projections as flat columns
+    //    (bench.py --unfused): a new worker process's first operator must not start on k_agg_lds
+    VX_FAST_ENTRY_K(4, FK_VIEW, FK_VIEW, FK_NONE, FK_NONE, 5, 6, 0xff21ff11fff0ff01ull, 0xff41ff31ull, 0x133u, 0x0u,
+                    0x0ull, 0x0u, 0x0u, 0x0ull, kFastNoExtraKeys),
     //  * TPC-H Q1 with a nullable l_discount
     VX_FAST_ENTRY_X(4, FK_VIEW, FK_VIEW, FK_I32, FK_NONE, 4, 9, 0xf212ff11fff0ff01ull, 0xff2132103213f210ull, 0x0u, 0x40u,
                     0xff20ull, 0x0u, 0x0u, 0x0ull),

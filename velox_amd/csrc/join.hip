@@ -334,7 +334,11 @@ struct InsertArgs {
   uint64_t capacity;
   uint32_t* next;
   int32_t phase;      // array mode: 1 = claim keys, 2 = chain the duplicates
-  int32_t pad;
+  // HashJoinNode::canDropDuplicates (core/PlanNode.h:3391-3398; HashBuild.cpp:517-548): a semi / anti
+  // join without an extra filter only asks whether a key exists - a row whose key is already in
+  // the table is not linked at all (no chain, no duplicate count: the table behaves like one with
+  // unique keys and the probe never walks a chain)
+  int32_t dropDups;
   BuildCounters* counters;
   const uint8_t* keyNull;  // rows kept for right / full joins only: not inserted
   int32_t nullAsValue;     // keyNull[row] is a mask of null keys instead, and such rows are inserted
@@ -504,6 +508,8 @@ __global__ __launch_bounds__(256) void k_join_insert(InsertArgs a) {
             a.head[keys[u]] = static_cast<uint32_t>(row);
             a.next[row] = kNoRow32;
             ++distinct;
+          } else if (a.dropDups) {
+            a.next[row] = kNoRow32;
           } else {
             a.next[row] = kPendingRow;
             ++dups;
@@ -567,8 +573,10 @@ __global__ __launch_bounds__(256) void k_join_insert(InsertArgs a) {
         if ((w >> 32) == tag) {
           const int64_t rep = static_cast<int64_t>(static_cast<uint32_t>(w)) - 1;
           if (storedKeysEqual(a, row, rep)) {
-            a.next[row] = atomicExch(a.next + rep, static_cast<uint32_t>(row));
-            ++dups;
+            if (!a.dropDups) {
+              a.next[row] = atomicExch(a.next + rep, static_cast<uint32_t>(row));
+              ++dups;
+            }
             placed = true;
             break;
           }
@@ -600,6 +608,13 @@ __global__ __launch_bounds__(256) void k_join_insert(InsertArgs a) {
     }
     if (!headWord) {
       a.counters->tableFull = 1;
+      continue;
+    }
+    if (a.dropDups) {
+      // the first row of a key stays its only row
+      const uint32_t old = atomicCAS(headWord, kNoRow32, static_cast<uint32_t>(row));
+      a.next[row] = kNoRow32;
+      distinct += old == kNoRow32 ? 1 : 0;
       continue;
     }
     // pushNext: the new row becomes the chain head.
@@ -2391,6 +2406,7 @@ struct vx355_join_build {
   bool finished = false;
   DevBuf keyNull;  // right / full joins: 1 byte per row, set for rows with a null key (nullAsValue: mask of null keys)
   bool nullAsValue = false;  // HashJoinNode::isNullAsValue
+  bool dropDuplicates = false;  // HashJoinNode::canDropDuplicates
   bool nullAware = false;    // HashJoinNode::isNullAware
   std::vector<int64_t> obsMin, obsMax;
   DevBuf countersBuf, scratch, validWords, rowList;
@@ -2408,6 +2424,7 @@ struct vx355_join_table {
   std::mutex lazyMutex;   // dynamic-filter state computed on first request
   int32_t mode = JMODE_ARRAY;
   int32_t joinType = 0;
+  bool droppedDuplicates = false;  // built with drop_duplicates: one linked row per key
   std::vector<int32_t> keyKinds, depKinds;
   std::vector<KeyRange> ranges;
   uint64_t capacity = 0;
@@ -2744,7 +2761,9 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
     t->keepsNullRows = true;
   }
   ia.nullAsValue = h.nullAsValue ? 1 : 0;
+  ia.dropDups = h.dropDuplicates ? 1 : 0;
   t->nullAsValue = h.nullAsValue;
+  t->droppedDuplicates = h.dropDuplicates;
   resetBuildCounters(h.countersBuf);
   ia.counters = h.countersBuf.as<BuildCounters>();
   t->next.ensure(static_cast<size_t>(std::max<int64_t>(1, h.numRows)) * 4 + 64);
@@ -3700,8 +3719,14 @@ int vx355_join_build_create(const vx355_join_build_spec* spec, vx355_join_build*
   if (spec->null_as_value && spec->null_aware) {
     VX_THROW(VX355_EINVAL, "nullAware and nullAsValue are mutually exclusive");  // core/PlanNode.h:3474
   }
+  if (spec->drop_duplicates && spec->join_type != VX355_JOIN_LEFT_SEMI_FILTER &&
+      spec->join_type != VX355_JOIN_LEFT_SEMI_PROJECT && spec->join_type != VX355_JOIN_ANTI) {
+    // HashJoinNode::canDropDuplicates (counting joins keep their counts: they always deduplicate)
+    VX_THROW(VX355_EINVAL, "drop_duplicates applies to left semi (filter / project) and anti joins without an extra filter");
+  }
   auto h = std::make_unique<vx355_join_build>();
   h->joinType = spec->join_type;
+  h->dropDuplicates = spec->drop_duplicates != 0;
   h->nullAsValue = spec->null_as_value != 0;
   h->nullAware = spec->null_aware != 0;
   for (int32_t k = 0; k < spec->num_keys; ++k) {
@@ -3955,6 +3980,10 @@ int vx355_join_probe_set_filter(vx355_join_probe* h, const vx355_join_filter_ter
   VX_CHECK_ARG(!h->hasInput, "set_filter after the first add_input");
   if (n_terms > 0 && countingJoin(h->joinType)) {
     VX_THROW(VX355_EUNSUPPORTED, "counting joins take no extra filter (exec/HashProbe.cpp:1345-1365)");
+  }
+  if (n_terms > 0 && h->table->droppedDuplicates) {
+    // a filter needs every build row of a key (the one that passes may be a duplicate)
+    VX_THROW(VX355_EINVAL, "the build side dropped duplicate keys (HashJoinNode::canDropDuplicates requires no filter)");
   }
   h->filter.assign(terms, terms + n_terms);
   h->usedCols = h->keyCols;

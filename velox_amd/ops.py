@@ -861,12 +861,12 @@ class HashBuild:
     """exec::HashBuild (exec/HashBuild.h): one per build Driver."""
 
     def __init__(self, key_cols, key_types, dep_cols=(), dep_types=(), join_type=abi.JOIN_INNER, null_aware=False,
-                 null_as_value=False):
+                 null_as_value=False, drop_duplicates=False):
         self._keep = [abi.i32_array(key_cols), abi.i32_array(key_types), abi.i32_array(dep_cols),
                       abi.i32_array(dep_types)]
         self.spec = abi.JoinBuildSpec(len(key_cols), self._keep[0], self._keep[1], len(dep_cols),
                                       self._keep[2], self._keep[3], join_type, 1 if null_aware else 0,
-                                      1 if null_as_value else 0, 0)
+                                      1 if null_as_value else 0, 1 if drop_duplicates else 0)
         self.dep_types = list(dep_types)
         h = C.c_void_p()
         _check(lib().vx355_join_build_create(C.byref(self.spec), C.byref(h)))
