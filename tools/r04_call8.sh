@@ -1,0 +1,16 @@
+#!/bin/bash
+# round 4, GPU call 8: optimistic level 1 (config 4), radix tests, dense + sparse lines
+mkdir -p gpurun_out/r04h
+cd "$GRAFT_REPO_ROOT"
+timeout 900 python -m pytest tests/test_gpu_agg.py tests/test_gpu_double_sums.py tests/test_gpu_bigint_sums.py -x -q -m gpu > gpurun_out/r04h/tests_agg.log 2>&1
+tail -4 gpurun_out/r04h/tests_agg.log
+timeout 900 python -m pytest tests/test_gpu_full_size.py tests/test_gpu_fuzz.py -x -q -m gpu -k "c4 or fuzz or plans" > gpurun_out/r04h/tests_full.log 2>&1
+tail -4 gpurun_out/r04h/tests_full.log
+for v in "" "--c4-sparse" "--c4-unordered"; do
+  timeout 600 python bench.py --workload c4 $v --steps 3 --warmup 1 --no-traffic --no-cpu-baseline > gpurun_out/r04h/bench_c4$v.json 2>/dev/null
+  python -c "
+import json,sys; d=json.loads(open('gpurun_out/r04h/bench_c4$v.json').read().strip().splitlines()[-1]); print('c4 $v', round(d['ms_per_step'],2), d['kernels_ms_per_step'])"
+done
+VX355_AGG_RADIX_OPTIMISTIC1=0 timeout 600 python bench.py --workload c4 --steps 3 --warmup 1 --no-traffic --no-cpu-baseline > gpurun_out/r04h/bench_c4_counted.json 2>/dev/null
+python -c "
+import json,sys; d=json.loads(open('gpurun_out/r04h/bench_c4_counted.json').read().strip().splitlines()[-1]); print('c4 counted level 1', round(d['ms_per_step'],2), d['kernels_ms_per_step'])"

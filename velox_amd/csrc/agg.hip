@@ -750,6 +750,14 @@ struct RadixArgs {
   uint32_t* hist;      // [bin][tile]
   const uint64_t* offsets;
   uint64_t* recs;      // output records of this pass
+  // Optimistic level 1 (no counting pass over the keys): bin b owns the region
+  // [binFirst[b], binFirst[b] + binCap) of 'recs' and a cursor; a sub-tile's run of records claims
+  // its place with one atomic. A bin that outgrows its region sets *binOverflow and the host redoes
+  // the level with the exact two-pass form.
+  const uint64_t* binFirst;
+  uint32_t* binCursor;
+  uint32_t* binOverflow;
+  uint64_t binCap;
 };
 static_assert(sizeof(RadixArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
@@ -1057,7 +1065,7 @@ __device__ inline void rpSortedEmit(SortLds<W>& l, int numBins, const uint64_t (
 
 // Level 1 with sorted sub-tiles (numBins <= kSortBins); same records as k_rp_scatter1.
 // HASHED: word 0 carries the home slot instead of the key, the last word the full key.
-template <int KW, int W, bool FLATV, bool HASHED>
+template <int KW, int W, bool FLATV, bool HASHED, bool OPT = false>
 __global__ __launch_bounds__(kSortThreads) void k_rp_scatter1_sorted(RadixArgs r) {
   __shared__ SortLds<W> l;
   constexpr int R = SortLds<W>::kRounds;
@@ -1068,8 +1076,10 @@ __global__ __launch_bounds__(kSortThreads) void k_rp_scatter1_sorted(RadixArgs r
     l.cnt[i] = 0;
   }
   for (int64_t tile = blockIdx.x; tile < r.numTiles; tile += gridDim.x) {
-    for (int i = threadIdx.x; i < r.numBins; i += kSortThreads) {
-      l.binBase[i] = r.offsets[static_cast<int64_t>(i) * r.numTiles + tile];
+    if constexpr (!OPT) {
+      for (int i = threadIdx.x; i < r.numBins; i += kSortThreads) {
+        l.binBase[i] = r.offsets[static_cast<int64_t>(i) * r.numTiles + tile];
+      }
     }
     blockSync();
     const int64_t begin = tile * r.tileRows;
@@ -1133,8 +1143,21 @@ __global__ __launch_bounds__(kSortThreads) void k_rp_scatter1_sorted(RadixArgs r
         bin[u] = static_cast<uint32_t>(part >> shift);
       }
       const uint64_t keyMask = (1ULL << r.keyBits) - 1;
-      rpSortedEmit<W, R>(l, r.numBins, vals, bin, r.recs,
-                         [&](uint64_t w0) { return static_cast<uint32_t>((w0 & keyMask) >> shift); });
+      if constexpr (OPT) {
+        rpSortedEmit<W, R>(
+            l, r.numBins, vals, bin, r.recs, [&](uint64_t w0) { return static_cast<uint32_t>((w0 & keyMask) >> shift); },
+            [&](uint32_t b, uint32_t count) -> unsigned long long {
+              const uint32_t at = atomicAdd(&r.binCursor[b], count);
+              if (static_cast<uint64_t>(at) + count > r.binCap) {
+                *r.binOverflow = 1;
+                return ~0ULL;
+              }
+              return r.binFirst[b] + at;
+            });
+      } else {
+        rpSortedEmit<W, R>(l, r.numBins, vals, bin, r.recs,
+                           [&](uint64_t w0) { return static_cast<uint32_t>((w0 & keyMask) >> shift); });
+      }
     }
   }
 }
@@ -1150,14 +1173,28 @@ struct RadixTile {
 
 // Builds the level-2 tile table and the partition -> histogram cell map from
 // the level-1 offsets, on device (no host round trip between the levels).
-__global__ __launch_bounds__(1024) void k_rp_tiles(const uint64_t* offsets1, int64_t numTiles1, int32_t numBins1,
+// Where level 1 put bin b: counted offsets, or (optimistic level 1) the bin's region and cursor.
+struct Level1Bins {
+  const uint64_t* offsets1;
+  int64_t numTiles1;
+  const uint64_t* binFirst;   // non-null: optimistic level 1
+  const uint32_t* binCursor;
+  __device__ uint64_t first(int b) const {
+    return binFirst ? binFirst[b] : offsets1[static_cast<int64_t>(b) * numTiles1];
+  }
+  __device__ uint64_t count(int b) const {
+    return binFirst ? binCursor[b]
+                    : offsets1[static_cast<int64_t>(b + 1) * numTiles1] - offsets1[static_cast<int64_t>(b) * numTiles1];
+  }
+};
+
+__global__ __launch_bounds__(1024) void k_rp_tiles(Level1Bins l1, int32_t numBins1,
                                                     int32_t numBins2, int32_t shift2, uint32_t tileRecs,
                                                     RadixTile* tiles, uint32_t* numTiles2, uint32_t* partCell,
                                                     int64_t numParts) {
   __shared__ uint32_t tileStart[kRadixMaxBins + 1];
   for (int b = threadIdx.x; b < numBins1; b += blockDim.x) {
-    const uint64_t count =
-        offsets1[static_cast<int64_t>(b + 1) * numTiles1] - offsets1[static_cast<int64_t>(b) * numTiles1];
+    const uint64_t count = l1.count(b);
     tileStart[b] = static_cast<uint32_t>((count + tileRecs - 1) / tileRecs);
   }
   blockSync();
@@ -1173,8 +1210,8 @@ __global__ __launch_bounds__(1024) void k_rp_tiles(const uint64_t* offsets1, int
   }
   blockSync();
   for (int b = threadIdx.x; b < numBins1; b += blockDim.x) {
-    const uint64_t first = offsets1[static_cast<int64_t>(b) * numTiles1];
-    const uint64_t count = offsets1[static_cast<int64_t>(b + 1) * numTiles1] - first;
+    const uint64_t first = l1.first(b);
+    const uint64_t count = l1.count(b);
     const uint32_t n = tileStart[b + 1] - tileStart[b];
     for (uint32_t j = 0; j < n; ++j) {
       RadixTile t;
@@ -1333,7 +1370,7 @@ struct Radix2OptArgs {
 // Every partition's region holds 1.5 x the even share of the FULLEST bucket + 256 records — a
 // bucket at the edge of the live key range has few live partitions, each as full as those of a
 // full bucket — but never more than its bucket holds.
-__global__ __launch_bounds__(1024) void k_rp_layout2(const uint64_t* offsets1, int64_t numTiles1, int32_t numBins1,
+__global__ __launch_bounds__(1024) void k_rp_layout2(Level1Bins l1, int32_t numBins1,
                                                       int32_t shift2, int64_t numParts, uint64_t* partBase,
                                                       uint32_t* bucketCap, uint64_t* totalOut) {
   __shared__ unsigned long long bucketBase[kRadixMaxBins + 1];
@@ -1344,15 +1381,14 @@ __global__ __launch_bounds__(1024) void k_rp_layout2(const uint64_t* offsets1, i
   }
   blockSync();
   for (int b = threadIdx.x; b < numBins1; b += blockDim.x) {
-    const unsigned long long count =
-        offsets1[static_cast<int64_t>(b + 1) * numTiles1] - offsets1[static_cast<int64_t>(b) * numTiles1];
+    const unsigned long long count = l1.count(b);
     atomicMax(&maxCount, count);
   }
   blockSync();
   const uint64_t share = (maxCount + bins2 - 1) / bins2;
   const uint64_t cap = share + share / 2 + 256;
   for (int b = threadIdx.x; b < numBins1; b += blockDim.x) {
-    const uint64_t count = offsets1[static_cast<int64_t>(b + 1) * numTiles1] - offsets1[static_cast<int64_t>(b) * numTiles1];
+    const uint64_t count = l1.count(b);
     bucketCap[b] = static_cast<uint32_t>(count < cap ? count : cap);
   }
   blockSync();
@@ -3536,8 +3572,9 @@ struct vx355_agg {
   int scratchBlocksPerCu = 2;  // VX355_AGG_SCRATCH_BLOCKS_PER_CU: workgroups (= copies) per CU of a scratch-flush launch
   int64_t scratchMinAtomics = 256 << 10;  // VX355_AGG_SCRATCH_MIN_ATOMICS: flushes below this many HBM atomics keep them
   // radix-partitioned path (high cardinality)
-  DevBuf rpRecs1, rpRecs2, rpHist, rpOffsets, rpTiles, rpMisc, rpScan, rpLayout2;
+  DevBuf rpRecs1, rpRecs2, rpHist, rpOffsets, rpTiles, rpMisc, rpScan, rpLayout2, rpLayout1;
   bool radixOptimistic = true;  // VX355_AGG_RADIX_OPTIMISTIC=0: level 2 always counts first
+  bool radixOptimistic1 = true;  // VX355_AGG_RADIX_OPTIMISTIC1=0: level 1 always counts first (k_rp_count1)
   int64_t radixRedone = 0;      // level-2 passes redone exactly after a region overflowed
   int64_t radixMinRows = 4 << 20;
   int32_t radixMaxBins = kRadixMaxBins;  // widest single-level fan-out
@@ -4988,17 +5025,90 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
           acc.in.kind == (wantInt ? VX355_BIGINT : VX355_DOUBLE);
     }
   }
-  if (kw == 8) {
-    VX_LAUNCH("k_rp_count1", k_rp_count1<8>, grid1, 1024, 0, r);
-  } else if (kw == 4) {
-    VX_LAUNCH("k_rp_count1", k_rp_count1<4>, grid1, 1024, 0, r);
-  } else {
-    VX_LAUNCH("k_rp_count1", k_rp_count1<0>, grid1, 1024, 0, r);
-  }
-  scanU32ToU64(r.hist, cells1, offsets1, h.rpScan);
   const bool sorted1 = h.radixSorted && r.numBins <= kSortBins;
+  // Optimistic level 1 (two-level launches over a flat integer key or over hashed home slots): no
+  // pass over the keys to count the bins - every bin that can be hit (the observed key range; all
+  // of them for home slots) owns a region of 1.25 x the even share + 4096 records and a cursor. A bin
+  // that outgrows its region (keys bunched inside the range) sends the level back to counting.
+  bool opt1 = h.radixOptimistic1 && h.radixOptimistic && sorted1 && r.shift2 != 0 && (hashed || kw != 0) && flatV;
+  int64_t firstLive = 0, liveBins = r.numBins;
+  if (opt1 && !hashed) {
+    const auto& ks = h.keys[0];
+    const int shift = r.shiftB + r.shift2;
+    const uint64_t idMin = static_cast<uint64_t>(ks.obsMin) - static_cast<uint64_t>(ks.range.min) + 1;
+    const uint64_t idMax = static_cast<uint64_t>(ks.obsMax) - static_cast<uint64_t>(ks.range.min) + 1;
+    firstLive = static_cast<int64_t>(idMin >> shift);
+    liveBins = static_cast<int64_t>(idMax >> shift) - firstLive + 1;
+    opt1 = ks.hasObserved && liveBins >= 1 && firstLive + liveBins <= r.numBins;
+  }
+  uint32_t* binCursor = nullptr;
+  uint64_t* binFirst = nullptr;
+  auto exactLevel1 = [&]() {
+    if (kw == 8) {
+      VX_LAUNCH("k_rp_count1", k_rp_count1<8>, grid1, 1024, 0, r);
+    } else if (kw == 4) {
+      VX_LAUNCH("k_rp_count1", k_rp_count1<4>, grid1, 1024, 0, r);
+    } else {
+      VX_LAUNCH("k_rp_count1", k_rp_count1<0>, grid1, 1024, 0, r);
+    }
+    scanU32ToU64(r.hist, cells1, offsets1, h.rpScan);
+  };
+  if (opt1) {
+    r.binCap = static_cast<uint64_t>(n / liveBins + n / liveBins / 4 + 4096);
+    // (the cursors are 32-bit: a region never holds more than that)
+    opt1 = r.binCap < (1ULL << 32);
+  }
+  if (opt1) {
+    h.rpRecs1.ensure((static_cast<size_t>(liveBins) * r.binCap + 64) * r.recWords * 8 + 64);
+    r.recs = h.rpRecs1.as<uint64_t>();
+    char* lay = static_cast<char*>(h.rpLayout1.ensure(static_cast<size_t>(r.numBins) * 12 + 64 + 64));
+    binFirst = reinterpret_cast<uint64_t*>(lay);
+    binCursor = reinterpret_cast<uint32_t*>(lay + static_cast<size_t>(r.numBins) * 8);
+    std::vector<uint64_t> first(static_cast<size_t>(r.numBins), 0);
+    for (int64_t b = 0; b < r.numBins; ++b) {
+      const int64_t live = std::min<int64_t>(std::max<int64_t>(b - firstLive, 0), liveBins - 1);
+      first[static_cast<size_t>(b)] = static_cast<uint64_t>(live) * r.binCap;  // (bins outside the range are never hit)
+    }
+    // cursors: 0 for the bins of the observed key range; a bin outside it (a key inside the PADDED
+    // range, VectorHasher's 50 % reserve, that the statistics pass did not see) has no region: its
+    // cursor starts beyond every capacity, so the first record sends the level back to counting
+    std::vector<uint32_t> cursors(static_cast<size_t>(r.numBins) + 16, 0);
+    for (int64_t b = 0; b < r.numBins; ++b) {
+      if (b < firstLive || b >= firstLive + liveBins) {
+        cursors[static_cast<size_t>(b)] = 0xffffff00u;
+      }
+    }
+    rt.sync();  // (the previous launch's staging of these small tables must be over)
+    copyIn(binFirst, first.data(), VX355_MEM_HOST, first.size() * 8);
+    copyIn(binCursor, cursors.data(), VX355_MEM_HOST, cursors.size() * 4);
+    rt.sync();
+    r.binFirst = binFirst;
+    r.binCursor = binCursor;
+    r.binOverflow = binCursor + r.numBins;
+  } else {
+    exactLevel1();
+  }
   auto scatter1 = [&](auto wTag) {
     constexpr int W = decltype(wTag)::value;
+    if (sorted1 && opt1) {
+      const int grid = static_cast<int>(std::min<int64_t>(r.numTiles, rt.numCUs * 2));
+      if constexpr (W >= 2) {
+        if (hashed) {
+          if (kw == 8) {
+            VX_LAUNCH("k_rp_scatter1", (k_rp_scatter1_sorted<8, W, true, true, true>), grid, kSortThreads, 0, r);
+          } else {
+            VX_LAUNCH("k_rp_scatter1", (k_rp_scatter1_sorted<0, W, false, true, true>), grid, kSortThreads, 0, r);
+          }
+          return;
+        }
+      }
+      if (kw == 8) {
+        VX_LAUNCH("k_rp_scatter1", (k_rp_scatter1_sorted<8, W, true, false, true>), grid, kSortThreads, 0, r);
+      } else {
+        VX_LAUNCH("k_rp_scatter1", (k_rp_scatter1_sorted<4, W, true, false, true>), grid, kSortThreads, 0, r);
+      }
+      return;
+    }
     if (sorted1) {
       const int grid = static_cast<int>(std::min<int64_t>(r.numTiles, rt.numCUs * 2));
       if constexpr (W >= 2) {
@@ -5045,6 +5155,24 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
     }
   };
   byWidth(scatter1);
+  if (opt1) {
+    uint32_t full = 0;
+    copyOut(&full, VX355_MEM_HOST, r.binOverflow, 4);
+    if (full != 0) {
+      // keys bunched inside the observed range: count, then scatter to exact offsets; this operator
+      // counts from now on
+      ++h.radixRedone;
+      h.radixOptimistic1 = false;
+      opt1 = false;
+      r.binFirst = nullptr;
+      r.binCursor = nullptr;
+      h.rpRecs1.ensure(recBytes);
+      r.recs = h.rpRecs1.as<uint64_t>();
+      exactLevel1();
+      byWidth(scatter1);
+    }
+  }
+  const Level1Bins level1{offsets1, r.numTiles, opt1 ? binFirst : nullptr, opt1 ? binCursor : nullptr};
 
   RadixAggArgs g{};
   g.recs = h.rpRecs1.as<uint64_t>();
@@ -5056,7 +5184,7 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
     h.rpMisc.ensure(64 + static_cast<size_t>(parts + 1) * 4 + 64);
     uint32_t* numTiles2 = h.rpMisc.as<uint32_t>();
     uint32_t* partCell = numTiles2 + 16;
-    VX_LAUNCH("k_rp_tiles", k_rp_tiles, 1, 1024, 0, offsets1, r.numTiles, r.numBins, bins2, r.shift2, tileRecs,
+    VX_LAUNCH("k_rp_tiles", k_rp_tiles, 1, 1024, 0, level1, r.numBins, bins2, r.shift2, tileRecs,
               h.rpTiles.as<RadixTile>(), numTiles2, partCell, static_cast<int64_t>(parts));
     Radix2Args r2{};
     r2.in = h.rpRecs1.as<uint64_t>();
@@ -5080,7 +5208,7 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
       uint32_t* partCount = bucketCap + r.numBins;
       uint32_t* overflow = partCount + partsPadded;   // [0] flag, [2..3] total records of the layout
       HIP_OK(hipMemsetAsync(partCount, 0, (partsPadded + 16) * 4, rt.stream));
-      VX_LAUNCH("k_rp_layout2", k_rp_layout2, 1, 1024, 0, offsets1, r.numTiles, r.numBins, r.shift2,
+      VX_LAUNCH("k_rp_layout2", k_rp_layout2, 1, 1024, 0, level1, r.numBins, r.shift2,
                 static_cast<int64_t>(partsPadded), partBase, bucketCap, reinterpret_cast<uint64_t*>(overflow + 2));
       uint64_t layoutRecs = 0;
       copyOut(&layoutRecs, VX355_MEM_HOST, overflow + 2, 8);
@@ -6652,6 +6780,9 @@ void configureFromEnv(vx355_agg& h) {
   }
   if (const char* e = std::getenv("VX355_AGG_RADIX_OPTIMISTIC")) {
     h.radixOptimistic = std::atoi(e) != 0;
+  }
+  if (const char* e = std::getenv("VX355_AGG_RADIX_OPTIMISTIC1")) {
+    h.radixOptimistic1 = std::atoi(e) != 0;
   }
   if (const char* e = std::getenv("VX355_AGG_RADIX_SORTED")) {
     h.radixSorted = std::atoi(e) != 0;
