@@ -1173,6 +1173,8 @@ struct RadixTile {
 
 // Builds the level-2 tile table and the partition -> histogram cell map from
 // the level-1 offsets, on device (no host round trip between the levels).
+constexpr uint32_t kDeadBinCursor = 0xffffff00u;
+
 // Where level 1 put bin b: counted offsets, or (optimistic level 1) the bin's region and cursor.
 struct Level1Bins {
   const uint64_t* offsets1;
@@ -1183,8 +1185,13 @@ struct Level1Bins {
     return binFirst ? binFirst[b] : offsets1[static_cast<int64_t>(b) * numTiles1];
   }
   __device__ uint64_t count(int b) const {
-    return binFirst ? binCursor[b]
-                    : offsets1[static_cast<int64_t>(b + 1) * numTiles1] - offsets1[static_cast<int64_t>(b) * numTiles1];
+    if (binFirst) {
+      // (a bin outside the observed key range has no region: its cursor starts at kDeadBinCursor
+      // and is never advanced without raising the overflow flag)
+      const uint32_t c = binCursor[b];
+      return c >= kDeadBinCursor ? 0 : c;
+    }
+    return offsets1[static_cast<int64_t>(b + 1) * numTiles1] - offsets1[static_cast<int64_t>(b) * numTiles1];
   }
 };
 
@@ -4988,11 +4995,10 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
   }
   const int64_t maxTiles2 = ceilDiv(n, tileRecs) + r.numBins;
   const int64_t cells2 = r.shift2 ? static_cast<int64_t>(bins2) * maxTiles2 : 0;
+  // (the record buffers are sized where the layout of each level is known: an optimistic level
+  // takes regions of 1.25 - 1.5 x the records, and growing a 24 GB buffer to 30 GB on every
+  // operator would cycle 54 GB through the block cache per level)
   const size_t recBytes = static_cast<size_t>(n) * r.recWords * 8 + 64;
-  h.rpRecs1.ensure(recBytes);
-  if (r.shift2) {
-    h.rpRecs2.ensure(recBytes);
-  }
   h.rpHist.ensure(static_cast<size_t>(std::max(cells1, cells2)) * 4 + 64);
   // offsets: level 1 [cells1 + 1], level 2 [cells2 + 1]
   h.rpOffsets.ensure(static_cast<size_t>(cells1 + 1 + cells2 + 1) * 8 + 64);
@@ -5000,7 +5006,6 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
   uint64_t* offsets2 = offsets1 + cells1 + 1;
   r.hist = h.rpHist.as<uint32_t>();
   r.offsets = offsets1;
-  r.recs = h.rpRecs1.as<uint64_t>();
   const int grid1 = static_cast<int>(std::min<int64_t>(r.numTiles, rt.numCUs * 2));
   // Shape of pass 1: flat single integer key? flat 8-byte operands?
   int kw = 0;
@@ -5044,6 +5049,8 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
   uint32_t* binCursor = nullptr;
   uint64_t* binFirst = nullptr;
   auto exactLevel1 = [&]() {
+    h.rpRecs1.ensure(recBytes);
+    r.recs = h.rpRecs1.as<uint64_t>();
     if (kw == 8) {
       VX_LAUNCH("k_rp_count1", k_rp_count1<8>, grid1, 1024, 0, r);
     } else if (kw == 4) {
@@ -5075,7 +5082,7 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
     std::vector<uint32_t> cursors(static_cast<size_t>(r.numBins) + 16, 0);
     for (int64_t b = 0; b < r.numBins; ++b) {
       if (b < firstLive || b >= firstLive + liveBins) {
-        cursors[static_cast<size_t>(b)] = 0xffffff00u;
+        cursors[static_cast<size_t>(b)] = kDeadBinCursor;
       }
     }
     rt.sync();  // (the previous launch's staging of these small tables must be over)
@@ -5166,8 +5173,6 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
       opt1 = false;
       r.binFirst = nullptr;
       r.binCursor = nullptr;
-      h.rpRecs1.ensure(recBytes);
-      r.recs = h.rpRecs1.as<uint64_t>();
       exactLevel1();
       byWidth(scatter1);
     }
@@ -5242,6 +5247,8 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
       }
     }
     if (exact) {
+      h.rpRecs2.ensure(recBytes);
+      r2.out = h.rpRecs2.as<uint64_t>();
       HIP_OK(hipMemsetAsync(r2.hist, 0, static_cast<size_t>(cells2) * 4, rt.stream));
       VX_LAUNCH("k_rp_count2", k_rp_count2, grid2, 1024, 0, r2);
       scanU32ToU64(r2.hist, cells2, offsets2, h.rpScan);
