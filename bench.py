@@ -133,7 +133,8 @@ def library_comm(args, torch, dist, rank, world, dev_index, share):
         if int(flag.item()) == 0:
             return None, "; ".join(x for x in reasons if x) or "commcheck failed"
     # (one rank: no RCCL at all, not even the id - see vx355_comm_create)
-    uid = [(ops.Comm.unique_id() if world > 1 else bytes(128)) if rank == 0 else None]
+    forced = os.environ.get("VX355_COMM_FORCE_RCCL", "0") not in ("", "0")   # one rank, but through RCCL all the same
+    uid = [(ops.Comm.unique_id() if (world > 1 or forced) else bytes(128)) if rank == 0 else None]
     if world > 1:
         dist.broadcast_object_list(uid, src=0)
     comm = ops.Comm(uid[0], world, rank)
@@ -1286,13 +1287,19 @@ def main():
         for _ in range(warmup):
             step_fn()
         barrier()
-        ops.profile_reset()
-        ops.profile_enable(True)
+        # EXACTLY 'steps' timed steps between two barriers, without the profiler's events (two per
+        # launch: a third of config 1's step); the kernel times come from the same number of steps
+        # repeated with the events on, outside the timed region
         t0 = time.perf_counter()
         for _ in range(steps):
             step_fn()
         barrier()
         dt = time.perf_counter() - t0
+        ops.profile_reset()
+        ops.profile_enable(True)
+        for _ in range(steps):
+            step_fn()
+        barrier()
         ops.profile_enable(False)
         prof_ = ops.profile()
         if world > 1:
@@ -1368,6 +1375,9 @@ def main():
                                    " over RCCL") if world > 1 else "1 GPU",
                    "exchange": exchange_note},
         "workload_info": wl.info() if hasattr(wl, "info") else {},
+        # N > 1: True = the in-library RCCL exchange was NOT used (its self-check failed or --exchange torch):
+        # the scaling numbers of such a line measure torch.distributed's collectives, not the library's
+        "exchange_downgraded": bool(world > 1 and comm is None),
         "result_check": result_check,
         "pipeline_algorithmic_GBps": wl.bytes_per_row * rows / elapsed / 1e9 / world,
         "roofline": roofline_block(wl, prof, args.steps, copy_ceiling, child_flags if measure else None),

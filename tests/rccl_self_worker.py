@@ -20,6 +20,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ["VX355_COMM_FORCE_RCCL"] = "1"
+if "--with-torch" in sys.argv:
+    # the arrangement of bench.py: torch first, so that libvx355 runs on torch's bundled HIP runtime and
+    # loads the librccl that ships with it (a different RCCL build than /opt/rocm's)
+    sys.argv.remove("--with-torch")
+    import torch  # noqa: F401
 
 from velox_amd import abi, ops as vx  # noqa: E402
 from gpu_util import batch_of  # noqa: E402

@@ -210,15 +210,18 @@ def test_bench_c5_through_the_library_exchange():
     assert line["workload_info"]["matches_on_rank0"] == 2000000   # every fact row finds its dim row
 
 
-def test_rccl_entry_points_run_on_one_gpu():
+@pytest.mark.parametrize("with_torch", [False, True])
+def test_rccl_entry_points_run_on_one_gpu(with_torch):
     """VX355_COMM_FORCE_RCCL=1 (tests/rccl_self_worker.py, own process): ncclCommInitRank, the counts
     all-gather, grouped ncclSend / ncclRecv to self with a 320 MiB column cut at 256 MiB, both
     all-gather forms and the exchange edge's payload stream really execute; every payload comes
-    back intact. The N > 1 code path no longer meets RCCL for the first time on the 8-GPU node."""
+    back intact. The N > 1 code path no longer meets RCCL for the first time on the 8-GPU node.
+    with_torch: torch is imported first, as in bench.py - the library then runs on torch's bundled
+    HIP runtime and the RCCL next to it (another build than /opt/rocm's)."""
     env = dict(os.environ)
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_self_worker.py")], capture_output=True,
-                       text=True, timeout=600, env=env)
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "rccl_self_worker.py")] + (["--with-torch"] if with_torch else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     checks = json.loads([line for line in r.stdout.splitlines() if line.startswith("{")][-1])
     assert checks.pop("comm_info") == [1, 0, 0]

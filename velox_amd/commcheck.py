@@ -22,6 +22,12 @@ import numpy as np
 
 def main(argv):
     rank, world, device, id_file = int(argv[0]), int(argv[1]), int(argv[2]), argv[3]
+    # bench.py has torch loaded before libvx355: the library then runs on torch's bundled HIP runtime
+    # and loads the librccl next to it. The check must exercise THAT pair, not /opt/rocm's.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     from velox_amd import ops
     ops.init(device)
     if rank == 0:
