@@ -566,11 +566,16 @@ class C4(C1):
     PASS_BYTES = {"k_rp_count1": 8, "k_rp_scatter1": 16 + 16, "k_rp_count2": 16, "k_rp_scatter2": 16 + 16,
                   "k_rp_aggregate": 16, "k_agg_global": 40}
 
+    # sparse keys (open-addressing table): records carry the full key as a third word
+    PASS_BYTES_SPARSE = {"k_rp_count1": 8, "k_rp_scatter1": 16 + 24, "k_rp_count2": 24, "k_rp_scatter2": 24 + 24,
+                         "k_rp_aggregate": 24, "k_agg_global": 40}
+
     def pick_dominant(self, prof):
         """The slowest pass is the roofline kernel of this workload."""
-        name = max(self.PASS_BYTES, key=lambda k: prof.get(k, (0.0, 0))[0])
+        table = self.PASS_BYTES_SPARSE if getattr(self, "sparse", False) else self.PASS_BYTES
+        name = max(table, key=lambda k: prof.get(k, (0.0, 0))[0])
         self.dominant = name
-        self.agg_bytes_per_row = self.PASS_BYTES[name]
+        self.agg_bytes_per_row = table[name]
 
     def __init__(self, torch, n, device, seed):
         g = torch.Generator(device=device)
@@ -1591,9 +1596,10 @@ def secondary_block(torch, device, args, copy_ceiling, measure, workload, attrs,
                                 "GBps_at_24B_per_probe": wl.rows_per_step() * 24 / (ms * 1e-3) / 1e9}
     if workload == "c4":
         # every pass of the radix path next to the bytes it has to move (the step's roofline kernel is the slowest)
-        block["passes"] = {k: {"ms_per_step": round(prof[k][0] / steps, 4),
-                               "algorithmic_GBps": wl.PASS_BYTES[k] * wl.rows_per_step() * steps / (prof[k][0] * 1e-3) / 1e9}
-                           for k in wl.PASS_BYTES if prof.get(k, (0, 0))[0] > 0}
+        table = wl.PASS_BYTES_SPARSE if getattr(wl, "sparse", False) else wl.PASS_BYTES
+        block["passes"] = {k: {"ms_per_step": round(prof[k][0] / steps, 4), "algorithmic_bytes_per_row": table[k],
+                               "algorithmic_GBps": table[k] * wl.rows_per_step() * steps / (prof[k][0] * 1e-3) / 1e9}
+                           for k in table if prof.get(k, (0, 0))[0] > 0}
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib

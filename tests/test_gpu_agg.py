@@ -886,10 +886,62 @@ def test_dense_folds_into_an_operator_without_groups(oracle, vx, shape, monkeypa
         prof = vx.profile()
         assert st.hash_mode == abi.MODE_NORMALIZED_KEY and "k_rp_aggregate" in prof
         if shape in ("one_batch", "refold"):
-            assert st.capacity == st.num_groups, (st.capacity, st.num_groups)   # the array of rows is the table
+            # the array of rows is the table: the groups plus the rows of the workgroups' blocks that no
+            # group took (a block is at least 256 rows, a launch has at most 4 workgroups per CU)
+            assert st.num_groups <= st.capacity <= st.num_groups + 256 * 4 * 256 + 4096, (st.capacity, st.num_groups)
             assert prof["k_rp_aggregate"][1] == (2 if shape == "refold" else 1)
         if shape == "hot_keys":
             assert "k_dense_merge" in prof
+
+
+@pytest.mark.parametrize("shape", ["sampled_slots", "small_table_overflows", "more_batches", "unordered"])
+def test_hashed_folds_size_their_lds_table_from_a_sample_of_the_keys(oracle, vx, shape, monkeypatch):
+    """Two scatter levels (> 1 M rows): k_rp_distinct_sample counts the distinct keys of 64 partitions and
+    the launch sizes the folds' LDS tables from that (512 entries for ~30 rows per key); a table forced
+    too small for the keys of its partitions (VX355_AGG_HASH_SLOTS=512 with ~700 distinct keys per
+    partition: nearly every row has a key of its own) sends the overflowing records straight to rows of their own, merged afterwards
+    (k_dense_merge); a second batch goes through the folds that look their groups up in the table; the
+    dense array of rows has holes (a workgroup takes rows in blocks), which neither the first-seen sort
+    nor the unordered listing may show."""
+    monkeypatch.setenv("VX355_AGG_RADIX_MIN_ROWS", "1")
+    monkeypatch.setenv("VX355_AGG_DENSE_MIN_ROWS", "1")
+    monkeypatch.setenv("VX355_AGG_COALESCE_ROWS", "0")
+    rng = np.random.default_rng(20260923)
+    n = 3_000_000
+    distinct = 50_000_000 if shape == "small_table_overflows" else 100_000
+    if shape == "small_table_overflows":
+        monkeypatch.setenv("VX355_AGG_HASH_SLOTS", "512")
+    batches = []
+    for b in range(2 if shape == "more_batches" else 1):
+        j = rng.integers(0, distinct * (b + 1), n).astype(np.uint64)
+        k = ((j * np.uint64(0x9E3779B97F4A7C15)) ^ np.uint64(0x5DEECE66D)).astype(np.int64)
+        batches.append(batch_of([k, _dyadic(rng, n), rng.integers(-1 << 40, 1 << 40, n).astype(np.int64)]))
+    aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT), (abi.AGG_MIN, 2, abi.BIGINT)]
+    exp, _ = run_agg(oracle, batches, [0], [abi.BIGINT], aggs, max_rows=1 << 20)
+    vx.profile_reset()
+    vx.profile_enable(True)
+    if shape == "unordered":
+        op = vx.Aggregation([0], [abi.BIGINT], aggs, abi.STEP_SINGLE, flags=abi.AGG_UNORDERED_OUTPUT)
+        for b in batches:
+            op.add_input(b)
+        op.no_more_input()
+        got = vx.collect_output(op, 1 << 20)
+        go, eo = np.argsort(got[0][0], kind="stable"), np.argsort(exp[0][0], kind="stable")
+        assert len(got[0][0]) == len(exp[0][0])
+        for c in range(4):
+            assert (np.asarray(got[c][0])[go] == np.asarray(exp[c][0])[eo]).all()
+        gop = op
+    else:
+        got, gop = run_agg(vx, batches, [0], [abi.BIGINT], aggs, max_rows=1 << 20)
+        assert_columns_equal(got, exp, gop.kinds, what="hashed folds %s" % shape)
+    vx.profile_enable(False)
+    prof = vx.profile()
+    st = gop.stats()
+    assert st.hash_mode == abi.MODE_NORMALIZED_KEY and "k_rp_aggregate" in prof
+    if shape == "small_table_overflows":
+        assert "k_dense_merge" in prof and "k_rp_distinct_sample" not in prof
+    else:
+        assert "k_rp_distinct_sample" in prof
 
 
 def test_radix_path_two_keys_fused_filter(oracle, vx, monkeypatch):

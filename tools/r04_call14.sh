@@ -1,0 +1,21 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r04n
+mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_agg.py -x -q -m gpu -k "radix or dense_folds or sorted or optimistic" 2>&1 | tail -5
+b() { name=$1; shift; timeout 600 python bench.py "$@" --steps 3 --warmup 1 --no-traffic --no-cpu-baseline --no-secondary 2> $O/$name.err | grep '^{"metric"' > $O/$name.json
+python - <<PY
+import json
+try:
+    d = json.load(open("$O/$name.json"))
+    print("$name", round(d["ms_per_step"], 3), {k: v for k, v in d["kernels_ms_per_step"].items() if v > 0.02}, d.get("result_check"))
+except Exception as e:
+    print("$name FAILED", e)
+PY
+}
+VX355_AGG_RADIX_PAIRS=0 b c4_nopairs --workload c4
+b c4_pairs --workload c4
+b c4s_auto --workload c4 --c4-sparse
+VX355_AGG_HASH_SLOTS=2048 b c4s_2048 --workload c4 --c4-sparse
+VX355_AGG_HASH_SLOTS=1024 b c4s_1024 --workload c4 --c4-sparse
+tail -3 $O/*.err | head -40

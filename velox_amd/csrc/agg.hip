@@ -1509,12 +1509,89 @@ struct RadixAggArgs {
   // flush - instead of an open-addressing table; rows beyond denseCap are counted, not written;
   // denseFlags[0] = 1 when some key may own more than one row (split partitions, LDS overflow).
   int32_t dense;
+  int32_t hashSlots;   // entries of the LDS table of a hashed fold: a power of two, 512 .. kHashSlots
   uint64_t denseCap;
+  // [0] = 1 when some key may own more than one row; [1] = rows handed out: a workgroup takes rows
+  // in blocks of denseChunk (one atomic on this word per block, not per partition - a fold would
+  // wait ~3 us for each) and leaves what it does not use of a block EMPTY (the pattern of an empty
+  // group row, a pair that sorts behind every group): the array has holes, counters->numNewGroups
+  // counts the groups
   uint32_t* denseFlags;
+  uint32_t denseChunk;
+  uint32_t pad2;
 };
+
+// The accumulator plan of a fold, in registers: read from the kernel arguments ONCE with constant
+// indices. (Indexing r.kind[j] / r.ldsIdx[j] with a run-time j made every record of every lane wait
+// for three scalar loads from the argument buffer: the folds were bound by that, not by HBM.)
+struct FoldPlan {
+  int32_t numAccs;
+  int32_t keyBits;
+  int32_t rowBits;
+  uint32_t rowMask;
+  int32_t kind[kRadixMaxAccs];
+  int32_t valIdx[kRadixMaxAccs];   // record word 1 + valIdx is the operand; < 0: the accumulator counts rows
+  int32_t ldsIdx[kRadixMaxAccs];   // first LDS word of the accumulator
+  double splitM[kRadixMaxAccs];
+};
+
+__device__ inline FoldPlan foldPlan(const RadixAggArgs& r) {
+  FoldPlan fp;
+  fp.numAccs = r.numAccs;
+  fp.keyBits = r.keyBits;
+  fp.rowBits = r.rowBits;
+  fp.rowMask = static_cast<uint32_t>((1ULL << r.rowBits) - 1);
+#pragma unroll
+  for (int j = 0; j < kRadixMaxAccs; ++j) {
+    fp.kind[j] = r.kind[j];
+    fp.valIdx[j] = r.valIdx[j];
+    fp.ldsIdx[j] = r.ldsIdx[j];
+    fp.splitM[j] = r.splitM[j];
+  }
+  return fp;
+}
+
+// Word 'idx' (1 .. W - 1) of a record held in registers: a chain of selects, because a register
+// array indexed with a run-time value is moved to scratch memory.
+template <int W>
+__device__ inline uint64_t recordWord(const uint64_t (&w)[W], int idx) {
+  uint64_t v = 0;
+#pragma unroll
+  for (int q = 1; q < W; ++q) {
+    v = q == idx ? w[q] : v;
+  }
+  return v;
+}
+
+// The operands of one record into the LDS accumulator words of its group ('acc' = the group's first word).
+template <int W>
+__device__ inline void foldAccumulate(const FoldPlan& fp, uint64_t* acc, const uint64_t (&w)[W], uint32_t mask,
+                                      Counters* counters) {
+#pragma unroll
+  for (int j = 0; j < kRadixMaxAccs; ++j) {
+    if (j >= fp.numAccs || !((mask >> j) & 1)) {
+      continue;
+    }
+    uint64_t* word = acc + fp.ldsIdx[j];
+    if (fp.valIdx[j] < 0) {
+      applyLds(word, fp.kind[j], 1ULL, counters);
+      continue;
+    }
+    const uint64_t v = recordWord<W>(w, 1 + fp.valIdx[j]);
+    if (fp.kind[j] == ACC_SUM_F64 && fp.splitM[j] != 0.0) {
+      double hi, lo;
+      splitDouble(__longlong_as_double(static_cast<long long>(v)), fp.splitM[j], &hi, &lo);
+      applyLds(word, ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(hi)), counters);
+      applyLds(word + 1, ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(lo)), counters);
+    } else {
+      applyLds(word, fp.kind[j], v, counters);
+    }
+  }
+}
 
 // LDS state of one fold: acc[B][A] + first[B], A = LDS words per group.
 struct RpFold {
+  FoldPlan plan;
   uint64_t* acc;
   uint32_t* first;
   uint32_t* scratch;   // [0] groups created by this flush, [1] their base in the launch's pair list
@@ -1532,10 +1609,23 @@ __device__ inline void rpFoldInit(const RpFold& f, const RadixAggArgs& r) {
   blockSync();
 }
 
+// One record applied to the LDS accumulators of its group.
+template <int W>
+__device__ inline void rpFoldRecord(const RpFold& f, const RadixAggArgs& r, const uint64_t (&w)[W]) {
+  const FoldPlan& fp = f.plan;
+  const uint64_t w0 = w[0];
+  const uint32_t g = static_cast<uint32_t>(w0) & static_cast<uint32_t>(f.B - 1);
+  const uint32_t row = static_cast<uint32_t>(w0 >> fp.keyBits) & fp.rowMask;
+  const uint32_t mask = static_cast<uint32_t>(w0 >> (fp.keyBits + fp.rowBits));
+  if (f.first[g] > row) {
+    atomicMin(&f.first[g], row);
+  }
+  foldAccumulate<W>(fp, f.acc + static_cast<size_t>(g) * f.A, w, mask, r.counters);
+}
+
 // Folds records [begin, end) of one partition into the LDS accumulators.
 template <int W>
 __device__ inline void rpFoldRecords(const RpFold& f, const RadixAggArgs& r, uint64_t begin, uint64_t end) {
-  const int A = f.A;
   for (uint64_t at = begin; at < end; at += kRadixUnroll * 512) {
     uint64_t w[kRadixUnroll][W];
 #pragma unroll
@@ -1548,39 +1638,82 @@ __device__ inline void rpFoldRecords(const RpFold& f, const RadixAggArgs& r, uin
 #pragma unroll
     for (int u = 0; u < kRadixUnroll; ++u) {
       const uint64_t i = at + u * 512 + threadIdx.x;
-      if (i >= end) {
-        continue;
-      }
-      const uint64_t w0 = w[u][0];
-      const uint32_t g = static_cast<uint32_t>(w0) & static_cast<uint32_t>(f.B - 1);
-      const uint32_t row = static_cast<uint32_t>(w0 >> r.keyBits) & static_cast<uint32_t>((1ULL << r.rowBits) - 1);
-      const uint32_t mask = static_cast<uint32_t>(w0 >> (r.keyBits + r.rowBits));
-      if (f.first[g] > row) {
-        atomicMin(&f.first[g], row);
-      }
-#pragma unroll
-      for (int q = 1; q < W; ++q) {
-        const int j = r.accOfVal[q - 1];
-        if ((mask >> j) & 1) {
-          uint64_t* word = f.acc + static_cast<size_t>(g) * A + r.ldsIdx[j];
-          if (r.kind[j] == ACC_SUM_F64 && r.splitM[j] != 0.0) {
-            double hi, lo;
-            splitDouble(__longlong_as_double(static_cast<long long>(w[u][q])), r.splitM[j], &hi, &lo);
-            applyLds(word, ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(hi)), r.counters);
-            applyLds(word + 1, ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(lo)), r.counters);
-          } else {
-            applyLds(word, r.kind[j], w[u][q], r.counters);
-          }
-        }
-      }
-      for (int j = 0; j < r.numAccs; ++j) {
-        if (r.valIdx[j] < 0 && ((mask >> j) & 1)) {
-          applyLds(f.acc + static_cast<size_t>(g) * A + r.ldsIdx[j], r.kind[j], 1ULL, r.counters);
-        }
+      if (i < end) {
+        rpFoldRecord<W>(f, r, w[u]);
       }
     }
   }
   blockSync();
+}
+
+// One group of a fold added into its group row (see rpFoldFlush); true = the group is new.
+__device__ inline bool rpFlushGroup(const RpFold& f, const RadixAggArgs& r, int g, uint64_t base, bool virgin,
+                                    bool exclusive, bool hasRecords) {
+  const int A = f.A;
+  const uint32_t fr = hasRecords ? f.first[g] : 0xffffffffu;
+  uint64_t* row = r.table + (base + g) * r.stride;
+  const uint64_t mine = r.rowBase + static_cast<uint64_t>(fr);
+  bool isNew = false;
+  if (virgin) {
+    isNew = fr != 0xffffffffu;
+    for (int w = 0; w < r.stride; ++w) {
+      uint64_t v = r.pattern[w];
+      if (isNew) {
+        const int j = r.ldsOfWord[w];
+        v = w == 1 ? mine : (j >= 0 ? f.acc[static_cast<size_t>(g) * A + j] : v);
+      }
+      row[w] = v;
+    }
+  } else if (fr == 0xffffffffu) {
+    // nothing for this group
+  } else if (!exclusive) {
+    const unsigned long long old = atomicMin(reinterpret_cast<unsigned long long*>(row + 1), mine);
+    isNew = old == kNoRow;
+    for (int j = 0; j < A; ++j) {
+      const uint64_t v = f.acc[static_cast<size_t>(g) * A + j];
+      const int32_t kind = r.wordKind[j];
+      if (v != accIdentity(kind)) {
+        if (kind == ACC_SUM_I64) {
+          addPartial128Global(row + r.wordOff[j], v, 0);  // its high word follows as word j + 1
+        } else {
+          applyGlobal(row + r.wordOff[j], kind == ACC_COUNT ? ACC_SUM_I64_WRAP : kind, v, r.counters);
+        }
+      }
+    }
+  } else {
+    const uint64_t old = row[1];
+    isNew = old == kNoRow;
+    if (mine < old) {
+      row[1] = mine;
+    }
+    for (int j = 0; j < A; ++j) {
+      const uint64_t v = f.acc[static_cast<size_t>(g) * A + j];
+      uint64_t* word = row + r.wordOff[j];
+      switch (r.wordKind[j]) {
+        case ACC_SUM_F64:
+          *reinterpret_cast<double*>(word) += __longlong_as_double(static_cast<long long>(v));
+          break;
+        case ACC_SUM_I64: {
+          const uint64_t before = *word;
+          *word = before + v;
+          word[1] += static_cast<uint64_t>(carryUnsigned(before, v));  // the fold's own high word is word j + 1
+          break;
+        }
+        case ACC_SUM_I64_HI:
+        case ACC_SUM_I64_WRAP:
+        case ACC_COUNT:
+          *word += v;
+          break;
+        case ACC_MIN:
+          *word = v < *word ? v : *word;
+          break;
+        default:
+          *word = v > *word ? v : *word;
+          break;
+      }
+    }
+  }
+  return isNew;
 }
 
 // Adds the LDS block into the partition's group rows. exclusive: this workgroup is the only
@@ -1592,7 +1725,6 @@ __device__ inline void rpFoldRecords(const RpFold& f, const RadixAggArgs& r, uin
 constexpr int kRpMaxPerThread = 8;  // B <= 4096 groups, 512 threads
 
 __device__ inline void rpFoldFlush(const RpFold& f, const RadixAggArgs& r, int64_t p, bool exclusive, bool hasRecords) {
-  const int A = f.A;
   const uint64_t base = static_cast<uint64_t>(p) << r.shiftB;
   const bool virgin = r.virgin != 0 && exclusive;
   if (threadIdx.x == 0) {
@@ -1609,69 +1741,7 @@ __device__ inline void rpFoldFlush(const RpFold& f, const RadixAggArgs& r, int64
     if (base + g >= r.capacity) {
       continue;
     }
-    const uint32_t fr = hasRecords ? f.first[g] : 0xffffffffu;
-    uint64_t* row = r.table + (base + g) * r.stride;
-    const uint64_t mine = r.rowBase + static_cast<uint64_t>(fr);
-    bool isNew = false;
-    if (virgin) {
-      isNew = fr != 0xffffffffu;
-      for (int w = 0; w < r.stride; ++w) {
-        uint64_t v = r.pattern[w];
-        if (isNew) {
-          const int j = r.ldsOfWord[w];
-          v = w == 1 ? mine : (j >= 0 ? f.acc[static_cast<size_t>(g) * A + j] : v);
-        }
-        row[w] = v;
-      }
-    } else if (fr == 0xffffffffu) {
-      // nothing for this group
-    } else if (!exclusive) {
-      const unsigned long long old = atomicMin(reinterpret_cast<unsigned long long*>(row + 1), mine);
-      isNew = old == kNoRow;
-      for (int j = 0; j < A; ++j) {
-        const uint64_t v = f.acc[static_cast<size_t>(g) * A + j];
-        const int32_t kind = r.wordKind[j];
-        if (v != accIdentity(kind)) {
-          if (kind == ACC_SUM_I64) {
-            addPartial128Global(row + r.wordOff[j], v, 0);  // its high word follows as word j + 1
-          } else {
-            applyGlobal(row + r.wordOff[j], kind == ACC_COUNT ? ACC_SUM_I64_WRAP : kind, v, r.counters);
-          }
-        }
-      }
-    } else {
-      const uint64_t old = row[1];
-      isNew = old == kNoRow;
-      if (mine < old) {
-        row[1] = mine;
-      }
-      for (int j = 0; j < A; ++j) {
-        const uint64_t v = f.acc[static_cast<size_t>(g) * A + j];
-        uint64_t* word = row + r.wordOff[j];
-        switch (r.wordKind[j]) {
-          case ACC_SUM_F64:
-            *reinterpret_cast<double*>(word) += __longlong_as_double(static_cast<long long>(v));
-            break;
-          case ACC_SUM_I64: {
-            const uint64_t before = *word;
-            *word = before + v;
-            word[1] += static_cast<uint64_t>(carryUnsigned(before, v));  // the fold's own high word is word j + 1
-            break;
-          }
-          case ACC_SUM_I64_HI:
-          case ACC_SUM_I64_WRAP:
-          case ACC_COUNT:
-            *word += v;
-            break;
-          case ACC_MIN:
-            *word = v < *word ? v : *word;
-            break;
-          default:
-            *word = v > *word ? v : *word;
-            break;
-        }
-      }
-    }
+    const bool isNew = rpFlushGroup(f, r, g, base, virgin, exclusive, hasRecords);
     if (isNew) {
       myPos[k] = atomicAdd(&f.scratch[0], 1u);
     }
@@ -1717,6 +1787,7 @@ __global__ __launch_bounds__(512) void k_rp_aggregate(RadixAggArgs r) {
   __shared__ uint32_t bigCount;
   __shared__ uint32_t scratch[2];
   RpFold f;
+  f.plan = foldPlan(r);
   f.B = 1 << r.shiftB;
   f.A = r.numWords;
   f.acc = reinterpret_cast<uint64_t*>(ldsRaw);                                       // [B][A]
@@ -1792,14 +1863,28 @@ __global__ __launch_bounds__(512) void k_rp_aggregate(RadixAggArgs r) {
 // neighbours in the table), plain read-modify-write, because a key has exactly one home slot and
 // therefore exactly one owner per launch. A record that finds the LDS table full goes to its group
 // row with HBM atomics on its own (and makes the whole partition flush with atomics).
-constexpr int kHashSlots = 2048;           // LDS entries per fold: 56 KB with two words, two workgroups per CU
+// The table has r.hashSlots entries: kHashSlots when nothing is known (load <= 0.5 even if all the
+// records of a partition are distinct), fewer - down to 512 - when a sample of the partitions
+// (k_rp_distinct_sample, behind the level-2 scatter) says that their keys repeat: initialising and
+// scanning 2048 entries for ~100 keys was a quarter of the fold (config 4, sparse keys: 21.8 ->
+// 16.1 ms together with the loads running one partition ahead, hashFoldLoadAhead).
+// What did NOT move the fold, each measured on that workload: one atomic per block of rows instead
+// of one per partition for the dense flush (-1 ms; kept), the accumulator plan in registers instead
+// of scalar loads from the argument buffer per record (0), three workgroups per CU at 80 registers
+// with spills instead of two (0), consecutive instead of strided partitions per workgroup (0; the
+// direct-index fold lost 2 ms), one WAVE per partition without any barrier for the direct-index
+// fold (0). With the fold and the flush switched off the loop still takes 7 ms for 24 GB.
+constexpr int kHashSlots = 2048;           // most LDS entries per fold: 56 KB with two words, two workgroups per CU
 constexpr int kHashRecsPerPart = 1024;     // records a partition is sized for (load <= 0.5 if all distinct)
 
 struct HashFold {
+  FoldPlan plan;
+  int posUp, posDown;        // home slot inside the partition -> entry of the LDS table: (x << posUp) >> posDown
   unsigned long long* keys;  // [S], kEmpty = free
   uint64_t* acc;             // [S][A]
   uint32_t* first;           // [S]
   uint32_t* scratch;         // [0] new groups, [1] pair base, [2] some record overflowed the window
+  uint32_t* alloc;           // dense folds: the workgroup's block of rows, see hashFoldFlushDense
   int S;
   int A;
 };
@@ -1816,18 +1901,6 @@ __device__ inline void hashFoldInit(const HashFold& f, const RadixAggArgs& r) {
     f.scratch[2] = 0;
   }
   blockSync();
-}
-
-// Word 'idx' (1 .. W - 1) of a record held in registers: a chain of selects, because a register
-// array indexed with a run-time value is moved to scratch memory.
-template <int W>
-__device__ inline uint64_t recordWord(const uint64_t (&w)[W], int idx) {
-  uint64_t v = 0;
-#pragma unroll
-  for (int q = 1; q < W; ++q) {
-    v = q == idx ? w[q] : v;
-  }
-  return v;
 }
 
 // The operands of one record applied to a group row in HBM with atomics: what updateGlobal does.
@@ -1856,7 +1929,8 @@ __device__ inline void hashFoldDirect(const RadixAggArgs& r, const uint64_t (&w)
                                       uint32_t mask) {
   if constexpr (DENSE) {
     // a row of its own; the merge pass (k_dense_merge) brings the rows of one key together
-    const uint64_t idx = atomicAdd(&r.counters->numNewGroups, 1u);
+    const uint64_t idx = atomicAdd(&r.denseFlags[1], 1u);
+    atomicAdd(&r.counters->numNewGroups, 1u);
     r.denseFlags[0] = 1;
     if (idx >= r.denseCap) {
       return;
@@ -1882,76 +1956,102 @@ __device__ inline void hashFoldDirect(const RadixAggArgs& r, const uint64_t (&w)
   hashApplyRecordGlobal<W>(r, g, w, mask);
 }
 
+// One record folded into the LDS table of its partition.
+template <int W, bool DENSE>
+__device__ inline void hashFoldRecord(const HashFold& f, const RadixAggArgs& r, uint64_t base, const uint64_t (&w)[W]) {
+  const FoldPlan& fp = f.plan;
+  const uint64_t w0 = w[0];
+  const uint64_t key = w[W - 1];
+  const uint32_t row = static_cast<uint32_t>(w0 >> fp.keyBits) & fp.rowMask;
+  const uint32_t mask = static_cast<uint32_t>(w0 >> (fp.keyBits + fp.rowBits));
+  // home slot inside the partition, scaled into the LDS table (both sizes are powers of two)
+  int pos = static_cast<int>((((w0 & ((1ULL << fp.keyBits) - 1)) - base) << f.posUp) >> f.posDown);
+  for (int probes = 0;; ++probes) {
+    const unsigned long long k = f.keys[pos];
+    if (k == key) {
+      break;
+    }
+    if (k == kEmpty) {
+      const unsigned long long old = atomicCAS(&f.keys[pos], kEmpty, static_cast<unsigned long long>(key));
+      if (old == kEmpty || old == key) {
+        break;
+      }
+    }
+    if (probes >= f.S) {
+      pos = -1;  // table full
+      break;
+    }
+    pos = (pos + 1) & (f.S - 1);
+  }
+  if (pos < 0) {
+    f.scratch[2] = 1;
+    hashFoldDirect<W, DENSE>(r, w, key, row, mask);
+    return;
+  }
+  if (f.first[pos] > row) {
+    atomicMin(&f.first[pos], row);
+  }
+  foldAccumulate<W>(fp, f.acc + static_cast<size_t>(pos) * f.A, w, mask, r.counters);
+}
+
+constexpr int kHashUnroll = 4;  // records per lane in flight beyond the ones loaded ahead
+
 template <int W, bool DENSE>
 __device__ inline void hashFoldRecords(const HashFold& f, const RadixAggArgs& r, int64_t p, uint64_t begin, uint64_t end) {
-  const int A = f.A;
   const uint64_t base = static_cast<uint64_t>(p) << r.shiftB;
-  const uint64_t keyMask = (1ULL << r.keyBits) - 1;
-  for (uint64_t at = begin; at < end; at += kRadixUnroll * 512) {
-    uint64_t w[kRadixUnroll][W];
+  for (uint64_t at = begin; at < end; at += kHashUnroll * 512) {
+    uint64_t w[kHashUnroll][W];
 #pragma unroll
-    for (int u = 0; u < kRadixUnroll; ++u) {
+    for (int u = 0; u < kHashUnroll; ++u) {
       const uint64_t i = at + u * 512 + threadIdx.x;
       if (i < end) {
         rpLoad<W>(r.recs + i * W, w[u]);
       }
     }
 #pragma unroll
-    for (int u = 0; u < kRadixUnroll; ++u) {
+    for (int u = 0; u < kHashUnroll; ++u) {
       const uint64_t i = at + u * 512 + threadIdx.x;
-      if (i >= end) {
-        continue;
-      }
-      const uint64_t w0 = w[u][0];
-      const uint64_t key = w[u][W - 1];
-      const uint32_t row = static_cast<uint32_t>(w0 >> r.keyBits) & static_cast<uint32_t>((1ULL << r.rowBits) - 1);
-      const uint32_t mask = static_cast<uint32_t>(w0 >> (r.keyBits + r.rowBits));
-      // home slot inside the partition, scaled into the LDS table
-      int pos = static_cast<int>((((w0 & keyMask) - base) * static_cast<uint64_t>(kHashSlots)) >> r.shiftB);
-      for (int probes = 0;; ++probes) {
-        const unsigned long long k = f.keys[pos];
-        if (k == key) {
-          break;
-        }
-        if (k == kEmpty) {
-          const unsigned long long old = atomicCAS(&f.keys[pos], kEmpty, static_cast<unsigned long long>(key));
-          if (old == kEmpty || old == key) {
-            break;
-          }
-        }
-        if (probes >= kHashSlots) {
-          pos = -1;  // table full
-          break;
-        }
-        pos = (pos + 1) & (kHashSlots - 1);
-      }
-      if (pos < 0) {
-        f.scratch[2] = 1;
-        hashFoldDirect<W, DENSE>(r, w[u], key, row, mask);
-        continue;
-      }
-      if (f.first[pos] > row) {
-        atomicMin(&f.first[pos], row);
-      }
-      for (int j = 0; j < r.numAccs; ++j) {
-        if (!((mask >> j) & 1)) {
-          continue;
-        }
-        uint64_t* word = f.acc + static_cast<size_t>(pos) * A + r.ldsIdx[j];
-        if (r.valIdx[j] < 0) {
-          applyLds(word, r.kind[j], 1ULL, r.counters);
-        } else if (r.kind[j] == ACC_SUM_F64 && r.splitM[j] != 0.0) {
-          double hi, lo;
-          splitDouble(__longlong_as_double(static_cast<long long>(recordWord<W>(w[u], 1 + r.valIdx[j]))), r.splitM[j], &hi, &lo);
-          applyLds(word, ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(hi)), r.counters);
-          applyLds(word + 1, ACC_SUM_F64, static_cast<uint64_t>(__double_as_longlong(lo)), r.counters);
-        } else {
-          applyLds(word, r.kind[j], recordWord<W>(w[u], 1 + r.valIdx[j]), r.counters);
-        }
+      if (i < end) {
+        hashFoldRecord<W, DENSE>(f, r, base, w[u]);
       }
     }
   }
   blockSync();
+}
+
+// The first kHashAhead x 512 records of a partition travel through registers one partition ahead
+// of the fold: a fold is a chain of HBM round trips (range, records, the group counter), and the
+// two or three workgroups a CU holds do not cover it (measured: 11 us per partition, 1.1 TB/s).
+constexpr int kHashAhead = 2;
+
+template <int W>
+__device__ inline void hashFoldLoadAhead(const RadixAggArgs& r, uint64_t begin, uint64_t end, uint64_t (&w)[kHashAhead][W]) {
+  const uint64_t stop = end - begin > r.sliceRecs ? begin + r.sliceRecs : end;
+#pragma unroll
+  for (int u = 0; u < kHashAhead; ++u) {
+    const uint64_t i = begin + u * 512 + threadIdx.x;
+    if (i < stop) {
+      rpLoad<W>(r.recs + i * W, w[u]);
+    }
+  }
+}
+
+// Range of partition p through the vector memory path (a buffer load: the index is uniform, and a
+// scalar load would be waited for at the next barrier together with the LDS).
+__device__ inline void rpPartitionRangeAhead(const RadixAggArgs& r, int64_t p, uint64_t* begin, uint64_t* end) {
+  if (r.partBase == nullptr) {
+    rpPartitionRange(r, p, begin, end);
+    return;
+  }
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  const auto bases = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(r.partBase), 0,
+                                                      static_cast<int>(r.numParts * 8), 0x00020000);
+  const auto counts = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(r.partCount), 0,
+                                                       static_cast<int>(r.numParts * 4), 0x00020000);
+  const u32x2 b = __builtin_amdgcn_raw_buffer_load_b64(bases, static_cast<int>(p * 8), 0, 0);
+  const uint32_t c = __builtin_amdgcn_raw_buffer_load_b32(counts, static_cast<int>(p * 4), 0, 0);
+  *begin = static_cast<uint64_t>(b.x) | (static_cast<uint64_t>(b.y) << 32);
+  *end = *begin + c;
 }
 
 // Flush: every lane owns kHashPerLane entries of the LDS table and works on all of them at once -
@@ -1981,7 +2081,7 @@ __device__ inline void hashFoldFlush(const HashFold& f, const RadixAggArgs& r, b
     // consecutive lanes take consecutive entries: the table is in home-slot order, so a wave's
     // probes walk the global table in ascending order
     const int e = k * 512 + threadIdx.x;
-    key[k] = f.keys[e];
+    key[k] = e < f.S ? f.keys[e] : kEmpty;
     pending[k] = key[k] != kEmpty;
     pos[k] = twangMix64(key[k]) & mask;
     row[k] = nullptr;
@@ -2114,38 +2214,88 @@ __device__ inline void hashFoldFlush(const HashFold& f, const RadixAggArgs& r, b
 }
 
 // Flush of a fold into an operator that has no groups yet: nothing to look up, so the fold's
-// entries are APPENDED to a plain array of group rows - one atomic on the group counter per
-// flush, complete rows stored side by side (coalesced) instead of one findOrInsert + one
-// read-modify-write per group at random places of an open-addressing table. Rows of one key come
-// from one fold only (a key has one partition), except when a partition is folded in slices or a
-// record overflowed the LDS table: denseFlags[0] tells the host to merge (k_dense_merge).
-__device__ inline void hashFoldFlushDense(const HashFold& f, const RadixAggArgs& r, bool owner) {
-  const int A = f.A;
-  if (threadIdx.x == 0) {
-    f.scratch[0] = 0;
-    if (!owner) {
-      r.denseFlags[0] = 1;
+// entries are APPENDED to a plain array of group rows, complete rows stored side by side
+// (coalesced) instead of one findOrInsert + one read-modify-write per group at random places of an
+// open-addressing table. A workgroup owns a block of rows at a time (f.alloc: {cursor, limit},
+// double buffered so that the lanes read one copy while lane 0 writes the other) and takes the
+// next one with ONE atomic on denseFlags[1]; its entries are counted with ballots. Rows of one key
+// come from one fold only (a key has one partition), except when a partition is folded in slices
+// or a record overflowed the LDS table: denseFlags[0] tells the host to merge (k_dense_merge).
+enum { DA_CURSOR = 0, DA_LIMIT = 2, DA_WAVES = 4, DA_START = 12, DA_WORDS = 16 };
+
+// Rows [from, to) of the dense array stay empty.
+__device__ inline void denseFillHoles(const RadixAggArgs& r, uint32_t from, uint32_t to) {
+  for (uint64_t i = static_cast<uint64_t>(from) + threadIdx.x; i < to && i < r.denseCap; i += blockDim.x) {
+    uint64_t* g = r.table + i * r.stride;
+    for (int x = 0; x < r.stride; ++x) {
+      g[x] = r.pattern[x];
+    }
+    if (r.pairKeys != nullptr) {
+      r.pairKeys[r.pairBase + i] = ~0ULL;
+      r.pairVals[r.pairBase + i] = 0;
     }
   }
-  blockSync();
-  uint32_t myPos[kHashPerLane];
+}
+
+__device__ inline void hashFoldFlushDense(const HashFold& f, const RadixAggArgs& r, bool owner, int* parity,
+                                          uint32_t* newGroups) {
+  const int A = f.A;
+  if (threadIdx.x == 0 && !owner) {
+    r.denseFlags[0] = 1;
+  }
+  const int wave = threadIdx.x >> 6;
+  uint32_t rank[kHashPerLane];
+  uint32_t waveTotal = 0;
 #pragma unroll
   for (int k = 0; k < kHashPerLane; ++k) {
     const int e = k * 512 + threadIdx.x;
-    myPos[k] = f.keys[e] != kEmpty ? atomicAdd(&f.scratch[0], 1u) : 0xffffffffu;
+    const bool live = e < f.S && f.keys[e] != kEmpty;
+    const uint64_t m = ballot(live);
+    rank[k] = live ? waveTotal + static_cast<uint32_t>(lanePrefix(m)) : 0xffffffffu;
+    waveTotal += static_cast<uint32_t>(popc64(m));
+  }
+  if (lane() == 0) {
+    f.alloc[DA_WAVES + wave] = waveTotal;
   }
   blockSync();
-  if (threadIdx.x == 0 && f.scratch[0] != 0) {
-    f.scratch[1] = atomicAdd(&r.counters->numNewGroups, f.scratch[0]);
+  uint32_t before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    const uint32_t t = f.alloc[DA_WAVES + w];
+    before += w < wave ? t : 0;
+    total += t;
   }
-  blockSync();
+  const int now = *parity;
+  const uint32_t cursor = f.alloc[DA_CURSOR + now];
+  const uint32_t limit = f.alloc[DA_LIMIT + now];
+  uint32_t base = cursor;
+  if (cursor + total <= limit) {  // uniform
+    if (threadIdx.x == 0) {
+      f.alloc[DA_CURSOR + (now ^ 1)] = cursor + total;
+      f.alloc[DA_LIMIT + (now ^ 1)] = limit;
+    }
+  } else {
+    // the next block; what is left of this one stays empty
+    if (threadIdx.x == 0) {
+      const uint32_t size = total > r.denseChunk ? total : r.denseChunk;
+      const uint32_t start = atomicAdd(&r.denseFlags[1], size);
+      f.alloc[DA_START] = start;
+      f.alloc[DA_CURSOR + (now ^ 1)] = start + total;
+      f.alloc[DA_LIMIT + (now ^ 1)] = start + size;
+    }
+    blockSync();
+    base = f.alloc[DA_START];
+    denseFillHoles(r, cursor, limit);
+  }
+  *parity = now ^ 1;
+  *newGroups += total;
 #pragma unroll
   for (int k = 0; k < kHashPerLane; ++k) {
-    if (myPos[k] == 0xffffffffu) {
+    if (rank[k] == 0xffffffffu) {
       continue;
     }
     const int e = k * 512 + threadIdx.x;
-    const uint64_t idx = static_cast<uint64_t>(f.scratch[1]) + myPos[k];
+    const uint64_t idx = static_cast<uint64_t>(base) + before + rank[k];
     if (idx >= r.denseCap) {
       continue;  // counted: the host grows the array and folds again
     }
@@ -2170,24 +2320,78 @@ __global__ __launch_bounds__(512) void k_rp_aggregate_hashed(RadixAggArgs r) {
   __shared__ uint32_t bigList[512];
   __shared__ uint32_t bigCount;
   __shared__ uint32_t scratch[4];
+  __shared__ uint32_t alloc[DA_WORDS];
   HashFold f;
-  f.S = kHashSlots;
+  f.alloc = alloc;
+  int parity = 0;
+  uint32_t newGroups = 0;
+  if (threadIdx.x < DA_WORDS) {
+    alloc[threadIdx.x] = 0;  // (the first fold's hashFoldInit ends with a barrier)
+  }
+  f.plan = foldPlan(r);
+  f.S = r.hashSlots;
+  {
+    const int slotBits = 31 - __builtin_clz(static_cast<unsigned>(r.hashSlots));
+    f.posUp = slotBits > r.shiftB ? slotBits - r.shiftB : 0;
+    f.posDown = r.shiftB > slotBits ? r.shiftB - slotBits : 0;
+  }
   f.A = r.numWords;
   f.keys = reinterpret_cast<unsigned long long*>(ldsRaw);
   f.acc = reinterpret_cast<uint64_t*>(f.keys + f.S);
   f.first = reinterpret_cast<uint32_t*>(f.acc + static_cast<size_t>(f.S) * f.A);
   f.scratch = scratch;
-  for (int64_t p = blockIdx.x; p < r.numParts; p += gridDim.x) {
-    uint64_t begin, end;
-    rpPartitionRange(r, p, &begin, &end);
+  // software pipeline over the workgroup's partitions: ranges two ahead, first records one ahead
+  const int64_t grid = gridDim.x;
+  const int64_t pFirst = blockIdx.x;
+  const int64_t pEnd = r.numParts;
+  uint64_t begin0 = 0, end0 = 0, begin1 = 0, end1 = 0;
+  if (pFirst < pEnd) {
+    rpPartitionRangeAhead(r, pFirst, &begin0, &end0);
+  }
+  if (pFirst + grid < pEnd) {
+    rpPartitionRangeAhead(r, pFirst + grid, &begin1, &end1);
+  }
+  uint64_t ahead[kHashAhead][W];
+  hashFoldLoadAhead<W>(r, begin0, end0, ahead);
+  for (int64_t p = pFirst; p < pEnd; p += grid) {
+    const uint64_t begin = begin0, end = end0;
+    uint64_t w[kHashAhead][W];
+#pragma unroll
+    for (int u = 0; u < kHashAhead; ++u) {
+#pragma unroll
+      for (int q = 0; q < W; ++q) {
+        w[u][q] = ahead[u][q];
+      }
+    }
+    begin0 = begin1;
+    end0 = end1;
+    begin1 = end1 = 0;
+    if (p + 2 * grid < pEnd) {
+      rpPartitionRangeAhead(r, p + 2 * grid, &begin1, &end1);
+    }
+    if (p + grid < pEnd) {
+      hashFoldLoadAhead<W>(r, begin0, end0, ahead);
+    }
     if (end == begin) {
       continue;  // uniform per workgroup
     }
     const bool split = end - begin > r.sliceRecs;
+    const uint64_t stop = split ? begin + r.sliceRecs : end;
+    const uint64_t base = static_cast<uint64_t>(p) << r.shiftB;
     hashFoldInit(f, r);
-    hashFoldRecords<W, DENSE>(f, r, p, begin, split ? begin + r.sliceRecs : end);
+#pragma unroll
+    for (int u = 0; u < kHashAhead; ++u) {
+      if (begin + u * 512 + threadIdx.x < stop) {
+        hashFoldRecord<W, DENSE>(f, r, base, w[u]);
+      }
+    }
+    if (stop - begin > kHashAhead * 512) {
+      hashFoldRecords<W, DENSE>(f, r, p, begin + kHashAhead * 512, stop);
+    } else {
+      blockSync();
+    }
     if constexpr (DENSE) {
-      hashFoldFlushDense(f, r, !split);
+      hashFoldFlushDense(f, r, !split, &parity, &newGroups);
     } else {
       hashFoldFlush(f, r, !split);
     }
@@ -2218,13 +2422,71 @@ __global__ __launch_bounds__(512) void k_rp_aggregate_hashed(RadixAggArgs r) {
         hashFoldInit(f, r);
         hashFoldRecords<W, DENSE>(f, r, p, b, b + r.sliceRecs < end ? b + r.sliceRecs : end);
         if constexpr (DENSE) {
-          hashFoldFlushDense(f, r, false);
+          hashFoldFlushDense(f, r, false, &parity, &newGroups);
         } else {
           hashFoldFlush(f, r, false);
         }
       }
     }
     blockSync();
+  }
+  if constexpr (DENSE) {
+    // what is left of the workgroup's last block stays empty; its groups are counted once
+    blockSync();
+    denseFillHoles(r, alloc[DA_CURSOR + parity], alloc[DA_LIMIT + parity]);
+    if (threadIdx.x == 0 && newGroups != 0) {
+      atomicAdd(&r.counters->numNewGroups, newGroups);
+    }
+  }
+}
+
+// How many distinct keys does a partition of a hashed level-2 layout hold? gridDim.x partitions
+// spread over the layout, one workgroup each, the keys of up to 2048 records into an LDS set:
+// out[0] += distinct keys, out[1] += records looked at, out[2] = max distinct keys of one partition.
+// (Partitions are ranges of the key HASH: their numbers of distinct keys are alike whatever the
+// keys' frequencies are - the launch sizes the folds' LDS tables from this, see hashSlots.)
+template <int W>
+__global__ __launch_bounds__(256) void k_rp_distinct_sample(const uint64_t* recs, const uint64_t* partBase,
+                                                            const uint32_t* partCount, int64_t numParts, uint32_t* out) {
+  constexpr int kSet = 4096;
+  __shared__ unsigned long long set[kSet];
+  __shared__ uint32_t found;
+  for (int i = threadIdx.x; i < kSet; i += blockDim.x) {
+    set[i] = kEmpty;
+  }
+  if (threadIdx.x == 0) {
+    found = 0;
+  }
+  blockSync();
+  const int64_t p = static_cast<int64_t>(blockIdx.x) * (numParts / gridDim.x);
+  const uint64_t begin = partBase[p];
+  const uint32_t n = partCount[p] < 2048u ? partCount[p] : 2048u;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const unsigned long long key = recs[(begin + i) * W + (W - 1)];
+    uint32_t pos = static_cast<uint32_t>(twangMix64(key) >> 20) & (kSet - 1);
+    for (;;) {
+      const unsigned long long k = set[pos];
+      if (k == key) {
+        break;
+      }
+      if (k == kEmpty) {
+        const unsigned long long old = atomicCAS(&set[pos], kEmpty, key);
+        if (old == kEmpty) {
+          atomicAdd(&found, 1u);
+          break;
+        }
+        if (old == key) {
+          break;
+        }
+      }
+      pos = (pos + 1) & (kSet - 1);
+    }
+  }
+  blockSync();
+  if (threadIdx.x == 0) {
+    atomicAdd(&out[0], found);
+    atomicAdd(&out[1], n);
+    atomicMax(&out[2], found);
   }
 }
 
@@ -2247,6 +2509,9 @@ __global__ __launch_bounds__(256) void k_dense_merge(DenseMergeArgs a) {
   for (uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; i < a.numRows;
        i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
     const uint64_t* row = a.rows + i * a.stride;
+    if (row[1] == kNoRow) {
+      continue;  // a row no fold used (see denseFlags)
+    }
     uint64_t* g = findOrInsert(a.table, a.stride, a.capacity, row[0], a.counters);
     if (g == nullptr) {
       continue;
@@ -3583,6 +3848,8 @@ struct vx355_agg {
   bool radixOptimistic = true;  // VX355_AGG_RADIX_OPTIMISTIC=0: level 2 always counts first
   bool radixOptimistic1 = true;  // VX355_AGG_RADIX_OPTIMISTIC1=0: level 1 always counts first (k_rp_count1)
   int64_t radixRedone = 0;      // level-2 passes redone exactly after a region overflowed
+  int32_t hashSlotsFixed = 0;   // VX355_AGG_HASH_SLOTS: LDS entries of the hashed folds (0 = from a sample of the keys)
+  int32_t lastHashSlots = 0;    // what the last hashed launch used
   int64_t radixMinRows = 4 << 20;
   int32_t radixMaxBins = kRadixMaxBins;  // widest single-level fan-out
   int64_t radixTileRows = 0;  // 0 = automatic
@@ -3608,6 +3875,7 @@ struct vx355_agg {
   // while every group came out of an exclusive radix fold of the current table.
   int64_t pairCount = 0;
   bool pairsComplete = true;
+  int64_t pairHoles = 0;   // entries of the list no group owns (dense folds: they sort behind every group)
   DevBuf orderKeys, orderVals, orderKeys2, orderVals2;
   const uint32_t* order = nullptr;
   int64_t numOutput = -1;  // set by finalize
@@ -4075,6 +4343,7 @@ void rebuildTable(vx355_agg& h, uint64_t extraGroups) {
   // group rows move: the listed pairs would point at the old places
   h.pairsComplete = h.numGroups == 0;
   h.pairCount = 0;
+  h.pairHoles = 0;
   if (h.tableReady && h.numGroups > 0) {
     settleTable(h);
     RekeyArgs ra{};
@@ -5180,6 +5449,7 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
   const Level1Bins level1{offsets1, r.numTiles, opt1 ? binFirst : nullptr, opt1 ? binCursor : nullptr};
 
   RadixAggArgs g{};
+  int32_t hashSlots = h.hashSlotsFixed > 0 ? h.hashSlotsFixed : kHashSlots;
   g.recs = h.rpRecs1.as<uint64_t>();
   g.partBegin = offsets1;
   g.partCell = nullptr;
@@ -5235,12 +5505,30 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
       byWidth([&](auto wTag) {
         VX_LAUNCH("k_rp_scatter2", (k_rp_scatter2_opt<decltype(wTag)::value>), grid2, kSortThreads, 0, o);
       });
-      uint32_t full = 0;
-      copyOut(&full, VX355_MEM_HOST, overflow, 4);
-      exact = full != 0;  // some partition outgrew its region (skewed keys): redo the level exactly
+      constexpr int kSampleParts = 64;
+      const bool sampleKeys = hashed && h.hashSlotsFixed == 0 && partsPadded >= kSampleParts;
+      if (sampleKeys) {
+        byWidth([&](auto wTag) {
+          constexpr int W = decltype(wTag)::value;
+          VX_LAUNCH("k_rp_distinct_sample", (k_rp_distinct_sample<W>), kSampleParts, 256, 0, o.out, partBase, partCount,
+                    static_cast<int64_t>(partsPadded), overflow + 4);
+        });
+      }
+      uint32_t flags[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // [0] overflow, [4..6] the key sample
+      copyOut(flags, VX355_MEM_HOST, overflow, sizeof(flags));
+      exact = flags[0] != 0;  // some partition outgrew its region (skewed keys): redo the level exactly
       if (!exact) {
         g.partBase = partBase;
         g.partCount = partCount;
+        if (sampleKeys && flags[5] != 0) {
+          // LDS entries of a fold: load <= 0.4 for the fullest sampled partition's keys scaled to a
+          // whole partition (the sample looks at 2048 records at most), with room for their spread
+          const double perRecord = static_cast<double>(flags[4]) / static_cast<double>(flags[5]);
+          const double recsPerPart = static_cast<double>(n) / static_cast<double>(parts);
+          const double mean = perRecord * recsPerPart;
+          const double fullest = std::max<double>(flags[6], mean + 6.0 * std::sqrt(mean + 1.0));
+          hashSlots = static_cast<int32_t>(nextPow2(static_cast<uint64_t>(std::min<double>(kHashSlots, std::max(512.0, 2.5 * fullest)))));
+        }
       } else {
         ++h.radixRedone;
         h.radixOptimistic = false;  // skewed keys: this operator counts from now on
@@ -5291,7 +5579,9 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
   }
   // LDS of one fold: dense = B groups x (words + first row); hashed = (B + margin) window entries x
   // (key + words + first row)
-  const size_t ldsBytes = hashed ? static_cast<size_t>(kHashSlots) * (8 + g.numWords * 8 + 4)
+  g.hashSlots = hashSlots;
+  h.lastHashSlots = hashed ? hashSlots : 0;
+  const size_t ldsBytes = hashed ? static_cast<size_t>(hashSlots) * (8 + g.numWords * 8 + 4)
                                  : (static_cast<size_t>(1) << r.shiftB) * (g.numWords * 8 + 4);
   // Few partitions or skewed keys: slices keep every CU busy.
   g.sliceRecs = static_cast<uint64_t>(std::max<int64_t>(1 << 16, ceilDiv(n, 2048)));
@@ -5323,20 +5613,27 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
     g.dense = 1;
     g.denseCap = denseCap;
     g.denseFlags = h.denseFlags.as<uint32_t>();
+    // rows a workgroup takes at a time: the holes stay ~1 % of the array
+    g.denseChunk = static_cast<uint32_t>(std::max<uint64_t>(256, std::min<uint64_t>(8192, denseCap / (static_cast<uint64_t>(rt.numCUs) * 16))));
+    if (const char* e = std::getenv("VX355_AGG_DENSE_CHUNK")) {
+      g.denseChunk = static_cast<uint32_t>(std::max(1, std::atoi(e)));
+    }
+
     g.table = denseRows.as<uint64_t>();
     h.pairsComplete = true;  // no groups yet: this launch lists all of them
     h.pairCount = 0;
+    h.pairHoles = 0;
   }
   if (h.pairsComplete && h.pairCount == h.numGroups) {
     // room for one new group per row of the chunk, at most one per group row
     const size_t room = dense ? static_cast<size_t>(denseCap)
                               : static_cast<size_t>(std::min<uint64_t>(a.capacity, static_cast<uint64_t>(h.numGroups + n)));
-    const size_t live = static_cast<size_t>(h.pairCount);
-    h.orderKeys.ensure(room * 8 + 64, true, live * 8);
-    h.orderVals.ensure(room * 4 + 64, true, live * 4);
+    const size_t live = static_cast<size_t>(h.pairCount + h.pairHoles);
+    h.orderKeys.ensure((room + static_cast<size_t>(h.pairHoles)) * 8 + 64, true, live * 8);
+    h.orderVals.ensure((room + static_cast<size_t>(h.pairHoles)) * 4 + 64, true, live * 4);
     g.pairKeys = h.orderKeys.as<uint64_t>();
     g.pairVals = h.orderVals.as<uint32_t>();
-    g.pairBase = static_cast<uint64_t>(h.pairCount);
+    g.pairBase = static_cast<uint64_t>(live);
   } else {
     h.pairsComplete = false;
   }
@@ -5367,12 +5664,13 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
     }
     ++h.denseLaunches;
     uint32_t* newGroups = &a.counters->numNewGroups;
-    uint32_t found = 0;
-    copyOut(&found, VX355_MEM_HOST, newGroups, 4);
-    if (found > denseCap) {
-      // more groups than the guess: now the number is known, fold the same records again
+    uint32_t flags[2] = {0, 0};   // [0] some key may own several rows, [1] rows handed out (groups + holes)
+    copyOut(flags, VX355_MEM_HOST, h.denseFlags.ptr(), 8);
+    while (flags[1] > denseCap) {
+      // more rows than the guess: now the number is known (the holes vary a little from run to run:
+      // hence the margin), fold the same records again
       ++h.denseRefolds;
-      denseCap = found;
+      denseCap = static_cast<uint64_t>(flags[1]) + flags[1] / 16 + 65536;
       denseRows.ensure(static_cast<size_t>(denseCap) * a.stride * 8 + 64);
       h.orderKeys.ensure(static_cast<size_t>(denseCap) * 8 + 64);
       h.orderVals.ensure(static_cast<size_t>(denseCap) * 4 + 64);
@@ -5383,11 +5681,13 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
       HIP_OK(hipMemsetAsync(newGroups, 0, 4, rt.stream));
       HIP_OK(hipMemsetAsync(h.denseFlags.ptr(), 0, 64, rt.stream));
       fold();
-      copyOut(&found, VX355_MEM_HOST, newGroups, 4);
+      copyOut(flags, VX355_MEM_HOST, h.denseFlags.ptr(), 8);
     }
-    uint32_t several = 0;
-    copyOut(&several, VX355_MEM_HOST, h.denseFlags.ptr(), 4);
-    if (several == 0) {
+    const uint32_t found = flags[1];
+    uint32_t groups = 0;
+    copyOut(&groups, VX355_MEM_HOST, newGroups, 4);
+    h.pairHoles = static_cast<int64_t>(found) - static_cast<int64_t>(groups);  // the caller adds the groups to pairCount
+    if (flags[0] == 0) {
       // the array of rows is the table from here on
       h.table = std::move(denseRows);
       h.capacity = found;
@@ -5422,6 +5722,7 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
     h.tableVirgin = false;
     h.tableReady = true;
     h.pairsComplete = false;
+    h.pairHoles = 0;
     return;
   }
   if (g.virgin) {
@@ -6240,7 +6541,9 @@ void finalize(vx355_agg& h) {
   const size_t g = static_cast<size_t>(h.numGroups);
   settleTable(h);
   // Every group was listed by the radix folds that created it: no scan of the table.
-  const bool listed = h.pairsComplete && h.pairCount == h.numGroups;
+  // (a list with holes - dense folds - is only good for sorting: the holes go behind the groups)
+  const bool listed = h.pairsComplete && h.pairCount == h.numGroups && !(h.unorderedOutput && h.pairHoles != 0);
+  const size_t listLen = listed ? g + static_cast<size_t>(h.pairHoles) : g;
   if (!listed && !h.unorderedOutput && h.capacity <= 65536 && g <= static_cast<size_t>(kSmallSortMax)) {
     uint32_t* order = static_cast<uint32_t*>(h.orderVals.ensure(g * 4 + 64));
     VX_LAUNCH("k_collect_sort_small", k_collect_sort_small, static_cast<int>(ceilDiv(static_cast<int64_t>(g), 64)), 1024,
@@ -6278,8 +6581,8 @@ void finalize(vx355_agg& h) {
                                     std::to_string(found));
     }
   }
-  h.orderKeys2.ensure(g * 8 + 64);
-  h.orderVals2.ensure(g * 4 + 64);
+  h.orderKeys2.ensure(listLen * 8 + 64);
+  h.orderVals2.ensure(listLen * 4 + 64);
   if (h.unorderedOutput) {
     rt.sync();
     h.order = h.orderVals.as<uint32_t>();  // table order as k_collect found it
@@ -6288,8 +6591,9 @@ void finalize(vx355_agg& h) {
   }
   bool inTmp = false;
   sortPairsU64U32(h.orderKeys.as<uint64_t>(), h.orderVals.as<uint32_t>(), h.orderKeys2.as<uint64_t>(),
-                  h.orderVals2.as<uint32_t>(), g, h.sortTmp, &inTmp,
-                  // first rows are < inputRows: sort only the bits that can be set
+                  h.orderVals2.as<uint32_t>(), listLen, h.sortTmp, &inTmp,
+                  // first rows are < inputRows: sort only the bits that can be set (a hole has all of
+                  // them set, and inputRows - 1 has not)
                   std::max(1, 64 - __builtin_clzll(static_cast<unsigned long long>(std::max<int64_t>(1, h.inputRows)))));
   rt.sync();
   h.order = inTmp ? h.orderVals2.as<uint32_t>() : h.orderVals.as<uint32_t>();
@@ -6319,6 +6623,7 @@ void resetAfterFlush(vx355_agg& h) {
   }
   rt.sync();
   h.pairCount = 0;
+  h.pairHoles = 0;
   h.pairsComplete = true;
   h.numGroups = 0;
   h.numOutput = -1;
@@ -6790,6 +7095,10 @@ void configureFromEnv(vx355_agg& h) {
   }
   if (const char* e = std::getenv("VX355_AGG_RADIX_OPTIMISTIC1")) {
     h.radixOptimistic1 = std::atoi(e) != 0;
+  }
+  if (const char* e = std::getenv("VX355_AGG_HASH_SLOTS")) {
+    const int v = std::atoi(e);
+    h.hashSlotsFixed = v <= 0 ? 0 : static_cast<int32_t>(nextPow2(static_cast<uint64_t>(std::min(kHashSlots, std::max(512, v)))));
   }
   if (const char* e = std::getenv("VX355_AGG_RADIX_SORTED")) {
     h.radixSorted = std::atoi(e) != 0;
