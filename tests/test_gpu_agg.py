@@ -944,6 +944,32 @@ def test_hashed_folds_size_their_lds_table_from_a_sample_of_the_keys(oracle, vx,
         assert "k_rp_distinct_sample" in prof
 
 
+@pytest.mark.parametrize("keys", ["dense", "sparse"])
+def test_first_seen_order_of_many_groups_without_the_library_sort(oracle, vx, keys, monkeypatch):
+    """The listed (first row, group) entries of the radix folds are put into first-seen order by the
+    library's own passes (k_fs_pack, two exact radix levels, k_fs_rank: a bitmap per partition) instead of
+    rocPRIM - forced here for 1.2 M groups (it starts at 4 M entries); direct-index table and the dense
+    folds' array of rows with its holes. Group order must be the oracle's."""
+    monkeypatch.setenv("VX355_AGG_RADIX_MIN_ROWS", "1")
+    monkeypatch.setenv("VX355_AGG_DENSE_MIN_ROWS", "1")
+    monkeypatch.setenv("VX355_AGG_COALESCE_ROWS", "0")
+    monkeypatch.setenv("VX355_AGG_OWN_SORT_MIN", "1")
+    rng = np.random.default_rng(77)
+    n = 3_000_000
+    j = rng.integers(0, 1_500_000, n).astype(np.uint64)
+    k = j.astype(np.int64) if keys == "dense" else ((j * np.uint64(0x9E3779B97F4A7C15)) ^ np.uint64(0x5DEECE66D)).astype(np.int64)
+    batches = [batch_of([k, _dyadic(rng, n)])]
+    aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    exp, _ = run_agg(oracle, batches, [0], [abi.BIGINT], aggs, max_rows=1 << 20)
+    vx.profile_reset()
+    vx.profile_enable(True)
+    got, gop = run_agg(vx, batches, [0], [abi.BIGINT], aggs, max_rows=1 << 20)
+    vx.profile_enable(False)
+    assert_columns_equal(got, exp, gop.kinds, what="own first-seen sort, %s keys" % keys)
+    prof = vx.profile()
+    assert "k_fs_rank" in prof and "k_rp_aggregate" in prof, sorted(prof)
+
+
 def test_radix_path_two_keys_fused_filter(oracle, vx, monkeypatch):
     """Two grouping keys (the normalized key is the partitioning key) behind a fused filter."""
     monkeypatch.setenv("VX355_AGG_RADIX_MIN_ROWS", "1")

@@ -1199,6 +1199,7 @@ __global__ __launch_bounds__(1024) void k_rp_tiles(Level1Bins l1, int32_t numBin
                                                     int32_t numBins2, int32_t shift2, uint32_t tileRecs,
                                                     RadixTile* tiles, uint32_t* numTiles2, uint32_t* partCell,
                                                     int64_t numParts) {
+  // (every workgroup derives the same tile starts, then takes its share of the two tables)
   __shared__ uint32_t tileStart[kRadixMaxBins + 1];
   for (int b = threadIdx.x; b < numBins1; b += blockDim.x) {
     const uint64_t count = l1.count(b);
@@ -1213,25 +1214,38 @@ __global__ __launch_bounds__(1024) void k_rp_tiles(Level1Bins l1, int32_t numBin
       run += n;
     }
     tileStart[numBins1] = run;
-    *numTiles2 = run;
-  }
-  blockSync();
-  for (int b = threadIdx.x; b < numBins1; b += blockDim.x) {
-    const uint64_t first = l1.first(b);
-    const uint64_t count = l1.count(b);
-    const uint32_t n = tileStart[b + 1] - tileStart[b];
-    for (uint32_t j = 0; j < n; ++j) {
-      RadixTile t;
-      t.begin = first + static_cast<uint64_t>(j) * tileRecs;
-      const uint64_t left = count - static_cast<uint64_t>(j) * tileRecs;
-      t.count = static_cast<uint32_t>(left < tileRecs ? left : tileRecs);
-      t.cell = static_cast<uint32_t>(numBins2) * tileStart[b] + j;
-      t.stride = n;
-      t.pad = 0;
-      tiles[tileStart[b] + j] = t;
+    if (blockIdx.x == 0) {
+      *numTiles2 = run;
     }
   }
-  for (int64_t p = threadIdx.x; p <= numParts; p += blockDim.x) {
+  blockSync();
+  const int64_t lanes = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const int64_t me = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const uint32_t totalTiles = tileStart[numBins1];
+  for (int64_t at = me; at < totalTiles; at += lanes) {
+    // the bucket of tile 'at': the last one that starts at or before it and is not empty
+    int lo = 0, hi = numBins1 - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (tileStart[mid] <= at) {
+        lo = mid;
+      } else {
+        hi = mid - 1;
+      }
+    }
+    const int b = lo;
+    const uint32_t j = static_cast<uint32_t>(at) - tileStart[b];
+    const uint64_t count = l1.count(b);
+    RadixTile t;
+    t.begin = l1.first(b) + static_cast<uint64_t>(j) * tileRecs;
+    const uint64_t left = count - static_cast<uint64_t>(j) * tileRecs;
+    t.count = static_cast<uint32_t>(left < tileRecs ? left : tileRecs);
+    t.cell = static_cast<uint32_t>(numBins2) * tileStart[b] + j;
+    t.stride = tileStart[b + 1] - tileStart[b];
+    t.pad = 0;
+    tiles[at] = t;
+  }
+  for (int64_t p = me; p <= numParts; p += lanes) {
     const int64_t b1 = p >> shift2;
     const uint32_t b2 = static_cast<uint32_t>(p & (numBins2 - 1));
     uint32_t cell;
@@ -3315,6 +3329,87 @@ __global__ __launch_bounds__(256) void k_collect(const uint64_t* table, uint64_t
       }
       base += popc64(m);
     }
+  }
+}
+
+// ---- first-seen order of many groups (config 4: 10^8 of them) -----------------------------------
+// rocPRIM's pair sort moves 12 bytes per entry four times (3.4 ms per 10^8 entries). The entries
+// are special: the keys are FIRST INPUT ROWS - distinct, because a row belongs to one group, and
+// below 2^bits (bits = those of the operator's input row count). So: pack an entry into one word
+// {group row : 32 | first row : 32} (k_fs_pack, in place; an entry no group owns - the holes of a
+// dense fold, key ~0 - gets a row number of its own behind the input, so that it sorts last and
+// the keys stay distinct), two MSD levels of 1024 bins with the radix path's own exact passes
+// (k_rp_tiles + k_rp_count2 + scan + k_rp_scatter2_sorted<1>: the first rows of random keys crowd
+// at the front of the input, regions of an even share would overflow), and then no third scatter:
+// a partition of the second level spans 2^(bits - 20) <= 4096 consecutive row numbers, so one wave
+// sets a bit per entry in an LDS bitmap and an entry's rank inside the partition is the number of
+// bits below its own (k_fs_rank). Measured at 10^8 entries: 3.1 ms (pack 0.4, levels 2 x 0.9, ranks
+// 0.7, tiles 0.1) against rocPRIM's 3.4 - the 8-byte scatters reach 2.3 TB/s only. (One level and a
+// workgroup per bin with the bin's whole 2^20-bit bitmap in LDS: 3.3 ms for the ranks alone - their
+// stores scatter over 4 MB per workgroup.)
+__global__ __launch_bounds__(256) void k_fs_pack(uint64_t* keys, const uint32_t* vals, uint64_t n, uint32_t firstFree) {
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const uint64_t first = keys[i];
+    // an entry no group owns: a row number of its own behind the input (its place in the list)
+    const uint32_t f = first >= firstFree ? firstFree + static_cast<uint32_t>(i) : static_cast<uint32_t>(first);
+    keys[i] = (static_cast<uint64_t>(vals[i]) << 32) | f;
+  }
+}
+
+__device__ inline void waveSync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int kFsMaxLowBits = 12;   // bitmap of one partition: 4096 bits = 64 words, one per lane
+
+__global__ __launch_bounds__(256) void k_fs_rank(const uint64_t* recs, const uint64_t* offsets, const uint32_t* partCell,
+                                                 int64_t numParts, int32_t lowBits, uint32_t* order, uint32_t* error) {
+  __shared__ unsigned long long bitmap[4][64];
+  __shared__ uint32_t below[4][64];
+  const int wave = threadIdx.x >> 6;
+  const int l = lane();
+  const int words = lowBits <= 6 ? 1 : 1 << (lowBits - 6);
+  const uint32_t lowMask = (1u << lowBits) - 1;
+  for (int64_t p = static_cast<int64_t>(blockIdx.x) * 4 + wave; p < numParts; p += static_cast<int64_t>(gridDim.x) * 4) {
+    const uint64_t begin = offsets[partCell[p]];
+    const uint64_t end = offsets[partCell[p + 1]];
+    if (begin == end) {
+      continue;  // uniform per wave
+    }
+    if (l < words) {
+      bitmap[wave][l] = 0;
+    }
+    waveSync();
+    for (uint64_t i = begin + l; i < end; i += 64) {
+      const uint32_t b = static_cast<uint32_t>(recs[i]) & lowMask;
+      const unsigned long long bit = 1ULL << (b & 63);
+      if (atomicOr(&bitmap[wave][b >> 6], bit) & bit) {
+        *error = 1;  // two entries with one first row: cannot happen
+      }
+    }
+    waveSync();
+    const uint32_t mine = l < words ? static_cast<uint32_t>(popc64(bitmap[wave][l])) : 0;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = __shfl_up(incl, off, kWave);
+      if (l >= off) {
+        incl += o;
+      }
+    }
+    below[wave][l] = incl - mine;
+    waveSync();
+    for (uint64_t i = begin + l; i < end; i += 64) {
+      const uint64_t w = recs[i];
+      const uint32_t b = static_cast<uint32_t>(w) & lowMask;
+      const uint64_t pos = begin + below[wave][b >> 6] +
+          static_cast<uint32_t>(popc64(bitmap[wave][b >> 6] & ((1ULL << (b & 63)) - 1)));
+      order[pos] = static_cast<uint32_t>(w >> 32);
+    }
+    waveSync();
   }
 }
 
@@ -5459,7 +5554,8 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
     h.rpMisc.ensure(64 + static_cast<size_t>(parts + 1) * 4 + 64);
     uint32_t* numTiles2 = h.rpMisc.as<uint32_t>();
     uint32_t* partCell = numTiles2 + 16;
-    VX_LAUNCH("k_rp_tiles", k_rp_tiles, 1, 1024, 0, level1, r.numBins, bins2, r.shift2, tileRecs,
+    VX_LAUNCH("k_rp_tiles", k_rp_tiles, static_cast<int>(std::max<uint64_t>(1, std::min<uint64_t>(64, parts >> 14))), 1024, 0,
+              level1, r.numBins, bins2, r.shift2, tileRecs,
               h.rpTiles.as<RadixTile>(), numTiles2, partCell, static_cast<int64_t>(parts));
     Radix2Args r2{};
     r2.in = h.rpRecs1.as<uint64_t>();
@@ -6522,6 +6618,84 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
   rt.sync();
 }
 
+// First-seen order of 'n' listed entries {orderKeys: first row, orderVals: group row} without
+// rocPRIM (see k_fs_pack): h.order <- group rows by ascending first row; 'holes' of the entries have
+// no group. false: not applicable (few entries, row numbers beyond 32 bits, switched off) - the
+// caller sorts with rocPRIM.
+bool sortFirstSeen(vx355_agg& h, size_t n, size_t holes) {
+  auto& rt = Runtime::get();
+  int64_t minEntries = 4LL << 20;
+  if (const char* e = std::getenv("VX355_AGG_OWN_SORT_MIN")) {
+    minEntries = std::strtoll(e, nullptr, 10);  // < 0: never
+  }
+  // row numbers: those of the input, then - if some entries have no group - one per place in the list
+  const uint64_t rows = static_cast<uint64_t>(std::max<int64_t>(1, h.inputRows)) + (holes ? n : 0);
+  const int bits = std::max(21, 64 - __builtin_clzll(static_cast<unsigned long long>(rows)));
+  if (minEntries < 0 || static_cast<int64_t>(n) < minEntries || bits > 20 + kFsMaxLowBits || !h.radixSorted) {
+    return false;
+  }
+  uint64_t* packed = h.orderKeys.as<uint64_t>();
+  uint64_t* tmp = static_cast<uint64_t*>(h.orderKeys2.ensure(n * 8 + 64));
+  uint32_t* order = static_cast<uint32_t*>(h.orderVals2.ensure(n * 4 + 64));
+  const uint32_t tileRecs = 65536;
+  const int64_t tiles1 = ceilDiv(static_cast<int64_t>(n), tileRecs);
+  const int64_t maxTiles2 = tiles1 + kSortBins;
+  const int64_t cells1 = static_cast<int64_t>(kSortBins) * tiles1;
+  const int64_t cells2 = static_cast<int64_t>(kSortBins) * maxTiles2;
+  const int64_t parts = static_cast<int64_t>(kSortBins) * kSortBins;
+  h.rpHist.ensure(static_cast<size_t>(std::max(cells1, cells2)) * 4 + 64);
+  uint64_t* offsets1 = static_cast<uint64_t*>(h.rpOffsets.ensure(static_cast<size_t>(cells1 + 1 + cells2 + 1) * 8 + 64));
+  uint64_t* offsets2 = offsets1 + cells1 + 1;
+  h.rpTiles.ensure(static_cast<size_t>(std::max(tiles1 + 1, maxTiles2)) * sizeof(RadixTile) + 64);
+  // [0..1] tile counts, [4] error flag, [8..11] the bounds of the one
+  // "bucket" of level 1, then the two partition -> cell maps
+  uint32_t* misc = static_cast<uint32_t*>(h.rpMisc.ensure(64 + static_cast<size_t>(kSortBins + 1 + parts + 1) * 4 + 64));
+  uint32_t* partCell1 = misc + 16;
+  uint32_t* partCell2 = partCell1 + kSortBins + 1;
+  const uint64_t bounds[2] = {0, static_cast<uint64_t>(n)};
+  HIP_OK(hipMemsetAsync(misc, 0, 64, rt.stream));
+  copyIn(misc + 8, bounds, VX355_MEM_HOST, 16);
+  VX_LAUNCH("k_fs_pack", k_fs_pack, streamGrid(static_cast<int64_t>(n), 256), 256, 0, packed, h.orderVals.as<uint32_t>(),
+            static_cast<uint64_t>(n), static_cast<uint32_t>(std::max<int64_t>(1, h.inputRows)));
+  Radix2Args r{};
+  r.tiles = h.rpTiles.as<RadixTile>();
+  r.recWords = 1;
+  r.numBins = kSortBins;
+  r.hist = h.rpHist.as<uint32_t>();
+  auto level = [&](const Level1Bins& from, int32_t numBins1, int64_t numParts, int64_t cells, uint32_t* numTiles,
+                   uint32_t* partCell, const uint64_t* in, uint64_t* out, uint64_t* offsets, int32_t shiftB, int64_t tiles) {
+    VX_LAUNCH("k_rp_tiles", k_rp_tiles, static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(64, numParts >> 14))), 1024, 0,
+              from, numBins1, kSortBins, 10, tileRecs, h.rpTiles.as<RadixTile>(),
+              numTiles, partCell, numParts);
+    r.in = in;
+    r.out = out;
+    r.numTiles = numTiles;
+    r.shiftB = shiftB;
+    r.offsets = offsets;
+    HIP_OK(hipMemsetAsync(r.hist, 0, static_cast<size_t>(cells) * 4, rt.stream));
+    const int grid = static_cast<int>(std::min<int64_t>(tiles, rt.numCUs * 2));
+    VX_LAUNCH("k_rp_count2", k_rp_count2, grid, 1024, 0, r);
+    scanU32ToU64(r.hist, cells, offsets, h.rpScan);
+    VX_LAUNCH("k_rp_scatter2", (k_rp_scatter2_sorted<1>), grid, kSortThreads, 0, r);
+  };
+  Level1Bins whole{};
+  whole.offsets1 = reinterpret_cast<const uint64_t*>(misc + 8);
+  whole.numTiles1 = 1;
+  level(whole, 1, kSortBins, cells1, misc, partCell1, packed, tmp, offsets1, bits - 10, tiles1);
+  Level1Bins bins1{};
+  bins1.offsets1 = offsets1;
+  bins1.numTiles1 = tiles1;
+  level(bins1, kSortBins, parts, cells2, misc + 1, partCell2, tmp, packed, offsets2, bits - 20, maxTiles2);
+  VX_LAUNCH("k_fs_rank", k_fs_rank, rt.numCUs * 8, 256, 0, packed, offsets2, partCell2, parts, bits - 20, order, misc + 4);
+  uint32_t error = 0;
+  copyOut(&error, VX355_MEM_HOST, misc + 4, 4);
+  if (error != 0) {
+    VX_THROW(VX355_EINTERNAL, "first-seen sort: two entries share a first input row");
+  }
+  h.order = order;
+  return true;
+}
+
 void finalize(vx355_agg& h) {
   auto& rt = Runtime::get();
   ensureBasics(h);
@@ -6589,12 +6763,16 @@ void finalize(vx355_agg& h) {
     h.numOutput = static_cast<int64_t>(g);
     return;
   }
+  // first rows are < inputRows: sort only the bits that can be set (a hole has all of them set, and
+  // inputRows - 1 has not)
+  const int bits = std::max(1, 64 - __builtin_clzll(static_cast<unsigned long long>(std::max<int64_t>(1, h.inputRows))));
+  if (sortFirstSeen(h, listLen, listLen - g)) {
+    h.numOutput = static_cast<int64_t>(g);
+    return;
+  }
   bool inTmp = false;
   sortPairsU64U32(h.orderKeys.as<uint64_t>(), h.orderVals.as<uint32_t>(), h.orderKeys2.as<uint64_t>(),
-                  h.orderVals2.as<uint32_t>(), listLen, h.sortTmp, &inTmp,
-                  // first rows are < inputRows: sort only the bits that can be set (a hole has all of
-                  // them set, and inputRows - 1 has not)
-                  std::max(1, 64 - __builtin_clzll(static_cast<unsigned long long>(std::max<int64_t>(1, h.inputRows)))));
+                  h.orderVals2.as<uint32_t>(), listLen, h.sortTmp, &inTmp, bits);
   rt.sync();
   h.order = inTmp ? h.orderVals2.as<uint32_t>() : h.orderVals.as<uint32_t>();
   h.numOutput = static_cast<int64_t>(g);
