@@ -3,6 +3,7 @@
 # passes (kernel trace with --stats; FETCH_SIZE and WRITE_SIZE in separate --kernel-trace-only runs, as
 # MI355X_MICROARCH.md prescribes), the RCCL self path under the kernel trace, smoke().
 cd "$GRAFT_REPO_ROOT" || exit 1
+( time timeout 1500 python -m pytest tests -x -q -m gpu ) > gpurun_out/r04_final_tests.log 2>&1; tail -3 gpurun_out/r04_final_tests.log
 O=gpurun_out/r04_final
 mkdir -p $O
 export TMPDIR=/tmp
@@ -30,17 +31,19 @@ run r04_bench_q1_unfused --unfused --no-secondary --no-traffic
 run r04_bench_q3_full_query --workload q3full --no-traffic
 run r04_bench_c4 --workload c4 --steps 3 --warmup 1
 run r04_bench_c4_unordered_output --workload c4 --c4-unordered --steps 3 --warmup 1 --no-traffic --no-cpu-baseline
-run r04_bench_c4_sparse_keys --workload c4 --c4-sparse --steps 3 --warmup 1 --no-traffic
+run r04_bench_c4_sparse_keys --workload c4 --c4-sparse --steps 3 --warmup 1
+run r04_bench_c4_sparse_keys_unordered_output --workload c4 --c4-sparse --c4-unordered --steps 3 --warmup 1 --no-traffic --no-cpu-baseline
 VX355_C5_CHUNKS=1 run r04_bench_c5_one_gpu --workload c5 --rows 200000000 --steps 5 --warmup 2 --no-traffic
 VX355_COMM_FORCE_RCCL=1 VX355_C5_CHUNKS=4 run r04_bench_c5_one_gpu_through_rccl --workload c5 --rows 200000000 --steps 3 --warmup 1 --no-traffic --no-cpu-baseline
 # rocprofv3
 R=$GRAFT_REPO_ROOT
 cd /tmp
-for wl in q1 q1x4 c1 c4; do
+for wl in q1 q1x4 c1 c4 c4s; do
   args="--steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-traffic"
   [ $wl = q1x4 ] && args="--workload q1x4 $args"
   [ $wl = c1 ] && args="--workload c1 --steps 50 --warmup 5 --no-cpu-baseline --no-traffic"
   [ $wl = c4 ] && args="--workload c4 --steps 2 --warmup 1 --no-cpu-baseline --no-traffic"
+  [ $wl = c4s ] && args="--workload c4 --c4-sparse --steps 2 --warmup 1 --no-cpu-baseline --no-traffic"
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_$wl/trace -- python $R/bench.py $args > $R/$O/prof_${wl}_trace.log 2>&1
   timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$O/prof_$wl/fetch -- python $R/bench.py $args > $R/$O/prof_${wl}_fetch.log 2>&1
   timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$O/prof_$wl/write -- python $R/bench.py $args > $R/$O/prof_${wl}_write.log 2>&1
