@@ -140,6 +140,19 @@ class HashAggregation {
 
 // PartitionedOutput's byte work (exec/PartitionedOutput.cpp:59-133): the rows of every destination
 // as PrestoPages. Returns the pages back to back; pageOffsets gets numPages + 1 entries.
+// wrapChild over an already wrapped vector (exec/OperatorUtils.cpp:393-422): out[i] = inner[outer[i]].
+inline void composeIndices(const int32_t* inner, int32_t innerSize, const int32_t* outer, int32_t numRows, int32_t* out,
+                           int32_t mem) {
+  check(vx355_compose_indices(inner, innerSize, outer, numRows, out, mem));
+}
+
+// GB/s of the library's read-only-stream (VX355_CEILING_READ) or copy (VX355_CEILING_COPY) kernel on this GPU.
+inline double hbmCeiling(int32_t kind, size_t bytes, int32_t iterations = 5) {
+  double gbps = 0;
+  check(vx355_hbm_ceiling(kind, bytes, iterations, &gbps));
+  return gbps;
+}
+
 inline std::vector<char> prestoSerialize(const vx355_batch& input, const int32_t* rows, int32_t rowsMem,
                                          const std::vector<int64_t>& offsets, int32_t flags,
                                          std::vector<int64_t>* pageOffsets) {
@@ -206,7 +219,7 @@ class HashBuild {
  public:
   HashBuild(std::vector<int32_t> keyChannels, std::vector<int32_t> keyTypes, std::vector<int32_t> dependentChannels,
             std::vector<int32_t> dependentTypes, vx355_join_type joinType = VX355_JOIN_INNER, bool nullAware = false,
-            bool nullAsValue = false)
+            bool nullAsValue = false, bool dropDuplicates = false /* HashJoinNode::canDropDuplicates */)
       : keyChannels_(std::move(keyChannels)),
         keyTypes_(std::move(keyTypes)),
         dependentChannels_(std::move(dependentChannels)),
@@ -221,6 +234,7 @@ class HashBuild {
     spec.join_type = joinType;
     spec.null_aware = nullAware ? 1 : 0;
     spec.null_as_value = nullAsValue ? 1 : 0;
+    spec.drop_duplicates = dropDuplicates ? 1 : 0;
     check(vx355_join_build_create(&spec, &handle_));
   }
   HashBuild(const HashBuild&) = delete;

@@ -145,6 +145,56 @@ int testAggregation() {
   return 0;
 }
 
+int testSemiJoinWithoutDuplicates() {
+  // HashBuild with dropDuplicates (HashBuild.cpp:517-548): a left semi join needs one build row per key; the
+  // table then has no duplicate chains, the probe lists every probe row with a match once. Plus the
+  // composition of two index vectors (wrapChild over a wrapped vector) on host memory.
+  std::mt19937_64 rng(5);
+  const int kBuild = 5000, kProbe = 7000;
+  std::vector<int64_t> bk(kBuild), pk(kProbe);
+  std::set<int64_t> keys;
+  for (auto& k : bk) {
+    k = rng() % 900;
+    keys.insert(k);
+  }
+  for (auto& k : pk) {
+    k = rng() % 1800;
+  }
+  vx355::HashBuild build({0}, {VX355_BIGINT}, {}, {}, VX355_JOIN_LEFT_SEMI_FILTER, false, false, /*dropDuplicates=*/true);
+  vx355_column bc = flat(VX355_BIGINT, bk.data());
+  build.addInput(vx355_batch{kBuild, 1, &bc});
+  vx355::JoinTable table = build.noMoreInput();
+  EXPECT(table.stats().has_duplicates == 0);
+  vx355::HashProbe probe(table, {0}, VX355_JOIN_LEFT_SEMI_FILTER);
+  vx355_column pc = flat(VX355_BIGINT, pk.data());
+  probe.addInput(vx355_batch{kProbe, 1, &pc});
+  std::vector<int32_t> got, mapping(1024), rows(1024);
+  for (;;) {
+    const int32_t n = probe.getOutput(1024, mapping.data(), rows.data());
+    if (n == 0) {
+      break;
+    }
+    got.insert(got.end(), mapping.begin(), mapping.begin() + n);
+  }
+  std::vector<int32_t> expected;
+  for (int p = 0; p < kProbe; ++p) {
+    if (keys.count(pk[p])) {
+      expected.push_back(p);
+    }
+  }
+  EXPECT(got == expected);
+  // indices of the semi join's output over a dictionary the probe side already carried
+  std::vector<int32_t> inner(kProbe), composed(got.size());
+  for (int i = 0; i < kProbe; ++i) {
+    inner[i] = (i * 7) % kProbe;
+  }
+  vx355::composeIndices(inner.data(), kProbe, got.data(), static_cast<int32_t>(got.size()), composed.data(), VX355_MEM_HOST);
+  for (size_t i = 0; i < got.size(); ++i) {
+    EXPECT(composed[i] == inner[got[i]]);
+  }
+  return 0;
+}
+
 int testJoin(vx355_join_type type) {
   // Two build drivers, duplicate and null keys, one payload column; inner / left / right / full.
   std::mt19937_64 rng(11);
@@ -480,6 +530,10 @@ int main() {
       return 1;
     }
     if (testDistinctAndPages()) {
+      return 1;
+    }
+    if (testSemiJoinWithoutDuplicates()) {
+      std::fprintf(stderr, "semi join over a build side without duplicates failed\n");
       return 1;
     }
     for (auto t : {VX355_JOIN_INNER, VX355_JOIN_LEFT, VX355_JOIN_RIGHT, VX355_JOIN_FULL}) {

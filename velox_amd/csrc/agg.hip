@@ -6664,7 +6664,7 @@ bool sortFirstSeen(vx355_agg& h, size_t n, size_t holes) {
   r.hist = h.rpHist.as<uint32_t>();
   auto level = [&](const Level1Bins& from, int32_t numBins1, int64_t numParts, int64_t cells, uint32_t* numTiles,
                    uint32_t* partCell, const uint64_t* in, uint64_t* out, uint64_t* offsets, int32_t shiftB, int64_t tiles) {
-    VX_LAUNCH("k_rp_tiles", k_rp_tiles, static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(64, numParts >> 14))), 1024, 0,
+    VX_LAUNCH("k_fs_tiles", k_rp_tiles, static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(64, numParts >> 14))), 1024, 0,
               from, numBins1, kSortBins, 10, tileRecs, h.rpTiles.as<RadixTile>(),
               numTiles, partCell, numParts);
     r.in = in;
@@ -6674,9 +6674,9 @@ bool sortFirstSeen(vx355_agg& h, size_t n, size_t holes) {
     r.offsets = offsets;
     HIP_OK(hipMemsetAsync(r.hist, 0, static_cast<size_t>(cells) * 4, rt.stream));
     const int grid = static_cast<int>(std::min<int64_t>(tiles, rt.numCUs * 2));
-    VX_LAUNCH("k_rp_count2", k_rp_count2, grid, 1024, 0, r);
+    VX_LAUNCH("k_fs_count", k_rp_count2, grid, 1024, 0, r);
     scanU32ToU64(r.hist, cells, offsets, h.rpScan);
-    VX_LAUNCH("k_rp_scatter2", (k_rp_scatter2_sorted<1>), grid, kSortThreads, 0, r);
+    VX_LAUNCH("k_fs_scatter", (k_rp_scatter2_sorted<1>), grid, kSortThreads, 0, r);
   };
   Level1Bins whole{};
   whole.offsets1 = reinterpret_cast<const uint64_t*>(misc + 8);
