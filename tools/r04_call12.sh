@@ -1,7 +1,7 @@
 #!/bin/bash
 # Where does k_rp_aggregate (hashed fold, config 4 with sparse keys) spend its time?
 cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r04l
+O=gpurun_out/r04w
 mkdir -p $O
 R=$GRAFT_REPO_ROOT
 export TMPDIR=/tmp
@@ -16,7 +16,7 @@ cd $R
 python tools/rocprof_summary.py $O/trace | head -30
 python - <<'PY'
 import csv, glob, collections
-for d in sorted(glob.glob('gpurun_out/r04l/pmc_*')):
+for d in sorted(glob.glob('gpurun_out/r04w/pmc_*')):
     for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         acc = collections.defaultdict(lambda: collections.defaultdict(float))
         cnt = collections.Counter()

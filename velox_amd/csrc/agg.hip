@@ -1508,7 +1508,7 @@ struct RadixAggArgs {
   // stores every one of its group rows completely - untouched words from 'pattern' - instead of
   // read-modify-write, and empty partitions are initialised on the way.
   int32_t virgin;
-  int32_t phase;                            // 0: owners only, 1: remaining slices of split partitions, -1: both
+  int32_t phase;                            // 0: the owners' launch, 1: the launch for the remaining slices of split partitions
   const uint64_t* pattern;                  // stride words of an empty group row
   int8_t ldsOfWord[2 + kMaxLdsAccs];        // word of the group row -> LDS word of the fold, -1 = none
   // (first input row, group row index) of every group this launch creates: finalize sorts these
@@ -1533,6 +1533,11 @@ struct RadixAggArgs {
   uint32_t* denseFlags;
   uint32_t denseChunk;
   uint32_t pad2;
+  // partitions folded in slices (more than sliceRecs records: skewed keys, few partitions): their
+  // owners list them here - [0] = how many, entries from [16] - and the launch for the other slices
+  // (phase 1) walks the list. (Every workgroup looking at every partition's range for them took
+  // 3.3 of the 16.3 ms of the hashed fold of 2^20 partitions.)
+  uint32_t* splitList;
 };
 
 // The accumulator plan of a fold, in registers: read from the kernel arguments ONCE with constant
@@ -1797,8 +1802,6 @@ __device__ inline void rpPartitionRange(const RadixAggArgs& r, int64_t p, uint64
 template <int W>
 __global__ __launch_bounds__(512) void k_rp_aggregate(RadixAggArgs r) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
-  __shared__ uint32_t bigList[512];
-  __shared__ uint32_t bigCount;
   __shared__ uint32_t scratch[2];
   RpFold f;
   f.plan = foldPlan(r);
@@ -1825,41 +1828,26 @@ __global__ __launch_bounds__(512) void k_rp_aggregate(RadixAggArgs r) {
       rpFoldFlush(f, r, p, !split || r.virgin != 0, true);
       if (split && threadIdx.x == 0) {
         r.counters->pairsBroken = 1;
+        r.splitList[16 + atomicAdd(&r.splitList[0], 1u)] = static_cast<uint32_t>(p);
       }
     }
   }
   if (r.phase == 0) {
     return;
   }
-  // Remaining slices of the split partitions.
-  for (int64_t p0 = 0; p0 < r.numParts; p0 += blockDim.x) {
-    if (threadIdx.x == 0) {
-      bigCount = 0;
+  // Remaining slices of the split partitions (a launch of its own: r.splitList is complete).
+  const uint32_t numSplit = r.splitList[0];
+  for (uint32_t k = 0; k < numSplit; ++k) {
+    const int64_t p = r.splitList[16 + k];
+    uint64_t begin, end;
+    rpPartitionRange(r, p, &begin, &end);
+    const uint64_t slices = (end - begin + r.sliceRecs - 1) / r.sliceRecs;
+    for (uint64_t s = 1 + blockIdx.x; s < slices; s += gridDim.x) {
+      const uint64_t b = begin + s * r.sliceRecs;
+      rpFoldInit(f, r);
+      rpFoldRecords<W>(f, r, b, b + r.sliceRecs < end ? b + r.sliceRecs : end);
+      rpFoldFlush(f, r, p, false, true);
     }
-    blockSync();
-    const int64_t mine = p0 + threadIdx.x;
-    if (mine < r.numParts) {
-      uint64_t begin, end;
-      rpPartitionRange(r, mine, &begin, &end);
-      if (end - begin > r.sliceRecs) {
-        bigList[atomicAdd(&bigCount, 1u)] = static_cast<uint32_t>(threadIdx.x);
-      }
-    }
-    blockSync();
-    const uint32_t n = bigCount;
-    for (uint32_t k = 0; k < n; ++k) {
-      const int64_t p = p0 + bigList[k];
-      uint64_t begin, end;
-      rpPartitionRange(r, p, &begin, &end);
-      const uint64_t slices = (end - begin + r.sliceRecs - 1) / r.sliceRecs;
-      for (uint64_t s = 1 + blockIdx.x; s < slices; s += gridDim.x) {
-        const uint64_t b = begin + s * r.sliceRecs;
-        rpFoldInit(f, r);
-        rpFoldRecords<W>(f, r, b, b + r.sliceRecs < end ? b + r.sliceRecs : end);
-        rpFoldFlush(f, r, p, false, true);
-      }
-    }
-    blockSync();
   }
 }
 
@@ -1915,6 +1903,16 @@ __device__ inline void hashFoldInit(const HashFold& f, const RadixAggArgs& r) {
     f.scratch[2] = 0;
   }
   blockSync();
+}
+
+// An entry a flush has read goes back to "free": the table is initialised once per launch, not
+// once per partition (a pass over all entries and a barrier less per fold).
+__device__ inline void hashFoldResetEntry(const HashFold& f, const RadixAggArgs& r, int e) {
+  f.keys[e] = kEmpty;
+  f.first[e] = 0xffffffffu;
+  for (int j = 0; j < f.A; ++j) {
+    f.acc[static_cast<size_t>(e) * f.A + j] = accIdentity(r.wordKind[j]);
+  }
 }
 
 // The operands of one record applied to a group row in HBM with atomics: what updateGlobal does.
@@ -2224,6 +2222,15 @@ __device__ inline void hashFoldFlush(const HashFold& f, const RadixAggArgs& r, b
       }
     }
   }
+#pragma unroll
+  for (int k = 0; k < kHashPerLane; ++k) {
+    if (key[k] != kEmpty) {
+      hashFoldResetEntry(f, r, k * 512 + threadIdx.x);
+    }
+  }
+  if (threadIdx.x == 0) {
+    f.scratch[2] = 0;
+  }
   blockSync();
 }
 
@@ -2310,20 +2317,23 @@ __device__ inline void hashFoldFlushDense(const HashFold& f, const RadixAggArgs&
     }
     const int e = k * 512 + threadIdx.x;
     const uint64_t idx = static_cast<uint64_t>(base) + before + rank[k];
-    if (idx >= r.denseCap) {
-      continue;  // counted: the host grows the array and folds again
+    if (idx < r.denseCap) {   // (beyond: counted - the host grows the array and folds again)
+      uint64_t* g = r.table + idx * r.stride;
+      const uint64_t first = r.rowBase + static_cast<uint64_t>(f.first[e]);
+      for (int x = 0; x < r.stride; ++x) {
+        const int j = r.ldsOfWord[x];
+        g[x] = x == 0 ? static_cast<uint64_t>(f.keys[e])
+                      : (x == 1 ? first : (j >= 0 ? f.acc[static_cast<size_t>(e) * A + j] : r.pattern[x]));
+      }
+      if (r.pairKeys != nullptr) {
+        r.pairKeys[r.pairBase + idx] = first;
+        r.pairVals[r.pairBase + idx] = static_cast<uint32_t>(idx);
+      }
     }
-    uint64_t* g = r.table + idx * r.stride;
-    const uint64_t first = r.rowBase + static_cast<uint64_t>(f.first[e]);
-    for (int x = 0; x < r.stride; ++x) {
-      const int j = r.ldsOfWord[x];
-      g[x] = x == 0 ? static_cast<uint64_t>(f.keys[e])
-                    : (x == 1 ? first : (j >= 0 ? f.acc[static_cast<size_t>(e) * A + j] : r.pattern[x]));
-    }
-    if (r.pairKeys != nullptr) {
-      r.pairKeys[r.pairBase + idx] = first;
-      r.pairVals[r.pairBase + idx] = static_cast<uint32_t>(idx);
-    }
+    hashFoldResetEntry(f, r, e);
+  }
+  if (threadIdx.x == 0) {
+    f.scratch[2] = 0;
   }
   blockSync();
 }
@@ -2331,8 +2341,6 @@ __device__ inline void hashFoldFlushDense(const HashFold& f, const RadixAggArgs&
 template <int W, bool DENSE>
 __global__ __launch_bounds__(512) void k_rp_aggregate_hashed(RadixAggArgs r) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
-  __shared__ uint32_t bigList[512];
-  __shared__ uint32_t bigCount;
   __shared__ uint32_t scratch[4];
   __shared__ uint32_t alloc[DA_WORDS];
   HashFold f;
@@ -2340,7 +2348,7 @@ __global__ __launch_bounds__(512) void k_rp_aggregate_hashed(RadixAggArgs r) {
   int parity = 0;
   uint32_t newGroups = 0;
   if (threadIdx.x < DA_WORDS) {
-    alloc[threadIdx.x] = 0;  // (the first fold's hashFoldInit ends with a barrier)
+    alloc[threadIdx.x] = 0;  // (hashFoldInit below ends with a barrier)
   }
   f.plan = foldPlan(r);
   f.S = r.hashSlots;
@@ -2354,13 +2362,14 @@ __global__ __launch_bounds__(512) void k_rp_aggregate_hashed(RadixAggArgs r) {
   f.acc = reinterpret_cast<uint64_t*>(f.keys + f.S);
   f.first = reinterpret_cast<uint32_t*>(f.acc + static_cast<size_t>(f.S) * f.A);
   f.scratch = scratch;
+  hashFoldInit(f, r);   // once: every flush leaves the table empty again
   // software pipeline over the workgroup's partitions: the first records of the next DEPTH partitions
   // are in flight, their ranges one partition further (DEPTH = 2 at 128 registers: the same 16.4 ms
   // for 10^9 three-word records - what bounds the loop is not the bytes in flight)
   constexpr int DEPTH = 1;
   const int64_t grid = gridDim.x;
   const int64_t pFirst = blockIdx.x;
-  const int64_t pEnd = r.numParts;
+  const int64_t pEnd = r.phase == 1 ? 0 : r.numParts;
   uint64_t rangeBegin[DEPTH + 1], rangeEnd[DEPTH + 1];
   uint64_t ahead[DEPTH][kHashAhead][W];
 #pragma unroll
@@ -2406,7 +2415,9 @@ __global__ __launch_bounds__(512) void k_rp_aggregate_hashed(RadixAggArgs r) {
     const bool split = end - begin > r.sliceRecs;
     const uint64_t stop = split ? begin + r.sliceRecs : end;
     const uint64_t base = static_cast<uint64_t>(p) << r.shiftB;
-    hashFoldInit(f, r);
+    if (split && threadIdx.x == 0) {
+      r.splitList[16 + atomicAdd(&r.splitList[0], 1u)] = static_cast<uint32_t>(p);
+    }
 #pragma unroll
     for (int u = 0; u < kHashAhead; ++u) {
       if (begin + u * 512 + threadIdx.x < stop) {
@@ -2424,39 +2435,23 @@ __global__ __launch_bounds__(512) void k_rp_aggregate_hashed(RadixAggArgs r) {
       hashFoldFlush(f, r, !split);
     }
   }
-  // Remaining slices of the split partitions (skewed keys): folded by all workgroups, flushed with atomics.
-  for (int64_t p0 = 0; p0 < r.numParts; p0 += blockDim.x) {
-    if (threadIdx.x == 0) {
-      bigCount = 0;
-    }
-    blockSync();
-    const int64_t mine = p0 + threadIdx.x;
-    if (mine < r.numParts) {
-      uint64_t begin, end;
-      rpPartitionRange(r, mine, &begin, &end);
-      if (end - begin > r.sliceRecs) {
-        bigList[atomicAdd(&bigCount, 1u)] = static_cast<uint32_t>(threadIdx.x);
+  // Remaining slices of the split partitions (skewed keys), in a launch of its own (r.splitList is
+  // complete): folded by all workgroups, flushed with atomics.
+  const uint32_t numSplit = r.phase == 1 ? r.splitList[0] : 0;
+  for (uint32_t q = 0; q < numSplit; ++q) {
+    const int64_t p = r.splitList[16 + q];
+    uint64_t begin, end;
+    rpPartitionRange(r, p, &begin, &end);
+    const uint64_t slices = (end - begin + r.sliceRecs - 1) / r.sliceRecs;
+    for (uint64_t sl = 1 + blockIdx.x; sl < slices; sl += gridDim.x) {
+      const uint64_t b = begin + sl * r.sliceRecs;
+      hashFoldRecords<W, DENSE>(f, r, p, b, b + r.sliceRecs < end ? b + r.sliceRecs : end);
+      if constexpr (DENSE) {
+        hashFoldFlushDense(f, r, false, &parity, &newGroups);
+      } else {
+        hashFoldFlush(f, r, false);
       }
     }
-    blockSync();
-    const uint32_t n = bigCount;
-    for (uint32_t q = 0; q < n; ++q) {
-      const int64_t p = p0 + bigList[q];
-      uint64_t begin, end;
-      rpPartitionRange(r, p, &begin, &end);
-      const uint64_t slices = (end - begin + r.sliceRecs - 1) / r.sliceRecs;
-      for (uint64_t sl = 1 + blockIdx.x; sl < slices; sl += gridDim.x) {
-        const uint64_t b = begin + sl * r.sliceRecs;
-        hashFoldInit(f, r);
-        hashFoldRecords<W, DENSE>(f, r, p, b, b + r.sliceRecs < end ? b + r.sliceRecs : end);
-        if constexpr (DENSE) {
-          hashFoldFlushDense(f, r, false, &parity, &newGroups);
-        } else {
-          hashFoldFlush(f, r, false);
-        }
-      }
-    }
-    blockSync();
   }
   if constexpr (DENSE) {
     // what is left of the workgroup's last block stays empty; its groups are counted once
@@ -3953,7 +3948,7 @@ struct vx355_agg {
   int scratchBlocksPerCu = 2;  // VX355_AGG_SCRATCH_BLOCKS_PER_CU: workgroups (= copies) per CU of a scratch-flush launch
   int64_t scratchMinAtomics = 256 << 10;  // VX355_AGG_SCRATCH_MIN_ATOMICS: flushes below this many HBM atomics keep them
   // radix-partitioned path (high cardinality)
-  DevBuf rpRecs1, rpRecs2, rpHist, rpOffsets, rpTiles, rpMisc, rpScan, rpLayout2, rpLayout1;
+  DevBuf rpRecs1, rpRecs2, rpHist, rpOffsets, rpTiles, rpMisc, rpScan, rpLayout2, rpLayout1, rpSplit;
   bool radixOptimistic = true;  // VX355_AGG_RADIX_OPTIMISTIC=0: level 2 always counts first
   bool radixOptimistic1 = true;  // VX355_AGG_RADIX_OPTIMISTIC1=0: level 1 always counts first (k_rp_count1)
   int64_t radixRedone = 0;      // level-2 passes redone exactly after a region overflowed
@@ -5663,6 +5658,8 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
     g.recs = h.rpRecs2.as<uint64_t>();
   }
   g.numParts = static_cast<int64_t>(parts);
+  g.splitList = static_cast<uint32_t*>(h.rpSplit.ensure((16 + static_cast<size_t>(parts)) * 4 + 64));
+  HIP_OK(hipMemsetAsync(g.splitList, 0, 64, rt.stream));
   g.recWords = r.recWords;
   g.numAccs = a.numAccs;
   g.shiftB = r.shiftB;
@@ -5756,16 +5753,20 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
   const int gridA = rt.numCUs * std::max(1, perCu);
   if (hashed) {
     auto fold = [&]() {
-      byWidth([&](auto wTag) {
-        constexpr int W = decltype(wTag)::value;
-        if constexpr (W >= 2) {
-          if (dense) {
-            VX_LAUNCH("k_rp_aggregate", (k_rp_aggregate_hashed<W, true>), gridA, 512, ldsBytes, g);
-          } else {
-            VX_LAUNCH("k_rp_aggregate", (k_rp_aggregate_hashed<W, false>), gridA, 512, ldsBytes, g);
+      HIP_OK(hipMemsetAsync(g.splitList, 0, 64, rt.stream));
+      for (int phase = 0; phase < 2; ++phase) {   // the owners, then the other slices of split partitions
+        g.phase = phase;
+        byWidth([&](auto wTag) {
+          constexpr int W = decltype(wTag)::value;
+          if constexpr (W >= 2) {
+            if (dense) {
+              VX_LAUNCH("k_rp_aggregate", (k_rp_aggregate_hashed<W, true>), gridA, 512, ldsBytes, g);
+            } else {
+              VX_LAUNCH("k_rp_aggregate", (k_rp_aggregate_hashed<W, false>), gridA, 512, ldsBytes, g);
+            }
           }
-        }
-      });
+        });
+      }
     };
     fold();
     ++h.radixLaunches;
@@ -5835,24 +5836,18 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
     h.pairHoles = 0;
     return;
   }
-  if (g.virgin) {
-    // owners store complete rows; the other slices of split partitions wait for the launch boundary
-    g.phase = 0;
-    byWidth([&](auto wTag) {
-      VX_LAUNCH("k_rp_aggregate", (k_rp_aggregate<decltype(wTag)::value>), gridA, 512, ldsBytes, g);
-    });
-    g.phase = 1;
-    g.virgin = 0;
-    byWidth([&](auto wTag) {
-      VX_LAUNCH("k_rp_aggregate", (k_rp_aggregate<decltype(wTag)::value>), gridA, 512, ldsBytes, g);
-    });
-    h.tableVirgin = false;
-  } else {
-    g.phase = -1;
-    byWidth([&](auto wTag) {
-      VX_LAUNCH("k_rp_aggregate", (k_rp_aggregate<decltype(wTag)::value>), gridA, 512, ldsBytes, g);
-    });
-  }
+  // Two launches: the owners of the partitions (a virgin table: they store complete rows), then the
+  // other slices of the partitions the owners listed as split (nothing to do for evenly spread keys).
+  g.phase = 0;
+  byWidth([&](auto wTag) {
+    VX_LAUNCH("k_rp_aggregate", (k_rp_aggregate<decltype(wTag)::value>), gridA, 512, ldsBytes, g);
+  });
+  g.phase = 1;
+  g.virgin = 0;
+  byWidth([&](auto wTag) {
+    VX_LAUNCH("k_rp_aggregate", (k_rp_aggregate<decltype(wTag)::value>), gridA, 512, ldsBytes, g);
+  });
+  h.tableVirgin = false;
   ++h.radixLaunches;
 }
 
