@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r04y
+O=gpurun_out/r04za
 mkdir -p $O
 timeout 1200 python -m pytest tests/test_gpu_agg.py tests/test_cpp_consumer.py -x -q -m gpu -k "radix or hashed_folds or dense_folds or first_seen or cpp or operator" 2>&1 | tail -3
 b() { name=$1; shift; timeout 600 python bench.py "$@" --steps 3 --warmup 1 --no-traffic --no-cpu-baseline --no-secondary 2> $O/$name.err | grep '^{"metric"' > $O/$name.json

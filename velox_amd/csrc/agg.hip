@@ -1780,6 +1780,17 @@ __device__ inline void rpFoldFlush(const RpFold& f, const RadixAggArgs& r, int64
       }
     }
   }
+  if (hasRecords) {
+    // the groups go back to "nothing seen": the block is initialised once per launch, not per partition
+    for (int g = threadIdx.x; g < f.B; g += blockDim.x) {
+      if (f.first[g] != 0xffffffffu) {
+        f.first[g] = 0xffffffffu;
+        for (int j = 0; j < f.A; ++j) {
+          f.acc[static_cast<size_t>(g) * f.A + j] = accIdentity(r.wordKind[j]);
+        }
+      }
+    }
+  }
   blockSync();  // the LDS block is reused by the next partition
 }
 
@@ -1810,6 +1821,7 @@ __global__ __launch_bounds__(512) void k_rp_aggregate(RadixAggArgs r) {
   f.acc = reinterpret_cast<uint64_t*>(ldsRaw);                                       // [B][A]
   f.first = reinterpret_cast<uint32_t*>(f.acc + static_cast<size_t>(f.B) * f.A);   // [B]
   f.scratch = scratch;
+  rpFoldInit(f, r);   // once: every flush leaves the block as it found it
   if (r.phase != 1) {
     for (int64_t p = blockIdx.x; p < r.numParts; p += gridDim.x) {
       uint64_t begin, end;
@@ -1821,7 +1833,6 @@ __global__ __launch_bounds__(512) void k_rp_aggregate(RadixAggArgs r) {
         continue;
       }
       const bool split = end - begin > r.sliceRecs;
-      rpFoldInit(f, r);
       rpFoldRecords<W>(f, r, begin, split ? begin + r.sliceRecs : end);
       // the owner of a split partition of a virgin table stores complete rows like any owner: the
       // other slices run in the next launch (phase 1), behind the launch boundary
@@ -1844,7 +1855,6 @@ __global__ __launch_bounds__(512) void k_rp_aggregate(RadixAggArgs r) {
     const uint64_t slices = (end - begin + r.sliceRecs - 1) / r.sliceRecs;
     for (uint64_t s = 1 + blockIdx.x; s < slices; s += gridDim.x) {
       const uint64_t b = begin + s * r.sliceRecs;
-      rpFoldInit(f, r);
       rpFoldRecords<W>(f, r, b, b + r.sliceRecs < end ? b + r.sliceRecs : end);
       rpFoldFlush(f, r, p, false, true);
     }
@@ -1978,8 +1988,12 @@ __device__ inline void hashFoldRecord(const HashFold& f, const RadixAggArgs& r, 
   const uint32_t mask = static_cast<uint32_t>(w0 >> (fp.keyBits + fp.rowBits));
   // home slot inside the partition, scaled into the LDS table (both sizes are powers of two)
   int pos = static_cast<int>((((w0 & ((1ULL << fp.keyBits) - 1)) - base) << f.posUp) >> f.posDown);
+  uint32_t seenFirst = 0xffffffffu;
   for (int probes = 0;; ++probes) {
     const unsigned long long k = f.keys[pos];
+    // read with the key, not behind it (one LDS round trip less per record); only a filter for the
+    // atomic below: a stale value is too high, never too low
+    seenFirst = f.first[pos];
     if (k == key) {
       break;
     }
@@ -2000,7 +2014,7 @@ __device__ inline void hashFoldRecord(const HashFold& f, const RadixAggArgs& r, 
     hashFoldDirect<W, DENSE>(r, w, key, row, mask);
     return;
   }
-  if (f.first[pos] > row) {
+  if (seenFirst > row) {
     atomicMin(&f.first[pos], row);
   }
   foldAccumulate<W>(fp, f.acc + static_cast<size_t>(pos) * f.A, w, mask, r.counters);
