@@ -1,8 +1,8 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r04zb
+O=gpurun_out/r04ze
 mkdir -p $O
-timeout 1200 python -m pytest tests/test_gpu_agg.py tests/test_cpp_consumer.py -x -q -m gpu -k "radix or hashed_folds or dense_folds or first_seen or cpp or operator" 2>&1 | tail -3
+timeout 1200 python -m pytest tests/test_gpu_agg.py -x -q -m gpu -k "radix or hashed_folds or dense_folds or first_seen" 2>&1 | tail -3
 b() { name=$1; shift; timeout 600 python bench.py "$@" --steps 3 --warmup 1 --no-traffic --no-cpu-baseline --no-secondary 2> $O/$name.err | grep '^{"metric"' > $O/$name.json
 python - <<PY
 import json
@@ -13,6 +13,6 @@ except Exception as e:
     print("$name FAILED", e)
 PY
 }
-b c4s --workload c4 --c4-sparse
-b c4s_again --workload c4 --c4-sparse
 b c4 --workload c4
+b c4_again --workload c4
+b c4s --workload c4 --c4-sparse
