@@ -66,6 +66,9 @@ def parse():
                     help="q1 at N = 1: skip the Q3 SF100 join block (the other half of BASELINE's metric)")
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the rocprofv3 FETCH_SIZE / WRITE_SIZE passes behind roofline.traffic")
+    ap.add_argument("--counter-child", action="store_true",
+                    help="(internal) a child run under rocprofv3 --pmc: the timed steps only, no second pass with "
+                         "the profiler's events - every dispatch of the run belongs to one of the --steps steps")
     ap.add_argument("--secondary-steps", type=int, default=5)
     ap.add_argument("--secondary", default="",
                     help="comma-separated keys of the secondary blocks to run (default: all of bench.SECONDARY)")
@@ -1103,7 +1106,8 @@ def measure_traffic(child_flags, kernel, steps=1):
         tmp = tempfile.mkdtemp(prefix="vx355_pmc_", dir="/tmp")
         cmd = [tool, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", tmp, "--",
                sys.executable, os.path.abspath(__file__)] + child_flags + [
-                   "--steps", str(steps), "--warmup", "0", "--no-cpu-baseline", "--no-secondary", "--no-traffic"]
+                   "--steps", str(steps), "--warmup", "0", "--no-cpu-baseline", "--no-secondary", "--no-traffic",
+                   "--counter-child"]
         env = dict(os.environ, TMPDIR="/tmp")
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
@@ -1301,6 +1305,8 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         ops.profile_reset()
+        if args.counter_child:
+            return dt, {}
         ops.profile_enable(True)
         for _ in range(steps):
             step_fn()

@@ -1331,7 +1331,7 @@ __global__ __launch_bounds__(1024) void k_rp_scatter2(Radix2Args r) {
 
 // Level 2 with sorted sub-tiles (numBins <= kSortBins).
 template <int W>
-__global__ __launch_bounds__(kSortThreads) void k_rp_scatter2_sorted(Radix2Args r) {
+__device__ inline void rpScatter2SortedBody(const Radix2Args& r) {
   __shared__ SortLds<W> l;
   constexpr int R = SortLds<W>::kRounds;
   const uint32_t numTiles = *r.numTiles;
@@ -1361,6 +1361,17 @@ __global__ __launch_bounds__(kSortThreads) void k_rp_scatter2_sorted(Radix2Args 
                          [&](uint64_t w0) { return (static_cast<uint32_t>(w0) >> r.shiftB) & binMask; });
     }
   }
+}
+
+template <int W>
+__global__ __launch_bounds__(kSortThreads) void k_rp_scatter2_sorted(Radix2Args r) {
+  rpScatter2SortedBody<W>(r);
+}
+
+// The same pass over the packed 8-byte entries of the first-seen sort (see k_fs_pack), under a name of
+// its own: profiles and counters of the radix path's level 2 stay its own.
+__global__ __launch_bounds__(kSortThreads) void k_fs_scatter(Radix2Args r) {
+  rpScatter2SortedBody<1>(r);
 }
 
 // ---- optimistic level 2: no counting pass -----------------------------------------------------
@@ -6699,7 +6710,7 @@ bool sortFirstSeen(vx355_agg& h, size_t n, size_t holes) {
     const int grid = static_cast<int>(std::min<int64_t>(tiles, rt.numCUs * 2));
     VX_LAUNCH("k_fs_count", k_rp_count2, grid, 1024, 0, r);
     scanU32ToU64(r.hist, cells, offsets, h.rpScan);
-    VX_LAUNCH("k_fs_scatter", (k_rp_scatter2_sorted<1>), grid, kSortThreads, 0, r);
+    VX_LAUNCH("k_fs_scatter", k_fs_scatter, grid, kSortThreads, 0, r);
   };
   Level1Bins whole{};
   whole.offsets1 = reinterpret_cast<const uint64_t*>(misc + 8);
