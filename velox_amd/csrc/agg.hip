@@ -1676,6 +1676,24 @@ __device__ inline void rpFoldRecords(const RpFold& f, const RadixAggArgs& r, uin
   blockSync();
 }
 
+// A complete group row stored: pairs of words as 16-byte stores when the stride is even (rows are
+// then 16-byte aligned: four 8-byte stores per 32-byte row made the fold write 8.7 GB for 5.5).
+template <typename WordFn>
+__device__ inline void storeRowWords(uint64_t* row, int stride, WordFn&& word) {
+  if ((stride & 1) == 0) {
+    for (int w = 0; w < stride; w += 2) {
+      RpU64x2 v;
+      v.x = word(w);
+      v.y = word(w + 1);
+      *reinterpret_cast<RpU64x2*>(row + w) = v;
+    }
+  } else {
+    for (int w = 0; w < stride; ++w) {
+      row[w] = word(w);
+    }
+  }
+}
+
 // One group of a fold added into its group row (see rpFoldFlush); true = the group is new.
 __device__ inline bool rpFlushGroup(const RpFold& f, const RadixAggArgs& r, int g, uint64_t base, bool virgin,
                                     bool exclusive, bool hasRecords) {
@@ -1686,14 +1704,14 @@ __device__ inline bool rpFlushGroup(const RpFold& f, const RadixAggArgs& r, int 
   bool isNew = false;
   if (virgin) {
     isNew = fr != 0xffffffffu;
-    for (int w = 0; w < r.stride; ++w) {
+    storeRowWords(row, r.stride, [&](int w) {
       uint64_t v = r.pattern[w];
       if (isNew) {
         const int j = r.ldsOfWord[w];
         v = w == 1 ? mine : (j >= 0 ? f.acc[static_cast<size_t>(g) * A + j] : v);
       }
-      row[w] = v;
-    }
+      return v;
+    });
   } else if (fr == 0xffffffffu) {
     // nothing for this group
   } else if (!exclusive) {
@@ -2273,9 +2291,7 @@ enum { DA_CURSOR = 0, DA_LIMIT = 2, DA_WAVES = 4, DA_START = 12, DA_WORDS = 16 }
 __device__ inline void denseFillHoles(const RadixAggArgs& r, uint32_t from, uint32_t to) {
   for (uint64_t i = static_cast<uint64_t>(from) + threadIdx.x; i < to && i < r.denseCap; i += blockDim.x) {
     uint64_t* g = r.table + i * r.stride;
-    for (int x = 0; x < r.stride; ++x) {
-      g[x] = r.pattern[x];
-    }
+    storeRowWords(g, r.stride, [&](int x) { return r.pattern[x]; });
     if (r.pairKeys != nullptr) {
       r.pairKeys[r.pairBase + i] = ~0ULL;
       r.pairVals[r.pairBase + i] = 0;
@@ -2345,11 +2361,11 @@ __device__ inline void hashFoldFlushDense(const HashFold& f, const RadixAggArgs&
     if (idx < r.denseCap) {   // (beyond: counted - the host grows the array and folds again)
       uint64_t* g = r.table + idx * r.stride;
       const uint64_t first = r.rowBase + static_cast<uint64_t>(f.first[e]);
-      for (int x = 0; x < r.stride; ++x) {
+      storeRowWords(g, r.stride, [&](int x) {
         const int j = r.ldsOfWord[x];
-        g[x] = x == 0 ? static_cast<uint64_t>(f.keys[e])
+        return x == 0 ? static_cast<uint64_t>(f.keys[e])
                       : (x == 1 ? first : (j >= 0 ? f.acc[static_cast<size_t>(e) * A + j] : r.pattern[x]));
-      }
+      });
       if (r.pairKeys != nullptr) {
         r.pairKeys[r.pairBase + idx] = first;
         r.pairVals[r.pairBase + idx] = static_cast<uint32_t>(idx);
@@ -3633,7 +3649,23 @@ __global__ __launch_bounds__(256) void k_extract(ExtractArgs a) {
     gi = a.global ? 0 : a.order[a.begin + pos];
   }
   const uint64_t* g = a.table + gi * a.stride;
-  const uint64_t key = a.mode == MODE_NORMALIZED ? (active ? g[0] : 0) : gi;
+  // Four-word group rows (key, first row, one DOUBLE sum: config 4) are read as two 16-byte loads, up
+  // front: with 10^8 groups every row is a random line of HBM, and reading its key word here and its
+  // accumulator words a few hundred instructions later fetched the line twice (27.6 GB for 10^8
+  // sparse groups where the direct-index table, whose key is the row number, fetched 14.8).
+  const bool rowInRegisters = a.stride == 4;
+  RpU64x2 rowLo{0, 0}, rowHi{0, 0};
+  if (rowInRegisters && active) {
+    rowLo = reinterpret_cast<const RpU64x2*>(g)[0];
+    rowHi = reinterpret_cast<const RpU64x2*>(g)[1];
+  }
+  auto word = [&](int x) -> uint64_t {
+    if (!rowInRegisters) {
+      return g[x];
+    }
+    return x == 0 ? rowLo.x : (x == 1 ? rowLo.y : (x == 2 ? rowHi.x : rowHi.y));
+  };
+  const uint64_t key = a.mode == MODE_NORMALIZED ? (active ? word(0) : 0) : gi;
   for (int k = 0; k < a.numKeys; ++k) {
     const OutKey& ok = a.keys[k];
     if (ok.values == nullptr) {
@@ -3700,8 +3732,8 @@ __global__ __launch_bounds__(256) void k_extract(ExtractArgs a) {
   }
   for (int j = 0; j < a.numAggs; ++j) {
     const OutAgg& oa = a.aggs[j];
-    const uint64_t mainWord = active ? g[oa.mainOff] : 0;
-    uint64_t seen = (active && oa.seenOff >= 0) ? g[oa.seenOff] : 1;
+    const uint64_t mainWord = active ? word(oa.mainOff) : 0;
+    uint64_t seen = (active && oa.seenOff >= 0) ? word(oa.seenOff) : 1;
     if (oa.seenOff == 1) {
       seen = seen != kNoRow ? 1 : 0;
     }
@@ -3721,13 +3753,13 @@ __global__ __launch_bounds__(256) void k_extract(ExtractArgs a) {
           if (inInt) {
             // the 128-bit total must fit int64: high word = sign extension of the low word
             if (valid && oa.loOff >= 0 &&
-                static_cast<int64_t>(g[oa.loOff]) != (static_cast<int64_t>(mainWord) < 0 ? -1 : 0)) {
+                static_cast<int64_t>(word(oa.loOff)) != (static_cast<int64_t>(mainWord) < 0 ? -1 : 0)) {
               *a.overflow = 1;
             }
             static_cast<int64_t*>(oa.values)[pos] = valid ? static_cast<int64_t>(mainWord) : 0;
           } else {
             double d = valid ? __longlong_as_double(static_cast<long long>(mainWord)) +
-                    __longlong_as_double(static_cast<long long>(g[oa.loOff]))
+                    __longlong_as_double(static_cast<long long>(word(oa.loOff)))
                              : 0.0;
             if (oa.inputType == VX355_REAL && oa.finalOut) {
               static_cast<float*>(oa.values)[pos] = static_cast<float>(d);
@@ -3753,7 +3785,7 @@ __global__ __launch_bounds__(256) void k_extract(ExtractArgs a) {
       default: {  // AVG
         writeBit(oa.nulls, pos, valid);
         const double sum = __longlong_as_double(static_cast<long long>(mainWord)) +
-            (active ? __longlong_as_double(static_cast<long long>(g[oa.loOff])) : 0.0);
+            (active ? __longlong_as_double(static_cast<long long>(word(oa.loOff))) : 0.0);
         const int64_t cnt = static_cast<int64_t>(seen);
         if (oa.finalOut) {
           if (active) {
