@@ -1,5 +1,6 @@
 // See Vx355Adapter.h. Compiled on the Velox side only.
 #include "Vx355Adapter.h"
+#include "Vx355JoinAdapter.h"
 
 #include <algorithm>
 #include <string>
@@ -120,7 +121,7 @@ std::shared_ptr<const core::PlanNode> planNodeOf(const exec::DriverFactory& fact
 }
 
 bool adapt(const exec::DriverFactory& factory, exec::Driver& driver) {
-  bool replaced = false;
+  bool replaced = adaptJoins(factory, driver);  // HashBuild / HashProbe: Vx355JoinAdapter.cpp
   auto operators = driver.operators();
   for (int32_t i = 0; i < static_cast<int32_t>(operators.size()); ++i) {
     auto* aggregation = dynamic_cast<exec::HashAggregation*>(operators[i]);
@@ -199,6 +200,18 @@ OutColumns::OutColumns(RowVector& result) {
     col.values = child->values() ? child->values()->asMutable<void>() : nullptr;  // flat scalar children of the result
     col.nulls = child->mutableRawNulls();
     columns_.push_back(col);
+  }
+}
+
+void ownStrings(const VectorPtr& column, vector_size_t numRows) {
+  if (column->typeKind() != TypeKind::VARCHAR && column->typeKind() != TypeKind::VARBINARY) {
+    return;
+  }
+  auto* flat = column->asFlatVector<StringView>();
+  for (vector_size_t i = 0; i < numRows; ++i) {
+    if (!flat->isNullAt(i) && !flat->valueAt(i).isInline()) {
+      flat->set(i, flat->valueAt(i));  // copies the bytes into a string buffer of the vector
+    }
   }
 }
 
@@ -301,6 +314,9 @@ RowVectorPtr Vx355HashAggregation::getOutput() {
   }
   if (numRows == 0) {
     return nullptr;
+  }
+  for (auto& child : result->children()) {
+    ownStrings(child, numRows);
   }
   result->resize(numRows);
   return result;

@@ -1,5 +1,6 @@
-// Velox-side adapter of libvx355: replaces exec::HashAggregation in a Driver by an operator that
-// runs on the MI355X through the C ABI of include/vx355.h. Built on the VELOX side (this
+// Velox-side adapter of libvx355: replaces exec::HashAggregation (this file) and exec::HashBuild /
+// exec::HashProbe (Vx355JoinAdapter.h) in a Driver by operators that run on the MI355X through the C
+// ABI of include/vx355.h. Built on the VELOX side (this
 // repository has no Velox to compile against): add shim/ to a Velox build with
 // shim/CMakeLists.txt and call facebook::velox::vx355::registerVx355() once per process, before
 // the first Task starts.
@@ -19,9 +20,9 @@
 
 namespace facebook::velox::vx355 {
 
-/// Registers the adapter: every Driver created afterwards has its HashAggregation operators
-/// replaced where libvx355 supports the plan (vx355_agg_create succeeds); everything else stays on
-/// the CPU operators. device: the GPU of this process (one process per GPU).
+/// Registers the adapter: every Driver created afterwards has its HashAggregation, HashBuild and
+/// HashProbe operators replaced where libvx355 supports the plan (the create call succeeds);
+/// everything else stays on the CPU operators. device: the GPU of this process (one process per GPU).
 void registerVx355(int device = 0);
 
 /// A RowVector reduced to what DecodedVector exposes per child: the vx355_batch of one addInput.
@@ -54,6 +55,10 @@ class OutColumns {
  private:
   std::vector<vx355_out_column> columns_;
 };
+
+/// VARCHAR / VARBINARY columns the library filled: views of more than 12 bytes point into a buffer the
+/// handle only keeps until its next output call - copy those strings into the vector's own buffers.
+void ownStrings(const VectorPtr& column, vector_size_t numRows);
 
 /// exec::HashAggregation on the GPU (exec/HashAggregation.h). Input batches are queued through the
 /// asynchronous boundary (vx355_agg_add_input_async): the Driver thread does not wait for staging

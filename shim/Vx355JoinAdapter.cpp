@@ -1,0 +1,466 @@
+// See Vx355JoinAdapter.h. Compiled on the Velox side only.
+#include "Vx355JoinAdapter.h"
+
+#include <algorithm>
+
+#include "velox/core/QueryConfig.h"
+#include "velox/exec/HashBuild.h"
+#include "velox/exec/HashProbe.h"
+#include "velox/exec/OperatorUtils.h"
+#include "velox/exec/Task.h"
+#include "velox/vector/FlatVector.h"
+
+namespace facebook::velox::vx355 {
+
+namespace {
+
+void check(int status) {
+  if (status == VX355_OK) {
+    return;
+  }
+  if (status == VX355_EUSER) {
+    VELOX_USER_FAIL("{}", vx355_last_error());
+  }
+  VELOX_FAIL("{}", vx355_last_error());
+}
+
+// TypeKind values equal vx355_type_kind (type/TypeKind.h:41-52); DATE is INTEGER.
+bool scalarKind(TypeKind kind) {
+  switch (kind) {
+    case TypeKind::BOOLEAN:
+    case TypeKind::TINYINT:
+    case TypeKind::SMALLINT:
+    case TypeKind::INTEGER:
+    case TypeKind::BIGINT:
+    case TypeKind::REAL:
+    case TypeKind::DOUBLE:
+    case TypeKind::VARCHAR:
+    case TypeKind::VARBINARY:
+    case TypeKind::TIMESTAMP:
+      return true;
+    default:
+      return false;
+  }
+}
+
+Vx355JoinTables::Key keyOf(exec::DriverCtx* ctx, const core::PlanNodeId& id) {
+  return {ctx->task->taskId(), ctx->splitGroupId, id};
+}
+
+std::shared_ptr<const core::HashJoinNode> joinNodeOf(const exec::DriverFactory& factory, const core::PlanNodeId& id) {
+  for (const auto& node : factory.planNodes) {
+    if (node->id() == id) {
+      return std::dynamic_pointer_cast<const core::HashJoinNode>(node);
+    }
+  }
+  // the build pipeline ends in the join node: it is that pipeline's consumer
+  if (factory.consumerNode && factory.consumerNode->id() == id) {
+    return std::dynamic_pointer_cast<const core::HashJoinNode>(factory.consumerNode);
+  }
+  return nullptr;
+}
+
+}  // namespace
+
+// ---- rendezvous --------------------------------------------------------------------------------
+
+Vx355JoinTables& Vx355JoinTables::instance() {
+  static Vx355JoinTables tables;
+  return tables;
+}
+
+void Vx355JoinTables::addProbe(const Key& key) {
+  std::lock_guard<std::mutex> l(mutex_);
+  ++entries_[key].probes;
+}
+
+void Vx355JoinTables::removeProbe(const Key& key) {
+  vx355_join_table* release = nullptr;
+  {
+    std::lock_guard<std::mutex> l(mutex_);
+    auto it = entries_.find(key);
+    if (it == entries_.end() || --it->second.probes > 0) {
+      return;
+    }
+    release = it->second.table;
+    entries_.erase(it);
+  }
+  if (release != nullptr) {
+    vx355_join_table_release(release);
+  }
+}
+
+vx355_join_table* Vx355JoinTables::tableOrFuture(const Key& key, ContinueFuture* future) {
+  std::lock_guard<std::mutex> l(mutex_);
+  auto& entry = entries_[key];
+  if (entry.table != nullptr) {
+    return entry.table;
+  }
+  entry.promises.emplace_back("Vx355JoinTables::tableOrFuture");
+  *future = entry.promises.back().getSemiFuture();
+  return nullptr;
+}
+
+void Vx355JoinTables::publish(const Key& key, vx355_join_table* table) {
+  std::vector<ContinuePromise> promises;
+  {
+    std::lock_guard<std::mutex> l(mutex_);
+    auto& entry = entries_[key];
+    entry.table = table;
+    promises = std::move(entry.promises);
+  }
+  for (auto& promise : promises) {
+    promise.setValue();
+  }
+}
+
+// ---- plan --------------------------------------------------------------------------------------
+
+bool toJoinPlan(const core::HashJoinNode& node, JoinPlan* out) {
+  if (node.filter() != nullptr) {
+    // conjunctions of up to four comparisons could be handed to
+    // vx355_join_probe_set_filter; this adapter leaves joins with a filter on the CPU
+    return false;
+  }
+  const auto& probeType = node.sources()[0]->outputType();
+  const auto& buildType = node.sources()[1]->outputType();
+  for (size_t i = 0; i < node.leftKeys().size(); ++i) {
+    const auto probeChannel = exec::exprToChannel(node.leftKeys()[i].get(), probeType);
+    const auto buildChannel = exec::exprToChannel(node.rightKeys()[i].get(), buildType);
+    if (probeChannel == kConstantChannel || buildChannel == kConstantChannel ||
+        !scalarKind(buildType->childAt(buildChannel)->kind()) ||
+        probeType->childAt(probeChannel)->kind() != buildType->childAt(buildChannel)->kind()) {
+      return false;
+    }
+    out->probeKeys.push_back(static_cast<int32_t>(probeChannel));
+    out->buildKeys.push_back(static_cast<int32_t>(buildChannel));
+    out->buildKeyTypes.push_back(static_cast<int32_t>(buildType->childAt(buildChannel)->kind()));
+  }
+  out->type = static_cast<vx355_join_type>(node.joinType());  // same numeric values (core/PlanNode.h:3078-3150)
+  out->nullAware = node.isNullAware();
+  out->nullAsValue = node.isNullAsValue();
+  out->dropDuplicates = node.canDropDuplicates();
+  const auto& outputType = node.outputType();
+  const bool semiProject = node.isLeftSemiProjectJoin() || node.isRightSemiProjectJoin();
+  for (uint32_t i = 0; i < outputType->size(); ++i) {
+    if (semiProject && i + 1 == outputType->size()) {
+      out->matchOutput = static_cast<int32_t>(i);  // the 'match' column comes last (core/PlanNode.h:3352-3366)
+      continue;
+    }
+    const auto& name = outputType->nameOf(i);
+    if (auto probeChannel = probeType->getChildIdxIfExists(name)) {
+      out->probeOutputs.emplace_back(static_cast<int32_t>(*probeChannel), static_cast<int32_t>(i));
+    } else if (auto buildChannel = buildType->getChildIdxIfExists(name)) {
+      if (!scalarKind(buildType->childAt(*buildChannel)->kind())) {
+        return false;
+      }
+      out->dependentChannels.push_back(static_cast<int32_t>(*buildChannel));
+      out->dependentTypes.push_back(static_cast<int32_t>(buildType->childAt(*buildChannel)->kind()));
+      out->dependentOutputs.push_back(static_cast<int32_t>(i));
+    } else {
+      return false;
+    }
+  }
+  return true;
+}
+
+// ---- build -------------------------------------------------------------------------------------
+
+Vx355HashBuild::Vx355HashBuild(
+    int32_t operatorId,
+    exec::DriverCtx* driverCtx,
+    const std::shared_ptr<const core::HashJoinNode>& node,
+    const JoinPlan& /*plan*/,
+    vx355_join_build* handle)
+    : Operator(driverCtx, nullptr, operatorId, node->id(), "Vx355HashBuild"),
+      handle_(handle),
+      key_(keyOf(driverCtx, node->id())) {}
+
+Vx355HashBuild::~Vx355HashBuild() {
+  if (handle_ != nullptr) {
+    vx355_join_build_destroy(handle_);
+  }
+}
+
+void Vx355HashBuild::addInput(RowVectorPtr input) {
+  DecodedBatch batch(*input);
+  check(vx355_join_build_add_input(handle_, batch.get()));  // the rows are in HBM when this returns
+}
+
+void Vx355HashBuild::noMoreInput() {
+  Operator::noMoreInput();
+  // HashBuild::finishHashBuild (exec/HashBuild.cpp:819-993): the last of the peer build Drivers
+  // merges all of them into one table and publishes it.
+  std::vector<ContinuePromise> promises;
+  std::vector<std::shared_ptr<exec::Driver>> peers;
+  if (!operatorCtx_->task()->allPeersFinished(planNodeId(), operatorCtx_->driver(), &future_, promises, peers)) {
+    return;  // isBlocked() hands future_ to the Driver; the last peer completes it
+  }
+  std::vector<vx355_join_build*> others;
+  for (auto& peer : peers) {
+    auto* build = dynamic_cast<Vx355HashBuild*>(peer->findOperator(planNodeId()));
+    VELOX_CHECK_NOT_NULL(build);
+    others.push_back(build->handle());
+  }
+  vx355_join_table* table = nullptr;
+  const int status =
+      vx355_join_build_finish(handle_, others.data(), static_cast<int32_t>(others.size()), &table);
+  // "the last peer is responsible for the promises' fulfillment even in case of an exception"
+  // (exec/Task.h:585-587)
+  for (auto& promise : promises) {
+    promise.setValue();
+  }
+  check(status);
+  Vx355JoinTables::instance().publish(key_, table);
+  for (auto& peer : peers) {
+    static_cast<Vx355HashBuild*>(peer->findOperator(planNodeId()))->finished_ = true;
+  }
+  finished_ = true;
+}
+
+exec::BlockingReason Vx355HashBuild::isBlocked(ContinueFuture* future) {
+  if (!future_.valid()) {
+    return exec::BlockingReason::kNotBlocked;
+  }
+  *future = std::move(future_);
+  finished_ = true;  // woken up by the last peer: nothing left to do here
+  return exec::BlockingReason::kWaitForJoinBuild;
+}
+
+void Vx355HashBuild::close() {
+  if (handle_ != nullptr) {
+    vx355_join_build_destroy(handle_);
+    handle_ = nullptr;
+  }
+  Operator::close();
+}
+
+// ---- probe -------------------------------------------------------------------------------------
+
+Vx355HashProbe::Vx355HashProbe(
+    int32_t operatorId,
+    exec::DriverCtx* driverCtx,
+    const std::shared_ptr<const core::HashJoinNode>& node,
+    JoinPlan plan)
+    : Operator(driverCtx, node->outputType(), operatorId, node->id(), "Vx355HashProbe"),
+      plan_(std::move(plan)),
+      key_(keyOf(driverCtx, node->id())) {
+  Vx355JoinTables::instance().addProbe(key_);
+}
+
+Vx355HashProbe::~Vx355HashProbe() {
+  if (handle_ != nullptr) {
+    vx355_join_probe_destroy(handle_);
+  }
+}
+
+bool Vx355HashProbe::emitsBuildSide() const {
+  return plan_.type == VX355_JOIN_RIGHT || plan_.type == VX355_JOIN_FULL || plan_.type == VX355_JOIN_RIGHT_SEMI_FILTER ||
+      plan_.type == VX355_JOIN_RIGHT_SEMI_PROJECT || plan_.type == VX355_JOIN_RIGHT_ANTI;
+}
+
+exec::BlockingReason Vx355HashProbe::isBlocked(ContinueFuture* future) {
+  if (handle_ != nullptr) {
+    return exec::BlockingReason::kNotBlocked;
+  }
+  table_ = Vx355JoinTables::instance().tableOrFuture(key_, future);  // exec/HashProbe.cpp:527
+  if (table_ == nullptr) {
+    return exec::BlockingReason::kWaitForJoinBuild;
+  }
+  vx355_join_probe_spec spec{};
+  spec.num_keys = static_cast<int32_t>(plan_.probeKeys.size());
+  spec.key_cols = plan_.probeKeys.data();
+  spec.join_type = plan_.type;
+  spec.null_aware = plan_.nullAware ? 1 : 0;
+  spec.null_as_value = plan_.nullAsValue ? 1 : 0;
+  check(vx355_join_probe_create(table_, &spec, &handle_));  // takes its own reference on the table
+  check(vx355_join_probe_set_output_batch_bytes(
+      handle_, static_cast<int64_t>(operatorCtx_->driverCtx()->queryConfig().preferredOutputBatchBytes())));
+  return exec::BlockingReason::kNotBlocked;
+}
+
+bool Vx355HashProbe::needsInput() const {
+  return handle_ != nullptr && !noMoreInput_ && inputDrained_;
+}
+
+void Vx355HashProbe::addInput(RowVectorPtr input) {
+  input_ = std::move(input);
+  decoded_ = std::make_unique<DecodedBatch>(*input_);
+  check(vx355_join_probe_add_input(handle_, decoded_->get()));
+  inputDrained_ = false;
+}
+
+void Vx355HashProbe::noMoreInput() {
+  Operator::noMoreInput();
+  if (!emitsBuildSide()) {
+    return;
+  }
+  // the last prober lists the build rows nobody matched (exec/HashProbe.cpp:1189-1219)
+  std::vector<ContinuePromise> promises;
+  std::vector<std::shared_ptr<exec::Driver>> peers;
+  lastProber_ = operatorCtx_->task()->allPeersFinished(planNodeId(), operatorCtx_->driver(), nullptr, promises, peers);
+}
+
+RowVectorPtr Vx355HashProbe::fillOutput(
+    int32_t numRows,
+    const BufferPtr& mapping,
+    const int32_t* buildRows,
+    std::vector<VectorPtr>& buildColumns,
+    bool buildSide) {
+  // HashProbe::fillOutput (exec/HashProbe.cpp:968-991): probe columns are the input's children
+  // behind the mapping (no copy), build columns are what the library gathered
+  std::vector<VectorPtr> children(outputType_->size());
+  for (const auto& [probeChannel, outputChannel] : plan_.probeOutputs) {
+    children[outputChannel] = buildSide
+        ? BaseVector::createNullConstant(outputType_->childAt(outputChannel), numRows, pool())  // :1044-1048
+        : exec::wrapChild(numRows, mapping, input_->childAt(probeChannel));
+  }
+  for (size_t j = 0; j < plan_.dependentOutputs.size(); ++j) {
+    ownStrings(buildColumns[j], numRows);
+    buildColumns[j]->resize(numRows);
+    children[plan_.dependentOutputs[j]] = buildColumns[j];
+  }
+  if (plan_.matchOutput >= 0) {
+    // LEFT_SEMI_PROJECT: build row >= 0 = TRUE, -1 = FALSE, -2 = NULL (null-aware IN)
+    auto match = BaseVector::create<FlatVector<bool>>(BOOLEAN(), numRows, pool());
+    for (int32_t i = 0; i < numRows; ++i) {
+      if (buildRows[i] == -2) {
+        match->setNull(i, true);
+      } else {
+        match->set(i, buildRows[i] >= 0);
+      }
+    }
+    children[plan_.matchOutput] = match;
+  }
+  return std::make_shared<RowVector>(pool(), outputType_, nullptr, numRows, std::move(children));
+}
+
+RowVectorPtr Vx355HashProbe::getOutput() {
+  if (handle_ == nullptr || finished_) {
+    return nullptr;
+  }
+  const bool buildSide = inputDrained_ && noMoreInput_ && lastProber_ && !buildSideDone_;
+  if (inputDrained_ && !buildSide) {
+    if (noMoreInput_) {
+      finished_ = true;
+    }
+    return nullptr;
+  }
+  const auto maxRows = outputBatchRows();
+  auto mapping = allocateIndices(maxRows, pool());
+  std::vector<int32_t> buildRows(maxRows);
+  std::vector<VectorPtr> buildColumns;
+  std::vector<vx355_out_column> out;
+  std::vector<int32_t> ids;
+  for (size_t j = 0; j < plan_.dependentOutputs.size(); ++j) {
+    auto column = BaseVector::create(outputType_->childAt(plan_.dependentOutputs[j]), maxRows, pool());
+    vx355_out_column c{};
+    c.type_kind = plan_.dependentTypes[j];
+    c.mem = VX355_MEM_HOST;
+    c.values = column->values()->asMutable<void>();
+    c.nulls = column->mutableRawNulls();
+    out.push_back(c);
+    ids.push_back(static_cast<int32_t>(j));
+    buildColumns.push_back(std::move(column));
+  }
+  int32_t numRows = 0, done = 0;
+  if (buildSide) {
+    check(vx355_join_probe_get_build_side_output(
+        handle_, maxRows, buildRows.data(), VX355_MEM_HOST, out.data(), ids.data(), static_cast<int32_t>(ids.size()),
+        &numRows, &done));
+    buildSideDone_ = done != 0;
+  } else {
+    check(vx355_join_probe_get_output(
+        handle_, maxRows, mapping->asMutable<int32_t>(), buildRows.data(), VX355_MEM_HOST, out.data(), ids.data(),
+        static_cast<int32_t>(ids.size()), &numRows, &done));
+    inputDrained_ = done != 0;
+  }
+  auto result = numRows > 0 ? fillOutput(numRows, mapping, buildRows.data(), buildColumns, buildSide) : nullptr;
+  if (inputDrained_) {
+    input_.reset();
+    decoded_.reset();
+  }
+  return result;
+}
+
+bool Vx355HashProbe::isFinished() {
+  return finished_ || (noMoreInput_ && inputDrained_ && (!lastProber_ || buildSideDone_));
+}
+
+void Vx355HashProbe::close() {
+  if (handle_ != nullptr) {
+    vx355_join_probe_destroy(handle_);
+    handle_ = nullptr;
+  }
+  if (std::get<2>(key_) != "") {
+    Vx355JoinTables::instance().removeProbe(key_);
+    std::get<2>(key_) = "";
+  }
+  input_.reset();
+  decoded_.reset();
+  Operator::close();
+}
+
+// ---- the adapter -------------------------------------------------------------------------------
+
+bool adaptJoins(const exec::DriverFactory& factory, exec::Driver& driver) {
+  bool replaced = false;
+  auto operators = driver.operators();
+  for (int32_t i = 0; i < static_cast<int32_t>(operators.size()); ++i) {
+    auto* build = dynamic_cast<exec::HashBuild*>(operators[i]);
+    auto* probe = dynamic_cast<exec::HashProbe*>(operators[i]);
+    if (build == nullptr && probe == nullptr) {
+      continue;
+    }
+    auto node = joinNodeOf(factory, operators[i]->planNodeId());
+    JoinPlan plan;
+    if (node == nullptr || !toJoinPlan(*node, &plan)) {
+      continue;
+    }
+    std::vector<std::unique_ptr<exec::Operator>> replacement;
+    if (build != nullptr) {
+      vx355_join_build_spec spec{};
+      spec.num_keys = static_cast<int32_t>(plan.buildKeys.size());
+      spec.key_cols = plan.buildKeys.data();
+      spec.key_types = plan.buildKeyTypes.data();
+      spec.num_dependents = static_cast<int32_t>(plan.dependentChannels.size());
+      spec.dependent_cols = plan.dependentChannels.data();
+      spec.dependent_types = plan.dependentTypes.data();
+      spec.join_type = plan.type;
+      spec.null_aware = plan.nullAware ? 1 : 0;
+      spec.null_as_value = plan.nullAsValue ? 1 : 0;
+      spec.drop_duplicates = plan.dropDuplicates ? 1 : 0;
+      vx355_join_build* handle = nullptr;
+      if (vx355_join_build_create(&spec, &handle) != VX355_OK) {
+        continue;  // VX355_EUNSUPPORTED: both pipelines get the same answer and keep the CPU operators
+      }
+      replacement.push_back(
+          std::make_unique<Vx355HashBuild>(build->operatorId(), driver.driverCtx(), node, plan, handle));
+    } else {
+      // (the probe pipeline must decide like the build pipeline did: try the same create call)
+      vx355_join_build_spec spec{};
+      spec.num_keys = static_cast<int32_t>(plan.buildKeys.size());
+      spec.key_cols = plan.buildKeys.data();
+      spec.key_types = plan.buildKeyTypes.data();
+      spec.num_dependents = static_cast<int32_t>(plan.dependentChannels.size());
+      spec.dependent_cols = plan.dependentChannels.data();
+      spec.dependent_types = plan.dependentTypes.data();
+      spec.join_type = plan.type;
+      spec.null_aware = plan.nullAware ? 1 : 0;
+      spec.null_as_value = plan.nullAsValue ? 1 : 0;
+      spec.drop_duplicates = plan.dropDuplicates ? 1 : 0;
+      vx355_join_build* trial = nullptr;
+      if (vx355_join_build_create(&spec, &trial) != VX355_OK) {
+        continue;
+      }
+      vx355_join_build_destroy(trial);
+      replacement.push_back(
+          std::make_unique<Vx355HashProbe>(probe->operatorId(), driver.driverCtx(), node, std::move(plan)));
+    }
+    factory.replaceOperators(driver, i, i + 1, std::move(replacement));
+    replaced = true;
+  }
+  return replaced;
+}
+
+}  // namespace facebook::velox::vx355

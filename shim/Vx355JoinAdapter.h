@@ -1,0 +1,140 @@
+// Velox-side adapter of libvx355, join half: replaces exec::HashBuild / exec::HashProbe of a
+// HashJoinNode by operators that run on the MI355X through the C ABI of include/vx355.h
+// (INTEGRATION.md section 3). Built on the VELOX side together with Vx355Adapter.cpp; registered by
+// the same registerVx355() call.
+//
+// The table travels from the build pipeline to the probe pipeline through a small rendezvous of its
+// own (Vx355JoinTables) instead of exec::HashJoinBridge, whose payload is a BaseHashTable
+// (exec/HashJoinBridge.h:57): the last build Driver publishes the vx355_join_table*, probe Drivers
+// that come earlier get a ContinueFuture (exec/HashProbe.cpp:527 does the same with the bridge).
+#pragma once
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "Vx355Adapter.h"
+#include "velox/common/future/VeloxPromise.h"
+#include "velox/core/PlanNode.h"
+
+namespace facebook::velox::vx355 {
+
+/// (task id, split group, plan node id) -> table, for the Drivers of this process.
+class Vx355JoinTables {
+ public:
+  using Key = std::tuple<std::string, uint32_t, core::PlanNodeId>;
+  static Vx355JoinTables& instance();
+
+  /// A probe operator exists for 'key' (constructor) / is gone (close). The entry and the
+  /// rendezvous' reference on the table go away with the last one.
+  void addProbe(const Key& key);
+  void removeProbe(const Key& key);
+  /// The table, or nullptr and a future that completes when it is published.
+  vx355_join_table* tableOrFuture(const Key& key, ContinueFuture* future);
+  /// Build side (last peer): hands over one reference on 'table'.
+  void publish(const Key& key, vx355_join_table* table);
+
+ private:
+  struct Entry {
+    vx355_join_table* table{nullptr};
+    int32_t probes{0};
+    std::vector<ContinuePromise> promises;
+  };
+  std::mutex mutex_;
+  std::map<Key, Entry> entries_;
+};
+
+/// What both operators need of a HashJoinNode, resolved against the types of its two sources.
+struct JoinPlan {
+  std::vector<int32_t> probeKeys, buildKeys, buildKeyTypes;
+  // build-side columns the join emits: their channels in the build input (= the table's dependent
+  // columns, in this order), their types, and where each one goes in the output row
+  std::vector<int32_t> dependentChannels, dependentTypes, dependentOutputs;
+  // probe-side columns the join emits: (probe channel, output channel)
+  std::vector<std::pair<int32_t, int32_t>> probeOutputs;
+  int32_t matchOutput{-1};  // semi project joins: the BOOLEAN 'match' column
+  vx355_join_type type{VX355_JOIN_INNER};
+  bool nullAware{false}, nullAsValue{false}, dropDuplicates{false};
+};
+
+/// false: a join the library does not take (extra filter outside INTEGRATION.md's class, key or
+/// payload types beyond the scalar kinds): the CPU operators stay.
+bool toJoinPlan(const core::HashJoinNode& node, JoinPlan* out);
+
+/// exec::HashBuild on the GPU (exec/HashBuild.h): one per build Driver.
+class Vx355HashBuild : public exec::Operator {
+ public:
+  Vx355HashBuild(
+      int32_t operatorId,
+      exec::DriverCtx* driverCtx,
+      const std::shared_ptr<const core::HashJoinNode>& node,
+      const JoinPlan& plan,
+      vx355_join_build* handle);
+  ~Vx355HashBuild() override;
+
+  bool needsInput() const override {
+    return !noMoreInput_;
+  }
+  void addInput(RowVectorPtr input) override;
+  void noMoreInput() override;
+  RowVectorPtr getOutput() override {
+    return nullptr;
+  }
+  exec::BlockingReason isBlocked(ContinueFuture* future) override;
+  bool isFinished() override {
+    return finished_;
+  }
+  void close() override;
+  vx355_join_build* handle() const {
+    return handle_;
+  }
+
+ private:
+  vx355_join_build* handle_;
+  Vx355JoinTables::Key key_;
+  ContinueFuture future_{ContinueFuture::makeEmpty()};
+  bool finished_{false};
+};
+
+/// exec::HashProbe on the GPU (exec/HashProbe.h).
+class Vx355HashProbe : public exec::Operator {
+ public:
+  Vx355HashProbe(
+      int32_t operatorId,
+      exec::DriverCtx* driverCtx,
+      const std::shared_ptr<const core::HashJoinNode>& node,
+      JoinPlan plan);
+  ~Vx355HashProbe() override;
+
+  bool needsInput() const override;
+  void addInput(RowVectorPtr input) override;
+  void noMoreInput() override;
+  RowVectorPtr getOutput() override;
+  exec::BlockingReason isBlocked(ContinueFuture* future) override;
+  bool isFinished() override;
+  void close() override;
+
+ private:
+  RowVectorPtr fillOutput(int32_t numRows, const BufferPtr& mapping, const int32_t* buildRows,
+                          std::vector<VectorPtr>& buildColumns, bool buildSide);
+  bool emitsBuildSide() const;
+
+  const JoinPlan plan_;
+  Vx355JoinTables::Key key_;
+  vx355_join_table* table_{nullptr};
+  vx355_join_probe* handle_{nullptr};
+  ContinueFuture future_{ContinueFuture::makeEmpty()};
+  RowVectorPtr input_;                      // kept until its output is drained (HashProbe does the same)
+  std::unique_ptr<DecodedBatch> decoded_;
+  bool inputDrained_{true};
+  bool lastProber_{false}, buildSideDone_{false}, finished_{false};
+};
+
+/// Called by the adapter of Vx355Adapter.cpp for every Driver: replaces the HashBuild / HashProbe
+/// operators of joins the library takes. Both pipelines of a join decide alike (the decision only
+/// depends on the plan node).
+bool adaptJoins(const exec::DriverFactory& factory, exec::Driver& driver);
+
+}  // namespace facebook::velox::vx355

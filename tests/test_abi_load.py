@@ -83,15 +83,17 @@ def test_ctypes_structures_have_the_layout_of_the_header(tmp_path):
 
 
 def test_shim_sources_only_use_declared_entry_points():
-    """shim/Vx355Adapter.{h,cpp} is compiled on the Velox side (no Velox here); what can be checked
-    without it: every vx355_* function, type and constant the adapter uses exists in include/vx355.h."""
+    """shim/Vx355Adapter.{h,cpp} and shim/Vx355JoinAdapter.{h,cpp} are compiled on the Velox side (no
+    Velox here); what can be checked without it: every vx355_* function, type and constant the adapters
+    use exists in include/vx355.h, and every source is in the CMake fragment."""
     header = open(os.path.join(ROOT, "include", "vx355.h")).read()
     declared = set(re.findall(r"\b(vx355_[a-z0-9_]+|VX355_[A-Z0-9_]+)\b", header))
     used = set()
-    for name in ("Vx355Adapter.h", "Vx355Adapter.cpp"):
+    for name in ("Vx355Adapter.h", "Vx355Adapter.cpp", "Vx355JoinAdapter.h", "Vx355JoinAdapter.cpp"):
         text = open(os.path.join(ROOT, "shim", name)).read()
         text = re.sub(r"//[^\n]*", "", text)
         used |= set(re.findall(r"\b(vx355_[a-z0-9_]+|VX355_[A-Z0-9_]+)\b", text))
     used -= {"vx355_adapter"}   # (a CMake target name, not an ABI symbol)
     assert used and used <= declared, sorted(used - declared)
-    assert os.path.exists(os.path.join(ROOT, "shim", "CMakeLists.txt"))
+    cmake = open(os.path.join(ROOT, "shim", "CMakeLists.txt")).read()
+    assert "Vx355Adapter.cpp" in cmake and "Vx355JoinAdapter.cpp" in cmake
