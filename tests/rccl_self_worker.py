@@ -54,7 +54,7 @@ def main():
     progress("creating the communicator")
     comm = vx.Comm(vx.Comm.unique_id(), 1, 0)
     checks["comm_info"] = list(comm.info())
-    steps = set(sys.argv[1:]) or {"counts", "columns", "all_gather", "all_gather_large", "all_gather_v", "edge"}
+    steps = set(sys.argv[1:]) or {"counts", "columns", "all_gather", "all_gather_large", "all_gather_v", "merge", "edge"}
     if "counts" in steps:
         progress("all-gather of counts")
         checks["counts"] = comm.exchange_counts([12345])
@@ -90,6 +90,36 @@ def main():
         h2d(rb, zeros[: n // 2])
         comm.all_gather_v(sb.value, [b.nbytes], rb.value)
         checks["all_gather_v"] = bool((d2h(rb, n, np.int32) == b).all())
+    if "merge" in steps:
+        # vx355_agg_merge_partials through the same communicator: partial groups -> one PrestoPage (avg as
+        # ROW(DOUBLE, BIGINT)) -> counts + all-gather of the pages over RCCL -> FINAL; equal to one SINGLE
+        # aggregation of the same rows (dyadic doubles: exact)
+        progress("merge of partials")
+        from velox_amd import dist as vdist
+        m = 200_000
+        key = rng.integers(0, 5000, m).astype(np.int64)
+        big = rng.integers(2 ** 44, 2 ** 46, m).astype(np.int64)
+        x = rng.integers(-1000, 1000, m).astype(np.float64) / 8
+        raw = [(abi.AGG_SUM, 1, abi.BIGINT), (abi.AGG_AVG, 2, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT),
+               (abi.AGG_MAX, 2, abi.DOUBLE)]
+        batch = batch_of([key, big, x], [None, None, rng.random(m) > 0.1])
+        single = vx.Aggregation([0], [abi.BIGINT], raw, abi.STEP_SINGLE)
+        single.add_input(batch)
+        single.no_more_input()
+        want = vx.collect_output(single, 4096)
+        part = vx.Aggregation([0], [abi.BIGINT], raw, abi.STEP_PARTIAL)
+        part.add_input(batch)
+        part.no_more_input()
+        fin = vx.merge_partials(comm, part, [0], [abi.BIGINT], vdist.final_aggs_for(raw, 1))
+        got = vx.collect_output(fin, 4096)
+        same = len(got) == len(want)
+        for (gv, gn), (wv, wn) in zip(got, want):
+            gv, wv = np.asarray(gv), np.asarray(wv)
+            gn = np.ones(len(gv), dtype=bool) if gn is None else np.asarray(gn, dtype=bool)
+            wn = np.ones(len(wv), dtype=bool) if wn is None else np.asarray(wn, dtype=bool)
+            same = same and len(gv) == len(wv) and bool((gn == wn).all()) and bool((gv[gn] == wv[wn]).all())
+        checks["merge_partials"] = bool(same)
+        del fin, part, single
     if "edge" not in steps:
         del comm
         print(json.dumps(checks), flush=True)

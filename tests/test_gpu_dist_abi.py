@@ -214,8 +214,8 @@ def test_bench_c5_through_the_library_exchange():
 def test_rccl_entry_points_run_on_one_gpu(with_torch):
     """VX355_COMM_FORCE_RCCL=1 (tests/rccl_self_worker.py, own process): ncclCommInitRank, the counts
     all-gather, grouped ncclSend / ncclRecv to self with a 320 MiB column cut at 256 MiB, both
-    all-gather forms and the exchange edge's payload stream really execute; every payload comes
-    back intact. The N > 1 code path no longer meets RCCL for the first time on the 8-GPU node.
+    all-gather forms, vx355_agg_merge_partials (avg travels as ROW(DOUBLE, BIGINT) in the page) and the
+    exchange edge's payload stream really execute; every payload comes back intact. The N > 1 code path no longer meets RCCL for the first time on the 8-GPU node.
     with_torch: torch is imported first, as in bench.py - the library then runs on torch's bundled
     HIP runtime and the RCCL next to it (another build than /opt/rocm's)."""
     env = dict(os.environ)
