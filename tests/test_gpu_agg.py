@@ -949,7 +949,7 @@ def test_hashed_folds_size_their_lds_table_from_a_sample_of_the_keys(oracle, vx,
 def test_first_seen_order_of_many_groups_without_the_library_sort(oracle, vx, keys, monkeypatch):
     """The listed (first row, group) entries of the radix folds are put into first-seen order by the
     library's own passes (k_fs_pack, two exact radix levels, k_fs_rank: a bitmap per partition) instead of
-    rocPRIM - forced here for 1.2 M groups (it starts at 4 M entries); direct-index table and the dense
+    rocPRIM - forced here for 1.2 M groups (it starts at 32 M entries); direct-index table and the dense
     folds' array of rows with its holes. Group order must be the oracle's."""
     monkeypatch.setenv("VX355_AGG_RADIX_MIN_ROWS", "1")
     monkeypatch.setenv("VX355_AGG_DENSE_MIN_ROWS", "1")

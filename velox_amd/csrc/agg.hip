@@ -6690,7 +6690,7 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
 // caller sorts with rocPRIM.
 bool sortFirstSeen(vx355_agg& h, size_t n, size_t holes) {
   auto& rt = Runtime::get();
-  int64_t minEntries = 4LL << 20;
+  int64_t minEntries = 32LL << 20;   // measured at 10^8 entries; below this rocPRIM's fixed costs are the smaller ones
   if (const char* e = std::getenv("VX355_AGG_OWN_SORT_MIN")) {
     minEntries = std::strtoll(e, nullptr, 10);  // < 0: never
   }
