@@ -14,7 +14,9 @@ timed region.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Other workloads (not the headline line): --workload c1 | c4 | q3.
-Prints ONE JSON line on rank 0.
+Rank 0 writes the full result object to --detail (bench_detail.json) and to stderr on a
+line tagged "BENCH_DETAIL " and then, as the LAST stdout line, the compact JSON line
+(< 4 KB: contract keys + roofline + cpu_baseline + reduced secondary blocks).
 """
 import argparse
 import ctypes as C
@@ -79,6 +81,9 @@ def parse():
                     help="N > 1 data path: lib = libvx355's own RCCL communicator (vx355_exchange_* / "
                          "vx355_agg_merge_partials), torch = torch.distributed collectives; auto = lib after "
                          "a self-check in child processes (velox_amd/commcheck.py), else torch")
+    ap.add_argument("--detail", default="bench_detail.json",
+                    help="file for the full result object (every per-kernel time, pass table and note); the last "
+                         "stdout line is the compact form, always < 4 KB. '' = do not write a file")
     ap.add_argument("--launch-check", action="store_true",
                     help="only start the ranks, form the process group and report n_gpus (no GPU work; CPU test of the launcher)")
     return ap.parse_args()
@@ -1421,7 +1426,7 @@ def main():
             except Exception as e:   # a failing secondary must not take the headline with it; it is reported
                 out["secondary"][key] = {"error": f"{type(e).__name__}: {e}"}
     C.CDLL(None).fflush(None)   # C stdio (RCCL prints a version banner there): the JSON line stays the last line
-    print(json.dumps(out), flush=True)
+    emit(out, args.detail)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -1430,6 +1435,120 @@ def main():
     # Whatever a library prints while the process winds down goes to stderr: the JSON line stays the
     # last line of stdout. (Not os._exit: a profiler - rocprofv3 - writes its output at normal exit.)
     os.dup2(2, 1)
+
+
+LINE_LIMIT = 4096   # the driver keeps an 8 KB tail of stdout: the final line must fit it with room to spare
+
+
+def _num(x, digits=6):
+    """floats to 'digits' significant digits: the line is for reading and parsing, the detail file keeps all"""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    return x
+
+
+def compact_roofline(r):
+    if not r:
+        return None
+    algo = r.get("algorithmic_bytes_per_step")
+    traffic = r.get("traffic")
+    return {"bound": r.get("bound"), "kernel": r.get("kernel"), "achieved": _num(r.get("achieved")),
+            "peak": r.get("peak"), "unit": r.get("unit"), "frac": _num(r.get("frac"), 4),
+            "traffic": _num(traffic), "algorithmic_bytes": _num(algo),
+            "traffic_ratio": _num(traffic / algo, 4) if (traffic and algo) else None,
+            "kernel_ms_per_step": _num(r.get("kernel_ms_per_step"), 5),
+            "launches_per_step": r.get("launches_per_step"),
+            "measured_copy_ceiling_GBps": _num((r.get("measured_ceiling") or {}).get(
+                "read_GBps" if r.get("measured_ceiling_kind") == "read" else "copy_GBps"), 5)}
+
+
+def compact_cpu(c):
+    if not c:
+        return None
+    return {"value": _num(c.get("value")), "unit": c.get("unit"), "cores": c.get("cores"), "kind": c.get("kind"),
+            "sample": (c.get("sample") or "")[:160]}
+
+
+def compact_line(out):
+    """The final stdout line: the contract's keys, the headline's roofline and cpu_baseline, and every
+    secondary block reduced to {value, ms_per_step, kernel, frac, traffic_ratio, cpu_value}. Everything
+    else (per-kernel times, pass tables, notes) is in the detail object printed before it / written to
+    bench_detail.json. Guaranteed shorter than LINE_LIMIT bytes: fields are dropped, never truncated."""
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                    "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["value"] = _num(line["value"], 8)
+    line["ms_per_step"] = _num(line["ms_per_step"], 6)
+    cfg = dict(out.get("config") or {})
+    for k in ("plan", "parallelism", "exchange"):
+        if isinstance(cfg.get(k), str):
+            cfg[k] = cfg[k][:120]
+    line["config"] = cfg
+    line["roofline"] = compact_roofline(out.get("roofline"))
+    line["cpu_baseline"] = compact_cpu(out.get("cpu_baseline"))
+    if out.get("cpu_baseline_mt"):
+        mt = out["cpu_baseline_mt"]
+        line["cpu_baseline_mt"] = {"value": _num(mt.get("value")), "unit": mt.get("unit"), "cores": mt.get("cores"),
+                                   "kind": mt.get("kind")}
+    if out.get("exchange_downgraded"):
+        line["exchange_downgraded"] = True
+    if out.get("result_check") is not None:
+        line["result_check_ok"] = bool(out["result_check"].get("ok"))
+    if out.get("strong_scaling"):
+        st = out["strong_scaling"]
+        line["strong_scaling"] = {"value": _num(st.get("value"), 8), "ms_per_step": _num(st.get("ms_per_step")),
+                                  "rows_total": st.get("rows_total")}
+    if out.get("secondary"):
+        sec = {}
+        for key, blk in out["secondary"].items():
+            if "error" in blk:
+                sec[key] = {"error": str(blk["error"])[:80]}
+                continue
+            r = blk.get("roofline") or {}
+            algo, traffic = r.get("algorithmic_bytes_per_step"), r.get("traffic")
+            sec[key] = {"value": _num(blk.get("value")), "ms_per_step": _num(blk.get("ms_per_step"), 5),
+                        "kernel": r.get("kernel"), "frac": _num(r.get("frac"), 4),
+                        "traffic_ratio": _num(traffic / algo, 4) if (traffic and algo) else None,
+                        "cpu_value": _num((blk.get("cpu_baseline") or {}).get("value"))}
+            if blk.get("host_ingest"):
+                sec[key]["host_GBps"] = _num(blk["host_ingest"].get("GBps"), 4)
+        line["secondary"] = sec
+    line["detail"] = out.get("detail_file")
+    text = json.dumps(line, separators=(",", ":"))
+    # shed optional fields until the line fits (never happens with today's blocks; the guard is the contract)
+    for victim in ("secondary", "cpu_baseline_mt", "strong_scaling"):
+        if len(text) < LINE_LIMIT:
+            break
+        if victim == "secondary" and "secondary" in line:
+            line["secondary"] = {k: {"value": v.get("value"), "ms_per_step": v.get("ms_per_step"), "frac": v.get("frac")}
+                                 for k, v in line["secondary"].items()}
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) < LINE_LIMIT:
+                break
+        line.pop(victim, None)
+        text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:
+        cfg = line["config"]
+        line["config"] = {"workload": cfg.get("workload")}
+        line["cpu_baseline"]["sample"] = line["cpu_baseline"]["sample"][:60] if line.get("cpu_baseline") else None
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < LINE_LIMIT, len(text)
+    return text
+
+
+def emit(out, detail_path):
+    """Full object -> detail file and stderr (tagged 'BENCH_DETAIL '); compact object -> the LAST stdout line."""
+    if detail_path:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(detail_path)), exist_ok=True)
+            with open(detail_path, "w") as f:
+                json.dump(out, f, indent=1)
+            out["detail_file"] = detail_path
+        except OSError as e:
+            out["detail_file"] = None
+            print(f"bench.py: could not write {detail_path}: {e}", file=sys.stderr)
+    # the full object goes to stderr: stdout carries nothing after warm-up but the compact line
+    print("BENCH_DETAIL " + json.dumps(out), file=sys.stderr, flush=True)
+    print(compact_line(out), flush=True)
 
 
 class GroupDist:
