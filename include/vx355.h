@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VX355_ABI_VERSION 6
+#define VX355_ABI_VERSION 7
 
 typedef enum vx355_status {
   VX355_OK = 0,
@@ -614,6 +614,12 @@ typedef struct vx355_agg_stats {
   int64_t num_flushes;    /* vx355_agg_flush calls completed (kFlushTimes) */
 } vx355_agg_stats;
 int vx355_agg_get_stats(const vx355_agg* h, vx355_agg_stats* out);
+/* The two numbers the shim's isPartialFull / abandon checks need, WITHOUT waiting (ABI 7):
+ * vx355_agg_get_stats drains the handle's queue and seals the open ingest chunk, which stalls the
+ * Driver thread and defeats the asynchronous boundary when called per batch. table_bytes / num_groups
+ * are as of the last batch the library finished feeding (see vx355_agg_poll for which one that is);
+ * after a flush has been drained they are the empty table's. Either pointer may be NULL. */
+int vx355_agg_table_bytes(const vx355_agg* h, int64_t* table_bytes, int64_t* num_groups);
 
 /* Partial-aggregation flush (HashAggregation.cpp:191-236,293-327: when the partial table
  * is "full" the operator emits what it has and starts over). PARTIAL / INTERMEDIATE steps

@@ -103,15 +103,42 @@ vx355_join_table* Vx355JoinTables::tableOrFuture(const Key& key, ContinueFuture*
 
 void Vx355JoinTables::publish(const Key& key, vx355_join_table* table) {
   std::vector<ContinuePromise> promises;
+  bool orphan = false;
   {
     std::lock_guard<std::mutex> l(mutex_);
-    auto& entry = entries_[key];
-    entry.table = table;
-    promises = std::move(entry.promises);
+    auto it = entries_.find(key);
+    if (it == entries_.end() || it->second.probes <= 0) {
+      // every probe operator is gone already (the task aborted between their close() and this
+      // build's finish): nobody will ever take the table
+      orphan = true;
+      if (it != entries_.end()) {
+        promises = std::move(it->second.promises);
+        entries_.erase(it);
+      }
+    } else {
+      it->second.table = table;
+      promises = std::move(it->second.promises);
+    }
+  }
+  if (orphan && table != nullptr) {
+    vx355_join_table_release(table);
   }
   for (auto& promise : promises) {
     promise.setValue();
   }
+}
+
+bool Vx355JoinTables::accepted(const Key& key, const std::function<bool()>& decide) {
+  std::lock_guard<std::mutex> l(mutex_);
+  auto it = entries_.find(key);
+  if (it != entries_.end() && it->second.accepted == 1) {
+    return true;
+  }
+  if (!decide()) {
+    return false;  // a refused join keeps no entry (the create call fails in its argument checks: cheap to repeat)
+  }
+  entries_[key].accepted = 1;  // lives until the join's last probe operator closes (removeProbe)
+  return true;
 }
 
 // ---- plan --------------------------------------------------------------------------------------
@@ -213,7 +240,7 @@ void Vx355HashBuild::noMoreInput() {
   check(status);
   Vx355JoinTables::instance().publish(key_, table);
   for (auto& peer : peers) {
-    static_cast<Vx355HashBuild*>(peer->findOperator(planNodeId()))->finished_ = true;
+    static_cast<Vx355HashBuild*>(peer->findOperator(planNodeId()))->markFinished();
   }
   finished_ = true;
 }
@@ -403,6 +430,25 @@ void Vx355HashProbe::close() {
 
 // ---- the adapter -------------------------------------------------------------------------------
 
+namespace {
+
+vx355_join_build_spec buildSpecOf(const JoinPlan& plan) {
+  vx355_join_build_spec spec{};
+  spec.num_keys = static_cast<int32_t>(plan.buildKeys.size());
+  spec.key_cols = plan.buildKeys.data();
+  spec.key_types = plan.buildKeyTypes.data();
+  spec.num_dependents = static_cast<int32_t>(plan.dependentChannels.size());
+  spec.dependent_cols = plan.dependentChannels.data();
+  spec.dependent_types = plan.dependentTypes.data();
+  spec.join_type = plan.type;
+  spec.null_aware = plan.nullAware ? 1 : 0;
+  spec.null_as_value = plan.nullAsValue ? 1 : 0;
+  spec.drop_duplicates = plan.dropDuplicates ? 1 : 0;
+  return spec;
+}
+
+}  // namespace
+
 bool adaptJoins(const exec::DriverFactory& factory, exec::Driver& driver) {
   bool replaced = false;
   auto operators = driver.operators();
@@ -417,43 +463,30 @@ bool adaptJoins(const exec::DriverFactory& factory, exec::Driver& driver) {
     if (node == nullptr || !toJoinPlan(*node, &plan)) {
       continue;
     }
+    // Both pipelines of a join must decide alike, and the library has the last word
+    // (VX355_EUNSUPPORTED at create): the first Driver of either pipeline asks it once with a trial
+    // handle, the answer stays with the rendezvous entry of (task, split group, join node).
+    const auto key = keyOf(driver.driverCtx(), node->id());
+    const bool take = Vx355JoinTables::instance().accepted(key, [&] {
+      const auto spec = buildSpecOf(plan);
+      vx355_join_build* trial = nullptr;
+      if (vx355_join_build_create(&spec, &trial) != VX355_OK) {
+        return false;
+      }
+      vx355_join_build_destroy(trial);
+      return true;
+    });
+    if (!take) {
+      continue;
+    }
     std::vector<std::unique_ptr<exec::Operator>> replacement;
     if (build != nullptr) {
-      vx355_join_build_spec spec{};
-      spec.num_keys = static_cast<int32_t>(plan.buildKeys.size());
-      spec.key_cols = plan.buildKeys.data();
-      spec.key_types = plan.buildKeyTypes.data();
-      spec.num_dependents = static_cast<int32_t>(plan.dependentChannels.size());
-      spec.dependent_cols = plan.dependentChannels.data();
-      spec.dependent_types = plan.dependentTypes.data();
-      spec.join_type = plan.type;
-      spec.null_aware = plan.nullAware ? 1 : 0;
-      spec.null_as_value = plan.nullAsValue ? 1 : 0;
-      spec.drop_duplicates = plan.dropDuplicates ? 1 : 0;
+      const auto spec = buildSpecOf(plan);
       vx355_join_build* handle = nullptr;
-      if (vx355_join_build_create(&spec, &handle) != VX355_OK) {
-        continue;  // VX355_EUNSUPPORTED: both pipelines get the same answer and keep the CPU operators
-      }
+      check(vx355_join_build_create(&spec, &handle));  // the trial succeeded: a failure now is an error
       replacement.push_back(
           std::make_unique<Vx355HashBuild>(build->operatorId(), driver.driverCtx(), node, plan, handle));
     } else {
-      // (the probe pipeline must decide like the build pipeline did: try the same create call)
-      vx355_join_build_spec spec{};
-      spec.num_keys = static_cast<int32_t>(plan.buildKeys.size());
-      spec.key_cols = plan.buildKeys.data();
-      spec.key_types = plan.buildKeyTypes.data();
-      spec.num_dependents = static_cast<int32_t>(plan.dependentChannels.size());
-      spec.dependent_cols = plan.dependentChannels.data();
-      spec.dependent_types = plan.dependentTypes.data();
-      spec.join_type = plan.type;
-      spec.null_aware = plan.nullAware ? 1 : 0;
-      spec.null_as_value = plan.nullAsValue ? 1 : 0;
-      spec.drop_duplicates = plan.dropDuplicates ? 1 : 0;
-      vx355_join_build* trial = nullptr;
-      if (vx355_join_build_create(&spec, &trial) != VX355_OK) {
-        continue;
-      }
-      vx355_join_build_destroy(trial);
       replacement.push_back(
           std::make_unique<Vx355HashProbe>(probe->operatorId(), driver.driverCtx(), node, std::move(plan)));
     }

@@ -9,6 +9,8 @@
 // that come earlier get a ContinueFuture (exec/HashProbe.cpp:527 does the same with the bridge).
 #pragma once
 
+#include <atomic>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -33,13 +35,18 @@ class Vx355JoinTables {
   void removeProbe(const Key& key);
   /// The table, or nullptr and a future that completes when it is published.
   vx355_join_table* tableOrFuture(const Key& key, ContinueFuture* future);
-  /// Build side (last peer): hands over one reference on 'table'.
+  /// Build side (last peer): hands over one reference on 'table'. Without a registered probe (the task
+  /// is being torn down: every probe operator is already closed) the reference is dropped at once.
   void publish(const Key& key, vx355_join_table* table);
+  /// Whether the library takes the join of 'key': decided once (by 'decide', a trial
+  /// vx355_join_build_create) for all Drivers of both pipelines, so that they decide alike.
+  bool accepted(const Key& key, const std::function<bool()>& decide);
 
  private:
   struct Entry {
     vx355_join_table* table{nullptr};
     int32_t probes{0};
+    int32_t accepted{-1};  // -1 = not decided yet
     std::vector<ContinuePromise> promises;
   };
   std::mutex mutex_;
@@ -84,18 +91,22 @@ class Vx355HashBuild : public exec::Operator {
   }
   exec::BlockingReason isBlocked(ContinueFuture* future) override;
   bool isFinished() override {
-    return finished_;
+    return finished_.load();
   }
   void close() override;
   vx355_join_build* handle() const {
     return handle_;
+  }
+  /// (the last peer, from its own Driver thread, once the table is published)
+  void markFinished() {
+    finished_.store(true);
   }
 
  private:
   vx355_join_build* handle_;
   Vx355JoinTables::Key key_;
   ContinueFuture future_{ContinueFuture::makeEmpty()};
-  bool finished_{false};
+  std::atomic<bool> finished_{false};
 };
 
 /// exec::HashProbe on the GPU (exec/HashProbe.h).
@@ -126,7 +137,7 @@ class Vx355HashProbe : public exec::Operator {
   vx355_join_table* table_{nullptr};
   vx355_join_probe* handle_{nullptr};
   ContinueFuture future_{ContinueFuture::makeEmpty()};
-  RowVectorPtr input_;                      // kept until its output is drained (HashProbe does the same)
+  // (Operator::input_ keeps the batch until its output is drained, as in exec::HashProbe)
   std::unique_ptr<DecodedBatch> decoded_;
   bool inputDrained_{true};
   bool lastProber_{false}, buildSideDone_{false}, finished_{false};

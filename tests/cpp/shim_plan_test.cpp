@@ -1,0 +1,358 @@
+// TEST (CPU): the Velox-side adapter (shim/*.cpp) compiled against tests/velox_api_stub and walked
+// through the reference's own TPC-H Q1 plan (exec/tests/utils/TpchQueryBuilder.cpp:203-252):
+//   scan -> [filter l_shipdate <= d] -> project(7 columns, 2 computed) -> partial aggregation
+//   (2 keys; sum x4, avg x3, count(0)) -> local exchange -> final aggregation.
+// Checks the plan translation (toAggSpec / toFusedInput), the flattening of avg's
+// ROW(DOUBLE, BIGINT) intermediate on the way in (DecodedBatch) and its assembly on the way out
+// (OutColumns). No GPU: nothing here creates a library handle.
+//   g++ -std=c++17 -Itests/velox_api_stub -Iinclude -Ishim tests/cpp/shim_plan_test.cpp shim/*.cpp -Lvelox_amd -lvx355
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "Vx355Adapter.h"
+#include "Vx355JoinAdapter.h"
+#include "shim_test_plans.h"
+
+using namespace facebook::velox;
+using namespace facebook::velox::vx355;
+
+#define EXPECT(cond)                                                                 \
+  do {                                                                               \
+    if (!(cond)) {                                                                   \
+      std::fprintf(stderr, "%s:%d: EXPECT(%s) failed\n", __FILE__, __LINE__, #cond); \
+      return 1;                                                                      \
+    }                                                                                \
+  } while (0)
+
+namespace {
+
+int testQ1PartialUnfused() {
+  auto plan = shimtest::q1Plan(/*filterAsNode=*/true);
+  AggSpec spec;
+  EXPECT(toAggSpec(*plan.partial, &spec));
+  EXPECT(spec.c.num_keys == 2 && spec.keyCols[0] == 0 && spec.keyCols[1] == 1);
+  EXPECT(spec.keyTypes[0] == VX355_VARCHAR && spec.keyTypes[1] == VX355_VARCHAR);
+  EXPECT(spec.c.step == VX355_STEP_PARTIAL);
+  EXPECT(spec.c.num_aggs == 8);
+  // sum(l_quantity), sum(l_extendedprice), sum(l_sum_disc_price), sum(l_sum_charge)
+  const int32_t sumCols[4] = {2, 3, 4, 5};
+  for (int i = 0; i < 4; ++i) {
+    EXPECT(spec.fns[i].kind == VX355_AGG_SUM && spec.fns[i].input_col == sumCols[i] && spec.fns[i].input_type == VX355_DOUBLE);
+  }
+  // avg(l_quantity), avg(l_extendedprice), avg(l_discount): raw input, no second column
+  const int32_t avgCols[3] = {2, 3, 6};
+  for (int i = 0; i < 3; ++i) {
+    EXPECT(spec.fns[4 + i].kind == VX355_AGG_AVG && spec.fns[4 + i].input_col == avgCols[i] && spec.fns[4 + i].input_col2 == -1);
+  }
+  // count(0): a non-null constant argument counts every row (exec/AggregateInfo.cpp:62-69)
+  EXPECT(spec.fns[7].kind == VX355_AGG_COUNT_STAR && spec.fns[7].input_col == -1);
+  EXPECT(spec.constants.empty());
+  return 0;
+}
+
+int testQ1Final() {
+  auto plan = shimtest::q1Plan(true);
+  // input of the final step: 2 keys, 4 DOUBLE sums, 3 x ROW(DOUBLE, BIGINT), BIGINT count
+  const auto& inputType = plan.final->sources()[0]->outputType();
+  EXPECT(inputType->size() == 10 && inputType->childAt(6)->isRow());
+  ColumnLayout layout(inputType);
+  EXPECT(layout.numColumns == 13);
+  EXPECT(layout.first[6] == 6 && layout.count[6] == 2 && layout.first[7] == 8 && layout.first[9] == 12);
+  AggSpec spec;
+  EXPECT(toAggSpec(*plan.final, &spec));
+  EXPECT(spec.c.step == VX355_STEP_FINAL && spec.c.num_aggs == 8);
+  for (int i = 0; i < 4; ++i) {
+    EXPECT(spec.fns[i].kind == VX355_AGG_SUM && spec.fns[i].input_col == 2 + i);
+  }
+  for (int i = 0; i < 3; ++i) {
+    const auto& fn = spec.fns[4 + i];
+    EXPECT(fn.kind == VX355_AGG_AVG && fn.input_col == 6 + 2 * i && fn.input_col2 == 7 + 2 * i && fn.input_type == VX355_DOUBLE);
+  }
+  // count's intermediate is a BIGINT column: the final step sums it (the library's COUNT with
+  // intermediate input), channel 9 moved to column 12 behind the three flattened structs
+  EXPECT(spec.fns[7].kind == VX355_AGG_COUNT && spec.fns[7].input_col == 12);
+  return 0;
+}
+
+int testQ1Fused() {
+  auto plan = shimtest::q1Plan(true);
+  FusedInput fused;
+  EXPECT(toFusedInput(plan.filter.get(), plan.project.get(), &fused));
+  EXPECT(fused.scanType->size() == 7);
+  EXPECT(fused.terms.size() == 1);
+  EXPECT(fused.terms[0].col == 6 && fused.terms[0].cmp == VX355_CMP_LE && fused.terms[0].const_kind == VX355_BIGINT &&
+         fused.terms[0].i64 == shimtest::kQ1Cutoff);
+  EXPECT(fused.projections.size() == 2 && fused.bindings.size() == 7);
+  // project output: returnflag, linestatus, quantity, extendedprice, disc_price, charge, discount
+  const int32_t expectCols[7] = {0, 1, 2, 3, VX355_PROJECTION_COL_BASE, VX355_PROJECTION_COL_BASE + 1, 4};
+  for (int i = 0; i < 7; ++i) {
+    EXPECT(fused.bindings[i].column == expectCols[i]);
+  }
+  // l_extendedprice * (1.0 - l_discount)
+  const auto& p0 = fused.projections[0];
+  EXPECT(p0.num_factors == 2);
+  EXPECT(p0.factors[0].col == 3 && p0.factors[0].scale == 1.0 && p0.factors[0].offset == 0.0 && std::signbit(p0.factors[0].offset));
+  EXPECT(p0.factors[1].col == 4 && p0.factors[1].scale == -1.0 && p0.factors[1].offset == 1.0);
+  // l_extendedprice * (1.0 - l_discount) * (1.0 + l_tax)
+  const auto& p1 = fused.projections[1];
+  EXPECT(p1.num_factors == 3);
+  EXPECT(p1.factors[2].col == 5 && p1.factors[2].scale == 1.0 && p1.factors[2].offset == 1.0);
+  AggSpec spec;
+  EXPECT(toAggSpec(*plan.partial, fused.bindings, ColumnLayout(fused.scanType), &spec));
+  EXPECT(spec.fns[2].input_col == VX355_PROJECTION_COL_BASE && spec.fns[3].input_col == VX355_PROJECTION_COL_BASE + 1);
+  EXPECT(spec.fns[6].kind == VX355_AGG_AVG && spec.fns[6].input_col == 4);  // avg(l_discount) reads the scan column
+  EXPECT(spec.fns[7].kind == VX355_AGG_COUNT_STAR);
+  return 0;
+}
+
+int testRefusals() {
+  auto scan = shimtest::q1Scan();
+  const auto& type = scan->outputType();
+  auto col = [&](const char* name) { return shimtest::field(type, name); };
+  auto project = [&](core::TypedExprPtr expr) {
+    return std::make_shared<core::ProjectNode>("p", std::vector<std::string>{"x"}, std::vector<core::TypedExprPtr>{expr}, scan);
+  };
+  auto sumOf = [&](const std::shared_ptr<const core::ProjectNode>& p) {
+    return shimtest::aggregation("a", core::AggregationNode::Step::kSingle, {}, {{"sum", "x", DOUBLE(), DOUBLE()}}, p);
+  };
+  FusedInput fused;
+  // a * (b * c) rounds differently from (a * b) * c: the projection is outside the class, and an
+  // aggregation that reads it is refused (the CPU FilterProject stays)
+  auto rightNested = project(shimtest::call("multiply", DOUBLE(),
+                                            {col("l_extendedprice"), shimtest::call("multiply", DOUBLE(), {col("l_discount"), col("l_tax")})}));
+  EXPECT(toFusedInput(nullptr, rightNested.get(), &fused));
+  EXPECT(fused.bindings[0].column == -1);
+  AggSpec spec;
+  EXPECT(!toAggSpec(*sumOf(rightNested), fused.bindings, ColumnLayout(fused.scanType), &spec));
+  // a comparison between two columns is not a column-vs-constant term
+  FusedInput f2;
+  auto twoColumns = std::make_shared<core::FilterNode>("f", shimtest::call("lt", BOOLEAN(), {col("l_discount"), col("l_tax")}), scan);
+  EXPECT(!toFusedInput(twoColumns.get(), nullptr, &f2));
+  // constant on the left: flipped
+  FusedInput f3;
+  auto flippedFilter = std::make_shared<core::FilterNode>(
+      "f", shimtest::call("gt", BOOLEAN(), {shimtest::constant(DOUBLE(), Variant(0.05)), col("l_discount")}), scan);
+  EXPECT(toFusedInput(flippedFilter.get(), nullptr, &f3));
+  EXPECT(f3.terms.size() == 1 && f3.terms[0].cmp == VX355_CMP_LT && f3.terms[0].const_kind == VX355_DOUBLE && f3.terms[0].f64 == 0.05);
+  // and(between(quantity, 1, 24), eq(returnflag, 'R'))
+  FusedInput f4;
+  auto conj = std::make_shared<core::FilterNode>(
+      "f",
+      shimtest::call("and", BOOLEAN(),
+                     {shimtest::call("between", BOOLEAN(),
+                                     {col("l_quantity"), shimtest::constant(DOUBLE(), Variant(1.0)), shimtest::constant(DOUBLE(), Variant(24.0))}),
+                      shimtest::call("eq", BOOLEAN(), {col("l_returnflag"), shimtest::constant(VARCHAR(), Variant("R"))})}),
+      scan);
+  EXPECT(toFusedInput(conj.get(), nullptr, &f4));
+  EXPECT(f4.terms.size() == 3 && f4.terms[0].cmp == VX355_CMP_GE && f4.terms[1].cmp == VX355_CMP_LE);
+  EXPECT(f4.terms[2].const_kind == VX355_VARCHAR && f4.terms[2].str_size == 1 && f4.terms[2].str[0] == 'R' && f4.terms[2].col == 0);
+  // an aggregate the library does not have
+  auto approx = shimtest::aggregation("a", core::AggregationNode::Step::kSingle, {"l_returnflag"},
+                                      {{"approx_distinct", "l_quantity", BIGINT(), DOUBLE()}}, scan);
+  AggSpec s2;
+  EXPECT(!toAggSpec(*approx, &s2));
+  // sum over a null constant: the constant travels as an extra CONSTANT column behind the batch's own
+  auto nullSum = shimtest::aggregationOverConstant("a", "sum", BIGINT(), Variant::null(TypeKind::BIGINT), scan);
+  AggSpec s3;
+  EXPECT(toAggSpec(*nullSum, &s3));
+  EXPECT(s3.constants.size() == 1 && s3.constants[0].isNull && s3.fns[0].input_col == 7 && s3.fns[0].kind == VX355_AGG_SUM);
+  // count(NULL) is not count(*)
+  auto nullCount = shimtest::aggregationOverConstant("a", "count", BIGINT(), Variant::null(TypeKind::BIGINT), scan);
+  AggSpec s4;
+  EXPECT(toAggSpec(*nullCount, &s4));
+  EXPECT(s4.fns[0].kind == VX355_AGG_COUNT && s4.fns[0].input_col == 7);
+  return 0;
+}
+
+int testDecodedBatchFlattensStructs() {
+  memory::MemoryPool pool;
+  const vector_size_t n = 130;
+  auto type = ROW({"k", "a", "c"}, {BIGINT(), ROW({"sum", "count"}, {DOUBLE(), BIGINT()}), BIGINT()});
+  auto input = std::static_pointer_cast<RowVector>(BaseVector::create(type, n, &pool));
+  auto* k = input->childAt(0)->asFlatVector<int64_t>();
+  auto* a = input->childAt(1)->as<RowVector>();
+  auto* sum = a->childAt(0)->asFlatVector<double>();
+  auto* count = a->childAt(1)->asFlatVector<int64_t>();
+  auto* c = input->childAt(2)->asFlatVector<int64_t>();
+  for (vector_size_t i = 0; i < n; ++i) {
+    k->set(i, i % 7);
+    sum->set(i, i * 0.5);
+    count->set(i, i);
+    c->set(i, 100 + i);
+    if (i % 5 == 0) {
+      a->setNull(i, true);  // the struct is null (a group without non-null input)
+    }
+  }
+  sum->setNull(3, true);  // a null field inside a non-null struct
+  ColumnLayout layout(type);
+  EXPECT(layout.numColumns == 4 && layout.first[2] == 3);
+  ConstantColumn seven;
+  seven.typeKind = VX355_BIGINT;
+  const int64_t v = 7;
+  std::memcpy(seven.value, &v, 8);
+  DecodedBatch batch(*input, layout, {seven});
+  const auto* b = batch.get();
+  EXPECT(b->num_rows == n && b->num_cols == 5);
+  EXPECT(b->cols[0].type_kind == VX355_BIGINT && b->cols[0].encoding == VX355_FLAT && b->cols[0].values == k->rawValues());
+  EXPECT(b->cols[1].type_kind == VX355_DOUBLE && b->cols[1].values == sum->rawValues());
+  EXPECT(b->cols[2].type_kind == VX355_BIGINT && b->cols[2].values == count->rawValues());
+  EXPECT(b->cols[3].values == c->rawValues() && b->cols[3].nulls == nullptr);
+  for (vector_size_t i = 0; i < n; ++i) {
+    const bool structNull = i % 5 == 0;
+    EXPECT(bits::isBitSet(b->cols[1].nulls, i) == !(structNull || i == 3));
+    EXPECT(bits::isBitSet(b->cols[2].nulls, i) == !structNull);
+  }
+  EXPECT(b->cols[4].encoding == VX355_CONSTANT && *static_cast<const int64_t*>(b->cols[4].values) == 7 && b->cols[4].nulls == nullptr);
+
+  // the same struct behind a dictionary (what a local exchange / a filter leaves): flattened first
+  auto indices = allocateIndices(n, &pool);
+  for (vector_size_t i = 0; i < n; ++i) {
+    indices->asMutable<vector_size_t>()[i] = n - 1 - i;
+  }
+  std::vector<VectorPtr> children = {input->childAt(0), BaseVector::wrapInDictionary(nullptr, indices, n, input->childAt(1)),
+                                     input->childAt(2)};
+  RowVector wrapped(&pool, type, nullptr, n, children);
+  DecodedBatch batch2(wrapped, layout, {});
+  const auto* b2 = batch2.get();
+  EXPECT(b2->num_cols == 4 && b2->cols[1].encoding == VX355_FLAT);
+  for (vector_size_t i = 0; i < n; ++i) {
+    const vector_size_t src = n - 1 - i;
+    const bool structNull = src % 5 == 0;
+    EXPECT(bits::isBitSet(b2->cols[2].nulls, i) == !structNull);
+    if (!structNull) {
+      EXPECT(static_cast<const int64_t*>(b2->cols[2].values)[i] == src);
+      if (src != 3) {
+        EXPECT(static_cast<const double*>(b2->cols[1].values)[i] == src * 0.5);
+      }
+    }
+  }
+
+  // dictionary and constant scalar children keep their encoding (DecodedVector's three shapes)
+  auto dictChild = BaseVector::wrapInDictionary(nullptr, indices, n, input->childAt(0));
+  auto constChild = BaseVector::wrapInConstant(n, 5, input->childAt(2));
+  auto nullConst = BaseVector::createNullConstant(BIGINT(), n, &pool);
+  auto type3 = ROW({"d", "c", "z"}, {BIGINT(), BIGINT(), BIGINT()});
+  RowVector encoded(&pool, type3, nullptr, n, {dictChild, constChild, nullConst});
+  DecodedBatch batch3(encoded);
+  const auto* b3 = batch3.get();
+  EXPECT(b3->cols[0].encoding == VX355_DICTIONARY && b3->cols[0].base_size == n && b3->cols[0].indices[0] == n - 1);
+  EXPECT(b3->cols[1].encoding == VX355_CONSTANT && *static_cast<const int64_t*>(b3->cols[1].values) == 105);
+  EXPECT(b3->cols[2].encoding == VX355_CONSTANT && b3->cols[2].nulls != nullptr && (b3->cols[2].nulls[0] & 1) == 0);
+  return 0;
+}
+
+int testOutColumnsAssembleStructs() {
+  memory::MemoryPool pool;
+  auto type = ROW({"k", "a", "n"}, {BIGINT(), ROW({"sum", "count"}, {DOUBLE(), BIGINT()}), BIGINT()});
+  const vector_size_t capacity = 100;
+  auto result = std::static_pointer_cast<RowVector>(BaseVector::create(type, capacity, &pool));
+  OutColumns out(*result);
+  EXPECT(out.size() == 4);
+  EXPECT(out.data()[1].type_kind == VX355_DOUBLE && out.data()[2].type_kind == VX355_BIGINT);
+  // what the library does: values + validity per flat column
+  const vector_size_t n = 70;
+  for (int c = 0; c < 4; ++c) {
+    EXPECT(out.data()[c].values != nullptr && out.data()[c].nulls != nullptr);
+    std::memset(out.data()[c].nulls, 0xff, bits::nwords(capacity) * 8);
+  }
+  for (vector_size_t i = 0; i < n; ++i) {
+    static_cast<int64_t*>(out.data()[0].values)[i] = i;
+    static_cast<double*>(out.data()[1].values)[i] = i * 1.5;
+    static_cast<int64_t*>(out.data()[2].values)[i] = i + 1;
+    static_cast<int64_t*>(out.data()[3].values)[i] = 2 * i;
+    if (i % 9 == 4) {  // a group whose avg saw no input: (null, null)
+      bits::clearBit(out.data()[1].nulls, i);
+      bits::clearBit(out.data()[2].nulls, i);
+    }
+  }
+  out.finish(n);
+  result->resize(n);
+  auto* a = result->childAt(1)->as<RowVector>();
+  EXPECT(a != nullptr && a->size() == n);
+  for (vector_size_t i = 0; i < n; ++i) {
+    EXPECT(a->isNullAt(i) == (i % 9 == 4));
+    if (!a->isNullAt(i)) {
+      EXPECT(a->childAt(0)->asFlatVector<double>()->valueAt(i) == i * 1.5);
+      EXPECT(a->childAt(1)->asFlatVector<int64_t>()->valueAt(i) == i + 1);
+    }
+    EXPECT(result->childAt(2)->asFlatVector<int64_t>()->valueAt(i) == 2 * i);
+  }
+  return 0;
+}
+
+int testJoinPlan() {
+  // TPC-H Q3's second join: lineitem (probe) x filtered orders (build) on l_orderkey = o_orderkey,
+  // emitting probe columns and two build columns (TpchQueryBuilder.cpp:467-558)
+  auto probe = std::make_shared<core::ValuesNode>("l", ROW({"l_orderkey", "l_extendedprice", "l_discount"}, {BIGINT(), DOUBLE(), DOUBLE()}));
+  auto build = std::make_shared<core::ValuesNode>("o", ROW({"o_orderkey", "o_orderdate", "o_shippriority"}, {BIGINT(), DATE(), INTEGER()}));
+  auto outputType = ROW({"l_extendedprice", "l_discount", "o_orderdate", "o_shippriority", "l_orderkey"},
+                        {DOUBLE(), DOUBLE(), DATE(), INTEGER(), BIGINT()});
+  auto join = std::make_shared<core::HashJoinNode>(
+      "j", core::JoinType::kInner, false, false,
+      std::vector<core::FieldAccessTypedExprPtr>{shimtest::field(probe->outputType(), "l_orderkey")},
+      std::vector<core::FieldAccessTypedExprPtr>{shimtest::field(build->outputType(), "o_orderkey")}, nullptr, probe, build, outputType);
+  JoinPlan plan;
+  EXPECT(toJoinPlan(*join, &plan));
+  EXPECT(plan.type == VX355_JOIN_INNER && plan.probeKeys[0] == 0 && plan.buildKeys[0] == 0 && plan.buildKeyTypes[0] == VX355_BIGINT);
+  EXPECT(plan.dependentChannels.size() == 2 && plan.dependentChannels[0] == 1 && plan.dependentChannels[1] == 2);
+  EXPECT(plan.dependentTypes[0] == VX355_INTEGER && plan.dependentOutputs[0] == 2 && plan.dependentOutputs[1] == 3);
+  EXPECT(plan.probeOutputs.size() == 3 && plan.probeOutputs[2].first == 0 && plan.probeOutputs[2].second == 4);
+  EXPECT(!plan.dropDuplicates);
+  // a left semi join without filter only asks whether a key exists
+  auto semi = std::make_shared<core::HashJoinNode>(
+      "s", core::JoinType::kLeftSemiFilter, false, false,
+      std::vector<core::FieldAccessTypedExprPtr>{shimtest::field(probe->outputType(), "l_orderkey")},
+      std::vector<core::FieldAccessTypedExprPtr>{shimtest::field(build->outputType(), "o_orderkey")}, nullptr, probe, build,
+      ROW({"l_orderkey"}, {BIGINT()}));
+  JoinPlan semiPlan;
+  EXPECT(toJoinPlan(*semi, &semiPlan));
+  EXPECT(semiPlan.type == VX355_JOIN_LEFT_SEMI_FILTER && semiPlan.dropDuplicates && semiPlan.dependentChannels.empty());
+  return 0;
+}
+
+int testAdapterLeavesTheCpuOperatorsWithoutAGpu() {
+  // no vx355_init: vx355_agg_create refuses, the Driver keeps its CPU operators and nothing leaks
+  auto plan = shimtest::q1Plan(true);
+  auto task = std::make_shared<exec::Task>("t0");
+  auto driver = std::make_shared<exec::Driver>(std::make_unique<exec::DriverCtx>(task, 0, 0, 0, 0));
+  exec::DriverFactory factory;
+  factory.planNodes = {plan.scan, plan.filter, plan.project, plan.partial};
+  driver->mutableOperators().push_back(std::make_unique<exec::FilterProject>(0, driver->driverCtx(), plan.filter, plan.project));
+  driver->mutableOperators().push_back(std::make_unique<exec::HashAggregation>(1, driver->driverCtx(), plan.partial));
+  if (vx355_device_count() == 0) {
+    EXPECT(!adaptDriver(factory, *driver));
+    EXPECT(driver->operators().size() == 2 && dynamic_cast<exec::HashAggregation*>(driver->operators()[1]) != nullptr);
+  }
+  return 0;
+}
+
+}  // namespace
+
+int main() {
+  struct {
+    const char* name;
+    int (*fn)();
+  } tests[] = {{"Q1 partial aggregation, unfused", testQ1PartialUnfused},
+               {"Q1 final aggregation over ROW intermediates", testQ1Final},
+               {"Q1 FilterProject fusion", testQ1Fused},
+               {"refusals and constants", testRefusals},
+               {"DecodedBatch flattens structs", testDecodedBatchFlattensStructs},
+               {"OutColumns assemble structs", testOutColumnsAssembleStructs},
+               {"join plans", testJoinPlan},
+               {"adapter without a GPU", testAdapterLeavesTheCpuOperatorsWithoutAGpu}};
+  for (const auto& t : tests) {
+    try {
+      if (t.fn() != 0) {
+        std::fprintf(stderr, "FAILED: %s\n", t.name);
+        return 1;
+      }
+    } catch (const std::exception& e) {
+      std::fprintf(stderr, "FAILED: %s threw %s\n", t.name, e.what());
+      return 1;
+    }
+    std::printf("ok: %s\n", t.name);
+  }
+  std::printf("shim plan tests: the reference's Q1 plan is accepted\n");
+  return 0;
+}

@@ -36,6 +36,7 @@
 #include "expr_device.h"
 
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 #include <chrono>
 #include <cmath>
@@ -3473,7 +3474,7 @@ __global__ __launch_bounds__(256) void k_fs_rank(const uint64_t* recs, const uin
 // ranking all of them alone took 20 us: 16 000 broadcast reads on one CU).
 constexpr int kSmallSortMax = 4096;
 __global__ __launch_bounds__(1024) void k_collect_sort_small(const uint64_t* table, uint32_t rows, int32_t stride,
-                                                              uint32_t* orderOut, uint32_t* found) {
+                                                              uint32_t* orderOut, uint32_t capacityOut, uint32_t* found) {
   __shared__ uint64_t keys[kSmallSortMax];
   __shared__ uint32_t vals[kSmallSortMax];
   __shared__ uint32_t waveCount[16];
@@ -3520,7 +3521,9 @@ __global__ __launch_bounds__(1024) void k_collect_sort_small(const uint64_t* tab
     atomicAdd(&rank[threadIdx.x & 63], smaller);
   }
   blockSync();
-  if (threadIdx.x < 64 && mineAt < n) {
+  // (more live rows than the host counted groups is the broken invariant *found reports: such ranks
+  // must not be written behind the capacityOut entries of the list - *found sits right there)
+  if (threadIdx.x < 64 && mineAt < n && rank[threadIdx.x] < capacityOut) {
     orderOut[rank[threadIdx.x]] = vals[mineAt];
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -3531,7 +3534,7 @@ __global__ __launch_bounds__(1024) void k_collect_sort_small(const uint64_t* tab
 // The same for a table too large for one workgroup to scan: k_collect has listed the live rows,
 // *count of them (<= kSmallSortMax, the host knows the number of groups); one workgroup ranks them.
 __global__ __launch_bounds__(1024) void k_rank_sort_small(const uint64_t* firstIn, const uint32_t* indexIn,
-                                                           const uint32_t* count, uint32_t* orderOut) {
+                                                           const uint32_t* count, uint32_t* orderOut, uint32_t capacityOut) {
   __shared__ uint64_t keys[kSmallSortMax];
   __shared__ uint32_t rank[64];
   const uint32_t n = *count < static_cast<uint32_t>(kSmallSortMax) ? *count : static_cast<uint32_t>(kSmallSortMax);
@@ -3556,7 +3559,7 @@ __global__ __launch_bounds__(1024) void k_rank_sort_small(const uint64_t* firstI
     atomicAdd(&rank[threadIdx.x & 63], smaller);
   }
   blockSync();
-  if (threadIdx.x < 64 && mineAt < n) {
+  if (threadIdx.x < 64 && mineAt < n && rank[threadIdx.x] < capacityOut) {
     orderOut[rank[threadIdx.x]] = indexIn[mineAt];
   }
 }
@@ -3957,6 +3960,10 @@ using namespace vx;
 struct vx355_agg {
   vx::Runtime* ctx = nullptr;  // this operator's execution context (stream, mailbox)
   vx::AsyncQueue* aq = nullptr;  // worker of vx355_agg_add_input_async (created on first use)
+  // vx355_agg_table_bytes: what get_stats would report, as of the last batch fed (written by
+  // whichever thread feeds - the Driver thread or the queue's worker -, read without waiting)
+  std::atomic<int64_t> publishedTableBytes{0};
+  std::atomic<int64_t> publishedGroups{0};
   int32_t step;
   bool ignoreNullKeys;
   std::vector<KeyState> keys;
@@ -6787,7 +6794,8 @@ void finalize(vx355_agg& h) {
   if (!listed && !h.unorderedOutput && h.capacity <= 65536 && g <= static_cast<size_t>(kSmallSortMax)) {
     uint32_t* order = static_cast<uint32_t*>(h.orderVals.ensure(g * 4 + 64));
     VX_LAUNCH("k_collect_sort_small", k_collect_sort_small, static_cast<int>(ceilDiv(static_cast<int64_t>(g), 64)), 1024,
-              0, h.table.as<uint64_t>(), static_cast<uint32_t>(h.capacity), h.stride, order, order + g);
+              0, h.table.as<uint64_t>(), static_cast<uint32_t>(h.capacity), h.stride, order, static_cast<uint32_t>(g),
+              order + g);
     h.order = order;
     h.numOutput = static_cast<int64_t>(g);
     h.collectCheck = static_cast<int64_t>(g);  // verified behind the first output page's synchronisation
@@ -6807,7 +6815,7 @@ void finalize(vx355_agg& h) {
       uint32_t* order = static_cast<uint32_t*>(h.orderVals2.ensure(g * 4 + 64));
       VX_LAUNCH("k_rank_sort_small", k_rank_sort_small, static_cast<int>(ceilDiv(static_cast<int64_t>(g), 64)), 1024, 0,
                 h.orderKeys.as<uint64_t>(),
-                h.orderVals.as<uint32_t>(), cursor, order);
+                h.orderVals.as<uint32_t>(), cursor, order, static_cast<uint32_t>(g));
       copyIn(order + g, cursor, VX355_MEM_DEVICE, 4);  // the count, for the check behind the output page
       h.order = order;
       h.numOutput = static_cast<int64_t>(g);
@@ -6844,6 +6852,26 @@ void finalize(vx355_agg& h) {
   h.numOutput = static_cast<int64_t>(g);
 }
 
+// HBM held by the group table (+ the set tables of DISTINCT aggregates / min / max over strings):
+// what GroupingSet::isPartialFull compares with max_partial_aggregation_memory.
+static int64_t tableBytesOf(const vx355_agg& h) {
+  int64_t bytes = static_cast<int64_t>(h.table.capacity());
+  for (const auto& d : h.distinct) {
+    if (d.dedup) {
+      bytes += static_cast<int64_t>(d.dedup->table.capacity());
+      for (const auto& b : d.dedup->strBlocks) {
+        bytes += static_cast<int64_t>(b.capacity());
+      }
+    }
+  }
+  return bytes;
+}
+
+static void publishStats(vx355_agg& h) {
+  h.publishedTableBytes.store(tableBytesOf(h), std::memory_order_relaxed);
+  h.publishedGroups.store(h.keys.empty() ? 1 : h.numGroups, std::memory_order_relaxed);
+}
+
 // GroupingSet::resetTable after a partial flush (HashAggregation::resetPartialOutputIfNeed,
 // HashAggregation.cpp:293-318): the table is emptied, key ranges and the mode stay.
 void resetAfterFlush(vx355_agg& h) {
@@ -6875,6 +6903,7 @@ void resetAfterFlush(vx355_agg& h) {
   h.order = nullptr;
   h.flushing = false;
   ++h.numFlushes;
+  publishStats(h);  // vx355_agg_table_bytes: the table is empty again
 }
 
 // ---- min / max over VARCHAR / VARBINARY ----------------------------------------------------
@@ -7810,6 +7839,7 @@ int vx355_agg_add_input(vx355_agg* h, const vx355_batch* batch) {
   for (auto& d : h->distinct) {
     feedInput(*d.dedup, batch);
   }
+  publishStats(*h);
   VX_API_END
 }
 
@@ -7991,18 +8021,23 @@ int vx355_agg_get_stats(const vx355_agg* h, vx355_agg_stats* out) {
   out->radix_launches = h->radixLaunches;
   out->input_rows = h->inputRows + h->coalescer.pendingRows();
   out->deferred_rows = h->deferredRows;
-  out->table_bytes = static_cast<int64_t>(h->table.capacity());
-  for (const auto& d : h->distinct) {
-    // the set tables of DISTINCT aggregates / min / max over strings count towards isPartialFull
-    if (d.dedup) {
-      out->table_bytes += static_cast<int64_t>(d.dedup->table.capacity());
-      for (const auto& b : d.dedup->strBlocks) {
-        out->table_bytes += static_cast<int64_t>(b.capacity());
-      }
-    }
-  }
+  out->table_bytes = tableBytesOf(*h);
   out->num_flushes = h->numFlushes;
   VX_API_END
+}
+
+int vx355_agg_table_bytes(const vx355_agg* h, int64_t* table_bytes, int64_t* num_groups) {
+  if (!h) {
+    vx::setLastError("NULL argument");
+    return VX355_EINVAL;
+  }
+  if (table_bytes) {
+    *table_bytes = h->publishedTableBytes.load(std::memory_order_relaxed);
+  }
+  if (num_groups) {
+    *num_groups = h->publishedGroups.load(std::memory_order_relaxed);
+  }
+  return VX355_OK;
 }
 
 void* vx355_agg_stream(vx355_agg* h) { return h ? static_cast<void*>(h->ctx->stream) : nullptr; }
@@ -8045,6 +8080,7 @@ int vx355_agg_add_input_async(vx355_agg* h, const vx355_batch* batch, int64_t* t
       for (auto& d : h->distinct) {
         feedInput(*d.dedup, b);
       }
+      publishStats(*h);
       VX_API_END
     });
     if (ticket_out) {

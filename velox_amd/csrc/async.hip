@@ -461,12 +461,14 @@ int64_t asyncSubmitBatch(AsyncQueue* q, DeviceState* ds, const vx355_batch* batc
     offset = c->rows;
     c->rows += n;
     ++c->tickets;
+    // Still under ing->m: a poll / get_stats / wait / destroy from another thread may seal this chunk
+    // (sealOpenChunk) the moment the lock is dropped, and a sealed chunk must hold every batch whose
+    // rows and ticket it counts. (Copier tasks carry pointers to the batches themselves; the worker
+    // clears the list after pending == 0. handOutCopies only takes c->m, as it does under seal.)
+    c->batches.push_back(std::make_unique<OwnedBatch>(batch));
+    c->offsets.push_back(offset);
+    handOutCopies(ing, c, false);
   }
-  // (only the submitting thread appends; copier tasks carry pointers to the batches themselves; the
-  // worker clears the list after pending == 0)
-  c->batches.push_back(std::make_unique<OwnedBatch>(batch));
-  c->offsets.push_back(offset);
-  handOutCopies(ing, c, false);
   return reserveTicket(q);
 }
 

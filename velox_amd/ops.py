@@ -43,7 +43,7 @@ SYMBOLS = [
     "vx355_value_dict_destroy",
     "vx355_all_gather_v", "vx355_exchange_create", "vx355_exchange_send", "vx355_exchange_receive",
     "vx355_exchange_stream", "vx355_exchange_destroy", "vx355_exchange_destinations", "vx355_join_repartition", "vx355_agg_merge_partials",
-    "vx355_hbm_ceiling", "vx355_compose_indices",
+    "vx355_hbm_ceiling", "vx355_compose_indices", "vx355_agg_table_bytes",
 ]
 
 # int (*vx355_join_chunk_sink)(void* arg, int32_t chunk, const vx355_batch* received, vx355_join_probe* probe)
@@ -101,6 +101,7 @@ def lib():
     L.vx355_agg_output_types.argtypes = [vp, P(i32), i32, P(i32)]
     L.vx355_agg_get_output.argtypes = [vp, P(abi.OutColumn), i32, i32, P(i32), P(i32)]
     L.vx355_agg_get_stats.argtypes = [vp, P(abi.AggStats)]
+    L.vx355_agg_table_bytes.argtypes = [vp, P(C.c_int64), P(C.c_int64)]
     L.vx355_agg_flush.argtypes = [vp]
     L.vx355_agg_to_intermediate.argtypes = [vp, P(abi.Batch), P(abi.OutColumn), i32]
     L.vx355_agg_destroy.argtypes = [vp]
