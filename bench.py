@@ -774,10 +774,12 @@ class Q3Full:
     lineitem (~600 M, dbgen order) -> probe -> 3-key aggregation. rows = customer +
     orders + lineitem rows scanned per step; scan bytes 24 + 24 + 28 B/row."""
     name = "tpch_q3_sf100_full_query"
-    # both probes read dictionary-wrapped keys: 4-byte index + 8-byte key in, 4-byte hit out
+    # both probes read their flat key column and the date column of the fused filter:
+    # 8-byte key + 4-byte date in (+ 4-byte hit out for the dense form)
     agg_bytes_per_row = 16
     contract_bytes_per_row = 24
     dominant = "k_join_probe"
+    fuse_filters = True
 
     def __init__(self, torch, n, device, seed):
         from velox_amd import tpch
@@ -825,7 +827,7 @@ class Q3Full:
         return self.scan_bytes / self.rows
 
     def step(self, step_kind=None):
-        out, info = self.tpch.run_q3(ops, self.torch, self.t)
+        out, info = self.tpch.run_q3(ops, self.torch, self.t, fuse_filters=self.fuse_filters)
         self.last_info = info
         self.selected = info["orders_selected"] + info["lineitems_selected"]   # rows the two probes see
         return out
@@ -842,11 +844,11 @@ class Q3Full:
         if listing >= dense:
             self.dominant = "k_join_probe_list"
             self.selected = self.last_info["lineitems_selected"]
-            self.agg_bytes_per_row = 12   # 4-byte index + 8-byte key in; only matches are written
+            self.agg_bytes_per_row = 12   # 8-byte key + 4-byte l_shipdate (fused filter) in; only matches are written
         else:
             self.dominant = "k_join_probe"
             self.selected = self.last_info["orders_selected"]
-            self.agg_bytes_per_row = 16   # + 4-byte hit out
+            self.agg_bytes_per_row = 16   # 8-byte key + 4-byte o_orderdate in, 4-byte hit out
 
     def info(self):
         return dict(self.last_info, rows={k: int(v.shape[0]) for k, v in self.t.items()
@@ -1247,6 +1249,10 @@ def main():
     n = n_total if (world == 1 or args.scaling == "weak") else max(1, n_total // world)
     if args.workload == "q3":
         cls.random_probe = args.q3_random_probe
+    if args.workload == "q3full":
+        cls.fuse_filters = not args.unfused
+        if args.unfused:
+            cls.name = "tpch_q3_sf100_full_query_unfused_filters"
     if args.workload == "c1":
         cls.stream = args.c1_stream
     if args.workload == "c4":

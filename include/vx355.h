@@ -816,6 +816,21 @@ typedef struct vx355_join_filter_term {
   char str[16];
 } vx355_join_filter_term;
 int vx355_join_probe_set_filter(vx355_join_probe* h, const vx355_join_filter_term* terms, int32_t n_terms);
+/* Operator fusion FilterProject -> HashProbe (ABI 7), the join-side twin of vx355_agg_set_fused_input:
+ * the adapter replaces a FilterProject that only filters (FilterNode without computed projections:
+ * every output column is an input column, exec/FilterProject.cpp:25-41) and the HashProbe behind it
+ * with one operator. After this call the batches handed to vx355_join_probe_add_input are the
+ * FilterProject's INPUT batches; a row failing the conjunction (vx355_filter_term, nulls fail) is
+ * treated as a probe row that found nothing. mapping_out of get_output then numbers the rows of the
+ * unfiltered batch - exactly the composition of FilterProject's selected indices with the probe's
+ * mapping that the two separate operators produce (exec/OperatorUtils.cpp:393-422). TPC-H Q3 probes
+ * lineitem WHERE l_shipdate > d and orders WHERE o_orderdate < d this way: no selection-bitmap pass,
+ * no compaction, no index vector between the scan and the probe.
+ * Only join kinds whose unmatched probe rows emit nothing (INNER, RIGHT, LEFT_SEMI_FILTER,
+ * COUNTING_LEFT_SEMI_FILTER, RIGHT_SEMI_*, RIGHT_ANTI), not null aware; anything else is
+ * VX355_EUNSUPPORTED and the FilterProject stays its own operator. Call before the first add_input;
+ * up to 4 terms over columns of the probe batch. */
+int vx355_join_probe_set_input_filter(vx355_join_probe* h, const vx355_filter_term* terms, int32_t n_terms);
 /* QueryConfig::preferredOutputBatchBytes (core/QueryConfig.h:479), the second bound of
  * listJoinResults (exec/HashTable.cpp:2087-2153): get_output stops a page once the requested build
  * columns of its rows reach 'bytes' (at least one row per page). 0 = row bound only. */

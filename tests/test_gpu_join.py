@@ -1094,3 +1094,150 @@ def test_build_side_drops_duplicate_keys_for_semi_and_anti_joins(oracle, vx, joi
     with pytest.raises(vx.Vx355Error) as e:
         vx.JoinBuild([0], [kind], [], [], abi.JOIN_INNER, drop_duplicates=True)
     assert e.value.status == abi.EINVAL
+
+
+@pytest.mark.parametrize("join_type", [abi.JOIN_INNER, abi.JOIN_LEFT_SEMI_FILTER, abi.JOIN_RIGHT])
+@pytest.mark.parametrize("shape", ["array_listing", "array_dense_hits", "array_partitioned", "normalized", "hash",
+                                   "dictionary_key", "two_keys_nullable_filter_column", "array_bigint_column_ne",
+                                   "array_partitioned_le"])
+def test_input_filter_fused_into_the_probe(oracle, vx, shape, join_type, monkeypatch):
+    """FilterProject -> HashProbe fusion (vx355_join_probe_set_input_filter): probing the UNFILTERED
+    batch with the filter inside the probe kernels equals filtering first (numpy here, FilterProject
+    in a plan) and probing the selected rows with the oracle, the mappings composed with the
+    selection (exec/OperatorUtils.cpp:393-422). Every probe kernel family: the listing probe, the
+    dense form (tiles full of hits), the range-partitioned probe (both scatter variants), normalized
+    keys, generic hash mode, a dictionary-wrapped key, two keys with a nullable filter column and a
+    second term on a DOUBLE column."""
+    rng = np.random.default_rng(123)
+    nb, npb = 70000, 700_000      # 64 x build rows >= the key range: array mode unless forced otherwise
+    space = 4_000_000
+    if shape.startswith("array_partitioned"):
+        monkeypatch.setenv("VX355_JOIN_PARTITION", "1")
+    if shape == "normalized":
+        monkeypatch.setenv("VX355_JOIN_ARRAY_MAX", "0")
+        space = 1 << 40
+    bk = np.unique(rng.integers(0, space, nb + nb // 4)).astype(np.int64)
+    bk = rng.permutation(bk)[:nb]
+    pay = rng.integers(0, 1 << 30, nb).astype(np.int64)
+    pk = rng.integers(0, space, npb).astype(np.int64)
+    pk[::40] = bk[rng.integers(0, nb, len(pk[::40]))]
+    if shape == "array_dense_hits":
+        pk[100_000:200_000] = bk[rng.integers(0, nb, 100_000)]
+    date = rng.integers(9000, 9400, npb).astype(np.int32)
+    price = rng.integers(0, 1000, npb).astype(np.float64) / 8
+    valid_date = None
+    terms = [(1, abi.CMP_GT, 9204)]
+    keep = date > 9204
+    if shape == "array_bigint_column_ne":
+        date = rng.integers(9200, 9208, npb).astype(np.int64)      # the range form of <> on a BIGINT column
+        terms = [(1, abi.CMP_NE, 9204)]
+        keep = date != 9204
+    if shape == "array_partitioned_le":
+        terms = [(1, abi.CMP_LE, 9204)]
+        keep = date <= 9204
+    key_cols, key_types = [0], [abi.BIGINT]
+    build_cols, probe_cols = [bk, pay], [pk, date, price]
+    dep_cols = [1]
+    if shape == "hash":
+        # a string key forces the generic hash mode
+        key_types = [abi.VARCHAR]
+        build_cols = [[b"k%015d" % v for v in bk], pay]
+        probe_cols = [[b"k%015d" % v for v in pk], date, price]
+    if shape == "two_keys_nullable_filter_column":
+        k2b = rng.integers(0, 3, nb).astype(np.int32)
+        k2p = rng.integers(0, 3, npb).astype(np.int32)
+        key_cols, key_types = [0, 3], [abi.BIGINT, abi.INTEGER]
+        build_cols = [bk, pay, pay, k2b]
+        probe_cols = [pk, date, price, k2p]
+        valid_date = rng.random(npb) > 0.1
+        terms = [(1, abi.CMP_GT, 9204), (2, abi.CMP_LE, 100.0)]
+        keep = (date > 9204) & valid_date & (price <= 100.0)     # a null fails its term
+    sel = np.flatnonzero(keep)
+
+    def host_batch(cols, rows=None):
+        out = []
+        for i, c in enumerate(cols):
+            valid = valid_date if (i == 1 and valid_date is not None) else None
+            if rows is not None:
+                c = [c[j] for j in rows] if isinstance(c, list) else c[rows]
+                valid = None if valid is None else valid[rows]
+            out.append(c if valid is None else abi.HostColumn(abi.INTEGER, np.ascontiguousarray(c), np.ascontiguousarray(valid)))
+        return batch_of(out)
+
+    res = {}
+    for impl in (oracle, vx):
+        b = impl.JoinBuild(key_cols, key_types, dep_cols, [abi.BIGINT], join_type)
+        b.add_input(batch_of(build_cols))
+        table = b.finish()
+        probe = impl.JoinProbe(table, key_cols, join_type)
+        if impl is vx:
+            probe.set_input_filter(terms)
+            if shape == "dictionary_key":
+                # the key column behind a dictionary (a pass-through column of an upstream operator)
+                perm = rng.permutation(npb).astype(np.int32)
+                inv = np.empty(npb, dtype=np.int32)
+                inv[perm] = np.arange(npb, dtype=np.int32)
+                hb = abi.HostBatch([abi.HostColumn(abi.BIGINT, pk[perm], None, abi.DICTIONARY, inv),
+                                    abi.HostColumn(abi.INTEGER, date), abi.HostColumn(abi.DOUBLE, price)])
+            else:
+                hb = host_batch(probe_cols)
+            vx.profile_reset()
+            vx.profile_enable(True)
+            probe.add_input(hb)
+        else:
+            probe.add_input(host_batch(probe_cols, sel))
+        maps, rows, pays = [], [], []
+        while True:
+            m, r, cols, fin = probe.get_output(50001, [0])
+            maps.append(np.asarray(m))
+            rows.append(np.asarray(r))
+            pays.append(np.where(np.asarray(cols[0][1]), np.asarray(cols[0][0]), -1))
+            if fin:
+                break
+        mapping = np.concatenate(maps)
+        if impl is oracle:
+            mapping = sel[mapping]       # FilterProject's indices under the probe's
+        out = [mapping, np.concatenate(rows), np.concatenate(pays)]
+        if impl is vx:
+            vx.profile_enable(False)
+            names = set(vx.profile().keys())
+            if shape.startswith("array_partitioned"):
+                assert "k_join_probe_part" in names and "k_pp_scatter" in names
+            if shape.startswith("array") or shape == "dictionary_key":
+                assert table.stats().hash_mode == 1
+            assert "k_filter_bits" not in names and "k_compact_write" not in names
+        if join_type == abi.JOIN_RIGHT:
+            br, bfin = [], False
+            while not bfin:
+                r2, c2, bfin = probe.get_build_side_output(60000, [0])
+                br.append(np.asarray(r2))
+            out.append(np.concatenate(br))
+        res[impl.__name__] = out
+    for g, e in zip(res[vx.__name__], res[oracle.__name__]):
+        assert len(g) == len(e) and (g == e).all()
+    assert len(res[vx.__name__][0]) > 1000
+
+
+def test_input_filter_is_refused_where_unmatched_probe_rows_come_out(vx):
+    t = vx.JoinBuild([0], [abi.BIGINT], [], [], abi.JOIN_LEFT)
+    t.add_input(batch_of([np.arange(10, dtype=np.int64)]))
+    table = t.finish()
+    for jt in (abi.JOIN_LEFT,):
+        p = vx.JoinProbe(table, [0], jt)
+        with pytest.raises(vx.Vx355Error) as e:
+            p.set_input_filter([(0, abi.CMP_GT, 3)])
+        assert e.value.status == abi.EUNSUPPORTED
+    for jt in (abi.JOIN_ANTI, abi.JOIN_FULL, abi.JOIN_LEFT_SEMI_PROJECT):
+        b = vx.JoinBuild([0], [abi.BIGINT], [], [], jt)
+        b.add_input(batch_of([np.arange(10, dtype=np.int64)]))
+        p = vx.JoinProbe(b.finish(), [0], jt)
+        with pytest.raises(vx.Vx355Error) as e:
+            p.set_input_filter([(0, abi.CMP_GT, 3)])
+        assert e.value.status == abi.EUNSUPPORTED
+    # after the first batch it is too late
+    b = vx.JoinBuild([0], [abi.BIGINT], [], [], abi.JOIN_INNER)
+    b.add_input(batch_of([np.arange(10, dtype=np.int64)]))
+    p = vx.JoinProbe(b.finish(), [0], abi.JOIN_INNER)
+    p.add_input(batch_of([np.arange(5, dtype=np.int64)]))
+    with pytest.raises(vx.Vx355Error):
+        p.set_input_filter([(0, abi.CMP_GT, 3)])

@@ -31,7 +31,11 @@ def _tables(rng, n_cust=3000, n_orders=30000):
                 l_shipdate=l_shipdate, l_extendedprice=l_ep, l_discount=l_disc)
 
 
-def test_q3_pipeline_matches_pandas(vx):
+@pytest.mark.parametrize("fuse_filters", [True, False])
+def test_q3_pipeline_matches_pandas(vx, fuse_filters):
+    """fuse_filters: the date filters inside the probes (vx355_join_probe_set_input_filter; the probes'
+    output pages are smaller than their outputs here, so the paged hand-over to the next build / the
+    aggregation runs too) or as FilterProject passes in front of them."""
     import torch
     rng = np.random.default_rng(77)
     t = _tables(rng)
@@ -39,7 +43,7 @@ def test_q3_pipeline_matches_pandas(vx):
     views, _keep = abi.string_views(t["c_mktsegment"])
     tables = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in t.items() if k != "c_mktsegment"}
     tables["c_mktsegment"] = torch.from_numpy(np.ascontiguousarray(views).view(np.int32).reshape(-1, 4)).to(dev)
-    out, info = tpch.run_q3(vx, torch, tables)
+    out, info = tpch.run_q3(vx, torch, tables, fuse_filters=fuse_filters)
     cust = pd.DataFrame({"c_custkey": t["c_custkey"], "seg": [s.decode() for s in t["c_mktsegment"]]})
     orders = pd.DataFrame({k: t[k] for k in ("o_orderkey", "o_custkey", "o_orderdate", "o_shippriority")})
     line = pd.DataFrame({k: t[k] for k in ("l_orderkey", "l_shipdate", "l_extendedprice", "l_discount")})

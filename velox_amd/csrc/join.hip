@@ -40,6 +40,7 @@ std::mutex gNoTableMutex;
 void compactBits(const uint64_t* dValues, const uint64_t* dNulls, const uint64_t* dRows,
                  int64_t numRows, int32_t* dOut, DevBuf& scratch, int64_t* total);
 void sortKeysU64(const uint64_t* in, uint64_t* out, size_t n, DevBuf& tmp);
+void makeTermArgs(const DeviceBatch& db, const vx355_filter_term* terms, int32_t n, TermArg* out);  // exprs.hip
 
 namespace {
 
@@ -717,6 +718,32 @@ constexpr int kProbeUnroll = 4;      // probes per lane in flight
 #endif
 constexpr int kProbeUnrollFast = VX355_PROBE_UNROLL_FAST;  // ... of the flat BIGINT key paths
 
+// FilterProject -> HashProbe fusion (vx355_join_probe_set_input_filter): the conjunction the
+// FilterProject in front of the probe would have applied, evaluated on the probe's own input rows.
+// A row that fails is a miss (the fusion is only offered for join kinds whose misses emit nothing).
+struct RowFilter {
+  TermArg terms[kMaxTerms];
+  int32_t numTerms;
+  // The common shape - ONE term over a flat INTEGER / DATE / BIGINT column without nulls against an
+  // integer constant (TPC-H Q3: l_shipdate > d, o_orderdate < d) - as a range test the flat-key
+  // probe paths evaluate on values they prefetch next to the keys: pass = (lo <= v <= hi) != invert.
+  int32_t fast;          // 0 = use terms[]; 4 / 8 = byte width of the fast column
+  const void* fastValues;
+  int64_t lo, hi;
+  int32_t invert;
+  int32_t pad;
+};
+__device__ inline int64_t fastFilterLoad(const RowFilter& f, int64_t row) {
+  return f.fast == 4 ? static_cast<int64_t>(__builtin_nontemporal_load(static_cast<const int32_t*>(f.fastValues) + row))
+                     : __builtin_nontemporal_load(static_cast<const int64_t*>(f.fastValues) + row);
+}
+__device__ inline bool fastFilterPass(const RowFilter& f, int64_t v) {
+  return ((v >= f.lo) & (v <= f.hi)) != (f.invert != 0);
+}
+__device__ inline bool rowPasses(const RowFilter& f, int64_t row) {
+  return evalFilter(f.terms, f.numTerms, row);
+}
+
 struct ProbeArgs {
   ColView keys[kMaxKeys];
   KeyRange ranges[kMaxKeys];
@@ -755,6 +782,7 @@ struct ProbeArgs {
   uint64_t presentWords;          // u32 words of the presence bitmap
   const WideSlot* wide;           // WIDE probes: slots with inline dependents ...
   uint64_t* hitVals[kWideDeps];   // ... whose values are staged per probe row next to hits[]
+  RowFilter rf;                   // fused input filter (numTerms == 0: none)
 };
 
 constexpr int kSparseCap = 1024;  // staged pairs per tile of 8192 probe rows (12.5 % hit rate)
@@ -764,7 +792,7 @@ constexpr uint32_t kNullKey32 = 0xfffffffeu;  // hits[]: the probe key holds a n
 __device__ inline bool isHit(uint32_t hit) { return hit < kNullKey32; }
 
 // Output rows of one probe row with 'matches' matching build rows.
-__device__ inline uint32_t outputCount(int32_t joinType, uint32_t matches, bool nullKey = false) {
+__host__ __device__ inline uint32_t outputCount(int32_t joinType, uint32_t matches, bool nullKey = false) {
   switch (joinType) {
     case VX355_JOIN_INNER:
     case VX355_JOIN_RIGHT:
@@ -949,7 +977,7 @@ struct SparseLds {
 #define VX355_KEY_LOAD(p) __builtin_nontemporal_load(p)
 #endif
 
-template <int MODE, int FAST, bool SPARSE, int WIDE = 0>
+template <int MODE, int FAST, bool SPARSE, int WIDE = 0, bool RF = false>
 __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, SparseLds* lds) {
   const int mode = MODE >= 0 ? MODE : a.mode;
   const int fastKey = FAST >= 0 ? FAST : a.fastKey;
@@ -968,12 +996,16 @@ __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, Spars
   // bitmap gathers of iteration it, so the HBM latency of the keys overlaps the cache
   // latency of the dependent gathers instead of adding to it.
   int64_t vnext[kU];
+  int64_t fnext[RF ? kU : 1];  // RF: the fused filter's column, prefetched like the keys
   if (FAST == 1) {
     const int64_t* kp = static_cast<const int64_t*>(a.keys[0].values);
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       const int64_t r = rowOf(0, u);
       vnext[u] = VX355_KEY_LOAD(kp + (r < a.numRows ? r : a.numRows - 1));
+      if constexpr (RF) {
+        fnext[u] = fastFilterLoad(a.rf, r < a.numRows ? r : a.numRows - 1);
+      }
     }
   }
   for (int it = 0; it < kIters; ++it) {
@@ -994,6 +1026,19 @@ __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, Spars
         candidate[u] = rows[u] < a.numRows && v >= a.ranges[0].min && v <= a.ranges[0].max;
         key[u] = static_cast<uint64_t>(v) - static_cast<uint64_t>(a.ranges[0].min) + 1;
       }
+      // the window of presence words hangs on the wave's first key whether or not its row passes
+      const bool firstInRange = candidate[0];
+      if constexpr (RF) {
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          candidate[u] = candidate[u] && fastFilterPass(a.rf, fnext[u]);
+        }
+      } else if (a.rf.numTerms) {  // uniform
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          candidate[u] = candidate[u] && rowPasses(a.rf, rows[u]);
+        }
+      }
       if (mode == JMODE_ARRAY) {
         if (SPARSE && a.window) {
           // A wave of the listing probe covers 256 consecutive rows per iteration. When the probe
@@ -1003,7 +1048,7 @@ __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, Spars
           // lane permute, and only rows outside it (unordered probe sides) gather on their own.
           // A dependent gather costs the CU's address path ~80 cycles per wave instruction even
           // when all 64 lanes hit one line; the permute costs a tenth of that.
-          const uint64_t w0 = readFirst64(candidate[0] ? key[0] >> 5 : 0);
+          const uint64_t w0 = readFirst64(firstInRange ? key[0] >> 5 : 0);
           const uint64_t mineWord = w0 + lane();
           const uint32_t win = a.present[mineWord < a.presentWords ? mineWord : a.presentWords - 1];
 #pragma unroll
@@ -1025,6 +1070,9 @@ __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, Spars
         for (int u = 0; u < kU; ++u) {
           const int64_t r = rowOf(it + 1, u);
           vnext[u] = VX355_KEY_LOAD(kp + (r < a.numRows ? r : a.numRows - 1));
+          if constexpr (RF) {
+            fnext[u] = fastFilterLoad(a.rf, r < a.numRows ? r : a.numRows - 1);
+          }
         }
       }
       if (mode == JMODE_ARRAY) {
@@ -1077,12 +1125,19 @@ __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, Spars
         candidate[u] = rows[u] < a.numRows && probeKey(a, rows[u], &key[u]);
       }
     }
+    if (FAST != 1 && mode != JMODE_HASH && a.rf.numTerms) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        candidate[u] = candidate[u] && rowPasses(a.rf, rows[u]);
+      }
+    }
     if (FAST == 1) {
       // looked up above
     } else if (mode == JMODE_HASH) {
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
-        hit[u] = rows[u] < a.numRows ? lookupGeneric(a, rows[u]) : kNoRow32;
+        hit[u] = (rows[u] < a.numRows && (a.rf.numTerms == 0 || rowPasses(a.rf, rows[u]))) ? lookupGeneric(a, rows[u])
+                                                                                                   : kNoRow32;
       }
     } else if (mode == JMODE_ARRAY) {
       uint32_t word[kU];
@@ -1170,7 +1225,7 @@ __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, Spars
   return mine;
 }
 
-template <int MODE, int FAST, bool SPARSE, int WIDE = 0>
+template <int MODE, int FAST, bool SPARSE, int WIDE = 0, bool RF = false>
 __global__ __launch_bounds__(256) void k_join_probe(ProbeArgs args) {
   __shared__ uint64_t waveSums[4];
   __shared__ __attribute__((aligned(16))) unsigned char sparseRaw[SPARSE ? sizeof(SparseLds) : 16];
@@ -1178,7 +1233,7 @@ __global__ __launch_bounds__(256) void k_join_probe(ProbeArgs args) {
   SparseLds* lds = reinterpret_cast<SparseLds*>(sparseRaw);
   int parity = 0;
   for (int64_t tile = a.tileBegin + blockIdx.x; tile < a.numTiles; tile += gridDim.x, parity ^= 1) {
-    uint64_t mine = probeTileBody<MODE, FAST, SPARSE, WIDE>(a, tile, lds);
+    uint64_t mine = probeTileBody<MODE, FAST, SPARSE, WIDE, RF>(a, tile, lds);
     if constexpr (SPARSE) {
       const int wave = threadIdx.x >> 6;
       if (lane() == 0) {
@@ -1217,7 +1272,7 @@ __global__ __launch_bounds__(256) void k_join_probe(ProbeArgs args) {
         a.tileDense[tile] = 1;
         atomicAdd(reinterpret_cast<unsigned long long*>(a.sparseStats), 1ULL);
       }
-      mine = probeTileBody<MODE, FAST, false, WIDE>(a, tile, lds);
+      mine = probeTileBody<MODE, FAST, false, WIDE, RF>(a, tile, lds);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -1250,6 +1305,13 @@ constexpr int kPartSliceWords = 1 << (kPartShift - 5);  // u32 words of one slic
 constexpr int kPartMaxBins = 4096;
 constexpr int kPartTileRows = 32768;
 
+__device__ inline bool ppRowPasses(const RowFilter& f, int64_t row) {
+  if (f.numTerms == 0) {
+    return true;
+  }
+  return f.fast ? fastFilterPass(f, fastFilterLoad(f, row)) : rowPasses(f, row);
+}
+
 struct PartArgs {
   const int64_t* keys;   // flat BIGINT probe keys
   int64_t numRows;
@@ -1260,6 +1322,7 @@ struct PartArgs {
   uint32_t* hist;        // [bin][tile]
   const uint64_t* offsets;
   uint64_t* recs;        // {key offset inside the bin : 32 | probe row : 32}
+  RowFilter rf;          // fused input filter: rows that fail are not scattered
 };
 
 __global__ __launch_bounds__(1024) void k_pp_count(PartArgs a) {
@@ -1281,7 +1344,7 @@ __global__ __launch_bounds__(1024) void k_pp_count(PartArgs a) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int64_t r = base + u * 1024 + threadIdx.x;
-        if (r < end && v[u] >= a.keyMin && v[u] <= a.keyMax) {
+        if (r < end && v[u] >= a.keyMin && v[u] <= a.keyMax && ppRowPasses(a.rf, r)) {
           const uint64_t key = static_cast<uint64_t>(v[u]) - static_cast<uint64_t>(a.keyMin) + 1;
           atomicAdd(&hist[key >> kPartShift], 1u);
         }
@@ -1330,7 +1393,7 @@ __global__ __launch_bounds__(1024) void k_pp_scatter(PartArgs a) {
         const int64_t r = base + u * 1024 + tid;
         const int64_t v = r < end ? a.keys[r] : INT64_MIN;
         bin[u] = 0xffffffffu;
-        if (r < end && v >= a.keyMin && v <= a.keyMax) {
+        if (r < end && v >= a.keyMin && v <= a.keyMax && ppRowPasses(a.rf, r)) {
           const uint64_t key = static_cast<uint64_t>(v) - static_cast<uint64_t>(a.keyMin) + 1;
           bin[u] = static_cast<uint32_t>(key >> kPartShift);
           rec[u] = ((key & ((1ULL << kPartShift) - 1)) << 32) | static_cast<uint32_t>(r);
@@ -1421,6 +1484,7 @@ struct PartFastArgs {
   uint32_t* binCount;       // cursors, zero on entry
   uint32_t* overflow;
   uint64_t* recs;           // bin b: recs[b * binCap ...]
+  RowFilter rf;             // fused input filter: rows that fail are not scattered
 };
 
 __global__ __launch_bounds__(1024) void k_pp_scatter_fast(PartFastArgs a) {
@@ -1446,7 +1510,7 @@ __global__ __launch_bounds__(1024) void k_pp_scatter_fast(PartFastArgs a) {
       const int64_t r = base + u * 1024 + tid;
       const int64_t v = r < a.numRows ? a.keys[r] : INT64_MIN;
       bin[u] = 0xffffffffu;
-      if (r < a.numRows && v >= a.keyMin && v <= a.keyMax) {
+      if (r < a.numRows && v >= a.keyMin && v <= a.keyMax && ppRowPasses(a.rf, r)) {
         const uint64_t key = static_cast<uint64_t>(v) - static_cast<uint64_t>(a.keyMin) + 1;
         bin[u] = static_cast<uint32_t>(key >> kPartShift);
         rec[u] = (static_cast<uint64_t>(bin[u]) << 52) | ((key & ((1ULL << kPartShift) - 1)) << 32) | static_cast<uint32_t>(r);
@@ -2480,7 +2544,8 @@ struct vx355_join_probe {
   DeviceBatch batch;                       // the batch being probed: the filter reads it at output time
   std::vector<std::vector<char>> hostStrings;  // long payload strings of the last page handed to a host caller
   std::vector<vx355_join_filter_term> filter;
-  std::vector<int32_t> usedCols;           // key columns + the filter's probe columns
+  std::vector<vx355_filter_term> inputFilter;  // fused FilterProject in front of the probe (set_input_filter)
+  std::vector<int32_t> usedCols;           // key columns + the filters' probe columns
   DevBuf hitBits, hitRows, hitWords, hitSorted, sortTmp;  // counting joins
   bool sparse = false;
   int32_t sparseMode = -1;   // VX355_JOIN_SPARSE: -1 adaptive, 0 never, 1 always
@@ -2993,6 +3058,46 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
       a.keyWords[k] = keyWordsOf(t.keyKinds[k]);
     }
   }
+  a.rf.numTerms = static_cast<int32_t>(p.inputFilter.size());
+  if (a.rf.numTerms > 0) {
+    makeTermArgs(db, p.inputFilter.data(), a.rf.numTerms, a.rf.terms);
+    const TermArg& t0 = a.rf.terms[0];
+    if (a.rf.numTerms == 1 && t0.constKind == VX355_BIGINT && t0.col.enc == VX355_FLAT && t0.col.nulls == nullptr &&
+        (t0.col.kind == VX355_INTEGER || t0.col.kind == VX355_BIGINT)) {
+      const int64_t c = t0.i64;
+      int64_t lo = INT64_MIN, hi = INT64_MAX;
+      bool empty = false;
+      switch (t0.cmp) {
+        case VX355_CMP_EQ:
+        case VX355_CMP_NE:
+          lo = hi = c;
+          break;
+        case VX355_CMP_LT:
+          empty = c == INT64_MIN;
+          hi = c - (empty ? 0 : 1);
+          break;
+        case VX355_CMP_LE:
+          hi = c;
+          break;
+        case VX355_CMP_GT:
+          empty = c == INT64_MAX;
+          lo = c + (empty ? 0 : 1);
+          break;
+        default:
+          lo = c;
+          break;
+      }
+      if (empty) {
+        lo = 1;
+        hi = 0;
+      }
+      a.rf.fast = t0.col.kind == VX355_INTEGER ? 4 : 8;
+      a.rf.fastValues = t0.col.values;
+      a.rf.lo = lo;
+      a.rf.hi = hi;
+      a.rf.invert = t0.cmp == VX355_CMP_NE ? 1 : 0;
+    }
+  }
   a.mode = t.mode;
   a.nullAsValue = t.nullAsValue ? 1 : 0;
   a.keyNullStore = (t.nullAsValue && t.keepsNullRows) ? t.keyNull.as<uint8_t>() : nullptr;
@@ -3056,7 +3161,11 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
     }
     // profile names: "k_join_probe" writes hits[] for k_emit, "k_join_probe_list" also lists the hits
     const char* name = SP ? "k_join_probe_list" : "k_join_probe";
-    if (t.mode == JMODE_ARRAY && a.fastKey == 1) {
+    if (t.mode == JMODE_ARRAY && a.fastKey == 1 && la.rf.fast) {
+      VX_LAUNCH(name, (k_join_probe<JMODE_ARRAY, 1, SP, 0, true>), grid, 256, 0, la);
+    } else if (t.mode == JMODE_NORMALIZED && a.fastKey == 1 && la.rf.fast && la.wide == nullptr) {
+      VX_LAUNCH(name, (k_join_probe<JMODE_NORMALIZED, 1, SP, 0, true>), grid, 256, 0, la);
+    } else if (t.mode == JMODE_ARRAY && a.fastKey == 1) {
       VX_LAUNCH(name, (k_join_probe<JMODE_ARRAY, 1, SP>), grid, 256, 0, la);
     } else if (t.mode == JMODE_ARRAY && a.fastKey == 2) {
       VX_LAUNCH(name, (k_join_probe<JMODE_ARRAY, 2, SP>), grid, 256, 0, la);
@@ -3130,6 +3239,7 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
         pa.keyMin = a.ranges[0].min;
         pa.keyMax = a.ranges[0].max;
         pa.numBins = static_cast<int32_t>(partBins);
+        pa.rf = a.rf;
         const int64_t cells = pa.numTiles * pa.numBins;
         const int pgrid = static_cast<int>(std::min<int64_t>(pa.numTiles, static_cast<int64_t>(rt.numCUs) * 2));
         PartProbeArgs pp{};
@@ -3141,6 +3251,7 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
           fa.keyMin = pa.keyMin;
           fa.keyMax = pa.keyMax;
           fa.numBins = pa.numBins;
+          fa.rf = a.rf;
           fa.binCap = static_cast<uint64_t>(n / pa.numBins + n / (2 * pa.numBins) + 4096);
           fa.recs = static_cast<uint64_t*>(p.ppRecs.ensure(static_cast<size_t>(fa.binCap) * pa.numBins * 8 + 64));
           fa.binCount = static_cast<uint32_t*>(p.ppHist.ensure(static_cast<size_t>(pa.numBins + 16) * 4 + 64));
@@ -3987,6 +4098,9 @@ int vx355_join_probe_set_filter(vx355_join_probe* h, const vx355_join_filter_ter
   }
   h->filter.assign(terms, terms + n_terms);
   h->usedCols = h->keyCols;
+  for (const auto& t : h->inputFilter) {
+    h->usedCols.push_back(t.col);
+  }
   for (const auto& t : h->filter) {
     VX_CHECK_ARG(t.left_side == 0 || t.left_side == 1, "join filter: left_side is 0 (probe) or 1 (build)");
     VX_CHECK_ARG(t.right_kind >= 0 && t.right_kind <= 2, "join filter: bad right_kind");
@@ -3997,6 +4111,30 @@ int vx355_join_probe_set_filter(vx355_join_probe* h, const vx355_join_filter_ter
     if (t.right_kind == 1) {
       h->usedCols.push_back(t.right_col);
     }
+  }
+  VX_API_END
+}
+
+int vx355_join_probe_set_input_filter(vx355_join_probe* h, const vx355_filter_term* terms, int32_t n_terms) {
+  VX_API_BEGIN_CTX(VX_CTX_OF(h))
+  VX_CHECK_ARG(h && (terms || n_terms == 0), "NULL argument");
+  VX_CHECK_ARG(n_terms >= 0 && n_terms <= vx::kMaxTerms, "0..4 filter terms");
+  VX_CHECK_ARG(!h->hasInput, "set_input_filter after the first add_input");
+  if (n_terms > 0 && vx::outputCount(h->joinType, 0) != 0) {
+    // LEFT / FULL / LEFT_SEMI_PROJECT / ANTI emit probe rows that found nothing: a row the filter
+    // removed must not come out as one of those (the FilterProject stays a separate operator)
+    VX_THROW(VX355_EUNSUPPORTED, "input filter fusion: only join kinds whose unmatched probe rows emit nothing");
+  }
+  if (n_terms > 0 && h->nullAware) {
+    VX_THROW(VX355_EUNSUPPORTED, "input filter fusion: not with null-aware joins");
+  }
+  for (int32_t i = 0; i < n_terms; ++i) {
+    VX_CHECK_ARG(terms[i].col >= 0, "input filter: bad column");
+    VX_CHECK_ARG(terms[i].cmp >= VX355_CMP_EQ && terms[i].cmp <= VX355_CMP_GE, "input filter: bad comparison");
+  }
+  h->inputFilter.assign(terms, terms + n_terms);
+  for (const auto& t : h->inputFilter) {
+    h->usedCols.push_back(t.col);
   }
   VX_API_END
 }

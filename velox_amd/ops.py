@@ -43,7 +43,7 @@ SYMBOLS = [
     "vx355_value_dict_destroy",
     "vx355_all_gather_v", "vx355_exchange_create", "vx355_exchange_send", "vx355_exchange_receive",
     "vx355_exchange_stream", "vx355_exchange_destroy", "vx355_exchange_destinations", "vx355_join_repartition", "vx355_agg_merge_partials",
-    "vx355_hbm_ceiling", "vx355_compose_indices", "vx355_agg_table_bytes",
+    "vx355_hbm_ceiling", "vx355_compose_indices", "vx355_agg_table_bytes", "vx355_join_probe_set_input_filter",
 ]
 
 # int (*vx355_join_chunk_sink)(void* arg, int32_t chunk, const vx355_batch* received, vx355_join_probe* probe)
@@ -132,6 +132,7 @@ def lib():
     L.vx355_bloom_test.argtypes = [vp, i64, i32, P(abi.Column), i32, vp, vp, i32]
     L.vx355_join_probe_set_filter.argtypes = [vp, P(abi.JoinFilterTerm), i32]
     L.vx355_join_probe_set_output_batch_bytes.argtypes = [vp, i64]
+    L.vx355_join_probe_set_input_filter.argtypes = [vp, P(abi.FilterTerm), i32]
     L.vx355_comm_get_unique_id.argtypes = [vp]
     L.vx355_comm_create.argtypes = [vp, i32, i32, P(vp)]
     L.vx355_comm_create_all.argtypes = [i32, P(i32), P(vp)]
@@ -1007,6 +1008,11 @@ class HashProbe:
 
     def set_output_batch_bytes(self, nbytes):
         _check(lib().vx355_join_probe_set_output_batch_bytes(self.h, nbytes))
+
+    def set_input_filter(self, terms):
+        """Fuse the filter-only FilterProject in front of the probe: add_input then takes ITS input
+        batches, rows failing [(col, cmp, constant)] find nothing, mappings number the unfiltered rows."""
+        _check(lib().vx355_join_probe_set_input_filter(self.h, abi.filter_terms(terms), len(terms)))
 
     def add_input(self, batch):
         self._batch = batch

@@ -34,7 +34,116 @@ class DevBatch:
         return C.byref(self.batch)
 
 
-def run_q3(ops, torch, tables, date=Q3_DATE):
+def run_q3(ops, torch, tables, date=Q3_DATE, fuse_filters=True):
+    """fuse_filters: the date filters of orders and lineitem run inside the probes
+    (vx355_join_probe_set_input_filter) instead of as FilterProject passes in front of them."""
+    if fuse_filters:
+        return run_q3_fused(ops, torch, tables, date)
+    return run_q3_unfused(ops, torch, tables, date)
+
+
+def run_q3_fused(ops, torch, tables, date=Q3_DATE):
+    """customer -> FilterProject -> HashBuild as below; orders and lineitem are probed straight from
+    their flat columns with the date filter fused into the probe: the probes' mappings number table
+    rows, so pass-through columns are dictionaries over ONE index vector and nothing is composed."""
+    def flat(kind, t):
+        return ops.DeviceColumn.from_ptr(kind, t.data_ptr(), int(t.shape[0]))
+
+    def wrapped(kind, t, idx, n):
+        return ops.DeviceColumn.from_ptr(kind, t.data_ptr(), n, None, abi.DICTIONARY, idx.data_ptr(),
+                                         int(t.shape[0]))
+
+    dev = tables["c_custkey"].device
+    info = {}
+    # -- customer (15 M rows, one 16-byte string column: the stand-alone FilterProject is 0.1 ms)
+    nc = int(tables["c_custkey"].shape[0])
+    cust = DevBatch([flat(abi.BIGINT, tables["c_custkey"]), flat(abi.VARCHAR, tables["c_mktsegment"])], nc)
+    idx_c = torch.empty(max(1, nc), dtype=torch.int32, device=dev)
+    mc = ops.filter_project_device(cust, [(1, abi.CMP_EQ, b"BUILDING")], [], idx_c.data_ptr(), [])
+    b1 = ops.HashBuild([0], [abi.BIGINT], [], [], abi.JOIN_INNER)
+    b1.add_input(DevBatch([wrapped(abi.BIGINT, tables["c_custkey"], idx_c, mc)], mc))
+    t1 = b1.finish()
+    info["customers_selected"] = mc
+
+    # -- orders: probe(o_custkey) WHERE o_orderdate < date; every output page feeds the next build
+    no = int(tables["o_orderkey"].shape[0])
+    p1 = ops.HashProbe(t1, [0], abi.JOIN_INNER)
+    p1.set_input_filter([(1, abi.CMP_LT, date)])
+    p1.add_input(DevBatch([flat(abi.BIGINT, tables["o_custkey"]), flat(abi.INTEGER, tables["o_orderdate"])], no))
+    b2 = ops.HashBuild([0], [abi.BIGINT], [1, 2], [abi.INTEGER, abi.INTEGER], abi.JOIN_INNER)
+    cap1 = max(1, no // 4)   # TPC-H: 10 % of the orders join (48 % pass the date, 20 % of the customers are BUILDING)
+    n1, keep = 0, []
+    while True:
+        ord_idx = torch.empty(cap1, dtype=torch.int32, device=dev)
+        got, fin = p1.get_output_device(cap1, ord_idx.data_ptr(), None, None, [])
+        if got:
+            b2.add_input(DevBatch([wrapped(abi.BIGINT, tables["o_orderkey"], ord_idx, got),
+                                   wrapped(abi.INTEGER, tables["o_orderdate"], ord_idx, got),
+                                   wrapped(abi.INTEGER, tables["o_shippriority"], ord_idx, got)], got))
+            keep.append(ord_idx)
+        n1 += got
+        if fin:
+            break
+    info["orders_selected"], info["orders_joined"] = no, n1   # rows the probe sees / emits
+    t2 = b2.finish()
+
+    # -- lineitem: probe(l_orderkey) WHERE l_shipdate > date; every output page is a batch of the aggregation
+    nl = int(tables["l_orderkey"].shape[0])
+    p2 = ops.HashProbe(t2, [0], abi.JOIN_INNER)
+    p2.set_input_filter([(1, abi.CMP_GT, date)])
+    p2.add_input(DevBatch([flat(abi.BIGINT, tables["l_orderkey"]), flat(abi.INTEGER, tables["l_shipdate"])], nl))
+    agg = ops.HashAggregation([0, 1, 2], [abi.BIGINT, abi.INTEGER, abi.INTEGER],
+                              [(abi.AGG_SUM, ops.PROJ(0), abi.DOUBLE)])
+    agg.set_fused_input([], [[(3, 1.0, 0.0), (4, -1.0, 1.0)]])
+    cap = max(1, nl // 16)   # TPC-H: 0.5 % of the lineitems join
+    n2 = 0
+    while True:
+        li_idx = torch.empty(cap, dtype=torch.int32, device=dev)
+        odate = torch.empty(cap, dtype=torch.int32, device=dev)
+        oprio = torch.empty(cap, dtype=torch.int32, device=dev)
+        nulls = torch.empty((cap // 64 + 1) * 2, dtype=torch.int64, device=dev)
+        descs = (abi.OutColumn * 2)()
+        for i, t in enumerate((odate, oprio)):
+            descs[i].type_kind, descs[i].mem = abi.INTEGER, abi.MEM_DEVICE
+            descs[i].values, descs[i].nulls = t.data_ptr(), nulls[i * (cap // 64 + 1):].data_ptr()
+        got, fin = p2.get_output_device(cap, li_idx.data_ptr(), None, descs, [0, 1])
+        if got:
+            agg.add_input(DevBatch([wrapped(abi.BIGINT, tables["l_orderkey"], li_idx, got),
+                                    ops.DeviceColumn.from_ptr(abi.INTEGER, odate.data_ptr(), got),
+                                    ops.DeviceColumn.from_ptr(abi.INTEGER, oprio.data_ptr(), got),
+                                    wrapped(abi.DOUBLE, tables["l_extendedprice"], li_idx, got),
+                                    wrapped(abi.DOUBLE, tables["l_discount"], li_idx, got)], got))
+        n2 += got
+        if fin:
+            break
+    info["lineitems_selected"], info["lineitems_joined"] = nl, n2
+    return _q3_drain(ops, torch, agg, dev, info)
+
+
+def _q3_drain(ops, torch, agg, dev, info):
+    """noMoreInput + the aggregation's groups as one device page: (l_orderkey, o_orderdate, o_shippriority, revenue)."""
+    agg.no_more_input()
+    groups = int(agg.stats().num_groups)
+    outcap = max(1, groups)
+    out = [torch.empty(outcap, dtype=torch.int64, device=dev), torch.empty(outcap, dtype=torch.int32, device=dev),
+           torch.empty(outcap, dtype=torch.int32, device=dev), torch.empty(outcap, dtype=torch.float64, device=dev)]
+    onulls = torch.empty((outcap // 64 + 1) * 4, dtype=torch.int64, device=dev)
+    od = (abi.OutColumn * 4)()
+    for i, (t, k) in enumerate(zip(out, (abi.BIGINT, abi.INTEGER, abi.INTEGER, abi.DOUBLE))):
+        od[i].type_kind, od[i].mem = k, abi.MEM_DEVICE
+        od[i].values, od[i].nulls = t.data_ptr(), onulls[i * (outcap // 64 + 1):].data_ptr()
+    total = 0
+    n, fin = C.c_int32(), C.c_int32(0)
+    if groups:
+        ops._check(ops.lib().vx355_agg_get_output(agg.h, od, 4, outcap, C.byref(n), C.byref(fin)))
+        total = n.value
+        assert fin.value
+    info["groups"] = total
+    info["agg_mode"] = int(agg.stats().hash_mode)
+    return [t[:total] for t in out], info
+
+
+def run_q3_unfused(ops, torch, tables, date=Q3_DATE):
     """tables: dict of torch tensors in HBM:
       c_custkey int64, c_mktsegment int32[n,4] (16-byte StringViews),
       o_orderkey int64, o_custkey int64, o_orderdate int32, o_shippriority int32,
