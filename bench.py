@@ -117,7 +117,9 @@ def library_comm(args, torch, dist, rank, world, dev_index, share):
     if args.exchange == "torch":
         return None, "--exchange torch"
     if share:
-        return None, "ranks share one GPU (VX355_BENCH_SHARE_GPU): RCCL refuses two ranks per device"
+        # RCCL refuses two ranks per device: the library's exchange runs over its shared-memory transport
+        # (velox_amd/csrc/shm_transport.hip) - the same protocol code above it, a few GB/s below it
+        os.environ.setdefault("VX355_COMM_TRANSPORT", "shm")
     ok = 1
     why = ""
     if args.exchange == "auto" and world > 1:
@@ -149,6 +151,8 @@ def library_comm(args, torch, dist, rank, world, dev_index, share):
     got = comm.info()
     if got != (world, rank, dev_index):
         raise SystemExit(f"RCCL reports (world, rank, device) = {got}, the launcher said {(world, rank, dev_index)}")
+    if os.environ.get("VX355_COMM_TRANSPORT") == "shm":
+        return comm, "libvx355 communicator over its shared-memory transport (ranks share one GPU; vx355_comm_create)"
     return comm, "libvx355 RCCL communicator (vx355_comm_create)"
 
 
@@ -1212,8 +1216,8 @@ def main():
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    # VX355_BENCH_SHARE_GPU=1 (debug on a 1-GPU box): every rank uses GPU 0 and
-    # the tiny exchange runs over gloo, because RCCL refuses two ranks per device.
+    # VX355_BENCH_SHARE_GPU=1 (debug on a 1-GPU box): every rank uses GPU 0 and the library's exchange
+    # runs over its host shared-memory transport, because RCCL refuses two ranks per device.
     share = os.environ.get("VX355_BENCH_SHARE_GPU") == "1"
     dev_index = 0 if share else local_rank
     if not share and torch.cuda.device_count() < world:

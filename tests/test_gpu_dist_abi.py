@@ -227,3 +227,32 @@ def test_rccl_entry_points_run_on_one_gpu(with_torch):
     assert checks.pop("comm_info") == [1, 0, 0]
     assert checks.pop("counts") == [12345]
     assert checks and all(checks.values()), checks
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_library_exchange_with_several_ranks_on_one_gpu(world, tmp_path):
+    """The library's own exchange between DIFFERENT ranks, on the one GPU a test box has:
+    VX355_COMM_TRANSPORT=shm puts a host shared-memory transport under the exchange's transport
+    table (RCCL refuses two ranks per device), everything above it is the code the 8-GPU node runs:
+    vx355_exchange_counts / _columns with real peers, both all-gathers, a 300 MiB slice across the
+    message cut, vx355_join_repartition (chunk-count agreement, three receive slots, the payload
+    stream) and vx355_agg_merge_partials - first with even shards (velox_amd/commcheck.py), then with
+    uneven and empty shards against the CPU oracle (tests/shm_ranks_worker.py)."""
+    env = dict(os.environ)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env["VX355_COMM_TRANSPORT"] = "shm"
+    id_file = str(tmp_path / "comm_id")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shm_ranks_worker.py"), str(r), str(world), id_file],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=900))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for r, (p, (out, err)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r}: rc {p.returncode}\n{out[-1500:]}\n{err[-3000:]}"
+        assert f"commcheck rank {r}/{world} on device 0: ok" in out
+        assert f"rank {r}/{world} uneven and empty shards match the oracle" in out

@@ -1311,10 +1311,11 @@ __global__ __launch_bounds__(1024) void k_rp_scatter2(Radix2Args r) {
       uint64_t w[kRadixUnroll][W];
 #pragma unroll
       for (int u = 0; u < kRadixUnroll; ++u) {
+        // (clamped, unconditional: a load inside `if (i < count)` is fused with its use by the compiler
+        // and every one of the kRadixUnroll loads then waits for the previous one - s_waitcnt vmcnt(0)
+        // behind each global_load in the ISA; issued back to back they overlap)
         const uint32_t i = base + u * 1024 + threadIdx.x;
-        if (i < tile.count) {
-          rpLoad<W>(r.in + (tile.begin + i) * W, w[u]);
-        }
+        rpLoad<W>(r.in + (tile.begin + (i < tile.count ? i : tile.count - 1)) * W, w[u]);
       }
 #pragma unroll
       for (int u = 0; u < kRadixUnroll; ++u) {
@@ -1351,12 +1352,14 @@ __device__ inline void rpScatter2SortedBody(const Radix2Args& r) {
       uint32_t bin[R];
 #pragma unroll
       for (int u = 0; u < R; ++u) {
+        // all loads of the sub-tile first (clamped, unconditional: see k_rp_scatter2), the bins after
         const uint32_t i = base + u * kSortThreads + threadIdx.x;
-        bin[u] = 0xffffffffu;
-        if (i < tile.count) {
-          rpLoad<W>(r.in + (tile.begin + i) * W, w[u]);
-          bin[u] = (static_cast<uint32_t>(w[u][0]) >> r.shiftB) & binMask;
-        }
+        rpLoad<W>(r.in + (tile.begin + (i < tile.count ? i : tile.count - 1)) * W, w[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const uint32_t i = base + u * kSortThreads + threadIdx.x;
+        bin[u] = i < tile.count ? ((static_cast<uint32_t>(w[u][0]) >> r.shiftB) & binMask) : 0xffffffffu;
       }
       rpSortedEmit<W, R>(l, r.numBins, w, bin, r.out,
                          [&](uint64_t w0) { return (static_cast<uint32_t>(w0) >> r.shiftB) & binMask; });
@@ -1464,12 +1467,14 @@ __global__ __launch_bounds__(kSortThreads) void k_rp_scatter2_opt(Radix2OptArgs 
       uint32_t bin[R];
 #pragma unroll
       for (int u = 0; u < R; ++u) {
+        // all loads of the sub-tile first (clamped, unconditional: see k_rp_scatter2), the bins after
         const uint32_t i = base + u * kSortThreads + threadIdx.x;
-        bin[u] = 0xffffffffu;
-        if (i < tile.count) {
-          rpLoad<W>(r.in + (tile.begin + i) * W, w[u]);
-          bin[u] = (static_cast<uint32_t>(w[u][0]) >> r.shiftB) & binMask;
-        }
+        rpLoad<W>(r.in + (tile.begin + (i < tile.count ? i : tile.count - 1)) * W, w[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const uint32_t i = base + u * kSortThreads + threadIdx.x;
+        bin[u] = i < tile.count ? ((static_cast<uint32_t>(w[u][0]) >> r.shiftB) & binMask) : 0xffffffffu;
       }
       rpSortedEmit<W, R>(
           l, r.numBins, w, bin, r.out, [&](uint64_t w0) { return (static_cast<uint32_t>(w0) >> r.shiftB) & binMask; },
@@ -1662,9 +1667,7 @@ __device__ inline void rpFoldRecords(const RpFold& f, const RadixAggArgs& r, uin
 #pragma unroll
     for (int u = 0; u < kRadixUnroll; ++u) {
       const uint64_t i = at + u * 512 + threadIdx.x;
-      if (i < end) {
-        rpLoad<W>(r.recs + i * W, w[u]);
-      }
+      rpLoad<W>(r.recs + (i < end ? i : end - 1) * W, w[u]);  // clamped, unconditional: see k_rp_scatter2
     }
 #pragma unroll
     for (int u = 0; u < kRadixUnroll; ++u) {
@@ -2060,9 +2063,7 @@ __device__ inline void hashFoldRecords(const HashFold& f, const RadixAggArgs& r,
 #pragma unroll
     for (int u = 0; u < kHashUnroll; ++u) {
       const uint64_t i = at + u * 512 + threadIdx.x;
-      if (i < end) {
-        rpLoad<W>(r.recs + i * W, w[u]);
-      }
+      rpLoad<W>(r.recs + (i < end ? i : end - 1) * W, w[u]);  // clamped, unconditional: see k_rp_scatter2
     }
 #pragma unroll
     for (int u = 0; u < kHashUnroll; ++u) {
@@ -2086,8 +2087,8 @@ __device__ inline void hashFoldLoadAhead(const RadixAggArgs& r, uint64_t begin, 
 #pragma unroll
   for (int u = 0; u < kHashAhead; ++u) {
     const uint64_t i = begin + u * 512 + threadIdx.x;
-    if (i < stop) {
-      rpLoad<W>(r.recs + i * W, w[u]);
+    if (begin < stop) {  // uniform
+      rpLoad<W>(r.recs + (i < stop ? i : stop - 1) * W, w[u]);  // clamped, unconditional: see k_rp_scatter2
     }
   }
 }

@@ -14,6 +14,7 @@
 // linked against (a process may hold a second HIP runtime / RCCL pair, e.g. PyTorch's
 // bundled one: streams of one runtime mean nothing to the other's RCCL).
 #include "common.h"
+#include "transport.h"
 
 #include <dlfcn.h>
 #include <unistd.h>
@@ -24,17 +25,7 @@
 namespace vx {
 namespace {
 
-// The part of rccl.h the exchange uses (RCCL keeps NCCL's ABI).
-using ncclComm_t = void*;
-constexpr int kUniqueIdBytes = 128;
-struct ncclUniqueId {
-  char internal[kUniqueIdBytes];
-};
-constexpr int kNcclSuccess = 0;
-constexpr int kNcclInt8 = 0;    // ncclInt8 / ncclChar
-constexpr int kNcclUint8 = 1;
-constexpr int kNcclInt64 = 4;
-
+// (the part of rccl.h the exchange uses - RCCL keeps NCCL's ABI - is declared in transport.h)
 struct Rccl {
   void* lib = nullptr;
   int (*GetUniqueId)(ncclUniqueId*) = nullptr;
@@ -60,6 +51,32 @@ Rccl& rccl() {
   std::lock_guard<std::mutex> lock(gRcclMutex);
   if (gRccl.lib) {
     return gRccl;
+  }
+  if (const char* e = std::getenv("VX355_COMM_TRANSPORT")) {
+    if (std::string(e) == "shm") {
+      // ranks that share one GPU (RCCL refuses two ranks per device): the same table, served through
+      // host shared memory (shm_transport.hip). CommInitAll - one process, one rank per GPU - stays RCCL's.
+      Rccl r;
+      r.lib = reinterpret_cast<void*>(&gRccl);
+      r.path = "shm transport (VX355_COMM_TRANSPORT=shm)";
+      r.GetUniqueId = shmx::GetUniqueId;
+      r.CommInitRank = shmx::CommInitRank;
+      r.CommInitAll = [](ncclComm_t*, int, const int*) -> int { return 4; };
+      r.CommDestroy = shmx::CommDestroy;
+      r.Send = shmx::Send;
+      r.Recv = shmx::Recv;
+      r.AllGather = shmx::AllGather;
+      r.GroupStart = shmx::GroupStart;
+      r.GroupEnd = shmx::GroupEnd;
+      r.CommCount = shmx::CommCount;
+      r.CommUserRank = shmx::CommUserRank;
+      r.CommCuDevice = shmx::CommCuDevice;
+      r.GetErrorString = shmx::GetErrorString;
+      gRccl = r;
+      return gRccl;
+    } else if (std::string(e) != "rccl" && e[0] != 0) {
+      VX_THROW(VX355_EINVAL, "VX355_COMM_TRANSPORT is 'rccl' (default) or 'shm'");
+    }
   }
   std::vector<std::string> candidates;
   if (const char* e = std::getenv("VX355_RCCL_PATH")) {
