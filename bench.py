@@ -493,25 +493,39 @@ class C1:
     dominant = "k_agg_fast"
     AGGS = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
 
+    # The input of a step is 160 MB; replayed every step it would sit in the 256 MiB Infinity Cache, whose
+    # hits the FETCH_SIZE counter cannot tell from HBM reads (MI355X_MICROARCH.md "Infinity Cache"). The
+    # steps therefore rotate through ROTATE distinct inputs (same distribution, other seeds): a working
+    # set of 480 MB, so that every step's input comes from HBM. VX355_C1_ROTATE=1 restores the replay.
+    ROTATE = int(os.environ.get("VX355_C1_ROTATE", "3"))
+
     def __init__(self, torch, n, device, seed):
-        g = torch.Generator(device=device)
-        g.manual_seed(seed)
         self.n = n
-        self.k = torch.randint(0, 1000, (n,), dtype=torch.int64, device=device, generator=g)
-        self.v = torch.rand(n, dtype=torch.float64, device=device, generator=g)
-        vcol = dcol(abi.DOUBLE, self.v)
+        self.inputs = []
         null_frac = float(os.environ.get("VX355_C1_NULLS", "0"))
-        if null_frac > 0:
-            # the reference's *_halfnull variants (SimpleAggregates.cpp): v carries a null bitmap
-            words = (n + 63) // 64
-            bits = torch.ones(words * 64, dtype=torch.bool, device=device)
-            bits[:n] = torch.rand(n, device=device, generator=g) >= null_frac
-            weights = torch.ones(64, dtype=torch.int64, device=device) << torch.arange(64, device=device)
-            self.v_nulls = (bits.view(-1, 64).to(torch.int64) * weights).sum(1)
-            vcol = ops.DeviceColumn.from_ptr(abi.DOUBLE, self.v.data_ptr(), n, self.v_nulls.data_ptr())
-            self.name = "c1_groupby_10m_1k_%d_percent_null_values" % round(null_frac * 100)
-            self.v_valid = bits[:n]
-        self.batch = DevBatch([dcol(abi.BIGINT, self.k), vcol], n)
+        for i in range(max(1, self.ROTATE)):
+            g = torch.Generator(device=device)
+            g.manual_seed(seed + 1000 * i)
+            k = torch.randint(0, 1000, (n,), dtype=torch.int64, device=device, generator=g)
+            v = torch.rand(n, dtype=torch.float64, device=device, generator=g)
+            vcol = dcol(abi.DOUBLE, v)
+            keep = [k, v]
+            if null_frac > 0:
+                # the reference's *_halfnull variants (SimpleAggregates.cpp): v carries a null bitmap
+                words = (n + 63) // 64
+                bits = torch.ones(words * 64, dtype=torch.bool, device=device)
+                bits[:n] = torch.rand(n, device=device, generator=g) >= null_frac
+                weights = torch.ones(64, dtype=torch.int64, device=device) << torch.arange(64, device=device)
+                v_nulls = (bits.view(-1, 64).to(torch.int64) * weights).sum(1)
+                vcol = ops.DeviceColumn.from_ptr(abi.DOUBLE, v.data_ptr(), n, v_nulls.data_ptr())
+                self.name = "c1_groupby_10m_1k_%d_percent_null_values" % round(null_frac * 100)
+                keep += [v_nulls]
+                if i == 0:
+                    self.v_valid = bits[:n]
+            self.inputs.append((DevBatch([dcol(abi.BIGINT, k), vcol], n), keep))
+        self.k, self.v = self.inputs[0][1][0], self.inputs[0][1][1]
+        self.batch = self.inputs[0][0]
+        self.steps_done = 0
         torch.cuda.synchronize()
 
     stream = False  # --c1-stream: 10 000-row HOST vectors, the way the reference feeds the operator
@@ -532,7 +546,8 @@ class C1:
                 # the handle's worker uploads and launches
                 self.submit_ms = stream_host_batches(op, self._host_batches)
         else:
-            op.add_input(self.batch)
+            op.add_input(self.inputs[self.steps_done % len(self.inputs)][0])
+            self.steps_done += 1
         op.no_more_input()
         return ops.collect_output(op, 4096)
 
@@ -545,7 +560,10 @@ class C1:
                     "driver_thread_ms_queueing_the_last_step": round(self.submit_ms, 3),
                     "host_bytes_per_step": self.n * 16}
         return {"input": "1000 x 10 000-row host vectors (PCIe inclusive)" if self.stream
-                else "one HBM-resident batch"}
+                else "one HBM-resident batch per step, rotating through %d distinct 160 MB inputs (%d MB working set: "
+                     "%s)" % (len(self.inputs), 160 * len(self.inputs),
+                              "beyond the 256 MiB Infinity Cache, every step reads HBM" if len(self.inputs) >= 2
+                              else "the replayed input sits in the Infinity Cache")}
 
     def host_sample(self, rows):
         rows = min(rows, self.n)
@@ -754,11 +772,17 @@ class Q3:
                 "pkey": self.pkey[:rows].cpu().numpy()}
 
     def cpu_reference(self, sample, oracle):
+        """Build and probe timed SEPARATELY. The build side is the whole build side (a join's table does
+        not shrink with the probe sample), the probe side a sample: the seconds returned are the probe
+        sample's own time plus the sample's SHARE of the build time, so that sample rows / seconds is the
+        rate of the whole step (build + probe of every row) - what the GPU figure divides by."""
         t0 = time.perf_counter()
         b = oracle.JoinBuild([0], [abi.BIGINT], [1], [abi.INTEGER], abi.JOIN_INNER)
         b.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, sample["bkey"]),
                                    abi.HostColumn(abi.INTEGER, sample["bdate"])]))
         t = b.finish()
+        build_s = time.perf_counter() - t0
+        t1 = time.perf_counter()
         p = oracle.JoinProbe(t, [0], abi.JOIN_INNER)
         total = 0
         pk = sample["pkey"]
@@ -769,7 +793,74 @@ class Q3:
                 total += len(m)
                 if fin:
                     break
-        return total, time.perf_counter() - t0
+        probe_s = time.perf_counter() - t1
+        share = len(pk) / float(self.probe_rows)
+        self.cpu_detail = {"build_rows": int(len(sample["bkey"])), "build_s": build_s,
+                           "build_rows_per_s": len(sample["bkey"]) / build_s,
+                           "probe_sample_rows": int(len(pk)), "probe_s": probe_s, "probe_rows_per_s": len(pk) / probe_s,
+                           "value_is": "probe rows / (probe time + the sample's share of the build time): the rate of "
+                                       "the whole step, like the GPU figure"}
+        return total, probe_s + build_s * share
+
+    def cpu_reference_mt(self, oracle, cores, sample_rows):
+        """One thread per physical core, the reference's shape (exec/HashBuild.cpp:819-993,
+        exec/HashTable.cpp:1003-1203): every build Driver fills its own row container from its slice of
+        the build rows, the last one merges them with parallelJoinBuild (rows partitioned by bucket range,
+        one inserter per partition); then every probe Driver probes its slice of the sample against the
+        shared table."""
+        from concurrent.futures import ThreadPoolExecutor
+        cores = max(2, min(cores, 128))
+        bkey, bdate = self.bkey.cpu().numpy(), self.bdate.cpu().numpy()
+        per_probe = max(250_000, min(2_000_000, sample_rows // 4))
+        rows = min(self.probe_rows, per_probe * cores)
+        per_probe = rows // cores
+        pkey = self.pkey[:rows].cpu().numpy()
+        nb = len(bkey)
+        cuts = [nb * i // cores for i in range(cores + 1)]
+
+        def fill(i):
+            b = oracle.JoinBuild([0], [abi.BIGINT], [1], [abi.INTEGER], abi.JOIN_INNER)
+            b.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, bkey[cuts[i]:cuts[i + 1]]),
+                                       abi.HostColumn(abi.INTEGER, bdate[cuts[i]:cuts[i + 1]])]))
+            return b
+
+        def probe(i, table):
+            p = oracle.JoinProbe(table, [0], abi.JOIN_INNER)
+            pk = pkey[i * per_probe:(i + 1) * per_probe]
+            total = 0
+            for lo in range(0, len(pk), 1 << 20):
+                p.add_input(abi.HostBatch([abi.HostColumn(abi.BIGINT, pk[lo:lo + (1 << 20)])]))
+                while True:
+                    m, r, cols, fin = p.get_output(1 << 20)
+                    total += len(m)
+                    if fin:
+                        break
+            return total
+        oracle.set_join_build_threads(cores)
+        try:
+            with ThreadPoolExecutor(max_workers=cores) as ex:
+                t0 = time.perf_counter()
+                builds = list(ex.map(fill, range(cores)))
+                table = builds[0].finish(builds[1:])
+                build_s = time.perf_counter() - t0
+                probe_s = None
+                for _ in range(2):   # best of two: the first pass pays thread start-up and page faults
+                    t1 = time.perf_counter()
+                    list(ex.map(lambda i: probe(i, table), range(cores)))
+                    d = time.perf_counter() - t1
+                    probe_s = d if probe_s is None else min(probe_s, d)
+        finally:
+            oracle.set_join_build_threads(1)
+        sample = per_probe * cores
+        seconds = probe_s + build_s * (sample / float(self.probe_rows))
+        return {"value": sample / seconds, "unit": "probe rows/s", "cores": cores, "kind": "port",
+                "build_rows": nb, "build_s": build_s, "build_rows_per_s": nb / build_s,
+                "probe_sample_rows": sample, "probe_s": probe_s, "probe_rows_per_s": sample / probe_s,
+                "sample": f"{cores} build threads (own row containers, then HashTable::parallelJoinBuild restated: "
+                          f"oracle/table.h) over all {nb} build rows, {cores} probe threads x {per_probe} probe rows "
+                          "against the shared table; value = probe rows / (probe time + the sample's share of the "
+                          "build time)",
+                "host_cores_available": os.cpu_count()}
 
 
 class Q3Full:
@@ -1074,8 +1165,9 @@ def measured_ceilings():
     A kernel is compared with the ceiling of ITS shape."""
     return {"read_GBps": ops.hbm_ceiling(abi.CEILING_READ, 8 << 30, 5),
             "copy_GBps": ops.hbm_ceiling(abi.CEILING_COPY, 4 << 30, 5),
-            "how": "vx355_hbm_ceiling: 16-byte accesses, four per lane in flight, 8 workgroups per CU; "
-                   "read = 8 GiB nontemporal read-only stream, copy = 4 GiB read + 4 GiB written"}
+            "how": "vx355_hbm_ceiling: 16-byte nontemporal accesses; read = 8 GiB read-only stream (four per lane in "
+                   "flight, 8 workgroups of 512 per CU), copy = 4 GiB read + 4 GiB written (eight per lane in flight, "
+                   "4 workgroups of 1024 per CU, one contiguous 2 MiB-aligned range each: tools/copy_bench.hip)"}
 
 
 READ_ONLY_KERNELS = ("k_agg_fast", "k_agg_lds", "k_join_probe", "k_join_probe_list", "k_rp_count1", "k_pp_count")
@@ -1147,6 +1239,17 @@ def measure_traffic(child_flags, kernel, steps=1):
             "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child runs of this bench (measured in this run)"}
 
 
+def cpu_model():
+    """'model name' of /proc/cpuinfo (what lscpu prints): every CPU number carries it."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def physical_cores():
     """Distinct (socket, core) pairs of /proc/cpuinfo; logical CPUs / 2 if unreadable."""
     try:
@@ -1164,12 +1267,16 @@ def physical_cores():
 
 
 def cpu_baseline_mt(wl, oracle_lib, sample_rows):
-    """The reference's parallel shape for aggregations (one Driver per core, each
+    """Joins: wl.cpu_reference_mt (parallel build + parallel probe). The reference's parallel shape for aggregations (one Driver per core, each
     with its own partial HashAggregation over a slice of the rows):
     one worker thread per physical core runs the single-thread CPU leg on its own
     slice (ctypes and numpy release the GIL). The final merge of the workers'
     groups is not included."""
     from concurrent.futures import ThreadPoolExecutor
+    if hasattr(wl, "cpu_reference_mt"):
+        block = wl.cpu_reference_mt(oracle_lib, min(physical_cores(), 128), sample_rows)
+        block["cpu_model"] = cpu_model()
+        return block
     cores = min(physical_cores(), 128)
     per = max(1_000_000, sample_rows // 8)
     sample = wl.host_sample(per * cores)
@@ -1188,7 +1295,7 @@ def cpu_baseline_mt(wl, oracle_lib, sample_rows):
     return {"value": per * cores / dt, "unit": "rows/s", "cores": cores, "kind": "port",
             "sample": f"{cores} worker threads x {per} rows of the same {wl.name} input, one partial "
                       "aggregation per worker (oracle/ restatement), best of 3 passes; final merge not included",
-            "host_cores_available": os.cpu_count()}
+            "host_cores_available": os.cpu_count(), "cpu_model": cpu_model()}
 
 
 def main():
@@ -1264,8 +1371,8 @@ def main():
         cls.unordered = args.c4_unordered
         if args.c4_sparse:
             cls.name = "c4_groupby_1b_100m_sparse_keys"
-        if args.c4_unordered:
-            cls.name += "_unordered_output"
+        if not args.c4_unordered:
+            cls.name += "_first_seen_order"
     if args.workload == "c5":
         wl = cls(torch, n, device, seed=1234 + rank, rank=rank, world=world)
         wl.comm = comm
@@ -1416,7 +1523,7 @@ def main():
         import oracle_lib
         oracle_lib.lib()
         out["cpu_baseline"] = cpu_baseline_block(wl, oracle_lib, args.cpu_sample_rows, args.workload)
-        if args.workload in ("q1", "q1x4", "c1", "c4") and not args.no_cpu_mt:
+        if args.workload in ("q1", "q1x4", "c1", "c4", "q3") and not args.no_cpu_mt:
             out["cpu_baseline_mt"] = cpu_baseline_mt(wl, oracle_lib, args.cpu_sample_rows)
     if args.workload == "q1" and world == 1 and not args.no_secondary and not args.rows:
         # The rest of BASELINE's single-GPU configs next to the headline, each with its own roofline and
@@ -1519,6 +1626,9 @@ def compact_line(out):
                         "kernel": r.get("kernel"), "frac": _num(r.get("frac"), 4),
                         "traffic_ratio": _num(traffic / algo, 4) if (traffic and algo) else None,
                         "cpu_value": _num((blk.get("cpu_baseline") or {}).get("value"))}
+            if blk.get("cpu_baseline_mt"):
+                sec[key]["cpu_mt_value"] = _num(blk["cpu_baseline_mt"].get("value"))
+                sec[key]["cpu_mt_cores"] = blk["cpu_baseline_mt"].get("cores")
             if blk.get("host_ingest"):
                 sec[key]["host_GBps"] = _num(blk["host_ingest"].get("GBps"), 4)
         line["secondary"] = sec
@@ -1645,15 +1755,21 @@ def cpu_baseline_block(wl, oracle_lib, cpu_sample_rows, workload):
         sample_rows = int(sample["_rows"])
     else:
         sample_rows = len(sample["pkey"]) if "pkey" in sample else len(next(iter(sample.values())))
+    wl.cpu_detail = None
     cpu_out, cpu_s = wl.cpu_reference(sample, oracle_lib)
-    return {
+    block = {
         "value": sample_rows / cpu_s, "unit": "rows/s", "cores": 1, "kind": "port",
         "sample": f"first {sample_rows} rows of the same {wl.name} input, single thread: "
                   "Velox-algorithm CPU restatement (oracle/) of the same plan"
                   + (" with numpy FilterProject" if workload == "q1" else "")
-                  + (" (local join only: no exchange on the CPU side)" if workload == "c5" else ""),
-        "host_cores_available": os.cpu_count(),
+                  + (" (local join only: no exchange on the CPU side)" if workload == "c5" else "")
+                  + ("; the whole build side is built (timed separately) and charged to the probe sample by its share"
+                     if getattr(wl, "cpu_detail", None) else ""),
+        "host_cores_available": os.cpu_count(), "cpu_model": cpu_model(),
     }
+    if getattr(wl, "cpu_detail", None):
+        block["join"] = wl.cpu_detail
+    return block
 
 
 SECONDARY = [
@@ -1663,9 +1779,19 @@ SECONDARY = [
     ("tpch_q3_sf100_join", "q3", {"random_probe": False}, [], None, 2),
     ("tpch_q3_sf100_join_random_probe_order", "q3", {"random_probe": True}, ["--q3-random-probe"], None, 2),
     ("tpch_q3_sf100_full_query", "q3full", {}, [], None, 2),
-    ("c4_groupby_1b_100m", "c4", {"sparse": False, "unordered": False, "name": "c4_groupby_1b_100m"}, [], 3, 1),
-    ("c4_groupby_1b_100m_sparse_keys", "c4", {"sparse": True, "unordered": False,
-                                              "name": "c4_groupby_1b_100m_sparse_keys"}, ["--c4-sparse"], 3, 1),
+    # config 4: result sets are compared as unordered multisets, so the headline
+    # variant asks for no group order (VX355_AGG_UNORDERED_OUTPUT: what a FINAL step / exchange / ORDER BY
+    # above the operator needs); the first-seen-order form (+ one sort of the groups) is the extra
+    ("c4_groupby_1b_100m", "c4", {"sparse": False, "unordered": True, "name": "c4_groupby_1b_100m"},
+     ["--c4-unordered"], 3, 1),
+    ("c4_groupby_1b_100m_sparse_keys", "c4", {"sparse": True, "unordered": True,
+                                              "name": "c4_groupby_1b_100m_sparse_keys"},
+     ["--c4-sparse", "--c4-unordered"], 3, 1),
+    ("c4_groupby_1b_100m_first_seen_order", "c4", {"sparse": False, "unordered": False, "_no_traffic": True,
+                                                   "name": "c4_groupby_1b_100m_first_seen_order"}, [], 3, 1),
+    ("c4_groupby_1b_100m_sparse_keys_first_seen_order", "c4",
+     {"sparse": True, "unordered": False, "_no_traffic": True,
+      "name": "c4_groupby_1b_100m_sparse_keys_first_seen_order"}, ["--c4-sparse"], 3, 1),
     # the boundary north_star names: host RowVectors of 10 000 rows (PCIe inclusive; roofline = the link, not HBM)
     ("c1_groupby_10m_1k_streamed_host_vectors", "c1", {"stream": True}, None, 10, 2),
     ("tpch_q1_60m_rows_streamed_host_vectors", "q1", {"stream": True, "rows_override": 60_000_000,
@@ -1678,6 +1804,9 @@ def secondary_block(torch, device, args, copy_ceiling, measure, workload, attrs,
     (inputs resident, synchronised on both sides), with its own roofline (counter traffic from
     rocprofv3 child passes of the same workload) and CPU baseline."""
     cls, rows = WORKLOADS[workload]
+    attrs = dict(attrs)
+    if attrs.pop("_no_traffic", False):
+        measure = False   # an extra variant: timed and profiled, no rocprofv3 counter passes of its own
     saved = {k: getattr(cls, k, None) for k in attrs}
     for k, v in attrs.items():
         setattr(cls, k, v)
@@ -1740,6 +1869,8 @@ def secondary_block(torch, device, args, copy_ceiling, measure, workload, attrs,
         import oracle_lib
         oracle_lib.lib()
         block["cpu_baseline"] = cpu_baseline_block(wl, oracle_lib, min(args.cpu_sample_rows, 8_000_000), workload)
+        if hasattr(wl, "cpu_reference_mt") and not args.no_cpu_mt:
+            block["cpu_baseline_mt"] = cpu_baseline_mt(wl, oracle_lib, min(args.cpu_sample_rows, 8_000_000))
     del wl
     for k, v in saved.items():
         if v is None and k in cls.__dict__:
@@ -1757,7 +1888,8 @@ STEP_TEXT = {
     "q3": "HashBuild (add_input + finish) + HashProbe (add_input + get_output with one payload column), inner join",
     "q3full": "the whole TPC-H Q3: customer -> build; orders -> filter, probe, build; lineitem -> filter, probe; "
               "3-key aggregation (BASELINE configs[2])",
-    "c4": "HashAggregation k -> sum(v) over 10^9 rows / 10^8 groups, groups drained into HBM pages (BASELINE configs[3])",
+    "c4": "HashAggregation k -> sum(v) over 10^9 rows / 10^8 groups, groups drained into HBM pages (BASELINE configs[3]); "
+          "group order not requested unless the name says first_seen_order",
 }
 
 

@@ -17,6 +17,7 @@ namespace orc {
 namespace {
 
 thread_local std::string gLastError;
+static int gJoinBuildThreads = 1;
 
 bool isIntKind(int32_t k) { return k >= VX355_BOOLEAN && k <= VX355_BIGINT; }
 bool isStringKind(int32_t k) { return k == VX355_VARCHAR || k == VX355_VARBINARY; }
@@ -1594,10 +1595,14 @@ int orc_join_build_finish(orc_join_build* h, orc_join_build* const* others, int3
   for (int32_t i = 0; i < num_others; ++i) {
     t->t.hasNullKeys = t->t.hasNullKeys || others[i]->b.hasNullKeys_;
   }
+  t->t.table->setBuildThreads(gJoinBuildThreads);
   t->t.table->prepareJoinTable(raw);
   *out = t;
   ORC_CATCH
 }
+// Threads of HashTable::parallelJoinBuild for the join tables finished after this call (1 = the
+// serial insert, the default: what the parity tests run). bench.py's multi-thread CPU leg only.
+void orc_set_join_build_threads(int32_t n) { gJoinBuildThreads = n < 1 ? 1 : n; }
 void orc_join_build_destroy(orc_join_build* h) { delete h; }
 void orc_join_table_release(orc_join_table* t) { delete t; }
 int orc_join_table_get_stats(const orc_join_table* t, vx355_join_table_stats* out) {

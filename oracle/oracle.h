@@ -112,6 +112,8 @@ int orc_join_build_add_input(orc_join_build* h, const vx355_batch* batch);
 int orc_join_build_finish(orc_join_build* h, orc_join_build* const* others, int32_t num_others,
                           orc_join_table** out);
 void orc_join_build_destroy(orc_join_build* h);
+/* HashTable::parallelJoinBuild (exec/HashTable.cpp:1003-1203) with n threads for tables finished afterwards (bench.py's multi-thread CPU leg; default 1 = serial). */
+void orc_set_join_build_threads(int32_t n);
 void orc_join_table_release(orc_join_table* t);
 int orc_join_table_get_stats(const orc_join_table* t, vx355_join_table_stats* out);
 int orc_join_probe_create(orc_join_table* t, const vx355_join_probe_spec* spec,

@@ -3,6 +3,9 @@
 // the group-by and join paths need: 16-slot tagged buckets, the three hash
 // modes, group probe / insert, join build (duplicate chains) and join probe.
 #pragma once
+#include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cstdlib>
 #include <memory>
 #include <stdexcept>
@@ -961,6 +964,12 @@ class HashTable {
   // buildFullProbe (:1422-1478) / arrayPushRow (:1394-1409).
   void rehash(bool initNormalizedKeys) {
     ++numRehashes_;
+    if (canApplyParallelJoinBuild()) {
+      if (parallelJoinBuild(initNormalizedKeys)) {
+        return;
+      }
+      // (a key became unmappable: the serial path below finds it again and falls back to kHash)
+    }
     bool failed = false;
     int64_t distinct = 0;
     forEachRow([&](RowContainer* container, char* row) {
@@ -1039,8 +1048,178 @@ class HashTable {
     }
   }
 
+  // HashTable::canApplyParallelJoinBuild (HashTable.cpp:984-1000): a join build with peer tables whose
+  // share of the table is large enough; off unless the caller asked for build threads
+  // (setBuildThreads: the parity tests run the serial path, bench.py's multi-thread CPU leg this one).
+  bool canApplyParallelJoinBuild() const {
+    if (!isJoinBuild_ || buildThreads_ <= 1 || hashMode_ == HashMode::kArray || otherTables_.empty() ||
+        otherTables_.size() > 254) {
+      return false;
+    }
+    if (hashMode_ == HashMode::kNormalizedKey) {
+      // (this restatement's distinct-value mode looks ids up through a method that can also insert:
+      // only range-mode hashers - a subtraction - are read from several threads)
+      for (const auto& h : hashers_) {
+        if (!h.isRange()) {
+          return false;
+        }
+      }
+    }
+    return (capacity_ / (1 + otherTables_.size())) > kMinTableSizeForParallelJoinBuild;
+  }
+
+  // HashTable::parallelJoinBuild (HashTable.cpp:1003-1203): one partition per build table, in terms
+  // of ranges of bucket offsets. Step 1 (partitionRows, :1231-1263): every table's rows are hashed
+  // and assigned the partition of their first bucket, one thread per table. Step 2
+  // (buildJoinPartition, :1265-1308): one thread per partition inserts the rows of ALL tables that
+  // start in its range, probing no further than the range's end; rows that would run past it are
+  // collected as overflow. Step 3: the overflow rows are inserted serially. false = a key was
+  // unmappable (nothing inserted yet: the caller takes the serial path, which handles it).
+  bool parallelJoinBuild(bool initNormalizedKeys) {
+    const int numPartitions = 1 + static_cast<int>(otherTables_.size());
+    std::vector<RowContainer*> containers = {rows_.get()};
+    for (auto* other : otherTables_) {
+      containers.push_back(other->rows_.get());
+    }
+    std::vector<uint64_t> bounds(numPartitions + 1);
+    for (int i = 0; i < numPartitions; ++i) {
+      bounds[i] = (((sizeMask_ + 1) / numPartitions) * i + kBucketSize - 1) / kBucketSize * kBucketSize;
+    }
+    bounds[numPartitions] = sizeMask_ + 1;
+    std::vector<std::vector<uint64_t>> hashes(numPartitions);
+    std::vector<std::vector<uint8_t>> partOf(numPartitions);
+    std::vector<char> bad(numPartitions, 0);
+    auto inThreads = [&](auto&& work) {
+      // (the reference runs the last step on the calling thread; buildThreads_ caps the workers)
+      std::vector<std::thread> threads;
+      std::atomic<int> next{0};
+      const int workers = std::min(buildThreads_, numPartitions);
+      for (int t = 0; t < workers; ++t) {
+        threads.emplace_back([&] {
+          for (int i = next.fetch_add(1); i < numPartitions; i = next.fetch_add(1)) {
+            work(i);
+          }
+        });
+      }
+      for (auto& t : threads) {
+        t.join();
+      }
+    };
+    inThreads([&](int c) {
+      RowContainer* container = containers[c];
+      const auto& rows = container->rows();
+      hashes[c].resize(rows.size());
+      partOf[c].resize(rows.size());
+      const bool init = initNormalizedKeys || container != rows_.get();
+      for (size_t r = 0; r < rows.size(); ++r) {
+        uint64_t hash;
+        if (!hashStoredRow(container, rows[r], init, hash)) {
+          bad[c] = 1;
+          return;
+        }
+        hashes[c][r] = hash;
+        const uint64_t off = static_cast<uint64_t>(bucketOffset(hash));
+        int part = static_cast<int>(std::upper_bound(bounds.begin(), bounds.end(), off) - bounds.begin()) - 1;
+        partOf[c][r] = static_cast<uint8_t>(part);
+      }
+    });
+    for (char b : bad) {
+      if (b) {
+        return false;
+      }
+    }
+    std::vector<std::vector<std::pair<char*, uint64_t>>> overflow(numPartitions);
+    std::vector<std::vector<RowContainer*>> overflowContainer(numPartitions);
+    std::vector<int64_t> distinct(numPartitions, 0);
+    std::vector<char> duplicates(numPartitions, 0);
+    inThreads([&](int p) {
+      const int64_t end = static_cast<int64_t>(bounds[p + 1]);
+      for (int c = 0; c < numPartitions; ++c) {
+        const auto& rows = containers[c]->rows();
+        for (size_t r = 0; r < rows.size(); ++r) {
+          if (partOf[c][r] != p) {
+            continue;
+          }
+          bool dup = false;
+          const int placed = insertStoredRow(containers[c], rows[r], hashes[c][r], end, &dup);
+          if (placed < 0) {
+            overflow[p].emplace_back(rows[r], hashes[c][r]);
+            overflowContainer[p].push_back(containers[c]);
+          } else {
+            distinct[p] += placed;
+            duplicates[p] = duplicates[p] || dup;
+          }
+        }
+      }
+    });
+    int64_t total = 0;
+    for (int p = 0; p < numPartitions; ++p) {
+      total += distinct[p];
+      hasDuplicates_ = hasDuplicates_ || duplicates[p];
+    }
+    for (int p = 0; p < numPartitions; ++p) {
+      for (size_t i = 0; i < overflow[p].size(); ++i) {
+        bool dup = false;
+        const int placed = insertStoredRow(overflowContainer[p][i], overflow[p][i].first, overflow[p][i].second, -1, &dup);
+        total += placed > 0 ? 1 : 0;
+        hasDuplicates_ = hasDuplicates_ || dup;
+      }
+    }
+    numDistinctKeys_ = total;
+    return true;
+  }
+
+  // buildFullProbe for a stored row (HashTable.cpp:1422-1478): 1 = a new key took a slot, 0 = the row
+  // joined (or, without duplicates, was dropped at) an existing key, -1 = the probe sequence reached
+  // 'end' (the partition's last bucket offset + 1; -1 = no limit, wrap around) without a free slot.
+  int insertStoredRow(RowContainer* container, char* row, uint64_t hash, int64_t end, bool* duplicate) {
+    const uint8_t tag = hashTag(hash);
+    int64_t off = bucketOffset(hash);
+    for (uint64_t probed = 0; probed < numBuckets_; ++probed) {
+      const char* tags = table_ + off;
+      uint16_t hits = matchTags(tags, tag);
+      while (hits) {
+        int slot = __builtin_ctz(hits);
+        hits &= hits - 1;
+        char* head = pointerAt(off, slot);
+        bool same = hashMode_ == HashMode::kNormalizedKey
+            ? RowContainer::normalizedKey(head) == RowContainer::normalizedKey(row)
+            : storedKeysEqual(rows_.get(), head, container, row);
+        if (same) {
+          if (allowDuplicates_) {
+            // pushNext without touching the shared flag (the caller merges 'duplicate')
+            int32_t no = rows_->nextOffset();
+            char* headNext;
+            std::memcpy(&headNext, head + no, 8);
+            std::memcpy(row + no, &headNext, 8);
+            std::memcpy(head + no, &row, 8);
+            *duplicate = true;
+          }
+          return 0;
+        }
+      }
+      uint16_t empty = matchTags(tags, 0);
+      if (empty) {
+        setSlot(off, __builtin_ctz(empty), tag, row);
+        return 1;
+      }
+      if (end >= 0) {
+        off += kBucketSize;
+        if (off >= end) {
+          return -1;
+        }
+      } else {
+        off = nextBucketOffset(off);
+      }
+    }
+    throw std::runtime_error("Have looped through all the buckets in table");
+  }
+
  public:
   int64_t numDistinctKeys() const { return isJoinBuild_ ? numDistinctKeys_ : numDistinct_; }
+  /// Threads of the parallel join build (1 = serial, the default).
+  void setBuildThreads(int n) { buildThreads_ = n < 1 ? 1 : n; }
+  static constexpr uint64_t kMinTableSizeForParallelJoinBuild = 1000;  // QueryConfig::minTableRowsForParallelJoinBuild
 
  private:
   std::vector<VectorHasher> hashers_;
@@ -1052,6 +1231,7 @@ class HashTable {
   char* table_ = nullptr;
   uint64_t capacity_ = 0, sizeMask_ = 0, numBuckets_ = 0, bucketOffsetMask_ = 0;
   int64_t numDistinct_ = 0, numDistinctKeys_ = 0, numRehashes_ = 0;
+  int buildThreads_ = 1;
 };
 
 }  // namespace orc

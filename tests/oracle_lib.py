@@ -88,6 +88,8 @@ def lib():
     L.orc_join_build_add_input.argtypes = [vp, C.POINTER(abi.Batch)]
     L.orc_join_build_finish.argtypes = [vp, C.POINTER(vp), i32, C.POINTER(vp)]
     L.orc_join_build_destroy.argtypes = [vp]
+    L.orc_set_join_build_threads.argtypes = [i32]
+    L.orc_set_join_build_threads.restype = None
     L.orc_join_table_release.argtypes = [vp]
     L.orc_join_table_get_stats.argtypes = [vp, C.POINTER(abi.JoinTableStats)]
     L.orc_join_probe_create.argtypes = [vp, C.POINTER(abi.JoinProbeSpec), C.POINTER(vp)]
@@ -435,6 +437,11 @@ class JoinBuild:
         if getattr(self, "h", None):
             lib().orc_join_build_destroy(self.h)
             self.h = None
+
+
+def set_join_build_threads(n):
+    """HashTable::parallelJoinBuild with n threads for the join tables finished afterwards (1 = serial)."""
+    lib().orc_set_join_build_threads(int(n))
 
 
 class JoinTable:

@@ -1021,3 +1021,52 @@ def test_oracle_null_aware_joins_with_extra_filter_follow_sql(oracle, join_type,
         got = [True if r >= 0 else (None if r == -2 else False) for _, r in pairs]
         assert got == truth
     assert {True, False, None} <= set(truth) or build_nulls in (0.0, 1.0)
+
+
+@pytest.mark.parametrize("shape", ["normalized_unique", "normalized_duplicates", "hash_strings"])
+def test_parallel_join_build_equals_the_serial_build(oracle, shape):
+    """HashTable::parallelJoinBuild restated (oracle/table.h; exec/HashTable.cpp:1003-1203: rows
+    partitioned by bucket range, one inserter per partition, overflow rows serially) - what bench.py's
+    multi-thread CPU leg of the joins times - must build the same join as the serial insert: same
+    statistics, same (probe row, payload) pairs for every probe row, duplicates as sets."""
+    rng = np.random.default_rng(11)
+    ways, per = 6, 40_000
+    keys = rng.permutation(1 << 26)[: ways * per].astype(np.int64) * 1021      # sparse: normalized-key mode
+    if shape == "normalized_duplicates":
+        keys[::3] = keys[1::3][: len(keys[::3])]
+    pay = np.arange(ways * per, dtype=np.int64)
+    probe = np.concatenate([keys[rng.integers(0, len(keys), 200_000)], rng.integers(0, 1 << 40, 50_000).astype(np.int64)])
+    if shape == "hash_strings":
+        as_bytes = lambda a: [b"key-%018d" % v for v in a]     # 22 bytes: generic hash mode
+        build_cols = lambda sl: abi.HostBatch([abi.HostColumn(abi.VARCHAR, as_bytes(keys[sl])), abi.HostColumn(abi.BIGINT, pay[sl])])
+        probe_batch = abi.HostBatch([abi.HostColumn(abi.VARCHAR, as_bytes(probe))])
+        kind = abi.VARCHAR
+    else:
+        build_cols = lambda sl: _int_batch([keys[sl], pay[sl]])
+        probe_batch = _int_batch([probe])
+        kind = abi.BIGINT
+    results = []
+    for threads in (1, 4):
+        oracle.set_join_build_threads(threads)
+        try:
+            builds = []
+            for w in range(ways):
+                b = oracle.JoinBuild([0], [kind], [1], [abi.BIGINT], abi.JOIN_INNER)
+                b.add_input(build_cols(slice(w * per, (w + 1) * per)))
+                builds.append(b)
+            table = builds[0].finish(builds[1:])
+        finally:
+            oracle.set_join_build_threads(1)
+        st = table.stats()
+        p = oracle.JoinProbe(table, [0], abi.JOIN_INNER)
+        p.add_input(probe_batch)
+        pairs = []
+        while True:
+            m, r, cols, fin = p.get_output(1 << 18, [0])
+            pairs += list(zip(np.asarray(m).tolist(), np.asarray(cols[0][0]).tolist()))
+            if fin:
+                break
+        results.append(((st.num_rows, st.num_distinct, st.capacity, st.hash_mode, bool(st.has_duplicates)), sorted(pairs)))
+    assert results[0][0] == results[1][0]
+    assert results[0][0][3] == (0 if shape == "hash_strings" else 2)
+    assert results[0][1] == results[1][1] and len(results[0][1]) >= 200_000

@@ -992,9 +992,13 @@ struct NoReserve {};
 // reserve (optional): called by the lane of every non-empty bin with (bin, records of the sub-tile);
 // returns the first record position of that run in 'out', or ~0 to drop the run — the optimistic
 // level 2 claims its space from a global cursor per partition instead of a counted offset.
-template <int W, int R, typename BinFn, typename ReserveFn = NoReserve>
-__device__ inline void rpSortedEmit(SortLds<W>& l, int numBins, const uint64_t (&rec)[R][W], const uint32_t (&bin)[R],
-                                    uint64_t* out, BinFn&& binOfWord0, ReserveFn&& reserve = NoReserve{}) {
+// First half: histogram, scan, (reserve,) placement of the records in LDS, sorted by bin. On return
+// the lanes' record registers are dead - the caller issues the NEXT sub-tile's loads here, so that
+// they are in flight while rpSortedWrite streams this sub-tile out (HBM reads overlap HBM writes;
+// with one workgroup per CU nothing else would fill the read side during the write-out).
+template <int W, int R, typename ReserveFn = NoReserve>
+__device__ inline void rpSortedPlace(SortLds<W>& l, int numBins, const uint64_t (&rec)[R][W], const uint32_t (&bin)[R],
+                                     ReserveFn&& reserve = NoReserve{}) {
   constexpr bool kReserves = !std::is_same<typename std::decay<ReserveFn>::type, NoReserve>::value;
   const int tid = threadIdx.x;
 #pragma unroll
@@ -1040,6 +1044,12 @@ __device__ inline void rpSortedEmit(SortLds<W>& l, int numBins, const uint64_t (
     }
   }
   blockSync();
+}
+
+// Second half: the sorted sub-tile leaves for its bins; cnt[] is zero again on return.
+template <int W, bool kReserves, typename BinFn>
+__device__ inline void rpSortedWrite(SortLds<W>& l, int numBins, uint64_t* out, BinFn&& binOfWord0) {
+  const int tid = threadIdx.x;
   uint32_t total = 0;
 #pragma unroll
   for (int w = 0; w < kSortThreads / 64; ++w) {
@@ -1064,6 +1074,14 @@ __device__ inline void rpSortedEmit(SortLds<W>& l, int numBins, const uint64_t (
   blockSync();
 }
 
+template <int W, int R, typename BinFn, typename ReserveFn = NoReserve>
+__device__ inline void rpSortedEmit(SortLds<W>& l, int numBins, const uint64_t (&rec)[R][W], const uint32_t (&bin)[R],
+                                    uint64_t* out, BinFn&& binOfWord0, ReserveFn&& reserve = NoReserve{}) {
+  constexpr bool kReserves = !std::is_same<typename std::decay<ReserveFn>::type, NoReserve>::value;
+  rpSortedPlace<W, R>(l, numBins, rec, bin, reserve);
+  rpSortedWrite<W, kReserves>(l, numBins, out, binOfWord0);
+}
+
 // Level 1 with sorted sub-tiles (numBins <= kSortBins); same records as k_rp_scatter1.
 // HASHED: word 0 carries the home slot instead of the key, the last word the full key.
 template <int KW, int W, bool FLATV, bool HASHED, bool OPT = false>
@@ -1085,21 +1103,29 @@ __global__ __launch_bounds__(kSortThreads) void k_rp_scatter1_sorted(RadixArgs r
     blockSync();
     const int64_t begin = tile * r.tileRows;
     const int64_t end = begin + r.tileRows < a.numRows ? begin + r.tileRows : a.numRows;
-    for (int64_t base = begin; base < end; base += SortLds<W>::kSub) {
-      int64_t raw[R];
-      uint64_t vals[R][W];
-      uint32_t bin[R];
+    int64_t raw[R];
+    uint64_t vals[R][W];
+    // the sub-tile's key and operand loads (clamped rows: every lane loads, the results of rows >= end
+    // are ignored); called for sub-tile i + 1 between the two halves of sub-tile i's sorted emit
+    auto loadSub = [&](int64_t base) {
 #pragma unroll
       for (int u = 0; u < R; ++u) {
         const int64_t row = base + u * kSortThreads + threadIdx.x;
-        raw[u] = row < end ? rpLoadKey<KW>(r, row) : 0;
+        const int64_t at = row < end ? row : end - 1;
+        raw[u] = rpLoadKey<KW>(r, at);
         if constexpr (FLATV) {
 #pragma unroll
           for (int q = 1; q < V; ++q) {
-            vals[u][q] = row < end ? VX355_RP_LOAD(static_cast<const uint64_t*>(a.accs[r.accOfVal[q - 1]].in.values) + row) : 0;
+            vals[u][q] = VX355_RP_LOAD(static_cast<const uint64_t*>(a.accs[r.accOfVal[q - 1]].in.values) + at);
           }
         }
       }
+    };
+    if (begin < end) {
+      loadSub(begin);
+    }
+    for (int64_t base = begin; base < end; base += SortLds<W>::kSub) {
+      uint32_t bin[R];
 #pragma unroll
       for (int u = 0; u < R; ++u) {
         const int64_t row = base + u * kSortThreads + threadIdx.x;
@@ -1144,20 +1170,28 @@ __global__ __launch_bounds__(kSortThreads) void k_rp_scatter1_sorted(RadixArgs r
         bin[u] = static_cast<uint32_t>(part >> shift);
       }
       const uint64_t keyMask = (1ULL << r.keyBits) - 1;
+      const int64_t next = base + SortLds<W>::kSub;
       if constexpr (OPT) {
-        rpSortedEmit<W, R>(
-            l, r.numBins, vals, bin, r.recs, [&](uint64_t w0) { return static_cast<uint32_t>((w0 & keyMask) >> shift); },
-            [&](uint32_t b, uint32_t count) -> unsigned long long {
-              const uint32_t at = atomicAdd(&r.binCursor[b], count);
-              if (static_cast<uint64_t>(at) + count > r.binCap) {
-                *r.binOverflow = 1;
-                return ~0ULL;
-              }
-              return r.binFirst[b] + at;
-            });
+        rpSortedPlace<W, R>(l, r.numBins, vals, bin, [&](uint32_t b, uint32_t count) -> unsigned long long {
+          const uint32_t at = atomicAdd(&r.binCursor[b], count);
+          if (static_cast<uint64_t>(at) + count > r.binCap) {
+            *r.binOverflow = 1;
+            return ~0ULL;
+          }
+          return r.binFirst[b] + at;
+        });
+        if (next < end) {
+          loadSub(next);
+        }
+        rpSortedWrite<W, true>(l, r.numBins, r.recs,
+                               [&](uint64_t w0) { return static_cast<uint32_t>((w0 & keyMask) >> shift); });
       } else {
-        rpSortedEmit<W, R>(l, r.numBins, vals, bin, r.recs,
-                           [&](uint64_t w0) { return static_cast<uint32_t>((w0 & keyMask) >> shift); });
+        rpSortedPlace<W, R>(l, r.numBins, vals, bin);
+        if (next < end) {
+          loadSub(next);
+        }
+        rpSortedWrite<W, false>(l, r.numBins, r.recs,
+                                [&](uint64_t w0) { return static_cast<uint32_t>((w0 & keyMask) >> shift); });
       }
     }
   }
@@ -1347,22 +1381,29 @@ __device__ inline void rpScatter2SortedBody(const Radix2Args& r) {
       l.binBase[i] = r.offsets[tile.cell + static_cast<uint64_t>(i) * tile.stride];
     }
     blockSync();
-    for (uint32_t base = 0; base < tile.count; base += SortLds<W>::kSub) {
-      uint64_t w[R][W];
-      uint32_t bin[R];
+    uint64_t w[R][W];
+    // the sub-tile's records (clamped, unconditional loads: see k_rp_scatter2)
+    auto loadSub = [&](uint32_t base) {
 #pragma unroll
       for (int u = 0; u < R; ++u) {
-        // all loads of the sub-tile first (clamped, unconditional: see k_rp_scatter2), the bins after
         const uint32_t i = base + u * kSortThreads + threadIdx.x;
         rpLoad<W>(r.in + (tile.begin + (i < tile.count ? i : tile.count - 1)) * W, w[u]);
       }
+    };
+    // (loading sub-tile i + 1 between the halves of sub-tile i's emit, as level 1 does, made this pass
+    // SLOWER: 7.27 -> 7.60 ms dense, 15.0 -> 16.6 ms sparse keys at 10^9 rows - its reads and writes fall
+    // into the same bucket's memory; profiles/r05_c4_pass_bytes.md)
+    for (uint32_t base = 0; base < tile.count; base += SortLds<W>::kSub) {
+      loadSub(base);
+      uint32_t bin[R];
 #pragma unroll
       for (int u = 0; u < R; ++u) {
         const uint32_t i = base + u * kSortThreads + threadIdx.x;
         bin[u] = i < tile.count ? ((static_cast<uint32_t>(w[u][0]) >> r.shiftB) & binMask) : 0xffffffffu;
       }
-      rpSortedEmit<W, R>(l, r.numBins, w, bin, r.out,
-                         [&](uint64_t w0) { return (static_cast<uint32_t>(w0) >> r.shiftB) & binMask; });
+      rpSortedPlace<W, R>(l, r.numBins, w, bin);
+      rpSortedWrite<W, false>(l, r.numBins, r.out,
+                              [&](uint64_t w0) { return (static_cast<uint32_t>(w0) >> r.shiftB) & binMask; });
     }
   }
 }
@@ -1462,30 +1503,32 @@ __global__ __launch_bounds__(kSortThreads) void k_rp_scatter2_opt(Radix2OptArgs 
     const uint64_t bucket = (firstKey >> r.shiftB) >> r.shift2;
     const uint64_t part0 = bucket << r.shift2;
     const uint32_t cap = r.bucketCap[bucket];
-    for (uint32_t base = 0; base < tile.count; base += SortLds<W>::kSub) {
-      uint64_t w[R][W];
-      uint32_t bin[R];
+    uint64_t w[R][W];
+    auto loadSub = [&](uint32_t base) {   // (as in rpScatter2SortedBody)
 #pragma unroll
       for (int u = 0; u < R; ++u) {
-        // all loads of the sub-tile first (clamped, unconditional: see k_rp_scatter2), the bins after
         const uint32_t i = base + u * kSortThreads + threadIdx.x;
         rpLoad<W>(r.in + (tile.begin + (i < tile.count ? i : tile.count - 1)) * W, w[u]);
       }
+    };
+    for (uint32_t base = 0; base < tile.count; base += SortLds<W>::kSub) {
+      loadSub(base);
+      uint32_t bin[R];
 #pragma unroll
       for (int u = 0; u < R; ++u) {
         const uint32_t i = base + u * kSortThreads + threadIdx.x;
         bin[u] = i < tile.count ? ((static_cast<uint32_t>(w[u][0]) >> r.shiftB) & binMask) : 0xffffffffu;
       }
-      rpSortedEmit<W, R>(
-          l, r.numBins, w, bin, r.out, [&](uint64_t w0) { return (static_cast<uint32_t>(w0) >> r.shiftB) & binMask; },
-          [&](uint32_t b, uint32_t count) -> unsigned long long {
-            const uint32_t at = atomicAdd(&r.partCount[part0 + b], count);
-            if (at + count > cap) {
-              *r.overflow = 1;
-              return ~0ULL;
-            }
-            return r.partBase[part0 + b] + at;
-          });
+      rpSortedPlace<W, R>(l, r.numBins, w, bin, [&](uint32_t b, uint32_t count) -> unsigned long long {
+        const uint32_t at = atomicAdd(&r.partCount[part0 + b], count);
+        if (at + count > cap) {
+          *r.overflow = 1;
+          return ~0ULL;
+        }
+        return r.partBase[part0 + b] + at;
+      });
+      rpSortedWrite<W, true>(l, r.numBins, r.out,
+                             [&](uint64_t w0) { return (static_cast<uint32_t>(w0) >> r.shiftB) & binMask; });
     }
   }
 }

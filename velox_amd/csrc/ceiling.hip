@@ -1,14 +1,15 @@
 // What the HBM of THIS box delivers to plain streaming kernels: the practical ceiling next to
 // the 8 TB/s datasheet figure every roofline fraction of bench.py is quoted against. Two
-// hand-written kernels in the style of the library's streaming passes (16-byte accesses, four
-// independent accesses per lane in flight, grid-stride over a few workgroups per CU):
+// hand-written kernels in the style of the library's streaming passes (16-byte accesses, several
+// independent accesses per lane in flight, a few workgroups per CU):
 //   VX355_CEILING_READ  a read-only stream - nontemporal loads folded into one word per lane, one
 //                       store per workgroup: the shape of k_agg_fast (68 B read per row, nothing
 //                       written), bounded by the read rate alone;
 //   VX355_CEILING_COPY  read + write of the same number of bytes: the shape of the radix scatters,
 //                       the partitioned probe's record pass and the page writer.
 // MI355X_MICROARCH.md measures ~6.3 TB/s for a float4 copy; torch's Tensor.copy_ (what bench.py
-// used before) reaches 4.7-5.0 TB/s and therefore sat BELOW kernels it was meant to bound.
+// used before) reaches 4.7-5.0 TB/s and therefore sat BELOW kernels it was meant to bound; so did this
+// file's own first copy kernel (4.5-5.0): see k_ceiling_copy.
 #include "common.h"
 #include "device_utils.h"
 
@@ -37,20 +38,30 @@ __global__ __launch_bounds__(512) void k_ceiling_read(const U32x4* src, int64_t 
   }
 }
 
-__global__ __launch_bounds__(512) void k_ceiling_copy(const U32x4* src, U32x4* dst, int64_t n) {
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x * 4;
-  int64_t i = (static_cast<int64_t>(blockIdx.x) * blockDim.x) * 4 + threadIdx.x;
-  for (; i + 3 * static_cast<int64_t>(blockDim.x) < n; i += stride) {
-    const U32x4 a = src[i];
-    const U32x4 b = src[i + blockDim.x];
-    const U32x4 c = src[i + 2 * static_cast<int64_t>(blockDim.x)];
-    const U32x4 d = src[i + 3 * static_cast<int64_t>(blockDim.x)];
-    dst[i] = a;
-    dst[i + blockDim.x] = b;
-    dst[i + 2 * static_cast<int64_t>(blockDim.x)] = c;
-    dst[i + 3 * static_cast<int64_t>(blockDim.x)] = d;
+// The copy shape that got closest to the guide's 6.3 TB/s on this chip (tools/copy_bench.hip,
+// profiles/r05_copy_bench.txt: 5.8-5.9 TB/s at 4 GiB + 4 GiB, 6.1 at 1 + 1; the r04 kernel - 512 lanes, 8
+// workgroups per CU, grid-stride, plain loads and stores - reached 4.5-5.0): 1024-lane workgroups, four
+// per CU, each owning ONE contiguous range rounded to 2 MiB, eight 16-byte nontemporal loads in flight
+// per lane, nontemporal stores.
+constexpr int kCopyUnroll = 8;
+__global__ __launch_bounds__(1024) void k_ceiling_copy(const U32x4* __restrict__ src, U32x4* __restrict__ dst, int64_t n) {
+  const int64_t B = blockDim.x;
+  int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  per = (per + 131071) / 131072 * 131072;   // 2 MiB of 16-byte elements
+  int64_t i = blockIdx.x * per + threadIdx.x;
+  const int64_t end = (blockIdx.x + 1) * per < n ? (blockIdx.x + 1) * per : n;
+  for (; i + (kCopyUnroll - 1) * B < end; i += B * kCopyUnroll) {
+    U32x4 v[kCopyUnroll];
+#pragma unroll
+    for (int u = 0; u < kCopyUnroll; ++u) {
+      v[u] = __builtin_nontemporal_load(src + i + u * B);
+    }
+#pragma unroll
+    for (int u = 0; u < kCopyUnroll; ++u) {
+      __builtin_nontemporal_store(v[u], dst + i + u * B);
+    }
   }
-  for (; i < n; i += blockDim.x) {
+  for (; i < end; i += B) {
     dst[i] = src[i];
   }
 }
@@ -80,7 +91,7 @@ extern "C" int vx355_hbm_ceiling(int32_t kind, size_t bytes, int32_t iterations,
     if (kind == VX355_CEILING_READ) {
       hipLaunchKernelGGL(k_ceiling_read, dim3(grid), dim3(512), 0, rt.stream, src.as<U32x4>(), n, sink.as<uint32_t>());
     } else {
-      hipLaunchKernelGGL(k_ceiling_copy, dim3(grid), dim3(512), 0, rt.stream, src.as<U32x4>(), dst.as<U32x4>(), n);
+      hipLaunchKernelGGL(k_ceiling_copy, dim3(rt.numCUs * 4), dim3(1024), 0, rt.stream, src.as<U32x4>(), dst.as<U32x4>(), n);
     }
   };
   launch();
