@@ -838,6 +838,15 @@ int vx355_join_probe_set_output_batch_bytes(vx355_join_probe* h, int64_t bytes);
 /* HashProbe::addInput (exec/HashProbe.cpp:796-900): prepareForJoinProbe
  * (HashTable.cpp:2680-2712) + joinProbe (:610-652) for the whole batch. */
 int vx355_join_probe_add_input(vx355_join_probe* h, const vx355_batch* batch);
+/* Asynchronous form (ABI 7), as for the aggregation and the build (see vx355_agg_add_input_async): the
+ * upload of the batch, the probe kernels and the read-back of the output size run on the handle's
+ * worker thread; the Driver thread returns at once (exec/Operator.h:285-299) and either polls
+ * (isBlocked) or simply calls get_output, which waits. One batch in flight: the next add_input
+ * follows the last get_output of this one. The batch's buffers stay valid until its output is
+ * drained, as for the synchronous form. */
+int vx355_join_probe_add_input_async(vx355_join_probe* h, const vx355_batch* batch, int64_t* ticket_out);
+int vx355_join_probe_poll(vx355_join_probe* h, int64_t* submitted, int64_t* completed);
+int vx355_join_probe_wait(vx355_join_probe* h);
 /* HashProbe::getOutput (:1154) -> listJoinResults (HashTable.cpp:2133-2350) +
  * fillOutput (HashProbe.cpp:968-991). Emits at most max_rows result rows in
  * ascending probe-row order, all matches of one probe row contiguous.

@@ -164,4 +164,6 @@ if __name__ == "__main__":
     code = commcheck.main([sys.argv[1], sys.argv[2], "0", sys.argv[3]])
     if code == 0:
         code = second_phase(sys.argv[1:])
-    sys.exit(code)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(code)   # (no tear-down: see velox_amd/commcheck.py)

@@ -148,3 +148,58 @@ def test_polling_alone_completes_the_batches_of_an_open_chunk(vx):
     op.no_more_input()
     got = vx.collect_output(op, 100)
     assert int(np.sum(got[1][0])) == 3000
+
+
+def test_probe_async_input_equals_the_synchronous_path(oracle, vx):
+    """vx355_join_probe_add_input_async (ABI 7): the batch's upload and probe kernels run on the handle's
+    worker thread; get_output waits for them. Batch after batch, mixed with the synchronous form, with an
+    input filter fused in: the same (probe row, build row, payload) lists as the oracle's."""
+    rng = np.random.default_rng(17)
+    nb = 60000
+    bk = rng.permutation(4_000_000)[:nb].astype(np.int64)
+    pay = rng.integers(0, 1 << 30, nb).astype(np.int64)
+    probes = []
+    for _ in range(6):
+        pk = rng.integers(0, 4_000_000, 300_000).astype(np.int64)
+        pk[::20] = bk[rng.integers(0, nb, len(pk[::20]))]
+        probes.append((pk, rng.integers(0, 100, len(pk)).astype(np.int32)))
+    res = {}
+    for impl in (oracle, vx):
+        b = impl.JoinBuild([0], [abi.BIGINT], [1], [abi.BIGINT], abi.JOIN_INNER)
+        b.add_input(batch_of([bk, pay]))
+        probe = impl.JoinProbe(b.finish(), [0], abi.JOIN_INNER)
+        if impl is vx:
+            probe.set_input_filter([(1, abi.CMP_LT, 50)])
+        out = []
+        for i, (pk, flag) in enumerate(probes):
+            if impl is vx:
+                hb = batch_of([pk, flag])
+                if i % 3 == 2:
+                    probe.add_input(hb)
+                else:
+                    ticket = probe.add_input_async(hb)
+                    assert ticket >= 1
+                    sub, done = probe.poll()
+                    assert sub == ticket and done in (ticket - 1, ticket)
+                    if i % 3 == 1:
+                        probe.wait()
+                        assert probe.poll() == (ticket, ticket)
+                sel = None
+            else:
+                sel = np.flatnonzero(flag < 50)
+                probe.add_input(batch_of([pk[sel]]))
+            maps, rows, pays = [], [], []
+            while True:
+                m, r, cols, fin = probe.get_output(40000, [0])
+                maps.append(np.asarray(m))
+                rows.append(np.asarray(r))
+                pays.append(np.asarray(cols[0][0]))
+                if fin:
+                    break
+            m = np.concatenate(maps)
+            out.append((m if sel is None else sel[m], np.concatenate(rows), np.concatenate(pays)))
+        res[impl.__name__] = out
+    for g, e in zip(res[vx.__name__], res[oracle.__name__]):
+        for a, b_ in zip(g, e):
+            assert len(a) == len(b_) and (a == b_).all()
+        assert len(g[0]) > 5000

@@ -6,6 +6,7 @@ import json
 import os
 import subprocess
 import sys
+import tempfile
 
 import numpy as np
 import pytest
@@ -185,7 +186,8 @@ def test_commcheck_world_size_one(tmp_path):
 
 def test_bench_gpus_2_starts_two_ranks_by_itself():
     """`python bench.py --gpus 2` without a launcher: bench.py starts the ranks itself; on a 1-GPU
-    box they share the GPU (VX355_BENCH_SHARE_GPU) and exchange over gloo. The line must say 2."""
+    box they share the GPU (VX355_BENCH_SHARE_GPU) and exchange through the LIBRARY (vx355_agg_merge_partials
+    over the shared-memory transport): the line must say 2 and must not report a downgraded exchange."""
     env = dict(os.environ, VX355_BENCH_SHARE_GPU="1")
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
@@ -197,17 +199,23 @@ def test_bench_gpus_2_starts_two_ranks_by_itself():
     assert line["n_gpus"] == 2 and line["config"]["rows_per_gpu"] == 200000
     assert line["value"] > 0 and line["scaling"] == "weak"
     assert line["strong_scaling"]["rows_total"] == 200000
+    assert "exchange_downgraded" not in line and "shared-memory transport" in line["config"]["exchange"]
 
 
 def test_bench_c5_through_the_library_exchange():
     """--workload c5 at N = 1 runs vx355_join_repartition end to end (the exchange is a device copy)."""
+    detail = os.path.join(tempfile.mkdtemp(prefix="vx355_bench_"), "detail.json")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c5", "--rows", "2000000", "--steps",
-                        "2", "--warmup", "1", "--no-traffic", "--no-cpu-baseline"], capture_output=True, text=True,
-                       timeout=600)
+                        "2", "--warmup", "1", "--no-traffic", "--no-cpu-baseline", "--detail", detail],
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    last = r.stdout.rstrip("\n").splitlines()[-1]
+    assert len(last) < 4096                                       # the compact line the driver parses
+    line = json.loads(last)
     assert line["n_gpus"] == 1 and "libvx355" in line["config"]["exchange"]
-    assert line["workload_info"]["matches_on_rank0"] == 2000000   # every fact row finds its dim row
+    assert line["detail"] == detail and line["result_check_ok"] is True
+    full = json.load(open(detail))                                # everything else is in the detail file
+    assert full["workload_info"]["matches_on_rank0"] == 2000000   # every fact row finds its dim row
 
 
 @pytest.mark.parametrize("with_torch", [False, True])

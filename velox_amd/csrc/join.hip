@@ -2525,6 +2525,7 @@ struct vx355_join_table {
 
 struct vx355_join_probe {
   vx::Runtime* ctx = nullptr;  // this operator's execution context (stream, mailbox)
+  vx::AsyncQueue* aq = nullptr;  // worker of vx355_join_probe_add_input_async (created on first use)
   vx355_join_table* table = nullptr;
   std::vector<int32_t> keyCols;
   int32_t joinType = 0;
@@ -4146,7 +4147,7 @@ int vx355_join_probe_set_output_batch_bytes(vx355_join_probe* h, int64_t bytes) 
   VX_API_CATCH
 }
 
-int vx355_join_probe_add_input(vx355_join_probe* h, const vx355_batch* batch) {
+static int joinProbeAddInputNow(vx355_join_probe* h, const vx355_batch* batch) {
   VX_API_BEGIN_CTX(VX_CTX_OF(h))
   Runtime::get().requireInit();
   VX_CHECK_ARG(h && batch, "NULL argument");
@@ -4154,10 +4155,71 @@ int vx355_join_probe_add_input(vx355_join_probe* h, const vx355_batch* batch) {
   VX_API_END
 }
 
+int vx355_join_probe_add_input(vx355_join_probe* h, const vx355_batch* batch) {
+  VX_ASYNC_DRAIN(h)
+  return joinProbeAddInputNow(h, batch);
+}
+
+// Asynchronous boundary for the probe side (exec/Operator.h:285-299: a Driver thread must not sit in
+// addInput): the batch's upload, probe kernels and the read-back of the output size run on the
+// handle's worker thread. One batch at a time, as for the synchronous form: the next add_input
+// (either form) follows the last get_output of this one. Every other entry point waits for it.
+int vx355_join_probe_add_input_async(vx355_join_probe* h, const vx355_batch* batch, int64_t* ticket_out) {
+  try {
+    if (!h || !batch || (batch->num_cols > 0 && !batch->cols)) {
+      vx::setLastError("NULL argument");
+      return VX355_EINVAL;
+    }
+    if (!h->aq) {
+      h->aq = vx::asyncCreate();
+    }
+    if (const int failed = vx::asyncFailed(h->aq)) {
+      return failed;
+    }
+    // (never through the parallel ingest: it merges vectors into chunks, and a probe's output rows
+    // number the rows of ONE input batch)
+    const int64_t ticket = vx::asyncSubmit(
+        h->aq, vx::asyncBatchTask(batch, [h](const vx355_batch* b) { return joinProbeAddInputNow(h, b); }));
+    if (ticket_out) {
+      *ticket_out = ticket;
+    }
+    return VX355_OK;
+  } catch (const std::exception& e) {
+    vx::setLastError(e.what());
+    return VX355_EINTERNAL;
+  }
+}
+
+int vx355_join_probe_poll(vx355_join_probe* h, int64_t* submitted, int64_t* completed) {
+  if (!h) {
+    vx::setLastError("NULL argument");
+    return VX355_EINVAL;
+  }
+  if (submitted) {
+    *submitted = 0;
+  }
+  if (completed) {
+    *completed = 0;
+  }
+  if (h->aq) {
+    vx::asyncPoll(h->aq, submitted, completed);
+  }
+  return VX355_OK;
+}
+
+int vx355_join_probe_wait(vx355_join_probe* h) {
+  if (!h) {
+    vx::setLastError("NULL argument");
+    return VX355_EINVAL;
+  }
+  return h->aq ? vx::asyncWait(h->aq) : VX355_OK;
+}
+
 int vx355_join_probe_get_output(vx355_join_probe* h, int32_t max_rows, int32_t* mapping_out,
                                 int32_t* build_rows_out, int32_t out_mem, vx355_out_column* build_cols,
                                 const int32_t* build_col_ids, int32_t num_build_cols, int32_t* n_out,
                                 int32_t* finished) {
+  VX_ASYNC_DRAIN(h)
   VX_API_BEGIN_CTX(VX_CTX_OF(h))
   Runtime::get().requireInit();
   VX_CHECK_ARG(h, "NULL argument");
@@ -4170,6 +4232,7 @@ int vx355_join_probe_get_build_side_output(vx355_join_probe* h, int32_t max_rows
                                            int32_t out_mem, vx355_out_column* build_cols,
                                            const int32_t* build_col_ids, int32_t num_build_cols, int32_t* n_out,
                                            int32_t* finished) {
+  VX_ASYNC_DRAIN(h)
   VX_API_BEGIN_CTX(VX_CTX_OF(h))
   Runtime::get().requireInit();
   VX_CHECK_ARG(h, "NULL argument");
@@ -4182,6 +4245,8 @@ void vx355_join_probe_destroy(vx355_join_probe* h) {
   if (!h) {
     return;
   }
+  vx::asyncDestroy(h->aq);  // waits for a batch in flight
+  h->aq = nullptr;
   vx355_join_table* t = h->table;
   Runtime* ctx = h->ctx;
   try {

@@ -44,6 +44,7 @@ SYMBOLS = [
     "vx355_all_gather_v", "vx355_exchange_create", "vx355_exchange_send", "vx355_exchange_receive",
     "vx355_exchange_stream", "vx355_exchange_destroy", "vx355_exchange_destinations", "vx355_join_repartition", "vx355_agg_merge_partials",
     "vx355_hbm_ceiling", "vx355_compose_indices", "vx355_agg_table_bytes", "vx355_join_probe_set_input_filter",
+    "vx355_join_probe_add_input_async", "vx355_join_probe_poll", "vx355_join_probe_wait",
 ]
 
 # int (*vx355_join_chunk_sink)(void* arg, int32_t chunk, const vx355_batch* received, vx355_join_probe* probe)
@@ -93,7 +94,7 @@ def lib():
     L.vx355_agg_create.argtypes = [P(abi.AggSpec), P(vp)]
     L.vx355_agg_set_fused_input.argtypes = [vp, P(abi.FilterTerm), i32, P(abi.Projection), i32]
     L.vx355_agg_add_input.argtypes = [vp, P(abi.Batch)]
-    for name in ("vx355_agg", "vx355_join_build"):
+    for name in ("vx355_agg", "vx355_join_build", "vx355_join_probe"):
         getattr(L, name + "_add_input_async").argtypes = [vp, P(abi.Batch), P(i64)]
         getattr(L, name + "_poll").argtypes = [vp, P(i64), P(i64)]
         getattr(L, name + "_wait").argtypes = [vp]
@@ -1017,6 +1018,21 @@ class HashProbe:
     def add_input(self, batch):
         self._batch = batch
         _check(lib().vx355_join_probe_add_input(self.h, batch.ref()))
+
+    def add_input_async(self, batch):
+        """-> ticket; the batch is kept alive here. get_output (or wait) waits for it."""
+        self._batch = batch
+        ticket = C.c_int64()
+        _check(lib().vx355_join_probe_add_input_async(self.h, batch.ref(), C.byref(ticket)))
+        return ticket.value
+
+    def poll(self):
+        sub, done = C.c_int64(), C.c_int64()
+        _check(lib().vx355_join_probe_poll(self.h, C.byref(sub), C.byref(done)))
+        return sub.value, done.value
+
+    def wait(self):
+        _check(lib().vx355_join_probe_wait(self.h))
 
     def get_output(self, max_rows=1024, build_col_ids=None):
         if build_col_ids is None:
