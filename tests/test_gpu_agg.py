@@ -1713,3 +1713,24 @@ print('KERNELS', sorted(ops.profile()), 'JIT', op.stats().reserved, 'SUM', float
     assert "k_agg_fast" in second.stdout and "k_agg_lds" not in second.stdout   # first batch, asynchronous mode
     assert first.stdout.split("SUM")[1] == second.stdout.split("SUM")[1]
     assert len(list(cache.glob("agg_fast_*.hsaco"))) == 1
+
+
+@pytest.mark.parametrize("groups", [3000, 150_000, 6_000_000])
+def test_first_seen_order_through_the_librarys_own_pair_sort(vx, groups):
+    """Groups come out in first-seen order (GroupingSet.cpp:828-839). Between 4096 and 32 M groups the
+    (first row, group row) pairs are put in order by the library's own LSD radix sort
+    (csrc/radix_sort.hip; rocPRIM until round 5): 3000 groups take the one-workgroup kernel of the
+    small tables, 150 000 the single-workgroup scan of the digit histograms, 6 M the multi-workgroup
+    scan. Keys arrive in a random permutation, twice: the output must list them in the order of their
+    first occurrence, with count 2 each - an order only the sort can produce (the table is indexed by key)."""
+    rng = np.random.default_rng(groups)
+    keys = (rng.permutation(groups).astype(np.int64) * 3 + 7)
+    op = vx.Aggregation([0], [abi.BIGINT], [(abi.AGG_COUNT_STAR, -1, abi.BIGINT)])
+    op.add_input(batch_of([keys]))
+    op.add_input(batch_of([keys[::-1].copy()]))
+    op.no_more_input()
+    out = vx.collect_output(op, 1 << 20)
+    got_keys, got_counts = np.asarray(out[0][0]), np.asarray(out[1][0])
+    assert len(got_keys) == groups
+    assert (got_keys == keys).all()
+    assert (got_counts == 2).all()

@@ -3428,7 +3428,8 @@ __global__ __launch_bounds__(256) void k_collect(const uint64_t* table, uint64_t
 }
 
 // ---- first-seen order of many groups (config 4: 10^8 of them) -----------------------------------
-// rocPRIM's pair sort moves 12 bytes per entry four times (3.4 ms per 10^8 entries). The entries
+// A generic LSD pair sort moves 12 bytes per entry four times (3.4 ms per 10^8 entries with the vendor
+// library's, measured in round 4). The entries
 // are special: the keys are FIRST INPUT ROWS - distinct, because a row belongs to one group, and
 // below 2^bits (bits = those of the operator's input row count). So: pack an entry into one word
 // {group row : 32 | first row : 32} (k_fs_pack, in place; an entry no group owns - the holes of a
@@ -3439,7 +3440,7 @@ __global__ __launch_bounds__(256) void k_collect(const uint64_t* table, uint64_t
 // a partition of the second level spans 2^(bits - 20) <= 4096 consecutive row numbers, so one wave
 // sets a bit per entry in an LDS bitmap and an entry's rank inside the partition is the number of
 // bits below its own (k_fs_rank). Measured at 10^8 entries: 3.1 ms (pack 0.4, levels 2 x 0.9, ranks
-// 0.7, tiles 0.1) against rocPRIM's 3.4 - the 8-byte scatters reach 2.3 TB/s only. (One level and a
+// 0.7, tiles 0.1) against 3.4 - the 8-byte scatters reach 2.3 TB/s only. (One level and a
 // workgroup per bin with the bin's whole 2^20-bit bitmap in LDS: 3.3 ms for the ranks alone - their
 // stores scatter over 4 MB per workgroup.)
 __global__ __launch_bounds__(256) void k_fs_pack(uint64_t* keys, const uint32_t* vals, uint64_t n, uint32_t firstFree) {
@@ -6735,13 +6736,13 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
   rt.sync();
 }
 
-// First-seen order of 'n' listed entries {orderKeys: first row, orderVals: group row} without
-// rocPRIM (see k_fs_pack): h.order <- group rows by ascending first row; 'holes' of the entries have
+// First-seen order of 'n' listed entries {orderKeys: first row, orderVals: group row} by the packed
+// two-level form (see k_fs_pack): h.order <- group rows by ascending first row; 'holes' of the entries have
 // no group. false: not applicable (few entries, row numbers beyond 32 bits, switched off) - the
-// caller sorts with rocPRIM.
+// caller sorts with the generic pair sort (radix_sort.hip).
 bool sortFirstSeen(vx355_agg& h, size_t n, size_t holes) {
   auto& rt = Runtime::get();
-  int64_t minEntries = 32LL << 20;   // measured at 10^8 entries; below this rocPRIM's fixed costs are the smaller ones
+  int64_t minEntries = 32LL << 20;   // measured at 10^8 entries; below this the generic sort's fixed costs are the smaller ones
   if (const char* e = std::getenv("VX355_AGG_OWN_SORT_MIN")) {
     minEntries = std::strtoll(e, nullptr, 10);  // < 0: never
   }

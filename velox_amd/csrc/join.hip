@@ -39,7 +39,7 @@ std::mutex gNoTableMutex;
 
 void compactBits(const uint64_t* dValues, const uint64_t* dNulls, const uint64_t* dRows,
                  int64_t numRows, int32_t* dOut, DevBuf& scratch, int64_t* total);
-void sortKeysU64(const uint64_t* in, uint64_t* out, size_t n, DevBuf& tmp);
+void sortKeysU64(const uint64_t* in, uint64_t* out, size_t n, DevBuf& tmp, int beginBit = 0, int endBit = 64);  // radix_sort.hip
 void makeTermArgs(const DeviceBatch& db, const vx355_filter_term* terms, int32_t n, TermArg* out);  // exprs.hip
 
 namespace {
@@ -3296,8 +3296,10 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
         uint64_t numPairs = 0;
         copyOut(&numPairs, VX355_MEM_HOST, a.sparseStats + 3, 8);
         if (numPairs > 0) {
+          // {probe row : 32 | build row : 32}, at most one hit per probe row: the probe-row bits decide
+          const int rowBits = std::max(1, 64 - __builtin_clzll(static_cast<unsigned long long>(std::max<int64_t>(1, n))));
           sortKeysU64(pp.pairs, static_cast<uint64_t*>(p.ppSorted.ensure(static_cast<size_t>(numPairs) * 8 + 64)),
-                      static_cast<size_t>(numPairs), p.ppSortTmp);
+                      static_cast<size_t>(numPairs), p.ppSortTmp, 32, 32 + rowBits);
         }
         rt.sync();
         p.totalOut = numPairs;
@@ -3329,7 +3331,10 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
       uint64_t* wordsIn = static_cast<uint64_t*>(p.hitWords.ensure(static_cast<size_t>(numHits) * 8 + 64));
       uint64_t* sorted = static_cast<uint64_t*>(p.hitSorted.ensure(static_cast<size_t>(numHits) * 8 + 64));
       VX_LAUNCH("k_hit_words", k_hit_words, streamGrid(numHits, 256), 256, 0, a.hits, rows, numHits, wordsIn);
-      sortKeysU64(wordsIn, sorted, static_cast<size_t>(numHits), p.sortTmp);
+      // {head build row : 32 | probe row : 32}; the words arrive in ascending probe-row order (compactBits),
+      // so a STABLE sort on the build-row bits alone gives (build row, probe row) order
+      const int headBits = std::max(1, 64 - __builtin_clzll(static_cast<unsigned long long>(std::max<int64_t>(1, t.numRows))));
+      sortKeysU64(wordsIn, sorted, static_cast<size_t>(numHits), p.sortTmp, 32, 32 + headBits);
       VX_LAUNCH("k_count_consume", k_count_consume, streamGrid(numHits, 256), 256, 0, sorted, numHits,
                 t.remaining.as<uint32_t>(), a.hits);
       VX_LAUNCH("k_count_settle", k_count_settle, streamGrid(numHits, 256), 256, 0, sorted, numHits,
