@@ -733,15 +733,30 @@ struct RowFilter {
   int32_t invert;
   int32_t pad;
 };
-__device__ inline int64_t fastFilterLoad(const RowFilter& f, int64_t row) {
-  return f.fast == 4 ? static_cast<int64_t>(__builtin_nontemporal_load(static_cast<const int32_t*>(f.fastValues) + row))
-                     : __builtin_nontemporal_load(static_cast<const int64_t*>(f.fastValues) + row);
+// The raw word of the fast filter's column (W = 4 or 8 bytes). NOT widened here: a conversion right
+// behind the load needs the loaded value and would make every load wait for itself (s_waitcnt vmcnt(0)
+// behind each global_load: the eight rows of an iteration then load one after the other).
+template <int W>
+struct FastWord {
+  using type = int64_t;
+};
+template <>
+struct FastWord<4> {
+  using type = int32_t;
+};
+template <int W>
+__device__ inline typename FastWord<W>::type fastFilterLoad(const RowFilter& f, int64_t row) {
+  return __builtin_nontemporal_load(static_cast<const typename FastWord<W>::type*>(f.fastValues) + row);
 }
 __device__ inline bool fastFilterPass(const RowFilter& f, int64_t v) {
   return ((v >= f.lo) & (v <= f.hi)) != (f.invert != 0);
 }
 __device__ inline bool rowPasses(const RowFilter& f, int64_t row) {
   return evalFilter(f.terms, f.numTerms, row);
+}
+// (32-bit column: lo / hi were clamped to the int32 range by the host, an empty range is lo > hi)
+__device__ inline bool fastFilterPass(const RowFilter& f, int32_t v) {
+  return ((v >= static_cast<int32_t>(f.lo)) & (v <= static_cast<int32_t>(f.hi))) != (f.invert != 0);
 }
 
 struct ProbeArgs {
@@ -977,7 +992,9 @@ struct SparseLds {
 #define VX355_KEY_LOAD(p) __builtin_nontemporal_load(p)
 #endif
 
-template <int MODE, int FAST, bool SPARSE, int WIDE = 0, bool RF = false>
+// RF: 0 = no fast input filter (a.rf.terms, if any, through evalFilter); 4 / 8 = byte width of the fast
+// filter's column (RowFilter::fast)
+template <int MODE, int FAST, bool SPARSE, int WIDE = 0, int RF = 0>
 __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, SparseLds* lds) {
   const int mode = MODE >= 0 ? MODE : a.mode;
   const int fastKey = FAST >= 0 ? FAST : a.fastKey;
@@ -996,7 +1013,7 @@ __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, Spars
   // bitmap gathers of iteration it, so the HBM latency of the keys overlaps the cache
   // latency of the dependent gathers instead of adding to it.
   int64_t vnext[kU];
-  int64_t fnext[RF ? kU : 1];  // RF: the fused filter's column, prefetched like the keys
+  typename FastWord<RF>::type fnext[RF ? kU : 1];  // RF: the fused filter's column, prefetched like the keys
   if (FAST == 1) {
     const int64_t* kp = static_cast<const int64_t*>(a.keys[0].values);
 #pragma unroll
@@ -1004,7 +1021,7 @@ __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, Spars
       const int64_t r = rowOf(0, u);
       vnext[u] = VX355_KEY_LOAD(kp + (r < a.numRows ? r : a.numRows - 1));
       if constexpr (RF) {
-        fnext[u] = fastFilterLoad(a.rf, r < a.numRows ? r : a.numRows - 1);
+        fnext[u] = fastFilterLoad<RF>(a.rf, r < a.numRows ? r : a.numRows - 1);
       }
     }
   }
@@ -1071,7 +1088,7 @@ __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, Spars
           const int64_t r = rowOf(it + 1, u);
           vnext[u] = VX355_KEY_LOAD(kp + (r < a.numRows ? r : a.numRows - 1));
           if constexpr (RF) {
-            fnext[u] = fastFilterLoad(a.rf, r < a.numRows ? r : a.numRows - 1);
+            fnext[u] = fastFilterLoad<RF>(a.rf, r < a.numRows ? r : a.numRows - 1);
           }
         }
       }
@@ -1225,7 +1242,7 @@ __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, Spars
   return mine;
 }
 
-template <int MODE, int FAST, bool SPARSE, int WIDE = 0, bool RF = false>
+template <int MODE, int FAST, bool SPARSE, int WIDE = 0, int RF = 0>
 __global__ __launch_bounds__(256) void k_join_probe(ProbeArgs args) {
   __shared__ uint64_t waveSums[4];
   __shared__ __attribute__((aligned(16))) unsigned char sparseRaw[SPARSE ? sizeof(SparseLds) : 16];
@@ -1309,7 +1326,10 @@ __device__ inline bool ppRowPasses(const RowFilter& f, int64_t row) {
   if (f.numTerms == 0) {
     return true;
   }
-  return f.fast ? fastFilterPass(f, fastFilterLoad(f, row)) : rowPasses(f, row);
+  if (f.fast == 4) {
+    return fastFilterPass(f, fastFilterLoad<4>(f, row));
+  }
+  return f.fast ? fastFilterPass(f, fastFilterLoad<8>(f, row)) : rowPasses(f, row);
 }
 
 struct PartArgs {
@@ -3094,6 +3114,16 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
       }
       a.rf.fast = t0.col.kind == VX355_INTEGER ? 4 : 8;
       a.rf.fastValues = t0.col.values;
+      if (a.rf.fast == 4) {
+        // the kernel compares 32-bit words: the range clamped to int32 (empty stays empty)
+        if (lo > INT32_MAX || hi < INT32_MIN) {
+          lo = 1;
+          hi = 0;
+        } else {
+          lo = std::max<int64_t>(lo, INT32_MIN);
+          hi = std::min<int64_t>(hi, INT32_MAX);
+        }
+      }
       a.rf.lo = lo;
       a.rf.hi = hi;
       a.rf.invert = t0.cmp == VX355_CMP_NE ? 1 : 0;
@@ -3162,10 +3192,14 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
     }
     // profile names: "k_join_probe" writes hits[] for k_emit, "k_join_probe_list" also lists the hits
     const char* name = SP ? "k_join_probe_list" : "k_join_probe";
-    if (t.mode == JMODE_ARRAY && a.fastKey == 1 && la.rf.fast) {
-      VX_LAUNCH(name, (k_join_probe<JMODE_ARRAY, 1, SP, 0, true>), grid, 256, 0, la);
-    } else if (t.mode == JMODE_NORMALIZED && a.fastKey == 1 && la.rf.fast && la.wide == nullptr) {
-      VX_LAUNCH(name, (k_join_probe<JMODE_NORMALIZED, 1, SP, 0, true>), grid, 256, 0, la);
+    if (t.mode == JMODE_ARRAY && a.fastKey == 1 && la.rf.fast == 4) {
+      VX_LAUNCH(name, (k_join_probe<JMODE_ARRAY, 1, SP, 0, 4>), grid, 256, 0, la);
+    } else if (t.mode == JMODE_ARRAY && a.fastKey == 1 && la.rf.fast == 8) {
+      VX_LAUNCH(name, (k_join_probe<JMODE_ARRAY, 1, SP, 0, 8>), grid, 256, 0, la);
+    } else if (t.mode == JMODE_NORMALIZED && a.fastKey == 1 && la.rf.fast == 4 && la.wide == nullptr) {
+      VX_LAUNCH(name, (k_join_probe<JMODE_NORMALIZED, 1, SP, 0, 4>), grid, 256, 0, la);
+    } else if (t.mode == JMODE_NORMALIZED && a.fastKey == 1 && la.rf.fast == 8 && la.wide == nullptr) {
+      VX_LAUNCH(name, (k_join_probe<JMODE_NORMALIZED, 1, SP, 0, 8>), grid, 256, 0, la);
     } else if (t.mode == JMODE_ARRAY && a.fastKey == 1) {
       VX_LAUNCH(name, (k_join_probe<JMODE_ARRAY, 1, SP>), grid, 256, 0, la);
     } else if (t.mode == JMODE_ARRAY && a.fastKey == 2) {
@@ -3224,10 +3258,13 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
       uint64_t stats[4] = {0, 0, 0, 0};
       copyOut(stats, VX355_MEM_HOST, a.sparseStats, 32);  // synchronises the stream
       const uint64_t overflowed = stats[0];
-      // dense when more than 1 tile in 16 overflowed or the average tile is half full
+      // dense when more than 1 tile in 16 overflowed or the average tile is 7/8 full. (Until round 5: half
+      // full. TPC-H Q3's orders probe with its date filter fused in hits on 9.7 % of its rows - 800 of the
+      // 1024 staged pairs a tile holds, 200 +- 13 of a wave's 256: no overflows - and listing them in the
+      // probe pass costs 117 MB of pairs instead of 600 MB of hits[] written and read again by k_emit.)
       const bool stay = p.sparseMode == 1 ||
           (overflowed * 16 <= static_cast<uint64_t>(sample) &&
-           stats[1] <= static_cast<uint64_t>(sample) * (kSparseCap / 2));
+           stats[1] <= static_cast<uint64_t>(sample) * (kSparseCap - kSparseCap / 8));
       // scattered probe keys: more than 16 distinct bitmap lines per wave on average
       const bool scattered = p.partitionMode == 1 || (stats[2] & 0xffffffffULL) > 64ULL * 16;
       if (stay && partEligible && scattered) {
