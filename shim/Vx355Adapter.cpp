@@ -483,6 +483,15 @@ bool toFusedInput(const core::FilterNode* filter, const core::ProjectNode* proje
   return true;
 }
 
+bool toFilterTerms(const core::FilterNode& filter, std::vector<vx355_filter_term>* out) {
+  const auto& scanType = filter.sources()[0]->outputType();
+  const ColumnLayout layout(scanType);
+  if (layout.numColumns != static_cast<int32_t>(scanType->size())) {
+    return false;  // a struct channel would renumber the columns the join's plan refers to
+  }
+  return addFilterTerms(filter.filter(), scanType, layout, out) && out->size() <= 4;
+}
+
 bool toAggSpec(const core::AggregationNode& node, const std::vector<InputBinding>& bindings, const ColumnLayout& layout,
                AggSpec* out) {
   const auto& inputType = node.sources()[0]->outputType();

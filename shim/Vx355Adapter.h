@@ -119,6 +119,10 @@ struct FusedInput {
 /// 'filter' and 'project' may each be null (not both).
 bool toFusedInput(const core::FilterNode* filter, const core::ProjectNode* project, FusedInput* out);
 
+/// The filter of a FilterNode alone as vx355_filter_terms over the columns of its input (scalar channels:
+/// column = channel): what vx355_join_probe_set_input_filter takes (Vx355JoinAdapter.cpp).
+bool toFilterTerms(const core::FilterNode& filter, std::vector<vx355_filter_term>* out);
+
 /// vx355_agg_spec of an AggregationNode: keys, aggregates, step, ignoreNullKeys
 /// (core/PlanNode.h:1120-1370). Returns false when the plan is outside what the library takes - the
 /// CPU operator then stays in place, like cuDF's adapter does (ToCudf.cpp:230-242).

@@ -4,6 +4,7 @@
 #include <algorithm>
 
 #include "velox/core/QueryConfig.h"
+#include "velox/exec/FilterProject.h"
 #include "velox/exec/HashBuild.h"
 #include "velox/exec/HashProbe.h"
 #include "velox/exec/OperatorUtils.h"
@@ -191,6 +192,24 @@ bool toJoinPlan(const core::HashJoinNode& node, JoinPlan* out) {
   return true;
 }
 
+bool fusesInputFilter(const JoinPlan& plan) {
+  if (plan.nullAware) {
+    return false;
+  }
+  switch (plan.type) {
+    case VX355_JOIN_INNER:
+    case VX355_JOIN_RIGHT:
+    case VX355_JOIN_LEFT_SEMI_FILTER:
+    case VX355_JOIN_COUNTING_LEFT_SEMI_FILTER:
+    case VX355_JOIN_RIGHT_SEMI_FILTER:
+    case VX355_JOIN_RIGHT_SEMI_PROJECT:
+    case VX355_JOIN_RIGHT_ANTI:
+      return true;
+    default:
+      return false;  // LEFT / FULL / LEFT_SEMI_PROJECT / ANTI emit probe rows that found nothing
+  }
+}
+
 // ---- build -------------------------------------------------------------------------------------
 
 Vx355HashBuild::Vx355HashBuild(
@@ -301,6 +320,11 @@ exec::BlockingReason Vx355HashProbe::isBlocked(ContinueFuture* future) {
   spec.null_aware = plan_.nullAware ? 1 : 0;
   spec.null_as_value = plan_.nullAsValue ? 1 : 0;
   check(vx355_join_probe_create(table_, &spec, &handle_));  // takes its own reference on the table
+  if (!plan_.inputFilter.empty()) {
+    // the FilterProject that stood in front of this operator (adaptJoins checked kind and terms)
+    check(vx355_join_probe_set_input_filter(
+        handle_, plan_.inputFilter.data(), static_cast<int32_t>(plan_.inputFilter.size())));
+  }
   check(vx355_join_probe_set_output_batch_bytes(
       handle_, static_cast<int64_t>(operatorCtx_->driverCtx()->queryConfig().preferredOutputBatchBytes())));
   return exec::BlockingReason::kNotBlocked;
@@ -479,6 +503,26 @@ bool adaptJoins(const exec::DriverFactory& factory, exec::Driver& driver) {
     if (!take) {
       continue;
     }
+    // FilterProject -> HashProbe fusion: the operator in front is the FilterProject of a FilterNode alone
+    // (no projections: every output column is an input column) that feeds this probe, its conjunction is
+    // in the library's class and the join kind lets a filtered-out row simply find nothing.
+    int32_t begin = i;
+    if (probe != nullptr && i > 0 && fusesInputFilter(plan)) {
+      auto* filterProject = dynamic_cast<exec::FilterProject*>(operators[i - 1]);
+      if (filterProject != nullptr && node->sources()[0]->id() == filterProject->planNodeId()) {
+        std::shared_ptr<const core::FilterNode> filter;
+        for (const auto& planNode : factory.planNodes) {
+          if (planNode->id() == filterProject->planNodeId()) {
+            filter = std::dynamic_pointer_cast<const core::FilterNode>(planNode);
+          }
+        }
+        std::vector<vx355_filter_term> terms;
+        if (filter != nullptr && toFilterTerms(*filter, &terms)) {
+          plan.inputFilter = std::move(terms);
+          begin = i - 1;
+        }
+      }
+    }
     std::vector<std::unique_ptr<exec::Operator>> replacement;
     if (build != nullptr) {
       const auto spec = buildSpecOf(plan);
@@ -488,10 +532,12 @@ bool adaptJoins(const exec::DriverFactory& factory, exec::Driver& driver) {
           std::make_unique<Vx355HashBuild>(build->operatorId(), driver.driverCtx(), node, plan, handle));
     } else {
       replacement.push_back(
-          std::make_unique<Vx355HashProbe>(probe->operatorId(), driver.driverCtx(), node, std::move(plan)));
+          std::make_unique<Vx355HashProbe>(operators[begin]->operatorId(), driver.driverCtx(), node, std::move(plan)));
     }
-    factory.replaceOperators(driver, i, i + 1, std::move(replacement));
+    factory.replaceOperators(driver, begin, i + 1, std::move(replacement));
     replaced = true;
+    operators = driver.operators();
+    i = begin;
   }
   return replaced;
 }

@@ -64,7 +64,13 @@ struct JoinPlan {
   int32_t matchOutput{-1};  // semi project joins: the BOOLEAN 'match' column
   vx355_join_type type{VX355_JOIN_INNER};
   bool nullAware{false}, nullAsValue{false}, dropDuplicates{false};
+  // FilterProject -> HashProbe fusion: the terms of the FilterNode in front of the probe (empty: none)
+  std::vector<vx355_filter_term> inputFilter;
 };
+
+/// Join kinds whose unmatched probe rows emit nothing: the only ones a filter in front of the probe can
+/// be folded into (vx355_join_probe_set_input_filter).
+bool fusesInputFilter(const JoinPlan& plan);
 
 /// false: a join the library does not take (extra filter outside INTEGRATION.md's class, key or
 /// payload types beyond the scalar kinds): the CPU operators stay.

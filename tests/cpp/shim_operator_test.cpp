@@ -262,15 +262,26 @@ int testQ1(bool fusedVariant, uint64_t maxPartialMemory, int* flushes) {
   return checkQ1(finals, data);
 }
 
-int testJoin() {
-  // orders (build): o_orderkey, o_orderdate, o_shippriority; lineitem (probe): l_orderkey, l_extendedprice
-  auto probeNode = std::make_shared<core::ValuesNode>("l", ROW({"l_orderkey", "l_extendedprice"}, {BIGINT(), DOUBLE()}));
+int testJoin(bool withFilter) {
+  // orders (build): o_orderkey, o_orderdate, o_shippriority; lineitem (probe): l_orderkey, l_extendedprice, l_shipdate.
+  // withFilter: TPC-H Q3's shape - FilterProject(l_shipdate > DATE) in front of the probe (a FilterNode alone), which
+  // the adapter folds into the probe operator (vx355_join_probe_set_input_filter).
+  constexpr int32_t kDate = 9204;
+  auto probeNode = std::make_shared<core::ValuesNode>("l", ROW({"l_orderkey", "l_extendedprice", "l_shipdate"}, {BIGINT(), DOUBLE(), DATE()}));
+  std::shared_ptr<const core::FilterNode> filterNode;
+  core::PlanNodePtr probeSource = probeNode;
+  if (withFilter) {
+    filterNode = std::make_shared<core::FilterNode>(
+        "lf", shimtest::call("gt", BOOLEAN(), {shimtest::field(probeNode->outputType(), "l_shipdate"),
+                                               shimtest::constant(DATE(), Variant(kDate))}), probeNode);
+    probeSource = filterNode;
+  }
   auto buildNode = std::make_shared<core::ValuesNode>("o", ROW({"o_orderkey", "o_orderdate", "o_shippriority"}, {BIGINT(), DATE(), INTEGER()}));
   auto outputType = ROW({"l_extendedprice", "o_orderdate", "o_shippriority", "l_orderkey"}, {DOUBLE(), DATE(), INTEGER(), BIGINT()});
   auto join = std::make_shared<core::HashJoinNode>(
       "join", core::JoinType::kInner, false, false,
       std::vector<core::FieldAccessTypedExprPtr>{shimtest::field(probeNode->outputType(), "l_orderkey")},
-      std::vector<core::FieldAccessTypedExprPtr>{shimtest::field(buildNode->outputType(), "o_orderkey")}, nullptr, probeNode, buildNode,
+      std::vector<core::FieldAccessTypedExprPtr>{shimtest::field(buildNode->outputType(), "o_orderkey")}, nullptr, probeSource, buildNode,
       outputType);
   std::mt19937_64 rng(7);
   const int64_t numOrders = 50000, numLineitems = 300000;
@@ -294,13 +305,16 @@ int testJoin() {
     auto batch = std::static_pointer_cast<RowVector>(BaseVector::create(probeNode->outputType(), 10000, &gPool));
     for (vector_size_t i = 0; i < 10000; ++i) {
       const int64_t key = static_cast<int64_t>(rng() % (numOrders * 4 + 8));
+      const auto ship = static_cast<int32_t>(9000 + rng() % 400);
       batch->childAt(0)->asFlatVector<int64_t>()->set(i, key);
-      batch->childAt(1)->asFlatVector<double>()->set(i, static_cast<double>(begin + i));
-      expectedRows += orders.count(key);
+      // the price encodes the ship date, so that the output can be checked against the filter
+      batch->childAt(1)->asFlatVector<double>()->set(i, static_cast<double>(ship));
+      batch->childAt(2)->asFlatVector<int32_t>()->set(i, ship);
+      expectedRows += (!withFilter || ship > kDate) ? orders.count(key) : 0;
     }
     probeBatches.push_back(batch);
   }
-  auto task = std::make_shared<exec::Task>("join_task");
+  auto task = std::make_shared<exec::Task>(withFilter ? "join_task_filter" : "join_task");
   task->mutableQueryConfig().preferredBatchRows = 4096;
   // build pipeline ends in the join node (its consumer)
   auto db = newDriver(task, 1);
@@ -310,11 +324,19 @@ int testJoin() {
   db->mutableOperators().push_back(std::make_unique<exec::HashBuild>(0, db->driverCtx(), join));
   auto dp = newDriver(task, 0);
   exec::DriverFactory fp;
-  fp.planNodes = {probeNode, join};
-  dp->mutableOperators().push_back(std::make_unique<exec::HashProbe>(0, dp->driverCtx(), join));
+  if (withFilter) {
+    fp.planNodes = {probeNode, filterNode, join};
+    dp->mutableOperators().push_back(std::make_unique<exec::FilterProject>(0, dp->driverCtx(), filterNode, nullptr));
+    dp->mutableOperators().push_back(std::make_unique<exec::HashProbe>(1, dp->driverCtx(), join));
+  } else {
+    fp.planNodes = {probeNode, join};
+    dp->mutableOperators().push_back(std::make_unique<exec::HashProbe>(0, dp->driverCtx(), join));
+  }
   // (Velox creates the Drivers of every pipeline before any of them runs)
   EXPECT(adaptDriver(fp, *dp));
   EXPECT(adaptDriver(fb, *db));
+  // (with the filter: FilterProject and HashProbe became ONE operator)
+  EXPECT(dp->operators().size() == 1 && dp->operators()[0]->operatorId() == 0);
   EXPECT(dp->operators()[0]->operatorType() == "Vx355HashProbe" && db->operators()[0]->operatorType() == "Vx355HashBuild");
   // the probe is blocked until the table is published
   ContinueFuture waitForBuild = ContinueFuture::makeEmpty();
@@ -334,7 +356,7 @@ int testJoin() {
       EXPECT(orders.count(k) == 1);
       EXPECT(page->childAt(1)->asFlatVector<int32_t>()->valueAt(r) == orders[k].first);
       EXPECT(page->childAt(2)->asFlatVector<int32_t>()->valueAt(r) == orders[k].second);
-      EXPECT(price.data<double>()[price.index(r)] >= 0);
+      EXPECT(!withFilter || price.data<double>()[price.index(r)] > kDate);   // only rows that pass the fused filter
     }
     rows += page->size();
   }
@@ -364,10 +386,14 @@ int main() {
     }
     EXPECT(flushes >= 2);
     std::printf("ok: Q1 plan with partial flushes (%d partial pages)\n", flushes);
-    if (testJoin() != 0) {
+    if (testJoin(false) != 0) {
       return 1;
     }
     std::printf("ok: inner join through Vx355HashBuild / Vx355HashProbe\n");
+    if (testJoin(true) != 0) {
+      return 1;
+    }
+    std::printf("ok: FilterProject(l_shipdate > d) folded into Vx355HashProbe\n");
   } catch (const std::exception& e) {
     std::fprintf(stderr, "FAILED: %s\n", e.what());
     return 1;

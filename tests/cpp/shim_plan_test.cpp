@@ -308,6 +308,24 @@ int testJoinPlan() {
   JoinPlan semiPlan;
   EXPECT(toJoinPlan(*semi, &semiPlan));
   EXPECT(semiPlan.type == VX355_JOIN_LEFT_SEMI_FILTER && semiPlan.dropDuplicates && semiPlan.dependentChannels.empty());
+  // FilterProject -> HashProbe fusion: which kinds, which filters (TPC-H Q3: l_shipdate > DATE '1995-03-15')
+  EXPECT(fusesInputFilter(plan) && fusesInputFilter(semiPlan));
+  JoinPlan leftPlan = plan;
+  leftPlan.type = VX355_JOIN_LEFT;
+  EXPECT(!fusesInputFilter(leftPlan));
+  leftPlan.type = VX355_JOIN_ANTI;
+  EXPECT(!fusesInputFilter(leftPlan));
+  auto lineitem = std::make_shared<core::ValuesNode>("li", ROW({"l_orderkey", "l_shipdate", "l_extendedprice"}, {BIGINT(), DATE(), DOUBLE()}));
+  auto shipFilter = std::make_shared<core::FilterNode>(
+      "f", shimtest::call("gt", BOOLEAN(), {shimtest::field(lineitem->outputType(), "l_shipdate"),
+                                            shimtest::constant(DATE(), Variant(static_cast<int32_t>(9204)))}), lineitem);
+  std::vector<vx355_filter_term> terms;
+  EXPECT(toFilterTerms(*shipFilter, &terms));
+  EXPECT(terms.size() == 1 && terms[0].col == 1 && terms[0].cmp == VX355_CMP_GT && terms[0].const_kind == VX355_BIGINT && terms[0].i64 == 9204);
+  auto orFilter = std::make_shared<core::FilterNode>(
+      "f2", shimtest::call("or", BOOLEAN(), {shipFilter->filter(), shipFilter->filter()}), lineitem);
+  std::vector<vx355_filter_term> none;
+  EXPECT(!toFilterTerms(*orFilter, &none));   // a disjunction is not in the class: the FilterProject stays
   return 0;
 }
 

@@ -1099,7 +1099,7 @@ def test_build_side_drops_duplicate_keys_for_semi_and_anti_joins(oracle, vx, joi
 @pytest.mark.parametrize("join_type", [abi.JOIN_INNER, abi.JOIN_LEFT_SEMI_FILTER, abi.JOIN_RIGHT])
 @pytest.mark.parametrize("shape", ["array_listing", "array_dense_hits", "array_partitioned", "normalized", "hash",
                                    "dictionary_key", "two_keys_nullable_filter_column", "array_bigint_column_ne",
-                                   "array_partitioned_le"])
+                                   "array_partitioned_le", "normalized_wide_slots_requested"])
 def test_input_filter_fused_into_the_probe(oracle, vx, shape, join_type, monkeypatch):
     """FilterProject -> HashProbe fusion (vx355_join_probe_set_input_filter): probing the UNFILTERED
     batch with the filter inside the probe kernels equals filtering first (numpy here, FilterProject
@@ -1113,9 +1113,12 @@ def test_input_filter_fused_into_the_probe(oracle, vx, shape, join_type, monkeyp
     space = 4_000_000
     if shape.startswith("array_partitioned"):
         monkeypatch.setenv("VX355_JOIN_PARTITION", "1")
-    if shape == "normalized":
+    if shape.startswith("normalized"):
         monkeypatch.setenv("VX355_JOIN_ARRAY_MAX", "0")
         space = 1 << 40
+    if shape == "normalized_wide_slots_requested":
+        # the inline-dependent ("wide") probe instantiations carry no input filter: with one they must not be chosen
+        monkeypatch.setenv("VX355_JOIN_WIDE", "1")
     bk = np.unique(rng.integers(0, space, nb + nb // 4)).astype(np.int64)
     bk = rng.permutation(bk)[:nb]
     pay = rng.integers(0, 1 << 30, nb).astype(np.int64)

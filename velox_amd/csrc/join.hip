@@ -992,8 +992,9 @@ struct SparseLds {
 #define VX355_KEY_LOAD(p) __builtin_nontemporal_load(p)
 #endif
 
-// RF: 0 = no fast input filter (a.rf.terms, if any, through evalFilter); 4 / 8 = byte width of the fast
-// filter's column (RowFilter::fast)
+// RF: 0 = no input filter at all (the instantiations every plain probe runs: not an instruction of the
+// fusion in them); 4 / 8 = byte width of the fast filter's column (RowFilter::fast); -1 = a.rf.terms through
+// evalFilter (any other filter shape: only the all-purpose instantiation <-1, -1> is built with it)
 template <int MODE, int FAST, bool SPARSE, int WIDE = 0, int RF = 0>
 __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, SparseLds* lds) {
   const int mode = MODE >= 0 ? MODE : a.mode;
@@ -1013,14 +1014,14 @@ __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, Spars
   // bitmap gathers of iteration it, so the HBM latency of the keys overlaps the cache
   // latency of the dependent gathers instead of adding to it.
   int64_t vnext[kU];
-  typename FastWord<RF>::type fnext[RF ? kU : 1];  // RF: the fused filter's column, prefetched like the keys
+  typename FastWord<RF>::type fnext[RF > 0 ? kU : 1];  // RF > 0: the fused filter's column, prefetched like the keys
   if (FAST == 1) {
     const int64_t* kp = static_cast<const int64_t*>(a.keys[0].values);
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       const int64_t r = rowOf(0, u);
       vnext[u] = VX355_KEY_LOAD(kp + (r < a.numRows ? r : a.numRows - 1));
-      if constexpr (RF) {
+      if constexpr (RF > 0) {
         fnext[u] = fastFilterLoad<RF>(a.rf, r < a.numRows ? r : a.numRows - 1);
       }
     }
@@ -1045,12 +1046,12 @@ __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, Spars
       }
       // the window of presence words hangs on the wave's first key whether or not its row passes
       const bool firstInRange = candidate[0];
-      if constexpr (RF) {
+      if constexpr (RF > 0) {
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
           candidate[u] = candidate[u] && fastFilterPass(a.rf, fnext[u]);
         }
-      } else if (a.rf.numTerms) {  // uniform
+      } else if constexpr (RF < 0) {
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
           candidate[u] = candidate[u] && rowPasses(a.rf, rows[u]);
@@ -1087,7 +1088,7 @@ __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, Spars
         for (int u = 0; u < kU; ++u) {
           const int64_t r = rowOf(it + 1, u);
           vnext[u] = VX355_KEY_LOAD(kp + (r < a.numRows ? r : a.numRows - 1));
-          if constexpr (RF) {
+          if constexpr (RF > 0) {
             fnext[u] = fastFilterLoad<RF>(a.rf, r < a.numRows ? r : a.numRows - 1);
           }
         }
@@ -1142,10 +1143,12 @@ __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, Spars
         candidate[u] = rows[u] < a.numRows && probeKey(a, rows[u], &key[u]);
       }
     }
-    if (FAST != 1 && mode != JMODE_HASH && a.rf.numTerms) {
+    if constexpr (RF < 0) {
+      if (FAST != 1 && mode != JMODE_HASH) {
 #pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        candidate[u] = candidate[u] && rowPasses(a.rf, rows[u]);
+        for (int u = 0; u < kU; ++u) {
+          candidate[u] = candidate[u] && rowPasses(a.rf, rows[u]);
+        }
       }
     }
     if (FAST == 1) {
@@ -1153,8 +1156,11 @@ __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, Spars
     } else if (mode == JMODE_HASH) {
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
-        hit[u] = (rows[u] < a.numRows && (a.rf.numTerms == 0 || rowPasses(a.rf, rows[u]))) ? lookupGeneric(a, rows[u])
-                                                                                                   : kNoRow32;
+        bool live = rows[u] < a.numRows;
+        if constexpr (RF < 0) {
+          live = live && rowPasses(a.rf, rows[u]);
+        }
+        hit[u] = live ? lookupGeneric(a, rows[u]) : kNoRow32;
       }
     } else if (mode == JMODE_ARRAY) {
       uint32_t word[kU];
@@ -3170,7 +3176,8 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
   a.presentWords = (t.capacity + 31) / 32;
   // inline dependents: inner joins whose output is one row per hit (no filter, no counting)
   p.wideStaged = 0;
-  if (a.fastKey == 1 && p.joinType == VX355_JOIN_INNER && !filtered && !counting && !a.nullAware) {
+  // (not with a fused input filter: the WIDE instantiations are built without it)
+  if (a.fastKey == 1 && p.joinType == VX355_JOIN_INNER && !filtered && !counting && !a.nullAware && p.inputFilter.empty()) {
     p.wideStaged = ensureWide(t, p.wideMode, n);
     if (p.wideStaged > 0) {
       a.wide = t.wide.as<WideSlot>();
@@ -3192,7 +3199,11 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
     }
     // profile names: "k_join_probe" writes hits[] for k_emit, "k_join_probe_list" also lists the hits
     const char* name = SP ? "k_join_probe_list" : "k_join_probe";
-    if (t.mode == JMODE_ARRAY && a.fastKey == 1 && la.rf.fast == 4) {
+    if (la.rf.numTerms > 0 && !(a.fastKey == 1 && la.rf.fast && la.wide == nullptr && t.mode != JMODE_HASH)) {
+      // any other filter shape (several terms, nulls, dictionaries, strings, doubles) or key shape: the
+      // all-purpose probe with the generic evaluator
+      VX_LAUNCH(name, (k_join_probe<-1, -1, SP, 0, -1>), grid, 256, 0, la);
+    } else if (t.mode == JMODE_ARRAY && a.fastKey == 1 && la.rf.fast == 4) {
       VX_LAUNCH(name, (k_join_probe<JMODE_ARRAY, 1, SP, 0, 4>), grid, 256, 0, la);
     } else if (t.mode == JMODE_ARRAY && a.fastKey == 1 && la.rf.fast == 8) {
       VX_LAUNCH(name, (k_join_probe<JMODE_ARRAY, 1, SP, 0, 8>), grid, 256, 0, la);
