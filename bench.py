@@ -602,9 +602,19 @@ class C4(C1):
     PASS_BYTES_SPARSE = {"k_rp_count1": 8, "k_rp_scatter1": 16 + 24, "k_rp_count2": 24, "k_rp_scatter2": 24 + 24,
                          "k_rp_aggregate": 24, "k_agg_global": 40}
 
+    # no group order wanted, dense keys: 12-byte records {32-bit key | mask word, operand} (compact_record_launches)
+    PASS_BYTES_COMPACT = {"k_rp_count1": 8, "k_rp_scatter1": 16 + 12, "k_rp_count2": 12, "k_rp_scatter2": 12 + 12,
+                          "k_rp_aggregate": 12, "k_agg_global": 40}
+    compact = False
+
+    def pass_table(self):
+        if getattr(self, "sparse", False):
+            return self.PASS_BYTES_SPARSE
+        return self.PASS_BYTES_COMPACT if self.compact else self.PASS_BYTES
+
     def pick_dominant(self, prof):
         """The slowest pass is the roofline kernel of this workload."""
-        table = self.PASS_BYTES_SPARSE if getattr(self, "sparse", False) else self.PASS_BYTES
+        table = self.pass_table()
         name = max(table, key=lambda k: prof.get(k, (0.0, 0))[0])
         self.dominant = name
         self.agg_bytes_per_row = table[name]
@@ -659,6 +669,7 @@ class C4(C1):
             if fin.value:
                 break
         self.groups = total
+        self.compact = op.stats().compact_record_launches > 0
         return total
 
     def cpu_reference(self, sample, oracle):
@@ -1866,7 +1877,8 @@ def secondary_block(torch, device, args, copy_ceiling, measure, workload, attrs,
                                 "GBps_at_24B_per_probe": wl.rows_per_step() * 24 / (ms * 1e-3) / 1e9}
     if workload == "c4":
         # every pass of the radix path next to the bytes it has to move (the step's roofline kernel is the slowest)
-        table = wl.PASS_BYTES_SPARSE if getattr(wl, "sparse", False) else wl.PASS_BYTES
+        table = wl.pass_table()
+        block["record_bytes"] = 24 if getattr(wl, "sparse", False) else (12 if wl.compact else 16)
         block["passes"] = {k: {"ms_per_step": round(prof[k][0] / steps, 4), "algorithmic_bytes_per_row": table[k],
                                "algorithmic_GBps": table[k] * wl.rows_per_step() * steps / (prof[k][0] * 1e-3) / 1e9}
                            for k in table if prof.get(k, (0, 0))[0] > 0}

@@ -1734,3 +1734,54 @@ def test_first_seen_order_through_the_librarys_own_pair_sort(vx, groups):
     assert len(got_keys) == groups
     assert (got_keys == keys).all()
     assert (got_counts == 2).all()
+
+
+@pytest.mark.parametrize("shape", ["uniform", "two_batches", "bunched_keys_overflow_a_region", "int32_key",
+                                   "compact_off"])
+def test_compact_records_when_no_group_order_is_wanted(oracle, vx, shape, monkeypatch):
+    """VX355_AGG_UNORDERED_OUTPUT + one operand + a direct-index table: the radix passes move 12-byte records
+    (32-bit {key | mask} word + operand, two streams) instead of 16-byte ones - no row number travels
+    (recLoad in agg.hip). Results per group equal the oracle's (compared as multisets); a second batch meets
+    the groups of the first; keys bunched into one level-1 bin overflow its optimistic region, which restarts
+    the chunk with 16-byte records (radix_redone is not what counts here: the result is); an INTEGER key; and
+    VX355_AGG_COMPACT_RECORDS=0 as the control."""
+    monkeypatch.setenv("VX355_AGG_RADIX_MIN_ROWS", "1")
+    monkeypatch.setenv("VX355_AGG_COALESCE_ROWS", "0")
+    if shape == "compact_off":
+        monkeypatch.setenv("VX355_AGG_COMPACT_RECORDS", "0")
+    rng = np.random.default_rng(515)
+    # the padded range is 2 x space = 4883 partitions of 2048 groups: two levels (> 4096), and rows >= 1024 per
+    # partition, the radix path's own rule
+    n, space = 8_000_000, 5_000_000
+    batches = []
+    for b in range(2 if shape == "two_batches" else 1):
+        k = rng.integers(0, space, n).astype(np.int64)
+        if shape == "bunched_keys_overflow_a_region":
+            k[: n * 6 // 10] = rng.integers(1_000_000, 1_100_000, n * 6 // 10)  # one level-1 bin holds 131072 keys
+            k = rng.permutation(k)
+        if shape == "int32_key":
+            k = k.astype(np.int32)
+        batches.append(batch_of([k, _dyadic(rng, n)]))
+    kind = abi.INTEGER if shape == "int32_key" else abi.BIGINT
+    aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    exp, _ = run_agg(oracle, batches, [0], [kind], aggs, max_rows=1 << 22)
+    vx.profile_reset()
+    vx.profile_enable(True)
+    op = vx.Aggregation([0], [kind], aggs, abi.STEP_SINGLE, flags=abi.AGG_UNORDERED_OUTPUT)
+    for b in batches:
+        op.add_input(vx.to_device(b))  # (host batches arrive in staging-sized chunks: too few rows per partition)
+    op.no_more_input()
+    got = vx.collect_output(op, 1 << 22)
+    vx.profile_enable(False)
+    prof = vx.profile()
+    assert "k_rp_scatter1" in prof and "k_rp_scatter2" in prof and "k_rp_aggregate" in prof
+    st = op.stats()
+    assert st.hash_mode == abi.MODE_ARRAY and st.radix_launches == len(batches)
+    # (the bunched keys send the chunk back to 16-byte records; so does the second batch's chunk when the
+    # first left the table with groups? no: records do not depend on the table)
+    assert st.compact_record_launches == {"compact_off": 0, "bunched_keys_overflow_a_region": 0}.get(shape, len(batches))
+    go, eo = np.argsort(got[0][0], kind="stable"), np.argsort(exp[0][0], kind="stable")
+    assert len(got[0][0]) == len(exp[0][0]) > 1000
+    for c in range(3):
+        assert (np.asarray(got[c][0])[go] == np.asarray(exp[c][0])[eo]).all(), c
+        assert np.asarray(got[c][1]).all()

@@ -86,7 +86,7 @@ class AggStats(C.Structure):
     _fields_ = [("num_groups", C.c_int64), ("capacity", C.c_int64), ("num_rehashes", C.c_int64),
                 ("hash_mode", C.c_int32), ("reserved", C.c_int32), ("input_rows", C.c_int64),
                 ("deferred_rows", C.c_int64), ("radix_launches", C.c_int64), ("table_bytes", C.c_int64),
-                ("num_flushes", C.c_int64)]
+                ("num_flushes", C.c_int64), ("compact_record_launches", C.c_int64)]
 
 
 class KeyFilter(C.Structure):

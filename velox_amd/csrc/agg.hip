@@ -759,6 +759,7 @@ struct RadixArgs {
   uint32_t* binCursor;
   uint32_t* binOverflow;
   uint64_t binCap;
+  uint64_t crCap;      // compact records: record capacity of 'recs' (see recLoad); rowBits is 0 then
 };
 static_assert(sizeof(RadixArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
@@ -880,6 +881,45 @@ __device__ inline void rpLoad(const uint64_t* src, uint64_t* w) {
     for (int i = 0; i < W; ++i) {
       w[i] = VX355_RP_LOAD(src + i);
     }
+  }
+}
+
+// Compact records (CR; round 5): when nobody asked for first-seen order, the row number need not travel and
+// word 0 = {key : keyBits | accumulator mask : 3} fits 32 bits - a 12-byte record {word 0, operand lo, operand hi}
+// instead of 16, record i at byte 12 i of the buffer (three dwords, 4-byte aligned: one dwordx3 access per
+// lane, a wave covers 768 consecutive bytes). One operand, direct-index tables, optimistic levels only
+// (launchRadix). In LDS and in registers a record stays two 64-bit words; only the HBM side is narrower:
+// 28 + 24 + 12 instead of 32 + 32 + 16 bytes per row through the three passes. 'cap' (the buffer's record
+// capacity) is only the "compact" flag of the host side.
+struct __attribute__((aligned(4))) Rec12 {
+  uint32_t word0, lo, hi;
+};
+__device__ inline uint32_t crWord0(const uint64_t* base, uint64_t i) {
+  return reinterpret_cast<const Rec12*>(base)[i].word0;
+}
+template <int W, bool CR>
+__device__ inline void recLoad(const uint64_t* base, uint64_t cap, uint64_t i, uint64_t* w) {
+  if constexpr (CR) {
+    static_assert(W == 2, "compact records carry one operand");
+    (void)cap;
+    const Rec12* p = reinterpret_cast<const Rec12*>(base) + i;
+    const uint32_t w0 = VX355_RP_LOAD(&p->word0), lo = VX355_RP_LOAD(&p->lo), hi = VX355_RP_LOAD(&p->hi);
+    w[0] = w0;   // (zero extension: no use of the loaded value, the load stays in flight)
+    w[1] = static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32);
+  } else {
+    rpLoad<W>(base + i * W, w);
+  }
+}
+template <int W, bool CR>
+__device__ inline void recStore(uint64_t* base, uint64_t cap, uint64_t i, const uint64_t* w) {
+  if constexpr (CR) {
+    (void)cap;
+    Rec12* p = reinterpret_cast<Rec12*>(base) + i;
+    p->word0 = static_cast<uint32_t>(w[0]);
+    p->lo = static_cast<uint32_t>(w[1]);
+    p->hi = static_cast<uint32_t>(w[1] >> 32);
+  } else {
+    rpStore<W>(base + i * W, w);
   }
 }
 
@@ -1047,8 +1087,8 @@ __device__ inline void rpSortedPlace(SortLds<W>& l, int numBins, const uint64_t 
 }
 
 // Second half: the sorted sub-tile leaves for its bins; cnt[] is zero again on return.
-template <int W, bool kReserves, typename BinFn>
-__device__ inline void rpSortedWrite(SortLds<W>& l, int numBins, uint64_t* out, BinFn&& binOfWord0) {
+template <int W, bool kReserves, typename BinFn, bool CR = false>
+__device__ inline void rpSortedWrite(SortLds<W>& l, int numBins, uint64_t* out, BinFn&& binOfWord0, uint64_t crCap = 0) {
   const int tid = threadIdx.x;
   uint32_t total = 0;
 #pragma unroll
@@ -1062,7 +1102,7 @@ __device__ inline void rpSortedWrite(SortLds<W>& l, int numBins, uint64_t* out, 
     if (kReserves && l.binBase[b] == ~0ULL) {
       continue;  // the partition's optimistic region is full: the host redoes the level exactly
     }
-    rpStore<W>(out + (l.binBase[b] + (i - l.start[b])) * W, w);
+    recStore<W, CR>(out, crCap, l.binBase[b] + (i - l.start[b]), w);
   }
   blockSync();
   if (tid < numBins) {
@@ -1084,7 +1124,7 @@ __device__ inline void rpSortedEmit(SortLds<W>& l, int numBins, const uint64_t (
 
 // Level 1 with sorted sub-tiles (numBins <= kSortBins); same records as k_rp_scatter1.
 // HASHED: word 0 carries the home slot instead of the key, the last word the full key.
-template <int KW, int W, bool FLATV, bool HASHED, bool OPT = false>
+template <int KW, int W, bool FLATV, bool HASHED, bool OPT = false, bool CR = false>
 __global__ __launch_bounds__(kSortThreads) void k_rp_scatter1_sorted(RadixArgs r) {
   __shared__ SortLds<W> l;
   constexpr int R = SortLds<W>::kRounds;
@@ -1166,7 +1206,8 @@ __global__ __launch_bounds__(kSortThreads) void k_rp_scatter1_sorted(RadixArgs r
           part = twangMix64(key) & r.slotMask;
           vals[u][W - 1] = key;
         }
-        vals[u][0] = part | (static_cast<uint64_t>(row) << r.keyBits) | (mask << (r.keyBits + r.rowBits));
+        // (compact records: no row, rowBits = 0 - the mask sits right behind the key)
+        vals[u][0] = part | (CR ? 0 : (static_cast<uint64_t>(row) << r.keyBits)) | (mask << (r.keyBits + r.rowBits));
         bin[u] = static_cast<uint32_t>(part >> shift);
       }
       const uint64_t keyMask = (1ULL << r.keyBits) - 1;
@@ -1183,8 +1224,8 @@ __global__ __launch_bounds__(kSortThreads) void k_rp_scatter1_sorted(RadixArgs r
         if (next < end) {
           loadSub(next);
         }
-        rpSortedWrite<W, true>(l, r.numBins, r.recs,
-                               [&](uint64_t w0) { return static_cast<uint32_t>((w0 & keyMask) >> shift); });
+        auto binOf = [&](uint64_t w0) { return static_cast<uint32_t>((w0 & keyMask) >> shift); };
+        rpSortedWrite<W, true, decltype(binOf)&, CR>(l, r.numBins, r.recs, binOf, r.crCap);
       } else {
         rpSortedPlace<W, R>(l, r.numBins, vals, bin);
         if (next < end) {
@@ -1441,6 +1482,7 @@ struct Radix2OptArgs {
   const uint32_t* bucketCap;  // region size of every partition of bucket b
   uint32_t* partCount;      // cursors, zero on entry
   uint32_t* overflow;       // set when a region is full
+  uint64_t crCapIn, crCapOut;  // compact records: record capacities of 'in' and 'out'
 };
 
 // partBase / bucketCap from the level-1 bucket sizes (one workgroup; buckets <= kRadixMaxBins).
@@ -1486,7 +1528,7 @@ __global__ __launch_bounds__(1024) void k_rp_layout2(Level1Bins l1, int32_t numB
   }
 }
 
-template <int W>
+template <int W, bool CR = false>
 __global__ __launch_bounds__(kSortThreads) void k_rp_scatter2_opt(Radix2OptArgs r) {
   __shared__ SortLds<W> l;
   constexpr int R = SortLds<W>::kRounds;
@@ -1499,7 +1541,8 @@ __global__ __launch_bounds__(kSortThreads) void k_rp_scatter2_opt(Radix2OptArgs 
   for (uint32_t t = blockIdx.x; t < numTiles; t += gridDim.x) {
     const RadixTile tile = r.tiles[t];
     // every record of a level-2 tile belongs to one level-1 bucket: its partitions are consecutive
-    const uint64_t firstKey = r.in[tile.begin * W] & ((1ULL << r.keyBits) - 1);
+    const uint64_t firstKey = (CR ? static_cast<uint64_t>(crWord0(r.in, tile.begin)) : r.in[tile.begin * W]) &
+        ((1ULL << r.keyBits) - 1);
     const uint64_t bucket = (firstKey >> r.shiftB) >> r.shift2;
     const uint64_t part0 = bucket << r.shift2;
     const uint32_t cap = r.bucketCap[bucket];
@@ -1508,7 +1551,7 @@ __global__ __launch_bounds__(kSortThreads) void k_rp_scatter2_opt(Radix2OptArgs 
 #pragma unroll
       for (int u = 0; u < R; ++u) {
         const uint32_t i = base + u * kSortThreads + threadIdx.x;
-        rpLoad<W>(r.in + (tile.begin + (i < tile.count ? i : tile.count - 1)) * W, w[u]);
+        recLoad<W, CR>(r.in, r.crCapIn, tile.begin + (i < tile.count ? i : tile.count - 1), w[u]);
       }
     };
     for (uint32_t base = 0; base < tile.count; base += SortLds<W>::kSub) {
@@ -1527,8 +1570,8 @@ __global__ __launch_bounds__(kSortThreads) void k_rp_scatter2_opt(Radix2OptArgs 
         }
         return r.partBase[part0 + b] + at;
       });
-      rpSortedWrite<W, true>(l, r.numBins, r.out,
-                             [&](uint64_t w0) { return (static_cast<uint32_t>(w0) >> r.shiftB) & binMask; });
+      auto binOf = [&](uint64_t w0) { return (static_cast<uint32_t>(w0) >> r.shiftB) & binMask; };
+      rpSortedWrite<W, true, decltype(binOf)&, CR>(l, r.numBins, r.out, binOf, r.crCapOut);
     }
   }
 }
@@ -1564,6 +1607,7 @@ struct RadixAggArgs {
   double splitM[kRadixMaxAccs];
   int32_t keyBits;                          // layout of record word 0
   int32_t rowBits;
+  uint64_t crCap;                           // compact records: record capacity of 'recs' (0 = 16-byte records)
   // virgin: the table has never been written (no k_init_table ran): the owner of a partition
   // stores every one of its group rows completely - untouched words from 'pattern' - instead of
   // read-modify-write, and empty partitions are initialised on the way.
@@ -1703,14 +1747,14 @@ __device__ inline void rpFoldRecord(const RpFold& f, const RadixAggArgs& r, cons
 }
 
 // Folds records [begin, end) of one partition into the LDS accumulators.
-template <int W>
+template <int W, bool CR = false>
 __device__ inline void rpFoldRecords(const RpFold& f, const RadixAggArgs& r, uint64_t begin, uint64_t end) {
   for (uint64_t at = begin; at < end; at += kRadixUnroll * 512) {
     uint64_t w[kRadixUnroll][W];
 #pragma unroll
     for (int u = 0; u < kRadixUnroll; ++u) {
       const uint64_t i = at + u * 512 + threadIdx.x;
-      rpLoad<W>(r.recs + (i < end ? i : end - 1) * W, w[u]);  // clamped, unconditional: see k_rp_scatter2
+      recLoad<W, CR>(r.recs, r.crCap, i < end ? i : end - 1, w[u]);  // clamped, unconditional: see k_rp_scatter2
     }
 #pragma unroll
     for (int u = 0; u < kRadixUnroll; ++u) {
@@ -1886,7 +1930,7 @@ __device__ inline void rpPartitionRange(const RadixAggArgs& r, int64_t p, uint64
 // its owner folds the first one, the others are spread over all workgroups
 // in a second phase, and every slice of such a partition is flushed with
 // atomics instead of plain read-modify-write.
-template <int W>
+template <int W, bool CR = false>
 __global__ __launch_bounds__(512) void k_rp_aggregate(RadixAggArgs r) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
   __shared__ uint32_t scratch[2];
@@ -1909,7 +1953,7 @@ __global__ __launch_bounds__(512) void k_rp_aggregate(RadixAggArgs r) {
         continue;
       }
       const bool split = end - begin > r.sliceRecs;
-      rpFoldRecords<W>(f, r, begin, split ? begin + r.sliceRecs : end);
+      rpFoldRecords<W, CR>(f, r, begin, split ? begin + r.sliceRecs : end);
       // the owner of a split partition of a virgin table stores complete rows like any owner: the
       // other slices run in the next launch (phase 1), behind the launch boundary
       rpFoldFlush(f, r, p, !split || r.virgin != 0, true);
@@ -1931,7 +1975,7 @@ __global__ __launch_bounds__(512) void k_rp_aggregate(RadixAggArgs r) {
     const uint64_t slices = (end - begin + r.sliceRecs - 1) / r.sliceRecs;
     for (uint64_t s = 1 + blockIdx.x; s < slices; s += gridDim.x) {
       const uint64_t b = begin + s * r.sliceRecs;
-      rpFoldRecords<W>(f, r, b, b + r.sliceRecs < end ? b + r.sliceRecs : end);
+      rpFoldRecords<W, CR>(f, r, b, b + r.sliceRecs < end ? b + r.sliceRecs : end);
       rpFoldFlush(f, r, p, false, true);
     }
   }
@@ -4060,6 +4104,7 @@ struct vx355_agg {
   DevBuf rpRecs1, rpRecs2, rpHist, rpOffsets, rpTiles, rpMisc, rpScan, rpLayout2, rpLayout1, rpSplit;
   bool radixOptimistic = true;  // VX355_AGG_RADIX_OPTIMISTIC=0: level 2 always counts first
   bool radixOptimistic1 = true;  // VX355_AGG_RADIX_OPTIMISTIC1=0: level 1 always counts first (k_rp_count1)
+  bool compactRecords = true;    // VX355_AGG_COMPACT_RECORDS=0: 16-byte records also when no group order is wanted (see recLoad)
   int64_t radixRedone = 0;      // level-2 passes redone exactly after a region overflowed
   int32_t hashSlotsFixed = 0;   // VX355_AGG_HASH_SLOTS: LDS entries of the hashed folds (0 = from a sample of the keys)
   int32_t lastHashSlots = 0;    // what the last hashed launch used
@@ -4067,6 +4112,7 @@ struct vx355_agg {
   int32_t radixMaxBins = kRadixMaxBins;  // widest single-level fan-out
   int64_t radixTileRows = 0;  // 0 = automatic
   int64_t radixLaunches = 0;
+  int64_t compactLaunches = 0;  // of those, with 12-byte records (launchRadix, 'cr')
   bool radixSorted = true;   // VX355_AGG_RADIX_SORTED=0: scatter passes store record by record
   bool radixSparse = true;   // VX355_AGG_RADIX_SPARSE=0: open-addressing tables stay on k_agg_global
   // Open-addressing mode, operator without groups, a large batch: the radix folds append their
@@ -5547,6 +5593,14 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
     // (the cursors are 32-bit: a region never holds more than that)
     opt1 = r.binCap < (1ULL << 32);
   }
+  // Compact records (recLoad): nobody wants first-seen order, one operand, word 0 fits 32 bits without the
+  // row, and both levels run their optimistic form (an overflow anywhere restarts the chunk with 16-byte records).
+  const bool cr = opt1 && h.compactRecords && h.unorderedOutput && !hashed && r.recWords == 2 && (kw == 8 || kw == 4) &&
+      r.keyBits + kRadixMaskBits <= 32 && h.radixOptimistic && bins2 <= kSortBins;
+  if (cr) {
+    r.rowBits = 0;
+    r.crCap = static_cast<uint64_t>(liveBins) * r.binCap + 64;
+  }
   if (opt1) {
     h.rpRecs1.ensure((static_cast<size_t>(liveBins) * r.binCap + 64) * r.recWords * 8 + 64);
     r.recs = h.rpRecs1.as<uint64_t>();
@@ -5587,6 +5641,16 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
             VX_LAUNCH("k_rp_scatter1", (k_rp_scatter1_sorted<8, W, true, true, true>), grid, kSortThreads, 0, r);
           } else {
             VX_LAUNCH("k_rp_scatter1", (k_rp_scatter1_sorted<0, W, false, true, true>), grid, kSortThreads, 0, r);
+          }
+          return;
+        }
+      }
+      if constexpr (W == 2) {
+        if (cr) {
+          if (kw == 8) {
+            VX_LAUNCH("k_rp_scatter1", (k_rp_scatter1_sorted<8, 2, true, false, true, true>), grid, kSortThreads, 0, r);
+          } else {
+            VX_LAUNCH("k_rp_scatter1", (k_rp_scatter1_sorted<4, 2, true, false, true, true>), grid, kSortThreads, 0, r);
           }
           return;
         }
@@ -5647,6 +5711,11 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
   if (opt1) {
     uint32_t full = 0;
     copyOut(&full, VX355_MEM_HOST, r.binOverflow, 4);
+    if (full != 0 && cr) {
+      h.compactRecords = false;  // (the exact passes below know 16-byte records only: start the chunk over)
+      launchRadix(h, a);
+      return;
+    }
     if (full != 0) {
       // keys bunched inside the observed range: count, then scatter to exact offsets; this operator
       // counts from now on
@@ -5716,9 +5785,15 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
       o.bucketCap = bucketCap;
       o.partCount = partCount;
       o.overflow = overflow;
-      byWidth([&](auto wTag) {
-        VX_LAUNCH("k_rp_scatter2", (k_rp_scatter2_opt<decltype(wTag)::value>), grid2, kSortThreads, 0, o);
-      });
+      o.crCapIn = r.crCap;
+      o.crCapOut = static_cast<uint64_t>(layoutRecs) + 64;
+      if (cr) {
+        VX_LAUNCH("k_rp_scatter2", (k_rp_scatter2_opt<2, true>), grid2, kSortThreads, 0, o);
+      } else {
+        byWidth([&](auto wTag) {
+          VX_LAUNCH("k_rp_scatter2", (k_rp_scatter2_opt<decltype(wTag)::value>), grid2, kSortThreads, 0, o);
+        });
+      }
       constexpr int kSampleParts = 64;
       const bool sampleKeys = hashed && h.hashSlotsFixed == 0 && partsPadded >= kSampleParts;
       if (sampleKeys) {
@@ -5731,7 +5806,13 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
       uint32_t flags[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // [0] overflow, [4..6] the key sample
       copyOut(flags, VX355_MEM_HOST, overflow, sizeof(flags));
       exact = flags[0] != 0;  // some partition outgrew its region (skewed keys): redo the level exactly
+      if (exact && cr) {
+        h.compactRecords = false;  // (as at level 1: the exact passes read 16-byte records)
+        launchRadix(h, a);
+        return;
+      }
       if (!exact) {
+        g.crCap = cr ? o.crCapOut : 0;
         g.partBase = partBase;
         g.partCount = partCount;
         if (sampleKeys && flags[5] != 0) {
@@ -5947,17 +6028,23 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
   }
   // Two launches: the owners of the partitions (a virgin table: they store complete rows), then the
   // other slices of the partitions the owners listed as split (nothing to do for evenly spread keys).
+  auto foldLaunch = [&]() {
+    if (g.crCap != 0) {
+      VX_LAUNCH("k_rp_aggregate", (k_rp_aggregate<2, true>), gridA, 512, ldsBytes, g);
+    } else {
+      byWidth([&](auto wTag) {
+        VX_LAUNCH("k_rp_aggregate", (k_rp_aggregate<decltype(wTag)::value>), gridA, 512, ldsBytes, g);
+      });
+    }
+  };
   g.phase = 0;
-  byWidth([&](auto wTag) {
-    VX_LAUNCH("k_rp_aggregate", (k_rp_aggregate<decltype(wTag)::value>), gridA, 512, ldsBytes, g);
-  });
+  foldLaunch();
   g.phase = 1;
   g.virgin = 0;
-  byWidth([&](auto wTag) {
-    VX_LAUNCH("k_rp_aggregate", (k_rp_aggregate<decltype(wTag)::value>), gridA, 512, ldsBytes, g);
-  });
+  foldLaunch();
   h.tableVirgin = false;
   ++h.radixLaunches;
+  h.compactLaunches += g.crCap != 0 ? 1 : 0;
 }
 
 // Grid of an LDS launch and how it flushes. Atomics: enough rows per workgroup that the flush (live
@@ -7414,6 +7501,9 @@ void configureFromEnv(vx355_agg& h) {
   if (const char* e = std::getenv("VX355_AGG_RADIX_OPTIMISTIC1")) {
     h.radixOptimistic1 = std::atoi(e) != 0;
   }
+  if (const char* e = std::getenv("VX355_AGG_COMPACT_RECORDS")) {
+    h.compactRecords = std::atoi(e) != 0;
+  }
   if (const char* e = std::getenv("VX355_AGG_HASH_SLOTS")) {
     const int v = std::atoi(e);
     h.hashSlotsFixed = v <= 0 ? 0 : static_cast<int32_t>(nextPow2(static_cast<uint64_t>(std::min(kHashSlots, std::max(512, v)))));
@@ -8068,6 +8158,7 @@ int vx355_agg_get_stats(const vx355_agg* h, vx355_agg_stats* out) {
   out->deferred_rows = h->deferredRows;
   out->table_bytes = tableBytesOf(*h);
   out->num_flushes = h->numFlushes;
+  out->compact_record_launches = h->compactLaunches;
   VX_API_END
 }
 
