@@ -607,9 +607,13 @@ class C4(C1):
                           "k_rp_aggregate": 12, "k_agg_global": 40}
     compact = False
 
+    # ... sparse keys: 16-byte records {key, operand}, the home slot recomputed from the key
+    PASS_BYTES_SPARSE_COMPACT = {"k_rp_count1": 8, "k_rp_scatter1": 16 + 16, "k_rp_count2": 16, "k_rp_scatter2": 16 + 16,
+                                 "k_rp_aggregate": 16, "k_agg_global": 40}
+
     def pass_table(self):
         if getattr(self, "sparse", False):
-            return self.PASS_BYTES_SPARSE
+            return self.PASS_BYTES_SPARSE_COMPACT if self.compact else self.PASS_BYTES_SPARSE
         return self.PASS_BYTES_COMPACT if self.compact else self.PASS_BYTES
 
     def pick_dominant(self, prof):
@@ -1878,7 +1882,7 @@ def secondary_block(torch, device, args, copy_ceiling, measure, workload, attrs,
     if workload == "c4":
         # every pass of the radix path next to the bytes it has to move (the step's roofline kernel is the slowest)
         table = wl.pass_table()
-        block["record_bytes"] = 24 if getattr(wl, "sparse", False) else (12 if wl.compact else 16)
+        block["record_bytes"] = (16 if wl.compact else 24) if getattr(wl, "sparse", False) else (12 if wl.compact else 16)
         block["passes"] = {k: {"ms_per_step": round(prof[k][0] / steps, 4), "algorithmic_bytes_per_row": table[k],
                                "algorithmic_GBps": table[k] * wl.rows_per_step() * steps / (prof[k][0] * 1e-3) / 1e9}
                            for k in table if prof.get(k, (0, 0))[0] > 0}

@@ -612,8 +612,9 @@ typedef struct vx355_agg_stats {
   int64_t table_bytes;    /* HBM held by the group table (what isPartialFull compares with
                              max_partial_aggregation_memory, GroupingSet::isPartialFull) */
   int64_t num_flushes;    /* vx355_agg_flush calls completed (kFlushTimes) */
-  int64_t compact_record_launches; /* radix launches whose passes moved 12-byte records (no row number:
-                             VX355_AGG_UNORDERED_OUTPUT, one operand, direct-index table) - ABI 7 */
+  int64_t compact_record_launches; /* radix launches whose passes moved records without row number and mask
+                             (VX355_AGG_UNORDERED_OUTPUT, one flat operand): 12 bytes {key : 32, operand} over
+                             a direct-index table, 16 bytes {key, operand} over an open-addressing one - ABI 7 */
 } vx355_agg_stats;
 int vx355_agg_get_stats(const vx355_agg* h, vx355_agg_stats* out);
 /* The two numbers the shim's isPartialFull / abandon checks need, WITHOUT waiting (ABI 7):

@@ -1737,28 +1737,37 @@ def test_first_seen_order_through_the_librarys_own_pair_sort(vx, groups):
 
 
 @pytest.mark.parametrize("shape", ["uniform", "two_batches", "bunched_keys_overflow_a_region", "int32_key",
-                                   "compact_off"])
+                                   "compact_off", "sparse", "sparse_two_batches", "sparse_one_hot_key",
+                                   "sparse_compact_off"])
 def test_compact_records_when_no_group_order_is_wanted(oracle, vx, shape, monkeypatch):
-    """VX355_AGG_UNORDERED_OUTPUT + one operand + a direct-index table: the radix passes move 12-byte records
-    (32-bit {key | mask} word + operand, two streams) instead of 16-byte ones - no row number travels
-    (recLoad in agg.hip). Results per group equal the oracle's (compared as multisets); a second batch meets
-    the groups of the first; keys bunched into one level-1 bin overflow its optimistic region, which restarts
-    the chunk with 16-byte records (radix_redone is not what counts here: the result is); an INTEGER key; and
+    """VX355_AGG_UNORDERED_OUTPUT + one flat operand: the radix passes move records without row number and
+    accumulator mask. Direct-index table: 12 bytes {32-bit key | mask word, operand} instead of 16 (recLoad in
+    agg.hip); open-addressing table ("sparse" shapes): 16 bytes {key, operand} instead of 24, the home slot
+    recomputed from the key (hashRecLoad). Results per group equal the oracle's (compared as multisets); a
+    second batch meets the groups of the first (for sparse keys: the folds that look groups up in the table
+    instead of the dense ones); keys bunched into one level-1 bin / one key on half of the rows overflow an
+    optimistic region, which restarts the chunk with complete records; an INTEGER key; and
     VX355_AGG_COMPACT_RECORDS=0 as the control."""
     monkeypatch.setenv("VX355_AGG_RADIX_MIN_ROWS", "1")
+    monkeypatch.setenv("VX355_AGG_DENSE_MIN_ROWS", "1")
     monkeypatch.setenv("VX355_AGG_COALESCE_ROWS", "0")
-    if shape == "compact_off":
+    if shape.endswith("compact_off"):
         monkeypatch.setenv("VX355_AGG_COMPACT_RECORDS", "0")
+    sparse = shape.startswith("sparse")
     rng = np.random.default_rng(515)
     # the padded range is 2 x space = 4883 partitions of 2048 groups: two levels (> 4096), and rows >= 1024 per
     # partition, the radix path's own rule
     n, space = 8_000_000, 5_000_000
     batches = []
-    for b in range(2 if shape == "two_batches" else 1):
+    for b in range(2 if shape.endswith("two_batches") else 1):
         k = rng.integers(0, space, n).astype(np.int64)
         if shape == "bunched_keys_overflow_a_region":
             k[: n * 6 // 10] = rng.integers(1_000_000, 1_100_000, n * 6 // 10)  # one level-1 bin holds 131072 keys
             k = rng.permutation(k)
+        if shape == "sparse_one_hot_key":
+            k[rng.random(n) < 0.5] = 77
+        if sparse:
+            k = ((k.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) ^ np.uint64(0x5DEECE66D)).astype(np.int64)
         if shape == "int32_key":
             k = k.astype(np.int32)
         batches.append(batch_of([k, _dyadic(rng, n)]))
@@ -1776,10 +1785,10 @@ def test_compact_records_when_no_group_order_is_wanted(oracle, vx, shape, monkey
     prof = vx.profile()
     assert "k_rp_scatter1" in prof and "k_rp_scatter2" in prof and "k_rp_aggregate" in prof
     st = op.stats()
-    assert st.hash_mode == abi.MODE_ARRAY and st.radix_launches == len(batches)
-    # (the bunched keys send the chunk back to 16-byte records; so does the second batch's chunk when the
-    # first left the table with groups? no: records do not depend on the table)
-    assert st.compact_record_launches == {"compact_off": 0, "bunched_keys_overflow_a_region": 0}.get(shape, len(batches))
+    assert st.hash_mode == (abi.MODE_NORMALIZED_KEY if sparse else abi.MODE_ARRAY) and st.radix_launches == len(batches)
+    compact = 0 if shape.endswith("compact_off") or shape in ("bunched_keys_overflow_a_region", "sparse_one_hot_key") \
+        else len(batches)
+    assert st.compact_record_launches == compact
     go, eo = np.argsort(got[0][0], kind="stable"), np.argsort(exp[0][0], kind="stable")
     assert len(got[0][0]) == len(exp[0][0]) > 1000
     for c in range(3):

@@ -28,6 +28,7 @@ def main():
     rows = 1e9
     algorithmic = {"dense": {"k_rp_scatter1_sorted": 32, "k_rp_scatter2_opt": 32, "k_rp_aggregate": 16 + 4.4},
                    "dense12": {"k_rp_scatter1_sorted": 28, "k_rp_scatter2_opt": 24, "k_rp_aggregate": 12 + 4.4},
+                   "sparse16": {"k_rp_scatter1_sorted": 32, "k_rp_scatter2_opt": 32, "k_rp_aggregate_hashed": 16 + 4.4},
                    "sparse": {"k_rp_scatter1_sorted": 40, "k_rp_scatter2_opt": 48, "k_rp_aggregate_hashed": 24 + 4.4}}[keys]
     ms = {}
     for name, calls, total, *_ in t[("trace", "trace")]:

@@ -1124,11 +1124,12 @@ __device__ inline void rpSortedEmit(SortLds<W>& l, int numBins, const uint64_t (
 
 // Level 1 with sorted sub-tiles (numBins <= kSortBins); same records as k_rp_scatter1.
 // HASHED: word 0 carries the home slot instead of the key, the last word the full key.
-template <int KW, int W, bool FLATV, bool HASHED, bool OPT = false, bool CR = false>
+template <int KW, int W, bool FLATV, bool HASHED, bool OPT = false, bool CR = false, bool KR = false>
 __global__ __launch_bounds__(kSortThreads) void k_rp_scatter1_sorted(RadixArgs r) {
   __shared__ SortLds<W> l;
   constexpr int R = SortLds<W>::kRounds;
-  constexpr int V = W - (HASHED ? 1 : 0);   // word 0 + operand words
+  static_assert(!KR || (HASHED && FLATV && OPT && W == 2 && !CR), "keyed records: see hashRecLoad");
+  constexpr int V = W - (HASHED && !KR ? 1 : 0);   // word 0 + operand words
   const AggArgs& a = r.a;
   const int shift = r.shiftB + r.shift2;
   for (int i = threadIdx.x; i < kSortBins; i += kSortThreads) {
@@ -1204,10 +1205,13 @@ __global__ __launch_bounds__(kSortThreads) void k_rp_scatter1_sorted(RadixArgs r
         uint64_t part = key;
         if constexpr (HASHED) {
           part = twangMix64(key) & r.slotMask;
-          vals[u][W - 1] = key;
+          if constexpr (!KR) {
+            vals[u][W - 1] = key;
+          }
         }
-        // (compact records: no row, rowBits = 0 - the mask sits right behind the key)
-        vals[u][0] = part | (CR ? 0 : (static_cast<uint64_t>(row) << r.keyBits)) | (mask << (r.keyBits + r.rowBits));
+        // (compact records: no row, rowBits = 0 - the mask sits right behind the key; keyed records: the key alone)
+        vals[u][0] = KR ? key
+                        : (part | (CR ? 0 : (static_cast<uint64_t>(row) << r.keyBits)) | (mask << (r.keyBits + r.rowBits)));
         bin[u] = static_cast<uint32_t>(part >> shift);
       }
       const uint64_t keyMask = (1ULL << r.keyBits) - 1;
@@ -1224,7 +1228,9 @@ __global__ __launch_bounds__(kSortThreads) void k_rp_scatter1_sorted(RadixArgs r
         if (next < end) {
           loadSub(next);
         }
-        auto binOf = [&](uint64_t w0) { return static_cast<uint32_t>((w0 & keyMask) >> shift); };
+        auto binOf = [&](uint64_t w0) {
+          return static_cast<uint32_t>(((KR ? (twangMix64(w0) & r.slotMask) : w0) & keyMask) >> shift);
+        };
         rpSortedWrite<W, true, decltype(binOf)&, CR>(l, r.numBins, r.recs, binOf, r.crCap);
       } else {
         rpSortedPlace<W, R>(l, r.numBins, vals, bin);
@@ -1483,6 +1489,7 @@ struct Radix2OptArgs {
   uint32_t* partCount;      // cursors, zero on entry
   uint32_t* overflow;       // set when a region is full
   uint64_t crCapIn, crCapOut;  // compact records: record capacities of 'in' and 'out'
+  uint64_t slotMask;           // keyed records (KR): home slot = twangMix64(word 0) & slotMask
 };
 
 // partBase / bucketCap from the level-1 bucket sizes (one workgroup; buckets <= kRadixMaxBins).
@@ -1528,7 +1535,7 @@ __global__ __launch_bounds__(1024) void k_rp_layout2(Level1Bins l1, int32_t numB
   }
 }
 
-template <int W, bool CR = false>
+template <int W, bool CR = false, bool KR = false>
 __global__ __launch_bounds__(kSortThreads) void k_rp_scatter2_opt(Radix2OptArgs r) {
   __shared__ SortLds<W> l;
   constexpr int R = SortLds<W>::kRounds;
@@ -1541,8 +1548,8 @@ __global__ __launch_bounds__(kSortThreads) void k_rp_scatter2_opt(Radix2OptArgs 
   for (uint32_t t = blockIdx.x; t < numTiles; t += gridDim.x) {
     const RadixTile tile = r.tiles[t];
     // every record of a level-2 tile belongs to one level-1 bucket: its partitions are consecutive
-    const uint64_t firstKey = (CR ? static_cast<uint64_t>(crWord0(r.in, tile.begin)) : r.in[tile.begin * W]) &
-        ((1ULL << r.keyBits) - 1);
+    const uint64_t firstWord = CR ? static_cast<uint64_t>(crWord0(r.in, tile.begin)) : r.in[tile.begin * W];
+    const uint64_t firstKey = (KR ? (twangMix64(firstWord) & r.slotMask) : firstWord) & ((1ULL << r.keyBits) - 1);
     const uint64_t bucket = (firstKey >> r.shiftB) >> r.shift2;
     const uint64_t part0 = bucket << r.shift2;
     const uint32_t cap = r.bucketCap[bucket];
@@ -1560,7 +1567,8 @@ __global__ __launch_bounds__(kSortThreads) void k_rp_scatter2_opt(Radix2OptArgs 
 #pragma unroll
       for (int u = 0; u < R; ++u) {
         const uint32_t i = base + u * kSortThreads + threadIdx.x;
-        bin[u] = i < tile.count ? ((static_cast<uint32_t>(w[u][0]) >> r.shiftB) & binMask) : 0xffffffffu;
+        const uint32_t part = static_cast<uint32_t>(KR ? (twangMix64(w[u][0]) & r.slotMask) : w[u][0]);
+        bin[u] = i < tile.count ? ((part >> r.shiftB) & binMask) : 0xffffffffu;
       }
       rpSortedPlace<W, R>(l, r.numBins, w, bin, [&](uint32_t b, uint32_t count) -> unsigned long long {
         const uint32_t at = atomicAdd(&r.partCount[part0 + b], count);
@@ -1570,7 +1578,9 @@ __global__ __launch_bounds__(kSortThreads) void k_rp_scatter2_opt(Radix2OptArgs 
         }
         return r.partBase[part0 + b] + at;
       });
-      auto binOf = [&](uint64_t w0) { return (static_cast<uint32_t>(w0) >> r.shiftB) & binMask; };
+      auto binOf = [&](uint64_t w0) {
+        return (static_cast<uint32_t>(KR ? (twangMix64(w0) & r.slotMask) : w0) >> r.shiftB) & binMask;
+      };
       rpSortedWrite<W, true, decltype(binOf)&, CR>(l, r.numBins, r.out, binOf, r.crCapOut);
     }
   }
@@ -1608,6 +1618,8 @@ struct RadixAggArgs {
   int32_t keyBits;                          // layout of record word 0
   int32_t rowBits;
   uint64_t crCap;                           // compact records: record capacity of 'recs' (0 = 16-byte records)
+  uint64_t krSlotMask;                      // keyed records (hashRecLoad): home slot = twangMix64(key) & krSlotMask
+  uint32_t krMask;                          // ... and every record's accumulator mask
   // virgin: the table has never been written (no k_init_table ran): the owner of a partition
   // stores every one of its group rows completely - untouched words from 'pattern' - instead of
   // read-modify-write, and empty partitions are initialised on the way.
@@ -1930,6 +1942,10 @@ __device__ inline void rpPartitionRange(const RadixAggArgs& r, int64_t p, uint64
 // its owner folds the first one, the others are spread over all workgroups
 // in a second phase, and every slice of such a partition is flushed with
 // atomics instead of plain read-modify-write.
+// (Measured and dropped, round 5: the next partition's first chunk of records loading while the current one is
+// flushed - 122 VGPRs with the chunk live across the flush, two workgroups per CU instead of three: 5.7 ms
+// instead of 4.2 for config 4's 12-byte records, 5.2 either way for 16-byte ones. With two register buffers
+// and loads a chunk ahead inside the partition as well: 131 VGPRs, one workgroup per CU.)
 template <int W, bool CR = false>
 __global__ __launch_bounds__(512) void k_rp_aggregate(RadixAggArgs r) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
@@ -2098,16 +2114,36 @@ __device__ inline void hashFoldDirect(const RadixAggArgs& r, const uint64_t (&w)
   hashApplyRecordGlobal<W>(r, g, w, mask);
 }
 
+// Keyed records (KR; round 5): when nobody asked for first-seen order and every record has the same accumulator
+// mask (flat operands without nulls or masks), word 0 of a hashed record says nothing the key does not: the home
+// slot is twangMix64(key) & slotMask - a dozen ALU operations against 8 bytes through three passes. The record
+// in HBM is {key, operand}, 16 bytes instead of 24 (and sub-tiles of 8192 instead of 4096 records in the
+// scatters' LDS); the folds load it into the three-word form with word 0 unused.
+template <int W, bool KR>
+__device__ inline void hashRecLoad(const RadixAggArgs& r, uint64_t i, uint64_t (&w)[W]) {
+  if constexpr (KR) {
+    static_assert(W == 3, "keyed records carry one operand");
+    uint64_t t[2];
+    rpLoad<2>(r.recs + i * 2, t);
+    w[0] = 0;
+    w[1] = t[1];
+    w[2] = t[0];
+  } else {
+    rpLoad<W>(r.recs + i * W, w);
+  }
+}
+
 // One record folded into the LDS table of its partition.
-template <int W, bool DENSE>
+template <int W, bool DENSE, bool KR = false>
 __device__ inline void hashFoldRecord(const HashFold& f, const RadixAggArgs& r, uint64_t base, const uint64_t (&w)[W]) {
   const FoldPlan& fp = f.plan;
   const uint64_t w0 = w[0];
   const uint64_t key = w[W - 1];
-  const uint32_t row = static_cast<uint32_t>(w0 >> fp.keyBits) & fp.rowMask;
-  const uint32_t mask = static_cast<uint32_t>(w0 >> (fp.keyBits + fp.rowBits));
+  const uint32_t row = KR ? 0u : static_cast<uint32_t>(w0 >> fp.keyBits) & fp.rowMask;
+  const uint32_t mask = KR ? r.krMask : static_cast<uint32_t>(w0 >> (fp.keyBits + fp.rowBits));
+  const uint64_t home = KR ? (twangMix64(key) & r.krSlotMask) : (w0 & ((1ULL << fp.keyBits) - 1));
   // home slot inside the partition, scaled into the LDS table (both sizes are powers of two)
-  int pos = static_cast<int>((((w0 & ((1ULL << fp.keyBits) - 1)) - base) << f.posUp) >> f.posDown);
+  int pos = static_cast<int>(((home - base) << f.posUp) >> f.posDown);
   uint32_t seenFirst = 0xffffffffu;
   for (int probes = 0;; ++probes) {
     const unsigned long long k = f.keys[pos];
@@ -2142,7 +2178,7 @@ __device__ inline void hashFoldRecord(const HashFold& f, const RadixAggArgs& r, 
 
 constexpr int kHashUnroll = 4;  // records per lane in flight beyond the ones loaded ahead
 
-template <int W, bool DENSE>
+template <int W, bool DENSE, bool KR = false>
 __device__ inline void hashFoldRecords(const HashFold& f, const RadixAggArgs& r, int64_t p, uint64_t begin, uint64_t end) {
   const uint64_t base = static_cast<uint64_t>(p) << r.shiftB;
   for (uint64_t at = begin; at < end; at += kHashUnroll * 512) {
@@ -2150,13 +2186,13 @@ __device__ inline void hashFoldRecords(const HashFold& f, const RadixAggArgs& r,
 #pragma unroll
     for (int u = 0; u < kHashUnroll; ++u) {
       const uint64_t i = at + u * 512 + threadIdx.x;
-      rpLoad<W>(r.recs + (i < end ? i : end - 1) * W, w[u]);  // clamped, unconditional: see k_rp_scatter2
+      hashRecLoad<W, KR>(r, i < end ? i : end - 1, w[u]);  // clamped, unconditional: see k_rp_scatter2
     }
 #pragma unroll
     for (int u = 0; u < kHashUnroll; ++u) {
       const uint64_t i = at + u * 512 + threadIdx.x;
       if (i < end) {
-        hashFoldRecord<W, DENSE>(f, r, base, w[u]);
+        hashFoldRecord<W, DENSE, KR>(f, r, base, w[u]);
       }
     }
   }
@@ -2168,14 +2204,14 @@ __device__ inline void hashFoldRecords(const HashFold& f, const RadixAggArgs& r,
 // two or three workgroups a CU holds do not cover it (measured: 11 us per partition, 1.1 TB/s).
 constexpr int kHashAhead = 2;
 
-template <int W>
+template <int W, bool KR = false>
 __device__ inline void hashFoldLoadAhead(const RadixAggArgs& r, uint64_t begin, uint64_t end, uint64_t (&w)[kHashAhead][W]) {
   const uint64_t stop = end - begin > r.sliceRecs ? begin + r.sliceRecs : end;
 #pragma unroll
   for (int u = 0; u < kHashAhead; ++u) {
     const uint64_t i = begin + u * 512 + threadIdx.x;
     if (begin < stop) {  // uniform
-      rpLoad<W>(r.recs + (i < stop ? i : stop - 1) * W, w[u]);  // clamped, unconditional: see k_rp_scatter2
+      hashRecLoad<W, KR>(r, i < stop ? i : stop - 1, w[u]);  // clamped, unconditional: see k_rp_scatter2
     }
   }
 }
@@ -2468,7 +2504,7 @@ __device__ inline void hashFoldFlushDense(const HashFold& f, const RadixAggArgs&
   blockSync();
 }
 
-template <int W, bool DENSE>
+template <int W, bool DENSE, bool KR = false>
 __global__ __launch_bounds__(512) void k_rp_aggregate_hashed(RadixAggArgs r) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
   __shared__ uint32_t scratch[4];
@@ -2511,7 +2547,7 @@ __global__ __launch_bounds__(512) void k_rp_aggregate_hashed(RadixAggArgs r) {
   }
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) {
-    hashFoldLoadAhead<W>(r, rangeBegin[d], rangeEnd[d], ahead[d]);
+    hashFoldLoadAhead<W, KR>(r, rangeBegin[d], rangeEnd[d], ahead[d]);
   }
   for (int64_t p = pFirst; p < pEnd; p += grid) {
     const uint64_t begin = rangeBegin[0], end = rangeEnd[0];
@@ -2537,7 +2573,7 @@ __global__ __launch_bounds__(512) void k_rp_aggregate_hashed(RadixAggArgs r) {
       rpPartitionRangeAhead(r, p + (DEPTH + 1) * grid, &rangeBegin[DEPTH], &rangeEnd[DEPTH]);
     }
     if (p + DEPTH * grid < pEnd) {
-      hashFoldLoadAhead<W>(r, rangeBegin[DEPTH - 1], rangeEnd[DEPTH - 1], ahead[DEPTH - 1]);
+      hashFoldLoadAhead<W, KR>(r, rangeBegin[DEPTH - 1], rangeEnd[DEPTH - 1], ahead[DEPTH - 1]);
     }
     if (end == begin) {
       continue;  // uniform per workgroup
@@ -2551,11 +2587,11 @@ __global__ __launch_bounds__(512) void k_rp_aggregate_hashed(RadixAggArgs r) {
 #pragma unroll
     for (int u = 0; u < kHashAhead; ++u) {
       if (begin + u * 512 + threadIdx.x < stop) {
-        hashFoldRecord<W, DENSE>(f, r, base, w[u]);
+        hashFoldRecord<W, DENSE, KR>(f, r, base, w[u]);
       }
     }
     if (stop - begin > kHashAhead * 512) {
-      hashFoldRecords<W, DENSE>(f, r, p, begin + kHashAhead * 512, stop);
+      hashFoldRecords<W, DENSE, KR>(f, r, p, begin + kHashAhead * 512, stop);
     } else {
       blockSync();
     }
@@ -2575,7 +2611,7 @@ __global__ __launch_bounds__(512) void k_rp_aggregate_hashed(RadixAggArgs r) {
     const uint64_t slices = (end - begin + r.sliceRecs - 1) / r.sliceRecs;
     for (uint64_t sl = 1 + blockIdx.x; sl < slices; sl += gridDim.x) {
       const uint64_t b = begin + sl * r.sliceRecs;
-      hashFoldRecords<W, DENSE>(f, r, p, b, b + r.sliceRecs < end ? b + r.sliceRecs : end);
+      hashFoldRecords<W, DENSE, KR>(f, r, p, b, b + r.sliceRecs < end ? b + r.sliceRecs : end);
       if constexpr (DENSE) {
         hashFoldFlushDense(f, r, false, &parity, &newGroups);
       } else {
@@ -2600,7 +2636,8 @@ __global__ __launch_bounds__(512) void k_rp_aggregate_hashed(RadixAggArgs r) {
 // keys' frequencies are - the launch sizes the folds' LDS tables from this, see hashSlots.)
 template <int W>
 __global__ __launch_bounds__(256) void k_rp_distinct_sample(const uint64_t* recs, const uint64_t* partBase,
-                                                            const uint32_t* partCount, int64_t numParts, uint32_t* out) {
+                                                            const uint32_t* partCount, int64_t numParts, uint32_t* out,
+                                                            int keyWord) {
   constexpr int kSet = 4096;
   __shared__ unsigned long long set[kSet];
   __shared__ uint32_t found;
@@ -2615,7 +2652,7 @@ __global__ __launch_bounds__(256) void k_rp_distinct_sample(const uint64_t* recs
   const uint64_t begin = partBase[p];
   const uint32_t n = partCount[p] < 2048u ? partCount[p] : 2048u;
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-    const unsigned long long key = recs[(begin + i) * W + (W - 1)];
+    const unsigned long long key = recs[(begin + i) * W + keyWord];
     uint32_t pos = static_cast<uint32_t>(twangMix64(key) >> 20) & (kSet - 1);
     for (;;) {
       const unsigned long long k = set[pos];
@@ -5601,6 +5638,13 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
     r.rowBits = 0;
     r.crCap = static_cast<uint64_t>(liveBins) * r.binCap + 64;
   }
+  // Keyed records (hashRecLoad): the same wish over an open-addressing table - flat BIGINT key, one flat operand
+  // (every record has the same accumulator mask): {key, operand}, the home slot recomputed where it is needed.
+  const bool kr = opt1 && h.compactRecords && h.unorderedOutput && hashed && flatV && kw == 8 && r.numVals == 1 &&
+      h.radixOptimistic && bins2 <= kSortBins;
+  if (kr) {
+    r.recWords = 2;
+  }
   if (opt1) {
     h.rpRecs1.ensure((static_cast<size_t>(liveBins) * r.binCap + 64) * r.recWords * 8 + 64);
     r.recs = h.rpRecs1.as<uint64_t>();
@@ -5635,6 +5679,12 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
     constexpr int W = decltype(wTag)::value;
     if (sorted1 && opt1) {
       const int grid = static_cast<int>(std::min<int64_t>(r.numTiles, rt.numCUs * 2));
+      if constexpr (W == 2) {
+        if (kr) {
+          VX_LAUNCH("k_rp_scatter1", (k_rp_scatter1_sorted<8, 2, true, true, true, false, true>), grid, kSortThreads, 0, r);
+          return;
+        }
+      }
       if constexpr (W >= 2) {
         if (hashed) {
           if (kw == 8) {
@@ -5711,8 +5761,9 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
   if (opt1) {
     uint32_t full = 0;
     copyOut(&full, VX355_MEM_HOST, r.binOverflow, 4);
-    if (full != 0 && cr) {
-      h.compactRecords = false;  // (the exact passes below know 16-byte records only: start the chunk over)
+    if (full != 0 && (cr || kr)) {
+      h.compactRecords = false;  // (the exact passes below know complete records only: start the chunk over)
+      h.denseNext = dense;
       launchRadix(h, a);
       return;
     }
@@ -5787,8 +5838,11 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
       o.overflow = overflow;
       o.crCapIn = r.crCap;
       o.crCapOut = static_cast<uint64_t>(layoutRecs) + 64;
+      o.slotMask = r.slotMask;
       if (cr) {
         VX_LAUNCH("k_rp_scatter2", (k_rp_scatter2_opt<2, true>), grid2, kSortThreads, 0, o);
+      } else if (kr) {
+        VX_LAUNCH("k_rp_scatter2", (k_rp_scatter2_opt<2, false, true>), grid2, kSortThreads, 0, o);
       } else {
         byWidth([&](auto wTag) {
           VX_LAUNCH("k_rp_scatter2", (k_rp_scatter2_opt<decltype(wTag)::value>), grid2, kSortThreads, 0, o);
@@ -5800,19 +5854,22 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
         byWidth([&](auto wTag) {
           constexpr int W = decltype(wTag)::value;
           VX_LAUNCH("k_rp_distinct_sample", (k_rp_distinct_sample<W>), kSampleParts, 256, 0, o.out, partBase, partCount,
-                    static_cast<int64_t>(partsPadded), overflow + 4);
+                    static_cast<int64_t>(partsPadded), overflow + 4, kr ? 0 : W - 1);
         });
       }
       uint32_t flags[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // [0] overflow, [4..6] the key sample
       copyOut(flags, VX355_MEM_HOST, overflow, sizeof(flags));
       exact = flags[0] != 0;  // some partition outgrew its region (skewed keys): redo the level exactly
-      if (exact && cr) {
-        h.compactRecords = false;  // (as at level 1: the exact passes read 16-byte records)
+      if (exact && (cr || kr)) {
+        h.compactRecords = false;  // (as at level 1: the exact passes read complete records)
+        h.denseNext = dense;
         launchRadix(h, a);
         return;
       }
       if (!exact) {
         g.crCap = cr ? o.crCapOut : 0;
+        g.krSlotMask = kr ? r.slotMask : 0;
+        g.krMask = static_cast<uint32_t>((1u << a.numAccs) - 1);
         g.partBase = partBase;
         g.partCount = partCount;
         if (sampleKeys && flags[5] != 0) {
@@ -5948,6 +6005,16 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
         g.phase = phase;
         byWidth([&](auto wTag) {
           constexpr int W = decltype(wTag)::value;
+          if constexpr (W == 2) {
+            if (g.krSlotMask != 0) {
+              if (dense) {
+                VX_LAUNCH("k_rp_aggregate", (k_rp_aggregate_hashed<3, true, true>), gridA, 512, ldsBytes, g);
+              } else {
+                VX_LAUNCH("k_rp_aggregate", (k_rp_aggregate_hashed<3, false, true>), gridA, 512, ldsBytes, g);
+              }
+              return;
+            }
+          }
           if constexpr (W >= 2) {
             if (dense) {
               VX_LAUNCH("k_rp_aggregate", (k_rp_aggregate_hashed<W, true>), gridA, 512, ldsBytes, g);
@@ -5960,6 +6027,7 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
     };
     fold();
     ++h.radixLaunches;
+    h.compactLaunches += g.krSlotMask != 0 ? 1 : 0;
     if (!dense) {
       return;
     }
