@@ -599,6 +599,24 @@ int vx355_agg_add_input_async(vx355_agg* h, const vx355_batch* batch, int64_t* t
 int vx355_agg_poll(vx355_agg* h, int64_t* submitted, int64_t* completed);
 int vx355_agg_wait(vx355_agg* h);
 
+/* Queued no_more_input / get_output (ABI 7): exec::Operator::noMoreInput() and getOutput() must not make
+ * the Driver thread sit through the last queued batches, the listing of the groups and the copies into
+ * the result vectors either (exec/Driver.cpp:538-800: a blocked operator hands the thread back).
+ * vx355_agg_no_more_input_async queues noMoreInput behind the batches submitted so far.
+ * vx355_agg_get_output_async queues ONE page of output (the arguments of vx355_agg_get_output; the
+ * descriptors are copied, the buffers they point to must stay valid until the ticket completes); when the
+ * page is there - or was skipped behind a failure - 'done' (may be NULL) is called ON THE LIBRARY'S WORKER
+ * THREAD with (done_arg, status, num_rows, finished): fulfil the ContinuePromise behind the future
+ * isBlocked() returned, nothing heavier. vx355_agg_output_result hands the page's (num_rows, finished) or
+ * its failure to the Driver thread, once, after vx355_agg_poll reported completed >= ticket (VX355_EINVAL
+ * before that). Several pages may be queued; they are filled in order. Every synchronous entry point still
+ * waits for the queue first. */
+typedef void (*vx355_output_done_fn)(void* arg, int status, int32_t num_rows, int32_t finished);
+int vx355_agg_no_more_input_async(vx355_agg* h, int64_t* ticket_out);
+int vx355_agg_get_output_async(vx355_agg* h, const vx355_out_column* cols, int32_t num_cols, int32_t max_rows,
+                               vx355_output_done_fn done, void* done_arg, int64_t* ticket_out);
+int vx355_agg_output_result(vx355_agg* h, int64_t ticket, int32_t* num_rows, int32_t* finished);
+
 /* hashtable.* runtime stats (exec/HashTable.h:155-182). */
 typedef struct vx355_agg_stats {
   int64_t num_groups;   /* hashtable.numDistinct */

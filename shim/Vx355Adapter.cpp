@@ -4,6 +4,7 @@
 #include "Vx355JoinAdapter.h"
 
 #include <algorithm>
+#include <thread>
 #include <cstring>
 #include <string>
 
@@ -897,7 +898,7 @@ bool Vx355HashAggregation::needsInput() const {
   return !noMoreInput_ && !flushing_;
 }
 
-exec::BlockingReason Vx355HashAggregation::isBlocked(ContinueFuture* /*future*/) {
+exec::BlockingReason Vx355HashAggregation::isBlocked(ContinueFuture* future) {
   // The library takes whole chunks of ~1 M rows (parallel ingest): a few thousand vectors may be in
   // flight. Bound the memory they pin: beyond the bound the operator waits for the library's queue
   // (the GPU side is the bottleneck then; the queue drains in milliseconds).
@@ -907,7 +908,35 @@ exec::BlockingReason Vx355HashAggregation::isBlocked(ContinueFuture* /*future*/)
     check(vx355_agg_wait(handle_));
     releaseCompleted();
   }
+  // Output: the page is queued here, behind the batches and noMoreInput, and the Driver goes off the
+  // thread until the worker has filled it (exec/Driver.cpp:538-800: blocked operators yield the thread).
+  if (wantsOutput()) {
+    if (page_ == nullptr) {
+      startPage();
+    }
+    if (!page_->done.load(std::memory_order_acquire)) {
+      *future = page_->promise.getSemiFuture();
+      return exec::BlockingReason::kWaitForConnector;  // (as TableScan waiting for an asynchronous source)
+    }
+  }
   return exec::BlockingReason::kNotBlocked;
+}
+
+void Vx355HashAggregation::onPageDone(void* arg, int /*status*/, int32_t /*numRows*/, int32_t /*finished*/) {
+  // on the library's worker thread: wake the Driver, nothing else (the status comes with the result)
+  auto* page = static_cast<Page*>(arg);
+  page->done.store(true, std::memory_order_release);
+  page->promise.setValue();
+}
+
+void Vx355HashAggregation::startPage() {
+  const auto maxRows = outputBatchRows();
+  auto page = std::make_unique<Page>();
+  page->result = std::static_pointer_cast<RowVector>(BaseVector::create(outputType_, maxRows, pool()));
+  page->out = std::make_unique<OutColumns>(*page->result);  // (gives every column a nulls buffer)
+  check(vx355_agg_get_output_async(handle_, page->out->data(), page->out->size(), maxRows, &onPageDone, page.get(),
+                                   &page->ticket));
+  page_ = std::move(page);
 }
 
 void Vx355HashAggregation::addInput(RowVectorPtr input) {
@@ -948,19 +977,26 @@ bool Vx355HashAggregation::partialFull() {
 
 void Vx355HashAggregation::noMoreInput() {
   Operator::noMoreInput();
-  check(vx355_agg_no_more_input(handle_));  // waits for the queued batches
-  inFlight_.clear();
+  check(vx355_agg_no_more_input_async(handle_, nullptr));  // queued behind the batches: nobody waits here
 }
 
 RowVectorPtr Vx355HashAggregation::getOutput() {
-  if (finished_ || (!noMoreInput_ && !flushing_)) {
+  if (!wantsOutput()) {
     return nullptr;
   }
-  const auto maxRows = outputBatchRows();
-  auto result = std::static_pointer_cast<RowVector>(BaseVector::create(outputType_, maxRows, pool()));
-  OutColumns out(*result);  // (gives every column a nulls buffer: the library writes validity for each)
+  if (page_ == nullptr) {
+    startPage();  // (a Driver that did not ask isBlocked() first)
+  }
+  if (!page_->done.load(std::memory_order_acquire)) {
+    check(vx355_agg_wait(handle_));
+    while (!page_->done.load(std::memory_order_acquire)) {
+      std::this_thread::yield();  // (the callback runs right behind the ticket's completion)
+    }
+  }
+  releaseCompleted();
+  auto page = std::move(page_);
   int32_t numRows = 0, finished = 0;
-  check(vx355_agg_get_output(handle_, out.data(), out.size(), maxRows, &numRows, &finished));
+  check(vx355_agg_output_result(handle_, page->ticket, &numRows, &finished));
   if (finished) {
     if (flushing_) {
       flushing_ = false;  // the table is empty again: GroupingSet::resetTable
@@ -971,7 +1007,8 @@ RowVectorPtr Vx355HashAggregation::getOutput() {
   if (numRows == 0) {
     return nullptr;
   }
-  out.finish(numRows);
+  page->out->finish(numRows);
+  auto result = std::move(page->result);
   for (auto& child : result->children()) {
     ownStrings(child, numRows);
   }
@@ -989,6 +1026,7 @@ void Vx355HashAggregation::close() {
     handle_ = nullptr;
   }
   inFlight_.clear();
+  page_.reset();  // (the handle's worker is gone: no callback can come)
   Operator::close();
 }
 

@@ -10,10 +10,12 @@
 // (experimental/cudf/exec/ToCudf.cpp:277-295). Operator contract: exec/Operator.h:241-299.
 #pragma once
 
+#include <atomic>
 #include <memory>
 #include <string>
 #include <vector>
 
+#include "velox/common/future/VeloxPromise.h"
 #include "velox/core/PlanNode.h"
 #include "velox/exec/Driver.h"
 #include "velox/exec/Operator.h"
@@ -142,7 +144,9 @@ bool toAggSpec(const core::AggregationNode& node, AggSpec* out);
 
 /// exec::HashAggregation on the GPU (exec/HashAggregation.h). Input batches are queued through the
 /// asynchronous boundary (vx355_agg_add_input_async): the Driver thread does not wait for staging
-/// copies, transfers and kernels; isBlocked() bounds the batches in flight.
+/// copies, transfers and kernels; isBlocked() bounds the batches in flight. noMoreInput and the output
+/// pages are queued too (vx355_agg_no_more_input_async / vx355_agg_get_output_async): isBlocked() hands the
+/// Driver a future that the library's worker fulfils when the page is in the result vector.
 class Vx355HashAggregation : public exec::Operator {
  public:
   Vx355HashAggregation(
@@ -169,6 +173,11 @@ class Vx355HashAggregation : public exec::Operator {
   static void check(int status);
   void releaseCompleted();
   bool partialFull();
+  bool wantsOutput() const {
+    return !finished_ && (noMoreInput_ || flushing_);
+  }
+  void startPage();
+  static void onPageDone(void* arg, int status, int32_t numRows, int32_t finished);
 
   vx355_agg* handle_;
   const ColumnLayout layout_;
@@ -187,6 +196,16 @@ class Vx355HashAggregation : public exec::Operator {
     std::unique_ptr<DecodedBatch> decoded;
   };
   std::vector<InFlight> inFlight_;
+  // the output page being filled by the library's worker (one at a time: the next one is queued when
+  // this one has been handed to the Driver)
+  struct Page {
+    RowVectorPtr result;
+    std::unique_ptr<OutColumns> out;
+    int64_t ticket{0};
+    ContinuePromise promise{"Vx355HashAggregation::getOutput"};
+    std::atomic<bool> done{false};
+  };
+  std::unique_ptr<Page> page_;
 };
 
 }  // namespace facebook::velox::vx355

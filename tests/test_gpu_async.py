@@ -203,3 +203,55 @@ def test_probe_async_input_equals_the_synchronous_path(oracle, vx):
         for a, b_ in zip(g, e):
             assert len(a) == len(b_) and (a == b_).all()
         assert len(g[0]) > 5000
+
+
+def test_queued_no_more_input_and_output_pages(oracle, vx):
+    """vx355_agg_no_more_input_async / vx355_agg_get_output_async (ABI 7): noMoreInput and several pages of
+    output queued behind the batches, none of the calls waits; 'done' fires on the worker thread per page
+    with (status, rows, finished); vx355_agg_output_result hands each page out once, and only after its
+    ticket completed. Same groups in the same order as the synchronous path and the oracle."""
+    import threading
+    rng = np.random.default_rng(14)
+    batches = _batches(rng, 60, 5000)
+    aggs = [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_MIN, 2, abi.BIGINT), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    exp, _ = run_agg(oracle, batches, [0], [abi.BIGINT], aggs, max_rows=4096)
+    op = vx.Aggregation([0], [abi.BIGINT], aggs)
+    for b in batches:
+        op.add_input_async(b)
+    assert op.no_more_input_async() == 61
+    fired, all_done = [], threading.Event()
+
+    def done(status, n, fin):
+        fired.append((status, n, fin))
+        if fin:
+            all_done.set()
+
+    pages = [op.get_output_async(200, done) for _ in range(3)]      # 500 groups: 200 + 200 + 100
+    assert [t for t, _ in pages] == [62, 63, 64]
+    early = pages[2][0]
+    if op.poll()[1] < early:
+        with pytest.raises(vx.Vx355Error) as e:
+            op.output_result(early, pages[2][1])                     # not there yet: said so, nothing handed out
+        assert e.value.status == abi.EINVAL
+    assert all_done.wait(60)
+    assert fired == [(0, 200, False), (0, 200, False), (0, 100, True)]
+    assert op.poll() == (64, 64)
+    cols = None
+    for ticket, out in pages:
+        page, n, fin = op.output_result(ticket, out)
+        assert (n, fin) == ((200, False) if ticket < 64 else (100, True))
+        cols = page if cols is None else [(np.concatenate([a[0], b[0]]), np.concatenate([a[1], b[1]]))
+                                          for a, b in zip(cols, page)]
+    assert_columns_equal(cols, exp, op.kinds, what="queued output pages")
+    with pytest.raises(vx.Vx355Error):
+        op.output_result(pages[0][0], pages[0][1])                   # handed out once
+    # a page queued behind a failed batch is skipped; its callback and its result carry the failure
+    op = vx.Aggregation([0], [abi.BIGINT], [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_SUM, 2, abi.BIGINT)])
+    op.add_input_async(batch_of([rng.integers(0, 5, 10).astype(np.int64)]))   # the plan reads columns 1 and 2
+    seen, skipped = [], threading.Event()
+    op.no_more_input_async()
+    ticket, out = op.get_output_async(100, lambda status, n, fin: (seen.append(status), skipped.set()))
+    assert skipped.wait(60) and seen == [abi.EINVAL]
+    with pytest.raises(vx.Vx355Error) as e:
+        op.output_result(ticket, out)
+    assert e.value.status == abi.EINVAL

@@ -37,6 +37,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <type_traits>
 #include <chrono>
 #include <cmath>
@@ -4086,6 +4089,16 @@ using namespace vx;
 struct vx355_agg {
   vx::Runtime* ctx = nullptr;  // this operator's execution context (stream, mailbox)
   vx::AsyncQueue* aq = nullptr;  // worker of vx355_agg_add_input_async (created on first use)
+  // pages of vx355_agg_get_output_async by ticket, until vx355_agg_output_result hands them out
+  struct QueuedPage {
+    std::vector<vx355_out_column> cols;
+    int32_t numRows = 0, finished = 0;
+    int status = VX355_OK;
+    std::string errorText;
+    std::atomic<bool> complete{false};
+  };
+  std::mutex pagesMutex;
+  std::map<int64_t, std::shared_ptr<QueuedPage>> pages;
   // vx355_agg_table_bytes: what get_stats would report, as of the last batch fed (written by
   // whichever thread feeds - the Driver thread or the queue's worker -, read without waiting)
   std::atomic<int64_t> publishedTableBytes{0};
@@ -8046,8 +8059,8 @@ int vx355_agg_add_input(vx355_agg* h, const vx355_batch* batch) {
   VX_API_END
 }
 
-int vx355_agg_no_more_input(vx355_agg* h) {
-  VX_ASYNC_DRAIN(h)
+// (the entry point minus its drain: what the queue's worker runs for vx355_agg_no_more_input_async)
+static int aggNoMoreInputNow(vx355_agg* h) {
   VX_API_BEGIN_CTX(VX_CTX_OF(h))
   VX_CHECK_ARG(h, "NULL argument");
   Runtime::get().requireInit();
@@ -8065,6 +8078,11 @@ int vx355_agg_no_more_input(vx355_agg* h) {
   VX_API_END
 }
 
+int vx355_agg_no_more_input(vx355_agg* h) {
+  VX_ASYNC_DRAIN(h)
+  return aggNoMoreInputNow(h);
+}
+
 int vx355_agg_output_types(const vx355_agg* h, int32_t* types, int32_t cap, int32_t* n) {
   VX_API_BEGIN
   VX_CHECK_ARG(h && n, "NULL argument");
@@ -8078,9 +8096,8 @@ int vx355_agg_output_types(const vx355_agg* h, int32_t* types, int32_t cap, int3
   VX_API_END
 }
 
-int vx355_agg_get_output(vx355_agg* h, vx355_out_column* cols, int32_t num_cols, int32_t max_rows,
-                         int32_t* n_out, int32_t* finished) {
-  VX_ASYNC_DRAIN(h)
+static int aggGetOutputNow(vx355_agg* h, vx355_out_column* cols, int32_t num_cols, int32_t max_rows,
+                           int32_t* n_out, int32_t* finished) {
   VX_API_BEGIN_CTX(VX_CTX_OF(h))
   Runtime::get().requireInit();
   VX_CHECK_ARG(h, "NULL argument");
@@ -8148,6 +8165,131 @@ int vx355_agg_get_output(vx355_agg* h, vx355_out_column* cols, int32_t num_cols,
     }
   }
   VX_API_END
+}
+
+int vx355_agg_get_output(vx355_agg* h, vx355_out_column* cols, int32_t num_cols, int32_t max_rows,
+                         int32_t* n_out, int32_t* finished) {
+  VX_ASYNC_DRAIN(h)
+  return aggGetOutputNow(h, cols, num_cols, max_rows, n_out, finished);
+}
+
+// Queued forms (ABI 7): no_more_input and get_output as tasks of the handle's worker, behind the batches
+// already queued. The Driver thread neither waits for the last batches nor for the listing of the groups and
+// the copies into the result vectors; 'done' fires on the worker thread when the page is there.
+int vx355_agg_no_more_input_async(vx355_agg* h, int64_t* ticket_out) {
+  try {
+    if (!h) {
+      vx::setLastError("NULL argument");
+      return VX355_EINVAL;
+    }
+    if (!h->aq) {
+      h->aq = vx::asyncCreate();
+    }
+    if (const int failed = vx::asyncFailed(h->aq)) {
+      return failed;
+    }
+    vx::asyncSealIngest(h->aq);
+    const int64_t ticket = vx::asyncSubmit(h->aq, [h](std::string* text) {
+      const int status = aggNoMoreInputNow(h);
+      if (status != VX355_OK) {
+        *text = vx355_last_error();
+      }
+      return status;
+    });
+    if (ticket_out) {
+      *ticket_out = ticket;
+    }
+    return VX355_OK;
+  } catch (const std::exception& e) {
+    vx::setLastError(e.what());
+    return VX355_EINTERNAL;
+  }
+}
+
+int vx355_agg_get_output_async(vx355_agg* h, const vx355_out_column* cols, int32_t num_cols, int32_t max_rows,
+                               vx355_output_done_fn done, void* done_arg, int64_t* ticket_out) {
+  try {
+    if (!h || (num_cols > 0 && !cols)) {
+      vx::setLastError("NULL argument");
+      return VX355_EINVAL;
+    }
+    if (!h->aq) {
+      h->aq = vx::asyncCreate();
+    }
+    if (const int failed = vx::asyncFailed(h->aq)) {
+      return failed;
+    }
+    vx::asyncSealIngest(h->aq);
+    auto page = std::make_shared<vx355_agg::QueuedPage>();
+    page->cols.assign(cols, cols + num_cols);
+    std::function<void(int)> fire;
+    if (done) {
+      fire = [page, done, done_arg](int queueStatus) {
+        done(done_arg, page->status != VX355_OK ? page->status : queueStatus, page->numRows, page->finished);
+      };
+    }
+    {
+      // (registered before the task can run: the ticket is only known after the submit)
+      std::lock_guard<std::mutex> lock(h->pagesMutex);
+      const int64_t ticket = vx::asyncSubmit(
+          h->aq,
+          [h, page, max_rows](std::string* text) {
+            page->status = aggGetOutputNow(h, page->cols.data(), static_cast<int32_t>(page->cols.size()), max_rows,
+                                           &page->numRows, &page->finished);
+            if (page->status != VX355_OK) {
+              *text = vx355_last_error();
+              page->errorText = *text;
+            }
+            page->complete.store(true, std::memory_order_release);
+            return page->status;
+          },
+          std::move(fire));
+      h->pages[ticket] = page;
+      if (ticket_out) {
+        *ticket_out = ticket;
+      }
+    }
+    return VX355_OK;
+  } catch (const std::exception& e) {
+    vx::setLastError(e.what());
+    return VX355_EINTERNAL;
+  }
+}
+
+int vx355_agg_output_result(vx355_agg* h, int64_t ticket, int32_t* n_out, int32_t* finished) {
+  if (!h || !n_out || !finished) {
+    vx::setLastError("NULL argument");
+    return VX355_EINVAL;
+  }
+  std::shared_ptr<vx355_agg::QueuedPage> page;
+  {
+    std::lock_guard<std::mutex> lock(h->pagesMutex);
+    auto it = h->pages.find(ticket);
+    if (it == h->pages.end()) {
+      vx::setLastError("no queued get_output with this ticket (results are handed out once)");
+      return VX355_EINVAL;
+    }
+    if (!it->second->complete.load(std::memory_order_acquire)) {
+      // a page skipped behind a failed batch never runs: the queue's failure is the answer then
+      int64_t submitted = 0, completed = 0;
+      vx::asyncPoll(h->aq, &submitted, &completed);
+      if (completed < ticket) {
+        vx::setLastError("the queued get_output has not completed (vx355_agg_poll: completed < ticket)");
+        return VX355_EINVAL;
+      }
+      h->pages.erase(it);
+      return vx::asyncFailed(h->aq);
+    }
+    page = it->second;
+    h->pages.erase(it);
+  }
+  if (page->status != VX355_OK) {
+    vx::setLastError(page->errorText);
+    return page->status;
+  }
+  *n_out = page->numRows;
+  *finished = page->finished;
+  return VX355_OK;
 }
 
 int vx355_agg_flush(vx355_agg* h) {

@@ -131,6 +131,7 @@ struct AsyncTask {
   std::function<int(std::string*)> fn;
   int64_t tickets;
   std::function<void()> cleanup;  // runs after fn - and instead of it when the task is skipped
+  std::function<void(int)> done;  // runs after the tickets have been reported complete (asyncSubmit)
 };
 
 struct AsyncQueue {
@@ -176,6 +177,13 @@ struct AsyncQueue {
       if (completed == submitted) {
         idle.notify_all();
       }
+      if (task.done) {
+        const int seen = firstError;
+        lock.unlock();
+        task.done(seen);
+        task.done = nullptr;
+        lock.lock();
+      }
     }
   }
 };
@@ -190,7 +198,7 @@ namespace {
 
 void enqueue(AsyncQueue* q, std::function<int(std::string*)> fn, int64_t tickets, std::function<void()> cleanup) {
   std::lock_guard<std::mutex> lock(q->m);
-  q->tasks.push_back(AsyncTask{std::move(fn), tickets, std::move(cleanup)});
+  q->tasks.push_back(AsyncTask{std::move(fn), tickets, std::move(cleanup), nullptr});
   q->wake.notify_one();
 }
 
@@ -354,9 +362,9 @@ bool eligible(const vx355_batch* batch, const std::vector<int32_t>& usedCols, in
 
 }  // namespace
 
-int64_t asyncSubmit(AsyncQueue* q, std::function<int(std::string*)> task) {
+int64_t asyncSubmit(AsyncQueue* q, std::function<int(std::string*)> task, std::function<void(int)> done) {
   std::lock_guard<std::mutex> lock(q->m);
-  q->tasks.push_back(AsyncTask{std::move(task), 1, nullptr});
+  q->tasks.push_back(AsyncTask{std::move(task), 1, nullptr, std::move(done)});
   const int64_t ticket = ++q->submitted;
   q->wake.notify_one();
   return ticket;

@@ -33,7 +33,11 @@ void setLastError(const std::string& m);
 // batches in order; every other entry point of the handle drains the queue first (VX_ASYNC_DRAIN).
 struct AsyncQueue;
 AsyncQueue* asyncCreate();
-int64_t asyncSubmit(AsyncQueue* q, std::function<int(std::string*)> task);
+// 'done' (optional) runs on the worker thread after the task's ticket has been reported complete - also when the
+// task was skipped behind a failed one - with the status the queue holds then.
+int64_t asyncSubmit(AsyncQueue* q, std::function<int(std::string*)> task, std::function<void(int)> done = nullptr);
+// The open chunk of the parallel ingest goes into the queue now (what is submitted next runs behind it).
+void asyncSealIngest(AsyncQueue* q);
 struct DeviceState;
 // A batch for the handle: through the parallel ingest (async.hip) when it qualifies, else as an
 // ordinary task; 'call' is how the handle takes a batch (on the queue's worker thread).

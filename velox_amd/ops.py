@@ -45,7 +45,11 @@ SYMBOLS = [
     "vx355_exchange_stream", "vx355_exchange_destroy", "vx355_exchange_destinations", "vx355_join_repartition", "vx355_agg_merge_partials",
     "vx355_hbm_ceiling", "vx355_compose_indices", "vx355_agg_table_bytes", "vx355_join_probe_set_input_filter",
     "vx355_join_probe_add_input_async", "vx355_join_probe_poll", "vx355_join_probe_wait",
+    "vx355_agg_no_more_input_async", "vx355_agg_get_output_async", "vx355_agg_output_result",
 ]
+
+# void (*vx355_output_done_fn)(void* arg, int status, int32_t num_rows, int32_t finished)
+OUTPUT_DONE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int32, C.c_int32)
 
 # int (*vx355_join_chunk_sink)(void* arg, int32_t chunk, const vx355_batch* received, vx355_join_probe* probe)
 JOIN_CHUNK_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(abi.Batch), C.c_void_p)
@@ -103,6 +107,9 @@ def lib():
     L.vx355_agg_get_output.argtypes = [vp, P(abi.OutColumn), i32, i32, P(i32), P(i32)]
     L.vx355_agg_get_stats.argtypes = [vp, P(abi.AggStats)]
     L.vx355_agg_table_bytes.argtypes = [vp, P(C.c_int64), P(C.c_int64)]
+    L.vx355_agg_no_more_input_async.argtypes = [vp, P(C.c_int64)]
+    L.vx355_agg_get_output_async.argtypes = [vp, P(abi.OutColumn), i32, i32, OUTPUT_DONE_FN, vp, P(C.c_int64)]
+    L.vx355_agg_output_result.argtypes = [vp, C.c_int64, P(i32), P(i32)]
     L.vx355_agg_flush.argtypes = [vp]
     L.vx355_agg_to_intermediate.argtypes = [vp, P(abi.Batch), P(abi.OutColumn), i32]
     L.vx355_agg_destroy.argtypes = [vp]
@@ -802,6 +809,28 @@ class HashAggregation:
 
     def no_more_input(self):
         _check(lib().vx355_agg_no_more_input(self.h))
+
+    # queued forms: neither call waits for the batches queued before it
+    def no_more_input_async(self):
+        ticket = C.c_int64()
+        _check(lib().vx355_agg_no_more_input_async(self.h, C.byref(ticket)))
+        return ticket.value
+
+    def get_output_async(self, max_rows=1024, done=None):
+        """One page queued behind everything submitted so far; 'done(status, num_rows, finished)' runs on the
+        library's worker thread. Returns (ticket, buffers): output_result(ticket, buffers) once poll() says so."""
+        out = abi.OutBuffers(self.kinds, max_rows)
+        ticket = C.c_int64()
+        cb = OUTPUT_DONE_FN(lambda _arg, status, n, fin: done(status, n, bool(fin))) if done else None
+        self.__dict__.setdefault("_page_callbacks", []).append(cb)  # (alive until the handle goes)
+        _check(lib().vx355_agg_get_output_async(self.h, out.descs, len(self.kinds), max_rows, cb, None,
+                                                C.byref(ticket)))
+        return ticket.value, out
+
+    def output_result(self, ticket, out):
+        n, fin = C.c_int32(), C.c_int32()
+        _check(lib().vx355_agg_output_result(self.h, C.c_int64(ticket), C.byref(n), C.byref(fin)))
+        return [out.column(i, n.value) for i in range(len(self.kinds))], n.value, bool(fin.value)
 
     def flush(self):
         """Partial flush: get_output then drains the groups so far; the table restarts empty."""
