@@ -43,8 +43,10 @@ STATUS_DATE = 9298                  # 1995-06-17
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    # (20 timed steps: runs of 5 steps scattered 6.6 - 7.1 ms on one box within a minute, 400 steps give 6.81 - 6.86;
+    # profiles/r05_q1_step_count_variance.txt)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="q1", choices=["q1", "q1x4", "c1", "c4", "q3", "q3full", "c5"],
                     help="q1 = the reference's TPC-H Q1 plan (2 keys, 8 aggregates; the headline); q1x4 = BASELINE.json's "
                          "wording of it (4 keys, 6 aggregates)")
