@@ -1643,6 +1643,7 @@ struct RadixAggArgs {
   // denseFlags[0] = 1 when some key may own more than one row (split partitions, LDS overflow).
   int32_t dense;
   int32_t hashSlots;   // entries of the LDS table of a hashed fold: a power of two, 512 .. kHashSlots
+  int32_t groupShift;  // log2(consecutive partitions folded into one LDS table and flushed together)
   uint64_t denseCap;
   // [0] = 1 when some key may own more than one row; [1] = rows handed out: a workgroup takes rows
   // in blocks of denseChunk (one atomic on this word per block, not per partition - a fold would
@@ -2182,8 +2183,7 @@ __device__ inline void hashFoldRecord(const HashFold& f, const RadixAggArgs& r, 
 constexpr int kHashUnroll = 4;  // records per lane in flight beyond the ones loaded ahead
 
 template <int W, bool DENSE, bool KR = false>
-__device__ inline void hashFoldRecords(const HashFold& f, const RadixAggArgs& r, int64_t p, uint64_t begin, uint64_t end) {
-  const uint64_t base = static_cast<uint64_t>(p) << r.shiftB;
+__device__ inline void hashFoldRecords(const HashFold& f, const RadixAggArgs& r, uint64_t base, uint64_t begin, uint64_t end) {
   for (uint64_t at = begin; at < end; at += kHashUnroll * 512) {
     uint64_t w[kHashUnroll][W];
 #pragma unroll
@@ -2521,10 +2521,17 @@ __global__ __launch_bounds__(512) void k_rp_aggregate_hashed(RadixAggArgs r) {
   }
   f.plan = foldPlan(r);
   f.S = r.hashSlots;
+  // Partitions per flush (round 5): 2^groupShift consecutive partitions - a contiguous range of home slots - are
+  // folded into ONE LDS table and flushed together when a sample of the keys said that they are few
+  // (launchRadix): a partition is ~1000 records, and a flush per partition (barriers, the block of rows, the
+  // groups' stores) cost more than its records.
+  const int gs = r.groupShift;
+  const int64_t G = 1LL << gs;
   {
     const int slotBits = 31 - __builtin_clz(static_cast<unsigned>(r.hashSlots));
-    f.posUp = slotBits > r.shiftB ? slotBits - r.shiftB : 0;
-    f.posDown = r.shiftB > slotBits ? r.shiftB - slotBits : 0;
+    const int span = r.shiftB + gs;   // log2(home slots of one table)
+    f.posUp = slotBits > span ? slotBits - span : 0;
+    f.posDown = span > slotBits ? span - slotBits : 0;
   }
   f.A = r.numWords;
   f.keys = reinterpret_cast<unsigned long long*>(ldsRaw);
@@ -2537,22 +2544,30 @@ __global__ __launch_bounds__(512) void k_rp_aggregate_hashed(RadixAggArgs r) {
   // for 10^9 three-word records - what bounds the loop is not the bytes in flight)
   constexpr int DEPTH = 1;
   const int64_t grid = gridDim.x;
-  const int64_t pFirst = blockIdx.x;
   const int64_t pEnd = r.phase == 1 ? 0 : r.numParts;
+  // the workgroup's i-th partition: partition (i mod G) of its (i / G)-th group of partitions
+  const int64_t numGroups = (pEnd + G - 1) >> gs;
+  const int64_t myGroups = blockIdx.x < numGroups ? (numGroups - blockIdx.x + grid - 1) / grid : 0;
+  const int64_t mine = myGroups << gs;
+  auto partOf = [&](int64_t i) -> int64_t {
+    return ((static_cast<int64_t>(blockIdx.x) + (i >> gs) * grid) << gs) + (i & (G - 1));
+  };
   uint64_t rangeBegin[DEPTH + 1], rangeEnd[DEPTH + 1];
   uint64_t ahead[DEPTH][kHashAhead][W];
 #pragma unroll
   for (int d = 0; d <= DEPTH; ++d) {
     rangeBegin[d] = rangeEnd[d] = 0;
-    if (pFirst + d * grid < pEnd) {
-      rpPartitionRangeAhead(r, pFirst + d * grid, &rangeBegin[d], &rangeEnd[d]);
+    if (d < mine && partOf(d) < pEnd) {
+      rpPartitionRangeAhead(r, partOf(d), &rangeBegin[d], &rangeEnd[d]);
     }
   }
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) {
     hashFoldLoadAhead<W, KR>(r, rangeBegin[d], rangeEnd[d], ahead[d]);
   }
-  for (int64_t p = pFirst; p < pEnd; p += grid) {
+  bool groupHas = false, groupSplit = false;
+  for (int64_t i = 0; i < mine; ++i) {
+    const int64_t p = partOf(i);
     const uint64_t begin = rangeBegin[0], end = rangeEnd[0];
     uint64_t w[kHashAhead][W];
 #pragma unroll
@@ -2572,36 +2587,40 @@ __global__ __launch_bounds__(512) void k_rp_aggregate_hashed(RadixAggArgs r) {
       rangeEnd[d] = rangeEnd[d + 1];
     }
     rangeBegin[DEPTH] = rangeEnd[DEPTH] = 0;
-    if (p + (DEPTH + 1) * grid < pEnd) {
-      rpPartitionRangeAhead(r, p + (DEPTH + 1) * grid, &rangeBegin[DEPTH], &rangeEnd[DEPTH]);
+    if (i + DEPTH + 1 < mine && partOf(i + DEPTH + 1) < pEnd) {
+      rpPartitionRangeAhead(r, partOf(i + DEPTH + 1), &rangeBegin[DEPTH], &rangeEnd[DEPTH]);
     }
-    if (p + DEPTH * grid < pEnd) {
+    if (i + DEPTH < mine) {
       hashFoldLoadAhead<W, KR>(r, rangeBegin[DEPTH - 1], rangeEnd[DEPTH - 1], ahead[DEPTH - 1]);
     }
-    if (end == begin) {
-      continue;  // uniform per workgroup
-    }
-    const bool split = end - begin > r.sliceRecs;
-    const uint64_t stop = split ? begin + r.sliceRecs : end;
-    const uint64_t base = static_cast<uint64_t>(p) << r.shiftB;
-    if (split && threadIdx.x == 0) {
-      r.splitList[16 + atomicAdd(&r.splitList[0], 1u)] = static_cast<uint32_t>(p);
-    }
-#pragma unroll
-    for (int u = 0; u < kHashAhead; ++u) {
-      if (begin + u * 512 + threadIdx.x < stop) {
-        hashFoldRecord<W, DENSE, KR>(f, r, base, w[u]);
+    const bool lastOfGroup = (i & (G - 1)) == G - 1;
+    if (end != begin) {  // uniform per workgroup
+      const bool split = end - begin > r.sliceRecs;
+      const uint64_t stop = split ? begin + r.sliceRecs : end;
+      const uint64_t base = static_cast<uint64_t>(p >> gs << gs) << r.shiftB;
+      if (split && threadIdx.x == 0) {
+        r.splitList[16 + atomicAdd(&r.splitList[0], 1u)] = static_cast<uint32_t>(p);
       }
+#pragma unroll
+      for (int u = 0; u < kHashAhead; ++u) {
+        if (begin + u * 512 + threadIdx.x < stop) {
+          hashFoldRecord<W, DENSE, KR>(f, r, base, w[u]);
+        }
+      }
+      if (stop - begin > kHashAhead * 512) {
+        hashFoldRecords<W, DENSE, KR>(f, r, base, begin + kHashAhead * 512, stop);
+      }
+      groupHas = true;
+      groupSplit = groupSplit || split;
     }
-    if (stop - begin > kHashAhead * 512) {
-      hashFoldRecords<W, DENSE, KR>(f, r, p, begin + kHashAhead * 512, stop);
-    } else {
-      blockSync();
-    }
-    if constexpr (DENSE) {
-      hashFoldFlushDense(f, r, !split, &parity, &newGroups);
-    } else {
-      hashFoldFlush(f, r, !split);
+    if (lastOfGroup && groupHas) {
+      blockSync();  // every record of the group is in the table
+      if constexpr (DENSE) {
+        hashFoldFlushDense(f, r, !groupSplit, &parity, &newGroups);
+      } else {
+        hashFoldFlush(f, r, !groupSplit);
+      }
+      groupHas = groupSplit = false;
     }
   }
   // Remaining slices of the split partitions (skewed keys), in a launch of its own (r.splitList is
@@ -2611,10 +2630,11 @@ __global__ __launch_bounds__(512) void k_rp_aggregate_hashed(RadixAggArgs r) {
     const int64_t p = r.splitList[16 + q];
     uint64_t begin, end;
     rpPartitionRange(r, p, &begin, &end);
+    const uint64_t base = static_cast<uint64_t>(p >> gs << gs) << r.shiftB;
     const uint64_t slices = (end - begin + r.sliceRecs - 1) / r.sliceRecs;
     for (uint64_t sl = 1 + blockIdx.x; sl < slices; sl += gridDim.x) {
       const uint64_t b = begin + sl * r.sliceRecs;
-      hashFoldRecords<W, DENSE, KR>(f, r, p, b, b + r.sliceRecs < end ? b + r.sliceRecs : end);
+      hashFoldRecords<W, DENSE, KR>(f, r, base, b, b + r.sliceRecs < end ? b + r.sliceRecs : end);
       if constexpr (DENSE) {
         hashFoldFlushDense(f, r, false, &parity, &newGroups);
       } else {
@@ -4157,6 +4177,7 @@ struct vx355_agg {
   bool compactRecords = true;    // VX355_AGG_COMPACT_RECORDS=0: 16-byte records also when no group order is wanted (see recLoad)
   int64_t radixRedone = 0;      // level-2 passes redone exactly after a region overflowed
   int32_t hashSlotsFixed = 0;   // VX355_AGG_HASH_SLOTS: LDS entries of the hashed folds (0 = from a sample of the keys)
+  bool foldGroups = true;       // VX355_AGG_FOLD_GROUPS=0: one partition per flush whatever the sample says
   int32_t lastHashSlots = 0;    // what the last hashed launch used
   int64_t radixMinRows = 4 << 20;
   int32_t radixMaxBins = kRadixMaxBins;  // widest single-level fan-out
@@ -5796,6 +5817,7 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
 
   RadixAggArgs g{};
   int32_t hashSlots = h.hashSlotsFixed > 0 ? h.hashSlotsFixed : kHashSlots;
+  int32_t groupShift = 0;   // hashed folds: log2(partitions per LDS table and flush), from the key sample below
   g.recs = h.rpRecs1.as<uint64_t>();
   g.partBegin = offsets1;
   g.partCell = nullptr;
@@ -5893,6 +5915,21 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
           const double mean = perRecord * recsPerPart;
           const double fullest = std::max<double>(flags[6], mean + 6.0 * std::sqrt(mean + 1.0));
           hashSlots = static_cast<int32_t>(nextPow2(static_cast<uint64_t>(std::min<double>(kHashSlots, std::max(512.0, 2.5 * fullest)))));
+          // ... and few keys per partition share a table: as many partitions per flush as the largest table takes
+          // (config 4 with sparse keys, ~95 keys per partition, fold alone: 11.0 ms one partition per flush, 10.0
+          // with two in 1024 entries, 9.4 with four in 2048 - fewer workgroups per CU, still faster)
+          int32_t groupMax = kHashSlots;
+          if (const char* e = std::getenv("VX355_AGG_FOLD_GROUP_SLOTS")) {
+            groupMax = std::max(512, std::min(kHashSlots, std::atoi(e)));
+          }
+          while (h.foldGroups && groupShift < 4 && 2.5 * fullest * (2 << groupShift) <= groupMax &&
+                 (parts >> (groupShift + 1)) >= static_cast<uint64_t>(rt.numCUs) * 16) {
+            ++groupShift;
+          }
+          if (groupShift > 0) {
+            hashSlots = static_cast<int32_t>(nextPow2(static_cast<uint64_t>(
+                std::min<double>(kHashSlots, std::max(512.0, 2.5 * fullest * (1 << groupShift))))));
+          }
         }
       } else {
         ++h.radixRedone;
@@ -5947,6 +5984,7 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
   // LDS of one fold: dense = B groups x (words + first row); hashed = (B + margin) window entries x
   // (key + words + first row)
   g.hashSlots = hashSlots;
+  g.groupShift = groupShift;
   h.lastHashSlots = hashed ? hashSlots : 0;
   const size_t ldsBytes = hashed ? static_cast<size_t>(hashSlots) * (8 + g.numWords * 8 + 4)
                                  : (static_cast<size_t>(1) << r.shiftB) * (g.numWords * 8 + 4);
@@ -7591,6 +7629,9 @@ void configureFromEnv(vx355_agg& h) {
   }
   if (const char* e = std::getenv("VX355_AGG_RADIX_SORTED")) {
     h.radixSorted = std::atoi(e) != 0;
+  }
+  if (const char* e = std::getenv("VX355_AGG_FOLD_GROUPS")) {
+    h.foldGroups = std::atoi(e) != 0;
   }
   if (const char* e = std::getenv("VX355_AGG_RADIX_MIN_ROWS")) {
     h.radixMinRows = std::strtoll(e, nullptr, 10);  // < 0 disables the path
