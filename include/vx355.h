@@ -868,6 +868,17 @@ int vx355_join_probe_add_input(vx355_join_probe* h, const vx355_batch* batch);
 int vx355_join_probe_add_input_async(vx355_join_probe* h, const vx355_batch* batch, int64_t* ticket_out);
 int vx355_join_probe_poll(vx355_join_probe* h, int64_t* submitted, int64_t* completed);
 int vx355_join_probe_wait(vx355_join_probe* h);
+/* Queued output page of the probe (ABI 7; the aggregation's vx355_agg_get_output_async, same callback type):
+ * vx355_join_probe_get_output (build_side = 0) or vx355_join_probe_get_build_side_output (build_side = 1,
+ * mapping_out unused) as a task behind the batch queued with vx355_join_probe_add_input_async. The descriptor
+ * arrays are copied; mapping_out, build_rows_out and the column buffers must stay valid until the ticket
+ * completes. vx355_join_probe_output_result: (num_rows, finished) or the failure, once, after
+ * vx355_join_probe_poll reported completed >= ticket. */
+int vx355_join_probe_get_output_async(vx355_join_probe* h, int32_t build_side, int32_t max_rows, int32_t* mapping_out,
+                                      int32_t* build_rows_out, int32_t out_mem, const vx355_out_column* build_cols,
+                                      const int32_t* build_col_ids, int32_t num_build_cols,
+                                      vx355_output_done_fn done, void* done_arg, int64_t* ticket_out);
+int vx355_join_probe_output_result(vx355_join_probe* h, int64_t ticket, int32_t* num_rows, int32_t* finished);
 /* HashProbe::getOutput (:1154) -> listJoinResults (HashTable.cpp:2133-2350) +
  * fillOutput (HashProbe.cpp:968-991). Emits at most max_rows result rows in
  * ascending probe-row order, all matches of one probe row contiguous.

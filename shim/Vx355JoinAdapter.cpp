@@ -1,6 +1,8 @@
 // See Vx355JoinAdapter.h. Compiled on the Velox side only.
 #include "Vx355JoinAdapter.h"
 
+#include <thread>
+
 #include <algorithm>
 
 #include "velox/core/QueryConfig.h"
@@ -307,6 +309,17 @@ bool Vx355HashProbe::emitsBuildSide() const {
 
 exec::BlockingReason Vx355HashProbe::isBlocked(ContinueFuture* future) {
   if (handle_ != nullptr) {
+    // a batch is being probed, or the unmatched build rows are due: the page is queued behind it and the
+    // Driver leaves the thread until the library's worker has filled it
+    if (!finished_ && (!inputDrained_ || wantsBuildSide())) {
+      if (page_ == nullptr) {
+        startPage(wantsBuildSide());
+      }
+      if (!page_->done.load(std::memory_order_acquire)) {
+        *future = page_->promise.getSemiFuture();
+        return exec::BlockingReason::kWaitForConnector;
+      }
+    }
     return exec::BlockingReason::kNotBlocked;
   }
   table_ = Vx355JoinTables::instance().tableOrFuture(key_, future);  // exec/HashProbe.cpp:527
@@ -337,8 +350,38 @@ bool Vx355HashProbe::needsInput() const {
 void Vx355HashProbe::addInput(RowVectorPtr input) {
   input_ = std::move(input);
   decoded_ = std::make_unique<DecodedBatch>(*input_);
-  check(vx355_join_probe_add_input(handle_, decoded_->get()));
+  check(vx355_join_probe_add_input_async(handle_, decoded_->get(), nullptr));  // (input_ / decoded_ keep the buffers)
   inputDrained_ = false;
+}
+
+void Vx355HashProbe::onPageDone(void* arg, int /*status*/, int32_t /*numRows*/, int32_t /*finished*/) {
+  auto* page = static_cast<Page*>(arg);  // on the library's worker thread: wake the Driver, nothing else
+  page->done.store(true, std::memory_order_release);
+  page->promise.setValue();
+}
+
+void Vx355HashProbe::startPage(bool buildSide) {
+  const auto maxRows = outputBatchRows();
+  auto page = std::make_unique<Page>();
+  page->buildSide = buildSide;
+  page->mapping = allocateIndices(maxRows, pool());
+  page->buildRows.resize(maxRows);
+  for (size_t j = 0; j < plan_.dependentOutputs.size(); ++j) {
+    auto column = BaseVector::create(outputType_->childAt(plan_.dependentOutputs[j]), maxRows, pool());
+    vx355_out_column c{};
+    c.type_kind = plan_.dependentTypes[j];
+    c.mem = VX355_MEM_HOST;
+    c.values = column->values()->asMutable<void>();
+    c.nulls = column->mutableRawNulls();
+    page->out.push_back(c);
+    page->ids.push_back(static_cast<int32_t>(j));
+    page->buildColumns.push_back(std::move(column));
+  }
+  check(vx355_join_probe_get_output_async(
+      handle_, buildSide ? 1 : 0, maxRows, page->mapping->asMutable<int32_t>(), page->buildRows.data(), VX355_MEM_HOST,
+      page->out.data(), page->ids.data(), static_cast<int32_t>(page->ids.size()), &onPageDone, page.get(),
+      &page->ticket));
+  page_ = std::move(page);
 }
 
 void Vx355HashProbe::noMoreInput() {
@@ -390,43 +433,33 @@ RowVectorPtr Vx355HashProbe::getOutput() {
   if (handle_ == nullptr || finished_) {
     return nullptr;
   }
-  const bool buildSide = inputDrained_ && noMoreInput_ && lastProber_ && !buildSideDone_;
+  const bool buildSide = wantsBuildSide();
   if (inputDrained_ && !buildSide) {
     if (noMoreInput_) {
       finished_ = true;
     }
     return nullptr;
   }
-  const auto maxRows = outputBatchRows();
-  auto mapping = allocateIndices(maxRows, pool());
-  std::vector<int32_t> buildRows(maxRows);
-  std::vector<VectorPtr> buildColumns;
-  std::vector<vx355_out_column> out;
-  std::vector<int32_t> ids;
-  for (size_t j = 0; j < plan_.dependentOutputs.size(); ++j) {
-    auto column = BaseVector::create(outputType_->childAt(plan_.dependentOutputs[j]), maxRows, pool());
-    vx355_out_column c{};
-    c.type_kind = plan_.dependentTypes[j];
-    c.mem = VX355_MEM_HOST;
-    c.values = column->values()->asMutable<void>();
-    c.nulls = column->mutableRawNulls();
-    out.push_back(c);
-    ids.push_back(static_cast<int32_t>(j));
-    buildColumns.push_back(std::move(column));
+  if (page_ == nullptr) {
+    startPage(buildSide);  // (a Driver that did not ask isBlocked() first)
   }
+  if (!page_->done.load(std::memory_order_acquire)) {
+    check(vx355_join_probe_wait(handle_));
+    while (!page_->done.load(std::memory_order_acquire)) {
+      std::this_thread::yield();  // (the callback runs right behind the ticket's completion)
+    }
+  }
+  auto page = std::move(page_);
   int32_t numRows = 0, done = 0;
-  if (buildSide) {
-    check(vx355_join_probe_get_build_side_output(
-        handle_, maxRows, buildRows.data(), VX355_MEM_HOST, out.data(), ids.data(), static_cast<int32_t>(ids.size()),
-        &numRows, &done));
+  check(vx355_join_probe_output_result(handle_, page->ticket, &numRows, &done));
+  if (page->buildSide) {
     buildSideDone_ = done != 0;
   } else {
-    check(vx355_join_probe_get_output(
-        handle_, maxRows, mapping->asMutable<int32_t>(), buildRows.data(), VX355_MEM_HOST, out.data(), ids.data(),
-        static_cast<int32_t>(ids.size()), &numRows, &done));
     inputDrained_ = done != 0;
   }
-  auto result = numRows > 0 ? fillOutput(numRows, mapping, buildRows.data(), buildColumns, buildSide) : nullptr;
+  auto result = numRows > 0
+      ? fillOutput(numRows, page->mapping, page->buildRows.data(), page->buildColumns, page->buildSide)
+      : nullptr;
   if (inputDrained_) {
     input_.reset();
     decoded_.reset();
@@ -449,6 +482,7 @@ void Vx355HashProbe::close() {
   }
   input_.reset();
   decoded_.reset();
+  page_.reset();  // (the handle's worker is gone: no callback can come)
   Operator::close();
 }
 

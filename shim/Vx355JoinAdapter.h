@@ -147,6 +147,25 @@ class Vx355HashProbe : public exec::Operator {
   std::unique_ptr<DecodedBatch> decoded_;
   bool inputDrained_{true};
   bool lastProber_{false}, buildSideDone_{false}, finished_{false};
+  // The page of output the library's worker is filling (vx355_join_probe_get_output_async): queued by
+  // isBlocked() behind the batch, handed to the Driver by getOutput() when the callback has fired.
+  struct Page {
+    BufferPtr mapping;
+    std::vector<int32_t> buildRows;
+    std::vector<VectorPtr> buildColumns;
+    std::vector<vx355_out_column> out;
+    std::vector<int32_t> ids;
+    bool buildSide{false};
+    int64_t ticket{0};
+    ContinuePromise promise{"Vx355HashProbe::getOutput"};
+    std::atomic<bool> done{false};
+  };
+  std::unique_ptr<Page> page_;
+  bool wantsBuildSide() const {
+    return inputDrained_ && noMoreInput_ && lastProber_ && !buildSideDone_;
+  }
+  void startPage(bool buildSide);
+  static void onPageDone(void* arg, int status, int32_t numRows, int32_t finished);
 };
 
 /// Called by the adapter of Vx355Adapter.cpp for every Driver: replaces the HashBuild / HashProbe

@@ -255,3 +255,61 @@ def test_queued_no_more_input_and_output_pages(oracle, vx):
     with pytest.raises(vx.Vx355Error) as e:
         op.output_result(ticket, out)
     assert e.value.status == abi.EINVAL
+
+
+def test_probe_output_pages_queued_behind_the_batch(oracle, vx):
+    """vx355_join_probe_get_output_async / _output_result (ABI 7): the probe batch and the pages of its output
+    queue up on the worker; nobody waits until the last callback has fired. A LEFT join (misses keep their probe
+    row) and then the unmatched build rows of a RIGHT join (build_side = 1): the same lists as the synchronous
+    calls give."""
+    import threading
+    rng = np.random.default_rng(18)
+    nb = 50_000
+    bk = rng.permutation(1_000_000)[:nb].astype(np.int64)
+    pay = rng.integers(0, 1 << 30, nb).astype(np.int64)
+    pk = rng.integers(0, 1_000_000, 200_000).astype(np.int64)
+    pk[::7] = bk[rng.integers(0, nb, len(pk[::7]))]
+    for kind in (abi.JOIN_LEFT, abi.JOIN_RIGHT):
+        lists = {}
+        for how in ("sync", "queued"):
+            b = vx.JoinBuild([0], [abi.BIGINT], [1], [abi.BIGINT], kind)
+            b.add_input(batch_of([bk, pay]))
+            probe = vx.JoinProbe(b.finish(), [0], kind)
+            hb = batch_of([pk])
+            got = []
+            if how == "sync":
+                probe.add_input(hb)
+                while True:
+                    m, r, cols, fin = probe.get_output(30000, [0])
+                    got.append((np.asarray(m), np.asarray(r), np.asarray(cols[0][0]), np.asarray(cols[0][1])))
+                    if fin:
+                        break
+                if kind == abi.JOIN_RIGHT:
+                    while True:
+                        r, cols, fin = probe.get_build_side_output(30000, [0])
+                        got.append((np.full(len(r), -1, np.int32), np.asarray(r), np.asarray(cols[0][0]),
+                                    np.asarray(cols[0][1])))
+                        if fin:
+                            break
+            else:
+                ticket = probe.add_input_async(hb)
+                for build_side in ([False, True] if kind == abi.JOIN_RIGHT else [False]):
+                    while True:
+                        fired = threading.Event()
+                        seen = []
+                        t, page = probe.get_output_async(30000, [0], lambda s, n, f: (seen.append((s, n, f)), fired.set()),
+                                                         build_side=build_side)
+                        assert t > ticket
+                        assert fired.wait(60) and seen[0][0] == 0
+                        m, r, cols, fin = probe.output_result(t, page)
+                        assert (len(m), fin) == (seen[0][1], seen[0][2])
+                        got.append((np.asarray(m) if not build_side else np.full(len(r), -1, np.int32), np.asarray(r),
+                                    np.asarray(cols[0][0]), np.asarray(cols[0][1])))
+                        if fin:
+                            break
+                with pytest.raises(vx.Vx355Error):
+                    probe.output_result(t, page)    # handed out once
+            lists[how] = [np.concatenate([g[i] for g in got]) for i in range(4)]
+        for a, b2 in zip(lists["sync"], lists["queued"]):
+            assert len(a) == len(b2) > 0 and (a == b2).all()
+        assert len(lists["sync"][0]) >= len(pk) if kind == abi.JOIN_LEFT else True

@@ -32,6 +32,9 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <map>
+#include <memory>
+#include <mutex>
 
 namespace vx {
 
@@ -2552,6 +2555,17 @@ struct vx355_join_table {
 struct vx355_join_probe {
   vx::Runtime* ctx = nullptr;  // this operator's execution context (stream, mailbox)
   vx::AsyncQueue* aq = nullptr;  // worker of vx355_join_probe_add_input_async (created on first use)
+  // pages of vx355_join_probe_get_output_async by ticket, until vx355_join_probe_output_result hands them out
+  struct QueuedPage {
+    std::vector<vx355_out_column> cols;
+    std::vector<int32_t> ids;
+    int32_t numRows = 0, finished = 0;
+    int status = VX355_OK;
+    std::string errorText;
+    std::atomic<bool> complete{false};
+  };
+  std::mutex pagesMutex;
+  std::map<int64_t, std::shared_ptr<QueuedPage>> pages;
   vx355_join_table* table = nullptr;
   std::vector<int32_t> keyCols;
   int32_t joinType = 0;
@@ -4268,11 +4282,11 @@ int vx355_join_probe_wait(vx355_join_probe* h) {
   return h->aq ? vx::asyncWait(h->aq) : VX355_OK;
 }
 
-int vx355_join_probe_get_output(vx355_join_probe* h, int32_t max_rows, int32_t* mapping_out,
-                                int32_t* build_rows_out, int32_t out_mem, vx355_out_column* build_cols,
-                                const int32_t* build_col_ids, int32_t num_build_cols, int32_t* n_out,
-                                int32_t* finished) {
-  VX_ASYNC_DRAIN(h)
+// (the entry points minus their drain: what the queue's worker runs for vx355_join_probe_get_output_async)
+static int joinProbeGetOutputNow(vx355_join_probe* h, int32_t max_rows, int32_t* mapping_out,
+                                 int32_t* build_rows_out, int32_t out_mem, vx355_out_column* build_cols,
+                                 const int32_t* build_col_ids, int32_t num_build_cols, int32_t* n_out,
+                                 int32_t* finished) {
   VX_API_BEGIN_CTX(VX_CTX_OF(h))
   Runtime::get().requireInit();
   VX_CHECK_ARG(h, "NULL argument");
@@ -4281,17 +4295,124 @@ int vx355_join_probe_get_output(vx355_join_probe* h, int32_t max_rows, int32_t* 
   VX_API_END
 }
 
-int vx355_join_probe_get_build_side_output(vx355_join_probe* h, int32_t max_rows, int32_t* build_rows_out,
-                                           int32_t out_mem, vx355_out_column* build_cols,
-                                           const int32_t* build_col_ids, int32_t num_build_cols, int32_t* n_out,
-                                           int32_t* finished) {
+int vx355_join_probe_get_output(vx355_join_probe* h, int32_t max_rows, int32_t* mapping_out,
+                                int32_t* build_rows_out, int32_t out_mem, vx355_out_column* build_cols,
+                                const int32_t* build_col_ids, int32_t num_build_cols, int32_t* n_out,
+                                int32_t* finished) {
   VX_ASYNC_DRAIN(h)
+  return joinProbeGetOutputNow(h, max_rows, mapping_out, build_rows_out, out_mem, build_cols, build_col_ids,
+                               num_build_cols, n_out, finished);
+}
+
+static int joinProbeGetBuildSideOutputNow(vx355_join_probe* h, int32_t max_rows, int32_t* build_rows_out,
+                                          int32_t out_mem, vx355_out_column* build_cols,
+                                          const int32_t* build_col_ids, int32_t num_build_cols, int32_t* n_out,
+                                          int32_t* finished) {
   VX_API_BEGIN_CTX(VX_CTX_OF(h))
   Runtime::get().requireInit();
   VX_CHECK_ARG(h, "NULL argument");
   probeGetBuildSideOutput(*h, max_rows, build_rows_out, out_mem, build_cols, build_col_ids, num_build_cols,
                           n_out, finished);
   VX_API_END
+}
+
+int vx355_join_probe_get_build_side_output(vx355_join_probe* h, int32_t max_rows, int32_t* build_rows_out,
+                                           int32_t out_mem, vx355_out_column* build_cols,
+                                           const int32_t* build_col_ids, int32_t num_build_cols, int32_t* n_out,
+                                           int32_t* finished) {
+  VX_ASYNC_DRAIN(h)
+  return joinProbeGetBuildSideOutputNow(h, max_rows, build_rows_out, out_mem, build_cols, build_col_ids,
+                                        num_build_cols, n_out, finished);
+}
+
+// Queued output page (ABI 7): vx355_join_probe_get_output / _get_build_side_output as a task of the handle's
+// worker, behind the batch queued with vx355_join_probe_add_input_async; 'done' fires on the worker thread.
+int vx355_join_probe_get_output_async(vx355_join_probe* h, int32_t build_side, int32_t max_rows, int32_t* mapping_out,
+                                      int32_t* build_rows_out, int32_t out_mem, const vx355_out_column* build_cols,
+                                      const int32_t* build_col_ids, int32_t num_build_cols,
+                                      vx355_output_done_fn done, void* done_arg, int64_t* ticket_out) {
+  try {
+    if (!h || (num_build_cols > 0 && (!build_cols || !build_col_ids))) {
+      vx::setLastError("NULL argument");
+      return VX355_EINVAL;
+    }
+    if (!h->aq) {
+      h->aq = vx::asyncCreate();
+    }
+    if (const int failed = vx::asyncFailed(h->aq)) {
+      return failed;
+    }
+    auto page = std::make_shared<vx355_join_probe::QueuedPage>();
+    page->cols.assign(build_cols, build_cols + num_build_cols);
+    page->ids.assign(build_col_ids, build_col_ids + num_build_cols);
+    std::function<void(int)> fire;
+    if (done) {
+      fire = [page, done, done_arg](int queueStatus) {
+        done(done_arg, page->status != VX355_OK ? page->status : queueStatus, page->numRows, page->finished);
+      };
+    }
+    std::lock_guard<std::mutex> lock(h->pagesMutex);
+    const int64_t ticket = vx::asyncSubmit(
+        h->aq,
+        [h, page, build_side, max_rows, mapping_out, build_rows_out, out_mem](std::string* text) {
+          const int32_t nc = static_cast<int32_t>(page->cols.size());
+          page->status = build_side
+              ? joinProbeGetBuildSideOutputNow(h, max_rows, build_rows_out, out_mem, page->cols.data(), page->ids.data(), nc,
+                                               &page->numRows, &page->finished)
+              : joinProbeGetOutputNow(h, max_rows, mapping_out, build_rows_out, out_mem, page->cols.data(),
+                                      page->ids.data(), nc, &page->numRows, &page->finished);
+          if (page->status != VX355_OK) {
+            *text = vx355_last_error();
+            page->errorText = *text;
+          }
+          page->complete.store(true, std::memory_order_release);
+          return page->status;
+        },
+        std::move(fire));
+    h->pages[ticket] = page;
+    if (ticket_out) {
+      *ticket_out = ticket;
+    }
+    return VX355_OK;
+  } catch (const std::exception& e) {
+    vx::setLastError(e.what());
+    return VX355_EINTERNAL;
+  }
+}
+
+int vx355_join_probe_output_result(vx355_join_probe* h, int64_t ticket, int32_t* n_out, int32_t* finished) {
+  if (!h || !n_out || !finished) {
+    vx::setLastError("NULL argument");
+    return VX355_EINVAL;
+  }
+  std::shared_ptr<vx355_join_probe::QueuedPage> page;
+  {
+    std::lock_guard<std::mutex> lock(h->pagesMutex);
+    auto it = h->pages.find(ticket);
+    if (it == h->pages.end()) {
+      vx::setLastError("no queued get_output with this ticket (results are handed out once)");
+      return VX355_EINVAL;
+    }
+    if (!it->second->complete.load(std::memory_order_acquire)) {
+      int64_t submitted = 0, completed = 0;
+      vx::asyncPoll(h->aq, &submitted, &completed);
+      if (completed < ticket) {
+        vx::setLastError("the queued get_output has not completed (vx355_join_probe_poll: completed < ticket)");
+        return VX355_EINVAL;
+      }
+      h->pages.erase(it);  // skipped behind a failed batch: the queue's failure is the answer
+      return vx::asyncFailed(h->aq);
+    }
+    page = it->second;
+    h->pages.erase(it);
+  }
+  if (page->status != VX355_OK) {
+    vx::setLastError(page->errorText);
+    return page->status;
+  }
+  *n_out = page->numRows;
+  *finished = page->finished;
+  return VX355_OK;
 }
 
 void vx355_join_probe_destroy(vx355_join_probe* h) {

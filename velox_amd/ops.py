@@ -46,6 +46,7 @@ SYMBOLS = [
     "vx355_hbm_ceiling", "vx355_compose_indices", "vx355_agg_table_bytes", "vx355_join_probe_set_input_filter",
     "vx355_join_probe_add_input_async", "vx355_join_probe_poll", "vx355_join_probe_wait",
     "vx355_agg_no_more_input_async", "vx355_agg_get_output_async", "vx355_agg_output_result",
+    "vx355_join_probe_get_output_async", "vx355_join_probe_output_result",
 ]
 
 # void (*vx355_output_done_fn)(void* arg, int status, int32_t num_rows, int32_t finished)
@@ -130,6 +131,9 @@ def lib():
                                               P(i32), P(i32)]
     L.vx355_join_probe_get_build_side_output.argtypes = [vp, i32, vp, i32, P(abi.OutColumn), P(i32), i32,
                                                          P(i32), P(i32)]
+    L.vx355_join_probe_get_output_async.argtypes = [vp, i32, i32, vp, vp, i32, P(abi.OutColumn), P(i32), i32,
+                                                    OUTPUT_DONE_FN, vp, P(C.c_int64)]
+    L.vx355_join_probe_output_result.argtypes = [vp, C.c_int64, P(i32), P(i32)]
     L.vx355_join_probe_destroy.argtypes = [vp]
     L.vx355_join_probe_destroy.restype = None
     L.vx355_join_table_key_filter.argtypes = [vp, i32, P(abi.KeyFilter)]
@@ -1077,6 +1081,31 @@ class HashProbe:
                                                  ids, len(kinds), C.byref(n), C.byref(fin)))
         cols = [out.column(i, n.value) for i in range(len(kinds))]
         return mapping[: n.value].copy(), build_rows[: n.value].copy(), cols, bool(fin.value)
+
+    def get_output_async(self, max_rows=1024, build_col_ids=None, done=None, build_side=False):
+        """One page of output queued behind the batch of add_input_async; -> (ticket, page): output_result(ticket,
+        page) once poll() reports it complete. 'done(status, rows, finished)' runs on the library's worker."""
+        if build_col_ids is None:
+            build_col_ids = list(range(len(self.table.dep_types)))
+        kinds = [self.table.dep_types[i] for i in build_col_ids]
+        page = {"out": abi.OutBuffers(kinds, max_rows), "mapping": np.zeros(max(1, max_rows), dtype=np.int32),
+                "build_rows": np.zeros(max(1, max_rows), dtype=np.int32), "ids": abi.i32_array(build_col_ids),
+                "kinds": kinds}
+        page["cb"] = OUTPUT_DONE_FN(lambda _arg, status, n, fin: done(status, n, bool(fin))) if done else None
+        ticket = C.c_int64()
+        _check(lib().vx355_join_probe_get_output_async(self.h, 1 if build_side else 0, max_rows, page["mapping"].ctypes.data,
+                                                       page["build_rows"].ctypes.data, abi.MEM_HOST, page["out"].descs,
+                                                       page["ids"], len(kinds), page["cb"], None, C.byref(ticket)))
+        self.__dict__.setdefault("_pages", {})[ticket.value] = page   # (buffers and callback stay alive)
+        return ticket.value, page
+
+    def output_result(self, ticket, page):
+        n, fin = C.c_int32(), C.c_int32()
+        status = lib().vx355_join_probe_output_result(self.h, C.c_int64(ticket), C.byref(n), C.byref(fin))
+        _check(status)
+        self.__dict__.get("_pages", {}).pop(ticket, None)
+        cols = [page["out"].column(i, n.value) for i in range(len(page["kinds"]))]
+        return page["mapping"][: n.value].copy(), page["build_rows"][: n.value].copy(), cols, bool(fin.value)
 
     def get_output_device(self, max_rows, mapping_ptr, build_rows_ptr, out_descs=None,
                           build_col_ids=()):
