@@ -4290,6 +4290,7 @@ struct vx355_agg {
     dropParts(retired);
   }
 
+  uint64_t pristineAtLaunch = 0;  // the context's launch count right behind k_init_state (ensureBasics)
   Counters* counters() { return countersBuf.as<Counters>(); }
 };
 
@@ -4577,38 +4578,62 @@ void settleTable(vx355_agg& h) {
   }
 }
 
+// The operator's small device state in ONE launch (round 5: three uploads - pattern, counter template,
+// counter reset - were three copy kernels in front of every operator's first batch, 15 us of config 1's
+// 150-us step): the pattern words arrive as a kernel argument.
+struct InitStateArgs {
+  uint64_t pattern[64];
+  int32_t stride;
+};
+__global__ __launch_bounds__(64) void k_init_state(InitStateArgs a, uint64_t* pattern, Counters* pristine, Counters* live) {
+  const int t = threadIdx.x;
+  if (t < a.stride) {
+    pattern[t] = a.pattern[t];
+  }
+  // sizeof(Counters) is a multiple of 8: every lane writes words of both copies
+  constexpr int kWords = static_cast<int>(sizeof(Counters) / 8);
+  static_assert(sizeof(Counters) % 8 == 0 && offsetof(Counters, keyMin) % 8 == 0, "Counters as words");
+  constexpr int kMinAt = static_cast<int>(offsetof(Counters, keyMin) / 8);
+  constexpr int kMaxAt = static_cast<int>(offsetof(Counters, keyMax) / 8);
+  for (int w = t; w < kWords; w += 64) {
+    uint64_t v = 0;
+    if (w >= kMinAt && w < kMinAt + kMaxKeys) {
+      v = static_cast<uint64_t>(INT64_MAX);
+    } else if (w >= kMaxAt && w < kMaxAt + kMaxKeys) {
+      v = static_cast<uint64_t>(INT64_MIN);
+    }
+    reinterpret_cast<uint64_t*>(pristine)[w] = v;
+    reinterpret_cast<uint64_t*>(live)[w] = v;
+  }
+}
+
 void ensureBasics(vx355_agg& h) {
-  auto& rt = Runtime::get();
   if (h.pattern.ptr()) {
     return;
   }
-  // Both uploads start in the context's pinned mailbox (words 128... and 192...: nothing else
-  // writes them, and the stream is drained whenever an entry point returns), so neither needs a
-  // stream synchronisation to protect a stack buffer.
-  static_assert(2 + kMaxLdsAccs <= 64 && 192 * 8 + sizeof(Counters) <= Mailbox::kWords * 8, "mailbox layout");
-  uint64_t* pat = rt.mail.host + 128;
-  pat[0] = kEmpty;
-  pat[1] = kNoRow;
+  static_assert(2 + kMaxLdsAccs <= 64, "the pattern travels as a kernel argument");
+  InitStateArgs ia{};
+  ia.pattern[0] = kEmpty;
+  ia.pattern[1] = kNoRow;
   for (size_t i = 0; i < h.phys.size(); ++i) {
     if (h.wordOf[i] >= 0) {
-      pat[2 + h.wordOf[i]] = accIdentity(h.phys[i].kind);
+      ia.pattern[2 + h.wordOf[i]] = accIdentity(h.phys[i].kind);
     }
   }
+  ia.stride = h.stride;
   h.pattern.ensure(static_cast<size_t>(h.stride) * 8);
-  copyIn(h.pattern.ptr(), pat, VX355_MEM_HOST, static_cast<size_t>(h.stride) * 8);
   // [0] the live counters, [kCountersTemplateAt] a pristine copy: a reset is one device-to-device
   // copy queued on the stream (a pageable host source made every reset a blocking staged copy)
   h.countersBuf.ensure(kCountersTemplateAt + sizeof(Counters));
-  Counters c{};
-  for (int k = 0; k < kMaxKeys; ++k) {
-    c.keyMin[k] = INT64_MAX;
-    c.keyMax[k] = INT64_MIN;
-  }
-  std::memcpy(rt.mail.host + 192, &c, sizeof(c));
-  copyIn(static_cast<char*>(h.countersBuf.ptr()) + kCountersTemplateAt, rt.mail.host + 192, VX355_MEM_HOST, sizeof(c));
+  VX_LAUNCH("k_init_state", k_init_state, 1, 64, 0, ia, h.pattern.as<uint64_t>(),
+            reinterpret_cast<Counters*>(static_cast<char*>(h.countersBuf.ptr()) + kCountersTemplateAt), h.counters());
+  h.pristineAtLaunch = Runtime::get().launchCount;  // (the live copy too: a resetCounters before any other launch has nothing to do)
 }
 
 void resetCounters(vx355_agg& h) {
+  if (h.pristineAtLaunch != 0 && h.pristineAtLaunch == Runtime::get().launchCount) {
+    return;  // k_init_state wrote them and no kernel has been launched since
+  }
   copyIn(h.counters(), static_cast<const char*>(h.countersBuf.ptr()) + kCountersTemplateAt, VX355_MEM_DEVICE,
          sizeof(Counters));
 }

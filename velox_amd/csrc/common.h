@@ -189,6 +189,7 @@ struct Runtime {
   std::atomic<uint64_t> doneCalls{0};  // calls that have returned (their stream work is complete)
   std::recursive_mutex callMutex;    // default contexts only
   bool isDefault = false;
+  uint64_t launchCount = 0;  // kernels launched through VX_LAUNCH in this context (see resetCounters in agg.hip)
   bool& profile;                     // = ds->profile
 
   explicit Runtime(DeviceState* d) : ds(d), profile(d->profile) {}
@@ -236,6 +237,7 @@ class ContextScope {
 #define VX_LAUNCH(name, kernel, grid, block, shmem, ...)                              \
   do {                                                                                \
     auto& rt__ = ::vx::Runtime::get();                                                \
+    ++rt__.launchCount;                                                               \
     if (rt__.profile) rt__.profBegin(name);                                           \
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (shmem), rt__.stream,         \
                        __VA_ARGS__);                                                  \
