@@ -268,10 +268,13 @@ def test_q3_sf100_join_is_complete_and_every_pair_is_valid(vx, torch_gpu):
     assert totals[abi.JOIN_LEFT_SEMI_FILTER] == n and totals[abi.JOIN_ANTI] == wl.probe_rows - n
 
 
+@pytest.mark.parametrize("unordered", [False, True])
 @pytest.mark.parametrize("sparse", [False, True])
-def test_c4_one_billion_rows_counts_exact_sums_close(vx, torch_gpu, sparse):
+def test_c4_one_billion_rows_counts_exact_sums_close(vx, torch_gpu, sparse, unordered):
     """BASELINE config 4 at full size (dense keys: radix-partitioned LDS path; sparse keys:
-    open addressing on the value): sum(v) + count(*) per group against torch reductions."""
+    open addressing on the value): sum(v) + count(*) per group against torch reductions. unordered:
+    VX355_AGG_UNORDERED_OUTPUT, i.e. the compact records of round 5 (12 bytes over the direct-index table,
+    16-byte {key, operand} over the open-addressing one) through both scatter levels and the folds at 10^9 rows."""
     torch = torch_gpu
     import bench
     n, distinct = 1_000_000_000, 100_000_000
@@ -284,11 +287,12 @@ def test_c4_one_billion_rows_counts_exact_sums_close(vx, torch_gpu, sparse):
         k = (j * -7046029254386353131) ^ 0x5DEECE66D   # odd multiplier mod 2^64: a bijection, keys all over int64
     torch.cuda.synchronize()   # the library runs on its own stream: device inputs must be complete
     op = vx.HashAggregation([0], [abi.BIGINT], [(abi.AGG_SUM, 1, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT)],
-                            abi.STEP_SINGLE)
+                            abi.STEP_SINGLE, flags=abi.AGG_UNORDERED_OUTPUT if unordered else 0)
     op.add_input(bench.DevBatch([bench.dcol(abi.BIGINT, k), bench.dcol(abi.DOUBLE, v)], n))
     op.no_more_input()
     st = op.stats()
     assert st.input_rows == n
+    assert st.compact_record_launches == (st.radix_launches if unordered else 0) and st.radix_launches >= 1
     if not sparse:
         assert st.hash_mode == abi.MODE_ARRAY and st.radix_launches >= 1   # 10^9 rows are ONE radix chunk since round 3
     else:
