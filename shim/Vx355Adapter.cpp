@@ -914,9 +914,13 @@ exec::BlockingReason Vx355HashAggregation::isBlocked(ContinueFuture* future) {
     if (page_ == nullptr) {
       startPage();
     }
-    if (!page_->done.load(std::memory_order_acquire)) {
-      *future = page_->promise.getSemiFuture();
-      return exec::BlockingReason::kWaitForConnector;  // (as TableScan waiting for an asynchronous source)
+    {
+      std::lock_guard<std::mutex> lock(page_->mutex);
+      if (!page_->done.load(std::memory_order_acquire)) {
+        page_->promises.emplace_back("Vx355HashAggregation::getOutput");
+        *future = page_->promises.back().getSemiFuture();
+        return exec::BlockingReason::kWaitForConnector;  // (as TableScan waiting for an asynchronous source)
+      }
     }
   }
   return exec::BlockingReason::kNotBlocked;
@@ -925,8 +929,15 @@ exec::BlockingReason Vx355HashAggregation::isBlocked(ContinueFuture* future) {
 void Vx355HashAggregation::onPageDone(void* arg, int /*status*/, int32_t /*numRows*/, int32_t /*finished*/) {
   // on the library's worker thread: wake the Driver, nothing else (the status comes with the result)
   auto* page = static_cast<Page*>(arg);
-  page->done.store(true, std::memory_order_release);
-  page->promise.setValue();
+  std::vector<ContinuePromise> promises;
+  {
+    std::lock_guard<std::mutex> lock(page->mutex);
+    page->done.store(true, std::memory_order_release);
+    promises.swap(page->promises);
+  }
+  for (auto& promise : promises) {
+    promise.setValue();
+  }
 }
 
 void Vx355HashAggregation::startPage() {
@@ -993,6 +1004,7 @@ RowVectorPtr Vx355HashAggregation::getOutput() {
       std::this_thread::yield();  // (the callback runs right behind the ticket's completion)
     }
   }
+  { std::lock_guard<std::mutex> callbackLeft(page_->mutex); }  // (the worker sets 'done' under this lock)
   releaseCompleted();
   auto page = std::move(page_);
   int32_t numRows = 0, finished = 0;

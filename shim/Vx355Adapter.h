@@ -12,6 +12,7 @@
 
 #include <atomic>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -202,7 +203,9 @@ class Vx355HashAggregation : public exec::Operator {
     RowVectorPtr result;
     std::unique_ptr<OutColumns> out;
     int64_t ticket{0};
-    ContinuePromise promise{"Vx355HashAggregation::getOutput"};
+    // (a promise per isBlocked() call: a folly promise hands out its future once; all are fulfilled together)
+    std::mutex mutex;
+    std::vector<ContinuePromise> promises;
     std::atomic<bool> done{false};
   };
   std::unique_ptr<Page> page_;

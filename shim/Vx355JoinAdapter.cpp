@@ -315,8 +315,10 @@ exec::BlockingReason Vx355HashProbe::isBlocked(ContinueFuture* future) {
       if (page_ == nullptr) {
         startPage(wantsBuildSide());
       }
+      std::lock_guard<std::mutex> lock(page_->mutex);
       if (!page_->done.load(std::memory_order_acquire)) {
-        *future = page_->promise.getSemiFuture();
+        page_->promises.emplace_back("Vx355HashProbe::getOutput");
+        *future = page_->promises.back().getSemiFuture();
         return exec::BlockingReason::kWaitForConnector;
       }
     }
@@ -356,8 +358,15 @@ void Vx355HashProbe::addInput(RowVectorPtr input) {
 
 void Vx355HashProbe::onPageDone(void* arg, int /*status*/, int32_t /*numRows*/, int32_t /*finished*/) {
   auto* page = static_cast<Page*>(arg);  // on the library's worker thread: wake the Driver, nothing else
-  page->done.store(true, std::memory_order_release);
-  page->promise.setValue();
+  std::vector<ContinuePromise> promises;
+  {
+    std::lock_guard<std::mutex> lock(page->mutex);
+    page->done.store(true, std::memory_order_release);
+    promises.swap(page->promises);
+  }
+  for (auto& promise : promises) {
+    promise.setValue();
+  }
 }
 
 void Vx355HashProbe::startPage(bool buildSide) {
@@ -449,6 +458,7 @@ RowVectorPtr Vx355HashProbe::getOutput() {
       std::this_thread::yield();  // (the callback runs right behind the ticket's completion)
     }
   }
+  { std::lock_guard<std::mutex> callbackLeft(page_->mutex); }  // (the worker sets 'done' under this lock)
   auto page = std::move(page_);
   int32_t numRows = 0, done = 0;
   check(vx355_join_probe_output_result(handle_, page->ticket, &numRows, &done));

@@ -157,7 +157,8 @@ class Vx355HashProbe : public exec::Operator {
     std::vector<int32_t> ids;
     bool buildSide{false};
     int64_t ticket{0};
-    ContinuePromise promise{"Vx355HashProbe::getOutput"};
+    std::mutex mutex;   // (a promise per isBlocked() call, as in Vx355HashAggregation)
+    std::vector<ContinuePromise> promises;
     std::atomic<bool> done{false};
   };
   std::unique_ptr<Page> page_;
