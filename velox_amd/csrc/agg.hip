@@ -2703,6 +2703,71 @@ __global__ __launch_bounds__(256) void k_rp_distinct_sample(const uint64_t* recs
   }
 }
 
+// The same question BEFORE level 2 (round 5): how many distinct keys would a partition hold? Level 1 has put the
+// records of 2^shift2 consecutive partitions into one bucket; kBucketSamples buckets are scanned completely
+// (kBucketSlices workgroups each) and the records of ONE of their partitions - (home slot >> shiftB) & (2^shift2 - 1)
+// == 0 - are counted exactly: their keys go into a set per bucket in HBM (~1000 inserts per bucket). A sample of the
+// input rows could not tell ten rows per key from one at 10^8 keys; all records of a slot range can. The launch
+// then moves bits from shift2 to shiftB: fewer, larger partitions whose keys still fit the folds' LDS table, i.e.
+// fewer bins at level 2 and longer runs per bin and sub-tile (config 4 with sparse keys: 1024 -> 256 bins).
+constexpr int kBucketSamples = 32;
+constexpr int kBucketSlices = 16;
+constexpr int kBucketSet = 4096;
+template <int W, bool KR>
+__global__ __launch_bounds__(1024) void k_rp_bucket_sample(const uint64_t* recs, const uint64_t* binFirst,
+                                                            const uint32_t* binCursor, int32_t numBins, int32_t shiftB,
+                                                            int32_t shift2, uint64_t slotMask, uint64_t keyMask,
+                                                            unsigned long long* sets, uint32_t* perBucket) {
+  const int sb = blockIdx.x / kBucketSlices, slice = blockIdx.x % kBucketSlices;
+  const int bucket = static_cast<int>((static_cast<int64_t>(sb) * numBins) / kBucketSamples);
+  const uint64_t begin = binFirst[bucket];
+  const uint32_t count = binCursor[bucket];
+  const uint32_t per = (count + kBucketSlices - 1) / kBucketSlices;
+  const uint32_t lo = slice * per;
+  const uint32_t hi = lo + per < count ? lo + per : count;
+  unsigned long long* set = sets + static_cast<size_t>(sb) * kBucketSet;
+  const uint64_t binMask = (1ULL << shift2) - 1;
+  uint32_t mineRecords = 0, mineFound = 0;
+  constexpr int kAhead = 8;   // loads in flight per lane (a scan of 16 - 24 MB per bucket: latency, not bytes)
+  for (uint32_t at = lo; at < hi; at += kAhead * blockDim.x) {
+    uint64_t w0s[kAhead];
+    unsigned long long keys[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      const uint32_t i = at + u * blockDim.x + threadIdx.x;
+      const uint64_t rec = begin + (i < hi ? i : hi - 1);   // clamped, unconditional
+      w0s[u] = recs[rec * W];
+      keys[u] = KR ? w0s[u] : recs[rec * W + (W - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      const uint32_t i = at + u * blockDim.x + threadIdx.x;
+      const unsigned long long key = keys[u];
+      const uint64_t part = KR ? (twangMix64(key) & slotMask) : (w0s[u] & keyMask);
+      if (i >= hi || ((part >> shiftB) & binMask) != 0) {
+        continue;
+      }
+      ++mineRecords;
+      uint32_t pos = static_cast<uint32_t>(twangMix64(key) >> 20) & (kBucketSet - 1);
+      for (int probes = 0; probes < kBucketSet; ++probes) {
+        const unsigned long long old = atomicCAS(&set[pos], static_cast<unsigned long long>(kEmpty), key);
+        if (old == kEmpty) {
+          ++mineFound;
+          break;
+        }
+        if (old == key) {
+          break;
+        }
+        pos = (pos + 1) & (kBucketSet - 1);
+      }
+    }
+  }
+  if (mineRecords != 0) {
+    atomicAdd(&perBucket[2 * sb], mineFound);
+    atomicAdd(&perBucket[2 * sb + 1], mineRecords);
+  }
+}
+
 // Rows appended by dense folds where one key may own several rows (skewed keys: a partition
 // folded in slices): every row goes to its group row in an initialised open-addressing table
 // with atomics, like the flush of a slice.
@@ -4178,6 +4243,9 @@ struct vx355_agg {
   int64_t radixRedone = 0;      // level-2 passes redone exactly after a region overflowed
   int32_t hashSlotsFixed = 0;   // VX355_AGG_HASH_SLOTS: LDS entries of the hashed folds (0 = from a sample of the keys)
   bool foldGroups = true;       // VX355_AGG_FOLD_GROUPS=0: one partition per flush whatever the sample says
+  bool coarseLevel2 = true;     // VX355_AGG_COARSE_LEVEL2=0: level 2 keeps the fan-out chosen before level 1
+  int64_t coarsenedLaunches = 0;
+  DevBuf rpSampleSets;          // k_rp_bucket_sample: a key set per sampled bucket + its counters
   int32_t lastHashSlots = 0;    // what the last hashed launch used
   int64_t radixMinRows = 4 << 20;
   int32_t radixMaxBins = kRadixMaxBins;  // widest single-level fan-out
@@ -5592,7 +5660,7 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
   r.hashed = hashed ? 1 : 0;
   r.slotMask = slotSpace - 1;
   r.shiftB = hashed ? radixHashedShift(slotSpace, n) : radixShiftB(radixWords(a));
-  const uint64_t parts = (slotSpace + (1ULL << r.shiftB) - 1) >> r.shiftB;
+  uint64_t parts = (slotSpace + (1ULL << r.shiftB) - 1) >> r.shiftB;   // (level 2 may be coarsened below: k_rp_bucket_sample)
   // One level while the fan-out fits the LDS cursors (measured: 2400 bins in one
   // pass beat 64 x 64 in two); otherwise two balanced levels.
   const uint64_t maxBins1 = hashed ? kSortBins : static_cast<uint64_t>(h.radixMaxBins);
@@ -5600,7 +5668,7 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
   r.numBins = static_cast<int32_t>((parts + (1ULL << r.shift2) - 1) >> r.shift2);
   r.keyBits = radixKeyBits(slotSpace);
   r.rowBits = radixRowBits(slotSpace);
-  const int32_t bins2 = 1 << r.shift2;
+  int32_t bins2 = 1 << r.shift2;
   for (int j = 0; j < a.numAccs; ++j) {
     r.valIdx[j] = a.accs[j].kind == ACC_COUNT ? -1 : r.numVals++;
     if (r.valIdx[j] >= 0) {
@@ -5836,6 +5904,57 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
       r.binCursor = nullptr;
       exactLevel1();
       byWidth(scatter1);
+    }
+  }
+  // Coarser level 2 when the keys repeat (k_rp_bucket_sample): hashed, both levels optimistic.
+  if (hashed && opt1 && h.coarseLevel2 && h.hashSlotsFixed == 0 && h.radixOptimistic && r.shift2 >= 3 &&
+      r.numBins >= kBucketSamples && bins2 <= kSortBins) {
+    unsigned long long* sets = static_cast<unsigned long long*>(
+        h.rpSampleSets.ensure(static_cast<size_t>(kBucketSamples) * kBucketSet * 8 + kBucketSamples * 8 + 64));
+    uint32_t* perBucket = reinterpret_cast<uint32_t*>(sets + static_cast<size_t>(kBucketSamples) * kBucketSet);
+    HIP_OK(hipMemsetAsync(sets, 0xff, static_cast<size_t>(kBucketSamples) * kBucketSet * 8, rt.stream));
+    HIP_OK(hipMemsetAsync(perBucket, 0, kBucketSamples * 8, rt.stream));
+    const uint64_t keyMask = (1ULL << r.keyBits) - 1;
+    const int gridS = kBucketSamples * kBucketSlices;
+    if (kr) {
+      VX_LAUNCH("k_rp_bucket_sample", (k_rp_bucket_sample<2, true>), gridS, 1024, 0, r.recs, binFirst, binCursor, r.numBins,
+                r.shiftB, r.shift2, r.slotMask, keyMask, sets, perBucket);
+    } else {
+      byWidth([&](auto wTag) {
+        constexpr int W = decltype(wTag)::value;
+        if constexpr (W >= 2) {
+          VX_LAUNCH("k_rp_bucket_sample", (k_rp_bucket_sample<W, false>), gridS, 1024, 0, r.recs, binFirst, binCursor,
+                    r.numBins, r.shiftB, r.shift2, r.slotMask, keyMask, sets, perBucket);
+        }
+      });
+    }
+    uint32_t counts[2 * kBucketSamples];
+    copyOut(counts, VX355_MEM_HOST, perBucket, sizeof(counts));
+    uint64_t found = 0, records = 0;
+    uint32_t fullest = 0;
+    for (int b = 0; b < kBucketSamples; ++b) {
+      found += counts[2 * b];
+      records += counts[2 * b + 1];
+      fullest = std::max(fullest, counts[2 * b]);
+    }
+    if (records >= 1024) {
+      // keys of a partition of the CURRENT size: the fullest one seen, or the mean with room for its spread
+      const double mean = static_cast<double>(found) / kBucketSamples;
+      const double perPart = std::max<double>(fullest, mean + 6.0 * std::sqrt(mean + 1.0));
+      int coarse = 0;
+      // (a partition that is 2^coarse times larger holds that many times the keys: they must fit the LDS table at
+      // load <= 0.4, and the chip must still see >= 16 partitions per CU)
+      while (coarse < 3 && r.shift2 - (coarse + 1) >= 2 && 2.5 * perPart * (2 << coarse) <= kHashSlots &&
+             (parts >> (coarse + 1)) >= static_cast<uint64_t>(rt.numCUs) * 16) {
+        ++coarse;
+      }
+      if (coarse > 0) {
+        r.shiftB += coarse;
+        r.shift2 -= coarse;
+        bins2 >>= coarse;
+        parts >>= coarse;
+        ++h.coarsenedLaunches;
+      }
     }
   }
   const Level1Bins level1{offsets1, r.numTiles, opt1 ? binFirst : nullptr, opt1 ? binCursor : nullptr};
@@ -7654,6 +7773,9 @@ void configureFromEnv(vx355_agg& h) {
   }
   if (const char* e = std::getenv("VX355_AGG_RADIX_SORTED")) {
     h.radixSorted = std::atoi(e) != 0;
+  }
+  if (const char* e = std::getenv("VX355_AGG_COARSE_LEVEL2")) {
+    h.coarseLevel2 = std::atoi(e) != 0;
   }
   if (const char* e = std::getenv("VX355_AGG_FOLD_GROUPS")) {
     h.foldGroups = std::atoi(e) != 0;
