@@ -116,6 +116,28 @@ class HashAggregation {
     finished_ = finished != 0;
     return n;
   }
+  // Queued forms (ABI 7): noMoreInput and one page of output as tasks behind the queued batches. 'done' (may be
+  // null) runs on the library's worker thread when the page is there - fulfil the promise behind the future
+  // exec::Operator::isBlocked returned. outputResult(ticket) hands the row count to the Driver thread, once, after
+  // completedTickets() >= ticket.
+  int64_t noMoreInputAsync() {
+    noMoreInput_ = true;
+    int64_t ticket = 0;
+    check(vx355_agg_no_more_input_async(handle_, &ticket));
+    return ticket;
+  }
+  int64_t getOutputAsync(const vx355_out_column* columns, int32_t numColumns, int32_t maxRows,
+                         vx355_output_done_fn done = nullptr, void* doneArg = nullptr) {
+    int64_t ticket = 0;
+    check(vx355_agg_get_output_async(handle_, columns, numColumns, maxRows, done, doneArg, &ticket));
+    return ticket;
+  }
+  int32_t outputResult(int64_t ticket) {
+    int32_t n = 0, finished = 0;
+    check(vx355_agg_output_result(handle_, ticket, &n, &finished));
+    finished_ = finished != 0;
+    return n;
+  }
   bool isFinished() const { return finished_; }
   vx355_agg* handle() const { return handle_; }  // for the entry points that take the handle (mergePartials)
   vx355_agg_stats stats() const {

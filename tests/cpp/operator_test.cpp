@@ -12,6 +12,7 @@
 #include <set>
 #include <thread>
 #include <array>
+#include <atomic>
 #include <vector>
 
 #include "vx355.hpp"
@@ -500,14 +501,36 @@ int testAsyncInput() {
     lastTicket = op.addInputAsync(vx355_batch{kRows, 2, cols[b].data()});
   }
   EXPECT(lastTicket == kBatches);
-  op.noMoreInput();   // waits for the queue
-  EXPECT(op.inFlight() == 0 && op.completedTickets() == kBatches);
   std::vector<int64_t> outKey(kGroups), outSum(kGroups), outCount(kGroups);
   std::vector<uint64_t> valid(6, 0);
   vx355_out_column out[3] = {{VX355_BIGINT, VX355_MEM_HOST, outKey.data(), valid.data()},
                              {VX355_BIGINT, VX355_MEM_HOST, outSum.data(), valid.data() + 2},
                              {VX355_BIGINT, VX355_MEM_HOST, outCount.data(), valid.data() + 4}};
-  const int32_t n = op.getOutput(out, 3, kGroups);
+  // noMoreInput and the output page queue behind the batches; the callback (the library's worker thread) is what
+  // a shim fulfils its ContinuePromise from
+  struct Done {
+    std::atomic<int> fired{0};
+    int status = -1;
+    int32_t rows = -1, finished = -1;
+  } done;
+  EXPECT(op.noMoreInputAsync() == kBatches + 1);
+  const int64_t page = op.getOutputAsync(
+      out, 3, kGroups,
+      [](void* arg, int status, int32_t rows, int32_t finished) {
+        auto* d = static_cast<Done*>(arg);
+        d->status = status;
+        d->rows = rows;
+        d->finished = finished;
+        d->fired.store(1, std::memory_order_release);
+      },
+      &done);
+  EXPECT(page == kBatches + 2);
+  while (done.fired.load(std::memory_order_acquire) == 0) {
+    std::this_thread::yield();  // a Driver would be off the thread, waiting for the future
+  }
+  EXPECT(done.status == VX355_OK && done.finished == 1 && op.completedTickets() == page && op.inFlight() == 0);
+  const int32_t n = op.outputResult(page);
+  EXPECT(n == done.rows && op.isFinished());
   EXPECT(n == static_cast<int32_t>(want.size()));
   for (int32_t i = 0; i < n; ++i) {
     EXPECT(want.count(outKey[i]) == 1);
