@@ -1139,7 +1139,10 @@ class C5:
         group by destination, exchange, build; probe side in 4 pipelined chunks. The sink drains
         every chunk's probe into HBM-resident output buffers (mapping, build rows, payload a)."""
         torch = self.torch
-        chunks = int(os.environ.get("VX355_C5_CHUNKS", "4"))
+        # chunks pipeline the probe side against the links (chunk i + 1 travels while chunk i is probed);
+        # one rank has no links to hide, and every chunk is one more pass over the join table
+        chunks = int(os.environ.get("VX355_C5_CHUNKS", "4" if self.world > 1 else "1"))
+        self.chunks = chunks
         cap = int(self.n // chunks * 1.25) + (1 << 20)
         if not hasattr(self, "_out"):
             dev = self.fk.device
@@ -1168,6 +1171,12 @@ class C5:
             self.payload_sum = sum(sums)
         return total[0]
 
+    def pick_dominant(self, prof):
+        """The probe kernel of the step: k_join_probe_grouped when the chunks were regrouped by slice of
+        the join table (vx355_join_probe_add_input_regrouped), else k_join_probe; SURVEY 8(d): 24 B per
+        probe row (8-byte key read, one 16-byte slot, the hit)."""
+        self.dominant = "k_join_probe_grouped" if prof.get("k_join_probe_grouped", (0.0, 0))[0] > 0 else "k_join_probe"
+
     def verify(self):
         """One untimed step with the outputs summed: (sum of the gathered dim.a, expected), mod 2^64."""
         self.checking = True
@@ -1182,7 +1191,8 @@ class C5:
 
     def info(self):
         return {"fact_rows_per_gpu": self.n, "dim_rows_per_gpu": int(self.pk.shape[0]),
-                "matches_on_rank0": int(self.matches), "table_mode": int(self.stats.hash_mode)}
+                "matches_on_rank0": int(self.matches), "table_mode": int(self.stats.hash_mode),
+                "probe_chunks": getattr(self, "chunks", None)}
 
     def host_sample(self, rows):
         rows = min(rows, self.n)
@@ -1222,7 +1232,7 @@ def measured_ceilings():
                    "4 workgroups of 1024 per CU, one contiguous 2 MiB-aligned range each: tools/copy_bench.hip)"}
 
 
-READ_ONLY_KERNELS = ("k_agg_fast", "k_agg_lds", "k_join_probe", "k_join_probe_list", "k_rp_count1", "k_pp_count")
+READ_ONLY_KERNELS = ("k_agg_fast", "k_agg_lds", "k_join_probe", "k_join_probe_list", "k_join_probe_grouped", "k_rp_count1", "k_pp_count")
 
 
 def pmc_traffic(workload, kernel):

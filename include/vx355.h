@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VX355_ABI_VERSION 7
+#define VX355_ABI_VERSION 8
 
 typedef enum vx355_status {
   VX355_OK = 0,
@@ -610,10 +610,12 @@ int vx355_agg_wait(vx355_agg* h);
  * descriptors are copied, the buffers they point to must stay valid until the ticket completes); when the
  * page is there - or was skipped behind a failure - 'done' (may be NULL) is called ON THE LIBRARY'S WORKER
  * THREAD with (done_arg, status, num_rows, finished): fulfil the ContinuePromise behind the future
- * isBlocked() returned, nothing heavier. vx355_agg_output_result hands the page's (num_rows, finished) or
- * its failure to the Driver thread, once, after vx355_agg_poll reported completed >= ticket (VX355_EINVAL
- * before that). Several pages may be queued; they are filled in order. Every synchronous entry point still
- * waits for the queue first. */
+ * isBlocked() returned, nothing heavier. The callback has RETURNED by the time vx355_agg_poll / _wait report
+ * completed >= ticket (ABI 8: it runs right before the ticket counts as completed), so done_arg may be freed
+ * from then on; vx355_agg_output_result may also be called from inside or right after the callback - it hands
+ * the page's (num_rows, finished) or its failure to the Driver thread, once, and is VX355_EINVAL only for a
+ * page that is neither filled nor skipped yet. Several pages may be queued; they are filled in order. Every
+ * synchronous entry point still waits for the queue first. */
 typedef void (*vx355_output_done_fn)(void* arg, int status, int32_t num_rows, int32_t finished);
 int vx355_agg_no_more_input_async(vx355_agg* h, int64_t* ticket_out);
 int vx355_agg_get_output_async(vx355_agg* h, const vx355_out_column* cols, int32_t num_cols, int32_t max_rows,
@@ -638,12 +640,41 @@ typedef struct vx355_agg_stats {
                              a direct-index table, 16 bytes {key, operand} over an open-addressing one - ABI 7 */
 } vx355_agg_stats;
 int vx355_agg_get_stats(const vx355_agg* h, vx355_agg_stats* out);
+
+/* What an operator cost on the GPU side so far (ABI 8) - the gpu.* runtime stats the adapter reports
+ * next to the reference's hashtable.* ones ("Metrics"; exec/Operator.h:359-362
+ * addRuntimeStat). Counted per operator handle (its execution context), no profiling mode needed,
+ * readable at any time without waiting for queued work:
+ *   busy_nanos   nanoseconds between entering an entry point of the handle and its stream being
+ *                drained (every entry point returns with its work complete): the kernels, copies and
+ *                host-side launch work of the operator                        -> gpu.kernelNanos
+ *   h2d_bytes    bytes copied host -> HBM (staging of host vectors)           -> gpu.h2dBytes
+ *   d2h_bytes    bytes copied HBM -> host (output pages, small read-backs)    -> gpu.d2hBytes
+ *   input_bytes  bytes of the input columns handed to kernels (values, null bitmaps, indices): what one
+ *                pass over the input reads from HBM                           -> gpu.hbmBytesRead
+ *   launches     kernels launched                                             -> gpu.kernelLaunches
+ * gpu.hbmBytesWritten is reported by the adapter as d2h_bytes plus the operator's table bytes. */
+typedef struct vx355_gpu_stats {
+  int64_t busy_nanos;
+  int64_t h2d_bytes;
+  int64_t d2h_bytes;
+  int64_t input_bytes;
+  int64_t launches;
+  int64_t reserved;
+} vx355_gpu_stats;
+int vx355_agg_get_gpu_stats(const vx355_agg* h, vx355_gpu_stats* out);
 /* The two numbers the shim's isPartialFull / abandon checks need, WITHOUT waiting (ABI 7):
  * vx355_agg_get_stats drains the handle's queue and seals the open ingest chunk, which stalls the
  * Driver thread and defeats the asynchronous boundary when called per batch. table_bytes / num_groups
  * are as of the last batch the library finished feeding (see vx355_agg_poll for which one that is);
  * after a flush has been drained they are the empty table's. Either pointer may be NULL. */
 int vx355_agg_table_bytes(const vx355_agg* h, int64_t* table_bytes, int64_t* num_groups);
+/* Bytes the groups held NOW occupy (ABI 8): the table's allocation scaled by the share of its rows in use,
+ * plus the DISTINCT sets. vx355_agg_table_bytes reports the allocation, which the library keeps across a
+ * flush (as GroupingSet::resetTable(freeTable = false) keeps the reference's): after the first flush only
+ * this number says how full the table is, and it is what the adapter compares with
+ * max_partial_aggregation_memory every time (exec/HashAggregation.cpp:191-236). Never waits. */
+int vx355_agg_bytes_in_use(const vx355_agg* h, int64_t* bytes);
 
 /* Partial-aggregation flush (HashAggregation.cpp:191-236,293-327: when the partial table
  * is "full" the operator emits what it has and starts over). PARTIAL / INTERMEDIATE steps
@@ -757,6 +788,9 @@ typedef struct vx355_join_table_stats {
   int32_t has_duplicates;
 } vx355_join_table_stats;
 int vx355_join_table_get_stats(const vx355_join_table* t, vx355_join_table_stats* out);
+/* gpu.* counters of a build / probe operator (see vx355_gpu_stats). */
+int vx355_join_build_get_gpu_stats(const vx355_join_build* h, vx355_gpu_stats* out);
+int vx355_join_probe_get_gpu_stats(const vx355_join_probe* h, vx355_gpu_stats* out);
 
 /* ---- dynamic filters from the build side (HashProbe::pushdownDynamicFilters,
  * exec/HashProbe.cpp:408-457) --------------------------------------------------
@@ -862,6 +896,28 @@ int vx355_join_probe_set_output_batch_bytes(vx355_join_probe* h, int64_t bytes);
 /* HashProbe::addInput (exec/HashProbe.cpp:796-900): prepareForJoinProbe
  * (HashTable.cpp:2680-2712) + joinProbe (:610-652) for the whole batch. */
 int vx355_join_probe_add_input(vx355_join_probe* h, const vx355_batch* batch);
+/* addInput for tables that no cache holds (ABI 8). The reference meets a table larger than the CPU's
+ * caches by partitioning the BUILD over threads that each own a contiguous range of buckets
+ * (parallelJoinBuild, exec/HashTable.cpp:1003-1203) and by keeping 64 probes in flight
+ * (joinNormalizedKeyProbe, :697-725). On the GPU a probe of a table of hundreds of MB is bound by
+ * the fabric's dependent-random-read rate, not by HBM bytes; the slot array is already cut into
+ * contiguous slices by the top bits of the slot number, so this entry point regroups the PROBE side:
+ * every column of 'batch' is moved into regrouped_values[c] (device buffers of num_rows x the
+ * column's width, allocated by the caller) so that rows whose keys begin their walk in the same slice
+ * (~4 MiB of slots: an XCD's L2) are adjacent, and the regrouped batch is probed slice by slice with each slice's
+ * workgroups on one XCD, whose L2 then holds the slice. *regrouped = 1: the operator's input batch
+ * IS the regrouped one - mapping_out of get_output numbers ITS rows (ascending, as always), so the
+ * caller wraps regrouped_values, not the original columns; the buffers stay valid until the output
+ * is drained. Inside a slice rows keep no particular order (an exchange does not define one either).
+ * *regrouped = 0: the table or the batch does not qualify (array / generic mode, a table that
+ * caches hold, a small batch, encodings other than FLAT, null bitmaps, a fused input filter) and the
+ * batch was probed as vx355_join_probe_add_input does; regrouped_values are untouched.
+ * All join kinds, extra filters and counting joins work on the regrouped batch as on any other.
+ * Used by vx355_join_repartition for every received chunk. Environment: VX355_JOIN_REGROUP = 0 never,
+ * 1 whenever eligible (tests), unset = tables >= 64 MiB and batches >= 4 M rows;
+ * VX355_JOIN_SLICE_BYTES (default 4 MiB). */
+int vx355_join_probe_add_input_regrouped(vx355_join_probe* h, const vx355_batch* batch, void* const* regrouped_values,
+                                         int32_t* regrouped);
 /* Asynchronous form (ABI 7), as for the aggregation and the build (see vx355_agg_add_input_async): the
  * upload of the batch, the probe kernels and the read-back of the output size run on the handle's
  * worker thread; the Driver thread returns at once (exec/Operator.h:285-299) and either polls
@@ -1017,7 +1073,11 @@ void vx355_exchange_destroy(vx355_exchange* x);
  * grouped and chunk i - 1 is probed. For every chunk the sink is called once, after
  * HashProbe::addInput of the rows that landed here: it drains 'probe' (vx355_join_probe_get_output)
  * before it returns; 'received' (device columns) is valid during the call. A non-zero return
- * aborts the join with that status. Collective: every rank calls it with the same 'chunks'. */
+ * aborts the join with that status. Collective: every rank calls it with the same 'chunks'.
+ * 'received' is the operator's input batch - the rows that landed here in an order the library
+ * chooses: since ABI 8 regrouped by slice of the join table when the table is beyond the caches
+ * (vx355_join_probe_add_input_regrouped); mapping_out numbers its rows. With one rank (no links)
+ * nothing is exchanged: the caller's rows go straight to the build and, regrouped, to the probe. */
 typedef int (*vx355_join_chunk_sink)(void* arg, int32_t chunk, const vx355_batch* received, vx355_join_probe* probe);
 int vx355_join_repartition(
     vx355_comm* c,

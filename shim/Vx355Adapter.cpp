@@ -607,6 +607,14 @@ bool toAggSpec(const core::AggregationNode& node, const std::vector<InputBinding
   out->c.aggs = out->fns.data();
   out->c.step = static_cast<int32_t>(node.step());  // same numeric values (core/PlanNode.h:1122-1131)
   out->c.ignore_null_keys = node.ignoreNullKeys() ? 1 : 0;
+  // HashAggregation promises no order of its groups: the reference lists RowContainer order
+  // (exec/GroupingSet.cpp:828-839), which changes with the number of Drivers, with spilling and with
+  // rehashes, and its own tests compare results as multisets (exec/tests/utils/QueryAssertions.h:36-42
+  // MaterializedRowMultiset). Whatever consumes this operator in a plan - a final aggregation, an
+  // exchange, an ORDER BY - does not depend on it, so the library may list groups in table order and
+  // move records without row numbers through its radix passes (VX355_AGG_UNORDERED_OUTPUT:
+  // 18.4 instead of 24.9 ms on BASELINE config 4).
+  out->c.flags = VX355_AGG_UNORDERED_OUTPUT;
   return true;
 }
 
@@ -971,19 +979,45 @@ bool Vx355HashAggregation::partialFull() {
     return false;
   }
   completedAtLastCheck_ = completed;
-  int64_t tableBytes = 0, numGroups = 0;
-  check(vx355_agg_table_bytes(handle_, &tableBytes, &numGroups));
-  if (groupsAtFirstFlush_ > 0) {
-    // The library keeps the flushed table's allocation (GroupingSet::resetTable frees it), so bytes no
-    // longer say how full the table is: flush again when it holds as many groups as it did when it
-    // first outgrew max_partial_aggregation_memory.
-    return numGroups >= groupsAtFirstFlush_;
+  // GroupingSet::isPartialFull (exec/GroupingSet.cpp:190-223) compares the bytes the groups occupy
+  // with max_partial_aggregation_memory every time; the library reports them without the part of its
+  // allocation that a flush left empty (vx355_agg_bytes_in_use).
+  int64_t bytesInUse = 0;
+  check(vx355_agg_bytes_in_use(handle_, &bytesInUse));
+  return bytesInUse > maxPartialMemory_;
+}
+
+void Vx355HashAggregation::recordStats() {
+  if (statsRecorded_ || handle_ == nullptr) {
+    return;
   }
-  if (tableBytes > maxPartialMemory_) {
-    groupsAtFirstFlush_ = std::max<int64_t>(numGroups, 1);
-    return true;
+  statsRecorded_ = true;
+  // HashAggregation::updateRuntimeStats -> BaseHashTable::addRuntimeStats (exec/HashAggregation.cpp:259-280,
+  // exec/HashTable.cpp: the names of exec/HashTable.h:155-159), once, when the operator is done
+  vx355_agg_stats table{};
+  if (vx355_agg_get_stats(handle_, &table) == VX355_OK) {
+    addRuntimeStat(exec::BaseHashTable::kCapacity, RuntimeCounter(table.capacity));
+    addRuntimeStat(exec::BaseHashTable::kNumRehashes, RuntimeCounter(table.num_rehashes));
+    addRuntimeStat(exec::BaseHashTable::kNumDistinct, RuntimeCounter(table.num_groups));
+    addRuntimeStat(exec::BaseHashTable::kHashMode, RuntimeCounter(table.hash_mode));
+    if (table.num_flushes > 0) {
+      addRuntimeStat(exec::HashAggregation::kFlushTimes, RuntimeCounter(table.num_flushes));
+    }
   }
-  return false;
+  vx355_gpu_stats gpu{};
+  if (vx355_agg_get_gpu_stats(handle_, &gpu) == VX355_OK) {
+    recordGpuStats(*this, gpu, table.table_bytes);
+  }
+}
+
+void recordGpuStats(exec::Operator& op, const vx355_gpu_stats& gpu, int64_t tableBytes) {
+  // SURVEY.md section 5 "Metrics": the reference's names plus what only a GPU operator has
+  op.addRuntimeStat("gpu.kernelNanos", RuntimeCounter(gpu.busy_nanos, RuntimeCounter::Unit::kNanos));
+  op.addRuntimeStat("gpu.h2dBytes", RuntimeCounter(gpu.h2d_bytes, RuntimeCounter::Unit::kBytes));
+  op.addRuntimeStat("gpu.d2hBytes", RuntimeCounter(gpu.d2h_bytes, RuntimeCounter::Unit::kBytes));
+  op.addRuntimeStat("gpu.hbmBytesRead", RuntimeCounter(gpu.input_bytes, RuntimeCounter::Unit::kBytes));
+  op.addRuntimeStat("gpu.hbmBytesWritten", RuntimeCounter(gpu.d2h_bytes + tableBytes, RuntimeCounter::Unit::kBytes));
+  op.addRuntimeStat("gpu.kernelLaunches", RuntimeCounter(gpu.launches));
 }
 
 void Vx355HashAggregation::noMoreInput() {
@@ -1014,6 +1048,7 @@ RowVectorPtr Vx355HashAggregation::getOutput() {
       flushing_ = false;  // the table is empty again: GroupingSet::resetTable
     } else {
       finished_ = true;
+      recordStats();
     }
   }
   if (numRows == 0) {
@@ -1033,6 +1068,7 @@ bool Vx355HashAggregation::isFinished() {
 }
 
 void Vx355HashAggregation::close() {
+  recordStats();
   if (handle_ != nullptr) {
     vx355_agg_destroy(handle_);
     handle_ = nullptr;

@@ -19,6 +19,7 @@
 #include "velox/common/future/VeloxPromise.h"
 #include "velox/core/PlanNode.h"
 #include "velox/exec/Driver.h"
+#include "velox/exec/HashTable.h"
 #include "velox/exec/Operator.h"
 #include "velox/vector/ComplexVector.h"
 #include "velox/vector/DecodedVector.h"
@@ -148,6 +149,10 @@ bool toAggSpec(const core::AggregationNode& node, AggSpec* out);
 /// copies, transfers and kernels; isBlocked() bounds the batches in flight. noMoreInput and the output
 /// pages are queued too (vx355_agg_no_more_input_async / vx355_agg_get_output_async): isBlocked() hands the
 /// Driver a future that the library's worker fulfils when the page is in the result vector.
+/// The gpu.* runtime stats of one operator: busy nanoseconds, bytes over PCIe in both
+/// directions, input bytes the kernels read, bytes written (output + the operator's table), launches.
+void recordGpuStats(exec::Operator& op, const vx355_gpu_stats& gpu, int64_t tableBytes);
+
 class Vx355HashAggregation : public exec::Operator {
  public:
   Vx355HashAggregation(
@@ -174,6 +179,8 @@ class Vx355HashAggregation : public exec::Operator {
   static void check(int status);
   void releaseCompleted();
   bool partialFull();
+  /// hashtable.* (exec/HashTable.h:155-159) and gpu.* runtime stats, once, when the operator is done.
+  void recordStats();
   bool wantsOutput() const {
     return !finished_ && (noMoreInput_ || flushing_);
   }
@@ -189,7 +196,7 @@ class Vx355HashAggregation : public exec::Operator {
   bool flushing_{false};
   bool finished_{false};
   int64_t completedAtLastCheck_{0};
-  int64_t groupsAtFirstFlush_{0};
+  bool statsRecorded_{false};
   // batches handed to the library and not yet reported complete: (ticket, input, decoded view)
   struct InFlight {
     int64_t ticket;

@@ -4,6 +4,7 @@
 #include <thread>
 
 #include <algorithm>
+#include <chrono>
 
 #include "velox/core/QueryConfig.h"
 #include "velox/exec/FilterProject.h"
@@ -131,6 +132,16 @@ void Vx355JoinTables::publish(const Key& key, vx355_join_table* table) {
   }
 }
 
+bool Vx355JoinTables::firstToFilter(const Key& key, int32_t channel) {
+  std::lock_guard<std::mutex> lock(mutex_);
+  auto& channels = entries_[key].filteredChannels;
+  if (std::find(channels.begin(), channels.end(), channel) != channels.end()) {
+    return false;
+  }
+  channels.push_back(channel);
+  return true;
+}
+
 bool Vx355JoinTables::accepted(const Key& key, const std::function<bool()>& decide) {
   std::lock_guard<std::mutex> l(mutex_);
   auto it = entries_.find(key);
@@ -251,6 +262,7 @@ void Vx355HashBuild::noMoreInput() {
     others.push_back(build->handle());
   }
   vx355_join_table* table = nullptr;
+  const auto buildStart = std::chrono::steady_clock::now();
   const int status =
       vx355_join_build_finish(handle_, others.data(), static_cast<int32_t>(others.size()), &table);
   // "the last peer is responsible for the promises' fulfillment even in case of an exception"
@@ -259,6 +271,21 @@ void Vx355HashBuild::noMoreInput() {
     promise.setValue();
   }
   check(status);
+  {
+    // HashBuild::addRuntimeStats (exec/HashBuild.cpp:953-957,1103-1145): the table's numbers under the
+    // reference's names, the time of the build, and what the build cost the GPU
+    const auto buildNanos = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - buildStart).count();
+    vx355_join_table_stats stats{};
+    check(vx355_join_table_get_stats(table, &stats));
+    addRuntimeStat(exec::BaseHashTable::kCapacity, RuntimeCounter(stats.capacity));
+    addRuntimeStat(exec::BaseHashTable::kNumRehashes, RuntimeCounter(0));  // built once from all rows: never rehashed
+    addRuntimeStat(exec::BaseHashTable::kNumDistinct, RuntimeCounter(stats.num_distinct));
+    addRuntimeStat(exec::BaseHashTable::kHashMode, RuntimeCounter(stats.hash_mode));
+    addRuntimeStat(exec::BaseHashTable::kBuildWallNanos, RuntimeCounter(buildNanos, RuntimeCounter::Unit::kNanos));
+    vx355_gpu_stats gpu{};
+    check(vx355_join_build_get_gpu_stats(handle_, &gpu));
+    recordGpuStats(*this, gpu, stats.capacity * 16);
+  }
   Vx355JoinTables::instance().publish(key_, table);
   for (auto& peer : peers) {
     static_cast<Vx355HashBuild*>(peer->findOperator(planNodeId()))->markFinished();
@@ -342,7 +369,66 @@ exec::BlockingReason Vx355HashProbe::isBlocked(ContinueFuture* future) {
   }
   check(vx355_join_probe_set_output_batch_bytes(
       handle_, static_cast<int64_t>(operatorCtx_->driverCtx()->queryConfig().preferredOutputBatchBytes())));
+  // exec/HashProbe.cpp:578-596: the join kinds whose unmatched probe rows come out of nothing, a table
+  // that is not in generic hash mode (its keys have value statistics) and is not empty
+  vx355_join_table_stats stats{};
+  check(vx355_join_table_get_stats(table_, &stats));
+  const bool filterable = plan_.type == VX355_JOIN_INNER || plan_.type == VX355_JOIN_LEFT_SEMI_FILTER ||
+      plan_.type == VX355_JOIN_COUNTING_LEFT_SEMI_FILTER || plan_.type == VX355_JOIN_RIGHT_SEMI_FILTER ||
+      (plan_.type == VX355_JOIN_RIGHT_SEMI_PROJECT && !plan_.nullAware) || plan_.type == VX355_JOIN_RIGHT ||
+      plan_.type == VX355_JOIN_RIGHT_ANTI;
+  if (filterable && stats.num_distinct > 0 && stats.hash_mode != 0 /* kHash */ &&
+      operatorCtx_->driverCtx()->queryConfig().hashProbeDynamicFilterPushdownEnabled()) {
+    pushdownDynamicFilters();
+  }
   return exec::BlockingReason::kNotBlocked;
+}
+
+void Vx355HashProbe::pushdownDynamicFilters() {
+  auto* driver = operatorCtx_->driverCtx()->driver;
+  const std::vector<column_index_t> keyChannels(plan_.probeKeys.begin(), plan_.probeKeys.end());
+  driver->pushdownFilters(this, keyChannels, [&](column_index_t key, common::FilterPtr& filter) {
+    vx355_key_filter described{};
+    check(vx355_join_table_key_filter(table_, static_cast<int32_t>(key), &described));
+    if (described.kind == VX355_KEY_FILTER_NONE) {
+      return false;  // a key kind without value statistics (VectorHasher::getFilter returns nullptr)
+    }
+    if (!Vx355JoinTables::instance().firstToFilter(key_, static_cast<int32_t>(key))) {
+      return true;  // a peer made it: the driver only installs the merged filter on this pipeline's scan
+    }
+    if (described.kind == VX355_KEY_FILTER_VALUES) {
+      // VectorHasher::getFilter (exec/VectorHasher.cpp:731-780) -> common::createBigintValues: a BigintRange
+      // when the values are consecutive, else a bitmask or a hash table
+      std::vector<int64_t> values(static_cast<size_t>(std::max<int64_t>(described.num_distinct, 1)));
+      int64_t count = 0;
+      check(vx355_join_table_key_filter_values(
+          table_, static_cast<int32_t>(key), values.data(), static_cast<int64_t>(values.size()), VX355_MEM_HOST, &count));
+      values.resize(static_cast<size_t>(count));
+      filter = common::createBigintValues(values, /*nullAllowed=*/false);
+    } else {
+      // more than kMaxDistinct values: the split-block Bloom filter of exec/HashTable.cpp:1133-1188, whose
+      // blocks the library computes bit for bit as inserting every build value on the CPU would
+      constexpr int32_t lanes = sizeof(SplitBlockBloomFilter::Block) / sizeof(uint32_t);
+      auto bloom = std::make_shared<common::BigintValuesUsingBloomFilter>(described.num_distinct, /*nullAllowed=*/false);
+      check(vx355_join_table_key_filter_bloom(
+          table_, static_cast<int32_t>(key), lanes, reinterpret_cast<uint32_t*>(bloom->mutableBlocks()),
+          common::BigintValuesUsingBloomFilter::numBlocks(described.num_distinct), VX355_MEM_HOST));
+      addRuntimeStat("bloomFilterSize", RuntimeCounter(bloom->blocksByteSize()));  // HashProbe::kBloomFilterSize
+      filter = std::move(bloom);
+    }
+    return true;
+  });
+}
+
+void Vx355HashProbe::recordStats() {
+  if (statsRecorded_ || handle_ == nullptr) {
+    return;
+  }
+  statsRecorded_ = true;
+  vx355_gpu_stats gpu{};
+  if (vx355_join_probe_get_gpu_stats(handle_, &gpu) == VX355_OK) {
+    recordGpuStats(*this, gpu, 0);
+  }
 }
 
 bool Vx355HashProbe::needsInput() const {
@@ -482,6 +568,7 @@ bool Vx355HashProbe::isFinished() {
 }
 
 void Vx355HashProbe::close() {
+  recordStats();
   if (handle_ != nullptr) {
     vx355_join_probe_destroy(handle_);
     handle_ = nullptr;

@@ -20,6 +20,7 @@
 #include "Vx355Adapter.h"
 #include "velox/common/future/VeloxPromise.h"
 #include "velox/core/PlanNode.h"
+#include "velox/type/Filter.h"
 
 namespace facebook::velox::vx355 {
 
@@ -41,6 +42,9 @@ class Vx355JoinTables {
   /// Whether the library takes the join of 'key': decided once (by 'decide', a trial
   /// vx355_join_build_create) for all Drivers of both pipelines, so that they decide alike.
   bool accepted(const Key& key, const std::function<bool()>& decide);
+  /// true for the first probe operator of 'key' that asks about join key 'channel': it makes the dynamic
+  /// filter, its peers find it made (HashProbe::dynamicFiltersProducedOnChannels_, exec/HashProbe.cpp:419-446).
+  bool firstToFilter(const Key& key, int32_t channel);
 
  private:
   struct Entry {
@@ -48,6 +52,7 @@ class Vx355JoinTables {
     int32_t probes{0};
     int32_t accepted{-1};  // -1 = not decided yet
     std::vector<ContinuePromise> promises;
+    std::vector<int32_t> filteredChannels;
   };
   std::mutex mutex_;
   std::map<Key, Entry> entries_;
@@ -137,6 +142,11 @@ class Vx355HashProbe : public exec::Operator {
   RowVectorPtr fillOutput(int32_t numRows, const BufferPtr& mapping, const int32_t* buildRows,
                           std::vector<VectorPtr>& buildColumns, bool buildSide);
   bool emitsBuildSide() const;
+  /// HashProbe::pushdownDynamicFilters (exec/HashProbe.cpp:408-457): one filter per join key whose column an
+  /// upstream operator accepts filters on (Driver::pushdownFilters walks there through identity projections),
+  /// made from the finished table: value list -> common::createBigintValues, or the table's Bloom blocks.
+  void pushdownDynamicFilters();
+  void recordStats();
 
   const JoinPlan plan_;
   Vx355JoinTables::Key key_;
@@ -147,6 +157,7 @@ class Vx355HashProbe : public exec::Operator {
   std::unique_ptr<DecodedBatch> decoded_;
   bool inputDrained_{true};
   bool lastProber_{false}, buildSideDone_{false}, finished_{false};
+  bool statsRecorded_{false};
   // The page of output the library's worker is filling (vx355_join_probe_get_output_async): queued by
   // isBlocked() behind the batch, handed to the Driver by getOutput() when the callback has fired.
   struct Page {

@@ -7,7 +7,11 @@
 //      intermediates -> final HashAggregation; and the same with the FilterProject left on the CPU
 //      side (unfused), with a tiny max_partial_aggregation_memory so that the flush path runs.
 //   2. a two-pipeline inner join with build payload through Vx355HashBuild / Vx355HashProbe and the
-//      table rendezvous.
+//      table rendezvous; with a scan stand-in in front of the probe that accepts dynamic filters
+//      (HashProbe::pushdownDynamicFilters, exec/HashProbe.cpp:408-457): a value filter for 50 000 build
+//      keys, the table's Bloom blocks for 150 000.
+//   3. the runtime stats of every operator: the reference's hashtable.* names (exec/HashTable.h:155-163),
+//      flushTimes, dynamicFiltersProduced / Accepted, and the gpu.* counters of SURVEY.md section 5.
 // Expected values come from plain loops over the same host data (all arithmetic exact in DOUBLE:
 // prices are multiples of 1/4, discounts and taxes multiples of 1/4).
 #include <cmath>
@@ -194,6 +198,77 @@ class TestFilterProject : public exec::Operator {
   }
 };
 
+/// A TableScan stand-in at the head of the probe pipeline: passes its input on, accepts dynamic filters
+/// (exec/Operator.h:315-329; TableScan::addDynamicFilterLocked hands them to the connector's reader) and
+/// applies them to the rows it passes on, as a scan would.
+class TestScan : public exec::Operator {
+ public:
+  TestScan(int32_t id, exec::DriverCtx* ctx, const std::shared_ptr<const core::ValuesNode>& node)
+      : Operator(ctx, node->outputType(), id, node->id(), "TestScan") {}
+  bool canAddDynamicFilter() const override {
+    return true;
+  }
+  void addDynamicFilterLocked(const core::PlanNodeId& producer, const exec::PushdownFilters& filters) override {
+    producer_ = producer;
+    for (const auto& [channel, filter] : filters.filters) {
+      filters_[channel] = filter;
+    }
+  }
+  bool needsInput() const override {
+    return input_ == nullptr;
+  }
+  void addInput(RowVectorPtr input) override {
+    input_ = std::move(input);
+  }
+  RowVectorPtr getOutput() override {
+    if (input_ == nullptr) {
+      return nullptr;
+    }
+    auto in = std::move(input_);
+    input_ = nullptr;
+    if (filters_.empty()) {
+      return in;
+    }
+    std::vector<vector_size_t> selected;
+    for (vector_size_t i = 0; i < in->size(); ++i) {
+      bool pass = true;
+      for (const auto& [channel, filter] : filters_) {
+        pass = pass && filter->testInt64(in->childAt(channel)->asFlatVector<int64_t>()->valueAt(i));
+      }
+      if (pass) {
+        selected.push_back(i);
+      }
+    }
+    rowsDropped += in->size() - static_cast<int64_t>(selected.size());
+    if (selected.empty()) {
+      return nullptr;
+    }
+    const auto n = static_cast<vector_size_t>(selected.size());
+    auto out = std::static_pointer_cast<RowVector>(BaseVector::create(outputType_, n, pool()));
+    for (vector_size_t j = 0; j < n; ++j) {
+      out->childAt(0)->asFlatVector<int64_t>()->set(j, in->childAt(0)->asFlatVector<int64_t>()->valueAt(selected[j]));
+      out->childAt(1)->asFlatVector<double>()->set(j, in->childAt(1)->asFlatVector<double>()->valueAt(selected[j]));
+      out->childAt(2)->asFlatVector<int32_t>()->set(j, in->childAt(2)->asFlatVector<int32_t>()->valueAt(selected[j]));
+    }
+    return out;
+  }
+  exec::BlockingReason isBlocked(ContinueFuture*) override {
+    return exec::BlockingReason::kNotBlocked;
+  }
+  bool isFinished() override {
+    return noMoreInput_ && input_ == nullptr;
+  }
+  std::map<column_index_t, common::FilterPtr> filters_;
+  core::PlanNodeId producer_;
+  int64_t rowsDropped{0};
+};
+
+int64_t statSum(const exec::Operator& op, const std::string& name) {
+  const auto stats = op.statsCopy();
+  const auto it = stats.runtimeStats.find(name);
+  return it == stats.runtimeStats.end() ? -1 : it->second.sum;
+}
+
 int checkQ1(const std::vector<RowVectorPtr>& finals, const Lineitem& data) {
   std::map<std::pair<std::string, std::string>, int> seen;
   for (const auto& page : finals) {
@@ -244,6 +319,16 @@ int testQ1(bool fusedVariant, uint64_t maxPartialMemory, int* flushes) {
   auto partials = runPipeline(*d0, data.batches);
   EXPECT(!partials.empty());
   *flushes = static_cast<int>(partials.size());
+  {
+    // runtime stats of the partial aggregation (recorded when it finished): the reference's names and the gpu.* ones
+    const auto& agg = *ops0.back();
+    EXPECT(statSum(agg, "hashtable.capacity") > 0 && statSum(agg, "hashtable.numRehashes") >= 0);
+    EXPECT(statSum(agg, "hashtable.hashMode") >= 0 && statSum(agg, "hashtable.numDistinct") >= 0);
+    EXPECT(statSum(agg, "gpu.kernelNanos") > 0 && statSum(agg, "gpu.kernelLaunches") > 0);
+    EXPECT(statSum(agg, "gpu.h2dBytes") >= 400000 * 8 && statSum(agg, "gpu.hbmBytesRead") >= statSum(agg, "gpu.h2dBytes"));
+    EXPECT(statSum(agg, "gpu.d2hBytes") > 0 && statSum(agg, "gpu.hbmBytesWritten") >= statSum(agg, "gpu.d2hBytes"));
+    EXPECT((statSum(agg, "flushTimes") >= 1) == (maxPartialMemory == 1));
+  }
   for (const auto& page : partials) {
     // the partial step's output type: avg travels as ROW(DOUBLE sum, BIGINT count)
     EXPECT(page->childrenSize() == 10 && page->childAt(6)->type()->isRow());
@@ -262,7 +347,7 @@ int testQ1(bool fusedVariant, uint64_t maxPartialMemory, int* flushes) {
   return checkQ1(finals, data);
 }
 
-int testJoin(bool withFilter) {
+int testJoin(bool withFilter, bool withScan = false, int64_t numOrders = 50000) {
   // orders (build): o_orderkey, o_orderdate, o_shippriority; lineitem (probe): l_orderkey, l_extendedprice, l_shipdate.
   // withFilter: TPC-H Q3's shape - FilterProject(l_shipdate > DATE) in front of the probe (a FilterNode alone), which
   // the adapter folds into the probe operator (vx355_join_probe_set_input_filter).
@@ -284,7 +369,7 @@ int testJoin(bool withFilter) {
       std::vector<core::FieldAccessTypedExprPtr>{shimtest::field(buildNode->outputType(), "o_orderkey")}, nullptr, probeSource, buildNode,
       outputType);
   std::mt19937_64 rng(7);
-  const int64_t numOrders = 50000, numLineitems = 300000;
+  const int64_t numLineitems = 300000;
   std::map<int64_t, std::pair<int32_t, int32_t>> orders;
   std::vector<RowVectorPtr> buildBatches, probeBatches;
   for (int64_t begin = 0; begin < numOrders; begin += 10000) {
@@ -314,7 +399,8 @@ int testJoin(bool withFilter) {
     }
     probeBatches.push_back(batch);
   }
-  auto task = std::make_shared<exec::Task>(withFilter ? "join_task_filter" : "join_task");
+  auto task = std::make_shared<exec::Task>(std::string(withFilter ? "join_task_filter" : "join_task") + (withScan ? "_scan" : "") +
+                                           std::to_string(numOrders));
   task->mutableQueryConfig().preferredBatchRows = 4096;
   // build pipeline ends in the join node (its consumer)
   auto db = newDriver(task, 1);
@@ -324,28 +410,86 @@ int testJoin(bool withFilter) {
   db->mutableOperators().push_back(std::make_unique<exec::HashBuild>(0, db->driverCtx(), join));
   auto dp = newDriver(task, 0);
   exec::DriverFactory fp;
+  int32_t next = 0;
+  if (withScan) {
+    dp->mutableOperators().push_back(std::make_unique<TestScan>(next++, dp->driverCtx(), probeNode));
+  }
   if (withFilter) {
     fp.planNodes = {probeNode, filterNode, join};
-    dp->mutableOperators().push_back(std::make_unique<exec::FilterProject>(0, dp->driverCtx(), filterNode, nullptr));
-    dp->mutableOperators().push_back(std::make_unique<exec::HashProbe>(1, dp->driverCtx(), join));
+    dp->mutableOperators().push_back(std::make_unique<exec::FilterProject>(next++, dp->driverCtx(), filterNode, nullptr));
+    dp->mutableOperators().push_back(std::make_unique<exec::HashProbe>(next++, dp->driverCtx(), join));
   } else {
     fp.planNodes = {probeNode, join};
-    dp->mutableOperators().push_back(std::make_unique<exec::HashProbe>(0, dp->driverCtx(), join));
+    dp->mutableOperators().push_back(std::make_unique<exec::HashProbe>(next++, dp->driverCtx(), join));
   }
   // (Velox creates the Drivers of every pipeline before any of them runs)
   EXPECT(adaptDriver(fp, *dp));
   EXPECT(adaptDriver(fb, *db));
   // (with the filter: FilterProject and HashProbe became ONE operator)
-  EXPECT(dp->operators().size() == 1 && dp->operators()[0]->operatorId() == 0);
-  EXPECT(dp->operators()[0]->operatorType() == "Vx355HashProbe" && db->operators()[0]->operatorType() == "Vx355HashBuild");
+  const size_t probeAt = withScan ? 1 : 0;
+  EXPECT(dp->operators().size() == probeAt + 1 && dp->operators()[probeAt]->operatorId() == static_cast<int32_t>(probeAt));
+  EXPECT(dp->operators()[probeAt]->operatorType() == "Vx355HashProbe" && db->operators()[0]->operatorType() == "Vx355HashBuild");
   // the probe is blocked until the table is published
   ContinueFuture waitForBuild = ContinueFuture::makeEmpty();
-  EXPECT(dp->operators()[0]->isBlocked(&waitForBuild) == exec::BlockingReason::kWaitForJoinBuild);
+  EXPECT(dp->operators()[probeAt]->isBlocked(&waitForBuild) == exec::BlockingReason::kWaitForJoinBuild);
   EXPECT(waitForBuild.valid() && !waitForBuild.isReady());
   auto none = runPipeline(*db, buildBatches);
   EXPECT(none.empty());
   EXPECT(waitForBuild.isReady());
+  {
+    // HashBuild::addRuntimeStats: the table under the reference's names, the build's wall time, the gpu.* counters
+    const auto& build = *db->operators()[0];
+    EXPECT(statSum(build, "hashtable.numDistinct") == numOrders && statSum(build, "hashtable.capacity") >= numOrders);
+    EXPECT(statSum(build, "hashtable.hashMode") >= 0 && statSum(build, "hashtable.buildWallNanos") > 0);
+    EXPECT(statSum(build, "gpu.kernelNanos") > 0 && statSum(build, "gpu.h2dBytes") >= numOrders * 16);
+  }
   auto pages = runPipeline(*dp, probeBatches);
+  {
+    const auto& probe = *dp->operators()[probeAt];
+    // (behind a scan that applies the dynamic filter the probe sees the surviving rows only)
+    EXPECT(statSum(probe, "gpu.kernelNanos") > 0 && statSum(probe, "gpu.hbmBytesRead") >= (withScan ? 8 : numLineitems * 8));
+    if (withScan) {
+      // the key's filter reached the scan: made from the table (<= 100 000 distinct values: the value list through
+      // common::createBigintValues; more: the table's Bloom blocks), counted on both operators, applied by the scan
+      auto* scan = dynamic_cast<TestScan*>(dp->operators()[0]);
+      EXPECT(scan != nullptr && scan->filters_.size() == 1 && scan->filters_.count(0) == 1 && scan->producer_ == "join");
+      EXPECT(statSum(probe, "dynamicFiltersProduced") == 1 && statSum(*scan, "dynamicFiltersAccepted") == 1);
+      const auto& filter = scan->filters_.at(0);
+      if (numOrders <= 100000) {
+        EXPECT(filter->kind() == common::FilterKind::kBigintValuesUsingHashTable);
+        auto* values = dynamic_cast<const common::BigintValuesUsingHashTable*>(filter.get());
+        EXPECT(values != nullptr && static_cast<int64_t>(values->values().size()) == numOrders);
+        EXPECT(values->min() == 1 && values->max() == (numOrders - 1) * 4 + 1);
+        EXPECT(filter->testInt64(5) && !filter->testInt64(6));
+        EXPECT(scan->rowsDropped > numLineitems / 2);   // three probe keys in four have no order
+      } else {
+        EXPECT(filter->kind() == common::FilterKind::kBigintValuesUsingBloomFilter);
+        auto* bloom = dynamic_cast<common::BigintValuesUsingBloomFilter*>(filter.get());
+        EXPECT(bloom != nullptr && bloom->blocksByteSize() == statSum(probe, "bloomFilterSize"));
+        // the blocks hold every build key and reject most others (checked with the library's own tester)
+        std::vector<int64_t> present, absent;
+        for (int64_t i = 0; i < 1000; ++i) {
+          present.push_back(i * 4 + 1);
+          absent.push_back(i * 4 + 2);
+        }
+        for (const auto* keys : {&present, &absent}) {
+          vx355_column column{};
+          column.type_kind = VX355_BIGINT;
+          column.encoding = VX355_FLAT;
+          column.values = keys->data();
+          column.mem = VX355_MEM_HOST;
+          std::vector<uint64_t> passed(16, 0);
+          EXPECT(vx355_bloom_test(reinterpret_cast<const uint32_t*>(bloom->mutableBlocks()), bloom->numBlocksHeld(), 8, &column,
+                                  1000, nullptr, passed.data(), VX355_MEM_HOST) == VX355_OK);
+          int64_t hits = 0;
+          for (uint64_t word : passed) {
+            hits += __builtin_popcountll(word);
+          }
+          EXPECT(keys == &present ? hits == 1000 : hits < 100);
+        }
+      }
+    }
+  }
   int64_t rows = 0;
   for (const auto& page : pages) {
     EXPECT(page->childrenSize() == 4);
@@ -394,6 +538,14 @@ int main() {
       return 1;
     }
     std::printf("ok: FilterProject(l_shipdate > d) folded into Vx355HashProbe\n");
+    if (testJoin(false, /*withScan=*/true) != 0 || testJoin(true, /*withScan=*/true) != 0) {
+      return 1;
+    }
+    std::printf("ok: dynamic filter (value list) pushed from the join table to the probe side's scan\n");
+    if (testJoin(false, /*withScan=*/true, 150000) != 0) {
+      return 1;
+    }
+    std::printf("ok: dynamic filter (Bloom blocks of the table) pushed to the probe side's scan\n");
   } catch (const std::exception& e) {
     std::fprintf(stderr, "FAILED: %s\n", e.what());
     return 1;

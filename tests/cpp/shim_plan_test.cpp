@@ -31,6 +31,8 @@ int testQ1PartialUnfused() {
   auto plan = shimtest::q1Plan(/*filterAsNode=*/true);
   AggSpec spec;
   EXPECT(toAggSpec(*plan.partial, &spec));
+  // a Velox plan never depends on HashAggregation's group order: the binding asks for the cheaper listing
+  EXPECT((spec.c.flags & VX355_AGG_UNORDERED_OUTPUT) != 0);
   EXPECT(spec.c.num_keys == 2 && spec.keyCols[0] == 0 && spec.keyCols[1] == 1);
   EXPECT(spec.keyTypes[0] == VX355_VARCHAR && spec.keyTypes[1] == VX355_VARCHAR);
   EXPECT(spec.c.step == VX355_STEP_PARTIAL);

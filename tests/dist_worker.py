@@ -1,6 +1,8 @@
 """Worker for tests/test_dist_gloo.py: one rank of the sharded aggregation
-(partial step per rank -> all-gather -> final step) on CPU with gloo, with the
-oracle standing in for the GPU operator."""
+(partial step per rank -> all-gather -> final step) over gloo. The operators are the
+oracle's on a box without a GPU (the -m "not gpu" suite: the exchange logic of
+velox_amd/dist.py with world_size 2) and the LIBRARY's when VX355_DIST_IMPL=vx (the
+-m gpu suite: both ranks share GPU 0, the groups travel through torch.distributed)."""
 import os
 import sys
 
@@ -23,10 +25,15 @@ def shard(rank, n=20000):
     return flags, status, qty, price, valid, big
 
 
-def raw_aggs(abi):
-    return [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_AVG, 3, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT),
+def raw_aggs(abi, device=None):
+    aggs = [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_AVG, 3, abi.DOUBLE), (abi.AGG_COUNT_STAR, -1, abi.BIGINT),
             (abi.AGG_MIN, 3, abi.DOUBLE), (abi.AGG_COUNT, 3, abi.DOUBLE), (abi.AGG_MAX, 2, abi.DOUBLE),
             (abi.AGG_SUM, 4, abi.BIGINT), (abi.AGG_MIN, 4, abi.BIGINT), (abi.AGG_MAX, 4, abi.BIGINT)]
+    if device is None:
+        device = os.environ.get("VX355_DIST_IMPL") == "vx"
+    # one device table holds 16 accumulators (DOUBLE sums and BIGINT sums own two words each): the
+    # library refuses the nine-aggregate plan at create time, as it would tell the adapter to
+    return aggs[:7] if device else aggs
 
 
 def batch_for(abi, rank):
@@ -52,9 +59,13 @@ def wide_aggs(abi):
 def run(rank, world, port, out_dir):
     import torch
     import torch.distributed as dist
-    import oracle_lib
     from velox_amd import abi
     from velox_amd import dist as vdist
+    if os.environ.get("VX355_DIST_IMPL") == "vx":
+        from velox_amd import ops as oracle_lib   # the product library is the operator on both ranks
+        oracle_lib.init(0)
+    else:
+        import oracle_lib
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     key_types = [abi.VARCHAR, abi.VARCHAR]
     op = oracle_lib.Aggregation([0, 1], key_types, raw_aggs(abi), abi.STEP_PARTIAL)

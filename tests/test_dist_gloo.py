@@ -8,6 +8,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from velox_amd import abi
 
@@ -23,14 +24,29 @@ def _free_port():
 
 
 def test_two_rank_partial_final_matches_single_process(oracle, tmp_path):
+    _two_rank_partial_final(oracle, tmp_path, None)
+
+
+@pytest.mark.gpu
+def test_two_rank_partial_final_with_the_library_as_the_operator(oracle, tmp_path):
+    """The same two-rank plan with libvx355 (not the oracle) as the operator on both ranks, which share GPU 0:
+    partial aggregation on the GPU, groups through torch.distributed (gloo), final aggregation on the GPU,
+    against the oracle's SINGLE aggregation of all rows - bit for bit, group order included."""
+    _two_rank_partial_final(oracle, tmp_path, "vx")
+
+
+def _two_rank_partial_final(oracle, tmp_path, impl):
     port = _free_port()
     world = 2
+    env = dict(os.environ)
+    if impl:
+        env["VX355_DIST_IMPL"] = impl
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world),
-                               str(port), str(tmp_path)]) for r in range(world)]
+                               str(port), str(tmp_path)], env=env) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=240) == 0
     key_types = [abi.VARCHAR, abi.VARCHAR]
-    single = oracle.Aggregation([0, 1], key_types, dist_worker.raw_aggs(abi), abi.STEP_SINGLE)
+    single = oracle.Aggregation([0, 1], key_types, dist_worker.raw_aggs(abi, impl == "vx"), abi.STEP_SINGLE)
     for r in range(world):
         single.add_input(dist_worker.batch_for(abi, r))
     single.no_more_input()

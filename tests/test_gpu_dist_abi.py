@@ -83,9 +83,16 @@ def test_exchange_destinations_equal_the_cpu_hash_partition(oracle, vx, world):
         assert len(np.unique(want)) == world
 
 
-def test_join_repartition_matches_the_oracle_join(oracle, vx):
+@pytest.mark.parametrize("regroup", [False, True])
+def test_join_repartition_matches_the_oracle_join(oracle, vx, regroup, monkeypatch):
     """vx355_join_repartition (exchange + build, then the probe side in pipelined chunks through
-    the sink) against the oracle's join of the same rows."""
+    the sink) against the oracle's join of the same rows. regroup: every chunk reaches the sink
+    regrouped by slice of the join table (vx355_join_probe_add_input_regrouped, forced here on a
+    small table) - 'received' is then the regrouped batch and the mappings number its rows."""
+    if regroup:
+        monkeypatch.setenv("VX355_JOIN_REGROUP", "1")
+        monkeypatch.setenv("VX355_JOIN_SLICE_BYTES", "65536")
+        monkeypatch.setenv("VX355_JOIN_ARRAY_MAX", "0")
     rng = np.random.default_rng(52)
     nd, nf = 40000, 300001
     pk = rng.permutation(1 << 20)[:nd].astype(np.int64)
@@ -118,8 +125,11 @@ def test_join_repartition_matches_the_oracle_join(oracle, vx):
             got_payload.append(pay.to_host(n).copy())
             if fin:
                 break
+    vx.profile_reset()
+    vx.profile_enable(True)
     table = vx.join_repartition(comm, ([0], [abi.BIGINT], [1], [abi.BIGINT], abi.JOIN_INNER), build,
                                 ([0], abi.JOIN_INNER), probe, 3, sink)
+    vx.profile_enable(False)
     assert seen_chunks == [0, 1, 2] and table.stats().num_rows == nd
     b = oracle.JoinBuild([0], [abi.BIGINT], [1], [abi.BIGINT], abi.JOIN_INNER)
     b.add_input(batch_of([pk, a]))
@@ -134,8 +144,12 @@ def test_join_repartition_matches_the_oracle_join(oracle, vx):
             break
     got = list(zip(np.concatenate(got_keys).tolist(), np.concatenate(got_m).tolist(),
                    np.concatenate(got_payload).tolist()))
-    # one rank, chunks in row order: the same rows in the same order as the single join
-    assert got == want and len(got) > 100000
+    if regroup:
+        assert sorted(got) == sorted(want) and len(got) > 100000
+        assert "k_grp_scatter" in vx.profile()
+    else:
+        # one rank, chunks in row order: the same rows in the same order as the single join
+        assert got == want and len(got) > 100000
 
     def failing(chunk, received, probe_op):
         raise RuntimeError("sink gave up")
@@ -264,3 +278,17 @@ def test_library_exchange_with_several_ranks_on_one_gpu(world, tmp_path):
         assert p.returncode == 0, f"rank {r}: rc {p.returncode}\n{out[-1500:]}\n{err[-3000:]}"
         assert f"commcheck rank {r}/{world} on device 0: ok" in out
         assert f"rank {r}/{world} uneven and empty shards match the oracle" in out
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_process_drives_every_rank(world):
+    """vx355_comm_create_all (one process drives the node, one Driver thread per rank):
+    the repartitioned join and the merged aggregation with uneven and empty shards against the oracle,
+    every rank a thread of ONE process with its own communicator, execution contexts and streams
+    (tests/one_process_ranks_worker.py; the ranks share GPU 0 through the shared-memory transport)."""
+    env = dict(os.environ)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "one_process_ranks_worker.py"), str(world)],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert f"one process, {world} ranks: join and merged aggregation match the oracle on every rank" in r.stdout

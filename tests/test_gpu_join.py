@@ -1244,3 +1244,110 @@ def test_input_filter_is_refused_where_unmatched_probe_rows_come_out(vx):
     p.add_input(batch_of([np.arange(5, dtype=np.int64)]))
     with pytest.raises(vx.Vx355Error):
         p.set_input_filter([(0, abi.CMP_GT, 3)])
+
+
+def _regroup_case(rng, keys, nb, npr, miss_rate):
+    """Build rows with sparse keys (normalized-key mode) and probe rows with misses inside and
+    outside the build side's key range; keys = 1 (BIGINT) or 2 (BIGINT, INTEGER)."""
+    bk = (rng.permutation(1 << 22)[:nb].astype(np.int64) * 104729 + 12345) * (1_000_003 if keys == 1 else 1)
+    bk2 = rng.integers(0, 50, nb).astype(np.int32)    # (two keys: the product of the ranges must fit 2^59)
+    pick = rng.integers(0, nb, npr)
+    miss = rng.random(npr) < miss_rate
+    pk = np.where(miss, np.where(rng.random(npr) < 0.5, bk[pick] + 1, -7), bk[pick]).astype(np.int64)
+    pk2 = bk2[pick]
+    if keys == 2:
+        pk2 = np.where(rng.random(npr) < 0.1, 77, pk2).astype(np.int32)   # out of the second key's range
+    return bk, bk2, pk, pk2
+
+
+@pytest.mark.parametrize("join_type", [abi.JOIN_INNER, abi.JOIN_LEFT, abi.JOIN_ANTI, abi.JOIN_LEFT_SEMI_FILTER])
+@pytest.mark.parametrize("keys,dups,wide_build,lds_build", [(1, False, "1", "1"), (1, False, "0", "0"), (1, True, "1", "1"),
+                                                            (1, True, "0", "1"), (2, False, "0", "1"), (1, False, "1", "0")])
+def test_probe_input_regrouped_by_table_slice(oracle, vx, join_type, keys, dups, wide_build, lds_build, monkeypatch):
+    """vx355_join_probe_add_input_regrouped: every column of the batch (8-, 4-, 2-, 1- and 16-byte
+    values) is moved so that rows probing the same slice of the slot array are adjacent, the operator
+    probes THAT batch. Checked: the moved batch is a permutation of the input rows; mappings ascend and
+    number the moved batch; the joined rows (probe row contents, build row) equal the oracle's as a
+    multiset - unique and duplicate build keys, tables built wide (dependents inline) and narrow, one
+    and two keys, misses inside and outside the key range, four join kinds, output taken in pages."""
+    monkeypatch.setenv("VX355_JOIN_REGROUP", "1")
+    monkeypatch.setenv("VX355_JOIN_SLICE_BYTES", "65536")    # 16-64 slices for a table of this size
+    monkeypatch.setenv("VX355_JOIN_WIDE_BUILD", wide_build)
+    monkeypatch.setenv("VX355_JOIN_LDS_BUILD", lds_build)     # the table assembled group by group in LDS, or slot by slot
+    monkeypatch.setenv("VX355_JOIN_ARRAY_MAX", "0")
+    rng = np.random.default_rng(1000 + keys + 2 * dups)
+    nb, npr = 30_000, 150_001          # five histogram tiles, the last one partial; 74 probe units
+    bk, bk2, pk, pk2 = _regroup_case(rng, keys, nb, npr, 0.2)
+    if dups:
+        bk[nb // 2:] = bk[: nb - nb // 2]
+    d0 = rng.integers(-1 << 60, 1 << 60, nb).astype(np.int64)
+    d1 = rng.random(nb)
+    pv = rng.random(npr)
+    pi = rng.integers(-1 << 30, 1 << 30, npr).astype(np.int32)
+    ps = rng.integers(-1 << 14, 1 << 14, npr).astype(np.int16)
+    pt = rng.integers(-100, 100, npr).astype(np.int8)
+    pstr = [b"%09d" % i for i in range(npr)]        # inline strings: the row's own number
+    key_cols = [0, 1][:keys]
+    key_types = [abi.BIGINT, abi.INTEGER][:keys]
+    build = batch_of([bk, bk2, d0, d1])
+    probe_cols = [pk, pk2, pv, pi, ps, pt, pstr]
+    probe_batch = batch_of(probe_cols)
+    to, _ = _build(oracle, [[build]], key_cols, key_types, [2, 3], [abi.BIGINT, abi.DOUBLE], join_type)
+    po = oracle.JoinProbe(to, key_cols, join_type)
+    po.add_input(probe_batch)
+    e_pairs, e_payload = _drain(po, 1 << 20)
+    want = sorted((m, r, pay) for (m, r), pay in zip(e_pairs, e_payload))
+
+    vx.profile_reset()
+    vx.profile_enable(True)
+    table, _b = _build(vx, [[vx.to_device(build)]], key_cols, key_types, [2, 3], [abi.BIGINT, abi.DOUBLE], join_type)
+    vx.profile_enable(False)
+    vx_build_prof = vx.profile()
+    st = table.stats()
+    assert st.hash_mode == abi.MODE_NORMALIZED_KEY and st.has_duplicates == (1 if dups else 0)
+    assert st.num_distinct == len(np.unique(bk))
+    probe = vx.JoinProbe(table, key_cols, join_type)
+    widths = [8, 4, 8, 4, 2, 1, 16]
+    outs = [vx.DeviceArray(npr * w, np.uint8) for w in widths]
+    vx.profile_reset()
+    vx.profile_enable(True)
+    assert probe.add_input_regrouped(vx.to_device(probe_batch), [o.ptr for o in outs]) is True
+    vx.profile_enable(False)
+    prof = vx.profile()
+    assert "k_grp_scatter" in prof and "k_join_probe_grouped" in prof and "k_widen_slots" not in prof
+    assert ("k_lds_build" in vx_build_prof) == (lds_build == "1")
+    moved = [o.to_host(npr * w) for o, w in zip(outs, widths)]
+    mk = moved[0].view(np.int64)
+    row_of = np.array([int(bytes(moved[6][i * 16 + 4: i * 16 + 13])) for i in range(npr)])   # StringView: size, 12 bytes
+    assert sorted(row_of.tolist()) == list(range(npr))                  # a permutation of the input rows ...
+    assert (mk == pk[row_of]).all() and (moved[1].view(np.int32) == pk2[row_of]).all()
+    assert (moved[2].view(np.float64) == pv[row_of]).all() and (moved[3].view(np.int32) == pi[row_of]).all()
+    assert (moved[4].view(np.int16) == ps[row_of]).all() and (moved[5].view(np.int8) == pt[row_of]).all()
+    pairs, payload = _drain(probe, 40_000)                              # ... ascending mappings (asserted in _drain)
+    _contiguous(pairs)
+    got = sorted((int(row_of[m]), r, pay) for (m, r), pay in zip(pairs, payload))
+    assert got == want      # (all rows of a duplicate chain are listed; sorted, so their order does not matter)
+    assert len(got) > 10_000
+
+
+def test_probe_input_is_not_regrouped_when_the_table_does_not_qualify(oracle, vx, monkeypatch):
+    """Array-mode tables, small tables / batches under the adaptive rule, columns with null bitmaps:
+    the batch is probed as it came, the caller's buffers stay untouched, results as add_input's."""
+    rng = np.random.default_rng(5)
+    nb, npr = 20_000, 60_000
+    bk = rng.permutation(1 << 18)[:nb].astype(np.int64)
+    pay = rng.integers(0, 1 << 40, nb).astype(np.int64)
+    pk = rng.integers(0, 1 << 18, npr).astype(np.int64)
+    pvalid = rng.random(npr) > 0.1
+    for env, cols, valids in (("1", [pk], None), ("-1", [pk], None), ("1", [pk], [pvalid])):
+        monkeypatch.setenv("VX355_JOIN_REGROUP", env)
+        if valids is not None:
+            monkeypatch.setenv("VX355_JOIN_ARRAY_MAX", "0")
+        table, _ = _build(vx, [[batch_of([bk, pay])]], [0], [abi.BIGINT], [1], [abi.BIGINT], abi.JOIN_INNER)
+        a, b = vx.JoinProbe(table, [0], abi.JOIN_INNER), vx.JoinProbe(table, [0], abi.JOIN_INNER)
+        out = vx.DeviceArray(np.full(npr, -1, dtype=np.int64))
+        batch = vx.to_device(batch_of(cols, valids))
+        assert a.add_input_regrouped(batch, [out.ptr]) is False
+        b.add_input(batch)
+        assert _drain(a, 50_000) == _drain(b, 50_000)
+        assert (out.to_host(npr) == -1).all()

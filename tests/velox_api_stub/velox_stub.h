@@ -33,7 +33,9 @@
 #include <stdexcept>
 #include <string>
 #include <string_view>
+#include <limits>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 namespace facebook::velox {
@@ -1444,12 +1446,177 @@ class QueryConfig {
   int32_t abandonPartialAggregationMinPct() const {
     return 80;
   }
+  bool hashProbeDynamicFilterPushdownEnabled() const {  // core/QueryConfig.h
+    return dynamicFilterPushdown;
+  }
+  bool dynamicFilterPushdown{true};
   uint64_t maxPartialAggregationMemory{1L << 24};
   uint64_t preferredBatchBytes{10UL << 20};
   vector_size_t preferredBatchRows{1024};
 };
 
 }  // namespace core
+
+// ---- type/Filter.h, common/base/SplitBlockBloomFilter.h, common/base/RuntimeMetrics.h -------------
+// What HashProbe::pushdownDynamicFilters (exec/HashProbe.cpp:408-457) hands to a scan: declarations with
+// the reference's names and signatures, the minimum of behaviour a test needs to look inside.
+
+struct RuntimeCounter {  // common/base/RuntimeMetrics.h:35-42
+  enum class Unit { kNone, kNanos, kBytes };
+  int64_t value;
+  Unit unit{Unit::kNone};
+  explicit RuntimeCounter(int64_t _value, Unit _unit = Unit::kNone) : value(_value), unit(_unit) {}
+};
+
+struct RuntimeMetric {  // common/base/RuntimeMetrics.h:44-70
+  RuntimeCounter::Unit unit;
+  int64_t sum{0};
+  uint64_t count{0};
+  int64_t min{std::numeric_limits<int64_t>::max()};
+  int64_t max{std::numeric_limits<int64_t>::min()};
+  explicit RuntimeMetric(RuntimeCounter::Unit _unit = RuntimeCounter::Unit::kNone) : unit(_unit) {}
+  explicit RuntimeMetric(int64_t value, RuntimeCounter::Unit _unit = RuntimeCounter::Unit::kNone)
+      : unit(_unit), sum{value}, count{1}, min{value}, max{value} {}
+  void addValue(int64_t value) {
+    sum += value;
+    ++count;
+    min = std::min(min, value);
+    max = std::max(max, value);
+  }
+};
+
+struct SplitBlockBloomFilter {  // common/base/SplitBlockBloomFilter.h: a block is one xsimd::batch<uint32_t>
+  struct Block {
+    uint32_t words[8];
+  };
+  static int64_t numBlocks(int64_t numElements, double falsePositive);  // (below: the library's restatement)
+};
+extern "C" int64_t vx355_bloom_num_blocks(int64_t num_elements, double false_positive, int32_t lanes);
+inline int64_t SplitBlockBloomFilter::numBlocks(int64_t numElements, double falsePositive) {
+  return vx355_bloom_num_blocks(numElements, falsePositive, sizeof(Block) / sizeof(uint32_t));
+}
+
+namespace common {
+
+enum class FilterKind { kBigintRange, kBigintValuesUsingHashTable, kBigintValuesUsingBitmask, kBigintValuesUsingBloomFilter, kBigintMultiRange };
+
+class Filter {  // type/Filter.h
+ public:
+  Filter(bool deterministic, bool nullAllowed, FilterKind kind) : nullAllowed_(nullAllowed), deterministic_(deterministic), kind_(kind) {}
+  virtual ~Filter() = default;
+  FilterKind kind() const {
+    return kind_;
+  }
+  bool nullAllowed() const {
+    return nullAllowed_;
+  }
+  virtual bool testInt64(int64_t value) const = 0;
+  /// Filter::merge (type/Filter.cpp): 'filter' AND whatever 'target' already holds.
+  static void merge(const std::shared_ptr<Filter>& filter, std::shared_ptr<Filter>& target);
+
+ protected:
+  const bool nullAllowed_;
+  const bool deterministic_;
+  const FilterKind kind_;
+};
+using FilterPtr = std::shared_ptr<Filter>;
+
+class BigintRange final : public Filter {
+ public:
+  BigintRange(int64_t lower, int64_t upper, bool nullAllowed)
+      : Filter(true, nullAllowed, FilterKind::kBigintRange), lower_(lower), upper_(upper) {}
+  bool testInt64(int64_t value) const final {
+    return value >= lower_ && value <= upper_;
+  }
+  int64_t lower() const {
+    return lower_;
+  }
+  int64_t upper() const {
+    return upper_;
+  }
+
+ private:
+  const int64_t lower_, upper_;
+};
+
+class BigintValuesUsingHashTable final : public Filter {
+ public:
+  BigintValuesUsingHashTable(int64_t min, int64_t max, const std::vector<int64_t>& values, bool nullAllowed)
+      : Filter(true, nullAllowed, FilterKind::kBigintValuesUsingHashTable), min_(min), max_(max), values_(values) {
+    std::sort(values_.begin(), values_.end());
+  }
+  bool testInt64(int64_t value) const final {
+    return std::binary_search(values_.begin(), values_.end(), value);
+  }
+  int64_t min() const {
+    return min_;
+  }
+  int64_t max() const {
+    return max_;
+  }
+  const std::vector<int64_t>& values() const {
+    return values_;
+  }
+
+ private:
+  const int64_t min_, max_;
+  std::vector<int64_t> values_;
+};
+
+/// type/Filter.cpp:1052-1114: a BigintRange when the values are consecutive, else a value-set filter
+/// (the reference picks bitmask or hash table by density; the stand-in keeps one class).
+inline std::unique_ptr<Filter> createBigintValues(const std::vector<int64_t>& values, bool nullAllowed) {
+  VELOX_CHECK(!values.empty(), "createBigintValues: no values");
+  const auto [lo, hi] = std::minmax_element(values.begin(), values.end());
+  if (static_cast<uint64_t>(*hi) - static_cast<uint64_t>(*lo) + 1 == values.size()) {
+    return std::make_unique<BigintRange>(*lo, *hi, nullAllowed);
+  }
+  return std::make_unique<BigintValuesUsingHashTable>(*lo, *hi, values, nullAllowed);
+}
+
+class BigintValuesUsingBloomFilter final : public Filter {  // type/Filter.h:1294-1360
+ public:
+  static int64_t numBlocks(int64_t capacity) {
+    return SplitBlockBloomFilter::numBlocks(capacity, 0.01);
+  }
+  BigintValuesUsingBloomFilter(int64_t capacity, bool nullAllowed)
+      : Filter(true, nullAllowed, FilterKind::kBigintValuesUsingBloomFilter), blocks_(numBlocks(capacity)) {}
+  bool testInt64(int64_t /*value*/) const final {
+    return true;  // (the test checks the blocks through vx355_bloom_test instead)
+  }
+  int64_t blocksByteSize() const {
+    return static_cast<int64_t>(blocks_.size() * sizeof(SplitBlockBloomFilter::Block));
+  }
+  /// NOT in the reference: the accessor INTEGRATION.md section 3 asks a maintainer to add (two lines) so that
+  /// blocks computed elsewhere can be installed; upstream only offers insert(value).
+  SplitBlockBloomFilter::Block* mutableBlocks() {
+    return blocks_.data();
+  }
+  int64_t numBlocksHeld() const {
+    return static_cast<int64_t>(blocks_.size());
+  }
+
+ private:
+  std::vector<SplitBlockBloomFilter::Block> blocks_;
+};
+
+/// (stand-in for the merged filter types of the reference: both must pass)
+class AndOfFilters final : public Filter {
+ public:
+  AndOfFilters(FilterPtr a, FilterPtr b) : Filter(true, false, FilterKind::kBigintMultiRange), a_(std::move(a)), b_(std::move(b)) {}
+  bool testInt64(int64_t value) const final {
+    return a_->testInt64(value) && b_->testInt64(value);
+  }
+
+ private:
+  FilterPtr a_, b_;
+};
+
+inline void Filter::merge(const FilterPtr& filter, FilterPtr& target) {
+  target = target ? std::make_shared<AndOfFilters>(target, filter) : filter;
+}
+
+}  // namespace common
 
 // ---- exec/ -------------------------------------------------------------------------------------
 
@@ -1528,6 +1695,31 @@ struct IdentityProjection {
   column_index_t outputChannel;
 };
 
+/// exec/Driver.h:344-355 (folly containers replaced by std ones).
+struct PushdownFilters {
+  std::unordered_map<column_index_t, common::FilterPtr> filters;
+  std::unordered_set<column_index_t> dynamicFilteredColumns;
+  bool staticFiltersInitialized = false;
+};
+
+/// exec/OperatorStats.h, the part the shim writes: runtime stats by name.
+struct OperatorStats {
+  std::unordered_map<std::string, RuntimeMetric> runtimeStats;
+  void addRuntimeStat(std::string_view name, const RuntimeCounter& value) {
+    auto it = runtimeStats.find(std::string(name));
+    if (it == runtimeStats.end()) {
+      runtimeStats.emplace(std::string(name), RuntimeMetric(value.value, value.unit));
+    } else {
+      it->second.addValue(value.value);
+    }
+  }
+};
+
+struct DriverStats {  // exec/Driver.h
+  static constexpr std::string_view kDynamicFiltersProduced{"dynamicFiltersProduced"};
+  static constexpr std::string_view kDynamicFiltersAccepted{"dynamicFiltersAccepted"};
+};
+
 class Operator {
  public:
   Operator(DriverCtx* driverCtx, RowTypePtr outputType, int32_t operatorId, std::string planNodeId, std::string_view operatorType)
@@ -1553,6 +1745,27 @@ class Operator {
   }
   virtual bool canReclaim() const {
     return false;
+  }
+  /// exec/Operator.h:315-329.
+  virtual bool canAddDynamicFilter() const {
+    return false;
+  }
+  virtual void addDynamicFilterLocked(const core::PlanNodeId& /*producer*/, const PushdownFilters& /*filters*/) {
+    VELOX_UNSUPPORTED("This operator doesn't support dynamic filter pushdown");
+  }
+  /// exec/Operator.h:336.
+  const std::vector<IdentityProjection>& identityProjections() const {
+    return identityProjections_;
+  }
+  /// exec/Operator.h:359-362 (folly::Synchronized<OperatorStats> replaced by a mutex).
+  void addRuntimeStat(std::string_view name, const RuntimeCounter& value) {
+    std::lock_guard<std::mutex> lock(statsMutex_);
+    stats_.addRuntimeStat(name, value);
+  }
+  /// (stub only) a copy of the stats for a test to look at
+  OperatorStats statsCopy() const {
+    std::lock_guard<std::mutex> lock(statsMutex_);
+    return stats_;
   }
   memory::MemoryPool* pool() const {
     return operatorCtx_->pool();
@@ -1586,6 +1799,8 @@ class Operator {
   RowVectorPtr input_;
   bool noMoreInput_{false};
   std::vector<IdentityProjection> identityProjections_;
+  mutable std::mutex statsMutex_;
+  OperatorStats stats_;
 };
 
 using OperatorSupplier = std::function<std::unique_ptr<Operator>(int32_t operatorId, DriverCtx* ctx)>;
@@ -1612,8 +1827,20 @@ class CpuOperatorStandIn : public Operator {
   }
 };
 
+/// exec/HashTable.h:155-163: the names of the runtime stats of operators that own a hash table.
+struct BaseHashTable {
+  static constexpr std::string_view kCapacity{"hashtable.capacity"};
+  static constexpr std::string_view kNumRehashes{"hashtable.numRehashes"};
+  static constexpr std::string_view kNumDistinct{"hashtable.numDistinct"};
+  static constexpr std::string_view kNumTombstones{"hashtable.numTombstones"};
+  static constexpr std::string_view kHashMode{"hashtable.hashMode"};
+  static constexpr std::string_view kBuildWallNanos{"hashtable.buildWallNanos"};
+};
+
 class HashAggregation : public CpuOperatorStandIn {
  public:
+  static constexpr std::string_view kFlushRowCount{"flushRowCount"};  // exec/HashAggregation.h:30-38
+  static constexpr std::string_view kFlushTimes{"flushTimes"};
   HashAggregation(int32_t operatorId, DriverCtx* driverCtx, const std::shared_ptr<const core::AggregationNode>& node)
       : CpuOperatorStandIn(driverCtx, node->outputType(), operatorId, node->id(), "Aggregation") {}
 };
@@ -1671,6 +1898,63 @@ class Driver : public std::enable_shared_from_this<Driver> {
   bool shouldYield() const {
     return false;
   }
+  int operatorIndex(const Operator* op) const {
+    for (size_t i = 0; i < operators_.size(); ++i) {
+      if (operators_[i].get() == op) {
+        return static_cast<int>(i);
+      }
+    }
+    VELOX_FAIL("operator not in this driver");
+  }
+  /// exec/Driver.h:463-467, exec/Driver.cpp:1183-1250: for every channel of 'filterSource', walk upstream
+  /// through operators that project the channel as it is; the operator the walk stops at takes the filter
+  /// if it can (a scan). Returns the number of filters produced.
+  int pushdownFilters(Operator* filterSource, const std::vector<column_index_t>& channels,
+                      const std::function<bool(column_index_t, common::FilterPtr&)>& makeFilter) {
+    const int sourceIndex = operatorIndex(filterSource);
+    pushdown_.resize(operators_.size());
+    std::vector<int> accepted(sourceIndex, 0);
+    int produced = 0;
+    for (size_t i = 0; i < channels.size(); ++i) {
+      column_index_t channel = channels[i];
+      int j = sourceIndex - 1;
+      for (; j > 0; --j) {
+        bool identity = false;
+        for (const auto& projection : operators_[j]->identityProjections()) {
+          if (projection.outputChannel == channel) {
+            channel = projection.inputChannel;
+            identity = true;
+            break;
+          }
+        }
+        if (!identity) {
+          break;
+        }
+      }
+      if (j < 0 || !operators_[j]->canAddDynamicFilter()) {
+        continue;
+      }
+      common::FilterPtr filter;
+      if (makeFilter(static_cast<column_index_t>(i), filter)) {
+        if (filter) {
+          common::Filter::merge(filter, pushdown_[j].filters[channel]);
+          pushdown_[j].dynamicFilteredColumns.insert(channel);
+        }
+        ++produced;
+        ++accepted[j];
+      }
+    }
+    for (int j = 0; j < sourceIndex; ++j) {
+      if (accepted[j] > 0) {
+        operators_[j]->addDynamicFilterLocked(filterSource->planNodeId(), pushdown_[j]);
+        operators_[j]->addRuntimeStat(DriverStats::kDynamicFiltersAccepted, RuntimeCounter(accepted[j]));
+      }
+    }
+    if (produced > 0) {
+      filterSource->addRuntimeStat(DriverStats::kDynamicFiltersProduced, RuntimeCounter(produced));
+    }
+    return produced;
+  }
   // (stub only) the pipeline under construction
   std::vector<std::unique_ptr<Operator>>& mutableOperators() {
     return operators_;
@@ -1679,6 +1963,7 @@ class Driver : public std::enable_shared_from_this<Driver> {
  private:
   std::unique_ptr<DriverCtx> ctx_;
   std::vector<std::unique_ptr<Operator>> operators_;
+  std::vector<PushdownFilters> pushdown_;
   friend struct DriverFactory;
 };
 

@@ -1,0 +1,17 @@
+python -m pytest tests/test_shim.py tests/test_gpu_join.py tests/test_gpu_dist_abi.py tests/test_gpu_async.py -x -q -m gpu 2>&1 | tail -8
+run() { # name env...
+  name=$1; shift
+  env "$@" python bench.py --workload c5 --rows 200000000 --steps 5 --warmup 2 --no-traffic --no-cpu-baseline --detail gpurun_out/c5_$name.json > /dev/null 2>&1
+  python - <<PY
+import json
+d=json.load(open("gpurun_out/c5_$name.json"))
+k=d["kernels_ms_per_step"]
+print("$name", round(d["ms_per_step"],2), {x:round(v,2) for x,v in k.items() if v>0.1}, d["result_check"]["ok"])
+PY
+}
+run default X=1
+run half VX355_JOIN_SCATTER_HALF=1
+run default2 X=1
+run half2 VX355_JOIN_SCATTER_HALF=1
+run slice4m VX355_JOIN_SLICE_BYTES=4194304
+run chunks4 VX355_C5_CHUNKS=4

@@ -44,6 +44,7 @@
 #include <chrono>
 #include <cmath>
 #include <future>
+#include <thread>
 #include <utility>
 #include <cstdio>
 #include <cstdlib>
@@ -4187,6 +4188,7 @@ struct vx355_agg {
   // vx355_agg_table_bytes: what get_stats would report, as of the last batch fed (written by
   // whichever thread feeds - the Driver thread or the queue's worker -, read without waiting)
   std::atomic<int64_t> publishedTableBytes{0};
+  std::atomic<int64_t> publishedUsedBytes{0};  // vx355_agg_bytes_in_use
   std::atomic<int64_t> publishedGroups{0};
   int32_t step;
   bool ignoreNullKeys;
@@ -5278,10 +5280,25 @@ void jitWriteCache(const std::string& path, const std::vector<char>& code) {
   }
 }
 
+// A process that exits while a background compile is still inside hiprtc / comgr dies in LLVM's torn-down
+// statics (seen as an intermittent SIGSEGV / abort "In function: k_agg_fast_jit" of a short-lived program).
+// exit() therefore waits for the compiles in flight: the handler is registered both when a compile is
+// launched (before comgr is loaded: it then runs after comgr's own exit handlers were registered, i.e. it
+// holds exit() while the helper thread finishes) and from the helper thread once hiprtc has loaded comgr
+// (registered later than comgr's statics, so it runs BEFORE they are destroyed).
+std::atomic<int> gJitInFlight{0};
+void waitForJitAtExit() {
+  for (int i = 0; i < 6000 && gJitInFlight.load(std::memory_order_acquire) > 0; ++i) {
+    std::this_thread::sleep_for(std::chrono::milliseconds(10));
+  }
+}
+
 // hiprtc half of an instantiation: CPU only, may run on any thread. Empty result = failure.
 std::vector<char> jitCompile(const std::string& src, const std::string& clangInclude, std::string* buildLog) {
   hiprtcProgram prog = nullptr;
   bool ok = hiprtcCreateProgram(&prog, src.c_str(), "vx355_agg_fast_jit.hip", 0, nullptr, nullptr) == HIPRTC_SUCCESS;
+  static std::once_flag afterComgr;
+  std::call_once(afterComgr, [] { std::atexit(waitForJitAtExit); });
   if (ok) {
     const std::string inc1 = "-I/opt/rocm/include";
     const std::string inc2 = "-I" + clangInclude;
@@ -5354,9 +5371,14 @@ hipFunction_t jitFastKernel(const FastSignature& sig, int unroll, bool log, bool
     }
   } else if (async) {
     const std::string inc = st.clangInclude;
+    static std::once_flag beforeComgr;
+    std::call_once(beforeComgr, [] { std::atexit(waitForJitAtExit); });
+    gJitInFlight.fetch_add(1, std::memory_order_acq_rel);
     st.pending[key] = std::async(std::launch::async, [src, inc]() {
                         std::string ignored;
-                        return jitCompile(src, inc, &ignored);
+                        auto code = jitCompile(src, inc, &ignored);
+                        gJitInFlight.fetch_sub(1, std::memory_order_acq_rel);
+                        return code;
                       }).share();
     if (log) {
       fprintf(stderr, "vx355: compiling an instance of shape %s in the background\n", key);
@@ -7265,6 +7287,21 @@ static int64_t tableBytesOf(const vx355_agg& h) {
 static void publishStats(vx355_agg& h) {
   h.publishedTableBytes.store(tableBytesOf(h), std::memory_order_relaxed);
   h.publishedGroups.store(h.keys.empty() ? 1 : h.numGroups, std::memory_order_relaxed);
+  // bytes the groups held now occupy: the allocation scaled by the share of its rows in use (the
+  // reference's measure after a flush - resetTable keeps the table, the rows are gone,
+  // exec/HashAggregation.cpp:293-318) plus the string blocks of the DISTINCT sets
+  const int64_t groups = h.keys.empty() ? 1 : h.numGroups;
+  const int64_t rows = std::max<int64_t>(1, static_cast<int64_t>(h.capacity));
+  int64_t used = static_cast<int64_t>(static_cast<double>(h.table.capacity()) * std::min<double>(1.0, static_cast<double>(groups) / rows));
+  for (const auto& d : h.distinct) {
+    if (d.dedup) {
+      used += static_cast<int64_t>(d.dedup->table.capacity());
+      for (const auto& b : d.dedup->strBlocks) {
+        used += static_cast<int64_t>(b.capacity());
+      }
+    }
+  }
+  h.publishedUsedBytes.store(used, std::memory_order_relaxed);
 }
 
 // GroupingSet::resetTable after a partial flush (HashAggregation::resetPartialOutputIfNeed,
@@ -8457,11 +8494,13 @@ int vx355_agg_output_result(vx355_agg* h, int64_t ticket, int32_t* n_out, int32_
       vx::setLastError("no queued get_output with this ticket (results are handed out once)");
       return VX355_EINVAL;
     }
+    // The queue's position FIRST, the page's flag after it: read the other way round, a worker that finishes
+    // the page between the two reads would make a completed page look like one skipped behind a failure.
+    int64_t submitted = 0, completed = 0;
+    vx::asyncPoll(h->aq, &submitted, &completed);
     if (!it->second->complete.load(std::memory_order_acquire)) {
       // a page skipped behind a failed batch never runs: the queue's failure is the answer then
-      int64_t submitted = 0, completed = 0;
-      vx::asyncPoll(h->aq, &submitted, &completed);
-      if (completed < ticket) {
+      if (completed < ticket || vx::asyncFailed(h->aq) == VX355_OK) {
         vx::setLastError("the queued get_output has not completed (vx355_agg_poll: completed < ticket)");
         return VX355_EINVAL;
       }
@@ -8558,6 +8597,17 @@ int vx355_agg_get_stats(const vx355_agg* h, vx355_agg_stats* out) {
   out->num_flushes = h->numFlushes;
   out->compact_record_launches = h->compactLaunches;
   VX_API_END
+}
+
+int vx355_agg_get_gpu_stats(const vx355_agg* h, vx355_gpu_stats* out) { return vx::gpuStatsOf(h ? h->ctx : nullptr, out); }
+
+int vx355_agg_bytes_in_use(const vx355_agg* h, int64_t* bytes) {
+  if (!h || !bytes) {
+    vx::setLastError("NULL argument");
+    return VX355_EINVAL;
+  }
+  *bytes = h->publishedUsedBytes.load(std::memory_order_relaxed);
+  return VX355_OK;
 }
 
 int vx355_agg_table_bytes(const vx355_agg* h, int64_t* table_bytes, int64_t* num_groups) {

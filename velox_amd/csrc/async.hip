@@ -173,16 +173,18 @@ struct AsyncQueue {
         firstError = status;
         errorText = text;
       }
-      completed += task.tickets;
-      if (completed == submitted) {
-        idle.notify_all();
-      }
+      // The callback BEFORE the tickets count as completed: a caller that sees completed >= ticket (poll,
+      // wait) may free what the callback touches - its argument, the page - right away.
       if (task.done) {
         const int seen = firstError;
         lock.unlock();
         task.done(seen);
         task.done = nullptr;
         lock.lock();
+      }
+      completed += task.tickets;
+      if (completed == submitted) {
+        idle.notify_all();
       }
     }
   }

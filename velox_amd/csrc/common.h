@@ -33,8 +33,9 @@ void setLastError(const std::string& m);
 // batches in order; every other entry point of the handle drains the queue first (VX_ASYNC_DRAIN).
 struct AsyncQueue;
 AsyncQueue* asyncCreate();
-// 'done' (optional) runs on the worker thread after the task's ticket has been reported complete - also when the
-// task was skipped behind a failed one - with the status the queue holds then.
+// 'done' (optional) runs on the worker thread right BEFORE the task's ticket is reported complete - also when the
+// task was skipped behind a failed one - with the status the queue holds then: once poll / wait report the ticket,
+// the callback has returned and its argument may be freed.
 int64_t asyncSubmit(AsyncQueue* q, std::function<int(std::string*)> task, std::function<void(int)> done = nullptr);
 // The open chunk of the parallel ingest goes into the queue now (what is submitted next runs behind it).
 void asyncSealIngest(AsyncQueue* q);
@@ -190,6 +191,18 @@ struct Runtime {
   std::recursive_mutex callMutex;    // default contexts only
   bool isDefault = false;
   uint64_t launchCount = 0;  // kernels launched through VX_LAUNCH in this context (see resetCounters in agg.hip)
+  // What the context's operator cost the GPU side so far (vx355_*_get_gpu_stats; reset when the context
+  // is handed to a new handle): nanoseconds between entering an entry point and its stream being
+  // drained, bytes copied host -> HBM and HBM -> host, bytes of input columns handed to kernels.
+  std::atomic<uint64_t> busyNanos{0}, h2dBytes{0}, d2hBytes{0}, inputBytes{0};
+  uint64_t launchesAtReset = 0;
+  void resetGpuStats() {
+    busyNanos = 0;
+    h2dBytes = 0;
+    d2hBytes = 0;
+    inputBytes = 0;
+    launchesAtReset = launchCount;
+  }
   bool& profile;                     // = ds->profile
 
   explicit Runtime(DeviceState* d) : ds(d), profile(d->profile) {}
@@ -231,6 +244,7 @@ class ContextScope {
   Runtime* prev_;
   bool locked_ = false;
   bool outer_ = false;
+  int64_t enteredNanos_ = 0;
 };
 
 // Launch on the library stream, bracketed by events when profiling is on.
@@ -382,6 +396,9 @@ class HostCoalescer {
 // Output columns of a PARTIAL / INTERMEDIATE aggregation that hold the sum half of an avg's
 // (sum, count) pair (agg.hip); the count follows in the next column.
 std::vector<int32_t> aggPartialAvgColumns(const vx355_agg* h);
+
+// vx355_*_get_gpu_stats: the counters of one execution context.
+int gpuStatsOf(const Runtime* ctx, vx355_gpu_stats* out);
 
 // Exclusive scan of n u32 cells into n + 1 u64 offsets (last = total), on the library stream.
 void scanU32ToU64(const uint32_t* in, int64_t n, uint64_t* out, DevBuf& scratch);

@@ -26,6 +26,10 @@ using namespace vx;
 extern "C" int vx355_all_gather_v(vx355_comm* c, const void* send, const int64_t* sizes, void* recv);
 
 namespace vx {
+bool commViaRccl(const vx355_comm* c);  // exchange.hip: false = one rank whose exchanges are local copies
+}
+
+namespace vx {
 namespace {
 
 void ok(int status) {
@@ -97,16 +101,24 @@ int vx355_join_repartition(vx355_comm* c, const vx355_join_build_spec* build_spe
   VX_CHECK_ARG(c && build_spec && build_rows && probe_spec && probe_rows && sink && table_out, "NULL argument");
   VX_CHECK_ARG(build_rows->num_cols >= 1 && probe_rows->num_cols >= 1, "batches without columns");
   VX_CHECK_ARG(build_spec->num_keys == probe_spec->num_keys && build_spec->num_keys >= 1, "key lists differ");
+  int32_t world = 1;
+  ok(vx355_comm_info(c, &world, nullptr, nullptr));
+  // One rank and no forced RCCL self-exchange: PartitionedOutput -> Exchange over one destination is
+  // the identity (the reference's LocalExchange with one partition passes vectors through); the
+  // caller's rows, which stay valid for the whole call, feed the operators directly.
+  const bool local = world == 1 && !commViaRccl(c);
   // ---- build side: one exchange, then HashBuild over the rows that landed here
   TableRef table;
   {
     ExchangeHandle ex;
-    const auto types = typesOf(build_rows);
-    ok(vx355_exchange_create(c, types.data(), build_rows->num_cols, build_spec->key_cols, build_spec->num_keys, &ex.x));
-    ok(vx355_exchange_send(ex.x, build_rows));
-    std::vector<vx355_column> got(build_rows->num_cols);
-    int64_t rows = 0;
-    ok(vx355_exchange_receive(ex.x, got.data(), &rows));
+    std::vector<vx355_column> got(build_rows->cols, build_rows->cols + build_rows->num_cols);
+    int64_t rows = build_rows->num_rows;
+    if (!local) {
+      const auto types = typesOf(build_rows);
+      ok(vx355_exchange_create(c, types.data(), build_rows->num_cols, build_spec->key_cols, build_spec->num_keys, &ex.x));
+      ok(vx355_exchange_send(ex.x, build_rows));
+      ok(vx355_exchange_receive(ex.x, got.data(), &rows));
+    }
     BuildHandle build;
     ok(vx355_join_build_create(build_spec, &build.b));
     int64_t at = 0;
@@ -128,8 +140,6 @@ int vx355_join_repartition(vx355_comm* c, const vx355_join_build_spec* build_spe
   // inside a batch's int32 row count; the ranks agree on that with one all-gather of the counts.
   int64_t numChunks = std::max<int64_t>(1, chunks);
   {
-    int32_t world = 1;
-    ok(vx355_comm_info(c, &world, nullptr, nullptr));
     std::vector<int64_t> mine(static_cast<size_t>(world), ceilDiv(n, kMaxBatchRows)), theirs(static_cast<size_t>(world), 0);
     ok(vx355_exchange_counts(c, mine.data(), theirs.data()));
     for (int64_t need : theirs) {
@@ -138,24 +148,62 @@ int vx355_join_repartition(vx355_comm* c, const vx355_join_build_spec* build_spe
   }
   ExchangeHandle ex;
   const auto types = typesOf(probe_rows);
-  ok(vx355_exchange_create(c, types.data(), probe_rows->num_cols, probe_spec->key_cols, probe_spec->num_keys, &ex.x));
+  if (!local) {
+    ok(vx355_exchange_create(c, types.data(), probe_rows->num_cols, probe_spec->key_cols, probe_spec->num_keys, &ex.x));
+  }
   ProbeHandle probe;
   ok(vx355_join_probe_create(table.t, probe_spec, &probe.p));
   auto sendChunk = [&](int64_t i) {
+    if (local) {
+      return;
+    }
     const int64_t begin = n * i / numChunks, end = n * (i + 1) / numChunks;
     const auto cols = sliceColumns(probe_rows, begin);
     vx355_batch piece{static_cast<int32_t>(end - begin), probe_rows->num_cols, cols.data()};
     ok(vx355_exchange_send(ex.x, &piece));
   };
+  // The operator's input batch is the chunk regrouped by slice of the join table when the table is
+  // beyond the caches (vx355_join_probe_add_input_regrouped): the sink sees that batch.
+  std::vector<DevBuf> moved(probe_rows->num_cols);
   auto consumeChunk = [&](int64_t i) {
     std::vector<vx355_column> got(probe_rows->num_cols);
     int64_t rows = 0;
-    ok(vx355_exchange_receive(ex.x, got.data(), &rows));
+    std::vector<vx355_column> sliced;
+    if (local) {
+      const int64_t begin = n * i / numChunks, end = n * (i + 1) / numChunks;
+      sliced = sliceColumns(probe_rows, begin);
+      got = sliced;
+      rows = end - begin;
+    } else {
+      ok(vx355_exchange_receive(ex.x, got.data(), &rows));
+    }
     if (rows > INT32_MAX) {
       VX_THROW(VX355_EINVAL, "a probe chunk received more than 2^31 rows: ask for more chunks");
     }
     vx355_batch received{static_cast<int32_t>(rows), probe_rows->num_cols, got.data()};
-    ok(vx355_join_probe_add_input(probe.p, &received));
+    std::vector<void*> movedPtrs(probe_rows->num_cols);
+    for (int32_t col = 0; col < probe_rows->num_cols; ++col) {
+      movedPtrs[col] = moved[col].ensure(static_cast<size_t>(std::max<int64_t>(rows, 1)) * kindWidth(types[col]) + 64);
+    }
+    int32_t regrouped = 0;
+    ok(vx355_join_probe_add_input_regrouped(probe.p, &received, movedPtrs.data(), &regrouped));
+    if (regrouped) {
+      for (int32_t col = 0; col < probe_rows->num_cols; ++col) {
+        got[col].values = movedPtrs[col];
+        got[col].mem = VX355_MEM_DEVICE;
+      }
+    } else if (local) {
+      // the sink's contract: 'received' holds device columns (an exchange lands them in HBM; here the
+      // caller's own rows were probed in place, and host columns are brought over for the sink)
+      for (int32_t col = 0; col < probe_rows->num_cols; ++col) {
+        if (got[col].mem == VX355_MEM_HOST && rows > 0) {
+          copyIn(movedPtrs[col], got[col].values, VX355_MEM_HOST, static_cast<size_t>(rows) * kindWidth(types[col]));
+          got[col].values = movedPtrs[col];
+          got[col].mem = VX355_MEM_DEVICE;
+        }
+      }
+      Runtime::get().sync();
+    }
     const int rc = sink(sink_arg, static_cast<int32_t>(i), &received, probe.p);
     if (rc != VX355_OK) {
       VX_THROW(rc, "vx355_join_repartition: the sink failed on chunk " + std::to_string(i));

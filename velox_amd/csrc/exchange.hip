@@ -55,13 +55,14 @@ Rccl& rccl() {
   if (const char* e = std::getenv("VX355_COMM_TRANSPORT")) {
     if (std::string(e) == "shm") {
       // ranks that share one GPU (RCCL refuses two ranks per device): the same table, served through
-      // host shared memory (shm_transport.hip). CommInitAll - one process, one rank per GPU - stays RCCL's.
+      // host shared memory (shm_transport.hip), CommInitAll - one process, one rank per entry of the
+      // device list - included.
       Rccl r;
       r.lib = reinterpret_cast<void*>(&gRccl);
       r.path = "shm transport (VX355_COMM_TRANSPORT=shm)";
       r.GetUniqueId = shmx::GetUniqueId;
       r.CommInitRank = shmx::CommInitRank;
-      r.CommInitAll = [](ncclComm_t*, int, const int*) -> int { return 4; };
+      r.CommInitAll = shmx::CommInitAll;
       r.CommDestroy = shmx::CommDestroy;
       r.Send = shmx::Send;
       r.Recv = shmx::Recv;
@@ -198,6 +199,10 @@ struct vx355_comm {
   bool viaRccl() const { return world > 1 || selfViaRccl; }
   DevBuf countsDev;            // all-gather of the slice sizes
 };
+
+namespace vx {
+bool commViaRccl(const vx355_comm* c) { return c->viaRccl(); }
+}  // namespace vx
 
 namespace vx {
 namespace {

@@ -306,6 +306,25 @@ struct WideSlot {
   uint64_t dep[kWideDeps];
 };
 
+// A table's slot array has ONE of the two layouts: slotShift 4 = Slot, 5 = WideSlot. Builds large
+// enough to leave every cache are inserted into wide slots directly (buildFinish): the row that
+// claims a key stores its dependents in the same 32 bytes, and no pass over the whole table
+// (k_widen_slots) is needed before the first probe. Every kernel addresses slots through slotAt.
+__device__ inline Slot* slotAt(Slot* base, uint64_t pos, int32_t shift) {
+  return reinterpret_cast<Slot*>(reinterpret_cast<char*>(base) + (pos << shift));
+}
+__device__ inline const Slot* slotAt(const Slot* base, uint64_t pos, int32_t shift) {
+  return reinterpret_cast<const Slot*>(reinterpret_cast<const char*>(base) + (pos << shift));
+}
+
+// Where a key's walk over the slots begins and how it goes on. homeMask = (capacity - 1) with the
+// low bits cleared that number the slots of one 64-byte sector (4 narrow / 2 wide slots): the walk
+// starts on a sector boundary, so its first slots cost ONE request to the L2 (a lookup is priced in
+// requests: ~90 G/s per chip however they are spread, profiles/r06_c5_counters.md). wrapMask: the walk
+// wraps inside the group of (wrapMask + 1) slots it started in - the whole table for tables
+// inserted slot by slot, 128 KB of slots for tables assembled group by group in LDS (k_lds_build).
+__device__ inline uint64_t nextSlot(uint64_t pos, uint64_t wrapMask) { return (pos & ~wrapMask) | ((pos + 1) & wrapMask); }
+
 __global__ __launch_bounds__(256) void k_widen_slots(const Slot* slots, WideSlot* wide, uint64_t capacity,
                                                      const uint64_t* dep0, const uint64_t* dep1) {
   for (uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; i < capacity;
@@ -333,7 +352,11 @@ struct InsertArgs {
   int64_t numRows;
   uint32_t* head;     // array mode (NOT initialised: 'present' says which entries are live)
   uint32_t* present;  // array mode: one bit per possible key
-  Slot* slots;        // normalized-key mode
+  Slot* slots;        // normalized-key mode (slotShift 4: Slot, 5: WideSlot)
+  int32_t slotShift;
+  int32_t pad0;
+  uint64_t homeMask, wrapMask;         // see nextSlot
+  const uint64_t* wideDep[kWideDeps];  // slotShift 5: the dependents the claiming row stores next to its key
   uint64_t* gslots;   // generic hash mode: {hash tag:32 | representative row + 1:32}
   uint64_t capacity;
   uint32_t* next;
@@ -592,42 +615,61 @@ __global__ __launch_bounds__(256) void k_join_insert(InsertArgs a) {
       }
       continue;
     }
+    // Normalized-key mode. Random read-modify-writes retire at ~20 G/s on this chip whatever their
+    // locality (profiles/r02_atomic_bench.txt), so an insert is priced in atomics: phase 1 is ONE
+    // compare-and-swap per row on the slot's key - the row that claims the key fills the rest of
+    // the slot with plain stores (nobody reads a head in this launch), a row that finds its key
+    // already there waits for phase 2, launched only when such rows exist, which pushes it in
+    // front of the chain (pushNext, HashTable.cpp:1412-1418) with one exchange on the head.
     const uint64_t key = buildKey(a, row);
-    uint32_t* headWord = nullptr;
     const uint64_t mask = a.capacity - 1;
-    uint64_t pos = twangMix64(key) & mask;
-    for (uint64_t probes = 0; probes <= mask; ++probes) {
-      Slot* s = a.slots + pos;
-      uint64_t k = __hip_atomic_load(&s->key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (k == kEmptyKey) {
-        unsigned long long old =
-            atomicCAS(reinterpret_cast<unsigned long long*>(&s->key), kEmptyKey, key);
-        k = old == kEmptyKey ? key : old;
+    uint64_t pos = twangMix64(key) & a.homeMask;
+    if (a.phase == 2) {
+      if (a.next[row] != kPendingRow) {
+        continue;
       }
-      if (k == key) {
-        headWord = &s->head;
+      for (uint64_t probes = 0; probes <= mask; ++probes) {
+        Slot* s = slotAt(a.slots, pos, a.slotShift);
+        if (s->key == key) {
+          a.next[row] = atomicExch(&s->head, static_cast<uint32_t>(row));
+          break;
+        }
+        pos = nextSlot(pos, a.wrapMask);
+      }
+      continue;
+    }
+    bool placed = false;
+    for (uint64_t probes = 0; probes <= mask; ++probes) {
+      Slot* s = slotAt(a.slots, pos, a.slotShift);
+      const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&s->key), kEmptyKey, key);
+      if (old == kEmptyKey) {
+        s->head = static_cast<uint32_t>(row);
+        if (a.slotShift == 5) {
+          // the claiming row's dependents ride in the slot (read only when the table turns out
+          // to hold no duplicate keys)
+          WideSlot* w = reinterpret_cast<WideSlot*>(s);
+          w->dep[0] = a.wideDep[0] ? a.wideDep[0][row] : 0;
+          w->dep[1] = a.wideDep[1] ? a.wideDep[1][row] : 0;
+        }
+        a.next[row] = kNoRow32;
+        ++distinct;
+        placed = true;
         break;
       }
-      pos = (pos + 1) & mask;
+      if (old == key) {
+        if (a.dropDups) {
+          a.next[row] = kNoRow32;  // the claiming row stays the key's only row
+        } else {
+          a.next[row] = kPendingRow;
+          ++dups;
+        }
+        placed = true;
+        break;
+      }
+      pos = nextSlot(pos, a.wrapMask);
     }
-    if (!headWord) {
+    if (!placed) {
       a.counters->tableFull = 1;
-      continue;
-    }
-    if (a.dropDups) {
-      // the first row of a key stays its only row
-      const uint32_t old = atomicCAS(headWord, kNoRow32, static_cast<uint32_t>(row));
-      a.next[row] = kNoRow32;
-      distinct += old == kNoRow32 ? 1 : 0;
-      continue;
-    }
-    // pushNext: the new row becomes the chain head.
-    const uint32_t old = atomicExch(headWord, static_cast<uint32_t>(row));
-    a.next[row] = old;
-    if (old == kNoRow32) {
-      ++distinct;
-    } else {
-      ++dups;
     }
   }
   // the loops above leave the wave converged here: one add per wave (see phase 1)
@@ -683,9 +725,9 @@ __global__ __launch_bounds__(256) void k_count_init(InsertArgs a, uint32_t* rema
     } else {
       const uint64_t key = buildKey(a, row);
       const uint64_t mask = a.capacity - 1;
-      uint64_t pos = twangMix64(key) & mask;
+      uint64_t pos = twangMix64(key) & a.homeMask;
       for (uint64_t probes = 0; probes <= mask; ++probes) {
-        const Slot sl = a.slots[pos];
+        const Slot sl = *slotAt(a.slots, pos, a.slotShift);
         if (sl.key == key) {
           head = sl.head;
           break;
@@ -693,7 +735,7 @@ __global__ __launch_bounds__(256) void k_count_init(InsertArgs a, uint32_t* rema
         if (sl.key == kEmptyKey) {
           break;
         }
-        pos = (pos + 1) & mask;
+        pos = nextSlot(pos, a.wrapMask);
       }
     }
     if (head != kNoRow32) {
@@ -702,12 +744,14 @@ __global__ __launch_bounds__(256) void k_count_init(InsertArgs a, uint32_t* rema
   }
 }
 
-__global__ __launch_bounds__(256) void k_fill_slots(Slot* p, uint64_t n) {
+// n 16-byte units; wide slots (two units each) get {empty key, no row} in the even unit, zeros in the odd one.
+__global__ __launch_bounds__(256) void k_fill_slots(Slot* p, uint64_t n, int32_t wide) {
   const uint64_t step = static_cast<uint64_t>(gridDim.x) * blockDim.x;
   for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += step) {
     Slot s;
-    s.key = kEmptyKey;
-    s.head = kNoRow32;
+    const bool keyUnit = !wide || (i & 1) == 0;
+    s.key = keyUnit ? kEmptyKey : 0;
+    s.head = keyUnit ? kNoRow32 : 0;
     s.pad = 0;
     p[i] = s;
   }
@@ -774,6 +818,9 @@ struct ProbeArgs {
   const uint32_t* head;
   const uint32_t* present;
   const Slot* slots;
+  int32_t slotShift;                   // 4: Slot, 5: WideSlot (slots == wide)
+  int32_t pad4;
+  uint64_t homeMask, wrapMask;         // see nextSlot
   const uint64_t* gslots;              // generic hash mode
   const uint64_t* keyStore[kMaxKeys];  // generic hash mode: build key images
   int32_t keyWords[kMaxKeys];
@@ -782,6 +829,7 @@ struct ProbeArgs {
   uint32_t* hits;       // first matching build row or kNoRow32
   uint32_t* counts;     // output rows per probe row; only kept for duplicate tables
   uint64_t* tileSums;   // output rows per tile
+  uint32_t* unitSums;   // grouped probe with units of a quarter tile: output rows per unit (k_emit skips its count pass)
   int32_t fastKey;      // single non-null BIGINT key (FK of TPC-H joins): 1 flat, 2 dictionary wrapped
   int32_t nullAware;    // null-aware anti join on a non-empty build side: null probe keys produce nothing
   uint8_t* probed;      // right / full / right semi: build rows some probe row matched
@@ -923,9 +971,9 @@ __device__ inline uint32_t lookupGeneric(const ProbeArgs& a, int64_t row) {
 
 __device__ inline uint32_t lookupSlots(const ProbeArgs& a, uint64_t key) {
   const uint64_t mask = a.capacity - 1;
-  uint64_t pos = twangMix64(key) & mask;
+  uint64_t pos = twangMix64(key) & a.homeMask;
   for (uint64_t probes = 0; probes <= mask; ++probes) {
-    const uint4 raw = *reinterpret_cast<const uint4*>(a.slots + pos);
+    const uint4 raw = *reinterpret_cast<const uint4*>(slotAt(a.slots, pos, a.slotShift));
     const uint64_t k = (static_cast<uint64_t>(raw.y) << 32) | raw.x;
     if (k == key) {
       return raw.z;
@@ -933,7 +981,7 @@ __device__ inline uint32_t lookupSlots(const ProbeArgs& a, uint64_t key) {
     if (k == kEmptyKey) {
       return kNoRow32;
     }
-    pos = (pos + 1) & mask;
+    pos = nextSlot(pos, a.wrapMask);
   }
   return kNoRow32;
 }
@@ -941,7 +989,7 @@ __device__ inline uint32_t lookupSlots(const ProbeArgs& a, uint64_t key) {
 template <int WIDE>
 __device__ inline uint32_t lookupWide(const ProbeArgs& a, uint64_t key, uint64_t (&vals)[kWideDeps]) {
   const uint64_t mask = a.capacity - 1;
-  uint64_t pos = twangMix64(key) & mask;
+  uint64_t pos = twangMix64(key) & a.homeMask;
   for (uint64_t probes = 0; probes <= mask; ++probes) {
     const uint4* at = reinterpret_cast<const uint4*>(a.wide + pos);
     const uint4 raw = at[0];
@@ -957,9 +1005,99 @@ __device__ inline uint32_t lookupWide(const ProbeArgs& a, uint64_t key, uint64_t
     if (k == kEmptyKey) {
       return kNoRow32;
     }
-    pos = (pos + 1) & mask;
+    pos = nextSlot(pos, a.wrapMask);
   }
   return kNoRow32;
+}
+
+// The KU lookups of one lane, first sectors first: the 64-byte sector every key's walk begins in
+// (4 narrow / 2 wide slots, see nextSlot) is loaded for four of the lane's keys at a time before any
+// is looked at - 16 independent 16-byte loads in flight, and since the four loads of one sector
+// merge into one request, one L2 request per key unless its walk leaves the sector (a walk per
+// key, slot by slot, keeps ONE load in flight and pays a request per slot). joinNormalizedKeyProbe
+// prefetches the 64 buckets of its window the same way before it compares
+// (exec/HashTable.cpp:697-725).
+template <int WIDE, int KU>
+__device__ inline void lookupFirstSlots(const ProbeArgs& a, const uint64_t (&key)[KU], const bool (&candidate)[KU],
+                                        uint32_t (&hit)[KU], uint64_t (*vals)[kWideDeps]) {
+  const uint64_t mask = a.capacity - 1;
+  const char* base = WIDE > 0 ? reinterpret_cast<const char*>(a.wide) : reinterpret_cast<const char*>(a.slots);
+  const int shift = WIDE > 0 ? 5 : a.slotShift;
+  constexpr int H = KU > 4 ? 4 : KU;
+  static_assert(KU % H == 0, "rounds of four keys");
+#pragma unroll
+  for (int h0 = 0; h0 < KU; h0 += H) {
+    uint64_t home[H];
+    uint4 q[H][4];
+#pragma unroll
+    for (int u = 0; u < H; ++u) {
+      home[u] = twangMix64(key[h0 + u]) & a.homeMask;
+    }
+#pragma unroll
+    for (int u = 0; u < H; ++u) {
+      // (rows that are no candidates read sector 0: unconditional loads stay back to back)
+      const uint4* at = reinterpret_cast<const uint4*>(base + ((candidate[h0 + u] ? home[u] : 0) << shift));
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        q[u][w] = at[w];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < H; ++u) {
+      const int g = h0 + u;
+      hit[g] = kNoRow32;
+      if (!candidate[g]) {
+        continue;
+      }
+      bool done = false;
+      const int inSector = 64 >> shift;
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) {
+        if (done || sl >= inSector) {
+          continue;
+        }
+        const uint4 kq = shift == 5 ? q[u][(2 * sl) & 3] : q[u][sl];
+        const uint64_t k = (static_cast<uint64_t>(kq.y) << 32) | kq.x;
+        if (k == key[g]) {
+          hit[g] = kq.z;
+          if constexpr (WIDE > 0) {
+            const uint4 d = q[u][(2 * sl + 1) & 3];
+            vals[g][0] = (static_cast<uint64_t>(d.y) << 32) | d.x;
+            if (WIDE > 1) {
+              vals[g][1] = (static_cast<uint64_t>(d.w) << 32) | d.z;
+            }
+          }
+          done = true;
+        } else if (k == kEmptyKey) {
+          done = true;
+        }
+      }
+      if (!done) {
+        // the sector is full of other keys: walk on from its last slot
+        uint64_t at = nextSlot(home[u] + static_cast<uint64_t>(inSector) - 1, a.wrapMask);
+        for (uint64_t probes = 1; probes <= mask; ++probes) {
+          const uint4* s = reinterpret_cast<const uint4*>(base + (at << shift));
+          const uint4 r = s[0];
+          const uint64_t k2 = (static_cast<uint64_t>(r.y) << 32) | r.x;
+          if (k2 == key[g]) {
+            hit[g] = r.z;
+            if constexpr (WIDE > 0) {
+              const uint4 d = s[1];
+              vals[g][0] = (static_cast<uint64_t>(d.y) << 32) | d.x;
+              if (WIDE > 1) {
+                vals[g][1] = (static_cast<uint64_t>(d.w) << 32) | d.z;
+              }
+            }
+            break;
+          }
+          if (k2 == kEmptyKey) {
+            break;
+          }
+          at = nextSlot(at, a.wrapMask);
+        }
+      }
+    }
+  }
 }
 
 // HashTable::joinProbe: hits[row] = first build row with an equal key. One
@@ -998,7 +1136,7 @@ struct SparseLds {
 // RF: 0 = no input filter at all (the instantiations every plain probe runs: not an instruction of the
 // fusion in them); 4 / 8 = byte width of the fast filter's column (RowFilter::fast); -1 = a.rf.terms through
 // evalFilter (any other filter shape: only the all-purpose instantiation <-1, -1> is built with it)
-template <int MODE, int FAST, bool SPARSE, int WIDE = 0, int RF = 0>
+template <int MODE, int FAST, bool SPARSE, int WIDE = 0, int RF = 0, int THREADS = 256, int ROWS = kTileRows>
 __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, SparseLds* lds) {
   const int mode = MODE >= 0 ? MODE : a.mode;
   const int fastKey = FAST >= 0 ? FAST : a.fastKey;
@@ -1006,12 +1144,14 @@ __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, Spars
   // the bytes they keep in flight (8 per lane: 0.63 ms per 323 M probes, 4: 0.76 ms); the other
   // paths carry more state per probe
   constexpr int kU = FAST == 1 ? kProbeUnrollFast : kProbeUnroll;
-  const int64_t tileBase = tile * kTileRows;
+  const int64_t tileBase = tile * ROWS;
   uint64_t mine = 0;
-  constexpr int kIters = kTileRows / (256 * kU);
+  static_assert(!SPARSE || (THREADS == 256 && ROWS == kTileRows), "the listing form is written for four waves and whole tiles");
+  constexpr int kIters = ROWS / (THREADS * kU);
+  static_assert(kIters >= 1, "a tile holds at least one round of the workgroup");
   auto rowOf = [&](int it, int u) -> int64_t {
     return SPARSE ? tileBase + (threadIdx.x >> 6) * (kTileRows / 4) + (it * kU + u) * 64 + lane()
-                  : tileBase + (it * kU + u) * 256 + threadIdx.x;
+                  : tileBase + (it * kU + u) * THREADS + threadIdx.x;
   };
   // Flat BIGINT key (FAST == 1): the key loads of iteration it + 1 are issued behind the
   // bitmap gathers of iteration it, so the HBM latency of the keys overlaps the cache
@@ -1106,15 +1246,9 @@ __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, Spars
           hit[u] = candidate[u] ? a.head[key[u]] : kNoRow32;
         }
       } else if constexpr (WIDE > 0 && !SPARSE) {
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-          hit[u] = candidate[u] ? lookupWide<WIDE>(a, key[u], vals[u]) : kNoRow32;
-        }
+        lookupFirstSlots<WIDE, kU>(a, key, candidate, hit, vals);
       } else {
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-          hit[u] = candidate[u] ? lookupSlots(a, key[u]) : kNoRow32;
-        }
+        lookupFirstSlots<0, kU>(a, key, candidate, hit, nullptr);
       }
     } else if (fastKey) {
       const int64_t* kp = static_cast<const int64_t*>(a.keys[0].values);
@@ -1218,12 +1352,13 @@ __device__ inline uint64_t probeTileBody(const ProbeArgs& a, int64_t tile, Spars
             hit[u] = kNullKey32;
           }
         }
-        a.hits[rows[u]] = hit[u];
+        // (written once, read by a later launch: past the caches, which hold table lines)
+        __builtin_nontemporal_store(hit[u], a.hits + rows[u]);
         if constexpr (WIDE > 0 && !SPARSE) {
           if (isHit(hit[u])) {
-            a.hitVals[0][rows[u]] = vals[u][0];
+            __builtin_nontemporal_store(vals[u][0], a.hitVals[0] + rows[u]);
             if (WIDE > 1) {
-              a.hitVals[1][rows[u]] = vals[u][1];
+              __builtin_nontemporal_store(vals[u][1], a.hitVals[1] + rows[u]);
             }
           }
         }
@@ -1714,6 +1849,437 @@ __global__ __launch_bounds__(64) void k_key_locality(const int64_t* keys, int64_
   }
 }
 
+// ---- regrouped probe input (normalized-key tables beyond every cache) -------------------------
+// A probe into a table of hundreds of MB is bound by the fabric's dependent-random-read rate
+// (~33 G probes/s on config 5's shape, profiles/r05_bench_c5_one_gpu.json), not by HBM bytes. The
+// reference answers the same problem on the CPU by partitioning the BUILD (parallelJoinBuild,
+// exec/HashTable.cpp:1003-1203: thread i owns a contiguous range of buckets) and keeping 64
+// probes in flight (:697-725). Here the slot array already is partitioned - the top bits of a
+// slot number name a contiguous slice of the array - so the PROBE side is regrouped instead:
+// vx355_join_probe_add_input_regrouped moves the rows of the batch (all columns) so that rows
+// whose keys start their walk in the same slice are adjacent, and probes the regrouped batch slice
+// by slice with the workgroups of one slice on one XCD: the slice (<= ~2 MiB) stays in that XCD's
+// L2 while its rows stream past (tools/partjoin_parts.hip: 101 G probes/s). The mapping the
+// operator emits refers to the regrouped batch, ascending, so there is no way back to pay for.
+//   1. k_grp_hist     per tile of 32 K rows: rows per slice                      (8 B/row read)
+//   2. scanU32ToU64   bin-major exclusive scan: every (slice, tile) owns a range of the output
+//   3. k_grp_scatter  per sub-tile of 8 K rows: counting sort by slice in LDS, then column by
+//                     column through LDS - coalesced reads, runs of a slice's rows written
+//                     to consecutive addresses                               (2 x row bytes)
+//   4. k_grp_tiles    probe tiles listed per XCD in slice order
+//   5. k_join_probe_grouped  persistent workgroups, block b works for XCD b % 8
+// Rows inside a slice keep their tile order; inside a sub-tile their order is whatever the LDS
+// cursor hands out (the reference's exchange does not define a row order either).
+constexpr int kGrpMaxBins = 4096;
+constexpr int kGrpTileRows = 32768;
+constexpr int kGrpSub = 8192;
+constexpr int kGrpMaxCols = 16;
+
+struct GroupArgs {
+  ColView keys[kMaxKeys];
+  KeyRange ranges[kMaxKeys];
+  int32_t numKeys;
+  int32_t nullAsValue;
+  int32_t fastKey;      // one flat BIGINT key without nulls
+  int32_t binShift;     // slice of a key = (twangMix64(key) & mask) >> binShift
+  uint64_t mask;        // capacity - 1
+  int32_t numBins;
+  int32_t numCols;
+  int64_t numRows;
+  int64_t numTiles;     // of kGrpTileRows rows
+  uint32_t* hist;            // [bin][tile]
+  const uint64_t* offsets;   // exclusive scan of hist (bin major), offsets[numBins * numTiles] = numRows
+  // the columns as 'parts' of at most 8 bytes (a 16-byte column is two): element r of part q sits at
+  // in[q] + r * stride[q] and is width[q] bytes wide
+  int32_t numParts;
+  int32_t pad;
+  const char* in[2 * kGrpMaxCols];   // nullptr: the part's value is the row number itself
+  char* out[2 * kGrpMaxCols];
+  int32_t stride[2 * kGrpMaxCols];
+  int32_t outStride[2 * kGrpMaxCols];  // (differs from stride when columns are gathered into records)
+  int32_t width[2 * kGrpMaxCols];
+};
+
+// The slice a row is probed in. Rows that are proven misses before any slot is read (a null key,
+// a value outside the build side's range: lookupValueIds, VectorHasher.cpp:550-565) touch no
+// slice; they are spread over the bins by their position.
+__device__ inline uint32_t groupBinOf(const GroupArgs& a, int64_t row) {
+  uint64_t key = 0;
+  bool ok = true;
+  if (a.fastKey) {
+    const int64_t v = static_cast<const int64_t*>(a.keys[0].values)[row];
+    ok = v >= a.ranges[0].min && v <= a.ranges[0].max;
+    key = static_cast<uint64_t>(v) - static_cast<uint64_t>(a.ranges[0].min) + 1;
+  } else {
+    for (int k = 0; k < a.numKeys && ok; ++k) {
+      const ColView& c = a.keys[k];
+      if (colIsNull(c, row)) {
+        ok = a.nullAsValue != 0;  // value id 0
+        continue;
+      }
+      int64_t v;
+      bool mappable;
+      const uint64_t id = valueIdAt(c, colIndex(c, row), a.ranges[k], &v, &mappable);
+      ok = id != 0;
+      key += a.ranges[k].multiplier * id;
+    }
+  }
+  return ok ? static_cast<uint32_t>((twangMix64(key) & a.mask) >> a.binShift)
+            : static_cast<uint32_t>(row >> 13) & static_cast<uint32_t>(a.numBins - 1);
+}
+
+__global__ __launch_bounds__(1024) void k_grp_hist(GroupArgs a) {
+  __shared__ uint32_t hist[kGrpMaxBins];
+  for (int64_t tile = blockIdx.x; tile < a.numTiles; tile += gridDim.x) {
+    for (int i = threadIdx.x; i < a.numBins; i += blockDim.x) {
+      hist[i] = 0;
+    }
+    blockSync();
+    const int64_t begin = tile * kGrpTileRows;
+    const int64_t end = begin + kGrpTileRows < a.numRows ? begin + kGrpTileRows : a.numRows;
+    for (int64_t base = begin; base < end; base += 8 * 1024) {
+      uint32_t bin[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t r = base + u * 1024 + threadIdx.x;
+        bin[u] = groupBinOf(a, r < end ? r : end - 1);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (base + u * 1024 + threadIdx.x < end) {
+          atomicAdd(&hist[bin[u]], 1u);
+        }
+      }
+    }
+    blockSync();
+    for (int i = threadIdx.x; i < a.numBins; i += blockDim.x) {
+      a.hist[static_cast<int64_t>(i) * a.numTiles + tile] = hist[i];
+    }
+    blockSync();
+  }
+}
+
+// Element 'r' of part q, zero extended.
+__device__ inline uint64_t groupLoadPart(const GroupArgs& a, int q, int64_t r) {
+  if (a.in[q] == nullptr) {
+    return static_cast<uint64_t>(r);
+  }
+  const char* at = a.in[q] + r * a.stride[q];
+  switch (a.width[q]) {
+    case 8:
+      return __builtin_nontemporal_load(reinterpret_cast<const uint64_t*>(at));
+    case 4:
+      return __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(at));
+    case 2:
+      return *reinterpret_cast<const uint16_t*>(at);
+    default:
+      return *reinterpret_cast<const uint8_t*>(at);
+  }
+}
+
+__device__ inline void groupStorePart(const GroupArgs& a, int q, uint64_t row, uint64_t v) {
+  char* at = a.out[q] + row * a.outStride[q];
+  switch (a.width[q]) {
+    case 8:
+      *reinterpret_cast<uint64_t*>(at) = v;
+      break;
+    case 4:
+      *reinterpret_cast<uint32_t*>(at) = static_cast<uint32_t>(v);
+      break;
+    case 2:
+      *reinterpret_cast<uint16_t*>(at) = static_cast<uint16_t>(v);
+      break;
+    default:
+      *reinterpret_cast<uint8_t*>(at) = static_cast<uint8_t>(v);
+      break;
+  }
+}
+
+// LDS (dynamic, sized by the host from the number of bins: groupScatterLds): the sorted sub-tile goes
+// through a stage of HALF its rows at a time - 64 KB in all for up to 1024 bins, so that two
+// workgroups share a CU and one's loads overlap the other's LDS phases.
+template <bool HALF>
+__host__ __device__ inline size_t groupScatterLds(int numBins) {
+  return static_cast<size_t>(numBins) * 16 + kGrpSub * 2 + (HALF ? kGrpSub / 2 : kGrpSub) * 8;
+}
+
+template <bool HALF>
+__global__ __launch_bounds__(1024) void k_grp_scatter(GroupArgs a) {
+  constexpr int kGrpStage = HALF ? kGrpSub / 2 : kGrpSub;
+  extern __shared__ __attribute__((aligned(16))) unsigned char grpLds[];
+  unsigned long long* binBase = reinterpret_cast<unsigned long long*>(grpLds);  // next free output row of the bin inside this tile's range
+  uint64_t* stage = reinterpret_cast<uint64_t*>(binBase + a.numBins);           // half of one part of the sub-tile, sorted
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(stage + kGrpStage);               // sub-tile histogram, then placement cursor
+  uint32_t* start = cnt + a.numBins;                                            // sub-tile exclusive scan
+  uint16_t* binAt = reinterpret_cast<uint16_t*>(start + a.numBins);             // bin of the i-th row of the sorted sub-tile
+  __shared__ uint32_t waveTotals[16];
+  constexpr int R = kGrpSub / 1024;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  for (int64_t tile = blockIdx.x; tile < a.numTiles; tile += gridDim.x) {
+    for (int i = tid; i < a.numBins; i += 1024) {
+      binBase[i] = a.offsets[static_cast<int64_t>(i) * a.numTiles + tile];
+    }
+    const int64_t tileBegin = tile * kGrpTileRows;
+    const int64_t end = tileBegin + kGrpTileRows < a.numRows ? tileBegin + kGrpTileRows : a.numRows;
+    for (int64_t base = tileBegin; base < end; base += kGrpSub) {
+      // the first part's values are on their way while the bins are computed; every later part is
+      // loaded while the one before it goes through LDS
+      uint64_t va[R], vb[R];
+      auto load = [&](int q, uint64_t (&v)[R]) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+          const int64_t r = base + u * 1024 + tid;
+          v[u] = groupLoadPart(a, q, r < end ? r : end - 1);
+        }
+      };
+      load(0, va);
+      for (int b = tid; b < a.numBins; b += 1024) {
+        cnt[b] = 0;
+      }
+      blockSync();
+      uint32_t bin[R];
+      if (a.fastKey) {
+        // part 0 IS the key column (the host lists it first): no second read of the keys
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+          const int64_t r = base + u * 1024 + tid;
+          const int64_t v = static_cast<int64_t>(va[u]);
+          const bool ok = v >= a.ranges[0].min && v <= a.ranges[0].max;
+          const uint64_t key = static_cast<uint64_t>(v) - static_cast<uint64_t>(a.ranges[0].min) + 1;
+          bin[u] = ok ? static_cast<uint32_t>((twangMix64(key) & a.mask) >> a.binShift)
+                      : static_cast<uint32_t>((r < end ? r : end - 1) >> 13) & static_cast<uint32_t>(a.numBins - 1);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+          const int64_t r = base + u * 1024 + tid;
+          bin[u] = groupBinOf(a, r < end ? r : end - 1);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        if (base + u * 1024 + tid < end) {
+          atomicAdd(&cnt[bin[u]], 1u);
+        } else {
+          bin[u] = 0xffffffffu;
+        }
+      }
+      blockSync();
+      // exclusive scan of the histogram: bins 4 t .. 4 t + 3 belong to thread t
+      constexpr int kBinsPerThread = kGrpMaxBins / 1024;
+      uint32_t mineBins[kBinsPerThread];
+      uint32_t mine = 0;
+#pragma unroll
+      for (int k = 0; k < kBinsPerThread; ++k) {
+        const int b = tid * kBinsPerThread + k;
+        mineBins[k] = b < a.numBins ? cnt[b] : 0;
+        mine += mineBins[k];
+      }
+      uint32_t incl = mine;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, kWave);
+        if (lane() >= off) {
+          incl += o;
+        }
+      }
+      if (lane() == 63) {
+        waveTotals[wave] = incl;
+      }
+      blockSync();
+      uint32_t run = incl - mine;
+      for (int w = 0; w < wave; ++w) {
+        run += waveTotals[w];
+      }
+#pragma unroll
+      for (int k = 0; k < kBinsPerThread; ++k) {
+        const int b = tid * kBinsPerThread + k;
+        if (b < a.numBins) {
+          start[b] = run;
+          cnt[b] = run;
+        }
+        run += mineBins[k];
+      }
+      blockSync();
+      uint32_t pos[R];
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        pos[u] = 0;
+        if (bin[u] != 0xffffffffu) {
+          pos[u] = atomicAdd(&cnt[bin[u]], 1u);
+          binAt[pos[u]] = static_cast<uint16_t>(bin[u]);
+        }
+      }
+      blockSync();
+      const uint32_t total = static_cast<uint32_t>(base + kGrpSub <= end ? kGrpSub : end - base);
+      uint64_t dst[R];
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        const uint32_t i = k * 1024 + tid;
+        dst[k] = 0;
+        if (i < total) {
+          const uint32_t b = binAt[i];
+          dst[k] = binBase[b] + (i - start[b]);
+        }
+      }
+      auto move = [&](int q, const uint64_t (&v)[R]) {
+        constexpr int kRounds = HALF ? 2 : 1;
+#pragma unroll
+        for (int half = 0; half < kRounds; ++half) {
+#pragma unroll
+          for (int u = 0; u < R; ++u) {
+            if (bin[u] != 0xffffffffu && (!HALF || (pos[u] >= kGrpStage) == (half == 1))) {
+              stage[pos[u] - half * kGrpStage] = v[u];
+            }
+          }
+          blockSync();
+#pragma unroll
+          for (int k = 0; k < R / kRounds; ++k) {
+            const uint32_t i = half * kGrpStage + k * 1024 + tid;
+            if (i < total) {
+              groupStorePart(a, q, dst[half * (R / kRounds) + k], stage[i - half * kGrpStage]);
+            }
+          }
+          blockSync();
+        }
+      };
+      for (int q = 0; q < a.numParts; q += 2) {
+        if (q + 1 < a.numParts) {
+          load(q + 1, vb);
+        }
+        move(q, va);
+        if (q + 1 < a.numParts) {
+          if (q + 2 < a.numParts) {
+            load(q + 2, va);
+          }
+          move(q + 1, vb);
+        }
+      }
+      for (int b = tid; b < a.numBins; b += 1024) {
+        binBase[b] += cnt[b] - start[b];
+      }
+      blockSync();
+    }
+  }
+}
+
+// The probe units (kGrpUnitRows rows of the regrouped batch: a quarter of a tile, so that the rows
+// in flight on an XCD can be held to about one slice's worth even when a slice has few rows)
+// listed per XCD: unit u belongs to the slice its first row is in, slice s to XCD s % 8; list x
+// holds the units of slices x, x + 8, ... in that order. xcdStart[0..8] = where each list begins.
+constexpr int kGrpUnitRows = 2048;
+static_assert(kTileRows % kGrpUnitRows == 0, "units do not straddle tiles");
+
+// unitList entry: {unit, its slice, its rank among the units of the slice, units of the slice}
+__global__ __launch_bounds__(1024) void k_grp_units(const uint64_t* offsets, int64_t histTiles, int32_t numBins,
+                                                    int64_t numUnits, int32_t unitRows, int4* unitList, uint32_t* xcdStart) {
+  __shared__ uint32_t first[kGrpMaxBins + 1];  // first unit whose first row is at or behind the bin's start
+  __shared__ uint32_t before[kGrpMaxBins];     // units of earlier bins on the same XCD
+  __shared__ uint32_t listStart[9];
+  const int tid = threadIdx.x;
+  for (int b = tid; b <= numBins; b += 1024) {
+    const uint64_t rowsBefore = offsets[static_cast<int64_t>(b) * histTiles];
+    first[b] = static_cast<uint32_t>((rowsBefore + unitRows - 1) / unitRows);
+  }
+  blockSync();
+  if (tid < 8) {
+    uint32_t run = 0;
+    for (int b = tid; b < numBins; b += 8) {
+      before[b] = run;
+      run += first[b + 1] - first[b];
+    }
+    listStart[tid + 1] = run;
+  }
+  blockSync();
+  if (tid == 0) {
+    listStart[0] = 0;
+    for (int x = 1; x <= 8; ++x) {
+      listStart[x] += listStart[x - 1];
+    }
+    if (blockIdx.x == 0) {
+      for (int x = 0; x <= 8; ++x) {
+        xcdStart[x] = listStart[x];
+      }
+    }
+  }
+  blockSync();
+  // every unit finds its bin (the last bin that begins at or before it) and from it its place
+  const int64_t u = static_cast<int64_t>(blockIdx.x) * 1024 + tid;
+  if (u < numUnits) {
+    int lo = 0, hi = numBins;  // first[lo] <= u < first[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (first[mid] <= static_cast<uint32_t>(u)) {
+        lo = mid;
+      } else {
+        hi = mid;
+      }
+    }
+    // empty bins share their 'first' with the next bin: take the last bin with first[b] <= u, which owns u
+    const uint32_t rank = static_cast<uint32_t>(u) - first[lo];
+    unitList[listStart[lo & 7] + before[lo] + rank] =
+        make_int4(static_cast<int32_t>(u), lo, static_cast<int32_t>(rank), static_cast<int32_t>(first[lo + 1] - first[lo]));
+  }
+}
+
+// k_join_probe over a regrouped batch, one unit per workgroup: block b takes the (b / 8)-th unit of
+// the list of XCD b % 8 (workgroups are dealt to the XCDs round robin and start in index order -
+// observed, not promised: another placement costs speed, never correctness). The launch asks for
+// LDS it does not use so that only a few workgroups fit a CU: the rows in flight on an XCD then
+// span about one slice, which is what lets the slice live in that XCD's L2. Lists longer than
+// gridDim.x / 8 (skewed slices) wrap around. tileSums[] is zero on entry.
+// Before it probes, a workgroup streams its share of the slice (sliceBytes / units of the slice)
+// through plain coalesced loads: the slice reaches the L2 in whole lines at streaming speed instead
+// of one dependent miss per first touch of a line (with few probe rows per slice - chunked input -
+// those misses were 19 % of the accesses, profiles/r06_c5_counters.md).
+template <int FAST, int WIDE, int UNIT>
+__global__ __launch_bounds__(256) void k_join_probe_grouped(ProbeArgs args, const int4* unitList, const uint32_t* xcdStart,
+                                                             const uint4* tableBase, uint64_t sliceUnits16) {
+  __shared__ uint64_t waveSums[4];
+  const ProbeArgs& a = args;
+  const uint32_t xcd = blockIdx.x & 7;
+  const uint32_t perXcd = gridDim.x >> 3;
+  const uint32_t end = xcdStart[xcd + 1];
+  uint32_t touched = 0;
+  for (uint32_t j = xcdStart[xcd] + (blockIdx.x >> 3); j < end; j += perXcd) {
+    const int4 info = unitList[j];
+    const int64_t unit = info.x;
+    if (sliceUnits16) {
+      const uint4* slice = tableBase + static_cast<uint64_t>(info.y) * sliceUnits16;
+      const uint64_t lo = sliceUnits16 * static_cast<uint64_t>(info.z) / static_cast<uint64_t>(info.w);
+      const uint64_t hi = sliceUnits16 * (static_cast<uint64_t>(info.z) + 1) / static_cast<uint64_t>(info.w);
+#pragma unroll 4
+      for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        touched ^= slice[i].x;
+      }
+    }
+    uint64_t mine = probeTileBody<JMODE_NORMALIZED, FAST, false, WIDE, 0, 256, UNIT>(a, unit, nullptr);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mine += shfl64(mine, lane() ^ off);
+    }
+    if (lane() == 0) {
+      waveSums[threadIdx.x >> 6] = mine;
+    }
+    blockSync();
+    if (threadIdx.x == 0) {
+      const uint64_t total = waveSums[0] + waveSums[1] + waveSums[2] + waveSums[3];
+      if (total) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.tileSums + unit / (kTileRows / UNIT)),
+                  static_cast<unsigned long long>(total));
+      }
+      if (UNIT == kTileRows / 4 && a.unitSums) {
+        a.unitSums[unit] = static_cast<uint32_t>(total);
+      }
+    }
+    blockSync();
+  }
+  if (touched == 0x9e3779b9u && a.numRows < 0) {
+    a.hits[0] = touched;  // never: keeps the streaming loads alive
+  }
+}
+
 __global__ __launch_bounds__(256) void k_emit_pairs(const uint64_t* sorted, int64_t begin, int32_t n, int32_t wantBuild,
                                                      int32_t* mapping, int32_t* buildRows) {
   const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1722,6 +2288,153 @@ __global__ __launch_bounds__(256) void k_emit_pairs(const uint64_t* sorted, int6
     mapping[i] = static_cast<int32_t>(w >> 32);
     if (buildRows) {
       buildRows[i] = wantBuild ? static_cast<int32_t>(static_cast<uint32_t>(w)) : -1;
+    }
+  }
+}
+
+// ---- normalized-key table assembled group by group in LDS ---------------------------------------
+// Inserting rows one by one into a table of hundreds of MB is a stream of random read-modify-writes:
+// ~20 G/s per chip whatever their locality (profiles/r02_atomic_bench.txt), 130 bytes written to HBM
+// per row (profiles/r06_c5_counters.md) - 2.7 ms for the 20 M rows of config 5's one-GPU shape. The
+// reference parallelises the same step by giving every thread a contiguous range of buckets and the
+// rows that hash there (parallelJoinBuild / buildJoinPartition, exec/HashTable.cpp:1003-1203,
+// :1255). Here a range is a 'group' of slots that fits LDS (128 KB), a row's walk wraps inside its
+// group (nextSlot), and:
+//   1. k_norm_keys          the normalized key of every build row                 (16 B/row)
+//   2. k_grp_hist/_scatter  {key, row, dependents} records grouped by the top bits of the slot
+//                           number - the passes that regroup a probe batch      (~ 2 x 32 B/row)
+//   3. k_lds_build          one workgroup per group: the records of the group's bin are streamed
+//                           (L2: the workgroups of one bin follow each other on one XCD), those of
+//                           the group inserted into the LDS image with LDS atomics, the image
+//                           written out in whole lines - no fill pass, no HBM atomic.
+struct LdsBuildArgs {
+  const char* recs;           // records of recBytes: {u64 key, u32 row, u32 -, [u64 dep0, u64 dep1]}
+  const uint64_t* offsets;    // bin-major scan of the regroup: bin b starts at offsets[b * histTiles]
+  int64_t histTiles;
+  int32_t groupsPerBinShift;  // group g belongs to bin g >> groupsPerBinShift
+  int32_t slotShift;          // 4 / 5 (records have the size of a slot)
+  int32_t groupShift;         // log2(slots per group)
+  int32_t dropDups;
+  uint64_t mask;              // capacity - 1
+  uint64_t homeMask;
+  char* slots;
+  uint32_t* next;
+  BuildCounters* counters;
+  int32_t numGroups;
+  int32_t pad;
+};
+
+__global__ __launch_bounds__(256) void k_norm_keys(InsertArgs a, uint64_t* out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < a.numRows; row += stride) {
+    out[row] = buildKey(a, row);
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_lds_build(LdsBuildArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char image[];
+  __shared__ uint32_t tallies[3];  // distinct, duplicates, overflow
+  // XCD-aware: block b works for XCD b % 8 and takes the (b / 8)-th group of that XCD's contiguous
+  // range of groups, so the groups of one bin (which stream the same records) share an L2
+  const uint32_t perXcd = (static_cast<uint32_t>(a.numGroups) + 7) / 8;
+  const uint32_t group = (blockIdx.x & 7) * perXcd + (blockIdx.x >> 3);
+  if (group >= static_cast<uint32_t>(a.numGroups)) {
+    return;
+  }
+  const uint32_t groupSlots = 1u << a.groupShift;
+  const uint32_t units = groupSlots << (a.slotShift - 4);
+  for (uint32_t i = threadIdx.x; i < units; i += 1024) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (a.slotShift == 4 || (i & 1) == 0) {
+      v = make_uint4(0xffffffffu, 0xffffffffu, kNoRow32, 0);
+    }
+    reinterpret_cast<uint4*>(image)[i] = v;
+  }
+  if (threadIdx.x < 3) {
+    tallies[threadIdx.x] = 0;
+  }
+  blockSync();
+  const uint32_t bin = group >> a.groupsPerBinShift;
+  const uint64_t begin = a.offsets[static_cast<int64_t>(bin) * a.histTiles];
+  const uint64_t end = a.offsets[static_cast<int64_t>(bin + 1) * a.histTiles];
+  const int recShift = a.slotShift;
+  uint32_t distinct = 0, dups = 0;
+  // (Tried and dropped, profiles/r06_c5_variants.md: the next round's records loaded before this round's
+  // are inserted - 4.0 instead of 1.6 ms, the second set of registers costs the occupancy that hid the
+  // latency; the fields as separate arrays, so that the scan reads 8 instead of 32 bytes per row - 2.1 ms,
+  // three dependent loads per inserted row instead of one.)
+  constexpr int kPer = 4;
+  for (uint64_t base = begin; base < end; base += kPer * 1024) {
+    uint4 head[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const uint64_t i = base + u * 1024 + threadIdx.x;
+      head[u] = *reinterpret_cast<const uint4*>(a.recs + ((i < end ? i : end - 1) << recShift));
+    }
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const uint64_t i = base + u * 1024 + threadIdx.x;
+      const uint64_t key = (static_cast<uint64_t>(head[u].y) << 32) | head[u].x;
+      const uint64_t home = twangMix64(key) & a.homeMask;
+      if (i >= end || (home >> a.groupShift) != group) {
+        continue;
+      }
+      const uint32_t row = head[u].z;
+      uint32_t pos = static_cast<uint32_t>(home) & (groupSlots - 1);
+      bool placed = false;
+      for (uint32_t probes = 0; probes < groupSlots; ++probes) {
+        unsigned char* slot = image + (static_cast<size_t>(pos) << a.slotShift);
+        const unsigned long long old =
+            atomicCAS(reinterpret_cast<unsigned long long*>(slot), static_cast<unsigned long long>(kEmptyKey),
+                      static_cast<unsigned long long>(key));
+        if (old == kEmptyKey) {
+          if (a.slotShift == 5) {
+            // (the dependents share the 32-byte sector of the key just read)
+            *reinterpret_cast<uint4*>(slot + 16) = *reinterpret_cast<const uint4*>(a.recs + (i << recShift) + 16);
+          }
+          ++distinct;
+        }
+        if (old == kEmptyKey || old == key) {
+          if (old == key && a.dropDups) {
+            a.next[row] = kNoRow32;  // the claiming row stays the key's only row
+          } else {
+            // pushNext (HashTable.cpp:1412-1418): the new row becomes the head of the key's chain
+            a.next[row] = atomicExch(reinterpret_cast<uint32_t*>(slot + 8), row);
+            dups += old == key ? 1 : 0;
+          }
+          placed = true;
+          break;
+        }
+        pos = (pos + 1) & (groupSlots - 1);
+      }
+      if (!placed) {
+        tallies[2] = 1;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    distinct += __shfl_xor(distinct, off, kWave);
+    dups += __shfl_xor(dups, off, kWave);
+  }
+  if (lane() == 0) {
+    atomicAdd(&tallies[0], distinct);
+    atomicAdd(&tallies[1], dups);
+  }
+  blockSync();
+  uint4* out = reinterpret_cast<uint4*>(a.slots + ((static_cast<size_t>(group) << a.groupShift) << a.slotShift));
+  for (uint32_t i = threadIdx.x; i < units; i += 1024) {
+    out[i] = reinterpret_cast<const uint4*>(image)[i];
+  }
+  if (threadIdx.x == 0) {
+    if (tallies[0]) {
+      atomicAdd(&a.counters->numDistinct, tallies[0]);
+    }
+    if (tallies[1]) {
+      atomicAdd(&a.counters->duplicates, tallies[1]);
+    }
+    if (tallies[2]) {
+      a.counters->tableFull = 1;
     }
   }
 }
@@ -2216,6 +2929,9 @@ struct EmitArgs {
   const uint64_t* hitVals[kWideDeps];
   const uint64_t* depVals[kWideDeps];
   uint64_t* outVals[kWideDeps];
+  // output rows of every quarter tile, when the probe pass counted them (k_join_probe_grouped): the
+  // 0-or-1-rows-per-probe-row path takes its wave totals from here instead of reading hits[] twice
+  const uint32_t* quarterSums;
 };
 static_assert(sizeof(EmitArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
@@ -2258,11 +2974,15 @@ __global__ __launch_bounds__(256) void k_emit(EmitArgs a) {
     constexpr int kWaveRows = kTileRows / 4;
     const int64_t waveBase = tile * kTileRows + static_cast<int64_t>(threadIdx.x >> 6) * kWaveRows;
     uint64_t total = 0;
-    for (int it = 0; it < kWaveRows / 64; ++it) {
-      const int64_t r = waveBase + it * 64 + lane();
-      const bool out = r < a.numRows &&
-          outputCount(a.joinType, isHit(a.hits[r]) ? 1 : 0, a.hits[r] == kNullKey32) != 0;
-      total += popc64(ballot(out));
+    if (a.quarterSums) {
+      total = a.quarterSums[tile * 4 + (threadIdx.x >> 6)];
+    } else {
+      for (int it = 0; it < kWaveRows / 64; ++it) {
+        const int64_t r = waveBase + it * 64 + lane();
+        const bool out = r < a.numRows &&
+            outputCount(a.joinType, isHit(a.hits[r]) ? 1 : 0, a.hits[r] == kNullKey32) != 0;
+        total += popc64(ballot(out));
+      }
     }
     if (lane() == 0) {
       waveTotals[threadIdx.x >> 6] = total;
@@ -2523,7 +3243,9 @@ struct vx355_join_table {
   uint64_t capacity = 0;
   DevBuf head;   // array mode: u32[capacity], only entries whose presence bit is set are valid
   DevBuf present;  // array mode: bit per possible key
-  DevBuf slots;  // hash mode: Slot[capacity]
+  DevBuf slots;  // hash mode: Slot[capacity], or WideSlot[capacity] when slotShift == 5
+  int32_t slotShift = 4;
+  uint64_t homeMask = 0, wrapMask = 0;  // see nextSlot (join.hip)
   DevBuf next;   // u32[numRows]
   DevBuf gslots;  // generic hash mode: u64[capacity]
   std::vector<DevBuf> keyStore;  // generic hash mode: build key images
@@ -2582,6 +3304,16 @@ struct vx355_join_probe {
   int32_t wideStaged = 0;      // how many of the table's wide dependents this batch staged
   int32_t denseStreak = 0;     // batches that still skip the sparse-listing sample
   bool partitionFast = true;   // VX355_JOIN_PARTITION_FAST=0: the range-partitioned probe always counts first
+  // vx355_join_probe_add_input_regrouped: VX355_JOIN_REGROUP -1 adaptive, 0 never, 1 whenever eligible;
+  // VX355_JOIN_SLICE_BYTES = bytes of the slot array one group of rows is probed against;
+  // VX355_JOIN_GROUP_WGS = workgroups per CU of the grouped probe (0: from the rows per slice)
+  int32_t regroupMode = -1;
+  int64_t sliceBytes = 4 << 20;   // (an XCD's L2; 2 MiB: probe 2 % faster, regrouping 10-15 % slower - twice the bins)
+  int32_t groupWgs = 0;
+  bool groupPrefetch = false;  // VX355_JOIN_GROUP_PREFETCH=1: the grouped probe streams its share of the slice first (measured: no gain)
+  int32_t groupUnit = 2048;    // VX355_JOIN_GROUP_UNIT: rows per workgroup of the grouped probe (2048 or 8192)
+  DevBuf grpHist, grpOffsets, grpScan, grpUnits, grpXcd, grpUnitSums;
+  bool haveUnitSums = false;   // the batch's output rows per quarter tile are in grpUnitSums
   DeviceBatch batch;                       // the batch being probed: the filter reads it at output time
   std::vector<std::vector<char>> hostStrings;  // long payload strings of the last page handed to a host caller
   std::vector<vx355_join_filter_term> filter;
@@ -2757,6 +3489,114 @@ void buildAddInput(vx355_join_build& h, const vx355_batch* batch) {
   h.numRows += selected;
 }
 
+void launchGroupScatter(const GroupArgs& g, int tiles) {
+  auto& rt = Runtime::get();
+  // The sorted sub-tile goes through a stage of half its rows at a time (64 KB of LDS in all up to 1024 bins:
+  // two workgroups per CU, one's loads behind the other's LDS phases): 2.75 instead of 3.15 ms per 200 M
+  // rows of two 8-byte columns in the same run (profiles/r06_c5_variants.md). VX355_JOIN_SCATTER_HALF=0: the
+  // whole sub-tile at once, one workgroup per CU.
+  static const bool half = !(std::getenv("VX355_JOIN_SCATTER_HALF") && std::atoi(std::getenv("VX355_JOIN_SCATTER_HALF")) == 0);
+  const size_t lds = half ? groupScatterLds<true>(g.numBins) : groupScatterLds<false>(g.numBins);
+  auto kernel = half ? k_grp_scatter<true> : k_grp_scatter<false>;
+  if (lds > (48u << 10)) {
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               static_cast<int>(lds)));
+  }
+  const int perCu = std::max<int>(1, static_cast<int>((160u << 10) / (lds + 1024)));
+  VX_LAUNCH("k_grp_scatter", kernel, std::min<int>(tiles, rt.numCUs * std::min(perCu, 2)), 1024, lds, g);
+}
+
+// The normalized-key table of 't' (capacity, slotShift, homeMask set; slots allocated) assembled
+// from the rows of 'h' group by group in LDS (see k_lds_build). false: some group overflowed (more
+// distinct keys than slots hash into 128 KB of the table - never with a mixing hash and load <= 0.7,
+// but not impossible): the caller inserts the classic way.
+bool buildInLds(vx355_join_build& h, vx355_join_table& t, const InsertArgs& ia) {
+  auto& rt = Runtime::get();
+  const int64_t n = h.numRows;
+  const uint64_t cap = t.capacity;
+  const int slotShift = t.slotShift;
+  // 64 KB of slots per group: two workgroups share a CU, one streams records while the other
+  // writes its image out
+  uint64_t groupBytes = 64 << 10;
+  if (const char* e = std::getenv("VX355_JOIN_LDS_GROUP_BYTES")) {
+    groupBytes = nextPow2(std::min<uint64_t>(std::max<uint64_t>(std::atoll(e), 4096), 128 << 10));
+  }
+  const uint64_t groupSlots = std::min<uint64_t>(cap, groupBytes >> slotShift);
+  const uint64_t numGroups = cap / groupSlots;
+  const uint64_t bins = std::min<uint64_t>(numGroups, kGrpMaxBins);
+  DevBuf normKeys, recs, hist, offsetsBuf, scan;
+  uint64_t* keys = static_cast<uint64_t*>(normKeys.ensure(static_cast<size_t>(n) * 8 + 64));
+  VX_LAUNCH("k_norm_keys", k_norm_keys, streamGrid(n, 256), 256, 0, ia, keys);
+  GroupArgs g{};
+  g.numKeys = 1;
+  g.keys[0].values = keys;
+  g.keys[0].kind = VX355_BIGINT;
+  g.keys[0].enc = VX355_FLAT;
+  g.ranges[0].min = 1;   // the column already holds normalized keys: id = v - 1 + 1
+  g.ranges[0].max = INT64_MAX;
+  g.ranges[0].multiplier = 1;
+  g.fastKey = 1;
+  g.numBins = static_cast<int32_t>(bins);
+  g.mask = cap - 1;
+  g.binShift = __builtin_ctzll(cap) - __builtin_ctzll(bins);
+  g.numRows = n;
+  g.numTiles = ceilDiv(n, kGrpTileRows);
+  char* records = static_cast<char*>(recs.ensure((static_cast<size_t>(n) << slotShift) + 64));
+  auto part = [&](const void* in, int stride, int offset, int width) {
+    const int q = g.numParts++;
+    g.in[q] = static_cast<const char*>(in);
+    g.stride[q] = stride;
+    g.out[q] = records + offset;
+    g.outStride[q] = 1 << slotShift;
+    g.width[q] = width;
+  };
+  part(keys, 8, 0, 8);        // part 0 = the key column (k_grp_scatter takes the bins from it)
+  part(nullptr, 0, 8, 4);     // the row number
+  if (slotShift == 5) {
+    part(ia.wideDep[0], 8, 16, 8);
+    if (ia.wideDep[1]) {
+      part(ia.wideDep[1], 8, 24, 8);
+    }
+  }
+  g.numCols = g.numParts;
+  const int64_t cells = g.numTiles * g.numBins;
+  g.hist = static_cast<uint32_t*>(hist.ensure(static_cast<size_t>(cells) * 4 + 64));
+  uint64_t* offsets = static_cast<uint64_t*>(offsetsBuf.ensure(static_cast<size_t>(cells + 1) * 8 + 64));
+  g.offsets = offsets;
+  const int grid = static_cast<int>(std::min<int64_t>(g.numTiles, static_cast<int64_t>(rt.numCUs) * 2));
+  VX_LAUNCH("k_grp_hist", k_grp_hist, grid, 1024, 0, g);
+  scanU32ToU64(g.hist, cells, offsets, scan);
+  launchGroupScatter(g, grid);
+  LdsBuildArgs b{};
+  b.recs = records;
+  b.offsets = offsets;
+  b.histTiles = g.numTiles;
+  b.groupsPerBinShift = __builtin_ctzll(numGroups) - __builtin_ctzll(bins);
+  b.slotShift = slotShift;
+  b.groupShift = __builtin_ctzll(groupSlots);
+  b.dropDups = ia.dropDups;
+  b.mask = cap - 1;
+  b.homeMask = t.homeMask;
+  b.slots = t.slots.as<char>();
+  b.next = ia.next;
+  b.counters = ia.counters;
+  b.numGroups = static_cast<int32_t>(numGroups);
+  const size_t lds = static_cast<size_t>(groupSlots) << slotShift;
+  if (lds > (48u << 10)) {
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lds_build), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               static_cast<int>(lds)));
+  }
+  const int blocks = static_cast<int>(ceilDiv(static_cast<int64_t>(numGroups), 8) * 8);
+  VX_LAUNCH("k_lds_build", k_lds_build, blocks, 1024, lds, b);
+  BuildCounters c = readBuildCounters(h.countersBuf);
+  if (c.tableFull) {
+    resetBuildCounters(h.countersBuf);
+    return false;
+  }
+  t.wrapMask = groupSlots - 1;
+  return true;
+}
+
 vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* others, int32_t numOthers) {
   auto& rt = Runtime::get();
   VX_CHECK_ARG(!h.finished, "finish called twice");
@@ -2874,6 +3714,7 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
   ia.counters = h.countersBuf.as<BuildCounters>();
   t->next.ensure(static_cast<size_t>(std::max<int64_t>(1, h.numRows)) * 4 + 64);
   ia.next = t->next.as<uint32_t>();
+  bool insertedInLds = false;
   if (generic) {
     t->mode = JMODE_HASH;
     const uint64_t cap = std::max<uint64_t>(2048, nextPow2(static_cast<uint64_t>(h.numRows) * 2));
@@ -2895,31 +3736,85 @@ vx355_join_table* buildFinish(vx355_join_build& h, vx355_join_build* const* othe
     ia.present = t->present.as<uint32_t>();
   } else {
     t->mode = JMODE_NORMALIZED;
-    // HashTable::newHashTableEntries (HashTable.h:946-956).
+    // Wide slots from the start (see slotAt) for an inner-join build that no cache will hold and
+    // that has 8-byte dependents without nulls: VX355_JOIN_WIDE_BUILD = 0 never, 1 whenever the
+    // dependents qualify, unset = builds of 2^20 rows and more.
+    int wideBuild = -1;
+    if (const char* e = std::getenv("VX355_JOIN_WIDE_BUILD")) {
+      wideBuild = std::atoi(e);
+    }
+    int32_t wideFound = 0;
+    if (wideBuild != 0 && h.joinType == VX355_JOIN_INNER && !h.dropDuplicates && !h.nullAsValue &&
+        (wideBuild > 0 || h.numRows >= (1 << 20))) {
+      for (size_t d = 0; d < h.depKinds.size() && wideFound < kWideDeps; ++d) {
+        if (kindWidth(h.depKinds[d]) == 8 && !isString(h.depKinds[d]) && !((h.depNulls >> d) & 1)) {
+          ia.wideDep[wideFound] = h.depVals[d].as<uint64_t>();
+          t->wideDeps[wideFound++] = static_cast<int32_t>(d);
+        }
+      }
+    }
+    t->slotShift = wideFound > 0 ? 5 : 4;
+    // HashTable::newHashTableEntries (HashTable.h:946-956): twice the rows, rounded up to a power of
+    // two (load <= 0.5). VX355_JOIN_WIDE_TIGHT=1 sizes a wide table for the reference's upper load bound
+    // (0.7, HashTable.h:143) instead: half the bytes, but 1.5 x the slots per lookup - measured on
+    // config 5's shape: grouped probe 4.2 ms instead of 2.9 ms (profiles/r06_c5_variants.md).
     uint64_t cap = std::max<uint64_t>(2048, nextPow2(static_cast<uint64_t>(h.numRows) * 2));
+    if (wideFound > 0 && std::getenv("VX355_JOIN_WIDE_TIGHT") && std::atoi(std::getenv("VX355_JOIN_WIDE_TIGHT")) != 0) {
+      cap = std::max<uint64_t>(2048, nextPow2((static_cast<uint64_t>(h.numRows) * 10 + 6) / 7));
+    }
     t->capacity = cap;
-    t->slots.ensure(static_cast<size_t>(cap) * sizeof(Slot) + 64);
-    VX_LAUNCH("k_fill_slots", k_fill_slots, streamGrid(static_cast<int64_t>(cap), 256, 2), 256, 0,
-              t->slots.as<Slot>(), cap);
+    t->slots.ensure((static_cast<size_t>(cap) << t->slotShift) + 64);
     ia.slots = t->slots.as<Slot>();
+    ia.slotShift = t->slotShift;
+    t->homeMask = (cap - 1) & ~static_cast<uint64_t>((64 >> t->slotShift) - 1);
+    ia.homeMask = t->homeMask;
+    ia.mode = t->mode;
+    ia.capacity = cap;
+    // Assembled group by group in LDS (k_lds_build) when the build is large: VX355_JOIN_LDS_BUILD = 0
+    // never, 1 whenever possible, unset = builds of 2^20 rows and more. Not for builds that keep rows
+    // with null keys out of the table (right / full joins), nor for normalized keys beyond 2^63.
+    int ldsBuild = -1;
+    if (const char* e = std::getenv("VX355_JOIN_LDS_BUILD")) {
+      ldsBuild = std::atoi(e);
+    }
+    if (ldsBuild != 0 && h.numRows > 0 && ia.keyNull == nullptr && range < (1ULL << 63) &&
+        (ldsBuild > 0 || h.numRows >= (1 << 20))) {
+      insertedInLds = buildInLds(h, *t, ia);
+    }
+    if (!insertedInLds) {
+      const uint64_t units = cap << (t->slotShift - 4);
+      VX_LAUNCH("k_fill_slots", k_fill_slots, streamGrid(static_cast<int64_t>(units), 256, 2), 256, 0,
+                t->slots.as<Slot>(), units, wideFound > 0 ? 1 : 0);
+      t->wrapMask = cap - 1;
+    }
+    ia.wrapMask = t->wrapMask;  // (k_count_init walks the finished table)
   }
   ia.mode = t->mode;
   ia.capacity = t->capacity;
   ia.phase = 1;
-  if (h.numRows > 0) {
+  if (h.numRows > 0 && !insertedInLds) {
     VX_LAUNCH("k_join_insert", k_join_insert, streamGrid(h.numRows, 256), 256, 0, ia);
   }
   BuildCounters c = readBuildCounters(h.countersBuf);
   if (c.tableFull) {
     VX_THROW(VX355_EINTERNAL, "join table full");
   }
-  if (t->mode == JMODE_ARRAY && c.duplicates) {
+  if ((t->mode == JMODE_ARRAY || t->mode == JMODE_NORMALIZED) && c.duplicates && !insertedInLds) {
     ia.phase = 2;
     VX_LAUNCH("k_join_insert", k_join_insert, streamGrid(h.numRows, 256), 256, 0, ia);
     rt.sync();
   }
   t->numDistinct = c.numDistinct;
   t->hasDuplicates = c.duplicates != 0;
+  if (t->slotShift == 5) {
+    // the inline dependents are those of the claiming row: only meaningful when it is the key's only row
+    t->wideTried = true;
+    int32_t found = 0;
+    while (found < kWideDeps && t->wideDeps[found] >= 0) {
+      ++found;
+    }
+    t->numWide = t->hasDuplicates ? 0 : found;
+  }
   if (countingJoin(h.joinType)) {
     const size_t bytes = static_cast<size_t>(std::max<int64_t>(1, h.numRows)) * 4;
     t->remaining.ensure(bytes + 64);
@@ -3046,7 +3941,14 @@ void fillFilterArgs(const vx355_join_probe& p, const DeviceBatch& db, JoinFilter
 
 int32_t ensureWide(vx355_join_table& t, int32_t mode, int64_t probeRows);
 
-void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
+// Where the slices of a regrouped batch begin (probeAddInputRegrouped).
+struct GroupedInput {
+  const uint64_t* offsets;  // bin-major scan of the (bin, tile) histogram: bin b starts at offsets[b * histTiles]
+  int64_t histTiles;
+  int32_t numBins;
+};
+
+void probeAddInput(vx355_join_probe& p, const vx355_batch* batch, const GroupedInput* grouped = nullptr) {
   auto& rt = Runtime::get();
   auto& t = *p.table;
   DeviceBatch& db = p.batch;
@@ -3059,6 +3961,7 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
   p.totalOut = 0;
   p.numTiles = 0;
   p.hasInput = true;
+  p.haveUnitSums = false;
   if (n == 0) {
     return;
   }
@@ -3157,6 +4060,9 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
   a.numRows = n;
   a.head = t.head.as<uint32_t>();
   a.slots = t.slots.as<Slot>();
+  a.slotShift = t.slotShift;
+  a.homeMask = t.homeMask;
+  a.wrapMask = t.wrapMask;
   a.gslots = t.gslots.as<uint64_t>();
   a.capacity = t.capacity;
   a.next = t.next.as<uint32_t>();
@@ -3194,7 +4100,7 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
   if (a.fastKey == 1 && p.joinType == VX355_JOIN_INNER && !filtered && !counting && !a.nullAware && p.inputFilter.empty()) {
     p.wideStaged = ensureWide(t, p.wideMode, n);
     if (p.wideStaged > 0) {
-      a.wide = t.wide.as<WideSlot>();
+      a.wide = t.slotShift == 5 ? t.slots.as<WideSlot>() : t.wide.as<WideSlot>();
       for (int i = 0; i < p.wideStaged; ++i) {
         a.hitVals[i] = static_cast<uint64_t*>(p.hitVals[i].ensure(static_cast<size_t>(n) * 8 + 64));
       }
@@ -3266,7 +4172,55 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
   const bool partEligible = p.partitionMode != 0 && t.mode == JMODE_ARRAY && a.fastKey == 1 &&
       partBins <= kPartMaxBins && n < (1LL << 32) &&
       (p.partitionMode == 1 || (n >= (4LL << 20) && presentWords * 4 > (16ULL << 20)));
-  if (sparseEligible) {
+  if (grouped && t.mode == JMODE_NORMALIZED && a.rf.numTerms == 0) {
+    // the batch arrives grouped by slice of the slot array: slice by slice, one XCD per slice
+    const int unitRows = p.groupUnit;
+    const int64_t units = ceilDiv(n, unitRows);
+    int4* unitList = static_cast<int4*>(p.grpUnits.ensure(static_cast<size_t>(units) * sizeof(int4) + 64));
+    uint32_t* xcdStart = static_cast<uint32_t*>(p.grpXcd.ensure(64));
+    VX_LAUNCH("k_grp_units", k_grp_units, static_cast<int>(ceilDiv(units, 1024)), 1024, 0, grouped->offsets,
+              grouped->histTiles, grouped->numBins, units, unitRows, unitList, xcdStart);
+    HIP_OK(hipMemsetAsync(sums, 0, static_cast<size_t>(p.numTiles) * 8, rt.stream));
+    // (not when a later pass rewrites hits[] - counting joins, extra filters - or per-row counts exist)
+    if (unitRows == kTileRows / 4 && !filtered && !counting && !p.haveCounts) {
+      a.unitSums = static_cast<uint32_t*>(p.grpUnitSums.ensure(static_cast<size_t>(p.numTiles) * 4 * 4 + 64));
+      HIP_OK(hipMemsetAsync(a.unitSums, 0, static_cast<size_t>(p.numTiles) * 4 * 4, rt.stream));  // (quarters past the last row)
+      p.haveUnitSums = true;
+    }
+    // workgroups per CU such that the rows in flight on an XCD (CUs / 8 x workgroups x unit) are about
+    // 1.25 slices' worth, between 2 and 8; the launch's unused LDS request enforces it
+    const int64_t cusPerXcd = std::max(1, rt.numCUs / 8);
+    int64_t perCu = p.groupWgs > 0 ? p.groupWgs : ceilDiv(n / grouped->numBins * 5 / 4, cusPerXcd * unitRows);
+    perCu = std::min<int64_t>(std::max<int64_t>(perCu, 2), 8);
+    const size_t ldsPad = perCu >= 8 ? 0 : (static_cast<size_t>(160) << 10) / static_cast<size_t>(perCu) - 1024;
+    const int grid = static_cast<int>(ceilDiv(units, 8) * 8);
+    const int shift = a.wide != nullptr ? 5 : t.slotShift;
+    const uint4* tableBase = a.wide != nullptr ? reinterpret_cast<const uint4*>(a.wide) : reinterpret_cast<const uint4*>(a.slots);
+    const uint64_t sliceUnits16 = p.groupPrefetch ? ((t.capacity / static_cast<uint64_t>(grouped->numBins)) << shift) / 16 : 0;
+    auto launchGrouped = [&](auto kernel) {
+      if (ldsPad > (48u << 10)) {
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(ldsPad)));
+      }
+      VX_LAUNCH("k_join_probe_grouped", kernel, grid, 256, ldsPad, a, unitList, xcdStart, tableBase, sliceUnits16);
+    };
+    const int wideKind = a.fastKey == 1 ? (a.wide != nullptr ? (a.hitVals[1] != nullptr ? 2 : 1) : 0) : -1;
+    if (unitRows == 8192) {
+      switch (wideKind) {
+        case 2: launchGrouped(k_join_probe_grouped<1, 2, 8192>); break;
+        case 1: launchGrouped(k_join_probe_grouped<1, 1, 8192>); break;
+        case 0: launchGrouped(k_join_probe_grouped<1, 0, 8192>); break;
+        default: launchGrouped(k_join_probe_grouped<-1, 0, 8192>); break;
+      }
+    } else {
+      switch (wideKind) {
+        case 2: launchGrouped(k_join_probe_grouped<1, 2, 2048>); break;
+        case 1: launchGrouped(k_join_probe_grouped<1, 1, 2048>); break;
+        case 0: launchGrouped(k_join_probe_grouped<1, 0, 2048>); break;
+        default: launchGrouped(k_join_probe_grouped<-1, 0, 2048>); break;
+      }
+    }
+  } else if (sparseEligible) {
     a.staged = static_cast<uint2*>(p.staged.ensure(static_cast<size_t>(p.numTiles) * kSparseCap * sizeof(uint2) + 64));
     a.tileDense = static_cast<uint8_t*>(p.tileDense.ensure(static_cast<size_t>(p.numTiles) + 64));
     a.sparseStats = static_cast<uint64_t*>(p.sparseStats.ensure(64));
@@ -3455,6 +4409,95 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
   }
 }
 
+// HashProbe::addInput with the batch regrouped by slice of the table's slot array first (see
+// k_grp_hist). *regrouped = 0: the table or the batch does not qualify and the batch was probed as
+// it came (outValues untouched).
+void probeAddInputRegrouped(vx355_join_probe& p, const vx355_batch* batch, void* const* outValues, int32_t* regrouped) {
+  auto& rt = Runtime::get();
+  auto& t = *p.table;
+  *regrouped = 0;
+  const int64_t n = batch->num_rows;
+  const uint64_t tableBytes = t.capacity << t.slotShift;
+  bool ok = p.regroupMode != 0 && t.mode == JMODE_NORMALIZED && t.numRows > 0 && n > 0 &&
+      batch->num_cols <= kGrpMaxCols && p.inputFilter.empty();
+  // worth two more passes over the batch: a table that no cache holds, a batch that fills the chip
+  ok = ok && (p.regroupMode == 1 || (tableBytes >= (64ULL << 20) && n >= (1 << 22)));
+  for (int32_t c = 0; ok && c < batch->num_cols; ++c) {
+    const vx355_column& col = batch->cols[c];
+    const int w = kindWidth(col.type_kind);
+    ok = col.encoding == VX355_FLAT && col.nulls == nullptr && col.values != nullptr &&
+        (w == 1 || w == 2 || w == 4 || w == 8 || w == 16) && outValues[c] != nullptr;
+  }
+  for (size_t k = 0; ok && k < p.keyCols.size(); ++k) {
+    const int32_t kind = batch->cols[p.keyCols[k]].type_kind;
+    ok = isString(kind) == isString(t.keyKinds[k]) && (isString(kind) || isIntLike(kind));
+  }
+  if (!ok) {
+    probeAddInput(p, batch);
+    return;
+  }
+  std::vector<int32_t> all(batch->num_cols);
+  for (int32_t c = 0; c < batch->num_cols; ++c) {
+    all[c] = c;
+  }
+  DeviceBatch in;
+  in.load(batch, all);  // host columns are staged; device columns aliased
+  GroupArgs g{};
+  g.numKeys = static_cast<int32_t>(p.keyCols.size());
+  for (int k = 0; k < g.numKeys; ++k) {
+    g.keys[k] = in.col(p.keyCols[k]);
+    g.ranges[k] = t.ranges[k];
+  }
+  g.nullAsValue = t.nullAsValue ? 1 : 0;
+  g.fastKey = (g.numKeys == 1 && g.keys[0].kind == VX355_BIGINT && g.ranges[0].multiplier == 1) ? 1 : 0;
+  uint64_t bins = nextPow2(std::max<uint64_t>(1, tableBytes / static_cast<uint64_t>(p.sliceBytes)));
+  bins = std::min<uint64_t>(std::max<uint64_t>(bins, 8), std::min<uint64_t>(kGrpMaxBins, t.capacity));
+  g.numBins = static_cast<int32_t>(bins);
+  g.mask = t.capacity - 1;
+  g.binShift = __builtin_ctzll(t.capacity) - __builtin_ctzll(bins);
+  g.numCols = batch->num_cols;
+  g.numRows = n;
+  g.numTiles = ceilDiv(n, kGrpTileRows);
+  // (a single flat BIGINT key goes first: k_grp_scatter takes its bins from part 0's values)
+  std::vector<int32_t> order;
+  if (g.fastKey) {
+    order.push_back(p.keyCols[0]);
+  }
+  for (int32_t c = 0; c < batch->num_cols; ++c) {
+    if (!g.fastKey || c != p.keyCols[0]) {
+      order.push_back(c);
+    }
+  }
+  for (int32_t c : order) {
+    const int w = kindWidth(batch->cols[c].type_kind);
+    for (int part = 0; part < (w == 16 ? 2 : 1); ++part) {
+      const int q = g.numParts++;
+      g.in[q] = static_cast<const char*>(in.col(c).values) + part * 8;
+      g.out[q] = static_cast<char*>(outValues[c]) + part * 8;
+      g.stride[q] = w;
+      g.outStride[q] = w;
+      g.width[q] = w == 16 ? 8 : w;
+    }
+  }
+  const int64_t cells = g.numTiles * g.numBins;
+  g.hist = static_cast<uint32_t*>(p.grpHist.ensure(static_cast<size_t>(cells) * 4 + 64));
+  uint64_t* offsets = static_cast<uint64_t*>(p.grpOffsets.ensure(static_cast<size_t>(cells + 1) * 8 + 64));
+  g.offsets = offsets;
+  const int grid = static_cast<int>(std::min<int64_t>(g.numTiles, static_cast<int64_t>(rt.numCUs) * 2));
+  VX_LAUNCH("k_grp_hist", k_grp_hist, grid, 1024, 0, g);
+  scanU32ToU64(g.hist, cells, offsets, p.grpScan);
+  launchGroupScatter(g, grid);
+  std::vector<vx355_column> cols(batch->cols, batch->cols + batch->num_cols);
+  for (int32_t c = 0; c < batch->num_cols; ++c) {
+    cols[c].values = outValues[c];
+    cols[c].mem = VX355_MEM_DEVICE;
+  }
+  vx355_batch moved{batch->num_rows, batch->num_cols, cols.data()};
+  GroupedInput gi{offsets, g.numTiles, g.numBins};
+  probeAddInput(p, &moved, &gi);
+  *regrouped = 1;
+}
+
 // extractColumns for 'n' listed build rows (-1 = null row) into caller columns.
 // The table's wide slots, built now if this is the first batch to ask and the table qualifies:
 // normalized-key mode, no duplicate keys, at least one 8-byte dependent without nulls. A batch
@@ -3464,6 +4507,9 @@ void probeAddInput(vx355_join_probe& p, const vx355_batch* batch) {
 int32_t ensureWide(vx355_join_table& t, int32_t mode, int64_t probeRows) {
   if (mode == 0 || t.mode != JMODE_NORMALIZED || t.hasDuplicates || t.numRows == 0) {
     return 0;
+  }
+  if (t.slotShift == 5) {
+    return t.numWide;  // built wide (or not usable: duplicate keys)
   }
   std::lock_guard<std::mutex> lock(t.lazyMutex);
   if (t.numWide > 0) {
@@ -3628,6 +4674,7 @@ void probeGetOutput(vx355_join_probe& p, int32_t maxRows, int32_t* mappingOut, i
   EmitArgs ea{};
   ea.hits = p.hits.as<uint32_t>();
   ea.counts = p.haveCounts ? p.counts.as<uint32_t>() : nullptr;
+  ea.quarterSums = p.haveUnitSums ? p.grpUnitSums.as<uint32_t>() : nullptr;
   ea.next = t.next.as<uint32_t>();
   ea.tileOffsets = p.tileOffsets.as<uint64_t>();
   ea.numRows = p.numRows;
@@ -4094,6 +5141,13 @@ int vx355_join_table_get_stats(const vx355_join_table* t, vx355_join_table_stats
   VX_API_END
 }
 
+int vx355_join_build_get_gpu_stats(const vx355_join_build* h, vx355_gpu_stats* out) {
+  return vx::gpuStatsOf(h ? h->ctx : nullptr, out);
+}
+int vx355_join_probe_get_gpu_stats(const vx355_join_probe* h, vx355_gpu_stats* out) {
+  return vx::gpuStatsOf(h ? h->ctx : nullptr, out);
+}
+
 int vx355_join_probe_create(vx355_join_table* table, const vx355_join_probe_spec* spec,
                             vx355_join_probe** out) {
   VX_API_BEGIN
@@ -4136,6 +5190,24 @@ int vx355_join_probe_create(vx355_join_table* table, const vx355_join_probe_spec
   }
   if (const char* e = std::getenv("VX355_JOIN_WIDE")) {
     p->wideMode = std::atoi(e);
+  }
+  if (const char* e = std::getenv("VX355_JOIN_REGROUP")) {
+    p->regroupMode = std::atoi(e);
+    if (p->regroupMode != 0 && p->regroupMode != 1) {
+      p->regroupMode = -1;
+    }
+  }
+  if (const char* e = std::getenv("VX355_JOIN_SLICE_BYTES")) {
+    p->sliceBytes = std::max<int64_t>(1 << 16, std::atoll(e));
+  }
+  if (const char* e = std::getenv("VX355_JOIN_GROUP_UNIT")) {
+    p->groupUnit = std::atoi(e) == 8192 ? 8192 : 2048;
+  }
+  if (const char* e = std::getenv("VX355_JOIN_GROUP_PREFETCH")) {
+    p->groupPrefetch = std::atoi(e) != 0;
+  }
+  if (const char* e = std::getenv("VX355_JOIN_GROUP_WGS")) {
+    p->groupWgs = std::max(0, std::atoi(e));
   }
   if (const char* e = std::getenv("VX355_JOIN_WINDOW")) {
     p->window = std::atoi(e) != 0;
@@ -4225,6 +5297,16 @@ static int joinProbeAddInputNow(vx355_join_probe* h, const vx355_batch* batch) {
 int vx355_join_probe_add_input(vx355_join_probe* h, const vx355_batch* batch) {
   VX_ASYNC_DRAIN(h)
   return joinProbeAddInputNow(h, batch);
+}
+
+int vx355_join_probe_add_input_regrouped(vx355_join_probe* h, const vx355_batch* batch, void* const* regrouped_values,
+                                         int32_t* regrouped) {
+  VX_ASYNC_DRAIN(h)
+  VX_API_BEGIN_CTX(VX_CTX_OF(h))
+  Runtime::get().requireInit();
+  VX_CHECK_ARG(h && batch && regrouped_values && regrouped, "NULL argument");
+  probeAddInputRegrouped(*h, batch, regrouped_values, regrouped);
+  VX_API_END
 }
 
 // Asynchronous boundary for the probe side (exec/Operator.h:285-299: a Driver thread must not sit in
@@ -4393,10 +5475,11 @@ int vx355_join_probe_output_result(vx355_join_probe* h, int64_t ticket, int32_t*
       vx::setLastError("no queued get_output with this ticket (results are handed out once)");
       return VX355_EINVAL;
     }
+    // The queue's position FIRST, the page's flag after it (see vx355_agg_output_result).
+    int64_t submitted = 0, completed = 0;
+    vx::asyncPoll(h->aq, &submitted, &completed);
     if (!it->second->complete.load(std::memory_order_acquire)) {
-      int64_t submitted = 0, completed = 0;
-      vx::asyncPoll(h->aq, &submitted, &completed);
-      if (completed < ticket) {
+      if (completed < ticket || vx::asyncFailed(h->aq) == VX355_OK) {
         vx::setLastError("the queued get_output has not completed (vx355_join_probe_poll: completed < ticket)");
         return VX355_EINVAL;
       }

@@ -1,6 +1,8 @@
 // libvx355 runtime: device binding, library stream, pinned mailbox, device
 // memory helpers, batch staging and the HIP-event profiler.
 #include "common.h"
+
+#include <chrono>
 #include <cstdlib>
 
 #include <algorithm>
@@ -95,6 +97,7 @@ Runtime* Runtime::createContext() {
     if (!ds->idleContexts.empty()) {
       Runtime* ctx = ds->idleContexts.back();
       ds->idleContexts.pop_back();
+      ctx->resetGpuStats();
       return ctx;  // idle: its last entry point drained the stream
     }
   }
@@ -141,6 +144,7 @@ ContextScope::ContextScope(Runtime* ctx) : ctx_(ctx), prev_(tlsCurrent) {
   }
   bindHipDevice(ctx_->device);
   tlsCurrent = ctx_;
+  enteredNanos_ = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
 ContextScope::~ContextScope() {
@@ -149,6 +153,9 @@ ContextScope::~ContextScope() {
   }
   // Everything the entry point queued is complete when it returns.
   (void)hipStreamSynchronize(ctx_->stream);
+  ctx_->busyNanos += static_cast<uint64_t>(
+      std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() -
+      enteredNanos_);
   ctx_->doneCalls.store(ctx_->currentCall);
   ++ctx_->currentCall;
   tlsCurrent = prev_;
@@ -386,6 +393,20 @@ int streamGrid(int64_t items, int block, int perThread) {
   return static_cast<int>(std::max<int64_t>(1, std::min(blocks, cap)));
 }
 
+int gpuStatsOf(const Runtime* ctx, vx355_gpu_stats* out) {
+  if (!ctx || !out) {
+    setLastError("NULL argument");
+    return VX355_EINVAL;
+  }
+  out->busy_nanos = static_cast<int64_t>(ctx->busyNanos.load());
+  out->h2d_bytes = static_cast<int64_t>(ctx->h2dBytes.load());
+  out->d2h_bytes = static_cast<int64_t>(ctx->d2hBytes.load());
+  out->input_bytes = static_cast<int64_t>(ctx->inputBytes.load());
+  out->launches = static_cast<int64_t>(ctx->launchCount - ctx->launchesAtReset);
+  out->reserved = 0;
+  return VX355_OK;
+}
+
 void copyOut(void* dst, int32_t dstMem, const void* devSrc, size_t bytes) {
   if (!bytes) {
     return;
@@ -395,6 +416,7 @@ void copyOut(void* dst, int32_t dstMem, const void* devSrc, size_t bytes) {
                         dstMem == VX355_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
                         rt.stream));
   if (dstMem == VX355_MEM_HOST) {
+    rt.d2hBytes += bytes;
     rt.sync();
   }
 }
@@ -407,6 +429,9 @@ void copyOutAsync(void* dst, int32_t dstMem, const void* devSrc, size_t bytes) {
   HIP_OK(hipMemcpyAsync(dst, devSrc, bytes,
                         dstMem == VX355_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
                         rt.stream));
+  if (dstMem == VX355_MEM_HOST) {
+    rt.d2hBytes += bytes;
+  }
 }
 
 void copyIn(void* devDst, const void* src, int32_t srcMem, size_t bytes) {
@@ -417,6 +442,9 @@ void copyIn(void* devDst, const void* src, int32_t srcMem, size_t bytes) {
   HIP_OK(hipMemcpyAsync(devDst, src, bytes,
                         srcMem == VX355_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
                         rt.stream));
+  if (srcMem == VX355_MEM_HOST) {
+    rt.h2dBytes += bytes;
+  }
 }
 
 namespace {
@@ -748,6 +776,10 @@ void DeviceBatch::load(const vx355_batch* batch, const std::vector<int32_t>& use
       }
       v.indices = static_cast<const int32_t*>(
           stage(col.indices, static_cast<size_t>(numRows_) * 4, col.mem));
+    }
+    if (Runtime* rt = Runtime::tryGet()) {
+      rt->inputBytes += valueBytes + (col.nulls ? static_cast<size_t>(ceilDiv(nullBits, 64)) * 8 : 0) +
+          (col.encoding == VX355_DICTIONARY ? static_cast<size_t>(numRows_) * 4 : 0);
     }
     views_[c] = v;
   }

@@ -16,6 +16,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdint>
@@ -24,6 +25,8 @@
 #include <cstring>
 #include <random>
 #include <string>
+#include <thread>
+#include <utility>
 #include <vector>
 
 namespace vx {
@@ -166,22 +169,32 @@ int progressAll() {
       return kErrInvalid;
     }
   }
+  // every error path below marks the segment aborted: peers then fail at once instead of spinning
+  // until VX355_SHM_TIMEOUT, and nobody reads a ring that holds half a message
+  auto abortAll = [&]() {
+    for (const Op& op : ops) {
+      op.comm->header()->aborted.store(1);
+    }
+  };
   const double deadline = seconds() + timeoutSeconds();
   for (;;) {
     bool all = true, moved = false;
-    // per channel only the FIRST unfinished operation may progress: messages match in posting order
-    bool sendBusy[kMaxWorld] = {false}, recvBusy[kMaxWorld] = {false};
+    // per channel only the FIRST unfinished operation may progress: messages match in posting order. A
+    // channel belongs to a communicator: operations of different communicators in one group do not wait
+    // for each other.
+    std::vector<std::pair<const Comm*, int>> sendBusy, recvBusy;
     for (Op& op : ops) {
       if (op.done == op.bytes) {
         continue;
       }
       all = false;
       Comm* c = op.comm;
-      bool* busy = op.send ? sendBusy : recvBusy;
-      if (busy[op.peer]) {
+      auto& busy = op.send ? sendBusy : recvBusy;
+      const std::pair<const Comm*, int> channelOf{c, op.peer};
+      if (std::find(busy.begin(), busy.end(), channelOf) != busy.end()) {
         continue;
       }
-      busy[op.peer] = true;
+      busy.push_back(channelOf);
       if (op.send) {
         Channel* ch = c->channel(c->rank, op.peer);
         const uint64_t w = ch->written.load(std::memory_order_relaxed);
@@ -191,6 +204,7 @@ int progressAll() {
         const size_t n = std::min(kPieceBytes, op.bytes - op.done);
         if (hipMemcpy(c->data(c->rank, op.peer, w), op.ptr + op.done, n, hipMemcpyDeviceToHost) != hipSuccess) {
           tError = "hipMemcpy (device to shared memory) failed";
+          abortAll();
           return kErrInternal;
         }
         ch->pieceBytes[w % kRing] = n;
@@ -211,6 +225,7 @@ int progressAll() {
         }
         if (hipMemcpy(op.ptr + op.done, c->data(op.peer, c->rank, r), n, hipMemcpyHostToDevice) != hipSuccess) {
           tError = "hipMemcpy (shared memory to device) failed";
+          abortAll();
           return kErrInternal;
         }
         ch->consumed.store(r + 1, std::memory_order_release);
@@ -350,6 +365,49 @@ int CommInitRank(ncclComm_t* out, int world, ncclUniqueId id, int rank) {
     shm_unlink(c->name.c_str());  // everybody has it mapped: the name can go
   }
   *out = c;
+  return kNcclSuccess;
+}
+
+// ncclCommInitAll: ONE process creates all 'world' communicators (the shape SURVEY.md 8(e) names: one
+// process, one Driver thread per rank). Every rank's CommInitRank waits for the others to join, so
+// they run on helper threads side by side; rank i's communicator reports devices[i].
+int CommInitAll(ncclComm_t* comms, int world, const int* devices) {
+  if (!comms || world < 1 || world > kMaxWorld) {
+    tError = "shm transport: bad communicator arguments (world <= 8)";
+    return kErrInvalid;
+  }
+  ncclUniqueId id;
+  const int rc = GetUniqueId(&id);
+  if (rc != kNcclSuccess) {
+    return rc;
+  }
+  std::vector<int> status(static_cast<size_t>(world), kNcclSuccess);
+  std::vector<std::string> errors(static_cast<size_t>(world));
+  std::vector<std::thread> helpers;
+  for (int r = 0; r < world; ++r) {
+    helpers.emplace_back([&, r] {
+      if (devices) {
+        (void)hipSetDevice(devices[r]);
+      }
+      status[r] = CommInitRank(&comms[r], world, id, r);
+      errors[r] = tError;
+    });
+  }
+  for (auto& t : helpers) {
+    t.join();
+  }
+  for (int r = 0; r < world; ++r) {
+    if (status[r] != kNcclSuccess) {
+      tError = errors[r];
+      for (int q = 0; q < world; ++q) {
+        if (status[q] == kNcclSuccess) {
+          CommDestroy(comms[q]);
+          comms[q] = nullptr;
+        }
+      }
+      return status[r];
+    }
+  }
   return kNcclSuccess;
 }
 

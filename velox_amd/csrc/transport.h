@@ -24,6 +24,7 @@ constexpr int kNcclInt64 = 4;
 namespace shmx {
 int GetUniqueId(ncclUniqueId* id);
 int CommInitRank(ncclComm_t* comm, int world, ncclUniqueId id, int rank);
+int CommInitAll(ncclComm_t* comms, int world, const int* devices);
 int CommDestroy(ncclComm_t comm);
 int Send(const void* buf, size_t count, int dtype, int peer, ncclComm_t comm, hipStream_t stream);
 int Recv(void* buf, size_t count, int dtype, int peer, ncclComm_t comm, hipStream_t stream);

@@ -47,6 +47,8 @@ SYMBOLS = [
     "vx355_join_probe_add_input_async", "vx355_join_probe_poll", "vx355_join_probe_wait",
     "vx355_agg_no_more_input_async", "vx355_agg_get_output_async", "vx355_agg_output_result",
     "vx355_join_probe_get_output_async", "vx355_join_probe_output_result",
+    "vx355_join_probe_add_input_regrouped",
+    "vx355_agg_bytes_in_use", "vx355_agg_get_gpu_stats", "vx355_join_build_get_gpu_stats", "vx355_join_probe_get_gpu_stats",
 ]
 
 # void (*vx355_output_done_fn)(void* arg, int status, int32_t num_rows, int32_t finished)
@@ -127,6 +129,7 @@ def lib():
     L.vx355_join_table_get_stats.argtypes = [vp, P(abi.JoinTableStats)]
     L.vx355_join_probe_create.argtypes = [vp, P(abi.JoinProbeSpec), P(vp)]
     L.vx355_join_probe_add_input.argtypes = [vp, P(abi.Batch)]
+    L.vx355_join_probe_add_input_regrouped.argtypes = [vp, P(abi.Batch), P(vp), P(i32)]
     L.vx355_join_probe_get_output.argtypes = [vp, i32, vp, vp, i32, P(abi.OutColumn), P(i32), i32,
                                               P(i32), P(i32)]
     L.vx355_join_probe_get_build_side_output.argtypes = [vp, i32, vp, i32, P(abi.OutColumn), P(i32), i32,
@@ -194,6 +197,11 @@ def init(device=0):
     _check(lib().vx355_init(device))
 
 
+def set_device(device):
+    """vx355_set_device: the GPU of the calling thread (one Driver thread per device / rank)."""
+    _check(lib().vx355_set_device(device))
+
+
 def synchronize():
     _check(lib().vx355_synchronize())
 
@@ -254,6 +262,21 @@ class Comm:
         buf = C.create_string_buffer(128)
         _check(lib().vx355_comm_get_unique_id(buf))
         return buf.raw
+
+    @staticmethod
+    def create_all(devices):
+        """vx355_comm_create_all: ONE process, one communicator per entry of 'devices' (rank i on
+        devices[i]; every device initialised with vx355_init) -> [Comm]. Each rank's collectives are then
+        called from that rank's own thread (one process drives the node)."""
+        n = len(devices)
+        handles = (C.c_void_p * n)()
+        _check(lib().vx355_comm_create_all(n, abi.i32_array(devices), handles))
+        comms = []
+        for rank in range(n):
+            c = Comm.__new__(Comm)
+            c.h, c.world, c.rank = C.c_void_p(handles[rank]), n, rank
+            comms.append(c)
+        return comms
 
     def exchange_counts(self, send_counts):
         send = (C.c_int64 * self.world)(*[int(x) for x in send_counts])
@@ -1051,6 +1074,16 @@ class HashProbe:
     def add_input(self, batch):
         self._batch = batch
         _check(lib().vx355_join_probe_add_input(self.h, batch.ref()))
+
+    def add_input_regrouped(self, batch, out_ptrs):
+        """vx355_join_probe_add_input_regrouped: out_ptrs = one device pointer per column of the batch
+        (num_rows x width bytes each). -> True when the operator's input batch now is the regrouped
+        copy in out_ptrs (mappings number ITS rows), False when the batch was probed as it came."""
+        self._batch = batch
+        self._regrouped_ptrs = (C.c_void_p * len(out_ptrs))(*out_ptrs)
+        moved = C.c_int32()
+        _check(lib().vx355_join_probe_add_input_regrouped(self.h, batch.ref(), self._regrouped_ptrs, C.byref(moved)))
+        return bool(moved.value)
 
     def add_input_async(self, batch):
         """-> ticket; the batch is kept alive here. get_output (or wait) waits for it."""
