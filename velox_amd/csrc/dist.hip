@@ -27,6 +27,7 @@ extern "C" int vx355_all_gather_v(vx355_comm* c, const void* send, const int64_t
 
 namespace vx {
 bool commViaRccl(const vx355_comm* c);  // exchange.hip: false = one rank whose exchanges are local copies
+Runtime* commContext(const vx355_comm* c);  // the communicator's execution context (nullptr for nullptr)
 }
 
 namespace vx {
@@ -97,7 +98,10 @@ extern "C" {
 int vx355_join_repartition(vx355_comm* c, const vx355_join_build_spec* build_spec, const vx355_batch* build_rows,
                            const vx355_join_probe_spec* probe_spec, const vx355_batch* probe_rows, int32_t chunks,
                            vx355_join_chunk_sink sink, void* sink_arg, vx355_join_table** table_out) {
-  VX_API_BEGIN
+  // In the communicator's own execution context, not the device's default one: a default context
+  // serialises its entry points (callMutex), and ranks that share a device inside one process
+  // (vx355_comm_create_all over one GPU) would wait for each other's collective forever.
+  VX_API_BEGIN_CTX(commContext(c))
   VX_CHECK_ARG(c && build_spec && build_rows && probe_spec && probe_rows && sink && table_out, "NULL argument");
   VX_CHECK_ARG(build_rows->num_cols >= 1 && probe_rows->num_cols >= 1, "batches without columns");
   VX_CHECK_ARG(build_spec->num_keys == probe_spec->num_keys && build_spec->num_keys >= 1, "key lists differ");
@@ -222,7 +226,7 @@ int vx355_join_repartition(vx355_comm* c, const vx355_join_build_spec* build_spe
 
 int vx355_agg_merge_partials(vx355_comm* c, vx355_agg* partial, const vx355_agg_spec* final_spec,
                              vx355_agg** final_out) {
-  VX_API_BEGIN
+  VX_API_BEGIN_CTX(commContext(c))  // (see vx355_join_repartition)
   VX_CHECK_ARG(c && partial && final_spec && final_out, "NULL argument");
   VX_CHECK_ARG(final_spec->step == VX355_STEP_FINAL || final_spec->step == VX355_STEP_INTERMEDIATE,
                "the merging operator takes intermediate input (FINAL or INTERMEDIATE step)");

@@ -202,6 +202,7 @@ struct vx355_comm {
 
 namespace vx {
 bool commViaRccl(const vx355_comm* c) { return c->viaRccl(); }
+Runtime* commContext(const vx355_comm* c) { return c ? c->ctx : nullptr; }
 }  // namespace vx
 
 namespace vx {
