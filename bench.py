@@ -1506,8 +1506,9 @@ def main():
     elapsed, prof = timed(one_step, args.steps, args.warmup)
     rows = wl.rows_per_step() * world * args.steps
     result_check = None
-    if hasattr(wl, "verify"):
-        # the job's output against what the generator implies, over all ranks (not timed)
+    if hasattr(wl, "verify") and not args.counter_child:
+        # the job's output against what the generator implies, over all ranks (not timed; not in a counter
+        # child: its extra step would be counted into the traffic of the timed ones)
         got_sum, want_sum = wl.verify()
         if world > 1:
             both = [None] * world
@@ -1637,8 +1638,9 @@ def compact_roofline(r):
             "traffic_ratio": _num(traffic / algo, 4) if (traffic and algo) else None,
             "kernel_ms_per_step": _num(r.get("kernel_ms_per_step"), 5),
             "launches_per_step": r.get("launches_per_step"),
-            "measured_copy_ceiling_GBps": _num((r.get("measured_ceiling") or {}).get(
-                "read_GBps" if r.get("measured_ceiling_kind") == "read" else "copy_GBps"), 5)}
+            "measured_read_ceiling_GBps": _num((r.get("measured_ceiling") or {}).get("read_GBps"), 5),
+            "measured_copy_ceiling_GBps": _num((r.get("measured_ceiling") or {}).get("copy_GBps"), 5),
+            "ceiling_for_this_kernel": r.get("measured_ceiling_kind")}
 
 
 def compact_cpu(c):
