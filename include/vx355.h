@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VX355_ABI_VERSION 8
+#define VX355_ABI_VERSION 9
 
 typedef enum vx355_status {
   VX355_OK = 0,
@@ -173,6 +173,25 @@ int vx355_profile_reset(void);
 int vx355_profile_get(const char* kernel, double* total_ms, int64_t* launches);
 /* Writes up to cap names of kernels seen since the last reset, '\n' joined. */
 int vx355_profile_names(char* buf, size_t cap);
+
+/* ---- memory beyond the operator's share (ABI 9) -------------------------------------------------
+ * The reference's operators allocate from a MemoryPool with a capacity; past it they reclaim - spill
+ * (HashBuild::ensureTableFits / reclaim, exec/HashBuild.cpp:995,1314; HashAggregation::reclaim,
+ * exec/HashAggregation.cpp:562; HashProbe::reclaim, exec/HashProbe.cpp:2182) - or the query fails with
+ * "Exceeded memory pool capacity". This library never spills (288 GB of HBM per
+ * GPU, and a join beyond that is repartitioned across GPUs with vx355_join_repartition); what it does
+ * guarantee is the failing half of that contract: an operator whose next allocation would pass the
+ * limit - this one, or the GPU's free HBM - returns VX355_ENOMEM from the entry point that needed the
+ * memory (add_input, no_more_input / finish, get_output), the message names the sizes, the handle
+ * stays destroyable (destroy releases everything it held; nothing of it leaks into the block cache's
+ * accounting) and other operators keep working. The adapter reports that as the Task's failure
+ * (canReclaim() == false).
+ * vx355_set_memory_limit: cap, in bytes, on the HBM blocks all operators of the calling thread's GPU
+ * hold at one time (tables, staged input, scratch; not caller-owned buffers); 0 = no cap (default).
+ * vx355_memory_usage: bytes held now, the peak since the previous call of this function, and bytes
+ * parked in the block cache for reuse (not counted against the limit). Any pointer may be NULL. */
+int vx355_set_memory_limit(int64_t bytes);
+int vx355_memory_usage(int64_t* in_use, int64_t* peak, int64_t* cached);
 
 /* What this GPU's HBM delivers to plain streaming kernels (measurement aid; bench.py quotes every
  * roofline fraction against the 8 TB/s datasheet peak and reports these next to it).
@@ -337,7 +356,31 @@ typedef enum vx355_page_flags {
   VX355_PAGE_CHECKSUM = 1,
   /* PrestoOptions::useLosslessTimestamp: {seconds, nanos} instead of milliseconds. */
   VX355_PAGE_LOSSLESS_TIMESTAMP = 2
+  /* bits 8..15: PrestoOptions::compressionKind of the exchange, see VX355_PAGE_COMPRESSION (ABI 9) */
 } vx355_page_flags;
+
+/* common::CompressionKind (common/compression/Compression.h:28-37), the values Velox itself uses. The
+ * page body of a compressed PrestoPage is what the folly codec of that kind emits
+ * (compressionKindToCodec, common/compression/Compression.cpp:27-46): ZLIB an RFC 1950 stream, SNAPPY
+ * raw snappy, ZSTD a zstd frame, LZ4 ONE raw LZ4 block (folly's CodecType::LZ4 does not store the
+ * length: the page header's uncompressedSize is it), GZIP an RFC 1952 member. LZO and LZ4_HADOOP have
+ * no folly codec ("Not support ... in folly") and are VX355_EUNSUPPORTED here too. LZ4 and SNAPPY are
+ * coded by the library itself; ZSTD and ZLIB / GZIP need libzstd.so.1 / libz.so.1 on the host (loaded
+ * on first use; without them only those kinds are VX355_EUNSUPPORTED). */
+typedef enum vx355_compression_kind {
+  VX355_COMPRESSION_NONE = 0,
+  VX355_COMPRESSION_ZLIB = 1,
+  VX355_COMPRESSION_SNAPPY = 2,
+  VX355_COMPRESSION_LZO = 3,
+  VX355_COMPRESSION_ZSTD = 4,
+  VX355_COMPRESSION_LZ4 = 5,
+  VX355_COMPRESSION_GZIP = 6
+} vx355_compression_kind;
+/* The exchange's compression kind inside a vx355_page_flags word (vx355_presto_deserialize). A page says
+ * only THAT it is compressed (codec marker bit 1, PrestoSerializerSerializationUtils.h:37-45); which
+ * codec is the reader's configuration, as in the reference (PrestoSerializer.cpp:144-145). */
+#define VX355_PAGE_COMPRESSION(kind) (((kind) & 0xff) << 8)
+#define VX355_PAGE_COMPRESSION_OF(flags) (((flags) >> 8) & 0xff)
 
 /* What PartitionedOutput's Destination does with the rows routed to it
  * (exec/PartitionedOutput.cpp:59-133: IterativeVectorSerializer::append(rows) + flush), for all
@@ -374,12 +417,35 @@ int vx355_presto_serialize(
     int32_t out_mem,
     int64_t* page_offsets);
 
+/* The writer's last step for a compressing exchange (flushCompressed,
+ * serializers/PrestoSerializerSerializationUtils.h:279-334), as a pure host function (no GPU, no
+ * vx355_init needed): 'page' is one uncompressed page as vx355_presto_serialize wrote it to host
+ * memory; its body (column count + columns) is compressed with the codec of 'compression'. When the
+ * result is larger than uncompressedSize x min_ratio (PrestoOptions::minCompressionRatio, 0.8 by
+ * default) the page is emitted as it came, exactly as the reference does; otherwise the header gets
+ * the compressed bit, size = compressed bytes, and - when the page carries a checksum - the CRC32
+ * over [compressed body | codec | numRows | uncompressedSize] (PrestoSerializer.cpp:39-79). The output
+ * never exceeds the input: out_capacity >= size always suffices. *out_size = bytes written. */
+int vx355_presto_compress_page(const void* page, int64_t size, int32_t compression, float min_ratio, void* out,
+                               int64_t out_capacity, int64_t* out_size);
+/* The inverse, also pure host work: a page with the compressed bit becomes the uncompressed page a
+ * non-compressing writer would have sent (checksum verified over the compressed bytes first and
+ * re-computed for the new body); a page without the bit is copied. out_capacity >= 21 + the header's
+ * uncompressedSize (little-endian int32 at byte 5 of the page). vx355_presto_deserialize does this by
+ * itself for every compressed page it is given. */
+int vx355_presto_uncompress_page(const void* page, int64_t size, int32_t compression, void* out, int64_t out_capacity,
+                                 int64_t* out_size);
+
 /* The other direction, what an Exchange does with the pages it received
  * (PrestoVectorSerde::deserialize, serializers/PrestoSerializer.cpp:120-200, appending page
- * after page into one RowVector): pages (host memory, uncompressed; a checksum is verified when
+ * after page into one RowVector): pages (host memory; a checksum is verified when
  * the codec marker carries one, "Received corrupted serialized page." -> VX355_EUSER) become
  * flat columns in HBM, rows of page 0 first (RLE and DICTIONARY columns are flattened on the
- * way). types[] is the RowType the exchange expects; a
+ * way). Compressed pages (codec marker bit 1; ABI 9) are uncompressed on the host with the codec
+ * named by VX355_PAGE_COMPRESSION(kind) in 'flags' (PrestoSerializer.cpp:185-199) - a compressed
+ * page without a kind in the flags is VX355_EINVAL, a body the codec rejects VX355_EUSER - and
+ * device_bytes must then hold 21 + uncompressedSize bytes for such a page instead of its wire size;
+ * encrypted pages stay VX355_EUNSUPPORTED. types[] is the RowType the exchange expects; a
  * page whose column encodings do not fit it is a VX355_EUSER. The page bytes are copied into
  * device_bytes (>= the sum of sizes); views of strings longer than 12 bytes point into that
  * buffer, so the caller keeps it as long as the columns (a vector's string buffer). cols: device

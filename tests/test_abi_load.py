@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_calls_that_need_no_gpu(lib):
-    assert lib.vx355_abi_version() == 8
+    assert lib.vx355_abi_version() == 9
     if lib.vx355_device_count() == 0:
         # No device: init must fail loudly, and operators refuse to be created.
         assert lib.vx355_init(0) != abi.OK

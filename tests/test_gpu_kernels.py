@@ -389,6 +389,49 @@ def test_presto_pages_deserialize_to_device_columns(oracle, vx, flags):
     assert [int(x) for x in got[0][0]] == dpy[0][0]
 
 
+@pytest.mark.parametrize("name", ["LZ4", "SNAPPY", "ZSTD", "ZLIB", "GZIP"])
+def test_compressed_presto_pages_deserialize_to_device_columns(oracle, vx, name):
+    """PrestoVectorSerde::deserialize with PrestoOptions::compressionKind set
+    (serializers/PrestoSerializer.cpp:144-145,185-199): pages a compressing exchange sent - bodies
+    compressed by the library's own writer step and by an independent codec (pyarrow / zlib), with and
+    without checksums, mixed with pages that travelled uncompressed - come back as the rows they were made of."""
+    from presto_page_reader import random_page_batch
+    from test_page_compression import KINDS, assemble, independent_compress
+    kind = KINDS[name]
+    rng = np.random.default_rng(6060)
+    n = 6000
+    batch, py = random_page_batch(rng, n)
+    kinds = [c.kind for c in batch.columns]
+    offsets = [0, 1, 700, 701, 4000, n]
+    want = _expect_rows(py, list(range(n)), False)
+    for flags in (0, abi.PAGE_CHECKSUM):
+        plain = oracle.presto_serialize(batch, offsets, None, flags)
+        ours = [vx.presto_compress_page(p, kind) for p in plain]
+        theirs = [assemble(p, name, independent_compress(name, p[21:])) if len(p) > 200 else p for p in plain]
+        mixed = [ours[0], plain[1], theirs[2], ours[3], plain[4]]
+        assert any(p[4] & 1 for p in ours) and any(p[4] & 1 for p in theirs)
+        for pages in (ours, theirs, mixed):
+            got_n, got = vx.presto_deserialize(pages, kinds, abi.page_compression(kind))
+            assert got_n == n
+            for c, k in enumerate(kinds):
+                gv, gvalid = got[c]
+                wv, wvalid = want[c]
+                assert list(gvalid) == wvalid, (name, c)
+                for r in range(n):
+                    if wvalid[r]:
+                        g = tuple(int(x) for x in gv[r]) if k == abi.TIMESTAMP else gv[r]
+                        assert g == wv[r], (name, c, r)
+    # the reader's configuration names the codec; a corrupt body is the sender's fault
+    with pytest.raises(vx.Vx355Error) as e:
+        vx.presto_deserialize(ours, kinds, 0)
+    assert e.value.status == abi.EINVAL
+    big = bytearray(next(p for p in ours if p[4] & 1 and len(p) > 500))
+    big[300] ^= 0x10
+    with pytest.raises(vx.Vx355Error) as e:
+        vx.presto_deserialize([bytes(big)], kinds, abi.page_compression(kind))
+    assert e.value.status == abi.EUSER
+
+
 def test_presto_deserialize_rejects_corrupt_and_mismatched_pages(oracle, vx):
     from presto_page_reader import random_page_batch
     rng = np.random.default_rng(5050)

@@ -80,6 +80,13 @@ AGG_UNORDERED_OUTPUT = 1
 AGG_FN_DISTINCT = 1  # vx355_agg_fn.flags
 PAGE_CHECKSUM = 1
 PAGE_LOSSLESS_TIMESTAMP = 2
+# vx355_compression_kind = common::CompressionKind (common/compression/Compression.h:28-37)
+COMPRESSION_NONE, COMPRESSION_ZLIB, COMPRESSION_SNAPPY, COMPRESSION_LZO, COMPRESSION_ZSTD, COMPRESSION_LZ4, COMPRESSION_GZIP = range(7)
+
+
+def page_compression(kind):
+    """VX355_PAGE_COMPRESSION(kind): the exchange's compression kind inside a page-flags word."""
+    return (kind & 0xff) << 8
 
 
 class AggStats(C.Structure):

@@ -149,6 +149,11 @@ struct DeviceState {
   size_t cachedBytes = 0;
   uint64_t cacheSeq = 0;
   size_t cacheLimit = 16ULL << 30;
+  // Bytes of blocks handed out and not yet released, and the cap on them (0 = none): what a Velox
+  // MemoryPool's capacity is to the reference's operators (vx355_set_memory_limit).
+  size_t liveBytes = 0;
+  size_t peakLiveBytes = 0;
+  size_t memoryLimit = 0;
   // Pinned host blocks (power-of-two sizes >= 64 KB): hipHostMalloc costs ~0.3 ms a
   // call, so released blocks are kept (up to pinnedLimit bytes) for the next operator.
   std::multimap<size_t, void*> freePinned;
@@ -396,6 +401,12 @@ class HostCoalescer {
 // Output columns of a PARTIAL / INTERMEDIATE aggregation that hold the sum half of an avg's
 // (sum, count) pair (agg.hip); the count follows in the next column.
 std::vector<int32_t> aggPartialAvgColumns(const vx355_agg* h);
+
+// Block codecs of compressed PrestoPages (codec.hip; host work). kind = vx355_compression_kind.
+// codecUncompress throws VX355_EUSER unless 'src' decodes to exactly dstLen bytes.
+const char* codecName(int32_t kind);   // nullptr: no folly codec for the kind
+void codecUncompress(int32_t kind, const unsigned char* src, size_t n, unsigned char* dst, size_t dstLen);
+void codecCompress(int32_t kind, const unsigned char* src, size_t n, std::vector<unsigned char>& out);
 
 // vx355_*_get_gpu_stats: the counters of one execution context.
 int gpuStatsOf(const Runtime* ctx, vx355_gpu_stats* out);

@@ -216,11 +216,21 @@ void* DeviceState::allocBlock(size_t bytes, size_t* actual) {
   Runtime* cur = Runtime::tryGet();
   {
     std::unique_lock<std::mutex> lock(memMutex);
+    if (memoryLimit != 0 && liveBytes + want > memoryLimit) {
+      // MemoryPool::allocate past its capacity (the reference then reclaims / spills, or fails the
+      // query with "Exceeded memory pool capacity"): here the operator's entry point fails with
+      // VX355_ENOMEM, its handle stays destroyable and everything it held goes back on destroy.
+      VX_THROW(VX355_ENOMEM, "memory limit of " + std::to_string(memoryLimit) + " bytes exceeded: " + std::to_string(want) +
+                                 " bytes asked with " + std::to_string(liveBytes) + " in use (vx355_set_memory_limit)");
+    }
     auto it = freeBlocks.lower_bound(want);
-    if (it != freeBlocks.end() && it->first <= want + want / 4) {
+    if (it != freeBlocks.end() && it->first <= want + want / 4 &&
+        (memoryLimit == 0 || liveBytes + it->first <= memoryLimit)) {
       const CachedBlock b = it->second;
       *actual = it->first;
       cachedBytes -= it->first;
+      liveBytes += it->first;
+      peakLiveBytes = std::max(peakLiveBytes, liveBytes);
       freeBlocks.erase(it);
       // Released by another context whose call has not returned yet: its stream
       // may still touch the block. Same context: ordered on the same stream.
@@ -253,6 +263,11 @@ void* DeviceState::allocBlock(size_t bytes, size_t* actual) {
     hipFail(e, "hipMalloc", __FILE__, __LINE__);
   }
   *actual = want;
+  {
+    std::lock_guard<std::mutex> lock(memMutex);
+    liveBytes += want;
+    peakLiveBytes = std::max(peakLiveBytes, liveBytes);
+  }
   return p;
 }
 
@@ -276,6 +291,7 @@ void DeviceState::freeBlock(void* p, size_t bytes) {
   bool keep = false;
   {
     std::lock_guard<std::mutex> lock(memMutex);
+    liveBytes -= std::min(liveBytes, bytes);
     if (alive && bytes <= cacheLimit) {
       while (cachedBytes + bytes > cacheLimit && !freeBlocks.empty()) {
         auto oldest = freeBlocks.begin();
@@ -903,6 +919,32 @@ void vx355_shutdown(void) {
   }
   vx::gDefaultDevice.store(-1);
   vx::tlsDevice = -1;
+}
+
+int vx355_set_memory_limit(int64_t bytes) {
+  try {
+    VX_CHECK_ARG(bytes >= 0, "a limit is >= 0 (0 = none)");
+    DeviceState* ds = Runtime::get().ds;
+    std::lock_guard<std::mutex> lock(ds->memMutex);
+    ds->memoryLimit = static_cast<size_t>(bytes);
+  VX_API_CATCH
+}
+
+int vx355_memory_usage(int64_t* in_use, int64_t* peak, int64_t* cached) {
+  try {
+    DeviceState* ds = Runtime::get().ds;
+    std::lock_guard<std::mutex> lock(ds->memMutex);
+    if (in_use) {
+      *in_use = static_cast<int64_t>(ds->liveBytes);
+    }
+    if (peak) {
+      *peak = static_cast<int64_t>(ds->peakLiveBytes);
+      ds->peakLiveBytes = ds->liveBytes;
+    }
+    if (cached) {
+      *cached = static_cast<int64_t>(ds->cachedBytes);
+    }
+  VX_API_CATCH
 }
 
 void* vx355_device_malloc(size_t bytes) {

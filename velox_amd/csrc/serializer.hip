@@ -1103,14 +1103,137 @@ int32_t getI32(const unsigned char* p) {
   return v;
 }
 
-void deserializePages(const void* const* pages, const int64_t* sizes, int32_t numPages, const int32_t* types,
+// computeChecksum (PrestoSerializer.cpp:39-79): the stored body, then codec, numRows, uncompressedSize.
+int64_t pageChecksum(const Crc32& crc, const unsigned char* body, size_t stored, unsigned char codec, int32_t numRows,
+                     int32_t uncompressed) {
+  uint32_t state = ~0u;
+  state = crc.update(state, body, stored);
+  state = crc.update(state, &codec, 1);
+  state = crc.update(state, reinterpret_cast<const unsigned char*>(&numRows), 4);
+  state = crc.update(state, reinterpret_cast<const unsigned char*>(&uncompressed), 4);
+  return static_cast<int64_t>(static_cast<uint32_t>(~state));
+}
+
+void putI32At(unsigned char* p, int32_t v) { std::memcpy(p, &v, 4); }
+
+// What the reader does with a compressed page before parsing it (PrestoSerializer.cpp:185-199):
+// checksum over the bytes as stored, then codec->uncompress(body, uncompressedSize). 'out' becomes the
+// page a non-compressing writer would have sent (marker without the compressed bit, size =
+// uncompressedSize, checksum - if the page carries one - over the new body).
+void uncompressPage(const unsigned char* page, int64_t size, int32_t kind, const std::string& who,
+                    std::vector<unsigned char>& out) {
+  static const Crc32 crc;
+  auto bad = [&](const std::string& what) { VX_THROW(VX355_EUSER, who + ": " + what); };
+  if (!page || size < kPageHeader) {
+    bad(std::to_string(size) + " bytes for header");
+  }
+  const int32_t n = getI32(page);
+  const unsigned char codec = page[4];
+  const int32_t uncompressed = getI32(page + 5);
+  const int32_t stored = getI32(page + 9);
+  if (n < 0 || uncompressed < 0 || stored < 0) {
+    bad("negative header field");
+  }
+  if (codec & 2) {
+    VX_THROW(VX355_EUNSUPPORTED, "encrypted PrestoPage");
+  }
+  if (static_cast<int64_t>(stored) + kPageHeader != size) {
+    bad("size fields do not match the page length");
+  }
+  if (!(codec & 1)) {
+    out.assign(page, page + size);
+    return;
+  }
+  if (kind == VX355_COMPRESSION_NONE) {
+    VX_THROW(VX355_EINVAL, who + " is compressed but the flags name no compression kind (VX355_PAGE_COMPRESSION)");
+  }
+  if (stored >= uncompressed) {
+    bad("compressed size is not below the uncompressed size");   // VELOX_CHECK_LT, PrestoSerializer.cpp:48
+  }
+  if (codec & 4) {
+    int64_t expected;
+    std::memcpy(&expected, page + 13, 8);
+    if (expected != pageChecksum(crc, page + kPageHeader, static_cast<size_t>(stored), codec, n, uncompressed)) {
+      bad("Received corrupted serialized page.");
+    }
+  }
+  out.resize(static_cast<size_t>(kPageHeader) + static_cast<size_t>(uncompressed));
+  codecUncompress(kind, page + kPageHeader, static_cast<size_t>(stored), out.data() + kPageHeader,
+                  static_cast<size_t>(uncompressed));
+  const unsigned char plain = static_cast<unsigned char>(codec & ~1u);
+  putI32At(out.data(), n);
+  out[4] = plain;
+  putI32At(out.data() + 5, uncompressed);
+  putI32At(out.data() + 9, uncompressed);
+  int64_t sum = 0;
+  if (plain & 4) {
+    sum = pageChecksum(crc, out.data() + kPageHeader, static_cast<size_t>(uncompressed), plain, n, uncompressed);
+  }
+  std::memcpy(out.data() + 13, &sum, 8);
+}
+
+// flushCompressed (PrestoSerializerSerializationUtils.h:279-334) for one finished page.
+void compressPage(const unsigned char* page, int64_t size, int32_t kind, float minRatio, std::vector<unsigned char>& out) {
+  static const Crc32 crc;
+  VX_CHECK_ARG(page && size >= kPageHeader, "a page is at least its 21-byte header");
+  const int32_t n = getI32(page);
+  const unsigned char codec = page[4];
+  const int32_t uncompressed = getI32(page + 5);
+  const int32_t stored = getI32(page + 9);
+  VX_CHECK_ARG(!(codec & 3), "the page is already compressed or encrypted");
+  VX_CHECK_ARG(n >= 0 && uncompressed == stored && static_cast<int64_t>(stored) + kPageHeader == size,
+               "size fields do not match the page length");
+  if (kind == VX355_COMPRESSION_NONE) {
+    out.assign(page, page + size);
+    return;
+  }
+  if (!codecName(kind)) {
+    VX_THROW(VX355_EUNSUPPORTED, "compression kind " + std::to_string(kind) + " has no folly codec (Compression.cpp:43)");
+  }
+  std::vector<unsigned char> body;
+  codecCompress(kind, page + kPageHeader, static_cast<size_t>(stored), body);
+  if (static_cast<double>(body.size()) > static_cast<double>(uncompressed) * static_cast<double>(minRatio) ||
+      body.size() >= static_cast<size_t>(uncompressed)) {
+    out.assign(page, page + size);   // not worth it: the page travels uncompressed (:314-323)
+    return;
+  }
+  out.resize(kPageHeader + body.size());
+  const unsigned char marked = static_cast<unsigned char>(codec | 1);
+  putI32At(out.data(), n);
+  out[4] = marked;
+  putI32At(out.data() + 5, uncompressed);
+  putI32At(out.data() + 9, static_cast<int32_t>(body.size()));
+  int64_t sum = 0;
+  if (marked & 4) {
+    sum = pageChecksum(crc, body.data(), body.size(), marked, n, uncompressed);
+  }
+  std::memcpy(out.data() + 13, &sum, 8);
+  std::memcpy(out.data() + kPageHeader, body.data(), body.size());
+}
+
+void deserializePages(const void* const* pagesIn, const int64_t* sizesIn, int32_t numPages, const int32_t* types,
                       int32_t numCols, int32_t flags, void* deviceBytes, int64_t deviceCapacity, vx355_out_column* cols,
                       int64_t capacityRows, int64_t* rowsOut) {
   auto& rt = Runtime::get();
   VX_CHECK_ARG(rowsOut && numPages >= 0 && numCols >= 0, "NULL argument");
-  VX_CHECK_ARG(numPages == 0 || (pages && sizes), "NULL argument");
+  VX_CHECK_ARG(numPages == 0 || (pagesIn && sizesIn), "NULL argument");
   VX_CHECK_ARG(numCols == 0 || (types && cols), "NULL argument");
   const bool lossless = (flags & VX355_PAGE_LOSSLESS_TIMESTAMP) != 0;
+  // Compressed pages are uncompressed on the host first (PrestoSerializer.cpp:185-199); from here on
+  // 'pages' / 'sizes' name the uncompressed images.
+  std::vector<const void*> pages(pagesIn, pagesIn + numPages);
+  std::vector<int64_t> sizes(sizesIn, sizesIn + numPages);
+  std::vector<std::vector<unsigned char>> uncompressedPages;
+  for (int32_t p = 0; p < numPages; ++p) {
+    const unsigned char* page = static_cast<const unsigned char*>(pages[p]);
+    if (page && sizes[p] >= kPageHeader && (page[4] & 1) && !(page[4] & 2)) {
+      uncompressedPages.emplace_back();
+      uncompressPage(page, sizes[p], VX355_PAGE_COMPRESSION_OF(flags), "PrestoPage " + std::to_string(p),
+                     uncompressedPages.back());
+      pages[p] = uncompressedPages.back().data();
+      sizes[p] = static_cast<int64_t>(uncompressedPages.back().size());
+    }
+  }
   static const Crc32 crc;
   std::vector<int64_t> pageRowBegin(numPages + 1, 0), pageDevBegin(numPages + 1, 0);
   std::vector<ReadSection> sections(static_cast<size_t>(numPages) * std::max(numCols, 1));
@@ -1132,7 +1255,7 @@ void deserializePages(const void* const* pages, const int64_t* sizes, int32_t nu
       bad("negative header field");
     }
     if (codec & 3) {
-      VX_THROW(VX355_EUNSUPPORTED, "compressed or encrypted PrestoPage (the shim decompresses first)");
+      VX_THROW(VX355_EUNSUPPORTED, "encrypted PrestoPage");   // (compressed ones were uncompressed above)
     }
     if (uncompressed != stored || static_cast<int64_t>(stored) + kPageHeader != size) {
       bad("size fields do not match the page length");
@@ -1450,6 +1573,31 @@ int vx355_presto_serialize(const vx355_batch* batch, const int32_t* rows, int32_
   vx::Runtime::get().requireInit();
   vx::serializePages(batch, rows, rows_mem, offsets, num_pages, flags, out, out_capacity, out_mem, page_offsets);
   VX_API_END
+}
+
+int vx355_presto_compress_page(const void* page, int64_t size, int32_t compression, float min_ratio, void* out,
+                               int64_t out_capacity, int64_t* out_size) {
+  try {   // host work only: no execution context, no GPU
+    VX_CHECK_ARG(page && out && out_size, "NULL argument");
+    VX_CHECK_ARG(min_ratio > 0, "min_ratio must be positive (PrestoOptions::minCompressionRatio)");
+    std::vector<unsigned char> result;
+    vx::compressPage(static_cast<const unsigned char*>(page), size, compression, min_ratio, result);
+    VX_CHECK_ARG(out_capacity >= static_cast<int64_t>(result.size()), "output buffer smaller than the page");
+    std::memcpy(out, result.data(), result.size());
+    *out_size = static_cast<int64_t>(result.size());
+  VX_API_CATCH
+}
+
+int vx355_presto_uncompress_page(const void* page, int64_t size, int32_t compression, void* out, int64_t out_capacity,
+                                 int64_t* out_size) {
+  try {
+    VX_CHECK_ARG(page && out && out_size, "NULL argument");
+    std::vector<unsigned char> result;
+    vx::uncompressPage(static_cast<const unsigned char*>(page), size, compression, "PrestoPage", result);
+    VX_CHECK_ARG(out_capacity >= static_cast<int64_t>(result.size()), "output buffer smaller than the uncompressed page");
+    std::memcpy(out, result.data(), result.size());
+    *out_size = static_cast<int64_t>(result.size());
+  VX_API_CATCH
 }
 
 int vx355_presto_deserialize(const void* const* pages, const int64_t* sizes, int32_t num_pages, const int32_t* types,

@@ -49,6 +49,8 @@ SYMBOLS = [
     "vx355_join_probe_get_output_async", "vx355_join_probe_output_result",
     "vx355_join_probe_add_input_regrouped",
     "vx355_agg_bytes_in_use", "vx355_agg_get_gpu_stats", "vx355_join_build_get_gpu_stats", "vx355_join_probe_get_gpu_stats",
+    "vx355_presto_compress_page", "vx355_presto_uncompress_page",
+    "vx355_set_memory_limit", "vx355_memory_usage",
 ]
 
 # void (*vx355_output_done_fn)(void* arg, int status, int32_t num_rows, int32_t finished)
@@ -96,6 +98,10 @@ def lib():
     L.vx355_partition_scatter.argtypes = [vp, i32, i32, P(vp), P(i32), i32, P(vp), P(i64), i32]
     L.vx355_presto_serialize.argtypes = [P(abi.Batch), vp, i32, vp, i32, i32, vp, i64, i32, vp]
     L.vx355_presto_deserialize.argtypes = [vp, vp, i32, vp, i32, i32, vp, i64, vp, i64, vp]
+    L.vx355_set_memory_limit.argtypes = [i64]
+    L.vx355_memory_usage.argtypes = [P(i64), P(i64), P(i64)]
+    L.vx355_presto_compress_page.argtypes = [vp, i64, i32, C.c_float, vp, i64, P(i64)]
+    L.vx355_presto_uncompress_page.argtypes = [vp, i64, i32, vp, i64, P(i64)]
     L.vx355_filter_project.argtypes = [P(abi.Batch), P(abi.FilterTerm), i32, P(abi.Projection), i32,
                                        vp, P(i32), P(vp), P(vp), i32]
     L.vx355_agg_create.argtypes = [P(abi.AggSpec), P(vp)]
@@ -200,6 +206,18 @@ def init(device=0):
 def set_device(device):
     """vx355_set_device: the GPU of the calling thread (one Driver thread per device / rank)."""
     _check(lib().vx355_set_device(device))
+
+
+def set_memory_limit(nbytes):
+    """vx355_set_memory_limit: cap on the HBM the operators of this GPU hold at one time (0 = none)."""
+    _check(lib().vx355_set_memory_limit(int(nbytes)))
+
+
+def memory_usage():
+    """vx355_memory_usage -> (bytes held by operators now, peak since the last call, bytes in the block cache)."""
+    a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+    _check(lib().vx355_memory_usage(C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value
 
 
 def synchronize():
@@ -685,6 +703,27 @@ def presto_serialize(batch, offsets, rows=None, flags=0, device_out=False):
     return [out[page_offsets[p]:page_offsets[p + 1]].tobytes() for p in range(num_pages)]
 
 
+def presto_compress_page(page, compression, min_ratio=0.8):
+    """vx355_presto_compress_page (host work, no GPU): one uncompressed page -> the page a compressing
+    exchange writes (the same bytes when compression does not reach min_ratio)."""
+    page = bytes(page)
+    out = C.create_string_buffer(max(len(page), 1))
+    size = C.c_int64()
+    _check(lib().vx355_presto_compress_page(page, len(page), compression, min_ratio, out, len(page), C.byref(size)))
+    return out.raw[:size.value]
+
+
+def presto_uncompress_page(page, compression):
+    """vx355_presto_uncompress_page (host work, no GPU): -> the uncompressed page."""
+    import struct
+    page = bytes(page)
+    cap = 21 + max(struct.unpack_from("<i", page, 5)[0], 0) if len(page) >= 21 else 21
+    out = C.create_string_buffer(max(cap, len(page), 1))
+    size = C.c_int64()
+    _check(lib().vx355_presto_uncompress_page(page, len(page), compression, out, len(out), C.byref(size)))
+    return out.raw[:size.value]
+
+
 def presto_deserialize(pages, kinds, flags=0):
     """vx355_presto_deserialize: list of page bytes -> [(values, valid)] per column, fetched back
     from the HBM columns the library wrote (strings longer than 12 bytes through the device copy
@@ -696,7 +735,8 @@ def presto_deserialize(pages, kinds, flags=0):
     keep = [C.create_string_buffer(p, len(p)) for p in pages]
     ptrs = (C.c_void_p * max(1, len(pages)))(*[C.addressof(k) for k in keep])
     sizes = np.array([len(p) for p in pages] or [0], dtype=np.int64)
-    total_bytes = int(sum(len(p) for p in pages))
+    # (a compressed page - codec marker bit 1 - occupies 21 + uncompressedSize bytes of the device buffer)
+    total_bytes = int(sum(21 + struct.unpack_from("<i", p, 5)[0] if len(p) >= 21 and (p[4] & 1) else len(p) for p in pages))
     dev_bytes = DeviceArray(max(total_bytes, 1), np.uint8)
     cap = max(total_rows, 1)
     words = (cap + 63) // 64
