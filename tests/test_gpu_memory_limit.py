@@ -44,6 +44,7 @@ def test_join_build_beyond_the_limit_fails_cleanly_and_releases_everything(oracl
             build.add_input(batch_of([keys[lo:lo + 500_000], pay[lo:lo + 500_000]]))
         build.finish()
     assert e.value.status == abi.ENOMEM and "memory limit" in str(e.value)
+    del e       # (the traceback keeps the frame of build.add_input, and with it the handle, alive)
     # a second operator, small enough, works while the failed one is still around ...
     small = vx.JoinBuild([0], [abi.BIGINT], [1], [abi.BIGINT], abi.JOIN_INNER)
     small.add_input(batch_of([keys[:1000], pay[:1000]]))
@@ -92,6 +93,7 @@ def test_aggregation_beyond_the_limit_fails_cleanly(oracle, limited):
         op.no_more_input()
         vx.collect_output(op, 1 << 20)
     assert e.value.status == abi.ENOMEM
+    del e
     del op
     assert _held(vx) == before
     # under the same limit a plan that fits still runs, and matches the oracle
