@@ -14,6 +14,7 @@
 #include "velox/exec/FilterProject.h"
 #include "velox/exec/HashAggregation.h"
 #include "velox/exec/Task.h"
+#include "velox/common/memory/MemoryArbitrator.h"
 #include "velox/vector/FlatVector.h"
 
 namespace facebook::velox::vx355 {
@@ -689,8 +690,9 @@ bool adaptDriver(const exec::DriverFactory& factory, exec::Driver& driver) {
   return replaced;
 }
 
-void registerVx355(int device) {
+void registerVx355(int device, int64_t memoryLimitBytes) {
   VELOX_CHECK_EQ(vx355_init(device), VX355_OK, "{}", vx355_last_error());
+  VELOX_CHECK_EQ(vx355_set_memory_limit(memoryLimitBytes), VX355_OK, "{}", vx355_last_error());
   exec::DriverFactory::registerAdapter(exec::DriverAdapter{"vx355", /*inspect=*/{}, adaptDriver});
 }
 
@@ -887,6 +889,12 @@ Vx355HashAggregation::~Vx355HashAggregation() {
 void Vx355HashAggregation::check(int status) {
   if (status == VX355_OK) {
     return;
+  }
+  if (status == VX355_ENOMEM) {
+    // The library's share of HBM (registerVx355's memoryLimitBytes / the GPU itself) is exhausted and it
+    // does not spill: the failure an operator reports when its MemoryPool cannot grow and nothing can be
+    // reclaimed (canReclaim() == false). The handle stays destroyable; the Task fails cleanly.
+    VELOX_MEM_POOL_CAP_EXCEEDED("{}", vx355_last_error());
   }
   if (status == VX355_EUSER) {
     VELOX_USER_FAIL("{}", vx355_last_error());  // e.g. "integer overflow" (sum(BIGINT))

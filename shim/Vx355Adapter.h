@@ -30,7 +30,10 @@ namespace facebook::velox::vx355 {
 /// Registers the adapter: every Driver created afterwards has its HashAggregation, HashBuild and
 /// HashProbe operators replaced where libvx355 supports the plan (the create call succeeds);
 /// everything else stays on the CPU operators. device: the GPU of this process (one process per GPU).
-void registerVx355(int device = 0);
+/// memoryLimitBytes: the share of the GPU's HBM the embedding gives to the operators' tables, staged input
+/// and scratch (0 = all of it); past it an operator fails with VELOX_MEM_POOL_CAP_EXCEEDED - the library does
+/// not spill (vx355_set_memory_limit, include/vx355.h).
+void registerVx355(int device = 0, int64_t memoryLimitBytes = 0);
 
 /// The adapter function itself (what registerVx355 registers); exposed for tests.
 bool adaptDriver(const exec::DriverFactory& factory, exec::Driver& driver);

@@ -12,6 +12,7 @@
 #include "velox/exec/HashProbe.h"
 #include "velox/exec/OperatorUtils.h"
 #include "velox/exec/Task.h"
+#include "velox/common/memory/MemoryArbitrator.h"
 #include "velox/vector/FlatVector.h"
 
 namespace facebook::velox::vx355 {
@@ -21,6 +22,12 @@ namespace {
 void check(int status) {
   if (status == VX355_OK) {
     return;
+  }
+  if (status == VX355_ENOMEM) {
+    // The library's share of HBM (registerVx355's memoryLimitBytes / the GPU itself) is exhausted and it
+    // does not spill: the failure an operator reports when its MemoryPool cannot grow and nothing can be
+    // reclaimed (canReclaim() == false). The handle stays destroyable; the Task fails cleanly.
+    VELOX_MEM_POOL_CAP_EXCEEDED("{}", vx355_last_error());
   }
   if (status == VX355_EUSER) {
     VELOX_USER_FAIL("{}", vx355_last_error());

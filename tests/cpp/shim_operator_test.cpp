@@ -546,6 +546,25 @@ int main() {
       return 1;
     }
     std::printf("ok: dynamic filter (Bloom blocks of the table) pushed to the probe side's scan\n");
+    // Beyond the operators' share of HBM: the build fails with the reference's memory-cap error, its handles
+    // are destroyed on the way out, and the same plan runs again once the limit is lifted.
+    int64_t inUse = 0;
+    EXPECT(vx355_memory_usage(&inUse, nullptr, nullptr) == VX355_OK);
+    EXPECT(vx355_set_memory_limit(inUse + (256 << 10)) == VX355_OK);
+    bool capped = false;
+    try {
+      (void)testJoin(false, false, 400000);
+    } catch (const VeloxRuntimeError& e) {
+      capped = e.errorCode() == error_code::kMemCapExceeded && std::string(e.what()).find("memory limit") != std::string::npos;
+    }
+    EXPECT(capped);
+    int64_t after = 0;
+    EXPECT(vx355_memory_usage(&after, nullptr, nullptr) == VX355_OK && after == inUse);
+    EXPECT(vx355_set_memory_limit(0) == VX355_OK);
+    if (testJoin(false, false, 400000) != 0) {
+      return 1;
+    }
+    std::printf("ok: VX355_ENOMEM -> VELOX_MEM_POOL_CAP_EXCEEDED, nothing leaked, the plan runs once the limit is lifted\n");
   } catch (const std::exception& e) {
     std::fprintf(stderr, "FAILED: %s\n", e.what());
     return 1;

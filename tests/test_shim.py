@@ -40,7 +40,7 @@ def test_shim_includes_only_headers_the_reference_has():
     against a recorded list: /root/reference is not on the GPU box) and in the stub."""
     import re
     recorded = {
-        "velox/common/future/VeloxPromise.h", "velox/core/Expressions.h", "velox/core/PlanNode.h",
+        "velox/common/future/VeloxPromise.h", "velox/common/memory/MemoryArbitrator.h", "velox/core/Expressions.h", "velox/core/PlanNode.h",
         "velox/core/QueryConfig.h", "velox/exec/Aggregate.h", "velox/exec/Driver.h", "velox/exec/FilterProject.h",
         "velox/exec/HashAggregation.h", "velox/exec/HashBuild.h", "velox/exec/HashProbe.h", "velox/exec/HashTable.h", "velox/exec/Operator.h", "velox/type/Filter.h",
         "velox/exec/OperatorUtils.h", "velox/exec/Task.h", "velox/vector/ComplexVector.h",

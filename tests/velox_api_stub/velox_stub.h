@@ -48,8 +48,16 @@ constexpr column_index_t kConstantChannel = std::numeric_limits<column_index_t>:
 
 class VeloxException : public std::runtime_error {
  public:
-  using std::runtime_error::runtime_error;
+  explicit VeloxException(const std::string& message, std::string errorCode = "")
+      : std::runtime_error(message), errorCode_(std::move(errorCode)) {}
+  const std::string& errorCode() const { return errorCode_; }  // common/base/VeloxException.h:236
+
+ private:
+  std::string errorCode_;
 };
+namespace error_code {
+inline constexpr const char* kMemCapExceeded = "MEM_CAP_EXCEEDED";  // common/base/VeloxException.h:123
+}
 class VeloxUserError : public VeloxException {
  public:
   using VeloxException::VeloxException;
@@ -87,6 +95,9 @@ std::string format(const char* fmt, const Args&... args) {
 
 #define VELOX_FAIL(...) throw ::facebook::velox::VeloxRuntimeError(::facebook::velox::detail::format(__VA_ARGS__))
 #define VELOX_USER_FAIL(...) throw ::facebook::velox::VeloxUserError(::facebook::velox::detail::format(__VA_ARGS__))
+// common/memory/MemoryArbitrator.h:33-39: a VeloxRuntimeError with error code kMemCapExceeded
+#define VELOX_MEM_POOL_CAP_EXCEEDED(...) \
+  throw ::facebook::velox::VeloxRuntimeError(::facebook::velox::detail::format(__VA_ARGS__), ::facebook::velox::error_code::kMemCapExceeded)
 #define VELOX_NYI(...) throw ::facebook::velox::VeloxRuntimeError("not yet implemented " + ::facebook::velox::detail::format(__VA_ARGS__))
 #define VELOX_UNSUPPORTED(...) throw ::facebook::velox::VeloxUserError(::facebook::velox::detail::format(__VA_ARGS__))
 #define VELOX_CHECK(cond, ...)                                                                         \

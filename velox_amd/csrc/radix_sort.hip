@@ -33,7 +33,7 @@ constexpr int kRsWaves = 4;         // waves per workgroup
 constexpr int kRsSmall = 2048;      // entries the one-workgroup kernel takes
 constexpr int64_t kRsSingleScan = 16 << 10;   // cells one workgroup scans (n <= 128 K entries); more: scanU32ToU64
 
-__global__ __launch_bounds__(256) void k_rs_hist(const uint64_t* keys, int64_t n, int shift, uint32_t* hist, int64_t numChunks) {
+__global__ __launch_bounds__(256) void k_rs_hist(const uint64_t* keys, int64_t n, int shift, uint32_t digitMask, uint32_t* hist, int64_t numChunks) {
   __shared__ uint32_t h[kRsWaves][256];
   const int w = threadIdx.x >> 6;
   const int64_t chunk = static_cast<int64_t>(blockIdx.x) * kRsWaves + w;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k_rs_hist(const uint64_t* keys, int64_t n
     for (int it = 0; it < kRsChunk / 64; ++it) {
       const int64_t i = base + it * 64 + lane();
       if (i < n) {
-        atomicAdd(&h[w][(keys[i] >> shift) & 255], 1u);
+        atomicAdd(&h[w][(keys[i] >> shift) & digitMask], 1u);
       }
     }
   }
@@ -91,8 +91,8 @@ __global__ __launch_bounds__(1024) void k_rs_scan(const uint32_t* in, int64_t n,
 
 template <bool PAIRS>
 __global__ __launch_bounds__(256) void k_rs_scatter(const uint64_t* keys, const uint32_t* vals, uint64_t* keysOut,
-                                                    uint32_t* valsOut, int64_t n, int shift, const uint64_t* offsets,
-                                                    int64_t numChunks) {
+                                                    uint32_t* valsOut, int64_t n, int shift, uint32_t digitMask,
+                                                    const uint64_t* offsets, int64_t numChunks) {
   __shared__ unsigned long long next[kRsWaves][256];  // where the wave's next entry with digit d goes
   const int w = threadIdx.x >> 6;
   const int64_t chunk = static_cast<int64_t>(blockIdx.x) * kRsWaves + w;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_rs_scatter(const uint64_t* keys, const 
     if (PAIRS && valid) {
       val = vals[i];
     }
-    const uint32_t d = static_cast<uint32_t>(key >> shift) & 255u;
+    const uint32_t d = static_cast<uint32_t>(key >> shift) & digitMask;
     // lanes holding the same digit (match-any by eight ballots)
     uint64_t same = ballot(valid);
 #pragma unroll
@@ -165,21 +165,24 @@ __global__ __launch_bounds__(1024) void k_rs_small(const uint64_t* keys, const u
   }
 }
 
-// One pass over bits [shift, shift + 8): (srcKeys, srcVals) -> (dstKeys, dstVals).
+// One pass over bits [shift, min(shift + 8, endBit)): (srcKeys, srcVals) -> (dstKeys, dstVals). The last
+// pass of a sort masks its digit at endBit, so that bits above it never order anything - the same
+// contract as the one-workgroup path (k_rs_small), whatever the callers keep up there.
 template <bool PAIRS>
 void radixPass(const uint64_t* srcKeys, const uint32_t* srcVals, uint64_t* dstKeys, uint32_t* dstVals, int64_t n, int shift,
-               uint32_t* hist, uint64_t* offsets, DevBuf& scanScratch) {
+               int endBit, uint32_t* hist, uint64_t* offsets, DevBuf& scanScratch) {
+  const uint32_t digitMask = endBit - shift >= 8 ? 255u : ((1u << (endBit - shift)) - 1u);
   const int64_t numChunks = ceilDiv(n, kRsChunk);
   const int grid = static_cast<int>(ceilDiv(numChunks, kRsWaves));
   const int64_t cells = numChunks * 256;
-  VX_LAUNCH("k_rs_hist", k_rs_hist, grid, 256, 0, srcKeys, n, shift, hist, numChunks);
+  VX_LAUNCH("k_rs_hist", k_rs_hist, grid, 256, 0, srcKeys, n, shift, digitMask, hist, numChunks);
   if (cells <= kRsSingleScan) {
     VX_LAUNCH("k_rs_scan", k_rs_scan, 1, 1024, 0, hist, cells, offsets);
   } else {
     scanU32ToU64(hist, cells, offsets, scanScratch);
   }
-  VX_LAUNCH("k_rs_scatter", (k_rs_scatter<PAIRS>), grid, 256, 0, srcKeys, srcVals, dstKeys, dstVals, n, shift, offsets,
-            numChunks);
+  VX_LAUNCH("k_rs_scatter", (k_rs_scatter<PAIRS>), grid, 256, 0, srcKeys, srcVals, dstKeys, dstVals, n, shift, digitMask,
+            offsets, numChunks);
 }
 
 struct SortScratch {
@@ -221,8 +224,8 @@ void sortPairsU64U32(uint64_t* keys, uint32_t* vals, uint64_t* keysTmp, uint32_t
   uint64_t* k[2] = {keys, keysTmp};
   uint32_t* v[2] = {vals, valsTmp};
   for (int p = 0; p < passes; ++p) {
-    radixPass<true>(k[p & 1], v[p & 1], k[(p + 1) & 1], v[(p + 1) & 1], static_cast<int64_t>(n), p * 8, s.hist, s.offsets,
-                    scanScratch);
+    radixPass<true>(k[p & 1], v[p & 1], k[(p + 1) & 1], v[(p + 1) & 1], static_cast<int64_t>(n), p * 8, endBit, s.hist,
+                    s.offsets, scanScratch);
   }
   *resultInTmp = (passes & 1) != 0;
   Runtime::get().sync();  // (scanScratch goes out of scope: the passes must have finished with it)
@@ -250,7 +253,8 @@ void sortKeysU64(const uint64_t* in, uint64_t* out, size_t n, DevBuf& tmp, int b
   const uint64_t* src = in;
   for (int p = 0; p < passes; ++p) {
     uint64_t* dst = ((passes - 1 - p) & 1) ? s.spare : out;
-    radixPass<false>(src, nullptr, dst, nullptr, static_cast<int64_t>(n), beginBit + p * 8, s.hist, s.offsets, scanScratch);
+    radixPass<false>(src, nullptr, dst, nullptr, static_cast<int64_t>(n), beginBit + p * 8, endBit, s.hist, s.offsets,
+                     scanScratch);
     src = dst;
   }
   Runtime::get().sync();
