@@ -7,6 +7,7 @@ slice of the Velox API it touches, with the reference's signatures - and
  - run on the GPU as operators of a Driver (tests/cpp/shim_operator_test.cpp)."""
 import os
 import subprocess
+import sys
 
 import pytest
 
@@ -54,6 +55,16 @@ def test_shim_includes_only_headers_the_reference_has():
         assert os.path.exists(os.path.join(ROOT, "tests", "velox_api_stub", h)), h
         if os.path.isdir("/root/reference/velox"):
             assert os.path.exists(os.path.join("/root/reference", h)), h
+
+
+def test_stub_names_exist_in_the_reference():
+    """tools/stub_drift.py: every class and function the API stub declares is a name of the reference's headers
+    (the stub's own stand-ins are listed there with what they stand in for). Needs /root/reference."""
+    if not os.path.isdir("/root/reference/velox"):
+        pytest.skip("the reference tree is not on this machine")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stub_drift.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert " 0 not found" in r.stdout
 
 
 def test_reference_q1_plan_is_accepted_by_the_shim(tmp_path):
