@@ -568,6 +568,20 @@ def test_async_instantiation_does_not_stall_the_first_batches(oracle, vx, monkey
     code object is there later batches take it. Results do not depend on which
     kernel consumed which batch."""
     import time
+    # (the very first compilation of a process runs on the calling thread - it constructs the compiler's
+    # statics, so that exit() can wait for later background compiles before they are destroyed: agg.hip,
+    # gJitWarm - so the process is warmed with another shape before the asynchronous path is timed)
+    monkeypatch.setenv("VX355_JIT", "sync")
+    warm_rng = np.random.default_rng(7)
+    warm = vx.Aggregation([0, 1], [abi.INTEGER, abi.BIGINT],
+                          [(abi.AGG_SUM, 2, abi.DOUBLE), (abi.AGG_MIN, 3, abi.DOUBLE), (abi.AGG_MAX, 2, abi.DOUBLE),
+                           (abi.AGG_COUNT_STAR, -1, abi.BIGINT)])
+    warm.add_input(vx.to_device(batch_of([warm_rng.integers(0, 5, 1 << 16).astype(np.int32),
+                                          warm_rng.integers(0, 3, 1 << 16).astype(np.int64),
+                                          _dyadic(warm_rng, 1 << 16), _dyadic(warm_rng, 1 << 16)])))
+    warm.no_more_input()
+    vx.collect_output(warm, 100)
+    assert warm.stats().reserved > 0, "the warm-up shape did not go through hiprtc"
     monkeypatch.setenv("VX355_JIT", "async")
     rng = np.random.default_rng(2025)
     n = 1 << 18

@@ -5286,7 +5286,16 @@ void jitWriteCache(const std::string& path, const std::vector<char>& code) {
 // launched (before comgr is loaded: it then runs after comgr's own exit handlers were registered, i.e. it
 // holds exit() while the helper thread finishes) and from the helper thread once hiprtc has loaded comgr
 // (registered later than comgr's statics, so it runs BEFORE they are destroyed).
+// Round 6: that was not enough. LLVM constructs function-local statics DURING a compilation; they register
+// their destructors after both handlers above, so exit() destroys them first and only then reaches the
+// handler that waits - a program that finished while its first background compile was still running (every
+// first run against an empty instance cache) aborted in LLVM ("Cannot implicitly convert a scalable size
+// ..."), crashed or hung about one time in five (profiles/r06_jit_exit_race.md). Therefore the FIRST
+// compilation of a process runs on the calling thread (gJitWarm: ~0.8 s once, and only when the on-disk
+// cache misses): when it returns, the compiler's statics exist, the handler registered after it runs before
+// their destructors, and every later background compile is covered.
 std::atomic<int> gJitInFlight{0};
+std::atomic<bool> gJitWarm{false};
 void waitForJitAtExit() {
   for (int i = 0; i < 6000 && gJitInFlight.load(std::memory_order_acquire) > 0; ++i) {
     std::this_thread::sleep_for(std::chrono::milliseconds(10));
@@ -5295,6 +5304,10 @@ void waitForJitAtExit() {
 
 // hiprtc half of an instantiation: CPU only, may run on any thread. Empty result = failure.
 std::vector<char> jitCompile(const std::string& src, const std::string& clangInclude, std::string* buildLog) {
+  // ONE compilation at a time in the process (hiprtc serialises its entry points itself; this keeps the
+  // order of "first compile, then the exit handler" below well defined when several Drivers miss at once).
+  static std::mutex oneCompiler;
+  std::lock_guard<std::mutex> serial(oneCompiler);
   hiprtcProgram prog = nullptr;
   bool ok = hiprtcCreateProgram(&prog, src.c_str(), "vx355_agg_fast_jit.hip", 0, nullptr, nullptr) == HIPRTC_SUCCESS;
   static std::once_flag afterComgr;
@@ -5325,6 +5338,9 @@ std::vector<char> jitCompile(const std::string& src, const std::string& clangInc
   }
   if (!ok) {
     code.clear();
+  }
+  if (!gJitWarm.exchange(true)) {
+    std::atexit(waitForJitAtExit);  // registered AFTER the compiler's lazily constructed statics: runs before their destructors
   }
   return code;
 }
@@ -5369,7 +5385,7 @@ hipFunction_t jitFastKernel(const FastSignature& sig, int unroll, bool log, bool
     if (log) {
       fprintf(stderr, "vx355: instance of shape %s loaded from %s\n", key, cachePath.c_str());
     }
-  } else if (async) {
+  } else if (async && gJitWarm.load()) {
     const std::string inc = st.clangInclude;
     static std::once_flag beforeComgr;
     std::call_once(beforeComgr, [] { std::atexit(waitForJitAtExit); });
