@@ -1227,9 +1227,15 @@ def measured_ceilings():
     A kernel is compared with the ceiling of ITS shape."""
     return {"read_GBps": ops.hbm_ceiling(abi.CEILING_READ, 8 << 30, 5),
             "copy_GBps": ops.hbm_ceiling(abi.CEILING_COPY, 4 << 30, 5),
+            # TPC-H Q1's scan with nothing behind it: seven column streams in k_agg_fast's row -> lane
+            # mapping (68 B/row, 20 GB = the 300 M rows of one launch); interleaved streams deliver less
+            # than one, and this - not the single stream - is what the kernel's arithmetic competes with
+            "q1_columns_GBps": ops.hbm_ceiling(abi.CEILING_READ_COLUMNS, 68 * 300_000_000, 5),
             "how": "vx355_hbm_ceiling: 16-byte nontemporal accesses; read = 8 GiB read-only stream (four per lane in "
                    "flight, 8 workgroups of 512 per CU), copy = 4 GiB read + 4 GiB written (eight per lane in flight, "
-                   "4 workgroups of 1024 per CU, one contiguous 2 MiB-aligned range each: tools/copy_bench.hip)"}
+                   "4 workgroups of 1024 per CU, one contiguous 2 MiB-aligned range each: tools/copy_bench.hip); "
+                   "q1_columns = the seven column streams of TPC-H Q1's scan (68 B/row, 300 M rows) in k_agg_fast's "
+                   "row -> lane mapping with nothing computed (tools/q1_stream_bench.hip)"}
 
 
 READ_ONLY_KERNELS = ("k_agg_fast", "k_agg_lds", "k_join_probe", "k_join_probe_list", "k_join_probe_grouped", "k_rp_count1", "k_pp_count")
@@ -1640,6 +1646,8 @@ def compact_roofline(r):
             "launches_per_step": r.get("launches_per_step"),
             "measured_read_ceiling_GBps": _num((r.get("measured_ceiling") or {}).get("read_GBps"), 5),
             "measured_copy_ceiling_GBps": _num((r.get("measured_ceiling") or {}).get("copy_GBps"), 5),
+            "measured_q1_columns_ceiling_GBps": _num((r.get("measured_ceiling") or {}).get("q1_columns_GBps"), 5),
+            "frac_of_q1_columns_ceiling": _num(r.get("frac_of_q1_columns_ceiling"), 4),
             "ceiling_for_this_kernel": r.get("measured_ceiling_kind")}
 
 
@@ -1796,6 +1804,10 @@ def roofline_block(wl, prof, steps, copy_ceiling, child_flags):
                                                              else "copy_GBps"])
                                      if (achieved and copy_ceiling) else None),
         "measured_ceiling_kind": "read" if wl.dominant in READ_ONLY_KERNELS else "copy",
+        "frac_of_q1_columns_ceiling": ((achieved / copy_ceiling["q1_columns_GBps"])
+                                       if (achieved and copy_ceiling and copy_ceiling.get("q1_columns_GBps")
+                                           and wl.name == "tpch_q1_sf100" and wl.dominant == "k_agg_fast")
+                                       else None),
         "kernel_ms_per_step": dom_ms / steps,
         "avg_launch_ms": (dom_ms / dom_launches) if dom_launches else None,
         "launches_per_step": dom_launches / steps,

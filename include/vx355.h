@@ -201,6 +201,11 @@ int vx355_memory_usage(int64_t* in_use, int64_t* peak, int64_t* cached);
  * bytes moved / elapsed time in GB/s. bytes >= 1 MiB. */
 #define VX355_CEILING_READ 0
 #define VX355_CEILING_COPY 1
+/* VX355_CEILING_READ_COLUMNS: 'bytes' bytes as SEVEN column streams read side by side in the row -> lane
+ * mapping of the fused aggregation kernel on TPC-H Q1's scan (two 16-byte view columns of which 8 bytes per
+ * row are loaded, one 4-byte and four 8-byte columns: 68 bytes of HBM traffic per row), nothing computed:
+ * what that kernel's arithmetic competes with on this box (interleaved streams deliver less than one). */
+#define VX355_CEILING_READ_COLUMNS 2
 int vx355_hbm_ceiling(int32_t kind, size_t bytes, int32_t iterations, double* gbytes_per_second);
 
 /* ---- standalone kernels (parity-test surface) --------------------------- */

@@ -540,7 +540,13 @@ def test_hbm_ceiling_kernels_report_plausible_rates(vx):
     read = vx.hbm_ceiling(abi.CEILING_READ, 2 << 30, 3)
     copy = vx.hbm_ceiling(abi.CEILING_COPY, 1 << 30, 3)
     assert 1000 < copy < 8000 and 1000 < read < 8000, (read, copy)
-    print("hbm ceilings GB/s: read", round(read), "copy", round(copy))
+    # the seven column streams of TPC-H Q1's scan, nothing computed: what k_agg_fast competes with
+    columns = vx.hbm_ceiling(abi.CEILING_READ_COLUMNS, 2 << 30, 3)
+    assert 1000 < columns < 8000, columns
+    print("hbm ceilings GB/s: read", round(read), "copy", round(copy), "seven column streams", round(columns))
+    with pytest.raises(vx.Vx355Error) as e:
+        vx.hbm_ceiling(3, 1 << 30, 1)
+    assert e.value.status == abi.EINVAL
 
 
 @pytest.mark.parametrize("device_resident", [False, True])

@@ -102,7 +102,7 @@ class KeyFilter(C.Structure):
 
 
 KEY_FILTER_NONE, KEY_FILTER_VALUES, KEY_FILTER_BLOOM = 0, 1, 2
-CEILING_READ, CEILING_COPY = 0, 1
+CEILING_READ, CEILING_COPY, CEILING_READ_COLUMNS = 0, 1, 2
 
 
 class JoinBuildSpec(C.Structure):

@@ -38,6 +38,64 @@ __global__ __launch_bounds__(512) void k_ceiling_read(const U32x4* src, int64_t 
   }
 }
 
+// VX355_CEILING_READ_COLUMNS: the scan of TPC-H Q1 with nothing behind it - the seven column streams of
+// k_agg_fast's plan (two 16-byte StringView columns of which the first 8 bytes of every view are loaded,
+// one 4-byte date, four 8-byte doubles = 68 bytes of HBM traffic per row) in k_agg_fast's own mapping of
+// rows to lanes (512 lanes, four rows per lane 512 rows apart, every load of an iteration issued before
+// the first use, nontemporal, three workgroups per CU, grid-stride), the loaded words xor-ed together.
+// Seven interleaved streams deliver less than one (round 6, tools/q1_stream_bench.hip: 6.3-6.5 TB/s on a
+// box whose single stream reaches 6.8; 16-byte loads over four ADJACENT rows per lane only 5.1): this is
+// the number k_agg_fast's arithmetic competes with, measured on the same box in the same process.
+struct ColumnStreams {
+  const uint64_t* view[2];
+  const uint32_t* date;
+  const uint64_t* f64[4];
+};
+constexpr int kColumnsUnroll = 4;
+__global__ __launch_bounds__(512, 4) void k_ceiling_columns(ColumnStreams c, int64_t n, uint32_t* sink) {
+  const int64_t tile = 512LL * kColumnsUnroll;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * tile;
+  const int64_t rounds = (n + stride - 1) / stride;
+  int64_t base = static_cast<int64_t>(blockIdx.x) * tile + threadIdx.x;
+  uint64_t acc = 0;
+  for (int64_t r = 0; r < rounds; ++r, base += stride) {
+    int64_t row[kColumnsUnroll];
+    uint64_t k0[kColumnsUnroll], k1[kColumnsUnroll], x[4][kColumnsUnroll];
+    uint32_t d[kColumnsUnroll];
+#pragma unroll
+    for (int u = 0; u < kColumnsUnroll; ++u) {
+      const int64_t t = base + u * 512LL;
+      row[u] = t < n ? t : n - 1;  // clamped, as k_agg_fast does: no load under a per-lane predicate
+    }
+#pragma unroll
+    for (int u = 0; u < kColumnsUnroll; ++u) {
+      k0[u] = __builtin_nontemporal_load(c.view[0] + row[u] * 2);
+    }
+#pragma unroll
+    for (int u = 0; u < kColumnsUnroll; ++u) {
+      k1[u] = __builtin_nontemporal_load(c.view[1] + row[u] * 2);
+    }
+#pragma unroll
+    for (int u = 0; u < kColumnsUnroll; ++u) {
+      d[u] = __builtin_nontemporal_load(c.date + row[u]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int u = 0; u < kColumnsUnroll; ++u) {
+        x[j][u] = __builtin_nontemporal_load(c.f64[j] + row[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kColumnsUnroll; ++u) {
+      acc ^= k0[u] ^ k1[u] ^ d[u] ^ x[0][u] ^ x[1][u] ^ x[2][u] ^ x[3][u];
+    }
+  }
+  if (acc == 0x9e3779b97f4a7c15ULL) {  // (never true for the fill pattern)
+    sink[blockIdx.x] = static_cast<uint32_t>(acc);
+  }
+}
+
 // The copy shape that got closest to the guide's 6.3 TB/s on this chip (tools/copy_bench.hip,
 // profiles/r05_copy_bench.txt: 5.8-5.9 TB/s at 4 GiB + 4 GiB, 6.1 at 1 + 1; the r04 kernel - 512 lanes, 8
 // workgroups per CU, grid-stride, plain loads and stores - reached 4.5-5.0): 1024-lane workgroups, four
@@ -74,13 +132,26 @@ using namespace vx;
 extern "C" int vx355_hbm_ceiling(int32_t kind, size_t bytes, int32_t iterations, double* gbytes_per_second) {
   VX_API_BEGIN
   VX_CHECK_ARG(gbytes_per_second && iterations >= 1 && bytes >= (1u << 20), "bad argument");
-  VX_CHECK_ARG(kind == VX355_CEILING_READ || kind == VX355_CEILING_COPY, "unknown ceiling kernel");
+  VX_CHECK_ARG(kind == VX355_CEILING_READ || kind == VX355_CEILING_COPY || kind == VX355_CEILING_READ_COLUMNS,
+               "unknown ceiling kernel");
   auto& rt = Runtime::get();
   rt.requireInit();
-  const int64_t n = static_cast<int64_t>(bytes / 16);
+  // (READ_COLUMNS: 'bytes' = all seven columns together, 68 bytes per row, rows a multiple of 64)
+  const int64_t rows = kind == VX355_CEILING_READ_COLUMNS ? static_cast<int64_t>(bytes / 68) & ~63LL : 0;
+  const int64_t n = kind == VX355_CEILING_READ_COLUMNS ? (rows * 68 + 15) / 16 : static_cast<int64_t>(bytes / 16);
   DevBuf src, dst, sink;
   src.ensure(static_cast<size_t>(n) * 16);
   HIP_OK(hipMemsetAsync(src.ptr(), 0x5a, static_cast<size_t>(n) * 16, rt.stream));
+  ColumnStreams cols{};
+  if (kind == VX355_CEILING_READ_COLUMNS) {
+    const unsigned char* p = src.as<unsigned char>();
+    cols.view[0] = reinterpret_cast<const uint64_t*>(p);
+    cols.view[1] = reinterpret_cast<const uint64_t*>(p + rows * 16);
+    for (int j = 0; j < 4; ++j) {
+      cols.f64[j] = reinterpret_cast<const uint64_t*>(p + rows * (32 + 8 * j));
+    }
+    cols.date = reinterpret_cast<const uint32_t*>(p + rows * 64);
+  }
   const int grid = rt.numCUs * 8;
   sink.ensure(static_cast<size_t>(grid) * 4 + 64);
   if (kind == VX355_CEILING_COPY) {
@@ -88,7 +159,9 @@ extern "C" int vx355_hbm_ceiling(int32_t kind, size_t bytes, int32_t iterations,
   }
   hipEvent_t begin = rt.newEvent(), end = rt.newEvent();
   auto launch = [&]() {
-    if (kind == VX355_CEILING_READ) {
+    if (kind == VX355_CEILING_READ_COLUMNS) {
+      hipLaunchKernelGGL(k_ceiling_columns, dim3(rt.numCUs * 3), dim3(512), 0, rt.stream, cols, rows, sink.as<uint32_t>());
+    } else if (kind == VX355_CEILING_READ) {
       hipLaunchKernelGGL(k_ceiling_read, dim3(grid), dim3(512), 0, rt.stream, src.as<U32x4>(), n, sink.as<uint32_t>());
     } else {
       hipLaunchKernelGGL(k_ceiling_copy, dim3(rt.numCUs * 4), dim3(1024), 0, rt.stream, src.as<U32x4>(), dst.as<U32x4>(), n);
@@ -107,7 +180,9 @@ extern "C" int vx355_hbm_ceiling(int32_t kind, size_t bytes, int32_t iterations,
   HIP_OK(hipEventElapsedTime(&ms, begin, end));
   (void)hipEventDestroy(begin);
   (void)hipEventDestroy(end);
-  const double moved = static_cast<double>(n) * 16 * (kind == VX355_CEILING_COPY ? 2 : 1) * iterations;
+  const double moved = kind == VX355_CEILING_READ_COLUMNS
+      ? static_cast<double>(rows) * 68 * iterations
+      : static_cast<double>(n) * 16 * (kind == VX355_CEILING_COPY ? 2 : 1) * iterations;
   *gbytes_per_second = moved / (static_cast<double>(ms) * 1e-3) / 1e9;
   VX_API_END
 }
