@@ -657,16 +657,6 @@ __device__ inline int64_t fastKeyValue(uint64_t raw) {
   }
 }
 
-// End of a rarely taken branch of phase 2 that issued scalar loads or memory operations of its own
-// (HBM atomics of the overflow path, the deferred list, the counters): drained here. Where such a
-// branch joins the main path the compiler otherwise has to assume its scalar loads and flat
-// atomics still pending, and waits with lgkmcnt(0) / vmcnt(0) before the NEXT row's first
-// instruction - which on the main path means: until the dozen LDS atomics of the previous row have
-// retired (round 6, ISA of the Q1 instance).
-__device__ inline void fastRarePathDone() {
-  __builtin_amdgcn_s_waitcnt(0);
-}
-
 template <typename S>
 __device__ inline void aggFastBody(const FastArgs& a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
@@ -767,14 +757,7 @@ __device__ inline void aggFastBody(const FastArgs& a) {
         }
       });
     }
-    // Phase 2: filter, key, LDS updates - in four passes over the UNROLL rows of the lane, so that
-    // the LDS READS of an iteration (slot map, first-row words) are issued side by side and waited
-    // for once: an LDS read queues behind every atomic issued before it, and with the passes
-    // interleaved per row each of the 2 x UNROLL reads waited for the previous row's dozen atomics
-    // to drain (round 6).
-    bool act[UNROLL];    // the row passed the filter and has in-range keys
-    bool dfr[UNROLL];    // the row goes to the deferred list
-    uint64_t keys[UNROLL];
+    // Phase 2: filter, key, LDS updates.
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const int64_t row = base + static_cast<int64_t>(u) * blockDim.x;
@@ -809,7 +792,6 @@ __device__ inline void aggFastBody(const FastArgs& a) {
               if (v != INT64_MIN) {
                 atomicMin(reinterpret_cast<long long*>(&p.counters->keyMin[k]), static_cast<long long>(v));
                 atomicMax(reinterpret_cast<long long*>(&p.counters->keyMax[k]), static_cast<long long>(v));
-                fastRarePathDone();
               }
             }
           } else {
@@ -818,57 +800,8 @@ __device__ inline void aggFastBody(const FastArgs& a) {
           }
         }
       });
-      act[u] = live && !defer;
-      dfr[u] = defer;
-      keys[u] = key;
-    }
-    // LDS slots of the rows: the map entries of all rows first (compact maps), the claim protocol
-    // only for the rows whose entry is still empty or pending.
-    int32_t slots[UNROLL];
-    if (p.direct == 0) {
-      int32_t seen[UNROLL];
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-        seen[u] = kSlotEmpty;
-        if (act[u]) {
-          seen[u] = __hip_atomic_load(st.slotOf + keys[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-        slots[u] = seen[u];
-        if (act[u] && seen[u] < 0) {
-          slots[u] = ldsSlot(p, st, keys[u]);
-          fastRarePathDone();
-        }
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-        slots[u] = act[u] ? ldsSlot(p, st, keys[u]) : kSlotEmpty;
-      }
-    }
-    {
-      uint32_t first[UNROLL];
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-        first[u] = (act[u] && slots[u] >= 0) ? st.slotFirst[slots[u]] : 0u;
-      }
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-        const uint32_t row32 = static_cast<uint32_t>(base + static_cast<int64_t>(u) * blockDim.x);
-        if (first[u] > row32) {
-          atomicMin(&st.slotFirst[slots[u]], row32);
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      const int64_t row = base + static_cast<int64_t>(u) * blockDim.x;
-      const uint64_t key = keys[u];
-      bool defer = dfr[u];
-      if (act[u]) {
-        const int32_t slot = slots[u];
+      if (live && !defer) {
+        const int32_t slot = ldsSlot(p, st, key);
         double vals[NA > 0 ? NA : 1];
         uint64_t opv[NA > 0 ? NA : 1];  // operand word of the accumulators with an op (FastOp)
         bool have[NA > 0 ? NA : 1];  // false: some input of accumulator j is null in this row
@@ -915,6 +848,7 @@ __device__ inline void aggFastBody(const FastArgs& a) {
           }
         });
         if (slot >= 0) {
+          ldsTouchFirst(st, slot, static_cast<uint32_t>(row));
           uint64_t* dst = st.acc + (static_cast<size_t>(slot) * A) * REP + rep;
           staticFor<NA>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
@@ -980,7 +914,6 @@ __device__ inline void aggFastBody(const FastArgs& a) {
             }
           });
           }
-          fastRarePathDone();
         }
       }
       // Rows the fast path cannot place go to the deferred list (one atomic per wave).
@@ -995,7 +928,6 @@ __device__ inline void aggFastBody(const FastArgs& a) {
         if (defer && at + lanePrefix(m) < a.deferCap) {
           a.deferred[at + lanePrefix(m)] = static_cast<int32_t>(row);
         }
-        fastRarePathDone();
       }
     }
   }
