@@ -519,6 +519,44 @@ __global__ __launch_bounds__(512, 4) void k_agg_fast(FastArgs a) {
   aggFastBody<S>(a);
 }
 
+// Counters on their way to the host without a launch of their own: the LAST workgroup of a launch
+// that finishes (a ticket per workgroup) copies the live counters into the context's pinned mailbox
+// and puts the pristine values back - what k_read_reset_counters does as a launch of its own
+// (BASELINE config 1: two of the eight dispatches of a 130-us step). live == nullptr: not wanted.
+struct CounterMail {
+  uint64_t* live;
+  const uint64_t* pristine;
+  uint64_t* mailbox;
+  uint32_t* ticket;
+};
+
+// Called by the first wave of EVERY workgroup once the workgroup's counter updates are behind it
+// (block-synchronised by the caller where other waves took part).
+__device__ inline void publishCountersFromLastBlock(const CounterMail& m, uint32_t workgroups) {
+  if (m.live == nullptr || threadIdx.x >= 64) {
+    return;
+  }
+  uint32_t t = 0;
+  if (lane() == 0) {
+    __threadfence();
+    t = atomicAdd(m.ticket, 1u);
+  }
+  t = __shfl(t, 0, kWave);
+  if (t != workgroups - 1) {
+    return;
+  }
+  __threadfence();
+  constexpr int kWords = static_cast<int>(sizeof(Counters) / 8);
+  for (int i = lane(); i < kWords; i += kWave) {
+    const uint64_t v = __hip_atomic_load(m.live + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(m.mailbox + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(m.live + i, m.pristine[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (lane() == 0) {
+    __hip_atomic_store(m.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // Second half of the scratch flush (ldsFlushScratch, agg_device.h): folds the workgroups' copies
 // scratch[copy][word][key] into the direct-index table. A block owns 64 consecutive (word, key)
 // elements; its 16 waves read them from every 16th copy (512-byte coalesced loads, ~numCopies / 16
@@ -528,7 +566,7 @@ __global__ __launch_bounds__(512, 4) void k_agg_fast(FastArgs a) {
 // every copy: the totals are STORED, identities included - the launch that would have initialised
 // the table (k_init_table) is not needed. Otherwise gridDim.y block columns share the copies and
 // meet in the table with atomics.
-__global__ __launch_bounds__(1024) void k_lds_reduce(LdsPlan p, int32_t numCopies, int32_t storeAll) {
+__global__ __launch_bounds__(1024) void k_lds_reduce(LdsPlan p, int32_t numCopies, int32_t storeAll, CounterMail mail) {
   __shared__ uint64_t part[16][64];
   __shared__ uint64_t partLow[16][64];
   const int R = static_cast<int>(p.capacity);
@@ -546,22 +584,42 @@ __global__ __launch_bounds__(1024) void k_lds_reduce(LdsPlan p, int32_t numCopie
   if (in) {
     const uint64_t* src = p.scratch + e;
     const int step = 16 * static_cast<int>(gridDim.y);
-#pragma unroll 4
-    for (int c = static_cast<int>(blockIdx.y) * 16 + w; c < numCopies; c += step) {
-      const uint64_t q = src[static_cast<int64_t>(c) * E];
-      if (kind == ACC_SUM_F64) {
-        v = static_cast<uint64_t>(__double_as_longlong(__longlong_as_double(static_cast<long long>(v)) +
-                                                       __longlong_as_double(static_cast<long long>(q))));
-      } else if (kind == ACC_MIN) {
-        v = q < v ? q : v;
-      } else if (kind == ACC_MAX) {
-        v = q > v ? q : v;
-      } else {
-        v += q;
-        if (kind == ACC_SUM_I64_HI) {
-          const uint64_t ql = src[static_cast<int64_t>(c) * E - R];
-          v += carryUnsigned(low, ql);
-          low += ql;
+    // kReduceBatch copies per lane in flight: the loop is a chain of HBM round trips (32 copies per
+    // wave for 512 workgroups: eight trips with the four loads a plain unrolled loop kept in flight
+    // = 17 - 19 us for BASELINE config 1's 16 MB; round 6)
+    constexpr int kReduceBatch = 16;
+    const uint64_t identity = accIdentity(kind);
+    for (int c = static_cast<int>(blockIdx.y) * 16 + w; c < numCopies; c += step * kReduceBatch) {
+      uint64_t q[kReduceBatch], ql[kReduceBatch];
+#pragma unroll
+      for (int i = 0; i < kReduceBatch; ++i) {
+        const int cc = c + i * step;
+        q[i] = cc < numCopies ? src[static_cast<int64_t>(cc) * E] : identity;
+      }
+      if (kind == ACC_SUM_I64_HI) {
+#pragma unroll
+        for (int i = 0; i < kReduceBatch; ++i) {
+          const int cc = c + i * step;
+          ql[i] = cc < numCopies ? src[static_cast<int64_t>(cc) * E - R] : 0;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < kReduceBatch; ++i) {
+        if (kind == ACC_SUM_F64) {
+          if (c + i * step < numCopies) {  // (not "+ 0.0": a sum of nothing but -0.0 keeps its sign)
+            v = static_cast<uint64_t>(__double_as_longlong(__longlong_as_double(static_cast<long long>(v)) +
+                                                           __longlong_as_double(static_cast<long long>(q[i]))));
+          }
+        } else if (kind == ACC_MIN) {
+          v = q[i] < v ? q[i] : v;
+        } else if (kind == ACC_MAX) {
+          v = q[i] > v ? q[i] : v;
+        } else {
+          v += q[i];
+          if (kind == ACC_SUM_I64_HI) {
+            v += carryUnsigned(low, ql[i]);
+            low += ql[i];
+          }
         }
       }
     }
@@ -617,6 +675,7 @@ __global__ __launch_bounds__(1024) void k_lds_reduce(LdsPlan p, int32_t numCopie
   if (m != 0 && l == __ffsll(static_cast<long long>(m)) - 1) {
     atomicAdd(&p.counters->numNewGroups, static_cast<uint32_t>(popc64(m)));
   }
+  publishCountersFromLastBlock(mail, gridDim.x * gridDim.y);  // (wave 0: the only one that got here)
 }
 
 // What the host derives from a launch to pick an instantiation.
@@ -3455,13 +3514,15 @@ __global__ __launch_bounds__(256) void k_sum_stats(AggArgs a) {
 // Both statistics passes of an operator's first batch in ONE launch (two tiny latency-bound kernels
 // in a row cost more in launch gaps than in work): blocks [0, keyBlocks) analyse the keys of the
 // first keyRows rows, the others the DOUBLE sums' inputs of the first a.numRows rows.
-__global__ __launch_bounds__(256) void k_first_stats(AggArgs a, int64_t keyRows, int32_t keyBlocks) {
+__global__ __launch_bounds__(256) void k_first_stats(AggArgs a, int64_t keyRows, int32_t keyBlocks, CounterMail mail) {
   if (static_cast<int32_t>(blockIdx.x) <= keyBlocks) {
     keyStatsBody(a, keyRows, blockIdx.x, keyBlocks);  // block keyBlocks: the distinct probe
   } else {
     sumStatsBody(a, a.numRows, static_cast<int>(blockIdx.x) - keyBlocks - 1,
                  static_cast<int>(gridDim.x) - keyBlocks - 1);
   }
+  blockSync();
+  publishCountersFromLastBlock(mail, gridDim.x);
 }
 
 // ---- table maintenance ---------------------------------------------------------
@@ -3817,6 +3878,10 @@ struct ExtractArgs {
   int32_t global;  // no keys: the single group is row 0
   const uint64_t* nullStore;  // generic hash mode
   uint32_t* overflow;         // set when a sum(BIGINT) total does not fit int64 (Counters::overflow)
+  // the number of groups the small sort found, on its way to the pinned mailbox (checked behind the
+  // page's synchronisation): carried by this launch instead of a copy command of its own
+  const uint32_t* checkSrc;
+  uint32_t* checkDst;
   OutKey keys[kMaxKeys];
   OutAgg aggs[kMaxAccs];
 };
@@ -3858,6 +3923,9 @@ __device__ inline void storeTyped(void* values, int32_t kind, int32_t pos, int64
 // and bit-packed BOOLEAN values are assembled with ballots.
 __global__ __launch_bounds__(256) void k_extract(ExtractArgs a) {
   const int32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos == 0 && a.checkSrc != nullptr) {
+    __hip_atomic_store(a.checkDst, *a.checkSrc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (pos - static_cast<int32_t>(lane()) >= a.count) {
     return;  // whole wave past the end: its bitmap word lies outside ceil(count / 64) words
   }
@@ -4166,6 +4234,8 @@ struct KeyState {
 
 constexpr int64_t kMaxRangeSpan = (1LL << 59) - 1;  // exec/VectorHasher.h:139 kMaxRange
 constexpr size_t kCountersTemplateAt = 512;  // offset of the pristine Counters inside vx355_agg::countersBuf
+constexpr size_t kCountersTicketAt = 1024;   // ... and of the ticket of publishCountersFromLastBlock
+static_assert(sizeof(Counters) <= 512, "live counters, pristine copy and ticket sit 512 bytes apart");
 
 }  // namespace
 }  // namespace vx
@@ -4360,6 +4430,7 @@ struct vx355_agg {
     dropParts(retired);
   }
 
+  bool countersPublished = false;  // the chunk's last launch publishes the counters itself (ldsReduce)
   uint64_t pristineAtLaunch = 0;  // the context's launch count right behind k_init_state (ensureBasics)
   Counters* counters() { return countersBuf.as<Counters>(); }
 };
@@ -4655,10 +4726,14 @@ struct InitStateArgs {
   uint64_t pattern[64];
   int32_t stride;
 };
-__global__ __launch_bounds__(64) void k_init_state(InitStateArgs a, uint64_t* pattern, Counters* pristine, Counters* live) {
+__global__ __launch_bounds__(64) void k_init_state(InitStateArgs a, uint64_t* pattern, Counters* pristine, Counters* live,
+                                                   uint32_t* ticket) {
   const int t = threadIdx.x;
   if (t < a.stride) {
     pattern[t] = a.pattern[t];
+  }
+  if (t == 0) {
+    *ticket = 0;  // publishCountersFromLastBlock
   }
   // sizeof(Counters) is a multiple of 8: every lane writes words of both copies
   constexpr int kWords = static_cast<int>(sizeof(Counters) / 8);
@@ -4694,9 +4769,10 @@ void ensureBasics(vx355_agg& h) {
   h.pattern.ensure(static_cast<size_t>(h.stride) * 8);
   // [0] the live counters, [kCountersTemplateAt] a pristine copy: a reset is one device-to-device
   // copy queued on the stream (a pageable host source made every reset a blocking staged copy)
-  h.countersBuf.ensure(kCountersTemplateAt + sizeof(Counters));
+  h.countersBuf.ensure(kCountersTicketAt + 64);
   VX_LAUNCH("k_init_state", k_init_state, 1, 64, 0, ia, h.pattern.as<uint64_t>(),
-            reinterpret_cast<Counters*>(static_cast<char*>(h.countersBuf.ptr()) + kCountersTemplateAt), h.counters());
+            reinterpret_cast<Counters*>(static_cast<char*>(h.countersBuf.ptr()) + kCountersTemplateAt), h.counters(),
+            reinterpret_cast<uint32_t*>(static_cast<char*>(h.countersBuf.ptr()) + kCountersTicketAt));
   h.pristineAtLaunch = Runtime::get().launchCount;  // (the live copy too: a resetCounters before any other launch has nothing to do)
 }
 
@@ -4714,6 +4790,49 @@ Counters readCounters(vx355_agg& h) {
   auto& rt = Runtime::get();
   static_assert(64 * 8 + sizeof(Counters) <= Mailbox::kWords * 8, "the mailbox holds the counters");
   HIP_OK(hipMemcpyAsync(rt.mail.host + 64, h.counters(), sizeof(Counters), hipMemcpyDeviceToHost, rt.stream));
+  rt.sync();
+  Counters c;
+  std::memcpy(&c, rt.mail.host + 64, sizeof(c));
+  return c;
+}
+
+// The counters into the pinned mailbox AND back to their pristine values, one launch: what
+// readCounters followed by the next launch's resetCounters did with two copy commands.
+__global__ __launch_bounds__(64) void k_read_reset_counters(uint64_t* live, const uint64_t* pristine, uint64_t* mailbox) {
+  constexpr int kWords = static_cast<int>(sizeof(Counters) / 8);
+  static_assert(sizeof(Counters) % 8 == 0, "whole words");
+  for (int i = threadIdx.x; i < kWords; i += 64) {
+    __hip_atomic_store(mailbox + i, live[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    live[i] = pristine[i];
+  }
+}
+
+Counters readAndResetCounters(vx355_agg& h) {
+  auto& rt = Runtime::get();
+  VX_LAUNCH("k_read_reset_counters", k_read_reset_counters, 1, 64, 0, reinterpret_cast<uint64_t*>(h.counters()),
+            reinterpret_cast<const uint64_t*>(static_cast<const char*>(h.countersBuf.ptr()) + kCountersTemplateAt),
+            rt.mail.dev + 64);
+  h.pristineAtLaunch = rt.launchCount;  // resetCounters: nothing to do until the next launch
+  rt.d2hBytes += sizeof(Counters);
+  rt.sync();
+  Counters c;
+  std::memcpy(&c, rt.mail.host + 64, sizeof(c));
+  return c;
+}
+
+// For a launch whose last workgroup publishes the counters itself (publishCountersFromLastBlock).
+CounterMail counterMail(vx355_agg& h) {
+  auto& rt = Runtime::get();
+  char* base = static_cast<char*>(h.countersBuf.ptr());
+  return CounterMail{reinterpret_cast<uint64_t*>(base), reinterpret_cast<const uint64_t*>(base + kCountersTemplateAt),
+                     rt.mail.dev + 64, reinterpret_cast<uint32_t*>(base + kCountersTicketAt)};
+}
+
+// ... and what the host does behind such a launch instead of readAndResetCounters.
+Counters takePublishedCounters(vx355_agg& h) {
+  auto& rt = Runtime::get();
+  h.pristineAtLaunch = rt.launchCount;
+  rt.d2hBytes += sizeof(Counters);
   rt.sync();
   Counters c;
   std::memcpy(&c, rt.mail.host + 64, sizeof(c));
@@ -5430,6 +5549,7 @@ void launchJitFast(hipFunction_t fn, const FastArgs& fa, int grid, size_t ldsByt
   size_t size = sizeof(FastArgs);
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<FastArgs*>(&fa),
                     HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  ++rt.launchCount;  // (as VX_LAUNCH does: resetCounters compares it)
   if (rt.profile) {
     rt.profBegin("k_agg_fast");
   }
@@ -6398,7 +6518,9 @@ void ldsReduce(vx355_agg& h, const LdsPlan& plan, int grid, bool storeAll) {
   // few (word, key) tiles: several block columns share the copies so that the chip is busy
   int columns = storeAll ? 1 : std::max(1, std::min({4, grid / 64, (Runtime::get().numCUs * 2) / std::max(1, tiles)}));
   ++h.scratchFlushes;
-  VX_LAUNCH("k_lds_reduce", k_lds_reduce, dim3(tiles, columns), 1024, 0, plan, grid, storeAll ? 1 : 0);
+  // (the last launch of the chunk: its last workgroup hands the counters to the host)
+  h.countersPublished = true;
+  VX_LAUNCH("k_lds_reduce", k_lds_reduce, dim3(tiles, columns), 1024, 0, plan, grid, storeAll ? 1 : 0, counterMail(h));
   h.tableVirgin = false;
 }
 
@@ -6872,13 +6994,16 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
       // them); large ones by a 256 K-row prefix.
       const int64_t keyRows = n <= (8 << 20) ? n : (1 << 18);
       // (small prefixes only: a whole batch of up to 8 M rows wants the chip)
-      const int keyBlocks = keyRows <= (1 << 18) ? std::min(streamGrid(keyRows, 256), 64)
+      // (128 blocks for a 256 K-row prefix: eight rows per thread, one dependent load after the other -
+      // with 64 the pass took 17 us of BASELINE config 1's 150; every block ends with one pair of
+      // atomics per key on the same two words, which is what keeps the number low)
+      const int keyBlocks = keyRows <= (1 << 18) ? std::min(streamGrid(keyRows, 256), 128)
                                                  : std::min(streamGrid(keyRows, 256), rt.numCUs * 8);
       if (sumStatsPending) {
         AggArgs sa = a;
         sa.numRows = std::min<int64_t>(n, 1 << 16);
         VX_LAUNCH("k_first_stats", k_first_stats, keyBlocks + 1 + std::min(streamGrid(sa.numRows, 256), 64), 256, 0, sa,
-                  keyRows, keyBlocks);
+                  keyRows, keyBlocks, counterMail(h));
       } else {
         StatsArgs sa{};
         sa.numKeys = a.numKeys;
@@ -6889,7 +7014,7 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
         sa.counters = h.counters();
         VX_LAUNCH("k_key_stats", k_key_stats, keyBlocks + 1, 256, 0, sa);  // + the distinct probe's block
       }
-      Counters c = readCounters(h);
+      Counters c = sumStatsPending ? takePublishedCounters(h) : readAndResetCounters(h);
       h.firstRowsDistinct = c.firstRowsDistinct;
       if (sumStatsPending) {
         applySumStats(h, a, c);
@@ -7054,10 +7179,12 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
       }
       h.denseNext = denseChunk && attempt == 0 && !rescan && list == nullptr && h.numGroups == 0;
       h.slotsOnlyLaunch = slotGroups > 0 && attempt == 0;
+      h.countersPublished = false;
       launchChunk(h, c);
       h.denseNext = false;
       h.slotsOnlyLaunch = false;
-      Counters ctr = readCounters(h);
+      Counters ctr = h.countersPublished ? takePublishedCounters(h) : readAndResetCounters(h);
+      h.countersPublished = false;
       // A key no VectorHasher range can hold (string longer than 7 bytes): its
       // rows were deferred; they force the generic mode below.
       bool toGeneric = ctr.unmappable != 0;
@@ -7466,6 +7593,7 @@ __global__ __launch_bounds__(256) void k_string_pass(ColView in, ColView mask, i
 }
 
 constexpr size_t kSmallPageBytes = 1 << 20;
+constexpr size_t kDirectPageBytes = 256 << 10;  // pages k_extract writes into pinned host memory itself
 
 void getOutput(vx355_agg& h, vx355_out_column* cols, int32_t numCols, int32_t maxRows, int32_t* nOut,
                int32_t* finished) {
@@ -7505,7 +7633,23 @@ void getOutput(vx355_agg& h, vx355_out_column* cols, int32_t numCols, int32_t ma
     nullOffsets[c] = total;
     total += (words * 8 + 63) & ~static_cast<size_t>(63);
   }
-  char* scratch = static_cast<char*>(h.scratch.ensure(total + 64));
+  bool anyHost = false;
+  for (int32_t i = 0; i < numCols; ++i) {
+    anyHost = anyHost || cols[i].mem == VX355_MEM_HOST;
+  }
+  // A small page for host columns (BASELINE config 1: 1000 rows of three columns, Q1: four rows of
+  // ten) is written by k_extract straight into the handle's pinned, device-mapped stage: no scratch
+  // block in HBM and no copy command behind the kernel (round 6; one launch less per page).
+  const bool directStage = anyHost && total <= kDirectPageBytes;
+  char* stage = nullptr;
+  char* scratch = nullptr;
+  if (directStage) {
+    h.outStage.clear();
+    stage = h.outStage.extend(total + 64);
+    HIP_OK(hipHostGetDevicePointer(reinterpret_cast<void**>(&scratch), stage, 0));
+  } else {
+    scratch = static_cast<char*>(h.scratch.ensure(total + 64));
+  }
   auto devValues = [&](int32_t c) -> void* {
     return cols[c].mem == VX355_MEM_HOST ? static_cast<void*>(scratch + offsets[c]) : cols[c].values;
   };
@@ -7575,18 +7719,15 @@ void getOutput(vx355_agg& h, vx355_out_column* cols, int32_t numCols, int32_t ma
   if (checksTotals) {
     resetCounters(h);
   }
-  VX_LAUNCH("k_extract", k_extract, static_cast<int>(ceilDiv(n, 256)), 256, 0, ea);
-  if (checksTotals) {
-    checkCounters(readCounters(h));  // "integer overflow": a sum(BIGINT) total left int64
-  }
-  bool anyHost = false;
-  for (int32_t i = 0; i < numCols; ++i) {
-    anyHost = anyHost || cols[i].mem == VX355_MEM_HOST;
-  }
   const int64_t expectFound = h.collectCheck;
   if (expectFound >= 0) {
     h.collectCheck = -1;
-    HIP_OK(hipMemcpyAsync(rt.mail.host + 63, h.order + expectFound, 4, hipMemcpyDeviceToHost, rt.stream));
+    ea.checkSrc = h.order + expectFound;
+    ea.checkDst = reinterpret_cast<uint32_t*>(rt.mail.dev + 63);
+  }
+  VX_LAUNCH("k_extract", k_extract, static_cast<int>(ceilDiv(n, 256)), 256, 0, ea);
+  if (checksTotals) {
+    checkCounters(readCounters(h));  // "integer overflow": a sum(BIGINT) total left int64
   }
   struct FoundCheck {
     vx::Runtime& rt;
@@ -7599,12 +7740,16 @@ void getOutput(vx355_agg& h, vx355_out_column* cols, int32_t numCols, int32_t ma
     }
   } foundCheck{rt, expectFound};
   if (anyHost && total <= kSmallPageBytes) {
-    // A small page (Q1: four rows of ten columns): one copy of the whole scratch block into pinned
-    // memory instead of twenty copies into the caller's pageable buffers (each of those is a
-    // separate synchronous transfer: 0.4 ms for Q1's page, 0.06 ms this way).
-    h.outStage.clear();
-    char* stage = h.outStage.extend(total);
-    copyOutAsync(stage, VX355_MEM_HOST, scratch, total);
+    // A small page: one copy of the whole scratch block into pinned memory instead of twenty copies
+    // into the caller's pageable buffers (each of those is a separate synchronous transfer: 0.4 ms
+    // for Q1's page, 0.06 ms this way) - or no copy at all (directStage).
+    if (!directStage) {
+      h.outStage.clear();
+      stage = h.outStage.extend(total);
+      copyOutAsync(stage, VX355_MEM_HOST, scratch, total);
+    } else {
+      rt.d2hBytes += total;  // (the kernel's own stores crossed the link: the same bytes a copy would have moved)
+    }
     rt.sync();
     foundCheck();
     for (int32_t i = 0; i < numCols; ++i) {
@@ -7712,7 +7857,23 @@ void toIntermediate(vx355_agg& h, const vx355_batch* batch, vx355_out_column* co
     nullOffsets[c] = total;
     total += (words * 8 + 63) & ~static_cast<size_t>(63);
   }
-  char* scratch = static_cast<char*>(h.scratch.ensure(total + 64));
+  bool anyHost = false;
+  for (int32_t i = 0; i < numCols; ++i) {
+    anyHost = anyHost || cols[i].mem == VX355_MEM_HOST;
+  }
+  // A small page for host columns (BASELINE config 1: 1000 rows of three columns, Q1: four rows of
+  // ten) is written by k_extract straight into the handle's pinned, device-mapped stage: no scratch
+  // block in HBM and no copy command behind the kernel (round 6; one launch less per page).
+  const bool directStage = anyHost && total <= kDirectPageBytes;
+  char* stage = nullptr;
+  char* scratch = nullptr;
+  if (directStage) {
+    h.outStage.clear();
+    stage = h.outStage.extend(total + 64);
+    HIP_OK(hipHostGetDevicePointer(reinterpret_cast<void**>(&scratch), stage, 0));
+  } else {
+    scratch = static_cast<char*>(h.scratch.ensure(total + 64));
+  }
   auto devValues = [&](int32_t c) -> void* {
     return cols[c].mem == VX355_MEM_HOST ? static_cast<void*>(scratch + offsets[c]) : cols[c].values;
   };
