@@ -4821,6 +4821,7 @@ Counters readAndResetCounters(vx355_agg& h) {
 }
 
 // For a launch whose last workgroup publishes the counters itself (publishCountersFromLastBlock).
+constexpr int kMaxPublishingBlocks = 256;  // one ticket word: beyond a few hundred workgroups the tickets cost more than a launch
 CounterMail counterMail(vx355_agg& h) {
   auto& rt = Runtime::get();
   char* base = static_cast<char*>(h.countersBuf.ptr());
@@ -6519,8 +6520,9 @@ void ldsReduce(vx355_agg& h, const LdsPlan& plan, int grid, bool storeAll) {
   int columns = storeAll ? 1 : std::max(1, std::min({4, grid / 64, (Runtime::get().numCUs * 2) / std::max(1, tiles)}));
   ++h.scratchFlushes;
   // (the last launch of the chunk: its last workgroup hands the counters to the host)
-  h.countersPublished = true;
-  VX_LAUNCH("k_lds_reduce", k_lds_reduce, dim3(tiles, columns), 1024, 0, plan, grid, storeAll ? 1 : 0, counterMail(h));
+  h.countersPublished = tiles * columns <= kMaxPublishingBlocks;
+  VX_LAUNCH("k_lds_reduce", k_lds_reduce, dim3(tiles, columns), 1024, 0, plan, grid, storeAll ? 1 : 0,
+            h.countersPublished ? counterMail(h) : CounterMail{});
   h.tableVirgin = false;
 }
 
@@ -6989,6 +6991,7 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
     // fall outside are handled by the deferred-row path.
     resetCounters(h);
     bool needGeneric = false;
+    bool statsPublished = false;
     if (a.numKeys > 0) {
       // Small first batches are analysed completely (no range widening later for
       // them); large ones by a 256 K-row prefix.
@@ -7002,8 +7005,12 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
       if (sumStatsPending) {
         AggArgs sa = a;
         sa.numRows = std::min<int64_t>(n, 1 << 16);
-        VX_LAUNCH("k_first_stats", k_first_stats, keyBlocks + 1 + std::min(streamGrid(sa.numRows, 256), 64), 256, 0, sa,
-                  keyRows, keyBlocks, counterMail(h));
+        // (every workgroup draws a ticket from ONE word: worth it for the small launches of a small
+        // first batch only - with 2 K workgroups the tickets alone took longer than the read-back launch)
+        const int statBlocks = keyBlocks + 1 + std::min(streamGrid(sa.numRows, 256), 64);
+        statsPublished = statBlocks <= kMaxPublishingBlocks;
+        VX_LAUNCH("k_first_stats", k_first_stats, statBlocks, 256, 0, sa, keyRows, keyBlocks,
+                  statsPublished ? counterMail(h) : CounterMail{});
       } else {
         StatsArgs sa{};
         sa.numKeys = a.numKeys;
@@ -7014,7 +7021,7 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
         sa.counters = h.counters();
         VX_LAUNCH("k_key_stats", k_key_stats, keyBlocks + 1, 256, 0, sa);  // + the distinct probe's block
       }
-      Counters c = sumStatsPending ? takePublishedCounters(h) : readAndResetCounters(h);
+      Counters c = statsPublished ? takePublishedCounters(h) : readAndResetCounters(h);
       h.firstRowsDistinct = c.firstRowsDistinct;
       if (sumStatsPending) {
         applySumStats(h, a, c);

@@ -286,6 +286,157 @@ __global__ __launch_bounds__(256) void k_build_append(AppendArgs a) {
   }
 }
 
+// The common build side - INTEGER / BIGINT keys and 4- or 8-byte dependents, flat or dictionary-wrapped,
+// none with a null bitmap, every row selected - without k_build_append's per-row interpretation: FOUR rows per
+// lane, every load of an iteration issued before the first store. The interpreting kernel keeps one
+// or two loads per lane in flight (a row after the other, each behind its kind switches) and moved
+// TPC-H Q3's 14.6 M-row build side at 0.9 TB/s: 0.26 of that join's 1.67 ms (round 6).
+constexpr int kAppendRows = 4;
+template <int NK, int ND>
+__global__ __launch_bounds__(256) void k_build_append_flat(AppendArgs a, uint32_t key32, uint32_t dep32, uint32_t keyDict,
+                                                          uint32_t depDict) {
+  const int64_t tile = 256LL * kAppendRows;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * tile;
+  int64_t mn[NK], mx[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    mn[k] = INT64_MAX;
+    mx[k] = INT64_MIN;
+  }
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * tile + threadIdx.x; base < a.count; base += stride) {
+    int64_t kv[kAppendRows][NK];
+    uint64_t dv[kAppendRows][ND > 0 ? ND : 1];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+#pragma unroll
+      for (int u = 0; u < kAppendRows; ++u) {
+        const int64_t row = base + u * 256LL;
+        int64_t at = row < a.count ? row : a.count - 1;  // clamped: no load under a lane predicate
+        if ((keyDict >> k) & 1) {
+          at = a.keys[k].indices[at];  // dictionary-wrapped (what a FilterProject or a probe hands on)
+        }
+        kv[u][k] = ((key32 >> k) & 1) ? static_cast<int64_t>(static_cast<const int32_t*>(a.keys[k].values)[at])
+                                      : static_cast<const int64_t*>(a.keys[k].values)[at];
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+#pragma unroll
+      for (int u = 0; u < kAppendRows; ++u) {
+        const int64_t row = base + u * 256LL;
+        int64_t at = row < a.count ? row : a.count - 1;
+        if ((depDict >> d) & 1) {
+          at = a.deps[d].indices[at];
+        }
+        dv[u][d] = ((dep32 >> d) & 1) ? static_cast<uint64_t>(static_cast<const uint32_t*>(a.deps[d].values)[at])
+                                      : static_cast<const uint64_t*>(a.deps[d].values)[at];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kAppendRows; ++u) {
+      const int64_t row = base + u * 256LL;
+      if (row >= a.count) {
+        continue;
+      }
+      const int64_t out = a.base + row;
+      if (a.keyNullOut) {
+        a.keyNullOut[out] = 0;
+      }
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        a.keyOut[k][out] = static_cast<uint64_t>(kv[u][k]);
+        mn[k] = kv[u][k] < mn[k] ? kv[u][k] : mn[k];
+        mx[k] = kv[u][k] > mx[k] ? kv[u][k] : mx[k];
+      }
+#pragma unroll
+      for (int d = 0; d < ND; ++d) {
+        a.depValid[d][out] = 1;
+        if ((dep32 >> d) & 1) {
+          reinterpret_cast<uint32_t*>(a.depOut[d])[out] = static_cast<uint32_t>(dv[u][d]);
+        } else {
+          reinterpret_cast<uint64_t*>(a.depOut[d])[out] = dv[u][d];
+        }
+      }
+    }
+  }
+  // one pair of atomics per key and WORKGROUP
+  __shared__ int64_t waveLo[4][NK];
+  __shared__ int64_t waveHi[4][NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    int64_t lo = mn[k], hi = mx[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const int64_t olo = static_cast<int64_t>(shfl64(static_cast<uint64_t>(lo), lane() ^ off));
+      const int64_t ohi = static_cast<int64_t>(shfl64(static_cast<uint64_t>(hi), lane() ^ off));
+      lo = olo < lo ? olo : lo;
+      hi = ohi > hi ? ohi : hi;
+    }
+    if (lane() == 0) {
+      waveLo[threadIdx.x >> 6][k] = lo;
+      waveHi[threadIdx.x >> 6][k] = hi;
+    }
+  }
+  blockSync();
+  if (threadIdx.x < NK) {
+    const int k = threadIdx.x;
+    int64_t lo = waveLo[0][k], hi = waveHi[0][k];
+    for (int w = 1; w < 4; ++w) {
+      lo = waveLo[w][k] < lo ? waveLo[w][k] : lo;
+      hi = waveHi[w][k] > hi ? waveHi[w][k] : hi;
+    }
+    if (lo <= hi) {
+      atomicMin(reinterpret_cast<long long*>(&a.counters->keyMin[k]), static_cast<long long>(lo));
+      atomicMax(reinterpret_cast<long long*>(&a.counters->keyMax[k]), static_cast<long long>(hi));
+    }
+  }
+}
+
+using AppendFlatLauncher = void (*)(const AppendArgs&, uint32_t, uint32_t, uint32_t, uint32_t, int);
+template <int NK, int ND>
+void launchAppendFlat(const AppendArgs& a, uint32_t key32, uint32_t dep32, uint32_t keyDict, uint32_t depDict, int grid) {
+  VX_LAUNCH("k_build_append", (k_build_append_flat<NK, ND>), grid, 256, 0, a, key32, dep32, keyDict, depDict);
+}
+constexpr int kAppendFlatKeys = 2;
+constexpr int kAppendFlatDeps = 4;
+const AppendFlatLauncher kAppendFlat[kAppendFlatKeys][kAppendFlatDeps + 1] = {
+    {&launchAppendFlat<1, 0>, &launchAppendFlat<1, 1>, &launchAppendFlat<1, 2>, &launchAppendFlat<1, 3>,
+     &launchAppendFlat<1, 4>},
+    {&launchAppendFlat<2, 0>, &launchAppendFlat<2, 1>, &launchAppendFlat<2, 2>, &launchAppendFlat<2, 3>,
+     &launchAppendFlat<2, 4>},
+};
+
+// true: the batch went through k_build_append_flat.
+bool appendFlat(const AppendArgs& a) {
+  if (a.rows != nullptr || a.keyValidWords != nullptr || a.nullAsValue || a.numKeys < 1 ||
+      a.numKeys > kAppendFlatKeys || a.numDeps > kAppendFlatDeps) {
+    return false;
+  }
+  uint32_t key32 = 0, dep32 = 0, keyDict = 0, depDict = 0;
+  for (int k = 0; k < a.numKeys; ++k) {
+    const ColView& c = a.keys[k];
+    if ((c.enc != VX355_FLAT && c.enc != VX355_DICTIONARY) || c.nulls != nullptr || a.keyWords[k] != 1 ||
+        (c.kind != VX355_INTEGER && c.kind != VX355_BIGINT)) {
+      return false;
+    }
+    key32 |= c.kind == VX355_INTEGER ? 1u << k : 0u;
+    keyDict |= c.enc == VX355_DICTIONARY ? 1u << k : 0u;
+  }
+  for (int d = 0; d < a.numDeps; ++d) {
+    const ColView& c = a.deps[d];
+    if ((c.enc != VX355_FLAT && c.enc != VX355_DICTIONARY) || c.nulls != nullptr ||
+        (a.depWidth[d] != 4 && a.depWidth[d] != 8)) {
+      return false;
+    }
+    dep32 |= a.depWidth[d] == 4 ? 1u << d : 0u;
+    depDict |= c.enc == VX355_DICTIONARY ? 1u << d : 0u;
+  }
+  const int grid = static_cast<int>(std::max<int64_t>(
+      1, std::min<int64_t>(ceilDiv(a.count, 256LL * kAppendRows), static_cast<int64_t>(Runtime::get().numCUs) * 8)));
+  kAppendFlat[a.numKeys - 1][a.numDeps](a, key32, dep32, keyDict, depDict, grid);
+  return true;
+}
+
 // ---- build: table -------------------------------------------------------------------
 struct Slot {
   uint64_t key;
@@ -3467,7 +3618,9 @@ void buildAddInput(vx355_join_build& h, const vx355_batch* batch) {
       aa.keyNullOut = h.keyNull.as<uint8_t>();
     }
     aa.nullAsValue = h.nullAsValue ? 1 : 0;
-    VX_LAUNCH("k_build_append", k_build_append, streamGrid(selected, 256), 256, 0, aa);
+    if (!appendFlat(aa)) {
+      VX_LAUNCH("k_build_append", k_build_append, streamGrid(selected, 256), 256, 0, aa);
+    }
   }
   BuildCounters c = readBuildCounters(h.countersBuf);
   if (c.unmappable) {
