@@ -7101,7 +7101,9 @@ void addInput(vx355_agg& h, const vx355_batch* batch) {
       }
     }
     if (slotGroups > 0) {
-      rows = std::min<int64_t>(rows, 1 << 28);  // (the deferred list holds every row of the chunk: 1 GB)
+      // (the deferred list holds every row of the chunk: 4 GB at most - 1 GB until round 6, which cut
+      // TPC-H Q1 SF100 with four keys into four launches instead of two)
+      rows = std::min<int64_t>(rows, 1LL << 30);
       if (h.tableDense || static_cast<uint64_t>(h.numGroups) + slotGroups > h.capacity * 7 / 10) {
         rebuildTable(h, slotGroups);
       }
