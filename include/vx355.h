@@ -720,7 +720,8 @@ int vx355_agg_get_stats(const vx355_agg* h, vx355_agg_stats* out);
  *                drained (every entry point returns with its work complete): the kernels, copies and
  *                host-side launch work of the operator                        -> gpu.kernelNanos
  *   h2d_bytes    bytes copied host -> HBM (staging of host vectors)           -> gpu.h2dBytes
- *   d2h_bytes    bytes copied HBM -> host (output pages, small read-backs)    -> gpu.d2hBytes
+ *   d2h_bytes    bytes moved HBM -> host (output pages, small read-backs; copies and the
+ *                stores of kernels that write a pinned page or the mailbox themselves) -> gpu.d2hBytes
  *   input_bytes  bytes of the input columns handed to kernels (values, null bitmaps, indices): what one
  *                pass over the input reads from HBM                           -> gpu.hbmBytesRead
  *   launches     kernels launched                                             -> gpu.kernelLaunches

@@ -1351,3 +1351,60 @@ def test_probe_input_is_not_regrouped_when_the_table_does_not_qualify(oracle, vx
         b.add_input(batch)
         assert _drain(a, 50_000) == _drain(b, 50_000)
         assert (out.to_host(npr) == -1).all()
+
+
+@pytest.mark.parametrize("wrapped", [False, True])
+@pytest.mark.parametrize("shape", ["bigint_4_8", "two_keys_four_deps", "no_deps", "nullable_dep_falls_back",
+                                   "five_deps_fall_back"])
+def test_build_append_of_flat_and_dictionary_wrapped_integer_batches(oracle, vx, wrapped, shape):
+    """HashBuild's append for the common build side (INTEGER / BIGINT keys, 4- or 8-byte dependents, FLAT or
+    DICTIONARY, no nulls: k_build_append_flat, four rows per lane) against the oracle - batches whose row counts
+    are not multiples of the kernel's 1024-row tile, several batches per build, both widths of keys and
+    dependents, and shapes that must keep the interpreting kernel (a nullable dependent, more dependents than
+    the specialised kernel takes). Semantics: HashBuild::addInput (exec/HashBuild.cpp:430-520)."""
+    rng = np.random.default_rng(sum(shape.encode()) * 2 + int(wrapped))
+    sizes = [1, 1023, 4097, 30000]
+    two_keys = shape == "two_keys_four_deps"
+    num_deps = {"bigint_4_8": 2, "two_keys_four_deps": 4, "no_deps": 0, "nullable_dep_falls_back": 2,
+                "five_deps_fall_back": 5}[shape]
+    dep_types = [abi.INTEGER if d % 2 == 0 else (abi.DOUBLE if d == 3 else abi.BIGINT) for d in range(num_deps)]
+    key_types = [abi.BIGINT, abi.INTEGER] if two_keys else [abi.BIGINT]
+
+    def column(kind, n, base_rows):
+        if kind == abi.INTEGER:
+            base = rng.integers(-50, 50, base_rows).astype(np.int32)
+        elif kind == abi.DOUBLE:
+            base = rng.random(base_rows)
+        else:
+            base = rng.integers(0, 5000, base_rows).astype(np.int64)
+        return base
+
+    batches = []
+    for n in sizes:
+        base_rows = 2 * n + 3 if wrapped else n
+        idx = rng.integers(0, base_rows, n).astype(np.int32)
+        cols = []
+        for c, kind in enumerate(key_types + dep_types):
+            base = column(kind, n, base_rows)
+            valid = None
+            if shape == "nullable_dep_falls_back" and c == len(key_types):
+                valid = rng.random(n) > 0.2
+            if wrapped:
+                cols.append(abi.HostColumn(kind, base, valid, abi.DICTIONARY, idx))
+            else:
+                cols.append(abi.HostColumn(kind, base, valid))
+        batches.append(abi.HostBatch(cols))
+    nk = len(key_types)
+    pk = [rng.integers(-100, 5100, 20000).astype(np.int64)]
+    if two_keys:
+        pk.append(rng.integers(-60, 60, 20000).astype(np.int32))
+    res = {}
+    for impl in (oracle, vx):
+        table, _b = _build(impl, [batches], list(range(nk)), key_types, list(range(nk, nk + num_deps)), dep_types,
+                           abi.JOIN_INNER)
+        probe = impl.JoinProbe(table, list(range(nk)), abi.JOIN_INNER)
+        probe.add_input(batch_of(pk))
+        pairs, payload = _drain(probe, 4096)
+        res[impl.__name__] = (_canon(pairs, payload), table.stats().num_distinct, table.stats().has_duplicates)
+    assert res[oracle.__name__] == res[vx.__name__]
+    assert len(res[vx.__name__][0]) > 0
