@@ -1816,6 +1816,15 @@ __global__ __launch_bounds__(1024) void k_pp_scatter_fast(PartFastArgs a) {
   }
   blockSync();
   const int64_t numSub = (a.numRows + kPartFastSub - 1) / kPartFastSub;
+  // The keys of a sub-tile are loaded one sub-tile ahead: behind the placement into LDS and in front
+  // of the write-out, so that their HBM latency overlaps the stores of the previous sub-tile (one
+  // workgroup per CU: nothing else would). Rows past the end are clamped, then ignored.
+  int64_t vnext[R];
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * kPartFastSub + u * 1024 + tid;
+    vnext[u] = a.keys[r < a.numRows ? r : a.numRows - 1];
+  }
   for (int64_t sub = blockIdx.x; sub < numSub; sub += gridDim.x) {
     const int64_t base = sub * kPartFastSub;
     uint64_t rec[R];
@@ -1823,7 +1832,7 @@ __global__ __launch_bounds__(1024) void k_pp_scatter_fast(PartFastArgs a) {
 #pragma unroll
     for (int u = 0; u < R; ++u) {
       const int64_t r = base + u * 1024 + tid;
-      const int64_t v = r < a.numRows ? a.keys[r] : INT64_MIN;
+      const int64_t v = r < a.numRows ? vnext[u] : INT64_MIN;
       bin[u] = 0xffffffffu;
       if (r < a.numRows && v >= a.keyMin && v <= a.keyMax && ppRowPasses(a.rf, r)) {
         const uint64_t key = static_cast<uint64_t>(v) - static_cast<uint64_t>(a.keyMin) + 1;
@@ -1871,6 +1880,14 @@ __global__ __launch_bounds__(1024) void k_pp_scatter_fast(PartFastArgs a) {
       }
     }
     blockSync();
+    if (sub + gridDim.x < numSub) {
+      const int64_t nextBase = (sub + gridDim.x) * kPartFastSub;
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const int64_t r = nextBase + u * 1024 + tid;
+        vnext[u] = a.keys[r < a.numRows ? r : a.numRows - 1];
+      }
+    }
     uint32_t total = 0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) {
