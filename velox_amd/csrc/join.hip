@@ -1958,15 +1958,31 @@ __global__ __launch_bounds__(1024) void k_pp_probe(PartProbeArgs a) {
       slice[i] = wordBase + i < a.presentWords ? a.present[wordBase + i] : 0;
     }
     blockSync();
-    for (uint64_t at = begin; at < end; at += 4 * 1024) {
-      uint64_t rec[4];
+    // kPer records per lane and round, the next round's loaded before this round's are tested: one
+    // workgroup per CU (the slice takes 128 KB of LDS), so the records in flight are all that hides
+    // the HBM latency - four per lane without the look-ahead kept 32 KB per CU in flight (2.5 TB/s)
+    constexpr int kPer = 8;
+    uint64_t recNext[kPer];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint64_t i = at + u * 1024 + threadIdx.x;
-        rec[u] = i < end ? a.recs[i] : 0;
+    for (int u = 0; u < kPer; ++u) {
+      const uint64_t i = begin + u * 1024 + threadIdx.x;
+      recNext[u] = a.recs[i < end ? i : end - 1];
+    }
+    for (uint64_t at = begin; at < end; at += kPer * 1024) {
+      uint64_t rec[kPer];
+#pragma unroll
+      for (int u = 0; u < kPer; ++u) {
+        rec[u] = recNext[u];
+      }
+      if (at + kPer * 1024 < end) {
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+          const uint64_t i = at + kPer * 1024 + u * 1024 + threadIdx.x;
+          recNext[u] = a.recs[i < end ? i : end - 1];
+        }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < kPer; ++u) {
         const uint64_t i = at + u * 1024 + threadIdx.x;
         const uint32_t off = static_cast<uint32_t>(rec[u] >> 32) & ((1u << kPartShift) - 1);  // bits 52.. may carry the bin
         const bool hit = i < end && ((slice[off >> 5] >> (off & 31)) & 1);
