@@ -1825,15 +1825,38 @@ __device__ inline void rpFoldRecord(const RpFold& f, const RadixAggArgs& r, cons
 // Folds records [begin, end) of one partition into the LDS accumulators.
 template <int W, bool CR = false>
 __device__ inline void rpFoldRecords(const RpFold& f, const RadixAggArgs& r, uint64_t begin, uint64_t end) {
-  for (uint64_t at = begin; at < end; at += kRadixUnroll * 512) {
-    uint64_t w[kRadixUnroll][W];
+  // kRadixUnroll / 2 records per lane and round, the next round's loaded before this round's go through the
+  // LDS atomics: the same records in flight as eight per round, but at every moment (round 6: the dense fold
+  // of config 4 4.3 - 4.4 -> 4.0 ms, tools/r06_fold.sh)
+  constexpr int kHalf = kRadixUnroll / 2;
+  if (begin >= end) {  // (uniform; the clamped loads below need one record)
+    blockSync();
+    return;
+  }
+  uint64_t nxt[kHalf][W];
 #pragma unroll
-    for (int u = 0; u < kRadixUnroll; ++u) {
-      const uint64_t i = at + u * 512 + threadIdx.x;
-      recLoad<W, CR>(r.recs, r.crCap, i < end ? i : end - 1, w[u]);  // clamped, unconditional: see k_rp_scatter2
+  for (int u = 0; u < kHalf; ++u) {
+    const uint64_t i = begin + u * 512 + threadIdx.x;
+    recLoad<W, CR>(r.recs, r.crCap, i < end ? i : end - 1, nxt[u]);
+  }
+  for (uint64_t at = begin; at < end; at += kHalf * 512) {
+    uint64_t w[kHalf][W];
+#pragma unroll
+    for (int u = 0; u < kHalf; ++u) {
+#pragma unroll
+      for (int q = 0; q < W; ++q) {
+        w[u][q] = nxt[u][q];
+      }
+    }
+    if (at + kHalf * 512 < end) {
+#pragma unroll
+      for (int u = 0; u < kHalf; ++u) {
+        const uint64_t i = at + kHalf * 512 + u * 512 + threadIdx.x;
+        recLoad<W, CR>(r.recs, r.crCap, i < end ? i : end - 1, nxt[u]);
+      }
     }
 #pragma unroll
-    for (int u = 0; u < kRadixUnroll; ++u) {
+    for (int u = 0; u < kHalf; ++u) {
       const uint64_t i = at + u * 512 + threadIdx.x;
       if (i < end) {
         rpFoldRecord<W>(f, r, w[u]);
