@@ -1,12 +1,12 @@
 #!/bin/bash
-# k_join_insert (array mode): a wave's claims of a round on consecutive rows, against the previous library.
+# A/B of the join workloads: product library against velox_amd/variants/libvx355_old.so (k_join_insert claims; later: the probe's cross-tile key prefetch).
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r06ins; mkdir -p $O
 for rep in 1 2; do
   for v in old new; do
     L=$GRAFT_REPO_ROOT/velox_amd/libvx355.so
     [ $v = old ] && L=$GRAFT_REPO_ROOT/velox_amd/variants/libvx355_old.so
-    for wl in "q3" "q3 --q3-random-probe" "q3full"; do
+    for wl in "q3" "q3full"; do
       VX355_LIB_PATH=$L python bench.py --workload $wl --steps 10 --warmup 3 --no-traffic --no-cpu-baseline --detail $O/x.json > /dev/null 2>$O/err.txt || tail -3 $O/err.txt
       python - $O/x.json "$v $wl" <<'PY'
 import json, sys
