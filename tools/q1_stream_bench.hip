@@ -13,6 +13,39 @@ struct Cols {
   const uint64_t* k0; const uint64_t* k1; const uint32_t* d; const uint64_t* x[4];
 };
 
+// The same loads with every workgroup walking ONE contiguous range of rows (rows / grid each) instead of
+// tiles a whole grid apart.
+template <int UNROLL>
+__global__ __launch_bounds__(512, 4) void k_streams_chunked(Cols c, int64_t n, uint64_t* out) {
+  const int64_t tile = 512LL * UNROLL;
+  const int64_t tiles = (n + tile - 1) / tile;
+  const int64_t per = (tiles + gridDim.x - 1) / gridDim.x;
+  const int64_t first = blockIdx.x * per;
+  const int64_t last = first + per < tiles ? first + per : tiles;
+  uint64_t acc = 0;
+  for (int64_t t = first; t < last; ++t) {
+    const int64_t base = t * tile + threadIdx.x;
+    int64_t row[UNROLL];
+    uint64_t a[UNROLL], b[UNROLL], x[UNROLL][4];
+    uint32_t d[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) { int64_t r = base + u * 512LL; row[u] = r < n ? r : n - 1; }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) a[u] = __builtin_nontemporal_load(c.k0 + row[u] * 2);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) b[u] = __builtin_nontemporal_load(c.k1 + row[u] * 2);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) d[u] = __builtin_nontemporal_load(c.d + row[u]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) x[u][j] = __builtin_nontemporal_load(c.x[j] + row[u]);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) acc ^= a[u] ^ b[u] ^ d[u] ^ x[u][0] ^ x[u][1] ^ x[u][2] ^ x[u][3];
+  }
+  if (acc == 0x1234567887654321ULL) out[0] = acc;
+}
+
 template <int UNROLL, bool PIPE>
 __global__ __launch_bounds__(512, 4) void k_streams(Cols c, int64_t n, uint64_t* out) {
   const int64_t tile = 512LL * UNROLL;
@@ -109,12 +142,13 @@ int main(int argc, char** argv) {
     float ms; OK(hipEventElapsedTime(&ms, e0, e1));
     printf("%-28s grid %5d  %.3f ms  %.0f GB/s\n", name, grid, ms / reps, bytes / (ms / reps) / 1e6);
   };
-  for (int grid : {256, 512, 768, 1024}) {
+  for (int grid : {256, 384, 512, 640, 768, 1024, 1536}) {
     run("unroll 4", k_streams<4, false>, grid);
     run("unroll 2", k_streams<2, false>, grid);
     run("unroll 2 pipelined", k_streams<2, true>, grid);
     run("unroll 4 pipelined", k_streams<4, true>, grid);
     run("4 adjacent rows, 16-B loads", k_streams_wide<true>, grid);
+    run("unroll 4, contiguous range", k_streams_chunked<4>, grid);
   }
   return 0;
 }

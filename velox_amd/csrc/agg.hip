@@ -4453,6 +4453,7 @@ struct vx355_agg {
     dropParts(retired);
   }
 
+  int ldsBlocksPerCuCap = 0;       // VX355_AGG_LDS_BLOCKS_PER_CU (0: what LDS allows, at most the caller's bound)
   bool countersPublished = false;  // the chunk's last launch publishes the counters itself (ldsReduce)
   uint64_t pristineAtLaunch = 0;  // the context's launch count right behind k_init_state (ensureBasics)
   Counters* counters() { return countersBuf.as<Counters>(); }
@@ -6499,7 +6500,10 @@ void launchRadix(vx355_agg& h, AggArgs& a) {
 // the chip, every one stores capacity x (words + 1) values, k_lds_reduce folds them.
 int ldsGrid(vx355_agg& h, LdsPlan& plan, size_t ldsBytes, int64_t rows, int threads, int unroll, int maxBlocksPerCu) {
   auto& rt = Runtime::get();
-  const int blocksPerCu = std::max<int>(1, std::min<int>(maxBlocksPerCu, static_cast<int>((150 * 1024) / ldsBytes)));
+  int blocksPerCu = std::max<int>(1, std::min<int>(maxBlocksPerCu, static_cast<int>((150 * 1024) / ldsBytes)));
+  if (h.ldsBlocksPerCuCap > 0) {
+    blocksPerCu = std::min(blocksPerCu, h.ldsBlocksPerCuCap);
+  }
   const int64_t full = static_cast<int64_t>(rt.numCUs) * blocksPerCu;
   const int64_t fullScratch = static_cast<int64_t>(rt.numCUs) * std::min(blocksPerCu, h.scratchBlocksPerCu);
   const int64_t tile = static_cast<int64_t>(threads) * unroll;
@@ -7973,6 +7977,9 @@ void configureFromEnv(vx355_agg& h) {
   }
   if (const char* e = std::getenv("VX355_AGG_DEFER_CAP")) {
     h.deferCap = std::max<int64_t>(1, std::strtoll(e, nullptr, 10));
+  }
+  if (const char* e = std::getenv("VX355_AGG_LDS_BLOCKS_PER_CU")) {
+    h.ldsBlocksPerCuCap = std::atoi(e);
   }
   if (const char* e = std::getenv("VX355_AGG_FAST_UNROLL")) {
     h.fastUnroll = std::atoi(e) == 2 ? 2 : 4;
