@@ -4955,6 +4955,14 @@ bool chooseLds(const vx355_agg& h, int numAccs, LdsPlan* plan, size_t* ldsBytes)
   // (two workgroups of up to 72 KB share a CU's 160 KB; BASELINE config 1's direct layout - 2003
   // possible keys x 3 words + the first-row words - takes 64 KB)
   const size_t budget = 72 * 1024;
+  // ... unless twice that buys a replica PER LANE (REP 64): with 32 replicas lanes l and l + 32 of a wave
+  // hit the same LDS word and every atomic of a row takes two passes. One workgroup per CU streams as
+  // fast as three (profiles/r06_q1_stream_ceiling.md #6), so a plan with many accumulator words is better
+  // off with 64 replicas in up to 128 KB: TPC-H Q1 (16 slots x 11 words: 90 KB) 6.91 - 6.96 -> 6.55 - 6.66 ms
+  // per query on the same box (round 6). VX355_AGG_LDS_FULL_REPLICAS=0 keeps the smaller layouts.
+  static const bool fullReplicas =
+      !(std::getenv("VX355_AGG_LDS_FULL_REPLICAS") && std::atoi(std::getenv("VX355_AGG_LDS_FULL_REPLICAS")) == 0);
+  const size_t bigBudget = fullReplicas ? std::min<size_t>(128 * 1024, Runtime::get().ldsPerBlock) : 0;
   const size_t accBytes = static_cast<size_t>(numAccs) * 8;
   if (h.mode == MODE_NORMALIZED || h.capacity > 8192) {
     // Too many possible keys for a map entry each (or an open-addressing table). Few of them
@@ -4984,6 +4992,9 @@ bool chooseLds(const vx355_agg& h, int numAccs, LdsPlan* plan, size_t* ldsBytes)
     if (rep == 0) {
       return false;
     }
+    if (rep < 64 && bytes(64) <= bigBudget) {
+      rep = 64;  // (a replica per lane, see above)
+    }
     plan->direct = 2;
     plan->mapWords = static_cast<int32_t>(M);
     plan->S = static_cast<int32_t>(S);
@@ -5006,6 +5017,9 @@ bool chooseLds(const vx355_agg& h, int numAccs, LdsPlan* plan, size_t* ldsBytes)
       break;
     }
   }
+  if (repDirect < 64 && repDirect > 0 && bytesFor(R, 64, true) <= bigBudget) {
+    repDirect = 64;
+  }
   // Compact layout: slots only for keys that occur, sized from what has been seen.
   uint64_t S = nextPow2(std::max<uint64_t>(16, 2 * static_cast<uint64_t>(h.numGroups)));
   S = std::min<uint64_t>(S, nextPow2(R));
@@ -5016,6 +5030,9 @@ bool chooseLds(const vx355_agg& h, int numAccs, LdsPlan* plan, size_t* ldsBytes)
         repCompact = rep;
         break;
       }
+    }
+    if (repCompact < 64 && repCompact > 0 && bytesFor(S, 64, false) <= bigBudget) {
+      repCompact = 64;
     }
   }
   if (repDirect == 0 && repCompact == 0) {
