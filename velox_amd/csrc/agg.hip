@@ -4992,9 +4992,8 @@ bool chooseLds(const vx355_agg& h, int numAccs, LdsPlan* plan, size_t* ldsBytes)
     if (rep == 0) {
       return false;
     }
-    if (rep < 64 && bytes(64) <= bigBudget) {
-      rep = 64;  // (a replica per lane, see above)
-    }
+    // (not the replica-per-lane rule of the other layouts: with the hashed map one workgroup per CU is what
+    // hurts - four-key Q1 with 4 instead of 2 replicas in 128 KB: 8.22 instead of 7.17 ms, round 6)
     plan->direct = 2;
     plan->mapWords = static_cast<int32_t>(M);
     plan->S = static_cast<int32_t>(S);
