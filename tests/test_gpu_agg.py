@@ -1810,3 +1810,27 @@ def test_compact_records_when_no_group_order_is_wanted(oracle, vx, shape, monkey
     for c in range(3):
         assert (np.asarray(got[c][0])[go] == np.asarray(exp[c][0])[eo]).all(), c
         assert np.asarray(got[c][1]).all()
+
+
+@pytest.mark.parametrize("later_groups", [5, 40, 700])
+@pytest.mark.parametrize("wide_plan", [False, True])
+def test_first_chunk_layout_sized_from_the_first_rows_survives_a_wrong_estimate(oracle, vx, later_groups, wide_plan):
+    """The first launch of a stream runs before the groups are counted: its LDS layout is sized from the distinct
+    keys among the first 2048 rows (round 6). Here those rows show 3 keys and the rest of the same batch 5 / 40 / 700
+    more: workgroups that run out of LDS slots update the group rows in HBM themselves, the result equals the
+    oracle's (first-seen order included), with few accumulator words and with the eleven of a Q1-like plan (the
+    layout with a replica per lane). GroupingSet::addInputForActiveRows semantics, exec/GroupingSet.cpp:190-365."""
+    rng = np.random.default_rng(100 + later_groups + int(wide_plan))
+    n = 120000
+    k = np.concatenate([rng.integers(0, 3, 4096), rng.integers(0, 3 + later_groups, n - 4096)]).astype(np.int64)
+    cols = [k, _dyadic(rng, n)]
+    aggs = list(C1_AGGS)
+    if wide_plan:
+        cols += [_dyadic(rng, n), _dyadic(rng, n), _dyadic(rng, n)]
+        aggs = [(abi.AGG_SUM, c, abi.DOUBLE) for c in (1, 2, 3, 4)] + \
+               [(abi.AGG_AVG, c, abi.DOUBLE) for c in (1, 2)] + [(abi.AGG_COUNT_STAR, -1, abi.BIGINT)]
+    batches = [batch_of(cols)]
+    exp, _ = run_agg(oracle, batches, [0], [abi.BIGINT], aggs)
+    got, gop = run_agg(vx, batches, [0], [abi.BIGINT], aggs)
+    assert_columns_equal(got, exp, gop.kinds, what="first chunk, estimate too small")
+    assert gop.stats().num_groups == len(np.unique(k))
